@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the embedding-lookup + feature-interaction hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM.
+
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+  deepfm_gather_fm: DeepFM batch 65 536, 26 sparse fields x 1M vocab x dim 16 -- the fused multi-slot
+  gather + FM second-order kernel, writing the [B, 416] concat the DNN consumes and the [B] FM logit.
+Other workloads (--workload) time the other configs' kernels for DESIGN.md / profiles; they are not
+the driver's bench line.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  Every rank owns the 'div'
+row shard of every table, draws its own batch of 65 536 samples over the GLOBAL vocabulary, and a step
+is ShardedTables.lookup (route -> all_to_all ids -> owner gather -> all_to_all rows -> un-permute) followed
+by the FM kernel.  value = samples all ranks processed / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0      # measured float4 copy ceiling (same guide)
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="deepfm_gather_fm",
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full"])
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--fields", type=int, default=26)
+    ap.add_argument("--vocab", type=int, default=1000000)
+    ap.add_argument("--dim", type=int, default=16)
+    ap.add_argument("--id-dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--id-layout", default="bf", choices=["bf", "fb"], help="ids stored [B,F] or [F,B]")
+    ap.add_argument("--rotate", type=int, default=4, help="distinct id batches rotated through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_ids(torch, args, gen, device, vocab):
+    B, F = args.batch, args.fields
+    out = []
+    for _ in range(args.rotate):
+        if args.id_dist == "uniform":
+            ids = torch.randint(0, vocab, (B, F), generator=gen, device=device)
+        else:  # Zipf(1.05) by inverse-CDF on a power law, clipped to the vocabulary
+            u = torch.rand((B, F), generator=gen, device=device, dtype=torch.float64)
+            a = 1.05
+            ids = ((vocab ** (1 - a) - 1) * u + 1).pow(1 / (1 - a)).floor().long().clamp_(1, vocab) - 1
+        if args.id_layout == "fb":
+            ids = ids.t().contiguous().t()
+        out.append(ids)
+    return out
+
+
+def cpu_baseline(args, tables_host, ids_host):
+    """The oracle (a port of the reference op sequence: per-field lookup -> concat -> FM four-op form),
+    timed on this box's host cores with OpenMP, on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    F, K = args.fields, args.dim
+    n, t0 = 0, time.perf_counter()
+    passes = 0
+    while True:
+        emb = O.embedding_bag(tables_host, ids_host)
+        O.fm_second_order(emb, F, K)
+        n += ids_host.shape[0]
+        passes += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or passes >= 200:
+            break
+    return {"value": n / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d passes of gather+FM over %d samples x %d fields (dim %d, vocab %d) in %.1f s, OpenMP" % (
+                passes, ids_host.shape[0], F, K, args.vocab)}
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+    import dir_amd
+    dir_amd.load_library()
+    from dir_amd import ops
+    from dir_amd.shard import ShardedTables, div_range
+
+    B, F, V, K = args.batch, args.fields, args.vocab, args.dim
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    wl = args.workload
+    roof = None
+    step = None
+    units = B
+    cfg = {"workload": wl, "batch": B}
+
+    if wl in ("deepfm_gather_fm", "gather_only", "fm_only", "linear", "deepfm_full"):
+        sigma = 1.0 / (K ** 0.5)  # [TF-upstream] embedding_column default initializer stddev
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "id_layout": args.id_layout})
+        if world == 1:
+            tables = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
+            ts = ops.TableSet(tables)
+            idsl = make_ids(torch, args, gen, device, V)
+            out = torch.empty((B, F * K), dtype=torch.float32, device=device)
+            fm = torch.empty((B, 1), dtype=torch.float32, device=device)
+            if wl == "deepfm_gather_fm":
+                step = lambda i: ops.gather_fm(ts, idsl[i % len(idsl)], out=out, fm=fm)  # noqa: E731
+                alg = B * (F * (8 + 2 * 4 * K) + 4)      # ids + rows read + concat written + logit
+                kname = "gather_onehot_k<fm,out>"
+            elif wl == "gather_only":
+                step = lambda i: ops.embedding_bag(ts, idsl[i % len(idsl)], out=out)  # noqa: E731
+                alg = B * F * (8 + 2 * 4 * K)
+                kname = "gather_onehot_k<out>"
+            elif wl == "fm_only":
+                ops.embedding_bag(ts, idsl[0], out=out)
+                step = lambda i: ops.fm_logit(out, F, K, out=fm)  # noqa: E731
+                alg = B * (4 * F * K + 4)
+                kname = "fm_k"
+            elif wl == "linear":
+                wts = ops.TableSet([torch.randn((V,), generator=gen, device=device) * 0.01 for _ in range(F)])
+                bias = torch.zeros(1, device=device)
+                step = lambda i: ops.linear_logit(wts, idsl[i % len(idsl)], bias=bias, out=fm)  # noqa: E731
+                alg = B * (F * (8 + 4) + 4)
+                kname = "linear_onehot_k"
+            else:  # deepfm_full: the whole DeepFM forward (gather+FM, linear term, 400-400-400 MLP via rocBLAS)
+                from dir_amd.deepfm import DeepFM
+                from dir_amd import feature_column as fc
+                cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+                model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                               dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
+                with torch.no_grad():
+                    step = lambda i: model.forward_ids(idsl[i % len(idsl)], idsl[i % len(idsl)])  # noqa: E731
+                alg = B * (F * (8 + 2 * 4 * K) + 4)
+                kname = "deepfm forward (gather+FM kernel bytes only)"
+            roof = {"bound": "hbm", "alg_bytes": alg, "kernel": kname}
+            cfg["parallelism"] = "single GPU, tables resident (1.66 GB)"
+        else:
+            loc = []
+            for f in range(F):
+                s, e = div_range(V, world, rank)
+                loc.append(torch.randn((e - s, K), generator=gen, device=device) * sigma)
+            st = ShardedTables(loc, [V] * F)
+            idsl = make_ids(torch, args, gen, device, V)
+            fm = torch.empty((B, 1), dtype=torch.float32, device=device)
+
+            def step(i):
+                emb = st.lookup(idsl[i % len(idsl)])
+                ops.fm_logit(emb, F, K, out=fm)
+            alg = B * (F * (8 + 2 * 4 * K) + 4)
+            roof = {"bound": "hbm", "alg_bytes": alg, "kernel": "sharded lookup (route+a2a+gather_rows+a2a) + fm_k"}
+            cfg["parallelism"] = "tables row-sharded 'div' over %d GPUs, RCCL all_to_all x2 per lookup" % world
+    elif wl == "dcn_cross":
+        d, L = F * K, 3
+        x0 = torch.randn((B, d), generator=gen, device=device) * 0.25
+        w = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
+        bb = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
+        out = torch.empty_like(x0)
+        step = lambda i: ops.cross_network(x0, w, bb, out=out)  # noqa: E731
+        roof = {"bound": "hbm", "alg_bytes": B * 2 * 4 * d + 2 * L * d * 4, "kernel": "cross_k"}
+        cfg.update({"d": d, "layers": L})
+    elif wl == "din":
+        T, Kd, Vd, H1, H2 = 50, 64, 10000000, 80, 40
+        table = torch.randn((Vd, Kd), generator=gen, device=device) * 0.125
+        hist = torch.randint(0, Vd, (B, T), generator=gen, device=device)
+        hl = torch.randint(1, T + 1, (B,), generator=gen, device=device, dtype=torch.int32)
+        cand = torch.randint(0, Vd, (B,), generator=gen, device=device)
+        W1 = torch.randn((4 * Kd, H1), generator=gen, device=device) * 0.05
+        b1 = torch.zeros(H1, device=device)
+        W2 = torch.randn((H1, H2), generator=gen, device=device) * 0.1
+        b2 = torch.zeros(H2, device=device)
+        W3 = torch.randn((H2,), generator=gen, device=device) * 0.1
+        b3 = torch.zeros(1, device=device)
+        step = lambda i: ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True)  # noqa: E731
+        flops = B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_k (VALU fp32; priced against the fp32 peak)"}
+        cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
+    elif wl == "cin":
+        m, D, Hs = F, K, (128, 128, 128)
+        x0 = torch.randn((B, m, D), generator=gen, device=device) * 0.25
+        Ws, hp = [], m
+        for h in Hs:
+            Ws.append(torch.randn((h, hp * m), generator=gen, device=device) * (1.0 / (hp * m) ** 0.5))
+            hp = h
+        pooled = torch.empty((B, sum(Hs)), dtype=torch.float32, device=device)
+
+        def step(i):
+            xk, off = x0, 0
+            for W, h in zip(Ws, Hs):
+                xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h])
+                off += h
+        flops, hp = 0, m
+        for h in Hs:
+            flops += 2 * B * D * hp * m * h
+            hp = h
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_k x3"}
+        cfg.update({"m": m, "D": D, "layers": list(Hs)})
+
+    # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                      # HIP events on the stream the kernels are launched on
+    for i in range(args.steps):
+        step(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        ms_per_step = el * 1e3 / args.steps
+        value = units * world * args.steps / el
+        res = {"metric": "CTR samples/sec (embedding gather + FM 2nd-order, 26-field batch 65536)" if wl == "deepfm_gather_fm"
+               else "samples/sec (%s)" % wl,
+               "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic", "config": cfg}
+        launch_us = dev_ms * 1e3 / args.steps
+        if roof["bound"] == "hbm":
+            ach = roof["alg_bytes"] / (launch_us * 1e-6) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath) and world == 1:
+                try:
+                    traffic = json.load(open(tpath)).get(wl)
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
+                               "traffic": traffic, "kernel": roof["kernel"], "alg_bytes_per_launch": roof["alg_bytes"],
+                               "avg_launch_us": launch_us}
+        else:
+            ach = roof["alg_flops"] / (launch_us * 1e-6) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "kernel": roof["kernel"],
+                               "alg_flops_per_step": roof["alg_flops"], "avg_step_us": launch_us}
+        if world == 1 and not args.no_cpu_baseline and wl in ("deepfm_gather_fm", "gather_only"):
+            tables_host = [t.cpu().numpy() for t in tables]
+            ids_host = idsl[0].cpu().numpy()
+            res["cpu_baseline"] = cpu_baseline(args, tables_host, ids_host)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""_lib.py -- ctypes binding of libdir_hip.so (C ABI: include/dir_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, every op raises.  The library
+is built in-tree by build.py (hipcc --offload-arch=gfx950).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdir_hip.so")
+
+c_i32, c_i64, c_f32p, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
+
+# name -> (restype, argtypes).  Device pointers travel as c_void_p (tensor.data_ptr()).
+SIGNATURES = {
+    "dir_version": (c_i32, []),
+    "dir_last_error": (ctypes.c_char_p, []),
+    "dir_embedding_bag_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i64,
+                                      c_vp, c_i64, c_vp]),
+    "dir_check_ids": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "dir_fm_second_order_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "dir_gather_fm_fused_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dir_linear_sparse_sum_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64,
+                                          c_vp, c_vp]),
+    "dir_dcn_cross_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "dir_dcn_cross_op_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "dir_din_attention_pool_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                           c_i32, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "dir_cin_layer_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "dir_fingerprint64": (ctypes.c_uint64, [ctypes.c_char_p, c_i64]),
+    "dir_hash_bucket_fast": (c_i32, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64), c_i64, c_i64,
+                                     ctypes.POINTER(c_i64)]),
+    "dir_hash_bucket_i64_device": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "dir_bucketize_f32": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
+    "dir_shard_div_owner": (None, [c_i64, c_i64, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
+    "dir_shard_route": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "dir_gather_rows_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
+}
+
+DIR_OK, DIR_E_BADARG, DIR_E_RANGE, DIR_E_HIP, DIR_E_UNSUPPORTED = 0, -1, -2, -3, -4
+_ERRNAMES = {-1: "DIR_E_BADARG", -2: "DIR_E_RANGE", -3: "DIR_E_HIP", -4: "DIR_E_UNSUPPORTED"}
+
+_lib = None
+
+
+class DirError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (_ERRNAMES.get(code, "DIR_E_?"), code, msg))
+        self.code = code
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libdir_hip.so and bind every symbol of include/dir_hip.h.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            "libdir_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`python details-in-recommendation_amd/build.py`. There is no CPU fallback." % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != DIR_OK:
+        raise DirError(rc, load().dir_last_error().decode("utf-8", "replace"))

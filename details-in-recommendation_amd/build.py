@@ -1,0 +1,58 @@
+"""build.py -- compile libdir_hip.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+One hipcc invocation per translation unit (objects cached under csrc/_build by mtime), then one link.
+The .so is git-ignored but travels with the gpurun snapshot.  No torch headers are involved: the
+library is plain HIP behind the C ABI of include/dir_hip.h.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(CSRC, "_build")
+LIB = os.path.join(HERE, "libdir_hip.so")
+SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "cin.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "dir_hip.h")]
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src):
+    s = os.path.join(CSRC, src)
+    o = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
+    if os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), _deps_mtime()):
+        return o
+    cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return o
+
+
+def build(force=False, jobs=None):
+    os.makedirs(BUILD, exist_ok=True)
+    if force:
+        for f in os.listdir(BUILD):
+            os.remove(os.path.join(BUILD, f))
+    jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

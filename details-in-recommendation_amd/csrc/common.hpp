@@ -1,0 +1,70 @@
+// common.hpp -- shared host/device helpers for libdir_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/dir_hip.h"
+
+namespace dir {
+
+// thread-local error text behind dir_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(dir_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define DIR_CHECK_ARG(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) return ::dir::fail(DIR_E_BADARG, __VA_ARGS__); \
+    } while (0)
+
+#define DIR_CHECK_LAUNCH(name)                                                              \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess)                                                              \
+            return ::dir::fail(DIR_E_HIP, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+constexpr int kWave = 64;     // gfx950 wavefront
+constexpr int kCUs = 256;     // MI355X compute units
+constexpr int kXCDs = 8;
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// grid size for a grid-stride kernel over `work_blocks` block-sized work items: enough blocks to fill
+// every CU several times over, capped so that launch cost stays flat.
+inline int grid_for(int64_t work_blocks, int blocks_per_cu = 8) {
+    int64_t cap = (int64_t)kCUs * blocks_per_cu;
+    int64_t g = work_blocks < cap ? work_blocks : cap;
+    return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace dir
+
+// ---- device helpers ------------------------------------------------------------------------
+#if defined(__HIPCC__)
+namespace dir {
+
+// Value of `v` from lane `src` of the wave (all lanes active).
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+
+// Sum over the LPS consecutive lanes that share a sample (butterfly; result in every lane).
+template <int LPS>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPS / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace dir
+#endif

@@ -1,0 +1,437 @@
+// embedding_bag.hip -- multi-slot sparse embedding gather (+ fused FM second-order) for gfx950.
+//
+// Replaces (reference, /root/reference):
+//   myself_input_layer                                   models/DeepFM/deepFM.py:363-400
+//   tf.feature_column.input_layer                        models/DeepCrossNetwork/DeepCrossNetwork.py:126
+//   fm_logit_fn (when fused)                             models/DeepFM/deepFM.py:321-335
+//   [TF-upstream] safe_embedding_lookup_sparse / embedding_lookup_sparse bag semantics
+//
+// Work decomposition (HBM-bound, no reuse, so no LDS): LPS = K/4 lanes own one sample; lane c of
+// the group owns the 16-byte chunk c of every row of that sample.  A wave therefore covers 64/LPS
+// samples, walks the F slots, and per slot issues ONE global_load_dwordx4 per lane = 64/LPS rows of
+// 16*LPS bytes.  UF slots are issued back to back before the first use, so each wave keeps
+// UF * 1 KiB of row reads in flight.  The FM accumulators (sum_f e, sum_f e^2) are per-lane float4
+// registers; the final sum over k runs lane c -> c+1 inside the group so that the result is the
+// f-ascending / k-ascending fp32 sum, bit for bit what oracle/dir_oracle.c computes.
+// The concat output [B, F*K] is written with the same lane mapping (16 B per lane, 64-B..1-KiB
+// contiguous per sample).
+#include "common.hpp"
+
+namespace dir {
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using T = float4; };
+template <> struct VecT<1> { using T = float; };
+
+__device__ __forceinline__ float4 ldv(const float* p, float4*) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float ldv(const float* p, float*) { return *p; }
+__device__ __forceinline__ void stv(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+__device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float vzero(float*) { return 0.f; }
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vmul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
+__device__ __forceinline__ float4 vscale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float vscale(float a, float s) { return a * s; }
+__device__ __forceinline__ float4 vdiv(float4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ float vdiv(float a, float s) { return a / s; }
+// ordered horizontal add: acc + v.x + v.y + v.z + v.w, left to right
+__device__ __forceinline__ float hadd_into(float acc, float4 v) { return (((acc + v.x) + v.y) + v.z) + v.w; }
+__device__ __forceinline__ float hadd_into(float acc, float v) { return acc + v; }
+
+// FM tail shared by the fused gather and the standalone kernel.  sum/sq hold this lane's chunk of
+// sum_f e and sum_f e^2; returns 0.5 * sum_k (sum^2 - sq) in lane LPS-1 of the group.
+template <int LPS, typename V>
+__device__ __forceinline__ float fm_tail(V sum, V sq, int lane, int c) {
+    V sm = vmul(sum, sum);
+    V d;
+    if constexpr (sizeof(V) == 16) {
+        d = make_float4(sm.x - sq.x, sm.y - sq.y, sm.z - sq.z, sm.w - sq.w);
+    } else {
+        d = sm - sq;
+    }
+    float acc = 0.f;
+    const int gbase = lane & ~(LPS - 1);
+#pragma unroll
+    for (int cc = 0; cc < LPS; ++cc) {
+        float carry = __shfl(acc, gbase + (cc > 0 ? cc - 1 : 0), 64);
+        if (c == cc) acc = hadd_into(cc == 0 ? 0.f : carry, d);
+    }
+    return 0.5f * acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one-hot gather, optional concat write, optional fused FM
+// ------------------------------------------------------------------------------------------------
+template <int LPS, int VEC, int KT, int UF, bool DO_FM, bool DO_OUT>
+__global__ __launch_bounds__(256) void gather_onehot_k(const float* const* __restrict__ tables,
+                                                       const int64_t* __restrict__ ids, int64_t sb,
+                                                       int64_t sf, int F, int Krt, int64_t B,
+                                                       float* __restrict__ out, int64_t out_ld,
+                                                       float* __restrict__ fm) {
+    using V = typename VecT<VEC>::T;
+    constexpr int SPW = 64 / LPS;
+    const int K = KT > 0 ? KT : Krt;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (LPS - 1);
+    const int s = lane / LPS;
+    const int kv = (K + VEC - 1) / VEC;
+    const bool cact = c < kv;
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
+        const int64_t b = g * SPW + s;
+        const bool act = cact && (b < B);
+        const int64_t* idp = ids + (act ? b * sb : 0);
+        float* op = DO_OUT ? out + (act ? b * out_ld : 0) + c * VEC : nullptr;
+        V sum = vzero((V*)nullptr), sq = vzero((V*)nullptr);
+        for (int f0 = 0; f0 < F; f0 += UF) {
+            int64_t id[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int f = f0 + u;
+                id[u] = (act && f < F) ? idp[(int64_t)f * sf] : (int64_t)-1;
+            }
+            V row[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int f = f0 + u;
+                row[u] = vzero((V*)nullptr);
+                if (f < F) {
+                    const float* t = tables[f];
+                    if (id[u] >= 0) row[u] = ldv(t + id[u] * K + c * VEC, (V*)nullptr);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int f = f0 + u;
+                if (f < F) {
+                    if (DO_OUT && act) stv(op + (int64_t)f * K, row[u]);
+                    if (DO_FM) {
+                        sum = vadd(sum, row[u]);
+                        sq = vadd(sq, vmul(row[u], row[u]));
+                    }
+                }
+            }
+        }
+        if (DO_FM) {
+            float r = fm_tail<LPS>(sum, sq, lane, c);
+            if (c == LPS - 1 && b < B) fm[b] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-hot (CSR) bags: entries reduced in order, then combiner
+// ------------------------------------------------------------------------------------------------
+template <int LPS, int VEC>
+__global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict__ tables,
+                                                 const int64_t* __restrict__ ids,
+                                                 const int64_t* __restrict__ offsets,
+                                                 const float* __restrict__ weights, int64_t sb, int64_t sf,
+                                                 int F, int K, int64_t B, int combiner, int flags,
+                                                 float* __restrict__ out, int64_t out_ld) {
+    using V = typename VecT<VEC>::T;
+    constexpr int SPW = 64 / LPS;
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (LPS - 1);
+    const int s = lane / LPS;
+    const int kv = (K + VEC - 1) / VEC;
+    const bool cact = c < kv;
+    const bool prune_w = (flags & DIR_BAG_PRUNE_NONPOSITIVE_WEIGHTS) != 0;
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
+        const int64_t b = g * SPW + s;
+        const bool act = cact && (b < B);
+        for (int f = 0; f < F; ++f) {
+            const float* t = tables[f];
+            int64_t beg = 0, end = 0;
+            if (act) {
+                const int64_t bag = b * sb + (int64_t)f * sf;
+                beg = offsets[bag];
+                end = offsets[bag + 1];
+            }
+            V acc = vzero((V*)nullptr);
+            float wsum = 0.f, w2sum = 0.f;
+            int cnt = 0;
+            for (int64_t e0 = beg; e0 < end; e0 += U) {
+                int64_t id[U];
+                float w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t e = e0 + u;
+                    id[u] = e < end ? ids[e] : (int64_t)-1;
+                    w[u] = (weights && e < end) ? weights[e] : 1.0f;
+                    if (weights && prune_w && !(w[u] > 0.0f)) id[u] = -1;
+                }
+                V row[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    row[u] = vzero((V*)nullptr);
+                    if (id[u] >= 0) row[u] = ldv(t + id[u] * K + c * VEC, (V*)nullptr);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (id[u] >= 0) {
+                        acc = weights ? vadd(acc, vscale(row[u], w[u])) : vadd(acc, row[u]);
+                        wsum = wsum + w[u];
+                        w2sum = w2sum + w[u] * w[u];
+                        ++cnt;
+                    }
+                }
+            }
+            if (cnt > 0) {
+                if (combiner == DIR_COMBINER_MEAN) {
+                    acc = vdiv(acc, weights ? wsum : (float)cnt);
+                } else if (combiner == DIR_COMBINER_SQRTN) {
+                    acc = vdiv(acc, weights ? sqrtf(w2sum) : sqrtf((float)cnt));
+                }
+            }
+            if (act) stv(out + b * out_ld + (int64_t)f * K + c * VEC, acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone FM over a materialised [B, F*K] embedding matrix
+// ------------------------------------------------------------------------------------------------
+template <int LPS, int VEC>
+__global__ __launch_bounds__(256) void fm_k(const float* __restrict__ emb, int64_t ld, int64_t B, int F,
+                                            int K, float* __restrict__ out) {
+    using V = typename VecT<VEC>::T;
+    constexpr int SPW = 64 / LPS;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (LPS - 1);
+    const int s = lane / LPS;
+    const int kv = (K + VEC - 1) / VEC;
+    const bool cact = c < kv;
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
+        const int64_t b = g * SPW + s;
+        const bool act = cact && (b < B);
+        const float* ep = emb + (act ? b * ld : 0) + c * VEC;
+        V sum = vzero((V*)nullptr), sq = vzero((V*)nullptr);
+#pragma unroll 8
+        for (int f = 0; f < F; ++f) {
+            V r = act ? ldv(ep + (int64_t)f * K, (V*)nullptr) : vzero((V*)nullptr);
+            sum = vadd(sum, r);
+            sq = vadd(sq, vmul(r, r));
+        }
+        float r = fm_tail<LPS>(sum, sq, lane, c);
+        if (c == LPS - 1 && b < B) out[b] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// id validation (debug aid)
+// ------------------------------------------------------------------------------------------------
+__global__ void check_ids_k(const int64_t* __restrict__ vocab, int F, const int64_t* __restrict__ ids,
+                            const int64_t* __restrict__ offsets, int64_t sb, int64_t sf, int64_t B,
+                            int32_t* __restrict__ bad) {
+    const int64_t n = B * F;
+    int local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / F;
+        const int f = (int)(i - b * F);
+        const int64_t v = vocab[f];
+        if (!offsets) {
+            if (ids[b * sb + f * sf] >= v) ++local;
+        } else {
+            const int64_t bag = b * sb + f * sf;
+            for (int64_t e = offsets[bag]; e < offsets[bag + 1]; ++e)
+                if (ids[e] >= v) ++local;
+        }
+    }
+    if (local) atomicAdd(bad, local);
+}
+
+// ---- host dispatch -----------------------------------------------------------------------------
+static int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <int LPS, int VEC, int KT, bool DO_FM, bool DO_OUT>
+static void launch_onehot_uf(int uf, dim3 grid, hipStream_t st, const float* const* tables,
+                             const int64_t* ids, int64_t sb, int64_t sf, int F, int K, int64_t B, float* out,
+                             int64_t out_ld, float* fm) {
+#define DIR_GO(UF) \
+    hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT>), grid, dim3(256), 0, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm)
+    switch (uf) {
+        case 2: DIR_GO(2); break;
+        case 4: DIR_GO(4); break;
+        case 13: DIR_GO(13); break;
+        case 16: DIR_GO(16); break;
+        case 26: DIR_GO(26); break;
+        default: DIR_GO(8); break;
+    }
+#undef DIR_GO
+}
+
+template <bool DO_FM, bool DO_OUT>
+static int launch_onehot(const float* const* tables, int F, int K, const int64_t* ids, int64_t sb, int64_t sf,
+                         int64_t B, float* out, int64_t out_ld, float* fm, hipStream_t st) {
+    const bool vec = (K % 4 == 0) && (!DO_OUT || (out_ld % 4 == 0 && aligned16(out)));
+    static const int uf_env = env_int("DIR_GATHER_UF", 0);
+    static const int bpc_env = env_int("DIR_GATHER_BLOCKS_PER_CU", 8);
+    int uf = uf_env > 0 ? uf_env : (F % 13 == 0 ? 13 : 8);
+    const int lps = next_pow2(vec ? K / 4 : K);
+    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "embedding row of K=%d floats is wider than one wave covers (max %d)", K, vec ? 256 : 64);
+    const int spw = 64 / lps;
+    const int64_t waves = (B + spw - 1) / spw;
+    dim3 grid(grid_for((waves + 3) / 4, bpc_env));
+#define DIR_CASE(L, V, KT) launch_onehot_uf<L, V, KT, DO_FM, DO_OUT>(uf, grid, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm)
+    if (vec) {
+        switch (lps) {
+            case 1: DIR_CASE(1, 4, 4); break;
+            case 2: if (K == 8) DIR_CASE(2, 4, 8); else DIR_CASE(2, 4, 0); break;
+            case 4: if (K == 16) DIR_CASE(4, 4, 16); else DIR_CASE(4, 4, 0); break;
+            case 8: if (K == 32) DIR_CASE(8, 4, 32); else DIR_CASE(8, 4, 0); break;
+            case 16: if (K == 64) DIR_CASE(16, 4, 64); else DIR_CASE(16, 4, 0); break;
+            case 32: DIR_CASE(32, 4, 0); break;
+            default: DIR_CASE(64, 4, 0); break;
+        }
+    } else {
+        switch (lps) {
+            case 1: DIR_CASE(1, 1, 1); break;
+            case 2: DIR_CASE(2, 1, 0); break;
+            case 4: DIR_CASE(4, 1, 0); break;
+            case 8: DIR_CASE(8, 1, 0); break;
+            case 16: DIR_CASE(16, 1, 0); break;
+            case 32: DIR_CASE(32, 1, 0); break;
+            default: DIR_CASE(64, 1, 0); break;
+        }
+    }
+#undef DIR_CASE
+    DIR_CHECK_LAUNCH("gather_onehot");
+    return DIR_OK;
+}
+
+static int launch_csr(const float* const* tables, int F, int K, const int64_t* ids, const int64_t* offsets,
+                      const float* weights, int64_t sb, int64_t sf, int combiner, int flags, int64_t B,
+                      float* out, int64_t out_ld, hipStream_t st) {
+    const bool vec = (K % 4 == 0) && (out_ld % 4 == 0) && aligned16(out);
+    const int lps = next_pow2(vec ? K / 4 : K);
+    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "embedding row of K=%d floats is wider than one wave covers", K);
+    const int spw = 64 / lps;
+    const int64_t waves = (B + spw - 1) / spw;
+    dim3 grid(grid_for((waves + 3) / 4));
+#define DIR_CASE(L, V) \
+    hipLaunchKernelGGL((bag_csr_k<L, V>), grid, dim3(256), 0, st, tables, ids, offsets, weights, sb, sf, F, K, B, combiner, flags, out, out_ld)
+    if (vec) {
+        switch (lps) {
+            case 1: DIR_CASE(1, 4); break;
+            case 2: DIR_CASE(2, 4); break;
+            case 4: DIR_CASE(4, 4); break;
+            case 8: DIR_CASE(8, 4); break;
+            case 16: DIR_CASE(16, 4); break;
+            case 32: DIR_CASE(32, 4); break;
+            default: DIR_CASE(64, 4); break;
+        }
+    } else {
+        switch (lps) {
+            case 1: DIR_CASE(1, 1); break;
+            case 2: DIR_CASE(2, 1); break;
+            case 4: DIR_CASE(4, 1); break;
+            case 8: DIR_CASE(8, 1); break;
+            case 16: DIR_CASE(16, 1); break;
+            case 32: DIR_CASE(32, 1); break;
+            default: DIR_CASE(64, 1); break;
+        }
+    }
+#undef DIR_CASE
+    DIR_CHECK_LAUNCH("bag_csr");
+    return DIR_OK;
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int dir_embedding_bag_f32(const float* const* tables, int F, int K, const int64_t* ids,
+                                     const int64_t* offsets, const float* weights, int64_t stride_b,
+                                     int64_t stride_f, int combiner, int flags, int64_t B, float* out,
+                                     int64_t out_ld, dir_stream_t stream) {
+    DIR_CHECK_ARG(tables && ids && out, "dir_embedding_bag_f32: null pointer");
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "dir_embedding_bag_f32: F=%d K=%d B=%lld", F, K, (long long)B);
+    DIR_CHECK_ARG(out_ld >= (int64_t)F * K, "dir_embedding_bag_f32: out_ld=%lld < F*K=%lld", (long long)out_ld, (long long)F * K);
+    DIR_CHECK_ARG(combiner >= DIR_COMBINER_SUM && combiner <= DIR_COMBINER_SQRTN, "dir_embedding_bag_f32: combiner=%d", combiner);
+    DIR_CHECK_ARG(offsets || !weights, "dir_embedding_bag_f32: weights need offsets (multi-hot)");
+    if (B == 0) return DIR_OK;
+    if (!offsets)  // a one-entry bag: every combiner is the identity on it
+        return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, B, out, out_ld, nullptr, as_stream(stream));
+    return launch_csr(tables, F, K, ids, offsets, weights, stride_b, stride_f, combiner, flags, B, out, out_ld, as_stream(stream));
+}
+
+extern "C" int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int64_t* ids,
+                                       int64_t stride_b, int64_t stride_f, int64_t B, float* out,
+                                       int64_t out_ld, float* fm, dir_stream_t stream) {
+    DIR_CHECK_ARG(tables && ids && (out || fm), "dir_gather_fm_fused_f32: null pointer");
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "dir_gather_fm_fused_f32: F=%d K=%d B=%lld", F, K, (long long)B);
+    DIR_CHECK_ARG(!out || out_ld >= (int64_t)F * K, "dir_gather_fm_fused_f32: out_ld=%lld < F*K", (long long)out_ld);
+    if (B == 0) return DIR_OK;
+    hipStream_t st = as_stream(stream);
+    if (out && fm) return launch_onehot<true, true>(tables, F, K, ids, stride_b, stride_f, B, out, out_ld, fm, st);
+    if (fm) return launch_onehot<true, false>(tables, F, K, ids, stride_b, stride_f, B, nullptr, 0, fm, st);
+    return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, B, out, out_ld, nullptr, st);
+}
+
+extern "C" int dir_fm_second_order_f32(const float* emb, int64_t emb_ld, int64_t B, int F, int K, float* out,
+                                       dir_stream_t stream) {
+    DIR_CHECK_ARG(emb && out, "dir_fm_second_order_f32: null pointer");
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && emb_ld >= (int64_t)F * K, "dir_fm_second_order_f32: F=%d K=%d B=%lld ld=%lld", F, K, (long long)B, (long long)emb_ld);
+    if (B == 0) return DIR_OK;
+    const bool vec = (K % 4 == 0) && (emb_ld % 4 == 0) && aligned16(emb);
+    const int lps = next_pow2(vec ? K / 4 : K);
+    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "dir_fm_second_order_f32: K=%d too wide", K);
+    const int spw = 64 / lps;
+    const int64_t waves = (B + spw - 1) / spw;
+    dim3 grid(grid_for((waves + 3) / 4));
+    hipStream_t st = as_stream(stream);
+#define DIR_CASE(L, V) hipLaunchKernelGGL((fm_k<L, V>), grid, dim3(256), 0, st, emb, emb_ld, B, F, K, out)
+    if (vec) {
+        switch (lps) {
+            case 1: DIR_CASE(1, 4); break;
+            case 2: DIR_CASE(2, 4); break;
+            case 4: DIR_CASE(4, 4); break;
+            case 8: DIR_CASE(8, 4); break;
+            case 16: DIR_CASE(16, 4); break;
+            case 32: DIR_CASE(32, 4); break;
+            default: DIR_CASE(64, 4); break;
+        }
+    } else {
+        switch (lps) {
+            case 1: DIR_CASE(1, 1); break;
+            case 2: DIR_CASE(2, 1); break;
+            case 4: DIR_CASE(4, 1); break;
+            case 8: DIR_CASE(8, 1); break;
+            case 16: DIR_CASE(16, 1); break;
+            case 32: DIR_CASE(32, 1); break;
+            default: DIR_CASE(64, 1); break;
+        }
+    }
+#undef DIR_CASE
+    DIR_CHECK_LAUNCH("fm_second_order");
+    return DIR_OK;
+}
+
+extern "C" int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, const int64_t* offsets,
+                             int64_t stride_b, int64_t stride_f, int64_t B, int32_t* bad_count,
+                             dir_stream_t stream) {
+    DIR_CHECK_ARG(vocab && ids && bad_count && F > 0 && B >= 0, "dir_check_ids: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess) return fail(DIR_E_HIP, "dir_check_ids: memset failed");
+    if (B == 0) return DIR_OK;
+    dim3 grid(grid_for((B * F + 255) / 256));
+    hipLaunchKernelGGL(check_ids_k, grid, dim3(256), 0, st, vocab, F, ids, offsets, stride_b, stride_f, B, bad_count);
+    DIR_CHECK_LAUNCH("check_ids");
+    return DIR_OK;
+}

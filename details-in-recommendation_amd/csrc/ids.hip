@@ -1,0 +1,311 @@
+// ids.hip -- integer id paths: hashing, bucketising, 'div' shard routing (bit-exact integer work).
+//
+// Replaces (reference, /root/reference):
+//   categorical_column_with_hash_bucket('occupation', 1000)   models/DeepCrossNetwork/train.py:85-86
+//     [TF-upstream] string_to_hash_bucket_fast = FarmHash Fingerprint64(bytes) mod buckets
+//   bucketized numeric columns (docstring)                    models/DeepFM/deepFM.py:95
+//   min_max_variable_partitioner + 'div' lookups              models/DeepFM/deepFM.py:163-167
+//
+// Fingerprint64 is farmhashna::Hash64 of FarmHash 1.1, restated from the public algorithm; checked
+// against published known answers in tests/ (lengths <= 16; longer branches have no published vector).
+#include "common.hpp"
+
+namespace dir {
+namespace fh {
+
+constexpr uint64_t k0 = 0xc3a5c85c97cb3127ULL;
+constexpr uint64_t k1 = 0xb492b66fbe98f273ULL;
+constexpr uint64_t k2 = 0x9ae16a3b2f90404fULL;
+
+__host__ __device__ inline uint64_t fetch64(const char* p) {
+    uint64_t v = 0;
+    for (int i = 0; i < 8; ++i) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+    return v;
+}
+__host__ __device__ inline uint64_t fetch32(const char* p) {
+    uint64_t v = 0;
+    for (int i = 0; i < 4; ++i) v |= (uint64_t)(uint8_t)p[i] << (8 * i);
+    return v;
+}
+__host__ __device__ inline uint64_t rot(uint64_t v, int s) { return s == 0 ? v : ((v >> s) | (v << (64 - s))); }
+__host__ __device__ inline uint64_t smix(uint64_t v) { return v ^ (v >> 47); }
+__host__ __device__ inline uint64_t hash16(uint64_t u, uint64_t v, uint64_t mul) {
+    uint64_t a = (u ^ v) * mul;
+    a ^= (a >> 47);
+    uint64_t b = (v ^ a) * mul;
+    b ^= (b >> 47);
+    b *= mul;
+    return b;
+}
+
+__host__ __device__ inline uint64_t len0to16(const char* s, size_t len) {
+    if (len >= 8) {
+        uint64_t mul = k2 + len * 2;
+        uint64_t a = fetch64(s) + k2;
+        uint64_t b = fetch64(s + len - 8);
+        uint64_t c = rot(b, 37) * mul + a;
+        uint64_t d = (rot(a, 25) + b) * mul;
+        return hash16(c, d, mul);
+    }
+    if (len >= 4) {
+        uint64_t mul = k2 + len * 2;
+        uint64_t a = fetch32(s);
+        return hash16(len + (a << 3), fetch32(s + len - 4), mul);
+    }
+    if (len > 0) {
+        uint8_t a = (uint8_t)s[0];
+        uint8_t b = (uint8_t)s[len >> 1];
+        uint8_t c = (uint8_t)s[len - 1];
+        uint32_t y = (uint32_t)a + ((uint32_t)b << 8);
+        uint32_t z = (uint32_t)len + ((uint32_t)c << 2);
+        return smix(y * k2 ^ z * k0) * k2;
+    }
+    return k2;
+}
+
+__host__ __device__ inline uint64_t len17to32(const char* s, size_t len) {
+    uint64_t mul = k2 + len * 2;
+    uint64_t a = fetch64(s) * k1;
+    uint64_t b = fetch64(s + 8);
+    uint64_t c = fetch64(s + len - 8) * mul;
+    uint64_t d = fetch64(s + len - 16) * k2;
+    return hash16(rot(a + b, 43) + rot(c, 30) + d, a + rot(b + k2, 18) + c, mul);
+}
+
+struct U128 { uint64_t first, second; };
+
+inline U128 weak32(uint64_t w, uint64_t x, uint64_t y, uint64_t z, uint64_t a, uint64_t b) {
+    a += w;
+    b = rot(b + a + z, 21);
+    uint64_t c = a;
+    a += x;
+    a += y;
+    b += rot(a, 44);
+    return U128{a + z, b + c};
+}
+inline U128 weak32(const char* s, uint64_t a, uint64_t b) {
+    return weak32(fetch64(s), fetch64(s + 8), fetch64(s + 16), fetch64(s + 24), a, b);
+}
+
+inline uint64_t len33to64(const char* s, size_t len) {
+    uint64_t mul = k2 + len * 2;
+    uint64_t a = fetch64(s) * k2;
+    uint64_t b = fetch64(s + 8);
+    uint64_t c = fetch64(s + len - 8) * mul;
+    uint64_t d = fetch64(s + len - 16) * k2;
+    uint64_t y = rot(a + b, 43) + rot(c, 30) + d;
+    uint64_t z = hash16(y, a + rot(b + k2, 18) + c, mul);
+    uint64_t e = fetch64(s + 16) * mul;
+    uint64_t f = fetch64(s + 24);
+    uint64_t g = (y + fetch64(s + len - 32)) * mul;
+    uint64_t h = (z + fetch64(s + len - 24)) * mul;
+    return hash16(rot(e + f, 43) + rot(g, 30) + h, e + rot(f + a, 18) + g, mul);
+}
+
+// host: every length
+inline uint64_t fingerprint64(const char* s, size_t len) {
+    if (len <= 16) return len0to16(s, len);
+    if (len <= 32) return len17to32(s, len);
+    if (len <= 64) return len33to64(s, len);
+    const uint64_t seed = 81;
+    uint64_t x = seed;
+    uint64_t y = seed * k1 + 113;
+    uint64_t z = smix(y * k2 + 113) * k2;
+    U128 v{0, 0}, w{0, 0};
+    x = x * k2 + fetch64(s);
+    const char* end = s + ((len - 1) / 64) * 64;
+    const char* last64 = end + ((len - 1) & 63) - 63;
+    do {
+        x = rot(x + y + v.first + fetch64(s + 8), 37) * k1;
+        y = rot(y + v.second + fetch64(s + 48), 42) * k1;
+        x ^= w.second;
+        y += v.first + fetch64(s + 40);
+        z = rot(z + w.first, 33) * k1;
+        v = weak32(s, v.second * k1, x + w.first);
+        w = weak32(s + 32, z + w.second, y + fetch64(s + 16));
+        uint64_t t = z; z = x; x = t;
+        s += 64;
+    } while (s != end);
+    uint64_t mul = k1 + ((z & 0xff) << 1);
+    s = last64;
+    w.first += ((len - 1) & 63);
+    v.first += w.first;
+    w.first += v.first;
+    x = rot(x + y + v.first + fetch64(s + 8), 37) * mul;
+    y = rot(y + v.second + fetch64(s + 48), 42) * mul;
+    x ^= w.second * 9;
+    y += v.first * 9 + fetch64(s + 40);
+    z = rot(z + w.first, 33) * mul;
+    v = weak32(s, v.second * mul, x + w.first);
+    w = weak32(s + 32, z + w.second, y + fetch64(s + 16));
+    uint64_t t = z; z = x; x = t;
+    return hash16(hash16(v.first, w.first, mul) + smix(y) * k0 + z, hash16(v.second, w.second, mul) + x, mul);
+}
+
+}  // namespace fh
+
+// decimal text of an int64, as [TF-upstream] as_string / StrCat write it; returns the length (<= 20)
+__device__ inline int i64_to_dec(int64_t v, char* buf) {
+    char tmp[20];
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + (u % 10));
+        u /= 10;
+    } while (u);
+    int p = 0;
+    if (v < 0) buf[p++] = '-';
+    while (n) buf[p++] = tmp[--n];
+    return p;
+}
+
+__global__ void hash_bucket_i64_k(const int64_t* __restrict__ keys, int64_t n, uint64_t buckets,
+                                  int64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        char buf[32];
+        const int len = i64_to_dec(keys[i], buf);
+        const uint64_t h = len <= 16 ? fh::len0to16(buf, (size_t)len) : fh::len17to32(buf, (size_t)len);
+        out[i] = (int64_t)(h % buckets);
+    }
+}
+
+__global__ void bucketize_k(const float* __restrict__ x, int64_t n, const float* __restrict__ bd, int nb,
+                            int64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        // upper_bound: number of boundaries <= v  (NaN compares false everywhere -> bucket 0)
+        int lo = 0, hi = nb;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (bd[mid] <= v) lo = mid + 1; else hi = mid;
+        }
+        out[i] = lo;
+    }
+}
+
+__host__ __device__ inline void div_owner(int64_t id, int64_t q, int64_t r, int64_t thr, int* owner, int64_t* local) {
+    if (id < thr) {
+        const int64_t o = id / (q + 1);
+        *owner = (int)o;
+        *local = id - o * (q + 1);
+    } else {
+        const int64_t o = r + (q > 0 ? (id - thr) / q : 0);
+        *owner = (int)o;
+        *local = id - (thr + (o - r) * q);
+    }
+}
+
+__global__ void shard_route_k(const int64_t* __restrict__ ids, int64_t n, const int64_t* __restrict__ vocab, int F,
+                              int P, int32_t* __restrict__ owner, int64_t* __restrict__ local) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = ids[i];
+        if (id < 0) {
+            owner[i] = (int32_t)(i % P);
+            local[i] = -1;
+        } else {
+            const int64_t V = vocab[i % F];
+            const int64_t q = V / P, r = V % P;
+            int o;
+            int64_t l;
+            div_owner(id, q, r, r * (q + 1), &o, &l);
+            owner[i] = o;
+            local[i] = l;
+        }
+    }
+}
+
+// flat row gather: out[i, :] = tables[slot[i]][row[i], :]  (row < 0 -> zeros).  LPS lanes per row,
+// 16 B per lane when K % 4 == 0.
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows_k(const float* const* __restrict__ tables, int K, int lps,
+                                                     const int32_t* __restrict__ slot,
+                                                     const int64_t* __restrict__ row, int64_t n,
+                                                     float* __restrict__ out) {
+    const int kv = K / VEC;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = tid; q < n * lps; q += nthr) {
+        const int64_t i = q / lps;
+        const int c = (int)(q - i * lps);
+        if (c >= kv) continue;
+        const int64_t r = row[i];
+        float* o = out + i * K + c * VEC;
+        if (VEC == 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r >= 0) v = *reinterpret_cast<const float4*>(tables[slot ? slot[i] : 0] + r * K + c * 4);
+            *reinterpret_cast<float4*>(o) = v;
+        } else {
+            float v = 0.f;
+            if (r >= 0) v = tables[slot ? slot[i] : 0][r * K + c];
+            *o = v;
+        }
+    }
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" uint64_t dir_fingerprint64(const char* s, int64_t len) {
+    if (!s || len < 0) return fh::k2;
+    return fh::fingerprint64(s, (size_t)len);
+}
+
+extern "C" int dir_hash_bucket_fast(const char* const* strs, const int64_t* lens, int64_t n, int64_t num_buckets,
+                                    int64_t* out) {
+    DIR_CHECK_ARG(strs && lens && out && n >= 0 && num_buckets > 0, "dir_hash_bucket_fast: bad argument");
+    for (int64_t i = 0; i < n; ++i) {
+        DIR_CHECK_ARG(strs[i] || lens[i] == 0, "dir_hash_bucket_fast: null string %lld", (long long)i);
+        out[i] = (int64_t)(fh::fingerprint64(strs[i], (size_t)lens[i]) % (uint64_t)num_buckets);
+    }
+    return DIR_OK;
+}
+
+extern "C" int dir_hash_bucket_i64_device(const int64_t* keys, int64_t n, int64_t num_buckets, int64_t* out,
+                                          dir_stream_t stream) {
+    DIR_CHECK_ARG(keys && out && n >= 0 && num_buckets > 0, "dir_hash_bucket_i64_device: bad argument");
+    if (n == 0) return DIR_OK;
+    hipLaunchKernelGGL(hash_bucket_i64_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, as_stream(stream), keys, n,
+                       (uint64_t)num_buckets, out);
+    DIR_CHECK_LAUNCH("hash_bucket_i64");
+    return DIR_OK;
+}
+
+extern "C" int dir_bucketize_f32(const float* x, int64_t n, const float* boundaries, int nb, int64_t* out,
+                                 dir_stream_t stream) {
+    DIR_CHECK_ARG(x && out && n >= 0 && nb >= 0 && (nb == 0 || boundaries), "dir_bucketize_f32: bad argument");
+    if (n == 0) return DIR_OK;
+    hipLaunchKernelGGL(bucketize_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n, boundaries,
+                       nb, out);
+    DIR_CHECK_LAUNCH("bucketize");
+    return DIR_OK;
+}
+
+extern "C" void dir_shard_div_owner(int64_t id, int64_t vocab, int P, int* owner, int64_t* local) {
+    const int64_t q = vocab / P, r = vocab % P;
+    div_owner(id, q, r, r * (q + 1), owner, local);
+}
+
+extern "C" int dir_shard_route(const int64_t* ids, int64_t n, const int64_t* vocab, int F, int P, int32_t* owner,
+                               int64_t* local, dir_stream_t stream) {
+    DIR_CHECK_ARG(ids && vocab && owner && local && n >= 0 && F > 0 && P > 0, "dir_shard_route: bad argument");
+    if (n == 0) return DIR_OK;
+    hipLaunchKernelGGL(shard_route_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, as_stream(stream), ids, n, vocab, F,
+                       P, owner, local);
+    DIR_CHECK_LAUNCH("shard_route");
+    return DIR_OK;
+}
+
+extern "C" int dir_gather_rows_f32(const float* const* tables, int K, const int32_t* slot, const int64_t* row,
+                                   int64_t n, float* out, dir_stream_t stream) {
+    DIR_CHECK_ARG(tables && row && out && K > 0 && n >= 0, "dir_gather_rows_f32: bad argument");
+    if (n == 0) return DIR_OK;
+    const bool vec = (K % 4 == 0) && aligned16(out);
+    int lps = 1;
+    while (lps < (vec ? K / 4 : K)) lps <<= 1;
+    dim3 grid(grid_for((n * lps + 255) / 256));
+    if (vec) hipLaunchKernelGGL((gather_rows_k<4>), grid, dim3(256), 0, as_stream(stream), tables, K, lps, slot, row, n, out);
+    else hipLaunchKernelGGL((gather_rows_k<1>), grid, dim3(256), 0, as_stream(stream), tables, K, lps, slot, row, n, out);
+    DIR_CHECK_LAUNCH("gather_rows");
+    return DIR_OK;
+}

@@ -1,0 +1,192 @@
+"""deepfm.py -- DeepFM forward on the HIP path, keeping the reference constructor kwargs.
+
+Mirrors models/DeepFM/deepFM.py (reference):
+  DeepFM.__init__ kwargs                                  :55-73
+  _DeepFM_model_fn: inputs -> dnn_fm logits + linear      :143-223
+  myself_input_layer (one shared embedding set)           :363-400   -> ops.gather_fm / embedding_bag
+  fm_logit_fn                                             :321-335   -> fused in ops.gather_fm
+  dnn_logit_fn                                            :284-319   -> torch linear (rocBLAS) + BN
+  _linear_logit_fn_builder                                :255-275   -> ops.linear_logit
+  head predictions (sigmoid / [1-p, p] / class_ids)       :107-117 + [TF-upstream] binary head
+Training-only kwargs (optimizers, loss_reduction, warm_start_from, config, model_dir ...) are accepted
+and stored; this module is the forward path.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from ._input import collect_ids, categorical_of
+
+
+def _glorot_uniform_(w):  # [TF-upstream] glorot_uniform_initializer, deepFM.py:299
+    fan_out, fan_in = w.shape
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return nn.init.uniform_(w, -lim, lim)
+
+
+class _BatchNormInfer(nn.Module):
+    """tf.layers.batch_normalization in inference form (deepFM.py:303-308): eps 1e-3, gamma and beta."""
+
+    def __init__(self, n, eps=1e-3, scale=True):
+        super().__init__()
+        self.eps = eps
+        self.gamma = nn.Parameter(torch.ones(n)) if scale else None
+        self.beta = nn.Parameter(torch.zeros(n))
+        self.register_buffer("moving_mean", torch.zeros(n))
+        self.register_buffer("moving_variance", torch.ones(n))
+
+    def forward(self, x):
+        inv = torch.rsqrt(self.moving_variance + self.eps)
+        if self.gamma is not None:
+            inv = inv * self.gamma
+        return x * inv + (self.beta - self.moving_mean * inv)
+
+
+class DeepFM(nn.Module):
+    def __init__(self, model_dir=None, linear_feature_columns=None, linear_optimizer="Ftrl",
+                 linear_sparse_combiner="sum", dnn_feature_columns=None, dnn_optimizer="Adagrad",
+                 dnn_hidden_units=None, dnn_activation_fn=torch.relu, dnn_dropout=None, fm_embedding_size=None,
+                 n_classes=2, weight_column=None, label_vocabulary=None, input_layer_partitioner=None,
+                 config=None, warm_start_from=None, loss_reduction="sum", batch_norm=False):
+        super().__init__()
+        linear_feature_columns = list(linear_feature_columns or [])
+        dnn_feature_columns = list(dnn_feature_columns or [])
+        if not (linear_feature_columns + dnn_feature_columns):
+            raise ValueError("empty columns.")                                   # deepFM.py:104-105
+        if n_classes != 2:
+            raise NotImplementedError("only the binary head (n_classes=2) is on the HIP path")
+        for c in dnn_feature_columns:
+            if not getattr(c, "is_dense", False):
+                raise ValueError("Items of feature_columns must be a _DenseColumn. You can wrap a categorical "
+                                 "column with an embedding_column or indicator_column. Given: {}".format(c))  # :371-373
+            if fm_embedding_size is not None and c.dimension != fm_embedding_size:
+                raise ValueError("every dnn column must have dimension fm_embedding_size (deepFM.py:329)")
+        self.hparams = dict(model_dir=model_dir, linear_optimizer=linear_optimizer, dnn_optimizer=dnn_optimizer,
+                            dnn_dropout=dnn_dropout, weight_column=weight_column, label_vocabulary=label_vocabulary,
+                            input_layer_partitioner=input_layer_partitioner, config=config,
+                            warm_start_from=warm_start_from, loss_reduction=loss_reduction)
+        self.linear_feature_columns = linear_feature_columns
+        self.dnn_feature_columns = dnn_feature_columns
+        self.linear_sparse_combiner = linear_sparse_combiner
+        self.activation = dnn_activation_fn
+        self.K = fm_embedding_size if fm_embedding_size is not None else (
+            dnn_feature_columns[0].dimension if dnn_feature_columns else 0)
+        self.F = len(dnn_feature_columns)
+        # embedding_weights per column ([TF-upstream] truncated normal, stddev 1/sqrt(K))
+        self.embedding_weights = nn.ParameterList()
+        for c in dnn_feature_columns:
+            w = torch.empty(c.num_buckets, c.dimension)
+            nn.init.trunc_normal_(w, std=1.0 / math.sqrt(c.dimension), a=-2.0 / math.sqrt(c.dimension),
+                                  b=2.0 / math.sqrt(c.dimension))
+            self.embedding_weights.append(nn.Parameter(w))
+        # linear_model weights: zeros ([TF-upstream]), bias zero
+        self.linear_weights = nn.ParameterList(
+            [nn.Parameter(torch.zeros(categorical_of(c).num_buckets)) for c in linear_feature_columns])
+        self.linear_bias = nn.Parameter(torch.zeros(1))
+        # dnn (deepFM.py:292-317)
+        self.hidden = nn.ModuleList()
+        self.bns = nn.ModuleList()
+        d = self.F * self.K
+        if dnn_feature_columns:
+            if dnn_hidden_units is None:
+                raise ValueError("dnn_hidden_units must be given (deepFM.py:292 iterates it)")
+            for n in dnn_hidden_units:
+                lin = nn.Linear(d, n)
+                _glorot_uniform_(lin.weight)
+                nn.init.zeros_(lin.bias)
+                self.hidden.append(lin)
+                if batch_norm:
+                    self.bns.append(_BatchNormInfer(n))
+                d = n
+            self.logits_layer = nn.Linear(d, 1)
+            _glorot_uniform_(self.logits_layer.weight)
+            nn.init.zeros_(self.logits_layer.bias)
+        self._emb_ts = None
+        self._lin_ts = None
+
+    # ---- TableSets follow the parameters' storage (rebuilt when .to()/.cuda() moved them) ------------
+    def _tablesets(self):
+        key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
+        if getattr(self, "_ts_key", None) != key:
+            self._emb_ts = ops.TableSet([p.data for p in self.embedding_weights]) if len(self.embedding_weights) else None
+            self._lin_ts = ops.TableSet([p.data for p in self.linear_weights]) if len(self.linear_weights) else None
+            self._ts_key = key
+        return self._emb_ts, self._lin_ts
+
+    # ---- logit builders ---------------------------------------------------------------------------
+    def dnn_logit_fn(self, net):
+        for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
+            net = self.activation(lin(net))
+            if len(self.bns):
+                net = self.bns[i](net)
+        return self.logits_layer(net)                                            # :311-317
+
+    def dnn_fm_logit_fn(self, features, device):
+        emb_ts, _ = self._tablesets()
+        got = collect_ids(self.dnn_feature_columns, features, device)
+        if got[0] == "onehot":
+            emb, fm = ops.gather_fm(emb_ts, got[1])                              # inputs + fm_logit_fn, one pass
+        else:
+            _, vals, offs, wts, _ = got
+            comb = self.dnn_feature_columns[0].combiner
+            if any(c.combiner != comb for c in self.dnn_feature_columns):
+                raise NotImplementedError("mixed combiners across dnn columns")
+            emb = ops.embedding_bag(emb_ts, vals, offs, wts, combiner=comb, field_major=True)
+            fm = ops.fm_logit(emb, self.F, self.K)
+        return fm + self.dnn_logit_fn(emb)                                       # deepFM.py:337-338
+
+    def linear_logit_fn(self, features, device):
+        _, lin_ts = self._tablesets()
+        got = collect_ids(self.linear_feature_columns, features, device)
+        if got[0] == "onehot":
+            return ops.linear_logit(lin_ts, got[1], bias=self.linear_bias.data)
+        _, vals, offs, wts, _ = got
+        return ops.linear_logit(lin_ts, vals, offs, wts, combiner=self.linear_sparse_combiner,
+                                bias=self.linear_bias.data, field_major=True)
+
+    def forward(self, features):
+        if not isinstance(features, dict):
+            raise ValueError("features should be a dictionary of `Tensor`s. Given type: {}".format(type(features)))  # :159-161
+        device = self.linear_bias.device
+        logits = None
+        if self.dnn_feature_columns:
+            logits = self.dnn_fm_logit_fn(features, device)
+        if self.linear_feature_columns:
+            lin = self.linear_logit_fn(features, device)
+            logits = lin if logits is None else logits + lin                     # add_n, deepFM.py:223
+        return logits
+
+    def forward_ids(self, dnn_ids, linear_ids=None):
+        """Fast path for pre-assembled one-hot id matrices [B, F] (any strides)."""
+        emb_ts, lin_ts = self._tablesets()
+        emb, fm = ops.gather_fm(emb_ts, dnn_ids)
+        logits = fm + self.dnn_logit_fn(emb)
+        if linear_ids is not None and lin_ts is not None:
+            logits = logits + ops.linear_logit(lin_ts, linear_ids, bias=self.linear_bias.data)
+        return logits
+
+    @torch.no_grad()
+    def predict(self, features):
+        """Binary head predictions ([TF-upstream] _binary_logistic_head_with_sigmoid_cross_entropy_loss)."""
+        logits = self.forward(features)
+        logistic = torch.sigmoid(logits)
+        two = torch.cat([torch.zeros_like(logits), logits], dim=-1)
+        return {"logits": logits, "logistic": logistic, "probabilities": torch.softmax(two, dim=-1),
+                "class_ids": torch.argmax(two, dim=-1, keepdim=True)}
+
+    def tf_variable_names(self):
+        """Reference checkpoint names of the parameters (deepFM.py:173-196,206-209 scopes)."""
+        names = {}
+        for c, _ in zip(self.dnn_feature_columns, self.embedding_weights):
+            names["embedding_weights.%d" % len(names)] = "dnn_fm_inputs/myself_input_layer/%s/embedding_weights" % c.name
+        for i in range(len(self.hidden)):
+            names["hidden.%d.weight" % i] = "dnn_fm/hiddenlayer_%d/kernel" % i
+            names["hidden.%d.bias" % i] = "dnn_fm/hiddenlayer_%d/bias" % i
+        names["logits_layer.weight"] = "dnn_fm/logits/kernel"
+        names["logits_layer.bias"] = "dnn_fm/logits/bias"
+        for i, c in enumerate(self.linear_feature_columns):
+            names["linear_weights.%d" % i] = "linear/linear_model/%s/weights" % categorical_of(c).name
+        names["linear_bias"] = "linear/linear_model/bias_weights"
+        return names

@@ -1,0 +1,331 @@
+"""ops.py -- functional ops over torch ROCm tensors; one per reference closure, each a thin call through
+the C ABI (include/dir_hip.h) on torch's current HIP stream.
+
+torch is plumbing here: device memory, streams, tensors as buffers.  Every op requires CUDA(ROCm)
+tensors and the in-tree libdir_hip.so; there is no CPU or eager fallback (a missing library or a CPU
+tensor raises).
+
+Reference closures (relative to /root/reference):
+  embedding_bag / TableSet   myself_input_layer            models/DeepFM/deepFM.py:363-400
+  fm_logit                   fm_logit_fn                   models/DeepFM/deepFM.py:321-335
+  gather_fm                  deepFM.py:169-177 + :321-335 fused (one pass over the rows)
+  linear_logit               _linear_logit_fn_builder      models/DeepFM/deepFM.py:255-275
+  cross_op / cross_network   _cross_op/_cross_architecture models/DeepCrossNetwork/DeepCrossNetwork.py:336-367
+  din_attention_pool         (no reference code; README.md:27)
+  cin_layer                  (no reference code; README.md:28)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+SUM, MEAN, SQRTN = 0, 1, 2
+_COMBINERS = {"sum": SUM, "mean": MEAN, "sqrtn": SQRTN, SUM: SUM, MEAN: MEAN, SQRTN: SQRTN}
+PRUNE_NONPOSITIVE_WEIGHTS = 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (ROCm) tensor: the HIP path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class TableSet:
+    """F embedding tables [vocab_f, K] plus the device array of their base pointers (built once; the
+    kernels read table f's base with a scalar load).  Mirrors the per-column `embedding_weights`
+    variables created under myself_input_layer (deepFM.py:386-390)."""
+
+    def __init__(self, tables):
+        tables = list(tables)
+        if not tables:
+            raise ValueError("empty columns.")  # deepFM.py:104-105
+        K = tables[0].shape[-1] if tables[0].dim() == 2 else 1
+        for i, t in enumerate(tables):
+            _dev(t, torch.float32, "table %d" % i)
+            if not t.is_contiguous():
+                raise ValueError("table %d must be contiguous" % i)
+            k = t.shape[-1] if t.dim() == 2 else 1
+            if k != K:
+                raise ValueError("all tables of one TableSet share K (got %d and %d)" % (K, k))
+            if (K * 4) % 16 == 0 and t.data_ptr() % 16:
+                raise ValueError("table %d is not 16-byte aligned" % i)
+        self.tables = tables
+        self.F = len(tables)
+        self.K = K
+        self.vocab = [int(t.shape[0]) for t in tables]
+        self.device = tables[0].device
+        self.ptrs = torch.tensor([t.data_ptr() for t in tables], dtype=torch.int64, device=self.device)
+        self.vocab_dev = torch.tensor(self.vocab, dtype=torch.int64, device=self.device)
+
+    def refresh(self):
+        """Rebuild the pointer array (after tables were re-allocated, e.g. .to())."""
+        self.ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=self.device)
+
+
+def _as_tableset(tables):
+    return tables if isinstance(tables, TableSet) else TableSet(tables)
+
+
+def _onehot_strides(ids, F):
+    """ids [B,F] (any strides) or [F,B] given as transposed view -> (B, stride_b, stride_f)."""
+    if ids.dim() != 2 or ids.shape[1] != F:
+        raise ValueError("one-hot ids must be [B, F=%d], got %s" % (F, tuple(ids.shape)))
+    return ids.shape[0], ids.stride(0), ids.stride(1)
+
+
+def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", field_major=False, flags=0,
+                  out=None):
+    """Multi-slot embedding bag -> [B, F*K] (slot order).
+
+    one-hot : ids LongTensor [B, F] (arbitrary strides, e.g. torch.stack(per_field).t()).
+    multi-hot: ids [nnz], offsets [B*F+1]; bag(b,f) = b*F+f, or f*B+b when field_major (the layout
+               that concatenating per-column CSR inputs gives); weights optional [nnz].
+    """
+    ts = _as_tableset(tables)
+    _dev(ids, torch.int64, "ids")
+    lib = _lib.load()
+    F, K = ts.F, ts.K
+    if offsets is None:
+        B, sb, sf = _onehot_strides(ids, F)
+    else:
+        _dev(offsets, torch.int64, "offsets")
+        if not (ids.is_contiguous() and offsets.is_contiguous()):
+            raise ValueError("multi-hot ids/offsets must be contiguous")
+        B = (offsets.numel() - 1) // F
+        if offsets.numel() != B * F + 1:
+            raise ValueError("offsets must have B*F+1 entries")
+        sb, sf = (1, B) if field_major else (F, 1)
+        if weights is not None:
+            _dev(weights, torch.float32, "weights")
+    if out is None:
+        out = torch.empty((B, F * K), dtype=torch.float32, device=ts.device)
+    _dev(out, torch.float32, "out")
+    _lib.check(lib.dir_embedding_bag_f32(_ptr(ts.ptrs), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
+                                         _COMBINERS[combiner], flags, B, _ptr(out), out.stride(0), _stream()))
+    return out
+
+
+def check_ids(tables, ids, offsets=None, field_major=False):
+    """Debug aid: raise DIR_E_RANGE if any id >= vocab ([TF-upstream] CPU lookups raise InvalidArgument)."""
+    ts = _as_tableset(tables)
+    lib = _lib.load()
+    if offsets is None:
+        B, sb, sf = _onehot_strides(ids, ts.F)
+    else:
+        B = (offsets.numel() - 1) // ts.F
+        sb, sf = (1, B) if field_major else (ts.F, 1)
+    bad = torch.zeros(1, dtype=torch.int32, device=ts.device)
+    _lib.check(lib.dir_check_ids(_ptr(ts.vocab_dev), ts.F, _ptr(ids), _ptr(offsets), sb, sf, B, _ptr(bad), _stream()))
+    n = int(bad.item())
+    if n:
+        raise _lib.DirError(_lib.DIR_E_RANGE, "%d ids are >= their table's vocabulary size" % n)
+
+
+def fm_logit(emb, F, K, out=None):
+    """fm_logit_fn (deepFM.py:321-335): emb [B, F*K] -> [B, 1]."""
+    _dev(emb, torch.float32, "emb")
+    if emb.dim() != 2 or emb.shape[1] != F * K or emb.stride(1) != 1:
+        raise ValueError("emb must be [B, F*K] with unit inner stride")  # deepFM.py:329 reshape contract
+    B = emb.shape[0]
+    if out is None:
+        out = torch.empty((B, 1), dtype=torch.float32, device=emb.device)
+    _lib.check(_lib.load().dir_fm_second_order_f32(_ptr(emb), emb.stride(0), B, F, K, _ptr(out), _stream()))
+    return out
+
+
+def gather_fm(tables, ids, want_emb=True, out=None, fm=None):
+    """Fused one-hot gather + FM second-order: returns (emb [B, F*K] or None, fm_logit [B, 1])."""
+    ts = _as_tableset(tables)
+    _dev(ids, torch.int64, "ids")
+    B, sb, sf = _onehot_strides(ids, ts.F)
+    if want_emb and out is None:
+        out = torch.empty((B, ts.F * ts.K), dtype=torch.float32, device=ts.device)
+    if fm is None:
+        fm = torch.empty((B, 1), dtype=torch.float32, device=ts.device)
+    _lib.check(_lib.load().dir_gather_fm_fused_f32(_ptr(ts.ptrs), ts.F, ts.K, _ptr(ids), sb, sf, B,
+                                                   _ptr(out) if want_emb else None,
+                                                   out.stride(0) if want_emb else 0, _ptr(fm), _stream()))
+    return (out if want_emb else None), fm
+
+
+def linear_logit(weights, ids, offsets=None, entry_weights=None, combiner="sum", bias=None, field_major=False,
+                 out=None, accumulate=False):
+    """First-order term, units = 1 (deepFM.py:255-275): -> [B, 1]."""
+    ts = _as_tableset(weights)
+    if ts.K != 1:
+        raise ValueError("linear_logit: weights are [vocab] or [vocab, 1] columns (units = 1)")
+    _dev(ids, torch.int64, "ids")
+    if offsets is None:
+        B, sb, sf = _onehot_strides(ids, ts.F)
+    else:
+        _dev(offsets, torch.int64, "offsets")
+        B = (offsets.numel() - 1) // ts.F
+        sb, sf = (1, B) if field_major else (ts.F, 1)
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs out")
+        out = torch.empty((B, 1), dtype=torch.float32, device=ts.device)
+    if bias is not None:
+        _dev(bias, torch.float32, "bias")
+    _lib.check(_lib.load().dir_linear_sparse_sum_f32(_ptr(ts.ptrs), ts.F, _ptr(ids), _ptr(offsets), _ptr(entry_weights),
+                                                     sb, sf, _COMBINERS[combiner], _ptr(bias), int(accumulate), B,
+                                                     _ptr(out), _stream()))
+    return out
+
+
+def cross_network(x0, w, b, out=None):
+    """_cross_architecture (DeepCrossNetwork.py:350-367): x0 [B,d], w,b [L,d] -> x_L [B,d]."""
+    _dev(x0, torch.float32, "x0")
+    _dev(w, torch.float32, "w")
+    _dev(b, torch.float32, "b")
+    if x0.dim() != 2 or x0.stride(1) != 1:
+        raise ValueError("x0 must be [B, d] with unit inner stride")
+    B, d = x0.shape
+    if w.dim() != 2 or w.shape[1] != d or tuple(b.shape) != tuple(w.shape):
+        raise ValueError("w and b must be [L, d=%d]" % d)
+    w = w.contiguous()
+    b = b.contiguous()
+    if out is None:
+        out = torch.empty((B, d), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().dir_dcn_cross_f32(_ptr(x0), x0.stride(0), _ptr(w), _ptr(b), w.shape[0], B, d, _ptr(out),
+                                             out.stride(0), _stream()))
+    return out
+
+
+def cross_op(x0, x, w, b, out=None):
+    """_cross_op (DeepCrossNetwork.py:336-347), one layer: y = x0 * (x . w)[:, None] + b + x."""
+    _dev(x0, torch.float32, "x0")
+    _dev(x, torch.float32, "x")
+    if x0.shape != x.shape or x0.dim() != 2 or x0.stride(1) != 1 or x.stride() != x0.stride():
+        raise ValueError("cross_op: x0 and x must be [B, d] with the same strides")
+    B, d = x0.shape
+    w = _dev(w, torch.float32, "w").reshape(-1).contiguous()
+    b = _dev(b, torch.float32, "b").reshape(-1).contiguous()
+    if w.numel() != d or b.numel() != d:
+        raise ValueError("cross_op: w and b must be [d=%d]" % d)
+    if out is None:
+        out = torch.empty((B, d), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().dir_dcn_cross_op_f32(_ptr(x0), _ptr(x), x0.stride(0), _ptr(w), _ptr(b), B, d, _ptr(out),
+                                                out.stride(0), _stream()))
+    return out
+
+
+def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, want_scores=False):
+    """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T])."""
+    _dev(table, torch.float32, "table")
+    _dev(hist, torch.int64, "hist")
+    _dev(cand, torch.int64, "cand")
+    if hist_len is not None:
+        _dev(hist_len, torch.int32, "hist_len")
+    B, T = hist.shape
+    K = table.shape[1]
+    H1, H2 = W1.shape[1], W2.shape[1]
+    if tuple(W1.shape) != (4 * K, H1) or tuple(W2.shape) != (H1, H2) or W3.numel() != H2:
+        raise ValueError("DIN weights must be W1 [4K,H1], W2 [H1,H2], W3 [H2]")
+    args = [t.contiguous() for t in (W1, b1, W2, b2, W3, b3)]
+    for t in args:
+        _dev(t, torch.float32, "DIN weight")
+    hist = hist.contiguous()
+    out = torch.empty((B, K), dtype=torch.float32, device=table.device)
+    scores = torch.empty((B, T), dtype=torch.float32, device=table.device) if want_scores else None
+    _lib.check(_lib.load().dir_din_attention_pool_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
+                                                      _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
+                                                      H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B,
+                                                      _ptr(out), _ptr(scores), _stream()))
+    return (out, scores) if want_scores else out
+
+
+def cin_layer(x0, xk, W, pooled=None):
+    """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
+    (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept)."""
+    _dev(x0, torch.float32, "x0")
+    _dev(xk, torch.float32, "xk")
+    _dev(W, torch.float32, "W")
+    if not (x0.is_contiguous() and xk.is_contiguous() and W.is_contiguous()):
+        raise ValueError("cin_layer operands must be contiguous")
+    B, m, D = x0.shape
+    Hp = xk.shape[1]
+    H = W.shape[0]
+    if W.shape[1] != Hp * m or xk.shape[0] != B or xk.shape[2] != D:
+        raise ValueError("cin_layer: W must be [H, Hp*m], xk [B,Hp,D]")
+    xout = torch.empty((B, H, D), dtype=torch.float32, device=x0.device)
+    if pooled is None:
+        pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().dir_cin_layer_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout), _ptr(pooled),
+                                             pooled.stride(0), _stream()))
+    return xout, pooled
+
+
+# ---- id paths (A3) ---------------------------------------------------------------------------------
+def fingerprint64(s):
+    if isinstance(s, str):
+        s = s.encode("utf-8")
+    return int(_lib.load().dir_fingerprint64(s, len(s)))
+
+
+def hash_bucket_strings(strings, num_buckets):
+    """categorical_column_with_hash_bucket on string keys (DeepCrossNetwork/train.py:85-86): host."""
+    bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in strings]
+    n = len(bs)
+    arr = (ctypes.c_char_p * n)(*bs)
+    lens = (ctypes.c_int64 * n)(*[len(b) for b in bs])
+    out = (ctypes.c_int64 * n)()
+    _lib.check(_lib.load().dir_hash_bucket_fast(arr, lens, n, num_buckets, out))
+    return torch.tensor(list(out), dtype=torch.int64)
+
+
+def hash_bucket_ints(keys, num_buckets):
+    """Integer keys hashed on the device as their decimal text ([TF-upstream] as_string -> hash)."""
+    _dev(keys, torch.int64, "keys")
+    keys = keys.contiguous()
+    out = torch.empty_like(keys)
+    _lib.check(_lib.load().dir_hash_bucket_i64_device(_ptr(keys), keys.numel(), num_buckets, _ptr(out), _stream()))
+    return out
+
+
+def bucketize(x, boundaries):
+    """bucketized_column: number of boundaries <= x -> int64 ids."""
+    _dev(x, torch.float32, "x")
+    _dev(boundaries, torch.float32, "boundaries")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int64, device=x.device)
+    _lib.check(_lib.load().dir_bucketize_f32(_ptr(x), x.numel(), _ptr(boundaries.contiguous()), boundaries.numel(),
+                                             _ptr(out), _stream()))
+    return out
+
+
+def shard_route(ids, vocab_dev, P):
+    """'div' owner / local row of every id of a flattened [.., F] id array; vocab_dev: device int64 [F].
+    -> (owner int32, local int64), same shape as ids."""
+    _dev(ids, torch.int64, "ids")
+    _dev(vocab_dev, torch.int64, "vocab_dev")
+    ids = ids.contiguous()
+    owner = torch.empty(ids.shape, dtype=torch.int32, device=ids.device)
+    local = torch.empty_like(ids)
+    _lib.check(_lib.load().dir_shard_route(_ptr(ids), ids.numel(), _ptr(vocab_dev), vocab_dev.numel(), P, _ptr(owner),
+                                           _ptr(local), _stream()))
+    return owner, local
+
+
+def gather_rows(tables, slot, row):
+    """Owner-side flat lookup of the sharded path: out[i] = tables[slot[i]][row[i]] (row < 0 -> zeros)."""
+    ts = _as_tableset(tables)
+    _dev(row, torch.int64, "row")
+    if slot is not None:
+        _dev(slot, torch.int32, "slot")
+    n = row.numel()
+    out = torch.empty((n, ts.K), dtype=torch.float32, device=ts.device)
+    _lib.check(_lib.load().dir_gather_rows_f32(_ptr(ts.ptrs), ts.K, _ptr(slot), _ptr(row.contiguous()), n, _ptr(out),
+                                               _stream()))
+    return out

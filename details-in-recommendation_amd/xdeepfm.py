@@ -1,0 +1,95 @@
+"""xdeepfm.py -- xDeepFM forward (linear + CIN + DNN) on the HIP path.  No reference code exists
+(/root/reference/README.md:28 links arXiv:1803.05170); the embedding / linear / DNN parts reuse the
+DeepFM-style column handling of the reference (models/DeepFM/deepFM.py:169-177,255-319)."""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from ._input import collect_ids, categorical_of
+from .deepfm import _glorot_uniform_
+
+
+class XDeepFM(nn.Module):
+    def __init__(self, linear_feature_columns=None, dnn_feature_columns=None, cin_layer_sizes=(128, 128, 128),
+                 dnn_hidden_units=(400, 400), dnn_activation_fn=torch.relu):
+        super().__init__()
+        self.linear_feature_columns = list(linear_feature_columns or [])
+        self.dnn_feature_columns = list(dnn_feature_columns or [])
+        if not self.dnn_feature_columns:
+            raise ValueError("empty columns.")
+        self.m = len(self.dnn_feature_columns)
+        self.D = self.dnn_feature_columns[0].dimension
+        if any(c.dimension != self.D for c in self.dnn_feature_columns):
+            raise ValueError("CIN needs one embedding dimension for every field")
+        self.activation = dnn_activation_fn
+        s = 1.0 / math.sqrt(self.D)
+        self.embedding_weights = nn.ParameterList(
+            [nn.Parameter(nn.init.trunc_normal_(torch.empty(c.num_buckets, self.D), std=s, a=-2 * s, b=2 * s))
+             for c in self.dnn_feature_columns])
+        self.linear_weights = nn.ParameterList(
+            [nn.Parameter(torch.zeros(categorical_of(c).num_buckets)) for c in self.linear_feature_columns])
+        self.linear_bias = nn.Parameter(torch.zeros(1))
+        self.cin_layer_sizes = tuple(cin_layer_sizes)
+        self.cin_W = nn.ParameterList()
+        hp = self.m
+        for h in self.cin_layer_sizes:
+            self.cin_W.append(nn.Parameter(_glorot_uniform_(torch.empty(h, hp * self.m))))
+            hp = h
+        self.cin_out = nn.Linear(sum(self.cin_layer_sizes), 1)
+        self.hidden = nn.ModuleList()
+        d = self.m * self.D
+        for n in dnn_hidden_units:
+            lin = nn.Linear(d, n)
+            _glorot_uniform_(lin.weight)
+            nn.init.zeros_(lin.bias)
+            self.hidden.append(lin)
+            d = n
+        self.dnn_out = nn.Linear(d, 1)
+        self._ts_key = None
+
+    def _tablesets(self):
+        key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
+        if self._ts_key != key:
+            self._emb_ts = ops.TableSet([p.data for p in self.embedding_weights])
+            self._lin_ts = ops.TableSet([p.data for p in self.linear_weights]) if len(self.linear_weights) else None
+            self._ts_key = key
+        return self._emb_ts, self._lin_ts
+
+    def cin(self, x0):
+        """x0 [B, m, D] -> pooled features [B, sum(H_k)]."""
+        B = x0.shape[0]
+        pooled = torch.empty((B, sum(self.cin_layer_sizes)), dtype=torch.float32, device=x0.device)
+        xk, off = x0, 0
+        for W, h in zip(self.cin_W, self.cin_layer_sizes):
+            xk, _ = ops.cin_layer(x0, xk, W.data, pooled=pooled[:, off:off + h])
+            off += h
+        return pooled
+
+    def forward_embedded(self, emb, linear_logit=None):
+        B = emb.shape[0]
+        logits = self.cin_out(self.cin(emb.view(B, self.m, self.D)))
+        net = emb
+        for lin in self.hidden:
+            net = self.activation(lin(net))
+        logits = logits + self.dnn_out(net)
+        if linear_logit is not None:
+            logits = logits + linear_logit
+        return logits
+
+    def forward(self, features):
+        device = self.linear_bias.device
+        emb_ts, lin_ts = self._tablesets()
+        got = collect_ids(self.dnn_feature_columns, features, device)
+        if got[0] == "onehot":
+            emb = ops.embedding_bag(emb_ts, got[1])
+        else:
+            emb = ops.embedding_bag(emb_ts, got[1], got[2], got[3], combiner=self.dnn_feature_columns[0].combiner,
+                                    field_major=True)
+        lin = None
+        if lin_ts is not None:
+            g2 = collect_ids(self.linear_feature_columns, features, device)
+            lin = ops.linear_logit(lin_ts, g2[1], bias=self.linear_bias.data) if g2[0] == "onehot" else \
+                ops.linear_logit(lin_ts, g2[1], g2[2], g2[3], bias=self.linear_bias.data, field_major=True)
+        return self.forward_embedded(emb, lin)

@@ -1,0 +1,191 @@
+/*
+ * dir_hip.h -- C ABI of libdir_hip.so: the MI355X (gfx950) drop-in boundary for the
+ * embedding-lookup + feature-interaction hot path of yinyajun/Details-In-Recommendation.
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, and is asynchronous on the
+ * hipStream_t it is given (passed as void*).  The caller owns every buffer; the library never
+ * allocates device memory and keeps no global mutable state besides a thread-local error string.
+ * Return value: DIR_OK (0) or a negative DIR_E_* code; dir_last_error() describes the failure.
+ *
+ * Citations are relative to the reference tree (/root/reference).  "[TF-upstream]" marks TensorFlow
+ * 1.x library behaviour that the reference calls but does not contain.
+ *
+ * All device pointers must be 16-byte aligned when the row width in bytes is a multiple of 16
+ * (the kernels use 16-byte vector accesses on that path); otherwise 4-byte alignment suffices.
+ */
+#ifndef DIR_HIP_H_
+#define DIR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dir_stream_t; /* hipStream_t */
+
+#define DIR_VERSION 100 /* 0.1.0 */
+
+enum {
+    DIR_OK = 0,
+    DIR_E_BADARG = -1,      /* null pointer, non-positive size, unsupported shape */
+    DIR_E_RANGE = -2,       /* an id outside [0, vocab) found by dir_check_ids */
+    DIR_E_HIP = -3,         /* a HIP runtime call failed */
+    DIR_E_UNSUPPORTED = -4  /* shape outside what the kernels are built for */
+};
+
+/* combiner of an embedding bag ([TF-upstream] embedding_lookup_sparse combiner=) */
+enum { DIR_COMBINER_SUM = 0, DIR_COMBINER_MEAN = 1, DIR_COMBINER_SQRTN = 2 };
+
+/* flags for dir_embedding_bag_f32 */
+enum {
+    DIR_BAG_PRUNE_NONPOSITIVE_WEIGHTS = 1 /* drop entries with weight <= 0 ([TF-upstream]
+                                             safe_embedding_lookup_sparse, later 1.x) */
+};
+
+int dir_version(void);
+const char* dir_last_error(void);
+
+/* --------------------------------------------------------------------------------------------
+ * A1/A2  multi-slot embedding bag.
+ * Replaces: myself_input_layer                        models/DeepFM/deepFM.py:363-400
+ *           column._get_dense_tensor(...)              models/DeepFM/deepFM.py:387-390
+ *           tf.feature_column.input_layer(...)         models/DeepCrossNetwork/DeepCrossNetwork.py:126
+ *           [TF-upstream] safe_embedding_lookup_sparse -> embedding_lookup_sparse
+ *
+ * tables   device array [F] of device pointers, slot f -> fp32 [vocab_f, K] row-major
+ * ids      one-hot  (offsets == NULL): id of (sample b, slot f) = ids[b*stride_b + f*stride_f]
+ *          multi-hot(offsets != NULL): bag(b,f) = b*stride_b + f*stride_f; its entries are
+ *                   ids[offsets[bag] .. offsets[bag+1]) in order; offsets has B*F+1 entries
+ * weights  NULL or per-entry fp32 weights (multi-hot only)
+ * out      out[b*out_ld + f*K + k]; out_ld >= F*K  (concat of the slots in slot order)
+ *
+ * Semantics (A2): entries with id < 0 are dropped; an empty bag yields zeros; the bag is reduced in
+ * entry order in fp32 (sum of w*row), then 'mean' divides by sum(w) (count when weights == NULL),
+ * 'sqrtn' by sqrt(sum(w*w)) (sqrt(count)).  0 <= id < vocab_f is a precondition (see dir_check_ids).
+ * ------------------------------------------------------------------------------------------ */
+int dir_embedding_bag_f32(const float* const* tables, int F, int K,
+                          const int64_t* ids, const int64_t* offsets, const float* weights,
+                          int64_t stride_b, int64_t stride_f, int combiner, int flags, int64_t B,
+                          float* out, int64_t out_ld, dir_stream_t stream);
+
+/* Validation of the precondition above (debug aid, asynchronous like everything else).
+ * vocab: DEVICE array [F].  bad_count: DEVICE int32; zeroed on the stream, then set to the number of
+ * ids >= vocab_f found (ids < 0 are legal: they are pruned).  The caller reads it back and treats a
+ * non-zero count as DIR_E_RANGE ([TF-upstream] CPU kernels raise InvalidArgument there). */
+int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, const int64_t* offsets,
+                  int64_t stride_b, int64_t stride_f, int64_t B, int32_t* bad_count,
+                  dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A4  FM second-order term.
+ * Replaces: fm_logit_fn                                 models/DeepFM/deepFM.py:321-335
+ * emb[b*emb_ld + f*K + k] -> out[b] = 0.5 * sum_k( (sum_f e)^2 - sum_f e^2 )
+ * Summation order is f ascending, then k ascending (deterministic; matches oracle/ bit for bit).
+ * ------------------------------------------------------------------------------------------ */
+int dir_fm_second_order_f32(const float* emb, int64_t emb_ld, int64_t B, int F, int K, float* out,
+                            dir_stream_t stream);
+
+/* A1+A4 fused for one-hot slots: one pass over the rows.  out may be NULL (FM only); fm may be NULL
+ * (gather only).  Replaces deepFM.py:169-177 (inputs) + :321-335 (fm_logit_fn) in one launch. */
+int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int64_t* ids,
+                            int64_t stride_b, int64_t stride_f, int64_t B, float* out,
+                            int64_t out_ld, float* fm, dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A6  first-order (linear) term, units = 1.
+ * Replaces: _linear_logit_fn_builder                    models/DeepFM/deepFM.py:255-275
+ *           [TF-upstream] feature_column.linear_model(..., sparse_combiner=)
+ * weights  device array [F] of device pointers, slot f -> fp32 [vocab_f]
+ * ids/offsets/entry_weights/strides as in dir_embedding_bag_f32.
+ * out[b] = (accumulate ? out[b] : 0) + (bias ? *bias : 0) + sum_f combine_f(bag(b,f))
+ * ------------------------------------------------------------------------------------------ */
+int dir_linear_sparse_sum_f32(const float* const* weights, int F, const int64_t* ids,
+                              const int64_t* offsets, const float* entry_weights, int64_t stride_b,
+                              int64_t stride_f, int combiner, const float* bias, int accumulate,
+                              int64_t B, float* out, dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A8  DCN cross network, all L layers in one launch.
+ * Replaces: _cross_op / _cross_architecture   models/DeepCrossNetwork/DeepCrossNetwork.py:336-367
+ * x0 [B, d] (row stride x_ld), w,b [L, d] contiguous; out [B, d] (row stride out_ld).
+ * x_{l+1} = ((x0 * (x_l . w_l)) + b_l) + x_l     (evaluation order of DeepCrossNetwork.py:346)
+ * ------------------------------------------------------------------------------------------ */
+int dir_dcn_cross_f32(const float* x0, int64_t x_ld, const float* w, const float* b, int L,
+                      int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream);
+
+/* One cross layer on a distinct x, the literal _cross_op(x0, x, w, b) of DeepCrossNetwork.py:336-347:
+ * out = ((x0 * (x . w)) + b) + x;  x0 and x share the row stride x_ld; w, b are [d]. */
+int dir_dcn_cross_op_f32(const float* x0, const float* x, int64_t x_ld, const float* w, const float* b,
+                         int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A13 DIN local activation unit + weighted pooling (no reference code: README.md:27 links
+ * arXiv:1706.06978; definition in DESIGN.md / oracle).
+ * table [vocab, K]; hist [B, T] int64 (entries j >= hist_len[b] or id < 0 are masked);
+ * cand [B] int64.  For every valid j:  h = table[hist[b,j]], a = table[cand[b]],
+ *   z1 = sigmoid(W1^T [h, a, h-a, h*a] + b1)   W1 [4K, H1]
+ *   z2 = sigmoid(W2^T z1 + b2)                 W2 [H1, H2]
+ *   s_j = W3 . z2 + b3                         W3 [H2]
+ * normalize = 0: w_j = s_j (paper); normalize = 1: w = softmax over valid j of s_j / sqrt(K).
+ * out[b, :] = sum_j w_j h_j  (zeros when no valid j).  scores (optional) [B, T] receives w_j
+ * (0 for masked j).
+ * ------------------------------------------------------------------------------------------ */
+int dir_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
+                               const int32_t* hist_len, const int64_t* cand, int T,
+                               const float* W1, const float* b1, int H1, const float* W2,
+                               const float* b2, int H2, const float* W3, const float* b3,
+                               int normalize, int64_t B, float* out, float* scores,
+                               dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A14 xDeepFM compressed interaction network, one layer (no reference code: README.md:28 links
+ * arXiv:1803.05170).
+ * x0 [B, m, D], xk [B, Hp, D], W [H, Hp*m] (column index i*m + j) ->
+ *   xout[b, h, d] = sum_{i<Hp} sum_{j<m} W[h, i*m+j] * xk[b,i,d] * x0[b,j,d]
+ *   pooled[b*pooled_ld + h] = sum_d xout[b,h,d]      (pooled may be NULL)
+ * The outer product Z is never materialised: it is formed in registers and fed to fp32 MFMA.
+ * ------------------------------------------------------------------------------------------ */
+int dir_cin_layer_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
+                      int64_t B, float* xout, float* pooled, int64_t pooled_ld,
+                      dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A3  categorical id paths.
+ * dir_hash_bucket_fast: HOST function. [TF-upstream] string_to_hash_bucket_fast =
+ *   FarmHash Fingerprint64(bytes) mod num_buckets; call site categorical_column_with_hash_bucket
+ *   models/DeepCrossNetwork/train.py:85-86.  strs: n pointers, lens: n byte lengths.
+ * dir_fingerprint64: HOST, the raw 64-bit fingerprint.
+ * dir_hash_bucket_i64_device: device kernel; ids are formatted as decimal strings (what
+ *   [TF-upstream] as_string does for integer keys) and hashed the same way.
+ * dir_bucketize_f32: device kernel. [TF-upstream] bucketized_column: out = number of boundaries
+ *   <= x (boundaries ascending, nb of them); docstring models/DeepFM/deepFM.py:95.
+ * ------------------------------------------------------------------------------------------ */
+uint64_t dir_fingerprint64(const char* s, int64_t len);
+int dir_hash_bucket_fast(const char* const* strs, const int64_t* lens, int64_t n,
+                         int64_t num_buckets, int64_t* out);
+int dir_hash_bucket_i64_device(const int64_t* keys, int64_t n, int64_t num_buckets, int64_t* out,
+                               dir_stream_t stream);
+int dir_bucketize_f32(const float* x, int64_t n, const float* boundaries, int nb, int64_t* out,
+                      dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * A12 row sharding, TF 'div' rule.
+ * Replaces: min_max_variable_partitioner + partition_strategy='div'
+ *           models/DeepFM/deepFM.py:163-167
+ * dir_shard_div_owner: HOST helper; owner and local row of one id for vocab rows over P shards.
+ * dir_shard_route: device kernel.  ids is a flattened [.., F] array (field of entry i is i % F);
+ *   vocab: DEVICE array [F].  owner[i], local[i] of every id (ids < 0: owner = i % P, local = -1).
+ * dir_gather_rows_f32: the owner-side lookup of the sharded path: out[i, :] = tables[slot[i]][row[i], :]
+ *   (row < 0 -> zeros; slot == NULL -> table 0).  tables: device array of device pointers.
+ * ------------------------------------------------------------------------------------------ */
+void dir_shard_div_owner(int64_t id, int64_t vocab, int P, int* owner, int64_t* local);
+int dir_shard_route(const int64_t* ids, int64_t n, const int64_t* vocab, int F, int P, int32_t* owner,
+                    int64_t* local, dir_stream_t stream);
+int dir_gather_rows_f32(const float* const* tables, int K, const int32_t* slot, const int64_t* row,
+                        int64_t n, float* out, dir_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIR_HIP_H_ */
