@@ -41,6 +41,28 @@ inline int grid_for(int64_t work_blocks, int blocks_per_cu = 8) {
     return g < 1 ? 1 : (int)g;
 }
 
+// Number of 256-thread workgroups of `kernel` that are co-resident on the chip (occupancy x CUs), cached
+// per kernel.  A grid-stride kernel launched with exactly this many workgroups has no partial last round.
+template <typename K>
+inline int resident_blocks(K kernel, size_t shmem = 0) {
+    static thread_local struct { const void* k; size_t sh; int n; } cache[64];
+    static thread_local int used = 0;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < used; ++i)
+        if (cache[i].k == key && cache[i].sh == shmem) return cache[i].n;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, shmem) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const int n = per_cu * kCUs;
+    if (used < 64) cache[used++] = {key, shmem, n};
+    return n;
+}
+
+inline int grid_resident(int64_t work_blocks, int resident) {
+    int64_t g = work_blocks < resident ? work_blocks : resident;
+    return g < 1 ? 1 : (int)g;
+}
+
 }  // namespace dir
 
 // ---- device helpers ------------------------------------------------------------------------

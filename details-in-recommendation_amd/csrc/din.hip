@@ -92,10 +92,11 @@ __global__ __launch_bounds__(256) void din_k(const float* __restrict__ table, Di
     const float inv_sqrt_k = 1.0f / sqrtf((float)K);
 
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        const int len = hist_len ? min((int)hist_len[b], T) : T;
+        const int len = hist_len ? min((int)hist_len[b], T) : T;   // rows j >= len are masked: never computed
         const int64_t cid = cand[b];
         // 1. gather rows -> u
-        for (int q = threadIdx.x; q < T * kc; q += blockDim.x) {
+        for (int j = len + threadIdx.x; j < T; j += blockDim.x) valid[j] = 0;
+        for (int q = threadIdx.x; q < len * kc; q += blockDim.x) {
             const int j = q / kc, c = q - j * kc;
             const int64_t id = hist[b * T + j];
             const bool ok = (j < len) && (id >= 0);
@@ -113,16 +114,18 @@ __global__ __launch_bounds__(256) void din_k(const float* __restrict__ table, Di
         }
         __syncthreads();
         // 2. the two hidden layers
-        dense_rows<JT, true>(u, dm.us, 4 * K, W1, b1, H1, z1, dm.z1s, T);
+        dense_rows<JT, true>(u, dm.us, 4 * K, W1, b1, H1, z1, dm.z1s, len);
         __syncthreads();
-        dense_rows<JT, true>(z1, dm.z1s, H1, W2, b2, H2, z2, dm.z2s, T);
+        dense_rows<JT, true>(z1, dm.z1s, H1, W2, b2, H2, z2, dm.z2s, len);
         __syncthreads();
         // 3. scores
         for (int j = threadIdx.x; j < T; j += blockDim.x) {
             float acc = 0.f;
-            const float* zr = z2 + j * dm.z2s;
-            for (int i = 0; i < H2; ++i) acc = fmaf(zr[i], W3[i], acc);
-            sc[j] = valid[j] ? acc + b3[0] : 0.f;
+            if (j < len) {
+                const float* zr = z2 + j * dm.z2s;
+                for (int i = 0; i < H2; ++i) acc = fmaf(zr[i], W3[i], acc);
+            }
+            sc[j] = (j < len && valid[j]) ? acc + b3[0] : 0.f;
         }
         __syncthreads();
         if (normalize) {
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void din_k(const float* __restrict__ table, Di
         // 4. pooling + optional score output
         for (int k = threadIdx.x; k < K; k += blockDim.x) {
             float acc = 0.f;
-            for (int j = 0; j < T; ++j)
+            for (int j = 0; j < len; ++j)
                 if (valid[j]) acc = fmaf(sc[j], u[j * dm.us + k], acc);
             out[b * K + k] = acc;
         }

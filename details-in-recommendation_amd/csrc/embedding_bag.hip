@@ -25,6 +25,14 @@ template <> struct VecT<1> { using T = float; };
 
 __device__ __forceinline__ float4 ldv(const float* p, float4*) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float ldv(const float* p, float*) { return *p; }
+// non-temporal (streaming) row loads: a table row is read once per launch, so it should not displace
+// the output / id lines in L2 and the Infinity Cache
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldv_nt(const float* p, float4*) {
+    f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ldv_nt(const float* p, float*) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void stv(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void stv(float* p, float v) { *p = v; }
 __device__ __forceinline__ float4 vzero(float4*) { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -65,7 +73,7 @@ __device__ __forceinline__ float fm_tail(V sum, V sq, int lane, int c) {
 // ------------------------------------------------------------------------------------------------
 // one-hot gather, optional concat write, optional fused FM
 // ------------------------------------------------------------------------------------------------
-template <int LPS, int VEC, int KT, int UF, bool DO_FM, bool DO_OUT>
+template <int LPS, int VEC, int KT, int UF, bool DO_FM, bool DO_OUT, bool NT>
 __global__ __launch_bounds__(256) void gather_onehot_k(const float* const* __restrict__ tables,
                                                        const int64_t* __restrict__ ids, int64_t sb,
                                                        int64_t sf, int F, int Krt, int64_t B,
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256) void gather_onehot_k(const float* const* __res
                 row[u] = vzero((V*)nullptr);
                 if (f < F) {
                     const float* t = tables[f];
-                    if (id[u] >= 0) row[u] = ldv(t + id[u] * K + c * VEC, (V*)nullptr);
+                    if (id[u] >= 0) row[u] = NT ? ldv_nt(t + id[u] * K + c * VEC, (V*)nullptr) : ldv(t + id[u] * K + c * VEC, (V*)nullptr);
                 }
             }
 #pragma unroll
@@ -260,16 +268,24 @@ static int env_int(const char* name, int dflt) {
 }
 
 template <int LPS, int VEC, int KT, bool DO_FM, bool DO_OUT>
-static void launch_onehot_uf(int uf, dim3 grid, hipStream_t st, const float* const* tables,
+static void launch_onehot_uf(int uf, bool stream_rows, int64_t work_blocks, hipStream_t st, const float* const* tables,
                              const int64_t* ids, int64_t sb, int64_t sf, int F, int K, int64_t B, float* out,
                              int64_t out_ld, float* fm) {
-#define DIR_GO(UF) \
-    hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT>), grid, dim3(256), 0, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm)
+    static const int nt_force = env_int("DIR_GATHER_NT", -1);   // development override: 0 / 1
+    const bool nt_env = nt_force >= 0 ? nt_force != 0 : stream_rows;
+#define DIR_GO(UF)                                                                                                  \
+    do {                                                                                                            \
+        if (nt_env) {                                                                                               \
+            dim3 grid(grid_resident(work_blocks, resident_blocks(gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, true>))); \
+            hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, true>), grid, dim3(256), 0, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm); \
+        } else {                                                                                                    \
+            dim3 grid(grid_resident(work_blocks, resident_blocks(gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, false>))); \
+            hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, false>), grid, dim3(256), 0, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm); \
+        }                                                                                                           \
+    } while (0)
     switch (uf) {
-        case 2: DIR_GO(2); break;
         case 4: DIR_GO(4); break;
         case 13: DIR_GO(13); break;
-        case 16: DIR_GO(16); break;
         case 26: DIR_GO(26); break;
         default: DIR_GO(8); break;
     }
@@ -278,17 +294,17 @@ static void launch_onehot_uf(int uf, dim3 grid, hipStream_t st, const float* con
 
 template <bool DO_FM, bool DO_OUT>
 static int launch_onehot(const float* const* tables, int F, int K, const int64_t* ids, int64_t sb, int64_t sf,
-                         int64_t B, float* out, int64_t out_ld, float* fm, hipStream_t st) {
+                         int flags, int64_t B, float* out, int64_t out_ld, float* fm, hipStream_t st) {
     const bool vec = (K % 4 == 0) && (!DO_OUT || (out_ld % 4 == 0 && aligned16(out)));
     static const int uf_env = env_int("DIR_GATHER_UF", 0);
-    static const int bpc_env = env_int("DIR_GATHER_BLOCKS_PER_CU", 8);
-    int uf = uf_env > 0 ? uf_env : (F % 13 == 0 ? 13 : 8);
+    int uf = uf_env > 0 ? uf_env : (F == 26 ? 26 : (F % 13 == 0 ? 13 : 8));
+    const bool stream_rows = (flags & DIR_GATHER_STREAM_ROWS) != 0;
     const int lps = next_pow2(vec ? K / 4 : K);
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "embedding row of K=%d floats is wider than one wave covers (max %d)", K, vec ? 256 : 64);
     const int spw = 64 / lps;
     const int64_t waves = (B + spw - 1) / spw;
-    dim3 grid(grid_for((waves + 3) / 4, bpc_env));
-#define DIR_CASE(L, V, KT) launch_onehot_uf<L, V, KT, DO_FM, DO_OUT>(uf, grid, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm)
+    const int64_t grid = (waves + 3) / 4;   // work blocks; the launch picks the resident count
+#define DIR_CASE(L, V, KT) launch_onehot_uf<L, V, KT, DO_FM, DO_OUT>(uf, stream_rows, grid, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm)
     if (vec) {
         switch (lps) {
             case 1: DIR_CASE(1, 4, 4); break;
@@ -360,28 +376,30 @@ extern "C" int dir_embedding_bag_f32(const float* const* tables, int F, int K, c
                                      const int64_t* offsets, const float* weights, int64_t stride_b,
                                      int64_t stride_f, int combiner, int flags, int64_t B, float* out,
                                      int64_t out_ld, dir_stream_t stream) {
-    DIR_CHECK_ARG(tables && ids && out, "dir_embedding_bag_f32: null pointer");
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "dir_embedding_bag_f32: F=%d K=%d B=%lld", F, K, (long long)B);
+    if (B == 0) return DIR_OK;  // an empty batch carries no buffers
+    DIR_CHECK_ARG(tables && ids && out, "dir_embedding_bag_f32: null pointer");
     DIR_CHECK_ARG(out_ld >= (int64_t)F * K, "dir_embedding_bag_f32: out_ld=%lld < F*K=%lld", (long long)out_ld, (long long)F * K);
     DIR_CHECK_ARG(combiner >= DIR_COMBINER_SUM && combiner <= DIR_COMBINER_SQRTN, "dir_embedding_bag_f32: combiner=%d", combiner);
     DIR_CHECK_ARG(offsets || !weights, "dir_embedding_bag_f32: weights need offsets (multi-hot)");
     if (B == 0) return DIR_OK;
     if (!offsets)  // a one-entry bag: every combiner is the identity on it
-        return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, B, out, out_ld, nullptr, as_stream(stream));
+        return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, nullptr, as_stream(stream));
     return launch_csr(tables, F, K, ids, offsets, weights, stride_b, stride_f, combiner, flags, B, out, out_ld, as_stream(stream));
 }
 
 extern "C" int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int64_t* ids,
-                                       int64_t stride_b, int64_t stride_f, int64_t B, float* out,
+                                       int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out,
                                        int64_t out_ld, float* fm, dir_stream_t stream) {
-    DIR_CHECK_ARG(tables && ids && (out || fm), "dir_gather_fm_fused_f32: null pointer");
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "dir_gather_fm_fused_f32: F=%d K=%d B=%lld", F, K, (long long)B);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(tables && ids && (out || fm), "dir_gather_fm_fused_f32: null pointer");
     DIR_CHECK_ARG(!out || out_ld >= (int64_t)F * K, "dir_gather_fm_fused_f32: out_ld=%lld < F*K", (long long)out_ld);
     if (B == 0) return DIR_OK;
     hipStream_t st = as_stream(stream);
-    if (out && fm) return launch_onehot<true, true>(tables, F, K, ids, stride_b, stride_f, B, out, out_ld, fm, st);
-    if (fm) return launch_onehot<true, false>(tables, F, K, ids, stride_b, stride_f, B, nullptr, 0, fm, st);
-    return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, B, out, out_ld, nullptr, st);
+    if (out && fm) return launch_onehot<true, true>(tables, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, fm, st);
+    if (fm) return launch_onehot<true, false>(tables, F, K, ids, stride_b, stride_f, flags, B, nullptr, 0, fm, st);
+    return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, nullptr, st);
 }
 
 extern "C" int dir_fm_second_order_f32(const float* emb, int64_t emb_ld, int64_t B, int F, int K, float* out,

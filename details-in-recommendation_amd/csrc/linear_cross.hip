@@ -120,9 +120,20 @@ __global__ __launch_bounds__(256) void cross_k(const float* __restrict__ x0, int
     constexpr int SPW = 64 / G;
     const int nchunk = d / VEC;
     const int Ld = L * d;
-    for (int i = threadIdx.x; i < Ld; i += blockDim.x) {
-        smem[i] = w[i];
-        smem[Ld + i] = bvec[i];
+    if (VEC == 4) {  // d % 4 == 0: w, b and the LDS image are 16-byte aligned
+        const int n4 = Ld >> 2;
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        const float4* b4 = reinterpret_cast<const float4*>(bvec);
+        float4* s4 = reinterpret_cast<float4*>(smem);
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+            s4[i] = w4[i];
+            s4[n4 + i] = b4[i];
+        }
+    } else {
+        for (int i = threadIdx.x; i < Ld; i += blockDim.x) {
+            smem[i] = w[i];
+            smem[Ld + i] = bvec[i];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -193,9 +204,13 @@ extern "C" int dir_linear_sparse_sum_f32(const float* const* weights, int F, con
 }
 
 template <int G, int VEC>
-static int launch_cross_nv(int nv, dim3 grid, size_t shmem, hipStream_t st, const float* x0, int64_t x_ld,
+static int launch_cross_nv(int nv, int64_t work_blocks, size_t shmem, hipStream_t st, const float* x0, int64_t x_ld,
                            const float* xinit, const float* w, const float* b, int L, int64_t B, int d, float* out, int64_t out_ld) {
-#define DIR_GO(NV) hipLaunchKernelGGL((cross_k<G, NV, VEC>), grid, dim3(256), shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld)
+#define DIR_GO(NV)                                                                                          \
+    do {                                                                                                    \
+        dim3 grid(grid_resident(work_blocks, resident_blocks(cross_k<G, NV, VEC>, shmem)));                 \
+        hipLaunchKernelGGL((cross_k<G, NV, VEC>), grid, dim3(256), shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld); \
+    } while (0)
     if (nv <= 2) DIR_GO(2);
     else if (nv <= 4) DIR_GO(4);
     else if (nv <= 8) DIR_GO(8);
@@ -207,22 +222,27 @@ static int launch_cross_nv(int nv, dim3 grid, size_t shmem, hipStream_t st, cons
 
 static int cross_dispatch(const float* x0, int64_t x_ld, const float* xinit, const float* w, const float* b, int L,
                           int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream) {
-    DIR_CHECK_ARG(x0 && w && b && out, "dir_dcn_cross_f32: null pointer");
+    DIR_CHECK_ARG(x0 && out && ((w && b) || L == 0), "dir_dcn_cross_f32: null pointer");
     DIR_CHECK_ARG(L >= 0 && d > 0 && B >= 0 && x_ld >= d && out_ld >= d, "dir_dcn_cross_f32: L=%d d=%d B=%lld x_ld=%lld out_ld=%lld", L, d, (long long)B, (long long)x_ld, (long long)out_ld);
     if (B == 0) return DIR_OK;
     const size_t shmem = (size_t)2 * L * d * sizeof(float);
     if (shmem > 64 * 1024) return fail(DIR_E_UNSUPPORTED, "dir_dcn_cross_f32: L*d=%d exceeds the 64 KiB LDS weight image", L * d);
     const bool vec = (d % 4 == 0) && (x_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(x0) && aligned16(out) &&
-                     (!xinit || aligned16(xinit));
+                     (!xinit || aligned16(xinit)) && (L == 0 || (aligned16(w) && aligned16(b)));
     const int nchunk = vec ? d / 4 : d;
     // smallest group width that keeps <= 16 chunks per lane
+    static const int g_env = getenv("DIR_CROSS_G") ? atoi(getenv("DIR_CROSS_G")) : 0;
+    // lanes per sample: the smallest power of two (>= 8) that leaves <= 4 chunks per lane.  Few registers
+    // per lane = many waves in flight; measured at d = 416: G = 8 / 16 / 32 -> 45.1 / 42.0 / 40.6 us.
     int G = 8;
+    while (G < 64 && (nchunk + G - 1) / G > 4) G <<= 1;
+    if (g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) G = g_env;
     while (G < 64 && (nchunk + G - 1) / G > 16) G <<= 1;
     const int nv = (nchunk + G - 1) / G;
     if (nv > 16) return fail(DIR_E_UNSUPPORTED, "dir_dcn_cross_f32: d=%d too wide for the register-resident kernel", d);
     const int spw = 64 / G;
     const int64_t waves = (B + spw - 1) / spw;
-    dim3 grid(grid_for((waves + 3) / 4, 4));
+    const int64_t grid = (waves + 3) / 4;   // work blocks; the launch picks the resident count
     hipStream_t st = as_stream(stream);
 #define DIR_G(GG)                                                                                        \
     if (vec) launch_cross_nv<GG, 4>(nv, grid, shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld);   \

@@ -23,6 +23,8 @@ from . import _lib
 SUM, MEAN, SQRTN = 0, 1, 2
 _COMBINERS = {"sum": SUM, "mean": MEAN, "sqrtn": SQRTN, SUM: SUM, MEAN: MEAN, SQRTN: SQRTN}
 PRUNE_NONPOSITIVE_WEIGHTS = 1
+STREAM_ROWS = 2  # DIR_GATHER_STREAM_ROWS: non-temporal row loads (uniform ids over tables >> Infinity Cache)
+INFINITY_CACHE_BYTES = 256 << 20
 
 
 def _stream():
@@ -67,6 +69,16 @@ class TableSet:
         self.device = tables[0].device
         self.ptrs = torch.tensor([t.data_ptr() for t in tables], dtype=torch.int64, device=self.device)
         self.vocab_dev = torch.tensor(self.vocab, dtype=torch.int64, device=self.device)
+        # row-read policy of the one-hot gather: "stream" = DIR_GATHER_STREAM_ROWS, "reuse" = cacheable,
+        # "auto" = stream iff the tables cannot live in the 256 MiB Infinity Cache anyway.  Callers who
+        # know their ids are heavily skewed should set "reuse" (see include/dir_hip.h).
+        self.row_policy = "auto"
+        self.nbytes = sum(t.numel() * 4 for t in tables)
+
+    def gather_flags(self):
+        if self.row_policy == "stream" or (self.row_policy == "auto" and self.nbytes > 2 * INFINITY_CACHE_BYTES):
+            return STREAM_ROWS
+        return 0
 
     def refresh(self):
         """Rebuild the pointer array (after tables were re-allocated, e.g. .to())."""
@@ -111,6 +123,8 @@ def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", fiel
     if out is None:
         out = torch.empty((B, F * K), dtype=torch.float32, device=ts.device)
     _dev(out, torch.float32, "out")
+    if offsets is None:
+        flags |= ts.gather_flags()
     _lib.check(lib.dir_embedding_bag_f32(_ptr(ts.ptrs), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
                                          _COMBINERS[combiner], flags, B, _ptr(out), out.stride(0), _stream()))
     return out
@@ -153,7 +167,7 @@ def gather_fm(tables, ids, want_emb=True, out=None, fm=None):
         out = torch.empty((B, ts.F * ts.K), dtype=torch.float32, device=ts.device)
     if fm is None:
         fm = torch.empty((B, 1), dtype=torch.float32, device=ts.device)
-    _lib.check(_lib.load().dir_gather_fm_fused_f32(_ptr(ts.ptrs), ts.F, ts.K, _ptr(ids), sb, sf, B,
+    _lib.check(_lib.load().dir_gather_fm_fused_f32(_ptr(ts.ptrs), ts.F, ts.K, _ptr(ids), sb, sf, ts.gather_flags(), B,
                                                    _ptr(out) if want_emb else None,
                                                    out.stride(0) if want_emb else 0, _ptr(fm), _stream()))
     return (out if want_emb else None), fm

@@ -39,8 +39,13 @@ enum { DIR_COMBINER_SUM = 0, DIR_COMBINER_MEAN = 1, DIR_COMBINER_SQRTN = 2 };
 
 /* flags for dir_embedding_bag_f32 */
 enum {
-    DIR_BAG_PRUNE_NONPOSITIVE_WEIGHTS = 1 /* drop entries with weight <= 0 ([TF-upstream]
-                                             safe_embedding_lookup_sparse, later 1.x) */
+    DIR_BAG_PRUNE_NONPOSITIVE_WEIGHTS = 1, /* drop entries with weight <= 0 ([TF-upstream]
+                                              safe_embedding_lookup_sparse, later 1.x) */
+    DIR_GATHER_STREAM_ROWS = 2             /* one-hot path: read table rows with non-temporal loads.  Right
+                                              when ids are spread over tables far larger than the 256 MiB
+                                              Infinity Cache (measured 70 -> 62 us at BASELINE config 2,
+                                              uniform ids); wrong for skewed ids whose hot rows should stay
+                                              cached (Zipf 1.05: 50 -> 60 us).  Values are identical. */
 };
 
 int dir_version(void);
@@ -87,9 +92,10 @@ int dir_fm_second_order_f32(const float* emb, int64_t emb_ld, int64_t B, int F, 
                             dir_stream_t stream);
 
 /* A1+A4 fused for one-hot slots: one pass over the rows.  out may be NULL (FM only); fm may be NULL
- * (gather only).  Replaces deepFM.py:169-177 (inputs) + :321-335 (fm_logit_fn) in one launch. */
+ * (gather only).  flags: DIR_GATHER_STREAM_ROWS.  Replaces deepFM.py:169-177 (inputs) + :321-335
+ * (fm_logit_fn) in one launch. */
 int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int64_t* ids,
-                            int64_t stride_b, int64_t stride_f, int64_t B, float* out,
+                            int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out,
                             int64_t out_ld, float* fm, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
