@@ -194,8 +194,12 @@ def main():
         W3 = torch.randn((H2,), generator=gen, device=device) * 0.1
         b3 = torch.zeros(1, device=device)
         step = lambda i: ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True)  # noqa: E731
-        flops = B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)
-        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_k (VALU fp32; priced against the fp32 peak)"}
+        flops = B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)   # full-T, 4K-wide input accounting
+        # what the MFMA kernel executes: valid rows only (padded to 16), layer 1 regrouped to a 2K reduction
+        rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
+        executed = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_mfma_k (fp32 MFMA 16x16x4)",
+                "executed_flops": executed}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
     elif wl == "cin":
         m, D, Hs = F, K, (128, 128, 128)
@@ -269,6 +273,9 @@ def main():
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "kernel": roof["kernel"],
                                "alg_flops_per_step": roof["alg_flops"], "avg_step_us": launch_us}
+            if "executed_flops" in roof:
+                res["roofline"]["executed_TFLOPs"] = roof["executed_flops"] / (launch_us * 1e-6) / 1e12
+                res["roofline"]["executed_frac"] = res["roofline"]["executed_TFLOPs"] / MFMA_F32_PEAK_TF
         if world == 1 and wl == "deepfm_gather_fm" and args.id_dist == "uniform":
             # secondary, cache-assisted case: Zipf(1.05) ids, rows read with the cacheable policy
             import copy

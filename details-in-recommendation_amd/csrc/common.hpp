@@ -44,14 +44,14 @@ inline int grid_for(int64_t work_blocks, int blocks_per_cu = 8) {
 // Number of 256-thread workgroups of `kernel` that are co-resident on the chip (occupancy x CUs), cached
 // per kernel.  A grid-stride kernel launched with exactly this many workgroups has no partial last round.
 template <typename K>
-inline int resident_blocks(K kernel, size_t shmem = 0) {
+inline int resident_blocks(K kernel, size_t shmem = 0, int block = 256) {
     static thread_local struct { const void* k; size_t sh; int n; } cache[64];
     static thread_local int used = 0;
     const void* key = reinterpret_cast<const void*>(kernel);
     for (int i = 0; i < used; ++i)
         if (cache[i].k == key && cache[i].sh == shmem) return cache[i].n;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, shmem) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, shmem) != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     const int n = per_cu * kCUs;
     if (used < 64) cache[used++] = {key, shmem, n};
@@ -81,6 +81,40 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+// ---- DPP reductions: cross-lane adds inside the VALU (no LDS round trip, unlike ds_bpermute shuffles) -----
+// A DPP "row" is 16 consecutive lanes.  quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140.  After the four steps every lane of a row holds the row's total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// whole-wave reductions: DPP inside the four rows, then four scalar lane reads
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

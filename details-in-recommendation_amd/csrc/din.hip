@@ -160,6 +160,376 @@ __global__ __launch_bounds__(256) void din_k(const float* __restrict__ table, Di
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA path (v_mfma_f32_16x16x4_f32, exact fp32) for T <= 64 and the instantiated (K, H1, H2) shapes.
+//
+// Layer 1 is regrouped (same unit, fewer flops):
+//     [h, a, h-a, h*a] . W1  =  h . (Wh + Wd)  +  (h*a) . Wp  +  a . (Wa - Wd)
+// The last term does not depend on the history position: it is one K-long dot per output column per
+// SAMPLE (VALU, folded into the accumulator's initial value together with b1).  Per history row the
+// reduction is 2K instead of 4K.  fp32 rounding differs from the sequential 4K sum by ~1e-7 relative
+// (pre-added weights, different association), inside the 1e-5 bar; tests compare against the oracle.
+//
+// GEMM view: rows = history positions (RT tiles of 16), cols = H1 (tiles of 16).  Wave w owns column tile w
+// and keeps its B fragments (Wh+Wd, Wp, Wa-Wd: 3 x K/4 registers) for the whole launch.  In the 16x16x4
+// instruction lane l supplies A[row l&15][k = l>>4]; lane group kk covers features [kk*K/4, (kk+1)*K/4), so
+// a lane reads its K/4 features of h[row] from LDS as 16-byte chunks, uses them directly as the A operand
+// of the (Wh+Wd) chain and multiplied by its K/4 candidate values (registers) for the Wp chain.
+// Layer 2 (waves 0..NC2-1) reads z1 from LDS the same way; layer 3, the masked softmax (wave butterflies)
+// and the pooling are VALU work on the LDS-staged rows.  The row-tile count is a template parameter, so
+// the MFMA loops are branch-free.
+// LDS per workgroup at (64, 80, 40): 64 x (68 + 84 + 52) x 4 B = 52 KB.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+
+template <int K, int NC1, int NC2>
+struct DinSh {
+    static constexpr int NW = 4;                      // waves per workgroup: one per SIMD
+    static constexpr bool SHARED = NC1 == 5;          // a 5th column tile, its reduction split over the 4 waves
+    static constexpr int H1P = 16 * NC1, H2P = 16 * NC2;
+    static constexpr int HS = K + 4, Z1S = H1P + 4;
+    static constexpr int NPART = (64 * NW) / K;       // pooling partitions (threads per output column)
+    float uh[64 * HS];          // history rows
+    float av[K];                // candidate row
+    float z1[64 * Z1S];         // layer-1 activations
+    float part[SHARED ? NW * 64 * 16 : 4];   // shared-tile partial pre-activations, one slab per wave
+    float scp[NC2 * 64];        // layer-3 partial scores, one slab per layer-2 column tile
+    float sc[64];               // final weights
+    float pool[NPART * K];      // pooling partials
+    int valid[64];
+};
+
+// B fragments of one wave (registers, loaded once per launch).  Step (it, e) of the own tile covers feature
+// kk*KQ + 4*((it + rot) % QN) + e, where rot = wave id when a shared tile exists (so that every wave meets
+// ITS quarter of the shared tile's reduction in iteration 0) and 0 otherwise.
+template <int K, int NC1>
+struct DinFrag {
+    float whd[K / 4], wp[K / 4], wc[K / 4];   // own column tile: Wh+Wd, Wp, Wa-Wd
+    float whd_s[4], wp_s[4], wc_s[4];         // this wave's quarter of the shared tile (NC1 == 5)
+    float wr2[4 * NC1];                       // layer 2 (waves 0..NC2-1)
+};
+
+// Layers 1-3 for a compile-time number of row tiles.  Leaves the per-column-tile partial scores in sh.scp.
+template <int K, int NC1, int NC2, int RT>
+__device__ __forceinline__ void din_mlp_tiles(DinSh<K, NC1, NC2>& sh, const DinFrag<K, NC1>& fr, float bias1, float bias1_s,
+                                              float bias2, float w3v, int w, int r16, int kk) {
+    using S = DinSh<K, NC1, NC2>;
+    constexpr int KQ = K / 4;          // features per lane group = k-steps per chain
+    constexpr int QN = KQ / 4;         // 16-byte groups per lane
+    constexpr int KS2 = S::H1P / 4;
+    constexpr int FT = NC1 < 4 ? NC1 : 4;   // column tiles owned by whole waves
+    static_assert(!S::SHARED || QN == 4, "the shared-tile split needs K = 64");
+    const int rot = S::SHARED ? w : 0;
+    const int tid = threadIdx.x;
+    if (w < FT || S::SHARED) {
+        // per-sample term a.(Wa-Wd), folded into the accumulators' initial values
+        float cpart = 0.f, cpart_s = 0.f;
+#pragma unroll
+        for (int it = 0; it < QN; ++it) {
+            const int g = (it + rot) % QN;
+            const float4 a4 = *reinterpret_cast<const float4*>(sh.av + kk * KQ + 4 * g);
+            cpart = fmaf(a4.x, fr.wc[4 * it], cpart);
+            cpart = fmaf(a4.y, fr.wc[4 * it + 1], cpart);
+            cpart = fmaf(a4.z, fr.wc[4 * it + 2], cpart);
+            cpart = fmaf(a4.w, fr.wc[4 * it + 3], cpart);
+            if (S::SHARED && it == 0) {
+                cpart_s = fmaf(a4.x, fr.wc_s[0], cpart_s);
+                cpart_s = fmaf(a4.y, fr.wc_s[1], cpart_s);
+                cpart_s = fmaf(a4.z, fr.wc_s[2], cpart_s);
+                cpart_s = fmaf(a4.w, fr.wc_s[3], cpart_s);
+            }
+        }
+        cpart += __shfl_xor(cpart, 16, 64);
+        cpart += __shfl_xor(cpart, 32, 64);
+        const float init = cpart + bias1;
+        float init_s = 0.f;
+        if (S::SHARED) {
+            cpart_s += __shfl_xor(cpart_s, 16, 64);
+            cpart_s += __shfl_xor(cpart_s, 32, 64);
+            init_s = cpart_s + (w == 0 ? bias1_s : 0.f);
+        }
+        f32x4m acch[RT], accp[RT], accs[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            acch[rt] = (f32x4m){init, init, init, init};
+            accp[rt] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+            accs[rt] = (f32x4m){init_s, init_s, init_s, init_s};
+        }
+#pragma unroll
+        for (int it = 0; it < QN; ++it) {
+            const int g = (it + rot) % QN;
+            const float4 a4 = *reinterpret_cast<const float4*>(sh.av + kk * KQ + 4 * g);   // group-uniform: broadcast
+            const float aq[4] = {a4.x, a4.y, a4.z, a4.w};
+            float hv[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float4 h4 = *reinterpret_cast<const float4*>(sh.uh + (rt * 16 + r16) * S::HS + kk * KQ + 4 * g);
+                hv[rt][0] = h4.x; hv[rt][1] = h4.y; hv[rt][2] = h4.z; hv[rt][3] = h4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float hp = hv[rt][e] * aq[e];
+                    acch[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][e], fr.whd[4 * it + e], acch[rt], 0, 0, 0);
+                    accp[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hp, fr.wp[4 * it + e], accp[rt], 0, 0, 0);
+                    if (S::SHARED && it == 0) {
+                        accs[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[rt][e], fr.whd_s[e], accs[rt], 0, 0, 0);
+                        accs[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hp, fr.wp_s[e], accs[rt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (w < FT) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    sh.z1[(rt * 16 + 4 * kk + g) * S::Z1S + 16 * w + r16] = fast_sigmoid(acch[rt][g] + accp[rt][g]);
+        }
+        if (S::SHARED) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sh.part[(w * 64 + rt * 16 + 4 * kk + g) * 16 + r16] = accs[rt][g];
+        }
+    }
+    __syncthreads();
+    if (S::SHARED) {   // finish the shared tile: add the four partial pre-activations
+        for (int idx = tid; idx < RT * 256; idx += 64 * S::NW) {
+            const int row = idx >> 4, col = idx & 15;
+            const float v = (sh.part[(0 * 64 + row) * 16 + col] + sh.part[(1 * 64 + row) * 16 + col]) +
+                            (sh.part[(2 * 64 + row) * 16 + col] + sh.part[(3 * 64 + row) * 16 + col]);
+            sh.z1[row * S::Z1S + 64 + col] = fast_sigmoid(v);
+        }
+        __syncthreads();
+    }
+    if (w < NC2) {
+        f32x4m acc2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc2[rt] = (f32x4m){bias2, bias2, bias2, bias2};
+#pragma unroll
+        for (int q = 0; q < KS2 / 4; ++q) {
+            float zv[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float4 z4 = *reinterpret_cast<const float4*>(sh.z1 + (rt * 16 + r16) * S::Z1S + kk * KS2 + 4 * q);
+                zv[rt][0] = z4.x; zv[rt][1] = z4.y; zv[rt][2] = z4.z; zv[rt][3] = z4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[rt][e], fr.wr2[4 * q + e], acc2[rt], 0, 0, 0);
+        }
+        // layer 3 fused: s[row] += sum over this tile's 16 columns of sigmoid(z2) * W3[col]
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float v = row16_sum(fast_sigmoid(acc2[rt][g]) * w3v);
+                if (r16 == 0) sh.scp[w * 64 + rt * 16 + 4 * kk + g] = v;
+            }
+    }
+}
+
+template <int K, int NC1, int NC2>
+__global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ table,
+                                                       const int64_t* __restrict__ hist,
+                                                       const int32_t* __restrict__ hist_len,
+                                                       const int64_t* __restrict__ cand, int T,
+                                                       const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       int H1, const float* __restrict__ W2,
+                                                       const float* __restrict__ b2, int H2,
+                                                       const float* __restrict__ W3, const float* __restrict__ b3,
+                                                       int normalize, int64_t B, float* __restrict__ out,
+                                                       float* __restrict__ scores) {
+    using S = DinSh<K, NC1, NC2>;
+    constexpr int NT = 64 * S::NW;
+    constexpr int KQ = K / 4;
+    constexpr int QN = KQ / 4;
+    constexpr int KS2 = S::H1P / 4;
+    constexpr int KC = K / 4;
+    constexpr int NPF = (64 * KC + NT - 1) / NT;   // row chunks a thread stages per sample (T <= 64)
+    static_assert(NC1 <= 5 && NC2 <= 4, "column tiles: at most 4 whole waves + 1 shared tile");
+    __shared__ __attribute__((aligned(16))) S sh;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int r16 = lane & 15;
+    const int kk = lane >> 4;
+    const float inv_sqrt_k = 1.0f / sqrtf((float)K);
+
+    // ---- B fragments, resident for the whole launch -----------------------------------------------------
+    DinFrag<K, NC1> fr;
+    auto w1parts = [&](int f, int col, float& hd, float& c, float& p) {
+        float vh = 0.f, va = 0.f, vd = 0.f, vp = 0.f;
+        if (col < H1) {
+            vh = W1[(size_t)f * H1 + col];
+            va = W1[(size_t)(K + f) * H1 + col];
+            vd = W1[(size_t)(2 * K + f) * H1 + col];
+            vp = W1[(size_t)(3 * K + f) * H1 + col];
+        }
+        hd = vh + vd;
+        c = va - vd;
+        p = vp;
+    };
+    {
+        const int rot = S::SHARED ? w : 0;
+        const int col = 16 * w + r16;      // own tile (waves >= NC1 get zeros through the col < H1 test)
+#pragma unroll
+        for (int it = 0; it < QN; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = kk * KQ + 4 * ((it + rot) % QN) + e;
+                w1parts(f, w < NC1 ? col : H1, fr.whd[4 * it + e], fr.wc[4 * it + e], fr.wp[4 * it + e]);
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = kk * KQ + 4 * (rot % QN) + e;
+            w1parts(f, S::SHARED ? 64 + r16 : H1, fr.whd_s[e], fr.wc_s[e], fr.wp_s[e]);
+        }
+    }
+    const float bias1 = (w < NC1 && (16 * w + r16) < H1) ? b1[16 * w + r16] : 0.f;
+    const float bias1_s = (S::SHARED && (64 + r16) < H1) ? b1[64 + r16] : 0.f;
+    float bias2 = 0.f, w3v = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS2; ++s2) {
+        const int i = kk * KS2 + s2;
+        const int col = 16 * w + r16;
+        fr.wr2[s2] = (w < NC2 && i < H1 && col < H2) ? W2[(size_t)i * H2 + col] : 0.f;
+    }
+    if (w < NC2 && (16 * w + r16) < H2) {
+        bias2 = b2[16 * w + r16];
+        w3v = W3[16 * w + r16];
+    }
+    const float bias3 = b3[0];
+
+    // ---- software pipeline over this workgroup's samples: ids two samples ahead, rows one ahead ----------
+    const int64_t G = gridDim.x;
+    auto load_meta = [&](int64_t bb, int& len, int64_t& cid, int64_t (&ids)[NPF]) {
+        len = 0;
+        cid = -1;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) ids[k] = -1;
+        if (bb < B) {
+            len = hist_len ? min((int)hist_len[bb], T) : T;
+            cid = cand[bb];
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int q = tid + k * NT;
+                if (q < len * KC) ids[k] = hist[bb * T + q / KC];
+            }
+        }
+    };
+    auto load_rows = [&](int len, int64_t cid, const int64_t (&ids)[NPF], float4 (&h)[NPF], float4& a) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            h[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < len * KC && ids[k] >= 0) h[k] = *reinterpret_cast<const float4*>(table + ids[k] * K + 4 * (q % KC));
+        }
+        a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < KC && cid >= 0) a = *reinterpret_cast<const float4*>(table + cid * K + 4 * tid);
+    };
+    int len0, len1;
+    int64_t cid0, cid1, id0[NPF], id1[NPF];
+    float4 hreg[NPF], areg4;
+    load_meta(blockIdx.x, len0, cid0, id0);
+    load_rows(len0, cid0, id0, hreg, areg4);
+    load_meta(blockIdx.x + G, len1, cid1, id1);
+
+    for (int64_t b = blockIdx.x; b < B; b += G) {
+        const int len = len0;
+        const int RT = (len + 15) >> 4;
+        // ---- stage this sample's rows (already in registers) into LDS --------------------------------------
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            if (q < len * KC) {
+                const int j = q / KC, c = q - j * KC;
+                *reinterpret_cast<float4*>(sh.uh + j * S::HS + 4 * c) = hreg[k];
+                if (c == 0) sh.valid[j] = id0[k] >= 0 ? 1 : 0;
+            }
+        }
+        for (int j = len + tid; j < 64; j += NT) sh.valid[j] = 0;
+        if (tid < KC) *reinterpret_cast<float4*>(sh.av + 4 * tid) = areg4;
+        __syncthreads();
+        // ---- issue the next sample's row reads and the ids of the one after; both land during the MFMAs -------
+        len0 = len1;
+        cid0 = cid1;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) id0[k] = id1[k];
+        load_rows(len0, cid0, id0, hreg, areg4);
+        load_meta(b + 2 * G, len1, cid1, id1);
+        // ---- hidden layers + fused layer 3, branch-free per row-tile count -----------------------------------
+        switch (RT) {   // block-uniform
+            case 1: din_mlp_tiles<K, NC1, NC2, 1>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk); break;
+            case 2: din_mlp_tiles<K, NC1, NC2, 2>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk); break;
+            case 3: din_mlp_tiles<K, NC1, NC2, 3>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk); break;
+            case 4: din_mlp_tiles<K, NC1, NC2, 4>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk); break;
+            default:   // len == 0: keep the barrier count uniform
+                __syncthreads();
+                if (S::SHARED) __syncthreads();
+                break;
+        }
+        __syncthreads();
+        // ---- scores: sum the column-tile partials, masked softmax (wave 0) -----------------------------------
+        if (tid < 64) {
+            const bool ok = tid < len && sh.valid[tid];
+            float sv = 0.f;
+            if (ok) {
+                sv = bias3;
+#pragma unroll
+                for (int c2 = 0; c2 < NC2; ++c2) sv += sh.scp[c2 * 64 + tid];
+            }
+            if (normalize) {
+                const float x = sv * inv_sqrt_k;
+                const float mx = wave_max_dpp(ok ? x : -INFINITY);
+                const float ex = ok ? __expf(x - mx) : 0.f;
+                const float sum = wave_sum_dpp(ex);
+                sv = ok ? ex / sum : 0.f;
+            }
+            sh.sc[tid] = sv;
+        }
+        __syncthreads();
+        // ---- pooling: NPART threads per output column, then one add tree -------------------------------------
+        if (tid < S::NPART * K) {
+            const int k = tid % K, part = tid / K;
+            float acc_o = 0.f;
+            for (int j = part; j < len; j += S::NPART)
+                if (sh.valid[j]) acc_o = fmaf(sh.sc[j], sh.uh[j * S::HS + k], acc_o);
+            sh.pool[part * K + k] = acc_o;
+        }
+        if (scores)
+            for (int j = tid; j < T; j += NT) scores[b * T + j] = j < 64 ? sh.sc[j] : 0.f;
+        __syncthreads();
+        if (tid < K) {
+            float acc_o = 0.f;
+#pragma unroll
+            for (int p = 0; p < S::NPART; ++p) acc_o += sh.pool[p * K + tid];
+            out[b * K + tid] = acc_o;
+        }
+        // next iteration's first LDS writes (uh, av, valid) do not touch pool/sc/scp; its later phases are
+        // ordered behind its own barriers
+    }
+}
+
+template <int K, int NC1, int NC2>
+static int launch_din_mfma(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len,
+                           const int64_t* cand, int T, const float* W1, const float* b1, int H1, const float* W2,
+                           const float* b2, int H2, const float* W3, const float* b3, int normalize, int64_t B,
+                           float* out, float* scores) {
+    const int res = resident_blocks(din_mfma_k<K, NC1, NC2>, 0, 256);
+    dim3 grid((unsigned)(B < res ? B : res));
+    hipLaunchKernelGGL((din_mfma_k<K, NC1, NC2>), grid, dim3(256), 0, st, table, hist, hist_len, cand, T, W1, b1, H1, W2,
+                       b2, H2, W3, b3, normalize, B, out, scores);
+    return 0;
+}
+
 }  // namespace dir
 
 using namespace dir;
@@ -169,13 +539,31 @@ extern "C" int dir_din_attention_pool_f32(const float* table, int K, const int64
                                           const float* W2, const float* b2, int H2, const float* W3,
                                           const float* b3, int normalize, int64_t B, float* out, float* scores,
                                           dir_stream_t stream) {
-    DIR_CHECK_ARG(table && hist && cand && W1 && b1 && W2 && b2 && W3 && b3 && out, "dir_din_attention_pool_f32: null pointer");
     DIR_CHECK_ARG(K > 0 && T > 0 && H1 > 0 && H2 > 0 && B >= 0, "dir_din_attention_pool_f32: K=%d T=%d H1=%d H2=%d", K, T, H1, H2);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(table && hist && cand && W1 && b1 && W2 && b2 && W3 && b3 && out, "dir_din_attention_pool_f32: null pointer");
     if ((K & 3) || (H1 & 3) || (H2 & 3))
         return fail(DIR_E_UNSUPPORTED, "dir_din_attention_pool_f32: K, H1, H2 must be multiples of 4 (K=%d H1=%d H2=%d)", K, H1, H2);
     if (!aligned16(table) || !aligned16(W1) || !aligned16(W2) || !aligned16(b1) || !aligned16(b2))
         return fail(DIR_E_BADARG, "dir_din_attention_pool_f32: table / W1 / W2 / b1 / b2 must be 16-byte aligned");
-    if (B == 0) return DIR_OK;
+    static const int mfma_env = getenv("DIR_DIN_MFMA") ? atoi(getenv("DIR_DIN_MFMA")) : 1;
+    if (mfma_env && T <= 64) {
+        const int nc1 = (H1 + 15) / 16, nc2 = (H2 + 15) / 16;
+        hipStream_t st = as_stream(stream);
+        bool done = true;
+        if (K == 64 && nc1 == 5 && nc2 == 3)
+            launch_din_mfma<64, 5, 3>(st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores);
+        else if (K == 16 && nc1 == 2 && nc2 == 1)
+            launch_din_mfma<16, 2, 1>(st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores);
+        else if (K == 32 && nc1 == 3 && nc2 == 1)
+            launch_din_mfma<32, 3, 1>(st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores);
+        else
+            done = false;
+        if (done) {
+            DIR_CHECK_LAUNCH("din_attention_pool(mfma)");
+            return DIR_OK;
+        }
+    }
     DinDims dm{K, T, H1, H2, 4 * K + 4, H1 + 4, H2 + 4};
     const size_t shmem = sizeof(float) * ((size_t)T * (dm.us + dm.z1s + dm.z2s) + ((T + 63) & ~63)) + sizeof(int) * (size_t)T;
     if (shmem > 160 * 1024) return fail(DIR_E_UNSUPPORTED, "dir_din_attention_pool_f32: T=%d K=%d needs %zu B of LDS (> 160 KiB)", T, K, shmem);

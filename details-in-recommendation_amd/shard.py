@@ -29,8 +29,9 @@ def div_range(vocab, P, rank):
 class ShardedTables:
     """This rank's row shard of F tables [vocab_f, K]."""
 
-    def __init__(self, local_tables, vocab, group=None, route_fn=None, gather_fn=None):
+    def __init__(self, local_tables, vocab, group=None, route_fn=None, gather_fn=None, force_collective=False):
         self.group = group
+        self.force_collective = force_collective  # issue the all_to_all calls even when world_size == 1
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.vocab = [int(v) for v in vocab]
@@ -62,7 +63,7 @@ class ShardedTables:
         return cls(loc, vocab, group=group, **kw)
 
     def _a2a(self, out, inp, out_splits, in_splits):
-        if self.P == 1:
+        if self.P == 1 and not (self.force_collective and dist.is_initialized()):
             out.copy_(inp)
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)

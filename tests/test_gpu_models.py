@@ -1,0 +1,236 @@
+"""GPU end-to-end tests of the modules that keep the reference constructor kwargs: logits against a NumPy
+float64 restatement of the reference graph with the SAME parameters (oracle/np_ref.py), tolerance
+1e-5 * (1 + |ref|) as BASELINE.json's north_star states.  Also the sharded lookup on one GPU under RCCL."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_ref as R  # noqa: E402
+
+
+def _close(got, ref, tol=1e-5):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref) / (1 + np.abs(ref))
+    assert err.max() <= tol, "max scaled err %.3e" % err.max()
+
+
+def _np(p):
+    return p.detach().cpu().numpy().astype(np.float64)
+
+
+def test_deepfm_config1_forward(built_lib, oracle):
+    """BASELINE configs[0] shape: 1k rows, 13 dense (bucketised, linear part only) + 26 sparse, dim 8."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    rng = np.random.default_rng(11)
+    B, F, K, V = 1000, 26, 8, 10000
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    nums = [fc.bucketized_column(fc.numeric_column("I%d" % i), [0.1 * j for j in range(1, 10)]) for i in range(13)]
+    model = DeepFM(linear_feature_columns=cats + nums, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[400, 400, 400], fm_embedding_size=K, batch_norm=True).cuda()
+    with torch.no_grad():
+        for w in model.linear_weights:
+            w.normal_(0, 0.05)
+        model.linear_bias.fill_(0.2)
+        for bn in model.bns:
+            bn.moving_mean.normal_(0, 0.1); bn.moving_variance.uniform_(0.5, 1.5); bn.gamma.uniform_(0.8, 1.2); bn.beta.normal_(0, 0.1)
+    ids = rng.integers(0, V, size=(B, F)).astype(np.int64)
+    dense = rng.uniform(0, 1, size=(B, 13)).astype(np.float32)
+    feats = {"C%d" % i: torch.from_numpy(ids[:, i].copy()).cuda() for i in range(F)}
+    feats.update({"I%d" % i: torch.from_numpy(dense[:, i].copy()).cuda() for i in range(13)})
+    with torch.no_grad():
+        pred = model.predict(feats)
+    # reference graph in float64 (deepFM.py:169-223)
+    tabs = [p.detach().cpu().numpy() for p in model.embedding_weights]
+    emb = oracle.embedding_bag(tabs, ids).astype(np.float64)
+    fm = R.fm_logit(emb, F, K, np.float64)
+    layers = [(_np(l.weight).T, _np(l.bias)) for l in model.hidden]
+    bn = [(_np(b.moving_mean), _np(b.moving_variance), _np(b.gamma), _np(b.beta)) for b in model.bns]
+    dnn = R.dnn_logit(emb, layers, (_np(model.logits_layer.weight).T, _np(model.logits_layer.bias)), bn=bn)
+    lin_ids = np.concatenate([ids, np.stack([R.bucketize(dense[:, i], nums[i].boundaries) for i in range(13)], 1)], 1)
+    lin = sum(_np(w)[lin_ids[:, f]] for f, w in enumerate(model.linear_weights)) + 0.2
+    ref = fm + dnn + lin[:, None]
+    _close(pred["logits"].cpu().numpy(), ref)
+    rp = R.predictions(ref)
+    _close(pred["logistic"].cpu().numpy(), rp["logistic"])
+    _close(pred["probabilities"].cpu().numpy(), rp["probabilities"])
+    np.testing.assert_array_equal(pred["class_ids"].cpu().numpy(), rp["class_ids"])
+    # forward_ids fast path == dict path
+    with torch.no_grad():
+        l2 = model.forward_ids(torch.from_numpy(ids).cuda())
+        lin_only = pred["logits"] - l2
+    assert torch.isfinite(lin_only).all()
+
+
+def test_deepfm_multihot_weighted(built_lib, oracle):
+    """The multi-hot path the reference advertises (deepFM.py:53,77; SequenceTensorFlowDataset/test4.py:50-59)."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    rng = np.random.default_rng(5)
+    B, K, V = 257, 8, 50
+    hist = fc.weighted_categorical_column(fc.categorical_column_with_identity("hist", V), "hist_w")
+    item = fc.categorical_column_with_identity("item", V)
+    cols = [fc.embedding_column(hist, K, combiner="mean"), fc.embedding_column(item, K)]
+    model = DeepFM(linear_feature_columns=[item], dnn_feature_columns=cols, dnn_hidden_units=[16], fm_embedding_size=K).cuda()
+    lens = rng.integers(0, 6, size=B)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    vals = rng.integers(-1, V, size=offs[-1]).astype(np.int64)
+    w = rng.uniform(0.1, 2, size=offs[-1]).astype(np.float32)
+    it = rng.integers(0, V, size=B).astype(np.int64)
+    feats = {"hist": fc.Ragged(torch.from_numpy(vals).cuda(), torch.from_numpy(offs).cuda()),
+             "hist_w": torch.from_numpy(w).cuda(), "item": torch.from_numpy(it).cuda()}
+    with torch.no_grad():
+        got = model(feats).cpu().numpy()
+    t0, t1 = [p.detach().cpu().numpy() for p in model.embedding_weights]
+    e0 = oracle.embedding_bag([t0], vals, offsets=offs, weights=w, combiner=oracle.MEAN, B=B)
+    e1 = oracle.embedding_bag([t1], it.reshape(B, 1))
+    emb = np.concatenate([e0, e1], 1).astype(np.float64)
+    ref = R.fm_logit(emb, 2, K, np.float64) + R.dnn_logit(emb, [(_np(model.hidden[0].weight).T, _np(model.hidden[0].bias))],
+                                                          (_np(model.logits_layer.weight).T, _np(model.logits_layer.bias)))
+    ref = ref + (_np(model.linear_weights[0])[it] + _np(model.linear_bias))[:, None]
+    _close(got, ref)
+
+
+def test_dcn_adult_schema_forward(built_lib, oracle):
+    """build_model_columns of DeepCrossNetwork/train.py:54-101: 5 numeric, 4 indicator, 1 hashed embedding (dim 8)
+    -> d = 51, concatenated in NAME-SORTED order (DeepCrossNetwork.py:126)."""
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd import feature_column as fc
+    rng = np.random.default_rng(3)
+    B = 256
+    nums = ["age", "education_num", "capital_gain", "capital_loss", "hours_per_week"]
+    vocabs = {"education": ["Bachelors", "HS-grad", "11th", "Masters", "9th", "Some-college", "Assoc-acdm", "Assoc-voc", "7th-8th",
+                            "Doctorate", "Prof-school", "5th-6th", "10th", "1st-4th", "Preschool", "12th"],
+              "marital_status": ["Married-civ-spouse", "Divorced", "Married-spouse-absent", "Never-married", "Separated",
+                                 "Married-AF-spouse", "Widowed"],
+              "relationship": ["Husband", "Not-in-family", "Wife", "Own-child", "Unmarried", "Other-relative"],
+              "workclass": ["Self-emp-not-inc", "Private", "State-gov", "Federal-gov", "Local-gov", "?", "Self-emp-inc", "Without-pay",
+                            "Never-worked"]}
+    occupation = fc.categorical_column_with_hash_bucket("occupation", hash_bucket_size=1000)
+    columns = [fc.numeric_column(n) for n in nums] + \
+              [fc.indicator_column(fc.categorical_column_with_vocabulary_list(k, v)) for k, v in
+               [("workclass", vocabs["workclass"]), ("education", vocabs["education"]), ("marital_status", vocabs["marital_status"]),
+                ("relationship", vocabs["relationship"])]] + [fc.embedding_column(occupation, dimension=8)]
+    model = DeepCrossNetwork(columns=columns, cross_layer_num=2, dnn_hidden_units=[32, 16, 8], batch_norm=True).cuda()
+    assert model.column_num == 51
+    with torch.no_grad():
+        for bn in model.bns:
+            bn.moving_mean.normal_(0, 0.1); bn.moving_variance.uniform_(0.5, 1.5); bn.beta.normal_(0, 0.1)
+    occ_strings = ["Tech-support", "Craft-repair", "Other-service", "Sales", "Exec-managerial", "Prof-specialty", "?"]
+    feats, raw = {}, {}
+    for n in nums:
+        raw[n] = rng.uniform(0, 2, size=B).astype(np.float32)
+        feats[n] = torch.from_numpy(raw[n]).cuda()
+    for k, v in vocabs.items():
+        raw[k] = [v[i] if i < len(v) else "OOV" for i in rng.integers(0, len(v) + 1, size=B)]
+        feats[k] = raw[k]
+    raw["occupation"] = [occ_strings[i] for i in rng.integers(0, len(occ_strings), size=B)]
+    feats["occupation"] = raw["occupation"]
+    with torch.no_grad():
+        got = model.predict(feats)
+    # NumPy restatement with name-sorted concat
+    parts = {}
+    for n in nums:
+        parts[n] = raw[n].astype(np.float64)[:, None]
+    for k, v in vocabs.items():
+        ind = np.zeros((B, len(v)))
+        for b, s in enumerate(raw[k]):
+            if s in v:
+                ind[b, v.index(s)] = 1.0
+        parts[k + "_indicator"] = ind
+    occ_ids = R.hash_bucket_fast(raw["occupation"], 1000)
+    parts["occupation_embedding"] = _np(model.embedding_weights[0])[occ_ids]
+    x0 = np.concatenate([parts[k] for k in sorted(parts)], axis=1)
+    assert [c.name for c in model.columns] == sorted(parts)
+    cross = R.cross_network(x0, _np(model.cross_w), _np(model.cross_b))
+    layers = [(_np(l.weight).T, _np(l.bias)) for l in model.hidden]
+    bn = [(_np(b.moving_mean), _np(b.moving_variance), _np(b.beta)) for b in model.bns]
+    deep = R.deep_architecture(x0, layers, bn=bn)
+    ref = np.concatenate([cross, deep], -1) @ _np(model.logits_layer.weight).T + _np(model.logits_layer.bias)
+    _close(got["logits"].cpu().numpy(), ref)
+    rp = R.predictions(ref)
+    _close(got["probabilities"].cpu().numpy(), rp["probabilities"])
+    np.testing.assert_array_equal(got["class_ids"].cpu().numpy(), rp["class_ids"])
+
+
+def test_xdeepfm_forward(built_lib, oracle):
+    from dir_amd.xdeepfm import XDeepFM
+    from dir_amd import feature_column as fc
+    rng = np.random.default_rng(9)
+    B, m, D, V = 130, 26, 16, 500
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(m)]
+    model = XDeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, D) for c in cats],
+                    cin_layer_sizes=(64, 32), dnn_hidden_units=(64, 32)).cuda()
+    with torch.no_grad():
+        for w in model.linear_weights:
+            w.normal_(0, 0.05)
+    ids = rng.integers(0, V, size=(B, m)).astype(np.int64)
+    feats = {"C%d" % i: torch.from_numpy(ids[:, i].copy()).cuda() for i in range(m)}
+    with torch.no_grad():
+        got = model(feats).cpu().numpy()
+    tabs = [p.detach().cpu().numpy() for p in model.embedding_weights]
+    emb = oracle.embedding_bag(tabs, ids).astype(np.float64)
+    x0 = emb.reshape(B, m, D)
+    xk, pooled = x0, []
+    for W in model.cin_W:
+        xk, p = R.cin_layer(x0, xk, _np(W))
+        pooled.append(p)
+    logit = np.concatenate(pooled, 1) @ _np(model.cin_out.weight).T + _np(model.cin_out.bias)
+    net = emb
+    for l in model.hidden:
+        net = R.relu(net @ _np(l.weight).T + _np(l.bias))
+    logit = logit + net @ _np(model.dnn_out.weight).T + _np(model.dnn_out.bias)
+    logit = logit + (sum(_np(w)[ids[:, f]] for f, w in enumerate(model.linear_weights)) + _np(model.linear_bias))[:, None]
+    _close(got, logit)
+
+
+def test_din_module(built_lib, oracle):
+    from dir_amd.din import DINAttentionPool
+    rng = np.random.default_rng(2)
+    V, K, B, T = 1000, 64, 40, 50
+    mod = DINAttentionPool(V, K, (80, 40), normalize=True).cuda()
+    with torch.no_grad():
+        mod.b1.normal_(0, 0.05); mod.b2.normal_(0, 0.05); mod.b3.fill_(0.01)
+    hist = rng.integers(0, V, size=(B, T)).astype(np.int64)
+    hl = rng.integers(1, T + 1, size=B).astype(np.int32)
+    cand = rng.integers(0, V, size=B).astype(np.int64)
+    got = mod(torch.from_numpy(hist).cuda(), torch.from_numpy(hl).cuda(), torch.from_numpy(cand).cuda()).cpu().numpy()
+    ref, _ = R.din_attention_pool(mod.table.detach().cpu().numpy(), hist, hl, cand, _np(mod.W1), _np(mod.b1), _np(mod.W2), _np(mod.b2),
+                                  _np(mod.W3), _np(mod.b3), normalize=True)
+    _close(got, ref)
+
+
+def test_gather_rows_and_sharded_lookup_single_gpu(built_lib, oracle):
+    """The sharded path end to end on ONE GPU under the nccl (RCCL) backend with world_size 1: the HIP route
+    and gather_rows kernels, the bucketing, both all_to_all calls' code path and the un-permute."""
+    import torch.distributed as dist
+    from dir_amd import ops
+    from dir_amd.shard import ShardedTables
+    rng = np.random.default_rng(8)
+    F, K, B = 7, 16, 513
+    vocab = [100, 17, 64, 1000, 5, 333, 64]
+    full = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
+    ids = np.stack([rng.integers(-1, v, size=B) for v in vocab], 1).astype(np.int64)
+    # flat row gather
+    slot = rng.integers(0, F, size=300).astype(np.int32)
+    row = np.array([rng.integers(-1, vocab[s]) for s in slot], np.int64)
+    got = ops.gather_rows([torch.from_numpy(t).cuda() for t in full], torch.from_numpy(slot).cuda(), torch.from_numpy(row).cuda())
+    ref = np.stack([full[s][r] if r >= 0 else np.zeros(K, np.float32) for s, r in zip(slot, row)])
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        st = ShardedTables.from_full([torch.from_numpy(t).cuda() for t in full], force_collective=True)
+        got = st.lookup(torch.from_numpy(ids).cuda()).cpu().numpy()
+        np.testing.assert_array_equal(got, R.embedding_bag_onehot(full, ids))
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -183,7 +183,8 @@ def test_cross_hand_kat(ops):
     np.testing.assert_allclose(ops.cross_network(x0, w, b).cpu().numpy(), [[-0.9, -1.9]], rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,T,K,H1,H2", [(33, 50, 64, 80, 40), (7, 5, 8, 12, 8), (100, 13, 16, 20, 12), (4, 70, 32, 36, 16)])
+@pytest.mark.parametrize("B,T,K,H1,H2", [(33, 50, 64, 80, 40), (7, 5, 8, 12, 8), (100, 13, 16, 20, 12), (4, 70, 32, 36, 16),
+                                            (65, 64, 32, 40, 16), (130, 64, 64, 80, 40), (20, 17, 64, 72, 36), (9, 1, 64, 80, 40)])
 @pytest.mark.parametrize("normalize", [False, True])
 def test_din_attention_pool(ops, oracle, B, T, K, H1, H2, normalize):
     rng = np.random.default_rng(T * 3 + K)
