@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
-                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full"])
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full",
+                             "sharded_1gpu"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -167,11 +168,20 @@ def main():
             fm = torch.empty((B, 1), dtype=torch.float32, device=device)
 
             def step(i):
-                emb = st.lookup(idsl[i % len(idsl)])
-                ops.fm_logit(emb, F, K, out=fm)
+                st.lookup(idsl[i % len(idsl)], want_fm=True)
             alg = B * (F * (8 + 2 * 4 * K) + 4)
-            roof = {"bound": "hbm", "alg_bytes": alg, "kernel": "sharded lookup (route+a2a+gather_rows+a2a) + fm_k"}
+            roof = {"bound": "hbm", "alg_bytes": alg,
+                    "kernel": "sharded lookup: bucket -> all_to_all ids -> gather_packed -> all_to_all rows -> gather_onehot_k<fm,out>"}
             cfg["parallelism"] = "tables row-sharded 'div' over %d GPUs, RCCL all_to_all x2 per lookup" % world
+    elif wl == "sharded_1gpu":
+        # the sharded code path on one GPU without collectives: what the exchange costs besides the network
+        sigma = 1.0 / (K ** 0.5)
+        loc = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
+        st = ShardedTables(loc, [V] * F)
+        idsl = make_ids(torch, args, gen, device, V)
+        step = lambda i: st.lookup(idsl[i % len(idsl)], want_fm=True)  # noqa: E731
+        roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K) + 4), "kernel": "bucket + gather_packed + gather_onehot_k"}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
     elif wl == "dcn_cross":
         d, L = F * K, 3
         x0 = torch.randn((B, d), generator=gen, device=device) * 0.25

@@ -35,6 +35,9 @@ SIGNATURES = {
     "dir_shard_div_owner": (None, [c_i64, c_i64, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
     "dir_shard_route": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "dir_gather_rows_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "dir_shard_bucket_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "dir_shard_bucket": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dir_gather_packed_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
 }
 
 DIR_OK, DIR_E_BADARG, DIR_E_RANGE, DIR_E_HIP, DIR_E_UNSUPPORTED = 0, -1, -2, -3, -4

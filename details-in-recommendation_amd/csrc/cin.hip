@@ -32,10 +32,11 @@ constexpr int CIN_ROWS = 256;      // rows per workgroup = 4 waves * RT * 32
 constexpr int CIN_HP = 129;        // padded H stride of the LDS W image
 constexpr int CIN_IC = 4;          // i values per chunk
 
-template <int MT /* m, compile-time */, int CT /* column tiles */>
+template <int MT /* m, compile-time */, int CT /* column tiles */, bool FP /* interleaved fast staging */>
 __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                 const float* __restrict__ W, int Hp, int H, int D, int dshift,
-                                                int64_t R /* B*D */, float* __restrict__ xout,
+                                                int64_t R /* B*D */,
+                                                float* __restrict__ xout,
                                                 float* __restrict__ pooled, int64_t pooled_ld) {
     constexpr int m = MT;
     constexpr int mp = (MT + 1) & ~1;
@@ -104,10 +105,14 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
             xreg[q] = v;
         }
     };
-    auto store_chunk = [&](int buf) {
+    // store the staged registers of chunk c+1 into LDS buffer `buf`; `part` selects one IC-th of the W elements
+    // (all parts when part < 0) so that the stores can be interleaved between the MFMA blocks of chunk c
+    auto store_chunk = [&](int buf, int part) {
         float* wb = Ws + buf * WCH;
+        constexpr int WPP = (WE + IC - 1) / IC;
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
+            if (part >= 0 && q / WPP != part) continue;
             const int e = tid + 256 * q;
             const int hl = e / (IC * MT);
             const int kkl = e - hl * (IC * MT);
@@ -115,9 +120,57 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
             const int j = kkl - il * MT;
             if (hl < 32 * CT) wb[(il * mp + j) * HP + hl] = wreg[q];
         }
-        float* xb = xks + buf * XCH;
+        if (part < 0 || part == IC - 1) {
+            float* xb = xks + buf * XCH;
 #pragma unroll
-        for (int q = 0; q < XE; ++q) xb[tid + 256 * q] = xreg[q];
+            for (int q = 0; q < XE; ++q) xb[tid + 256 * q] = xreg[q];
+        }
+    };
+
+    // ---- fast staging of the NEXT chunk, spread over the k-steps of the current one -------------------------
+    // TPR threads share one W row of the chunk (IC*m contiguous floats in global memory); a thread owns RL
+    // consecutive floats of it: 16-byte global loads, and LDS destinations that differ from a per-thread base by
+    // compile-time offsets only (no per-element address arithmetic inside the MFMA stream).
+    constexpr int TPR = 256 / (32 * CT);
+    constexpr bool FAST = FP;                          // the host only selects FP when cin_fast_shape<MT, CT>() holds
+    constexpr int RL = FAST ? (IC * MT) / TPR : 4;
+    constexpr bool VEC4 = FAST && (RL % 4 == 0) && ((IC * MT) % 4 == 0);
+    constexpr int NLD = VEC4 ? RL / 4 : RL;            // load slots
+    static_assert(!FAST || RL <= WE, "staging registers are shared with the generic path");
+    const int srow = tid / TPR, spart = tid - srow * TPR;
+    const bool srow_ok = hbase + srow < H;
+    // loads are unconditional from clamped (always valid) addresses; validity is a select at store time
+    const float* wsrc = W + (int64_t)(srow_ok ? hbase + srow : 0) * Kd + spart * RL;
+    const int sil0 = (spart * RL) / MT, sj0 = spart * RL - sil0 * MT;
+    const int wdst0 = (sil0 * mp + sj0) * HP + srow;
+    constexpr bool fast_ok = FAST;
+    auto fast_i0 = [&](int c) {   // first i of chunk c, clamped so that the loads stay inside W (a clamped
+        const int i0 = c * IC;    // chunk is re-staged by the generic path afterwards)
+        return i0 + IC <= Hp ? i0 : Hp - IC;
+    };
+    auto fast_load = [&](int slot, int i0) {
+        const float* src = wsrc + (int64_t)i0 * MT;
+        if (VEC4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * slot);
+            wreg[4 * slot] = v.x; wreg[4 * slot + 1] = v.y; wreg[4 * slot + 2] = v.z; wreg[4 * slot + 3] = v.w;
+        } else {
+            wreg[slot] = src[slot];
+        }
+    };
+    const int64_t xrow = (row0 + tid < R) ? row0 + tid : R - 1;          // XE == IC: element q is (il = q, r = tid)
+    const float* xsrc = xk + ((xrow >> dshift) * Hp) * D + (xrow & (D - 1));
+    const bool xrow_ok = row0 + tid < R;
+    auto fast_load_xk = [&](int i0) {
+#pragma unroll
+        for (int q = 0; q < XE; ++q) xreg[q] = xsrc[(int64_t)(i0 + q) * D];
+    };
+    auto fast_store = [&](int idx, int buf) {   // idx < RL: W element; RL <= idx < RL + XE: xk element
+        if (idx < RL) {
+            const int off = (RL % MT == 0) ? ((idx / MT) * mp + (idx % MT)) * HP : idx * HP;
+            Ws[buf * WCH + wdst0 + off] = srow_ok ? wreg[idx] : 0.f;
+        } else if (idx < RL + XE) {
+            xks[buf * XCH + tid + 256 * (idx - RL)] = xrow_ok ? xreg[idx - RL] : 0.f;
+        }
     };
 
     // zero the j = m pad rows of both W buffers once (odd m only)
@@ -132,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
 
     const int nchunk = (Hp + IC - 1) / IC;
     fetch_chunk(0);
-    store_chunk(0);
+    store_chunk(0, -1);
     __syncthreads();
 
     // this lane's x0 operands: x0r[t][jp] = x0s[2*jp + hh][wave*64 + t*32 + n]
@@ -152,20 +205,53 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
 
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) fetch_chunk(c + 1);
+        const bool more = c + 1 < nchunk;
+        // the next chunk is staged by the interleaved fast path when it is a whole chunk; a partial (last) or
+        // irregular one by the generic bulk path after this chunk's MFMAs
+        const bool next_bulk = more && (!fast_ok || (c + 2) * IC > Hp);
+        const int i0n = fast_ok ? fast_i0(more ? c + 1 : c) : 0;
         const float* wb = Ws + buf * WCH + hh * HP + n;
         const float* xb = xks + buf * XCH + wave * 64 + n;
-#pragma unroll 1
-        for (int il = 0; il < IC; ++il) {
-            float xkv[CIN_RT];
+        // operands of step (il, jp) are read one whole step ahead of their MFMAs (LDS latency ~100 cycles vs
+        // 512 cycles of MFMA issue per step); sched_barrier pins "reads for the next step, then this step's
+        // MFMAs" so that the compiler does not sink the reads back to their first use
+        float bw[CT], xkv[CIN_RT];
 #pragma unroll
-            for (int t = 0; t < CIN_RT; ++t) xkv[t] = xb[il * CIN_ROWS + t * 32];
-            const float* wr = wb + il * mp * HP;
+        for (int cc = 0; cc < CT; ++cc) bw[cc] = wb[32 * cc];
+#pragma unroll
+        for (int t = 0; t < CIN_RT; ++t) xkv[t] = xb[t * 32];
+#pragma unroll
+        for (int il = 0; il < IC; ++il) {
 #pragma unroll
             for (int jp = 0; jp < MP2; ++jp) {
-                float bw[CT];
+                constexpr int LAST = IC * MP2 - 1;
+                const int step = il * MP2 + jp;
+                const int nil = (jp + 1 < MP2) ? il : il + 1;
+                const int njp = (jp + 1 < MP2) ? jp + 1 : 0;
+                float bwn[CT], xkn[CIN_RT];
 #pragma unroll
-                for (int cc = 0; cc < CT; ++cc) bw[cc] = wr[(2 * jp) * HP + 32 * cc];
+                for (int cc = 0; cc < CT; ++cc) bwn[cc] = bw[cc];
+#pragma unroll
+                for (int t = 0; t < CIN_RT; ++t) xkn[t] = xkv[t];
+                if (step < LAST) {
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) bwn[cc] = wb[(nil * mp + 2 * njp) * HP + 32 * cc];
+                    if (njp == 0) {
+#pragma unroll
+                        for (int t = 0; t < CIN_RT; ++t) xkn[t] = xb[nil * CIN_ROWS + t * 32];
+                    }
+                }
+                if (FAST && fast_ok) {   // a few staging instructions per k-step, in the shadow of the previous MFMA
+                    constexpr int NS = IC * MP2, SS = NS / 2;
+                    constexpr int SPS = (RL + XE + (NS - SS) - 1) / (NS - SS);
+                    if (step < NLD) fast_load(step, i0n);
+                    if (step == (NLD < SS ? NLD : SS - 1)) fast_load_xk(i0n);
+                    if (step >= SS) {
+#pragma unroll
+                        for (int k = 0; k < SPS; ++k) fast_store((step - SS) * SPS + k, buf ^ 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 float a[CIN_RT];
 #pragma unroll
                 for (int t = 0; t < CIN_RT; ++t) a[t] = xkv[t] * x0r[t][jp];
@@ -174,9 +260,17 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
 #pragma unroll
                     for (int cc = 0; cc < CT; ++cc)
                         acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bw[cc], acc[t][cc], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cc = 0; cc < CT; ++cc) bw[cc] = bwn[cc];
+#pragma unroll
+                for (int t = 0; t < CIN_RT; ++t) xkv[t] = xkn[t];
             }
         }
-        if (c + 1 < nchunk) store_chunk(buf ^ 1);
+        if (next_bulk) {
+            fetch_chunk(c + 1);
+            store_chunk(buf ^ 1, -1);
+        }
         __syncthreads();
     }
 
@@ -241,25 +335,49 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     }
 }
 
+template <int MT, int CT>
+constexpr bool cin_fast_shape() {
+    constexpr int TPR = 256 / (32 * CT);
+    constexpr int N = CIN_IC * MT;
+    return (N % TPR == 0) && (((N / TPR) % MT == 0) || (MT % (N / TPR) == 0)) && ((N / TPR) % 4 == 0) && (N % 4 == 0);
+}
+
+template <int MT, int CT, bool FP>
+static void launch_cin_one(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* W,
+                           int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
+    static bool set = false;
+    if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, FP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        set = true;
+    }
+    hipLaunchKernelGGL((cin_k<MT, CT, FP>), grid, dim3(256), shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+}
+
+template <int MT, int CT>
+static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* W,
+                          int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
+    // interleaved fast staging needs: a compatible (m, column-tile) shape, whole 16-byte aligned W rows and at
+    // least one whole chunk; everything else takes the generic bulk staging
+    static const int fast_env = getenv("DIR_CIN_FAST") ? atoi(getenv("DIR_CIN_FAST")) : 1;
+    const bool wvec = ((int64_t)Hp * MT) % 4 == 0 && aligned16(W);
+    if constexpr (cin_fast_shape<MT, CT>()) {
+        if (fast_env && wvec && Hp >= CIN_IC) {
+            launch_cin_one<MT, CT, true>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+            return;
+        }
+    }
+    launch_cin_one<MT, CT, false>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+}
+
 template <int MT>
 static int launch_cin(int ct, dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk,
                       const float* W, int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled,
                       int64_t pooled_ld) {
-#define DIR_GO(CT)                                                                                         \
-    do {                                                                                                   \
-        static bool set = false;                                                                           \
-        if (!set) {                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            set = true;                                                                                    \
-        }                                                                                                  \
-        hipLaunchKernelGGL((cin_k<MT, CT>), grid, dim3(256), shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); \
-    } while (0)
     switch (ct) {
-        case 1: DIR_GO(1); break;
-        case 2: DIR_GO(2); break;
-        default: DIR_GO(4); break;
+        case 1: launch_cin_ct<MT, 1>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
+        case 2: launch_cin_ct<MT, 2>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
+        default: launch_cin_ct<MT, 4>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
     }
-#undef DIR_GO
     return 0;
 }
 

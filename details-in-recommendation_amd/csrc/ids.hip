@@ -242,6 +242,231 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* const* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bucketing by owner for the sharded lookup: a counting sort over P <= 64 owners in three launches.
+//   k1: per-workgroup histogram of owners (LDS atomics)            -> wg_counts[wg][P]
+//   k2: one workgroup: exclusive scan over workgroups per owner    -> wg_base[wg][P], counts[P], starts[P]
+//   k3: every element gets dst = starts[o] + wg_base[wg][o] + (LDS atomic rank);
+//       payload[dst] = local*F + slot (or -1 for a pruned id), inv[i] = dst
+// The order inside a bucket is arbitrary (atomics) but inv is its exact inverse, so the values routed back
+// through inv are independent of it.
+// ------------------------------------------------------------------------------------------------
+constexpr int BK_EPB = 4096;   // elements per workgroup
+constexpr int BK_MAXF = 256;   // fields whose 'div' constants are cached in LDS (more: read from global)
+
+// per-field 'div' constants q = V / P, thr = (V % P) * (q + 1), r = V % P, staged once per workgroup
+struct FieldDiv { int64_t q, thr; int r; int small; };
+
+__device__ __forceinline__ FieldDiv make_fielddiv(int64_t V, int P) {
+    FieldDiv d;
+    d.q = V / P;
+    d.r = (int)(V % P);
+    d.thr = (int64_t)d.r * (d.q + 1);
+    d.small = V < (int64_t)0x7fffffff ? 1 : 0;   // every quotient fits 32-bit unsigned arithmetic
+    return d;
+}
+
+__device__ __forceinline__ void route_fd(int64_t id, const FieldDiv& d, int* owner, int64_t* local) {
+    if (d.small) {   // 32-bit divisions (ids < vocab < 2^31): ~4x cheaper than the 64-bit software division
+        const uint32_t u = (uint32_t)id, q = (uint32_t)d.q, thr = (uint32_t)d.thr;
+        if (u < thr) {
+            const uint32_t o = u / (q + 1);
+            *owner = (int)o;
+            *local = (int64_t)(u - o * (q + 1));
+        } else {
+            const uint32_t o = (uint32_t)d.r + (q > 0 ? (u - thr) / q : 0u);
+            *owner = (int)o;
+            *local = (int64_t)(u - (thr + (o - (uint32_t)d.r) * q));
+        }
+    } else {
+        div_owner(id, d.q, d.r, d.thr, owner, local);
+    }
+}
+
+// element e of workgroup `wg`: its id, slot f = i % F and owner / local row; pruned ids spread as i % P
+#define BK_ROUTE_ELEMENT()                                                        \
+    const int64_t i = base + e;                                                   \
+    const int f = (int)((uint32_t)(f0 + e) % (uint32_t)F);                        \
+    const int64_t id = ids[i];                                                    \
+    int oo_;                                                                      \
+    int64_t l;                                                                    \
+    if (id < 0) {                                                                 \
+        oo_ = (int)((uint32_t)(p0 + e) % (uint32_t)P);                            \
+        l = -1;                                                                   \
+    } else if (f < BK_MAXF) {                                                     \
+        route_fd(id, fd[f], &oo_, &l);                                            \
+    } else {                                                                      \
+        FieldDiv dd = make_fielddiv(vocab[f], P);                                 \
+        route_fd(id, dd, &oo_, &l);                                               \
+    }
+
+// Wave-aggregated LDS counter update: lanes of a wave that target the same owner issue ONE atomic (the
+// lowest such lane), the others take consecutive ranks behind it.  Returns this lane's rank in cnt[o].
+// `active` lanes take part; the loop runs once per distinct owner present in the wave.
+__device__ __forceinline__ int wave_agg_rank(int* cnt, int o, bool active) {
+    const unsigned long long lt = (1ull << (threadIdx.x & 63)) - 1ull;
+    unsigned long long todo = __ballot(active);
+    int rank = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int oo = __shfl(o, leader, 64);
+        const unsigned long long same = __ballot(active && o == oo) & todo;
+        int basev = 0;
+        if ((int)(threadIdx.x & 63) == leader) basev = atomicAdd(&cnt[oo], __popcll(same));
+        basev = __shfl(basev, leader, 64);
+        if (active && o == oo) rank = basev + __popcll(same & lt);
+        todo &= ~same;
+    }
+    return rank;
+}
+
+__global__ __launch_bounds__(256) void bucket_hist_k(const int64_t* __restrict__ ids, int64_t n,
+                                                     const int64_t* __restrict__ vocab, int F, int P,
+                                                     int32_t* __restrict__ wg_counts) {
+    __shared__ int cnt[64];
+    __shared__ FieldDiv fd[BK_MAXF];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], P);
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * BK_EPB;
+    const int f0 = (int)(base % F), p0 = (int)(base % P);
+    const int lim = (int)((n - base) < BK_EPB ? (n - base) : BK_EPB);
+    for (int e0 = 0; e0 < lim; e0 += 256) {   // uniform trip count: the aggregation uses wave-wide ballots
+        const int e = e0 + threadIdx.x;
+        const bool active = e < lim;
+        int o = 0;
+        if (active) {
+            BK_ROUTE_ELEMENT()
+            (void)l;
+            (void)i;
+            o = oo_;
+        }
+        wave_agg_rank(cnt, o, active);
+    }
+    __syncthreads();
+    if (threadIdx.x < P) wg_counts[(int64_t)blockIdx.x * P + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// one workgroup of 16 waves; wave w scans owners w, w+16, ...: 64 workgroup counts per step with a
+// shuffle prefix scan and a running carry
+__global__ __launch_bounds__(1024) void bucket_scan_k(const int32_t* __restrict__ wg_counts, int nwg, int P,
+                                                      int32_t* __restrict__ wg_base, int64_t* __restrict__ counts,
+                                                      int64_t* __restrict__ starts) {
+    __shared__ int64_t tot[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = wave; o < P; o += 16) {
+        int run = 0;
+        for (int c = 0; c < nwg; c += 64) {
+            const int wg = c + lane;
+            const int v = wg < nwg ? wg_counts[(int64_t)wg * P + o] : 0;
+            int inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += t;
+            }
+            if (wg < nwg) wg_base[(int64_t)wg * P + o] = run + inc - v;
+            run += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) {
+            tot[o] = run;
+            counts[o] = run;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int k = 0; k < P; ++k) {
+            starts[k] = run;
+            run += tot[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_k(const int64_t* __restrict__ ids, int64_t n,
+                                                        const int64_t* __restrict__ vocab, int F, int P,
+                                                        const int32_t* __restrict__ wg_base,
+                                                        const int64_t* __restrict__ starts,
+                                                        int64_t* __restrict__ payload, int64_t* __restrict__ inv) {
+    __shared__ int cnt[64];
+    __shared__ int64_t basev[64];
+    __shared__ FieldDiv fd[BK_MAXF];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < P) basev[threadIdx.x] = starts[threadIdx.x] + wg_base[(int64_t)blockIdx.x * P + threadIdx.x];
+    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], P);
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * BK_EPB;
+    const int f0 = (int)(base % F), p0 = (int)(base % P);
+    const int lim = (int)((n - base) < BK_EPB ? (n - base) : BK_EPB);
+    for (int e0 = 0; e0 < lim; e0 += 256) {
+        const int e = e0 + threadIdx.x;
+        const bool active = e < lim;
+        int o = 0, fsl = 0;
+        int64_t ll = -1, ii = 0;
+        if (active) {
+            BK_ROUTE_ELEMENT()
+            o = oo_;
+            ll = l;
+            ii = i;
+            fsl = f;
+        }
+        const int rank = wave_agg_rank(cnt, o, active);
+        if (active) {
+            const int64_t dst = basev[o] + rank;
+            payload[dst] = ll < 0 ? (int64_t)-1 : ll * F + fsl;
+            inv[ii] = dst;
+        }
+    }
+}
+#undef BK_ROUTE_ELEMENT
+
+// owner side: unpack payload -> (slot, row) and gather; out[i, :] = tables[p % F][p / F, :]  (p < 0 -> zeros)
+typedef float f32x4_ids __attribute__((ext_vector_type(4)));
+template <int VEC, bool NT>
+__global__ __launch_bounds__(256) void gather_packed_k(const float* const* __restrict__ tables, int K, int lps, int F,
+                                                       const int64_t* __restrict__ payload, int64_t n,
+                                                       float* __restrict__ out) {
+    const int kv = K / VEC;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = tid; q < n * lps; q += nthr) {
+        const int64_t i = q / lps;
+        const int c = (int)(q - i * lps);
+        if (c >= kv) continue;
+        const int64_t p = payload[i];
+        float* o = out + i * K + c * VEC;
+        int slot = 0;
+        int64_t row = 0;
+        if (p >= 0) {
+            if (p < (int64_t)0x7fffffff) {   // 32-bit division when it fits
+                const uint32_t r32 = (uint32_t)p / (uint32_t)F;
+                slot = (int)((uint32_t)p - r32 * (uint32_t)F);
+                row = r32;
+            } else {
+                row = p / F;
+                slot = (int)(p - row * F);
+            }
+        }
+        if (VEC == 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p >= 0) {
+                const float* src = tables[slot] + row * K + c * 4;
+                if (NT) {
+                    const f32x4_ids t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ids*>(src));
+                    v = make_float4(t.x, t.y, t.z, t.w);
+                } else {
+                    v = *reinterpret_cast<const float4*>(src);
+                }
+            }
+            *reinterpret_cast<float4*>(o) = v;
+        } else {
+            float v = 0.f;
+            if (p >= 0) v = NT ? __builtin_nontemporal_load(tables[slot] + row * K + c) : tables[slot][row * K + c];
+            *o = v;
+        }
+    }
+}
+
 }  // namespace dir
 
 using namespace dir;
@@ -307,5 +532,50 @@ extern "C" int dir_gather_rows_f32(const float* const* tables, int K, const int3
     if (vec) hipLaunchKernelGGL((gather_rows_k<4>), grid, dim3(256), 0, as_stream(stream), tables, K, lps, slot, row, n, out);
     else hipLaunchKernelGGL((gather_rows_k<1>), grid, dim3(256), 0, as_stream(stream), tables, K, lps, slot, row, n, out);
     DIR_CHECK_LAUNCH("gather_rows");
+    return DIR_OK;
+}
+
+extern "C" int64_t dir_shard_bucket_workspace_bytes(int64_t n, int P) {
+    const int64_t nwg = (n + BK_EPB - 1) / BK_EPB;
+    return 2 * nwg * (int64_t)P * (int64_t)sizeof(int32_t);
+}
+
+extern "C" int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, int F, int P, int64_t* payload,
+                                int64_t* inv, int64_t* counts, int64_t* starts, void* workspace, dir_stream_t stream) {
+    DIR_CHECK_ARG(n >= 0 && F > 0 && P > 0 && P <= 64, "dir_shard_bucket: n=%lld F=%d P=%d (P <= 64)", (long long)n, F, P);
+    DIR_CHECK_ARG(counts && starts, "dir_shard_bucket: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(counts, 0, sizeof(int64_t) * P, st) != hipSuccess || hipMemsetAsync(starts, 0, sizeof(int64_t) * P, st) != hipSuccess)
+            return fail(DIR_E_HIP, "dir_shard_bucket: memset failed");
+        return DIR_OK;
+    }
+    DIR_CHECK_ARG(ids && vocab && payload && inv && workspace, "dir_shard_bucket: null pointer");
+    const int nwg = (int)((n + BK_EPB - 1) / BK_EPB);
+    int32_t* wg_counts = static_cast<int32_t*>(workspace);
+    int32_t* wg_base = wg_counts + (int64_t)nwg * P;
+    hipLaunchKernelGGL(bucket_hist_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, F, P, wg_counts);
+    hipLaunchKernelGGL(bucket_scan_k, dim3(1), dim3(1024), 0, st, wg_counts, nwg, P, wg_base, counts, starts);
+    hipLaunchKernelGGL(bucket_scatter_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, F, P, wg_base, starts, payload, inv);
+    DIR_CHECK_LAUNCH("shard_bucket");
+    return DIR_OK;
+}
+
+extern "C" int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_t* payload, int64_t n,
+                                     int flags, float* out, dir_stream_t stream) {
+    DIR_CHECK_ARG(F > 0 && K > 0 && n >= 0, "dir_gather_packed_f32: bad argument");
+    if (n == 0) return DIR_OK;
+    DIR_CHECK_ARG(tables && payload && out, "dir_gather_packed_f32: null pointer");
+    const bool vec = (K % 4 == 0) && aligned16(out);
+    int lps = 1;
+    while (lps < (vec ? K / 4 : K)) lps <<= 1;
+    dim3 grid(grid_for((n * lps + 255) / 256));
+    const bool nt = (flags & DIR_GATHER_STREAM_ROWS) != 0;
+    hipStream_t st = as_stream(stream);
+    if (vec && nt) hipLaunchKernelGGL((gather_packed_k<4, true>), grid, dim3(256), 0, st, tables, K, lps, F, payload, n, out);
+    else if (vec) hipLaunchKernelGGL((gather_packed_k<4, false>), grid, dim3(256), 0, st, tables, K, lps, F, payload, n, out);
+    else if (nt) hipLaunchKernelGGL((gather_packed_k<1, true>), grid, dim3(256), 0, st, tables, K, lps, F, payload, n, out);
+    else hipLaunchKernelGGL((gather_packed_k<1, false>), grid, dim3(256), 0, st, tables, K, lps, F, payload, n, out);
+    DIR_CHECK_LAUNCH("gather_packed");
     return DIR_OK;
 }

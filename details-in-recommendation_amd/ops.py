@@ -343,3 +343,35 @@ def gather_rows(tables, slot, row):
     _lib.check(_lib.load().dir_gather_rows_f32(_ptr(ts.ptrs), ts.K, _ptr(slot), _ptr(row.contiguous()), n, _ptr(out),
                                                _stream()))
     return out
+
+
+def shard_bucket(ids, vocab_dev, P, payload=None, inv=None):
+    """Route + counting-sort by owner in one call (requester side of the sharded lookup).
+    -> (payload [n] int64 grouped by owner, inv [n] int64, counts [P] int64, starts [P] int64), all on device."""
+    _dev(ids, torch.int64, "ids")
+    ids = ids.contiguous()
+    n = ids.numel()
+    lib = _lib.load()
+    F = vocab_dev.numel()
+    if payload is None:
+        payload = torch.empty(n, dtype=torch.int64, device=ids.device)
+    if inv is None:
+        inv = torch.empty(n, dtype=torch.int64, device=ids.device)
+    counts = torch.empty(P, dtype=torch.int64, device=ids.device)
+    starts = torch.empty(P, dtype=torch.int64, device=ids.device)
+    ws = torch.empty(max(1, int(lib.dir_shard_bucket_workspace_bytes(n, P))), dtype=torch.uint8, device=ids.device)
+    _lib.check(lib.dir_shard_bucket(_ptr(ids), n, _ptr(vocab_dev), F, P, _ptr(payload), _ptr(inv), _ptr(counts),
+                                    _ptr(starts), _ptr(ws), _stream()))
+    return payload, inv, counts, starts
+
+
+def gather_packed(tables, payload, out=None):
+    """Owner side: payload p = local_row*F + slot (p < 0 -> zeros) -> rows [n, K]."""
+    ts = _as_tableset(tables)
+    _dev(payload, torch.int64, "payload")
+    n = payload.numel()
+    if out is None:
+        out = torch.empty((n, ts.K), dtype=torch.float32, device=ts.device)
+    _lib.check(_lib.load().dir_gather_packed_f32(_ptr(ts.ptrs), ts.F, ts.K, _ptr(payload.contiguous()), n,
+                                                 ts.gather_flags(), _ptr(out), _stream()))
+    return out

@@ -5,13 +5,17 @@ row-partitions the embedding variables and lookups resolve with partition_strate
 (models/DeepFM/deepFM.py:163-167; [TF-upstream] embedding_lookup).  Here every rank of a
 torch.distributed group owns the contiguous 'div' row range of EVERY table, and one lookup is
 
-    route (HIP)  ->  bucket by owner  ->  all_to_all(ids)  ->  local row gather (HIP)
-                 ->  all_to_all(rows) ->  un-permute into [B_local, F*K]
+    bucket   (HIP: route every id to its owner + counting sort by owner -> packed payload, inverse perm)
+    exchange (all_to_all_single of the per-owner counts, then of the int64 payload)
+    gather   (HIP on the owner: payload -> rows)
+    exchange (all_to_all_single of the fp32 rows back)
+    finish   (HIP: the fused gather+FM kernel with "table" = the received row buffer and ids = the inverse
+              permutation: one pass un-permutes into [B_local, F*K] and produces the FM logit)
 
-The two collectives are torch.distributed.all_to_all_single (backend "nccl" = RCCL on ROCm; "gloo" in the
-CPU tests).  world_size == 1 skips both collectives but still runs route / bucket / gather / un-permute,
-so the single-GPU run exercises the same kernels.  The route and gather steps are injectable so that the
-CPU (gloo) tests can stand in the oracle for the two HIP kernels; the defaults are the HIP ops.
+The collectives are torch.distributed.all_to_all_single (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
+tests); the split sizes cost one host read of 2*P integers per lookup.  world_size == 1 skips the collectives
+(unless force_collective) but still runs the three HIP steps.  The HIP steps sit behind a small backend
+object so that the CPU (gloo) tests can stand the oracle in for them; the default backend is the HIP one.
 """
 import torch
 import torch.distributed as dist
@@ -26,10 +30,43 @@ def div_range(vocab, P, rank):
     return start, start + (q + 1 if rank < r else q)
 
 
+class HipBackend:
+    """The product path: three launches of libdir_hip.so kernels."""
+
+    def __init__(self, local_tables, vocab_dev, P):
+        self.ts = ops.TableSet(local_tables)
+        # row policy "auto": the owner-side gather streams (non-temporal) when this rank's shards exceed the
+        # Infinity Cache, like the single-GPU gather
+        self.vocab_dev = vocab_dev
+        self.P = P
+        self._back = None
+        self._back_ts = None
+
+    def bucket(self, flat_ids):
+        return ops.shard_bucket(flat_ids, self.vocab_dev, self.P)
+
+    def gather_packed(self, payload):
+        return ops.gather_packed(self.ts, payload)
+
+    def back_buffer(self, n, K, device):
+        if self._back is None or self._back.shape[0] != n:
+            self._back = torch.empty((n, K), dtype=torch.float32, device=device)
+            self._back_ts = None
+        return self._back
+
+    def finish(self, back, inv, B, F, want_fm):
+        if self._back_ts is None or self._back_ts.tables[0].data_ptr() != back.data_ptr():
+            self._back_ts = ops.TableSet([back] * F)
+            self._back_ts.row_policy = "reuse"   # just received: largely cache-resident
+        if want_fm:
+            return ops.gather_fm(self._back_ts, inv.view(B, F))
+        return ops.embedding_bag(self._back_ts, inv.view(B, F)), None
+
+
 class ShardedTables:
     """This rank's row shard of F tables [vocab_f, K]."""
 
-    def __init__(self, local_tables, vocab, group=None, route_fn=None, gather_fn=None, force_collective=False):
+    def __init__(self, local_tables, vocab, group=None, backend=None, force_collective=False):
         self.group = group
         self.force_collective = force_collective  # issue the all_to_all calls even when world_size == 1
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -44,11 +81,7 @@ class ShardedTables:
                 raise ValueError("table %d: rank %d must hold rows [%d,%d) (%d rows), got %d" % (f, self.rank, s, e, e - s, t.shape[0]))
         self.device = self.local_tables[0].device
         self.vocab_dev = torch.tensor(self.vocab, dtype=torch.int64, device=self.device)
-        self._route = route_fn or (lambda ids: ops.shard_route(ids, self.vocab_dev, self.P))
-        if gather_fn is None:
-            self._ts = ops.TableSet(self.local_tables)
-            gather_fn = lambda slot, row: ops.gather_rows(self._ts, slot, row)  # noqa: E731
-        self._gather = gather_fn
+        self.backend = backend or HipBackend(self.local_tables, self.vocab_dev, self.P)
 
     @classmethod
     def from_full(cls, full_tables, group=None, **kw):
@@ -62,37 +95,33 @@ class ShardedTables:
             loc.append(t[s:e].contiguous())
         return cls(loc, vocab, group=group, **kw)
 
-    def _a2a(self, out, inp, out_splits, in_splits):
-        if self.P == 1 and not (self.force_collective and dist.is_initialized()):
-            out.copy_(inp)
-        else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+    def _collective(self):
+        return self.P > 1 or (self.force_collective and dist.is_initialized())
 
-    def lookup(self, ids):
-        """ids [B_local, F] int64 (global row ids; < 0 pruned -> zeros) -> [B_local, F*K] fp32."""
+    def _a2a(self, out, inp, out_splits, in_splits):
+        if self._collective():
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+        else:
+            out.copy_(inp)
+
+    def lookup(self, ids, want_fm=False):
+        """ids [B_local, F] int64 (global row ids; < 0 pruned -> zeros) -> emb [B_local, F*K] fp32
+        (and the FM second-order logit [B_local, 1] when want_fm)."""
         B, F = ids.shape
         if F != self.F:
             raise ValueError("ids must be [B, F=%d]" % self.F)
-        P, K = self.P, self.K
+        K, be = self.K, self.backend
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
-        owner, local = self._route(flat)                                   # HIP: 'div' owner + local row
-        owner = owner.to(torch.int64)
-        order = torch.argsort(owner, stable=True)                          # bucket by owner (P buckets)
-        send_counts = torch.bincount(owner, minlength=P)
-        slot = (torch.arange(n, device=flat.device, dtype=torch.int64) % F)
-        payload = (local * F + slot)[order]                                # local row and slot in one int64
-        payload = torch.where(local[order] < 0, torch.full_like(payload, -1), payload)
+        payload, inv, send_counts, _ = be.bucket(flat)                      # HIP
         recv_counts = torch.empty_like(send_counts)
         self._a2a(recv_counts, send_counts, None, None)
-        sc, rc = send_counts.tolist(), recv_counts.tolist()                # host sync: split sizes
+        both = torch.stack([send_counts, recv_counts]).tolist()             # the one host read per lookup
+        sc, rc = [int(v) for v in both[0]], [int(v) for v in both[1]]
         recv = torch.empty(sum(rc), dtype=torch.int64, device=flat.device)
         self._a2a(recv, payload, rc, sc)
-        rrow = torch.where(recv < 0, recv, torch.div(recv, F, rounding_mode="floor"))
-        rslot = torch.where(recv < 0, torch.zeros_like(recv), recv % F).to(torch.int32)
-        rows = self._gather(rslot, rrow)                                   # HIP: owner-side row gather
-        back = torch.empty((n, K), dtype=torch.float32, device=flat.device)
+        rows = be.gather_packed(recv)                                       # HIP (owner side)
+        back = be.back_buffer(n, K, flat.device)
         self._a2a(back.view(-1), rows.reshape(-1), [c * K for c in sc], [c * K for c in rc])
-        out = torch.empty((n, K), dtype=torch.float32, device=flat.device)
-        out[order] = back                                                  # un-permute
-        return out.view(B, F * K)
+        emb, fm = be.finish(back, inv, B, F, want_fm)                       # HIP: un-permute (+ FM)
+        return (emb, fm) if want_fm else emb

@@ -191,6 +191,18 @@ int dir_shard_route(const int64_t* ids, int64_t n, const int64_t* vocab, int F, 
 int dir_gather_rows_f32(const float* const* tables, int K, const int32_t* slot, const int64_t* row,
                         int64_t n, float* out, dir_stream_t stream);
 
+/* Requester side of the sharded lookup in one call: route every id of the flattened [.., F] array and
+ * counting-sort the entries by owner (P <= 64).
+ *   payload[dst] = local_row * F + slot   (-1 for a pruned id), grouped by owner, owner o at
+ *                  [starts[o], starts[o] + counts[o]);  inv[i] = dst of entry i;
+ *   counts, starts: DEVICE int64 [P];  workspace: dir_shard_bucket_workspace_bytes(n, P) device bytes.
+ * dir_gather_packed_f32 is the owner side for that payload: out[i,:] = tables[p % F][p / F, :]. */
+int64_t dir_shard_bucket_workspace_bytes(int64_t n, int P);
+int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, int F, int P, int64_t* payload,
+                     int64_t* inv, int64_t* counts, int64_t* starts, void* workspace, dir_stream_t stream);
+int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_t* payload, int64_t n,
+                          int flags /* DIR_GATHER_STREAM_ROWS */, float* out, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,8 +229,29 @@ def test_gather_rows_and_sharded_lookup_single_gpu(built_lib, oracle):
         created = True
     try:
         st = ShardedTables.from_full([torch.from_numpy(t).cuda() for t in full], force_collective=True)
-        got = st.lookup(torch.from_numpy(ids).cuda()).cpu().numpy()
-        np.testing.assert_array_equal(got, R.embedding_bag_onehot(full, ids))
+        got, fm = st.lookup(torch.from_numpy(ids).cuda(), want_fm=True)
+        ref = R.embedding_bag_onehot(full, ids)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+        np.testing.assert_array_equal(fm.cpu().numpy()[:, 0], oracle.fm_second_order(ref, F, K))
+        np.testing.assert_array_equal(st.lookup(torch.from_numpy(ids).cuda()).cpu().numpy(), ref)
+        # the device bucketing against a NumPy counting sort: same buckets, inv is the exact inverse
+        flat = torch.from_numpy(ids.reshape(-1)).cuda()
+        for P in (1, 2, 3, 8):
+            vdev = torch.tensor(vocab, dtype=torch.int64, device="cuda")
+            payload, inv, counts, starts = ops.shard_bucket(flat, vdev, P)
+            payload, inv, counts, starts = [t.cpu().numpy() for t in (payload, inv, counts, starts)]
+            a = ids.reshape(-1)
+            own = np.empty(a.size, np.int64); loc = np.empty(a.size, np.int64)
+            for f in range(F):
+                sel = np.arange(f, a.size, F)
+                o, l = R.shard_div_owner(np.maximum(a[sel], 0), vocab[f], P)
+                own[sel] = np.where(a[sel] < 0, sel % P, o); loc[sel] = np.where(a[sel] < 0, -1, l)
+            np.testing.assert_array_equal(counts, np.bincount(own, minlength=P))
+            np.testing.assert_array_equal(starts, np.concatenate([[0], np.cumsum(counts)[:-1]]))
+            assert sorted(inv.tolist()) == list(range(a.size))
+            want = np.where(loc < 0, -1, loc * F + np.arange(a.size) % F)
+            np.testing.assert_array_equal(payload[inv], want)
+            assert ((inv >= starts[own]) & (inv < starts[own] + counts[own])).all()
     finally:
         if created:
             dist.destroy_process_group()

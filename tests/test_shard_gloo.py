@@ -2,8 +2,8 @@
 
 The exchange logic under test is exactly what runs on the GPU box under RCCL: 'div' routing, bucketing by
 owner, all_to_all of ids, owner-side row gather, all_to_all of rows, un-permute.  The two HIP kernels
-(route, gather_rows) cannot run without a GPU, so the oracle stands in for them here through the
-route_fn / gather_fn injection points (test infrastructure; the product defaults are the HIP ops)."""
+cannot run without a GPU, so a NumPy/oracle backend stands in for them here through the `backend` injection
+point (test infrastructure; the product default is shard.HipBackend)."""
 import os
 import socket
 
@@ -43,31 +43,53 @@ def _worker(rank, world, port, vocab, K, B, seed, out_q):
             s, e = div_range(v, world, rank)
             local.append(torch.from_numpy(full[f][s:e].copy()))
 
-        def route_fn(flat):
-            a = flat.numpy()
-            own = np.empty(a.size, np.int32)
-            loc = np.empty(a.size, np.int64)
-            for f in range(F):
-                sel = np.arange(f, a.size, F)
-                o, l = R.shard_div_owner(np.maximum(a[sel], 0), vocab[f], world)
-                neg = a[sel] < 0
-                o = np.where(neg, sel % world, o)
-                l = np.where(neg, -1, l)
-                own[sel], loc[sel] = o, l
-            return torch.from_numpy(own), torch.from_numpy(loc)
+        class OracleBackend:
+            """NumPy stand-ins for the three HIP steps (bucket / gather_packed / finish)."""
 
-        def gather_fn(slot, row):
-            out = np.zeros((row.numel(), K), np.float32)
-            sl, rw = slot.numpy(), row.numpy()
-            for i in range(rw.size):
-                if rw[i] >= 0:
-                    out[i] = local[sl[i]].numpy()[rw[i]]
-            return torch.from_numpy(out)
+            def bucket(self, flat):
+                a = flat.numpy()
+                n = a.size
+                own = np.empty(n, np.int64)
+                loc = np.empty(n, np.int64)
+                for f in range(F):
+                    sel = np.arange(f, n, F)
+                    o, l = R.shard_div_owner(np.maximum(a[sel], 0), vocab[f], world)
+                    neg = a[sel] < 0
+                    own[sel] = np.where(neg, sel % world, o)
+                    loc[sel] = np.where(neg, -1, l)
+                order = np.argsort(own, kind="stable")
+                inv = np.empty(n, np.int64)
+                inv[order] = np.arange(n)
+                packed = np.where(loc < 0, -1, loc * F + (np.arange(n) % F))[order]
+                counts = np.bincount(own, minlength=world).astype(np.int64)
+                starts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+                return (torch.from_numpy(packed), torch.from_numpy(inv), torch.from_numpy(counts), torch.from_numpy(starts))
 
-        st = ShardedTables(local, vocab, route_fn=route_fn, gather_fn=gather_fn)
-        got = st.lookup(torch.from_numpy(ids)).numpy()
+            def gather_packed(self, payload):
+                p = payload.numpy()
+                out = np.zeros((p.size, K), np.float32)
+                for i, v in enumerate(p):
+                    if v >= 0:
+                        out[i] = local[v % F].numpy()[v // F]
+                return torch.from_numpy(out)
+
+            def back_buffer(self, n, K_, device):
+                return torch.empty((n, K_), dtype=torch.float32)
+
+            def finish(self, back, inv, B_, F_, want_fm):
+                emb = back.numpy()[inv.numpy()].reshape(B_, F_ * K)
+                fm = None
+                if want_fm:
+                    from oracle import oracle as O
+                    fm = torch.from_numpy(O.fm_second_order(emb, F_, K).reshape(B_, 1))
+                return torch.from_numpy(emb), fm
+
+        st = ShardedTables(local, vocab, backend=OracleBackend())
+        got, fm = st.lookup(torch.from_numpy(ids), want_fm=True)
+        got = got.numpy()
         ref = R.embedding_bag_onehot(full, ids)
-        ok = bool(np.array_equal(got, ref))
+        from oracle import oracle as O
+        ok = bool(np.array_equal(got, ref)) and bool(np.array_equal(fm.numpy()[:, 0], O.fm_second_order(ref, F, K)))
         out_q.put((rank, ok, int(got.shape[0]), int(got.shape[1])))
     finally:
         dist.destroy_process_group()
