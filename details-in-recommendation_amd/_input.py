@@ -9,7 +9,11 @@ import torch
 
 
 def categorical_of(col):
-    return getattr(col, "categorical_column", col)
+    """The categorical column behind a dense wrapper (embedding / indicator); categorical columns -- including
+    weighted_categorical_column, which also carries a `.categorical_column` -- are returned as they are."""
+    if getattr(col, "is_dense", False) and hasattr(col, "categorical_column"):
+        return col.categorical_column
+    return col
 
 
 def collect_ids(columns, features, device):
