@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full",
-                             "sharded_1gpu"])
+                             "sharded_1gpu", "transform", "dcn_full"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -182,6 +182,41 @@ def main():
         step = lambda i: st.lookup(idsl[i % len(idsl)], want_fm=True)  # noqa: E731
         roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K) + 4), "kernel": "bucket + gather_packed + gather_onehot_k"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
+    elif wl == "transform":
+        # raw Criteo-style features -> gather-ready ids on the device
+        # (26 integer categorical keys hashed per field, 13 dense values bucketised into 10 buckets)
+        keys = torch.randint(-2**40, 2**40, (B, F), generator=gen, device=device)
+        nbf = torch.full((F,), V, dtype=torch.int64, device=device)
+        dense = torch.rand((B, 13), generator=gen, device=device)
+        bd = torch.linspace(0.1, 0.9, 9, device=device)
+
+        def step(i):
+            ops.hash_bucket_ints_fields(keys, nbf)
+            ops.bucketize(dense, bd)
+        roof = {"bound": "hbm", "alg_bytes": B * F * 16 + B * 13 * 12, "kernel": "hash_bucket_i64_k + bucketize_k"}
+        cfg.update({"fields": F, "dense": 13})
+    elif wl == "dcn_full":
+        # BASELINE configs[2]: DCN, 3 cross layers on the 26-field schema (+13 dense -> d = 429), deep 1024-1024
+        from dir_amd.dcn import DeepCrossNetwork
+        from dir_amd import feature_column as fc
+        cols = [fc.embedding_column(fc.categorical_column_with_identity("C%02d" % i, V), K) for i in range(F)]
+        cols += [fc.numeric_column("I%02d" % i) for i in range(13)]
+        model = DeepCrossNetwork(columns=cols, cross_layer_num=3, dnn_hidden_units=[1024, 1024], batch_norm=True).to(device)
+        idsl = make_ids(torch, args, gen, device, V)
+        dense = torch.rand((B, 13), generator=gen, device=device)
+        feats = []
+        for ids in idsl:
+            f = {"C%02d" % i: ids[:, i].contiguous() for i in range(F)}
+            f.update({"I%02d" % i: dense[:, i].contiguous() for i in range(13)})
+            feats.append(f)
+        with torch.no_grad():
+            model(feats[0])
+
+        def step(i):
+            with torch.no_grad():
+                model(feats[i % len(feats)])
+        roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K)), "kernel": "DCN forward (embedding-bag bytes only)"}
+        cfg.update({"fields": F, "dense": 13, "d": model.column_num, "cross_layers": 3, "deep": [1024, 1024]})
     elif wl == "dcn_cross":
         d, L = F * K, 3
         x0 = torch.randn((B, d), generator=gen, device=device) * 0.25

@@ -31,6 +31,8 @@ SIGNATURES = {
     "dir_hash_bucket_fast": (c_i32, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64), c_i64, c_i64,
                                      ctypes.POINTER(c_i64)]),
     "dir_hash_bucket_i64_device": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "dir_hash_bucket_i64_fields_device": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
+    "dir_hash_bucket_bytes_device": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "dir_bucketize_f32": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "dir_shard_div_owner": (None, [c_i64, c_i64, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
     "dir_shard_route": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),

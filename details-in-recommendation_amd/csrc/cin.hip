@@ -30,18 +30,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CIN_RT = 2;          // row tiles per wave
 constexpr int CIN_ROWS = 256;      // rows per workgroup = 4 waves * RT * 32
 constexpr int CIN_HP = 129;        // padded H stride of the LDS W image
-constexpr int CIN_IC = 4;          // i values per chunk
+constexpr int cin_ic(int MT) { return MT > 26 ? 2 : 4; }   // i values per chunk (LDS: 2*IC*mp*129*4 B of W)
 
-template <int MT /* m, compile-time */, int CT /* column tiles */, bool FP /* interleaved fast staging */>
+template <int MT /* field count padded to an instantiated size: register arrays, unrolling */, int CT /* column tiles */,
+          bool FP /* interleaved fast staging; needs m == MT */>
 __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, const float* __restrict__ xk,
-                                                const float* __restrict__ W, int Hp, int H, int D, int dshift,
+                                                const float* __restrict__ W, int m /* actual fields, <= MT */, int Hp, int H,
+                                                int D, int dshift,
                                                 int64_t R /* B*D */,
                                                 float* __restrict__ xout,
                                                 float* __restrict__ pooled, int64_t pooled_ld) {
-    constexpr int m = MT;
+    if (FP) m = MT;   // the fast path is only selected when m == MT: keep the divisions compile-time there
     constexpr int mp = (MT + 1) & ~1;
     constexpr int MP2 = mp / 2;
-    constexpr int IC = CIN_IC;
+    constexpr int IC = cin_ic(MT);
     constexpr int HP = CIN_HP;
     constexpr int WCH = IC * mp * HP;     // floats per W buffer
     constexpr int XCH = IC * CIN_ROWS;    // floats per xk buffer
@@ -82,13 +84,13 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
         const int i0 = c * IC;
 #pragma unroll
         for (int q = 0; q < WE; ++q) {
-            const int e = tid + 256 * q;           // e = hl * (IC*m) + kkl
-            const int hl = e / (IC * MT);
-            const int kkl = e - hl * (IC * MT);
-            const int il = kkl / MT;
+            const int e = tid + 256 * q;           // e = hl * (IC*m) + kkl   (runtime m: generic path)
+            const int hl = e / (IC * m);
+            const int kkl = e - hl * (IC * m);
+            const int il = kkl / m;
             const int h = hbase + hl;
             float v = 0.f;
-            if (hl < 32 * CT && h < H && i0 + il < Hp) v = W[(int64_t)h * Kd + (int64_t)i0 * MT + kkl];
+            if (hl < 32 * CT && h < H && i0 + il < Hp) v = W[(int64_t)h * Kd + (int64_t)i0 * m + kkl];
             wreg[q] = v;
         }
 #pragma unroll
@@ -114,10 +116,10 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
         for (int q = 0; q < WE; ++q) {
             if (part >= 0 && q / WPP != part) continue;
             const int e = tid + 256 * q;
-            const int hl = e / (IC * MT);
-            const int kkl = e - hl * (IC * MT);
-            const int il = kkl / MT;
-            const int j = kkl - il * MT;
+            const int hl = e / (IC * m);
+            const int kkl = e - hl * (IC * m);
+            const int il = kkl / m;
+            const int j = kkl - il * m;
             if (hl < 32 * CT) wb[(il * mp + j) * HP + hl] = wreg[q];
         }
         if (part < 0 || part == IC - 1) {
@@ -173,13 +175,16 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
         }
     };
 
-    // zero the j = m pad rows of both W buffers once (odd m only)
+    // zero the pad rows j in [m, mp) of both W buffers once (m < MT, or odd MT); the staging never writes them
     if (mp != m) {
-        for (int e = tid; e < 2 * IC * HP; e += 256) {
-            const int buf = e / (IC * HP);
-            const int rem = e - buf * (IC * HP);
-            const int il = rem / HP, hl = rem - il * HP;
-            Ws[buf * WCH + (il * mp + m) * HP + hl] = 0.f;
+        const int npad = mp - m;
+        for (int e = tid; e < 2 * IC * npad * HP; e += 256) {
+            const int buf = e / (IC * npad * HP);
+            int rem = e - buf * (IC * npad * HP);
+            const int il = rem / (npad * HP);
+            rem -= il * (npad * HP);
+            const int jp_ = rem / HP, hl = rem - jp_ * HP;
+            Ws[buf * WCH + (il * mp + m + jp_) * HP + hl] = 0.f;
         }
     }
 
@@ -338,45 +343,49 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
 template <int MT, int CT>
 constexpr bool cin_fast_shape() {
     constexpr int TPR = 256 / (32 * CT);
-    constexpr int N = CIN_IC * MT;
+    constexpr int N = cin_ic(MT) * MT;
     return (N % TPR == 0) && (((N / TPR) % MT == 0) || (MT % (N / TPR) == 0)) && ((N / TPR) % 4 == 0) && (N % 4 == 0);
 }
 
 template <int MT, int CT, bool FP>
 static void launch_cin_one(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* W,
-                           int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
+                           int m, int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled,
+                           int64_t pooled_ld) {
     static bool set = false;
     if (!set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, FP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         set = true;
     }
-    hipLaunchKernelGGL((cin_k<MT, CT, FP>), grid, dim3(256), shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    hipLaunchKernelGGL((cin_k<MT, CT, FP>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
 }
 
 template <int MT, int CT>
 static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* W,
-                          int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
+                          int m, int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled,
+                          int64_t pooled_ld) {
     // interleaved fast staging needs: a compatible (m, column-tile) shape, whole 16-byte aligned W rows and at
     // least one whole chunk; everything else takes the generic bulk staging
     static const int fast_env = getenv("DIR_CIN_FAST") ? atoi(getenv("DIR_CIN_FAST")) : 1;
-    const bool wvec = ((int64_t)Hp * MT) % 4 == 0 && aligned16(W);
+    const bool wvec = m == MT && ((int64_t)Hp * MT) % 4 == 0 && aligned16(W);
     if constexpr (cin_fast_shape<MT, CT>()) {
-        if (fast_env && wvec && Hp >= CIN_IC) {
-            launch_cin_one<MT, CT, true>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+        if (fast_env && wvec && Hp >= cin_ic(MT)) {
+            launch_cin_one<MT, CT, true>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
             return;
         }
     }
-    launch_cin_one<MT, CT, false>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    launch_cin_one<MT, CT, false>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
 }
 
 template <int MT>
-static int launch_cin(int ct, dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk,
-                      const float* W, int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled,
-                      int64_t pooled_ld) {
+static int launch_cin(int ct, dim3 grid, hipStream_t st, const float* x0, const float* xk, const float* W, int m,
+                      int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
+    constexpr int mp = (MT + 1) & ~1;
+    constexpr int IC = cin_ic(MT);
+    const size_t shmem = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)IC * mp * CIN_HP + 2 * (size_t)IC * CIN_ROWS);
     switch (ct) {
-        case 1: launch_cin_ct<MT, 1>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
-        case 2: launch_cin_ct<MT, 2>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
-        default: launch_cin_ct<MT, 4>(grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
+        case 1: launch_cin_ct<MT, 1>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
+        case 2: launch_cin_ct<MT, 2>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
+        default: launch_cin_ct<MT, 4>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
     }
     return 0;
 }
@@ -400,18 +409,14 @@ extern "C" int dir_cin_layer_f32(const float* x0, const float* xk, const float* 
     int ct = (H + 31) / 32;
     ct = ct >= 3 ? 4 : ct;                   // column tiles per workgroup: 1, 2 or 4
     const int colblocks = (H + 32 * ct - 1) / (32 * ct);
-    const int mp = (m + 1) & ~1;
-    const size_t shmem = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)CIN_IC * mp * CIN_HP + 2 * (size_t)CIN_IC * CIN_ROWS);
-    if (shmem > 160 * 1024) return fail(DIR_E_UNSUPPORTED, "dir_cin_layer_f32: m=%d needs %zu B of LDS", m, shmem);
     dim3 grid((unsigned)((R + CIN_ROWS - 1) / CIN_ROWS), (unsigned)colblocks);
     hipStream_t st = as_stream(stream);
-    switch (m) {
-        case 26: launch_cin<26>(ct, grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
-        case 8: launch_cin<8>(ct, grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
-        case 5: launch_cin<5>(ct, grid, shmem, st, x0, xk, W, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
-        default:
-            return fail(DIR_E_UNSUPPORTED, "dir_cin_layer_f32: field count m=%d is not among the built instantiations (5, 8, 26)", m);
-    }
+    // the kernel is instantiated for padded field counts 8, 16, 26, 40; fields beyond m are zero operands
+    if (m <= 8) launch_cin<8>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    else if (m <= 16) launch_cin<16>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    else if (m <= 26) launch_cin<26>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    else if (m <= 40) launch_cin<40>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    else return fail(DIR_E_UNSUPPORTED, "dir_cin_layer_f32: field count m=%d exceeds 40", m);
     DIR_CHECK_LAUNCH("cin_layer");
     return DIR_OK;
 }

@@ -74,7 +74,7 @@ __host__ __device__ inline uint64_t len17to32(const char* s, size_t len) {
 
 struct U128 { uint64_t first, second; };
 
-inline U128 weak32(uint64_t w, uint64_t x, uint64_t y, uint64_t z, uint64_t a, uint64_t b) {
+__host__ __device__ inline U128 weak32(uint64_t w, uint64_t x, uint64_t y, uint64_t z, uint64_t a, uint64_t b) {
     a += w;
     b = rot(b + a + z, 21);
     uint64_t c = a;
@@ -83,11 +83,11 @@ inline U128 weak32(uint64_t w, uint64_t x, uint64_t y, uint64_t z, uint64_t a, u
     b += rot(a, 44);
     return U128{a + z, b + c};
 }
-inline U128 weak32(const char* s, uint64_t a, uint64_t b) {
+__host__ __device__ inline U128 weak32(const char* s, uint64_t a, uint64_t b) {
     return weak32(fetch64(s), fetch64(s + 8), fetch64(s + 16), fetch64(s + 24), a, b);
 }
 
-inline uint64_t len33to64(const char* s, size_t len) {
+__host__ __device__ inline uint64_t len33to64(const char* s, size_t len) {
     uint64_t mul = k2 + len * 2;
     uint64_t a = fetch64(s) * k2;
     uint64_t b = fetch64(s + 8);
@@ -102,8 +102,8 @@ inline uint64_t len33to64(const char* s, size_t len) {
     return hash16(rot(e + f, 43) + rot(g, 30) + h, e + rot(f + a, 18) + g, mul);
 }
 
-// host: every length
-inline uint64_t fingerprint64(const char* s, size_t len) {
+// every length (host and device)
+__host__ __device__ inline uint64_t fingerprint64(const char* s, size_t len) {
     if (len <= 16) return len0to16(s, len);
     if (len <= 32) return len17to32(s, len);
     if (len <= 64) return len33to64(s, len);
@@ -144,28 +144,95 @@ inline uint64_t fingerprint64(const char* s, size_t len) {
 
 }  // namespace fh
 
-// decimal text of an int64, as [TF-upstream] as_string / StrCat write it; returns the length (<= 20)
-__device__ inline int i64_to_dec(int64_t v, char* buf) {
-    char tmp[20];
+// Decimal text of an int64 ([TF-upstream] as_string / StrCat) built IN REGISTERS: the <= 20 characters live in three
+// little-endian 64-bit words (byte k of the string = byte k of w[0..2]); no private-memory byte array.
+struct DecStr {
+    uint64_t w0, w1, w2;
+    int len;
+};
+
+__device__ __forceinline__ DecStr i64_to_dec_regs(int64_t v) {
+    DecStr d{0, 0, 0, 0};
     uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
-    int n = 0;
-    do {
-        tmp[n++] = (char)('0' + (u % 10));
-        u /= 10;
+    do {   // prepend one character: shift the 192-bit string up by a byte, put the new digit at byte 0
+        const uint64_t q = u / 10;
+        const uint64_t c = (uint64_t)'0' + (u - q * 10);
+        d.w2 = (d.w2 << 8) | (d.w1 >> 56);
+        d.w1 = (d.w1 << 8) | (d.w0 >> 56);
+        d.w0 = (d.w0 << 8) | c;
+        ++d.len;
+        u = q;
     } while (u);
-    int p = 0;
-    if (v < 0) buf[p++] = '-';
-    while (n) buf[p++] = tmp[--n];
-    return p;
+    if (v < 0) {
+        d.w2 = (d.w2 << 8) | (d.w1 >> 56);
+        d.w1 = (d.w1 << 8) | (d.w0 >> 56);
+        d.w0 = (d.w0 << 8) | (uint64_t)'-';
+        ++d.len;
+    }
+    return d;
 }
 
+// 8 (or 4) string bytes starting at byte offset `off` (0 <= off <= 16), as Fetch64 / Fetch32 read them
+__device__ __forceinline__ uint64_t dec_fetch64(const DecStr& d, int off) {
+    const int wi = off >> 3, sh = (off & 7) * 8;
+    const uint64_t lo = wi == 0 ? d.w0 : (wi == 1 ? d.w1 : d.w2);
+    const uint64_t hi = wi == 0 ? d.w1 : (wi == 1 ? d.w2 : 0);
+    return sh == 0 ? lo : ((lo >> sh) | (hi << (64 - sh)));
+}
+__device__ __forceinline__ uint64_t dec_fetch32(const DecStr& d, int off) { return dec_fetch64(d, off) & 0xffffffffULL; }
+
+// farmhashna::Hash64 for len <= 32 over a register-resident string (same arithmetic as fh::len0to16 / len17to32)
+__device__ __forceinline__ uint64_t fingerprint64_dec(const DecStr& d) {
+    using namespace fh;
+    const uint64_t len = (uint64_t)d.len;
+    if (d.len > 16) {
+        const uint64_t mul = k2 + len * 2;
+        const uint64_t a = dec_fetch64(d, 0) * k1;
+        const uint64_t b = dec_fetch64(d, 8);
+        const uint64_t c = dec_fetch64(d, d.len - 8) * mul;
+        const uint64_t e = dec_fetch64(d, d.len - 16) * k2;
+        return hash16(rot(a + b, 43) + rot(c, 30) + e, a + rot(b + k2, 18) + c, mul);
+    }
+    if (d.len >= 8) {
+        const uint64_t mul = k2 + len * 2;
+        const uint64_t a = dec_fetch64(d, 0) + k2;
+        const uint64_t b = dec_fetch64(d, d.len - 8);
+        const uint64_t c = rot(b, 37) * mul + a;
+        const uint64_t e = (rot(a, 25) + b) * mul;
+        return hash16(c, e, mul);
+    }
+    if (d.len >= 4) {
+        const uint64_t mul = k2 + len * 2;
+        const uint64_t a = dec_fetch32(d, 0);
+        return hash16(len + (a << 3), dec_fetch32(d, d.len - 4), mul);
+    }
+    // 1..3 characters (an int64 always has at least one digit)
+    const uint32_t a = (uint32_t)(d.w0 & 0xff);
+    const uint32_t b = (uint32_t)((d.w0 >> (8 * (d.len >> 1))) & 0xff);
+    const uint32_t c = (uint32_t)((d.w0 >> (8 * (d.len - 1))) & 0xff);
+    const uint32_t y = a + (b << 8);
+    const uint32_t z = (uint32_t)d.len + (c << 2);
+    return smix(y * k2 ^ z * k0) * k2;
+}
+
+// keys: flattened [.., F]; buckets_f: nullptr -> one bucket count for all, else device array [F] (entry i uses
+// buckets_f[i % F])
 __global__ void hash_bucket_i64_k(const int64_t* __restrict__ keys, int64_t n, uint64_t buckets,
-                                  int64_t* __restrict__ out) {
+                                  const int64_t* __restrict__ buckets_f, int F, int64_t* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        char buf[32];
-        const int len = i64_to_dec(keys[i], buf);
-        const uint64_t h = len <= 16 ? fh::len0to16(buf, (size_t)len) : fh::len17to32(buf, (size_t)len);
-        out[i] = (int64_t)(h % buckets);
+        const DecStr d = i64_to_dec_regs(keys[i]);
+        const uint64_t h = fingerprint64_dec(d);
+        const uint64_t nb = buckets_f ? (uint64_t)buckets_f[(uint64_t)i % (uint32_t)F] : buckets;
+        out[i] = (int64_t)(h % nb);
+    }
+}
+
+// byte strings in one buffer: string i = bytes[offsets[i] .. offsets[i+1])
+__global__ void hash_bucket_bytes_k(const char* __restrict__ bytes, const int64_t* __restrict__ offsets, int64_t n,
+                                    uint64_t buckets, int64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = offsets[i], e = offsets[i + 1];
+        out[i] = (int64_t)(fh::fingerprint64(bytes + b, (size_t)(e - b)) % buckets);
     }
 }
 
@@ -491,8 +558,30 @@ extern "C" int dir_hash_bucket_i64_device(const int64_t* keys, int64_t n, int64_
     DIR_CHECK_ARG(keys && out && n >= 0 && num_buckets > 0, "dir_hash_bucket_i64_device: bad argument");
     if (n == 0) return DIR_OK;
     hipLaunchKernelGGL(hash_bucket_i64_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, as_stream(stream), keys, n,
-                       (uint64_t)num_buckets, out);
+                       (uint64_t)num_buckets, (const int64_t*)nullptr, 1, out);
     DIR_CHECK_LAUNCH("hash_bucket_i64");
+    return DIR_OK;
+}
+
+extern "C" int dir_hash_bucket_i64_fields_device(const int64_t* keys, int64_t n, const int64_t* buckets_f, int F,
+                                                 int64_t* out, dir_stream_t stream) {
+    DIR_CHECK_ARG(n >= 0 && F > 0, "dir_hash_bucket_i64_fields_device: bad argument");
+    if (n == 0) return DIR_OK;
+    DIR_CHECK_ARG(keys && buckets_f && out, "dir_hash_bucket_i64_fields_device: null pointer");
+    hipLaunchKernelGGL(hash_bucket_i64_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, as_stream(stream), keys, n,
+                       (uint64_t)1, buckets_f, F, out);
+    DIR_CHECK_LAUNCH("hash_bucket_i64_fields");
+    return DIR_OK;
+}
+
+extern "C" int dir_hash_bucket_bytes_device(const char* bytes, const int64_t* offsets, int64_t n, int64_t num_buckets,
+                                            int64_t* out, dir_stream_t stream) {
+    DIR_CHECK_ARG(n >= 0 && num_buckets > 0, "dir_hash_bucket_bytes_device: bad argument");
+    if (n == 0) return DIR_OK;
+    DIR_CHECK_ARG(offsets && out, "dir_hash_bucket_bytes_device: null pointer");
+    hipLaunchKernelGGL(hash_bucket_bytes_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, as_stream(stream), bytes, offsets,
+                       n, (uint64_t)num_buckets, out);
+    DIR_CHECK_LAUNCH("hash_bucket_bytes");
     return DIR_OK;
 }
 

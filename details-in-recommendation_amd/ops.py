@@ -308,6 +308,29 @@ def hash_bucket_ints(keys, num_buckets):
     return out
 
 
+def hash_bucket_ints_fields(keys, buckets_dev):
+    """keys [B, F] (contiguous) with one bucket count per field (device int64 [F]) -> ids [B, F]."""
+    _dev(keys, torch.int64, "keys")
+    _dev(buckets_dev, torch.int64, "buckets_dev")
+    keys = keys.contiguous()
+    out = torch.empty_like(keys)
+    _lib.check(_lib.load().dir_hash_bucket_i64_fields_device(_ptr(keys), keys.numel(), _ptr(buckets_dev), buckets_dev.numel(),
+                                                             _ptr(out), _stream()))
+    return out
+
+
+def hash_bucket_bytes(bytes_dev, offsets, num_buckets):
+    """Byte strings already on the device (uint8 buffer + int64 offsets [n+1]) -> ids [n]."""
+    if bytes_dev.dtype != torch.uint8 or not bytes_dev.is_cuda:
+        raise TypeError("bytes_dev must be a CUDA uint8 tensor")
+    _dev(offsets, torch.int64, "offsets")
+    n = offsets.numel() - 1
+    out = torch.empty(n, dtype=torch.int64, device=offsets.device)
+    _lib.check(_lib.load().dir_hash_bucket_bytes_device(_ptr(bytes_dev.contiguous()), _ptr(offsets.contiguous()), n,
+                                                        num_buckets, _ptr(out), _stream()))
+    return out
+
+
 def bucketize(x, boundaries):
     """bucketized_column: number of boundaries <= x -> int64 ids."""
     _dev(x, torch.float32, "x")

@@ -151,6 +151,7 @@ int dir_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
  *   xout[b, h, d] = sum_{i<Hp} sum_{j<m} W[h, i*m+j] * xk[b,i,d] * x0[b,j,d]
  *   pooled[b*pooled_ld + h] = sum_d xout[b,h,d]      (pooled may be NULL)
  * The outer product Z is never materialised: it is formed in registers and fed to fp32 MFMA.
+ * Shapes: D in {4, 8, 16, 32}; any m <= 40 (instantiated for padded field counts 8/16/26/40); any Hp, H.
  * ------------------------------------------------------------------------------------------ */
 int dir_cin_layer_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                       int64_t B, float* xout, float* pooled, int64_t pooled_ld,
@@ -172,6 +173,13 @@ int dir_hash_bucket_fast(const char* const* strs, const int64_t* lens, int64_t n
                          int64_t num_buckets, int64_t* out);
 int dir_hash_bucket_i64_device(const int64_t* keys, int64_t n, int64_t num_buckets, int64_t* out,
                                dir_stream_t stream);
+/* the same over a flattened [.., F] key array with one bucket count per field (buckets_f: DEVICE [F]):
+ * raw Criteo-style categorical keys -> the [B, F] id matrix the gather takes, in one launch */
+int dir_hash_bucket_i64_fields_device(const int64_t* keys, int64_t n, const int64_t* buckets_f, int F,
+                                      int64_t* out, dir_stream_t stream);
+/* byte strings on the device: string i = bytes[offsets[i] .. offsets[i+1]); every FarmHash length branch */
+int dir_hash_bucket_bytes_device(const char* bytes, const int64_t* offsets, int64_t n, int64_t num_buckets,
+                                 int64_t* out, dir_stream_t stream);
 int dir_bucketize_f32(const float* x, int64_t n, const float* boundaries, int nb, int64_t* out,
                       dir_stream_t stream);
 

@@ -206,7 +206,10 @@ def test_din_attention_pool(ops, oracle, B, T, K, H1, H2, normalize):
 
 
 @pytest.mark.parametrize("B,m,D,Hp,H", [(64, 26, 16, 26, 128), (37, 26, 16, 128, 128), (16, 26, 16, 7, 40), (21, 8, 8, 5, 32),
-                                         (9, 5, 4, 6, 7), (5, 5, 32, 3, 64), (3, 8, 16, 9, 200)])
+                                         (9, 5, 4, 6, 7), (5, 5, 32, 3, 64), (3, 8, 16, 9, 200),
+                                         # field counts that are not an instantiated size (padded with zero operands)
+                                         (33, 39, 16, 39, 128), (17, 39, 16, 64, 96), (12, 13, 16, 13, 64), (8, 3, 8, 3, 32),
+                                         (10, 22, 16, 50, 128), (6, 40, 16, 2, 16), (5, 1, 4, 1, 8)])
 def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     rng = np.random.default_rng(Hp * 13 + H)
     x0 = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
@@ -239,6 +242,20 @@ def test_id_paths_bit_exact(ops, oracle):
     for nb in (1000, 3, 10**6 + 3):
         got = ops.hash_bucket_ints(_dev(keys), nb).cpu().numpy()
         np.testing.assert_array_equal(got, R.hash_bucket_int(keys, nb))
+    # per-field bucket counts over a [B, F] key matrix
+    km = rng.integers(-2**40, 2**40, size=(257, 5)).astype(np.int64)
+    nbf = np.array([1000, 3, 10**6 + 3, 1, 977], np.int64)
+    got = ops.hash_bucket_ints_fields(_dev(km), _dev(nbf)).cpu().numpy()
+    for f in range(5):
+        np.testing.assert_array_equal(got[:, f], R.hash_bucket_int(km[:, f], int(nbf[f])))
+    # byte strings on the device: every FarmHash length branch (0..16, 17..32, 33..64, > 64)
+    strs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8).tolist()) for n in list(range(0, 70)) + [64, 65, 127, 128, 129, 200, 777]]
+    strs += [b"Hello", b"TensorFlow", b"2.x", b"1footrue"]
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in strs])]).astype(np.int64)
+    buf = np.frombuffer(b"".join(strs) or b"\0", dtype=np.uint8).copy()
+    got = ops.hash_bucket_bytes(_dev(buf), _dev(offs), 1000003).cpu().numpy()
+    np.testing.assert_array_equal(got, np.array([R.fingerprint64(x) % 1000003 for x in strs], np.int64))
+    assert ops.hash_bucket_bytes(_dev(buf), _dev(offs), 3).cpu().numpy()[-4:-1].tolist() == [0, 2, 2]   # TF doc example
     x = rng.uniform(-2, 12, 5000).astype(np.float32)
     bd = np.array([0.0, 1.0, 2.5, 2.5, 7.0, 10.0], np.float32)
     x[:6] = bd
