@@ -1,0 +1,71 @@
+"""esmm.py -- ESMM (entire-space multi-task) forward on the HIP gather, keeping the reference constructor kwargs.
+
+Mirrors models/ESMM/ESMM.py (reference):
+  ESMM.__init__ kwargs                                     :23-32
+  _model_fn: two towers under 'ctr_model' / 'cvr_model'    :62-78   (each tower creates its OWN embedding variables)
+  _base_model: input_layer -> (dense(act, glorot_normal))* -> dense(1)       :130-147
+  predictions: ctr/cvr sigmoid, ctcvr = product, ctcvr_logits = logit(clip(p, 1e-7, 1-1e-7))   :67-92
+SURVEY.md 8(f) rank 3: the same gather kernel, used twice per step.
+"""
+import torch
+from torch import nn
+
+from .dcn import _glorot_normal_
+from .deepfm import _glorot_uniform_
+from .input_layer import InputLayer
+
+_EPSILON = 1e-7                                                                  # ESMM.py:19
+
+
+class _BaseModel(nn.Module):
+    def __init__(self, columns, hidden_units, activation):
+        super().__init__()
+        self.input_layer = InputLayer(columns)                                   # ESMM.py:135
+        self.activation = activation
+        self.hidden = nn.ModuleList()
+        d = self.input_layer.column_num
+        for n in hidden_units:
+            lin = nn.Linear(d, n)
+            _glorot_normal_(lin.weight)                                          # ESMM.py:141
+            nn.init.zeros_(lin.bias)
+            self.hidden.append(lin)
+            d = n
+        self.logits = nn.Linear(d, 1)                                            # ESMM.py:146
+        _glorot_uniform_(self.logits.weight)
+        nn.init.zeros_(self.logits.bias)
+
+    def forward(self, features):
+        net = self.input_layer(features)
+        for lin in self.hidden:
+            net = self.activation(lin(net))
+        return self.logits(net)
+
+
+class ESMM(nn.Module):
+    def __init__(self, model_dir=None, columns=None, ctr_weight_column=None, ctcvr_weight_column=None,
+                 dnn_hidden_units=None, dnn_dropout=None, config=None, dnn_activation_fn=torch.relu, optimizer=None):
+        super().__init__()
+        self.hparams = dict(model_dir=model_dir, ctr_weight_column=ctr_weight_column,
+                            ctcvr_weight_column=ctcvr_weight_column, dnn_dropout=dnn_dropout, config=config,
+                            optimizer=optimizer)
+        hidden = list(dnn_hidden_units or [])
+        self.ctr_model = _BaseModel(columns, hidden, dnn_activation_fn)          # ESMM.py:63-64
+        self.cvr_model = _BaseModel(columns, hidden, dnn_activation_fn)          # ESMM.py:65-66
+
+    def forward(self, features):
+        """-> {'ctr_logits', 'ctcvr_logits'} (the `logits` dict of ESMM.py:77)."""
+        ctr_logits = self.ctr_model(features)
+        cvr_logits = self.cvr_model(features)
+        ctcvr_logistic = torch.sigmoid(ctr_logits) * torch.sigmoid(cvr_logits)  # :69-71
+        p = ctcvr_logistic.clamp(_EPSILON, 1 - _EPSILON)                         # :73-74
+        return {"ctr_logits": ctr_logits, "ctcvr_logits": torch.log(p / (1 - p)), "cvr_logits": cvr_logits}
+
+    @torch.no_grad()
+    def predict(self, features):
+        out = self.forward(features)
+        ctr_logistic = torch.sigmoid(out["ctr_logits"])
+        ctcvr_logistic = ctr_logistic * torch.sigmoid(out["cvr_logits"])
+        two = torch.cat([torch.zeros_like(out["ctcvr_logits"]), out["ctcvr_logits"]], dim=-1)          # :83-86
+        return {"probabilities": torch.softmax(two, dim=-1), "logistic": ctcvr_logistic,             # :88-91
+                "class_ids": torch.argmax(two, dim=-1, keepdim=True), "ctr_logistic": ctr_logistic,
+                "ctr_logits": out["ctr_logits"], "ctcvr_logits": out["ctcvr_logits"]}

@@ -1,0 +1,111 @@
+"""input_layer.py -- the dense input layer of the reference's Estimators: [TF-upstream]
+tf.feature_column.input_layer(features, feature_columns) as called at
+models/DeepCrossNetwork/DeepCrossNetwork.py:126 and models/ESMM/ESMM.py:135.
+
+Columns are concatenated SORTED BY NAME ([TF-upstream] input_layer sorts by column.name).  Embedding columns are
+looked up by the HIP embedding-bag kernel straight into their slice of the output (row stride = total width, so
+no concat pass); runs of name-adjacent embedding columns with equal (dimension, combiner) share one launch.
+Numeric columns are copied, indicator columns are multi-hot counts (torch index ops: plumbing).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from ._input import collect_ids, categorical_of
+from .feature_column import EmbeddingColumn, IndicatorColumn, NumericColumn
+
+
+class InputLayer(nn.Module):
+    def __init__(self, columns):
+        super().__init__()
+        columns = list(columns or [])
+        if not columns:
+            raise ValueError("empty columns.")
+        for c in columns:
+            if not getattr(c, "is_dense", False):
+                raise ValueError("Items of feature_columns must be a _DenseColumn. Given: {}".format(c))
+        self.columns = sorted(columns, key=lambda c: c.name)
+        self.offsets = []
+        d = 0
+        for c in self.columns:
+            self.offsets.append(d)
+            d += c.dimension
+        self.column_num = d
+        self.emb_cols = [c for c in self.columns if isinstance(c, EmbeddingColumn)]
+        self.embedding_weights = nn.ParameterList()
+        for c in self.emb_cols:
+            w = torch.empty(c.num_buckets, c.dimension)
+            s = 1.0 / math.sqrt(c.dimension)          # [TF-upstream] embedding_column default initializer
+            nn.init.trunc_normal_(w, std=s, a=-2 * s, b=2 * s)
+            self.embedding_weights.append(nn.Parameter(w))
+        self._ts_key = None
+
+    def _col_offset(self, col):
+        return self.offsets[self.columns.index(col)]
+
+    def _tablesets(self):
+        key = tuple(p.data_ptr() for p in self.embedding_weights)
+        if self._ts_key != key:
+            self._groups = []  # (TableSet, [indices into self.emb_cols], combiner)
+            seen = {}
+            for i, c in enumerate(self.emb_cols):
+                seen.setdefault((c.dimension, c.combiner), []).append(i)
+            for (dim, comb), idxs in seen.items():
+                run = []
+                for i in idxs:  # only runs ADJACENT in the sorted concat can share one launch
+                    if run and self._col_offset(self.emb_cols[i]) != self._col_offset(self.emb_cols[run[-1]]) + dim:
+                        self._groups.append((ops.TableSet([self.embedding_weights[j].data for j in run]), run, comb))
+                        run = []
+                    run.append(i)
+                self._groups.append((ops.TableSet([self.embedding_weights[j].data for j in run]), run, comb))
+            self._ts_key = key
+        return self._groups
+
+    def forward(self, features):
+        device = self.embedding_weights[0].device if len(self.embedding_weights) else next(iter(
+            v for v in features.values() if isinstance(v, torch.Tensor))).device
+        B = None
+        x0 = None
+
+        def alloc(nb):
+            return torch.empty((nb, self.column_num), dtype=torch.float32, device=device)
+
+        for c in self.columns:
+            if isinstance(c, NumericColumn):
+                v = features[c.key].to(device=device, dtype=torch.float32).reshape(-1, c.dimension)
+                if x0 is None:
+                    B = v.shape[0]
+                    x0 = alloc(B)
+                x0[:, self._col_offset(c):self._col_offset(c) + c.dimension] = v
+        for ts, idxs, comb in self._tablesets():
+            cols = [self.emb_cols[i] for i in idxs]
+            got = collect_ids(cols, features, device)
+            nb = got[1].shape[0] if got[0] == "onehot" else got[4]
+            if x0 is None:
+                B = nb
+                x0 = alloc(B)
+            off = self._col_offset(cols[0])
+            view = x0[:, off:off + len(cols) * cols[0].dimension]
+            if got[0] == "onehot":
+                ops.embedding_bag(ts, got[1], out=view)
+            else:
+                ops.embedding_bag(ts, got[1], got[2], got[3], combiner=comb, field_major=True, out=view)
+        for c in self.columns:
+            if isinstance(c, IndicatorColumn):  # multi-hot counts ([TF-upstream] indicator_column)
+                ids = categorical_of(c).ids(features, device)
+                if x0 is None:
+                    B = ids.numel() if not isinstance(ids, tuple) else ids[1].numel() - 1
+                    x0 = alloc(B)
+                ind = torch.zeros((B, c.dimension), dtype=torch.float32, device=device)
+                if isinstance(ids, tuple):
+                    vals, offs, _ = ids
+                    rows = torch.repeat_interleave(torch.arange(B, device=device), offs[1:] - offs[:-1])
+                    ok = vals >= 0
+                    ind.index_put_((rows[ok], vals[ok]), torch.ones(int(ok.sum()), device=device), accumulate=True)
+                else:
+                    ok = ids >= 0
+                    ind[torch.arange(B, device=device)[ok], ids[ok]] = 1.0
+                x0[:, self._col_offset(c):self._col_offset(c) + c.dimension] = ind
+        return x0

@@ -1,0 +1,89 @@
+"""Seeded shape fuzzing on the GPU: random (B, F, K, vocab, strides, bag lengths, d, L) through the C ABI against the
+oracle.  Same bars as test_gpu_parity.py: bit-exact for gather / bags / FM / linear, 1e-5 scaled for cross."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops(built_lib):
+    from dir_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_gather_bag_fm_linear(ops, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    F = int(rng.integers(1, 40))
+    K = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 20, 24, 32, 48, 64, 100, 128, 200, 256]))
+    B = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 257, 1000, 4096, 5001]))
+    if B * F * K > 6_000_000:
+        B = max(1, 6_000_000 // (F * K))
+    vocab = [int(rng.integers(1, 3000)) for _ in range(F)]
+    tables = [(rng.standard_normal((v, K)) * 0.3).astype(np.float32) for v in vocab]
+    ids = np.stack([rng.integers(-1, v, size=B) for v in vocab], axis=1).astype(np.int64)
+    ts = ops.TableSet([_dev(t) for t in tables])
+    ts.row_policy = ["auto", "stream", "reuse"][seed % 3]
+    ref = oracle.embedding_bag(tables, ids)
+    layout = seed % 3
+    if layout == 0:
+        dids = _dev(ids)
+    elif layout == 1:
+        dids = _dev(ids.T.copy()).t()                       # [F,B] storage
+    else:
+        wide = np.full((B, F + 3), 7, np.int64); wide[:, 1:F + 1] = ids
+        dids = _dev(wide)[:, 1:F + 1]                        # a strided window of a wider matrix
+    # output into a wider buffer (out_ld > F*K), as DCN's x0 does
+    pad = int(rng.choice([0, 1, 4, 13]))
+    buf = torch.zeros((B, F * K + pad), dtype=torch.float32, device="cuda")
+    out = buf[:, :F * K] if pad else None
+    got = ops.embedding_bag(ts, dids, out=out)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    emb, fm = ops.gather_fm(ts, dids)
+    np.testing.assert_array_equal(emb.cpu().numpy(), ref)
+    np.testing.assert_array_equal(fm.cpu().numpy()[:, 0], oracle.fm_second_order(ref, F, K))
+    np.testing.assert_array_equal(ops.fm_logit(emb, F, K).cpu().numpy()[:, 0], oracle.fm_second_order(ref, F, K))
+    # ragged weighted bags on the same tables
+    lens = rng.integers(0, 6, size=B * F)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = max(int(offs[-1]), 1)
+    f_of = np.repeat(np.tile(np.arange(F), B), lens) if offs[-1] else np.zeros(0, np.int64)
+    vals = np.array([rng.integers(-1, vocab[f]) for f in f_of], np.int64) if offs[-1] else np.zeros(1, np.int64)
+    w = rng.uniform(-0.2, 2.0, size=nnz).astype(np.float32)
+    comb = int(rng.integers(0, 3))
+    use_w = bool(seed & 1)
+    refb = oracle.embedding_bag(tables, vals, offsets=offs, weights=w if use_w else None, combiner=comb, B=B)
+    gotb = ops.embedding_bag(ts, _dev(vals), offsets=_dev(offs), weights=_dev(w) if use_w else None,
+                             combiner=["sum", "mean", "sqrtn"][comb])
+    np.testing.assert_array_equal(gotb.cpu().numpy(), refb)
+    # linear term over the same ids (tables reduced to their first column)
+    lw = [np.ascontiguousarray(t[:, 0]) for t in tables]
+    lts = ops.TableSet([_dev(x) for x in lw])
+    bias = np.array([rng.standard_normal()], np.float32)
+    np.testing.assert_array_equal(ops.linear_logit(lts, dids, bias=_dev(bias)).cpu().numpy()[:, 0],
+                                  oracle.linear_sparse_sum(lw, ids, bias=bias))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_cross(ops, oracle, seed):
+    rng = np.random.default_rng(2000 + seed)
+    d = int(rng.choice([1, 3, 4, 7, 16, 51, 64, 100, 128, 255, 256, 416, 429, 512, 1000, 1024, 2048]))
+    L = int(rng.integers(0, 7))
+    B = int(rng.choice([1, 7, 8, 9, 64, 333, 2048, 4097]))
+    x0 = (rng.standard_normal((B, d)) * 0.3).astype(np.float32)
+    w = np.clip(rng.standard_normal((max(L, 1), d)) * 0.1, -0.2, 0.2).astype(np.float32)[:L]
+    b = np.clip(rng.standard_normal((max(L, 1), d)) * 0.1, -0.2, 0.2).astype(np.float32)[:L]
+    ref = oracle.dcn_cross(x0, w.reshape(L, d), b.reshape(L, d), acc64=True).astype(np.float64)
+    # x0 as a window of a wider buffer (row stride > d)
+    pad = int(rng.choice([0, 4, 5]))
+    xb = torch.zeros((B, d + pad), dtype=torch.float32, device="cuda")
+    xb[:, :d] = _dev(x0)
+    got = ops.cross_network(xb[:, :d], _dev(w.reshape(L, d)), _dev(b.reshape(L, d))).cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref) / (1 + np.abs(ref))
+    assert err.max() <= 1e-5, (d, L, B, err.max())
