@@ -1,0 +1,112 @@
+"""checkpoint.py -- parameters <-> the reference's TensorFlow checkpoint variable names and layouts.
+
+SURVEY.md 8(f) rank 4.  The reference models are tf.estimator.Estimators that checkpoint into `model_dir`
+(models/DeepFM/deepFM.py:56,138-140; models/DeepCrossNetwork/DeepCrossNetwork.py:36,115; models/ESMM/ESMM.py:60).
+This module maps every parameter of the modules here to the variable name the reference graph would give it
+(variable scopes: deepFM.py:173-196,206-209,286-317; DeepCrossNetwork.py:109,125,134,329-331,393-403;
+ESMM.py:62-66,139-146) and to TensorFlow's layout (dense kernels are [in, out], i.e. the transpose of
+nn.Linear.weight; linear_model weights are [vocab, 1]).  `export_npz` / `load_npz` move a whole model through a
+.npz keyed by those names -- the route to true cross-implementation parity once a TF 1.x environment exists to dump
+a reference checkpoint (`tf.train.load_checkpoint(...).get_tensor(name)` -> np.savez).
+
+[TF-upstream] names that cannot be verified in this container (TensorFlow is not installable): the
+`<column>/embedding_weights`, `linear_model/<column>/weights`, `batch_normalization` (gamma/beta/moving_*) and
+contrib `BatchNorm` (beta/moving_*) suffixes follow TF r1.10-r1.13 naming.
+"""
+import numpy as np
+import torch
+
+from ._input import categorical_of
+
+
+def _lin(prefix, layer, out):
+    out[prefix + "/kernel"] = (layer.weight, "T")       # TF dense kernel = weight^T
+    out[prefix + "/bias"] = (layer.bias, None)
+
+
+def tf_variable_map(model):
+    """-> {tf_name: (parameter_or_buffer, layout)} with layout None | 'T' (transpose) | 'col' ([V] <-> [V,1])."""
+    from .deepfm import DeepFM
+    from .dcn import DeepCrossNetwork
+    from .esmm import ESMM
+    m = {}
+    if isinstance(model, DeepFM):
+        for c, p in zip(model.dnn_feature_columns, model.embedding_weights):
+            m["dnn_fm_inputs/myself_input_layer/%s/embedding_weights" % c.name] = (p, None)    # deepFM.py:173-177,386
+        for i, lin in enumerate(model.hidden):
+            _lin("dnn_fm/hiddenlayer_%d" % i, lin, m)                                          # deepFM.py:293-300
+            if len(model.bns):
+                bn = model.bns[i]
+                pre = "dnn_fm/hiddenlayer_%d/batchnorm_%d" % (i, i)                            # deepFM.py:304-308
+                m[pre + "/gamma"], m[pre + "/beta"] = (bn.gamma, None), (bn.beta, None)
+                m[pre + "/moving_mean"], m[pre + "/moving_variance"] = (bn.moving_mean, None), (bn.moving_variance, None)
+        if len(model.hidden) or model.dnn_feature_columns:
+            _lin("dnn_fm/logits", model.logits_layer, m)                                       # deepFM.py:311-317
+        for c, p in zip(model.linear_feature_columns, model.linear_weights):
+            m["linear/linear_model/%s/weights" % categorical_of(c).name] = (p, "col")          # deepFM.py:206-213
+        m["linear/linear_model/bias_weights"] = (model.linear_bias, None)
+    elif isinstance(model, DeepCrossNetwork):
+        il = model.input_layer
+        for c, p in zip(il.emb_cols, il.embedding_weights):
+            m["dcn_model/input_from_feature_columns/input_layer/%s/embedding_weights" % c.name] = (p, None)   # :109,125-126
+        m["dcn_model/input_from_feature_columns/cross_w"] = (model.cross_w, None)              # :329-330
+        m["dcn_model/input_from_feature_columns/cross_b"] = (model.cross_b, None)              # :331-332
+        bi = 0
+        n = len(model.hidden)
+        for i, lin in enumerate(model.hidden):
+            pre = "dcn_model/input_from_feature_columns/hidden_layer_%d" % i                   # :393-399
+            _lin(pre, lin, m)
+            if model.batch_norm and i < n - 1:
+                bn = model.bns[bi]
+                bi += 1
+                m[pre + "/bn_%d/beta" % i] = (bn.beta, None)                                   # :403, 418-419
+                m[pre + "/bn_%d/moving_mean" % i] = (bn.moving_mean, None)
+                m[pre + "/bn_%d/moving_variance" % i] = (bn.moving_variance, None)
+        _lin("dcn_model/logits/dense", model.logits_layer, m)                                  # :134-137
+    elif isinstance(model, ESMM):
+        for scope, tower in (("esmm/ctr_model", model.ctr_model), ("esmm/cvr_model", model.cvr_model)):   # ESMM.py:62-66
+            il = tower.input_layer
+            for c, p in zip(il.emb_cols, il.embedding_weights):
+                m["%s/input_layer/%s/embedding_weights" % (scope, c.name)] = (p, None)          # ESMM.py:135
+            for i, lin in enumerate(tower.hidden):
+                _lin("%s/hiddenlayer_%d" % (scope, i), lin, m)                                  # ESMM.py:137-142
+            _lin("%s/dense" % scope, tower.logits, m)                                           # ESMM.py:146
+    else:
+        raise TypeError("no TensorFlow name mapping for %s" % type(model).__name__)
+    return m
+
+
+def _to_tf(t, layout):
+    a = t.detach().cpu().numpy()
+    if layout == "T":
+        a = a.T
+    elif layout == "col":
+        a = a.reshape(-1, 1)
+    return np.ascontiguousarray(a)
+
+
+def export_npz(model, path):
+    """Write every mapped variable in TensorFlow's name and layout."""
+    np.savez(path, **{k: _to_tf(t, lay) for k, (t, lay) in tf_variable_map(model).items()})
+
+
+def load_npz(model, path, strict=True):
+    """Load a .npz keyed by TensorFlow variable names (e.g. dumped from a reference checkpoint)."""
+    data = np.load(path)
+    vm = tf_variable_map(model)
+    missing = [k for k in vm if k not in data.files]
+    if strict and missing:
+        raise KeyError("variables missing from %s: %s" % (path, missing[:5]))
+    with torch.no_grad():
+        for k, (t, lay) in vm.items():
+            if k not in data.files:
+                continue
+            a = data[k]
+            if lay == "T":
+                a = a.T
+            elif lay == "col":
+                a = a.reshape(-1)
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError("%s: checkpoint shape %s vs parameter %s" % (k, a.shape, tuple(t.shape)))
+            t.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(t.device, t.dtype))
+    return missing

@@ -112,3 +112,46 @@ def test_shard_div_range_and_table_check(built_lib):
     from dir_amd.shard import div_range
     assert [div_range(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert [div_range(7, 8, r) for r in range(8)][-2:] == [(6, 7), (7, 7)]
+
+
+def test_tf_checkpoint_mapping_roundtrip(built_lib, tmp_path):
+    """parameters <-> reference checkpoint names/layouts; export -> load is the identity."""
+    from dir_amd import feature_column as fc
+    from dir_amd import checkpoint as ck
+    from dir_amd.deepfm import DeepFM
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd.esmm import ESMM
+    cats = [fc.categorical_column_with_identity("C%d" % i, 30) for i in range(3)]
+    embs = [fc.embedding_column(c, 4) for c in cats]
+
+    def fresh(kind):
+        if kind == "deepfm":
+            return DeepFM(linear_feature_columns=cats, dnn_feature_columns=embs, dnn_hidden_units=[8, 4], fm_embedding_size=4,
+                          batch_norm=True)
+        if kind == "dcn":
+            return DeepCrossNetwork(columns=embs + [fc.numeric_column("x")], cross_layer_num=2, dnn_hidden_units=[8, 4, 2])
+        return ESMM(columns=embs + [fc.numeric_column("x")], dnn_hidden_units=[8, 4])
+
+    for kind in ("deepfm", "dcn", "esmm"):
+        a, b = fresh(kind), fresh(kind)
+        with torch.no_grad():
+            for p in a.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        names = ck.tf_variable_map(a)
+        # every parameter and BN buffer is mapped exactly once
+        mapped = {id(t) for t, _ in names.values()}
+        want = {id(p) for p in a.parameters()} | {id(v) for k, v in a.named_buffers()}
+        assert mapped == want, kind
+        path = str(tmp_path / (kind + ".npz"))
+        ck.export_npz(a, path)
+        assert ck.load_npz(b, path) == []
+        for (ka, ta), (kb, tb) in zip(sorted(ck.tf_variable_map(a).items()), sorted(ck.tf_variable_map(b).items())):
+            assert ka == kb and torch.equal(ta[0], tb[0])
+    m = ck.tf_variable_map(fresh("deepfm"))
+    assert "dnn_fm_inputs/myself_input_layer/C0_embedding/embedding_weights" in m and "dnn_fm/hiddenlayer_0/kernel" in m
+    assert "linear/linear_model/C1/weights" in m and "dnn_fm/hiddenlayer_1/batchnorm_1/moving_variance" in m
+    d = np.load(str(tmp_path / "deepfm.npz"))
+    assert d["dnn_fm/hiddenlayer_0/kernel"].shape == (12, 8) and d["linear/linear_model/C0/weights"].shape == (30, 1)
+    m = ck.tf_variable_map(fresh("dcn"))
+    assert "dcn_model/input_from_feature_columns/cross_w" in m and "dcn_model/logits/dense/kernel" in m
+    assert "esmm/cvr_model/hiddenlayer_1/kernel" in ck.tf_variable_map(fresh("esmm"))
