@@ -1,0 +1,206 @@
+"""autograd.py -- differentiable wrappers of the HIP ops (backward of the interaction path).
+
+The reference trains its Estimators through TensorFlow autodiff with Adagrad on the dnn/fm/embedding variables and
+FTRL on the linear ones (models/DeepFM/deepFM.py:58,61,225-245).  Here every forward op keeps running in HIP; its
+backward is either a HIP kernel (FM second-order, DCN cross: csrc/backward.hip) or, for the table gradients, the
+SPARSE gradient the reference's embedding lookups produce (IndexedSlices): indices = the looked-up ids, values = the
+incoming row gradients times the bag coefficient.  The sparse tensors are handed to torch.optim (Adagrad accepts
+sparse gradients and, like TensorFlow's _apply_sparse_duplicate_indices, sums duplicate ids before the update).
+"""
+import torch
+
+from . import ops
+
+
+def _sparse_rows(ids, rows, vocab):
+    """Sparse [vocab, K] (or [vocab]) gradient: entry i adds rows[i] to row ids[i]; pruned ids (< 0) add nothing."""
+    ok = ids >= 0
+    idx = torch.where(ok, ids, torch.zeros_like(ids))
+    if rows.dim() == 2:
+        vals = rows * ok.unsqueeze(1).to(rows.dtype)
+        size = (vocab, rows.shape[1])
+    else:
+        vals = rows * ok.to(rows.dtype)
+        size = (vocab,)
+    return torch.sparse_coo_tensor(idx.reshape(1, -1), vals.contiguous(), size=size)
+
+
+class GatherFm(torch.autograd.Function):
+    """emb, fm = gather_fm(tables, ids) with d/d(tables) as sparse gradients (one-hot slots)."""
+
+    @staticmethod
+    def forward(ctx, ts, ids, *tables):
+        emb, fm = ops.gather_fm(ts, ids)
+        ctx.ts = ts
+        ctx.save_for_backward(ids, emb)
+        return emb, fm
+
+    @staticmethod
+    def backward(ctx, g_emb, g_fm):
+        ids, emb = ctx.saved_tensors
+        ts = ctx.ts
+        F, K = ts.F, ts.K
+        add_in = g_emb.contiguous() if g_emb is not None else None
+        if g_fm is not None:
+            demb = ops.fm_logit_backward(emb, g_fm.contiguous(), F, K, add_in=add_in)      # HIP: FM + DNN branch, one pass
+        else:
+            demb = add_in
+        grads = []
+        for f in range(F):
+            grads.append(_sparse_rows(ids[:, f].contiguous(), demb[:, f * K:(f + 1) * K], ts.vocab[f]))
+        return (None, None) + tuple(grads)
+
+
+class EmbeddingBag(torch.autograd.Function):
+    """One-hot or multi-hot embedding bag (any combiner) with sparse table gradients."""
+
+    @staticmethod
+    def forward(ctx, ts, ids, offsets, weights, combiner, field_major, out, *tables):
+        res = ops.embedding_bag(ts, ids, offsets, weights, combiner=combiner, field_major=field_major, out=out)
+        ctx.ts, ctx.combiner, ctx.field_major = ts, combiner, field_major
+        ctx.save_for_backward(ids, offsets if offsets is not None else torch.empty(0), weights if weights is not None else torch.empty(0))
+        ctx.has_offsets, ctx.has_weights = offsets is not None, weights is not None
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, offsets, weights = ctx.saved_tensors
+        ts = ctx.ts
+        F, K = ts.F, ts.K
+        g = g.contiguous() if g.stride(1) == 1 else g.clone()
+        grads = []
+        if not ctx.has_offsets:
+            for f in range(F):
+                grads.append(_sparse_rows(ids[:, f].contiguous(), g[:, f * K:(f + 1) * K], ts.vocab[f]))
+        else:
+            B = (offsets.numel() - 1) // F
+            lens = offsets[1:] - offsets[:-1]
+            bag_of = torch.repeat_interleave(torch.arange(B * F, device=ids.device), lens)
+            w = weights if ctx.has_weights else torch.ones(ids.numel(), dtype=torch.float32, device=ids.device)
+            valid = (ids >= 0).to(torch.float32)
+            wv = w * valid
+            comb = ops._COMBINERS[ctx.combiner]
+            if comb == ops.SUM:
+                coef = wv
+            else:
+                den = torch.zeros(B * F, dtype=torch.float32, device=ids.device)
+                if comb == ops.MEAN:
+                    den.index_add_(0, bag_of, wv if ctx.has_weights else valid)
+                else:
+                    den.index_add_(0, bag_of, (wv * wv) if ctx.has_weights else valid)
+                    den = den.sqrt()
+                coef = wv / den.clamp_min(1e-30)[bag_of]
+            if ctx.field_major:
+                f_of, b_of = bag_of // B, bag_of % B
+            else:
+                b_of, f_of = bag_of // F, bag_of % F
+            gv = g.view(B, F, K)[b_of, f_of] * coef.unsqueeze(1)
+            for f in range(F):
+                sel = f_of == f
+                grads.append(_sparse_rows(ids[sel], gv[sel], ts.vocab[f]))
+        return (None, None, None, None, None, None, None) + tuple(grads)
+
+
+class LinearLogit(torch.autograd.Function):
+    """First-order term (units = 1, one-hot ids, 'sum'): sparse gradients for the weight columns, dense for the bias."""
+
+    @staticmethod
+    def forward(ctx, ts, ids, bias, *weights):
+        out = ops.linear_logit(ts, ids, bias=bias.detach())
+        ctx.ts = ts
+        ctx.save_for_backward(ids)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        ts = ctx.ts
+        gv = g.reshape(-1)
+        grads = [_sparse_rows(ids[:, f].contiguous(), gv, ts.vocab[f]) for f in range(ts.F)]
+        return (None, None, gv.sum().reshape(1)) + tuple(grads)
+
+
+class FmLogit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, F, K):
+        ctx.F, ctx.K = F, K
+        ctx.save_for_backward(emb)
+        return ops.fm_logit(emb, F, K)
+
+    @staticmethod
+    def backward(ctx, g):
+        (emb,) = ctx.saved_tensors
+        return ops.fm_logit_backward(emb, g.contiguous(), ctx.F, ctx.K), None, None
+
+
+class CrossNetwork(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, w, b):
+        ctx.save_for_backward(x0, w, b)
+        return ops.cross_network(x0, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, w, b = ctx.saved_tensors
+        g = g.contiguous() if g.stride(1) == 1 else g.clone()
+        gx0, gw, gb = ops.cross_network_backward(x0, w, b, g)
+        return gx0, gw, gb
+
+
+def gather_fm(ts, ids, tables):
+    return GatherFm.apply(ts, ids, *tables)
+
+
+def embedding_bag(ts, ids, tables, offsets=None, weights=None, combiner="mean", field_major=False, out=None):
+    return EmbeddingBag.apply(ts, ids, offsets, weights, combiner, field_major, out, *tables)
+
+
+def linear_logit(ts, ids, bias, weights):
+    return LinearLogit.apply(ts, ids, bias, *weights)
+
+
+def fm_logit(emb, F, K):
+    return FmLogit.apply(emb, F, K)
+
+
+def cross_network(x0, w, b):
+    return CrossNetwork.apply(x0, w, b)
+
+
+class Ftrl(torch.optim.Optimizer):
+    """FTRL-Proximal with [TF-upstream] tf.train.FtrlOptimizer's defaults and update rule (the reference's
+    linear_optimizer='Ftrl', deepFM.py:58): learning_rate_power = -0.5, initial_accumulator_value = 0.1,
+    l1 = l2 = 0.  Dense and sparse gradients (sparse ones are coalesced first, as TensorFlow sums duplicate ids)."""
+
+    def __init__(self, params, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
+        super().__init__(params, dict(lr=lr, init=initial_accumulator_value, l1=l1, l2=l2))
+
+    @torch.no_grad()
+    def step(self):
+        for group in self.param_groups:
+            lr, l1, l2 = group["lr"], group["l1"], group["l2"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["accum"] = torch.full_like(p, group["init"])
+                    st["linear"] = torch.zeros_like(p)
+                g = p.grad
+                if g.is_sparse:
+                    g = g.coalesce()
+                    idx = g.indices()[0]
+                    gv = g.values()
+                    n, z, w = st["accum"][idx], st["linear"][idx], p[idx]
+                else:
+                    idx, gv = None, g
+                    n, z, w = st["accum"], st["linear"], p
+                n_new = n + gv * gv
+                sigma = (n_new.sqrt() - n.sqrt()) / lr
+                z_new = z + gv - sigma * w
+                quad = n_new.sqrt() / lr + 2 * l2
+                w_new = torch.where(z_new.abs() > l1, (torch.sign(z_new) * l1 - z_new) / quad, torch.zeros_like(z_new))
+                if idx is None:
+                    st["accum"].copy_(n_new); st["linear"].copy_(z_new); p.copy_(w_new)
+                else:
+                    st["accum"][idx] = n_new; st["linear"][idx] = z_new; p[idx] = w_new

@@ -1,0 +1,295 @@
+// backward.hip -- gradients of the HBM-bound interaction ops, gfx950.
+//
+// The reference trains through TensorFlow's autodiff of the closures this library replaces:
+//   fm_logit_fn                     models/DeepFM/deepFM.py:321-335
+//   _cross_op / _cross_architecture models/DeepCrossNetwork/DeepCrossNetwork.py:336-367
+// so the backward formulas below are the derivatives of exactly those expressions.
+//
+//   FM:    y_b = 0.5 * sum_k[(sum_f e)^2 - sum_f e^2]   =>   dL/de[b,f,k] = g_b * (S[b,k] - e[b,f,k]),  S = sum_f e
+//   cross: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l ; with g = dL/dx_{l+1}, s_l = x_l . w_l, t = g . x0:
+//              db_l += g ;  dw_l += t * x_l ;  dx0 += s_l * g ;  dL/dx_l = g + t * w_l ;  finally dx0 += dL/dx_0
+//
+// Both are streaming kernels.  FM backward keeps the forward's lane mapping (K/4 lanes per sample) and can add
+// the gradient arriving from the DNN branch in the same pass (the total d/d(embedding) of DeepFM in one launch).
+// Cross backward gives one row to a wave: x_0..x_L of the row are recomputed into an LDS slab, the weight /
+// bias gradients accumulate in per-wave LDS slabs (lane-private addresses, no atomics), each workgroup writes
+// one partial [2, L, d] and a second launch adds the partials in a fixed order (bitwise reproducible).
+#include "common.hpp"
+
+namespace dir {
+
+template <int VEC> struct BV;
+template <> struct BV<4> {
+    using T = float4;
+    static __device__ __forceinline__ T ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st(float* p, T v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ T add(T a, T b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+    static __device__ __forceinline__ T sub(T a, T b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+    static __device__ __forceinline__ T scale(T a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+    static __device__ __forceinline__ T fma(T a, float s, T c) { return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w)); }
+    static __device__ __forceinline__ float dot(T a, T b, float acc) {
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        return acc;
+    }
+    static __device__ __forceinline__ T upd(T x0, float xw, T b, T xl) {
+        return make_float4(((x0.x * xw) + b.x) + xl.x, ((x0.y * xw) + b.y) + xl.y, ((x0.z * xw) + b.z) + xl.z, ((x0.w * xw) + b.w) + xl.w);
+    }
+};
+template <> struct BV<1> {
+    using T = float;
+    static __device__ __forceinline__ T ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
+    static __device__ __forceinline__ T zero() { return 0.f; }
+    static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+    static __device__ __forceinline__ T sub(T a, T b) { return a - b; }
+    static __device__ __forceinline__ T scale(T a, float s) { return a * s; }
+    static __device__ __forceinline__ T fma(T a, float s, T c) { return fmaf(a, s, c); }
+    static __device__ __forceinline__ float dot(T a, T b, float acc) { return fmaf(a, b, acc); }
+    static __device__ __forceinline__ T upd(T x0, float xw, T b, T xl) { return ((x0 * xw) + b) + xl; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// FM backward: demb[b, f, :] = g[b] * (S[b, :] - e[b, f, :]) (+ add_in[b, f, :])
+// ------------------------------------------------------------------------------------------------
+template <int LPS, int VEC>
+__global__ __launch_bounds__(256) void fm_bwd_k(const float* __restrict__ emb, int64_t ld, const float* __restrict__ g,
+                                                const float* __restrict__ add_in, int64_t ld_a, int64_t B, int F, int K,
+                                                float* __restrict__ demb, int64_t ld_o) {
+    using V = BV<VEC>;
+    using T = typename V::T;
+    constexpr int SPW = 64 / LPS;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (LPS - 1);
+    const int s = lane / LPS;
+    const int kv = (K + VEC - 1) / VEC;
+    const bool cact = c < kv;
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w * SPW < B; w += nwave) {
+        const int64_t b = w * SPW + s;
+        const bool act = cact && b < B;
+        if (!act) continue;
+        const float* ep = emb + b * ld + c * VEC;
+        T S = V::zero();
+#pragma unroll 8
+        for (int f = 0; f < F; ++f) S = V::add(S, V::ld(ep + (int64_t)f * K));   // f ascending, as the forward
+        const float gb = g[b];
+        float* op = demb + b * ld_o + c * VEC;
+        const float* ap = add_in ? add_in + b * ld_a + c * VEC : nullptr;
+#pragma unroll 8
+        for (int f = 0; f < F; ++f) {
+            T d = V::scale(V::sub(S, V::ld(ep + (int64_t)f * K)), gb);
+            if (ap) d = V::add(d, V::ld(ap + (int64_t)f * K));
+            V::st(op + (int64_t)f * K, d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross backward.  One row per wave; NV chunks of VEC floats per lane (chunk ch = i*64 + lane).
+// LDS: wb [2][L][d] (shared), then per wave: xs [(L+1)][d] (x_0..x_L of the current row), gacc [2][L][d].
+// ------------------------------------------------------------------------------------------------
+template <int NV, int VEC>
+__global__ __launch_bounds__(256) void cross_bwd_k(const float* __restrict__ x0, int64_t x_ld,
+                                                   const float* __restrict__ w, const float* __restrict__ bvec, int L,
+                                                   const float* __restrict__ gout, int64_t g_ld, int64_t B, int d,
+                                                   float* __restrict__ gx0, int64_t gx_ld,
+                                                   float* __restrict__ partial /* [gridDim.x][2][L][d] */) {
+    using V = BV<VEC>;
+    using T = typename V::T;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ld = L * d;
+    const int nw = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* wsh = smem;                       // [L][d]
+    float* bsh = smem + Ld;                  // [L][d]
+    const int Lp = (L + 3) & ~3;
+    const int wstride = (L + 1) * d + 2 * Ld + Lp;               // floats per wave slab
+    float* xs = smem + 2 * Ld + wave * wstride;                  // [(L+1)][d]
+    float* gw = xs + (L + 1) * d;            // [L][d]
+    float* gb = gw + Ld;                     // [L][d]
+    float* sls = gb + Ld;                    // [L]: s_l = x_l . w_l of the current row
+    for (int i = threadIdx.x; i < Ld; i += blockDim.x) {
+        wsh[i] = w[i];
+        bsh[i] = bvec[i];
+    }
+    for (int i = lane; i < 2 * Ld; i += 64) gw[i] = 0.f;   // gw and gb are contiguous
+    __syncthreads();
+    const int nchunk = d / VEC;
+    const int64_t nwave = (int64_t)gridDim.x * nw;
+    for (int64_t r = (int64_t)blockIdx.x * nw + wave; r < B; r += nwave) {
+        const float* xp = x0 + r * x_ld;
+        const float* gp = gout + r * g_ld;
+        T xv[NV], g[NV], gx[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = i * 64 + lane;
+            const bool ok = ch < nchunk;
+            xv[i] = ok ? V::ld(xp + ch * VEC) : V::zero();
+            g[i] = ok ? V::ld(gp + ch * VEC) : V::zero();
+            gx[i] = V::zero();
+            if (ok) V::st(xs + ch * VEC, xv[i]);          // x_0
+        }
+        // forward recompute: x_1..x_L and s_0..s_{L-1} into the wave's slab
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int ch = i * 64 + lane;
+                if (ch < nchunk) part = V::dot(V::ld(xs + l * d + ch * VEC), V::ld(wsh + l * d + ch * VEC), part);
+            }
+            const float s = wave_sum(part);
+            if (lane == 0) sls[l] = s;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int ch = i * 64 + lane;
+                if (ch < nchunk)
+                    V::st(xs + (l + 1) * d + ch * VEC,
+                          V::upd(xv[i], s, V::ld(bsh + l * d + ch * VEC), V::ld(xs + l * d + ch * VEC)));
+            }
+        }
+        // backward through the layers
+#pragma unroll 1
+        for (int l = L - 1; l >= 0; --l) {
+            float tp = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) tp = V::dot(g[i], xv[i], tp);
+            const float t = wave_sum(tp);
+            const float s = sls[l];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int ch = i * 64 + lane;
+                if (ch < nchunk) {
+                    const T xl = V::ld(xs + l * d + ch * VEC);
+                    V::st(gb + l * d + ch * VEC, V::add(V::ld(gb + l * d + ch * VEC), g[i]));          // db_l += g
+                    V::st(gw + l * d + ch * VEC, V::fma(xl, t, V::ld(gw + l * d + ch * VEC)));         // dw_l += t * x_l
+                    gx[i] = V::fma(g[i], s, gx[i]);                                                    // dx0 += s_l * g
+                    g[i] = V::fma(V::ld(wsh + l * d + ch * VEC), t, g[i]);                             // dL/dx_l
+                }
+            }
+        }
+        float* op = gx0 + r * gx_ld;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = i * 64 + lane;
+            if (ch < nchunk) V::st(op + ch * VEC, V::add(gx[i], g[i]));                                // + dL/dx_0
+        }
+    }
+    __syncthreads();
+    // workgroup partial = sum of the per-wave slabs in wave order
+    float* pout = partial + (int64_t)blockIdx.x * 2 * Ld;
+    for (int i = threadIdx.x; i < 2 * Ld; i += blockDim.x) {
+        float acc = 0.f;
+        for (int wv = 0; wv < nw; ++wv) acc += smem[2 * Ld + wv * wstride + (L + 1) * d + i];
+        pout[i] = acc;
+    }
+}
+
+__global__ void reduce_partials_k(const float* __restrict__ partial, int nblk, int n, float* __restrict__ gw,
+                                  float* __restrict__ gb, int Ld) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int b = 0; b < nblk; ++b) acc += partial[(int64_t)b * n + i];   // fixed order: reproducible
+        if (i < Ld) gw[i] = acc; else gb[i - Ld] = acc;
+    }
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int dir_fm_second_order_backward_f32(const float* emb, int64_t emb_ld, const float* g, const float* add_in,
+                                                int64_t add_ld, int64_t B, int F, int K, float* demb, int64_t demb_ld,
+                                                dir_stream_t stream) {
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && emb_ld >= (int64_t)F * K && demb_ld >= (int64_t)F * K, "dir_fm_second_order_backward_f32: bad shape");
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(emb && g && demb, "dir_fm_second_order_backward_f32: null pointer");
+    DIR_CHECK_ARG(!add_in || add_ld >= (int64_t)F * K, "dir_fm_second_order_backward_f32: add_ld");
+    const bool vec = (K % 4 == 0) && (emb_ld % 4 == 0) && (demb_ld % 4 == 0) && aligned16(emb) && aligned16(demb) &&
+                     (!add_in || ((add_ld % 4 == 0) && aligned16(add_in)));
+    int lps = 1;
+    while (lps < (vec ? K / 4 : K)) lps <<= 1;
+    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "dir_fm_second_order_backward_f32: K=%d too wide", K);
+    const int spw = 64 / lps;
+    const int64_t waves = (B + spw - 1) / spw;
+    dim3 grid(grid_for((waves + 3) / 4));
+    hipStream_t st = as_stream(stream);
+#define DIR_CASE(L, V) hipLaunchKernelGGL((fm_bwd_k<L, V>), grid, dim3(256), 0, st, emb, emb_ld, g, add_in, add_ld, B, F, K, demb, demb_ld)
+    if (vec) {
+        switch (lps) {
+            case 1: DIR_CASE(1, 4); break;
+            case 2: DIR_CASE(2, 4); break;
+            case 4: DIR_CASE(4, 4); break;
+            case 8: DIR_CASE(8, 4); break;
+            case 16: DIR_CASE(16, 4); break;
+            case 32: DIR_CASE(32, 4); break;
+            default: DIR_CASE(64, 4); break;
+        }
+    } else {
+        switch (lps) {
+            case 1: DIR_CASE(1, 1); break;
+            case 2: DIR_CASE(2, 1); break;
+            case 4: DIR_CASE(4, 1); break;
+            case 8: DIR_CASE(8, 1); break;
+            case 16: DIR_CASE(16, 1); break;
+            case 32: DIR_CASE(32, 1); break;
+            default: DIR_CASE(64, 1); break;
+        }
+    }
+#undef DIR_CASE
+    DIR_CHECK_LAUNCH("fm_second_order_backward");
+    return DIR_OK;
+}
+
+// workspace: dir_dcn_cross_backward_workspace_bytes(L, d) device bytes (the per-workgroup partials)
+static int cross_bwd_blocks() { return kCUs * 2; }
+
+extern "C" int64_t dir_dcn_cross_backward_workspace_bytes(int L, int d) {
+    return (int64_t)cross_bwd_blocks() * 2 * L * d * (int64_t)sizeof(float);
+}
+
+extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const float* w, const float* b, int L,
+                                          const float* gout, int64_t g_ld, int64_t B, int d, float* gx0, int64_t gx_ld,
+                                          float* gw, float* gb, void* workspace, dir_stream_t stream) {
+    DIR_CHECK_ARG(L >= 0 && d > 0 && B >= 0 && x_ld >= d && g_ld >= d && gx_ld >= d, "dir_dcn_cross_backward_f32: bad shape");
+    hipStream_t st = as_stream(stream);
+    if (L > 0) {
+        DIR_CHECK_ARG(gw && gb, "dir_dcn_cross_backward_f32: null pointer");
+        if (hipMemsetAsync(gw, 0, sizeof(float) * L * d, st) != hipSuccess || hipMemsetAsync(gb, 0, sizeof(float) * L * d, st) != hipSuccess)
+            return fail(DIR_E_HIP, "dir_dcn_cross_backward_f32: memset failed");
+    }
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(x0 && gout && gx0 && ((w && b && workspace) || L == 0), "dir_dcn_cross_backward_f32: null pointer");
+    const bool vec = (d % 4 == 0) && (x_ld % 4 == 0) && (g_ld % 4 == 0) && (gx_ld % 4 == 0) && aligned16(x0) && aligned16(gout) &&
+                     aligned16(gx0) && (L == 0 || (aligned16(w) && aligned16(b)));
+    const int nchunk = vec ? d / 4 : d;
+    const int nv = (nchunk + 63) / 64;
+    if (nv > 16) return fail(DIR_E_UNSUPPORTED, "dir_dcn_cross_backward_f32: d=%d too wide", d);
+    // waves per workgroup so that the LDS image fits: 2*L*d shared + per wave (L+1)*d + 2*L*d
+    int nw = 4;
+    auto lds = [&](int waves) { return sizeof(float) * ((size_t)2 * L * d + (size_t)waves * ((size_t)(L + 1) * d + (size_t)2 * L * d + (size_t)((L + 3) & ~3))); };
+    while (nw > 1 && lds(nw) > 150 * 1024) nw >>= 1;
+    if (lds(nw) > 150 * 1024) return fail(DIR_E_UNSUPPORTED, "dir_dcn_cross_backward_f32: L=%d d=%d needs %zu B of LDS", L, d, lds(nw));
+    const size_t shmem = lds(nw);
+    const int nblk = (int)((B + nw - 1) / nw < cross_bwd_blocks() ? (B + nw - 1) / nw : cross_bwd_blocks());
+    float* partial = static_cast<float*>(workspace);
+#define DIR_GO(NV, V)                                                                                                  \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_bwd_k<NV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((cross_bwd_k<NV, V>), dim3(nblk), dim3(64 * nw), shmem, st, x0, x_ld, w, b, L, gout, g_ld, B, d, gx0, gx_ld, partial); \
+    } while (0)
+    if (vec) {
+        if (nv <= 1) DIR_GO(1, 4); else if (nv <= 2) DIR_GO(2, 4); else if (nv <= 4) DIR_GO(4, 4); else if (nv <= 8) DIR_GO(8, 4); else DIR_GO(16, 4);
+    } else {
+        if (nv <= 1) DIR_GO(1, 1); else if (nv <= 2) DIR_GO(2, 1); else if (nv <= 4) DIR_GO(4, 1); else if (nv <= 8) DIR_GO(8, 1); else DIR_GO(16, 1);
+    }
+#undef DIR_GO
+    DIR_CHECK_LAUNCH("dcn_cross_backward");
+    if (L > 0) {
+        const int n = 2 * L * d;
+        hipLaunchKernelGGL(reduce_partials_k, dim3((n + 255) / 256), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
+        DIR_CHECK_LAUNCH("dcn_cross_backward(reduce)");
+    }
+    return DIR_OK;
+}

@@ -14,6 +14,7 @@ import math
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 from .deepfm import _BatchNormInfer, _glorot_uniform_
 from .input_layer import InputLayer
@@ -63,6 +64,8 @@ class DeepCrossNetwork(nn.Module):
         nn.init.zeros_(self.logits_layer.bias)
 
     def cross_architecture(self, x0):
+        if torch.is_grad_enabled():
+            return ag.cross_network(x0, self.cross_w, self.cross_b)
         return ops.cross_network(x0, self.cross_w.data, self.cross_b.data)       # :350-367
 
     def deep_architecture(self, net):

@@ -16,6 +16,7 @@ import math
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of
 
@@ -126,21 +127,31 @@ class DeepFM(nn.Module):
     def dnn_fm_logit_fn(self, features, device):
         emb_ts, _ = self._tablesets()
         got = collect_ids(self.dnn_feature_columns, features, device)
+        train = torch.is_grad_enabled()                                          # autograd path: HIP forward + HIP/sparse backward
         if got[0] == "onehot":
-            emb, fm = ops.gather_fm(emb_ts, got[1])                              # inputs + fm_logit_fn, one pass
+            if train:
+                emb, fm = ag.gather_fm(emb_ts, got[1], list(self.embedding_weights))
+            else:
+                emb, fm = ops.gather_fm(emb_ts, got[1])                          # inputs + fm_logit_fn, one pass
         else:
             _, vals, offs, wts, _ = got
             comb = self.dnn_feature_columns[0].combiner
             if any(c.combiner != comb for c in self.dnn_feature_columns):
                 raise NotImplementedError("mixed combiners across dnn columns")
-            emb = ops.embedding_bag(emb_ts, vals, offs, wts, combiner=comb, field_major=True)
-            fm = ops.fm_logit(emb, self.F, self.K)
+            if train:
+                emb = ag.embedding_bag(emb_ts, vals, list(self.embedding_weights), offs, wts, combiner=comb, field_major=True)
+                fm = ag.fm_logit(emb, self.F, self.K)
+            else:
+                emb = ops.embedding_bag(emb_ts, vals, offs, wts, combiner=comb, field_major=True)
+                fm = ops.fm_logit(emb, self.F, self.K)
         return fm + self.dnn_logit_fn(emb)                                       # deepFM.py:337-338
 
     def linear_logit_fn(self, features, device):
         _, lin_ts = self._tablesets()
         got = collect_ids(self.linear_feature_columns, features, device)
         if got[0] == "onehot":
+            if torch.is_grad_enabled():
+                return ag.linear_logit(lin_ts, got[1], self.linear_bias, list(self.linear_weights))
             return ops.linear_logit(lin_ts, got[1], bias=self.linear_bias.data)
         _, vals, offs, wts, _ = got
         return ops.linear_logit(lin_ts, vals, offs, wts, combiner=self.linear_sparse_combiner,

@@ -12,6 +12,7 @@ import math
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of
 from .feature_column import EmbeddingColumn, IndicatorColumn, NumericColumn
@@ -63,9 +64,52 @@ class InputLayer(nn.Module):
             self._ts_key = key
         return self._groups
 
+    def _indicator(self, c, features, device, B):
+        ids = categorical_of(c).ids(features, device)
+        if B is None:
+            B = ids.numel() if not isinstance(ids, tuple) else ids[1].numel() - 1
+        ind = torch.zeros((B, c.dimension), dtype=torch.float32, device=device)
+        if isinstance(ids, tuple):
+            vals, offs, _ = ids
+            rows = torch.repeat_interleave(torch.arange(B, device=device), offs[1:] - offs[:-1])
+            ok = vals >= 0
+            ind.index_put_((rows[ok], vals[ok]), torch.ones(int(ok.sum()), device=device), accumulate=True)
+        else:
+            ok = ids >= 0
+            ind[torch.arange(B, device=device)[ok], ids[ok]] = 1.0
+        return ind
+
+    def _forward_train(self, features, device):
+        """Differentiable path: every column's block is its own tensor, concatenated in name order (autograd tracks
+        the concat; the embedding blocks carry sparse table gradients, see autograd.EmbeddingBag)."""
+        blocks = {}
+        for ts, idxs, comb in self._tablesets():
+            cols = [self.emb_cols[i] for i in idxs]
+            tabs = [self.embedding_weights[i] for i in idxs]
+            got = collect_ids(cols, features, device)
+            if got[0] == "onehot":
+                blk = ag.embedding_bag(ts, got[1], tabs)
+            else:
+                blk = ag.embedding_bag(ts, got[1], tabs, got[2], got[3], combiner=comb, field_major=True)
+            dim = cols[0].dimension
+            for k, c in enumerate(cols):
+                blocks[c.name] = blk[:, k * dim:(k + 1) * dim]
+        pieces = []
+        B = next(iter(blocks.values())).shape[0] if blocks else None
+        for c in self.columns:
+            if isinstance(c, NumericColumn):
+                pieces.append(features[c.key].to(device=device, dtype=torch.float32).reshape(-1, c.dimension))
+            elif isinstance(c, IndicatorColumn):
+                pieces.append(self._indicator(c, features, device, B))
+            else:
+                pieces.append(blocks[c.name])
+        return torch.cat(pieces, dim=1)
+
     def forward(self, features):
         device = self.embedding_weights[0].device if len(self.embedding_weights) else next(iter(
             v for v in features.values() if isinstance(v, torch.Tensor))).device
+        if torch.is_grad_enabled():
+            return self._forward_train(features, device)
         B = None
         x0 = None
 
@@ -94,18 +138,9 @@ class InputLayer(nn.Module):
                 ops.embedding_bag(ts, got[1], got[2], got[3], combiner=comb, field_major=True, out=view)
         for c in self.columns:
             if isinstance(c, IndicatorColumn):  # multi-hot counts ([TF-upstream] indicator_column)
-                ids = categorical_of(c).ids(features, device)
+                ind = self._indicator(c, features, device, B)
                 if x0 is None:
-                    B = ids.numel() if not isinstance(ids, tuple) else ids[1].numel() - 1
+                    B = ind.shape[0]
                     x0 = alloc(B)
-                ind = torch.zeros((B, c.dimension), dtype=torch.float32, device=device)
-                if isinstance(ids, tuple):
-                    vals, offs, _ = ids
-                    rows = torch.repeat_interleave(torch.arange(B, device=device), offs[1:] - offs[:-1])
-                    ok = vals >= 0
-                    ind.index_put_((rows[ok], vals[ok]), torch.ones(int(ok.sum()), device=device), accumulate=True)
-                else:
-                    ok = ids >= 0
-                    ind[torch.arange(B, device=device)[ok], ids[ok]] = 1.0
                 x0[:, self._col_offset(c):self._col_offset(c) + c.dimension] = ind
         return x0

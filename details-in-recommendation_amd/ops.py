@@ -398,3 +398,42 @@ def gather_packed(tables, payload, out=None):
     _lib.check(_lib.load().dir_gather_packed_f32(_ptr(ts.ptrs), ts.F, ts.K, _ptr(payload.contiguous()), n,
                                                  ts.gather_flags(), _ptr(out), _stream()))
     return out
+
+
+# ---- backward of the interaction ops --------------------------------------------------
+def fm_logit_backward(emb, g, F, K, add_in=None, out=None):
+    """d fm_logit / d emb: demb[b,f,:] = g[b] * (sum_f' e[b,f',:] - e[b,f,:]) (+ add_in).  g: [B] or [B,1]."""
+    _dev(emb, torch.float32, "emb")
+    g = _dev(g, torch.float32, "g").reshape(-1).contiguous()
+    B = emb.shape[0]
+    if emb.shape[1] != F * K or emb.stride(1) != 1 or g.numel() != B:
+        raise ValueError("fm_logit_backward: emb [B, F*K], g [B]")
+    if add_in is not None:
+        _dev(add_in, torch.float32, "add_in")
+        if add_in.shape != emb.shape or add_in.stride(1) != 1:
+            raise ValueError("add_in must match emb")
+    if out is None:
+        out = torch.empty((B, F * K), dtype=torch.float32, device=emb.device)
+    _lib.check(_lib.load().dir_fm_second_order_backward_f32(_ptr(emb), emb.stride(0), _ptr(g), _ptr(add_in),
+                                                            add_in.stride(0) if add_in is not None else 0, B, F, K,
+                                                            _ptr(out), out.stride(0), _stream()))
+    return out
+
+
+def cross_network_backward(x0, w, b, gout):
+    """Backward of cross_network: -> (gx0 [B,d], gw [L,d], gb [L,d])."""
+    for t, n in ((x0, "x0"), (w, "w"), (b, "b"), (gout, "gout")):
+        _dev(t, torch.float32, n)
+    B, d = x0.shape
+    L = w.shape[0]
+    w, b = w.contiguous(), b.contiguous()
+    if gout.shape != x0.shape or gout.stride(1) != 1 or x0.stride(1) != 1:
+        raise ValueError("gout must be [B, d] like x0")
+    lib = _lib.load()
+    gx0 = torch.empty((B, d), dtype=torch.float32, device=x0.device)
+    gw = torch.empty((L, d), dtype=torch.float32, device=x0.device)
+    gb = torch.empty((L, d), dtype=torch.float32, device=x0.device)
+    ws = torch.empty(max(1, int(lib.dir_dcn_cross_backward_workspace_bytes(L, d))), dtype=torch.uint8, device=x0.device)
+    _lib.check(lib.dir_dcn_cross_backward_f32(_ptr(x0), x0.stride(0), _ptr(w), _ptr(b), L, _ptr(gout), gout.stride(0), B, d,
+                                              _ptr(gx0), gx0.stride(0), _ptr(gw), _ptr(gb), _ptr(ws), _stream()))
+    return gx0, gw, gb

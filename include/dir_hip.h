@@ -211,6 +211,25 @@ int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, int F,
 int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_t* payload, int64_t n,
                           int flags /* DIR_GATHER_STREAM_ROWS */, float* out, dir_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Backward of the HBM-bound interaction ops: derivatives of the same reference
+ * expressions (the reference trains through TensorFlow autodiff of deepFM.py:321-335 and
+ * DeepCrossNetwork.py:336-367).
+ *
+ * dir_fm_second_order_backward_f32: demb[b,f,:] = g[b] * (sum_f' e[b,f',:] - e[b,f,:]) (+ add_in[b,f,:]).
+ *   add_in (optional) is the gradient arriving from the DNN branch: the total d/d(embedding) of DeepFM in one pass.
+ * dir_dcn_cross_backward_f32: given gout = dL/dx_L, returns gx0 = dL/dx0 [B,d] and gw, gb = dL/dw, dL/db [L,d]
+ *   (summed over the batch through per-workgroup partials added in a fixed order: bitwise reproducible).
+ *   workspace: dir_dcn_cross_backward_workspace_bytes(L, d) device bytes.
+ * ------------------------------------------------------------------------------------------ */
+int dir_fm_second_order_backward_f32(const float* emb, int64_t emb_ld, const float* g, const float* add_in,
+                                     int64_t add_ld, int64_t B, int F, int K, float* demb, int64_t demb_ld,
+                                     dir_stream_t stream);
+int64_t dir_dcn_cross_backward_workspace_bytes(int L, int d);
+int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const float* w, const float* b, int L,
+                               const float* gout, int64_t g_ld, int64_t B, int d, float* gx0, int64_t gx_ld,
+                               float* gw, float* gb, void* workspace, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
