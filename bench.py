@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full",
-                             "sharded_1gpu", "transform", "dcn_full"])
+                             "sharded_1gpu", "transform", "dcn_full", "train_sparse"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -181,6 +181,29 @@ def main():
         idsl = make_ids(torch, args, gen, device, V)
         step = lambda i: st.lookup(idsl[i % len(idsl)], want_fm=True)  # noqa: E731
         roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K) + 4), "kernel": "bucket + gather_packed + gather_onehot_k"}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
+    elif wl == "train_sparse":
+        # the sparse side of one DeepFM training step on the config-2 shape:
+        # gather + FM forward, FM backward (+ the DNN branch's gradient), fused sparse Adagrad on the 26 tables
+        sigma = 1.0 / (K ** 0.5)
+        tables = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
+        ts = ops.TableSet(tables)
+        opt = ops.SparseAdagrad(ts, lr=0.01)
+        idsl = make_ids(torch, args, gen, device, V)
+        out = torch.empty((B, F * K), dtype=torch.float32, device=device)
+        fm = torch.empty((B, 1), dtype=torch.float32, device=device)
+        gfm = torch.randn((B, 1), generator=gen, device=device) * 0.01
+        gdnn = torch.randn((B, F * K), generator=gen, device=device) * 0.01
+        demb = torch.empty_like(out)
+
+        def step(i):
+            ids = idsl[i % len(idsl)]
+            ops.gather_fm(ts, ids, out=out, fm=fm)
+            ops.fm_logit_backward(out, gfm, F, K, add_in=gdnn, out=demb)
+            opt.step(ids, demb)
+        # forward 3 540 B + FM backward (emb, dnn grad read, demb written) + adagrad (ids, demb, w and accum read+write)
+        roof = {"bound": "hbm", "alg_bytes": B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)),
+                "kernel": "gather_onehot_k + fm_bwd_k + adagrad_link_k + adagrad_apply_k"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
     elif wl == "transform":
         # raw Criteo-style features -> gather-ready ids on the device

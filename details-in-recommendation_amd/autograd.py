@@ -45,6 +45,11 @@ class GatherFm(torch.autograd.Function):
             demb = ops.fm_logit_backward(emb, g_fm.contiguous(), F, K, add_in=add_in)      # HIP: FM + DNN branch, one pass
         else:
             demb = add_in
+        if ts.grad_sink is not None:
+            # fused optimiser attached (ops.SparseAdagrad): the row gradients go straight to its HIP update kernel;
+            # no sparse tensors are built and the tables receive no .grad
+            ts.grad_sink(ids, demb)
+            return (None, None) + (None,) * F
         grads = []
         for f in range(F):
             grads.append(_sparse_rows(ids[:, f].contiguous(), demb[:, f * K:(f + 1) * K], ts.vocab[f]))

@@ -195,6 +195,72 @@ __global__ void reduce_partials_k(const float* __restrict__ partial, int nblk, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused sparse Adagrad on the embedding tables (the reference's dnn_optimizer='Adagrad', deepFM.py:61, applied to
+// the IndexedSlices gradients of its lookups).  [TF-upstream] semantics: gradients of duplicate ids are SUMMED
+// first (Optimizer._apply_sparse_duplicate_indices), then  accum += g*g ;  var -= lr * g / sqrt(accum).
+//
+//   link : every entry e = b*F+f with id >= 0 pushes itself on the chain of its row:
+//          next[e] = atomicExch(&head[base_f + id], e)            (one 4-byte integer atomic per entry)
+//   apply: the entry that is still the chain head is the row's leader: it walks the chain, adds the gradient rows
+//          (LPS lanes per row, 16 B per lane), updates accumulator and weights in place and resets head to -1.
+// head is a persistent int32 array over all rows of all tables (-1 = no chain); no float atomics are used, and a
+// row with <= 2 contributions is bitwise reproducible (a + b commutes); longer chains add in chain order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adagrad_link_k(const int64_t* __restrict__ ids, int64_t sb, int64_t sf, int F,
+                                                      int64_t n, const int64_t* __restrict__ head_base,
+                                                      int32_t* __restrict__ head, int32_t* __restrict__ next) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = e / F;
+        const int f = (int)(e - b * F);
+        const int64_t id = ids[b * sb + f * sf];
+        next[e] = id >= 0 ? atomicExch(&head[head_base[f] + id], (int32_t)e) : -2;
+    }
+}
+
+template <int LPS, int VEC>
+__global__ __launch_bounds__(256) void adagrad_apply_k(float* const* __restrict__ tables, float* const* __restrict__ accums,
+                                                       const int64_t* __restrict__ ids, int64_t sb, int64_t sf, int F, int K,
+                                                       int64_t n, const float* __restrict__ grad, int64_t g_ld, float lr,
+                                                       const int64_t* __restrict__ head_base, int32_t* __restrict__ head,
+                                                       const int32_t* __restrict__ next) {
+    using V = BV<VEC>;
+    using T = typename V::T;
+    const int kv = K / VEC;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = tid; q < n * LPS; q += nthr) {
+        const int64_t e = q / LPS;
+        const int c = (int)(q - e * LPS);
+        const int64_t b = e / F;
+        const int f = (int)(e - b * F);
+        const int64_t id = ids[b * sb + f * sf];
+        if (id < 0 || c >= kv) continue;
+        int32_t* hp = head + head_base[f] + id;
+        if (*hp != (int32_t)e) continue;                  // not the chain head: some other entry leads this row
+        T g = V::zero();
+        for (int32_t cur = (int32_t)e; cur >= 0; cur = next[cur]) {
+            const int64_t cb = cur / F;
+            const int cf = cur - (int)(cb * F);           // == f
+            g = V::add(g, V::ld(grad + cb * g_ld + (int64_t)cf * K + c * VEC));
+        }
+        float* ap = accums[f] + id * K + c * VEC;
+        float* wp = tables[f] + id * K + c * VEC;
+        T acc = V::ld(ap), wv = V::ld(wp);
+        if constexpr (VEC == 4) {
+            acc = make_float4(acc.x + g.x * g.x, acc.y + g.y * g.y, acc.z + g.z * g.z, acc.w + g.w * g.w);
+            wv = make_float4(wv.x - lr * g.x / sqrtf(acc.x), wv.y - lr * g.y / sqrtf(acc.y), wv.z - lr * g.z / sqrtf(acc.z),
+                             wv.w - lr * g.w / sqrtf(acc.w));
+        } else {
+            acc = acc + g * g;
+            wv = wv - lr * g / sqrtf(acc);
+        }
+        V::st(ap, acc);
+        V::st(wp, wv);
+        if (c == 0) *hp = -1;                             // unlink for the next step
+    }
+}
+
 }  // namespace dir
 
 using namespace dir;
@@ -291,5 +357,49 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
         hipLaunchKernelGGL(reduce_partials_k, dim3((n + 255) / 256), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
         DIR_CHECK_LAUNCH("dcn_cross_backward(reduce)");
     }
+    return DIR_OK;
+}
+
+extern "C" int dir_sparse_adagrad_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
+                                      int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
+                                      int64_t B, const int64_t* head_base, int32_t* head, int32_t* next,
+                                      dir_stream_t stream) {
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && grad_ld >= (int64_t)F * K, "dir_sparse_adagrad_f32: bad shape");
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(tables && accums && ids && grad && head_base && head && next, "dir_sparse_adagrad_f32: null pointer");
+    if (B * F >= (int64_t)0x7fffffff) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_f32: B*F must fit int32");
+    const int64_t n = B * F;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(adagrad_link_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, head_base,
+                       head, next);
+    const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && aligned16(grad);
+    int lps = 1;
+    while (lps < (vec ? K / 4 : K)) lps <<= 1;
+    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_f32: K=%d too wide", K);
+    dim3 grid(grid_for((n * lps + 255) / 256));
+#define DIR_CASE(L, V) hipLaunchKernelGGL((adagrad_apply_k<L, V>), grid, dim3(256), 0, st, tables, accums, ids, stride_b, stride_f, F, K, n, grad, grad_ld, lr, head_base, head, next)
+    if (vec) {
+        switch (lps) {
+            case 1: DIR_CASE(1, 4); break;
+            case 2: DIR_CASE(2, 4); break;
+            case 4: DIR_CASE(4, 4); break;
+            case 8: DIR_CASE(8, 4); break;
+            case 16: DIR_CASE(16, 4); break;
+            case 32: DIR_CASE(32, 4); break;
+            default: DIR_CASE(64, 4); break;
+        }
+    } else {
+        switch (lps) {
+            case 1: DIR_CASE(1, 1); break;
+            case 2: DIR_CASE(2, 1); break;
+            case 4: DIR_CASE(4, 1); break;
+            case 8: DIR_CASE(8, 1); break;
+            case 16: DIR_CASE(16, 1); break;
+            case 32: DIR_CASE(32, 1); break;
+            default: DIR_CASE(64, 1); break;
+        }
+    }
+#undef DIR_CASE
+    DIR_CHECK_LAUNCH("sparse_adagrad");
     return DIR_OK;
 }

@@ -169,6 +169,12 @@ class DeepFM(nn.Module):
             logits = lin if logits is None else logits + lin                     # add_n, deepFM.py:223
         return logits
 
+    def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
+        """Attach the fused HIP sparse-Adagrad update to the embedding tables (the reference trains them with
+        dnn_optimizer='Adagrad', deepFM.py:61): backward() then updates them in place, with duplicate ids summed first."""
+        emb_ts, _ = self._tablesets()
+        return ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()
+
     def forward_ids(self, dnn_ids, linear_ids=None):
         """Fast path for pre-assembled one-hot id matrices [B, F] (any strides)."""
         emb_ts, lin_ts = self._tablesets()

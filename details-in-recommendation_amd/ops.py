@@ -74,6 +74,7 @@ class TableSet:
         # know their ids are heavily skewed should set "reuse" (see include/dir_hip.h).
         self.row_policy = "auto"
         self.nbytes = sum(t.numel() * 4 for t in tables)
+        self.grad_sink = None   # callable(ids, d_rows) consuming the gather's row gradients (see SparseAdagrad.attach)
 
     def gather_flags(self):
         if self.row_policy == "stream" or (self.row_policy == "auto" and self.nbytes > 2 * INFINITY_CACHE_BYTES):
@@ -437,3 +438,41 @@ def cross_network_backward(x0, w, b, gout):
     _lib.check(lib.dir_dcn_cross_backward_f32(_ptr(x0), x0.stride(0), _ptr(w), _ptr(b), L, _ptr(gout), gout.stride(0), B, d,
                                               _ptr(gx0), gx0.stride(0), _ptr(gw), _ptr(gb), _ptr(ws), _stream()))
     return gx0, gw, gb
+
+
+class SparseAdagrad:
+    """Fused sparse Adagrad over a TableSet (include/dir_hip.h: dir_sparse_adagrad_f32).  Holds the accumulators
+    ([TF-upstream] initial_accumulator_value = 0.1) and the persistent per-row chain heads."""
+
+    def __init__(self, tables, lr, initial_accumulator_value=0.1):
+        self.ts = _as_tableset(tables)
+        self.lr = float(lr)
+        dev = self.ts.device
+        self.accums = [torch.full_like(t, initial_accumulator_value) for t in self.ts.tables]
+        self.acc_ptrs = torch.tensor([a.data_ptr() for a in self.accums], dtype=torch.int64, device=dev)
+        base = [0]
+        for v in self.ts.vocab[:-1]:
+            base.append(base[-1] + v)
+        self.head_base = torch.tensor(base, dtype=torch.int64, device=dev)
+        self.head = torch.full((sum(self.ts.vocab),), -1, dtype=torch.int32, device=dev)
+        self._next = None
+
+    def attach(self):
+        """Consume the gather's row gradients directly in backward (autograd.GatherFm): loss.backward() then
+        performs the embedding update itself; the tables get no .grad."""
+        self.ts.grad_sink = self.step
+        return self
+
+    def step(self, ids, grad):
+        """ids [B, F] int64 (any strides), grad [B, F*K] fp32: d loss / d gathered rows."""
+        ts = self.ts
+        _dev(ids, torch.int64, "ids")
+        _dev(grad, torch.float32, "grad")
+        B, sb, sf = _onehot_strides(ids, ts.F)
+        if grad.shape != (B, ts.F * ts.K) or grad.stride(1) != 1:
+            raise ValueError("grad must be [B, F*K] with unit inner stride")
+        if self._next is None or self._next.numel() < B * ts.F:
+            self._next = torch.empty(B * ts.F, dtype=torch.int32, device=ts.device)
+        _lib.check(_lib.load().dir_sparse_adagrad_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
+                                                      _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
+                                                      _ptr(self.head), _ptr(self._next), _stream()))

@@ -230,6 +230,18 @@ int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const float* w, co
                                const float* gout, int64_t g_ld, int64_t B, int d, float* gx0, int64_t gx_ld,
                                float* gw, float* gb, void* workspace, dir_stream_t stream);
 
+/* Fused sparse Adagrad on the embedding tables (the reference's dnn_optimizer='Adagrad', deepFM.py:61):
+ * for every distinct id of slot f in the batch: g = SUM of the gradient rows of its occurrences ([TF-upstream]
+ * duplicate indices are summed before the update), accum[f][id] += g*g, tables[f][id] -= lr * g / sqrt(accum).
+ * tables / accums: device arrays [F] of device pointers ([vocab_f, K] fp32, updated in place);
+ * ids / strides as in dir_embedding_bag_f32 (one-hot; ids < 0 are skipped); grad [B, F*K] (row stride grad_ld);
+ * head_base: DEVICE int64 [F], slot f's first entry in head; head: persistent DEVICE int32 [sum vocab_f], all -1
+ * before the first call (left all -1 again on return); next: DEVICE int32 [B*F] scratch. */
+int dir_sparse_adagrad_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
+                           int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
+                           int64_t B, const int64_t* head_base, int32_t* head, int32_t* next,
+                           dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

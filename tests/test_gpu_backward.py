@@ -156,3 +156,60 @@ def test_training_steps_reduce_loss(built_lib):
         opt.step(); opt_e.step()
         l0 = l0 or float(loss.detach())
     assert float(loss.detach()) < 0.8 * l0
+
+
+@pytest.mark.parametrize("B,F,K,V", [(1, 1, 4, 5), (300, 5, 16, 20), (4096, 26, 16, 1000), (777, 3, 6, 50), (500, 4, 64, 7)])
+def test_fused_sparse_adagrad(built_lib, B, F, K, V):
+    """dir_sparse_adagrad_f32 vs a float64 dedup-sum Adagrad ([TF-upstream]: duplicates summed, then
+    accum += g^2, var -= lr*g/sqrt(accum)); two consecutive steps (the chain heads must be left clean)."""
+    from dir_amd import ops
+    rng = np.random.default_rng(B + K)
+    tabs = [rng.standard_normal((V, K)).astype(np.float32) for _ in range(F)]
+    dev = [torch.from_numpy(t.copy()).cuda() for t in tabs]
+    opt = ops.SparseAdagrad(dev, lr=0.05, initial_accumulator_value=0.1)
+    ref_w = [t.astype(np.float64) for t in tabs]
+    ref_a = [np.full((V, K), 0.1) for _ in range(F)]
+    for step in range(2):
+        ids = rng.integers(-1, V, size=(B, F)).astype(np.int64)          # many duplicates, some pruned
+        grad = (rng.standard_normal((B, F * K)) * 0.5).astype(np.float32)
+        opt.step(torch.from_numpy(ids).cuda(), torch.from_numpy(grad).cuda())
+        for f in range(F):
+            gsum = np.zeros((V, K))
+            ok = ids[:, f] >= 0
+            np.add.at(gsum, ids[ok, f], grad[ok, f * K:(f + 1) * K].astype(np.float64))
+            touched = np.zeros(V, bool); touched[ids[ok, f]] = True
+            ref_a[f][touched] += gsum[touched] ** 2
+            ref_w[f][touched] -= 0.05 * gsum[touched] / np.sqrt(ref_a[f][touched])
+        assert int((opt.head != -1).sum()) == 0
+    for f in range(F):
+        _close(dev[f], ref_w[f], tol=2e-5)
+        _close(opt.accums[f], ref_a[f], tol=2e-5)
+
+
+def test_deepfm_fused_adagrad_matches_torch_adagrad(built_lib):
+    """The fused path (row gradients consumed inside backward) must equal torch.optim.Adagrad on the sparse grads."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    B, F, K, V = 256, 4, 8, 12        # tiny vocabulary: many duplicate ids per batch
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+
+    def make():
+        torch.manual_seed(5)
+        return DeepFM(linear_feature_columns=[], dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                      dnn_hidden_units=[16], fm_embedding_size=K).cuda()
+    a, b = make(), make()
+    fused = a.fused_sparse_adagrad(lr=0.1)
+    opt_b = torch.optim.Adagrad(list(b.embedding_weights), lr=0.1, initial_accumulator_value=0.1, eps=0.0)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        ids = torch.randint(0, V, (B, F), generator=g)
+        labels = torch.randint(0, 2, (B, 1), generator=g).float().cuda()
+        feats = {"C%d" % i: ids[:, i].cuda() for i in range(F)}
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+            torch.nn.functional.binary_cross_entropy_with_logits(m(feats), labels, reduction="sum").backward()
+        assert a.embedding_weights[0].grad is None          # consumed by the fused kernel
+        opt_b.step()
+    for pa, pb in zip(a.embedding_weights, b.embedding_weights):
+        _close(pa, pb, tol=2e-5)
+    assert fused.accums[0].min().item() >= 0.1
