@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full",
-                             "sharded_1gpu", "transform", "dcn_full", "train_sparse"])
+                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -205,6 +205,35 @@ def main():
         roof = {"bound": "hbm", "alg_bytes": B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)),
                 "kernel": "gather_onehot_k + fm_bwd_k + adagrad_link_k + adagrad_apply_k"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
+    elif wl == "small_batch":
+        # the reference's own batch size (256, DeepCrossNetwork/train.py:17): launch-bound; eager vs HIP-graph replay
+        from dir_amd.deepfm import DeepFM
+        from dir_amd import feature_column as fc
+        from dir_amd.serving import GraphedForward
+        Bs = 256
+        cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+        model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                       dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
+        ids = torch.randint(0, V, (Bs, F), generator=gen, device=device)
+        fwd = lambda x: model.forward_ids(x, x)  # noqa: E731
+        graphed = GraphedForward(fwd, ids)
+        with torch.no_grad():
+            ref = fwd(ids)
+        assert torch.equal(graphed(ids), ref)
+        # eager timing first (reported in config), then the graph replay is the timed step
+        with torch.no_grad():
+            for _ in range(20):
+                fwd(ids)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                fwd(ids)
+            torch.cuda.synchronize()
+            eager_us = (time.perf_counter() - t0) / 200 * 1e6
+        step = lambda i: graphed(ids)  # noqa: E731
+        units = Bs
+        roof = {"bound": "hbm", "alg_bytes": Bs * (F * (8 + 2 * 4 * K) + 4), "kernel": "DeepFM forward, batch 256, hipGraph replay"}
+        cfg.update({"batch": Bs, "fields": F, "eager_us_per_forward": eager_us})
     elif wl == "transform":
         # raw Criteo-style features -> gather-ready ids on the device
         # (26 integer categorical keys hashed per field, 13 dense values bucketised into 10 buckets)

@@ -302,3 +302,27 @@ def test_gather_rows_and_sharded_lookup_single_gpu(built_lib, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_graphed_forward_matches_eager(built_lib):
+    """HIP-graph capture of a DeepFM forward (serving.GraphedForward): replays equal the eager result bit for bit,
+    also for new inputs copied into the static buffers."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    from dir_amd.serving import GraphedForward
+    torch.manual_seed(1)
+    B, F, K, V = 256, 26, 16, 1000
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[64, 32], fm_embedding_size=K).cuda()
+    with torch.no_grad():
+        for w in model.linear_weights:
+            w.normal_(0, 0.1)
+    ids = torch.randint(0, V, (B, F), device="cuda")
+    fwd = lambda x: model.forward_ids(x, x)
+    g = GraphedForward(fwd, ids)
+    for _ in range(3):
+        ids = torch.randint(0, V, (B, F), device="cuda")
+        with torch.no_grad():
+            ref = fwd(ids)
+        assert torch.equal(g(ids), ref)
