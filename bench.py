@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full",
-                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch"])
+                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -182,6 +182,21 @@ def main():
         step = lambda i: st.lookup(idsl[i % len(idsl)], want_fm=True)  # noqa: E731
         roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K) + 4), "kernel": "bucket + gather_packed + gather_onehot_k"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
+    elif wl == "deepfm_sparse_packed":
+        # DeepFM's three sparse terms (concat, FM, linear) from packed 128-byte rows in ONE pass, vs gather_fm + linear
+        sigma = 1.0 / (K ** 0.5)
+        tables = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
+        lws = [torch.randn((V,), generator=gen, device=device) * 0.01 for _ in range(F)]
+        pt = ops.PackedTables(tables, lws)
+        del tables
+        bias = torch.zeros(1, device=device)
+        idsl = make_ids(torch, args, gen, device, V)
+        out = torch.empty((B, F * K), dtype=torch.float32, device=device)
+        fm = torch.empty((B, 1), dtype=torch.float32, device=device)
+        lin = torch.empty((B, 1), dtype=torch.float32, device=device)
+        step = lambda i: ops.gather_fm_linear(pt, idsl[i % len(idsl)], bias=bias, out=out, fm=fm, lin=lin)  # noqa: E731
+        roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K + 4) + 8), "kernel": "gather_packed_rows_k (concat + FM + linear)"}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "row_bytes": pt.ld * 4})
     elif wl == "train_sparse":
         # the sparse side of one DeepFM training step on the config-2 shape:
         # gather + FM forward, FM backward (+ the DNN branch's gradient), fused sparse Adagrad on the 26 tables

@@ -131,6 +131,75 @@ __global__ __launch_bounds__(256) void gather_onehot_k(const float* const* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// Packed rows (serving layout): slot f's table is [vocab_f, ld] with the K embedding floats at columns [0, K) and the
+// first-order (linear_model) weight at column lin_col.  With ld*4 = 128 B and 128-byte aligned tables one row is one
+// memory line: the gather moves the same DRAM bytes as the 64-byte-row layout (a 64-byte request costs a 128-byte
+// slot) and the linear term of DeepFM (deepFM.py:255-275) rides along for free.
+// Same lane mapping and the same ordered sums as gather_onehot_k: emb / fm / lin are bit-identical to the separate
+// gather_fm + linear_sparse_sum path.
+// ------------------------------------------------------------------------------------------------
+template <int LPS, int UF, bool NT>
+__global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* __restrict__ tables,
+                                                            const int64_t* __restrict__ ids, int64_t sb, int64_t sf,
+                                                            int F, int K, int64_t ld, int lin_col, int64_t B,
+                                                            float* __restrict__ out, int64_t out_ld,
+                                                            float* __restrict__ fm, const float* __restrict__ bias,
+                                                            float* __restrict__ lin_out) {
+    constexpr int SPW = 64 / LPS;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & (LPS - 1);
+    const int s = lane / LPS;
+    const int kv = K >> 2;
+    const bool cact = c < kv;
+    const bool want_lin = lin_out != nullptr && lin_col >= 0;
+    const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
+        const int64_t b = g * SPW + s;
+        const bool act = cact && (b < B);
+        const int64_t* idp = ids + (act ? b * sb : 0);
+        float* op = out ? out + (act ? b * out_ld : 0) + c * 4 : nullptr;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
+        float lin = 0.f;
+        for (int f0 = 0; f0 < F; f0 += UF) {
+            int64_t id[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int f = f0 + u;
+                id[u] = (act && f < F) ? idp[(int64_t)f * sf] : (int64_t)-1;
+            }
+            float4 row[UF];
+            float lw[UF];
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int f = f0 + u;
+                row[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                lw[u] = 0.f;
+                if (f < F && id[u] >= 0) {
+                    const float* t = tables[f] + id[u] * ld;
+                    row[u] = NT ? ldv_nt(t + c * 4, (float4*)nullptr) : ldv(t + c * 4, (float4*)nullptr);
+                    if (want_lin && c == 0) lw[u] = NT ? ldv_nt(t + lin_col, (float*)nullptr) : t[lin_col];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UF; ++u) {
+                const int f = f0 + u;
+                if (f < F) {
+                    if (op && act) stv(op + (int64_t)f * K, row[u]);
+                    sum = vadd(sum, row[u]);
+                    sq = vadd(sq, vmul(row[u], row[u]));
+                    lin = lin + lw[u];                    // slot order, as linear_onehot_k / the oracle
+                }
+            }
+        }
+        if (fm) {
+            const float r = fm_tail<LPS>(sum, sq, lane, c);
+            if (c == LPS - 1 && b < B) fm[b] = r;
+        }
+        if (want_lin && c == 0 && b < B) lin_out[b] = lin + (bias ? bias[0] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // multi-hot (CSR) bags: entries reduced in order, then combiner
 // ------------------------------------------------------------------------------------------------
 template <int LPS, int VEC>
@@ -451,5 +520,42 @@ extern "C" int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, co
     dim3 grid(grid_for((B * F + 255) / 256));
     hipLaunchKernelGGL(check_ids_k, grid, dim3(256), 0, st, vocab, F, ids, offsets, stride_b, stride_f, B, bad_count);
     DIR_CHECK_LAUNCH("check_ids");
+    return DIR_OK;
+}
+
+extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, int F, int K, int64_t ld, int lin_col,
+                                               const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
+                                               int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
+                                               float* lin_out, dir_stream_t stream) {
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && ld >= K && lin_col < ld, "dir_gather_fm_linear_packed_f32: F=%d K=%d ld=%lld lin_col=%d", F, K, (long long)ld, lin_col);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(tables && ids && (out || fm || lin_out), "dir_gather_fm_linear_packed_f32: null pointer");
+    DIR_CHECK_ARG(!out || out_ld >= (int64_t)F * K, "dir_gather_fm_linear_packed_f32: out_ld");
+    if ((K & 3) || (ld & 3) || (out && ((out_ld & 3) || !aligned16(out))))
+        return fail(DIR_E_UNSUPPORTED, "dir_gather_fm_linear_packed_f32: K, ld, out_ld must be multiples of 4 and out 16-byte aligned");
+    const int lps = next_pow2(K / 4);
+    if (lps > 16) return fail(DIR_E_UNSUPPORTED, "dir_gather_fm_linear_packed_f32: K=%d (supported: up to 64)", K);
+    const int spw = 64 / lps;
+    const int64_t waves = (B + spw - 1) / spw;
+    const int64_t work = (waves + 3) / 4;
+    const bool nt = (flags & DIR_GATHER_STREAM_ROWS) != 0;
+    hipStream_t st = as_stream(stream);
+#define DIR_GO(L, NTV)                                                                                          \
+    do {                                                                                                        \
+        dim3 grid(grid_resident(work, resident_blocks(gather_packed_rows_k<L, 13, NTV>)));                     \
+        hipLaunchKernelGGL((gather_packed_rows_k<L, 13, NTV>), grid, dim3(256), 0, st, tables, ids, stride_b, stride_f, F, K, ld, \
+                           lin_col, B, out, out_ld, fm, bias, lin_out);                                        \
+    } while (0)
+#define DIR_L(L) do { if (nt) DIR_GO(L, true); else DIR_GO(L, false); } while (0)
+    switch (lps) {
+        case 1: DIR_L(1); break;
+        case 2: DIR_L(2); break;
+        case 4: DIR_L(4); break;
+        case 8: DIR_L(8); break;
+        default: DIR_L(16); break;
+    }
+#undef DIR_L
+#undef DIR_GO
+    DIR_CHECK_LAUNCH("gather_fm_linear_packed");
     return DIR_OK;
 }

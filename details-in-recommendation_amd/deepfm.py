@@ -175,8 +175,28 @@ class DeepFM(nn.Module):
         emb_ts, _ = self._tablesets()
         return ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()
 
+    def pack_for_serving(self):
+        """Inference-only: copy the embedding tables and the first-order weights of the same categorical columns into
+        the packed 128-byte-row layout (ops.PackedTables), so that forward_ids() reads one memory line per
+        (sample, field) for all three sparse terms.  Needs linear_feature_columns to start with the dnn columns'
+        categorical columns in the same order (the DeepFM case: deepFM.py:89-95).  Re-pack after changing weights."""
+        n = self.F
+        lin_names = [categorical_of(c).name for c in self.linear_feature_columns[:n]]
+        if len(lin_names) < n or lin_names != [categorical_of(c).name for c in self.dnn_feature_columns]:
+            raise ValueError("pack_for_serving: the first %d linear columns must be the dnn columns' categorical columns" % n)
+        self._packed = ops.PackedTables([p.data for p in self.embedding_weights], [p.data for p in self.linear_weights[:n]])
+        self._packed_extra = ops.TableSet([p.data for p in self.linear_weights[n:]]) if len(self.linear_weights) > n else None
+        return self._packed
+
     def forward_ids(self, dnn_ids, linear_ids=None):
-        """Fast path for pre-assembled one-hot id matrices [B, F] (any strides)."""
+        """Fast path for pre-assembled one-hot id matrices [B, F] (any strides).  linear_ids: the ids of ALL linear
+        columns [B, F_lin] (its first F columns equal dnn_ids in the DeepFM case)."""
+        if getattr(self, "_packed", None) is not None and linear_ids is not None:
+            emb, fm, lin = ops.gather_fm_linear(self._packed, dnn_ids, bias=self.linear_bias.data)
+            logits = fm + self.dnn_logit_fn(emb) + lin
+            if self._packed_extra is not None:
+                logits = logits + ops.linear_logit(self._packed_extra, linear_ids[:, self.F:])
+            return logits
         emb_ts, lin_ts = self._tablesets()
         emb, fm = ops.gather_fm(emb_ts, dnn_ids)
         logits = fm + self.dnn_logit_fn(emb)

@@ -476,3 +476,56 @@ class SparseAdagrad:
         _lib.check(_lib.load().dir_sparse_adagrad_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
                                                       _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
                                                       _ptr(self.head), _ptr(self._next), _stream()))
+
+
+class PackedTables:
+    """Serving layout: one [vocab_f, ld] buffer per slot, embedding at columns [0, K), first-order weight at column K
+    (include/dir_hip.h: dir_gather_fm_linear_packed_f32).  ld = 32 floats = one 128-byte line for K <= 31.  Built from
+    the reference-layout parameters (embedding tables [V,K] and linear weight columns [V])."""
+
+    def __init__(self, emb_tables, lin_weights=None):
+        emb_tables = list(emb_tables)
+        K = emb_tables[0].shape[1]
+        ld = 32
+        while ld < K + 1:
+            ld *= 2
+        self.F, self.K, self.ld = len(emb_tables), K, ld
+        self.lin_col = K if lin_weights is not None else -1
+        self.device = emb_tables[0].device
+        self.vocab = [int(t.shape[0]) for t in emb_tables]
+        # one arena, every slot's rows 128-byte aligned
+        total = sum(self.vocab) * ld
+        arena = torch.zeros(total + 32, dtype=torch.float32, device=self.device)
+        off = (-(arena.data_ptr() // 4)) % 32
+        self.arena = arena
+        self.rows = []
+        for f, t in enumerate(emb_tables):
+            v = self.vocab[f]
+            blk = arena[off:off + v * ld].view(v, ld)
+            blk[:, :K] = t
+            if lin_weights is not None:
+                blk[:, K] = lin_weights[f].reshape(-1)
+            self.rows.append(blk)
+            off += v * ld
+        self.ptrs = torch.tensor([r.data_ptr() for r in self.rows], dtype=torch.int64, device=self.device)
+        self.nbytes = total * 4
+
+    def flags(self):
+        return STREAM_ROWS if self.nbytes > 2 * INFINITY_CACHE_BYTES else 0
+
+
+def gather_fm_linear(pt, ids, bias=None, want_emb=True, out=None, fm=None, lin=None):
+    """DeepFM's three sparse terms in one pass over packed rows: -> (emb [B,F*K] | None, fm [B,1], lin [B,1] | None)."""
+    _dev(ids, torch.int64, "ids")
+    B, sb, sf = _onehot_strides(ids, pt.F)
+    if want_emb and out is None:
+        out = torch.empty((B, pt.F * pt.K), dtype=torch.float32, device=pt.device)
+    if fm is None:
+        fm = torch.empty((B, 1), dtype=torch.float32, device=pt.device)
+    if lin is None and pt.lin_col >= 0:
+        lin = torch.empty((B, 1), dtype=torch.float32, device=pt.device)
+    _lib.check(_lib.load().dir_gather_fm_linear_packed_f32(_ptr(pt.ptrs), pt.F, pt.K, pt.ld, pt.lin_col, _ptr(ids), sb, sf,
+                                                           pt.flags(), B, _ptr(out) if want_emb else None,
+                                                           out.stride(0) if want_emb else 0, _ptr(fm), _ptr(bias),
+                                                           _ptr(lin), _stream()))
+    return (out if want_emb else None), fm, lin

@@ -98,6 +98,17 @@ int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int6
                             int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out,
                             int64_t out_ld, float* fm, dir_stream_t stream);
 
+/* Packed serving layout (an MI355X-specific option; the reference layout above stays the default): slot f's table is
+ * [vocab_f, ld] fp32 with the embedding at columns [0, K) and the first-order weight of the same feature value at
+ * column lin_col (-1: none).  With ld*4 = 128 B and 128-byte aligned tables a row is exactly one memory line, so
+ * DeepFM's three sparse terms -- inputs (deepFM.py:169-177), fm_logit_fn (:321-335) and the linear term (:255-275)
+ * over the same columns -- cost one line fetch per (sample, slot).  out / fm / lin_out may each be NULL;
+ * lin_out[b] = sum_f w_f[id] (+ *bias), summed in slot order: bit-identical to dir_linear_sparse_sum_f32. */
+int dir_gather_fm_linear_packed_f32(const float* const* tables, int F, int K, int64_t ld, int lin_col,
+                                    const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
+                                    int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
+                                    float* lin_out, dir_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * A6  first-order (linear) term, units = 1.
  * Replaces: _linear_logit_fn_builder                    models/DeepFM/deepFM.py:255-275

@@ -326,3 +326,26 @@ def test_graphed_forward_matches_eager(built_lib):
         with torch.no_grad():
             ref = fwd(ids)
         assert torch.equal(g(ids), ref)
+
+
+def test_deepfm_packed_serving_equals_reference_layout(built_lib):
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    torch.manual_seed(2)
+    B, F, K, V = 700, 26, 16, 500
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    nums = [fc.bucketized_column(fc.numeric_column("I%d" % i), [0.25, 0.5, 0.75]) for i in range(3)]
+    model = DeepFM(linear_feature_columns=cats + nums, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[64, 32], fm_embedding_size=K).cuda()
+    with torch.no_grad():
+        for w in model.linear_weights:
+            w.normal_(0, 0.1)
+        model.linear_bias.fill_(-0.3)
+    ids = torch.randint(-1, V, (B, F), device="cuda")
+    lin_ids = torch.cat([ids, torch.randint(0, 4, (B, 3), device="cuda")], dim=1)
+    with torch.no_grad():
+        ref = model.forward_ids(ids, lin_ids)
+        model.pack_for_serving()
+        got = model.forward_ids(ids, lin_ids)
+    # same kernels' arithmetic for emb / fm / first-order sums; only the final additions associate differently
+    assert float((got - ref).abs().max()) <= 1e-5

@@ -301,3 +301,23 @@ def test_full_size_properties(ops, oracle):
     ref = oracle.embedding_bag(sub, ids_s)
     np.testing.assert_array_equal(emb[sel].cpu().numpy(), ref)
     np.testing.assert_array_equal(fm[sel].cpu().numpy()[:, 0], oracle.fm_second_order(ref, F, K))
+
+
+@pytest.mark.parametrize("B,F,K,V", [(1, 1, 16, 7), (513, 26, 16, 1000), (300, 5, 8, 64), (129, 3, 64, 50), (77, 4, 32, 33), (64, 2, 4, 9)])
+def test_packed_rows_gather_fm_linear(ops, oracle, B, F, K, V):
+    """Packed serving layout: emb / fm / lin bit-identical to the reference-layout path and to the oracle."""
+    rng = np.random.default_rng(B + 3 * K)
+    tables = _tables(rng, F, V, K)
+    lws = [(rng.standard_normal(V) * 0.1).astype(np.float32) for _ in range(F)]
+    ids = rng.integers(-1, V, size=(B, F)).astype(np.int64)
+    bias = np.array([0.25], np.float32)
+    pt = ops.PackedTables([_dev(t) for t in tables], [_dev(w) for w in lws])
+    assert all(r.data_ptr() % 128 == 0 for r in pt.rows) and pt.ld * 4 % 128 == 0
+    emb, fm, lin = ops.gather_fm_linear(pt, _dev(ids), bias=_dev(bias))
+    ref = oracle.embedding_bag(tables, ids)
+    np.testing.assert_array_equal(emb.cpu().numpy(), ref)
+    np.testing.assert_array_equal(fm.cpu().numpy()[:, 0], oracle.fm_second_order(ref, F, K))
+    np.testing.assert_array_equal(lin.cpu().numpy()[:, 0], oracle.linear_sparse_sum(lws, ids, bias=bias))
+    # field-major ids, no concat output
+    _, fm2, lin2 = ops.gather_fm_linear(pt, _dev(ids.T.copy()).t(), bias=_dev(bias), want_emb=False)
+    assert torch.equal(fm2, fm) and torch.equal(lin2, lin)
