@@ -16,8 +16,9 @@
 //
 // LDS (one array, 16-byte aligned carve):
 //   x0s [mp][256]            the workgroup's x0 slice, transposed so that lanes read consecutive rows
-//   Ws  [2][IC*mp][HP]       W chunk of IC values of i, transposed to [kk][h] (HP = 129: conflict-free
-//                            for both the transposing store and the per-column read)
+//   Ws  [2][IC*mp][32][4]    W chunk of IC values of i, transposed to [kk][n][cc] with h = 32*cc + n: the four
+//                            column-tile operands of a lane are ONE ds_read_b128 (LDS reads and VALU work are
+//                            not hidden behind fp32 MFMAs -- tools/mfma_probe2.hip -- so their count matters)
 //   xks [2][IC][256]         xk chunk
 // Chunk c+1 is fetched from global into registers before chunk c's MFMAs and written to the other LDS
 // buffer after them: one barrier per chunk of IC*mp/2*RT*CT = 416 MFMAs.
@@ -27,13 +28,24 @@ namespace dir {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Diagnostic build only (DIR_CIN_STAMP=1): per-chunk cycle shares, never used by the product path.
+// [0] cycles from chunk start to the end of its MFMA stream, [1] cycles from there to past the barrier,
+// [2] chunks counted, [3] cycles of the prologue (x0 staging + first chunk), [4] epilogue cycles, [5] workgroups
+__device__ unsigned long long cin_stamp_acc[8];
+__device__ __forceinline__ unsigned long long cin_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 constexpr int CIN_RT = 2;          // row tiles per wave
 constexpr int CIN_ROWS = 256;      // rows per workgroup = 4 waves * RT * 32
-constexpr int CIN_HP = 129;        // padded H stride of the LDS W image
+constexpr int CIN_WS = 128;        // floats per kk row of the LDS W image: [32 n][4 cc]
+constexpr int CIN_KS = 2;          // k-steps per MFMA burst (one VALU/LDS cluster per burst)
 constexpr int cin_ic(int MT) { return MT > 26 ? 2 : 4; }   // i values per chunk (LDS: 2*IC*mp*129*4 B of W)
 
 template <int MT /* field count padded to an instantiated size: register arrays, unrolling */, int CT /* column tiles */,
-          bool FP /* interleaved fast staging; needs m == MT */>
+          bool FP /* interleaved fast staging; needs m == MT */, bool STAMP = false /* diagnostic cycle stamps */>
 __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                 const float* __restrict__ W, int m /* actual fields, <= MT */, int Hp, int H,
                                                 int D, int dshift,
@@ -44,8 +56,8 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     constexpr int mp = (MT + 1) & ~1;
     constexpr int MP2 = mp / 2;
     constexpr int IC = cin_ic(MT);
-    constexpr int HP = CIN_HP;
-    constexpr int WCH = IC * mp * HP;     // floats per W buffer
+    constexpr int WS = CIN_WS;
+    constexpr int WCH = IC * mp * WS;     // floats per W buffer
     constexpr int XCH = IC * CIN_ROWS;    // floats per xk buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* x0s = smem;                       // [mp][256]
@@ -57,21 +69,23 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     const int wave = tid >> 6;
     const int n = lane & 31;
     const int hh = lane >> 5;
+    unsigned long long st_a = 0, st_b = 0, st_pro = 0, st_t0 = 0, st_cnt = 0;
+    if (STAMP) st_t0 = cin_now();
     const int64_t row0 = (int64_t)blockIdx.x * CIN_ROWS;   // first (b,d) row of this workgroup
     const int hbase = blockIdx.y * (32 * CT);              // first output column of this workgroup
     const int Kd = Hp * m;
 
-    // ---- stage x0 slice: x0s[j][r] = x0[b, j, d] with (b,d) = row0 + r ------------------------------
-    for (int e = tid; e < mp * CIN_ROWS; e += 256) {
-        const int j = e / CIN_ROWS, r = e - j * CIN_ROWS;
-        const int64_t gr = row0 + r;
-        float v = 0.f;
-        if (j < m && gr < R) {
-            const int64_t b = gr >> dshift;
-            const int d = (int)(gr & (D - 1));
-            v = x0[(b * m + j) * D + d];
-        }
-        x0s[e] = v;
+    // ---- stage x0 slice: x0s[j][r] = x0[b, j, d] with (b,d) = row0 + r; thread tid owns row r = tid.  All loads
+    // are issued before the first store (and before chunk 0's loads below) so that the prologue pays one memory
+    // round trip, not one per field.
+    float x0v[mp];
+    {
+        const int64_t gr = row0 + tid;
+        const bool ok = gr < R;
+        const int64_t grc = ok ? gr : R - 1;
+        const float* src = x0 + ((grc >> dshift) * m) * D + (grc & (D - 1));
+#pragma unroll
+        for (int j = 0; j < mp; ++j) x0v[j] = (j < m && ok) ? src[(int64_t)j * D] : 0.f;
     }
 
     // per-thread staging registers for the next chunk
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
             const int kkl = e - hl * (IC * m);
             const int il = kkl / m;
             const int j = kkl - il * m;
-            if (hl < 32 * CT) wb[(il * mp + j) * HP + hl] = wreg[q];
+            if (hl < 32 * CT) wb[(il * mp + j) * WS + (hl & 31) * 4 + (hl >> 5)] = wreg[q];
         }
         if (part < 0 || part == IC - 1) {
             float* xb = xks + buf * XCH;
@@ -141,10 +155,11 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     static_assert(!FAST || RL <= WE, "staging registers are shared with the generic path");
     const int srow = tid / TPR, spart = tid - srow * TPR;
     const bool srow_ok = hbase + srow < H;
-    // loads are unconditional from clamped (always valid) addresses; validity is a select at store time
+    // loads are unconditional from clamped (always valid) addresses.  No select is needed: a W row h >= H only
+    // feeds output column h and an xk row >= R only feeds output row r, neither of which is ever stored.
     const float* wsrc = W + (int64_t)(srow_ok ? hbase + srow : 0) * Kd + spart * RL;
     const int sil0 = (spart * RL) / MT, sj0 = spart * RL - sil0 * MT;
-    const int wdst0 = (sil0 * mp + sj0) * HP + srow;
+    const int wdst0 = (sil0 * mp + sj0) * WS + (srow & 31) * 4 + (srow >> 5);
     constexpr bool fast_ok = FAST;
     auto fast_i0 = [&](int c) {   // first i of chunk c, clamped so that the loads stay inside W (a clamped
         const int i0 = c * IC;    // chunk is re-staged by the generic path afterwards)
@@ -161,36 +176,49 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     };
     const int64_t xrow = (row0 + tid < R) ? row0 + tid : R - 1;          // XE == IC: element q is (il = q, r = tid)
     const float* xsrc = xk + ((xrow >> dshift) * Hp) * D + (xrow & (D - 1));
-    const bool xrow_ok = row0 + tid < R;
     auto fast_load_xk = [&](int i0) {
 #pragma unroll
         for (int q = 0; q < XE; ++q) xreg[q] = xsrc[(int64_t)(i0 + q) * D];
     };
     auto fast_store = [&](int idx, int buf) {   // idx < RL: W element; RL <= idx < RL + XE: xk element
         if (idx < RL) {
-            const int off = (RL % MT == 0) ? ((idx / MT) * mp + (idx % MT)) * HP : idx * HP;
-            Ws[buf * WCH + wdst0 + off] = srow_ok ? wreg[idx] : 0.f;
+            const int off = (RL % MT == 0) ? ((idx / MT) * mp + (idx % MT)) * WS : idx * WS;
+            Ws[buf * WCH + wdst0 + off] = wreg[idx];
         } else if (idx < RL + XE) {
-            xks[buf * XCH + tid + 256 * (idx - RL)] = xrow_ok ? xreg[idx - RL] : 0.f;
+            xks[buf * XCH + tid + 256 * (idx - RL)] = xreg[idx - RL];
         }
     };
 
     // zero the pad rows j in [m, mp) of both W buffers once (m < MT, or odd MT); the staging never writes them
     if (mp != m) {
         const int npad = mp - m;
-        for (int e = tid; e < 2 * IC * npad * HP; e += 256) {
-            const int buf = e / (IC * npad * HP);
-            int rem = e - buf * (IC * npad * HP);
-            const int il = rem / (npad * HP);
-            rem -= il * (npad * HP);
-            const int jp_ = rem / HP, hl = rem - jp_ * HP;
-            Ws[buf * WCH + (il * mp + m + jp_) * HP + hl] = 0.f;
+        for (int e = tid; e < 2 * IC * npad * WS; e += 256) {
+            const int buf = e / (IC * npad * WS);
+            int rem = e - buf * (IC * npad * WS);
+            const int il = rem / (npad * WS);
+            rem -= il * (npad * WS);
+            const int jp_ = rem / WS, hl = rem - jp_ * WS;
+            Ws[buf * WCH + (il * mp + m + jp_) * WS + hl] = 0.f;
         }
     }
 
     const int nchunk = (Hp + IC - 1) / IC;
-    fetch_chunk(0);
-    store_chunk(0, -1);
+    auto store_x0 = [&]() {
+#pragma unroll
+        for (int j = 0; j < mp; ++j) x0s[j * CIN_ROWS + tid] = x0v[j];
+    };
+    if (FAST) {   // chunk 0 through the same contiguous-run staging (the host guarantees Hp >= IC on this path)
+#pragma unroll
+        for (int slot = 0; slot < NLD; ++slot) fast_load(slot, 0);
+        fast_load_xk(0);
+        store_x0();
+#pragma unroll
+        for (int idx = 0; idx < RL + XE; ++idx) fast_store(idx, 0);
+    } else {
+        fetch_chunk(0);
+        store_x0();
+        store_chunk(0, -1);
+    }
     __syncthreads();
 
     // this lane's x0 operands: x0r[t][jp] = x0s[2*jp + hh][wave*64 + t*32 + n]
@@ -208,47 +236,70 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][c][q] = 0.f;
 
+    if (STAMP) st_pro = cin_now() - st_t0;
     for (int c = 0; c < nchunk; ++c) {
+        unsigned long long st_c0 = 0;
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            st_c0 = cin_now();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const int buf = c & 1;
         const bool more = c + 1 < nchunk;
         // the next chunk is staged by the interleaved fast path when it is a whole chunk; a partial (last) or
         // irregular one by the generic bulk path after this chunk's MFMAs
         const bool next_bulk = more && (!fast_ok || (c + 2) * IC > Hp);
         const int i0n = fast_ok ? fast_i0(more ? c + 1 : c) : 0;
-        const float* wb = Ws + buf * WCH + hh * HP + n;
+        const float* wb = Ws + buf * WCH + hh * WS + n * 4;
         const float* xb = xks + buf * XCH + wave * 64 + n;
-        // operands of step (il, jp) are read one whole step ahead of their MFMAs (LDS latency ~100 cycles vs
-        // 512 cycles of MFMA issue per step); sched_barrier pins "reads for the next step, then this step's
-        // MFMAs" so that the compiler does not sink the reads back to their first use
-        float bw[CT], xkv[CIN_RT];
+        // One burst = KS k-steps = KS*RT*CT MFMAs issued back to back.  Everything else of those steps -- the LDS
+        // operand reads for the NEXT burst (latency ~100 cycles vs >= 1000 cycles of MFMA issue), a few staging
+        // instructions of the next chunk and the KS*RT products forming this burst's A operands -- sits in ONE
+        // cluster in front of the burst: a VALU/LDS instruction between two fp32 MFMAs costs ~20 cycles for the
+        // first of a cluster and ~5 for each further one, while scalar instructions and s_nop are free.
+        constexpr int NS = IC * MP2, KS = (NS % CIN_KS == 0) ? CIN_KS : 1, NG = NS / KS;
+        float bw[KS][CT], xkv[KS][CIN_RT];
+        auto read_ops = [&](int g, float (&bo)[KS][CT], float (&xo)[KS][CIN_RT], const float (&xprev)[CIN_RT]) {
 #pragma unroll
-        for (int cc = 0; cc < CT; ++cc) bw[cc] = wb[32 * cc];
+            for (int ks = 0; ks < KS; ++ks) {
+                const int s_ = g * KS + ks, il = s_ / MP2, jp = s_ - il * MP2;
+                const float* src = wb + (il * mp + 2 * jp) * WS;
+                if (CT == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    bo[ks][0] = v.x; bo[ks][1 % CT] = v.y; bo[ks][2 % CT] = v.z; bo[ks][3 % CT] = v.w;
+                } else {
 #pragma unroll
-        for (int t = 0; t < CIN_RT; ++t) xkv[t] = xb[t * 32];
-#pragma unroll
-        for (int il = 0; il < IC; ++il) {
-#pragma unroll
-            for (int jp = 0; jp < MP2; ++jp) {
-                constexpr int LAST = IC * MP2 - 1;
-                const int step = il * MP2 + jp;
-                const int nil = (jp + 1 < MP2) ? il : il + 1;
-                const int njp = (jp + 1 < MP2) ? jp + 1 : 0;
-                float bwn[CT], xkn[CIN_RT];
-#pragma unroll
-                for (int cc = 0; cc < CT; ++cc) bwn[cc] = bw[cc];
-#pragma unroll
-                for (int t = 0; t < CIN_RT; ++t) xkn[t] = xkv[t];
-                if (step < LAST) {
-#pragma unroll
-                    for (int cc = 0; cc < CT; ++cc) bwn[cc] = wb[(nil * mp + 2 * njp) * HP + 32 * cc];
-                    if (njp == 0) {
-#pragma unroll
-                        for (int t = 0; t < CIN_RT; ++t) xkn[t] = xb[nil * CIN_ROWS + t * 32];
-                    }
+                    for (int cc = 0; cc < CT; ++cc) bo[ks][cc] = src[cc];
                 }
-                if (FAST && fast_ok) {   // a few staging instructions per k-step, in the shadow of the previous MFMA
-                    constexpr int NS = IC * MP2, SS = NS / 2;
-                    constexpr int SPS = (RL + XE + (NS - SS) - 1) / (NS - SS);
+#pragma unroll
+                for (int t = 0; t < CIN_RT; ++t)
+                    xo[ks][t] = (jp == 0) ? xb[il * CIN_ROWS + t * 32] : (ks == 0 ? xprev[t] : xo[ks - 1][t]);
+            }
+        };
+        {
+            const float none[CIN_RT] = {0.f, 0.f};
+            read_ops(0, bw, xkv, none);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float bwn[KS][CT], xkn[KS][CIN_RT];
+            if (g + 1 < NG) {
+                read_ops(g + 1, bwn, xkn, xkv[KS - 1]);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) bwn[ks][cc] = bw[ks][cc];
+#pragma unroll
+                    for (int t = 0; t < CIN_RT; ++t) xkn[ks][t] = xkv[ks][t];
+                }
+            }
+            if (FAST && fast_ok) {   // a few staging instructions of the next chunk per k-step
+                constexpr int SS = NS / 2;
+                constexpr int SPS = (RL + XE + (NS - SS) - 1) / (NS - SS);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int step = g * KS + ks;
                     if (step < NLD) fast_load(step, i0n);
                     if (step == (NLD < SS ? NLD : SS - 1)) fast_load_xk(i0n);
                     if (step >= SS) {
@@ -256,28 +307,50 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
                         for (int k = 0; k < SPS; ++k) fast_store((step - SS) * SPS + k, buf ^ 1);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                float a[CIN_RT];
+            }
+            float a[KS][CIN_RT];
 #pragma unroll
-                for (int t = 0; t < CIN_RT; ++t) a[t] = xkv[t] * x0r[t][jp];
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < CIN_RT; ++t) a[ks][t] = xkv[ks][t] * x0r[t][(g * KS + ks) % MP2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int t = 0; t < CIN_RT; ++t)
 #pragma unroll
                     for (int cc = 0; cc < CT; ++cc)
-                        acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bw[cc], acc[t][cc], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                        acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][t], bw[ks][cc], acc[t][cc], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int cc = 0; cc < CT; ++cc) bw[cc] = bwn[cc];
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int t = 0; t < CIN_RT; ++t) xkv[t] = xkn[t];
+                for (int cc = 0; cc < CT; ++cc) bw[ks][cc] = bwn[ks][cc];
+#pragma unroll
+                for (int t = 0; t < CIN_RT; ++t) xkv[ks][t] = xkn[ks][t];
             }
+        }
+        unsigned long long st_c1 = 0;
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            st_c1 = cin_now();
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (next_bulk) {
             fetch_chunk(c + 1);
             store_chunk(buf ^ 1, -1);
         }
         __syncthreads();
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long st_c2 = cin_now();
+            st_a += st_c1 - st_c0;
+            st_b += st_c2 - st_c1;
+            ++st_cnt;
+        }
     }
+    unsigned long long st_e0 = 0;
+    if (STAMP) st_e0 = cin_now();
 
     // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -------------------
 #pragma unroll
@@ -338,6 +411,14 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
             }
         }
     }
+    if (STAMP && lane == 0) {
+        atomicAdd(&cin_stamp_acc[0], st_a);
+        atomicAdd(&cin_stamp_acc[1], st_b);
+        atomicAdd(&cin_stamp_acc[2], st_cnt);
+        atomicAdd(&cin_stamp_acc[3], st_pro);
+        atomicAdd(&cin_stamp_acc[4], cin_now() - st_e0);
+        atomicAdd(&cin_stamp_acc[5], 1ULL);
+    }
 }
 
 template <int MT, int CT>
@@ -367,6 +448,18 @@ static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* 
     // least one whole chunk; everything else takes the generic bulk staging
     static const int fast_env = getenv("DIR_CIN_FAST") ? atoi(getenv("DIR_CIN_FAST")) : 1;
     const bool wvec = m == MT && ((int64_t)Hp * MT) % 4 == 0 && aligned16(W);
+    if constexpr (MT == 26 && CT == 4) {
+        static const int stamp_env = getenv("DIR_CIN_STAMP") ? atoi(getenv("DIR_CIN_STAMP")) : 0;
+        if (stamp_env && fast_env && wvec && Hp >= cin_ic(MT)) {   // diagnostic build: cycle stamps, same arithmetic
+            static bool set = false;
+            if (!set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<26, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                set = true;
+            }
+            hipLaunchKernelGGL((cin_k<26, 4, true, true>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+            return;
+        }
+    }
     if constexpr (cin_fast_shape<MT, CT>()) {
         if (fast_env && wvec && Hp >= cin_ic(MT)) {
             launch_cin_one<MT, CT, true>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
@@ -381,7 +474,7 @@ static int launch_cin(int ct, dim3 grid, hipStream_t st, const float* x0, const 
                       int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
     constexpr int mp = (MT + 1) & ~1;
     constexpr int IC = cin_ic(MT);
-    const size_t shmem = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)IC * mp * CIN_HP + 2 * (size_t)IC * CIN_ROWS);
+    const size_t shmem = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)IC * mp * CIN_WS + 2 * (size_t)IC * CIN_ROWS);
     switch (ct) {
         case 1: launch_cin_ct<MT, 1>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
         case 2: launch_cin_ct<MT, 2>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
@@ -418,5 +511,15 @@ extern "C" int dir_cin_layer_f32(const float* x0, const float* xk, const float* 
     else if (m <= 40) launch_cin<40>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
     else return fail(DIR_E_UNSUPPORTED, "dir_cin_layer_f32: field count m=%d exceeds 40", m);
     DIR_CHECK_LAUNCH("cin_layer");
+    return DIR_OK;
+}
+
+// Diagnostic only: read (and clear) the cycle stamps accumulated by the DIR_CIN_STAMP=1 build.
+extern "C" int dir_debug_cin_stamps(unsigned long long* out8) {
+    if (!out8) return dir::fail(DIR_E_BADARG, "dir_debug_cin_stamps: null pointer");
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return dir::fail(DIR_E_HIP, "dir_debug_cin_stamps: sync failed");
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(dir::cin_stamp_acc), sizeof(zero)) != hipSuccess) return dir::fail(DIR_E_HIP, "dir_debug_cin_stamps: copy failed");
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dir::cin_stamp_acc), zero, sizeof(zero)) != hipSuccess) return dir::fail(DIR_E_HIP, "dir_debug_cin_stamps: clear failed");
     return DIR_OK;
 }

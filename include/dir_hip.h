@@ -253,6 +253,11 @@ int dir_sparse_adagrad_f32(float* const* tables, float* const* accums, int F, in
                            int64_t B, const int64_t* head_base, int32_t* head, int32_t* next,
                            dir_stream_t stream);
 
+/* Diagnostic only (never on the product path): cycle stamps of the DIR_CIN_STAMP=1 build of the CIN kernel, summed
+ * over waves since the last call: [0] chunk start -> end of its MFMA stream, [1] -> past the chunk barrier,
+ * [2] chunks, [3] prologue, [4] epilogue, [5] waves.  Synchronises the device. */
+int dir_debug_cin_stamps(unsigned long long* out8);
+
 #ifdef __cplusplus
 }
 #endif
