@@ -324,15 +324,15 @@ def main():
 
         def step(i):
             xk, off = x0, 0
-            for W, h in zip(Ws, Hs):
-                xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h])
+            for k, (W, h) in enumerate(zip(Ws, Hs)):   # as XDeepFM.cin: the last layer's map feeds nothing
+                xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Hs))
                 off += h
         flops, hp = 0, m
         for h in Hs:
             flops += 2 * B * D * hp * m * h
             hp = h
         roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_k x3"}
-        cfg.update({"m": m, "D": D, "layers": list(Hs)})
+        cfg.update({"m": m, "D": D, "layers": list(Hs), "outputs": "pooled [B,384]; xout of layers 1-2"})
 
     # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------
     for i in range(args.warmup):

@@ -27,6 +27,7 @@
 namespace dir {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Diagnostic build only (DIR_CIN_STAMP=1): per-chunk cycle shares, never used by the product path.
 // [0] cycles from chunk start to the end of its MFMA stream, [1] cycles from there to past the barrier,
@@ -221,12 +222,13 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     }
     __syncthreads();
 
-    // this lane's x0 operands: x0r[t][jp] = x0s[2*jp + hh][wave*64 + t*32 + n]
-    float x0r[CIN_RT][MP2];
+    // this lane's x0 operands: x0p[jp][t] = x0s[2*jp + hh][wave*64 + t*32 + n]
+    f32x2 x0p[MP2];   // {row tile 0, row tile 1}: register pairs for the packed multiply
 #pragma unroll
-    for (int t = 0; t < CIN_RT; ++t)
-#pragma unroll
-        for (int jp = 0; jp < MP2; ++jp) x0r[t][jp] = x0s[(2 * jp + hh) * CIN_ROWS + wave * 64 + t * 32 + n];
+    for (int jp = 0; jp < MP2; ++jp) {
+        const float* src = x0s + (2 * jp + hh) * CIN_ROWS + wave * 64 + n;
+        x0p[jp] = f32x2{src[0], src[32]};
+    }
 
     f32x16 acc[CIN_RT][CT];
 #pragma unroll
@@ -255,8 +257,10 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
         // One burst = KS k-steps = KS*RT*CT MFMAs issued back to back.  Everything else of those steps -- the LDS
         // operand reads for the NEXT burst (latency ~100 cycles vs >= 1000 cycles of MFMA issue), a few staging
         // instructions of the next chunk and the KS*RT products forming this burst's A operands -- sits in ONE
-        // cluster in front of the burst: a VALU/LDS instruction between two fp32 MFMAs costs ~20 cycles for the
-        // first of a cluster and ~5 for each further one, while scalar instructions and s_nop are free.
+        // cluster in front of the burst: a VALU or LDS instruction in an fp32 MFMA stream costs ~7.5 issue cycles
+        // (nothing hides behind v_mfma_f32_32x32x2_f32 except scalar instructions and s_nop), so their COUNT is
+        // what is minimised.  Keep the burst sequence ONE straight-line block: with control flow inside the chunk
+        // loop the compiler copies all 128 accumulator registers between AGPRs and VGPRs on every edge.
         constexpr int NS = IC * MP2, KS = (NS % CIN_KS == 0) ? CIN_KS : 1, NG = NS / KS;
         float bw[KS][CT], xkv[KS][CIN_RT];
         auto read_ops = [&](int g, float (&bo)[KS][CT], float (&xo)[KS][CIN_RT], const float (&xprev)[CIN_RT]) {
@@ -309,10 +313,15 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
                 }
             }
             float a[KS][CIN_RT];
+            static_assert(CIN_RT == 2, "the A products of the two row tiles are one packed multiply");
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int t = 0; t < CIN_RT; ++t) a[ks][t] = xkv[ks][t] * x0r[t][(g * KS + ks) % MP2];
+            for (int ks = 0; ks < KS; ++ks) {   // v_pk_mul_f32: same IEEE products, half the VALU instructions
+                const int jp = (g * KS + ks) % MP2;
+                const f32x2 xv = {xkv[ks][0], xkv[ks][1]};
+                f32x2 pr;
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(xv), "v"(x0p[jp]));
+                a[ks][0] = pr.x; a[ks][1] = pr.y;
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     if (STAMP) st_e0 = cin_now();
 
     // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -------------------
+    if (xout) {   // NULL: the caller only wants the pooled sums (last layer of a CIN stack)
 #pragma unroll
     for (int t = 0; t < CIN_RT; ++t) {
         const int64_t trow = row0 + wave * 64 + t * 32;
@@ -370,6 +380,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
                 }
             }
         }
+    }
     }
     if (pooled) {
         // sum over d: the D rows of one sample are whole g groups (8 rows each, 4 per lane half)
@@ -489,12 +500,12 @@ using namespace dir;
 
 extern "C" int dir_cin_layer_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                                  int64_t B, float* xout, float* pooled, int64_t pooled_ld, dir_stream_t stream) {
-    DIR_CHECK_ARG(x0 && xk && W && xout, "dir_cin_layer_f32: null pointer");
+    DIR_CHECK_ARG(x0 && xk && W && (xout || pooled), "dir_cin_layer_f32: null pointer");
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "dir_cin_layer_f32: m=%d Hp=%d H=%d D=%d", m, Hp, H, D);
     DIR_CHECK_ARG(!pooled || pooled_ld >= H, "dir_cin_layer_f32: pooled_ld=%lld < H=%d", (long long)pooled_ld, H);
     if (!(D == 4 || D == 8 || D == 16 || D == 32))
         return fail(DIR_E_UNSUPPORTED, "dir_cin_layer_f32: D=%d (supported: 4, 8, 16, 32)", D);
-    if (!aligned16(xout)) return fail(DIR_E_BADARG, "dir_cin_layer_f32: xout must be 16-byte aligned");
+    if (xout && !aligned16(xout)) return fail(DIR_E_BADARG, "dir_cin_layer_f32: xout must be 16-byte aligned");
     if (B == 0) return DIR_OK;
     int dshift = 0;
     while ((1 << dshift) < D) ++dshift;

@@ -261,9 +261,10 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     return (out, scores) if want_scores else out
 
 
-def cin_layer(x0, xk, W, pooled=None):
+def cin_layer(x0, xk, W, pooled=None, want_xout=True):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
-    (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept)."""
+    (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
+    want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None."""
     _dev(x0, torch.float32, "x0")
     _dev(xk, torch.float32, "xk")
     _dev(W, torch.float32, "W")
@@ -274,10 +275,11 @@ def cin_layer(x0, xk, W, pooled=None):
     H = W.shape[0]
     if W.shape[1] != Hp * m or xk.shape[0] != B or xk.shape[2] != D:
         raise ValueError("cin_layer: W must be [H, Hp*m], xk [B,Hp,D]")
-    xout = torch.empty((B, H, D), dtype=torch.float32, device=x0.device)
+    xout = torch.empty((B, H, D), dtype=torch.float32, device=x0.device) if want_xout else None
     if pooled is None:
         pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
-    _lib.check(_lib.load().dir_cin_layer_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout), _ptr(pooled),
+    _lib.check(_lib.load().dir_cin_layer_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B,
+                                             _ptr(xout) if want_xout else None, _ptr(pooled),
                                              pooled.stride(0), _stream()))
     return xout, pooled
 

@@ -62,8 +62,10 @@ class XDeepFM(nn.Module):
         B = x0.shape[0]
         pooled = torch.empty((B, sum(self.cin_layer_sizes)), dtype=torch.float32, device=x0.device)
         xk, off = x0, 0
-        for W, h in zip(self.cin_W, self.cin_layer_sizes):
-            xk, _ = ops.cin_layer(x0, xk, W.data, pooled=pooled[:, off:off + h])
+        last = len(self.cin_layer_sizes) - 1
+        for k, (W, h) in enumerate(zip(self.cin_W, self.cin_layer_sizes)):
+            # the last layer's [B,H,D] map feeds nothing: only its pooled sums are written
+            xk, _ = ops.cin_layer(x0, xk, W.data, pooled=pooled[:, off:off + h], want_xout=k < last)
             off += h
         return pooled
 

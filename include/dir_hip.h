@@ -160,7 +160,8 @@ int dir_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
  * arXiv:1803.05170).
  * x0 [B, m, D], xk [B, Hp, D], W [H, Hp*m] (column index i*m + j) ->
  *   xout[b, h, d] = sum_{i<Hp} sum_{j<m} W[h, i*m+j] * xk[b,i,d] * x0[b,j,d]
- *   pooled[b*pooled_ld + h] = sum_d xout[b,h,d]      (pooled may be NULL)
+ *   pooled[b*pooled_ld + h] = sum_d xout[b,h,d]      (pooled may be NULL; xout may be NULL when
+ *                                                     pooled is given: the last layer of a stack)
  * The outer product Z is never materialised: it is formed in registers and fed to fp32 MFMA.
  * Shapes: D in {4, 8, 16, 32}; any m <= 40 (instantiated for padded field counts 8/16/26/40); any Hp, H.
  * ------------------------------------------------------------------------------------------ */

@@ -209,7 +209,10 @@ def test_din_attention_pool(ops, oracle, B, T, K, H1, H2, normalize):
                                          (9, 5, 4, 6, 7), (5, 5, 32, 3, 64), (3, 8, 16, 9, 200),
                                          # field counts that are not an instantiated size (padded with zero operands)
                                          (33, 39, 16, 39, 128), (17, 39, 16, 64, 96), (12, 13, 16, 13, 64), (8, 3, 8, 3, 32),
-                                         (10, 22, 16, 50, 128), (6, 40, 16, 2, 16), (5, 1, 4, 1, 8)])
+                                         (10, 22, 16, 50, 128), (6, 40, 16, 2, 16), (5, 1, 4, 1, 8),
+                                         # tails: half a chunk (fast clamped staging + half burst sequence) and others
+                                         (20, 26, 16, 6, 128), (20, 26, 16, 10, 128), (11, 16, 16, 6, 64), (9, 8, 8, 14, 32),
+                                         (7, 40, 16, 3, 128), (7, 40, 16, 9, 128), (20, 26, 16, 5, 128), (20, 26, 16, 7, 128)])
 def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     rng = np.random.default_rng(Hp * 13 + H)
     x0 = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
@@ -219,6 +222,20 @@ def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     got_x, got_p = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))
     _close(got_x.cpu().numpy(), ref_x)
     _close(got_p.cpu().numpy(), ref_p)
+
+
+def test_cin_pooled_only(ops):
+    """xout = NULL (last layer of a stack): the pooled sums are bit-identical to the full call, and a
+    call with neither output is a BADARG."""
+    rng = np.random.default_rng(77)
+    for B, m, D, Hp, H in [(300, 26, 16, 26, 128), (37, 10, 8, 7, 40), (5, 3, 4, 2, 3)]:
+        x0 = _dev((rng.standard_normal((B, m, D)) * 0.5).astype(np.float32))
+        xk = _dev((rng.standard_normal((B, Hp, D)) * 0.5).astype(np.float32))
+        W = _dev((rng.standard_normal((H, Hp * m)) / np.sqrt(Hp * m)).astype(np.float32))
+        _, full = ops.cin_layer(x0, xk, W)
+        none, only = ops.cin_layer(x0, xk, W, want_xout=False)
+        assert none is None
+        np.testing.assert_array_equal(only.cpu().numpy(), full.cpu().numpy())
 
 
 def test_cin_identity_layout(ops):
