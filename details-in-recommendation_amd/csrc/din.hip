@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void din_k(const float* __restrict__ table, Di
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// v_exp + v_rcp (1 ulp each): a correctly rounded division is a 10-instruction sequence, and VALU work is not
+// hidden behind fp32 MFMAs
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int K, int NC1, int NC2>
 struct DinSh {
