@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
-                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "deepfm_full",
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "cin_backward", "deepfm_full",
                              "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
@@ -333,6 +333,37 @@ def main():
             hp = h
         roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_k x3"}
         cfg.update({"m": m, "D": D, "layers": list(Hs), "outputs": "pooled [B,384]; xout of layers 1-2"})
+
+    elif wl == "cin_backward":
+        # backward of the 3-layer CIN stack given dL/dpooled (the forward's saved activations are inputs):
+        # per layer dW (cin_dw_k, fp32 MFMA) + dxk, dx0 (the forward kernel on permuted weights)
+        m, D, Hs = F, K, (128, 128, 128)
+        x0 = torch.randn((B, m, D), generator=gen, device=device) * 0.25
+        Ws, hp = [], m
+        for h in Hs:
+            Ws.append(torch.randn((h, hp * m), generator=gen, device=device) * (1.0 / (hp * m) ** 0.5))
+            hp = h
+        xks, xk = [x0], x0
+        for k, W in enumerate(Ws[:-1]):
+            xk, _ = ops.cin_layer(x0, xk, W)
+            xks.append(xk)
+        gp = torch.randn((B, sum(Hs)), generator=gen, device=device) * 0.1
+
+        def step(i):
+            gx = None            # gradient flowing into xout of the layer being processed
+            off = sum(Hs)
+            for k in range(len(Hs) - 1, -1, -1):
+                h = Hs[k]
+                off -= h
+                g_p = gp[:, off:off + h].reshape(B, h, 1)
+                G = g_p.expand(B, h, D).contiguous() if gx is None else gx.add_(g_p)
+                dx0, gx, dW = ops.cin_layer_backward(x0, xks[k], Ws[k], G)
+        flops, hp = 0, m
+        for h in Hs:
+            flops += 3 * 2 * B * D * hp * m * h
+            hp = h
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_dw_k + cin_k (dxk, dx0) x3"}
+        cfg.update({"m": m, "D": D, "layers": list(Hs)})
 
     # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------
     for i in range(args.warmup):

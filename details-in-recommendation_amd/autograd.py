@@ -152,6 +152,38 @@ class CrossNetwork(torch.autograd.Function):
         return gx0, gw, gb
 
 
+class CinLayer(torch.autograd.Function):
+    """One CIN layer with both outputs (xout [B,H,D], pooled [B,H]); backward through ops.cin_layer_backward."""
+
+    @staticmethod
+    def forward(ctx, x0, xk, W):
+        ctx.save_for_backward(x0, xk, W)
+        ctx.set_materialize_grads(False)     # an unused output (the last layer's xout) arrives as None, not as zeros
+        xout, pooled = ops.cin_layer(x0, xk, W)
+        return xout, pooled
+
+    @staticmethod
+    def backward(ctx, g_xout, g_pooled):
+        x0, xk, W = ctx.saved_tensors
+        B, H = x0.shape[0], W.shape[0]
+        D = x0.shape[2]
+        if g_xout is None and g_pooled is None:
+            return None, None, None
+        if g_xout is None:
+            G = g_pooled.reshape(B, H, 1).expand(B, H, D).contiguous()
+        elif g_pooled is None:
+            G = g_xout.contiguous()
+        else:
+            G = g_xout + g_pooled.reshape(B, H, 1)      # pooled = sum_d xout
+        need = ctx.needs_input_grad
+        dx0, dxk, dW = ops.cin_layer_backward(x0, xk, W, G, need_x0=need[0], need_xk=need[1], need_w=need[2])
+        return dx0, dxk, dW
+
+
+def cin_layer(x0, xk, W):
+    return CinLayer.apply(x0, xk, W)
+
+
 def gather_fm(ts, ids, tables):
     return GatherFm.apply(ts, ids, *tables)
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libdir_hip.so")
-SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "cin.hip", "backward.hip"]
+SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "cin.hip", "cin_bwd.hip", "backward.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
          "-Wall", "-Wno-unused-function"]

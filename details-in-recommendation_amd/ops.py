@@ -442,6 +442,58 @@ def cross_network_backward(x0, w, b, gout):
     return gx0, gw, gb
 
 
+def cin_dw(x0, xk, G, dW=None, accumulate=False):
+    """Weight gradient of one CIN layer (include/dir_hip.h, dir_cin_dw_f32): x0 [B,m,D], xk [B,Hp,D], G = dL/dxout
+    [B,H,D] -> dW [H, Hp*m] (added into `dW` when accumulate)."""
+    for t, n in ((x0, "x0"), (xk, "xk"), (G, "G")):
+        _dev(t, torch.float32, n)
+        if not t.is_contiguous():
+            raise ValueError("cin_dw operands must be contiguous")
+    B, m, D = x0.shape
+    Hp, H = xk.shape[1], G.shape[1]
+    if xk.shape[0] != B or xk.shape[2] != D or G.shape[0] != B or G.shape[2] != D:
+        raise ValueError("cin_dw: xk must be [B,Hp,D] and G [B,H,D]")
+    if dW is None:
+        if accumulate:
+            raise ValueError("cin_dw: accumulate needs dW")
+        dW = torch.empty((H, Hp * m), dtype=torch.float32, device=x0.device)
+    elif dW.shape != (H, Hp * m) or not dW.is_contiguous():
+        raise ValueError("cin_dw: dW must be a contiguous [H, Hp*m] tensor")
+    lib = _lib.load()
+    ws = torch.empty(max(16, int(lib.dir_cin_dw_workspace_bytes(m, Hp, H, D, B))), dtype=torch.uint8, device=x0.device)
+    _lib.check(lib.dir_cin_dw_f32(_ptr(x0), _ptr(xk), _ptr(G), m, Hp, H, D, B, 1 if accumulate else 0, _ptr(dW), _ptr(ws),
+                                  _stream()))
+    return dW
+
+
+CIN_MAX_FIELDS = 40   # largest register-resident operand of dir_cin_layer_f32
+
+
+def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True):
+    """Backward of cin_layer given G = dL/dxout [B,H,D] (pooled gradient already broadcast in):
+    -> (dx0 [B,m,D] | None, dxk [B,Hp,D] | None, dW [H,Hp*m] | None).
+    The two data gradients are the forward contraction with permuted weights (include/dir_hip.h):
+      dxk = cin_layer(x0, G, W1),  W1[i, h*m+j]  = W[h, i*m+j]
+      dx0 = sum over channel groups g of cin_layer(xk[:, g], G, W2g),  W2g[j, h*mg+ig] = W[h, (g0+ig)*m+j]."""
+    B, m, D = x0.shape
+    Hp, H = xk.shape[1], W.shape[0]
+    W3 = W.view(H, Hp, m)
+    dxk = dx0 = dW = None
+    if need_xk:
+        W1 = W3.permute(1, 0, 2).reshape(Hp, H * m).contiguous()
+        dxk, _ = cin_layer(x0, G, W1)
+    if need_x0:
+        for g0 in range(0, Hp, CIN_MAX_FIELDS):
+            mg = min(CIN_MAX_FIELDS, Hp - g0)
+            xg = xk if mg == Hp else xk[:, g0:g0 + mg, :].contiguous()
+            W2 = W3[:, g0:g0 + mg, :].permute(2, 0, 1).reshape(m, H * mg).contiguous()
+            part, _ = cin_layer(xg, G, W2)
+            dx0 = part if dx0 is None else dx0.add_(part)
+    if need_w:
+        dW = cin_dw(x0, xk, G)
+    return dx0, dxk, dW
+
+
 class SparseAdagrad:
     """Fused sparse Adagrad over a TableSet (include/dir_hip.h: dir_sparse_adagrad_f32).  Holds the accumulators
     ([TF-upstream] initial_accumulator_value = 0.1) and the persistent per-row chain heads."""

@@ -6,6 +6,7 @@ import math
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of
 from .deepfm import _glorot_uniform_
@@ -60,6 +61,12 @@ class XDeepFM(nn.Module):
     def cin(self, x0):
         """x0 [B, m, D] -> pooled features [B, sum(H_k)]."""
         B = x0.shape[0]
+        if torch.is_grad_enabled() and (x0.requires_grad or any(W.requires_grad for W in self.cin_W)):
+            outs, xk = [], x0                  # differentiable path: autograd.CinLayer (dW on MFMA, dx via the forward)
+            for W in self.cin_W:
+                xk, p = ag.cin_layer(x0, xk, W)
+                outs.append(p)
+            return torch.cat(outs, dim=1)
         pooled = torch.empty((B, sum(self.cin_layer_sizes)), dtype=torch.float32, device=x0.device)
         xk, off = x0, 0
         last = len(self.cin_layer_sizes) - 1
@@ -83,15 +90,23 @@ class XDeepFM(nn.Module):
     def forward(self, features):
         device = self.linear_bias.device
         emb_ts, lin_ts = self._tablesets()
+        train = torch.is_grad_enabled()
         got = collect_ids(self.dnn_feature_columns, features, device)
-        if got[0] == "onehot":
+        comb = self.dnn_feature_columns[0].combiner
+        if train:      # sparse table gradients (autograd.EmbeddingBag / LinearLogit)
+            tabs = list(self.embedding_weights)
+            emb = ag.embedding_bag(emb_ts, got[1], tabs) if got[0] == "onehot" else \
+                ag.embedding_bag(emb_ts, got[1], tabs, got[2], got[3], combiner=comb, field_major=True)
+        elif got[0] == "onehot":
             emb = ops.embedding_bag(emb_ts, got[1])
         else:
-            emb = ops.embedding_bag(emb_ts, got[1], got[2], got[3], combiner=self.dnn_feature_columns[0].combiner,
-                                    field_major=True)
+            emb = ops.embedding_bag(emb_ts, got[1], got[2], got[3], combiner=comb, field_major=True)
         lin = None
         if lin_ts is not None:
             g2 = collect_ids(self.linear_feature_columns, features, device)
-            lin = ops.linear_logit(lin_ts, g2[1], bias=self.linear_bias.data) if g2[0] == "onehot" else \
-                ops.linear_logit(lin_ts, g2[1], g2[2], g2[3], bias=self.linear_bias.data, field_major=True)
+            if train and g2[0] == "onehot":
+                lin = ag.linear_logit(lin_ts, g2[1], self.linear_bias, list(self.linear_weights))
+            else:
+                lin = ops.linear_logit(lin_ts, g2[1], bias=self.linear_bias.data) if g2[0] == "onehot" else \
+                    ops.linear_logit(lin_ts, g2[1], g2[2], g2[3], bias=self.linear_bias.data, field_major=True)
         return self.forward_embedded(emb, lin)

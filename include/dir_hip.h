@@ -242,6 +242,22 @@ int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const float* w, co
                                const float* gout, int64_t g_ld, int64_t B, int d, float* gx0, int64_t gx_ld,
                                float* gw, float* gb, void* workspace, dir_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Backward of the CIN layer (A14; no reference code).  With G = dL/dxout [B, H, D] (the caller adds the pooled
+ * gradient, broadcast over d, into G):
+ *   dW[h, i*m+j]  = sum_{b,d} G[b,h,d] * xk[b,i,d] * x0[b,j,d]          -> dir_cin_dw_f32 (fp32 MFMA)
+ *   dxk[b,i,d]    = sum_{h,j} W[h, i*m+j] * G[b,h,d] * x0[b,j,d]        = dir_cin_layer_f32(x0, G, W1) with
+ *                   W1[i, h*m+j] = W[h, i*m+j]
+ *   dx0[b,j,d]    = sum_{h,i} W[h, i*m+j] * G[b,h,d] * xk[b,i,d]        = dir_cin_layer_f32(xk, G, W2) with
+ *                   W2[j, h*Hp+i] = W[h, i*m+j]   (xk in channel groups of <= 40 when Hp > 40)
+ * i.e. the two data gradients are the forward contraction with permuted weights (host mirror: autograd.CinLayer).
+ * dir_cin_dw_f32: accumulate != 0 adds into dW; workspace: dir_cin_dw_workspace_bytes(...) device bytes,
+ * 16-byte aligned.  Row ranges are reduced in a fixed order: bitwise reproducible.
+ * ------------------------------------------------------------------------------------------ */
+int64_t dir_cin_dw_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
+int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,
+                   int accumulate, float* dW, void* workspace, dir_stream_t stream);
+
 /* Fused sparse Adagrad on the embedding tables (the reference's dnn_optimizer='Adagrad', deepFM.py:61):
  * for every distinct id of slot f in the batch: g = SUM of the gradient rows of its occurrences ([TF-upstream]
  * duplicate indices are summed before the update), accum[f][id] += g*g, tables[f][id] -= lr * g / sqrt(accum).

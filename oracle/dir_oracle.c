@@ -361,6 +361,66 @@ int orc_cin_layer_f32(const float* x0, const float* xk, const float* W, int m, i
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward of the CIN layer (no reference code; derivatives of the definition above), double accumulation:
+ *   dW[h,i*m+j] = sum_{b,d} G[b,h,d] xk[b,i,d] x0[b,j,d]
+ *   dxk[b,i,d]  = sum_{h,j} W[h,i*m+j] G[b,h,d] x0[b,j,d]
+ *   dx0[b,j,d]  = sum_{h,i} W[h,i*m+j] G[b,h,d] xk[b,i,d]
+ * dW is returned in double (dW64, caller rounds) so that tests can bound the fp32 reduction error.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_cin_backward(const float* x0, const float* xk, const float* W, const float* G, int m, int Hp, int H, int D,
+                     int64_t B, double* dW64, float* dxk, float* dx0) {
+    if (!x0 || !xk || !W || !G || !dW64 || !dxk || !dx0 || m <= 0 || Hp <= 0 || H <= 0 || D <= 0 || B < 0) return -1;
+    const int64_t Kd = (int64_t)Hp * m;
+    for (int64_t e = 0; e < (int64_t)H * Kd; ++e) dW64[e] = 0.0;
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < H; ++h) {              /* each thread owns rows of dW: no races, fixed order over b,d */
+        double* dWh = dW64 + (int64_t)h * Kd;
+        for (int64_t b = 0; b < B; ++b) {
+            const float* X0 = x0 + b * (int64_t)m * D;
+            const float* XK = xk + b * (int64_t)Hp * D;
+            const float* Gb = G + (b * H + h) * (int64_t)D;
+            for (int d = 0; d < D; ++d) {
+                const double g = Gb[d];
+                for (int i = 0; i < Hp; ++i) {
+                    const double gx = g * (double)XK[i * D + d];
+                    for (int j = 0; j < m; ++j) dWh[i * m + j] += gx * (double)X0[j * D + d];
+                }
+            }
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const float* X0 = x0 + b * (int64_t)m * D;
+        const float* XK = xk + b * (int64_t)Hp * D;
+        for (int d = 0; d < D; ++d) {
+            for (int i = 0; i < Hp; ++i) {
+                double a = 0.0;
+                for (int h = 0; h < H; ++h) {
+                    const double g = G[(b * H + h) * (int64_t)D + d];
+                    const float* Wh = W + (int64_t)h * Kd + (int64_t)i * m;
+                    double t = 0.0;
+                    for (int j = 0; j < m; ++j) t += (double)Wh[j] * (double)X0[j * D + d];
+                    a += g * t;
+                }
+                dxk[(b * Hp + i) * (int64_t)D + d] = (float)a;
+            }
+            for (int j = 0; j < m; ++j) {
+                double a = 0.0;
+                for (int h = 0; h < H; ++h) {
+                    const double g = G[(b * H + h) * (int64_t)D + d];
+                    const float* Wh = W + (int64_t)h * Kd + j;
+                    double t = 0.0;
+                    for (int i = 0; i < Hp; ++i) t += (double)Wh[(int64_t)i * m] * (double)XK[i * D + d];
+                    a += g * t;
+                }
+                dx0[(b * m + j) * (int64_t)D + d] = (float)a;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Bucketized column. [TF-upstream] bucketized_column -> math_ops._bucketize: bucket = number of
  * boundaries <= x (boundaries ascending).  Docstring use: models/DeepFM/deepFM.py:95.
  * ---------------------------------------------------------------------------------------------- */

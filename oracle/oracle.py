@@ -160,6 +160,22 @@ def cin_layer(x0, xk, W, acc64=False):
     return xout, pooled
 
 
+def cin_backward(x0, xk, W, G):
+    """-> (dW float64 [H, Hp*m], dxk float32 [B,Hp,D], dx0 float32 [B,m,D]); double accumulation."""
+    x0, xk, W, G = _f32(x0), _f32(xk), _f32(W), _f32(G)
+    B, m, D = x0.shape
+    Hp = xk.shape[1]
+    H = W.shape[0]
+    dW = np.zeros((H, Hp * m), np.float64)
+    dxk = np.zeros((B, Hp, D), np.float32)
+    dx0 = np.zeros((B, m, D), np.float32)
+    f = ctypes.c_float
+    rc = lib().orc_cin_backward(_p(x0, f), _p(xk, f), _p(W, f), _p(G, f), m, Hp, H, D, ctypes.c_int64(B),
+                                _p(dW, ctypes.c_double), _p(dxk, f), _p(dx0, f))
+    assert rc == 0, rc
+    return dW, dxk, dx0
+
+
 def bucketize(x, boundaries):
     x = _f32(x).reshape(-1)
     bd = _f32(boundaries)

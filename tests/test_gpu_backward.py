@@ -213,3 +213,109 @@ def test_deepfm_fused_adagrad_matches_torch_adagrad(built_lib):
     for pa, pb in zip(a.embedding_weights, b.embedding_weights):
         _close(pa, pb, tol=2e-5)
     assert fused.accums[0].min().item() >= 0.1
+
+
+# ---- CIN backward (no reference code; derivatives of the definition in include/dir_hip.h A14) -----------------------
+@pytest.mark.parametrize("B,m,D,Hp,H", [(64, 26, 16, 26, 128), (33, 26, 16, 128, 128), (7, 5, 4, 6, 7), (9, 8, 8, 5, 32),
+                                         (5, 3, 4, 2, 3), (3, 8, 16, 9, 200), (21, 39, 16, 39, 96), (1, 4, 4, 3, 5),
+                                         (18, 13, 32, 50, 130), (250, 10, 4, 45, 64)])
+def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
+    from dir_amd import ops
+    from oracle import oracle as O
+    rng = np.random.default_rng(B * 7 + Hp)
+    x0 = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
+    xk = (rng.standard_normal((B, Hp, D)) * 0.5).astype(np.float32)
+    W = (rng.standard_normal((H, Hp * m)) / np.sqrt(Hp * m)).astype(np.float32)
+    G = (rng.standard_normal((B, H, D)) * 0.5).astype(np.float32)
+    ref_dW, ref_dxk, ref_dx0 = O.cin_backward(x0, xk, W, G)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    dx0, dxk, dW = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G))
+    _close(dxk, ref_dxk)
+    _close(dx0, ref_dx0)
+    # dW sums B*D fp32 terms: scale the tolerance by the magnitude that was summed
+    mag = np.sqrt(B * D) * 0.125 + 1.0
+    err = np.abs(dW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
+    assert err.max() <= 1e-5, "dW max scaled err %.3e" % err.max()
+    # accumulate form and bitwise reproducibility
+    again = ops.cin_dw(dev(x0), dev(xk), dev(G))
+    assert torch.equal(again, dW)
+    acc = dW.clone()
+    ops.cin_dw(dev(x0), dev(xk), dev(G), dW=acc, accumulate=True)
+    _close(acc, 2 * ref_dW, tol=1e-5 * mag)
+
+
+def test_cin_dw_large_rows(built_lib):
+    """Many row groups per split (the pipelined main loop), a row count with R % 8 == 4, all-ones check of the sums."""
+    from dir_amd import ops
+    B, m, D, Hp, H = 4097, 6, 4, 5, 40
+    x0 = torch.full((B, m, D), 0.5, device="cuda")
+    xk = torch.full((B, Hp, D), 2.0, device="cuda")
+    G = torch.ones((B, H, D), device="cuda")
+    dW = ops.cin_dw(x0, xk, G)
+    assert torch.equal(dW, torch.full_like(dW, float(B * D)))      # 1 * 2 * 0.5 summed over B*D rows, exact in fp32
+
+
+def test_cin_autograd_matches_float64(built_lib):
+    from dir_amd import autograd as ag
+    g = torch.Generator().manual_seed(5)
+    B, m, D, Hs = 37, 7, 8, (12, 9)
+    x0 = (torch.randn(B, m, D, generator=g) * 0.5)
+    Ws = [torch.randn(Hs[0], m * m, generator=g) / m, torch.randn(Hs[1], Hs[0] * m, generator=g) / (Hs[0] * m) ** 0.5]
+    head = torch.randn(sum(Hs), generator=g)
+
+    def model64():
+        x = x0.double().requires_grad_(True)
+        ws = [w.double().requires_grad_(True) for w in Ws]
+        xk, outs = x, []
+        for w in ws:
+            H = w.shape[0]
+            xk = torch.einsum("hij,bid,bjd->bhd", w.view(H, xk.shape[1], m), xk, x)
+            outs.append(xk.sum(2))
+        loss = (torch.cat(outs, 1) @ head.double()).square().sum()
+        loss.backward()
+        return loss, x.grad, [w.grad for w in ws]
+
+    l64, gx64, gw64 = model64()
+    x = x0.cuda().requires_grad_(True)
+    ws = [w.cuda().requires_grad_(True) for w in Ws]
+    xk, outs = x, []
+    for w in ws:
+        xk, p = ag.cin_layer(x, xk, w)
+        outs.append(p)
+    loss = (torch.cat(outs, 1) @ head.cuda()).square().sum()
+    loss.backward()
+    _close(loss, l64, tol=1e-5)
+    scale = float(gx64.abs().max())
+    _close(x.grad / scale, gx64 / scale, tol=2e-5)
+    for w, g64 in zip(ws, gw64):
+        s = float(g64.abs().max())
+        _close(w.grad / s, g64 / s, tol=2e-5)
+
+
+def test_xdeepfm_training_step(built_lib):
+    """A few SGD steps of a small xDeepFM through the HIP backward path reduce a logistic loss."""
+    from dir_amd import feature_column as fc
+    from dir_amd.xdeepfm import XDeepFM
+    torch.manual_seed(0)
+    F, V, D, B = 6, 50, 8, 256
+    cats = [fc.categorical_column_with_identity("c%d" % i, V) for i in range(F)]
+    model = XDeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, D) for c in cats],
+                    cin_layer_sizes=(16, 16), dnn_hidden_units=(32,)).cuda()
+    g = torch.Generator().manual_seed(1)
+    feats = {"c%d" % i: torch.randint(0, V, (B,), generator=g).cuda() for i in range(F)}
+    y = ((feats["c0"] + feats["c1"]) % 2).float().reshape(B, 1)
+    dense = [p for n, p in model.named_parameters() if not (n.startswith("embedding_weights") or n.startswith("linear_weights"))]
+    sparse = [p for n, p in model.named_parameters() if n.startswith("embedding_weights") or n.startswith("linear_weights")]
+    opt = torch.optim.Adagrad(dense, lr=0.05)
+    opt_s = torch.optim.SGD(sparse, lr=0.5)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad(set_to_none=True)
+        opt_s.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(model(feats), y)
+        loss.backward()
+        assert all(w.grad is not None for w in model.cin_W)
+        opt.step()
+        opt_s.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.8 * losses[0], losses[::6]
