@@ -184,6 +184,65 @@ def cin_layer(x0, xk, W):
     return CinLayer.apply(x0, xk, W)
 
 
+class DinAttentionPool(torch.autograd.Function):
+    """DIN local activation unit + pooling (include/dir_hip.h A13).  Forward: the fused HIP kernel.  Backward: the
+    unit is recomputed over the VALID (sample, position) rows only and differentiated on the GPU -- gathers and
+    elementwise steps as torch kernels, the four small GEMMs and their transposes through rocBLAS -- giving a
+    sparse gradient for the table (history rows and candidate rows) and dense ones for the six MLP tensors.
+    (A fused HIP backward is the next step for this op; this composite never leaves the device.)"""
+
+    @staticmethod
+    def forward(ctx, table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize):
+        ctx.normalize = bool(normalize)
+        ctx.save_for_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3)
+        return ops.din_attention_pool(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(), W2.detach(),
+                                      b2.detach(), W3.detach(), b3.detach(), normalize=normalize)
+
+    @staticmethod
+    def backward(ctx, g):
+        table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3 = ctx.saved_tensors
+        B, T = hist.shape
+        K = table.shape[1]
+        pos = torch.arange(T, device=hist.device).unsqueeze(0)
+        valid = hist >= 0
+        if hist_len is not None:
+            valid &= pos < hist_len.clamp(0, T).unsqueeze(1)
+        b_idx, j_idx = valid.nonzero(as_tuple=True)                 # rows in (b, j) order
+        ids_h = hist[b_idx, j_idx]
+        with torch.enable_grad():
+            h = table.detach()[ids_h].requires_grad_(True)
+            a = table.detach()[cand].requires_grad_(True)
+            ws = [t.detach().requires_grad_(True) for t in (W1, b1, W2, b2, W3, b3)]
+            ab = a[b_idx]
+            u = torch.cat([h, ab, h - ab, h * ab], dim=1)
+            z1 = torch.sigmoid(u @ ws[0] + ws[1])
+            z2 = torch.sigmoid(z1 @ ws[2] + ws[3])
+            s = z2 @ ws[4].reshape(-1) + ws[5]
+            if ctx.normalize:                                       # softmax over the valid positions of each sample
+                x = s * (1.0 / K ** 0.5)
+                mx = torch.full((B,), float("-inf"), device=x.device).scatter_reduce(0, b_idx, x.detach(), "amax")
+                e = torch.exp(x - mx[b_idx])
+                w = e / torch.zeros(B, device=x.device).index_add(0, b_idx, e)[b_idx]
+            else:
+                w = s
+            out = torch.zeros((B, K), device=h.device).index_add(0, b_idx, w.unsqueeze(1) * h)
+            gh, ga, *gws = torch.autograd.grad(out, [h, a] + ws, g.contiguous(), allow_unused=True)
+        gtab = None
+        if ctx.needs_input_grad[0]:
+            if gh is None:                                          # no valid position in the whole batch
+                gtab = torch.sparse_coo_tensor(torch.zeros((1, 0), dtype=torch.int64, device=table.device),
+                                               torch.zeros((0, K), device=table.device), table.shape)
+            else:
+                idx = torch.cat([ids_h, cand]).unsqueeze(0)
+                gtab = torch.sparse_coo_tensor(idx, torch.cat([gh, ga]), table.shape)
+        gws = [gw if gw is not None else torch.zeros_like(t) for gw, t in zip(gws, (W1, b1, W2, b2, W3, b3))]
+        return (gtab, None, None, None) + tuple(gws) + (None,)
+
+
+def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False):
+    return DinAttentionPool.apply(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize)
+
+
 def gather_fm(ts, ids, tables):
     return GatherFm.apply(ts, ids, *tables)
 

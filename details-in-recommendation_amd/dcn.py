@@ -85,6 +85,15 @@ class DeepCrossNetwork(nn.Module):
         return self.logits_layer(torch.cat([cross, deep], dim=-1))               # :136-137
 
     @torch.no_grad()
+    def train_step(self):
+        """The reference's train_op for this model (_get_train_op_fn, DeepCrossNetwork.py:264-290) built from the
+        constructor's optimizer / optimizer_spec / learning_rate_spec / l2_reg: see train_spec.TrainStep."""
+        from .train_spec import TrainStep
+        hp = self.hparams
+        return TrainStep(self, optimizer=hp["optimizer"] or "Adam", optimizer_spec=hp["optimizer_spec"],
+                         learning_rate_spec=hp["learning_rate_spec"], l2_reg=hp["l2_reg"],
+                         l2_params=[lin.weight for lin in self.hidden])      # l2 on the deep kernels, :386-399
+
     def predict(self, features):
         logits = self.forward(features)                                          # :153-165
         two = torch.cat([torch.zeros_like(logits), logits], dim=-1)

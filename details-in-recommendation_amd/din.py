@@ -5,6 +5,7 @@ import math
 import torch
 from torch import nn
 
+from . import autograd as ag
 from . import ops
 
 
@@ -25,6 +26,9 @@ class DINAttentionPool(nn.Module):
         self.normalize = normalize
 
     def forward(self, hist, hist_len, cand, want_scores=False):
+        if torch.is_grad_enabled() and not want_scores and any(p.requires_grad for p in self.parameters()):
+            return ag.din_attention_pool(self.table, hist, hist_len, cand, self.W1, self.b1, self.W2, self.b2, self.W3,
+                                         self.b3, normalize=self.normalize)       # sparse table gradient
         return ops.din_attention_pool(self.table.data, hist, hist_len, cand, self.W1.data, self.b1.data, self.W2.data,
                                       self.b2.data, self.W3.data, self.b3.data, normalize=self.normalize,
                                       want_scores=want_scores)

@@ -1,0 +1,159 @@
+"""train_spec.py -- the reference DCN's training step around the HIP forward/backward path.
+
+Mirrors models/DeepCrossNetwork/DeepCrossNetwork.py (reference):
+  _get_train_op_fn                 :264-290   lr = _learning_rate_decay(params); optimizer(**optimizer_spec, learning_rate=lr);
+                                              every gradient tensor clipped on its own with tf.clip_by_norm(g, 100.0)
+  _learning_rate_decay / _no_decay :422-458   learning_rate_spec = {'learning_rate': ..., 'decay_method': name, **kwargs}
+  _DECAY_METHOD_NAME               :26-31     the six tf.train decay schedules ([TF-upstream] formulas restated below)
+  l2_reg                           :181-183   loss += l2_reg * sum of the deep kernels' l2 losses
+Reference use: models/DeepCrossNetwork/train.py:111-125 (Adam, epsilon 1e-4, cosine_decay over 3000 steps, alpha 0.5).
+Host-side scalar logic only; the gradients themselves come from autograd.py's HIP backward kernels.
+"""
+import math
+
+import torch
+
+CLIP_NORM = 100.0   # DeepCrossNetwork.py:283
+
+
+def exponential_decay(learning_rate, global_step, decay_steps, decay_rate, staircase=False, **_):
+    p = global_step / decay_steps
+    if staircase:
+        p = math.floor(p)
+    return learning_rate * decay_rate ** p
+
+
+def piecewise_constant(x=None, boundaries=(), values=(), global_step=None, **_):
+    x = global_step if x is None else x
+    if len(values) != len(boundaries) + 1:
+        raise ValueError("The length of boundaries should be 1 less than the length of values")
+    for b, v in zip(boundaries, values):
+        if x <= b:
+            return v
+    return values[-1]
+
+
+def polynomial_decay(learning_rate, global_step, decay_steps, end_learning_rate=0.0001, power=1.0, cycle=False, **_):
+    step = global_step
+    if cycle:
+        mult = 1.0 if step == 0 else math.ceil(step / decay_steps)
+        decay_steps = decay_steps * mult
+    else:
+        step = min(step, decay_steps)
+    return (learning_rate - end_learning_rate) * (1 - step / decay_steps) ** power + end_learning_rate
+
+
+def cosine_decay(learning_rate, global_step, decay_steps, alpha=0.0, **_):
+    step = min(global_step, decay_steps)
+    cosine = 0.5 * (1 + math.cos(math.pi * step / decay_steps))
+    return learning_rate * ((1 - alpha) * cosine + alpha)
+
+
+def cosine_decay_restarts(learning_rate, global_step, first_decay_steps, t_mul=2.0, m_mul=1.0, alpha=0.0, **_):
+    cf = global_step / first_decay_steps
+    if t_mul == 1.0:
+        i = math.floor(cf)
+        cf -= i
+    else:
+        i = math.floor(math.log(1.0 - cf * (1.0 - t_mul)) / math.log(t_mul))
+        cf = (cf - (1.0 - t_mul ** i) / (1.0 - t_mul)) / t_mul ** i
+    cosine = 0.5 * (m_mul ** i) * (1 + math.cos(math.pi * cf))
+    return learning_rate * ((1 - alpha) * cosine + alpha)
+
+
+def noisy_linear_cosine_decay(learning_rate, global_step, decay_steps, initial_variance=1.0, variance_decay=0.55,
+                              num_periods=0.5, alpha=0.0, beta=0.001, generator=None, **_):
+    step = min(global_step, decay_steps)
+    std = math.sqrt(initial_variance / (1 + step) ** variance_decay)
+    noise = float(torch.randn((), generator=generator)) * std
+    linear = 1.0 - step / decay_steps + noise
+    cosine = 0.5 * (1 + math.cos(math.pi * 2.0 * num_periods * step / decay_steps))
+    return learning_rate * ((alpha + linear) * cosine + beta)
+
+
+DECAY_METHODS = {   # _DECAY_METHOD_NAME, DeepCrossNetwork.py:26-31
+    "exponential_decay": exponential_decay, "piecewise_constant": piecewise_constant, "polynomial_decay": polynomial_decay,
+    "cosine_decay": cosine_decay, "cosine_decay_restarts": cosine_decay_restarts,
+    "noisy_linear_cosine_decay": noisy_linear_cosine_decay,
+}
+
+
+def learning_rate_decay(learning_rate_spec, global_step):
+    """_learning_rate_decay(params), DeepCrossNetwork.py:422-447 (same error texts)."""
+    if not isinstance(learning_rate_spec, dict):
+        raise ValueError("learning_rate_spec must be a dict.")
+    spec = dict(learning_rate_spec)
+    spec["global_step"] = global_step
+    name = spec.pop("decay_method", None)
+    if name is None:                                    # _no_decay, :450-456
+        if "learning_rate" not in spec:
+            raise KeyError("learning rate must be provided in no_decay.")
+        return spec["learning_rate"]
+    if name not in DECAY_METHODS:
+        raise ValueError("Unsupported learning rate name: {}. Supported names are: {}".format(name, tuple(sorted(DECAY_METHODS))))
+    try:
+        return DECAY_METHODS[name](**spec)
+    except TypeError:
+        raise TypeError("{} argument are not correct. Check again and note that global_step is omitted.".format(name))
+
+
+def clip_by_norm_(grad, clip_norm=CLIP_NORM):
+    """tf.clip_by_norm on one tensor, in place: g * clip / max(||g||_2, clip).  Sparse gradients: over their values."""
+    if grad is None:
+        return None
+    vals = grad.coalesce().values() if grad.is_sparse else grad
+    norm = torch.linalg.vector_norm(vals.float())
+    scale = clip_norm / torch.clamp(norm, min=clip_norm)
+    if grad.is_sparse:
+        g = grad.coalesce()
+        return torch.sparse_coo_tensor(g.indices(), g.values() * scale, g.shape)
+    return grad.mul_(scale)
+
+
+_OPTIMIZERS = {"Adam": torch.optim.Adam, "Adagrad": torch.optim.Adagrad, "SGD": torch.optim.SGD, "RMSProp": torch.optim.RMSprop}
+_SPEC_KEYS = {"epsilon": "eps", "beta1": None, "beta2": None}   # tf.train.AdamOptimizer names -> torch names
+
+
+class TrainStep:
+    """train_op of the reference DCN (_get_train_op_fn): one call = backward + per-tensor clip + optimizer step with the
+    decayed learning rate, global_step += 1.  `optimizer` is a torch optimizer class or one of the names above;
+    `optimizer_spec` uses the tf.train names (epsilon, beta1, beta2)."""
+
+    def __init__(self, model, optimizer="Adam", optimizer_spec=None, learning_rate_spec=None, l2_reg=None, l2_params=None):
+        if not isinstance(optimizer_spec or {}, dict):
+            raise ValueError("optimizer_spec must be a dict.")
+        spec = dict(optimizer_spec or {})
+        spec.pop("learning_rate", None)                               # :275-279
+        self.learning_rate_spec = dict(learning_rate_spec or {"learning_rate": 0.001})
+        self.global_step = 0
+        kw = {}
+        betas = [0.9, 0.999]
+        for k, v in spec.items():
+            if k == "beta1":
+                betas[0] = v
+            elif k == "beta2":
+                betas[1] = v
+            else:
+                kw[_SPEC_KEYS.get(k, k) or k] = v
+        cls = _OPTIMIZERS[optimizer] if isinstance(optimizer, str) else optimizer
+        if cls is torch.optim.Adam:
+            kw["betas"] = tuple(betas)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.optimizer = cls(self.params, lr=learning_rate_decay(self.learning_rate_spec, 0), **kw)
+        self.l2_reg, self.l2_params = l2_reg, list(l2_params or [])
+
+    def __call__(self, loss):
+        if self.l2_reg:                                               # :181-183 (tf.nn.l2_loss = sum(w^2)/2)
+            loss = loss + self.l2_reg * sum(0.5 * (w * w).sum() for w in self.l2_params)
+        lr = learning_rate_decay(self.learning_rate_spec, self.global_step)
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        for p in self.params:
+            if p.grad is not None:
+                g = clip_by_norm_(p.grad)
+                p.grad = g.to_dense() if g.is_sparse else g           # torch's Adam/Adagrad here take dense gradients
+        self.optimizer.step()
+        self.global_step += 1
+        return loss.detach(), lr

@@ -319,3 +319,103 @@ def test_xdeepfm_training_step(built_lib):
         opt_s.step()
         losses.append(float(loss))
     assert losses[-1] < 0.8 * losses[0], losses[::6]
+
+
+# ---- DIN backward (no reference code; derivatives of the unit defined in include/dir_hip.h A13) ---------------------
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("B,T,K,H1,H2,V", [(33, 50, 64, 80, 40, 500), (17, 7, 16, 12, 8, 40), (9, 20, 32, 36, 20, 64)])
+def test_din_autograd_matches_float64(built_lib, normalize, B, T, K, H1, H2, V):
+    from dir_amd import autograd as ag
+    g = torch.Generator().manual_seed(B + T)
+    table = torch.randn(V, K, generator=g) * 0.3
+    hist = torch.randint(0, V, (B, T), generator=g)
+    hist[1, 2] = -1                                           # a pruned id inside the valid range
+    hl = torch.randint(0, T + 1, (B,), generator=g).int()
+    hl[0] = 0                                                 # an empty history
+    cand = torch.randint(0, V, (B,), generator=g)
+    Ws = [torch.randn(4 * K, H1, generator=g) * 0.2, torch.randn(H1, generator=g) * 0.1, torch.randn(H1, H2, generator=g) * 0.3,
+          torch.randn(H2, generator=g) * 0.1, torch.randn(H2, generator=g) * 0.4, torch.randn(1, generator=g) * 0.1]
+    gout = torch.randn(B, K, generator=g)
+
+    # float64 dense restatement of the definition
+    t64 = table.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in Ws]
+    h = t64[hist.clamp(min=0)]                                 # [B,T,K]
+    a = t64[cand].unsqueeze(1).expand(B, T, K)
+    u = torch.cat([h, a, h - a, h * a], dim=2)
+    s = torch.sigmoid(torch.sigmoid(u @ w64[0] + w64[1]) @ w64[2] + w64[3]) @ w64[4] + w64[5]
+    valid = (torch.arange(T).unsqueeze(0) < hl.unsqueeze(1)) & (hist >= 0)
+    if normalize:
+        x = (s / K ** 0.5).masked_fill(~valid, float("-inf"))
+        w = torch.softmax(x, dim=1)
+        w = torch.where(valid, w, torch.zeros_like(w))
+    else:
+        w = torch.where(valid, s, torch.zeros_like(s))
+    out64 = (w.unsqueeze(2) * h).sum(1)
+    out64.backward(gout.double())
+
+    tab = table.cuda().requires_grad_(True)
+    ws = [w.cuda().requires_grad_(True) for w in Ws]
+    out = ag.din_attention_pool(tab, hist.cuda(), hl.cuda(), cand.cuda(), *ws, normalize=normalize)
+    _close(out, out64, tol=2e-5)
+    out.backward(gout.cuda())
+    assert tab.grad.is_sparse
+    _close(tab.grad.to_dense(), t64.grad, tol=2e-5)
+    for w, r in zip(ws, w64):
+        _close(w.grad, r.grad, tol=5e-5)
+
+
+def test_din_module_training_step(built_lib):
+    from dir_amd.din import DINAttentionPool
+    torch.manual_seed(3)
+    V, K, B, T = 200, 16, 128, 12
+    pool = DINAttentionPool(V, embedding_dim=K, hidden_units=(16, 8), normalize=True).cuda()
+    head = torch.nn.Linear(K, 1).cuda()
+    g = torch.Generator().manual_seed(4)
+    hist = torch.randint(0, V, (B, T), generator=g).cuda()
+    hl = torch.randint(1, T + 1, (B,), generator=g).int().cuda()
+    cand = torch.randint(0, V, (B,), generator=g).cuda()
+    y = (cand % 2).float().reshape(B, 1)
+    dense = [p for n, p in pool.named_parameters() if n != "table"] + list(head.parameters())
+    opt = torch.optim.Adagrad(dense, lr=0.1)
+    opt_t = torch.optim.SGD([pool.table], lr=1.0)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad(set_to_none=True)
+        opt_t.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(head(pool(hist, hl, cand)), y)
+        loss.backward()
+        assert pool.table.grad.is_sparse
+        opt.step()
+        opt_t.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.85 * losses[0], losses[::8]
+
+
+def test_dcn_reference_train_step(built_lib):
+    """DeepCrossNetwork.train_step(): the reference train_op (Adam eps 1e-4, cosine decay, per-tensor clip_by_norm 100,
+    DeepCrossNetwork.py:264-290 with the spec of DeepCrossNetwork/train.py:111-125) over the HIP forward/backward."""
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd import feature_column as fc
+    torch.manual_seed(1)
+    B, F, K, V = 512, 5, 8, 30
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    ids = torch.randint(0, V, (B, F))
+    labels = (ids[:, 0] < V // 2).float().reshape(B, 1).cuda()
+    feats = {"C%d" % i: ids[:, i].cuda() for i in range(F)}
+    feats["x"] = torch.rand(B).cuda()
+    dcn = DeepCrossNetwork(columns=[fc.embedding_column(c, K) for c in cats] + [fc.numeric_column("x")], cross_layer_num=2,
+                           dnn_hidden_units=[32, 16], batch_norm=False, l2_reg=1e-4, optimizer="Adam",
+                           optimizer_spec={"epsilon": 1e-4, "learning_rate": 123.0},     # the spec's own lr is dropped (:275-279)
+                           learning_rate_spec={"learning_rate": 0.02, "decay_method": "cosine_decay", "decay_steps": 40,
+                                               "alpha": 0.5}).cuda()
+    step = dcn.train_step()
+    assert step.optimizer.defaults["eps"] == 1e-4
+    losses, lrs = [], []
+    for _ in range(50):
+        loss, lr = step(torch.nn.functional.binary_cross_entropy_with_logits(dcn(feats), labels))
+        losses.append(float(loss))
+        lrs.append(lr)
+    assert lrs[0] == pytest.approx(0.02) and lrs[40] == pytest.approx(0.01) and lrs[-1] == pytest.approx(0.01)
+    assert step.global_step == 50
+    assert losses[-1] < 0.8 * losses[0], losses[::10]

@@ -155,3 +155,54 @@ def test_tf_checkpoint_mapping_roundtrip(built_lib, tmp_path):
     m = ck.tf_variable_map(fresh("dcn"))
     assert "dcn_model/input_from_feature_columns/cross_w" in m and "dcn_model/logits/dense/kernel" in m
     assert "esmm/cvr_model/hiddenlayer_1/kernel" in ck.tf_variable_map(fresh("esmm"))
+
+
+# ---- DCN training spec (DeepCrossNetwork.py:264-290, 422-458; [TF-upstream] tf.train decay formulas) -----------------
+def test_learning_rate_decay_methods():
+    import math
+    import dir_amd  # noqa: F401
+    from dir_amd import train_spec as ts
+    spec = {"learning_rate": 0.001, "decay_method": "cosine_decay", "decay_steps": 3000, "alpha": 0.5}   # train.py:121-124
+    assert ts.learning_rate_decay(spec, 0) == pytest.approx(0.001)
+    assert ts.learning_rate_decay(spec, 1500) == pytest.approx(0.00075)
+    assert ts.learning_rate_decay(spec, 3000) == pytest.approx(0.0005)
+    assert ts.learning_rate_decay(spec, 99999) == pytest.approx(0.0005)
+    assert spec == {"learning_rate": 0.001, "decay_method": "cosine_decay", "decay_steps": 3000, "alpha": 0.5}   # not mutated
+    assert ts.learning_rate_decay({"learning_rate": 0.01}, 7) == 0.01                                       # _no_decay
+    with pytest.raises(KeyError):
+        ts.learning_rate_decay({}, 0)
+    with pytest.raises(ValueError, match="Unsupported learning rate name"):
+        ts.learning_rate_decay({"learning_rate": 0.1, "decay_method": "nope"}, 0)
+    with pytest.raises(TypeError, match="argument are not correct"):
+        ts.learning_rate_decay({"learning_rate": 0.1, "decay_method": "cosine_decay"}, 0)               # decay_steps missing
+    e = {"learning_rate": 0.1, "decay_method": "exponential_decay", "decay_steps": 100, "decay_rate": 0.5}
+    assert ts.learning_rate_decay(e, 100) == pytest.approx(0.05)
+    assert ts.learning_rate_decay(e, 150) == pytest.approx(0.1 * 0.5 ** 1.5)
+    assert ts.learning_rate_decay(dict(e, staircase=True), 150) == pytest.approx(0.05)
+    pw = {"decay_method": "piecewise_constant", "boundaries": [10, 20], "values": [1.0, 0.5, 0.1]}
+    assert [ts.learning_rate_decay(pw, s) for s in (0, 10, 11, 20, 21)] == [1.0, 1.0, 0.5, 0.5, 0.1]
+    po = {"learning_rate": 0.1, "decay_method": "polynomial_decay", "decay_steps": 100, "end_learning_rate": 0.01, "power": 2.0}
+    assert ts.learning_rate_decay(po, 50) == pytest.approx(0.09 * 0.25 + 0.01)
+    assert ts.learning_rate_decay(po, 500) == pytest.approx(0.01)
+    assert ts.learning_rate_decay(dict(po, cycle=True), 150) == pytest.approx(0.09 * 0.25 ** 2 + 0.01)     # period 200
+    cr = {"learning_rate": 1.0, "decay_method": "cosine_decay_restarts", "first_decay_steps": 10}
+    assert ts.learning_rate_decay(cr, 0) == pytest.approx(1.0)
+    assert ts.learning_rate_decay(cr, 10) == pytest.approx(1.0)                                             # restart
+    assert ts.learning_rate_decay(cr, 20) == pytest.approx(0.5 * (1 + math.cos(math.pi * 0.5)))            # 2nd period is 20 long
+    assert ts.learning_rate_decay(dict(cr, t_mul=1.0, m_mul=0.5), 15) == pytest.approx(0.5 * 0.5 * (1 + math.cos(math.pi * 0.5)))
+    nl = {"learning_rate": 1.0, "decay_method": "noisy_linear_cosine_decay", "decay_steps": 100, "initial_variance": 0.0}
+    assert ts.learning_rate_decay(nl, 50) == pytest.approx((0.5) * 0.5 * (1 + math.cos(math.pi * 0.5)) + 0.001)
+
+
+def test_clip_by_norm_per_tensor():
+    import dir_amd  # noqa: F401
+    from dir_amd import train_spec as ts
+    g = torch.full((4, 100), 10.0)                     # norm 200 -> scaled to 100
+    out = ts.clip_by_norm_(g.clone())
+    assert torch.linalg.vector_norm(out).item() == pytest.approx(100.0, rel=1e-6)
+    small = torch.ones(5)
+    assert torch.equal(ts.clip_by_norm_(small.clone()), small)
+    sp = torch.sparse_coo_tensor(torch.tensor([[1, 3, 1]]), torch.full((3, 2), 100.0), (5, 2))
+    out = ts.clip_by_norm_(sp)
+    assert out.is_sparse and torch.linalg.vector_norm(out.to_dense()).item() == pytest.approx(100.0, rel=1e-6)
+    assert ts.clip_by_norm_(None) is None
