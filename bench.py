@@ -336,7 +336,7 @@ def main():
 
     elif wl == "cin_backward":
         # backward of the 3-layer CIN stack given dL/dpooled (the forward's saved activations are inputs):
-        # per layer dW (cin_dw_k, fp32 MFMA) + dxk, dx0 (the forward kernel on permuted weights)
+        # per layer dW (cin_dw_k) + dxk and dx0 in one pass (cin_dx_k), both fp32 MFMA
         m, D, Hs = F, K, (128, 128, 128)
         x0 = torch.randn((B, m, D), generator=gen, device=device) * 0.25
         Ws, hp = [], m
@@ -359,10 +359,10 @@ def main():
                 G = g_p.expand(B, h, D).contiguous() if gx is None else gx.add_(g_p)
                 dx0, gx, dW = ops.cin_layer_backward(x0, xks[k], Ws[k], G)
         flops, hp = 0, m
-        for h in Hs:
-            flops += 3 * 2 * B * D * hp * m * h
+        for h in Hs:      # two GEMMs of the forward's size per layer: dW (reduction over rows) and T = G x W (both data gradients)
+            flops += 2 * 2 * B * D * hp * m * h
             hp = h
-        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_dw_k + cin_k (dxk, dx0) x3"}
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_dw_k + cin_dx_k, x3"}
         cfg.update({"m": m, "D": D, "layers": list(Hs)})
 
     # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------

@@ -14,6 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libdir_hip.so")
 SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "cin.hip", "cin_bwd.hip", "backward.hip"]
+# per-file flags: cin_bwd's epilogues read the MFMA results on the VALU, so keep them in VGPRs (no v_accvgpr_read)
+EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
          "-Wall", "-Wno-unused-function"]
@@ -29,7 +31,7 @@ def _compile(src):
     o = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
     if os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), _deps_mtime()):
         return o
-    cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr))

@@ -246,6 +246,237 @@ __global__ __launch_bounds__(256) void cin_dw_reduce_k(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Data gradients of one CIN layer, both from ONE pass:
+//   T_j[r, i]  = sum_h G[r,h] * W[h, i*m + j]          plain GEMM per j: A = G (row tile x H), B = W_j (H x Hp)
+//   dxk[r, i] += x0[r, j] * T_j[r, i]                   FMA epilogue, accumulated over j in registers
+//   dx0[r, j]  = sum_i xk[r, i] * T_j[r, i]             reduction over the columns = over the 32 lanes of a half-wave
+// A is stationary: a wave keeps its 32-row slice of G in HT/2 registers (lane = row l&31, k parity l>>5) for the
+// whole kernel; W_j streams through LDS, double buffered, one barrier per j (HT/2 * CT MFMAs per wave).  The host
+// passes W already permuted to the LDS image Wp[j][h][n][cc] = W[h, (32*cc + n)*m + j] (zero for 32*cc + n >= Hp),
+// so staging is 16-byte loads and 16-byte LDS stores at the same offsets and a lane's CT B operands of a k-step are one
+// ds_read_b128.  MFMA count = rows/32 * ceil(Hp/32) * m * HT/2: no padding of the 26 fields (the forward kernel
+// run on permuted weights pads the 26 output columns to 32 and needs two passes: 21 ms -> ~7 ms per 128-wide layer).
+// Limits (the host mirror falls back to the forward-kernel formulation otherwise): H <= 128, Hp <= 128, m <= 64.
+// ------------------------------------------------------------------------------------------------------------------
+// Sums of 16 per-lane values over the 32 lanes of each half-wave.  v_permlane16_swap (gfx950) exchanges the odd rows of
+// one register with the even rows of another, so ONE add folds the two 16-lane rows of a half for TWO values at once:
+// afterwards rows 0/2 carry values 0..7 and rows 1/3 values 8..15, and only 8 registers go through the in-row DPP steps.
+__device__ __forceinline__ void half32_sum16(const float (&v)[16], float (&u)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        // inline asm: with this compiler the builtin's two results fold to the same register when both feed one add
+        float a = v[q], b = v[q + 8];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        u[q] = row16_sum(a + b);
+    }
+}
+
+template <int CT /* column tiles: ceil(Hp/32) rounded to 1, 2, 4 */, int HT /* H padded: 32, 64, 128 */>
+__global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0, const float* __restrict__ xk,
+                                                   const float* __restrict__ Wp /* [m][H][32][CT] */,
+                                                   const float* __restrict__ G, int m, int Hp, int H, int D, int dshift,
+                                                   int64_t R, float* __restrict__ dxk, float* __restrict__ dx0) {
+    constexpr int KS = HT / 2;                 // k-steps per j
+    constexpr int WJ = HT * 32 * CT;           // floats of one W_j image (rows h >= H stay zero)
+    constexpr int NV = WJ / 4 / 256;           // float4 per thread per j
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wb = smem;                          // [2][WJ]
+    float* x0s = smem + 2 * WJ;                // [m][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;     // this wave's row tile
+    const int wrows = H * 32 * CT;             // valid floats of a W_j image
+
+    // ---- one-time loads ---------------------------------------------------------------------------------------------
+    // A operand: ga[s] = G[row0 + n, h = 2s + hh]
+    float ga[KS];
+    {
+        const int64_t r = row0 + n;
+        const bool ok = r < R;
+        const int64_t rc = ok ? r : R - 1;
+        const float* src = G + ((rc >> dshift) * H) * D + (rc & (D - 1));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int h = 2 * s + hh;
+            ga[s] = (ok && h < H) ? src[(int64_t)h * D] : 0.f;
+        }
+    }
+    // C/D rows of this lane: rr(reg) = (reg&3) + 8*(reg>>2) + 4*hh; 4 consecutive regs = 4 consecutive rows (same sample)
+    float xkv[CT][16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int64_t r = row0 + 8 * g + 4 * hh;
+        const bool ok = r < R;
+        const int64_t rc = ok ? r : R - 4;
+        const float* src = xk + ((rc >> dshift) * Hp) * D + (rc & (D - 1));
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) {
+            const int i = 32 * cc + n;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && i < Hp) v = *reinterpret_cast<const float4*>(src + (int64_t)i * D);
+            xkv[cc][4 * g] = v.x; xkv[cc][4 * g + 1] = v.y; xkv[cc][4 * g + 2] = v.z; xkv[cc][4 * g + 3] = v.w;
+        }
+    }
+    // x0 slice of the workgroup's 128 rows, [j][row]; zero the W rows h in [H, HT) of both buffers once
+    for (int e = tid; e < m * 128; e += 256) {
+        const int j = e >> 7, rl = e & 127;
+        const int64_t r = (int64_t)blockIdx.x * 128 + rl;
+        x0s[e] = r < R ? x0[((r >> dshift) * m + j) * D + (r & (D - 1))] : 0.f;
+    }
+    for (int e = wrows + tid; e < WJ; e += 256) { Wb[e] = 0.f; Wb[WJ + e] = 0.f; }
+
+    // W_{j+1} is staged in NP parts (fewer live registers; the second part's loads sit mid-way in the MFMA stream)
+    constexpr int NP = NV >= 2 ? 2 : 1, NVP = NV / NP;
+    float4 wst[NVP];
+    auto w_load = [&](int j, int part) {
+        const float4* src = reinterpret_cast<const float4*>(Wp + (int64_t)j * wrows);
+#pragma unroll
+        for (int q = 0; q < NVP; ++q) {
+            const int e4 = tid + 256 * (part * NVP + q);
+            wst[q] = (e4 * 4 < wrows) ? src[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto w_store = [&](int buf, int part) {
+        float4* dst = reinterpret_cast<float4*>(Wb + buf * WJ);
+#pragma unroll
+        for (int q = 0; q < NVP; ++q) {
+            const int e4 = tid + 256 * (part * NVP + q);
+            if (e4 * 4 < wrows) dst[e4] = wst[q];
+        }
+    };
+#pragma unroll
+    for (int part = 0; part < NP; ++part) {
+        w_load(0, part);
+        w_store(0, part);
+    }
+    __syncthreads();
+
+    f32x16 dk[CT];
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dk[cc][q] = 0.f;
+
+    for (int j = 0; j < m; ++j) {
+        const int buf = j & 1;
+        const bool more = j + 1 < m;
+        if (more) w_load(j + 1, 0);
+        const float* wb = Wb + buf * WJ + (hh * 32 + n) * CT;      // [h][n][cc]: h = 2s + hh
+        f32x16 T[CT];
+        // bursts of 2 k-steps = 2*CT MFMAs; operand reads run one burst ahead (cin.hip)
+        float bw[2][CT];
+        auto read_b = [&](int s, float (&o)[CT]) {
+            const float* src = wb + s * (2 * 32 * CT);
+            if (CT == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                o[0] = v.x; o[1 % CT] = v.y; o[2 % CT] = v.z; o[3 % CT] = v.w;
+            } else if (CT == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(src);
+                o[0] = v.x; o[1 % CT] = v.y;
+            } else {
+                o[0] = src[0];
+            }
+        };
+        read_b(0, bw[0]);
+        read_b(1, bw[1]);
+#pragma unroll
+        for (int s = 0; s < KS; s += 2) {
+            float bn[2][CT];
+            if (s + 2 < KS) {
+                read_b(s + 2, bn[0]);
+                read_b(s + 3, bn[1]);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < CT; ++cc) { bn[0][cc] = bw[0][cc]; bn[1][cc] = bw[1][cc]; }
+            }
+            if (NP == 2 && s == (KS / 4) * 2 && more) {   // mid-way: first part to LDS, second part's loads
+                w_store(buf ^ 1, 0);
+                w_load(j + 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int cc = 0; cc < CT; ++cc) {
+                    if (s + e == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) z[q] = 0.f;
+                        T[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[0], bw[0][cc], z, 0, 0, 0);
+                    } else {
+                        T[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s + e], bw[e][cc], T[cc], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 0; cc < CT; ++cc) { bw[0][cc] = bn[0][cc]; bw[1][cc] = bn[1][cc]; }
+        }
+        // ---- epilogue of j ------------------------------------------------------------------------------------------
+        float x0v[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4*>(x0s + j * 128 + wave * 32 + 8 * g + 4 * hh);
+            x0v[4 * g] = v.x; x0v[4 * g + 1] = v.y; x0v[4 * g + 2] = v.z; x0v[4 * g + 3] = v.w;
+        }
+        float p[16], u[8];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float acc = T[0][q] * xkv[0][q];
+#pragma unroll
+            for (int cc = 1; cc < CT; ++cc) acc = __builtin_fmaf(T[cc][q], xkv[cc][q], acc);
+            p[q] = acc;
+#pragma unroll
+            for (int cc = 0; cc < CT; ++cc) dk[cc][q] = __builtin_fmaf(x0v[q], T[cc][q], dk[cc][q]);
+        }
+        half32_sum16(p, u);
+        if ((lane & 15) == 0) {   // rows 0/2 hold the totals of C/D regs 0..7, rows 1/3 of regs 8..15: 2 runs of 4 rows (d) each
+            const int gsel = (lane >> 4) & 1;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int64_t r = row0 + 8 * (2 * gsel + e) + 4 * hh;
+                if (r < R)
+                    *reinterpret_cast<float4*>(dx0 + ((r >> dshift) * m + j) * D + (r & (D - 1))) =
+                        make_float4(u[4 * e], u[4 * e + 1], u[4 * e + 2], u[4 * e + 3]);
+            }
+        }
+        if (more) w_store(buf ^ 1, NP - 1);
+        __syncthreads();
+    }
+
+    // ---- dxk: C/D map col = lane&31 (i within the column tile), rows as above ------------------------------------------
+#pragma unroll
+    for (int cc = 0; cc < CT; ++cc) {
+        const int i = 32 * cc + n;
+        if (i >= Hp) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t r = row0 + 8 * g + 4 * hh;
+            if (r < R)
+                *reinterpret_cast<float4*>(dxk + ((r >> dshift) * Hp + i) * D + (r & (D - 1))) =
+                    make_float4(dk[cc][4 * g], dk[cc][4 * g + 1], dk[cc][4 * g + 2], dk[cc][4 * g + 3]);
+        }
+    }
+}
+
+template <int CT, int HT>
+static void launch_cin_dx(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* Wp,
+                          const float* G, int m, int Hp, int H, int D, int dshift, int64_t R, float* dxk, float* dx0) {
+    static bool set = false;
+    if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        set = true;
+    }
+    hipLaunchKernelGGL((cin_dx_k<CT, HT>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+}
+
+template <int CT>
+static void launch_cin_dx_ct(int ht, dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* Wp,
+                             const float* G, int m, int Hp, int H, int D, int dshift, int64_t R, float* dxk, float* dx0) {
+    if (ht == 32) launch_cin_dx<CT, 32>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else if (ht == 64) launch_cin_dx<CT, 64>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else launch_cin_dx<CT, 128>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+}
+
 struct CinDwPlan { int nwg, nslot, nhb; int64_t NQ, L; };
 static CinDwPlan cin_dw_plan(int m, int Hp, int H, int D, int64_t B) {
     CinDwPlan p;
@@ -300,5 +531,30 @@ extern "C" int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, 
     hipLaunchKernelGGL(cin_dw_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(workspace),
                        p.nwg, p.nslot, p.NQ, p.L, H, (int)Kd, accumulate, dW);
     DIR_CHECK_LAUNCH("cin_dw_reduce");
+    return DIR_OK;
+}
+
+extern "C" int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp, const float* G, int m, int Hp, int H, int D,
+                              int64_t B, float* dxk, float* dx0, dir_stream_t stream) {
+    DIR_CHECK_ARG(x0 && xk && Wp && G && dxk && dx0, "dir_cin_dx_f32: null pointer");
+    DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "dir_cin_dx_f32: m=%d Hp=%d H=%d D=%d", m, Hp, H, D);
+    if (!(D == 4 || D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "dir_cin_dx_f32: D=%d (supported: 4, 8, 16, 32)", D);
+    if (H > 128 || Hp > 128 || m > 64)
+        return fail(DIR_E_UNSUPPORTED, "dir_cin_dx_f32: needs H <= 128, Hp <= 128, m <= 64 (H=%d Hp=%d m=%d): use the forward formulation", H, Hp, m);
+    if (!(aligned16(x0) && aligned16(xk) && aligned16(Wp) && aligned16(G) && aligned16(dxk) && aligned16(dx0)))
+        return fail(DIR_E_BADARG, "dir_cin_dx_f32: all tensors must be 16-byte aligned");
+    if (B == 0) return DIR_OK;
+    int dshift = 0;
+    while ((1 << dshift) < D) ++dshift;
+    const int64_t R = B * D;
+    const int ct = Hp <= 32 ? 1 : Hp <= 64 ? 2 : 4;
+    const int ht = H <= 32 ? 32 : H <= 64 ? 64 : 128;
+    const size_t shmem = sizeof(float) * (2 * (size_t)ht * 32 * ct + (size_t)m * 128);
+    dim3 grid((unsigned)((R + 127) / 128));
+    hipStream_t st = as_stream(stream);
+    if (ct == 1) launch_cin_dx_ct<1>(ht, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else if (ct == 2) launch_cin_dx_ct<2>(ht, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else launch_cin_dx_ct<4>(ht, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    DIR_CHECK_LAUNCH("cin_dx");
     return DIR_OK;
 }

@@ -255,6 +255,12 @@ int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const float* w, co
  * 16-byte aligned.  Row ranges are reduced in a fixed order: bitwise reproducible.
  * ------------------------------------------------------------------------------------------ */
 int64_t dir_cin_dw_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
+/* dir_cin_dx_f32: both data gradients in one pass (T_j = G x W_j on fp32 MFMA with G held in registers, then an FMA
+ * epilogue for dxk and a half-wave reduction for dx0).  Wp is W permuted to [m][H][32][CT], CT = 1, 2 or 4 column
+ * tiles covering Hp: Wp[j][h][n][cc] = W[h, (32*cc + n)*m + j], zero where 32*cc + n >= Hp.
+ * Limits: H <= 128, Hp <= 128, m <= 64 (DIR_E_UNSUPPORTED otherwise: use the dir_cin_layer_f32 formulation above). */
+int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp, const float* G, int m, int Hp, int H, int D,
+                   int64_t B, float* dxk, float* dx0, dir_stream_t stream);
 int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,
                    int accumulate, float* dW, void* workspace, dir_stream_t stream);
 

@@ -232,6 +232,10 @@ def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
     dx0, dxk, dW = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G))
     _close(dxk, ref_dxk)
     _close(dx0, ref_dx0)
+    # the other formulation of the data gradients (forward kernel on permuted weights; the only one for H or Hp > 128)
+    fx0, fxk, _ = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G), need_w=False, force_forward_form=True)
+    _close(fxk, ref_dxk)
+    _close(fx0, ref_dx0)
     # dW sums B*D fp32 terms: scale the tolerance by the magnitude that was summed
     mag = np.sqrt(B * D) * 0.125 + 1.0
     err = np.abs(dW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
@@ -317,7 +321,7 @@ def test_xdeepfm_training_step(built_lib):
         assert all(w.grad is not None for w in model.cin_W)
         opt.step()
         opt_s.step()
-        losses.append(float(loss))
+        losses.append(loss.item())
     assert losses[-1] < 0.8 * losses[0], losses[::6]
 
 
@@ -414,7 +418,7 @@ def test_dcn_reference_train_step(built_lib):
     losses, lrs = [], []
     for _ in range(50):
         loss, lr = step(torch.nn.functional.binary_cross_entropy_with_logits(dcn(feats), labels))
-        losses.append(float(loss))
+        losses.append(loss.item())
         lrs.append(lr)
     assert lrs[0] == pytest.approx(0.02) and lrs[40] == pytest.approx(0.01) and lrs[-1] == pytest.approx(0.01)
     assert step.global_step == 50
