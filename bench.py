@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--id-dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--id-layout", default="bf", choices=["bf", "fb"], help="ids stored [B,F] or [F,B]")
     ap.add_argument("--rotate", type=int, default=4, help="distinct id batches rotated through")
+    ap.add_argument("--adagrad-method", default="sorted", choices=["sorted", "chains"], help="train_sparse: SparseAdagrad method")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -203,7 +204,7 @@ def main():
         sigma = 1.0 / (K ** 0.5)
         tables = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
         ts = ops.TableSet(tables)
-        opt = ops.SparseAdagrad(ts, lr=0.01)
+        opt = ops.SparseAdagrad(ts, lr=0.01, method=args.adagrad_method)
         idsl = make_ids(torch, args, gen, device, V)
         out = torch.empty((B, F * K), dtype=torch.float32, device=device)
         fm = torch.empty((B, 1), dtype=torch.float32, device=device)
@@ -218,8 +219,9 @@ def main():
             opt.step(ids, demb)
         # forward 3 540 B + FM backward (emb, dnn grad read, demb written) + adagrad (ids, demb, w and accum read+write)
         roof = {"bound": "hbm", "alg_bytes": B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)),
-                "kernel": "gather_onehot_k + fm_bwd_k + adagrad_link_k + adagrad_apply_k"}
-        cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
+                "kernel": "gather_onehot_k + fm_bwd_k + " + ("adagrad_keys_k + rocprim radix sort + adagrad_tile_k + adagrad_fix_k"
+                                                            if args.adagrad_method == "sorted" else "adagrad_link_k + adagrad_apply_k")}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "adagrad": args.adagrad_method, "ids": args.id_dist})
     elif wl == "small_batch":
         # the reference's own batch size (256, DeepCrossNetwork/train.py:17): launch-bound; eager vs HIP-graph replay
         from dir_amd.deepfm import DeepFM

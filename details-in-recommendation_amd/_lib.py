@@ -35,6 +35,9 @@ SIGNATURES = {
                                            c_vp, c_vp]),
     "dir_sparse_adagrad_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.c_float, c_i64, c_vp,
                                        c_vp, c_vp, c_vp]),
+    "dir_sparse_adagrad_sorted_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i64]),
+    "dir_sparse_adagrad_sorted_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.c_float, c_i64,
+                                              c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_din_attention_pool_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                            c_i32, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "dir_cin_layer_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp]),

@@ -14,6 +14,8 @@
 // Cross backward gives one row to a wave: x_0..x_L of the row are recomputed into an LDS slab, the weight /
 // bias gradients accumulate in per-wave LDS slabs (lane-private addresses, no atomics), each workgroup writes
 // one partial [2, L, d] and a second launch adds the partials in a fixed order (bitwise reproducible).
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "common.hpp"
 
 namespace dir {
@@ -261,9 +263,227 @@ __global__ __launch_bounds__(256) void adagrad_apply_k(float* const* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sorted sparse Adagrad: the chain walk above serialises on hot rows (Zipf ids: one thread group sums thousands of
+// gradient rows).  Here the (global row, entry) pairs are radix-sorted (rocPRIM, stable: duplicates keep their batch
+// order, so every sum has a fixed order), a workgroup reduces the runs of equal rows inside its tile of 256 sorted
+// entries and applies the update for runs that lie inside the tile; a run that crosses tile borders leaves one
+// partial per tile (`carry`) and adagrad_fix_k adds them in tile order.  No atomics, bitwise reproducible, and the
+// longest serial walk is 256 entries whatever the skew.
+// ------------------------------------------------------------------------------------------------
+constexpr int ADA_TILE = 256;
+
+__global__ __launch_bounds__(256) void adagrad_keys_k(const int64_t* __restrict__ ids, int64_t sb, int64_t sf, int F, int64_t n,
+                                                      const int64_t* __restrict__ row_base, uint32_t total_rows,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / F;
+        const int f = (int)(e - b * F);
+        const int64_t id = ids[b * sb + f * sf];
+        keys[e] = id >= 0 ? (uint32_t)(row_base[f] + id) : total_rows;     // pruned ids sort behind every row
+        vals[e] = (uint32_t)e;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void adagrad_apply_row(float* __restrict__ ap, float* __restrict__ wp, typename BV<VEC>::T g, float lr) {
+    using V = BV<VEC>;
+    typename V::T acc = V::ld(ap), wv = V::ld(wp);
+    if constexpr (VEC == 4) {
+        acc = make_float4(acc.x + g.x * g.x, acc.y + g.y * g.y, acc.z + g.z * g.z, acc.w + g.w * g.w);
+        wv = make_float4(wv.x - lr * g.x / sqrtf(acc.x), wv.y - lr * g.y / sqrtf(acc.y), wv.z - lr * g.z / sqrtf(acc.z),
+                         wv.w - lr * g.w / sqrtf(acc.w));
+    } else {
+        acc = acc + g * g;
+        wv = wv - lr * g / sqrtf(acc);
+    }
+    V::st(ap, acc);
+    V::st(wp, wv);
+}
+
+template <int LPS, int VEC>
+__global__ __launch_bounds__(256) void adagrad_tile_k(float* const* __restrict__ tables, float* const* __restrict__ accums, int F, int K,
+                                                      int64_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                      const float* __restrict__ grad, int64_t g_ld, float lr,
+                                                      const int64_t* __restrict__ row_base, uint32_t total_rows,
+                                                      float* __restrict__ carry /* [tiles][2][K] */) {
+    using V = BV<VEC>;
+    using T = typename V::T;
+    constexpr int NG = 256 / LPS;
+    __shared__ uint32_t skey[ADA_TILE], sval[ADA_TILE];
+    __shared__ int rstart[ADA_TILE + 1];
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t = blockIdx.x, e0 = t * ADA_TILE;
+    const int ne = (int)((n - e0) < ADA_TILE ? (n - e0) : ADA_TILE);
+    const bool in = tid < ne;
+    const uint32_t key = in ? keys[e0 + tid] : 0xffffffffu;
+    skey[tid] = key;
+    sval[tid] = in ? vals[e0 + tid] : 0u;
+    const bool start = in && (tid == 0 || key != keys[e0 + tid - 1]);
+    const unsigned long long m = __ballot(start);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) woff += (w < wave) ? wcnt[w] : 0;
+    const int nruns = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (start) rstart[woff + __popcll(m & ((1ull << lane) - 1ull))] = tid;
+    if (tid == 0) rstart[nruns] = ne;
+    __syncthreads();
+    const bool cont_l = t > 0 && keys[e0 - 1] == skey[0];
+    const bool cont_r = e0 + ne < n && keys[e0 + ne] == skey[ne - 1];
+    const int g = tid / LPS, c = tid - g * LPS, kv = K / VEC;
+    for (int r = g; r < nruns; r += NG) {
+        const int s = rstart[r], e = rstart[r + 1];
+        const uint32_t rk = skey[s];
+        if (rk >= total_rows || c >= kv) continue;          // pruned ids / idle lanes of a padded group
+        T sum = V::zero();
+        int f = 0;
+        for (int i = s; i < e; ++i) {
+            const uint32_t ent = sval[i];
+            const uint32_t b = ent / (uint32_t)F;
+            f = (int)(ent - b * (uint32_t)F);
+            sum = V::add(sum, V::ld(grad + (int64_t)b * g_ld + (int64_t)f * K + c * VEC));
+        }
+        const bool open_l = r == 0 && cont_l, open_r = r == nruns - 1 && cont_r;
+        if (!open_l && !open_r) {
+            const int64_t id = (int64_t)rk - row_base[f];
+            adagrad_apply_row<VEC>(accums[f] + id * K + c * VEC, tables[f] + id * K + c * VEC, sum, lr);
+        } else {
+            V::st(carry + (t * 2 + (open_l ? 0 : 1)) * K + c * VEC, sum);   // a run open on both sides goes to slot 0
+        }
+    }
+}
+
+// one thread group per tile: if a run STARTS in this tile and continues to the right, add the partials of the tiles it
+// runs through (in tile order) and apply
+template <int LPS, int VEC>
+__global__ __launch_bounds__(256) void adagrad_fix_k(float* const* __restrict__ tables, float* const* __restrict__ accums, int F, int K,
+                                                     int64_t n, int64_t ntiles, const uint32_t* __restrict__ keys,
+                                                     const uint32_t* __restrict__ vals, float lr, const int64_t* __restrict__ row_base,
+                                                     uint32_t total_rows, const float* __restrict__ carry) {
+    using V = BV<VEC>;
+    using T = typename V::T;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = q / LPS;
+    const int c = (int)(q - t * LPS), kv = K / VEC;
+    if (t >= ntiles || c >= kv) return;
+    const int64_t e0 = t * ADA_TILE;
+    const int64_t e1 = (e0 + ADA_TILE < n) ? e0 + ADA_TILE : n;      // first entry of the next tile
+    if (e1 >= n) return;
+    const uint32_t kl = keys[e1 - 1];
+    if (kl >= total_rows || keys[e1] != kl) return;                   // not open to the right
+    if (t > 0 && keys[e0] == kl && keys[e0 - 1] == kl) return;        // the run started in an earlier tile
+    T sum = V::ld(carry + (t * 2 + 1) * K + c * VEC);
+    for (int64_t u = t + 1; u < ntiles; ++u) {
+        sum = V::add(sum, V::ld(carry + (u * 2) * K + c * VEC));
+        const int64_t u1 = (u + 1) * ADA_TILE;
+        if (!(u1 < n && keys[u1] == kl)) break;                       // the run ends inside tile u
+    }
+    const uint32_t ent = vals[e1 - 1];
+    const int f = (int)(ent % (uint32_t)F);
+    const int64_t id = (int64_t)kl - row_base[f];
+    adagrad_apply_row<VEC>(accums[f] + id * K + c * VEC, tables[f] + id * K + c * VEC, sum, lr);
+}
+
+struct AdaSortedPlan { size_t n, ntiles, off_keys[2], off_vals[2], off_carry, off_tmp, tmp_bytes, total; unsigned bits; };
+static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedPlan& p) {
+    p.n = (size_t)n;
+    p.ntiles = (p.n + ADA_TILE - 1) / ADA_TILE;
+    unsigned bits = 1;
+    while (bits < 32 && (((uint64_t)1 << bits) <= (uint64_t)total_rows)) ++bits;    // keys go up to total_rows (pruned)
+    p.bits = bits;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    p.off_keys[0] = take(p.n * 4); p.off_keys[1] = take(p.n * 4);
+    p.off_vals[0] = take(p.n * 4); p.off_vals[1] = take(p.n * 4);
+    p.off_carry = take(p.ntiles * 2 * (size_t)K * 4);
+    size_t tmp = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  p.n, 0u, bits, (hipStream_t)0) != hipSuccess)
+        return false;
+    p.tmp_bytes = tmp;
+    p.off_tmp = take(tmp ? tmp : 256);
+    p.total = off;
+    return true;
+}
+
 }  // namespace dir
 
 using namespace dir;
+
+extern "C" int64_t dir_sparse_adagrad_sorted_workspace_bytes(int64_t B, int F, int K, int64_t total_rows) {
+    if (B <= 0 || F <= 0 || K <= 0 || total_rows <= 0 || total_rows >= 0xffffffffll || B * F >= 0x7fffffffll) return 0;
+    AdaSortedPlan p;
+    return adagrad_sorted_plan(B * F, K, total_rows, p) ? (int64_t)p.total : 0;
+}
+
+extern "C" int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
+                                             int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
+                                             int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
+                                             int64_t workspace_bytes, dir_stream_t stream) {
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && grad_ld >= (int64_t)F * K, "dir_sparse_adagrad_sorted_f32: bad shape");
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(tables && accums && ids && grad && row_base && workspace, "dir_sparse_adagrad_sorted_f32: null pointer");
+    if (B * F >= 0x7fffffffll) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_sorted_f32: B*F must fit int32");
+    if (total_rows <= 0 || total_rows >= 0xffffffffll) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_sorted_f32: total_rows must be in [1, 2^32-1)");
+    const int64_t n = B * F;
+    AdaSortedPlan p;
+    if (!adagrad_sorted_plan(n, K, total_rows, p)) return fail(DIR_E_HIP, "dir_sparse_adagrad_sorted_f32: sort size query failed");
+    if ((int64_t)p.total > workspace_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail(DIR_E_BADARG, "dir_sparse_adagrad_sorted_f32: workspace needs %lld bytes, 256-byte aligned", (long long)p.total);
+    hipStream_t st = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    uint32_t* k0 = reinterpret_cast<uint32_t*>(ws + p.off_keys[0]);
+    uint32_t* k1 = reinterpret_cast<uint32_t*>(ws + p.off_keys[1]);
+    uint32_t* v0 = reinterpret_cast<uint32_t*>(ws + p.off_vals[0]);
+    uint32_t* v1 = reinterpret_cast<uint32_t*>(ws + p.off_vals[1]);
+    float* carry = reinterpret_cast<float*>(ws + p.off_carry);
+    hipLaunchKernelGGL(adagrad_keys_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, row_base,
+                       (uint32_t)total_rows, k0, v0);
+    DIR_CHECK_LAUNCH("sparse_adagrad_sorted(keys)");
+    size_t tmp = p.tmp_bytes;
+    if (rocprim::radix_sort_pairs(ws + p.off_tmp, tmp, (const uint32_t*)k0, k1, (const uint32_t*)v0, v1, (size_t)n, 0u, p.bits, st) != hipSuccess)
+        return fail(DIR_E_HIP, "dir_sparse_adagrad_sorted_f32: radix sort failed");
+    const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && aligned16(grad);
+    int lps = 1;
+    while (lps < (vec ? K / 4 : K)) lps <<= 1;
+    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_sorted_f32: K=%d too wide", K);
+    const int64_t ntiles = (int64_t)p.ntiles;
+    dim3 gfix((unsigned)((ntiles * lps + 255) / 256));
+#define DIR_CASE(L, V)                                                                                                         \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((adagrad_tile_k<L, V>), dim3((unsigned)ntiles), dim3(256), 0, st, tables, accums, F, K, n, k1, v1, grad, grad_ld, \
+                           lr, row_base, (uint32_t)total_rows, carry);                                                          \
+        hipLaunchKernelGGL((adagrad_fix_k<L, V>), gfix, dim3(256), 0, st, tables, accums, F, K, n, ntiles, k1, v1, lr, row_base,     \
+                           (uint32_t)total_rows, carry);                                                                        \
+    } while (0)
+    if (vec) {
+        switch (lps) {
+            case 1: DIR_CASE(1, 4); break;
+            case 2: DIR_CASE(2, 4); break;
+            case 4: DIR_CASE(4, 4); break;
+            case 8: DIR_CASE(8, 4); break;
+            case 16: DIR_CASE(16, 4); break;
+            case 32: DIR_CASE(32, 4); break;
+            default: DIR_CASE(64, 4); break;
+        }
+    } else {
+        switch (lps) {
+            case 1: DIR_CASE(1, 1); break;
+            case 2: DIR_CASE(2, 1); break;
+            case 4: DIR_CASE(4, 1); break;
+            case 8: DIR_CASE(8, 1); break;
+            case 16: DIR_CASE(16, 1); break;
+            case 32: DIR_CASE(32, 1); break;
+            default: DIR_CASE(64, 1); break;
+        }
+    }
+#undef DIR_CASE
+    DIR_CHECK_LAUNCH("sparse_adagrad_sorted");
+    return DIR_OK;
+}
 
 extern "C" int dir_fm_second_order_backward_f32(const float* emb, int64_t emb_ld, const float* g, const float* add_in,
                                                 int64_t add_ld, int64_t B, int F, int K, float* demb, int64_t demb_ld,

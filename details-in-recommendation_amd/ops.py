@@ -522,21 +522,28 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
 
 
 class SparseAdagrad:
-    """Fused sparse Adagrad over a TableSet (include/dir_hip.h: dir_sparse_adagrad_f32).  Holds the accumulators
-    ([TF-upstream] initial_accumulator_value = 0.1) and the persistent per-row chain heads."""
+    """Fused sparse Adagrad over a TableSet.  Holds the accumulators ([TF-upstream] initial_accumulator_value = 0.1).
+    method "sorted" (default; include/dir_hip.h: dir_sparse_adagrad_sorted_f32): radix sort of (row, entry) pairs +
+    per-tile segmented reduce -- skew-proof and bitwise reproducible.  method "chains" (dir_sparse_adagrad_f32): per-row
+    chains built with integer atomics -- a little faster on near-unique ids, serialises on hot rows."""
 
-    def __init__(self, tables, lr, initial_accumulator_value=0.1):
+    def __init__(self, tables, lr, initial_accumulator_value=0.1, method="sorted"):
+        if method not in ("sorted", "chains"):
+            raise ValueError("method must be 'sorted' or 'chains'")
         self.ts = _as_tableset(tables)
         self.lr = float(lr)
+        self.method = method
         dev = self.ts.device
         self.accums = [torch.full_like(t, initial_accumulator_value) for t in self.ts.tables]
         self.acc_ptrs = torch.tensor([a.data_ptr() for a in self.accums], dtype=torch.int64, device=dev)
         base = [0]
         for v in self.ts.vocab[:-1]:
             base.append(base[-1] + v)
+        self.total_rows = sum(self.ts.vocab)
         self.head_base = torch.tensor(base, dtype=torch.int64, device=dev)
-        self.head = torch.full((sum(self.ts.vocab),), -1, dtype=torch.int32, device=dev)
+        self.head = torch.full((self.total_rows,), -1, dtype=torch.int32, device=dev) if method == "chains" else None
         self._next = None
+        self._ws = None
 
     def attach(self):
         """Consume the gather's row gradients directly in backward (autograd.GatherFm): loss.backward() then
@@ -552,11 +559,25 @@ class SparseAdagrad:
         B, sb, sf = _onehot_strides(ids, ts.F)
         if grad.shape != (B, ts.F * ts.K) or grad.stride(1) != 1:
             raise ValueError("grad must be [B, F*K] with unit inner stride")
-        if self._next is None or self._next.numel() < B * ts.F:
-            self._next = torch.empty(B * ts.F, dtype=torch.int32, device=ts.device)
-        _lib.check(_lib.load().dir_sparse_adagrad_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
-                                                      _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
-                                                      _ptr(self.head), _ptr(self._next), _stream()))
+        lib = _lib.load()
+        if self.method == "chains":
+            if self._next is None or self._next.numel() < B * ts.F:
+                self._next = torch.empty(B * ts.F, dtype=torch.int32, device=ts.device)
+            _lib.check(lib.dir_sparse_adagrad_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
+                                                  _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
+                                                  _ptr(self.head), _ptr(self._next), _stream()))
+            return
+        if B == 0:
+            return
+        need = int(lib.dir_sparse_adagrad_sorted_workspace_bytes(B, ts.F, ts.K, self.total_rows))
+        if need <= 0:
+            raise _lib.DirError(-4, "sparse_adagrad_sorted: unsupported size (B*F < 2^31, total rows < 2^32-1)")
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=ts.device)
+        off = (-self._ws.data_ptr()) % 256
+        _lib.check(lib.dir_sparse_adagrad_sorted_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
+                                                     _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
+                                                     self.total_rows, ctypes.c_void_p(self._ws.data_ptr() + off), need, _stream()))
 
 
 class PackedTables:

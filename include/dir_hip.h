@@ -276,6 +276,17 @@ int dir_sparse_adagrad_f32(float* const* tables, float* const* accums, int F, in
                            int64_t B, const int64_t* head_base, int32_t* head, int32_t* next,
                            dir_stream_t stream);
 
+/* The same update with the (row, entry) pairs radix-sorted first (stable: duplicates are summed in batch order; no
+ * atomics; bitwise reproducible) and the runs of equal rows reduced per tile of 256 sorted entries -- the longest serial
+ * walk is 256 entries whatever the skew of the ids (the chain walk above serialises on hot rows).
+ * row_base: DEVICE int64 [F], slot f's first row in the concatenation of all tables; total_rows = sum of the vocab sizes
+ * (< 2^32 - 1).  workspace: dir_sparse_adagrad_sorted_workspace_bytes(B, F, K, total_rows) device bytes, 256-byte aligned. */
+int64_t dir_sparse_adagrad_sorted_workspace_bytes(int64_t B, int F, int K, int64_t total_rows);
+int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
+                                  int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
+                                  int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
+                                  int64_t workspace_bytes, dir_stream_t stream);
+
 /* Diagnostic only (never on the product path): cycle stamps of the DIR_CIN_STAMP=1 build of the CIN kernel, summed
  * over waves since the last call: [0] chunk start -> end of its MFMA stream, [1] -> past the chunk barrier,
  * [2] chunks, [3] prologue, [4] epilogue, [5] waves.  Synchronises the device. */

@@ -158,15 +158,18 @@ def test_training_steps_reduce_loss(built_lib):
     assert float(loss.detach()) < 0.8 * l0
 
 
-@pytest.mark.parametrize("B,F,K,V", [(1, 1, 4, 5), (300, 5, 16, 20), (4096, 26, 16, 1000), (777, 3, 6, 50), (500, 4, 64, 7)])
-def test_fused_sparse_adagrad(built_lib, B, F, K, V):
-    """dir_sparse_adagrad_f32 vs a float64 dedup-sum Adagrad ([TF-upstream]: duplicates summed, then
-    accum += g^2, var -= lr*g/sqrt(accum)); two consecutive steps (the chain heads must be left clean)."""
+@pytest.mark.parametrize("method", ["sorted", "chains"])
+@pytest.mark.parametrize("B,F,K,V", [(1, 1, 4, 5), (300, 5, 16, 20), (4096, 26, 16, 1000), (777, 3, 6, 50), (500, 4, 64, 7),
+                                     (3000, 2, 16, 3), (1025, 1, 8, 1), (700, 3, 16, 100000)])
+def test_fused_sparse_adagrad(built_lib, B, F, K, V, method):
+    """dir_sparse_adagrad_sorted_f32 / dir_sparse_adagrad_f32 vs a float64 dedup-sum Adagrad ([TF-upstream]: duplicates
+    summed, then accum += g^2, var -= lr*g/sqrt(accum)); two consecutive steps (the chain heads must be left clean).
+    V = 3 and V = 1: runs of equal rows spanning many 256-entry tiles (the carry / fix-up path of the sorted kernel)."""
     from dir_amd import ops
     rng = np.random.default_rng(B + K)
     tabs = [rng.standard_normal((V, K)).astype(np.float32) for _ in range(F)]
     dev = [torch.from_numpy(t.copy()).cuda() for t in tabs]
-    opt = ops.SparseAdagrad(dev, lr=0.05, initial_accumulator_value=0.1)
+    opt = ops.SparseAdagrad(dev, lr=0.05, initial_accumulator_value=0.1, method=method)
     ref_w = [t.astype(np.float64) for t in tabs]
     ref_a = [np.full((V, K), 0.1) for _ in range(F)]
     for step in range(2):
@@ -180,10 +183,26 @@ def test_fused_sparse_adagrad(built_lib, B, F, K, V):
             touched = np.zeros(V, bool); touched[ids[ok, f]] = True
             ref_a[f][touched] += gsum[touched] ** 2
             ref_w[f][touched] -= 0.05 * gsum[touched] / np.sqrt(ref_a[f][touched])
-        assert int((opt.head != -1).sum()) == 0
+        if method == "chains":
+            assert int((opt.head != -1).sum()) == 0
     for f in range(F):
         _close(dev[f], ref_w[f], tol=2e-5)
         _close(opt.accums[f], ref_a[f], tol=2e-5)
+
+
+def test_sorted_adagrad_bitwise_reproducible_on_skewed_ids(built_lib):
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, F, K, V = 8192, 4, 16, 5000
+    ids = (torch.rand(B, F, generator=g) ** 6 * V).long().clamp(max=V - 1).cuda()      # heavy head: hot rows repeat thousands of times
+    grad = torch.randn(B, F * K, generator=g).cuda()
+    outs = []
+    for _ in range(2):
+        tabs = [torch.zeros(V, K, device="cuda") for _ in range(F)]
+        opt = ops.SparseAdagrad(tabs, lr=0.1)
+        opt.step(ids, grad)
+        outs.append(torch.stack(tabs).clone())
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_deepfm_fused_adagrad_matches_torch_adagrad(built_lib):
