@@ -245,7 +245,12 @@ def test_din_module(built_lib, oracle):
     hist = rng.integers(0, V, size=(B, T)).astype(np.int64)
     hl = rng.integers(1, T + 1, size=B).astype(np.int32)
     cand = rng.integers(0, V, size=B).astype(np.int64)
-    got = mod(torch.from_numpy(hist).cuda(), torch.from_numpy(hl).cuda(), torch.from_numpy(cand).cuda()).cpu().numpy()
+    args = (torch.from_numpy(hist).cuda(), torch.from_numpy(hl).cuda(), torch.from_numpy(cand).cuda())
+    out = mod(*args)                                   # grad enabled: the autograd wrapper around the same kernel
+    assert out.requires_grad
+    with torch.no_grad():
+        assert torch.equal(mod(*args), out.detach())
+    got = out.detach().cpu().numpy()
     ref, _ = R.din_attention_pool(mod.table.detach().cpu().numpy(), hist, hl, cand, _np(mod.W1), _np(mod.b1), _np(mod.W2), _np(mod.b2),
                                   _np(mod.W3), _np(mod.b3), normalize=True)
     _close(got, ref)
