@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
-                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "cin", "cin_backward", "deepfm_full",
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full",
                              "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
@@ -314,6 +314,27 @@ def main():
         executed = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)
         roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_mfma_k (fp32 MFMA 16x16x4)",
                 "executed_flops": executed}
+        cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
+    elif wl == "din_train":
+        # forward (fused kernel) + backward (autograd.DinAttentionPool: GPU composite, sparse table gradient) of the DIN unit
+        from dir_amd import autograd as ag
+        T, Kd, Vd, H1, H2 = 50, 64, 10000000, 80, 40
+        table = (torch.randn((Vd, Kd), generator=gen, device=device) * 0.125).requires_grad_(True)
+        hist = torch.randint(0, Vd, (B, T), generator=gen, device=device)
+        hl = torch.randint(1, T + 1, (B,), generator=gen, device=device, dtype=torch.int32)
+        cand = torch.randint(0, Vd, (B,), generator=gen, device=device)
+        ws = [(torch.randn((4 * Kd, H1), generator=gen, device=device) * 0.05).requires_grad_(True), torch.zeros(H1, device=device, requires_grad=True),
+              (torch.randn((H1, H2), generator=gen, device=device) * 0.1).requires_grad_(True), torch.zeros(H2, device=device, requires_grad=True),
+              (torch.randn((H2,), generator=gen, device=device) * 0.1).requires_grad_(True), torch.zeros(1, device=device, requires_grad=True)]
+        gout = torch.randn((B, Kd), generator=gen, device=device) * 0.01
+
+        def step(i):
+            table.grad = None
+            for w in ws:
+                w.grad = None
+            ag.din_attention_pool(table, hist, hl, cand, *ws, normalize=True).backward(gout)
+        flops = 3 * B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_mfma_k + composite backward (torch + rocBLAS)"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
     elif wl == "cin":
         m, D, Hs = F, K, (128, 128, 128)
