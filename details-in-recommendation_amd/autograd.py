@@ -184,12 +184,26 @@ def cin_layer(x0, xk, W):
     return CinLayer.apply(x0, xk, W)
 
 
+def _tn_matmul(A, Bm, splits=128):
+    """A^T @ Bm for tall-skinny A [N, m], Bm [N, n] (N in the millions, m, n ~ 100): the reduction over N is split into
+    `splits` batched GEMMs that are then added (rocBLAS has no good single kernel for this shape: 2.6 ms vs 0.3 ms)."""
+    N = A.shape[0]
+    per = N // splits
+    if per < 64:
+        return A.t() @ Bm
+    nm = per * splits
+    out = torch.bmm(A[:nm].view(splits, per, A.shape[1]).transpose(1, 2), Bm[:nm].view(splits, per, Bm.shape[1])).sum(dim=0)
+    if nm < N:
+        out = out + A[nm:].t() @ Bm[nm:]
+    return out
+
+
 class DinAttentionPool(torch.autograd.Function):
-    """DIN local activation unit + pooling (include/dir_hip.h A13).  Forward: the fused HIP kernel.  Backward: the
-    unit is recomputed over the VALID (sample, position) rows only and differentiated on the GPU -- gathers and
-    elementwise steps as torch kernels, the four small GEMMs and their transposes through rocBLAS -- giving a
-    sparse gradient for the table (history rows and candidate rows) and dense ones for the six MLP tensors.
-    (A fused HIP backward is the next step for this op; this composite never leaves the device.)"""
+    """DIN local activation unit + pooling (include/dir_hip.h A13).  Forward: the fused HIP kernel.  Backward: hand-derived,
+    over the VALID (sample, position) rows only, entirely on the GPU: the unit is recomputed in the regrouped form the
+    forward kernel uses ([h, a, h-a, h*a].W1 = h.(Wh+Wd) + (h*a).Wp + a.(Wa-Wd)), its six GEMMs and their transposes go
+    through rocBLAS, the elementwise steps and the per-sample segment sums are torch kernels; the table gets a sparse
+    gradient (history rows and candidate rows).  No autograd graph is built.  (A fused HIP backward is the next step.)"""
 
     @staticmethod
     def forward(ctx, table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize):
@@ -199,44 +213,63 @@ class DinAttentionPool(torch.autograd.Function):
                                       b2.detach(), W3.detach(), b3.detach(), normalize=normalize)
 
     @staticmethod
+    @torch.no_grad()
     def backward(ctx, g):
         table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3 = ctx.saved_tensors
         B, T = hist.shape
-        K = table.shape[1]
-        pos = torch.arange(T, device=hist.device).unsqueeze(0)
+        K, H1 = table.shape[1], W1.shape[1]
+        dev = table.device
+        g = g.contiguous()
         valid = hist >= 0
         if hist_len is not None:
-            valid &= pos < hist_len.clamp(0, T).unsqueeze(1)
+            valid &= torch.arange(T, device=dev).unsqueeze(0) < hist_len.clamp(0, T).unsqueeze(1)
         b_idx, j_idx = valid.nonzero(as_tuple=True)                 # rows in (b, j) order
         ids_h = hist[b_idx, j_idx]
-        with torch.enable_grad():
-            h = table.detach()[ids_h].requires_grad_(True)
-            a = table.detach()[cand].requires_grad_(True)
-            ws = [t.detach().requires_grad_(True) for t in (W1, b1, W2, b2, W3, b3)]
-            ab = a[b_idx]
-            u = torch.cat([h, ab, h - ab, h * ab], dim=1)
-            z1 = torch.sigmoid(u @ ws[0] + ws[1])
-            z2 = torch.sigmoid(z1 @ ws[2] + ws[3])
-            s = z2 @ ws[4].reshape(-1) + ws[5]
-            if ctx.normalize:                                       # softmax over the valid positions of each sample
-                x = s * (1.0 / K ** 0.5)
-                mx = torch.full((B,), float("-inf"), device=x.device).scatter_reduce(0, b_idx, x.detach(), "amax")
-                e = torch.exp(x - mx[b_idx])
-                w = e / torch.zeros(B, device=x.device).index_add(0, b_idx, e)[b_idx]
-            else:
-                w = s
-            out = torch.zeros((B, K), device=h.device).index_add(0, b_idx, w.unsqueeze(1) * h)
-            gh, ga, *gws = torch.autograd.grad(out, [h, a] + ws, g.contiguous(), allow_unused=True)
+        w3 = W3.reshape(-1)
+        Wh, Wa, Wd, Wp = W1[:K], W1[K:2 * K], W1[2 * K:3 * K], W1[3 * K:]
+        A, C = Wh + Wd, Wa - Wd
+        AP = torch.cat([A, Wp], dim=0)                              # [2K, H1]
+        # ---- recompute the unit on the valid rows -------------------------------------------------------------------
+        h = table[ids_h]                                            # [N, K]
+        a = table[cand]                                             # [B, K]
+        ab = a[b_idx]
+        X = torch.cat([h, h * ab], dim=1)                           # [N, 2K]
+        z1 = torch.sigmoid_(torch.addmm((a @ C + b1)[b_idx], X, AP))
+        z2 = torch.sigmoid_(torch.addmm(b2, z1, W2))
+        s = (z2 * w3.unsqueeze(0)).sum(dim=1) + b3
+        gb = g[b_idx]
+        if ctx.normalize:                                           # softmax over the valid positions of each sample
+            x = s * (1.0 / K ** 0.5)
+            mx = torch.full((B,), float("-inf"), device=dev).scatter_reduce(0, b_idx, x, "amax")
+            e = torch.exp_(x - mx[b_idx])
+            w = e / torch.zeros(B, device=dev).index_add_(0, b_idx, e)[b_idx]
+        else:
+            w = s
+        # ---- backward -------------------------------------------------------------------------------------------------
+        dw = (gb * h).sum(dim=1)                                    # d out / d w_j . g
+        if ctx.normalize:
+            t = torch.zeros(B, device=dev).index_add_(0, b_idx, w * dw)
+            ds = w * (dw - t[b_idx]) * (1.0 / K ** 0.5)
+        else:
+            ds = dw
+        dpre2 = (ds.unsqueeze(1) * w3.unsqueeze(0)) * z2 * (1.0 - z2)
+        gW3 = (z2 * ds.unsqueeze(1)).sum(dim=0)                    # (a [H2 x N] gemv runs at 15 ms in rocBLAS)
+        gW2 = _tn_matmul(z1, dpre2)
+        dpre1 = (dpre2 @ W2.t()) * z1 * (1.0 - z1)
+        gWx = _tn_matmul(X, dpre1)                                  # [2K, H1]: d(Wh+Wd), dWp
+        S = torch.zeros((B, H1), device=dev).index_add_(0, b_idx, dpre1)
+        gC = a.t() @ S                                              # d(Wa-Wd)
+        gA, gWp = gWx[:K], gWx[K:]
+        gW1 = torch.cat([gA, gC, gA - gC, gWp], dim=0)              # dWh, dWa, dWd = dWh - dWa, dWp
+        dX = dpre1 @ AP.t()                                         # [N, 2K]
+        gh = dX[:, :K] + dX[:, K:] * ab + w.unsqueeze(1) * gb
+        ga = torch.zeros((B, K), device=dev).index_add_(0, b_idx, dX[:, K:] * h) + S @ C.t()
         gtab = None
         if ctx.needs_input_grad[0]:
-            if gh is None:                                          # no valid position in the whole batch
-                gtab = torch.sparse_coo_tensor(torch.zeros((1, 0), dtype=torch.int64, device=table.device),
-                                               torch.zeros((0, K), device=table.device), table.shape)
-            else:
-                idx = torch.cat([ids_h, cand]).unsqueeze(0)
-                gtab = torch.sparse_coo_tensor(idx, torch.cat([gh, ga]), table.shape)
-        gws = [gw if gw is not None else torch.zeros_like(t) for gw, t in zip(gws, (W1, b1, W2, b2, W3, b3))]
-        return (gtab, None, None, None) + tuple(gws) + (None,)
+            idx = torch.cat([ids_h, cand]).unsqueeze(0)
+            gtab = torch.sparse_coo_tensor(idx, torch.cat([gh, ga]), table.shape)
+        return (gtab, None, None, None, gW1, dpre1.sum(dim=0), gW2, dpre2.sum(dim=0), gW3.reshape(W3.shape),
+                ds.sum().reshape(b3.shape), None)
 
 
 def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False):
