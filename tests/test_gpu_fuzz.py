@@ -87,3 +87,40 @@ def test_fuzz_cross(ops, oracle, seed):
     got = ops.cross_network(xb[:, :d], _dev(w.reshape(L, d)), _dev(b.reshape(L, d))).cpu().numpy().astype(np.float64)
     err = np.abs(got - ref) / (1 + np.abs(ref))
     assert err.max() <= 1e-5, (d, L, B, err.max())
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_cin_forward_backward(ops, oracle, seed):
+    """Random (B, m, D, Hp, H) through dir_cin_layer_f32, dir_cin_dw_f32, dir_cin_dx_f32 (and the forward-kernel
+    formulation of the data gradients) against the double-accumulating oracle.  Row counts with B*D % 8 == 4, field counts
+    that are not an instantiated size, H / Hp on both sides of the 32 / 64 / 128 tile limits."""
+    rng = np.random.default_rng(5000 + seed)
+    D = int(rng.choice([4, 8, 16, 32]))
+    m = int(rng.choice([1, 2, 5, 8, 13, 16, 26, 30, 39]))
+    Hp = int(rng.choice([1, 3, 7, 26, 32, 33, 50, 64, 100, 128])) if seed % 4 else m
+    H = int(rng.choice([1, 5, 16, 31, 32, 40, 64, 96, 128, 130, 200]))
+    B = int(rng.choice([1, 3, 7, 33, 64, 129, 300]))
+    if B * D * Hp * m * H > 4e9:
+        B = max(1, int(4e9 // (D * Hp * m * H)))
+    x0 = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
+    xk = (rng.standard_normal((B, Hp, D)) * 0.5).astype(np.float32)
+    W = (rng.standard_normal((H, Hp * m)) / np.sqrt(Hp * m)).astype(np.float32)
+    G = (rng.standard_normal((B, H, D)) * 0.5).astype(np.float32)
+
+    def close(got, ref, tol=1e-5, mag=1.0):
+        err = np.abs(got.cpu().double().numpy() - ref) / (mag + np.abs(ref))
+        assert err.max() <= tol, "max scaled err %.3e (B %d m %d D %d Hp %d H %d)" % (err.max(), B, m, D, Hp, H)
+
+    ref_x, ref_p = oracle.cin_layer(x0, xk, W, acc64=True)
+    got_x, got_p = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))
+    close(got_x, ref_x)
+    close(got_p, ref_p)
+    ref_dW, ref_dxk, ref_dx0 = oracle.cin_backward(x0, xk, W, G)
+    dx0, dxk, dW = ops.cin_layer_backward(_dev(x0), _dev(xk), _dev(W), _dev(G))
+    close(dxk, ref_dxk)
+    close(dx0, ref_dx0)
+    close(dW, ref_dW, mag=np.sqrt(B * D) * 0.125 + 1.0)
+    if m <= 40:   # the forward-kernel formulation (register-resident operand <= 40 fields)
+        fx0, fxk, _ = ops.cin_layer_backward(_dev(x0), _dev(xk), _dev(W), _dev(G), need_w=False, force_forward_form=True)
+        close(fxk, ref_dxk)
+        close(fx0, ref_dx0)
