@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
-                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full",
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full", "deepfm_train",
                              "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
@@ -222,6 +222,37 @@ def main():
                 "kernel": "gather_onehot_k + fm_bwd_k + " + ("adagrad_keys_k + rocprim radix sort + adagrad_tile_k + adagrad_fix_k"
                                                             if args.adagrad_method == "sorted" else "adagrad_link_k + adagrad_apply_k")}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "adagrad": args.adagrad_method, "ids": args.id_dist})
+    elif wl == "deepfm_train":
+        # one whole DeepFM training step with the reference's optimisers (deepFM.py:58,61): forward (gather+FM kernel,
+        # linear term, 400-400-400 MLP on rocBLAS), BCE loss, backward (HIP FM backward, sparse row gradients), fused sorted
+        # sparse Adagrad on the 26 embedding tables and fused sparse FTRL on the 26 linear columns inside backward(), torch Adagrad on the MLP
+        from dir_amd.deepfm import DeepFM
+        from dir_amd import feature_column as fc
+        from dir_amd.autograd import Ftrl
+        cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+        model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                       dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
+        model.fused_sparse_adagrad(lr=0.01)
+        model.fused_sparse_ftrl(lr=0.2)
+        lin = [model.linear_bias]                          # the weight columns are updated by the fused kernel inside backward()
+        skip = {id(p) for p in model.linear_weights} | {id(p) for p in lin} | {id(p) for p in model.embedding_weights}
+        opt_dense = torch.optim.Adagrad([p for p in model.parameters() if id(p) not in skip], lr=0.01, initial_accumulator_value=0.1)
+        opt_lin = Ftrl(lin, lr=0.2)
+        idsl = make_ids(torch, args, gen, device, V)
+        featl = [{"C%d" % f: ids[:, f] for f in range(F)} for ids in idsl]
+        labels = (torch.rand((B, 1), generator=gen, device=device) < 0.25).float()
+
+        def step(i):
+            opt_dense.zero_grad(set_to_none=True)
+            opt_lin.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(model(featl[i % len(featl)]), labels)
+            loss.backward()
+            opt_dense.step()
+            opt_lin.step()
+        roof = {"bound": "hbm", "alg_bytes": B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)),
+                "kernel": "whole training step; bytes = the sparse side only (gather+FM, FM backward, sparse Adagrad)"}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "mlp": [400, 400, 400],
+                    "optimizers": "sparse Adagrad + sparse FTRL (HIP, sorted, inside backward) + torch Adagrad (MLP)"})
     elif wl == "small_batch":
         # the reference's own batch size (256, DeepCrossNetwork/train.py:17): launch-bound; eager vs HIP-graph replay
         from dir_amd.deepfm import DeepFM

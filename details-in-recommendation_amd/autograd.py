@@ -121,6 +121,9 @@ class LinearLogit(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         ts = ctx.ts
         gv = g.reshape(-1)
+        if ts.grad_sink is not None:     # fused optimiser attached (ops.SparseFtrl): d logit [B, 1] is every slot's gradient row
+            ts.grad_sink(ids, gv.contiguous().reshape(-1, 1))
+            return (None, None, gv.sum().reshape(1)) + (None,) * ts.F
         grads = [_sparse_rows(ids[:, f].contiguous(), gv, ts.vocab[f]) for f in range(ts.F)]
         return (None, None, gv.sum().reshape(1)) + tuple(grads)
 

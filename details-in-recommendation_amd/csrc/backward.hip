@@ -285,26 +285,67 @@ __global__ __launch_bounds__(256) void adagrad_keys_k(const int64_t* __restrict_
     }
 }
 
-template <int VEC>
-__device__ __forceinline__ void adagrad_apply_row(float* __restrict__ ap, float* __restrict__ wp, typename BV<VEC>::T g, float lr) {
-    using V = BV<VEC>;
-    typename V::T acc = V::ld(ap), wv = V::ld(wp);
-    if constexpr (VEC == 4) {
-        acc = make_float4(acc.x + g.x * g.x, acc.y + g.y * g.y, acc.z + g.z * g.z, acc.w + g.w * g.w);
-        wv = make_float4(wv.x - lr * g.x / sqrtf(acc.x), wv.y - lr * g.y / sqrtf(acc.y), wv.z - lr * g.z / sqrtf(acc.z),
-                         wv.w - lr * g.w / sqrtf(acc.w));
-    } else {
-        acc = acc + g * g;
-        wv = wv - lr * g / sqrtf(acc);
+// per-row update rules of the sorted path: g = the summed gradient chunk of one row
+struct AdagradUpd {   // accum += g^2; w -= lr * g / sqrt(accum)   ([TF-upstream] tf.train.AdagradOptimizer, deepFM.py:61)
+    float* const* tables;
+    float* const* accums;
+    float lr;
+    template <int VEC>
+    __device__ __forceinline__ void apply(int f, int64_t off, typename BV<VEC>::T g) const {
+        using V = BV<VEC>;
+        float* ap = accums[f] + off;
+        float* wp = tables[f] + off;
+        typename V::T acc = V::ld(ap), wv = V::ld(wp);
+        if constexpr (VEC == 4) {
+            acc = make_float4(acc.x + g.x * g.x, acc.y + g.y * g.y, acc.z + g.z * g.z, acc.w + g.w * g.w);
+            wv = make_float4(wv.x - lr * g.x / sqrtf(acc.x), wv.y - lr * g.y / sqrtf(acc.y), wv.z - lr * g.z / sqrtf(acc.z),
+                             wv.w - lr * g.w / sqrtf(acc.w));
+        } else {
+            acc = acc + g * g;
+            wv = wv - lr * g / sqrtf(acc);
+        }
+        V::st(ap, acc);
+        V::st(wp, wv);
     }
-    V::st(ap, acc);
-    V::st(wp, wv);
-}
+};
 
-template <int LPS, int VEC>
-__global__ __launch_bounds__(256) void adagrad_tile_k(float* const* __restrict__ tables, float* const* __restrict__ accums, int F, int K,
+struct FtrlUpd {      // FTRL-Proximal, learning_rate_power = -0.5 ([TF-upstream] tf.train.FtrlOptimizer, deepFM.py:58)
+    float* const* tables;
+    float* const* accums;    // n
+    float* const* linears;   // z
+    float lr, l1, l2;
+    __device__ __forceinline__ void one(float g, float& n, float& z, float& w) const {
+        const float n_new = n + g * g;
+        const float sigma = (sqrtf(n_new) - sqrtf(n)) / lr;
+        const float z_new = z + g - sigma * w;
+        const float quad = sqrtf(n_new) / lr + 2.f * l2;
+        const float sgn = z_new > 0.f ? 1.f : (z_new < 0.f ? -1.f : 0.f);
+        w = fabsf(z_new) > l1 ? (sgn * l1 - z_new) / quad : 0.f;
+        n = n_new;
+        z = z_new;
+    }
+    template <int VEC>
+    __device__ __forceinline__ void apply(int f, int64_t off, typename BV<VEC>::T g) const {
+        using V = BV<VEC>;
+        float* np_ = accums[f] + off;
+        float* zp = linears[f] + off;
+        float* wp = tables[f] + off;
+        typename V::T n = V::ld(np_), z = V::ld(zp), w = V::ld(wp);
+        if constexpr (VEC == 4) {
+            one(g.x, n.x, z.x, w.x); one(g.y, n.y, z.y, w.y); one(g.z, n.z, z.z, w.z); one(g.w, n.w, z.w, w.w);
+        } else {
+            one(g, n, z, w);
+        }
+        V::st(np_, n);
+        V::st(zp, z);
+        V::st(wp, w);
+    }
+};
+
+template <int LPS, int VEC, class U>
+__global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
                                                       int64_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                      const float* __restrict__ grad, int64_t g_ld, float lr,
+                                                      const float* __restrict__ grad, int64_t g_ld, int64_t g_fs /* grad stride per slot */,
                                                       const int64_t* __restrict__ row_base, uint32_t total_rows,
                                                       float* __restrict__ carry /* [tiles][2][K] */) {
     using V = BV<VEC>;
@@ -344,12 +385,12 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(float* const* __restrict__
             const uint32_t ent = sval[i];
             const uint32_t b = ent / (uint32_t)F;
             f = (int)(ent - b * (uint32_t)F);
-            sum = V::add(sum, V::ld(grad + (int64_t)b * g_ld + (int64_t)f * K + c * VEC));
+            sum = V::add(sum, V::ld(grad + (int64_t)b * g_ld + (int64_t)f * g_fs + c * VEC));
         }
         const bool open_l = r == 0 && cont_l, open_r = r == nruns - 1 && cont_r;
         if (!open_l && !open_r) {
             const int64_t id = (int64_t)rk - row_base[f];
-            adagrad_apply_row<VEC>(accums[f] + id * K + c * VEC, tables[f] + id * K + c * VEC, sum, lr);
+            upd.template apply<VEC>(f, id * K + c * VEC, sum);
         } else {
             V::st(carry + (t * 2 + (open_l ? 0 : 1)) * K + c * VEC, sum);   // a run open on both sides goes to slot 0
         }
@@ -358,10 +399,10 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(float* const* __restrict__
 
 // one thread group per tile: if a run STARTS in this tile and continues to the right, add the partials of the tiles it
 // runs through (in tile order) and apply
-template <int LPS, int VEC>
-__global__ __launch_bounds__(256) void adagrad_fix_k(float* const* __restrict__ tables, float* const* __restrict__ accums, int F, int K,
+template <int LPS, int VEC, class U>
+__global__ __launch_bounds__(256) void adagrad_fix_k(U upd, int F, int K,
                                                      int64_t n, int64_t ntiles, const uint32_t* __restrict__ keys,
-                                                     const uint32_t* __restrict__ vals, float lr, const int64_t* __restrict__ row_base,
+                                                     const uint32_t* __restrict__ vals, const int64_t* __restrict__ row_base,
                                                      uint32_t total_rows, const float* __restrict__ carry) {
     using V = BV<VEC>;
     using T = typename V::T;
@@ -384,7 +425,7 @@ __global__ __launch_bounds__(256) void adagrad_fix_k(float* const* __restrict__ 
     const uint32_t ent = vals[e1 - 1];
     const int f = (int)(ent % (uint32_t)F);
     const int64_t id = (int64_t)kl - row_base[f];
-    adagrad_apply_row<VEC>(accums[f] + id * K + c * VEC, tables[f] + id * K + c * VEC, sum, lr);
+    upd.template apply<VEC>(f, id * K + c * VEC, sum);
 }
 
 struct AdaSortedPlan { size_t n, ntiles, off_keys[2], off_vals[2], off_carry, off_tmp, tmp_bytes, total; unsigned bits; };
@@ -419,20 +460,20 @@ extern "C" int64_t dir_sparse_adagrad_sorted_workspace_bytes(int64_t B, int F, i
     return adagrad_sorted_plan(B * F, K, total_rows, p) ? (int64_t)p.total : 0;
 }
 
-extern "C" int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
-                                             int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
-                                             int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
-                                             int64_t workspace_bytes, dir_stream_t stream) {
-    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && grad_ld >= (int64_t)F * K, "dir_sparse_adagrad_sorted_f32: bad shape");
+template <class U>
+static int sparse_sorted_update(const char* name, U upd, int F, int K, const int64_t* ids, int64_t stride_b, int64_t stride_f,
+                                const float* grad, int64_t grad_ld, int64_t grad_fs, int64_t B, const int64_t* row_base,
+                                int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "%s: bad shape", name);
     if (B == 0) return DIR_OK;
-    DIR_CHECK_ARG(tables && accums && ids && grad && row_base && workspace, "dir_sparse_adagrad_sorted_f32: null pointer");
-    if (B * F >= 0x7fffffffll) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_sorted_f32: B*F must fit int32");
-    if (total_rows <= 0 || total_rows >= 0xffffffffll) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_sorted_f32: total_rows must be in [1, 2^32-1)");
+    DIR_CHECK_ARG(ids && grad && row_base && workspace, "%s: null pointer", name);
+    if (B * F >= 0x7fffffffll) return fail(DIR_E_UNSUPPORTED, "%s: B*F must fit int32", name);
+    if (total_rows <= 0 || total_rows >= 0xffffffffll) return fail(DIR_E_UNSUPPORTED, "%s: total_rows must be in [1, 2^32-1)", name);
     const int64_t n = B * F;
     AdaSortedPlan p;
-    if (!adagrad_sorted_plan(n, K, total_rows, p)) return fail(DIR_E_HIP, "dir_sparse_adagrad_sorted_f32: sort size query failed");
+    if (!adagrad_sorted_plan(n, K, total_rows, p)) return fail(DIR_E_HIP, "%s: sort size query failed", name);
     if ((int64_t)p.total > workspace_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255u))
-        return fail(DIR_E_BADARG, "dir_sparse_adagrad_sorted_f32: workspace needs %lld bytes, 256-byte aligned", (long long)p.total);
+        return fail(DIR_E_BADARG, "%s: workspace needs %lld bytes, 256-byte aligned", name, (long long)p.total);
     hipStream_t st = as_stream(stream);
     char* ws = static_cast<char*>(workspace);
     uint32_t* k0 = reinterpret_cast<uint32_t*>(ws + p.off_keys[0]);
@@ -442,21 +483,21 @@ extern "C" int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const*
     float* carry = reinterpret_cast<float*>(ws + p.off_carry);
     hipLaunchKernelGGL(adagrad_keys_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, row_base,
                        (uint32_t)total_rows, k0, v0);
-    DIR_CHECK_LAUNCH("sparse_adagrad_sorted(keys)");
+    DIR_CHECK_LAUNCH(name);
     size_t tmp = p.tmp_bytes;
     if (rocprim::radix_sort_pairs(ws + p.off_tmp, tmp, (const uint32_t*)k0, k1, (const uint32_t*)v0, v1, (size_t)n, 0u, p.bits, st) != hipSuccess)
-        return fail(DIR_E_HIP, "dir_sparse_adagrad_sorted_f32: radix sort failed");
-    const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && aligned16(grad);
+        return fail(DIR_E_HIP, "%s: radix sort failed", name);
+    const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && (grad_fs % 4 == 0) && aligned16(grad);
     int lps = 1;
     while (lps < (vec ? K / 4 : K)) lps <<= 1;
-    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_sorted_f32: K=%d too wide", K);
+    if (lps > 64) return fail(DIR_E_UNSUPPORTED, "%s: K=%d too wide", name, K);
     const int64_t ntiles = (int64_t)p.ntiles;
     dim3 gfix((unsigned)((ntiles * lps + 255) / 256));
 #define DIR_CASE(L, V)                                                                                                         \
     do {                                                                                                                       \
-        hipLaunchKernelGGL((adagrad_tile_k<L, V>), dim3((unsigned)ntiles), dim3(256), 0, st, tables, accums, F, K, n, k1, v1, grad, grad_ld, \
-                           lr, row_base, (uint32_t)total_rows, carry);                                                          \
-        hipLaunchKernelGGL((adagrad_fix_k<L, V>), gfix, dim3(256), 0, st, tables, accums, F, K, n, ntiles, k1, v1, lr, row_base,     \
+        hipLaunchKernelGGL((adagrad_tile_k<L, V, U>), dim3((unsigned)ntiles), dim3(256), 0, st, upd, F, K, n, k1, v1, grad, grad_ld, \
+                           grad_fs, row_base, (uint32_t)total_rows, carry);                                                     \
+        hipLaunchKernelGGL((adagrad_fix_k<L, V, U>), gfix, dim3(256), 0, st, upd, F, K, n, ntiles, k1, v1, row_base,             \
                            (uint32_t)total_rows, carry);                                                                        \
     } while (0)
     if (vec) {
@@ -481,8 +522,28 @@ extern "C" int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const*
         }
     }
 #undef DIR_CASE
-    DIR_CHECK_LAUNCH("sparse_adagrad_sorted");
+    DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
+                                             int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
+                                             int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
+                                             int64_t workspace_bytes, dir_stream_t stream) {
+    DIR_CHECK_ARG(tables && accums, "dir_sparse_adagrad_sorted_f32: null pointer");
+    DIR_CHECK_ARG(grad_ld >= (int64_t)F * K, "dir_sparse_adagrad_sorted_f32: grad_ld");
+    return sparse_sorted_update("dir_sparse_adagrad_sorted_f32", AdagradUpd{tables, accums, lr}, F, K, ids, stride_b, stride_f, grad,
+                                grad_ld, (int64_t)K, B, row_base, total_rows, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* accums, float* const* linears, int F, int K,
+                                          const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld,
+                                          int64_t grad_slot_stride, float lr, float l1, float l2, int64_t B, const int64_t* row_base,
+                                          int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    DIR_CHECK_ARG(tables && accums && linears, "dir_sparse_ftrl_sorted_f32: null pointer");
+    DIR_CHECK_ARG(lr > 0.f && l1 >= 0.f && l2 >= 0.f, "dir_sparse_ftrl_sorted_f32: lr=%g l1=%g l2=%g", lr, l1, l2);
+    return sparse_sorted_update("dir_sparse_ftrl_sorted_f32", FtrlUpd{tables, accums, linears, lr, l1, l2}, F, K, ids, stride_b,
+                                stride_f, grad, grad_ld, grad_slot_stride, B, row_base, total_rows, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dir_fm_second_order_backward_f32(const float* emb, int64_t emb_ld, const float* g, const float* add_in,

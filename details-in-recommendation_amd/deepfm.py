@@ -175,6 +175,14 @@ class DeepFM(nn.Module):
         emb_ts, _ = self._tablesets()
         return ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()
 
+    def fused_sparse_ftrl(self, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
+        """Attach the fused HIP sparse FTRL update to the linear weight columns (linear_optimizer='Ftrl', deepFM.py:58):
+        backward() then updates them in place; the bias keeps a dense gradient for a dense optimiser."""
+        _, lin_ts = self._tablesets()
+        if lin_ts is None:
+            raise ValueError("fused_sparse_ftrl: the model has no linear feature columns")
+        return ops.SparseFtrl(lin_ts, lr, initial_accumulator_value, l1, l2).attach()
+
     def pack_for_serving(self):
         """Inference-only: copy the embedding tables and the first-order weights of the same categorical columns into
         the packed 128-byte-row layout (ops.PackedTables), so that forward_ids() reads one memory line per

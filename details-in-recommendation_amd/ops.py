@@ -580,6 +580,55 @@ class SparseAdagrad:
                                                      self.total_rows, ctypes.c_void_p(self._ws.data_ptr() + off), need, _stream()))
 
 
+class SparseFtrl:
+    """Fused sparse FTRL-Proximal over a TableSet (include/dir_hip.h: dir_sparse_ftrl_sorted_f32; the reference's
+    linear_optimizer='Ftrl', deepFM.py:58, with [TF-upstream] tf.train.FtrlOptimizer defaults: initial accumulator 0.1,
+    learning_rate_power -0.5, l1 = l2 = 0).  step(ids, grad): grad is [B, F*K] (one gradient row per slot) or [B, K] (the same
+    row for every slot: the linear term, whose d logit is shared by all columns)."""
+
+    def __init__(self, tables, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
+        self.ts = _as_tableset(tables)
+        self.lr, self.l1, self.l2 = float(lr), float(l1), float(l2)
+        dev = self.ts.device
+        self.accums = [torch.full_like(t, initial_accumulator_value) for t in self.ts.tables]
+        self.linears = [torch.zeros_like(t) for t in self.ts.tables]
+        self.acc_ptrs = torch.tensor([a.data_ptr() for a in self.accums], dtype=torch.int64, device=dev)
+        self.lin_ptrs = torch.tensor([z.data_ptr() for z in self.linears], dtype=torch.int64, device=dev)
+        base = [0]
+        for v in self.ts.vocab[:-1]:
+            base.append(base[-1] + v)
+        self.total_rows = sum(self.ts.vocab)
+        self.row_base = torch.tensor(base, dtype=torch.int64, device=dev)
+        self._ws = None
+
+    def attach(self):
+        """Consume the linear term's gradient directly in backward (autograd.LinearLogit)."""
+        self.ts.grad_sink = self.step
+        return self
+
+    def step(self, ids, grad):
+        ts = self.ts
+        _dev(ids, torch.int64, "ids")
+        _dev(grad, torch.float32, "grad")
+        B, sb, sf = _onehot_strides(ids, ts.F)
+        if grad.dim() != 2 or grad.shape[0] != B or grad.stride(1) != 1 or grad.shape[1] not in (ts.K, ts.F * ts.K):
+            raise ValueError("grad must be [B, F*K] or [B, K] with unit inner stride")
+        if B == 0:
+            return
+        slot_stride = ts.K if grad.shape[1] == ts.F * ts.K and ts.F > 1 else 0
+        lib = _lib.load()
+        need = int(lib.dir_sparse_adagrad_sorted_workspace_bytes(B, ts.F, ts.K, self.total_rows))
+        if need <= 0:
+            raise _lib.DirError(-4, "sparse_ftrl_sorted: unsupported size (B*F < 2^31, total rows < 2^32-1)")
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=ts.device)
+        off = (-self._ws.data_ptr()) % 256
+        _lib.check(lib.dir_sparse_ftrl_sorted_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), _ptr(self.lin_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
+                                                  _ptr(grad), grad.stride(0), slot_stride, self.lr, self.l1, self.l2, B,
+                                                  _ptr(self.row_base), self.total_rows,
+                                                  ctypes.c_void_p(self._ws.data_ptr() + off), need, _stream()))
+
+
 class PackedTables:
     """Serving layout: one [vocab_f, ld] buffer per slot, embedding at columns [0, K), first-order weight at column K
     (include/dir_hip.h: dir_gather_fm_linear_packed_f32).  ld = 32 floats = one 128-byte line for K <= 31.  Built from

@@ -287,6 +287,18 @@ int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, in
                                   int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
                                   int64_t workspace_bytes, dir_stream_t stream);
 
+/* FTRL-Proximal on sparse rows through the same sorted machinery (the reference's linear_optimizer='Ftrl', deepFM.py:58;
+ * [TF-upstream] tf.train.FtrlOptimizer with learning_rate_power = -0.5): per touched row, g = sum of its gradient rows,
+ *   n' = n + g^2; sigma = (sqrt(n') - sqrt(n)) / lr; z' = z + g - sigma*w;
+ *   w' = |z'| > l1 ? (sign(z')*l1 - z') / (sqrt(n')/lr + 2*l2) : 0.
+ * tables / accums (n) / linears (z): device arrays [F] of device pointers, [vocab_f, K] each.  The gradient row of entry
+ * (b, f) is grad + b*grad_ld + f*grad_slot_stride (K floats): grad_slot_stride = 0 hands every slot the same [B, K] rows
+ * -- the linear term's d logit (K = 1, deepFM.py:258-263).  Workspace as for dir_sparse_adagrad_sorted_f32. */
+int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* accums, float* const* linears, int F, int K,
+                               const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld,
+                               int64_t grad_slot_stride, float lr, float l1, float l2, int64_t B, const int64_t* row_base,
+                               int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+
 /* Diagnostic only (never on the product path): cycle stamps of the DIR_CIN_STAMP=1 build of the CIN kernel, summed
  * over waves since the last call: [0] chunk start -> end of its MFMA stream, [1] -> past the chunk barrier,
  * [2] chunks, [3] prologue, [4] epilogue, [5] waves.  Synchronises the device. */

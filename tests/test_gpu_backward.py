@@ -442,3 +442,72 @@ def test_dcn_reference_train_step(built_lib):
     assert lrs[0] == pytest.approx(0.02) and lrs[40] == pytest.approx(0.01) and lrs[-1] == pytest.approx(0.01)
     assert step.global_step == 50
     assert losses[-1] < 0.8 * losses[0], losses[::10]
+
+
+@pytest.mark.parametrize("B,F,K,V,shared", [(300, 5, 1, 20, True), (4096, 26, 1, 1000, True), (777, 3, 4, 50, False), (2000, 2, 1, 3, True),
+                                            (513, 4, 8, 7, False)])
+def test_fused_sparse_ftrl(built_lib, B, F, K, V, shared):
+    """dir_sparse_ftrl_sorted_f32 vs a float64 FTRL-Proximal ([TF-upstream] tf.train.FtrlOptimizer: duplicates summed first),
+    l1 and l2 active, two steps; `shared`: one [B, K] gradient row for every slot (the linear term)."""
+    from dir_amd import ops
+    rng = np.random.default_rng(B + K + F)
+    shape = (V,) if K == 1 else (V, K)
+    tabs = [(rng.standard_normal(shape) * 0.1).astype(np.float32) for _ in range(F)]
+    dev = [torch.from_numpy(t.copy()).cuda() for t in tabs]
+    lr, l1, l2 = 0.2, 0.01, 0.05
+    opt = ops.SparseFtrl(dev, lr=lr, initial_accumulator_value=0.1, l1=l1, l2=l2)
+    w = [t.astype(np.float64).reshape(V, K) for t in tabs]
+    n = [np.full((V, K), 0.1) for _ in range(F)]
+    z = [np.zeros((V, K)) for _ in range(F)]
+    for step in range(2):
+        ids = rng.integers(-1, V, size=(B, F)).astype(np.int64)
+        grad = (rng.standard_normal((B, K if shared else F * K)) * 0.5).astype(np.float32)
+        opt.step(torch.from_numpy(ids).cuda(), torch.from_numpy(grad).cuda())
+        for f in range(F):
+            gsum = np.zeros((V, K))
+            ok = ids[:, f] >= 0
+            gf = grad if shared else grad[:, f * K:(f + 1) * K]
+            np.add.at(gsum, ids[ok, f], gf[ok].astype(np.float64))
+            t = np.zeros(V, bool); t[ids[ok, f]] = True
+            n_new = n[f][t] + gsum[t] ** 2
+            sigma = (np.sqrt(n_new) - np.sqrt(n[f][t])) / lr
+            z_new = z[f][t] + gsum[t] - sigma * w[f][t]
+            quad = np.sqrt(n_new) / lr + 2 * l2
+            w[f][t] = np.where(np.abs(z_new) > l1, (np.sign(z_new) * l1 - z_new) / quad, 0.0)
+            n[f][t], z[f][t] = n_new, z_new
+    for f in range(F):
+        _close(dev[f].reshape(V, K), w[f], tol=2e-5)
+        _close(opt.accums[f].reshape(V, K), n[f], tol=2e-5)
+        _close(opt.linears[f].reshape(V, K), z[f], tol=5e-5)
+
+
+def test_deepfm_fused_ftrl_matches_torch_ftrl(built_lib):
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    from dir_amd.autograd import Ftrl
+    B, F, K, V = 256, 4, 8, 12
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+
+    def make():
+        torch.manual_seed(7)
+        m = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[16], fm_embedding_size=K).cuda()
+        with torch.no_grad():
+            for p in m.linear_weights:
+                p.normal_(0, 0.05)
+        return m
+    a, b = make(), make()
+    a.fused_sparse_ftrl(lr=0.2)
+    opt_b = Ftrl(list(b.linear_weights), lr=0.2)
+    g = torch.Generator().manual_seed(2)
+    for _ in range(3):
+        ids = torch.randint(0, V, (B, F), generator=g)
+        labels = torch.randint(0, 2, (B, 1), generator=g).float().cuda()
+        feats = {"C%d" % i: ids[:, i].cuda() for i in range(F)}
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+            torch.nn.functional.binary_cross_entropy_with_logits(m(feats), labels, reduction="sum").backward()
+        assert a.linear_weights[0].grad is None and a.linear_bias.grad is not None
+        opt_b.step()
+    for pa, pb in zip(a.linear_weights, b.linear_weights):
+        _close(pa, pb, tol=2e-5)
