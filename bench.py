@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
-                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full", "deepfm_train",
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
                              "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
@@ -317,6 +317,65 @@ def main():
                 model(feats[i % len(feats)])
         roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K)), "kernel": "DCN forward (embedding-bag bytes only)"}
         cfg.update({"fields": F, "dense": 13, "d": model.column_num, "cross_layers": 3, "deep": [1024, 1024]})
+    elif wl == "dcn_train":
+        # whole DCN training step with the reference's train_op (Adam eps 1e-4, cosine decay, per-tensor clip_by_norm 100:
+        # DeepCrossNetwork.py:264-290, DeepCrossNetwork/train.py:111-125) on the configs[2] model
+        from dir_amd.dcn import DeepCrossNetwork
+        from dir_amd import feature_column as fc
+        cols = [fc.embedding_column(fc.categorical_column_with_identity("C%02d" % i, V), K) for i in range(F)]
+        cols += [fc.numeric_column("I%02d" % i) for i in range(13)]
+        model = DeepCrossNetwork(columns=cols, cross_layer_num=3, dnn_hidden_units=[1024, 1024], batch_norm=True, optimizer="Adam",
+                                 optimizer_spec={"epsilon": 1e-4},
+                                 learning_rate_spec={"learning_rate": 0.001, "decay_method": "cosine_decay", "decay_steps": 3000,
+                                                     "alpha": 0.5}).to(device)
+        train_op = model.train_step()
+        idsl = make_ids(torch, args, gen, device, V)
+        dense = torch.rand((B, 13), generator=gen, device=device)
+        feats = []
+        for ids in idsl:
+            f = {"C%02d" % i: ids[:, i].contiguous() for i in range(F)}
+            f.update({"I%02d" % i: dense[:, i].contiguous() for i in range(13)})
+            feats.append(f)
+        labels = (torch.rand((B, 1), generator=gen, device=device) < 0.25).float()
+
+        def step(i):
+            train_op(torch.nn.functional.binary_cross_entropy_with_logits(model(feats[i % len(feats)]), labels))
+        roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K)), "kernel": "whole DCN training step (embedding-bag bytes only)"}
+        cfg.update({"fields": F, "dense": 13, "d": model.column_num, "cross_layers": 3, "deep": [1024, 1024],
+                    "train_op": "Adam(eps 1e-4) dense on all variables incl. tables, cosine decay, clip_by_norm 100 per tensor"})
+    elif wl in ("xdeepfm_full", "xdeepfm_train"):
+        # BASELINE configs[4] on one GPU: xDeepFM (CIN 128-128-128 + DNN 400-400 + linear) forward, or a whole training step
+        # (CIN backward on MFMA, sparse table gradients, torch Adagrad on everything dense, SGD on the sparse parameters)
+        from dir_amd.xdeepfm import XDeepFM
+        from dir_amd import feature_column as fc
+        cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+        model = XDeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                        cin_layer_sizes=(128, 128, 128), dnn_hidden_units=(400, 400)).to(device)
+        idsl = make_ids(torch, args, gen, device, V)
+        featl = [{"C%d" % f: ids[:, f] for f in range(F)} for ids in idsl]
+        flops, hp = 0, F
+        for h in (128, 128, 128):
+            flops += 2 * B * K * hp * F * h
+            hp = h
+        if wl == "xdeepfm_full":
+            def step(i):
+                with torch.no_grad():
+                    model(featl[i % len(featl)])
+            roof = {"bound": "mfma", "alg_flops": flops, "kernel": "xDeepFM forward (CIN flops only)"}
+        else:
+            sparse_ids = {id(p) for p in model.embedding_weights} | {id(p) for p in model.linear_weights}
+            opt_d = torch.optim.Adagrad([p for p in model.parameters() if id(p) not in sparse_ids], lr=0.01, initial_accumulator_value=0.1)
+            opt_s = torch.optim.SGD([p for p in model.parameters() if id(p) in sparse_ids], lr=0.01)
+            labels = (torch.rand((B, 1), generator=gen, device=device) < 0.25).float()
+
+            def step(i):
+                opt_d.zero_grad(set_to_none=True)
+                opt_s.zero_grad(set_to_none=True)
+                torch.nn.functional.binary_cross_entropy_with_logits(model(featl[i % len(featl)]), labels).backward()
+                opt_d.step()
+                opt_s.step()
+            roof = {"bound": "mfma", "alg_flops": 3 * flops, "kernel": "xDeepFM training step (CIN forward + backward flops only)"}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "cin": [128, 128, 128], "dnn": [400, 400]})
     elif wl == "dcn_cross":
         d, L = F * K, 3
         x0 = torch.randn((B, d), generator=gen, device=device) * 0.25
