@@ -337,6 +337,15 @@ __device__ __forceinline__ void din_mlp_tiles(DinSh<K, NC1, NC2>& sh, const DinF
     }
 }
 
+#ifdef DIN_STAMP   // tools/din_probe.hip only: cycles per phase, summed over workgroups (thread 0) -- [0] stage [1] mlp [2] softmax
+__device__ unsigned long long din_stamp[8];   // [3] pool+out [4] samples [5] workgroups [6] total
+#define DIN_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define DIN_ACC(i, a, b) if (threadIdx.x == 0) atomicAdd(&din_stamp[i], (b) - (a))
+#else
+#define DIN_T(v)
+#define DIN_ACC(i, a, b)
+#endif
+
 template <int K, int NC1, int NC2>
 __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ table,
                                                        const int64_t* __restrict__ hist,
@@ -444,7 +453,9 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
     load_rows(len0, cid0, id0, hreg, areg4);
     load_meta(blockIdx.x + G, len1, cid1, id1);
 
+    DIN_T(st_begin);
     for (int64_t b = blockIdx.x; b < B; b += G) {
+        DIN_T(st0);
         const int len = len0;
         const int RT = (len + 15) >> 4;
         // ---- stage this sample's rows (already in registers) into LDS --------------------------------------
@@ -460,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
         for (int j = len + tid; j < 64; j += NT) sh.valid[j] = 0;
         if (tid < KC) *reinterpret_cast<float4*>(sh.av + 4 * tid) = areg4;
         __syncthreads();
+        DIN_T(st1);
         // ---- issue the next sample's row reads and the ids of the one after; both land during the MFMAs -------
         len0 = len1;
         cid0 = cid1;
@@ -479,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
                 break;
         }
         __syncthreads();
+        DIN_T(st2);
         // ---- scores: sum the column-tile partials, masked softmax (wave 0) -----------------------------------
         if (tid < 64) {
             const bool ok = tid < len && sh.valid[tid];
@@ -498,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
             sh.sc[tid] = sv;
         }
         __syncthreads();
+        DIN_T(st3);
         // ---- pooling: NPART threads per output column, then one add tree -------------------------------------
         if (tid < S::NPART * K) {
             const int k = tid % K, part = tid / K;
@@ -515,9 +529,15 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
             for (int p = 0; p < S::NPART; ++p) acc_o += sh.pool[p * K + tid];
             out[b * K + tid] = acc_o;
         }
+        DIN_T(st4);
+        DIN_ACC(0, st0, st1); DIN_ACC(1, st1, st2); DIN_ACC(2, st2, st3); DIN_ACC(3, st3, st4);
+        DIN_ACC(4, 0ull, 1ull);
         // next iteration's first LDS writes (uh, av, valid) do not touch pool/sc/scp; its later phases are
         // ordered behind its own barriers
     }
+    DIN_T(st_end);
+    DIN_ACC(6, st_begin, st_end);
+    DIN_ACC(5, 0ull, 1ull);
 }
 
 template <int K, int NC1, int NC2>
