@@ -511,3 +511,55 @@ def test_deepfm_fused_ftrl_matches_torch_ftrl(built_lib):
         opt_b.step()
     for pa, pb in zip(a.linear_weights, b.linear_weights):
         _close(pa, pb, tol=2e-5)
+
+
+@pytest.mark.parametrize("combiner", ["mean", "sum", "sqrtn"])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("field_major", [False, True])
+def test_multihot_bag_backward(built_lib, combiner, weighted, field_major):
+    """Sparse table gradients of weighted variable-length bags ([TF-upstream] embedding_lookup_sparse: id < 0 pruned, empty bag
+    -> zeros, mean = sum / sum(w), sqrtn = sum / sqrt(sum(w^2))) against float64 autograd of the same expression."""
+    from dir_amd import autograd as ag, ops
+    g = torch.Generator().manual_seed(11)
+    B, F, K, V = 37, 3, 8, 20
+    lens = torch.randint(0, 5, (B * F,), generator=g)
+    lens[3] = 0
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
+    nnz = int(offs[-1])
+    ids = torch.randint(-1, V, (nnz,), generator=g)
+    wts = (torch.rand(nnz, generator=g) + 0.25) if weighted else None
+    tabs = [torch.randn(V, K, generator=g) * 0.3 for _ in range(F)]
+    gout = torch.randn(B, F * K, generator=g)
+
+    t64 = [t.double().requires_grad_(True) for t in tabs]
+    out64 = torch.zeros(B, F * K, dtype=torch.float64)
+    rows = []
+    for bag in range(B * F):
+        b, f = (bag % B, bag // B) if field_major else (bag // F, bag % F)
+        s, e = int(offs[bag]), int(offs[bag + 1])
+        acc = torch.zeros(K, dtype=torch.float64)
+        sw = 0.0
+        sw2 = 0.0
+        for i in range(s, e):
+            if ids[i] < 0:
+                continue
+            w = float(wts[i]) if weighted else 1.0
+            acc = acc + w * t64[f][ids[i]]
+            sw += w
+            sw2 += w * w
+        if combiner == "mean" and sw > 0:
+            acc = acc / sw
+        if combiner == "sqrtn" and sw2 > 0:
+            acc = acc / sw2 ** 0.5
+        rows.append((b, f, acc))
+    out64 = torch.stack([torch.cat([r[2] for r in sorted(rows, key=lambda x: (x[0], x[1])) if r[0] == b]) for b in range(B)])
+    out64.backward(gout.double())
+
+    dev = [t.cuda().requires_grad_(True) for t in tabs]
+    ts = ops.TableSet([t.data for t in dev])
+    out = ag.embedding_bag(ts, ids.cuda(), dev, offs.cuda(), wts.cuda() if weighted else None, combiner=combiner, field_major=field_major)
+    _close(out, out64, tol=2e-6)
+    out.backward(gout.cuda())
+    for t, r in zip(dev, t64):
+        assert t.grad.is_sparse
+        _close(t.grad.to_dense(), r.grad if r.grad is not None else torch.zeros_like(r), tol=1e-5)
