@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
-                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
                              "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
@@ -222,6 +222,21 @@ def main():
                 "kernel": "gather_onehot_k + fm_bwd_k + " + ("adagrad_keys_k + rocprim radix sort + adagrad_tile_k + adagrad_fix_k"
                                                             if args.adagrad_method == "sorted" else "adagrad_link_k + adagrad_apply_k")}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "adagrad": args.adagrad_method, "ids": args.id_dist})
+    elif wl == "multihot_bag":
+        # weighted variable-length bags (dataset/SequenceTensorFlowDataset/test4.py:50-59 style input): per
+        # (sample, field) a bag of 0..8 ids with fp32 weights, combiner "mean", CSR sample-major
+        sigma = 1.0 / (K ** 0.5)
+        tables = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
+        ts = ops.TableSet(tables)
+        lens = torch.randint(0, 9, (B * F,), generator=gen, device=device)
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), lens.cumsum(0)])
+        nnz = int(offs[-1].item())
+        vals = [torch.randint(0, V, (nnz,), generator=gen, device=device) for _ in range(args.rotate)]
+        wts = torch.rand((nnz,), generator=gen, device=device) + 0.25
+        out = torch.empty((B, F * K), dtype=torch.float32, device=device)
+        step = lambda i: ops.embedding_bag(ts, vals[i % len(vals)], offs, wts, combiner="mean", out=out)  # noqa: E731
+        roof = {"bound": "hbm", "alg_bytes": nnz * (8 + 4 + 4 * K) + B * F * (8 + 4 * K), "kernel": "bag_csr_k (weighted mean)"}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "nnz": nnz, "bag_len": "U{0..8}", "combiner": "mean", "weights": True})
     elif wl == "deepfm_train":
         # one whole DeepFM training step with the reference's optimisers (deepFM.py:58,61): forward (gather+FM kernel,
         # linear term, 400-400-400 MLP on rocBLAS), BCE loss, backward (HIP FM backward, sparse row gradients), fused sorted

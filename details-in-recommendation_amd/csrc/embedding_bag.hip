@@ -209,52 +209,69 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
                                                  const float* __restrict__ weights, int64_t sb, int64_t sf,
                                                  int F, int K, int64_t B, int combiner, int flags,
                                                  float* __restrict__ out, int64_t out_ld) {
+    // A bag needs three dependent global reads (offsets -> ids/weights -> rows).  The loop over the fields of a sample is
+    // software-pipelined so that only the row reads are on the critical path: at field f the offsets of field f+2 and the
+    // first U ids/weights of field f+1 are issued before the rows of field f are summed.  Entries are still reduced in bag
+    // order (bit-exact against the oracle); bags longer than U continue with the plain loop.
     using V = typename VecT<VEC>::T;
     constexpr int SPW = 64 / LPS;
-    constexpr int U = 4;
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63;
     const int c = lane & (LPS - 1);
     const int s = lane / LPS;
     const int kv = (K + VEC - 1) / VEC;
     const bool cact = c < kv;
     const bool prune_w = (flags & DIR_BAG_PRUNE_NONPOSITIVE_WEIGHTS) != 0;
+    const bool nt = (flags & DIR_GATHER_STREAM_ROWS) != 0;      // tables far beyond the Infinity Cache: rows bypass the caches
     const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
         const int64_t b = g * SPW + s;
         const bool act = cact && (b < B);
-        for (int f = 0; f < F; ++f) {
-            const float* t = tables[f];
-            int64_t beg = 0, end = 0;
-            if (act) {
+        auto load_off = [&](int f, int64_t& beg, int64_t& end) {
+            beg = 0;
+            end = 0;
+            if (act && f < F) {
                 const int64_t bag = b * sb + (int64_t)f * sf;
                 beg = offsets[bag];
                 end = offsets[bag + 1];
             }
+        };
+        auto load_ent = [&](int64_t e0, int64_t end, int64_t (&id)[U], float (&w)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t e = e0 + u;
+                id[u] = e < end ? ids[e] : (int64_t)-1;
+                w[u] = (weights && e < end) ? weights[e] : 1.0f;
+                if (weights && prune_w && !(w[u] > 0.0f)) id[u] = -1;
+            }
+        };
+        int64_t beg0, end0, beg1, end1, beg2, end2;
+        int64_t id0[U], id1[U];
+        float w0[U], w1[U];
+        load_off(0, beg0, end0);
+        load_off(1, beg1, end1);
+        load_ent(beg0, end0, id0, w0);
+        for (int f = 0; f < F; ++f) {
+            const float* t = tables[f];
+            load_off(f + 2, beg2, end2);
+            load_ent(beg1, end1, id1, w1);              // field f+1 (empty range when f+1 == F)
             V acc = vzero((V*)nullptr);
             float wsum = 0.f, w2sum = 0.f;
             int cnt = 0;
-            for (int64_t e0 = beg; e0 < end; e0 += U) {
-                int64_t id[U];
-                float w[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int64_t e = e0 + u;
-                    id[u] = e < end ? ids[e] : (int64_t)-1;
-                    w[u] = (weights && e < end) ? weights[e] : 1.0f;
-                    if (weights && prune_w && !(w[u] > 0.0f)) id[u] = -1;
-                }
+            for (int64_t e0 = beg0; e0 < end0; e0 += U) {
+                if (e0 != beg0) load_ent(e0, end0, id0, w0);   // a bag longer than U
                 V row[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     row[u] = vzero((V*)nullptr);
-                    if (id[u] >= 0) row[u] = ldv(t + id[u] * K + c * VEC, (V*)nullptr);
+                    if (id0[u] >= 0) row[u] = nt ? ldv_nt(t + id0[u] * K + c * VEC, (V*)nullptr) : ldv(t + id0[u] * K + c * VEC, (V*)nullptr);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    if (id[u] >= 0) {
-                        acc = weights ? vadd(acc, vscale(row[u], w[u])) : vadd(acc, row[u]);
-                        wsum = wsum + w[u];
-                        w2sum = w2sum + w[u] * w[u];
+                    if (id0[u] >= 0) {
+                        acc = weights ? vadd(acc, vscale(row[u], w0[u])) : vadd(acc, row[u]);
+                        wsum = wsum + w0[u];
+                        w2sum = w2sum + w0[u] * w0[u];
                         ++cnt;
                     }
                 }
@@ -267,6 +284,9 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
                 }
             }
             if (act) stv(out + b * out_ld + (int64_t)f * K + c * VEC, acc);
+            beg0 = beg1; end0 = end1; beg1 = beg2; end1 = end2;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { id0[u] = id1[u]; w0[u] = w1[u]; }
         }
     }
 }
