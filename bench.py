@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
-                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
+                    choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "dcn_cross_backward", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
                              "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--id-layout", default="bf", choices=["bf", "fb"], help="ids stored [B,F] or [F,B]")
     ap.add_argument("--rotate", type=int, default=4, help="distinct id batches rotated through")
     ap.add_argument("--adagrad-method", default="sorted", choices=["sorted", "chains"], help="train_sparse: SparseAdagrad method")
+    ap.add_argument("--cross-d", type=int, default=416, help="dcn_cross_backward: row width (416 = 26 x 16; 429 with the 13 dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -399,6 +400,16 @@ def main():
         out = torch.empty_like(x0)
         step = lambda i: ops.cross_network(x0, w, bb, out=out)  # noqa: E731
         roof = {"bound": "hbm", "alg_bytes": B * 2 * 4 * d + 2 * L * d * 4, "kernel": "cross_k"}
+        cfg.update({"d": d, "layers": L})
+    elif wl == "dcn_cross_backward":
+        d, L = args.cross_d, 3
+        x0 = torch.randn((B, d), generator=gen, device=device) * 0.25
+        w = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
+        bb = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
+        gout = torch.randn((B, d), generator=gen, device=device) * 0.01
+        step = lambda i: ops.cross_network_backward(x0, w, bb, gout)  # noqa: E731
+        # x0 and gout read, gx0 written (the forward is recomputed per row on chip)
+        roof = {"bound": "hbm", "alg_bytes": B * 3 * 4 * d, "kernel": "cross_bwd_k + reduce_partials_k"}
         cfg.update({"d": d, "layers": L})
     elif wl == "din":
         T, Kd, Vd, H1, H2 = 50, 64, 10000000, 80, 40

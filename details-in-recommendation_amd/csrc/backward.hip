@@ -14,6 +14,7 @@
 // Cross backward gives one row to a wave: x_0..x_L of the row are recomputed into an LDS slab, the weight /
 // bias gradients accumulate in per-wave LDS slabs (lane-private addresses, no atomics), each workgroup writes
 // one partial [2, L, d] and a second launch adds the partials in a fixed order (bitwise reproducible).
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "common.hpp"
@@ -188,11 +189,123 @@ __global__ __launch_bounds__(256) void cross_bwd_k(const float* __restrict__ x0,
     }
 }
 
-__global__ void reduce_partials_k(const float* __restrict__ partial, int nblk, int n, float* __restrict__ gw,
-                                  float* __restrict__ gb, int Ld) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        for (int b = 0; b < nblk; ++b) acc += partial[(int64_t)b * n + i];   // fixed order: reproducible
+// Register-resident variant for the common shapes (1 <= L <= 4, a row fits NV chunks per lane): one row per wave, the
+// lane keeps its chunks of x_0..x_{L-1}, of the running gradient and of dL/dx0 in registers, and its share of dw / db as
+// register accumulators over all the rows the wave visits -- no LDS in the row loop (the slab kernel above makes ~10 LDS
+// accesses per chunk and layer: 279 us at d = 416 against a 65 us traffic floor).  The next row is loaded before the
+// current one is processed; two DPP wave sums per layer.  Same per-workgroup partial layout as the slab kernel.
+template <int NV, int VEC, int LT>
+__global__ __launch_bounds__(256) void cross_bwd_reg_k(const float* __restrict__ x0, int64_t x_ld, const float* __restrict__ w,
+                                                       const float* __restrict__ bvec, const float* __restrict__ gout, int64_t g_ld,
+                                                       int64_t B, int d, float* __restrict__ gx0, int64_t gx_ld,
+                                                       float* __restrict__ partial /* [gridDim.x][2][LT][d] */) {
+    using V = BV<VEC>;
+    using T = typename V::T;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][LT][d]: only for the final cross-wave sum
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunk = d / VEC;
+    bool ok[NV];
+    T wv[LT][NV], bv[LT][NV], aw[LT][NV], ab[LT][NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int ch = i * 64 + lane;
+        ok[i] = ch < nchunk;
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            wv[l][i] = ok[i] ? V::ld(w + l * d + ch * VEC) : V::zero();
+            bv[l][i] = ok[i] ? V::ld(bvec + l * d + ch * VEC) : V::zero();
+            aw[l][i] = V::zero();
+            ab[l][i] = V::zero();
+        }
+    }
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    T xn[NV], gn[NV];
+    auto load_row = [&](int64_t row) {
+        const int64_t rc = row < B ? row : B - 1;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = i * 64 + lane;
+            xn[i] = ok[i] ? V::ld(x0 + rc * x_ld + ch * VEC) : V::zero();
+            gn[i] = ok[i] ? V::ld(gout + rc * g_ld + ch * VEC) : V::zero();
+        }
+    };
+    if (r < B) load_row(r);
+    for (; r < B; r += nwave) {
+        T xl[LT][NV], g[NV], gx[NV];
+        float sl[LT];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            xl[0][i] = xn[i];
+            g[i] = gn[i];
+            gx[i] = V::zero();
+        }
+        load_row(r + nwave);                                   // lands while this row is processed
+        // forward recompute: s_l = x_l . w_l, x_{l+1} = ((x0 * s_l) + b_l) + x_l   (DeepCrossNetwork.py:345-346)
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) part = V::dot(xl[l][i], wv[l][i], part);
+            sl[l] = wave_sum_dpp(part);
+            if (l + 1 < LT) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) xl[l + 1][i] = V::upd(xl[0][i], sl[l], bv[l][i], xl[l][i]);
+            }
+        }
+        // backward through the layers
+#pragma unroll
+        for (int l = LT - 1; l >= 0; --l) {
+            float tp = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) tp = V::dot(g[i], xl[0][i], tp);
+            const float t = wave_sum_dpp(tp);                  // dL/ds_l
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                ab[l][i] = V::add(ab[l][i], g[i]);             // db_l += g
+                aw[l][i] = V::fma(xl[l][i], t, aw[l][i]);      // dw_l += t * x_l
+                gx[i] = V::fma(g[i], sl[l], gx[i]);            // dx0 += s_l * g
+                g[i] = V::fma(wv[l][i], t, g[i]);              // dL/dx_l
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = i * 64 + lane;
+            if (ok[i]) V::st(gx0 + r * gx_ld + ch * VEC, V::add(gx[i], g[i]));      // + dL/dx_0
+        }
+    }
+    // workgroup partial = the four waves' accumulators added in wave order
+    const int Ld = LT * d;
+    float* slab = smem + wave * 2 * Ld;
+#pragma unroll
+    for (int l = 0; l < LT; ++l)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ch = i * 64 + lane;
+            if (ok[i]) {
+                V::st(slab + l * d + ch * VEC, aw[l][i]);
+                V::st(slab + Ld + l * d + ch * VEC, ab[l][i]);
+            }
+        }
+    __syncthreads();
+    float* pout = partial + (int64_t)blockIdx.x * 2 * Ld;
+    for (int i = threadIdx.x; i < 2 * Ld; i += blockDim.x)
+        pout[i] = ((smem[i] + smem[2 * Ld + i]) + smem[4 * Ld + i]) + smem[6 * Ld + i];
+}
+
+// gw / gb = sum of the per-workgroup partials.  8 lanes share one output element: lane j adds partials j, j+8, ... in
+// order, then a fixed xor tree joins the eight sums (reproducible; a single thread per element spent 120 us on 512 dependent adds).
+__global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ partial, int nblk, int n, float* __restrict__ gw,
+                                                         float* __restrict__ gb, int Ld) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(q >> 3), j = (int)(q & 7);
+    float acc = 0.f;
+    if (i < n)
+        for (int b = j; b < nblk; b += 8) acc += partial[(int64_t)b * n + i];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (i < n && j == 0) {
         if (i < Ld) gw[i] = acc; else gb[i - Ld] = acc;
     }
 }
@@ -618,9 +731,35 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
     auto lds = [&](int waves) { return sizeof(float) * ((size_t)2 * L * d + (size_t)waves * ((size_t)(L + 1) * d + (size_t)2 * L * d + (size_t)((L + 3) & ~3))); };
     while (nw > 1 && lds(nw) > 150 * 1024) nw >>= 1;
     if (lds(nw) > 150 * 1024) return fail(DIR_E_UNSUPPORTED, "dir_dcn_cross_backward_f32: L=%d d=%d needs %zu B of LDS", L, d, lds(nw));
+    float* partial = static_cast<float*>(workspace);
+    static const int reg_env = getenv("DIR_CROSS_BWD_REG") ? atoi(getenv("DIR_CROSS_BWD_REG")) : 1;   // 0: slab kernel (A/B runs)
+    if (reg_env && L >= 1 && L <= 4 && nv <= (vec ? 4 : 8)) {
+        const int nblk = (int)((B + 3) / 4 < cross_bwd_blocks() ? (B + 3) / 4 : cross_bwd_blocks());
+        const size_t sh = sizeof(float) * (size_t)4 * 2 * L * d;
+#define DIR_REG(NV, V, LT)                                                                                                      \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_bwd_reg_k<NV, V, LT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((cross_bwd_reg_k<NV, V, LT>), dim3(nblk), dim3(256), sh, st, x0, x_ld, w, b, gout, g_ld, B, d, gx0, gx_ld, partial); \
+    } while (0)
+#define DIR_REG_L(NV, V)                                                                                                        \
+    do {                                                                                                                        \
+        if (L == 1) DIR_REG(NV, V, 1); else if (L == 2) DIR_REG(NV, V, 2); else if (L == 3) DIR_REG(NV, V, 3); else DIR_REG(NV, V, 4); \
+    } while (0)
+        if (vec) {
+            if (nv <= 1) DIR_REG_L(1, 4); else if (nv <= 2) DIR_REG_L(2, 4); else DIR_REG_L(4, 4);
+        } else {
+            if (nv <= 1) DIR_REG_L(1, 1); else if (nv <= 2) DIR_REG_L(2, 1); else if (nv <= 4) DIR_REG_L(4, 1); else DIR_REG_L(8, 1);
+        }
+#undef DIR_REG_L
+#undef DIR_REG
+        DIR_CHECK_LAUNCH("dcn_cross_backward(reg)");
+        const int n = 2 * L * d;
+        hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)(((int64_t)n * 8 + 255) / 256)), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
+        DIR_CHECK_LAUNCH("dcn_cross_backward(reduce)");
+        return DIR_OK;
+    }
     const size_t shmem = lds(nw);
     const int nblk = (int)((B + nw - 1) / nw < cross_bwd_blocks() ? (B + nw - 1) / nw : cross_bwd_blocks());
-    float* partial = static_cast<float*>(workspace);
 #define DIR_GO(NV, V)                                                                                                  \
     do {                                                                                                               \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_bwd_k<NV, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -635,7 +774,7 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
     DIR_CHECK_LAUNCH("dcn_cross_backward");
     if (L > 0) {
         const int n = 2 * L * d;
-        hipLaunchKernelGGL(reduce_partials_k, dim3((n + 255) / 256), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
+        hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)(((int64_t)n * 8 + 255) / 256)), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
         DIR_CHECK_LAUNCH("dcn_cross_backward(reduce)");
     }
     return DIR_OK;
