@@ -398,6 +398,17 @@ __global__ __launch_bounds__(256) void adagrad_keys_k(const int64_t* __restrict_
     }
 }
 
+// payload entries of the sharded lookup (p = local_row * F + slot, p < 0 pruned): the owner side of a sharded backward
+__global__ __launch_bounds__(256) void adagrad_keys_payload_k(const int64_t* __restrict__ payload, int F, int64_t n,
+                                                              const int64_t* __restrict__ row_base, uint32_t total_rows,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t p = payload[e];
+        keys[e] = p >= 0 ? (uint32_t)(row_base[p % F] + p / F) : total_rows;
+        vals[e] = (uint32_t)e;
+    }
+}
+
 // per-row update rules of the sorted path: g = the summed gradient chunk of one row
 struct AdagradUpd {   // accum += g^2; w -= lr * g / sqrt(accum)   ([TF-upstream] tf.train.AdagradOptimizer, deepFM.py:61)
     float* const* tables;
@@ -460,6 +471,7 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
                                                       int64_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                       const float* __restrict__ grad, int64_t g_ld, int64_t g_fs /* grad stride per slot */,
                                                       const int64_t* __restrict__ row_base, uint32_t total_rows,
+                                                      int nt /* > 0: payload mode, the table is found from the key among nt tables */,
                                                       float* __restrict__ carry /* [tiles][2][K] */) {
     using V = BV<VEC>;
     using T = typename V::T;
@@ -500,6 +512,10 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
             f = (int)(ent - b * (uint32_t)F);
             sum = V::add(sum, V::ld(grad + (int64_t)b * g_ld + (int64_t)f * g_fs + c * VEC));
         }
+        if (nt > 0) {                                      // payload mode: entries carry no slot; row_base is ascending
+            f = 0;
+            for (int q = 1; q < nt; ++q) f += (int64_t)rk >= row_base[q] ? 1 : 0;
+        }
         const bool open_l = r == 0 && cont_l, open_r = r == nruns - 1 && cont_r;
         if (!open_l && !open_r) {
             const int64_t id = (int64_t)rk - row_base[f];
@@ -516,7 +532,7 @@ template <int LPS, int VEC, class U>
 __global__ __launch_bounds__(256) void adagrad_fix_k(U upd, int F, int K,
                                                      int64_t n, int64_t ntiles, const uint32_t* __restrict__ keys,
                                                      const uint32_t* __restrict__ vals, const int64_t* __restrict__ row_base,
-                                                     uint32_t total_rows, const float* __restrict__ carry) {
+                                                     uint32_t total_rows, int nt, const float* __restrict__ carry) {
     using V = BV<VEC>;
     using T = typename V::T;
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -536,7 +552,11 @@ __global__ __launch_bounds__(256) void adagrad_fix_k(U upd, int F, int K,
         if (!(u1 < n && keys[u1] == kl)) break;                       // the run ends inside tile u
     }
     const uint32_t ent = vals[e1 - 1];
-    const int f = (int)(ent % (uint32_t)F);
+    int f = (int)(ent % (uint32_t)F);
+    if (nt > 0) {
+        f = 0;
+        for (int q = 1; q < nt; ++q) f += (int64_t)kl >= row_base[q] ? 1 : 0;
+    }
     const int64_t id = (int64_t)kl - row_base[f];
     upd.template apply<VEC>(f, id * K + c * VEC, sum);
 }
@@ -576,7 +596,13 @@ extern "C" int64_t dir_sparse_adagrad_sorted_workspace_bytes(int64_t B, int F, i
 template <class U>
 static int sparse_sorted_update(const char* name, U upd, int F, int K, const int64_t* ids, int64_t stride_b, int64_t stride_f,
                                 const float* grad, int64_t grad_ld, int64_t grad_fs, int64_t B, const int64_t* row_base,
-                                int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+                                int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
+                                const int64_t* payload = nullptr /* payload mode: B entries, ids unused, grad is [B, K] */) {
+    const int nt = payload ? F : 0;        // tables to search by key
+    if (payload) {                         // entries are a flat list: one "slot" per entry
+        ids = payload;
+        F = 1;
+    }
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "%s: bad shape", name);
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(ids && grad && row_base && workspace, "%s: null pointer", name);
@@ -594,8 +620,12 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
     uint32_t* v0 = reinterpret_cast<uint32_t*>(ws + p.off_vals[0]);
     uint32_t* v1 = reinterpret_cast<uint32_t*>(ws + p.off_vals[1]);
     float* carry = reinterpret_cast<float*>(ws + p.off_carry);
-    hipLaunchKernelGGL(adagrad_keys_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, row_base,
-                       (uint32_t)total_rows, k0, v0);
+    if (payload)
+        hipLaunchKernelGGL(adagrad_keys_payload_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, payload, nt, n, row_base,
+                           (uint32_t)total_rows, k0, v0);
+    else
+        hipLaunchKernelGGL(adagrad_keys_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, row_base,
+                           (uint32_t)total_rows, k0, v0);
     DIR_CHECK_LAUNCH(name);
     size_t tmp = p.tmp_bytes;
     if (rocprim::radix_sort_pairs(ws + p.off_tmp, tmp, (const uint32_t*)k0, k1, (const uint32_t*)v0, v1, (size_t)n, 0u, p.bits, st) != hipSuccess)
@@ -609,9 +639,9 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
 #define DIR_CASE(L, V)                                                                                                         \
     do {                                                                                                                       \
         hipLaunchKernelGGL((adagrad_tile_k<L, V, U>), dim3((unsigned)ntiles), dim3(256), 0, st, upd, F, K, n, k1, v1, grad, grad_ld, \
-                           grad_fs, row_base, (uint32_t)total_rows, carry);                                                     \
+                           grad_fs, row_base, (uint32_t)total_rows, nt, carry);                                                 \
         hipLaunchKernelGGL((adagrad_fix_k<L, V, U>), gfix, dim3(256), 0, st, upd, F, K, n, ntiles, k1, v1, row_base,             \
-                           (uint32_t)total_rows, carry);                                                                        \
+                           (uint32_t)total_rows, nt, carry);                                                                    \
     } while (0)
     if (vec) {
         switch (lps) {
@@ -822,4 +852,13 @@ extern "C" int dir_sparse_adagrad_f32(float* const* tables, float* const* accums
 #undef DIR_CASE
     DIR_CHECK_LAUNCH("sparse_adagrad");
     return DIR_OK;
+}
+
+extern "C" int dir_sparse_adagrad_sorted_payload_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* payload,
+                                                     int64_t n, const float* grad, float lr, const int64_t* row_base,
+                                                     int64_t total_rows, void* workspace, int64_t workspace_bytes,
+                                                     dir_stream_t stream) {
+    DIR_CHECK_ARG(tables && accums && (payload || n == 0), "dir_sparse_adagrad_sorted_payload_f32: null pointer");
+    return sparse_sorted_update("dir_sparse_adagrad_sorted_payload_f32", AdagradUpd{tables, accums, lr}, F, K, nullptr, 0, 0, grad,
+                                (int64_t)K, 0, n, row_base, total_rows, workspace, workspace_bytes, stream, payload);
 }

@@ -579,6 +579,33 @@ class SparseAdagrad:
                                                      _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
                                                      self.total_rows, ctypes.c_void_p(self._ws.data_ptr() + off), need, _stream()))
 
+    def step_payload(self, payload, grad):
+        """Owner side of a sharded backward (shard.ShardedTables): payload [n] int64 (local_row * F + slot, < 0 pruned) as
+        received from all ranks, grad [n, K] in the same order (include/dir_hip.h: dir_sparse_adagrad_sorted_payload_f32)."""
+        ts = self.ts
+        _dev(payload, torch.int64, "payload")
+        _dev(grad, torch.float32, "grad")
+        n = payload.numel()
+        if grad.shape != (n, ts.K) or not grad.is_contiguous() or not payload.is_contiguous():
+            raise ValueError("grad must be a contiguous [n, K] tensor matching the payload")
+        if n == 0:
+            return
+        lib = _lib.load()
+        ws, need = _sorted_ws(self, lib, n, 1, ts.K, self.total_rows, ts.device)
+        _lib.check(lib.dir_sparse_adagrad_sorted_payload_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(payload), n,
+                                                             _ptr(grad), self.lr, _ptr(self.head_base), self.total_rows, ws, need,
+                                                             _stream()))
+
+
+def _sorted_ws(holder, lib, n_entries, F, K, total_rows, device):
+    need = int(lib.dir_sparse_adagrad_sorted_workspace_bytes(n_entries, F, K, total_rows))
+    if need <= 0:
+        raise _lib.DirError(-4, "sorted sparse update: unsupported size (entries < 2^31, total rows < 2^32-1)")
+    if holder._ws is None or holder._ws.numel() < need + 256:
+        holder._ws = torch.empty(need + 256, dtype=torch.uint8, device=device)
+    off = (-holder._ws.data_ptr()) % 256
+    return ctypes.c_void_p(holder._ws.data_ptr() + off), need
+
 
 class SparseFtrl:
     """Fused sparse FTRL-Proximal over a TableSet (include/dir_hip.h: dir_sparse_ftrl_sorted_f32; the reference's

@@ -48,6 +48,12 @@ class HipBackend:
     def gather_packed(self, payload):
         return ops.gather_packed(self.ts, payload)
 
+    def make_optimizer(self, lr, initial_accumulator_value):
+        return ops.SparseAdagrad(self.ts, lr, initial_accumulator_value)
+
+    def apply_adagrad(self, opt, payload, grad_rows):
+        opt.step_payload(payload, grad_rows)                     # HIP: sorted (row, entry) pairs, per-tile segmented reduce
+
     def back_buffer(self, n, K, device):
         if self._back is None or self._back.shape[0] != n:
             self._back = torch.empty((n, K), dtype=torch.float32, device=device)
@@ -104,6 +110,51 @@ class ShardedTables:
         else:
             out.copy_(inp)
 
+    # ---- training: the gradient rows travel the forward's row exchange backwards and the OWNER updates its shard -------
+    def enable_training(self, lr, initial_accumulator_value=0.1):
+        """Attach the owner-side sparse Adagrad (the reference's dnn_optimizer='Adagrad', deepFM.py:61, applied by the
+        parameter server that holds the partition: deepFM.py:163-167).  lookup_train() then returns an embedding matrix
+        whose backward() updates every rank's shard in place; duplicate rows -- from one rank or several -- are summed
+        first, i.e. one synchronous step over the global batch."""
+        self.optimizer = self.backend.make_optimizer(lr, initial_accumulator_value)
+        return self
+
+    def lookup_train(self, ids):
+        """Differentiable lookup: emb [B_local, F*K] with a grad_fn (the tables themselves get no .grad)."""
+        if getattr(self, "optimizer", None) is None:
+            raise RuntimeError("call enable_training(lr) first")
+        anchor = torch.zeros((), dtype=torch.float32, device=ids.device, requires_grad=True)
+        return _ShardedLookup.apply(self, ids, anchor)
+
+    def _forward_saved(self, ids):
+        B, F = ids.shape
+        K, be = self.K, self.backend
+        flat = ids.reshape(-1).contiguous()
+        n = flat.numel()
+        payload, inv, send_counts, _ = be.bucket(flat)
+        recv_counts = torch.empty_like(send_counts)
+        self._a2a(recv_counts, send_counts, None, None)
+        both = torch.stack([send_counts, recv_counts]).tolist()
+        sc, rc = [int(v) for v in both[0]], [int(v) for v in both[1]]
+        recv = torch.empty(sum(rc), dtype=torch.int64, device=flat.device)
+        self._a2a(recv, payload, rc, sc)
+        rows = be.gather_packed(recv)
+        back = torch.empty((n, K), dtype=torch.float32, device=flat.device)       # private: kept alive by autograd users
+        self._a2a(back.view(-1), rows.reshape(-1), [c * K for c in sc], [c * K for c in rc])
+        emb, _ = be.finish(back, inv, B, F, False)
+        return emb, (inv, sc, rc, recv)
+
+    def _backward_apply(self, saved, g_emb):
+        inv, sc, rc, recv = saved
+        K = self.K
+        n = inv.numel()
+        g = g_emb.contiguous().view(n, K)
+        gsend = torch.empty_like(g)
+        gsend[inv] = g                                   # entry e's row sits at position inv[e] of the exchange order
+        grecv = torch.empty((recv.numel(), K), dtype=torch.float32, device=g.device)
+        self._a2a(grecv.view(-1), gsend.view(-1), [c * K for c in rc], [c * K for c in sc])   # the forward exchange, reversed
+        self.backend.apply_adagrad(self.optimizer, recv, grecv)
+
     def lookup(self, ids, want_fm=False):
         """ids [B_local, F] int64 (global row ids; < 0 pruned -> zeros) -> emb [B_local, F*K] fp32
         (and the FM second-order logit [B_local, 1] when want_fm)."""
@@ -125,3 +176,19 @@ class ShardedTables:
         self._a2a(back.view(-1), rows.reshape(-1), [c * K for c in sc], [c * K for c in rc])
         emb, fm = be.finish(back, inv, B, F, want_fm)                       # HIP: un-permute (+ FM)
         return (emb, fm) if want_fm else emb
+
+
+class _ShardedLookup(torch.autograd.Function):
+    """emb = ShardedTables.lookup(ids) with a backward that routes the row gradients to their owners and lets each owner
+    apply the sparse Adagrad update to its shard (no gradient tensor is returned for the tables)."""
+
+    @staticmethod
+    def forward(ctx, st, ids, anchor):
+        emb, saved = st._forward_saved(ids)
+        ctx.st, ctx.saved = st, saved
+        return emb
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.st._backward_apply(ctx.saved, g)
+        return None, None, None

@@ -287,6 +287,13 @@ int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, in
                                   int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
                                   int64_t workspace_bytes, dir_stream_t stream);
 
+/* Owner side of a SHARDED backward: the n entries are the payload of dir_shard_bucket / dir_gather_packed_f32
+ * (p = local_row * F + slot, p < 0 pruned) as received from all ranks, grad is [n, K] in the same order, tables / accums /
+ * row_base / total_rows describe this rank's shards.  Workspace: dir_sparse_adagrad_sorted_workspace_bytes(n, 1, K, total_rows). */
+int dir_sparse_adagrad_sorted_payload_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* payload,
+                                          int64_t n, const float* grad, float lr, const int64_t* row_base,
+                                          int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+
 /* FTRL-Proximal on sparse rows through the same sorted machinery (the reference's linear_optimizer='Ftrl', deepFM.py:58;
  * [TF-upstream] tf.train.FtrlOptimizer with learning_rate_power = -0.5): per touched row, g = sum of its gradient rows,
  *   n' = n + g^2; sigma = (sqrt(n') - sqrt(n)) / lr; z' = z + g - sigma*w;

@@ -354,3 +354,45 @@ def test_deepfm_packed_serving_equals_reference_layout(built_lib):
         got = model.forward_ids(ids, lin_ids)
     # same kernels' arithmetic for emb / fm / first-order sums; only the final additions associate differently
     assert float((got - ref).abs().max()) <= 1e-5
+
+
+def test_sharded_training_step_single_gpu(built_lib):
+    """ShardedTables.enable_training + lookup_train + backward on ONE GPU under nccl (RCCL) with world_size 1: the row-gradient
+    exchange code path and the owner-side dir_sparse_adagrad_sorted_payload_f32 against a float64 dedup-sum Adagrad."""
+    import torch.distributed as dist
+    from dir_amd.shard import ShardedTables
+    rng = np.random.default_rng(18)
+    F, K, B = 5, 16, 700
+    vocab = [50, 7, 300, 3, 64]
+    full = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
+    ids = np.stack([rng.integers(-1, v, size=B) for v in vocab], 1).astype(np.int64)
+    gout = (rng.standard_normal((B, F * K)) * 0.5).astype(np.float32)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        tabs = [torch.from_numpy(t.copy()).cuda() for t in full]
+        st = ShardedTables.from_full(tabs, force_collective=True).enable_training(lr=0.05, initial_accumulator_value=0.1)
+        for step in range(2):
+            emb = st.lookup_train(torch.from_numpy(ids).cuda())
+            if step == 0:
+                np.testing.assert_array_equal(emb.detach().cpu().numpy(), R.embedding_bag_onehot(full, ids))
+            (emb * torch.from_numpy(gout).cuda()).sum().backward()
+        ref_w = [t.astype(np.float64) for t in full]
+        ref_a = [np.full((v, K), 0.1) for v in vocab]
+        for step in range(2):
+            for f, v in enumerate(vocab):
+                gsum = np.zeros((v, K))
+                ok = ids[:, f] >= 0
+                np.add.at(gsum, ids[ok, f], gout[ok, f * K:(f + 1) * K].astype(np.float64))
+                t = np.zeros(v, bool); t[ids[ok, f]] = True
+                ref_a[f][t] += gsum[t] ** 2
+                ref_w[f][t] -= 0.05 * gsum[t] / np.sqrt(ref_a[f][t])
+        for f in range(F):
+            _close(st.local_tables[f].cpu().numpy(), ref_w[f].astype(np.float32))
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, vocab, K, B, seed, out_q):
+def _worker(rank, world, port, vocab, K, B, seed, out_q, train=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -84,6 +84,47 @@ def _worker(rank, world, port, vocab, K, B, seed, out_q):
                     fm = torch.from_numpy(O.fm_second_order(emb, F_, K).reshape(B_, 1))
                 return torch.from_numpy(emb), fm
 
+            def make_optimizer(self, lr, init):
+                return {"lr": lr, "acc": [np.full(t.shape, init, np.float64) for t in local]}
+
+            def apply_adagrad(self, opt, payload, grad_rows):
+                p, g = payload.numpy(), grad_rows.numpy().astype(np.float64)
+                for f in range(F):
+                    sel = (p >= 0) & (p % F == f)
+                    rows = p[sel] // F
+                    gsum = np.zeros(local[f].shape)
+                    np.add.at(gsum, rows, g[sel])
+                    t = np.zeros(local[f].shape[0], bool)
+                    t[rows] = True
+                    opt["acc"][f][t] += gsum[t] ** 2
+                    w = local[f].numpy().astype(np.float64)
+                    w[t] -= opt["lr"] * gsum[t] / np.sqrt(opt["acc"][f][t])
+                    local[f].copy_(torch.from_numpy(w.astype(np.float32)))
+
+        if train:
+            st = ShardedTables(local, vocab, backend=OracleBackend()).enable_training(lr=0.05, initial_accumulator_value=0.1)
+            gout = rng_b.standard_normal((B, F * K)).astype(np.float32)
+            emb = st.lookup_train(torch.from_numpy(ids))
+            fwd_ok = bool(np.array_equal(emb.detach().numpy(), R.embedding_bag_onehot(full, ids)))
+            (emb * torch.from_numpy(gout)).sum().backward()
+            # reference: one synchronous Adagrad step on the FULL tables over the batches of all ranks
+            allb = [None] * world
+            dist.all_gather_object(allb, (ids, gout))
+            ok = fwd_ok
+            for f, v in enumerate(vocab):
+                gsum = np.zeros((v, K))
+                for ids_r, g_r in allb:
+                    sel = ids_r[:, f] >= 0
+                    np.add.at(gsum, ids_r[sel, f], g_r[sel, f * K:(f + 1) * K].astype(np.float64))
+                t = np.abs(gsum).sum(1) > 0
+                acc = np.full((v, K), 0.1)
+                acc[t] += gsum[t] ** 2
+                ref = full[f].astype(np.float64)
+                ref[t] -= 0.05 * gsum[t] / np.sqrt(acc[t])
+                s_, e_ = div_range(v, world, rank)
+                ok = ok and bool(np.allclose(local[f].numpy(), ref[s_:e_], rtol=1e-6, atol=1e-7))
+            out_q.put((rank, ok, B, F * K))
+            return
         st = ShardedTables(local, vocab, backend=OracleBackend())
         got, fm = st.lookup(torch.from_numpy(ids), want_fm=True)
         got = got.numpy()
@@ -112,6 +153,25 @@ def test_sharded_lookup_matches_full_tables(world, vocab):
     for rank, ok, b, w in res:
         assert ok, "rank %d: sharded lookup differs from the full-table gather" % rank
         assert (b, w) == (B, len(vocab) * K)
+
+
+@pytest.mark.parametrize("world,vocab", [(2, [10, 7, 33]), (3, [40, 5, 64, 9])])
+def test_sharded_training_step_matches_full_table_adagrad(world, vocab):
+    """lookup_train + backward over gloo: every rank's row gradients reach the owners (the forward exchange reversed) and
+    the owners' shards end up equal to one synchronous Adagrad step on the full tables over all ranks' batches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    K, B = 8, 29
+    procs = [ctx.Process(target=_worker, args=(r, world, port, vocab, K, B, 777, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, b, w in res:
+        assert ok, "rank %d: shard differs from the full-table Adagrad step" % rank
 
 
 def test_div_range_covers_vocab():
