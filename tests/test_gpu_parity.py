@@ -338,3 +338,65 @@ def test_packed_rows_gather_fm_linear(ops, oracle, B, F, K, V):
     # field-major ids, no concat output
     _, fm2, lin2 = ops.gather_fm_linear(pt, _dev(ids.T.copy()).t(), bias=_dev(bias), want_emb=False)
     assert torch.equal(fm2, fm) and torch.equal(lin2, lin)
+
+
+def test_full_size_properties_cross_cin_din(ops, oracle):
+    """BASELINE configs 3-5 at full size (B = 65536) through size-independent properties + sampled rows against the oracle.
+    cross: with w = 0 every layer is x + b (exact); scaling x0 and b by 2 scales... only the affine part, so use w = 0 there and
+    sampled rows for the general case.  CIN: xout is linear in xk -- scaling xk by a power of two scales xout exactly; pooled is
+    the d-sum of xout.  DIN (normalize): the weights of a sample sum to 1 and out is that convex combination of its history rows."""
+    B = 65536
+    g = torch.Generator(device="cuda").manual_seed(99)
+    # ---- cross, d = 416, L = 3 ----------------------------------------------------------------------------------------
+    d, L = 416, 3
+    x0 = torch.randn((B, d), generator=g, device="cuda") * 0.25
+    w = (torch.randn((L, d), generator=g, device="cuda") * 0.1).clamp_(-0.2, 0.2)
+    b = (torch.randn((L, d), generator=g, device="cuda") * 0.1).clamp_(-0.2, 0.2)
+    out0 = ops.cross_network(x0, torch.zeros_like(w), b)
+    want = x0
+    for l in range(L):
+        want = ((x0 * 0.0) + b[l]) + want
+    assert torch.equal(out0, want)
+    out = ops.cross_network(x0, w, b)
+    sel = torch.arange(0, B, 1499, device="cuda")
+    ref = oracle.dcn_cross(x0[sel].cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), acc64=True)
+    err = np.abs(out[sel].cpu().double().numpy() - ref) / (1 + np.abs(ref))
+    assert err.max() <= 1e-5
+    # ---- CIN, m = 26, D = 16, Hp = H = 128 ------------------------------------------------------------------------------
+    m, D, H = 26, 16, 128
+    c0 = torch.randn((B, m, D), generator=g, device="cuda") * 0.25
+    xk = torch.randn((B, H, D), generator=g, device="cuda") * 0.25
+    W = torch.randn((H, H * m), generator=g, device="cuda") * (1.0 / (H * m) ** 0.5)
+    xo, po = ops.cin_layer(c0, xk, W)
+    xo2, po2 = ops.cin_layer(c0, xk * 2.0, W)
+    assert torch.equal(xo2, xo * 2.0) and torch.equal(po2, po * 2.0)
+    assert torch.allclose(po, xo.sum(2), rtol=1e-5, atol=1e-6)
+    sel = torch.arange(0, B, 4099, device="cuda")
+    rx, rp = oracle.cin_layer(c0[sel].cpu().numpy(), xk[sel].cpu().numpy(), W.cpu().numpy(), acc64=True)
+    assert (np.abs(xo[sel].cpu().double().numpy() - rx) / (1 + np.abs(rx))).max() <= 1e-5
+    assert (np.abs(po[sel].cpu().double().numpy() - rp) / (1 + np.abs(rp))).max() <= 1e-5
+    del xo, xo2, po2, xk
+    # ---- DIN, T = 50, K = 64, 80-40-1, normalised -----------------------------------------------------------------------
+    T, K, V, H1, H2 = 50, 64, 1000000, 80, 40
+    table = torch.randn((V, K), generator=g, device="cuda") * 0.125
+    hist = torch.randint(0, V, (B, T), generator=g, device="cuda")
+    hl = torch.randint(0, T + 1, (B,), generator=g, device="cuda", dtype=torch.int32)
+    cand = torch.randint(0, V, (B,), generator=g, device="cuda")
+    W1 = torch.randn((4 * K, H1), generator=g, device="cuda") * 0.05
+    W2 = torch.randn((H1, H2), generator=g, device="cuda") * 0.1
+    W3 = torch.randn((H2,), generator=g, device="cuda") * 0.1
+    b1, b2, b3 = torch.zeros(H1, device="cuda"), torch.zeros(H2, device="cuda"), torch.zeros(1, device="cuda")
+    out, sc = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True, want_scores=True)
+    ssum = sc.sum(1)
+    nonempty = hl > 0
+    assert torch.allclose(ssum[nonempty], torch.ones_like(ssum[nonempty]), atol=1e-5)
+    assert (sc[~nonempty] == 0).all() and (out[~nonempty] == 0).all()
+    mask = torch.arange(T, device="cuda").unsqueeze(0) < hl.unsqueeze(1)
+    assert (sc[~mask] == 0).all()
+    sel = torch.arange(0, B, 257, device="cuda")
+    comb = (sc[sel].unsqueeze(2) * table[hist[sel]]).sum(1)
+    assert torch.allclose(out[sel], comb, rtol=1e-5, atol=1e-6)
+    ro, rs = oracle.din_attention_pool(table.cpu().numpy(), hist[sel[:64]].cpu().numpy(), hl[sel[:64]].cpu().numpy(), cand[sel[:64]].cpu().numpy(),
+                                       W1.cpu().numpy(), b1.cpu().numpy(), W2.cpu().numpy(), b2.cpu().numpy(), W3.cpu().numpy(),
+                                       b3.cpu().numpy(), normalize=True, acc64=True)
+    assert (np.abs(out[sel[:64]].cpu().double().numpy() - ro) / (1 + np.abs(ro))).max() <= 1e-5
