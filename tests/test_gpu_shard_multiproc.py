@@ -1,0 +1,99 @@
+"""World-size-2 run of the sharded lookup and the sharded training step with the PRODUCT HIP backend (dir_shard_bucket with
+P = 2, dir_gather_packed_f32, the fused finish kernel, dir_sparse_adagrad_sorted_payload_f32): two processes share the one
+GPU of the test box.  RCCL refuses two ranks on one device, so the all_to_all_single calls are staged through host memory
+over gloo (a subclass overrides ShardedTables._a2a only); on a multi-GPU node the same code runs with backend "nccl"."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, vocab, K, B, seed, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import dir_amd  # noqa: F401
+        from dir_amd.shard import ShardedTables, div_range
+        from oracle import np_ref as R
+        from oracle import oracle as O
+
+        class HostStaged(ShardedTables):
+            def _a2a(self, out, inp, out_splits, in_splits):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+                out.copy_(o)
+
+        F = len(vocab)
+        rng = np.random.default_rng(seed)
+        full = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
+        rng_b = np.random.default_rng(seed + 100 + rank)
+        ids = np.stack([rng_b.integers(-1, v, size=B) for v in vocab], axis=1).astype(np.int64)
+        gout = rng_b.standard_normal((B, F * K)).astype(np.float32)
+        st = HostStaged.from_full([torch.from_numpy(t).cuda() for t in full])
+        assert st.P == world and type(st.backend).__name__ == "HipBackend"
+        emb, fm = st.lookup(torch.from_numpy(ids).cuda(), want_fm=True)
+        ref = R.embedding_bag_onehot(full, ids)
+        ok = bool(np.array_equal(emb.cpu().numpy(), ref)) and bool(np.array_equal(fm.cpu().numpy()[:, 0], O.fm_second_order(ref, F, K)))
+        # training step: owners end up with one synchronous Adagrad step over both ranks' batches
+        st.enable_training(lr=0.05, initial_accumulator_value=0.1)
+        e2 = st.lookup_train(torch.from_numpy(ids).cuda())
+        ok = ok and bool(np.array_equal(e2.detach().cpu().numpy(), ref))
+        (e2 * torch.from_numpy(gout).cuda()).sum().backward()
+        allb = [None] * world
+        dist.all_gather_object(allb, (ids, gout))
+        worst = 0.0
+        for f, v in enumerate(vocab):
+            gsum = np.zeros((v, K))
+            for ids_r, g_r in allb:
+                sel = ids_r[:, f] >= 0
+                np.add.at(gsum, ids_r[sel, f], g_r[sel, f * K:(f + 1) * K].astype(np.float64))
+            t = np.zeros(v, bool)
+            for ids_r, _ in allb:
+                t[ids_r[ids_r[:, f] >= 0, f]] = True
+            acc = np.full((v, K), 0.1)
+            acc[t] += gsum[t] ** 2
+            want = full[f].astype(np.float64)
+            want[t] -= 0.05 * gsum[t] / np.sqrt(acc[t])
+            s_, e_ = div_range(v, world, rank)
+            got = st.local_tables[f].cpu().numpy().astype(np.float64)
+            worst = max(worst, float((np.abs(got - want[s_:e_]) / (1 + np.abs(want[s_:e_]))).max()) if e_ > s_ else 0.0)
+        q.put((rank, ok, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("vocab", [[100, 17, 64, 1000, 5], [3, 3000]])
+def test_two_ranks_share_one_gpu(built_lib, vocab):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, K, B = 2, 16, 257
+    procs = [ctx.Process(target=_worker, args=(r, world, port, vocab, K, B, 4242, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, worst in res:
+        assert ok, "rank %d: sharded lookup differs from the full-table gather" % rank
+        assert worst <= 1e-5, "rank %d: shard differs from the global Adagrad step (%.2e)" % (rank, worst)
