@@ -22,7 +22,8 @@ int main() {
     std::vector<int32_t> hl(B);
     for (auto& v : hh) { s = s * 1664525u + 1013904223u; v = (s >> 4) % V; }
     for (auto& v : hc) { s = s * 1664525u + 1013904223u; v = (s >> 4) % V; }
-    for (auto& v : hl) { s = s * 1664525u + 1013904223u; v = 1 + (s >> 8) % T; }
+    const int fixed_len = getenv("DIN_PROBE_LEN") ? atoi(getenv("DIN_PROBE_LEN")) : 0;   // 0: uniform 1..T
+    for (auto& v : hl) { s = s * 1664525u + 1013904223u; v = fixed_len ? fixed_len : 1 + (s >> 8) % T; }
     float *table, *w1, *b1, *w2, *b2, *w3, *b3, *out; int64_t *hist, *cand; int32_t* len;
     CK(hipMalloc(&table, ht.size() * 4)); CK(hipMalloc(&w1, hw1.size() * 4)); CK(hipMalloc(&w2, hw2.size() * 4)); CK(hipMalloc(&w3, hw3.size() * 4));
     CK(hipMalloc(&b1, H1 * 4)); CK(hipMalloc(&b2, H2 * 4)); CK(hipMalloc(&b3, 4)); CK(hipMalloc(&out, B * K * 4));
