@@ -98,9 +98,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # development switches (a 1-GPU box): DIR_BENCH_BACKEND=gloo + DIR_BENCH_SAME_DEVICE=1 + DIR_SHARD_HOST_STAGED=1 run the
+    # multi-rank code path as several processes on cuda:0 with the exchange staged through host memory; the driver's runs
+    # use the defaults (one rank per GPU, RCCL)
+    backend = os.environ.get("DIR_BENCH_BACKEND", "nccl")
+    if os.environ.get("DIR_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
@@ -524,7 +533,7 @@ def main():
     el = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=device)
+        t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 

@@ -17,10 +17,14 @@ tests); the split sizes cost one host read of 2*P integers per lookup.  world_si
 (unless force_collective) but still runs the three HIP steps.  The HIP steps sit behind a small backend
 object so that the CPU (gloo) tests can stand the oracle in for them; the default backend is the HIP one.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from . import ops
+
+_HOST_STAGED = os.environ.get("DIR_SHARD_HOST_STAGED") == "1"
 
 
 def div_range(vocab, P, rank):
@@ -106,7 +110,12 @@ class ShardedTables:
 
     def _a2a(self, out, inp, out_splits, in_splits):
         if self._collective():
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            if _HOST_STAGED:     # development transport (several ranks on ONE GPU over gloo): never set on a multi-GPU node
+                o = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+                out.copy_(o)
+            else:
+                dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
         else:
             out.copy_(inp)
 
