@@ -12,6 +12,8 @@
  *
  * All device pointers must be 16-byte aligned when the row width in bytes is a multiple of 16
  * (the kernels use 16-byte vector accesses on that path); otherwise 4-byte alignment suffices.
+ * Row width limits of the gather / bag kernels (one wave covers a row): K <= 256 floats on the 16-byte path (K a multiple
+ * of 4, 16-byte aligned tables and output, out_ld a multiple of 4), K <= 64 otherwise; wider rows return DIR_E_UNSUPPORTED.
  */
 #ifndef DIR_HIP_H_
 #define DIR_HIP_H_
@@ -127,6 +129,8 @@ int dir_linear_sparse_sum_f32(const float* const* weights, int F, const int64_t*
  * Replaces: _cross_op / _cross_architecture   models/DeepCrossNetwork/DeepCrossNetwork.py:336-367
  * x0 [B, d] (row stride x_ld), w,b [L, d] contiguous; out [B, d] (row stride out_ld).
  * x_{l+1} = ((x0 * (x_l . w_l)) + b_l) + x_l     (evaluation order of DeepCrossNetwork.py:346)
+ * Limits: L*d*8 B <= 64 KiB (LDS weight image); d <= 4096 on the 16-byte path (d and the row strides multiples of 4,
+ * 16-byte aligned pointers), d <= 1024 otherwise (DIR_E_UNSUPPORTED beyond; the same limits hold for the backward).
  * ------------------------------------------------------------------------------------------ */
 int dir_dcn_cross_f32(const float* x0, int64_t x_ld, const float* w, const float* b, int L,
                       int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream);
