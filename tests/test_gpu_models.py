@@ -12,6 +12,15 @@ pytestmark = pytest.mark.gpu
 from oracle import np_ref as R  # noqa: E402
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def _close(got, ref, tol=1e-5):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     err = np.abs(got - ref) / (1 + np.abs(ref))
@@ -274,7 +283,7 @@ def test_gather_rows_and_sharded_lookup_single_gpu(built_lib, oracle):
     ref = np.stack([full[s][r] if r >= 0 else np.zeros(K, np.float32) for s, r in zip(slot, row)])
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = str(_free_port())        # a fresh port per rendezvous: no TIME_WAIT clashes between tests
     created = False
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -368,7 +377,7 @@ def test_sharded_training_step_single_gpu(built_lib):
     ids = np.stack([rng.integers(-1, v, size=B) for v in vocab], 1).astype(np.int64)
     gout = (rng.standard_normal((B, F * K)) * 0.5).astype(np.float32)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = str(_free_port())        # a fresh port per rendezvous: no TIME_WAIT clashes between tests
     created = False
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

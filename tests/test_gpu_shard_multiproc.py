@@ -22,12 +22,21 @@ def _free_port():
 
 
 def _worker(rank, world, port, vocab, K, B, seed, q):
+    try:
+        _worker_body(rank, world, port, vocab, K, B, seed, q)
+    except Exception:                      # surface the reason instead of leaving the parent to time out
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+def _worker_body(rank, world, port, vocab, K, B, seed, q):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         torch.cuda.set_device(0)
         import dir_amd  # noqa: F401
@@ -95,5 +104,6 @@ def test_two_ranks_share_one_gpu(built_lib, vocab):
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, ok, worst in res:
+        assert not isinstance(worst, str), "rank %d raised:\n%s" % (rank, worst)
         assert ok, "rank %d: sharded lookup differs from the full-table gather" % rank
         assert worst <= 1e-5, "rank %d: shard differs from the global Adagrad step (%.2e)" % (rank, worst)

@@ -25,11 +25,20 @@ def _free_port():
 
 
 def _worker(rank, world, port, vocab, K, B, seed, out_q, train=False):
+    try:
+        _worker_body(rank, world, port, vocab, K, B, seed, out_q, train)
+    except Exception:                      # surface the reason instead of leaving the parent to time out
+        import traceback
+        out_q.put((rank, traceback.format_exc(), 0, 0))
+
+
+def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         from dir_amd.shard import ShardedTables, div_range
         from oracle import np_ref as R
@@ -151,6 +160,7 @@ def test_sharded_lookup_matches_full_tables(world, vocab):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world))
     for rank, ok, b, w in res:
+        assert not isinstance(ok, str), "rank %d raised:\n%s" % (rank, ok)
         assert ok, "rank %d: sharded lookup differs from the full-table gather" % rank
         assert (b, w) == (B, len(vocab) * K)
 
@@ -171,6 +181,7 @@ def test_sharded_training_step_matches_full_table_adagrad(world, vocab):
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, ok, b, w in res:
+        assert not isinstance(ok, str), "rank %d raised:\n%s" % (rank, ok)
         assert ok, "rank %d: shard differs from the full-table Adagrad step" % rank
 
 
