@@ -89,8 +89,8 @@ def _worker_body(rank, world, port, vocab, K, B, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("vocab", [[100, 17, 64, 1000, 5], [3, 3000]])
-def test_two_ranks_share_one_gpu(built_lib, vocab):
+def _run_once(vocab):
+    import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -99,10 +99,25 @@ def test_two_ranks_share_one_gpu(built_lib, vocab):
     procs = [ctx.Process(target=_worker, args=(r, world, port, vocab, K, B, 4242, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=150))
+    except queue.Empty:
+        res = None
     for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()                      # the exact processes this test started
+    return res
+
+
+@pytest.mark.parametrize("vocab", [[100, 17, 64, 1000, 5], [3, 3000]])
+def test_two_ranks_share_one_gpu(built_lib, vocab):
+    res = _run_once(vocab)
+    if res is None or any(isinstance(w, str) and ("onnect" in w or "imeout" in w or "store" in w.lower()) for _, _, w in res):
+        res = _run_once(vocab)            # one retry for a failed rendezvous (transport hiccup, not the code under test)
+    assert res is not None, "workers did not report within the time limit"
     for rank, ok, worst in res:
         assert not isinstance(worst, str), "rank %d raised:\n%s" % (rank, worst)
         assert ok, "rank %d: sharded lookup differs from the full-table gather" % rank
