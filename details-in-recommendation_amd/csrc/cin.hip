@@ -46,7 +46,8 @@ constexpr int CIN_KS = 2;          // k-steps per MFMA burst (one VALU/LDS clust
 constexpr int cin_ic(int MT) { return MT > 26 ? 2 : 4; }   // i values per chunk (LDS: 2*IC*mp*129*4 B of W)
 
 template <int MT /* field count padded to an instantiated size: register arrays, unrolling */, int CT /* column tiles */,
-          bool FP /* interleaved fast staging; needs m == MT */, bool STAMP = false /* diagnostic cycle stamps */>
+          bool FP /* interleaved fast staging; needs m == MT */, bool STAMP = false /* diagnostic cycle stamps */,
+          int ICT = 0 /* i values per chunk; 0: cin_ic(MT) */>
 __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                 const float* __restrict__ W, int m /* actual fields, <= MT */, int Hp, int H,
                                                 int D, int dshift,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     if (FP) m = MT;   // the fast path is only selected when m == MT: keep the divisions compile-time there
     constexpr int mp = (MT + 1) & ~1;
     constexpr int MP2 = mp / 2;
-    constexpr int IC = cin_ic(MT);
+    constexpr int IC = ICT > 0 ? ICT : cin_ic(MT);
     constexpr int WS = CIN_WS;
     constexpr int WCH = IC * mp * WS;     // floats per W buffer
     constexpr int XCH = IC * CIN_ROWS;    // floats per xk buffer
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     constexpr bool FAST = FP;                          // the host only selects FP when cin_fast_shape<MT, CT>() holds
     constexpr int RL = FAST ? (IC * MT) / TPR : 4;
     constexpr bool VEC4 = FAST && (RL % 4 == 0) && ((IC * MT) % 4 == 0);
-    constexpr int NLD = VEC4 ? RL / 4 : RL;            // load slots
+    constexpr bool VEC2 = FAST && !VEC4 && (RL % 2 == 0) && ((IC * MT) % 2 == 0);   // 8-byte loads (IC = 2 at m = 26)
+    constexpr int NLD = VEC4 ? RL / 4 : (VEC2 ? RL / 2 : RL);            // load slots
     static_assert(!FAST || RL <= WE, "staging registers are shared with the generic path");
     const int srow = tid / TPR, spart = tid - srow * TPR;
     const bool srow_ok = hbase + srow < H;
@@ -171,6 +173,9 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
         if (VEC4) {
             const float4 v = *reinterpret_cast<const float4*>(src + 4 * slot);
             wreg[4 * slot] = v.x; wreg[4 * slot + 1] = v.y; wreg[4 * slot + 2] = v.z; wreg[4 * slot + 3] = v.w;
+        } else if (VEC2) {
+            const float2 v = *reinterpret_cast<const float2*>(src + 2 * slot);
+            wreg[2 * slot] = v.x; wreg[2 * slot + 1] = v.y;
         } else {
             wreg[slot] = src[slot];
         }
@@ -432,11 +437,12 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     }
 }
 
-template <int MT, int CT>
-constexpr bool cin_fast_shape() {
+template <int MT, int CT, int IC = 0>
+constexpr bool cin_fast_shape() {   // a thread's contiguous run of a W row must be whole 16-byte (or 8-byte) loads
     constexpr int TPR = 256 / (32 * CT);
-    constexpr int N = cin_ic(MT) * MT;
-    return (N % TPR == 0) && (((N / TPR) % MT == 0) || (MT % (N / TPR) == 0)) && ((N / TPR) % 4 == 0) && (N % 4 == 0);
+    constexpr int N = (IC > 0 ? IC : cin_ic(MT)) * MT;
+    constexpr int RL = N / TPR;
+    return (N % TPR == 0) && ((RL % MT == 0) || (MT % RL == 0)) && ((RL % 4 == 0 && N % 4 == 0) || (RL % 2 == 0 && N % 2 == 0));
 }
 
 template <int MT, int CT, bool FP>
@@ -468,6 +474,22 @@ static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* 
                 set = true;
             }
             hipLaunchKernelGGL((cin_k<26, 4, true, true>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+            return;
+        }
+    }
+    // Hp a multiple of 2 but not of the chunk size (layer 1 of the BASELINE stack: Hp = m = 26): chunks of 2 values of i divide
+    // it exactly, instead of a zero-padded tail chunk that also falls off the interleaved staging
+    if constexpr (cin_ic(MT) == 4 && cin_fast_shape<MT, CT, 2>()) {
+        const bool w8 = m == MT && ((int64_t)Hp * MT) % 2 == 0 && (reinterpret_cast<uintptr_t>(W) & 7u) == 0;
+        if (fast_env && w8 && Hp % 4 != 0 && Hp % 2 == 0) {
+            constexpr int mp = (MT + 1) & ~1;
+            const size_t sh2 = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)2 * mp * CIN_WS + 2 * (size_t)2 * CIN_ROWS);
+            static bool set = false;
+            if (!set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                set = true;
+            }
+            hipLaunchKernelGGL((cin_k<MT, CT, true, false, 2>), grid, dim3(256), sh2, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
             return;
         }
     }
