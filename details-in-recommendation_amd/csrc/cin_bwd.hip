@@ -272,7 +272,8 @@ __device__ __forceinline__ void half32_sum16(const float (&v)[16], float (&u)[8]
     }
 }
 
-template <int CT /* column tiles: ceil(Hp/32) rounded to 1, 2, 4 */, int HT /* H padded: 32, 64, 128 */>
+template <int CT /* column tiles: ceil(Hp/32) rounded to 1, 2, 4 */, int HT /* H padded: 32, 64, 128 */,
+          bool FULLH /* H == HT: the W staging needs no per-element predicate (49 exec-mask branches per j otherwise) */>
 __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                    const float* __restrict__ Wp /* [m][H][32][CT] */,
                                                    const float* __restrict__ G, int m, int Hp, int H, int D, int dshift,
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0,
 #pragma unroll
         for (int q = 0; q < NVP; ++q) {
             const int e4 = tid + 256 * (part * NVP + q);
-            wst[q] = (e4 * 4 < wrows) ? src[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            wst[q] = (FULLH || e4 * 4 < wrows) ? src[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto w_store = [&](int buf, int part) {
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0,
 #pragma unroll
         for (int q = 0; q < NVP; ++q) {
             const int e4 = tid + 256 * (part * NVP + q);
-            if (e4 * 4 < wrows) dst[e4] = wst[q];
+            if (FULLH || e4 * 4 < wrows) dst[e4] = wst[q];
         }
     };
 #pragma unroll
@@ -356,6 +357,19 @@ __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0,
     for (int cc = 0; cc < CT; ++cc)
 #pragma unroll
         for (int q = 0; q < 16; ++q) dk[cc][q] = 0.f;
+    // dx0 store targets of this lane (lanes with (lane & 15) == 0 store two runs of 4 rows per j): element offsets for j = 0,
+    // computed once -- inside the j loop the address is this plus j * D
+    int64_t dx0_off[2];
+    bool dx0_ok[2];
+    {
+        const int gsel = (lane >> 4) & 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t r = row0 + 8 * (2 * gsel + e) + 4 * hh;
+            dx0_ok[e] = r < R;
+            dx0_off[e] = ((r >> dshift) * m) * D + (r & (D - 1));
+        }
+    }
 
     for (int j = 0; j < m; ++j) {
         const int buf = j & 1;
@@ -430,14 +444,10 @@ __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0,
         }
         half32_sum16(p, u);
         if ((lane & 15) == 0) {   // rows 0/2 hold the totals of C/D regs 0..7, rows 1/3 of regs 8..15: 2 runs of 4 rows (d) each
-            const int gsel = (lane >> 4) & 1;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int64_t r = row0 + 8 * (2 * gsel + e) + 4 * hh;
-                if (r < R)
-                    *reinterpret_cast<float4*>(dx0 + ((r >> dshift) * m + j) * D + (r & (D - 1))) =
-                        make_float4(u[4 * e], u[4 * e + 1], u[4 * e + 2], u[4 * e + 3]);
-            }
+            for (int e = 0; e < 2; ++e)
+                if (dx0_ok[e])
+                    *reinterpret_cast<float4*>(dx0 + dx0_off[e] + (int64_t)j * D) = make_float4(u[4 * e], u[4 * e + 1], u[4 * e + 2], u[4 * e + 3]);
         }
         if (more) w_store(buf ^ 1, NP - 1);
         __syncthreads();
@@ -463,10 +473,14 @@ static void launch_cin_dx(dim3 grid, size_t shmem, hipStream_t st, const float* 
                           const float* G, int m, int Hp, int H, int D, int dshift, int64_t R, float* dxk, float* dx0) {
     static bool set = false;
     if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         set = true;
     }
-    hipLaunchKernelGGL((cin_dx_k<CT, HT>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    if (H == HT)
+        hipLaunchKernelGGL((cin_dx_k<CT, HT, true>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else
+        hipLaunchKernelGGL((cin_dx_k<CT, HT, false>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
 }
 
 template <int CT>
