@@ -293,19 +293,19 @@ __global__ __launch_bounds__(256) void cross_bwd_reg_k(const float* __restrict__
         pout[i] = ((smem[i] + smem[2 * Ld + i]) + smem[4 * Ld + i]) + smem[6 * Ld + i];
 }
 
-// gw / gb = sum of the per-workgroup partials.  8 lanes share one output element: lane j adds partials j, j+8, ... in
-// order, then a fixed xor tree joins the eight sums (reproducible; a single thread per element spent 120 us on 512 dependent adds).
+// gw / gb = sum of the per-workgroup partials.  One WAVE per output element: lane j adds partials j, j+64, ... in order,
+// then a fixed xor tree joins the 64 sums (reproducible).  A single thread per element spent 120 us on 512 dependent loads,
+// eight lanes per element still 21 us; this is 8 dependent loads per lane.
 __global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ partial, int nblk, int n, float* __restrict__ gw,
                                                          float* __restrict__ gb, int Ld) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = (int)(q >> 3), j = (int)(q & 7);
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);          // wave-uniform
+    if (i >= n) return;
     float acc = 0.f;
-    if (i < n)
-        for (int b = j; b < nblk; b += 8) acc += partial[(int64_t)b * n + i];
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (i < n && j == 0) {
+    for (int b = lane; b < nblk; b += 64) acc += partial[(int64_t)b * n + i];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
         if (i < Ld) gw[i] = acc; else gb[i - Ld] = acc;
     }
 }
@@ -733,7 +733,7 @@ extern "C" int dir_fm_second_order_backward_f32(const float* emb, int64_t emb_ld
 }
 
 // workspace: dir_dcn_cross_backward_workspace_bytes(L, d) device bytes (the per-workgroup partials)
-static int cross_bwd_blocks() { return kCUs * 2; }
+static int cross_bwd_blocks() { return kCUs * 2; }   // measured: 256 and 1024 workgroups are both slower at d = 416
 
 extern "C" int64_t dir_dcn_cross_backward_workspace_bytes(int L, int d) {
     return (int64_t)cross_bwd_blocks() * 2 * L * d * (int64_t)sizeof(float);
@@ -744,12 +744,12 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
                                           float* gw, float* gb, void* workspace, dir_stream_t stream) {
     DIR_CHECK_ARG(L >= 0 && d > 0 && B >= 0 && x_ld >= d && g_ld >= d && gx_ld >= d, "dir_dcn_cross_backward_f32: bad shape");
     hipStream_t st = as_stream(stream);
-    if (L > 0) {
-        DIR_CHECK_ARG(gw && gb, "dir_dcn_cross_backward_f32: null pointer");
-        if (hipMemsetAsync(gw, 0, sizeof(float) * L * d, st) != hipSuccess || hipMemsetAsync(gb, 0, sizeof(float) * L * d, st) != hipSuccess)
+    if (L > 0) DIR_CHECK_ARG(gw && gb, "dir_dcn_cross_backward_f32: null pointer");
+    if (B == 0) {   // no rows: the gradients are zero (otherwise the reduce kernel writes every element of gw / gb)
+        if (L > 0 && (hipMemsetAsync(gw, 0, sizeof(float) * L * d, st) != hipSuccess || hipMemsetAsync(gb, 0, sizeof(float) * L * d, st) != hipSuccess))
             return fail(DIR_E_HIP, "dir_dcn_cross_backward_f32: memset failed");
+        return DIR_OK;
     }
-    if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(x0 && gout && gx0 && ((w && b && workspace) || L == 0), "dir_dcn_cross_backward_f32: null pointer");
     const bool vec = (d % 4 == 0) && (x_ld % 4 == 0) && (g_ld % 4 == 0) && (gx_ld % 4 == 0) && aligned16(x0) && aligned16(gout) &&
                      aligned16(gx0) && (L == 0 || (aligned16(w) && aligned16(b)));
@@ -784,7 +784,7 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
 #undef DIR_REG
         DIR_CHECK_LAUNCH("dcn_cross_backward(reg)");
         const int n = 2 * L * d;
-        hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)(((int64_t)n * 8 + 255) / 256)), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
+        hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
         DIR_CHECK_LAUNCH("dcn_cross_backward(reduce)");
         return DIR_OK;
     }
@@ -804,7 +804,7 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
     DIR_CHECK_LAUNCH("dcn_cross_backward");
     if (L > 0) {
         const int n = 2 * L * d;
-        hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)(((int64_t)n * 8 + 255) / 256)), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
+        hipLaunchKernelGGL(reduce_partials_k, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, partial, nblk, n, gw, gb, L * d);
         DIR_CHECK_LAUNCH("dcn_cross_backward(reduce)");
     }
     return DIR_OK;

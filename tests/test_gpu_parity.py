@@ -184,7 +184,10 @@ def test_cross_hand_kat(ops):
 
 
 @pytest.mark.parametrize("B,T,K,H1,H2", [(33, 50, 64, 80, 40), (7, 5, 8, 12, 8), (100, 13, 16, 20, 12), (4, 70, 32, 36, 16),
-                                            (65, 64, 32, 40, 16), (130, 64, 64, 80, 40), (20, 17, 64, 72, 36), (9, 1, 64, 80, 40)])
+                                            (65, 64, 32, 40, 16), (130, 64, 64, 80, 40), (20, 17, 64, 72, 36), (9, 1, 64, 80, 40),
+                                            # hidden layers narrower than the instantiated tile counts (zero-padded columns)
+                                            (40, 50, 64, 64, 32), (40, 33, 64, 16, 4), (40, 50, 32, 20, 8), (40, 21, 16, 12, 4),
+                                            (25, 40, 64, 48, 48)])
 @pytest.mark.parametrize("normalize", [False, True])
 def test_din_attention_pool(ops, oracle, B, T, K, H1, H2, normalize):
     rng = np.random.default_rng(T * 3 + K)
