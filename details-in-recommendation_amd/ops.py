@@ -278,6 +278,13 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True):
     xout = torch.empty((B, H, D), dtype=torch.float32, device=x0.device) if want_xout else None
     if pooled is None:
         pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
+    mt = next((t for t in CIN_FIELD_TILES if t >= m), m)
+    if mt != m and B > 0:
+        # the kernel's fast (interleaved-staging) path exists for the instantiated field counts only; a zero field and zero
+        # weight columns change nothing in the sum and cost one small copy (m = 39 -> 40: 85 -> ~135 TFLOP/s)
+        x0 = torch.nn.functional.pad(x0, (0, 0, 0, mt - m))
+        W = torch.nn.functional.pad(W.view(H, Hp, m), (0, mt - m)).reshape(H, Hp * mt)
+        m = mt
     _lib.check(_lib.load().dir_cin_layer_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B,
                                              _ptr(xout) if want_xout else None, _ptr(pooled),
                                              pooled.stride(0), _stream()))
@@ -467,6 +474,7 @@ def cin_dw(x0, xk, G, dW=None, accumulate=False):
 
 
 CIN_MAX_FIELDS = 40   # largest register-resident operand of dir_cin_layer_f32
+CIN_FIELD_TILES = (8, 16, 26, 40)   # field counts dir_cin_layer_f32 is instantiated for
 
 
 def cin_dx(x0, xk, W, G):
