@@ -16,7 +16,7 @@ from torch import nn
 
 from . import autograd as ag
 from . import ops
-from .deepfm import _BatchNormInfer, _glorot_uniform_
+from .deepfm import _BatchNormInfer, _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
 
 
@@ -76,6 +76,7 @@ class DeepCrossNetwork(nn.Module):
             if self.batch_norm and i < n - 1:
                 net = self.bns[bi](net)
                 bi += 1
+            net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :405-408 (TRAIN only), after the BN
         return net
 
     def forward(self, features):

@@ -27,22 +27,47 @@ def _glorot_uniform_(w):  # [TF-upstream] glorot_uniform_initializer, deepFM.py:
     return nn.init.uniform_(w, -lim, lim)
 
 
-class _BatchNormInfer(nn.Module):
-    """tf.layers.batch_normalization in inference form (deepFM.py:303-308): eps 1e-3, gamma and beta."""
+def _train_mode(module):
+    """The reference's mode == TRAIN: the module is in train() state AND autograd is recording (inference calls run under
+    torch.no_grad(), so an un-eval()'ed module still takes the inference forms)."""
+    return module.training and torch.is_grad_enabled()
 
-    def __init__(self, n, eps=1e-3, scale=True):
+
+class _BatchNormInfer(nn.Module):
+    """tf.layers.batch_normalization / contrib batch_norm (deepFM.py:303-308, DeepCrossNetwork.py:413-419): eps 1e-3, beta,
+    optional gamma.  Inference: x * inv + (beta - mean * inv), inv = gamma * rsqrt(moving_variance + eps).  Training
+    ([TF-upstream] training=True): the batch's mean and population variance normalise, and the moving statistics are
+    updated as moving = moving * momentum + batch * (1 - momentum), momentum 0.999."""
+
+    def __init__(self, n, eps=1e-3, scale=True, momentum=0.999):
         super().__init__()
         self.eps = eps
+        self.momentum = momentum
         self.gamma = nn.Parameter(torch.ones(n)) if scale else None
         self.beta = nn.Parameter(torch.zeros(n))
         self.register_buffer("moving_mean", torch.zeros(n))
         self.register_buffer("moving_variance", torch.ones(n))
 
     def forward(self, x):
-        inv = torch.rsqrt(self.moving_variance + self.eps)
+        if _train_mode(self):
+            mean = x.mean(dim=0)
+            var = x.var(dim=0, unbiased=False)
+            with torch.no_grad():
+                self.moving_mean.mul_(self.momentum).add_(mean.detach(), alpha=1.0 - self.momentum)
+                self.moving_variance.mul_(self.momentum).add_(var.detach(), alpha=1.0 - self.momentum)
+        else:
+            mean, var = self.moving_mean, self.moving_variance
+        inv = torch.rsqrt(var + self.eps)
         if self.gamma is not None:
             inv = inv * self.gamma
-        return x * inv + (self.beta - self.moving_mean * inv)
+        return x * inv + (self.beta - mean * inv)
+
+
+def _dropout_train(module, net, rate):
+    """core_layers.dropout(net, rate, training=True) in TRAIN mode only (deepFM.py:301-302, DeepCrossNetwork.py:405-408)."""
+    if rate and _train_mode(module):
+        return torch.nn.functional.dropout(net, p=float(rate), training=True)
+    return net
 
 
 class DeepFM(nn.Module):
@@ -120,6 +145,7 @@ class DeepFM(nn.Module):
     def dnn_logit_fn(self, net):
         for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
             net = self.activation(lin(net))
+            net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :301-302 (TRAIN only), before the BN
             if len(self.bns):
                 net = self.bns[i](net)
         return self.logits_layer(net)                                            # :311-317

@@ -11,15 +11,16 @@ import torch
 from torch import nn
 
 from .dcn import _glorot_normal_
-from .deepfm import _glorot_uniform_
+from .deepfm import _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
 
 _EPSILON = 1e-7                                                                  # ESMM.py:19
 
 
 class _BaseModel(nn.Module):
-    def __init__(self, columns, hidden_units, activation):
+    def __init__(self, columns, hidden_units, activation, dropout=None):
         super().__init__()
+        self.dropout = dropout
         self.input_layer = InputLayer(columns)                                   # ESMM.py:135
         self.activation = activation
         self.hidden = nn.ModuleList()
@@ -38,6 +39,7 @@ class _BaseModel(nn.Module):
         net = self.input_layer(features)
         for lin in self.hidden:
             net = self.activation(lin(net))
+            net = _dropout_train(self, net, self.dropout)                        # ESMM.py:143-144 (TRAIN only)
         return self.logits(net)
 
 
@@ -49,8 +51,8 @@ class ESMM(nn.Module):
                             ctcvr_weight_column=ctcvr_weight_column, dnn_dropout=dnn_dropout, config=config,
                             optimizer=optimizer)
         hidden = list(dnn_hidden_units or [])
-        self.ctr_model = _BaseModel(columns, hidden, dnn_activation_fn)          # ESMM.py:63-64
-        self.cvr_model = _BaseModel(columns, hidden, dnn_activation_fn)          # ESMM.py:65-66
+        self.ctr_model = _BaseModel(columns, hidden, dnn_activation_fn, dnn_dropout)          # ESMM.py:63-64
+        self.cvr_model = _BaseModel(columns, hidden, dnn_activation_fn, dnn_dropout)          # ESMM.py:65-66
 
     def forward(self, features):
         """-> {'ctr_logits', 'ctcvr_logits'} (the `logits` dict of ESMM.py:77)."""

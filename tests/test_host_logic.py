@@ -206,3 +206,37 @@ def test_clip_by_norm_per_tensor():
     out = ts.clip_by_norm_(sp)
     assert out.is_sparse and torch.linalg.vector_norm(out.to_dense()).item() == pytest.approx(100.0, rel=1e-6)
     assert ts.clip_by_norm_(None) is None
+
+
+def test_batch_norm_train_and_inference_forms():
+    """_BatchNormInfer: inference uses the moving statistics; TRAIN (train() state + autograd on) normalises with the batch's
+    mean / population variance and moves the statistics with momentum 0.999 ([TF-upstream] batch_normalization)."""
+    import dir_amd  # noqa: F401
+    from dir_amd.deepfm import _BatchNormInfer, _dropout_train
+    torch.manual_seed(0)
+    bn = _BatchNormInfer(5)
+    x = torch.randn(64, 5) * 3 + 1.5
+    with torch.no_grad():                                  # inference form even though the module is in train() state
+        y = bn(x)
+    assert torch.allclose(y, x / (1 + 1e-3) ** 0.5, atol=1e-6)
+    assert torch.equal(bn.moving_mean, torch.zeros(5))
+    y = bn(x)                                              # TRAIN
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    assert torch.allclose(y, (x - mean) / torch.sqrt(var + 1e-3), atol=1e-5)
+    assert torch.allclose(bn.moving_mean, 0.001 * mean, atol=1e-7)
+    assert torch.allclose(bn.moving_variance, 0.999 + 0.001 * var, atol=1e-6)
+    bn.eval()
+    before = bn.moving_mean.clone()
+    y2 = bn(x)
+    assert torch.equal(bn.moving_mean, before)             # eval(): no update, moving statistics used
+    assert not torch.allclose(y2, y)
+    # dropout: TRAIN only, scaled by 1 / (1 - rate)
+    m = torch.nn.Module()
+    ones = torch.ones(1000, 10)
+    d = _dropout_train(m, ones, 0.5)
+    assert set(d.unique().tolist()) == {0.0, 2.0}
+    with torch.no_grad():
+        assert torch.equal(_dropout_train(m, ones, 0.5), ones)
+    m.eval()
+    assert torch.equal(_dropout_train(m, ones, 0.5), ones)
+    assert torch.equal(_dropout_train(torch.nn.Module(), ones, None), ones)
