@@ -85,7 +85,13 @@ class DeepCrossNetwork(nn.Module):
         deep = self.deep_architecture(x0)
         return self.logits_layer(torch.cat([cross, deep], dim=-1))               # :136-137
 
-    @torch.no_grad()
+    def create_loss(self, features, logits, labels):
+        """_create_loss (DeepCrossNetwork.py:209-225): sigmoid cross entropy, weight_column weights, MEAN reduction
+        -> (weighted_loss, unweighted_loss)."""
+        from .train_spec import _weights_of, weighted_sigmoid_cross_entropy
+        w = _weights_of(features, self.hparams["weight_column"], logits) if isinstance(features, dict) else None
+        return weighted_sigmoid_cross_entropy(logits, labels, w, "mean")
+
     def train_step(self):
         """The reference's train_op for this model (_get_train_op_fn, DeepCrossNetwork.py:264-290) built from the
         constructor's optimizer / optimizer_spec / learning_rate_spec / l2_reg: see train_spec.TrainStep."""
@@ -95,6 +101,7 @@ class DeepCrossNetwork(nn.Module):
                          learning_rate_spec=hp["learning_rate_spec"], l2_reg=hp["l2_reg"],
                          l2_params=[lin.weight for lin in self.hidden])      # l2 on the deep kernels, :386-399
 
+    @torch.no_grad()
     def predict(self, features):
         logits = self.forward(features)                                          # :153-165
         two = torch.cat([torch.zeros_like(logits), logits], dim=-1)

@@ -195,6 +195,13 @@ class DeepFM(nn.Module):
             logits = lin if logits is None else logits + lin                     # add_n, deepFM.py:223
         return logits
 
+    def create_loss(self, features, logits, labels):
+        """The canned binary head's loss (deepFM.py:107-117: weight_column, loss_reduction -- default SUM, deepFM.py:72)
+        -> (weighted_loss, unweighted_loss)."""
+        from .train_spec import _weights_of, weighted_sigmoid_cross_entropy
+        w = _weights_of(features, self.hparams["weight_column"], logits) if isinstance(features, dict) else None
+        return weighted_sigmoid_cross_entropy(logits, labels, w, str(self.hparams["loss_reduction"] or "sum").lower())
+
     def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
         """Attach the fused HIP sparse-Adagrad update to the embedding tables (the reference trains them with
         dnn_optimizer='Adagrad', deepFM.py:61): backward() then updates them in place, with duplicate ids summed first."""

@@ -62,6 +62,17 @@ class ESMM(nn.Module):
         p = ctcvr_logistic.clamp(_EPSILON, 1 - _EPSILON)                         # :73-74
         return {"ctr_logits": ctr_logits, "ctcvr_logits": torch.log(p / (1 - p)), "cvr_logits": cvr_logits}
 
+    def get_loss(self, features, labels, logits):
+        """_get_loss (ESMM.py:150-175): labels {'click_label', 'convert_label'}; CTR and CTCVR sigmoid cross entropies, each
+        MEAN-reduced with its own weight column, added -> (weighted_loss, unweighted_loss = ctr + ctcvr per example)."""
+        from .train_spec import _weights_of, weighted_sigmoid_cross_entropy
+        hp = self.hparams
+        ctr_w = _weights_of(features, hp["ctr_weight_column"], logits["ctr_logits"])
+        ctcvr_w = _weights_of(features, hp["ctcvr_weight_column"], logits["ctcvr_logits"])
+        ctr_loss, ctr_un = weighted_sigmoid_cross_entropy(logits["ctr_logits"], labels["click_label"], ctr_w, "mean")
+        ctcvr_loss, ctcvr_un = weighted_sigmoid_cross_entropy(logits["ctcvr_logits"], labels["convert_label"], ctcvr_w, "mean")
+        return ctr_loss + ctcvr_loss, ctr_un + ctcvr_un
+
     @torch.no_grad()
     def predict(self, features):
         out = self.forward(features)

@@ -97,6 +97,39 @@ def learning_rate_decay(learning_rate_spec, global_step):
         raise TypeError("{} argument are not correct. Check again and note that global_step is omitted.".format(name))
 
 
+def _weights_of(features, weight_column, like):
+    """_get_weights_and_check_match_logits: a feature key, a numeric_column-like object with `.key`, or None (weight 1)."""
+    if weight_column is None:
+        return None
+    key = weight_column if isinstance(weight_column, str) else getattr(weight_column, "key", None)
+    if key is None or key not in features:
+        raise ValueError("weight_column %r is not a key of features" % (weight_column,))
+    w = features[key].to(device=like.device, dtype=torch.float32).reshape(-1, 1)
+    if w.shape[0] != like.shape[0]:
+        raise ValueError("weights shape must be [batch_size, 1]; given %s for logits %s" % (tuple(w.shape), tuple(like.shape)))
+    return w
+
+
+def weighted_sigmoid_cross_entropy(logits, labels, weights=None, reduction="mean"):
+    """The losses of the three model_fns: unweighted = tf.nn.sigmoid_cross_entropy_with_logits(labels, logits), then
+    [TF-upstream] tf.losses.compute_weighted_loss: 'mean' = sum(w * loss) / sum(w broadcast to the losses)
+    (DeepCrossNetwork.py:209-225, ESMM.py:150-175), 'sum' = sum(w * loss) (the canned binary head's default
+    loss_reduction=SUM used by DeepFM, deepFM.py:72,107-117), 'sum_over_batch_size' = sum(w * loss) / number of losses.
+    -> (weighted_loss scalar, unweighted_loss [B,1])"""
+    labels = labels.to(dtype=torch.float32).reshape(logits.shape)
+    unweighted = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction="none")
+    w = torch.ones_like(unweighted) if weights is None else weights.to(unweighted.dtype).expand_as(unweighted)
+    total = (unweighted * w).sum()
+    if reduction in ("sum", "weighted_sum"):
+        return total, unweighted
+    if reduction in ("mean", "weighted_mean"):
+        den = w.sum()
+        return torch.where(den > 0, total / den.clamp_min(1e-30), torch.zeros_like(total)), unweighted
+    if reduction == "sum_over_batch_size":
+        return total / unweighted.numel(), unweighted
+    raise ValueError("unknown loss reduction %r" % (reduction,))
+
+
 def clip_by_norm_(grad, clip_norm=CLIP_NORM):
     """tf.clip_by_norm on one tensor, in place: g * clip / max(||g||_2, clip).  Sparse gradients: over their values."""
     if grad is None:

@@ -563,3 +563,49 @@ def test_multihot_bag_backward(built_lib, combiner, weighted, field_major):
     for t, r in zip(dev, t64):
         assert t.grad.is_sparse
         _close(t.grad.to_dense(), r.grad if r.grad is not None else torch.zeros_like(r), tol=1e-5)
+
+
+def test_esmm_and_dcn_training_with_reference_losses(built_lib):
+    """ESMM.get_loss (ESMM.py:150-175, with a click weight column) and DeepCrossNetwork.create_loss (:209-225) drive a few
+    optimiser steps through the HIP forward/backward; dropout and train-mode batch norm are active (TRAIN mode)."""
+    from dir_amd.esmm import ESMM
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd import feature_column as fc
+    torch.manual_seed(3)
+    B, V = 512, 40
+    cols = [fc.numeric_column("x"), fc.embedding_column(fc.categorical_column_with_identity("a", V), dimension=8),
+            fc.embedding_column(fc.categorical_column_with_identity("b", V), dimension=8)]
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randint(0, V, (B,), generator=g), torch.randint(0, V, (B,), generator=g)
+    feats = {"x": torch.rand(B, generator=g).cuda(), "a": a.cuda(), "b": b.cuda(), "w": (torch.rand(B, generator=g) + 0.5).cuda()}
+    click = (a < V // 2).float().cuda()
+    convert = ((a < V // 2) & (b < V // 2)).float().cuda()
+    esmm = ESMM(columns=cols, dnn_hidden_units=[32, 16], dnn_dropout=0.1, ctr_weight_column="w").cuda()
+    dense = [p for n, p in esmm.named_parameters() if "embedding_weights" not in n]
+    sparse = [p for n, p in esmm.named_parameters() if "embedding_weights" in n]
+    opt, opt_s = torch.optim.Adam(dense, lr=0.01), torch.optim.SparseAdam(sparse, lr=0.01)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad(); opt_s.zero_grad()
+        loss, unw = esmm.get_loss(feats, {"click_label": click, "convert_label": convert}, esmm(feats))
+        assert unw.shape == (B, 1)
+        loss.backward()
+        opt.step(); opt_s.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.8 * losses[0], losses[::8]
+    dcn = DeepCrossNetwork(columns=cols, cross_layer_num=2, dnn_hidden_units=[32, 16, 8], dnn_dropout=0.2, batch_norm=True,
+                           weight_column="w", optimizer="Adam", optimizer_spec={"epsilon": 1e-4},
+                           learning_rate_spec={"learning_rate": 0.01}).cuda()
+    step = dcn.train_step()
+    first = last = None
+    for _ in range(40):
+        loss, _ = dcn.create_loss(feats, dcn(feats), click)
+        loss, _lr = step(loss)
+        first = first if first is not None else float(loss)
+        last = float(loss)
+    assert last < 0.85 * first
+    assert float(dcn.bns[0].moving_mean.abs().sum()) > 0          # the moving statistics moved (TRAIN-mode batch norm)
+    dcn.eval()
+    with torch.no_grad():
+        p = dcn.predict(feats)
+    assert set(p) >= {"logits", "logistic", "probabilities", "class_ids"}

@@ -240,3 +240,27 @@ def test_batch_norm_train_and_inference_forms():
     m.eval()
     assert torch.equal(_dropout_train(m, ones, 0.5), ones)
     assert torch.equal(_dropout_train(torch.nn.Module(), ones, None), ones)
+
+
+def test_weighted_losses_of_the_model_fns():
+    """weighted_sigmoid_cross_entropy against hand values of tf.losses.compute_weighted_loss's reductions
+    (DeepCrossNetwork.py:209-225 MEAN, deepFM.py:72 SUM, ESMM.py:150-175 sum of two MEANs)."""
+    import math
+    import dir_amd  # noqa: F401
+    from dir_amd import train_spec as ts
+    logits = torch.tensor([[0.0], [2.0], [-1.0]])
+    labels = torch.tensor([1, 0, 1])
+    un = [math.log(2.0), 2.0 + math.log1p(math.exp(-2.0)), 1.0 + math.log1p(math.exp(-1.0))]     # max(x,0) - x*z + log(1+e^-|x|)
+    loss, unw = ts.weighted_sigmoid_cross_entropy(logits, labels, None, "sum")
+    assert loss.item() == pytest.approx(sum(un), rel=1e-6) and unw.reshape(-1).tolist() == pytest.approx(un, rel=1e-6)
+    assert ts.weighted_sigmoid_cross_entropy(logits, labels, None, "mean")[0].item() == pytest.approx(sum(un) / 3, rel=1e-6)
+    w = torch.tensor([[2.0], [0.0], [1.0]])
+    assert ts.weighted_sigmoid_cross_entropy(logits, labels, w, "mean")[0].item() == pytest.approx((2 * un[0] + un[2]) / 3.0, rel=1e-6)
+    assert ts.weighted_sigmoid_cross_entropy(logits, labels, w, "sum")[0].item() == pytest.approx(2 * un[0] + un[2], rel=1e-6)
+    assert ts.weighted_sigmoid_cross_entropy(logits, labels, torch.zeros(3, 1), "mean")[0].item() == 0.0
+    with pytest.raises(ValueError):
+        ts.weighted_sigmoid_cross_entropy(logits, labels, None, "nope")
+    feats = {"w": torch.tensor([2.0, 0.0, 1.0])}
+    assert torch.equal(ts._weights_of(feats, "w", logits), w)
+    with pytest.raises(ValueError):
+        ts._weights_of(feats, "missing", logits)
