@@ -386,7 +386,7 @@ static int launch_onehot(const float* const* tables, int F, int K, const int64_t
                          int flags, int64_t B, float* out, int64_t out_ld, float* fm, hipStream_t st) {
     const bool vec = (K % 4 == 0) && (!DO_OUT || (out_ld % 4 == 0 && aligned16(out)));
     static const int uf_env = env_int("DIR_GATHER_UF", 0);
-    int uf = uf_env > 0 ? uf_env : (F == 26 ? 26 : (F % 13 == 0 ? 13 : 8));
+    int uf = uf_env > 0 ? uf_env : (F == 26 ? 26 : (F % 13 == 0 ? 13 : (F > 48 ? 26 : 8)));   // measured at F = 100: 26 -> 260 us, 8 -> 298 us
     const bool stream_rows = (flags & DIR_GATHER_STREAM_ROWS) != 0;
     const int lps = next_pow2(vec ? K / 4 : K);
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "embedding row of K=%d floats is wider than one wave covers (max %d)", K, vec ? 256 : 64);
