@@ -37,7 +37,8 @@ def _tables(rng, F, V, K, scale=0.25):
 
 @pytest.mark.parametrize("B,F,K,V", [(1, 1, 16, 10), (64, 26, 16, 1000), (1000, 26, 8, 10000), (4099, 26, 16, 5000),
                                       (333, 3, 64, 100), (257, 5, 4, 50), (130, 7, 12, 64), (100, 4, 1, 30),
-                                      (77, 3, 6, 40), (65, 2, 128, 33), (19, 2, 256, 9)])
+                                      (77, 3, 6, 40), (65, 2, 128, 33), (19, 2, 256, 9),
+                                      (300, 60, 16, 200), (129, 100, 8, 50), (64, 52, 16, 77), (200, 39, 16, 300)])   # wide slot counts
 def test_gather_onehot_bit_exact(ops, oracle, B, F, K, V):
     rng = np.random.default_rng(B * 31 + K)
     tables = _tables(rng, F, V, K)
