@@ -264,3 +264,35 @@ def test_weighted_losses_of_the_model_fns():
     assert torch.equal(ts._weights_of(feats, "w", logits), w)
     with pytest.raises(ValueError):
         ts._weights_of(feats, "missing", logits)
+
+
+def test_binary_metrics_match_hand_values_and_sklearn():
+    """metrics.BinaryMetrics (DeepCrossNetwork.py:293-319): counters against hand values; the 200-threshold trapezoidal AUC
+    against scikit-learn's exact ROC AUC (they agree to the bucket resolution); streaming == one shot."""
+    import dir_amd  # noqa: F401
+    from dir_amd.metrics import BinaryMetrics
+    from sklearn.metrics import roc_auc_score
+    g = torch.Generator().manual_seed(0)
+    y = (torch.rand(4000, generator=g) < 0.3).float()
+    p = torch.sigmoid(torch.randn(4000, generator=g) + 1.5 * (y - 0.3))
+    w = torch.rand(4000, generator=g) + 0.5
+    loss = torch.nn.functional.binary_cross_entropy(p, y, reduction="none")
+    one = BinaryMetrics(device="cpu").update(y, p, loss, w).result()
+    two = BinaryMetrics(device="cpu")
+    for a in range(0, 4000, 1000):
+        two.update(y[a:a + 1000], p[a:a + 1000], loss[a:a + 1000], w[a:a + 1000])
+    two = two.result()
+    for k in one:
+        assert one[k] == pytest.approx(two[k], rel=1e-9), k
+    pred = (p > 0.5).float()
+    assert one["accuracy"] == pytest.approx(float((w * (pred == y)).sum() / w.sum()), rel=1e-6)
+    assert one["precision"] == pytest.approx(float((w * pred * y).sum() / (w * pred).sum()), rel=1e-6)
+    assert one["recall"] == pytest.approx(float((w * pred * y).sum() / (w * y).sum()), rel=1e-6)
+    assert one["average_loss"] == pytest.approx(float((w * loss).sum() / w.sum()), rel=1e-6)
+    lm = float((w * y).sum() / w.sum())
+    assert one["label/mean"] == pytest.approx(lm, rel=1e-6) and one["accuracy_baseline"] == pytest.approx(max(lm, 1 - lm), rel=1e-6)
+    assert one["auc"] == pytest.approx(roc_auc_score(y.numpy(), p.numpy(), sample_weight=w.numpy()), abs=2e-3)
+    # a perfect and an inverted ranking
+    yy = torch.tensor([0.0, 0.0, 1.0, 1.0])
+    assert BinaryMetrics(device="cpu").update(yy, torch.tensor([0.1, 0.2, 0.8, 0.9])).result()["auc"] == pytest.approx(1.0, abs=1e-4)
+    assert BinaryMetrics(device="cpu").update(yy, torch.tensor([0.9, 0.8, 0.2, 0.1])).result()["auc"] == pytest.approx(0.0, abs=1e-4)
