@@ -609,3 +609,8 @@ def test_esmm_and_dcn_training_with_reference_losses(built_lib):
     with torch.no_grad():
         p = dcn.predict(feats)
     assert set(p) >= {"logits", "logistic", "probabilities", "class_ids"}
+    # the reference's evaluation metrics (DeepCrossNetwork.py:293-319) on the fitted batch: the label is a function of field a
+    from dir_amd.metrics import BinaryMetrics
+    _, unw = dcn.create_loss(feats, p["logits"], click)
+    m = BinaryMetrics().update(click, p["logistic"], unw, feats["w"]).result()
+    assert m["auc"] > 0.9 and m["accuracy"] > m["accuracy_baseline"] and 0.0 < m["average_loss"] < 0.7, m
