@@ -404,3 +404,25 @@ def test_full_size_properties_cross_cin_din(ops, oracle):
                                        W1.cpu().numpy(), b1.cpu().numpy(), W2.cpu().numpy(), b2.cpu().numpy(), W3.cpu().numpy(),
                                        b3.cpu().numpy(), normalize=True, acc64=True)
     assert (np.abs(out[sel[:64]].cpu().double().numpy() - ro) / (1 + np.abs(ro))).max() <= 1e-5
+
+
+def test_table_beyond_4gib_offsets(ops):
+    """BASELINE configs[4]'s logical table: 10^8 rows x 16 floats = 6.4 GB shared by the slots; ids at the top of the table
+    need > 2^32-byte offsets in the gather, the fused FM and the multi-hot bag kernels."""
+    V, K, F, B = 100_000_000, 16, 6, 2048
+    g = torch.Generator(device="cuda").manual_seed(0)
+    table = torch.empty((V, K), device="cuda")
+    for s in range(0, V, 25_000_000):
+        table[s:s + 25_000_000].normal_(0, 0.25, generator=g)
+    ts = ops.TableSet([table] * F)
+    ids = torch.randint(V - 5_000_000, V, (B, F), generator=g, device="cuda")
+    ids[0, 0] = V - 1
+    ids[1, 1] = 0
+    emb, fm = ops.gather_fm(ts, ids)
+    ref = table[ids.reshape(-1)].reshape(B, F * K)
+    assert torch.equal(emb, ref)
+    assert torch.equal(fm, ops.fm_logit(ref, F, K))
+    offs = torch.arange(0, B * F * 2 + 1, 2, device="cuda", dtype=torch.int64)
+    vals = torch.randint(V - 1000, V, (B * F * 2,), generator=g, device="cuda")
+    bag = ops.embedding_bag(ts, vals, offs, None, combiner="sum")
+    assert torch.equal(bag, (table[vals[0::2]] + table[vals[1::2]]).reshape(B, F * K))
