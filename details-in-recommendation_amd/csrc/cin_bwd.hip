@@ -272,32 +272,40 @@ __device__ __forceinline__ void half32_sum16(const float (&v)[16], float (&u)[8]
     }
 }
 
-template <int CT /* column tiles: ceil(Hp/32) rounded to 1, 2, 4 */, int HT /* H padded: 32, 64, 128 */,
-          bool FULLH /* H == HT: the W staging needs no per-element predicate (49 exec-mask branches per j otherwise) */>
+template <int CT /* column tiles per column block: 1, 2, 4 */, int HT /* rows of one H slice: 32, 64, 128 */,
+          bool FULLH /* H == NHC * HT: the W staging needs no per-element predicate (49 exec-mask branches per j otherwise) */,
+          int NHC /* slices of H: 1, or 2 for 128 < H <= 256 (HT = 128) */>
 __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0, const float* __restrict__ xk,
-                                                   const float* __restrict__ Wp /* [m][H][32][CT] */,
+                                                   const float* __restrict__ Wp /* [column block][m][H][32][CT] */,
                                                    const float* __restrict__ G, int m, int Hp, int H, int D, int dshift,
                                                    int64_t R, float* __restrict__ dxk, float* __restrict__ dx0) {
-    constexpr int KS = HT / 2;                 // k-steps per j
-    constexpr int WJ = HT * 32 * CT;           // floats of one W_j image (rows h >= H stay zero)
-    constexpr int NV = WJ / 4 / 256;           // float4 per thread per j
+    constexpr int KS = HT / 2;                 // k-steps per slice
+    constexpr int WJ = HT * 32 * CT;           // floats of one W slice image (rows h >= H stay zero)
+    constexpr int NV = WJ / 4 / 256;           // float4 per thread per slice
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wb = smem;                          // [2][WJ]
     float* x0s = smem + 2 * WJ;                // [m][128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;     // this wave's row tile
-    const int wrows = H * 32 * CT;             // valid floats of a W_j image
+    const int cbase = blockIdx.y * (32 * CT);  // first column (i) of this column block
+    const bool multi = gridDim.y > 1;          // two column blocks: each adds its dx0 contribution (exactly two addends: order-free)
+    Wp += (int64_t)blockIdx.y * m * H * (32 * CT);
+    auto slice_floats = [&](int hc) {          // valid floats of slice hc of a W_j image
+        int rows = H - hc * HT;
+        rows = rows < 0 ? 0 : (rows > HT ? HT : rows);
+        return rows * 32 * CT;
+    };
 
     // ---- one-time loads ---------------------------------------------------------------------------------------------
-    // A operand: ga[s] = G[row0 + n, h = 2s + hh]
-    float ga[KS];
+    // A operand: ga[hc*KS + s] = G[row0 + n, h = hc*HT + 2s + hh]
+    float ga[NHC * KS];
     {
         const int64_t r = row0 + n;
         const bool ok = r < R;
         const int64_t rc = ok ? r : R - 1;
         const float* src = G + ((rc >> dshift) * H) * D + (rc & (D - 1));
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s = 0; s < NHC * KS; ++s) {
             const int h = 2 * s + hh;
             ga[s] = (ok && h < H) ? src[(int64_t)h * D] : 0.f;
         }
@@ -312,43 +320,48 @@ __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0,
         const float* src = xk + ((rc >> dshift) * Hp) * D + (rc & (D - 1));
 #pragma unroll
         for (int cc = 0; cc < CT; ++cc) {
-            const int i = 32 * cc + n;
+            const int i = cbase + 32 * cc + n;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok && i < Hp) v = *reinterpret_cast<const float4*>(src + (int64_t)i * D);
             xkv[cc][4 * g] = v.x; xkv[cc][4 * g + 1] = v.y; xkv[cc][4 * g + 2] = v.z; xkv[cc][4 * g + 3] = v.w;
         }
     }
-    // x0 slice of the workgroup's 128 rows, [j][row]; zero the W rows h in [H, HT) of both buffers once
+    // x0 slice of the workgroup's 128 rows, [j][row]
     for (int e = tid; e < m * 128; e += 256) {
         const int j = e >> 7, rl = e & 127;
         const int64_t r = (int64_t)blockIdx.x * 128 + rl;
         x0s[e] = r < R ? x0[((r >> dshift) * m + j) * D + (r & (D - 1))] : 0.f;
     }
-    for (int e = wrows + tid; e < WJ; e += 256) { Wb[e] = 0.f; Wb[WJ + e] = 0.f; }
+    // zero, once, the rows the staging never writes: buffer b always holds slice b when NHC == 2, slice 0 otherwise
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+        for (int e = slice_floats(NHC == 2 ? bq : 0) + tid; e < WJ; e += 256) Wb[bq * WJ + e] = 0.f;
 
-    // W_{j+1} is staged in NP parts (fewer live registers; the second part's loads sit mid-way in the MFMA stream)
+    // the next slice is staged in NP parts (fewer live registers; the second part's loads sit mid-way in the MFMA stream)
     constexpr int NP = NV >= 2 ? 2 : 1, NVP = NV / NP;
     float4 wst[NVP];
-    auto w_load = [&](int j, int part) {
-        const float4* src = reinterpret_cast<const float4*>(Wp + (int64_t)j * wrows);
+    auto w_load = [&](int j, int hc, int part) {
+        const float4* src = reinterpret_cast<const float4*>(Wp + ((int64_t)j * H + hc * HT) * (32 * CT));
+        const int wr = slice_floats(hc);
 #pragma unroll
         for (int q = 0; q < NVP; ++q) {
             const int e4 = tid + 256 * (part * NVP + q);
-            wst[q] = (FULLH || e4 * 4 < wrows) ? src[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            wst[q] = (FULLH || e4 * 4 < wr) ? src[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto w_store = [&](int buf, int part) {
+    auto w_store = [&](int buf, int hc, int part) {
         float4* dst = reinterpret_cast<float4*>(Wb + buf * WJ);
+        const int wr = slice_floats(hc);
 #pragma unroll
         for (int q = 0; q < NVP; ++q) {
             const int e4 = tid + 256 * (part * NVP + q);
-            if (FULLH || e4 * 4 < wrows) dst[e4] = wst[q];
+            if (FULLH || e4 * 4 < wr) dst[e4] = wst[q];
         }
     };
 #pragma unroll
     for (int part = 0; part < NP; ++part) {
-        w_load(0, part);
-        w_store(0, part);
+        w_load(0, 0, part);
+        w_store(0, 0, part);
     }
     __syncthreads();
 
@@ -372,91 +385,105 @@ __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0,
     }
 
     for (int j = 0; j < m; ++j) {
-        const int buf = j & 1;
-        const bool more = j + 1 < m;
-        if (more) w_load(j + 1, 0);
-        const float* wb = Wb + buf * WJ + (hh * 32 + n) * CT;      // [h][n][cc]: h = 2s + hh
         f32x16 T[CT];
-        // bursts of 2 k-steps = 2*CT MFMAs; operand reads run one burst ahead (cin.hip)
-        float bw[2][CT];
-        auto read_b = [&](int s, float (&o)[CT]) {
-            const float* src = wb + s * (2 * 32 * CT);
-            if (CT == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(src);
-                o[0] = v.x; o[1 % CT] = v.y; o[2 % CT] = v.z; o[3 % CT] = v.w;
-            } else if (CT == 2) {
-                const float2 v = *reinterpret_cast<const float2*>(src);
-                o[0] = v.x; o[1 % CT] = v.y;
-            } else {
-                o[0] = src[0];
-            }
-        };
-        read_b(0, bw[0]);
-        read_b(1, bw[1]);
 #pragma unroll
-        for (int s = 0; s < KS; s += 2) {
-            float bn[2][CT];
-            if (s + 2 < KS) {
-                read_b(s + 2, bn[0]);
-                read_b(s + 3, bn[1]);
-            } else {
-#pragma unroll
-                for (int cc = 0; cc < CT; ++cc) { bn[0][cc] = bw[0][cc]; bn[1][cc] = bw[1][cc]; }
-            }
-            if (NP == 2 && s == (KS / 4) * 2 && more) {   // mid-way: first part to LDS, second part's loads
-                w_store(buf ^ 1, 0);
-                w_load(j + 1, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int cc = 0; cc < CT; ++cc) {
-                    if (s + e == 0) {
-                        f32x16 z;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) z[q] = 0.f;
-                        T[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[0], bw[0][cc], z, 0, 0, 0);
-                    } else {
-                        T[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s + e], bw[e][cc], T[cc], 0, 0, 0);
-                    }
+        for (int hc = 0; hc < NHC; ++hc) {
+            const int buf = NHC == 2 ? hc : (j & 1);
+            // the stage after (j, hc)
+            const int nj = hc + 1 < NHC ? j : j + 1, nhc = hc + 1 < NHC ? hc + 1 : 0;
+            const bool more = nj < m;
+            if (more) w_load(nj, nhc, 0);
+            const float* wb = Wb + buf * WJ + (hh * 32 + n) * CT;      // [h][n][cc]: h = 2s + hh within the slice
+            // bursts of 2 k-steps = 2*CT MFMAs; operand reads run one burst ahead (cin.hip)
+            float bw[2][CT];
+            auto read_b = [&](int s, float (&o)[CT]) {
+                const float* src = wb + s * (2 * 32 * CT);
+                if (CT == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    o[0] = v.x; o[1 % CT] = v.y; o[2 % CT] = v.z; o[3 % CT] = v.w;
+                } else if (CT == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(src);
+                    o[0] = v.x; o[1 % CT] = v.y;
+                } else {
+                    o[0] = src[0];
                 }
-            __builtin_amdgcn_sched_barrier(0);
+            };
+            read_b(0, bw[0]);
+            read_b(1, bw[1]);
 #pragma unroll
-            for (int cc = 0; cc < CT; ++cc) { bw[0][cc] = bn[0][cc]; bw[1][cc] = bn[1][cc]; }
+            for (int s = 0; s < KS; s += 2) {
+                float bn[2][CT];
+                if (s + 2 < KS) {
+                    read_b(s + 2, bn[0]);
+                    read_b(s + 3, bn[1]);
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) { bn[0][cc] = bw[0][cc]; bn[1][cc] = bw[1][cc]; }
+                }
+                if (NP == 2 && s == (KS / 4) * 2 && more) {   // mid-way: first part to LDS, second part's loads
+                    w_store(buf ^ 1, nhc, 0);
+                    w_load(nj, nhc, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) {
+                        if (hc == 0 && s + e == 0) {
+                            f32x16 z;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) z[q] = 0.f;
+                            T[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[0], bw[0][cc], z, 0, 0, 0);
+                        } else {
+                            T[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[hc * KS + s + e], bw[e][cc], T[cc], 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cc = 0; cc < CT; ++cc) { bw[0][cc] = bn[0][cc]; bw[1][cc] = bn[1][cc]; }
+            }
+            if (hc == NHC - 1) {
+                // ---- epilogue of j --------------------------------------------------------------------------------------
+                float x0v[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = *reinterpret_cast<const float4*>(x0s + j * 128 + wave * 32 + 8 * g + 4 * hh);
+                    x0v[4 * g] = v.x; x0v[4 * g + 1] = v.y; x0v[4 * g + 2] = v.z; x0v[4 * g + 3] = v.w;
+                }
+                float p[16], u[8];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float acc = T[0][q] * xkv[0][q];
+#pragma unroll
+                    for (int cc = 1; cc < CT; ++cc) acc = __builtin_fmaf(T[cc][q], xkv[cc][q], acc);
+                    p[q] = acc;
+#pragma unroll
+                    for (int cc = 0; cc < CT; ++cc) dk[cc][q] = __builtin_fmaf(x0v[q], T[cc][q], dk[cc][q]);
+                }
+                half32_sum16(p, u);
+                if ((lane & 15) == 0) {   // rows 0/2 hold the totals of C/D regs 0..7, rows 1/3 of regs 8..15: 2 runs of 4 rows (d) each
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (dx0_ok[e]) {
+                            float* dst = dx0 + dx0_off[e] + (int64_t)j * D;
+                            if (multi) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) atomicAdd(dst + q, u[4 * e + q]);
+                            } else {
+                                *reinterpret_cast<float4*>(dst) = make_float4(u[4 * e], u[4 * e + 1], u[4 * e + 2], u[4 * e + 3]);
+                            }
+                        }
+                }
+            }
+            if (more) w_store(buf ^ 1, nhc, NP - 1);
+            __syncthreads();
         }
-        // ---- epilogue of j ------------------------------------------------------------------------------------------
-        float x0v[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(x0s + j * 128 + wave * 32 + 8 * g + 4 * hh);
-            x0v[4 * g] = v.x; x0v[4 * g + 1] = v.y; x0v[4 * g + 2] = v.z; x0v[4 * g + 3] = v.w;
-        }
-        float p[16], u[8];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float acc = T[0][q] * xkv[0][q];
-#pragma unroll
-            for (int cc = 1; cc < CT; ++cc) acc = __builtin_fmaf(T[cc][q], xkv[cc][q], acc);
-            p[q] = acc;
-#pragma unroll
-            for (int cc = 0; cc < CT; ++cc) dk[cc][q] = __builtin_fmaf(x0v[q], T[cc][q], dk[cc][q]);
-        }
-        half32_sum16(p, u);
-        if ((lane & 15) == 0) {   // rows 0/2 hold the totals of C/D regs 0..7, rows 1/3 of regs 8..15: 2 runs of 4 rows (d) each
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                if (dx0_ok[e])
-                    *reinterpret_cast<float4*>(dx0 + dx0_off[e] + (int64_t)j * D) = make_float4(u[4 * e], u[4 * e + 1], u[4 * e + 2], u[4 * e + 3]);
-        }
-        if (more) w_store(buf ^ 1, NP - 1);
-        __syncthreads();
     }
 
     // ---- dxk: C/D map col = lane&31 (i within the column tile), rows as above ------------------------------------------
 #pragma unroll
     for (int cc = 0; cc < CT; ++cc) {
-        const int i = 32 * cc + n;
+        const int i = cbase + 32 * cc + n;
         if (i >= Hp) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -468,27 +495,28 @@ __global__ __launch_bounds__(256, 1) void cin_dx_k(const float* __restrict__ x0,
     }
 }
 
-template <int CT, int HT>
+template <int CT, int HT, int NHC>
 static void launch_cin_dx(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* Wp,
                           const float* G, int m, int Hp, int H, int D, int dshift, int64_t R, float* dxk, float* dx0) {
     static bool set = false;
     if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT, true, NHC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, HT, false, NHC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         set = true;
     }
-    if (H == HT)
-        hipLaunchKernelGGL((cin_dx_k<CT, HT, true>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    if (H == HT * NHC)
+        hipLaunchKernelGGL((cin_dx_k<CT, HT, true, NHC>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
     else
-        hipLaunchKernelGGL((cin_dx_k<CT, HT, false>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+        hipLaunchKernelGGL((cin_dx_k<CT, HT, false, NHC>), grid, dim3(256), shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
 }
 
 template <int CT>
-static void launch_cin_dx_ct(int ht, dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* Wp,
+static void launch_cin_dx_ct(int ht, int nhc, dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* Wp,
                              const float* G, int m, int Hp, int H, int D, int dshift, int64_t R, float* dxk, float* dx0) {
-    if (ht == 32) launch_cin_dx<CT, 32>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
-    else if (ht == 64) launch_cin_dx<CT, 64>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
-    else launch_cin_dx<CT, 128>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    if (nhc == 2) launch_cin_dx<CT, 128, 2>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else if (ht == 32) launch_cin_dx<CT, 32, 1>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else if (ht == 64) launch_cin_dx<CT, 64, 1>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else launch_cin_dx<CT, 128, 1>(grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
 }
 
 struct CinDwPlan { int nwg, nslot, nhb; int64_t NQ, L; };
@@ -553,8 +581,8 @@ extern "C" int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp,
     DIR_CHECK_ARG(x0 && xk && Wp && G && dxk && dx0, "dir_cin_dx_f32: null pointer");
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "dir_cin_dx_f32: m=%d Hp=%d H=%d D=%d", m, Hp, H, D);
     if (!(D == 4 || D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "dir_cin_dx_f32: D=%d (supported: 4, 8, 16, 32)", D);
-    if (H > 128 || Hp > 128 || m > 64)
-        return fail(DIR_E_UNSUPPORTED, "dir_cin_dx_f32: needs H <= 128, Hp <= 128, m <= 64 (H=%d Hp=%d m=%d): use the forward formulation", H, Hp, m);
+    if (H > 256 || Hp > 256 || m > 64)
+        return fail(DIR_E_UNSUPPORTED, "dir_cin_dx_f32: needs H <= 256, Hp <= 256, m <= 64 (H=%d Hp=%d m=%d): use the forward formulation", H, Hp, m);
     if (!(aligned16(x0) && aligned16(xk) && aligned16(Wp) && aligned16(G) && aligned16(dxk) && aligned16(dx0)))
         return fail(DIR_E_BADARG, "dir_cin_dx_f32: all tensors must be 16-byte aligned");
     if (B == 0) return DIR_OK;
@@ -562,13 +590,17 @@ extern "C" int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp,
     while ((1 << dshift) < D) ++dshift;
     const int64_t R = B * D;
     const int ct = Hp <= 32 ? 1 : Hp <= 64 ? 2 : 4;
-    const int ht = H <= 32 ? 32 : H <= 64 ? 64 : 128;
+    const int ncb = (Hp + 32 * ct - 1) / (32 * ct);            // column blocks: 2 when 128 < Hp <= 256
+    const int nhc = H > 128 ? 2 : 1;
+    const int ht = nhc == 2 ? 128 : (H <= 32 ? 32 : H <= 64 ? 64 : 128);
     const size_t shmem = sizeof(float) * (2 * (size_t)ht * 32 * ct + (size_t)m * 128);
-    dim3 grid((unsigned)((R + 127) / 128));
+    dim3 grid((unsigned)((R + 127) / 128), (unsigned)ncb);
     hipStream_t st = as_stream(stream);
-    if (ct == 1) launch_cin_dx_ct<1>(ht, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
-    else if (ct == 2) launch_cin_dx_ct<2>(ht, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
-    else launch_cin_dx_ct<4>(ht, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    if (ncb > 1 && hipMemsetAsync(dx0, 0, sizeof(float) * (size_t)B * m * D, st) != hipSuccess)
+        return fail(DIR_E_HIP, "dir_cin_dx_f32: memset failed");          // the two column blocks ADD their dx0 shares
+    if (ct == 1) launch_cin_dx_ct<1>(ht, nhc, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else if (ct == 2) launch_cin_dx_ct<2>(ht, nhc, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
+    else launch_cin_dx_ct<4>(ht, nhc, grid, shmem, st, x0, xk, Wp, G, m, Hp, H, D, dshift, R, dxk, dx0);
     DIR_CHECK_LAUNCH("cin_dx");
     return DIR_OK;
 }

@@ -479,8 +479,8 @@ CIN_FIELD_TILES = (8, 16, 26, 40)   # field counts dir_cin_layer_f32 is instanti
 
 def cin_dx(x0, xk, W, G):
     """Both data gradients of one CIN layer in one pass (include/dir_hip.h, dir_cin_dx_f32): -> (dxk [B,Hp,D],
-    dx0 [B,m,D]).  Needs H <= 128, Hp <= 128, m <= 64.  W is permuted here to the kernel's LDS image
-    Wp[j][h][n][cc] = W[h, (32*cc + n)*m + j] (a 1.7 MB tensor at the BASELINE shape)."""
+    dx0 [B,m,D]).  Needs H <= 256, Hp <= 256, m <= 64.  W is permuted here to the kernel's LDS image
+    Wp[nb][j][h][n][cc] = W[h, (nb*32*ct + 32*cc + n)*m + j] (a 1.7 MB tensor at the BASELINE shape)."""
     for t, n in ((x0, "x0"), (xk, "xk"), (W, "W"), (G, "G")):
         _dev(t, torch.float32, n)
         if not t.is_contiguous():
@@ -490,10 +490,11 @@ def cin_dx(x0, xk, W, G):
     if W.shape[1] != Hp * m or G.shape != (B, H, D) or xk.shape[0] != B or xk.shape[2] != D:
         raise ValueError("cin_dx: W must be [H, Hp*m], xk [B,Hp,D], G [B,H,D]")
     ct = 1 if Hp <= 32 else 2 if Hp <= 64 else 4
+    nb = -(-Hp // (32 * ct))                                 # column blocks (2 when 128 < Hp <= 256)
     W3 = W.view(H, Hp, m)
-    if 32 * ct != Hp:
-        W3 = torch.nn.functional.pad(W3, (0, 0, 0, 32 * ct - Hp))
-    Wp = W3.reshape(H, ct, 32, m).permute(3, 0, 2, 1).contiguous()
+    if nb * 32 * ct != Hp:
+        W3 = torch.nn.functional.pad(W3, (0, 0, 0, nb * 32 * ct - Hp))
+    Wp = W3.reshape(H, nb, ct, 32, m).permute(1, 4, 0, 3, 2).contiguous()       # [nb][m][H][32 n][ct]
     dxk = torch.empty((B, Hp, D), dtype=torch.float32, device=x0.device)
     dx0 = torch.empty((B, m, D), dtype=torch.float32, device=x0.device)
     _lib.check(_lib.load().dir_cin_dx_f32(_ptr(x0), _ptr(xk), _ptr(Wp), _ptr(G), m, Hp, H, D, B, _ptr(dxk), _ptr(dx0), _stream()))
@@ -503,7 +504,7 @@ def cin_dx(x0, xk, W, G):
 def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, force_forward_form=False):
     """Backward of cin_layer given G = dL/dxout [B,H,D] (pooled gradient already broadcast in):
     -> (dx0 [B,m,D] | None, dxk [B,Hp,D] | None, dW [H,Hp*m] | None).
-    Data gradients: dir_cin_dx_f32 (one pass for both) when H, Hp <= 128 and m <= 64; otherwise, or with
+    Data gradients: dir_cin_dx_f32 (one pass for both) when H, Hp <= 256 and m <= 64; otherwise, or with
     force_forward_form, the forward contraction with permuted weights (include/dir_hip.h):
       dxk = cin_layer(x0, G, W1),  W1[i, h*m+j]  = W[h, i*m+j]
       dx0 = sum over channel groups g of cin_layer(xk[:, g], G, W2g),  W2g[j, h*mg+ig] = W[h, (g0+ig)*m+j]."""
@@ -511,7 +512,7 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
     Hp, H = xk.shape[1], W.shape[0]
     W3 = W.view(H, Hp, m)
     dxk = dx0 = dW = None
-    if (need_xk or need_x0) and H <= 128 and Hp <= 128 and m <= 64 and not force_forward_form:
+    if (need_xk or need_x0) and H <= 256 and Hp <= 256 and m <= 64 and not force_forward_form:
         dxk, dx0 = cin_dx(x0, xk, W, G)             # one pass for both (G stationary in registers)
         need_xk = need_x0 = False
     if need_xk:

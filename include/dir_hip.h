@@ -260,9 +260,12 @@ int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const float* w, co
  * ------------------------------------------------------------------------------------------ */
 int64_t dir_cin_dw_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
 /* dir_cin_dx_f32: both data gradients in one pass (T_j = G x W_j on fp32 MFMA with G held in registers, then an FMA
- * epilogue for dxk and a half-wave reduction for dx0).  Wp is W permuted to [m][H][32][CT], CT = 1, 2 or 4 column
- * tiles covering Hp: Wp[j][h][n][cc] = W[h, (32*cc + n)*m + j], zero where 32*cc + n >= Hp.
- * Limits: H <= 128, Hp <= 128, m <= 64 (DIR_E_UNSUPPORTED otherwise: use the dir_cin_layer_f32 formulation above). */
+ * epilogue for dxk and a half-wave reduction for dx0).  Wp is W permuted to [NB][m][H][32][CT]: CT = 1, 2 or 4 column tiles
+ * (Hp <= 32, <= 64, else 4), NB = ceil(Hp / (32*CT)) column blocks (2 when 128 < Hp <= 256),
+ * Wp[nb][j][h][n][cc] = W[h, i*m + j] with i = nb*32*CT + 32*cc + n, zero where i >= Hp.
+ * 128 < H <= 256 runs as two 128-row slices of H per field; with two column blocks each adds its dx0 share (two addends on a
+ * zeroed buffer: order-free, still reproducible).
+ * Limits: H <= 256, Hp <= 256, m <= 64 (DIR_E_UNSUPPORTED otherwise: use the dir_cin_layer_f32 formulation above). */
 int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp, const float* G, int m, int Hp, int H, int D,
                    int64_t B, float* dxk, float* dx0, dir_stream_t stream);
 int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,

@@ -237,7 +237,10 @@ def test_deepfm_fused_adagrad_matches_torch_adagrad(built_lib):
 # ---- CIN backward (no reference code; derivatives of the definition in include/dir_hip.h A14) -----------------------
 @pytest.mark.parametrize("B,m,D,Hp,H", [(64, 26, 16, 26, 128), (33, 26, 16, 128, 128), (7, 5, 4, 6, 7), (9, 8, 8, 5, 32),
                                          (5, 3, 4, 2, 3), (3, 8, 16, 9, 200), (21, 39, 16, 39, 96), (1, 4, 4, 3, 5),
-                                         (18, 13, 32, 50, 130), (250, 10, 4, 45, 64)])
+                                         (18, 13, 32, 50, 130), (250, 10, 4, 45, 64),
+                                         # 128 < H, Hp <= 256: two slices of H per field, two column blocks adding their dx0 shares
+                                         (19, 26, 16, 200, 200), (11, 8, 8, 130, 256), (9, 26, 4, 256, 129), (7, 5, 16, 129, 40),
+                                         (6, 4, 16, 20, 257)])
 def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
     from dir_amd import ops
     from oracle import oracle as O
