@@ -86,6 +86,10 @@ def load():
         raise RuntimeError(
             "libdir_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`python details-in-recommendation_amd/build.py`. There is no CPU fallback." % _LIB_PATH)
+    # One HIP runtime per process: torch's wheel carries its own libamdhip64 (same SONAME as /opt/rocm's), and the tensors and
+    # streams handed to the C ABI are torch's.  Map torch's copy first so libdir_hip.so binds to it; loaded the other way
+    # round the process ends up with /opt/rocm's runtime under torch's HSA and the first launch reports "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(_LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted

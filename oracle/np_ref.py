@@ -330,3 +330,66 @@ def shard_div_owner(ids, vocab, P):
     owner = np.where(ids < thr, ids // (q + 1), r + (ids - thr) // max(q, 1))
     start = np.where(owner < r, owner * (q + 1), thr + (owner - r) * q)
     return owner.astype(np.int64), (ids - start).astype(np.int64)
+
+
+# ---- backward / optimiser restatements (float64; derivatives of the expressions above and the [TF-upstream] update rules) ------
+def fm_logit_backward(emb, g, F, K, add_in=None):
+    """d/d emb of sum_b g[b] * fm_logit(emb)[b] (+ add_in): g[b] * (sum_f' e[b,f',:] - e[b,f,:])   (deepFM.py:329-334)."""
+    e = np.asarray(emb, np.float64).reshape(-1, F, K)
+    d = np.asarray(g, np.float64).reshape(-1, 1, 1) * (e.sum(1, keepdims=True) - e)
+    d = d.reshape(e.shape[0], F * K)
+    return d if add_in is None else d + np.asarray(add_in, np.float64)
+
+
+def cross_network_backward(x0, w, b, gout):
+    """Backward of cross_network (DeepCrossNetwork.py:345-346,361-365): -> (gx0 [B,d], gw [L,d], gb [L,d])."""
+    x0 = np.asarray(x0, np.float64)
+    w, b = np.asarray(w, np.float64), np.asarray(b, np.float64)
+    L = w.shape[0]
+    xs, s = [x0], []
+    for l in range(L):
+        s.append(xs[l] @ w[l])
+        xs.append(x0 * s[l][:, None] + b[l] + xs[l])
+    g = np.asarray(gout, np.float64).copy()
+    gx0 = np.zeros_like(x0)
+    gw, gb = np.zeros_like(w), np.zeros_like(b)
+    for l in range(L - 1, -1, -1):
+        t = (g * x0).sum(1)                       # dL/ds_l
+        gb[l] = g.sum(0)
+        gw[l] = (t[:, None] * xs[l]).sum(0)
+        gx0 += g * s[l][:, None]
+        g = g + t[:, None] * w[l]
+    return gx0 + g, gw, gb
+
+
+def _dedup_sum(ids_f, grad_f, V):
+    gs = np.zeros((V, grad_f.shape[1]))
+    ok = ids_f >= 0
+    np.add.at(gs, ids_f[ok], np.asarray(grad_f, np.float64)[ok])
+    touched = np.zeros(V, bool)
+    touched[ids_f[ok]] = True
+    return gs, touched
+
+
+def sparse_adagrad_step(tables, accums, ids, grad, lr):
+    """[TF-upstream] AdagradOptimizer on IndexedSlices (duplicates summed first): accum += g^2; w -= lr*g/sqrt(accum).
+    tables / accums: lists of float64 [V,K] arrays updated in place; ids [B,F]; grad [B,F*K]."""
+    K = tables[0].shape[1]
+    for f, (w, a) in enumerate(zip(tables, accums)):
+        gs, t = _dedup_sum(ids[:, f], grad[:, f * K:(f + 1) * K], w.shape[0])
+        a[t] += gs[t] ** 2
+        w[t] -= lr * gs[t] / np.sqrt(a[t])
+
+
+def sparse_ftrl_step(tables, accums, linears, ids, grad, lr, l1=0.0, l2=0.0):
+    """[TF-upstream] FtrlOptimizer (learning_rate_power -0.5) on IndexedSlices; grad [B,F*K] or [B,K] (shared by the slots)."""
+    K = tables[0].shape[1]
+    for f, (w, n, z) in enumerate(zip(tables, accums, linears)):
+        gf = grad if grad.shape[1] == K else grad[:, f * K:(f + 1) * K]
+        gs, t = _dedup_sum(ids[:, f], gf, w.shape[0])
+        n_new = n[t] + gs[t] ** 2
+        sigma = (np.sqrt(n_new) - np.sqrt(n[t])) / lr
+        z_new = z[t] + gs[t] - sigma * w[t]
+        quad = np.sqrt(n_new) / lr + 2 * l2
+        w[t] = np.where(np.abs(z_new) > l1, (np.sign(z_new) * l1 - z_new) / quad, 0.0)
+        n[t], z[t] = n_new, z_new

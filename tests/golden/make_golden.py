@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""make_golden.py -- writes tests/golden/golden_v1.npz.
+"""make_golden.py -- writes tests/golden/golden_v1.npz and golden_v2_backward.npz.
 
 WHAT THESE VECTORS ARE: seeded inputs (np.random.default_rng(20240607)) and the outputs of oracle/ on
 them, plus the hand known-answer cases of SURVEY.md 8(c).  The reference repository holds no golden
@@ -96,6 +96,54 @@ def main():
     g["kat_cross_b"] = np.array([[.1, .2], [0, -.1]], np.float32)
     g["kat_cross_out"] = np.array([[-0.9, -1.9]], np.float32)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024))
+    make_backward()
+
+
+def make_backward():
+    """golden_v2_backward.npz: seeded inputs and the float64 backward / optimiser restatements of oracle/ (np_ref.py,
+    dir_oracle.c orc_cin_backward).  Same status as v1: a regression anchor for the oracle and a target for the HIP backward
+    kernels, not reference output."""
+    rng = np.random.default_rng(20240608)
+    g = {}
+    B, F, K = 48, 7, 16
+    emb = (rng.standard_normal((B, F * K)) * 0.3).astype(np.float32)
+    gfm = rng.standard_normal((B, 1)).astype(np.float32)
+    gdnn = rng.standard_normal((B, F * K)).astype(np.float32)
+    g["fmb_emb"], g["fmb_g"], g["fmb_add"] = emb, gfm, gdnn
+    g["fmb_out"] = R.fm_logit_backward(emb, gfm, F, K, gdnn)
+    for d, L in ((416, 3), (51, 2)):
+        x0 = (rng.standard_normal((B, d)) * 0.25).astype(np.float32)
+        w = np.clip(rng.standard_normal((L, d)) * 0.1, -0.2, 0.2).astype(np.float32)
+        b = np.clip(rng.standard_normal((L, d)) * 0.1, -0.2, 0.2).astype(np.float32)
+        go = rng.standard_normal((B, d)).astype(np.float32)
+        gx0, gw, gb = R.cross_network_backward(x0, w, b, go)
+        for k, v in dict(x0=x0, w=w, b=b, gout=go, gx0=gx0, gw=gw, gb=gb).items():
+            g["crossb%d_%s" % (d, k)] = v
+    Bc, m, D, Hp, H = 6, 26, 16, 26, 40
+    x0 = (rng.standard_normal((Bc, m, D)) * 0.5).astype(np.float32)
+    xk = (rng.standard_normal((Bc, Hp, D)) * 0.5).astype(np.float32)
+    W = (rng.standard_normal((H, Hp * m)) / np.sqrt(Hp * m)).astype(np.float32)
+    G = (rng.standard_normal((Bc, H, D)) * 0.5).astype(np.float32)
+    dW, dxk, dx0 = O.cin_backward(x0, xk, W, G)
+    for k, v in dict(x0=x0, xk=xk, W=W, G=G, dW=dW, dxk=dxk, dx0=dx0).items():
+        g["cinb_" + k] = v
+    Bo, Fo, Ko, Vo = 200, 3, 8, 17
+    tabs = [rng.standard_normal((Vo, Ko)).astype(np.float32) for _ in range(Fo)]
+    ids = rng.integers(-1, Vo, size=(Bo, Fo)).astype(np.int64)
+    grad = (rng.standard_normal((Bo, Fo * Ko)) * 0.5).astype(np.float32)
+    w64 = [t.astype(np.float64) for t in tabs]
+    a64 = [np.full((Vo, Ko), 0.1) for _ in range(Fo)]
+    R.sparse_adagrad_step(w64, a64, ids, grad, 0.05)
+    g["opt_tables"], g["opt_ids"], g["opt_grad"] = np.stack(tabs), ids, grad
+    g["opt_adagrad_w"], g["opt_adagrad_acc"] = np.stack(w64), np.stack(a64)
+    w64 = [t.astype(np.float64) for t in tabs]
+    n64 = [np.full((Vo, Ko), 0.1) for _ in range(Fo)]
+    z64 = [np.zeros((Vo, Ko)) for _ in range(Fo)]
+    R.sparse_ftrl_step(w64, n64, z64, ids, grad, 0.2, l1=0.01, l2=0.05)
+    g["opt_ftrl_w"], g["opt_ftrl_n"], g["opt_ftrl_z"] = np.stack(w64), np.stack(n64), np.stack(z64)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v2_backward.npz")
     np.savez_compressed(out, **g)
     print("wrote", out, "%.1f KB" % (os.path.getsize(out) / 1024))
 
