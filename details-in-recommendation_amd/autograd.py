@@ -7,6 +7,8 @@ SPARSE gradient the reference's embedding lookups produce (IndexedSlices): indic
 incoming row gradients times the bag coefficient.  The sparse tensors are handed to torch.optim (Adagrad accepts
 sparse gradients and, like TensorFlow's _apply_sparse_duplicate_indices, sums duplicate ids before the update).
 """
+import os
+
 import torch
 
 from . import ops
@@ -201,12 +203,16 @@ def _tn_matmul(A, Bm, splits=128):
     return out
 
 
+_DIN_COMPOSITE_BACKWARD = os.environ.get("DIR_DIN_COMPOSITE_BACKWARD", "0") == "1"   # dev switch: A/B against the fused kernel
+
+
 class DinAttentionPool(torch.autograd.Function):
-    """DIN local activation unit + pooling (include/dir_hip.h A13).  Forward: the fused HIP kernel.  Backward: hand-derived,
-    over the VALID (sample, position) rows only, entirely on the GPU: the unit is recomputed in the regrouped form the
-    forward kernel uses ([h, a, h-a, h*a].W1 = h.(Wh+Wd) + (h*a).Wp + a.(Wa-Wd)), its six GEMMs and their transposes go
-    through rocBLAS, the elementwise steps and the per-sample segment sums are torch kernels; the table gets a sparse
-    gradient (history rows and candidate rows).  No autograd graph is built.  (A fused HIP backward is the next step.)"""
+    """DIN local activation unit + pooling (include/dir_hip.h A13).  Forward: the fused HIP kernel.  Backward: the fused HIP
+    backward (ops.din_attention_pool_backward) for the shape class it covers (K = 64, H1 <= 80, H2 <= 48, T <= 64); other
+    shapes take the hand-derived GPU composite below: the unit recomputed over the VALID (sample, position) rows in the
+    regrouped form the forward kernel uses ([h, a, h-a, h*a].W1 = h.(Wh+Wd) + (h*a).Wp + a.(Wa-Wd)), six GEMMs through rocBLAS,
+    the elementwise steps and per-sample segment sums as torch kernels.  Either way the table gets a sparse gradient (history
+    rows and candidate rows) and no autograd graph is built."""
 
     @staticmethod
     def forward(ctx, table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize):
@@ -223,6 +229,15 @@ class DinAttentionPool(torch.autograd.Function):
         K, H1 = table.shape[1], W1.shape[1]
         dev = table.device
         g = g.contiguous()
+        if ops.din_backward_supported(K, T, H1, W2.shape[1]) and not _DIN_COMPOSITE_BACKWARD:
+            r = ops.din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=ctx.normalize)
+            gtab = None
+            if ctx.needs_input_grad[0]:
+                ok = cand >= 0                                      # a pruned candidate (zero vector in the forward) adds nothing
+                idx = torch.cat([r["ids_h"], torch.where(ok, cand, torch.zeros_like(cand))]).unsqueeze(0)
+                gtab = torch.sparse_coo_tensor(idx, torch.cat([r["gh"], r["ga"] * ok.unsqueeze(1)]), table.shape)
+            return (gtab, None, None, None, r["gW1"], r["gb1"], r["gW2"], r["gb2"], r["gW3"].reshape(W3.shape),
+                    r["gb3"].reshape(b3.shape), None)
         valid = hist >= 0
         if hist_len is not None:
             valid &= torch.arange(T, device=dev).unsqueeze(0) < hist_len.clamp(0, T).unsqueeze(1)

@@ -214,9 +214,10 @@ struct DinFrag {
 };
 
 // Layers 1-3 for a compile-time number of row tiles.  Leaves the per-column-tile partial scores in sh.scp.
-template <int K, int NC1, int NC2, int RT>
+// KEEP (the backward kernel's recompute): also leaves the layer-2 activations in z2out[row][H2P + 4].
+template <int K, int NC1, int NC2, int RT, bool KEEP = false>
 __device__ __forceinline__ void din_mlp_tiles(DinSh<K, NC1, NC2>& sh, const DinFrag<K, NC1>& fr, float bias1, float bias1_s,
-                                              float bias2, float w3v, int w, int r16, int kk) {
+                                              float bias2, float w3v, int w, int r16, int kk, float* z2out = nullptr) {
     using S = DinSh<K, NC1, NC2>;
     constexpr int KQ = K / 4;          // features per lane group = k-steps per chain
     constexpr int QN = KQ / 4;         // 16-byte groups per lane
@@ -331,7 +332,9 @@ __device__ __forceinline__ void din_mlp_tiles(DinSh<K, NC1, NC2>& sh, const DinF
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float v = row16_sum(fast_sigmoid(acc2[rt][g]) * w3v);
+                const float z2v = fast_sigmoid(acc2[rt][g]);
+                if (KEEP) z2out[(rt * 16 + 4 * kk + g) * (S::H2P + 4) + 16 * w + r16] = z2v;
+                const float v = row16_sum(z2v * w3v);
                 if (r16 == 0) sh.scp[w * 64 + rt * 16 + 4 * kk + g] = v;
             }
     }
@@ -552,6 +555,529 @@ static int launch_din_mfma(hipStream_t st, const float* table, const int64_t* hi
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward of the unit + pooling (training).  Shape class (K, H1, H2) = (64, <= 80, <= 48), T <= 64.
+// Same workgroup / sample structure as din_mfma_k; per sample:
+//   1. recompute layers 1-3 with the forward's code (din_mlp_tiles<KEEP>: z1 and z2 stay in LDS);
+//   2. wave 0: weights w (masked softmax or raw scores), d score from dw_j = g . h_j, compact output rows;
+//   3. dpre2 = ds * W3 * z2 (1 - z2) in place of z2 (+ the running sums for dW3, db2, db3);
+//   4. MFMA, reduction over rows: dW2 += z1^T dpre2;   reduction over H2: dz1 = dpre2 W2^T -> dpre1 = dz1 z1 (1 - z1);
+//   5. MFMA, reduction over rows: d[Wh+Wd | Wp] += [h | h*a]^T dpre1;   reduction over H1: dX = dpre1 [Wh+Wd | Wp]^T
+//      -> d h_j = dXh + dXp * a + w_j g  (written to the compact row list),  d a += sum_j dXp * h_j.
+// The weight gradients accumulate in registers over the whole launch (56 accumulator registers per lane) and leave as one
+// partial record per workgroup; din_bwd_sum_k / din_bwd_finish_k add the records.  The per-sample term's gradients (through a.(Wa-Wd) + b1)
+// only need S_b = sum_j dpre1, which is written out: the host finishes them with two small GEMMs.
+// Row-reduction operands come from the row-major LDS tiles with 4-byte reads (k-step s, lane group kk <-> row 4s + kk);
+// column-reduction operands are 16-byte reads as in the forward.
+// ------------------------------------------------------------------------------------------------
+template <int K, int NC1, int NC2>
+struct DinBwdSh {
+    using F = DinSh<K, NC1, NC2>;
+    static constexpr int Z2S = F::H2P + 4;
+    F f;                       // the forward's staging: uh, av, z1, part, scp, sc, valid
+    float z2[64 * Z2S];        // layer-2 activations, then dpre2 in place
+    float dp1[64 * F::Z1S];    // dpre1
+    float gv[K];               // d out of this sample
+    float ds[64];              // d score
+    float dw[64];              // g . h_j
+    float S[F::H1P];           // column sums of dpre1
+    float gaout[K];            // d a of this sample (leaves with the flush)
+    int rank[64];              // compact output row of position j (-1: not a valid row)
+};
+
+#ifdef DIN_STAMP   // tools/din_bwd_probe.hip only: [0] stage [1] dw + recompute [2] weights/ds [3] dpre2 [4] dW2/dz1 [5] dAP/dX [6] samples
+__device__ unsigned long long din_bwd_stamp[12];
+#define DINB_ACC(i, a, b) if (threadIdx.x == 0) atomicAdd(&din_bwd_stamp[i], (b) - (a))
+#else
+#define DINB_ACC(i, a, b)
+#endif
+
+constexpr int kDinBwdGAP = 2 * 64 * 80, kDinBwdGW2 = 80 * 48;
+// per-workgroup partial record: gAP [128][80] | gW2 [80][48] | gb2 [4][48] | gW3 [4][48] | gb3 [64]
+constexpr int kDinBwdRec = kDinBwdGAP + kDinBwdGW2 + 4 * 48 + 4 * 48 + 64;
+
+template <int K, int NC1, int NC2>
+__global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
+                                                      const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand,
+                                                      int T, const float* __restrict__ W1, const float* __restrict__ b1, int H1,
+                                                      const float* __restrict__ W2, const float* __restrict__ b2, int H2,
+                                                      const float* __restrict__ W3, const float* __restrict__ b3, int normalize,
+                                                      int64_t B, const float* __restrict__ gout,
+                                                      const int64_t* __restrict__ row_off, float* __restrict__ gh,
+                                                      float* __restrict__ ga, float* __restrict__ Sout,
+                                                      float* __restrict__ partials) {
+    static_assert(K == 64 && NC1 == 5 && NC2 == 3, "din_bwd_k is written for the (64, 80, 48) shape class");
+    using S = DinSh<K, NC1, NC2>;
+    using SB = DinBwdSh<K, NC1, NC2>;
+    constexpr int NT = 64 * S::NW;
+    constexpr int KQ = K / 4;
+    constexpr int QN = KQ / 4;
+    constexpr int KS2 = S::H1P / 4;
+    constexpr int KC = K / 4;
+    constexpr int NPF = (64 * KC + NT - 1) / NT;
+    constexpr int HS = S::HS, Z1S = S::Z1S, Z2S = SB::Z2S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char din_bwd_smem[];
+    SB& sb = *reinterpret_cast<SB*>(din_bwd_smem);
+    S& sh = sb.f;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int r16 = lane & 15;
+    const int kk = lane >> 4;
+    const float inv_sqrt_k = 1.0f / sqrtf((float)K);
+
+    // ---- the forward's B fragments (as in din_mfma_k) ---------------------------------------------------------------
+    DinFrag<K, NC1> fr;
+    auto w1parts = [&](int f, int col, float& hd, float& c, float& p) {
+        float vh = 0.f, va = 0.f, vd = 0.f, vp = 0.f;
+        if (col < H1) {
+            vh = W1[(size_t)f * H1 + col];
+            va = W1[(size_t)(K + f) * H1 + col];
+            vd = W1[(size_t)(2 * K + f) * H1 + col];
+            vp = W1[(size_t)(3 * K + f) * H1 + col];
+        }
+        hd = vh + vd;
+        c = va - vd;
+        p = vp;
+    };
+    {
+        const int rot = w;
+        const int col = 16 * w + r16;
+#pragma unroll
+        for (int it = 0; it < QN; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = kk * KQ + 4 * ((it + rot) % QN) + e;
+                w1parts(f, col, fr.whd[4 * it + e], fr.wc[4 * it + e], fr.wp[4 * it + e]);
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = kk * KQ + 4 * (rot % QN) + e;
+            w1parts(f, 64 + r16, fr.whd_s[e], fr.wc_s[e], fr.wp_s[e]);
+        }
+    }
+    const float bias1 = (16 * w + r16) < H1 ? b1[16 * w + r16] : 0.f;
+    const float bias1_s = (64 + r16) < H1 ? b1[64 + r16] : 0.f;
+    float bias2 = 0.f, w3v = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < KS2; ++s2) {
+        const int i = kk * KS2 + s2;
+        const int col = 16 * w + r16;
+        fr.wr2[s2] = (w < NC2 && i < H1 && col < H2) ? W2[(size_t)i * H2 + col] : 0.f;
+    }
+    if (w < NC2 && (16 * w + r16) < H2) {
+        bias2 = b2[16 * w + r16];
+        w3v = W3[16 * w + r16];
+    }
+    const float bias3 = b3[0];
+    // ---- backward B fragments: W2^T for dz1 (own H1 tile; wave 3 also the 5th), [Wh+Wd | Wp]^T for dX (own feature tile) ----
+    float w2t[12], w2t4[12], aph[20], app[20];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c2 = kk * 12 + i, c1 = 16 * w + r16, c1b = 64 + r16;
+        w2t[i] = (c1 < H1 && c2 < H2) ? W2[(size_t)c1 * H2 + c2] : 0.f;
+        w2t4[i] = (w == 3 && c1b < H1 && c2 < H2) ? W2[(size_t)c1b * H2 + c2] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        const int c1 = kk * 20 + i, feat = 16 * w + r16;
+        aph[i] = c1 < H1 ? W1[(size_t)feat * H1 + c1] + W1[(size_t)(2 * K + feat) * H1 + c1] : 0.f;
+        app[i] = c1 < H1 ? W1[(size_t)(3 * K + feat) * H1 + c1] : 0.f;
+    }
+    const int c2e = tid % 48, rge = tid / 48;             // step 3: thread <-> (H2 column, row group), tid < 192
+    const float w3c = (tid < 192 && c2e < H2) ? W3[c2e] : 0.f;
+
+    // ---- accumulators that live for the whole launch ------------------------------------------------------------------
+    f32x4m gAPh[5], gAPp[5], gW2a[4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) gAPh[i] = gAPp[i] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gW2a[i] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+    float gW3acc = 0.f, gb2acc = 0.f, gb3acc = 0.f;
+
+    // ---- software pipeline: ids two samples ahead, rows (and d out) one ahead ---------------------------------------
+    const int64_t G = gridDim.x;
+    // three stages: the per-sample scalars (length, candidate id, output row) three samples ahead, the history ids two ahead
+    // (their predicate is a length that arrived an iteration ago), the rows one ahead: no load is consumed in the iteration
+    // that issues it
+    auto load_scalars = [&](int64_t bb, int& len, int64_t& cid, int64_t& base) {
+        len = 0;
+        cid = -1;
+        base = 0;
+        if (bb < B) {
+            len = hist_len ? min((int)hist_len[bb], T) : T;
+            len = max(len, 0);
+            cid = cand[bb];
+            base = row_off[bb];
+        }
+    };
+    auto load_ids = [&](int64_t bb, int len, int64_t (&ids)[NPF]) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            ids[k] = -1;
+            if (q < len * KC) ids[k] = hist[bb * T + q / KC];      // len == 0 beyond the batch
+        }
+    };
+    auto load_rows = [&](int64_t bb, int len, int64_t cid, const int64_t (&ids)[NPF], float4 (&h)[NPF], float4& a) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            h[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < len * KC && ids[k] >= 0) h[k] = *reinterpret_cast<const float4*>(table + ids[k] * K + 4 * (q % KC));
+        }
+        a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < KC && cid >= 0) a = *reinterpret_cast<const float4*>(table + cid * K + 4 * tid);
+        if (tid >= KC && tid < 2 * KC && bb < B) a = *reinterpret_cast<const float4*>(gout + bb * K + 4 * (tid - KC));
+    };
+    int len0, len1, len2;
+    int64_t cid0, cid1, cid2, base0, base1, base2, id0[NPF], id1[NPF];
+    float4 hreg[NPF], areg4;
+    load_scalars(blockIdx.x, len0, cid0, base0);
+    load_scalars(blockIdx.x + G, len1, cid1, base1);
+    load_scalars(blockIdx.x + 2 * G, len2, cid2, base2);
+    load_ids(blockIdx.x, len0, id0);
+    load_ids(blockIdx.x + G, len1, id1);
+    load_rows(blockIdx.x, len0, cid0, id0, hreg, areg4);
+
+    // d h rows, d a and S of a sample leave one iteration later (flush): they wait in LDS (the rows in z1's place) and are
+    // written after the NEXT sample's loads have been issued, so that no store sits between a load and its wait
+    int64_t b_prev = -1, base_prev = 0;
+    int len_prev = 0;
+    float* ghbuf = sh.z1;                               // [64][Z1S], dead between step 4 and the next sample's layer 1
+    auto flush_read = [&](float4 (&fl)[NPF], int (&frk)[NPF], float& fga, float& fs) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            const int j = q / KC, c = q - j * KC;
+            frk[k] = (b_prev >= 0 && j < len_prev) ? sb.rank[j] : -1;
+            fl[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (frk[k] >= 0) fl[k] = *reinterpret_cast<const float4*>(ghbuf + j * Z1S + 4 * c);
+        }
+        fga = (b_prev >= 0 && tid < K) ? sb.gaout[tid] : 0.f;
+        fs = (b_prev >= 0 && tid < S::H1P) ? sb.S[tid] : 0.f;
+    };
+    auto flush_write = [&](const float4 (&fl)[NPF], const int (&frk)[NPF], float fga, float fs) {
+        if (b_prev < 0) return;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            const int c = q % KC;
+            if (frk[k] >= 0) *reinterpret_cast<float4*>(gh + (base_prev + frk[k]) * K + 4 * c) = fl[k];
+        }
+        if (tid < K) ga[b_prev * K + tid] = fga;
+        if (tid < H1) Sout[b_prev * H1 + tid] = fs;
+    };
+
+    for (int64_t b = blockIdx.x; b < B; b += G) {
+        DIN_T(t0);
+        const int len = len0;
+        const int RT = (len + 15) >> 4;
+        const int64_t base = base0;
+        float4 fl[NPF];
+        int frk[NPF];
+        float fga, fs;
+        flush_read(fl, frk, fga, fs);
+        // ---- stage rows (zero-padded to whole row tiles: every later product with a padded row is an exact zero) -------
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            if (q < len * KC) {
+                const int j = q / KC, c = q - j * KC;
+                *reinterpret_cast<float4*>(sh.uh + j * HS + 4 * c) = hreg[k];
+                if (c == 0) sh.valid[j] = id0[k] >= 0 ? 1 : 0;
+            }
+        }
+        for (int q = len * KC + tid; q < RT * 16 * KC; q += NT) {
+            const int j = q / KC, c = q - j * KC;
+            *reinterpret_cast<float4*>(sh.uh + j * HS + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int j = len + tid; j < 64; j += NT) sh.valid[j] = 0;
+        if (tid < KC) *reinterpret_cast<float4*>(sh.av + 4 * tid) = areg4;
+        if (tid >= KC && tid < 2 * KC) *reinterpret_cast<float4*>(sb.gv + 4 * (tid - KC)) = areg4;
+        __syncthreads();
+        DIN_T(t0a);
+        len0 = len1; cid0 = cid1; base0 = base1;
+        len1 = len2; cid1 = cid2; base1 = base2;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) id0[k] = id1[k];
+        load_ids(b + 2 * G, len1, id1);
+        load_rows(b + G, len0, cid0, id0, hreg, areg4);
+        load_scalars(b + 3 * G, len2, cid2, base2);
+        flush_write(fl, frk, fga, fs);
+        b_prev = b;
+        base_prev = base;
+        len_prev = len;
+        if (RT == 0) {   // block-uniform: nothing reaches the unit; the per-sample outputs are zero
+            if (tid < K) sb.gaout[tid] = 0.f;
+            if (tid < S::H1P) sb.S[tid] = 0.f;
+            __syncthreads();
+            continue;
+        }
+        DIN_T(t1);
+        // ---- dw_j = g . h_j (four threads per row) --------------------------------------------------------------------
+        {
+            const int row = tid >> 2, qd = tid & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 h4 = *reinterpret_cast<const float4*>(sh.uh + row * HS + qd * 16 + 4 * c);
+                const float4 g4 = *reinterpret_cast<const float4*>(sb.gv + qd * 16 + 4 * c);
+                v = fmaf(h4.x, g4.x, v); v = fmaf(h4.y, g4.y, v); v = fmaf(h4.z, g4.z, v); v = fmaf(h4.w, g4.w, v);
+            }
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if (qd == 0) sb.dw[row] = v;
+        }
+        // ---- 1. recompute the unit ----------------------------------------------------------------------------------------
+        switch (RT) {
+            case 1: din_mlp_tiles<K, NC1, NC2, 1, true>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk, sb.z2); break;
+            case 2: din_mlp_tiles<K, NC1, NC2, 2, true>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk, sb.z2); break;
+            case 3: din_mlp_tiles<K, NC1, NC2, 3, true>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk, sb.z2); break;
+            default: din_mlp_tiles<K, NC1, NC2, 4, true>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk, sb.z2); break;
+        }
+        __syncthreads();
+        DIN_T(t2);
+        // ---- 2. weights, d score, compact rows (wave 0) -------------------------------------------------------------------
+        if (tid < 64) {
+            const bool ok = tid < len && sh.valid[tid];
+            float sv = 0.f;
+            if (ok) {
+                sv = bias3;
+#pragma unroll
+                for (int c2 = 0; c2 < NC2; ++c2) sv += sh.scp[c2 * 64 + tid];
+            }
+            const float dwv = ok ? sb.dw[tid] : 0.f;
+            float dsv = dwv;
+            if (normalize) {
+                const float x = sv * inv_sqrt_k;
+                const float mx = wave_max_dpp(ok ? x : -INFINITY);
+                const float ex = ok ? __expf(x - mx) : 0.f;
+                const float sum = wave_sum_dpp(ex);
+                sv = ok ? ex / sum : 0.f;
+                const float tsum = wave_sum_dpp(sv * dwv);
+                dsv = sv * (dwv - tsum) * inv_sqrt_k;
+            }
+            dsv = ok ? dsv : 0.f;
+            sh.sc[tid] = sv;
+            sb.ds[tid] = dsv;
+            const unsigned long long bal = __ballot(ok);
+            sb.rank[tid] = ok ? __popcll(bal & ((1ull << tid) - 1ull)) : -1;
+            gb3acc += dsv;
+        }
+        __syncthreads();
+        DIN_T(t3);
+        // ---- 3. dpre2 in place of z2; running sums for dW3 and db2 -------------------------------------------------------
+        if (tid < 192) {
+            for (int row = rge; row < 16 * RT; row += 4) {
+                const float z = sb.z2[row * Z2S + c2e];
+                const float d = sb.ds[row];
+                gW3acc = fmaf(d, z, gW3acc);
+                const float dp = d * w3c * z * (1.0f - z);
+                gb2acc += dp;
+                sb.z2[row * Z2S + c2e] = dp;
+            }
+        }
+        __syncthreads();
+        DIN_T(t4);
+        // ---- 4. dW2 += z1^T dpre2;  dz1 = dpre2 W2^T -> dpre1 ---------------------------------------------------------------
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = rt * 16 + 4 * s + kk;
+                const float a = sh.z1[row * Z1S + 16 * w + r16];
+                const float a4 = sh.z1[row * Z1S + 64 + r16];
+                const float b0 = sb.z2[row * Z2S + r16], b1v = sb.z2[row * Z2S + 16 + r16], b2v = sb.z2[row * Z2S + 32 + r16];
+                gW2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, gW2a[0], 0, 0, 0);
+                gW2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, gW2a[1], 0, 0, 0);
+                gW2a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2v, gW2a[2], 0, 0, 0);
+                const float bw = w == 0 ? b0 : (w == 1 ? b1v : b2v);
+                if (w < 3) gW2a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4, bw, gW2a[3], 0, 0, 0);   // H1 tile 4 x H2 tile w
+            }
+        }
+        DIN_T(t4a);
+        {
+            float colsum = 0.f, colsum4 = 0.f;
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4m acc = (f32x4m){0.f, 0.f, 0.f, 0.f}, acc4 = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(sb.z2 + (rt * 16 + r16) * Z2S + kk * 12 + 4 * q);
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], w2t[4 * q + e], acc, 0, 0, 0);
+                        if (w == 3) acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], w2t4[4 * q + e], acc4, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rt * 16 + 4 * kk + g;
+                    const float z = sh.z1[row * Z1S + 16 * w + r16];
+                    const float d1 = acc[g] * z * (1.0f - z);
+                    sb.dp1[row * Z1S + 16 * w + r16] = d1;
+                    colsum += d1;
+                    if (w == 3) {
+                        const float z4 = sh.z1[row * Z1S + 64 + r16];
+                        const float d14 = acc4[g] * z4 * (1.0f - z4);
+                        sb.dp1[row * Z1S + 64 + r16] = d14;
+                        colsum4 += d14;
+                    }
+                }
+            }
+            colsum += __shfl_xor(colsum, 16, 64);
+            colsum += __shfl_xor(colsum, 32, 64);
+            if (kk == 0) sb.S[16 * w + r16] = colsum;
+            if (w == 3) {
+                colsum4 += __shfl_xor(colsum4, 16, 64);
+                colsum4 += __shfl_xor(colsum4, 32, 64);
+                if (kk == 0) sb.S[64 + r16] = colsum4;
+            }
+        }
+        __syncthreads();
+        DIN_T(t5);
+        // ---- 5. d[Wh+Wd | Wp] += [h | h*a]^T dpre1;  dX = dpre1 [Wh+Wd | Wp]^T -> d h rows, d a ----------------------------
+        const float a_f = sh.av[16 * w + r16], g_f = sb.gv[16 * w + r16];
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = rt * 16 + 4 * s + kk;
+                const float hrow = sh.uh[row * HS + 16 * w + r16];
+                const float hp = hrow * a_f;
+#pragma unroll
+                for (int ni = 0; ni < 5; ++ni) {
+                    const float bv = sb.dp1[row * Z1S + 16 * ni + r16];
+                    gAPh[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(hrow, bv, gAPh[ni], 0, 0, 0);
+                    gAPp[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(hp, bv, gAPp[ni], 0, 0, 0);
+                }
+            }
+        }
+        DIN_T(t5a);
+        {
+            float ga_acc = 0.f;
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4m acch = (f32x4m){0.f, 0.f, 0.f, 0.f}, accp = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(sb.dp1 + (rt * 16 + r16) * Z1S + kk * 20 + 4 * q);
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acch = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], aph[4 * q + e], acch, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], app[4 * q + e], accp, 0, 0, 0);
+                    }
+                }
+                const float4 sc4 = *reinterpret_cast<const float4*>(sh.sc + rt * 16 + 4 * kk);
+                const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rt * 16 + 4 * kk + g;
+                    const float hval = sh.uh[row * HS + 16 * w + r16];
+                    ga_acc = fmaf(accp[g], hval, ga_acc);
+                    ghbuf[row * Z1S + 16 * w + r16] = fmaf(accp[g], a_f, acch[g]) + scv[g] * g_f;
+                }
+            }
+            ga_acc += __shfl_xor(ga_acc, 16, 64);
+            ga_acc += __shfl_xor(ga_acc, 32, 64);
+            if (kk == 0) sb.gaout[16 * w + r16] = ga_acc;
+        }
+        __syncthreads();   // the next sample's staging overwrites uh / av / gv; its flush reads ghbuf / gaout / S
+        DIN_T(t6);
+        DINB_ACC(0, t0, t0a); DINB_ACC(7, t0a, t1); DINB_ACC(1, t1, t2); DINB_ACC(2, t2, t3); DINB_ACC(3, t3, t4); DINB_ACC(4, t4, t5); DINB_ACC(5, t5, t6); DINB_ACC(8, t4, t4a); DINB_ACC(9, t5, t5a);
+        DINB_ACC(6, 0ull, 1ull);
+    }
+
+    {
+        float4 fl[NPF];
+        int frk[NPF];
+        float fga, fs;
+        flush_read(fl, frk, fga, fs);
+        flush_write(fl, frk, fga, fs);
+    }
+    // ---- this workgroup's partial record ------------------------------------------------------------------------------------
+    float* rec = partials + (size_t)blockIdx.x * kDinBwdRec;
+#pragma unroll
+    for (int ni = 0; ni < 5; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            rec[(16 * w + 4 * kk + g) * 80 + 16 * ni + r16] = gAPh[ni][g];
+            rec[(64 + 16 * w + 4 * kk + g) * 80 + 16 * ni + r16] = gAPp[ni][g];
+        }
+#pragma unroll
+    for (int ni = 0; ni < 3; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rec[kDinBwdGAP + (16 * w + 4 * kk + g) * 48 + 16 * ni + r16] = gW2a[ni][g];
+    if (w < 3) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rec[kDinBwdGAP + (64 + 4 * kk + g) * 48 + 16 * w + r16] = gW2a[3][g];
+    }
+    if (tid < 192) {
+        rec[kDinBwdGAP + kDinBwdGW2 + rge * 48 + c2e] = gb2acc;
+        rec[kDinBwdGAP + kDinBwdGW2 + 192 + rge * 48 + c2e] = gW3acc;
+    }
+    if (tid < 64) rec[kDinBwdGAP + kDinBwdGW2 + 384 + tid] = gb3acc;
+}
+
+// sums the per-workgroup records into one record: 16 waves per 64 values, each wave adds a contiguous range of records, the 16
+// partial sums meet in LDS in a fixed order
+__global__ __launch_bounds__(1024) void din_bwd_sum_k(const float* __restrict__ partials, int nwg, float* __restrict__ red) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int per = (nwg + 15) / 16;
+    const int g0 = wv * per, g1 = min(nwg, g0 + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < kDinBwdRec) {
+        const float* p = partials + e;
+        int g = g0;
+        for (; g + 4 <= g1; g += 4) {
+            a0 += p[(size_t)(g + 0) * kDinBwdRec];
+            a1 += p[(size_t)(g + 1) * kDinBwdRec];
+            a2 += p[(size_t)(g + 2) * kDinBwdRec];
+            a3 += p[(size_t)(g + 3) * kDinBwdRec];
+        }
+        for (; g < g1; ++g) a0 += p[(size_t)g * kDinBwdRec];
+    }
+    part[wv][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wv == 0 && e < kDinBwdRec) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += part[i][lane];
+        red[e] = acc;
+    }
+}
+
+// the summed record -> the caller's arrays (drops the padding columns, adds the row-group / lane slots)
+__global__ __launch_bounds__(256) void din_bwd_finish_k(const float* __restrict__ red, int K, int H1, int H2,
+                                                         float* __restrict__ gAP, float* __restrict__ gW2,
+                                                         float* __restrict__ gb2, float* __restrict__ gW3,
+                                                         float* __restrict__ gb3) {
+    const int n_ap = 2 * K * H1, n_w2 = H1 * H2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_ap + n_w2 + 2 * H2 + 1) return;
+    if (idx < n_ap) {
+        gAP[idx] = red[(idx / H1) * 80 + idx % H1];
+    } else if (idx < n_ap + n_w2) {
+        const int i = idx - n_ap;
+        gW2[i] = red[kDinBwdGAP + (i / H2) * 48 + i % H2];
+    } else if (idx < n_ap + n_w2 + 2 * H2) {
+        const int i = idx - n_ap - n_w2;
+        const bool w3 = i >= H2;
+        const float* p = red + kDinBwdGAP + kDinBwdGW2 + (w3 ? 192 + i - H2 : i);
+        (w3 ? gW3 : gb2)[w3 ? i - H2 : i] = (p[0] + p[48]) + (p[96] + p[144]);
+    } else {
+        const float* p = red + kDinBwdGAP + kDinBwdGW2 + 384;
+        float acc = 0.f;
+        for (int l = 0; l < 64; ++l) acc += p[l];
+        gb3[0] = acc;
+    }
+}
+
+constexpr int kDinBwdMaxWg = kCUs;   // one workgroup per CU (93 KB of LDS)
+
 }  // namespace dir
 
 using namespace dir;
@@ -599,5 +1125,49 @@ extern "C" int dir_din_attention_pool_f32(const float* table, int K, const int64
     dim3 grid((unsigned)(B < (int64_t)kCUs * per_cu * 4 ? B : (int64_t)kCUs * per_cu * 4));
     hipLaunchKernelGGL((din_k<5>), grid, dim3(256), shmem, as_stream(stream), table, dm, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize, B, out, scores);
     DIR_CHECK_LAUNCH("din_attention_pool");
+    return DIR_OK;
+}
+
+extern "C" int64_t dir_din_backward_workspace_bytes(int K, int H1, int H2) {
+    if (K != 64 || H1 <= 0 || H2 <= 0 || H1 > 80 || H2 > 48) return 0;
+    return (int64_t)(kDinBwdMaxWg + 1) * kDinBwdRec * (int64_t)sizeof(float);   // one record per workgroup + their sum
+}
+
+extern "C" int dir_din_attention_pool_backward_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
+                                                   const int64_t* cand, int T, const float* W1, const float* b1, int H1,
+                                                   const float* W2, const float* b2, int H2, const float* W3, const float* b3,
+                                                   int normalize, int64_t B, const float* gout, const int64_t* row_off,
+                                                   float* gh, float* ga, float* S, float* gAP, float* gW2, float* gb2,
+                                                   float* gW3, float* gb3, void* workspace, dir_stream_t stream) {
+    const char* name = "dir_din_attention_pool_backward_f32";
+    DIR_CHECK_ARG(K > 0 && T > 0 && H1 > 0 && H2 > 0 && B >= 0, "%s: K=%d T=%d H1=%d H2=%d", name, K, T, H1, H2);
+    if (K != 64 || H1 > 80 || H2 > 48 || (H1 & 3) || (H2 & 3) || T > 64)
+        return fail(DIR_E_UNSUPPORTED, "%s: the fused backward covers K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 64 (K=%d H1=%d H2=%d T=%d)",
+                    name, K, H1, H2, T);
+    DIR_CHECK_ARG(table && hist && cand && W1 && b1 && W2 && b2 && W3 && b3 && gAP && gW2 && gb2 && gW3 && gb3 && workspace,
+                  "%s: null pointer", name);
+    DIR_CHECK_ARG(B == 0 || (gout && row_off && ga && S), "%s: null pointer", name);   // gh may be NULL when there is no valid row
+    if (!aligned16(table) || !aligned16(gout))
+        return fail(DIR_E_BADARG, "%s: table / gout must be 16-byte aligned", name);
+    hipStream_t st = as_stream(stream);
+    static bool attr_set = false;
+    const size_t shmem = sizeof(DinBwdSh<64, 5, 3>);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&din_bwd_k<64, 5, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+            return fail(DIR_E_HIP, "%s: cannot reserve %zu B of LDS", name, shmem);
+        attr_set = true;
+    }
+    int nwg = (int)(B < kDinBwdMaxWg ? B : kDinBwdMaxWg);
+    float* partials = static_cast<float*>(workspace);
+    if (nwg > 0) {
+        hipLaunchKernelGGL((din_bwd_k<64, 5, 3>), dim3((unsigned)nwg), dim3(256), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1,
+                           W2, b2, H2, W3, b3, normalize, B, gout, row_off, gh, ga, S, partials);
+        DIR_CHECK_LAUNCH(name);
+    }
+    float* red = partials + (size_t)kDinBwdMaxWg * kDinBwdRec;
+    hipLaunchKernelGGL(din_bwd_sum_k, dim3((unsigned)((kDinBwdRec + 63) / 64)), dim3(1024), 0, st, partials, nwg, red);
+    const int nout = 2 * K * H1 + H1 * H2 + 2 * H2 + 1;
+    hipLaunchKernelGGL(din_bwd_finish_k, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, red, K, H1, H2, gAP, gW2, gb2, gW3, gb3);
+    DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }

@@ -261,6 +261,68 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     return (out, scores) if want_scores else out
 
 
+def din_backward_supported(K, T, H1, H2):
+    """Shapes the fused DIN backward covers (include/dir_hip.h: dir_din_attention_pool_backward_f32)."""
+    return K == 64 and T <= 64 and H1 <= 80 and H2 <= 48 and H1 % 4 == 0 and H2 % 4 == 0
+
+
+_DIN_BWD_WS = {}
+
+
+def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=False):
+    """Backward of din_attention_pool given g = dL/dout [B, K] (include/dir_hip.h: dir_din_attention_pool_backward_f32 + the
+    per-sample term's two small GEMMs) -> dict:
+      ids_h [N] int64, gh [N, K]: the valid history positions' table rows and their gradients, (b, j) order;
+      ga [B, K]: the candidate rows' gradients;  gW1 [4K, H1], gb1, gW2, gb2, gW3 [H2], gb3 [1]."""
+    _dev(table, torch.float32, "table")
+    _dev(hist, torch.int64, "hist")
+    _dev(cand, torch.int64, "cand")
+    _dev(g, torch.float32, "g")
+    if hist_len is not None:
+        _dev(hist_len, torch.int32, "hist_len")
+    B, T = hist.shape
+    K = table.shape[1]
+    H1, H2 = W1.shape[1], W2.shape[1]
+    if tuple(W1.shape) != (4 * K, H1) or tuple(W2.shape) != (H1, H2) or W3.numel() != H2 or tuple(g.shape) != (B, K):
+        raise ValueError("DIN backward: W1 [4K,H1], W2 [H1,H2], W3 [H2], g [B,K]")
+    lib = _lib.load()
+    need = int(lib.dir_din_backward_workspace_bytes(K, H1, H2))
+    if need <= 0 or T > 64:
+        raise _lib.DirError(-4, "din_attention_pool_backward: the fused backward covers K = 64, H1 <= 80, H2 <= 48, T <= 64")
+    dev = table.device
+    args = [t.contiguous() for t in (W1, b1, W2, b2, W3, b3)]
+    for t in args:
+        _dev(t, torch.float32, "DIN weight")
+    hist, g = hist.contiguous(), g.contiguous()
+    valid = hist >= 0
+    if hist_len is not None:
+        valid &= torch.arange(T, device=dev).unsqueeze(0) < hist_len.clamp(0, T).unsqueeze(1)
+    cnt = valid.sum(dim=1)
+    incl = torch.cumsum(cnt, 0)
+    row_off = (incl - cnt).contiguous()
+    N = int(incl[-1]) if B else 0                                  # the one host read (sizes the row list)
+    ws = _DIN_BWD_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _DIN_BWD_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    gh, ga, S = torch.empty((N, K), **f32), torch.empty((B, K), **f32), torch.empty((B, H1), **f32)
+    gAP, gW2, gb2 = torch.empty((2 * K, H1), **f32), torch.empty((H1, H2), **f32), torch.empty(H2, **f32)
+    gW3, gb3 = torch.empty(H2, **f32), torch.empty(1, **f32)
+    _lib.check(lib.dir_din_attention_pool_backward_f32(
+        _ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]), H2,
+        _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B, _ptr(g), _ptr(row_off), _ptr(gh), _ptr(ga), _ptr(S), _ptr(gAP),
+        _ptr(gW2), _ptr(gb2), _ptr(gW3), _ptr(gb3), _ptr(ws), _stream()))
+    # the per-sample term a.(Wa - Wd) + b1: two [B, .] GEMMs (rocBLAS)
+    W1 = args[0]
+    C = W1[K:2 * K] - W1[2 * K:3 * K]
+    a = table[cand.clamp(min=0)] * (cand >= 0).unsqueeze(1)
+    ga.addmm_(S, C.t())
+    gC = a.t() @ S
+    gA, gWp = gAP[:K], gAP[K:]
+    return {"ids_h": hist[valid], "gh": gh, "ga": ga, "gW1": torch.cat([gA, gC, gA - gC, gWp], dim=0), "gb1": S.sum(dim=0),
+            "gW2": gW2, "gb2": gb2, "gW3": gW3, "gb3": gb3}
+
+
 def cin_layer(x0, xk, W, pooled=None, want_xout=True):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).

@@ -271,6 +271,34 @@ int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp, const floa
 int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,
                    int accumulate, float* dW, void* workspace, dir_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Backward of the DIN unit + pooling (A13; no reference code: the derivative of dir_din_attention_pool_f32's definition).
+ * One fused pass over the VALID (sample, position) rows: the unit is recomputed, then with g = dL/dout [B, K]
+ *   dw_j = g . h_j;   ds_j = dw_j  (normalize = 0)   or   w_j (dw_j - sum_i w_i dw_i) / sqrt(K)  (masked softmax)
+ *   dpre2 = ds W3 z2 (1 - z2);   dpre1 = (dpre2 W2^T) z1 (1 - z1)
+ * and, in the regrouped form of layer 1 ([h, a, h-a, h*a].W1 = h.(Wh+Wd) + (h*a).Wp + a.(Wa-Wd), W1 = [Wh; Wa; Wd; Wp]):
+ *   gAP [2K, H1]  = [h | h*a]^T dpre1      (rows [0,K): d(Wh+Wd); rows [K,2K): dWp)
+ *   gW2 [H1, H2]  = z1^T dpre2,   gb2 [H2] = sum dpre2,   gW3 [H2] = sum ds z2,   gb3 [1] = sum ds
+ *   gh  [N, K]    = dX_h + dX_p * a + w_j g      with dX = dpre1 [Wh+Wd | Wp]^T: the gradient of history row j, written to
+ *                   compact row  row_off[b] + (number of valid positions before j in sample b)
+ *   ga  [B, K]    = sum_j dX_p * h_j            the candidate row's gradient WITHOUT the per-sample term
+ *   S   [B, H1]   = sum_j dpre1                 the per-sample term's seed: the caller finishes
+ *                   ga += S (Wa-Wd)^T,  d(Wa-Wd) = a^T S,  db1 = sum_b S,
+ *                   dWh = gAP[:K],  dWa = d(Wa-Wd),  dWd = dWh - dWa,  dWp = gAP[K:]     (host mirror: ops.din_attention_pool_backward)
+ * A position is valid when j < min(hist_len[b], T) and hist[b, j] >= 0; row_off [B] int64 is the exclusive prefix sum of the
+ * per-sample valid counts (so gh has N = row_off[B-1] + count[B-1] rows, in (b, j) order; gh may be NULL when N = 0).
+ * Weight gradients are summed through one partial record per workgroup, added in a fixed order: bitwise reproducible.
+ * workspace: dir_din_backward_workspace_bytes(K, H1, H2) device bytes (0 = shape not covered).
+ * Limits: K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 64; DIR_E_UNSUPPORTED otherwise.
+ * ------------------------------------------------------------------------------------------ */
+int64_t dir_din_backward_workspace_bytes(int K, int H1, int H2);
+int dir_din_attention_pool_backward_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
+                                        const int64_t* cand, int T, const float* W1, const float* b1, int H1,
+                                        const float* W2, const float* b2, int H2, const float* W3, const float* b3,
+                                        int normalize, int64_t B, const float* gout, const int64_t* row_off, float* gh,
+                                        float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
+                                        void* workspace, dir_stream_t stream);
+
 /* Fused sparse Adagrad on the embedding tables (the reference's dnn_optimizer='Adagrad', deepFM.py:61):
  * for every distinct id of slot f in the batch: g = SUM of the gradient rows of its occurrences ([TF-upstream]
  * duplicate indices are summed before the update), accum[f][id] += g*g, tables[f][id] -= lr * g / sqrt(accum).

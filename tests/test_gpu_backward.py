@@ -349,13 +349,17 @@ def test_xdeepfm_training_step(built_lib):
 
 # ---- DIN backward (no reference code; derivatives of the unit defined in include/dir_hip.h A13) ---------------------
 @pytest.mark.parametrize("normalize", [False, True])
-@pytest.mark.parametrize("B,T,K,H1,H2,V", [(33, 50, 64, 80, 40, 500), (17, 7, 16, 12, 8, 40), (9, 20, 32, 36, 20, 64)])
+@pytest.mark.parametrize("B,T,K,H1,H2,V", [(33, 50, 64, 80, 40, 500), (17, 7, 16, 12, 8, 40), (9, 20, 32, 36, 20, 64),
+                                           # the fused backward's shape class: > one sample per workgroup, full-length T = 64 with
+                                           # narrower layers, a single position, H2 at its 48 limit
+                                           (600, 50, 64, 80, 40, 3000), (70, 64, 64, 72, 36, 200), (5, 1, 64, 8, 4, 30),
+                                           (21, 30, 64, 80, 48, 100)])
 def test_din_autograd_matches_float64(built_lib, normalize, B, T, K, H1, H2, V):
     from dir_amd import autograd as ag
     g = torch.Generator().manual_seed(B + T)
     table = torch.randn(V, K, generator=g) * 0.3
     hist = torch.randint(0, V, (B, T), generator=g)
-    hist[1, 2] = -1                                           # a pruned id inside the valid range
+    hist[1, min(2, T - 1)] = -1                                # a pruned id inside the valid range
     hl = torch.randint(0, T + 1, (B,), generator=g).int()
     hl[0] = 0                                                 # an empty history
     cand = torch.randint(0, V, (B,), generator=g)
@@ -617,3 +621,55 @@ def test_esmm_and_dcn_training_with_reference_losses(built_lib):
     _, unw = dcn.create_loss(feats, p["logits"], click)
     m = BinaryMetrics().update(click, p["logistic"], unw, feats["w"]).result()
     assert m["auc"] > 0.9 and m["accuracy"] > m["accuracy_baseline"] and 0.0 < m["average_loss"] < 0.7, m
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_din_fused_backward_matches_composite(built_lib, normalize, monkeypatch):
+    """The fused HIP backward against the GPU composite it replaces (same inputs, hist_len = None, pruned ids and a pruned
+    candidate), and bitwise run-to-run reproducibility of its weight gradients."""
+    from dir_amd import autograd as ag
+    B, T, K, H1, H2, V = 300, 40, 64, 80, 40, 1000
+    g = torch.Generator().manual_seed(5)
+    table = (torch.randn(V, K, generator=g) * 0.3).cuda()
+    hist = torch.randint(-1, V, (B, T), generator=g).cuda()
+    cand = torch.randint(0, V, (B,), generator=g).cuda()
+    Ws = [torch.randn(4 * K, H1, generator=g) * 0.2, torch.randn(H1, generator=g) * 0.1, torch.randn(H1, H2, generator=g) * 0.3,
+          torch.randn(H2, generator=g) * 0.1, torch.randn(H2, generator=g) * 0.4, torch.randn(1, generator=g) * 0.1]
+    gout = torch.randn(B, K, generator=g).cuda()
+
+    def run():
+        tab = table.clone().requires_grad_(True)
+        ws = [w.cuda().requires_grad_(True) for w in Ws]
+        ag.din_attention_pool(tab, hist, None, cand, *ws, normalize=normalize).backward(gout)
+        return [tab.grad.to_dense()] + [w.grad for w in ws]
+
+    fused = run()
+    again = run()
+    for a, b in zip(fused[1:], again[1:]):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(ag, "_DIN_COMPOSITE_BACKWARD", True)
+    comp = run()
+    for a, b in zip(fused, comp):
+        _close(a, b, tol=2e-5)
+
+
+def test_din_fused_backward_empty_and_limits(built_lib):
+    from dir_amd import ops
+    from dir_amd._lib import DirError
+    K, H1, H2, T, V = 64, 80, 40, 10, 50
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(V, K, generator=g).cuda()
+    Ws = [torch.randn(4 * K, H1, generator=g).cuda(), torch.zeros(H1).cuda(), torch.randn(H1, H2, generator=g).cuda(), torch.zeros(H2).cuda(),
+          torch.randn(H2, generator=g).cuda(), torch.zeros(1).cuda()]
+    hist = torch.randint(0, V, (4, T), generator=g).cuda()
+    r = ops.din_attention_pool_backward(table, hist, torch.zeros(4, dtype=torch.int32).cuda(), torch.zeros(4, dtype=torch.int64).cuda(),
+                                        *Ws, torch.randn(4, K, generator=g).cuda())
+    assert r["gh"].shape == (0, K) and r["ids_h"].numel() == 0
+    for k in ("ga", "gW1", "gb1", "gW2", "gb2", "gW3", "gb3"):
+        assert float(r[k].abs().max()) == 0.0, k
+    assert not ops.din_backward_supported(32, 10, 36, 20) and not ops.din_backward_supported(64, 65, 80, 40)
+    t32 = torch.randn(V, 32).cuda()
+    with pytest.raises(DirError):
+        ops.din_attention_pool_backward(t32, hist, None, torch.zeros(4, dtype=torch.int64).cuda(), torch.randn(128, 36).cuda(),
+                                        torch.zeros(36).cuda(), torch.randn(36, 20).cuda(), torch.zeros(20).cuda(),
+                                        torch.randn(20).cuda(), torch.zeros(1).cuda(), torch.randn(4, 32).cuda())
