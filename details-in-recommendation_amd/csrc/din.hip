@@ -581,9 +581,12 @@ struct DinBwdSh {
     float gv[K];               // d out of this sample
     float ds[64];              // d score
     float dw[64];              // g . h_j
-    float S[F::H1P];           // column sums of dpre1
+    float S[64];               // column sums of dpre1, H1 tiles 0-3
+    float S4[4 * 16];          // H1 tile 4: one partial per wave (row tile)
     float gaout[K];            // d a of this sample (leaves with the flush)
     int rank[64];              // compact output row of position j (-1: not a valid row)
+    float ap[2 * K * F::Z1S];  // [Wh+Wd | Wp] as [2K][H1P + 4]: B fragments of dX
+    float w2[F::H1P * Z2S];    // W2 as [H1P][H2P + 4]: B fragments of dz1
 };
 
 #ifdef DIN_STAMP   // tools/din_bwd_probe.hip only: [0] stage [1] dw + recompute [2] weights/ds [3] dpre2 [4] dW2/dz1 [5] dAP/dX [6] samples
@@ -673,19 +676,18 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
     }
     const float bias3 = b3[0];
     // ---- backward B fragments: W2^T for dz1 (own H1 tile; wave 3 also the 5th), [Wh+Wd | Wp]^T for dX (own feature tile) ----
-    float w2t[12], w2t4[12], aph[20], app[20];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int c2 = kk * 12 + i, c1 = 16 * w + r16, c1b = 64 + r16;
-        w2t[i] = (c1 < H1 && c2 < H2) ? W2[(size_t)c1 * H2 + c2] : 0.f;
-        w2t4[i] = (w == 3 && c1b < H1 && c2 < H2) ? W2[(size_t)c1b * H2 + c2] : 0.f;
+    // (LDS-resident, read as 16-byte B fragments per row tile: keeping them in registers as well put the kernel past 512)
+    for (int i = tid; i < 2 * K * S::H1P; i += NT) {
+        const int x = i / S::H1P, c1 = i - x * S::H1P;
+        float v = 0.f;
+        if (c1 < H1) v = x < K ? W1[(size_t)x * H1 + c1] + W1[(size_t)(2 * K + x) * H1 + c1] : W1[(size_t)(2 * K + x) * H1 + c1];
+        sb.ap[x * Z1S + c1] = v;                         // rows [K, 2K): Wp = W1[3K + f]
     }
-#pragma unroll
-    for (int i = 0; i < 20; ++i) {
-        const int c1 = kk * 20 + i, feat = 16 * w + r16;
-        aph[i] = c1 < H1 ? W1[(size_t)feat * H1 + c1] + W1[(size_t)(2 * K + feat) * H1 + c1] : 0.f;
-        app[i] = c1 < H1 ? W1[(size_t)(3 * K + feat) * H1 + c1] : 0.f;
+    for (int i = tid; i < S::H1P * S::H2P; i += NT) {
+        const int c1 = i / S::H2P, c2 = i - c1 * S::H2P;
+        sb.w2[c1 * Z2S + c2] = (c1 < H1 && c2 < H2) ? W2[(size_t)c1 * H2 + c2] : 0.f;
     }
+    // (the first sample's staging barrier orders these writes before their first readers)
     const int c2e = tid % 48, rge = tid / 48;             // step 3: thread <-> (H2 column, row group), tid < 192
     const float w3c = (tid < 192 && c2e < H2) ? W3[c2e] : 0.f;
 
@@ -699,9 +701,9 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
 
     // ---- software pipeline: ids two samples ahead, rows (and d out) one ahead ---------------------------------------
     const int64_t G = gridDim.x;
-    // three stages: the per-sample scalars (length, candidate id, output row) three samples ahead, the history ids two ahead
-    // (their predicate is a length that arrived an iteration ago), the rows one ahead: no load is consumed in the iteration
-    // that issues it
+    // Three load stages -- per-sample scalars (length, candidate id, output row) three samples ahead, history ids two ahead, rows
+    // one ahead -- ordered so that every consumer runs BEFORE the iteration issues anything new: the loads are conditional, so
+    // the compiler can only wait with vmcnt(0), and a younger load in flight would be waited for as well.
     auto load_scalars = [&](int64_t bb, int& len, int64_t& cid, int64_t& base) {
         len = 0;
         cid = -1;
@@ -721,26 +723,30 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
             if (q < len * KC) ids[k] = hist[bb * T + q / KC];      // len == 0 beyond the batch
         }
     };
-    auto load_rows = [&](int64_t bb, int len, int64_t cid, const int64_t (&ids)[NPF], float4 (&h)[NPF], float4& a) {
+    auto load_rows = [&](int64_t bb, int len, int64_t cid, const int64_t (&ids)[NPF], float4 (&h)[NPF], float4& a, int& vmask) {
+        vmask = 0;
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int q = tid + k * NT;
             h[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < len * KC && ids[k] >= 0) h[k] = *reinterpret_cast<const float4*>(table + ids[k] * K + 4 * (q % KC));
+            if (q < len * KC && ids[k] >= 0) {
+                h[k] = *reinterpret_cast<const float4*>(table + ids[k] * K + 4 * (q % KC));
+                vmask |= 1 << k;
+            }
         }
         a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < KC && cid >= 0) a = *reinterpret_cast<const float4*>(table + cid * K + 4 * tid);
         if (tid >= KC && tid < 2 * KC && bb < B) a = *reinterpret_cast<const float4*>(gout + bb * K + 4 * (tid - KC));
     };
-    int len0, len1, len2;
-    int64_t cid0, cid1, cid2, base0, base1, base2, id0[NPF], id1[NPF];
+    int lenC, lenN, lenNN, vmask;                         // C: the sample whose rows are in hreg; N: ids in idn; NN: the one after
+    int64_t cidC, cidN, cidNN, baseC, baseN, baseNN, idn[NPF];
     float4 hreg[NPF], areg4;
-    load_scalars(blockIdx.x, len0, cid0, base0);
-    load_scalars(blockIdx.x + G, len1, cid1, base1);
-    load_scalars(blockIdx.x + 2 * G, len2, cid2, base2);
-    load_ids(blockIdx.x, len0, id0);
-    load_ids(blockIdx.x + G, len1, id1);
-    load_rows(blockIdx.x, len0, cid0, id0, hreg, areg4);
+    load_scalars(blockIdx.x, lenC, cidC, baseC);
+    load_scalars(blockIdx.x + G, lenN, cidN, baseN);
+    load_scalars(blockIdx.x + 2 * G, lenNN, cidNN, baseNN);
+    load_ids(blockIdx.x, lenC, idn);
+    load_rows(blockIdx.x, lenC, cidC, idn, hreg, areg4, vmask);
+    load_ids(blockIdx.x + G, lenN, idn);
 
     // d h rows, d a and S of a sample leave one iteration later (flush): they wait in LDS (the rows in z1's place) and are
     // written after the NEXT sample's loads have been issued, so that no store sits between a load and its wait
@@ -757,7 +763,9 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
             if (frk[k] >= 0) fl[k] = *reinterpret_cast<const float4*>(ghbuf + j * Z1S + 4 * c);
         }
         fga = (b_prev >= 0 && tid < K) ? sb.gaout[tid] : 0.f;
-        fs = (b_prev >= 0 && tid < S::H1P) ? sb.S[tid] : 0.f;
+        fs = 0.f;
+        if (b_prev >= 0 && tid < S::H1P)
+            fs = tid < 64 ? sb.S[tid] : (sb.S4[tid - 64] + sb.S4[tid - 48]) + (sb.S4[tid - 32] + sb.S4[tid - 16]);
     };
     auto flush_write = [&](const float4 (&fl)[NPF], const int (&frk)[NPF], float fga, float fs) {
         if (b_prev < 0) return;
@@ -773,9 +781,9 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
 
     for (int64_t b = blockIdx.x; b < B; b += G) {
         DIN_T(t0);
-        const int len = len0;
+        const int len = lenC;
         const int RT = (len + 15) >> 4;
-        const int64_t base = base0;
+        const int64_t base = baseC;
         float4 fl[NPF];
         int frk[NPF];
         float fga, fs;
@@ -787,7 +795,7 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
             if (q < len * KC) {
                 const int j = q / KC, c = q - j * KC;
                 *reinterpret_cast<float4*>(sh.uh + j * HS + 4 * c) = hreg[k];
-                if (c == 0) sh.valid[j] = id0[k] >= 0 ? 1 : 0;
+                if (c == 0) sh.valid[j] = (vmask >> k) & 1;
             }
         }
         for (int q = len * KC + tid; q < RT * 16 * KC; q += NT) {
@@ -799,20 +807,18 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
         if (tid >= KC && tid < 2 * KC) *reinterpret_cast<float4*>(sb.gv + 4 * (tid - KC)) = areg4;
         __syncthreads();
         DIN_T(t0a);
-        len0 = len1; cid0 = cid1; base0 = base1;
-        len1 = len2; cid1 = cid2; base1 = base2;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) id0[k] = id1[k];
-        load_ids(b + 2 * G, len1, id1);
-        load_rows(b + G, len0, cid0, id0, hreg, areg4);
-        load_scalars(b + 3 * G, len2, cid2, base2);
+        lenC = lenN; cidC = cidN; baseC = baseN;          // arrived an iteration ago: nothing younger is in flight yet
+        lenN = lenNN; cidN = cidNN; baseN = baseNN;
+        load_rows(b + G, lenC, cidC, idn, hreg, areg4, vmask);
+        load_ids(b + 2 * G, lenN, idn);
+        load_scalars(b + 3 * G, lenNN, cidNN, baseNN);
         flush_write(fl, frk, fga, fs);
         b_prev = b;
         base_prev = base;
         len_prev = len;
         if (RT == 0) {   // block-uniform: nothing reaches the unit; the per-sample outputs are zero
             if (tid < K) sb.gaout[tid] = 0.f;
-            if (tid < S::H1P) sb.S[tid] = 0.f;
+            if (tid < 64) sb.S[tid] = sb.S4[tid] = 0.f;
             __syncthreads();
             continue;
         }
@@ -883,90 +889,89 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
         __syncthreads();
         DIN_T(t4);
         // ---- 4. dW2 += z1^T dpre2;  dz1 = dpre2 W2^T -> dpre1 ---------------------------------------------------------------
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int row = rt * 16 + 4 * s + kk;
-                const float a = sh.z1[row * Z1S + 16 * w + r16];
-                const float a4 = sh.z1[row * Z1S + 64 + r16];
-                const float b0 = sb.z2[row * Z2S + r16], b1v = sb.z2[row * Z2S + 16 + r16], b2v = sb.z2[row * Z2S + 32 + r16];
-                gW2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, gW2a[0], 0, 0, 0);
-                gW2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, gW2a[1], 0, 0, 0);
-                gW2a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2v, gW2a[2], 0, 0, 0);
-                const float bw = w == 0 ? b0 : (w == 1 ? b1v : b2v);
-                if (w < 3) gW2a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4, bw, gW2a[3], 0, 0, 0);   // H1 tile 4 x H2 tile w
-            }
-        }
-        DIN_T(t4a);
+        // (no branch inside the MFMA loops: a branch makes the compiler shuttle the live accumulators between AGPRs and VGPRs.)
+        // Row reductions: k-step s of lane group kk is row 4 kk + s (rows 4 apart sit 16 banks apart at all three strides).
+        const int c2w = 16 * (w < 3 ? w : 2) + r16;     // H1 tile 4 x H2 tile w; wave 3 repeats wave 2's (its copy is dropped)
         {
-            float colsum = 0.f, colsum4 = 0.f;
-            for (int rt = 0; rt < RT; ++rt) {
-                f32x4m acc = (f32x4m){0.f, 0.f, 0.f, 0.f}, acc4 = (f32x4m){0.f, 0.f, 0.f, 0.f};
+            // dz1 of one (row tile, H1 tile): 12 k-steps over H2, then dpre1 = dz1 z1 (1 - z1) -> dp1, returns the column sum
+            auto dz1_tile = [&](int rt, int col) -> float {
+                f32x4m acc = (f32x4m){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const float4 d4 = *reinterpret_cast<const float4*>(sb.z2 + (rt * 16 + r16) * Z2S + kk * 12 + 4 * q);
-                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const float4 w4 = *reinterpret_cast<const float4*>(sb.w2 + col * Z2S + kk * 12 + 4 * q);
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, wt[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], w2t[4 * q + e], acc, 0, 0, 0);
-                        if (w == 3) acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], w2t4[4 * q + e], acc4, 0, 0, 0);
-                    }
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], wt[e], acc, 0, 0, 0);
                 }
+                float cs = 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = rt * 16 + 4 * kk + g;
-                    const float z = sh.z1[row * Z1S + 16 * w + r16];
+                    const float z = sh.z1[row * Z1S + col];
                     const float d1 = acc[g] * z * (1.0f - z);
-                    sb.dp1[row * Z1S + 16 * w + r16] = d1;
-                    colsum += d1;
-                    if (w == 3) {
-                        const float z4 = sh.z1[row * Z1S + 64 + r16];
-                        const float d14 = acc4[g] * z4 * (1.0f - z4);
-                        sb.dp1[row * Z1S + 64 + r16] = d14;
-                        colsum4 += d14;
-                    }
+                    sb.dp1[row * Z1S + col] = d1;
+                    cs += d1;
                 }
+                return cs;
+            };
+            float colsum = 0.f;
+            for (int rt = 0; rt < RT; ++rt) {   // one block per row tile: the scheduler overlaps one product's LDS reads with the other's MFMAs
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int row = rt * 16 + 4 * kk + s;
+                    const float a = sh.z1[row * Z1S + 16 * w + r16];
+                    const float a4 = sh.z1[row * Z1S + 64 + r16];
+                    const float b0 = sb.z2[row * Z2S + r16], b1v = sb.z2[row * Z2S + 16 + r16], b2v = sb.z2[row * Z2S + 32 + r16];
+                    const float bw = sb.z2[row * Z2S + c2w];
+                    gW2a[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, gW2a[0], 0, 0, 0);
+                    gW2a[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1v, gW2a[1], 0, 0, 0);
+                    gW2a[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2v, gW2a[2], 0, 0, 0);
+                    gW2a[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4, bw, gW2a[3], 0, 0, 0);
+                }
+                colsum += dz1_tile(rt, 16 * w + r16);
             }
             colsum += __shfl_xor(colsum, 16, 64);
             colsum += __shfl_xor(colsum, 32, 64);
             if (kk == 0) sb.S[16 * w + r16] = colsum;
-            if (w == 3) {
-                colsum4 += __shfl_xor(colsum4, 16, 64);
-                colsum4 += __shfl_xor(colsum4, 32, 64);
-                if (kk == 0) sb.S[64 + r16] = colsum4;
-            }
+            // the 5th H1 tile: wave w takes row tile w (outside the loop; S4[w] = its column sums, zero when it has none)
+            float colsum4 = 0.f;
+            if (w < RT) colsum4 = dz1_tile(w, 64 + r16);
+            colsum4 += __shfl_xor(colsum4, 16, 64);
+            colsum4 += __shfl_xor(colsum4, 32, 64);
+            if (kk == 0) sb.S4[w * 16 + r16] = colsum4;
         }
         __syncthreads();
         DIN_T(t5);
         // ---- 5. d[Wh+Wd | Wp] += [h | h*a]^T dpre1;  dX = dpre1 [Wh+Wd | Wp]^T -> d h rows, d a ----------------------------
         const float a_f = sh.av[16 * w + r16], g_f = sb.gv[16 * w + r16];
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int row = rt * 16 + 4 * s + kk;
-                const float hrow = sh.uh[row * HS + 16 * w + r16];
-                const float hp = hrow * a_f;
-#pragma unroll
-                for (int ni = 0; ni < 5; ++ni) {
-                    const float bv = sb.dp1[row * Z1S + 16 * ni + r16];
-                    gAPh[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(hrow, bv, gAPh[ni], 0, 0, 0);
-                    gAPp[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(hp, bv, gAPp[ni], 0, 0, 0);
-                }
-            }
-        }
-        DIN_T(t5a);
         {
             float ga_acc = 0.f;
             for (int rt = 0; rt < RT; ++rt) {
+                float hv4[4];                       // h[rows 4 kk .. 4 kk + 3][own feature]: A operand here, and the epilogue's h values
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int row = rt * 16 + 4 * kk + s;
+                    hv4[s] = sh.uh[row * HS + 16 * w + r16];
+                    const float hp = hv4[s] * a_f;
+#pragma unroll
+                    for (int ni = 0; ni < 5; ++ni) {
+                        const float bv = sb.dp1[row * Z1S + 16 * ni + r16];
+                        gAPh[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv4[s], bv, gAPh[ni], 0, 0, 0);
+                        gAPp[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(hp, bv, gAPp[ni], 0, 0, 0);
+                    }
+                }
                 f32x4m acch = (f32x4m){0.f, 0.f, 0.f, 0.f}, accp = (f32x4m){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     const float4 d4 = *reinterpret_cast<const float4*>(sb.dp1 + (rt * 16 + r16) * Z1S + kk * 20 + 4 * q);
-                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const float4 h4 = *reinterpret_cast<const float4*>(sb.ap + (16 * w + r16) * Z1S + kk * 20 + 4 * q);
+                    const float4 p4 = *reinterpret_cast<const float4*>(sb.ap + (K + 16 * w + r16) * Z1S + kk * 20 + 4 * q);
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, aph[4] = {h4.x, h4.y, h4.z, h4.w}, app[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        acch = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], aph[4 * q + e], acch, 0, 0, 0);
-                        accp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], app[4 * q + e], accp, 0, 0, 0);
+                        acch = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], aph[e], acch, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[e], app[e], accp, 0, 0, 0);
                     }
                 }
                 const float4 sc4 = *reinterpret_cast<const float4*>(sh.sc + rt * 16 + 4 * kk);
@@ -974,8 +979,7 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int row = rt * 16 + 4 * kk + g;
-                    const float hval = sh.uh[row * HS + 16 * w + r16];
-                    ga_acc = fmaf(accp[g], hval, ga_acc);
+                    ga_acc = fmaf(accp[g], hv4[g], ga_acc);
                     ghbuf[row * Z1S + 16 * w + r16] = fmaf(accp[g], a_f, acch[g]) + scv[g] * g_f;
                 }
             }
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void din_bwd_k(const float* __restrict__ ta
         }
         __syncthreads();   // the next sample's staging overwrites uh / av / gv; its flush reads ghbuf / gaout / S
         DIN_T(t6);
-        DINB_ACC(0, t0, t0a); DINB_ACC(7, t0a, t1); DINB_ACC(1, t1, t2); DINB_ACC(2, t2, t3); DINB_ACC(3, t3, t4); DINB_ACC(4, t4, t5); DINB_ACC(5, t5, t6); DINB_ACC(8, t4, t4a); DINB_ACC(9, t5, t5a);
+        DINB_ACC(0, t0, t0a); DINB_ACC(7, t0a, t1); DINB_ACC(1, t1, t2); DINB_ACC(2, t2, t3); DINB_ACC(3, t3, t4); DINB_ACC(4, t4, t5); DINB_ACC(5, t5, t6);
         DINB_ACC(6, 0ull, 1ull);
     }
 
@@ -1076,7 +1080,7 @@ __global__ __launch_bounds__(256) void din_bwd_finish_k(const float* __restrict_
     }
 }
 
-constexpr int kDinBwdMaxWg = kCUs;   // one workgroup per CU (93 KB of LDS)
+constexpr int kDinBwdMaxWg = kCUs;   // one workgroup per CU (153 KB of LDS)
 
 }  // namespace dir
 
