@@ -422,39 +422,49 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
     }
     const float bias3 = b3[0];
 
-    // ---- software pipeline over this workgroup's samples: ids two samples ahead, rows one ahead ----------
+    // ---- software pipeline over this workgroup's samples: per-sample scalars (length, candidate id) three samples ahead,
+    // history ids two ahead, rows one ahead.  The loads are conditional, so the compiler can only wait for one with vmcnt(0):
+    // every consumer therefore runs BEFORE the iteration issues anything new (a younger load in flight would be waited for too).
     const int64_t G = gridDim.x;
-    auto load_meta = [&](int64_t bb, int& len, int64_t& cid, int64_t (&ids)[NPF]) {
+    auto load_scalars = [&](int64_t bb, int& len, int64_t& cid) {
         len = 0;
         cid = -1;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) ids[k] = -1;
         if (bb < B) {
             len = hist_len ? min((int)hist_len[bb], T) : T;
             cid = cand[bb];
-#pragma unroll
-            for (int k = 0; k < NPF; ++k) {
-                const int q = tid + k * NT;
-                if (q < len * KC) ids[k] = hist[bb * T + q / KC];
-            }
         }
     };
-    auto load_rows = [&](int len, int64_t cid, const int64_t (&ids)[NPF], float4 (&h)[NPF], float4& a) {
+    auto load_ids = [&](int64_t bb, int len, int64_t (&ids)[NPF]) {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int q = tid + k * NT;
+            ids[k] = -1;
+            if (q < len * KC) ids[k] = hist[bb * T + q / KC];      // len == 0 beyond the batch
+        }
+    };
+    auto load_rows = [&](int len, int64_t cid, const int64_t (&ids)[NPF], float4 (&h)[NPF], float4& a, int& vmask) {
+        vmask = 0;
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int q = tid + k * NT;
             h[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < len * KC && ids[k] >= 0) h[k] = *reinterpret_cast<const float4*>(table + ids[k] * K + 4 * (q % KC));
+            if (q < len * KC && ids[k] >= 0) {
+                h[k] = *reinterpret_cast<const float4*>(table + ids[k] * K + 4 * (q % KC));
+                vmask |= 1 << k;
+            }
         }
         a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < KC && cid >= 0) a = *reinterpret_cast<const float4*>(table + cid * K + 4 * tid);
     };
-    int len0, len1;
-    int64_t cid0, cid1, id0[NPF], id1[NPF];
+    int len0, len1, len2, vmask;                 // 0: the sample whose rows are in hreg; 1: ids in idn; 2: the one after
+    int64_t cid0, cid1, cid2, idn[NPF];
     float4 hreg[NPF], areg4;
-    load_meta(blockIdx.x, len0, cid0, id0);
-    load_rows(len0, cid0, id0, hreg, areg4);
-    load_meta(blockIdx.x + G, len1, cid1, id1);
+    load_scalars(blockIdx.x, len0, cid0);
+    load_scalars(blockIdx.x + G, len1, cid1);
+    load_scalars(blockIdx.x + 2 * G, len2, cid2);
+    load_ids(blockIdx.x, len0, idn);
+    load_rows(len0, cid0, idn, hreg, areg4, vmask);
+    load_ids(blockIdx.x + G, len1, idn);
 
     DIN_T(st_begin);
     for (int64_t b = blockIdx.x; b < B; b += G) {
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
             if (q < len * KC) {
                 const int j = q / KC, c = q - j * KC;
                 *reinterpret_cast<float4*>(sh.uh + j * S::HS + 4 * c) = hreg[k];
-                if (c == 0) sh.valid[j] = id0[k] >= 0 ? 1 : 0;
+                if (c == 0) sh.valid[j] = (vmask >> k) & 1;
             }
         }
         for (int j = len + tid; j < 64; j += NT) sh.valid[j] = 0;
@@ -476,12 +486,11 @@ __global__ __launch_bounds__(256, 2) void din_mfma_k(const float* __restrict__ t
         __syncthreads();
         DIN_T(st1);
         // ---- issue the next sample's row reads and the ids of the one after; both land during the MFMAs -------
-        len0 = len1;
-        cid0 = cid1;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) id0[k] = id1[k];
-        load_rows(len0, cid0, id0, hreg, areg4);
-        load_meta(b + 2 * G, len1, cid1, id1);
+        len0 = len1; cid0 = cid1;
+        len1 = len2; cid1 = cid2;
+        load_rows(len0, cid0, idn, hreg, areg4, vmask);
+        load_ids(b + 2 * G, len1, idn);
+        load_scalars(b + 3 * G, len2, cid2);
         // ---- hidden layers + fused layer 3, branch-free per row-tile count -----------------------------------
         switch (RT) {   // block-uniform
             case 1: din_mlp_tiles<K, NC1, NC2, 1>(sh, fr, bias1, bias1_s, bias2, w3v, w, r16, kk); break;

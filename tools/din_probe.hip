@@ -1,7 +1,9 @@
 // din_probe.hip -- cycles per phase of din_mfma_k (development tool, not product).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude tools/din_probe.hip \
-//        details-in-recommendation_amd/csrc/capi.cpp -o tools/din_probe
+//        details-in-recommendation_amd/csrc/capi.cpp -o tools/din_probe      (add -DDIN_PLAIN -o tools/din_probe_plain for the unstamped kernel)
+#ifndef DIN_PLAIN
 #define DIN_STAMP 1
+#endif
 #include "../details-in-recommendation_amd/csrc/din.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +37,9 @@ int main() {
     CK(hipMemcpy(len, hl.data(), B * 4, hipMemcpyHostToDevice));
     for (int it = 0; it < 3; ++it) {
         unsigned long long z[8] = {0};
+#ifdef DIN_STAMP
         CK(hipMemcpyToSymbol(HIP_SYMBOL(dir::din_stamp), z, sizeof(z)));
+#endif
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0, 0));
         if (dir_din_attention_pool_f32(table, K, hist, len, cand, T, w1, b1, H1, w2, b2, H2, w3, b3, 1, B, out, nullptr, nullptr) != 0) {
@@ -43,7 +47,11 @@ int main() {
         }
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+#ifdef DIN_STAMP
         CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(dir::din_stamp), sizeof(z)));
+#else
+        z[4] = 1;
+#endif
         const double n = (double)z[4];
         printf("launch %.3f ms, %llu workgroups | cycles per sample (stamped build: s_memtime serialises, shares matter): stage %.0f  mlp %.0f  softmax %.0f  pool+out %.0f\n",
                ms, z[5], z[0] / n, z[1] / n, z[2] / n, z[3] / n);
