@@ -138,3 +138,68 @@ def test_fuzz_cin_forward_backward(ops, oracle, seed):
         fx0, fxk, _ = ops.cin_layer_backward(_dev(x0), _dev(xk), _dev(W), _dev(G), need_w=False, force_forward_form=True)
         close(fxk, ref_dxk)
         close(fx0, ref_dx0)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DIR_FUZZ_SEEDS", "16"))))
+def test_fuzz_din_forward_backward(ops, oracle, seed):
+    """Random (B, T, K, H1, H2, lengths, pruned ids, normalize) through dir_din_attention_pool_f32 against the double-accumulating
+    oracle, and through the training path (the fused dir_din_attention_pool_backward_f32 for K = 64, the GPU composite for the
+    other widths) against float64 autograd of the dense definition."""
+    from dir_amd import autograd as ag
+    rng = np.random.default_rng(7000 + seed)
+    K = 64 if seed % 4 else int(rng.choice([16, 32]))
+    T = int(rng.integers(1, 65))
+    H1 = 4 * int(rng.integers(1, 21)) if K == 64 else int(rng.choice([8, 12, 16]))
+    H2 = 4 * int(rng.integers(1, 13)) if K == 64 else int(rng.choice([4, 8]))
+    B = int(rng.choice([1, 2, 7, 33, 257, 400]))
+    V = int(rng.choice([5, 50, 3000]))
+    normalize = bool(seed % 2)
+    table = (rng.standard_normal((V, K)) * 0.3).astype(np.float32)
+    hist = rng.integers(0, V, size=(B, T)).astype(np.int64)
+    hist[rng.random((B, T)) < 0.1] = -1
+    use_len = seed % 3 != 0
+    hl = rng.integers(0, T + 1, size=B).astype(np.int32) if use_len else np.full(B, T, np.int32)
+    cand = rng.integers(0, V, size=B).astype(np.int64)
+    Ws = [(rng.standard_normal((4 * K, H1)) * 0.2).astype(np.float32), (rng.standard_normal(H1) * 0.1).astype(np.float32),
+          (rng.standard_normal((H1, H2)) * 0.3).astype(np.float32), (rng.standard_normal(H2) * 0.1).astype(np.float32),
+          (rng.standard_normal(H2) * 0.4).astype(np.float32), (rng.standard_normal(1) * 0.1).astype(np.float32)]
+    gout = rng.standard_normal((B, K)).astype(np.float32)
+    tag = "(B %d T %d K %d H1 %d H2 %d norm %d len %d)" % (B, T, K, H1, H2, normalize, use_len)
+
+    def close(got, ref, tol):
+        got, ref = got.detach().cpu().double().numpy(), np.asarray(ref, np.float64)
+        err = np.abs(got - ref) / (1 + np.abs(ref))
+        assert err.max() <= tol, "max scaled err %.3e %s" % (err.max(), tag)
+
+    ref_out, ref_sc = oracle.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, acc64=True)
+    out, sc = ops.din_attention_pool(_dev(table), _dev(hist), _dev(hl) if use_len else None, _dev(cand), *[_dev(w) for w in Ws],
+                                     normalize=normalize, want_scores=True)
+    close(out, ref_out, 2e-5)
+    close(sc, ref_sc, 2e-5)
+
+    t64 = torch.from_numpy(table).double().requires_grad_(True)
+    w64 = [torch.from_numpy(w).double().requires_grad_(True) for w in Ws]
+    hT, cT = torch.from_numpy(hist), torch.from_numpy(cand)
+    h = t64[hT.clamp(min=0)]
+    a = t64[cT].unsqueeze(1).expand(B, T, K)
+    u = torch.cat([h, a, h - a, h * a], dim=2)
+    s = torch.sigmoid(torch.sigmoid(u @ w64[0] + w64[1]) @ w64[2] + w64[3]) @ w64[4] + w64[5]
+    valid = (torch.arange(T).unsqueeze(0) < torch.from_numpy(hl).unsqueeze(1)) & (hT >= 0)
+    if normalize:
+        wgt = torch.softmax((s / K ** 0.5).masked_fill(~valid, float("-inf")), dim=1)
+        wgt = torch.where(valid, wgt, torch.zeros_like(wgt))
+    else:
+        wgt = torch.where(valid, s, torch.zeros_like(s))
+    (wgt.unsqueeze(2) * h).sum(1).backward(torch.from_numpy(gout).double())
+
+    tab = _dev(table).requires_grad_(True)
+    ws = [_dev(w).requires_grad_(True) for w in Ws]
+    ag.din_attention_pool(tab, _dev(hist), _dev(hl) if use_len else None, _dev(cand), *ws, normalize=normalize).backward(_dev(gout))
+    def close_sum(got, ref, tol):      # gradients are sums over up to B*T rows: the error scales with the tensor's magnitude
+        got, ref = got.detach().cpu().double().numpy(), ref.numpy()
+        assert np.abs(got - ref).max() <= tol * (1 + np.abs(ref).max()), "max err %.3e vs max |ref| %.3e %s" % (
+            np.abs(got - ref).max(), np.abs(ref).max(), tag)
+
+    close_sum(tab.grad.to_dense(), t64.grad, 2e-5)
+    for w, r in zip(ws, w64):
+        close_sum(w.grad, r.grad, 2e-5)
