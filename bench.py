@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "dcn_cross_backward", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
-                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed"])
+                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -513,6 +513,26 @@ def main():
                 "note": "frac prices SURVEY 8d's figure (all T positions, 4K-wide layer 1); the kernel skips masked positions and "
                         "regroups layer 1 to a 2K reduction, so executed_frac is the MFMA pipe's share of peak"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
+    elif wl == "mlp_dense":
+        # the three hidden layers of DeepFM's DNN tower (416 -> 400 -> 400 -> 400, ReLU): dir_dense_f32, or torch (rocBLAS GEMM +
+        # ReLU pass) with DIR_BENCH_DENSE=torch
+        dims = [F * K, 400, 400, 400]
+        x = torch.randn((B, dims[0]), generator=gen, device=device) * 0.25
+        Wl = [torch.randn((dims[i + 1], dims[i]), generator=gen, device=device) / dims[i] ** 0.5 for i in range(3)]
+        bl = [torch.randn((dims[i + 1],), generator=gen, device=device) * 0.1 for i in range(3)]
+        ys = [torch.empty((B, dims[i + 1]), dtype=torch.float32, device=device) for i in range(3)]
+        use_torch = os.environ.get("DIR_BENCH_DENSE") == "torch"
+        if not use_torch:
+            from dir_amd.dense import pack_weight
+            Wl = [pack_weight(w) for w in Wl]      # row stride a multiple of 64 floats (dense.py)
+
+        def step(i):
+            h = x
+            for l in range(3):
+                h = torch.relu(torch.addmm(bl[l], h, Wl[l].t())) if use_torch else ops.dense(h, Wl[l], bl[l], relu=True, out=ys[l])
+        flops = sum(2 * B * dims[i] * dims[i + 1] for i in range(3))
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "rocBLAS GEMM + relu x3" if use_torch else "dense_k<80, relu> x3"}
+        cfg.update({"layers": dims})
     elif wl == "din_train":
         # forward (fused kernel) + backward (autograd.DinAttentionPool: fused HIP backward, sparse table gradient) of the DIN unit
         from dir_amd import autograd as ag

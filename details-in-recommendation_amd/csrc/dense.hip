@@ -1,0 +1,240 @@
+// dense.hip -- Y = act(X . Wt^T + bias) on fp32 MFMA for gfx950: the hidden layers of the reference's DNN towers.
+//
+// Reference: dnn_logit_fn, models/DeepFM/deepFM.py:295-300 (tf.layers.dense(units, activation)), _deep_architecture,
+// models/DeepCrossNetwork/DeepCrossNetwork.py:394-399, _base_model, models/ESMM/ESMM.py:139-142.  [TF-upstream] dense =
+// matmul + bias add + activation; fp32 throughout.  Wt is the [N, Kd] transpose of the TF kernel (torch's nn.Linear.weight).
+//
+// M = batch rows (65 536), Kd and N a few hundred: too skinny for the library's tiles (rocBLAS picks 32x256 macro tiles and
+// reaches 0.56 of the fp32 MFMA peak at 65 536 x 416 x 400, with the activation as a second pass over Y).  Here a 256-thread
+// workgroup owns a 128 x NT tile of Y (NT = 80 divides the 400-wide layers exactly; 128 otherwise); wave w owns rows
+// [32w, 32w+32) x all NT columns as 2 x NT/16 accumulators of v_mfma_f32_16x16x4_f32.  X and Wt stream through LDS in 32-wide
+// k chunks, double-buffered (the next chunk's global loads are issued before the current chunk's MFMAs, stored after them: one
+// barrier per chunk).  Both operands are k-contiguous in LDS (row stride 36 words: the sixteen rows of a 16-byte fragment read
+// land in sixteen different bank quads), so a lane's four k-steps come from ONE ds_read_b128: 14 LDS reads per 80 MFMAs at
+// NT = 80.  Bias and ReLU are applied to the accumulators.  Workgroup ids are remapped so that the N-blocks of one row block run
+// on the same XCD (they share the X tile through that XCD's L2).
+#include "common.hpp"
+
+namespace dir {
+
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load: resource base + lane byte offset (VGPR) + wave-uniform byte offset (SGPR); lanes past the resource's size
+// read zeros
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t wave_off) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)wave_off, 0);
+    const f32x4d v = __builtin_bit_cast(f32x4d, raw);   // (assigning the builtin's result to an int vector type splats .x)
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+constexpr int DN_KC = 32;           // k chunk
+constexpr int DN_LS = DN_KC + 4;    // LDS row stride (floats)
+constexpr int DN_MT = 128;          // rows per workgroup
+
+template <int NT, bool RELU>
+__global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, int64_t x_ld, const float* __restrict__ Wt,
+                                                    int64_t w_ld, const float* __restrict__ bias, int64_t M, int Kd, int N,
+                                                    float* __restrict__ Y, int64_t y_ld, int nb, int remap, int vec_out) {
+    constexpr int NTILES = NT / 16;
+    constexpr int BJ = (NT * 8 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float dense_smem[];
+    float (*As)[DN_MT * DN_LS] = reinterpret_cast<float (*)[DN_MT * DN_LS]>(dense_smem);
+    float (*Bs)[NT * DN_LS] = reinterpret_cast<float (*)[NT * DN_LS]>(dense_smem + 2 * DN_MT * DN_LS);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
+
+    int id = blockIdx.x;
+    if (remap) id = (id % kXCDs) * ((int)gridDim.x / kXCDs) + id / kXCDs;      // round-robin XCD dispatch -> contiguous ids per XCD
+    const int nblk = id % nb;
+    const int64_t m0 = (int64_t)(id / nb) * DN_MT;
+    const int n0 = nblk * NT;
+
+    // Staging: thread <-> (row, 16-byte column c) of the k chunk.  Rows beyond M / N are clamped to the last valid row (their
+    // results are dropped by the epilogue), so the full chunks need no predicate; only a k tail (Kd % 32) is masked.
+    // Staging: thread <-> (row, 16-byte column c) of the k chunk, as buffer loads: address = resource base + per-lane byte offset
+    // (fixed for the whole kernel) + wave-uniform k offset in an SGPR -- no address arithmetic on the VALU, which fp32 MFMAs do
+    // not hide -- and rows beyond M / N read as zeros through the resource's range check.  Only a k tail (Kd % 32) is masked.
+    const int64_t rows_x = (M - m0) < DN_MT ? (M - m0) : DN_MT;
+    const int rows_w = (N - n0) < NT ? (N - n0) : NT;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + m0 * x_ld), 0,
+                                                                        (int)(uint32_t)(((rows_x - 1) * x_ld + Kd) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt + (int64_t)n0 * w_ld), 0,
+                                                                        (int)(uint32_t)((((int64_t)rows_w - 1) * w_ld + Kd) * 4), 0x00020000);
+    uint32_t xo[4], wo[BJ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+        xo[j] = (uint32_t)((row * x_ld + 4 * c) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+        wo[j] = row < NT ? (uint32_t)((row * w_ld + 4 * c) * 4) : 0xfffffff0u;
+    }
+    const int nfull = Kd / DN_KC;
+    const int nchunks = (Kd + DN_KC - 1) / DN_KC;
+    float4 ar[4], br[BJ];
+    auto gload_full = [&](int ch) {
+        const uint32_t kb = (uint32_t)(ch * DN_KC * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ar[j] = buf_load4(rx, xo[j], kb);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) br[j] = buf_load4(rw, wo[j], kb);
+    };
+    auto gload_masked = [&](int ch) {                      // any chunk; lanes past Kd get an out-of-range offset (-> zeros)
+        const uint32_t kb = (uint32_t)(ch * DN_KC * 4);
+        const uint32_t big = (ch * DN_KC + 4 * (tid & 7) < Kd) ? 0u : 0xfffffff0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ar[j] = buf_load4(rx, xo[j] | big, kb);
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) br[j] = buf_load4(rw, wo[j] | big, kb);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+            *reinterpret_cast<float4*>(&As[buf][row * DN_LS + 4 * c]) = ar[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+            if (row < NT) *reinterpret_cast<float4*>(&Bs[buf][row * DN_LS + 4 * c]) = br[j];
+        }
+    };
+
+    f32x4d acc[2][NTILES];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTILES; ++nt) acc[mt][nt] = (f32x4d){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const float* ab = &As[buf][(32 * w + r16) * DN_LS + kk * 8];
+        const float* bb = &Bs[buf][r16 * DN_LS + kk * 8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 a0 = *reinterpret_cast<const float4*>(ab + 4 * q);
+            const float4 a1 = *reinterpret_cast<const float4*>(ab + 16 * DN_LS + 4 * q);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int nt = 0; nt < NTILES; ++nt) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bb + nt * 16 * DN_LS + 4 * q);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[e], bv[e], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[e], bv[e], acc[1][nt], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    gload_masked(0);
+    lstore(0);
+    __syncthreads();
+    int ch = 0;
+    for (; ch + 1 < nfull; ++ch) {          // the steady state: the next chunk is a full one (no predicate anywhere in the loop)
+        gload_full(ch + 1);
+        compute(ch & 1);
+        lstore((ch + 1) & 1);
+        __syncthreads();
+    }
+    for (; ch < nchunks; ++ch) {            // at most two iterations: the last full chunk (prefetching a k tail) and the tail
+        if (ch + 1 < nchunks) gload_masked(ch + 1);
+        compute(ch & 1);
+        if (ch + 1 < nchunks) lstore((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias + activation on the accumulators (lane: rows 4 kk + g of its row tile, column r16 of its column tile).
+    // vec_out: the wave's 32 x NT block goes through LDS (the operand buffers are dead after the loop's last barrier) and leaves
+    // as whole rows, 16 bytes per lane -- 4-byte stores in 64-byte pieces made the Y write the largest fixed cost of a tile.
+    if (vec_out) {
+        constexpr int EPS = NT + 4;
+        float* ep = dense_smem + w * (32 * EPS);
+#pragma unroll
+        for (int nt = 0; nt < NTILES; ++nt) {
+            const int col = n0 + 16 * nt + r16;
+            const float bcol = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v = acc[mt][nt][g] + bcol;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    ep[(16 * mt + 4 * kk + g) * EPS + 16 * nt + r16] = v;
+                }
+        }
+        constexpr int C4 = NT / 4;
+#pragma unroll
+        for (int i = 0; i < (32 * C4) / 64; ++i) {
+            const int idx = lane + 64 * i, row = idx / C4, c4 = idx - row * C4;
+            const float4 v = *reinterpret_cast<const float4*>(ep + row * EPS + 4 * c4);
+            const int64_t grow = m0 + 32 * w + row;
+            const int col = n0 + 4 * c4;
+            if (grow < M && col < N) *reinterpret_cast<float4*>(Y + grow * y_ld + col) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTILES; ++nt) {
+        const int col = n0 + 16 * nt + r16;
+        const float bcol = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t row = m0 + 32 * w + 16 * mt + 4 * kk + g;
+                float v = acc[mt][nt][g] + bcol;
+                if (RELU) v = fmaxf(v, 0.f);
+                if (row < M && col < N) Y[row * y_ld + col] = v;
+            }
+    }
+}
+
+template <int NT>
+static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M,
+                         int Kd, int N, float* Y, int64_t y_ld) {
+    const int nb = (N + NT - 1) / NT;
+    const int64_t mb = (M + DN_MT - 1) / DN_MT;
+    const int64_t total = mb * nb;
+    const int remap = (total % kXCDs) == 0 ? 1 : 0;
+    const int vec_out = ((N & 3) == 0 && (y_ld & 3) == 0 && aligned16(Y)) ? 1 : 0;
+    const size_t shmem = sizeof(float) * 2 * (DN_MT + NT) * DN_LS;      // 60 KB (NT = 80) / 74 KB (NT = 128): two workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr_set = true;
+    }
+    if (act)
+        hipLaunchKernelGGL((dense_k<NT, true>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out);
+    else
+        hipLaunchKernelGGL((dense_k<NT, false>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out);
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd, int N,
+                             float* Y, int64_t y_ld, dir_stream_t stream) {
+    const char* name = "dir_dense_f32";
+    DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && w_ld >= Kd && y_ld >= N, "%s: M=%lld Kd=%d N=%d x_ld=%lld w_ld=%lld y_ld=%lld", name,
+                  (long long)M, Kd, N, (long long)x_ld, (long long)w_ld, (long long)y_ld);
+    DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
+    if (M == 0) return DIR_OK;
+    DIR_CHECK_ARG(X && Wt && Y, "%s: null pointer", name);
+    if ((Kd & 3) || (x_ld & 3) || (w_ld & 3) || !aligned16(X) || !aligned16(Wt))
+        return fail(DIR_E_UNSUPPORTED, "%s: Kd and x_ld must be multiples of 4 and X / Wt 16-byte aligned (Kd=%d x_ld=%lld)", name, Kd,
+                    (long long)x_ld);
+    const int64_t mb = (M + DN_MT - 1) / DN_MT;
+    if (mb * ((N + 79) / 80) > 0x7fffffffLL) return fail(DIR_E_UNSUPPORTED, "%s: M=%lld too large", name, (long long)M);
+    hipStream_t st = as_stream(stream);
+    if (N % 80 == 0 && N % 128 != 0)
+        launch_dense<80>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld);
+    else
+        launch_dense<128>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}

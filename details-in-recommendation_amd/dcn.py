@@ -14,6 +14,7 @@ import math
 import torch
 from torch import nn
 
+from .dense import dense_act
 from . import autograd as ag
 from . import ops
 from .deepfm import _BatchNormInfer, _dropout_train, _glorot_uniform_
@@ -72,7 +73,7 @@ class DeepCrossNetwork(nn.Module):
         n = len(self.hidden)
         bi = 0
         for i, lin in enumerate(self.hidden):                                    # :392-403
-            net = self.activation(lin(net))
+            net = dense_act(lin, net, self.activation)                           # dir_dense_f32 when covered
             if self.batch_norm and i < n - 1:
                 net = self.bns[bi](net)
                 bi += 1

@@ -16,6 +16,7 @@ import math
 import torch
 from torch import nn
 
+from .dense import dense_act
 from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of
@@ -144,7 +145,7 @@ class DeepFM(nn.Module):
     # ---- logit builders ---------------------------------------------------------------------------
     def dnn_logit_fn(self, net):
         for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
-            net = self.activation(lin(net))
+            net = dense_act(lin, net, self.activation)                          # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :301-302 (TRAIN only), before the BN
             if len(self.bns):
                 net = self.bns[i](net)

@@ -1,0 +1,94 @@
+"""dense.py -- the hidden layers of the DNN towers on the HIP dense kernel (include/dir_hip.h: dir_dense_f32).
+
+Mirrors tf.layers.dense(units, activation) as the reference uses it (dnn_logit_fn, models/DeepFM/deepFM.py:295-300;
+_deep_architecture, models/DeepCrossNetwork/DeepCrossNetwork.py:394-399; _base_model, models/ESMM/ESMM.py:139-142): matmul +
+bias + activation, here in ONE pass (bias and ReLU on the MFMA accumulators).  `dense_act(lin, x, activation)` is what the
+models call: the kernel when it covers the layer (CUDA fp32, in_features % 4 == 0, >= 16 units, activation ReLU or none),
+`activation(lin(x))` otherwise (the units = 1 logit layers are matrix-vector products and stay library code).
+
+Weight rows are handed to the kernel with a stride that is a multiple of 64 floats: a 416-float stride (1 664 bytes, the first
+DeepFM / DCN layer) costs the kernel -- and rocBLAS -- 20 % (tools/dense_sweep.py); the padded copy is 640 KB per layer.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+_RELUS = (torch.relu, F.relu, torch.nn.functional.relu)
+_PACK_CACHE = {}
+
+
+def pack_weight(weight):
+    """[N, Kd] -> the same values with row stride round_up(Kd, 64) (a view [:, :Kd] of a padded buffer); no copy when Kd % 64 == 0."""
+    N, Kd = weight.shape
+    ld = (Kd + 63) // 64 * 64
+    w = weight.detach()
+    if ld == Kd and w.is_contiguous():
+        return w
+    buf = torch.zeros((N, ld), dtype=w.dtype, device=w.device)
+    buf[:, :Kd].copy_(w)
+    return buf[:, :Kd]
+
+
+def _packed_cached(weight):
+    """Inference: one padded copy per weight tensor, refreshed when the parameter is modified in place (tensor._version)."""
+    key = id(weight)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+    packed = pack_weight(weight)
+    if len(_PACK_CACHE) > 256:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (weight, weight._version, weight.data_ptr(), packed)
+    return packed
+
+
+def _tn_matmul(g, x, splits=16):
+    """g^T x for tall operands ([M, N]^T [M, Kd], M = batch rows): the library's single TN GEMM runs at 0.33 of the fp32 MFMA peak
+    at 65 536 x 400 x 416 (a 400 x 416 output leaves most CUs idle); sixteen batched row slices + one sum run at 0.53
+    (tools/tn_gemm_probe.py: 425 -> 261 us)."""
+    M = g.shape[0]
+    if M >= 8192 and M % splits == 0 and g.is_contiguous() and x.is_contiguous():
+        return torch.bmm(g.view(splits, M // splits, -1).transpose(1, 2), x.view(splits, M // splits, -1)).sum(dim=0)
+    return g.t() @ x
+
+
+class _DenseFn(torch.autograd.Function):
+    """y = act(x W^T + b) with the HIP kernel forward and for dL/dx (= g W, the same kernel on W^T); dL/dW = g^T x and
+    dL/db = sum g go through the library (a reduction over the batch rows: a different shape class)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = ops.dense(x, pack_weight(weight), bias, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            g = g * (y > 0)
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = pack_weight(weight.t())                           # [Kd, N]: the "weight" of the transposed product
+            gx = ops.dense(g, wt, None, relu=False) if ops.dense_supported(g, wt) else g @ weight
+        if ctx.needs_input_grad[1]:
+            gw = _tn_matmul(g, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(dim=0)
+        return gx, gw, gb, None
+
+
+def dense_act(lin, x, activation=None):
+    """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered."""
+    relu = activation in _RELUS
+    if (activation is None or relu) and ops.dense_supported(x, lin.weight):
+        if torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
+            return _DenseFn.apply(x, lin.weight, lin.bias, relu)
+        return ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu)
+    y = lin(x)
+    return activation(y) if activation is not None else y

@@ -10,6 +10,7 @@ SURVEY.md 8(f) rank 3: the same gather kernel, used twice per step.
 import torch
 from torch import nn
 
+from .dense import dense_act
 from .dcn import _glorot_normal_
 from .deepfm import _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
@@ -38,7 +39,7 @@ class _BaseModel(nn.Module):
     def forward(self, features):
         net = self.input_layer(features)
         for lin in self.hidden:
-            net = self.activation(lin(net))
+            net = dense_act(lin, net, self.activation)                           # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.dropout)                        # ESMM.py:143-144 (TRAIN only)
         return self.logits(net)
 

@@ -261,6 +261,34 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     return (out, scores) if want_scores else out
 
 
+def dense_supported(x, weight):
+    """Shapes dir_dense_f32 covers: fp32 CUDA tensors, in_features a multiple of 4, at least 16 output columns (narrower layers --
+    the final units=1 logit layers -- are matrix-vector products: library code)."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0
+            and weight.shape[0] >= 16 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def dense(x, weight, bias=None, relu=False, out=None):
+    """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32).  x [M, Kd], weight [N, Kd] (nn.Linear layout), bias [N]."""
+    _dev(x, torch.float32, "x")
+    _dev(weight, torch.float32, "weight")
+    M, Kd = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != Kd or x.stride(1) != 1:
+        raise ValueError("dense: x [M, Kd] with unit inner stride, weight [N, Kd]")
+    if weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
+        weight = weight.contiguous()
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "bias").contiguous()
+        if bias.numel() != N:
+            raise ValueError("dense: bias [N]")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dir_dense_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), 1 if relu else 0, M, Kd, N, _ptr(out),
+                                         out.stride(0), _stream()))
+    return out
+
+
 def din_backward_supported(K, T, H1, H2):
     """Shapes the fused DIN backward covers (include/dir_hip.h: dir_din_attention_pool_backward_f32)."""
     return K == 64 and T <= 64 and H1 <= 80 and H2 <= 48 and H1 % 4 == 0 and H2 % 4 == 0

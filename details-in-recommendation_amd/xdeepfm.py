@@ -6,6 +6,7 @@ import math
 import torch
 from torch import nn
 
+from .dense import dense_act
 from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of
@@ -81,7 +82,7 @@ class XDeepFM(nn.Module):
         logits = self.cin_out(self.cin(emb.view(B, self.m, self.D)))
         net = emb
         for lin in self.hidden:
-            net = self.activation(lin(net))
+            net = dense_act(lin, net, self.activation)                          # dir_dense_f32 when covered
         logits = logits + self.dnn_out(net)
         if linear_logit is not None:
             logits = logits + linear_logit

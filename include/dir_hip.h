@@ -228,6 +228,19 @@ int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_
                           int flags /* DIR_GATHER_STREAM_ROWS */, float* out, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
+ * A5 / A9  hidden layers of the DNN towers: Y[M, N] = act(X[M, Kd] . Wt[N, Kd]^T + bias[N])   (row strides x_ld, w_ld, y_ld).
+ *   reference: dnn_logit_fn, models/DeepFM/deepFM.py:295-300; _deep_architecture,
+ *              models/DeepCrossNetwork/DeepCrossNetwork.py:394-399; _base_model, models/ESMM/ESMM.py:139-142
+ *              ([TF-upstream] tf.layers.dense = matmul + bias + activation; Wt is the transpose of the TF kernel)
+ * fp32 MFMA, bias and activation applied to the accumulators (one pass over Y).  bias may be NULL.
+ * Limits: Kd, x_ld and w_ld multiples of 4, X / Wt 16-byte aligned (DIR_E_UNSUPPORTED otherwise: use a library GEMM).
+ * ------------------------------------------------------------------------------------------ */
+#define DIR_ACT_NONE 0
+#define DIR_ACT_RELU 1
+int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd, int N,
+                  float* Y, int64_t y_ld, dir_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
  * Backward of the HBM-bound interaction ops: derivatives of the same reference
  * expressions (the reference trains through TensorFlow autodiff of deepFM.py:321-335 and
  * DeepCrossNetwork.py:336-367).

@@ -426,3 +426,40 @@ def test_table_beyond_4gib_offsets(ops):
     vals = torch.randint(V - 1000, V, (B * F * 2,), generator=g, device="cuda")
     bag = ops.embedding_bag(ts, vals, offs, None, combiner="sum")
     assert torch.equal(bag, (table[vals[0::2]] + table[vals[1::2]]).reshape(B, F * K))
+
+
+# ---- A5 / A9 hidden layers: dir_dense_f32 (fp32 MFMA GEMM + bias + ReLU) ------------------------------------------------------
+@pytest.mark.parametrize("M,Kd,N", [(300, 416, 400), (129, 400, 400), (1000, 64, 16), (77, 1024, 1024), (5, 4, 200), (128, 36, 80),
+                                    (256, 416, 1024), (1, 16, 17), (1025, 428, 160)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_dense_matches_float64(built_lib, M, Kd, N, relu):
+    import torch
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(M + Kd + N)
+    xfull = torch.randn(M, Kd + 4, generator=g)
+    x = xfull.cuda()[:, :Kd]                                   # row stride Kd + 4
+    w = torch.randn(N, Kd, generator=g) / Kd ** 0.5
+    b = torch.randn(N, generator=g) * 0.1 if (M + N) % 2 else None
+    assert ops.dense_supported(x, w.cuda())
+    ref = xfull[:, :Kd].double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    got = ops.dense(x, w.cuda(), None if b is None else b.cuda(), relu=relu)
+    err = (got.cpu().double() - ref).abs() / (1 + ref.abs())
+    assert err.max() <= 1e-5, float(err.max())
+    out = torch.full((M, N + 3), -7.0).cuda()                  # strided output, untouched padding
+    ops.dense(x, w.cuda(), None if b is None else b.cuda(), relu=relu, out=out[:, :N])
+    assert torch.equal(out[:, :N], got) and float(out[:, N:].max()) == -7.0 and float(out[:, N:].min()) == -7.0
+
+
+def test_dense_limits(built_lib):
+    import torch
+    from dir_amd import ops
+    from dir_amd._lib import DirError
+    x = torch.randn(8, 10).cuda()
+    assert not ops.dense_supported(x, torch.randn(32, 10).cuda())          # in_features not a multiple of 4
+    with pytest.raises(DirError):
+        ops.dense(x, torch.randn(32, 10).cuda())
+    assert not ops.dense_supported(torch.randn(8, 16).cuda(), torch.randn(1, 16).cuda())   # units = 1: library matrix-vector product
