@@ -25,7 +25,7 @@ def pack_weight(weight):
     w = weight.detach()
     if ld == Kd and w.is_contiguous():
         return w
-    buf = torch.zeros((N, ld), dtype=w.dtype, device=w.device)
+    buf = torch.empty((N, ld), dtype=w.dtype, device=w.device)      # the padding columns are never read (the kernel stops at Kd)
     buf[:, :Kd].copy_(w)
     return buf[:, :Kd]
 
