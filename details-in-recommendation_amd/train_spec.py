@@ -10,6 +10,7 @@ Reference use: models/DeepCrossNetwork/train.py:111-125 (Adam, epsilon 1e-4, cos
 Host-side scalar logic only; the gradients themselves come from autograd.py's HIP backward kernels.
 """
 import math
+import os
 
 import torch
 
@@ -172,8 +173,12 @@ class TrainStep:
         if cls is torch.optim.Adam:
             kw["betas"] = tuple(betas)
         self.params = [p for p in model.parameters() if p.requires_grad]
+        if cls in (torch.optim.Adam, torch.optim.Adagrad, torch.optim.SGD) and self.params and all(p.is_cuda for p in self.params) \
+                and os.environ.get("DIR_TRAIN_FUSED_OPTIMIZER", "1") == "1":
+            kw.setdefault("fused", True)      # one multi-tensor launch per step instead of ~10 elementwise passes over every variable
         self.optimizer = cls(self.params, lr=learning_rate_decay(self.learning_rate_spec, 0), **kw)
         self.l2_reg, self.l2_params = l2_reg, list(l2_params or [])
+        self._dense_grad = {}                                         # table -> persistent all-zero dense gradient buffer
 
     def __call__(self, loss):
         if self.l2_reg:                                               # :181-183 (tf.nn.l2_loss = sum(w^2)/2)
@@ -183,10 +188,32 @@ class TrainStep:
             group["lr"] = lr
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        touched = []
         for p in self.params:
-            if p.grad is not None:
-                g = clip_by_norm_(p.grad)
+            g = p.grad
+            if g is None:
+                continue
+            if g.is_sparse and g.dim() == 2 and p.is_cuda:
+                # The embedding tables' IndexedSlices-style gradients.  The reference's optimizers update EVERY row of such a
+                # variable ([TF-upstream] Adam _apply_sparse decays all of m and v and steps all of var), i.e. a dense step with
+                # zeros outside the looked-up rows: scatter-add the rows into a persistent all-zero buffer (duplicates add up,
+                # which is also what the per-tensor norm is taken over), clip the touched rows in place, step, re-zero the rows.
+                idx, vals = g._indices()[0], g._values()
+                buf = self._dense_grad.get(p)
+                if buf is None:
+                    buf = self._dense_grad[p] = torch.zeros_like(p)
+                buf.index_add_(0, idx, vals.to(buf.dtype))
+                norm = torch.linalg.vector_norm(buf)
+                scale = CLIP_NORM / torch.clamp(norm, min=CLIP_NORM)
+                rows = buf.index_select(0, idx)                      # read before any write: duplicate ids copy the same row
+                buf.index_copy_(0, idx, rows * scale)
+                p.grad = buf
+                touched.append((buf, idx))
+            else:
+                g = clip_by_norm_(g)
                 p.grad = g.to_dense() if g.is_sparse else g           # torch's Adam/Adagrad here take dense gradients
         self.optimizer.step()
+        for buf, idx in touched:
+            buf.index_fill_(0, idx, 0.0)
         self.global_step += 1
         return loss.detach(), lr
