@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "dcn_cross_backward", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
-                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense"])
+                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense", "esmm_full", "esmm_train"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -439,6 +439,34 @@ def main():
         roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K)), "kernel": "whole DCN training step (embedding-bag bytes only)"}
         cfg.update({"fields": F, "dense": 13, "d": model.column_num, "cross_layers": 3, "deep": [1024, 1024],
                     "train_op": "Adam(eps 1e-4) dense on all variables incl. tables, cosine decay, clip_by_norm 100 per tensor"})
+    elif wl in ("esmm_full", "esmm_train"):
+        # ESMM (models/ESMM/ESMM.py:62-92): two towers, each with its OWN embedding variables over the same 26 columns, 360-200-80
+        # hidden units; forward, or a training step (CTR + CTCVR losses, ESMM.py:150-175) with torch Adagrad (sparse on the tables)
+        from dir_amd.esmm import ESMM
+        from dir_amd import feature_column as fc
+        cols = [fc.embedding_column(fc.categorical_column_with_identity("C%02d" % i, V), K) for i in range(F)]
+        model = ESMM(columns=cols, dnn_hidden_units=[360, 200, 80]).to(device)
+        idsl = make_ids(torch, args, gen, device, V)
+        feats = [{"C%02d" % i: ids[:, i].contiguous() for i in range(F)} for ids in idsl]
+        if wl == "esmm_full":
+            with torch.no_grad():
+                step = lambda i: model(feats[i % len(feats)])  # noqa: E731
+        else:
+            labels = {"click_label": (torch.rand((B, 1), generator=gen, device=device) < 0.25).float(),
+                      "convert_label": (torch.rand((B, 1), generator=gen, device=device) < 0.05).float()}
+            dense_p = [p for n, p in model.named_parameters() if "embedding_weights" not in n]
+            opt_d = torch.optim.Adagrad(dense_p, lr=0.05, initial_accumulator_value=0.1, eps=0.0)
+            sparse_opts = model.ctr_model.input_layer.fused_sparse_adagrad(0.05) + model.cvr_model.input_layer.fused_sparse_adagrad(0.05)
+            cfg["sparse_optimizers"] = len(sparse_opts)
+
+            def step(i):
+                f = feats[i % len(feats)]
+                opt_d.zero_grad(set_to_none=True)
+                loss, _ = model.get_loss(f, labels, model(f))
+                loss.backward()                                   # the fused sparse Adagrad updates the 52 tables inside backward
+                opt_d.step()
+        roof = {"bound": "hbm", "alg_bytes": 2 * B * (F * (8 + 2 * 4 * K)), "kernel": "ESMM %s (two embedding-bag passes' bytes only)" % wl}
+        cfg.update({"fields": F, "towers": 2, "hidden": [360, 200, 80]})
     elif wl in ("xdeepfm_full", "xdeepfm_train"):
         # BASELINE configs[4] on one GPU: xDeepFM (CIN 128-128-128 + DNN 400-400 + linear) forward, or a whole training step
         # (CIN backward on MFMA, sparse table gradients, torch Adagrad on everything dense, SGD on the sparse parameters)

@@ -76,6 +76,9 @@ class EmbeddingBag(torch.autograd.Function):
         F, K = ts.F, ts.K
         g = g.contiguous() if g.stride(1) == 1 else g.clone()
         grads = []
+        if not ctx.has_offsets and ts.grad_sink is not None:     # fused optimiser attached (ops.SparseAdagrad.attach): no table .grad
+            ts.grad_sink(ids, g)
+            return (None,) * (7 + F)
         if not ctx.has_offsets:
             for f in range(F):
                 grads.append(_sparse_rows(ids[:, f].contiguous(), g[:, f * K:(f + 1) * K], ts.vocab[f]))

@@ -64,6 +64,12 @@ class InputLayer(nn.Module):
             self._ts_key = key
         return self._groups
 
+    def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
+        """Attach the fused sparse Adagrad (include/dir_hip.h: dir_sparse_adagrad_sorted_f32; the reference's Adagrad on
+        `embedding_weights`) to every group of embedding columns: backward() then updates the tables in place for one-hot
+        inputs and they get no .grad.  Returns the optimiser objects (they own the accumulators)."""
+        return [ops.SparseAdagrad(ts, lr, initial_accumulator_value=initial_accumulator_value).attach() for ts, _, _ in self._tablesets()]
+
     def _indicator(self, c, features, device, B):
         ids = categorical_of(c).ids(features, device)
         if B is None:
@@ -82,7 +88,7 @@ class InputLayer(nn.Module):
     def _forward_train(self, features, device):
         """Differentiable path: every column's block is its own tensor, concatenated in name order (autograd tracks
         the concat; the embedding blocks carry sparse table gradients, see autograd.EmbeddingBag)."""
-        blocks = {}
+        blocks, inside = {}, set()
         for ts, idxs, comb in self._tablesets():
             cols = [self.emb_cols[i] for i in idxs]
             tabs = [self.embedding_weights[i] for i in idxs]
@@ -91,9 +97,10 @@ class InputLayer(nn.Module):
                 blk = ag.embedding_bag(ts, got[1], tabs)
             else:
                 blk = ag.embedding_bag(ts, got[1], tabs, got[2], got[3], combiner=comb, field_major=True)
-            dim = cols[0].dimension
-            for k, c in enumerate(cols):
-                blocks[c.name] = blk[:, k * dim:(k + 1) * dim]
+            # a group is a run of columns that are ADJACENT in the concat (see _tablesets): its block enters the concat whole, at
+            # its first column's position (26 per-column slices would each cost a [B, 26*dim] zero fill + add in the backward)
+            blocks[cols[0].name] = blk
+            inside.update(c.name for c in cols[1:])
         pieces = []
         B = next(iter(blocks.values())).shape[0] if blocks else None
         for c in self.columns:
@@ -101,9 +108,9 @@ class InputLayer(nn.Module):
                 pieces.append(features[c.key].to(device=device, dtype=torch.float32).reshape(-1, c.dimension))
             elif isinstance(c, IndicatorColumn):
                 pieces.append(self._indicator(c, features, device, B))
-            else:
+            elif c.name not in inside:
                 pieces.append(blocks[c.name])
-        return torch.cat(pieces, dim=1)
+        return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=1)
 
     def forward(self, features):
         device = self.embedding_weights[0].device if len(self.embedding_weights) else next(iter(

@@ -173,10 +173,16 @@ class TrainStep:
         if cls is torch.optim.Adam:
             kw["betas"] = tuple(betas)
         self.params = [p for p in model.parameters() if p.requires_grad]
-        if cls in (torch.optim.Adam, torch.optim.Adagrad, torch.optim.SGD) and self.params and all(p.is_cuda for p in self.params) \
-                and os.environ.get("DIR_TRAIN_FUSED_OPTIMIZER", "1") == "1":
-            kw.setdefault("fused", True)      # one multi-tensor launch per step instead of ~10 elementwise passes over every variable
-        self.optimizer = cls(self.params, lr=learning_rate_decay(self.learning_rate_spec, 0), **kw)
+        lr0 = learning_rate_decay(self.learning_rate_spec, 0)
+        self.optimizer = None
+        if cls is torch.optim.Adam and self.params and all(p.is_cuda for p in self.params) \
+                and os.environ.get("DIR_TRAIN_FUSED_OPTIMIZER", "1") == "1" and "fused" not in kw:
+            try:      # one multi-tensor launch family per step instead of ~10 elementwise passes over every variable
+                self.optimizer = cls(self.params, lr=lr0, fused=True, **kw)
+            except (RuntimeError, TypeError):
+                self.optimizer = None
+        if self.optimizer is None:
+            self.optimizer = cls(self.params, lr=lr0, **kw)
         self.l2_reg, self.l2_params = l2_reg, list(l2_params or [])
         self._dense_grad = {}                                         # table -> persistent all-zero dense gradient buffer
 

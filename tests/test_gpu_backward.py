@@ -673,3 +673,38 @@ def test_din_fused_backward_empty_and_limits(built_lib):
         ops.din_attention_pool_backward(t32, hist, None, torch.zeros(4, dtype=torch.int64).cuda(), torch.randn(128, 36).cuda(),
                                         torch.zeros(36).cuda(), torch.randn(36, 20).cuda(), torch.zeros(20).cuda(),
                                         torch.randn(20).cuda(), torch.zeros(1).cuda(), torch.randn(4, 32).cuda())
+
+
+def test_input_layer_fused_sparse_adagrad_matches_torch(built_lib):
+    """InputLayer.fused_sparse_adagrad (the ESMM / DCN towers' tables updated inside backward) against torch's sparse Adagrad."""
+    from dir_amd import feature_column as fc
+    from dir_amd.esmm import ESMM
+    V, K, F, B = 60, 8, 5, 90
+    cols = [fc.embedding_column(fc.categorical_column_with_identity("C%d" % i, V), K) for i in range(F)]
+    torch.manual_seed(3)
+    a = ESMM(columns=cols, dnn_hidden_units=[16, 8]).cuda()
+    b = ESMM(columns=cols, dnn_hidden_units=[16, 8]).cuda()
+    b.load_state_dict(a.state_dict())
+    tabs_b = [p for n, p in b.named_parameters() if "embedding_weights" in n]
+    opt_b = torch.optim.Adagrad(tabs_b, lr=0.1, initial_accumulator_value=0.1, eps=0.0)
+    keep = a.ctr_model.input_layer.fused_sparse_adagrad(0.1) + a.cvr_model.input_layer.fused_sparse_adagrad(0.1)
+    assert keep
+    g = torch.Generator().manual_seed(4)
+    for _ in range(3):
+        ids = torch.randint(0, V, (B, F), generator=g)
+        feats = {"C%d" % i: ids[:, i].cuda() for i in range(F)}
+        labels = {"click_label": torch.randint(0, 2, (B, 1), generator=g).float().cuda(),
+                  "convert_label": torch.randint(0, 2, (B, 1), generator=g).float().cuda()}
+        la, _ = a.get_loss(feats, labels, a(feats))
+        la.backward()
+        opt_b.zero_grad(set_to_none=True)
+        lb, _ = b.get_loss(feats, labels, b(feats))
+        lb.backward()
+        opt_b.step()
+        for p in a.parameters():            # the dense parameters are not stepped in this test
+            p.grad = None
+        for p in b.parameters():
+            p.grad = None
+    ta = [p for n, p in a.named_parameters() if "embedding_weights" in n]
+    for pa, pb in zip(ta, tabs_b):
+        _close(pa, pb, tol=2e-6)
