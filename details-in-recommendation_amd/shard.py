@@ -201,3 +201,72 @@ class _ShardedLookup(torch.autograd.Function):
     def backward(ctx, g):
         ctx.st._backward_apply(ctx.saved, g)
         return None, None, None
+
+
+# ---- the dense (replicated) side of multi-GPU training -----------------------------------------------------------------
+def allreduce_grads(params, group=None, bucket_bytes=64 << 20, average=False):
+    """Sum (or average) the .grad of replicated parameters over the ranks: the gradients are packed into flat buckets of about
+    `bucket_bytes` (xGMI is point-to-point: few large all-reduces, not one per tensor), every bucket's all_reduce is issued
+    before the first is waited for, then the results are copied back.  Parameters without a gradient are skipped on every rank
+    alike (the caller guarantees the ranks agree on which parameters have gradients)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    host_staged = _HOST_STAGED or (dist.get_backend(group) == "gloo" and grads[0].is_cuda)
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        if g.is_sparse:
+            raise ValueError("allreduce_grads: dense gradients only (sharded tables update at their owners)")
+        cur.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    flats, works = [], []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        if host_staged:
+            flat = flat.cpu()
+        flats.append(flat)
+        works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    scale = 1.0 / dist.get_world_size(group) if average else 1.0
+    for b, flat, w in zip(buckets, flats, works):
+        w.wait()
+        off = 0
+        for g in b:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g).to(g.device) * scale if average else flat[off:off + n].view_as(g))
+            off += n
+
+
+class ShardedDeepFMTrainer:
+    """One synchronous multi-GPU training step of a DeepFM: the embedding tables are row-sharded over the ranks
+    (ShardedTables: lookup = two all-to-alls, backward = the row exchange reversed + the owner's sparse Adagrad), the dense
+    tower is replicated and its gradients are summed with bucketed all-reduces.  This is the reference's between-graph
+    replicated training on parameter servers (partitioned embedding variables, deepFM.py:163-167; Adagrad on them, :61; the
+    canned head's SUM loss reduction, :72 -- so gradients ADD over workers) restated for one process per GPU.
+    `model` supplies the tower (dnn_logit_fn) and F, K; its own embedding_weights are not used."""
+
+    def __init__(self, model, tables, lr_sparse, dense_optimizer, group=None, initial_accumulator_value=0.1):
+        self.model, self.tables, self.group = model, tables, group
+        self.dense_params = [p for n, p in model.named_parameters()
+                             if not (n.startswith("embedding_weights") or n.startswith("linear_weights"))]
+        self.dense_optimizer = dense_optimizer
+        tables.enable_training(lr_sparse, initial_accumulator_value)
+
+    def step(self, ids, labels):
+        """ids [B_local, F] global row ids, labels [B_local, 1] -> this rank's summed loss (detached)."""
+        from . import autograd as ag
+        m = self.model
+        self.dense_optimizer.zero_grad(set_to_none=True)
+        emb = self.tables.lookup_train(ids)                                   # tables update inside backward()
+        logits = ag.fm_logit(emb, m.F, m.K) + m.dnn_logit_fn(emb)             # fm_logit_fn + dnn_logit_fn, deepFM.py:337-338
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction="sum")
+        loss.backward()
+        allreduce_grads(self.dense_params, self.group)
+        self.dense_optimizer.step()
+        return loss.detach()

@@ -122,3 +122,114 @@ def test_two_ranks_share_one_gpu(built_lib, vocab):
         assert not isinstance(worst, str), "rank %d raised:\n%s" % (rank, worst)
         assert ok, "rank %d: sharded lookup differs from the full-table gather" % rank
         assert worst <= 1e-5, "rank %d: shard differs from the global Adagrad step (%.2e)" % (rank, worst)
+
+
+def _trainer_worker(rank, world, port, q):
+    try:
+        import sys
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["DIR_SHARD_HOST_STAGED"] = "1"          # two ranks on ONE GPU: exchanges staged through host memory over gloo
+        import datetime
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        try:
+            torch.cuda.set_device(0)
+            import dir_amd  # noqa: F401
+            from dir_amd import feature_column as fc
+            from dir_amd.deepfm import DeepFM
+            from dir_amd.shard import ShardedTables, ShardedDeepFMTrainer, div_range
+            V, K, F, B, steps = 50, 8, 4, 64, 3
+            cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+            torch.manual_seed(7)                               # same dense initialisation on every rank
+            model = DeepFM(linear_feature_columns=[], dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                           dnn_hidden_units=[16, 16], fm_embedding_size=K).cuda()
+            full = [p.detach().clone() for p in model.embedding_weights]
+            st = ShardedTables.from_full(full)
+            dense = [p for n, p in model.named_parameters() if not n.startswith(("embedding_weights", "linear_weights"))]
+            opt = torch.optim.Adagrad(dense, lr=0.05, initial_accumulator_value=0.1, eps=0.0)
+            tr = ShardedDeepFMTrainer(model, st, lr_sparse=0.05, dense_optimizer=opt)
+            # float64 single-process reference of the same global batches (every rank computes it: cheap)
+            t64 = [t.double().cpu().clone() for t in full]
+            acc64 = [torch.full_like(t, 0.1) for t in t64]
+            d64 = [p.detach().double().cpu().clone().requires_grad_(True) for p in dense]
+            dacc = [torch.full_like(p, 0.1) for p in d64]
+            names = [n for n, _ in model.named_parameters() if not n.startswith(("embedding_weights", "linear_weights"))]
+            for s in range(steps):
+                gb = torch.Generator().manual_seed(1000 + s)
+                ids_all = torch.randint(0, V, (world * B, F), generator=gb)
+                lab_all = torch.randint(0, 2, (world * B, 1), generator=gb).double()
+                ids, lab = ids_all[rank * B:(rank + 1) * B].cuda(), lab_all[rank * B:(rank + 1) * B].float().cuda()
+                tr.step(ids, lab)
+                # reference step
+                tl = [t.clone().requires_grad_(True) for t in t64]
+                emb = torch.cat([tl[f][ids_all[:, f]] for f in range(F)], dim=1)
+                e3 = emb.view(-1, F, K)
+                fm = 0.5 * ((e3.sum(1) ** 2) - (e3 ** 2).sum(1)).sum(1, keepdim=True)
+                net = emb
+                pd = dict(zip(names, d64))
+                for i in range(2):
+                    net = torch.relu(net @ pd["hidden.%d.weight" % i].t() + pd["hidden.%d.bias" % i])
+                logit = fm + net @ pd["logits_layer.weight"].t() + pd["logits_layer.bias"]
+                loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, lab_all, reduction="sum")
+                grads = torch.autograd.grad(loss, tl + d64, allow_unused=True)      # (linear_bias is not part of this step)
+                with torch.no_grad():
+                    for f in range(F):
+                        g = grads[f]
+                        touched = g.abs().sum(1) > 0
+                        acc64[f][touched] += g[touched] ** 2
+                        t64[f][touched] -= 0.05 * g[touched] / acc64[f][touched].sqrt()
+                    for p, a, g in zip(d64, dacc, grads[F:]):
+                        if g is None:
+                            continue
+                        a += g ** 2
+                        p -= 0.05 * g / a.sqrt()
+            worst = 0.0
+            for p, r in zip(dense, d64):
+                worst = max(worst, float(((p.detach().double().cpu() - r.detach()).abs() / (1 + r.detach().abs())).max()))
+            for f in range(F):
+                s_, e_ = div_range(V, world, rank)
+                got = st.local_tables[f].double().cpu()
+                worst = max(worst, float(((got - t64[f][s_:e_]).abs() / (1 + t64[f][s_:e_].abs())).max()))
+            q.put((rank, True, worst))
+        finally:
+            dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+
+
+def test_sharded_deepfm_trainer_matches_single_process(built_lib):
+    """ShardedDeepFMTrainer at world size 2 (two processes on the one GPU, exchanges staged through gloo): three synchronous
+    steps -- sharded tables with owner-side Adagrad, replicated tower with all-reduced gradients -- against a float64
+    single-process run of the same global batches."""
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+
+    def run():
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            for _ in range(2):
+                res.append(q.get(timeout=150))
+        except queue.Empty:
+            res = None
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+        return res
+
+    res = run()
+    if res is None or any(isinstance(w, str) and ("onnect" in w or "imeout" in w or "store" in w.lower()) for _, _, w in res):
+        res = run()
+    assert res is not None, "workers did not report within the time limit"
+    for rank, ok, worst in res:
+        assert not isinstance(worst, str), "rank %d raised:\n%s" % (rank, worst)
+        assert worst <= 2e-5, "rank %d: parameters differ from the single-process run (%.2e)" % (rank, worst)

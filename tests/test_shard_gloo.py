@@ -200,3 +200,52 @@ def test_div_range_covers_vocab():
         for i, o, l in zip(ids, own, loc):
             s, e = edges[o]
             assert s <= i < e and l == i - s
+
+
+def _allreduce_worker(rank, world, port, out_q):
+    try:
+        import sys
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        try:
+            from dir_amd.shard import allreduce_grads
+            g = torch.Generator().manual_seed(11)
+            shapes = [(7, 5), (3,), (64, 33), (1,), (9, 2, 2)]
+            params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(4))]   # the last has no grad
+            base = [torch.randn(s, generator=g) for s in shapes]
+            for p, b in zip(params, base):
+                p.grad = b * (rank + 1)
+            allreduce_grads(params, bucket_bytes=1024)                      # several buckets
+            tot = sum(r + 1 for r in range(world))
+            ok = all(torch.allclose(p.grad, b * tot, rtol=1e-6, atol=1e-6) for p, b in zip(params, base)) and params[-1].grad is None
+            for p, b in zip(params, base):
+                p.grad = b * (rank + 1)
+            allreduce_grads(params, average=True)
+            ok = ok and all(torch.allclose(p.grad, b * tot / world, rtol=1e-6, atol=1e-6) for p, b in zip(params, base))
+            out_q.put((rank, ok))
+        finally:
+            dist.destroy_process_group()
+    except Exception:
+        import traceback
+        out_q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allreduce_grads_sums_replicated_gradients(world):
+    """shard.allreduce_grads (the dense side of ShardedDeepFMTrainer): bucketed flat all-reduce = per-tensor sum / mean."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert not isinstance(ok, str), "rank %d raised:\n%s" % (rank, ok)
+        assert ok, "rank %d: all-reduced gradients differ" % rank
