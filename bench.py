@@ -14,6 +14,10 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling.  Ever
 row shard of every table, draws its own batch of 65 536 samples over the GLOBAL vocabulary, and a step
 is ShardedTables.lookup (route -> all_to_all ids -> owner gather -> all_to_all rows -> un-permute) followed
 by the FM kernel.  value = samples all ranks processed / max-over-ranks time.
+
+The default line also carries two secondary legs, timed after the primary steps: `secondary_zipf` (N = 1: the same kernel on
+Zipf(1.05) ids) and `secondary_cfg5_xdeepfm_cin` (every N: BASELINE configs[4], xDeepFM CIN 3 x 128 on a 1e8-row table,
+row-sharded when N > 1; a watchdog guarantees the primary line is printed even if this leg hangs).
 """
 import argparse
 import json
