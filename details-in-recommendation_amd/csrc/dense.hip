@@ -34,7 +34,8 @@ constexpr int DN_MT = 128;          // rows per workgroup
 template <int NT, bool RELU>
 __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, int64_t x_ld, const float* __restrict__ Wt,
                                                     int64_t w_ld, const float* __restrict__ bias, int64_t M, int Kd, int N,
-                                                    float* __restrict__ Y, int64_t y_ld, int nb, int remap, int vec_out) {
+                                                    float* __restrict__ Y, int64_t y_ld, int nb, int remap, int vec_out,
+                                                    const float* __restrict__ gate, int64_t gate_ld) {
     constexpr int NTILES = NT / 16;
     constexpr int BJ = (NT * 8 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float dense_smem[];
@@ -169,10 +170,19 @@ __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, i
 #pragma unroll
         for (int i = 0; i < (32 * C4) / 64; ++i) {
             const int idx = lane + 64 * i, row = idx / C4, c4 = idx - row * C4;
-            const float4 v = *reinterpret_cast<const float4*>(ep + row * EPS + 4 * c4);
+            float4 v = *reinterpret_cast<const float4*>(ep + row * EPS + 4 * c4);
             const int64_t grow = m0 + 32 * w + row;
             const int col = n0 + 4 * c4;
-            if (grow < M && col < N) *reinterpret_cast<float4*>(Y + grow * y_ld + col) = v;
+            if (grow < M && col < N) {
+                if (gate) {      // backward through the previous layer's ReLU: pass the value where that layer's output was positive
+                    const float4 gt = *reinterpret_cast<const float4*>(gate + grow * gate_ld + col);
+                    v.x = gt.x > 0.f ? v.x : 0.f;
+                    v.y = gt.y > 0.f ? v.y : 0.f;
+                    v.z = gt.z > 0.f ? v.z : 0.f;
+                    v.w = gt.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(Y + grow * y_ld + col) = v;
+            }
         }
         return;
     }
@@ -187,19 +197,22 @@ __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, i
                 const int64_t row = m0 + 32 * w + 16 * mt + 4 * kk + g;
                 float v = acc[mt][nt][g] + bcol;
                 if (RELU) v = fmaxf(v, 0.f);
-                if (row < M && col < N) Y[row * y_ld + col] = v;
+                if (row < M && col < N) {
+                    if (gate && !(gate[row * gate_ld + col] > 0.f)) v = 0.f;
+                    Y[row * y_ld + col] = v;
+                }
             }
     }
 }
 
 template <int NT>
 static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M,
-                         int Kd, int N, float* Y, int64_t y_ld) {
+                         int Kd, int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld) {
     const int nb = (N + NT - 1) / NT;
     const int64_t mb = (M + DN_MT - 1) / DN_MT;
     const int64_t total = mb * nb;
     const int remap = (total % kXCDs) == 0 ? 1 : 0;
-    const int vec_out = ((N & 3) == 0 && (y_ld & 3) == 0 && aligned16(Y)) ? 1 : 0;
+    const int vec_out = ((N & 3) == 0 && (y_ld & 3) == 0 && aligned16(Y) && (!gate || ((gate_ld & 3) == 0 && aligned16(gate)))) ? 1 : 0;
     const size_t shmem = sizeof(float) * 2 * (DN_MT + NT) * DN_LS;      // 60 KB (NT = 80) / 74 KB (NT = 128): two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
@@ -208,18 +221,17 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
         attr_set = true;
     }
     if (act)
-        hipLaunchKernelGGL((dense_k<NT, true>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out);
+        hipLaunchKernelGGL((dense_k<NT, true>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
     else
-        hipLaunchKernelGGL((dense_k<NT, false>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out);
+        hipLaunchKernelGGL((dense_k<NT, false>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
 }
 
 }  // namespace dir
 
 using namespace dir;
 
-extern "C" int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd, int N,
-                             float* Y, int64_t y_ld, dir_stream_t stream) {
-    const char* name = "dir_dense_f32";
+static int dense_entry(const char* name, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd,
+                       int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld, dir_stream_t stream) {
     DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && w_ld >= Kd && y_ld >= N, "%s: M=%lld Kd=%d N=%d x_ld=%lld w_ld=%lld y_ld=%lld", name,
                   (long long)M, Kd, N, (long long)x_ld, (long long)w_ld, (long long)y_ld);
     DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
@@ -232,9 +244,20 @@ extern "C" int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int6
     if (mb * ((N + 79) / 80) > 0x7fffffffLL) return fail(DIR_E_UNSUPPORTED, "%s: M=%lld too large", name, (long long)M);
     hipStream_t st = as_stream(stream);
     if (N % 80 == 0 && N % 128 != 0)
-        launch_dense<80>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld);
+        launch_dense<80>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
     else
-        launch_dense<128>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld);
+        launch_dense<128>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd, int N,
+                             float* Y, int64_t y_ld, dir_stream_t stream) {
+    return dense_entry("dir_dense_f32", X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, nullptr, 0, stream);
+}
+
+extern "C" int dir_dense_gated_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* gate, int64_t gate_ld, int64_t M,
+                                   int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
+    DIR_CHECK_ARG(M == 0 || (gate && gate_ld >= N), "dir_dense_gated_f32: gate [M, N] with gate_ld >= N (gate_ld=%lld N=%d)", (long long)gate_ld, N);
+    return dense_entry("dir_dense_gated_f32", X, x_ld, Wt, w_ld, nullptr, DIR_ACT_NONE, M, Kd, N, Y, y_ld, gate, gate_ld, stream);
 }

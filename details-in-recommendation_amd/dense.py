@@ -83,6 +83,69 @@ class _DenseFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _MlpStackFn(torch.autograd.Function):
+    """A stack of dense + ReLU layers as ONE autograd node.  Forward: dir_dense_f32 per layer.  Backward, per layer from the top:
+    dL/dW = g^T x (batched library GEMM), dL/db = sum g, and the data gradient goes straight through the previous layer's ReLU in
+    the kernel's epilogue (dir_dense_gated_f32) -- the separate `g * (y > 0)` pass over [B, units] survives only for the top
+    layer."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        L = len(params) // 2
+        ys, h = [], x
+        for l in range(L):
+            h = ops.dense(h, pack_weight(params[2 * l]), params[2 * l + 1], relu=True)
+            ys.append(h)
+        ctx.L = L
+        ctx.save_for_backward(x, *params[0::2], *ys)
+        return h
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        x, ws, ys = saved[0], saved[1:1 + L], saved[1 + L:]
+        g = (g * (ys[-1] > 0)).contiguous()
+        grads = [None] * (2 * L)
+        gx = None
+        for l in range(L - 1, -1, -1):
+            xin = ys[l - 1] if l > 0 else x
+            if ctx.needs_input_grad[1 + 2 * l]:
+                grads[2 * l] = _tn_matmul(g, xin)
+            if ctx.needs_input_grad[2 + 2 * l]:
+                grads[2 * l + 1] = g.sum(dim=0)
+            wt = pack_weight(ws[l].t())
+            if l > 0:
+                g = ops.dense_gated(g, wt, xin)
+            elif ctx.needs_input_grad[0]:
+                gx = ops.dense(g, wt, None, relu=False)
+        return (gx,) + tuple(grads)
+
+
+def mlp_stack_supported(lins, x, activation):
+    """A run of nn.Linear layers + ReLU the stack node covers: every layer on the kernel, biases present, and the data gradient
+    of the first layer expressible as a dense product too (its in_features a multiple of 4 and >= 16)."""
+    if activation not in _RELUS or not len(lins) or not torch.is_grad_enabled():
+        return False
+    h_dim = x.shape[1]
+    if not ops.dense_supported(x, lins[0].weight) or h_dim < 16:
+        return False
+    for lin in lins:
+        if lin.bias is None or lin.in_features != h_dim or lin.in_features % 4 or lin.out_features % 4 or lin.out_features < 16:
+            return False
+        h_dim = lin.out_features
+    return True
+
+
+def mlp_stack(lins, x):
+    """relu(lin_L(... relu(lin_1(x)))) through _MlpStackFn (check mlp_stack_supported first)."""
+    params = []
+    for lin in lins:
+        params += [lin.weight, lin.bias]
+    return _MlpStackFn.apply(x, *params)
+
+
 def dense_act(lin, x, activation=None):
     """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered."""
     relu = activation in _RELUS

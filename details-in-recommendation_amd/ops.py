@@ -289,6 +289,24 @@ def dense(x, weight, bias=None, relu=False, out=None):
     return out
 
 
+def dense_gated(x, weight, gate, out=None):
+    """where(gate > 0, x @ weight.T, 0) (include/dir_hip.h: dir_dense_gated_f32): x [M, Kd], weight [N, Kd], gate [M, N]."""
+    _dev(x, torch.float32, "x")
+    _dev(weight, torch.float32, "weight")
+    _dev(gate, torch.float32, "gate")
+    M, Kd = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != Kd or x.stride(1) != 1 or tuple(gate.shape) != (M, N) or gate.stride(1) != 1:
+        raise ValueError("dense_gated: x [M, Kd], weight [N, Kd], gate [M, N], unit inner strides")
+    if weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
+        weight = weight.contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dir_dense_gated_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(gate), gate.stride(0), M, Kd, N,
+                                               _ptr(out), out.stride(0), _stream()))
+    return out
+
+
 def din_backward_supported(K, T, H1, H2):
     """Shapes the fused DIN backward covers (include/dir_hip.h: dir_din_attention_pool_backward_f32)."""
     return K == 64 and T <= 64 and H1 <= 80 and H2 <= 48 and H1 % 4 == 0 and H2 % 4 == 0

@@ -6,7 +6,7 @@ import math
 import torch
 from torch import nn
 
-from .dense import dense_act
+from .dense import dense_act, mlp_stack, mlp_stack_supported
 from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of
@@ -81,8 +81,11 @@ class XDeepFM(nn.Module):
         B = emb.shape[0]
         logits = self.cin_out(self.cin(emb.view(B, self.m, self.D)))
         net = emb
-        for lin in self.hidden:
-            net = dense_act(lin, net, self.activation)                          # dir_dense_f32 when covered
+        if mlp_stack_supported(self.hidden, net, self.activation):
+            net = mlp_stack(self.hidden, net)                                   # training: the whole tower as one autograd node
+        else:
+            for lin in self.hidden:
+                net = dense_act(lin, net, self.activation)                      # dir_dense_f32 when covered
         logits = logits + self.dnn_out(net)
         if linear_logit is not None:
             logits = logits + linear_logit

@@ -708,3 +708,32 @@ def test_input_layer_fused_sparse_adagrad_matches_torch(built_lib):
     ta = [p for n, p in a.named_parameters() if "embedding_weights" in n]
     for pa, pb in zip(ta, tabs_b):
         _close(pa, pb, tol=2e-6)
+
+
+@pytest.mark.parametrize("dims", [[416, 400, 400, 400], [64, 80, 16], [32, 1024]])
+def test_mlp_stack_matches_float64(built_lib, dims):
+    """dense._MlpStackFn (dir_dense_f32 forward, dir_dense_gated_f32 data gradients through the ReLUs) against float64 autograd."""
+    from dir_amd import dense as D
+    g = torch.Generator().manual_seed(sum(dims))
+    M = 300
+    lins = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]).cuda()
+    x = torch.randn(M, dims[0], generator=g).cuda().requires_grad_(True)
+    gout = torch.randn(M, dims[-1], generator=g).cuda()
+    assert D.mlp_stack_supported(lins, x, torch.relu)
+    y = D.mlp_stack(lins, x)
+    y.backward(gout)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    p64 = [(l.weight.detach().double().cpu().requires_grad_(True), l.bias.detach().double().cpu().requires_grad_(True)) for l in lins]
+    h = x64
+    for w, b in p64:
+        h = torch.relu(h @ w.t() + b)
+    h.backward(gout.double().cpu())
+    _close(y, h, tol=1e-5)
+    _close(x.grad, x64.grad, tol=2e-5)
+    for l, (w, b) in zip(lins, p64):
+        scale = 1 + float(w.grad.abs().max())
+        assert float((l.weight.grad.double().cpu() - w.grad).abs().max()) <= 2e-5 * scale
+        assert float((l.bias.grad.double().cpu() - b.grad).abs().max()) <= 2e-5 * (1 + float(b.grad.abs().max()))
+    assert not D.mlp_stack_supported(lins, x, torch.tanh)
+    with torch.no_grad():
+        assert not D.mlp_stack_supported(lins, x, torch.relu)
