@@ -16,7 +16,7 @@ import math
 import torch
 from torch import nn
 
-from .dense import dense_act, mlp_stack, mlp_stack_supported
+from .dense import dense_act, mlp_stack, mlp_stack_supported, units1
 from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of
@@ -145,13 +145,13 @@ class DeepFM(nn.Module):
     # ---- logit builders ---------------------------------------------------------------------------
     def dnn_logit_fn(self, net):
         if not len(self.bns) and not self.hparams.get("dnn_dropout") and mlp_stack_supported(self.hidden, net, self.activation):
-            return self.logits_layer(mlp_stack(self.hidden, net))               # training: the whole tower as one autograd node
+            return units1(self.logits_layer, mlp_stack(self.hidden, net))               # training: the whole tower as one autograd node
         for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
             net = dense_act(lin, net, self.activation)                          # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :301-302 (TRAIN only), before the BN
             if len(self.bns):
                 net = self.bns[i](net)
-        return self.logits_layer(net)                                            # :311-317
+        return units1(self.logits_layer, net)                                    # :311-317
 
     def dnn_fm_logit_fn(self, features, device):
         emb_ts, _ = self._tablesets()

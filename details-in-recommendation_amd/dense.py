@@ -146,6 +146,35 @@ def mlp_stack(lins, x):
     return _MlpStackFn.apply(x, *params)
 
 
+class _Units1Fn(torch.autograd.Function):
+    """The units = 1 logit layers (deepFM.py:311-317, DeepCrossNetwork.py:137, ESMM.py:146) in training: the library's backward
+    of a [B, in] x [in, 1] product is a TN GEMM with one output row (112-158 us at 65 536 x 400) and a rank-1 GEMM (40 us); as
+    elementwise products they cost 72 and 22 us (tools/units1_probe.py)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        y = x @ weight.t()
+        return y + bias if bias is not None else y
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = g * weight if ctx.needs_input_grad[0] else None                    # [B, 1] * [1, in]
+        gw = (g * x).sum(dim=0, keepdim=True) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def units1(lin, x):
+    """lin(x) for an nn.Linear with one output unit; the elementwise backward when training on the GPU."""
+    if lin.out_features == 1 and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
+        return _Units1Fn.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 def dense_act(lin, x, activation=None):
     """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered."""
     relu = activation in _RELUS
