@@ -203,3 +203,33 @@ def test_fuzz_din_forward_backward(ops, oracle, seed):
     close_sum(tab.grad.to_dense(), t64.grad, 2e-5)
     for w, r in zip(ws, w64):
         close_sum(w.grad, r.grad, 2e-5)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DIR_FUZZ_SEEDS", "16"))))
+def test_fuzz_dense(ops, seed):
+    """Random (M, Kd, N, row strides, bias, ReLU, gate) through dir_dense_f32 / dir_dense_gated_f32 against float64 matmul."""
+    rng = np.random.default_rng(9000 + seed)
+    M = int(rng.choice([1, 2, 31, 127, 128, 129, 300, 1000]))
+    Kd = 4 * int(rng.integers(1, 140))
+    N = int(rng.choice([16, 17, 40, 80, 81, 128, 160, 200, 400, 513]))
+    xl, wl, yl = Kd + 4 * int(rng.integers(0, 3)), Kd + 4 * int(rng.integers(0, 20)), N + int(rng.integers(0, 5))
+    x = (rng.standard_normal((M, xl)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((N, wl)) / np.sqrt(Kd)).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32) if seed % 3 else None
+    relu = bool(seed % 2)
+    xd, wd = _dev(x)[:, :Kd], _dev(w)[:, :Kd]
+    ref = x[:, :Kd].astype(np.float64) @ w[:, :Kd].astype(np.float64).T
+    if b is not None:
+        ref = ref + b.astype(np.float64)
+    if relu:
+        ref = np.maximum(ref, 0)
+    out = torch.full((M, yl), 3.0, device="cuda")
+    ops.dense(xd, wd, None if b is None else _dev(b), relu=relu, out=out[:, :N])
+    got = out.cpu().numpy()
+    assert (np.abs(got[:, :N] - ref) / (1 + np.abs(ref))).max() <= 1e-5, (M, Kd, N, xl, wl, yl)
+    assert (got[:, N:] == 3.0).all()
+    gate = rng.standard_normal((M, N)).astype(np.float32)
+    gate[rng.random((M, N)) < 0.3] = 0.0
+    refg = np.where(gate > 0, x[:, :Kd].astype(np.float64) @ w[:, :Kd].astype(np.float64).T, 0.0)
+    gotg = ops.dense_gated(xd, wd, _dev(gate)).cpu().numpy()
+    assert (np.abs(gotg - refg) / (1 + np.abs(refg))).max() <= 1e-5, (M, Kd, N)
