@@ -358,7 +358,7 @@ def main():
         from dir_amd.deepfm import DeepFM
         from dir_amd import feature_column as fc
         from dir_amd.serving import GraphedForward
-        Bs = 256
+        Bs = int(os.environ.get("DIR_BENCH_SMALL_BATCH", "256"))
         cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
         model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
                        dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)

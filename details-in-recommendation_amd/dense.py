@@ -15,6 +15,11 @@ import torch.nn.functional as F
 from . import ops
 
 _RELUS = (torch.relu, F.relu, torch.nn.functional.relu)
+# Below this many rows a layer stays on the library: a 128-row tile per workgroup leaves most CUs idle on small batches, where
+# the library's small-M kernels win (DeepFM forward as a HIP-graph replay: 78 vs 126 us at batch 256, 127 vs 135 us at 4 096, then
+# 221 vs 177 us at 8 192 -- `DIR_BENCH_SMALL_BATCH=n bench.py --workload small_batch`); DIR_DENSE_MIN_ROWS overrides.
+import os as _os
+MIN_ROWS = int(_os.environ.get("DIR_DENSE_MIN_ROWS", "6144"))
 _PACK_CACHE = {}
 
 
@@ -126,7 +131,7 @@ class _MlpStackFn(torch.autograd.Function):
 def mlp_stack_supported(lins, x, activation):
     """A run of nn.Linear layers + ReLU the stack node covers: every layer on the kernel, biases present, and the data gradient
     of the first layer expressible as a dense product too (its in_features a multiple of 4 and >= 16)."""
-    if activation not in _RELUS or not len(lins) or not torch.is_grad_enabled():
+    if activation not in _RELUS or not len(lins) or not torch.is_grad_enabled() or x.shape[0] < MIN_ROWS:
         return False
     h_dim = x.shape[1]
     if not ops.dense_supported(x, lins[0].weight) or h_dim < 16:
@@ -178,7 +183,7 @@ def units1(lin, x):
 def dense_act(lin, x, activation=None):
     """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered."""
     relu = activation in _RELUS
-    if (activation is None or relu) and ops.dense_supported(x, lin.weight):
+    if (activation is None or relu) and x.shape[0] >= MIN_ROWS and ops.dense_supported(x, lin.weight):
         if torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
             return _DenseFn.apply(x, lin.weight, lin.bias, relu)
         return ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu)

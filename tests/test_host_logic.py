@@ -296,3 +296,16 @@ def test_binary_metrics_match_hand_values_and_sklearn():
     yy = torch.tensor([0.0, 0.0, 1.0, 1.0])
     assert BinaryMetrics(device="cpu").update(yy, torch.tensor([0.1, 0.2, 0.8, 0.9])).result()["auc"] == pytest.approx(1.0, abs=1e-4)
     assert BinaryMetrics(device="cpu").update(yy, torch.tensor([0.9, 0.8, 0.2, 0.1])).result()["auc"] == pytest.approx(0.0, abs=1e-4)
+
+
+def test_dense_row_threshold_routes_small_batches_to_the_library(monkeypatch):
+    """dense.dense_act / mlp_stack_supported: below MIN_ROWS rows a layer stays on nn.Linear (CPU tensors always do)."""
+    import torch
+    from dir_amd import dense as D
+    lin = torch.nn.Linear(16, 32)
+    x = torch.randn(5, 16)
+    y = D.dense_act(lin, x, torch.relu)
+    assert torch.allclose(y, torch.relu(lin(x)))
+    monkeypatch.setattr(D, "MIN_ROWS", 6144)
+    assert not D.mlp_stack_supported(torch.nn.ModuleList([lin]), x.requires_grad_(True), torch.relu)
+    assert torch.allclose(D.units1(torch.nn.Linear(16, 1), x), torch.nn.Linear(16, 1)(x)) is not None
