@@ -92,6 +92,12 @@ def test_fuzz_cross(ops, oracle, seed):
     pad = int(rng.choice([0, 4, 5]))
     xb = torch.zeros((B, d + pad), dtype=torch.float32, device="cuda")
     xb[:, :d] = _dev(x0)
+    if L * d * 8 > 64 * 1024:
+        # documented limit (include/dir_hip.h): the L x d weights and biases are staged in LDS once per workgroup
+        from dir_amd._lib import DirError
+        with pytest.raises(DirError, match="LDS weight image"):
+            ops.cross_network(xb[:, :d], _dev(w.reshape(L, d)), _dev(b.reshape(L, d)))
+        return
     if d > 1024 and (d % 4 or pad % 4):
         # documented limit (include/dir_hip.h): rows wider than 1024 floats need the 16-byte path (d and the row strides multiples of 4)
         from dir_amd._lib import DirError
