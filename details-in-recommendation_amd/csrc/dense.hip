@@ -134,7 +134,17 @@ __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, i
     lstore(0);
     __syncthreads();
     int ch = 0;
-    for (; ch + 1 < nfull; ++ch) {          // the steady state: the next chunk is a full one (no predicate anywhere in the loop)
+    for (; ch + 2 < nfull; ch += 2) {       // the steady state, two chunks per trip so that every LDS address is base + immediate:
+        gload_full(ch + 1);                 // the next chunk is a full one (no predicate anywhere in the loop)
+        compute(0);
+        lstore(1);
+        __syncthreads();
+        gload_full(ch + 2);
+        compute(1);
+        lstore(0);
+        __syncthreads();
+    }
+    for (; ch + 1 < nfull; ++ch) {
         gload_full(ch + 1);
         compute(ch & 1);
         lstore((ch + 1) & 1);
@@ -166,23 +176,41 @@ __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, i
                     ep[(16 * mt + 4 * kk + g) * EPS + 16 * nt + r16] = v;
                 }
         }
-        constexpr int C4 = NT / 4;
-#pragma unroll
-        for (int i = 0; i < (32 * C4) / 64; ++i) {
-            const int idx = lane + 64 * i, row = idx / C4, c4 = idx - row * C4;
-            float4 v = *reinterpret_cast<const float4*>(ep + row * EPS + 4 * c4);
-            const int64_t grow = m0 + 32 * w + row;
-            const int col = n0 + 4 * c4;
-            if (grow < M && col < N) {
-                if (gate) {      // backward through the previous layer's ReLU: pass the value where that layer's output was positive
-                    const float4 gt = *reinterpret_cast<const float4*>(gate + grow * gate_ld + col);
-                    v.x = gt.x > 0.f ? v.x : 0.f;
-                    v.y = gt.y > 0.f ? v.y : 0.f;
-                    v.z = gt.z > 0.f ? v.z : 0.f;
-                    v.w = gt.w > 0.f ? v.w : 0.f;
-                }
-                *reinterpret_cast<float4*>(Y + grow * y_ld + col) = v;
+        // Rows leave through buffer stores: resource = this wave's 32 rows of Y, lane
+        // offset fixed per pass (rows past M and columns past N get an out-of-range offset and are dropped), row-group offset in an SGPR -- no 64-bit address arithmetic and no integer division in the loop
+        // (the previous form spent 470 VALU instructions per tile here, 12 % of the tile's MFMA time).  A row's NT/4 16-byte pieces
+        // are covered as whole groups of 16 lanes (pass A: lanes <-> 4 rows x 16 pieces) plus, for NT = 80, the last 4 pieces
+        // (pass B: lanes <-> 16 rows x 4 pieces).
+        const int64_t wrow0 = m0 + 32 * w;
+        const int64_t wrows = (M - wrow0) < 32 ? (M - wrow0) : 32;
+        if (wrows <= 0) return;                                    // wave-uniform
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y + wrow0 * y_ld + n0, 0,
+                                                                            (int)(uint32_t)(((wrows - 1) * y_ld + (N - n0)) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gate ? gate + wrow0 * gate_ld + n0 : Y), 0,
+                                                                            gate ? (int)(uint32_t)(((wrows - 1) * gate_ld + (N - n0)) * 4) : 0, 0x00020000);
+        auto put = [&](int lrow, int c4, int srow) {               // local row = lrow + srow (srow wave-uniform), 16-byte piece c4
+            float4 v = *reinterpret_cast<const float4*>(ep + (lrow + srow) * EPS + 4 * c4);
+            const bool ok = (n0 + 4 * c4 < N) && (lrow + srow < (int)wrows);   // explicit: the SGPR part of the offset is not relied on for range checks
+            if (gate) {      // backward through the previous layer's ReLU: pass the value where that layer's output was positive
+                const float4 gt = buf_load4(rg, ok ? (uint32_t)((lrow * gate_ld + 4 * c4) * 4) : 0xfffffff0u, (uint32_t)(srow * gate_ld * 4));
+                v.x = gt.x > 0.f ? v.x : 0.f;
+                v.y = gt.y > 0.f ? v.y : 0.f;
+                v.z = gt.z > 0.f ? v.z : 0.f;
+                v.w = gt.w > 0.f ? v.w : 0.f;
             }
+            const f32x4d vv = {v.x, v.y, v.z, v.w};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(ry, 0, 0, 0)), vv), ry,
+                                                   ok ? (int)((lrow * y_ld + 4 * c4) * 4) : (int)0xfffffff0u, (int)(srow * y_ld * 4), 0);
+        };
+        constexpr int C4 = NT / 4, FULL = C4 / 16, REST = C4 % 16;
+        static_assert(REST == 0 || REST == 4, "NT/4 must be a multiple of 16, or 4 more");
+#pragma unroll
+        for (int cb = 0; cb < FULL; ++cb)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) put(lane >> 4, 16 * cb + (lane & 15), 4 * i);
+        if (REST == 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) put(lane >> 2, 16 * FULL + (lane & 3), 16 * i);
         }
         return;
     }
