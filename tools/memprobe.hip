@@ -101,6 +101,16 @@ __global__ void fill_idx(uint32_t* idx, int64_t n, uint32_t mod, uint64_t seed) 
         idx[i] = (uint32_t)(mix(i * 0x9E3779B97F4A7C15ULL + seed) % mod);
 }
 
+// sorted variant: a uniformly spaced, jittered, INCREASING index list (what sorting a uniform random id set gives)
+__global__ void fill_idx_sorted(uint32_t* idx, int64_t n, uint32_t mod, uint64_t seed) {
+    const double stride = (double)mod / (double)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t base = (uint32_t)(i * stride);
+        const uint32_t jit = (uint32_t)(mix(i * 0x9E3779B97F4A7C15ULL + seed) % (uint32_t)(stride < 1 ? 1 : stride));
+        idx[i] = base + jit < mod ? base + jit : mod - 1;
+    }
+}
+
 template <typename F> static double timeit(F f, int iters = 30) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (int i = 0; i < 5; ++i) f(i);
@@ -134,6 +144,17 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(fill_idx, dim3(1024), dim3(256), 0, 0, idx, nrows * NB, (uint32_t)(TAB_BYTES / RB), 7ULL); \
         double us = timeit([&](int i) { hipLaunchKernelGGL((rd_rows<RB / 16, NT, UF>), dim3(grids[gi]), dim3(256), 0, 0, tab, idx + (i % NB) * nrows, nrows, sink); }); \
         report(NAME, grids[gi], us, (double)ROW_BYTES_TOTAL + nrows * 4);                                 \
+    }
+    if (getenv("MEMPROBE_SORTED")) {   // random rows visited in increasing address order (per launch): is the request ceiling a DRAM-page effect?
+        for (int gi = 1; gi < 3; ++gi) {
+            const int64_t nrows = ROW_BYTES_TOTAL / 64;
+            for (int b = 0; b < NB; ++b)
+                hipLaunchKernelGGL(fill_idx_sorted, dim3(1024), dim3(256), 0, 0, idx + b * nrows, nrows, (uint32_t)(TAB_BYTES / 64), 7ULL + b);
+            double us = timeit([&](int i) { hipLaunchKernelGGL((rd_rows<4, false, 8>), dim3(grids[gi]), dim3(256), 0, 0, tab, idx + (i % NB) * nrows, nrows, sink); });
+            report("R64sorted", grids[gi], us, (double)ROW_BYTES_TOTAL + nrows * 4);
+            us = timeit([&](int i) { hipLaunchKernelGGL((rd_rows<4, true, 8>), dim3(grids[gi]), dim3(256), 0, 0, tab, idx + (i % NB) * nrows, nrows, sink); });
+            report("R64sortNT", grids[gi], us, (double)ROW_BYTES_TOTAL + nrows * 4);
+        }
     }
     RUN_RD(64, false, 8, "R64");
     RUN_RD(64, true, 8, "R64nt");
