@@ -7,9 +7,9 @@
 // M = batch rows (65 536), Kd and N a few hundred: too skinny for the library's tiles (rocBLAS picks 32x256 macro tiles and
 // reaches 0.56 of the fp32 MFMA peak at 65 536 x 416 x 400, with the activation as a second pass over Y).  Here a 256-thread
 // workgroup owns a 128 x NT tile of Y (NT = 80 divides the 400-wide layers exactly; 128 otherwise); wave w owns rows
-// [32w, 32w+32) x all NT columns as 2 x NT/16 accumulators of v_mfma_f32_16x16x4_f32.  X and Wt stream through LDS in 32-wide
+// [32w, 32w+32) x all NT columns as 2 x NT/16 accumulators of v_mfma_f32_16x16x4_f32.  X and Wt stream through LDS in 16- or 32-wide
 // k chunks, double-buffered (the next chunk's global loads are issued before the current chunk's MFMAs, stored after them: one
-// barrier per chunk).  Both operands are k-contiguous in LDS (row stride 36 words: the sixteen rows of a 16-byte fragment read
+// barrier per chunk).  Both operands are k-contiguous in LDS (row stride chunk + 4 words: the sixteen rows of a 16-byte fragment read
 // land in sixteen different bank quads), so a lane's four k-steps come from ONE ds_read_b128: 14 LDS reads per 80 MFMAs at
 // NT = 80.  Bias and ReLU are applied to the accumulators.  Workgroup ids are remapped so that the N-blocks of one row block run
 // on the same XCD (they share the X tile through that XCD's L2).
@@ -27,17 +27,17 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t l
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-constexpr int DN_KC = 32;           // k chunk
-constexpr int DN_LS = DN_KC + 4;    // LDS row stride (floats)
 constexpr int DN_MT = 128;          // rows per workgroup
 
-template <int NT, bool RELU>
-__global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, int64_t x_ld, const float* __restrict__ Wt,
+template <int NT, bool RELU, int KC>
+__global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __restrict__ X, int64_t x_ld, const float* __restrict__ Wt,
                                                     int64_t w_ld, const float* __restrict__ bias, int64_t M, int Kd, int N,
                                                     float* __restrict__ Y, int64_t y_ld, int nb, int remap, int vec_out,
                                                     const float* __restrict__ gate, int64_t gate_ld) {
     constexpr int NTILES = NT / 16;
-    constexpr int BJ = (NT * 8 + 255) / 256;
+    constexpr int DN_KC = KC, DN_LS = KC + 4;      // k chunk, LDS row stride (floats)
+    constexpr int TPR = KC / 4;                    // threads (16-byte pieces) per staged row
+    constexpr int AJ = DN_MT * TPR / 256, BJ = (NT * TPR + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float dense_smem[];
     float (*As)[DN_MT * DN_LS] = reinterpret_cast<float (*)[DN_MT * DN_LS]>(dense_smem);
     float (*Bs)[NT * DN_LS] = reinterpret_cast<float (*)[NT * DN_LS]>(dense_smem + 2 * DN_MT * DN_LS);
@@ -54,51 +54,51 @@ __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, i
     // results are dropped by the epilogue), so the full chunks need no predicate; only a k tail (Kd % 32) is masked.
     // Staging: thread <-> (row, 16-byte column c) of the k chunk, as buffer loads: address = resource base + per-lane byte offset
     // (fixed for the whole kernel) + wave-uniform k offset in an SGPR -- no address arithmetic on the VALU, which fp32 MFMAs do
-    // not hide -- and rows beyond M / N read as zeros through the resource's range check.  Only a k tail (Kd % 32) is masked.
+    // not hide -- and rows beyond M / N read as zeros through the resource's range check.  Only a k tail (Kd % KC) is masked.
     const int64_t rows_x = (M - m0) < DN_MT ? (M - m0) : DN_MT;
     const int rows_w = (N - n0) < NT ? (N - n0) : NT;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + m0 * x_ld), 0,
                                                                         (int)(uint32_t)(((rows_x - 1) * x_ld + Kd) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt + (int64_t)n0 * w_ld), 0,
                                                                         (int)(uint32_t)((((int64_t)rows_w - 1) * w_ld + Kd) * 4), 0x00020000);
-    uint32_t xo[4], wo[BJ];
+    uint32_t xo[AJ], wo[BJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+    for (int j = 0; j < AJ; ++j) {
+        const int i = tid + 256 * j, row = i / TPR, c = i % TPR;
         xo[j] = (uint32_t)((row * x_ld + 4 * c) * 4);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+        const int i = tid + 256 * j, row = i / TPR, c = i % TPR;
         wo[j] = row < NT ? (uint32_t)((row * w_ld + 4 * c) * 4) : 0xfffffff0u;
     }
     const int nfull = Kd / DN_KC;
     const int nchunks = (Kd + DN_KC - 1) / DN_KC;
-    float4 ar[4], br[BJ];
+    float4 ar[AJ], br[BJ];
     auto gload_full = [&](int ch) {
         const uint32_t kb = (uint32_t)(ch * DN_KC * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ar[j] = buf_load4(rx, xo[j], kb);
+        for (int j = 0; j < AJ; ++j) ar[j] = buf_load4(rx, xo[j], kb);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) br[j] = buf_load4(rw, wo[j], kb);
     };
     auto gload_masked = [&](int ch) {                      // any chunk; lanes past Kd get an out-of-range offset (-> zeros)
         const uint32_t kb = (uint32_t)(ch * DN_KC * 4);
-        const uint32_t big = (ch * DN_KC + 4 * (tid & 7) < Kd) ? 0u : 0xfffffff0u;
+        const uint32_t big = (ch * DN_KC + 4 * (tid % TPR) < Kd) ? 0u : 0xfffffff0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ar[j] = buf_load4(rx, xo[j] | big, kb);
+        for (int j = 0; j < AJ; ++j) ar[j] = buf_load4(rx, xo[j] | big, kb);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) br[j] = buf_load4(rw, wo[j] | big, kb);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+        for (int j = 0; j < AJ; ++j) {
+            const int i = tid + 256 * j, row = i / TPR, c = i % TPR;
             *reinterpret_cast<float4*>(&As[buf][row * DN_LS + 4 * c]) = ar[j];
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            const int i = tid + 256 * j, row = i >> 3, c = i & 7;
+            const int i = tid + 256 * j, row = i / TPR, c = i % TPR;
             if (row < NT) *reinterpret_cast<float4*>(&Bs[buf][row * DN_LS + 4 * c]) = br[j];
         }
     };
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, i
         for (int nt = 0; nt < NTILES; ++nt) acc[mt][nt] = (f32x4d){0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
-        const float* ab = &As[buf][(32 * w + r16) * DN_LS + kk * 8];
-        const float* bb = &Bs[buf][r16 * DN_LS + kk * 8];
+        const float* ab = &As[buf][(32 * w + r16) * DN_LS + kk * (KC / 4)];
+        const float* bb = &Bs[buf][r16 * DN_LS + kk * (KC / 4)];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < KC / 16; ++q) {
             const float4 a0 = *reinterpret_cast<const float4*>(ab + 4 * q);
             const float4 a1 = *reinterpret_cast<const float4*>(ab + 16 * DN_LS + 4 * q);
             const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void dense_k(const float* __restrict__ X, i
     }
 }
 
-template <int NT>
+template <int NT, int KC>
 static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M,
                          int Kd, int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld) {
     const int nb = (N + NT - 1) / NT;
@@ -241,17 +241,19 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
     const int64_t total = mb * nb;
     const int remap = (total % kXCDs) == 0 ? 1 : 0;
     const int vec_out = ((N & 3) == 0 && (y_ld & 3) == 0 && aligned16(Y) && (!gate || ((gate_ld & 3) == 0 && aligned16(gate)))) ? 1 : 0;
-    const size_t shmem = sizeof(float) * 2 * (DN_MT + NT) * DN_LS;      // 60 KB (NT = 80) / 74 KB (NT = 128): two workgroups per CU
+    size_t shmem = sizeof(float) * 2 * (DN_MT + NT) * (KC + 4);       // 60 KB (NT = 80) / 74 KB (NT = 128) at KC = 32
+    const size_t ep_bytes = sizeof(float) * 4 * 32 * (NT + 4);             // the epilogue's row staging
+    if (shmem < ep_bytes) shmem = ep_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, true, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, false, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr_set = true;
     }
     if (act)
-        hipLaunchKernelGGL((dense_k<NT, true>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
+        hipLaunchKernelGGL((dense_k<NT, true, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
     else
-        hipLaunchKernelGGL((dense_k<NT, false>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
+        hipLaunchKernelGGL((dense_k<NT, false, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
 }
 
 }  // namespace dir
@@ -271,10 +273,17 @@ static int dense_entry(const char* name, const float* X, int64_t x_ld, const flo
     const int64_t mb = (M + DN_MT - 1) / DN_MT;
     if (mb * ((N + 79) / 80) > 0x7fffffffLL) return fail(DIR_E_UNSUPPORTED, "%s: M=%lld too large", name, (long long)M);
     hipStream_t st = as_stream(stream);
-    if (N % 80 == 0 && N % 128 != 0)
-        launch_dense<80>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
-    else
-        launch_dense<128>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+    // k chunk: 16 for the 80-column tiles (33 KB of LDS per workgroup: four workgroups per CU hide the per-chunk latencies; 0.77 vs
+    // 0.72-0.74 of peak at 400-wide layers, and 400 = 25 x 16 has no k tail), 32 for the 128-column tiles (0.82 vs 0.80 at 1024 x 1024).
+    // DIR_DENSE_KC = 16 / 32 forces one (tools/dense_sweep.py).
+    static const int kc_env = getenv("DIR_DENSE_KC") ? atoi(getenv("DIR_DENSE_KC")) : 0;
+    if (N % 80 == 0 && N % 128 != 0) {
+        if (kc_env == 32) launch_dense<80, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+        else launch_dense<80, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+    } else {
+        if (kc_env == 16) launch_dense<128, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+        else launch_dense<128, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+    }
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
