@@ -162,23 +162,10 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
     // as whole rows, 16 bytes per lane -- 4-byte stores in 64-byte pieces made the Y write the largest fixed cost of a tile.
     if (vec_out) {
         constexpr int EPS = NT + 4;
-        float* ep = dense_smem + w * (32 * EPS);
-#pragma unroll
-        for (int nt = 0; nt < NTILES; ++nt) {
-            const int col = n0 + 16 * nt + r16;
-            const float bcol = (bias && col < N) ? bias[col] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v = acc[mt][nt][g] + bcol;
-                    if (RELU) v = fmaxf(v, 0.f);
-                    ep[(16 * mt + 4 * kk + g) * EPS + 16 * nt + r16] = v;
-                }
-        }
-        // Rows leave through buffer stores: resource = this wave's 32 rows of Y, lane
-        // offset fixed per pass (rows past M and columns past N get an out-of-range offset and are dropped), row-group offset in an SGPR -- no 64-bit address arithmetic and no integer division in the loop
-        // (the previous form spent 470 VALU instructions per tile here, 12 % of the tile's MFMA time).  A row's NT/4 16-byte pieces
+        float* ep = dense_smem + w * (16 * EPS);                   // 16 rows at a time: the staging fits the smallest operand image
+        // Rows leave through buffer stores: resource = this wave's 32 rows of Y, lane offset fixed per pass (rows past M and columns
+        // past N get an out-of-range offset and are dropped), row-group offset in an SGPR -- no 64-bit address arithmetic and no
+        // integer division in the loop (the previous form spent 470 VALU instructions per tile here).  A row's NT/4 16-byte pieces
         // are covered as whole groups of 16 lanes (pass A: lanes <-> 4 rows x 16 pieces) plus, for NT = 80, the last 4 pieces
         // (pass B: lanes <-> 16 rows x 4 pieces).
         const int64_t wrow0 = m0 + 32 * w;
@@ -188,8 +175,8 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
                                                                             (int)(uint32_t)(((wrows - 1) * y_ld + (N - n0)) * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gate ? gate + wrow0 * gate_ld + n0 : Y), 0,
                                                                             gate ? (int)(uint32_t)(((wrows - 1) * gate_ld + (N - n0)) * 4) : 0, 0x00020000);
-        auto put = [&](int lrow, int c4, int srow) {               // local row = lrow + srow (srow wave-uniform), 16-byte piece c4
-            float4 v = *reinterpret_cast<const float4*>(ep + (lrow + srow) * EPS + 4 * c4);
+        auto put = [&](int lrow, int c4, int srow) {               // row srow + lrow of the wave's block (srow wave-uniform), 16-byte piece c4
+            float4 v = *reinterpret_cast<const float4*>(ep + (lrow + (srow & 15)) * EPS + 4 * c4);
             const bool ok = (n0 + 4 * c4 < N) && (lrow + srow < (int)wrows);   // explicit: the SGPR part of the offset is not relied on for range checks
             if (gate) {      // backward through the previous layer's ReLU: pass the value where that layer's output was positive
                 const float4 gt = buf_load4(rg, ok ? (uint32_t)((lrow * gate_ld + 4 * c4) * 4) : 0xfffffff0u, (uint32_t)(srow * gate_ld * 4));
@@ -205,12 +192,23 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
         constexpr int C4 = NT / 4, FULL = C4 / 16, REST = C4 % 16;
         static_assert(REST == 0 || REST == 4, "NT/4 must be a multiple of 16, or 4 more");
 #pragma unroll
-        for (int cb = 0; cb < FULL; ++cb)
+        for (int mt = 0; mt < 2; ++mt) {       // (a wave's LDS operations execute in order: the second half's writes follow the first half's reads)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) put(lane >> 4, 16 * cb + (lane & 15), 4 * i);
-        if (REST == 4) {
+            for (int nt = 0; nt < NTILES; ++nt) {
+                const int col = n0 + 16 * nt + r16;
+                const float bcol = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) put(lane >> 2, 16 * FULL + (lane & 3), 16 * i);
+                for (int g = 0; g < 4; ++g) {
+                    float v = acc[mt][nt][g] + bcol;
+                    if (RELU) v = fmaxf(v, 0.f);
+                    ep[(4 * kk + g) * EPS + 16 * nt + r16] = v;
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < FULL; ++cb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) put(lane >> 4, 16 * cb + (lane & 15), 16 * mt + 4 * i);
+            if (REST == 4) put(lane >> 2, 16 * FULL + (lane & 3), 16 * mt);
         }
         return;
     }
@@ -242,7 +240,7 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
     const int remap = (total % kXCDs) == 0 ? 1 : 0;
     const int vec_out = ((N & 3) == 0 && (y_ld & 3) == 0 && aligned16(Y) && (!gate || ((gate_ld & 3) == 0 && aligned16(gate)))) ? 1 : 0;
     size_t shmem = sizeof(float) * 2 * (DN_MT + NT) * (KC + 4);       // 60 KB (NT = 80) / 74 KB (NT = 128) at KC = 32
-    const size_t ep_bytes = sizeof(float) * 4 * 32 * (NT + 4);             // the epilogue's row staging
+    const size_t ep_bytes = sizeof(float) * 4 * 16 * (NT + 4);             // the epilogue's row staging (16 rows per wave at a time)
     if (shmem < ep_bytes) shmem = ep_bytes;
     static bool attr_set = false;
     if (!attr_set) {
@@ -273,16 +271,16 @@ static int dense_entry(const char* name, const float* X, int64_t x_ld, const flo
     const int64_t mb = (M + DN_MT - 1) / DN_MT;
     if (mb * ((N + 79) / 80) > 0x7fffffffLL) return fail(DIR_E_UNSUPPORTED, "%s: M=%lld too large", name, (long long)M);
     hipStream_t st = as_stream(stream);
-    // k chunk: 16 for the 80-column tiles (33 KB of LDS per workgroup: four workgroups per CU hide the per-chunk latencies; 0.77 vs
-    // 0.72-0.74 of peak at 400-wide layers, and 400 = 25 x 16 has no k tail), 32 for the 128-column tiles (0.82 vs 0.80 at 1024 x 1024).
-    // DIR_DENSE_KC = 16 / 32 forces one (tools/dense_sweep.py).
-    static const int kc_env = getenv("DIR_DENSE_KC") ? atoi(getenv("DIR_DENSE_KC")) : 0;
+    // k chunk 16: 33 KB (NT = 80) / 41 KB (NT = 128) of LDS per workgroup, so four / three workgroups share a CU and hide each other's
+    // per-chunk latencies: 0.80 vs 0.72 of the fp32 MFMA peak at 400-wide layers, 0.89 vs 0.81 at 1024 x 1024 (32-wide chunks: two
+    // workgroups per CU).  DIR_DENSE_KC = 32 selects the wide chunks (tools/dense_sweep.py).
+    static const int kc_env = getenv("DIR_DENSE_KC") ? atoi(getenv("DIR_DENSE_KC")) : 16;
     if (N % 80 == 0 && N % 128 != 0) {
         if (kc_env == 32) launch_dense<80, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
         else launch_dense<80, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
     } else {
-        if (kc_env == 16) launch_dense<128, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
-        else launch_dense<128, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+        if (kc_env == 32) launch_dense<128, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+        else launch_dense<128, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
     }
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
