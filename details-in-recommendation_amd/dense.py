@@ -3,8 +3,9 @@
 Mirrors tf.layers.dense(units, activation) as the reference uses it (dnn_logit_fn, models/DeepFM/deepFM.py:295-300;
 _deep_architecture, models/DeepCrossNetwork/DeepCrossNetwork.py:394-399; _base_model, models/ESMM/ESMM.py:139-142): matmul +
 bias + activation, here in ONE pass (bias and ReLU on the MFMA accumulators).  `dense_act(lin, x, activation)` is what the
-models call: the kernel when it covers the layer (CUDA fp32, in_features % 4 == 0, >= 16 units, activation ReLU or none),
-`activation(lin(x))` otherwise (the units = 1 logit layers are matrix-vector products and stay library code).
+models call: the kernel when it covers the layer (CUDA fp32, >= 16 units, activation ReLU or none, at least MIN_ROWS rows; an
+in_features that is not a multiple of 4 is zero-padded), `activation(lin(x))` otherwise (the units = 1 logit layers are
+matrix-vector products: library forward, elementwise backward).
 
 Weight rows are handed to the kernel with a stride that is a multiple of 64 floats: a 416-float stride (1 664 bytes, the first
 DeepFM / DCN layer) costs the kernel -- and rocBLAS -- 20 % (tools/dense_sweep.py); the padded copy is 640 KB per layer.
@@ -56,6 +57,19 @@ def _tn_matmul(g, x, splits=16):
     if M >= 8192 and M % splits == 0 and g.is_contiguous() and x.is_contiguous():
         return torch.bmm(g.view(splits, M // splits, -1).transpose(1, 2), x.view(splits, M // splits, -1)).sum(dim=0)
     return g.t() @ x
+
+
+def _packed_cached_padded(weight, pad):
+    """Inference: the weight with `pad` zero input columns appended, packed; cached like _packed_cached."""
+    key = (id(weight), pad)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+    packed = pack_weight(F.pad(weight.detach(), (0, pad)))
+    if len(_PACK_CACHE) > 256:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (weight, weight._version, weight.data_ptr(), packed)
+    return packed
 
 
 class _DenseFn(torch.autograd.Function):
@@ -183,9 +197,19 @@ def units1(lin, x):
 def dense_act(lin, x, activation=None):
     """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered."""
     relu = activation in _RELUS
-    if (activation is None or relu) and x.shape[0] >= MIN_ROWS and ops.dense_supported(x, lin.weight):
-        if torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
-            return _DenseFn.apply(x, lin.weight, lin.bias, relu)
-        return ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu)
+    if (activation is None or relu) and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and lin.out_features >= 16:
+        train = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
+        pad = (-x.shape[1]) % 4
+        if pad and x.dtype == torch.float32:
+            # in_features not a multiple of 4 (DCN's 429-wide first layer: 26 x 16 + 13 numeric columns): zero-pad x and the weight
+            # to the next multiple of 4 -- one [B, in] copy (45 us at 65 536 x 429) against 200 us saved on the GEMM
+            xp = F.pad(x, (0, pad))
+            if train:
+                return _DenseFn.apply(xp, F.pad(lin.weight, (0, pad)), lin.bias, relu)     # pad's backward slices the gradients back
+            return ops.dense(xp, _packed_cached_padded(lin.weight, pad), lin.bias, relu=relu)
+        if ops.dense_supported(x, lin.weight):
+            if train:
+                return _DenseFn.apply(x, lin.weight, lin.bias, relu)
+            return ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu)
     y = lin(x)
     return activation(y) if activation is not None else y

@@ -737,3 +737,29 @@ def test_mlp_stack_matches_float64(built_lib, dims):
     assert not D.mlp_stack_supported(lins, x, torch.tanh)
     with torch.no_grad():
         assert not D.mlp_stack_supported(lins, x, torch.relu)
+
+
+def test_dense_act_pads_odd_input_width(built_lib):
+    """dense.dense_act with in_features % 4 != 0 (DCN's 429-wide first layer): zero-padded onto the HIP kernel, forward and
+    gradients equal to nn.Linear + ReLU in float64."""
+    from dir_amd import dense as D
+    g = torch.Generator().manual_seed(9)
+    M, Kd, N = 200, 429, 64
+    lin = torch.nn.Linear(Kd, N).cuda()
+    x = torch.randn(M, Kd, generator=g).cuda().requires_grad_(True)
+    gout = torch.randn(M, N, generator=g).cuda()
+    y = D.dense_act(lin, x, torch.relu)
+    y.backward(gout)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = lin.weight.detach().double().cpu().requires_grad_(True)
+    b64 = lin.bias.detach().double().cpu().requires_grad_(True)
+    ref = torch.relu(x64 @ w64.t() + b64)
+    ref.backward(gout.double().cpu())
+    _close(y, ref, tol=1e-5)
+    _close(x.grad, x64.grad, tol=2e-5)
+    assert lin.weight.grad.shape == (N, Kd)
+    assert float((lin.weight.grad.double().cpu() - w64.grad).abs().max()) <= 2e-5 * (1 + float(w64.grad.abs().max()))
+    assert float((lin.bias.grad.double().cpu() - b64.grad).abs().max()) <= 2e-5 * (1 + float(b64.grad.abs().max()))
+    with torch.no_grad():
+        y2 = D.dense_act(lin, x.detach(), torch.relu)
+    assert torch.equal(y2, y.detach())
