@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "dcn_cross_backward", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
-                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense", "esmm_full", "esmm_train"])
+                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense", "esmm_full", "esmm_train", "deepfm_full_packed"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -201,7 +201,7 @@ def main():
     units = B
     cfg = {"workload": wl, "batch": B}
 
-    if wl in ("deepfm_gather_fm", "gather_only", "fm_only", "linear", "deepfm_full"):
+    if wl in ("deepfm_gather_fm", "gather_only", "fm_only", "linear", "deepfm_full", "deepfm_full_packed"):
         sigma = 1.0 / (K ** 0.5)  # [TF-upstream] embedding_column default initializer stddev
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "id_layout": args.id_layout})
         if world == 1:
@@ -232,12 +232,14 @@ def main():
                 step = lambda i: ops.linear_logit(wts, idsl[i % len(idsl)], bias=bias, out=fm)  # noqa: E731
                 alg = B * (F * (8 + 4) + 4)
                 kname = "linear_onehot_k"
-            else:  # deepfm_full: the whole DeepFM forward (gather+FM, linear term, 400-400-400 MLP via rocBLAS)
+            else:  # deepfm_full[_packed]: the whole DeepFM forward (gather+FM, linear term, 400-400-400 tower on dir_dense_f32)
                 from dir_amd.deepfm import DeepFM
                 from dir_amd import feature_column as fc
                 cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
                 model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
                                dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
+                if wl == "deepfm_full_packed":      # serving layout: one 128-byte row per feature value (embedding + first-order weight)
+                    model.pack_for_serving()
                 with torch.no_grad():
                     step = lambda i: model.forward_ids(idsl[i % len(idsl)], idsl[i % len(idsl)])  # noqa: E731
                 alg = B * (F * (8 + 2 * 4 * K) + 4)
