@@ -5,7 +5,7 @@ Mirrors models/DeepCrossNetwork/DeepCrossNetwork.py (reference):
   _dcn_logit_fn_builder / dcn_logits_fn                    :118-141
   input_layer (columns concatenated SORTED BY NAME [TF-upstream])   :126   -> ops.embedding_bag into x0
   _cross_architecture / _cross_op                          :336-367      -> ops.cross_network (one launch)
-  _deep_architecture (dense(act) -> BN on all but last)    :370-410      -> torch linear (rocBLAS)
+  _deep_architecture (dense(act) -> BN on all but last)    :370-410      -> dense.dense_act (dir_dense_f32)
   concat + dense(1)                                        :134-139
   predictions                                              :153-165
 """

@@ -5,7 +5,7 @@ Mirrors models/DeepFM/deepFM.py (reference):
   _DeepFM_model_fn: inputs -> dnn_fm logits + linear      :143-223
   myself_input_layer (one shared embedding set)           :363-400   -> ops.gather_fm / embedding_bag
   fm_logit_fn                                             :321-335   -> fused in ops.gather_fm
-  dnn_logit_fn                                            :284-319   -> torch linear (rocBLAS) + BN
+  dnn_logit_fn                                            :284-319   -> dense.dense_act (dir_dense_f32) + BN
   _linear_logit_fn_builder                                :255-275   -> ops.linear_logit
   head predictions (sigmoid / [1-p, p] / class_ids)       :107-117 + [TF-upstream] binary head
 Training-only kwargs (optimizers, loss_reduction, warm_start_from, config, model_dir ...) are accepted
