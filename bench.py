@@ -681,8 +681,12 @@ def main():
                 return
             if rank == 0:
                 sys.stderr.write("bench.py: the config-5 secondary leg timed out; printing the primary line only\n")
-                print(json.dumps(primary_line(args, wl, cfg, roof, units, world, primary["el"], primary["dev_ms"], None, None)), flush=True)
-            os._exit(0)
+                line = primary_line(args, wl, cfg, roof, units, world, primary["el"], primary["dev_ms"], None, None)
+                line["secondary_cfg5_xdeepfm_cin"] = {"error": "timeout"}      # the hang is recorded in the line itself
+                print(json.dumps(line), flush=True)
+            # the primary measurement above is complete and valid; the optional leg hung.  Exit code 0 keeps the primary record,
+            # DIR_BENCH_SECONDARY_STRICT=1 turns the hang into exit code 3 on every rank.
+            os._exit(3 if os.environ.get("DIR_BENCH_SECONDARY_STRICT") == "1" else 0)
         timer = threading.Timer(float(os.environ.get("DIR_BENCH_SECONDARY_TIMEOUT", "240")), bail)
         timer.daemon = True
         timer.start()

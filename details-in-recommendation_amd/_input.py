@@ -5,7 +5,11 @@ transposed VIEW keeps the C ABI's (stride_b, stride_f) = (1, B) without a second
 column is Ragged (multi-hot), every column is expressed as CSR and concatenated field-major
 (bag(b, f) = f*B + b), which is exactly what per-column SparseTensors concatenate to.
 """
+import os
+
 import torch
+
+CHECK_IDS = os.environ.get("DIR_CHECK_IDS", "1") != "0"
 
 
 def categorical_of(col):
@@ -16,10 +20,46 @@ def categorical_of(col):
     return col
 
 
+def _range_checked(cats):
+    """(indices, num_buckets) of the columns whose ids TensorFlow range-checks: categorical_column_with_identity without a
+    default_value asserts 0 <= id < num_buckets on the sparse values ([TF-upstream] _IdentityCategoricalColumn; a dense -1
+    is the 'missing' marker and is dropped before the check).  Hash / vocabulary / bucketized ids are in range by construction."""
+    idx = [i for i, c in enumerate(cats) if getattr(c, "range_checked", False)]
+    return idx, [cats[i].num_buckets for i in idx]
+
+
+def check_id_range(cats, got, device):
+    """Raise like TF's InvalidArgumentError when an identity column (default_value=None) is fed an id outside [0, num_buckets)
+    (-1 = missing is allowed).  One fused comparison and ONE host read for all columns; DIR_CHECK_IDS=0 skips it (the kernels
+    then treat such ids as pruned: they never read or write outside a table)."""
+    if not CHECK_IDS:
+        return
+    idx, nb = _range_checked(cats)
+    if not idx:
+        return
+    vals = [got[i][0] if isinstance(got[i], tuple) else got[i] for i in idx]
+    sizes = [int(v.numel()) for v in vals]
+    flat = torch.cat([v.reshape(-1) for v in vals])
+    bound = torch.repeat_interleave(torch.tensor(nb, dtype=torch.int64, device=device),
+                                    torch.tensor(sizes, dtype=torch.int64, device=device), output_size=sum(sizes))
+    bad = ((flat >= bound) | (flat < -1))
+    if bool(bad.any()):
+        pos = int(bad.nonzero()[0])
+        k = 0
+        while pos >= sizes[k]:
+            pos -= sizes[k]
+            k += 1
+        c = cats[idx[k]]
+        raise ValueError("categorical_column_with_identity %r: id %d is outside [0, num_buckets=%d) and no default_value is set"
+                         % (c.key, int(vals[k].reshape(-1)[pos]), c.num_buckets))
+
+
 def collect_ids(columns, features, device):
     """columns: categorical columns (or embedding/indicator wrappers).
     -> ("onehot", ids_view [B,F])  or  ("ragged", values, offsets [F*B+1], weights|None, B)"""
-    got = [categorical_of(c).ids(features, device) for c in columns]
+    cats = [categorical_of(c) for c in columns]
+    got = [c.ids(features, device) for c in cats]
+    check_id_range(cats, got, device)
     if all(not isinstance(g, tuple) for g in got):
         B = got[0].numel()
         for g in got:

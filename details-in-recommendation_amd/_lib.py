@@ -17,12 +17,14 @@ SIGNATURES = {
     "dir_last_error": (ctypes.c_char_p, []),
     "dir_embedding_bag_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i64,
                                       c_vp, c_i64, c_vp]),
+    "dir_embedding_bag_ex_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, ctypes.c_float, c_i32,
+                                         c_i64, c_vp, c_i64, c_vp]),
     "dir_check_ids": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "dir_fm_second_order_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
-    "dir_gather_fm_fused_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),
-    "dir_gather_fm_linear_packed_f32": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64,
+    "dir_gather_fm_fused_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dir_gather_fm_linear_packed_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64,
                                                 c_vp, c_vp, c_vp, c_vp]),
-    "dir_linear_sparse_sum_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64,
+    "dir_linear_sparse_sum_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64,
                                           c_vp, c_vp]),
     "dir_dcn_cross_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "dir_dcn_cross_op_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
@@ -39,7 +41,7 @@ SIGNATURES = {
     "dir_dcn_cross_backward_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp,
                                            c_vp, c_vp]),
     "dir_sparse_adagrad_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.c_float, c_i64, c_vp,
-                                       c_vp, c_vp, c_vp]),
+                                       c_i64, c_vp, c_vp, c_vp]),
     "dir_sparse_adagrad_sorted_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i64]),
     "dir_sparse_adagrad_sorted_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.c_float, c_i64,
                                               c_vp, c_i64, c_vp, c_i64, c_vp]),

@@ -54,17 +54,27 @@ class GatherFm(torch.autograd.Function):
             return (None, None) + (None,) * F
         grads = []
         for f in range(F):
-            grads.append(_sparse_rows(ids[:, f].contiguous(), demb[:, f * K:(f + 1) * K], ts.vocab[f]))
+            grads.append(_sparse_rows(_in_range(ids[:, f].contiguous(), ts.vocab[f]), demb[:, f * K:(f + 1) * K], ts.vocab[f]))
         return (None, None) + tuple(grads)
 
 
+def _clip_backward(rows, g, max_norm):
+    """Gradient through [TF-upstream] clip_by_norm: y = r * m / max(||r||, m).  ||r|| <= m: y = r (dy/dr = I);
+    otherwise y = m r / ||r||  ->  dL/dr = m (g / ||r|| - r (r . g) / ||r||^3)."""
+    n = rows.norm(dim=1, keepdim=True)
+    big = n > max_norm
+    nn_ = n.clamp_min(1e-30)
+    gc = max_norm * (g / nn_ - rows * ((rows * g).sum(dim=1, keepdim=True) / (nn_ * nn_ * nn_)))
+    return torch.where(big, gc, g)
+
+
 class EmbeddingBag(torch.autograd.Function):
-    """One-hot or multi-hot embedding bag (any combiner) with sparse table gradients."""
+    """One-hot or multi-hot embedding bag (one combiner, or one per slot; optional max_norm) with sparse table gradients."""
 
     @staticmethod
-    def forward(ctx, ts, ids, offsets, weights, combiner, field_major, out, *tables):
-        res = ops.embedding_bag(ts, ids, offsets, weights, combiner=combiner, field_major=field_major, out=out)
-        ctx.ts, ctx.combiner, ctx.field_major = ts, combiner, field_major
+    def forward(ctx, ts, ids, offsets, weights, combiner, field_major, out, max_norm, *tables):
+        res = ops.embedding_bag(ts, ids, offsets, weights, combiner=combiner, field_major=field_major, out=out, max_norm=max_norm)
+        ctx.ts, ctx.combiner, ctx.field_major, ctx.max_norm = ts, combiner, field_major, max_norm
         ctx.save_for_backward(ids, offsets if offsets is not None else torch.empty(0), weights if weights is not None else torch.empty(0))
         ctx.has_offsets, ctx.has_weights = offsets is not None, weights is not None
         return res
@@ -76,39 +86,51 @@ class EmbeddingBag(torch.autograd.Function):
         F, K = ts.F, ts.K
         g = g.contiguous() if g.stride(1) == 1 else g.clone()
         grads = []
-        if not ctx.has_offsets and ts.grad_sink is not None:     # fused optimiser attached (ops.SparseAdagrad.attach): no table .grad
+        nfix = 8
+        if not ctx.has_offsets and ts.grad_sink is not None and not ctx.max_norm:   # fused optimiser attached (ops.SparseAdagrad.attach): no table .grad
             ts.grad_sink(ids, g)
-            return (None,) * (7 + F)
+            return (None,) * (nfix + F)
         if not ctx.has_offsets:
             for f in range(F):
-                grads.append(_sparse_rows(ids[:, f].contiguous(), g[:, f * K:(f + 1) * K], ts.vocab[f]))
+                idf, gf = ids[:, f].contiguous(), g[:, f * K:(f + 1) * K]
+                if ctx.max_norm:
+                    gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(ctx.max_norm))
+                grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf, ts.vocab[f]))
         else:
             B = (offsets.numel() - 1) // F
             lens = offsets[1:] - offsets[:-1]
             bag_of = torch.repeat_interleave(torch.arange(B * F, device=ids.device), lens)
-            w = weights if ctx.has_weights else torch.ones(ids.numel(), dtype=torch.float32, device=ids.device)
-            valid = (ids >= 0).to(torch.float32)
-            wv = w * valid
-            comb = ops._COMBINERS[ctx.combiner]
-            if comb == ops.SUM:
-                coef = wv
-            else:
-                den = torch.zeros(B * F, dtype=torch.float32, device=ids.device)
-                if comb == ops.MEAN:
-                    den.index_add_(0, bag_of, wv if ctx.has_weights else valid)
-                else:
-                    den.index_add_(0, bag_of, (wv * wv) if ctx.has_weights else valid)
-                    den = den.sqrt()
-                coef = wv / den.clamp_min(1e-30)[bag_of]
             if ctx.field_major:
                 f_of, b_of = bag_of // B, bag_of % B
             else:
                 b_of, f_of = bag_of // F, bag_of % F
+            vocab_e = ts.vocab_dev[f_of]
+            w = weights if ctx.has_weights else torch.ones(ids.numel(), dtype=torch.float32, device=ids.device)
+            valid = ((ids >= 0) & (ids < vocab_e)).to(torch.float32)
+            wv = w * valid
+            slot, comb0 = ops.slot_combiners(ts, ctx.combiner)
+            den_mean = torch.zeros(B * F, dtype=torch.float32, device=ids.device).index_add_(0, bag_of, wv if ctx.has_weights else valid)
+            den_sqrt = torch.zeros(B * F, dtype=torch.float32, device=ids.device).index_add_(0, bag_of, (wv * wv) if ctx.has_weights else valid).sqrt()
+            if slot is None:
+                den = den_mean if comb0 == ops.MEAN else den_sqrt if comb0 == ops.SQRTN else torch.ones_like(den_mean)
+            else:
+                fb = (torch.arange(B * F, device=ids.device) // B) if ctx.field_major else (torch.arange(B * F, device=ids.device) % F)
+                code = slot.to(torch.int64)[fb]
+                den = torch.where(code == ops.MEAN, den_mean, torch.where(code == ops.SQRTN, den_sqrt, torch.ones_like(den_mean)))
+            coef = wv / den.clamp_min(1e-30)[bag_of]
             gv = g.view(B, F, K)[b_of, f_of] * coef.unsqueeze(1)
             for f in range(F):
                 sel = f_of == f
-                grads.append(_sparse_rows(ids[sel], gv[sel], ts.vocab[f]))
-        return (None, None, None, None, None, None, None) + tuple(grads)
+                idf, gf = ids[sel], gv[sel]
+                if ctx.max_norm:
+                    gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(ctx.max_norm))
+                grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf, ts.vocab[f]))
+        return (None,) * nfix + tuple(grads)
+
+
+def _in_range(ids, vocab):
+    """ids outside [0, vocab) become -1 (pruned): the forward kernels give them no row, so they get no gradient."""
+    return torch.where(ids < vocab, ids, torch.full_like(ids, -1))
 
 
 class LinearLogit(torch.autograd.Function):
@@ -129,7 +151,7 @@ class LinearLogit(torch.autograd.Function):
         if ts.grad_sink is not None:     # fused optimiser attached (ops.SparseFtrl): d logit [B, 1] is every slot's gradient row
             ts.grad_sink(ids, gv.contiguous().reshape(-1, 1))
             return (None, None, gv.sum().reshape(1)) + (None,) * ts.F
-        grads = [_sparse_rows(ids[:, f].contiguous(), gv, ts.vocab[f]) for f in range(ts.F)]
+        grads = [_sparse_rows(_in_range(ids[:, f].contiguous(), ts.vocab[f]), gv, ts.vocab[f]) for f in range(ts.F)]
         return (None, None, gv.sum().reshape(1)) + tuple(grads)
 
 
@@ -252,7 +274,8 @@ class DinAttentionPool(torch.autograd.Function):
         AP = torch.cat([A, Wp], dim=0)                              # [2K, H1]
         # ---- recompute the unit on the valid rows -------------------------------------------------------------------
         h = table[ids_h]                                            # [N, K]
-        a = table[cand]                                             # [B, K]
+        cok = cand >= 0                                             # a pruned candidate is the zero vector in the forward
+        a = table[cand.clamp(min=0)] * cok.unsqueeze(1)             # [B, K]
         ab = a[b_idx]
         X = torch.cat([h, h * ab], dim=1)                           # [N, 2K]
         z1 = torch.sigmoid_(torch.addmm((a @ C + b1)[b_idx], X, AP))
@@ -287,8 +310,8 @@ class DinAttentionPool(torch.autograd.Function):
         ga = torch.zeros((B, K), device=dev).index_add_(0, b_idx, dX[:, K:] * h) + S @ C.t()
         gtab = None
         if ctx.needs_input_grad[0]:
-            idx = torch.cat([ids_h, cand]).unsqueeze(0)
-            gtab = torch.sparse_coo_tensor(idx, torch.cat([gh, ga]), table.shape)
+            idx = torch.cat([ids_h, cand.clamp(min=0)]).unsqueeze(0)
+            gtab = torch.sparse_coo_tensor(idx, torch.cat([gh, ga * cok.unsqueeze(1)]), table.shape)
         return (gtab, None, None, None, gW1, dpre1.sum(dim=0), gW2, dpre2.sum(dim=0), gW3.reshape(W3.shape),
                 ds.sum().reshape(b3.shape), None)
 
@@ -301,8 +324,8 @@ def gather_fm(ts, ids, tables):
     return GatherFm.apply(ts, ids, *tables)
 
 
-def embedding_bag(ts, ids, tables, offsets=None, weights=None, combiner="mean", field_major=False, out=None):
-    return EmbeddingBag.apply(ts, ids, offsets, weights, combiner, field_major, out, *tables)
+def embedding_bag(ts, ids, tables, offsets=None, weights=None, combiner="mean", field_major=False, out=None, max_norm=None):
+    return EmbeddingBag.apply(ts, ids, offsets, weights, combiner, field_major, out, max_norm, *tables)
 
 
 def linear_logit(ts, ids, bias, weights):

@@ -43,7 +43,7 @@ def tf_variable_map(model):
         if len(model.hidden) or model.dnn_feature_columns:
             _lin("dnn_fm/logits", model.logits_layer, m)                                       # deepFM.py:311-317
         for c, p in zip(model.linear_feature_columns, model.linear_weights):
-            m["linear/linear_model/%s/weights" % categorical_of(c).name] = (p, "col")          # deepFM.py:206-213
+            m["linear/linear_model/%s/weights" % categorical_of(c).name] = (p, "col" if p.dim() == 1 else None)   # deepFM.py:206-213
         m["linear/linear_model/bias_weights"] = (model.linear_bias, None)
     elif isinstance(model, DeepCrossNetwork):
         il = model.input_layer

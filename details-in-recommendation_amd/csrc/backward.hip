@@ -323,13 +323,14 @@ __global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict
 // row with <= 2 contributions is bitwise reproducible (a + b commutes); longer chains add in chain order.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adagrad_link_k(const int64_t* __restrict__ ids, int64_t sb, int64_t sf, int F,
-                                                      int64_t n, const int64_t* __restrict__ head_base,
+                                                      int64_t n, const int64_t* __restrict__ head_base, int64_t total_rows,
                                                       int32_t* __restrict__ head, int32_t* __restrict__ next) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = e / F;
         const int f = (int)(e - b * F);
         const int64_t id = ids[b * sb + f * sf];
-        next[e] = id >= 0 ? atomicExch(&head[head_base[f] + id], (int32_t)e) : -2;
+        const int64_t vf = (f + 1 < F ? head_base[f + 1] : total_rows) - head_base[f];       // an id >= vocab_f is pruned, never written
+        next[e] = (uint64_t)id < (uint64_t)vf ? atomicExch(&head[head_base[f] + id], (int32_t)e) : -2;
     }
 }
 
@@ -337,8 +338,8 @@ template <int LPS, int VEC>
 __global__ __launch_bounds__(256) void adagrad_apply_k(float* const* __restrict__ tables, float* const* __restrict__ accums,
                                                        const int64_t* __restrict__ ids, int64_t sb, int64_t sf, int F, int K,
                                                        int64_t n, const float* __restrict__ grad, int64_t g_ld, float lr,
-                                                       const int64_t* __restrict__ head_base, int32_t* __restrict__ head,
-                                                       const int32_t* __restrict__ next) {
+                                                       const int64_t* __restrict__ head_base, int64_t total_rows,
+                                                       int32_t* __restrict__ head, const int32_t* __restrict__ next) {
     using V = BV<VEC>;
     using T = typename V::T;
     const int kv = K / VEC;
@@ -350,7 +351,8 @@ __global__ __launch_bounds__(256) void adagrad_apply_k(float* const* __restrict_
         const int64_t b = e / F;
         const int f = (int)(e - b * F);
         const int64_t id = ids[b * sb + f * sf];
-        if (id < 0 || c >= kv) continue;
+        const int64_t vf = (f + 1 < F ? head_base[f + 1] : total_rows) - head_base[f];
+        if (!((uint64_t)id < (uint64_t)vf) || c >= kv) continue;
         int32_t* hp = head + head_base[f] + id;
         if (*hp != (int32_t)e) continue;                  // not the chain head: some other entry leads this row
         T g = V::zero();
@@ -393,7 +395,9 @@ __global__ __launch_bounds__(256) void adagrad_keys_k(const int64_t* __restrict_
         const int64_t b = e / F;
         const int f = (int)(e - b * F);
         const int64_t id = ids[b * sb + f * sf];
-        keys[e] = id >= 0 ? (uint32_t)(row_base[f] + id) : total_rows;     // pruned ids sort behind every row
+        const int64_t vf = (f + 1 < F ? row_base[f + 1] : (int64_t)total_rows) - row_base[f];
+        // pruned ids (id < 0, and id >= vocab_f: never written) sort behind every row
+        keys[e] = (uint64_t)id < (uint64_t)vf ? (uint32_t)(row_base[f] + id) : total_rows;
         vals[e] = (uint32_t)e;
     }
 }
@@ -404,7 +408,10 @@ __global__ __launch_bounds__(256) void adagrad_keys_payload_k(const int64_t* __r
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const int64_t p = payload[e];
-        keys[e] = p >= 0 ? (uint32_t)(row_base[p % F] + p / F) : total_rows;
+        const int f = p >= 0 ? (int)(p % F) : 0;
+        const int64_t row = p >= 0 ? p / F : -1;
+        const int64_t vf = (f + 1 < F ? row_base[f + 1] : (int64_t)total_rows) - row_base[f];
+        keys[e] = (uint64_t)row < (uint64_t)vf ? (uint32_t)(row_base[f] + row) : total_rows;
         vals[e] = (uint32_t)e;
     }
 }
@@ -812,22 +819,23 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
 
 extern "C" int dir_sparse_adagrad_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
                                       int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
-                                      int64_t B, const int64_t* head_base, int32_t* head, int32_t* next,
+                                      int64_t B, const int64_t* head_base, int64_t total_rows, int32_t* head, int32_t* next,
                                       dir_stream_t stream) {
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && grad_ld >= (int64_t)F * K, "dir_sparse_adagrad_f32: bad shape");
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(tables && accums && ids && grad && head_base && head && next, "dir_sparse_adagrad_f32: null pointer");
+    DIR_CHECK_ARG(total_rows > 0, "dir_sparse_adagrad_f32: total_rows=%lld", (long long)total_rows);
     if (B * F >= (int64_t)0x7fffffff) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_f32: B*F must fit int32");
     const int64_t n = B * F;
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(adagrad_link_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, head_base,
-                       head, next);
+                       total_rows, head, next);
     const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && aligned16(grad);
     int lps = 1;
     while (lps < (vec ? K / 4 : K)) lps <<= 1;
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_f32: K=%d too wide", K);
     dim3 grid(grid_for((n * lps + 255) / 256));
-#define DIR_CASE(L, V) hipLaunchKernelGGL((adagrad_apply_k<L, V>), grid, dim3(256), 0, st, tables, accums, ids, stride_b, stride_f, F, K, n, grad, grad_ld, lr, head_base, head, next)
+#define DIR_CASE(L, V) hipLaunchKernelGGL((adagrad_apply_k<L, V>), grid, dim3(256), 0, st, tables, accums, ids, stride_b, stride_f, F, K, n, grad, grad_ld, lr, head_base, total_rows, head, next)
     if (vec) {
         switch (lps) {
             case 1: DIR_CASE(1, 4); break;

@@ -49,6 +49,12 @@ __device__ __forceinline__ float vdiv(float a, float s) { return a / s; }
 __device__ __forceinline__ float hadd_into(float acc, float4 v) { return (((acc + v.x) + v.y) + v.z) + v.w; }
 __device__ __forceinline__ float hadd_into(float acc, float v) { return acc + v; }
 
+// Exclusive upper bound of the ids of slot f as an unsigned value: ids are looked up iff (uint64_t)id < bound, which prunes
+// id < 0 always and id >= vocab_f when the caller passed the vocabulary sizes (DEVICE [F]; NULL = precondition unchecked).
+__device__ __forceinline__ uint64_t id_bound(const int64_t* __restrict__ vocab, int f) {
+    return vocab ? (uint64_t)vocab[f] : (uint64_t)1 << 63;
+}
+
 // FM tail shared by the fused gather and the standalone kernel.  sum/sq hold this lane's chunk of
 // sum_f e and sum_f e^2; returns 0.5 * sum_k (sum^2 - sq) in lane LPS-1 of the group.
 template <int LPS, typename V>
@@ -75,6 +81,7 @@ __device__ __forceinline__ float fm_tail(V sum, V sq, int lane, int c) {
 // ------------------------------------------------------------------------------------------------
 template <int LPS, int VEC, int KT, int UF, bool DO_FM, bool DO_OUT, bool NT>
 __global__ __launch_bounds__(256) void gather_onehot_k(const float* const* __restrict__ tables,
+                                                       const int64_t* __restrict__ vocab,
                                                        const int64_t* __restrict__ ids, int64_t sb,
                                                        int64_t sf, int F, int Krt, int64_t B,
                                                        float* __restrict__ out, int64_t out_ld,
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(256) void gather_onehot_k(const float* const* __res
                 row[u] = vzero((V*)nullptr);
                 if (f < F) {
                     const float* t = tables[f];
-                    if (id[u] >= 0) row[u] = NT ? ldv_nt(t + id[u] * K + c * VEC, (V*)nullptr) : ldv(t + id[u] * K + c * VEC, (V*)nullptr);
+                    // id < 0 is pruned; with a vocab array id >= vocab_f is pruned too (one unsigned compare, scalar bound)
+                    if ((uint64_t)id[u] < id_bound(vocab, f)) row[u] = NT ? ldv_nt(t + id[u] * K + c * VEC, (V*)nullptr) : ldv(t + id[u] * K + c * VEC, (V*)nullptr);
                 }
             }
 #pragma unroll
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(256) void gather_onehot_k(const float* const* __res
 // ------------------------------------------------------------------------------------------------
 template <int LPS, int UF, bool NT>
 __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* __restrict__ tables,
+                                                            const int64_t* __restrict__ vocab,
                                                             const int64_t* __restrict__ ids, int64_t sb, int64_t sf,
                                                             int F, int K, int64_t ld, int lin_col, int64_t B,
                                                             float* __restrict__ out, int64_t out_ld,
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
                 const int f = f0 + u;
                 row[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 lw[u] = 0.f;
-                if (f < F && id[u] >= 0) {
+                if (f < F && (uint64_t)id[u] < id_bound(vocab, f)) {
                     const float* t = tables[f] + id[u] * ld;
                     row[u] = NT ? ldv_nt(t + c * 4, (float4*)nullptr) : ldv(t + c * 4, (float4*)nullptr);
                     if (want_lin && c == 0) lw[u] = NT ? ldv_nt(t + lin_col, (float*)nullptr) : t[lin_col];
@@ -202,12 +211,33 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
 // ------------------------------------------------------------------------------------------------
 // multi-hot (CSR) bags: entries reduced in order, then combiner
 // ------------------------------------------------------------------------------------------------
+// [TF-upstream] embedding_lookup(..., max_norm): every looked-up row is clipped to l2-norm max_norm BEFORE it is weighted
+// (clip_ops.clip_by_norm, r1.10+ form):  row * max_norm / max(||row||, max_norm),  ||row|| = sqrt(sum_k row_k^2) (0 when
+// the sum is 0).  The sum of squares runs k-ascending through the LPS lanes of the group (lane c -> c+1), so it is the
+// oracle's sequential fp32 sum bit for bit.
+template <int LPS, typename V>
+__device__ __forceinline__ V clip_row(V row, float max_norm, int lane, int c) {
+    V sq = vmul(row, row);
+    float acc = 0.f;
+    const int gbase = lane & ~(LPS - 1);
+#pragma unroll
+    for (int cc = 0; cc < LPS; ++cc) {
+        float carry = __shfl(acc, gbase + (cc > 0 ? cc - 1 : 0), 64);
+        if (c == cc) acc = hadd_into(cc == 0 ? 0.f : carry, sq);
+    }
+    const float l2sum = __shfl(acc, gbase + LPS - 1, 64);
+    const float l2norm = l2sum > 0.f ? sqrtf(l2sum) : l2sum;
+    return vdiv(vscale(row, max_norm), fmaxf(l2norm, max_norm));
+}
+
 template <int LPS, int VEC>
 __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict__ tables,
+                                                 const int64_t* __restrict__ vocab,
                                                  const int64_t* __restrict__ ids,
-                                                 const int64_t* __restrict__ offsets,
+                                                 const int64_t* __restrict__ offsets /* nullptr: one entry per bag */,
                                                  const float* __restrict__ weights, int64_t sb, int64_t sf,
-                                                 int F, int K, int64_t B, int combiner, int flags,
+                                                 int F, int K, int64_t B, const int32_t* __restrict__ slot_combiner,
+                                                 int combiner, float max_norm, int flags,
                                                  float* __restrict__ out, int64_t out_ld) {
     // A bag needs three dependent global reads (offsets -> ids/weights -> rows).  The loop over the fields of a sample is
     // software-pipelined so that only the row reads are on the critical path: at field f the offsets of field f+2 and the
@@ -223,25 +253,34 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
     const bool cact = c < kv;
     const bool prune_w = (flags & DIR_BAG_PRUNE_NONPOSITIVE_WEIGHTS) != 0;
     const bool nt = (flags & DIR_GATHER_STREAM_ROWS) != 0;      // tables far beyond the Infinity Cache: rows bypass the caches
+    const bool clip = max_norm > 0.f;
     const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
         const int64_t b = g * SPW + s;
-        const bool act = cact && (b < B);
+        const bool sact = b < B;              // every lane of a sample's group walks the same bag (clip_row shuffles inside it)
+        const bool act = cact && sact;
         auto load_off = [&](int f, int64_t& beg, int64_t& end) {
             beg = 0;
             end = 0;
-            if (act && f < F) {
+            if (sact && f < F) {
                 const int64_t bag = b * sb + (int64_t)f * sf;
-                beg = offsets[bag];
-                end = offsets[bag + 1];
+                if (offsets) {
+                    beg = offsets[bag];
+                    end = offsets[bag + 1];
+                } else {          // one-hot ids: the bag index addresses its single entry
+                    beg = bag;
+                    end = bag + 1;
+                }
             }
         };
-        auto load_ent = [&](int64_t e0, int64_t end, int64_t (&id)[U], float (&w)[U]) {
+        auto load_ent = [&](int64_t e0, int64_t end, int f, int64_t (&id)[U], float (&w)[U]) {
+            const uint64_t bound = f < F ? id_bound(vocab, f) : 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t e = e0 + u;
                 id[u] = e < end ? ids[e] : (int64_t)-1;
                 w[u] = (weights && e < end) ? weights[e] : 1.0f;
+                if (!((uint64_t)id[u] < bound)) id[u] = -1;                 // id < 0 and id >= vocab_f are pruned
                 if (weights && prune_w && !(w[u] > 0.0f)) id[u] = -1;
             }
         };
@@ -250,21 +289,26 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
         float w0[U], w1[U];
         load_off(0, beg0, end0);
         load_off(1, beg1, end1);
-        load_ent(beg0, end0, id0, w0);
+        load_ent(beg0, end0, 0, id0, w0);
         for (int f = 0; f < F; ++f) {
             const float* t = tables[f];
+            const int comb = slot_combiner ? slot_combiner[f] : combiner;
             load_off(f + 2, beg2, end2);
-            load_ent(beg1, end1, id1, w1);              // field f+1 (empty range when f+1 == F)
+            load_ent(beg1, end1, f + 1, id1, w1);       // field f+1 (empty range when f+1 == F)
             V acc = vzero((V*)nullptr);
             float wsum = 0.f, w2sum = 0.f;
             int cnt = 0;
             for (int64_t e0 = beg0; e0 < end0; e0 += U) {
-                if (e0 != beg0) load_ent(e0, end0, id0, w0);   // a bag longer than U
+                if (e0 != beg0) load_ent(e0, end0, f, id0, w0);   // a bag longer than U
                 V row[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     row[u] = vzero((V*)nullptr);
-                    if (id0[u] >= 0) row[u] = nt ? ldv_nt(t + id0[u] * K + c * VEC, (V*)nullptr) : ldv(t + id0[u] * K + c * VEC, (V*)nullptr);
+                    if (id0[u] >= 0 && cact) row[u] = nt ? ldv_nt(t + id0[u] * K + c * VEC, (V*)nullptr) : ldv(t + id0[u] * K + c * VEC, (V*)nullptr);
+                }
+                if (clip) {                              // wave-uniform branch; every lane takes part in the shuffles
+#pragma unroll
+                    for (int u = 0; u < U; ++u) row[u] = clip_row<LPS>(row[u], max_norm, lane, c);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -277,9 +321,9 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
                 }
             }
             if (cnt > 0) {
-                if (combiner == DIR_COMBINER_MEAN) {
+                if (comb == DIR_COMBINER_MEAN) {
                     acc = vdiv(acc, weights ? wsum : (float)cnt);
-                } else if (combiner == DIR_COMBINER_SQRTN) {
+                } else if (comb == DIR_COMBINER_SQRTN) {
                     acc = vdiv(acc, weights ? sqrtf(w2sum) : sqrtf((float)cnt));
                 }
             }
@@ -358,7 +402,7 @@ static int env_int(const char* name, int dflt) {
 
 template <int LPS, int VEC, int KT, bool DO_FM, bool DO_OUT>
 static void launch_onehot_uf(int uf, bool stream_rows, int64_t work_blocks, hipStream_t st, const float* const* tables,
-                             const int64_t* ids, int64_t sb, int64_t sf, int F, int K, int64_t B, float* out,
+                             const int64_t* vocab, const int64_t* ids, int64_t sb, int64_t sf, int F, int K, int64_t B, float* out,
                              int64_t out_ld, float* fm) {
     static const int nt_force = env_int("DIR_GATHER_NT", -1);   // development override: 0 / 1
     const bool nt_env = nt_force >= 0 ? nt_force != 0 : stream_rows;
@@ -366,10 +410,10 @@ static void launch_onehot_uf(int uf, bool stream_rows, int64_t work_blocks, hipS
     do {                                                                                                            \
         if (nt_env) {                                                                                               \
             dim3 grid(grid_resident(work_blocks, resident_blocks(gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, true>))); \
-            hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, true>), grid, dim3(256), 0, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm); \
+            hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, true>), grid, dim3(256), 0, st, tables, vocab, ids, sb, sf, F, K, B, out, out_ld, fm); \
         } else {                                                                                                    \
             dim3 grid(grid_resident(work_blocks, resident_blocks(gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, false>))); \
-            hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, false>), grid, dim3(256), 0, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm); \
+            hipLaunchKernelGGL((gather_onehot_k<LPS, VEC, KT, UF, DO_FM, DO_OUT, false>), grid, dim3(256), 0, st, tables, vocab, ids, sb, sf, F, K, B, out, out_ld, fm); \
         }                                                                                                           \
     } while (0)
     switch (uf) {
@@ -382,7 +426,7 @@ static void launch_onehot_uf(int uf, bool stream_rows, int64_t work_blocks, hipS
 }
 
 template <bool DO_FM, bool DO_OUT>
-static int launch_onehot(const float* const* tables, int F, int K, const int64_t* ids, int64_t sb, int64_t sf,
+static int launch_onehot(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids, int64_t sb, int64_t sf,
                          int flags, int64_t B, float* out, int64_t out_ld, float* fm, hipStream_t st) {
     const bool vec = (K % 4 == 0) && (!DO_OUT || (out_ld % 4 == 0 && aligned16(out)));
     static const int uf_env = env_int("DIR_GATHER_UF", 0);
@@ -393,7 +437,7 @@ static int launch_onehot(const float* const* tables, int F, int K, const int64_t
     const int spw = 64 / lps;
     const int64_t waves = (B + spw - 1) / spw;
     const int64_t grid = (waves + 3) / 4;   // work blocks; the launch picks the resident count
-#define DIR_CASE(L, V, KT) launch_onehot_uf<L, V, KT, DO_FM, DO_OUT>(uf, stream_rows, grid, st, tables, ids, sb, sf, F, K, B, out, out_ld, fm)
+#define DIR_CASE(L, V, KT) launch_onehot_uf<L, V, KT, DO_FM, DO_OUT>(uf, stream_rows, grid, st, tables, vocab, ids, sb, sf, F, K, B, out, out_ld, fm)
     if (vec) {
         switch (lps) {
             case 1: DIR_CASE(1, 4, 4); break;
@@ -420,9 +464,9 @@ static int launch_onehot(const float* const* tables, int F, int K, const int64_t
     return DIR_OK;
 }
 
-static int launch_csr(const float* const* tables, int F, int K, const int64_t* ids, const int64_t* offsets,
-                      const float* weights, int64_t sb, int64_t sf, int combiner, int flags, int64_t B,
-                      float* out, int64_t out_ld, hipStream_t st) {
+static int launch_csr(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids, const int64_t* offsets,
+                      const float* weights, int64_t sb, int64_t sf, const int32_t* slot_combiner, int combiner, float max_norm,
+                      int flags, int64_t B, float* out, int64_t out_ld, hipStream_t st) {
     const bool vec = (K % 4 == 0) && (out_ld % 4 == 0) && aligned16(out);
     const int lps = next_pow2(vec ? K / 4 : K);
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "embedding row of K=%d floats is wider than one wave covers", K);
@@ -430,7 +474,7 @@ static int launch_csr(const float* const* tables, int F, int K, const int64_t* i
     const int64_t waves = (B + spw - 1) / spw;
     dim3 grid(grid_for((waves + 3) / 4));
 #define DIR_CASE(L, V) \
-    hipLaunchKernelGGL((bag_csr_k<L, V>), grid, dim3(256), 0, st, tables, ids, offsets, weights, sb, sf, F, K, B, combiner, flags, out, out_ld)
+    hipLaunchKernelGGL((bag_csr_k<L, V>), grid, dim3(256), 0, st, tables, vocab, ids, offsets, weights, sb, sf, F, K, B, slot_combiner, combiner, max_norm, flags, out, out_ld)
     if (vec) {
         switch (lps) {
             case 1: DIR_CASE(1, 4); break;
@@ -461,34 +505,42 @@ static int launch_csr(const float* const* tables, int F, int K, const int64_t* i
 
 using namespace dir;
 
-extern "C" int dir_embedding_bag_f32(const float* const* tables, int F, int K, const int64_t* ids,
-                                     const int64_t* offsets, const float* weights, int64_t stride_b,
-                                     int64_t stride_f, int combiner, int flags, int64_t B, float* out,
-                                     int64_t out_ld, dir_stream_t stream) {
+extern "C" int dir_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
+                                        const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
+                                        const int32_t* slot_combiner, int combiner, float max_norm, int flags, int64_t B,
+                                        float* out, int64_t out_ld, dir_stream_t stream) {
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "dir_embedding_bag_f32: F=%d K=%d B=%lld", F, K, (long long)B);
     if (B == 0) return DIR_OK;  // an empty batch carries no buffers
     DIR_CHECK_ARG(tables && ids && out, "dir_embedding_bag_f32: null pointer");
     DIR_CHECK_ARG(out_ld >= (int64_t)F * K, "dir_embedding_bag_f32: out_ld=%lld < F*K=%lld", (long long)out_ld, (long long)F * K);
     DIR_CHECK_ARG(combiner >= DIR_COMBINER_SUM && combiner <= DIR_COMBINER_SQRTN, "dir_embedding_bag_f32: combiner=%d", combiner);
     DIR_CHECK_ARG(offsets || !weights, "dir_embedding_bag_f32: weights need offsets (multi-hot)");
-    if (B == 0) return DIR_OK;
-    if (!offsets)  // a one-entry bag: every combiner is the identity on it
-        return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, nullptr, as_stream(stream));
-    return launch_csr(tables, F, K, ids, offsets, weights, stride_b, stride_f, combiner, flags, B, out, out_ld, as_stream(stream));
+    DIR_CHECK_ARG(!(max_norm < 0.f), "dir_embedding_bag_f32: max_norm=%g", max_norm);
+    if (!offsets && !(max_norm > 0.f))  // a one-entry bag without clipping: every combiner is the identity on it
+        return launch_onehot<false, true>(tables, vocab, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, nullptr, as_stream(stream));
+    return launch_csr(tables, vocab, F, K, ids, offsets, weights, stride_b, stride_f, slot_combiner, combiner, max_norm, flags, B, out,
+                      out_ld, as_stream(stream));
 }
 
-extern "C" int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int64_t* ids,
+extern "C" int dir_embedding_bag_f32(const float* const* tables, int F, int K, const int64_t* ids,
+                                     const int64_t* offsets, const float* weights, int64_t stride_b,
+                                     int64_t stride_f, int combiner, int flags, int64_t B, float* out,
+                                     int64_t out_ld, dir_stream_t stream) {
+    return dir_embedding_bag_ex_f32(tables, nullptr, F, K, ids, offsets, weights, stride_b, stride_f, nullptr, combiner, 0.f, flags, B,
+                                    out, out_ld, stream);
+}
+
+extern "C" int dir_gather_fm_fused_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
                                        int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out,
                                        int64_t out_ld, float* fm, dir_stream_t stream) {
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "dir_gather_fm_fused_f32: F=%d K=%d B=%lld", F, K, (long long)B);
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(tables && ids && (out || fm), "dir_gather_fm_fused_f32: null pointer");
     DIR_CHECK_ARG(!out || out_ld >= (int64_t)F * K, "dir_gather_fm_fused_f32: out_ld=%lld < F*K", (long long)out_ld);
-    if (B == 0) return DIR_OK;
     hipStream_t st = as_stream(stream);
-    if (out && fm) return launch_onehot<true, true>(tables, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, fm, st);
-    if (fm) return launch_onehot<true, false>(tables, F, K, ids, stride_b, stride_f, flags, B, nullptr, 0, fm, st);
-    return launch_onehot<false, true>(tables, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, nullptr, st);
+    if (out && fm) return launch_onehot<true, true>(tables, vocab, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, fm, st);
+    if (fm) return launch_onehot<true, false>(tables, vocab, F, K, ids, stride_b, stride_f, flags, B, nullptr, 0, fm, st);
+    return launch_onehot<false, true>(tables, vocab, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, nullptr, st);
 }
 
 extern "C" int dir_fm_second_order_f32(const float* emb, int64_t emb_ld, int64_t B, int F, int K, float* out,
@@ -543,7 +595,7 @@ extern "C" int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, co
     return DIR_OK;
 }
 
-extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, int F, int K, int64_t ld, int lin_col,
+extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
                                                const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
                                                int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
                                                float* lin_out, dir_stream_t stream) {
@@ -563,7 +615,7 @@ extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, int F
 #define DIR_GO(L, NTV)                                                                                          \
     do {                                                                                                        \
         dim3 grid(grid_resident(work, resident_blocks(gather_packed_rows_k<L, 13, NTV>)));                     \
-        hipLaunchKernelGGL((gather_packed_rows_k<L, 13, NTV>), grid, dim3(256), 0, st, tables, ids, stride_b, stride_f, F, K, ld, \
+        hipLaunchKernelGGL((gather_packed_rows_k<L, 13, NTV>), grid, dim3(256), 0, st, tables, vocab, ids, stride_b, stride_f, F, K, ld, \
                            lin_col, B, out, out_ld, fm, bias, lin_out);                                        \
     } while (0)
 #define DIR_L(L) do { if (nt) DIR_GO(L, true); else DIR_GO(L, false); } while (0)

@@ -20,6 +20,7 @@ namespace dir {
 // ------------------------------------------------------------------------------------------------
 template <int UF>
 __global__ __launch_bounds__(256) void linear_onehot_k(const float* const* __restrict__ wts,
+                                                       const int64_t* __restrict__ vocab,
                                                        const int64_t* __restrict__ ids, int64_t sb, int64_t sf,
                                                        int F, const float* __restrict__ bias, int accumulate,
                                                        int64_t B, float* __restrict__ out) {
@@ -36,7 +37,8 @@ __global__ __launch_bounds__(256) void linear_onehot_k(const float* const* __res
                 v[u] = 0.f;
                 if (f0 + u < F) {
                     const float* w = wts[f0 + u];
-                    if (id[u] >= 0) v[u] = w[id[u]];
+                    const uint64_t bound = vocab ? (uint64_t)vocab[f0 + u] : (uint64_t)1 << 63;   // id < 0 / id >= vocab_f: pruned
+                    if ((uint64_t)id[u] < bound) v[u] = w[id[u]];
                 }
             }
 #pragma unroll
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(256) void linear_onehot_k(const float* const* __res
 }
 
 __global__ __launch_bounds__(256) void linear_csr_k(const float* const* __restrict__ wts,
+                                                    const int64_t* __restrict__ vocab,
                                                     const int64_t* __restrict__ ids,
                                                     const int64_t* __restrict__ offsets,
                                                     const float* __restrict__ ew, int64_t sb, int64_t sf, int F,
@@ -58,13 +61,14 @@ __global__ __launch_bounds__(256) void linear_csr_k(const float* const* __restri
         float acc = 0.f;
         for (int f = 0; f < F; ++f) {
             const float* w = wts[f];
+            const uint64_t bound = vocab ? (uint64_t)vocab[f] : (uint64_t)1 << 63;
             const int64_t bag = b * sb + (int64_t)f * sf;
             const int64_t beg = offsets[bag], end = offsets[bag + 1];
             float v = 0.f, wsum = 0.f, w2sum = 0.f;
             int cnt = 0;
             for (int64_t e = beg; e < end; ++e) {
                 const int64_t id = ids[e];
-                if (id < 0) continue;
+                if (!((uint64_t)id < bound)) continue;
                 const float wt = ew ? ew[e] : 1.0f;
                 v = ew ? v + wt * w[id] : v + w[id];
                 wsum = wsum + wt;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void cross_k(const float* __restrict__ x0, int
 
 using namespace dir;
 
-extern "C" int dir_linear_sparse_sum_f32(const float* const* weights, int F, const int64_t* ids,
+extern "C" int dir_linear_sparse_sum_f32(const float* const* weights, const int64_t* vocab, int F, const int64_t* ids,
                                          const int64_t* offsets, const float* entry_weights, int64_t stride_b,
                                          int64_t stride_f, int combiner, const float* bias, int accumulate,
                                          int64_t B, float* out, dir_stream_t stream) {
@@ -195,9 +199,9 @@ extern "C" int dir_linear_sparse_sum_f32(const float* const* weights, int F, con
     hipStream_t st = as_stream(stream);
     dim3 grid(grid_for((B + 255) / 256));
     if (!offsets) {
-        hipLaunchKernelGGL((linear_onehot_k<13>), grid, dim3(256), 0, st, weights, ids, stride_b, stride_f, F, bias, accumulate, B, out);
+        hipLaunchKernelGGL((linear_onehot_k<13>), grid, dim3(256), 0, st, weights, vocab, ids, stride_b, stride_f, F, bias, accumulate, B, out);
     } else {
-        hipLaunchKernelGGL(linear_csr_k, grid, dim3(256), 0, st, weights, ids, offsets, entry_weights, stride_b, stride_f, F, combiner, bias, accumulate, B, out);
+        hipLaunchKernelGGL(linear_csr_k, grid, dim3(256), 0, st, weights, vocab, ids, offsets, entry_weights, stride_b, stride_f, F, combiner, bias, accumulate, B, out);
     }
     DIR_CHECK_LAUNCH("linear_sparse_sum");
     return DIR_OK;

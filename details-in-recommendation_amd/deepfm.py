@@ -82,8 +82,11 @@ class DeepFM(nn.Module):
         dnn_feature_columns = list(dnn_feature_columns or [])
         if not (linear_feature_columns + dnn_feature_columns):
             raise ValueError("empty columns.")                                   # deepFM.py:104-105
-        if n_classes != 2:
-            raise NotImplementedError("only the binary head (n_classes=2) is on the HIP path")
+        if n_classes is None or n_classes < 2:
+            raise ValueError("n_classes must be >= 2")                            # [TF-upstream] head validation
+        # deepFM.py:107-117: binary head (logits_dimension 1) or the multi-class softmax head (logits_dimension n_classes)
+        self.n_classes = int(n_classes)
+        self.units = 1 if n_classes == 2 else int(n_classes)
         for c in dnn_feature_columns:
             if not getattr(c, "is_dense", False):
                 raise ValueError("Items of feature_columns must be a _DenseColumn. You can wrap a categorical "
@@ -108,10 +111,11 @@ class DeepFM(nn.Module):
             nn.init.trunc_normal_(w, std=1.0 / math.sqrt(c.dimension), a=-2.0 / math.sqrt(c.dimension),
                                   b=2.0 / math.sqrt(c.dimension))
             self.embedding_weights.append(nn.Parameter(w))
-        # linear_model weights: zeros ([TF-upstream]), bias zero
+        # linear_model weights: zeros ([TF-upstream]; [vocab, units] -- kept as [vocab] for units = 1), bias zero
         self.linear_weights = nn.ParameterList(
-            [nn.Parameter(torch.zeros(categorical_of(c).num_buckets)) for c in linear_feature_columns])
-        self.linear_bias = nn.Parameter(torch.zeros(1))
+            [nn.Parameter(torch.zeros(categorical_of(c).num_buckets) if self.units == 1 else
+                          torch.zeros(categorical_of(c).num_buckets, self.units)) for c in linear_feature_columns])
+        self.linear_bias = nn.Parameter(torch.zeros(self.units))
         # dnn (deepFM.py:292-317)
         self.hidden = nn.ModuleList()
         self.bns = nn.ModuleList()
@@ -127,7 +131,7 @@ class DeepFM(nn.Module):
                 if batch_norm:
                     self.bns.append(_BatchNormInfer(n))
                 d = n
-            self.logits_layer = nn.Linear(d, 1)
+            self.logits_layer = nn.Linear(d, self.units)                          # deepFM.py:311-317, units = head.logits_dimension
             _glorot_uniform_(self.logits_layer.weight)
             nn.init.zeros_(self.logits_layer.bias)
         self._emb_ts = None
@@ -143,20 +147,30 @@ class DeepFM(nn.Module):
         return self._emb_ts, self._lin_ts
 
     # ---- logit builders ---------------------------------------------------------------------------
+    def _logits_of(self, net):
+        return units1(self.logits_layer, net) if self.units == 1 else self.logits_layer(net)
+
     def dnn_logit_fn(self, net):
         if not len(self.bns) and not self.hparams.get("dnn_dropout") and mlp_stack_supported(self.hidden, net, self.activation):
-            return units1(self.logits_layer, mlp_stack(self.hidden, net))               # training: the whole tower as one autograd node
+            return self._logits_of(mlp_stack(self.hidden, net))                         # training: the whole tower as one autograd node
         for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
             net = dense_act(lin, net, self.activation)                          # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :301-302 (TRAIN only), before the BN
             if len(self.bns):
                 net = self.bns[i](net)
-        return units1(self.logits_layer, net)                                    # :311-317
+        return self._logits_of(net)                                              # :311-317
 
     def dnn_fm_logit_fn(self, features, device):
         emb_ts, _ = self._tablesets()
         got = collect_ids(self.dnn_feature_columns, features, device)
         train = torch.is_grad_enabled()                                          # autograd path: HIP forward + HIP/sparse backward
+        max_norm = self._max_norm()
+        if got[0] == "onehot" and max_norm:                                      # clipping needs the bag kernel: one-entry bags
+            ids = got[1]
+            emb = (ag.embedding_bag(emb_ts, ids, list(self.embedding_weights), max_norm=max_norm) if train
+                   else ops.embedding_bag(emb_ts, ids, max_norm=max_norm))
+            fm = ag.fm_logit(emb, self.F, self.K) if train else ops.fm_logit(emb, self.F, self.K)
+            return fm + self.dnn_logit_fn(emb)
         if got[0] == "onehot":
             if train:
                 emb, fm = ag.gather_fm(emb_ts, got[1], list(self.embedding_weights))
@@ -164,27 +178,51 @@ class DeepFM(nn.Module):
                 emb, fm = ops.gather_fm(emb_ts, got[1])                          # inputs + fm_logit_fn, one pass
         else:
             _, vals, offs, wts, _ = got
-            comb = self.dnn_feature_columns[0].combiner
-            if any(c.combiner != comb for c in self.dnn_feature_columns):
-                raise NotImplementedError("mixed combiners across dnn columns")
+            comb = [c.combiner for c in self.dnn_feature_columns]                # every embedding_column carries its own combiner
             if train:
-                emb = ag.embedding_bag(emb_ts, vals, list(self.embedding_weights), offs, wts, combiner=comb, field_major=True)
+                emb = ag.embedding_bag(emb_ts, vals, list(self.embedding_weights), offs, wts, combiner=comb, field_major=True,
+                                       max_norm=max_norm)
                 fm = ag.fm_logit(emb, self.F, self.K)
             else:
-                emb = ops.embedding_bag(emb_ts, vals, offs, wts, combiner=comb, field_major=True)
+                emb = ops.embedding_bag(emb_ts, vals, offs, wts, combiner=comb, field_major=True, max_norm=max_norm)
                 fm = ops.fm_logit(emb, self.F, self.K)
-        return fm + self.dnn_logit_fn(emb)                                       # deepFM.py:337-338
+        return fm + self.dnn_logit_fn(emb)                                       # deepFM.py:337-338 ([B,1] + [B,units] broadcasts)
+
+    def _max_norm(self):
+        mn = [getattr(c, "max_norm", None) for c in self.dnn_feature_columns]
+        if any(m != mn[0] for m in mn):
+            raise NotImplementedError("embedding columns of one DeepFM must share max_norm (one value per launch)")
+        return mn[0] if mn else None
 
     def linear_logit_fn(self, features, device):
+        """_linear_logit_fn_builder (deepFM.py:255-275): linear_model(units, sparse_combiner) + bias -> [B, units]."""
         _, lin_ts = self._tablesets()
         got = collect_ids(self.linear_feature_columns, features, device)
-        if got[0] == "onehot":
-            if torch.is_grad_enabled():
+        train = torch.is_grad_enabled()
+        if self.units == 1 and got[0] == "onehot":
+            if train:
                 return ag.linear_logit(lin_ts, got[1], self.linear_bias, list(self.linear_weights))
             return ops.linear_logit(lin_ts, got[1], bias=self.linear_bias.data)
-        _, vals, offs, wts, _ = got
-        return ops.linear_logit(lin_ts, vals, offs, wts, combiner=self.linear_sparse_combiner,
-                                bias=self.linear_bias.data, field_major=True)
+        if self.units == 1 and not train:
+            _, vals, offs, wts, _ = got
+            return ops.linear_logit(lin_ts, vals, offs, wts, combiner=self.linear_sparse_combiner,
+                                    bias=self.linear_bias.data, field_major=True)
+        # multi-hot under autograd, or units > 1 (multi-class head): the first-order term is a bag lookup with K = units and the
+        # linear_model's sparse_combiner, summed over the columns; the bag op's backward gives the weights sparse gradients
+        Fl = len(self.linear_feature_columns)
+        comb = self.linear_sparse_combiner
+        tabs = list(self.linear_weights)
+        if got[0] == "onehot":
+            args, kw = (got[1],), {}
+            B = got[1].shape[0]
+        else:
+            _, vals, offs, wts, B = got
+            args, kw = (vals,), dict(offsets=offs, weights=wts, field_major=True)
+        if train:
+            per = ag.embedding_bag(lin_ts, args[0], tabs, combiner=comb, **kw)
+        else:
+            per = ops.embedding_bag(lin_ts, args[0], combiner=comb, **kw)
+        return per.view(B, Fl, self.units).sum(dim=1) + self.linear_bias
 
     def forward(self, features):
         if not isinstance(features, dict):
@@ -201,9 +239,12 @@ class DeepFM(nn.Module):
     def create_loss(self, features, logits, labels):
         """The canned binary head's loss (deepFM.py:107-117: weight_column, loss_reduction -- default SUM, deepFM.py:72)
         -> (weighted_loss, unweighted_loss)."""
-        from .train_spec import _weights_of, weighted_sigmoid_cross_entropy
+        from .train_spec import _weights_of, weighted_sigmoid_cross_entropy, weighted_softmax_cross_entropy
         w = _weights_of(features, self.hparams["weight_column"], logits) if isinstance(features, dict) else None
-        return weighted_sigmoid_cross_entropy(logits, labels, w, str(self.hparams["loss_reduction"] or "sum").lower())
+        red = str(self.hparams["loss_reduction"] or "sum").lower()
+        if self.units > 1:                       # _multi_class_head_with_softmax_cross_entropy_loss (deepFM.py:112-117)
+            return weighted_softmax_cross_entropy(logits, labels, w, red)
+        return weighted_sigmoid_cross_entropy(logits, labels, w, red)
 
     def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
         """Attach the fused HIP sparse-Adagrad update to the embedding tables (the reference trains them with
@@ -235,23 +276,37 @@ class DeepFM(nn.Module):
     def forward_ids(self, dnn_ids, linear_ids=None):
         """Fast path for pre-assembled one-hot id matrices [B, F] (any strides).  linear_ids: the ids of ALL linear
         columns [B, F_lin] (its first F columns equal dnn_ids in the DeepFM case)."""
-        if getattr(self, "_packed", None) is not None and linear_ids is not None:
+        if getattr(self, "_packed", None) is not None and linear_ids is not None and not torch.is_grad_enabled():
             emb, fm, lin = ops.gather_fm_linear(self._packed, dnn_ids, bias=self.linear_bias.data)
             logits = fm + self.dnn_logit_fn(emb) + lin
             if self._packed_extra is not None:
                 logits = logits + ops.linear_logit(self._packed_extra, linear_ids[:, self.F:])
             return logits
         emb_ts, lin_ts = self._tablesets()
-        emb, fm = ops.gather_fm(emb_ts, dnn_ids)
+        train = torch.is_grad_enabled()
+        if train:                                                                # differentiable: the tables get (sparse) gradients
+            emb, fm = ag.gather_fm(emb_ts, dnn_ids, list(self.embedding_weights))
+        else:
+            emb, fm = ops.gather_fm(emb_ts, dnn_ids)
         logits = fm + self.dnn_logit_fn(emb)
         if linear_ids is not None and lin_ts is not None:
-            logits = logits + ops.linear_logit(lin_ts, linear_ids, bias=self.linear_bias.data)
+            if self.units != 1:
+                raise NotImplementedError("forward_ids: the multi-class head takes the features-dict path")
+            if train:
+                logits = logits + ag.linear_logit(lin_ts, linear_ids, self.linear_bias, list(self.linear_weights))
+            else:
+                logits = logits + ops.linear_logit(lin_ts, linear_ids, bias=self.linear_bias.data)
         return logits
 
     @torch.no_grad()
     def predict(self, features):
-        """Binary head predictions ([TF-upstream] _binary_logistic_head_with_sigmoid_cross_entropy_loss)."""
+        """Head predictions: binary ([TF-upstream] _binary_logistic_head_with_sigmoid_cross_entropy_loss: logits, logistic,
+        probabilities = softmax([0, logit]), class_ids) or, for n_classes > 2, the multi-class softmax head
+        (_multi_class_head_with_softmax_cross_entropy_loss: logits, probabilities = softmax(logits), class_ids = argmax)."""
         logits = self.forward(features)
+        if self.units > 1:
+            return {"logits": logits, "probabilities": torch.softmax(logits, dim=-1),
+                    "class_ids": torch.argmax(logits, dim=-1, keepdim=True)}
         logistic = torch.sigmoid(logits)
         two = torch.cat([torch.zeros_like(logits), logits], dim=-1)
         return {"logits": logits, "logistic": logistic, "probabilities": torch.softmax(two, dim=-1),

@@ -57,10 +57,19 @@ class _Categorical(_Column):
 
 class IdentityCategoricalColumn(_Categorical):
     def __init__(self, key, num_buckets, default_value=None):
+        if num_buckets is None or num_buckets < 1:
+            raise ValueError("num_buckets {} < 1, column_name {}".format(num_buckets, key))
+        if default_value is not None and not (0 <= default_value < num_buckets):
+            raise ValueError("default_value {} not in range [0, {}), column_name {}".format(default_value, num_buckets, key))
         self.key = key
         self.name = key
         self.num_buckets = int(num_buckets)
         self.default_value = default_value
+
+    @property
+    def range_checked(self):
+        """Without a default_value TensorFlow asserts 0 <= id < num_buckets (see _input.check_id_range)."""
+        return self.default_value is None
 
     def _to_ids(self, raw, device):
         t = raw.to(device=device, dtype=torch.int64)
@@ -115,6 +124,8 @@ class BucketizedColumn(_Categorical):
 
 
 class WeightedCategoricalColumn(_Categorical):
+    range_checked = property(lambda self: getattr(self.categorical_column, "range_checked", False))
+
     """weighted_categorical_column (dataset/SequenceTensorFlowDataset/test4.py:53): ids from the wrapped
     column, per-entry weights from features[weight_feature_key] (same ragged layout)."""
 
@@ -139,7 +150,7 @@ class WeightedCategoricalColumn(_Categorical):
 class EmbeddingColumn(_Column):
     is_dense = True
 
-    def __init__(self, categorical_column, dimension, combiner="mean"):
+    def __init__(self, categorical_column, dimension, combiner="mean", max_norm=None):
         if dimension is None or dimension < 1:
             raise ValueError("Invalid dimension {}.".format(dimension))
         if combiner not in ("mean", "sqrtn", "sum"):
@@ -147,6 +158,7 @@ class EmbeddingColumn(_Column):
         self.categorical_column = categorical_column
         self.dimension = int(dimension)
         self.combiner = combiner
+        self.max_norm = max_norm          # [TF-upstream] embedding_column(max_norm=): l2-clip every looked-up row
         self.name = categorical_column.name + "_embedding"
         self.num_buckets = categorical_column.num_buckets
 
@@ -184,8 +196,8 @@ def weighted_categorical_column(categorical_column, weight_feature_key):
     return WeightedCategoricalColumn(categorical_column, weight_feature_key)
 
 
-def embedding_column(categorical_column, dimension, combiner="mean"):
-    return EmbeddingColumn(categorical_column, dimension, combiner)
+def embedding_column(categorical_column, dimension, combiner="mean", max_norm=None):
+    return EmbeddingColumn(categorical_column, dimension, combiner, max_norm)
 
 
 def indicator_column(categorical_column):

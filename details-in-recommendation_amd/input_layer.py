@@ -49,18 +49,23 @@ class InputLayer(nn.Module):
     def _tablesets(self):
         key = tuple(p.data_ptr() for p in self.embedding_weights)
         if self._ts_key != key:
-            self._groups = []  # (TableSet, [indices into self.emb_cols], combiner)
+            self._groups = []  # (TableSet, [indices into self.emb_cols], [combiner per column], max_norm)
             seen = {}
-            for i, c in enumerate(self.emb_cols):
-                seen.setdefault((c.dimension, c.combiner), []).append(i)
-            for (dim, comb), idxs in seen.items():
+            for i, c in enumerate(self.emb_cols):      # one launch takes one row width and one max_norm; combiners go per slot
+                seen.setdefault((c.dimension, getattr(c, "max_norm", None)), []).append(i)
+
+            def close(run, mn):
+                self._groups.append((ops.TableSet([self.embedding_weights[j].data for j in run]), run,
+                                     [self.emb_cols[j].combiner for j in run], mn))
+
+            for (dim, mn), idxs in seen.items():
                 run = []
                 for i in idxs:  # only runs ADJACENT in the sorted concat can share one launch
                     if run and self._col_offset(self.emb_cols[i]) != self._col_offset(self.emb_cols[run[-1]]) + dim:
-                        self._groups.append((ops.TableSet([self.embedding_weights[j].data for j in run]), run, comb))
+                        close(run, mn)
                         run = []
                     run.append(i)
-                self._groups.append((ops.TableSet([self.embedding_weights[j].data for j in run]), run, comb))
+                close(run, mn)
             self._ts_key = key
         return self._groups
 
@@ -68,7 +73,7 @@ class InputLayer(nn.Module):
         """Attach the fused sparse Adagrad (include/dir_hip.h: dir_sparse_adagrad_sorted_f32; the reference's Adagrad on
         `embedding_weights`) to every group of embedding columns: backward() then updates the tables in place for one-hot
         inputs and they get no .grad.  Returns the optimiser objects (they own the accumulators)."""
-        return [ops.SparseAdagrad(ts, lr, initial_accumulator_value=initial_accumulator_value).attach() for ts, _, _ in self._tablesets()]
+        return [ops.SparseAdagrad(ts, lr, initial_accumulator_value=initial_accumulator_value).attach() for ts, _, _, _ in self._tablesets()]
 
     def _indicator(self, c, features, device, B):
         ids = categorical_of(c).ids(features, device)
@@ -89,14 +94,14 @@ class InputLayer(nn.Module):
         """Differentiable path: every column's block is its own tensor, concatenated in name order (autograd tracks
         the concat; the embedding blocks carry sparse table gradients, see autograd.EmbeddingBag)."""
         blocks, inside = {}, set()
-        for ts, idxs, comb in self._tablesets():
+        for ts, idxs, comb, mn in self._tablesets():
             cols = [self.emb_cols[i] for i in idxs]
             tabs = [self.embedding_weights[i] for i in idxs]
             got = collect_ids(cols, features, device)
             if got[0] == "onehot":
-                blk = ag.embedding_bag(ts, got[1], tabs)
+                blk = ag.embedding_bag(ts, got[1], tabs, max_norm=mn)
             else:
-                blk = ag.embedding_bag(ts, got[1], tabs, got[2], got[3], combiner=comb, field_major=True)
+                blk = ag.embedding_bag(ts, got[1], tabs, got[2], got[3], combiner=comb, field_major=True, max_norm=mn)
             # a group is a run of columns that are ADJACENT in the concat (see _tablesets): its block enters the concat whole, at
             # its first column's position (26 per-column slices would each cost a [B, 26*dim] zero fill + add in the backward)
             blocks[cols[0].name] = blk
@@ -130,7 +135,7 @@ class InputLayer(nn.Module):
                     B = v.shape[0]
                     x0 = alloc(B)
                 x0[:, self._col_offset(c):self._col_offset(c) + c.dimension] = v
-        for ts, idxs, comb in self._tablesets():
+        for ts, idxs, comb, mn in self._tablesets():
             cols = [self.emb_cols[i] for i in idxs]
             got = collect_ids(cols, features, device)
             nb = got[1].shape[0] if got[0] == "onehot" else got[4]
@@ -140,9 +145,9 @@ class InputLayer(nn.Module):
             off = self._col_offset(cols[0])
             view = x0[:, off:off + len(cols) * cols[0].dimension]
             if got[0] == "onehot":
-                ops.embedding_bag(ts, got[1], out=view)
+                ops.embedding_bag(ts, got[1], out=view, max_norm=mn)
             else:
-                ops.embedding_bag(ts, got[1], got[2], got[3], combiner=comb, field_major=True, out=view)
+                ops.embedding_bag(ts, got[1], got[2], got[3], combiner=comb, field_major=True, out=view, max_norm=mn)
         for c in self.columns:
             if isinstance(c, IndicatorColumn):  # multi-hot counts ([TF-upstream] indicator_column)
                 ind = self._indicator(c, features, device, B)

@@ -97,13 +97,32 @@ def _onehot_strides(ids, F):
     return ids.shape[0], ids.stride(0), ids.stride(1)
 
 
+def slot_combiners(ts, combiner):
+    """`combiner` as the C ABI takes it: (slot_combiner device int32 [F] | None, combiner code).  A str / code applies to
+    every slot; a sequence gives one combiner per slot (every embedding_column carries its own, DeepCrossNetwork/train.py:99)."""
+    if isinstance(combiner, (str, int)):
+        return None, _COMBINERS[combiner]
+    codes = [_COMBINERS[c] for c in combiner]
+    if len(codes) != ts.F:
+        raise ValueError("one combiner per slot: got %d for F=%d" % (len(codes), ts.F))
+    if all(c == codes[0] for c in codes):
+        return None, codes[0]
+    key = tuple(codes)
+    cache = ts.__dict__.setdefault("_slot_combiner_cache", {})
+    if key not in cache:
+        cache[key] = torch.tensor(codes, dtype=torch.int32, device=ts.device)
+    return cache[key], codes[0]
+
+
 def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", field_major=False, flags=0,
-                  out=None):
+                  out=None, max_norm=None):
     """Multi-slot embedding bag -> [B, F*K] (slot order).
 
     one-hot : ids LongTensor [B, F] (arbitrary strides, e.g. torch.stack(per_field).t()).
     multi-hot: ids [nnz], offsets [B*F+1]; bag(b,f) = b*F+f, or f*B+b when field_major (the layout
                that concatenating per-column CSR inputs gives); weights optional [nnz].
+    combiner: one name for all slots or a sequence of F names; max_norm: [TF-upstream] embedding_column(max_norm=).
+    ids outside [0, vocab_f) contribute nothing (id < 0: pruned as in the reference; id >= vocab_f: zeros as on TF GPU).
     """
     ts = _as_tableset(tables)
     _dev(ids, torch.int64, "ids")
@@ -126,8 +145,10 @@ def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", fiel
     _dev(out, torch.float32, "out")
     if offsets is None:
         flags |= ts.gather_flags()
-    _lib.check(lib.dir_embedding_bag_f32(_ptr(ts.ptrs), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
-                                         _COMBINERS[combiner], flags, B, _ptr(out), out.stride(0), _stream()))
+    slot_comb, comb = slot_combiners(ts, combiner)
+    _lib.check(lib.dir_embedding_bag_ex_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
+                                            _ptr(slot_comb), comb, float(max_norm or 0.0), flags, B, _ptr(out), out.stride(0),
+                                            _stream()))
     return out
 
 
@@ -168,7 +189,7 @@ def gather_fm(tables, ids, want_emb=True, out=None, fm=None):
         out = torch.empty((B, ts.F * ts.K), dtype=torch.float32, device=ts.device)
     if fm is None:
         fm = torch.empty((B, 1), dtype=torch.float32, device=ts.device)
-    _lib.check(_lib.load().dir_gather_fm_fused_f32(_ptr(ts.ptrs), ts.F, ts.K, _ptr(ids), sb, sf, ts.gather_flags(), B,
+    _lib.check(_lib.load().dir_gather_fm_fused_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, _ptr(ids), sb, sf, ts.gather_flags(), B,
                                                    _ptr(out) if want_emb else None,
                                                    out.stride(0) if want_emb else 0, _ptr(fm), _stream()))
     return (out if want_emb else None), fm
@@ -193,7 +214,7 @@ def linear_logit(weights, ids, offsets=None, entry_weights=None, combiner="sum",
         out = torch.empty((B, 1), dtype=torch.float32, device=ts.device)
     if bias is not None:
         _dev(bias, torch.float32, "bias")
-    _lib.check(_lib.load().dir_linear_sparse_sum_f32(_ptr(ts.ptrs), ts.F, _ptr(ids), _ptr(offsets), _ptr(entry_weights),
+    _lib.check(_lib.load().dir_linear_sparse_sum_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), ts.F, _ptr(ids), _ptr(offsets), _ptr(entry_weights),
                                                      sb, sf, _COMBINERS[combiner], _ptr(bias), int(accumulate), B,
                                                      _ptr(out), _stream()))
     return out
@@ -251,7 +272,13 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     args = [t.contiguous() for t in (W1, b1, W2, b2, W3, b3)]
     for t in args:
         _dev(t, torch.float32, "DIN weight")
-    hist = hist.contiguous()
+    # include/dir_hip.h declares hist [B,T], cand [B] and hist_len [B] as dense arrays (no stride arguments): a strided view
+    # (ids[:, j], lens[:, 0]) must be packed before its data_ptr() is handed over
+    hist, cand = hist.contiguous(), cand.contiguous()
+    if hist_len is not None:
+        hist_len = hist_len.contiguous()
+    if cand.numel() != B or (hist_len is not None and hist_len.numel() != B):
+        raise ValueError("DIN: cand and hist_len must have one entry per sample")
     out = torch.empty((B, K), dtype=torch.float32, device=table.device)
     scores = torch.empty((B, T), dtype=torch.float32, device=table.device) if want_scores else None
     _lib.check(_lib.load().dir_din_attention_pool_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
@@ -339,7 +366,9 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     args = [t.contiguous() for t in (W1, b1, W2, b2, W3, b3)]
     for t in args:
         _dev(t, torch.float32, "DIN weight")
-    hist, g = hist.contiguous(), g.contiguous()
+    hist, g, cand = hist.contiguous(), g.contiguous(), cand.contiguous()
+    if hist_len is not None:
+        hist_len = hist_len.contiguous()
     valid = hist >= 0
     if hist_len is not None:
         valid &= torch.arange(T, device=dev).unsqueeze(0) < hist_len.clamp(0, T).unsqueeze(1)
@@ -682,7 +711,7 @@ class SparseAdagrad:
                 self._next = torch.empty(B * ts.F, dtype=torch.int32, device=ts.device)
             _lib.check(lib.dir_sparse_adagrad_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
                                                   _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
-                                                  _ptr(self.head), _ptr(self._next), _stream()))
+                                                  self.total_rows, _ptr(self.head), _ptr(self._next), _stream()))
             return
         if B == 0:
             return
@@ -803,6 +832,7 @@ class PackedTables:
             self.rows.append(blk)
             off += v * ld
         self.ptrs = torch.tensor([r.data_ptr() for r in self.rows], dtype=torch.int64, device=self.device)
+        self.vocab_dev = torch.tensor(self.vocab, dtype=torch.int64, device=self.device)
         self.nbytes = total * 4
 
     def flags(self):
@@ -819,7 +849,7 @@ def gather_fm_linear(pt, ids, bias=None, want_emb=True, out=None, fm=None, lin=N
         fm = torch.empty((B, 1), dtype=torch.float32, device=pt.device)
     if lin is None and pt.lin_col >= 0:
         lin = torch.empty((B, 1), dtype=torch.float32, device=pt.device)
-    _lib.check(_lib.load().dir_gather_fm_linear_packed_f32(_ptr(pt.ptrs), pt.F, pt.K, pt.ld, pt.lin_col, _ptr(ids), sb, sf,
+    _lib.check(_lib.load().dir_gather_fm_linear_packed_f32(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, pt.lin_col, _ptr(ids), sb, sf,
                                                            pt.flags(), B, _ptr(out) if want_emb else None,
                                                            out.stride(0) if want_emb else 0, _ptr(fm), _ptr(bias),
                                                            _ptr(lin), _stream()))

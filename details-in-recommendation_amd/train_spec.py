@@ -131,6 +131,24 @@ def weighted_sigmoid_cross_entropy(logits, labels, weights=None, reduction="mean
     raise ValueError("unknown loss reduction %r" % (reduction,))
 
 
+def weighted_softmax_cross_entropy(logits, labels, weights=None, reduction="sum"):
+    """The multi-class canned head's loss (deepFM.py:112-117, [TF-upstream] _multi_class_head_with_softmax_cross_entropy_loss):
+    unweighted = sparse_softmax_cross_entropy(labels [B] or [B,1] class ids, logits [B, n_classes]) as [B,1], then
+    compute_weighted_loss with the head's loss_reduction (default SUM).  -> (weighted_loss scalar, unweighted_loss [B,1])"""
+    y = labels.reshape(-1).to(torch.int64)
+    unweighted = torch.nn.functional.cross_entropy(logits, y, reduction="none").unsqueeze(1)
+    w = torch.ones_like(unweighted) if weights is None else weights.to(unweighted.dtype).reshape(-1, 1).expand_as(unweighted)
+    total = (unweighted * w).sum()
+    if reduction in ("sum", "weighted_sum"):
+        return total, unweighted
+    if reduction in ("mean", "weighted_mean"):
+        den = w.sum()
+        return torch.where(den > 0, total / den.clamp_min(1e-30), torch.zeros_like(total)), unweighted
+    if reduction == "sum_over_batch_size":
+        return total / unweighted.numel(), unweighted
+    raise ValueError("unknown loss reduction %r" % (reduction,))
+
+
 def clip_by_norm_(grad, clip_norm=CLIP_NORM):
     """tf.clip_by_norm on one tensor, in place: g * clip / max(||g||_2, clip).  Sparse gradients: over their values."""
     if grad is None:
@@ -170,8 +188,15 @@ class TrainStep:
             else:
                 kw[_SPEC_KEYS.get(k, k) or k] = v
         cls = _OPTIMIZERS[optimizer] if isinstance(optimizer, str) else optimizer
+        self._tf_adam_eps = None
         if cls is torch.optim.Adam:
             kw["betas"] = tuple(betas)
+            # tf.train.AdamOptimizer applies epsilon AFTER folding the bias corrections into the step size ("epsilon hat"):
+            #   var -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps_tf)
+            # torch.optim.Adam divides by sqrt(v) / sqrt(1 - b2^t) + eps, i.e. the same update with
+            # eps_torch = eps_tf / sqrt(1 - b2^t) (31.6x larger at t = 1 for b2 = 0.999); __call__ sets it every step.
+            self._tf_adam_eps = float(kw.get("eps", 1e-8))
+            self._beta2 = float(betas[1])
         self.params = [p for p in model.parameters() if p.requires_grad]
         lr0 = learning_rate_decay(self.learning_rate_spec, 0)
         self.optimizer = None
@@ -192,6 +217,8 @@ class TrainStep:
         lr = learning_rate_decay(self.learning_rate_spec, self.global_step)
         for group in self.optimizer.param_groups:
             group["lr"] = lr
+            if self._tf_adam_eps is not None:
+                group["eps"] = self._tf_adam_eps / math.sqrt(1.0 - self._beta2 ** (self.global_step + 1))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         touched = []

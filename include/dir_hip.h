@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* dir_stream_t; /* hipStream_t */
 
-#define DIR_VERSION 100 /* 0.1.0 */
+#define DIR_VERSION 200 /* 0.2.0: vocab bounds on the lookups, dir_embedding_bag_ex_f32, fixed-capacity shard exchange */
 
 enum {
     DIR_OK = 0,
@@ -69,12 +69,28 @@ const char* dir_last_error(void);
  *
  * Semantics (A2): entries with id < 0 are dropped; an empty bag yields zeros; the bag is reduced in
  * entry order in fp32 (sum of w*row), then 'mean' divides by sum(w) (count when weights == NULL),
- * 'sqrtn' by sqrt(sum(w*w)) (sqrt(count)).  0 <= id < vocab_f is a precondition (see dir_check_ids).
+ * 'sqrtn' by sqrt(sum(w*w)) (sqrt(count)).  0 <= id < vocab_f is a precondition of this entry point (see dir_check_ids and
+ * the vocab argument of dir_embedding_bag_ex_f32).
  * ------------------------------------------------------------------------------------------ */
 int dir_embedding_bag_f32(const float* const* tables, int F, int K,
                           const int64_t* ids, const int64_t* offsets, const float* weights,
                           int64_t stride_b, int64_t stride_f, int combiner, int flags, int64_t B,
                           float* out, int64_t out_ld, dir_stream_t stream);
+
+/* The same with the per-column attributes a tf.feature_column.embedding_column carries (constructor call sites
+ * models/DeepCrossNetwork/train.py:99, dataset/SequenceTensorFlowDataset/test4.py:53-55):
+ *   vocab          DEVICE int64 [F] or NULL.  With it an id >= vocab_f is pruned like id < 0 (what [TF-upstream] GPU lookups
+ *                  return for an out-of-range id: zeros; the CPU kernels raise InvalidArgument -- the host mirror's
+ *                  IdentityCategoricalColumn does that check).  NULL: 0 <= id < vocab_f stays a precondition.
+ *   slot_combiner  DEVICE int32 [F] or NULL: one DIR_COMBINER_* per slot (every embedding_column has its own combiner=);
+ *                  NULL: `combiner` for all slots.
+ *   max_norm       > 0: [TF-upstream] embedding_lookup(max_norm=): every looked-up row is clipped to that l2 norm before it
+ *                  is weighted -- row * max_norm / max(||row||, max_norm), ||row|| = sqrt(sum_k row_k^2) summed k-ascending
+ *                  (clip_ops.clip_by_norm, r1.10+ form).  0: no clipping.  One-hot ids (offsets == NULL) are accepted too. */
+int dir_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, int F, int K,
+                             const int64_t* ids, const int64_t* offsets, const float* weights,
+                             int64_t stride_b, int64_t stride_f, const int32_t* slot_combiner, int combiner,
+                             float max_norm, int flags, int64_t B, float* out, int64_t out_ld, dir_stream_t stream);
 
 /* Validation of the precondition above (debug aid, asynchronous like everything else).
  * vocab: DEVICE array [F].  bad_count: DEVICE int32; zeroed on the stream, then set to the number of
@@ -95,8 +111,9 @@ int dir_fm_second_order_f32(const float* emb, int64_t emb_ld, int64_t B, int F, 
 
 /* A1+A4 fused for one-hot slots: one pass over the rows.  out may be NULL (FM only); fm may be NULL
  * (gather only).  flags: DIR_GATHER_STREAM_ROWS.  Replaces deepFM.py:169-177 (inputs) + :321-335
- * (fm_logit_fn) in one launch. */
-int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int64_t* ids,
+ * (fm_logit_fn) in one launch.  vocab: DEVICE int64 [F] or NULL, as in dir_embedding_bag_ex_f32 (an id >= vocab_f
+ * contributes a zero row; one scalar compare per slot). */
+int dir_gather_fm_fused_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
                             int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out,
                             int64_t out_ld, float* fm, dir_stream_t stream);
 
@@ -105,8 +122,9 @@ int dir_gather_fm_fused_f32(const float* const* tables, int F, int K, const int6
  * column lin_col (-1: none).  With ld*4 = 128 B and 128-byte aligned tables a row is exactly one memory line, so
  * DeepFM's three sparse terms -- inputs (deepFM.py:169-177), fm_logit_fn (:321-335) and the linear term (:255-275)
  * over the same columns -- cost one line fetch per (sample, slot).  out / fm / lin_out may each be NULL;
- * lin_out[b] = sum_f w_f[id] (+ *bias), summed in slot order: bit-identical to dir_linear_sparse_sum_f32. */
-int dir_gather_fm_linear_packed_f32(const float* const* tables, int F, int K, int64_t ld, int lin_col,
+ * lin_out[b] = sum_f w_f[id] (+ *bias), summed in slot order: bit-identical to dir_linear_sparse_sum_f32.
+ * vocab: DEVICE int64 [F] or NULL (ids >= vocab_f pruned), as in dir_embedding_bag_ex_f32. */
+int dir_gather_fm_linear_packed_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
                                     const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
                                     int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
                                     float* lin_out, dir_stream_t stream);
@@ -116,10 +134,10 @@ int dir_gather_fm_linear_packed_f32(const float* const* tables, int F, int K, in
  * Replaces: _linear_logit_fn_builder                    models/DeepFM/deepFM.py:255-275
  *           [TF-upstream] feature_column.linear_model(..., sparse_combiner=)
  * weights  device array [F] of device pointers, slot f -> fp32 [vocab_f]
- * ids/offsets/entry_weights/strides as in dir_embedding_bag_f32.
+ * ids/offsets/entry_weights/strides as in dir_embedding_bag_f32; vocab: DEVICE int64 [F] or NULL (ids >= vocab_f pruned).
  * out[b] = (accumulate ? out[b] : 0) + (bias ? *bias : 0) + sum_f combine_f(bag(b,f))
  * ------------------------------------------------------------------------------------------ */
-int dir_linear_sparse_sum_f32(const float* const* weights, int F, const int64_t* ids,
+int dir_linear_sparse_sum_f32(const float* const* weights, const int64_t* vocab, int F, const int64_t* ids,
                               const int64_t* offsets, const float* entry_weights, int64_t stride_b,
                               int64_t stride_f, int combiner, const float* bias, int accumulate,
                               int64_t B, float* out, dir_stream_t stream);
@@ -322,18 +340,21 @@ int dir_din_attention_pool_backward_f32(const float* table, int K, const int64_t
  * duplicate indices are summed before the update), accum[f][id] += g*g, tables[f][id] -= lr * g / sqrt(accum).
  * tables / accums: device arrays [F] of device pointers ([vocab_f, K] fp32, updated in place);
  * ids / strides as in dir_embedding_bag_f32 (one-hot; ids < 0 are skipped); grad [B, F*K] (row stride grad_ld);
- * head_base: DEVICE int64 [F], slot f's first entry in head; head: persistent DEVICE int32 [sum vocab_f], all -1
- * before the first call (left all -1 again on return); next: DEVICE int32 [B*F] scratch. */
+ * head_base: DEVICE int64 [F], slot f's first entry in head; total_rows = sum vocab_f (slot f has
+ * head_base[f+1] - head_base[f] rows, the last one total_rows - head_base[F-1]: an id outside its slot is skipped, never
+ * written); head: persistent DEVICE int32 [total_rows], all -1 before the first call (left all -1 again on return);
+ * next: DEVICE int32 [B*F] scratch. */
 int dir_sparse_adagrad_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
                            int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
-                           int64_t B, const int64_t* head_base, int32_t* head, int32_t* next,
+                           int64_t B, const int64_t* head_base, int64_t total_rows, int32_t* head, int32_t* next,
                            dir_stream_t stream);
 
 /* The same update with the (row, entry) pairs radix-sorted first (stable: duplicates are summed in batch order; no
  * atomics; bitwise reproducible) and the runs of equal rows reduced per tile of 256 sorted entries -- the longest serial
  * walk is 256 entries whatever the skew of the ids (the chain walk above serialises on hot rows).
  * row_base: DEVICE int64 [F], slot f's first row in the concatenation of all tables; total_rows = sum of the vocab sizes
- * (< 2^32 - 1).  workspace: dir_sparse_adagrad_sorted_workspace_bytes(B, F, K, total_rows) device bytes, 256-byte aligned. */
+ * (< 2^32 - 1).  An id outside [0, vocab_f) (vocab_f from row_base / total_rows) is skipped like a pruned id: the update
+ * never writes outside slot f's table.  workspace: dir_sparse_adagrad_sorted_workspace_bytes(B, F, K, total_rows) device bytes, 256-byte aligned. */
 int64_t dir_sparse_adagrad_sorted_workspace_bytes(int64_t B, int F, int K, int64_t total_rows);
 int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, int F, int K, const int64_t* ids,
                                   int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,

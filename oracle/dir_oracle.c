@@ -40,31 +40,52 @@ int orc_version(void) { return 100; }
  *       without weights: sparse_segment_{sum,mean,sqrt_n}: sum / count, sum / sqrt(count).
  * Addressing is that of include/dir_hip.h (dir_embedding_bag_f32).
  * ---------------------------------------------------------------------------------------------- */
-int orc_embedding_bag_f32(const float* const* tables, int F, int K, const int64_t* ids,
-                          const int64_t* offsets, const float* weights, int64_t stride_b,
-                          int64_t stride_f, int combiner, int flags, int64_t B, float* out,
-                          int64_t out_ld) {
-    if (!tables || !ids || !out || F <= 0 || K <= 0 || B < 0) return -1;
+/* Extended form (include/dir_hip.h: dir_embedding_bag_ex_f32): vocab [F] or NULL (id >= vocab_f pruned like id < 0),
+ * slot_combiner [F] or NULL (one combiner per column: every tf.feature_column.embedding_column carries its own,
+ * models/DeepCrossNetwork/train.py:99), max_norm > 0: [TF-upstream] embedding_lookup(max_norm=) -> clip_ops.clip_by_norm
+ * (r1.10+): row * max_norm / max(l2norm, max_norm) with l2norm = sqrt(sum_k row_k^2), k ascending, 0 when the sum is 0;
+ * applied to each looked-up row before it is weighted. */
+static void orc_clip_row(const float* row, int K, float max_norm, float* dst) {
+    float l2sum = 0.0f;
+    for (int k = 0; k < K; ++k) l2sum = l2sum + row[k] * row[k];
+    float l2norm = l2sum > 0.0f ? sqrtf(l2sum) : l2sum;
+    float den = l2norm > max_norm ? l2norm : max_norm;
+    for (int k = 0; k < K; ++k) dst[k] = (row[k] * max_norm) / den;
+}
+
+int orc_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
+                             const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
+                             const int32_t* slot_combiner, int combiner, float max_norm, int flags, int64_t B,
+                             float* out, int64_t out_ld) {
+    if (!tables || !ids || !out || F <= 0 || K <= 0 || B < 0 || K > 4096) return -1;
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
+        float clipped[4096];
         for (int f = 0; f < F; ++f) {
             float* o = out + b * out_ld + (int64_t)f * K;
             const float* tab = tables[f];
+            const int comb = slot_combiner ? slot_combiner[f] : combiner;
+            const int64_t vf = vocab ? vocab[f] : INT64_MAX;
             for (int k = 0; k < K; ++k) o[k] = 0.0f;
-            if (!offsets) { /* one-hot: a bag of one entry, weight 1 */
-                int64_t id = ids[b * stride_b + f * stride_f];
-                if (id >= 0) memcpy(o, tab + id * K, sizeof(float) * (size_t)K);
+            int64_t bag = b * stride_b + f * stride_f;
+            int64_t beg = offsets ? offsets[bag] : bag, end = offsets ? offsets[bag + 1] : bag + 1; /* one-hot: a bag of one entry */
+            if (!offsets && !(max_norm > 0.0f)) { /* weight 1, no clipping: every combiner is the identity */
+                int64_t id = ids[bag];
+                if (id >= 0 && id < vf) memcpy(o, tab + id * K, sizeof(float) * (size_t)K);
                 continue;
             }
-            int64_t bag = b * stride_b + f * stride_f;
             float wsum = 0.0f, w2sum = 0.0f;
             int64_t cnt = 0;
-            for (int64_t e = offsets[bag]; e < offsets[bag + 1]; ++e) {
+            for (int64_t e = beg; e < end; ++e) {
                 int64_t id = ids[e];
-                if (id < 0) continue;
+                if (id < 0 || id >= vf) continue;
                 float w = weights ? weights[e] : 1.0f;
                 if (weights && (flags & ORC_PRUNE_NONPOSITIVE_WEIGHTS) && !(w > 0.0f)) continue;
                 const float* row = tab + id * K;
+                if (max_norm > 0.0f) {
+                    orc_clip_row(row, K, max_norm, clipped);
+                    row = clipped;
+                }
                 if (weights) {
                     for (int k = 0; k < K; ++k) o[k] = o[k] + w * row[k];
                 } else {
@@ -75,16 +96,24 @@ int orc_embedding_bag_f32(const float* const* tables, int F, int K, const int64_
                 ++cnt;
             }
             if (cnt == 0) continue; /* empty bag -> zeros */
-            if (combiner == ORC_MEAN) {
+            if (comb == ORC_MEAN) {
                 float den = weights ? wsum : (float)cnt;
                 for (int k = 0; k < K; ++k) o[k] = o[k] / den;
-            } else if (combiner == ORC_SQRTN) {
+            } else if (comb == ORC_SQRTN) {
                 float den = weights ? sqrtf(w2sum) : sqrtf((float)cnt);
                 for (int k = 0; k < K; ++k) o[k] = o[k] / den;
             }
         }
     }
     return 0;
+}
+
+int orc_embedding_bag_f32(const float* const* tables, int F, int K, const int64_t* ids,
+                          const int64_t* offsets, const float* weights, int64_t stride_b,
+                          int64_t stride_f, int combiner, int flags, int64_t B, float* out,
+                          int64_t out_ld) {
+    return orc_embedding_bag_ex_f32(tables, NULL, F, K, ids, offsets, weights, stride_b, stride_f, NULL, combiner, 0.0f, flags, B,
+                                    out, out_ld);
 }
 
 /* ------------------------------------------------------------------------------------------------

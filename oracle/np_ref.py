@@ -22,7 +22,17 @@ SUM, MEAN, SQRTN = 0, 1, 2
 # [TF-upstream] safe_embedding_lookup_sparse / embedding_lookup_sparse; call site
 # models/DeepFM/deepFM.py:387-390.
 # ---------------------------------------------------------------------------------------------
-def bag(table, ids, weights=None, combiner=MEAN, prune_nonpositive_weights=False):
+def clip_by_norm(row, max_norm):
+    """[TF-upstream] clip_ops.clip_by_norm (r1.10+) on one looked-up row (embedding_lookup(max_norm=)), fp32."""
+    row = row.astype(np.float32)
+    l2sum = np.float32(0)
+    for v in row:
+        l2sum = np.float32(l2sum + v * v)
+    l2norm = np.sqrt(l2sum) if l2sum > 0 else l2sum
+    return ((row * np.float32(max_norm)) / np.maximum(np.float32(l2norm), np.float32(max_norm))).astype(np.float32)
+
+
+def bag(table, ids, weights=None, combiner=MEAN, prune_nonpositive_weights=False, max_norm=None):
     K = table.shape[1]
     acc = np.zeros(K, np.float32)
     wsum = np.float32(0)
@@ -34,7 +44,11 @@ def bag(table, ids, weights=None, combiner=MEAN, prune_nonpositive_weights=False
         w = np.float32(1) if weights is None else np.float32(weights[e])
         if weights is not None and prune_nonpositive_weights and not (w > 0):
             continue
+        if i >= table.shape[0]:
+            continue                     # out of range: no contribution (TF GPU lookups return zeros)
         row = table[int(i)].astype(np.float32)
+        if max_norm:
+            row = clip_by_norm(row, max_norm)
         acc = (acc + w * row).astype(np.float32) if weights is not None else (acc + row).astype(np.float32)
         wsum = np.float32(wsum + w)
         w2sum = np.float32(w2sum + w * w)

@@ -51,8 +51,10 @@ def _ptr_array(arrs):
 
 
 def embedding_bag(tables, ids, offsets=None, weights=None, stride_b=None, stride_f=None,
-                  combiner=MEAN, flags=0, B=None, out_ld=None):
-    """tables: list of F arrays [V_f,K].  One-hot: ids [B,F] (strides default to its layout)."""
+                  combiner=MEAN, flags=0, B=None, out_ld=None, vocab=None, max_norm=0.0, out=None):
+    """tables: list of F arrays [V_f,K].  One-hot: ids [B,F] (strides default to its layout).
+    combiner: one code or a sequence of F codes; vocab: True (the tables' row counts) / sequence / None;
+    out: a preallocated [B, out_ld] fp32 array to write into (the CPU-baseline leg reuses one)."""
     tables = [_f32(t) for t in tables]
     F, K = len(tables), tables[0].shape[1]
     ids = _i64(ids)
@@ -69,11 +71,22 @@ def embedding_bag(tables, ids, offsets=None, weights=None, stride_b=None, stride
             stride_b, stride_f = F, 1
     weights = _f32(weights) if weights is not None else None
     out_ld = out_ld or F * K
-    out = np.zeros((B, out_ld), np.float32)
-    rc = lib().orc_embedding_bag_f32(_ptr_array(tables), F, K, _p(ids, ctypes.c_int64),
-                                     _p(offsets, ctypes.c_int64), _p(weights, ctypes.c_float),
-                                     ctypes.c_int64(stride_b), ctypes.c_int64(stride_f), combiner, flags,
-                                     ctypes.c_int64(B), _p(out, ctypes.c_float), ctypes.c_int64(out_ld))
+    if out is None:
+        out = np.zeros((B, out_ld), np.float32)
+    assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (B, out_ld)
+    slot = None
+    if not isinstance(combiner, (int, np.integer)):
+        slot = np.ascontiguousarray(combiner, np.int32)
+        assert slot.size == F
+        combiner = int(slot[0])
+    if vocab is True:
+        vocab = [t.shape[0] for t in tables]
+    voc = _i64(vocab) if vocab is not None else None
+    rc = lib().orc_embedding_bag_ex_f32(_ptr_array(tables), _p(voc, ctypes.c_int64), F, K, _p(ids, ctypes.c_int64),
+                                        _p(offsets, ctypes.c_int64), _p(weights, ctypes.c_float),
+                                        ctypes.c_int64(stride_b), ctypes.c_int64(stride_f), _p(slot, ctypes.c_int32),
+                                        int(combiner), ctypes.c_float(max_norm), flags,
+                                        ctypes.c_int64(B), _p(out, ctypes.c_float), ctypes.c_int64(out_ld))
     assert rc == 0, rc
     return out
 

@@ -190,6 +190,49 @@ def test_fused_sparse_adagrad(built_lib, B, F, K, V, method):
         _close(opt.accums[f], ref_a[f], tol=2e-5)
 
 
+@pytest.mark.parametrize("method", ["sorted", "chains"])
+def test_sparse_updates_never_write_outside_a_table(built_lib, method):
+    """an id >= vocab_f must not alias a row of the NEXT table (key = row_base[f] + id) nor write past the
+    end: the update kernels derive vocab_f from row_base / total_rows and skip such ids like pruned ones.  The tables live
+    back to back in one arena with guard rows, so any stray write is caught."""
+    from dir_amd import ops
+    rng = np.random.default_rng(21)
+    B, F, K = 2048, 3, 16
+    vocab = [5, 9, 7]
+    arena = torch.zeros(sum(vocab) + 8, K, device="cuda")                      # 8 guard rows behind the last table
+    tabs, o = [], 0
+    for v in vocab:
+        tabs.append(arena[o:o + v])
+        o += v
+    init = torch.randn(sum(vocab), K, device="cuda")
+    arena[:sum(vocab)] = init
+    opt = ops.SparseAdagrad(tabs, lr=0.05, method=method)
+    acc0 = [a.clone() for a in opt.accums]
+    ids = np.stack([rng.integers(-1, v + 6, size=B) for v in vocab], 1).astype(np.int64)     # up to 5 rows past each table
+    grad = rng.standard_normal((B, F * K)).astype(np.float32)
+    opt.step(torch.from_numpy(ids).cuda(), torch.from_numpy(grad).cuda())
+    assert float(arena[sum(vocab):].abs().max()) == 0.0                        # nothing written behind the last table
+    o = 0
+    for f, v in enumerate(vocab):
+        ok = (ids[:, f] >= 0) & (ids[:, f] < v)
+        gsum = np.zeros((v, K))
+        np.add.at(gsum, ids[ok, f], grad[ok, f * K:(f + 1) * K].astype(np.float64))
+        touched = np.zeros(v, bool); touched[ids[ok, f]] = True
+        a = np.full((v, K), 0.1); a[touched] += gsum[touched] ** 2
+        w = init[o:o + v].cpu().double().numpy(); w[touched] -= 0.05 * gsum[touched] / np.sqrt(a[touched])
+        _close(tabs[f], w, tol=2e-5)
+        _close(opt.accums[f], a, tol=2e-5)
+        assert torch.equal(opt.accums[f][~torch.from_numpy(touched).cuda()], acc0[f][~torch.from_numpy(touched).cuda()])
+        o += v
+    # FTRL through the same sorted machinery
+    lw = [torch.zeros(v, device="cuda") for v in vocab]
+    ftrl = ops.SparseFtrl(lw, lr=0.2)
+    ftrl.step(torch.from_numpy(ids).cuda(), torch.from_numpy(grad[:, :1].copy()).cuda())
+    for f, v in enumerate(vocab):
+        untouched = np.ones(v, bool); untouched[ids[(ids[:, f] >= 0) & (ids[:, f] < v), f]] = False
+        assert float(lw[f][torch.from_numpy(untouched).cuda()].abs().sum()) == 0.0
+
+
 def test_sorted_adagrad_bitwise_reproducible_on_skewed_ids(built_lib):
     from dir_amd import ops
     g = torch.Generator().manual_seed(9)

@@ -463,3 +463,114 @@ def test_dense_limits(built_lib):
     with pytest.raises(DirError):
         ops.dense(x, torch.randn(32, 10).cuda())
     assert not ops.dense_supported(torch.randn(8, 16).cuda(), torch.randn(1, 16).cuda())   # units = 1: library matrix-vector product
+
+
+# ---- dir_embedding_bag_ex_f32: per-column combiners, max_norm, vocabulary bound (round 2) --------------------------------------
+@pytest.mark.parametrize("K,F,V,B", [(16, 5, 97, 257), (8, 3, 41, 130), (6, 4, 33, 65), (64, 2, 50, 40), (1, 3, 20, 77)])
+def test_bag_ex_slot_combiners_max_norm_vocab_bit_exact(ops, oracle, K, F, V, B):
+    rng = np.random.default_rng(K * 7 + F)
+    tables = _tables(rng, F, V, K, scale=1.0)
+    lens = rng.integers(0, 6, size=B * F)
+    lens[::5] = 0
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ids = rng.integers(-1, V + 3, size=offs[-1]).astype(np.int64)          # -1 pruned, V..V+2 out of range
+    w = rng.uniform(0.1, 2.0, size=offs[-1]).astype(np.float32)
+    combs = [(f * 2 + 1) % 3 for f in range(F)]                            # mean, sum, sqrtn, ... per column
+    names = [["sum", "mean", "sqrtn"][c] for c in combs]
+    ts = ops.TableSet([_dev(t) for t in tables])
+    for mn in (None, 0.75):
+        for wts in (None, w):
+            ref = oracle.embedding_bag(tables, ids, offsets=offs, weights=wts, combiner=combs, B=B, vocab=True, max_norm=mn or 0.0)
+            got = ops.embedding_bag(ts, _dev(ids), _dev(offs), None if wts is None else _dev(wts), combiner=names, max_norm=mn)
+            np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    # one-hot ids: out-of-range ids give zero rows in every gather flavour; max_norm clips one-hot rows too
+    oh = rng.integers(-1, V + 2, size=(B, F)).astype(np.int64)
+    ref = oracle.embedding_bag(tables, oh, vocab=True)
+    assert (ref[(oh >= V).repeat(K, axis=1)] == 0).all()
+    np.testing.assert_array_equal(ops.embedding_bag(ts, _dev(oh)).cpu().numpy(), ref)
+    emb, fm = ops.gather_fm(ts, _dev(oh))
+    np.testing.assert_array_equal(emb.cpu().numpy(), ref)
+    np.testing.assert_array_equal(fm.cpu().numpy()[:, 0], oracle.fm_second_order(ref, F, K))
+    refc = oracle.embedding_bag(tables, oh, vocab=True, max_norm=0.5)
+    np.testing.assert_array_equal(ops.embedding_bag(ts, _dev(oh), max_norm=0.5).cpu().numpy(), refc)
+    nrm = np.linalg.norm(refc.reshape(B, F, K), axis=2)
+    assert nrm.max() <= 0.5 * (1 + 1e-6)
+    if K == 1:                                                             # the linear term prunes out-of-range ids as well
+        lts = ops.TableSet([_dev(t[:, 0].copy()) for t in tables])
+        refl = oracle.embedding_bag(tables, oh, vocab=True).sum(axis=1)
+        _close(ops.linear_logit(lts, _dev(oh)).cpu().numpy()[:, 0], refl)
+
+
+def test_np_ref_bag_agrees_with_c_oracle_on_max_norm(oracle):
+    rng = np.random.default_rng(5)
+    table = rng.standard_normal((30, 8)).astype(np.float32)
+    for _ in range(20):
+        n = int(rng.integers(0, 6))
+        ids = rng.integers(-1, 32, size=n).astype(np.int64)
+        w = rng.uniform(0.1, 2, size=n).astype(np.float32)
+        for comb in (0, 1, 2):
+            a = R.bag(table, ids, w, comb, max_norm=0.9)
+            b = oracle.embedding_bag([table], ids, offsets=np.array([0, n]), weights=w, combiner=comb, B=1, vocab=True, max_norm=0.9)[0]
+            np.testing.assert_array_equal(a, b)
+
+
+def test_din_strided_candidate_and_lengths(ops, oracle):
+    """cand = ids[:, j] / hist_len = lens[:, 0] are strided views; the C ABI takes dense [B] arrays."""
+    rng = np.random.default_rng(11)
+    V, K, T, H1, H2, B = 200, 64, 20, 80, 40, 37
+    table = (rng.standard_normal((V, K)) * 0.125).astype(np.float32)
+    both = rng.integers(0, V, size=(B, 3)).astype(np.int64)
+    lens2 = rng.integers(0, T + 1, size=(B, 2)).astype(np.int32)
+    hist = rng.integers(-1, V, size=(B, T)).astype(np.int64)
+    W = [(rng.standard_normal(s) * 0.1).astype(np.float32) for s in ((4 * K, H1), (H1,), (H1, H2), (H2,), (H2,), (1,))]
+    cand_v, len_v = _dev(both)[:, 1], _dev(lens2)[:, 0]
+    assert not cand_v.is_contiguous() and not len_v.is_contiguous()
+    out = ops.din_attention_pool(_dev(table), _dev(hist), len_v, cand_v, *[_dev(x) for x in W], normalize=True)
+    ref, _ = oracle.din_attention_pool(table, hist, lens2[:, 0].copy(), both[:, 1].copy(), *W, normalize=True, acc64=True)
+    _close(out.cpu().numpy(), ref)
+
+
+def test_full_size_config4_din_on_the_10m_row_table(ops, oracle):
+    """BASELINE.json configs[3] at its own size: 10 000 000-item vocabulary x dim 64 (2.56 GB, ten times the Infinity Cache),
+    B = 65 536, T = 50, 256-80-40-1 unit, masked softmax.  Size-independent properties on the whole batch + 64 sampled samples
+    against the double-accumulating oracle."""
+    B, T, K, V, H1, H2 = 65536, 50, 64, 10_000_000, 80, 40
+    g = torch.Generator(device="cuda").manual_seed(4)
+    table = torch.empty((V, K), device="cuda")
+    for s in range(0, V, 2_500_000):
+        table[s:s + 2_500_000].normal_(0, 0.125, generator=g)
+    hist = torch.randint(0, V, (B, T), generator=g, device="cuda")
+    hist[:, 0] = torch.randint(V - 1000, V, (B,), generator=g, device="cuda")        # rows at the very top of the table
+    hl = torch.randint(0, T + 1, (B,), generator=g, device="cuda", dtype=torch.int32)
+    cand = torch.randint(0, V, (B,), generator=g, device="cuda")
+    W1 = torch.randn((4 * K, H1), generator=g, device="cuda") * 0.05
+    W2 = torch.randn((H1, H2), generator=g, device="cuda") * 0.1
+    W3 = torch.randn((H2,), generator=g, device="cuda") * 0.1
+    b1 = torch.randn(H1, generator=g, device="cuda") * 0.05
+    b2 = torch.randn(H2, generator=g, device="cuda") * 0.05
+    b3 = torch.zeros(1, device="cuda")
+    for norm in (True, False):
+        out, sc = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=norm, want_scores=True)
+        nonempty = hl > 0
+        mask = torch.arange(T, device="cuda").unsqueeze(0) < hl.unsqueeze(1)
+        assert (sc[~mask] == 0).all() and (out[~nonempty] == 0).all()
+        if norm:
+            ssum = sc.sum(1)
+            assert torch.allclose(ssum[nonempty], torch.ones_like(ssum[nonempty]), atol=1e-5)
+        sel = torch.arange(0, B, 1021, device="cuda")[:64]
+        comb = (sc[sel].unsqueeze(2) * table[hist[sel]]).sum(1)                       # out = sum_j w_j h_j with the kernel's own weights
+        assert torch.allclose(out[sel], comb, rtol=1e-5, atol=1e-6)
+        # the oracle on a compact copy of exactly the rows these 64 samples touch (the 2.56 GB table stays on the device)
+        rows = torch.unique(torch.cat([hist[sel].reshape(-1), cand[sel]]))
+        small = table[rows].cpu().numpy()
+        remap = {int(r): i for i, r in enumerate(rows.cpu().tolist())}
+        h_s = np.vectorize(remap.get)(hist[sel].cpu().numpy()).astype(np.int64)
+        c_s = np.vectorize(remap.get)(cand[sel].cpu().numpy()).astype(np.int64)
+        ro, rs = oracle.din_attention_pool(small, h_s, hl[sel].cpu().numpy(), c_s, W1.cpu().numpy(), b1.cpu().numpy(),
+                                           W2.cpu().numpy(), b2.cpu().numpy(), W3.cpu().numpy(), b3.cpu().numpy(),
+                                           normalize=norm, acc64=True)
+        _close(out[sel].cpu().numpy(), ro)
+        _close(sc[sel].cpu().numpy(), rs)
+    # run-to-run bitwise reproducibility at full size
+    out2 = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=False)
+    assert torch.equal(out2, out)

@@ -1,0 +1,186 @@
+"""Tests against tests/golden/ref_text_v1.npz -- vectors produced by EXECUTING THE REFERENCE'S OWN TEXT
+(deepFM.py:143-400, DeepCrossNetwork.py:118-419) under a NumPy stand-in for tensorflow (oracle/tf_stub.py; generator
+tests/golden/make_ref_text.py, build container only).  Label: "stubbed tf" -- op order / axes / constants / concat orders /
+variable scopes are the reference's; the arithmetic of each primitive is the stub's restatement of TF 1.x behaviour.
+
+CPU (this file, not gpu): the oracle (C and NumPy restatements) agrees with what the reference text computed, the
+checkpoint name map equals the variable names the reference text asked for, and -- when /root/reference is present -- the
+committed fixture is exactly what the generator produces.  GPU: tests/test_gpu_ref_text.py."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "ref_text_v1.npz"))
+VARIANTS = ("onehot", "onehot_bn", "ragged")
+
+
+def _close(got, ref, tol=1e-5):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = np.abs(got - ref) / (1 + np.abs(ref))
+    assert err.max() <= tol, err.max()
+
+
+def deepfm_vars():
+    return {k[len("deepfm_var:"):]: G[k] for k in G.files if k.startswith("deepfm_var:")}
+
+
+def dcn_vars():
+    return {k[len("dcn_var:"):]: G[k] for k in G.files if k.startswith("dcn_var:")}
+
+
+def deepfm_csr(variant):
+    """The fixture's dnn features as one field-major CSR (bag(b, f) = f*B + b) + per-field combiners."""
+    ids = G["deepfm_ids"]
+    B, F = ids.shape
+    vals, offs, wts, base = [], [], [], 0
+    combs = ["mean"] * F
+    if variant == "ragged":
+        combs[4] = "sum"
+    for f in range(F):
+        if variant == "ragged" and f in (1, 4):
+            v, o, w = G["deepfm_rag%d_values" % f], G["deepfm_rag%d_offsets" % f], G["deepfm_rag%d_weights" % f]
+        else:
+            v, o, w = ids[:, f], np.arange(B + 1), np.ones(B, np.float32)
+        vals.append(v); offs.append(o[:-1] + base); wts.append(w)
+        base += v.size
+    offs.append(np.array([base]))
+    return np.concatenate(vals).astype(np.int64), np.concatenate(offs).astype(np.int64), np.concatenate(wts).astype(np.float32), combs
+
+
+def test_fp32_and_fp64_runs_of_the_reference_text_agree():
+    for k in G.files:
+        if k.endswith("_f32") and k[:-4] + "_f64" in G.files and G[k].dtype == np.float32:
+            _close(G[k], G[k[:-4] + "_f64"], 2e-6)
+
+
+def test_oracle_fm_matches_reference_text(oracle):
+    from oracle import np_ref as R
+    _close(oracle.fm_second_order(G["fm26_emb"], 26, 16), G["fm26_logit_f64"][:, 0])
+    _close(oracle.fm_second_order(G["fm26_emb"], 26, 16, acc64=True), G["fm26_logit_f64"][:, 0], 1e-6)
+    np.testing.assert_array_equal(R.fm_logit(G["fm26_emb"], 26, 16), G["fm26_logit_f32"])      # same four NumPy ops, same order
+    for v in VARIANTS:
+        emb = G["deepfm_%s_inputs_f32" % v]
+        _close(oracle.fm_second_order(emb, 6, 8), G["deepfm_%s_fm_f64" % v][:, 0])
+        _close(R.fm_logit(emb, 6, 8, np.float64), G["deepfm_%s_fm_f64" % v])
+
+
+def test_oracle_bags_match_reference_text(oracle):
+    """myself_input_layer (deepFM.py:363-400) output through the stub's lookup == the C oracle's bags, bit for bit: both
+    are in-order fp32 sums of w*row with id < 0 pruned and empty bags -> zeros."""
+    vars_ = deepfm_vars()
+    tabs = [vars_["dnn_fm_inputs/myself_input_layer/C%d_embedding/embedding_weights" % f] for f in range(6)]
+    np.testing.assert_array_equal(oracle.embedding_bag(tabs, G["deepfm_ids"]), G["deepfm_onehot_inputs_f32"])
+    vals, offs, wts, combs = deepfm_csr("ragged")
+    B = G["deepfm_ids"].shape[0]
+    ref = G["deepfm_ragged_inputs_f32"]
+    for f in range(6):      # one column at a time: the C oracle takes one combiner per call
+        o = offs[f * B:(f + 1) * B + 1]
+        got = oracle.embedding_bag([tabs[f]], vals, offsets=o, weights=wts, combiner={"sum": 0, "mean": 1}[combs[f]], B=B)
+        np.testing.assert_array_equal(got, ref[:, f * 8:(f + 1) * 8])
+
+
+def test_oracle_linear_matches_reference_text(oracle):
+    vars_ = deepfm_vars()
+    names = ["C%d" % f for f in range(6)] + ["L0", "L1"]
+    wts = [vars_["linear/linear_model/%s/weights" % n][:, 0].copy() for n in names]
+    ids = np.concatenate([G["deepfm_ids"], G["deepfm_ids_extra"]], axis=1)
+    got = oracle.linear_sparse_sum(wts, ids, bias=vars_["linear/linear_model/bias_weights"])
+    _close(got, G["deepfm_onehot_linear_f64"][:, 0])
+
+
+def test_oracle_cross_matches_reference_text(oracle):
+    from oracle import np_ref as R
+    for d in (51, 416, 429):
+        x0, x, w, b = (G["cross%d_%s" % (d, n)] for n in ("x0", "x", "w", "b"))
+        _close(oracle.dcn_cross(x0, w, b), G["cross%d_arch_f64" % d])
+        _close(oracle.dcn_cross(x0, w, b, acc64=True), G["cross%d_arch_f64" % d], 2e-6)
+        _close(R.cross_network(x0, w, b), G["cross%d_arch_f64" % d])
+        _close(R.cross_op(x0, x, w[1], b[1]), G["cross%d_op_f64" % d])
+
+
+def test_oracle_model_assembly_matches_reference_text():
+    """np_ref's dnn_logit / deep_architecture / predictions against the reference text's own dnn_logit_fn, dcn_logits_fn and
+    _create_estimator_spec."""
+    from oracle import np_ref as R
+    V = deepfm_vars()
+    for v in VARIANTS:
+        layers = [(V["dnn_fm/hiddenlayer_%d/kernel" % i], V["dnn_fm/hiddenlayer_%d/bias" % i]) for i in range(2)]
+        bn = None
+        if v == "onehot_bn":
+            bn = [tuple(V["dnn_fm/hiddenlayer_%d/batchnorm_%d/%s" % (i, i, n)] for n in ("moving_mean", "moving_variance", "gamma", "beta"))
+                  for i in range(2)]
+        emb = G["deepfm_%s_inputs_f32" % v]
+        dnn = R.dnn_logit(emb, layers, (V["dnn_fm/logits/kernel"], V["dnn_fm/logits/bias"]), bn)
+        _close(dnn, G["deepfm_%s_dnn_f64" % v])
+        total = R.fm_logit(emb, 6, 8) + dnn + G["deepfm_%s_linear_f32" % v]                     # deepFM.py:337-338, :223
+        _close(total, G["deepfm_%s_logits_f64" % v])
+    D = dcn_vars()
+    pre = "dcn_model/input_from_feature_columns/"
+    x0 = G["dcn_x0_f32"]
+    cross = R.cross_network(x0, D[pre + "cross_w"], D[pre + "cross_b"])
+    layers = [(D[pre + "hidden_layer_%d/kernel" % i], D[pre + "hidden_layer_%d/bias" % i]) for i in range(3)]
+    bn = [tuple(D[pre + "hidden_layer_%d/bn_%d/%s" % (i, i, n)] for n in ("moving_mean", "moving_variance", "beta")) for i in range(2)]
+    deep = R.deep_architecture(x0, layers, bn)
+    logits = np.concatenate([cross, deep], -1) @ D["dcn_model/logits/dense/kernel"] + D["dcn_model/logits/dense/bias"]
+    _close(logits, G["dcn_logits_f64"])
+    p = R.predictions(logits.astype(np.float32))
+    _close(p["logistic"], G["dcn_logistic_f64"]); _close(p["probabilities"], G["dcn_probabilities_f64"])
+    np.testing.assert_array_equal(p["class_ids"], G["dcn_class_ids_f32"])
+
+
+def _build_deepfm(variant, fc, DeepFM):
+    vocab, extra = G["deepfm_vocab"], G["deepfm_lin_extra_vocab"]
+    combs = ["mean"] * 6
+    if variant == "ragged":
+        combs[4] = "sum"
+    cats = [fc.categorical_column_with_identity("C%d" % f, int(vocab[f])) for f in range(6)]
+    lcats = cats + [fc.categorical_column_with_identity("L%d" % j, int(extra[j])) for j in range(2)]
+    return DeepFM(linear_feature_columns=lcats, dnn_feature_columns=[fc.embedding_column(c, 8, combs[f]) for f, c in enumerate(cats)],
+                  dnn_hidden_units=[int(h) for h in G["deepfm_hidden"]], fm_embedding_size=8, batch_norm=(variant == "onehot_bn"),
+                  dnn_dropout=0.5)
+
+
+def _build_dcn(fc, DeepCrossNetwork):
+    cols = ([fc.numeric_column(k) for k in ("age", "hours", "gain")]
+            + [fc.indicator_column(fc.categorical_column_with_identity(k, n)) for k, n in (("workclass", 9), ("marital", 7))]
+            + [fc.embedding_column(fc.categorical_column_with_identity("occupation", 50), 8, "mean"),
+               fc.embedding_column(fc.categorical_column_with_identity("native", 23), 4, "sqrtn")])
+    return DeepCrossNetwork(columns=cols, cross_layer_num=3, dnn_hidden_units=[int(h) for h in G["dcn_hidden"]], dnn_dropout=0.3,
+                            batch_norm=True)
+
+
+def test_checkpoint_names_are_the_names_the_reference_text_creates(built_lib):
+    """checkpoint.tf_variable_map() == the variables the reference text asked tf.get_variable / layers.dense / batch_norm /
+    the columns for, under the scopes the text itself opened."""
+    from dir_amd import feature_column as fc
+    from dir_amd.checkpoint import tf_variable_map
+    from dir_amd.deepfm import DeepFM
+    from dir_amd.dcn import DeepCrossNetwork
+    for v in VARIANTS:
+        m = tf_variable_map(_build_deepfm(v, fc, DeepFM))
+        assert set(m) == set(str(s) for s in G["deepfm_%s_created" % v])
+    m = tf_variable_map(_build_dcn(fc, DeepCrossNetwork))
+    assert set(m) == set(str(s) for s in G["dcn_created"])
+    for name, (p, lay) in m.items():      # and the layouts
+        ref = G["dcn_var:" + name]
+        want = tuple(ref.T.shape) if lay == "T" else tuple(ref.reshape(-1).shape) if lay == "col" else tuple(ref.shape)
+        assert tuple(p.shape) == want, name
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_committed_fixture_is_what_the_reference_text_produces(tmp_path, monkeypatch):
+    """Re-run the generator (reference text under the stub) and compare with the committed arrays."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_ref_text", os.path.join(HERE, "golden", "make_ref_text.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(20241003)
+    g = {}
+    mod.deepfm_cases(g, rng)
+    mod.dcn_cases(g, rng)
+    assert set(g) == set(G.files)
+    for k, v in g.items():
+        np.testing.assert_array_equal(np.asarray(v), G[k], err_msg=k)
