@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--id-layout", default="bf", choices=["bf", "fb"], help="ids stored [B,F] or [F,B]")
     ap.add_argument("--rotate", type=int, default=4, help="distinct id batches rotated through")
     ap.add_argument("--adagrad-method", default="sorted", choices=["sorted", "chains"], help="train_sparse: SparseAdagrad method")
-    ap.add_argument("--cross-d", type=int, default=416, help="dcn_cross_backward: row width (416 = 26 x 16; 429 with the 13 dense)")
+    ap.add_argument("--cross-d", type=int, default=416, help="dcn_cross / dcn_cross_backward: row width (416 = 26 x 16; 429 with the 13 dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -72,27 +72,90 @@ def make_ids(torch, args, gen, device, vocab):
     return out
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, tables_host, ids_host):
-    """The oracle (a port of the reference op sequence: per-field lookup -> concat -> FM four-op form),
-    timed on this box's host cores with OpenMP, on a bounded sample of the same workload."""
+    """The oracle (a C/OpenMP port of the reference op sequence: per-field lookup -> concat -> FM four-op form), timed on this
+    box's host cores on a bounded sample of the same workload.  The [B, F*K] output is allocated ONCE and touched before the
+    clock starts (a fresh 109 MB np.zeros per pass made the threads spend their time in page faults); 3 untimed passes, then
+    the MEDIAN of >= 10 timed passes (bounded by --cpu-seconds)."""
+    import numpy as np
     from oracle import oracle as O
     O.build()
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     F, K = args.fields, args.dim
-    n, t0 = 0, time.perf_counter()
-    passes = 0
-    while True:
-        emb = O.embedding_bag(tables_host, ids_host)
+    B = ids_host.shape[0]
+    emb = np.zeros((B, F * K), np.float32)
+    times = []
+    t_all = time.perf_counter()
+    for p in range(3 + 200):
+        t0 = time.perf_counter()
+        O.embedding_bag(tables_host, ids_host, out=emb)
         O.fm_second_order(emb, F, K)
-        n += ids_host.shape[0]
-        passes += 1
-        el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or passes >= 200:
+        dt = time.perf_counter() - t0
+        if p >= 3:
+            times.append(dt)
+        if len(times) >= 10 and time.perf_counter() - t_all >= args.cpu_seconds:
             break
-    return {"value": n / el, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d passes of gather+FM over %d samples x %d fields (dim %d, vocab %d) in %.1f s, OpenMP" % (
-                passes, ids_host.shape[0], F, K, args.vocab, el)}
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "median_pass_ms": med * 1e3, "p10_pass_ms": times[len(times) // 10] * 1e3, "p90_pass_ms": times[(len(times) * 9) // 10] * 1e3,
+            "sample": "median of %d passes (after 3 untimed) of gather+FM over %d samples x %d fields (dim %d, vocab %d), output "
+                      "preallocated, C/OpenMP port of the reference op sequence on %d threads, %.1f s in all" % (
+                          len(times), B, F, K, args.vocab, cores, time.perf_counter() - t_all)}
+
+
+def measured_ceilings(torch, ops_lib, tables, stream_ptr, nbytes=109_051_904, iters=12):
+    """This box's streaming ceilings, measured in this run with dir_debug_stream_{read,copy}_f32: a linear non-temporal read of
+    ~109 MB (the gather's row bytes) and a copy of the same size (read + write), each over a window that ROTATES through the
+    1.66 GB of tables so that no window is re-read before ~1.5 GB of other traffic went by (nothing is served by the 256 MiB
+    Infinity Cache).  -> GB/s of bytes moved."""
+    import ctypes
+    n = (nbytes // 4) // 4 * 4
+    per = tables[0].numel()
+    wins = []
+    for f in range(len(tables)):          # windows inside single tables (each table is its own allocation)
+        off = 0
+        while off + n <= per:
+            wins.append((tables[f], off))
+            off += n
+    if not wins:                          # small tables (test configurations): whatever fits
+        n = per // 4 * 4
+        wins = [(t, 0) for t in tables]
+    sink = torch.zeros(4, device=tables[0].device)
+    dst = torch.empty(n, dtype=torch.float32, device=tables[0].device)
+    res = {}
+    for name in ("read", "copy"):
+        def run(i):
+            t, off = wins[i % len(wins)]
+            ptr = ctypes.c_void_p(t.data_ptr() + off * 4)
+            if name == "read":
+                rc = ops_lib.dir_debug_stream_read_f32(ptr, n, ctypes.c_void_p(sink.data_ptr()), stream_ptr)
+            else:
+                rc = ops_lib.dir_debug_stream_copy_f32(ptr, ctypes.c_void_p(dst.data_ptr()), n, stream_ptr)
+            assert rc == 0
+        for i in range(3):
+            run(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            run(3 + i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        res[name] = (n * 4 * (1 if name == "read" else 2)) / (us * 1e-6) / 1e9
+    return res
 
 
 def primary_line(args, wl, cfg, roof, units, world, el, dev_ms, traffic, extra):
@@ -240,8 +303,9 @@ def main():
                                dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
                 if wl == "deepfm_full_packed":      # serving layout: one 128-byte row per feature value (embedding + first-order weight)
                     model.pack_for_serving()
-                with torch.no_grad():
-                    step = lambda i: model.forward_ids(idsl[i % len(idsl)], idsl[i % len(idsl)])  # noqa: E731
+                def step(i):
+                    with torch.no_grad():
+                        model.forward_ids(idsl[i % len(idsl)], idsl[i % len(idsl)])
                 alg = B * (F * (8 + 2 * 4 * K) + 4)
                 kname = "deepfm forward (gather+FM kernel bytes only)"
             roof = {"bound": "hbm", "alg_bytes": alg, "kernel": kname}
@@ -507,14 +571,19 @@ def main():
             roof = {"bound": "mfma", "alg_flops": 3 * flops, "kernel": "xDeepFM training step (CIN forward + backward flops only)"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "cin": [128, 128, 128], "dnn": [400, 400]})
     elif wl == "dcn_cross":
-        d, L = F * K, 3
-        x0 = torch.randn((B, d), generator=gen, device=device) * 0.25
-        w = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
-        bb = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
+        d, L = args.cross_d, 3
+        dp = ops.pad4(d)
+        # the DCN input layer's layout: row stride pad4(d), zero pad columns (d = 429 -> 432); algorithmic bytes count the d real columns
+        x0 = torch.zeros((B, dp), device=device)
+        x0[:, :d] = torch.randn((B, d), generator=gen, device=device) * 0.25
+        w = torch.zeros((L, dp), device=device)
+        w[:, :d] = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
+        bb = torch.zeros((L, dp), device=device)
+        bb[:, :d] = (torch.randn((L, d), generator=gen, device=device) * 0.1).clamp_(-0.2, 0.2)
         out = torch.empty_like(x0)
         step = lambda i: ops.cross_network(x0, w, bb, out=out)  # noqa: E731
         roof = {"bound": "hbm", "alg_bytes": B * 2 * 4 * d + 2 * L * d * 4, "kernel": "cross_k"}
-        cfg.update({"d": d, "layers": L})
+        cfg.update({"d": d, "row_stride": dp, "layers": L})
     elif wl == "dcn_cross_backward":
         d, L = args.cross_d, 3
         x0 = torch.randn((B, d), generator=gen, device=device) * 0.25
@@ -716,9 +785,39 @@ def main():
                 except Exception:
                     traffic = None
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
-                               "traffic": traffic, "kernel": roof["kernel"], "alg_bytes_per_launch": roof["alg_bytes"],
+                               "frac": ach / HBM_PEAK_GBS, "frac_of_guide_copy_ceiling": ach / HBM_COPY_GBS,
+                               "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command; not re-measured in this run)" if traffic else None,
+                               "kernel": roof["kernel"], "alg_bytes_per_launch": roof["alg_bytes"],
                                "avg_launch_us": launch_us}
+            if world == 1 and wl in ("deepfm_gather_fm", "gather_only"):
+                # (a) what the launch costs on the DRAM side: beyond L2 a 64-byte row miss occupies a 128-byte slot
+                # (profiles/r01_memprobe_rows.txt: random 64-B rows 2.97 TB/s vs 128-B rows 4.98 TB/s at the same request rate),
+                # so the row reads count twice; ids and the concat / logit writes stream.
+                row_b = 4 * K
+                dram = B * F * (8 + (2 * row_b if row_b < 128 else row_b) + row_b) + (4 * B if wl == "deepfm_gather_fm" else 0)
+                res["roofline"]["dram_side_bytes"] = dram
+                res["roofline"]["dram_side_GBps"] = dram / (launch_us * 1e-6) / 1e9
+                # (b) this box's streaming ceilings, measured now (rotating windows of the tables: nothing cache-resident)
+                import ctypes
+                ceil = measured_ceilings(torch, dir_amd.load_library(), tables, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                res["roofline"]["measured_read_ceiling_GBps"] = ceil["read"]
+                res["roofline"]["measured_copy_ceiling_GBps"] = ceil["copy"]
+                res["roofline"]["frac_of_measured_copy_ceiling"] = ach / ceil["copy"]
+                res["roofline"]["dram_side_frac_of_measured_copy_ceiling"] = res["roofline"]["dram_side_GBps"] / ceil["copy"]
+                # (c) per-launch distribution (median + p10/p90 of >= 100 launches), outside the timed region
+                if args.steps >= 100:
+                    nl = 200
+                    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nl + 1)]
+                    evs[0].record()
+                    for i in range(nl):
+                        step(i)
+                        evs[i + 1].record()
+                    torch.cuda.synchronize()
+                    per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(nl))
+                    res["roofline"]["launch_us_median"] = per[nl // 2]
+                    res["roofline"]["launch_us_p10"] = per[nl // 10]
+                    res["roofline"]["launch_us_p90"] = per[(nl * 9) // 10]
+                    res["roofline"]["frac_at_median"] = roof["alg_bytes"] / (per[nl // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS
         else:
             ach = roof["alg_flops"] / (launch_us * 1e-6) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",

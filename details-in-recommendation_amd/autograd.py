@@ -95,7 +95,7 @@ class EmbeddingBag(torch.autograd.Function):
                 idf, gf = ids[:, f].contiguous(), g[:, f * K:(f + 1) * K]
                 if ctx.max_norm:
                     gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(ctx.max_norm))
-                grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf, ts.vocab[f]))
+                grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf.reshape(-1) if ts.tables[f].dim() == 1 else gf, ts.vocab[f]))
         else:
             B = (offsets.numel() - 1) // F
             lens = offsets[1:] - offsets[:-1]
@@ -124,7 +124,7 @@ class EmbeddingBag(torch.autograd.Function):
                 idf, gf = ids[sel], gv[sel]
                 if ctx.max_norm:
                     gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(ctx.max_norm))
-                grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf, ts.vocab[f]))
+                grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf.reshape(-1) if ts.tables[f].dim() == 1 else gf, ts.vocab[f]))
         return (None,) * nfix + tuple(grads)
 
 

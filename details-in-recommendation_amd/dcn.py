@@ -80,7 +80,34 @@ class DeepCrossNetwork(nn.Module):
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :405-408 (TRAIN only), after the BN
         return net
 
+    def _padded_cross_params(self):
+        """cross_w / cross_b zero-padded to a multiple of 4 columns, cached until the parameters change."""
+        key = (self.cross_w._version, self.cross_b._version, self.cross_w.data_ptr())
+        if getattr(self, "_cross_pad_key", None) != key:
+            pad = ops.pad4(self.column_num) - self.column_num
+            self._cross_pad = (torch.nn.functional.pad(self.cross_w.data, (0, pad)), torch.nn.functional.pad(self.cross_b.data, (0, pad)))
+            self._cross_pad_key = key
+        return self._cross_pad
+
+    def _forward_padded(self, features):
+        """Inference with an input width that is not a multiple of 4 (429 = 26 x 16 + 13): the input layer writes x0 with row
+        stride pad4(d) and zero pad columns ONCE; the cross kernel runs its 16-byte instantiation on it (zero-padded w, b keep
+        the pad columns exactly 0), the first deep layer reads the same buffer with Kd = pad4(d) against a zero-padded weight,
+        and the final dense(1) over concat([cross, deep]) (:136-137) is evaluated as cross . w_c + deep . w_d + bias -- the
+        concat is never materialised.  Values: the same sums over the same real columns."""
+        d, dp = self.column_num, ops.pad4(self.column_num)
+        x0p = self.input_layer(features, pad_to=4)
+        wp, bp = self._padded_cross_params()
+        cross = ops.cross_network(x0p, wp, bp)                                   # [B, dp], zero tail
+        deep = self.deep_architecture(x0p)                                       # dense_act pads the first weight (in_features d -> dp)
+        wl = self.logits_layer.weight                                            # [1, d + h]
+        wc = torch.nn.functional.pad(wl[:, :d], (0, dp - d))
+        return torch.addmm(self.logits_layer.bias, cross, wc.t()).addmm_(deep, wl[:, d:].t())
+
     def forward(self, features):
+        if (not torch.is_grad_enabled() and not isinstance(features, torch.Tensor) and self.column_num % 4
+                and len(self.hidden) and self.cross_layer_num > 0):
+            return self._forward_padded(features)
         x0 = features if isinstance(features, torch.Tensor) else self.input_layer(features)
         cross = self.cross_architecture(x0)
         deep = self.deep_architecture(x0)

@@ -195,10 +195,17 @@ def units1(lin, x):
 
 
 def dense_act(lin, x, activation=None):
-    """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered."""
+    """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered.  x may arrive row-padded with zero
+    columns up to the next multiple of 4 (InputLayer(pad_to=4), inference): then only the weight gets its zero columns."""
     relu = activation in _RELUS
+    prepadded = x.dim() == 2 and x.shape[1] != lin.in_features and x.shape[1] == lin.in_features + (-lin.in_features) % 4
     if (activation is None or relu) and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and lin.out_features >= 16:
         train = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
+        if prepadded and not train and x.dtype == torch.float32:
+            return ops.dense(x, _packed_cached_padded(lin.weight, x.shape[1] - lin.in_features), lin.bias, relu=relu)
+        if prepadded:
+            x = x[:, :lin.in_features]
+            prepadded = False
         pad = (-x.shape[1]) % 4
         if pad and x.dtype == torch.float32:
             # in_features not a multiple of 4 (DCN's 429-wide first layer: 26 x 16 + 13 numeric columns): zero-pad x and the weight
@@ -211,5 +218,7 @@ def dense_act(lin, x, activation=None):
             if train:
                 return _DenseFn.apply(x, lin.weight, lin.bias, relu)
             return ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu)
+    if prepadded:
+        x = x[:, :lin.in_features]
     y = lin(x)
     return activation(y) if activation is not None else y

@@ -117,7 +117,10 @@ class InputLayer(nn.Module):
                 pieces.append(blocks[c.name])
         return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=1)
 
-    def forward(self, features):
+    def forward(self, features, pad_to=1):
+        """-> x0 [B, column_num].  pad_to = 4 (inference only): x0 is returned as [B, round_up(column_num, 4)] whose extra
+        columns are zero -- the row stride the 16-byte paths of dir_dcn_cross_f32 / dir_dense_f32 want when column_num is odd
+        (DCN's 26 x 16 + 13 = 429): written once here, no padded copy later."""
         device = self.embedding_weights[0].device if len(self.embedding_weights) else next(iter(
             v for v in features.values() if isinstance(v, torch.Tensor))).device
         if torch.is_grad_enabled():
@@ -125,8 +128,13 @@ class InputLayer(nn.Module):
         B = None
         x0 = None
 
+        ld = (self.column_num + pad_to - 1) // pad_to * pad_to
+
         def alloc(nb):
-            return torch.empty((nb, self.column_num), dtype=torch.float32, device=device)
+            buf = torch.empty((nb, ld), dtype=torch.float32, device=device)
+            if ld != self.column_num:
+                buf[:, self.column_num:].zero_()
+            return buf
 
         for c in self.columns:
             if isinstance(c, NumericColumn):

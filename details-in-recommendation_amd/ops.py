@@ -239,6 +239,26 @@ def cross_network(x0, w, b, out=None):
     return out
 
 
+def pad4(d):
+    return (d + 3) // 4 * 4
+
+
+def cross_network_padded(x0p, w, b, out=None):
+    """cross_network on a row-padded input: x0p [B, dp] holds the d = w.shape[1] real columns followed by dp - d ZERO columns
+    (dp = pad4(d); what InputLayer(pad_to=4) produces for DCN's 429-wide input).  w, b [L, d] are zero-padded to [L, dp], so a
+    pad column stays exactly 0 through every layer (0 * xw + 0 + 0) and the dot products see only zeros there: the real columns
+    are computed exactly as cross_network does, in the same order (DeepCrossNetwork.py:345-346), on the 16-byte vector path.
+    -> [B, dp] with the same zero tail."""
+    L, d = w.shape
+    dp = x0p.shape[1]
+    if dp != pad4(d) or x0p.stride(1) != 1:
+        raise ValueError("cross_network_padded: x0p must be [B, pad4(d)=%d] with unit inner stride" % pad4(d))
+    if dp != d:
+        w = torch.nn.functional.pad(w, (0, dp - d))
+        b = torch.nn.functional.pad(b, (0, dp - d))
+    return cross_network(x0p, w, b, out=out)
+
+
 def cross_op(x0, x, w, b, out=None):
     """_cross_op (DeepCrossNetwork.py:336-347), one layer: y = x0 * (x . w)[:, None] + b + x."""
     _dev(x0, torch.float32, "x0")

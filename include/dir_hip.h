@@ -385,6 +385,13 @@ int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* accums, float
  * [2] chunks, [3] prologue, [4] epilogue, [5] waves.  Synchronises the device. */
 int dir_debug_cin_stamps(unsigned long long* out8);
 
+/* Diagnostic only: the streaming ceilings of this box, for bench.py's roofline (measured in the run they are compared in).
+ * dir_debug_stream_read_f32: a pure linear read of n floats (16 B per lane per load, non-temporal; sink is written only if the
+ * sum takes a value it cannot take).  dir_debug_stream_copy_f32: q[i] = p[i] the same way (n floats read + n written).
+ * n a multiple of 4, pointers 16-byte aligned. */
+int dir_debug_stream_read_f32(const float* p, int64_t n, float* sink, dir_stream_t stream);
+int dir_debug_stream_copy_f32(const float* p, float* q, int64_t n, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
