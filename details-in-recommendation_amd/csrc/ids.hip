@@ -321,15 +321,20 @@ __global__ __launch_bounds__(256) void gather_rows_k(const float* const* __restr
 constexpr int BK_EPB = 4096;   // elements per workgroup
 constexpr int BK_MAXF = 256;   // fields whose 'div' constants are cached in LDS (more: read from global)
 
-// per-field 'div' constants q = V / P, thr = (V % P) * (q + 1), r = V % P, staged once per workgroup
-struct FieldDiv { int64_t q, thr; int r; int small; };
+// per-field 'div' constants q = V / Pf, thr = (V % Pf) * (q + 1), r = V % Pf, staged once per workgroup.  Pf = the number of
+// row slices of the table (parts[f]; P when parts == NULL) and first = the rank holding slice 0 (slice j lives on rank
+// (first + j) % P): the reference's min_max_variable_partitioner cuts a table into <= P slices of >= min_slice_size bytes
+// (models/DeepFM/deepFM.py:163-167) and [TF-upstream] replica_device_setter deals the slices round-robin over the ps tasks.
+struct FieldDiv { int64_t q, thr, V; int r; int small; int first; };
 
-__device__ __forceinline__ FieldDiv make_fielddiv(int64_t V, int P) {
+__device__ __forceinline__ FieldDiv make_fielddiv(int64_t V, int Pf, int first = 0) {
     FieldDiv d;
-    d.q = V / P;
-    d.r = (int)(V % P);
+    d.q = V / Pf;
+    d.r = (int)(V % Pf);
     d.thr = (int64_t)d.r * (d.q + 1);
+    d.V = V;
     d.small = V < (int64_t)0x7fffffff ? 1 : 0;   // every quotient fits 32-bit unsigned arithmetic
+    d.first = first;
     return d;
 }
 
@@ -357,14 +362,18 @@ __device__ __forceinline__ void route_fd(int64_t id, const FieldDiv& d, int* own
     const int64_t id = ids[i];                                                    \
     int oo_;                                                                      \
     int64_t l;                                                                    \
-    if (id < 0) {                                                                 \
+    if (id < 0 || id >= (f < BK_MAXF ? fd[f].V : vocab[f])) {  /* pruned, or out of range: nobody owns it */ \
         oo_ = (int)((uint32_t)(p0 + e) % (uint32_t)P);                            \
         l = -1;                                                                   \
     } else if (f < BK_MAXF) {                                                     \
         route_fd(id, fd[f], &oo_, &l);                                            \
+        oo_ += fd[f].first;                                                       \
+        if (oo_ >= P) oo_ -= P;                                                   \
     } else {                                                                      \
-        FieldDiv dd = make_fielddiv(vocab[f], P);                                 \
+        FieldDiv dd = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0); \
         route_fd(id, dd, &oo_, &l);                                               \
+        oo_ += dd.first;                                                          \
+        if (oo_ >= P) oo_ -= P;                                                   \
     }
 
 // Wave-aggregated LDS counter update: lanes of a wave that target the same owner issue ONE atomic (the
@@ -388,12 +397,13 @@ __device__ __forceinline__ int wave_agg_rank(int* cnt, int o, bool active) {
 }
 
 __global__ __launch_bounds__(256) void bucket_hist_k(const int64_t* __restrict__ ids, int64_t n,
-                                                     const int64_t* __restrict__ vocab, int F, int P,
+                                                     const int64_t* __restrict__ vocab, const int32_t* __restrict__ parts,
+                                                     const int32_t* __restrict__ first, int F, int P,
                                                      int32_t* __restrict__ wg_counts) {
     __shared__ int cnt[64];
     __shared__ FieldDiv fd[BK_MAXF];
     if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], P);
+    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0);
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * BK_EPB;
     const int f0 = (int)(base % F), p0 = (int)(base % P);
@@ -451,7 +461,8 @@ __global__ __launch_bounds__(1024) void bucket_scan_k(const int32_t* __restrict_
 }
 
 __global__ __launch_bounds__(256) void bucket_scatter_k(const int64_t* __restrict__ ids, int64_t n,
-                                                        const int64_t* __restrict__ vocab, int F, int P,
+                                                        const int64_t* __restrict__ vocab, const int32_t* __restrict__ parts,
+                                                        const int32_t* __restrict__ first, int F, int P,
                                                         const int32_t* __restrict__ wg_base,
                                                         const int64_t* __restrict__ starts,
                                                         int64_t* __restrict__ payload, int64_t* __restrict__ inv) {
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_k(const int64_t* __restric
     __shared__ FieldDiv fd[BK_MAXF];
     if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
     if (threadIdx.x < P) basev[threadIdx.x] = starts[threadIdx.x] + wg_base[(int64_t)blockIdx.x * P + threadIdx.x];
-    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], P);
+    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0);
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * BK_EPB;
     const int f0 = (int)(base % F), p0 = (int)(base % P);
@@ -485,10 +496,141 @@ __global__ __launch_bounds__(256) void bucket_scatter_k(const int64_t* __restric
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-capacity bucketing (the sync-free lookup): owner o gets a SLAB of cap payload slots behind a one-word header,
+//   payload[o*(cap+1)] = number of valid slots (written by bucket_cap_fin_k), payload[o*(cap+1) + 1 + pos] = local*F + slot.
+// One pass: every workgroup routes its 4096 elements keeping (owner, rank-in-workgroup, payload) in registers, reserves a
+// contiguous range of every owner's slab with ONE global atomic per owner, and scatters.  inv[i] = o*cap + pos is the row of
+// element i in the [P*cap, K] row buffer that comes back; pruned / out-of-range ids and elements that do not fit the slab
+// get inv = -1 (the finish gather turns that into a zero row; an overflow is reported through the flag and the caller
+// repeats the lookup on the exact variable-size path).  The order inside a slab is arbitrary (atomics); inv is its exact
+// inverse, so the looked-up values do not depend on it.  gcount: P int32 counters, zero on entry, zeroed again by fin.
+// ------------------------------------------------------------------------------------------------
+constexpr int BK_EPT = BK_EPB / 256;   // elements per thread
+typedef float f32x4_ids __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void bucket_cap_k(const int64_t* __restrict__ ids, int64_t n,
+                                                    const int64_t* __restrict__ vocab, const int32_t* __restrict__ parts,
+                                                    const int32_t* __restrict__ first, int F, int P, int64_t cap,
+                                                    int32_t* __restrict__ gcount, int64_t* __restrict__ payload,
+                                                    int64_t* __restrict__ inv) {
+    __shared__ int cnt[64];
+    __shared__ int basev[64];
+    __shared__ FieldDiv fd[BK_MAXF];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0);
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * BK_EPB;
+    const int f0 = (int)(base % F), p0 = (int)(base % P);
+    const int lim = (int)((n - base) < BK_EPB ? (n - base) : BK_EPB);
+    int orank[BK_EPT];        // owner << 16 | rank inside the workgroup (rank < 4096); -1: pruned / inactive
+    int64_t pv[BK_EPT];
+#pragma unroll
+    for (int k = 0; k < BK_EPT; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        const bool active = e < lim;
+        int o = 0;
+        bool keep = false;
+        pv[k] = -1;
+        if (active) {
+            BK_ROUTE_ELEMENT()
+            (void)i;
+            o = oo_;
+            keep = l >= 0;
+            pv[k] = l * F + f;
+        }
+        const int rank = wave_agg_rank(cnt, o, keep);
+        orank[k] = keep ? (o << 16) | rank : -1;
+    }
+    __syncthreads();
+    if (threadIdx.x < P) basev[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&gcount[threadIdx.x], cnt[threadIdx.x]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BK_EPT; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        if (e >= lim) continue;
+        int64_t dst = -1;
+        if (orank[k] >= 0) {
+            const int o = orank[k] >> 16;
+            const int64_t pos = (int64_t)basev[o] + (orank[k] & 0xffff);
+            if (pos < cap) {
+                payload[(int64_t)o * (cap + 1) + 1 + pos] = pv[k];
+                dst = (int64_t)o * cap + pos;
+            }
+        }
+        inv[base + e] = dst;
+    }
+}
+
+__global__ void bucket_cap_fin_k(int32_t* __restrict__ gcount, int P, int64_t cap, int64_t* __restrict__ payload,
+                                 int64_t* __restrict__ counts, int32_t* __restrict__ overflow) {
+    const int o = threadIdx.x;
+    int over = 0;
+    if (o < P) {
+        const int64_t c = gcount[o];
+        counts[o] = c;                                    // the true demand (may exceed cap): the caller sizes the next cap from it
+        payload[(int64_t)o * (cap + 1)] = c < cap ? c : cap;
+        gcount[o] = 0;
+        over = c > cap ? 1 : 0;
+    }
+    const unsigned long long any = __ballot(over);
+    if (o == 0) overflow[0] = any ? 1 : 0;
+}
+
+// owner side of the fixed-capacity exchange: recv = P slabs [header | cap slots] as received (slab s from rank s);
+// out[(s*cap + j), :] = tables[p % F][p / F, :] for j < header_s.  Slots behind the header are neither read nor written
+// (the requester never looks at them); with sanitize the slot itself is overwritten with -1 so that the slab can later be
+// walked as a flat pruned-aware payload (the owner side of the sharded backward).
+template <int VEC, bool NT>
+__global__ __launch_bounds__(256) void gather_slabs_k(const float* const* __restrict__ tables, int K, int lps, int F,
+                                                      int64_t* __restrict__ recv, int P, int64_t cap, int sanitize,
+                                                      float* __restrict__ out) {
+    const int kv = K / VEC;
+    const int64_t total = (int64_t)P * cap;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = tid; q < total * lps; q += nthr) {
+        const int64_t i = q / lps;
+        const int c = (int)(q - i * lps);
+        const int64_t sl = i / cap, j = i - sl * cap;
+        int64_t* slab = recv + sl * (cap + 1);
+        const int64_t valid = slab[0];
+        if (j >= valid) {
+            if (sanitize && c == 0) slab[1 + j] = -1;
+            continue;
+        }
+        if (c >= kv) continue;
+        const int64_t p = slab[1 + j];
+        int slot;
+        int64_t row;
+        if (p < (int64_t)0x7fffffff) {   // 32-bit division when it fits
+            const uint32_t r32 = (uint32_t)p / (uint32_t)F;
+            slot = (int)((uint32_t)p - r32 * (uint32_t)F);
+            row = r32;
+        } else {
+            row = p / F;
+            slot = (int)(p - row * F);
+        }
+        float* o = out + i * K + c * VEC;
+        const float* src = tables[slot] + row * K + c * VEC;
+        if (VEC == 4) {
+            float4 v;
+            if (NT) {
+                const f32x4_ids t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ids*>(src));
+                v = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                v = *reinterpret_cast<const float4*>(src);
+            }
+            *reinterpret_cast<float4*>(o) = v;
+        } else {
+            *o = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+    }
+}
 #undef BK_ROUTE_ELEMENT
 
 // owner side: unpack payload -> (slot, row) and gather; out[i, :] = tables[p % F][p / F, :]  (p < 0 -> zeros)
-typedef float f32x4_ids __attribute__((ext_vector_type(4)));
 template <int VEC, bool NT>
 __global__ __launch_bounds__(256) void gather_packed_k(const float* const* __restrict__ tables, int K, int lps, int F,
                                                        const int64_t* __restrict__ payload, int64_t n,
@@ -629,7 +771,8 @@ extern "C" int64_t dir_shard_bucket_workspace_bytes(int64_t n, int P) {
     return 2 * nwg * (int64_t)P * (int64_t)sizeof(int32_t);
 }
 
-extern "C" int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, int F, int P, int64_t* payload,
+extern "C" int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first,
+                                int F, int P, int64_t* payload,
                                 int64_t* inv, int64_t* counts, int64_t* starts, void* workspace, dir_stream_t stream) {
     DIR_CHECK_ARG(n >= 0 && F > 0 && P > 0 && P <= 64, "dir_shard_bucket: n=%lld F=%d P=%d (P <= 64)", (long long)n, F, P);
     DIR_CHECK_ARG(counts && starts, "dir_shard_bucket: null pointer");
@@ -643,10 +786,49 @@ extern "C" int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vo
     const int nwg = (int)((n + BK_EPB - 1) / BK_EPB);
     int32_t* wg_counts = static_cast<int32_t*>(workspace);
     int32_t* wg_base = wg_counts + (int64_t)nwg * P;
-    hipLaunchKernelGGL(bucket_hist_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, F, P, wg_counts);
+    hipLaunchKernelGGL(bucket_hist_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, parts, first, F, P, wg_counts);
     hipLaunchKernelGGL(bucket_scan_k, dim3(1), dim3(1024), 0, st, wg_counts, nwg, P, wg_base, counts, starts);
-    hipLaunchKernelGGL(bucket_scatter_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, F, P, wg_base, starts, payload, inv);
+    hipLaunchKernelGGL(bucket_scatter_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, parts, first, F, P, wg_base, starts, payload, inv);
     DIR_CHECK_LAUNCH("shard_bucket");
+    return DIR_OK;
+}
+
+extern "C" int64_t dir_shard_bucket_cap_workspace_bytes(int P) { return P > 0 && P <= 64 ? 64 * (int64_t)sizeof(int32_t) : 0; }
+
+extern "C" int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first,
+                                    int F, int P, int64_t cap, int64_t* payload, int64_t* inv, int64_t* counts, int32_t* overflow,
+                                    void* workspace, dir_stream_t stream) {
+    DIR_CHECK_ARG(n >= 0 && F > 0 && P > 0 && P <= 64 && cap > 0, "dir_shard_bucket_cap: n=%lld F=%d P=%d cap=%lld (P <= 64)", (long long)n, F, P, (long long)cap);
+    DIR_CHECK_ARG(vocab && payload && counts && overflow && workspace && (n == 0 || (ids && inv)), "dir_shard_bucket_cap: null pointer");
+    if ((int64_t)P * cap >= (int64_t)1 << 40) return fail(DIR_E_UNSUPPORTED, "dir_shard_bucket_cap: P*cap too large");
+    hipStream_t st = as_stream(stream);
+    int32_t* gcount = static_cast<int32_t*>(workspace);
+    if (n > 0) {
+        const int nwg = (int)((n + BK_EPB - 1) / BK_EPB);
+        hipLaunchKernelGGL(bucket_cap_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, parts, first, F, P, cap, gcount, payload, inv);
+    }
+    hipLaunchKernelGGL(bucket_cap_fin_k, dim3(1), dim3(64), 0, st, gcount, P, cap, payload, counts, overflow);
+    DIR_CHECK_LAUNCH("shard_bucket_cap");
+    return DIR_OK;
+}
+
+extern "C" int dir_gather_slabs_f32(const float* const* tables, int F, int K, int64_t* recv, int P, int64_t cap, int flags,
+                                    float* out, dir_stream_t stream) {
+    DIR_CHECK_ARG(F > 0 && K > 0 && P > 0 && cap > 0, "dir_gather_slabs_f32: bad argument");
+    DIR_CHECK_ARG(tables && recv && out, "dir_gather_slabs_f32: null pointer");
+    const bool vec = (K % 4 == 0) && aligned16(out);
+    int lps = 1;
+    while (lps < (vec ? K / 4 : K)) lps <<= 1;
+    const int64_t n = (int64_t)P * cap;
+    dim3 grid(grid_for((n * lps + 255) / 256));
+    const bool nt = (flags & DIR_GATHER_STREAM_ROWS) != 0;
+    const int sanitize = (flags & DIR_SLAB_SANITIZE) ? 1 : 0;
+    hipStream_t st = as_stream(stream);
+    if (vec && nt) hipLaunchKernelGGL((gather_slabs_k<4, true>), grid, dim3(256), 0, st, tables, K, lps, F, recv, P, cap, sanitize, out);
+    else if (vec) hipLaunchKernelGGL((gather_slabs_k<4, false>), grid, dim3(256), 0, st, tables, K, lps, F, recv, P, cap, sanitize, out);
+    else if (nt) hipLaunchKernelGGL((gather_slabs_k<1, true>), grid, dim3(256), 0, st, tables, K, lps, F, recv, P, cap, sanitize, out);
+    else hipLaunchKernelGGL((gather_slabs_k<1, false>), grid, dim3(256), 0, st, tables, K, lps, F, recv, P, cap, sanitize, out);
+    DIR_CHECK_LAUNCH("gather_slabs");
     return DIR_OK;
 }
 

@@ -535,9 +535,10 @@ def gather_rows(tables, slot, row):
     return out
 
 
-def shard_bucket(ids, vocab_dev, P, payload=None, inv=None):
-    """Route + counting-sort by owner in one call (requester side of the sharded lookup).
-    -> (payload [n] int64 grouped by owner, inv [n] int64, counts [P] int64, starts [P] int64), all on device."""
+def shard_bucket(ids, vocab_dev, P, payload=None, inv=None, parts=None, first=None):
+    """Route + counting-sort by owner in one call (requester side of the sharded lookup, variable-size form).
+    -> (payload [n] int64 grouped by owner, inv [n] int64, counts [P] int64, starts [P] int64), all on device.
+    parts / first: device int32 [F] (slices per table and the rank of slice 0) or None = every table cut P ways."""
     _dev(ids, torch.int64, "ids")
     ids = ids.contiguous()
     n = ids.numel()
@@ -550,9 +551,33 @@ def shard_bucket(ids, vocab_dev, P, payload=None, inv=None):
     counts = torch.empty(P, dtype=torch.int64, device=ids.device)
     starts = torch.empty(P, dtype=torch.int64, device=ids.device)
     ws = torch.empty(max(1, int(lib.dir_shard_bucket_workspace_bytes(n, P))), dtype=torch.uint8, device=ids.device)
-    _lib.check(lib.dir_shard_bucket(_ptr(ids), n, _ptr(vocab_dev), F, P, _ptr(payload), _ptr(inv), _ptr(counts),
+    _lib.check(lib.dir_shard_bucket(_ptr(ids), n, _ptr(vocab_dev), _ptr(parts), _ptr(first), F, P, _ptr(payload), _ptr(inv), _ptr(counts),
                                     _ptr(starts), _ptr(ws), _stream()))
     return payload, inv, counts, starts
+
+
+def shard_bucket_cap(ids, vocab_dev, P, cap, payload, inv, counts, overflow, workspace, parts=None, first=None):
+    """Fixed-capacity requester side (include/dir_hip.h: dir_shard_bucket_cap) into caller-owned buffers: payload
+    [P*(cap+1)] int64 slabs, inv [n] int64, counts [P] int64, overflow [1] int32, workspace (zeroed once) -- no host read."""
+    _dev(ids, torch.int64, "ids")
+    if not ids.is_contiguous():
+        raise ValueError("shard_bucket_cap: ids must be contiguous")
+    _lib.check(_lib.load().dir_shard_bucket_cap(_ptr(ids), ids.numel(), _ptr(vocab_dev), _ptr(parts), _ptr(first), vocab_dev.numel(), P,
+                                                cap, _ptr(payload), _ptr(inv), _ptr(counts), _ptr(overflow), _ptr(workspace), _stream()))
+
+
+SLAB_SANITIZE = 4
+
+
+def gather_slabs(tables, recv, P, cap, out, sanitize=False):
+    """Owner side of the fixed-capacity exchange: recv [P*(cap+1)] int64 slabs -> out [P*cap, K] (rows behind a slab's header
+    are left untouched)."""
+    ts = _as_tableset(tables)
+    _dev(recv, torch.int64, "recv")
+    _dev(out, torch.float32, "out")
+    _lib.check(_lib.load().dir_gather_slabs_f32(_ptr(ts.ptrs), ts.F, ts.K, _ptr(recv), P, cap,
+                                                ts.gather_flags() | (SLAB_SANITIZE if sanitize else 0), _ptr(out), _stream()))
+    return out
 
 
 def gather_packed(tables, payload, out=None):

@@ -1,22 +1,32 @@
 """shard.py -- row-sharded embedding tables with an all-to-all lookup (RCCL over xGMI on the GPU box).
 
-Semantic precedent in the reference: min_max_variable_partitioner(max_partitions=num_ps_replicas, ...)
+Semantic precedent in the reference: min_max_variable_partitioner(max_partitions=num_ps_replicas, min_slice_size=64 << 20)
 row-partitions the embedding variables and lookups resolve with partition_strategy='div'
-(models/DeepFM/deepFM.py:163-167; [TF-upstream] embedding_lookup).  Here every rank of a
-torch.distributed group owns the contiguous 'div' row range of EVERY table, and one lookup is
+(models/DeepFM/deepFM.py:163-167; [TF-upstream] embedding_lookup).  Here every rank of a torch.distributed group owns
+contiguous 'div' row slices of the tables (by default one slice of EVERY table; `partitions=` applies the reference's
+slice-count rule instead) and one lookup is, per micro-batch,
 
-    bucket   (HIP: route every id to its owner + counting sort by owner -> packed payload, inverse perm)
-    exchange (all_to_all_single of the per-owner counts, then of the int64 payload)
-    gather   (HIP on the owner: payload -> rows)
-    exchange (all_to_all_single of the fp32 rows back)
-    finish   (HIP: the fused gather+FM kernel with "table" = the received row buffer and ids = the inverse
-              permutation: one pass un-permutes into [B_local, F*K] and produces the FM logit)
+    bucket   (HIP: route every id to its owner, one fixed-capacity slab per owner -> payload slabs, inverse positions)
+    exchange (all_to_all_single of the slabs, EQUAL splits: no split sizes ever reach the host)
+    gather   (HIP on the owner: slab -> rows)
+    exchange (all_to_all_single of the fp32 rows back, equal splits)
+    finish   (HIP: the fused gather+FM kernel with "table" = the received row buffer and ids = the inverse positions:
+              one pass un-permutes into [B_local, F*K] and produces the FM logit)
 
-The collectives are torch.distributed.all_to_all_single (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
-tests); the split sizes cost one host read of 2*P integers per lookup.  world_size == 1 skips the collectives
-(unless force_collective) but still runs the three HIP steps.  The HIP steps sit behind a small backend
-object so that the CPU (gloo) tests can stand the oracle in for them; the default backend is the HIP one.
+The batch is cut into `chunks` micro-batches on two streams, software-pipelined so that the id exchange of chunk c+1 is
+issued before the row exchange of chunk c: owner gather / finish of neighbouring chunks run under the (link-bound) row
+exchange.  A slab that is too small is detected on the device (overflow flag, read AFTER the whole pipeline has been
+enqueued, so the stream never drains); the lookup is then repeated on the exact variable-size path (one host read of the
+split sizes) and the capacity grows.  `dedup=True` sends each (slot, row) once per owner and chunk ([TF-upstream]
+embedding_lookup_sparse's unique-before-gather): on skewed ids it cuts the link-bound bytes.
+
+The collectives are torch.distributed.all_to_all_single (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+world_size == 1 skips the collectives (unless force_collective) but still runs the three HIP steps.  The HIP steps sit
+behind a small backend object so that the CPU (gloo) tests can stand the oracle in for them; the default backend is the
+HIP one.
 """
+import contextlib
+import math
 import os
 
 import torch
@@ -25,6 +35,7 @@ import torch.distributed as dist
 from . import ops
 
 _HOST_STAGED = os.environ.get("DIR_SHARD_HOST_STAGED") == "1"
+MIN_SLICE_SIZE = 64 << 20     # deepFM.py:167
 
 
 def div_range(vocab, P, rank):
@@ -34,20 +45,53 @@ def div_range(vocab, P, rank):
     return start, start + (q + 1 if rank < r else q)
 
 
-class HipBackend:
-    """The product path: three launches of libdir_hip.so kernels."""
+def partitions_for(vocab, K, max_partitions, min_slice_size=MIN_SLICE_SIZE, bytes_per_element=4):
+    """[TF-upstream] partitioned_variables.min_max_variable_partitioner(max_partitions, axis=0, min_slice_size) as the reference
+    calls it (models/DeepFM/deepFM.py:163-167, ESMM_wide_deep.py:213-217): a [vocab, K] variable is cut along axis 0 into
+        max(1, min(vocab, max_partitions, ceil(vocab * K * bytes_per_element / min_slice_size)))
+    slices (so every slice holds at least min_slice_size bytes, and num_ps_replicas = 0 leaves the variable whole).  The
+    slices are the 'div' row ranges (the first vocab % n slices hold one extra row: div_range)."""
+    total = int(vocab) * int(K) * int(bytes_per_element)
+    return max(1, min(int(vocab), int(max_partitions), int(math.ceil(total / float(min_slice_size)))))
 
-    def __init__(self, local_tables, vocab_dev, P):
+
+def place_slices(parts, P):
+    """Rank of slice 0 of every table: the slices are dealt round-robin over the ranks in creation order ([TF-upstream]
+    replica_device_setter's default strategy places each slice -- a variable of its own -- on the next ps task)."""
+    first, nxt = [], 0
+    for p in parts:
+        first.append(nxt % P)
+        nxt += p
+    return first
+
+
+def local_slice(vocab, parts, first, P, rank):
+    """Rows [start, end) of a table that `rank` holds: slice j = (rank - first) mod P when j < parts, else nothing."""
+    j = (rank - first) % P
+    return div_range(vocab, parts, j) if j < parts else (0, 0)
+
+
+def _round_up(x, m):
+    return (int(x) + m - 1) // m * m
+
+
+class HipBackend:
+    """The product path: launches of libdir_hip.so kernels."""
+
+    def __init__(self, local_tables, vocab_dev, P, parts_dev=None, first_dev=None):
         self.ts = ops.TableSet(local_tables)
         # row policy "auto": the owner-side gather streams (non-temporal) when this rank's shards exceed the
         # Infinity Cache, like the single-GPU gather
         self.vocab_dev = vocab_dev
         self.P = P
+        self.parts_dev, self.first_dev = parts_dev, first_dev
         self._back = None
         self._back_ts = None
+        self._finish_ts = {}
 
+    # ---- variable-size (exact) path -----------------------------------------------------------------------
     def bucket(self, flat_ids):
-        return ops.shard_bucket(flat_ids, self.vocab_dev, self.P)
+        return ops.shard_bucket(flat_ids, self.vocab_dev, self.P, parts=self.parts_dev, first=self.first_dev)
 
     def gather_packed(self, payload):
         return ops.gather_packed(self.ts, payload)
@@ -64,19 +108,84 @@ class HipBackend:
             self._back_ts = None
         return self._back
 
-    def finish(self, back, inv, B, F, want_fm):
-        if self._back_ts is None or self._back_ts.tables[0].data_ptr() != back.data_ptr():
+    def finish(self, back, inv, B, F, want_fm, out=None, fm=None):
+        if self._back_ts is None or self._back_ts.tables[0].data_ptr() != back.data_ptr() or self._back_ts.vocab[0] != back.shape[0]:
             self._back_ts = ops.TableSet([back] * F)
             self._back_ts.row_policy = "reuse"   # just received: largely cache-resident
         if want_fm:
-            return ops.gather_fm(self._back_ts, inv.view(B, F))
-        return ops.embedding_bag(self._back_ts, inv.view(B, F)), None
+            return ops.gather_fm(self._back_ts, inv.view(B, F), out=out, fm=fm)
+        return ops.embedding_bag(self._back_ts, inv.view(B, F), out=out), None
+
+    # ---- fixed-capacity path ------------------------------------------------------------------------------
+    def new_workspace(self, device):
+        return torch.zeros(64, dtype=torch.int32, device=device)
+
+    def bucket_cap(self, flat_ids, cap, payload, inv, counts, overflow, workspace):
+        ops.shard_bucket_cap(flat_ids, self.vocab_dev, self.P, cap, payload, inv, counts, overflow, workspace,
+                             parts=self.parts_dev, first=self.first_dev)
+
+    def gather_slabs(self, recv, cap, out):
+        ops.gather_slabs(self.ts, recv, self.P, cap, out)
+
+    def finish_chunk(self, back, inv2d, want_fm, out, fm):
+        key = (back.data_ptr(), back.shape[0], inv2d.shape[1])
+        ts = self._finish_ts.get(key)
+        if ts is None:
+            if len(self._finish_ts) > 64:
+                self._finish_ts.clear()
+            ts = self._finish_ts[key] = ops.TableSet([back] * inv2d.shape[1])
+            ts.row_policy = "reuse"
+        if want_fm:
+            ops.gather_fm(ts, inv2d, out=out, fm=fm)
+        else:
+            ops.embedding_bag(ts, inv2d, out=out)
+
+
+class _Plan:
+    """Persistent buffers of the fixed-capacity pipeline for one (batch, chunk count, capacities) combination: stable
+    addresses, so nothing is allocated per lookup and a lookup can be captured in a HIP graph."""
+
+    def __init__(self, st, B, chunks, cap, cap_x):
+        dev, P, F, K = st.device, st.P, st.F, st.K
+        self.B, self.cap, self.cap_x = B, cap, cap_x
+        C = max(1, min(chunks, B))
+        per = -(-B // C)
+        self.bounds = [(c * per, min(B, (c + 1) * per)) for c in range(C) if c * per < B]
+        C = self.C = len(self.bounds)
+        i64 = dict(dtype=torch.int64, device=dev)
+        alias = not st._collective()                     # one rank, no collectives: receive buffers ARE the send buffers
+        self.payload_s = [torch.empty(P * (cap + 1), **i64) for _ in range(C)]
+        self.inv = [torch.empty((e - s) * F, **i64) for s, e in self.bounds]
+        self.counts = torch.zeros((C, P), **i64)
+        self.ucounts = torch.zeros((C, P), **i64)
+        self.flags = torch.zeros((C, 2), dtype=torch.int32, device=dev)      # [:, 0] slab overflow, [:, 1] exchange-slab overflow (dedup)
+        self.ws = [st.backend.new_workspace(dev) for _ in range(C)]
+        if st.dedup:
+            self.send_x = [torch.empty(P * (cap_x + 1), **i64) for _ in range(C)]
+        else:
+            self.send_x = self.payload_s
+        self.recv_x = self.send_x if alias else [torch.empty(P * (cap_x + 1), **i64) for _ in range(C)]
+        self.rows = [torch.empty((P * cap_x, K), dtype=torch.float32, device=dev) for _ in range(C)]
+        self.back = self.rows if alias else [torch.empty((P * cap_x, K), dtype=torch.float32, device=dev) for _ in range(C)]
+        self.stat = torch.zeros(3, **i64)                 # [any overflow, max demand, max distinct demand], MAX over ranks
+        self.host = torch.empty(3, dtype=torch.int64, pin_memory=dev.type == "cuda")
 
 
 class ShardedTables:
-    """This rank's row shard of F tables [vocab_f, K]."""
+    """This rank's row slices of F tables [vocab_f, K].
 
-    def __init__(self, local_tables, vocab, group=None, backend=None, force_collective=False):
+    partitions: None = every table cut into P slices, slice r on rank r (the north star's row sharding); "reference" = the
+      reference partitioner's slice-count rule (partitions_for with max_partitions = P) with the slices dealt round-robin; or an
+      explicit list of slice counts.  local_tables[f] holds local_slice(...) rows of table f (possibly zero rows).
+    chunks: micro-batches per lookup (pipelined on two streams);  slack: slab capacity = ceil(slack * n / P) entries per owner
+      and chunk (None: n / P + 8 sigma of the binomial count + 64: ~3 % padding at 16 384 x 26 ids over 8 ranks);
+    mode: "auto" (fixed capacity, exact fallback on overflow; switches to "exact" when the owners' demand is so uneven that
+      padding would cost more than the host read), "fixed", "exact";  check: "eager" (read the overflow flag after enqueuing
+      the pipeline), "lazy" (read it at the next lookup -- raises), "never" (graph capture; call check_overflow() yourself);
+    dedup: send each (slot, row) once per owner and chunk."""
+
+    def __init__(self, local_tables, vocab, group=None, backend=None, force_collective=False, partitions=None, chunks=4,
+                 slack=None, mode="auto", check="eager", dedup=False):
         self.group = group
         self.force_collective = force_collective  # issue the all_to_all calls even when world_size == 1
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -85,13 +194,34 @@ class ShardedTables:
         self.F = len(self.vocab)
         self.local_tables = list(local_tables)
         self.K = self.local_tables[0].shape[1]
+        P = self.P
+        if partitions is None:
+            self.parts, self.first = [P] * self.F, [0] * self.F
+        else:
+            self.parts = ([partitions_for(v, self.K, P) for v in self.vocab] if partitions == "reference"
+                          else [int(p) for p in partitions])
+            if len(self.parts) != self.F or any(p < 1 or p > P for p in self.parts):
+                raise ValueError("partitions: one slice count in [1, P=%d] per table" % P)
+            self.first = place_slices(self.parts, P)
         for f, t in enumerate(self.local_tables):
-            s, e = div_range(self.vocab[f], self.P, self.rank)
+            s, e = local_slice(self.vocab[f], self.parts[f], self.first[f], P, self.rank)
             if t.shape[0] != e - s:
                 raise ValueError("table %d: rank %d must hold rows [%d,%d) (%d rows), got %d" % (f, self.rank, s, e, e - s, t.shape[0]))
         self.device = self.local_tables[0].device
         self.vocab_dev = torch.tensor(self.vocab, dtype=torch.int64, device=self.device)
-        self.backend = backend or HipBackend(self.local_tables, self.vocab_dev, self.P)
+        custom = partitions is not None
+        self.parts_dev = torch.tensor(self.parts, dtype=torch.int32, device=self.device) if custom else None
+        self.first_dev = torch.tensor(self.first, dtype=torch.int32, device=self.device) if custom else None
+        self.backend = backend or HipBackend(self.local_tables, self.vocab_dev, P, self.parts_dev, self.first_dev)
+        if mode not in ("auto", "fixed", "exact") or check not in ("eager", "lazy", "never"):
+            raise ValueError("mode: auto | fixed | exact; check: eager | lazy | never")
+        self.chunks, self.slack, self.mode, self.check, self.dedup = int(chunks), slack, mode, check, bool(dedup)
+        self._plans = {}
+        self._cap_floor = {}          # B -> capacities learnt from overflows / observed demand
+        self._use_exact = mode == "exact"
+        self._pending = None          # lazy check: the plan whose flags have not been read yet
+        self._streams = None
+        self.stats = {"lookups": 0, "fallbacks": 0, "cap": None, "cap_exchange": None}
 
     @classmethod
     def from_full(cls, full_tables, group=None, **kw):
@@ -99,9 +229,16 @@ class ShardedTables:
         P = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         vocab = [t.shape[0] for t in full_tables]
+        K = full_tables[0].shape[1]
+        partitions = kw.get("partitions")
+        if partitions is None:
+            parts, first = [P] * len(vocab), [0] * len(vocab)
+        else:
+            parts = [partitions_for(v, K, P) for v in vocab] if partitions == "reference" else [int(p) for p in partitions]
+            first = place_slices(parts, P)
         loc = []
-        for t in full_tables:
-            s, e = div_range(t.shape[0], P, rank)
+        for f, t in enumerate(full_tables):
+            s, e = local_slice(vocab[f], parts[f], first[f], P, rank)
             loc.append(t[s:e].contiguous())
         return cls(loc, vocab, group=group, **kw)
 
@@ -118,6 +255,17 @@ class ShardedTables:
                 dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
         else:
             out.copy_(inp)
+
+    def _a2a_equal(self, out, inp):
+        """Equal-split all-to-all, asynchronous where the transport allows: -> a work handle (or None when done / aliased)."""
+        if not self._collective():
+            return None                                   # out IS inp (see _Plan)
+        if _HOST_STAGED or (out.is_cuda and dist.get_backend(self.group) == "gloo"):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+            return None
+        return dist.all_to_all_single(out, inp, group=self.group, async_op=True)
 
     # ---- training: the gradient rows travel the forward's row exchange backwards and the OWNER updates its shard -------
     def enable_training(self, lr, initial_accumulator_value=0.1):
@@ -164,27 +312,249 @@ class ShardedTables:
         self._a2a(grecv.view(-1), gsend.view(-1), [c * K for c in rc], [c * K for c in sc])   # the forward exchange, reversed
         self.backend.apply_adagrad(self.optimizer, recv, grecv)
 
-    def lookup(self, ids, want_fm=False):
-        """ids [B_local, F] int64 (global row ids; < 0 pruned -> zeros) -> emb [B_local, F*K] fp32
-        (and the FM second-order logit [B_local, 1] when want_fm)."""
+    # ---- the exact, variable-size lookup (one host read of the split sizes) --------------------------------
+    def _lookup_exact(self, ids, want_fm, out=None, fm=None):
         B, F = ids.shape
-        if F != self.F:
-            raise ValueError("ids must be [B, F=%d]" % self.F)
         K, be = self.K, self.backend
         flat = ids.reshape(-1).contiguous()
         n = flat.numel()
         payload, inv, send_counts, _ = be.bucket(flat)                      # HIP
         recv_counts = torch.empty_like(send_counts)
         self._a2a(recv_counts, send_counts, None, None)
-        both = torch.stack([send_counts, recv_counts]).tolist()             # the one host read per lookup
+        both = torch.stack([send_counts, recv_counts]).tolist()             # the host read of this path
         sc, rc = [int(v) for v in both[0]], [int(v) for v in both[1]]
         recv = torch.empty(sum(rc), dtype=torch.int64, device=flat.device)
         self._a2a(recv, payload, rc, sc)
         rows = be.gather_packed(recv)                                       # HIP (owner side)
         back = be.back_buffer(n, K, flat.device)
         self._a2a(back.view(-1), rows.reshape(-1), [c * K for c in sc], [c * K for c in rc])
-        emb, fm = be.finish(back, inv, B, F, want_fm)                       # HIP: un-permute (+ FM)
-        return (emb, fm) if want_fm else emb
+        return be.finish(back, inv, B, F, want_fm, out=out, fm=fm)          # HIP: un-permute (+ FM)
+
+    # ---- the fixed-capacity, pipelined lookup ---------------------------------------------------------------
+    def _default_cap(self, n_chunk):
+        P = self.P
+        if self.slack is not None:
+            return _round_up(max(1, math.ceil(float(self.slack) * n_chunk / P)), 16)
+        p = 1.0 / P
+        return min(_round_up(n_chunk * p + 8.0 * math.sqrt(n_chunk * p * (1 - p)) + 64, 16), _round_up(max(n_chunk, 16), 16))
+
+    def _plan(self, B):
+        C = max(1, min(self.chunks, B))
+        n_chunk = -(-B // C) * self.F
+        cap, cap_x = self._cap_floor.get(B, (0, 0))
+        cap = max(cap, self._default_cap(n_chunk))
+        cap = min(cap, _round_up(n_chunk, 16))           # a slab never needs more than the whole chunk
+        cap_x = min(max(cap_x, 16), cap) if (self.dedup and cap_x) else cap
+        key = (B, C, cap, cap_x)
+        plan = self._plans.get(key)
+        if plan is None:
+            if self._collective():
+                # equal-split exchanges need the SAME slab sizes on every rank: agree once per new plan (a host-side MAX; every
+                # rank reaches this point together because capacities only change on globally reduced statistics)
+                t = torch.tensor([cap, cap_x, C, -C], dtype=torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group) if dist.get_backend(self.group) == "gloo" else None
+                if dist.get_backend(self.group) != "gloo":
+                    td = t.to(self.device)
+                    dist.all_reduce(td, op=dist.ReduceOp.MAX, group=self.group)
+                    t = td.cpu()
+                if int(t[2]) != C or int(t[3]) != -C:
+                    raise RuntimeError("ShardedTables: every rank must look up the same local batch size (chunk counts differ)")
+                cap, cap_x = int(t[0]), int(t[1])
+                key = (B, C, cap, cap_x)
+            self._plans = {k: v for k, v in self._plans.items() if k[0] != B}        # one plan per batch size
+            plan = self._plans[key] = _Plan(self, B, C, cap, cap_x)
+        self.stats["cap"], self.stats["cap_exchange"] = cap, cap_x
+        return plan
+
+    def _dedup(self, plan, c):
+        """Compact chunk c's slabs to one slot per distinct (slot, row): torch ops only (sort per slab, head flags, prefix
+        sum, scatter), no host read.  payload_s[c] [P, cap+1] -> send_x[c] [P, cap_x+1]; inv[c] is re-pointed at the compact
+        positions; an owner with more than cap_x distinct rows raises flag 1."""
+        P, cap, cx = self.P, plan.cap, plan.cap_x
+        slabs = plan.payload_s[c].view(P, cap + 1)
+        hdr, slots = slabs[:, 0], slabs[:, 1:]
+        big = torch.iinfo(torch.int64).max
+        pos = torch.arange(cap, device=slots.device)
+        keys = torch.where(pos.unsqueeze(0) < hdr.unsqueeze(1), slots, torch.full_like(slots, big))
+        skeys, order = torch.sort(keys, dim=1)
+        head = torch.ones_like(skeys, dtype=torch.bool)
+        head[:, 1:] = skeys[:, 1:] != skeys[:, :-1]
+        head &= skeys != big
+        uidx = torch.cumsum(head, dim=1) - 1                                   # compact index of every sorted position
+        ucount = head.sum(dim=1)
+        plan.ucounts[c].copy_(ucount)
+        plan.flags[c, 1:2].copy_((ucount > cx).any().to(torch.int32).reshape(1))
+        tgt = torch.where((skeys != big) & (uidx < cx), uidx, torch.full_like(uidx, cx))   # column cx = dump
+        comp = torch.empty((P, cx + 1), dtype=torch.int64, device=slots.device)
+        comp.scatter_(1, tgt, skeys)                                           # duplicates write the same key: benign
+        out = plan.send_x[c].view(P, cx + 1)
+        out[:, 1:].copy_(comp[:, :cx])
+        out[:, 0].copy_(torch.minimum(ucount, torch.full_like(ucount, cx)))
+        rank_of = torch.empty_like(order)
+        rank_of.scatter_(1, order, pos.unsqueeze(0).expand(P, cap))            # inverse of the sort permutation
+        newpos = uidx.gather(1, rank_of)                                       # [P, cap]: compact index of every original slot
+        newpos = torch.where(newpos < cx, newpos + torch.arange(P, device=slots.device).unsqueeze(1) * cx, torch.full_like(newpos, -1))
+        inv = plan.inv[c]
+        plan.inv[c].copy_(torch.where(inv >= 0, newpos.view(-1)[inv.clamp(min=0)], inv))
+
+    def _ensure_streams(self):
+        if self._streams is None and self.device.type == "cuda":
+            self._streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self._chk_stream = torch.cuda.Stream(device=self.device)
+        return self._streams
+
+    def _lookup_fixed(self, ids, want_fm, out, fm):
+        B, F = ids.shape
+        K, be, P = self.K, self.backend, self.P
+        plan = self._plan(B)
+        C = plan.C
+        ids = ids if ids.is_contiguous() else ids.contiguous()
+        S = self._ensure_streams()
+        cur = torch.cuda.current_stream(self.device) if S else None
+        if S:
+            for s in S:
+                s.wait_stream(cur)
+
+        def on(c):
+            return torch.cuda.stream(S[c % 2]) if S else contextlib.nullcontext()
+
+        def bucket(c):
+            s, e = plan.bounds[c]
+            be.bucket_cap(ids[s:e].reshape(-1), plan.cap, plan.payload_s[c], plan.inv[c], plan.counts[c], plan.flags[c, 0:1], plan.ws[c])
+            if self.dedup:
+                self._dedup(plan, c)
+            return self._a2a_equal(plan.recv_x[c], plan.send_x[c])
+
+        def wait(w):
+            if w is not None:
+                w.wait()
+
+        def reduce_stat():
+            """Right behind the LAST bucket: [any overflow, max demand, max distinct demand] -> MAX over the ranks.  Every rank
+            must take the same decision (fallback, capacity growth) or the collectives would mismatch."""
+            ctx = torch.cuda.stream(self._chk_stream) if S else contextlib.nullcontext()
+            with ctx:
+                if S:
+                    for e in ev[-2:]:
+                        self._chk_stream.wait_event(e)
+                torch.stack([plan.flags.max().to(torch.int64), plan.counts.max(), plan.ucounts.max()], out=plan.stat)
+                if self._collective():
+                    if _HOST_STAGED or (plan.stat.is_cuda and dist.get_backend(self.group) == "gloo"):
+                        h = plan.stat.cpu()
+                        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                        plan.stat.copy_(h)
+                    else:
+                        dist.all_reduce(plan.stat, op=dist.ReduceOp.MAX, group=self.group)   # the stream waits for it, not the host
+                if S:
+                    plan.host.copy_(plan.stat, non_blocking=True)
+                    return self._chk_stream.record_event()
+            return None
+
+        wi, wr = [None] * C, [None] * C
+        ev = []
+        done = None
+        with on(0):
+            wi[0] = bucket(0)
+            if S:
+                ev.append(S[0].record_event())
+        if C == 1:
+            done = reduce_stat()
+        for c in range(C):
+            if c + 1 < C:
+                with on(c + 1):
+                    wi[c + 1] = bucket(c + 1)
+                    if S:
+                        ev.append(S[(c + 1) % 2].record_event())
+                if c + 1 == C - 1:
+                    done = reduce_stat()
+            with on(c):
+                wait(wi[c])
+                be.gather_slabs(plan.recv_x[c], plan.cap_x, plan.rows[c])
+                wr[c] = self._a2a_equal(plan.back[c], plan.rows[c])
+            if c >= 1:
+                with on(c - 1):
+                    wait(wr[c - 1])
+                    s, e = plan.bounds[c - 1]
+                    be.finish_chunk(plan.back[c - 1], plan.inv[c - 1].view(e - s, F), want_fm, out[s:e], fm[s:e] if want_fm else None)
+        with on(C - 1):
+            wait(wr[C - 1])
+            s, e = plan.bounds[C - 1]
+            be.finish_chunk(plan.back[C - 1], plan.inv[C - 1].view(e - s, F), want_fm, out[s:e], fm[s:e] if want_fm else None)
+        if S:
+            for s in S:
+                cur.wait_stream(s)
+            cur.wait_stream(self._chk_stream)
+        return plan, done
+
+    def _read_flags(self, plan, done):
+        """The globally reduced overflow flag and demand of the lookup just enqueued.  On the GPU the reduction and its copy to
+        pinned memory ran on their own stream behind the LAST bucket kernels only (issued early in the pipeline): the host waits
+        for work that is long done while the row exchanges and finish kernels keep the GPU busy."""
+        if done is not None:
+            done.synchronize()
+            host = plan.host
+        else:
+            host = plan.stat
+        return bool(host[0]), int(host[1]), int(host[2])
+
+    def _learn(self, plan, over, cmax, umax):
+        """Capacity policy after a checked lookup: grow to the observed demand after an overflow; give up on fixed slabs
+        (mode auto) when one owner wants more than twice its share even after dedup -- padding every slab to that size would cost
+        more link bytes than the host read of the exact path; shrink the exchange slabs to what dedup left."""
+        B = plan.B
+        n_chunk = (plan.bounds[0][1] - plan.bounds[0][0]) * self.F
+        cap, cap_x = plan.cap, plan.cap_x
+        if over:
+            cap = max(cap, _round_up(cmax * 1.25 + 64, 16))
+        if self.dedup:
+            want = _round_up(umax * 1.25 + 64, 16)
+            if over or want < 0.7 * cap_x:
+                cap_x = want
+        self._cap_floor[B] = (cap, cap_x)
+        demand = umax if self.dedup else cmax
+        if self.mode == "auto" and demand > 2.0 * n_chunk / self.P + 16:
+            self._use_exact = True
+
+    def check_overflow(self):
+        """check="lazy"/"never": read the flags of the last fixed-capacity lookup; raises if a slab overflowed (its result was
+        incomplete: repeat it with mode="exact" or a larger slack)."""
+        if self._pending is None:
+            return False
+        plan, ev = self._pending
+        self._pending = None
+        over, cmax, umax = self._read_flags(plan, ev)
+        self._learn(plan, over, cmax, umax)
+        if over:
+            raise RuntimeError("ShardedTables: a slab of the previous fixed-capacity lookup overflowed (demand %d > capacity %d): "
+                               "that result was incomplete" % (max(cmax, umax), plan.cap_x))
+        return False
+
+    def lookup(self, ids, want_fm=False, out=None, fm=None):
+        """ids [B_local, F] int64 (global row ids; < 0 or >= vocab_f -> zeros) -> emb [B_local, F*K] fp32
+        (and the FM second-order logit [B_local, 1] when want_fm).  out / fm: preallocated results (stable addresses)."""
+        B, F = ids.shape
+        if F != self.F:
+            raise ValueError("ids must be [B, F=%d]" % self.F)
+        self.stats["lookups"] += 1
+        if self.check == "lazy":
+            self.check_overflow()
+        if self._use_exact or B == 0:
+            emb, fmo = self._lookup_exact(ids, want_fm, out=out, fm=fm)
+            return (emb, fmo) if want_fm else emb
+        if out is None:
+            out = torch.empty((B, F * self.K), dtype=torch.float32, device=ids.device)
+        if want_fm and fm is None:
+            fm = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
+        plan, ev = self._lookup_fixed(ids, want_fm, out, fm)
+        if self.check == "eager":
+            over, cmax, umax = self._read_flags(plan, ev)
+            self._learn(plan, over, cmax, umax)
+            if over:                                      # rare: repeat on the exact path (results overwrite out / fm in stream order)
+                self.stats["fallbacks"] += 1
+                self._lookup_exact(ids, want_fm, out=out, fm=fm)
+        else:
+            self._pending = (plan, ev)
+        return (out, fm) if want_fm else out
 
 
 class _ShardedLookup(torch.autograd.Function):

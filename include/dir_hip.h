@@ -240,8 +240,35 @@ int dir_gather_rows_f32(const float* const* tables, int K, const int32_t* slot, 
  *   counts, starts: DEVICE int64 [P];  workspace: dir_shard_bucket_workspace_bytes(n, P) device bytes.
  * dir_gather_packed_f32 is the owner side for that payload: out[i,:] = tables[p % F][p / F, :]. */
 int64_t dir_shard_bucket_workspace_bytes(int64_t n, int P);
-int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, int F, int P, int64_t* payload,
-                     int64_t* inv, int64_t* counts, int64_t* starts, void* workspace, dir_stream_t stream);
+int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first, int F, int P,
+                     int64_t* payload, int64_t* inv, int64_t* counts, int64_t* starts, void* workspace, dir_stream_t stream);
+
+/* Partitioning of one table, as the reference's partitioner decides it (models/DeepFM/deepFM.py:163-167:
+ * min_max_variable_partitioner(max_partitions=num_ps_replicas, min_slice_size=64 << 20)): table f is cut into parts[f] <= P
+ * contiguous 'div' row slices and slice j lives on rank (first[f] + j) % P.  parts / first: DEVICE int32 [F] or NULL
+ * (= every table cut P ways starting at rank 0, what the routines above did before).  Ids outside [0, vocab_f) have no owner:
+ * they are treated as pruned.
+ *
+ * Fixed-capacity form of the requester side -- no split sizes ever reach the host, so a lookup is one stream-ordered chain
+ * that can be captured in a graph and pipelined in micro-batches:
+ *   payload  [P * (cap + 1)]: owner o's SLAB = one header word (number of valid slots, <= cap) + cap slots local_row*F + slot
+ *   inv      [n]: row of entry i in the [P*cap, K] buffer the row exchange returns (o*cap + position), -1 for a pruned id or
+ *            an entry that did not fit its slab
+ *   counts   [P] int64: the true per-owner demand (can exceed cap);  overflow [1] int32: 1 iff some count > cap -- the caller
+ *            then repeats the lookup on the variable-size path (dir_shard_bucket)
+ *   workspace: dir_shard_bucket_cap_workspace_bytes(P) bytes, ZERO before the first call (left zero on return).
+ * Both exchanges are all-to-alls with EQUAL splits (cap + 1 words / cap rows per peer).
+ * dir_gather_slabs_f32 is the owner side: recv = the P slabs as received; out[(s*cap + j), :] = the row of slot j of slab s for
+ * j < header_s; the other rows are left untouched (never read by the requester).  flags: DIR_GATHER_STREAM_ROWS,
+ * DIR_SLAB_SANITIZE (overwrite the slots behind each header with -1: the slab can then be walked as a flat payload by
+ * dir_sparse_adagrad_sorted_payload_f32 -- the owner side of a sharded backward). */
+enum { DIR_SLAB_SANITIZE = 4 };
+int64_t dir_shard_bucket_cap_workspace_bytes(int P);
+int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first, int F, int P,
+                         int64_t cap, int64_t* payload, int64_t* inv, int64_t* counts, int32_t* overflow, void* workspace,
+                         dir_stream_t stream);
+int dir_gather_slabs_f32(const float* const* tables, int F, int K, int64_t* recv, int P, int64_t cap, int flags, float* out,
+                         dir_stream_t stream);
 int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_t* payload, int64_t n,
                           int flags /* DIR_GATHER_STREAM_ROWS */, float* out, dir_stream_t stream);
 

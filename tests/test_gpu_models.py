@@ -609,3 +609,123 @@ def test_dcn_odd_width_padded_inference_path(built_lib, oracle):
     deep = R.deep_architecture(xr, layers, bn)
     ref = np.concatenate([cross, deep], -1) @ _np(model.logits_layer.weight).T + _np(model.logits_layer.bias)
     _close(fast.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("P,parts", [(1, None), (2, None), (3, None), (8, None), (8, [1, 8, 3, 2, 1, 5, 8]), (4, [4, 1, 2, 2, 3, 1, 4])])
+def test_fixed_capacity_bucket_and_slab_gather(built_lib, P, parts):
+    """dir_shard_bucket_cap / dir_gather_slabs_f32 (the sync-free requester / owner steps) against a NumPy restatement: per-owner
+    counts, slab headers, inv = the exact inverse into the slab layout, overflow flag, self-cleaning workspace; with and without
+    the reference partitioner's per-table slice counts."""
+    from dir_amd import ops
+    from dir_amd.shard import place_slices, local_slice
+    rng = np.random.default_rng(P * 7 + (len(parts) if parts else 0))
+    F, K, B = 7, 16, 1500
+    vocab = [100, 17, 64, 1000, 5, 333, 64]
+    pl = parts or [P] * F
+    first = place_slices(pl, P) if parts else [0] * F
+    ids = np.stack([rng.integers(-1, v + 2, size=B) for v in vocab], 1).astype(np.int64)      # pruned and out-of-range ids too
+    a = ids.reshape(-1)
+    n = a.size
+    own = np.full(n, -1, np.int64); loc = np.full(n, -1, np.int64)
+    for f in range(F):
+        sel = np.arange(f, n, F)
+        ok = (a[sel] >= 0) & (a[sel] < vocab[f])
+        o, l = R.shard_div_owner(np.where(ok, a[sel], 0), vocab[f], pl[f])
+        own[sel] = np.where(ok, (np.asarray(o) + first[f]) % P, -1); loc[sel] = np.where(ok, l, -1)
+    true_counts = np.bincount(own[own >= 0], minlength=P)
+    vdev = torch.tensor(vocab, dtype=torch.int64, device="cuda")
+    pdev = torch.tensor(pl, dtype=torch.int32, device="cuda") if parts else None
+    fdev = torch.tensor(first, dtype=torch.int32, device="cuda") if parts else None
+    ws = torch.zeros(64, dtype=torch.int32, device="cuda")
+    flat = torch.from_numpy(a).cuda()
+    for cap in (int(true_counts.max()) + 5, max(1, int(true_counts.max()) // 2)):          # roomy, then overflowing
+        payload = torch.full((P * (cap + 1),), -7, dtype=torch.int64, device="cuda")
+        inv = torch.empty(n, dtype=torch.int64, device="cuda")
+        counts = torch.empty(P, dtype=torch.int64, device="cuda")
+        over = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+        ops.shard_bucket_cap(flat, vdev, P, cap, payload, inv, counts, over, ws, parts=pdev, first=fdev)
+        pay = payload.cpu().numpy().reshape(P, cap + 1)
+        iv = inv.cpu().numpy()
+        np.testing.assert_array_equal(counts.cpu().numpy(), true_counts)
+        np.testing.assert_array_equal(pay[:, 0], np.minimum(true_counts, cap))
+        assert int(over.item()) == int((true_counts > cap).any())
+        assert int(ws.abs().sum()) == 0                                                   # left zero for the next call
+        assert (iv[own < 0] == -1).all()
+        kept = iv >= 0
+        if (true_counts <= cap).all():
+            assert kept[own >= 0].all()
+        assert len(set(iv[kept].tolist())) == int(kept.sum())                             # distinct slots
+        o_k, pos_k = iv[kept] // cap, iv[kept] % cap
+        np.testing.assert_array_equal(o_k, own[kept])
+        assert (pos_k < pay[o_k, 0]).all()
+        np.testing.assert_array_equal(pay[o_k, 1 + pos_k], loc[kept] * F + (np.nonzero(kept)[0] % F))
+        for o in range(P):                                                                # every valid slot is somebody's
+            assert np.bincount(pos_k[o_k == o], minlength=1).max(initial=0) <= 1 and (o_k == o).sum() == pay[o, 0]
+    # owner side: slabs addressed to "rank 0" of a P-way split hold local rows of rank 0's slices
+    cap = int(true_counts.max()) + 3
+    payload = torch.empty(P * (cap + 1), dtype=torch.int64, device="cuda")
+    ops.shard_bucket_cap(flat, vdev, P, cap, payload, inv, counts, over, ws, parts=pdev, first=fdev)
+    full = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
+    for r in range(min(P, 3)):
+        local = []
+        for f, v in enumerate(vocab):
+            s, e = local_slice(v, pl[f], first[f], P, r)
+            local.append(torch.from_numpy(full[f][s:e].copy()).cuda() if e > s else torch.zeros((0, K), device="cuda"))
+        # pretend every peer sent rank r the slab this requester built for it
+        recv = payload.view(P, cap + 1)[r].repeat(P).contiguous()
+        out = torch.full((P * cap, K), 5.0, device="cuda")
+        ops.gather_slabs(ops.TableSet(local), recv, P, cap, out, sanitize=True)
+        o = out.cpu().numpy().reshape(P, cap, K)
+        hdr = int(payload.view(P, cap + 1)[r, 0])
+        slots = payload.view(P, cap + 1)[r, 1:1 + hdr].cpu().numpy()
+        want = np.stack([local[p % F].cpu().numpy()[p // F] for p in slots]) if hdr else np.zeros((0, K), np.float32)
+        for sl in range(P):
+            np.testing.assert_array_equal(o[sl, :hdr], want)
+            assert (o[sl, hdr:] == 5.0).all()                                              # rows behind the header: untouched
+        assert (recv.view(P, cap + 1)[:, 1 + hdr:] == -1).all()                            # sanitised
+
+
+def test_sharded_lookup_fixed_capacity_paths_single_gpu(built_lib, oracle):
+    """The pipelined fixed-capacity lookup with the HIP backend under nccl (RCCL) at world size 1 (collectives issued):
+    chunked, preallocated outputs, overflow -> exact fallback -> grown capacity, dedup, lazy check."""
+    import torch.distributed as dist
+    from dir_amd.shard import ShardedTables
+    rng = np.random.default_rng(18)
+    F, K, B = 6, 16, 2000
+    vocab = [100, 17, 64, 1000, 5, 333]
+    full = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
+    ids = np.stack([rng.integers(-1, v, size=B) for v in vocab], 1).astype(np.int64)
+    ref = R.embedding_bag_onehot(full, ids)
+    ref_fm = oracle.fm_second_order(ref, F, K)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        tabs = [torch.from_numpy(t).cuda() for t in full]
+        idd = torch.from_numpy(ids).cuda()
+        for kw in ({}, {"chunks": 1}, {"chunks": 7}, {"dedup": True}, {"dedup": True, "chunks": 2}, {"check": "lazy"}, {"mode": "exact"}):
+            st = ShardedTables.from_full(tabs, force_collective=True, **kw)
+            for _ in range(3):
+                out = torch.full((B, F * K), 3.0, device="cuda")
+                fm = torch.full((B, 1), 3.0, device="cuda")
+                e, f = st.lookup(idd, want_fm=True, out=out, fm=fm)
+                assert e.data_ptr() == out.data_ptr()
+                np.testing.assert_array_equal(out.cpu().numpy(), ref)
+                np.testing.assert_array_equal(fm.cpu().numpy()[:, 0], ref_fm)
+            np.testing.assert_array_equal(st.lookup(idd).cpu().numpy(), ref)
+            assert st.stats["fallbacks"] == 0
+        st = ShardedTables.from_full(tabs, force_collective=True, slack=0.25, mode="fixed")     # slabs a quarter of the demand
+        np.testing.assert_array_equal(st.lookup(idd).cpu().numpy(), ref)
+        assert st.stats["fallbacks"] == 1
+        np.testing.assert_array_equal(st.lookup(idd).cpu().numpy(), ref)                          # capacity grown: fixed path again
+        assert st.stats["fallbacks"] == 1 and st.stats["cap"] >= B * F // 4
+        lazy = ShardedTables.from_full(tabs, force_collective=True, slack=0.25, mode="fixed", check="lazy")
+        lazy.lookup(idd)
+        with pytest.raises(RuntimeError, match="overflowed"):
+            lazy.lookup(idd)
+    finally:
+        if created:
+            dist.destroy_process_group()

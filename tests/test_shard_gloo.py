@@ -24,15 +24,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, vocab, K, B, seed, out_q, train=False):
+def _worker(rank, world, port, vocab, K, B, seed, out_q, train=False, opts=None):
     try:
-        _worker_body(rank, world, port, vocab, K, B, seed, out_q, train)
+        _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts or {})
     except Exception:                      # surface the reason instead of leaving the parent to time out
         import traceback
         out_q.put((rank, traceback.format_exc(), 0, 0))
 
 
-def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train=False):
+def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,32 +40,45 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train=False):
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
-        from dir_amd.shard import ShardedTables, div_range
+        from dir_amd.shard import ShardedTables, div_range, local_slice, place_slices
         from oracle import np_ref as R
         F = len(vocab)
+        parts = opts.get("partitions") or [world] * F
+        first = place_slices(parts, world) if opts.get("partitions") else [0] * F
         rng = np.random.default_rng(seed)           # same full tables on every rank
         full = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
         rng_b = np.random.default_rng(seed + 100 + rank)  # each rank draws its own batch
-        ids = np.stack([rng_b.integers(-1, v, size=B) for v in vocab], axis=1).astype(np.int64)
+        hi = opts.get("id_hi")                       # small id range: many duplicates (dedup) / one hot owner (overflow)
+        ids = np.stack([rng_b.integers(-1, min(v, hi) if hi else v, size=B) for v in vocab], axis=1).astype(np.int64)
+        if opts.get("out_of_range"):
+            ids[::5, 0] = vocab[0] + 3               # an id nobody owns: zeros, like a pruned id
         local = []
         for f, v in enumerate(vocab):
-            s, e = div_range(v, world, rank)
+            s, e = local_slice(v, parts[f], first[f], world, rank)
             local.append(torch.from_numpy(full[f][s:e].copy()))
 
-        class OracleBackend:
-            """NumPy stand-ins for the three HIP steps (bucket / gather_packed / finish)."""
+        def route(a):
+            """owner rank / local row of every entry of a flat [.., F] id array (-1: pruned or out of range)."""
+            n = a.size
+            own = np.full(n, -1, np.int64)
+            loc = np.full(n, -1, np.int64)
+            for f in range(F):
+                sel = np.arange(f, n, F)
+                ok = (a[sel] >= 0) & (a[sel] < vocab[f])
+                o, l = R.shard_div_owner(np.where(ok, a[sel], 0), vocab[f], parts[f])
+                own[sel] = np.where(ok, (np.asarray(o) + first[f]) % world, -1)
+                loc[sel] = np.where(ok, l, -1)
+            return own, loc
 
+        class OracleBackend:
+            """NumPy stand-ins for the HIP steps of both lookup paths."""
+
+            # ---- exact path ----
             def bucket(self, flat):
                 a = flat.numpy()
                 n = a.size
-                own = np.empty(n, np.int64)
-                loc = np.empty(n, np.int64)
-                for f in range(F):
-                    sel = np.arange(f, n, F)
-                    o, l = R.shard_div_owner(np.maximum(a[sel], 0), vocab[f], world)
-                    neg = a[sel] < 0
-                    own[sel] = np.where(neg, sel % world, o)
-                    loc[sel] = np.where(neg, -1, l)
+                own, loc = route(a)
+                own = np.where(own < 0, np.arange(n) % world, own)          # pruned entries travel as -1 payloads
                 order = np.argsort(own, kind="stable")
                 inv = np.empty(n, np.int64)
                 inv[order] = np.arange(n)
@@ -85,13 +98,56 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train=False):
             def back_buffer(self, n, K_, device):
                 return torch.empty((n, K_), dtype=torch.float32)
 
-            def finish(self, back, inv, B_, F_, want_fm):
-                emb = back.numpy()[inv.numpy()].reshape(B_, F_ * K)
-                fm = None
+            def finish(self, back, inv, B_, F_, want_fm, out=None, fm=None):
+                iv = inv.numpy()
+                emb = np.where((iv >= 0)[:, None], back.numpy()[np.maximum(iv, 0)], 0).astype(np.float32).reshape(B_, F_ * K)
+                fmv = None
                 if want_fm:
                     from oracle import oracle as O
-                    fm = torch.from_numpy(O.fm_second_order(emb, F_, K).reshape(B_, 1))
-                return torch.from_numpy(emb), fm
+                    fmv = torch.from_numpy(O.fm_second_order(emb, F_, K).reshape(B_, 1))
+                    if fm is not None:
+                        fm.copy_(fmv)
+                        fmv = fm
+                emb = torch.from_numpy(emb)
+                if out is not None:
+                    out.copy_(emb)
+                    emb = out
+                return emb, fmv
+
+            # ---- fixed-capacity path ----
+            def new_workspace(self, device):
+                return torch.zeros(64, dtype=torch.int32)
+
+            def bucket_cap(self, flat, cap, payload, inv, counts, overflow, workspace):
+                a = flat.numpy()
+                own, loc = route(a)
+                pay = payload.numpy().reshape(world, cap + 1)
+                iv = inv.numpy()
+                iv[:] = -1
+                fill = np.zeros(world, np.int64)
+                for i in range(a.size):
+                    o = own[i]
+                    if o < 0:
+                        continue
+                    if fill[o] < cap:
+                        pay[o, 1 + fill[o]] = loc[i] * F + (i % F)
+                        iv[i] = o * cap + fill[o]
+                    fill[o] += 1
+                pay[:, 0] = np.minimum(fill, cap)
+                counts.copy_(torch.from_numpy(fill))
+                overflow.fill_(int((fill > cap).any()))
+
+            def gather_slabs(self, recv, cap, out):
+                r = recv.numpy().reshape(world, cap + 1)
+                o = out.numpy()
+                for sl in range(world):
+                    for j in range(int(r[sl, 0])):
+                        v = r[sl, 1 + j]
+                        o[sl * cap + j] = local[v % F].numpy()[v // F]
+
+            def finish_chunk(self, back, inv2d, want_fm, out, fm):
+                b_, f_ = inv2d.shape
+                self.finish(back, inv2d.reshape(-1), b_, f_, want_fm, out=out, fm=fm)
 
             def make_optimizer(self, lr, init):
                 return {"lr": lr, "acc": [np.full(t.shape, init, np.float64) for t in local]}
@@ -110,8 +166,9 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train=False):
                     w[t] -= opt["lr"] * gsum[t] / np.sqrt(opt["acc"][f][t])
                     local[f].copy_(torch.from_numpy(w.astype(np.float32)))
 
+        kw = {k: opts[k] for k in ("partitions", "chunks", "slack", "mode", "check", "dedup") if k in opts}
         if train:
-            st = ShardedTables(local, vocab, backend=OracleBackend()).enable_training(lr=0.05, initial_accumulator_value=0.1)
+            st = ShardedTables(local, vocab, backend=OracleBackend(), **kw).enable_training(lr=0.05, initial_accumulator_value=0.1)
             gout = rng_b.standard_normal((B, F * K)).astype(np.float32)
             emb = st.lookup_train(torch.from_numpy(ids))
             fwd_ok = bool(np.array_equal(emb.detach().numpy(), R.embedding_bag_onehot(full, ids)))
@@ -130,28 +187,41 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train=False):
                 acc[t] += gsum[t] ** 2
                 ref = full[f].astype(np.float64)
                 ref[t] -= 0.05 * gsum[t] / np.sqrt(acc[t])
-                s_, e_ = div_range(v, world, rank)
+                s_, e_ = local_slice(v, parts[f], first[f], world, rank)
                 ok = ok and bool(np.allclose(local[f].numpy(), ref[s_:e_], rtol=1e-6, atol=1e-7))
             out_q.put((rank, ok, B, F * K))
             return
-        st = ShardedTables(local, vocab, backend=OracleBackend())
-        got, fm = st.lookup(torch.from_numpy(ids), want_fm=True)
-        got = got.numpy()
-        ref = R.embedding_bag_onehot(full, ids)
+        st = ShardedTables(local, vocab, backend=OracleBackend(), **kw)
+        ids_ref = ids.copy()
+        for f in range(F):
+            ids_ref[ids_ref[:, f] >= vocab[f], f] = -1
+        ref = R.embedding_bag_onehot(full, ids_ref)
         from oracle import oracle as O
-        ok = bool(np.array_equal(got, ref)) and bool(np.array_equal(fm.numpy()[:, 0], O.fm_second_order(ref, F, K)))
+        ok = True
+        for rep in range(int(opts.get("repeats", 1))):          # repeated lookups: the capacity policy adapts between them
+            got, fm = st.lookup(torch.from_numpy(ids), want_fm=True)
+            ok = ok and bool(np.array_equal(got.numpy(), ref)) and bool(np.array_equal(fm.numpy()[:, 0], O.fm_second_order(ref, F, K)))
+        got2 = st.lookup(torch.from_numpy(ids))                 # without the FM logit
+        ok = ok and bool(np.array_equal(got2.numpy(), ref))
+        want = opts.get("expect")
+        if want == "fallback":
+            ok = ok and st.stats["fallbacks"] >= 1
+        elif want == "no_fallback":
+            ok = ok and st.stats["fallbacks"] == 0
+        elif want == "exact_after":
+            ok = ok and st._use_exact
+        if opts.get("dedup") and want == "shrinks":
+            ok = ok and st.stats["cap_exchange"] < st.stats["cap"]
         out_q.put((rank, ok, int(got.shape[0]), int(got.shape[1])))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,vocab", [(2, [10, 7, 33]), (3, [100, 5, 64, 9]), (2, [1000] * 6)])
-def test_sharded_lookup_matches_full_tables(world, vocab):
+def _run(world, vocab, K, B, seed, train=False, opts=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    K, B = 8, 37
-    procs = [ctx.Process(target=_worker, args=(r, world, port, vocab, K, B, 4321, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, vocab, K, B, seed, q, train, opts)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
@@ -161,28 +231,61 @@ def test_sharded_lookup_matches_full_tables(world, vocab):
     assert sorted(r[0] for r in res) == list(range(world))
     for rank, ok, b, w in res:
         assert not isinstance(ok, str), "rank %d raised:\n%s" % (rank, ok)
-        assert ok, "rank %d: sharded lookup differs from the full-table gather" % rank
+        assert ok, "rank %d: sharded result differs from the full-table computation" % rank
+    return res
+
+
+@pytest.mark.parametrize("world,vocab,opts", [
+    (2, [10, 7, 33], {"expect": "no_fallback"}),                                    # fixed-capacity pipeline, default slack
+    (3, [100, 5, 64, 9], {"chunks": 3, "out_of_range": True}),
+    (2, [1000] * 6, {"chunks": 1}),
+    (2, [50, 50, 50], {"slack": 0.5, "mode": "fixed", "expect": "fallback", "repeats": 2}),   # slabs too small: exact fallback, then grown
+    (3, [3000, 3000], {"id_hi": 40, "chunks": 1, "expect": "exact_after", "repeats": 2}),         # every id owned by rank 0: auto gives up on slabs
+    (2, [200, 300, 100], {"dedup": True, "id_hi": 12, "chunks": 2, "repeats": 4, "B": 600, "expect": "shrinks"}),   # duplicates sent once
+    (3, [64, 64, 9, 200], {"dedup": True, "slack": 0.6, "mode": "fixed", "repeats": 3}),
+    (3, [40, 90, 64, 9, 17], {"partitions": [1, 3, 2, 1, 2]}),                       # the partitioner rule's slice counts, round-robin placement
+    (2, [10, 7, 33], {"mode": "exact"}),
+    (2, [30, 30], {"check": "lazy", "repeats": 2}),
+])
+def test_sharded_lookup_matches_full_tables(world, vocab, opts):
+    K, B = 8, opts.get("B", 37)
+    res = _run(world, vocab, K, B, 4321, opts=opts)
+    for rank, ok, b, w in res:
         assert (b, w) == (B, len(vocab) * K)
 
 
-@pytest.mark.parametrize("world,vocab", [(2, [10, 7, 33]), (3, [40, 5, 64, 9])])
-def test_sharded_training_step_matches_full_table_adagrad(world, vocab):
+@pytest.mark.parametrize("world,vocab,opts", [(2, [10, 7, 33], None), (3, [40, 5, 64, 9], None), (3, [40, 5, 64, 9], {"partitions": [2, 1, 3, 1]})])
+def test_sharded_training_step_matches_full_table_adagrad(world, vocab, opts):
     """lookup_train + backward over gloo: every rank's row gradients reach the owners (the forward exchange reversed) and
     the owners' shards end up equal to one synchronous Adagrad step on the full tables over all ranks' batches."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    K, B = 8, 29
-    procs = [ctx.Process(target=_worker, args=(r, world, port, vocab, K, B, 777, q, True)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, ok, b, w in res:
-        assert not isinstance(ok, str), "rank %d raised:\n%s" % (rank, ok)
-        assert ok, "rank %d: shard differs from the full-table Adagrad step" % rank
+    _run(world, vocab, 8, 29, 777, train=True, opts=opts)
+
+
+def test_partitioner_slice_count_rule():
+    """min_max_variable_partitioner(max_partitions=num_ps_replicas, min_slice_size=64 << 20) as called at deepFM.py:163-167:
+    slices = max(1, min(rows, max_partitions, ceil(bytes / min_slice_size))); KATs from the BASELINE configurations."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from dir_amd.shard import partitions_for, place_slices, local_slice
+    assert partitions_for(1_000_000, 16, 8) == 1            # cfg 2: 64 000 000 B < 64 MiB -> ceil(0.954) = 1: NOT split
+    assert partitions_for(1_048_576, 16, 8) == 1            # exactly 64 MiB: still one slice
+    assert partitions_for(1_048_577, 16, 8) == 2            # one row more: ceil(1.0000009) = 2
+    assert partitions_for(10_000_000, 64, 8) == 8           # cfg 4: 2.56 GB -> 39 wanted, capped by the 8 servers
+    assert partitions_for(100_000_000, 16, 8) == 8          # cfg 5
+    assert partitions_for(100_000_000, 16, 128) == 96       # 6.4e9 / 64 MiB = 95.4 -> 96
+    assert partitions_for(5, 1 << 26, 8) == 5               # never more slices than rows
+    assert partitions_for(1_000_000, 16, 0) == 1            # num_ps_replicas = 0 (deepFM.py:162): unpartitioned
+    assert partitions_for(3_000_000, 16, 8, min_slice_size=256 << 10, bytes_per_element=4) == 8
+    parts = [1, 8, 3, 1]
+    first = place_slices(parts, 8)
+    assert first == [0, 1, 1, 4]                            # slices dealt round-robin over the ranks in creation order
+    # every row of every table is held by exactly one rank
+    for v, p, f0 in zip([10, 1000, 7, 3], parts, first):
+        cover = np.zeros(v, int)
+        for r in range(8):
+            s, e = local_slice(v, p, f0, 8, r)
+            cover[s:e] += 1
+        assert (cover == 1).all()
 
 
 def test_div_range_covers_vocab():
