@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void bucket_scatter_k(const int64_t* __restric
 // repeats the lookup on the exact variable-size path).  The order inside a slab is arbitrary (atomics); inv is its exact
 // inverse, so the looked-up values do not depend on it.  gcount: P int32 counters, zero on entry, zeroed again by fin.
 // ------------------------------------------------------------------------------------------------
-constexpr int BK_EPT = BK_EPB / 256;   // elements per thread
+constexpr int BKC_EPB = 1024;          // elements per workgroup of the one-pass kernel: a micro-batch of 16 384 x 26 ids still
+constexpr int BK_EPT = BKC_EPB / 256;  // makes 416 workgroups (4096 per workgroup left 60 % of the CUs idle: 24 us per chunk)
 typedef float f32x4_ids __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void bucket_cap_k(const int64_t* __restrict__ ids, int64_t n,
@@ -521,10 +522,10 @@ __global__ __launch_bounds__(256) void bucket_cap_k(const int64_t* __restrict__ 
     if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
     for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0);
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * BK_EPB;
+    const int64_t base = (int64_t)blockIdx.x * BKC_EPB;
     const int f0 = (int)(base % F), p0 = (int)(base % P);
-    const int lim = (int)((n - base) < BK_EPB ? (n - base) : BK_EPB);
-    int orank[BK_EPT];        // owner << 16 | rank inside the workgroup (rank < 4096); -1: pruned / inactive
+    const int lim = (int)((n - base) < BKC_EPB ? (n - base) : BKC_EPB);
+    int orank[BK_EPT];        // owner << 16 | rank inside the workgroup (rank < 1024); -1: pruned / inactive
     int64_t pv[BK_EPT];
 #pragma unroll
     for (int k = 0; k < BK_EPT; ++k) {
@@ -564,18 +565,28 @@ __global__ __launch_bounds__(256) void bucket_cap_k(const int64_t* __restrict__ 
 }
 
 __global__ void bucket_cap_fin_k(int32_t* __restrict__ gcount, int P, int64_t cap, int64_t* __restrict__ payload,
-                                 int64_t* __restrict__ counts, int32_t* __restrict__ overflow) {
+                                 int64_t* __restrict__ counts, int32_t* __restrict__ overflow, int64_t* __restrict__ stat) {
     const int o = threadIdx.x;
     int over = 0;
+    int c32 = 0;
     if (o < P) {
         const int64_t c = gcount[o];
         counts[o] = c;                                    // the true demand (may exceed cap): the caller sizes the next cap from it
         payload[(int64_t)o * (cap + 1)] = c < cap ? c : cap;
         gcount[o] = 0;
         over = c > cap ? 1 : 0;
+        c32 = (int)c;
     }
     const unsigned long long any = __ballot(over);
-    if (o == 0) overflow[0] = any ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c32 = max(c32, __shfl_xor(c32, d, 64));
+    if (o == 0) {
+        overflow[0] = any ? 1 : 0;
+        if (stat) {          // [overflow, largest per-owner demand]: what the caller reduces over chunks and ranks
+            stat[0] = any ? 1 : 0;
+            stat[1] = c32;
+        }
+    }
 }
 
 // owner side of the fixed-capacity exchange: recv = P slabs [header | cap slots] as received (slab s from rank s);
@@ -797,17 +808,17 @@ extern "C" int64_t dir_shard_bucket_cap_workspace_bytes(int P) { return P > 0 &&
 
 extern "C" int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first,
                                     int F, int P, int64_t cap, int64_t* payload, int64_t* inv, int64_t* counts, int32_t* overflow,
-                                    void* workspace, dir_stream_t stream) {
+                                    int64_t* stat, void* workspace, dir_stream_t stream) {
     DIR_CHECK_ARG(n >= 0 && F > 0 && P > 0 && P <= 64 && cap > 0, "dir_shard_bucket_cap: n=%lld F=%d P=%d cap=%lld (P <= 64)", (long long)n, F, P, (long long)cap);
     DIR_CHECK_ARG(vocab && payload && counts && overflow && workspace && (n == 0 || (ids && inv)), "dir_shard_bucket_cap: null pointer");
     if ((int64_t)P * cap >= (int64_t)1 << 40) return fail(DIR_E_UNSUPPORTED, "dir_shard_bucket_cap: P*cap too large");
     hipStream_t st = as_stream(stream);
     int32_t* gcount = static_cast<int32_t*>(workspace);
     if (n > 0) {
-        const int nwg = (int)((n + BK_EPB - 1) / BK_EPB);
+        const int nwg = (int)((n + BKC_EPB - 1) / BKC_EPB);
         hipLaunchKernelGGL(bucket_cap_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, parts, first, F, P, cap, gcount, payload, inv);
     }
-    hipLaunchKernelGGL(bucket_cap_fin_k, dim3(1), dim3(64), 0, st, gcount, P, cap, payload, counts, overflow);
+    hipLaunchKernelGGL(bucket_cap_fin_k, dim3(1), dim3(64), 0, st, gcount, P, cap, payload, counts, overflow, stat);
     DIR_CHECK_LAUNCH("shard_bucket_cap");
     return DIR_OK;
 }

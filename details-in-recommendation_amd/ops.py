@@ -556,14 +556,14 @@ def shard_bucket(ids, vocab_dev, P, payload=None, inv=None, parts=None, first=No
     return payload, inv, counts, starts
 
 
-def shard_bucket_cap(ids, vocab_dev, P, cap, payload, inv, counts, overflow, workspace, parts=None, first=None):
+def shard_bucket_cap(ids, vocab_dev, P, cap, payload, inv, counts, overflow, workspace, parts=None, first=None, stat=None):
     """Fixed-capacity requester side (include/dir_hip.h: dir_shard_bucket_cap) into caller-owned buffers: payload
     [P*(cap+1)] int64 slabs, inv [n] int64, counts [P] int64, overflow [1] int32, workspace (zeroed once) -- no host read."""
     _dev(ids, torch.int64, "ids")
     if not ids.is_contiguous():
         raise ValueError("shard_bucket_cap: ids must be contiguous")
     _lib.check(_lib.load().dir_shard_bucket_cap(_ptr(ids), ids.numel(), _ptr(vocab_dev), _ptr(parts), _ptr(first), vocab_dev.numel(), P,
-                                                cap, _ptr(payload), _ptr(inv), _ptr(counts), _ptr(overflow), _ptr(workspace), _stream()))
+                                                cap, _ptr(payload), _ptr(inv), _ptr(counts), _ptr(overflow), _ptr(stat), _ptr(workspace), _stream()))
 
 
 SLAB_SANITIZE = 4

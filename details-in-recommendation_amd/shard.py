@@ -120,9 +120,9 @@ class HipBackend:
     def new_workspace(self, device):
         return torch.zeros(64, dtype=torch.int32, device=device)
 
-    def bucket_cap(self, flat_ids, cap, payload, inv, counts, overflow, workspace):
+    def bucket_cap(self, flat_ids, cap, payload, inv, counts, overflow, workspace, stat=None):
         ops.shard_bucket_cap(flat_ids, self.vocab_dev, self.P, cap, payload, inv, counts, overflow, workspace,
-                             parts=self.parts_dev, first=self.first_dev)
+                             parts=self.parts_dev, first=self.first_dev, stat=stat)
 
     def gather_slabs(self, recv, cap, out):
         ops.gather_slabs(self.ts, recv, self.P, cap, out)
@@ -167,7 +167,8 @@ class _Plan:
         self.recv_x = self.send_x if alias else [torch.empty(P * (cap_x + 1), **i64) for _ in range(C)]
         self.rows = [torch.empty((P * cap_x, K), dtype=torch.float32, device=dev) for _ in range(C)]
         self.back = self.rows if alias else [torch.empty((P * cap_x, K), dtype=torch.float32, device=dev) for _ in range(C)]
-        self.stat = torch.zeros(3, **i64)                 # [any overflow, max demand, max distinct demand], MAX over ranks
+        self.cstat = torch.zeros((C, 3), **i64)           # per chunk [overflow, max demand, max distinct demand]
+        self.stat = torch.zeros(3, **i64)                 # ... MAX over chunks and ranks
         self.host = torch.empty(3, dtype=torch.int64, pin_memory=dev.type == "cuda")
 
 
@@ -177,14 +178,15 @@ class ShardedTables:
     partitions: None = every table cut into P slices, slice r on rank r (the north star's row sharding); "reference" = the
       reference partitioner's slice-count rule (partitions_for with max_partitions = P) with the slices dealt round-robin; or an
       explicit list of slice counts.  local_tables[f] holds local_slice(...) rows of table f (possibly zero rows).
-    chunks: micro-batches per lookup (pipelined on two streams);  slack: slab capacity = ceil(slack * n / P) entries per owner
+    chunks: micro-batches per lookup when there is an exchange to hide (pipelined on two streams; every collective costs
+      host time, so 2 by default; without collectives -- one rank -- a lookup is ONE chunk on the caller's stream);  slack: slab capacity = ceil(slack * n / P) entries per owner
       and chunk (None: n / P + 8 sigma of the binomial count + 64: ~3 % padding at 16 384 x 26 ids over 8 ranks);
     mode: "auto" (fixed capacity, exact fallback on overflow; switches to "exact" when the owners' demand is so uneven that
       padding would cost more than the host read), "fixed", "exact";  check: "eager" (read the overflow flag after enqueuing
       the pipeline), "lazy" (read it at the next lookup -- raises), "never" (graph capture; call check_overflow() yourself);
     dedup: send each (slot, row) once per owner and chunk."""
 
-    def __init__(self, local_tables, vocab, group=None, backend=None, force_collective=False, partitions=None, chunks=4,
+    def __init__(self, local_tables, vocab, group=None, backend=None, force_collective=False, partitions=None, chunks=2,
                  slack=None, mode="auto", check="eager", dedup=False):
         self.group = group
         self.force_collective = force_collective  # issue the all_to_all calls even when world_size == 1
@@ -339,7 +341,7 @@ class ShardedTables:
         return min(_round_up(n_chunk * p + 8.0 * math.sqrt(n_chunk * p * (1 - p)) + 64, 16), _round_up(max(n_chunk, 16), 16))
 
     def _plan(self, B):
-        C = max(1, min(self.chunks, B))
+        C = max(1, min(self.chunks, B)) if self._collective() else 1
         n_chunk = -(-B // C) * self.F
         cap, cap_x = self._cap_floor.get(B, (0, 0))
         cap = max(cap, self._default_cap(n_chunk))
@@ -383,7 +385,9 @@ class ShardedTables:
         uidx = torch.cumsum(head, dim=1) - 1                                   # compact index of every sorted position
         ucount = head.sum(dim=1)
         plan.ucounts[c].copy_(ucount)
-        plan.flags[c, 1:2].copy_((ucount > cx).any().to(torch.int32).reshape(1))
+        umax = ucount.max()
+        plan.cstat[c, 2:3].copy_(umax.reshape(1))
+        plan.cstat[c, 0:1].copy_(torch.maximum(plan.cstat[c, 0:1], (umax > cx).to(torch.int64).reshape(1)))
         tgt = torch.where((skeys != big) & (uidx < cx), uidx, torch.full_like(uidx, cx))   # column cx = dump
         comp = torch.empty((P, cx + 1), dtype=torch.int64, device=slots.device)
         comp.scatter_(1, tgt, skeys)                                           # duplicates write the same key: benign
@@ -409,6 +413,16 @@ class ShardedTables:
         plan = self._plan(B)
         C = plan.C
         ids = ids if ids.is_contiguous() else ids.contiguous()
+        if C == 1 and not self._collective():
+            # one rank, no exchange: the three kernels back to back on the caller's stream.  A slab holds the whole chunk
+            # (cap >= n), so nothing can overflow and there is nothing to check.
+            be.bucket_cap(ids.reshape(-1), plan.cap, plan.payload_s[0], plan.inv[0], plan.counts[0], plan.flags[0, 0:1], plan.ws[0],
+                          stat=plan.cstat[0])
+            if self.dedup:
+                self._dedup(plan, 0)
+            be.gather_slabs(plan.recv_x[0], plan.cap_x, plan.rows[0])
+            be.finish_chunk(plan.back[0], plan.inv[0].view(B, F), want_fm, out, fm if want_fm else None)
+            return plan, None
         S = self._ensure_streams()
         cur = torch.cuda.current_stream(self.device) if S else None
         if S:
@@ -420,7 +434,8 @@ class ShardedTables:
 
         def bucket(c):
             s, e = plan.bounds[c]
-            be.bucket_cap(ids[s:e].reshape(-1), plan.cap, plan.payload_s[c], plan.inv[c], plan.counts[c], plan.flags[c, 0:1], plan.ws[c])
+            be.bucket_cap(ids[s:e].reshape(-1), plan.cap, plan.payload_s[c], plan.inv[c], plan.counts[c], plan.flags[c, 0:1], plan.ws[c],
+                          stat=plan.cstat[c])
             if self.dedup:
                 self._dedup(plan, c)
             return self._a2a_equal(plan.recv_x[c], plan.send_x[c])
@@ -437,7 +452,7 @@ class ShardedTables:
                 if S:
                     for e in ev[-2:]:
                         self._chk_stream.wait_event(e)
-                torch.stack([plan.flags.max().to(torch.int64), plan.counts.max(), plan.ucounts.max()], out=plan.stat)
+                torch.amax(plan.cstat, dim=0, out=plan.stat)          # one small kernel: the fin kernels left [overflow, demand] per chunk
                 if self._collective():
                     if _HOST_STAGED or (plan.stat.is_cuda and dist.get_backend(self.group) == "gloo"):
                         h = plan.stat.cpu()
@@ -494,7 +509,9 @@ class ShardedTables:
             done.synchronize()
             host = plan.host
         else:
-            host = plan.stat
+            if not self._collective():                    # single-chunk path: the per-chunk record is the statistic
+                torch.amax(plan.cstat, dim=0, out=plan.stat)
+            host = plan.stat.cpu()
         return bool(host[0]), int(host[1]), int(host[2])
 
     def _learn(self, plan, over, cmax, umax):
@@ -546,6 +563,8 @@ class ShardedTables:
         if want_fm and fm is None:
             fm = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
         plan, ev = self._lookup_fixed(ids, want_fm, out, fm)
+        if ev is None and not self._collective() and not (self.dedup and plan.cap_x < plan.cap):
+            return (out, fm) if want_fm else out          # one rank, slabs as large as the chunk: cannot overflow
         if self.check == "eager":
             over, cmax, umax = self._read_flags(plan, ev)
             self._learn(plan, over, cmax, umax)

@@ -255,7 +255,8 @@ int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, const 
  *   inv      [n]: row of entry i in the [P*cap, K] buffer the row exchange returns (o*cap + position), -1 for a pruned id or
  *            an entry that did not fit its slab
  *   counts   [P] int64: the true per-owner demand (can exceed cap);  overflow [1] int32: 1 iff some count > cap -- the caller
- *            then repeats the lookup on the variable-size path (dir_shard_bucket)
+ *            then repeats the lookup on the variable-size path (dir_shard_bucket);  stat (optional, may be NULL): int64 [2] =
+ *            {overflow, max_o counts[o]} -- the two numbers a caller MAX-reduces over micro-batches and ranks
  *   workspace: dir_shard_bucket_cap_workspace_bytes(P) bytes, ZERO before the first call (left zero on return).
  * Both exchanges are all-to-alls with EQUAL splits (cap + 1 words / cap rows per peer).
  * dir_gather_slabs_f32 is the owner side: recv = the P slabs as received; out[(s*cap + j), :] = the row of slot j of slab s for
@@ -265,8 +266,8 @@ int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, const 
 enum { DIR_SLAB_SANITIZE = 4 };
 int64_t dir_shard_bucket_cap_workspace_bytes(int P);
 int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first, int F, int P,
-                         int64_t cap, int64_t* payload, int64_t* inv, int64_t* counts, int32_t* overflow, void* workspace,
-                         dir_stream_t stream);
+                         int64_t cap, int64_t* payload, int64_t* inv, int64_t* counts, int32_t* overflow, int64_t* stat,
+                         void* workspace, dir_stream_t stream);
 int dir_gather_slabs_f32(const float* const* tables, int F, int K, int64_t* recv, int P, int64_t cap, int flags, float* out,
                          dir_stream_t stream);
 int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_t* payload, int64_t n,

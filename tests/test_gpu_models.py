@@ -643,7 +643,9 @@ def test_fixed_capacity_bucket_and_slab_gather(built_lib, P, parts):
         inv = torch.empty(n, dtype=torch.int64, device="cuda")
         counts = torch.empty(P, dtype=torch.int64, device="cuda")
         over = torch.full((1,), 9, dtype=torch.int32, device="cuda")
-        ops.shard_bucket_cap(flat, vdev, P, cap, payload, inv, counts, over, ws, parts=pdev, first=fdev)
+        stat = torch.full((3,), -1, dtype=torch.int64, device="cuda")
+        ops.shard_bucket_cap(flat, vdev, P, cap, payload, inv, counts, over, ws, parts=pdev, first=fdev, stat=stat)
+        assert stat.tolist()[:2] == [int((true_counts > cap).any()), int(true_counts.max())]
         pay = payload.cpu().numpy().reshape(P, cap + 1)
         iv = inv.cpu().numpy()
         np.testing.assert_array_equal(counts.cpu().numpy(), true_counts)

@@ -118,7 +118,7 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
             def new_workspace(self, device):
                 return torch.zeros(64, dtype=torch.int32)
 
-            def bucket_cap(self, flat, cap, payload, inv, counts, overflow, workspace):
+            def bucket_cap(self, flat, cap, payload, inv, counts, overflow, workspace, stat=None):
                 a = flat.numpy()
                 own, loc = route(a)
                 pay = payload.numpy().reshape(world, cap + 1)
@@ -136,6 +136,9 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
                 pay[:, 0] = np.minimum(fill, cap)
                 counts.copy_(torch.from_numpy(fill))
                 overflow.fill_(int((fill > cap).any()))
+                if stat is not None:
+                    stat[0] = int((fill > cap).any())
+                    stat[1] = int(fill.max())
 
             def gather_slabs(self, recv, cap, out):
                 r = recv.numpy().reshape(world, cap + 1)
