@@ -63,6 +63,12 @@ inline int grid_resident(int64_t work_blocks, int resident) {
     return g < 1 ? 1 : (int)g;
 }
 
+// csrc/din_wave.hip: the wave-per-sample DIN forward for the (K = 64, H1 <= 80, H2 <= 48, T <= 64) shape class
+bool din_wave_covers(int K, int T, int H1, int H2);
+int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                    const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                    const float* b3, int normalize, int64_t B, float* out, float* scores);
+
 }  // namespace dir
 
 // ---- device helpers ------------------------------------------------------------------------

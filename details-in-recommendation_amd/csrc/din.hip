@@ -1108,6 +1108,13 @@ extern "C" int dir_din_attention_pool_f32(const float* table, int K, const int64
     if (!aligned16(table) || !aligned16(W1) || !aligned16(W2) || !aligned16(b1) || !aligned16(b2))
         return fail(DIR_E_BADARG, "dir_din_attention_pool_f32: table / W1 / W2 / b1 / b2 must be 16-byte aligned");
     static const int mfma_env = getenv("DIR_DIN_MFMA") ? atoi(getenv("DIR_DIN_MFMA")) : 1;
+    static const int wave_env = getenv("DIR_DIN_WAVE") ? atoi(getenv("DIR_DIN_WAVE")) : 1;     // 0: the round-1 workgroup-per-sample kernel (A/B)
+    if (mfma_env && wave_env && din_wave_covers(K, T, H1, H2)) {
+        const int rc = launch_din_wave(as_stream(stream), table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores);
+        if (rc != DIR_OK) return rc;
+        DIR_CHECK_LAUNCH("din_attention_pool(wave)");
+        return DIR_OK;
+    }
     if (mfma_env && T <= 64) {
         const int nc1 = (H1 + 15) / 16, nc2 = (H2 + 15) / 16;
         hipStream_t st = as_stream(stream);

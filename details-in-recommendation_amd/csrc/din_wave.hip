@@ -1,0 +1,380 @@
+// din_wave.hip -- DIN local activation unit + pooling, forward, for the (K = 64, H1 <= 80, H2 <= 48, T <= 64) shape class
+// (BASELINE.json configs[3]).  NO REFERENCE CODE (README.md:27 links arXiv:1706.06978); the definition is the one in
+// include/dir_hip.h (A13) and oracle/dir_oracle.c.
+//
+// ONE WAVE OWNS ONE SAMPLE -- no workgroup barrier anywhere in the sample loop (the round-1 kernel spent 60 % of a sample's
+// time outside MFMA issue: seven barriers per sample, single-wave softmax / pooling phases, LDS round trips between layers).
+//
+// Everything is computed TRANSPOSED so that one layer's MFMA result is directly the next layer's MFMA operand:
+//   pre1^T [H1 x rows] = (Wh+Wd)^T [H1 x K] . h^T [K x rows] + Wp^T . (h*a)^T + c 1^T,     c = (Wa-Wd)^T a + b1   (per sample)
+//   pre2^T [H2 x rows] = W2^T [H2 x H1] . sigmoid(pre1^T)                                  + b2 1^T
+// v_mfma_f32_16x16x4_f32: lane (kk = l >> 4, r = l & 15) supplies A[m = r][k = kk] and B[k = kk][n = r] and holds
+// D[m = 4 kk + g][n = r].  With N = history rows a lane's B operand is ITS OWN row r: the 16 features {16 i + 4 kk + e} of
+// row (16 t + r) sit in 16 registers straight from HBM (four 16-byte loads; a row's four lane groups read one contiguous 64-byte
+// segment per load) -- the history never goes through LDS.  The result D holds hidden units {16 mt + 4 kk + g} of row r, which is
+// exactly a B operand of layer 2 if layer 2's reduction index is enumerated as (mt, g) <-> hidden 16 mt + 4 kk + g: the weights
+// (A operands, from LDS) are laid out to match.  So layers chain in registers; the LDS only holds weights (85 KB, filled once
+// per workgroup) and is read with one ds_read_b128 per four MFMA steps, shared by the row tiles of a pass.
+// A sample is processed in passes of <= 2 row tiles (<= 256 VGPRs: two waves per SIMD hide each other's load latencies);
+// the masked softmax runs ONLINE over the passes (running max / sum, rescaled pooled accumulator), so a pass's rows are
+// pooled while they are still in registers.
+// Samples are handed out by a device-side queue (one atomic per sample, issued a whole sample ahead): history lengths vary
+// 1..50, and a static split of 32 samples per wave would leave the slowest wave ~25 % behind the mean.  The forward has no
+// cross-sample reduction, so the result does not depend on the order.
+#include <atomic>
+
+#include "common.hpp"
+
+namespace dir {
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+constexpr int DW_K = 64, DW_H1P = 80, DW_H2P = 48;
+constexpr int DW_WS = DW_K + 4;        // row stride of the [hidden][feature] weight images
+constexpr int DW_W2S = DW_H1P + 4;     // row stride of the [h2][hidden] image
+constexpr int DW_WAVES = 8;            // waves per workgroup (two per SIMD), one workgroup per CU
+constexpr int DW_GROUPS = 8;           // queue shards (sample ranges)
+constexpr int DW_SLOTS = 64;           // queue records for launches in flight
+
+struct DinWaveSh {
+    float whd[DW_H1P * DW_WS];         // (Wh + Wd)^T
+    float wp[DW_H1P * DW_WS];          // Wp^T
+    float wc[DW_H1P * DW_WS];          // (Wa - Wd)^T
+    float w2[DW_H2P * DW_W2S];         // W2^T
+    float b1[DW_H1P], b2[DW_H2P], w3[DW_H2P];
+    float cvec[DW_WAVES][DW_H1P];      // per wave: the per-sample term c (+ b1)
+};
+
+// [slot][0..7] next sample of each range, [slot][8] waves finished.  All zero between launches (the last wave of a launch
+// clears its record).
+__device__ unsigned int dw_queue[DW_SLOTS][16];
+
+__device__ __forceinline__ float dw_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float4 dw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dw_dot4(float4 a, float4 b, float acc) {
+    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+#define DW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// next sample of this wave (lane 0's value is the answer; -1: all ranges exhausted).  g walks the ranges.
+__device__ __forceinline__ long long dw_take(unsigned int* q, int& g, int& tried, long long B) {
+    long long res = -1;
+    while (tried < DW_GROUPS) {
+        const long long lo = (long long)g * B / DW_GROUPS, hi = (long long)(g + 1) * B / DW_GROUPS;
+        unsigned int idx = 0;
+        if ((threadIdx.x & 63) == 0) idx = atomicAdd(&q[g], 1u);
+        idx = (unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
+        if (lo + (long long)idx < hi) {
+            res = lo + (long long)idx;
+            break;
+        }
+        g = (g + 1) & (DW_GROUPS - 1);
+        ++tried;
+    }
+    return res;
+}
+
+// One pass: NT row tiles whose history ids are id[rt] (-1: masked row).  Updates the online-softmax state.
+template <int NT>
+__device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const float* __restrict__ table, const int w, const int r16, const int kk,
+                                        const long long (&id)[NT], const float4 (&a4)[4], const float b3, const bool normalize,
+                                        const float inv_sqrt_k, float& m_run, float& l_run, float4 (&o)[4], float (&xs)[NT]) {
+    constexpr int NA = NT == 1 ? 2 : 1;      // a single row tile alternates two accumulators (dependent MFMAs need 40 cycles)
+    // ---- rows: this lane's 16 features of its own row, straight from HBM ---------------------------------------------------
+    float4 hv[NT][4], hp[NT][4];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hv[rt][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id[rt] >= 0) hv[rt][i] = dw_ld4(table + id[rt] * DW_K + 16 * i + 4 * kk);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            hp[rt][i] = make_float4(hv[rt][i].x * a4[i].x, hv[rt][i].y * a4[i].y, hv[rt][i].z * a4[i].z, hv[rt][i].w * a4[i].w);
+    // ---- layer 1: pre1^T, accumulators start at the per-sample term -------------------------------------------------------------
+    f32x4w acc1[5][NT][NA];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+        const float4 c4 = dw_ld4(&sh.cvec[w][16 * mt + 4 * kk]);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            acc1[mt][rt][0] = (f32x4w){c4.x, c4.y, c4.z, c4.w};
+            if (NA == 2) acc1[mt][rt][NA - 1] = (f32x4w){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 ah = dw_ld4(&sh.whd[(16 * mt + r16) * DW_WS + 16 * i + 4 * kk]);
+            const float4 ap = dw_ld4(&sh.wp[(16 * mt + r16) * DW_WS + 16 * i + 4 * kk]);
+            const float ahv[4] = {ah.x, ah.y, ah.z, ah.w}, apv[4] = {ap.x, ap.y, ap.z, ap.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) {
+                    const float hve = e == 0 ? hv[rt][i].x : e == 1 ? hv[rt][i].y : e == 2 ? hv[rt][i].z : hv[rt][i].w;
+                    acc1[mt][rt][0] = DW_MFMA(ahv[e], hve, acc1[mt][rt][0]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) {
+                    const float hpe = e == 0 ? hp[rt][i].x : e == 1 ? hp[rt][i].y : e == 2 ? hp[rt][i].z : hp[rt][i].w;
+                    acc1[mt][rt][NA - 1] = DW_MFMA(apv[e], hpe, acc1[mt][rt][NA - 1]);
+                }
+            }
+        }
+    }
+    // z1 = sigmoid(pre1), in place: lane (kk, r) holds hidden 16 mt + 4 kk + g of row r -- a B operand of layer 2
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float pre = NA == 2 ? acc1[mt][rt][0][g] + acc1[mt][rt][NA - 1][g] : acc1[mt][rt][0][g];
+                acc1[mt][rt][0][g] = dw_sigmoid(pre);
+            }
+    // ---- layer 2: pre2^T; the reduction walks (mt, g) <-> hidden 16 mt + 4 kk + g --------------------------------------------------
+    f32x4w acc2[3][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 3; ++m2) {
+        const float4 c4 = dw_ld4(&sh.b2[16 * m2 + 4 * kk]);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = (f32x4w){c4.x, c4.y, c4.z, c4.w};
+    }
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+        float aw[3][4];
+#pragma unroll
+        for (int m2 = 0; m2 < 3; ++m2) {
+            const float4 t4 = dw_ld4(&sh.w2[(16 * m2 + r16) * DW_W2S + 16 * mt + 4 * kk]);
+            aw[m2][0] = t4.x; aw[m2][1] = t4.y; aw[m2][2] = t4.z; aw[m2][3] = t4.w;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int m2 = 0; m2 < 3; ++m2)
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = DW_MFMA(aw[m2][g], acc1[mt][rt][0][g], acc2[m2][rt]);
+    }
+    // ---- layer 3 + mask + online softmax + pooling of this pass's rows -----------------------------------------------------------------
+    float wv[3][4];
+#pragma unroll
+    for (int m2 = 0; m2 < 3; ++m2) {
+        const float4 t4 = dw_ld4(&sh.w3[16 * m2 + 4 * kk]);
+        wv[m2][0] = t4.x; wv[m2][1] = t4.y; wv[m2][2] = t4.z; wv[m2][3] = t4.w;
+    }
+    float sc[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        float sp = 0.f;
+#pragma unroll
+        for (int m2 = 0; m2 < 3; ++m2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sp = fmaf(dw_sigmoid(acc2[m2][rt][g]), wv[m2][g], sp);
+        sp += __shfl_xor(sp, 16, 64);        // the four lane groups hold the four quarters of the H2 sum of row r
+        sp += __shfl_xor(sp, 32, 64);
+        sc[rt] = sp + b3;
+    }
+    if (normalize) {
+        float mx = m_run;
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            xs[rt] = id[rt] >= 0 ? sc[rt] * inv_sqrt_k : -INFINITY;
+            mx = fmaxf(mx, row16_max(xs[rt]));
+        }
+        if (mx > -INFINITY) {                // wave-uniform (row maxima are identical in the four lane groups)
+            const float rescale = __expf(m_run - mx);      // m_run = -inf: 0
+            float psum = 0.f;
+            float p[NT];
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) {
+                p[rt] = id[rt] >= 0 ? __expf(xs[rt] - mx) : 0.f;
+                psum += row16_sum(p[rt]);
+            }
+            l_run = l_run * rescale + psum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 acc = make_float4(o[i].x * rescale, o[i].y * rescale, o[i].z * rescale, o[i].w * rescale);
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) {
+                    acc.x = fmaf(p[rt], hv[rt][i].x, acc.x); acc.y = fmaf(p[rt], hv[rt][i].y, acc.y);
+                    acc.z = fmaf(p[rt], hv[rt][i].z, acc.z); acc.w = fmaf(p[rt], hv[rt][i].w, acc.w);
+                }
+                o[i] = acc;
+            }
+            m_run = mx;
+        }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            xs[rt] = id[rt] >= 0 ? sc[rt] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i].x = fmaf(xs[rt], hv[rt][i].x, o[i].x); o[i].y = fmaf(xs[rt], hv[rt][i].y, o[i].y);
+                o[i].z = fmaf(xs[rt], hv[rt][i].z, o[i].z); o[i].w = fmaf(xs[rt], hv[rt][i].w, o[i].w);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
+                                                               const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand,
+                                                               int T, const float* __restrict__ W1, const float* __restrict__ b1, int H1,
+                                                               const float* __restrict__ W2, const float* __restrict__ b2, int H2,
+                                                               const float* __restrict__ W3, const float* __restrict__ b3, int normalize,
+                                                               long long B, float* __restrict__ out, float* __restrict__ scores, int slot) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    DinWaveSh& sh = *reinterpret_cast<DinWaveSh*>(dw_smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
+    // ---- weight images, once per workgroup ---------------------------------------------------------------------------------------------------
+    for (int idx = tid; idx < DW_H1P * DW_K; idx += 64 * DW_WAVES) {
+        const int f = idx / DW_H1P, m = idx - f * DW_H1P;           // m fastest: coalesced reads of W1 rows
+        float vh = 0.f, va = 0.f, vd = 0.f, vp = 0.f;
+        if (m < H1) {
+            vh = W1[(size_t)f * H1 + m];
+            va = W1[(size_t)(DW_K + f) * H1 + m];
+            vd = W1[(size_t)(2 * DW_K + f) * H1 + m];
+            vp = W1[(size_t)(3 * DW_K + f) * H1 + m];
+        }
+        sh.whd[m * DW_WS + f] = vh + vd;
+        sh.wp[m * DW_WS + f] = vp;
+        sh.wc[m * DW_WS + f] = va - vd;
+    }
+    for (int idx = tid; idx < DW_H2P * DW_H1P; idx += 64 * DW_WAVES) {
+        const int hid = idx / DW_H2P, h2 = idx - hid * DW_H2P;
+        sh.w2[h2 * DW_W2S + hid] = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] : 0.f;     // a padded hidden unit is sigmoid(0) = 0.5:
+    }                                                                                           // its weights are zero
+    for (int idx = tid; idx < DW_H1P; idx += 64 * DW_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] : 0.f;
+    for (int idx = tid; idx < DW_H2P; idx += 64 * DW_WAVES) {
+        sh.b2[idx] = idx < H2 ? b2[idx] : 0.f;
+        sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
+    }
+    __syncthreads();
+    const float bias3 = b3[0];
+    const float inv_sqrt_k = 1.0f / sqrtf((float)DW_K);
+    const int ntile_t = (T + 15) >> 4;
+    unsigned int* q = dw_queue[slot];
+    int g = blockIdx.x & (DW_GROUPS - 1), tried = 0;
+    long long b = dw_take(q, g, tried, B);
+    while (b >= 0) {
+        const long long bn = dw_take(q, g, tried, B);           // the next sample's ticket is in flight during this one
+        const int len = hist_len ? min((int)hist_len[b], T) : T;
+        const long long cid = cand[b];
+        const int RT = (len + 15) >> 4;
+        long long id[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = 16 * t + r16;
+            id[t] = j < len ? hist[b * T + j] : -1;
+        }
+        float4 a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cid >= 0) a4[i] = dw_ld4(table + cid * DW_K + 16 * i + 4 * kk);
+        }
+        // per-sample term c[m] = sum_f a[f] (Wa - Wd)[f][m] + b1[m]: lane (kk, r) sums its 16 features for m = 16 mt + r
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part = dw_dot4(a4[i], dw_ld4(&sh.wc[(16 * mt + r16) * DW_WS + 16 * i + 4 * kk]), part);
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (kk == 0) sh.cvec[w][16 * mt + r16] = part + sh.b1[16 * mt + r16];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same-wave LDS hand-off: the DS queue is in order, the fence
+        __builtin_amdgcn_wave_barrier();                         // only keeps the compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float m_run = -INFINITY, l_run = 0.f;
+        float4 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float xs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (normalize) xs[0] = xs[1] = xs[2] = xs[3] = -INFINITY;
+        if (RT >= 2) {
+            const long long idp[2] = {id[0], id[1]};
+            float xp[2];
+            dw_pass<2>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            xs[0] = xp[0]; xs[1] = xp[1];
+        } else if (RT == 1) {
+            const long long idp[1] = {id[0]};
+            float xp[1];
+            dw_pass<1>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            xs[0] = xp[0];
+        }
+        if (RT >= 4) {
+            const long long idp[2] = {id[2], id[3]};
+            float xp[2];
+            dw_pass<2>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            xs[2] = xp[0]; xs[3] = xp[1];
+        } else if (RT == 3) {
+            const long long idp[1] = {id[2]};
+            float xp[1];
+            dw_pass<1>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            xs[2] = xp[0];
+        }
+        // ---- pooled output: sum the 16 rows of the lane group, lane r = 0 stores the group's 16 features --------------------------------------
+        const float inv_l = (normalize && l_run > 0.f) ? 1.0f / l_run : (normalize ? 0.f : 1.0f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 t4;
+            t4.x = row16_sum(o[i].x) * inv_l; t4.y = row16_sum(o[i].y) * inv_l;
+            t4.z = row16_sum(o[i].z) * inv_l; t4.w = row16_sum(o[i].w) * inv_l;
+            if (r16 == 0) *reinterpret_cast<float4*>(out + b * DW_K + 16 * i + 4 * kk) = t4;
+        }
+        if (scores && kk == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = 16 * t + r16;
+                if (t < ntile_t && j < T) {
+                    float v = 0.f;
+                    if (t < RT) v = normalize ? (xs[t] > -INFINITY ? __expf(xs[t] - m_run) * inv_l : 0.f) : xs[t];
+                    scores[b * T + j] = v;
+                }
+            }
+        }
+        b = bn;
+    }
+    // ---- leave the queue record clean for the next launch that draws this slot -------------------------------------------------------------------
+    if (lane == 0) {
+        const unsigned int done = atomicAdd(&q[DW_GROUPS], 1u);
+        if (done == gridDim.x * DW_WAVES - 1) {
+#pragma unroll
+            for (int i = 0; i <= DW_GROUPS; ++i) atomicExch(&q[i], 0u);
+        }
+    }
+}
+
+static std::atomic<unsigned int> dw_next_slot{0};
+
+bool din_wave_covers(int K, int T, int H1, int H2) { return K == DW_K && T <= 64 && H1 <= DW_H1P && H2 <= DW_H2P; }
+
+int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                    const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                    const float* b3, int normalize, int64_t B, float* out, float* scores) {
+    static bool attr_set = false;
+    const size_t shmem = sizeof(DinWaveSh);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&din_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+            return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
+        attr_set = true;
+    }
+    // Up to DW_SLOTS launches may be in flight at once (distinct streams); a record is reused only after DW_SLOTS further launches.
+    const int slot = (int)(dw_next_slot.fetch_add(1) % DW_SLOTS);
+    const int64_t waves_wanted = (B + 1) / 2;            // a wave should see at least a couple of samples
+    int64_t nwg = (waves_wanted + DW_WAVES - 1) / DW_WAVES;
+    if (nwg > kCUs) nwg = kCUs;
+    if (nwg < 1) nwg = 1;
+    hipLaunchKernelGGL(din_wave_k, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2,
+                       H2, W3, b3, normalize, (long long)B, out, scores, slot);
+    return DIR_OK;
+}
+
+}  // namespace dir

@@ -507,10 +507,12 @@ __global__ __launch_bounds__(256) void bucket_scatter_k(const int64_t* __restric
 // repeats the lookup on the exact variable-size path).  The order inside a slab is arbitrary (atomics); inv is its exact
 // inverse, so the looked-up values do not depend on it.  gcount: P int32 counters, zero on entry, zeroed again by fin.
 // ------------------------------------------------------------------------------------------------
-constexpr int BKC_EPB = 1024;          // elements per workgroup of the one-pass kernel: a micro-batch of 16 384 x 26 ids still
-constexpr int BK_EPT = BKC_EPB / 256;  // makes 416 workgroups (4096 per workgroup left 60 % of the CUs idle: 24 us per chunk)
+// Elements per workgroup of the one-pass kernel = 256 * EPT.  Two opposing costs: few workgroups leave CUs idle (4096 elements
+// per workgroup on a 16 384 x 26 micro-batch: 104 workgroups, 24 us), many workgroups queue up on the P slab counters (same-address
+// atomics retire at ~90 per us: 1 664 workgroups on the whole 65 536 x 26 batch: 28 us).  The host picks EPT for ~400-800 workgroups.
 typedef float f32x4_ids __attribute__((ext_vector_type(4)));
 
+template <int BK_EPT>
 __global__ __launch_bounds__(256) void bucket_cap_k(const int64_t* __restrict__ ids, int64_t n,
                                                     const int64_t* __restrict__ vocab, const int32_t* __restrict__ parts,
                                                     const int32_t* __restrict__ first, int F, int P, int64_t cap,
@@ -522,10 +524,11 @@ __global__ __launch_bounds__(256) void bucket_cap_k(const int64_t* __restrict__ 
     if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
     for (int f = threadIdx.x; f < F && f < BK_MAXF; f += 256) fd[f] = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0);
     __syncthreads();
+    constexpr int BKC_EPB = 256 * BK_EPT;
     const int64_t base = (int64_t)blockIdx.x * BKC_EPB;
     const int f0 = (int)(base % F), p0 = (int)(base % P);
     const int lim = (int)((n - base) < BKC_EPB ? (n - base) : BKC_EPB);
-    int orank[BK_EPT];        // owner << 16 | rank inside the workgroup (rank < 1024); -1: pruned / inactive
+    int orank[BK_EPT];        // owner << 16 | rank inside the workgroup (rank < 4096); -1: pruned / inactive
     int64_t pv[BK_EPT];
 #pragma unroll
     for (int k = 0; k < BK_EPT; ++k) {
@@ -815,8 +818,13 @@ extern "C" int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t
     hipStream_t st = as_stream(stream);
     int32_t* gcount = static_cast<int32_t*>(workspace);
     if (n > 0) {
-        const int nwg = (int)((n + BKC_EPB - 1) / BKC_EPB);
-        hipLaunchKernelGGL(bucket_cap_k, dim3(nwg), dim3(256), 0, st, ids, n, vocab, parts, first, F, P, cap, gcount, payload, inv);
+#define DIR_BK(EPT)                                                                                                            \
+    hipLaunchKernelGGL((bucket_cap_k<EPT>), dim3((unsigned)((n + 256 * EPT - 1) / (256 * EPT))), dim3(256), 0, st, ids, n, vocab, \
+                       parts, first, F, P, cap, gcount, payload, inv)
+        if (n <= 768 * 1024) DIR_BK(4);
+        else if (n <= 2560 * 1024) DIR_BK(8);
+        else DIR_BK(16);
+#undef DIR_BK
     }
     hipLaunchKernelGGL(bucket_cap_fin_k, dim3(1), dim3(64), 0, st, gcount, P, cap, payload, counts, overflow, stat);
     DIR_CHECK_LAUNCH("shard_bucket_cap");
