@@ -18,6 +18,9 @@
 // A sample is processed in passes of <= 2 row tiles (<= 256 VGPRs: two waves per SIMD hide each other's load latencies);
 // the masked softmax runs ONLINE over the passes (running max / sum, rescaled pooled accumulator), so a pass's rows are
 // pooled while they are still in registers.
+// Loads are software-pipelined across passes and samples: the rows (and candidate row) of the NEXT pass are issued before the
+// current pass's MFMAs, the NEXT sample's scalars and history ids one sample ahead, its queue ticket two ahead -- a wave never
+// waits for HBM inside a sample.  The current candidate row lives in a per-wave LDS slot (its registers hold the prefetch).
 // Samples are handed out by a device-side queue (one atomic per sample, issued a whole sample ahead): history lengths vary
 // 1..50, and a static split of 32 samples per wave would leave the slowest wave ~25 % behind the mean.  The forward has no
 // cross-sample reduction, so the result does not depend on the order.
@@ -43,6 +46,7 @@ struct DinWaveSh {
     float w2[DW_H2P * DW_W2S];         // W2^T
     float b1[DW_H1P], b2[DW_H2P], w3[DW_H2P];
     float cvec[DW_WAVES][DW_H1P];      // per wave: the per-sample term c (+ b1)
+    float av[DW_WAVES][DW_K];          // per wave: the candidate row of the sample being computed
 };
 
 // [slot][0..7] next sample of each range, [slot][8] waves finished.  All zero between launches (the last wave of a launch
@@ -57,45 +61,90 @@ __device__ __forceinline__ float dw_dot4(float4 a, float4 b, float acc) {
 }
 #define DW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// next sample of this wave (lane 0's value is the answer; -1: all ranges exhausted).  g walks the ranges.
-__device__ __forceinline__ long long dw_take(unsigned int* q, int& g, int& tried, long long B) {
-    long long res = -1;
-    while (tried < DW_GROUPS) {
-        const long long lo = (long long)g * B / DW_GROUPS, hi = (long long)(g + 1) * B / DW_GROUPS;
-        unsigned int idx = 0;
-        if ((threadIdx.x & 63) == 0) idx = atomicAdd(&q[g], 1u);
-        idx = (unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
-        if (lo + (long long)idx < hi) {
-            res = lo + (long long)idx;
-            break;
-        }
-        g = (g + 1) & (DW_GROUPS - 1);
-        ++tried;
+// The sample queue.  A wave belongs to one of DW_GROUPS sample ranges (blockIdx & 7) and draws tickets of DW_CH consecutive samples
+// from that range's counter.  The atomic of the NEXT ticket is issued when the current one is opened and is only waited for when
+// its samples are needed, DW_CH samples (> 10 us) later: the ticket round trip (1-3 us under load; it cost 0.1-0.16 ms of a 0.7 ms
+// launch when every sample waited for its own ticket) is off the critical path.  q == nullptr (DIR_DIN_STATIC=1, an A/B switch):
+// a static stride over the samples instead.
+constexpr int DW_CH = 2;
+struct DwQueue {
+    unsigned int* q;
+    long long lo, hi, next;
+    int left;
+    bool dead;
+    unsigned int ticket;       // lane 0: the in-flight atomic's result
+    long long stride_next, stride;   // static mode
+
+    __device__ __forceinline__ void issue() {
+        ticket = 0;
+        if ((threadIdx.x & 63) == 0) ticket = atomicAdd(q, (unsigned int)DW_CH);
     }
-    return res;
+    __device__ __forceinline__ void init(unsigned int* qrec, long long B) {
+        const int G = (int)gridDim.x < DW_GROUPS ? (int)gridDim.x : DW_GROUPS;   // every range needs at least one workgroup
+        const int g = (int)(blockIdx.x % (unsigned)G);
+        q = qrec ? qrec + g : nullptr;
+        lo = (long long)g * B / G;
+        hi = (long long)(g + 1) * B / G;
+        left = 0;
+        dead = false;
+        next = 0;
+        stride = (long long)gridDim.x * DW_WAVES;
+        stride_next = (long long)blockIdx.x * DW_WAVES + (threadIdx.x >> 6);
+        hi = q ? hi : B;
+        if (q) issue();
+    }
+    __device__ __forceinline__ long long take() {
+        if (!q) {
+            const long long bb = stride_next;
+            stride_next += stride;
+            return bb < hi ? bb : -1;
+        }
+        if (left == 0) {
+            if (dead) return -1;
+            const long long base = lo + (long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+            if (base >= hi) {
+                dead = true;
+                return -1;
+            }
+            next = base;
+            left = (int)((hi - base) < DW_CH ? (hi - base) : DW_CH);
+            issue();
+        }
+        --left;
+        return next++;
+    }
+    __device__ __forceinline__ void drain() {            // the outstanding ticket must have landed before the record is cleared
+        if (q && !dead) (void)__builtin_amdgcn_readfirstlane((int)ticket);
+    }
+};
+
+// rows of up to two tiles: this lane's 16 features {16 i + 4 kk + e} of its own row (16 t + r), straight from HBM; a masked
+// row (id < 0) is zeros
+__device__ __forceinline__ void dw_load_rows(const float* __restrict__ table, const int kk, const long long id0, const long long id1,
+                                             float4 (&hv)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hv[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hv[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id0 >= 0) hv[0][i] = dw_ld4(table + id0 * DW_K + 16 * i + 4 * kk);
+        if (id1 >= 0) hv[1][i] = dw_ld4(table + id1 * DW_K + 16 * i + 4 * kk);
+    }
 }
 
-// One pass: NT row tiles whose history ids are id[rt] (-1: masked row).  Updates the online-softmax state.
+// One pass: NT row tiles whose rows are hv[rt] and whose history ids are id[rt] (-1: masked row).  Updates the online-softmax state.
 template <int NT>
-__device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const float* __restrict__ table, const int w, const int r16, const int kk,
-                                        const long long (&id)[NT], const float4 (&a4)[4], const float b3, const bool normalize,
+__device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const int r16, const int kk,
+                                        const long long (&id)[NT], const float4 (&hv)[2][4], const float b3, const bool normalize,
                                         const float inv_sqrt_k, float& m_run, float& l_run, float4 (&o)[4], float (&xs)[NT]) {
     constexpr int NA = NT == 1 ? 2 : 1;      // a single row tile alternates two accumulators (dependent MFMAs need 40 cycles)
-    // ---- rows: this lane's 16 features of its own row, straight from HBM ---------------------------------------------------
-    float4 hv[NT][4], hp[NT][4];
+    float4 hp[NT][4];
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt) {
+    for (int i = 0; i < 4; ++i) {
+        const float4 a4 = dw_ld4(&sh.av[w][16 * i + 4 * kk]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            hv[rt][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (id[rt] >= 0) hv[rt][i] = dw_ld4(table + id[rt] * DW_K + 16 * i + 4 * kk);
-        }
+        for (int rt = 0; rt < NT; ++rt)
+            hp[rt][i] = make_float4(hv[rt][i].x * a4.x, hv[rt][i].y * a4.y, hv[rt][i].z * a4.z, hv[rt][i].w * a4.w);
     }
-#pragma unroll
-    for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            hp[rt][i] = make_float4(hv[rt][i].x * a4[i].x, hv[rt][i].y * a4[i].y, hv[rt][i].z * a4[i].z, hv[rt][i].w * a4[i].w);
     // ---- layer 1: pre1^T, accumulators start at the per-sample term -------------------------------------------------------------
     f32x4w acc1[5][NT][NA];
 #pragma unroll
@@ -233,18 +282,25 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
     DinWaveSh& sh = *reinterpret_cast<DinWaveSh*>(dw_smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
     // ---- weight images, once per workgroup ---------------------------------------------------------------------------------------------------
-    for (int idx = tid; idx < DW_H1P * DW_K; idx += 64 * DW_WAVES) {
-        const int f = idx / DW_H1P, m = idx - f * DW_H1P;           // m fastest: coalesced reads of W1 rows
-        float vh = 0.f, va = 0.f, vd = 0.f, vp = 0.f;
+#pragma unroll 3
+    for (int idx = tid; idx < (DW_H1P / 4) * DW_K; idx += 64 * DW_WAVES) {      // 16-byte loads along m (H1 % 4 == 0, W1 16-byte aligned)
+        const int f = idx / (DW_H1P / 4), m = 4 * (idx - f * (DW_H1P / 4));
+        float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), va = vh, vd = vh, vp = vh;
         if (m < H1) {
-            vh = W1[(size_t)f * H1 + m];
-            va = W1[(size_t)(DW_K + f) * H1 + m];
-            vd = W1[(size_t)(2 * DW_K + f) * H1 + m];
-            vp = W1[(size_t)(3 * DW_K + f) * H1 + m];
+            vh = dw_ld4(W1 + (size_t)f * H1 + m);
+            va = dw_ld4(W1 + (size_t)(DW_K + f) * H1 + m);
+            vd = dw_ld4(W1 + (size_t)(2 * DW_K + f) * H1 + m);
+            vp = dw_ld4(W1 + (size_t)(3 * DW_K + f) * H1 + m);
         }
-        sh.whd[m * DW_WS + f] = vh + vd;
-        sh.wp[m * DW_WS + f] = vp;
-        sh.wc[m * DW_WS + f] = va - vd;
+        const float h4[4] = {vh.x + vd.x, vh.y + vd.y, vh.z + vd.z, vh.w + vd.w};
+        const float p4[4] = {vp.x, vp.y, vp.z, vp.w};
+        const float c4[4] = {va.x - vd.x, va.y - vd.y, va.z - vd.z, va.w - vd.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sh.whd[(m + e) * DW_WS + f] = h4[e];
+            sh.wp[(m + e) * DW_WS + f] = p4[e];
+            sh.wc[(m + e) * DW_WS + f] = c4[e];
+        }
     }
     for (int idx = tid; idx < DW_H2P * DW_H1P; idx += 64 * DW_WAVES) {
         const int hid = idx / DW_H2P, h2 = idx - hid * DW_H2P;
@@ -259,38 +315,58 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
     const float bias3 = b3[0];
     const float inv_sqrt_k = 1.0f / sqrtf((float)DW_K);
     const int ntile_t = (T + 15) >> 4;
-    unsigned int* q = dw_queue[slot];
-    int g = blockIdx.x & (DW_GROUPS - 1), tried = 0;
-    long long b = dw_take(q, g, tried, B);
-    while (b >= 0) {
-        const long long bn = dw_take(q, g, tried, B);           // the next sample's ticket is in flight during this one
-        const int len = hist_len ? min((int)hist_len[b], T) : T;
-        const long long cid = cand[b];
-        const int RT = (len + 15) >> 4;
-        long long id[4];
+    unsigned int* q = slot >= 0 ? dw_queue[slot] : nullptr;
+    DwQueue dq;
+    dq.init(q, B);
+    // sample descriptors: scalars + the 4 x 16 history ids of this lane's rows
+    auto load_desc = [&](const long long bb, int& len, long long& cid, long long (&id)[4]) {
+        len = 0;
+        cid = -1;
+        if (bb >= 0) {
+            len = hist_len ? min((int)hist_len[bb], T) : T;
+            cid = cand[bb];
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int j = 16 * t + r16;
-            id[t] = j < len ? hist[b * T + j] : -1;
+            id[t] = j < len ? hist[bb * T + j] : -1;
         }
-        float4 a4[4];
+    };
+    auto load_cand = [&](const long long cid, float4 (&a)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cid >= 0) a4[i] = dw_ld4(table + cid * DW_K + 16 * i + 4 * kk);
+            a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cid >= 0) a[i] = dw_ld4(table + cid * DW_K + 16 * i + 4 * kk);
         }
-        // per-sample term c[m] = sum_f a[f] (Wa - Wd)[f][m] + b1[m]: lane (kk, r) sums its 16 features for m = 16 mt + r
+    };
+    long long b = dq.take();
+    long long bn = b >= 0 ? dq.take() : -1;
+    long long bt = bn >= 0 ? dq.take() : -1;                     // sample index two ahead
+    int len, len_n;
+    long long cid, cid_n, id[4], id_n[4];
+    load_desc(b, len, cid, id);
+    load_desc(bn, len_n, cid_n, id_n);
+    float4 hv[2][4], hvn[2][4], an[4];
+    load_cand(cid, an);
+    dw_load_rows(table, kk, id[0], id[1], hv);
+    while (b >= 0) {
+        const int RT = (len + 15) >> 4;
+        // ---- this sample's candidate row -> its LDS slot; per-sample term c[m] = sum_f a[f] (Wa - Wd)[f][m] + b1[m] ----------------------------
+        if (r16 == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&sh.av[w][16 * i + 4 * kk]) = an[i];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {          // lane (kk, r) sums its 16 features for m = 16 mt + r
             float part = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part = dw_dot4(a4[i], dw_ld4(&sh.wc[(16 * mt + r16) * DW_WS + 16 * i + 4 * kk]), part);
+            for (int i = 0; i < 4; ++i) part = dw_dot4(an[i], dw_ld4(&sh.wc[(16 * mt + r16) * DW_WS + 16 * i + 4 * kk]), part);
             part += __shfl_xor(part, 16, 64);
             part += __shfl_xor(part, 32, 64);
             if (kk == 0) sh.cvec[w][16 * mt + r16] = part + sh.b1[16 * mt + r16];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same-wave LDS hand-off: the DS queue is in order, the fence
-        __builtin_amdgcn_wave_barrier();                         // only keeps the compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same-wave LDS hand-off: the DS queue is in order, the fences
+        __builtin_amdgcn_wave_barrier();                         // only keep the compiler from moving the reads above the writes
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float m_run = -INFINITY, l_run = 0.f;
         float4 o[4];
@@ -298,27 +374,47 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
         for (int i = 0; i < 4; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         float xs[4] = {0.f, 0.f, 0.f, 0.f};
         if (normalize) xs[0] = xs[1] = xs[2] = xs[3] = -INFINITY;
+        // ---- pass 0 (tiles 0, 1), with the next pass's loads in flight under it -------------------------------------------------------------------
+        if (RT > 2) {
+            dw_load_rows(table, kk, id[2], id[3], hvn);
+        } else {
+            dw_load_rows(table, kk, id_n[0], id_n[1], hvn);
+            load_cand(cid_n, an);
+        }
         if (RT >= 2) {
             const long long idp[2] = {id[0], id[1]};
             float xp[2];
-            dw_pass<2>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
             xs[0] = xp[0]; xs[1] = xp[1];
         } else if (RT == 1) {
             const long long idp[1] = {id[0]};
             float xp[1];
-            dw_pass<1>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
             xs[0] = xp[0];
         }
-        if (RT >= 4) {
-            const long long idp[2] = {id[2], id[3]};
-            float xp[2];
-            dw_pass<2>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
-            xs[2] = xp[0]; xs[3] = xp[1];
-        } else if (RT == 3) {
-            const long long idp[1] = {id[2]};
-            float xp[1];
-            dw_pass<1>(sh, table, w, r16, kk, idp, a4, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
-            xs[2] = xp[0];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[rt][i] = hvn[rt][i];
+        // ---- pass 1 (tiles 2, 3) -----------------------------------------------------------------------------------------------------------------
+        if (RT > 2) {
+            dw_load_rows(table, kk, id_n[0], id_n[1], hvn);
+            load_cand(cid_n, an);
+            if (RT >= 4) {
+                const long long idp[2] = {id[2], id[3]};
+                float xp[2];
+                dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+                xs[2] = xp[0]; xs[3] = xp[1];
+            } else {
+                const long long idp[1] = {id[2]};
+                float xp[1];
+                dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+                xs[2] = xp[0];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[rt][i] = hvn[rt][i];
         }
         // ---- pooled output: sum the 16 rows of the lane group, lane r = 0 stores the group's 16 features --------------------------------------
         const float inv_l = (normalize && l_run > 0.f) ? 1.0f / l_run : (normalize ? 0.f : 1.0f);
@@ -340,10 +436,17 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
                 }
             }
         }
-        b = bn;
+        // ---- advance: the next sample's rows / candidate are in hv / an; fetch the descriptor after it and a new ticket -----------------------------
+        b = bn; len = len_n; cid = cid_n;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) id[t] = id_n[t];
+        bn = bt;
+        load_desc(bn, len_n, cid_n, id_n);
+        bt = bn >= 0 ? dq.take() : -1;
     }
     // ---- leave the queue record clean for the next launch that draws this slot -------------------------------------------------------------------
-    if (lane == 0) {
+    dq.drain();
+    if (lane == 0 && q) {
         const unsigned int done = atomicAdd(&q[DW_GROUPS], 1u);
         if (done == gridDim.x * DW_WAVES - 1) {
 #pragma unroll
@@ -367,7 +470,8 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
         attr_set = true;
     }
     // Up to DW_SLOTS launches may be in flight at once (distinct streams); a record is reused only after DW_SLOTS further launches.
-    const int slot = (int)(dw_next_slot.fetch_add(1) % DW_SLOTS);
+    static const bool static_split = getenv("DIR_DIN_STATIC") && atoi(getenv("DIR_DIN_STATIC")) != 0;
+    const int slot = static_split ? -1 : (int)(dw_next_slot.fetch_add(1) % DW_SLOTS);
     const int64_t waves_wanted = (B + 1) / 2;            // a wave should see at least a couple of samples
     int64_t nwg = (waves_wanted + DW_WAVES - 1) / DW_WAVES;
     if (nwg > kCUs) nwg = kCUs;
