@@ -15,7 +15,10 @@ BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libdir_hip.so")
 SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "din_wave.hip", "cin.hip", "cin_bwd.hip", "backward.hip", "dense.hip", "diag.hip"]
 # per-file flags: cin_bwd's epilogues read the MFMA results on the VALU, so keep them in VGPRs (no v_accvgpr_read)
-EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               # din_wave's queue ticket is ONE lane's atomic whose result is consumed a sample later; the atomic optimizer would rewrite
+               # it as a wave reduction + immediate s_waitcnt / readfirstlane, putting the round trip back on the critical path
+               "din_wave.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
          "-Wall", "-Wno-unused-function"]

@@ -53,7 +53,10 @@ struct DinWaveSh {
 // clears its record).
 __device__ unsigned int dw_queue[DW_SLOTS][16];
 
-__device__ __forceinline__ float dw_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// sigmoid(x) = 1 / (1 + 2^(-x log2 e)).  The factor -log2 e is folded into the weight / bias images (the MFMA result IS the
+// exponent), so a sigmoid is v_exp + v_add + v_rcp: VALU work is not hidden behind fp32 MFMAs, every instruction saved counts.
+constexpr float DW_NLOG2E = -1.4426950408889634f;
+__device__ __forceinline__ float dw_sigmoid_pre(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
 __device__ __forceinline__ float4 dw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float dw_dot4(float4 a, float4 b, float acc) {
     acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
@@ -186,7 +189,7 @@ __device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float pre = NA == 2 ? acc1[mt][rt][0][g] + acc1[mt][rt][NA - 1][g] : acc1[mt][rt][0][g];
-                acc1[mt][rt][0][g] = dw_sigmoid(pre);
+                acc1[mt][rt][0][g] = dw_sigmoid_pre(pre);
             }
     // ---- layer 2: pre2^T; the reduction walks (mt, g) <-> hidden 16 mt + 4 kk + g --------------------------------------------------
     f32x4w acc2[3][NT];
@@ -225,7 +228,7 @@ __device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const 
 #pragma unroll
         for (int m2 = 0; m2 < 3; ++m2)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) sp = fmaf(dw_sigmoid(acc2[m2][rt][g]), wv[m2][g], sp);
+            for (int g = 0; g < 4; ++g) sp = fmaf(dw_sigmoid_pre(acc2[m2][rt][g]), wv[m2][g], sp);
         sp += __shfl_xor(sp, 16, 64);        // the four lane groups hold the four quarters of the H2 sum of row r
         sp += __shfl_xor(sp, 32, 64);
         sc[rt] = sp + b3;
@@ -292,9 +295,10 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
             vd = dw_ld4(W1 + (size_t)(2 * DW_K + f) * H1 + m);
             vp = dw_ld4(W1 + (size_t)(3 * DW_K + f) * H1 + m);
         }
-        const float h4[4] = {vh.x + vd.x, vh.y + vd.y, vh.z + vd.z, vh.w + vd.w};
-        const float p4[4] = {vp.x, vp.y, vp.z, vp.w};
-        const float c4[4] = {va.x - vd.x, va.y - vd.y, va.z - vd.z, va.w - vd.w};
+        const float sc_ = DW_NLOG2E;      // pre-activations come out of the MFMAs already multiplied by -log2 e
+        const float h4[4] = {(vh.x + vd.x) * sc_, (vh.y + vd.y) * sc_, (vh.z + vd.z) * sc_, (vh.w + vd.w) * sc_};
+        const float p4[4] = {vp.x * sc_, vp.y * sc_, vp.z * sc_, vp.w * sc_};
+        const float c4[4] = {(va.x - vd.x) * sc_, (va.y - vd.y) * sc_, (va.z - vd.z) * sc_, (va.w - vd.w) * sc_};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             sh.whd[(m + e) * DW_WS + f] = h4[e];
@@ -304,11 +308,11 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
     }
     for (int idx = tid; idx < DW_H2P * DW_H1P; idx += 64 * DW_WAVES) {
         const int hid = idx / DW_H2P, h2 = idx - hid * DW_H2P;
-        sh.w2[h2 * DW_W2S + hid] = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] : 0.f;     // a padded hidden unit is sigmoid(0) = 0.5:
+        sh.w2[h2 * DW_W2S + hid] = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] * DW_NLOG2E : 0.f;   // a padded hidden unit is sigmoid(0) = 0.5:
     }                                                                                           // its weights are zero
-    for (int idx = tid; idx < DW_H1P; idx += 64 * DW_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] : 0.f;
+    for (int idx = tid; idx < DW_H1P; idx += 64 * DW_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * DW_NLOG2E : 0.f;
     for (int idx = tid; idx < DW_H2P; idx += 64 * DW_WAVES) {
-        sh.b2[idx] = idx < H2 ? b2[idx] : 0.f;
+        sh.b2[idx] = idx < H2 ? b2[idx] * DW_NLOG2E : 0.f;
         sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
     }
     __syncthreads();
@@ -318,18 +322,27 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
     unsigned int* q = slot >= 0 ? dw_queue[slot] : nullptr;
     DwQueue dq;
     dq.init(q, B);
-    // sample descriptors: scalars + the 4 x 16 history ids of this lane's rows
-    auto load_desc = [&](const long long bb, int& len, long long& cid, long long (&id)[4]) {
+    // Sample descriptors travel through three stages, each consumed one sample after it was issued (nothing blocks):
+    //   index (queue ticket) -> scalars (length, candidate id; the index is wave-uniform: scalar loads) -> the 4 x 16 history ids
+    auto uniform64 = [](long long v) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)v);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    auto load_scalars = [&](const long long bb, int& len, long long& cid) {
         len = 0;
         cid = -1;
         if (bb >= 0) {
-            len = hist_len ? min((int)hist_len[bb], T) : T;
-            cid = cand[bb];
+            const long long bs = uniform64(bb);
+            len = hist_len ? min((int)hist_len[bs], T) : T;
+            cid = cand[bs];
         }
+    };
+    auto load_ids = [&](const long long bb, const int len, long long (&id)[4]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int j = 16 * t + r16;
-            id[t] = j < len ? hist[bb * T + j] : -1;
+            id[t] = j < len ? hist[bb * T + j] : -1;           // len == 0 beyond the last sample
         }
     };
     auto load_cand = [&](const long long cid, float4 (&a)[4]) {
@@ -341,11 +354,15 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
     };
     long long b = dq.take();
     long long bn = b >= 0 ? dq.take() : -1;
-    long long bt = bn >= 0 ? dq.take() : -1;                     // sample index two ahead
-    int len, len_n;
-    long long cid, cid_n, id[4], id_n[4];
-    load_desc(b, len, cid, id);
-    load_desc(bn, len_n, cid_n, id_n);
+    long long bt = bn >= 0 ? dq.take() : -1;                     // scalars in flight
+    long long bq = bt >= 0 ? dq.take() : -1;                     // index only
+    int len, len_n, len_t;
+    long long cid, cid_n, cid_t, id[4], id_n[4];
+    load_scalars(b, len, cid);
+    load_scalars(bn, len_n, cid_n);
+    load_scalars(bt, len_t, cid_t);
+    load_ids(b, len, id);
+    load_ids(bn, len_n, id_n);
     float4 hv[2][4], hvn[2][4], an[4];
     load_cand(cid, an);
     dw_load_rows(table, kk, id[0], id[1], hv);
@@ -440,9 +457,11 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
         b = bn; len = len_n; cid = cid_n;
 #pragma unroll
         for (int t = 0; t < 4; ++t) id[t] = id_n[t];
-        bn = bt;
-        load_desc(bn, len_n, cid_n, id_n);
-        bt = bn >= 0 ? dq.take() : -1;
+        bn = bt; len_n = len_t; cid_n = cid_t;                   // its scalars were issued a sample ago
+        load_ids(bn, len_n, id_n);
+        bt = bq;
+        load_scalars(bt, len_t, cid_t);
+        bq = bt >= 0 ? dq.take() : -1;
     }
     // ---- leave the queue record clean for the next launch that draws this slot -------------------------------------------------------------------
     dq.drain();
