@@ -39,12 +39,15 @@ def check_id_range(cats, got, device):
         return
     vals = [got[i][0] if isinstance(got[i], tuple) else got[i] for i in idx]
     sizes = [int(v.numel()) for v in vals]
-    flat = torch.cat([v.reshape(-1) for v in vals])
-    bound = torch.repeat_interleave(torch.tensor(nb, dtype=torch.int64, device=device),
-                                    torch.tensor(sizes, dtype=torch.int64, device=device), output_size=sum(sizes))
-    bad = ((flat >= bound) | (flat < -1))
+    nbt = torch.tensor(nb, dtype=torch.int64, device=device)
+    if len(set(sizes)) == 1:          # the common case (one-hot columns of one batch): one broadcast comparison, no index expansion
+        st = torch.stack([v.reshape(-1) for v in vals])
+        bad = (st >= nbt.unsqueeze(1)) | (st < -1)
+    else:
+        st = None
+        bad = torch.cat([((v.reshape(-1) >= n) | (v.reshape(-1) < -1)) for v, n in zip(vals, nb)])
     if bool(bad.any()):
-        pos = int(bad.nonzero()[0])
+        pos = int(bad.reshape(-1).nonzero()[0])
         k = 0
         while pos >= sizes[k]:
             pos -= sizes[k]

@@ -33,7 +33,8 @@ template <int NT, bool RELU, int KC>
 __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __restrict__ X, int64_t x_ld, const float* __restrict__ Wt,
                                                     int64_t w_ld, const float* __restrict__ bias, int64_t M, int Kd, int N,
                                                     float* __restrict__ Y, int64_t y_ld, int nb, int remap, int vec_out,
-                                                    const float* __restrict__ gate, int64_t gate_ld) {
+                                                    const float* __restrict__ gate, int64_t gate_ld,
+                                                    const float* __restrict__ pscale, const float* __restrict__ pshift) {
     constexpr int NTILES = NT / 16;
     constexpr int DN_KC = KC, DN_LS = KC + 4;      // k chunk, LDS row stride (floats)
     constexpr int TPR = KC / 4;                    // threads (16-byte pieces) per staged row
@@ -197,10 +198,12 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
             for (int nt = 0; nt < NTILES; ++nt) {
                 const int col = n0 + 16 * nt + r16;
                 const float bcol = (bias && col < N) ? bias[col] : 0.f;
+                const float sc = (pscale && col < N) ? pscale[col] : 1.f, sf = (pscale && col < N) ? pshift[col] : 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v = acc[mt][nt][g] + bcol;
                     if (RELU) v = fmaxf(v, 0.f);
+                    if (pscale) v = v * sc + sf;     // the inference batch-norm that follows the activation, per column
                     ep[(4 * kk + g) * EPS + 16 * nt + r16] = v;
                 }
             }
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
     for (int nt = 0; nt < NTILES; ++nt) {
         const int col = n0 + 16 * nt + r16;
         const float bcol = (bias && col < N) ? bias[col] : 0.f;
+        const float sc = (pscale && col < N) ? pscale[col] : 1.f, sf = (pscale && col < N) ? pshift[col] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
                 const int64_t row = m0 + 32 * w + 16 * mt + 4 * kk + g;
                 float v = acc[mt][nt][g] + bcol;
                 if (RELU) v = fmaxf(v, 0.f);
+                if (pscale) v = v * sc + sf;
                 if (row < M && col < N) {
                     if (gate && !(gate[row * gate_ld + col] > 0.f)) v = 0.f;
                     Y[row * y_ld + col] = v;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
 
 template <int NT, int KC>
 static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M,
-                         int Kd, int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld) {
+                         int Kd, int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld, const float* ps, const float* psh) {
     const int nb = (N + NT - 1) / NT;
     const int64_t mb = (M + DN_MT - 1) / DN_MT;
     const int64_t total = mb * nb;
@@ -249,9 +254,9 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
         attr_set = true;
     }
     if (act)
-        hipLaunchKernelGGL((dense_k<NT, true, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
+        hipLaunchKernelGGL((dense_k<NT, true, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld, ps, psh);
     else
-        hipLaunchKernelGGL((dense_k<NT, false, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld);
+        hipLaunchKernelGGL((dense_k<NT, false, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld, ps, psh);
 }
 
 }  // namespace dir
@@ -259,7 +264,8 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
 using namespace dir;
 
 static int dense_entry(const char* name, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd,
-                       int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld, dir_stream_t stream) {
+                       int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld, dir_stream_t stream, const float* ps = nullptr,
+                       const float* psh = nullptr) {
     DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && w_ld >= Kd && y_ld >= N, "%s: M=%lld Kd=%d N=%d x_ld=%lld w_ld=%lld y_ld=%lld", name,
                   (long long)M, Kd, N, (long long)x_ld, (long long)w_ld, (long long)y_ld);
     DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
@@ -276,11 +282,11 @@ static int dense_entry(const char* name, const float* X, int64_t x_ld, const flo
     // workgroups per CU).  DIR_DENSE_KC = 32 selects the wide chunks (tools/dense_sweep.py).
     static const int kc_env = getenv("DIR_DENSE_KC") ? atoi(getenv("DIR_DENSE_KC")) : 16;
     if (N % 80 == 0 && N % 128 != 0) {
-        if (kc_env == 32) launch_dense<80, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
-        else launch_dense<80, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+        if (kc_env == 32) launch_dense<80, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld, ps, psh);
+        else launch_dense<80, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld, ps, psh);
     } else {
-        if (kc_env == 32) launch_dense<128, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
-        else launch_dense<128, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld);
+        if (kc_env == 32) launch_dense<128, 32>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld, ps, psh);
+        else launch_dense<128, 16>(st, X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, gate, gate_ld, ps, psh);
     }
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
@@ -295,4 +301,10 @@ extern "C" int dir_dense_gated_f32(const float* X, int64_t x_ld, const float* Wt
                                    int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
     DIR_CHECK_ARG(M == 0 || (gate && gate_ld >= N), "dir_dense_gated_f32: gate [M, N] with gate_ld >= N (gate_ld=%lld N=%d)", (long long)gate_ld, N);
     return dense_entry("dir_dense_gated_f32", X, x_ld, Wt, w_ld, nullptr, DIR_ACT_NONE, M, Kd, N, Y, y_ld, gate, gate_ld, stream);
+}
+
+extern "C" int dir_dense_affine_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
+                                    const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
+    DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "dir_dense_affine_f32: post_scale and post_shift come together");
+    return dense_entry("dir_dense_affine_f32", X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, nullptr, 0, stream, post_scale, post_shift);
 }

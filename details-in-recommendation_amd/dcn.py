@@ -73,10 +73,11 @@ class DeepCrossNetwork(nn.Module):
         n = len(self.hidden)
         bi = 0
         for i, lin in enumerate(self.hidden):                                    # :392-403
-            net = dense_act(lin, net, self.activation)                           # dir_dense_f32 when covered
+            bn = None
             if self.batch_norm and i < n - 1:
-                net = self.bns[bi](net)
+                bn = self.bns[bi]
                 bi += 1
+            net = dense_act(lin, net, self.activation, bn=bn)                    # dir_dense_f32 when covered; inference BN in its epilogue
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :405-408 (TRAIN only), after the BN
         return net
 

@@ -154,6 +154,9 @@ class DeepFM(nn.Module):
         if not len(self.bns) and not self.hparams.get("dnn_dropout") and mlp_stack_supported(self.hidden, net, self.activation):
             return self._logits_of(mlp_stack(self.hidden, net))                         # training: the whole tower as one autograd node
         for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
+            if len(self.bns) and not _train_mode(self):                        # inference: no dropout, BN folded into the layer's epilogue
+                net = dense_act(lin, net, self.activation, bn=self.bns[i])
+                continue
             net = dense_act(lin, net, self.activation)                          # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :301-302 (TRAIN only), before the BN
             if len(self.bns):

@@ -194,15 +194,50 @@ def units1(lin, x):
     return lin(x)
 
 
-def dense_act(lin, x, activation=None):
+_BN_CACHE = {}
+
+
+def _bn_affine(bn):
+    """Inference batch-norm as one per-column affine (scale, shift), cached until a statistic or parameter changes."""
+    key = id(bn)
+    ver = (bn.moving_mean._version, bn.moving_variance._version, bn.beta._version, bn.gamma._version if bn.gamma is not None else -1,
+           bn.beta.data_ptr())
+    hit = _BN_CACHE.get(key)
+    if hit is not None and hit[0] is bn and hit[1] == ver:
+        return hit[2], hit[3]
+    inv = torch.rsqrt(bn.moving_variance + bn.eps)
+    if bn.gamma is not None:
+        inv = inv * bn.gamma.data
+    shift = bn.beta.data - bn.moving_mean * inv
+    if len(_BN_CACHE) > 256:
+        _BN_CACHE.clear()
+    _BN_CACHE[key] = (bn, ver, inv.contiguous(), shift.contiguous())
+    return _BN_CACHE[key][2], _BN_CACHE[key][3]
+
+
+def dense_act(lin, x, activation=None, bn=None):
     """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered.  x may arrive row-padded with zero
-    columns up to the next multiple of 4 (InputLayer(pad_to=4), inference): then only the weight gets its zero columns."""
+    columns up to the next multiple of 4 (InputLayer(pad_to=4), inference): then only the weight gets its zero columns.
+    bn: the batch-norm module that follows the activation (deepFM.py:303-308, DeepCrossNetwork.py:400-403) -- in inference it is
+    folded into the kernel's epilogue (one pass over the layer's output instead of three); otherwise it is applied here."""
+    y = _dense_act(lin, x, activation, bn)
+    return y
+
+
+def _apply_bn(bn, y):
+    return bn(y) if bn is not None else y
+
+
+def _dense_act(lin, x, activation, bn):
     relu = activation in _RELUS
     prepadded = x.dim() == 2 and x.shape[1] != lin.in_features and x.shape[1] == lin.in_features + (-lin.in_features) % 4
     if (activation is None or relu) and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and lin.out_features >= 16:
         train = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
+        fold = bn is not None and not (bn.training and torch.is_grad_enabled())
+        ps, psh = _bn_affine(bn) if fold else (None, None)
         if prepadded and not train and x.dtype == torch.float32:
-            return ops.dense(x, _packed_cached_padded(lin.weight, x.shape[1] - lin.in_features), lin.bias, relu=relu)
+            y = ops.dense(x, _packed_cached_padded(lin.weight, x.shape[1] - lin.in_features), lin.bias, relu=relu, post_scale=ps, post_shift=psh)
+            return y if fold else _apply_bn(bn, y)
         if prepadded:
             x = x[:, :lin.in_features]
             prepadded = False
@@ -212,13 +247,15 @@ def dense_act(lin, x, activation=None):
             # to the next multiple of 4 -- one [B, in] copy (45 us at 65 536 x 429) against 200 us saved on the GEMM
             xp = F.pad(x, (0, pad))
             if train:
-                return _DenseFn.apply(xp, F.pad(lin.weight, (0, pad)), lin.bias, relu)     # pad's backward slices the gradients back
-            return ops.dense(xp, _packed_cached_padded(lin.weight, pad), lin.bias, relu=relu)
+                return _apply_bn(bn, _DenseFn.apply(xp, F.pad(lin.weight, (0, pad)), lin.bias, relu))     # pad's backward slices the gradients back
+            y = ops.dense(xp, _packed_cached_padded(lin.weight, pad), lin.bias, relu=relu, post_scale=ps, post_shift=psh)
+            return y if fold else _apply_bn(bn, y)
         if ops.dense_supported(x, lin.weight):
             if train:
-                return _DenseFn.apply(x, lin.weight, lin.bias, relu)
-            return ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu)
+                return _apply_bn(bn, _DenseFn.apply(x, lin.weight, lin.bias, relu))
+            y = ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu, post_scale=ps, post_shift=psh)
+            return y if fold else _apply_bn(bn, y)
     if prepadded:
         x = x[:, :lin.in_features]
     y = lin(x)
-    return activation(y) if activation is not None else y
+    return _apply_bn(bn, activation(y) if activation is not None else y)

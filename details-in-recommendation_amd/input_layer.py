@@ -136,13 +136,27 @@ class InputLayer(nn.Module):
                 buf[:, self.column_num:].zero_()
             return buf
 
+        run, run_off = [], 0          # name-adjacent numeric columns are written as ONE block (13 Criteo numerics: 2 kernels, not 13)
+
+        def flush():
+            nonlocal run, x0, B
+            if run:
+                blk = run[0] if len(run) == 1 else torch.cat(run, dim=1)
+                if x0 is None:
+                    B = blk.shape[0]
+                    x0 = alloc(B)
+                x0[:, run_off:run_off + blk.shape[1]] = blk
+                run = []
+
         for c in self.columns:
             if isinstance(c, NumericColumn):
                 v = features[c.key].to(device=device, dtype=torch.float32).reshape(-1, c.dimension)
-                if x0 is None:
-                    B = v.shape[0]
-                    x0 = alloc(B)
-                x0[:, self._col_offset(c):self._col_offset(c) + c.dimension] = v
+                if not run:
+                    run_off = self._col_offset(c)
+                run.append(v)
+            else:
+                flush()
+        flush()
         for ts, idxs, comb, mn in self._tablesets():
             cols = [self.emb_cols[i] for i in idxs]
             got = collect_ids(cols, features, device)

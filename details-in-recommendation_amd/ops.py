@@ -315,8 +315,10 @@ def dense_supported(x, weight):
             and weight.shape[0] >= 16 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
-def dense(x, weight, bias=None, relu=False, out=None):
-    """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32).  x [M, Kd], weight [N, Kd] (nn.Linear layout), bias [N]."""
+def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None):
+    """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32).  x [M, Kd], weight [N, Kd] (nn.Linear layout), bias [N].
+    post_scale / post_shift [N]: the inference batch-norm that follows the activation, as y * post_scale + post_shift in the same
+    pass (dir_dense_affine_f32)."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     M, Kd = x.shape
@@ -331,6 +333,13 @@ def dense(x, weight, bias=None, relu=False, out=None):
             raise ValueError("dense: bias [N]")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if post_scale is not None:
+        post_scale, post_shift = _dev(post_scale, torch.float32, "post_scale").contiguous(), _dev(post_shift, torch.float32, "post_shift").contiguous()
+        if post_scale.numel() != N or post_shift.numel() != N:
+            raise ValueError("dense: post_scale / post_shift [N]")
+        _lib.check(_lib.load().dir_dense_affine_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), 1 if relu else 0,
+                                                    _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
+        return out
     _lib.check(_lib.load().dir_dense_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), 1 if relu else 0, M, Kd, N, _ptr(out),
                                          out.stride(0), _stream()))
     return out

@@ -285,6 +285,12 @@ int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_
 #define DIR_ACT_RELU 1
 int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd, int N,
                   float* Y, int64_t y_ld, dir_stream_t stream);
+/* dir_dense_affine_f32: Y = act(X . Wt^T + bias) * post_scale[N] + post_shift[N] -- the layer followed by its INFERENCE batch
+ * normalisation (models/DeepFM/deepFM.py:303-308, DeepCrossNetwork.py:400-403: the reference normalises AFTER the activation),
+ * folded to one per-column affine: post_scale = gamma * rsqrt(moving_variance + eps), post_shift = beta - moving_mean * post_scale
+ * (gamma = 1 for contrib batch_norm).  Multiply then add, unfused.  One pass over Y instead of three. */
+int dir_dense_affine_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
+                         const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
 /* dir_dense_gated_f32: Y = (gate > 0) ? X . Wt^T : 0 -- the data gradient of a dense layer taken straight through the previous
  * layer's ReLU: X = dL/d(pre-activation of layer l) [M, Kd = units of l], Wt = the TRANSPOSE of layer l's nn.Linear weight
  * ([in_l, units_l] rows), gate = layer l-1's output [M, N = in_l]; the result is dL/d(pre-activation of layer l-1). */
