@@ -519,8 +519,9 @@ def main():
         idsl = make_ids(torch, args, gen, device, V)
         feats = [{"C%02d" % i: ids[:, i].contiguous() for i in range(F)} for ids in idsl]
         if wl == "esmm_full":
-            with torch.no_grad():
-                step = lambda i: model(feats[i % len(feats)])  # noqa: E731
+            def step(i):
+                with torch.no_grad():
+                    model(feats[i % len(feats)])
         else:
             labels = {"click_label": (torch.rand((B, 1), generator=gen, device=device) < 0.25).float(),
                       "convert_label": (torch.rand((B, 1), generator=gen, device=device) < 0.05).float()}

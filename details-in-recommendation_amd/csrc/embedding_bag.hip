@@ -378,11 +378,12 @@ __global__ void check_ids_k(const int64_t* __restrict__ vocab, int F, const int6
         const int f = (int)(i - b * F);
         const int64_t v = vocab[f];
         if (!offsets) {
-            if (ids[b * sb + f * sf] >= v) ++local;
+            const int64_t id = ids[b * sb + f * sf];
+            if (id >= v || id < -1) ++local;          // -1 is the "missing" marker; anything below it is as invalid as id >= vocab
         } else {
             const int64_t bag = b * sb + f * sf;
             for (int64_t e = offsets[bag]; e < offsets[bag + 1]; ++e)
-                if (ids[e] >= v) ++local;
+                if (ids[e] >= v || ids[e] < -1) ++local;
         }
     }
     if (local) atomicAdd(bad, local);

@@ -19,6 +19,7 @@ from . import autograd as ag
 from . import ops
 from .deepfm import _BatchNormInfer, _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
+from ._input import raise_pending
 
 
 def _glorot_normal_(w):  # glorot_normal_initializer, DeepCrossNetwork.py:397 ([TF-upstream] truncated normal)
@@ -103,7 +104,9 @@ class DeepCrossNetwork(nn.Module):
         deep = self.deep_architecture(x0p)                                       # dense_act pads the first weight (in_features d -> dp)
         wl = self.logits_layer.weight                                            # [1, d + h]
         wc = torch.nn.functional.pad(wl[:, :d], (0, dp - d))
-        return torch.addmm(self.logits_layer.bias, cross, wc.t()).addmm_(deep, wl[:, d:].t())
+        out = torch.addmm(self.logits_layer.bias, cross, wc.t()).addmm_(deep, wl[:, d:].t())
+        raise_pending()
+        return out
 
     def forward(self, features):
         if (not torch.is_grad_enabled() and not isinstance(features, torch.Tensor) and self.column_num % 4
@@ -112,7 +115,9 @@ class DeepCrossNetwork(nn.Module):
         x0 = features if isinstance(features, torch.Tensor) else self.input_layer(features)
         cross = self.cross_architecture(x0)
         deep = self.deep_architecture(x0)
-        return self.logits_layer(torch.cat([cross, deep], dim=-1))               # :136-137
+        out = self.logits_layer(torch.cat([cross, deep], dim=-1))                # :136-137
+        raise_pending()                                                          # id-range verdicts of the input layer's columns
+        return out
 
     def create_loss(self, features, logits, labels):
         """_create_loss (DeepCrossNetwork.py:209-225): sigmoid cross entropy, weight_column weights, MEAN reduction

@@ -19,7 +19,7 @@ from torch import nn
 from .dense import dense_act, mlp_stack, mlp_stack_supported, units1
 from . import autograd as ag
 from . import ops
-from ._input import collect_ids, categorical_of
+from ._input import collect_ids, categorical_of, raise_pending
 
 
 def _glorot_uniform_(w):  # [TF-upstream] glorot_uniform_initializer, deepFM.py:299
@@ -237,6 +237,7 @@ class DeepFM(nn.Module):
         if self.linear_feature_columns:
             lin = self.linear_logit_fn(features, device)
             logits = lin if logits is None else logits + lin                     # add_n, deepFM.py:223
+        raise_pending()                                                          # the id-range verdicts (checked on the device, read here)
         return logits
 
     def create_loss(self, features, logits, labels):

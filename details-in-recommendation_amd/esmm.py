@@ -63,7 +63,10 @@ class ESMM(nn.Module):
         cvr_logits = self.cvr_model(features)
         ctcvr_logistic = torch.sigmoid(ctr_logits) * torch.sigmoid(cvr_logits)  # :69-71
         p = ctcvr_logistic.clamp(_EPSILON, 1 - _EPSILON)                         # :73-74
-        return {"ctr_logits": ctr_logits, "ctcvr_logits": torch.log(p / (1 - p)), "cvr_logits": cvr_logits}
+        out = {"ctr_logits": ctr_logits, "ctcvr_logits": torch.log(p / (1 - p)), "cvr_logits": cvr_logits}
+        from ._input import raise_pending
+        raise_pending()                                                          # id-range verdicts of both towers' input layers
+        return out
 
     def get_loss(self, features, labels, logits):
         """_get_loss (ESMM.py:150-175): labels {'click_label', 'convert_label'}; CTR and CTCVR sigmoid cross entropies, each

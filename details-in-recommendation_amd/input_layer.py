@@ -14,7 +14,7 @@ from torch import nn
 
 from . import autograd as ag
 from . import ops
-from ._input import collect_ids, categorical_of
+from ._input import collect_ids, categorical_of, raise_pending
 from .feature_column import EmbeddingColumn, IndicatorColumn, NumericColumn
 
 

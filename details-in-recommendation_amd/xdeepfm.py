@@ -113,4 +113,7 @@ class XDeepFM(nn.Module):
             else:
                 lin = ops.linear_logit(lin_ts, g2[1], bias=self.linear_bias.data) if g2[0] == "onehot" else \
                     ops.linear_logit(lin_ts, g2[1], g2[2], g2[3], bias=self.linear_bias.data, field_major=True)
-        return self.forward_embedded(emb, lin)
+        out = self.forward_embedded(emb, lin)
+        from ._input import raise_pending
+        raise_pending()
+        return out

@@ -94,7 +94,7 @@ int dir_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, i
 
 /* Validation of the precondition above (debug aid, asynchronous like everything else).
  * vocab: DEVICE array [F].  bad_count: DEVICE int32; zeroed on the stream, then set to the number of
- * ids >= vocab_f found (ids < 0 are legal: they are pruned).  The caller reads it back and treats a
+ * ids >= vocab_f or < -1 found (-1 is the legal "missing" marker: pruned).  The caller reads it back and treats a
  * non-zero count as DIR_E_RANGE ([TF-upstream] CPU kernels raise InvalidArgument there). */
 int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, const int64_t* offsets,
                   int64_t stride_b, int64_t stride_f, int64_t B, int32_t* bad_count,

@@ -569,9 +569,23 @@ def test_identity_column_range_check(built_lib):
     with torch.no_grad():
         assert torch.isfinite(model(ok)).all()                     # b's out-of-range ids take default_value
     bad = dict(ok, a=torch.tensor([0, 10, 2, 3, 4, 5]).cuda())
-    with pytest.raises(ValueError, match="num_buckets=10"):
+    from dir_amd import _input
+    with pytest.raises(ValueError, match="num_buckets=10"):            # default: TensorFlow's timing, the offending forward raises
         with torch.no_grad():
             model(bad)
+    with torch.no_grad():
+        assert torch.isfinite(model(ok)).all()                         # a clean forward afterwards does not raise
+    old = _input.CHECK_MODE
+    _input.CHECK_MODE = "deferred"                                     # DIR_CHECK_IDS=deferred: never waits; the verdict is read on demand
+    try:
+        with pytest.raises(ValueError, match="num_buckets=10"):
+            with torch.no_grad():
+                out = model(bad)                                       # kernels treat the id as pruned: finite output, no fault
+                assert torch.isfinite(out).all()
+                torch.cuda.synchronize()
+                _input.raise_pending(block=True)
+    finally:
+        _input.CHECK_MODE = old
     with pytest.raises(ValueError):
         fc.categorical_column_with_identity("c", 10, default_value=10)
 
