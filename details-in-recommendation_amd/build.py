@@ -19,6 +19,8 @@ EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # din_wave's queue ticket is ONE lane's atomic whose result is consumed a sample later; the atomic optimizer would rewrite
                # it as a wave reduction + immediate s_waitcnt / readfirstlane, putting the round trip back on the critical path
                "din_wave.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+if os.environ.get("DIR_DB_FAKE_SPLIT") == "1":       # tools/dense_bf3_probe.py timing experiment
+    EXTRA_FLAGS["dense.hip"] = ["-DDB_FAKE_SPLIT"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
          "-Wall", "-Wno-unused-function"]

@@ -345,6 +345,40 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     return out
 
 
+def dense_bf3_planes(weight):
+    """weight [N, Kd] fp32 -> the three bf16 planes [3, N, ld] (ld = Kd rounded up to 8) whose sum is the weight (experiment:
+    dir_dense_bf16x3_f32)."""
+    w = weight.detach().float()
+    N, Kd = w.shape
+    ld = (Kd + 7) // 8 * 8
+    planes = torch.zeros((3, N, ld), dtype=torch.bfloat16, device=w.device)
+    r = w
+    for p in range(3):
+        q = r.to(torch.bfloat16)
+        planes[p, :, :Kd] = q
+        r = r - q.float()
+    return planes
+
+
+def dense_bf3(x, planes, Kd, bias=None, relu=False, out=None, post_scale=None, post_shift=None):
+    """y = act(x @ W.T + bias) with W given as dense_bf3_planes(W): the bf16 x 3 split-operand experiment (include/dir_hip.h:
+    dir_dense_bf16x3_f32).  x [M, Kd] fp32 with Kd % 8 == 0."""
+    _dev(x, torch.float32, "x")
+    if planes.dtype != torch.bfloat16 or planes.dim() != 3 or planes.shape[0] != 3 or not planes.is_contiguous():
+        raise ValueError("dense_bf3: planes from dense_bf3_planes()")
+    M = x.shape[0]
+    N, ld = planes.shape[1], planes.shape[2]
+    if x.shape[1] != Kd or x.stride(1) != 1:
+        raise ValueError("dense_bf3: x [M, Kd] with unit inner stride")
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "bias").contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(planes), ld, _ptr(bias), 1 if relu else 0, _ptr(post_scale),
+                                                _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
+    return out
+
+
 def dense_gated(x, weight, gate, out=None):
     """where(gate > 0, x @ weight.T, 0) (include/dir_hip.h: dir_dense_gated_f32): x [M, Kd], weight [N, Kd], gate [M, N]."""
     _dev(x, torch.float32, "x")

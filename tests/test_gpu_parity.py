@@ -574,3 +574,26 @@ def test_full_size_config4_din_on_the_10m_row_table(ops, oracle):
     # run-to-run bitwise reproducibility at full size
     out2 = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=False)
     assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("M,Kd,N", [(300, 416, 400), (129, 400, 400), (1000, 64, 80), (77, 1024, 1024), (128, 40, 80), (256, 432, 1024), (1, 16, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_dense_bf16x3_experiment_matches_float64(built_lib, M, Kd, N, relu):
+    """dir_dense_bf16x3_f32 (opt-in experiment): fp32 operands split into three bf16 pieces, six cross products on the bf16 matrix
+    pipe, fp32 accumulation -- the same 1e-5 bar as the fp32-MFMA kernel against float64."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(M + Kd + N)
+    x = torch.randn(M, Kd, generator=g).cuda()
+    w = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    planes = ops.dense_bf3_planes(w)
+    assert torch.equal(planes.float().sum(0)[:, :Kd], w)                 # the three planes add up to the weight exactly
+    ref = x.cpu().double() @ w.cpu().double().t() + b.cpu().double()
+    if relu:
+        ref = ref.clamp(min=0)
+    got = ops.dense_bf3(x, planes, Kd, b, relu=relu)
+    err = (got.cpu().double() - ref).abs() / (1 + ref.abs())
+    assert err.max() <= 1e-5, float(err.max())
+    ps, psh = torch.rand(N).cuda() + 0.5, torch.randn(N).cuda()
+    got2 = ops.dense_bf3(x, planes, Kd, b, relu=relu, post_scale=ps, post_shift=psh)
+    assert torch.allclose(got2, got * ps + psh, rtol=1e-6, atol=1e-6)
