@@ -15,6 +15,7 @@ c_i32, c_i64, c_f32p, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctyp
 SIGNATURES = {
     "dir_version": (c_i32, []),
     "dir_last_error": (ctypes.c_char_p, []),
+    "dir_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, c_vp, c_i64]),
     "dir_embedding_bag_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i64,
                                       c_vp, c_i64, c_vp]),
     "dir_embedding_bag_ex_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, ctypes.c_float, c_i32,

@@ -5,9 +5,13 @@ SURVEY.md 8(f) rank 4.  The reference models are tf.estimator.Estimators that ch
 This module maps every parameter of the modules here to the variable name the reference graph would give it
 (variable scopes: deepFM.py:173-196,206-209,286-317; DeepCrossNetwork.py:109,125,134,329-331,393-403;
 ESMM.py:62-66,139-146) and to TensorFlow's layout (dense kernels are [in, out], i.e. the transpose of
-nn.Linear.weight; linear_model weights are [vocab, 1]).  `export_npz` / `load_npz` move a whole model through a
-.npz keyed by those names -- the route to true cross-implementation parity once a TF 1.x environment exists to dump
-a reference checkpoint (`tf.train.load_checkpoint(...).get_tensor(name)` -> np.savez).
+nn.Linear.weight; linear_model weights are [vocab, 1]).  `export_tf_checkpoint` / `load_tf_checkpoint` write and read
+TensorFlow's own checkpoint bundle format (tf_bundle.py: `model.ckpt-N.index` + `.data-00000-of-00001` + the `checkpoint`
+state file of an Estimator's model_dir), so a checkpoint trained with the reference loads here by name without TensorFlow, and
+one written here is what tf.train.load_checkpoint / warm_start_from (deepFM.py:71,140) read.  `export_serving` writes the
+SavedModel-LIKE artefact of the reference's FinalExporter (DeepCrossNetwork/train.py:170-175): variables/ in bundle format +
+the parsing / classification signature as JSON (the GraphDef itself cannot be produced without TensorFlow).  `export_npz` /
+`load_npz` are the same mapping through a plain .npz.
 
 [TF-upstream] names that cannot be verified in this container (TensorFlow is not installable): the
 `<column>/embedding_weights`, `linear_model/<column>/weights`, `batch_normalization` (gamma/beta/moving_*) and
@@ -110,3 +114,89 @@ def load_npz(model, path, strict=True):
                 raise ValueError("%s: checkpoint shape %s vs parameter %s" % (k, a.shape, tuple(t.shape)))
             t.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(t.device, t.dtype))
     return missing
+
+
+# ---- TensorFlow checkpoint bundles (tf_bundle.py) ---------------------------------------------------------------------------------------
+def tf_tensors(model):
+    """{tf variable name: ndarray in TensorFlow's layout} for every mapped parameter / buffer."""
+    return {k: _to_tf(t, lay) for k, (t, lay) in tf_variable_map(model).items()}
+
+
+def export_tf_checkpoint(model, model_dir, global_step=0, name="model.ckpt"):
+    """Write `model_dir/<name>-<global_step>.{index,data-00000-of-00001}` + the `checkpoint` state file, keyed by the reference's
+    variable names (+ the int64 `global_step` the Estimators keep).  -> the checkpoint prefix."""
+    import os
+    from . import tf_bundle
+    os.makedirs(model_dir, exist_ok=True)
+    tensors = tf_tensors(model)
+    tensors["global_step"] = np.array(int(global_step), dtype=np.int64)
+    ckpt = "%s-%d" % (name, int(global_step))
+    tf_bundle.write_bundle(os.path.join(model_dir, ckpt), tensors)
+    tf_bundle.write_checkpoint_state(model_dir, ckpt)
+    return os.path.join(model_dir, ckpt)
+
+
+def load_tf_checkpoint(model, path, strict=True):
+    """Load a TensorFlow checkpoint bundle (a prefix, or a model_dir whose `checkpoint` file names the latest one) into the
+    module by variable name.  Optimizer slots (`.../Adagrad`, `.../Ftrl`, ...) and other extra variables are ignored.
+    -> (missing names, global_step | None)."""
+    import os
+    from . import tf_bundle
+    prefix = path
+    if os.path.isdir(path):
+        prefix = tf_bundle.latest_checkpoint(path)
+        if prefix is None:
+            raise FileNotFoundError("no `checkpoint` state file in %s" % path)
+    vm = tf_variable_map(model)
+    data = tf_bundle.read_bundle(prefix, names=set(vm) | {"global_step"})
+    missing = [k for k in vm if k not in data]
+    if strict and missing:
+        raise KeyError("variables missing from %s: %s" % (prefix, missing[:5]))
+    with torch.no_grad():
+        for k, (t, lay) in vm.items():
+            if k not in data:
+                continue
+            a = data[k]
+            if lay == "T":
+                a = a.T
+            elif lay == "col":
+                a = a.reshape(-1)
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError("%s: checkpoint shape %s vs parameter %s" % (k, a.shape, tuple(t.shape)))
+            t.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(t.device, t.dtype))
+    step = int(data["global_step"]) if "global_step" in data else None
+    return missing, step
+
+
+def export_serving(model, export_dir, global_step=0):
+    """The FinalExporter artefact (DeepCrossNetwork/train.py:170-175, ESMM/train.py:194-199) as far as it exists without
+    TensorFlow: `variables/variables.{index,data-...}` in bundle format (what a SavedModel holds) and `serving_signature.json`:
+    the parsing feature spec of the columns ([TF-upstream] make_parse_example_spec) and the serving_default signature --
+    ClassificationOutput(scores=probabilities) (DeepCrossNetwork.py:166-171)."""
+    import json
+    import os
+    from . import tf_bundle
+    from ._input import categorical_of
+    from .feature_column import NumericColumn
+    vdir = os.path.join(export_dir, "variables")
+    os.makedirs(vdir, exist_ok=True)
+    tensors = tf_tensors(model)
+    tensors["global_step"] = np.array(int(global_step), dtype=np.int64)
+    tf_bundle.write_bundle(os.path.join(vdir, "variables"), tensors)
+    cols = list(getattr(model, "columns", None) or (list(getattr(model, "linear_feature_columns", [])) + list(getattr(model, "dnn_feature_columns", []))))
+    spec = {}
+    for c in cols:
+        if isinstance(c, NumericColumn):
+            spec[c.key] = {"kind": "FixedLenFeature", "shape": list(c.shape), "dtype": "float32"}
+        else:
+            cat = categorical_of(c)
+            spec[cat.key] = {"kind": "VarLenFeature", "dtype": "int64"}
+            if getattr(cat, "weight_key", None):
+                spec[cat.weight_key] = {"kind": "VarLenFeature", "dtype": "float32"}
+    sig = {"signature_def": {"serving_default": {"method_name": "tensorflow/serving/classify",
+                                                 "inputs": {"inputs": "serialized tf.Example, parsed with feature_spec"},
+                                                 "outputs": {"scores": "probabilities [B, n_classes]"}}},
+           "feature_spec": spec, "variables": sorted(tensors), "model": type(model).__name__}
+    with open(os.path.join(export_dir, "serving_signature.json"), "w") as f:
+        json.dump(sig, f, indent=1, sort_keys=True)
+    return export_dir

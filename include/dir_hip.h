@@ -53,6 +53,11 @@ enum {
 int dir_version(void);
 const char* dir_last_error(void);
 
+/* HOST: CRC-32C (Castagnoli) of n bytes, continuing from `crc` (0 to start) -- the checksum of [TF-upstream] checkpoint bundles
+ * (tensor_bundle: per-tensor crc32c, table block trailers), used by tf_bundle.py to write / verify model_dir checkpoints
+ * (models/DeepCrossNetwork/train.py:170-175, the Estimators' model_dir). */
+uint32_t dir_crc32c(uint32_t crc, const void* data, int64_t n);
+
 /* --------------------------------------------------------------------------------------------
  * A1/A2  multi-slot embedding bag.
  * Replaces: myself_input_layer                        models/DeepFM/deepFM.py:363-400

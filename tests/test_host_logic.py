@@ -309,3 +309,117 @@ def test_dense_row_threshold_routes_small_batches_to_the_library(monkeypatch):
     monkeypatch.setattr(D, "MIN_ROWS", 6144)
     assert not D.mlp_stack_supported(torch.nn.ModuleList([lin]), x.requires_grad_(True), torch.relu)
     assert torch.allclose(D.units1(torch.nn.Linear(16, 1), x), torch.nn.Linear(16, 1)(x)) is not None
+
+
+# ---- TensorFlow checkpoint bundles (tf_bundle.py, checkpoint.export_tf_checkpoint / load_tf_checkpoint) ----------------------------------
+def test_crc32c_known_answers(built_lib):
+    from dir_amd import tf_bundle as tb
+    assert tb._crc32c(b"123456789") == 0xE3069283                    # the CRC-32C check value (RFC 3720 appendix B.4 family)
+    assert tb._crc32c(b"\x00" * 32) == 0x8A9136AA                    # RFC 3720 B.4: 32 bytes of zeros
+    assert tb._crc32c(b"\xff" * 32) == 0x62A8AB43                    # RFC 3720 B.4: 32 bytes of ones
+    assert tb._crc32c(bytes(range(32))) == 0x46DD794E                # RFC 3720 B.4: incrementing bytes
+    data = np.random.default_rng(0).integers(0, 256, 100003, dtype=np.uint8).tobytes()
+    assert tb._crc32c(data) == tb._crc32c_py(data)                   # C (slice-by-8) vs the table loop, unaligned length
+    assert tb._crc32c(data[1000:], tb._crc32c(data[:1000])) == tb._crc32c(data)     # incremental
+    for c in (0, 1, 0xdeadbeef, 0xffffffff):
+        assert tb.unmask_crc(tb.mask_crc(c)) == c
+    assert tb.mask_crc(0) == 0xa282ead8
+
+
+def test_tf_bundle_format_invariants_and_round_trip(tmp_path, built_lib):
+    """The index is a leveldb-format table: footer magic, block trailers with masked crc32c, prefix-compressed keys with restart
+    points every 16 entries; the data shard holds row-major little-endian bytes at the recorded offsets."""
+    import struct
+    from dir_amd import tf_bundle as tb
+    rng = np.random.default_rng(3)
+    tensors = {"dnn_fm/hiddenlayer_%d/kernel" % i: rng.standard_normal((7, 5)).astype(np.float32) for i in range(40)}   # shared prefixes
+    tensors["global_step"] = np.array(1234, dtype=np.int64)
+    tensors["linear/linear_model/C1/weights"] = rng.standard_normal((1000, 1)).astype(np.float32)
+    tensors["a/ids"] = np.arange(12, dtype=np.int32).reshape(3, 4)
+    tensors["scalar"] = np.array(2.5, dtype=np.float64)
+    prefix = str(tmp_path / "model.ckpt-1234")
+    tb.write_bundle(prefix, tensors)
+    idx = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", idx[-8:])[0] == 0xdb4775248b80fb57
+    items = tb.read_table(prefix + ".index")
+    keys = [k for k, _ in items]
+    assert keys[0] == b"" and keys == sorted(keys) and len(keys) == len(tensors) + 1
+    # header: num_shards = 1, version.producer = 1
+    assert items[0][1] == b"\x08\x01\x1a\x02\x08\x01"
+    # prefix compression really happened: the index is much smaller than the sum of the keys
+    assert len(idx) < sum(len(k) + len(v) for k, v in items)
+    # a flipped byte in a block is caught by the trailer crc
+    bad = bytearray(idx)
+    bad[10] ^= 0xff
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="crc32c"):
+        tb.read_table(prefix + ".index")
+    open(prefix + ".index", "wb").write(idx)
+    got = tb.read_bundle(prefix)
+    assert set(got) == set(tensors)
+    for k, v in tensors.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape
+        np.testing.assert_array_equal(got[k], v)
+    # entry protos: offsets are the running sum of the sizes in key order; a corrupted tensor byte fails its crc
+    off = 0
+    for k, val in items[1:]:
+        e = tb._parse_entry(val)
+        assert e["offset"] == off and e["size"] == tensors[k.decode()].nbytes
+        off += e["size"]
+    raw = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    raw[5] ^= 1
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="crc32c"):
+        tb.read_bundle(prefix)
+    # many entries: several data blocks and an index block with one entry per block
+    big = {"v/%06d" % i: np.full((3,), i, np.float32) for i in range(30000)}
+    tb.write_bundle(str(tmp_path / "big"), big)
+    g2 = tb.read_bundle(str(tmp_path / "big"), names={"v/000000", "v/029999", "v/012345"})
+    assert float(g2["v/012345"][0]) == 12345.0 and len(g2) == 3
+    assert len(tb.read_table(str(tmp_path / "big.index"))) == 30001
+
+
+def test_tf_checkpoint_export_load_round_trip(tmp_path, built_lib):
+    """A model_dir as the reference's Estimators keep it: `checkpoint` state file + bundle keyed by the reference's variable
+    names; loading it into a freshly initialised module reproduces every parameter (incl. the transposed dense kernels)."""
+    from dir_amd import feature_column as fc, tf_bundle as tb
+    from dir_amd.checkpoint import export_tf_checkpoint, load_tf_checkpoint, export_serving, tf_variable_map
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd.deepfm import DeepFM
+
+    def dcn():
+        cols = ([fc.numeric_column(k) for k in ("age", "hours")] + [fc.indicator_column(fc.categorical_column_with_identity("wc", 9))]
+                + [fc.embedding_column(fc.categorical_column_with_hash_bucket("occ", 50), 8)])
+        return DeepCrossNetwork(columns=cols, cross_layer_num=2, dnn_hidden_units=[16, 8], batch_norm=True)
+
+    def deepfm():
+        cats = [fc.categorical_column_with_identity("C%d" % i, 20 + i) for i in range(3)]
+        return DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, 4) for c in cats], dnn_hidden_units=[8],
+                      fm_embedding_size=4, batch_norm=True)
+
+    for make in (dcn, deepfm):
+        torch.manual_seed(1)
+        a = make()
+        with torch.no_grad():
+            for p in a.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        mdir = str(tmp_path / make.__name__)
+        prefix = export_tf_checkpoint(a, mdir, global_step=77)
+        assert os.path.basename(prefix) == "model.ckpt-77" and tb.latest_checkpoint(mdir) == prefix
+        names = [k.decode() for k, _ in tb.read_table(prefix + ".index")][1:]
+        assert set(names) == set(tf_variable_map(a)) | {"global_step"}
+        torch.manual_seed(2)
+        b = make()
+        missing, step = load_tf_checkpoint(b, mdir)
+        assert missing == [] and step == 77
+        for (n1, p1), (n2, p2) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert n1 == n2 and torch.equal(p1, p2), n1
+        # TensorFlow layout on disk: dense kernels are [in, out]
+        raw = tb.read_bundle(prefix)
+        k = [n for n in raw if n.endswith("hidden_layer_0/kernel") or n.endswith("hiddenlayer_0/kernel")][0]
+        assert raw[k].shape == tuple(reversed(a.hidden[0].weight.shape))
+        exp = export_serving(a, str(tmp_path / (make.__name__ + "_export")), global_step=77)
+        import json
+        sig = json.load(open(os.path.join(exp, "serving_signature.json")))
+        assert sig["signature_def"]["serving_default"]["method_name"] == "tensorflow/serving/classify"
+        assert set(tb.read_bundle(os.path.join(exp, "variables", "variables"))) == set(raw)
