@@ -1,5 +1,7 @@
 """CPU tests of the host-side mirror of the reference interface (no GPU, no kernels): column shims, the
 features-dict -> id-layout assembly, DCN's name-sorted input layout, constructor/argument errors."""
+import os
+
 import numpy as np
 import pytest
 import torch
