@@ -97,7 +97,7 @@ def cpu_baseline(args, tables_host, ids_host):
     emb = np.zeros((B, F * K), np.float32)
     times = []
     t_all = time.perf_counter()
-    for p in range(3 + 200):
+    for p in range(3 + 100000):
         t0 = time.perf_counter()
         O.embedding_bag(tables_host, ids_host, out=emb)
         O.fm_second_order(emb, F, K)

@@ -230,7 +230,7 @@ __device__ __forceinline__ V clip_row(V row, float max_norm, int lane, int c) {
     return vdiv(vscale(row, max_norm), fmaxf(l2norm, max_norm));
 }
 
-template <int LPS, int VEC>
+template <int LPS, int VEC, bool CLIP>
 __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict__ tables,
                                                  const int64_t* __restrict__ vocab,
                                                  const int64_t* __restrict__ ids,
@@ -253,7 +253,6 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
     const bool cact = c < kv;
     const bool prune_w = (flags & DIR_BAG_PRUNE_NONPOSITIVE_WEIGHTS) != 0;
     const bool nt = (flags & DIR_GATHER_STREAM_ROWS) != 0;      // tables far beyond the Infinity Cache: rows bypass the caches
-    const bool clip = max_norm > 0.f;
     const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
         const int64_t b = g * SPW + s;
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
                     row[u] = vzero((V*)nullptr);
                     if (id0[u] >= 0 && cact) row[u] = nt ? ldv_nt(t + id0[u] * K + c * VEC, (V*)nullptr) : ldv(t + id0[u] * K + c * VEC, (V*)nullptr);
                 }
-                if (clip) {                              // wave-uniform branch; every lane takes part in the shuffles
+                if (CLIP) {                              // (a template parameter: the unclipped kernel carries none of this)
 #pragma unroll
                     for (int u = 0; u < U; ++u) row[u] = clip_row<LPS>(row[u], max_norm, lane, c);
                 }
@@ -474,8 +473,15 @@ static int launch_csr(const float* const* tables, const int64_t* vocab, int F, i
     const int spw = 64 / lps;
     const int64_t waves = (B + spw - 1) / spw;
     dim3 grid(grid_for((waves + 3) / 4));
-#define DIR_CASE(L, V) \
-    hipLaunchKernelGGL((bag_csr_k<L, V>), grid, dim3(256), 0, st, tables, vocab, ids, offsets, weights, sb, sf, F, K, B, slot_combiner, combiner, max_norm, flags, out, out_ld)
+#define DIR_CASE(L, V)                                                                                                              \
+    do {                                                                                                                            \
+        if (max_norm > 0.f)                                                                                                         \
+            hipLaunchKernelGGL((bag_csr_k<L, V, true>), grid, dim3(256), 0, st, tables, vocab, ids, offsets, weights, sb, sf, F, K, B, \
+                               slot_combiner, combiner, max_norm, flags, out, out_ld);                                              \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((bag_csr_k<L, V, false>), grid, dim3(256), 0, st, tables, vocab, ids, offsets, weights, sb, sf, F, K, B, \
+                               slot_combiner, combiner, max_norm, flags, out, out_ld);                                              \
+    } while (0)
     if (vec) {
         switch (lps) {
             case 1: DIR_CASE(1, 4); break;
