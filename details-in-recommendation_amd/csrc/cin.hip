@@ -50,7 +50,7 @@ template <int MT /* field count padded to an instantiated size: register arrays,
           int ICT = 0 /* i values per chunk; 0: cin_ic(MT) */>
 __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                 const float* __restrict__ W, int m /* actual fields, <= MT */, int Hp, int H,
-                                                int D, int dshift,
+                                                int D, int dshift, int hoff /* first output column of this launch */,
                                                 int64_t R /* B*D */,
                                                 float* __restrict__ xout,
                                                 float* __restrict__ pooled, int64_t pooled_ld) {
@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     constexpr int mp = (MT + 1) & ~1;
     constexpr int MP2 = mp / 2;
     constexpr int IC = ICT > 0 ? ICT : cin_ic(MT);
+    constexpr int CS = CT == 3 ? 4 : CT;  // column tiles STAGED: the W image holds 4 tile slots per column index, so a 3-tile block
+                                          // stages like a 4-tile one (same contiguous runs, same b128 operand reads) and computes 3
     constexpr int WS = CIN_WS;
     constexpr int WCH = IC * mp * WS;     // floats per W buffer
     constexpr int XCH = IC * CIN_ROWS;    // floats per xk buffer
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     unsigned long long st_a = 0, st_b = 0, st_pro = 0, st_t0 = 0, st_cnt = 0;
     if (STAMP) st_t0 = cin_now();
     const int64_t row0 = (int64_t)blockIdx.x * CIN_ROWS;   // first (b,d) row of this workgroup
-    const int hbase = blockIdx.y * (32 * CT);              // first output column of this workgroup
+    const int hbase = hoff + blockIdx.y * (32 * CT);       // first output column of this workgroup
     const int Kd = Hp * m;
 
     // ---- stage x0 slice: x0s[j][r] = x0[b, j, d] with (b,d) = row0 + r; thread tid owns row r = tid.  All loads
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     }
 
     // per-thread staging registers for the next chunk
-    constexpr int WE = (IC * MT * 32 * CT + 255) / 256;   // W elements per thread per chunk
+    constexpr int WE = (IC * MT * 32 * CS + 255) / 256;   // W elements per thread per chunk
     constexpr int XE = XCH / 256;                         // xk elements per thread per chunk (= IC)
     float wreg[WE];
     float xreg[XE];
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
             const int il = kkl / m;
             const int h = hbase + hl;
             float v = 0.f;
-            if (hl < 32 * CT && h < H && i0 + il < Hp) v = W[(int64_t)h * Kd + (int64_t)i0 * m + kkl];
+            if (hl < 32 * CS && h < H && i0 + il < Hp) v = W[(int64_t)h * Kd + (int64_t)i0 * m + kkl];
             wreg[q] = v;
         }
 #pragma unroll
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
             const int kkl = e - hl * (IC * m);
             const int il = kkl / m;
             const int j = kkl - il * m;
-            if (hl < 32 * CT) wb[(il * mp + j) * WS + (hl & 31) * 4 + (hl >> 5)] = wreg[q];
+            if (hl < 32 * CS) wb[(il * mp + j) * WS + (hl & 31) * 4 + (hl >> 5)] = wreg[q];
         }
         if (part < 0 || part == IC - 1) {
             float* xb = xks + buf * XCH;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     // TPR threads share one W row of the chunk (IC*m contiguous floats in global memory); a thread owns RL
     // consecutive floats of it: 16-byte global loads, and LDS destinations that differ from a per-thread base by
     // compile-time offsets only (no per-element address arithmetic inside the MFMA stream).
-    constexpr int TPR = 256 / (32 * CT);
+    constexpr int TPR = 256 / (32 * CS);
     constexpr bool FAST = FP;                          // the host only selects FP when cin_fast_shape<MT, CT>() holds
     constexpr int RL = FAST ? (IC * MT) / TPR : 4;
     constexpr bool VEC4 = FAST && (RL % 4 == 0) && ((IC * MT) % 4 == 0);
@@ -276,6 +278,9 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
                 if (CT == 4) {
                     const float4 v = *reinterpret_cast<const float4*>(src);
                     bo[ks][0] = v.x; bo[ks][1 % CT] = v.y; bo[ks][2 % CT] = v.z; bo[ks][3 % CT] = v.w;
+                } else if (CT == 3) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    bo[ks][0] = v.x; bo[ks][1 % CT] = v.y; bo[ks][2 % CT] = v.z;
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < CT; ++cc) bo[ks][cc] = src[cc];
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
 
 template <int MT, int CT, int IC = 0>
 constexpr bool cin_fast_shape() {   // a thread's contiguous run of a W row must be whole 16-byte (or 8-byte) loads
-    constexpr int TPR = 256 / (32 * CT);
+    constexpr int TPR = 256 / (32 * (CT == 3 ? 4 : CT));
     constexpr int N = (IC > 0 ? IC : cin_ic(MT)) * MT;
     constexpr int RL = N / TPR;
     return (N % TPR == 0) && ((RL % MT == 0) || (MT % RL == 0)) && ((RL % 4 == 0 && N % 4 == 0) || (RL % 2 == 0 && N % 2 == 0));
@@ -447,19 +452,19 @@ constexpr bool cin_fast_shape() {   // a thread's contiguous run of a W row must
 
 template <int MT, int CT, bool FP>
 static void launch_cin_one(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* W,
-                           int m, int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled,
+                           int m, int Hp, int H, int D, int dshift, int hoff, int64_t R, float* xout, float* pooled,
                            int64_t pooled_ld) {
     static bool set = false;
     if (!set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, FP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         set = true;
     }
-    hipLaunchKernelGGL((cin_k<MT, CT, FP>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    hipLaunchKernelGGL((cin_k<MT, CT, FP>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
 }
 
 template <int MT, int CT>
 static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* W,
-                          int m, int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled,
+                          int m, int Hp, int H, int D, int dshift, int hoff, int64_t R, float* xout, float* pooled,
                           int64_t pooled_ld) {
     // interleaved fast staging needs: a compatible (m, column-tile) shape, whole 16-byte aligned W rows and at
     // least one whole chunk; everything else takes the generic bulk staging
@@ -473,7 +478,7 @@ static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* 
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<26, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 set = true;
             }
-            hipLaunchKernelGGL((cin_k<26, 4, true, true>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+            hipLaunchKernelGGL((cin_k<26, 4, true, true>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
             return;
         }
     }
@@ -489,29 +494,30 @@ static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* 
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 set = true;
             }
-            hipLaunchKernelGGL((cin_k<MT, CT, true, false, 2>), grid, dim3(256), sh2, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+            hipLaunchKernelGGL((cin_k<MT, CT, true, false, 2>), grid, dim3(256), sh2, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
             return;
         }
     }
     if constexpr (cin_fast_shape<MT, CT>()) {
         if (fast_env && wvec && Hp >= cin_ic(MT)) {
-            launch_cin_one<MT, CT, true>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+            launch_cin_one<MT, CT, true>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
             return;
         }
     }
-    launch_cin_one<MT, CT, false>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
+    launch_cin_one<MT, CT, false>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
 }
 
 template <int MT>
 static int launch_cin(int ct, dim3 grid, hipStream_t st, const float* x0, const float* xk, const float* W, int m,
-                      int Hp, int H, int D, int dshift, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
+                      int Hp, int H, int D, int dshift, int hoff, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
     constexpr int mp = (MT + 1) & ~1;
     constexpr int IC = cin_ic(MT);
     const size_t shmem = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)IC * mp * CIN_WS + 2 * (size_t)IC * CIN_ROWS);
     switch (ct) {
-        case 1: launch_cin_ct<MT, 1>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
-        case 2: launch_cin_ct<MT, 2>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
-        default: launch_cin_ct<MT, 4>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld); break;
+        case 1: launch_cin_ct<MT, 1>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld); break;
+        case 2: launch_cin_ct<MT, 2>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld); break;
+        case 3: launch_cin_ct<MT, 3>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld); break;
+        default: launch_cin_ct<MT, 4>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld); break;
     }
     return 0;
 }
@@ -532,17 +538,31 @@ extern "C" int dir_cin_layer_f32(const float* x0, const float* xk, const float* 
     int dshift = 0;
     while ((1 << dshift) < D) ++dshift;
     const int64_t R = B * D;
-    int ct = (H + 31) / 32;
-    ct = ct >= 3 ? 4 : ct;                   // column tiles per workgroup: 1, 2 or 4
-    const int colblocks = (H + 32 * ct - 1) / (32 * ct);
-    dim3 grid((unsigned)((R + CIN_ROWS - 1) / CIN_ROWS), (unsigned)colblocks);
+    // Column blocks: a workgroup computes 1..4 tiles of 32 output columns.  H's tiles are split into 4-tile blocks plus ONE smaller
+    // block for the remainder (a lone remainder tile borrows from a 4-block: 4 + 1 -> 3 + 2), each block size its own launch, so
+    // H = 200 computes 224 columns (4 + 3 tiles), not 256.
+    const int nt = (H + 31) / 32;
+    int cnt[5] = {0, 0, 0, 0, 0};            // cnt[c] = number of c-tile blocks
+    if (nt <= 4) cnt[nt] = 1;
+    else {
+        cnt[4] = nt / 4;
+        const int r = nt % 4;
+        if (r == 1) { --cnt[4]; cnt[3] = 1; cnt[2] = 1; }
+        else if (r) cnt[r] = 1;
+    }
     hipStream_t st = as_stream(stream);
-    // the kernel is instantiated for padded field counts 8, 16, 26, 40; fields beyond m are zero operands
-    if (m <= 8) launch_cin<8>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
-    else if (m <= 16) launch_cin<16>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
-    else if (m <= 26) launch_cin<26>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
-    else if (m <= 40) launch_cin<40>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld);
-    else return fail(DIR_E_UNSUPPORTED, "dir_cin_layer_f32: field count m=%d exceeds 40", m);
+    int hoff = 0;
+    for (int ct = 4; ct >= 1; --ct) {
+        if (!cnt[ct]) continue;
+        dim3 grid((unsigned)((R + CIN_ROWS - 1) / CIN_ROWS), (unsigned)cnt[ct]);
+        // the kernel is instantiated for padded field counts 8, 16, 26, 40; fields beyond m are zero operands
+        if (m <= 8) launch_cin<8>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
+        else if (m <= 16) launch_cin<16>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
+        else if (m <= 26) launch_cin<26>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
+        else if (m <= 40) launch_cin<40>(ct, grid, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
+        else return fail(DIR_E_UNSUPPORTED, "dir_cin_layer_f32: field count m=%d exceeds 40", m);
+        hoff += 32 * ct * cnt[ct];
+    }
     DIR_CHECK_LAUNCH("cin_layer");
     return DIR_OK;
 }

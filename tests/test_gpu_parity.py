@@ -216,7 +216,10 @@ def test_din_attention_pool(ops, oracle, B, T, K, H1, H2, normalize):
                                          (10, 22, 16, 50, 128), (6, 40, 16, 2, 16), (5, 1, 4, 1, 8),
                                          # tails: half a chunk (fast clamped staging + half burst sequence) and others
                                          (20, 26, 16, 6, 128), (20, 26, 16, 10, 128), (11, 16, 16, 6, 64), (9, 8, 8, 14, 32),
-                                         (7, 40, 16, 3, 128), (7, 40, 16, 9, 128), (20, 26, 16, 5, 128), (20, 26, 16, 7, 128)])
+                                         (7, 40, 16, 3, 128), (7, 40, 16, 9, 128), (20, 26, 16, 5, 128), (20, 26, 16, 7, 128),
+                                         # column-block splits (csrc/cin.hip dir_cin_layer_f32): 3 | 3+2 | 4+2 | 4+3 | 4+3+2 | 4+4+3 tiles
+                                         (19, 26, 16, 26, 96), (19, 26, 16, 12, 70), (10, 26, 16, 8, 160), (10, 26, 16, 200, 200),
+                                         (6, 26, 16, 8, 190), (6, 16, 8, 8, 224), (5, 26, 16, 4, 270), (5, 8, 16, 6, 350), (7, 39, 16, 4, 90)])
 def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     rng = np.random.default_rng(Hp * 13 + H)
     x0 = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
