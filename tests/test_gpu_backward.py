@@ -283,7 +283,11 @@ def test_deepfm_fused_adagrad_matches_torch_adagrad(built_lib):
                                          (18, 13, 32, 50, 130), (250, 10, 4, 45, 64),
                                          # 128 < H, Hp <= 256: two slices of H per field, two column blocks adding their dx0 shares
                                          (19, 26, 16, 200, 200), (11, 8, 8, 130, 256), (9, 26, 4, 256, 129), (7, 5, 16, 129, 40),
-                                         (6, 4, 16, 20, 257)])
+                                         (6, 4, 16, 20, 257),
+                                         # tile counts that follow the widths (cin_bwd.hip): 3-tile column blocks (Hp 65..96, 193..224), slices
+                                         # of 96 rows (H 65..96) and 128 + 32/64/96/128, h blocks of 1 / 2 / 3 tiles in dW
+                                         (10, 26, 16, 70, 96), (10, 26, 16, 96, 70), (8, 8, 8, 200, 150), (8, 8, 8, 224, 190), (8, 8, 8, 100, 224),
+                                         (7, 26, 16, 160, 160), (7, 16, 4, 192, 225), (9, 12, 16, 40, 64), (9, 12, 16, 33, 33)])
 def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
     from dir_amd import ops
     from oracle import oracle as O
