@@ -12,11 +12,14 @@
 // v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain): lane l holds A[row l&31][k = l>>5] and
 // B[k = l>>5][col l&31]; the two k of one instruction are the field pair j = 2*jp + (l>>5).
 // A wave owns RT = 2 row tiles (64 rows = 4 samples at D = 16) x CT <= 4 column tiles (all H <= 128)
-// = 8 accumulators (128 VGPRs).  A 256-thread workgroup (one wave per SIMD) owns 256 rows.
+// = 8 accumulators (128 VGPRs).  A 256-thread workgroup (one wave per SIMD) owns 256 rows.  H's 32-column tiles are cut into
+// 4-tile blocks plus one smaller block (dir_cin_layer_f32: 200 columns = 4 + 3 tiles, one launch per block size); a 3-tile block
+// stages the 4-slot image and computes three tiles; a 1-tile block (H <= 32) has a quarter-size image and runs TWO workgroups
+// per CU, so that one's staging and operand reads issue under the other's MFMAs.
 //
 // LDS (one array, 16-byte aligned carve):
 //   x0s [mp][256]            the workgroup's x0 slice, transposed so that lanes read consecutive rows
-//   Ws  [2][IC*mp][32][4]    W chunk of IC values of i, transposed to [kk][n][cc] with h = 32*cc + n: the four
+//   Ws  [2][IC*mp][32][CS]   W chunk of IC values of i, transposed to [kk][n][cc] with h = 32*cc + n (CS = 1, 2 or 4 slots): the four
 //                            column-tile operands of a lane are ONE ds_read_b128 (LDS reads and VALU work are
 //                            not hidden behind fp32 MFMAs -- tools/mfma_probe2.hip -- so their count matters)
 //   xks [2][IC][256]         xk chunk
@@ -41,14 +44,14 @@ __device__ __forceinline__ unsigned long long cin_now() {
 
 constexpr int CIN_RT = 2;          // row tiles per wave
 constexpr int CIN_ROWS = 256;      // rows per workgroup = 4 waves * RT * 32
-constexpr int CIN_WS = 128;        // floats per kk row of the LDS W image: [32 n][4 cc]
+constexpr int cin_ws(int CT) { return 32 * (CT == 3 ? 4 : CT); }   // floats per kk row of the LDS W image: [32 n][1 | 2 | 4 cc]
 constexpr int CIN_KS = 2;          // k-steps per MFMA burst (one VALU/LDS cluster per burst)
 constexpr int cin_ic(int MT) { return MT > 26 ? 2 : 4; }   // i values per chunk (LDS: 2*IC*mp*129*4 B of W)
 
 template <int MT /* field count padded to an instantiated size: register arrays, unrolling */, int CT /* column tiles */,
           bool FP /* interleaved fast staging; needs m == MT */, bool STAMP = false /* diagnostic cycle stamps */,
           int ICT = 0 /* i values per chunk; 0: cin_ic(MT) */>
-__global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, const float* __restrict__ xk,
+__global__ __launch_bounds__(256, CT == 1 ? 2 : 1) void cin_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                 const float* __restrict__ W, int m /* actual fields, <= MT */, int Hp, int H,
                                                 int D, int dshift, int hoff /* first output column of this launch */,
                                                 int64_t R /* B*D */,
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     constexpr int IC = ICT > 0 ? ICT : cin_ic(MT);
     constexpr int CS = CT == 3 ? 4 : CT;  // column tiles STAGED: the W image holds 4 tile slots per column index, so a 3-tile block
                                           // stages like a 4-tile one (same contiguous runs, same b128 operand reads) and computes 3
-    constexpr int WS = CIN_WS;
+    constexpr int WS = cin_ws(CT);
     constexpr int WCH = IC * mp * WS;     // floats per W buffer
     constexpr int XCH = IC * CIN_ROWS;    // floats per xk buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
             const int kkl = e - hl * (IC * m);
             const int il = kkl / m;
             const int j = kkl - il * m;
-            if (hl < 32 * CS) wb[(il * mp + j) * WS + (hl & 31) * 4 + (hl >> 5)] = wreg[q];
+            if (hl < 32 * CS) wb[(il * mp + j) * WS + (hl & 31) * CS + (hl >> 5)] = wreg[q];
         }
         if (part < 0 || part == IC - 1) {
             float* xb = xks + buf * XCH;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
     // feeds output column h and an xk row >= R only feeds output row r, neither of which is ever stored.
     const float* wsrc = W + (int64_t)(srow_ok ? hbase + srow : 0) * Kd + spart * RL;
     const int sil0 = (spart * RL) / MT, sj0 = spart * RL - sil0 * MT;
-    const int wdst0 = (sil0 * mp + sj0) * WS + (srow & 31) * 4 + (srow >> 5);
+    const int wdst0 = (sil0 * mp + sj0) * WS + (srow & 31) * CS + (srow >> 5);
     constexpr bool fast_ok = FAST;
     auto fast_i0 = [&](int c) {   // first i of chunk c, clamped so that the loads stay inside W (a clamped
         const int i0 = c * IC;    // chunk is re-staged by the generic path afterwards)
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
         // irregular one by the generic bulk path after this chunk's MFMAs
         const bool next_bulk = more && (!fast_ok || (c + 2) * IC > Hp);
         const int i0n = fast_ok ? fast_i0(more ? c + 1 : c) : 0;
-        const float* wb = Ws + buf * WCH + hh * WS + n * 4;
+        const float* wb = Ws + buf * WCH + hh * WS + n * CS;
         const float* xb = xks + buf * XCH + wave * 64 + n;
         // One burst = KS k-steps = KS*RT*CT MFMAs issued back to back.  Everything else of those steps -- the LDS
         // operand reads for the NEXT burst (latency ~100 cycles vs >= 1000 cycles of MFMA issue), a few staging
@@ -281,9 +284,11 @@ __global__ __launch_bounds__(256, 1) void cin_k(const float* __restrict__ x0, co
                 } else if (CT == 3) {
                     const float4 v = *reinterpret_cast<const float4*>(src);
                     bo[ks][0] = v.x; bo[ks][1 % CT] = v.y; bo[ks][2 % CT] = v.z;
+                } else if (CT == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(src);
+                    bo[ks][0] = v.x; bo[ks][1 % CT] = v.y;
                 } else {
-#pragma unroll
-                    for (int cc = 0; cc < CT; ++cc) bo[ks][cc] = src[cc];
+                    bo[ks][0] = src[0];
                 }
 #pragma unroll
                 for (int t = 0; t < CIN_RT; ++t)
@@ -447,7 +452,8 @@ constexpr bool cin_fast_shape() {   // a thread's contiguous run of a W row must
     constexpr int TPR = 256 / (32 * (CT == 3 ? 4 : CT));
     constexpr int N = (IC > 0 ? IC : cin_ic(MT)) * MT;
     constexpr int RL = N / TPR;
-    return (N % TPR == 0) && ((RL % MT == 0) || (MT % RL == 0)) && ((RL % 4 == 0 && N % 4 == 0) || (RL % 2 == 0 && N % 2 == 0));
+    // (a 1-tile block takes the interleaved staging with scalar loads too: its two workgroups per CU hide them)
+    return (N % TPR == 0) && ((RL % MT == 0) || (MT % RL == 0)) && ((RL % 4 == 0 && N % 4 == 0) || (RL % 2 == 0 && N % 2 == 0) || CT == 1);
 }
 
 template <int MT, int CT, bool FP>
@@ -488,7 +494,7 @@ static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* 
         const bool w8 = m == MT && ((int64_t)Hp * MT) % 2 == 0 && (reinterpret_cast<uintptr_t>(W) & 7u) == 0;
         if (fast_env && w8 && Hp % 4 != 0 && Hp % 2 == 0) {
             constexpr int mp = (MT + 1) & ~1;
-            const size_t sh2 = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)2 * mp * CIN_WS + 2 * (size_t)2 * CIN_ROWS);
+            const size_t sh2 = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)2 * mp * cin_ws(CT) + 2 * (size_t)2 * CIN_ROWS);
             static bool set = false;
             if (!set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -512,7 +518,7 @@ static int launch_cin(int ct, dim3 grid, hipStream_t st, const float* x0, const 
                       int Hp, int H, int D, int dshift, int hoff, int64_t R, float* xout, float* pooled, int64_t pooled_ld) {
     constexpr int mp = (MT + 1) & ~1;
     constexpr int IC = cin_ic(MT);
-    const size_t shmem = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)IC * mp * CIN_WS + 2 * (size_t)IC * CIN_ROWS);
+    const size_t shmem = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)IC * mp * cin_ws(ct) + 2 * (size_t)IC * CIN_ROWS);
     switch (ct) {
         case 1: launch_cin_ct<MT, 1>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld); break;
         case 2: launch_cin_ct<MT, 2>(grid, shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld); break;
