@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--id-layout", default="bf", choices=["bf", "fb"], help="ids stored [B,F] or [F,B]")
     ap.add_argument("--rotate", type=int, default=4, help="distinct id batches rotated through")
     ap.add_argument("--adagrad-method", default="sorted", choices=["sorted", "chains"], help="train_sparse: SparseAdagrad method")
+    ap.add_argument("--train-layout", default="packed", choices=["packed", "split", "split_unfused"],
+                    help="train_sparse: packed = [embedding | accumulator] rows + FM backward folded into the update; split = separate "
+                         "[V,K] tables and accumulators (the reference's variable layout) with the fold; split_unfused = round 1's path")
     ap.add_argument("--cross-d", type=int, default=416, help="dcn_cross / dcn_cross_backward: row width (416 = 26 x 16; 429 with the 13 dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -354,25 +357,38 @@ def main():
         # gather + FM forward, FM backward (+ the DNN branch's gradient), fused sparse Adagrad on the 26 tables
         sigma = 1.0 / (K ** 0.5)
         tables = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
-        ts = ops.TableSet(tables)
+        layout = args.train_layout if args.adagrad_method == "sorted" else "split_unfused"
+        ts = ops.TableSet.train_rows(tables) if layout == "packed" else ops.TableSet(tables)
+        del tables
         opt = ops.SparseAdagrad(ts, lr=0.01, method=args.adagrad_method)
         idsl = make_ids(torch, args, gen, device, V)
         out = torch.empty((B, F * K), dtype=torch.float32, device=device)
         fm = torch.empty((B, 1), dtype=torch.float32, device=device)
+        fsum = torch.empty((B, K), dtype=torch.float32, device=device)
         gfm = torch.randn((B, 1), generator=gen, device=device) * 0.01
         gdnn = torch.randn((B, F * K), generator=gen, device=device) * 0.01
         demb = torch.empty_like(out)
 
-        def step(i):
-            ids = idsl[i % len(idsl)]
-            ops.gather_fm(ts, ids, out=out, fm=fm)
-            ops.fm_logit_backward(out, gfm, F, K, add_in=gdnn, out=demb)
-            opt.step(ids, demb)
+        if layout == "split_unfused":
+            def step(i):
+                ids = idsl[i % len(idsl)]
+                ops.gather_fm(ts, ids, out=out, fm=fm)
+                ops.fm_logit_backward(out, gfm, F, K, add_in=gdnn, out=demb)
+                opt.step(ids, demb)
+        else:
+            def step(i):
+                ids = idsl[i % len(idsl)]
+                ops.gather_fm(ts, ids, out=out, fm=fm, fsum=fsum)
+                opt.step_fm(ids, gdnn, gfm, fsum)
         # forward 3 540 B + FM backward (emb, dnn grad read, demb written) + adagrad (ids, demb, w and accum read+write)
-        roof = {"bound": "hbm", "alg_bytes": B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)),
-                "kernel": "gather_onehot_k + fm_bwd_k + " + ("adagrad_keys_k + rocprim radix sort + adagrad_tile_k + adagrad_fix_k"
-                                                            if args.adagrad_method == "sorted" else "adagrad_link_k + adagrad_apply_k")}
-        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "adagrad": args.adagrad_method, "ids": args.id_dist})
+        # folded: forward + field sums written, then per entry ids, sort key/value, DNN gradient row, w and accum read + write
+        alg = (B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)) if layout == "split_unfused" else
+               B * ((F * (8 + 8 * K) + 4) + 4 * K + F * (8 + 4 + 4 * K + 4 * 4 * K)))
+        roof = {"bound": "hbm", "alg_bytes": alg,
+                "kernel": ("gather_onehot_k + fm_bwd_k + " if layout == "split_unfused" else "gather_packed_rows_k (+ field sums) + ") +
+                          ("adagrad_keys_k + rocprim radix sort + adagrad_tile_k" + ("" if layout == "split_unfused" else "<FM folded in>") +
+                           " + adagrad_fix_k" if args.adagrad_method == "sorted" else "adagrad_link_k + adagrad_apply_k")}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "adagrad": args.adagrad_method, "ids": args.id_dist, "layout": layout})
     elif wl == "multihot_bag":
         # weighted variable-length bags (dataset/SequenceTensorFlowDataset/test4.py:50-59 style input): per
         # (sample, field) a bag of 0..8 ids with fp32 weights, combiner "mean", CSR sample-major

@@ -25,6 +25,7 @@ SIGNATURES = {
     "dir_gather_fm_fused_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dir_gather_fm_linear_packed_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64,
                                                 c_vp, c_vp, c_vp, c_vp]),
+    "dir_gather_fm_rows_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_linear_sparse_sum_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64,
                                           c_vp, c_vp]),
     "dir_dcn_cross_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp]),
@@ -48,6 +49,8 @@ SIGNATURES = {
     "dir_sparse_adagrad_sorted_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i64]),
     "dir_sparse_adagrad_sorted_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.c_float, c_i64,
                                               c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "dir_sparse_adagrad_sorted_rows_f32": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
+                                                   ctypes.c_float, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_sparse_adagrad_sorted_payload_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, ctypes.c_float, c_vp, c_i64, c_vp,
                                                       c_i64, c_vp]),
     "dir_sparse_ftrl_sorted_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, ctypes.c_float,

@@ -32,9 +32,18 @@ class GatherFm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ts, ids, *tables):
-        emb, fm = ops.gather_fm(ts, ids)
         ctx.ts = ts
-        ctx.save_for_backward(ids, emb)
+        ctx.fused = ts.fm_sink is not None
+        if ctx.fused:
+            # a fused optimiser that also takes the FM backward (ops.SparseAdagrad.step_fm): keep the [B, K] field sums, not emb
+            fsum = torch.empty((ids.shape[0], ts.K), dtype=torch.float32, device=ts.device)
+            emb, fm = ops.gather_fm(ts, ids, fsum=fsum)
+            ctx.save_for_backward(ids, fsum)
+        else:
+            if ts.ld != ts.K:
+                raise ValueError("packed training rows train through a fused optimiser (ops.SparseAdagrad(...).attach())")
+            emb, fm = ops.gather_fm(ts, ids)
+            ctx.save_for_backward(ids, emb)
         return emb, fm
 
     @staticmethod
@@ -42,6 +51,13 @@ class GatherFm(torch.autograd.Function):
         ids, emb = ctx.saved_tensors
         ts = ctx.ts
         F, K = ts.F, ts.K
+        if ctx.fused:
+            add_in = g_emb.contiguous() if g_emb is not None else None
+            if g_fm is not None:
+                ts.fm_sink(ids, add_in, g_fm.contiguous(), emb)      # emb slot holds the field sums here
+            elif add_in is not None:
+                ts.grad_sink(ids, add_in)
+            return (None, None) + (None,) * F
         add_in = g_emb.contiguous() if g_emb is not None else None
         if g_fm is not None:
             demb = ops.fm_logit_backward(emb, g_fm.contiguous(), F, K, add_in=add_in)      # HIP: FM + DNN branch, one pass

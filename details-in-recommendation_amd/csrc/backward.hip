@@ -18,6 +18,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "common.hpp"
+#include <type_traits>
 
 namespace dir {
 
@@ -421,9 +422,11 @@ struct AdagradUpd {   // accum += g^2; w -= lr * g / sqrt(accum)   ([TF-upstream
     float* const* tables;
     float* const* accums;
     float lr;
+    int64_t ld;            // floats between consecutive rows of a table / accumulator (K, or 2K for the packed [w | accum] rows)
     template <int VEC>
-    __device__ __forceinline__ void apply(int f, int64_t off, typename BV<VEC>::T g) const {
+    __device__ __forceinline__ void apply(int f, int64_t id, int col, typename BV<VEC>::T g) const {
         using V = BV<VEC>;
+        const int64_t off = id * ld + col;
         float* ap = accums[f] + off;
         float* wp = tables[f] + off;
         typename V::T acc = V::ld(ap), wv = V::ld(wp);
@@ -445,6 +448,7 @@ struct FtrlUpd {      // FTRL-Proximal, learning_rate_power = -0.5 ([TF-upstream
     float* const* accums;    // n
     float* const* linears;   // z
     float lr, l1, l2;
+    int64_t ld;
     __device__ __forceinline__ void one(float g, float& n, float& z, float& w) const {
         const float n_new = n + g * g;
         const float sigma = (sqrtf(n_new) - sqrtf(n)) / lr;
@@ -456,8 +460,9 @@ struct FtrlUpd {      // FTRL-Proximal, learning_rate_power = -0.5 ([TF-upstream
         z = z_new;
     }
     template <int VEC>
-    __device__ __forceinline__ void apply(int f, int64_t off, typename BV<VEC>::T g) const {
+    __device__ __forceinline__ void apply(int f, int64_t id, int col, typename BV<VEC>::T g) const {
         using V = BV<VEC>;
+        const int64_t off = id * ld + col;
         float* np_ = accums[f] + off;
         float* zp = linears[f] + off;
         float* wp = tables[f] + off;
@@ -473,13 +478,15 @@ struct FtrlUpd {      // FTRL-Proximal, learning_rate_power = -0.5 ([TF-upstream
     }
 };
 
-template <int LPS, int VEC, class U>
+template <int LPS, int VEC, class U, bool FM = false>
 __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
                                                       int64_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                       const float* __restrict__ grad, int64_t g_ld, int64_t g_fs /* grad stride per slot */,
                                                       const int64_t* __restrict__ row_base, uint32_t total_rows,
                                                       int nt /* > 0: payload mode, the table is found from the key among nt tables */,
-                                                      float* __restrict__ carry /* [tiles][2][K] */) {
+                                                      float* __restrict__ carry /* [tiles][2][K] */,
+                                                      const float* __restrict__ fm_g = nullptr /* FM: d loss / d fm_logit [B] */,
+                                                      const float* __restrict__ fm_sum = nullptr /* FM: S[b] = sum_f e[b,f], [B, K] */) {
     using V = BV<VEC>;
     using T = typename V::T;
     constexpr int NG = 256 / LPS;
@@ -507,17 +514,54 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
     const bool cont_l = t > 0 && keys[e0 - 1] == skey[0];
     const bool cont_r = e0 + ne < n && keys[e0 + ne] == skey[ne - 1];
     const int g = tid / LPS, c = tid - g * LPS, kv = K / VEC;
+    // Phase 1 (rows up to 32 floats): every entry's gradient chunk is formed by its own thread group -- all global loads of the tile
+    // in flight at once -- and parked in LDS; phase 2 then walks each run over LDS, in entry order (the same sums bit for bit).
+    // (A hot row's run was a serial chain of HBM round trips before.)
+    constexpr bool STAGE = LPS * VEC <= 32;
+    __shared__ __attribute__((aligned(16))) float sd[STAGE ? ADA_TILE * LPS * VEC : 4];
+    auto entry_grad = [&](int i, T wv, bool have_w) {
+        const uint32_t ent = sval[i];
+        const uint32_t b = ent / (uint32_t)F;
+        const int f = (int)(ent - b * (uint32_t)F);
+        if constexpr (FM) {
+            // the FM backward folded in (fm_bwd_k's arithmetic, so the row sums are the unfused path's bit for bit): entry (b, f)'s
+            // gradient is (S[b] - e) * g[b] + grad[b, f], and e IS the entry's table row
+            if (!have_w) wv = V::ld(upd.tables[f] + ((int64_t)skey[i] - row_base[f]) * upd.ld + c * VEC);
+            T d = V::scale(V::sub(V::ld(fm_sum + (int64_t)b * K + c * VEC), wv), fm_g[b]);
+            if (grad) d = V::add(d, V::ld(grad + (int64_t)b * g_ld + (int64_t)f * g_fs + c * VEC));
+            return d;
+        } else {
+            return V::ld(grad + (int64_t)b * g_ld + (int64_t)f * g_fs + c * VEC);
+        }
+    };
+    // a tile of (nearly) distinct rows has nothing serial to hide: it skips the LDS round trip (workgroup-uniform choice)
+    const bool staged = STAGE && ne - nruns >= 8;
+    if (staged) {
+#pragma unroll
+        for (int q = 0; q < LPS; ++q) {                     // ADA_TILE / NG = LPS entries per group
+            const int i = g + q * NG;
+            if (i < ne && c < kv && skey[i] < total_rows) V::st(sd + i * (LPS * VEC) + c * VEC, entry_grad(i, V::zero(), false));
+        }
+        __syncthreads();
+    }
     for (int r = g; r < nruns; r += NG) {
         const int s = rstart[r], e = rstart[r + 1];
         const uint32_t rk = skey[s];
         if (rk >= total_rows || c >= kv) continue;          // pruned ids / idle lanes of a padded group
         T sum = V::zero();
-        int f = 0;
-        for (int i = s; i < e; ++i) {
-            const uint32_t ent = sval[i];
-            const uint32_t b = ent / (uint32_t)F;
-            f = (int)(ent - b * (uint32_t)F);
-            sum = V::add(sum, V::ld(grad + (int64_t)b * g_ld + (int64_t)f * g_fs + c * VEC));
+        int f = (int)(sval[s] % (uint32_t)F);
+        if (staged) {
+            for (int i = s; i < e; ++i) sum = V::add(sum, V::ld(sd + i * (LPS * VEC) + c * VEC));
+        } else {
+            T wv = V::zero();
+            if constexpr (FM) wv = V::ld(upd.tables[f] + ((int64_t)rk - row_base[f]) * upd.ld + c * VEC);
+            int i = s;
+            for (; i + 4 <= e; i += 4) {                    // four entries' loads in flight before their (ordered) adds
+                const T d0 = entry_grad(i, wv, true), d1 = entry_grad(i + 1, wv, true), d2 = entry_grad(i + 2, wv, true),
+                        d3 = entry_grad(i + 3, wv, true);
+                sum = V::add(V::add(V::add(V::add(sum, d0), d1), d2), d3);
+            }
+            for (; i < e; ++i) sum = V::add(sum, entry_grad(i, wv, true));
         }
         if (nt > 0) {                                      // payload mode: entries carry no slot; row_base is ascending
             f = 0;
@@ -526,7 +570,7 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
         const bool open_l = r == 0 && cont_l, open_r = r == nruns - 1 && cont_r;
         if (!open_l && !open_r) {
             const int64_t id = (int64_t)rk - row_base[f];
-            upd.template apply<VEC>(f, id * K + c * VEC, sum);
+            upd.template apply<VEC>(f, id, c * VEC, sum);
         } else {
             V::st(carry + (t * 2 + (open_l ? 0 : 1)) * K + c * VEC, sum);   // a run open on both sides goes to slot 0
         }
@@ -565,7 +609,20 @@ __global__ __launch_bounds__(256) void adagrad_fix_k(U upd, int F, int K,
         for (int q = 1; q < nt; ++q) f += (int64_t)kl >= row_base[q] ? 1 : 0;
     }
     const int64_t id = (int64_t)kl - row_base[f];
-    upd.template apply<VEC>(f, id * K + c * VEC, sum);
+    upd.template apply<VEC>(f, id, c * VEC, sum);
+}
+
+// The (row, entry) sort.  rocprim's default onesweep configuration sorts 8 bits per pass: 4 passes for the 25-bit keys of the
+// BASELINE shape (26 x 1 M rows), each ~28 us of mostly fixed cost at 1.7 M pairs.  9 bits per pass (match ranking, 1024 x 8 tiles)
+// needs 3: 144 -> 90 us (tools/sort_probe.hip).  Used whenever it saves a pass; the result is the same stable sort.
+using AdaSort9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 9,
+                                                                                rocprim::block_radix_rank_algorithm::match>, 0>;
+static hipError_t ada_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* k0, uint32_t* k1, const uint32_t* v0, uint32_t* v1, size_t n,
+                                 unsigned bits, hipStream_t st) {
+    if (n >= ((size_t)1 << 18) && (bits + 8) / 9 < (bits + 7) / 8)     // (small inputs keep the library's own choice of algorithm)
+        return rocprim::radix_sort_pairs<AdaSort9>(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, bits, st);
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, bits, st);
 }
 
 struct AdaSortedPlan { size_t n, ntiles, off_keys[2], off_vals[2], off_carry, off_tmp, tmp_bytes, total; unsigned bits; };
@@ -581,8 +638,7 @@ static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedP
     p.off_vals[0] = take(p.n * 4); p.off_vals[1] = take(p.n * 4);
     p.off_carry = take(p.ntiles * 2 * (size_t)K * 4);
     size_t tmp = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  p.n, 0u, bits, (hipStream_t)0) != hipSuccess)
+    if (ada_sort_pairs(nullptr, tmp, nullptr, nullptr, nullptr, nullptr, p.n, bits, (hipStream_t)0) != hipSuccess)
         return false;
     p.tmp_bytes = tmp;
     p.off_tmp = take(tmp ? tmp : 256);
@@ -604,7 +660,8 @@ template <class U>
 static int sparse_sorted_update(const char* name, U upd, int F, int K, const int64_t* ids, int64_t stride_b, int64_t stride_f,
                                 const float* grad, int64_t grad_ld, int64_t grad_fs, int64_t B, const int64_t* row_base,
                                 int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
-                                const int64_t* payload = nullptr /* payload mode: B entries, ids unused, grad is [B, K] */) {
+                                const int64_t* payload = nullptr /* payload mode: B entries, ids unused, grad is [B, K] */,
+                                const float* fm_g = nullptr, const float* fm_sum = nullptr /* fold the FM backward in (AdagradUpd only) */) {
     const int nt = payload ? F : 0;        // tables to search by key
     if (payload) {                         // entries are a flat list: one "slot" per entry
         ids = payload;
@@ -612,7 +669,7 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
     }
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "%s: bad shape", name);
     if (B == 0) return DIR_OK;
-    DIR_CHECK_ARG(ids && grad && row_base && workspace, "%s: null pointer", name);
+    DIR_CHECK_ARG(ids && (grad || fm_g) && row_base && workspace, "%s: null pointer", name);
     if (B * F >= 0x7fffffffll) return fail(DIR_E_UNSUPPORTED, "%s: B*F must fit int32", name);
     if (total_rows <= 0 || total_rows >= 0xffffffffll) return fail(DIR_E_UNSUPPORTED, "%s: total_rows must be in [1, 2^32-1)", name);
     const int64_t n = B * F;
@@ -635,9 +692,9 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
                            (uint32_t)total_rows, k0, v0);
     DIR_CHECK_LAUNCH(name);
     size_t tmp = p.tmp_bytes;
-    if (rocprim::radix_sort_pairs(ws + p.off_tmp, tmp, (const uint32_t*)k0, k1, (const uint32_t*)v0, v1, (size_t)n, 0u, p.bits, st) != hipSuccess)
+    if (ada_sort_pairs(ws + p.off_tmp, tmp, k0, k1, v0, v1, (size_t)n, p.bits, st) != hipSuccess)
         return fail(DIR_E_HIP, "%s: radix sort failed", name);
-    const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && (grad_fs % 4 == 0) && aligned16(grad);
+    const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && (grad_fs % 4 == 0) && aligned16(grad) && (!fm_sum || aligned16(fm_sum));
     int lps = 1;
     while (lps < (vec ? K / 4 : K)) lps <<= 1;
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "%s: K=%d too wide", name, K);
@@ -645,8 +702,14 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
     dim3 gfix((unsigned)((ntiles * lps + 255) / 256));
 #define DIR_CASE(L, V)                                                                                                         \
     do {                                                                                                                       \
-        hipLaunchKernelGGL((adagrad_tile_k<L, V, U>), dim3((unsigned)ntiles), dim3(256), 0, st, upd, F, K, n, k1, v1, grad, grad_ld, \
-                           grad_fs, row_base, (uint32_t)total_rows, nt, carry);                                                 \
+        if constexpr (std::is_same<U, AdagradUpd>::value) {                                                                    \
+            if (fm_g)                                                                                                          \
+                hipLaunchKernelGGL((adagrad_tile_k<L, V, U, true>), dim3((unsigned)ntiles), dim3(256), 0, st, upd, F, K, n, k1, v1, grad, \
+                                   grad_ld, grad_fs, row_base, (uint32_t)total_rows, nt, carry, fm_g, fm_sum);                  \
+        }                                                                                                                      \
+        if (!fm_g)                                                                                                             \
+            hipLaunchKernelGGL((adagrad_tile_k<L, V, U>), dim3((unsigned)ntiles), dim3(256), 0, st, upd, F, K, n, k1, v1, grad, grad_ld, \
+                               grad_fs, row_base, (uint32_t)total_rows, nt, carry);                                             \
         hipLaunchKernelGGL((adagrad_fix_k<L, V, U>), gfix, dim3(256), 0, st, upd, F, K, n, ntiles, k1, v1, row_base,             \
                            (uint32_t)total_rows, nt, carry);                                                                    \
     } while (0)
@@ -682,8 +745,22 @@ extern "C" int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const*
                                              int64_t workspace_bytes, dir_stream_t stream) {
     DIR_CHECK_ARG(tables && accums, "dir_sparse_adagrad_sorted_f32: null pointer");
     DIR_CHECK_ARG(grad_ld >= (int64_t)F * K, "dir_sparse_adagrad_sorted_f32: grad_ld");
-    return sparse_sorted_update("dir_sparse_adagrad_sorted_f32", AdagradUpd{tables, accums, lr}, F, K, ids, stride_b, stride_f, grad,
+    return sparse_sorted_update("dir_sparse_adagrad_sorted_f32", AdagradUpd{tables, accums, lr, (int64_t)K}, F, K, ids, stride_b, stride_f, grad,
                                 grad_ld, (int64_t)K, B, row_base, total_rows, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dir_sparse_adagrad_sorted_rows_f32(float* const* tables, float* const* accums, int64_t row_ld, int F, int K,
+                                                  const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad,
+                                                  int64_t grad_ld, const float* fm_g, const float* fm_sum, float lr, int64_t B,
+                                                  const int64_t* row_base, int64_t total_rows, void* workspace,
+                                                  int64_t workspace_bytes, dir_stream_t stream) {
+    DIR_CHECK_ARG(tables && accums, "dir_sparse_adagrad_sorted_rows_f32: null pointer");
+    DIR_CHECK_ARG(row_ld >= K && (!grad || grad_ld >= (int64_t)F * K), "dir_sparse_adagrad_sorted_rows_f32: row_ld / grad_ld");
+    DIR_CHECK_ARG((fm_g == nullptr) == (fm_sum == nullptr), "dir_sparse_adagrad_sorted_rows_f32: fm_g and fm_sum go together");
+    if (K % 4 == 0 && (row_ld & 3)) return fail(DIR_E_UNSUPPORTED, "dir_sparse_adagrad_sorted_rows_f32: row_ld must be a multiple of 4");
+    return sparse_sorted_update("dir_sparse_adagrad_sorted_rows_f32", AdagradUpd{tables, accums, lr, row_ld}, F, K, ids, stride_b, stride_f,
+                                grad, grad ? grad_ld : (int64_t)F * K, (int64_t)K, B, row_base, total_rows, workspace, workspace_bytes, stream,
+                                nullptr, fm_g, fm_sum);
 }
 
 extern "C" int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* accums, float* const* linears, int F, int K,
@@ -692,7 +769,7 @@ extern "C" int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* ac
                                           int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     DIR_CHECK_ARG(tables && accums && linears, "dir_sparse_ftrl_sorted_f32: null pointer");
     DIR_CHECK_ARG(lr > 0.f && l1 >= 0.f && l2 >= 0.f, "dir_sparse_ftrl_sorted_f32: lr=%g l1=%g l2=%g", lr, l1, l2);
-    return sparse_sorted_update("dir_sparse_ftrl_sorted_f32", FtrlUpd{tables, accums, linears, lr, l1, l2}, F, K, ids, stride_b,
+    return sparse_sorted_update("dir_sparse_ftrl_sorted_f32", FtrlUpd{tables, accums, linears, lr, l1, l2, (int64_t)K}, F, K, ids, stride_b,
                                 stride_f, grad, grad_ld, grad_slot_stride, B, row_base, total_rows, workspace, workspace_bytes, stream);
 }
 
@@ -867,6 +944,6 @@ extern "C" int dir_sparse_adagrad_sorted_payload_f32(float* const* tables, float
                                                      int64_t total_rows, void* workspace, int64_t workspace_bytes,
                                                      dir_stream_t stream) {
     DIR_CHECK_ARG(tables && accums && (payload || n == 0), "dir_sparse_adagrad_sorted_payload_f32: null pointer");
-    return sparse_sorted_update("dir_sparse_adagrad_sorted_payload_f32", AdagradUpd{tables, accums, lr}, F, K, nullptr, 0, 0, grad,
+    return sparse_sorted_update("dir_sparse_adagrad_sorted_payload_f32", AdagradUpd{tables, accums, lr, (int64_t)K}, F, K, nullptr, 0, 0, grad,
                                 (int64_t)K, 0, n, row_base, total_rows, workspace, workspace_bytes, stream, payload);
 }

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
                                                             int F, int K, int64_t ld, int lin_col, int64_t B,
                                                             float* __restrict__ out, int64_t out_ld,
                                                             float* __restrict__ fm, const float* __restrict__ bias,
-                                                            float* __restrict__ lin_out) {
+                                                            float* __restrict__ lin_out,
+                                                            float* __restrict__ fsum /* [B, K] field sums S[b] = sum_f e[b,f] or NULL */) {
     constexpr int SPW = 64 / LPS;
     const int lane = threadIdx.x & 63;
     const int c = lane & (LPS - 1);
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
                 }
             }
         }
+        if (fsum && act) stv(fsum + b * K + c * 4, sum);     // f-ascending fp32 sums: the S of the FM backward, bit for bit
         if (fm) {
             const float r = fm_tail<LPS>(sum, sq, lane, c);
             if (c == LPS - 1 && b < B) fm[b] = r;
@@ -602,13 +604,13 @@ extern "C" int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, co
     return DIR_OK;
 }
 
-extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
-                                               const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
-                                               int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
-                                               float* lin_out, dir_stream_t stream) {
+static int gather_packed_launch(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                                const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
+                                int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
+                                float* lin_out, float* fsum, dir_stream_t stream) {
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && ld >= K && lin_col < ld, "dir_gather_fm_linear_packed_f32: F=%d K=%d ld=%lld lin_col=%d", F, K, (long long)ld, lin_col);
     if (B == 0) return DIR_OK;
-    DIR_CHECK_ARG(tables && ids && (out || fm || lin_out), "dir_gather_fm_linear_packed_f32: null pointer");
+    DIR_CHECK_ARG(tables && ids && (out || fm || lin_out || fsum), "dir_gather_fm_linear_packed_f32: null pointer");
     DIR_CHECK_ARG(!out || out_ld >= (int64_t)F * K, "dir_gather_fm_linear_packed_f32: out_ld");
     if ((K & 3) || (ld & 3) || (out && ((out_ld & 3) || !aligned16(out))))
         return fail(DIR_E_UNSUPPORTED, "dir_gather_fm_linear_packed_f32: K, ld, out_ld must be multiples of 4 and out 16-byte aligned");
@@ -623,7 +625,7 @@ extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, const
     do {                                                                                                        \
         dim3 grid(grid_resident(work, resident_blocks(gather_packed_rows_k<L, 13, NTV>)));                     \
         hipLaunchKernelGGL((gather_packed_rows_k<L, 13, NTV>), grid, dim3(256), 0, st, tables, vocab, ids, stride_b, stride_f, F, K, ld, \
-                           lin_col, B, out, out_ld, fm, bias, lin_out);                                        \
+                           lin_col, B, out, out_ld, fm, bias, lin_out, fsum);                                        \
     } while (0)
 #define DIR_L(L) do { if (nt) DIR_GO(L, true); else DIR_GO(L, false); } while (0)
     switch (lps) {
@@ -637,4 +639,17 @@ extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, const
 #undef DIR_GO
     DIR_CHECK_LAUNCH("gather_fm_linear_packed");
     return DIR_OK;
+}
+
+extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                                               const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
+                                               int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
+                                               float* lin_out, dir_stream_t stream) {
+    return gather_packed_launch(tables, vocab, F, K, ld, lin_col, ids, stride_b, stride_f, flags, B, out, out_ld, fm, bias, lin_out, nullptr, stream);
+}
+
+extern "C" int dir_gather_fm_rows_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, const int64_t* ids,
+                                      int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out, int64_t out_ld,
+                                      float* fm, float* fsum, dir_stream_t stream) {
+    return gather_packed_launch(tables, vocab, F, K, ld, -1, ids, stride_b, stride_f, flags, B, out, out_ld, fm, nullptr, nullptr, fsum, stream);
 }

@@ -250,10 +250,20 @@ class DeepFM(nn.Module):
             return weighted_softmax_cross_entropy(logits, labels, w, red)
         return weighted_sigmoid_cross_entropy(logits, labels, w, red)
 
-    def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
+    def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1, packed=False):
         """Attach the fused HIP sparse-Adagrad update to the embedding tables (the reference trains them with
-        dnn_optimizer='Adagrad', deepFM.py:61): backward() then updates them in place, with duplicate ids summed first."""
+        dnn_optimizer='Adagrad', deepFM.py:61): backward() then updates them in place, with duplicate ids summed first, and
+        the FM term's backward is folded into the update.  packed=True moves the tables into the packed training layout
+        (ops.TableSet.train_rows: [embedding | accumulator] rows, one memory line per row and its optimiser state at K = 16);
+        the embedding parameters become [vocab, K] views of it -- same values, same checkpoints, one-hot columns only."""
         emb_ts, _ = self._tablesets()
+        if packed:
+            if emb_ts.ld == emb_ts.K:
+                emb_ts = ops.TableSet.train_rows([p.data for p in self.embedding_weights], initial_accumulator_value)
+                for p, view in zip(self.embedding_weights, emb_ts.tables):
+                    p.data = view
+                self._emb_ts = emb_ts
+                self._ts_key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
         return ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()
 
     def fused_sparse_ftrl(self, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0):

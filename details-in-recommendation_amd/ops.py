@@ -48,15 +48,17 @@ class TableSet:
     kernels read table f's base with a scalar load).  Mirrors the per-column `embedding_weights`
     variables created under myself_input_layer (deepFM.py:386-390)."""
 
-    def __init__(self, tables):
+    def __init__(self, tables, ld=None):
         tables = list(tables)
         if not tables:
             raise ValueError("empty columns.")  # deepFM.py:104-105
         K = tables[0].shape[-1] if tables[0].dim() == 2 else 1
         for i, t in enumerate(tables):
             _dev(t, torch.float32, "table %d" % i)
-            if not t.is_contiguous():
+            if ld is None and not t.is_contiguous():
                 raise ValueError("table %d must be contiguous" % i)
+            if ld is not None and (t.dim() != 2 or tuple(t.stride()) != (ld, 1)):
+                raise ValueError("table %d must be a [vocab, K] view with row stride %d" % (i, ld))
             k = t.shape[-1] if t.dim() == 2 else 1
             if k != K:
                 raise ValueError("all tables of one TableSet share K (got %d and %d)" % (K, k))
@@ -67,14 +69,49 @@ class TableSet:
         self.K = K
         self.vocab = [int(t.shape[0]) for t in tables]
         self.device = tables[0].device
-        self.ptrs = torch.tensor([t.data_ptr() for t in tables], dtype=torch.int64, device=self.device)
+        self.ld = K if ld is None else int(ld)   # floats between rows (> K: packed training rows, see train_rows)
+        self.accums = None                       # train_rows: the Adagrad accumulators living in the same rows
+        self._ptrs = torch.tensor([t.data_ptr() for t in tables], dtype=torch.int64, device=self.device)
         self.vocab_dev = torch.tensor(self.vocab, dtype=torch.int64, device=self.device)
         # row-read policy of the one-hot gather: "stream" = DIR_GATHER_STREAM_ROWS, "reuse" = cacheable,
         # "auto" = stream iff the tables cannot live in the 256 MiB Infinity Cache anyway.  Callers who
         # know their ids are heavily skewed should set "reuse" (see include/dir_hip.h).
         self.row_policy = "auto"
-        self.nbytes = sum(t.numel() * 4 for t in tables)
+        self.nbytes = sum(int(t.shape[0]) * self.ld * 4 for t in tables)
         self.grad_sink = None   # callable(ids, d_rows) consuming the gather's row gradients (see SparseAdagrad.attach)
+        self.fm_sink = None     # callable(ids, d_rows | None, d_fm, field_sums): the same with the FM backward folded in
+
+    @property
+    def ptrs(self):
+        """Device array of the table base pointers, for the kernels that read [vocab, K] rows K floats apart."""
+        if self.ld != self.K:
+            raise ValueError("this TableSet holds packed training rows (row stride %d, K = %d): only gather_fm and the "
+                             "SparseAdagrad update read that layout" % (self.ld, self.K))
+        return self._ptrs
+
+    @classmethod
+    def train_rows(cls, tables, initial_accumulator_value=0.1):
+        """Packed TRAINING layout (include/dir_hip.h: dir_gather_fm_rows_f32): every slot's table becomes [vocab, 2K] rows
+        = [embedding | Adagrad accumulator] in one arena (K = 16: one 128-byte line per row and its optimiser state).
+        .tables are [vocab, K] VIEWS of it (row stride 2K) initialised from `tables`, .accums the accumulator views."""
+        tables = list(tables)
+        K = int(tables[0].shape[1])
+        ld = 2 * K
+        vocab = [int(t.shape[0]) for t in tables]
+        dev = tables[0].device
+        arena = torch.empty(sum(vocab) * ld + 32, dtype=torch.float32, device=dev)
+        off = (-(arena.data_ptr() // 4)) % 32              # rows 128-byte aligned
+        rows = []
+        for t, v in zip(tables, vocab):
+            blk = arena[off:off + v * ld].view(v, ld)
+            blk[:, :K] = t
+            blk[:, K:] = initial_accumulator_value
+            rows.append(blk)
+            off += v * ld
+        ts = cls([r[:, :K] for r in rows], ld=ld)
+        ts.accums = [r[:, K:] for r in rows]
+        ts.arena, ts.rows = arena, rows
+        return ts
 
     def gather_flags(self):
         if self.row_policy == "stream" or (self.row_policy == "auto" and self.nbytes > 2 * INFINITY_CACHE_BYTES):
@@ -83,7 +120,7 @@ class TableSet:
 
     def refresh(self):
         """Rebuild the pointer array (after tables were re-allocated, e.g. .to())."""
-        self.ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=self.device)
+        self._ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=self.device)
 
 
 def _as_tableset(tables):
@@ -180,8 +217,10 @@ def fm_logit(emb, F, K, out=None):
     return out
 
 
-def gather_fm(tables, ids, want_emb=True, out=None, fm=None):
-    """Fused one-hot gather + FM second-order: returns (emb [B, F*K] or None, fm_logit [B, 1])."""
+def gather_fm(tables, ids, want_emb=True, out=None, fm=None, fsum=None):
+    """Fused one-hot gather + FM second-order: returns (emb [B, F*K] or None, fm_logit [B, 1]).  fsum [B, K] (optional
+    output): the field sums S[b] = sum_f e[b,f] the FM backward needs (dir_gather_fm_rows_f32; also the kernel that reads
+    packed training rows, TableSet.train_rows)."""
     ts = _as_tableset(tables)
     _dev(ids, torch.int64, "ids")
     B, sb, sf = _onehot_strides(ids, ts.F)
@@ -189,6 +228,13 @@ def gather_fm(tables, ids, want_emb=True, out=None, fm=None):
         out = torch.empty((B, ts.F * ts.K), dtype=torch.float32, device=ts.device)
     if fm is None:
         fm = torch.empty((B, 1), dtype=torch.float32, device=ts.device)
+    if ts.ld != ts.K or fsum is not None:
+        if fsum is not None and (fsum.shape != (B, ts.K) or not fsum.is_contiguous()):
+            raise ValueError("fsum must be a contiguous [B, K] tensor")
+        _lib.check(_lib.load().dir_gather_fm_rows_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, ts.ld, _ptr(ids), sb, sf,
+                                                      ts.gather_flags(), B, _ptr(out) if want_emb else None,
+                                                      out.stride(0) if want_emb else 0, _ptr(fm), _ptr(fsum), _stream()))
+        return (out if want_emb else None), fm
     _lib.check(_lib.load().dir_gather_fm_fused_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, _ptr(ids), sb, sf, ts.gather_flags(), B,
                                                    _ptr(out) if want_emb else None,
                                                    out.stride(0) if want_emb else 0, _ptr(fm), _stream()))
@@ -759,7 +805,9 @@ class SparseAdagrad:
     """Fused sparse Adagrad over a TableSet.  Holds the accumulators ([TF-upstream] initial_accumulator_value = 0.1).
     method "sorted" (default; include/dir_hip.h: dir_sparse_adagrad_sorted_f32): radix sort of (row, entry) pairs +
     per-tile segmented reduce -- skew-proof and bitwise reproducible.  method "chains" (dir_sparse_adagrad_f32): per-row
-    chains built with integer atomics -- a little faster on near-unique ids, serialises on hot rows."""
+    chains built with integer atomics -- a little faster on near-unique ids, serialises on hot rows.
+    A TableSet.train_rows set brings its accumulators with it (packed [embedding | accumulator] rows: one read and one write
+    per touched row; dir_sparse_adagrad_sorted_rows_f32); step_fm folds the FM backward into the update on either layout."""
 
     def __init__(self, tables, lr, initial_accumulator_value=0.1, method="sorted"):
         if method not in ("sorted", "chains"):
@@ -768,7 +816,12 @@ class SparseAdagrad:
         self.lr = float(lr)
         self.method = method
         dev = self.ts.device
-        self.accums = [torch.full_like(t, initial_accumulator_value) for t in self.ts.tables]
+        if self.ts.accums is not None:           # packed training rows: the accumulators live beside the embeddings
+            if method != "sorted":
+                raise ValueError("packed training rows are updated by the sorted method")
+            self.accums = self.ts.accums
+        else:
+            self.accums = [torch.full_like(t, initial_accumulator_value) for t in self.ts.tables]
         self.acc_ptrs = torch.tensor([a.data_ptr() for a in self.accums], dtype=torch.int64, device=dev)
         base = [0]
         for v in self.ts.vocab[:-1]:
@@ -783,7 +836,43 @@ class SparseAdagrad:
         """Consume the gather's row gradients directly in backward (autograd.GatherFm): loss.backward() then
         performs the embedding update itself; the tables get no .grad."""
         self.ts.grad_sink = self.step
+        if self.method == "sorted":
+            self.ts.fm_sink = self.step_fm
         return self
+
+    def _sorted_ws(self, lib, B):
+        ts = self.ts
+        need = int(lib.dir_sparse_adagrad_sorted_workspace_bytes(B, ts.F, ts.K, self.total_rows))
+        if need <= 0:
+            raise _lib.DirError(-4, "sparse_adagrad_sorted: unsupported size (B*F < 2^31, total rows < 2^32-1)")
+        if self._ws is None or self._ws.numel() < need + 256:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=ts.device)
+        off = (-self._ws.data_ptr()) % 256
+        return ctypes.c_void_p(self._ws.data_ptr() + off), need
+
+    def step_fm(self, ids, grad, fm_g, fm_sum):
+        """The update with the FM backward folded in (include/dir_hip.h: dir_sparse_adagrad_sorted_rows_f32): entry (b, f)'s
+        gradient is (fm_sum[b] - row) * fm_g[b] + grad[b, f].  grad [B, F*K] or None, fm_g [B] / [B, 1], fm_sum [B, K] from
+        gather_fm(..., fsum=).  Tables bit-identical to fm_logit_backward(add_in=grad) followed by step()."""
+        ts = self.ts
+        _dev(ids, torch.int64, "ids")
+        B, sb, sf = _onehot_strides(ids, ts.F)
+        if grad is not None:
+            _dev(grad, torch.float32, "grad")
+            if grad.shape != (B, ts.F * ts.K) or grad.stride(1) != 1:
+                raise ValueError("grad must be [B, F*K] with unit inner stride")
+        _dev(fm_g, torch.float32, "fm_g")
+        _dev(fm_sum, torch.float32, "fm_sum")
+        if fm_g.numel() != B or not fm_g.is_contiguous() or fm_sum.shape != (B, ts.K) or not fm_sum.is_contiguous():
+            raise ValueError("fm_g must be a contiguous [B] / [B, 1] tensor and fm_sum a contiguous [B, K] one")
+        if B == 0:
+            return
+        lib = _lib.load()
+        ws, need = self._sorted_ws(lib, B)
+        _lib.check(lib.dir_sparse_adagrad_sorted_rows_f32(_ptr(ts._ptrs), _ptr(self.acc_ptrs), ts.ld, ts.F, ts.K, _ptr(ids), sb, sf,
+                                                          _ptr(grad), grad.stride(0) if grad is not None else 0, _ptr(fm_g),
+                                                          _ptr(fm_sum), self.lr, B, _ptr(self.head_base), self.total_rows, ws, need,
+                                                          _stream()))
 
     def step(self, ids, grad):
         """ids [B, F] int64 (any strides), grad [B, F*K] fp32: d loss / d gathered rows."""
@@ -794,6 +883,14 @@ class SparseAdagrad:
         if grad.shape != (B, ts.F * ts.K) or grad.stride(1) != 1:
             raise ValueError("grad must be [B, F*K] with unit inner stride")
         lib = _lib.load()
+        if ts.ld != ts.K:
+            if B == 0:
+                return
+            ws, need = self._sorted_ws(lib, B)
+            _lib.check(lib.dir_sparse_adagrad_sorted_rows_f32(_ptr(ts._ptrs), _ptr(self.acc_ptrs), ts.ld, ts.F, ts.K, _ptr(ids), sb, sf,
+                                                              _ptr(grad), grad.stride(0), None, None, self.lr, B,
+                                                              _ptr(self.head_base), self.total_rows, ws, need, _stream()))
+            return
         if self.method == "chains":
             if self._next is None or self._next.numel() < B * ts.F:
                 self._next = torch.empty(B * ts.F, dtype=torch.int32, device=ts.device)

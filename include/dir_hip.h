@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* dir_stream_t; /* hipStream_t */
 
-#define DIR_VERSION 200 /* 0.2.0: vocab bounds on the lookups, dir_embedding_bag_ex_f32, fixed-capacity shard exchange */
+#define DIR_VERSION 201 /* 0.2.1: + packed training rows (dir_gather_fm_rows_f32, dir_sparse_adagrad_sorted_rows_f32) */
 
 enum {
     DIR_OK = 0,
@@ -133,6 +133,17 @@ int dir_gather_fm_linear_packed_f32(const float* const* tables, const int64_t* v
                                     const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
                                     int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
                                     float* lin_out, dir_stream_t stream);
+
+/* Packed TRAINING layout (MI355X-specific option): slot f's table is [vocab_f, ld] fp32 with the embedding at columns
+ * [0, K) and -- by the convention of dir_sparse_adagrad_sorted_rows_f32 below -- its Adagrad accumulator at [K, 2K): with
+ * K = 16, ld = 32 a row and its optimiser state are ONE 128-byte line, so the update issues one read and one write per touched
+ * row instead of two each, and the forward's 64-byte row read costs what it did (a 64-byte miss occupies a 128-byte
+ * DRAM-side slot anyway).  The same one-hot gather + fm_logit_fn (deepFM.py:169-177, :321-335) as
+ * dir_gather_fm_fused_f32, values bit-identical, plus fsum [B, K] (may be NULL): S[b] = sum_f e[b,f] (f ascending, fp32) --
+ * what the FM backward needs of the forward, so that the training graph keeps [B, K] instead of [B, F*K]. */
+int dir_gather_fm_rows_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, const int64_t* ids,
+                           int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out, int64_t out_ld,
+                           float* fm, float* fsum, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * A6  first-order (linear) term, units = 1.
@@ -408,6 +419,20 @@ int dir_sparse_adagrad_sorted_f32(float* const* tables, float* const* accums, in
                                   int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr,
                                   int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
                                   int64_t workspace_bytes, dir_stream_t stream);
+
+/* dir_sparse_adagrad_sorted_f32 over rows with a stride: table f's row id is tables[f] + id*row_ld, its accumulator row
+ * accums[f] + id*row_ld (the packed training layout passes accums[f] = tables[f] + K, row_ld = 2K; row_ld = K with separate
+ * arrays is dir_sparse_adagrad_sorted_f32).  Optionally with the FM backward folded in: fm_g [B] = d loss / d fm_logit and
+ * fm_sum [B, K] = S of dir_gather_fm_rows_f32 (both or neither); the gradient of entry (b, f) is then
+ *     (fm_sum[b] - tables[f][id]) * fm_g[b] + grad[b, f]          (grad may be NULL: zero)
+ * -- dir_fm_second_order_backward_f32's arithmetic on the row the update reads anyway, so the [B, F*K] gradient tensor of
+ * the FM term is never written or read.  Same sort, same summation order, same update: the tables end up bit-identical to
+ * dir_fm_second_order_backward_f32(add_in = grad) followed by dir_sparse_adagrad_sorted_f32. */
+int dir_sparse_adagrad_sorted_rows_f32(float* const* tables, float* const* accums, int64_t row_ld, int F, int K,
+                                       const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad,
+                                       int64_t grad_ld, const float* fm_g, const float* fm_sum, float lr, int64_t B,
+                                       const int64_t* row_base, int64_t total_rows, void* workspace,
+                                       int64_t workspace_bytes, dir_stream_t stream);
 
 /* Owner side of a SHARDED backward: the n entries are the payload of dir_shard_bucket / dir_gather_packed_f32
  * (p = local_row * F + slot, p < 0 pruned) as received from all ranks, grad is [n, K] in the same order, tables / accums /

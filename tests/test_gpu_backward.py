@@ -810,3 +810,87 @@ def test_dense_act_pads_odd_input_width(built_lib):
     with torch.no_grad():
         y2 = D.dense_act(lin, x.detach(), torch.relu)
     assert torch.equal(y2, y.detach())
+
+
+# ---- packed training rows + FM backward folded into the update (include/dir_hip.h: dir_gather_fm_rows_f32,
+# dir_sparse_adagrad_sorted_rows_f32) -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("dist", ["uniform", "hot"])
+@pytest.mark.parametrize("K", [16, 8, 32])
+def test_packed_train_rows_bit_identical_to_split_layout(built_lib, dist, K):
+    """Three training steps of the sparse side (gather + FM, FM backward + DNN-branch gradient, sorted sparse Adagrad) on the
+    packed [embedding | accumulator] rows and with the FM backward folded into the update: forward values, tables and
+    accumulators bit-identical to the split layout with the separate FM-backward pass, including duplicate, pruned and
+    out-of-range ids."""
+    from dir_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(K)
+    B, F, V = 3000, 5, 700
+    tabs = [torch.randn((V + 13 * f, K), generator=g, device="cuda") * 0.25 for f in range(F)]
+    split = ops.TableSet([t.clone() for t in tabs])
+    packed = ops.TableSet.train_rows(tabs, 0.1)
+    fold = ops.TableSet([t.clone() for t in tabs])                   # split layout, FM backward folded in
+    o_split, o_packed, o_fold = (ops.SparseAdagrad(ts, lr=0.05) for ts in (split, packed, fold))
+    for step in range(3):
+        if dist == "hot":
+            ids = (torch.rand((B, F), generator=g, device="cuda") ** 6 * V).long()
+        else:
+            ids = torch.randint(0, V, (B, F), generator=g, device="cuda")
+        ids[::97, 1] = -1                                            # pruned
+        ids[5::89, 2] = V + 13 * 2 + 4                               # out of range: zero row, never written
+        gfm = torch.randn((B, 1), generator=g, device="cuda") * 0.1
+        gdnn = torch.randn((B, F * K), generator=g, device="cuda") * 0.1
+        emb_s, fm_s = ops.gather_fm(split, ids)
+        fsum = torch.empty((B, K), device="cuda")
+        emb_p, fm_p = ops.gather_fm(packed, ids, fsum=fsum)
+        assert torch.equal(emb_s, emb_p) and torch.equal(fm_s, fm_p)
+        fsum_f = torch.empty((B, K), device="cuda")
+        emb_f, fm_f = ops.gather_fm(fold, ids, fsum=fsum_f)          # the rows kernel on plain [V, K] tables (ld = K)
+        assert torch.equal(emb_s, emb_f) and torch.equal(fm_s, fm_f) and torch.equal(fsum, fsum_f)
+        assert torch.equal(fsum, emb_s.view(B, F, K).transpose(0, 1).contiguous().cumsum(0)[-1]) or \
+            torch.allclose(fsum, emb_s.view(B, F, K).sum(1), atol=1e-5)
+        demb = ops.fm_logit_backward(emb_s, gfm, F, K, add_in=gdnn)
+        o_split.step(ids, demb)
+        o_packed.step_fm(ids, gdnn, gfm, fsum) if step % 2 == 0 else o_packed.step(ids, demb)
+        o_fold.step_fm(ids, gdnn, gfm, fsum_f)
+        for f in range(F):
+            assert torch.equal(split.tables[f], packed.tables[f]), (step, f)
+            assert torch.equal(o_split.accums[f], o_packed.accums[f]), (step, f)
+            assert torch.equal(split.tables[f], fold.tables[f]) and torch.equal(o_split.accums[f], o_fold.accums[f]), (step, f)
+    with pytest.raises(ValueError):
+        ops.embedding_bag(packed, ids)                               # the packed layout is read by gather_fm / SparseAdagrad only
+
+
+def test_deepfm_packed_training_matches_split(built_lib):
+    """DeepFM.fused_sparse_adagrad(packed=True): the same model trained three steps on packed rows and on the reference layout
+    ends with identical logits and embedding tables (the dense side is the same code; the sparse side is bit-identical)."""
+    from dir_amd import feature_column as fc
+    from dir_amd.deepfm import DeepFM
+    torch.manual_seed(3)
+    F, V, K, B = 6, 500, 16, 2048
+    def build():
+        torch.manual_seed(11)
+        cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+        return DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                      dnn_hidden_units=[32, 16], fm_embedding_size=K).cuda()
+    a, b = build(), build()
+    a.fused_sparse_adagrad(lr=0.05)
+    b.fused_sparse_adagrad(lr=0.05, packed=True)
+    assert b.embedding_weights[0].stride() == (2 * K, 1)
+    def dense_params(m):
+        skip = {id(p) for p in m.embedding_weights}
+        return [p for p in m.parameters() if id(p) not in skip]
+    oa, ob = torch.optim.SGD(dense_params(a), lr=0.05), torch.optim.SGD(dense_params(b), lr=0.05)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for _ in range(3):
+        ids = torch.randint(0, V, (B, F), generator=g, device="cuda")
+        feats = {"C%d" % f: ids[:, f] for f in range(F)}
+        y = (torch.rand((B, 1), generator=g, device="cuda") < 0.3).float()
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad(set_to_none=True)
+            torch.nn.functional.binary_cross_entropy_with_logits(m(feats), y).backward()
+            o.step()
+    for pa, pb in zip(a.embedding_weights, b.embedding_weights):
+        assert torch.equal(pa.data, pb.data)
+    with torch.no_grad():       # (the linear columns train through torch's sparse gradients, whose duplicate sums are not ordered)
+        torch.testing.assert_close(a(feats), b(feats), rtol=0, atol=2e-6)
+    sd = b.state_dict()
+    assert sd["embedding_weights.0"].shape == (V, K)
