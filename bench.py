@@ -414,7 +414,7 @@ def main():
         cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
         model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
                        dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
-        model.fused_sparse_adagrad(lr=0.01)
+        model.fused_sparse_adagrad(lr=0.01, packed=(args.train_layout == "packed"))
         model.fused_sparse_ftrl(lr=0.2)
         lin = [model.linear_bias]                          # the weight columns are updated by the fused kernel inside backward()
         skip = {id(p) for p in model.linear_weights} | {id(p) for p in lin} | {id(p) for p in model.embedding_weights}
@@ -433,7 +433,7 @@ def main():
             opt_lin.step()
         roof = {"bound": "hbm", "alg_bytes": B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)),
                 "kernel": "whole training step; bytes = the sparse side only (gather+FM, FM backward, sparse Adagrad)"}
-        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "mlp": [400, 400, 400],
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "mlp": [400, 400, 400], "layout": args.train_layout,
                     "optimizers": "sparse Adagrad + sparse FTRL (HIP, sorted, inside backward) + torch Adagrad (MLP)"})
     elif wl == "small_batch":
         # the reference's own batch size (256, DeepCrossNetwork/train.py:17): launch-bound; eager vs HIP-graph replay
