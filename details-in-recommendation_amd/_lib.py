@@ -44,6 +44,10 @@ SIGNATURES = {
     "dir_dcn_cross_backward_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "dir_dcn_cross_backward_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp,
                                            c_vp, c_vp]),
+    "dir_din_backward_rows_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i64]),
+    "dir_din_attention_pool_backward_rows_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                                         c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                         c_vp, c_vp, c_i64, c_vp]),
     "dir_sparse_adagrad_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.c_float, c_i64, c_vp,
                                        c_i64, c_vp, c_vp, c_vp]),
     "dir_sparse_adagrad_sorted_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i64]),

@@ -258,20 +258,27 @@ class DinAttentionPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize):
         ctx.normalize = bool(normalize)
-        ctx.save_for_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3)
-        return ops.din_attention_pool(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(), W2.detach(),
-                                      b2.detach(), W3.detach(), b3.detach(), normalize=normalize)
+        B, T = hist.shape
+        fused = ops.din_backward_supported(table.shape[1], T, W1.shape[1], W2.shape[1]) and not _DIN_COMPOSITE_BACKWARD
+        res = ops.din_attention_pool(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(), W2.detach(),
+                                     b2.detach(), W3.detach(), b3.detach(), normalize=normalize, want_scores=fused)
+        out, scores = res if fused else (res, None)       # the attention weights [B, T] feed the backward (no softmax recompute)
+        ctx.has_scores = scores is not None
+        ctx.save_for_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, *([scores] if scores is not None else []))
+        return out
 
     @staticmethod
     @torch.no_grad()
     def backward(ctx, g):
-        table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3 = ctx.saved_tensors
+        table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3 = ctx.saved_tensors[:10]
+        scores = ctx.saved_tensors[10] if ctx.has_scores else None
         B, T = hist.shape
         K, H1 = table.shape[1], W1.shape[1]
         dev = table.device
         g = g.contiguous()
         if ops.din_backward_supported(K, T, H1, W2.shape[1]) and not _DIN_COMPOSITE_BACKWARD:
-            r = ops.din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=ctx.normalize)
+            r = ops.din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=ctx.normalize,
+                                                scores=scores)
             gtab = None
             if ctx.needs_input_grad[0]:
                 ok = cand >= 0                                      # a pruned candidate (zero vector in the forward) adds nothing

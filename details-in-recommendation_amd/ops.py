@@ -15,6 +15,7 @@ Reference closures (relative to /root/reference):
   cin_layer                  (no reference code; README.md:28)
 """
 import ctypes
+import os
 
 import torch
 
@@ -451,9 +452,11 @@ def din_backward_supported(K, T, H1, H2):
 _DIN_BWD_WS = {}
 
 
-def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=False):
+def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=False, scores=None):
     """Backward of din_attention_pool given g = dL/dout [B, K] (include/dir_hip.h: dir_din_attention_pool_backward_f32 + the
-    per-sample term's two small GEMMs) -> dict:
+    per-sample term's two small GEMMs).  scores [B, T]: the forward's attention weights (din_attention_pool(..., want_scores=True));
+    with them the two-kernel form runs (dir_din_attention_pool_backward_rows_f32: no softmax recompute, wave-per-sample row pass +
+    streaming weight-gradient pass); DIR_DIN_BWD_ROWS=0 keeps the round-1 single kernel.  -> dict:
       ids_h [N] int64, gh [N, K]: the valid history positions' table rows and their gradients, (b, j) order;
       ga [B, K]: the candidate rows' gradients;  gW1 [4K, H1], gb1, gW2, gb2, gW3 [H2], gb3 [1]."""
     _dev(table, torch.float32, "table")
@@ -484,7 +487,18 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     cnt = valid.sum(dim=1)
     incl = torch.cumsum(cnt, 0)
     row_off = (incl - cnt).contiguous()
-    N = int(incl[-1]) if B else 0                                  # the one host read (sizes the row list)
+    use_rows = scores is not None and B > 0 and os.environ.get("DIR_DIN_BWD_ROWS", "1") != "0"
+    if use_rows:
+        _dev(scores, torch.float32, "scores")
+        if tuple(scores.shape) != (B, T) or not scores.is_contiguous():
+            raise ValueError("DIN backward: scores must be a contiguous [B, T] tensor")
+        lens = hist_len.clamp(0, T).to(torch.int64) if hist_len is not None else torch.full((B,), T, dtype=torch.int64, device=dev)
+        tcnt = (lens + 15) // 16
+        tincl = torch.cumsum(tcnt, 0)
+        tile_off = (tincl - tcnt).contiguous()
+        N, n_tiles = (int(v) for v in torch.stack([incl[-1], tincl[-1]]).tolist())      # the one host read (sizes row list + scratch)
+    else:
+        N = int(incl[-1]) if B else 0                              # the one host read (sizes the row list)
     ws = _DIN_BWD_WS.get(dev)
     if ws is None or ws.numel() < need:
         ws = _DIN_BWD_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -492,10 +506,20 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     gh, ga, S = torch.empty((N, K), **f32), torch.empty((B, K), **f32), torch.empty((B, H1), **f32)
     gAP, gW2, gb2 = torch.empty((2 * K, H1), **f32), torch.empty((H1, H2), **f32), torch.empty(H2, **f32)
     gW3, gb3 = torch.empty(H2, **f32), torch.empty(1, **f32)
-    _lib.check(lib.dir_din_attention_pool_backward_f32(
-        _ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]), H2,
-        _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B, _ptr(g), _ptr(row_off), _ptr(gh), _ptr(ga), _ptr(S), _ptr(gAP),
-        _ptr(gW2), _ptr(gb2), _ptr(gW3), _ptr(gb3), _ptr(ws), _stream()))
+    if use_rows:
+        need2 = int(lib.dir_din_backward_rows_workspace_bytes(K, H1, H2, n_tiles))
+        ws2 = _DIN_BWD_WS.get((dev, "rows"))
+        if ws2 is None or ws2.numel() < need2:
+            ws2 = _DIN_BWD_WS[(dev, "rows")] = torch.empty(need2, dtype=torch.uint8, device=dev)
+        _lib.check(lib.dir_din_attention_pool_backward_rows_f32(
+            _ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]), H2,
+            _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B, _ptr(g), _ptr(scores), _ptr(row_off), _ptr(tile_off), n_tiles,
+            _ptr(gh), _ptr(ga), _ptr(S), _ptr(gAP), _ptr(gW2), _ptr(gb2), _ptr(gW3), _ptr(gb3), _ptr(ws2), need2, _stream()))
+    else:
+        _lib.check(lib.dir_din_attention_pool_backward_f32(
+            _ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]), H2,
+            _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B, _ptr(g), _ptr(row_off), _ptr(gh), _ptr(ga), _ptr(S), _ptr(gAP),
+            _ptr(gW2), _ptr(gb2), _ptr(gW3), _ptr(gb3), _ptr(ws), _stream()))
     # the per-sample term a.(Wa - Wd) + b1: two [B, .] GEMMs (rocBLAS)
     W1 = args[0]
     C = W1[K:2 * K] - W1[2 * K:3 * K]

@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* dir_stream_t; /* hipStream_t */
 
-#define DIR_VERSION 201 /* 0.2.1: + packed training rows (dir_gather_fm_rows_f32, dir_sparse_adagrad_sorted_rows_f32) */
+#define DIR_VERSION 202 /* 0.2.1: + packed training rows (dir_gather_fm_rows_f32, dir_sparse_adagrad_sorted_rows_f32) */
 
 enum {
     DIR_OK = 0,
@@ -393,6 +393,22 @@ int dir_din_attention_pool_backward_f32(const float* table, int K, const int64_t
                                         int normalize, int64_t B, const float* gout, const int64_t* row_off, float* gh,
                                         float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
                                         void* workspace, dir_stream_t stream);
+
+/* The same backward as two kernels (csrc/din_bwd_rows.hip): a wave-per-sample pass for everything that is per history row or per
+ * sample (gh, ga, S) and a streaming pass over its scratch records for the batch-wide weight gradients.  Two more inputs:
+ *   scores   [B, T]: the attention weights of the forward (dir_din_attention_pool_f32's `scores` output: softmax weights when
+ *            normalize, raw scores otherwise) -- the softmax is not recomputed;
+ *   tile_off [B] DEVICE int64: exclusive prefix sum of ceil(min(max(hist_len[b], 0), T) / 16), n_tiles = its total (a host value:
+ *            it sizes the scratch, dir_din_backward_rows_workspace_bytes(K, H1, H2, n_tiles) bytes, 16-byte aligned).
+ * Outputs, row_off and the meaning of every other argument as dir_din_attention_pool_backward_f32; b3 is not read. */
+int64_t dir_din_backward_rows_workspace_bytes(int K, int H1, int H2, int64_t n_tiles);
+int dir_din_attention_pool_backward_rows_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
+                                             const int64_t* cand, int T, const float* W1, const float* b1, int H1,
+                                             const float* W2, const float* b2, int H2, const float* W3, const float* b3,
+                                             int normalize, int64_t B, const float* gout, const float* scores,
+                                             const int64_t* row_off, const int64_t* tile_off, int64_t n_tiles, float* gh,
+                                             float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
+                                             void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 
 /* Fused sparse Adagrad on the embedding tables (the reference's dnn_optimizer='Adagrad', deepFM.py:61):
  * for every distinct id of slot f in the batch: g = SUM of the gradient rows of its occurrences ([TF-upstream]

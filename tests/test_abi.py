@@ -26,7 +26,7 @@ def test_header_symbols_exported(built_lib):
 def test_binding_table_matches_header(built_lib):
     from dir_amd import _lib
     assert sorted(_lib.SIGNATURES) == _header_functions()
-    assert built_lib.dir_version() == 201
+    assert built_lib.dir_version() == 202
 
 
 def test_host_hash_matches_published_kats(built_lib):

@@ -896,3 +896,36 @@ def test_deepfm_packed_training_matches_split(built_lib):
         assert torch.equal(a(feats), b(feats))
     sd = b.state_dict()
     assert sd["embedding_weights.0"].shape == (V, K)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("B,T,H1,H2", [(300, 50, 80, 40), (67, 64, 80, 48), (41, 17, 36, 20), (9, 5, 64, 32), (130, 33, 72, 44)])
+def test_din_rows_backward_matches_single_kernel(built_lib, normalize, B, T, H1, H2):
+    """dir_din_attention_pool_backward_rows_f32 (wave-per-sample row pass + streaming weight-gradient pass, fed with the forward's
+    attention weights) against the round-1 single-kernel backward on the same inputs: every output within fp32 summation-order
+    noise; pruned ids, empty and full-length histories, pruned candidates included."""
+    import os
+    from dir_amd import ops
+    K, V = 64, 5000
+    g = torch.Generator().manual_seed(B + T)
+    table = (torch.randn(V, K, generator=g) * 0.3).cuda()
+    Ws = [(torch.randn(4 * K, H1, generator=g) * 0.1).cuda(), (torch.randn(H1, generator=g) * 0.1).cuda(),
+          (torch.randn(H1, H2, generator=g) * 0.2).cuda(), (torch.randn(H2, generator=g) * 0.1).cuda(),
+          (torch.randn(H2, generator=g) * 0.5).cuda(), torch.randn(1, generator=g).cuda()]
+    hist = torch.randint(0, V, (B, T), generator=g)
+    hist[torch.rand((B, T), generator=g) < 0.1] = -1
+    hl = torch.randint(0, T + 1, (B,), generator=g).to(torch.int32)
+    hl[0], hl[1 % B] = T, 0
+    cand = torch.randint(0, V, (B,), generator=g)
+    cand[3 % B] = -1
+    hist, hl, cand = hist.cuda(), hl.cuda(), cand.cuda()
+    gout = torch.randn(B, K, generator=g).cuda()
+    out, scores = ops.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, want_scores=True)
+    ref = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize)
+    got = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=scores)
+    assert torch.equal(ref["ids_h"], got["ids_h"])
+    for k in ("gh", "ga", "gW1", "gb1", "gW2", "gb2", "gW3", "gb3"):
+        a, b = ref[k].double(), got[k].double()
+        err = ((a - b).abs() / (1e-3 + 0.05 * a.abs().max() + a.abs())).max().item() if a.numel() else 0.0
+        # (with the softmax, d b3 = sum of d score is a sum that cancels to ~0: only its absolute size is meaningful)
+        assert err < (5e-3 if (k == "gb3" and normalize) else 2e-4), (k, err)
