@@ -495,7 +495,8 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
 // MFMAs on it: wave w owns feature tile w of d[Wh+Wd] and dWp (10 accumulators) and hidden tile w (+ a share of the fifth) of dW2 (4).
 // ------------------------------------------------------------------------------------------------------------------------------------
 constexpr int WG_HS = RB_K + 4;           // LDS row stride of the staged history rows
-constexpr int WG_RS = RB_ROW + 4;         // LDS row stride of the staged scratch rows (216: rows 4 apart sit 32 banks apart... see reads)
+constexpr int WG_RS = RB_ROW;             // LDS row stride of the staged scratch rows: 212 -> rows 4 apart sit 16 banks apart (the
+                                          // row-reduction reads of lane groups kk = 0..3 hit 64 different banks); 68 does the same for h
 struct DinWgradSh {
     float h[2][16 * WG_HS];
     float r[2][16 * WG_RS];               // z1 | dpre1 | z2 -> dpre2 in place | ds
