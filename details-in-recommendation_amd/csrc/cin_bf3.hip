@@ -1,0 +1,339 @@
+// cin_bf3.hip -- the CIN layer of cin.hip on the bf16 matrix pipe with fp32-equivalent arithmetic ("bf16 x 3").
+//
+// NO REFERENCE CODE (README.md:28 links arXiv:1803.05170); definition as in cin.hip / include/dir_hip.h:
+//   xout[b,h,d] = sum_{i<Hp} sum_{j<m} W[h, i*m+j] * xk[b,i,d] * x0[b,j,d]
+//
+// Arithmetic.  Every fp32 operand of the GEMM view (A[r,(i,j)] = fl(xk[b,i,d] * x0[b,j,d]) -- the same rounded product cin.hip feeds
+// its fp32 MFMA -- and B = W) is split into three bf16 pieces by round-to-nearest: v = v0 + v1 + v2 exactly (3 x 8 significant bits
+// plus the pieces' signs cover fp32's 24).  Of the nine piece products the six with weight >= 2^-16 are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 (a bf16 x bf16 product is exact in fp32); the three dropped ones are <= 2^-24 relative each and of
+// random sign.  The bf16 pipe runs 16 x the fp32 MFMA rate, so the six products cost 6/16 of cin.hip's MFMA time.
+//
+// Reduction order.  One MFMA step covers 16 reduction indices: lane half g = lane >> 5 supplies the 8 values i = 8*ib + e (e < 8)
+// of field j = 2*t + g.  Steps run s = ib * MP2 + t (MP2 = ceil(m / 2)); four steps are a chunk (one barrier per 192 MFMAs).
+//
+// LDS (one workgroup of 4 waves = 256 rows (b,d) x 128 columns h, one wave per SIMD, accumulators in AGPRs):
+//   x0s [mp][256] f32         the workgroup's x0 slice (whole kernel)
+//   xks [2][2][256][4] f32    xk for one block of 8 values of i, [parity of ib][e >> 2][row][e & 3]: two conflict-free ds_read_b128
+//   Wb  [2][4 steps][3 planes][4 cc][2 g][32 n][8 e] bf16   W chunk, in exactly the order cin_bf3_pack_w_k writes the global image,
+//                             so a chunk arrives by 48 global_load_lds_dwordx4 per workgroup (no staging registers, no ds_write)
+//                             and the 8 bf16 of one (plane, column tile) operand are ONE ds_read_b128.
+#include "common.hpp"
+
+namespace dir {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BF3_ROWS = 256;                 // rows per workgroup
+constexpr int BF3_CH = 4;                     // steps per chunk
+constexpr int BF3_STEP_BYTES = 3 * 4 * 2 * 32 * 16;   // 12 KB of W image per step
+constexpr int BF3_CHUNK_BYTES = BF3_CH * BF3_STEP_BYTES;
+
+__host__ __device__ inline int bf3_steps(int m, int Hp) {      // padded to whole chunks
+    const int s = ((Hp + 7) / 8) * ((m + 1) / 2);
+    return (s + BF3_CH - 1) / BF3_CH * BF3_CH;
+}
+
+__device__ __forceinline__ unsigned int bf3_pk(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even
+    const bf16x2_t v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned int, v);
+}
+
+// W [H, Hp*m] fp32 -> image [column block of 128][step][plane][cc][g][n][8 e] bf16 (zero where h >= H, i >= Hp, j >= m or the step is padding)
+__global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict__ W, int m, int Hp, int H, int nsteps, int ncb,
+                                                       unsigned int* __restrict__ img) {
+    const int MP2 = (m + 1) / 2;
+    const int nblk = (Hp + 7) / 8;
+    const int64_t total = (int64_t)ncb * nsteps * (4 * 2 * 32 * 4);   // one thread per (cb, step, cc, g, n, pair of e) -> 3 dwords
+    for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
+        int64_t q = e_;
+        const int ep = (int)(q & 3); q >>= 2;
+        const int n = (int)(q & 31); q >>= 5;
+        const int g = (int)(q & 1); q >>= 1;
+        const int cc = (int)(q & 3); q >>= 2;
+        const int s = (int)(q % nsteps);
+        const int cb = (int)(q / nsteps);
+        const int ib = s / MP2, t = s - ib * MP2;
+        const int h = cb * 128 + 32 * cc + n;
+        const int j = 2 * t + g;
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = 8 * ib + 2 * ep + u;
+            v[u] = (ib < nblk && h < H && i < Hp && j < m) ? W[(int64_t)h * Hp * m + (int64_t)i * m + j] : 0.f;
+        }
+        const unsigned int p0 = bf3_pk(v[0], v[1]);
+        const float r0 = v[0] - __builtin_bit_cast(float, p0 << 16), r1 = v[1] - __builtin_bit_cast(float, p0 & 0xffff0000u);
+        const unsigned int p1 = bf3_pk(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, p1 << 16), s1 = r1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+        const unsigned int p2 = bf3_pk(s0, s1);
+        // dword index inside the step: ((plane*4 + cc)*2 + g)*32*4 + n*4 + ep
+        const int64_t base = ((int64_t)cb * nsteps + s) * (BF3_STEP_BYTES / 4) + ((cc * 2 + g) * 32 + n) * 4 + ep;
+        img[base] = p0;
+        img[base + 1 * (4 * 2 * 32 * 4)] = p1;
+        img[base + 2 * (4 * 2 * 32 * 4)] = p2;
+    }
+}
+
+// 8 products of one row tile -> three bf16x8 operands whose sum is the products
+__device__ __forceinline__ void bf3_split(const float (&x)[8], bf16x8_t& a0, bf16x8_t& a1, bf16x8_t& a2) {
+    unsigned int w0[4], w1[4], w2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        w0[i] = bf3_pk(a, b);
+        const float ra = a - __builtin_bit_cast(float, w0[i] << 16), rb = b - __builtin_bit_cast(float, w0[i] & 0xffff0000u);
+        w1[i] = bf3_pk(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, w1[i] << 16), sb = rb - __builtin_bit_cast(float, w1[i] & 0xffff0000u);
+        w2[i] = bf3_pk(sa, sb);
+    }
+    a0 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w0[0], w0[1], w0[2], w0[3]});
+    a1 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w1[0], w1[1], w1[2], w1[3]});
+    a2 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w2[0], w2[1], w2[2], w2[3]});
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__global__ __launch_bounds__(256, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
+                                                    const unsigned char* __restrict__ img /* packed W image */, int m, int Hp, int H,
+                                                    int D, int dshift, int nsteps, int64_t R, float* __restrict__ xout,
+                                                    float* __restrict__ pooled, int64_t pooled_ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bf3_smem[];
+    const int mp = (m + 1) & ~1, MP2 = mp >> 1;
+    const int nblk = (Hp + 7) >> 3;
+    unsigned char* Wb = bf3_smem;                                                   // [2][BF3_CHUNK_BYTES]
+    float* xks = reinterpret_cast<float*>(bf3_smem + 2 * BF3_CHUNK_BYTES);          // [2][2][256][4]
+    float* x0s = xks + 2 * 2 * BF3_ROWS * 4;                                        // [mp][256]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n = lane & 31;
+    const int g = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * BF3_ROWS;
+    const int hbase = blockIdx.y * 128;
+    const unsigned char* gimg = img + (int64_t)blockIdx.y * nsteps * BF3_STEP_BYTES;
+    const int nchunk = nsteps / BF3_CH;
+
+    // this thread's staging row (b,d) = row0 + tid, clamped (a row >= R only feeds output rows that are never stored)
+    const int64_t srow = (row0 + tid < R) ? row0 + tid : R - 1;
+    const float* x0src = x0 + ((srow >> dshift) * m) * D + (srow & (D - 1));
+    const float* xksrc = xk + ((srow >> dshift) * Hp) * D + (srow & (D - 1));
+
+    auto stage_w = [&](int c, int buf) {     // 12 x 1 KB pieces per wave, lane-linear
+#pragma unroll
+        for (int q = 0; q < BF3_CHUNK_BYTES / 1024 / 4; ++q) {
+            const int piece = q * 4 + wave;
+            const unsigned char* src = gimg + (int64_t)c * BF3_CHUNK_BYTES + piece * 1024 + lane * 16;
+            unsigned char* dst = Wb + buf * BF3_CHUNK_BYTES + piece * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+    float xreg[8];
+    auto load_xk = [&](int ib) {             // block ib of 8 values of i (zeros past Hp: the W image is zero there, 0 * garbage must stay 0)
+        const int ibc = ib < nblk ? ib : nblk - 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = 8 * ibc + e;
+            const float v = xksrc[(int64_t)(i < Hp ? i : Hp - 1) * D];
+            xreg[e] = i < Hp ? v : 0.f;
+        }
+    };
+    auto store_xk = [&](int ib) {
+        const int ibc = ib < nblk ? ib : nblk - 1;
+        float* dst = xks + (ibc & 1) * (2 * BF3_ROWS * 4) + tid * 4;
+        *reinterpret_cast<float4*>(dst) = make_float4(xreg[0], xreg[1], xreg[2], xreg[3]);
+        *reinterpret_cast<float4*>(dst + BF3_ROWS * 4) = make_float4(xreg[4], xreg[5], xreg[6], xreg[7]);
+    };
+
+    // ---- prologue: W chunk 0, x0 slice, xk block 0
+    stage_w(0, 0);
+    load_xk(0);
+    for (int j = 0; j < mp; ++j) x0s[j * BF3_ROWS + tid] = j < m ? x0src[(int64_t)j * D] : 0.f;
+    store_xk(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][c][q] = 0.f;
+
+    const int rl = wave * 64 + n;                       // this lane's row in the workgroup (tile 0; tile 1 = +32)
+    // A operands of step s: products xk[r, 8*ib + e] * x0[r, 2*t + g] of both row tiles, split
+    auto build_a = [&](int ib, int t, bf16x8_t (&a)[2][3]) {
+        const float* xb = xks + (ib & 1) * (2 * BF3_ROWS * 4) + rl * 4;
+        const float* x0b = x0s + (2 * t + g) * BF3_ROWS + rl;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const float4 lo = *reinterpret_cast<const float4*>(xb + tl * 32 * 4);
+            const float4 hi = *reinterpret_cast<const float4*>(xb + BF3_ROWS * 4 + tl * 32 * 4);
+            const float xv = x0b[tl * 32];
+            const float p[8] = {lo.x * xv, lo.y * xv, lo.z * xv, lo.w * xv, hi.x * xv, hi.y * xv, hi.z * xv, hi.w * xv};
+            bf3_split(p, a[tl][0], a[tl][1], a[tl][2]);
+        }
+    };
+
+    int ib = 0, t = 0;                                   // (ib, t) of the step whose A operands are in `a`
+    bf16x8_t a[2][3];
+    build_a(0, 0, a);
+
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) stage_w(c + 1, buf ^ 1);
+        const int ibs = (BF3_CH * c + 8) / MP2;          // see the staging rule below
+        load_xk(ibs);
+        const unsigned char* wl = Wb + buf * BF3_CHUNK_BYTES + (g * 32 + n) * 16;
+        // xk staging rule (needs MP2 >= 8, checked by the host): chunk c stages the block of step 4c + 8.  Chunk c reads the blocks of
+        // steps 4c .. 4c + 4 (its own steps and the A operands of step 4c + 4, built under its last step); those were staged by
+        // chunk c-1 (block of step 4c + 4) or earlier and published by a barrier.  The staged block is block(4c) or block(4c) + 1:
+        // re-staging a block that is being read writes identical values, and a new block goes to the buffer of the other parity,
+        // whose previous content (block(4c) - 1) has no reader left.
+#pragma unroll
+        for (int st = 0; st < BF3_CH; ++st) {
+            // next step's indices and A operands (built under this step's MFMAs)
+            int tn = t + 1, ibn = ib;
+            if (tn == MP2) { tn = 0; ibn = ib + 1; }
+            bf16x8_t an[2][3];
+            const unsigned char* ws = wl + st * BF3_STEP_BYTES;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(ws + (0 * 4 + cc) * 1024);
+                const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(ws + (1 * 4 + cc) * 1024);
+                const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(ws + (2 * 4 + cc) * 1024);
+                if (cc == 1) build_a(ibn < nblk ? ibn : nblk - 1, tn, an);
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    f32x16 v = acc[tl][cc];
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b2, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][2], b0, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][1], b1, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b1, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][1], b0, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b0, v, 0, 0, 0);
+                    acc[tl][cc] = v;
+                }
+            }
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[tl][p] = an[tl][p];
+            t = tn; ib = ibn;
+        }
+        store_xk(ibs);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of chunk c + 1 have landed in LDS
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  (as cin.hip)
+    if (xout) {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int64_t trow = row0 + wave * 64 + tl * 32;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int h = hbase + 32 * cc + n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t gr = trow + 8 * q + 4 * g;
+                    if (h < H && gr < R) {
+                        const int64_t b = gr >> dshift;
+                        const int d = (int)(gr & (D - 1));
+                        float4 v = make_float4(acc[tl][cc][4 * q], acc[tl][cc][4 * q + 1], acc[tl][cc][4 * q + 2], acc[tl][cc][4 * q + 3]);
+                        *reinterpret_cast<float4*>(xout + (b * H + h) * D + d) = v;
+                    }
+                }
+            }
+        }
+    }
+    if (pooled) {
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int64_t trow = row0 + wave * 64 + tl * 32;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int h = hbase + 32 * cc + n;
+                const float p0 = (acc[tl][cc][0] + acc[tl][cc][1]) + (acc[tl][cc][2] + acc[tl][cc][3]);
+                const float p1 = (acc[tl][cc][4] + acc[tl][cc][5]) + (acc[tl][cc][6] + acc[tl][cc][7]);
+                const float p2 = (acc[tl][cc][8] + acc[tl][cc][9]) + (acc[tl][cc][10] + acc[tl][cc][11]);
+                const float p3 = (acc[tl][cc][12] + acc[tl][cc][13]) + (acc[tl][cc][14] + acc[tl][cc][15]);
+                if (D == 4) {
+                    const float pv[4] = {p0, p1, p2, p3};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t gr = trow + 8 * q + 4 * g;
+                        if (h < H && gr < R) pooled[(gr >> dshift) * pooled_ld + h] = pv[q];
+                    }
+                } else {
+                    float s0, s1, s2, s3;
+                    if (D == 8) { s0 = p0; s1 = p1; s2 = p2; s3 = p3; }
+                    else if (D == 16) { s0 = p0 + p1; s1 = p2 + p3; s2 = 0.f; s3 = 0.f; }
+                    else { s0 = (p0 + p1) + (p2 + p3); s1 = 0.f; s2 = 0.f; s3 = 0.f; }
+                    s0 += __shfl_xor(s0, 32, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    s3 += __shfl_xor(s3, 32, 64);
+                    const int ns = 32 >> dshift;
+                    const float sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t gr = trow + (int64_t)q * D;
+                        if (q < ns && g == 0 && h < H && gr < R) pooled[(gr >> dshift) * pooled_ld + h] = sv[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
+    if (m <= 0 || Hp <= 0 || H <= 0) return 0;
+    return (int64_t)((H + 127) / 128) * bf3_steps(m, Hp) * BF3_STEP_BYTES;
+}
+
+extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
+                                        float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                        dir_stream_t stream) {
+    const char* name = "dir_cin_layer_bf16x3_f32";
+    DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
+    DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
+    DIR_CHECK_ARG(!pooled || pooled_ld >= H, "%s: pooled_ld=%lld < H=%d", name, (long long)pooled_ld, H);
+    if (!(D == 4 || D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 4, 8, 16, 32)", name, D);
+    if (m > 40 || m < 15) return fail(DIR_E_UNSUPPORTED, "%s: field count m=%d (supported: 15..40; use dir_cin_layer_f32)", name, m);
+    if (xout && !aligned16(xout)) return fail(DIR_E_BADARG, "%s: xout must be 16-byte aligned", name);
+    DIR_CHECK_ARG(aligned16(workspace) && workspace_bytes >= dir_cin_bf16x3_workspace_bytes(m, Hp, H),
+                  "%s: workspace must be 16-byte aligned and hold dir_cin_bf16x3_workspace_bytes(m, Hp, H) bytes", name);
+    if (B == 0) return DIR_OK;
+    int dshift = 0;
+    while ((1 << dshift) < D) ++dshift;
+    const int64_t R = B * D;
+    const int nsteps = bf3_steps(m, Hp);
+    const int ncb = (H + 127) / 128;
+    hipStream_t st = as_stream(stream);
+    const int64_t pack_threads = (int64_t)ncb * nsteps * 1024;
+    hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((pack_threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, nsteps, ncb,
+                       static_cast<unsigned int*>(workspace));
+    const int mp = (m + 1) & ~1;
+    const size_t shmem = 2 * (size_t)BF3_CHUNK_BYTES + sizeof(float) * (2 * 2 * BF3_ROWS * 4 + (size_t)mp * BF3_ROWS);
+    static bool set = false;
+    if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        set = true;
+    }
+    dim3 grid((unsigned)((R + BF3_ROWS - 1) / BF3_ROWS), (unsigned)ncb);
+    hipLaunchKernelGGL(cin_bf3_k, grid, dim3(256), shmem, st, x0, xk, static_cast<const unsigned char*>(workspace), m, Hp, H, D, dshift,
+                       nsteps, R, xout, pooled, pooled_ld);
+    DIR_CHECK_LAUNCH("cin_layer_bf16x3");
+    return DIR_OK;
+}

@@ -531,10 +531,24 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
             "gW2": gW2, "gb2": gb2, "gW3": gW3, "gb3": gb3}
 
 
-def cin_layer(x0, xk, W, pooled=None, want_xout=True):
+CIN_ARITH = os.environ.get("DIR_CIN_ARITH", "f32")   # default arithmetic of cin_layer: "f32" (fp32 MFMA) | "bf16x3"
+
+
+def cin_bf16x3_covers(m, D):
+    """Shapes dir_cin_layer_bf16x3_f32 accepts (csrc/cin_bf3.hip)."""
+    return 15 <= m <= 40 and D in (4, 8, 16, 32)
+
+
+def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
-    want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None."""
+    want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
+    arith: "f32" = dir_cin_layer_f32 (fp32 MFMA, an exact fma chain); "bf16x3" = dir_cin_layer_bf16x3_f32 (three-way bf16 split of
+    both operands, six products on the bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same); None = CIN_ARITH.
+    "bf16x3" on a shape that kernel does not cover raises."""
+    arith = arith or CIN_ARITH
+    if arith not in ("f32", "bf16x3"):
+        raise ValueError("cin_layer: arith must be 'f32' or 'bf16x3'")
     _dev(x0, torch.float32, "x0")
     _dev(xk, torch.float32, "xk")
     _dev(W, torch.float32, "W")
@@ -548,6 +562,15 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True):
     xout = torch.empty((B, H, D), dtype=torch.float32, device=x0.device) if want_xout else None
     if pooled is None:
         pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
+    if arith == "bf16x3":
+        if not cin_bf16x3_covers(m, D):
+            raise ValueError("cin_layer: arith='bf16x3' covers 15 <= m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (m, D))
+        lib = _lib.load()
+        nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, Hp, H))
+        ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+        _lib.check(lib.dir_cin_layer_bf16x3_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None,
+                                                _ptr(pooled), pooled.stride(0), _ptr(ws), nbytes, _stream()))
+        return xout, pooled
     mt = next((t for t in CIN_FIELD_TILES if t >= m), m)
     if mt != m and B > 0:
         # the kernel's fast (interleaved-staging) path exists for the instantiated field counts only; a zero field and zero
