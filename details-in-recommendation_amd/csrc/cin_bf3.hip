@@ -37,9 +37,14 @@ __host__ __device__ inline int bf3_steps(int m, int Hp) {      // padded to whol
     return (s + BF3_CH - 1) / BF3_CH * BF3_CH;
 }
 
-__device__ __forceinline__ unsigned int bf3_pk(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even
+__device__ __forceinline__ unsigned int bf3_pk_c(float a, float b) {
     const bf16x2_t v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ unsigned int bf3_pk(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even; a in the low half
+    unsigned int w;   // (asm: written as a cast the compiler converts `a` a second time, alone, to form float(bf16(a)) by a shift)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
+    return w;
 }
 
 // W [H, Hp*m] fp32 -> image [column block of 128][step][plane][cc][g][n][8 e] bf16 (zero where h >= H, i >= Hp, j >= m or the step is padding)
@@ -95,9 +100,39 @@ __device__ __forceinline__ void bf3_split(const float (&x)[8], bf16x8_t& a0, bf1
     a2 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w2[0], w2[1], w2[2], w2[3]});
 }
 
+// Issue order of one region of the step loop (12 MFMAs, 26 VALU instructions of the next step's A operands, the LDS reads of the
+// next region's B operands; the first region of a step also reads the A inputs and starts with three bare MFMAs that cover the
+// latency of those reads): MFMA : VALU = 1 : 2-3.
+template <bool FIRST>
+__device__ __forceinline__ void bf3_region_order() {
+    if constexpr (FIRST) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+    } else {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+template <int VAR>
 __global__ __launch_bounds__(256, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                     const unsigned char* __restrict__ img /* packed W image */, int m, int Hp, int H,
                                                     int D, int dshift, int nsteps, int64_t R, float* __restrict__ xout,
@@ -167,69 +202,134 @@ __global__ __launch_bounds__(256, 1) void cin_bf3_k(const float* __restrict__ x0
             for (int q = 0; q < 16; ++q) acc[t][c][q] = 0.f;
 
     const int rl = wave * 64 + n;                       // this lane's row in the workgroup (tile 0; tile 1 = +32)
-    // A operands of step s: products xk[r, 8*ib + e] * x0[r, 2*t + g] of both row tiles, split
-    auto build_a = [&](int ib, int t, bf16x8_t (&a)[2][3]) {
-        const float* xb = xks + (ib & 1) * (2 * BF3_ROWS * 4) + rl * 4;
-        const float* x0b = x0s + (2 * t + g) * BF3_ROWS + rl;
+    // Inputs of one step's A operands: xk[r, 8*ib .. 8*ib+7] and x0[r, 2*t + g] of both row tiles (six LDS reads) ...
+    struct AIn { float4 lo[2], hi[2]; float xv[2]; };
+    auto read_in = [&](int ib_, int t_, AIn& in) {
+        const float* xb = xks + (ib_ & 1) * (2 * BF3_ROWS * 4) + rl * 4;
+        const float* x0b = x0s + (2 * t_ + g) * BF3_ROWS + rl;
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
-            const float4 lo = *reinterpret_cast<const float4*>(xb + tl * 32 * 4);
-            const float4 hi = *reinterpret_cast<const float4*>(xb + BF3_ROWS * 4 + tl * 32 * 4);
-            const float xv = x0b[tl * 32];
-            const float p[8] = {lo.x * xv, lo.y * xv, lo.z * xv, lo.w * xv, hi.x * xv, hi.y * xv, hi.z * xv, hi.w * xv};
-            bf3_split(p, a[tl][0], a[tl][1], a[tl][2]);
+            in.lo[tl] = *reinterpret_cast<const float4*>(xb + tl * 32 * 4);
+            in.hi[tl] = *reinterpret_cast<const float4*>(xb + BF3_ROWS * 4 + tl * 32 * 4);
+            in.xv[tl] = x0b[tl * 32];
         }
     };
+    // ... and one "unit" u = 0..7 of the build: the two products e = 2*(u&3), 2*(u&3)+1 of row tile u >> 2, split into the three
+    // bf16 pieces (13 VALU instructions; a step's 8 units are spread over its 48 MFMAs)
+    auto build_unit = [&](const AIn& in, int u, unsigned int (&w)[2][3][4]) {
+        const int tl = u >> 2, pr = u & 3;
+        const float4 src = pr < 2 ? in.lo[tl] : in.hi[tl];
+        const float a = ((pr & 1) ? src.z : src.x) * in.xv[tl], b = ((pr & 1) ? src.w : src.y) * in.xv[tl];
+        const unsigned int w0 = (VAR & 2) ? bf3_pk(a, b) : bf3_pk_c(a, b);
+        const float ra = a - __builtin_bit_cast(float, w0 << 16), rb = b - __builtin_bit_cast(float, w0 & 0xffff0000u);
+        const unsigned int w1 = (VAR & 2) ? bf3_pk(ra, rb) : bf3_pk_c(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, w1 << 16), sb = rb - __builtin_bit_cast(float, w1 & 0xffff0000u);
+        w[tl][0][pr] = w0; w[tl][1][pr] = w1; w[tl][2][pr] = (VAR & 2) ? bf3_pk(sa, sb) : bf3_pk_c(sa, sb);
+    };
+    auto as_op = [](const unsigned int (&w)[4]) { return __builtin_bit_cast(bf16x8_t, (u32x4_t){w[0], w[1], w[2], w[3]}); };
 
-    int ib = 0, t = 0;                                   // (ib, t) of the step whose A operands are in `a`
-    bf16x8_t a[2][3];
-    build_a(0, 0, a);
+    int ib = 0, t = 0;                                   // (ib, t) of the step whose A operands are in `aw`
+    unsigned int aw[2][3][4];
+    {
+        AIn in;
+        read_in(0, 0, in);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) build_unit(in, u, aw);
+    }
+    int ib8 = 8 / MP2, t8 = 8 - ib8 * MP2;               // (block, field pair) of step 4c + 8
+    bf16x8_t b[3], bn[3];                                // B operands (three planes) of the current / next region
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8_t*>(Wb + (g * 32 + n) * 16 + (p * 4) * 1024);
 
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) stage_w(c + 1, buf ^ 1);
-        const int ibs = (BF3_CH * c + 8) / MP2;          // see the staging rule below
-        load_xk(ibs);
-        const unsigned char* wl = Wb + buf * BF3_CHUNK_BYTES + (g * 32 + n) * 16;
+        if (c + 1 < nchunk && !(VAR & 16)) stage_w(c + 1, buf ^ 1);
         // xk staging rule (needs MP2 >= 8, checked by the host): chunk c stages the block of step 4c + 8.  Chunk c reads the blocks of
-        // steps 4c .. 4c + 4 (its own steps and the A operands of step 4c + 4, built under its last step); those were staged by
-        // chunk c-1 (block of step 4c + 4) or earlier and published by a barrier.  The staged block is block(4c) or block(4c) + 1:
+        // steps 4c .. 4c + 4 (its own steps and the inputs of step 4c + 4's A operands, built under its last step); those were staged
+        // by chunk c-1 (block of step 4c + 4) or earlier and published by a barrier.  The staged block is block(4c) or block(4c) + 1:
         // re-staging a block that is being read writes identical values, and a new block goes to the buffer of the other parity,
         // whose previous content (block(4c) - 1) has no reader left.
+        const int ibs = ib8;
+        if (!(VAR & 32)) load_xk(ibs);
+        t8 += BF3_CH;
+        if (t8 >= MP2) { t8 -= MP2; ++ib8; }
+        const unsigned char* wl = Wb + buf * BF3_CHUNK_BYTES + (g * 32 + n) * 16;
+        if (!(VAR & 1)) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8_t*>(wl + (p * 4) * 1024);
+        }
 #pragma unroll
         for (int st = 0; st < BF3_CH; ++st) {
-            // next step's indices and A operands (built under this step's MFMAs)
             int tn = t + 1, ibn = ib;
             if (tn == MP2) { tn = 0; ibn = ib + 1; }
-            bf16x8_t an[2][3];
             const unsigned char* ws = wl + st * BF3_STEP_BYTES;
+            unsigned int an[2][3][4];
+            AIn in;
+            bf16x8_t a[2][3];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[tl][p] = as_op(aw[tl][p]);
+            // Four regions per step, one per column tile cc: 12 MFMAs + two units of the next step's A operands + the LDS reads of
+            // the next region's B operands (region 0 also reads the inputs of the units).  Inside a region the MFMAs and the VALU work
+            // are interleaved 1 : 2-3 (one wave per SIMD: a VALU instruction only hides in the shadow of an MFMA of the same wave).
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(ws + (0 * 4 + cc) * 1024);
-                const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(ws + (1 * 4 + cc) * 1024);
-                const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(ws + (2 * 4 + cc) * 1024);
-                if (cc == 1) build_a(ibn < nblk ? ibn : nblk - 1, tn, an);
+                if (cc == 0 && !(VAR & 4)) read_in(ibn < nblk ? ibn : nblk - 1, tn, in);
+                const bool last = (cc == 3 && st == BF3_CH - 1);
+                if (!last && !(VAR & 8)) {
+                    const unsigned char* wn = cc < 3 ? ws + (cc + 1) * 1024 : ws + BF3_STEP_BYTES;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const bf16x8_t*>(wn + (p * 4) * 1024);
+                }
+                if (last && (VAR & 1)) {
+                    // The chunk's barrier sits IN FRONT of its last region: the 12 MFMAs below only need registers, and they cover
+                    // the latency of the first LDS reads from the next chunk's buffer (one wave per SIMD: nothing else would).
+                    store_xk(ibs);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of chunk c + 1 have landed in LDS
+                    __syncthreads();
+                    const unsigned char* wn = Wb + (buf ^ 1) * BF3_CHUNK_BYTES + (g * 32 + n) * 16;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const bf16x8_t*>(wn + (p * 4) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl) {
                     f32x16 v = acc[tl][cc];
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b2, v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][2], b0, v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][1], b1, v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b1, v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][1], b0, v, 0, 0, 0);
-                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b0, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b[2], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][2], b[0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][1], b[1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b[1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][1], b[0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tl][0], b[0], v, 0, 0, 0);
                     acc[tl][cc] = v;
+                }
+                if (!(VAR & 4)) {
+                    build_unit(in, 2 * cc, an);
+                    build_unit(in, 2 * cc + 1, an);
+                }
+                // the region's issue order: LDS reads first, then MFMA : VALU = 1 : 2 (region 0 starts with three bare MFMAs that
+                // cover the latency of the input reads)
+                if (cc == 0) bf3_region_order<true>(); else bf3_region_order<false>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(VAR & 8) && !(last && !(VAR & 1))) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = bn[p];
                 }
             }
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[tl][p] = an[tl][p];
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) aw[tl][p][q] = (VAR & 4) ? aw[tl][p][q] : an[tl][p][q];
             t = tn; ib = ibn;
         }
-        store_xk(ibs);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of chunk c + 1 have landed in LDS
-        __syncthreads();
+        if (!(VAR & 1) && !(VAR & 32)) {
+            store_xk(ibs);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  (as cin.hip)
@@ -326,14 +426,31 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
                        static_cast<unsigned int*>(workspace));
     const int mp = (m + 1) & ~1;
     const size_t shmem = 2 * (size_t)BF3_CHUNK_BYTES + sizeof(float) * (2 * 2 * BF3_ROWS * 4 + (size_t)mp * BF3_ROWS);
-    static bool set = false;
-    if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        set = true;
-    }
     dim3 grid((unsigned)((R + BF3_ROWS - 1) / BF3_ROWS), (unsigned)ncb);
-    hipLaunchKernelGGL(cin_bf3_k, grid, dim3(256), shmem, st, x0, xk, static_cast<const unsigned char*>(workspace), m, Hp, H, D, dshift,
-                       nsteps, R, xout, pooled, pooled_ld);
+    const int var = getenv("DIR_BF3_VAR") ? atoi(getenv("DIR_BF3_VAR")) : 2;   // development switch (tools/cin_bf3_var.py)
+    const unsigned char* img = static_cast<const unsigned char*>(workspace);
+#define BF3_LAUNCH(V)                                                                                                              \
+    do {                                                                                                                           \
+        static bool set = false;                                                                                                   \
+        if (!set) {                                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            set = true;                                                                                                            \
+        }                                                                                                                          \
+        hipLaunchKernelGGL(cin_bf3_k<V>, grid, dim3(256), shmem, st, x0, xk, img, m, Hp, H, D, dshift, nsteps, R, xout, pooled, pooled_ld); \
+    } while (0)
+    switch (var) {
+        case 0: BF3_LAUNCH(0); break;
+        case 1: BF3_LAUNCH(1); break;
+        case 2: BF3_LAUNCH(2); break;
+        case 6: BF3_LAUNCH(6); break;      // timing ablations (results wrong by construction): no A build
+        case 10: BF3_LAUNCH(10); break;    // no B reads
+        case 18: BF3_LAUNCH(18); break;    // no W staging after chunk 0
+        case 34: BF3_LAUNCH(34); break;    // no barrier / xk staging
+        case 62: BF3_LAUNCH(62); break;    // MFMAs only
+        case 3: BF3_LAUNCH(3); break;
+        default: BF3_LAUNCH(2); break;
+    }
+#undef BF3_LAUNCH
     DIR_CHECK_LAUNCH("cin_layer_bf16x3");
     return DIR_OK;
 }

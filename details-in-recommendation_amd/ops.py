@@ -531,7 +531,8 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
             "gW2": gW2, "gb2": gb2, "gW3": gW3, "gb3": gb3}
 
 
-CIN_ARITH = os.environ.get("DIR_CIN_ARITH", "f32")   # default arithmetic of cin_layer: "f32" (fp32 MFMA) | "bf16x3"
+# default arithmetic of cin_layer: "auto" (bf16x3 on the shapes it covers, fp32 MFMA otherwise) | "f32" | "bf16x3"
+CIN_ARITH = os.environ.get("DIR_CIN_ARITH", "auto")
 
 
 def cin_bf16x3_covers(m, D):
@@ -544,11 +545,13 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
     want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
     arith: "f32" = dir_cin_layer_f32 (fp32 MFMA, an exact fma chain); "bf16x3" = dir_cin_layer_bf16x3_f32 (three-way bf16 split of
-    both operands, six products on the bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same); None = CIN_ARITH.
-    "bf16x3" on a shape that kernel does not cover raises."""
+    both operands, six products on the bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same; raises on a shape that
+    kernel does not cover); "auto" = bf16x3 where covered, else f32; None = CIN_ARITH (env DIR_CIN_ARITH, default "auto")."""
     arith = arith or CIN_ARITH
-    if arith not in ("f32", "bf16x3"):
-        raise ValueError("cin_layer: arith must be 'f32' or 'bf16x3'")
+    if arith not in ("auto", "f32", "bf16x3"):
+        raise ValueError("cin_layer: arith must be 'auto', 'f32' or 'bf16x3'")
+    if arith == "auto":
+        arith = "bf16x3" if cin_bf16x3_covers(x0.shape[1], x0.shape[2]) else "f32"
     _dev(x0, torch.float32, "x0")
     _dev(xk, torch.float32, "xk")
     _dev(W, torch.float32, "W")

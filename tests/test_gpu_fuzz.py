@@ -116,7 +116,7 @@ def test_fuzz_cin_forward_backward(ops, oracle, seed):
     that are not an instantiated size, H / Hp on both sides of the 32 / 64 / 128 tile limits."""
     rng = np.random.default_rng(5000 + seed)
     D = int(rng.choice([4, 8, 16, 32]))
-    m = int(rng.choice([1, 2, 5, 8, 13, 16, 26, 30, 39]))
+    m = int(rng.choice([1, 2, 5, 8, 13, 15, 16, 17, 26, 30, 39]))
     Hp = int(rng.choice([1, 3, 7, 26, 32, 33, 50, 64, 100, 128])) if seed % 4 else m
     H = int(rng.choice([1, 5, 16, 31, 32, 40, 64, 96, 128, 130, 200]))
     B = int(rng.choice([1, 3, 7, 33, 64, 129, 300]))
@@ -133,9 +133,10 @@ def test_fuzz_cin_forward_backward(ops, oracle, seed):
         assert err.max() <= tol, "max scaled err %.3e (B %d m %d D %d Hp %d H %d)" % (err.max(), B, m, D, Hp, H)
 
     ref_x, ref_p = oracle.cin_layer(x0, xk, W, acc64=True)
-    got_x, got_p = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))
-    close(got_x, ref_x)
-    close(got_p, ref_p)
+    for arith in ("f32", "bf16x3") if ops.cin_bf16x3_covers(m, D) else ("f32",):
+        got_x, got_p = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith=arith)
+        close(got_x, ref_x)
+        close(got_p, ref_p)
     ref_dW, ref_dxk, ref_dx0 = oracle.cin_backward(x0, xk, W, G)
     dx0, dxk, dW = ops.cin_layer_backward(_dev(x0), _dev(xk), _dev(W), _dev(G))
     close(dxk, ref_dxk)

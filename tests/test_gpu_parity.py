@@ -221,14 +221,48 @@ def test_din_attention_pool(ops, oracle, B, T, K, H1, H2, normalize):
                                          (19, 26, 16, 26, 96), (19, 26, 16, 12, 70), (10, 26, 16, 8, 160), (10, 26, 16, 200, 200),
                                          (6, 26, 16, 8, 190), (6, 16, 8, 8, 224), (5, 26, 16, 4, 270), (5, 8, 16, 6, 350), (7, 39, 16, 4, 90)])
 def test_cin_layer(ops, oracle, B, m, D, Hp, H):
+    """Both arithmetics of the layer against the double-accumulating oracle at the same 1e-5 bar: dir_cin_layer_f32 (fp32 MFMA) on
+    every shape, dir_cin_layer_bf16x3_f32 (three-way bf16 split, csrc/cin_bf3.hip) on the shapes it covers -- which is also what
+    the default arith="auto" runs there."""
     rng = np.random.default_rng(Hp * 13 + H)
     x0 = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
     xk = (rng.standard_normal((B, Hp, D)) * 0.5).astype(np.float32)
     W = (rng.standard_normal((H, Hp * m)) * (1.0 / np.sqrt(Hp * m))).astype(np.float32)
     ref_x, ref_p = oracle.cin_layer(x0, xk, W, acc64=True)
-    got_x, got_p = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))
+    got_x, got_p = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="f32")
     _close(got_x.cpu().numpy(), ref_x)
     _close(got_p.cpu().numpy(), ref_p)
+    if ops.cin_bf16x3_covers(m, D):
+        bx, bp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="bf16x3")
+        _close(bx.cpu().numpy(), ref_x)
+        _close(bp.cpu().numpy(), ref_p)
+        ax, ap = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))            # "auto" is the bf16x3 kernel here: bitwise the same
+        assert torch.equal(ax, bx) and torch.equal(ap, bp)
+    else:
+        with pytest.raises(ValueError):
+            ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="bf16x3")
+
+
+@pytest.mark.parametrize("B,m,D,Hp,H", [(300, 26, 16, 128, 128), (257, 15, 8, 9, 33), (64, 17, 4, 24, 129), (31, 40, 32, 8, 256),
+                                         (130, 16, 16, 1, 5), (65, 33, 16, 17, 100), (1, 26, 16, 26, 128), (513, 26, 16, 100, 64)])
+def test_cin_layer_bf16x3_shapes(ops, oracle, B, m, D, Hp, H):
+    """csrc/cin_bf3.hip on its own edge shapes: the smallest field counts (the xk staging rule needs ceil(m/2) >= 8), odd m (a zero
+    field pads the pair), Hp that is not a multiple of the 8-wide i blocks, step counts that are not whole chunks, several
+    column blocks, partial last workgroups, D = 4 .. 32, and operands of very different magnitudes (the split keeps fp32's
+    exponent range: the error bar is relative to the terms, not to 1)."""
+    rng = np.random.default_rng(B * 7 + Hp)
+    for scale in (1.0, 1e-3, 64.0):
+        x0 = (rng.standard_normal((B, m, D)) * 0.5 * scale).astype(np.float32)
+        xk = (rng.standard_normal((B, Hp, D)) * 0.5).astype(np.float32)
+        W = (rng.standard_normal((H, Hp * m)) * (1.0 / np.sqrt(Hp * m))).astype(np.float32)
+        ref_x, ref_p = oracle.cin_layer(x0, xk, W, acc64=True)
+        bx, bp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="bf16x3")
+        err_x = np.abs(bx.cpu().double().numpy() - ref_x) / (scale + np.abs(ref_x))
+        err_p = np.abs(bp.cpu().double().numpy() - ref_p) / (scale + np.abs(ref_p))
+        assert err_x.max() <= 1e-5 and err_p.max() <= 1e-5, (scale, err_x.max(), err_p.max())
+    # pooled-only call: bitwise the pooled sums of the full call
+    none, only = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), want_xout=False, arith="bf16x3")
+    assert none is None and torch.equal(only, bp)
 
 
 def test_cin_pooled_only(ops):
@@ -382,7 +416,12 @@ def test_full_size_properties_cross_cin_din(ops, oracle):
     rx, rp = oracle.cin_layer(c0[sel].cpu().numpy(), xk[sel].cpu().numpy(), W.cpu().numpy(), acc64=True)
     assert (np.abs(xo[sel].cpu().double().numpy() - rx) / (1 + np.abs(rx))).max() <= 1e-5
     assert (np.abs(po[sel].cpu().double().numpy() - rp) / (1 + np.abs(rp))).max() <= 1e-5
-    del xo, xo2, po2, xk
+    # (the default "auto" ran the bf16x3 kernel above; the fp32-MFMA kernel at the same size, same checks)
+    fo, fp_ = ops.cin_layer(c0, xk, W, arith="f32")
+    assert (np.abs(fo[sel].cpu().double().numpy() - rx) / (1 + np.abs(rx))).max() <= 1e-5
+    assert (np.abs(fp_[sel].cpu().double().numpy() - rp) / (1 + np.abs(rp))).max() <= 1e-5
+    assert float(((fo - xo).abs() / (1 + fo.abs())).max()) <= 1e-5       # the two arithmetics against each other, every element
+    del xo, xo2, po2, xk, fo, fp_
     # ---- DIN, T = 50, K = 64, 80-40-1, normalised -----------------------------------------------------------------------
     T, K, V, H1, H2 = 50, 64, 1000000, 80, 40
     table = torch.randn((V, K), generator=g, device="cuda") * 0.125
