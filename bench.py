@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0      # measured float4 copy ceiling (same guide)
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA peak
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the 2:1-sparsity figure is not used)
 
 
 def parse():
@@ -53,6 +54,8 @@ def parse():
     ap.add_argument("--train-layout", default="packed", choices=["packed", "split", "split_unfused"],
                     help="train_sparse: packed = [embedding | accumulator] rows + FM backward folded into the update; split = separate "
                          "[V,K] tables and accumulators (the reference's variable layout) with the fold; split_unfused = round 1's path")
+    ap.add_argument("--cin-arith", default=None, choices=["auto", "f32", "bf16x3"],
+                    help="cin: arithmetic of ops.cin_layer (default: the library default, 'auto' = bf16x3 where covered)")
     ap.add_argument("--cross-d", type=int, default=416, help="dcn_cross / dcn_cross_backward: row width (416 = 26 x 16; 429 with the 13 dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -197,38 +200,53 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
         hp = h
     pooled = torch.empty((B, sum(Hs)), dtype=torch.float32, device=device)
 
-    def step(i):
+    def step(i, arith):
         x0 = lookup(idsl[i % 2]).view(B, F, K)
         xk, off = x0, 0
         for k, (W, h) in enumerate(zip(Ws, Hs)):
-            xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Hs))
+            xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Hs), arith=arith)
             off += h
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+
+    def run(arith):     # the contract's timing (barrier + synchronize on both sides, max over ranks) for one arithmetic
+        for i in range(warmup):
+            step(i, arith)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, arith)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     flops, hp = 0, F
     for h in Hs:
         flops += 2 * B * K * hp * F * h
         hp = h
-    tf = flops * steps / el / 1e12
+    # Two arithmetics of the same layer: the default is the bf16x3 kernel (every fp32 operand split into three bf16 pieces,
+    # six piece products on the bf16 matrix pipe, fp32 accumulate: same 1e-5 parity bar); the fp32-MFMA kernel is timed beside it.
+    el = run(None)
+    el32 = run("f32")
+    tf, tf32 = flops * steps / el / 1e12, flops * steps / el32 / 1e12
+    default_is_bf3 = ops.CIN_ARITH in ("auto", "bf16x3")
     return {"metric": "samples/sec (xDeepFM CIN 3x128 + embedding lookup, table 1e8 x 16%s)" % (" row-sharded" if world > 1 else ""),
             "value": B * world * steps / el, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": el * 1e3 / steps, "scaling": "weak", "per_gpu_TFLOPs_lookup_included": tf, "per_gpu_frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TF,
+            "ms_per_step": el * 1e3 / steps, "scaling": "weak",
+            "dtype": "f32 via bf16x3 split, f32 accumulate" if default_is_bf3 else "f32",
+            "per_gpu_fp32_equiv_TFLOPs_lookup_included": tf,
+            "per_gpu_bf16_pipe_TFLOPs_executed": 6 * tf if default_is_bf3 else None,
+            "per_gpu_frac_of_bf16_mfma_peak": 6 * tf / MFMA_BF16_PEAK_TF if default_is_bf3 else None,
+            "fp32_mfma_kernel": {"dtype": "f32", "ms_per_step": el32 * 1e3 / steps, "value": B * world * steps / el32,
+                                 "per_gpu_TFLOPs_lookup_included": tf32, "per_gpu_frac_of_fp32_mfma_peak": tf32 / MFMA_F32_PEAK_TF},
             "config": {"workload": "xdeepfm_cin_sharded", "batch_per_gpu": B, "m": F, "D": K, "layers": list(Hs), "table_rows": Vf * F}}
 
 
@@ -689,14 +707,24 @@ def main():
         def step(i):
             xk, off = x0, 0
             for k, (W, h) in enumerate(zip(Ws, Hs)):   # as XDeepFM.cin: the last layer's map feeds nothing
-                xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Hs))
+                xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Hs), arith=args.cin_arith)
                 off += h
         flops, hp = 0, m
         for h in Hs:
             flops += 2 * B * D * hp * m * h
             hp = h
-        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_k x3"}
-        cfg.update({"m": m, "D": D, "layers": list(Hs), "outputs": "pooled [B,384]; xout of layers 1-2"})
+        arith = args.cin_arith or ops.CIN_ARITH
+        if arith == "auto":
+            arith = "bf16x3" if ops.cin_bf16x3_covers(m, D) else "f32"
+        if arith == "bf16x3":
+            # priced on the pipe it runs on: six bf16 piece products per fp32 product (csrc/cin_bf3.hip) against the dense bf16 peak;
+            # the fp32-equivalent rate (the algorithm's flops / time) is reported beside it
+            roof = {"bound": "mfma", "alg_flops": 6 * flops, "kernel": "cin_bf3_k x3", "peak_tf": MFMA_BF16_PEAK_TF,
+                    "dtype": "f32 via bf16x3 split, f32 accumulate", "fp32_equiv_flops": flops,
+                    "note": "alg_flops = 6 bf16 piece products per fp32 product; peak = dense bf16 MFMA"}
+        else:
+            roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_k x3"}
+        cfg.update({"m": m, "D": D, "layers": list(Hs), "outputs": "pooled [B,384]; xout of layers 1-2", "arith": arith})
 
     elif wl == "cin_backward":
         # backward of the 3-layer CIN stack given dL/dpooled (the forward's saved activations are inputs):
@@ -837,9 +865,15 @@ def main():
                     res["roofline"]["frac_at_median"] = roof["alg_bytes"] / (per[nl // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS
         else:
             ach = roof["alg_flops"] / (launch_us * 1e-6) / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "kernel": roof["kernel"],
+            peak_tf = roof.get("peak_tf", MFMA_F32_PEAK_TF)
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s",
+                               "frac": ach / peak_tf, "traffic": None, "kernel": roof["kernel"],
                                "alg_flops_per_step": roof["alg_flops"], "avg_step_us": launch_us}
+            if "dtype" in roof:
+                res["dtype"] = roof["dtype"]
+            if "fp32_equiv_flops" in roof:
+                res["roofline"]["fp32_equiv_TFLOPs"] = roof["fp32_equiv_flops"] / (launch_us * 1e-6) / 1e12
+                res["roofline"]["fp32_equiv_frac_of_fp32_mfma_peak"] = res["roofline"]["fp32_equiv_TFLOPs"] / MFMA_F32_PEAK_TF
             if "executed_flops" in roof:
                 res["roofline"]["executed_TFLOPs"] = roof["executed_flops"] / (launch_us * 1e-6) / 1e12
                 res["roofline"]["executed_frac"] = res["roofline"]["executed_TFLOPs"] / MFMA_F32_PEAK_TF

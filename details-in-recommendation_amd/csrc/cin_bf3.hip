@@ -159,14 +159,15 @@ __global__ __launch_bounds__(256, 1) void cin_bf3_k(const float* __restrict__ x0
     const float* x0src = x0 + ((srow >> dshift) * m) * D + (srow & (D - 1));
     const float* xksrc = xk + ((srow >> dshift) * Hp) * D + (srow & (D - 1));
 
-    auto stage_w = [&](int c, int buf) {     // 12 x 1 KB pieces per wave, lane-linear
+    auto stage_piece = [&](int c, int buf, int q) {   // piece q of this wave's 12 x 1 KB pieces of chunk c, lane-linear
+        const int piece = q * 4 + wave;
+        const unsigned char* src = gimg + (int64_t)((VAR & 128) ? 0 : c) * BF3_CHUNK_BYTES + piece * 1024 + lane * 16;
+        unsigned char* dst = Wb + buf * BF3_CHUNK_BYTES + piece * 1024;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    };
+    auto stage_w = [&](int c, int buf) {
 #pragma unroll
-        for (int q = 0; q < BF3_CHUNK_BYTES / 1024 / 4; ++q) {
-            const int piece = q * 4 + wave;
-            const unsigned char* src = gimg + (int64_t)c * BF3_CHUNK_BYTES + piece * 1024 + lane * 16;
-            unsigned char* dst = Wb + buf * BF3_CHUNK_BYTES + piece * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
-        }
+        for (int q = 0; q < BF3_CHUNK_BYTES / 1024 / 4; ++q) stage_piece(c, buf, q);
     };
     float xreg[8];
     auto load_xk = [&](int ib) {             // block ib of 8 values of i (zeros past Hp: the W image is zero there, 0 * garbage must stay 0)
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void cin_bf3_k(const float* __restrict__ x0
 
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk && !(VAR & 16)) stage_w(c + 1, buf ^ 1);
+        if (c + 1 < nchunk && !(VAR & 16) && !(VAR & 64)) stage_w(c + 1, buf ^ 1);
+        const int cn = c + 1 < nchunk ? c + 1 : c;    // (VAR & 64: pieces issued region by region; the last chunk re-stages itself into the idle buffer)
         // xk staging rule (needs MP2 >= 8, checked by the host): chunk c stages the block of step 4c + 8.  Chunk c reads the blocks of
         // steps 4c .. 4c + 4 (its own steps and the inputs of step 4c + 4's A operands, built under its last step); those were staged
         // by chunk c-1 (block of step 4c + 4) or earlier and published by a barrier.  The staged block is block(4c) or block(4c) + 1:
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(256, 1) void cin_bf3_k(const float* __restrict__ x0
             // are interleaved 1 : 2-3 (one wave per SIMD: a VALU instruction only hides in the shadow of an MFMA of the same wave).
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
+                if ((VAR & 64) && st * 4 + cc < BF3_CHUNK_BYTES / 1024 / 4) stage_piece(cn, buf ^ 1, st * 4 + cc);
                 if (cc == 0 && !(VAR & 4)) read_in(ibn < nblk ? ibn : nblk - 1, tn, in);
                 const bool last = (cc == 3 && st == BF3_CH - 1);
                 if (!last && !(VAR & 8)) {
@@ -399,7 +402,8 @@ using namespace dir;
 
 extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     if (m <= 0 || Hp <= 0 || H <= 0) return 0;
-    return (int64_t)((H + 127) / 128) * bf3_steps(m, Hp) * BF3_STEP_BYTES;
+    const int64_t a = (int64_t)((H + 127) / 128) * bf3_steps(m, Hp) * BF3_STEP_BYTES, b = cin_bf3t_workspace_bytes(m, Hp, H);
+    return a > b ? a : b;
 }
 
 extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
@@ -410,7 +414,8 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     DIR_CHECK_ARG(!pooled || pooled_ld >= H, "%s: pooled_ld=%lld < H=%d", name, (long long)pooled_ld, H);
     if (!(D == 4 || D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 4, 8, 16, 32)", name, D);
-    if (m > 40 || m < 15) return fail(DIR_E_UNSUPPORTED, "%s: field count m=%d (supported: 15..40; use dir_cin_layer_f32)", name, m);
+    const int kern = getenv("DIR_BF3_KERNEL") ? atoi(getenv("DIR_BF3_KERNEL")) : 1;   // development switch: 1 = cin_bf3_k, 2 = cin_bf3t_k
+    if (m > 40 || (kern != 2 && m < 15)) return fail(DIR_E_UNSUPPORTED, "%s: field count m=%d (supported: 15..40; use dir_cin_layer_f32)", name, m);
     if (xout && !aligned16(xout)) return fail(DIR_E_BADARG, "%s: xout must be 16-byte aligned", name);
     DIR_CHECK_ARG(aligned16(workspace) && workspace_bytes >= dir_cin_bf16x3_workspace_bytes(m, Hp, H),
                   "%s: workspace must be 16-byte aligned and hold dir_cin_bf16x3_workspace_bytes(m, Hp, H) bytes", name);
@@ -421,6 +426,11 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
     const int nsteps = bf3_steps(m, Hp);
     const int ncb = (H + 127) / 128;
     hipStream_t st = as_stream(stream);
+    if (kern == 2) {
+        launch_cin_bf3t(st, x0, xk, W, m, Hp, H, D, dshift, R, xout, pooled, pooled_ld, workspace);
+        DIR_CHECK_LAUNCH("cin_layer_bf16x3");
+        return DIR_OK;
+    }
     const int64_t pack_threads = (int64_t)ncb * nsteps * 1024;
     hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((pack_threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, nsteps, ncb,
                        static_cast<unsigned int*>(workspace));
@@ -442,6 +452,8 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
         case 0: BF3_LAUNCH(0); break;
         case 1: BF3_LAUNCH(1); break;
         case 2: BF3_LAUNCH(2); break;
+        case 66: BF3_LAUNCH(66); break;    // W pieces issued region by region
+        case 130: BF3_LAUNCH(130); break;  // ablation: W staged from chunk 0 every time (L1/L2-hot source)
         case 6: BF3_LAUNCH(6); break;      // timing ablations (results wrong by construction): no A build
         case 10: BF3_LAUNCH(10); break;    // no B reads
         case 18: BF3_LAUNCH(18); break;    // no W staging after chunk 0

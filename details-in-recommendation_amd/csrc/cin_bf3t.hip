@@ -1,0 +1,282 @@
+// cin_bf3t.hip -- the bf16x3 CIN layer, second formulation: the field factor is applied AFTER the matrix product.
+//
+// NO REFERENCE CODE (README.md:28 links arXiv:1803.05170); definition as in cin.hip / include/dir_hip.h:
+//   xout[b,h,d] = sum_{i<Hp} sum_{j<m} W[h, i*m+j] * xk[b,i,d] * x0[b,j,d]
+//               = sum_j x0[r,j] * T_j[r,h],      T_j[r,h] = sum_i xk[r,i] * W[h,i,j]        (r = (b,d))
+//
+// T_j is a plain GEMM whose left operand xk does not depend on j, so its three-way bf16 split (cin_bf3.hip: v = v0 + v1 + v2, round to
+// nearest, six piece products of weight >= 2^-16 on the bf16 matrix pipe, fp32 accumulate) is done ONCE per 64 values of i and kept in
+// registers for all m fields -- the MFMA loop has no split arithmetic at all; what remains on the VALU is out += x0[r,j] * T_j (one fma
+// per accumulator register and field).  Matrix instruction: v_mfma_f32_16x16x32_bf16, which on random operands holds a higher clock
+// than the 32x32x16 form (tools/bf16_shape_probe.hip: 2.20 vs 1.79 PFLOP/s chip-wide at equal cycles per flop).
+//
+// Work split.  A workgroup of 8 waves (two per SIMD) owns 256 rows x 128 columns; wave w rows [32w, 32w+32) = 2 row tiles x 8 column
+// tiles of 16 x 16: 64 accumulator registers for T_j and 64 for out.  i runs in halves of KS*32 values (KS = 2; 1 when Hp <= 32); a
+// chunk is one (half, field j): KS k-steps x 16 tiles x 6 = 192 MFMAs per wave, one barrier per chunk.
+//
+// LDS: Wb [2][KS][3 planes][8 ct][64 lanes][8 bf16]  the chunk's W operand image, written by global_load_lds in the order
+//                                                    cin_bf3t_pack_w_k lays the global image out (one ds_read_b128 per operand);
+//      x0s [m][256] f32                              the workgroup's x0 slice.
+#include "common.hpp"
+
+namespace dir {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int BT_ROWS = 256;
+constexpr int BT_STEP_BYTES = 3 * 8 * 64 * 16;     // 24 KB of W image per k-step of 32
+
+__device__ __forceinline__ unsigned int bt_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
+    unsigned int w;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
+    return w;
+}
+__device__ __forceinline__ void bt_split_pair(float a, float b, unsigned int& w0, unsigned int& w1, unsigned int& w2) {
+    w0 = bt_pk(a, b);
+    const float ra = a - __builtin_bit_cast(float, w0 << 16), rb = b - __builtin_bit_cast(float, w0 & 0xffff0000u);
+    w1 = bt_pk(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, w1 << 16), sb = rb - __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = bt_pk(sa, sb);
+}
+
+// W [H, Hp*m] fp32 -> image [column block of 128][half kh][field j][ks][plane][ct][lane][8 e] bf16, element e of lane l of column tile ct
+// in k-step ks = piece of W[h = 128*cb + 16*ct + (l & 15)][i = KS*32*kh + 32*ks + 8*(l >> 4) + e][j]; zero where h >= H or i >= Hp.
+__global__ __launch_bounds__(256) void cin_bf3t_pack_w_k(const float* __restrict__ W, int m, int Hp, int H, int KS, int nkh, int ncb,
+                                                        unsigned int* __restrict__ img) {
+    const int64_t total = (int64_t)ncb * nkh * m * KS * 8 * 64 * 4;   // one thread per pair of e
+    for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
+        int64_t q = e_;
+        const int ep = (int)(q & 3); q >>= 2;
+        const int l = (int)(q & 63); q >>= 6;
+        const int ct = (int)(q & 7); q >>= 3;
+        const int ks = (int)(q % KS); q /= KS;
+        const int j = (int)(q % m); q /= m;
+        const int kh = (int)(q % nkh);
+        const int cb = (int)(q / nkh);
+        const int h = cb * 128 + 16 * ct + (l & 15);
+        const int i = KS * 32 * kh + 32 * ks + 8 * (l >> 4) + 2 * ep;
+        const float v0 = (h < H && i < Hp) ? W[(int64_t)h * Hp * m + (int64_t)i * m + j] : 0.f;
+        const float v1 = (h < H && i + 1 < Hp) ? W[(int64_t)h * Hp * m + (int64_t)(i + 1) * m + j] : 0.f;
+        unsigned int p0, p1, p2;
+        bt_split_pair(v0, v1, p0, p1, p2);
+        const int64_t chunk = ((int64_t)cb * nkh + kh) * m + j;
+        const int64_t base = (chunk * KS + ks) * (BT_STEP_BYTES / 4) + (ct * 64 + l) * 4 + ep;     // plane stride: 8*64*4 dwords
+        img[base] = p0;
+        img[base + 8 * 64 * 4] = p1;
+        img[base + 2 * 8 * 64 * 4] = p2;
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 1) void cin_bf3t_k(const float* __restrict__ x0, const float* __restrict__ xk,
+                                                     const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
+                                                     int nkh, int64_t R, float* __restrict__ xout, float* __restrict__ pooled,
+                                                     int64_t pooled_ld) {
+    constexpr int CHB = KS * BT_STEP_BYTES;                      // bytes of W image per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char bt_smem[];
+    unsigned char* Wb = bt_smem;                                 // [2][CHB]
+    float* x0s = reinterpret_cast<float*>(bt_smem + 2 * CHB);    // [m][256]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n = lane & 15;
+    const int lg = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * BT_ROWS;
+    const int hbase = blockIdx.y * 128;
+    const int nchunk = nkh * m;
+    const unsigned char* gimg = img + (int64_t)blockIdx.y * nchunk * CHB;
+
+    auto stage_w = [&](int c, int buf) {     // CHB / 1 KB pieces over 8 waves, lane-linear
+#pragma unroll
+        for (int q = 0; q < CHB / 1024 / 8; ++q) {
+            const int piece = q * 8 + wave;
+            const unsigned char* src = gimg + (int64_t)c * CHB + piece * 1024 + lane * 16;
+            unsigned char* dst = Wb + buf * CHB + piece * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+
+    // ---- prologue: W chunk 0 and the x0 slice (thread t: row t & 255, fields of parity t >> 8)
+    stage_w(0, 0);
+    {
+        const int r = tid & 255;
+        const int64_t srow = (row0 + r < R) ? row0 + r : R - 1;     // a row >= R only feeds output rows that are never stored
+        const float* x0src = x0 + ((srow >> dshift) * m) * D + (srow & (D - 1));
+        for (int j = tid >> 8; j < m; j += 2) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
+    }
+
+    // this lane's A rows: row tile rt -> row 32*wave + 16*rt + n of the workgroup; k slot 8*lg + e of each k-step
+    const float* xsrc[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int64_t gr = row0 + wave * 32 + rt * 16 + n;
+        const int64_t grc = gr < R ? gr : R - 1;
+        xsrc[rt] = xk + ((grc >> dshift) * Hp) * D + (grc & (D - 1));
+    }
+
+    f32x4 out[2][8], T[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            out[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            T[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    f32x4 xprev[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};     // x0[rows of the lane's accumulator registers, previous field]
+    bf16x8_t a[KS][2][3];                                                            // the half's A operands: [k-step][row tile][piece]
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const unsigned char* wlane = Wb + lane * 16;
+    const float* x0lane = x0s + wave * 32 + 4 * lg;      // + j*256 + 16*rt: the 4 rows of accumulator registers 0..3 of tile rt
+
+    int c = 0;
+    for (int kh = 0; kh < nkh; ++kh) {
+        // ---- A operands of this half: xk[r, KS*32*kh + 32*ks + 8*lg + e], split once, used by all m fields
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = KS * 32 * kh + 32 * ks + 8 * lg + e;
+                    const float x = xsrc[rt][(int64_t)(i < Hp ? i : Hp - 1) * D];
+                    v[e] = i < Hp ? x : 0.f;          // the W image is zero there; 0 * garbage must stay 0
+                }
+                unsigned int w[3][4];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) bt_split_pair(v[2 * pr], v[2 * pr + 1], w[0][pr], w[1][pr], w[2][pr]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[ks][rt][p] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
+            }
+        for (int j = 0; j < m; ++j, ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunk) stage_w(c + 1, buf ^ 1);
+            const unsigned char* wl = wlane + buf * CHB;
+            f32x4 xcur[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) xcur[rt] = *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {
+                    const unsigned char* wp = wl + ks * BT_STEP_BYTES + ct * 1024;
+                    const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(wp);
+                    const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(wp + 8 * 1024);
+                    const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(wp + 16 * 1024);
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        f32x4 t;
+                        if (ks == 0) {
+                            // the previous chunk's T tile goes into `out` just before this chunk's first MFMA chain overwrites it
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
+                            t = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            t = T[rt][ct];
+                        }
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][0], b2, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][2], b0, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][1], b1, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][0], b1, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][1], b0, t, 0, 0, 0);
+                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][0], b0, t, 0, 0, 0);
+                        T[rt][ct] = t;
+                    }
+                }
+            }
+            xprev[0] = xcur[0];
+            xprev[1] = xcur[1];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of chunk c + 1 have landed in LDS
+            __syncthreads();
+        }
+    }
+    // the last chunk's T
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
+
+    // ---- epilogue: C/D map of 16x16x32: col = lane & 15, row = 4*(lane >> 4) + reg
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int64_t gr = row0 + wave * 32 + rt * 16 + 4 * lg;     // first of the lane's 4 consecutive rows (same sample: D >= 4)
+        const int64_t b = gr >> dshift;
+        const int d = (int)(gr & (D - 1));
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int h = hbase + 16 * ct + n;
+            const f32x4 v = out[rt][ct];
+            if (xout && h < H && gr < R) *reinterpret_cast<f32x4*>(xout + (b * H + h) * D + d) = v;
+        }
+    }
+    if (pooled) {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int h = hbase + 16 * ct + n;
+            float s[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x4 v = out[rt][ct];
+                float p = (v[0] + v[1]) + (v[2] + v[3]);          // rows 4*lg .. 4*lg+3 of the tile
+                if (D >= 8) p += __shfl_xor(p, 16, 64);           // lane groups of one sample
+                if (D >= 16) p += __shfl_xor(p, 32, 64);
+                s[rt] = p;
+            }
+            if (D == 32) { s[0] += s[1]; }
+            const bool writer = D == 4 ? true : (D == 8 ? (lg & 1) == 0 : lg == 0);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                if (D == 32 && rt == 1) continue;
+                const int64_t gr = row0 + wave * 32 + rt * 16 + 4 * lg;
+                if (writer && h < H && gr < R) pooled[(gr >> dshift) * pooled_ld + h] = s[rt];
+            }
+        }
+    }
+}
+
+int64_t cin_bf3t_workspace_bytes(int m, int Hp, int H) {
+    const int KS = Hp <= 32 ? 1 : 2;
+    const int nkh = (Hp + KS * 32 - 1) / (KS * 32);
+    return (int64_t)((H + 127) / 128) * nkh * m * KS * BT_STEP_BYTES;
+}
+
+int launch_cin_bf3t(hipStream_t st, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int dshift, int64_t R,
+                    float* xout, float* pooled, int64_t pooled_ld, void* workspace) {
+    const int KS = Hp <= 32 ? 1 : 2;
+    const int nkh = (Hp + KS * 32 - 1) / (KS * 32);
+    const int ncb = (H + 127) / 128;
+    const int64_t pack_threads = (int64_t)ncb * nkh * m * KS * 8 * 64 * 4;
+    hipLaunchKernelGGL(cin_bf3t_pack_w_k, dim3((unsigned)((pack_threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, KS, nkh, ncb,
+                       static_cast<unsigned int*>(workspace));
+    const size_t shmem = 2 * (size_t)KS * BT_STEP_BYTES + sizeof(float) * (size_t)m * BT_ROWS;
+    dim3 grid((unsigned)((R + BT_ROWS - 1) / BT_ROWS), (unsigned)ncb);
+    const unsigned char* img = static_cast<const unsigned char*>(workspace);
+    if (KS == 1) {
+        static bool set = false;
+        if (!set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3t_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            set = true;
+        }
+        hipLaunchKernelGGL(cin_bf3t_k<1>, grid, dim3(512), shmem, st, x0, xk, img, m, Hp, H, D, dshift, nkh, R, xout, pooled, pooled_ld);
+    } else {
+        static bool set = false;
+        if (!set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3t_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            set = true;
+        }
+        hipLaunchKernelGGL(cin_bf3t_k<2>, grid, dim3(512), shmem, st, x0, xk, img, m, Hp, H, D, dshift, nkh, R, xout, pooled, pooled_ld);
+    }
+    return 0;
+}
+
+}  // namespace dir
