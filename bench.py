@@ -715,7 +715,7 @@ def main():
             hp = h
         arith = args.cin_arith or ops.CIN_ARITH
         if arith == "auto":
-            arith = "bf16x3" if ops.cin_bf16x3_covers(m, D) else "f32"
+            arith = ops.cin_auto_arith(m, D, Hs[0], Hs[0])
         if arith == "bf16x3":
             # priced on the pipe it runs on: six bf16 piece products per fp32 product (csrc/cin_bf3.hip) against the dense bf16 peak;
             # the fp32-equivalent rate (the algorithm's flops / time) is reported beside it

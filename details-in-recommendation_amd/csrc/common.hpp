@@ -69,11 +69,6 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
                     const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                     const float* b3, int normalize, int64_t B, float* out, float* scores);
 
-// csrc/cin_bf3t.hip: the bf16x3 CIN layer with the field factor applied after the matrix product (16x16x32 MFMA, any m)
-int64_t cin_bf3t_workspace_bytes(int m, int Hp, int H);
-int launch_cin_bf3t(hipStream_t st, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int dshift, int64_t R,
-                    float* xout, float* pooled, int64_t pooled_ld, void* workspace);
-
 }  // namespace dir
 
 // ---- device helpers ------------------------------------------------------------------------

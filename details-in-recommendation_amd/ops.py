@@ -537,7 +537,17 @@ CIN_ARITH = os.environ.get("DIR_CIN_ARITH", "auto")
 
 def cin_bf16x3_covers(m, D):
     """Shapes dir_cin_layer_bf16x3_f32 accepts (csrc/cin_bf3.hip)."""
-    return 15 <= m <= 40 and D in (4, 8, 16, 32)
+    return 1 <= m <= 40 and D in (4, 8, 16, 32)
+
+
+def cin_auto_arith(m, D, Hp, H):
+    """What arith="auto" runs: the bf16x3 kernel where it accepts the shape and does not waste more than a third of its matrix work
+    on padding (it computes columns in blocks of 128 and i in blocks of 32 / 64: H = 32 or Hp = 7 belong to the fp32-MFMA kernel)."""
+    if not cin_bf16x3_covers(m, D):
+        return "f32"
+    hpad = -(-H // 128) * 128
+    ipad = 32 if Hp <= 32 else -(-Hp // 64) * 64
+    return "bf16x3" if hpad * ipad <= 1.34 * H * Hp else "f32"
 
 
 def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
@@ -546,12 +556,12 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
     want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
     arith: "f32" = dir_cin_layer_f32 (fp32 MFMA, an exact fma chain); "bf16x3" = dir_cin_layer_bf16x3_f32 (three-way bf16 split of
     both operands, six products on the bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same; raises on a shape that
-    kernel does not cover); "auto" = bf16x3 where covered, else f32; None = CIN_ARITH (env DIR_CIN_ARITH, default "auto")."""
+    kernel does not cover); "auto" = cin_auto_arith(m, D, Hp, H); None = CIN_ARITH (env DIR_CIN_ARITH, default "auto")."""
     arith = arith or CIN_ARITH
     if arith not in ("auto", "f32", "bf16x3"):
         raise ValueError("cin_layer: arith must be 'auto', 'f32' or 'bf16x3'")
     if arith == "auto":
-        arith = "bf16x3" if cin_bf16x3_covers(x0.shape[1], x0.shape[2]) else "f32"
+        arith = cin_auto_arith(x0.shape[1], x0.shape[2], xk.shape[1], W.shape[0])
     _dev(x0, torch.float32, "x0")
     _dev(xk, torch.float32, "xk")
     _dev(W, torch.float32, "W")
@@ -567,7 +577,7 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
         pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
     if arith == "bf16x3":
         if not cin_bf16x3_covers(m, D):
-            raise ValueError("cin_layer: arith='bf16x3' covers 15 <= m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (m, D))
+            raise ValueError("cin_layer: arith='bf16x3' covers m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (m, D))
         lib = _lib.load()
         nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, Hp, H))
         ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)

@@ -206,13 +206,15 @@ int dir_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
 int dir_cin_layer_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                       int64_t B, float* xout, float* pooled, int64_t pooled_ld,
                       dir_stream_t stream);
-/* The same layer on the bf16 matrix pipe with fp32-equivalent arithmetic (csrc/cin_bf3.hip): the rounded fp32 product
- * xk*x0 and W are each split into three bf16 pieces (round to nearest; the pieces sum to the operand exactly) and the six
- * piece products of weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- same 1e-5 bar against the
- * double-accumulating oracle as dir_cin_layer_f32, 6/16 of its matrix-pipe time.  Results are not bitwise those of
- * dir_cin_layer_f32 (different summation tree).  workspace: dir_cin_bf16x3_workspace_bytes(m, Hp, H) device bytes, 16-byte
- * aligned (the packed bf16 image of W, rebuilt by every call).  Shapes: D in {4, 8, 16, 32}; 15 <= m <= 40; any Hp, H
- * (DIR_E_UNSUPPORTED otherwise: use dir_cin_layer_f32). */
+/* The same layer on the bf16 matrix pipe with fp32-equivalent arithmetic (csrc/cin_bf3.hip).  Evaluated as
+ *   xout = sum_j x0[.,j] * T_j,  T_j[r,h] = sum_i xk[r,i] * W[h, i*m+j]:
+ * xk and W are each split into three bf16 pieces (round to nearest; the pieces sum to the operand exactly, fp32 exponent range), the
+ * six piece products of weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16, and the field factor is one fp32 fma
+ * per accumulator and field.  Same 1e-5 bar against the double-accumulating oracle as dir_cin_layer_f32 (measured error 2-3e-7),
+ * half its time on 128-wide layers.  Results are not bitwise those of dir_cin_layer_f32 (different summation tree).
+ * workspace: dir_cin_bf16x3_workspace_bytes(m, Hp, H) device bytes, 16-byte aligned (the packed bf16 image of W, rebuilt by
+ * every call).  Shapes: D in {4, 8, 16, 32}; m <= 40; any Hp, H (columns are computed in blocks of 128, i in blocks of 32 / 64:
+ * narrow layers are better served by dir_cin_layer_f32). */
 int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H);
 int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                              int64_t B, float* xout, float* pooled, int64_t pooled_ld,

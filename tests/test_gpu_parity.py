@@ -232,22 +232,29 @@ def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     got_x, got_p = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="f32")
     _close(got_x.cpu().numpy(), ref_x)
     _close(got_p.cpu().numpy(), ref_p)
-    if ops.cin_bf16x3_covers(m, D):
-        bx, bp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="bf16x3")
-        _close(bx.cpu().numpy(), ref_x)
-        _close(bp.cpu().numpy(), ref_p)
-        ax, ap = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))            # "auto" is the bf16x3 kernel here: bitwise the same
-        assert torch.equal(ax, bx) and torch.equal(ap, bp)
-    else:
-        with pytest.raises(ValueError):
-            ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="bf16x3")
+    assert ops.cin_bf16x3_covers(m, D)
+    bx, bp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="bf16x3")
+    _close(bx.cpu().numpy(), ref_x)
+    _close(bp.cpu().numpy(), ref_p)
+    ax, ap = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))            # "auto" is one of the two, bitwise
+    want = (bx, bp) if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
+    assert torch.equal(ax, want[0]) and torch.equal(ap, want[1])
+
+
+def test_cin_bf16x3_refuses_uncovered_shapes(ops):
+    x0 = torch.zeros((4, 41, 16), device="cuda"); xk = torch.zeros((4, 3, 16), device="cuda"); W = torch.zeros((8, 3 * 41), device="cuda")
+    assert not ops.cin_bf16x3_covers(41, 16) and ops.cin_auto_arith(41, 16, 3, 8) == "f32"
+    with pytest.raises(ValueError):
+        ops.cin_layer(x0, xk, W, arith="bf16x3")
+    assert ops.cin_auto_arith(26, 16, 128, 128) == "bf16x3" and ops.cin_auto_arith(26, 16, 26, 128) == "bf16x3"
+    assert ops.cin_auto_arith(26, 16, 128, 32) == "f32" and ops.cin_auto_arith(26, 16, 7, 128) == "f32"
 
 
 @pytest.mark.parametrize("B,m,D,Hp,H", [(300, 26, 16, 128, 128), (257, 15, 8, 9, 33), (64, 17, 4, 24, 129), (31, 40, 32, 8, 256),
-                                         (130, 16, 16, 1, 5), (65, 33, 16, 17, 100), (1, 26, 16, 26, 128), (513, 26, 16, 100, 64)])
+                                         (130, 16, 16, 1, 5), (65, 33, 16, 17, 100), (1, 26, 16, 26, 128), (513, 26, 16, 100, 64),
+                                         (40, 1, 8, 70, 20), (77, 3, 4, 33, 130), (19, 8, 32, 64, 128), (260, 13, 16, 65, 16)])
 def test_cin_layer_bf16x3_shapes(ops, oracle, B, m, D, Hp, H):
-    """csrc/cin_bf3.hip on its own edge shapes: the smallest field counts (the xk staging rule needs ceil(m/2) >= 8), odd m (a zero
-    field pads the pair), Hp that is not a multiple of the 8-wide i blocks, step counts that are not whole chunks, several
+    """csrc/cin_bf3.hip on its own edge shapes: one field, odd field counts, Hp on both sides of the 32 / 64-wide i blocks, several
     column blocks, partial last workgroups, D = 4 .. 32, and operands of very different magnitudes (the split keeps fp32's
     exponent range: the error bar is relative to the terms, not to 1)."""
     rng = np.random.default_rng(B * 7 + Hp)
