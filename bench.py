@@ -590,7 +590,12 @@ def main():
             def step(i):
                 with torch.no_grad():
                     model(featl[i % len(featl)])
-            roof = {"bound": "mfma", "alg_flops": flops, "kernel": "xDeepFM forward (CIN flops only)"}
+            if ops.cin_auto_arith(F, K, 128, 128) == "bf16x3" and ops.CIN_ARITH in ("auto", "bf16x3"):
+                roof = {"bound": "mfma", "alg_flops": 6 * flops, "kernel": "xDeepFM forward (CIN flops only; cin_bf3_k)", "peak_tf": MFMA_BF16_PEAK_TF,
+                        "dtype": "f32 (CIN: f32 via bf16x3 split, f32 accumulate)", "fp32_equiv_flops": flops,
+                        "note": "alg_flops = 6 bf16 piece products per fp32 product of the CIN; peak = dense bf16 MFMA"}
+            else:
+                roof = {"bound": "mfma", "alg_flops": flops, "kernel": "xDeepFM forward (CIN flops only)"}
         else:
             sparse_ids = {id(p) for p in model.embedding_weights} | {id(p) for p in model.linear_weights}
             opt_d = torch.optim.Adagrad([p for p in model.parameters() if id(p) not in sparse_ids], lr=0.01, initial_accumulator_value=0.1)

@@ -248,6 +248,7 @@ def test_cin_bf16x3_refuses_uncovered_shapes(ops):
         ops.cin_layer(x0, xk, W, arith="bf16x3")
     assert ops.cin_auto_arith(26, 16, 128, 128) == "bf16x3" and ops.cin_auto_arith(26, 16, 26, 128) == "bf16x3"
     assert ops.cin_auto_arith(26, 16, 128, 32) == "f32" and ops.cin_auto_arith(26, 16, 7, 128) == "f32"
+    assert ops.cin_auto_arith(26, 16, 200, 200) == "bf16x3" and ops.cin_auto_arith(26, 16, 64, 64) == "f32"
 
 
 @pytest.mark.parametrize("B,m,D,Hp,H", [(300, 26, 16, 128, 128), (257, 15, 8, 9, 33), (64, 17, 4, 24, 129), (31, 40, 32, 8, 256),

@@ -25,10 +25,11 @@ def timeit(fn, iters=5, warm=2):
 def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     B = 65536
-    print("### CIN layer, B = 65536 (forward: dir_cin_layer_f32; backward: dir_cin_dw_f32 + dir_cin_dx_f32 or the forward-kernel form)\n")
-    print("| m | D | Hp | H | forward ms | TFLOP/s | backward ms | TFLOP/s (2 GEMMs) |")
-    print("|---|---|---|---|---|---|---|---|")
-    for m, D, Hp, H in [(26, 16, 26, 128), (26, 16, 128, 128), (26, 16, 64, 64), (26, 16, 200, 200), (39, 16, 39, 128), (39, 16, 128, 128),
+    print("### CIN layer, B = 65536 (forward: dir_cin_layer_f32 and what arith='auto' runs; backward: dir_cin_dw_f32 + dir_cin_dx_f32 or the "
+          "forward-kernel form; TFLOP/s are fp32-equivalent = 2*B*D*Hp*m*H / time)\n")
+    print("| m | D | Hp | H | fp32-MFMA forward ms | TFLOP/s | of 157.3 | auto | auto forward ms | TFLOP/s | backward ms | TFLOP/s (2 GEMMs) | of 157.3 |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for m, D, Hp, H in [(26, 16, 26, 128), (26, 16, 128, 128), (26, 16, 64, 64), (26, 16, 200, 200), (26, 16, 200, 100), (26, 16, 100, 200), (39, 16, 39, 128), (39, 16, 128, 128),
                         (16, 16, 128, 128), (8, 16, 64, 64), (26, 8, 128, 128), (26, 32, 128, 128), (26, 4, 128, 128), (26, 16, 128, 32)]:
         Bs = B if D * max(Hp, H) * B * 4 < 3e9 else B // 2
         x0 = torch.randn((Bs, m, D), generator=g, device="cuda") * 0.25
@@ -36,9 +37,12 @@ def main():
         W = torch.randn((H, Hp * m), generator=g, device="cuda") / (Hp * m) ** 0.5
         G = torch.randn((Bs, H, D), generator=g, device="cuda") * 0.1
         fl = 2.0 * Bs * D * Hp * m * H
-        tf = timeit(lambda: ops.cin_layer(x0, xk, W))
+        tf = timeit(lambda: ops.cin_layer(x0, xk, W, arith="f32"))
+        auto = ops.cin_auto_arith(m, D, Hp, H)
+        ta = timeit(lambda: ops.cin_layer(x0, xk, W, arith=auto)) if auto != "f32" else tf
         tb = timeit(lambda: ops.cin_layer_backward(x0, xk, W, G), iters=3, warm=1)
-        print("| %d | %d | %d | %d | %.3f | %.1f | %.3f | %.1f |" % (m, D, Hp, H, tf, fl / tf / 1e9, tb, 2 * fl / tb / 1e9))
+        print("| %d | %d | %d | %d | %.3f | %.1f | %.2f | %s | %.3f | %.1f | %.3f | %.1f | %.2f |" % (
+            m, D, Hp, H, tf, fl / tf / 1e9, fl / tf / 1e9 / 157.3, auto, ta, fl / ta / 1e9, tb, 2 * fl / tb / 1e9, 2 * fl / tb / 1e9 / 157.3))
         del x0, xk, W, G
     print("\n### DCN cross, B = 65536, L = 3 (forward / backward)\n")
     print("| d | forward µs | TB/s | backward µs | TB/s |")
