@@ -651,7 +651,7 @@ def main():
         # what the MFMA kernel executes: valid rows only (padded to 16), layer 1 regrouped to a 2K reduction
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
         executed = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)
-        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_mfma_k (fp32 MFMA 16x16x4)",
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_wave_k (fp32 MFMA 16x16x4)",
                 "executed_flops": executed,
                 "note": "frac prices SURVEY 8d's figure (all T positions, 4K-wide layer 1); the kernel skips masked positions and "
                         "regroups layer 1 to a 2K reduction, so executed_frac is the MFMA pipe's share of peak"}
@@ -697,7 +697,7 @@ def main():
         flops = 3 * B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
         executed = 2.0 * 1024 * rt * (220 + 660)     # 16x16x4 MFMAs per 16-row tile: forward 220; backward 220 recompute + 440
-        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_mfma_k + din_bwd_k (fp32 MFMA 16x16x4)", "executed_flops": executed,
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "din_wave_k + din_rows_k + din_wgrad_k (fp32 MFMA 16x16x4)", "executed_flops": executed,
                 "note": "frac prices 3x SURVEY 8d's forward figure (all T positions, 4K-wide layer 1); executed_frac counts the MFMAs issued"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
     elif wl == "cin":
