@@ -236,236 +236,6 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void dense_k(const float* __
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (round 2): the same layer on the bf16 matrix pipe with every fp32 operand split into THREE bf16 pieces
-//     x = x0 + x1 + x2   (x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 3 x 8 significant bits = fp32's 24, exact)
-// and the six significant cross products (x0 w0, x0 w1, x1 w0, x1 w1, x0 w2, x2 w0; the three dropped ones are below 2^-24
-// relative) accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  bf16 x bf16 products are exact in the MFMA's fp32 accumulation, so
-// the result differs from an fp32 FMA chain only by summation order (measured against float64: oracle/ tests).
-// The bf16 pipe is 16x the fp32 MFMA rate: 6 products cost 6/16 of the fp32 time.  X is split in registers after its LDS read
-// (13 VALU instructions per pair of elements; VALU issues beside bf16 MFMAs, unlike beside fp32 ones); the weights arrive pre-split
-// as three bf16 planes [3][N][w_ld] (host: ops.dense_bf3_planes).
-// ------------------------------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned int pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even
-    const bf16x2_t v = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned int, v);
-}
-// 8 floats -> three bf16x8 fragments whose sum is the input
-__device__ __forceinline__ void split3(const float (&x)[8], bf16x8_t& p0, bf16x8_t& p1, bf16x8_t& p2) {
-    unsigned int w0[4], w1[4], w2[4];
-#ifdef DB_FAKE_SPLIT   // timing experiment only: no residual arithmetic (wrong values)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w0[i] = w1[i] = w2[i] = pk_bf16(x[2 * i], x[2 * i + 1]);
-    p0 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w0[0], w0[1], w0[2], w0[3]});
-    p1 = p0; p2 = p0;
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = x[2 * i], b = x[2 * i + 1];
-        w0[i] = pk_bf16(a, b);
-        const float ra = a - __builtin_bit_cast(float, w0[i] << 16), rb = b - __builtin_bit_cast(float, w0[i] & 0xffff0000u);
-        w1[i] = pk_bf16(ra, rb);
-        const float sa = ra - __builtin_bit_cast(float, w1[i] << 16), sb = rb - __builtin_bit_cast(float, w1[i] & 0xffff0000u);
-        w2[i] = pk_bf16(sa, sb);
-    }
-    p0 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w0[0], w0[1], w0[2], w0[3]});
-    p1 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w1[0], w1[1], w1[2], w1[3]});
-    p2 = __builtin_bit_cast(bf16x8_t, (u32x4_t){w2[0], w2[1], w2[2], w2[3]});
-}
-
-constexpr int DB_KB = 32;                 // one 16x16x32 MFMA step
-constexpr int DB_KC = 64;                 // W chunk staged per barrier = 2 MFMA steps
-constexpr int DB_WS = DB_KC + 8;          // W plane row stride in LDS (bf16)
-
-// X never touches LDS: in the 16x16x32 A layout a lane owns 8 consecutive k of ONE row, i.e. 32 contiguous bytes of X -- two
-// 16-byte global loads per row tile and k step, a row's four lane groups covering 128 contiguous bytes.  The loads for step s+1
-// are issued before step s's MFMAs.  Only the (shared) weight planes go through LDS, 64 k per barrier, double buffered.
-template <int NT, bool RELU>
-__global__ __launch_bounds__(256, 2) void dense_bf3_k(const float* __restrict__ X, int64_t x_ld, const __bf16* __restrict__ Wp /*[3][N][w_ld]*/,
-                                                      int64_t w_ld, const float* __restrict__ bias, int64_t M, int Kd, int N,
-                                                      float* __restrict__ Y, int64_t y_ld, int nb, int remap,
-                                                      const float* __restrict__ pscale, const float* __restrict__ pshift) {
-    constexpr int NTILES = NT / 16;
-    constexpr int WPIECES = 3 * NT * (DB_KC / 8);                    // 16-byte W pieces per chunk (8 bf16 each)
-    constexpr int WJ = (WPIECES + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float dense_smem[];
-    __bf16 (*Ws)[3 * NT * DB_WS] = reinterpret_cast<__bf16 (*)[3 * NT * DB_WS]>(dense_smem);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
-    int id = blockIdx.x;
-    if (remap) id = (id % kXCDs) * ((int)gridDim.x / kXCDs) + id / kXCDs;
-    const int nblk = id % nb;
-    const int64_t m0 = (int64_t)(id / nb) * DN_MT;
-    const int n0 = nblk * NT;
-    const int64_t plane = (int64_t)N * w_ld;                          // elements between the three weight planes
-    const int nsteps = (Kd + DB_KB - 1) / DB_KB;
-    const int nchunks = (Kd + DB_KC - 1) / DB_KC;
-
-    // Buffer loads: per-lane byte offsets fixed for the whole kernel + a wave-uniform k offset in an SGPR (no address arithmetic and
-    // no exec-mask branches in the loop); a row / piece outside the operand gets an out-of-range offset and reads zeros.  W pieces
-    // past Kd inside a row may read the next row's values: they only ever meet X values that are zero (X's k tail is masked).
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wp), 0, (int)(uint32_t)(3 * plane * 2), 0x00020000);
-    uint32_t wo[WJ];
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-        const int i = tid + 256 * j;
-        const int pl = i / (NT * (DB_KC / 8)), rem = i % (NT * (DB_KC / 8)), row = rem / (DB_KC / 8), c = rem % (DB_KC / 8);
-        wo[j] = (i < WPIECES && n0 + row < N) ? (uint32_t)((pl * plane + (int64_t)(n0 + row) * w_ld + 8 * c) * 2) : 0xfffffff0u;
-    }
-    u32x4_t wr[WJ];
-    auto gload_w = [&](int ch) {
-        const uint32_t kb = (uint32_t)(ch * DB_KC * 2);
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const float4 t = buf_load4(rw, wo[j], kb);
-            wr[j] = __builtin_bit_cast(u32x4_t, (f32x4d){t.x, t.y, t.z, t.w});
-        }
-    };
-    auto lstore_w = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int i = tid + 256 * j;
-            const int pl = i / (NT * (DB_KC / 8)), rem = i % (NT * (DB_KC / 8)), row = rem / (DB_KC / 8), c = rem % (DB_KC / 8);
-            if (i < WPIECES) *reinterpret_cast<u32x4_t*>(&Ws[buf][(pl * NT + row) * DB_WS + 8 * c]) = wr[j];
-        }
-    };
-    // this lane's rows (one per row tile) and its 8-float slice of a k step
-    const int64_t rows_x = (M - m0) < DN_MT ? (M - m0) : DN_MT;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X + m0 * x_ld), 0,
-                                                                        (int)(uint32_t)(((rows_x - 1) * x_ld + Kd) * 4), 0x00020000);
-    uint32_t xo[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int row = 32 * w + 16 * mt + r16;
-        xo[mt] = row < rows_x ? (uint32_t)((row * x_ld + 8 * kk) * 4) : 0xfffffff0u;
-    }
-    float4 x0[2][2], x1[2][2], x2[2][2], x3[2][2];      // a ring of four k steps: a step's loads are issued three steps before its MFMAs
-    auto gload_x = [&](int step, float4 (&x)[2][2]) {
-        const uint32_t kb = (uint32_t)(step * DB_KB * 4);
-        const uint32_t big = (step * DB_KB + 8 * kk < Kd) ? 0u : 0xfffffff0u;     // Kd % 8 == 0: a lane's 8 floats are all inside or all outside
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            x[mt][0] = buf_load4(rx, xo[mt] | big, kb);
-            x[mt][1] = buf_load4(rx, (xo[mt] | big) + (big ? 0u : 16u), kb);
-        }
-    };
-    f32x4d acc[2][NTILES];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTILES; ++nt) acc[mt][nt] = (f32x4d){0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int buf, int sub, const float4 (&x)[2][2]) {
-        bf16x8_t a0[2], a1[2], a2[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const float xv[8] = {x[mt][0].x, x[mt][0].y, x[mt][0].z, x[mt][0].w, x[mt][1].x, x[mt][1].y, x[mt][1].z, x[mt][1].w};
-            split3(xv, a0[mt], a1[mt], a2[mt]);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTILES; ++nt) {
-            const __bf16* bp = &Ws[buf][(16 * nt + r16) * DB_WS + sub * DB_KB + 8 * kk];
-            const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(bp);
-            const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(bp + NT * DB_WS);
-            const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(bp + 2 * NT * DB_WS);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {      // smallest products first
-                f32x4d c = acc[mt][nt];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], b2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mt], b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], b0, c, 0, 0, 0);
-                acc[mt][nt] = c;
-            }
-        }
-    };
-    // Two W chunks (four k steps) per trip: chunk c in LDS buffer 0, c + 1 in buffer 1; the chunk after next travels in registers
-    // (wr / wr2) for a whole half trip before it is stored.  Steps / chunks past the end load zeros and are not computed.
-    u32x4_t wr2[WJ];
-    auto gload_w2 = [&](int ch) {
-        const uint32_t kb = (uint32_t)(ch * DB_KC * 2);
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const float4 t = buf_load4(rw, wo[j], kb);
-            wr2[j] = __builtin_bit_cast(u32x4_t, (f32x4d){t.x, t.y, t.z, t.w});
-        }
-    };
-    auto lstore_w2 = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int i = tid + 256 * j;
-            const int pl = i / (NT * (DB_KC / 8)), rem = i % (NT * (DB_KC / 8)), row = rem / (DB_KC / 8), c = rem % (DB_KC / 8);
-            if (i < WPIECES) *reinterpret_cast<u32x4_t*>(&Ws[buf][(pl * NT + row) * DB_WS + 8 * c]) = wr2[j];
-        }
-    };
-    gload_w(0);
-    gload_x(0, x0);
-    gload_x(1, x1);
-    gload_x(2, x2);
-    lstore_w(0);
-    gload_w(1);                                          // wr: chunk 1
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 2) {
-        const int st = 2 * ch;
-        gload_x(st + 3, x3);
-        gload_w2(ch + 2);                                // wr2: chunk ch + 2
-        compute(0, 0, x0);
-        gload_x(st + 4, x0);
-        if (st + 1 < nsteps) compute(0, 1, x1);
-        gload_x(st + 5, x1);
-        lstore_w(1);                                     // chunk ch + 1 (loaded a half trip ago)
-        __syncthreads();
-        if (st + 2 < nsteps) compute(1, 0, x2);
-        gload_x(st + 6, x2);
-        gload_w(ch + 3);                                 // wr: chunk ch + 3
-        if (st + 3 < nsteps) compute(1, 1, x3);
-        lstore_w2(0);                                    // chunk ch + 2
-        __syncthreads();
-    }
-    // epilogue (plain form): bias + activation (+ folded batch-norm) on the accumulators
-#pragma unroll
-    for (int nt = 0; nt < NTILES; ++nt) {
-        const int col = n0 + 16 * nt + r16;
-        const float bcol = (bias && col < N) ? bias[col] : 0.f;
-        const float sc = (pscale && col < N) ? pscale[col] : 1.f, sf = (pscale && col < N) ? pshift[col] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t row = m0 + 32 * w + 16 * mt + 4 * kk + g;
-                float v = acc[mt][nt][g] + bcol;
-                if (RELU) v = fmaxf(v, 0.f);
-                if (pscale) v = v * sc + sf;
-                if (row < M && col < N) Y[row * y_ld + col] = v;
-            }
-    }
-}
-
-template <int NT>
-static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const __bf16* Wp, int64_t w_ld, const float* bias, int act, int64_t M,
-                             int Kd, int N, float* Y, int64_t y_ld, const float* ps, const float* psh) {
-    const int nb = (N + NT - 1) / NT;
-    const int64_t total = ((M + DN_MT - 1) / DN_MT) * nb;
-    const int remap = (total % kXCDs) == 0 ? 1 : 0;
-    const size_t shmem = sizeof(__bf16) * 2 * 3 * NT * DB_WS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bf3_k<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bf3_k<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        attr_set = true;
-    }
-    if (act)
-        hipLaunchKernelGGL((dense_bf3_k<NT, true>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wp, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, ps, psh);
-    else
-        hipLaunchKernelGGL((dense_bf3_k<NT, false>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wp, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, ps, psh);
-}
-
 template <int NT, int KC>
 static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M,
                          int Kd, int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld, const float* ps, const float* psh) {
@@ -488,6 +258,7 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
     else
         hipLaunchKernelGGL((dense_k<NT, false, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld, ps, psh);
 }
+
 
 }  // namespace dir
 
@@ -537,23 +308,4 @@ extern "C" int dir_dense_affine_f32(const float* X, int64_t x_ld, const float* W
                                     const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
     DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "dir_dense_affine_f32: post_scale and post_shift come together");
     return dense_entry("dir_dense_affine_f32", X, x_ld, Wt, w_ld, bias, act, M, Kd, N, Y, y_ld, nullptr, 0, stream, post_scale, post_shift);
-}
-
-extern "C" int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* Wplanes, int64_t w_ld, const float* bias, int act,
-                                    const float* post_scale, const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
-                                    dir_stream_t stream) {
-    const char* name = "dir_dense_bf16x3_f32";
-    DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && w_ld >= Kd && y_ld >= N, "%s: bad shape", name);
-    DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
-    DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
-    if (M == 0) return DIR_OK;
-    DIR_CHECK_ARG(X && Wplanes && Y, "%s: null pointer", name);
-    if ((Kd & 7) || (x_ld & 3) || (w_ld & 7) || !aligned16(X) || !aligned16(Wplanes))
-        return fail(DIR_E_UNSUPPORTED, "%s: Kd and w_ld multiples of 8, x_ld of 4, X / planes 16-byte aligned (Kd=%d)", name, Kd);
-    hipStream_t st = as_stream(stream);
-    const __bf16* Wp = static_cast<const __bf16*>(Wplanes);
-    if (N % 80 == 0 && N % 128 != 0) launch_dense_bf3<80>(st, X, x_ld, Wp, w_ld, bias, act, M, Kd, N, Y, y_ld, post_scale, post_shift);
-    else launch_dense_bf3<128>(st, X, x_ld, Wp, w_ld, bias, act, M, Kd, N, Y, y_ld, post_scale, post_shift);
-    DIR_CHECK_LAUNCH(name);
-    return DIR_OK;
 }

@@ -1,0 +1,320 @@
+// dense_bf3.hip -- the hidden layers of the DNN towers (dense.hip: y = act(x W^T + b)) on the bf16 matrix pipe with fp32-equivalent
+// arithmetic ("bf16 x 3", the recipe of cin_bf3.hip).
+//
+// Reference: tf.layers.dense(units, activation) as called by dnn_logit_fn (models/DeepFM/deepFM.py:295-300), _deep_architecture
+// (models/DeepCrossNetwork/DeepCrossNetwork.py:394-399) and _base_model (models/ESMM/ESMM.py:139-142): matmul + bias + activation;
+// the batch normalisation that follows the activation (deepFM.py:303-308) is the optional per-column affine of the epilogue.
+//
+// Arithmetic.  Both fp32 operands are split into three bf16 pieces by round-to-nearest (v = v0 + v1 + v2 exactly, fp32 exponent
+// range); the six piece products of weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (a bf16 x bf16 product is
+// exact in fp32), the three of weight <= 2^-24 are dropped.  Same 1e-5 bar against float64 as dense.hip's fp32 MFMA kernel.
+//
+// Why it is faster than round 2's first attempt (dense_bf3_k, removed: 1.07-1.15 x the fp32 kernel).  That kernel split X once per
+// 128 x 80 output tile -- 13 VALU instructions per pair of elements in front of only 5 column tiles of MFMAs -- and staged both
+// operands through LDS.  Here a wave splits its X rows once per k-step for a block of 13 or 16 column tiles (0.5 VALU instructions
+// per MFMA), X goes from global memory straight into the registers it is split in (a lane's 8 k-values are 32 contiguous bytes; a row
+// tile's four lane groups read whole 128-byte lines), and W arrives pre-split as a packed bf16 image through global_load_lds: no
+// staging registers, no ds_write, one ds_read_b128 per operand.  The product is evaluated transposed, D = W-piece (A operand:
+// rows = output columns) x X-piece (B operand: columns = batch rows), so that a lane's four accumulator registers are four
+// CONSECUTIVE output columns of one row: bias / ReLU / affine / gate on float4s and 16-byte stores.
+//
+// Work split.  A workgroup of 8 waves (two per SIMD) owns 256 rows x one column block of CT tiles (CT = 13: 208 columns, 16: 256,
+// 8: 128 -- the host picks the one that pads N least); wave w rows [32w, 32w+32) = 2 row tiles x CT column tiles.  One k-step of 32
+// per barrier: 12*CT MFMAs per wave.  One persistent workgroup per CU walks a contiguous range of tiles (the column blocks of a row
+// block back to back: the second finds X in the L2), software-pipelined across tiles so that a tile's stores drain under the next
+// tile's first k-step.
+//
+// LDS: Wb [2][3 pieces][CT][64 lanes][8 bf16] -- the k-step's W image, in the order dense_bf3_pack_k writes the global image.
+#include "common.hpp"
+
+namespace dir {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int DB3_ROWS = 256;
+
+__device__ __forceinline__ unsigned int db3_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
+    unsigned int w;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
+    return w;
+}
+__device__ __forceinline__ void db3_split_pair(float a, float b, unsigned int& w0, unsigned int& w1, unsigned int& w2) {
+    w0 = db3_pk(a, b);
+    const float ra = a - __builtin_bit_cast(float, w0 << 16), rb = b - __builtin_bit_cast(float, w0 & 0xffff0000u);
+    w1 = db3_pk(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, w1 << 16), sb = rb - __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = db3_pk(sa, sb);
+}
+
+__host__ __device__ inline int db3_ct_for(int N) {     // column tiles per block: the choice that pads N least (ties: the wider block)
+    const int tiles = (N + 15) / 16;
+    int best = 16, pad = (tiles + 15) / 16 * 16;
+    const int p13 = (tiles + 12) / 13 * 13, p8 = (tiles + 7) / 8 * 8;
+    if (p13 < pad) { best = 13; pad = p13; }
+    if (p8 < pad) { best = 8; pad = p8; }
+    return best;
+}
+
+// W [N, Kd] fp32 (row stride w_ld) -> image [column block][k-step][piece][ct][lane][8 e] bf16: element e of lane l of column tile ct =
+// piece of W[n = 16*(cb*CT + ct) + (l & 15)][k = 32*ks + 8*(l >> 4) + e]; zero where n >= N or k >= Kd.
+__global__ __launch_bounds__(256) void dense_bf3_pack_k(const float* __restrict__ W, int64_t w_ld, int Kd, int N, int CT, int nks, int ncb,
+                                                        unsigned int* __restrict__ img) {
+    const int64_t total = (int64_t)ncb * nks * CT * 64 * 4;   // one thread per pair of e
+    for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
+        int64_t q = e_;
+        const int ep = (int)(q & 3); q >>= 2;
+        const int l = (int)(q & 63); q >>= 6;
+        const int ct = (int)(q % CT); q /= CT;
+        const int ks = (int)(q % nks);
+        const int cb = (int)(q / nks);
+        const int n = 16 * (cb * CT + ct) + (l & 15);
+        const int k = 32 * ks + 8 * (l >> 4) + 2 * ep;
+        const float v0 = (n < N && k < Kd) ? W[(int64_t)n * w_ld + k] : 0.f;
+        const float v1 = (n < N && k + 1 < Kd) ? W[(int64_t)n * w_ld + k + 1] : 0.f;
+        unsigned int p0, p1, p2;
+        db3_split_pair(v0, v1, p0, p1, p2);
+        const int64_t step = (int64_t)cb * nks + ks;
+        const int64_t base = step * (3 * CT * 64 * 4) + (ct * 64 + l) * 4 + ep;     // piece stride: CT*64*4 dwords
+        img[base] = p0;
+        img[base + CT * 64 * 4] = p1;
+        img[base + 2 * CT * 64 * 4] = p2;
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ X, int64_t x_ld, const unsigned char* __restrict__ img,
+                                                     const float* __restrict__ bias, int relu, const float* __restrict__ post_scale,
+                                                     const float* __restrict__ post_shift, const float* __restrict__ gate, int64_t gate_ld,
+                                                     int64_t M, int Kd, int N, int nks, int ncb, float* __restrict__ Y, int64_t y_ld) {
+    constexpr int STEPB = 3 * CT * 1024;                       // bytes of W image per k-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char db3_smem[];
+    unsigned char* Wb = db3_smem;                              // [2][STEPB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int n = lane & 15;
+    const int lg = lane >> 4;
+    // Persistent workgroups, software-pipelined across their tiles: the last k-step of a tile prefetches the next tile's first
+    // operands, and the epilogue's stores are issued without waiting for them, so that they drain under the next tile's first k-step
+    // (with one tile per workgroup the whole chip stores in lockstep and nothing computes meanwhile).  Tiles are numbered
+    // (row block, column block) and dealt in rounds of gridDim.x; within a round hardware workgroup g (XCD g % 8) takes logical slot
+    // xcd * per + g / 8, so that the column blocks of one row block run at the same time on one XCD: X is read from HBM once and
+    // found in that XCD's L2 by the others.
+    const int64_t nrb = (M + DB3_ROWS - 1) / DB3_ROWS;
+    const int64_t ntiles = nrb * ncb;
+    const int G = gridDim.x, per = G / 8, rem = G % 8, xcd = blockIdx.x % 8;
+    const int lslot = xcd * per + (xcd < rem ? xcd : rem) + blockIdx.x / 8;
+    const int t0 = lslot, t1 = (int)ntiles;             // this workgroup's tiles: t0, t0 + G, ... < t1
+    if (t0 >= t1) return;
+
+    struct Tile { const float* xs[2]; const unsigned char* gi; int cb; int64_t row0; };
+    auto setup = [&](int t, Tile& tl) {
+        tl.cb = t % ncb;
+        tl.row0 = (int64_t)(t / ncb) * DB3_ROWS;
+        tl.gi = img + (int64_t)tl.cb * nks * STEPB;
+        // this lane's X rows: row tile rt -> row 32*wave + 16*rt + n of the tile (clamped: a row >= M only feeds outputs that are never
+        // stored); k slots 8*lg .. 8*lg+7 of each k-step
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t r = tl.row0 + wave * 32 + rt * 16 + n;
+            tl.xs[rt] = X + (r < M ? r : M - 1) * x_ld + 8 * lg;
+        }
+    };
+    auto stage_w = [&](const Tile& tl, int ks, int buf) {     // 3*CT pieces of 1 KB over 8 waves, lane-linear
+        for (int piece = wave; piece < 3 * CT; piece += 8) {
+            const unsigned char* src = tl.gi + (int64_t)ks * STEPB + piece * 1024 + lane * 16;
+            unsigned char* dst = Wb + buf * STEPB + piece * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+    auto load_x = [&](const Tile& tl, int ks, f32x4 (&v)[2][2]) {      // Kd % 4 == 0: a 16-byte piece is wholly inside or outside the row
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const int k = 32 * ks + 8 * lg + 4 * hq;
+                v[rt][hq] = k < Kd ? *reinterpret_cast<const f32x4*>(tl.xs[rt] + 32 * ks + 4 * hq) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    };
+
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    Tile cur, nxt;
+    setup(t0, cur);
+    stage_w(cur, 0, 0);
+    f32x4 xv[2][2], xn[2][2];
+    load_x(cur, 0, xv);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const unsigned char* wlane = Wb + lane * 16;
+    int buf = 0;
+    for (int t = t0; t < t1; t += G) {
+        const bool more = t + G < t1;
+        setup(more ? t + G : t, nxt);
+        for (int ks = 0; ks < nks; ++ks, buf ^= 1) {
+            // the next step's operands: of this tile, or the first of the next tile (the very last step re-reads its own X: no
+            // branch around the loads)
+            if (ks + 1 < nks) {
+                stage_w(cur, ks + 1, buf ^ 1);
+                load_x(cur, ks + 1, xn);
+            } else {
+                if (more) stage_w(nxt, 0, buf ^ 1);
+                load_x(nxt, more ? 0 : ks, xn);
+            }
+            // split this step's X: three bf16x8 operands per row tile
+            bf16x8_t xa[2][3];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                unsigned int w[3][4];
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    db3_split_pair(xv[rt][hq][0], xv[rt][hq][1], w[0][2 * hq], w[1][2 * hq], w[2][2 * hq]);
+                    db3_split_pair(xv[rt][hq][2], xv[rt][hq][3], w[0][2 * hq + 1], w[1][2 * hq + 1], w[2][2 * hq + 1]);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xa[rt][p] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
+            }
+            const unsigned char* wl = wlane + buf * STEPB;
+            bf16x8_t wc[3], wn[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wc[p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (ct + 1 < CT) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wn[p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024 + (ct + 1) * 1024);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    f32x4 tt = acc[rt][ct];
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][2], tt, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2], xa[rt][0], tt, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[rt][1], tt, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][1], tt, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[rt][0], tt, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][0], tt, 0, 0, 0);
+                    acc[rt][ct] = tt;
+                }
+                if (ct + 1 < CT) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wc[p] = wn[p];
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) xv[rt][hq] = xn[rt][hq];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of the next step have landed in LDS (and, in the
+            __syncthreads();                                    // first step of a tile, the previous tile's stores have drained)
+        }
+
+        // ---- epilogue: D = W-piece x X-piece, C/D map of 16x16x32: col = lane & 15 = batch row, row = 4*lg + reg = output column.
+        // The stores are not waited for here.
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t r = cur.row0 + wave * 32 + rt * 16 + n;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col = 16 * (cur.cb * CT + ct) + 4 * lg;      // N % 4 == 0: the lane's four columns are inside or outside together
+                if (r < M && col < N) {
+                    f32x4 v = acc[rt][ct];
+                    if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                    if (relu) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                    }
+                    if (post_scale) {           // multiply then add, unfused (dense.hip's affine epilogue)
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(post_scale + col), sh = *reinterpret_cast<const f32x4*>(post_shift + col);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
+                    }
+                    if (gate) {                 // data gradient through the previous layer's ReLU: y = (x W^T) where gate > 0, else 0
+                        const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + r * gate_ld + col);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = gt[q] > 0.f ? v[q] : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(Y + r * y_ld + col) = v;
+                }
+                acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <int CT>
+static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const unsigned char* img, const float* bias, int relu,
+                             const float* ps, const float* psh, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, int nks, int ncb,
+                             float* Y, int64_t y_ld) {
+    const size_t shmem = 2 * (size_t)3 * CT * 1024;
+    static bool set = false;
+    if (!set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bf3_k<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        set = true;
+    }
+    const int64_t ntiles = (M + DB3_ROWS - 1) / DB3_ROWS * ncb;
+    const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;         // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
+    hipLaunchKernelGGL((dense_bf3_k<CT>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
+                       nks, ncb, Y, y_ld);
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int64_t dir_dense_bf16x3_image_bytes(int Kd, int N) {
+    if (Kd <= 0 || N <= 0) return 0;
+    const int CT = db3_ct_for(N);
+    const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
+    return (int64_t)ncb * nks * 3 * CT * 1024;
+}
+
+extern "C" int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
+    const char* name = "dir_dense_bf16x3_pack_f32";
+    DIR_CHECK_ARG(W && image && Kd > 0 && N > 0 && w_ld >= Kd, "%s: bad argument (Kd=%d N=%d w_ld=%lld)", name, Kd, N, (long long)w_ld);
+    DIR_CHECK_ARG(aligned16(image) && image_bytes >= dir_dense_bf16x3_image_bytes(Kd, N), "%s: image must be 16-byte aligned and hold "
+                  "dir_dense_bf16x3_image_bytes(Kd, N) bytes", name);
+    const int CT = db3_ct_for(N);
+    const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
+    const int64_t threads = (int64_t)ncb * nks * CT * 64 * 4;
+    hipLaunchKernelGGL(dense_bf3_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, Kd, N, CT, nks, ncb,
+                       static_cast<unsigned int*>(image));
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
+extern "C" int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                                    const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y,
+                                    int64_t y_ld, dir_stream_t stream) {
+    const char* name = "dir_dense_bf16x3_f32";
+    DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && y_ld >= N, "%s: bad shape", name);
+    DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
+    DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
+    DIR_CHECK_ARG(!gate || gate_ld >= N, "%s: gate [M, N] with gate_ld >= N", name);
+    if (M == 0) return DIR_OK;
+    DIR_CHECK_ARG(X && image && Y, "%s: null pointer", name);
+    if ((Kd & 3) || (N & 3) || (x_ld & 3) || (y_ld & 3) || (gate && (gate_ld & 3)) || !aligned16(X) || !aligned16(image) || !aligned16(Y) ||
+        (bias && !aligned16(bias)) || (post_scale && (!aligned16(post_scale) || !aligned16(post_shift))) || (gate && !aligned16(gate)))
+        return fail(DIR_E_UNSUPPORTED, "%s: Kd, N and the row strides must be multiples of 4 and every operand 16-byte aligned (Kd=%d N=%d)",
+                    name, Kd, N);
+    const int CT = db3_ct_for(N);
+    const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
+    hipStream_t st = as_stream(stream);
+    const unsigned char* img = static_cast<const unsigned char*>(image);
+    const int relu = act == DIR_ACT_RELU;
+    if (CT == 8) launch_dense_bf3<8>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+    else if (CT == 13) launch_dense_bf3<13>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+    else launch_dense_bf3<16>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}

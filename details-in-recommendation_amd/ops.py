@@ -362,10 +362,72 @@ def dense_supported(x, weight):
             and weight.shape[0] >= 16 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
-def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None):
-    """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32).  x [M, Kd], weight [N, Kd] (nn.Linear layout), bias [N].
-    post_scale / post_shift [N]: the inference batch-norm that follows the activation, as y * post_scale + post_shift in the same
-    pass (dir_dense_affine_f32)."""
+# default arithmetic of dense / dense_gated: "auto" (bf16x3 where covered and not padding-bound, fp32 MFMA otherwise) | "f32" | "bf16x3"
+DENSE_ARITH = os.environ.get("DIR_DENSE_ARITH", "auto")
+DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
+_DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
+
+
+def dense_bf16x3_covers(x, weight, out=None, gate=None):
+    """Operands dir_dense_bf16x3_f32 accepts: Kd, N and every row stride a multiple of 4, 16-byte aligned bases."""
+    M, Kd = x.shape
+    N = weight.shape[0]
+    ok = (Kd % 4 == 0 and N % 4 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+    if out is not None:
+        ok = ok and out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+    if gate is not None:
+        ok = ok and gate.stride(1) == 1 and gate.stride(0) % 4 == 0 and gate.data_ptr() % 16 == 0
+    return ok
+
+
+def dense_auto_arith(M, Kd, N):
+    """What arith="auto" runs for a layer shape: bf16x3 (csrc/dense_bf3.hip) when the batch fills its 256-row workgroups and its
+    column blocks (128 / 208 / 256 wide, whichever pads N least) and 32-wide k-steps pad the layer by at most a third."""
+    if M < DENSE_BF3_MIN_ROWS or N < 64:
+        return "f32"
+    tiles = -(-N // 16)
+    pad = min(-(-tiles // c) * c for c in (8, 13, 16)) * 16
+    kpad = -(-Kd // 32) * 32
+    return "bf16x3" if pad * kpad <= 1.34 * N * Kd else "f32"
+
+
+def dense_bf3_image(weight):
+    """The packed bf16 image of a [N, Kd] fp32 weight (dir_dense_bf16x3_pack_f32), cached per tensor until it is modified in place
+    (tensor._version) or goes away."""
+    import weakref
+    key = weight.data_ptr()
+    sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
+    hit = _DENSE_IMAGES.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == sig:
+        return hit[2]
+    N, Kd = weight.shape
+    lib = _lib.load()
+    nbytes = int(lib.dir_dense_bf16x3_image_bytes(Kd, N))
+    img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _lib.check(lib.dir_dense_bf16x3_pack_f32(_ptr(weight), weight.stride(0), Kd, N, _ptr(img), nbytes, _stream()))
+    if len(_DENSE_IMAGES) > 256:
+        _DENSE_IMAGES.clear()
+    _DENSE_IMAGES[key] = (weakref.ref(weight), sig, img)
+    return img
+
+
+def _dense_arith(arith, x, weight, out, gate):
+    arith = arith or DENSE_ARITH
+    if arith not in ("auto", "f32", "bf16x3"):
+        raise ValueError("dense: arith must be 'auto', 'f32' or 'bf16x3'")
+    covered = dense_bf16x3_covers(x, weight, out, gate)
+    if arith == "auto":
+        return "bf16x3" if covered and dense_auto_arith(x.shape[0], x.shape[1], weight.shape[0]) == "bf16x3" else "f32"
+    if arith == "bf16x3" and not covered:
+        raise ValueError("dense: arith='bf16x3' needs Kd, N and the row strides to be multiples of 4 and 16-byte aligned operands")
+    return arith
+
+
+def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None, arith=None):
+    """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32 / dir_dense_bf16x3_f32).  x [M, Kd], weight [N, Kd] (nn.Linear
+    layout), bias [N].  post_scale / post_shift [N]: the inference batch-norm that follows the activation, as
+    y * post_scale + post_shift in the same pass.  arith: "f32" (fp32 MFMA), "bf16x3" (three-way bf16 split of both operands on the
+    bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same), "auto" (dense_auto_arith), None = DENSE_ARITH."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     M, Kd = x.shape
@@ -384,6 +446,11 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
         post_scale, post_shift = _dev(post_scale, torch.float32, "post_scale").contiguous(), _dev(post_shift, torch.float32, "post_shift").contiguous()
         if post_scale.numel() != N or post_shift.numel() != N:
             raise ValueError("dense: post_scale / post_shift [N]")
+    if _dense_arith(arith, x, weight, out, None) == "bf16x3":
+        _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0,
+                                                    _ptr(post_scale), _ptr(post_shift), None, 0, M, Kd, N, _ptr(out), out.stride(0), _stream()))
+        return out
+    if post_scale is not None:
         _lib.check(_lib.load().dir_dense_affine_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), 1 if relu else 0,
                                                     _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
         return out
@@ -392,42 +459,9 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     return out
 
 
-def dense_bf3_planes(weight):
-    """weight [N, Kd] fp32 -> the three bf16 planes [3, N, ld] (ld = Kd rounded up to 8) whose sum is the weight (experiment:
-    dir_dense_bf16x3_f32)."""
-    w = weight.detach().float()
-    N, Kd = w.shape
-    ld = (Kd + 7) // 8 * 8
-    planes = torch.zeros((3, N, ld), dtype=torch.bfloat16, device=w.device)
-    r = w
-    for p in range(3):
-        q = r.to(torch.bfloat16)
-        planes[p, :, :Kd] = q
-        r = r - q.float()
-    return planes
-
-
-def dense_bf3(x, planes, Kd, bias=None, relu=False, out=None, post_scale=None, post_shift=None):
-    """y = act(x @ W.T + bias) with W given as dense_bf3_planes(W): the bf16 x 3 split-operand experiment (include/dir_hip.h:
-    dir_dense_bf16x3_f32).  x [M, Kd] fp32 with Kd % 8 == 0."""
-    _dev(x, torch.float32, "x")
-    if planes.dtype != torch.bfloat16 or planes.dim() != 3 or planes.shape[0] != 3 or not planes.is_contiguous():
-        raise ValueError("dense_bf3: planes from dense_bf3_planes()")
-    M = x.shape[0]
-    N, ld = planes.shape[1], planes.shape[2]
-    if x.shape[1] != Kd or x.stride(1) != 1:
-        raise ValueError("dense_bf3: x [M, Kd] with unit inner stride")
-    if bias is not None:
-        bias = _dev(bias, torch.float32, "bias").contiguous()
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(planes), ld, _ptr(bias), 1 if relu else 0, _ptr(post_scale),
-                                                _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
-    return out
-
-
-def dense_gated(x, weight, gate, out=None):
-    """where(gate > 0, x @ weight.T, 0) (include/dir_hip.h: dir_dense_gated_f32): x [M, Kd], weight [N, Kd], gate [M, N]."""
+def dense_gated(x, weight, gate, out=None, arith=None):
+    """where(gate > 0, x @ weight.T, 0) (include/dir_hip.h: dir_dense_gated_f32 / dir_dense_bf16x3_f32 with a gate): x [M, Kd],
+    weight [N, Kd], gate [M, N]."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     _dev(gate, torch.float32, "gate")
@@ -439,6 +473,10 @@ def dense_gated(x, weight, gate, out=None):
         weight = weight.contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if _dense_arith(arith, x, weight, out, gate) == "bf16x3":
+        _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), None, 0, None, None, _ptr(gate),
+                                                    gate.stride(0), M, Kd, N, _ptr(out), out.stride(0), _stream()))
+        return out
     _lib.check(_lib.load().dir_dense_gated_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(gate), gate.stride(0), M, Kd, N,
                                                _ptr(out), out.stride(0), _stream()))
     return out

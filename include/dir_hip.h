@@ -320,14 +320,20 @@ int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, c
  * (gamma = 1 for contrib batch_norm).  Multiply then add, unfused.  One pass over Y instead of three. */
 int dir_dense_affine_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
                          const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
-/* dir_dense_bf16x3_f32 (EXPERIMENT, not the default path): the same layer on the bf16 matrix pipe.  Every fp32 operand is split
- * into three bf16 pieces whose sum is the operand (3 x 8 = 24 significant bits) and the six significant cross products are
- * accumulated in fp32 by v_mfma_f32_16x16x32_bf16: fp32-equivalent results (the error against float64 is that of an fp32 sum in
- * another order) at 6/16 of the fp32 MFMA time.  Wplanes: the weight pre-split by the caller into three bf16 planes
- * [3][N][w_ld] (plane p, row n, column k; w_ld >= Kd, a multiple of 8); X stays fp32 and is split in registers.
- * Limits: Kd, w_ld multiples of 8; x_ld a multiple of 4; X / planes 16-byte aligned. */
-int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* Wplanes, int64_t w_ld, const float* bias, int act,
-                         const float* post_scale, const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
+/* The same layer on the bf16 matrix pipe with fp32-equivalent arithmetic (csrc/dense_bf3.hip; the recipe of
+ * dir_cin_layer_bf16x3_f32): X and W are each split into three bf16 pieces (round to nearest; the pieces sum to the operand exactly,
+ * fp32 exponent range), the six piece products of weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Same 1e-5
+ * bar against float64 as dir_dense_f32; not bitwise equal to it.
+ *   dir_dense_bf16x3_image_bytes(Kd, N): device bytes of the packed bf16 image of a [N, Kd] weight.
+ *   dir_dense_bf16x3_pack_f32: W [N, Kd] fp32 (row stride w_ld) -> image (once per weight version; ~5 us).
+ *   dir_dense_bf16x3_f32: Y = epilogue(X . W^T) from the image: + bias, ReLU (act), * post_scale + post_shift (the folded inference
+ *     batch-norm of dir_dense_affine_f32), and/or the ReLU gate of dir_dense_gated_f32 (gate [M, N], NULL: none).
+ * Limits: Kd, N, x_ld, y_ld, gate_ld multiples of 4, every operand 16-byte aligned (DIR_E_UNSUPPORTED otherwise).  Columns are
+ * computed in blocks of 128 / 208 / 256 (whichever pads N least), k in steps of 32. */
+int64_t dir_dense_bf16x3_image_bytes(int Kd, int N);
+int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, int N, void* image, int64_t image_bytes, dir_stream_t stream);
+int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                         const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
                          dir_stream_t stream);
 /* dir_dense_gated_f32: Y = (gate > 0) ? X . Wt^T : 0 -- the data gradient of a dense layer taken straight through the previous
  * layer's ReLU: X = dL/d(pre-activation of layer l) [M, Kd = units of l], Wt = the TRANSPOSE of layer l's nn.Linear weight

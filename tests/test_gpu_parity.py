@@ -496,11 +496,11 @@ def test_dense_matches_float64(built_lib, M, Kd, N, relu):
         ref = ref + b.double()
     if relu:
         ref = ref.clamp(min=0)
-    got = ops.dense(x, w.cuda(), None if b is None else b.cuda(), relu=relu)
+    got = ops.dense(x, w.cuda(), None if b is None else b.cuda(), relu=relu, arith="f32")
     err = (got.cpu().double() - ref).abs() / (1 + ref.abs())
     assert err.max() <= 1e-5, float(err.max())
     out = torch.full((M, N + 3), -7.0).cuda()                  # strided output, untouched padding
-    ops.dense(x, w.cuda(), None if b is None else b.cuda(), relu=relu, out=out[:, :N])
+    ops.dense(x, w.cuda(), None if b is None else b.cuda(), relu=relu, out=out[:, :N], arith="f32")
     assert torch.equal(out[:, :N], got) and float(out[:, N:].max()) == -7.0 and float(out[:, N:].min()) == -7.0
 
 
@@ -626,24 +626,54 @@ def test_full_size_config4_din_on_the_10m_row_table(ops, oracle):
     assert torch.equal(out2, out)
 
 
-@pytest.mark.parametrize("M,Kd,N", [(300, 416, 400), (129, 400, 400), (1000, 64, 80), (77, 1024, 1024), (128, 40, 80), (256, 432, 1024), (1, 16, 32)])
+@pytest.mark.parametrize("M,Kd,N", [(300, 416, 400), (129, 400, 400), (1000, 64, 80), (77, 1024, 1024), (128, 40, 80), (256, 432, 1024), (1, 16, 32),
+                                    (513, 36, 208), (257, 100, 260), (700, 8, 128), (31, 416, 200), (2100, 360, 200)])
 @pytest.mark.parametrize("relu", [False, True])
-def test_dense_bf16x3_experiment_matches_float64(built_lib, M, Kd, N, relu):
-    """dir_dense_bf16x3_f32 (opt-in experiment): fp32 operands split into three bf16 pieces, six cross products on the bf16 matrix
-    pipe, fp32 accumulation -- the same 1e-5 bar as the fp32-MFMA kernel against float64."""
+def test_dense_bf16x3_matches_float64(built_lib, M, Kd, N, relu):
+    """dir_dense_bf16x3_f32 (csrc/dense_bf3.hip): fp32 operands split into three bf16 pieces, six piece products on the bf16 matrix
+    pipe, fp32 accumulation -- the same 1e-5 bar as the fp32-MFMA kernel against float64; all three column-block widths, k tails,
+    row tails, strided x / out, the affine and gated epilogues, operands of very different magnitudes."""
     from dir_amd import ops
     g = torch.Generator().manual_seed(M + Kd + N)
-    x = torch.randn(M, Kd, generator=g).cuda()
+    xfull = torch.randn(M, Kd + 4, generator=g).cuda()
+    x = xfull[:, :Kd]                                              # row stride Kd + 4
     w = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).cuda()
     b = (torch.randn(N, generator=g) * 0.1).cuda()
-    planes = ops.dense_bf3_planes(w)
-    assert torch.equal(planes.float().sum(0)[:, :Kd], w)                 # the three planes add up to the weight exactly
+    assert ops.dense_bf16x3_covers(x, w)
     ref = x.cpu().double() @ w.cpu().double().t() + b.cpu().double()
     if relu:
         ref = ref.clamp(min=0)
-    got = ops.dense_bf3(x, planes, Kd, b, relu=relu)
+    got = ops.dense(x, w, b, relu=relu, arith="bf16x3")
     err = (got.cpu().double() - ref).abs() / (1 + ref.abs())
     assert err.max() <= 1e-5, float(err.max())
+    f32 = ops.dense(x, w, b, relu=relu, arith="f32")                # the two arithmetics against each other
+    assert float(((got - f32).abs() / (1 + f32.abs())).max()) <= 1e-5
     ps, psh = torch.rand(N).cuda() + 0.5, torch.randn(N).cuda()
-    got2 = ops.dense_bf3(x, planes, Kd, b, relu=relu, post_scale=ps, post_shift=psh)
-    assert torch.allclose(got2, got * ps + psh, rtol=1e-6, atol=1e-6)
+    got2 = ops.dense(x, w, b, relu=relu, post_scale=ps, post_shift=psh, arith="bf16x3")
+    assert torch.equal(got2, got * ps + psh)
+    out = torch.full((M, N + 4), -7.0).cuda()                       # strided output, untouched padding
+    ops.dense(x, w, b, relu=relu, out=out[:, :N], arith="bf16x3")
+    assert torch.equal(out[:, :N], got) and float(out[:, N:].max()) == -7.0 and float(out[:, N:].min()) == -7.0
+    gate = torch.randn(M, N, generator=g).cuda()
+    gg = ops.dense_gated(x, w, gate, arith="bf16x3")
+    lin = ops.dense(x, w, None, relu=False, arith="bf16x3")
+    assert torch.equal(gg, torch.where(gate > 0, lin, torch.zeros_like(lin)))
+    for scale in (1e-4, 300.0):                                     # fp32 exponent range: the bar is relative to the terms
+        ys = ops.dense(x * scale, w, None, arith="bf16x3")
+        refs = (x.cpu().double() * scale) @ w.cpu().double().t()
+        assert float(((ys.cpu().double() - refs).abs() / (scale + refs.abs())).max()) <= 1e-5
+    # a weight modified in place is re-packed (the image cache follows tensor._version)
+    w.mul_(2.0)
+    assert torch.equal(ops.dense(x, w, None, arith="bf16x3"), lin * 2.0)
+
+
+def test_dense_bf16x3_limits_and_auto(built_lib):
+    from dir_amd import ops
+    x = torch.randn(64, 18).cuda()
+    w = torch.randn(32, 18).cuda()
+    assert not ops.dense_bf16x3_covers(x, w)                       # Kd not a multiple of 4
+    with pytest.raises(ValueError):
+        ops.dense(x, w, arith="bf16x3")
+    assert ops.dense_auto_arith(65536, 416, 400) == "bf16x3" and ops.dense_auto_arith(65536, 1024, 1024) == "bf16x3"
+    assert ops.dense_auto_arith(65536, 360, 200) == "bf16x3" and ops.dense_auto_arith(65536, 200, 80) == "f32"
+    assert ops.dense_auto_arith(4096, 416, 400) == "f32" and ops.dense_auto_arith(65536, 400, 16) == "f32"
