@@ -757,12 +757,16 @@ def test_input_layer_fused_sparse_adagrad_matches_torch(built_lib):
         _close(pa, pb, tol=2e-6)
 
 
-@pytest.mark.parametrize("dims", [[416, 400, 400, 400], [64, 80, 16], [32, 1024]])
-def test_mlp_stack_matches_float64(built_lib, dims):
-    """dense._MlpStackFn (dir_dense_f32 forward, dir_dense_gated_f32 data gradients through the ReLUs) against float64 autograd."""
+@pytest.mark.parametrize("dims,M", [([416, 400, 400, 400], 300), ([64, 80, 16], 300), ([32, 1024], 300),
+                                    # at >= ops.DENSE_BF3_MIN_ROWS rows the layers (forward, gated data gradients) run on the bf16x3 kernel
+                                    ([416, 400, 400, 400], 12288), ([432, 1024, 1024], 12300)])
+def test_mlp_stack_matches_float64(built_lib, dims, M):
+    """dense._MlpStackFn (dir_dense_f32 / dir_dense_bf16x3_f32 forward, gated data gradients through the ReLUs) against float64
+    autograd."""
     from dir_amd import dense as D
+    from dir_amd import ops
     g = torch.Generator().manual_seed(sum(dims))
-    M = 300
+    assert (ops.dense_auto_arith(M, dims[0], dims[1]) == "bf16x3") == (M >= ops.DENSE_BF3_MIN_ROWS)
     lins = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]).cuda()
     x = torch.randn(M, dims[0], generator=g).cuda().requires_grad_(True)
     gout = torch.randn(M, dims[-1], generator=g).cuda()
