@@ -40,7 +40,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int BT_ROWS = 256;
-constexpr int BT_STEP_BYTES = 3 * 8 * 64 * 16;     // 24 KB of W image per k-step of 32
 
 __device__ __forceinline__ unsigned int bt_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
     unsigned int w;
@@ -55,40 +54,43 @@ __device__ __forceinline__ void bt_split_pair(float a, float b, unsigned int& w0
     w2 = bt_pk(sa, sb);
 }
 
-// W [H, Hp*m] fp32 -> image [column block of 128][half kh][field j][ks][plane][ct][lane][8 e] bf16, element e of lane l of column tile ct
-// in k-step ks = piece of W[h = 128*cb + 16*ct + (l & 15)][i = KS*32*kh + 32*ks + 8*(l >> 4) + e][j]; zero where h >= H or i >= Hp.
-__global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict__ W, int m, int Hp, int H, int KS, int nkh, int ncb,
-                                                        unsigned int* __restrict__ img) {
-    const int64_t total = (int64_t)ncb * nkh * m * KS * 8 * 64 * 4;   // one thread per pair of e
+// W [H, Hp*m] fp32 -> image [column block of CT tiles][half kh][field j][ks][plane][ct][lane][8 e] bf16, element e of lane l of column
+// tile ct in k-step ks = piece of W[h = hoff + 16*(CT*cb + ct) + (l & 15)][i = KS*32*kh + 32*ks + 8*(l >> 4) + e][j]; zero where h >= H or
+// i >= Hp.  One launch per block width (the 128-wide blocks, then the narrower last block).
+__global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict__ W, int m, int Hp, int H, int KS, int nkh, int ncb, int CT,
+                                                        int hoff, unsigned int* __restrict__ img) {
+    const int64_t total = (int64_t)ncb * nkh * m * KS * CT * 64 * 4;   // one thread per pair of e
+    const int stepdw = 3 * CT * 64 * 4;                                // dwords per k-step
     for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
         int64_t q = e_;
         const int ep = (int)(q & 3); q >>= 2;
         const int l = (int)(q & 63); q >>= 6;
-        const int ct = (int)(q & 7); q >>= 3;
+        const int ct = (int)(q % CT); q /= CT;
         const int ks = (int)(q % KS); q /= KS;
         const int j = (int)(q % m); q /= m;
         const int kh = (int)(q % nkh);
         const int cb = (int)(q / nkh);
-        const int h = cb * 128 + 16 * ct + (l & 15);
+        const int h = hoff + 16 * (CT * cb + ct) + (l & 15);
         const int i = KS * 32 * kh + 32 * ks + 8 * (l >> 4) + 2 * ep;
         const float v0 = (h < H && i < Hp) ? W[(int64_t)h * Hp * m + (int64_t)i * m + j] : 0.f;
         const float v1 = (h < H && i + 1 < Hp) ? W[(int64_t)h * Hp * m + (int64_t)(i + 1) * m + j] : 0.f;
         unsigned int p0, p1, p2;
         bt_split_pair(v0, v1, p0, p1, p2);
         const int64_t chunk = ((int64_t)cb * nkh + kh) * m + j;
-        const int64_t base = (chunk * KS + ks) * (BT_STEP_BYTES / 4) + (ct * 64 + l) * 4 + ep;     // plane stride: 8*64*4 dwords
+        const int64_t base = (chunk * KS + ks) * stepdw + (ct * 64 + l) * 4 + ep;     // plane stride: CT*64*4 dwords
         img[base] = p0;
-        img[base + 8 * 64 * 4] = p1;
-        img[base + 2 * 8 * 64 * 4] = p2;
+        img[base + CT * 64 * 4] = p1;
+        img[base + 2 * CT * 64 * 4] = p2;
     }
 }
 
-template <int KS>
+template <int KS, int CT /* column tiles of 16 per workgroup: 8 (128 columns), or 6 / 4 / 2 for the last block of a layer */>
 __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                      const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
-                                                     int nkh, int64_t R, float* __restrict__ xout, float* __restrict__ pooled,
-                                                     int64_t pooled_ld) {
-    constexpr int CHB = KS * BT_STEP_BYTES;                      // bytes of W image per chunk
+                                                     int nkh, int hoff /* first output column of this launch */, int64_t R,
+                                                     float* __restrict__ xout, float* __restrict__ pooled, int64_t pooled_ld) {
+    constexpr int STEPB = 3 * CT * 1024;                         // bytes of W image per k-step of 32
+    constexpr int CHB = KS * STEPB;                              // bytes of W image per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char bt_smem[];
     unsigned char* Wb = bt_smem;                                 // [2][CHB]
     float* x0s = reinterpret_cast<float*>(bt_smem + 2 * CHB);    // [m][256]
@@ -99,14 +101,12 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     const int n = lane & 15;
     const int lg = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * BT_ROWS;
-    const int hbase = blockIdx.y * 128;
+    const int hbase = hoff + blockIdx.y * (16 * CT);
     const int nchunk = nkh * m;
     const unsigned char* gimg = img + (int64_t)blockIdx.y * nchunk * CHB;
 
-    auto stage_w = [&](int c, int buf) {     // CHB / 1 KB pieces over 8 waves, lane-linear
-#pragma unroll
-        for (int q = 0; q < CHB / 1024 / 8; ++q) {
-            const int piece = q * 8 + wave;
+    auto stage_w = [&](int c, int buf) {     // KS * 3 * CT pieces of 1 KB over 8 waves, lane-linear
+        for (int piece = wave; piece < KS * 3 * CT; piece += 8) {
             const unsigned char* src = gimg + (int64_t)c * CHB + piece * 1024 + lane * 16;
             unsigned char* dst = Wb + buf * CHB + piece * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
@@ -131,11 +131,11 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         xsrc[rt] = xk + ((grc >> dshift) * Hp) * D + (grc & (D - 1));
     }
 
-    f32x4 out[2][8], T[2][8];
+    f32x4 out[2][CT], T[2][CT];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             out[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
             T[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[ks][rt][p] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
             }
-        for (int j = 0; j < m; ++j, ++c) {
+        for (int j = 0; j < m; ++j, ++c) {      // one chunk = (this half, field j)
+            constexpr int KSN = KS;
             const int buf = c & 1;
             if (c + 1 < nchunk) stage_w(c + 1, buf ^ 1);
             const unsigned char* wl = wlane + buf * CHB;
@@ -179,16 +180,16 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
             bf16x8_t bc[3], bn[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bc[p] = *reinterpret_cast<const bf16x8_t*>(wl + p * 8 * 1024);
+            for (int p = 0; p < 3; ++p) bc[p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+            for (int ks = 0; ks < KSN; ++ks) {
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct) {
-                    const bool lastg = (ks == KS - 1 && ct == 7);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const bool lastg = (ks == KSN - 1 && ct == CT - 1);
                     if (!lastg) {
-                        const unsigned char* wp = wl + (ct < 7 ? ks : ks + 1) * BT_STEP_BYTES + ((ct + 1) & 7) * 1024;
+                        const unsigned char* wp = wl + (ct + 1 < CT ? ks : ks + 1) * STEPB + ((ct + 1) % CT) * 1024;
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const bf16x8_t*>(wp + p * 8 * 1024);
+                        for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const bf16x8_t*>(wp + p * CT * 1024);
                     }
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
@@ -222,8 +223,6 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                             __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (!lastg) {
 #pragma unroll
                         for (int p = 0; p < 3; ++p) bc[p] = bn[p];
                     }
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
 
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         const int64_t b = gr >> dshift;
         const int d = (int)(gr & (D - 1));
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             const int h = hbase + 16 * ct + n;
             const f32x4 v = out[rt][ct];
             if (xout && h < H && gr < R) *reinterpret_cast<f32x4*>(xout + (b * H + h) * D + d) = v;
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     }
     if (pooled) {
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             const int h = hbase + 16 * ct + n;
             float s[2];
 #pragma unroll
@@ -285,11 +284,25 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 
 using namespace dir;
 
+// Shape plan shared by the workspace query and the launcher: halves of i, column blocks
+struct Bf3Plan { int KS, nkh, nfull, ctl; int64_t chunks, bytes_full, bytes_last; };
+static Bf3Plan bf3_plan(int m, int Hp, int H) {
+    Bf3Plan p;
+    p.KS = Hp <= 32 ? 1 : 2;
+    p.nkh = (Hp + p.KS * 32 - 1) / (p.KS * 32);
+    p.nfull = H / 128;                                                        // 128-column blocks
+    const int r = H - 128 * p.nfull;
+    p.ctl = r ? ((r + 15) / 16 + 1) / 2 * 2 : 0;                              // tiles of the last block: 2, 4, 6 or 8
+    p.chunks = (int64_t)p.nkh * m;
+    p.bytes_full = (int64_t)p.nfull * p.chunks * p.KS * 3 * 8 * 1024;
+    p.bytes_last = p.chunks * p.KS * 3 * p.ctl * 1024;
+    return p;
+}
+
 extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     if (m <= 0 || Hp <= 0 || H <= 0) return 0;
-    const int KS = Hp <= 32 ? 1 : 2;
-    const int nkh = (Hp + KS * 32 - 1) / (KS * 32);
-    return (int64_t)((H + 127) / 128) * nkh * m * KS * BT_STEP_BYTES;
+    const Bf3Plan p = bf3_plan(m, Hp, H);
+    return p.bytes_full + p.bytes_last;
 }
 
 extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
@@ -309,26 +322,44 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
     while ((1 << dshift) < D) ++dshift;
     const int64_t R = B * D;
     hipStream_t st = as_stream(stream);
-    const int KS = Hp <= 32 ? 1 : 2;
-    const int nkh = (Hp + KS * 32 - 1) / (KS * 32);
-    const int ncb = (H + 127) / 128;
-    const int64_t pack_threads = (int64_t)ncb * nkh * m * KS * 8 * 64 * 4;
-    hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((pack_threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, KS, nkh, ncb,
-                       static_cast<unsigned int*>(workspace));
-    const size_t shmem = 2 * (size_t)KS * BT_STEP_BYTES + sizeof(float) * (size_t)m * BT_ROWS;
-    dim3 grid((unsigned)((R + BT_ROWS - 1) / BT_ROWS), (unsigned)ncb);
-    const unsigned char* img = static_cast<const unsigned char*>(workspace);
-#define BT_LAUNCH(K)                                                                                                                  \
+    const Bf3Plan pl = bf3_plan(m, Hp, H);
+    unsigned char* img = static_cast<unsigned char*>(workspace);
+    auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
+        const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
+        hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
+                           reinterpret_cast<unsigned int*>(dst));
+    };
+    if (pl.nfull) pack(pl.nfull, 8, 0, img);
+    if (pl.ctl) pack(1, pl.ctl, 128 * pl.nfull, img + pl.bytes_full);
+    const unsigned nrb = (unsigned)((R + BT_ROWS - 1) / BT_ROWS);
+#define BT_LAUNCH(K, C, NCB, HOFF, IMG)                                                                                               \
     do {                                                                                                                              \
         static bool set = false;                                                                                                      \
         if (!set) {                                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<K, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             set = true;                                                                                                               \
         }                                                                                                                             \
-        hipLaunchKernelGGL((cin_bf3_k<K>), grid, dim3(512), shmem, st, x0, xk, img, m, Hp, H, D, dshift, nkh, R, xout, pooled, pooled_ld); \
+        const size_t shmem = 2 * (size_t)K * 3 * C * 1024 + sizeof(float) * (size_t)m * BT_ROWS;                                      \
+        hipLaunchKernelGGL((cin_bf3_k<K, C>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, pl.nkh, \
+                           HOFF, R, xout, pooled, pooled_ld);                                                             \
     } while (0)
-    if (KS == 1) BT_LAUNCH(1);
-    else BT_LAUNCH(2);
+#define BT_LAUNCH_CT(C, NCB, HOFF, IMG)                                \
+    do {                                                               \
+        if (pl.KS == 1) BT_LAUNCH(1, C, NCB, HOFF, IMG);               \
+        else BT_LAUNCH(2, C, NCB, HOFF, IMG);                          \
+    } while (0)
+    if (pl.nfull) BT_LAUNCH_CT(8, pl.nfull, 0, img);
+    if (pl.ctl) {
+        const unsigned char* li = img + pl.bytes_full;
+        const int lo = 128 * pl.nfull;
+        switch (pl.ctl) {
+            case 2: BT_LAUNCH_CT(2, 1, lo, li); break;
+            case 4: BT_LAUNCH_CT(4, 1, lo, li); break;
+            case 6: BT_LAUNCH_CT(6, 1, lo, li); break;
+            default: BT_LAUNCH_CT(8, 1, lo, li); break;
+        }
+    }
+#undef BT_LAUNCH_CT
 #undef BT_LAUNCH
     DIR_CHECK_LAUNCH("cin_layer_bf16x3");
     return DIR_OK;

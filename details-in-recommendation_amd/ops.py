@@ -580,12 +580,11 @@ def cin_bf16x3_covers(m, D):
 
 def cin_auto_arith(m, D, Hp, H):
     """What arith="auto" runs: the bf16x3 kernel where it accepts the shape and its padding does not eat its advantage.  It computes
-    columns in blocks of 128 and i in blocks of 32 (Hp <= 32) or 64, at about twice the fp32-MFMA kernel's rate per padded product
-    (profiles/r02_sweep_shapes.md: 275 vs 127-142 fp32-equivalent TFLOP/s), so it is chosen while padded work <= 1.8 x real work:
-    H = Hp = 200 (256 x 256 computed) still gains, H = 32 or Hp = 7 belong to the fp32-MFMA kernel."""
+    columns in blocks of 128 plus one last block of 32 / 64 / 96 / 128 and i in blocks of 32 (Hp <= 32) or 64, at 1.7-2 x the
+    fp32-MFMA kernel's rate per padded product (profiles/r02_sweep_shapes.md): it is chosen while padded work <= 1.8 x real work."""
     if not cin_bf16x3_covers(m, D):
         return "f32"
-    hpad = -(-H // 128) * 128
+    hpad = -(-H // 32) * 32
     ipad = 32 if Hp <= 32 else -(-Hp // 64) * 64
     return "bf16x3" if hpad * ipad <= 1.8 * H * Hp else "f32"
 

@@ -213,8 +213,8 @@ int dir_cin_layer_f32(const float* x0, const float* xk, const float* W, int m, i
  * per accumulator and field.  Same 1e-5 bar against the double-accumulating oracle as dir_cin_layer_f32 (measured error 2-3e-7),
  * half its time on 128-wide layers.  Results are not bitwise those of dir_cin_layer_f32 (different summation tree).
  * workspace: dir_cin_bf16x3_workspace_bytes(m, Hp, H) device bytes, 16-byte aligned (the packed bf16 image of W, rebuilt by
- * every call).  Shapes: D in {4, 8, 16, 32}; m <= 40; any Hp, H (columns are computed in blocks of 128, i in blocks of 32 / 64:
- * narrow layers are better served by dir_cin_layer_f32). */
+ * every call).  Shapes: D in {4, 8, 16, 32}; m <= 40; any Hp, H (columns are computed in blocks of 128 plus one last block of
+ * 32 / 64 / 96 / 128, i in blocks of 32 (Hp <= 32) or 64: narrow layers are better served by dir_cin_layer_f32). */
 int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H);
 int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                              int64_t B, float* xout, float* pooled, int64_t pooled_ld,

@@ -247,13 +247,15 @@ def test_cin_bf16x3_refuses_uncovered_shapes(ops):
     with pytest.raises(ValueError):
         ops.cin_layer(x0, xk, W, arith="bf16x3")
     assert ops.cin_auto_arith(26, 16, 128, 128) == "bf16x3" and ops.cin_auto_arith(26, 16, 26, 128) == "bf16x3"
-    assert ops.cin_auto_arith(26, 16, 128, 32) == "f32" and ops.cin_auto_arith(26, 16, 7, 128) == "f32"
-    assert ops.cin_auto_arith(26, 16, 200, 200) == "bf16x3" and ops.cin_auto_arith(26, 16, 64, 64) == "f32"
+    assert ops.cin_auto_arith(26, 16, 128, 32) == "bf16x3" and ops.cin_auto_arith(26, 16, 200, 200) == "bf16x3"
+    assert ops.cin_auto_arith(26, 16, 7, 128) == "f32" and ops.cin_auto_arith(26, 16, 128, 10) == "f32"
 
 
 @pytest.mark.parametrize("B,m,D,Hp,H", [(300, 26, 16, 128, 128), (257, 15, 8, 9, 33), (64, 17, 4, 24, 129), (31, 40, 32, 8, 256),
                                          (130, 16, 16, 1, 5), (65, 33, 16, 17, 100), (1, 26, 16, 26, 128), (513, 26, 16, 100, 64),
-                                         (40, 1, 8, 70, 20), (77, 3, 4, 33, 130), (19, 8, 32, 64, 128), (260, 13, 16, 65, 16)])
+                                         (40, 1, 8, 70, 20), (77, 3, 4, 33, 130), (19, 8, 32, 64, 128), (260, 13, 16, 65, 16),
+                                         # narrow last column blocks (2 / 4 / 6 tiles) and short last halves (Hp % 64 in 1..32)
+                                         (100, 26, 16, 200, 200), (70, 26, 16, 96, 160), (33, 20, 8, 72, 224), (50, 26, 16, 130, 32), (64, 16, 16, 160, 288)])
 def test_cin_layer_bf16x3_shapes(ops, oracle, B, m, D, Hp, H):
     """csrc/cin_bf3.hip on its own edge shapes: one field, odd field counts, Hp on both sides of the 32 / 64-wide i blocks, several
     column blocks, partial last workgroups, D = 4 .. 32, and operands of very different magnitudes (the split keeps fp32's
