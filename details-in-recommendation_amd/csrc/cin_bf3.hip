@@ -42,8 +42,13 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 constexpr int BT_ROWS = 256;
 
 __device__ __forceinline__ unsigned int bt_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
-    unsigned int w;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
+    typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
+    const pk2_t v = {(__bf16)a, (__bf16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    // An EMPTY asm: it only hides where w came from (otherwise the compiler converts `a` a second time, alone, to form float(bf16(a))
+    // instead of shifting w).  The convert itself stays a compiler-generated instruction: its results become MFMA operands, and the
+    // compiler's hazard recognizer does not see inside inline asm.
+    asm("" : "+v"(w));
     return w;
 }
 __device__ __forceinline__ void bt_split_pair(float a, float b, unsigned int& w0, unsigned int& w1, unsigned int& w2) {

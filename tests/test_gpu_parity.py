@@ -431,6 +431,10 @@ def test_full_size_properties_cross_cin_din(ops, oracle):
     assert (np.abs(fo[sel].cpu().double().numpy() - rx) / (1 + np.abs(rx))).max() <= 1e-5
     assert (np.abs(fp_[sel].cpu().double().numpy() - rp) / (1 + np.abs(rp))).max() <= 1e-5
     assert float(((fo - xo).abs() / (1 + fo.abs())).max()) <= 1e-5       # the two arithmetics against each other, every element
+    for _ in range(3):                                                    # run-to-run bitwise reproducibility of the bf16x3 kernel at full size
+        xr, pr = ops.cin_layer(c0, xk, W)
+        assert torch.equal(xr, xo) and torch.equal(pr, po)
+    del xr, pr
     del xo, xo2, po2, xk, fo, fp_
     # ---- DIN, T = 50, K = 64, 80-40-1, normalised -----------------------------------------------------------------------
     T, K, V, H1, H2 = 50, 64, 1000000, 80, 40
