@@ -39,7 +39,6 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-constexpr int BT_ROWS = 256;
 
 __device__ __forceinline__ unsigned int bt_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
     typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
@@ -89,16 +88,25 @@ __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict_
     }
 }
 
-template <int KS, int CT /* column tiles of 16 per workgroup: 8 (128 columns), or 6 / 4 / 2 for the last block of a layer */>
+// DOT (the backward's data gradients, dir_cin_dx_bf16x3_f32): besides out = sum_j x0_j * T_j the kernel also forms, for every field,
+//   dot[r, j] = sum_h y[r, h] * T_j[r, h]      (y in the layout of xout; the sum runs over this workgroup's columns and this half of i)
+// from the same T_j tiles, just before the next chunk overwrites them.  Called with xk := G, W := W1 (W1[i, h*m+j] = W[h, i*m+j]) and
+// y := the layer's xk, `out` is dxk and the dot partials add up to dx0.  It keeps y's tile in registers, so a wave owns RT = 1 row tile.
+template <int KS, int CT /* column tiles of 16 per workgroup: 8 (128 columns), or 6 / 4 / 2 for the last block of a layer */,
+          int RT = 2 /* row tiles of 16 per wave */, bool DOT = false>
 __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                      const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
                                                      int nkh, int hoff /* first output column of this launch */, int64_t R,
-                                                     float* __restrict__ xout, float* __restrict__ pooled, int64_t pooled_ld) {
+                                                     float* __restrict__ xout, float* __restrict__ pooled, int64_t pooled_ld,
+                                                     const float* __restrict__ y /* DOT: [B, H, D] */,
+                                                     float* __restrict__ dotp /* DOT: partials [nkh][B, m, D] of this launch's column block */) {
     constexpr int STEPB = 3 * CT * 1024;                         // bytes of W image per k-step of 32
     constexpr int CHB = KS * STEPB;                              // bytes of W image per chunk
+    constexpr int BT_ROWS = 8 * 16 * RT;                         // rows per workgroup (shadows the 256 of the forward)
+    constexpr int WR = 16 * RT;                                  // rows per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char bt_smem[];
     unsigned char* Wb = bt_smem;                                 // [2][CHB]
-    float* x0s = reinterpret_cast<float*>(bt_smem + 2 * CHB);    // [m][256]
+    float* x0s = reinterpret_cast<float*>(bt_smem + 2 * CHB);    // [m][BT_ROWS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -121,37 +129,67 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     // ---- prologue: W chunk 0 and the x0 slice (thread t: row t & 255, fields of parity t >> 8)
     stage_w(0, 0);
     {
-        const int r = tid & 255;
+        constexpr int TPR = 512 / BT_ROWS;                           // threads sharing a row: they take the fields j = t / BT_ROWS, + TPR, ...
+        const int r = tid % BT_ROWS;
         const int64_t srow = (row0 + r < R) ? row0 + r : R - 1;     // a row >= R only feeds output rows that are never stored
         const float* x0src = x0 + ((srow >> dshift) * m) * D + (srow & (D - 1));
-        for (int j = tid >> 8; j < m; j += 2) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
+        for (int j = tid / BT_ROWS; j < m; j += TPR) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
     }
 
-    // this lane's A rows: row tile rt -> row 32*wave + 16*rt + n of the workgroup; k slot 8*lg + e of each k-step
-    const float* xsrc[2];
+    // this lane's A rows: row tile rt -> row WR*wave + 16*rt + n of the workgroup; k slot 8*lg + e of each k-step
+    const float* xsrc[RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int64_t gr = row0 + wave * 32 + rt * 16 + n;
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t gr = row0 + wave * WR + rt * 16 + n;
         const int64_t grc = gr < R ? gr : R - 1;
         xsrc[rt] = xk + ((grc >> dshift) * Hp) * D + (grc & (D - 1));
     }
 
-    f32x4 out[2][CT], T[2][CT];
+    f32x4 out[RT][CT], T[RT][CT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             out[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
             T[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    f32x4 xprev[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};     // x0[rows of the lane's accumulator registers, previous field]
-    bf16x8_t a[KS][2][3];                                                            // the half's A operands: [k-step][row tile][piece]
+    f32x4 xprev[RT];                                                                 // x0[rows of the lane's accumulator registers, previous field]
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) xprev[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t a[KS][RT][3];                                                           // the half's A operands: [k-step][row tile][piece]
+    // DOT: y in the accumulators' layout (rows 4*lg .. 4*lg+3 of tile rt = four consecutive d of one sample, column 16*ct + n)
+    f32x4 yv[DOT ? RT : 1][DOT ? CT : 1];
+    if constexpr (DOT) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t gr = row0 + wave * WR + rt * 16 + 4 * lg;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int h = hbase + 16 * ct + n;
+                yv[rt][ct] = (h < H && gr < R) ? *reinterpret_cast<const f32x4*>(y + ((gr >> dshift) * H + h) * D + (gr & (D - 1)))
+                                               : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if constexpr (DOT) dotp += (int64_t)blockIdx.y * nkh * (R >> dshift) * m * D;     // this column block's partials
     const unsigned char* wlane = Wb + lane * 16;
-    const float* x0lane = x0s + wave * 32 + 4 * lg;      // + j*256 + 16*rt: the 4 rows of accumulator registers 0..3 of tile rt
+    const float* x0lane = x0s + wave * WR + 4 * lg;      // + j*BT_ROWS + 16*rt: the 4 rows of accumulator registers 0..3 of tile rt
+    // DOT: the finished dot of one chunk (field jd of half khd): reduce over the 16 columns of a lane group, lane n == 0 stores
+    auto store_dot = [&](const f32x4 (&sd)[RT], int khd, int jd) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = row16_sum(sd[rt][q]);
+            const int64_t gr = row0 + wave * WR + rt * 16 + 4 * lg;
+            if (n == 0 && gr < R)
+                *reinterpret_cast<f32x4*>(dotp + (((int64_t)khd * (R >> dshift) + (gr >> dshift)) * m + jd) * D + (gr & (D - 1))) = v;
+        }
+    };
 
     int c = 0;
     for (int kh = 0; kh < nkh; ++kh) {
@@ -159,7 +197,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -178,9 +216,12 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             const int buf = c & 1;
             if (c + 1 < nchunk) stage_w(c + 1, buf ^ 1);
             const unsigned char* wl = wlane + buf * CHB;
-            f32x4 xcur[2];
+            f32x4 xcur[RT], sd[RT];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) xcur[rt] = *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
+            for (int rt = 0; rt < RT; ++rt) {
+                xcur[rt] = *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
+                sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
             // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
             bf16x8_t bc[3], bn[3];
@@ -197,12 +238,16 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                         for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const bf16x8_t*>(wp + p * CT * 1024);
                     }
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
                         f32x4 t;
                         if (ks == 0) {
                             // the previous chunk's T tile goes into `out` just before this chunk's first MFMA chain overwrites it
 #pragma unroll
                             for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
+                            if constexpr (DOT) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) sd[rt][q] = __builtin_fmaf(yv[rt][ct][q], T[rt][ct][q], sd[rt][q]);
+                            }
                             t = (f32x4){0.f, 0.f, 0.f, 0.f};
                         } else {
                             t = T[rt][ct];
@@ -233,24 +278,36 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     }
                 }
             }
-            xprev[0] = xcur[0];
-            xprev[1] = xcur[1];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) xprev[rt] = xcur[rt];
+            if constexpr (DOT) {          // sd holds the dot of the PREVIOUS chunk (its T tiles were consumed during this chunk's first k-step)
+                if (c > 0) store_dot(sd, j == 0 ? kh - 1 : kh, j == 0 ? m - 1 : j - 1);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of chunk c + 1 have landed in LDS
             __syncthreads();
         }
     }
     // the last chunk's T
+    {
+        f32x4 sd[RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt) {
+            sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
+                for (int q = 0; q < 4; ++q) {
+                    out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
+                    if constexpr (DOT) sd[rt][q] = __builtin_fmaf(yv[rt][ct][q], T[rt][ct][q], sd[rt][q]);
+                }
+        }
+        if constexpr (DOT) store_dot(sd, nkh - 1, m - 1);
+    }
 
     // ---- epilogue: C/D map of 16x16x32: col = lane & 15, row = 4*(lane >> 4) + reg
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int64_t gr = row0 + wave * 32 + rt * 16 + 4 * lg;     // first of the lane's 4 consecutive rows (same sample: D >= 4)
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t gr = row0 + wave * WR + rt * 16 + 4 * lg;     // first of the lane's 4 consecutive rows (same sample: D >= 4)
         const int64_t b = gr >> dshift;
         const int d = (int)(gr & (D - 1));
 #pragma unroll
@@ -261,6 +318,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         }
     }
     if (pooled) {
+        static_assert(RT == 2 || DOT, "the pooled sums are written by the forward configuration (two row tiles per wave)");
+        if constexpr (RT == 2) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int h = hbase + 16 * ct + n;
@@ -281,6 +340,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 const int64_t gr = row0 + wave * 32 + rt * 16 + 4 * lg;
                 if (writer && h < H && gr < R) pooled[(gr >> dshift) * pooled_ld + h] = s[rt];
             }
+        }
         }
     }
 }
@@ -310,10 +370,9 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     return p.bytes_full + p.bytes_last;
 }
 
-extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
-                                        float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
-                                        dir_stream_t stream) {
-    const char* name = "dir_cin_layer_bf16x3_f32";
+// Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: one row tile per wave, dot partials)
+static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
+                   float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     DIR_CHECK_ARG(!pooled || pooled_ld >= H, "%s: pooled_ld=%lld < H=%d", name, (long long)pooled_ld, H);
@@ -336,36 +395,67 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
     };
     if (pl.nfull) pack(pl.nfull, 8, 0, img);
     if (pl.ctl) pack(1, pl.ctl, 128 * pl.nfull, img + pl.bytes_full);
-    const unsigned nrb = (unsigned)((R + BT_ROWS - 1) / BT_ROWS);
-#define BT_LAUNCH(K, C, NCB, HOFF, IMG)                                                                                               \
+    const bool dot = y != nullptr;
+    const int rows = dot ? 128 : 256;
+    const unsigned nrb = (unsigned)((R + rows - 1) / rows);
+    const int64_t dot_block = (int64_t)pl.nkh * B * m * D;         // floats of dot partials per column block
+#define BT_LAUNCH(K, C, RT_, DOT_, NCB, HOFF, IMG, DOTP)                                                                              \
     do {                                                                                                                              \
         static bool set = false;                                                                                                      \
         if (!set) {                                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<K, C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<K, C, RT_, DOT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             set = true;                                                                                                               \
         }                                                                                                                             \
-        const size_t shmem = 2 * (size_t)K * 3 * C * 1024 + sizeof(float) * (size_t)m * BT_ROWS;                                      \
-        hipLaunchKernelGGL((cin_bf3_k<K, C>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, pl.nkh, \
-                           HOFF, R, xout, pooled, pooled_ld);                                                             \
+        const size_t shmem = 2 * (size_t)K * 3 * C * 1024 + sizeof(float) * (size_t)m * (128 * RT_);                                  \
+        hipLaunchKernelGGL((cin_bf3_k<K, C, RT_, DOT_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, \
+                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP);                                                        \
     } while (0)
-#define BT_LAUNCH_CT(C, NCB, HOFF, IMG)                                \
-    do {                                                               \
-        if (pl.KS == 1) BT_LAUNCH(1, C, NCB, HOFF, IMG);               \
-        else BT_LAUNCH(2, C, NCB, HOFF, IMG);                          \
+#define BT_LAUNCH_CT(C, NCB, HOFF, IMG, DOTP)                                       \
+    do {                                                                            \
+        if (dot) {                                                                  \
+            if (pl.KS == 1) BT_LAUNCH(1, C, 1, true, NCB, HOFF, IMG, DOTP);         \
+            else BT_LAUNCH(2, C, 1, true, NCB, HOFF, IMG, DOTP);                    \
+        } else {                                                                    \
+            if (pl.KS == 1) BT_LAUNCH(1, C, 2, false, NCB, HOFF, IMG, DOTP);        \
+            else BT_LAUNCH(2, C, 2, false, NCB, HOFF, IMG, DOTP);                   \
+        }                                                                           \
     } while (0)
-    if (pl.nfull) BT_LAUNCH_CT(8, pl.nfull, 0, img);
+    if (pl.nfull) BT_LAUNCH_CT(8, pl.nfull, 0, img, dotp);
     if (pl.ctl) {
         const unsigned char* li = img + pl.bytes_full;
         const int lo = 128 * pl.nfull;
+        float* ld_ = dot ? dotp + pl.nfull * dot_block : nullptr;
         switch (pl.ctl) {
-            case 2: BT_LAUNCH_CT(2, 1, lo, li); break;
-            case 4: BT_LAUNCH_CT(4, 1, lo, li); break;
-            case 6: BT_LAUNCH_CT(6, 1, lo, li); break;
-            default: BT_LAUNCH_CT(8, 1, lo, li); break;
+            case 2: BT_LAUNCH_CT(2, 1, lo, li, ld_); break;
+            case 4: BT_LAUNCH_CT(4, 1, lo, li, ld_); break;
+            case 6: BT_LAUNCH_CT(6, 1, lo, li, ld_); break;
+            default: BT_LAUNCH_CT(8, 1, lo, li, ld_); break;
         }
     }
 #undef BT_LAUNCH_CT
 #undef BT_LAUNCH
-    DIR_CHECK_LAUNCH("cin_layer_bf16x3");
+    DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
+                                        float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                        dir_stream_t stream) {
+    return bf3_run("dir_cin_layer_bf16x3_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace, workspace_bytes,
+                   stream);
+}
+
+extern "C" int dir_cin_bf16x3_dot_partials(int m, int Hp, int H) {
+    if (m <= 0 || Hp <= 0 || H <= 0) return 0;
+    const Bf3Plan p = bf3_plan(m, Hp, H);
+    return p.nkh * (p.nfull + (p.ctl ? 1 : 0));
+}
+
+extern "C" int dir_cin_layer_dot_bf16x3_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D,
+                                            int64_t B, float* xout, float* dot_partials, void* workspace, int64_t workspace_bytes,
+                                            dir_stream_t stream) {
+    const char* name = "dir_cin_layer_dot_bf16x3_f32";
+    DIR_CHECK_ARG(y && dot_partials && xout, "%s: null pointer", name);
+    DIR_CHECK_ARG(aligned16(y) && aligned16(dot_partials), "%s: y and dot_partials must be 16-byte aligned", name);
+    return bf3_run(name, x0, xk, W, m, Hp, H, D, B, xout, nullptr, 0, y, dot_partials, workspace, workspace_bytes, stream);
 }

@@ -871,17 +871,51 @@ def cin_dx(x0, xk, W, G):
     return dxk, dx0
 
 
-def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, force_forward_form=False):
+def cin_dx_bf16x3(x0, xk, W, G):
+    """Both data gradients of one CIN layer on the bf16x3 kernel (include/dir_hip.h, dir_cin_layer_dot_bf16x3_f32): the forward
+    contraction on the permuted weight W1[i, h*m+j] = W[h, i*m+j] with G as its left operand gives dxk, and the same T_j tiles dotted
+    with xk give dx0 (partial sums per column block and half of i, added here in a fixed order).  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
+    for t, n in ((x0, "x0"), (xk, "xk"), (W, "W"), (G, "G")):
+        _dev(t, torch.float32, n)
+        if not t.is_contiguous():
+            raise ValueError("cin_dx_bf16x3 operands must be contiguous")
+    B, m, D = x0.shape
+    Hp, H = xk.shape[1], W.shape[0]
+    if W.shape[1] != Hp * m or G.shape != (B, H, D) or xk.shape[0] != B or xk.shape[2] != D:
+        raise ValueError("cin_dx_bf16x3: W must be [H, Hp*m], xk [B,Hp,D], G [B,H,D]")
+    if not cin_bf16x3_covers(m, D):
+        raise ValueError("cin_dx_bf16x3 covers m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (m, D))
+    lib = _lib.load()
+    W1 = W.view(H, Hp, m).permute(1, 0, 2).reshape(Hp, H * m).contiguous()
+    # roles in the kernel: left operand G (reduction over its H channels), output columns = the Hp channels of xk
+    nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, H, Hp))
+    P = int(lib.dir_cin_bf16x3_dot_partials(m, H, Hp))
+    ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+    dxk = torch.empty((B, Hp, D), dtype=torch.float32, device=x0.device)
+    parts = torch.empty((P, B, m, D), dtype=torch.float32, device=x0.device)
+    _lib.check(lib.dir_cin_layer_dot_bf16x3_f32(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(dxk), _ptr(parts), _ptr(ws), nbytes,
+                                                _stream()))
+    return dxk, (parts[0] if P == 1 else parts.sum(dim=0))
+
+
+def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, force_forward_form=False, arith=None):
     """Backward of cin_layer given G = dL/dxout [B,H,D] (pooled gradient already broadcast in):
     -> (dx0 [B,m,D] | None, dxk [B,Hp,D] | None, dW [H,Hp*m] | None).
-    Data gradients: dir_cin_dx_f32 (one pass for both) when H, Hp <= 256 and m <= 64; otherwise, or with
-    force_forward_form, the forward contraction with permuted weights (include/dir_hip.h):
+    Data gradients: cin_dx_bf16x3 (bf16 pipe, one pass for both) where arith (None = CIN_ARITH; "auto": cin_auto_arith of the
+    transposed problem) selects it; dir_cin_dx_f32 (fp32 MFMA, one pass for both) when H, Hp <= 256 and m <= 64; otherwise, or
+    with force_forward_form, the forward contraction with permuted weights (include/dir_hip.h):
       dxk = cin_layer(x0, G, W1),  W1[i, h*m+j]  = W[h, i*m+j]
       dx0 = sum over channel groups g of cin_layer(xk[:, g], G, W2g),  W2g[j, h*mg+ig] = W[h, (g0+ig)*m+j]."""
     B, m, D = x0.shape
     Hp, H = xk.shape[1], W.shape[0]
     W3 = W.view(H, Hp, m)
     dxk = dx0 = dW = None
+    arith = arith or CIN_ARITH
+    if arith == "auto":
+        arith = cin_auto_arith(m, D, H, Hp)          # the data gradients' GEMM: reduction over H, Hp output columns
+    if (need_xk or need_x0) and arith == "bf16x3" and cin_bf16x3_covers(m, D) and not force_forward_form:
+        dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G)
+        need_xk = need_x0 = False
     if (need_xk or need_x0) and H <= 256 and Hp <= 256 and m <= 64 and not force_forward_form:
         dxk, dx0 = cin_dx(x0, xk, W, G)             # one pass for both (G stationary in registers)
         need_xk = need_x0 = False

@@ -298,9 +298,18 @@ def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
     G = (rng.standard_normal((B, H, D)) * 0.5).astype(np.float32)
     ref_dW, ref_dxk, ref_dx0 = O.cin_backward(x0, xk, W, G)
     dev = lambda a: torch.from_numpy(a).cuda()
-    dx0, dxk, dW = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G))
+    dx0, dxk, dW = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G), arith="f32")      # dir_cin_dx_f32 / forward form, dir_cin_dw_f32
     _close(dxk, ref_dxk)
     _close(dx0, ref_dx0)
+    if ops.cin_bf16x3_covers(m, D):     # both data gradients in one pass of the bf16x3 kernel (dir_cin_layer_dot_bf16x3_f32), bitwise reproducible
+        bxk, bx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G))
+        _close(bxk, ref_dxk)
+        _close(bx0, ref_dx0)
+        cxk, cx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G))
+        assert torch.equal(cxk, bxk) and torch.equal(cx0, bx0)
+        ax0, axk, _ = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G), need_w=False)  # "auto": one of the two, bitwise
+        want = (bx0, bxk) if ops.cin_auto_arith(m, D, H, Hp) == "bf16x3" else (dx0, dxk)
+        assert torch.equal(ax0, want[0]) and torch.equal(axk, want[1])
     # the other formulation of the data gradients (forward kernel on permuted weights; the only one for H or Hp > 128)
     fx0, fxk, _ = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G), need_w=False, force_forward_form=True)
     _close(fxk, ref_dxk)
