@@ -1,0 +1,216 @@
+// cin_dw_bf3.hip -- weight gradient of the CIN layer on the bf16 matrix pipe with fp32-equivalent arithmetic ("bf16 x 3", cin_bf3.hip).
+//
+// NO REFERENCE CODE (README.md:28 links arXiv:1803.05170); derivative of the definition in include/dir_hip.h (A14):
+//   dW[h, i*m + j] = sum_{b,d} G[b,h,d] * xk[b,i,d] * x0[b,j,d]
+// For one field j this is a GEMM whose REDUCTION runs over the rows r = (b,d):  dW_j = (G * x0_j)^T . xk  -- the field factor sits
+// inside an operand, so unlike the forward (cin_bf3.hip) the operand A_j = G * x0_j has to be formed and split per field: 52 VALU
+// instructions per field and k-step in front of the 48 MFMAs of a wave's 8 column tiles (about 1.3 per MFMA with xk's split).
+// Both operands are read along the reduction: a lane's 8 k-slots of a 32-row step are 8 consecutive d of one (sample, channel) --
+// contiguous in memory for D = 8, 16, 32 -- so G, xk and x0 come straight from global memory, 32 bytes per lane and operand.
+//
+// Work split.  A work item is (block of 128 h, block of 128 i, block of JB = 4 fields, span of rows); a workgroup of 8 waves (two per
+// SIMD) takes one item: wave w owns h tile w (16 rows of the output) x 8 i tiles x 4 fields = 32 accumulators (128 registers).
+// Per k-step: xk's 128 x 32 tile is split once by the whole workgroup (thread = one lane-octet) into LDS as three bf16 pieces
+// [piece][i tile][lane][8] (double-buffered, one barrier per step); every wave builds its four A_j (G octet x x0_j octet, split) and
+// then, per i tile, reads the three B pieces once (one ds_read_b128 each) for the 24 MFMAs of the four fields.
+// Spans leave partial sums part[item][span][JB][128][128]; cin_dw_bf3_reduce_k adds them in span order (bitwise reproducible).
+#include "common.hpp"
+
+namespace dir {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int DWB_JB = 4;
+
+__device__ __forceinline__ unsigned int dwb_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
+    typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
+    const pk2_t v = {(__bf16)a, (__bf16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));      // (empty: hides w's origin so that float(bf16(a)) is formed by a shift, not a second convert; see cin_bf3.hip)
+    return w;
+}
+__device__ __forceinline__ void dwb_split8(const float (&x)[8], bf16x8_t (&p)[3]) {     // 8 values -> three bf16x8 operands that sum to them
+    unsigned int w[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        w[0][i] = dwb_pk(a, b);
+        const float ra = a - __builtin_bit_cast(float, w[0][i] << 16), rb = b - __builtin_bit_cast(float, w[0][i] & 0xffff0000u);
+        w[1][i] = dwb_pk(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, w[1][i] << 16), sb = rb - __builtin_bit_cast(float, w[1][i] & 0xffff0000u);
+        w[2][i] = dwb_pk(sa, sb);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
+}
+
+struct DwbPlan { int nhb, nib, njb, items, nspan; int64_t steps, steps_per_span; };
+static DwbPlan dwb_plan(int m, int Hp, int H, int D, int64_t B) {
+    DwbPlan p;
+    p.nhb = (H + 127) / 128;
+    p.nib = (Hp + 127) / 128;
+    p.njb = (m + DWB_JB - 1) / DWB_JB;
+    p.items = p.nhb * p.nib * p.njb;
+    p.steps = (B * D + 31) / 32;
+    int ns = kCUs / p.items;
+    if (ns < 1) ns = 1;
+    if ((int64_t)ns > p.steps) ns = (int)(p.steps > 0 ? p.steps : 1);
+    p.nspan = ns;
+    p.steps_per_span = (p.steps + ns - 1) / ns;
+    return p;
+}
+
+__global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ G,
+                                                       int m, int Hp, int H, int D, int dshift, int nib, int njb, int nspan,
+                                                       int64_t steps_per_span, int64_t steps, int64_t R, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) unsigned int Bp[2][3][8][64][4];      // xk pieces of one k-step: [buffer][piece][i tile][lane][8 bf16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, lg = lane >> 4;
+    // work item: blockIdx.x = ((hb * nib + ib) * njb + jb) * nspan + span
+    int q = blockIdx.x;
+    const int span = q % nspan; q /= nspan;
+    const int jb = q % njb; q /= njb;
+    const int ib = q % nib;
+    const int hb = q / nib;
+    const int64_t s_begin = (int64_t)span * steps_per_span;
+    int64_t s_end = s_begin + steps_per_span;
+    if (s_end > steps) s_end = steps;
+
+    // a lane's 8 k-slots of step s: rows r = 32 s + 8 lg + e  ->  one (sample, 8 consecutive d) for D >= 8
+    const int hrow = min(128 * hb + 16 * wave + n, H - 1);          // this lane's output row h (A operand); clamped rows are never reduced
+    const int icol = min(128 * ib + 16 * wave + n, Hp - 1);         // the xk channel this THREAD splits (i tile = its wave index)
+    const int j0 = DWB_JB * jb;
+
+    f32x4 acc[DWB_JB][8];
+#pragma unroll
+    for (int j = 0; j < DWB_JB; ++j)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) acc[j][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto octet = [&](const float* base, int ch, int C, int64_t s, float (&v)[8]) {     // 8 consecutive d of channel ch of the lane's sample
+        const int64_t r = 32 * s + 8 * lg;
+        if (r < R) {                                                                  // R % 8 == 0 (D >= 8): an octet is inside or outside
+            const float* p = base + (((r >> dshift) * C + ch) << dshift) + (r & (D - 1));
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+    };
+    auto stage_b = [&](int64_t s, int buf) {      // this thread's octet of xk -> three pieces in LDS
+        float v[8];
+        octet(xk, icol, Hp, s, v);
+        if (128 * ib + 16 * wave + n >= Hp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        bf16x8_t p[3];
+        dwb_split8(v, p);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(&Bp[buf][pc][wave][lane][0]) = p[pc];
+    };
+
+    if (s_begin < s_end) stage_b(s_begin, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t s = s_begin; s < s_end; ++s, buf ^= 1) {
+        if (s + 1 < s_end) stage_b(s + 1, buf ^ 1);
+        // A operands: G octet of row h times the x0 octet of each of the JB fields, split
+        float g8[8];
+        octet(G, hrow, H, s, g8);
+        bf16x8_t a[DWB_JB][3];
+#pragma unroll
+        for (int j = 0; j < DWB_JB; ++j) {
+            float x8[8];
+            octet(x0, min(j0 + j, m - 1), m, s, x8);
+            const float keep = (j0 + j < m) ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x8[e] = g8[e] * (x8[e] * keep);
+            dwb_split8(x8, a[j]);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            bf16x8_t b[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) b[pc] = *reinterpret_cast<const bf16x8_t*>(&Bp[buf][pc][it][lane][0]);
+#pragma unroll
+            for (int j = 0; j < DWB_JB; ++j) {
+                f32x4 c = acc[j][it];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][0], b[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][2], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][1], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][0], b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][1], b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][0], b[0], c, 0, 0, 0);
+                acc[j][it] = c;
+            }
+        }
+        __syncthreads();
+    }
+    // partial sums: part[blockIdx.x][j][h = 16 wave + 4 lg + q][i = 16 it + n]   (C/D map: col = lane & 15, row = 4 (lane >> 4) + reg)
+    float* dst = part + (int64_t)blockIdx.x * DWB_JB * 128 * 128;
+#pragma unroll
+    for (int j = 0; j < DWB_JB; ++j)
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) dst[((int64_t)j * 128 + 16 * wave + 4 * lg + qq) * 128 + 16 * it + n] = acc[j][it][qq];
+}
+
+// dW[h, i*m + j] (+)= sum over spans, in span order
+__global__ __launch_bounds__(256) void cin_dw_bf3_reduce_k(const float* __restrict__ part, int m, int Hp, int H, int nib, int njb, int nspan,
+                                                          int accumulate, float* __restrict__ dW) {
+    const int64_t total = (int64_t)H * Hp * m;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % m);
+        const int i = (int)((e / m) % Hp);
+        const int h = (int)(e / ((int64_t)m * Hp));
+        const int hb = h >> 7, ib = i >> 7, jb = j / DWB_JB;
+        const int64_t item = ((int64_t)hb * nib + ib) * njb + jb;
+        const float* p = part + ((item * nspan) * DWB_JB + (j - jb * DWB_JB)) * 128 * 128 + (int64_t)(h & 127) * 128 + (i & 127);
+        float s = 0.f;
+        for (int sp = 0; sp < nspan; ++sp) s += p[(int64_t)sp * DWB_JB * 128 * 128];
+        dW[e] = accumulate ? dW[e] + s : s;
+    }
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int64_t dir_cin_dw_bf16x3_workspace_bytes(int m, int Hp, int H, int D, int64_t B) {
+    if (m <= 0 || Hp <= 0 || H <= 0 || D <= 0 || B < 0) return 0;
+    const DwbPlan p = dwb_plan(m, Hp, H, D, B);
+    return (int64_t)p.items * p.nspan * DWB_JB * 128 * 128 * (int64_t)sizeof(float);
+}
+
+extern "C" int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
+                                     float* dW, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    const char* name = "dir_cin_dw_bf16x3_f32";
+    DIR_CHECK_ARG(x0 && xk && G && dW && workspace, "%s: null pointer", name);
+    DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
+    if (!(D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 8, 16, 32; use dir_cin_dw_f32)", name, D);
+    if (!(aligned16(x0) && aligned16(xk) && aligned16(G) && aligned16(workspace)))
+        return fail(DIR_E_BADARG, "%s: x0 / xk / G / workspace must be 16-byte aligned", name);
+    DIR_CHECK_ARG(workspace_bytes >= dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B), "%s: workspace smaller than "
+                  "dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B)", name);
+    hipStream_t st = as_stream(stream);
+    const int64_t n = (int64_t)H * Hp * m;
+    if (B == 0) {
+        if (!accumulate && hipMemsetAsync(dW, 0, n * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        return DIR_OK;
+    }
+    int dshift = 0;
+    while ((1 << dshift) < D) ++dshift;
+    const DwbPlan p = dwb_plan(m, Hp, H, D, B);
+    hipLaunchKernelGGL(cin_dw_bf3_k, dim3((unsigned)(p.items * p.nspan)), dim3(512), 0, st, x0, xk, G, m, Hp, H, D, dshift, p.nib, p.njb, p.nspan,
+                       p.steps_per_span, p.steps, B * D, static_cast<float*>(workspace));
+    DIR_CHECK_LAUNCH(name);
+    hipLaunchKernelGGL(cin_dw_bf3_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(workspace), m, Hp, H, p.nib,
+                       p.njb, p.nspan, accumulate, dW);
+    DIR_CHECK_LAUNCH("cin_dw_bf16x3 reduce");
+    return DIR_OK;
+}

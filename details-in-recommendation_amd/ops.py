@@ -819,7 +819,17 @@ def cross_network_backward(x0, w, b, gout):
     return gx0, gw, gb
 
 
-def cin_dw(x0, xk, G, dW=None, accumulate=False):
+def cin_dw_auto_arith(m, D, Hp, H):
+    """What cin_dw(arith="auto") runs: the bf16x3 kernel (csrc/cin_dw_bf3.hip) for D >= 8 and layers at least 96 channels wide on the
+    xk side (a wave's 8 column tiles are i tiles: narrower layers leave them idle) with at most a third of the 128 x 128 output
+    blocks padding; the fp32-MFMA kernel otherwise."""
+    if D not in (8, 16, 32) or Hp < 96:
+        return "f32"
+    pad = (-(-H // 128) * 128) * (-(-Hp // 128) * 128) * (-(-m // 4) * 4)
+    return "bf16x3" if pad <= 1.34 * H * Hp * m else "f32"
+
+
+def cin_dw(x0, xk, G, dW=None, accumulate=False, arith=None):
     """Weight gradient of one CIN layer (include/dir_hip.h, dir_cin_dw_f32): x0 [B,m,D], xk [B,Hp,D], G = dL/dxout
     [B,H,D] -> dW [H, Hp*m] (added into `dW` when accumulate)."""
     for t, n in ((x0, "x0"), (xk, "xk"), (G, "G")):
@@ -837,6 +847,17 @@ def cin_dw(x0, xk, G, dW=None, accumulate=False):
     elif dW.shape != (H, Hp * m) or not dW.is_contiguous():
         raise ValueError("cin_dw: dW must be a contiguous [H, Hp*m] tensor")
     lib = _lib.load()
+    arith = arith or CIN_ARITH
+    if arith == "auto":
+        arith = cin_dw_auto_arith(m, D, Hp, H)
+    if arith == "bf16x3":
+        if D not in (8, 16, 32):
+            raise ValueError("cin_dw: arith='bf16x3' covers D in {8, 16, 32} (got %d)" % D)
+        nbytes = int(lib.dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B))
+        ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+        _lib.check(lib.dir_cin_dw_bf16x3_f32(_ptr(x0), _ptr(xk), _ptr(G), m, Hp, H, D, B, 1 if accumulate else 0, _ptr(dW), _ptr(ws), nbytes,
+                                             _stream()))
+        return dW
     ws = torch.empty(max(16, int(lib.dir_cin_dw_workspace_bytes(m, Hp, H, D, B))), dtype=torch.uint8, device=x0.device)
     _lib.check(lib.dir_cin_dw_f32(_ptr(x0), _ptr(xk), _ptr(G), m, Hp, H, D, B, 1 if accumulate else 0, _ptr(dW), _ptr(ws),
                                   _stream()))
@@ -911,6 +932,7 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
     W3 = W.view(H, Hp, m)
     dxk = dx0 = dW = None
     arith = arith or CIN_ARITH
+    dw_arith = arith                                 # cin_dw resolves "auto" by its own rule
     if arith == "auto":
         arith = cin_auto_arith(m, D, H, Hp)          # the data gradients' GEMM: reduction over H, Hp output columns
     if (need_xk or need_x0) and arith == "bf16x3" and cin_bf16x3_covers(m, D) and not force_forward_form:
@@ -930,7 +952,7 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
             part, _ = cin_layer(xg, G, W2)
             dx0 = part if dx0 is None else dx0.add_(part)
     if need_w:
-        dW = cin_dw(x0, xk, G)
+        dW = cin_dw(x0, xk, G, arith=dw_arith)
     return dx0, dxk, dW
 
 

@@ -390,6 +390,14 @@ int64_t dir_cin_dw_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
  * 128 < H <= 256 runs as two 128-row slices of H per field; with two column blocks each adds its dx0 share (two addends on a
  * zeroed buffer: order-free, still reproducible).
  * Limits: H <= 256, Hp <= 256, m <= 64 (DIR_E_UNSUPPORTED otherwise: use the dir_cin_layer_f32 formulation above). */
+/* dir_cin_dw_bf16x3_f32: the weight gradient on the bf16 matrix pipe with fp32-equivalent arithmetic (csrc/cin_dw_bf3.hip): per field j,
+ * dW_j = (G * x0_j)^T . xk with both operands split into three bf16 pieces (six piece products, fp32 accumulate; the field factor is
+ * inside an operand, so that operand is formed and split per field).  Same semantics as dir_cin_dw_f32 (accumulate, fixed-order
+ * reduction of the row spans: bitwise reproducible); D in {8, 16, 32}; best for Hp >= 96 (narrower layers leave its 8 column tiles
+ * idle: dir_cin_dw_f32).  workspace: dir_cin_dw_bf16x3_workspace_bytes(...) device bytes, 16-byte aligned. */
+int64_t dir_cin_dw_bf16x3_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
+int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
+                          float* dW, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp, const float* G, int m, int Hp, int H, int D,
                    int64_t B, float* dxk, float* dx0, dir_stream_t stream);
 int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,

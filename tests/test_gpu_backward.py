@@ -318,11 +318,20 @@ def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
     mag = np.sqrt(B * D) * 0.125 + 1.0
     err = np.abs(dW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
     assert err.max() <= 1e-5, "dW max scaled err %.3e" % err.max()
+    if D >= 8:                          # the bf16x3 weight-gradient kernel (dir_cin_dw_bf16x3_f32): same bar, bitwise reproducible, accumulate form
+        bW = ops.cin_dw(dev(x0), dev(xk), dev(G), arith="bf16x3")
+        err = np.abs(bW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
+        assert err.max() <= 1e-5, "bf16x3 dW max scaled err %.3e" % err.max()
+        assert torch.equal(ops.cin_dw(dev(x0), dev(xk), dev(G), arith="bf16x3"), bW)
+        acc2 = ops.cin_dw(dev(x0), dev(xk), dev(G), dW=bW.clone(), accumulate=True, arith="bf16x3")
+        assert torch.allclose(acc2, 2 * bW, rtol=1e-6, atol=1e-6)
     # accumulate form and bitwise reproducibility
-    again = ops.cin_dw(dev(x0), dev(xk), dev(G))
+    again = ops.cin_dw(dev(x0), dev(xk), dev(G), arith="f32")
     assert torch.equal(again, dW)
     acc = dW.clone()
-    ops.cin_dw(dev(x0), dev(xk), dev(G), dW=acc, accumulate=True)
+    ops.cin_dw(dev(x0), dev(xk), dev(G), dW=acc, accumulate=True, arith="f32")
+    auto = ops.cin_dw(dev(x0), dev(xk), dev(G))                      # "auto" is one of the two kernels, bitwise
+    assert torch.equal(auto, bW if (D >= 8 and ops.cin_dw_auto_arith(m, D, Hp, H) == "bf16x3") else dW)
     _close(acc, 2 * ref_dW, tol=1e-5 * mag)
 
 
