@@ -25,6 +25,16 @@ for Hp, H, n in [(128, 128, 40), (26, 128, 40), (200, 200, 10)]:
     for _ in range(n):
         k2, z2 = ops.cin_dx_bf16x3(x0, xk, W, G)
         neq2 += (not torch.equal(k2, bk)) or (not torch.equal(z2, b0))
+    w32 = ops.cin_dw(x0, xk, G, arith="f32")
+    w3 = ops.cin_dw(x0, xk, G, arith="bf16x3")
+    e3 = float(((w3 - w32).abs() / (129.0 + w32.abs())).max())
+    neq3 = 0
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(n):
+        neq3 += not torch.equal(ops.cin_dw(x0, xk, G, arith="bf16x3"), w3)
+    t1.record(); torch.cuda.synchronize()
+    print("   weight gradient vs fp32 kernel %.2e (scaled by 129 + |ref|), reruns not equal %d / %d, %.2f ms per call (incl. the compare)" % (e3, neq3, n, t0.elapsed_time(t1) / n))
     print("Hp %d H %d: forward vs fp32 kernel %.2e, reruns not bitwise equal %d / %d; data gradients vs fp32 kernel %.2e, reruns not equal %d / %d"
           % (Hp, H, e, neq, n, e2, neq2, n), flush=True)
     del xk, W, G, rx, rp, fx, fp, d0, dk, bk, b0
