@@ -425,3 +425,27 @@ def test_tf_checkpoint_export_load_round_trip(tmp_path, built_lib):
         sig = json.load(open(os.path.join(exp, "serving_signature.json")))
         assert sig["signature_def"]["serving_default"]["method_name"] == "tensorflow/serving/classify"
         assert set(tb.read_bundle(os.path.join(exp, "variables", "variables"))) == set(raw)
+
+
+def test_arithmetic_selection_rules():
+    """ops.cin_auto_arith / cin_dw_auto_arith / dense_auto_arith (pure host logic): which kernel arith="auto" runs.  The bf16x3
+    kernels compute whole column blocks / k-steps, so they are chosen while their padding costs less than their advantage."""
+    from dir_amd import ops
+    # CIN forward (and, transposed, its data gradients): the BASELINE stack and the paper's 200-wide layers on bf16x3 ...
+    assert ops.cin_auto_arith(26, 16, 26, 128) == "bf16x3" and ops.cin_auto_arith(26, 16, 128, 128) == "bf16x3"
+    assert ops.cin_auto_arith(26, 16, 200, 200) == "bf16x3" and ops.cin_auto_arith(26, 16, 128, 32) == "bf16x3"
+    # ... a 7-channel input (32-wide k-step: 4.6 x padding), a 10-wide output, more than 40 fields or an odd D on fp32 MFMA
+    assert ops.cin_auto_arith(26, 16, 7, 128) == "f32" and ops.cin_auto_arith(26, 16, 128, 10) == "f32"
+    assert ops.cin_auto_arith(41, 16, 128, 128) == "f32" and ops.cin_auto_arith(26, 12, 128, 128) == "f32"
+    assert ops.cin_bf16x3_covers(1, 4) and ops.cin_bf16x3_covers(40, 32) and not ops.cin_bf16x3_covers(41, 16)
+    # weight gradient: wide layers with D >= 8 only (a wave's 8 column tiles are xk channels; D = 4 splits an octet over two samples)
+    assert ops.cin_dw_auto_arith(26, 16, 128, 128) == "bf16x3" and ops.cin_dw_auto_arith(24, 8, 128, 128) == "bf16x3"
+    assert ops.cin_dw_auto_arith(26, 16, 26, 128) == "f32" and ops.cin_dw_auto_arith(26, 4, 128, 128) == "f32"
+    assert ops.cin_dw_auto_arith(26, 16, 200, 200) == "f32"            # 256 x 256 x 28 computed for 200 x 200 x 26
+    # dense layers: the tower shapes at training / serving batch sizes on bf16x3; small batches, narrow or badly padded layers on fp32
+    assert ops.dense_auto_arith(65536, 416, 400) == "bf16x3" and ops.dense_auto_arith(65536, 1024, 1024) == "bf16x3"
+    assert ops.dense_auto_arith(ops.DENSE_BF3_MIN_ROWS, 360, 200) == "bf16x3"
+    assert ops.dense_auto_arith(ops.DENSE_BF3_MIN_ROWS - 1, 416, 400) == "f32"
+    assert ops.dense_auto_arith(65536, 200, 80) == "f32" and ops.dense_auto_arith(65536, 400, 16) == "f32"
+    with pytest.raises(ValueError):
+        ops.cin_layer(torch.zeros(2, 3, 4), torch.zeros(2, 3, 4), torch.zeros(5, 9), arith="bf16")      # CPU tensors / bad arith: refused
