@@ -22,7 +22,13 @@
 // rows [32w, 32w+32) = 2 row tiles x 8 column tiles of 16 x 16: 64 registers for T_j and 64 for out.  i runs in halves of KS*32
 // values (KS = 2; 1 when Hp <= 32); a chunk is one (half, field j): KS k-steps x 16 tiles x 6 = 192 MFMAs per wave, one barrier
 // per chunk.  B operands are read one (k-step, column tile) group ahead of their 12 MFMAs; the accumulate fmas of a tile sit
-// between the MFMAs of the chain that overwrites it.
+// between the MFMAs of the chain that overwrites it.  H's columns are cut into 128-wide blocks plus ONE narrower last block of
+// 2 / 4 / 6 column tiles (template parameter CT; its own launch with a column offset).
+// Operand registers and two waves per SIMD: the A operands are rewritten once per half behind a barrier, the B operands arrive by
+// LDS reads into alternating registers -- no VALU instruction writes an MFMA source register close behind the MFMAs that read it
+// (the pattern that made a bf16x3 DIN unit irreproducible at two waves per SIMD); run-to-run bitwise equality is tested.
+//
+// The data-gradient form (template parameters RT = 1, DOT; dir_cin_layer_dot_bf16x3_f32) is described at the kernel.
 //
 // LDS: Wb [2][KS][3 planes][8 ct][64 lanes][8 bf16]  the chunk's W operand image, written by global_load_lds in the order
 //                                                    cin_bf3_pack_w_k lays the global image out (one ds_read_b128 per operand);
@@ -38,7 +44,6 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
 
 __device__ __forceinline__ unsigned int bt_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
     typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
