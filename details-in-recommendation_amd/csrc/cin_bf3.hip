@@ -378,15 +378,15 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: one row tile per wave, dot partials)
 static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                    float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
-    DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
+    if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
+    DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
     DIR_CHECK_ARG(!pooled || pooled_ld >= H, "%s: pooled_ld=%lld < H=%d", name, (long long)pooled_ld, H);
     if (!(D == 4 || D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 4, 8, 16, 32)", name, D);
     if (m > 40) return fail(DIR_E_UNSUPPORTED, "%s: field count m=%d exceeds 40 (LDS-resident x0 slice)", name, m);
     if (xout && !aligned16(xout)) return fail(DIR_E_BADARG, "%s: xout must be 16-byte aligned", name);
     DIR_CHECK_ARG(aligned16(workspace) && workspace_bytes >= dir_cin_bf16x3_workspace_bytes(m, Hp, H),
                   "%s: workspace must be 16-byte aligned and hold dir_cin_bf16x3_workspace_bytes(m, Hp, H) bytes", name);
-    if (B == 0) return DIR_OK;
     int dshift = 0;
     while ((1 << dshift) < D) ++dshift;
     const int64_t R = B * D;
@@ -460,6 +460,7 @@ extern "C" int dir_cin_layer_dot_bf16x3_f32(const float* x0, const float* xk, co
                                             int64_t B, float* xout, float* dot_partials, void* workspace, int64_t workspace_bytes,
                                             dir_stream_t stream) {
     const char* name = "dir_cin_layer_dot_bf16x3_f32";
+    if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(y && dot_partials && xout, "%s: null pointer", name);
     DIR_CHECK_ARG(aligned16(y) && aligned16(dot_partials), "%s: y and dot_partials must be 16-byte aligned", name);
     return bf3_run(name, x0, xk, W, m, Hp, H, D, B, xout, nullptr, 0, y, dot_partials, workspace, workspace_bytes, stream);

@@ -190,19 +190,20 @@ extern "C" int64_t dir_cin_dw_bf16x3_workspace_bytes(int m, int Hp, int H, int D
 extern "C" int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
                                      float* dW, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     const char* name = "dir_cin_dw_bf16x3_f32";
-    DIR_CHECK_ARG(x0 && xk && G && dW && workspace, "%s: null pointer", name);
+    DIR_CHECK_ARG(dW, "%s: null pointer", name);
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (!(D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 8, 16, 32; use dir_cin_dw_f32)", name, D);
+    hipStream_t st = as_stream(stream);
+    const int64_t n = (int64_t)H * Hp * m;
+    if (B == 0) {                                    // an empty batch has a zero gradient (empty operands have no storage: null allowed)
+        if (!accumulate && hipMemsetAsync(dW, 0, n * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        return DIR_OK;
+    }
+    DIR_CHECK_ARG(x0 && xk && G && workspace, "%s: null pointer", name);
     if (!(aligned16(x0) && aligned16(xk) && aligned16(G) && aligned16(workspace)))
         return fail(DIR_E_BADARG, "%s: x0 / xk / G / workspace must be 16-byte aligned", name);
     DIR_CHECK_ARG(workspace_bytes >= dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B), "%s: workspace smaller than "
                   "dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B)", name);
-    hipStream_t st = as_stream(stream);
-    const int64_t n = (int64_t)H * Hp * m;
-    if (B == 0) {
-        if (!accumulate && hipMemsetAsync(dW, 0, n * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
-        return DIR_OK;
-    }
     int dshift = 0;
     while ((1 << dshift) < D) ++dshift;
     const DwbPlan p = dwb_plan(m, Hp, H, D, B);

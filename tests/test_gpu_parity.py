@@ -241,6 +241,32 @@ def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     assert torch.equal(ax, want[0]) and torch.equal(ap, want[1])
 
 
+def test_bf16x3_kernels_on_empty_and_single_row_batches(ops):
+    """B = 0 is a no-op that returns empty results (dW: zeros) and B = 1 (a single partial workgroup) is exact to the bar, on every
+    bf16x3 entry point: CIN forward, data gradients, weight gradient, dense layer."""
+    m, D, Hp, H = 26, 16, 128, 128
+    W = torch.randn((H, Hp * m), device="cuda") / (Hp * m) ** 0.5
+    for B in (0, 1):
+        x0 = torch.randn((B, m, D), device="cuda")
+        xk = torch.randn((B, Hp, D), device="cuda")
+        G = torch.randn((B, H, D), device="cuda")
+        xo, po = ops.cin_layer(x0, xk, W, arith="bf16x3")
+        dxk, dx0 = ops.cin_dx_bf16x3(x0, xk, W, G)
+        dW = ops.cin_dw(x0, xk, G, arith="bf16x3")
+        assert xo.shape == (B, H, D) and po.shape == (B, H) and dxk.shape == (B, Hp, D) and dx0.shape == (B, m, D) and dW.shape == (H, Hp * m)
+        if B == 0:
+            assert float(dW.abs().max()) == 0.0
+        else:
+            fo, fp_ = ops.cin_layer(x0, xk, W, arith="f32")
+            f0, fk, fW = ops.cin_layer_backward(x0, xk, W, G, arith="f32")
+            for a, b in ((xo, fo), (po, fp_), (dxk, fk), (dx0, f0), (dW, fW)):
+                assert float(((a - b).abs() / (1 + b.abs())).max()) <= 1e-5
+    w = torch.randn((400, 416), device="cuda") / 20.0
+    assert ops.dense(torch.zeros((0, 416), device="cuda"), w, arith="bf16x3").shape == (0, 400)
+    x1 = torch.randn((1, 416), device="cuda")
+    assert float((ops.dense(x1, w, arith="bf16x3") - ops.dense(x1, w, arith="f32")).abs().max()) <= 1e-5
+
+
 def test_cin_bf16x3_refuses_uncovered_shapes(ops):
     x0 = torch.zeros((4, 41, 16), device="cuda"); xk = torch.zeros((4, 3, 16), device="cuda"); W = torch.zeros((8, 3 * 41), device="cuda")
     assert not ops.cin_bf16x3_covers(41, 16) and ops.cin_auto_arith(41, 16, 3, 8) == "f32"
