@@ -30,3 +30,17 @@ def built_lib():
         import __graft_entry__
         __graft_entry__.build()
     return dir_amd.load_library()
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_generators(request):
+    """Every test starts from the same global torch / numpy generator state (derived from its name): modules initialised with
+    nn.init and the few torch.randn(...) calls without an explicit generator draw the same values in every process, so a test that
+    passes once passes always (a discontinuity such as a ReLU boundary cannot be hit in one run and missed in the next)."""
+    import zlib
+    import numpy as np
+    import torch
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff
+    torch.manual_seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    yield
