@@ -229,19 +229,23 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             }
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
             // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
-            bf16x8_t bc[3], bn[3];
+            // (two register sets used alternately: the loops are unrolled, the set index is a compile-time constant -- copying "next"
+            // into "current" would cost 12 v_mov per group, one VALU instruction per MFMA)
+            bf16x8_t bq[2][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bc[p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
+            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
 #pragma unroll
             for (int ks = 0; ks < KSN; ++ks) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const bool lastg = (ks == KSN - 1 && ct == CT - 1);
+                    const int gi = ks * CT + ct;                     // group index inside the chunk (compile-time after unrolling)
                     if (!lastg) {
                         const unsigned char* wp = wl + (ct + 1 < CT ? ks : ks + 1) * STEPB + ((ct + 1) % CT) * 1024;
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) bn[p] = *reinterpret_cast<const bf16x8_t*>(wp + p * CT * 1024);
+                        for (int p = 0; p < 3; ++p) bq[(gi + 1) & 1][p] = *reinterpret_cast<const bf16x8_t*>(wp + p * CT * 1024);
                     }
+                    const bf16x8_t (&bc)[3] = bq[gi & 1];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         f32x4 t;
@@ -278,8 +282,6 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                             __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) bc[p] = bn[p];
                     }
                 }
             }

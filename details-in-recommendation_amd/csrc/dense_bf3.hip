@@ -190,15 +190,18 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                 for (int p = 0; p < 3; ++p) xa[rt][p] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
             }
             const unsigned char* wl = wlane + buf * STEPB;
-            bf16x8_t wc[3], wn[3];
+            // W operands one column tile ahead, in two register sets used alternately (the loop is unrolled: the set index is a
+            // compile-time constant; copying "next" into "current" costs 12 v_mov per tile, one VALU instruction per MFMA)
+            bf16x8_t wq[2][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wc[p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
+            for (int p = 0; p < 3; ++p) wq[0][p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 if (ct + 1 < CT) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wn[p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024 + (ct + 1) * 1024);
+                    for (int p = 0; p < 3; ++p) wq[(ct + 1) & 1][p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024 + (ct + 1) * 1024);
                 }
+                const bf16x8_t (&wc)[3] = wq[ct & 1];
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     f32x4 tt = acc[rt][ct];
@@ -209,10 +212,6 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                     tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[rt][0], tt, 0, 0, 0);
                     tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][0], tt, 0, 0, 0);
                     acc[rt][ct] = tt;
-                }
-                if (ct + 1 < CT) {
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) wc[p] = wn[p];
                 }
             }
 #pragma unroll
