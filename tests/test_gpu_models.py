@@ -75,6 +75,49 @@ def test_deepfm_config1_forward(built_lib, oracle):
     assert torch.isfinite(lin_only).all()
 
 
+@pytest.mark.parametrize("batch_norm", [False, True])
+def test_deepfm_forward_at_a_batch_that_takes_the_bf16x3_towers(built_lib, oracle, batch_norm):
+    """DeepFM (cfg-2 style schema: 26 sparse x dim 16, 400-400-400) at 12 288 rows, where dense.dense_act runs the hidden layers on
+    dir_dense_bf16x3_f32 (with the folded inference batch-norm in its epilogue): logits against the float64 reference graph
+    (deepFM.py:169-223), and against the same model with the towers forced onto the fp32-MFMA kernel."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    from dir_amd import ops
+    rng = np.random.default_rng(21)
+    B, F, K, V = 12288, 26, 16, 5000
+    assert ops.dense_auto_arith(B, F * K, 400) == "bf16x3"
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[400, 400, 400], fm_embedding_size=K, batch_norm=batch_norm).cuda()
+    with torch.no_grad():
+        for w in model.linear_weights:
+            w.normal_(0, 0.05)
+        model.linear_bias.fill_(-0.1)
+        for bn in model.bns:
+            bn.moving_mean.normal_(0, 0.1); bn.moving_variance.uniform_(0.5, 1.5); bn.gamma.uniform_(0.8, 1.2); bn.beta.normal_(0, 0.1)
+    ids = rng.integers(0, V, size=(B, F)).astype(np.int64)
+    feats = {"C%d" % i: torch.from_numpy(ids[:, i].copy()).cuda() for i in range(F)}
+    with torch.no_grad():
+        logits = model(feats)
+        old = ops.DENSE_ARITH
+        ops.DENSE_ARITH = "f32"
+        try:
+            logits32 = model(feats)
+        finally:
+            ops.DENSE_ARITH = old
+    tabs = [p.detach().cpu().numpy() for p in model.embedding_weights]
+    emb = oracle.embedding_bag(tabs, ids).astype(np.float64)
+    fm = R.fm_logit(emb, F, K, np.float64)
+    layers = [(_np(l.weight).T, _np(l.bias)) for l in model.hidden]
+    bn = [(_np(b.moving_mean), _np(b.moving_variance), _np(b.gamma), _np(b.beta)) for b in model.bns] if batch_norm else None
+    dnn = R.dnn_logit(emb, layers, (_np(model.logits_layer.weight).T, _np(model.logits_layer.bias)), bn=bn)
+    lin = sum(_np(w)[ids[:, f]] for f, w in enumerate(model.linear_weights)) - 0.1
+    ref = fm + dnn + lin[:, None]
+    _close(logits.cpu().numpy(), ref)
+    _close(logits32.cpu().numpy(), ref)
+    assert not torch.equal(logits, logits32)          # two different kernels did run
+
+
 def test_deepfm_multihot_weighted(built_lib, oracle):
     """The multi-hot path the reference advertises (deepFM.py:53,77; SequenceTensorFlowDataset/test4.py:50-59)."""
     from dir_amd.deepfm import DeepFM
