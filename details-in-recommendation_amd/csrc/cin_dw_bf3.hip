@@ -31,16 +31,18 @@ __device__ __forceinline__ unsigned int dwb_pk(float a, float b) {      // v_cvt
     asm("" : "+v"(w));      // (empty: hides w's origin so that float(bf16(a)) is formed by a shift, not a second convert; see cin_bf3.hip)
     return w;
 }
-__device__ __forceinline__ void dwb_split8(const float (&x)[8], bf16x8_t (&p)[3]) {     // 8 values -> three bf16x8 operands that sum to them
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 8 values (four pairs) -> three bf16x8 operands that sum to them; residuals on pairs (one v_pk_add_f32 per two elements)
+__device__ __forceinline__ void dwb_split8(f32x2 v0, f32x2 v1, f32x2 v2, f32x2 v3, bf16x8_t (&p)[3]) {
+    const f32x2 v[4] = {v0, v1, v2, v3};
     unsigned int w[3][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float a = x[2 * i], b = x[2 * i + 1];
-        w[0][i] = dwb_pk(a, b);
-        const float ra = a - __builtin_bit_cast(float, w[0][i] << 16), rb = b - __builtin_bit_cast(float, w[0][i] & 0xffff0000u);
-        w[1][i] = dwb_pk(ra, rb);
-        const float sa = ra - __builtin_bit_cast(float, w[1][i] << 16), sb = rb - __builtin_bit_cast(float, w[1][i] & 0xffff0000u);
-        w[2][i] = dwb_pk(sa, sb);
+        w[0][i] = dwb_pk(v[i][0], v[i][1]);
+        const f32x2 r = v[i] - (f32x2){__builtin_bit_cast(float, w[0][i] << 16), __builtin_bit_cast(float, w[0][i] & 0xffff0000u)};
+        w[1][i] = dwb_pk(r[0], r[1]);
+        const f32x2 t = r - (f32x2){__builtin_bit_cast(float, w[1][i] << 16), __builtin_bit_cast(float, w[1][i] & 0xffff0000u)};
+        w[2][i] = dwb_pk(t[0], t[1]);
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
@@ -89,48 +91,58 @@ __global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__
 #pragma unroll
         for (int it = 0; it < 8; ++it) acc[j][it] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto octet = [&](const float* base, int ch, int C, int64_t s, float (&v)[8]) {     // 8 consecutive d of channel ch of the lane's sample
+    auto octet = [&](const float* base, int ch, int C, int64_t s, f32x4 (&v)[2]) {     // 8 consecutive d of channel ch of the lane's sample
         const int64_t r = 32 * s + 8 * lg;
         if (r < R) {                                                                  // R % 8 == 0 (D >= 8): an octet is inside or outside
             const float* p = base + (((r >> dshift) * C + ch) << dshift) + (r & (D - 1));
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
-            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            v[0] = *reinterpret_cast<const f32x4*>(p);
+            v[1] = *reinterpret_cast<const f32x4*>(p + 4);
         } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            v[0] = v[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto stage_b = [&](int64_t s, int buf) {      // this thread's octet of xk -> three pieces in LDS
-        float v[8];
-        octet(xk, icol, Hp, s, v);
-        if (128 * ib + 16 * wave + n >= Hp) {
+    // Raw operands travel one step ahead of their use: the loads of step s+1 (G, x0) and s+2 (xk) are issued after step s's splits
+    // and land under its 192 MFMAs, in the registers the splits have just freed.
+    f32x4 rg[2], rx[DWB_JB][2], rb[2];
+    auto load_a = [&](int64_t s) {
+        octet(G, hrow, H, s, rg);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int j = 0; j < DWB_JB; ++j) {
+            if (j0 + j < m) octet(x0, j0 + j, m, s, rx[j]);
+            else rx[j][0] = rx[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    };
+    const bool icol_in = 128 * ib + 16 * wave + n < Hp;
+    auto load_b = [&](int64_t s) {
+        octet(xk, icol, Hp, s, rb);
+        if (!icol_in) rb[0] = rb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto split_b = [&](int buf) {                 // this thread's octet of xk -> three pieces in LDS
         bf16x8_t p[3];
-        dwb_split8(v, p);
+        dwb_split8((f32x2){rb[0][0], rb[0][1]}, (f32x2){rb[0][2], rb[0][3]}, (f32x2){rb[1][0], rb[1][1]}, (f32x2){rb[1][2], rb[1][3]}, p);
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(&Bp[buf][pc][wave][lane][0]) = p[pc];
     };
 
-    if (s_begin < s_end) stage_b(s_begin, 0);
+    if (s_begin < s_end) {
+        load_b(s_begin);
+        load_a(s_begin);
+        split_b(0);
+        load_b(s_begin + 1);
+    }
     __syncthreads();
     int buf = 0;
     for (int64_t s = s_begin; s < s_end; ++s, buf ^= 1) {
-        if (s + 1 < s_end) stage_b(s + 1, buf ^ 1);
         // A operands: G octet of row h times the x0 octet of each of the JB fields, split
-        float g8[8];
-        octet(G, hrow, H, s, g8);
         bf16x8_t a[DWB_JB][3];
+        const f32x2 g0 = {rg[0][0], rg[0][1]}, g1 = {rg[0][2], rg[0][3]}, g2 = {rg[1][0], rg[1][1]}, g3 = {rg[1][2], rg[1][3]};
 #pragma unroll
-        for (int j = 0; j < DWB_JB; ++j) {
-            float x8[8];
-            octet(x0, min(j0 + j, m - 1), m, s, x8);
-            const float keep = (j0 + j < m) ? 1.f : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x8[e] = g8[e] * (x8[e] * keep);
-            dwb_split8(x8, a[j]);
-        }
+        for (int j = 0; j < DWB_JB; ++j)
+            dwb_split8(g0 * (f32x2){rx[j][0][0], rx[j][0][1]}, g1 * (f32x2){rx[j][0][2], rx[j][0][3]}, g2 * (f32x2){rx[j][1][0], rx[j][1][1]},
+                       g3 * (f32x2){rx[j][1][2], rx[j][1][3]}, a[j]);
+        if (s + 1 < s_end) split_b(buf ^ 1);
+        load_a(s + 1);                                   // (rows past R read as zeros; a step past the span is loaded and not used)
+        load_b(s + 2);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             bf16x8_t b[3];
