@@ -96,9 +96,12 @@ __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict_
 // DOT (the backward's data gradients, dir_cin_dx_bf16x3_f32): besides out = sum_j x0_j * T_j the kernel also forms, for every field,
 //   dot[r, j] = sum_h y[r, h] * T_j[r, h]      (y in the layout of xout; the sum runs over this workgroup's columns and this half of i)
 // from the same T_j tiles, just before the next chunk overwrites them.  Called with xk := G, W := W1 (W1[i, h*m+j] = W[h, i*m+j]) and
-// y := the layer's xk, `out` is dxk and the dot partials add up to dx0.  It keeps y's tile in registers, so a wave owns RT = 1 row tile.
+// y := the layer's xk, `out` is dxk and the dot partials add up to dx0.  It keeps y's tile in registers next to `out` and T, so its
+// column blocks are 64 wide (CT <= 4) and one staged chunk holds FJ = 2 fields: per barrier a wave still issues the forward's 192
+// MFMAs on 256 rows (one row tile per wave on 128-column blocks -- the first version of this form -- halves the MFMAs per B-operand
+// read and per barrier: 4.7 ms against the forward's 3.3 ms at 128 x 128).
 template <int KS, int CT /* column tiles of 16 per workgroup: 8 (128 columns), or 6 / 4 / 2 for the last block of a layer */,
-          int RT = 2 /* row tiles of 16 per wave */, bool DOT = false>
+          int RT = 2 /* row tiles of 16 per wave */, bool DOT = false, int FJ = 1 /* fields per staged chunk */>
 __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                      const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
                                                      int nkh, int hoff /* first output column of this launch */, int64_t R,
@@ -106,12 +109,12 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      const float* __restrict__ y /* DOT: [B, H, D] */,
                                                      float* __restrict__ dotp /* DOT: partials [nkh][B, m, D] of this launch's column block */) {
     constexpr int STEPB = 3 * CT * 1024;                         // bytes of W image per k-step of 32
-    constexpr int CHB = KS * STEPB;                              // bytes of W image per chunk
+    constexpr int CHB = KS * STEPB;                              // bytes of W image per (half, field); a staged chunk holds FJ of them
     constexpr int BT_ROWS = 8 * 16 * RT;                         // rows per workgroup (shadows the 256 of the forward)
     constexpr int WR = 16 * RT;                                  // rows per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char bt_smem[];
-    unsigned char* Wb = bt_smem;                                 // [2][CHB]
-    float* x0s = reinterpret_cast<float*>(bt_smem + 2 * CHB);    // [m][BT_ROWS]
+    unsigned char* Wb = bt_smem;                                 // [2][FJ * CHB]
+    float* x0s = reinterpret_cast<float*>(bt_smem + 2 * FJ * CHB);   // [m][BT_ROWS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,16 +126,16 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     const int nchunk = nkh * m;
     const unsigned char* gimg = img + (int64_t)blockIdx.y * nchunk * CHB;
 
-    auto stage_w = [&](int c, int buf) {     // KS * 3 * CT pieces of 1 KB over 8 waves, lane-linear
-        for (int piece = wave; piece < KS * 3 * CT; piece += 8) {
+    auto stage_w = [&](int c, int nf, int buf) {     // fields c .. c + nf - 1: nf * KS * 3 * CT pieces of 1 KB over 8 waves, lane-linear
+        for (int piece = wave; piece < nf * KS * 3 * CT; piece += 8) {
             const unsigned char* src = gimg + (int64_t)c * CHB + piece * 1024 + lane * 16;
-            unsigned char* dst = Wb + buf * CHB + piece * 1024;
+            unsigned char* dst = Wb + buf * (FJ * CHB) + piece * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
         }
     };
 
     // ---- prologue: W chunk 0 and the x0 slice (thread t: row t & 255, fields of parity t >> 8)
-    stage_w(0, 0);
+    stage_w(0, min(FJ, m), 0);
     {
         constexpr int TPR = 512 / BT_ROWS;                           // threads sharing a row: they take the fields j = t / BT_ROWS, + TPR, ...
         const int r = tid % BT_ROWS;
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         }
     };
 
-    int c = 0;
+    int c = 0;                                  // (half, field) index = kh * m + j
+    int u = 0;                                  // staged chunk index (its LDS buffer: u & 1)
     for (int kh = 0; kh < nkh; ++kh) {
         // ---- A operands of this half: xk[r, KS*32*kh + 32*ks + 8*lg + e], split once, used by all m fields
 #pragma unroll
@@ -216,11 +220,18 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[ks][rt][p] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
             }
-        for (int j = 0; j < m; ++j, ++c) {      // one chunk = (this half, field j)
+        for (int j0 = 0; j0 < m; j0 += FJ, ++u) {      // one staged chunk = (this half, fields j0 .. j0 + nf - 1)
+          const int buf = u & 1;
+          const int nf = min(FJ, m - j0);
+          {
+              const int cn = kh * m + j0 + nf;        // first field of the next chunk (the next half starts at a chunk boundary)
+              if (cn < nchunk) stage_w(cn, min(FJ, m - (j0 + nf < m ? j0 + nf : 0)), buf ^ 1);
+          }
+#pragma unroll 1
+          for (int f = 0; f < nf; ++f, ++c) {
             constexpr int KSN = KS;
-            const int buf = c & 1;
-            if (c + 1 < nchunk) stage_w(c + 1, buf ^ 1);
-            const unsigned char* wl = wlane + buf * CHB;
+            const int j = j0 + f;
+            const unsigned char* wl = wlane + buf * (FJ * CHB) + f * CHB;
             f32x4 xcur[RT], sd[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -290,8 +301,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             if constexpr (DOT) {          // sd holds the dot of the PREVIOUS chunk (its T tiles were consumed during this chunk's first k-step)
                 if (c > 0) store_dot(sd, j == 0 ? kh - 1 : kh, j == 0 ? m - 1 : j - 1);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of chunk c + 1 have landed in LDS
-            __syncthreads();
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of the next chunk have landed in LDS
+          __syncthreads();
         }
     }
     // the last chunk's T
@@ -357,24 +369,26 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 using namespace dir;
 
 // Shape plan shared by the workspace query and the launcher: halves of i, column blocks
-struct Bf3Plan { int KS, nkh, nfull, ctl; int64_t chunks, bytes_full, bytes_last; };
-static Bf3Plan bf3_plan(int m, int Hp, int H) {
+struct Bf3Plan { int KS, nkh, bw, nfull, ctl; int64_t chunks, bytes_full, bytes_last; };
+static Bf3Plan bf3_plan(int m, int Hp, int H, bool dot) {
     Bf3Plan p;
     p.KS = Hp <= 32 ? 1 : 2;
     p.nkh = (Hp + p.KS * 32 - 1) / (p.KS * 32);
-    p.nfull = H / 128;                                                        // 128-column blocks
-    const int r = H - 128 * p.nfull;
-    p.ctl = r ? ((r + 15) / 16 + 1) / 2 * 2 : 0;                              // tiles of the last block: 2, 4, 6 or 8
+    p.bw = dot ? 4 : 8;                                                       // tiles per full column block: 128 columns, 64 in the dot form
+    p.nfull = H / (16 * p.bw);
+    const int r = H - 16 * p.bw * p.nfull;
+    p.ctl = r ? ((r + 15) / 16 + 1) / 2 * 2 : 0;                              // tiles of the last block: 2, 4, 6 or 8 (dot form: 2 or 4)
     p.chunks = (int64_t)p.nkh * m;
-    p.bytes_full = (int64_t)p.nfull * p.chunks * p.KS * 3 * 8 * 1024;
+    p.bytes_full = (int64_t)p.nfull * p.chunks * p.KS * 3 * p.bw * 1024;
     p.bytes_last = p.chunks * p.KS * 3 * p.ctl * 1024;
     return p;
 }
 
 extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     if (m <= 0 || Hp <= 0 || H <= 0) return 0;
-    const Bf3Plan p = bf3_plan(m, Hp, H);
-    return p.bytes_full + p.bytes_last;
+    const Bf3Plan p = bf3_plan(m, Hp, H, false), q = bf3_plan(m, Hp, H, true);      // either form of the layer
+    const int64_t a = p.bytes_full + p.bytes_last, b = q.bytes_full + q.bytes_last;
+    return a > b ? a : b;
 }
 
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: one row tile per wave, dot partials)
@@ -393,53 +407,61 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     while ((1 << dshift) < D) ++dshift;
     const int64_t R = B * D;
     hipStream_t st = as_stream(stream);
-    const Bf3Plan pl = bf3_plan(m, Hp, H);
+    const bool dot = y != nullptr;
+    const Bf3Plan pl = bf3_plan(m, Hp, H, dot);
     unsigned char* img = static_cast<unsigned char*>(workspace);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
         const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
         hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
                            reinterpret_cast<unsigned int*>(dst));
     };
-    if (pl.nfull) pack(pl.nfull, 8, 0, img);
-    if (pl.ctl) pack(1, pl.ctl, 128 * pl.nfull, img + pl.bytes_full);
-    const bool dot = y != nullptr;
-    const int rows = dot ? 128 : 256;
-    const unsigned nrb = (unsigned)((R + rows - 1) / rows);
+    if (pl.nfull) pack(pl.nfull, pl.bw, 0, img);
+    if (pl.ctl) pack(1, pl.ctl, 16 * pl.bw * pl.nfull, img + pl.bytes_full);
+    const unsigned nrb = (unsigned)((R + 255) / 256);
     const int64_t dot_block = (int64_t)pl.nkh * B * m * D;         // floats of dot partials per column block
-#define BT_LAUNCH(K, C, RT_, DOT_, NCB, HOFF, IMG, DOTP)                                                                              \
+#define BT_LAUNCH(K, C, DOT_, FJ_, NCB, HOFF, IMG, DOTP)                                                                              \
     do {                                                                                                                              \
         static bool set = false;                                                                                                      \
         if (!set) {                                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<K, C, RT_, DOT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<K, C, 2, DOT_, FJ_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             set = true;                                                                                                               \
         }                                                                                                                             \
-        const size_t shmem = 2 * (size_t)K * 3 * C * 1024 + sizeof(float) * (size_t)m * (128 * RT_);                                  \
-        hipLaunchKernelGGL((cin_bf3_k<K, C, RT_, DOT_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, \
+        const size_t shmem = 2 * (size_t)FJ_ * K * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                    \
+        hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, \
                            pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP);                                                        \
     } while (0)
-#define BT_LAUNCH_CT(C, NCB, HOFF, IMG, DOTP)                                       \
+#define BT_LAUNCH_FWD(C, NCB, HOFF, IMG)                                            \
     do {                                                                            \
-        if (dot) {                                                                  \
-            if (pl.KS == 1) BT_LAUNCH(1, C, 1, true, NCB, HOFF, IMG, DOTP);         \
-            else BT_LAUNCH(2, C, 1, true, NCB, HOFF, IMG, DOTP);                    \
-        } else {                                                                    \
-            if (pl.KS == 1) BT_LAUNCH(1, C, 2, false, NCB, HOFF, IMG, DOTP);        \
-            else BT_LAUNCH(2, C, 2, false, NCB, HOFF, IMG, DOTP);                   \
-        }                                                                           \
+        if (pl.KS == 1) BT_LAUNCH(1, C, false, 1, NCB, HOFF, IMG, nullptr);         \
+        else BT_LAUNCH(2, C, false, 1, NCB, HOFF, IMG, nullptr);                    \
     } while (0)
-    if (pl.nfull) BT_LAUNCH_CT(8, pl.nfull, 0, img, dotp);
-    if (pl.ctl) {
-        const unsigned char* li = img + pl.bytes_full;
-        const int lo = 128 * pl.nfull;
-        float* ld_ = dot ? dotp + pl.nfull * dot_block : nullptr;
+#define BT_LAUNCH_DOT(C, NCB, HOFF, IMG, DOTP)                                      \
+    do {                                                                            \
+        if (pl.KS == 1) BT_LAUNCH(1, C, true, 2, NCB, HOFF, IMG, DOTP);             \
+        else BT_LAUNCH(2, C, true, 2, NCB, HOFF, IMG, DOTP);                        \
+    } while (0)
+    const unsigned char* li = img + pl.bytes_full;
+    const int lo = 16 * pl.bw * pl.nfull;
+    if (!dot) {
+        if (pl.nfull) BT_LAUNCH_FWD(8, pl.nfull, 0, img);
         switch (pl.ctl) {
-            case 2: BT_LAUNCH_CT(2, 1, lo, li, ld_); break;
-            case 4: BT_LAUNCH_CT(4, 1, lo, li, ld_); break;
-            case 6: BT_LAUNCH_CT(6, 1, lo, li, ld_); break;
-            default: BT_LAUNCH_CT(8, 1, lo, li, ld_); break;
+            case 0: break;
+            case 2: BT_LAUNCH_FWD(2, 1, lo, li); break;
+            case 4: BT_LAUNCH_FWD(4, 1, lo, li); break;
+            case 6: BT_LAUNCH_FWD(6, 1, lo, li); break;
+            default: BT_LAUNCH_FWD(8, 1, lo, li); break;
+        }
+    } else {
+        float* ld_ = dotp + pl.nfull * dot_block;
+        if (pl.nfull) BT_LAUNCH_DOT(4, pl.nfull, 0, img, dotp);
+        switch (pl.ctl) {
+            case 0: break;
+            case 2: BT_LAUNCH_DOT(2, 1, lo, li, ld_); break;
+            default: BT_LAUNCH_DOT(4, 1, lo, li, ld_); break;
         }
     }
-#undef BT_LAUNCH_CT
+#undef BT_LAUNCH_DOT
+#undef BT_LAUNCH_FWD
 #undef BT_LAUNCH
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
@@ -454,7 +476,7 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
 
 extern "C" int dir_cin_bf16x3_dot_partials(int m, int Hp, int H) {
     if (m <= 0 || Hp <= 0 || H <= 0) return 0;
-    const Bf3Plan p = bf3_plan(m, Hp, H);
+    const Bf3Plan p = bf3_plan(m, Hp, H, true);
     return p.nkh * (p.nfull + (p.ctl ? 1 : 0));
 }
 
