@@ -759,8 +759,8 @@ def main():
         for h in Hs:      # two GEMMs of the forward's size per layer: dW (reduction over rows) and T = G x W (both data gradients)
             flops += 2 * 2 * B * D * hp * m * h
             hp = h
-        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_dw_k (fp32 MFMA) + cin_bf3_k<DOT> (data gradients, bf16x3), x3",
-                "note": "alg_flops = fp32-equivalent flops of the three GEMMs per layer; frac is against the fp32 MFMA peak (the data gradients run on the bf16 pipe)"}
+        roof = {"bound": "mfma", "alg_flops": flops, "kernel": "cin_dw_bf3_k (weight gradient; layer 1: cin_dw_k on fp32 MFMA) + cin_bf3_k<DOT> (data gradients), bf16x3, x3",
+                "note": "alg_flops = fp32-equivalent flops of the three GEMMs per layer; frac is against the fp32 MFMA peak (both gradient kernels run on the bf16 pipe)"}
         cfg.update({"m": m, "D": D, "layers": list(Hs)})
 
     # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------

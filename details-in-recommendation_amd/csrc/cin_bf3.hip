@@ -28,7 +28,7 @@
 // LDS reads into alternating registers -- no VALU instruction writes an MFMA source register close behind the MFMAs that read it
 // (the pattern that made a bf16x3 DIN unit irreproducible at two waves per SIMD); run-to-run bitwise equality is tested.
 //
-// The data-gradient form (template parameters RT = 1, DOT; dir_cin_layer_dot_bf16x3_f32) is described at the kernel.
+// The data-gradient form (template parameters DOT, FJ = 2, CT <= 4; dir_cin_layer_dot_bf16x3_f32) is described at the kernel.
 //
 // LDS: Wb [2][KS][3 planes][8 ct][64 lanes][8 bf16]  the chunk's W operand image, written by global_load_lds in the order
 //                                                    cin_bf3_pack_w_k lays the global image out (one ds_read_b128 per operand);
@@ -391,7 +391,7 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     return a > b ? a : b;
 }
 
-// Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: one row tile per wave, dot partials)
+// Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: 64-column blocks, two fields per chunk, dot partials)
 static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                    float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);

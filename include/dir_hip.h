@@ -219,9 +219,9 @@ int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H);
 int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                              int64_t B, float* xout, float* pooled, int64_t pooled_ld,
                              void* workspace, int64_t workspace_bytes, dir_stream_t stream);
-/* The same kernel with a second result per field, for the layer's data gradients (one row tile per wave; y's tile in registers):
+/* The same kernel with a second result per field, for the layer's data gradients (y's tile in registers; 64-column blocks):
  *   xout[b,h,d] as above, and  dot[b,j,d] = sum_h y[b,h,d] * T_j[(b,d),h],  T_j[r,h] = sum_i xk[r,i] * W[h, i*m+j]
- * written as dir_cin_bf16x3_dot_partials(m, Hp, H) partial sums [P][B, m, D] (one per column block and half of i; the caller adds
+ * written as dir_cin_bf16x3_dot_partials(m, Hp, H) partial sums [P][B, m, D] (one per 64-column block and half of i; the caller adds
  * them: a fixed order, no atomics).  Backward of xout = CIN(x0, xk_l, W) given G = dL/dxout: call with xk := G [B,H,D],
  * W := W1 [Hp_l, H*m] (W1[i, h*m+j] = W[h, i*m+j]), y := xk_l [B,Hp_l,D] -- then xout is dL/dxk_l and the partials add up to
  * dL/dx0.  Same shape limits and workspace as dir_cin_layer_bf16x3_f32. */
