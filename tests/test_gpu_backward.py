@@ -287,7 +287,9 @@ def test_deepfm_fused_adagrad_matches_torch_adagrad(built_lib):
                                          # tile counts that follow the widths (cin_bwd.hip): 3-tile column blocks (Hp 65..96, 193..224), slices
                                          # of 96 rows (H 65..96) and 128 + 32/64/96/128, h blocks of 1 / 2 / 3 tiles in dW
                                          (10, 26, 16, 70, 96), (10, 26, 16, 96, 70), (8, 8, 8, 200, 150), (8, 8, 8, 224, 190), (8, 8, 8, 100, 224),
-                                         (7, 26, 16, 160, 160), (7, 16, 4, 192, 225), (9, 12, 16, 40, 64), (9, 12, 16, 33, 33)])
+                                         (7, 26, 16, 160, 160), (7, 16, 4, 192, 225), (9, 12, 16, 40, 64), (9, 12, 16, 33, 33),
+                                         # one and two fields (a staged chunk of the bf16x3 data-gradient form holds two), row counts off the 256 grid
+                                         (40, 1, 16, 70, 33), (17, 2, 8, 64, 64), (300, 7, 16, 128, 65), (33, 3, 32, 65, 128)])
 def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
     from dir_amd import ops
     from oracle import oracle as O
