@@ -47,6 +47,30 @@ class T(np.ndarray):
     def name(self):
         return "T"
 
+    @property
+    def dtype(self):                      # Tensor.dtype.base_dtype (ESMM.py:73); NumPy itself reads the C field, not this property
+        return _DT(np.ndarray.dtype.__get__(self))
+
+
+class _DT:
+    """np.dtype with the one DType attribute the reference text reads (`base_dtype`); everything else is delegated."""
+
+    def __init__(self, dt):
+        self._dt = dt
+        self.base_dtype = dt
+
+    def __getattr__(self, item):
+        return getattr(self._dt, item)
+
+    def __eq__(self, other):
+        return self._dt == (other._dt if isinstance(other, _DT) else other)
+
+    def __hash__(self):
+        return hash(self._dt)
+
+    def __repr__(self):
+        return repr(self._dt)
+
 
 def _t(a):
     return np.asarray(a).view(T)
@@ -253,6 +277,14 @@ def _contrib_batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0
     return _bn_infer(inputs, mean, var, beta, gamma, epsilon)
 
 
+def _weights_and_check(features, weight_column, logits, **kw):
+    """[TF-upstream] head._get_weights_and_check_match_logits: 1.0 without a weight column, else the feature as float [B, 1]."""
+    if weight_column is None:
+        return 1.0
+    w = np.asarray(features[weight_column], dtype=DTYPE[0])
+    return _t(w.reshape(w.shape[0], -1))
+
+
 def _cond(pred, true_fn, false_fn, **kw):
     return true_fn() if bool(pred) else false_fn()
 
@@ -373,6 +405,7 @@ class CategoricalColumn:
 def _bag_lookup(table, feat, combiner):
     """[TF-upstream] safe_embedding_lookup_sparse: feat is ids [B] / [B,1] (one-hot) or (ids, offsets[, weights]) CSR per
     sample; id < 0 pruned, empty bag -> zeros, in-order sum, mean = /sum(w), sqrtn = /sqrt(sum(w^2))."""
+    table = np.asarray(table)
     dt = table.dtype
     if isinstance(feat, tuple):
         ids, offs = np.asarray(feat[0]), np.asarray(feat[1])
@@ -485,6 +518,13 @@ def install():
         "cast": (lambda x, dtype=None, name=None: bool(x) if dtype is bool else x, []),
         "to_float": (lambda x, name=None: _t(np.asarray(x, dtype=DTYPE[0])), []),
         "cond": (_cond, []),
+        "multiply": (lambda a, b, name=None: _t(np.asarray(a) * np.asarray(b)), ["tensorflow.python.ops.math_ops.multiply"]),
+        "add": (lambda a, b, name=None: _t(np.asarray(a) + np.asarray(b)), ["tensorflow.python.ops.math_ops.add"]),
+        "log": (lambda x, name=None: _t(np.log(np.asarray(x))), ["tensorflow.python.ops.math_ops.log"]),
+        "clip_by_value": (lambda t, lo, hi, name=None: _t(np.minimum(np.maximum(np.asarray(t), np.asarray(lo)), np.asarray(hi))),
+                          ["tensorflow.python.ops.clip_ops.clip_by_value"]),
+        "convert_to_tensor": (lambda v, dtype=None, name=None, **k: _t(np.asarray(v, dtype=dtype)),
+                              ["tensorflow.python.framework.ops.convert_to_tensor"]),
         "get_variable": (_get_variable, []),
         "variable_scope": (_VarScope, ["tensorflow.python.ops.variable_scope.variable_scope"]),
         "name_scope": (lambda *a, **k: contextlib.nullcontext(), []),
@@ -515,6 +555,7 @@ def install():
     _put("tensorflow.python.feature_column.feature_column._normalize_feature_columns", _normalize_feature_columns)
     _put("tensorflow.python.feature_column.feature_column._LazyBuilder", _LazyBuilder)
     _put("tensorflow.python.feature_column.feature_column._DenseColumn", _DenseColumn)
+    _put("tensorflow.python.estimator.canned.head._get_weights_and_check_match_logits", _weights_and_check)
     _put("tensorflow.python.framework.ops.add_to_collection", _add_to_collection)
     _put("tensorflow.python.framework.ops.get_collection", _get_collection)
     _put("tensorflow.python.ops.variable_scope.get_variable_scope",

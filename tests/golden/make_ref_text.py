@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """make_ref_text.py -- writes tests/golden/ref_text_v1.npz by EXECUTING THE REFERENCE'S OWN SOURCE TEXT
-(/root/reference/models/DeepFM/deepFM.py and models/DeepCrossNetwork/DeepCrossNetwork.py) under oracle/tf_stub.py, a NumPy
+(/root/reference/models/DeepFM/deepFM.py, models/DeepCrossNetwork/DeepCrossNetwork.py and models/ESMM/ESMM.py -> ref_text_v2_esmm.npz)
+under oracle/tf_stub.py, a NumPy
 stand-in for the tensorflow symbols those files touch.  Build container only: /root/reference does not exist on the GPU
 box and no reference file travels -- only the arrays written here do.
 
@@ -243,6 +244,83 @@ def dcn_cases(g, rng):
         g["dcn_loss_%s" % tag], g["dcn_unweighted_loss_%s" % tag] = np.asarray(wl), np.asarray(ul)
 
 
+def esmm_cases(g, rng):
+    """ESMM.py:62-175 -- _model_fn (PREDICT and EVAL), _base_model, _get_loss, with the reference text's own scopes:
+    two towers under esmm/ctr_model and esmm/cvr_model, each with its OWN input_layer variables."""
+    mod = S.load_reference(os.path.join(REF, "models/ESMM/ESMM.py"), "ref_esmm")
+    B = 48
+    embc = [("user", 40, 8, "mean"), ("item", 60, 8, "mean"), ("tags", 25, 4, "sqrtn")]
+    num_keys = ["price", "age"]
+    hidden = [24, 12]
+    cols = [S.EmbeddingColumn(k, v, dim, comb) for k, v, dim, comb in embc] + [S.NumericColumn(k) for k in num_keys]
+    feats = {k: rng.uniform(-1, 1, size=(B, 1)).astype(np.float32) for k in num_keys}
+    feats["user"] = rng.integers(-1, 40, size=(B, 1)).astype(np.int64)
+    feats["item"] = rng.integers(0, 60, size=(B, 1)).astype(np.int64)
+    lens = rng.integers(0, 4, size=B)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tag_w = rng.uniform(0.5, 2.0, size=offs[-1]).astype(np.float32)
+    feats["tags"] = (rng.integers(0, 25, size=offs[-1]).astype(np.int64), offs, tag_w)
+    feats["w_click"] = rng.uniform(0.5, 1.5, size=(B, 1)).astype(np.float32)
+    for k in num_keys + ["user", "item", "w_click"]:
+        g["esmm_feat:" + k] = feats[k]
+    g["esmm_feat:tags_values"], g["esmm_feat:tags_offsets"], g["esmm_feat:tags_weights"] = feats["tags"][0], offs, tag_w
+    d = sum(dim for _, _, dim, _ in embc) + len(num_keys)
+    weights = {}
+    for tower in ("ctr_model", "cvr_model"):
+        pre = "esmm/%s/" % tower
+        for k, v, dim, _ in embc:
+            weights[pre + "input_layer/%s_embedding/embedding_weights" % k] = (rng.standard_normal((v, dim)) / np.sqrt(dim)).astype(np.float32)
+        fi = d
+        for i, n in enumerate(hidden):
+            weights[pre + "hiddenlayer_%d/kernel" % i] = (rng.standard_normal((fi, n)) * np.sqrt(2.0 / (fi + n))).astype(np.float32)
+            weights[pre + "hiddenlayer_%d/bias" % i] = (rng.standard_normal(n) * 0.05).astype(np.float32)
+            fi = n
+        weights[pre + "dense/kernel"] = _glorot(rng, fi, 1)
+        weights[pre + "dense/bias"] = np.array([0.125 if tower == "ctr_model" else -0.25], np.float32)
+    for k, v in weights.items():
+        g["esmm_var:" + k] = v
+    g["esmm_hidden"] = np.array(hidden)
+    click = rng.integers(0, 2, size=B).astype(np.int64)
+    convert = (click * rng.integers(0, 2, size=B)).astype(np.int64)
+    g["esmm_click_label"], g["esmm_convert_label"] = click, convert
+    real_get_loss = mod._get_loss
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        params = S.HParams(feature_columns=cols, ctr_weight_column="w_click", ctcvr_weight_column=None, hidden_units=hidden,
+                           dnn_activation_fn=S._relu, dnn_dropout=None, optimizer=None)
+        S.reset(dt)
+        S.VARS.update(weights)
+        spec = mod._model_fn(feats, None, S._ModeKeys.PREDICT, params)
+        g["esmm_created"] = np.array(S.CREATED)
+        for k in ("probabilities", "logistic", "class_ids"):
+            g["esmm_%s_%s" % (k, tag)] = np.asarray(spec.predictions[k])
+        # EVAL: the same text goes on to _get_loss; its arguments and results are recorded as the text hands them over
+        seen = {}
+
+        def spy(features, labels, logits, params_):
+            out = real_get_loss(features, labels, logits, params_)
+            seen["logits"], seen["out"] = logits, out
+            return out
+        mod._get_loss = spy
+        try:
+            S.reset(dt)
+            S.VARS.update(weights)
+            labels = {"click_label": S._t(click.copy()), "convert_label": S._t(convert.copy())}
+            spec = mod._model_fn(feats, labels, S._ModeKeys.EVAL, params)
+        finally:
+            mod._get_loss = real_get_loss
+        g["esmm_loss_%s" % tag] = np.asarray(spec.loss)
+        g["esmm_ctr_logits_%s" % tag] = np.asarray(seen["logits"]["ctr_logits"])
+        g["esmm_ctcvr_logits_%s" % tag] = np.asarray(seen["logits"]["ctcvr_logits"])
+        g["esmm_weighted_loss_%s" % tag] = np.asarray(seen["out"][0])
+        g["esmm_unweighted_loss_%s" % tag] = np.asarray(seen["out"][1])
+        # one tower's input layer, through the reference's _base_model scopes
+        S.reset(dt)
+        S.VARS.update(weights)
+        with S._VarScope("esmm"), S._VarScope("cvr_model"):
+            g["esmm_cvr_inputs_%s" % tag] = np.asarray(S._input_layer(feats, cols))
+            g["esmm_cvr_logits_%s" % tag] = np.asarray(mod._base_model(feats, S._ModeKeys.PREDICT, params))
+
+
 def main():
     if not os.path.isdir(REF):
         print("make_ref_text: %s is absent (this generator runs in the build container only)" % REF)
@@ -254,6 +332,11 @@ def main():
     out = os.path.join(ROOT, "tests", "golden", "ref_text_v1.npz")
     np.savez_compressed(out, **g)
     print("wrote %s: %d arrays, %.1f KB" % (out, len(g), os.path.getsize(out) / 1024))
+    g2 = {}
+    esmm_cases(g2, np.random.default_rng(20241004))      # its own file and generator state: v1 stays byte-for-byte what it was
+    out = os.path.join(ROOT, "tests", "golden", "ref_text_v2_esmm.npz")
+    np.savez_compressed(out, **g2)
+    print("wrote %s: %d arrays, %.1f KB" % (out, len(g2), os.path.getsize(out) / 1024))
     return 0
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.test_ref_text import G, VARIANTS, _build_dcn, _build_deepfm, _close, dcn_vars, deepfm_csr, deepfm_vars
+from tests.test_ref_text import G, G2, VARIANTS, _build_dcn, _build_deepfm, _build_esmm, _close, dcn_vars, deepfm_csr, deepfm_vars, esmm_vars
 
 pytestmark = pytest.mark.gpu
 
@@ -115,3 +115,29 @@ def test_dcn_module_matches_reference_model_fn(built_lib):
         wl, ul = model.create_loss(feats, logits, _dev(G["dcn_labels"]))
         _close(wl.cpu().numpy(), G["dcn_loss_f64"])
         _close(ul.cpu().numpy(), G["dcn_unweighted_loss_f64"])
+
+
+def test_esmm_module_matches_reference_model_fn(built_lib):
+    """ESMM.forward / .predict / .get_loss == the reference's _model_fn (ESMM.py:62-175 executed under the stub, PREDICT and EVAL):
+    two towers with their own variables, name-sorted input_layer (bit-exact), ctcvr = sigmoid(ctr) * sigmoid(cvr) turned back into a
+    logit through clip(p, 1e-7, 1 - 1e-7), the predictions dict, and the CTR (weight column) + CTCVR MEAN-reduced losses."""
+    from dir_amd import feature_column as fc
+    from dir_amd.esmm import ESMM
+    model = _load(_build_esmm(fc, ESMM).cuda(), esmm_vars()).eval()
+    feats = {k: _dev(G2["esmm_feat:" + k]) for k in ("price", "age", "user", "item", "w_click")}
+    feats["tags"] = fc.Ragged(_dev(G2["esmm_feat:tags_values"]), _dev(G2["esmm_feat:tags_offsets"]), _dev(G2["esmm_feat:tags_weights"]))
+    with torch.no_grad():
+        np.testing.assert_array_equal(model.cvr_model.input_layer(feats).cpu().numpy(), G2["esmm_cvr_inputs_f32"])
+        out = model(feats)
+        _close(out["cvr_logits"].cpu().numpy(), G2["esmm_cvr_logits_f64"])
+        _close(out["ctr_logits"].cpu().numpy(), G2["esmm_ctr_logits_f64"])
+        _close(out["ctcvr_logits"].cpu().numpy(), G2["esmm_ctcvr_logits_f64"])
+        p = model.predict(feats)
+        _close(p["logistic"].cpu().numpy(), G2["esmm_logistic_f64"])
+        _close(p["probabilities"].cpu().numpy(), G2["esmm_probabilities_f64"])
+        np.testing.assert_array_equal(p["class_ids"].cpu().numpy(), G2["esmm_class_ids_f32"])
+        labels = {"click_label": _dev(G2["esmm_click_label"]), "convert_label": _dev(G2["esmm_convert_label"])}
+        wl, ul = model.get_loss(feats, labels, out)
+        _close(wl.cpu().numpy(), G2["esmm_loss_f64"])
+        _close(ul.cpu().numpy(), G2["esmm_unweighted_loss_f64"])
+

@@ -13,6 +13,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 G = np.load(os.path.join(HERE, "golden", "ref_text_v1.npz"))
+G2 = np.load(os.path.join(HERE, "golden", "ref_text_v2_esmm.npz"))        # models/ESMM/ESMM.py:62-175 under the same stub
 VARIANTS = ("onehot", "onehot_bn", "ragged")
 
 
@@ -51,9 +52,58 @@ def deepfm_csr(variant):
 
 
 def test_fp32_and_fp64_runs_of_the_reference_text_agree():
-    for k in G.files:
-        if k.endswith("_f32") and k[:-4] + "_f64" in G.files and G[k].dtype == np.float32:
-            _close(G[k], G[k[:-4] + "_f64"], 2e-6)
+    for g in (G, G2):
+        for k in g.files:
+            if k.endswith("_f32") and k[:-4] + "_f64" in g.files and g[k].dtype == np.float32:
+                _close(g[k], g[k[:-4] + "_f64"], 2e-6)
+
+
+def esmm_vars():
+    return {k[len("esmm_var:"):]: G2[k] for k in G2.files if k.startswith("esmm_var:")}
+
+
+def _build_esmm(fc, ESMM):
+    cols = [fc.embedding_column(fc.categorical_column_with_identity("user", 40, default_value=None), 8, "mean"),
+            fc.embedding_column(fc.categorical_column_with_identity("item", 60), 8, "mean"),
+            fc.embedding_column(fc.categorical_column_with_identity("tags", 25), 4, "sqrtn"),
+            fc.numeric_column("price"), fc.numeric_column("age")]
+    return ESMM(columns=cols, ctr_weight_column="w_click", ctcvr_weight_column=None, dnn_hidden_units=[int(h) for h in G2["esmm_hidden"]])
+
+
+def test_oracle_esmm_assembly_matches_reference_text(oracle):
+    """ESMM.py:62-175 executed under the stub vs the restatements: the tower input (name-sorted input_layer: the C oracle's bags),
+    the tower MLP, ctcvr = sigmoid(ctr) * sigmoid(cvr) -> logit(clip(p, 1e-7, 1 - 1e-7)), the two MEAN-reduced losses."""
+    V = esmm_vars()
+    B = G2["esmm_click_label"].shape[0]
+    pre = "esmm/cvr_model/"
+    # input_layer: item | price?? -- name-sorted: age, item, price, tags, user
+    item = oracle.embedding_bag([V[pre + "input_layer/item_embedding/embedding_weights"]], G2["esmm_feat:item"].reshape(B, 1))
+    user = oracle.embedding_bag([V[pre + "input_layer/user_embedding/embedding_weights"]], G2["esmm_feat:user"].reshape(B, 1))
+    tags = oracle.embedding_bag([V[pre + "input_layer/tags_embedding/embedding_weights"]], G2["esmm_feat:tags_values"],
+                                offsets=G2["esmm_feat:tags_offsets"], weights=G2["esmm_feat:tags_weights"], combiner=oracle.SQRTN)
+    x = np.concatenate([G2["esmm_feat:age"], item, G2["esmm_feat:price"], tags, user], axis=1).astype(np.float32)
+    np.testing.assert_array_equal(x, G2["esmm_cvr_inputs_f32"])
+
+    def tower(pre, x):
+        h = x.astype(np.float64)
+        for i in range(len(G2["esmm_hidden"])):
+            h = np.maximum(h @ V[pre + "hiddenlayer_%d/kernel" % i] + V[pre + "hiddenlayer_%d/bias" % i], 0)
+        return h @ V[pre + "dense/kernel"] + V[pre + "dense/bias"]
+    cvr = tower(pre, x)
+    _close(cvr, G2["esmm_cvr_logits_f64"], 1e-6)
+    sig = lambda z: 1 / (1 + np.exp(-z))
+    p = np.clip(sig(G2["esmm_ctr_logits_f64"]) * sig(cvr), 1e-7, 1 - 1e-7)
+    _close(p, G2["esmm_logistic_f64"], 1e-6)
+    ctcvr = np.log(p / (1 - p))
+    _close(ctcvr, G2["esmm_ctcvr_logits_f64"], 1e-6)
+    xent = lambda z, y: np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))
+    l_ctr = xent(G2["esmm_ctr_logits_f64"], G2["esmm_click_label"].reshape(B, 1))
+    l_ctcvr = xent(ctcvr, G2["esmm_convert_label"].reshape(B, 1))
+    _close(l_ctr + l_ctcvr, G2["esmm_unweighted_loss_f64"], 1e-6)
+    w = G2["esmm_feat:w_click"].astype(np.float64)
+    _close((l_ctr * w).sum() / w.sum() + l_ctcvr.mean(), G2["esmm_loss_f64"], 1e-6)
+    np.testing.assert_array_equal(G2["esmm_loss_f64"], G2["esmm_weighted_loss_f64"])
+    np.testing.assert_array_equal(G2["esmm_class_ids_f64"], (ctcvr > 0).astype(np.int64))
 
 
 def test_oracle_fm_matches_reference_text(oracle):
@@ -162,6 +212,12 @@ def test_checkpoint_names_are_the_names_the_reference_text_creates(built_lib):
     for v in VARIANTS:
         m = tf_variable_map(_build_deepfm(v, fc, DeepFM))
         assert set(m) == set(str(s) for s in G["deepfm_%s_created" % v])
+    from dir_amd.esmm import ESMM
+    me = tf_variable_map(_build_esmm(fc, ESMM))
+    assert set(me) == set(str(s) for s in G2["esmm_created"])                     # ESMM.py:62-66,135-146: each tower its own variables
+    for name, (p, lay) in me.items():
+        ref = G2["esmm_var:" + name]
+        assert tuple(p.shape) == (tuple(ref.T.shape) if lay == "T" else tuple(ref.shape)), name
     m = tf_variable_map(_build_dcn(fc, DeepCrossNetwork))
     assert set(m) == set(str(s) for s in G["dcn_created"])
     for name, (p, lay) in m.items():      # and the layouts
@@ -184,3 +240,8 @@ def test_committed_fixture_is_what_the_reference_text_produces(tmp_path, monkeyp
     assert set(g) == set(G.files)
     for k, v in g.items():
         np.testing.assert_array_equal(np.asarray(v), G[k], err_msg=k)
+    g2 = {}
+    mod.esmm_cases(g2, np.random.default_rng(20241004))
+    assert set(g2) == set(G2.files)
+    for k, v in g2.items():
+        np.testing.assert_array_equal(np.asarray(v), G2[k], err_msg=k)
