@@ -1,0 +1,129 @@
+// head_bwd.hip -- backward of the units = 1 logit layer taken straight through the ReLU of the hidden layer below it.
+//
+// Reference: the logits layer of dnn_logit_fn (models/DeepFM/deepFM.py:311-317) and of ESMM's _base_model (models/ESMM/ESMM.py:146) on
+// top of a ReLU hidden layer (deepFM.py:293-300, ESMM.py:137-142); the reference trains through TensorFlow autodiff of those lines.
+// With logit[b] = sum_n y[b,n] * w[n] + bias and y = relu(pre):
+//   dpre[b,n] = (y[b,n] > 0) ? g[b] * w[n] : 0        g = dL/dlogit [B]
+//   dw[n]     = sum_b g[b] * y[b,n]
+//   dbias_y[n]= sum_b dpre[b,n]                       (the bias gradient of the hidden layer)
+// As torch ops this is five passes over [B, N] (outer product, g*y, compare, mask multiply, two column sums: 189 us at 65 536 x 400);
+// here y is read once and dpre written once.  HBM-bound: 8 bytes per element.
+//
+// A workgroup owns a span of rows; thread (rr, c) walks rows rr, rr + RPI, ... of the span for the float4 column chunks c, c + TPR, ...
+// and keeps both column sums in registers (rows in ascending order); the RPI row lanes are added in lane order through LDS and the
+// workgroup writes one partial row pair part[block][2][N].  The caller adds the partials (a fixed order: bitwise reproducible).
+#include "common.hpp"
+
+namespace dir {
+
+constexpr int HB_MAXCH = 4;          // float4 column chunks per thread: N <= 4 * 4 * 256
+
+template <int TPR>
+__global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ y,
+                                                   int64_t y_ld, int64_t B, int N, int64_t rows_per_block, float* __restrict__ gx,
+                                                   int64_t gx_ld, float* __restrict__ part) {
+    constexpr int RPI = 256 / TPR;
+    __shared__ float4 red[2][256];
+    const int tid = threadIdx.x, c0 = tid % TPR, rr = tid / TPR;
+    const int nv = N >> 2;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(B, r0 + rows_per_block);
+    float4 wv[HB_MAXCH], sx[HB_MAXCH], sw[HB_MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < HB_MAXCH; ++ch) {
+        const int c = c0 + ch * TPR;
+        wv[ch] = c < nv ? *reinterpret_cast<const float4*>(w + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sx[ch] = sw[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t r = r0 + rr; r < r1; r += RPI) {
+        const float gr = g[r];
+#pragma unroll
+        for (int ch = 0; ch < HB_MAXCH; ++ch) {
+            const int c = c0 + ch * TPR;
+            if (c < nv) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + r * y_ld + 4 * c);
+                float4 v;
+                v.x = yv.x > 0.f ? gr * wv[ch].x : 0.f;
+                v.y = yv.y > 0.f ? gr * wv[ch].y : 0.f;
+                v.z = yv.z > 0.f ? gr * wv[ch].z : 0.f;
+                v.w = yv.w > 0.f ? gr * wv[ch].w : 0.f;
+                *reinterpret_cast<float4*>(gx + r * gx_ld + 4 * c) = v;
+                sx[ch].x += v.x; sx[ch].y += v.y; sx[ch].z += v.z; sx[ch].w += v.w;
+                sw[ch].x += gr * yv.x; sw[ch].y += gr * yv.y; sw[ch].z += gr * yv.z; sw[ch].w += gr * yv.w;
+            }
+        }
+    }
+    float* p0 = part + (int64_t)blockIdx.x * 2 * N;
+#pragma unroll
+    for (int ch = 0; ch < HB_MAXCH; ++ch) {
+        const int c = c0 + ch * TPR;
+        if (ch * TPR < nv) {                        // uniform: the chunk exists for some thread
+            red[0][tid] = sx[ch];
+            red[1][tid] = sw[ch];
+            __syncthreads();
+            if (rr == 0 && c < nv) {
+                float4 a = red[0][c0], b = red[1][c0];
+#pragma unroll
+                for (int q = 1; q < RPI; ++q) {
+                    const float4 u = red[0][q * TPR + c0], v = red[1][q * TPR + c0];
+                    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+                }
+                *reinterpret_cast<float4*>(p0 + 4 * c) = a;
+                *reinterpret_cast<float4*>(p0 + N + 4 * c) = b;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct HbPlan { int tpr; int64_t nblk, rows_per_block; };
+static HbPlan hb_plan(int64_t B, int N) {
+    HbPlan p;
+    const int nv = N / 4;
+    p.tpr = nv <= 64 ? 64 : (nv <= 128 ? 128 : 256);
+    const int rpi = 256 / p.tpr;
+    int64_t nblk = (B + rpi * 16 - 1) / (rpi * 16);          // >= 16 rows per row lane
+    if (nblk > 4 * kCUs) nblk = 4 * kCUs;
+    if (nblk < 1) nblk = 1;
+    int64_t rpb = (B + nblk - 1) / nblk;
+    rpb = (rpb + rpi - 1) / rpi * rpi;
+    p.rows_per_block = rpb > 0 ? rpb : rpi;
+    p.nblk = B > 0 ? (B + p.rows_per_block - 1) / p.rows_per_block : 0;
+    return p;
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int64_t dir_units1_relu_backward_partials(int64_t B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return hb_plan(B, N).nblk;
+}
+
+extern "C" int dir_units1_relu_backward_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx,
+                                            int64_t gx_ld, float* partials, int64_t n_partials, dir_stream_t stream) {
+    const char* name = "dir_units1_relu_backward_f32";
+    DIR_CHECK_ARG(B >= 0 && N > 0, "%s: B=%lld N=%d", name, (long long)B, N);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(g && w && y && gx && partials, "%s: null pointer", name);
+    if (N % 4 || y_ld % 4 || gx_ld % 4 || N > 4 * HB_MAXCH * 256)
+        return fail(DIR_E_UNSUPPORTED, "%s: N=%d y_ld=%lld gx_ld=%lld (multiples of 4, N <= %d)", name, N, (long long)y_ld, (long long)gx_ld,
+                    4 * HB_MAXCH * 256);
+    DIR_CHECK_ARG(y_ld >= N && gx_ld >= N, "%s: row strides smaller than N", name);
+    if (!(aligned16(w) && aligned16(y) && aligned16(gx) && aligned16(partials)))
+        return fail(DIR_E_BADARG, "%s: w / y / gx / partials must be 16-byte aligned", name);
+    const HbPlan p = hb_plan(B, N);
+    DIR_CHECK_ARG(n_partials >= p.nblk, "%s: partials holds %lld row pairs, dir_units1_relu_backward_partials(B, N) = %lld", name,
+                  (long long)n_partials, (long long)p.nblk);
+    hipStream_t st = as_stream(stream);
+    if (p.tpr == 64)
+        hipLaunchKernelGGL(head_bwd_k<64>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials);
+    else if (p.tpr == 128)
+        hipLaunchKernelGGL(head_bwd_k<128>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials);
+    else
+        hipLaunchKernelGGL(head_bwd_k<256>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}

@@ -16,7 +16,7 @@ import math
 import torch
 from torch import nn
 
-from .dense import dense_act, mlp_stack, mlp_stack_supported, units1
+from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack_supported, units1
 from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of, raise_pending
@@ -152,6 +152,8 @@ class DeepFM(nn.Module):
 
     def dnn_logit_fn(self, net):
         if not len(self.bns) and not self.hparams.get("dnn_dropout") and mlp_stack_supported(self.hidden, net, self.activation):
+            if self.units == 1 and mlp_head_supported(self.hidden, self.logits_layer, net, self.activation):
+                return mlp_head(self.hidden, self.logits_layer, net)                    # training: tower + logit layer as one autograd node
             return self._logits_of(mlp_stack(self.hidden, net))                         # training: the whole tower as one autograd node
         for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
             if len(self.bns) and not _train_mode(self):                        # inference: no dropout, BN folded into the layer's epilogue

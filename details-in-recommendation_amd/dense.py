@@ -142,6 +142,65 @@ class _MlpStackFn(torch.autograd.Function):
         return (gx,) + tuple(grads)
 
 
+MLP_HEAD = _os.environ.get("DIR_MLP_HEAD", "1") != "0"        # development switch: 0 keeps the two-node formulation (mlp_stack + units1)
+
+
+class _MlpHeadFn(torch.autograd.Function):
+    """A stack of dense + ReLU layers AND the units = 1 logit layer on top of it (deepFM.py:284-317, ESMM.py:130-147) as one autograd
+    node.  Forward: dir_dense_f32 per layer, the head as a library GEMV.  Backward: the head's three gradients and the ReLU gate of the
+    top hidden layer in ONE pass over its output (dir_units1_relu_backward_f32: dL/dpre_top, dL/dw_head and the top layer's bias
+    gradient; as separate torch ops: an outer product, g * y, a compare, a mask multiply and two column sums), then _MlpStackFn's
+    loop."""
+
+    @staticmethod
+    def forward(ctx, x, head_w, head_b, *params):
+        L = len(params) // 2
+        ys, h = [], x
+        for l in range(L):
+            h = ops.dense(h, pack_weight(params[2 * l]), params[2 * l + 1], relu=True)
+            ys.append(h)
+        ctx.L = L
+        ctx.save_for_backward(x, head_w, *params[0::2], *ys)
+        return torch.addmv(head_b, h, head_w.reshape(-1)).unsqueeze(1)
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        x, head_w, ws, ys = saved[0], saved[1], saved[2:2 + L], saved[2 + L:]
+        g_head_b = g.reshape(-1).sum(dim=0, keepdim=True) if ctx.needs_input_grad[2] else None
+        g, gw_head, gb_top = ops.units1_relu_backward(g, head_w, ys[-1])
+        grads = [None] * (2 * L)
+        gx = None
+        for l in range(L - 1, -1, -1):
+            xin = ys[l - 1] if l > 0 else x
+            if ctx.needs_input_grad[3 + 2 * l]:
+                grads[2 * l] = _tn_matmul(g, xin)
+            if ctx.needs_input_grad[4 + 2 * l]:
+                grads[2 * l + 1] = gb_top if l == L - 1 else g.sum(dim=0)
+            wt = pack_weight(ws[l].t())
+            if l > 0:
+                g = ops.dense_gated(g, wt, xin)
+            elif ctx.needs_input_grad[0]:
+                gx = ops.dense(g, wt, None, relu=False)
+        return (gx, gw_head.reshape(1, -1) if ctx.needs_input_grad[1] else None, g_head_b) + tuple(grads)
+
+
+def mlp_head_supported(lins, head, x, activation):
+    """mlp_stack_supported and a units = 1 head with a bias on top (the fused head backward reads the top layer's output once)."""
+    return (MLP_HEAD and mlp_stack_supported(lins, x, activation) and head.out_features == 1 and head.bias is not None
+            and head.in_features == lins[-1].out_features and head.in_features <= 4096)
+
+
+def mlp_head(lins, head, x):
+    """head(relu(lin_L(... relu(lin_1(x))))) -> [B, 1] through _MlpHeadFn (check mlp_head_supported first)."""
+    params = []
+    for lin in lins:
+        params += [lin.weight, lin.bias]
+    return _MlpHeadFn.apply(x, head.weight, head.bias, *params)
+
+
 def mlp_stack_supported(lins, x, activation):
     """A run of nn.Linear layers + ReLU the stack node covers: every layer on the kernel, biases present, and the data gradient
     of the first layer expressible as a dense product too (its in_features a multiple of 4 and >= 16)."""

@@ -482,6 +482,38 @@ def dense_gated(x, weight, gate, out=None, arith=None):
     return out
 
 
+def units1_relu_backward_supported(y):
+    """Shapes dir_units1_relu_backward_f32 takes: a float32 CUDA [B, N] activation with N and its row stride multiples of 4, N <= 4096."""
+    return (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1 and y.shape[1] % 4 == 0 and y.shape[1] <= 4096
+            and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)
+
+
+def units1_relu_backward(g, w, y):
+    """Backward of logit = y . w + bias (units = 1; deepFM.py:311-317, ESMM.py:146) through y = relu(pre) in one pass
+    (include/dir_hip.h: dir_units1_relu_backward_f32).  g [B] or [B, 1] = dL/dlogit, w [N] or [1, N], y [B, N] ->
+    (dpre [B, N] = where(y > 0, g * w, 0), dw [N] = sum_b g * y, dbias_y [N] = sum_b dpre)."""
+    _dev(g, torch.float32, "g")
+    _dev(w, torch.float32, "w")
+    _dev(y, torch.float32, "y")
+    B, N = y.shape
+    if g.numel() != B or w.numel() != N:
+        raise ValueError("units1_relu_backward: g [B], w [N], y [B, N]")
+    if not units1_relu_backward_supported(y):
+        raise ValueError("units1_relu_backward: y must be float32 [B, N] with N and its row stride multiples of 4 (N <= 4096), 16-byte aligned")
+    g = g.reshape(B).contiguous()
+    w = w.reshape(N).contiguous()
+    lib = _lib.load()
+    gx = torch.empty((B, N), dtype=torch.float32, device=y.device)
+    P = int(lib.dir_units1_relu_backward_partials(B, N))
+    if P == 0:
+        z = torch.zeros(N, dtype=torch.float32, device=y.device)
+        return gx, z, z.clone()
+    part = torch.empty((P, 2, N), dtype=torch.float32, device=y.device)
+    _lib.check(lib.dir_units1_relu_backward_f32(_ptr(g), _ptr(w), _ptr(y), y.stride(0), B, N, _ptr(gx), gx.stride(0), _ptr(part), P, _stream()))
+    s = part[0] if P == 1 else part.sum(dim=0)
+    return gx, s[1], s[0]
+
+
 def din_backward_supported(K, T, H1, H2):
     """Shapes the fused DIN backward covers (include/dir_hip.h: dir_din_attention_pool_backward_f32)."""
     return K == 64 and T <= 64 and H1 <= 80 and H2 <= 48 and H1 % 4 == 0 and H2 % 4 == 0

@@ -350,6 +350,17 @@ int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const 
  * ([in_l, units_l] rows), gate = layer l-1's output [M, N = in_l]; the result is dL/d(pre-activation of layer l-1). */
 int dir_dense_gated_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* gate, int64_t gate_ld, int64_t M,
                         int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
+/* Backward of the units = 1 logit layer (models/DeepFM/deepFM.py:311-317, models/ESMM/ESMM.py:146) taken straight through the ReLU
+ * of the hidden layer below it, in one pass (csrc/head_bwd.hip).  g = dL/dlogit [B], w = the logit layer's weight [N], y = the hidden
+ * layer's output [B, N] (row stride y_ld):
+ *   gx[b,n] = (y[b,n] > 0) ? g[b] * w[n] : 0          dL/d(pre-activation of the hidden layer), row stride gx_ld
+ *   partials[p][0][n] = this block's share of sum_b gx[b,n]        (the hidden layer's bias gradient)
+ *   partials[p][1][n] = this block's share of sum_b g[b] * y[b,n]  (the logit layer's weight gradient)
+ * for p < dir_units1_relu_backward_partials(B, N); the caller adds the row pairs (fixed order: bitwise reproducible, no atomics).
+ * Limits: N, y_ld, gx_ld multiples of 4, N <= 4096, w / y / gx / partials 16-byte aligned (DIR_E_UNSUPPORTED / DIR_E_BADARG). */
+int64_t dir_units1_relu_backward_partials(int64_t B, int N);
+int dir_units1_relu_backward_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx, int64_t gx_ld,
+                                 float* partials, int64_t n_partials, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Backward of the HBM-bound interaction ops: derivatives of the same reference

@@ -825,6 +825,76 @@ def test_mlp_stack_matches_float64(built_lib, dims, M):
         assert not D.mlp_stack_supported(lins, x, torch.relu)
 
 
+@pytest.mark.parametrize("B,N,pad", [(300, 400, 0), (1, 16, 0), (65, 64, 4), (1000, 1024, 0), (777, 520, 8), (4096, 4096, 0), (33, 132, 0)])
+def test_units1_relu_backward_kernel(built_lib, B, N, pad):
+    """dir_units1_relu_backward_f32 (the logit layer's backward through the ReLU below it, one pass) against float64, strided
+    activations, bitwise reproducible; refusals."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(B + N)
+    ybuf = torch.relu(torch.randn(B, N + pad, generator=g)).cuda()
+    y = ybuf[:, :N]
+    dl = torch.randn(B, 1, generator=g).cuda()
+    w = (torch.randn(1, N, generator=g) / N ** 0.5).cuda()
+    gx, gw, gb = ops.units1_relu_backward(dl, w, y)
+    y64, dl64, w64 = y.double().cpu(), dl.double().cpu(), w.double().cpu()
+    rx = torch.where(y64 > 0, dl64 * w64, torch.zeros((), dtype=torch.float64))
+    assert torch.equal(gx.cpu(), torch.where(y.cpu() > 0, dl.cpu() * w.cpu(), torch.zeros(())))      # one fp32 product per element: exact
+    _close(gw, (dl64 * y64).sum(0), tol=1e-5 * (1 + B ** 0.5 * 0.05))
+    _close(gb, rx.sum(0), tol=1e-5 * (1 + B ** 0.5 * 0.05))
+    gx2, gw2, gb2 = ops.units1_relu_backward(dl.reshape(B), w.reshape(N), y)
+    assert torch.equal(gx2, gx) and torch.equal(gw2, gw) and torch.equal(gb2, gb)
+    with pytest.raises(ValueError):
+        ops.units1_relu_backward(dl, w[:, :N - 1], y)
+    if N >= 8:
+        with pytest.raises(ValueError):
+            ops.units1_relu_backward(dl, w[:, :N - 2], y[:, :N - 2])          # N % 4 != 0
+
+
+@pytest.mark.parametrize("dims,M", [([416, 400, 400, 400], 300), ([64, 80, 16], 300), ([416, 400, 400], 12288)])
+def test_mlp_head_matches_float64(built_lib, dims, M):
+    """dense._MlpHeadFn (the tower and its units = 1 logit layer as one node: dir_units1_relu_backward_f32 + the stack's gated data
+    gradients) against float64 autograd, and against the two-node formulation (mlp_stack + units1)."""
+    from dir_amd import dense as D
+    g = torch.Generator().manual_seed(sum(dims) + 1)
+    torch.manual_seed(sum(dims) + M + 1)
+    lins = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]).cuda()
+    head = torch.nn.Linear(dims[-1], 1).cuda()
+    xraw = torch.randn(M + M // 4 + 8, dims[0], generator=g)
+    with torch.no_grad():                        # rows with a pre-activation within 2e-5 of zero are left out (see test_mlp_stack_matches_float64)
+        h, keep = xraw.double(), torch.ones(xraw.shape[0], dtype=torch.bool)
+        for l in lins:
+            z = h @ l.weight.detach().double().cpu().t() + l.bias.detach().double().cpu()
+            keep &= z.abs().min(dim=1).values > 2e-5
+            h = torch.relu(z)
+    x = xraw[keep][:M].contiguous().cuda().requires_grad_(True)
+    gout = torch.randn(M, 1, generator=g).cuda()
+    assert D.mlp_head_supported(lins, head, x, torch.relu)
+    y = D.mlp_head(lins, head, x)
+    y.backward(gout)
+    got = [x.grad.clone(), head.weight.grad.clone(), head.bias.grad.clone()] + [p.grad.clone() for l in lins for p in (l.weight, l.bias)]
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    p64 = [(l.weight.detach().double().cpu().requires_grad_(True), l.bias.detach().double().cpu().requires_grad_(True)) for l in lins]
+    hw, hb = head.weight.detach().double().cpu().requires_grad_(True), head.bias.detach().double().cpu().requires_grad_(True)
+    h = x64
+    for w, b in p64:
+        h = torch.relu(h @ w.t() + b)
+    out = h @ hw.t() + hb
+    out.backward(gout.double().cpu())
+    _close(y, out, tol=1e-5)
+    ref = [x64.grad, hw.grad, hb.grad] + [t.grad for wb in p64 for t in wb]
+    for a, r in zip(got, ref):
+        assert float((a.double().cpu() - r).abs().max()) <= 2e-5 * (1 + float(r.abs().max()))
+    # the two-node formulation computes the same thing with torch ops for the head
+    for p in [x, head.weight, head.bias] + [q for l in lins for q in (l.weight, l.bias)]:
+        p.grad = None
+    y2 = D.units1(head, D.mlp_stack(lins, x))
+    y2.backward(gout)
+    _close(y2, y, tol=1e-6)
+    two = [x.grad, head.weight.grad, head.bias.grad] + [p.grad for l in lins for p in (l.weight, l.bias)]
+    for a, r in zip(got, two):
+        assert float((a - r).abs().max()) <= 2e-5 * (1 + float(r.abs().max()))
+
+
 def test_dense_act_pads_odd_input_width(built_lib):
     """dense.dense_act with in_features % 4 != 0 (DCN's 429-wide first layer): zero-padded onto the HIP kernel, forward and
     gradients equal to nn.Linear + ReLU in float64."""
