@@ -424,7 +424,7 @@ def main():
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "nnz": nnz, "bag_len": "U{0..8}", "combiner": "mean", "weights": True})
     elif wl == "deepfm_train":
         # one whole DeepFM training step with the reference's optimisers (deepFM.py:58,61): forward (gather+FM kernel,
-        # linear term, 400-400-400 MLP on rocBLAS), BCE loss, backward (HIP FM backward, sparse row gradients), fused sorted
+        # linear term, 400-400-400 MLP on the dense kernels), BCE loss, backward (HIP FM backward, head + gated data gradients, sparse row gradients), fused sorted
         # sparse Adagrad on the 26 embedding tables and fused sparse FTRL on the 26 linear columns inside backward(), torch Adagrad on the MLP
         from dir_amd.deepfm import DeepFM
         from dir_amd import feature_column as fc

@@ -147,7 +147,7 @@ MLP_HEAD = _os.environ.get("DIR_MLP_HEAD", "1") != "0"        # development swit
 
 class _MlpHeadFn(torch.autograd.Function):
     """A stack of dense + ReLU layers AND the units = 1 logit layer on top of it (deepFM.py:284-317, ESMM.py:130-147) as one autograd
-    node.  Forward: dir_dense_f32 per layer, the head as a library GEMV.  Backward: the head's three gradients and the ReLU gate of the
+    node.  Forward: dir_dense_f32 per layer, the head as a library GEMM with one output column.  Backward: the head's three gradients and the ReLU gate of the
     top hidden layer in ONE pass over its output (dir_units1_relu_backward_f32: dL/dpre_top, dL/dw_head and the top layer's bias
     gradient; as separate torch ops: an outer product, g * y, a compare, a mask multiply and two column sums), then _MlpStackFn's
     loop."""
@@ -161,7 +161,7 @@ class _MlpHeadFn(torch.autograd.Function):
             ys.append(h)
         ctx.L = L
         ctx.save_for_backward(x, head_w, *params[0::2], *ys)
-        return torch.addmv(head_b, h, head_w.reshape(-1)).unsqueeze(1)
+        return h @ head_w.t() + head_b              # (a [B, N] x [N, 1] GEMM: 26 us at 65 536 x 400; the library's GEMV takes 62)
 
     @staticmethod
     @torch.no_grad()
