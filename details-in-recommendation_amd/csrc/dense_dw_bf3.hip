@@ -1,0 +1,266 @@
+// dense_dw_bf3.hip -- weight gradient of a dense layer, dW[n, k] = sum_r g[r, n] * x[r, k], on the bf16 matrix pipe with fp32-equivalent
+// arithmetic ("bf16 x 3": dense_bf3.hip, cin_dw_bf3.hip).
+//
+// Reference: the hidden layers of dnn_logit_fn (models/DeepFM/deepFM.py:293-300), _deep_architecture
+// (models/DeepCrossNetwork/DeepCrossNetwork.py:394-399) and _base_model (models/ESMM/ESMM.py:137-142); the reference trains through
+// TensorFlow autodiff of tf.layers.dense, whose kernel gradient is this product (g = dL/d(pre-activation) [M, N], x = the layer's
+// input [M, K], M = batch rows).
+//
+// The REDUCTION runs over the batch rows, the slow index of both operands -- the opposite of what the MFMA operand layout wants (a
+// lane's 8 k-slots would be 8 consecutive rows of one column).  So both operands go through a transposing stage: per step of 32 rows
+// a thread loads "octets" -- 8 consecutive rows of ONE column (8 scalar loads; consecutive threads take consecutive columns, so a wave's
+// load is a contiguous 256-byte row segment) --, splits each into its three bf16 pieces in registers (52 VALU instructions) and writes
+// three 16-byte operand fragments into LDS in the operand layout [piece][tile][lane][8] (conflict-free ds_write_b128).  After a barrier
+// every wave reads its A fragments (two 16-column tiles of g: the wave's 32 output rows) once and the B fragments of the block's x
+// tiles one tile ahead of their 12 MFMAs.  One LDS buffer, two barriers per step: the split phase and the MFMA phase of the two waves
+// of a SIMD do not overlap anyway (cin_dw_bf3.hip); the raw loads of step s+1 are issued before step s's MFMAs and land
+// under them.
+//
+// Work split.  A work item is (block of 256 columns of g = 16 tiles, block of KB tiles of x, span of rows); workgroup of 8 waves (two
+// per SIMD): wave w owns g tiles w and w+8 (32 output rows) x the KB x tiles = 2*KB accumulators.  KB = 13 / 16 / 8, whichever pads K
+// least.  Every element is split once per workgroup that uses it: about 1.2 VALU instructions per MFMA at 400 x 416.  Spans leave
+// partial sums part[span][N][K]; dense_dw_bf3_reduce_k adds them in span order (bitwise reproducible, no atomics).
+#include "common.hpp"
+
+namespace dir {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int DDW_NT = 16;           // g tiles per block (two per wave)
+
+__device__ __forceinline__ unsigned int ddw_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
+    typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
+    const pk2_t v = {(__bf16)a, (__bf16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));      // (empty: hides w's origin so that float(bf16(a)) is formed by a shift, not a second convert; see cin_bf3.hip)
+    return w;
+}
+__device__ __forceinline__ void ddw_split8(const float (&x)[8], bf16x8_t (&p)[3]) {     // 8 values -> three bf16x8 fragments that sum to them
+    unsigned int w[3][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = {x[2 * i], x[2 * i + 1]};
+        w[0][i] = ddw_pk(v[0], v[1]);
+        const f32x2 r = v - (f32x2){__builtin_bit_cast(float, w[0][i] << 16), __builtin_bit_cast(float, w[0][i] & 0xffff0000u)};
+        w[1][i] = ddw_pk(r[0], r[1]);
+        const f32x2 t = r - (f32x2){__builtin_bit_cast(float, w[1][i] << 16), __builtin_bit_cast(float, w[1][i] & 0xffff0000u)};
+        w[2][i] = ddw_pk(t[0], t[1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
+}
+
+__host__ __device__ inline int ddw_kb_for(int K) {     // x tiles per block: the choice that pads K least (ties: the wider block)
+    const int tiles = (K + 15) / 16;
+    int best = 16, pad = (tiles + 15) / 16 * 16;
+    const int p13 = (tiles + 12) / 13 * 13, p8 = (tiles + 7) / 8 * 8;
+    if (p13 < pad) { best = 13; pad = p13; }
+    if (p8 < pad) { best = 8; pad = p8; }
+    return best;
+}
+
+struct DdwPlan { int KB, nnb, nkb, nspan; int64_t steps, steps_per_span; };
+static DdwPlan ddw_plan(int64_t M, int N, int K) {
+    DdwPlan p;
+    p.KB = ddw_kb_for(K);
+    p.nnb = (N + 16 * DDW_NT - 1) / (16 * DDW_NT);
+    p.nkb = ((K + 15) / 16 + p.KB - 1) / p.KB;
+    p.steps = (M + 31) / 32;
+    int ns = kCUs / (p.nnb * p.nkb);
+    if (ns < 1) ns = 1;
+    if ((int64_t)ns > p.steps) ns = (int)(p.steps > 0 ? p.steps : 1);
+    p.nspan = ns;
+    p.steps_per_span = (p.steps + ns - 1) / ns;
+    return p;
+}
+
+template <int KB>
+__global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ x, int64_t x_ld,
+                                                          int64_t M, int N, int K, int nkb, int nspan, int64_t steps_per_span, int64_t steps,
+                                                          float* __restrict__ part) {
+    constexpr int TT = DDW_NT + KB;                   // tiles staged per step: 16 of g, KB of x
+    extern __shared__ __attribute__((aligned(16))) unsigned char ddw_smem[];      // [3 pieces][TT tiles][64 lanes][8 bf16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, ln = lane & 15;
+    int q = blockIdx.x;
+    const int span = q % nspan; q /= nspan;
+    const int kb = q % nkb;
+    const int nb = q / nkb;
+    const int n0 = 16 * DDW_NT * nb, k0 = 16 * KB * kb;
+    const int ntg = min(DDW_NT, (N - n0 + 15) / 16), ktx = min(KB, (K - k0 + 15) / 16);
+    const int64_t s_begin = (int64_t)span * steps_per_span;
+    int64_t s_end = s_begin + steps_per_span;
+    if (s_end > steps) s_end = steps;
+
+    // this thread's octets: column c = tid & 255 of the g strip (256 columns) and, for c < 16 KB, of the x strip; row octets ro and
+    // ro + 2 with ro = tid >> 8 -- uniform over a wave, so a row's base address is a scalar and the 32 loads of a step share two
+    // per-lane column offsets.  Consecutive threads read consecutive columns; an octet's fragment goes to tile (c / 16),
+    // lane (c % 16) + 16 * octet.  Columns past N / K read column 0 instead: they only feed outputs that are never stored.
+    constexpr int XC = 16 * KB;
+    const int c = tid & 255;
+    const int ro = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const bool xth = c < XC;
+    const int goff = (n0 + c < N) ? n0 + c : 0;
+    const int xoff = (xth && k0 + c < K) ? k0 + c : 0;
+    const int gdst = ((c >> 4) * 64 + (c & 15) + 16 * ro) * 16;                      // second octet: + 32 lanes = + 512 bytes
+    const int xdst = ((DDW_NT + (c >> 4)) * 64 + (c & 15) + 16 * ro) * 16;
+    float raw[4][8];                                                                  // g octets ro, ro + 2; x octets ro, ro + 2
+    auto load_octet = [&](const float* base, int64_t ld, int off, int64_t r0, float (&v)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t r = r0 + e;                                                // scalar
+            v[e] = r < M ? (base + r * ld)[off] : 0.f;
+        }
+    };
+    auto load_raw = [&](int64_t s) {
+        float (&rw)[4][8] = raw;
+        load_octet(g, g_ld, goff, 32 * s + 8 * ro, rw[0]);
+        load_octet(g, g_ld, goff, 32 * s + 8 * ro + 16, rw[1]);
+        if (xth) {
+            load_octet(x, x_ld, xoff, 32 * s + 8 * ro, rw[2]);
+            load_octet(x, x_ld, xoff, 32 * s + 8 * ro + 16, rw[3]);
+        }
+    };
+    auto put = [&](const float (&v)[8], int off) {
+        bf16x8_t p[3];
+        ddw_split8(v, p);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(ddw_smem + pc * (TT * 1024) + off) = p[pc];
+    };
+
+    f32x4 acc[2][KB];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < KB; ++kt) acc[rt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool has0 = wave < ntg, has1 = wave + 8 < ntg;
+
+    // one step: split the raw octets into LDS, barrier, refill the same registers with step s + 1 (the loads land under the MFMAs;
+    // two steps of loads in flight, in a second register set, measured slower: 227 against 200 us at 65 536 x 400 x 416), MFMAs, barrier
+    if (s_begin < s_end) load_raw(s_begin);
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        put(raw[0], gdst);
+        put(raw[1], gdst + 512);
+        if (xth) {
+            put(raw[2], xdst);
+            put(raw[3], xdst + 512);
+        }
+        __syncthreads();
+        if (s + 1 < s_end) load_raw(s + 1);
+        if (has0) {
+            const unsigned char* fl = ddw_smem + lane * 16;
+            bf16x8_t a[2][3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[0][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + wave * 1024);
+                a[1][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + (has1 ? wave + 8 : wave) * 1024);
+            }
+            bf16x8_t bq[2][3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + DDW_NT * 1024);
+#pragma unroll
+            for (int kt = 0; kt < KB; ++kt) {
+                if (kt < ktx) {
+                    if (kt + 1 < KB) {
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            bq[(kt + 1) & 1][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + (DDW_NT + kt + 1) * 1024);
+                    }
+                    const bf16x8_t (&b)[3] = bq[kt & 1];
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt) {
+                        f32x4 c = acc[rt][kt];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0], b[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][2], b[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][1], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][1], b[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0], b[0], c, 0, 0, 0);
+                        acc[rt][kt] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // partial sums: part[span][n][k]   (C/D map: col = lane & 15, row = 4 (lane >> 4) + reg)
+    float* pp = part + (int64_t)span * N * K;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        if (rt == 0 ? has0 : has1) {
+#pragma unroll
+            for (int kt = 0; kt < KB; ++kt) {
+                const int k = k0 + 16 * kt + ln;
+                if (kt < ktx && k < K) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int n = n0 + 16 * (wave + 8 * rt) + 4 * lg + qq;
+                        if (n < N) pp[(int64_t)n * K + k] = acc[rt][kt][qq];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// dW[n, k] (row stride dw_ld) = sum over spans, in span order
+__global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __restrict__ part, int N, int K, int nspan, float* __restrict__ dW,
+                                                            int64_t dw_ld) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < nspan; ++sp) s += part[(int64_t)sp * total + e];
+        dW[(e / K) * dw_ld + (e % K)] = s;
+    }
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const DdwPlan p = ddw_plan(M, N, K);
+    return (int64_t)p.nspan * N * K * (int64_t)sizeof(float);
+}
+
+extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
+                                       int64_t dw_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    const char* name = "dir_dense_dw_bf16x3_f32";
+    DIR_CHECK_ARG(dW && M >= 0 && N > 0 && K > 0 && dw_ld >= K, "%s: bad argument (M=%lld N=%d K=%d dw_ld=%lld)", name, (long long)M, N, K,
+                  (long long)dw_ld);
+    hipStream_t st = as_stream(stream);
+    if (M == 0) {                                    // an empty batch has a zero gradient (empty operands have no storage: null allowed)
+        if (hipMemset2DAsync(dW, dw_ld * sizeof(float), 0, K * sizeof(float), N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        return DIR_OK;
+    }
+    DIR_CHECK_ARG(g && x && workspace && g_ld >= N && x_ld >= K, "%s: null pointer or row stride smaller than the width", name);
+    DIR_CHECK_ARG(aligned16(workspace) && workspace_bytes >= dir_dense_dw_bf16x3_workspace_bytes(M, N, K),
+                  "%s: workspace must be 16-byte aligned and hold dir_dense_dw_bf16x3_workspace_bytes(M, N, K) bytes", name);
+    const DdwPlan p = ddw_plan(M, N, K);
+    const unsigned grid = (unsigned)(p.nnb * p.nkb * p.nspan);
+    float* part = static_cast<float*>(workspace);
+#define DDW_LAUNCH(KB_)                                                                                                            \
+    do {                                                                                                                           \
+        static bool set = false;                                                                                                   \
+        const size_t lds = 3 * (size_t)(DDW_NT + KB_) * 1024;                                                                      \
+        if (!set) {                                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dw_bf3_k<KB_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            set = true;                                                                                                            \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((dense_dw_bf3_k<KB_>), dim3(grid), dim3(512), lds, st, g, g_ld, x, x_ld, M, N, K, p.nkb, p.nspan,       \
+                           p.steps_per_span, p.steps, part);                                                                       \
+    } while (0)
+    if (p.KB == 13) DDW_LAUNCH(13);
+    else if (p.KB == 8) DDW_LAUNCH(8);
+    else DDW_LAUNCH(16);
+#undef DDW_LAUNCH
+    DIR_CHECK_LAUNCH(name);
+    const int64_t n = (int64_t)N * K;
+    hipLaunchKernelGGL(dense_dw_bf3_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, part, N, K, p.nspan, dW, dw_ld);
+    DIR_CHECK_LAUNCH("dense_dw_bf16x3 reduce");
+    return DIR_OK;
+}

@@ -54,6 +54,9 @@ def _tn_matmul(g, x, splits=16):
     at 65 536 x 400 x 416 (a 400 x 416 output leaves most CUs idle); sixteen batched row slices + one sum run at 0.53
     (tools/tn_gemm_probe.py: 425 -> 261 us)."""
     M = g.shape[0]
+    if g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
+            and ops.dense_dw_auto_arith(M, g.shape[1], x.shape[1]) == "bf16x3":
+        return ops.dense_dw(g, x, arith="bf16x3")       # dir_dense_dw_bf16x3_f32: 230 -> ~120 us at 65 536 x 400 x 416
     if M >= 8192 and M % splits == 0 and g.is_contiguous() and x.is_contiguous():
         return torch.bmm(g.view(splits, M // splits, -1).transpose(1, 2), x.view(splits, M // splits, -1)).sum(dim=0)
     return g.t() @ x

@@ -482,6 +482,47 @@ def dense_gated(x, weight, gate, out=None, arith=None):
     return out
 
 
+DENSE_DW_MIN_ROWS = 8192
+DENSE_DW_ARITH = os.environ.get("DIR_DENSE_DW_ARITH", "auto")        # "f32": the weight gradients of the towers stay on the library
+
+
+def dense_dw_auto_arith(M, N, K):
+    """"bf16x3" where dir_dense_dw_bf16x3_f32 is the faster weight-gradient formulation (tools/dense_dw_probe.py): a tall reduction
+    (>= 8192 rows), a gradient of at least 150 000 elements (smaller ones leave the library's batched GEMM ahead: 200 x 360, 512 x 256)
+    and a block grid (256 output rows x 8 / 13 / 16 column tiles) that pads it by at most 1.4; otherwise "f32" (the library)."""
+    if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or M < DENSE_DW_MIN_ROWS or N * K < 150000:
+        return "f32"
+    nt, kt = -(-N // 16), -(-K // 16)
+    kpad = min(-(-kt // 16) * 16, -(-kt // 13) * 13, -(-kt // 8) * 8)
+    return "bf16x3" if (-(-nt // 16) * 16) * kpad <= 1.4 * nt * kt else "f32"
+
+
+def dense_dw(g, x, arith=None):
+    """dW [N, K] = g^T x, the kernel gradient of a dense layer (include/dir_hip.h: dir_dense_dw_bf16x3_f32): g [M, N], x [M, K], unit
+    inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the HIP kernel."""
+    _dev(g, torch.float32, "g")
+    _dev(x, torch.float32, "x")
+    if g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0] or g.stride(1) != 1 or x.stride(1) != 1:
+        raise ValueError("dense_dw: g [M, N], x [M, K], unit inner strides")
+    M, N = g.shape
+    K = x.shape[1]
+    arith = arith or DENSE_ARITH
+    if arith == "auto":
+        arith = dense_dw_auto_arith(M, N, K)
+    if arith == "f32":
+        if M >= 8192 and M % 16 == 0 and g.is_contiguous() and x.is_contiguous():
+            return torch.bmm(g.view(16, M // 16, N).transpose(1, 2), x.view(16, M // 16, K)).sum(dim=0)
+        return g.t() @ x
+    if arith != "bf16x3":
+        raise ValueError("dense_dw: arith must be 'auto', 'f32' or 'bf16x3'")
+    lib = _lib.load()
+    nbytes = int(lib.dir_dense_dw_bf16x3_workspace_bytes(M, N, K))
+    ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=g.device)
+    dW = torch.empty((N, K), dtype=torch.float32, device=g.device)
+    _lib.check(lib.dir_dense_dw_bf16x3_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(ws), nbytes, _stream()))
+    return dW
+
+
 def units1_relu_backward_supported(y):
     """Shapes dir_units1_relu_backward_f32 takes: a float32 CUDA [B, N] activation with N and its row stride multiples of 4, N <= 4096."""
     return (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1 and y.shape[1] % 4 == 0 and y.shape[1] <= 4096

@@ -825,6 +825,42 @@ def test_mlp_stack_matches_float64(built_lib, dims, M):
         assert not D.mlp_stack_supported(lins, x, torch.relu)
 
 
+@pytest.mark.parametrize("M,N,K,gpad,xpad", [(300, 40, 52, 0, 0), (1, 16, 16, 0, 0), (33, 17, 5, 3, 1), (1000, 400, 416, 0, 16), (257, 260, 210, 4, 0),
+                                              (4100, 513, 129, 0, 0), (8192, 400, 400, 0, 0), (9000, 1024, 432, 0, 0), (5000, 300, 1030, 8, 8)])
+def test_dense_dw_bf16x3_matches_float64(built_lib, M, N, K, gpad, xpad):
+    """dir_dense_dw_bf16x3_f32 (dW = g^T x with both operands transposed and split on the fly) against float64: every tail (rows off the
+    32 grid, widths off the 16 / 256 / block grids), strided operands, bitwise reproducible, same bar as the library formulation."""
+    from dir_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    gbuf = (torch.randn(M, N + gpad, generator=gen) * 0.5).cuda()
+    xbuf = torch.randn(M, K + xpad, generator=gen).cuda()
+    g, x = gbuf[:, :N], xbuf[:, :K]
+    ref = g.double().t() @ x.double()
+    got = ops.dense_dw(g, x, arith="bf16x3")
+    assert got.shape == (N, K)
+    scale = 1 + M ** 0.5 * 0.5
+    err = float((got.double() - ref).abs().max()) / scale
+    lib = float((ops.dense_dw(g, x, arith="f32").double() - ref).abs().max()) / scale
+    assert err <= 1e-5, (err, lib)
+    assert torch.equal(ops.dense_dw(g, x, arith="bf16x3"), got)
+    auto = ops.dense_dw(g, x)
+    assert torch.equal(auto, got) == (ops.dense_dw_auto_arith(M, N, K) == "bf16x3") or M < 16
+
+
+def test_dense_dw_bf16x3_edges(built_lib):
+    from dir_amd import ops
+    z = ops.dense_dw(torch.empty(0, 24, device="cuda"), torch.empty(0, 36, device="cuda"), arith="bf16x3")        # empty batch: zero gradient
+    assert z.shape == (24, 36) and float(z.abs().max()) == 0.0
+    big = torch.full((64, 16), 3.0e18, device="cuda")                                                               # fp32 exponent range
+    small = torch.full((64, 16), 1.0e-18, device="cuda")
+    got = ops.dense_dw(big, small, arith="bf16x3")
+    assert float((got - 192.0).abs().max()) <= 1e-3
+    with pytest.raises(ValueError):
+        ops.dense_dw(torch.zeros(8, 4, device="cuda"), torch.zeros(9, 4, device="cuda"))
+    assert ops.dense_dw_auto_arith(65536, 400, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 200, 360) == "f32"
+    assert ops.dense_dw_auto_arith(4096, 400, 416) == "f32"
+
+
 @pytest.mark.parametrize("B,N,pad", [(300, 400, 0), (1, 16, 0), (65, 64, 4), (1000, 1024, 0), (777, 520, 8), (4096, 4096, 0), (33, 132, 0)])
 def test_units1_relu_backward_kernel(built_lib, B, N, pad):
     """dir_units1_relu_backward_f32 (the logit layer's backward through the ReLU below it, one pass) against float64, strided
