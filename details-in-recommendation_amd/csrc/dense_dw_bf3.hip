@@ -8,9 +8,10 @@
 //
 // The REDUCTION runs over the batch rows, the slow index of both operands -- the opposite of what the MFMA operand layout wants (a
 // lane's 8 k-slots would be 8 consecutive rows of one column).  So both operands go through a transposing stage: per step of 32 rows
-// a thread loads "octets" -- 8 consecutive rows of ONE column (8 scalar loads; consecutive threads take consecutive columns, so a wave's
-// load is a contiguous 256-byte row segment) --, splits each into its three bf16 pieces in registers (52 VALU instructions) and writes
-// three 16-byte operand fragments into LDS in the operand layout [piece][tile][lane][8] (conflict-free ds_write_b128).  After a barrier
+// a thread loads 8 consecutive rows of a QUAD of columns (eight 16-byte loads; a wave reads a contiguous kilobyte per row), i.e. four
+// "octets" -- 8 consecutive rows of ONE column --, splits each octet into its three bf16 pieces in registers (52 VALU instructions) and
+// writes three 16-byte operand fragments into LDS in the operand layout [piece][tile][slot][8] (XOR-swizzled slots: conflict-free
+// ds_write_b128).  After a barrier
 // every wave reads its A fragments (two 16-column tiles of g: the wave's 32 output rows) once and the B fragments of the block's x
 // tiles one tile ahead of their 12 MFMAs.  One LDS buffer, two barriers per step: the split phase and the MFMA phase of the two waves
 // of a SIMD do not overlap anyway (cin_dw_bf3.hip); the raw loads of step s+1 are issued before step s's MFMAs and land
@@ -95,40 +96,45 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
     int64_t s_end = s_begin + steps_per_span;
     if (s_end > steps) s_end = steps;
 
-    // this thread's octets: column c = tid & 255 of the g strip (256 columns) and, for c < 16 KB, of the x strip; row octets ro and
-    // ro + 2 with ro = tid >> 8 -- uniform over a wave, so a row's base address is a scalar and the 32 loads of a step share two
-    // per-lane column offsets.  Consecutive threads read consecutive columns; an octet's fragment goes to tile (c / 16),
-    // lane (c % 16) + 16 * octet.  Columns past N / K read column 0 instead: they only feed outputs that are never stored.
-    constexpr int XC = 16 * KB;
-    const int c = tid & 255;
-    const int ro = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const bool xth = c < XC;
-    const int goff = (n0 + c < N) ? n0 + c : 0;
-    const int xoff = (xth && k0 + c < K) ? k0 + c : 0;
-    const int gdst = ((c >> 4) * 64 + (c & 15) + 16 * ro) * 16;                      // second octet: + 32 lanes = + 512 bytes
-    const int xdst = ((DDW_NT + (c >> 4)) * 64 + (c & 15) + 16 * ro) * 16;
-    float raw[4][8];                                                                  // g octets ro, ro + 2; x octets ro, ro + 2
-    auto load_octet = [&](const float* base, int64_t ld, int off, int64_t r0, float (&v)[8]) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t r = r0 + e;                                                // scalar
-            v[e] = r < M ? (base + r * ld)[off] : 0.f;
-        }
-    };
+    // this thread's four octets of a step: one QUAD of columns (4 q .. 4 q + 3) x one row octet ro.  Waves 0..3 stage the g strip (256
+    // columns = 64 quads, ro = wave), waves 4..7 the x strip (4 KB quads on the first lanes, ro = wave - 4): eight 16-byte loads per
+    // thread whose row base is a scalar (a wave reads a contiguous kilobyte per row).  The fragment of column c = 4 q + j goes to tile
+    // c / 16, slot ((c % 16) + 16 ro) ^ (tile & 3): the XOR spreads a store instruction's 64 lanes (16 tiles x 4 quads, 64 bytes apart)
+    // over all LDS banks; readers apply the same XOR to their lane.  Columns past N / K are read as they come (N, K and the row strides
+    // are multiples of 4 here, so a quad is inside the row): they only feed outputs that are never stored.  (The first version staged
+    // single columns with scalar loads: 32 loads per thread and step, 39 of its 200 us.)
+    constexpr int XQ = 4 * KB;
+    const bool isg = wave < 4;
+    const int ro = __builtin_amdgcn_readfirstlane(isg ? wave : wave - 4);
+    const bool active = isg || lane < XQ;
+    const int qd = active ? lane : 0;
+    const float* sbase = isg ? g + n0 : x + k0;
+    const int64_t sld = isg ? g_ld : x_ld;
+    const int width = isg ? N - n0 : K - k0;                                          // valid columns of the strip
+    const int soff = (4 * qd < width) ? 4 * qd : 0;
+    const int stile = (isg ? 0 : DDW_NT) + (qd >> 2);
+    const int sdst = stile * 1024 + (4 * (qd & 3) + 16 * ro) * 16;                    // + ((j ^ (tile & 3)) * 16): j is the slot's bits 0..1
+    f32x4 raw[8];
     auto load_raw = [&](int64_t s) {
-        float (&rw)[4][8] = raw;
-        load_octet(g, g_ld, goff, 32 * s + 8 * ro, rw[0]);
-        load_octet(g, g_ld, goff, 32 * s + 8 * ro + 16, rw[1]);
-        if (xth) {
-            load_octet(x, x_ld, xoff, 32 * s + 8 * ro, rw[2]);
-            load_octet(x, x_ld, xoff, 32 * s + 8 * ro + 16, rw[3]);
-        }
-    };
-    auto put = [&](const float (&v)[8], int off) {
-        bf16x8_t p[3];
-        ddw_split8(v, p);
+        const int64_t r0 = 32 * s + 8 * ro;                                           // scalar
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(ddw_smem + pc * (TT * 1024) + off) = p[pc];
+        for (int e = 0; e < 8; ++e)
+            raw[e] = (active && r0 + e < M) ? *reinterpret_cast<const f32x4*>(sbase + (r0 + e) * sld + soff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto put_all = [&]() {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = raw[e][j];
+                bf16x8_t p[3];
+                ddw_split8(v, p);
+                const int off = sdst + ((j ^ (stile & 3)) * 16);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(ddw_smem + pc * (TT * 1024) + off) = p[pc];
+            }
+        }
     };
 
     f32x4 acc[2][KB];
@@ -142,32 +148,29 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
     // two steps of loads in flight, in a second register set, measured slower: 227 against 200 us at 65 536 x 400 x 416), MFMAs, barrier
     if (s_begin < s_end) load_raw(s_begin);
     for (int64_t s = s_begin; s < s_end; ++s) {
-        put(raw[0], gdst);
-        put(raw[1], gdst + 512);
-        if (xth) {
-            put(raw[2], xdst);
-            put(raw[3], xdst + 512);
-        }
+        put_all();
         __syncthreads();
         if (s + 1 < s_end) load_raw(s + 1);
         if (has0) {
-            const unsigned char* fl = ddw_smem + lane * 16;
+            // a lane's fragment of tile t sits in slot lane ^ (t & 3)
+            const unsigned char* fa = ddw_smem + ((lane ^ (wave & 3)) * 16);
+            const unsigned char* fb[4] = {ddw_smem + lane * 16, ddw_smem + ((lane ^ 1) * 16), ddw_smem + ((lane ^ 2) * 16), ddw_smem + ((lane ^ 3) * 16)};
             bf16x8_t a[2][3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
-                a[0][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + wave * 1024);
-                a[1][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + (has1 ? wave + 8 : wave) * 1024);
+                a[0][pc] = *reinterpret_cast<const bf16x8_t*>(fa + pc * (TT * 1024) + wave * 1024);
+                a[1][pc] = *reinterpret_cast<const bf16x8_t*>(fa + pc * (TT * 1024) + (has1 ? wave + 8 : wave) * 1024);
             }
             bf16x8_t bq[2][3];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + DDW_NT * 1024);
+            for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const bf16x8_t*>(fb[0] + pc * (TT * 1024) + DDW_NT * 1024);
 #pragma unroll
             for (int kt = 0; kt < KB; ++kt) {
                 if (kt < ktx) {
                     if (kt + 1 < KB) {
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc)
-                            bq[(kt + 1) & 1][pc] = *reinterpret_cast<const bf16x8_t*>(fl + pc * (TT * 1024) + (DDW_NT + kt + 1) * 1024);
+                            bq[(kt + 1) & 1][pc] = *reinterpret_cast<const bf16x8_t*>(fb[(kt + 1) & 3] + pc * (TT * 1024) + (DDW_NT + kt + 1) * 1024);
                     }
                     const bf16x8_t (&b)[3] = bq[kt & 1];
 #pragma unroll
@@ -238,6 +241,9 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
         return DIR_OK;
     }
     DIR_CHECK_ARG(g && x && workspace && g_ld >= N && x_ld >= K, "%s: null pointer or row stride smaller than the width", name);
+    if (N % 4 || K % 4 || g_ld % 4 || x_ld % 4 || !aligned16(g) || !aligned16(x))
+        return fail(DIR_E_UNSUPPORTED, "%s: N=%d K=%d g_ld=%lld x_ld=%lld must be multiples of 4 and g / x 16-byte aligned (rows are staged "
+                    "with 16-byte loads)", name, N, K, (long long)g_ld, (long long)x_ld);
     DIR_CHECK_ARG(aligned16(workspace) && workspace_bytes >= dir_dense_dw_bf16x3_workspace_bytes(M, N, K),
                   "%s: workspace must be 16-byte aligned and hold dir_dense_dw_bf16x3_workspace_bytes(M, N, K) bytes", name);
     const DdwPlan p = ddw_plan(M, N, K);

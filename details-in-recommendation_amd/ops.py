@@ -490,7 +490,7 @@ def dense_dw_auto_arith(M, N, K):
     """"bf16x3" where dir_dense_dw_bf16x3_f32 is the faster weight-gradient formulation (tools/dense_dw_probe.py): a tall reduction
     (>= 8192 rows), a gradient of at least 150 000 elements (smaller ones leave the library's batched GEMM ahead: 200 x 360, 512 x 256)
     and a block grid (256 output rows x 8 / 13 / 16 column tiles) that pads it by at most 1.4; otherwise "f32" (the library)."""
-    if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or M < DENSE_DW_MIN_ROWS or N * K < 150000:
+    if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or M < DENSE_DW_MIN_ROWS or N * K < 150000 or N % 4 or K % 4:
         return "f32"
     nt, kt = -(-N // 16), -(-K // 16)
     kpad = min(-(-kt // 16) * 16, -(-kt // 13) * 13, -(-kt // 8) * 8)
@@ -507,8 +507,11 @@ def dense_dw(g, x, arith=None):
     M, N = g.shape
     K = x.shape[1]
     arith = arith or DENSE_ARITH
+    covered = N % 4 == 0 and K % 4 == 0 and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
     if arith == "auto":
-        arith = dense_dw_auto_arith(M, N, K)
+        arith = dense_dw_auto_arith(M, N, K) if covered else "f32"
+    if arith == "bf16x3" and not covered:
+        raise ValueError("dense_dw(arith='bf16x3'): N, K and the row strides must be multiples of 4, g and x 16-byte aligned")
     if arith == "f32":
         if M >= 8192 and M % 16 == 0 and g.is_contiguous() and x.is_contiguous():
             return torch.bmm(g.view(16, M // 16, N).transpose(1, 2), x.view(16, M // 16, K)).sum(dim=0)

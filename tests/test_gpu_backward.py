@@ -825,8 +825,8 @@ def test_mlp_stack_matches_float64(built_lib, dims, M):
         assert not D.mlp_stack_supported(lins, x, torch.relu)
 
 
-@pytest.mark.parametrize("M,N,K,gpad,xpad", [(300, 40, 52, 0, 0), (1, 16, 16, 0, 0), (33, 17, 5, 3, 1), (1000, 400, 416, 0, 16), (257, 260, 210, 4, 0),
-                                              (4100, 513, 129, 0, 0), (8192, 400, 400, 0, 0), (9000, 1024, 432, 0, 0), (5000, 300, 1030, 8, 8)])
+@pytest.mark.parametrize("M,N,K,gpad,xpad", [(300, 40, 52, 0, 0), (1, 16, 16, 0, 0), (33, 20, 4, 4, 8), (1000, 400, 416, 0, 16), (257, 260, 212, 4, 0),
+                                              (4100, 516, 132, 0, 0), (8192, 400, 400, 0, 0), (9000, 1024, 432, 0, 0), (5000, 300, 1028, 8, 8)])
 def test_dense_dw_bf16x3_matches_float64(built_lib, M, N, K, gpad, xpad):
     """dir_dense_dw_bf16x3_f32 (dW = g^T x with both operands transposed and split on the fly) against float64: every tail (rows off the
     32 grid, widths off the 16 / 256 / block grids), strided operands, bitwise reproducible, same bar as the library formulation."""
@@ -857,6 +857,12 @@ def test_dense_dw_bf16x3_edges(built_lib):
     assert float((got - 192.0).abs().max()) <= 1e-3
     with pytest.raises(ValueError):
         ops.dense_dw(torch.zeros(8, 4, device="cuda"), torch.zeros(9, 4, device="cuda"))
+    odd_g, odd_x = torch.randn(64, 18, device="cuda"), torch.randn(64, 20, device="cuda")       # N % 4 != 0: the library takes it
+    with pytest.raises(ValueError):
+        ops.dense_dw(odd_g, odd_x, arith="bf16x3")
+    assert torch.allclose(ops.dense_dw(odd_g, odd_x), odd_g.t() @ odd_x, atol=1e-4)
+    with pytest.raises(ValueError):
+        ops.dense_dw(torch.randn(64, 24, device="cuda")[:, 1:21], odd_x, arith="bf16x3")        # a view that is not 16-byte aligned
     assert ops.dense_dw_auto_arith(65536, 400, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 200, 360) == "f32"
     assert ops.dense_dw_auto_arith(4096, 400, 416) == "f32"
 
