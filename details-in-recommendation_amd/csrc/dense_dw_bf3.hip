@@ -81,7 +81,7 @@ static DdwPlan ddw_plan(int64_t M, int N, int K) {
 template <int KB>
 __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ x, int64_t x_ld,
                                                           int64_t M, int N, int K, int nkb, int nspan, int64_t steps_per_span, int64_t steps,
-                                                          float* __restrict__ part) {
+                                                          float* __restrict__ part, float* __restrict__ bpart /* [nspan][N] or NULL */) {
     constexpr int TT = DDW_NT + KB;                   // tiles staged per step: 16 of g, KB of x
     extern __shared__ __attribute__((aligned(16))) unsigned char ddw_smem[];      // [3 pieces][TT tiles][64 lanes][8 bf16]
 
@@ -115,6 +115,9 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
     const int stile = (isg ? 0 : DDW_NT) + (qd >> 2);
     const int sdst = stile * 1024 + (4 * (qd & 3) + 16 * ro) * 16;                    // + ((j ^ (tile & 3)) * 16): j is the slot's bits 0..1
     f32x4 raw[8];
+    // the bias gradient db[n] = sum_r g[r, n] rides along: the workgroups of the first x block add up the g rows they stage anyway
+    const bool want_b = bpart != nullptr && kb == 0 && isg;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto load_raw = [&](int64_t s) {
         const int64_t r0 = 32 * s + 8 * ro;                                           // scalar
 #pragma unroll
@@ -122,6 +125,10 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
             raw[e] = (active && r0 + e < M) ? *reinterpret_cast<const f32x4*>(sbase + (r0 + e) * sld + soff) : (f32x4){0.f, 0.f, 0.f, 0.f};
     };
     auto put_all = [&]() {
+        if (want_b) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += raw[e];          // rows ascending
+        }
         if (active) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -189,6 +196,15 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
         }
         __syncthreads();
     }
+    if (bpart != nullptr && kb == 0) {                           // (uniform) the four row octets' sums, added in octet order
+        f32x4* bs = reinterpret_cast<f32x4*>(ddw_smem);          // the fragments are dead behind the loop's last barrier
+        if (isg) bs[ro * 64 + lane] = bsum;
+        __syncthreads();
+        if (wave == 0 && n0 + 4 * lane < N) {
+            const f32x4 t = ((bs[lane] + bs[64 + lane]) + bs[128 + lane]) + bs[192 + lane];
+            *reinterpret_cast<f32x4*>(bpart + (int64_t)span * N + n0 + 4 * lane) = t;
+        }
+    }
     // partial sums: part[span][n][k]   (C/D map: col = lane & 15, row = 4 (lane >> 4) + reg)
     float* pp = part + (int64_t)span * N * K;
 #pragma unroll
@@ -210,13 +226,20 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
 }
 
 // dW[n, k] (row stride dw_ld) = sum over spans, in span order
-__global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __restrict__ part, int N, int K, int nspan, float* __restrict__ dW,
-                                                            int64_t dw_ld) {
+__global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __restrict__ part, const float* __restrict__ bpart, int N, int K,
+                                                            int nspan, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db) {
     const int64_t total = (int64_t)N * K;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         float s = 0.f;
         for (int sp = 0; sp < nspan; ++sp) s += part[(int64_t)sp * total + e];
         dW[(e / K) * dw_ld + (e % K)] = s;
+    }
+    if (db != nullptr) {
+        for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+            float s = 0.f;
+            for (int sp = 0; sp < nspan; ++sp) s += bpart[(int64_t)sp * N + n];
+            db[n] = s;
+        }
     }
 }
 
@@ -227,17 +250,18 @@ using namespace dir;
 extern "C" int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const DdwPlan p = ddw_plan(M, N, K);
-    return (int64_t)p.nspan * N * K * (int64_t)sizeof(float);
+    return (int64_t)p.nspan * ((int64_t)N * K + N) * (int64_t)sizeof(float);      // span partials of dW, then of db
 }
 
 extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
-                                       int64_t dw_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+                                       int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     const char* name = "dir_dense_dw_bf16x3_f32";
     DIR_CHECK_ARG(dW && M >= 0 && N > 0 && K > 0 && dw_ld >= K, "%s: bad argument (M=%lld N=%d K=%d dw_ld=%lld)", name, (long long)M, N, K,
                   (long long)dw_ld);
     hipStream_t st = as_stream(stream);
     if (M == 0) {                                    // an empty batch has a zero gradient (empty operands have no storage: null allowed)
         if (hipMemset2DAsync(dW, dw_ld * sizeof(float), 0, K * sizeof(float), N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
         return DIR_OK;
     }
     DIR_CHECK_ARG(g && x && workspace && g_ld >= N && x_ld >= K, "%s: null pointer or row stride smaller than the width", name);
@@ -249,6 +273,7 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
     const DdwPlan p = ddw_plan(M, N, K);
     const unsigned grid = (unsigned)(p.nnb * p.nkb * p.nspan);
     float* part = static_cast<float*>(workspace);
+    float* bpart = db ? part + (int64_t)p.nspan * N * K : nullptr;
 #define DDW_LAUNCH(KB_)                                                                                                            \
     do {                                                                                                                           \
         static bool set = false;                                                                                                   \
@@ -258,7 +283,7 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
             set = true;                                                                                                            \
         }                                                                                                                          \
         hipLaunchKernelGGL((dense_dw_bf3_k<KB_>), dim3(grid), dim3(512), lds, st, g, g_ld, x, x_ld, M, N, K, p.nkb, p.nspan,       \
-                           p.steps_per_span, p.steps, part);                                                                       \
+                           p.steps_per_span, p.steps, part, bpart);                                                                \
     } while (0)
     if (p.KB == 13) DDW_LAUNCH(13);
     else if (p.KB == 8) DDW_LAUNCH(8);
@@ -266,7 +291,7 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
 #undef DDW_LAUNCH
     DIR_CHECK_LAUNCH(name);
     const int64_t n = (int64_t)N * K;
-    hipLaunchKernelGGL(dense_dw_bf3_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, part, N, K, p.nspan, dW, dw_ld);
+    hipLaunchKernelGGL(dense_dw_bf3_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, part, bpart, N, K, p.nspan, dW, dw_ld, db);
     DIR_CHECK_LAUNCH("dense_dw_bf16x3 reduce");
     return DIR_OK;
 }

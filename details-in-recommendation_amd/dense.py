@@ -75,6 +75,17 @@ def _packed_cached_padded(weight, pad):
     return packed
 
 
+def _wb_grads(g, x, need_w, need_b):
+    """(dL/dW, dL/db) of a dense layer from g = dL/d(pre-activation) and its input x: one pass of dir_dense_dw_bf16x3_f32 for both where
+    it covers the shape, otherwise the library GEMM and a column sum."""
+    if need_w and need_b and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
+            and ops.dense_dw_auto_arith(g.shape[0], g.shape[1], x.shape[1]) == "bf16x3":
+        gw, gb = ops.dense_dw(g, x, want_bias=True)
+        if gb is not None:
+            return gw, gb
+    return (_tn_matmul(g, x) if need_w else None), (g.sum(dim=0) if need_b else None)
+
+
 class _DenseFn(torch.autograd.Function):
     """y = act(x W^T + b) with the HIP kernel forward and for dL/dx (= g W, the same kernel on W^T); dL/dW = g^T x and
     dL/db = sum g go through the library (a reduction over the batch rows: a different shape class)."""
@@ -98,10 +109,7 @@ class _DenseFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = pack_weight(weight.t())                           # [Kd, N]: the "weight" of the transposed product
             gx = ops.dense(g, wt, None, relu=False) if ops.dense_supported(g, wt) else g @ weight
-        if ctx.needs_input_grad[1]:
-            gw = _tn_matmul(g, x)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(dim=0)
+        gw, gb = _wb_grads(g, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return gx, gw, gb, None
 
 
@@ -133,10 +141,7 @@ class _MlpStackFn(torch.autograd.Function):
         gx = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
-            if ctx.needs_input_grad[1 + 2 * l]:
-                grads[2 * l] = _tn_matmul(g, xin)
-            if ctx.needs_input_grad[2 + 2 * l]:
-                grads[2 * l + 1] = g.sum(dim=0)
+            grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l])
             wt = pack_weight(ws[l].t())
             if l > 0:
                 g = ops.dense_gated(g, wt, xin)
@@ -178,10 +183,11 @@ class _MlpHeadFn(torch.autograd.Function):
         gx = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
-            if ctx.needs_input_grad[3 + 2 * l]:
-                grads[2 * l] = _tn_matmul(g, xin)
-            if ctx.needs_input_grad[4 + 2 * l]:
-                grads[2 * l + 1] = gb_top if l == L - 1 else g.sum(dim=0)
+            if l == L - 1:                                           # the top layer's bias gradient came with the head's backward
+                grads[2 * l] = _tn_matmul(g, xin) if ctx.needs_input_grad[3 + 2 * l] else None
+                grads[2 * l + 1] = gb_top if ctx.needs_input_grad[4 + 2 * l] else None
+            else:
+                grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l])
             wt = pack_weight(ws[l].t())
             if l > 0:
                 g = ops.dense_gated(g, wt, xin)

@@ -497,9 +497,10 @@ def dense_dw_auto_arith(M, N, K):
     return "bf16x3" if (-(-nt // 16) * 16) * kpad <= 1.4 * nt * kt else "f32"
 
 
-def dense_dw(g, x, arith=None):
+def dense_dw(g, x, arith=None, want_bias=False):
     """dW [N, K] = g^T x, the kernel gradient of a dense layer (include/dir_hip.h: dir_dense_dw_bf16x3_f32): g [M, N], x [M, K], unit
-    inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the HIP kernel."""
+    inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the HIP kernel.
+    want_bias: -> (dW, db) with db [N] = g.sum(0), the bias gradient (in the kernel's pass over g on the bf16x3 path)."""
     _dev(g, torch.float32, "g")
     _dev(x, torch.float32, "x")
     if g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0] or g.stride(1) != 1 or x.stride(1) != 1:
@@ -514,16 +515,20 @@ def dense_dw(g, x, arith=None):
         raise ValueError("dense_dw(arith='bf16x3'): N, K and the row strides must be multiples of 4, g and x 16-byte aligned")
     if arith == "f32":
         if M >= 8192 and M % 16 == 0 and g.is_contiguous() and x.is_contiguous():
-            return torch.bmm(g.view(16, M // 16, N).transpose(1, 2), x.view(16, M // 16, K)).sum(dim=0)
-        return g.t() @ x
+            dW = torch.bmm(g.view(16, M // 16, N).transpose(1, 2), x.view(16, M // 16, K)).sum(dim=0)
+        else:
+            dW = g.t() @ x
+        return (dW, g.sum(dim=0)) if want_bias else dW
     if arith != "bf16x3":
         raise ValueError("dense_dw: arith must be 'auto', 'f32' or 'bf16x3'")
     lib = _lib.load()
     nbytes = int(lib.dir_dense_dw_bf16x3_workspace_bytes(M, N, K))
     ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=g.device)
     dW = torch.empty((N, K), dtype=torch.float32, device=g.device)
-    _lib.check(lib.dir_dense_dw_bf16x3_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(ws), nbytes, _stream()))
-    return dW
+    db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
+    _lib.check(lib.dir_dense_dw_bf16x3_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(db), _ptr(ws), nbytes,
+                                           _stream()))
+    return (dW, db) if want_bias else dW
 
 
 def units1_relu_backward_supported(y):

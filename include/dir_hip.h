@@ -354,12 +354,13 @@ int dir_dense_gated_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w
  * ESMM.py:139-142 under TensorFlow autodiff):  dW[n, k] = sum_r g[r, n] * x[r, k],  g = dL/d(pre-activation) [M, N] (row stride g_ld),
  * x = the layer's input [M, K] (row stride x_ld), dW [N, K] (row stride dw_ld; nn.Linear's weight layout) -- on the bf16 matrix pipe
  * with fp32-equivalent arithmetic (csrc/dense_dw_bf3.hip; the recipe of dir_dense_bf16x3_f32), both operands transposed and split
- * on the fly.  Row spans leave partial sums in `workspace` (dir_dense_dw_bf16x3_workspace_bytes(M, N, K) bytes, 16-byte aligned)
+ * on the fly.  db [N] (or NULL): the layer's bias gradient sum_r g[r, n], formed from the g rows the kernel stages anyway.
+ * Row spans leave partial sums in `workspace` (dir_dense_dw_bf16x3_workspace_bytes(M, N, K) bytes, 16-byte aligned)
  * that are added in span order: bitwise reproducible, no atomics.  Any M (row tails are zero-filled); N, K, g_ld, x_ld multiples of 4
  * and g / x 16-byte aligned (DIR_E_UNSUPPORTED otherwise: rows are staged with 16-byte loads). */
 int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K);
 int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
-                            void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+                            float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 /* Backward of the units = 1 logit layer (models/DeepFM/deepFM.py:311-317, models/ESMM/ESMM.py:146) taken straight through the ReLU
  * of the hidden layer below it, in one pass (csrc/head_bwd.hip).  g = dL/dlogit [B], w = the logit layer's weight [N], y = the hidden
  * layer's output [B, N] (row stride y_ld):

@@ -843,14 +843,18 @@ def test_dense_dw_bf16x3_matches_float64(built_lib, M, N, K, gpad, xpad):
     lib = float((ops.dense_dw(g, x, arith="f32").double() - ref).abs().max()) / scale
     assert err <= 1e-5, (err, lib)
     assert torch.equal(ops.dense_dw(g, x, arith="bf16x3"), got)
+    gw2, gb = ops.dense_dw(g, x, arith="bf16x3", want_bias=True)           # the bias gradient from the same pass over g
+    assert torch.equal(gw2, got)
+    assert float((gb.double() - g.double().sum(0)).abs().max()) <= 1e-5 * scale
+    assert torch.equal(ops.dense_dw(g, x, arith="bf16x3", want_bias=True)[1], gb)
     auto = ops.dense_dw(g, x)
     assert torch.equal(auto, got) == (ops.dense_dw_auto_arith(M, N, K) == "bf16x3") or M < 16
 
 
 def test_dense_dw_bf16x3_edges(built_lib):
     from dir_amd import ops
-    z = ops.dense_dw(torch.empty(0, 24, device="cuda"), torch.empty(0, 36, device="cuda"), arith="bf16x3")        # empty batch: zero gradient
-    assert z.shape == (24, 36) and float(z.abs().max()) == 0.0
+    z, zb = ops.dense_dw(torch.empty(0, 24, device="cuda"), torch.empty(0, 36, device="cuda"), arith="bf16x3", want_bias=True)    # empty batch: zero gradients
+    assert z.shape == (24, 36) and float(z.abs().max()) == 0.0 and zb.shape == (24,) and float(zb.abs().max()) == 0.0
     big = torch.full((64, 16), 3.0e18, device="cuda")                                                               # fp32 exponent range
     small = torch.full((64, 16), 1.0e-18, device="cuda")
     got = ops.dense_dw(big, small, arith="bf16x3")
