@@ -34,6 +34,8 @@ SIGNATURES = {
     "dir_dense_gated_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_dw_bf16x3_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
     "dir_dense_dw_bf16x3_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "dir_dense_dw_small_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
+    "dir_dense_dw_small_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "dir_units1_relu_backward_partials": (c_i64, [c_i64, c_i32]),
     "dir_units1_relu_backward_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_dense_affine_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -225,27 +225,177 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
     }
 }
 
-// dW[n, k] (row stride dw_ld) = sum over spans, in span order
+// dW[n, k] (row stride dw_ld) = sum over spans in a fixed order: a workgroup takes 256 / SG consecutive elements, span group q adds spans
+// q, q + SG, ... (ascending) and the SG group sums are added in group order through LDS.  (One thread per element walking all spans is a
+// chain of nspan dependent loads: 240 us for the 512 spans of an 80 x 64 gradient.)
+template <int SG>
 __global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __restrict__ part, const float* __restrict__ bpart, int N, int K,
                                                             int nspan, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db) {
-    const int64_t total = (int64_t)N * K;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    constexpr int EPB = 256 / SG;
+    __shared__ float red[SG][EPB];
+    const int q = threadIdx.x / EPB, el = threadIdx.x % EPB;
+    const int64_t total = (int64_t)N * K, all = total + (db != nullptr ? N : 0);
+    for (int64_t e0 = (int64_t)blockIdx.x * EPB; e0 < all; e0 += (int64_t)gridDim.x * EPB) {
+        const int64_t e = e0 + el;
         float s = 0.f;
-        for (int sp = 0; sp < nspan; ++sp) s += part[(int64_t)sp * total + e];
-        dW[(e / K) * dw_ld + (e % K)] = s;
+        if (e < total) {
+            for (int sp = q; sp < nspan; sp += SG) s += part[(int64_t)sp * total + e];
+        } else if (e < all) {
+            for (int sp = q; sp < nspan; sp += SG) s += bpart[(int64_t)sp * N + (e - total)];
+        }
+        red[q][el] = s;
+        __syncthreads();
+        if (q == 0 && e < all) {
+            float t = red[0][el];
+#pragma unroll
+            for (int i = 1; i < SG; ++i) t += red[i][el];
+            if (e < total) dW[(e / K) * dw_ld + (e % K)] = t;
+            else db[e - total] = t;
+        }
+        __syncthreads();
     }
-    if (db != nullptr) {
-        for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
-            float s = 0.f;
-            for (int sp = 0; sp < nspan; ++sp) s += bpart[(int64_t)sp * N + n];
-            db[n] = s;
+}
+
+static void ddw_reduce(const float* part, const float* bpart, int N, int K, int nspan, float* dW, int64_t dw_ld, float* db, hipStream_t st) {
+    const int64_t all = (int64_t)N * K + (db ? N : 0);
+    if (all <= 65536)
+        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<16>, dim3(grid_for((all + 15) / 16)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db);
+    else
+        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<4>, dim3(grid_for((all + 63) / 64)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db);
+}
+
+// ---- small gradients (N, K <= 128): fp32 FMAs on a register tile ---------------------------------------------------------------------
+// The same product for outputs of at most 128 x 128 -- the per-sample term of the DIN unit's first layer (csrc/din_bwd_rows.hip: S^T a,
+// 80 x 64) and the narrow last layers of the towers.  The library runs these tall-and-skinny TN GEMMs at 200 us (65 536 rows, 80 x 64:
+// 37 MB of operands); the MFMA kernel above at 137 (its stage-split-multiply structure is mostly overhead here).  A workgroup owns a
+// span of rows; per step it stages 32 rows of both operands in LDS (16-byte loads) and every thread walks them with a TN x TK register
+// tile of fp32 FMAs (rows ascending: exact fp32 products, one rounding per accumulate), two 16-byte LDS reads per operand and row at
+// most.  Span partials and the final sums as above.
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void dense_dw_small_k(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ x, int64_t x_ld,
+                                                        int64_t M, int N, int K, int64_t rows_per_span, float* __restrict__ part,
+                                                        float* __restrict__ bpart) {
+    constexpr int R = 32;
+    __shared__ __attribute__((aligned(16))) float sg[R][128 + 4], sx[R][128 + 4];
+    const int tid = threadIdx.x;
+    const int ntk = (K + TK - 1) / TK, ntn = (N + TN - 1) / TN;
+    const int in = tid / ntk, ik = tid % ntk;
+    const bool act = in < ntn;
+    const int n0 = in * TN, k0 = ik * TK;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_span, r1 = min(M, r0 + rows_per_span);
+    float acc[TN][TK], bs[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        bs[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = 0.f;
+    }
+    const int gq = N >> 2, xq = K >> 2;                 // float4 per row of each operand
+    for (int64_t rb = r0; rb < r1; rb += R) {
+        const int rows = (int)min((int64_t)R, r1 - rb);
+        for (int e = tid; e < R * gq; e += 256) {
+            const int r = e / gq, q = e % gq;
+            *reinterpret_cast<f32x4*>(&sg[r][4 * q]) = r < rows ? *reinterpret_cast<const f32x4*>(g + (rb + r) * g_ld + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int e = tid; e < R * xq; e += 256) {
+            const int r = e / xq, q = e % xq;
+            *reinterpret_cast<f32x4*>(&sx[r][4 * q]) = r < rows ? *reinterpret_cast<const f32x4*>(x + (rb + r) * x_ld + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll 4
+            for (int r = 0; r < R; ++r) {
+                float gv[TN], xv[TK];
+#pragma unroll
+                for (int i = 0; i < TN; i += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(&sg[r][n0 + i]);
+                    gv[i] = t[0]; gv[i + 1] = t[1]; gv[i + 2] = t[2]; gv[i + 3] = t[3];
+                }
+#pragma unroll
+                for (int j = 0; j < TK; j += 4) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(&sx[r][k0 + j]);
+                    xv[j] = t[0]; xv[j + 1] = t[1]; xv[j + 2] = t[2]; xv[j + 3] = t[3];
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    bs[i] += gv[i];
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_fmaf(gv[i], xv[j], acc[i][j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (act) {
+        float* pp = part + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            if (n0 + i < N) {
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    if (k0 + j < K) pp[(int64_t)(n0 + i) * K + k0 + j] = acc[i][j];
+                if (bpart != nullptr && ik == 0) bpart[(int64_t)blockIdx.x * N + n0 + i] = bs[i];
+            }
         }
     }
+}
+
+struct DdwSmallPlan { int tn, tk, nspan; int64_t rows_per_span; };
+static DdwSmallPlan ddw_small_plan(int64_t M, int N, int K) {
+    DdwSmallPlan p;
+    p.tn = 4;
+    p.tk = ((N + 3) / 4) * ((K + 3) / 4) <= 256 ? 4 : 8;
+    if (((N + p.tn - 1) / p.tn) * ((K + p.tk - 1) / p.tk) > 256) p.tn = 8;
+    int64_t ns = 2 * kCUs;
+    const int64_t steps = (M + 31) / 32;
+    if (ns > steps) ns = steps > 0 ? steps : 1;
+    p.rows_per_span = ((steps + ns - 1) / ns) * 32;
+    p.nspan = (int)((M + p.rows_per_span - 1) / p.rows_per_span);
+    if (p.nspan < 1) p.nspan = 1;
+    return p;
 }
 
 }  // namespace dir
 
 using namespace dir;
+
+extern "C" int64_t dir_dense_dw_small_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const DdwSmallPlan p = ddw_small_plan(M, N, K);
+    return (int64_t)p.nspan * ((int64_t)N * K + N) * (int64_t)sizeof(float);
+}
+
+extern "C" int dir_dense_dw_small_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
+                                      int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    const char* name = "dir_dense_dw_small_f32";
+    DIR_CHECK_ARG(dW && M >= 0 && N > 0 && K > 0 && dw_ld >= K, "%s: bad argument (M=%lld N=%d K=%d dw_ld=%lld)", name, (long long)M, N, K,
+                  (long long)dw_ld);
+    hipStream_t st = as_stream(stream);
+    if (M == 0) {
+        if (hipMemset2DAsync(dW, dw_ld * sizeof(float), 0, K * sizeof(float), N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        return DIR_OK;
+    }
+    DIR_CHECK_ARG(g && x && workspace && g_ld >= N && x_ld >= K, "%s: null pointer or row stride smaller than the width", name);
+    if (N > 128 || K > 128 || N % 4 || K % 4 || g_ld % 4 || x_ld % 4 || !aligned16(g) || !aligned16(x))
+        return fail(DIR_E_UNSUPPORTED, "%s: N=%d K=%d (<= 128), and N, K, g_ld=%lld, x_ld=%lld multiples of 4 with g / x 16-byte aligned", name, N, K,
+                    (long long)g_ld, (long long)x_ld);
+    DIR_CHECK_ARG(aligned16(workspace) && workspace_bytes >= dir_dense_dw_small_workspace_bytes(M, N, K),
+                  "%s: workspace must be 16-byte aligned and hold dir_dense_dw_small_workspace_bytes(M, N, K) bytes", name);
+    const DdwSmallPlan p = ddw_small_plan(M, N, K);
+    float* part = static_cast<float*>(workspace);
+    float* bpart = db ? part + (int64_t)p.nspan * N * K : nullptr;
+#define DDW_SMALL(TN_, TK_) hipLaunchKernelGGL((dense_dw_small_k<TN_, TK_>), dim3((unsigned)p.nspan), dim3(256), 0, st, g, g_ld, x, x_ld, M, N, K, \
+                                               p.rows_per_span, part, bpart)
+    if (p.tn == 4 && p.tk == 4) DDW_SMALL(4, 4);
+    else if (p.tn == 4) DDW_SMALL(4, 8);
+    else DDW_SMALL(8, 8);
+#undef DDW_SMALL
+    DIR_CHECK_LAUNCH(name);
+    ddw_reduce(part, bpart, N, K, p.nspan, dW, dw_ld, db, st);
+    DIR_CHECK_LAUNCH("dense_dw_small reduce");
+    return DIR_OK;
+}
 
 extern "C" int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -290,8 +440,7 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
     else DDW_LAUNCH(16);
 #undef DDW_LAUNCH
     DIR_CHECK_LAUNCH(name);
-    const int64_t n = (int64_t)N * K;
-    hipLaunchKernelGGL(dense_dw_bf3_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, part, bpart, N, K, p.nspan, dW, dw_ld, db);
+    ddw_reduce(part, bpart, N, K, p.nspan, dW, dw_ld, db, st);
     DIR_CHECK_LAUNCH("dense_dw_bf16x3 reduce");
     return DIR_OK;
 }

@@ -491,7 +491,12 @@ def dense_dw_auto_arith(M, N, K):
     M = 65 536: 360 x 416 190 vs 243 us for the library GEMM + column sum, 208 x 416 135 vs 172, 1024 x 128 139 vs 178): a tall reduction
     (>= 8192 rows), at least 200 output rows and 80 000 elements (200 x 360 ties, 128 x 1024 loses: 211 vs 151) and a block grid (256
     output rows x 8 / 13 / 16 column tiles) that pads the gradient by at most 1.4 (320 x 320 pads 1.6 and loses); otherwise "f32"."""
-    if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or M < DENSE_DW_MIN_ROWS or N < 200 or N * K < 80000 or N % 4 or K % 4:
+    if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or N % 4 or K % 4:
+        return "f32"
+    if N <= 128 and K <= 128:
+        # tall and skinny (the DIN unit's per-sample term, 80 x 64: 215 us on the library, 137 on the MFMA kernel, ~25 on the FMA kernel)
+        return "small" if M >= 2048 and N * K >= 512 else "f32"
+    if M < DENSE_DW_MIN_ROWS or N < 200 or N * K < 80000:
         return "f32"
     nt, kt = -(-N // 16), -(-K // 16)
     kpad = min(-(-kt // 16) * 16, -(-kt // 13) * 13, -(-kt // 8) * 8)
@@ -500,7 +505,8 @@ def dense_dw_auto_arith(M, N, K):
 
 def dense_dw(g, x, arith=None, want_bias=False):
     """dW [N, K] = g^T x, the kernel gradient of a dense layer (include/dir_hip.h: dir_dense_dw_bf16x3_f32): g [M, N], x [M, K], unit
-    inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the HIP kernel.
+    inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the MFMA kernel;
+    "small": the fp32 FMA kernel for N, K <= 128 (dir_dense_dw_small_f32).
     want_bias: -> (dW, db) with db [N] = g.sum(0), the bias gradient (in the kernel's pass over g on the bf16x3 path)."""
     _dev(g, torch.float32, "g")
     _dev(x, torch.float32, "x")
@@ -512,23 +518,26 @@ def dense_dw(g, x, arith=None, want_bias=False):
     covered = N % 4 == 0 and K % 4 == 0 and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
     if arith == "auto":
         arith = dense_dw_auto_arith(M, N, K) if covered else "f32"
-    if arith == "bf16x3" and not covered:
-        raise ValueError("dense_dw(arith='bf16x3'): N, K and the row strides must be multiples of 4, g and x 16-byte aligned")
+    if arith in ("bf16x3", "small") and not covered:
+        raise ValueError("dense_dw(arith='%s'): N, K and the row strides must be multiples of 4, g and x 16-byte aligned" % arith)
+    if arith == "small" and (N > 128 or K > 128):
+        raise ValueError("dense_dw(arith='small') covers N, K <= 128")
     if arith == "f32":
         if M >= 8192 and M % 16 == 0 and g.is_contiguous() and x.is_contiguous():
             dW = torch.bmm(g.view(16, M // 16, N).transpose(1, 2), x.view(16, M // 16, K)).sum(dim=0)
         else:
             dW = g.t() @ x
         return (dW, g.sum(dim=0)) if want_bias else dW
-    if arith != "bf16x3":
-        raise ValueError("dense_dw: arith must be 'auto', 'f32' or 'bf16x3'")
+    if arith not in ("bf16x3", "small"):
+        raise ValueError("dense_dw: arith must be 'auto', 'f32', 'bf16x3' or 'small'")
     lib = _lib.load()
-    nbytes = int(lib.dir_dense_dw_bf16x3_workspace_bytes(M, N, K))
+    wsq, run = ((lib.dir_dense_dw_bf16x3_workspace_bytes, lib.dir_dense_dw_bf16x3_f32) if arith == "bf16x3" else
+                (lib.dir_dense_dw_small_workspace_bytes, lib.dir_dense_dw_small_f32))
+    nbytes = int(wsq(M, N, K))
     ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=g.device)
     dW = torch.empty((N, K), dtype=torch.float32, device=g.device)
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
-    _lib.check(lib.dir_dense_dw_bf16x3_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(db), _ptr(ws), nbytes,
-                                           _stream()))
+    _lib.check(run(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(db), _ptr(ws), nbytes, _stream()))
     return (dW, db) if want_bias else dW
 
 
@@ -623,7 +632,8 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     if ws is None or ws.numel() < need:
         ws = _DIN_BWD_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    gh, ga, S = torch.empty((N, K), **f32), torch.empty((B, K), **f32), torch.empty((B, H1), **f32)
+    grows = torch.empty((N + B, K), **f32)                 # the table gradient's rows in one buffer: history rows, then the candidates'
+    gh, ga, S = grows[:N], grows[N:], torch.empty((B, H1), **f32)
     gAP, gW2, gb2 = torch.empty((2 * K, H1), **f32), torch.empty((H1, H2), **f32), torch.empty(H2, **f32)
     gW3, gb3 = torch.empty(H2, **f32), torch.empty(1, **f32)
     if use_rows:
@@ -645,9 +655,10 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     C = W1[K:2 * K] - W1[2 * K:3 * K]
     a = table[cand.clamp(min=0)] * (cand >= 0).unsqueeze(1)
     ga.addmm_(S, C.t())
-    gC = a.t() @ S
+    gCt, gb1 = dense_dw(S, a, want_bias=True)            # S^T a [H1, K] and S's column sums in one pass (dir_dense_dw_small_f32 at 80 x 64)
+    gC = gCt.t()
     gA, gWp = gAP[:K], gAP[K:]
-    return {"ids_h": hist[valid], "gh": gh, "ga": ga, "gW1": torch.cat([gA, gC, gA - gC, gWp], dim=0), "gb1": S.sum(dim=0),
+    return {"ids_h": hist[valid], "gh": gh, "ga": ga, "grows": grows, "gW1": torch.cat([gA, gC, gA - gC, gWp], dim=0), "gb1": gb1,
             "gW2": gW2, "gb2": gb2, "gW3": gW3, "gb3": gb3}
 
 

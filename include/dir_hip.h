@@ -361,6 +361,12 @@ int dir_dense_gated_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w
 int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K);
 int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
                             float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+/* The same product for small gradients (N, K <= 128; multiples of 4): fp32 FMAs on register tiles over row spans (exact fp32 products),
+ * for the tall-and-skinny TN products the library runs at 200 us -- the per-sample term of the DIN unit's first layer (S^T a, 80 x 64)
+ * and the narrow last layers of the towers.  Same arguments, workspace query and determinism as dir_dense_dw_bf16x3_f32. */
+int64_t dir_dense_dw_small_workspace_bytes(int64_t M, int N, int K);
+int dir_dense_dw_small_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
+                           float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 /* Backward of the units = 1 logit layer (models/DeepFM/deepFM.py:311-317, models/ESMM/ESMM.py:146) taken straight through the ReLU
  * of the hidden layer below it, in one pass (csrc/head_bwd.hip).  g = dL/dlogit [B], w = the logit layer's weight [N], y = the hidden
  * layer's output [B, N] (row stride y_ld):

@@ -851,6 +851,29 @@ def test_dense_dw_bf16x3_matches_float64(built_lib, M, N, K, gpad, xpad):
     assert torch.equal(auto, got) == (ops.dense_dw_auto_arith(M, N, K) == "bf16x3") or M < 16
 
 
+@pytest.mark.parametrize("M,N,K,gpad,xpad", [(65536, 80, 64, 0, 0), (5000, 128, 128, 0, 4), (2049, 4, 128, 4, 0), (3000, 84, 36, 0, 0), (7, 16, 8, 0, 0),
+                                              (40000, 48, 32, 8, 8), (33, 128, 4, 0, 0)])
+def test_dense_dw_small_matches_float64(built_lib, M, N, K, gpad, xpad):
+    """dir_dense_dw_small_f32 (the tall-and-skinny TN product on fp32 FMAs; the DIN unit's per-sample term is 80 x 64) against float64,
+    with the column sums of g; strided operands, every register-tile shape, bitwise reproducible."""
+    from dir_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    g = (torch.randn(M, N + gpad, generator=gen) * 0.5).cuda()[:, :N]
+    x = torch.randn(M, K + xpad, generator=gen).cuda()[:, :K]
+    ref = g.double().t() @ x.double()
+    got, gb = ops.dense_dw(g, x, arith="small", want_bias=True)
+    scale = 1 + M ** 0.5 * 0.5
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * scale
+    assert float((gb.double() - g.double().sum(0)).abs().max()) <= 1e-5 * scale
+    again, gb2 = ops.dense_dw(g, x, arith="small", want_bias=True)
+    assert torch.equal(again, got) and torch.equal(gb2, gb)
+    assert torch.equal(ops.dense_dw(g, x, arith="small"), got)
+    if M >= 2048 and N * K >= 512:
+        assert ops.dense_dw_auto_arith(M, N, K) == "small" and torch.equal(ops.dense_dw(g, x), got)
+    with pytest.raises(ValueError):
+        ops.dense_dw(torch.zeros(64, 132, device="cuda"), torch.zeros(64, 8, device="cuda"), arith="small")
+
+
 def test_dense_dw_bf16x3_edges(built_lib):
     from dir_amd import ops
     z, zb = ops.dense_dw(torch.empty(0, 24, device="cuda"), torch.empty(0, 36, device="cuda"), arith="bf16x3", want_bias=True)    # empty batch: zero gradients
