@@ -489,14 +489,14 @@ DENSE_DW_ARITH = os.environ.get("DIR_DENSE_DW_ARITH", "auto")        # "f32": th
 def dense_dw_auto_arith(M, N, K):
     """"bf16x3" where dir_dense_dw_bf16x3_f32 (weight and bias gradient in one pass) is the faster formulation (tools/dense_dw_probe.py,
     M = 65 536: 360 x 416 190 vs 243 us for the library GEMM + column sum, 208 x 416 135 vs 172, 1024 x 128 139 vs 178): a tall reduction
-    (>= 8192 rows), at least 200 output rows and 80 000 elements (200 x 360 ties, 128 x 1024 loses: 211 vs 151) and a block grid (256
+    (>= 8192 rows), at least 200 output rows and 70 000 elements (200 x 360: 97 vs 120 + the column sum; 128 x 1024 loses: 211 vs 151) and a block grid (256
     output rows x 8 / 13 / 16 column tiles) that pads the gradient by at most 1.4 (320 x 320 pads 1.6 and loses); otherwise "f32"."""
     if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or N % 4 or K % 4:
         return "f32"
     if N <= 128 and K <= 128:
         # tall and skinny (the DIN unit's per-sample term, 80 x 64: 215 us on the library, 137 on the MFMA kernel, ~25 on the FMA kernel)
         return "small" if M >= 2048 and N * K >= 512 else "f32"
-    if M < DENSE_DW_MIN_ROWS or N < 200 or N * K < 80000:
+    if M < DENSE_DW_MIN_ROWS or N < 200 or N * K < 70000:
         return "f32"
     nt, kt = -(-N // 16), -(-K // 16)
     kpad = min(-(-kt // 16) * 16, -(-kt // 13) * 13, -(-kt // 8) * 8)

@@ -890,7 +890,7 @@ def test_dense_dw_bf16x3_edges(built_lib):
     assert torch.allclose(ops.dense_dw(odd_g, odd_x), odd_g.t() @ odd_x, atol=1e-4)
     with pytest.raises(ValueError):
         ops.dense_dw(torch.randn(64, 24, device="cuda")[:, 1:21], odd_x, arith="bf16x3")        # a view that is not 16-byte aligned
-    assert ops.dense_dw_auto_arith(65536, 400, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 200, 360) == "f32"
+    assert ops.dense_dw_auto_arith(65536, 400, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 200, 360) == "bf16x3"
     assert ops.dense_dw_auto_arith(65536, 360, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 320, 320) == "f32"
     assert ops.dense_dw_auto_arith(65536, 128, 1024) == "f32" and ops.dense_dw_auto_arith(65536, 1024, 128) == "bf16x3"
     assert ops.dense_dw_auto_arith(4096, 400, 416) == "f32"
