@@ -264,8 +264,8 @@ static void ddw_reduce(const float* part, const float* bpart, int N, int K, int 
         hipLaunchKernelGGL(dense_dw_bf3_reduce_k<4>, dim3(grid_for((all + 63) / 64)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db);
 }
 
-// ---- small gradients (N, K <= 128): fp32 FMAs on a register tile ---------------------------------------------------------------------
-// The same product for outputs of at most 128 x 128 -- the per-sample term of the DIN unit's first layer (csrc/din_bwd_rows.hip: S^T a,
+// ---- small gradients (N <= 128, K <= 256): fp32 FMAs on a register tile ---------------------------------------------------------------------
+// The same product for outputs of at most 128 x 256 -- the per-sample term of the DIN unit's first layer (csrc/din_bwd_rows.hip: S^T a,
 // 80 x 64) and the narrow last layers of the towers.  The library runs these tall-and-skinny TN GEMMs at 200 us (65 536 rows, 80 x 64:
 // 37 MB of operands); the MFMA kernel above at 137 (its stage-split-multiply structure is mostly overhead here).  A workgroup owns a
 // span of rows; per step it stages 32 rows of both operands in LDS (16-byte loads) and every thread walks them with a TN x TK register
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void dense_dw_small_k(const float* __restrict_
                                                         int64_t M, int N, int K, int64_t rows_per_span, float* __restrict__ part,
                                                         float* __restrict__ bpart) {
     constexpr int R = 32;
-    __shared__ __attribute__((aligned(16))) float sg[R][128 + 4], sx[R][128 + 4];
+    __shared__ __attribute__((aligned(16))) float sg[R][128 + 4], sx[R][256 + 4];
     const int tid = threadIdx.x;
     const int ntk = (K + TK - 1) / TK, ntn = (N + TN - 1) / TN;
     const int in = tid / ntk, ik = tid % ntk;
@@ -377,9 +377,9 @@ extern "C" int dir_dense_dw_small_f32(const float* g, int64_t g_ld, const float*
         return DIR_OK;
     }
     DIR_CHECK_ARG(g && x && workspace && g_ld >= N && x_ld >= K, "%s: null pointer or row stride smaller than the width", name);
-    if (N > 128 || K > 128 || N % 4 || K % 4 || g_ld % 4 || x_ld % 4 || !aligned16(g) || !aligned16(x))
-        return fail(DIR_E_UNSUPPORTED, "%s: N=%d K=%d (<= 128), and N, K, g_ld=%lld, x_ld=%lld multiples of 4 with g / x 16-byte aligned", name, N, K,
-                    (long long)g_ld, (long long)x_ld);
+    if (N > 128 || K > 256 || ((N + 7) / 8) * ((K + 7) / 8) > 256 || N % 4 || K % 4 || g_ld % 4 || x_ld % 4 || !aligned16(g) || !aligned16(x))
+        return fail(DIR_E_UNSUPPORTED, "%s: N=%d (<= 128) K=%d (<= 256; at most 256 register tiles of 8 x 8), and N, K, g_ld=%lld, x_ld=%lld "
+                    "multiples of 4 with g / x 16-byte aligned", name, N, K, (long long)g_ld, (long long)x_ld);
     DIR_CHECK_ARG(aligned16(workspace) && workspace_bytes >= dir_dense_dw_small_workspace_bytes(M, N, K),
                   "%s: workspace must be 16-byte aligned and hold dir_dense_dw_small_workspace_bytes(M, N, K) bytes", name);
     const DdwSmallPlan p = ddw_small_plan(M, N, K);

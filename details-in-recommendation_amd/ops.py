@@ -493,7 +493,7 @@ def dense_dw_auto_arith(M, N, K):
     output rows x 8 / 13 / 16 column tiles) that pads the gradient by at most 1.4 (320 x 320 pads 1.6 and loses); otherwise "f32"."""
     if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or N % 4 or K % 4:
         return "f32"
-    if N <= 128 and K <= 128:
+    if N <= 128 and K <= 256 and -(-N // 8) * -(-K // 8) <= 256:
         # tall and skinny (the DIN unit's per-sample term, 80 x 64: 215 us on the library, 137 on the MFMA kernel, ~25 on the FMA kernel)
         return "small" if M >= 2048 and N * K >= 512 else "f32"
     if M < DENSE_DW_MIN_ROWS or N < 200 or N * K < 70000:
@@ -506,7 +506,7 @@ def dense_dw_auto_arith(M, N, K):
 def dense_dw(g, x, arith=None, want_bias=False):
     """dW [N, K] = g^T x, the kernel gradient of a dense layer (include/dir_hip.h: dir_dense_dw_bf16x3_f32): g [M, N], x [M, K], unit
     inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the MFMA kernel;
-    "small": the fp32 FMA kernel for N, K <= 128 (dir_dense_dw_small_f32).
+    "small": the fp32 FMA kernel for N <= 128, K <= 256 (dir_dense_dw_small_f32).
     want_bias: -> (dW, db) with db [N] = g.sum(0), the bias gradient (in the kernel's pass over g on the bf16x3 path)."""
     _dev(g, torch.float32, "g")
     _dev(x, torch.float32, "x")
@@ -520,8 +520,8 @@ def dense_dw(g, x, arith=None, want_bias=False):
         arith = dense_dw_auto_arith(M, N, K) if covered else "f32"
     if arith in ("bf16x3", "small") and not covered:
         raise ValueError("dense_dw(arith='%s'): N, K and the row strides must be multiples of 4, g and x 16-byte aligned" % arith)
-    if arith == "small" and (N > 128 or K > 128):
-        raise ValueError("dense_dw(arith='small') covers N, K <= 128")
+    if arith == "small" and (N > 128 or K > 256 or -(-N // 8) * -(-K // 8) > 256):
+        raise ValueError("dense_dw(arith='small') covers N <= 128, K <= 256 (at most 256 register tiles of 8 x 8)")
     if arith == "f32":
         if M >= 8192 and M % 16 == 0 and g.is_contiguous() and x.is_contiguous():
             dW = torch.bmm(g.view(16, M // 16, N).transpose(1, 2), x.view(16, M // 16, K)).sum(dim=0)

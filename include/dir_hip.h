@@ -361,7 +361,7 @@ int dir_dense_gated_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w
 int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K);
 int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
                             float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
-/* The same product for small gradients (N, K <= 128; multiples of 4): fp32 FMAs on register tiles over row spans (exact fp32 products),
+/* The same product for small gradients (N <= 128, K <= 256, at most 256 tiles of 8 x 8; multiples of 4): fp32 FMAs on register tiles over row spans (exact fp32 products),
  * for the tall-and-skinny TN products the library runs at 200 us -- the per-sample term of the DIN unit's first layer (S^T a, 80 x 64)
  * and the narrow last layers of the towers.  Same arguments, workspace query and determinism as dir_dense_dw_bf16x3_f32. */
 int64_t dir_dense_dw_small_workspace_bytes(int64_t M, int N, int K);

@@ -852,7 +852,7 @@ def test_dense_dw_bf16x3_matches_float64(built_lib, M, N, K, gpad, xpad):
 
 
 @pytest.mark.parametrize("M,N,K,gpad,xpad", [(65536, 80, 64, 0, 0), (5000, 128, 128, 0, 4), (2049, 4, 128, 4, 0), (3000, 84, 36, 0, 0), (7, 16, 8, 0, 0),
-                                              (40000, 48, 32, 8, 8), (33, 128, 4, 0, 0)])
+                                              (40000, 48, 32, 8, 8), (33, 128, 4, 0, 0), (65536, 80, 200, 0, 0), (4000, 64, 256, 0, 0), (3000, 128, 128, 0, 0)])
 def test_dense_dw_small_matches_float64(built_lib, M, N, K, gpad, xpad):
     """dir_dense_dw_small_f32 (the tall-and-skinny TN product on fp32 FMAs; the DIN unit's per-sample term is 80 x 64) against float64,
     with the column sums of g; strided operands, every register-tile shape, bitwise reproducible."""
@@ -872,6 +872,8 @@ def test_dense_dw_small_matches_float64(built_lib, M, N, K, gpad, xpad):
         assert ops.dense_dw_auto_arith(M, N, K) == "small" and torch.equal(ops.dense_dw(g, x), got)
     with pytest.raises(ValueError):
         ops.dense_dw(torch.zeros(64, 132, device="cuda"), torch.zeros(64, 8, device="cuda"), arith="small")
+    with pytest.raises(ValueError):
+        ops.dense_dw(torch.zeros(64, 128, device="cuda"), torch.zeros(64, 256, device="cuda"), arith="small")       # 512 tiles of 8 x 8
 
 
 def test_dense_dw_bf16x3_edges(built_lib):
