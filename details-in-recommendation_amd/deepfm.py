@@ -165,9 +165,10 @@ class DeepFM(nn.Module):
                 net = self.bns[i](net)
         return self._logits_of(net)                                              # :311-317
 
-    def dnn_fm_logit_fn(self, features, device):
+    def dnn_fm_logit_fn(self, features, device, got=None):
         emb_ts, _ = self._tablesets()
-        got = collect_ids(self.dnn_feature_columns, features, device)
+        if got is None:
+            got = collect_ids(self.dnn_feature_columns, features, device)
         train = torch.is_grad_enabled()                                          # autograd path: HIP forward + HIP/sparse backward
         max_norm = self._max_norm()
         if got[0] == "onehot" and max_norm:                                      # clipping needs the bag kernel: one-entry bags
@@ -193,16 +194,25 @@ class DeepFM(nn.Module):
                 fm = ops.fm_logit(emb, self.F, self.K)
         return fm + self.dnn_logit_fn(emb)                                       # deepFM.py:337-338 ([B,1] + [B,units] broadcasts)
 
+    def _same_categoricals(self):
+        same = getattr(self, "_same_cats", None)
+        if same is None:
+            a = [categorical_of(c) for c in self.dnn_feature_columns]
+            b = [categorical_of(c) for c in self.linear_feature_columns]
+            same = self._same_cats = len(a) == len(b) and all(x is y for x, y in zip(a, b))
+        return same
+
     def _max_norm(self):
         mn = [getattr(c, "max_norm", None) for c in self.dnn_feature_columns]
         if any(m != mn[0] for m in mn):
             raise NotImplementedError("embedding columns of one DeepFM must share max_norm (one value per launch)")
         return mn[0] if mn else None
 
-    def linear_logit_fn(self, features, device):
+    def linear_logit_fn(self, features, device, got=None):
         """_linear_logit_fn_builder (deepFM.py:255-275): linear_model(units, sparse_combiner) + bias -> [B, units]."""
         _, lin_ts = self._tablesets()
-        got = collect_ids(self.linear_feature_columns, features, device)
+        if got is None:
+            got = collect_ids(self.linear_feature_columns, features, device)
         train = torch.is_grad_enabled()
         if self.units == 1 and got[0] == "onehot":
             if train:
@@ -234,10 +244,14 @@ class DeepFM(nn.Module):
             raise ValueError("features should be a dictionary of `Tensor`s. Given type: {}".format(type(features)))  # :159-161
         device = self.linear_bias.device
         logits = None
+        got = None
         if self.dnn_feature_columns:
-            logits = self.dnn_fm_logit_fn(features, device)
+            got = collect_ids(self.dnn_feature_columns, features, device)
+            logits = self.dnn_fm_logit_fn(features, device, got)
         if self.linear_feature_columns:
-            lin = self.linear_logit_fn(features, device)
+            # the DeepFM case (deepFM.py:89-95): the linear columns ARE the dnn columns' categorical columns -- one id matrix (and one
+            # range check) serves both terms, and their sorted sparse updates see the same tensor
+            lin = self.linear_logit_fn(features, device, got if (got is not None and self._same_categoricals()) else None)
             logits = lin if logits is None else logits + lin                     # add_n, deepFM.py:223
         raise_pending()                                                          # the id-range verdicts (checked on the device, read here)
         return logits
