@@ -661,7 +661,10 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
                                 const float* grad, int64_t grad_ld, int64_t grad_fs, int64_t B, const int64_t* row_base,
                                 int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
                                 const int64_t* payload = nullptr /* payload mode: B entries, ids unused, grad is [B, K] */,
-                                const float* fm_g = nullptr, const float* fm_sum = nullptr /* fold the FM backward in (AdagradUpd only) */) {
+                                const float* fm_g = nullptr, const float* fm_sum = nullptr /* fold the FM backward in (AdagradUpd only) */,
+                                const void* sorted_from = nullptr /* the workspace of an earlier sorted update of the SAME entries (ids,
+                                                                     strides, B, F, row_base, total_rows) on this stream: its sorted
+                                                                     (row, entry) pairs are used and the sort is skipped */) {
     const int nt = payload ? F : 0;        // tables to search by key
     if (payload) {                         // entries are a flat list: one "slot" per entry
         ids = payload;
@@ -684,7 +687,12 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
     uint32_t* v0 = reinterpret_cast<uint32_t*>(ws + p.off_vals[0]);
     uint32_t* v1 = reinterpret_cast<uint32_t*>(ws + p.off_vals[1]);
     float* carry = reinterpret_cast<float*>(ws + p.off_carry);
-    if (payload)
+    if (sorted_from) {                     // the pair arrays sit at offsets that depend on the entry count only
+        if (reinterpret_cast<uintptr_t>(sorted_from) & 255u) return fail(DIR_E_BADARG, "%s: sorted_from must be a 256-byte aligned workspace", name);
+        char* src = const_cast<char*>(static_cast<const char*>(sorted_from));
+        k1 = reinterpret_cast<uint32_t*>(src + p.off_keys[1]);
+        v1 = reinterpret_cast<uint32_t*>(src + p.off_vals[1]);
+    } else if (payload)
         hipLaunchKernelGGL(adagrad_keys_payload_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, payload, nt, n, row_base,
                            (uint32_t)total_rows, k0, v0);
     else
@@ -692,7 +700,7 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
                            (uint32_t)total_rows, k0, v0);
     DIR_CHECK_LAUNCH(name);
     size_t tmp = p.tmp_bytes;
-    if (ada_sort_pairs(ws + p.off_tmp, tmp, k0, k1, v0, v1, (size_t)n, p.bits, st) != hipSuccess)
+    if (!sorted_from && ada_sort_pairs(ws + p.off_tmp, tmp, k0, k1, v0, v1, (size_t)n, p.bits, st) != hipSuccess)
         return fail(DIR_E_HIP, "%s: radix sort failed", name);
     const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && (grad_fs % 4 == 0) && aligned16(grad) && (!fm_sum || aligned16(fm_sum));
     int lps = 1;
@@ -771,6 +779,36 @@ extern "C" int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* ac
     DIR_CHECK_ARG(lr > 0.f && l1 >= 0.f && l2 >= 0.f, "dir_sparse_ftrl_sorted_f32: lr=%g l1=%g l2=%g", lr, l1, l2);
     return sparse_sorted_update("dir_sparse_ftrl_sorted_f32", FtrlUpd{tables, accums, linears, lr, l1, l2, (int64_t)K}, F, K, ids, stride_b,
                                 stride_f, grad, grad_ld, grad_slot_stride, B, row_base, total_rows, workspace, workspace_bytes, stream);
+}
+
+// The two updates of one training step of a DeepFM -- Adagrad on the embedding tables (deepFM.py:61), FTRL on the linear columns (:58) --
+// see the same (row, entry) pairs when both table sets have the same vocabularies: the second one takes the first one's sorted pairs.
+extern "C" int dir_sparse_adagrad_sorted_rows_from_f32(float* const* tables, float* const* accums, int64_t row_ld, int F, int K,
+                                                       const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad,
+                                                       int64_t grad_ld, const float* fm_g, const float* fm_sum, float lr, int64_t B,
+                                                       const int64_t* row_base, int64_t total_rows, void* workspace,
+                                                       int64_t workspace_bytes, const void* sorted_from, dir_stream_t stream) {
+    const char* name = "dir_sparse_adagrad_sorted_rows_from_f32";
+    DIR_CHECK_ARG(tables && accums && sorted_from, "%s: null pointer", name);
+    DIR_CHECK_ARG(row_ld >= K && (!grad || grad_ld >= (int64_t)F * K), "%s: row_ld / grad_ld", name);
+    DIR_CHECK_ARG((fm_g == nullptr) == (fm_sum == nullptr), "%s: fm_g and fm_sum go together", name);
+    if (K % 4 == 0 && (row_ld & 3)) return fail(DIR_E_UNSUPPORTED, "%s: row_ld must be a multiple of 4", name);
+    return sparse_sorted_update(name, AdagradUpd{tables, accums, lr, row_ld}, F, K, ids, stride_b, stride_f, grad,
+                                grad ? grad_ld : (int64_t)F * K, (int64_t)K, B, row_base, total_rows, workspace, workspace_bytes, stream, nullptr,
+                                fm_g, fm_sum, sorted_from);
+}
+
+extern "C" int dir_sparse_ftrl_sorted_from_f32(float* const* tables, float* const* accums, float* const* linears, int F, int K,
+                                               const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld,
+                                               int64_t grad_slot_stride, float lr, float l1, float l2, int64_t B, const int64_t* row_base,
+                                               int64_t total_rows, void* workspace, int64_t workspace_bytes, const void* sorted_from,
+                                               dir_stream_t stream) {
+    const char* name = "dir_sparse_ftrl_sorted_from_f32";
+    DIR_CHECK_ARG(tables && accums && linears && sorted_from, "%s: null pointer", name);
+    DIR_CHECK_ARG(lr > 0.f && l1 >= 0.f && l2 >= 0.f, "%s: lr=%g l1=%g l2=%g", name, lr, l1, l2);
+    return sparse_sorted_update(name, FtrlUpd{tables, accums, linears, lr, l1, l2, (int64_t)K}, F, K, ids, stride_b, stride_f, grad, grad_ld,
+                                grad_slot_stride, B, row_base, total_rows, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr,
+                                sorted_from);
 }
 
 extern "C" int dir_fm_second_order_backward_f32(const float* emb, int64_t emb_ld, const float* g, const float* add_in,

@@ -280,7 +280,9 @@ class DeepFM(nn.Module):
                     p.data = view
                 self._emb_ts = emb_ts
                 self._ts_key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
-        return ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()
+        self._sparse_adagrad = ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()
+        self._link_sparse_optimisers()
+        return self._sparse_adagrad
 
     def fused_sparse_ftrl(self, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
         """Attach the fused HIP sparse FTRL update to the linear weight columns (linear_optimizer='Ftrl', deepFM.py:58):
@@ -288,7 +290,15 @@ class DeepFM(nn.Module):
         _, lin_ts = self._tablesets()
         if lin_ts is None:
             raise ValueError("fused_sparse_ftrl: the model has no linear feature columns")
-        return ops.SparseFtrl(lin_ts, lr, initial_accumulator_value, l1, l2).attach()
+        self._sparse_ftrl = ops.SparseFtrl(lin_ts, lr, initial_accumulator_value, l1, l2).attach()
+        self._link_sparse_optimisers()
+        return self._sparse_ftrl
+
+    def _link_sparse_optimisers(self):
+        """Adagrad on the embedding tables and FTRL on the linear columns of the SAME categorical columns see the same ids: one sort."""
+        a, f = getattr(self, "_sparse_adagrad", None), getattr(self, "_sparse_ftrl", None)
+        if a is not None and f is not None and self._same_categoricals():
+            ops.share_sorted_entries(a, f)
 
     def pack_for_serving(self):
         """Inference-only: copy the embedding tables and the first-order weights of the same categorical columns into

@@ -1049,6 +1049,47 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
     return dx0, dxk, dW
 
 
+class _SortedShare:
+    """Two sorted sparse updates of one training step that see the same (row, entry) pairs -- DeepFM's Adagrad on the embedding tables
+    and FTRL on the linear columns of the same categorical columns (deepFM.py:58,61) -- sort once: whichever runs first in backward()
+    leaves a token (the id tensor's identity and version, its layout, the stream) and its workspace, the other takes the sorted pairs
+    from it (include/dir_hip.h: dir_sparse_*_sorted_*_from_f32).  A token is used at most once and only by the other optimiser."""
+
+    def __init__(self):
+        self.token = None
+        self.owner = None
+        self.ws = None
+        self.ws_tensor = None
+        self.hits = 0                       # sorts saved so far
+
+    @staticmethod
+    def _token(ids, B, sb, sf):
+        return (ids.data_ptr(), ids._version, B, sb, sf, torch.cuda.current_stream(ids.device).cuda_stream)
+
+    def take(self, who, ids, B, sb, sf):
+        """-> the other optimiser's workspace pointer if it sorted exactly these entries last, else None."""
+        if self.token is not None and self.owner is not who and self.token == self._token(ids, B, sb, sf) \
+                and self.owner._ws is self.ws_tensor:               # (the owner's workspace has not been reallocated since)
+            ws = self.ws
+            self.token = None
+            self.hits += 1
+            return ws
+        return None
+
+    def leave(self, who, ids, B, sb, sf, ws):
+        self.token, self.owner, self.ws, self.ws_tensor = self._token(ids, B, sb, sf), who, ws, who._ws
+
+
+def share_sorted_entries(a, b):
+    """Let two sorted sparse optimisers over table sets with the same vocabularies share one sort per step (see _SortedShare).
+    -> True if they were linked."""
+    if list(a.ts.vocab) != list(b.ts.vocab) or a.ts.F != b.ts.F or getattr(a, "method", "sorted") != "sorted" \
+            or os.environ.get("DIR_SHARE_SORT", "1") == "0":           # (development switch for A/B runs)
+        return False
+    a._share = b._share = _SortedShare()
+    return True
+
+
 class SparseAdagrad:
     """Fused sparse Adagrad over a TableSet.  Holds the accumulators ([TF-upstream] initial_accumulator_value = 0.1).
     method "sorted" (default; include/dir_hip.h: dir_sparse_adagrad_sorted_f32): radix sort of (row, entry) pairs +
@@ -1079,6 +1120,21 @@ class SparseAdagrad:
         self.head = torch.full((self.total_rows,), -1, dtype=torch.int32, device=dev) if method == "chains" else None
         self._next = None
         self._ws = None
+        self._share = None
+
+    def _rows_update(self, lib, ids, B, sb, sf, grad, fm_g, fm_sum):
+        """dir_sparse_adagrad_sorted_rows_f32, or its _from form when the linked optimiser has just sorted the same entries."""
+        ts = self.ts
+        ws, need = self._sorted_ws(lib, B)
+        src = self._share.take(self, ids, B, sb, sf) if self._share is not None else None
+        args = (_ptr(ts._ptrs), _ptr(self.acc_ptrs), ts.ld, ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad), grad.stride(0) if grad is not None else 0,
+                _ptr(fm_g), _ptr(fm_sum), self.lr, B, _ptr(self.head_base), self.total_rows, ws, need)
+        if src is not None:
+            _lib.check(lib.dir_sparse_adagrad_sorted_rows_from_f32(*args, src, _stream()))
+            return
+        _lib.check(lib.dir_sparse_adagrad_sorted_rows_f32(*args, _stream()))
+        if self._share is not None:
+            self._share.leave(self, ids, B, sb, sf, ws)
 
     def attach(self):
         """Consume the gather's row gradients directly in backward (autograd.GatherFm): loss.backward() then
@@ -1115,12 +1171,7 @@ class SparseAdagrad:
             raise ValueError("fm_g must be a contiguous [B] / [B, 1] tensor and fm_sum a contiguous [B, K] one")
         if B == 0:
             return
-        lib = _lib.load()
-        ws, need = self._sorted_ws(lib, B)
-        _lib.check(lib.dir_sparse_adagrad_sorted_rows_f32(_ptr(ts._ptrs), _ptr(self.acc_ptrs), ts.ld, ts.F, ts.K, _ptr(ids), sb, sf,
-                                                          _ptr(grad), grad.stride(0) if grad is not None else 0, _ptr(fm_g),
-                                                          _ptr(fm_sum), self.lr, B, _ptr(self.head_base), self.total_rows, ws, need,
-                                                          _stream()))
+        self._rows_update(_lib.load(), ids, B, sb, sf, grad, fm_g, fm_sum)
 
     def step(self, ids, grad):
         """ids [B, F] int64 (any strides), grad [B, F*K] fp32: d loss / d gathered rows."""
@@ -1131,13 +1182,10 @@ class SparseAdagrad:
         if grad.shape != (B, ts.F * ts.K) or grad.stride(1) != 1:
             raise ValueError("grad must be [B, F*K] with unit inner stride")
         lib = _lib.load()
-        if ts.ld != ts.K:
+        if ts.ld != ts.K or (self._share is not None and self.method == "sorted"):
             if B == 0:
                 return
-            ws, need = self._sorted_ws(lib, B)
-            _lib.check(lib.dir_sparse_adagrad_sorted_rows_f32(_ptr(ts._ptrs), _ptr(self.acc_ptrs), ts.ld, ts.F, ts.K, _ptr(ids), sb, sf,
-                                                              _ptr(grad), grad.stride(0), None, None, self.lr, B,
-                                                              _ptr(self.head_base), self.total_rows, ws, need, _stream()))
+            self._rows_update(lib, ids, B, sb, sf, grad, None, None)
             return
         if self.method == "chains":
             if self._next is None or self._next.numel() < B * ts.F:
@@ -1206,6 +1254,7 @@ class SparseFtrl:
         self.total_rows = sum(self.ts.vocab)
         self.row_base = torch.tensor(base, dtype=torch.int64, device=dev)
         self._ws = None
+        self._share = None
 
     def attach(self):
         """Consume the linear term's gradient directly in backward (autograd.LinearLogit)."""
@@ -1229,10 +1278,16 @@ class SparseFtrl:
         if self._ws is None or self._ws.numel() < need + 256:
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=ts.device)
         off = (-self._ws.data_ptr()) % 256
-        _lib.check(lib.dir_sparse_ftrl_sorted_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), _ptr(self.lin_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
-                                                  _ptr(grad), grad.stride(0), slot_stride, self.lr, self.l1, self.l2, B,
-                                                  _ptr(self.row_base), self.total_rows,
-                                                  ctypes.c_void_p(self._ws.data_ptr() + off), need, _stream()))
+        ws = ctypes.c_void_p(self._ws.data_ptr() + off)
+        args = (_ptr(ts.ptrs), _ptr(self.acc_ptrs), _ptr(self.lin_ptrs), ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad), grad.stride(0), slot_stride,
+                self.lr, self.l1, self.l2, B, _ptr(self.row_base), self.total_rows, ws, need)
+        src = self._share.take(self, ids, B, sb, sf) if self._share is not None else None
+        if src is not None:
+            _lib.check(lib.dir_sparse_ftrl_sorted_from_f32(*args, src, _stream()))
+            return
+        _lib.check(lib.dir_sparse_ftrl_sorted_f32(*args, _stream()))
+        if self._share is not None:
+            self._share.leave(self, ids, B, sb, sf, ws)
 
 
 class PackedTables:

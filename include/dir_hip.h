@@ -534,6 +534,22 @@ int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* accums, float
                                int64_t grad_slot_stride, float lr, float l1, float l2, int64_t B, const int64_t* row_base,
                                int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 
+/* The same two updates taking their sorted (row, entry) pairs from the workspace of an EARLIER sorted update of the same entries on the
+ * same stream (same ids / strides / B / F and the same vocabularies, i.e. equal row_base and total_rows; sorted_from = that call's
+ * 256-byte aligned workspace, still intact): the key building and the radix sort are skipped.  One training step of a DeepFM updates
+ * the embedding tables (Adagrad, deepFM.py:61) and the linear columns (FTRL, :58) from the same ids; results are bit-identical to the
+ * calls that sort themselves. */
+int dir_sparse_adagrad_sorted_rows_from_f32(float* const* tables, float* const* accums, int64_t row_ld, int F, int K,
+                                            const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad,
+                                            int64_t grad_ld, const float* fm_g, const float* fm_sum, float lr, int64_t B,
+                                            const int64_t* row_base, int64_t total_rows, void* workspace,
+                                            int64_t workspace_bytes, const void* sorted_from, dir_stream_t stream);
+int dir_sparse_ftrl_sorted_from_f32(float* const* tables, float* const* accums, float* const* linears, int F, int K,
+                                    const int64_t* ids, int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld,
+                                    int64_t grad_slot_stride, float lr, float l1, float l2, int64_t B, const int64_t* row_base,
+                                    int64_t total_rows, void* workspace, int64_t workspace_bytes, const void* sorted_from,
+                                    dir_stream_t stream);
+
 /* Diagnostic only (never on the product path): cycle stamps of the DIR_CIN_STAMP=1 build of the CIN kernel, summed
  * over waves since the last call: [0] chunk start -> end of its MFMA stream, [1] -> past the chunk barrier,
  * [2] chunks, [3] prologue, [4] epilogue, [5] waves.  Synchronises the device. */

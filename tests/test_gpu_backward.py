@@ -1080,6 +1080,51 @@ def test_deepfm_packed_training_matches_split(built_lib):
     assert sd["embedding_weights.0"].shape == (V, K)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_deepfm_sparse_optimisers_share_one_sort(built_lib, packed):
+    """Adagrad on the embedding tables and FTRL on the linear columns of the same categorical columns see the same id matrix: the second
+    update of a step takes the first one's sorted (row, entry) pairs (dir_sparse_*_sorted_*_from_f32).  Same tables, accumulators and
+    linear weights, bit for bit, as two updates that sort themselves; a changed id tensor or a reallocated workspace is not shared."""
+    from dir_amd import feature_column as fc
+    from dir_amd.deepfm import DeepFM
+    F, V, K, B = 5, 300, 16, 1500
+    def build():
+        torch.manual_seed(21)
+        cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+        m = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[32, 16], fm_embedding_size=K).cuda()
+        return m, m.fused_sparse_adagrad(lr=0.05, packed=packed), m.fused_sparse_ftrl(lr=0.1, l1=0.001)
+    (a, a_ada, a_ftrl), (b, b_ada, b_ftrl) = build(), build()
+    assert a_ada._share is not None and a_ada._share is a_ftrl._share
+    b_ada._share = b_ftrl._share = None                              # b: every update sorts for itself
+    def dense_params(m):
+        skip = {id(p) for p in m.embedding_weights} | {id(p) for p in m.linear_weights}
+        return [p for p in m.parameters() if id(p) not in skip]
+    oa, ob = torch.optim.SGD(dense_params(a), lr=0.05), torch.optim.SGD(dense_params(b), lr=0.05)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    for step in range(4):
+        ids = torch.randint(-1 if step == 2 else 0, V, (B + 7 * step, F), generator=g, device="cuda")      # a growing batch: workspaces get reallocated
+        feats = {"C%d" % f: ids[:, f] for f in range(F)}
+        y = (torch.rand((ids.shape[0], 1), generator=g, device="cuda") < 0.3).float()
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad(set_to_none=True)
+            torch.nn.functional.binary_cross_entropy_with_logits(m(feats), y).backward()
+            o.step()
+    assert a_ada._share.hits == 4                                    # one sort saved per step
+    for pa, pb in zip(list(a.embedding_weights) + list(a.linear_weights), list(b.embedding_weights) + list(b.linear_weights)):
+        assert torch.equal(pa.data, pb.data)
+    for xa, xb in zip(a_ada.accums + a_ftrl.accums + a_ftrl.linears, b_ada.accums + b_ftrl.accums + b_ftrl.linears):
+        assert torch.equal(xa, xb)
+    # a token is bound to the id tensor: another tensor (same values) is not shared
+    sh = a_ada._share
+    ids2 = ids.clone()
+    gr = torch.zeros((ids.shape[0], 1), device="cuda")
+    a_ftrl.step(ids, gr)
+    assert sh.token is not None
+    a_ada.step(ids2, torch.zeros((ids.shape[0], F * K), device="cuda"))
+    assert sh.hits == 4
+
+
 @pytest.mark.parametrize("normalize", [True, False])
 @pytest.mark.parametrize("B,T,H1,H2", [(300, 50, 80, 40), (67, 64, 80, 48), (41, 17, 36, 20), (9, 5, 64, 32), (130, 33, 72, 44)])
 def test_din_rows_backward_matches_single_kernel(built_lib, normalize, B, T, H1, H2):
