@@ -561,7 +561,7 @@ def main():
                       "convert_label": (torch.rand((B, 1), generator=gen, device=device) < 0.05).float()}
             dense_p = [p for n, p in model.named_parameters() if "embedding_weights" not in n]
             opt_d = torch.optim.Adagrad(dense_p, lr=0.05, initial_accumulator_value=0.1, eps=0.0)
-            sparse_opts = model.ctr_model.input_layer.fused_sparse_adagrad(0.05) + model.cvr_model.input_layer.fused_sparse_adagrad(0.05)
+            sparse_opts = model.fused_sparse_adagrad(0.05)        # both towers' tables; the two sorted updates share one sort per step
             cfg["sparse_optimizers"] = len(sparse_opts)
 
             def step(i):

@@ -148,10 +148,20 @@ def raise_pending(block=None):
             raise ValueError(describe())
 
 
-def collect_ids(columns, features, device):
+def collect_ids(columns, features, device, memo=None):
     """columns: categorical columns (or embedding/indicator wrappers).
-    -> ("onehot", ids_view [B,F])  or  ("ragged", values, offsets [F*B+1], weights|None, B)"""
+    -> ("onehot", ids_view [B,F])  or  ("ragged", values, offsets [F*B+1], weights|None, B)
+    memo: a dict that lives for ONE forward over one features dict -- a second request for the same categorical columns (ESMM's two
+    towers read the same 26 columns into their own tables) gets the same tensors back: one stack, one range check, and the two
+    towers' sorted sparse updates see one id tensor."""
     cats = [categorical_of(c) for c in columns]
+    if memo is not None:
+        key = tuple(id(c) for c in cats)
+        if key in memo:
+            return memo[key]
+        out = collect_ids(columns, features, device)
+        memo[key] = out
+        return out
     got = [c.ids(features, device) for c in cats]
     if all(not isinstance(g, tuple) for g in got):
         B = got[0].numel()

@@ -36,8 +36,8 @@ class _BaseModel(nn.Module):
         _glorot_uniform_(self.logits.weight)
         nn.init.zeros_(self.logits.bias)
 
-    def forward(self, features):
-        net = self.input_layer(features)
+    def forward(self, features, memo=None):
+        net = self.input_layer(features, memo=memo)
         if not self.dropout and mlp_stack_supported(self.hidden, net, self.activation):
             if mlp_head_supported(self.hidden, self.logits, net, self.activation):
                 return mlp_head(self.hidden, self.logits, net)                           # training: tower + logit layer as one autograd node
@@ -61,14 +61,25 @@ class ESMM(nn.Module):
 
     def forward(self, features):
         """-> {'ctr_logits', 'ctcvr_logits'} (the `logits` dict of ESMM.py:77)."""
-        ctr_logits = self.ctr_model(features)
-        cvr_logits = self.cvr_model(features)
+        memo = {}                                                                # both towers read the same columns: one id matrix
+        ctr_logits = self.ctr_model(features, memo)
+        cvr_logits = self.cvr_model(features, memo)
         ctcvr_logistic = torch.sigmoid(ctr_logits) * torch.sigmoid(cvr_logits)  # :69-71
         p = ctcvr_logistic.clamp(_EPSILON, 1 - _EPSILON)                         # :73-74
         out = {"ctr_logits": ctr_logits, "ctcvr_logits": torch.log(p / (1 - p)), "cvr_logits": cvr_logits}
         from ._input import raise_pending
         raise_pending()                                                          # id-range verdicts of both towers' input layers
         return out
+
+    def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
+        """The fused sparse Adagrad on both towers' embedding tables (InputLayer.fused_sparse_adagrad); the two towers see the same
+        ids, so their sorted updates share one sort per step (ops.share_sorted_entries).  -> the optimiser objects."""
+        from . import ops
+        a = self.ctr_model.input_layer.fused_sparse_adagrad(lr, initial_accumulator_value)
+        b = self.cvr_model.input_layer.fused_sparse_adagrad(lr, initial_accumulator_value)
+        for x, y in zip(a, b):
+            ops.share_sorted_entries(x, y)
+        return a + b
 
     def get_loss(self, features, labels, logits):
         """_get_loss (ESMM.py:150-175): labels {'click_label', 'convert_label'}; CTR and CTCVR sigmoid cross entropies, each

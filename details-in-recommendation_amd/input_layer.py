@@ -90,14 +90,14 @@ class InputLayer(nn.Module):
             ind[torch.arange(B, device=device)[ok], ids[ok]] = 1.0
         return ind
 
-    def _forward_train(self, features, device):
+    def _forward_train(self, features, device, memo=None):
         """Differentiable path: every column's block is its own tensor, concatenated in name order (autograd tracks
         the concat; the embedding blocks carry sparse table gradients, see autograd.EmbeddingBag)."""
         blocks, inside = {}, set()
         for ts, idxs, comb, mn in self._tablesets():
             cols = [self.emb_cols[i] for i in idxs]
             tabs = [self.embedding_weights[i] for i in idxs]
-            got = collect_ids(cols, features, device)
+            got = collect_ids(cols, features, device, memo)
             if got[0] == "onehot":
                 blk = ag.embedding_bag(ts, got[1], tabs, max_norm=mn)
             else:
@@ -117,14 +117,14 @@ class InputLayer(nn.Module):
                 pieces.append(blocks[c.name])
         return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=1)
 
-    def forward(self, features, pad_to=1):
+    def forward(self, features, pad_to=1, memo=None):
         """-> x0 [B, column_num].  pad_to = 4 (inference only): x0 is returned as [B, round_up(column_num, 4)] whose extra
         columns are zero -- the row stride the 16-byte paths of dir_dcn_cross_f32 / dir_dense_f32 want when column_num is odd
         (DCN's 26 x 16 + 13 = 429): written once here, no padded copy later."""
         device = self.embedding_weights[0].device if len(self.embedding_weights) else next(iter(
             v for v in features.values() if isinstance(v, torch.Tensor))).device
         if torch.is_grad_enabled():
-            return self._forward_train(features, device)
+            return self._forward_train(features, device, memo)
         B = None
         x0 = None
 
@@ -159,7 +159,7 @@ class InputLayer(nn.Module):
         flush()
         for ts, idxs, comb, mn in self._tablesets():
             cols = [self.emb_cols[i] for i in idxs]
-            got = collect_ids(cols, features, device)
+            got = collect_ids(cols, features, device, memo)
             nb = got[1].shape[0] if got[0] == "onehot" else got[4]
             if x0 is None:
                 B = nb

@@ -690,6 +690,43 @@ def test_esmm_and_dcn_training_with_reference_losses(built_lib):
     assert m["auc"] > 0.9 and m["accuracy"] > m["accuracy_baseline"] and 0.0 < m["average_loss"] < 0.7, m
 
 
+def test_esmm_towers_share_ids_and_one_sort(built_lib):
+    """ESMM's two towers read the same columns into their own tables: one id matrix per forward (collect_ids memo) and one sort per step
+    for their two fused sparse Adagrad updates (ESMM.fused_sparse_adagrad) -- tables and accumulators bit-identical to towers that
+    collect and sort for themselves."""
+    from dir_amd.esmm import ESMM
+    from dir_amd import feature_column as fc
+    F, V, K, B = 6, 200, 16, 1024
+    def build(shared):
+        torch.manual_seed(31)
+        cols = [fc.embedding_column(fc.categorical_column_with_identity("C%d" % i, V), K) for i in range(F)]
+        m = ESMM(columns=cols, dnn_hidden_units=[32, 16]).cuda()
+        if shared:
+            opts = m.fused_sparse_adagrad(0.05)
+        else:
+            opts = m.ctr_model.input_layer.fused_sparse_adagrad(0.05) + m.cvr_model.input_layer.fused_sparse_adagrad(0.05)
+        dense = [p for n, p in m.named_parameters() if "embedding_weights" not in n]
+        return m, opts, torch.optim.SGD(dense, lr=0.05)
+    (a, oa, da), (b, ob, db) = build(True), build(False)
+    assert oa[0]._share is not None and oa[0]._share is oa[1]._share and ob[0]._share is None
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for _ in range(3):
+        ids = torch.randint(0, V, (B, F), generator=g, device="cuda")
+        feats = {"C%d" % f: ids[:, f].contiguous() for f in range(F)}
+        labels = {"click_label": (torch.rand((B, 1), generator=g, device="cuda") < 0.3).float(),
+                  "convert_label": (torch.rand((B, 1), generator=g, device="cuda") < 0.1).float()}
+        for m, d in ((a, da), (b, db)):
+            d.zero_grad(set_to_none=True)
+            loss, _ = m.get_loss(feats, labels, m(feats))
+            loss.backward()
+            d.step()
+    assert oa[0]._share.hits == 3
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and torch.equal(pa.data, pb.data), na
+    for xa, xb in zip(oa[0].accums + oa[1].accums, ob[0].accums + ob[1].accums):
+        assert torch.equal(xa, xb)
+
+
 @pytest.mark.parametrize("normalize", [False, True])
 def test_din_fused_backward_matches_composite(built_lib, normalize, monkeypatch):
     """The fused HIP backward against the GPU composite it replaces (same inputs, hist_len = None, pruned ids and a pruned
