@@ -690,6 +690,31 @@ def test_esmm_and_dcn_training_with_reference_losses(built_lib):
     assert m["auc"] > 0.9 and m["accuracy"] > m["accuracy_baseline"] and 0.0 < m["average_loss"] < 0.7, m
 
 
+def test_train_step_clips_table_gradients_by_their_dense_norm(built_lib):
+    """train_spec.TrainStep on an embedding table's sparse gradient (duplicate ids): tf.clip_by_norm over the dense-equivalent gradient
+    (DeepCrossNetwork.py:281-286), whose norm is taken from the looked-up rows only -- sum_i <vals_i, S_row(i)> -- not from a pass over
+    the table."""
+    from dir_amd.train_spec import TrainStep, CLIP_NORM
+    V, K, B = 500, 8, 3000
+    torch.manual_seed(2)
+    emb = torch.nn.Embedding(V, K, sparse=True).cuda()
+    ids = torch.randint(0, 40, (B,), device="cuda")                      # heavy duplication
+    coef = torch.randn(B, K, device="cuda") * 7.0
+    w0 = emb.weight.detach().clone()
+    step = TrainStep(emb, optimizer="SGD", learning_rate_spec={"learning_rate": 1.0})
+    step((emb(ids) * coef).sum())
+    dense = torch.zeros(V, K, device="cuda", dtype=torch.float64).index_add_(0, ids, coef.double())
+    norm = float(dense.norm())
+    assert norm > CLIP_NORM                                               # the clip is active
+    want = w0.double() - dense * (CLIP_NORM / norm)
+    assert float((emb.weight.detach().double() - want).abs().max()) <= 1e-5 * (1 + float(want.abs().max()))
+    # a small gradient passes unclipped, and the persistent buffer went back to zero
+    w1 = emb.weight.detach().clone()
+    step((emb(ids[:10]) * 0.01).sum())
+    d2 = torch.zeros(V, K, device="cuda").index_add_(0, ids[:10], torch.full((10, K), 0.01, device="cuda"))
+    assert torch.allclose(emb.weight.detach(), w1 - d2, atol=1e-6)
+
+
 def test_esmm_towers_share_ids_and_one_sort(built_lib):
     """ESMM's two towers read the same columns into their own tables: one id matrix per forward (collect_ids memo) and one sort per step
     for their two fused sparse Adagrad updates (ESMM.fused_sparse_adagrad) -- tables and accumulators bit-identical to towers that
