@@ -938,6 +938,30 @@ def test_dense_dw_small_matches_float64(built_lib, M, N, K, gpad, xpad):
         ops.dense_dw(torch.zeros(64, 128, device="cuda"), torch.zeros(64, 256, device="cuda"), arith="small")       # 512 tiles of 8 x 8
 
 
+@pytest.mark.parametrize("M,N,K,arith", [(65536, 400, 416, "bf16x3"), (65521, 1024, 432, "bf16x3"), (65536, 80, 64, "small"), (65536, 64, 256, "small")])
+def test_dense_dw_full_size_selection_is_exact(built_lib, M, N, K, arith):
+    """A size-independent property at the BASELINE batch: with g[r_n, n] = 1 for one row r_n per output row n (zero elsewhere) the
+    gradient row n is x[r_n, :] EXACTLY -- the three bf16 pieces of a value sum to it, products with 1 and sums with 0 are exact --
+    and the bias gradient is all ones; with g = 2^-3 on two selected rows per n, the sum of two scaled rows (exact on the FMA kernel)."""
+    from dir_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(N + K)
+    x = torch.randn((M, K), generator=gen, device="cuda") * 3.0
+    rows = torch.randperm(M, generator=gen, device="cuda")[:2 * N]
+    r1, r2 = rows[:N], rows[N:]
+    g = torch.zeros((M, N), device="cuda")
+    g[r1, torch.arange(N, device="cuda")] = 1.0
+    dW, db = ops.dense_dw(g, x, arith=arith, want_bias=True)
+    assert torch.equal(dW, x[r1]) and torch.equal(db, torch.ones(N, device="cuda"))
+    g[r2, torch.arange(N, device="cuda")] = 0.125
+    g[r1, torch.arange(N, device="cuda")] = 0.125
+    dW2 = ops.dense_dw(g, x, arith=arith)
+    want = x[r1] * 0.125 + x[r2] * 0.125
+    if arith == "small":          # fp32 FMAs: two exact products, one rounding -- the fp32 sum, in whichever order the spans add them
+        assert torch.equal(dW2, want)
+    else:                         # bf16x3: the six piece products of the two terms interleave in the fp32 accumulator (fp32-equivalent, not fp32-identical)
+        assert float((dW2 - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
 def test_dense_dw_bf16x3_edges(built_lib):
     from dir_amd import ops
     z, zb = ops.dense_dw(torch.empty(0, 24, device="cuda"), torch.empty(0, 36, device="cuda"), arith="bf16x3", want_bias=True)    # empty batch: zero gradients
