@@ -574,7 +574,7 @@ def main():
         cfg.update({"fields": F, "towers": 2, "hidden": [360, 200, 80]})
     elif wl in ("xdeepfm_full", "xdeepfm_train"):
         # BASELINE configs[4] on one GPU: xDeepFM (CIN 128-128-128 + DNN 400-400 + linear) forward, or a whole training step
-        # (CIN backward on MFMA, sparse table gradients, torch Adagrad on everything dense, SGD on the sparse parameters)
+        # (CIN backward on MFMA, fused sparse Adagrad / FTRL on the tables and linear columns inside backward, torch Adagrad on everything dense)
         from dir_amd.xdeepfm import XDeepFM
         from dir_amd import feature_column as fc
         cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
@@ -597,17 +597,18 @@ def main():
             else:
                 roof = {"bound": "mfma", "alg_flops": flops, "kernel": "xDeepFM forward (CIN flops only)"}
         else:
+            # the DeepFM recipe (deepFM.py:58,61): fused sorted sparse Adagrad on the embedding tables and FTRL on the linear columns
+            # inside backward() (one sort for both), torch Adagrad on everything dense
+            model.fused_sparse_adagrad(lr=0.01)
+            model.fused_sparse_ftrl(lr=0.2)
             sparse_ids = {id(p) for p in model.embedding_weights} | {id(p) for p in model.linear_weights}
             opt_d = torch.optim.Adagrad([p for p in model.parameters() if id(p) not in sparse_ids], lr=0.01, initial_accumulator_value=0.1)
-            opt_s = torch.optim.SGD([p for p in model.parameters() if id(p) in sparse_ids], lr=0.01)
             labels = (torch.rand((B, 1), generator=gen, device=device) < 0.25).float()
 
             def step(i):
                 opt_d.zero_grad(set_to_none=True)
-                opt_s.zero_grad(set_to_none=True)
                 torch.nn.functional.binary_cross_entropy_with_logits(model(featl[i % len(featl)]), labels).backward()
                 opt_d.step()
-                opt_s.step()
             roof = {"bound": "mfma", "alg_flops": 3 * flops, "kernel": "xDeepFM training step (CIN forward + backward flops only)"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "cin": [128, 128, 128], "dnn": [400, 400]})
     elif wl == "dcn_cross":

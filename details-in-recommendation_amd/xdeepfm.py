@@ -59,6 +59,33 @@ class XDeepFM(nn.Module):
             self._ts_key = key
         return self._emb_ts, self._lin_ts
 
+    def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
+        """Attach the fused HIP sparse Adagrad to the embedding tables (as DeepFM.fused_sparse_adagrad; the xDeepFM paper trains with
+        the DeepFM recipe): backward() then updates them in place, duplicate ids summed first; the tables get no .grad."""
+        emb_ts, _ = self._tablesets()
+        self._sparse_adagrad = ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()
+        self._link_sparse_optimisers()
+        return self._sparse_adagrad
+
+    def fused_sparse_ftrl(self, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
+        """Attach the fused HIP sparse FTRL to the linear weight columns (as DeepFM.fused_sparse_ftrl)."""
+        _, lin_ts = self._tablesets()
+        if lin_ts is None:
+            raise ValueError("fused_sparse_ftrl: the model has no linear feature columns")
+        self._sparse_ftrl = ops.SparseFtrl(lin_ts, lr, initial_accumulator_value, l1, l2).attach()
+        self._link_sparse_optimisers()
+        return self._sparse_ftrl
+
+    def _same_categoricals(self):
+        a = [categorical_of(c) for c in self.dnn_feature_columns]
+        b = [categorical_of(c) for c in self.linear_feature_columns]
+        return len(a) == len(b) and all(x is y for x, y in zip(a, b))
+
+    def _link_sparse_optimisers(self):
+        a, f = getattr(self, "_sparse_adagrad", None), getattr(self, "_sparse_ftrl", None)
+        if a is not None and f is not None and self._same_categoricals():
+            ops.share_sorted_entries(a, f)
+
     def cin(self, x0):
         """x0 [B, m, D] -> pooled features [B, sum(H_k)]."""
         B = x0.shape[0]
@@ -107,7 +134,7 @@ class XDeepFM(nn.Module):
             emb = ops.embedding_bag(emb_ts, got[1], got[2], got[3], combiner=comb, field_major=True)
         lin = None
         if lin_ts is not None:
-            g2 = collect_ids(self.linear_feature_columns, features, device)
+            g2 = got if self._same_categoricals() else collect_ids(self.linear_feature_columns, features, device)
             if train and g2[0] == "onehot":
                 lin = ag.linear_logit(lin_ts, g2[1], self.linear_bias, list(self.linear_weights))
             else:
