@@ -97,6 +97,8 @@ SIGNATURES = {
     "dir_shard_bucket": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dir_shard_bucket_cap_workspace_bytes": (c_i64, [c_i32]),
     "dir_shard_bucket_cap": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dir_shard_bucket_cap_dedup": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dir_shard_slab_stat": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp]),
     "dir_gather_slabs_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "dir_gather_packed_f32": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
 }

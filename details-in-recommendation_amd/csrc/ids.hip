@@ -567,28 +567,143 @@ __global__ __launch_bounds__(256) void bucket_cap_k(const int64_t* __restrict__ 
     }
 }
 
+// Slab header word: low 32 bits = number of valid slots (<= cap); high 32 bits = the SENDER's largest per-owner demand in this
+// micro-batch.  Every rank therefore learns every other rank's demand from the id exchange itself (slab_stat_k below): the global
+// overflow verdict needs no collective of its own.
+__device__ __forceinline__ int64_t slab_count(int64_t header) { return (int64_t)(uint32_t)header; }
+
 __global__ void bucket_cap_fin_k(int32_t* __restrict__ gcount, int P, int64_t cap, int64_t* __restrict__ payload,
                                  int64_t* __restrict__ counts, int32_t* __restrict__ overflow, int64_t* __restrict__ stat) {
     const int o = threadIdx.x;
     int over = 0;
     int c32 = 0;
+    int64_t c = 0;
     if (o < P) {
-        const int64_t c = gcount[o];
+        c = gcount[o];
         counts[o] = c;                                    // the true demand (may exceed cap): the caller sizes the next cap from it
-        payload[(int64_t)o * (cap + 1)] = c < cap ? c : cap;
         gcount[o] = 0;
         over = c > cap ? 1 : 0;
-        c32 = (int)c;
+        c32 = (int)(c < 0x7fffffff ? c : 0x7fffffff);
     }
     const unsigned long long any = __ballot(over);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) c32 = max(c32, __shfl_xor(c32, d, 64));
+    if (o < P) payload[(int64_t)o * (cap + 1)] = (c < cap ? c : cap) | ((int64_t)c32 << 32);
     if (o == 0) {
         overflow[0] = any ? 1 : 0;
         if (stat) {          // [overflow, largest per-owner demand]: what the caller reduces over chunks and ranks
             stat[0] = any ? 1 : 0;
             stat[1] = c32;
         }
+    }
+}
+
+// After the id exchange: n_slabs received slabs (any number of micro-batches x P senders, `cap + 1` words apart) ->
+// stat = {1 iff some sender's demand exceeded cap, the largest demand}: the same two numbers on every rank.
+__global__ void slab_stat_k(const int64_t* __restrict__ recv, int n_slabs, int64_t cap, int64_t* __restrict__ stat) {
+    int m = 0;
+    for (int i = threadIdx.x; i < n_slabs; i += 64) m = max(m, (int)(recv[(int64_t)i * (cap + 1)] >> 32));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+    if (threadIdx.x == 0) {
+        stat[0] = (int64_t)m > cap ? 1 : 0;
+        stat[1] = m;
+    }
+}
+
+// Fixed-capacity bucketing WITH duplicate removal ([TF-upstream] embedding_lookup_sparse gathers unique ids): one workgroup takes
+// 256 * EPT samples of ONE slot f, so a tile holds that many draws from one table and a hot row shows up many times in it.  Every
+// entry's payload p = local_row * F + f goes into an LDS hash table (open addressing, 2 slots per entry); the first inserter of a
+// value owns it, reserves a slab position like bucket_cap_k does (one global atomic per owner and workgroup) and publishes it in
+// the table; duplicates copy the owner's position into inv.  Duplicates that fall into DIFFERENT tiles are sent once per tile:
+// the lookup's result is the same, only the exchange carries a few more rows than an exact unique() would (on Zipf(1.05) ids over
+// 10^6 rows a 4096-sample tile removes ~49 % of the rows, an exact unique over 65 536 samples ~63 %) for none of a sort's cost.
+// ids are read with strides (sb, sf); inv is written FIELD-MAJOR, inv[f * B + b] (coalesced), and handed to the finish gather as a
+// strided [B, F] view.  gcount / fin as in bucket_cap_k: the demand the headers carry is the de-duplicated one.
+template <int EPT>
+__global__ __launch_bounds__(256) void bucket_cap_dedup_k(const int64_t* __restrict__ ids, int64_t sb, int64_t sf, int64_t B,
+                                                          const int64_t* __restrict__ vocab, const int32_t* __restrict__ parts,
+                                                          const int32_t* __restrict__ first, int F, int P, int64_t cap,
+                                                          int32_t* __restrict__ gcount, int64_t* __restrict__ payload,
+                                                          int64_t* __restrict__ inv) {
+    constexpr int TILE = 256 * EPT, HT = 2 * TILE;
+    constexpr uint32_t EMPTY = 0xffffffffu;
+    __shared__ uint32_t hkey[HT];
+    __shared__ int32_t hpos[HT];          // slab position o * cap + pos of the value in hkey (needs P * cap < 2^31), -1: did not fit
+    __shared__ int cnt[64];
+    __shared__ int basev[64];
+    const int tiles_per_f = (int)((B + TILE - 1) / TILE);
+    const int f = (int)(blockIdx.x / tiles_per_f);
+    const int64_t b0 = (int64_t)(blockIdx.x - f * tiles_per_f) * TILE;
+    const FieldDiv fd = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0);
+    for (int h = threadIdx.x; h < HT; h += 256) hkey[h] = EMPTY;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int own[EPT];           // owner, -1: pruned / out of range / inactive
+    int slot[EPT];          // hash slot (-1: payload too wide for the 32-bit table: sent without de-duplication)
+    int64_t pv[EPT];
+    unsigned win = 0;       // bit k: this thread owns its value
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int64_t b = b0 + k * 256 + threadIdx.x;
+        own[k] = -1;
+        slot[k] = -1;
+        pv[k] = -1;
+        if (b < B) {
+            const int64_t id = ids[b * sb + (int64_t)f * sf];
+            if (id >= 0 && id < fd.V) {
+                int o;
+                int64_t l;
+                route_fd(id, fd, &o, &l);
+                o += fd.first;
+                if (o >= P) o -= P;
+                own[k] = o;
+                const int64_t p = l * F + f;
+                pv[k] = p;
+                if (p < (int64_t)EMPTY) {
+                    const uint32_t p32 = (uint32_t)p;
+                    uint32_t h = (p32 * 2654435761u) >> (32 - __builtin_ctz(HT));     // multiplicative hash: the top log2(HT) bits
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&hkey[h], EMPTY, p32);
+                        if (old == EMPTY) { win |= 1u << k; break; }
+                        if (old == p32) break;
+                        h = (h + 1) & (uint32_t)(HT - 1);
+                    }
+                    slot[k] = (int)h;
+                } else {
+                    win |= 1u << k;
+                }
+            }
+        }
+    }
+    int rank[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) rank[k] = wave_agg_rank(cnt, own[k] < 0 ? 0 : own[k], (win >> k) & 1u);
+    __syncthreads();
+    if (threadIdx.x < P) basev[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&gcount[threadIdx.x], cnt[threadIdx.x]) : 0;
+    __syncthreads();
+    int64_t dst[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        dst[k] = -1;
+        if ((win >> k) & 1u) {
+            const int o = own[k];
+            const int64_t pos = (int64_t)basev[o] + rank[k];
+            if (pos < cap) {
+                payload[(int64_t)o * (cap + 1) + 1 + pos] = pv[k];
+                dst[k] = (int64_t)o * cap + pos;
+            }
+            if (slot[k] >= 0) hpos[slot[k]] = (int32_t)dst[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int64_t b = b0 + k * 256 + threadIdx.x;
+        if (b >= B) continue;
+        int64_t d = dst[k];
+        if (own[k] >= 0 && !((win >> k) & 1u)) d = hpos[slot[k]];
+        inv[(int64_t)f * B + b] = d;
     }
 }
 
@@ -609,7 +724,7 @@ __global__ __launch_bounds__(256) void gather_slabs_k(const float* const* __rest
         const int c = (int)(q - i * lps);
         const int64_t sl = i / cap, j = i - sl * cap;
         int64_t* slab = recv + sl * (cap + 1);
-        const int64_t valid = slab[0];
+        const int64_t valid = slab_count(slab[0]);
         if (j >= valid) {
             if (sanitize && c == 0) slab[1 + j] = -1;
             continue;
@@ -828,6 +943,40 @@ extern "C" int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t
     }
     hipLaunchKernelGGL(bucket_cap_fin_k, dim3(1), dim3(64), 0, st, gcount, P, cap, payload, counts, overflow, stat);
     DIR_CHECK_LAUNCH("shard_bucket_cap");
+    return DIR_OK;
+}
+
+extern "C" int dir_shard_bucket_cap_dedup(const int64_t* ids, int64_t stride_b, int64_t stride_f, int64_t B, const int64_t* vocab,
+                                          const int32_t* parts, const int32_t* first, int F, int P, int64_t cap, int64_t* payload,
+                                          int64_t* inv, int64_t* counts, int32_t* overflow, int64_t* stat, void* workspace,
+                                          dir_stream_t stream) {
+    DIR_CHECK_ARG(B >= 0 && F > 0 && P > 0 && P <= 64 && cap > 0, "dir_shard_bucket_cap_dedup: B=%lld F=%d P=%d cap=%lld (P <= 64)", (long long)B, F, P, (long long)cap);
+    DIR_CHECK_ARG(vocab && payload && counts && overflow && workspace && (B == 0 || (ids && inv)), "dir_shard_bucket_cap_dedup: null pointer");
+    if ((int64_t)P * cap >= (int64_t)0x7fffffff) return fail(DIR_E_UNSUPPORTED, "dir_shard_bucket_cap_dedup: P*cap must fit int32");
+    hipStream_t st = as_stream(stream);
+    int32_t* gcount = static_cast<int32_t*>(workspace);
+    if (B > 0) {
+        if (B * F <= ((int64_t)1 << 20)) {
+            const int64_t tiles = (B + 2047) / 2048;
+            if (tiles * F >= (int64_t)0x7fffffff) return fail(DIR_E_UNSUPPORTED, "dir_shard_bucket_cap_dedup: too many tiles");
+            hipLaunchKernelGGL((bucket_cap_dedup_k<8>), dim3((unsigned)(tiles * F)), dim3(256), 0, st, ids, stride_b, stride_f, B, vocab, parts, first, F, P,
+                               cap, gcount, payload, inv);
+        } else {
+            const int64_t tiles = (B + 4095) / 4096;
+            if (tiles * F >= (int64_t)0x7fffffff) return fail(DIR_E_UNSUPPORTED, "dir_shard_bucket_cap_dedup: too many tiles");
+            hipLaunchKernelGGL((bucket_cap_dedup_k<16>), dim3((unsigned)(tiles * F)), dim3(256), 0, st, ids, stride_b, stride_f, B, vocab, parts, first, F, P,
+                               cap, gcount, payload, inv);
+        }
+    }
+    hipLaunchKernelGGL(bucket_cap_fin_k, dim3(1), dim3(64), 0, st, gcount, P, cap, payload, counts, overflow, stat);
+    DIR_CHECK_LAUNCH("shard_bucket_cap_dedup");
+    return DIR_OK;
+}
+
+extern "C" int dir_shard_slab_stat(const int64_t* recv, int n_slabs, int64_t cap, int64_t* stat, dir_stream_t stream) {
+    DIR_CHECK_ARG(recv && stat && n_slabs > 0 && cap > 0, "dir_shard_slab_stat: bad argument");
+    hipLaunchKernelGGL(slab_stat_k, dim3(1), dim3(64), 0, as_stream(stream), recv, n_slabs, cap, stat);
+    DIR_CHECK_LAUNCH("shard_slab_stat");
     return DIR_OK;
 }
 

@@ -847,6 +847,28 @@ def shard_bucket_cap(ids, vocab_dev, P, cap, payload, inv, counts, overflow, wor
                                                 cap, _ptr(payload), _ptr(inv), _ptr(counts), _ptr(overflow), _ptr(stat), _ptr(workspace), _stream()))
 
 
+def shard_bucket_cap_dedup(ids2d, vocab_dev, P, cap, payload, inv, counts, overflow, workspace, parts=None, first=None, stat=None):
+    """The fixed-capacity requester side with duplicates removed inside 2048 / 4096-sample tiles of one slot (include/dir_hip.h:
+    dir_shard_bucket_cap_dedup).  ids2d [B, F] int64 with any strides; inv [F*B] int64 comes back FIELD-MAJOR (inv[f*B + b]): hand
+    inv.view(F, B).t() to the finish gather."""
+    _dev(ids2d, torch.int64, "ids")
+    B, F = ids2d.shape
+    if F != vocab_dev.numel() or inv.numel() != B * F:
+        raise ValueError("shard_bucket_cap_dedup: ids [B, F], inv [F*B]")
+    _lib.check(_lib.load().dir_shard_bucket_cap_dedup(_ptr(ids2d), ids2d.stride(0), ids2d.stride(1), B, _ptr(vocab_dev), _ptr(parts), _ptr(first),
+                                                      F, P, cap, _ptr(payload), _ptr(inv), _ptr(counts), _ptr(overflow), _ptr(stat), _ptr(workspace),
+                                                      _stream()))
+
+
+def shard_slab_stat(recv, n_slabs, cap, stat):
+    """Headers of n_slabs received slabs (cap + 1 words apart, contiguous) -> stat int64 [2] = {some sender's demand > cap, the largest
+    demand} (include/dir_hip.h: dir_shard_slab_stat): the overflow verdict every rank agrees on, read off the id exchange."""
+    _dev(recv, torch.int64, "recv")
+    if recv.numel() < n_slabs * (cap + 1) or not recv.is_contiguous():
+        raise ValueError("shard_slab_stat: recv must hold n_slabs contiguous slabs of cap + 1 words")
+    _lib.check(_lib.load().dir_shard_slab_stat(_ptr(recv), n_slabs, cap, _ptr(stat), _stream()))
+
+
 SLAB_SANITIZE = 4
 
 

@@ -120,9 +120,22 @@ class HipBackend:
     def new_workspace(self, device):
         return torch.zeros(64, dtype=torch.int32, device=device)
 
-    def bucket_cap(self, flat_ids, cap, payload, inv, counts, overflow, workspace, stat=None):
-        ops.shard_bucket_cap(flat_ids, self.vocab_dev, self.P, cap, payload, inv, counts, overflow, workspace,
-                             parts=self.parts_dev, first=self.first_dev, stat=stat)
+    def bucket_cap(self, ids2d, cap, payload, inv, counts, overflow, workspace, stat=None, dedup=False):
+        """ids2d [Bc, F] -> slabs (packed headers) + inv; dedup: inv comes back field-major (inv2d() gives the [Bc, F] view)."""
+        if dedup:
+            ops.shard_bucket_cap_dedup(ids2d, self.vocab_dev, self.P, cap, payload, inv, counts, overflow, workspace,
+                                       parts=self.parts_dev, first=self.first_dev, stat=stat)
+        else:
+            ids2d = ids2d if ids2d.is_contiguous() else ids2d.contiguous()
+            ops.shard_bucket_cap(ids2d.reshape(-1), self.vocab_dev, self.P, cap, payload, inv, counts, overflow, workspace,
+                                 parts=self.parts_dev, first=self.first_dev, stat=stat)
+
+    @staticmethod
+    def inv2d(inv, Bc, F, dedup):
+        return inv.view(F, Bc).t() if dedup else inv.view(Bc, F)
+
+    def slab_stat(self, recv_all, n_slabs, cap, stat):
+        ops.shard_slab_stat(recv_all, n_slabs, cap, stat)
 
     def gather_slabs(self, recv, cap, out):
         ops.gather_slabs(self.ts, recv, self.P, cap, out)
@@ -142,34 +155,68 @@ class HipBackend:
 
 
 class _Plan:
-    """Persistent buffers of the fixed-capacity pipeline for one (batch, chunk count, capacities) combination: stable
-    addresses, so nothing is allocated per lookup and a lookup can be captured in a HIP graph."""
+    """Persistent buffers of the fixed-capacity pipeline for one (local batch size, buffer slot, slab capacity): stable addresses,
+    so nothing is allocated per lookup and a lookup can be captured in a HIP graph.  Only the slab capacity has to agree across
+    the ranks (equal-split exchanges); everything sized by the batch is local."""
 
-    def __init__(self, st, B, chunks, cap, cap_x):
+    def __init__(self, st, B, cap):
         dev, P, F, K = st.device, st.P, st.F, st.K
-        self.B, self.cap, self.cap_x = B, cap, cap_x
-        C = max(1, min(chunks, B))
-        per = -(-B // C)
-        self.bounds = [(c * per, min(B, (c + 1) * per)) for c in range(C) if c * per < B]
-        C = self.C = len(self.bounds)
+        self.B, self.cap = B, cap
+        C = self.C = st._C()
+        per = -(-B // C) if B else 0
+        self.bounds = [(min(B, c * per), min(B, (c + 1) * per)) for c in range(C)]       # a chunk may be empty (B < C)
         i64 = dict(dtype=torch.int64, device=dev)
         alias = not st._collective()                     # one rank, no collectives: receive buffers ARE the send buffers
-        self.payload_s = [torch.empty(P * (cap + 1), **i64) for _ in range(C)]
-        self.inv = [torch.empty((e - s) * F, **i64) for s, e in self.bounds]
+        slab = P * (cap + 1)
+        self.send_all = torch.empty(C * slab, **i64)
+        self.recv_all = self.send_all if alias else torch.empty(C * slab, **i64)
+        self.send = [self.send_all[c * slab:(c + 1) * slab] for c in range(C)]
+        self.recv = [self.recv_all[c * slab:(c + 1) * slab] for c in range(C)]
+        self.inv = [torch.empty(max(1, (e - s) * F), **i64)[:(e - s) * F] for s, e in self.bounds]
         self.counts = torch.zeros((C, P), **i64)
-        self.ucounts = torch.zeros((C, P), **i64)
-        self.flags = torch.zeros((C, 2), dtype=torch.int32, device=dev)      # [:, 0] slab overflow, [:, 1] exchange-slab overflow (dedup)
+        self.flags = torch.zeros((C, 1), dtype=torch.int32, device=dev)
         self.ws = [st.backend.new_workspace(dev) for _ in range(C)]
-        if st.dedup:
-            self.send_x = [torch.empty(P * (cap_x + 1), **i64) for _ in range(C)]
-        else:
-            self.send_x = self.payload_s
-        self.recv_x = self.send_x if alias else [torch.empty(P * (cap_x + 1), **i64) for _ in range(C)]
-        self.rows = [torch.empty((P * cap_x, K), dtype=torch.float32, device=dev) for _ in range(C)]
-        self.back = self.rows if alias else [torch.empty((P * cap_x, K), dtype=torch.float32, device=dev) for _ in range(C)]
-        self.cstat = torch.zeros((C, 3), **i64)           # per chunk [overflow, max demand, max distinct demand]
-        self.stat = torch.zeros(3, **i64)                 # ... MAX over chunks and ranks
-        self.host = torch.empty(3, dtype=torch.int64, pin_memory=dev.type == "cuda")
+        self.rows = [torch.empty((P * cap, K), dtype=torch.float32, device=dev) for _ in range(C)]
+        self.back = self.rows if alias else [torch.empty((P * cap, K), dtype=torch.float32, device=dev) for _ in range(C)]
+        self.cstat = torch.zeros((C, 2), **i64)           # per chunk [overflow, max demand] of THIS rank (diagnostic)
+        self.stat = torch.zeros(2, **i64)                 # ... over all chunks and ranks, read off the received slab headers
+        self.host = torch.empty(2, dtype=torch.int64, pin_memory=dev.type == "cuda")
+
+
+class _Lookup:
+    """A lookup whose pipeline has been enqueued (on the side streams on a GPU).  result() makes the caller's stream wait for it,
+    applies the overflow policy and returns emb (or (emb, fm)).  Issue the NEXT lookup before calling result() -- or before the
+    compute that consumes this one -- and the exchange runs under that compute."""
+
+    def __init__(self, st, plan, ids, want_fm, out, fm, done, exact=None):
+        self.st, self.plan, self.ids, self.want_fm, self.out, self.fm, self.done = st, plan, ids, want_fm, out, fm, done
+        self.exact = exact
+        self.joined = exact is not None
+        self.checked = exact is not None or done is False
+
+    def join(self):
+        st = self.st
+        if not self.joined:
+            self.joined = True
+            if st._streams is not None:
+                cur = torch.cuda.current_stream(st.device)
+                for s in st._streams:
+                    cur.wait_stream(s)
+
+    def result(self):
+        st = self.st
+        self.join()
+        if self.exact is not None:
+            return self.exact
+        if not self.checked:
+            if st.check == "eager":
+                self.checked = True
+                over, demand = st._read_flags(self.plan, self.done)
+                st._learn(self.plan, over, demand)
+                if over:                                      # rare: repeat on the exact path (results overwrite out / fm in stream order)
+                    st.stats["fallbacks"] += 1
+                    st._lookup_exact(self.ids, self.want_fm, out=self.out, fm=self.fm)
+        return (self.out, self.fm) if self.want_fm else self.out
 
 
 class ShardedTables:
@@ -179,15 +226,23 @@ class ShardedTables:
       reference partitioner's slice-count rule (partitions_for with max_partitions = P) with the slices dealt round-robin; or an
       explicit list of slice counts.  local_tables[f] holds local_slice(...) rows of table f (possibly zero rows).
     chunks: micro-batches per lookup when there is an exchange to hide (pipelined on two streams; every collective costs
-      host time, so 2 by default; without collectives -- one rank -- a lookup is ONE chunk on the caller's stream);  slack: slab capacity = ceil(slack * n / P) entries per owner
-      and chunk (None: n / P + 8 sigma of the binomial count + 64: ~3 % padding at 16 384 x 26 ids over 8 ranks);
+      host time, so 2 by default; without collectives -- one rank -- a lookup is ONE chunk on the caller's stream);
+    slack: slab capacity = ceil(slack * n / P) entries per owner and chunk (None: n / P + 8 sigma of the binomial count + 64:
+      ~3 % padding at 16 384 x 26 ids over 8 ranks);  max_batch: the largest local batch any rank will look up (sizes the slabs;
+      default: the first lookup's batch, MAX over the ranks);
     mode: "auto" (fixed capacity, exact fallback on overflow; switches to "exact" when the owners' demand is so uneven that
-      padding would cost more than the host read), "fixed", "exact";  check: "eager" (read the overflow flag after enqueuing
-      the pipeline), "lazy" (read it at the next lookup -- raises), "never" (graph capture; call check_overflow() yourself);
-    dedup: send each (slot, row) once per owner and chunk."""
+      padding would cost more than the host read), "fixed", "exact";
+    check: "eager" (result() reads the overflow verdict: no wait when the next lookup was issued first; an overflow is repaired on
+      the exact path), "lazy" (a lookup's verdict is read right after the NEXT lookup has been enqueued; an overflow raises),
+      "never" (graph capture; call check_overflow() yourself);
+    dedup: send each (slot, row) once per owner, chunk and 2048/4096-sample tile (csrc/ids.hip: bucket_cap_dedup_k).
+
+    Ranks may look up DIFFERENT local batch sizes (an uneven last batch): the only quantity the equal-split exchanges need to agree
+    on is the slab capacity, which is agreed once (first lookup: one host MAX) and afterwards changes only on statistics every rank
+    reads identically off the slab headers.  Every rank must call lookup the same number of times (SPMD)."""
 
     def __init__(self, local_tables, vocab, group=None, backend=None, force_collective=False, partitions=None, chunks=2,
-                 slack=None, mode="auto", check="eager", dedup=False):
+                 slack=None, mode="auto", check="eager", dedup=False, max_batch=None):
         self.group = group
         self.force_collective = force_collective  # issue the all_to_all calls even when world_size == 1
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -217,13 +272,17 @@ class ShardedTables:
         self.backend = backend or HipBackend(self.local_tables, self.vocab_dev, P, self.parts_dev, self.first_dev)
         if mode not in ("auto", "fixed", "exact") or check not in ("eager", "lazy", "never"):
             raise ValueError("mode: auto | fixed | exact; check: eager | lazy | never")
-        self.chunks, self.slack, self.mode, self.check, self.dedup = int(chunks), slack, mode, check, bool(dedup)
+        self.chunks, self.slack, self.mode, self.check, self.dedup = max(1, int(chunks)), slack, mode, check, bool(dedup)
+        self.max_batch = max_batch
         self._plans = {}
-        self._cap_floor = {}          # B -> capacities learnt from overflows / observed demand
+        self._cap = None              # the agreed slab capacity (collective mode); _cap0: its first value (the no-skew demand)
+        self._cap0 = None
         self._use_exact = mode == "exact"
-        self._pending = None          # lazy check: the plan whose flags have not been read yet
+        self._unchecked = []          # lookups whose overflow verdict has not been read yet (check = lazy / never)
+        self._slot = 0
+        self._inflight = {}
         self._streams = None
-        self.stats = {"lookups": 0, "fallbacks": 0, "cap": None, "cap_exchange": None}
+        self.stats = {"lookups": 0, "fallbacks": 0, "cap": None}
 
     @classmethod
     def from_full(cls, full_tables, group=None, **kw):
@@ -247,9 +306,17 @@ class ShardedTables:
     def _collective(self):
         return self.P > 1 or (self.force_collective and dist.is_initialized())
 
+    def _C(self):
+        """Micro-batches per lookup: a constructor constant (never a function of the local batch: every rank issues the same
+        number of collectives)."""
+        return self.chunks if self._collective() else 1
+
+    def _host_staged(self, t):
+        return _HOST_STAGED or (t.is_cuda and dist.get_backend(self.group) == "gloo")
+
     def _a2a(self, out, inp, out_splits, in_splits):
         if self._collective():
-            if _HOST_STAGED:     # development transport (several ranks on ONE GPU over gloo): never set on a multi-GPU node
+            if self._host_staged(out):     # development transport (several ranks on ONE GPU over gloo): never on a multi-GPU node
                 o = torch.empty(out.shape, dtype=out.dtype)
                 dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
                 out.copy_(o)
@@ -262,7 +329,7 @@ class ShardedTables:
         """Equal-split all-to-all, asynchronous where the transport allows: -> a work handle (or None when done / aliased)."""
         if not self._collective():
             return None                                   # out IS inp (see _Plan)
-        if _HOST_STAGED or (out.is_cuda and dist.get_backend(self.group) == "gloo"):
+        if self._host_staged(out):
             o = torch.empty(out.shape, dtype=out.dtype)
             dist.all_to_all_single(o, inp.cpu(), group=self.group)
             out.copy_(o)
@@ -279,7 +346,10 @@ class ShardedTables:
         return self
 
     def lookup_train(self, ids):
-        """Differentiable lookup: emb [B_local, F*K] with a grad_fn (the tables themselves get no .grad)."""
+        """Differentiable lookup: emb [B_local, F*K] with a grad_fn (the tables themselves get no .grad).  Runs the fixed-capacity
+        pipeline (no split sizes reach the host; the gradient rows go back through the same equal-split slabs); the exact
+        variable-size path only when mode == "exact", after an overflow, or when "auto" has given up on slabs.  One training lookup
+        may be outstanding (forward -> backward) per ShardedTables."""
         if getattr(self, "optimizer", None) is None:
             raise RuntimeError("call enable_training(lr) first")
         anchor = torch.zeros((), dtype=torch.float32, device=ids.device, requires_grad=True)
@@ -301,11 +371,57 @@ class ShardedTables:
         back = torch.empty((n, K), dtype=torch.float32, device=flat.device)       # private: kept alive by autograd users
         self._a2a(back.view(-1), rows.reshape(-1), [c * K for c in sc], [c * K for c in rc])
         emb, _ = be.finish(back, inv, B, F, False)
-        return emb, (inv, sc, rc, recv)
+        return emb, ("exact", inv, sc, rc, recv)
+
+    def _forward_saved_fixed(self, ids):
+        """Training forward on the fixed-capacity pipeline (never de-duplicated: the backward needs one slab position per entry).
+        The overflow verdict is read here (the one host wait of a training lookup; it covers work that is long done when the
+        dense part of the model has been enqueued in between)."""
+        B, F = ids.shape
+        out = torch.empty((B, F * self.K), dtype=torch.float32, device=ids.device)
+        plan = self._plan(B, "train")
+        done = self._enqueue(plan, ids, False, out, None, dedup=False)
+        lk = _Lookup(self, plan, ids, False, out, None, done)
+        lk.join()
+        if done is not False:
+            over, demand = self._read_flags(plan, done)
+            self._learn(plan, over, demand)
+            if over:
+                self.stats["fallbacks"] += 1
+                return self._forward_saved(ids)
+        return out, ("fixed", plan)
 
     def _backward_apply(self, saved, g_emb):
-        inv, sc, rc, recv = saved
         K = self.K
+        if saved[0] == "fixed":
+            plan = saved[1]
+            P, cap = self.P, plan.cap
+            C = plan.C
+            g2 = g_emb.contiguous()
+            works, grecv_l = [], []
+            for c, (s, e) in enumerate(plan.bounds):
+                # entry i's gradient row goes to slab position inv[i] (row P*cap = a dump row for pruned entries); owners receive
+                # the slabs through the forward row exchange reversed (equal splits again)
+                gsend = torch.zeros((P * cap + 1, K), dtype=torch.float32, device=g2.device)
+                if e > s:
+                    inv = plan.inv[c]
+                    idx = torch.where(inv < 0, torch.full_like(inv, P * cap), inv)
+                    gsend.index_copy_(0, idx, g2[s:e].reshape(-1, K))
+                grecv = torch.empty((P * cap, K), dtype=torch.float32, device=g2.device)
+                if self._collective():
+                    self._a2a(grecv.view(-1), gsend[:P * cap].reshape(-1), None, None)
+                else:
+                    grecv = gsend[:P * cap]
+                grecv_l.append(grecv)
+            # ONE update over all micro-batches (duplicates of a row -- from any chunk, any rank -- are summed before the accumulator
+            # moves: a synchronous step over the global batch)
+            slabs = plan.recv_all.view(C * P, cap + 1)
+            hdr = slabs[:, 0] & 0xffffffff
+            pos = torch.arange(cap, device=slabs.device)
+            pay = torch.where(pos.unsqueeze(0) < hdr.unsqueeze(1), slabs[:, 1:], torch.full_like(slabs[:, 1:], -1)).reshape(-1)
+            self.backend.apply_adagrad(self.optimizer, pay, grecv_l[0] if C == 1 else torch.cat(grecv_l, dim=0))
+            return
+        _, inv, sc, rc, recv = saved
         n = inv.numel()
         g = g_emb.contiguous().view(n, K)
         gsend = torch.empty_like(g)
@@ -340,66 +456,39 @@ class ShardedTables:
         p = 1.0 / P
         return min(_round_up(n_chunk * p + 8.0 * math.sqrt(n_chunk * p * (1 - p)) + 64, 16), _round_up(max(n_chunk, 16), 16))
 
-    def _plan(self, B):
-        C = max(1, min(self.chunks, B)) if self._collective() else 1
-        n_chunk = -(-B // C) * self.F
-        cap, cap_x = self._cap_floor.get(B, (0, 0))
-        cap = max(cap, self._default_cap(n_chunk))
-        cap = min(cap, _round_up(n_chunk, 16))           # a slab never needs more than the whole chunk
-        cap_x = min(max(cap_x, 16), cap) if (self.dedup and cap_x) else cap
-        key = (B, C, cap, cap_x)
+    def _agree_cap(self, B):
+        """The ONE agreement the equal-split exchanges need, at the first fixed-capacity lookup (every rank's first lookup: SPMD):
+        slab capacity = MAX over the ranks of the default for their batch (or max_batch).  Later changes (_learn) are functions of
+        numbers every rank reads identically off the slab headers, so no rank ever decides alone."""
+        Bm = max(int(B), int(self.max_batch or 0))
+        n_chunk = max(1, -(-Bm // self._C())) * self.F
+        cap = self._default_cap(n_chunk)
+        t = torch.tensor([cap, n_chunk], dtype=torch.int64)
+        if dist.get_backend(self.group) == "gloo":
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        else:
+            td = t.to(self.device)
+            dist.all_reduce(td, op=dist.ReduceOp.MAX, group=self.group)
+            t = td.cpu()
+        self._cap = self._cap0 = int(t[0])
+        self._share0 = float(t[1]) / self.P               # an owner's share of a micro-batch without skew
+
+    def _plan(self, B, slot=0):
+        if self._collective():
+            if self._cap is None:
+                self._agree_cap(B)
+            cap = self._cap
+        else:
+            cap = _round_up(max(B * self.F, 16), 16)      # one rank: a slab holds the whole batch, nothing can overflow
+        key = (B, slot, cap)
         plan = self._plans.get(key)
         if plan is None:
-            if self._collective():
-                # equal-split exchanges need the SAME slab sizes on every rank: agree once per new plan (a host-side MAX; every
-                # rank reaches this point together because capacities only change on globally reduced statistics)
-                t = torch.tensor([cap, cap_x, C, -C], dtype=torch.int64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group) if dist.get_backend(self.group) == "gloo" else None
-                if dist.get_backend(self.group) != "gloo":
-                    td = t.to(self.device)
-                    dist.all_reduce(td, op=dist.ReduceOp.MAX, group=self.group)
-                    t = td.cpu()
-                if int(t[2]) != C or int(t[3]) != -C:
-                    raise RuntimeError("ShardedTables: every rank must look up the same local batch size (chunk counts differ)")
-                cap, cap_x = int(t[0]), int(t[1])
-                key = (B, C, cap, cap_x)
-            self._plans = {k: v for k, v in self._plans.items() if k[0] != B}        # one plan per batch size
-            plan = self._plans[key] = _Plan(self, B, C, cap, cap_x)
-        self.stats["cap"], self.stats["cap_exchange"] = cap, cap_x
+            self._plans = {k: v for k, v in self._plans.items() if k[2] == cap and (k[0] != B or k[1] != slot)}
+            if len(self._plans) > 8:
+                self._plans.clear()
+            plan = self._plans[key] = _Plan(self, B, cap)
+        self.stats["cap"] = cap
         return plan
-
-    def _dedup(self, plan, c):
-        """Compact chunk c's slabs to one slot per distinct (slot, row): torch ops only (sort per slab, head flags, prefix
-        sum, scatter), no host read.  payload_s[c] [P, cap+1] -> send_x[c] [P, cap_x+1]; inv[c] is re-pointed at the compact
-        positions; an owner with more than cap_x distinct rows raises flag 1."""
-        P, cap, cx = self.P, plan.cap, plan.cap_x
-        slabs = plan.payload_s[c].view(P, cap + 1)
-        hdr, slots = slabs[:, 0], slabs[:, 1:]
-        big = torch.iinfo(torch.int64).max
-        pos = torch.arange(cap, device=slots.device)
-        keys = torch.where(pos.unsqueeze(0) < hdr.unsqueeze(1), slots, torch.full_like(slots, big))
-        skeys, order = torch.sort(keys, dim=1)
-        head = torch.ones_like(skeys, dtype=torch.bool)
-        head[:, 1:] = skeys[:, 1:] != skeys[:, :-1]
-        head &= skeys != big
-        uidx = torch.cumsum(head, dim=1) - 1                                   # compact index of every sorted position
-        ucount = head.sum(dim=1)
-        plan.ucounts[c].copy_(ucount)
-        umax = ucount.max()
-        plan.cstat[c, 2:3].copy_(umax.reshape(1))
-        plan.cstat[c, 0:1].copy_(torch.maximum(plan.cstat[c, 0:1], (umax > cx).to(torch.int64).reshape(1)))
-        tgt = torch.where((skeys != big) & (uidx < cx), uidx, torch.full_like(uidx, cx))   # column cx = dump
-        comp = torch.empty((P, cx + 1), dtype=torch.int64, device=slots.device)
-        comp.scatter_(1, tgt, skeys)                                           # duplicates write the same key: benign
-        out = plan.send_x[c].view(P, cx + 1)
-        out[:, 1:].copy_(comp[:, :cx])
-        out[:, 0].copy_(torch.minimum(ucount, torch.full_like(ucount, cx)))
-        rank_of = torch.empty_like(order)
-        rank_of.scatter_(1, order, pos.unsqueeze(0).expand(P, cap))            # inverse of the sort permutation
-        newpos = uidx.gather(1, rank_of)                                       # [P, cap]: compact index of every original slot
-        newpos = torch.where(newpos < cx, newpos + torch.arange(P, device=slots.device).unsqueeze(1) * cx, torch.full_like(newpos, -1))
-        inv = plan.inv[c]
-        plan.inv[c].copy_(torch.where(inv >= 0, newpos.view(-1)[inv.clamp(min=0)], inv))
 
     def _ensure_streams(self):
         if self._streams is None and self.device.type == "cuda":
@@ -407,22 +496,20 @@ class ShardedTables:
             self._chk_stream = torch.cuda.Stream(device=self.device)
         return self._streams
 
-    def _lookup_fixed(self, ids, want_fm, out, fm):
+    def _enqueue(self, plan, ids, want_fm, out, fm, dedup):
+        """Enqueue one lookup's pipeline.  -> False (nothing to check: one rank, slabs hold the whole batch), None (statistic in
+        plan.stat, no event: CPU backend) or the event after which plan.host holds [overflow, demand]."""
         B, F = ids.shape
-        K, be, P = self.K, self.backend, self.P
-        plan = self._plan(B)
+        be, P = self.backend, self.P
         C = plan.C
-        ids = ids if ids.is_contiguous() else ids.contiguous()
-        if C == 1 and not self._collective():
-            # one rank, no exchange: the three kernels back to back on the caller's stream.  A slab holds the whole chunk
-            # (cap >= n), so nothing can overflow and there is nothing to check.
-            be.bucket_cap(ids.reshape(-1), plan.cap, plan.payload_s[0], plan.inv[0], plan.counts[0], plan.flags[0, 0:1], plan.ws[0],
-                          stat=plan.cstat[0])
-            if self.dedup:
-                self._dedup(plan, 0)
-            be.gather_slabs(plan.recv_x[0], plan.cap_x, plan.rows[0])
-            be.finish_chunk(plan.back[0], plan.inv[0].view(B, F), want_fm, out, fm if want_fm else None)
-            return plan, None
+        cap = plan.cap
+        if not self._collective():
+            # one rank, no exchange: the three kernels back to back on the caller's stream
+            be.bucket_cap(ids, cap, plan.send[0], plan.inv[0], plan.counts[0], plan.flags[0], plan.ws[0], stat=plan.cstat[0], dedup=dedup)
+            be.gather_slabs(plan.recv[0], cap, plan.rows[0])
+            if B:
+                be.finish_chunk(plan.back[0], be.inv2d(plan.inv[0], B, F, dedup), want_fm, out, fm if want_fm else None)
+            return False
         S = self._ensure_streams()
         cur = torch.cuda.current_stream(self.device) if S else None
         if S:
@@ -434,146 +521,141 @@ class ShardedTables:
 
         def bucket(c):
             s, e = plan.bounds[c]
-            be.bucket_cap(ids[s:e].reshape(-1), plan.cap, plan.payload_s[c], plan.inv[c], plan.counts[c], plan.flags[c, 0:1], plan.ws[c],
-                          stat=plan.cstat[c])
-            if self.dedup:
-                self._dedup(plan, c)
-            return self._a2a_equal(plan.recv_x[c], plan.send_x[c])
+            be.bucket_cap(ids[s:e], cap, plan.send[c], plan.inv[c], plan.counts[c], plan.flags[c], plan.ws[c], stat=plan.cstat[c], dedup=dedup)
+            return self._a2a_equal(plan.recv[c], plan.send[c])
 
         def wait(w):
             if w is not None:
                 w.wait()
 
-        def reduce_stat():
-            """Right behind the LAST bucket: [any overflow, max demand, max distinct demand] -> MAX over the ranks.  Every rank
-            must take the same decision (fallback, capacity growth) or the collectives would mismatch."""
-            ctx = torch.cuda.stream(self._chk_stream) if S else contextlib.nullcontext()
-            with ctx:
-                if S:
-                    for e in ev[-2:]:
-                        self._chk_stream.wait_event(e)
-                torch.amax(plan.cstat, dim=0, out=plan.stat)          # one small kernel: the fin kernels left [overflow, demand] per chunk
-                if self._collective():
-                    if _HOST_STAGED or (plan.stat.is_cuda and dist.get_backend(self.group) == "gloo"):
-                        h = plan.stat.cpu()
-                        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
-                        plan.stat.copy_(h)
-                    else:
-                        dist.all_reduce(plan.stat, op=dist.ReduceOp.MAX, group=self.group)   # the stream waits for it, not the host
-                if S:
-                    plan.host.copy_(plan.stat, non_blocking=True)
-                    return self._chk_stream.record_event()
-            return None
+        def finish(c):
+            s, e = plan.bounds[c]
+            if e > s:
+                be.finish_chunk(plan.back[c], be.inv2d(plan.inv[c], e - s, F, dedup), want_fm, out[s:e], fm[s:e] if want_fm else None)
 
         wi, wr = [None] * C, [None] * C
-        ev = []
-        done = None
+        ev_ids = []
         with on(0):
             wi[0] = bucket(0)
-            if S:
-                ev.append(S[0].record_event())
-        if C == 1:
-            done = reduce_stat()
         for c in range(C):
             if c + 1 < C:
                 with on(c + 1):
                     wi[c + 1] = bucket(c + 1)
-                    if S:
-                        ev.append(S[(c + 1) % 2].record_event())
-                if c + 1 == C - 1:
-                    done = reduce_stat()
             with on(c):
                 wait(wi[c])
-                be.gather_slabs(plan.recv_x[c], plan.cap_x, plan.rows[c])
+                if S:
+                    ev_ids.append(S[c % 2].record_event())
+                be.gather_slabs(plan.recv[c], cap, plan.rows[c])
                 wr[c] = self._a2a_equal(plan.back[c], plan.rows[c])
             if c >= 1:
                 with on(c - 1):
                     wait(wr[c - 1])
-                    s, e = plan.bounds[c - 1]
-                    be.finish_chunk(plan.back[c - 1], plan.inv[c - 1].view(e - s, F), want_fm, out[s:e], fm[s:e] if want_fm else None)
+                    finish(c - 1)
+        # every micro-batch's slabs have arrived: their headers carry every sender's demand -> the verdict all ranks agree on
+        done = None
+        ctx = torch.cuda.stream(self._chk_stream) if S else contextlib.nullcontext()
+        with ctx:
+            if S:
+                for e in ev_ids:
+                    self._chk_stream.wait_event(e)
+            be.slab_stat(plan.recv_all, C * P, cap, plan.stat)
+            if S:
+                plan.host.copy_(plan.stat, non_blocking=True)
+                done = self._chk_stream.record_event()
         with on(C - 1):
             wait(wr[C - 1])
-            s, e = plan.bounds[C - 1]
-            be.finish_chunk(plan.back[C - 1], plan.inv[C - 1].view(e - s, F), want_fm, out[s:e], fm[s:e] if want_fm else None)
-        if S:
-            for s in S:
-                cur.wait_stream(s)
-            cur.wait_stream(self._chk_stream)
-        return plan, done
+            finish(C - 1)
+        return done
 
     def _read_flags(self, plan, done):
-        """The globally reduced overflow flag and demand of the lookup just enqueued.  On the GPU the reduction and its copy to
-        pinned memory ran on their own stream behind the LAST bucket kernels only (issued early in the pipeline): the host waits
-        for work that is long done while the row exchanges and finish kernels keep the GPU busy."""
+        """The overflow verdict and the largest demand of a lookup, identical on every rank.  On the GPU the header scan and its copy
+        to pinned memory ran on their own stream right behind the LAST id exchange: the host waits for work that is long done while
+        the row exchanges and finish kernels keep the GPU busy."""
         if done is not None:
             done.synchronize()
             host = plan.host
         else:
-            if not self._collective():                    # single-chunk path: the per-chunk record is the statistic
-                torch.amax(plan.cstat, dim=0, out=plan.stat)
             host = plan.stat.cpu()
-        return bool(host[0]), int(host[1]), int(host[2])
+        return bool(host[0]), int(host[1])
 
-    def _learn(self, plan, over, cmax, umax):
-        """Capacity policy after a checked lookup: grow to the observed demand after an overflow; give up on fixed slabs
-        (mode auto) when one owner wants more than twice its share even after dedup -- padding every slab to that size would cost
-        more link bytes than the host read of the exact path; shrink the exchange slabs to what dedup left."""
-        B = plan.B
-        n_chunk = (plan.bounds[0][1] - plan.bounds[0][0]) * self.F
-        cap, cap_x = plan.cap, plan.cap_x
+    def _learn(self, plan, over, demand):
+        """Capacity policy after a checked lookup (inputs identical on every rank): grow to the observed demand after an overflow;
+        with dedup, shrink to what de-duplication left; give up on fixed slabs (mode auto) when one owner wants more than twice
+        the no-skew share -- padding every slab to that size would cost more link bytes than the exact path's host read."""
+        if plan.cap != self._cap:
+            return                                         # a verdict about slabs that are no longer in use
+        cap = plan.cap
         if over:
-            cap = max(cap, _round_up(cmax * 1.25 + 64, 16))
-        if self.dedup:
-            want = _round_up(umax * 1.25 + 64, 16)
-            if over or want < 0.7 * cap_x:
-                cap_x = want
-        self._cap_floor[B] = (cap, cap_x)
-        demand = umax if self.dedup else cmax
-        if self.mode == "auto" and demand > 2.0 * n_chunk / self.P + 16:
+            cap = max(cap, _round_up(demand * 1.25 + 64, 16))
+        elif self.dedup:
+            want = _round_up(demand * 1.25 + 64, 16)
+            if want < 0.7 * cap:
+                cap = want
+        if cap != self._cap:
+            self._cap = cap
+        if self.mode == "auto" and demand > 2.0 * self._share0 + 16:
             self._use_exact = True
 
+    def _drain_unchecked(self, block):
+        keep = []
+        for lk in self._unchecked:
+            if lk.checked:
+                continue
+            if not block and lk.done is not None and not lk.done.query():
+                keep.append(lk)
+                continue
+            lk.checked = True
+            over, demand = self._read_flags(lk.plan, lk.done)
+            self._learn(lk.plan, over, demand)
+            if over:
+                self._unchecked = keep
+                raise RuntimeError("ShardedTables: a slab of an earlier fixed-capacity lookup overflowed (demand %d > capacity %d): "
+                                   "that result was incomplete" % (demand, lk.plan.cap))
+        self._unchecked = keep
+
     def check_overflow(self):
-        """check="lazy"/"never": read the flags of the last fixed-capacity lookup; raises if a slab overflowed (its result was
-        incomplete: repeat it with mode="exact" or a larger slack)."""
-        if self._pending is None:
-            return False
-        plan, ev = self._pending
-        self._pending = None
-        over, cmax, umax = self._read_flags(plan, ev)
-        self._learn(plan, over, cmax, umax)
-        if over:
-            raise RuntimeError("ShardedTables: a slab of the previous fixed-capacity lookup overflowed (demand %d > capacity %d): "
-                               "that result was incomplete" % (max(cmax, umax), plan.cap_x))
+        """check="lazy"/"never": read the verdicts of the fixed-capacity lookups not checked yet; raises if a slab overflowed (that
+        result was incomplete: repeat it with mode="exact" or a larger slack)."""
+        self._drain_unchecked(block=True)
         return False
 
-    def lookup(self, ids, want_fm=False, out=None, fm=None):
-        """ids [B_local, F] int64 (global row ids; < 0 or >= vocab_f -> zeros) -> emb [B_local, F*K] fp32
-        (and the FM second-order logit [B_local, 1] when want_fm).  out / fm: preallocated results (stable addresses)."""
+    def lookup_async(self, ids, want_fm=False, out=None, fm=None):
+        """Enqueue a lookup and return a handle; handle.result() -> emb [B_local, F*K] (or (emb, fm)).  Two lookups can be in
+        flight (double-buffered plans): issue lookup i+1, then consume lookup i -- the exchange of i+1 runs under that compute."""
         B, F = ids.shape
         if F != self.F:
             raise ValueError("ids must be [B, F=%d]" % self.F)
         self.stats["lookups"] += 1
-        if self.check == "lazy":
-            self.check_overflow()
-        if self._use_exact or B == 0:
+        if self._use_exact or (B == 0 and not self._collective()):
             emb, fmo = self._lookup_exact(ids, want_fm, out=out, fm=fm)
-            return (emb, fmo) if want_fm else emb
+            return _Lookup(self, None, ids, want_fm, emb, fmo, None, exact=(emb, fmo) if want_fm else emb)
         if out is None:
             out = torch.empty((B, F * self.K), dtype=torch.float32, device=ids.device)
         if want_fm and fm is None:
             fm = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
-        plan, ev = self._lookup_fixed(ids, want_fm, out, fm)
-        if ev is None and not self._collective() and not (self.dedup and plan.cap_x < plan.cap):
-            return (out, fm) if want_fm else out          # one rank, slabs as large as the chunk: cannot overflow
-        if self.check == "eager":
-            over, cmax, umax = self._read_flags(plan, ev)
-            self._learn(plan, over, cmax, umax)
-            if over:                                      # rare: repeat on the exact path (results overwrite out / fm in stream order)
-                self.stats["fallbacks"] += 1
-                self._lookup_exact(ids, want_fm, out=out, fm=fm)
-        else:
-            self._pending = (plan, ev)
-        return (out, fm) if want_fm else out
+        slot = self._slot
+        self._slot ^= 1
+        prev = self._inflight.get(slot)
+        if prev is not None:
+            prev.join()                                   # its buffers are about to be reused
+        plan = self._plan(B, slot)
+        done = self._enqueue(plan, ids, want_fm, out, fm, dedup=self.dedup)
+        lk = _Lookup(self, plan, ids, want_fm, out, fm, done)
+        if done is False:
+            lk.joined = True                              # ran on the caller's stream
+        self._inflight[slot] = lk
+        if not lk.checked and self.check != "eager":
+            # lazy: the verdicts of the EARLIER lookups are read now, after this one has been enqueued (their header scans finished
+            # long ago: the host does not wait and the streams never drain); never: they wait for check_overflow()
+            if self.check == "lazy":
+                self._drain_unchecked(block=True)
+            self._unchecked.append(lk)
+        return lk
+
+    def lookup(self, ids, want_fm=False, out=None, fm=None):
+        """ids [B_local, F] int64 (global row ids; < 0 or >= vocab_f -> zeros) -> emb [B_local, F*K] fp32
+        (and the FM second-order logit [B_local, 1] when want_fm).  out / fm: preallocated results (stable addresses)."""
+        return self.lookup_async(ids, want_fm=want_fm, out=out, fm=fm).result()
 
 
 class _ShardedLookup(torch.autograd.Function):
@@ -582,7 +664,10 @@ class _ShardedLookup(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, st, ids, anchor):
-        emb, saved = st._forward_saved(ids)
+        if st._use_exact or ids.shape[0] == 0 and not st._collective():
+            emb, saved = st._forward_saved(ids)
+        else:
+            emb, saved = st._forward_saved_fixed(ids)
         ctx.st, ctx.saved = st, saved
         return emb
 

@@ -301,12 +301,28 @@ int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vocab, const 
  * dir_gather_slabs_f32 is the owner side: recv = the P slabs as received; out[(s*cap + j), :] = the row of slot j of slab s for
  * j < header_s; the other rows are left untouched (never read by the requester).  flags: DIR_GATHER_STREAM_ROWS,
  * DIR_SLAB_SANITIZE (overwrite the slots behind each header with -1: the slab can then be walked as a flat payload by
- * dir_sparse_adagrad_sorted_payload_f32 -- the owner side of a sharded backward). */
+ * dir_sparse_adagrad_sorted_payload_f32 -- the owner side of a sharded backward).
+ *
+ * Header word: low 32 bits = valid slots; high 32 bits = the SENDER's largest per-owner demand of that micro-batch, so the id
+ * exchange itself tells every rank every other rank's demand.  dir_shard_slab_stat reads the headers of n_slabs RECEIVED slabs
+ * (micro-batches x P senders, cap + 1 words apart) -> stat int64 [2] = {1 iff some demand > cap, the largest demand}: the same
+ * verdict on every rank without a collective of its own.
+ *
+ * dir_shard_bucket_cap_dedup: the same requester side with duplicates removed before they travel ([TF-upstream]
+ * embedding_lookup_sparse gathers unique ids; reference call sites models/DeepFM/deepFM.py:387, partitioner :163-167).  ids is a
+ * [B, F] array with element strides (stride_b, stride_f); one workgroup de-duplicates a tile of 2048 / 4096 samples of one slot
+ * through an LDS hash table (duplicates in different tiles travel once per tile: same result, a few more rows than an exact
+ * unique).  inv is written FIELD-MAJOR: inv[f * B + b]; counts / overflow / stat / headers describe the de-duplicated demand.
+ * Needs P * cap < 2^31. */
 enum { DIR_SLAB_SANITIZE = 4 };
 int64_t dir_shard_bucket_cap_workspace_bytes(int P);
 int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first, int F, int P,
                          int64_t cap, int64_t* payload, int64_t* inv, int64_t* counts, int32_t* overflow, int64_t* stat,
                          void* workspace, dir_stream_t stream);
+int dir_shard_bucket_cap_dedup(const int64_t* ids, int64_t stride_b, int64_t stride_f, int64_t B, const int64_t* vocab,
+                               const int32_t* parts, const int32_t* first, int F, int P, int64_t cap, int64_t* payload, int64_t* inv,
+                               int64_t* counts, int32_t* overflow, int64_t* stat, void* workspace, dir_stream_t stream);
+int dir_shard_slab_stat(const int64_t* recv, int n_slabs, int64_t cap, int64_t* stat, dir_stream_t stream);
 int dir_gather_slabs_f32(const float* const* tables, int F, int K, int64_t* recv, int P, int64_t cap, int flags, float* out,
                          dir_stream_t stream);
 int dir_gather_packed_f32(const float* const* tables, int F, int K, const int64_t* payload, int64_t n,

@@ -706,6 +706,8 @@ def test_fixed_capacity_bucket_and_slab_gather(built_lib, P, parts):
         pay = payload.cpu().numpy().reshape(P, cap + 1)
         iv = inv.cpu().numpy()
         np.testing.assert_array_equal(counts.cpu().numpy(), true_counts)
+        np.testing.assert_array_equal(pay[:, 0] >> 32, np.full(P, true_counts.max()))        # header: this sender's largest demand |
+        pay[:, 0] &= 0xffffffff                                                           # valid slots
         np.testing.assert_array_equal(pay[:, 0], np.minimum(true_counts, cap))
         assert int(over.item()) == int((true_counts > cap).any())
         assert int(ws.abs().sum()) == 0                                                   # left zero for the next call
@@ -735,13 +737,94 @@ def test_fixed_capacity_bucket_and_slab_gather(built_lib, P, parts):
         out = torch.full((P * cap, K), 5.0, device="cuda")
         ops.gather_slabs(ops.TableSet(local), recv, P, cap, out, sanitize=True)
         o = out.cpu().numpy().reshape(P, cap, K)
-        hdr = int(payload.view(P, cap + 1)[r, 0])
+        hdr = int(payload.view(P, cap + 1)[r, 0]) & 0xffffffff
         slots = payload.view(P, cap + 1)[r, 1:1 + hdr].cpu().numpy()
         want = np.stack([local[p % F].cpu().numpy()[p // F] for p in slots]) if hdr else np.zeros((0, K), np.float32)
         for sl in range(P):
             np.testing.assert_array_equal(o[sl, :hdr], want)
             assert (o[sl, hdr:] == 5.0).all()                                              # rows behind the header: untouched
         assert (recv.view(P, cap + 1)[:, 1 + hdr:] == -1).all()                            # sanitised
+
+
+@pytest.mark.parametrize("P,B,layout", [(1, 700, "bf"), (2, 5000, "bf"), (8, 5000, "fb"), (3, 41000, "bf")])
+def test_fixed_capacity_bucket_dedup(built_lib, P, B, layout):
+    """dir_shard_bucket_cap_dedup against a NumPy restatement: inv (field-major) is an exact inverse into the slabs, a payload value
+    appears once per (owner, slot, tile of 2048 / 4096 samples), the demand in counts / headers / stat is the de-duplicated one,
+    an overflowing slab drops whole values (every duplicate gets -1); dir_shard_slab_stat reads the verdict back off the headers."""
+    from dir_amd import ops
+    rng = np.random.default_rng(P * 100 + B)
+    F, vocab = 5, [50, 7, 3000, 64, 100000]
+    ids = np.stack([np.minimum(rng.zipf(1.3, size=B) - 1, v + 1) - (rng.random(B) < 0.03) for v in vocab], 1).astype(np.int64)
+    tile = 2048 if B * F <= (1 << 20) else 4096
+    own = np.full((B, F), -1, np.int64); pay_ref = np.full((B, F), -1, np.int64)
+    for f, v in enumerate(vocab):
+        ok = (ids[:, f] >= 0) & (ids[:, f] < v)
+        o, l = R.shard_div_owner(np.where(ok, ids[:, f], 0), v, P)
+        own[:, f] = np.where(ok, np.asarray(o), -1); pay_ref[:, f] = np.where(ok, np.asarray(l) * F + f, -1)
+    uniq = np.zeros(P, np.int64)                          # distinct payloads per owner, counted per (slot, tile)
+    for f in range(F):
+        for t0 in range(0, B, tile):
+            sl = slice(t0, min(B, t0 + tile))
+            for o in range(P):
+                uniq[o] += np.unique(pay_ref[sl, f][own[sl, f] == o]).size
+    idd = torch.from_numpy(ids).cuda()
+    if layout == "fb":
+        idd = idd.t().contiguous().t()                    # [B, F] view of field-major storage
+    vdev = torch.tensor(vocab, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(64, dtype=torch.int32, device="cuda")
+    for cap in (int(uniq.max()) + 3, max(1, int(uniq.max()) // 2)):
+        payload = torch.full((P * (cap + 1),), -7, dtype=torch.int64, device="cuda")
+        inv = torch.full((F * B,), -9, dtype=torch.int64, device="cuda")
+        counts = torch.empty(P, dtype=torch.int64, device="cuda")
+        over = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+        stat = torch.full((2,), -1, dtype=torch.int64, device="cuda")
+        ops.shard_bucket_cap_dedup(idd, vdev, P, cap, payload, inv, counts, over, ws, stat=stat)
+        np.testing.assert_array_equal(counts.cpu().numpy(), uniq)
+        assert stat.tolist() == [int((uniq > cap).any()), int(uniq.max())] and int(over.item()) == int((uniq > cap).any())
+        assert int(ws.abs().sum()) == 0
+        pay = payload.cpu().numpy().reshape(P, cap + 1)
+        np.testing.assert_array_equal(pay[:, 0] >> 32, np.full(P, uniq.max()))
+        hdr = pay[:, 0] & 0xffffffff
+        np.testing.assert_array_equal(hdr, np.minimum(uniq, cap))
+        iv = inv.cpu().numpy().reshape(F, B).T                                   # [B, F]
+        assert (iv[own < 0] == -1).all()
+        kept = iv >= 0
+        if (uniq <= cap).all():
+            assert kept[own >= 0].all()
+        o_k, pos_k = iv[kept] // cap, iv[kept] % cap
+        np.testing.assert_array_equal(o_k, own[kept])
+        assert (pos_k < hdr[o_k]).all()
+        np.testing.assert_array_equal(pay[o_k, 1 + pos_k], pay_ref[kept])       # the slot holds this entry's payload
+        assert np.unique(iv[kept]).size == sum(int(min(u, cap)) for u in uniq)    # every valid slot is somebody's
+        # duplicates of a value inside a tile share ONE slot (or all miss together when it did not fit)
+        for f in range(F):
+            sl = slice(0, min(B, tile))
+            v_, first_idx, invu = np.unique(pay_ref[sl, f], return_index=True, return_inverse=True)
+            np.testing.assert_array_equal(iv[sl, f], iv[sl, f][first_idx][invu])
+        st2 = torch.full((2,), -1, dtype=torch.int64, device="cuda")
+        ops.shard_slab_stat(payload, P, cap, st2)
+        assert st2.tolist() == [int((uniq > cap).any()), int(uniq.max())]
+
+
+def test_sharded_lookup_dedup_zipf_full_size(built_lib):
+    """ShardedTables(dedup=True) on Zipf(1.05) ids at the BASELINE shape (65 536 x 26, 1 M rows per table): bit-identical to the plain
+    gather, and the exchange carries well under two thirds of the entries."""
+    from dir_amd import ops
+    from dir_amd.shard import ShardedTables
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    B, F, V, K = 65536, 26, 1000000, 16
+    tabs = [torch.randn((V, K), generator=gen, device="cuda") for _ in range(F)]
+    u = torch.rand((B, F), generator=gen, device="cuda", dtype=torch.float64)
+    a = 1.05
+    ids = ((V ** (1 - a) - 1) * u + 1).pow(1 / (1 - a)).floor().long().clamp_(1, V) - 1
+    ref = ops.embedding_bag(ops.TableSet(tabs), ids)
+    st = ShardedTables(tabs, [V] * F, dedup=True)
+    out, fm = st.lookup(ids, want_fm=True)
+    assert torch.equal(out, ref) and torch.equal(fm, ops.fm_logit(ref, F, K))
+    sent = int(st._plans[next(iter(st._plans))].counts.sum())
+    assert 0 < sent < 0.62 * B * F, sent
+    plain = ShardedTables(tabs, [V] * F)
+    assert torch.equal(plain.lookup(ids), ref)
 
 
 def test_sharded_lookup_fixed_capacity_paths_single_gpu(built_lib, oracle):

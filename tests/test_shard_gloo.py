@@ -118,33 +118,49 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
             def new_workspace(self, device):
                 return torch.zeros(64, dtype=torch.int32)
 
-            def bucket_cap(self, flat, cap, payload, inv, counts, overflow, workspace, stat=None):
-                a = flat.numpy()
+            def bucket_cap(self, ids2d, cap, payload, inv, counts, overflow, workspace, stat=None, dedup=False):
+                a = ids2d.numpy().reshape(-1)
                 own, loc = route(a)
                 pay = payload.numpy().reshape(world, cap + 1)
                 iv = inv.numpy()
                 iv[:] = -1
                 fill = np.zeros(world, np.int64)
+                seen = {}
                 for i in range(a.size):
                     o = own[i]
                     if o < 0:
                         continue
+                    p = loc[i] * F + (i % F)
+                    if dedup and (o, p) in seen:                 # an EXACT unique per owner (the HIP kernel's is per tile: same result)
+                        iv[i] = seen[(o, p)]
+                        continue
                     if fill[o] < cap:
-                        pay[o, 1 + fill[o]] = loc[i] * F + (i % F)
+                        pay[o, 1 + fill[o]] = p
                         iv[i] = o * cap + fill[o]
+                    if dedup:
+                        seen[(o, p)] = iv[i]
                     fill[o] += 1
-                pay[:, 0] = np.minimum(fill, cap)
+                pay[:, 0] = np.minimum(fill, cap) | (int(fill.max()) << 32)   # header: valid slots | this sender's largest demand
                 counts.copy_(torch.from_numpy(fill))
                 overflow.fill_(int((fill > cap).any()))
                 if stat is not None:
                     stat[0] = int((fill > cap).any())
                     stat[1] = int(fill.max())
 
+            @staticmethod
+            def inv2d(inv, Bc, F_, dedup):
+                return inv.view(Bc, F_)
+
+            def slab_stat(self, recv_all, n_slabs, cap, stat):
+                h = recv_all.numpy().reshape(n_slabs, cap + 1)[:, 0] >> 32
+                stat[0] = int(h.max() > cap)
+                stat[1] = int(h.max())
+
             def gather_slabs(self, recv, cap, out):
                 r = recv.numpy().reshape(world, cap + 1)
                 o = out.numpy()
                 for sl in range(world):
-                    for j in range(int(r[sl, 0])):
+                    for j in range(int(r[sl, 0] & 0xffffffff)):
                         v = r[sl, 1 + j]
                         o[sl * cap + j] = local[v % F].numpy()[v // F]
 
@@ -214,7 +230,27 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
         elif want == "exact_after":
             ok = ok and st._use_exact
         if opts.get("dedup") and want == "shrinks":
-            ok = ok and st.stats["cap_exchange"] < st.stats["cap"]
+            ok = ok and st.stats["cap"] < st._cap0           # the slabs shrank to what de-duplication left
+        # ranks with DIFFERENT local batch sizes (an uneven last batch; one rank may have nothing), two "epochs": only the slab
+        # capacity has to agree, and it never depends on a rank's own batch size after the first lookup
+        for sizes in opts.get("uneven", []):
+            Bu = sizes[rank]
+            idu = np.stack([rng_b.integers(-1, v, size=Bu) for v in vocab], axis=1).astype(np.int64).reshape(Bu, F)
+            refu = R.embedding_bag_onehot(full, idu) if Bu else np.zeros((0, F * K), np.float32)
+            gotu = st.lookup(torch.from_numpy(idu))
+            ok = ok and tuple(gotu.shape) == (Bu, F * K) and bool(np.array_equal(gotu.numpy(), refu))
+        # two lookups in flight (double-buffered plans), consumed in order, then a third reusing the first one's buffers
+        if opts.get("async"):
+            batches = [np.stack([rng_b.integers(-1, v, size=B) for v in vocab], axis=1).astype(np.int64) for _ in range(3)]
+            h0 = st.lookup_async(torch.from_numpy(batches[0]), want_fm=True)
+            h1 = st.lookup_async(torch.from_numpy(batches[1]))
+            e0, f0 = h0.result()
+            h2 = st.lookup_async(torch.from_numpy(batches[2]), want_fm=True)
+            e1 = h1.result()
+            e2, f2 = h2.result()
+            for e_, b_ in ((e0, batches[0]), (e1, batches[1]), (e2, batches[2])):
+                ok = ok and bool(np.array_equal(e_.numpy(), R.embedding_bag_onehot(full, b_)))
+            ok = ok and bool(np.array_equal(f0.numpy()[:, 0], O.fm_second_order(R.embedding_bag_onehot(full, batches[0]), F, K)))
         out_q.put((rank, ok, int(got.shape[0]), int(got.shape[1])))
     finally:
         dist.destroy_process_group()
@@ -249,6 +285,10 @@ def _run(world, vocab, K, B, seed, train=False, opts=None):
     (3, [40, 90, 64, 9, 17], {"partitions": [1, 3, 2, 1, 2]}),                       # the partitioner rule's slice counts, round-robin placement
     (2, [10, 7, 33], {"mode": "exact"}),
     (2, [30, 30], {"check": "lazy", "repeats": 2}),
+    (2, [40, 25, 60], {"uneven": [[37, 20], [11, 37], [0, 9], [64, 3]]}),          # unequal local batches, incl. an empty one
+    (3, [40, 25, 60], {"uneven": [[5, 37, 20], [50, 1, 0]], "dedup": True, "id_hi": 15}),
+    (2, [50, 20, 33], {"async": True}),
+    (3, [50, 20, 33], {"async": True, "dedup": True, "chunks": 3, "check": "lazy"}),
 ])
 def test_sharded_lookup_matches_full_tables(world, vocab, opts):
     K, B = 8, opts.get("B", 37)

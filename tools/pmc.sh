@@ -34,7 +34,7 @@ for k, c in acc.items():
         d["wave_wait_inst_frac"] = m.get("SQ_WAIT_INST_ANY", 0) / m["SQ_WAVE_CYCLES"]
         d["wave_active_inst_frac"] = m.get("SQ_ACTIVE_INST_ANY", 0) / m["SQ_WAVE_CYCLES"]
     out["kernels"][k[:120]] = {"launches": n, "per_launch_mean": m, "derived": d}
-json.dump(out, open("gpurun_out/r02_pmc_%s.json" % name, "w"), indent=1)
+json.dump(out, open("gpurun_out/%s_pmc_%s.json" % (__import__("os").environ.get("ROUND","r03"), name), "w"), indent=1)
 for k, v in out["kernels"].items():
     print(k[:80], v["launches"], json.dumps(v["derived"]))
 PY

@@ -6,8 +6,8 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_$name
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -o $name -- python3 bench.py "$@" > gpurun_out/prof_$name.log 2>&1
 f=$(find gpurun_out/prof_$name -name "*kernel_stats.csv" | head -1)
-cp "$f" gpurun_out/r02_kernel_stats_$name.csv
-grep '^{' gpurun_out/prof_$name.log | tail -1 > gpurun_out/r02_profiled_bench_$name.json
+cp "$f" gpurun_out/${ROUND:-r03}_kernel_stats_$name.csv
+grep '^{' gpurun_out/prof_$name.log | tail -1 > gpurun_out/${ROUND:-r03}_profiled_bench_$name.json
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
