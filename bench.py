@@ -340,7 +340,8 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
         for f in range(F):
             s0, e0 = div_range(Vf, world, rank)
             loc.append(torch.randn((e0 - s0, K), generator=gen, device=device) * sigma)
-        st = ShardedTables(loc, [Vf] * F, force_collective=True, check="lazy", max_batch=B)
+        side = os.environ.get("DIR_BENCH_CFG5_SIDE_CUS", "16")
+        st = ShardedTables(loc, [Vf] * F, force_collective=True, check="lazy", max_batch=B, side_cus=int(side) or None)
     idsl = [torch.randint(0, Vf, (B, F), generator=gen, device=device) for _ in range(2)]
     Ws, hp = [], F
     for h in Hs:
@@ -405,7 +406,8 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
     return {"metric": "samples/sec (xDeepFM CIN 3x128 + embedding lookup, table 1e8 x 16%s)" % (" row-sharded" if world > 1 else ""),
             "value": B * world * steps / el, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": el * 1e3 / steps, "cin_only_ms_per_step": el_cin * 1e3 / steps, "lookup_exposed_frac": (el - el_cin) / el_cin,
-            "lookup": ("ShardedTables.lookup_async of batch i+1 issued before the CIN of batch i (2 all_to_all per chunk, 2 chunks, check lazy)"
+            "lookup": ("ShardedTables.lookup_async of batch i+1 issued before the CIN of batch i (2 all_to_all per chunk, 2 chunks, check lazy, "
+                       "side streams on %s CUs each)" % (st.side_cus or "all")
                        if st is not None else "local gather (one GPU holds the table)"), "scaling": "weak",
             "dtype": "f32 via bf16x3 split, f32 accumulate" if default_is_bf3 else "f32",
             "per_gpu_fp32_equiv_TFLOPs_lookup_included": tf,
@@ -414,6 +416,9 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
             "fp32_mfma_kernel": {"dtype": "f32", "ms_per_step": el32 * 1e3 / steps, "value": B * world * steps / el32,
                                  "per_gpu_TFLOPs_lookup_included": tf32, "per_gpu_frac_of_fp32_mfma_peak": tf32 / MFMA_F32_PEAK_TF},
             "config": {"workload": "xdeepfm_cin_sharded", "batch_per_gpu": B, "m": F, "D": K, "layers": list(Hs), "table_rows": Vf * F}}
+
+
+CPU_BASELINE_WORKLOADS = ("deepfm_gather_fm", "gather_only", "dcn_cross", "din", "cin")
 
 
 def main():
@@ -842,11 +847,14 @@ def main():
         bl = [torch.randn((dims[i + 1],), generator=gen, device=device) * 0.1 for i in range(3)]
         ys = [torch.empty((B, dims[i + 1]), dtype=torch.float32, device=device) for i in range(3)]
         use_torch = os.environ.get("DIR_BENCH_DENSE") == "torch"
-        if not use_torch:
+        use_tower = os.environ.get("DIR_BENCH_DENSE", "tower") == "tower" and ops.tower_covers(x, Wl)   # "layers": one dense_bf3_k per layer
+        if not use_torch and not use_tower:
             from dir_amd.dense import pack_weight
             Wl = [pack_weight(w) for w in Wl]      # row stride a multiple of 64 floats (dense.py)
 
         def step(i):
+            if use_tower:
+                return ops.tower(x, Wl, bl, relu=True, out=ys[2])
             h = x
             for l in range(3):
                 h = torch.relu(torch.addmm(bl[l], h, Wl[l].t())) if use_torch else ops.dense(h, Wl[l], bl[l], relu=True, out=ys[l])
@@ -854,11 +862,13 @@ def main():
         modes = {}
         for i in range(3):
             f = 2.0 * B * dims[i] * dims[i + 1]
-            a = "f32" if use_torch or ops.DENSE_ARITH == "f32" else ops.DENSE_ARITH if ops.DENSE_ARITH != "auto" else ops.dense_auto_arith(B, dims[i], dims[i + 1])
+            a = ("bf16x3" if use_tower else "f32" if use_torch or ops.DENSE_ARITH == "f32" else ops.DENSE_ARITH if ops.DENSE_ARITH != "auto"
+                 else ops.dense_auto_arith(B, dims[i], dims[i + 1]))
             alg, pipe = alg + f, pipe + f * PIPE_COST[a]
             modes["layer%d" % (i + 1)] = a
         roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes,
-                "kernel": "rocBLAS GEMM + relu x3" if use_torch else "dense_bf3_k<13> x3" if "bf16x3" in modes.values() else "dense_k<80, relu> x3",
+                "kernel": "rocBLAS GEMM + relu x3" if use_torch else "tower_bf3_k (three layers, one launch)" if use_tower else
+                          "dense_bf3_k<13> x3" if "bf16x3" in modes.values() else "dense_k<80, relu> x3",
                 "dtype": "f32 via bf16x3 split, f32 accumulate" if "bf16x3" in modes.values() else "f32"}
         cfg.update({"layers": dims})
     elif wl == "din_train":

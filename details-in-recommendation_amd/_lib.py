@@ -39,6 +39,9 @@ SIGNATURES = {
     "dir_units1_relu_backward_partials": (c_i64, [c_i64, c_i32]),
     "dir_units1_relu_backward_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_dense_affine_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "dir_tower_bf16x3_image_bytes": (c_i64, [c_i32, c_i32]),
+    "dir_tower_bf16x3_pack_f32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "dir_tower_bf16x3_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_image_bytes": (c_i64, [c_i32, c_i32]),
     "dir_dense_bf16x3_pack_f32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -13,13 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libdir_hip.so")
-SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "din_wave.hip", "din_bwd_rows.hip", "cin.hip", "cin_bf3.hip", "cin_dw_bf3.hip", "cin_bwd.hip", "backward.hip", "dense.hip", "dense_bf3.hip", "dense_dw_bf3.hip", "head_bwd.hip", "diag.hip"]
+SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "din_wave.hip", "din_bwd_rows.hip", "cin.hip", "cin_bf3.hip", "cin_dw_bf3.hip", "cin_bwd.hip", "backward.hip", "dense.hip", "dense_bf3.hip", "tower_bf3.hip", "dense_dw_bf3.hip", "head_bwd.hip", "diag.hip"]
 # per-file flags: cin_bwd's epilogues read the MFMA results on the VALU, so keep them in VGPRs (no v_accvgpr_read)
 EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # cin_bf3 applies the field factor to the MFMA results on the VALU: keep them in VGPRs (no v_accvgpr_read); a packed fp32
                # VALU instruction beside bf16 MFMAs costs more than the two scalar ones it replaces
                "cin_bf3.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "dense_bf3.hip": ["-fno-slp-vectorize"],
+               "tower_bf3.hip": ["-fno-slp-vectorize"],
                "cin_dw_bf3.hip": ["-fno-slp-vectorize"],
                "dense_dw_bf3.hip": ["-fno-slp-vectorize"],
                # din_wave's queue ticket is ONE lane's atomic whose result is consumed a sample later; the atomic optimizer would rewrite

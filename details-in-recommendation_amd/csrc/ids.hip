@@ -613,7 +613,7 @@ __global__ void slab_stat_k(const int64_t* __restrict__ recv, int n_slabs, int64
 
 // Fixed-capacity bucketing WITH duplicate removal ([TF-upstream] embedding_lookup_sparse gathers unique ids): one workgroup takes
 // 256 * EPT samples of ONE slot f, so a tile holds that many draws from one table and a hot row shows up many times in it.  Every
-// entry's payload p = local_row * F + f goes into an LDS hash table (open addressing, 2 slots per entry); the first inserter of a
+// entry's row id goes into an LDS hash table (open addressing, 2 slots per entry); the first inserter of a
 // value owns it, reserves a slab position like bucket_cap_k does (one global atomic per owner and workgroup) and publishes it in
 // the table; duplicates copy the owner's position into inv.  Duplicates that fall into DIFFERENT tiles are sent once per tile:
 // the lookup's result is the same, only the exchange carries a few more rows than an exact unique() would (on Zipf(1.05) ids over
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void bucket_cap_dedup_k(const int64_t* __restr
     if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
     __syncthreads();
     int own[EPT];           // owner, -1: pruned / out of range / inactive
-    int slot[EPT];          // hash slot (-1: payload too wide for the 32-bit table: sent without de-duplication)
+    int slot[EPT];          // hash slot (-1: row id too wide for the 32-bit table: sent without de-duplication)
     int64_t pv[EPT];
     unsigned win = 0;       // bit k: this thread owns its value
 #pragma unroll
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(256) void bucket_cap_dedup_k(const int64_t* __restr
                 own[k] = o;
                 const int64_t p = l * F + f;
                 pv[k] = p;
-                if (p < (int64_t)EMPTY) {
-                    const uint32_t p32 = (uint32_t)p;
+                if (id < (int64_t)EMPTY) {                  // the tile is ONE slot: the row id itself identifies the value (owner included)
+                    const uint32_t p32 = (uint32_t)id;
                     uint32_t h = (p32 * 2654435761u) >> (32 - __builtin_ctz(HT));     // multiplicative hash: the top log2(HT) bits
                     for (;;) {
                         const uint32_t old = atomicCAS(&hkey[h], EMPTY, p32);

@@ -16,7 +16,7 @@ import math
 import torch
 from torch import nn
 
-from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack_supported, units1
+from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack_supported, tower_infer, units1
 from . import autograd as ag
 from . import ops
 from ._input import collect_ids, categorical_of, raise_pending
@@ -150,7 +150,23 @@ class DeepFM(nn.Module):
     def _logits_of(self, net):
         return units1(self.logits_layer, net) if self.units == 1 else self.logits_layer(net)
 
-    def dnn_logit_fn(self, net):
+    def dnn_logit_fn(self, net, adds=()):
+        """deepFM.py:284-319.  adds: [B, 1] logits to add to the result (fm_logit_fn's, deepFM.py:337-338) -- inside the fused tower
+        kernel's epilogue when that runs, here otherwise."""
+        if not _train_mode(self):
+            fused = tower_infer(self.hidden, net, self.activation, bns=self.bns if len(self.bns) else None,
+                                head=self.logits_layer if self.units == 1 else None, adds=adds if self.units == 1 else ())
+            if fused is not None:                                               # inference: the whole tower (+ logit layer) in one launch
+                out = fused if self.units == 1 else self._logits_of(fused)
+                for a in (adds if self.units != 1 else ()):
+                    out = a + out
+                return out
+        out = self._dnn_logit_layers(net)
+        for a in adds:
+            out = a + out
+        return out
+
+    def _dnn_logit_layers(self, net):
         if not len(self.bns) and not self.hparams.get("dnn_dropout") and mlp_stack_supported(self.hidden, net, self.activation):
             if self.units == 1 and mlp_head_supported(self.hidden, self.logits_layer, net, self.activation):
                 return mlp_head(self.hidden, self.logits_layer, net)                    # training: tower + logit layer as one autograd node
@@ -176,7 +192,7 @@ class DeepFM(nn.Module):
             emb = (ag.embedding_bag(emb_ts, ids, list(self.embedding_weights), max_norm=max_norm) if train
                    else ops.embedding_bag(emb_ts, ids, max_norm=max_norm))
             fm = ag.fm_logit(emb, self.F, self.K) if train else ops.fm_logit(emb, self.F, self.K)
-            return fm + self.dnn_logit_fn(emb)
+            return self.dnn_logit_fn(emb, adds=(fm,))
         if got[0] == "onehot":
             if train:
                 emb, fm = ag.gather_fm(emb_ts, got[1], list(self.embedding_weights))
@@ -192,7 +208,7 @@ class DeepFM(nn.Module):
             else:
                 emb = ops.embedding_bag(emb_ts, vals, offs, wts, combiner=comb, field_major=True, max_norm=max_norm)
                 fm = ops.fm_logit(emb, self.F, self.K)
-        return fm + self.dnn_logit_fn(emb)                                       # deepFM.py:337-338 ([B,1] + [B,units] broadcasts)
+        return self.dnn_logit_fn(emb, adds=(fm,))                                # deepFM.py:337-338 ([B,1] + [B,units] broadcasts)
 
     def _same_categoricals(self):
         same = getattr(self, "_same_cats", None)
@@ -247,6 +263,14 @@ class DeepFM(nn.Module):
         got = None
         if self.dnn_feature_columns:
             got = collect_ids(self.dnn_feature_columns, features, device)
+            pk = self._serving_pack() if got[0] == "onehot" else None
+            if pk is not None:
+                # inference, the DeepFM case (the linear columns ARE the dnn columns' categoricals, deepFM.py:89-95): concat, FM term and
+                # first-order term from ONE packed 128-byte row per (sample, field), then the tower with both logits added in its epilogue
+                emb, fm, lin = ops.gather_fm_linear(pk, got[1], bias=self.linear_bias.data)
+                logits = self.dnn_logit_fn(emb, adds=(fm, lin))
+                raise_pending()
+                return logits
             logits = self.dnn_fm_logit_fn(features, device, got)
         if self.linear_feature_columns:
             # the DeepFM case (deepFM.py:89-95): the linear columns ARE the dnn columns' categorical columns -- one id matrix (and one
@@ -300,6 +324,35 @@ class DeepFM(nn.Module):
         if a is not None and f is not None and self._same_categoricals():
             ops.share_sorted_entries(a, f)
 
+    AUTO_PACK_MAX_BYTES = 32 << 30      # the packed copy of tables beyond this size is built on request only (pack_for_serving)
+
+    def _pack_signature(self):
+        return tuple((p._version, p.data_ptr()) for p in self.embedding_weights) + tuple((p._version, p.data_ptr()) for p in self.linear_weights)
+
+    def _serving_pack(self):
+        """The packed serving layout when it applies to this forward (inference, binary head, one-hot columns, the linear columns equal
+        to the dnn columns' categoricals, no max_norm), built on first use and rebuilt when a parameter has changed since
+        (tensor._version / storage): the default inference layout.  None: the reference layout's kernels run."""
+        if torch.is_grad_enabled() or self.units != 1 or not self.hparams.get("serving_layout", "auto") or not self.linear_feature_columns:
+            return None                                   # (hparams["serving_layout"] = None / DIR_SERVING_LAYOUT=reference: never pack)
+        import os
+        if os.environ.get("DIR_SERVING_LAYOUT") == "reference":
+            return None
+        if not self._same_categoricals() or any(getattr(c, "max_norm", None) for c in self.dnn_feature_columns):
+            return None
+        if not self.embedding_weights[0].is_cuda:
+            return None
+        sig = self._pack_signature()
+        if getattr(self, "_packed", None) is not None and getattr(self, "_packed_sig", None) == sig and self._packed_extra is None:
+            return self._packed
+        ld = 32
+        while ld < self.K + 1:
+            ld *= 2
+        if sum(int(p.shape[0]) for p in self.embedding_weights) * ld * 4 > self.AUTO_PACK_MAX_BYTES:
+            return None
+        self.pack_for_serving()
+        return self._packed
+
     def pack_for_serving(self):
         """Inference-only: copy the embedding tables and the first-order weights of the same categorical columns into
         the packed 128-byte-row layout (ops.PackedTables), so that forward_ids() reads one memory line per
@@ -311,14 +364,18 @@ class DeepFM(nn.Module):
             raise ValueError("pack_for_serving: the first %d linear columns must be the dnn columns' categorical columns" % n)
         self._packed = ops.PackedTables([p.data for p in self.embedding_weights], [p.data for p in self.linear_weights[:n]])
         self._packed_extra = ops.TableSet([p.data for p in self.linear_weights[n:]]) if len(self.linear_weights) > n else None
+        self._packed_sig = self._pack_signature()
         return self._packed
 
     def forward_ids(self, dnn_ids, linear_ids=None):
         """Fast path for pre-assembled one-hot id matrices [B, F] (any strides).  linear_ids: the ids of ALL linear
         columns [B, F_lin] (its first F columns equal dnn_ids in the DeepFM case)."""
-        if getattr(self, "_packed", None) is not None and linear_ids is not None and not torch.is_grad_enabled():
+        if linear_ids is not None and not torch.is_grad_enabled() and linear_ids.shape[1] == self.F:
+            self._serving_pack()                                                 # the default inference layout (built / refreshed here)
+        if (getattr(self, "_packed", None) is not None and linear_ids is not None and not torch.is_grad_enabled()
+                and getattr(self, "_packed_sig", None) == self._pack_signature()):
             emb, fm, lin = ops.gather_fm_linear(self._packed, dnn_ids, bias=self.linear_bias.data)
-            logits = fm + self.dnn_logit_fn(emb) + lin
+            logits = self.dnn_logit_fn(emb, adds=(fm, lin))
             if self._packed_extra is not None:
                 logits = logits + ops.linear_logit(self._packed_extra, linear_ids[:, self.F:])
             return logits
@@ -328,7 +385,7 @@ class DeepFM(nn.Module):
             emb, fm = ag.gather_fm(emb_ts, dnn_ids, list(self.embedding_weights))
         else:
             emb, fm = ops.gather_fm(emb_ts, dnn_ids)
-        logits = fm + self.dnn_logit_fn(emb)
+        logits = self.dnn_logit_fn(emb, adds=(fm,))
         if linear_ids is not None and lin_ts is not None:
             if self.units != 1:
                 raise NotImplementedError("forward_ids: the multi-class head takes the features-dict path")

@@ -459,6 +459,99 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     return out
 
 
+TOWER_MAX_WIDTH = 416
+TOWER_MIN_ROWS = 4096          # below this the 128-row tiles leave most of the chip idle: the per-layer kernels run
+TOWER = os.environ.get("DIR_TOWER", "auto")      # "0": never fuse (per-layer kernels)
+_TOWER_IMAGES = {}
+
+
+def tower_covers(x, weights, head=None):
+    """Shapes dir_tower_bf16x3_f32 takes: 1..4 layers, every width and the input width multiples of 4 and <= 416."""
+    if TOWER == "0" or not (1 <= len(weights) <= 4) or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    dims = [x.shape[1]] + [int(w.shape[0]) for w in weights]
+    if any(d % 4 or d > TOWER_MAX_WIDTH or d <= 0 for d in dims) or any(int(w.shape[1]) != dims[i] for i, w in enumerate(weights)):
+        return False
+    return x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and (DENSE_ARITH in ("auto", "bf16x3"))
+
+
+def tower_image(weight):
+    """The packed bf16x3 image of one layer's [N, K] weight in the tower kernel's k order, cached per tensor until it is modified in
+    place (tensor._version) or goes away."""
+    import weakref
+    key = weight.data_ptr()
+    sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
+    hit = _TOWER_IMAGES.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == sig:
+        return hit[2]
+    N, K = weight.shape
+    lib = _lib.load()
+    nbytes = int(lib.dir_tower_bf16x3_image_bytes(K, N))
+    img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    w = weight if weight.stride(1) == 1 else weight.contiguous()
+    _lib.check(lib.dir_tower_bf16x3_pack_f32(_ptr(w), w.stride(0), K, N, _ptr(img), nbytes, _stream()))
+    if len(_TOWER_IMAGES) > 256:
+        _TOWER_IMAGES.clear()
+    _TOWER_IMAGES[key] = (weakref.ref(weight), sig, img)
+    return img
+
+
+def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, head=None, adds=(), out=None):
+    """A DNN tower in one launch (include/dir_hip.h: dir_tower_bf16x3_f32; dnn_logit_fn, deepFM.py:284-319).  x [M, Kd]; weights: 1..4
+    nn.Linear weights [N_l, K_l]; biases: list of [N_l] or None; relu: bool or per-layer list; post_scale / post_shift: per-layer lists
+    of [N_l] vectors or None entries (the folded inference batch-norm).  head = (w [N_last] or [1, N_last], b [1]): -> logits [M, 1]
+    (+ the [M] / [M, 1] tensors in adds, at most two); without a head -> the last activation [M, N_last]."""
+    _dev(x, torch.float32, "x")
+    L = len(weights)
+    if not tower_covers(x, weights):
+        raise ValueError("tower: 1..4 layers, input and layer widths multiples of 4 and <= %d, x 16-byte aligned with a row stride multiple of 4" % TOWER_MAX_WIDTH)
+    M, Kd = x.shape
+    lib = _lib.load()
+    relu_l = list(relu) if isinstance(relu, (list, tuple)) else [bool(relu)] * L
+    keep = []
+
+    def vec(seq, l, n, what):
+        t = seq[l] if seq is not None else None
+        if t is None:
+            return None
+        t = _dev(t, torch.float32, what).reshape(-1).contiguous()
+        if t.numel() != n:
+            raise ValueError("tower: %s of layer %d must have %d entries" % (what, l, n))
+        keep.append(t)
+        return t.data_ptr()
+    Ns = (ctypes.c_int * L)(*[int(w.shape[0]) for w in weights])
+    acts = (ctypes.c_int * L)(*[1 if r else 0 for r in relu_l])
+    imgs_t = [tower_image(_dev(w, torch.float32, "weight")) for w in weights]
+    VP = ctypes.c_void_p * L
+    imgs = VP(*[t.data_ptr() for t in imgs_t])
+    b_arr = VP(*[vec(biases, l, Ns[l], "bias") for l in range(L)])
+    s_arr = VP(*[vec(post_scale, l, Ns[l], "post_scale") for l in range(L)])
+    h_arr = VP(*[vec(post_shift, l, Ns[l], "post_shift") for l in range(L)])
+    if head is not None:
+        hw = _dev(head[0], torch.float32, "head weight").reshape(-1).contiguous()
+        hb = _dev(head[1], torch.float32, "head bias").reshape(-1).contiguous()
+        if hw.numel() != Ns[L - 1] or hb.numel() != 1 or len(adds) > 2:
+            raise ValueError("tower: head = (w [N_last], b [1]), at most two addends")
+        add = []
+        for a in adds:
+            a = _dev(a, torch.float32, "addend").reshape(-1).contiguous()
+            if a.numel() != M:
+                raise ValueError("tower: an addend has one value per row")
+            add.append(a)
+        if out is None:
+            out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+        _lib.check(lib.dir_tower_bf16x3_f32(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, _ptr(hw), _ptr(hb),
+                                            _ptr(add[0]) if add else None, _ptr(add[1]) if len(add) > 1 else None, _ptr(out), out.stride(0), _stream()))
+        return out
+    if adds:
+        raise ValueError("tower: addends need a head")
+    if out is None:
+        out = torch.empty((M, Ns[L - 1]), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dir_tower_bf16x3_f32(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, None, None, None, None, _ptr(out),
+                                        out.stride(0), _stream()))
+    return out
+
+
 def dense_gated(x, weight, gate, out=None, arith=None):
     """where(gate > 0, x @ weight.T, 0) (include/dir_hip.h: dir_dense_gated_f32 / dir_dense_bf16x3_f32 with a gate): x [M, Kd],
     weight [N, Kd], gate [M, N]."""

@@ -181,6 +181,7 @@ class _Plan:
         self.cstat = torch.zeros((C, 2), **i64)           # per chunk [overflow, max demand] of THIS rank (diagnostic)
         self.stat = torch.zeros(2, **i64)                 # ... over all chunks and ranks, read off the received slab headers
         self.host = torch.empty(2, dtype=torch.int64, pin_memory=dev.type == "cuda")
+        self.fin = None                                   # events behind the last enqueued lookup's final kernels (one per side stream)
 
 
 class _Lookup:
@@ -191,17 +192,19 @@ class _Lookup:
     def __init__(self, st, plan, ids, want_fm, out, fm, done, exact=None):
         self.st, self.plan, self.ids, self.want_fm, self.out, self.fm, self.done = st, plan, ids, want_fm, out, fm, done
         self.exact = exact
+        self.fin = plan.fin if plan is not None else None      # this lookup's completion events on the side streams
         self.joined = exact is not None
         self.checked = exact is not None or done is False
 
     def join(self):
-        st = self.st
+        """The caller's stream waits for THIS lookup's last kernels (events recorded when it was enqueued), not for whatever else has
+        been queued on the side streams since: a later lookup keeps running under the compute that follows."""
         if not self.joined:
             self.joined = True
-            if st._streams is not None:
-                cur = torch.cuda.current_stream(st.device)
-                for s in st._streams:
-                    cur.wait_stream(s)
+            if self.fin:
+                cur = torch.cuda.current_stream(self.st.device)
+                for e in self.fin:
+                    cur.wait_event(e)
 
     def result(self):
         st = self.st
@@ -235,14 +238,15 @@ class ShardedTables:
     check: "eager" (result() reads the overflow verdict: no wait when the next lookup was issued first; an overflow is repaired on
       the exact path), "lazy" (a lookup's verdict is read right after the NEXT lookup has been enqueued; an overflow raises),
       "never" (graph capture; call check_overflow() yourself);
-    dedup: send each (slot, row) once per owner, chunk and 2048/4096-sample tile (csrc/ids.hip: bucket_cap_dedup_k).
+    dedup: send each (slot, row) once per owner, chunk and 2048/4096-sample tile (csrc/ids.hip: bucket_cap_dedup_k);
+    side_cus: confine the lookup's side streams to that many compute units each (for lookups prefetched under MFMA-bound compute).
 
     Ranks may look up DIFFERENT local batch sizes (an uneven last batch): the only quantity the equal-split exchanges need to agree
     on is the slab capacity, which is agreed once (first lookup: one host MAX) and afterwards changes only on statistics every rank
     reads identically off the slab headers.  Every rank must call lookup the same number of times (SPMD)."""
 
     def __init__(self, local_tables, vocab, group=None, backend=None, force_collective=False, partitions=None, chunks=2,
-                 slack=None, mode="auto", check="eager", dedup=False, max_batch=None):
+                 slack=None, mode="auto", check="eager", dedup=False, max_batch=None, side_cus=None):
         self.group = group
         self.force_collective = force_collective  # issue the all_to_all calls even when world_size == 1
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -274,6 +278,7 @@ class ShardedTables:
             raise ValueError("mode: auto | fixed | exact; check: eager | lazy | never")
         self.chunks, self.slack, self.mode, self.check, self.dedup = max(1, int(chunks)), slack, mode, check, bool(dedup)
         self.max_batch = max_batch
+        self.side_cus = side_cus      # None: ordinary side streams; n: the lookup's two side streams are confined to n CUs each
         self._plans = {}
         self._cap = None              # the agreed slab capacity (collective mode); _cap0: its first value (the no-skew demand)
         self._cap0 = None
@@ -492,7 +497,10 @@ class ShardedTables:
 
     def _ensure_streams(self):
         if self._streams is None and self.device.type == "cuda":
-            self._streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            if self.side_cus:
+                self._streams = [_masked_stream(self.device, self.side_cus, k) for k in range(2)]
+            else:
+                self._streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
             self._chk_stream = torch.cuda.Stream(device=self.device)
         return self._streams
 
@@ -565,6 +573,7 @@ class ShardedTables:
         with on(C - 1):
             wait(wr[C - 1])
             finish(C - 1)
+        plan.fin = [s.record_event() for s in S] if S else None
         return done
 
     def _read_flags(self, plan, done):
@@ -656,6 +665,34 @@ class ShardedTables:
         """ids [B_local, F] int64 (global row ids; < 0 or >= vocab_f -> zeros) -> emb [B_local, F*K] fp32
         (and the FM second-order logit [B_local, 1] when want_fm).  out / fm: preallocated results (stable addresses)."""
         return self.lookup_async(ids, want_fm=want_fm, out=out, fm=fm).result()
+
+
+_MASKED = []      # (hipStream_t, ExternalStream) pairs kept alive for the life of the process
+
+
+def _masked_stream(device, n_cus, which):
+    """A HIP stream whose kernels may only run on n_cus of the 256 compute units (hipExtStreamCreateWithCUMask), wrapped for torch.
+    The lookup's kernels and RCCL's run there; the interaction kernels on the caller's stream keep the rest of the chip, so a lookup
+    prefetched under a CIN or a tower costs it those CUs for as long as the lookup runs instead of fragmenting every CU's residency.
+    The CUs are spread evenly over the mask (one per 256 / n_cus bits: every XCD and shader engine contributes)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    n = max(1, min(int(n_cus), total))
+    step = max(1, total // n)
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for k in range(n):
+        bit = (k * step + which * (step // 2)) % total      # the two side streams take interleaved CUs
+        mask[bit // 32] |= 1 << (bit % 32)
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0 or not st.value:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    ext = torch.cuda.ExternalStream(st.value, device=device)
+    _MASKED.append((st, ext))
+    return ext
 
 
 class _ShardedLookup(torch.autograd.Function):

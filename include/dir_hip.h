@@ -361,6 +361,26 @@ int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, int N, void*
 int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                          const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
                          dir_stream_t stream);
+/* A whole DNN tower in ONE launch (csrc/tower_bf3.hip): L <= 4 hidden layers of width <= 416 over X [M, Kd <= 416] and, optionally, the
+ * units = 1 logit layer behind them -- dnn_logit_fn, models/DeepFM/deepFM.py:284-319 (concat -> [dense(units, act) ->
+ * batch_normalization]* -> dense(units=1)); _base_model, models/ESMM/ESMM.py:139-146.  The arithmetic of dir_dense_bf16x3_f32 (bf16 x 3
+ * split of both operands, fp32 accumulate, 1e-5 against float64); a 128-row tile's activations stay in registers from layer to layer
+ * (an accumulator tile of v_mfma_f32_32x32x16_bf16 is the next layer's B operand when the weight image enumerates k the same way), so
+ * only X is read and only the result is written.
+ *   dir_tower_bf16x3_image_bytes(K, N) / dir_tower_bf16x3_pack_f32: the packed image of ONE layer's weight W [N, K] (nn.Linear layout,
+ *     row stride w_ld) in that k order (once per weight version).
+ *   dir_tower_bf16x3_f32: N, images, bias, post_scale, post_shift, act are HOST arrays of L entries (device pointers / ints; bias,
+ *     post_scale, post_shift may be NULL or hold NULL entries); layer l: y = act(x W_l^T + bias_l) (* post_scale_l + post_shift_l: the
+ *     folded inference batch-norm of dir_dense_affine_f32).  head_w [N_last], head_b [1] (both or neither): out[r * out_ld] =
+ *     y_last[r] . head_w + head_b (+ add0[r] + add1[r]: the other logits of add_n, deepFM.py:217-223; NULL: none); without a head
+ *     out [M, N_last] (row stride out_ld) receives the last activation.
+ * Limits: Kd, every N_l, x_ld (and out_ld without a head) multiples of 4, <= 416; 16-byte aligned operands (DIR_E_UNSUPPORTED). */
+int64_t dir_tower_bf16x3_image_bytes(int K, int N);
+int dir_tower_bf16x3_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream);
+int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
+                         const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
+                         const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
+                         dir_stream_t stream);
 /* dir_dense_gated_f32: Y = (gate > 0) ? X . Wt^T : 0 -- the data gradient of a dense layer taken straight through the previous
  * layer's ReLU: X = dL/d(pre-activation of layer l) [M, Kd = units of l], Wt = the TRANSPOSE of layer l's nn.Linear weight
  * ([in_l, units_l] rows), gate = layer l-1's output [M, N = in_l]; the result is dL/d(pre-activation of layer l-1). */

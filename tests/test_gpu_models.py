@@ -799,7 +799,8 @@ def test_fixed_capacity_bucket_dedup(built_lib, P, B, layout):
         # duplicates of a value inside a tile share ONE slot (or all miss together when it did not fit)
         for f in range(F):
             sl = slice(0, min(B, tile))
-            v_, first_idx, invu = np.unique(pay_ref[sl, f], return_index=True, return_inverse=True)
+            key = np.where(own[sl, f] >= 0, ids[sl, f], -1)                        # the row id identifies a value (owner included)
+            v_, first_idx, invu = np.unique(key, return_index=True, return_inverse=True)
             np.testing.assert_array_equal(iv[sl, f], iv[sl, f][first_idx][invu])
         st2 = torch.full((2,), -1, dtype=torch.int64, device="cuda")
         ops.shard_slab_stat(payload, P, cap, st2)

@@ -1,0 +1,160 @@
+"""GPU tests of the fused tower kernel (csrc/tower_bf3.hip, dir_tower_bf16x3_f32): dnn_logit_fn (models/DeepFM/deepFM.py:284-319) in one
+launch against a float64 restatement, against the layer-by-layer kernels, rerun-bitwise, and inside the DeepFM module."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref64(x, Ws, bs, relus, scales, shifts, head=None, adds=()):
+    h = x.astype(np.float64)
+    for W, b, r, sc, sh in zip(Ws, bs, relus, scales, shifts):
+        h = h @ W.astype(np.float64).T
+        if b is not None:
+            h = h + b.astype(np.float64)
+        if r:
+            h = np.maximum(h, 0.0)
+        if sc is not None:
+            h = h * sc.astype(np.float64) + sh.astype(np.float64)
+    if head is not None:
+        h = h @ head[0].astype(np.float64).reshape(-1, 1) + float(head[1][0])
+        for a in adds:
+            h = h + a.astype(np.float64).reshape(-1, 1)
+    return h
+
+
+def _scaled_err(got, ref):
+    return float((np.abs(got.astype(np.float64) - ref) / (1 + np.abs(ref))).max())
+
+
+@pytest.mark.parametrize("M,Kd,Ns,head,nadd,bn,relu", [
+    (300, 416, [400, 400, 400], True, 2, False, True),        # the DeepFM tower (deepFM.py:284-319) + fm and linear logits added
+    (129, 64, [32], False, 0, False, True),                   # one narrow layer, activation out, a partial tile
+    (5000, 416, [360, 200, 80], True, 0, False, True),        # ESMM's tower (ESMM.py:139-146)
+    (1000, 52, [100, 36], True, 1, True, True),               # batch-norm affine behind the activation (deepFM.py:303-308)
+    (257, 416, [416, 4, 416, 16], False, 0, True, False),     # four layers, no activation, widths from 4 to 416
+    (1, 16, [8], True, 0, False, True),
+])
+def test_tower_matches_float64_and_layerwise(built_lib, M, Kd, Ns, head, nadd, bn, relu):
+    from dir_amd import ops
+    rng = np.random.default_rng(M + Kd + len(Ns))
+    x = (rng.standard_normal((M, Kd)) * 0.5).astype(np.float32)
+    dims = [Kd] + Ns
+    Ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(Ns))]
+    bs = [(rng.standard_normal(n) * 0.1).astype(np.float32) for n in Ns]
+    scales = [(1 + 0.2 * rng.standard_normal(n)).astype(np.float32) if bn else None for n in Ns]
+    shifts = [(0.1 * rng.standard_normal(n)).astype(np.float32) if bn else None for n in Ns]
+    hw = (rng.standard_normal(Ns[-1]) / np.sqrt(Ns[-1])).astype(np.float32)
+    hb = np.array([0.3], np.float32)
+    adds = [rng.standard_normal(M).astype(np.float32) for _ in range(nadd)]
+    d = lambda a: torch.from_numpy(a).cuda() if a is not None else None  # noqa: E731
+    xd, Wd, bd = d(x), [d(w) for w in Ws], [d(b) for b in bs]
+    kw = dict(relu=relu, post_scale=[d(s) for s in scales] if bn else None, post_shift=[d(s) for s in shifts] if bn else None)
+    if head:
+        got = ops.tower(xd, Wd, bd, head=(d(hw), d(hb)), adds=[d(a) for a in adds], **kw)
+        assert tuple(got.shape) == (M, 1)
+    else:
+        got = ops.tower(xd, Wd, bd, **kw)
+        assert tuple(got.shape) == (M, Ns[-1])
+    ref = _ref64(x, Ws, bs, [relu] * len(Ns), scales, shifts, (hw, hb) if head else None, adds)
+    assert _scaled_err(got.cpu().numpy(), ref) <= 1e-5
+    # the same tower layer by layer on the fp32-MFMA kernel: both sit inside the 1e-5 bar, so they agree to 2e-5
+    h = xd
+    for l in range(len(Ns)):
+        ok = ops.dense_supported(h, Wd[l])
+        if ok:
+            h = ops.dense(h, Wd[l], bd[l], relu=relu, post_scale=kw["post_scale"][l] if bn else None, post_shift=kw["post_shift"][l] if bn else None,
+                          arith="f32")
+        else:
+            h = h @ Wd[l].t() + bd[l]
+            h = torch.relu(h) if relu else h
+            h = h * kw["post_scale"][l] + kw["post_shift"][l] if bn else h
+    if head:
+        h = h @ d(hw).reshape(-1, 1) + d(hb)
+        for a in adds:
+            h = h + d(a).reshape(-1, 1)
+    assert _scaled_err(got.cpu().numpy(), h.double().cpu().numpy()) <= 2e-5
+    again = ops.tower(xd, Wd, bd, head=(d(hw), d(hb)), adds=[d(a) for a in adds], **kw) if head else ops.tower(xd, Wd, bd, **kw)
+    assert torch.equal(got, again)
+
+
+def test_tower_full_size_rerun_and_image_refresh(built_lib):
+    """BASELINE config 2's tower at its own size (65 536 x 416 -> 400 -> 400 -> 400 -> 1): against float64 on a row sample, 5 reruns
+    bitwise equal, and the cached weight image follows an in-place weight update."""
+    from dir_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    M, dims = 65536, [416, 400, 400, 400]
+    x = torch.randn((M, dims[0]), generator=gen, device="cuda") * 0.25
+    Ws = [torch.randn((dims[i + 1], dims[i]), generator=gen, device="cuda") / dims[i] ** 0.5 for i in range(3)]
+    bs = [torch.randn((dims[i + 1],), generator=gen, device="cuda") * 0.1 for i in range(3)]
+    hw, hb = torch.randn((1, 400), generator=gen, device="cuda") / 20, torch.full((1,), 0.1, device="cuda")
+    got = ops.tower(x, Ws, bs, head=(hw, hb))
+    for _ in range(5):
+        assert torch.equal(ops.tower(x, Ws, bs, head=(hw, hb)), got)
+    rows = torch.arange(0, M, 257, device="cuda")
+    h = x[rows].double()
+    for W, b in zip(Ws, bs):
+        h = torch.relu(h @ W.double().t() + b.double())
+    ref = (h @ hw.double().t() + hb.double()).cpu().numpy()
+    assert _scaled_err(got[rows].cpu().numpy(), ref) <= 1e-5
+    Ws[1].mul_(0.5)                                        # in place: tensor._version moves, the image is re-packed
+    h = x[rows].double()
+    for W, b in zip(Ws, bs):
+        h = torch.relu(h @ W.double().t() + b.double())
+    ref2 = (h @ hw.double().t() + hb.double()).cpu().numpy()
+    assert _scaled_err(ops.tower(x, Ws, bs, head=(hw, hb))[rows].cpu().numpy(), ref2) <= 1e-5
+
+
+def test_tower_refuses_uncovered_shapes(built_lib):
+    from dir_amd import ops
+    x = torch.zeros((64, 420), device="cuda")
+    assert not ops.tower_covers(x, [torch.zeros((400, 420), device="cuda")])                 # wider than 416
+    assert not ops.tower_covers(torch.zeros((64, 16), device="cuda"), [torch.zeros((6, 16), device="cuda")])   # width not a multiple of 4
+    with pytest.raises(ValueError):
+        ops.tower(x, [torch.zeros((400, 420), device="cuda")])
+    assert ops.tower(torch.zeros((0, 16), device="cuda"), [torch.zeros((8, 16), device="cuda")]).shape == (0, 8)
+
+
+def test_deepfm_inference_takes_the_fused_tower_and_packed_rows(built_lib, oracle):
+    """DeepFM.forward under no_grad at a batch the fused path covers: packed serving rows (default layout) + the tower kernel with the FM
+    and first-order logits added in its epilogue == the reference-layout, layer-by-layer forward within 1e-5, and the float64 graph."""
+    import os
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc, ops
+    torch.manual_seed(11)
+    B, F, K, V = 8192, 26, 16, 5000
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).cuda()
+    with torch.no_grad():
+        for p in model.linear_weights:
+            p.normal_(0, 0.05)
+    ids = torch.randint(0, V, (B, F), device="cuda")
+    feats = {"C%d" % i: ids[:, i].contiguous() for i in range(F)}
+    with torch.no_grad():
+        fused = model(feats)
+        assert model._packed is not None                                         # the default inference layout was built
+        os.environ["DIR_SERVING_LAYOUT"] = "reference"
+        old = ops.TOWER
+        ops.TOWER = "0"
+        try:
+            plain = model(feats)
+        finally:
+            ops.TOWER = old
+            del os.environ["DIR_SERVING_LAYOUT"]
+    assert _scaled_err(fused.cpu().numpy(), plain.double().cpu().numpy()) <= 2e-5
+    # float64 graph (fm_logit_fn + dnn_logit_fn + linear, deepFM.py:217-223)
+    E = torch.stack([model.embedding_weights[f].double()[ids[:, f]] for f in range(F)], 1)      # [B, F, K]
+    fm = 0.5 * ((E.sum(1) ** 2) - (E ** 2).sum(1)).sum(1, keepdim=True)
+    h = E.reshape(B, F * K)
+    for lin in model.hidden:
+        h = torch.relu(h @ lin.weight.double().t() + lin.bias.double())
+    dnn = h @ model.logits_layer.weight.double().t() + model.logits_layer.bias.double()
+    lin = sum(model.linear_weights[f].double().reshape(-1)[ids[:, f]] for f in range(F)).reshape(B, 1) + model.linear_bias.double()
+    assert _scaled_err(fused.cpu().numpy(), (fm + dnn + lin).detach().cpu().numpy()) <= 1e-5
+    # training changes a table: the packed copy is refreshed on the next inference forward
+    with torch.no_grad():
+        model.embedding_weights[3].add_(0.01)
+        after = model(feats)
+    assert not torch.equal(after, fused)
