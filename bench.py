@@ -340,7 +340,9 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
         for f in range(F):
             s0, e0 = div_range(Vf, world, rank)
             loc.append(torch.randn((e0 - s0, K), generator=gen, device=device) * sigma)
-        side = os.environ.get("DIR_BENCH_CFG5_SIDE_CUS", "16")
+        # (side streams confined to a few CUs -- ShardedTables(side_cus=n) -- made this leg SLOWER on one GPU: 9.3 vs 7.8 ms at 8-32 CUs,
+        # profiles/r03_cfg5_overlap.md; the default leaves them unmasked)
+        side = os.environ.get("DIR_BENCH_CFG5_SIDE_CUS", "0")
         st = ShardedTables(loc, [Vf] * F, force_collective=True, check="lazy", max_batch=B, side_cus=int(side) or None)
     idsl = [torch.randint(0, Vf, (B, F), generator=gen, device=device) for _ in range(2)]
     Ws, hp = [], F
