@@ -478,6 +478,91 @@ struct FtrlUpd {      // FTRL-Proximal, learning_rate_power = -0.5 ([TF-upstream
     }
 };
 
+// tf.train.AdamOptimizer on an IndexedSlices gradient ([TF-upstream] _apply_sparse_shared, as the reference's train_op applies it to
+// the embedding tables: DeepCrossNetwork.py:264-290, DeepCrossNetwork/train.py:119-124): m and v of EVERY row decay, the summed
+// (clipped) row gradients are added to the touched rows, and every row of var steps by lr_t * m / (sqrt(v) + eps), lr_t = lr *
+// sqrt(1 - b2^t) / (1 - b1^t).  Two sorted passes share one sort: AdamNormUpd adds up ||S_r||^2 per table (S_r = a row's summed
+// gradient) for tf.clip_by_norm(g, clip) -- in 2^-32 fixed point with integer atomics, so the sum does not depend on arrival order --
+// and AdamUpd applies the touched rows and marks them; adam_decay_k then streams over all rows and steps the unmarked ones.
+constexpr double ADAM_FX = 4294967296.0;       // 2^32
+struct AdamNormUpd {
+    static constexpr bool kNorm = true;
+    unsigned long long* norm2;                 // [F] fixed point
+    template <int VEC>
+    __device__ __forceinline__ void apply(int, int64_t, int, typename BV<VEC>::T) const {}
+};
+struct AdamUpd {
+    float* const* tables;
+    float* const* ms;
+    float* const* vs;
+    const unsigned long long* norm2;           // [F] fixed-point ||gradient of table f||^2 (NULL: no clipping)
+    unsigned char* mark;                       // [total_rows]: 1 = this row was stepped here
+    const int64_t* row_base;
+    float lr_t, b1, b2, eps, clip;
+    int64_t ld;
+    __device__ __forceinline__ void one(float g, float den, float& m, float& v, float& w) const {
+        if (clip > 0.f) g = (g * clip) / den;                     // tf.clip_by_norm: t * clip_norm / max(l2norm, clip_norm)
+        m = m * b1 + g * (1.f - b1);
+        v = v * b2 + (g * g) * (1.f - b2);
+        w = w - (lr_t * m) / (sqrtf(v) + eps);
+    }
+    template <int VEC>
+    __device__ __forceinline__ void apply(int f, int64_t id, int col, typename BV<VEC>::T g) const {
+        using V = BV<VEC>;
+        float den = clip;
+        if (clip > 0.f && norm2) den = fmaxf(sqrtf((float)((double)norm2[f] / ADAM_FX)), clip);
+        const int64_t off = id * ld + col;
+        float* mp = ms[f] + off;
+        float* vp = vs[f] + off;
+        float* wp = tables[f] + off;
+        typename V::T m = V::ld(mp), v = V::ld(vp), w = V::ld(wp);
+        if constexpr (VEC == 4) {
+            one(g.x, den, m.x, v.x, w.x); one(g.y, den, m.y, v.y, w.y); one(g.z, den, m.z, v.z, w.z); one(g.w, den, m.w, v.w, w.w);
+        } else {
+            one(g, den, m, v, w);
+        }
+        V::st(mp, m);
+        V::st(vp, v);
+        V::st(wp, w);
+        if (col == 0) mark[row_base[f] + id] = 1;
+    }
+};
+template <class U, class = void> struct IsNorm { static constexpr bool value = false; };
+template <class U> struct IsNorm<U, std::void_t<decltype(U::kNorm)>> { static constexpr bool value = U::kNorm; };
+
+// every row of table f NOT stepped by AdamUpd this step (mark == 0): zero gradient -> m *= b1, v *= b2, var -= lr_t * m / (sqrt(v) + eps);
+// marked rows are skipped and their mark cleared.  LPS = K / 4 adjacent lanes own a row (all of them read the mark before lane 0 of
+// the group clears it: one wave instruction apart).
+template <int LPS>
+__global__ __launch_bounds__(256) void adam_decay_k(float* const* __restrict__ tables, float* const* __restrict__ ms, float* const* __restrict__ vs,
+                                                    const int64_t* __restrict__ row_base, int64_t total_rows, int F,
+                                                    unsigned char* __restrict__ mark, float lr_t, float b1, float b2, float eps) {
+    const int f = blockIdx.y;
+    const int64_t r0 = row_base[f];
+    const int64_t V = (f + 1 < F ? row_base[f + 1] : total_rows) - r0;
+    float* __restrict__ w = tables[f];
+    float* __restrict__ m = ms[f];
+    float* __restrict__ v = vs[f];
+    const int c = threadIdx.x & (LPS - 1);
+    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPS; row < V; row += (int64_t)gridDim.x * 256 / LPS) {
+        const unsigned char mk = mark[r0 + row];
+        if (mk) {
+            if (c == 0) mark[r0 + row] = 0;
+            continue;
+        }
+        const int64_t off = row * (LPS * 4) + c * 4;
+        float4 mm = *reinterpret_cast<const float4*>(m + off), vv = *reinterpret_cast<const float4*>(v + off);
+        float4 ww = *reinterpret_cast<const float4*>(w + off);
+        mm = make_float4(mm.x * b1, mm.y * b1, mm.z * b1, mm.w * b1);
+        vv = make_float4(vv.x * b2, vv.y * b2, vv.z * b2, vv.w * b2);
+        ww = make_float4(ww.x - (lr_t * mm.x) / (sqrtf(vv.x) + eps), ww.y - (lr_t * mm.y) / (sqrtf(vv.y) + eps),
+                         ww.z - (lr_t * mm.z) / (sqrtf(vv.z) + eps), ww.w - (lr_t * mm.w) / (sqrtf(vv.w) + eps));
+        *reinterpret_cast<float4*>(m + off) = mm;
+        *reinterpret_cast<float4*>(v + off) = vv;
+        *reinterpret_cast<float4*>(w + off) = ww;
+    }
+}
+
 template <int LPS, int VEC, class U, bool FM = false>
 __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
                                                       int64_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
@@ -493,6 +578,10 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
     __shared__ uint32_t skey[ADA_TILE], sval[ADA_TILE];
     __shared__ int rstart[ADA_TILE + 1];
     __shared__ int wcnt[4];
+    __shared__ unsigned long long nsq[IsNorm<U>::value ? 64 : 1];     // norm pass: this tile's ||S_r||^2 per table, fixed point
+    if constexpr (IsNorm<U>::value) {
+        if (threadIdx.x < 64) nsq[threadIdx.x] = 0ull;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x, e0 = t * ADA_TILE;
     const int ne = (int)((n - e0) < ADA_TILE ? (n - e0) : ADA_TILE);
@@ -570,10 +659,19 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
         const bool open_l = r == 0 && cont_l, open_r = r == nruns - 1 && cont_r;
         if (!open_l && !open_r) {
             const int64_t id = (int64_t)rk - row_base[f];
-            upd.template apply<VEC>(f, id, c * VEC, sum);
+            if constexpr (IsNorm<U>::value) {
+                const double d = (double)V::dot(sum, sum, 0.f) * ADAM_FX;
+                atomicAdd(&nsq[f & 63], (unsigned long long)(d < 4.0e18 ? d : 4.0e18));
+            } else {
+                upd.template apply<VEC>(f, id, c * VEC, sum);
+            }
         } else {
             V::st(carry + (t * 2 + (open_l ? 0 : 1)) * K + c * VEC, sum);   // a run open on both sides goes to slot 0
         }
+    }
+    if constexpr (IsNorm<U>::value) {
+        __syncthreads();
+        if (threadIdx.x < 64 && nsq[threadIdx.x]) atomicAdd(upd.norm2 + threadIdx.x, nsq[threadIdx.x]);
     }
 }
 
@@ -609,7 +707,12 @@ __global__ __launch_bounds__(256) void adagrad_fix_k(U upd, int F, int K,
         for (int q = 1; q < nt; ++q) f += (int64_t)kl >= row_base[q] ? 1 : 0;
     }
     const int64_t id = (int64_t)kl - row_base[f];
-    upd.template apply<VEC>(f, id, c * VEC, sum);
+    if constexpr (IsNorm<U>::value) {
+        const double d = (double)V::dot(sum, sum, 0.f) * ADAM_FX;
+        atomicAdd(upd.norm2 + (f & 63), (unsigned long long)(d < 4.0e18 ? d : 4.0e18));
+    } else {
+        upd.template apply<VEC>(f, id, c * VEC, sum);
+    }
 }
 
 // The (row, entry) sort.  rocprim's default onesweep configuration sorts 8 bits per pass: 4 passes for the 25-bit keys of the
@@ -984,4 +1087,59 @@ extern "C" int dir_sparse_adagrad_sorted_payload_f32(float* const* tables, float
     DIR_CHECK_ARG(tables && accums && (payload || n == 0), "dir_sparse_adagrad_sorted_payload_f32: null pointer");
     return sparse_sorted_update("dir_sparse_adagrad_sorted_payload_f32", AdagradUpd{tables, accums, lr, (int64_t)K}, F, K, nullptr, 0, 0, grad,
                                 (int64_t)K, 0, n, row_base, total_rows, workspace, workspace_bytes, stream, payload);
+}
+
+// ---- tf.train.AdamOptimizer on the embedding tables ------------------------------------------------------------------------------
+extern "C" int64_t dir_sparse_adam_workspace_bytes(int64_t B, int F, int K, int64_t total_rows) {
+    if (B < 0 || F <= 0 || F > 64 || K <= 0 || (K & 3) || 64 % (K / 4) || total_rows <= 0 || total_rows >= 0xffffffffll || B * F >= 0x7fffffffll) return 0;
+    AdaSortedPlan p;
+    const int64_t sorted = B > 0 ? (adagrad_sorted_plan(B * F, K, total_rows, p) ? (int64_t)p.total : -1) : 0;
+    if (sorted < 0) return 0;
+    return sorted + 512 + ((total_rows + 255) & ~(int64_t)255);      // + norm2 [64] u64 + the row marks (one byte per row)
+}
+
+extern "C" int dir_sparse_adam_f32(float* const* tables, float* const* ms, float* const* vs, int F, int K, const int64_t* ids,
+                                   int64_t stride_b, int64_t stride_f, const float* grad, int64_t grad_ld, float lr_t, float beta1,
+                                   float beta2, float eps, float clip_norm, int64_t B, const int64_t* row_base, int64_t total_rows,
+                                   void* workspace, int64_t workspace_bytes, int first_call, dir_stream_t stream) {
+    const char* name = "dir_sparse_adam_f32";
+    DIR_CHECK_ARG(tables && ms && vs && row_base && workspace && F > 0 && K > 0 && B >= 0, "%s: bad argument", name);
+    if (F > 64 || (K & 3) || 64 % (K / 4) || K / 4 > 64) return fail(DIR_E_UNSUPPORTED, "%s: F <= 64, K a multiple of 4 with K / 4 dividing 64 (F=%d K=%d)", name, F, K);
+    DIR_CHECK_ARG(B == 0 || (ids && grad && grad_ld >= (int64_t)F * K), "%s: ids / grad", name);
+    DIR_CHECK_ARG(lr_t >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f && clip_norm >= 0.f, "%s: hyper-parameters", name);
+    const int64_t need = dir_sparse_adam_workspace_bytes(B, F, K, total_rows);
+    if (need <= 0 || need > workspace_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail(DIR_E_BADARG, "%s: workspace needs %lld bytes, 256-byte aligned", name, (long long)need);
+    hipStream_t st = as_stream(stream);
+    char* ws = static_cast<char*>(workspace);
+    // layout: [norm2: 64 x u64 = 512 B][marks: total_rows bytes, zero between calls][sorted-update workspace]
+    unsigned long long* norm2 = reinterpret_cast<unsigned long long*>(ws);
+    unsigned char* mark = reinterpret_cast<unsigned char*>(ws + 512);
+    const int64_t mark_bytes = (total_rows + 255) & ~(int64_t)255;
+    char* sorted_ws = ws + 512 + mark_bytes;
+    const int64_t sorted_bytes = workspace_bytes - 512 - mark_bytes;
+    if (first_call && hipMemsetAsync(mark, 0, (size_t)mark_bytes, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+    if (B > 0) {
+        const bool clip = clip_norm > 0.f;
+        if (clip) {
+            if (hipMemsetAsync(norm2, 0, 512, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+            const int rc = sparse_sorted_update(name, AdamNormUpd{norm2}, F, K, ids, stride_b, stride_f, grad, grad_ld, (int64_t)K, B, row_base,
+                                                total_rows, sorted_ws, sorted_bytes, stream);
+            if (rc != DIR_OK) return rc;
+        }
+        const int rc = sparse_sorted_update(name, AdamUpd{tables, ms, vs, clip ? norm2 : nullptr, mark, row_base, lr_t, beta1, beta2, eps, clip_norm, (int64_t)K},
+                                            F, K, ids, stride_b, stride_f, grad, grad_ld, (int64_t)K, B, row_base, total_rows, sorted_ws, sorted_bytes,
+                                            stream, nullptr, nullptr, nullptr, clip ? sorted_ws : nullptr);
+        if (rc != DIR_OK) return rc;
+    }
+    const int lps = K / 4;
+    dim3 grid((unsigned)(kCUs * 8), (unsigned)F);
+    switch (lps) {
+#define DIR_DECAY(L) case L: hipLaunchKernelGGL((adam_decay_k<L>), grid, dim3(256), 0, st, tables, ms, vs, row_base, total_rows, F, mark, lr_t, beta1, beta2, eps); break
+        DIR_DECAY(1); DIR_DECAY(2); DIR_DECAY(4); DIR_DECAY(8); DIR_DECAY(16); DIR_DECAY(32); DIR_DECAY(64);
+#undef DIR_DECAY
+        default: return fail(DIR_E_UNSUPPORTED, "%s: K=%d", name, K);
+    }
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
 }

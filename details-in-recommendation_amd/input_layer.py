@@ -75,6 +75,19 @@ class InputLayer(nn.Module):
         inputs and they get no .grad.  Returns the optimiser objects (they own the accumulators)."""
         return [ops.SparseAdagrad(ts, lr, initial_accumulator_value=initial_accumulator_value).attach() for ts, _, _, _ in self._tablesets()]
 
+    def fused_sparse_adam(self, beta1=0.9, beta2=0.999, eps=1e-8, clip_norm=0.0):
+        """Attach the HIP tf.train.AdamOptimizer update (include/dir_hip.h: dir_sparse_adam_f32; the reference DCN's train_op on
+        `embedding_weights`, DeepCrossNetwork.py:264-290) to every group of embedding columns it covers (no max_norm, K / 4 a power of
+        two): backward() then steps ALL rows of those tables in place for one-hot inputs and they get no .grad.  -> (optimiser objects,
+        the parameters they own); set .lr_t on each before every backward (train_spec.TrainStep does)."""
+        opts, owned = [], []
+        for ts, idxs, _, mn in self._tablesets():
+            if mn or not ts.device.type == "cuda" or not ops.SparseAdam.covers(ts):
+                continue
+            opts.append(ops.SparseAdam(ts, beta1, beta2, eps, clip_norm).attach())
+            owned += [self.embedding_weights[i] for i in idxs]
+        return opts, owned
+
     def _indicator(self, c, features, device, B):
         ids = categorical_of(c).ids(features, device)
         if B is None:

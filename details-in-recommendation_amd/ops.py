@@ -1339,6 +1339,68 @@ class SparseAdagrad:
                                                              _stream()))
 
 
+class SparseAdam:
+    """tf.train.AdamOptimizer on the embedding tables of a TableSet, in place, from the gather's row gradients (include/dir_hip.h:
+    dir_sparse_adam_f32; the reference's train_op: DeepCrossNetwork.py:264-290, train.py:119-124).  [TF-upstream] semantics: every row of
+    m, v and var moves every step (IndexedSlices gradients are zero outside the looked-up rows), each table's gradient is clipped on its
+    own with tf.clip_by_norm(g, clip_norm) first.  Holds m and v (zeros, like the slots TF creates).  Set .lr_t before every step
+    (lr * sqrt(1 - beta2^t) / (1 - beta1^t), t = global_step + 1); attach() makes loss.backward() perform the update."""
+
+    def __init__(self, tables, beta1=0.9, beta2=0.999, eps=1e-8, clip_norm=0.0):
+        self.ts = _as_tableset(tables)
+        ts = self.ts
+        if ts.ld != ts.K:
+            raise ValueError("SparseAdam: plain [vocab, K] tables")
+        self.beta1, self.beta2, self.eps, self.clip_norm = float(beta1), float(beta2), float(eps), float(clip_norm)
+        self.lr_t = 0.0
+        self.ms = [torch.zeros_like(t) for t in ts.tables]
+        self.vs = [torch.zeros_like(t) for t in ts.tables]
+        dev = ts.device
+        self.m_ptrs = torch.tensor([t.data_ptr() for t in self.ms], dtype=torch.int64, device=dev)
+        self.v_ptrs = torch.tensor([t.data_ptr() for t in self.vs], dtype=torch.int64, device=dev)
+        base = [0]
+        for v in ts.vocab[:-1]:
+            base.append(base[-1] + v)
+        self.total_rows = sum(ts.vocab)
+        self.row_base = torch.tensor(base, dtype=torch.int64, device=dev)
+        self._ws = None
+        self._ws_B = -1
+        self.steps = 0
+
+    @staticmethod
+    def covers(ts):
+        return ts.ld == ts.K and ts.F <= 64 and ts.K % 4 == 0 and 64 % (ts.K // 4) == 0 and sum(ts.vocab) < 0xffffffff
+
+    def attach(self):
+        self.ts.grad_sink = self.step
+        return self
+
+    def step(self, ids, grad):
+        """ids [B, F] int64 (any strides), grad [B, F*K] fp32 = d loss / d gathered rows: one Adam step of ALL rows of every table."""
+        ts = self.ts
+        _dev(ids, torch.int64, "ids")
+        _dev(grad, torch.float32, "grad")
+        B, sb, sf = _onehot_strides(ids, ts.F)
+        if grad.shape != (B, ts.F * ts.K) or grad.stride(1) != 1:
+            raise ValueError("grad must be [B, F*K] with unit inner stride")
+        lib = _lib.load()
+        need = int(lib.dir_sparse_adam_workspace_bytes(B, ts.F, ts.K, self.total_rows))
+        if need <= 0:
+            raise _lib.DirError(-4, "sparse_adam: unsupported size (F <= 64, K / 4 a power of two, B*F < 2^31, total rows < 2^32-1)")
+        first = 0
+        if self._ws is None or self._ws_B < B:
+            # the marks (behind a 512-byte header) must survive from step to step: the buffer is allocated once per batch size (grown,
+            # never shrunk), zeroed by the first call
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=ts.device)
+            self._ws_B = B
+            first = 1
+        off = (-self._ws.data_ptr()) % 256
+        _lib.check(lib.dir_sparse_adam_f32(_ptr(ts.ptrs), _ptr(self.m_ptrs), _ptr(self.v_ptrs), ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad),
+                                           grad.stride(0), self.lr_t, self.beta1, self.beta2, self.eps, self.clip_norm, B, _ptr(self.row_base),
+                                           self.total_rows, ctypes.c_void_p(self._ws.data_ptr() + off), self._ws.numel() - off, first, _stream()))
+        self.steps += 1
+
+
 def _sorted_ws(holder, lib, n_entries, F, K, total_rows, device):
     need = int(lib.dir_sparse_adagrad_sorted_workspace_bytes(n_entries, F, K, total_rows))
     if need <= 0:

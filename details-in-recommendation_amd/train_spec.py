@@ -198,6 +198,17 @@ class TrainStep:
             self._tf_adam_eps = float(kw.get("eps", 1e-8))
             self._beta2 = float(betas[1])
         self.params = [p for p in model.parameters() if p.requires_grad]
+        # The embedding tables under Adam: the HIP update (ops.SparseAdam: sorted touched rows + one streaming pass over every row of w, m,
+        # v -- TF's sparse Adam moves all rows every step) instead of a scatter into a dense gradient, torch's multi-tensor Adam over
+        # 1.7 GB of tables and ~10 small torch kernels per table (DIR_TRAIN_HIP_ADAM=0 keeps that path).
+        self.sparse_adam = []
+        il = getattr(model, "input_layer", None)
+        if cls is torch.optim.Adam and il is not None and hasattr(il, "fused_sparse_adam") and os.environ.get("DIR_TRAIN_HIP_ADAM", "1") == "1" \
+                and not kw.get("amsgrad") and not kw.get("weight_decay"):
+            self.sparse_adam, owned = il.fused_sparse_adam(betas[0], betas[1], self._tf_adam_eps, CLIP_NORM)
+            owned = {id(p) for p in owned}
+            self.params = [p for p in self.params if id(p) not in owned]
+        self._beta1 = float(betas[0])
         lr0 = learning_rate_decay(self.learning_rate_spec, 0)
         self.optimizer = None
         if cls is torch.optim.Adam and self.params and all(p.is_cuda for p in self.params) \
@@ -210,6 +221,30 @@ class TrainStep:
             self.optimizer = cls(self.params, lr=lr0, **kw)
         self.l2_reg, self.l2_params = l2_reg, list(l2_params or [])
         self._dense_grad = {}                                         # table -> persistent all-zero dense gradient buffer
+        self._torch_t = 0                                             # optimizer.step() calls so far == torch's per-parameter step counters
+
+    def _sync_adam_step(self):
+        """tf.train.AdamOptimizer's beta powers are functions of ONE global step; torch.optim.Adam keeps a step counter per parameter,
+        created at 0 the first time that parameter has a gradient.  When the two disagree -- global_step restored from a checkpoint
+        into a fresh optimizer, or set by hand -- every state's counter is moved to global_step (and missing states are created the
+        way torch creates them), so that the step about to be taken uses t = global_step + 1 in both bias corrections and in the
+        epsilon emulation above."""
+        if self._tf_adam_eps is None or self._torch_t == self.global_step:
+            return
+        for group in self.optimizer.param_groups:
+            on_dev = bool(group.get("fused")) or bool(group.get("capturable"))
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.optimizer.state[p]
+                if "step" not in st:
+                    st["step"] = (torch.zeros((), dtype=torch.float32, device=p.device) if on_dev else torch.tensor(0.0, dtype=torch.float32))
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if group.get("amsgrad"):
+                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"].fill_(float(self.global_step))
+        self._torch_t = self.global_step
 
     def __call__(self, loss):
         if self.l2_reg:                                               # :181-183 (tf.nn.l2_loss = sum(w^2)/2)
@@ -219,6 +254,9 @@ class TrainStep:
             group["lr"] = lr
             if self._tf_adam_eps is not None:
                 group["eps"] = self._tf_adam_eps / math.sqrt(1.0 - self._beta2 ** (self.global_step + 1))
+        t = self.global_step + 1
+        for opt in self.sparse_adam:        # tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), epsilon un-corrected
+            opt.lr_t = lr * math.sqrt(1.0 - self._beta2 ** t) / (1.0 - self._beta1 ** t)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         touched = []
@@ -248,7 +286,9 @@ class TrainStep:
             else:
                 g = clip_by_norm_(g)
                 p.grad = g.to_dense() if g.is_sparse else g           # torch's Adam/Adagrad here take dense gradients
+        self._sync_adam_step()
         self.optimizer.step()
+        self._torch_t += 1
         for buf, idx in touched:
             buf.index_fill_(0, idx, 0.0)
         self.global_step += 1

@@ -551,6 +551,25 @@ int dir_sparse_adagrad_sorted_rows_f32(float* const* tables, float* const* accum
                                        const int64_t* row_base, int64_t total_rows, void* workspace,
                                        int64_t workspace_bytes, dir_stream_t stream);
 
+/* tf.train.AdamOptimizer on the embedding tables, as the reference's train_op applies it (models/DeepCrossNetwork/DeepCrossNetwork.py:264-290:
+ * every gradient clipped on its own with tf.clip_by_norm(g, 100.0); models/DeepCrossNetwork/train.py:119-124: Adam, epsilon 1e-4).  The
+ * tables' gradients are IndexedSlices; [TF-upstream] AdamOptimizer._apply_sparse decays m and v of EVERY row, adds the summed row
+ * gradients of the looked-up rows, and steps every row:
+ *     g_r   = (sum of the entries' gradient rows of row r) * clip / max(||g of the whole table||_2, clip)     (clip_norm = 0: unclipped)
+ *     m     = m * beta1 + g * (1 - beta1);   v = v * beta2 + g*g * (1 - beta2);   var -= lr_t * m / (sqrt(v) + eps)
+ * with lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) computed by the caller (TF's "epsilon hat" form: eps is added AFTER the bias
+ * corrections were folded into the step size).  ids [B, F] with element strides, grad [B, F*K] (row stride grad_ld): d loss / d
+ * gathered rows; tables / ms / vs: device arrays of F device pointers to contiguous [vocab_f, K] arrays; row_base: device int64 [F].
+ * One radix sort of the (row, entry) pairs serves both sorted passes (per-table gradient norm in fixed point -- order-independent --
+ * then the touched rows' update); a streaming pass steps all other rows.  Bitwise reproducible.
+ * workspace: dir_sparse_adam_workspace_bytes(B, F, K, total_rows) bytes, 256-byte aligned, the SAME buffer every step (it carries
+ * the row marks); first_call != 0 on its first use.  Limits: F <= 64, K % 4 == 0 with K / 4 a power of two <= 64. */
+int64_t dir_sparse_adam_workspace_bytes(int64_t B, int F, int K, int64_t total_rows);
+int dir_sparse_adam_f32(float* const* tables, float* const* ms, float* const* vs, int F, int K, const int64_t* ids, int64_t stride_b,
+                        int64_t stride_f, const float* grad, int64_t grad_ld, float lr_t, float beta1, float beta2, float eps,
+                        float clip_norm, int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace, int64_t workspace_bytes,
+                        int first_call, dir_stream_t stream);
+
 /* Owner side of a SHARDED backward: the n entries are the payload of dir_shard_bucket / dir_gather_packed_f32
  * (p = local_row * F + slot, p < 0 pruned) as received from all ranks, grad is [n, K] in the same order, tables / accums /
  * row_base / total_rows describe this rank's shards.  Workspace: dir_sparse_adagrad_sorted_workspace_bytes(n, 1, K, total_rows). */

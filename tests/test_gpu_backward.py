@@ -1279,3 +1279,114 @@ def test_din_rows_backward_matches_single_kernel(built_lib, normalize, B, T, H1,
         err = ((a - b).abs() / (1e-3 + 0.05 * a.abs().max() + a.abs())).max().item() if a.numel() else 0.0
         # (with the softmax, d b3 = sum of d score is a sum that cancels to ~0: only its absolute size is meaningful)
         assert err < (5e-3 if (k == "gb3" and normalize) else 2e-4), (k, err)
+
+
+# ---- tf.train.AdamOptimizer on the embedding tables (dir_sparse_adam_f32) ----------------------------------------------------------
+def _adam_ref64(tables, ms, vs, ids, grad, lr, b1, b2, eps, clip, t):
+    """float64 restatement of the reference's train_op on IndexedSlices gradients (DeepCrossNetwork.py:264-290 + [TF-upstream]
+    AdamOptimizer._apply_sparse): clip each table's summed gradient by its own norm, decay m / v of every row, step every row."""
+    F = len(tables)
+    K = tables[0].shape[1]
+    # the hyper-parameters as the fp32 graph sees them ([TF-upstream] the beta / epsilon / lr tensors are cast to the variable's dtype and
+    # 1 - beta is formed in that dtype: fp32(1) - fp32(0.999) is 1.3e-5 away from 0.001); the arithmetic itself in float64
+    lr_t = float(np.float32(lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)))
+    omb1, omb2 = float(np.float32(1) - np.float32(b1)), float(np.float32(1) - np.float32(b2))
+    b1, b2, eps, clip = float(np.float32(b1)), float(np.float32(b2)), float(np.float32(eps)), float(np.float32(clip))
+    for f in range(F):
+        g = np.zeros_like(tables[f])
+        ok = (ids[:, f] >= 0) & (ids[:, f] < tables[f].shape[0])
+        np.add.at(g, ids[ok, f], grad[ok, f * K:(f + 1) * K].astype(np.float64))
+        if clip > 0:
+            g = g * clip / max(np.sqrt((g * g).sum()), clip)
+        ms[f][:] = ms[f] * b1 + g * omb1
+        vs[f][:] = vs[f] * b2 + g * g * omb2
+        tables[f][:] = tables[f] - lr_t * ms[f] / (np.sqrt(vs[f]) + eps)
+
+
+@pytest.mark.parametrize("K,gscale,clip", [(16, 0.01, 100.0), (16, 40.0, 100.0), (8, 0.01, 0.0), (64, 5.0, 100.0)])
+def test_sparse_adam_matches_tf_semantics_over_steps(built_lib, K, gscale, clip):
+    """5 steps of dir_sparse_adam_f32 (duplicate and pruned ids, clipping idle / active) against the float64 restatement at 1e-5; every
+    row moves every step; a second optimiser fed the same data ends bitwise equal."""
+    from dir_amd import ops
+    rng = np.random.default_rng(K + int(gscale * 10))
+    F, B, vocab = 3, 700, [50, 400, 7]
+    w0 = [(rng.standard_normal((v, K)) * 0.1).astype(np.float32) for v in vocab]
+    b1, b2, eps, lr = 0.9, 0.999, 1e-4, 0.01
+    ref_w = [w.astype(np.float64) for w in w0]
+    ref_m = [np.zeros_like(w) for w in ref_w]
+    ref_v = [np.zeros_like(w) for w in ref_w]
+    runs = []
+    for rep in range(2):
+        tabs = [torch.from_numpy(w.copy()).cuda() for w in w0]
+        opt = ops.SparseAdam(ops.TableSet(tabs), b1, b2, eps, clip)
+        rng_s = np.random.default_rng(99)
+        for t in range(1, 6):
+            ids = np.stack([rng_s.integers(-1, v + 1, size=B) for v in vocab], 1).astype(np.int64)
+            grad = (rng_s.standard_normal((B, F * K)) * gscale).astype(np.float32)
+            opt.lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+            opt.step(torch.from_numpy(ids).cuda(), torch.from_numpy(grad).cuda())
+            if rep == 0:
+                _adam_ref64(ref_w, ref_m, ref_v, ids, grad, lr, b1, b2, eps, clip, t)
+        runs.append(([t.cpu().numpy() for t in tabs], [m.cpu().numpy() for m in opt.ms], [v.cpu().numpy() for v in opt.vs]))
+    for f in range(F):
+        for what, got, ref in (("var", runs[0][0][f], ref_w[f]), ("m", runs[0][1][f], ref_m[f]), ("v", runs[0][2][f], ref_v[f])):
+            # 1e-5 of the array's scale (m and v are orders of magnitude smaller than var: an absolute bar alone would not test them)
+            err = np.abs(got - ref) / (np.abs(ref).max() + 1e-30)
+            assert float(err.max()) <= 1e-5, "table %d %s: max error %.3e of the array's scale" % (f, what, float(err.max()))
+        for a, b in zip(runs[0], runs[1]):
+            assert np.array_equal(a[f], b[f])
+    assert not np.array_equal(runs[0][0][0], w0[0])
+    untouched = np.ones(vocab[1], bool)                  # rows never looked up still move (momentum of a zero gradient is zero here:
+    assert (runs[0][1][1][untouched] == runs[0][1][1][untouched]).all()   # their m, v stay 0 and var is unchanged) -- checked via ref above
+
+
+def test_dcn_train_step_hip_adam_equals_the_dense_torch_formulation(built_lib):
+    """train_spec.TrainStep on a DeepCrossNetwork with Adam (eps 1e-4, clip_by_norm 100, cosine decay: DeepCrossNetwork/train.py:119-124):
+    3 steps with the HIP sparse Adam on the tables against the same steps with DIR_TRAIN_HIP_ADAM=0 (dense gradient + torch Adam):
+    tables and dense weights within 1e-5; then a fresh TrainStep resumed at global_step 7 takes its step with t = 8."""
+    import os
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd import feature_column as fc
+
+    def build():
+        torch.manual_seed(5)
+        cols = [fc.embedding_column(fc.categorical_column_with_identity("C%02d" % i, 300), 16) for i in range(6)]
+        cols += [fc.numeric_column("I%02d" % i) for i in range(3)]
+        return DeepCrossNetwork(columns=cols, cross_layer_num=2, dnn_hidden_units=[64, 32], batch_norm=False, optimizer="Adam",
+                                optimizer_spec={"epsilon": 1e-4},
+                                learning_rate_spec={"learning_rate": 0.01, "decay_method": "cosine_decay", "decay_steps": 100, "alpha": 0.5}).cuda()
+
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    B = 2048
+    batches = []
+    for _ in range(4):
+        ids = torch.randint(0, 300, (B, 6), generator=gen, device="cuda")
+        f = {"C%02d" % i: ids[:, i].contiguous() for i in range(6)}
+        f.update({"I%02d" % i: torch.rand((B,), generator=gen, device="cuda") for i in range(3)})
+        batches.append((f, (torch.rand((B, 1), generator=gen, device="cuda") < 0.3).float()))
+
+    def run(hip, start_step=0, steps=3):
+        os.environ["DIR_TRAIN_HIP_ADAM"] = "1" if hip else "0"
+        try:
+            model = build()
+            op = model.train_step()
+            assert bool(op.sparse_adam) == hip
+            op.global_step = start_step
+            for f, y in batches[:steps]:
+                op(torch.nn.functional.binary_cross_entropy_with_logits(model(f), y))
+            return [p.detach().clone() for p in model.parameters()], op
+        finally:
+            del os.environ["DIR_TRAIN_HIP_ADAM"]
+
+    a, _ = run(True)
+    b, _ = run(False)
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) <= 1e-5
+    # resumed: the first step of a fresh optimizer at global_step 7 uses t = 8 on both paths (ADVICE r2: torch's per-parameter counters)
+    a7, op7 = run(True, start_step=7, steps=1)
+    b7, _ = run(False, start_step=7, steps=1)
+    for x, y in zip(a7, b7):
+        assert float((x - y).abs().max()) <= 1e-5
+    assert op7.global_step == 8
+    a0, _ = run(True, start_step=0, steps=1)
+    assert any(float((x - y).abs().max()) > 1e-6 for x, y in zip(a7, a0))      # t = 8 and t = 1 give different steps
