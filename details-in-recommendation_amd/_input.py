@@ -41,8 +41,28 @@ _SIDE = {}           # device -> (side stream, pinned ring of verdict slots, nex
 _BOUNDS = {}
 
 
+def checked_forward(fn):
+    """Decorator of a model's forward: the id-range verdicts it posts belong to THAT forward.  If the forward raises midway, its unread
+    verdicts are dropped with it instead of surfacing as a ValueError in a later, unrelated forward (of this or another model); on a
+    normal return the forward itself has called raise_pending().  (A standalone InputLayer / collect_ids caller reads its verdicts with
+    raise_pending(block=True).)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(self, *args, **kwargs):
+        mark = len(_PENDING)
+        try:
+            return fn(self, *args, **kwargs)
+        except BaseException:
+            del _PENDING[mark:]
+            raise
+    return wrap
+
+
 def _post_verdict(any_bad, describe):
     """Queue a device-side verdict (a 1-element tensor, non-zero = violation) for raise_pending()."""
+    if any_bad.is_cuda and torch.cuda.is_current_stream_capturing():
+        return          # inside a HIP-graph capture nothing may be read back: the captured forward runs unchecked (like DIR_CHECK_IDS=0)
     if any_bad.is_cuda:
         dev = any_bad.device
         st = _SIDE.get(dev)

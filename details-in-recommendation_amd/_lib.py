@@ -20,6 +20,8 @@ SIGNATURES = {
                                       c_vp, c_i64, c_vp]),
     "dir_embedding_bag_ex_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, ctypes.c_float, c_i32,
                                          c_i64, c_vp, c_i64, c_vp]),
+    "dir_embedding_bag_ex2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, ctypes.c_float, c_i32,
+                                          c_i64, c_vp, c_i64, c_vp]),
     "dir_check_ids": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "dir_fm_second_order_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "dir_gather_fm_fused_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),

@@ -103,14 +103,16 @@ class EmbeddingBag(torch.autograd.Function):
         g = g.contiguous() if g.stride(1) == 1 else g.clone()
         grads = []
         nfix = 8
-        if not ctx.has_offsets and ts.grad_sink is not None and not ctx.max_norm:   # fused optimiser attached (ops.SparseAdagrad.attach): no table .grad
+        mns = list(ctx.max_norm) if isinstance(ctx.max_norm, (list, tuple)) else [ctx.max_norm] * F      # one max_norm per slot
+        any_mn = any(m for m in mns)
+        if not ctx.has_offsets and ts.grad_sink is not None and not any_mn:   # fused optimiser attached (ops.SparseAdagrad.attach): no table .grad
             ts.grad_sink(ids, g)
             return (None,) * (nfix + F)
         if not ctx.has_offsets:
             for f in range(F):
                 idf, gf = ids[:, f].contiguous(), g[:, f * K:(f + 1) * K]
-                if ctx.max_norm:
-                    gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(ctx.max_norm))
+                if mns[f]:
+                    gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(mns[f]))
                 grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf.reshape(-1) if ts.tables[f].dim() == 1 else gf, ts.vocab[f]))
         else:
             B = (offsets.numel() - 1) // F
@@ -138,8 +140,8 @@ class EmbeddingBag(torch.autograd.Function):
             for f in range(F):
                 sel = f_of == f
                 idf, gf = ids[sel], gv[sel]
-                if ctx.max_norm:
-                    gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(ctx.max_norm))
+                if mns[f]:
+                    gf = _clip_backward(ts.tables[f][idf.clamp(0, ts.vocab[f] - 1)], gf, float(mns[f]))
                 grads.append(_sparse_rows(_in_range(idf, ts.vocab[f]), gf.reshape(-1) if ts.tables[f].dim() == 1 else gf, ts.vocab[f]))
         return (None,) * nfix + tuple(grads)
 

@@ -113,6 +113,8 @@ def load_npz(model, path, strict=True):
             if tuple(a.shape) != tuple(t.shape):
                 raise ValueError("%s: checkpoint shape %s vs parameter %s" % (k, a.shape, tuple(t.shape)))
             t.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(t.device, t.dtype))
+    from . import ops
+    ops.invalidate_caches()          # weight images cached per tensor version: a load is a new version whatever the counters say
     return missing
 
 
@@ -122,16 +124,29 @@ def tf_tensors(model):
     return {k: _to_tf(t, lay) for k, (t, lay) in tf_variable_map(model).items()}
 
 
-def export_tf_checkpoint(model, model_dir, global_step=0, name="model.ckpt"):
+def export_tf_checkpoint(model, model_dir, global_step=0, name="model.ckpt", num_ps_replicas=0):
     """Write `model_dir/<name>-<global_step>.{index,data-00000-of-00001}` + the `checkpoint` state file, keyed by the reference's
-    variable names (+ the int64 `global_step` the Estimators keep).  -> the checkpoint prefix."""
+    variable names (+ the int64 `global_step` the Estimators keep).  num_ps_replicas > 0: the [vocab, K] embedding / linear weight
+    variables are written as PARTITIONED variables, cut by the reference's partitioner (min_max_variable_partitioner(max_partitions =
+    num_ps_replicas, min_slice_size = 64 << 20), models/DeepFM/deepFM.py:163-167: shard.partitions_for) -- what a run on parameter
+    servers leaves in model_dir.  -> the checkpoint prefix."""
     import os
     from . import tf_bundle
     os.makedirs(model_dir, exist_ok=True)
     tensors = tf_tensors(model)
+    partitions = {}
+    if num_ps_replicas:
+        from .shard import partitions_for
+        for k, a in tensors.items():
+            if k.endswith("embedding_weights") or k.endswith("/weights"):
+                a2 = np.asarray(a)
+                if a2.ndim == 2:
+                    n = partitions_for(a2.shape[0], a2.shape[1], num_ps_replicas, bytes_per_element=a2.dtype.itemsize)
+                    if n > 1:
+                        partitions[k] = n
     tensors["global_step"] = np.array(int(global_step), dtype=np.int64)
     ckpt = "%s-%d" % (name, int(global_step))
-    tf_bundle.write_bundle(os.path.join(model_dir, ckpt), tensors)
+    tf_bundle.write_bundle(os.path.join(model_dir, ckpt), tensors, partitions=partitions)
     tf_bundle.write_checkpoint_state(model_dir, ckpt)
     return os.path.join(model_dir, ckpt)
 
@@ -165,6 +180,8 @@ def load_tf_checkpoint(model, path, strict=True):
                 raise ValueError("%s: checkpoint shape %s vs parameter %s" % (k, a.shape, tuple(t.shape)))
             t.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(t.device, t.dtype))
     step = int(data["global_step"]) if "global_step" in data else None
+    from . import ops
+    ops.invalidate_caches()
     return missing, step
 
 

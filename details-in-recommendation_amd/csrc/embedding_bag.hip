@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
                                                  const int64_t* __restrict__ offsets /* nullptr: one entry per bag */,
                                                  const float* __restrict__ weights, int64_t sb, int64_t sf,
                                                  int F, int K, int64_t B, const int32_t* __restrict__ slot_combiner,
-                                                 int combiner, float max_norm, int flags,
+                                                 int combiner, const float* __restrict__ slot_max_norm, float max_norm, int flags,
                                                  float* __restrict__ out, int64_t out_ld) {
     // A bag needs three dependent global reads (offsets -> ids/weights -> rows).  The loop over the fields of a sample is
     // software-pipelined so that only the row reads are on the critical path: at field f the offsets of field f+2 and the
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
         for (int f = 0; f < F; ++f) {
             const float* t = tables[f];
             const int comb = slot_combiner ? slot_combiner[f] : combiner;
+            const float mn = slot_max_norm ? slot_max_norm[f] : max_norm;     // every embedding_column carries its own max_norm (0: none)
             load_off(f + 2, beg2, end2);
             load_ent(beg1, end1, f + 1, id1, w1);       // field f+1 (empty range when f+1 == F)
             V acc = vzero((V*)nullptr);
@@ -307,9 +308,9 @@ __global__ __launch_bounds__(256) void bag_csr_k(const float* const* __restrict_
                     row[u] = vzero((V*)nullptr);
                     if (id0[u] >= 0 && cact) row[u] = nt ? ldv_nt(t + id0[u] * K + c * VEC, (V*)nullptr) : ldv(t + id0[u] * K + c * VEC, (V*)nullptr);
                 }
-                if (CLIP) {                              // (a template parameter: the unclipped kernel carries none of this)
+                if (CLIP && mn > 0.f) {                  // (CLIP is a template parameter: the unclipped kernel carries none of this)
 #pragma unroll
-                    for (int u = 0; u < U; ++u) row[u] = clip_row<LPS>(row[u], max_norm, lane, c);
+                    for (int u = 0; u < U; ++u) row[u] = clip_row<LPS>(row[u], mn, lane, c);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -467,8 +468,8 @@ static int launch_onehot(const float* const* tables, const int64_t* vocab, int F
 }
 
 static int launch_csr(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids, const int64_t* offsets,
-                      const float* weights, int64_t sb, int64_t sf, const int32_t* slot_combiner, int combiner, float max_norm,
-                      int flags, int64_t B, float* out, int64_t out_ld, hipStream_t st) {
+                      const float* weights, int64_t sb, int64_t sf, const int32_t* slot_combiner, int combiner, const float* slot_max_norm,
+                      float max_norm, int flags, int64_t B, float* out, int64_t out_ld, hipStream_t st) {
     const bool vec = (K % 4 == 0) && (out_ld % 4 == 0) && aligned16(out);
     const int lps = next_pow2(vec ? K / 4 : K);
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "embedding row of K=%d floats is wider than one wave covers", K);
@@ -477,12 +478,12 @@ static int launch_csr(const float* const* tables, const int64_t* vocab, int F, i
     dim3 grid(grid_for((waves + 3) / 4));
 #define DIR_CASE(L, V)                                                                                                              \
     do {                                                                                                                            \
-        if (max_norm > 0.f)                                                                                                         \
+        if (max_norm > 0.f || slot_max_norm)                                                                                        \
             hipLaunchKernelGGL((bag_csr_k<L, V, true>), grid, dim3(256), 0, st, tables, vocab, ids, offsets, weights, sb, sf, F, K, B, \
-                               slot_combiner, combiner, max_norm, flags, out, out_ld);                                              \
+                               slot_combiner, combiner, slot_max_norm, max_norm, flags, out, out_ld);                               \
         else                                                                                                                        \
             hipLaunchKernelGGL((bag_csr_k<L, V, false>), grid, dim3(256), 0, st, tables, vocab, ids, offsets, weights, sb, sf, F, K, B, \
-                               slot_combiner, combiner, max_norm, flags, out, out_ld);                                              \
+                               slot_combiner, combiner, slot_max_norm, max_norm, flags, out, out_ld);                               \
     } while (0)
     if (vec) {
         switch (lps) {
@@ -514,10 +515,10 @@ static int launch_csr(const float* const* tables, const int64_t* vocab, int F, i
 
 using namespace dir;
 
-extern "C" int dir_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
-                                        const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
-                                        const int32_t* slot_combiner, int combiner, float max_norm, int flags, int64_t B,
-                                        float* out, int64_t out_ld, dir_stream_t stream) {
+extern "C" int dir_embedding_bag_ex2_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
+                                         const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
+                                         const int32_t* slot_combiner, int combiner, const float* slot_max_norm, float max_norm, int flags,
+                                         int64_t B, float* out, int64_t out_ld, dir_stream_t stream) {
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0, "dir_embedding_bag_f32: F=%d K=%d B=%lld", F, K, (long long)B);
     if (B == 0) return DIR_OK;  // an empty batch carries no buffers
     DIR_CHECK_ARG(tables && ids && out, "dir_embedding_bag_f32: null pointer");
@@ -525,10 +526,18 @@ extern "C" int dir_embedding_bag_ex_f32(const float* const* tables, const int64_
     DIR_CHECK_ARG(combiner >= DIR_COMBINER_SUM && combiner <= DIR_COMBINER_SQRTN, "dir_embedding_bag_f32: combiner=%d", combiner);
     DIR_CHECK_ARG(offsets || !weights, "dir_embedding_bag_f32: weights need offsets (multi-hot)");
     DIR_CHECK_ARG(!(max_norm < 0.f), "dir_embedding_bag_f32: max_norm=%g", max_norm);
-    if (!offsets && !(max_norm > 0.f))  // a one-entry bag without clipping: every combiner is the identity on it
+    if (!offsets && !(max_norm > 0.f) && !slot_max_norm)  // a one-entry bag without clipping: every combiner is the identity on it
         return launch_onehot<false, true>(tables, vocab, F, K, ids, stride_b, stride_f, flags, B, out, out_ld, nullptr, as_stream(stream));
-    return launch_csr(tables, vocab, F, K, ids, offsets, weights, stride_b, stride_f, slot_combiner, combiner, max_norm, flags, B, out,
-                      out_ld, as_stream(stream));
+    return launch_csr(tables, vocab, F, K, ids, offsets, weights, stride_b, stride_f, slot_combiner, combiner, slot_max_norm, max_norm, flags, B,
+                      out, out_ld, as_stream(stream));
+}
+
+extern "C" int dir_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
+                                        const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
+                                        const int32_t* slot_combiner, int combiner, float max_norm, int flags, int64_t B,
+                                        float* out, int64_t out_ld, dir_stream_t stream) {
+    return dir_embedding_bag_ex2_f32(tables, vocab, F, K, ids, offsets, weights, stride_b, stride_f, slot_combiner, combiner, nullptr, max_norm,
+                                     flags, B, out, out_ld, stream);
 }
 
 extern "C" int dir_embedding_bag_f32(const float* const* tables, int F, int K, const int64_t* ids,

@@ -19,6 +19,7 @@ from . import autograd as ag
 from . import ops
 from .deepfm import _BatchNormInfer, _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
+from ._input import checked_forward as _checked_forward
 from ._input import raise_pending
 
 
@@ -108,6 +109,7 @@ class DeepCrossNetwork(nn.Module):
         raise_pending()
         return out
 
+    @_checked_forward
     def forward(self, features):
         if (not torch.is_grad_enabled() and not isinstance(features, torch.Tensor) and self.column_num % 4
                 and len(self.hidden) and self.cross_layer_num > 0):

@@ -19,6 +19,7 @@ from torch import nn
 from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack_supported, tower_infer, units1
 from . import autograd as ag
 from . import ops
+from ._input import checked_forward as _checked_forward
 from ._input import collect_ids, categorical_of, raise_pending
 
 
@@ -220,9 +221,9 @@ class DeepFM(nn.Module):
 
     def _max_norm(self):
         mn = [getattr(c, "max_norm", None) for c in self.dnn_feature_columns]
-        if any(m != mn[0] for m in mn):
-            raise NotImplementedError("embedding columns of one DeepFM must share max_norm (one value per launch)")
-        return mn[0] if mn else None
+        if not mn or all(m == mn[0] for m in mn):
+            return mn[0] if mn else None
+        return mn                                            # one max_norm per column: the bag kernel takes a per-slot array
 
     def linear_logit_fn(self, features, device, got=None):
         """_linear_logit_fn_builder (deepFM.py:255-275): linear_model(units, sparse_combiner) + bias -> [B, units]."""
@@ -255,6 +256,7 @@ class DeepFM(nn.Module):
             per = ops.embedding_bag(lin_ts, args[0], combiner=comb, **kw)
         return per.view(B, Fl, self.units).sum(dim=1) + self.linear_bias
 
+    @_checked_forward
     def forward(self, features):
         if not isinstance(features, dict):
             raise ValueError("features should be a dictionary of `Tensor`s. Given type: {}".format(type(features)))  # :159-161

@@ -14,6 +14,7 @@ from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack
 from .dcn import _glorot_normal_
 from .deepfm import _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
+from ._input import checked_forward as _checked_forward
 
 _EPSILON = 1e-7                                                                  # ESMM.py:19
 
@@ -59,6 +60,7 @@ class ESMM(nn.Module):
         self.ctr_model = _BaseModel(columns, hidden, dnn_activation_fn, dnn_dropout)          # ESMM.py:63-64
         self.cvr_model = _BaseModel(columns, hidden, dnn_activation_fn, dnn_dropout)          # ESMM.py:65-66
 
+    @_checked_forward
     def forward(self, features):
         """-> {'ctr_logits', 'ctcvr_logits'} (the `logits` dict of ESMM.py:77)."""
         memo = {}                                                                # both towers read the same columns: one id matrix

@@ -152,6 +152,25 @@ def slot_combiners(ts, combiner):
     return cache[key], codes[0]
 
 
+def slot_max_norms(ts, max_norm):
+    """`max_norm` as the C ABI takes it: (slot_max_norm device fp32 [F] | None, max_norm).  None / a number applies to every slot; a
+    sequence gives one value per slot (None / 0: that slot is not clipped)."""
+    if max_norm is None or isinstance(max_norm, (int, float)):
+        return None, float(max_norm or 0.0)
+    vals = [float(m or 0.0) for m in max_norm]
+    if len(vals) != ts.F:
+        raise ValueError("one max_norm per slot: got %d for F=%d" % (len(vals), ts.F))
+    if any(v < 0 for v in vals):
+        raise ValueError("max_norm must be >= 0")
+    if all(v == vals[0] for v in vals):
+        return None, vals[0]
+    key = tuple(vals)
+    cache = ts.__dict__.setdefault("_slot_max_norm_cache", {})
+    if key not in cache:
+        cache[key] = torch.tensor(vals, dtype=torch.float32, device=ts.device)
+    return cache[key], 0.0
+
+
 def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", field_major=False, flags=0,
                   out=None, max_norm=None):
     """Multi-slot embedding bag -> [B, F*K] (slot order).
@@ -159,7 +178,8 @@ def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", fiel
     one-hot : ids LongTensor [B, F] (arbitrary strides, e.g. torch.stack(per_field).t()).
     multi-hot: ids [nnz], offsets [B*F+1]; bag(b,f) = b*F+f, or f*B+b when field_major (the layout
                that concatenating per-column CSR inputs gives); weights optional [nnz].
-    combiner: one name for all slots or a sequence of F names; max_norm: [TF-upstream] embedding_column(max_norm=).
+    combiner: one name for all slots or a sequence of F names; max_norm: [TF-upstream] embedding_column(max_norm=), one value or a
+    sequence of F values (None / 0: no clipping for that slot).
     ids outside [0, vocab_f) contribute nothing (id < 0: pruned as in the reference; id >= vocab_f: zeros as on TF GPU).
     """
     ts = _as_tableset(tables)
@@ -184,9 +204,9 @@ def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", fiel
     if offsets is None:
         flags |= ts.gather_flags()
     slot_comb, comb = slot_combiners(ts, combiner)
-    _lib.check(lib.dir_embedding_bag_ex_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
-                                            _ptr(slot_comb), comb, float(max_norm or 0.0), flags, B, _ptr(out), out.stride(0),
-                                            _stream()))
+    slot_mn, mn = slot_max_norms(ts, max_norm)
+    _lib.check(lib.dir_embedding_bag_ex2_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
+                                             _ptr(slot_comb), comb, _ptr(slot_mn), mn, flags, B, _ptr(out), out.stride(0), _stream()))
     return out
 
 
@@ -366,6 +386,14 @@ def dense_supported(x, weight):
 DENSE_ARITH = os.environ.get("DIR_DENSE_ARITH", "auto")
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
+
+
+def invalidate_caches():
+    """Drop every cached weight image (dense / tower bf16x3 images).  The caches follow tensor._version, which in-place torch ops bump;
+    a write through `param.data`, a raw-pointer kernel or a checkpoint loader that copies into storage directly does not -- call this
+    after such a write (checkpoint.load_* do)."""
+    _DENSE_IMAGES.clear()
+    _TOWER_IMAGES.clear()
 
 
 def dense_bf16x3_covers(x, weight, out=None, gate=None):

@@ -19,8 +19,16 @@ The arithmetic lives in a third-party dependency that is not vendored in /root/r
   * crc32c masking (lib/hash/crc32c.h): ((crc >> 15) | (crc << 17)) + 0xa282ead8.
 PARITY NOTE: no TensorFlow checkpoint file exists in this container to read back, so the implementation is pinned by the format
 invariants above (tests/test_host_logic.py: footer magic, block CRCs, prefix compression with restart points, round trips) -- not
-by a TF-written fixture.  Partitioned variables (entries with `slices`) are not supported on read (the reference's local runs have
-num_ps_replicas = 0: unpartitioned, deepFM.py:162).
+by a TF-written fixture.
+Partitioned variables.  Under a partitioner scope (models/DeepFM/deepFM.py:163-175 with num_ps_replicas > 0) TensorFlow creates
+`.../embedding_weights/part_N` variables carrying a SaveSliceInfo, and the Saver stores them as SLICES of the full tensor: the index holds
+the full name -> BundleEntryProto {dtype, FULL shape, slices = [TensorSliceProto ...]} (no data of its own) and, per slice, a key
+checkpoint::EncodeTensorNameSlice(name, slice) -> BundleEntryProto {dtype, slice shape, shard_id, offset, size, crc32c}
+(tensorflow/core/util/saved_tensor_slice_util.cc; the key is an OrderedCode string: NumIncreasing(0), String(name),
+NumIncreasing(rank), then SignedNumIncreasing(start), SignedNumIncreasing(length) per dimension, a full dimension as (0, -1);
+tensorflow/core/lib/strings/ordered_code.cc).  read_bundle assembles such a variable from its slices; write_bundle(partitions=) cuts a
+tensor along axis 0 into the 'div' row ranges of shard.div_range and writes it that way.  Restated from the published sources like the
+rest of the format; KATs of the key encoding in tests/test_host_logic.py.
 """
 import os
 import struct
@@ -46,7 +54,7 @@ def _crc32c(data, crc=0):
             return crc
         buf = np.ascontiguousarray(buf)
         return int(lib.dir_crc32c(crc, buf.ctypes.data, buf.size))
-    except (RuntimeError, OSError):
+    except (RuntimeError, OSError, AttributeError):      # library not built / a stale build without dir_crc32c
         return _crc32c_py(bytes(data), crc)
 
 
@@ -54,6 +62,8 @@ _PYT = None
 
 
 def _crc32c_py(data, crc=0):
+    """Table-driven fallback (~10 MB/s in CPython: fine for index blocks; for multi-GB tensor shards build the library, or read with
+    verify=False)."""
     global _PYT
     if _PYT is None:
         _PYT = []
@@ -138,10 +148,15 @@ def _shape_proto(shape):
     return out
 
 
-def _entry_proto(dtype, shape, offset, size, crc_masked):
+def _entry_proto(dtype, shape, offset, size, crc_masked, slices=None):
     out = b"\x08" + _varint(dtype)
     sp = _shape_proto(shape)
     out += b"\x12" + _varint(len(sp)) + sp
+    if slices is not None:                                   # a partitioned variable's header entry: full shape + its slices, no data
+        for ext in slices:
+            sl = _slice_proto(ext)
+            out += b"\x3a" + _varint(len(sl)) + sl
+        return out
     if offset:
         out += b"\x20" + _varint(offset)                     # shard_id = 0 (default) is not written
     out += b"\x28" + _varint(size)
@@ -150,7 +165,7 @@ def _entry_proto(dtype, shape, offset, size, crc_masked):
 
 
 def _parse_entry(buf):
-    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "slices": 0}
+    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": None, "slices": []}
     for f, wt, v in _fields(buf):
         if f == 1:
             e["dtype"] = v
@@ -171,8 +186,92 @@ def _parse_entry(buf):
         elif f == 6:
             e["crc32c"] = v
         elif f == 7:
-            e["slices"] += 1
+            e["slices"].append(_parse_slice(v))
     return e
+
+
+# ---- tensor slices (partitioned variables) -------------------------------------------------------------------------------------------
+def _parse_slice(buf):
+    """TensorSliceProto {repeated Extent extent = 1}, Extent {int64 start = 1; oneof {int64 length = 2}} -> [(start, length | -1)]
+    (-1 = the whole dimension: TensorSlice::kFullExtent)."""
+    ext = []
+    for f, _, v in _fields(buf):
+        if f == 1:
+            start, length = 0, -1
+            for f2, _, v2 in _fields(v):
+                if f2 == 1:
+                    start = v2 if v2 < (1 << 63) else v2 - (1 << 64)
+                elif f2 == 2:
+                    length = v2 if v2 < (1 << 63) else v2 - (1 << 64)
+            ext.append((start, length))
+    return ext
+
+
+def _slice_proto(extents):
+    out = b""
+    for start, length in extents:
+        e = b""
+        if start:
+            e += b"\x08" + _varint(start)
+        if length >= 0:
+            e += b"\x10" + _varint(length)
+        out += b"\x0a" + _varint(len(e)) + e
+    return out
+
+
+def _oc_num_increasing(v):
+    """OrderedCode::WriteNumIncreasing: one length byte, then the value big-endian without leading zero bytes."""
+    b = b""
+    while v > 0:
+        b = bytes([v & 0xff]) + b
+        v >>= 8
+    return bytes([len(b)]) + b
+
+
+def _oc_string(s):
+    """OrderedCode::WriteString: \\x00 -> \\x00\\xff, \\xff -> \\xff\\x00, terminated by \\x00\\x01."""
+    return _oc_escape(s) + b"\x00\x01"
+
+
+def _oc_escape(s):
+    out = bytearray()
+    for c in s:
+        if c == 0:
+            out += b"\x00\xff"
+        elif c == 0xff:
+            out += b"\xff\x00"
+        else:
+            out.append(c)
+    return bytes(out)
+
+
+_OC_HEADER = {1: (0x80, 0), 2: (0xc0, 0), 3: (0xe0, 0), 4: (0xf0, 0), 5: (0xf8, 0), 6: (0xfc, 0), 7: (0xfe, 0), 8: (0xff, 0),
+              9: (0xff, 0x80), 10: (0xff, 0xc0)}
+
+
+def _oc_signed_increasing(val):
+    """OrderedCode::WriteSignedNumIncreasing: 7 payload bits per byte, a unary length prefix XORed into the sign-extended big-endian
+    value (|val| < 64 -> one byte 0x80 ^ val)."""
+    x = ~val if val < 0 else val
+    if x < 64:
+        return bytes([(0x80 ^ val) & 0xff])
+    bits = x.bit_length() + 1                               # value bits + the sign bit
+    n = -(-bits // 7)
+    raw = (val & ((1 << 80) - 1)).to_bytes(10, "big")       # sign-extended to 10 bytes
+    b = bytearray(raw[10 - n:])
+    h0, h1 = _OC_HEADER[n]
+    b[0] ^= h0
+    if n >= 2:
+        b[1] ^= h1
+    return bytes(b)
+
+
+def encode_tensor_name_slice(name, extents):
+    """checkpoint::EncodeTensorNameSlice: the index key under which one slice of a partitioned variable is stored."""
+    out = _oc_num_increasing(0) + _oc_string(name.encode("utf-8")) + _oc_num_increasing(len(extents))
+    for start, length in extents:
+        out += _oc_signed_increasing(start) + _oc_signed_increasing(length)
+    return out
 
 
 # ---- the sorted table ------------------------------------------------------------------------------------------------------------------
@@ -288,11 +387,20 @@ def read_table(path, verify=True):
 
 
 # ---- bundles -----------------------------------------------------------------------------------------------------------------------------
-def write_bundle(prefix, tensors):
-    """tensors: {name: ndarray} -> `<prefix>.index` + `<prefix>.data-00000-of-00001` (one shard, little endian)."""
+def write_bundle(prefix, tensors, partitions=None):
+    """tensors: {name: ndarray} -> `<prefix>.index` + `<prefix>.data-00000-of-00001` (one shard, little endian).
+    partitions: {name: n} -- write that tensor as a partitioned variable of n axis-0 slices ('div' row ranges, what
+    min_max_variable_partitioner + partition_strategy='div' produce: models/DeepFM/deepFM.py:163-167)."""
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
-    items = [(b"", _header_proto())]
+    partitions = dict(partitions or {})
+    items = {b"": _header_proto()}
     with open(prefix + ".data-00000-of-00001", "wb") as data:
+        def put(key, a):
+            off = data.tell()
+            raw = a.reshape(-1).view(np.uint8)
+            data.write(raw.tobytes() if raw.size < (1 << 20) else memoryview(raw))
+            items[key] = _entry_proto(_NP2DT[a.dtype], a.shape, off, raw.size, mask_crc(_crc32c(raw)))
+
         for name in sorted(tensors, key=lambda s: s.encode("utf-8")):
             a = np.asarray(tensors[name])
             if not a.flags.c_contiguous:
@@ -300,15 +408,27 @@ def write_bundle(prefix, tensors):
             if a.dtype not in _NP2DT:
                 raise TypeError("%s: dtype %s has no checkpoint DataType here" % (name, a.dtype))
             a = a.astype(a.dtype.newbyteorder("<"), copy=False)
-            off = data.tell()
-            raw = a.reshape(-1).view(np.uint8)
-            data.write(raw.tobytes() if raw.size < (1 << 20) else memoryview(raw))
-            items.append((name.encode("utf-8"), _entry_proto(_NP2DT[a.dtype], a.shape, off, raw.size, mask_crc(_crc32c(raw)))))
-    write_table(prefix + ".index", items)
+            n = int(partitions.get(name, 1))
+            if n <= 1:
+                put(name.encode("utf-8"), a)
+                continue
+            if a.ndim < 1 or n > a.shape[0]:
+                raise ValueError("%s: cannot cut %s into %d axis-0 slices" % (name, a.shape, n))
+            q, r = divmod(a.shape[0], n)
+            exts, start = [], 0
+            for j in range(n):
+                rows = q + 1 if j < r else q
+                ext = [(start, rows)] + [(0, -1)] * (a.ndim - 1)
+                exts.append(ext)
+                put(encode_tensor_name_slice(name, ext), np.ascontiguousarray(a[start:start + rows]))
+                start += rows
+            items[name.encode("utf-8")] = _entry_proto(_NP2DT[a.dtype], a.shape, 0, 0, 0, slices=exts)
+    write_table(prefix + ".index", sorted(items.items()))
 
 
 def read_bundle(prefix, names=None, verify=True):
-    """-> {name: ndarray} of `<prefix>.index` + its data shards (all tensors, or just `names`)."""
+    """-> {name: ndarray} of `<prefix>.index` + its data shards (all tensors, or just `names`).  A partitioned variable (an entry
+    with `slices`) comes back whole, assembled from its slices; the slices' own keys are not listed."""
     items = read_table(prefix + ".index", verify)
     if not items or items[0][0] != b"":
         raise ValueError("%s.index has no bundle header" % prefix)
@@ -318,15 +438,10 @@ def read_bundle(prefix, names=None, verify=True):
             num_shards = v
         elif f == 2 and v != 0:
             raise ValueError("big-endian bundles are not supported")
+    table = dict(items[1:])
     shards = {}
-    out = {}
-    for key, val in items[1:]:
-        name = key.decode("utf-8")
-        if names is not None and name not in names:
-            continue
-        e = _parse_entry(val)
-        if e["slices"]:
-            raise NotImplementedError("%s is a partitioned variable (saved as slices): not supported" % name)
+
+    def load(name, e):
         if e["dtype"] not in _DT:
             raise TypeError("%s: checkpoint DataType %d is not supported" % (name, e["dtype"]))
         sid = e["shard_id"]
@@ -336,7 +451,36 @@ def read_bundle(prefix, names=None, verify=True):
         if verify and e["crc32c"] is not None and unmask_crc(e["crc32c"]) != _crc32c(raw):
             raise ValueError("%s fails its crc32c" % name)
         dt = np.dtype(_DT[e["dtype"]]).newbyteorder("<")
-        out[name] = raw.view(dt).reshape(e["shape"]).astype(_DT[e["dtype"]], copy=True)
+        return raw.view(dt).reshape(e["shape"]).astype(_DT[e["dtype"]], copy=True)
+
+    out = {}
+    for key, val in items[1:]:
+        if key[:1] == b"\x00":                              # a slice's own key (EncodeTensorNameSlice starts with NumIncreasing(0))
+            continue
+        name = key.decode("utf-8")
+        if names is not None and name not in names:
+            continue
+        e = _parse_entry(val)
+        if not e["slices"]:
+            out[name] = load(name, e)
+            continue
+        if e["dtype"] not in _DT:
+            raise TypeError("%s: checkpoint DataType %d is not supported" % (name, e["dtype"]))
+        full = np.empty(e["shape"], _DT[e["dtype"]])
+        covered = 0
+        for ext in e["slices"]:
+            skey = encode_tensor_name_slice(name, ext)
+            if skey not in table:
+                raise ValueError("%s: the index lists a slice %s whose data entry is missing" % (name, ext))
+            part = load("%s%s" % (name, ext), _parse_entry(table[skey]))
+            idx = tuple(slice(st, None if ln < 0 else st + ln) for st, ln in ext)
+            if full[idx].shape != part.shape:
+                raise ValueError("%s: slice %s has shape %s, expected %s" % (name, ext, part.shape, full[idx].shape))
+            full[idx] = part
+            covered += part.size
+        if covered != full.size:
+            raise ValueError("%s: its %d slices cover %d of %d elements" % (name, len(e["slices"]), covered, full.size))
+        out[name] = full
     return out
 
 

@@ -9,6 +9,7 @@ from torch import nn
 from .dense import dense_act, mlp_stack, mlp_stack_supported
 from . import autograd as ag
 from . import ops
+from ._input import checked_forward as _checked_forward
 from ._input import collect_ids, categorical_of
 from .deepfm import _glorot_uniform_
 
@@ -118,6 +119,7 @@ class XDeepFM(nn.Module):
             logits = logits + linear_logit
         return logits
 
+    @_checked_forward
     def forward(self, features):
         device = self.linear_bias.device
         emb_ts, lin_ts = self._tablesets()

@@ -97,6 +97,14 @@ int dir_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, i
                              int64_t stride_b, int64_t stride_f, const int32_t* slot_combiner, int combiner,
                              float max_norm, int flags, int64_t B, float* out, int64_t out_ld, dir_stream_t stream);
 
+/* ... and with one max_norm PER SLOT (every embedding_column carries its own max_norm=, like its own combiner=):
+ *   slot_max_norm  DEVICE fp32 [F] or NULL; entry f > 0 clips slot f's rows to that norm, 0 leaves them; NULL: `max_norm` for all. */
+int dir_embedding_bag_ex2_f32(const float* const* tables, const int64_t* vocab, int F, int K,
+                              const int64_t* ids, const int64_t* offsets, const float* weights,
+                              int64_t stride_b, int64_t stride_f, const int32_t* slot_combiner, int combiner,
+                              const float* slot_max_norm, float max_norm, int flags, int64_t B, float* out, int64_t out_ld,
+                              dir_stream_t stream);
+
 /* Validation of the precondition above (debug aid, asynchronous like everything else).
  * vocab: DEVICE array [F].  bad_count: DEVICE int32; zeroed on the stream, then set to the number of
  * ids >= vocab_f or < -1 found (-1 is the legal "missing" marker: pruned).  The caller reads it back and treats a

@@ -53,10 +53,11 @@ static void orc_clip_row(const float* row, int K, float max_norm, float* dst) {
     for (int k = 0; k < K; ++k) dst[k] = (row[k] * max_norm) / den;
 }
 
-int orc_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
-                             const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
-                             const int32_t* slot_combiner, int combiner, float max_norm, int flags, int64_t B,
-                             float* out, int64_t out_ld) {
+/* ex2: slot_max_norm [F] or NULL -- one max_norm per column (an embedding_column carries its own, like its combiner); entry 0 = none. */
+int orc_embedding_bag_ex2_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
+                              const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
+                              const int32_t* slot_combiner, int combiner, const float* slot_max_norm, float max_norm_all, int flags,
+                              int64_t B, float* out, int64_t out_ld) {
     if (!tables || !ids || !out || F <= 0 || K <= 0 || B < 0 || K > 4096) return -1;
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
@@ -65,6 +66,7 @@ int orc_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, i
             float* o = out + b * out_ld + (int64_t)f * K;
             const float* tab = tables[f];
             const int comb = slot_combiner ? slot_combiner[f] : combiner;
+            const float max_norm = slot_max_norm ? slot_max_norm[f] : max_norm_all;
             const int64_t vf = vocab ? vocab[f] : INT64_MAX;
             for (int k = 0; k < K; ++k) o[k] = 0.0f;
             int64_t bag = b * stride_b + f * stride_f;
@@ -106,6 +108,14 @@ int orc_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, i
         }
     }
     return 0;
+}
+
+int orc_embedding_bag_ex_f32(const float* const* tables, const int64_t* vocab, int F, int K, const int64_t* ids,
+                             const int64_t* offsets, const float* weights, int64_t stride_b, int64_t stride_f,
+                             const int32_t* slot_combiner, int combiner, float max_norm, int flags, int64_t B,
+                             float* out, int64_t out_ld) {
+    return orc_embedding_bag_ex2_f32(tables, vocab, F, K, ids, offsets, weights, stride_b, stride_f, slot_combiner, combiner, NULL, max_norm,
+                                     flags, B, out, out_ld);
 }
 
 int orc_embedding_bag_f32(const float* const* tables, int F, int K, const int64_t* ids,

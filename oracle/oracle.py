@@ -82,11 +82,16 @@ def embedding_bag(tables, ids, offsets=None, weights=None, stride_b=None, stride
     if vocab is True:
         vocab = [t.shape[0] for t in tables]
     voc = _i64(vocab) if vocab is not None else None
-    rc = lib().orc_embedding_bag_ex_f32(_ptr_array(tables), _p(voc, ctypes.c_int64), F, K, _p(ids, ctypes.c_int64),
-                                        _p(offsets, ctypes.c_int64), _p(weights, ctypes.c_float),
-                                        ctypes.c_int64(stride_b), ctypes.c_int64(stride_f), _p(slot, ctypes.c_int32),
-                                        int(combiner), ctypes.c_float(max_norm), flags,
-                                        ctypes.c_int64(B), _p(out, ctypes.c_float), ctypes.c_int64(out_ld))
+    slot_mn = None
+    if max_norm is not None and not isinstance(max_norm, (int, float, np.floating, np.integer)):   # one max_norm per slot (None / 0: none)
+        slot_mn = np.ascontiguousarray([float(m or 0.0) for m in max_norm], np.float32)
+        assert slot_mn.size == F
+        max_norm = 0.0
+    rc = lib().orc_embedding_bag_ex2_f32(_ptr_array(tables), _p(voc, ctypes.c_int64), F, K, _p(ids, ctypes.c_int64),
+                                         _p(offsets, ctypes.c_int64), _p(weights, ctypes.c_float),
+                                         ctypes.c_int64(stride_b), ctypes.c_int64(stride_f), _p(slot, ctypes.c_int32),
+                                         int(combiner), _p(slot_mn, ctypes.c_float), ctypes.c_float(max_norm or 0.0), flags,
+                                         ctypes.c_int64(B), _p(out, ctypes.c_float), ctypes.c_int64(out_ld))
     assert rc == 0, rc
     return out
 
