@@ -20,7 +20,10 @@ EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # VALU instruction beside bf16 MFMAs costs more than the two scalar ones it replaces
                "cin_bf3.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "dense_bf3.hip": ["-fno-slp-vectorize"],
-               "tower_bf3.hip": ["-fno-slp-vectorize"],
+               # tower_bf3's k loop must be unrolled completely (register arrays need static indices): 13 x 26 x 12 MFMAs exceed the default
+               # full-unroll thresholds, and a rolled loop sends the activations to scratch
+               "tower_bf3.hip": ["-fno-slp-vectorize", "-mllvm", "-unroll-threshold=1000000", "-mllvm", "-unroll-max-count=64",
+                                 "-mllvm", "-unroll-full-max-count=64"],
                "cin_dw_bf3.hip": ["-fno-slp-vectorize"],
                "dense_dw_bf3.hip": ["-fno-slp-vectorize"],
                # din_wave's queue ticket is ONE lane's atomic whose result is consumed a sample later; the atomic optimizer would rewrite

@@ -334,7 +334,7 @@ def tower_infer(lins, x, activation, bns=None, head=None, adds=()):
     to an affine), and the units = 1 logit layer `head` on top when given -- in ONE launch of dir_tower_bf16x3_f32 (csrc/tower_bf3.hip:
     the activations of a 128-row tile stay in registers from layer to layer).  -> the logits [B, 1] (+ the [B, 1] tensors in adds, at
     most two: the other terms of add_n, deepFM.py:217-223) or, without a head, the last activation; None when the tower is not covered
-    (autograd recording, fewer than ops.TOWER_MIN_ROWS rows, a width over 416 or not a multiple of 4, an activation other than ReLU /
+    (autograd recording, fewer than ops.TOWER_MIN_ROWS rows, a width over 416, under ops.TOWER_MIN_WIDTH or not a multiple of 4, an activation other than ReLU /
     none, a head with more than one unit): the caller then runs it layer by layer."""
     if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in lins)):
         return None
@@ -343,7 +343,7 @@ def tower_infer(lins, x, activation, bns=None, head=None, adds=()):
     if bns is not None and len(bns) and any(b.training and torch.is_grad_enabled() for b in bns):
         return None
     ws = [l.weight for l in lins]
-    if not ops.tower_covers(x, ws):
+    if not ops.tower_covers(x, ws) or min(int(w.shape[0]) for w in ws) < ops.TOWER_MIN_WIDTH:
         return None
     if head is not None and (head.out_features != 1 or head.bias is None or head.in_features != lins[-1].out_features):
         return None

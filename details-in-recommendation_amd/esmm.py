@@ -10,7 +10,7 @@ SURVEY.md 8(f) rank 3: the same gather kernel, used twice per step.
 import torch
 from torch import nn
 
-from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack_supported, units1
+from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack_supported, tower_infer, units1
 from .dcn import _glorot_normal_
 from .deepfm import _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
@@ -39,6 +39,9 @@ class _BaseModel(nn.Module):
 
     def forward(self, features, memo=None):
         net = self.input_layer(features, memo=memo)
+        fused = tower_infer(self.hidden, net, self.activation, head=self.logits)          # inference: tower + logit layer in one launch
+        if fused is not None:
+            return fused
         if not self.dropout and mlp_stack_supported(self.hidden, net, self.activation):
             if mlp_head_supported(self.hidden, self.logits, net, self.activation):
                 return mlp_head(self.hidden, self.logits, net)                           # training: tower + logit layer as one autograd node

@@ -6,7 +6,7 @@ import math
 import torch
 from torch import nn
 
-from .dense import dense_act, mlp_stack, mlp_stack_supported
+from .dense import dense_act, mlp_stack, mlp_stack_supported, tower_infer
 from . import autograd as ag
 from . import ops
 from ._input import checked_forward as _checked_forward
@@ -109,6 +109,12 @@ class XDeepFM(nn.Module):
         B = emb.shape[0]
         logits = self.cin_out(self.cin(emb.view(B, self.m, self.D)))
         net = emb
+        if self.dnn_out.out_features == 1:
+            # inference: the DNN tower and its logit layer in one launch, the CIN's (and the linear term's) logits added in its epilogue
+            adds = (logits,) if linear_logit is None else (logits, linear_logit)
+            fused = tower_infer(self.hidden, net, self.activation, head=self.dnn_out, adds=adds)
+            if fused is not None:
+                return fused
         if mlp_stack_supported(self.hidden, net, self.activation):
             net = mlp_stack(self.hidden, net)                                   # training: the whole tower as one autograd node
         else:
