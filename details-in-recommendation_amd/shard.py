@@ -658,7 +658,9 @@ class ShardedTables:
             # long ago: the host does not wait and the streams never drain); never: they wait for check_overflow()
             if self.check == "lazy":
                 self._drain_unchecked(block=True)
-            self._unchecked.append(lk)
+            else:
+                self._unchecked = self._unchecked[-1:]    # "never": a plan slot's verdict is overwritten two lookups later -- keep the
+            self._unchecked.append(lk)                   # two newest handles only (check_overflow() reads what is still there)
         return lk
 
     def lookup(self, ids, want_fm=False, out=None, fm=None):
