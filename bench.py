@@ -835,8 +835,11 @@ def main():
         # reduction -> 220 v_mfma_f32_16x16x4_f32 (1024 multiply-adds each) per tile, on the fp32 MFMA pipe
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
         executed = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)
-        roof = {"bound": "mfma", "alg_flops": executed, "pipe_flops": executed * PIPE_COST["f32"], "kernel": "din_wave_k (fp32 MFMA 16x16x4)",
-                "modes": {"din_wave_k": "f32"}, "survey_8d_flops": survey,
+        din_arith = "f32" if os.environ.get("DIR_DIN_ARITH") == "f32" else "bf16x3"
+        roof = {"bound": "mfma", "alg_flops": executed, "pipe_flops": executed * PIPE_COST[din_arith],
+                "kernel": "din_wave_k (%s)" % ("fp32 MFMA 16x16x4" if din_arith == "f32" else "bf16x3 on MFMA 16x16x32"),
+                "modes": {"din_wave_k": din_arith}, "survey_8d_flops": survey,
+                "dtype": "f32 via bf16x3 split, f32 accumulate" if din_arith == "bf16x3" else "f32",
                 "note": "flops = the MFMAs the kernel issues (masked history positions are skipped, layer 1 is regrouped to a 2K reduction); "
                         "SURVEY 8d's all-T, 4K-wide count is reported as survey_8d_flops and not priced"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
@@ -893,9 +896,11 @@ def main():
             ag.din_attention_pool(table, hist, hl, cand, *ws, normalize=True).backward(gout)
         survey = 3 * B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
-        executed = 2.0 * 1024 * rt * (220 + 660)     # 16x16x4 MFMAs per 16-row tile: forward 220; backward 220 recompute + 440
-        roof = {"bound": "mfma", "alg_flops": executed, "pipe_flops": executed * PIPE_COST["f32"], "modes": {"din_wave_k": "f32", "din_rows_k": "f32", "din_wgrad_k": "f32"},
-                "kernel": "din_wave_k + din_rows_k + din_wgrad_k (fp32 MFMA 16x16x4)", "survey_8d_flops": survey,
+        executed = 2.0 * 1024 * rt * (220 + 660)     # 16x16x4-MFMA equivalents per 16-row tile: forward 220; backward 220 recompute + 440
+        din_arith = "f32" if os.environ.get("DIR_DIN_ARITH") == "f32" else "bf16x3"      # the forward's arithmetic; the backward kernels are fp32 MFMA
+        pipe = 2.0 * 1024 * rt * (220 * PIPE_COST[din_arith] + 660 * PIPE_COST["f32"])
+        roof = {"bound": "mfma", "alg_flops": executed, "pipe_flops": pipe, "modes": {"din_wave_k": din_arith, "din_rows_k": "f32", "din_wgrad_k": "f32"},
+                "kernel": "din_wave_k (%s) + din_rows_k + din_wgrad_k (fp32 MFMA 16x16x4)" % din_arith, "survey_8d_flops": survey,
                 "note": "flops = the MFMAs the three kernels issue over valid history rows; 3x SURVEY 8d's forward count is survey_8d_flops, not priced"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
     elif wl == "cin":

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdir_hip.so")
+# DIR_HIP_LIBRARY: a development switch (tools/*_stress.py A/B builds of one kernel); the product loads the in-tree library
+_LIB_PATH = os.environ.get("DIR_HIP_LIBRARY") or os.path.join(_HERE, "libdir_hip.so")
 
 c_i32, c_i64, c_f32p, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
 

@@ -25,6 +25,7 @@
 // 1..50, and a static split of 32 samples per wave would leave the slowest wave ~25 % behind the mean.  The forward has no
 // cross-sample reduction, so the result does not depend on the order.
 #include <atomic>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -39,7 +40,11 @@ constexpr int DW_WAVES = 8;            // waves per workgroup (two per SIMD), on
 constexpr int DW_GROUPS = 8;           // queue shards (sample ranges)
 constexpr int DW_SLOTS = 64;           // queue records for launches in flight
 
+typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
+
 struct DinWaveSh {
+    static constexpr bool kBf3 = false;
     float whd[DW_H1P * DW_WS];         // (Wh + Wd)^T
     float wp[DW_H1P * DW_WS];          // Wp^T
     float wc[DW_H1P * DW_WS];          // (Wa - Wd)^T
@@ -47,6 +52,31 @@ struct DinWaveSh {
     float b1[DW_H1P], b2[DW_H2P], w3[DW_H2P];
     float cvec[DW_WAVES][DW_H1P];      // per wave: the per-sample term c (+ b1)
     float av[DW_WAVES][DW_K];          // per wave: the candidate row of the sample being computed
+};
+
+// The bf16x3 variant (the recipe of cin_bf3.hip / tower_bf3.hip: an fp32 operand is the sum of three bf16 pieces by round-to-nearest,
+// the six piece products of weight >= 2^-16 accumulate in fp32 on v_mfma_f32_16x16x32_bf16 -- 6 x 16 cycles per 32 k instead of
+// 8 x 32 on the fp32 pipe).  The operand / result layouts are those of the fp32 kernel with two of its k-groups per MFMA:
+// element j of lane (kk, r) in k-step ks is reduction index 16 (2 ks + (j >> 2)) + 4 kk + (j & 3), which for layer 1 is the lane's
+// own registers hv[2 ks], hv[2 ks + 1] and for layer 2 its accumulator tiles 2 ks, 2 ks + 1 -- layers still chain in registers.
+// The weight images are split once per workgroup and stored in MFMA A-operand order: [k-step][m tile][piece][lane][8] bf16,
+// one ds_read_b128 per piece per (k-step, m tile), shared by the row tiles of a pass.
+// THIS FILE IS COMPILED WITHOUT PACKED fp32 VALU INSTRUCTIONS (build.py: -target-feature -packed-fp32-ops).  On gfx950 a
+// v_pk_add_f32 / v_pk_fma_f32 whose op_sel sends src1's HIGH register to the LOW result loses that low result in lanes 48..63 when a
+// v_mfma_*_16x16x32_{bf16,f16} is issued on the same SIMD right behind it -- by the same wave (half of all executions) or by the other
+// wave of the SIMD (1-2 %); s_nop in between does not help, the compiler (ROCm 7.2) does not know the hazard (tools/pk_mfma_probe.hip,
+// profiles/NOTES.md R3.6).  The round-2 attempt at this kernel failed on exactly that: the packed (row tile 0, row tile 1) sums of
+// layer 3 lost one sigmoid(pre2) * w3 term of the FIRST row tile in 30-150 samples per launch.  tools/check_pk_mfma.py (run by build.py)
+// rejects any kernel that holds both instruction kinds.
+struct DinWaveSh3 {
+    static constexpr bool kBf3 = true;
+    unsigned int whd3[2 * 5 * 3 * 64 * 4];     // (Wh + Wd)^T pieces
+    unsigned int wp3[2 * 5 * 3 * 64 * 4];      // Wp^T pieces
+    unsigned int w23[3 * 3 * 3 * 64 * 4];      // W2^T pieces; hidden 80..95 of the third k-step are zero
+    float wc[DW_H1P * DW_WS];                  // (Wa - Wd)^T (the per-sample term stays on the VALU in fp32)
+    float b1[DW_H1P], b2[DW_H2P], w3[DW_H2P];
+    float cvec[DW_WAVES][DW_H1P];
+    float av[DW_WAVES][DW_K];
 };
 
 // [slot][0..7] next sample of each range, [slot][8] waves finished.  All zero between launches (the last wave of a launch
@@ -63,6 +93,42 @@ __device__ __forceinline__ float dw_dot4(float4 a, float4 b, float acc) {
     return acc;
 }
 #define DW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define DW_MFMA3(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned int dw_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
+    typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
+    const pk2_t v = {(__bf16)a, (__bf16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));      // see dense_bf3.hip (db3_pk): keeps the compiler from folding the split away
+    return w;
+}
+__device__ __forceinline__ void dw_split_pair(float a, float b, unsigned int& w0, unsigned int& w1, unsigned int& w2) {
+    w0 = dw_pk(a, b);
+    const float ra = a - __builtin_bit_cast(float, w0 << 16), rb = b - __builtin_bit_cast(float, w0 & 0xffff0000u);
+    w1 = dw_pk(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, w1 << 16), sb = rb - __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = dw_pk(sa, sb);
+}
+// eight fp32 values (two float4) -> the three bf16x8 operands that sum to them
+__device__ __forceinline__ void dw_split8(const float4 s0, const float4 s1, dw_bf16x8 (&x)[3]) {
+    unsigned int w[3][4];
+    dw_split_pair(s0.x, s0.y, w[0][0], w[1][0], w[2][0]);
+    dw_split_pair(s0.z, s0.w, w[0][1], w[1][1], w[2][1]);
+    dw_split_pair(s1.x, s1.y, w[0][2], w[1][2], w[2][2]);
+    dw_split_pair(s1.z, s1.w, w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) x[pc] = __builtin_bit_cast(dw_bf16x8, (dw_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
+}
+// acc += A . B with A = a[0] + a[1] + a[2], B = x[0] + x[1] + x[2]: the six products of weight >= 2^-16, smallest first
+__device__ __forceinline__ f32x4w dw_mfma6(const dw_bf16x8 (&a)[3], const dw_bf16x8 (&x)[3], f32x4w c) {
+    c = DW_MFMA3(a[0], x[2], c);
+    c = DW_MFMA3(a[2], x[0], c);
+    c = DW_MFMA3(a[1], x[1], c);
+    c = DW_MFMA3(a[0], x[1], c);
+    c = DW_MFMA3(a[1], x[0], c);
+    c = DW_MFMA3(a[0], x[0], c);
+    return c;
+}
 
 // The sample queue.  A wave belongs to one of DW_GROUPS sample ranges (blockIdx & 7) and draws tickets of DW_CH consecutive samples
 // from that range's counter.  The atomic of the NEXT ticket is issued when the current one is opened and is only waited for when
@@ -135,8 +201,8 @@ __device__ __forceinline__ void dw_load_rows(const float* __restrict__ table, co
 }
 
 // One pass: NT row tiles whose rows are hv[rt] and whose history ids are id[rt] (-1: masked row).  Updates the online-softmax state.
-template <int NT>
-__device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const int r16, const int kk,
+template <int NT, typename Sh>
+__device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16, const int kk,
                                         const long long (&id)[NT], const float4 (&hv)[2][4], const float b3, const bool normalize,
                                         const float inv_sqrt_k, float& m_run, float& l_run, float4 (&o)[4], float (&xs)[NT]) {
     constexpr int NA = NT == 1 ? 2 : 1;      // a single row tile alternates two accumulators (dependent MFMAs need 40 cycles)
@@ -148,6 +214,70 @@ __device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const 
         for (int rt = 0; rt < NT; ++rt)
             hp[rt][i] = make_float4(hv[rt][i].x * a4.x, hv[rt][i].y * a4.y, hv[rt][i].z * a4.z, hv[rt][i].w * a4.w);
     }
+    f32x4w acc2[3][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 3; ++m2) {
+        const float4 c4 = dw_ld4(&sh.b2[16 * m2 + 4 * kk]);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = (f32x4w){c4.x, c4.y, c4.z, c4.w};
+    }
+    if constexpr (Sh::kBf3) {
+        const int lane4 = 4 * (16 * kk + r16);          // dword offset of this lane's 16 bytes inside a 1 KB operand tile
+        // ---- layer 1: pre1^T = (Wh+Wd)^T h^T + Wp^T (h*a)^T + c 1^T, four k-steps of 32 ------------------------------------------
+        f32x4w acc1[5][NT];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            const float4 c4 = dw_ld4(&sh.cvec[w][16 * mt + 4 * kk]);
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) acc1[mt][rt] = (f32x4w){c4.x, c4.y, c4.z, c4.w};
+        }
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                dw_bf16x8 xb[NT][3];
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) dw_split8(part ? hp[rt][2 * ks] : hv[rt][2 * ks], part ? hp[rt][2 * ks + 1] : hv[rt][2 * ks + 1], xb[rt]);
+                const unsigned int* img = part ? sh.wp3 : sh.whd3;
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    dw_bf16x8 a[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        a[pc] = __builtin_bit_cast(dw_bf16x8, *reinterpret_cast<const dw_u32x4*>(img + ((ks * 5 + mt) * 3 + pc) * 256 + lane4));
+#pragma unroll
+                    for (int rt = 0; rt < NT; ++rt) acc1[mt][rt] = dw_mfma6(a, xb[rt], acc1[mt][rt]);
+                }
+            }
+        }
+        // z1 = sigmoid(pre1) in place: hidden 16 mt + 4 kk + g of row r -- element (mt & 1) * 4 + g of layer 2's k-step mt >> 1
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc1[mt][rt][g] = dw_sigmoid_pre(acc1[mt][rt][g]);
+        // ---- layer 2: pre2^T, three k-steps (hidden 80..95 are zeros on both sides) -------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            dw_bf16x8 xb[NT][3];
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) {
+                const f32x4w z0 = acc1[2 * ks][rt];
+                const f32x4w z1 = 2 * ks + 1 < 5 ? acc1[2 * ks + 1 < 5 ? 2 * ks + 1 : 0][rt] : (f32x4w){0.f, 0.f, 0.f, 0.f};
+                dw_split8(make_float4(z0[0], z0[1], z0[2], z0[3]), make_float4(z1[0], z1[1], z1[2], z1[3]), xb[rt]);
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < 3; ++m2) {
+                dw_bf16x8 a[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    a[pc] = __builtin_bit_cast(dw_bf16x8, *reinterpret_cast<const dw_u32x4*>(sh.w23 + ((ks * 3 + m2) * 3 + pc) * 256 + lane4));
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = dw_mfma6(a, xb[rt], acc2[m2][rt]);
+            }
+        }
+    } else {
     // ---- layer 1: pre1^T, accumulators start at the per-sample term -------------------------------------------------------------
     f32x4w acc1[5][NT][NA];
 #pragma unroll
@@ -192,13 +322,6 @@ __device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const 
                 acc1[mt][rt][0][g] = dw_sigmoid_pre(pre);
             }
     // ---- layer 2: pre2^T; the reduction walks (mt, g) <-> hidden 16 mt + 4 kk + g --------------------------------------------------
-    f32x4w acc2[3][NT];
-#pragma unroll
-    for (int m2 = 0; m2 < 3; ++m2) {
-        const float4 c4 = dw_ld4(&sh.b2[16 * m2 + 4 * kk]);
-#pragma unroll
-        for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = (f32x4w){c4.x, c4.y, c4.z, c4.w};
-    }
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) {
         float aw[3][4];
@@ -213,6 +336,7 @@ __device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const 
             for (int m2 = 0; m2 < 3; ++m2)
 #pragma unroll
                 for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = DW_MFMA(aw[m2][g], acc1[mt][rt][0][g], acc2[m2][rt]);
+    }
     }
     // ---- layer 3 + mask + online softmax + pooling of this pass's rows -----------------------------------------------------------------
     float wv[3][4];
@@ -275,6 +399,7 @@ __device__ __forceinline__ void dw_pass(const DinWaveSh& sh, const int w, const 
     }
 }
 
+template <typename Sh>
 __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
                                                                const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand,
                                                                int T, const float* __restrict__ W1, const float* __restrict__ b1, int H1,
@@ -282,7 +407,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
                                                                const float* __restrict__ W3, const float* __restrict__ b3, int normalize,
                                                                long long B, float* __restrict__ out, float* __restrict__ scores, int slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
-    DinWaveSh& sh = *reinterpret_cast<DinWaveSh*>(dw_smem);
+    Sh& sh = *reinterpret_cast<Sh*>(dw_smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
     // ---- weight images, once per workgroup ---------------------------------------------------------------------------------------------------
 #pragma unroll 3
@@ -301,15 +426,60 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
         const float c4[4] = {(va.x - vd.x) * sc_, (va.y - vd.y) * sc_, (va.z - vd.z) * sc_, (va.w - vd.w) * sc_};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            sh.whd[(m + e) * DW_WS + f] = h4[e];
-            sh.wp[(m + e) * DW_WS + f] = p4[e];
+            if constexpr (!Sh::kBf3) {
+                sh.whd[(m + e) * DW_WS + f] = h4[e];
+                sh.wp[(m + e) * DW_WS + f] = p4[e];
+            }
             sh.wc[(m + e) * DW_WS + f] = c4[e];
         }
     }
-    for (int idx = tid; idx < DW_H2P * DW_H1P; idx += 64 * DW_WAVES) {
-        const int hid = idx / DW_H2P, h2 = idx - hid * DW_H2P;
-        sh.w2[h2 * DW_W2S + hid] = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] * DW_NLOG2E : 0.f;   // a padded hidden unit is sigmoid(0) = 0.5:
-    }                                                                                           // its weights are zero
+    if constexpr (Sh::kBf3) {
+        // A-operand images: dword jp of lane l of tile (ks, mt) holds elements j = 2 jp, 2 jp + 1 = W[m = 16 mt + (l & 15)][k], k + 1,
+        // k = 16 (2 ks + (j >> 2)) + 4 (l >> 4) + (j & 3)
+        for (int idx = tid; idx < 2 * 5 * 64 * 4; idx += 64 * DW_WAVES) {
+            const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+            const int ks = t / 5, mt = t - 5 * ks;
+            const int m = 16 * mt + (l & 15);
+            const int f = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+            float hd[2] = {0.f, 0.f}, pp[2] = {0.f, 0.f};
+            if (m < H1) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    hd[e] = (W1[(size_t)(f + e) * H1 + m] + W1[(size_t)(2 * DW_K + f + e) * H1 + m]) * DW_NLOG2E;
+                    pp[e] = W1[(size_t)(3 * DW_K + f + e) * H1 + m] * DW_NLOG2E;
+                }
+            }
+            unsigned int q0, q1, q2;
+            dw_split_pair(hd[0], hd[1], q0, q1, q2);
+            sh.whd3[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
+            sh.whd3[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
+            sh.whd3[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
+            dw_split_pair(pp[0], pp[1], q0, q1, q2);
+            sh.wp3[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
+            sh.wp3[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
+            sh.wp3[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
+        }
+        for (int idx = tid; idx < 3 * 3 * 64 * 4; idx += 64 * DW_WAVES) {
+            const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+            const int ks = t / 3, m2 = t - 3 * ks;
+            const int h2 = 16 * m2 + (l & 15);
+            const int hid = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)      // a padded hidden unit is sigmoid(0) = 0.5: its weights are zero
+                v[e] = (hid + e < H1 && h2 < H2) ? W2[(size_t)(hid + e) * H2 + h2] * DW_NLOG2E : 0.f;
+            unsigned int q0, q1, q2;
+            dw_split_pair(v[0], v[1], q0, q1, q2);
+            sh.w23[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
+            sh.w23[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
+            sh.w23[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
+        }
+    } else {
+        for (int idx = tid; idx < DW_H2P * DW_H1P; idx += 64 * DW_WAVES) {
+            const int hid = idx / DW_H2P, h2 = idx - hid * DW_H2P;
+            sh.w2[h2 * DW_W2S + hid] = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] * DW_NLOG2E : 0.f;   // a padded hidden unit is sigmoid(0) = 0.5:
+        }                                                                                           // its weights are zero
+    }
     for (int idx = tid; idx < DW_H1P; idx += 64 * DW_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * DW_NLOG2E : 0.f;
     for (int idx = tid; idx < DW_H2P; idx += 64 * DW_WAVES) {
         sh.b2[idx] = idx < H2 ? b2[idx] * DW_NLOG2E : 0.f;
@@ -481,22 +651,34 @@ bool din_wave_covers(int K, int T, int H1, int H2) { return K == DW_K && T <= 64
 int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                     const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                     const float* b3, int normalize, int64_t B, float* out, float* scores) {
-    static bool attr_set = false;
-    const size_t shmem = sizeof(DinWaveSh);
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&din_wave_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+    // DIR_DIN_ARITH = bf16x3 (default) | f32: the arithmetic of the two MFMA layers; DIR_DIN_STATIC = 1 | 0: a static stride over the
+    // samples instead of the device-side queue (default: static for bf16x3 -- its per-sample time is short enough that the ticket
+    // atomics cost more than the imbalance they remove, 0.43 vs 0.49 ms at config 4 -- and the queue for fp32).  Both are read per call
+    // (A/B runs and tests flip them inside one process).
+    const char* arith = getenv("DIR_DIN_ARITH");
+    const bool bf3 = !(arith && strcmp(arith, "f32") == 0);
+    static bool attr_set[2] = {false, false};
+    const size_t shmem = bf3 ? sizeof(DinWaveSh3) : sizeof(DinWaveSh);
+    if (!attr_set[bf3]) {
+        const void* fn = bf3 ? reinterpret_cast<const void*>(&din_wave_k<DinWaveSh3>) : reinterpret_cast<const void*>(&din_wave_k<DinWaveSh>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
             return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
-        attr_set = true;
+        attr_set[bf3] = true;
     }
     // Up to DW_SLOTS launches may be in flight at once (distinct streams); a record is reused only after DW_SLOTS further launches.
-    static const bool static_split = getenv("DIR_DIN_STATIC") && atoi(getenv("DIR_DIN_STATIC")) != 0;
+    const char* stat = getenv("DIR_DIN_STATIC");
+    const bool static_split = stat ? atoi(stat) != 0 : bf3;
     const int slot = static_split ? -1 : (int)(dw_next_slot.fetch_add(1) % DW_SLOTS);
     const int64_t waves_wanted = (B + 1) / 2;            // a wave should see at least a couple of samples
     int64_t nwg = (waves_wanted + DW_WAVES - 1) / DW_WAVES;
     if (nwg > kCUs) nwg = kCUs;
     if (nwg < 1) nwg = 1;
-    hipLaunchKernelGGL(din_wave_k, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2,
-                       H2, W3, b3, normalize, (long long)B, out, scores, slot);
+    if (bf3)
+        hipLaunchKernelGGL(din_wave_k<DinWaveSh3>, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1,
+                           H1, W2, b2, H2, W3, b3, normalize, (long long)B, out, scores, slot);
+    else
+        hipLaunchKernelGGL(din_wave_k<DinWaveSh>, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1,
+                           H1, W2, b2, H2, W3, b3, normalize, (long long)B, out, scores, slot);
     return DIR_OK;
 }
 
