@@ -78,3 +78,30 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "libdir_oracle" not in txt, f
+
+
+def test_no_packed_fp32_beside_wide_mfma_in_the_built_objects(built_lib):
+    """dir_amd/isa_check.py over every object of the in-tree build: no kernel that issues 16x16x32-class MFMAs may hold a packed fp32 VALU
+    instruction whose op_sel sends a source's high register to the low result (the pair loses the low result in lanes 48..63 on gfx950:
+    tools/pk_mfma_probe.hip), and no other kernel holds the form either (a bf16-MFMA kernel of another stream could corrupt it)."""
+    import glob
+    import os
+    import dir_amd
+    from dir_amd import isa_check
+    objs = sorted(glob.glob(os.path.join(os.path.dirname(dir_amd.library_path()), "csrc", "_build", "*.o")))
+    assert len(objs) >= 18
+    errors, exposed = isa_check.check(objs)
+    assert errors == [], errors
+    assert exposed == [], exposed
+    # the scanner itself: the failing pair of the round-2 DIN build is recognised, harmless forms are not
+    text = """0000000000001000 <victim>:
+\tv_pk_add_f32 v[138:139], v[138:139], v[252:253] op_sel:[0,1]   // 000000001000: D3B24086 1803F98A
+\tv_mfma_f32_16x16x32_bf16 v[146:149], v[208:211], v[114:117], v[146:149] // 000000001008: D3B58092 0A4AE5D0
+0000000000002000 <fine>:
+\tv_pk_add_f32 v[10:11], v[10:11], v[12:13] op_sel_hi:[1,0]        // 000000002000: D3B2400A 0802190A
+\tv_pk_add_f32 v[10:11], v[10:11], v[12:13] neg_lo:[0,1] neg_hi:[0,1] // 000000002008: D3B2400A 0802190A
+\tv_mfma_f32_16x16x32_bf16 v[146:149], v[208:211], v[114:117], v[146:149] // 000000002010: D3B58092 0A4AE5D0
+"""
+    per = isa_check.scan(text)
+    assert per["victim"][0] == 1 and len(per["victim"][1]) == 1
+    assert per["fine"][0] == 1 and per["fine"][1] == []
