@@ -62,6 +62,11 @@ SIGNATURES = {
     "dir_din_attention_pool_backward_rows_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                                          c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                          c_vp, c_vp, c_i64, c_vp]),
+    "dir_din_attention_pool_backward_saved_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                                         c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                         c_vp, c_vp, c_i64, c_vp]),
+    "dir_din_attention_pool_save_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i64,
+                                        c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_sparse_adam_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i64]),
     "dir_sparse_adam_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, ctypes.c_float, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),

@@ -247,6 +247,7 @@ def _tn_matmul(A, Bm, splits=128):
 
 
 _DIN_COMPOSITE_BACKWARD = os.environ.get("DIR_DIN_COMPOSITE_BACKWARD", "0") == "1"   # dev switch: A/B against the fused kernel
+_DIN_SAVE_ACTIVATIONS = os.environ.get("DIR_DIN_SAVE", "1") != "0"                   # 0: the backward recomputes the two hidden layers (round 2's form)
 
 
 class DinAttentionPool(torch.autograd.Function):
@@ -262,9 +263,15 @@ class DinAttentionPool(torch.autograd.Function):
         ctx.normalize = bool(normalize)
         B, T = hist.shape
         fused = ops.din_backward_supported(table.shape[1], T, W1.shape[1], W2.shape[1]) and not _DIN_COMPOSITE_BACKWARD
-        res = ops.din_attention_pool(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(), W2.detach(),
-                                     b2.detach(), W3.detach(), b3.detach(), normalize=normalize, want_scores=fused)
-        out, scores = res if fused else (res, None)       # the attention weights [B, T] feed the backward (no softmax recompute)
+        ctx.saved_state = None
+        if fused and B > 0 and _DIN_SAVE_ACTIVATIONS:
+            # the forward leaves z1 / z2 of every history row in a workspace this node owns: the backward recomputes nothing
+            out, scores, ctx.saved_state = ops.din_attention_pool_save(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(),
+                                                                       W2.detach(), b2.detach(), W3.detach(), b3.detach(), normalize=normalize)
+        else:
+            res = ops.din_attention_pool(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(), W2.detach(),
+                                         b2.detach(), W3.detach(), b3.detach(), normalize=normalize, want_scores=fused)
+            out, scores = res if fused else (res, None)   # the attention weights [B, T] feed the backward (no softmax recompute)
         ctx.has_scores = scores is not None
         ctx.save_for_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, *([scores] if scores is not None else []))
         return out
@@ -280,7 +287,8 @@ class DinAttentionPool(torch.autograd.Function):
         g = g.contiguous()
         if ops.din_backward_supported(K, T, H1, W2.shape[1]) and not _DIN_COMPOSITE_BACKWARD:
             r = ops.din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=ctx.normalize,
-                                                scores=scores)
+                                                scores=scores, saved=ctx.saved_state)
+            ctx.saved_state = None                                  # the workspace (1.8 GB at config 4) goes back to the allocator
             gtab = None
             if ctx.needs_input_grad[0]:
                 ok = cand >= 0                                      # a pruned candidate (zero vector in the forward) adds nothing

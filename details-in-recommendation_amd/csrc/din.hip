@@ -1148,6 +1148,30 @@ extern "C" int dir_din_attention_pool_f32(const float* table, int K, const int64
     return DIR_OK;
 }
 
+extern "C" int64_t dir_din_backward_rows_workspace_bytes(int K, int H1, int H2, int64_t n_tiles);
+
+extern "C" int dir_din_attention_pool_save_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
+                                               int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
+                                               const float* W3, const float* b3, int normalize, int64_t B, float* out, float* scores,
+                                               const int64_t* tile_off, int64_t n_tiles, void* workspace, int64_t workspace_bytes,
+                                               dir_stream_t stream) {
+    const char* name = "dir_din_attention_pool_save_f32";
+    DIR_CHECK_ARG(K > 0 && T > 0 && H1 > 0 && H2 > 0 && B >= 0 && n_tiles >= 0, "%s: K=%d T=%d H1=%d H2=%d", name, K, T, H1, H2);
+    if ((H1 & 3) || (H2 & 3) || !din_wave_covers(K, T, H1, H2))
+        return fail(DIR_E_UNSUPPORTED, "%s: covers K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 64 (K=%d H1=%d H2=%d T=%d)", name, K, H1, H2, T);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(table && hist && cand && W1 && b1 && W2 && b2 && W3 && b3 && out && scores && tile_off && workspace, "%s: null pointer", name);
+    if (!aligned16(table) || !aligned16(W1) || !aligned16(W2) || !aligned16(b1) || !aligned16(b2) || !aligned16(workspace))
+        return fail(DIR_E_BADARG, "%s: table / W1 / W2 / b1 / b2 / workspace must be 16-byte aligned", name);
+    const int64_t need = dir_din_backward_rows_workspace_bytes(K, H1, H2, n_tiles);
+    if (workspace_bytes < need) return fail(DIR_E_BADARG, "%s: workspace needs %lld bytes", name, (long long)need);
+    const int rc = launch_din_wave(as_stream(stream), table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores,
+                                   tile_off, static_cast<float*>(workspace));
+    if (rc != DIR_OK) return rc;
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
 extern "C" int64_t dir_din_backward_workspace_bytes(int K, int H1, int H2) {
     if (K != 64 || H1 <= 0 || H2 <= 0 || H1 > 80 || H2 > 48) return 0;
     return (int64_t)(kDinBwdMaxWg + 1) * kDinBwdRec * (int64_t)sizeof(float);   // one record per workgroup + their sum

@@ -40,8 +40,8 @@ constexpr int RB_W2BS = RB_H2P + 4;     // [hidden][h2] backward image (A of dz1
 constexpr int RB_WCS = RB_H1P + 4;      // [feature 2K][hidden] backward image (A of dX^T)
 constexpr int RB_WAVES = 8;
 constexpr int RB_GROUPS = 8, RB_SLOTS = 64, RB_CH = 2;
-constexpr int RB_ROW = 212;             // scratch floats per history row: z1 [80] | dpre1 [80] | z2 [48] | d score | 3 pad
-constexpr int RB_Z1 = 0, RB_DP1 = 80, RB_Z2 = 160, RB_DS = 208;
+constexpr int RB_ROW = kDinRecRow;       // floats per history row's record (common.hpp): z1 [80] | dpre1 [80] | z2 [48] | d score | 3 pad
+constexpr int RB_Z1 = kDinRecZ1, RB_DP1 = kDinRecDp1, RB_Z2 = kDinRecZ2, RB_DS = kDinRecDs;
 constexpr int kRowsBwdGAP = 2 * 64 * 80, kRowsBwdGW2 = 80 * 48;
 constexpr int kRowsBwdRec = kRowsBwdGAP + kRowsBwdGW2 + 4 * 48 + 4 * 48 + 64;      // == din.hip's kDinBwdRec (checked by the host code)
 
@@ -131,6 +131,9 @@ __device__ __forceinline__ void rb_load_row(const float* __restrict__ table, con
     }
 }
 
+// SAVED: the records already hold z1 and z2 (written by the training forward, dir_din_attention_pool_save_f32): nothing of the forward is
+// recomputed -- half of the MFMAs, no per-sample term, no forward weight images.
+template <bool SAVED>
 __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
                                                                const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand,
                                                                int T, const float* __restrict__ W1, const float* __restrict__ b1, int H1,
@@ -150,18 +153,20 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
         float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), va = vh, vd = vh, vp = vh;
         if (m < H1) {
             vh = rb_ld4(W1 + (size_t)f * H1 + m);
-            va = rb_ld4(W1 + (size_t)(RB_K + f) * H1 + m);
             vd = rb_ld4(W1 + (size_t)(2 * RB_K + f) * H1 + m);
             vp = rb_ld4(W1 + (size_t)(3 * RB_K + f) * H1 + m);
+            if (!SAVED) va = rb_ld4(W1 + (size_t)(RB_K + f) * H1 + m);
         }
         const float h4[4] = {vh.x + vd.x, vh.y + vd.y, vh.z + vd.z, vh.w + vd.w};
         const float p4[4] = {vp.x, vp.y, vp.z, vp.w};
-        const float c4[4] = {va.x - vd.x, va.y - vd.y, va.z - vd.z, va.w - vd.w};
+        if (!SAVED) {
+            const float c4[4] = {va.x - vd.x, va.y - vd.y, va.z - vd.z, va.w - vd.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sh.whd[(m + e) * RB_WS + f] = h4[e] * RB_NLOG2E;
-            sh.wp[(m + e) * RB_WS + f] = p4[e] * RB_NLOG2E;
-            sh.wc[(m + e) * RB_WS + f] = c4[e] * RB_NLOG2E;
+            for (int e = 0; e < 4; ++e) {
+                sh.whd[(m + e) * RB_WS + f] = h4[e] * RB_NLOG2E;
+                sh.wp[(m + e) * RB_WS + f] = p4[e] * RB_NLOG2E;
+                sh.wc[(m + e) * RB_WS + f] = c4[e] * RB_NLOG2E;
+            }
         }
         *reinterpret_cast<float4*>(&sh.wcat[f * RB_WCS + m]) = make_float4(h4[0], h4[1], h4[2], h4[3]);
         *reinterpret_cast<float4*>(&sh.wcat[(RB_K + f) * RB_WCS + m]) = make_float4(p4[0], p4[1], p4[2], p4[3]);
@@ -169,12 +174,14 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
     for (int idx = tid; idx < RB_H2P * RB_H1P; idx += 64 * RB_WAVES) {
         const int hid = idx / RB_H2P, h2 = idx - hid * RB_H2P;
         const float v = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] : 0.f;
-        sh.w2[h2 * RB_W2S + hid] = v * RB_NLOG2E;
+        if (!SAVED) sh.w2[h2 * RB_W2S + hid] = v * RB_NLOG2E;
         sh.w2b[hid * RB_W2BS + h2] = v;
     }
-    for (int idx = tid; idx < RB_H1P; idx += 64 * RB_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * RB_NLOG2E : 0.f;
+    if (!SAVED) {
+        for (int idx = tid; idx < RB_H1P; idx += 64 * RB_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * RB_NLOG2E : 0.f;
+    }
     for (int idx = tid; idx < RB_H2P; idx += 64 * RB_WAVES) {
-        sh.b2[idx] = idx < H2 ? b2[idx] * RB_NLOG2E : 0.f;
+        if (!SAVED) sh.b2[idx] = idx < H2 ? b2[idx] * RB_NLOG2E : 0.f;
         sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
     }
     __syncthreads();
@@ -287,14 +294,16 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                 *reinterpret_cast<float4*>(&sh.gv[w][16 * i + 4 * kk]) = gn[i];
             }
         }
+        if (!SAVED) {
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt) {
-            float part = 0.f;
+            for (int mt = 0; mt < 5; ++mt) {
+                float part = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part = rb_dot4(an[i], rb_ld4(&sh.wc[(16 * mt + r16) * RB_WS + 16 * i + 4 * kk]), part);
-            part += __shfl_xor(part, 16, 64);
-            part += __shfl_xor(part, 32, 64);
-            if (kk == 0) sh.cvec[w][16 * mt + r16] = part + sh.b1[16 * mt + r16];
+                for (int i = 0; i < 4; ++i) part = rb_dot4(an[i], rb_ld4(&sh.wc[(16 * mt + r16) * RB_WS + 16 * i + 4 * kk]), part);
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                if (kk == 0) sh.cvec[w][16 * mt + r16] = part + sh.b1[16 * mt + r16];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -321,6 +330,26 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
             }
             float* srow = scratch + ((toff + t) * 16 + r16) * RB_ROW;
             const bool inlen = 16 * t + r16 < len;              // rows past the history's end leave no record (din_wgrad_k reads zeros)
+            f32x4r z1[5], dp2[3];
+            if constexpr (SAVED) {
+                // z1, z2 of this row from its record; dpre2^T = d score * W3 * z2 (1 - z2)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (inlen) v = rb_ld4(srow + RB_Z1 + 16 * mt + 4 * kk);
+                    z1[mt] = (f32x4r){v.x, v.y, v.z, v.w};
+                }
+#pragma unroll
+                for (int m2 = 0; m2 < 3; ++m2) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (inlen) v = rb_ld4(srow + RB_Z2 + 16 * m2 + 4 * kk);
+                    const float4 w4 = rb_ld4(&sh.w3[16 * m2 + 4 * kk]);
+                    const float zz[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) dp2[m2][g] = dst * rb_c(w4, g) * zz[g] * (1.0f - zz[g]);
+                }
+                if (kk == 0 && inlen) srow[RB_DS] = dst;
+            } else {
             // ---- layer 1 (recompute): pre1^T -> z1^T -------------------------------------------------------------------------------------------------
             f32x4r acc1[5][2];
             {
@@ -351,7 +380,6 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                     RB_SCHED_FENCE();
                 }
             }
-            f32x4r z1[5];
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
 #pragma unroll
@@ -359,7 +387,6 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                 if (inlen) *reinterpret_cast<float4*>(srow + RB_Z1 + 16 * mt + 4 * kk) = make_float4(z1[mt][0], z1[mt][1], z1[mt][2], z1[mt][3]);
             }
             // ---- layer 2 (recompute): pre2^T -> z2^T; dpre2^T = d score * W3 * z2 (1 - z2) ---------------------------------------------------------------
-            f32x4r dp2[3];
             {
                 f32x4r acc2[3];
 #pragma unroll
@@ -390,6 +417,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                     if (inlen) *reinterpret_cast<float4*>(srow + RB_Z2 + 16 * m2 + 4 * kk) = make_float4(zz[0], zz[1], zz[2], zz[3]);
                 }
                 if (kk == 0 && inlen) srow[RB_DS] = dst;
+            }
             }
             // ---- dz1^T = W2 dpre2^T -> dpre1^T = dz1 z1 (1 - z1) ------------------------------------------------------------------------------------------
             f32x4r dp1[5];
@@ -683,14 +711,11 @@ extern "C" int64_t dir_din_backward_rows_workspace_bytes(int K, int H1, int H2, 
     return scratch + (int64_t)(kRowsWgradWg + 1) * kRowsBwdRec * (int64_t)sizeof(float);
 }
 
-extern "C" int dir_din_attention_pool_backward_rows_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
-                                                        const int64_t* cand, int T, const float* W1, const float* b1, int H1,
-                                                        const float* W2, const float* b2, int H2, const float* W3, const float* b3,
-                                                        int normalize, int64_t B, const float* gout, const float* scores,
-                                                        const int64_t* row_off, const int64_t* tile_off, int64_t n_tiles, float* gh,
-                                                        float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
-                                                        void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
-    const char* name = "dir_din_attention_pool_backward_rows_f32";
+static int din_backward_rows(const char* name, bool saved, const float* table, int K, const int64_t* hist, const int32_t* hist_len,
+                             const int64_t* cand, int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
+                             const float* W3, const float* b3, int normalize, int64_t B, const float* gout, const float* scores,
+                             const int64_t* row_off, const int64_t* tile_off, int64_t n_tiles, float* gh, float* ga, float* S, float* gAP,
+                             float* gW2, float* gb2, float* gW3, float* gb3, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     (void)b3;
     DIR_CHECK_ARG(K > 0 && T > 0 && H1 > 0 && H2 > 0 && B >= 0 && n_tiles >= 0, "%s: K=%d T=%d H1=%d H2=%d", name, K, T, H1, H2);
     if (K != 64 || H1 > 80 || H2 > 48 || (H1 & 3) || (H2 & 3) || T > 64)
@@ -708,21 +733,27 @@ extern "C" int dir_din_attention_pool_backward_rows_f32(const float* table, int 
     float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + scratch_bytes);
     int nwg2 = 0;
     if (B > 0) {
-        static bool attr_set = false;
+        static bool attr_set[2] = {false, false};
         const size_t shmem = sizeof(DinRowsSh);
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&din_rows_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+        const void* fn = saved ? reinterpret_cast<const void*>(&din_rows_k<true>) : reinterpret_cast<const void*>(&din_rows_k<false>);
+        if (!attr_set[saved]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
                 return fail(DIR_E_HIP, "%s: cannot reserve %zu B of LDS", name, shmem);
-            attr_set = true;
+            attr_set[saved] = true;
         }
-        static const bool static_split = getenv("DIR_DIN_STATIC") && atoi(getenv("DIR_DIN_STATIC")) != 0;
+        const char* stat = getenv("DIR_DIN_STATIC");
+        const bool static_split = stat && atoi(stat) != 0;
         const int slot = static_split ? -1 : (int)(rb_next_slot.fetch_add(1) % RB_SLOTS);
         const int64_t waves_wanted = (B + 1) / 2;
         int64_t nwg = (waves_wanted + RB_WAVES - 1) / RB_WAVES;
         if (nwg > kCUs) nwg = kCUs;
         if (nwg < 1) nwg = 1;
-        hipLaunchKernelGGL(din_rows_k, dim3((unsigned)nwg), dim3(64 * RB_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2,
-                           W3, normalize, (long long)B, gout, scores, row_off, tile_off, gh, ga, S, scratch, slot);
+        if (saved)
+            hipLaunchKernelGGL(din_rows_k<true>, dim3((unsigned)nwg), dim3(64 * RB_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2,
+                               b2, H2, W3, normalize, (long long)B, gout, scores, row_off, tile_off, gh, ga, S, scratch, slot);
+        else
+            hipLaunchKernelGGL(din_rows_k<false>, dim3((unsigned)nwg), dim3(64 * RB_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2,
+                               b2, H2, W3, normalize, (long long)B, gout, scores, row_off, tile_off, gh, ga, S, scratch, slot);
         DIR_CHECK_LAUNCH(name);
         nwg2 = (int)(B < kRowsWgradWg ? B : kRowsWgradWg);
         hipLaunchKernelGGL(din_wgrad_k, dim3((unsigned)nwg2), dim3(256), 0, st, table, hist, hist_len, cand, T, W3, H2, (long long)B, tile_off,
@@ -735,4 +766,30 @@ extern "C" int dir_din_attention_pool_backward_rows_f32(const float* table, int 
     hipLaunchKernelGGL(din_bwd_finish_k, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, red, K, H1, H2, gAP, gW2, gb2, gW3, gb3);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_din_attention_pool_backward_rows_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
+                                                        const int64_t* cand, int T, const float* W1, const float* b1, int H1,
+                                                        const float* W2, const float* b2, int H2, const float* W3, const float* b3,
+                                                        int normalize, int64_t B, const float* gout, const float* scores,
+                                                        const int64_t* row_off, const int64_t* tile_off, int64_t n_tiles, float* gh,
+                                                        float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
+                                                        void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    return din_backward_rows("dir_din_attention_pool_backward_rows_f32", false, table, K, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3,
+                             normalize, B, gout, scores, row_off, tile_off, n_tiles, gh, ga, S, gAP, gW2, gb2, gW3, gb3, workspace,
+                             workspace_bytes, stream);
+}
+
+// As above, with the records' z1 and z2 already in `workspace` (its first n_tiles * 16 * 212 floats): the workspace that
+// dir_din_attention_pool_save_f32 filled on the same (hist, hist_len, tile_off) -- the forward is not recomputed.
+extern "C" int dir_din_attention_pool_backward_saved_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
+                                                         const int64_t* cand, int T, const float* W1, const float* b1, int H1,
+                                                         const float* W2, const float* b2, int H2, const float* W3, const float* b3,
+                                                         int normalize, int64_t B, const float* gout, const float* scores,
+                                                         const int64_t* row_off, const int64_t* tile_off, int64_t n_tiles, float* gh,
+                                                         float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
+                                                         void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    return din_backward_rows("dir_din_attention_pool_backward_saved_f32", true, table, K, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3,
+                             normalize, B, gout, scores, row_off, tile_off, n_tiles, gh, ga, S, gAP, gW2, gb2, gW3, gb3, workspace,
+                             workspace_bytes, stream);
 }

@@ -201,10 +201,12 @@ __device__ __forceinline__ void dw_load_rows(const float* __restrict__ table, co
 }
 
 // One pass: NT row tiles whose rows are hv[rt] and whose history ids are id[rt] (-1: masked row).  Updates the online-softmax state.
+// rec[rt] != nullptr (training forward): the row's z1 and z2 go into its record (common.hpp: kDinRec*).
 template <int NT, typename Sh>
 __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16, const int kk,
                                         const long long (&id)[NT], const float4 (&hv)[2][4], const float b3, const bool normalize,
-                                        const float inv_sqrt_k, float& m_run, float& l_run, float4 (&o)[4], float (&xs)[NT]) {
+                                        const float inv_sqrt_k, float& m_run, float& l_run, float4 (&o)[4], float (&xs)[NT],
+                                        float* const (&rec)[NT]) {
     constexpr int NA = NT == 1 ? 2 : 1;      // a single row tile alternates two accumulators (dependent MFMAs need 40 cycles)
     float4 hp[NT][4];
 #pragma unroll
@@ -257,6 +259,13 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc1[mt][rt][g] = dw_sigmoid_pre(acc1[mt][rt][g]);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+            if (rec[rt]) {
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt)
+                    *reinterpret_cast<float4*>(rec[rt] + kDinRecZ1 + 16 * mt + 4 * kk) = make_float4(acc1[mt][rt][0], acc1[mt][rt][1], acc1[mt][rt][2], acc1[mt][rt][3]);
+            }
         // ---- layer 2: pre2^T, three k-steps (hidden 80..95 are zeros on both sides) -------------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
@@ -321,6 +330,14 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
                 const float pre = NA == 2 ? acc1[mt][rt][0][g] + acc1[mt][rt][NA - 1][g] : acc1[mt][rt][0][g];
                 acc1[mt][rt][0][g] = dw_sigmoid_pre(pre);
             }
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+        if (rec[rt]) {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+                *reinterpret_cast<float4*>(rec[rt] + kDinRecZ1 + 16 * mt + 4 * kk) =
+                    make_float4(acc1[mt][rt][0][0], acc1[mt][rt][0][1], acc1[mt][rt][0][2], acc1[mt][rt][0][3]);
+        }
     // ---- layer 2: pre2^T; the reduction walks (mt, g) <-> hidden 16 mt + 4 kk + g --------------------------------------------------
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) {
@@ -350,9 +367,15 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
     for (int rt = 0; rt < NT; ++rt) {
         float sp = 0.f;
 #pragma unroll
-        for (int m2 = 0; m2 < 3; ++m2)
+        for (int m2 = 0; m2 < 3; ++m2) {
+            float zz[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) sp = fmaf(dw_sigmoid_pre(acc2[m2][rt][g]), wv[m2][g], sp);
+            for (int g = 0; g < 4; ++g) {
+                zz[g] = dw_sigmoid_pre(acc2[m2][rt][g]);
+                sp = fmaf(zz[g], wv[m2][g], sp);
+            }
+            if (rec[rt]) *reinterpret_cast<float4*>(rec[rt] + kDinRecZ2 + 16 * m2 + 4 * kk) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        }
         sp += __shfl_xor(sp, 16, 64);        // the four lane groups hold the four quarters of the H2 sum of row r
         sp += __shfl_xor(sp, 32, 64);
         sc[rt] = sp + b3;
@@ -399,13 +422,14 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
     }
 }
 
-template <typename Sh>
+template <typename Sh, bool SAVE>
 __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
                                                                const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand,
                                                                int T, const float* __restrict__ W1, const float* __restrict__ b1, int H1,
                                                                const float* __restrict__ W2, const float* __restrict__ b2, int H2,
                                                                const float* __restrict__ W3, const float* __restrict__ b3, int normalize,
-                                                               long long B, float* __restrict__ out, float* __restrict__ scores, int slot) {
+                                                               long long B, float* __restrict__ out, float* __restrict__ scores, int slot,
+                                                               const int64_t* __restrict__ tile_off, float* __restrict__ saved) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
     Sh& sh = *reinterpret_cast<Sh*>(dw_smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
@@ -499,13 +523,15 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
         const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
         return (long long)(((unsigned long long)hi << 32) | lo);
     };
-    auto load_scalars = [&](const long long bb, int& len, long long& cid) {
+    auto load_scalars = [&](const long long bb, int& len, long long& cid, long long& toff) {
         len = 0;
         cid = -1;
+        toff = 0;
         if (bb >= 0) {
             const long long bs = uniform64(bb);
             len = hist_len ? min((int)hist_len[bs], T) : T;
             cid = cand[bs];
+            if (SAVE) toff = tile_off[bs];
         }
     };
     auto load_ids = [&](const long long bb, const int len, long long (&id)[4]) {
@@ -527,10 +553,10 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
     long long bt = bn >= 0 ? dq.take() : -1;                     // scalars in flight
     long long bq = bt >= 0 ? dq.take() : -1;                     // index only
     int len, len_n, len_t;
-    long long cid, cid_n, cid_t, id[4], id_n[4];
-    load_scalars(b, len, cid);
-    load_scalars(bn, len_n, cid_n);
-    load_scalars(bt, len_t, cid_t);
+    long long cid, cid_n, cid_t, toff, toff_n, toff_t, id[4], id_n[4];
+    load_scalars(b, len, cid, toff);
+    load_scalars(bn, len_n, cid_n, toff_n);
+    load_scalars(bt, len_t, cid_t, toff_t);
     load_ids(b, len, id);
     load_ids(bn, len_n, id_n);
     float4 hv[2][4], hvn[2][4], an[4];
@@ -561,6 +587,9 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
         for (int i = 0; i < 4; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         float xs[4] = {0.f, 0.f, 0.f, 0.f};
         if (normalize) xs[0] = xs[1] = xs[2] = xs[3] = -INFINITY;
+        auto record = [&](const int t) -> float* {               // training forward: the record of this lane's row of tile t (rows inside the length)
+            return (SAVE && 16 * t + r16 < len) ? saved + ((toff + t) * 16 + r16) * kDinRecRow : nullptr;
+        };
         // ---- pass 0 (tiles 0, 1), with the next pass's loads in flight under it -------------------------------------------------------------------
         if (RT > 2) {
             dw_load_rows(table, kk, id[2], id[3], hvn);
@@ -571,12 +600,14 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
         if (RT >= 2) {
             const long long idp[2] = {id[0], id[1]};
             float xp[2];
-            dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            float* const recp[2] = {record(0), record(1)};
+            dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
             xs[0] = xp[0]; xs[1] = xp[1];
         } else if (RT == 1) {
             const long long idp[1] = {id[0]};
             float xp[1];
-            dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+            float* const recp[1] = {record(0)};
+            dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
             xs[0] = xp[0];
         }
 #pragma unroll
@@ -590,12 +621,14 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
             if (RT >= 4) {
                 const long long idp[2] = {id[2], id[3]};
                 float xp[2];
-                dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+                float* const recp[2] = {record(2), record(3)};
+                dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
                 xs[2] = xp[0]; xs[3] = xp[1];
             } else {
                 const long long idp[1] = {id[2]};
                 float xp[1];
-                dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp);
+                float* const recp[1] = {record(2)};
+                dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
                 xs[2] = xp[0];
             }
 #pragma unroll
@@ -624,13 +657,13 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
             }
         }
         // ---- advance: the next sample's rows / candidate are in hv / an; fetch the descriptor after it and a new ticket -----------------------------
-        b = bn; len = len_n; cid = cid_n;
+        b = bn; len = len_n; cid = cid_n; toff = toff_n;
 #pragma unroll
         for (int t = 0; t < 4; ++t) id[t] = id_n[t];
-        bn = bt; len_n = len_t; cid_n = cid_t;                   // its scalars were issued a sample ago
+        bn = bt; len_n = len_t; cid_n = cid_t; toff_n = toff_t;  // its scalars were issued a sample ago
         load_ids(bn, len_n, id_n);
         bt = bq;
-        load_scalars(bt, len_t, cid_t);
+        load_scalars(bt, len_t, cid_t, toff_t);
         bq = bt >= 0 ? dq.take() : -1;
     }
     // ---- leave the queue record clean for the next launch that draws this slot -------------------------------------------------------------------
@@ -650,20 +683,25 @@ bool din_wave_covers(int K, int T, int H1, int H2) { return K == DW_K && T <= 64
 
 int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                     const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
-                    const float* b3, int normalize, int64_t B, float* out, float* scores) {
+                    const float* b3, int normalize, int64_t B, float* out, float* scores, const int64_t* tile_off, float* saved) {
     // DIR_DIN_ARITH = bf16x3 (default) | f32: the arithmetic of the two MFMA layers; DIR_DIN_STATIC = 1 | 0: a static stride over the
     // samples instead of the device-side queue (default: static for bf16x3 -- its per-sample time is short enough that the ticket
-    // atomics cost more than the imbalance they remove, 0.43 vs 0.49 ms at config 4 -- and the queue for fp32).  Both are read per call
-    // (A/B runs and tests flip them inside one process).
+    // atomics cost more than the imbalance they remove, 0.45 vs 0.50 ms at config 4 -- and the queue for fp32).  Both are read per call
+    // (A/B runs and tests flip them inside one process).  saved != nullptr: the training forward (z1, z2 records for the backward).
     const char* arith = getenv("DIR_DIN_ARITH");
     const bool bf3 = !(arith && strcmp(arith, "f32") == 0);
-    static bool attr_set[2] = {false, false};
+    const bool save = saved != nullptr;
+    typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,
+                           const float*, int, const float*, const float*, int, long long, float*, float*, int, const int64_t*, float*);
+    static const kern_t kerns[2][2] = {{&din_wave_k<DinWaveSh, false>, &din_wave_k<DinWaveSh, true>},
+                                       {&din_wave_k<DinWaveSh3, false>, &din_wave_k<DinWaveSh3, true>}};
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
     const size_t shmem = bf3 ? sizeof(DinWaveSh3) : sizeof(DinWaveSh);
-    if (!attr_set[bf3]) {
-        const void* fn = bf3 ? reinterpret_cast<const void*>(&din_wave_k<DinWaveSh3>) : reinterpret_cast<const void*>(&din_wave_k<DinWaveSh>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+    const kern_t kern = kerns[bf3][save];
+    if (!attr_set[bf3][save]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
             return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
-        attr_set[bf3] = true;
+        attr_set[bf3][save] = true;
     }
     // Up to DW_SLOTS launches may be in flight at once (distinct streams); a record is reused only after DW_SLOTS further launches.
     const char* stat = getenv("DIR_DIN_STATIC");
@@ -673,12 +711,8 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
     int64_t nwg = (waves_wanted + DW_WAVES - 1) / DW_WAVES;
     if (nwg > kCUs) nwg = kCUs;
     if (nwg < 1) nwg = 1;
-    if (bf3)
-        hipLaunchKernelGGL(din_wave_k<DinWaveSh3>, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1,
-                           H1, W2, b2, H2, W3, b3, normalize, (long long)B, out, scores, slot);
-    else
-        hipLaunchKernelGGL(din_wave_k<DinWaveSh>, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1,
-                           H1, W2, b2, H2, W3, b3, normalize, (long long)B, out, scores, slot);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3,
+                       normalize, (long long)B, out, scores, slot, tile_off, saved);
     return DIR_OK;
 }
 

@@ -375,6 +375,63 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     return (out, scores) if want_scores else out
 
 
+class DinTrainPlan:
+    """Row bookkeeping one training call of the DIN unit needs, computed once (one host read) and shared by the forward that saves its
+    activations and the backward: `valid` [B, T] (position inside the length and not pruned), row_off [B] (exclusive prefix of the valid
+    counts: the compact gradient row list), tile_off [B] (exclusive prefix of ceil(len / 16): the records), N, n_tiles."""
+
+    def __init__(self, hist, hist_len):
+        B, T = hist.shape
+        dev = hist.device
+        valid = hist >= 0
+        if hist_len is not None:
+            valid &= torch.arange(T, device=dev).unsqueeze(0) < hist_len.clamp(0, T).unsqueeze(1)
+        cnt = valid.sum(dim=1)
+        incl = torch.cumsum(cnt, 0)
+        lens = hist_len.clamp(0, T).to(torch.int64) if hist_len is not None else torch.full((B,), T, dtype=torch.int64, device=dev)
+        tcnt = (lens + 15) // 16
+        tincl = torch.cumsum(tcnt, 0)
+        self.valid, self.row_off, self.tile_off = valid, (incl - cnt).contiguous(), (tincl - tcnt).contiguous()
+        self.N, self.n_tiles = (int(v) for v in torch.stack([incl[-1], tincl[-1]]).tolist()) if B else (0, 0)     # the one host read
+
+
+def din_attention_pool_save(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, plan=None):
+    """Training forward of the (K 64, H1 <= 80, H2 <= 48, T <= 64) unit (include/dir_hip.h: dir_din_attention_pool_save_f32): as
+    din_attention_pool(..., want_scores=True), and every history row's hidden activations stay in a workspace for
+    din_attention_pool_backward(..., saved=...), which then recomputes nothing.  -> out, scores, (plan, workspace)."""
+    _dev(table, torch.float32, "table")
+    _dev(hist, torch.int64, "hist")
+    _dev(cand, torch.int64, "cand")
+    if hist_len is not None:
+        _dev(hist_len, torch.int32, "hist_len")
+    B, T = hist.shape
+    K = table.shape[1]
+    H1, H2 = W1.shape[1], W2.shape[1]
+    if tuple(W1.shape) != (4 * K, H1) or tuple(W2.shape) != (H1, H2) or W3.numel() != H2:
+        raise ValueError("DIN weights must be W1 [4K,H1], W2 [H1,H2], W3 [H2]")
+    if not din_backward_supported(K, T, H1, H2):
+        raise _lib.DirError(-4, "din_attention_pool_save covers K = 64, H1 <= 80, H2 <= 48, T <= 64")
+    args = [t.contiguous() for t in (W1, b1, W2, b2, W3, b3)]
+    for t in args:
+        _dev(t, torch.float32, "DIN weight")
+    hist, cand = hist.contiguous(), cand.contiguous()
+    if hist_len is not None:
+        hist_len = hist_len.contiguous()
+    if cand.numel() != B or (hist_len is not None and hist_len.numel() != B):
+        raise ValueError("DIN: cand and hist_len must have one entry per sample")
+    if plan is None:
+        plan = DinTrainPlan(hist, hist_len)
+    lib = _lib.load()
+    need = int(lib.dir_din_backward_rows_workspace_bytes(K, H1, H2, plan.n_tiles))
+    ws = torch.empty(need, dtype=torch.uint8, device=table.device)       # owned by this call's autograd node until its backward ran
+    out = torch.empty((B, K), dtype=torch.float32, device=table.device)
+    scores = torch.empty((B, T), dtype=torch.float32, device=table.device)
+    _lib.check(lib.dir_din_attention_pool_save_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1,
+                                                   _ptr(args[2]), _ptr(args[3]), H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B,
+                                                   _ptr(out), _ptr(scores), _ptr(plan.tile_off), plan.n_tiles, _ptr(ws), need, _stream()))
+    return out, scores, (plan, ws)
+
+
 def dense_supported(x, weight):
     """Shapes dir_dense_f32 covers: fp32 CUDA tensors, in_features a multiple of 4, at least 16 output columns (narrower layers --
     the final units=1 logit layers -- are matrix-vector products: library code)."""
@@ -704,11 +761,12 @@ def din_backward_supported(K, T, H1, H2):
 _DIN_BWD_WS = {}
 
 
-def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=False, scores=None):
+def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, g, normalize=False, scores=None, saved=None):
     """Backward of din_attention_pool given g = dL/dout [B, K] (include/dir_hip.h: dir_din_attention_pool_backward_f32 + the
     per-sample term's two small GEMMs).  scores [B, T]: the forward's attention weights (din_attention_pool(..., want_scores=True));
     with them the two-kernel form runs (dir_din_attention_pool_backward_rows_f32: no softmax recompute, wave-per-sample row pass +
-    streaming weight-gradient pass); DIR_DIN_BWD_ROWS=0 keeps the round-1 single kernel.  -> dict:
+    streaming weight-gradient pass); DIR_DIN_BWD_ROWS=0 keeps the round-1 single kernel.  saved: the (plan, workspace) of
+    din_attention_pool_save on the same inputs -- the row pass then reads the hidden activations instead of recomputing them.  -> dict:
       ids_h [N] int64, gh [N, K]: the valid history positions' table rows and their gradients, (b, j) order;
       ga [B, K]: the candidate rows' gradients;  gW1 [4K, H1], gb1, gW2, gb2, gW3 [H2], gb3 [1]."""
     _dev(table, torch.float32, "table")
@@ -733,24 +791,15 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     hist, g, cand = hist.contiguous(), g.contiguous(), cand.contiguous()
     if hist_len is not None:
         hist_len = hist_len.contiguous()
-    valid = hist >= 0
-    if hist_len is not None:
-        valid &= torch.arange(T, device=dev).unsqueeze(0) < hist_len.clamp(0, T).unsqueeze(1)
-    cnt = valid.sum(dim=1)
-    incl = torch.cumsum(cnt, 0)
-    row_off = (incl - cnt).contiguous()
     use_rows = scores is not None and B > 0 and os.environ.get("DIR_DIN_BWD_ROWS", "1") != "0"
+    if saved is not None and not use_rows:
+        raise ValueError("DIN backward: saved activations need the forward's scores")
+    plan = saved[0] if saved is not None else DinTrainPlan(hist, hist_len)
+    valid, row_off, tile_off, N, n_tiles = plan.valid, plan.row_off, plan.tile_off, plan.N, plan.n_tiles
     if use_rows:
         _dev(scores, torch.float32, "scores")
         if tuple(scores.shape) != (B, T) or not scores.is_contiguous():
             raise ValueError("DIN backward: scores must be a contiguous [B, T] tensor")
-        lens = hist_len.clamp(0, T).to(torch.int64) if hist_len is not None else torch.full((B,), T, dtype=torch.int64, device=dev)
-        tcnt = (lens + 15) // 16
-        tincl = torch.cumsum(tcnt, 0)
-        tile_off = (tincl - tcnt).contiguous()
-        N, n_tiles = (int(v) for v in torch.stack([incl[-1], tincl[-1]]).tolist())      # the one host read (sizes row list + scratch)
-    else:
-        N = int(incl[-1]) if B else 0                              # the one host read (sizes the row list)
     ws = _DIN_BWD_WS.get(dev)
     if ws is None or ws.numel() < need:
         ws = _DIN_BWD_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -761,10 +810,16 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     gW3, gb3 = torch.empty(H2, **f32), torch.empty(1, **f32)
     if use_rows:
         need2 = int(lib.dir_din_backward_rows_workspace_bytes(K, H1, H2, n_tiles))
-        ws2 = _DIN_BWD_WS.get((dev, "rows"))
-        if ws2 is None or ws2.numel() < need2:
-            ws2 = _DIN_BWD_WS[(dev, "rows")] = torch.empty(need2, dtype=torch.uint8, device=dev)
-        _lib.check(lib.dir_din_attention_pool_backward_rows_f32(
+        if saved is not None:
+            ws2 = saved[1]
+            if ws2.numel() < need2:
+                raise ValueError("DIN backward: the saved workspace is smaller than this batch needs")
+        else:
+            ws2 = _DIN_BWD_WS.get((dev, "rows"))
+            if ws2 is None or ws2.numel() < need2:
+                ws2 = _DIN_BWD_WS[(dev, "rows")] = torch.empty(need2, dtype=torch.uint8, device=dev)
+        entry = lib.dir_din_attention_pool_backward_saved_f32 if saved is not None else lib.dir_din_attention_pool_backward_rows_f32
+        _lib.check(entry(
             _ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]), H2,
             _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B, _ptr(g), _ptr(scores), _ptr(row_off), _ptr(tile_off), n_tiles,
             _ptr(gh), _ptr(ga), _ptr(S), _ptr(gAP), _ptr(gW2), _ptr(gb2), _ptr(gW3), _ptr(gb3), _ptr(ws2), need2, _stream()))

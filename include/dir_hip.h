@@ -519,6 +519,28 @@ int dir_din_attention_pool_backward_rows_f32(const float* table, int K, const in
                                              float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
                                              void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 
+/* Training pair that does not recompute the forward (K = 64, H1 <= 80, H2 <= 48, T <= 64 only).
+ * dir_din_attention_pool_save_f32: dir_din_attention_pool_f32 (same outputs; `scores` is required) that also leaves, for every
+ *   history position inside its sample's length, the two hidden layers' activations z1 [H1 -> 80] and z2 [H2 -> 48] in the row's record
+ *   of `workspace` (212 floats per row, 16 rows per tile, sample b's tiles from tile_off[b]; tile_off / n_tiles as above;
+ *   workspace_bytes >= dir_din_backward_rows_workspace_bytes(K, H1, H2, n_tiles), 16-byte aligned).  3.4 KB per 16-row tile of HBM
+ *   instead of 220 of the backward's 440 MFMAs per tile.
+ * dir_din_attention_pool_backward_saved_f32: dir_din_attention_pool_backward_rows_f32 on the SAME workspace, hist, hist_len and
+ *   tile_off, reading z1 / z2 from the records instead of recomputing them (W1's candidate block, b1 and b2 are not read).
+ * The workspace belongs to the caller between the two calls (one per forward in flight). */
+int dir_din_attention_pool_save_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
+                                    int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
+                                    const float* W3, const float* b3, int normalize, int64_t B, float* out, float* scores,
+                                    const int64_t* tile_off, int64_t n_tiles, void* workspace, int64_t workspace_bytes,
+                                    dir_stream_t stream);
+int dir_din_attention_pool_backward_saved_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
+                                              const int64_t* cand, int T, const float* W1, const float* b1, int H1,
+                                              const float* W2, const float* b2, int H2, const float* W3, const float* b3,
+                                              int normalize, int64_t B, const float* gout, const float* scores,
+                                              const int64_t* row_off, const int64_t* tile_off, int64_t n_tiles, float* gh,
+                                              float* ga, float* S, float* gAP, float* gW2, float* gb2, float* gW3, float* gb3,
+                                              void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+
 /* Fused sparse Adagrad on the embedding tables (the reference's dnn_optimizer='Adagrad', deepFM.py:61):
  * for every distinct id of slot f in the batch: g = SUM of the gradient rows of its occurrences ([TF-upstream]
  * duplicate indices are summed before the update), accum[f][id] += g*g, tables[f][id] -= lr * g / sqrt(accum).

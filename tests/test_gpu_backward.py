@@ -1281,6 +1281,47 @@ def test_din_rows_backward_matches_single_kernel(built_lib, normalize, B, T, H1,
         assert err < (5e-3 if (k == "gb3" and normalize) else 2e-4), (k, err)
 
 
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("B,T,H1,H2", [(300, 50, 80, 40), (67, 64, 80, 48), (41, 17, 36, 20), (9, 5, 64, 32)])
+def test_din_saved_activations_backward_matches_recompute(built_lib, normalize, B, T, H1, H2, monkeypatch):
+    """The training pair dir_din_attention_pool_save_f32 + dir_din_attention_pool_backward_saved_f32 (the forward leaves z1 / z2 of every
+    history row in a workspace, the row pass reads them) against the recomputing row pass on the same inputs: same forward outputs bit
+    for bit, every gradient within the 2e-4 bar of the row-pass test above (sums that cancel under the softmax set it; the saved activations come from the forward's bf16x3 arithmetic, the recomputed ones from
+    fp32 MFMA: both within 1e-6 of the exact sigmoid).  Pruned ids, empty and full-length histories, a pruned candidate included."""
+    from dir_amd import ops
+    K, V = 64, 5000
+    g = torch.Generator().manual_seed(B * 3 + T)
+    table = (torch.randn(V, K, generator=g) * 0.3).cuda()
+    Ws = [(torch.randn(4 * K, H1, generator=g) * 0.1).cuda(), (torch.randn(H1, generator=g) * 0.1).cuda(),
+          (torch.randn(H1, H2, generator=g) * 0.2).cuda(), (torch.randn(H2, generator=g) * 0.1).cuda(),
+          (torch.randn(H2, generator=g) * 0.5).cuda(), torch.randn(1, generator=g).cuda()]
+    hist = torch.randint(0, V, (B, T), generator=g)
+    hist[torch.rand((B, T), generator=g) < 0.1] = -1
+    hl = torch.randint(0, T + 1, (B,), generator=g).to(torch.int32)
+    hl[0], hl[1 % B] = T, 0
+    cand = torch.randint(0, V, (B,), generator=g)
+    cand[3 % B] = -1
+    hist, hl, cand = hist.cuda(), hl.cuda(), cand.cuda()
+    gout = torch.randn(B, K, generator=g).cuda()
+    for arith in ("bf16x3", "f32"):
+        monkeypatch.setenv("DIR_DIN_ARITH", arith)
+        out0, sc0 = ops.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, want_scores=True)
+        out1, sc1, saved = ops.din_attention_pool_save(table, hist, hl, cand, *Ws, normalize=normalize)
+        assert torch.equal(out0, out1) and torch.equal(sc0, sc1)
+        ref = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=sc0)
+        got = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=sc1, saved=saved)
+        assert torch.equal(ref["ids_h"], got["ids_h"])
+        for k in ("gh", "ga", "gW1", "gb1", "gW2", "gb2", "gW3", "gb3"):
+            a, b = ref[k].double(), got[k].double()
+            err = ((a - b).abs() / (1e-3 + 0.05 * a.abs().max() + a.abs())).max().item() if a.numel() else 0.0
+            assert err < (5e-3 if (k == "gb3" and normalize) else 2e-4), (arith, k, err)
+        # bitwise reproducible
+        out2, sc2, saved2 = ops.din_attention_pool_save(table, hist, hl, cand, *Ws, normalize=normalize)
+        got2 = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=sc2, saved=saved2)
+        for k in ("gh", "ga", "gW1", "gb1", "gW2", "gb2", "gW3", "gb3"):
+            assert torch.equal(got[k], got2[k]), k
+
+
 # ---- tf.train.AdamOptimizer on the embedding tables (dir_sparse_adam_f32) ----------------------------------------------------------
 def _adam_ref64(tables, ms, vs, ids, grad, lr, b1, b2, eps, clip, t):
     """float64 restatement of the reference's train_op on IndexedSlices gradients (DeepCrossNetwork.py:264-290 + [TF-upstream]
