@@ -36,7 +36,7 @@ EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # ... and NO packed fp32 VALU instructions beside its 16x16x32 bf16 MFMAs (a gfx950 hazard: see the file's header and
                # tools/pk_mfma_probe.hip); the host pass prints "not a recognized feature" for the flag and ignores it
                "din_wave.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + NO_PACKED_FP32,
-               "din_bwd_rows.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+               "din_bwd_rows.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + NO_PACKED_FP32}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
          "-Wall", "-Wno-unused-function"]

@@ -21,6 +21,7 @@
 //
 // The attention weights of the forward (dir_din_attention_pool_f32's `scores` output) are an INPUT: the softmax is not recomputed.
 #include <atomic>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -46,6 +47,7 @@ constexpr int kRowsBwdGAP = 2 * 64 * 80, kRowsBwdGW2 = 80 * 48;
 constexpr int kRowsBwdRec = kRowsBwdGAP + kRowsBwdGW2 + 4 * 48 + 4 * 48 + 64;      // == din.hip's kDinBwdRec (checked by the host code)
 
 struct DinRowsSh {
+    static constexpr bool kBf3 = false;
     float whd[RB_H1P * RB_WS];          // (Wh + Wd)^T  x -log2 e
     float wp[RB_H1P * RB_WS];           // Wp^T         x -log2 e
     float wc[RB_H1P * RB_WS];           // (Wa - Wd)^T  x -log2 e
@@ -57,6 +59,61 @@ struct DinRowsSh {
     float av[RB_WAVES][RB_K];           // candidate row of the wave's sample
     float gv[RB_WAVES][RB_K];           // d out of the wave's sample
 };
+
+// The row pass on saved activations with its two GEMMs (dz1^T = W2 dpre2^T, dX^T = [Wh+Wd ; Wp] dpre1^T) on the bf16 x 3 recipe of
+// din_wave.hip: only the two backward images, split into three bf16 pieces in MFMA A-operand order [k-step][m tile][piece][lane][8]
+// (element j of lane (kk, r) in k-step ks = A[16 mtile + r][16 (2 ks + (j >> 2)) + 4 kk + (j & 3)]) -- 102 KB; the B operands are the
+// lane's own accumulator tiles 2 ks, 2 ks + 1 of the GEMM before (dpre2, dpre1), as in the forward.
+// This file is compiled without packed fp32 VALU instructions (build.py; the gfx950 hazard of isa_check.py).
+struct DinRowsSh3 {
+    static constexpr bool kBf3 = true;
+    unsigned int w2b3[2 * 5 * 3 * 256];     // W2 [hidden 80 -> 5 tiles][h2 48 -> 2 k-steps of 32]
+    unsigned int wcat3[3 * 8 * 3 * 256];    // [Wh + Wd ; Wp] [feature 128 -> 8 tiles][hidden 80 -> 3 k-steps of 32]
+    float w3[RB_H2P];
+    float av[RB_WAVES][RB_K];
+    float gv[RB_WAVES][RB_K];
+};
+
+typedef __bf16 rb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int rb_u32x4 __attribute__((ext_vector_type(4)));
+#define RB_MFMA3(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned int rb_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
+    typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
+    const pk2_t v = {(__bf16)a, (__bf16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));
+    return w;
+}
+__device__ __forceinline__ void rb_split_pair(float a, float b, unsigned int& w0, unsigned int& w1, unsigned int& w2) {
+    w0 = rb_pk(a, b);
+    const float ra = a - __builtin_bit_cast(float, w0 << 16), rb = b - __builtin_bit_cast(float, w0 & 0xffff0000u);
+    w1 = rb_pk(ra, rb);
+    const float sa = ra - __builtin_bit_cast(float, w1 << 16), sb = rb - __builtin_bit_cast(float, w1 & 0xffff0000u);
+    w2 = rb_pk(sa, sb);
+}
+typedef float f32x4r_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rb_split8(const f32x4r_ s0, const f32x4r_ s1, rb_bf16x8 (&x)[3]) {
+    unsigned int w[3][4];
+    rb_split_pair(s0[0], s0[1], w[0][0], w[1][0], w[2][0]);
+    rb_split_pair(s0[2], s0[3], w[0][1], w[1][1], w[2][1]);
+    rb_split_pair(s1[0], s1[1], w[0][2], w[1][2], w[2][2]);
+    rb_split_pair(s1[2], s1[3], w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) x[pc] = __builtin_bit_cast(rb_bf16x8, (rb_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
+}
+__device__ __forceinline__ f32x4r_ rb_mfma6(const rb_bf16x8 (&a)[3], const rb_bf16x8 (&x)[3], f32x4r_ c) {
+    c = RB_MFMA3(a[0], x[2], c);
+    c = RB_MFMA3(a[2], x[0], c);
+    c = RB_MFMA3(a[1], x[1], c);
+    c = RB_MFMA3(a[0], x[1], c);
+    c = RB_MFMA3(a[1], x[0], c);
+    c = RB_MFMA3(a[0], x[0], c);
+    return c;
+}
+__device__ __forceinline__ void rb_lda(const unsigned int* img, int tile, int lane4, rb_bf16x8 (&a)[3]) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) a[pc] = __builtin_bit_cast(rb_bf16x8, *reinterpret_cast<const rb_u32x4*>(img + (tile * 3 + pc) * 256 + lane4));
+}
 
 __device__ unsigned int rb_queue[RB_SLOTS][16];
 
@@ -133,7 +190,7 @@ __device__ __forceinline__ void rb_load_row(const float* __restrict__ table, con
 
 // SAVED: the records already hold z1 and z2 (written by the training forward, dir_din_attention_pool_save_f32): nothing of the forward is
 // recomputed -- half of the MFMAs, no per-sample term, no forward weight images.
-template <bool SAVED>
+template <bool SAVED, typename Sh>
 __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
                                                                const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand,
                                                                int T, const float* __restrict__ W1, const float* __restrict__ b1, int H1,
@@ -144,45 +201,83 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                                                                float* __restrict__ gh, float* __restrict__ ga, float* __restrict__ Sout,
                                                                float* __restrict__ scratch, int slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
-    DinRowsSh& sh = *reinterpret_cast<DinRowsSh*>(rb_smem);
+    static_assert(SAVED || !Sh::kBf3, "the bf16x3 row pass has no forward images: saved activations only");
+    Sh& sh = *reinterpret_cast<Sh*>(rb_smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
     // ---- weight images, once per workgroup ---------------------------------------------------------------------------------------------------
-#pragma unroll 2
-    for (int idx = tid; idx < (RB_H1P / 4) * RB_K; idx += 64 * RB_WAVES) {
-        const int f = idx / (RB_H1P / 4), m = 4 * (idx - f * (RB_H1P / 4));
-        float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), va = vh, vd = vh, vp = vh;
-        if (m < H1) {
-            vh = rb_ld4(W1 + (size_t)f * H1 + m);
-            vd = rb_ld4(W1 + (size_t)(2 * RB_K + f) * H1 + m);
-            vp = rb_ld4(W1 + (size_t)(3 * RB_K + f) * H1 + m);
-            if (!SAVED) va = rb_ld4(W1 + (size_t)(RB_K + f) * H1 + m);
-        }
-        const float h4[4] = {vh.x + vd.x, vh.y + vd.y, vh.z + vd.z, vh.w + vd.w};
-        const float p4[4] = {vp.x, vp.y, vp.z, vp.w};
-        if (!SAVED) {
-            const float c4[4] = {va.x - vd.x, va.y - vd.y, va.z - vd.z, va.w - vd.w};
+    if constexpr (Sh::kBf3) {
+        for (int idx = tid; idx < 2 * 5 * 64 * 4; idx += 64 * RB_WAVES) {          // W2 as A[m = hidden][k = h2]: dword jp of lane l of tile t = (ks, mt)
+            const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+            const int ks = t / 5, mt = t - 5 * ks;
+            const int hid = 16 * mt + (l & 15);
+            const int h2 = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+            float v[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sh.whd[(m + e) * RB_WS + f] = h4[e] * RB_NLOG2E;
-                sh.wp[(m + e) * RB_WS + f] = p4[e] * RB_NLOG2E;
-                sh.wc[(m + e) * RB_WS + f] = c4[e] * RB_NLOG2E;
-            }
+            for (int e = 0; e < 2; ++e) v[e] = (hid < H1 && h2 + e < H2) ? W2[(size_t)hid * H2 + h2 + e] : 0.f;
+            unsigned int q0, q1, q2;
+            rb_split_pair(v[0], v[1], q0, q1, q2);
+            sh.w2b3[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
+            sh.w2b3[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
+            sh.w2b3[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
         }
-        *reinterpret_cast<float4*>(&sh.wcat[f * RB_WCS + m]) = make_float4(h4[0], h4[1], h4[2], h4[3]);
-        *reinterpret_cast<float4*>(&sh.wcat[(RB_K + f) * RB_WCS + m]) = make_float4(p4[0], p4[1], p4[2], p4[3]);
-    }
-    for (int idx = tid; idx < RB_H2P * RB_H1P; idx += 64 * RB_WAVES) {
-        const int hid = idx / RB_H2P, h2 = idx - hid * RB_H2P;
-        const float v = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] : 0.f;
-        if (!SAVED) sh.w2[h2 * RB_W2S + hid] = v * RB_NLOG2E;
-        sh.w2b[hid * RB_W2BS + h2] = v;
-    }
-    if (!SAVED) {
-        for (int idx = tid; idx < RB_H1P; idx += 64 * RB_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * RB_NLOG2E : 0.f;
-    }
-    for (int idx = tid; idx < RB_H2P; idx += 64 * RB_WAVES) {
-        if (!SAVED) sh.b2[idx] = idx < H2 ? b2[idx] * RB_NLOG2E : 0.f;
-        sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
+        for (int idx = tid; idx < 3 * 8 * 64 * 4; idx += 64 * RB_WAVES) {          // [Wh + Wd ; Wp] as A[m = feature][k = hidden], t = (ks, ft)
+            const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+            const int ks = t / 8, ft = t - 8 * ks;
+            const int feat = 16 * ft + (l & 15);
+            const int hid = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v[e] = 0.f;
+                if (hid + e < H1)
+                    v[e] = feat < RB_K ? W1[(size_t)feat * H1 + hid + e] + W1[(size_t)(2 * RB_K + feat) * H1 + hid + e]
+                                       : W1[(size_t)(3 * RB_K + feat - RB_K) * H1 + hid + e];
+            }
+            unsigned int q0, q1, q2;
+            rb_split_pair(v[0], v[1], q0, q1, q2);
+            sh.wcat3[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
+            sh.wcat3[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
+            sh.wcat3[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
+        }
+        for (int idx = tid; idx < RB_H2P; idx += 64 * RB_WAVES) sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
+    } else {
+#pragma unroll 2
+        for (int idx = tid; idx < (RB_H1P / 4) * RB_K; idx += 64 * RB_WAVES) {
+            const int f = idx / (RB_H1P / 4), m = 4 * (idx - f * (RB_H1P / 4));
+            float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), va = vh, vd = vh, vp = vh;
+            if (m < H1) {
+                vh = rb_ld4(W1 + (size_t)f * H1 + m);
+                vd = rb_ld4(W1 + (size_t)(2 * RB_K + f) * H1 + m);
+                vp = rb_ld4(W1 + (size_t)(3 * RB_K + f) * H1 + m);
+                if (!SAVED) va = rb_ld4(W1 + (size_t)(RB_K + f) * H1 + m);
+            }
+            const float h4[4] = {vh.x + vd.x, vh.y + vd.y, vh.z + vd.z, vh.w + vd.w};
+            const float p4[4] = {vp.x, vp.y, vp.z, vp.w};
+            if (!SAVED) {
+                const float c4[4] = {va.x - vd.x, va.y - vd.y, va.z - vd.z, va.w - vd.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sh.whd[(m + e) * RB_WS + f] = h4[e] * RB_NLOG2E;
+                    sh.wp[(m + e) * RB_WS + f] = p4[e] * RB_NLOG2E;
+                    sh.wc[(m + e) * RB_WS + f] = c4[e] * RB_NLOG2E;
+                }
+            }
+            *reinterpret_cast<float4*>(&sh.wcat[f * RB_WCS + m]) = make_float4(h4[0], h4[1], h4[2], h4[3]);
+            *reinterpret_cast<float4*>(&sh.wcat[(RB_K + f) * RB_WCS + m]) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+        }
+        for (int idx = tid; idx < RB_H2P * RB_H1P; idx += 64 * RB_WAVES) {
+            const int hid = idx / RB_H2P, h2 = idx - hid * RB_H2P;
+            const float v = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] : 0.f;
+            if (!SAVED) sh.w2[h2 * RB_W2S + hid] = v * RB_NLOG2E;
+            sh.w2b[hid * RB_W2BS + h2] = v;
+        }
+        if (!SAVED) {
+            for (int idx = tid; idx < RB_H1P; idx += 64 * RB_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * RB_NLOG2E : 0.f;
+        }
+        for (int idx = tid; idx < RB_H2P; idx += 64 * RB_WAVES) {
+            if (!SAVED) sh.b2[idx] = idx < H2 ? b2[idx] * RB_NLOG2E : 0.f;
+            sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
+        }
     }
     __syncthreads();
     const float inv_sqrt_k = 1.0f / sqrtf((float)RB_K);
@@ -294,7 +389,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                 *reinterpret_cast<float4*>(&sh.gv[w][16 * i + 4 * kk]) = gn[i];
             }
         }
-        if (!SAVED) {
+        if constexpr (!SAVED) {
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
                 float part = 0.f;
@@ -423,16 +518,31 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
             f32x4r dp1[5];
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) dp1[mt] = (f32x4r){0.f, 0.f, 0.f, 0.f};
+            if constexpr (Sh::kBf3) {
+                const int lane4 = 4 * lane;
 #pragma unroll
-            for (int m2 = 0; m2 < 3; ++m2) {
-                float4 aw[5];
+                for (int ks = 0; ks < 2; ++ks) {           // h2 0..31 | 32..47 (+ 16 zeros)
+                    rb_bf16x8 xb[3];
+                    rb_split8(dp2[2 * ks], ks == 0 ? dp2[1] : (f32x4r){0.f, 0.f, 0.f, 0.f}, xb);
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt) aw[mt] = rb_ld4(&sh.w2b[(16 * mt + r16) * RB_W2BS + 16 * m2 + 4 * kk]);
+                    for (int mt = 0; mt < 5; ++mt) {
+                        rb_bf16x8 aw[3];
+                        rb_lda(sh.w2b3, ks * 5 + mt, lane4, aw);
+                        dp1[mt] = rb_mfma6(aw, xb, dp1[mt]);
+                    }
+                }
+            } else {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+                for (int m2 = 0; m2 < 3; ++m2) {
+                    float4 aw[5];
 #pragma unroll
-                    for (int mt = 0; mt < 5; ++mt) dp1[mt] = RB_MFMA(rb_c(aw[mt], g), dp2[m2][g], dp1[mt]);
-                RB_SCHED_FENCE();
+                    for (int mt = 0; mt < 5; ++mt) aw[mt] = rb_ld4(&sh.w2b[(16 * mt + r16) * RB_W2BS + 16 * m2 + 4 * kk]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int mt = 0; mt < 5; ++mt) dp1[mt] = RB_MFMA(rb_c(aw[mt], g), dp2[m2][g], dp1[mt]);
+                    RB_SCHED_FENCE();
+                }
             }
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
@@ -447,18 +557,33 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
             f32x4r dx[8];
 #pragma unroll
             for (int ft = 0; ft < 8; ++ft) dx[ft] = (f32x4r){0.f, 0.f, 0.f, 0.f};
+            if constexpr (Sh::kBf3) {
+                const int lane4 = 4 * lane;
 #pragma unroll
-            for (int mt = 0; mt < 5; ++mt) {
+                for (int ks = 0; ks < 3; ++ks) {           // hidden 0..31 | 32..63 | 64..79 (+ 16 zeros)
+                    rb_bf16x8 xb[3];
+                    rb_split8(dp1[2 * ks], 2 * ks + 1 < 5 ? dp1[2 * ks + 1 < 5 ? 2 * ks + 1 : 0] : (f32x4r){0.f, 0.f, 0.f, 0.f}, xb);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float4 aw[4];
+                    for (int ft = 0; ft < 8; ++ft) {
+                        rb_bf16x8 aw[3];
+                        rb_lda(sh.wcat3, ks * 8 + ft, lane4, aw);
+                        dx[ft] = rb_mfma6(aw, xb, dx[ft]);
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) aw[qd] = rb_ld4(&sh.wcat[(16 * (4 * half + qd) + r16) * RB_WCS + 16 * mt + 4 * kk]);
+                for (int mt = 0; mt < 5; ++mt) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int half = 0; half < 2; ++half) {
+                        float4 aw[4];
 #pragma unroll
-                        for (int qd = 0; qd < 4; ++qd) dx[4 * half + qd] = RB_MFMA(rb_c(aw[qd], g), dp1[mt][g], dx[4 * half + qd]);
-                    RB_SCHED_FENCE();
+                        for (int qd = 0; qd < 4; ++qd) aw[qd] = rb_ld4(&sh.wcat[(16 * (4 * half + qd) + r16) * RB_WCS + 16 * mt + 4 * kk]);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+#pragma unroll
+                            for (int qd = 0; qd < 4; ++qd) dx[4 * half + qd] = RB_MFMA(rb_c(aw[qd], g), dp1[mt][g], dx[4 * half + qd]);
+                        RB_SCHED_FENCE();
+                    }
                 }
             }
             // d h_j = dXh + dXp * a + w_j g (compact row list); d a += dXp * h_j
@@ -733,13 +858,20 @@ static int din_backward_rows(const char* name, bool saved, const float* table, i
     float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + scratch_bytes);
     int nwg2 = 0;
     if (B > 0) {
-        static bool attr_set[2] = {false, false};
-        const size_t shmem = sizeof(DinRowsSh);
-        const void* fn = saved ? reinterpret_cast<const void*>(&din_rows_k<true>) : reinterpret_cast<const void*>(&din_rows_k<false>);
-        if (!attr_set[saved]) {
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+        // DIR_DIN_BWD_ARITH = bf16x3 (default) | f32: the arithmetic of the saved-activation row pass's two GEMMs (read per call)
+        const char* arith = getenv("DIR_DIN_BWD_ARITH");
+        const bool bf3 = saved && !(arith && strcmp(arith, "f32") == 0);
+        typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,
+                               const float*, int, const float*, int, long long, const float*, const float*, const int64_t*, const int64_t*, float*,
+                               float*, float*, float*, int);
+        const int which = bf3 ? 2 : saved ? 1 : 0;
+        static const kern_t kerns[3] = {&din_rows_k<false, DinRowsSh>, &din_rows_k<true, DinRowsSh>, &din_rows_k<true, DinRowsSh3>};
+        static bool attr_set[3] = {false, false, false};
+        const size_t shmem = bf3 ? sizeof(DinRowsSh3) : sizeof(DinRowsSh);
+        if (!attr_set[which]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[which]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
                 return fail(DIR_E_HIP, "%s: cannot reserve %zu B of LDS", name, shmem);
-            attr_set[saved] = true;
+            attr_set[which] = true;
         }
         const char* stat = getenv("DIR_DIN_STATIC");
         const bool static_split = stat && atoi(stat) != 0;
@@ -748,12 +880,8 @@ static int din_backward_rows(const char* name, bool saved, const float* table, i
         int64_t nwg = (waves_wanted + RB_WAVES - 1) / RB_WAVES;
         if (nwg > kCUs) nwg = kCUs;
         if (nwg < 1) nwg = 1;
-        if (saved)
-            hipLaunchKernelGGL(din_rows_k<true>, dim3((unsigned)nwg), dim3(64 * RB_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2,
-                               b2, H2, W3, normalize, (long long)B, gout, scores, row_off, tile_off, gh, ga, S, scratch, slot);
-        else
-            hipLaunchKernelGGL(din_rows_k<false>, dim3((unsigned)nwg), dim3(64 * RB_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2,
-                               b2, H2, W3, normalize, (long long)B, gout, scores, row_off, tile_off, gh, ga, S, scratch, slot);
+        hipLaunchKernelGGL(kerns[which], dim3((unsigned)nwg), dim3(64 * RB_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2,
+                           W3, normalize, (long long)B, gout, scores, row_off, tile_off, gh, ga, S, scratch, slot);
         DIR_CHECK_LAUNCH(name);
         nwg2 = (int)(B < kRowsWgradWg ? B : kRowsWgradWg);
         hipLaunchKernelGGL(din_wgrad_k, dim3((unsigned)nwg2), dim3(256), 0, st, table, hist, hist_len, cand, T, W3, H2, (long long)B, tile_off,
