@@ -15,7 +15,11 @@ b dcn_cross --workload dcn_cross --steps 100 --warmup 10
 b dcn_cross429 --workload dcn_cross --cross-d 429 --steps 100 --warmup 10 --no-cpu-baseline
 b dcn_cross_backward --workload dcn_cross_backward --steps 100 --warmup 10 --no-cpu-baseline
 b din --workload din --steps 50 --warmup 5
+DIR_DIN_STATIC=0 b din_queue --workload din --steps 50 --warmup 5 --no-cpu-baseline
+DIR_DIN_ARITH=f32 b din_f32 --workload din --steps 50 --warmup 5 --no-cpu-baseline
 b din_train --workload din_train --steps 30 --warmup 5 --no-cpu-baseline
+DIR_DIN_BWD_ARITH=f32 b din_train_bwd_f32 --workload din_train --steps 30 --warmup 5 --no-cpu-baseline
+DIR_DIN_SAVE=0 b din_train_recompute --workload din_train --steps 30 --warmup 5 --no-cpu-baseline
 b cin --workload cin --steps 5 --warmup 2
 b cin_backward --workload cin_backward --steps 5 --warmup 2 --no-cpu-baseline
 b mlp_dense --workload mlp_dense --steps 50 --warmup 5 --no-cpu-baseline
@@ -32,8 +36,8 @@ b train_sparse --workload train_sparse --steps 100 --warmup 10 --no-cpu-baseline
 b sharded_1gpu --workload sharded_1gpu --steps 100 --warmup 10 --no-cpu-baseline
 b transform --workload transform --steps 100 --warmup 10 --no-cpu-baseline
 b small_batch --workload small_batch --steps 200 --warmup 20 --no-cpu-baseline
-for w in default deepfm_full esmm_full dcn_full train_sparse sharded_1gpu cin_backward; do
-    if [ $w = default ]; then a="--steps 100 --warmup 10 --no-cpu-baseline"; else a="--workload $w --steps 10 --warmup 3 --no-cpu-baseline"; fi
+for w in default deepfm_full esmm_full dcn_full train_sparse sharded_1gpu cin_backward din din_train; do
+    if [ $w = default ]; then a="--steps 100 --warmup 10 --no-cpu-baseline"; elif [ $w = din ] || [ $w = din_train ]; then a="--workload $w --steps 50 --warmup 10 --no-cpu-baseline"; else a="--workload $w --steps 10 --warmup 3 --no-cpu-baseline"; fi
     DIR_BENCH_NO_SECONDARY=1 bash tools/prof.sh $w -- $a > gpurun_out/prof_$w.txt 2>&1; echo "== $w"; head -5 gpurun_out/prof_$w.txt | cut -c1-150
 done
 bash tools/traffic.sh > gpurun_out/traffic_r03.txt 2>&1; tail -16 gpurun_out/traffic_r03.txt
