@@ -791,7 +791,12 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     hist, g, cand = hist.contiguous(), g.contiguous(), cand.contiguous()
     if hist_len is not None:
         hist_len = hist_len.contiguous()
-    use_rows = scores is not None and B > 0 and os.environ.get("DIR_DIN_BWD_ROWS", "1") != "0"
+    if B == 0:                                           # an empty batch: zero gradients, nothing to launch (empty tensors have no storage)
+        f32 = dict(dtype=torch.float32, device=dev)
+        z = torch.zeros((0, K), **f32)
+        return {"ids_h": hist.reshape(-1)[:0], "gh": z, "ga": z, "grows": z, "gW1": torch.zeros((4 * K, H1), **f32), "gb1": torch.zeros(H1, **f32),
+                "gW2": torch.zeros((H1, H2), **f32), "gb2": torch.zeros(H2, **f32), "gW3": torch.zeros(H2, **f32), "gb3": torch.zeros(1, **f32)}
+    use_rows = scores is not None and os.environ.get("DIR_DIN_BWD_ROWS", "1") != "0"
     if saved is not None and not use_rows:
         raise ValueError("DIN backward: saved activations need the forward's scores")
     plan = saved[0] if saved is not None else DinTrainPlan(hist, hist_len)

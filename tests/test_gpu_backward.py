@@ -841,6 +841,58 @@ def test_din_fused_backward_empty_and_limits(built_lib):
                                         torch.randn(20).cuda(), torch.zeros(1).cuda(), torch.randn(4, 32).cuda())
 
 
+def test_din_saved_activations_edges(built_lib):
+    """The training pair at its edges: every history empty (no tile, no record), full-length histories of T = 64 (four tiles), a batch of
+    one, an empty batch through autograd, and the C entry's argument checks (unsupported shape class, workspace too small)."""
+    import ctypes
+    from dir_amd import _lib, ops
+    from dir_amd import autograd as ag
+    from dir_amd._lib import DirError
+    K, H1, H2, V = 64, 80, 40, 300
+    g = torch.Generator().manual_seed(11)
+    table = (torch.randn(V, K, generator=g) * 0.3).cuda()
+    Ws = [(torch.randn(4 * K, H1, generator=g) * 0.1).cuda(), torch.zeros(H1).cuda(), (torch.randn(H1, H2, generator=g) * 0.2).cuda(),
+          torch.zeros(H2).cuda(), (torch.randn(H2, generator=g) * 0.5).cuda(), torch.zeros(1).cuda()]
+    for B, T, lens in ((5, 10, "zero"), (3, 64, "full"), (1, 50, "full"), (6, 33, "mixed")):
+        hist = torch.randint(0, V, (B, T), generator=g).cuda()
+        hl = {"zero": torch.zeros(B, dtype=torch.int32), "full": torch.full((B,), T, dtype=torch.int32),
+              "mixed": torch.randint(0, T + 1, (B,), generator=g).to(torch.int32)}[lens].cuda()
+        cand = torch.randint(0, V, (B,), generator=g).cuda()
+        gout = torch.randn(B, K, generator=g).cuda()
+        for normalize in (True, False):
+            out, sc, saved = ops.din_attention_pool_save(table, hist, hl, cand, *Ws, normalize=normalize)
+            out0, sc0 = ops.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, want_scores=True)
+            assert torch.equal(out, out0) and torch.equal(sc, sc0)
+            assert saved[0].n_tiles == int(((hl.clamp(0, T).long() + 15) // 16).sum())
+            ref = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=sc0)
+            got = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=sc, saved=saved)
+            for k in ("gh", "ga", "gW1", "gb1", "gW2", "gb2", "gW3", "gb3"):
+                a, b = ref[k].double(), got[k].double()
+                err = ((a - b).abs() / (1e-3 + 0.05 * a.abs().max() + a.abs())).max().item() if a.numel() else 0.0
+                assert err < (5e-3 if (k == "gb3" and normalize) else 2e-4), (B, T, lens, normalize, k, err)
+    # an empty batch through autograd: zero gradients of the right shapes
+    params = [w.clone().requires_grad_(True) for w in Ws]
+    tab = table.clone().requires_grad_(True)
+    e = ag.din_attention_pool(tab, torch.zeros((0, 7), dtype=torch.int64).cuda(), torch.zeros(0, dtype=torch.int32).cuda(),
+                              torch.zeros(0, dtype=torch.int64).cuda(), *params, normalize=True)
+    assert tuple(e.shape) == (0, K)
+    e.sum().backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in params)
+    # argument checks of the C entry
+    with pytest.raises(DirError):                       # K = 32 is not this kernel's shape class
+        ops.din_attention_pool_save(torch.randn(V, 32).cuda(), hist, hl, cand, torch.randn(128, 36).cuda(), torch.zeros(36).cuda(),
+                                    torch.randn(36, 20).cuda(), torch.zeros(20).cuda(), torch.randn(20).cuda(), torch.zeros(1).cuda())
+    lib = _lib.load()
+    plan = ops.DinTrainPlan(hist, hl)
+    small = torch.empty(256, dtype=torch.uint8, device="cuda")
+    out = torch.empty((hist.shape[0], K), device="cuda")
+    sc = torch.empty(hist.shape, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    rc = lib.dir_din_attention_pool_save_f32(p(table), K, p(hist), p(hl), p(cand), hist.shape[1], p(Ws[0]), p(Ws[1]), H1, p(Ws[2]), p(Ws[3]), H2,
+                                             p(Ws[4]), p(Ws[5]), 1, hist.shape[0], p(out), p(sc), p(plan.tile_off), plan.n_tiles, p(small), 256, None)
+    assert rc == _lib.DIR_E_BADARG and b"workspace" in lib.dir_last_error()
+
+
 def test_input_layer_fused_sparse_adagrad_matches_torch(built_lib):
     """InputLayer.fused_sparse_adagrad (the ESMM / DCN towers' tables updated inside backward) against torch's sparse Adagrad."""
     from dir_amd import feature_column as fc
