@@ -73,6 +73,10 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
 // a sample's tiles consecutive from tile_off[b]): z1 [80] | dpre1 [80] | z2 [48] | d score | 3 pad.  The training forward
 // (dir_din_attention_pool_save_f32) writes z1 and z2; the backward's row pass adds dpre1 and d score; its weight-gradient pass reads all.
 constexpr int kDinRecRow = 212, kDinRecZ1 = 0, kDinRecDp1 = 80, kDinRecZ2 = 160, kDinRecDs = 208;
+#ifndef DIN_NT
+#define DIN_NT 0          // 1: non-temporal record stores / loads.  Measured (tools/build_nt_variants.sh, one box): the step 2.77 -> 2.87 ms,
+                          // the row pass 0.88 -> 0.99 ms, the saving forward 0.56 -> 0.64 ms -- the records do profit from L2 / Infinity Cache
+#endif
 
 }  // namespace dir
 
@@ -82,6 +86,25 @@ namespace dir {
 
 // Value of `v` from lane `src` of the wave (all lanes active).
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+
+// 16-byte accesses to the DIN training records (streamed: each byte is written once and read once or twice by LATER kernels)
+typedef float din_rec_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void din_rec_store(float* p, float a, float b, float c, float d) {
+    const din_rec_f4 v = {a, b, c, d};
+#if DIN_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<din_rec_f4*>(p));
+#else
+    *reinterpret_cast<din_rec_f4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ float4 din_rec_load(const float* p) {
+#if DIN_NT
+    const din_rec_f4 v = __builtin_nontemporal_load(reinterpret_cast<const din_rec_f4*>(p));
+#else
+    const din_rec_f4 v = *reinterpret_cast<const din_rec_f4*>(p);
+#endif
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 // Sum over the LPS consecutive lanes that share a sample (butterfly; result in every lane).
 template <int LPS>

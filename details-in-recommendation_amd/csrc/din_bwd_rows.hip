@@ -431,13 +431,13 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
 #pragma unroll
                 for (int mt = 0; mt < 5; ++mt) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (inlen) v = rb_ld4(srow + RB_Z1 + 16 * mt + 4 * kk);
+                    if (inlen) v = din_rec_load(srow + RB_Z1 + 16 * mt + 4 * kk);
                     z1[mt] = (f32x4r){v.x, v.y, v.z, v.w};
                 }
 #pragma unroll
                 for (int m2 = 0; m2 < 3; ++m2) {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (inlen) v = rb_ld4(srow + RB_Z2 + 16 * m2 + 4 * kk);
+                    if (inlen) v = din_rec_load(srow + RB_Z2 + 16 * m2 + 4 * kk);
                     const float4 w4 = rb_ld4(&sh.w3[16 * m2 + 4 * kk]);
                     const float zz[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                     dp1[mt][g] = dp1[mt][g] * z1[mt][g] * (1.0f - z1[mt][g]);
                     Sacc[mt][g] += dp1[mt][g];
                 }
-                if (inlen) *reinterpret_cast<float4*>(srow + RB_DP1 + 16 * mt + 4 * kk) = make_float4(dp1[mt][0], dp1[mt][1], dp1[mt][2], dp1[mt][3]);
+                if (inlen) din_rec_store(srow + RB_DP1 + 16 * mt + 4 * kk, dp1[mt][0], dp1[mt][1], dp1[mt][2], dp1[mt][3]);
             }
             // ---- dX^T = [Wh+Wd ; Wp] dpre1^T: features 0..63 -> d h through h, 64..127 -> through h * a -------------------------------------------------
             f32x4r dx[8];
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64 * RB_WAVES, 2) void din_rows_k(const float* __re
                     o.y = fmaf(dx[4 + i][1], a4.y, dx[i][1]) + wt * g4.y;
                     o.z = fmaf(dx[4 + i][2], a4.z, dx[i][2]) + wt * g4.z;
                     o.w = fmaf(dx[4 + i][3], a4.w, dx[i][3]) + wt * g4.w;
-                    if (okrow) *reinterpret_cast<float4*>(ghrow + 16 * i + 4 * kk) = o;
+                    if (okrow) din_rec_store(ghrow + 16 * i + 4 * kk, o.x, o.y, o.z, o.w);       // the table gradient's rows: read later by torch
                     gacc[i].x = fmaf(dx[4 + i][0], hv[i].x, gacc[i].x);
                     gacc[i].y = fmaf(dx[4 + i][1], hv[i].y, gacc[i].y);
                     gacc[i].z = fmaf(dx[4 + i][2], hv[i].z, gacc[i].z);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256, 4) void din_wgrad_k(const float* __restrict__ 
         for (int k = 0; k < NSC; ++k) {
             const int e = tid + 256 * k;
             sreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < nrow4) sreg[k] = src[e];
+            if (e < nrow4) sreg[k] = din_rec_load(reinterpret_cast<const float*>(src + e));
         }
         areg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t == 0 && tid < 16) {

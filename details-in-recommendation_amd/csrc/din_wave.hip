@@ -264,7 +264,7 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
             if (rec[rt]) {
 #pragma unroll
                 for (int mt = 0; mt < 5; ++mt)
-                    *reinterpret_cast<float4*>(rec[rt] + kDinRecZ1 + 16 * mt + 4 * kk) = make_float4(acc1[mt][rt][0], acc1[mt][rt][1], acc1[mt][rt][2], acc1[mt][rt][3]);
+                    din_rec_store(rec[rt] + kDinRecZ1 + 16 * mt + 4 * kk, acc1[mt][rt][0], acc1[mt][rt][1], acc1[mt][rt][2], acc1[mt][rt][3]);
             }
         // ---- layer 2: pre2^T, three k-steps (hidden 80..95 are zeros on both sides) -------------------------------------------------
 #pragma unroll
@@ -335,8 +335,7 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
         if (rec[rt]) {
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt)
-                *reinterpret_cast<float4*>(rec[rt] + kDinRecZ1 + 16 * mt + 4 * kk) =
-                    make_float4(acc1[mt][rt][0][0], acc1[mt][rt][0][1], acc1[mt][rt][0][2], acc1[mt][rt][0][3]);
+                din_rec_store(rec[rt] + kDinRecZ1 + 16 * mt + 4 * kk, acc1[mt][rt][0][0], acc1[mt][rt][0][1], acc1[mt][rt][0][2], acc1[mt][rt][0][3]);
         }
     // ---- layer 2: pre2^T; the reduction walks (mt, g) <-> hidden 16 mt + 4 kk + g --------------------------------------------------
 #pragma unroll
@@ -374,7 +373,7 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
                 zz[g] = dw_sigmoid_pre(acc2[m2][rt][g]);
                 sp = fmaf(zz[g], wv[m2][g], sp);
             }
-            if (rec[rt]) *reinterpret_cast<float4*>(rec[rt] + kDinRecZ2 + 16 * m2 + 4 * kk) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+            if (rec[rt]) din_rec_store(rec[rt] + kDinRecZ2 + 16 * m2 + 4 * kk, zz[0], zz[1], zz[2], zz[3]);
         }
         sp += __shfl_xor(sp, 16, 64);        // the four lane groups hold the four quarters of the H2 sum of row r
         sp += __shfl_xor(sp, 32, 64);
