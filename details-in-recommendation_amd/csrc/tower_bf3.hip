@@ -58,6 +58,14 @@ struct TowerParams {
     const float* add1;
     float* out;
     int64_t out_ld;
+    // GATHER variant (dir_deepfm_tower_bf16x3_f32): layer 1's input row is the concatenation of F packed serving rows looked up here
+    // (slot f's table [vocab_f, row_ld], the K = 16 embedding floats first, the first-order weight at column lin_col); X / x_ld unused
+    const float* const* tables;
+    const int64_t* vocab;
+    const int64_t* ids;
+    int64_t ids_sb, ids_sf, row_ld;
+    int F, lin_col;
+    const float* lin_bias;
 };
 
 __device__ __forceinline__ unsigned int tw_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
@@ -106,6 +114,12 @@ __global__ __launch_bounds__(256) void tower_bf3_pack_k(const float* __restrict_
     }
 }
 
+// GATHER: DeepFM inference in one launch.  The lane that would load X[row][16 ct + 4 g .. + 3] loads the same four floats from slot ct's
+// table row of sample `row` instead (an id outside [0, vocab) reads as a zero row, as in gather_packed_rows_k), and the lookups' two other
+// consumers ride along in the order the gather kernel uses, so the logit is bit for bit the two-launch path's: the FM second-order term
+// 0.5 sum_k ((sum_f e)^2 - sum_f e^2) (field sums f-ascending, then k-ascending across the row's four lanes) and the first-order term
+// sum_f w_f + bias (f-ascending), both added to the head's logit in the epilogue.  The 109 MB concat is never written or read.
+template <bool GATHER>
 __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];      // [2][TW_BUFB]: the W image of one stage
     const int tid = threadIdx.x;
@@ -138,7 +152,41 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
     stage(0, 0, 0, 0);
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t r = t * TW_ROWS + wave * 16 + r16;
-        {   // X -> act, accumulator layout: register e of tile ct = X[row][16*ct + 4*g + e] (Kd % 4 == 0: a piece is in or out)
+        float fm_r = 0.f, lin_r = 0.f;                 // GATHER: the row's FM and first-order terms, both valid in lane group g == 0
+        if constexpr (GATHER) {
+            const int64_t rr = r < p.M ? r : p.M - 1;
+            const int64_t* idp = p.ids + rr * p.ids_sb;
+            tw_f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = sum;
+            float lin = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < TW_NT; ++ct) {
+                tw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                float lw = 0.f;
+                if (ct < p.F) {
+                    const int64_t id = idp[(int64_t)ct * p.ids_sf];
+                    const uint64_t bound = p.vocab ? (uint64_t)p.vocab[ct] : (uint64_t)1 << 63;
+                    if ((uint64_t)id < bound) {
+                        const float* t = p.tables[ct] + id * p.row_ld;
+                        v = *reinterpret_cast<const tw_f32x4*>(t + 4 * g);
+                        if (g == 0 && p.lin_col >= 0) lw = t[p.lin_col];
+                    }
+                }
+                act[ct] = v;
+                sum += v;                              // f-ascending fp32 sums, as gather_packed_rows_k
+                sq += v * v;
+                lin = lin + lw;
+            }
+            // 0.5 * sum_k (sum^2 - sq), k ascending through the row's four lanes (g = 0..3 hold k = 4 g .. 4 g + 3): fm_tail<4>'s chain
+            const tw_f32x4 d = sum * sum - sq;
+            float acc_fm = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const float carry = __shfl(acc_fm, r16 + 16 * (cc > 0 ? cc - 1 : 0), 64);
+                if (g == cc) acc_fm = ((((cc == 0 ? 0.f : carry) + d[0]) + d[1]) + d[2]) + d[3];
+            }
+            fm_r = __shfl(0.5f * acc_fm, r16 + 48, 64);
+            lin_r = lin + (p.lin_bias ? p.lin_bias[0] : 0.f);
+        } else {   // X -> act, accumulator layout: register e of tile ct = X[row][16*ct + 4*g + e] (Kd % 4 == 0: a piece is in or out)
             const float* xr = p.X + (r < p.M ? r : p.M - 1) * p.x_ld + 4 * g;
 #pragma unroll
             for (int ct = 0; ct < TW_NT; ++ct)
@@ -268,6 +316,10 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
                 part += __shfl_xor(part, 32, 64);
                 if (g == 0 && r < p.M) {
                     float o = part + p.head_b[0];
+                    if constexpr (GATHER) {
+                        o += fm_r;                                // the order of ops.tower(..., adds=(fm, lin))
+                        if (p.lin_col >= 0) o += lin_r;
+                    }
                     if (p.add0) o += p.add0[r];
                     if (p.add1) o += p.add1[r];
                     p.out[r * p.out_ld] = o;
@@ -300,17 +352,15 @@ extern "C" int dir_tower_bf16x3_pack_f32(const float* W, int64_t w_ld, int K, in
     return DIR_OK;
 }
 
-extern "C" int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
-                                    const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
-                                    const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
-                                    dir_stream_t stream) {
-    const char* name = "dir_tower_bf16x3_f32";
-    DIR_CHECK_ARG(M >= 0 && Kd > 0 && L >= 1 && L <= TW_MAXL && N && images && act, "%s: bad shape (M=%lld Kd=%d L=%d)", name, (long long)M, Kd, L);
-    if (Kd > 16 * TW_NT || (Kd & 3) || (x_ld & 3) || x_ld < Kd) return fail(DIR_E_UNSUPPORTED, "%s: Kd=%d (a multiple of 4, <= %d), x_ld=%lld", name, Kd, 16 * TW_NT, (long long)x_ld);
+// the layers / head part of the argument checks, shared by the two entries
+static int tower_fill(const char* name, TowerParams& p, int Kd, int L, const int* N, const void* const* images, const float* const* bias,
+                      const float* const* post_scale, const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                      const float* add0, const float* add1, float* out, int64_t out_ld) {
+    DIR_CHECK_ARG(Kd > 0 && L >= 1 && L <= TW_MAXL && N && images && act, "%s: bad shape (Kd=%d L=%d)", name, Kd, L);
+    if (Kd > 16 * TW_NT || (Kd & 3)) return fail(DIR_E_UNSUPPORTED, "%s: Kd=%d (a multiple of 4, <= %d)", name, Kd, 16 * TW_NT);
     DIR_CHECK_ARG((head_w == nullptr) == (head_b == nullptr), "%s: head_w and head_b come together", name);
     DIR_CHECK_ARG(head_w || (!add0 && !add1), "%s: add0 / add1 are addends of the head's logit", name);
-    TowerParams p;
-    p.X = X; p.x_ld = x_ld; p.M = M; p.Kd = Kd; p.L = L;
+    p.Kd = Kd; p.L = L;
     for (int l = 0; l < TW_MAXL; ++l) {
         p.N[l] = 0; p.img[l] = nullptr; p.bias[l] = p.scale[l] = p.shift[l] = nullptr; p.relu[l] = 0;
     }
@@ -326,22 +376,63 @@ extern "C" int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int
         p.N[l] = N[l]; p.img[l] = static_cast<const unsigned char*>(images[l]); p.bias[l] = b; p.scale[l] = sc; p.shift[l] = sh;
         p.relu[l] = act[l] == DIR_ACT_RELU;
     }
-    if (M == 0) return DIR_OK;
-    DIR_CHECK_ARG(X && out && aligned16(X), "%s: null or unaligned pointer", name);
     if (head_w) {
         if (!aligned16(head_w) || out_ld < 1) return fail(DIR_E_UNSUPPORTED, "%s: head_w must be 16-byte aligned, out_ld >= 1", name);
     } else if ((out_ld & 3) || out_ld < N[L - 1] || !aligned16(out)) {
         return fail(DIR_E_UNSUPPORTED, "%s: out [M, N_last] needs out_ld %% 4 == 0 and a 16-byte aligned base", name);
     }
     p.head_w = head_w; p.head_b = head_b; p.add0 = add0; p.add1 = add1; p.out = out; p.out_ld = out_ld;
+    p.X = nullptr; p.x_ld = 0;
+    p.tables = nullptr; p.vocab = nullptr; p.ids = nullptr; p.ids_sb = p.ids_sf = p.row_ld = 0; p.F = 0; p.lin_col = -1; p.lin_bias = nullptr;
+    return DIR_OK;
+}
+
+template <bool GATHER>
+static int tower_launch(const char* name, const TowerParams& p, dir_stream_t stream) {
     static bool set = false;
     if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_bf3_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_bf3_k<GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         set = true;
     }
-    const int64_t ntiles = (M + TW_ROWS - 1) / TW_ROWS;
+    const int64_t ntiles = (p.M + TW_ROWS - 1) / TW_ROWS;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;            // one persistent workgroup per CU (8 waves x 256 registers, 78 KB of LDS)
-    hipLaunchKernelGGL(tower_bf3_k, dim3((unsigned)nwg), dim3(512), 2 * TW_BUFB, as_stream(stream), p);
+    hipLaunchKernelGGL(tower_bf3_k<GATHER>, dim3((unsigned)nwg), dim3(512), 2 * TW_BUFB, as_stream(stream), p);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
+                                    const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
+                                    const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
+                                    dir_stream_t stream) {
+    const char* name = "dir_tower_bf16x3_f32";
+    DIR_CHECK_ARG(M >= 0, "%s: M=%lld", name, (long long)M);
+    if ((x_ld & 3) || x_ld < Kd) return fail(DIR_E_UNSUPPORTED, "%s: x_ld=%lld (a multiple of 4, >= Kd)", name, (long long)x_ld);
+    TowerParams p;
+    const int rc = tower_fill(name, p, Kd, L, N, images, bias, post_scale, post_shift, act, head_w, head_b, add0, add1, out, out_ld);
+    if (rc != DIR_OK) return rc;
+    if (M == 0) return DIR_OK;
+    DIR_CHECK_ARG(X && out && aligned16(X), "%s: null or unaligned pointer", name);
+    p.X = X; p.x_ld = x_ld; p.M = M;
+    return tower_launch<false>(name, p, stream);
+}
+
+extern "C" int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                                           const int64_t* ids, int64_t stride_b, int64_t stride_f, int64_t M, const float* lin_bias, int L,
+                                           const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
+                                           const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                                           const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream) {
+    const char* name = "dir_deepfm_tower_bf16x3_f32";
+    DIR_CHECK_ARG(M >= 0 && F > 0, "%s: M=%lld F=%d", name, (long long)M, F);
+    if (K != 16 || F > TW_NT) return fail(DIR_E_UNSUPPORTED, "%s: K=%d F=%d (K = 16, F <= %d: one column tile per slot)", name, K, F, TW_NT);
+    if (ld < K + (lin_col >= 0 ? 1 : 0) || (ld & 3) || lin_col >= ld) return fail(DIR_E_UNSUPPORTED, "%s: ld=%lld lin_col=%d", name, (long long)ld, lin_col);
+    DIR_CHECK_ARG(head_w, "%s: the FM and first-order terms are addends of the head's logit: head_w / head_b are required", name);
+    TowerParams p;
+    const int rc = tower_fill(name, p, F * K, L, N, images, bias, post_scale, post_shift, act, head_w, head_b, add0, add1, out, out_ld);
+    if (rc != DIR_OK) return rc;
+    if (M == 0) return DIR_OK;
+    DIR_CHECK_ARG(tables && ids && out, "%s: null pointer", name);
+    p.M = M; p.tables = tables; p.vocab = vocab; p.ids = ids; p.ids_sb = stride_b; p.ids_sf = stride_f; p.row_ld = ld; p.F = F; p.lin_col = lin_col;
+    p.lin_bias = lin_bias;
+    return tower_launch<true>(name, p, stream);
 }

@@ -269,8 +269,7 @@ class DeepFM(nn.Module):
             if pk is not None:
                 # inference, the DeepFM case (the linear columns ARE the dnn columns' categoricals, deepFM.py:89-95): concat, FM term and
                 # first-order term from ONE packed 128-byte row per (sample, field), then the tower with both logits added in its epilogue
-                emb, fm, lin = ops.gather_fm_linear(pk, got[1], bias=self.linear_bias.data)
-                logits = self.dnn_logit_fn(emb, adds=(fm, lin))
+                logits = self._packed_logits(got[1], pk)
                 raise_pending()
                 return logits
             logits = self.dnn_fm_logit_fn(features, device, got)
@@ -369,6 +368,18 @@ class DeepFM(nn.Module):
         self._packed_sig = self._pack_signature()
         return self._packed
 
+    def _packed_logits(self, ids, pk):
+        """Inference from the packed serving rows `pk`: DNN + FM + first-order logits of the columns the packed layout holds -- in one launch
+        (the lookups inside the tower kernel, dir_deepfm_tower_bf16x3_f32) where that kernel covers the model, else the packed gather
+        followed by dnn_logit_fn; the two are bit-identical."""
+        if self.units == 1 and not _train_mode(self):
+            logits = tower_infer(self.hidden, None, self.activation, bns=self.bns if len(self.bns) else None, head=self.logits_layer,
+                                 gather=(pk, ids, self.linear_bias.data))
+            if logits is not None:
+                return logits
+        emb, fm, lin = ops.gather_fm_linear(pk, ids, bias=self.linear_bias.data)
+        return self.dnn_logit_fn(emb, adds=(fm, lin))
+
     def forward_ids(self, dnn_ids, linear_ids=None):
         """Fast path for pre-assembled one-hot id matrices [B, F] (any strides).  linear_ids: the ids of ALL linear
         columns [B, F_lin] (its first F columns equal dnn_ids in the DeepFM case)."""
@@ -376,8 +387,7 @@ class DeepFM(nn.Module):
             self._serving_pack()                                                 # the default inference layout (built / refreshed here)
         if (getattr(self, "_packed", None) is not None and linear_ids is not None and not torch.is_grad_enabled()
                 and getattr(self, "_packed_sig", None) == self._pack_signature()):
-            emb, fm, lin = ops.gather_fm_linear(self._packed, dnn_ids, bias=self.linear_bias.data)
-            logits = self.dnn_logit_fn(emb, adds=(fm, lin))
+            logits = self._packed_logits(dnn_ids, self._packed)
             if self._packed_extra is not None:
                 logits = logits + ops.linear_logit(self._packed_extra, linear_ids[:, self.F:])
             return logits

@@ -329,21 +329,27 @@ def _dense_act(lin, x, activation, bn):
     return _apply_bn(bn, activation(y) if activation is not None else y)
 
 
-def tower_infer(lins, x, activation, bns=None, head=None, adds=()):
+def tower_infer(lins, x, activation, bns=None, head=None, adds=(), gather=None):
     """Inference of a whole tower -- activation(lin_l(...)) for every nn.Linear in `lins`, each followed by its batch-norm (bns[l], folded
     to an affine), and the units = 1 logit layer `head` on top when given -- in ONE launch of dir_tower_bf16x3_f32 (csrc/tower_bf3.hip:
     the activations of a 128-row tile stay in registers from layer to layer).  -> the logits [B, 1] (+ the [B, 1] tensors in adds, at
     most two: the other terms of add_n, deepFM.py:217-223) or, without a head, the last activation; None when the tower is not covered
     (autograd recording, fewer than ops.TOWER_MIN_ROWS rows, a width over 416, under ops.TOWER_MIN_WIDTH or not a multiple of 4, an activation other than ReLU /
-    none, a head with more than one unit): the caller then runs it layer by layer."""
-    if torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in lins)):
+    none, a head with more than one unit): the caller then runs it layer by layer.
+    gather = (ops.PackedTables, ids [B, F], linear bias) with x = None: the input rows are looked up inside the same launch and the FM
+    and first-order terms join the logit (dir_deepfm_tower_bf16x3_f32; needs a head)."""
+    if gather is not None:
+        if (x is not None or head is None or torch.is_grad_enabled() or gather[1].shape[0] < ops.TOWER_MIN_ROWS
+                or not ops.tower_gather_covers(gather[0], [l.weight for l in lins])):
+            return None
+    elif torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in lins)):
         return None
-    if not len(lins) or x.dim() != 2 or x.shape[0] < ops.TOWER_MIN_ROWS or not (activation is None or activation in _RELUS):
+    if not len(lins) or (gather is None and (x.dim() != 2 or x.shape[0] < ops.TOWER_MIN_ROWS)) or not (activation is None or activation in _RELUS):
         return None
     if bns is not None and len(bns) and any(b.training and torch.is_grad_enabled() for b in bns):
         return None
     ws = [l.weight for l in lins]
-    if not ops.tower_covers(x, ws) or min(int(w.shape[0]) for w in ws) < ops.TOWER_MIN_WIDTH:
+    if (gather is None and not ops.tower_covers(x, ws)) or min(int(w.shape[0]) for w in ws) < ops.TOWER_MIN_WIDTH:
         return None
     if head is not None and (head.out_features != 1 or head.bias is None or head.in_features != lins[-1].out_features):
         return None
@@ -353,4 +359,4 @@ def tower_infer(lins, x, activation, bns=None, head=None, adds=()):
         aff += [(None, None)] * (len(lins) - len(aff))
         ps, psh = [a[0] for a in aff], [a[1] for a in aff]
     return ops.tower(x, ws, [l.bias for l in lins], relu=activation is not None, post_scale=ps, post_shift=psh,
-                     head=(head.weight, head.bias) if head is not None else None, adds=adds if head is not None else ())
+                     head=(head.weight, head.bias) if head is not None else None, adds=adds if head is not None else (), gather=gather)

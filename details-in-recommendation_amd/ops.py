@@ -546,6 +546,7 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
 
 TOWER_MAX_WIDTH = 416
 TOWER_MIN_ROWS = 4096          # below this the 128-row tiles leave most of the chip idle: the per-layer kernels run
+TOWER_GATHER = os.environ.get("DIR_TOWER_GATHER", "1")      # 0: DeepFM inference as two launches (packed gather, then the tower)
 TOWER_MIN_WIDTH = 128          # dense.tower_infer: a stage always computes 13 column tiles, so a narrower layer (ESMM's 80-wide one) pads more
                                # than the fusion saves (ESMM forward 0.574 ms layer by layer, 0.580 fused)
 TOWER = os.environ.get("DIR_TOWER", "auto")      # "0": never fuse (per-layer kernels)
@@ -561,6 +562,21 @@ def tower_covers(x, weights, head=None):
         return False
     return x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and (DENSE_ARITH in ("auto", "bf16x3"))
 
+
+def tower_gather_covers(pt, weights):
+    """Serving tables and layers dir_deepfm_tower_bf16x3_f32 accepts: K = 16 (one 16-column tile per slot), F <= 26, 1..4 layers of
+    widths <= 416 that are multiples of 4, the first one reading the F*K-wide concatenation."""
+    ws = list(weights)
+    if TOWER == "0" or TOWER_GATHER == "0" or DENSE_ARITH not in ("auto", "bf16x3"):
+        return False
+    if pt is None or pt.K != 16 or pt.F > 26 or not (1 <= len(ws) <= 4):
+        return False
+    k = pt.F * pt.K
+    for w in ws:
+        if w.dim() != 2 or w.shape[1] != k or w.shape[0] % 4 or w.shape[0] > TOWER_MAX_WIDTH or w.dtype != torch.float32 or not w.is_cuda:
+            return False
+        k = int(w.shape[0])
+    return True
 
 def tower_image(weight):
     """The packed bf16x3 image of one layer's [N, K] weight in the tower kernel's k order, cached per tensor until it is modified in
@@ -583,16 +599,27 @@ def tower_image(weight):
     return img
 
 
-def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, head=None, adds=(), out=None):
+def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, head=None, adds=(), out=None, gather=None):
     """A DNN tower in one launch (include/dir_hip.h: dir_tower_bf16x3_f32; dnn_logit_fn, deepFM.py:284-319).  x [M, Kd]; weights: 1..4
     nn.Linear weights [N_l, K_l]; biases: list of [N_l] or None; relu: bool or per-layer list; post_scale / post_shift: per-layer lists
     of [N_l] vectors or None entries (the folded inference batch-norm).  head = (w [N_last] or [1, N_last], b [1]): -> logits [M, 1]
-    (+ the [M] / [M, 1] tensors in adds, at most two); without a head -> the last activation [M, N_last]."""
-    _dev(x, torch.float32, "x")
+    (+ the [M] / [M, 1] tensors in adds, at most two); without a head -> the last activation [M, N_last].
+    gather = (PackedTables, ids [M, F], linear bias [1] or None) with x = None: DeepFM inference in one launch
+    (dir_deepfm_tower_bf16x3_f32) -- the input rows are looked up inside the kernel and the FM and first-order terms join the logit,
+    bit for bit the result of gather_fm_linear + tower(..., adds=(fm, lin))."""
     L = len(weights)
-    if not tower_covers(x, weights):
-        raise ValueError("tower: 1..4 layers, input and layer widths multiples of 4 and <= %d, x 16-byte aligned with a row stride multiple of 4" % TOWER_MAX_WIDTH)
-    M, Kd = x.shape
+    if gather is not None:
+        pt, ids, lin_bias = gather
+        _dev(ids, torch.int64, "ids")
+        if x is not None or head is None or not tower_gather_covers(pt, weights):
+            raise ValueError("tower(gather=...): x = None, a head, K = 16, F <= 26 and widths the tower covers")
+        M, sb, sf = _onehot_strides(ids, pt.F)
+        Kd = pt.F * pt.K
+    else:
+        _dev(x, torch.float32, "x")
+        if not tower_covers(x, weights):
+            raise ValueError("tower: 1..4 layers, input and layer widths multiples of 4 and <= %d, x 16-byte aligned with a row stride multiple of 4" % TOWER_MAX_WIDTH)
+        M, Kd = x.shape
     lib = _lib.load()
     relu_l = list(relu) if isinstance(relu, (list, tuple)) else [bool(relu)] * L
     keep = []
@@ -626,7 +653,13 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
                 raise ValueError("tower: an addend has one value per row")
             add.append(a)
         if out is None:
-            out = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+            out = torch.empty((M, 1), dtype=torch.float32, device=hw.device)
+        if gather is not None:
+            lb = _dev(lin_bias, torch.float32, "linear bias").reshape(-1) if lin_bias is not None else None
+            _lib.check(lib.dir_deepfm_tower_bf16x3_f32(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, pt.lin_col, _ptr(ids), sb, sf, M, _ptr(lb),
+                                                       L, Ns, imgs, b_arr, s_arr, h_arr, acts, _ptr(hw), _ptr(hb), _ptr(add[0]) if add else None,
+                                                       _ptr(add[1]) if len(add) > 1 else None, _ptr(out), out.stride(0), _stream()))
+            return out
         _lib.check(lib.dir_tower_bf16x3_f32(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, _ptr(hw), _ptr(hb),
                                             _ptr(add[0]) if add else None, _ptr(add[1]) if len(add) > 1 else None, _ptr(out), out.stride(0), _stream()))
         return out

@@ -389,6 +389,20 @@ int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L,
                          const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
                          const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
                          dir_stream_t stream);
+
+/* DeepFM inference in ONE launch (deepFM.py:107-117,217-223,284-338 on the serving layout of dir_gather_fm_linear_packed_f32): the tower
+ * above with layer 1's input rows looked up inside the kernel -- row b = the concatenation of slot f's K = 16 embedding floats of
+ * tables[f][ids[b, f]] (an id outside [0, vocab[f]) reads as a zero row) -- and the FM second-order term and the first-order term
+ * (sum_f tables[f][id][lin_col] + lin_bias[0], skipped when lin_col < 0) added to the head's logit:
+ *   out[b] = head(tower(concat_b)) + fm_b + lin_b (+ add0[b] + add1[b]).
+ * Every sum runs in the order of dir_gather_fm_linear_packed_f32 + dir_tower_bf16x3_f32(add0 = fm, add1 = lin): the result is that
+ * two-launch path's bit for bit, without the [M, F*K] concat ever reaching memory.  F <= 26, K = 16, head required;
+ * tables / vocab / ids / strides as dir_gather_fm_linear_packed_f32, the other arguments as dir_tower_bf16x3_f32. */
+int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                                const int64_t* ids, int64_t stride_b, int64_t stride_f, int64_t M, const float* lin_bias, int L,
+                                const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
+                                const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                                const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream);
 /* dir_dense_gated_f32: Y = (gate > 0) ? X . Wt^T : 0 -- the data gradient of a dense layer taken straight through the previous
  * layer's ReLU: X = dL/d(pre-activation of layer l) [M, Kd = units of l], Wt = the TRANSPOSE of layer l's nn.Linear weight
  * ([in_l, units_l] rows), gate = layer l-1's output [M, N = in_l]; the result is dL/d(pre-activation of layer l-1). */

@@ -158,3 +158,56 @@ def test_deepfm_inference_takes_the_fused_tower_and_packed_rows(built_lib, oracl
         model.embedding_weights[3].add_(0.01)
         after = model(feats)
     assert not torch.equal(after, fused)
+
+
+@pytest.mark.parametrize("B,F,hidden,bn", [(8192, 26, [400, 400, 400], False), (4101, 13, [256, 128], False), (5000, 26, [400, 400], True)])
+def test_deepfm_one_launch_inference_is_bitwise_the_two_launch_path(built_lib, B, F, hidden, bn):
+    """dir_deepfm_tower_bf16x3_f32 (the lookups, the FM term and the first-order term inside the tower kernel) against the packed gather
+    followed by the tower with both logits as addends, through ops and through the module: bit for bit.  Ids outside the vocabulary on
+    both sides (pruned: zero rows), a strided [F, B]-major id matrix, a partial last tile."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc, ops
+    torch.manual_seed(5 + F)
+    K, V = 16, 3000
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats], dnn_hidden_units=hidden,
+                   fm_embedding_size=K, batch_norm=bn).cuda().eval()
+    with torch.no_grad():
+        for p in model.linear_weights:
+            p.normal_(0, 0.05)
+        model.linear_bias.fill_(0.125)
+    ids = torch.randint(0, V, (B, F), device="cuda")
+    ids[torch.rand((B, F), device="cuda") < 0.02] = -1
+    ids[torch.rand((B, F), device="cuda") < 0.02] = V + 7
+    ids_fb = ids.t().contiguous().t()                                             # same values, strides (1, B)
+    assert ids_fb.stride() == (1, B)
+    with torch.no_grad():
+        model.forward_ids(ids, ids)                                               # builds the packed serving rows
+        pt = model._packed
+        ws, bs = [l.weight for l in model.hidden], [l.bias for l in model.hidden]
+        assert ops.tower_gather_covers(pt, ws)
+        head = (model.logits_layer.weight, model.logits_layer.bias)
+        emb, fm, lin = ops.gather_fm_linear(pt, ids, bias=model.linear_bias.data)
+        if not bn:
+            two = ops.tower(emb, ws, bs, head=head, adds=(fm, lin))
+            one = ops.tower(None, ws, bs, head=head, gather=(pt, ids, model.linear_bias.data))
+            assert torch.equal(one, two)
+            assert torch.equal(ops.tower(None, ws, bs, head=head, gather=(pt, ids_fb, model.linear_bias.data)), two)
+        # through the module: the default path is the one-launch kernel; DIR_TOWER_GATHER=0's path is the two-launch one
+        fused = model.forward_ids(ids, ids)
+        old = ops.TOWER_GATHER
+        ops.TOWER_GATHER = "0"
+        try:
+            plain = model.forward_ids(ids, ids)
+        finally:
+            ops.TOWER_GATHER = old
+        assert torch.equal(fused, plain)
+        ok = ids.clamp(0, V - 1)                                                  # (the features-dict path validates ids, as the reference's columns do)
+        feats = {"C%d" % i: ok[:, i].contiguous() for i in range(F)}
+        assert torch.equal(model(feats), model.forward_ids(ok, ok))
+        # reruns are bitwise equal
+        assert torch.equal(model.forward_ids(ids, ids), fused)
+    # the C entry refuses what the kernel does not cover
+    from dir_amd._lib import DirError
+    with pytest.raises(ValueError):
+        ops.tower(None, ws, bs, gather=(pt, ids, None))                           # no head: the FM term has nothing to join
