@@ -64,7 +64,7 @@ struct TowerParams {
     const int64_t* vocab;
     const int64_t* ids;
     int64_t ids_sb, ids_sf, row_ld;
-    int F, lin_col;
+    int F, lin_col, want_fm;
     const float* lin_bias;
 };
 
@@ -177,14 +177,16 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
                 lin = lin + lw;
             }
             // 0.5 * sum_k (sum^2 - sq), k ascending through the row's four lanes (g = 0..3 hold k = 4 g .. 4 g + 3): fm_tail<4>'s chain
-            const tw_f32x4 d = sum * sum - sq;
-            float acc_fm = 0.f;
+            if (p.want_fm) {                                       // (kernel-uniform)
+                const tw_f32x4 d = sum * sum - sq;
+                float acc_fm = 0.f;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const float carry = __shfl(acc_fm, r16 + 16 * (cc > 0 ? cc - 1 : 0), 64);
-                if (g == cc) acc_fm = ((((cc == 0 ? 0.f : carry) + d[0]) + d[1]) + d[2]) + d[3];
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float carry = __shfl(acc_fm, r16 + 16 * (cc > 0 ? cc - 1 : 0), 64);
+                    if (g == cc) acc_fm = ((((cc == 0 ? 0.f : carry) + d[0]) + d[1]) + d[2]) + d[3];
+                }
+                fm_r = __shfl(0.5f * acc_fm, r16 + 48, 64);
             }
-            fm_r = __shfl(0.5f * acc_fm, r16 + 48, 64);
             lin_r = lin + (p.lin_bias ? p.lin_bias[0] : 0.f);
         } else {   // X -> act, accumulator layout: register e of tile ct = X[row][16*ct + 4*g + e] (Kd % 4 == 0: a piece is in or out)
             const float* xr = p.X + (r < p.M ? r : p.M - 1) * p.x_ld + 4 * g;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
                 if (g == 0 && r < p.M) {
                     float o = part + p.head_b[0];
                     if constexpr (GATHER) {
-                        o += fm_r;                                // the order of ops.tower(..., adds=(fm, lin))
+                        if (p.want_fm) o += fm_r;                 // the order of ops.tower(..., adds=(fm, lin))
                         if (p.lin_col >= 0) o += lin_r;
                     }
                     if (p.add0) o += p.add0[r];
@@ -383,7 +385,7 @@ static int tower_fill(const char* name, TowerParams& p, int Kd, int L, const int
     }
     p.head_w = head_w; p.head_b = head_b; p.add0 = add0; p.add1 = add1; p.out = out; p.out_ld = out_ld;
     p.X = nullptr; p.x_ld = 0;
-    p.tables = nullptr; p.vocab = nullptr; p.ids = nullptr; p.ids_sb = p.ids_sf = p.row_ld = 0; p.F = 0; p.lin_col = -1; p.lin_bias = nullptr;
+    p.tables = nullptr; p.vocab = nullptr; p.ids = nullptr; p.ids_sb = p.ids_sf = p.row_ld = 0; p.F = 0; p.lin_col = -1; p.want_fm = 0; p.lin_bias = nullptr;
     return DIR_OK;
 }
 
@@ -418,21 +420,22 @@ extern "C" int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int
 }
 
 extern "C" int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
-                                           const int64_t* ids, int64_t stride_b, int64_t stride_f, int64_t M, const float* lin_bias, int L,
+                                           const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
                                            const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
                                            const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
                                            const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream) {
     const char* name = "dir_deepfm_tower_bf16x3_f32";
     DIR_CHECK_ARG(M >= 0 && F > 0, "%s: M=%lld F=%d", name, (long long)M, F);
     if (K != 16 || F > TW_NT) return fail(DIR_E_UNSUPPORTED, "%s: K=%d F=%d (K = 16, F <= %d: one column tile per slot)", name, K, F, TW_NT);
+    DIR_CHECK_ARG(want_fm == 0 || want_fm == 1, "%s: want_fm=%d", name, want_fm);
     if (ld < K + (lin_col >= 0 ? 1 : 0) || (ld & 3) || lin_col >= ld) return fail(DIR_E_UNSUPPORTED, "%s: ld=%lld lin_col=%d", name, (long long)ld, lin_col);
-    DIR_CHECK_ARG(head_w, "%s: the FM and first-order terms are addends of the head's logit: head_w / head_b are required", name);
+    DIR_CHECK_ARG(head_w || (!want_fm && lin_col < 0), "%s: the FM and first-order terms are addends of the head's logit: head_w / head_b are required", name);
     TowerParams p;
     const int rc = tower_fill(name, p, F * K, L, N, images, bias, post_scale, post_shift, act, head_w, head_b, add0, add1, out, out_ld);
     if (rc != DIR_OK) return rc;
     if (M == 0) return DIR_OK;
     DIR_CHECK_ARG(tables && ids && out, "%s: null pointer", name);
     p.M = M; p.tables = tables; p.vocab = vocab; p.ids = ids; p.ids_sb = stride_b; p.ids_sf = stride_f; p.row_ld = ld; p.F = F; p.lin_col = lin_col;
-    p.lin_bias = lin_bias;
+    p.want_fm = want_fm; p.lin_bias = lin_bias;
     return tower_launch<true>(name, p, stream);
 }

@@ -339,7 +339,7 @@ def tower_infer(lins, x, activation, bns=None, head=None, adds=(), gather=None):
     gather = (ops.PackedTables, ids [B, F], linear bias) with x = None: the input rows are looked up inside the same launch and the FM
     and first-order terms join the logit (dir_deepfm_tower_bf16x3_f32; needs a head)."""
     if gather is not None:
-        if (x is not None or head is None or torch.is_grad_enabled() or gather[1].shape[0] < ops.TOWER_MIN_ROWS
+        if (x is not None or (head is None and (len(gather) < 4 or gather[3])) or torch.is_grad_enabled() or gather[1].shape[0] < ops.TOWER_MIN_ROWS
                 or not ops.tower_gather_covers(gather[0], [l.weight for l in lins])):
             return None
     elif torch.is_grad_enabled() and (x.requires_grad or any(l.weight.requires_grad for l in lins)):
@@ -349,8 +349,8 @@ def tower_infer(lins, x, activation, bns=None, head=None, adds=(), gather=None):
     if bns is not None and len(bns) and any(b.training and torch.is_grad_enabled() for b in bns):
         return None
     ws = [l.weight for l in lins]
-    if (gather is None and not ops.tower_covers(x, ws)) or min(int(w.shape[0]) for w in ws) < ops.TOWER_MIN_WIDTH:
-        return None
+    if (gather is None and not ops.tower_covers(x, ws)) or min(int(w.shape[0]) for w in ws) < (ops.TOWER_MIN_WIDTH if gather is None else 16):
+        return None                                   # (with the lookups inside, the launch it saves outweighs the idle column tiles of a narrow layer)
     if head is not None and (head.out_features != 1 or head.bias is None or head.in_features != lins[-1].out_features):
         return None
     ps = psh = None

@@ -38,6 +38,11 @@ class _BaseModel(nn.Module):
         nn.init.zeros_(self.logits.bias)
 
     def forward(self, features, memo=None):
+        src = self.input_layer.onehot_source(features, memo) if not self.dropout or not self.training else None
+        if src is not None:                           # inference: the lookups, the tower and the logit layer in ONE launch
+            fused = tower_infer(self.hidden, None, self.activation, head=self.logits, gather=(src[0], src[1], None, False))
+            if fused is not None:
+                return fused
         net = self.input_layer(features, memo=memo)
         fused = tower_infer(self.hidden, net, self.activation, head=self.logits)          # inference: tower + logit layer in one launch
         if fused is not None:

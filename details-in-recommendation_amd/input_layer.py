@@ -130,6 +130,19 @@ class InputLayer(nn.Module):
                 pieces.append(blocks[c.name])
         return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=1)
 
+    def onehot_source(self, features, memo=None):
+        """-> (TableSet, ids [B, F]) when this layer's output is exactly the concatenation of one-hot embedding lookups that ONE launch
+        reads (every column an embedding column of one width, no max_norm, adjacent in the sorted concat) and the features carry one id
+        per sample and column; else None.  What dense.tower_infer(..., gather=...) needs to do the lookups inside the tower kernel."""
+        if torch.is_grad_enabled() or len(self.emb_cols) != len(self.columns) or not len(self.embedding_weights):
+            return None
+        groups = self._tablesets()
+        if len(groups) != 1 or groups[0][3] or len(groups[0][1]) != len(self.emb_cols) or self._col_offset(self.emb_cols[groups[0][1][0]]) != 0:
+            return None
+        ts, idxs, _, _ = groups[0]
+        got = collect_ids([self.emb_cols[i] for i in idxs], features, self.embedding_weights[0].device, memo)
+        return (ts, got[1]) if got[0] == "onehot" else None
+
     def forward(self, features, pad_to=1, memo=None):
         """-> x0 [B, column_num].  pad_to = 4 (inference only): x0 is returned as [B, round_up(column_num, 4)] whose extra
         columns are zero -- the row stride the 16-byte paths of dir_dcn_cross_f32 / dir_dense_f32 want when column_num is odd

@@ -609,10 +609,12 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
     bit for bit the result of gather_fm_linear + tower(..., adds=(fm, lin))."""
     L = len(weights)
     if gather is not None:
-        pt, ids, lin_bias = gather
+        pt, ids, lin_bias = gather[:3]
+        want_fm = bool(gather[3]) if len(gather) > 3 else True
+        lin_col = getattr(pt, "lin_col", -1)
         _dev(ids, torch.int64, "ids")
-        if x is not None or head is None or not tower_gather_covers(pt, weights):
-            raise ValueError("tower(gather=...): x = None, a head, K = 16, F <= 26 and widths the tower covers")
+        if x is not None or (head is None and (want_fm or lin_col >= 0)) or not tower_gather_covers(pt, weights):
+            raise ValueError("tower(gather=...): x = None, a head for the FM / first-order terms, K = 16, F <= 26 and widths the tower covers")
         M, sb, sf = _onehot_strides(ids, pt.F)
         Kd = pt.F * pt.K
     else:
@@ -656,7 +658,7 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
             out = torch.empty((M, 1), dtype=torch.float32, device=hw.device)
         if gather is not None:
             lb = _dev(lin_bias, torch.float32, "linear bias").reshape(-1) if lin_bias is not None else None
-            _lib.check(lib.dir_deepfm_tower_bf16x3_f32(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, pt.lin_col, _ptr(ids), sb, sf, M, _ptr(lb),
+            _lib.check(lib.dir_deepfm_tower_bf16x3_f32(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, lin_col, _ptr(ids), sb, sf, int(want_fm), M, _ptr(lb),
                                                        L, Ns, imgs, b_arr, s_arr, h_arr, acts, _ptr(hw), _ptr(hb), _ptr(add[0]) if add else None,
                                                        _ptr(add[1]) if len(add) > 1 else None, _ptr(out), out.stride(0), _stream()))
             return out
@@ -665,6 +667,12 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
         return out
     if adds:
         raise ValueError("tower: addends need a head")
+    if gather is not None:
+        if out is None:
+            out = torch.empty((M, Ns[L - 1]), dtype=torch.float32, device=ids.device)
+        _lib.check(lib.dir_deepfm_tower_bf16x3_f32(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, lin_col, _ptr(ids), sb, sf, 0, M, None, L, Ns,
+                                                   imgs, b_arr, s_arr, h_arr, acts, None, None, None, None, _ptr(out), out.stride(0), _stream()))
+        return out
     if out is None:
         out = torch.empty((M, Ns[L - 1]), dtype=torch.float32, device=x.device)
     _lib.check(lib.dir_tower_bf16x3_f32(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, None, None, None, None, _ptr(out),

@@ -396,10 +396,11 @@ int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L,
  * (sum_f tables[f][id][lin_col] + lin_bias[0], skipped when lin_col < 0) added to the head's logit:
  *   out[b] = head(tower(concat_b)) + fm_b + lin_b (+ add0[b] + add1[b]).
  * Every sum runs in the order of dir_gather_fm_linear_packed_f32 + dir_tower_bf16x3_f32(add0 = fm, add1 = lin): the result is that
- * two-launch path's bit for bit, without the [M, F*K] concat ever reaching memory.  F <= 26, K = 16, head required;
+ * two-launch path's bit for bit, without the [M, F*K] concat ever reaching memory.  want_fm = 0 leaves the FM term out (with lin_col < 0:
+ * a plain tower over looked-up rows -- ESMM's towers on [vocab, 16] tables, ld = 16; the head is then optional).  F <= 26, K = 16;
  * tables / vocab / ids / strides as dir_gather_fm_linear_packed_f32, the other arguments as dir_tower_bf16x3_f32. */
 int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
-                                const int64_t* ids, int64_t stride_b, int64_t stride_f, int64_t M, const float* lin_bias, int L,
+                                const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
                                 const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
                                 const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
                                 const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream);

@@ -211,3 +211,35 @@ def test_deepfm_one_launch_inference_is_bitwise_the_two_launch_path(built_lib, B
     from dir_amd._lib import DirError
     with pytest.raises(ValueError):
         ops.tower(None, ws, bs, gather=(pt, ids, None))                           # no head: the FM term has nothing to join
+
+
+def test_esmm_inference_towers_do_their_own_lookups(built_lib):
+    """ESMM (ESMM.py:62-78,130-147) under no_grad at a batch the kernel covers: each tower's lookups, hidden layers and logit layer in one
+    launch (dir_deepfm_tower_bf16x3_f32 with want_fm = 0 on the [vocab, 16] tables) against the gather + layer-by-layer path: the same
+    1e-5-class bar as the other bf16x3 / fp32 comparisons, bitwise equal reruns, and the no-head form of the entry against the plain tower."""
+    from dir_amd.esmm import ESMM
+    from dir_amd import feature_column as fc, ops
+    torch.manual_seed(21)
+    B, F, K, V = 6000, 26, 16, 4000
+    cols = [fc.embedding_column(fc.categorical_column_with_identity("C%02d" % i, V), K) for i in range(F)]
+    model = ESMM(columns=cols, dnn_hidden_units=[360, 200, 80]).cuda().eval()
+    ids = torch.randint(0, V, (B, F), device="cuda")
+    feats = {"C%02d" % i: ids[:, i].contiguous() for i in range(F)}
+    with torch.no_grad():
+        src = model.ctr_model.input_layer.onehot_source(feats)
+        assert src is not None and src[0].F == F and torch.equal(src[1], ids)
+        fused = model(feats)
+        old = ops.TOWER_GATHER
+        ops.TOWER_GATHER = "0"
+        try:
+            plain = model(feats)
+        finally:
+            ops.TOWER_GATHER = old
+        for k in ("ctr_logits", "cvr_logits", "ctcvr_logits"):
+            assert _scaled_err(fused[k].cpu().numpy(), plain[k].double().cpu().numpy()) <= 2e-5, k
+            assert torch.equal(model(feats)[k], fused[k])
+        # the entry without a head: the last activation, bit for bit the plain tower on the gathered rows
+        ts = src[0]
+        ws, bs = [l.weight for l in model.ctr_model.hidden], [l.bias for l in model.ctr_model.hidden]
+        emb = ops.embedding_bag(ts, ids)
+        assert torch.equal(ops.tower(None, ws, bs, gather=(ts, ids, None, False)), ops.tower(emb, ws, bs))
