@@ -33,6 +33,7 @@ SIGNATURES = {
                                           c_vp, c_vp]),
     "dir_dcn_cross_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "dir_dcn_cross_op_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "dir_dcn_cross_head_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_fm_second_order_backward_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_gated_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_dw_bf16x3_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),

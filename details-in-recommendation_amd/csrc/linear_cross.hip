@@ -117,10 +117,11 @@ template <int G, int NV, int VEC>
 __global__ __launch_bounds__(256) void cross_k(const float* __restrict__ x0, int64_t x_ld,
                                                const float* __restrict__ xinit /* nullptr: x_0 = x0 */,
                                                const float* __restrict__ w, const float* __restrict__ bvec,
-                                               int L, int64_t B, int d, float* __restrict__ out, int64_t out_ld) {
+                                               int L, int64_t B, int d, float* __restrict__ out, int64_t out_ld,
+                                               const float* __restrict__ head_w /* [d] or nullptr */, float* __restrict__ head_out /* [B] */) {
     using C = CV<VEC>;
     using V = typename C::T;
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][L][d]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][L][d] (+ [d]: the head's weights)
     constexpr int SPW = 64 / G;
     const int nchunk = d / VEC;
     const int Ld = L * d;
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(256) void cross_k(const float* __restrict__ x0, int
             smem[Ld + i] = bvec[i];
         }
     }
+    if (head_w)
+        for (int i = threadIdx.x; i < d; i += blockDim.x) smem[2 * Ld + i] = head_w[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int j = lane & (G - 1);
@@ -172,7 +175,18 @@ __global__ __launch_bounds__(256) void cross_k(const float* __restrict__ x0, int
                 if (ch < nchunk) xl[i] = C::upd(xv[i], xw, C::ld(bl + ch * VEC), xl[i]);
             }
         }
-        if (act) {
+        if (head_w) {     // the cross branch's share of the final dense(1) over concat([cross, deep]) (DeepCrossNetwork.py:136-137): x_L . w_c
+            const float* hw = smem + 2 * Ld;
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int ch = i * G + j;
+                if (ch < nchunk) part = C::dot(xl[i], C::ld(hw + ch * VEC), part);
+            }
+            const float hs = group_sum<G>(part);
+            if (act && j == 0) head_out[r] = hs;
+        }
+        if (act && out) {
             float* op = out + r * out_ld;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -209,11 +223,12 @@ extern "C" int dir_linear_sparse_sum_f32(const float* const* weights, const int6
 
 template <int G, int VEC>
 static int launch_cross_nv(int nv, int64_t work_blocks, size_t shmem, hipStream_t st, const float* x0, int64_t x_ld,
-                           const float* xinit, const float* w, const float* b, int L, int64_t B, int d, float* out, int64_t out_ld) {
+                           const float* xinit, const float* w, const float* b, int L, int64_t B, int d, float* out, int64_t out_ld,
+                           const float* head_w, float* head_out) {
 #define DIR_GO(NV)                                                                                          \
     do {                                                                                                    \
         dim3 grid(grid_resident(work_blocks, resident_blocks(cross_k<G, NV, VEC>, shmem)));                 \
-        hipLaunchKernelGGL((cross_k<G, NV, VEC>), grid, dim3(256), shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld); \
+        hipLaunchKernelGGL((cross_k<G, NV, VEC>), grid, dim3(256), shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld, head_w, head_out); \
     } while (0)
     if (nv <= 2) DIR_GO(2);
     else if (nv <= 4) DIR_GO(4);
@@ -225,13 +240,14 @@ static int launch_cross_nv(int nv, int64_t work_blocks, size_t shmem, hipStream_
 }
 
 static int cross_dispatch(const float* x0, int64_t x_ld, const float* xinit, const float* w, const float* b, int L,
-                          int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream) {
-    DIR_CHECK_ARG(x0 && out && ((w && b) || L == 0), "dir_dcn_cross_f32: null pointer");
-    DIR_CHECK_ARG(L >= 0 && d > 0 && B >= 0 && x_ld >= d && out_ld >= d, "dir_dcn_cross_f32: L=%d d=%d B=%lld x_ld=%lld out_ld=%lld", L, d, (long long)B, (long long)x_ld, (long long)out_ld);
+                          int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream, const float* head_w = nullptr,
+                          float* head_out = nullptr) {
+    DIR_CHECK_ARG(x0 && (out || head_out) && ((w && b) || L == 0) && ((head_w == nullptr) == (head_out == nullptr)), "dir_dcn_cross_f32: null pointer");
+    DIR_CHECK_ARG(L >= 0 && d > 0 && B >= 0 && x_ld >= d && (!out || out_ld >= d), "dir_dcn_cross_f32: L=%d d=%d B=%lld x_ld=%lld out_ld=%lld", L, d, (long long)B, (long long)x_ld, (long long)out_ld);
     if (B == 0) return DIR_OK;
-    const size_t shmem = (size_t)2 * L * d * sizeof(float);
+    const size_t shmem = ((size_t)2 * L + (head_w ? 1 : 0)) * d * sizeof(float);
     if (shmem > 64 * 1024) return fail(DIR_E_UNSUPPORTED, "dir_dcn_cross_f32: L*d=%d exceeds the 64 KiB LDS weight image", L * d);
-    const bool vec = (d % 4 == 0) && (x_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(x0) && aligned16(out) &&
+    const bool vec = (d % 4 == 0) && (x_ld % 4 == 0) && (!out || ((out_ld % 4 == 0) && aligned16(out))) && aligned16(x0) &&
                      (!xinit || aligned16(xinit)) && (L == 0 || (aligned16(w) && aligned16(b)));
     const int nchunk = vec ? d / 4 : d;
     // smallest group width that keeps <= 16 chunks per lane
@@ -249,8 +265,8 @@ static int cross_dispatch(const float* x0, int64_t x_ld, const float* xinit, con
     const int64_t grid = (waves + 3) / 4;   // work blocks; the launch picks the resident count
     hipStream_t st = as_stream(stream);
 #define DIR_G(GG)                                                                                        \
-    if (vec) launch_cross_nv<GG, 4>(nv, grid, shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld);   \
-    else launch_cross_nv<GG, 1>(nv, grid, shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld)
+    if (vec) launch_cross_nv<GG, 4>(nv, grid, shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld, head_w, head_out);   \
+    else launch_cross_nv<GG, 1>(nv, grid, shmem, st, x0, x_ld, xinit, w, b, L, B, d, out, out_ld, head_w, head_out)
     switch (G) {
         case 8: DIR_G(8); break;
         case 16: DIR_G(16); break;
@@ -271,4 +287,12 @@ extern "C" int dir_dcn_cross_op_f32(const float* x0, const float* x, int64_t x_l
                                     int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream) {
     DIR_CHECK_ARG(x, "dir_dcn_cross_op_f32: null pointer");
     return cross_dispatch(x0, x_ld, x, w, b, 1, B, d, out, out_ld, stream);
+}
+
+// _cross_architecture followed by the cross branch's share of the final dense(1) (DeepCrossNetwork.py:136-137):
+// head_out[r] = x_L[r] . head_w.  out may be NULL: x_L then never reaches memory.
+extern "C" int dir_dcn_cross_head_f32(const float* x0, int64_t x_ld, const float* w, const float* b, int L, int64_t B, int d,
+                                      const float* head_w, float* out, int64_t out_ld, float* head_out, dir_stream_t stream) {
+    DIR_CHECK_ARG(head_w && head_out, "dir_dcn_cross_head_f32: null pointer");
+    return cross_dispatch(x0, x_ld, nullptr, w, b, L, B, d, out, out_ld, stream, head_w, head_out);
 }

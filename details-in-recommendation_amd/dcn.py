@@ -97,15 +97,15 @@ class DeepCrossNetwork(nn.Module):
         stride pad4(d) and zero pad columns ONCE; the cross kernel runs its 16-byte instantiation on it (zero-padded w, b keep
         the pad columns exactly 0), the first deep layer reads the same buffer with Kd = pad4(d) against a zero-padded weight,
         and the final dense(1) over concat([cross, deep]) (:136-137) is evaluated as cross . w_c + deep . w_d + bias -- the
-        concat is never materialised.  Values: the same sums over the same real columns."""
+        concat is never materialised, and cross . w_c comes out of the cross kernel itself (the cross output has no other reader).  Values: the same sums over the same real columns."""
         d, dp = self.column_num, ops.pad4(self.column_num)
         x0p = self.input_layer(features, pad_to=4)
         wp, bp = self._padded_cross_params()
-        cross = ops.cross_network(x0p, wp, bp)                                   # [B, dp], zero tail
-        deep = self.deep_architecture(x0p)                                       # dense_act pads the first weight (in_features d -> dp)
         wl = self.logits_layer.weight                                            # [1, d + h]
         wc = torch.nn.functional.pad(wl[:, :d], (0, dp - d))
-        out = torch.addmm(self.logits_layer.bias, cross, wc.t()).addmm_(deep, wl[:, d:].t())
+        cross_logit = ops.cross_network_head(x0p, wp, bp, wc)                    # [B, 1] = x_L . w_c in the cross kernel's epilogue: x_L is not written
+        deep = self.deep_architecture(x0p)                                       # dense_act pads the first weight (in_features d -> dp)
+        out = cross_logit.add_(self.logits_layer.bias).addmm_(deep, wl[:, d:].t())
         raise_pending()
         return out
 

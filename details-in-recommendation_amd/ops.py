@@ -306,6 +306,26 @@ def cross_network(x0, w, b, out=None):
     return out
 
 
+def cross_network_head(x0, w, b, head_w, want_x=False):
+    """cross_network followed by the cross branch's share of the final dense(1) over concat([cross, deep]) (DeepCrossNetwork.py:136-137)
+    in the same launch (include/dir_hip.h: dir_dcn_cross_head_f32): -> (x_L . head_w) [B, 1] (, x_L [B, d] when want_x; otherwise the
+    cross output never reaches memory)."""
+    _dev(x0, torch.float32, "x0")
+    if x0.dim() != 2 or x0.stride(1) != 1:
+        raise ValueError("x0 must be [B, d] with unit inner stride")
+    B, d = x0.shape
+    w = _dev(w, torch.float32, "w").contiguous()
+    b = _dev(b, torch.float32, "b").contiguous()
+    hw = _dev(head_w, torch.float32, "head_w").reshape(-1).contiguous()
+    if w.dim() != 2 or w.shape[1] != d or tuple(b.shape) != tuple(w.shape) or hw.numel() != d:
+        raise ValueError("cross_network_head: w, b [L, d=%d], head_w [d]" % d)
+    out = torch.empty((B, d), dtype=torch.float32, device=x0.device) if want_x else None
+    ho = torch.empty((B, 1), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().dir_dcn_cross_head_f32(_ptr(x0), x0.stride(0), _ptr(w), _ptr(b), w.shape[0], B, d, _ptr(hw), _ptr(out),
+                                                  out.stride(0) if want_x else 0, _ptr(ho), _stream()))
+    return (ho, out) if want_x else ho
+
+
 def pad4(d):
     return (d + 3) // 4 * 4
 

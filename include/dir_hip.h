@@ -182,6 +182,12 @@ int dir_dcn_cross_f32(const float* x0, int64_t x_ld, const float* w, const float
 int dir_dcn_cross_op_f32(const float* x0, const float* x, int64_t x_ld, const float* w, const float* b,
                          int64_t B, int d, float* out, int64_t out_ld, dir_stream_t stream);
 
+/* dir_dcn_cross_f32 followed by the cross branch's share of the final dense(1) over concat([cross, deep])
+ * (DeepCrossNetwork.py:136-137): head_out[r] = x_L[r] . head_w  (head_w DEVICE [d], head_out DEVICE [B]); out may be NULL -- the
+ * cross output then never reaches memory (inference: it has no other reader). */
+int dir_dcn_cross_head_f32(const float* x0, int64_t x_ld, const float* w, const float* b, int L, int64_t B, int d,
+                           const float* head_w, float* out, int64_t out_ld, float* head_out, dir_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * A13 DIN local activation unit + weighted pooling (no reference code: README.md:27 links
  * arXiv:1706.06978; definition in DESIGN.md / oracle).

@@ -778,3 +778,23 @@ def test_dense_bf16x3_limits_and_auto(built_lib):
     assert ops.dense_auto_arith(65536, 416, 400) == "bf16x3" and ops.dense_auto_arith(65536, 1024, 1024) == "bf16x3"
     assert ops.dense_auto_arith(65536, 360, 200) == "bf16x3" and ops.dense_auto_arith(65536, 200, 80) == "f32"
     assert ops.dense_auto_arith(4096, 416, 400) == "f32" and ops.dense_auto_arith(65536, 400, 16) == "f32"
+
+
+@pytest.mark.parametrize("B,d,L", [(300, 416, 3), (77, 432, 3), (1000, 51, 2), (5, 16, 1), (129, 429, 3)])
+def test_cross_network_head_epilogue(ops, oracle, B, d, L):
+    """dir_dcn_cross_head_f32: the cross stack's output is bit for bit dir_dcn_cross_f32's, and x_L . head_w (the cross branch's share of
+    the final dense(1) over concat([cross, deep]), DeepCrossNetwork.py:136-137) is within 1e-6-class rounding of the float64 dot; with
+    out = NULL the head value is the same bits."""
+    g = torch.Generator().manual_seed(B + d)
+    x0 = (torch.randn(B, d, generator=g) * 0.5).cuda()
+    w = (torch.randn(L, d, generator=g) * 0.1).cuda()
+    b = (torch.randn(L, d, generator=g) * 0.1).cuda()
+    hw = (torch.randn(d, generator=g) * 0.2).cuda()
+    ref_x = ops.cross_network(x0, w, b)
+    h, x = ops.cross_network_head(x0, w, b, hw, want_x=True)
+    assert torch.equal(x, ref_x)
+    h_only = ops.cross_network_head(x0, w, b, hw)
+    assert torch.equal(h_only, h)
+    ref = (ref_x.double() @ hw.double()).reshape(B, 1)
+    err = ((h.double() - ref).abs() / (1 + ref.abs())).max().item()
+    assert err < 2e-6, err
