@@ -94,7 +94,9 @@ template <int CT>
 __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ X, int64_t x_ld, const unsigned char* __restrict__ img,
                                                      const float* __restrict__ bias, int relu, const float* __restrict__ post_scale,
                                                      const float* __restrict__ post_shift, const float* __restrict__ gate, int64_t gate_ld,
-                                                     int64_t M, int Kd, int N, int nks, int ncb, float* __restrict__ Y, int64_t y_ld) {
+                                                     int64_t M, int Kd, int N, int nks, int ncb, float* __restrict__ Y, int64_t y_ld,
+                                                     const float* __restrict__ head_w /* [N] or nullptr */,
+                                                     float* __restrict__ head_part /* [ncb][M]: this column block's share of y . head_w */) {
     constexpr int STEPB = 3 * CT * 1024;                       // bytes of W image per k-step
     extern __shared__ __attribute__((aligned(16))) unsigned char db3_smem[];
     unsigned char* Wb = db3_smem;                              // [2][STEPB]
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t r = cur.row0 + wave * 32 + rt * 16 + n;
+            float hpart = 0.f;                  // head: this lane's share of the row's dot product with head_w (columns of this block)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int col = 16 * (cur.cb * CT + ct) + 4 * lg;      // N % 4 == 0: the lane's four columns are inside or outside together
@@ -247,9 +250,21 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = gt[q] > 0.f ? v[q] : 0.f;
                     }
-                    *reinterpret_cast<f32x4*>(Y + r * y_ld + col) = v;
+                    if (Y) *reinterpret_cast<f32x4*>(Y + r * y_ld + col) = v;
+                    if (head_w) {
+                        const f32x4 h4 = *reinterpret_cast<const f32x4*>(head_w + col);
+                        hpart += v[0] * h4[0];
+                        hpart += v[1] * h4[1];
+                        hpart += v[2] * h4[2];
+                        hpart += v[3] * h4[3];
+                    }
                 }
                 acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (head_w) {                       // the row's other columns of this block live in the other three lane groups
+                hpart += __shfl_xor(hpart, 16, 64);
+                hpart += __shfl_xor(hpart, 32, 64);
+                if (lg == 0 && r < M) head_part[(int64_t)cur.cb * M + r] = hpart;
             }
         }
         cur = nxt;
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
 template <int CT>
 static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const unsigned char* img, const float* bias, int relu,
                              const float* ps, const float* psh, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, int nks, int ncb,
-                             float* Y, int64_t y_ld) {
+                             float* Y, int64_t y_ld, const float* head_w = nullptr, float* head_part = nullptr) {
     const size_t shmem = 2 * (size_t)3 * CT * 1024;
     static bool set = false;
     if (!set) {
@@ -269,7 +284,7 @@ static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const
     const int64_t ntiles = (M + DB3_ROWS - 1) / DB3_ROWS * ncb;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;         // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
     hipLaunchKernelGGL((dense_bf3_k<CT>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
-                       nks, ncb, Y, y_ld);
+                       nks, ncb, Y, y_ld, head_w, head_part);
 }
 
 }  // namespace dir
@@ -319,6 +334,41 @@ extern "C" int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* im
     if (CT == 8) launch_dense_bf3<8>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
     else if (CT == 13) launch_dense_bf3<13>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
     else launch_dense_bf3<16>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
+// The layer with the head of the tower's output folded into its epilogue (DCN's last deep layer, DeepCrossNetwork.py:136-137: the deep
+// branch's share of the final dense(1)): head_part[cb][r] = sum over column block cb of y[r, c] * head_w[c]  (ncb =
+// dir_dense_bf16x3_head_blocks(N) blocks, added by the caller in block order: a fixed order).  Y may be NULL: the activation then
+// never reaches memory.
+extern "C" int dir_dense_bf16x3_head_blocks(int N) {
+    if (N <= 0) return 0;
+    const int CT = db3_ct_for(N);
+    return ((N + 15) / 16 + CT - 1) / CT;
+}
+
+extern "C" int dir_dense_bf16x3_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                                         const float* post_shift, int64_t M, int Kd, int N, const float* head_w, float* Y, int64_t y_ld,
+                                         float* head_part, dir_stream_t stream) {
+    const char* name = "dir_dense_bf16x3_head_f32";
+    DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && (!Y || y_ld >= N), "%s: bad shape", name);
+    DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
+    DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
+    if (M == 0) return DIR_OK;
+    DIR_CHECK_ARG(X && image && head_w && head_part, "%s: null pointer", name);
+    if ((Kd & 3) || (N & 3) || (x_ld & 3) || (Y && ((y_ld & 3) || !aligned16(Y))) || !aligned16(X) || !aligned16(image) || !aligned16(head_w) ||
+        (bias && !aligned16(bias)) || (post_scale && (!aligned16(post_scale) || !aligned16(post_shift))))
+        return fail(DIR_E_UNSUPPORTED, "%s: Kd, N and the row strides must be multiples of 4 and every operand 16-byte aligned (Kd=%d N=%d)",
+                    name, Kd, N);
+    const int CT = db3_ct_for(N);
+    const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
+    hipStream_t st = as_stream(stream);
+    const unsigned char* img = static_cast<const unsigned char*>(image);
+    const int relu = act == DIR_ACT_RELU;
+    if (CT == 8) launch_dense_bf3<8>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
+    else if (CT == 13) launch_dense_bf3<13>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
+    else launch_dense_bf3<16>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }

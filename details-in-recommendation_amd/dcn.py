@@ -14,7 +14,7 @@ import math
 import torch
 from torch import nn
 
-from .dense import dense_act
+from .dense import dense_act, _RELUS
 from . import autograd as ag
 from . import ops
 from .deepfm import _BatchNormInfer, _dropout_train, _glorot_uniform_
@@ -83,6 +83,24 @@ class DeepCrossNetwork(nn.Module):
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :405-408 (TRAIN only), after the BN
         return net
 
+    def _deep_logit(self, net, wd):
+        """Inference: _deep_architecture with the deep branch's share of the final dense(1), deep . w_d, folded into the last layer's
+        epilogue (ops.dense_head: the [B, h] activation is never written) -> [B, 1], or None when that kernel does not cover the layer."""
+        n = len(self.hidden)
+        if not n or not (self.activation is None or self.activation in _RELUS) or torch.is_grad_enabled():
+            return None
+        bi = 0
+        for i, lin in enumerate(self.hidden[:-1]):
+            bn = None
+            if self.batch_norm:
+                bn = self.bns[bi]
+                bi += 1
+            net = dense_act(lin, net, self.activation, bn=bn)
+        last = self.hidden[-1]
+        if net.shape[1] != last.in_features:
+            return None
+        return ops.dense_head(net, last.weight, last.bias, wd, relu=self.activation is not None)
+
     def _padded_cross_params(self):
         """cross_w / cross_b zero-padded to a multiple of 4 columns, cached until the parameters change."""
         key = (self.cross_w._version, self.cross_b._version, self.cross_w.data_ptr())
@@ -104,8 +122,13 @@ class DeepCrossNetwork(nn.Module):
         wl = self.logits_layer.weight                                            # [1, d + h]
         wc = torch.nn.functional.pad(wl[:, :d], (0, dp - d))
         cross_logit = ops.cross_network_head(x0p, wp, bp, wc)                    # [B, 1] = x_L . w_c in the cross kernel's epilogue: x_L is not written
-        deep = self.deep_architecture(x0p)                                       # dense_act pads the first weight (in_features d -> dp)
-        out = cross_logit.add_(self.logits_layer.bias).addmm_(deep, wl[:, d:].t())
+        out = cross_logit.add_(self.logits_layer.bias)
+        deep_logit = self._deep_logit(x0p, wl[:, d:])                            # the last deep layer with deep . w_d in its epilogue, when covered
+        if deep_logit is not None:
+            out.add_(deep_logit)
+        else:
+            deep = self.deep_architecture(x0p)                                   # dense_act pads the first weight (in_features d -> dp)
+            out.addmm_(deep, wl[:, d:].t())
         raise_pending()
         return out
 

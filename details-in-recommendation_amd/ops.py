@@ -564,6 +564,39 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     return out
 
 
+def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=None):
+    """act(x @ weight.T + bias) . head_w without writing the activation (include/dir_hip.h: dir_dense_bf16x3_head_f32): the last layer of a
+    tower and its share of a following dense(1), e.g. DCN's deep branch (DeepCrossNetwork.py:136-137).  -> [M, 1], or None when the
+    bf16x3 kernel does not cover the operands (the caller then runs the two steps)."""
+    _dev(x, torch.float32, "x")
+    _dev(weight, torch.float32, "weight")
+    M, Kd = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != Kd or x.stride(1) != 1 or M < DENSE_BF3_MIN_ROWS or DENSE_ARITH not in ("auto", "bf16x3"):
+        return None
+    if weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
+        weight = weight.contiguous()
+    if not dense_bf16x3_covers(x, weight):
+        return None
+    bias = _dev(bias, torch.float32, "bias").contiguous() if bias is not None else None
+    hw = _dev(head_w, torch.float32, "head_w").reshape(-1).contiguous()
+    if hw.numel() != N:
+        raise ValueError("dense_head: head_w [N]")
+    if hw.data_ptr() % 16:                                # e.g. the tail of a wider weight row (DCN: columns d.. of the final dense(1))
+        hw = hw.clone()
+    if post_scale is not None:
+        post_scale, post_shift = post_scale.contiguous(), post_shift.contiguous()
+    lib = _lib.load()
+    ncb = int(lib.dir_dense_bf16x3_head_blocks(N))
+    part = torch.empty((ncb, M), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dir_dense_bf16x3_head_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0, _ptr(post_scale),
+                                             _ptr(post_shift), M, Kd, N, _ptr(hw), None, 0, _ptr(part), _stream()))
+    out = part[0].clone() if ncb > 1 else part[0]
+    for cb in range(1, ncb):                              # block order: a fixed order
+        out += part[cb]
+    return out.reshape(M, 1)
+
+
 TOWER_MAX_WIDTH = 416
 TOWER_MIN_ROWS = 4096          # below this the 128-row tiles leave most of the chip idle: the per-layer kernels run
 TOWER_GATHER = os.environ.get("DIR_TOWER_GATHER", "1")      # 0: DeepFM inference as two launches (packed gather, then the tower)

@@ -375,6 +375,15 @@ int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, int N, void*
 int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                          const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
                          dir_stream_t stream);
+
+/* dir_dense_bf16x3_f32 (no gate) with the head of a tower folded into the epilogue -- DCN's last deep layer and the deep branch's share of
+ * the final dense(1) over concat([cross, deep]) (DeepCrossNetwork.py:136-137): head_part [ncb, M] (DEVICE), ncb =
+ * dir_dense_bf16x3_head_blocks(N): head_part[cb][r] = the dot product of row r's activations in column block cb with head_w [N]
+ * (DEVICE, 16-byte aligned); the caller adds the ncb rows in block order.  Y may be NULL: the layer's output then never reaches memory. */
+int dir_dense_bf16x3_head_blocks(int N);
+int dir_dense_bf16x3_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                              const float* post_shift, int64_t M, int Kd, int N, const float* head_w, float* Y, int64_t y_ld,
+                              float* head_part, dir_stream_t stream);
 /* A whole DNN tower in ONE launch (csrc/tower_bf3.hip): L <= 4 hidden layers of width <= 416 over X [M, Kd <= 416] and, optionally, the
  * units = 1 logit layer behind them -- dnn_logit_fn, models/DeepFM/deepFM.py:284-319 (concat -> [dense(units, act) ->
  * batch_normalization]* -> dense(units=1)); _base_model, models/ESMM/ESMM.py:139-146.  The arithmetic of dir_dense_bf16x3_f32 (bf16 x 3

@@ -798,3 +798,23 @@ def test_cross_network_head_epilogue(ops, oracle, B, d, L):
     ref = (ref_x.double() @ hw.double()).reshape(B, 1)
     err = ((h.double() - ref).abs() / (1 + ref.abs())).max().item()
     assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("M,Kd,N,relu", [(16384, 1024, 1024, True), (12300, 432, 1024, True), (20000, 400, 416, False), (13000, 64, 80, True)])
+def test_dense_head_epilogue(ops, M, Kd, N, relu):
+    """dir_dense_bf16x3_head_f32: act(x W^T + b) . head_w with the activation never written, against the same layer followed by the dot
+    product in float64 (the layer itself is the bf16x3 kernel's: 1e-5 class), rerun bitwise."""
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, Kd, generator=g) * 0.5).cuda()
+    w = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    hw = (torch.randn(N, generator=g) * 0.1).cuda()
+    got = ops.dense_head(x, w, b, hw, relu=relu)
+    assert got is not None and tuple(got.shape) == (M, 1)
+    y = x.double() @ w.double().t() + b.double()
+    if relu:
+        y = torch.relu(y)
+    ref = (y @ hw.double()).reshape(M, 1)
+    err = ((got.double() - ref).abs() / (1 + ref.abs())).max().item()
+    assert err < 1e-5, err
+    assert torch.equal(ops.dense_head(x, w, b, hw, relu=relu), got)
