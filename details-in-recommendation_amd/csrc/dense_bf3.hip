@@ -36,6 +36,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int DB3_ROWS = 256;
+// DB3_CHAIN: a scheduling fence behind every accumulator's six MFMAs keeps them one dependent chain.  A SIMD gives its other wave's VALU
+// instructions (the next k-step's operand split) issue slots only while this wave waits on a dependent MFMA -- none while it has
+// independent MFMAs to issue (tools/coexec_probe.hip); left alone the compiler interleaves the chains of the two row tiles.  Same
+// results bit for bit; 65 536 x 1024 -> 1024: 623 -> 597 us, x 432 -> 1024: 345 -> 336, x 416 -> 400: 114.6 -> 111.8.
+#ifndef DB3_CHAIN
+#define DB3_CHAIN 1
+#endif
 
 __device__ __forceinline__ unsigned int db3_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
     typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
@@ -214,6 +221,9 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                     tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[rt][0], tt, 0, 0, 0);
                     tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][0], tt, 0, 0, 0);
                     acc[rt][ct] = tt;
+#if DB3_CHAIN
+                    __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (tools/coexec_probe.hip)
+#endif
                 }
             }
 #pragma unroll
