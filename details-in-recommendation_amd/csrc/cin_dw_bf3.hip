@@ -23,6 +23,9 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int DWB_JB = 4;
+#ifndef DWB_CHAIN
+#define DWB_CHAIN 1      // see dense_bf3.hip (DB3_CHAIN): a 128 x 128 layer 4.14 -> 3.9 ms
+#endif
 
 __device__ __forceinline__ unsigned int dwb_pk(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even), a in the low half
     typedef __bf16 pk2_t __attribute__((ext_vector_type(2)));
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][1], b[0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][0], b[0], c, 0, 0, 0);
                 acc[j][it] = c;
+#if DWB_CHAIN
+                __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (dense_bf3.hip: DB3_CHAIN)
+#endif
             }
         }
         __syncthreads();

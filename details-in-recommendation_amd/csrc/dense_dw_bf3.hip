@@ -23,6 +23,10 @@
 // partial sums part[span][N][K]; dense_dw_bf3_reduce_k adds them in span order (bitwise reproducible, no atomics).
 #include "common.hpp"
 
+#ifndef DDW_CHAIN
+#define DDW_CHAIN 1      // see dense_bf3.hip (DB3_CHAIN): 65 536 x 400 x 416: 175 -> 169 us, 1024 x 1024: 786 -> 755 us
+#endif
+
 namespace dir {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -190,6 +194,9 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][1], b[0], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0], b[0], c, 0, 0, 0);
                         acc[rt][kt] = c;
+#if DDW_CHAIN
+                        __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (dense_bf3.hip: DB3_CHAIN)
+#endif
                     }
                 }
             }
