@@ -42,6 +42,13 @@ SIGNATURES = {
     "dir_dense_dw_small_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "dir_units1_relu_backward_partials": (c_i64, [c_i64, c_i32]),
     "dir_units1_relu_backward_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "dir_units1_backward_partials": (c_i64, [c_i64, c_i32]),
+    "dir_units1_backward_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "dir_bn_train_partials": (c_i64, [c_i64, c_i32]),
+    "dir_bn_train_stats_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                       c_i64, c_vp]),
+    "dir_bn_train_backward_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                          c_vp]),
     "dir_dense_affine_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_tower_bf16x3_image_bytes": (c_i64, [c_i32, c_i32]),
     "dir_tower_bf16x3_pack_f32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -176,6 +176,9 @@ class DeepFM(nn.Module):
             if len(self.bns) and not _train_mode(self):                        # inference: no dropout, BN folded into the layer's epilogue
                 net = dense_act(lin, net, self.activation, bn=self.bns[i])
                 continue
+            if len(self.bns) and not self.hparams.get("dnn_dropout"):          # training without dropout: layer + batch norm as one autograd node
+                net = dense_act(lin, net, self.activation, bn=self.bns[i])
+                continue
             net = dense_act(lin, net, self.activation)                          # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.hparams.get("dnn_dropout"))    # :301-302 (TRAIN only), before the BN
             if len(self.bns):

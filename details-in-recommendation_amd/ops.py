@@ -835,6 +835,8 @@ def units1_relu_backward(g, w, y):
         raise ValueError("units1_relu_backward: y must be float32 [B, N] with N and its row stride multiples of 4 (N <= 4096), 16-byte aligned")
     g = g.reshape(B).contiguous()
     w = w.reshape(N).contiguous()
+    if w.data_ptr() % 16:                                   # (a slice of a wider weight row: DCN's logit weights behind the cross columns)
+        w = w.clone()
     lib = _lib.load()
     gx = torch.empty((B, N), dtype=torch.float32, device=y.device)
     P = int(lib.dir_units1_relu_backward_partials(B, N))
@@ -845,6 +847,75 @@ def units1_relu_backward(g, w, y):
     _lib.check(lib.dir_units1_relu_backward_f32(_ptr(g), _ptr(w), _ptr(y), y.stride(0), B, N, _ptr(gx), gx.stride(0), _ptr(part), P, _stream()))
     s = part[0] if P == 1 else part.sum(dim=0)
     return gx, s[1], s[0]
+
+
+def units1_backward(g, w, x, want_gx=True):
+    """Backward of logit = x . w (units = 1) for an activation of any width that is not a ReLU output (include/dir_hip.h:
+    dir_units1_backward_f32; DCN's cross output under DeepCrossNetwork.py:136-137).  g [B] or [B, 1], w [N] or [1, N], x [B, N] (unit column
+    stride) -> (gx [B, N] = g * w | None, dw [N] = sum_b g * x)."""
+    _dev(g, torch.float32, "g")
+    _dev(w, torch.float32, "w")
+    _dev(x, torch.float32, "x")
+    B, N = x.shape
+    if g.numel() != B or w.numel() != N or (B > 0 and x.stride(1) != 1):
+        raise ValueError("units1_backward: g [B], w [N], x [B, N] with unit column stride")
+    g = g.reshape(B).contiguous()
+    w = w.reshape(N).contiguous()
+    lib = _lib.load()
+    gx = torch.empty((B, N), dtype=torch.float32, device=x.device) if want_gx else None
+    dw = torch.empty(N, dtype=torch.float32, device=x.device)
+    P = int(lib.dir_units1_backward_partials(B, N))
+    part = torch.empty((max(P, 1), N), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dir_units1_backward_f32(_ptr(g), _ptr(w), _ptr(x), x.stride(0) if B > 0 else N, B, N, _ptr(gx), N, _ptr(dw), _ptr(part), P,
+                                           _stream()))
+    return gx, dw
+
+
+def bn_train_supported(y):
+    """Shapes the training-mode batch-norm kernels take (include/dir_hip.h: dir_bn_train_stats_f32): the same class as
+    units1_relu_backward_supported, at least one row."""
+    return units1_relu_backward_supported(y) and y.shape[0] > 0
+
+
+def bn_train_stats(y, gamma, beta, moving_mean, moving_var, eps, momentum):
+    """Batch statistics of y [B, N] in one read (include/dir_hip.h: dir_bn_train_stats_f32; deepFM.py:303-308, DeepCrossNetwork.py:400-403):
+    -> (mean, inv = rsqrt(var + eps), scale = inv * gamma, shift = beta - mean * scale), each [N]; the moving statistics (tensors or None)
+    are updated in place as moving * momentum + batch * (1 - momentum).  The normalised activation is y * scale + shift."""
+    _dev(y, torch.float32, "y")
+    if not bn_train_supported(y):
+        raise ValueError("bn_train_stats: y must be float32 [B > 0, N] with N and its row stride multiples of 4 (N <= 4096), 16-byte aligned")
+    B, N = y.shape
+    lib = _lib.load()
+    P = int(lib.dir_bn_train_partials(B, N))
+    out = torch.empty((4, N), dtype=torch.float32, device=y.device)
+    part = torch.empty((P, 2, N), dtype=torch.float32, device=y.device)
+    vecs = [None if t is None else t.detach() for t in (gamma, beta, moving_mean, moving_var)]
+    for t in vecs:
+        if t is not None and (t.dtype != torch.float32 or t.numel() != N or not t.is_contiguous() or t.device != y.device):
+            raise ValueError("bn_train_stats: gamma / beta / moving statistics must be contiguous float32 [N] tensors on y's device")
+    _lib.check(lib.dir_bn_train_stats_f32(_ptr(y), y.stride(0), B, N, float(eps), float(momentum), _ptr(vecs[0]), _ptr(vecs[1]), _ptr(vecs[2]),
+                                          _ptr(vecs[3]), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(part), P, _stream()))
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_train_backward(g, y, mean, inv, gamma=None, relu_gate=False):
+    """Backward of the training-mode batch norm (include/dir_hip.h: dir_bn_train_backward_f32): g = dL/d(y * scale + shift) [B, N] ->
+    (gy [B, N], gbeta [N], ggamma [N]); relu_gate: gy is zeroed where y <= 0 (y = relu(pre) of the layer below: gy is dL/dpre)."""
+    _dev(g, torch.float32, "g")
+    _dev(y, torch.float32, "y")
+    if g.shape != y.shape or not bn_train_supported(y) or not bn_train_supported(g):
+        raise ValueError("bn_train_backward: g and y must be float32 [B > 0, N] with N and the row strides multiples of 4, 16-byte aligned")
+    B, N = y.shape
+    lib = _lib.load()
+    P = int(lib.dir_bn_train_partials(B, N))
+    gy = torch.empty((B, N), dtype=torch.float32, device=y.device)
+    vec = torch.empty((5, N), dtype=torch.float32, device=y.device)           # gbeta, ggamma, the three coefficients
+    part = torch.empty((P, 2, N), dtype=torch.float32, device=y.device)
+    gam = None if gamma is None else gamma.detach().contiguous()
+    _lib.check(lib.dir_bn_train_backward_f32(_ptr(g), g.stride(0), _ptr(y), y.stride(0), B, N, _ptr(mean.contiguous()), _ptr(inv.contiguous()),
+                                             _ptr(gam), 1 if relu_gate else 0, _ptr(gy), gy.stride(0), _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+                                             _ptr(part), P, _stream()))
+    return gy, vec[0], vec[1]
 
 
 def din_backward_supported(K, T, H1, H2):

@@ -453,6 +453,34 @@ int64_t dir_units1_relu_backward_partials(int64_t B, int N);
 int dir_units1_relu_backward_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx, int64_t gx_ld,
                                  float* partials, int64_t n_partials, dir_stream_t stream);
 
+/* The units = 1 logit layer on top of an activation of any width that is not a ReLU output -- DCN's cross output under the final dense(1)
+ * over concat([cross, deep]) (models/DeepCrossNetwork/DeepCrossNetwork.py:136-137), d = 429: gx[b,n] = g[b] * w[n] (gx NULL: skipped),
+ * dw[n] = sum_b g[b] * x[b,n], one pass over x.  partials: N * dir_units1_backward_partials(B, N) floats of scratch; the column sums are
+ * added in workgroup order (bitwise reproducible, no atomics).  No alignment or width limits (4-byte accesses). */
+int64_t dir_units1_backward_partials(int64_t B, int N);
+int dir_units1_backward_f32(const float* g, const float* w, const float* x, int64_t x_ld, int64_t B, int N, float* gx, int64_t gx_ld, float* dw,
+                            float* partials, int64_t n_partials, dir_stream_t stream);
+/* Training-mode batch normalisation of a hidden layer's activation y [B, N] (row stride y_ld): tf.layers.batch_normalization(training=True)
+ * after each hidden layer of dnn_logit_fn (models/DeepFM/deepFM.py:303-308) and tf.contrib.layers.batch_norm(scale=False) in
+ * _deep_architecture (models/DeepCrossNetwork/DeepCrossNetwork.py:400-403, 413-419); csrc/bn_train.hip.  [TF-upstream] rank-2 input:
+ * the batch's mean and POPULATION variance normalise; moving = moving * momentum + batch * (1 - momentum).
+ * dir_bn_train_stats_f32: one read of y -> mean[n], inv[n] = rsqrt(var[n] + eps), scale[n] = inv * gamma (gamma NULL: inv),
+ *   shift[n] = beta - mean * scale (beta NULL: 0); moving_mean / moving_var (NULL: skipped) updated in place.  The normalised activation
+ *   is y * scale + shift (one elementwise pass, the caller's).
+ * dir_bn_train_backward_f32: given g = dL/d(normalised activation) [B, N] -> gy = scale * (g - mean_b(g) - xhat * mean_b(g * xhat)),
+ *   xhat = (y - mean) * inv; relu_gate != 0: gy is zeroed where y <= 0 (y is the ReLU output of the layer below: gy is then dL/d of that
+ *   layer's pre-activation); gbeta[n] = sum_b g, ggamma[n] = sum_b g * xhat (either may be NULL).  coef: 3 * N floats of scratch.
+ * partials: 2 * N * dir_bn_train_partials(B, N) floats of scratch; column sums are fp32 within a workgroup and fp64 across workgroups in
+ * workgroup order (bitwise reproducible, no atomics).  Limits: N and the row strides multiples of 4, N <= 4096, B > 0, 16-byte aligned
+ * y / g / gy / coef / partials (DIR_E_UNSUPPORTED / DIR_E_BADARG). */
+int64_t dir_bn_train_partials(int64_t B, int N);
+int dir_bn_train_stats_f32(const float* y, int64_t y_ld, int64_t B, int N, float eps, float momentum, const float* gamma, const float* beta,
+                           float* moving_mean, float* moving_var, float* mean, float* inv, float* scale, float* shift, float* partials,
+                           int64_t n_partials, dir_stream_t stream);
+int dir_bn_train_backward_f32(const float* g, int64_t g_ld, const float* y, int64_t y_ld, int64_t B, int N, const float* mean,
+                              const float* inv, const float* gamma, int relu_gate, float* gy, int64_t gy_ld, float* gbeta, float* ggamma,
+                              float* coef, float* partials, int64_t n_partials, dir_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * Backward of the HBM-bound interaction ops: derivatives of the same reference
  * expressions (the reference trains through TensorFlow autodiff of deepFM.py:321-335 and

@@ -1483,3 +1483,175 @@ def test_dcn_train_step_hip_adam_equals_the_dense_torch_formulation(built_lib):
     assert op7.global_step == 8
     a0, _ = run(True, start_step=0, steps=1)
     assert any(float((x - y).abs().max()) > 1e-6 for x, y in zip(a7, a0))      # t = 8 and t = 1 give different steps
+
+
+def _bn_ref64(y64, gamma64, beta64, eps):
+    mean = y64.mean(dim=0)
+    var = y64.var(dim=0, unbiased=False)
+    inv = torch.rsqrt(var + eps)
+    scale = inv * gamma64 if gamma64 is not None else inv
+    return y64 * scale + ((beta64 if beta64 is not None else 0.0) - mean * scale), mean, var
+
+
+@pytest.mark.parametrize("B,N,pad,scale", [(1, 4, 0, True), (300, 16, 4, True), (1000, 400, 0, False), (4097, 1024, 8, True), (257, 2048, 0, False),
+                                           (65, 36, 0, True)])
+def test_bn_train_kernels_match_float64(built_lib, B, N, pad, scale):
+    """dir_bn_train_stats_f32 / dir_bn_train_backward_f32 (training-mode batch norm, deepFM.py:303-308 / DeepCrossNetwork.py:400-403) against
+    float64 autograd of the same expression: statistics, moving statistics, the normalised activation, dL/dy with and without the ReLU gate,
+    dgamma, dbeta; strided operands; reruns bitwise equal."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + N)
+    eps, mom = 1e-3, 0.999
+    ybuf = (torch.relu(torch.randn(B, N + pad, generator=g)) * 1.7 + 0.1 * torch.randn(B, N + pad, generator=g).abs()).cuda()
+    y = ybuf[:, :N]
+    gbuf = torch.randn(B, N + pad, generator=g).cuda()
+    gout = gbuf[:, :N]
+    gamma = (1.0 + 0.3 * torch.randn(N, generator=g)).cuda() if scale else None
+    beta = (0.2 * torch.randn(N, generator=g)).cuda()
+    mm0, mv0 = torch.randn(N, generator=g).cuda(), (torch.rand(N, generator=g) + 0.5).cuda()
+    mm, mv = mm0.clone(), mv0.clone()
+    mean, inv, sc, sh = ops.bn_train_stats(y, gamma, beta, mm, mv, eps, mom)
+    y64 = y.double().cpu().requires_grad_(True)
+    g64 = None if gamma is None else gamma.double().cpu().requires_grad_(True)
+    b64 = beta.double().cpu().requires_grad_(True)
+    out64, mean64, var64 = _bn_ref64(y64, g64, b64, eps)
+    _close(mean, mean64)
+    _close(inv, torch.rsqrt(var64 + eps), tol=2e-5)
+    _close(y * sc + sh, out64, tol=2e-5)
+    _close(mm, mm0.double().cpu() * mom + mean64 * (1 - mom))
+    _close(mv, mv0.double().cpu() * mom + var64 * (1 - mom))
+    out64.backward(gout.double().cpu())
+    gy, gb, gg = ops.bn_train_backward(gout, y, mean, inv, gamma, relu_gate=False)
+    bar = 2e-5 * (1 + B ** 0.5 * 0.05)
+    _close(gy, y64.grad, tol=bar)
+    _close(gb, b64.grad, tol=bar)
+    if gamma is not None:
+        _close(gg, g64.grad, tol=bar)
+    gy2, gb2, gg2 = ops.bn_train_backward(gout, y, mean, inv, gamma, relu_gate=True)
+    assert torch.equal(gy2, torch.where(y > 0, gy, torch.zeros((), device="cuda"))) and torch.equal(gb2, gb) and torch.equal(gg2, gg)
+    mm2, mv2 = mm0.clone(), mv0.clone()
+    again = ops.bn_train_stats(y, gamma, beta, mm2, mv2, eps, mom)
+    assert all(torch.equal(a, b) for a, b in zip(again, (mean, inv, sc, sh))) and torch.equal(mm2, mm) and torch.equal(mv2, mv)
+    assert torch.equal(ops.bn_train_backward(gout, y, mean, inv, gamma, relu_gate=False)[0], gy)
+    if N >= 8:
+        with pytest.raises(ValueError):
+            ops.bn_train_stats(y[:, :N - 2], None, None, None, None, eps, mom)          # N % 4 != 0
+    with pytest.raises(ValueError):
+        ops.bn_train_stats(y[:0], gamma, beta, None, None, eps, mom)
+
+
+@pytest.mark.parametrize("din,dout,M,scale", [(416, 400, 8192, True), (432, 1024, 6200, False)])
+def test_dense_bn_train_node_matches_the_torch_formulation(built_lib, din, dout, M, scale):
+    """dense._DenseBnFn (hidden layer + training batch norm as one node) against float64 autograd of relu(x W^T + b) -> batch norm and against
+    the module formulation it replaces (DIR_BN_TRAIN_FUSED=0: _DenseFn + _BatchNormInfer): output, every gradient, the moving statistics."""
+    from dir_amd import dense as D
+    from dir_amd.deepfm import _BatchNormInfer
+    g = torch.Generator().manual_seed(din + dout)
+    torch.manual_seed(din)
+    lin = torch.nn.Linear(din, dout).cuda()
+    bn = _BatchNormInfer(dout, eps=1e-3, scale=scale).cuda().train()
+    with torch.no_grad():
+        bn.beta.copy_(0.1 * torch.randn(dout, generator=g))
+        if scale:
+            bn.gamma.copy_(1.0 + 0.2 * torch.randn(dout, generator=g))
+    xraw = torch.randn(M + M // 4, din, generator=g)
+    with torch.no_grad():                        # rows with a pre-activation within 2e-5 of zero are left out (the ReLU gate is discontinuous there)
+        z = xraw.double() @ lin.weight.detach().double().cpu().t() + lin.bias.detach().double().cpu()
+        keep = z.abs().min(dim=1).values > 2e-5
+    x = xraw[keep][:M].contiguous().cuda().requires_grad_(True)
+    assert x.shape[0] == M
+    gout = torch.randn(M, dout, generator=g).cuda()
+    params = [lin.weight, lin.bias, bn.beta] + ([bn.gamma] if scale else [])
+
+    def run(fused):
+        for p in [x] + params:
+            p.grad = None
+        bn.moving_mean.zero_()
+        bn.moving_variance.fill_(1.0)
+        D.BN_TRAIN_FUSED = fused
+        try:
+            out = D.dense_act(lin, x, torch.relu, bn=bn)
+        finally:
+            D.BN_TRAIN_FUSED = True
+        out.backward(gout)
+        return [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in params] + [bn.moving_mean.clone(), bn.moving_variance.clone()]
+
+    got = run(True)
+    two = run(False)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    p64 = [p.detach().double().cpu().requires_grad_(True) for p in params]
+    y64 = torch.relu(x64 @ p64[0].t() + p64[1])
+    out64, mean64, var64 = _bn_ref64(y64, p64[3] if scale else None, p64[2], 1e-3)
+    out64.backward(gout.double().cpu())
+    ref = [out64.detach(), x64.grad] + [p.grad for p in p64] + [mean64.detach() * 0.001, 0.999 + var64.detach() * 0.001]
+    for a, r in zip(got, ref):
+        assert float((a.double().cpu() - r).abs().max()) <= 3e-5 * (1 + float(r.abs().max()))
+    for a, r in zip(got, two):
+        assert float((a - r).abs().max()) <= 3e-5 * (1 + float(r.abs().max()))
+
+
+def test_dcn_training_forward_without_the_concat_equals_the_plain_form(built_lib):
+    """DeepCrossNetwork in TRAIN mode: logits and every parameter gradient of the split form (cross . w_c + deep . w_d, last hidden layer +
+    logit share as one node, hidden layer + batch norm as one node) against the plain form (concat + nn.Linear, module batch norm)."""
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd import feature_column as fc
+    from dir_amd import dense as D
+    torch.manual_seed(5)
+    B, F, K, V = 6400, 6, 8, 50
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    cols = [fc.embedding_column(c, K) for c in cats] + [fc.numeric_column("x")]            # d = 49: the odd-width first layer
+    dcn = DeepCrossNetwork(columns=cols, cross_layer_num=2, dnn_hidden_units=[64, 32, 48], batch_norm=True).cuda().train()
+    ids = torch.randint(0, V, (B, F))
+    feats = {"C%d" % i: ids[:, i].cuda() for i in range(F)}
+    feats["x"] = torch.rand(B).cuda()
+    labels = (torch.rand(B, 1) < 0.3).float().cuda()
+    params = [p for p in dcn.parameters()]
+
+    def run(split):
+        for p in params:
+            p.grad = None
+        for bn in dcn.bns:
+            bn.moving_mean.zero_()
+            bn.moving_variance.fill_(1.0)
+        old = (D.BN_TRAIN_FUSED, dcn._train_logits)
+        if not split:
+            D.BN_TRAIN_FUSED = False
+            dcn._train_logits = lambda x0, cross: None
+        try:
+            out = dcn(feats)
+            torch.nn.functional.binary_cross_entropy_with_logits(out, labels).backward()
+        finally:
+            D.BN_TRAIN_FUSED = old[0]
+            if not split:
+                del dcn._train_logits
+        grads = [(p.grad.to_dense() if p.grad.is_sparse else p.grad).clone() for p in params]
+        return out.detach().clone(), grads, [bn.moving_mean.clone() for bn in dcn.bns]
+
+    out_a, grads_a, mm_a = run(True)
+    out_b, grads_b, mm_b = run(False)
+    assert float((out_a - out_b).abs().max()) <= 2e-5 * (1 + float(out_b.abs().max()))
+    for a, b in zip(grads_a, grads_b):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 3e-5 * (1 + float(b.abs().max()))
+    for a, b in zip(mm_a, mm_b):
+        assert float((a - b).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("B,N,pad", [(1, 1, 0), (300, 429, 3), (4099, 51, 0), (65, 1453, 0), (1000, 16, 4)])
+def test_units1_backward_kernel_any_width(built_lib, B, N, pad):
+    """dir_units1_backward_f32 (the units = 1 layer on an activation of any width: DCN's 429-wide cross output) against float64; strided x;
+    reruns bitwise equal; the gx-less form; an empty batch."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(B + N)
+    xbuf = torch.randn(B, N + pad, generator=g).cuda()
+    x = xbuf[:, :N]
+    dl = torch.randn(B, 1, generator=g).cuda()
+    w = (torch.randn(1, N, generator=g) / N ** 0.5).cuda()
+    gx, gw = ops.units1_backward(dl, w, x)
+    assert torch.equal(gx, dl * w)                                         # one fp32 product per element: exact
+    _close(gw, (dl.double().cpu() * x.double().cpu()).sum(0), tol=1e-5 * (1 + B ** 0.5 * 0.05))
+    gx2, gw2 = ops.units1_backward(dl.reshape(B), w.reshape(N), x, want_gx=False)
+    assert gx2 is None and torch.equal(gw2, gw)
+    e = ops.units1_backward(dl[:0], w, x[:0])
+    assert e[0].shape == (0, N) and float(e[1].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        ops.units1_backward(dl, w[:, :N - 1] if N > 1 else torch.zeros(1, 2).cuda(), x)
