@@ -109,11 +109,21 @@ __global__ __launch_bounds__(256) void head_lin_bwd_k(const float* __restrict__ 
     }
 }
 
+// 32 columns per workgroup, eight lanes of partials per column added in lane order (as bn_train.hip's bn_col_sums)
 __global__ __launch_bounds__(256) void head_lin_fin_k(const float* __restrict__ part, int64_t P, int N, float* __restrict__ dw) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ double red[8][32];
+    const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
     double s = 0.0;
-    for (int64_t p = 0; p < P; ++p) s += (double)part[p * N + n];
+    if (n < N) {
+#pragma unroll 4
+        for (int64_t p = l; p < P; p += 8) s += (double)part[p * N + n];
+    }
+    red[l][c] = s;
+    __syncthreads();
+    if (l != 0 || n >= N) return;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += red[q][c];
     dw[n] = (float)s;
 }
 
@@ -197,7 +207,7 @@ extern "C" int dir_units1_backward_f32(const float* g, const float* w, const flo
     const int64_t rpb = (B + nblk - 1) / nblk;
     hipLaunchKernelGGL(head_lin_bwd_k, dim3((unsigned)nblk), dim3(256), 0, st, g, w, x, x_ld, B, N, rpb, gx, gx_ld, partials);
     DIR_CHECK_LAUNCH(name);
-    hipLaunchKernelGGL(head_lin_fin_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partials, (B + rpb - 1) / rpb, N, dw);
+    hipLaunchKernelGGL(head_lin_fin_k, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, partials, (B + rpb - 1) / rpb, N, dw);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
