@@ -89,6 +89,8 @@ def parse():
                     help="cin: arithmetic of ops.cin_layer (default: the library default, 'auto' = bf16x3 where covered)")
     ap.add_argument("--cross-d", type=int, default=416, help="dcn_cross / dcn_cross_backward: row width (416 = 26 x 16; 429 with the 13 dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-profile", default=None, help="development: write torch.profiler's device time per (op, input shapes) of 4 untimed "
+                                                          "steps after the warmup to this file (which torch ops a step still runs beside the HIP kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-child", action="store_true", help="internal: the cpu_baseline worker process (see cpu_child_main)")
     return ap.parse_args()
@@ -108,6 +110,27 @@ def make_ids(torch, args, gen, device, vocab):
             ids = ids.t().contiguous().t()
         out.append(ids)
     return out
+
+
+def torch_profile(torch, step, path, n=4):
+    """--torch-profile: device time per step of every (op, input shapes) and kernel, largest first."""
+    from torch.profiler import profile, ProfilerActivity
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for i in range(n):
+            step(i)
+        torch.cuda.synchronize()
+    rows = []
+    for e in prof.key_averages(group_by_input_shape=True):
+        t = getattr(e, "self_device_time_total", None)
+        if t is None:
+            t = e.self_cuda_time_total
+        if t > 0:
+            rows.append((t / n, e.count / n, e.key, str(e.input_shapes)[:120]))
+    rows.sort(reverse=True)
+    with open(path, "w") as f:
+        for t, c, k, sh in rows[:120]:
+            f.write("%9.1f us  x%-6.1f %-60s %s\n" % (t, c, k[:60], sh))
 
 
 def _cpu_model():
@@ -961,6 +984,8 @@ def main():
     # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------
     for i in range(args.warmup):
         step(i)
+    if args.torch_profile:
+        torch_profile(torch, step, args.torch_profile)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

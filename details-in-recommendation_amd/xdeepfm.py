@@ -6,7 +6,7 @@ import math
 import torch
 from torch import nn
 
-from .dense import dense_act, mlp_stack, mlp_stack_supported, tower_infer
+from .dense import dense_act, mlp_head, mlp_head_supported, mlp_stack, mlp_stack_supported, tower_infer, units1
 from . import autograd as ag
 from . import ops
 from ._input import checked_forward as _checked_forward
@@ -107,7 +107,7 @@ class XDeepFM(nn.Module):
 
     def forward_embedded(self, emb, linear_logit=None):
         B = emb.shape[0]
-        logits = self.cin_out(self.cin(emb.view(B, self.m, self.D)))
+        logits = units1(self.cin_out, self.cin(emb.view(B, self.m, self.D)))      # (training: one pass for the layer's two gradients)
         net = emb
         if self.dnn_out.out_features == 1:
             # inference: the DNN tower and its logit layer in one launch, the CIN's (and the linear term's) logits added in its epilogue
@@ -115,12 +115,15 @@ class XDeepFM(nn.Module):
             fused = tower_infer(self.hidden, net, self.activation, head=self.dnn_out, adds=adds)
             if fused is not None:
                 return fused
-        if mlp_stack_supported(self.hidden, net, self.activation):
-            net = mlp_stack(self.hidden, net)                                   # training: the whole tower as one autograd node
+        if mlp_head_supported(self.hidden, self.dnn_out, net, self.activation):
+            logits = logits + mlp_head(self.hidden, self.dnn_out, net)          # training: the tower + its logit layer as one autograd node
         else:
-            for lin in self.hidden:
-                net = dense_act(lin, net, self.activation)                      # dir_dense_f32 when covered
-        logits = logits + self.dnn_out(net)
+            if mlp_stack_supported(self.hidden, net, self.activation):
+                net = mlp_stack(self.hidden, net)                               # training: the whole tower as one autograd node
+            else:
+                for lin in self.hidden:
+                    net = dense_act(lin, net, self.activation)                  # dir_dense_f32 when covered
+            logits = logits + units1(self.dnn_out, net)
         if linear_logit is not None:
             logits = logits + linear_logit
         return logits
