@@ -476,6 +476,7 @@ def main():
     import dir_amd
     dir_amd.load_library()
     from dir_amd import ops
+    from dir_amd import autograd as ag_opt      # Adagrad / Ftrl on dense variables (the reference's dnn / linear optimisers)
     from dir_amd.shard import ShardedTables, div_range
 
     B, F, V, K = args.batch, args.fields, args.vocab, args.dim
@@ -645,7 +646,7 @@ def main():
         model.fused_sparse_ftrl(lr=0.2)
         lin = [model.linear_bias]                          # the weight columns are updated by the fused kernel inside backward()
         skip = {id(p) for p in model.linear_weights} | {id(p) for p in lin} | {id(p) for p in model.embedding_weights}
-        opt_dense = torch.optim.Adagrad([p for p in model.parameters() if id(p) not in skip], lr=0.01, initial_accumulator_value=0.1)
+        opt_dense = ag_opt.Adagrad([p for p in model.parameters() if id(p) not in skip], lr=0.01, initial_accumulator_value=0.1)
         opt_lin = Ftrl(lin, lr=0.2)
         idsl = make_ids(torch, args, gen, device, V)
         featl = [{"C%d" % f: ids[:, f] for f in range(F)} for ids in idsl]
@@ -769,7 +770,7 @@ def main():
             labels = {"click_label": (torch.rand((B, 1), generator=gen, device=device) < 0.25).float(),
                       "convert_label": (torch.rand((B, 1), generator=gen, device=device) < 0.05).float()}
             dense_p = [p for n, p in model.named_parameters() if "embedding_weights" not in n]
-            opt_d = torch.optim.Adagrad(dense_p, lr=0.05, initial_accumulator_value=0.1, eps=0.0)
+            opt_d = ag_opt.Adagrad(dense_p, lr=0.05, initial_accumulator_value=0.1, eps=0.0)
             sparse_opts = model.fused_sparse_adagrad(0.05)        # both towers' tables; the two sorted updates share one sort per step
             cfg["sparse_optimizers"] = len(sparse_opts)
 
@@ -804,7 +805,7 @@ def main():
             model.fused_sparse_adagrad(lr=0.01)
             model.fused_sparse_ftrl(lr=0.2)
             sparse_ids = {id(p) for p in model.embedding_weights} | {id(p) for p in model.linear_weights}
-            opt_d = torch.optim.Adagrad([p for p in model.parameters() if id(p) not in sparse_ids], lr=0.01, initial_accumulator_value=0.1)
+            opt_d = ag_opt.Adagrad([p for p in model.parameters() if id(p) not in sparse_ids], lr=0.01, initial_accumulator_value=0.1)
             labels = (torch.rand((B, 1), generator=gen, device=device) < 0.25).float()
 
             def step(i):

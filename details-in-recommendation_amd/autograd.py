@@ -374,6 +374,47 @@ def cross_network(x0, w, b):
     return CrossNetwork.apply(x0, w, b)
 
 
+_DENSE_OPT_HIP = os.environ.get("DIR_DENSE_OPT_HIP", "1") != "0"      # development switch: 0 keeps the library's dense Adagrad / torch-op FTRL steps
+
+
+class Adagrad(torch.optim.Adagrad):
+    """torch.optim.Adagrad ([TF-upstream] tf.train.AdagradOptimizer's rule with eps = 0; the reference's dnn_optimizer='Adagrad',
+    deepFM.py:61) whose step on dense float32 CUDA variables is ONE elementwise HIP pass per variable (dir_adagrad_dense_f32) instead of
+    the library's five multi-tensor passes (0.16-0.27 ms of a 2-3 ms training step spent on a few hundred thousand weights).  Sparse
+    gradients, lr_decay, weight_decay, maximize and non-CUDA variables take the library's step."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        rest = []
+        for group in self.param_groups:
+            plain = not group["lr_decay"] and not group["weight_decay"] and not group.get("maximize", False)
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if not (_DENSE_OPT_HIP and plain and not g.is_sparse and p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous()
+                        and g.is_contiguous()):
+                    rest.append(p)
+                    continue
+                st = self.state[p]
+                st["step"] += 1
+                ops.adagrad_dense_(p, st["sum"], g, group["lr"], group["eps"])
+        if rest:                                   # the library's step for everything else: hide the gradients already applied
+            held = [(p, p.grad) for group in self.param_groups for p in group["params"] if p.grad is not None and all(p is not r for r in rest)]
+            for p, _ in held:
+                p.grad = None
+            try:
+                super().step()
+            finally:
+                for p, g in held:
+                    p.grad = g
+        return loss
+
+
 class Ftrl(torch.optim.Optimizer):
     """FTRL-Proximal with [TF-upstream] tf.train.FtrlOptimizer's defaults and update rule (the reference's
     linear_optimizer='Ftrl', deepFM.py:58): learning_rate_power = -0.5, initial_accumulator_value = 0.1,
@@ -394,6 +435,10 @@ class Ftrl(torch.optim.Optimizer):
                     st["accum"] = torch.full_like(p, group["init"])
                     st["linear"] = torch.zeros_like(p)
                 g = p.grad
+                if (_DENSE_OPT_HIP and not g.is_sparse and p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous()
+                        and g.is_contiguous()):
+                    ops.ftrl_dense_(p, st["accum"], st["linear"], g, lr, l1, l2)          # one elementwise HIP pass (dir_ftrl_dense_f32)
+                    continue
                 if g.is_sparse:
                     g = g.coalesce()
                     idx = g.indices()[0]

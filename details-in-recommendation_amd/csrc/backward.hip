@@ -749,6 +749,30 @@ static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedP
     return true;
 }
 
+// FTRL on a dense variable (the linear model's bias under linear_optimizer='Ftrl', deepFM.py:58,268-275): FtrlUpd::one per element
+__global__ __launch_bounds__(256) void ftrl_dense_k(float* __restrict__ w, float* __restrict__ n, float* __restrict__ z, const float* __restrict__ g,
+                                                     int64_t count, float lr, float l1, float l2) {
+    FtrlUpd u{nullptr, nullptr, nullptr, lr, l1, l2, 0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        float nn = n[i], zz = z[i], ww = w[i];
+        u.one(g[i], nn, zz, ww);
+        n[i] = nn;
+        z[i] = zz;
+        w[i] = ww;
+    }
+}
+
+// Adagrad on a dense variable (dnn_optimizer='Adagrad', deepFM.py:61, on the hidden layers' kernels and biases): AdagradUpd's rule per element
+__global__ __launch_bounds__(256) void adagrad_dense_k(float* __restrict__ w, float* __restrict__ acc, const float* __restrict__ g, int64_t count,
+                                                        float lr, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float a = acc[i] + gi * gi;
+        acc[i] = a;
+        w[i] = w[i] - lr * (gi / (sqrtf(a) + eps));
+    }
+}
+
 }  // namespace dir
 
 using namespace dir;
@@ -1140,6 +1164,27 @@ extern "C" int dir_sparse_adam_f32(float* const* tables, float* const* ms, float
 #undef DIR_DECAY
         default: return fail(DIR_E_UNSUPPORTED, "%s: K=%d", name, K);
     }
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
+extern "C" int dir_ftrl_dense_f32(float* w, float* accum, float* linear, const float* grad, int64_t count, float lr, float l1, float l2,
+                                  dir_stream_t stream) {
+    const char* name = "dir_ftrl_dense_f32";
+    DIR_CHECK_ARG(count >= 0 && lr > 0.f, "%s: count=%lld lr=%g", name, (long long)count, (double)lr);
+    if (count == 0) return DIR_OK;
+    DIR_CHECK_ARG(w && accum && linear && grad, "%s: null pointer", name);
+    hipLaunchKernelGGL(ftrl_dense_k, dim3(grid_for((count + 255) / 256)), dim3(256), 0, as_stream(stream), w, accum, linear, grad, count, lr, l1, l2);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
+extern "C" int dir_adagrad_dense_f32(float* w, float* accum, const float* grad, int64_t count, float lr, float eps, dir_stream_t stream) {
+    const char* name = "dir_adagrad_dense_f32";
+    DIR_CHECK_ARG(count >= 0, "%s: count=%lld", name, (long long)count);
+    if (count == 0) return DIR_OK;
+    DIR_CHECK_ARG(w && accum && grad, "%s: null pointer", name);
+    hipLaunchKernelGGL(adagrad_dense_k, dim3(grid_for((count + 255) / 256)), dim3(256), 0, as_stream(stream), w, accum, grad, count, lr, eps);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }

@@ -871,6 +871,28 @@ def units1_backward(g, w, x, want_gx=True):
     return gx, dw
 
 
+def adagrad_dense_(w, accum, grad, lr, eps=0.0):
+    """Adagrad step of a dense variable in place (include/dir_hip.h: dir_adagrad_dense_f32; deepFM.py:61): accum += grad^2,
+    w -= lr * grad / (sqrt(accum) + eps).  Contiguous float32 CUDA tensors of one shape."""
+    for t, n in ((w, "w"), (accum, "accum"), (grad, "grad")):
+        _dev(t, torch.float32, n)
+        if not t.is_contiguous() or t.shape != w.shape:
+            raise ValueError("adagrad_dense_: w / accum / grad must be contiguous tensors of one shape")
+    _lib.check(_lib.load().dir_adagrad_dense_f32(_ptr(w), _ptr(accum), _ptr(grad), w.numel(), float(lr), float(eps), _stream()))
+    return w
+
+
+def ftrl_dense_(w, accum, linear, grad, lr, l1=0.0, l2=0.0):
+    """FTRL-Proximal step of a dense variable in place (include/dir_hip.h: dir_ftrl_dense_f32; the linear bias under deepFM.py:58):
+    w, accum (n), linear (z), grad: contiguous float32 CUDA tensors of one shape."""
+    for t, n in ((w, "w"), (accum, "accum"), (linear, "linear"), (grad, "grad")):
+        _dev(t, torch.float32, n)
+        if not t.is_contiguous() or t.shape != w.shape:
+            raise ValueError("ftrl_dense_: w / accum / linear / grad must be contiguous tensors of one shape")
+    _lib.check(_lib.load().dir_ftrl_dense_f32(_ptr(w), _ptr(accum), _ptr(linear), _ptr(grad), w.numel(), float(lr), float(l1), float(l2), _stream()))
+    return w
+
+
 def bn_train_supported(y):
     """Shapes the training-mode batch-norm kernels take (include/dir_hip.h: dir_bn_train_stats_f32): the same class as
     units1_relu_backward_supported, at least one row."""

@@ -677,6 +677,16 @@ int dir_sparse_ftrl_sorted_f32(float* const* tables, float* const* accums, float
                                int64_t grad_slot_stride, float lr, float l1, float l2, int64_t B, const int64_t* row_base,
                                int64_t total_rows, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 
+/* The same update rule on a dense variable of `count` elements with a dense gradient (the linear model's bias, deepFM.py:268-275, under
+ * linear_optimizer='Ftrl', :58): one elementwise pass instead of some twenty library kernels. */
+int dir_ftrl_dense_f32(float* w, float* accum, float* linear, const float* grad, int64_t count, float lr, float l1, float l2,
+                       dir_stream_t stream);
+
+/* Adagrad on a dense variable of `count` elements with a dense gradient (dnn_optimizer='Adagrad', deepFM.py:61, on the hidden layers'
+ * kernels and biases; [TF-upstream] tf.train.AdagradOptimizer): accum += g^2; w -= lr * g / (sqrt(accum) + eps) (eps = 0 is TensorFlow's
+ * rule) -- one elementwise pass per variable. */
+int dir_adagrad_dense_f32(float* w, float* accum, const float* grad, int64_t count, float lr, float eps, dir_stream_t stream);
+
 /* The same two updates taking their sorted (row, entry) pairs from the workspace of an EARLIER sorted update of the same entries on the
  * same stream (same ids / strides / B / F and the same vocabularies, i.e. equal row_base and total_rows; sorted_from = that call's
  * 256-byte aligned workspace, still intact): the key building and the radix sort are skipped.  One training step of a DeepFM updates

@@ -1655,3 +1655,63 @@ def test_units1_backward_kernel_any_width(built_lib, B, N, pad):
     assert e[0].shape == (0, N) and float(e[1].abs().max()) == 0.0
     with pytest.raises(ValueError):
         ops.units1_backward(dl, w[:, :N - 1] if N > 1 else torch.zeros(1, 2).cuda(), x)
+
+
+@pytest.mark.parametrize("shape,l1,l2", [((1,), 0.0, 0.0), ((1000, 3), 0.01, 0.05), ((257,), 0.5, 0.0)])
+def test_dense_ftrl_step_matches_the_torch_formulation(built_lib, shape, l1, l2):
+    """autograd.Ftrl on a dense CUDA variable (dir_ftrl_dense_f32: one pass) against the same optimiser's torch-op path on the CPU
+    ([TF-upstream] tf.train.FtrlOptimizer's rule, deepFM.py:58), five steps, including weights that l1 holds at zero."""
+    from dir_amd.autograd import Ftrl
+    g = torch.Generator().manual_seed(len(shape) + int(l1 * 100))
+    w0 = torch.randn(shape, generator=g) * 0.1
+    a = torch.nn.Parameter(w0.clone().cuda())
+    b = torch.nn.Parameter(w0.clone())
+    oa, ob = Ftrl([a], lr=0.2, l1=l1, l2=l2), Ftrl([b], lr=0.2, l1=l1, l2=l2)
+    for _ in range(5):
+        grad = torch.randn(shape, generator=g) * 0.3
+        a.grad, b.grad = grad.cuda(), grad.clone()
+        oa.step()
+        ob.step()
+        _close(a, b, tol=2e-6)
+    _close(oa.state[a]["accum"], ob.state[b]["accum"], tol=2e-6)
+    _close(oa.state[a]["linear"], ob.state[b]["linear"], tol=2e-6)
+    if l1 >= 0.5:
+        assert float((b == 0).float().mean()) > 0.2 and torch.equal(a.detach().cpu() == 0, b.detach() == 0)
+
+
+def test_dense_adagrad_step_matches_torch_adagrad(built_lib):
+    """autograd.Adagrad (dir_adagrad_dense_f32 per dense CUDA variable) against torch.optim.Adagrad on the CPU over five steps: weights
+    and accumulators; a sparse gradient and a weight_decay group fall back to the library's step."""
+    from dir_amd.autograd import Adagrad
+    g = torch.Generator().manual_seed(11)
+    shapes = [(400, 416), (400,), (1, 400), (1,)]
+    w0 = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    pa = [torch.nn.Parameter(w.clone().cuda()) for w in w0]
+    pb = [torch.nn.Parameter(w.clone()) for w in w0]
+    oa = Adagrad(pa, lr=0.05, initial_accumulator_value=0.1, eps=0.0)
+    ob = torch.optim.Adagrad(pb, lr=0.05, initial_accumulator_value=0.1, eps=0.0)
+    for it in range(5):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g) * 0.2
+            a.grad, b.grad = gr.cuda(), gr.clone()
+        if it == 3:
+            pa[1].grad = pb[1].grad = None                       # a variable without a gradient is skipped
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            _close(a, b, tol=2e-6)
+    for a, b in zip(pa, pb):
+        _close(oa.state[a]["sum"], ob.state[b]["sum"], tol=2e-6)
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])
+    # fallbacks: weight decay, a sparse gradient
+    e1, e2 = torch.nn.Parameter(torch.zeros(10, 4).cuda()), torch.nn.Parameter(torch.zeros(10, 4))
+    d1, d2 = torch.nn.Parameter(torch.ones(5).cuda()), torch.nn.Parameter(torch.ones(5))
+    o1 = Adagrad([{"params": [e1]}, {"params": [d1], "weight_decay": 0.1}], lr=0.1)
+    o2 = torch.optim.Adagrad([{"params": [e2]}, {"params": [d2], "weight_decay": 0.1}], lr=0.1)
+    idx, val = torch.tensor([[1, 7]]), torch.ones(2, 4)
+    e1.grad, e2.grad = torch.sparse_coo_tensor(idx.cuda(), val.cuda(), (10, 4)), torch.sparse_coo_tensor(idx, val, (10, 4))
+    d1.grad, d2.grad = torch.full((5,), 0.5).cuda(), torch.full((5,), 0.5)
+    o1.step()
+    o2.step()
+    _close(e1, e2, tol=2e-6)
+    _close(d1, d2, tol=2e-6)
