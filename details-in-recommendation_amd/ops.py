@@ -395,6 +395,17 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     return (out, scores) if want_scores else out
 
 
+def _masked_rows(x, mask, n):
+    """x[mask] when the number of selected elements n is already known on the host: no second device-to-host read (boolean indexing
+    sizes its result through one)."""
+    if hasattr(torch, "nonzero_static") and x.is_cuda:
+        try:
+            return x.reshape(-1)[torch.nonzero_static(mask.reshape(-1), size=n).squeeze(1)]
+        except (RuntimeError, NotImplementedError):
+            pass
+    return x[mask]
+
+
 class DinTrainPlan:
     """Row bookkeeping one training call of the DIN unit needs, computed once (one host read) and shared by the forward that saves its
     activations and the backward: `valid` [B, T] (position inside the length and not pruned), row_off [B] (exclusive prefix of the valid
@@ -1028,7 +1039,7 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
     gCt, gb1 = dense_dw(S, a, want_bias=True)            # S^T a [H1, K] and S's column sums in one pass (dir_dense_dw_small_f32 at 80 x 64)
     gC = gCt.t()
     gA, gWp = gAP[:K], gAP[K:]
-    return {"ids_h": hist[valid], "gh": gh, "ga": ga, "grows": grows, "gW1": torch.cat([gA, gC, gA - gC, gWp], dim=0), "gb1": gb1,
+    return {"ids_h": _masked_rows(hist, valid, N), "gh": gh, "ga": ga, "grows": grows, "gW1": torch.cat([gA, gC, gA - gC, gWp], dim=0), "gb1": gb1,
             "gW2": gW2, "gb2": gb2, "gW3": gW3, "gb3": gb3}
 
 
