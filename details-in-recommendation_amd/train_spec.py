@@ -259,7 +259,7 @@ class TrainStep:
             opt.lr_t = lr * math.sqrt(1.0 - self._beta2 ** t) / (1.0 - self._beta1 ** t)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        touched = []
+        touched, dense = [], []
         for p in self.params:
             g = p.grad
             if g is None:
@@ -283,9 +283,14 @@ class TrainStep:
                 buf.index_copy_(0, idx, rows * scale)
                 p.grad = buf
                 touched.append((buf, idx))
-            else:
+            elif g.is_sparse or not g.is_cuda or g.dtype != torch.float32:
                 g = clip_by_norm_(g)
                 p.grad = g.to_dense() if g.is_sparse else g           # torch's Adam/Adagrad here take dense gradients
+            else:
+                dense.append(g)
+        if dense:       # tf.clip_by_norm per tensor, all dense tensors in four launches (one tensor at a time: five launches EACH)
+            scales = CLIP_NORM / torch.clamp(torch.stack(torch._foreach_norm(dense)), min=CLIP_NORM)
+            torch._foreach_mul_(dense, list(scales.unbind()))
         self._sync_adam_step()
         self.optimizer.step()
         self._torch_t += 1

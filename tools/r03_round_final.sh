@@ -1,10 +1,13 @@
 #!/bin/bash
 # tools/r03_round_final.sh (GPU box): the round-3 bench lines of every workload, kernel-trace summaries of the ones DESIGN.md quotes, the
 # PMC traffic passes of the default command -> gpurun_out/r03_*
+# usage: r03_round_final.sh [lines|traces|all]   (two gpurun calls keep each under the 20-minute limit)
+part=${1:-all}
 cd "$GRAFT_REPO_ROOT"
 b() { name=$1; shift; timeout -k 10 400 python3 bench.py "$@" > gpurun_out/bench_$name.log 2>&1 && grep '^{' gpurun_out/bench_$name.log | tail -1 > gpurun_out/r03_bench_$name.json; echo "$name: $(python3 -c "
 import json,sys
 d=json.load(open('gpurun_out/r03_bench_$name.json')); r=d['roofline']; print(round(d['ms_per_step'],4),'ms', 'frac', round(r['frac'],3), r.get('bound'))" 2>&1)"; }
+if [ $part != traces ]; then
 b default --steps 200 --warmup 20
 b gather_only --workload gather_only --steps 200 --warmup 20 --no-cpu-baseline
 b fm_only --workload fm_only --steps 200 --warmup 20 --no-cpu-baseline
@@ -17,7 +20,7 @@ b dcn_cross_backward --workload dcn_cross_backward --steps 100 --warmup 10 --no-
 b din --workload din --steps 50 --warmup 5
 DIR_DIN_STATIC=0 b din_queue --workload din --steps 50 --warmup 5 --no-cpu-baseline
 DIR_DIN_ARITH=f32 b din_f32 --workload din --steps 50 --warmup 5 --no-cpu-baseline
-b din_train --workload din_train --steps 30 --warmup 5 --no-cpu-baseline
+b din_train --workload din_train --steps 100 --warmup 10 --no-cpu-baseline
 DIR_DIN_BWD_ARITH=f32 b din_train_bwd_f32 --workload din_train --steps 30 --warmup 5 --no-cpu-baseline
 DIR_DIN_SAVE=0 b din_train_recompute --workload din_train --steps 30 --warmup 5 --no-cpu-baseline
 b cin --workload cin --steps 5 --warmup 2
@@ -28,15 +31,17 @@ b deepfm_full --workload deepfm_full --steps 50 --warmup 10 --no-cpu-baseline
 b dcn_full --workload dcn_full --steps 50 --warmup 5 --no-cpu-baseline
 b esmm_full --workload esmm_full --steps 50 --warmup 5 --no-cpu-baseline
 b xdeepfm_full --workload xdeepfm_full --steps 10 --warmup 2 --no-cpu-baseline
-b deepfm_train --workload deepfm_train --steps 30 --warmup 5 --no-cpu-baseline
-b dcn_train --workload dcn_train --steps 10 --warmup 2 --no-cpu-baseline
-b esmm_train --workload esmm_train --steps 30 --warmup 5 --no-cpu-baseline
+b deepfm_train --workload deepfm_train --steps 100 --warmup 10 --no-cpu-baseline
+b dcn_train --workload dcn_train --steps 30 --warmup 5 --no-cpu-baseline
+b esmm_train --workload esmm_train --steps 100 --warmup 10 --no-cpu-baseline
 b xdeepfm_train --workload xdeepfm_train --steps 10 --warmup 2 --no-cpu-baseline
 b train_sparse --workload train_sparse --steps 100 --warmup 10 --no-cpu-baseline
 b sharded_1gpu --workload sharded_1gpu --steps 100 --warmup 10 --no-cpu-baseline
 b transform --workload transform --steps 100 --warmup 10 --no-cpu-baseline
 b small_batch --workload small_batch --steps 200 --warmup 20 --no-cpu-baseline
-for w in default deepfm_full esmm_full dcn_full train_sparse sharded_1gpu cin_backward din din_train; do
+fi
+if [ $part = lines ]; then exit 0; fi
+for w in default deepfm_full esmm_full dcn_full dcn_train deepfm_train esmm_train train_sparse sharded_1gpu cin_backward multihot_bag din din_train; do
     if [ $w = default ]; then a="--steps 100 --warmup 10 --no-cpu-baseline"; elif [ $w = din ] || [ $w = din_train ]; then a="--workload $w --steps 50 --warmup 10 --no-cpu-baseline"; else a="--workload $w --steps 10 --warmup 3 --no-cpu-baseline"; fi
     DIR_BENCH_NO_SECONDARY=1 bash tools/prof.sh $w -- $a > gpurun_out/prof_$w.txt 2>&1; echo "== $w"; head -5 gpurun_out/prof_$w.txt | cut -c1-150
 done
