@@ -60,8 +60,13 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
             alg, pipe = alg + f, pipe + f * PIPE_COST[a]
             modes["dx%d" % (k + 1)] = a
             a = ops.cin_dw_auto_arith(m, D, hp, h) if arith == "auto" else arith
-            alg, pipe = alg + f, pipe + f * PIPE_COST[a]
-            modes["dw%d" % (k + 1)] = a
+            if k == 0 and arith in ("auto", "bf16x3") and getattr(ops, "CIN_DW_SYM", False) and D in (8, 16, 32) and m <= 64:
+                # the first layer (xk is x0): dir_cin_dw_sym_bf16x3_f32 multiplies the m (m + 1) / 2 unordered pairs only -- priced on what it executes
+                alg, pipe = alg + f, pipe + f * (m + 1) / (2.0 * m) * PIPE_COST["bf16x3"]
+                modes["dw1"] = "bf16x3_sym"
+            else:
+                alg, pipe = alg + f, pipe + f * PIPE_COST[a]
+                modes["dw%d" % (k + 1)] = a
         hp = h
     return alg, pipe, modes
 
@@ -978,7 +983,7 @@ def main():
         # two GEMMs of the forward's size per layer: dW (reduction over rows) and T = G x W (both data gradients)
         alg, pipe, modes = cin_flops(ops, B, m, D, Hs, forward=False, backward=True)
         roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes,
-                "kernel": "cin_bf3_k<DOT> (data gradients) + cin_dw_bf3_k (weight gradient; layer 1: cin_dw_k on fp32 MFMA), x3",
+                "kernel": "cin_bf3_k<DOT> (data gradients) + cin_dw_bf3_k (weight gradient; layer 1: cin_dw_sym_bf3_k over the unordered field pairs), x3",
                 "dtype": "f32 via bf16x3 split, f32 accumulate"}
         cfg.update({"m": m, "D": D, "layers": list(Hs)})
 

@@ -1315,6 +1315,9 @@ def cross_network_backward(x0, w, b, gout):
     return gx0, gw, gb
 
 
+CIN_DW_SYM = os.environ.get("DIR_CIN_DW_SYM", "1") != "0"      # development switch: 0 keeps the general kernels on the first layer
+
+
 def cin_dw_auto_arith(m, D, Hp, H):
     """What cin_dw(arith="auto") runs: the bf16x3 kernel (csrc/cin_dw_bf3.hip) for D >= 8 and layers at least 96 channels wide on the
     xk side (a wave's 8 column tiles are i tiles: narrower layers leave them idle) with at most a third of the 128 x 128 output
@@ -1327,7 +1330,9 @@ def cin_dw_auto_arith(m, D, Hp, H):
 
 def cin_dw(x0, xk, G, dW=None, accumulate=False, arith=None):
     """Weight gradient of one CIN layer (include/dir_hip.h, dir_cin_dw_f32): x0 [B,m,D], xk [B,Hp,D], G = dL/dxout
-    [B,H,D] -> dW [H, Hp*m] (added into `dW` when accumulate)."""
+    [B,H,D] -> dW [H, Hp*m] (added into `dW` when accumulate).  arith: "f32" | "bf16x3" | "auto" (cin_dw_auto_arith) | None = CIN_ARITH;
+    when xk IS x0 (the first layer of a stack: same storage) "auto" and "bf16x3" run the symmetric kernel dir_cin_dw_sym_bf16x3_f32
+    ("bf16x3_sym" asks for it by name)."""
     for t, n in ((x0, "x0"), (xk, "xk"), (G, "G")):
         _dev(t, torch.float32, n)
         if not t.is_contiguous():
@@ -1344,6 +1349,15 @@ def cin_dw(x0, xk, G, dW=None, accumulate=False, arith=None):
         raise ValueError("cin_dw: dW must be a contiguous [H, Hp*m] tensor")
     lib = _lib.load()
     arith = arith or CIN_ARITH
+    first_layer = xk.data_ptr() == x0.data_ptr() and xk.shape == x0.shape and D in (8, 16, 32) and m <= 64
+    if arith == "bf16x3_sym" and not first_layer:
+        raise ValueError("cin_dw: arith='bf16x3_sym' is the first layer's kernel: xk must BE x0 (same storage), D in {8, 16, 32}, m <= 64")
+    if arith == "bf16x3_sym" or (first_layer and arith in ("auto", "bf16x3") and CIN_DW_SYM):
+        # the first layer of a stack (xk is x0): dW is symmetric in (i, j) and the unordered pairs are the GEMM's columns (dir_cin_dw_sym_bf16x3_f32)
+        nbytes = int(lib.dir_cin_dw_sym_bf16x3_workspace_bytes(m, H, D, B))
+        ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+        _lib.check(lib.dir_cin_dw_sym_bf16x3_f32(_ptr(x0), _ptr(G), m, H, D, B, 1 if accumulate else 0, _ptr(dW), _ptr(ws), nbytes, _stream()))
+        return dW
     if arith == "auto":
         arith = cin_dw_auto_arith(m, D, Hp, H)
     if arith == "bf16x3":

@@ -528,6 +528,13 @@ int64_t dir_cin_dw_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
 int64_t dir_cin_dw_bf16x3_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
 int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
                           float* dW, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+/* The same gradient for the FIRST layer of a stack (xk = x0, Hp = m), where the result is symmetric in (i, j): the m (m + 1) / 2
+ * unordered pairs are the GEMM's columns (operand x0_i * x0_j formed and split per k-step, G split once per step), csrc/cin_dw_sym_bf3.hip;
+ * dW [H, m*m] gets both halves.  D in {8, 16, 32}, m <= 64; workspace: dir_cin_dw_sym_bf16x3_workspace_bytes(m, H, D, B) bytes, 16-byte
+ * aligned; partial sums are added in span order (bitwise reproducible). */
+int64_t dir_cin_dw_sym_bf16x3_workspace_bytes(int m, int H, int D, int64_t B);
+int dir_cin_dw_sym_bf16x3_f32(const float* x0, const float* G, int m, int H, int D, int64_t B, int accumulate, float* dW, void* workspace,
+                              int64_t workspace_bytes, dir_stream_t stream);
 int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp, const float* G, int m, int Hp, int H, int D,
                    int64_t B, float* dxk, float* dx0, dir_stream_t stream);
 int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,

@@ -1715,3 +1715,39 @@ def test_dense_adagrad_step_matches_torch_adagrad(built_lib):
     o2.step()
     _close(e1, e2, tol=2e-6)
     _close(d1, d2, tol=2e-6)
+
+
+@pytest.mark.parametrize("B,m,D,H", [(64, 26, 16, 128), (300, 26, 16, 128), (33, 40, 8, 70), (17, 1, 16, 16), (129, 7, 32, 200), (4097, 5, 8, 130),
+                                     (50, 28, 16, 64)])
+def test_cin_dw_first_layer_symmetric_kernel(built_lib, B, m, D, H):
+    """dir_cin_dw_sym_bf16x3_f32 (first layer: xk is x0, the unordered field pairs are the GEMM's columns) against the double-accumulating
+    oracle at the bar of the other weight-gradient kernels, against the fp32-MFMA kernel, symmetric bit for bit, reruns bitwise equal,
+    accumulate form; one / two / three pair blocks (m = 26 / 28 / 40), several h blocks, rows off the 32-row step."""
+    from dir_amd import ops
+    from oracle import oracle as O
+    rng = np.random.default_rng(B * 3 + m)
+    x0n = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
+    Gn = (rng.standard_normal((B, H, D)) * 0.5).astype(np.float32)
+    Wn = np.zeros((H, m * m), np.float32)
+    ref_dW, _, _ = O.cin_backward(x0n, x0n, Wn, Gn)
+    x0, G = torch.from_numpy(x0n).cuda(), torch.from_numpy(Gn).cuda()
+    dW = ops.cin_dw(x0, x0, G, arith="bf16x3_sym")
+    mag = np.sqrt(B * D) * 0.125 + 1.0
+    err = np.abs(dW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
+    assert err.max() <= 1e-5, "sym dW max scaled err %.3e" % err.max()
+    d3 = dW.view(H, m, m)
+    assert torch.equal(d3, d3.transpose(1, 2))                                   # both halves come from one sum
+    f32 = ops.cin_dw(x0, x0, G, arith="f32")
+    assert float((dW - f32).abs().max()) <= 2e-5 * mag * (1 + float(f32.abs().max()))
+    assert torch.equal(ops.cin_dw(x0, x0, G), dW)                                # "auto" on a first layer is this kernel
+    assert torch.equal(ops.cin_dw(x0, x0, G, arith="bf16x3_sym"), dW)
+    acc = ops.cin_dw(x0, x0, G, dW=dW.clone(), accumulate=True, arith="bf16x3_sym")
+    assert torch.allclose(acc, 2 * dW, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        ops.cin_dw(x0, x0.clone(), G, arith="bf16x3_sym")                        # xk must BE x0
+    e = ops.cin_dw(x0[:0], x0[:0], G[:0], arith="bf16x3_sym") if False else None  # (an empty batch has no storage to alias: covered by the C entry below)
+    z = torch.full((H, m * m), 7.0, device="cuda")
+    lib = __import__("dir_amd._lib", fromlist=["load"]).load()
+    assert lib.dir_cin_dw_sym_bf16x3_f32(None, None, m, H, D, 0, 0, z.data_ptr(), None, 0, None) == 0
+    torch.cuda.synchronize()
+    assert float(z.abs().max()) == 0.0
