@@ -972,7 +972,9 @@ def main():
         gp = torch.randn((B, sum(Hs)), generator=gen, device=device) * 0.1
 
         def step(i):
-            gx = None            # gradient flowing into xout of the layer being processed
+            if os.environ.get("DIR_CIN_STACK_NODE", "1") != "0":
+                return ops.cin_stack_backward(x0, xks, Ws, gp)       # what autograd.CinStack.backward runs
+            gx = None            # per-layer form: gradient flowing into xout of the layer being processed
             off = sum(Hs)
             for k in range(len(Hs) - 1, -1, -1):
                 h = Hs[k]

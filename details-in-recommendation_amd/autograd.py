@@ -228,6 +228,42 @@ class CinLayer(torch.autograd.Function):
         return dx0, dxk, dW
 
 
+class CinStack(torch.autograd.Function):
+    """A whole CIN stack as ONE autograd node: x0 [B, m, D], W_k [H_k, H_{k-1} * m] -> pooled [B, sum H_k] (xDeepFM's CIN output; the last
+    layer's map is not written).  Backward: ops.cin_stack_backward -- dL/dxout of every layer is completed inside the data-gradient kernel
+    of the layer above and dx0 is accumulated by the partial-sum pass (per-layer nodes cost one [B, H, D] add and one [B, m, D] add each)."""
+
+    @staticmethod
+    def forward(ctx, x0, *Ws):
+        B = x0.shape[0]
+        Hs = [int(W.shape[0]) for W in Ws]
+        pooled = torch.empty((B, sum(Hs)), dtype=torch.float32, device=x0.device)
+        xks, xk, off = [], x0, 0
+        for k, (W, h) in enumerate(zip(Ws, Hs)):
+            xks.append(xk)
+            xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Ws))
+            off += h
+        ctx.L = len(Ws)
+        ctx.save_for_backward(x0, *xks[1:], *Ws)
+        return pooled
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        L = ctx.L
+        x0, xks, Ws = saved[0], [saved[0]] + list(saved[1:L]), list(saved[L:])
+        if g.dim() != 2 or (g.shape[0] > 0 and g.stride(1) != 1):
+            g = g.contiguous()
+        dx0, dWs = ops.cin_stack_backward(x0, xks, Ws, g, need_x0=ctx.needs_input_grad[0])
+        return (dx0,) + tuple(dWs)
+
+
+def cin_stack(x0, Ws):
+    """pooled [B, sum H_k] of a CIN stack through CinStack (x0 contiguous float32 [B, m, D] on the GPU)."""
+    return CinStack.apply(x0, *Ws)
+
+
 def cin_layer(x0, xk, W):
     return CinLayer.apply(x0, xk, W)
 

@@ -107,7 +107,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      int nkh, int hoff /* first output column of this launch */, int64_t R,
                                                      float* __restrict__ xout, float* __restrict__ pooled, int64_t pooled_ld,
                                                      const float* __restrict__ y /* DOT: [B, H, D] */,
-                                                     float* __restrict__ dotp /* DOT: partials [nkh][B, m, D] of this launch's column block */) {
+                                                     float* __restrict__ dotp /* DOT: partials [nkh][B, m, D] of this launch's column block */,
+                                                     const float* __restrict__ addp /* optional [B, H] (row stride addp_ld): added to xout[b, h, :] */,
+                                                     int64_t addp_ld) {
     constexpr int STEPB = 3 * CT * 1024;                         // bytes of W image per k-step of 32
     constexpr int CHB = KS * STEPB;                              // bytes of W image per (half, field); a staged chunk holds FJ of them
     constexpr int BT_ROWS = 8 * 16 * RT;                         // rows per workgroup (shadows the 256 of the forward)
@@ -332,8 +334,12 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int h = hbase + 16 * ct + n;
-            const f32x4 v = out[rt][ct];
-            if (xout && h < H && gr < R) *reinterpret_cast<f32x4*>(xout + (b * H + h) * D + d) = v;
+            f32x4 v = out[rt][ct];
+            if (xout && h < H && gr < R) {
+                // (the backward of a stack: dL/dxout of the layer below = this data gradient + that layer's pooled gradient, broadcast over d)
+                if (addp) v += addp[b * addp_ld + h];
+                *reinterpret_cast<f32x4*>(xout + (b * H + h) * D + d) = v;
+            }
         }
     }
     if (pooled) {
@@ -393,7 +399,8 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
 
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: 64-column blocks, two fields per chunk, dot partials)
 static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
-                   float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+                   float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
+                   const float* addp = nullptr, int64_t addp_ld = 0) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -428,7 +435,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         }                                                                                                                             \
         const size_t shmem = 2 * (size_t)FJ_ * K * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                    \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, \
-                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP);                                                        \
+                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld);                                                        \
     } while (0)
 #define BT_LAUNCH_FWD(C, NCB, HOFF, IMG)                                            \
     do {                                                                            \
@@ -488,4 +495,36 @@ extern "C" int dir_cin_layer_dot_bf16x3_f32(const float* x0, const float* xk, co
     DIR_CHECK_ARG(y && dot_partials && xout, "%s: null pointer", name);
     DIR_CHECK_ARG(aligned16(y) && aligned16(dot_partials), "%s: y and dot_partials must be 16-byte aligned", name);
     return bf3_run(name, x0, xk, W, m, Hp, H, D, B, xout, nullptr, 0, y, dot_partials, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dir_cin_layer_dot_add_bf16x3_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D,
+                                                int64_t B, const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials,
+                                                void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    const char* name = "dir_cin_layer_dot_add_bf16x3_f32";
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(y && dot_partials && xout, "%s: null pointer", name);
+    DIR_CHECK_ARG(aligned16(y) && aligned16(dot_partials), "%s: y and dot_partials must be 16-byte aligned", name);
+    DIR_CHECK_ARG(!add_pooled || add_pooled_ld >= H, "%s: add_pooled_ld=%lld < H=%d", name, (long long)add_pooled_ld, H);
+    return bf3_run(name, x0, xk, W, m, Hp, H, D, B, xout, nullptr, 0, y, dot_partials, workspace, workspace_bytes, stream, add_pooled, add_pooled_ld);
+}
+
+// out[e] (+)= sum over p of parts[p][e] in p order, e < n (n % 4 == 0, 16-byte aligned): the dot partials of dir_cin_layer_dot_*_f32 -> dx0,
+// accumulated over the layers of a stack in one pass instead of a library reduction plus an add
+__global__ __launch_bounds__(256) void sum_partials_k(const float* __restrict__ parts, int P, int64_t n4, int accumulate, float* __restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        f32x4 s = accumulate ? reinterpret_cast<const f32x4*>(out)[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < P; ++p) s += reinterpret_cast<const f32x4*>(parts)[(int64_t)p * n4 + e];
+        reinterpret_cast<f32x4*>(out)[e] = s;
+    }
+}
+
+extern "C" int dir_sum_partials_f32(const float* parts, int P, int64_t n, int accumulate, float* out, dir_stream_t stream) {
+    const char* name = "dir_sum_partials_f32";
+    DIR_CHECK_ARG(P >= 0 && n >= 0, "%s: P=%d n=%lld", name, P, (long long)n);
+    if (n == 0 || (P == 0 && accumulate)) return DIR_OK;
+    DIR_CHECK_ARG(out && (parts || P == 0), "%s: null pointer", name);
+    if (n % 4 || !aligned16(parts) || !aligned16(out)) return fail(DIR_E_UNSUPPORTED, "%s: n must be a multiple of 4, parts / out 16-byte aligned", name);
+    hipLaunchKernelGGL(sum_partials_k, dim3(grid_for((n / 4 + 255) / 256, 16)), dim3(256), 0, as_stream(stream), parts, P, n / 4, accumulate, out);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
 }

@@ -1402,10 +1402,13 @@ def cin_dx(x0, xk, W, G):
     return dxk, dx0
 
 
-def cin_dx_bf16x3(x0, xk, W, G):
+def cin_dx_bf16x3(x0, xk, W, G, add_pooled=None, dx0=None):
     """Both data gradients of one CIN layer on the bf16x3 kernel (include/dir_hip.h, dir_cin_layer_dot_bf16x3_f32): the forward
     contraction on the permuted weight W1[i, h*m+j] = W[h, i*m+j] with G as its left operand gives dxk, and the same T_j tiles dotted
-    with xk give dx0 (partial sums per column block and half of i, added here in a fixed order).  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
+    with xk give dx0 (partial sums per column block and half of i, added in a fixed order by dir_sum_partials_f32).
+    add_pooled [B, Hp] (unit column stride): added to dxk[b, i, :] in the kernel's epilogue (dir_cin_layer_dot_add_bf16x3_f32) -- in the
+    backward of a stack that sum is the layer below's dL/dxout.  dx0: a [B, m, D] tensor the partial sums are ACCUMULATED into (the
+    running dx0 of a stack); None: a new tensor.  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
     for t, n in ((x0, "x0"), (xk, "xk"), (W, "W"), (G, "G")):
         _dev(t, torch.float32, n)
         if not t.is_contiguous():
@@ -1424,9 +1427,23 @@ def cin_dx_bf16x3(x0, xk, W, G):
     ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
     dxk = torch.empty((B, Hp, D), dtype=torch.float32, device=x0.device)
     parts = torch.empty((P, B, m, D), dtype=torch.float32, device=x0.device)
-    _lib.check(lib.dir_cin_layer_dot_bf16x3_f32(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(dxk), _ptr(parts), _ptr(ws), nbytes,
-                                                _stream()))
-    return dxk, (parts[0] if P == 1 else parts.sum(dim=0))
+    if add_pooled is not None:
+        _dev(add_pooled, torch.float32, "add_pooled")
+        if tuple(add_pooled.shape) != (B, Hp) or (B > 0 and add_pooled.stride(1) != 1):
+            raise ValueError("cin_dx_bf16x3: add_pooled must be [B, Hp] with unit column stride")
+    _lib.check(lib.dir_cin_layer_dot_add_bf16x3_f32(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(add_pooled),
+                                                    add_pooled.stride(0) if add_pooled is not None and B > 0 else Hp, _ptr(dxk), _ptr(parts),
+                                                    _ptr(ws), nbytes, _stream()))
+    acc = dx0 is not None
+    if acc and (tuple(dx0.shape) != (B, m, D) or not dx0.is_contiguous() or dx0.dtype != torch.float32):
+        raise ValueError("cin_dx_bf16x3: dx0 must be a contiguous float32 [B, m, D] tensor")
+    n = B * m * D
+    if n % 4 or B == 0:
+        s_ = parts[0] if P == 1 else parts.sum(dim=0)
+        return dxk, (dx0.add_(s_) if acc else s_)
+    out = dx0 if acc else torch.empty((B, m, D), dtype=torch.float32, device=x0.device)
+    _lib.check(lib.dir_sum_partials_f32(_ptr(parts), P, n, 1 if acc else 0, _ptr(out), _stream()))
+    return dxk, out
 
 
 def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, force_forward_form=False, arith=None):
@@ -1464,6 +1481,46 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
     if need_w:
         dW = cin_dw(x0, xk, G, arith=dw_arith)
     return dx0, dxk, dW
+
+
+def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None):
+    """Backward of a whole CIN stack (xDeepFM: pooled = concat_k sum_d X^k) given g_pooled [B, sum H_k] (unit column stride): xks[k] is
+    layer k's input (xks[0] IS x0), Ws[k] [H_k, H_{k-1} * m].  -> (dx0 [B, m, D] | None, [dW_k]).  Layer by layer from the top as
+    cin_layer_backward, but the sum dL/dxout_k = dL/dxk_{k+1} + g_pooled_k (broadcast over d) comes out of layer k+1's data-gradient
+    kernel (its epilogue adds the pooled gradient), and every layer's dx0 share is accumulated into one tensor by the partial-sum pass:
+    no [B, H, D] add and no [B, m, D] add per layer."""
+    B, m, D = x0.shape
+    L = len(Ws)
+    Hs = [int(W.shape[0]) for W in Ws]
+    if tuple(g_pooled.shape) != (B, sum(Hs)) or (B > 0 and g_pooled.stride(1) != 1):
+        raise ValueError("cin_stack_backward: g_pooled must be [B, sum(H_k)] with unit column stride")
+    offs = [0]
+    for h in Hs:
+        offs.append(offs[-1] + h)
+    gps = [g_pooled[:, offs[k]:offs[k + 1]] for k in range(L)]
+    arith = arith or CIN_ARITH
+    dWs, dx0, G = [None] * L, None, None
+    for k in range(L - 1, -1, -1):
+        xk, W, H = xks[k], Ws[k], Hs[k]
+        Hp = xk.shape[1]
+        if G is None:                                        # the top layer's map feeds nothing but its pooled sums
+            G = gps[k].reshape(B, H, 1).expand(B, H, D).contiguous()
+        dWs[k] = cin_dw(x0, xk, G, arith=arith)
+        if k == 0 and not need_x0:
+            break
+        below = gps[k - 1] if k > 0 else None
+        a = cin_auto_arith(m, D, H, Hp) if arith == "auto" else arith
+        if a == "bf16x3" and cin_bf16x3_covers(m, D):
+            dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G, add_pooled=below, dx0=dx0)
+        else:
+            d0, dxk, _ = cin_layer_backward(x0, xk, W, G, need_w=False, arith=arith)
+            dx0 = d0 if dx0 is None else dx0.add_(d0)
+            if below is not None:
+                dxk = dxk.add_(below.unsqueeze(2))
+        G = dxk
+    if need_x0:
+        dx0 = dx0.add_(G)                                    # layer 1's xk IS x0: its dL/dxk is the last share
+    return (dx0 if need_x0 else None), dWs
 
 
 class _SortedShare:

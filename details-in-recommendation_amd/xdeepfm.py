@@ -12,6 +12,9 @@ from . import ops
 from ._input import checked_forward as _checked_forward
 from ._input import collect_ids, categorical_of
 from .deepfm import _glorot_uniform_
+import os as _os
+
+CIN_STACK_NODE = _os.environ.get("DIR_CIN_STACK_NODE", "1") != "0"      # development switch: 0 keeps one autograd node per CIN layer
 
 
 class XDeepFM(nn.Module):
@@ -91,7 +94,9 @@ class XDeepFM(nn.Module):
         """x0 [B, m, D] -> pooled features [B, sum(H_k)]."""
         B = x0.shape[0]
         if torch.is_grad_enabled() and (x0.requires_grad or any(W.requires_grad for W in self.cin_W)):
-            outs, xk = [], x0                  # differentiable path: autograd.CinLayer (dW on MFMA, dx via the forward)
+            if x0.is_cuda and x0.dtype == torch.float32 and CIN_STACK_NODE:
+                return ag.cin_stack(x0.contiguous(), list(self.cin_W))      # the whole stack as one autograd node (autograd.CinStack)
+            outs, xk = [], x0                  # per-layer nodes: autograd.CinLayer (dW on MFMA, dx via the forward)
             for W in self.cin_W:
                 xk, p = ag.cin_layer(x0, xk, W)
                 outs.append(p)

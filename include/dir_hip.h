@@ -243,6 +243,14 @@ int dir_cin_bf16x3_dot_partials(int m, int Hp, int H);
 int dir_cin_layer_dot_bf16x3_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D,
                                  int64_t B, float* xout, float* dot_partials, void* workspace, int64_t workspace_bytes,
                                  dir_stream_t stream);
+/* dir_cin_layer_dot_bf16x3_f32 with add_pooled [B, H] (row stride add_pooled_ld; NULL: none) added to xout[b, h, :] in the epilogue: in the
+ * backward of a stack xout is dL/dxk of layer k+1 and add_pooled the pooled gradient of layer k -- their sum is layer k's dL/dxout, formed
+ * without a pass of its own.  dir_sum_partials_f32: out[e] (+)= sum_p parts[p][e] in p order (n % 4 == 0, 16-byte aligned): the dot
+ * partials into dx0, accumulated over the layers of a stack. */
+int dir_cin_layer_dot_add_bf16x3_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D, int64_t B,
+                                     const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
+                                     int64_t workspace_bytes, dir_stream_t stream);
+int dir_sum_partials_f32(const float* parts, int P, int64_t n, int accumulate, float* out, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * A3  categorical id paths.

@@ -1751,3 +1751,55 @@ def test_cin_dw_first_layer_symmetric_kernel(built_lib, B, m, D, H):
     assert lib.dir_cin_dw_sym_bf16x3_f32(None, None, m, H, D, 0, 0, z.data_ptr(), None, 0, None) == 0
     torch.cuda.synchronize()
     assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,m,D,Hs", [(37, 7, 8, (12, 9)), (300, 26, 16, (128, 128, 128)), (65, 5, 4, (20, 33)), (129, 12, 16, (40, 64, 16)), (50, 3, 32, (8,))])
+def test_cin_stack_node_matches_float64_and_the_per_layer_nodes(built_lib, B, m, D, Hs):
+    """autograd.CinStack (the whole CIN stack as one node: pooled gradients added in the data-gradient kernels' epilogues, dx0 accumulated by
+    dir_sum_partials_f32) against float64 autograd of the definition and against the per-layer nodes (autograd.CinLayer)."""
+    from dir_amd import autograd as ag
+    g = torch.Generator().manual_seed(B + m)
+    x0 = torch.randn(B, m, D, generator=g) * 0.5
+    Ws, hp = [], m
+    for h in Hs:
+        Ws.append(torch.randn(h, hp * m, generator=g) / (hp * m) ** 0.5)
+        hp = h
+    head = torch.randn(sum(Hs), generator=g)
+
+    x64 = x0.double().requires_grad_(True)
+    w64 = [w.double().requires_grad_(True) for w in Ws]
+    xk, outs = x64, []
+    for w in w64:
+        xk = torch.einsum("hij,bid,bjd->bhd", w.view(w.shape[0], xk.shape[1], m), xk, x64)
+        outs.append(xk.sum(2))
+    l64 = (torch.cat(outs, 1) @ head.double()).square().sum()
+    l64.backward()
+
+    def run(stack):
+        x = x0.cuda().requires_grad_(True)
+        ws = [w.cuda().requires_grad_(True) for w in Ws]
+        if stack:
+            pooled = ag.cin_stack(x, ws)
+        else:
+            xk, outs = x, []
+            for w in ws:
+                xk, p = ag.cin_layer(x, xk, w)
+                outs.append(p)
+            pooled = torch.cat(outs, 1)
+        loss = (pooled @ head.cuda()).square().sum()
+        loss.backward()
+        return loss.detach(), pooled.detach(), x.grad, [w.grad for w in ws]
+
+    ls, ps, gxs, gws = run(True)
+    ll, pl, gxl, gwl = run(False)
+    _close(ls, l64, tol=1e-5)
+    assert torch.equal(ps, pl)                                          # the same forward kernels
+    sx = float(x64.grad.abs().max())
+    _close(gxs / sx, x64.grad / sx, tol=2e-5)
+    _close(gxs / sx, gxl / sx, tol=2e-5)
+    for a, b, r in zip(gws, gwl, w64):
+        sw = float(r.grad.abs().max())
+        _close(a / sw, r.grad / sw, tol=2e-5)
+        _close(a / sw, b / sw, tol=2e-5)
+    ls2, _, gxs2, gws2 = run(True)                                      # bitwise reproducible
+    assert torch.equal(gxs2, gxs) and all(torch.equal(a, b) for a, b in zip(gws2, gws))
