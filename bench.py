@@ -53,8 +53,15 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
         f = 2.0 * B * D * hp * m * h
         if forward:
             a = ops.cin_auto_arith(m, D, hp, h) if arith == "auto" else arith
-            alg, pipe = alg + f, pipe + f * PIPE_COST[a]
-            modes["fwd%d" % (k + 1)] = a
+            if k == 0 and a == "bf16x3" and getattr(ops, "CIN_L1_PAIRS", False) and 8 <= m <= 40:
+                # the first layer (xk is x0): dir_cin_layer1_bf16x3_f32 multiplies the m (m + 1) / 2 unordered pairs only (padded to 64-pair halves)
+                # -- priced on the reduction slots it executes
+                slots = -(-(m * (m + 1) // 2) // 64) * 64
+                alg, pipe = alg + f, pipe + f * slots / float(m * m) * PIPE_COST["bf16x3"]
+                modes["fwd1"] = "bf16x3_pairs"
+            else:
+                alg, pipe = alg + f, pipe + f * PIPE_COST[a]
+                modes["fwd%d" % (k + 1)] = a
         if backward:
             a = (ops.cin_auto_arith(m, D, h, hp) if arith == "auto" else arith) if ops.cin_bf16x3_covers(m, D) else "f32"
             alg, pipe = alg + f, pipe + f * PIPE_COST[a]
@@ -431,6 +438,7 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
     el32 = run("f32")
     tf, tf32 = flops * steps / el / 1e12, flops * steps / el32 / 1e12
     default_is_bf3 = ops.CIN_ARITH in ("auto", "bf16x3")
+    _, pipe_flops, _ = cin_flops(ops, B, F, K, Hs)          # bf16-pipe flops the default arithmetic executes (the first layer over field pairs)
     if st is not None:
         st.check_overflow()
     return {"metric": "samples/sec (xDeepFM CIN 3x128 + embedding lookup, table 1e8 x 16%s)" % (" row-sharded" if world > 1 else ""),
@@ -441,8 +449,8 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
                        if st is not None else "local gather (one GPU holds the table)"), "scaling": "weak",
             "dtype": "f32 via bf16x3 split, f32 accumulate" if default_is_bf3 else "f32",
             "per_gpu_fp32_equiv_TFLOPs_lookup_included": tf,
-            "per_gpu_bf16_pipe_TFLOPs_executed": 6 * tf if default_is_bf3 else None,
-            "per_gpu_frac_of_bf16_mfma_peak": 6 * tf / MFMA_BF16_PEAK_TF if default_is_bf3 else None,
+            "per_gpu_bf16_pipe_TFLOPs_executed": pipe_flops * steps / el / 1e12 if default_is_bf3 else None,
+            "per_gpu_frac_of_bf16_mfma_peak": pipe_flops * steps / el / 1e12 / MFMA_BF16_PEAK_TF if default_is_bf3 else None,
             "fp32_mfma_kernel": {"dtype": "f32", "ms_per_step": el32 * 1e3 / steps, "value": B * world * steps / el32,
                                  "per_gpu_TFLOPs_lookup_included": tf32, "per_gpu_frac_of_fp32_mfma_peak": tf32 / MFMA_F32_PEAK_TF},
             "config": {"workload": "xdeepfm_cin_sharded", "batch_per_gpu": B, "m": F, "D": K, "layers": list(Hs), "table_rows": Vf * F}}

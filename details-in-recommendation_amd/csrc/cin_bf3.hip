@@ -100,8 +100,13 @@ __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict_
 // column blocks are 64 wide (CT <= 4) and one staged chunk holds FJ = 2 fields: per barrier a wave still issues the forward's 192
 // MFMAs on 256 rows (one row tile per wave on 128-column blocks -- the first version of this form -- halves the MFMAs per B-operand
 // read and per barrier: 4.7 ms against the forward's 3.3 ms at 128 x 128).
+// PAIRS (the FIRST layer of a stack, xk = x0; dir_cin_layer1_bf16x3_f32): xout[r,h] = sum_{i,j} W[h,i,j] x0_i x0_j is a quadratic form, so
+// only the m (m + 1) / 2 unordered pairs need multiplying: the reduction runs over PAIRS p = (i <= j) with the weight
+// W[h,i,j] + W[h,j,i] (W[h,i,i] on the diagonal) -- the kernel is called with ONE "field" whose factor is 1, "Hp" = the pair count, and the
+// A operand of pair p is the product x0[r, i(p)] * x0[r, j(p)], formed from the LDS-resident x0 slice when the half's operands are split
+// (ptab[p] = i | j << 8; mx = the real field count).  351 reduction slots instead of 26 x 32 = 832 at m = 26.
 template <int KS, int CT /* column tiles of 16 per workgroup: 8 (128 columns), or 6 / 4 / 2 for the last block of a layer */,
-          int RT = 2 /* row tiles of 16 per wave */, bool DOT = false, int FJ = 1 /* fields per staged chunk */>
+          int RT = 2 /* row tiles of 16 per wave */, bool DOT = false, int FJ = 1 /* fields per staged chunk */, bool PAIRS = false>
 __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                      const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
                                                      int nkh, int hoff /* first output column of this launch */, int64_t R,
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      const float* __restrict__ y /* DOT: [B, H, D] */,
                                                      float* __restrict__ dotp /* DOT: partials [nkh][B, m, D] of this launch's column block */,
                                                      const float* __restrict__ addp /* optional [B, H] (row stride addp_ld): added to xout[b, h, :] */,
-                                                     int64_t addp_ld) {
+                                                     int64_t addp_ld, const unsigned short* __restrict__ ptab /* PAIRS: i | j << 8 per pair */,
+                                                     int mx /* fields of the x0 slice (= m unless PAIRS) */) {
     constexpr int STEPB = 3 * CT * 1024;                         // bytes of W image per k-step of 32
     constexpr int CHB = KS * STEPB;                              // bytes of W image per (half, field); a staged chunk holds FJ of them
     constexpr int BT_ROWS = 8 * 16 * RT;                         // rows per workgroup (shadows the 256 of the forward)
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         constexpr int TPR = 512 / BT_ROWS;                           // threads sharing a row: they take the fields j = t / BT_ROWS, + TPR, ...
         const int r = tid % BT_ROWS;
         const int64_t srow = (row0 + r < R) ? row0 + r : R - 1;     // a row >= R only feeds output rows that are never stored
-        const float* x0src = x0 + ((srow >> dshift) * m) * D + (srow & (D - 1));
-        for (int j = tid / BT_ROWS; j < m; j += TPR) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
+        const float* x0src = x0 + ((srow >> dshift) * mx) * D + (srow & (D - 1));
+        for (int j = tid / BT_ROWS; j < mx; j += TPR) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
     }
 
     // this lane's A rows: row tile rt -> row WR*wave + 16*rt + n of the workgroup; k slot 8*lg + e of each k-step
@@ -210,11 +216,22 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 float v[8];
+                if constexpr (PAIRS) {
+                    // the lane's 8 consecutive pairs of this k-step (the table is padded with (0, 0) up to the halves' end: their weights are zero)
+                    const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(ptab + (KS * 32 * kh + 32 * ks + 8 * lg));
+                    const float* xr = x0s + wave * WR + rt * 16 + n;               // this lane's row of the x0 slice: + field * BT_ROWS
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned int ent = (pv[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                        v[e] = xr[(ent & 255u) * BT_ROWS] * xr[(ent >> 8) * BT_ROWS];
+                    }
+                } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int i = KS * 32 * kh + 32 * ks + 8 * lg + e;
                     const float x = xsrc[rt][(int64_t)(i < Hp ? i : Hp - 1) * D];
                     v[e] = i < Hp ? x : 0.f;          // the W image is zero there; 0 * garbage must stay 0
+                }
                 }
                 unsigned int w[3][4];
 #pragma unroll
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             f32x4 xcur[RT], sd[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                xcur[rt] = *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
+                xcur[rt] = PAIRS ? (f32x4){1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
@@ -435,7 +452,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         }                                                                                                                             \
         const size_t shmem = 2 * (size_t)FJ_ * K * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                    \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, \
-                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld);                                                        \
+                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m);                                                        \
     } while (0)
 #define BT_LAUNCH_FWD(C, NCB, HOFF, IMG)                                            \
     do {                                                                            \
@@ -479,6 +496,103 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
                                         dir_stream_t stream) {
     return bf3_run("dir_cin_layer_bf16x3_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace, workspace_bytes,
                    stream);
+}
+
+// ---- the first layer over field pairs (PAIRS) -----------------------------------------------------------------------------------------------
+namespace dir {
+__host__ __device__ __forceinline__ int l1_pair_index(int a, int b, int m) { return a * m - a * (a - 1) / 2 + (b - a); }      // a <= b, row-major over a
+
+// W [H, m*m] -> W2 [H, np] (np = m (m + 1) / 2): W2[h, p(i <= j)] = W[h,i,j] + W[h,j,i] (W[h,i,i] on the diagonal);
+// ptab[p] = i | j << 8 for p < np, 0 up to npad
+__global__ __launch_bounds__(256) void cin_l1_pairs_k(const float* __restrict__ W, int m, int H, int np, int npad, float* __restrict__ W2,
+                                                       unsigned short* __restrict__ ptab) {
+    const int64_t total = (int64_t)H * m * m;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % m), i = (int)((e / m) % m), h = (int)(e / ((int64_t)m * m));
+        if (i > j) continue;
+        const float w = i == j ? W[e] : W[e] + W[((int64_t)h * m + j) * m + i];
+        W2[(int64_t)h * np + l1_pair_index(i, j, m)] = w;
+        if (h == 0) ptab[l1_pair_index(i, j, m)] = (unsigned short)(i | (j << 8));
+    }
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npad - np; p += (int64_t)gridDim.x * 256) ptab[np + p] = 0;
+}
+}  // namespace dir
+
+struct L1Plan { int np, npad; Bf3Plan pl; int64_t off_w2, off_tab, total; };
+static L1Plan l1_plan(int m, int H) {
+    L1Plan q;
+    q.np = m * (m + 1) / 2;
+    q.pl = bf3_plan(1, q.np, H, false);                       // one "field", the pairs as the reduction channels
+    q.npad = q.pl.nkh * q.pl.KS * 32;
+    int64_t off = q.pl.bytes_full + q.pl.bytes_last;
+    off = (off + 255) & ~(int64_t)255;
+    q.off_w2 = off;
+    off += ((int64_t)H * q.np * 4 + 255) & ~(int64_t)255;
+    q.off_tab = off;
+    off += ((int64_t)q.npad * 2 + 255) & ~(int64_t)255;
+    q.total = off;
+    return q;
+}
+
+extern "C" int64_t dir_cin_layer1_bf16x3_workspace_bytes(int m, int H) {
+    if (m <= 0 || H <= 0) return 0;
+    return l1_plan(m, H).total;
+}
+
+extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
+                                         int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    const char* name = "dir_cin_layer1_bf16x3_f32";
+    DIR_CHECK_ARG(m > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d H=%d D=%d", name, m, H, D);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(x0 && W && (xout || pooled) && workspace, "%s: null pointer", name);
+    DIR_CHECK_ARG(!pooled || pooled_ld >= H, "%s: pooled_ld=%lld < H=%d", name, (long long)pooled_ld, H);
+    if (!(D == 4 || D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 4, 8, 16, 32)", name, D);
+    if (m < 8 || m > 40) return fail(DIR_E_UNSUPPORTED, "%s: m=%d (supported: 8..40; use dir_cin_layer_bf16x3_f32)", name, m);
+    if (xout && !aligned16(xout)) return fail(DIR_E_BADARG, "%s: xout must be 16-byte aligned", name);
+    const L1Plan q = l1_plan(m, H);
+    DIR_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0 && workspace_bytes >= q.total,
+                  "%s: workspace must be 256-byte aligned and hold dir_cin_layer1_bf16x3_workspace_bytes(m, H) bytes", name);
+    const Bf3Plan& pl = q.pl;                                  // KS = 2 (m >= 8: more than 32 pairs)
+    int dshift = 0;
+    while ((1 << dshift) < D) ++dshift;
+    const int64_t R = B * D;
+    hipStream_t st = as_stream(stream);
+    unsigned char* img = static_cast<unsigned char*>(workspace);
+    float* W2 = reinterpret_cast<float*>(img + q.off_w2);
+    unsigned short* ptab = reinterpret_cast<unsigned short*>(img + q.off_tab);
+    hipLaunchKernelGGL(cin_l1_pairs_k, dim3(grid_for(((int64_t)H * m * m + 255) / 256)), dim3(256), 0, st, W, m, H, q.np, q.npad, W2, ptab);
+    auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
+        const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
+        hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W2, 1, q.np, H, pl.KS, pl.nkh, ncb, CT, hoff,
+                           reinterpret_cast<unsigned int*>(dst));
+    };
+    if (pl.nfull) pack(pl.nfull, pl.bw, 0, img);
+    if (pl.ctl) pack(1, pl.ctl, 16 * pl.bw * pl.nfull, img + pl.bytes_full);
+    const unsigned nrb = (unsigned)((R + 255) / 256);
+#define L1_LAUNCH(C, NCB, HOFF, IMG)                                                                                                    \
+    do {                                                                                                                                \
+        static bool set = false;                                                                                                        \
+        if (!set) {                                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<2, C, 2, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            set = true;                                                                                                                 \
+        }                                                                                                                               \
+        const size_t shmem = 2 * (size_t)2 * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                            \
+        hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, dshift, \
+                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m);                              \
+    } while (0)
+    const unsigned char* li = img + pl.bytes_full;
+    const int lo = 16 * pl.bw * pl.nfull;
+    if (pl.nfull) L1_LAUNCH(8, pl.nfull, 0, img);
+    switch (pl.ctl) {
+        case 0: break;
+        case 2: L1_LAUNCH(2, 1, lo, li); break;
+        case 4: L1_LAUNCH(4, 1, lo, li); break;
+        case 6: L1_LAUNCH(6, 1, lo, li); break;
+        default: L1_LAUNCH(8, 1, lo, li); break;
+    }
+#undef L1_LAUNCH
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
 }
 
 extern "C" int dir_cin_bf16x3_dot_partials(int m, int Hp, int H) {

@@ -1063,13 +1063,18 @@ def cin_auto_arith(m, D, Hp, H):
     return "bf16x3" if hpad * ipad <= 1.8 * H * Hp else "f32"
 
 
+CIN_L1_PAIRS = os.environ.get("DIR_CIN_L1_PAIRS", "1") != "0"      # development switch: 0 runs a stack's first layer on the general kernel
+
+
 def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
     want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
     arith: "f32" = dir_cin_layer_f32 (fp32 MFMA, an exact fma chain); "bf16x3" = dir_cin_layer_bf16x3_f32 (three-way bf16 split of
     both operands, six products on the bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same; raises on a shape that
-    kernel does not cover); "auto" = cin_auto_arith(m, D, Hp, H); None = CIN_ARITH (env DIR_CIN_ARITH, default "auto")."""
+    kernel does not cover); "auto" = cin_auto_arith(m, D, Hp, H); None = CIN_ARITH (env DIR_CIN_ARITH, default "auto").
+    When xk IS x0 (same storage: the first layer of a stack, 8 <= m <= 40) the bf16x3 arithmetic runs over the unordered field pairs
+    (dir_cin_layer1_bf16x3_f32): the same sums in another order."""
     arith = arith or CIN_ARITH
     if arith not in ("auto", "f32", "bf16x3"):
         raise ValueError("cin_layer: arith must be 'auto', 'f32' or 'bf16x3'")
@@ -1092,6 +1097,15 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
         if not cin_bf16x3_covers(m, D):
             raise ValueError("cin_layer: arith='bf16x3' covers m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (m, D))
         lib = _lib.load()
+        if CIN_L1_PAIRS and xk.data_ptr() == x0.data_ptr() and Hp == m and 8 <= m <= 40 and B > 0:
+            # the first layer of a stack (xk IS x0): a quadratic form in x0 -- the kernel multiplies the m (m + 1) / 2 unordered pairs only
+            # (dir_cin_layer1_bf16x3_f32)
+            nbytes = int(lib.dir_cin_layer1_bf16x3_workspace_bytes(m, H))
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x0.device)
+            wp = ctypes.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
+            _lib.check(lib.dir_cin_layer1_bf16x3_f32(_ptr(x0), _ptr(W), m, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled),
+                                                     pooled.stride(0), wp, nbytes, _stream()))
+            return xout, pooled
         nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, Hp, H))
         ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
         _lib.check(lib.dir_cin_layer_bf16x3_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None,

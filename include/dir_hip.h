@@ -233,6 +233,14 @@ int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H);
 int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                              int64_t B, float* xout, float* pooled, int64_t pooled_ld,
                              void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+/* The FIRST layer of a stack (xk = x0, Hp = m) on the same recipe, over the m (m + 1) / 2 unordered field pairs: xout[b,h,d] =
+ * sum_{i<=j} (W[h,i,j] + W[h,j,i] | W[h,i,i]) x0[b,i,d] x0[b,j,d] -- the pair products are formed and split inside the kernel, 351 reduction
+ * slots instead of 26 x 32 at m = 26 (csrc/cin_bf3.hip, PAIRS).  8 <= m <= 40, D in {4, 8, 16, 32}; workspace:
+ * dir_cin_layer1_bf16x3_workspace_bytes(m, H) bytes, 256-byte aligned.  Same outputs as dir_cin_layer_bf16x3_f32(x0, x0, W, ...) up to the
+ * summation order (the same 1e-5 bar), bitwise reproducible. */
+int64_t dir_cin_layer1_bf16x3_workspace_bytes(int m, int H);
+int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled, int64_t pooled_ld,
+                              void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 /* The same kernel with a second result per field, for the layer's data gradients (y's tile in registers; 64-column blocks):
  *   xout[b,h,d] as above, and  dot[b,j,d] = sum_h y[b,h,d] * T_j[(b,d),h],  T_j[r,h] = sum_i xk[r,i] * W[h, i*m+j]
  * written as dir_cin_bf16x3_dot_partials(m, Hp, H) partial sums [P][B, m, D] (one per 64-column block and half of i; the caller adds

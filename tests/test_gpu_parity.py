@@ -818,3 +818,28 @@ def test_dense_head_epilogue(ops, M, Kd, N, relu):
     err = ((got.double() - ref).abs() / (1 + ref.abs())).max().item()
     assert err < 1e-5, err
     assert torch.equal(ops.dense_head(x, w, b, hw, relu=relu), got)
+
+
+@pytest.mark.parametrize("B,m,D,H", [(64, 26, 16, 128), (300, 26, 16, 128), (33, 40, 8, 70), (129, 8, 32, 200), (4097, 12, 4, 130), (50, 28, 16, 64),
+                                     (17, 9, 16, 16)])
+def test_cin_first_layer_over_field_pairs(ops, oracle, B, m, D, H):
+    """dir_cin_layer1_bf16x3_f32 (the first layer of a stack, xk IS x0: the kernel multiplies the m (m + 1) / 2 unordered field pairs with
+    the symmetrised weights) against the double-accumulating oracle at the general kernel's bar, against the general bf16x3 kernel on a
+    copy of x0, pooled sums, the pooled-only form, reruns bitwise equal."""
+    import torch
+    rng = np.random.default_rng(B * 5 + m)
+    x0n = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
+    Wn = (rng.standard_normal((H, m * m)) / m).astype(np.float32)
+    ref_x, ref_p = oracle.cin_layer(x0n, x0n, Wn)
+    x0, W = torch.from_numpy(x0n).cuda(), torch.from_numpy(Wn).cuda()
+    xo, po = ops.cin_layer(x0, x0, W, arith="bf16x3")                       # xk IS x0: the pair kernel
+    scale = 1.0 + np.abs(ref_x)
+    assert (np.abs(xo.cpu().double().numpy() - ref_x) / scale).max() <= 1e-5
+    assert (np.abs(po.cpu().double().numpy() - ref_p) / (1.0 + np.abs(ref_p))).max() <= 1e-5 * np.sqrt(D)
+    xg, pg = ops.cin_layer(x0, x0.clone(), W, arith="bf16x3")               # a copy: the general kernel
+    assert float((xo - xg).abs().max()) <= 2e-6 * (1 + float(xg.abs().max()))
+    x2, p2 = ops.cin_layer(x0, x0, W, arith="bf16x3")
+    assert torch.equal(x2, xo) and torch.equal(p2, po)
+    wide = torch.zeros((B, H + 8), device="cuda")
+    none, p3 = ops.cin_layer(x0, x0, W, pooled=wide[:, 4:4 + H], want_xout=False, arith="bf16x3")
+    assert none is None and torch.equal(wide[:, 4:4 + H], po) and float(wide[:, :4].abs().max()) == 0.0
