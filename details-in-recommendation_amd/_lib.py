@@ -56,6 +56,7 @@ SIGNATURES = {
     "dir_deepfm_tower_bf16x3_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
                                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_image_bytes": (c_i64, [c_i32, c_i32]),
+    "dir_dense_bf16x3_pack_strided_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_pack_f32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_head_blocks": (c_i32, [c_i32]),

@@ -73,7 +73,8 @@ __host__ __device__ inline int db3_ct_for(int N) {     // column tiles per block
 
 // W [N, Kd] fp32 (row stride w_ld) -> image [column block][k-step][piece][ct][lane][8 e] bf16: element e of lane l of column tile ct =
 // piece of W[n = 16*(cb*CT + ct) + (l & 15)][k = 32*ks + 8*(l >> 4) + e]; zero where n >= N or k >= Kd.
-__global__ __launch_bounds__(256) void dense_bf3_pack_k(const float* __restrict__ W, int64_t w_ld, int Kd, int N, int CT, int nks, int ncb,
+__global__ __launch_bounds__(256) void dense_bf3_pack_k(const float* __restrict__ W, int64_t w_ld, int64_t w_cs /* column stride: 1, or the row
+                                                        stride of the tensor whose transpose W is */, int Kd, int N, int CT, int nks, int ncb,
                                                         unsigned int* __restrict__ img) {
     const int64_t total = (int64_t)ncb * nks * CT * 64 * 4;   // one thread per pair of e
     for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void dense_bf3_pack_k(const float* __restrict_
         const int cb = (int)(q / nks);
         const int n = 16 * (cb * CT + ct) + (l & 15);
         const int k = 32 * ks + 8 * (l >> 4) + 2 * ep;
-        const float v0 = (n < N && k < Kd) ? W[(int64_t)n * w_ld + k] : 0.f;
-        const float v1 = (n < N && k + 1 < Kd) ? W[(int64_t)n * w_ld + k + 1] : 0.f;
+        const float v0 = (n < N && k < Kd) ? W[(int64_t)n * w_ld + k * w_cs] : 0.f;
+        const float v1 = (n < N && k + 1 < Kd) ? W[(int64_t)n * w_ld + (k + 1) * w_cs] : 0.f;
         unsigned int p0, p1, p2;
         db3_split_pair(v0, v1, p0, p1, p2);
         const int64_t step = (int64_t)cb * nks + ks;
@@ -308,6 +309,22 @@ extern "C" int64_t dir_dense_bf16x3_image_bytes(int Kd, int N) {
     return (int64_t)ncb * nks * 3 * CT * 1024;
 }
 
+extern "C" int dir_dense_bf16x3_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
+                                                 dir_stream_t stream) {
+    const char* name = "dir_dense_bf16x3_pack_strided_f32";
+    DIR_CHECK_ARG(W && image && Kd > 0 && N > 0 && w_rs >= 1 && w_cs >= 1, "%s: bad argument (Kd=%d N=%d strides %lld, %lld)", name, Kd, N,
+                  (long long)w_rs, (long long)w_cs);
+    DIR_CHECK_ARG(aligned16(image) && image_bytes >= dir_dense_bf16x3_image_bytes(Kd, N), "%s: image must be 16-byte aligned and hold "
+                  "dir_dense_bf16x3_image_bytes(Kd, N) bytes", name);
+    const int CT = db3_ct_for(N);
+    const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
+    const int64_t threads = (int64_t)ncb * nks * CT * 64 * 4;
+    hipLaunchKernelGGL(dense_bf3_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_rs, w_cs, Kd, N, CT, nks, ncb,
+                       static_cast<unsigned int*>(image));
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
 extern "C" int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
     const char* name = "dir_dense_bf16x3_pack_f32";
     DIR_CHECK_ARG(W && image && Kd > 0 && N > 0 && w_ld >= Kd, "%s: bad argument (Kd=%d N=%d w_ld=%lld)", name, Kd, N, (long long)w_ld);
@@ -316,8 +333,8 @@ extern "C" int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, i
     const int CT = db3_ct_for(N);
     const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
     const int64_t threads = (int64_t)ncb * nks * CT * 64 * 4;
-    hipLaunchKernelGGL(dense_bf3_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, Kd, N, CT, nks, ncb,
-                       static_cast<unsigned int*>(image));
+    hipLaunchKernelGGL(dense_bf3_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, (int64_t)1, Kd, N, CT, nks,
+                       ncb, static_cast<unsigned int*>(image));
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }

@@ -36,6 +36,19 @@ def pack_weight(weight):
     return buf[:, :Kd]
 
 
+STRIDED_WEIGHTS = _os.environ.get("DIR_DENSE_STRIDED_W", "1") != "0"      # development switch: 0 always makes the padded / transposed copy
+
+
+def _kernel_weight(x, weight):
+    """The weight argument for ops.dense / ops.dense_gated in the training paths: the tensor (or `.t()` view) itself when the bf16x3 kernel
+    will run -- its image is packed straight from any strides, a [400, 400] transpose copy per layer and step is 12 us -- otherwise the
+    64-float-stride copy the fp32 kernel wants."""
+    w = weight.detach()
+    if STRIDED_WEIGHTS and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and ops.dense_runs_bf16x3(x, w):
+        return w
+    return pack_weight(weight)
+
+
 def _packed_cached(weight):
     """Inference: one padded copy per weight tensor, refreshed when the parameter is modified in place (tensor._version)."""
     key = id(weight)
@@ -92,7 +105,7 @@ class _DenseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        y = ops.dense(x, pack_weight(weight), bias, relu=relu)
+        y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
@@ -107,7 +120,7 @@ class _DenseFn(torch.autograd.Function):
         g = g.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wt = pack_weight(weight.t())                           # [Kd, N]: the "weight" of the transposed product
+            wt = _kernel_weight(g, weight.t())                     # [Kd, N]: the "weight" of the transposed product
             gx = ops.dense(g, wt, None, relu=False) if ops.dense_supported(g, wt) else g @ weight
         gw, gb = _wb_grads(g, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return gx, gw, gb, None
@@ -125,7 +138,7 @@ class _DenseBnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, bn, relu):
-        y = ops.dense(x, pack_weight(weight), bias, relu=relu)
+        y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu)
         mean, inv, scale, shift = ops.bn_train_stats(y, gamma, beta, bn.moving_mean, bn.moving_variance, bn.eps, bn.momentum)
         ctx.relu = relu
         ctx.has_bias = bias is not None
@@ -141,7 +154,7 @@ class _DenseBnFn(torch.autograd.Function):
         gpre, gbeta, ggamma = ops.bn_train_backward(g, y, mean, inv, gamma, relu_gate=ctx.relu)
         gx = None
         if ctx.needs_input_grad[0]:
-            wt = pack_weight(weight.t())
+            wt = _kernel_weight(gpre, weight.t())
             gx = ops.dense(gpre, wt, None, relu=False) if ops.dense_supported(gpre, wt) else gpre @ weight
         gw, gb = _wb_grads(gpre, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return (gx, gw, gb, ggamma if gamma is not None and ctx.needs_input_grad[3] else None, gbeta if ctx.needs_input_grad[4] else None,
@@ -167,7 +180,7 @@ class _MlpStackFn(torch.autograd.Function):
         L = len(params) // 2
         ys, h = [], x
         for l in range(L):
-            h = ops.dense(h, pack_weight(params[2 * l]), params[2 * l + 1], relu=True)
+            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True)
             ys.append(h)
         ctx.L = L
         ctx.save_for_backward(x, *params[0::2], *ys)
@@ -185,7 +198,7 @@ class _MlpStackFn(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
             grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l])
-            wt = pack_weight(ws[l].t())
+            wt = _kernel_weight(g, ws[l].t())
             if l > 0:
                 g = ops.dense_gated(g, wt, xin)
             elif ctx.needs_input_grad[0]:
@@ -208,7 +221,7 @@ class _MlpHeadFn(torch.autograd.Function):
         L = len(params) // 2
         ys, h = [], x
         for l in range(L):
-            h = ops.dense(h, pack_weight(params[2 * l]), params[2 * l + 1], relu=True)
+            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True)
             ys.append(h)
         ctx.L = L
         ctx.save_for_backward(x, head_w, *params[0::2], *ys)
@@ -231,7 +244,7 @@ class _MlpHeadFn(torch.autograd.Function):
                 grads[2 * l + 1] = gb_top if ctx.needs_input_grad[4 + 2 * l] else None
             else:
                 grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l])
-            wt = pack_weight(ws[l].t())
+            wt = _kernel_weight(g, ws[l].t())
             if l > 0:
                 g = ops.dense_gated(g, wt, xin)
             elif ctx.needs_input_grad[0]:

@@ -496,6 +496,12 @@ def dense_bf16x3_covers(x, weight, out=None, gate=None):
     return ok
 
 
+def dense_runs_bf16x3(x, weight, arith=None):
+    """Whether dense / dense_gated will run the bf16x3 kernel on these operands -- it packs its weight image from any strides, so the caller
+    need not lay the weight (or its transpose) out for the fp32 kernel first."""
+    return _dense_arith(arith, x, weight, None, None) == "bf16x3"
+
+
 def dense_auto_arith(M, Kd, N):
     """What arith="auto" runs for a layer shape: bf16x3 (csrc/dense_bf3.hip) when the batch fills its 256-row workgroups and its
     column blocks (128 / 208 / 256 wide, whichever pads N least) and 32-wide k-steps pad the layer by at most a third."""
@@ -508,8 +514,8 @@ def dense_auto_arith(M, Kd, N):
 
 
 def dense_bf3_image(weight):
-    """The packed bf16 image of a [N, Kd] fp32 weight (dir_dense_bf16x3_pack_f32), cached per tensor until it is modified in place
-    (tensor._version) or goes away."""
+    """The packed bf16 image of a [N, Kd] fp32 weight of ANY strides (dir_dense_bf16x3_pack_strided_f32: a `.t()` view is packed straight
+    from the storage of the tensor it transposes), cached per tensor until it is modified in place (tensor._version) or goes away."""
     import weakref
     key = weight.data_ptr()
     sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
@@ -520,7 +526,7 @@ def dense_bf3_image(weight):
     lib = _lib.load()
     nbytes = int(lib.dir_dense_bf16x3_image_bytes(Kd, N))
     img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _lib.check(lib.dir_dense_bf16x3_pack_f32(_ptr(weight), weight.stride(0), Kd, N, _ptr(img), nbytes, _stream()))
+    _lib.check(lib.dir_dense_bf16x3_pack_strided_f32(_ptr(weight), weight.stride(0), weight.stride(1), Kd, N, _ptr(img), nbytes, _stream()))
     if len(_DENSE_IMAGES) > 256:
         _DENSE_IMAGES.clear()
     _DENSE_IMAGES[key] = (weakref.ref(weight), sig, img)
@@ -550,19 +556,20 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     N = weight.shape[0]
     if weight.shape[1] != Kd or x.stride(1) != 1:
         raise ValueError("dense: x [M, Kd] with unit inner stride, weight [N, Kd]")
-    if weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
-        weight = weight.contiguous()
     if bias is not None:
         bias = _dev(bias, torch.float32, "bias").contiguous()
         if bias.numel() != N:
             raise ValueError("dense: bias [N]")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    use_bf3 = _dense_arith(arith, x, weight, out, None) == "bf16x3"
+    if not use_bf3 and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16):
+        weight = weight.contiguous()          # (the fp32 kernel reads rows with 16-byte loads; the bf16x3 image is packed from any strides)
     if post_scale is not None:
         post_scale, post_shift = _dev(post_scale, torch.float32, "post_scale").contiguous(), _dev(post_shift, torch.float32, "post_shift").contiguous()
         if post_scale.numel() != N or post_shift.numel() != N:
             raise ValueError("dense: post_scale / post_shift [N]")
-    if _dense_arith(arith, x, weight, out, None) == "bf16x3":
+    if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0,
                                                     _ptr(post_scale), _ptr(post_shift), None, 0, M, Kd, N, _ptr(out), out.stride(0), _stream()))
         return out
@@ -754,11 +761,12 @@ def dense_gated(x, weight, gate, out=None, arith=None):
     N = weight.shape[0]
     if weight.shape[1] != Kd or x.stride(1) != 1 or tuple(gate.shape) != (M, N) or gate.stride(1) != 1:
         raise ValueError("dense_gated: x [M, Kd], weight [N, Kd], gate [M, N], unit inner strides")
-    if weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
-        weight = weight.contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    if _dense_arith(arith, x, weight, out, gate) == "bf16x3":
+    use_bf3 = _dense_arith(arith, x, weight, out, gate) == "bf16x3"
+    if not use_bf3 and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16):
+        weight = weight.contiguous()
+    if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), None, 0, None, None, _ptr(gate),
                                                     gate.stride(0), M, Kd, N, _ptr(out), out.stride(0), _stream()))
         return out

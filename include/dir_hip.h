@@ -388,6 +388,10 @@ int dir_dense_affine_f32(const float* X, int64_t x_ld, const float* Wt, int64_t 
  * computed in blocks of 128 / 208 / 256 (whichever pads N least), k in steps of 32. */
 int64_t dir_dense_bf16x3_image_bytes(int Kd, int N);
 int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, int N, void* image, int64_t image_bytes, dir_stream_t stream);
+/* The same image from a weight with any element strides (w_rs between rows n, w_cs between columns k): the TRANSPOSE of a layer's kernel
+ * for its data gradient g . W is packed straight from W's storage (w_rs = 1, w_cs = W's row stride) -- no transposed copy per step. */
+int dir_dense_bf16x3_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
+                                      dir_stream_t stream);
 int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                          const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
                          dir_stream_t stream);
