@@ -38,3 +38,35 @@ for Hp, H, n in [(128, 128, 40), (26, 128, 40), (200, 200, 10)]:
     print("Hp %d H %d: forward vs fp32 kernel %.2e, reruns not bitwise equal %d / %d; data gradients vs fp32 kernel %.2e, reruns not equal %d / %d"
           % (Hp, H, e, neq, n, e2, neq2, n), flush=True)
     del xk, W, G, rx, rp, fx, fp, d0, dk, bk, b0
+
+# the first layer of a stack (xk IS x0): the pair-form forward (dir_cin_layer1_bf16x3_f32), the pair-form weight gradient
+# (dir_cin_dw_sym_bf16x3_f32) and the whole-stack backward (ops.cin_stack_backward) at the BASELINE shape
+H, n = 128, 40
+W = torch.randn((H, m * m), generator=g, device="cuda") / m
+G = torch.randn((B, H, D), generator=g, device="cuda") * 0.5
+rx, rp = ops.cin_layer(x0, x0.clone(), W, arith="bf16x3")            # a copy: the general kernel
+fx, fp = ops.cin_layer(x0, x0, W, arith="bf16x3")
+e = float(((fx - rx).abs() / (1 + rx.abs())).max())
+neq = sum(int((not torch.equal(a, fx)) or (not torch.equal(b, fp))) for a, b in (ops.cin_layer(x0, x0, W, arith="bf16x3") for _ in range(n)))
+w32 = ops.cin_dw(x0, x0, G, arith="f32")
+ws = ops.cin_dw(x0, x0, G, arith="bf16x3_sym")
+e3 = float(((ws - w32).abs() / (129.0 + w32.abs())).max())
+neq3 = sum(int(not torch.equal(ops.cin_dw(x0, x0, G, arith="bf16x3_sym"), ws)) for _ in range(n))
+print("first layer (xk is x0): pair forward vs the general bf16x3 kernel %.2e, reruns not bitwise equal %d / %d; pair weight gradient vs fp32 kernel "
+      "%.2e, reruns not equal %d / %d" % (e, neq, n, e3, neq3, n), flush=True)
+Hs = (128, 128, 128)
+Ws, hp = [], m
+for h in Hs:
+    Ws.append(torch.randn((h, hp * m), generator=g, device="cuda") / (hp * m) ** 0.5)
+    hp = h
+xks, xk = [x0], x0
+for Wk in Ws[:-1]:
+    xk, _ = ops.cin_layer(x0, xk, Wk)
+    xks.append(xk)
+gp = torch.randn((B, sum(Hs)), generator=g, device="cuda") * 0.1
+d0, dws = ops.cin_stack_backward(x0, xks, Ws, gp)
+neq4 = 0
+for _ in range(10):
+    d1, dw1 = ops.cin_stack_backward(x0, xks, Ws, gp)
+    neq4 += int((not torch.equal(d1, d0)) or any(not torch.equal(a, b) for a, b in zip(dw1, dws)))
+print("whole-stack backward (3 x 128): reruns not bitwise equal %d / 10" % neq4, flush=True)
