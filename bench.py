@@ -51,6 +51,22 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
     hp = m
     for k, h in enumerate(Hs):
         f = 2.0 * B * D * hp * m * h
+        if (k == len(Hs) - 1 and arith in ("auto", "bf16x3") and getattr(ops, "CIN_POOLED_LAST", False) and ops.cin_pooled_covers(m, D, hp)
+                and h % 4 == 0):
+            # The last layer's map only feeds its pooled sums: the sum over d is taken first (csrc/cin_pool.hip, on the vector ALUs) and the
+            # contraction with W is ONE dense product on [B, hp*m] rows -- 1/D of the definition's flops reach the matrix pipe; the backward
+            # is two more such products (dW on dense_dw's arithmetic, dZ on the dense kernel's).
+            if forward:
+                alg, pipe = alg + f, pipe + f / D * PIPE_COST["bf16x3" if ops.dense_auto_arith(B, hp * m, h) == "bf16x3" else "f32"]
+                modes["fwd%d" % (k + 1)] = "pooled (sum over d first; 1/D of the flops on the pipe)"
+            if backward:
+                dwa = ops.dense_dw_auto_arith(B, h, hp * m)
+                dza = ops.dense_auto_arith(B, h, hp * m)
+                alg = alg + 2 * f
+                pipe = pipe + f / D * (PIPE_COST["bf16x3" if dwa == "bf16x3" else "f32"] + PIPE_COST["bf16x3" if dza == "bf16x3" else "f32"])
+                modes["dx%d" % (k + 1)] = modes["dw%d" % (k + 1)] = "pooled"
+            hp = h
+            continue
         if forward:
             a = ops.cin_auto_arith(m, D, hp, h) if arith == "auto" else arith
             if k == 0 and a == "bf16x3" and getattr(ops, "CIN_L1_PAIRS", False) and 8 <= m <= 40:
@@ -959,7 +975,8 @@ def main():
         bf3 = "bf16x3" in modes.values()
         # priced on the pipe it runs on: six bf16 piece products per fp32 product (csrc/cin_bf3.hip) against the dense bf16 peak;
         # the fp32-equivalent rate (the algorithm's flops / time) is reported beside it
-        roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes, "kernel": "cin_bf3_k x3" if bf3 else "cin_k x3",
+        roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes, "kernel": ("cin_bf3_k<PAIRS> (layer 1) + cin_bf3_k (layer 2) + the last layer in its pooled form (cin_pool_z_k + dense_bf3_k)"
+                           if any(str(v).startswith("pooled") for v in modes.values()) else "cin_bf3_k x3") if bf3 else "cin_k x3",
                 "dtype": "f32 via bf16x3 split, f32 accumulate" if bf3 else "f32"}
         arith = "bf16x3" if bf3 else "f32"
         cfg.update({"m": m, "D": D, "layers": list(Hs), "outputs": "pooled [B,384]; xout of layers 1-2", "arith": arith})
@@ -978,10 +995,13 @@ def main():
             xk, _ = ops.cin_layer(x0, xk, W)
             xks.append(xk)
         gp = torch.randn((B, sum(Hs)), generator=gen, device=device) * 0.1
+        zl = []
+        ops.cin_layer(x0, xks[-1], Ws[-1], want_xout=False, z_out=zl)       # the top layer's Z = sum_d xk x0: one more saved activation
+        z_top = zl[0] if zl else None
 
         def step(i):
             if os.environ.get("DIR_CIN_STACK_NODE", "1") != "0":
-                return ops.cin_stack_backward(x0, xks, Ws, gp)       # what autograd.CinStack.backward runs
+                return ops.cin_stack_backward(x0, xks, Ws, gp, z_top=z_top)       # what autograd.CinStack.backward runs
             gx = None            # per-layer form: gradient flowing into xout of the layer being processed
             off = sum(Hs)
             for k in range(len(Hs) - 1, -1, -1):
@@ -993,7 +1013,7 @@ def main():
         # two GEMMs of the forward's size per layer: dW (reduction over rows) and T = G x W (both data gradients)
         alg, pipe, modes = cin_flops(ops, B, m, D, Hs, forward=False, backward=True)
         roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes,
-                "kernel": "cin_bf3_k<DOT> (data gradients) + cin_dw_bf3_k (weight gradient; layer 1: cin_dw_sym_bf3_k over the unordered field pairs), x3",
+                "kernel": "cin_bf3_k<DOT> (data gradients) + cin_dw_bf3_k (weight gradient; layer 1: cin_dw_sym_bf3_k over the unordered field pairs; the top layer in its pooled form: dense kernels + cin_pool_dx_k)",
                 "dtype": "f32 via bf16x3 split, f32 accumulate"}
         cfg.update({"m": m, "D": D, "layers": list(Hs)})
 

@@ -238,13 +238,14 @@ class CinStack(torch.autograd.Function):
         B = x0.shape[0]
         Hs = [int(W.shape[0]) for W in Ws]
         pooled = torch.empty((B, sum(Hs)), dtype=torch.float32, device=x0.device)
-        xks, xk, off = [], x0, 0
+        xks, xk, off, zl = [], x0, 0, []
         for k, (W, h) in enumerate(zip(Ws, Hs)):
             xks.append(xk)
-            xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Ws))
+            xk, _ = ops.cin_layer(x0, xk, W, pooled=pooled[:, off:off + h], want_xout=k + 1 < len(Ws), z_out=zl)
             off += h
         ctx.L = len(Ws)
-        ctx.save_for_backward(x0, *xks[1:], *Ws)
+        ctx.has_z = len(zl) == 1                              # the top layer ran in its pooled form: its Z [B, Hp*m] serves the backward
+        ctx.save_for_backward(x0, *xks[1:], *Ws, *zl)
         return pooled
 
     @staticmethod
@@ -252,10 +253,10 @@ class CinStack(torch.autograd.Function):
     def backward(ctx, g):
         saved = ctx.saved_tensors
         L = ctx.L
-        x0, xks, Ws = saved[0], [saved[0]] + list(saved[1:L]), list(saved[L:])
+        x0, xks, Ws = saved[0], [saved[0]] + list(saved[1:L]), list(saved[L:2 * L])
         if g.dim() != 2 or (g.shape[0] > 0 and g.stride(1) != 1):
             g = g.contiguous()
-        dx0, dWs = ops.cin_stack_backward(x0, xks, Ws, g, need_x0=ctx.needs_input_grad[0])
+        dx0, dWs = ops.cin_stack_backward(x0, xks, Ws, g, need_x0=ctx.needs_input_grad[0], z_top=saved[2 * L] if ctx.has_z else None)
         return (dx0,) + tuple(dWs)
 
 

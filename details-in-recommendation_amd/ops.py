@@ -1072,9 +1072,55 @@ def cin_auto_arith(m, D, Hp, H):
 
 
 CIN_L1_PAIRS = os.environ.get("DIR_CIN_L1_PAIRS", "1") != "0"      # development switch: 0 runs a stack's first layer on the general kernel
+CIN_POOLED_LAST = os.environ.get("DIR_CIN_POOLED_LAST", "1") != "0"  # development switch: 0 runs a pooled-only layer on the layer kernel
 
 
-def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
+def cin_pooled_covers(m, D, Hp):
+    """Shapes of the pooled-only form of a layer (csrc/cin_pool.hip + the dense kernels): m <= 64, D in {4, 8, 16, 32}, Hp * m a multiple of 4."""
+    return m <= 64 and D in (4, 8, 16, 32) and (Hp * m) % 4 == 0
+
+
+def cin_pool_z(x0, xk):
+    """Z [B, Hp*m], Z[b, i*m + j] = sum_d xk[b,i,d] x0[b,j,d] (include/dir_hip.h: dir_cin_pool_z_f32): what a layer whose map only feeds its
+    pooled sums needs of its inputs -- pooled = Z @ W.T."""
+    _dev(x0, torch.float32, "x0")
+    _dev(xk, torch.float32, "xk")
+    B, m, D = x0.shape
+    Hp = xk.shape[1]
+    if not (x0.is_contiguous() and xk.is_contiguous()) or xk.shape[0] != B or xk.shape[2] != D:
+        raise ValueError("cin_pool_z: contiguous x0 [B,m,D], xk [B,Hp,D]")
+    Z = torch.empty((B, Hp * m), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().dir_cin_pool_z_f32(_ptr(x0), _ptr(xk), m, Hp, D, B, _ptr(Z), _stream()))
+    return Z
+
+
+def cin_pool_dx(x0, xk, dZ, add_pooled=None, dx0=None):
+    """The data gradients of a pooled-only layer from dZ [B, Hp*m] = g_pooled @ W (include/dir_hip.h: dir_cin_pool_dx_f32):
+    dxk[b,i,d] = sum_j dZ[b,i,j] x0[b,j,d] (+ add_pooled[b,i]: the pooled gradient of the layer below), dx0[b,j,d] = sum_i dZ[b,i,j] xk[b,i,d]
+    (accumulated into `dx0` when given).  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
+    _dev(x0, torch.float32, "x0")
+    _dev(xk, torch.float32, "xk")
+    _dev(dZ, torch.float32, "dZ")
+    B, m, D = x0.shape
+    Hp = xk.shape[1]
+    if not (x0.is_contiguous() and xk.is_contiguous() and dZ.is_contiguous()) or tuple(dZ.shape) != (B, Hp * m):
+        raise ValueError("cin_pool_dx: contiguous x0 [B,m,D], xk [B,Hp,D], dZ [B,Hp*m]")
+    if add_pooled is not None:
+        _dev(add_pooled, torch.float32, "add_pooled")
+        if tuple(add_pooled.shape) != (B, Hp) or (B > 0 and add_pooled.stride(1) != 1):
+            raise ValueError("cin_pool_dx: add_pooled must be [B, Hp] with unit column stride")
+    acc = dx0 is not None
+    if acc and (tuple(dx0.shape) != (B, m, D) or not dx0.is_contiguous() or dx0.dtype != torch.float32):
+        raise ValueError("cin_pool_dx: dx0 must be a contiguous float32 [B, m, D] tensor")
+    dxk = torch.empty((B, Hp, D), dtype=torch.float32, device=x0.device)
+    out = dx0 if acc else torch.empty((B, m, D), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().dir_cin_pool_dx_f32(_ptr(x0), _ptr(xk), _ptr(dZ), m, Hp, D, B, _ptr(add_pooled),
+                                               add_pooled.stride(0) if add_pooled is not None and B > 0 else Hp, _ptr(dxk), _ptr(out),
+                                               1 if acc else 0, _stream()))
+    return dxk, out
+
+
+def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
     want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
@@ -1082,10 +1128,27 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None):
     both operands, six products on the bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same; raises on a shape that
     kernel does not cover); "auto" = cin_auto_arith(m, D, Hp, H); None = CIN_ARITH (env DIR_CIN_ARITH, default "auto").
     When xk IS x0 (same storage: the first layer of a stack, 8 <= m <= 40) the bf16x3 arithmetic runs over the unordered field pairs
-    (dir_cin_layer1_bf16x3_f32): the same sums in another order."""
+    (dir_cin_layer1_bf16x3_f32): the same sums in another order.
+    want_xout=False with arith "auto" / "bf16x3": the pooled sums alone are sum_{i,j} W[h,i,j] Z[b,i,j], Z = sum_d xk x0 (cin_pool_z) --
+    the sum over d first, then ONE dense product, 1/D of the layer's matrix work; z_out (a list): Z is appended to it when that form ran
+    (the backward of a stack reuses it)."""
     arith = arith or CIN_ARITH
     if arith not in ("auto", "f32", "bf16x3"):
         raise ValueError("cin_layer: arith must be 'auto', 'f32' or 'bf16x3'")
+    if (not want_xout and arith != "f32" and CIN_POOLED_LAST and x0.dim() == 3 and xk.dim() == 3 and x0.shape[0] > 0
+            and cin_pooled_covers(x0.shape[1], x0.shape[2], xk.shape[1]) and x0.is_cuda and x0.is_contiguous() and xk.is_contiguous()
+            and W.dim() == 2 and W.shape[1] == xk.shape[1] * x0.shape[1]):
+        B, H = x0.shape[0], W.shape[0]
+        Z = cin_pool_z(x0, xk)
+        if pooled is None:
+            pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
+        if pooled.stride(1) == 1 and pooled.stride(0) % 4 == 0 and pooled.data_ptr() % 16 == 0:
+            dense(Z, W, out=pooled)
+        else:
+            pooled.copy_(dense(Z, W))
+        if z_out is not None:
+            z_out.append(Z)
+        return None, pooled
     if arith == "auto":
         arith = cin_auto_arith(x0.shape[1], x0.shape[2], xk.shape[1], W.shape[0])
     _dev(x0, torch.float32, "x0")
@@ -1505,12 +1568,14 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
     return dx0, dxk, dW
 
 
-def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None):
+def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None, z_top=None):
     """Backward of a whole CIN stack (xDeepFM: pooled = concat_k sum_d X^k) given g_pooled [B, sum H_k] (unit column stride): xks[k] is
     layer k's input (xks[0] IS x0), Ws[k] [H_k, H_{k-1} * m].  -> (dx0 [B, m, D] | None, [dW_k]).  Layer by layer from the top as
     cin_layer_backward, but the sum dL/dxout_k = dL/dxk_{k+1} + g_pooled_k (broadcast over d) comes out of layer k+1's data-gradient
     kernel (its epilogue adds the pooled gradient), and every layer's dx0 share is accumulated into one tensor by the partial-sum pass:
-    no [B, H, D] add and no [B, m, D] add per layer."""
+    no [B, H, D] add and no [B, m, D] add per layer.  The TOP layer's map feeds only its pooled sums, so its backward is the pooled form
+    (csrc/cin_pool.hip): dW = g^T Z and dZ = g W on the dense kernels, the data gradients by cin_pool_dx -- 1/D of the matrix work;
+    z_top: that layer's Z from the forward (cin_layer(..., want_xout=False, z_out=...)), recomputed when None."""
     B, m, D = x0.shape
     L = len(Ws)
     Hs = [int(W.shape[0]) for W in Ws]
@@ -1525,6 +1590,17 @@ def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None):
     for k in range(L - 1, -1, -1):
         xk, W, H = xks[k], Ws[k], Hs[k]
         Hp = xk.shape[1]
+        if (G is None and arith != "f32" and CIN_POOLED_LAST and B > 0 and cin_pooled_covers(m, D, Hp) and H % 4 == 0
+                and gps[k].stride(0) % 4 == 0 and gps[k].data_ptr() % 16 == 0 and xk.is_contiguous()):
+            # the top layer in its pooled form: everything on [B, Hp*m] rows
+            gk = gps[k]
+            Z = z_top if z_top is not None else cin_pool_z(x0, xk)
+            dWs[k] = dense_dw(gk, Z)
+            if k == 0 and not need_x0:
+                break
+            dZ = dense(gk, W.t())
+            G, dx0 = cin_pool_dx(x0, xk, dZ, add_pooled=gps[k - 1] if k > 0 else None, dx0=dx0)
+            continue
         if G is None:                                        # the top layer's map feeds nothing but its pooled sums
             G = gps[k].reshape(B, H, 1).expand(B, H, D).contiguous()
         dWs[k] = cin_dw(x0, xk, G, arith=arith)

@@ -233,6 +233,16 @@ int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H);
 int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D,
                              int64_t B, float* xout, float* pooled, int64_t pooled_ld,
                              void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+/* The LAST layer of a stack, whose map feeds nothing but its pooled sums (csrc/cin_pool.hip): the sum over d commutes with the contraction,
+ *   pooled[b,h] = sum_{i,j} W[h,i,j] Z[b,i,j],   Z[b, i*m + j] = sum_d xk[b,i,d] x0[b,j,d]   -- 1/D of the layer's matrix work;
+ * dir_cin_pool_z_f32 forms Z [B, Hp*m] (the pooled sums are then dir_dense_* on (Z, W [H, Hp*m])).  Backward given g = dL/dpooled [B, H]:
+ * dW = g^T Z (dir_dense_dw_*), dZ = g W (dir_dense_*), and dir_cin_pool_dx_f32: dxk[b,i,d] = sum_j dZ[b,i,j] x0[b,j,d] (+ add_pooled[b,i],
+ * NULL: none -- the pooled gradient of the layer below), dx0[b,j,d] (+)= sum_i dZ[b,i,j] xk[b,i,d] (accumulate_dx0).
+ * m <= 64, D in {4, 8, 16, 32}; x0 / xk / dxk / dx0 16-byte aligned. */
+int dir_cin_pool_z_f32(const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, dir_stream_t stream);
+int dir_cin_pool_dx_f32(const float* x0, const float* xk, const float* dZ, int m, int Hp, int D, int64_t B, const float* add_pooled,
+                        int64_t add_pooled_ld, float* dxk, float* dx0, int accumulate_dx0, dir_stream_t stream);
+
 /* The FIRST layer of a stack (xk = x0, Hp = m) on the same recipe, over the m (m + 1) / 2 unordered field pairs: xout[b,h,d] =
  * sum_{i<=j} (W[h,i,j] + W[h,j,i] | W[h,i,i]) x0[b,i,d] x0[b,j,d] -- the pair products are formed and split inside the kernel, 351 reduction
  * slots instead of 26 x 32 at m = 26 (csrc/cin_bf3.hip, PAIRS).  8 <= m <= 40, D in {4, 8, 16, 32}; workspace:

@@ -1793,7 +1793,7 @@ def test_cin_stack_node_matches_float64_and_the_per_layer_nodes(built_lib, B, m,
     ls, ps, gxs, gws = run(True)
     ll, pl, gxl, gwl = run(False)
     _close(ls, l64, tol=1e-5)
-    assert torch.equal(ps, pl)                                          # the same forward kernels
+    _close(ps, pl, tol=1e-5)                                            # (the stack's last layer runs in its pooled form: another summation order)
     sx = float(x64.grad.abs().max())
     _close(gxs / sx, x64.grad / sx, tol=2e-5)
     _close(gxs / sx, gxl / sx, tol=2e-5)

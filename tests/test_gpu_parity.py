@@ -301,14 +301,25 @@ def test_cin_layer_bf16x3_shapes(ops, oracle, B, m, D, Hp, H):
         err_x = np.abs(bx.cpu().double().numpy() - ref_x) / (scale + np.abs(ref_x))
         err_p = np.abs(bp.cpu().double().numpy() - ref_p) / (scale + np.abs(ref_p))
         assert err_x.max() <= 1e-5 and err_p.max() <= 1e-5, (scale, err_x.max(), err_p.max())
-    # pooled-only call: bitwise the pooled sums of the full call
+    # pooled-only call: the pooled form (sum over d first, csrc/cin_pool.hip + the dense kernel) at the same bar; on the layer kernel
+    # (DIR_CIN_POOLED_LAST=0) bitwise the pooled sums of the full call
     none, only = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), want_xout=False, arith="bf16x3")
+    assert none is None
+    err_o = np.abs(only.cpu().double().numpy() - ref_p) / (scale + np.abs(ref_p))
+    assert err_o.max() <= 1e-5, err_o.max()
+    old = ops.CIN_POOLED_LAST
+    ops.CIN_POOLED_LAST = False
+    try:
+        none, only = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), want_xout=False, arith="bf16x3")
+    finally:
+        ops.CIN_POOLED_LAST = old
     assert none is None and torch.equal(only, bp)
 
 
-def test_cin_pooled_only(ops):
-    """xout = NULL (last layer of a stack): the pooled sums are bit-identical to the full call, and a
-    call with neither output is a BADARG."""
+def test_cin_pooled_only(ops, monkeypatch):
+    """xout = NULL (last layer of a stack) on the layer kernels: the pooled sums are bit-identical to the full call, and a
+    call with neither output is a BADARG.  (The default pooled-only path is the pooled form: test_cin_pooled_form_of_the_last_layer.)"""
+    monkeypatch.setattr(ops, "CIN_POOLED_LAST", False)
     rng = np.random.default_rng(77)
     for B, m, D, Hp, H in [(300, 26, 16, 26, 128), (37, 10, 8, 7, 40), (5, 3, 4, 2, 3)]:
         x0 = _dev((rng.standard_normal((B, m, D)) * 0.5).astype(np.float32))
@@ -842,4 +853,43 @@ def test_cin_first_layer_over_field_pairs(ops, oracle, B, m, D, H):
     assert torch.equal(x2, xo) and torch.equal(p2, po)
     wide = torch.zeros((B, H + 8), device="cuda")
     none, p3 = ops.cin_layer(x0, x0, W, pooled=wide[:, 4:4 + H], want_xout=False, arith="bf16x3")
-    assert none is None and torch.equal(wide[:, 4:4 + H], po) and float(wide[:, :4].abs().max()) == 0.0
+    assert none is None and float(wide[:, :4].abs().max()) == 0.0          # (pooled-only: the pooled form, another summation order)
+    assert float((wide[:, 4:4 + H] - po).abs().max()) <= 1e-5 * (1 + float(po.abs().max())) * np.sqrt(D)
+
+
+@pytest.mark.parametrize("B,m,D,Hp,H", [(300, 26, 16, 128, 128), (37, 10, 8, 8, 40), (5, 3, 4, 4, 3), (129, 26, 16, 300, 64), (64, 64, 32, 5, 36),
+                                         (4099, 12, 16, 40, 128), (20000, 26, 16, 128, 128)])
+def test_cin_pooled_form_of_the_last_layer(ops, oracle, B, m, D, Hp, H):
+    """A layer whose map only feeds its pooled sums (want_xout=False): pooled = Z W^T with Z = sum_d xk x0 (dir_cin_pool_z_f32 + the dense
+    kernels) against the double-accumulating oracle; Z itself against float64; the backward pieces (dir_cin_pool_dx_f32 with the pooled
+    gradient of the layer below added, accumulation into dx0) against float64; reruns bitwise equal."""
+    rng = np.random.default_rng(B + Hp)
+    x0n = (rng.standard_normal((B, m, D)) * 0.5).astype(np.float32)
+    xkn = (rng.standard_normal((B, Hp, D)) * 0.5).astype(np.float32)
+    Wn = (rng.standard_normal((H, Hp * m)) / np.sqrt(Hp * m)).astype(np.float32)
+    x0, xk, W = _dev(x0n), _dev(xkn), _dev(Wn)
+    zl = []
+    none, p = ops.cin_layer(x0, xk, W, want_xout=False, z_out=zl)
+    assert none is None and len(zl) == 1
+    _, ref_p = oracle.cin_layer(x0n, xkn, Wn, acc64=True)
+    assert (np.abs(p.cpu().double().numpy() - ref_p) / (1.0 + np.abs(ref_p))).max() <= 1e-5
+    z64 = torch.einsum("bid,bjd->bij", torch.from_numpy(xkn).double(), torch.from_numpy(x0n).double()).reshape(B, Hp * m)
+    assert float((zl[0].cpu().double() - z64).abs().max()) <= 2e-6 * (1 + float(z64.abs().max()))
+    assert torch.equal(ops.cin_layer(x0, xk, W, want_xout=False)[1], p) and torch.equal(ops.cin_pool_z(x0, xk), zl[0])
+    wide = torch.zeros((B, H + 5), device="cuda")                    # a pooled view that is not 16-byte aligned: through a copy
+    ops.cin_layer(x0, xk, W, pooled=wide[:, 3:3 + H], want_xout=False)
+    assert torch.equal(wide[:, 3:3 + H], p) and float(wide[:, :3].abs().max()) == 0.0
+    dZn = (rng.standard_normal((B, Hp * m)) * 0.1).astype(np.float32)
+    addn = (rng.standard_normal((B, Hp)) * 0.1).astype(np.float32)
+    accn = (rng.standard_normal((B, m, D)) * 0.1).astype(np.float32)
+    dZ, add, acc = _dev(dZn), _dev(addn), _dev(accn)
+    dxk, dx0 = ops.cin_pool_dx(x0, xk, dZ, add_pooled=add, dx0=acc)
+    assert dx0 is acc
+    d3 = torch.from_numpy(dZn).double().view(B, Hp, m)
+    rk = torch.einsum("bij,bjd->bid", d3, torch.from_numpy(x0n).double()) + torch.from_numpy(addn).double().unsqueeze(2)
+    r0 = torch.einsum("bij,bid->bjd", d3, torch.from_numpy(xkn).double()) + torch.from_numpy(accn).double()
+    assert float((dxk.cpu().double() - rk).abs().max()) <= 2e-6 * (1 + float(rk.abs().max()))
+    assert float((dx0.cpu().double() - r0).abs().max()) <= 1e-5 * (1 + float(r0.abs().max()))
+    k2, z2 = ops.cin_pool_dx(x0, xk, dZ, add_pooled=add)
+    k3, z3 = ops.cin_pool_dx(x0, xk, dZ, add_pooled=add)
+    assert torch.equal(k2, dxk) and torch.equal(k3, k2) and torch.equal(z3, z2)
