@@ -60,7 +60,7 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
                 alg, pipe = alg + f, pipe + f / D * PIPE_COST["bf16x3" if ops.dense_auto_arith(B, hp * m, h) == "bf16x3" else "f32"]
                 modes["fwd%d" % (k + 1)] = "pooled (sum over d first; 1/D of the flops on the pipe)"
             if backward:
-                dwa = ops.dense_dw_auto_arith(B, h, hp * m)
+                dwa = ops.dense_dw_auto_arith(B, hp * m, h)
                 dza = ops.dense_auto_arith(B, h, hp * m)
                 alg = alg + 2 * f
                 pipe = pipe + f / D * (PIPE_COST["bf16x3" if dwa == "bf16x3" else "f32"] + PIPE_COST["bf16x3" if dza == "bf16x3" else "f32"])

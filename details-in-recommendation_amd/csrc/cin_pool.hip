@@ -16,11 +16,12 @@
 
 namespace dir {
 
-constexpr int CP_MAXM = 64, CP_THREADS = 256;
+constexpr int CP_MAXM = 64;
+// NT threads per workgroup: 128 when the layer has at most 128 input channels (one chunk, twice the resident workgroups), else 256
 
 // Z[b, i*m + j] = sum_d xk[b,i,d] x0[b,j,d].  Thread i keeps its channel's D values in registers and walks the fields (x0 rows are LDS
 // broadcasts); the Hp x m tile goes through LDS so that the global stores are contiguous 16-byte pieces.
-template <int D>
+template <int D, int CP_THREADS>
 __global__ __launch_bounds__(CP_THREADS) void cin_pool_z_k(const float* __restrict__ x0, const float* __restrict__ xk, int m, int Hp, int64_t B,
                                                             float* __restrict__ Z) {
     extern __shared__ __attribute__((aligned(16))) float cp_smem[];
@@ -42,11 +43,15 @@ __global__ __launch_bounds__(CP_THREADS) void cin_pool_z_k(const float* __restri
                     const float4 v = *reinterpret_cast<const float4*>(xk + (b * Hp + i) * D + d);
                     xv[d] = v.x; xv[d + 1] = v.y; xv[d + 2] = v.z; xv[d + 3] = v.w;
                 }
+#pragma unroll 2
                 for (int j = 0; j < m; ++j) {
-                    float s = 0.f;
+                    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);      // four partial sums (d mod 4): four short dependent chains instead of one of D
 #pragma unroll
-                    for (int d = 0; d < D; ++d) s = fmaf(xv[d], x0s[j * D + d], s);
-                    zt[tid * zs + j] = s;
+                    for (int d = 0; d < D; d += 4) {                 // (a wave-wide broadcast read of the field's row)
+                        const float4 v = *reinterpret_cast<const float4*>(x0s + j * D + d);
+                        s.x = fmaf(xv[d], v.x, s.x); s.y = fmaf(xv[d + 1], v.y, s.y); s.z = fmaf(xv[d + 2], v.z, s.z); s.w = fmaf(xv[d + 3], v.w, s.w);
+                    }
+                    zt[tid * zs + j] = (s.x + s.y) + (s.z + s.w);
                 }
             }
             __syncthreads();
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(CP_THREADS) void cin_pool_z_k(const float* __restri
 }
 
 // dxk[b,i,d] = sum_j dZ[b,i,j] x0[b,j,d] (+ addp[b,i]);   dx0[b,j,d] (+)= sum_i dZ[b,i,j] xk[b,i,d]
-template <int D>
+template <int D, int CP_THREADS>
 __global__ __launch_bounds__(CP_THREADS) void cin_pool_dx_k(const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ dZ,
                                                              int m, int Hp, int64_t B, const float* __restrict__ addp, int64_t addp_ld,
                                                              float* __restrict__ dxk, float* __restrict__ dx0, int accumulate) {
@@ -68,12 +73,14 @@ __global__ __launch_bounds__(CP_THREADS) void cin_pool_dx_k(const float* __restr
     float* xks = zt + ((CP_THREADS * (m + 1) + 3) & ~3);    // [256 channels][D]: the chunk's xk rows (for the reduction over i)
     const int tid = threadIdx.x;
     const int zs = m + 1;
-    const int nq = m * (D / 4);                             // (field, d-quad) pairs of dx0: one thread each (nq <= 512: two rounds at most)
+    const int nq = m * (D / 4);                             // (field, d-quad) pairs of dx0: one thread each, NR rounds (nq <= 512)
+    constexpr int NR = 512 / CP_THREADS;
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         for (int e = tid; e < m * D; e += CP_THREADS) x0s[e] = x0[b * m * D + e];
-        float4 acc0[2];
-        acc0[0] = acc0[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc0[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc0[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i0 = 0; i0 < Hp; i0 += CP_THREADS) {
             const int nch = min(CP_THREADS, Hp - i0);
             __syncthreads();                                // x0s staged / the previous chunk's readers are done
@@ -95,10 +102,14 @@ __global__ __launch_bounds__(CP_THREADS) void cin_pool_dx_k(const float* __restr
                 const float a = addp ? addp[b * addp_ld + i] : 0.f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) o[d] = a;
+#pragma unroll 2
                 for (int j = 0; j < m; ++j) {
                     const float z = zt[tid * zs + j];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) o[d] = fmaf(z, x0s[j * D + d], o[d]);
+                    for (int d = 0; d < D; d += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(x0s + j * D + d);
+                        o[d] = fmaf(z, v.x, o[d]); o[d + 1] = fmaf(z, v.y, o[d + 1]); o[d + 2] = fmaf(z, v.z, o[d + 2]); o[d + 3] = fmaf(z, v.w, o[d + 3]);
+                    }
                 }
 #pragma unroll
                 for (int d = 0; d < D; d += 4)
@@ -106,22 +117,39 @@ __global__ __launch_bounds__(CP_THREADS) void cin_pool_dx_k(const float* __restr
             }
             // dx0: thread (j, d-quad) adds this chunk's channels in channel order
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < NR; ++r) {
                 const int q = tid + r * CP_THREADS;
                 if (q < nq) {
                     const int j = q / (D / 4), dq = q - j * (D / 4);
-                    float4 s = acc0[r];
-                    for (int c = 0; c < nch; ++c) {
+                    float4 s = acc0[r], s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    int c = 0;
+                    for (; c + 8 <= nch; c += 8) {                  // eight channels' LDS reads in flight; even / odd channels on two accumulator sets
+                        float z[8];
+                        float4 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            z[u] = zt[(c + u) * zs + j];
+                            v[u] = *reinterpret_cast<const float4*>(xks + (c + u) * D + 4 * dq);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u += 2) {
+                            s.x = fmaf(z[u], v[u].x, s.x); s.y = fmaf(z[u], v[u].y, s.y); s.z = fmaf(z[u], v[u].z, s.z); s.w = fmaf(z[u], v[u].w, s.w);
+                            s2.x = fmaf(z[u + 1], v[u + 1].x, s2.x); s2.y = fmaf(z[u + 1], v[u + 1].y, s2.y);
+                            s2.z = fmaf(z[u + 1], v[u + 1].z, s2.z); s2.w = fmaf(z[u + 1], v[u + 1].w, s2.w);
+                        }
+                    }
+                    for (; c < nch; ++c) {
                         const float z = zt[c * zs + j];
                         const float4 v = *reinterpret_cast<const float4*>(xks + c * D + 4 * dq);
                         s.x = fmaf(z, v.x, s.x); s.y = fmaf(z, v.y, s.y); s.z = fmaf(z, v.z, s.z); s.w = fmaf(z, v.w, s.w);
                     }
+                    s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
                     acc0[r] = s;
                 }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int q = tid + r * CP_THREADS;
             if (q < nq) {
                 float4* p = reinterpret_cast<float4*>(dx0 + b * m * D) + q;       // q = j * (D / 4) + dq: the sample's [m, D] block in order
@@ -153,17 +181,20 @@ extern "C" int dir_cin_pool_z_f32(const float* x0, const float* xk, int m, int H
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(x0 && xk && Z, "%s: null pointer", name);
     if (!(aligned16(x0) && aligned16(xk))) return fail(DIR_E_BADARG, "%s: x0 / xk must be 16-byte aligned", name);
-    const size_t sh = sizeof(float) * (size_t)(((m * D + 3) & ~3) + CP_THREADS * (m + 1));
-    const dim3 grid((unsigned)(B < 8 * kCUs ? B : 8 * kCUs));
+    const int nt = Hp <= 128 ? 128 : 256;
+    const size_t sh = sizeof(float) * (size_t)(((m * D + 3) & ~3) + nt * (m + 1));
+    const dim3 grid((unsigned)(B < 32 * kCUs ? B : 32 * kCUs));        // one sample per workgroup and turn: many small workgroups hide each other's loads
     hipStream_t st = as_stream(stream);
 #define DIR_CP_Z(DD)                                                                                              \
     do {                                                                                                          \
         static bool set = false;                                                                                  \
-        if (!set) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_z_k<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (!set) {                               /* wide layers (m = 64, D = 32) stage more than the default 64 KB */ \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_z_k<DD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_z_k<DD, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             set = true;                                                                                           \
         }                                                                                                         \
-        hipLaunchKernelGGL(cin_pool_z_k<DD>, grid, dim3(CP_THREADS), sh, st, x0, xk, m, Hp, B, Z);                \
+        if (nt == 128) hipLaunchKernelGGL((cin_pool_z_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, m, Hp, B, Z); \
+        else hipLaunchKernelGGL((cin_pool_z_k<DD, 256>), grid, dim3(256), sh, st, x0, xk, m, Hp, B, Z);           \
     } while (0)
     switch (D) {
         case 4: DIR_CP_Z(4); break;
@@ -184,17 +215,24 @@ extern "C" int dir_cin_pool_dx_f32(const float* x0, const float* xk, const float
     DIR_CHECK_ARG(x0 && xk && dZ && dxk && dx0, "%s: null pointer", name);
     DIR_CHECK_ARG(!add_pooled || add_pooled_ld >= Hp, "%s: add_pooled_ld=%lld < Hp=%d", name, (long long)add_pooled_ld, Hp);
     if (!(aligned16(x0) && aligned16(xk) && aligned16(dxk) && aligned16(dx0))) return fail(DIR_E_BADARG, "%s: x0 / xk / dxk / dx0 must be 16-byte aligned", name);
-    const size_t sh = sizeof(float) * (size_t)(((m * D + 3) & ~3) + ((CP_THREADS * (m + 1) + 3) & ~3) + CP_THREADS * D);
-    const dim3 grid((unsigned)(B < 8 * kCUs ? B : 8 * kCUs));
+    const int nt = Hp <= 128 ? 128 : 256;
+    const size_t sh = sizeof(float) * (size_t)(((m * D + 3) & ~3) + ((nt * (m + 1) + 3) & ~3) + nt * D);
+    const dim3 grid((unsigned)(B < 32 * kCUs ? B : 32 * kCUs));
     hipStream_t st = as_stream(stream);
 #define DIR_CP_DX(DD)                                                                                             \
     do {                                                                                                          \
         static bool set = false;                                                                                  \
         if (!set) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx_k<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx_k<DD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx_k<DD, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             set = true;                                                                                           \
         }                                                                                                         \
-        hipLaunchKernelGGL(cin_pool_dx_k<DD>, grid, dim3(CP_THREADS), sh, st, x0, xk, dZ, m, Hp, B, add_pooled, add_pooled_ld, dxk, dx0, accumulate_dx0); \
+        if (nt == 128)                                                                                            \
+            hipLaunchKernelGGL((cin_pool_dx_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, dZ, m, Hp, B, add_pooled, add_pooled_ld, dxk, dx0, \
+                               accumulate_dx0);                                                                   \
+        else                                                                                                      \
+            hipLaunchKernelGGL((cin_pool_dx_k<DD, 256>), grid, dim3(256), sh, st, x0, xk, dZ, m, Hp, B, add_pooled, add_pooled_ld, dxk, dx0, \
+                               accumulate_dx0);                                                                   \
     } while (0)
     switch (D) {
         case 4: DIR_CP_DX(4); break;
