@@ -41,7 +41,7 @@ b transform --workload transform --steps 100 --warmup 10 --no-cpu-baseline
 b small_batch --workload small_batch --steps 200 --warmup 20 --no-cpu-baseline
 fi
 if [ $part = lines ]; then exit 0; fi
-for w in default deepfm_full esmm_full dcn_full dcn_train deepfm_train esmm_train train_sparse sharded_1gpu cin_backward multihot_bag din din_train; do
+for w in default deepfm_full esmm_full dcn_full dcn_train deepfm_train esmm_train train_sparse sharded_1gpu cin cin_backward multihot_bag din din_train; do
     if [ $w = default ]; then a="--steps 100 --warmup 10 --no-cpu-baseline"; elif [ $w = din ] || [ $w = din_train ]; then a="--workload $w --steps 50 --warmup 10 --no-cpu-baseline"; else a="--workload $w --steps 10 --warmup 3 --no-cpu-baseline"; fi
     DIR_BENCH_NO_SECONDARY=1 bash tools/prof.sh $w -- $a > gpurun_out/prof_$w.txt 2>&1; echo "== $w"; head -5 gpurun_out/prof_$w.txt | cut -c1-150
 done
