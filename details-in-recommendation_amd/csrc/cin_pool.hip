@@ -164,6 +164,121 @@ __global__ __launch_bounds__(CP_THREADS) void cin_pool_dx_k(const float* __restr
     }
 }
 
+// The same for a layer of at most NT channels and at most 32 fields (one chunk per sample), software-pipelined: the NEXT sample's dZ rows,
+// xk rows and x0 slice are loaded into registers before the current sample is computed, so that a workgroup's turn no longer begins
+// with two dependent round trips to memory (cin_pool_dx_k moved 2.2 GB at 2.8 TB/s).
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void cin_pool_dx1_k(const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ dZ, int m,
+                                                      int Hp, int64_t B, const float* __restrict__ addp, int64_t addp_ld, float* __restrict__ dxk,
+                                                      float* __restrict__ dx0, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float cp_smem[];
+    float* x0s = cp_smem;                                   // [m][D]
+    float* zt = cp_smem + ((m * D + 3) & ~3);               // [NT channels][m + 1]
+    float* xks = zt + ((NT * (m + 1) + 3) & ~3);            // [NT channels][D]
+    constexpr int ME = 32, M0 = 32 * 32 / NT;               // dZ elements / x0 elements per thread (m <= 32, D <= 32)
+    const int tid = threadIdx.x;
+    const int zs = m + 1, nz = Hp * m, n0 = m * D;
+    const int nq = n0 / 4;                                  // (field, d-quad) pairs of dx0
+    constexpr int NR = 512 / NT;
+    int off[ME];                                            // where element tid + k * NT of a sample's [Hp, m] block goes in zt
+#pragma unroll
+    for (int k = 0; k < ME; ++k) {
+        const int e = tid + k * NT;
+        off[k] = (e / m) * zs + (e % m);
+    }
+    float pz[ME], p0[M0], pa = 0.f;
+    float4 px[D / 4];
+    auto fetch = [&](int64_t bb) {
+        const float* src = dZ + bb * nz;
+#pragma unroll
+        for (int k = 0; k < ME; ++k) {
+            const int e = tid + k * NT;
+            pz[k] = e < nz ? src[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < M0; ++k) {
+            const int e = tid + k * NT;
+            p0[k] = e < n0 ? x0[bb * n0 + e] : 0.f;
+        }
+        if (tid < Hp) {
+#pragma unroll
+            for (int d = 0; d < D; d += 4) px[d / 4] = *reinterpret_cast<const float4*>(xk + (bb * Hp + tid) * D + d);
+            pa = addp ? addp[bb * addp_ld + tid] : 0.f;
+        }
+    };
+    int64_t b = blockIdx.x;
+    if (b < B) fetch(b);
+    for (; b < B; b += gridDim.x) {
+        __syncthreads();                                    // the previous sample's LDS readers are done
+#pragma unroll
+        for (int k = 0; k < ME; ++k)
+            if (tid + k * NT < nz) zt[off[k]] = pz[k];
+#pragma unroll
+        for (int k = 0; k < M0; ++k)
+            if (tid + k * NT < n0) x0s[tid + k * NT] = p0[k];
+        const float a = pa;
+        if (tid < Hp) {
+#pragma unroll
+            for (int d = 0; d < D; d += 4) *reinterpret_cast<float4*>(xks + tid * D + d) = px[d / 4];
+        }
+        if (b + gridDim.x < B) fetch(b + gridDim.x);        // in flight under this sample's arithmetic
+        __syncthreads();
+        if (tid < Hp) {                                     // dxk row: walk the fields, x0 rows are LDS broadcasts
+            float o[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[d] = a;
+#pragma unroll 2
+            for (int j = 0; j < m; ++j) {
+                const float z = zt[tid * zs + j];
+#pragma unroll
+                for (int d = 0; d < D; d += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(x0s + j * D + d);
+                    o[d] = fmaf(z, v.x, o[d]); o[d + 1] = fmaf(z, v.y, o[d + 1]); o[d + 2] = fmaf(z, v.z, o[d + 2]); o[d + 3] = fmaf(z, v.w, o[d + 3]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; d += 4)
+                *reinterpret_cast<float4*>(dxk + (b * Hp + tid) * D + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {                      // dx0: thread (j, d-quad) adds the channels in order, eight in flight
+            const int q = tid + r * NT;
+            if (q < nq) {
+                const int j = q / (D / 4), dq = q - j * (D / 4);
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+                int c = 0;
+                for (; c + 8 <= Hp; c += 8) {
+                    float z[8];
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        z[u] = zt[(c + u) * zs + j];
+                        v[u] = *reinterpret_cast<const float4*>(xks + (c + u) * D + 4 * dq);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        s.x = fmaf(z[u], v[u].x, s.x); s.y = fmaf(z[u], v[u].y, s.y); s.z = fmaf(z[u], v[u].z, s.z); s.w = fmaf(z[u], v[u].w, s.w);
+                        s2.x = fmaf(z[u + 1], v[u + 1].x, s2.x); s2.y = fmaf(z[u + 1], v[u + 1].y, s2.y);
+                        s2.z = fmaf(z[u + 1], v[u + 1].z, s2.z); s2.w = fmaf(z[u + 1], v[u + 1].w, s2.w);
+                    }
+                }
+                for (; c < Hp; ++c) {
+                    const float z = zt[c * zs + j];
+                    const float4 v = *reinterpret_cast<const float4*>(xks + c * D + 4 * dq);
+                    s.x = fmaf(z, v.x, s.x); s.y = fmaf(z, v.y, s.y); s.z = fmaf(z, v.z, s.z); s.w = fmaf(z, v.w, s.w);
+                }
+                s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
+                float4* p = reinterpret_cast<float4*>(dx0 + b * n0) + q;
+                if (accumulate) {
+                    const float4 o = *p;
+                    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+                }
+                *p = s;
+            }
+        }
+    }
+}
+
 static int cp_check(const char* name, int m, int Hp, int D, int64_t B) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d D=%d", name, m, Hp, D);
     if (!(D == 4 || D == 8 || D == 16 || D == 32) || m > CP_MAXM)
@@ -224,10 +339,14 @@ extern "C" int dir_cin_pool_dx_f32(const float* x0, const float* xk, const float
         static bool set = false;                                                                                  \
         if (!set) {                                                                                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx_k<DD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx1_k<DD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx_k<DD, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             set = true;                                                                                           \
         }                                                                                                         \
-        if (nt == 128)                                                                                            \
+        if (Hp <= nt && m <= 32 && nt == 128)            /* one chunk per sample: the software-pipelined kernel */ \
+            hipLaunchKernelGGL((cin_pool_dx1_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, dZ, m, Hp, B, add_pooled, add_pooled_ld, dxk, dx0, \
+                               accumulate_dx0);                                                                   \
+        else if (nt == 128)                                                                                       \
             hipLaunchKernelGGL((cin_pool_dx_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, dZ, m, Hp, B, add_pooled, add_pooled_ld, dxk, dx0, \
                                accumulate_dx0);                                                                   \
         else                                                                                                      \
