@@ -362,7 +362,7 @@ def primary_line(args, wl, cfg, roof, units, world, el, dev_ms, traffic, extra):
     launch_us = dev_ms * 1e3 / args.steps
     res = {"metric": "CTR samples/sec (embedding gather + FM 2nd-order, 26-field batch 65536)", "value": units * world * args.steps / el,
            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el * 1e3 / args.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg}
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg, "world_size": world}
     ach = roof["alg_bytes"] / (launch_us * 1e-6) / 1e9
     res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                        "kernel": roof["kernel"], "alg_bytes_per_launch": roof["alg_bytes"], "avg_launch_us": launch_us}
@@ -472,6 +472,93 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
             "config": {"workload": "xdeepfm_cin_sharded", "batch_per_gpu": B, "m": F, "D": K, "layers": list(Hs), "table_rows": Vf * F}}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks HERE, one fresh child process
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, the same command line), forward rank 0's JSON line and the
+    first non-zero exit code.  This parent never imports torch and never touches the GPU: the children are ordinary child processes,
+    not re-execs of a process that initialised HIP.  A rank that cannot find its device exits non-zero (main()), which ends the job:
+    the line is never printed with fewer ranks than --gpus asked for."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ)
+    base.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                 "DIR_BENCH_LAUNCHED_BY": "bench.py"})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs between processes on these hosts
+    base.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "GROUP_RANK": "0"})
+        # rank 0's stdout carries the line (forwarded below); the other ranks print nothing on stdout by contract, and whatever a
+        # library writes there goes to this process's stderr so it cannot be mistaken for the line
+        procs.append(subprocess.Popen(cmd, env=env, cwd=os.getcwd(), stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      text=(r == 0) or None, start_new_session=True))
+    limit = float(os.environ.get("DIR_BENCH_LAUNCH_TIMEOUT", "1500"))
+    t0 = time.time()
+    rc = 0
+    out0 = []
+    import threading
+    rd = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    rd.start()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 128 - c
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, c))
+        if rc != 0 or time.time() - t0 > limit:
+            if rc == 0:
+                rc = 124
+                sys.stderr.write("bench.py: the %d-rank job did not finish within %.0f s\n" % (n, limit))
+            for r in live:                      # exactly the process groups started above
+                try:
+                    os.killpg(procs[r].pid, signal.SIGTERM)
+                except OSError:
+                    pass
+            t1 = time.time()
+            while any(procs[r].poll() is None for r in live) and time.time() - t1 < 10:
+                time.sleep(0.1)
+            for r in live:
+                if procs[r].poll() is None:
+                    try:
+                        os.killpg(procs[r].pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+            break
+        time.sleep(0.05)
+    rd.join(timeout=10)
+    lines = [l for l in out0 if l.strip()]
+    js = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l not in js:
+            sys.stderr.write(l)
+    if js:
+        try:
+            got = json.loads(js[-1])
+            if rc == 0 and got.get("n_gpus") != n:
+                sys.stderr.write("bench.py: rank 0 reported n_gpus=%r, --gpus asked for %d\n" % (got.get("n_gpus"), n))
+                rc = 5
+        except ValueError:
+            rc = rc or 5
+        if rc in (0, 3):          # 3: the primary line is complete, the config-5 secondary leg hung (see the watchdog in main())
+            sys.stdout.write(js[-1] if js[-1].endswith("\n") else js[-1] + "\n")
+            sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        rc = 5
+    return rc
+
+
 CPU_BASELINE_WORKLOADS = ("deepfm_gather_fm", "gather_only", "dcn_cross", "din", "cin")
 
 
@@ -479,8 +566,20 @@ def main():
     args = parse()
     if args.cpu_child:
         return cpu_child_main()
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)          # the parent of the N ranks: no torch, no HIP in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        # a launcher (torch.distributed.run) started a different number of ranks than --gpus names: refuse rather than print a line whose
+        # n_gpus is not what was asked for
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or run `python bench.py --gpus %d` "
+                             "and let it start the ranks itself)\n" % (args.gpus, world, args.gpus, args.gpus))
+        return 2
     cpu = None
     if world == 1 and not args.no_cpu_baseline and args.workload in CPU_BASELINE_WORKLOADS:
         cpu = CpuBaseline()         # started before torch / HIP are touched; idle (blocked on stdin) until the GPU timing is over
@@ -493,6 +592,13 @@ def main():
     backend = os.environ.get("DIR_BENCH_BACKEND", "nccl")
     if os.environ.get("DIR_BENCH_SAME_DEVICE") == "1":
         local_rank = 0
+    same_device = os.environ.get("DIR_BENCH_SAME_DEVICE") == "1"
+    ndev = torch.cuda.device_count()          # counts devices without initialising HIP on this image
+    if ndev < (1 if same_device else world):
+        sys.stderr.write("bench.py: rank %d: --gpus %d needs %d visible GPU(s), this process sees %d\n" % (rank, world, 1 if same_device else world, ndev))
+        if cpu is not None:
+            cpu.close()
+        return 4
     if world > 1:
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -1081,6 +1187,14 @@ def main():
                "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic", "config": cfg}
+        # what actually ran: the process group's size as torch.distributed reports it (not the --gpus argument), and how the ranks were started
+        res["world_size"] = dist.get_world_size() if dist.is_initialized() else 1
+        res["launcher"] = os.environ.get("DIR_BENCH_LAUNCHED_BY") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                                                                      "external" if "WORLD_SIZE" in os.environ else "single process")
+        if world > 1:
+            res["backend"] = backend + (" (exchange staged through host memory)" if os.environ.get("DIR_SHARD_HOST_STAGED") == "1" else "")
+            if "link_bytes" in roof:
+                res["per_peer_bytes_per_step"] = roof["link_bytes"]
         launch_us = dev_ms * 1e3 / args.steps
         if roof["bound"] == "xgmi":
             link = roof["link_bytes"] / (launch_us * 1e-6) / 1e9
@@ -1196,4 +1310,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
