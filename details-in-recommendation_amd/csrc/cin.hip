@@ -460,11 +460,8 @@ template <int MT, int CT, bool FP>
 static void launch_cin_one(dim3 grid, size_t shmem, hipStream_t st, const float* x0, const float* xk, const float* W,
                            int m, int Hp, int H, int D, int dshift, int hoff, int64_t R, float* xout, float* pooled,
                            int64_t pooled_ld) {
-    static bool set = false;
-    if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, FP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        set = true;
-    }
+    static LdsOnce once;
+    (void)lds_limit(once, 160 * 1024, &cin_k<MT, CT, FP>);
     hipLaunchKernelGGL((cin_k<MT, CT, FP>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
 }
 
@@ -479,11 +476,8 @@ static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* 
     if constexpr (MT == 26 && CT == 4) {
         static const int stamp_env = getenv("DIR_CIN_STAMP") ? atoi(getenv("DIR_CIN_STAMP")) : 0;
         if (stamp_env && fast_env && wvec && Hp >= cin_ic(MT)) {   // diagnostic build: cycle stamps, same arithmetic
-            static bool set = false;
-            if (!set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<26, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                set = true;
-            }
+            static LdsOnce once;
+            (void)lds_limit(once, 160 * 1024, &cin_k<26, 4, true, true>);
             hipLaunchKernelGGL((cin_k<26, 4, true, true>), grid, dim3(256), shmem, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
             return;
         }
@@ -495,11 +489,8 @@ static void launch_cin_ct(dim3 grid, size_t shmem, hipStream_t st, const float* 
         if (fast_env && w8 && Hp % 4 != 0 && Hp % 2 == 0) {
             constexpr int mp = (MT + 1) & ~1;
             const size_t sh2 = sizeof(float) * ((size_t)mp * CIN_ROWS + 2 * (size_t)2 * mp * cin_ws(CT) + 2 * (size_t)2 * CIN_ROWS);
-            static bool set = false;
-            if (!set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_k<MT, CT, true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                set = true;
-            }
+            static LdsOnce once;
+            (void)lds_limit(once, 160 * 1024, &cin_k<MT, CT, true, false, 2>);
             hipLaunchKernelGGL((cin_k<MT, CT, true, false, 2>), grid, dim3(256), sh2, st, x0, xk, W, m, Hp, H, D, dshift, hoff, R, xout, pooled, pooled_ld);
             return;
         }

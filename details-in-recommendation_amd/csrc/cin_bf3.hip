@@ -445,11 +445,8 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     const int64_t dot_block = (int64_t)pl.nkh * B * m * D;         // floats of dot partials per column block
 #define BT_LAUNCH(K, C, DOT_, FJ_, NCB, HOFF, IMG, DOTP)                                                                              \
     do {                                                                                                                              \
-        static bool set = false;                                                                                                      \
-        if (!set) {                                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<K, C, 2, DOT_, FJ_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            set = true;                                                                                                               \
-        }                                                                                                                             \
+        static LdsOnce once;                                                                                                      \
+        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_>);                                                        \
         const size_t shmem = 2 * (size_t)FJ_ * K * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                    \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, \
                            pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m);                                                        \
@@ -571,11 +568,8 @@ extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m,
     const unsigned nrb = (unsigned)((R + 255) / 256);
 #define L1_LAUNCH(C, NCB, HOFF, IMG)                                                                                                    \
     do {                                                                                                                                \
-        static bool set = false;                                                                                                        \
-        if (!set) {                                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_bf3_k<2, C, 2, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            set = true;                                                                                                                 \
-        }                                                                                                                               \
+        static LdsOnce once;                                                                                                      \
+        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true>);                                                   \
         const size_t shmem = 2 * (size_t)2 * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                            \
         hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, dshift, \
                            pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m);                              \

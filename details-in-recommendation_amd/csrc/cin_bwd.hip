@@ -538,12 +538,8 @@ struct CinDxArgs {
 
 template <int CT, int CC, int HT, int HL, int NHC>
 static void launch_cin_dx(const CinDxArgs& a, dim3 grid, int yoff) {
-    static bool set = false;
-    if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, CC, HT, HL, true, NHC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_dx_k<CT, CC, HT, HL, false, NHC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        set = true;
-    }
+    static LdsOnce once;
+    (void)lds_limit(once, 160 * 1024, &cin_dx_k<CT, CC, HT, HL, true, NHC>, &cin_dx_k<CT, CC, HT, HL, false, NHC>);
     if (a.H == (NHC == 2 ? HT + HL : HT))
         hipLaunchKernelGGL((cin_dx_k<CT, CC, HT, HL, true, NHC>), grid, dim3(256), a.shmem, a.st, a.x0, a.xk, a.Wp, a.G, a.m, a.Hp, a.H, a.D, a.dshift, yoff,
                            a.multi, a.ks_last, a.R, a.dxk, a.dx0);

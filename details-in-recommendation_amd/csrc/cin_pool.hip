@@ -302,12 +302,8 @@ extern "C" int dir_cin_pool_z_f32(const float* x0, const float* xk, int m, int H
     hipStream_t st = as_stream(stream);
 #define DIR_CP_Z(DD)                                                                                              \
     do {                                                                                                          \
-        static bool set = false;                                                                                  \
-        if (!set) {                               /* wide layers (m = 64, D = 32) stage more than the default 64 KB */ \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_z_k<DD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_z_k<DD, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            set = true;                                                                                           \
-        }                                                                                                         \
+        static LdsOnce once;                                                                                                      \
+        (void)lds_limit(once, 160 * 1024, &cin_pool_z_k<DD, 128>, &cin_pool_z_k<DD, 256>);                                        \
         if (nt == 128) hipLaunchKernelGGL((cin_pool_z_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, m, Hp, B, Z); \
         else hipLaunchKernelGGL((cin_pool_z_k<DD, 256>), grid, dim3(256), sh, st, x0, xk, m, Hp, B, Z);           \
     } while (0)
@@ -336,13 +332,8 @@ extern "C" int dir_cin_pool_dx_f32(const float* x0, const float* xk, const float
     hipStream_t st = as_stream(stream);
 #define DIR_CP_DX(DD)                                                                                             \
     do {                                                                                                          \
-        static bool set = false;                                                                                  \
-        if (!set) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx_k<DD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx1_k<DD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cin_pool_dx_k<DD, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            set = true;                                                                                           \
-        }                                                                                                         \
+        static LdsOnce once;                                                                                                      \
+        (void)lds_limit(once, 160 * 1024, &cin_pool_dx_k<DD, 128>, &cin_pool_dx1_k<DD, 128>, &cin_pool_dx_k<DD, 256>);            \
         if (Hp <= nt && m <= 32 && nt == 128)            /* one chunk per sample: the software-pipelined kernel */ \
             hipLaunchKernelGGL((cin_pool_dx1_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, dZ, m, Hp, B, add_pooled, add_pooled_ld, dxk, dx0, \
                                accumulate_dx0);                                                                   \

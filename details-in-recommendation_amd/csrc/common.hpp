@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/dir_hip.h"
 
@@ -56,6 +57,22 @@ inline int resident_blocks(K kernel, size_t shmem = 0, int block = 256) {
     const int n = per_cu * kCUs;
     if (used < 64) cache[used++] = {key, shmem, n};
     return n;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE): one LdsOnce per call site, one bit per device, set only after the
+// runtime accepted the call (two host threads racing both make the idempotent call; a process that launches on a second GPU sets it there
+// too).  -> false if the runtime refused: the launch that follows then fails and DIR_CHECK_LAUNCH reports it.
+struct LdsOnce { std::atomic<uint64_t> done{0}; };
+template <typename... Ks>
+inline bool lds_limit(LdsOnce& o, int bytes, Ks... kernels) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (o.done.load(std::memory_order_acquire) & bit) return true;
+    bool ok = true;
+    ((ok = (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) && ok), ...);
+    if (ok) o.done.fetch_or(bit, std::memory_order_release);
+    return ok;
 }
 
 inline int grid_resident(int64_t work_blocks, int resident) {

@@ -247,12 +247,8 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
     size_t shmem = sizeof(float) * 2 * (DN_MT + NT) * (KC + 4);       // 60 KB (NT = 80) / 74 KB (NT = 128) at KC = 32
     const size_t ep_bytes = sizeof(float) * 4 * 16 * (NT + 4);             // the epilogue's row staging (16 rows per wave at a time)
     if (shmem < ep_bytes) shmem = ep_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, true, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_k<NT, false, KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        attr_set = true;
-    }
+    static LdsOnce once;           // (the limit is the chip's: the first call's own size would be too small for a later, larger one)
+    (void)lds_limit(once, 160 * 1024, &dense_k<NT, true, KC>, &dense_k<NT, false, KC>);
     if (act)
         hipLaunchKernelGGL((dense_k<NT, true, KC>), dim3((unsigned)total), dim3(256), shmem, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, nb, remap, vec_out, gate, gate_ld, ps, psh);
     else

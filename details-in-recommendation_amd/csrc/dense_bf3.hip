@@ -287,11 +287,8 @@ static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const
                              const float* ps, const float* psh, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, int nks, int ncb,
                              float* Y, int64_t y_ld, const float* head_w = nullptr, float* head_part = nullptr) {
     const size_t shmem = 2 * (size_t)3 * CT * 1024;
-    static bool set = false;
-    if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_bf3_k<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        set = true;
-    }
+    static LdsOnce once;
+    (void)lds_limit(once, 160 * 1024, &dense_bf3_k<CT>);
     const int64_t ntiles = (M + DB3_ROWS - 1) / DB3_ROWS * ncb;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;         // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
     hipLaunchKernelGGL((dense_bf3_k<CT>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,

@@ -433,12 +433,9 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
     float* bpart = db ? part + (int64_t)p.nspan * N * K : nullptr;
 #define DDW_LAUNCH(KB_)                                                                                                            \
     do {                                                                                                                           \
-        static bool set = false;                                                                                                   \
+        static LdsOnce once;                                                                                                      \
         const size_t lds = 3 * (size_t)(DDW_NT + KB_) * 1024;                                                                      \
-        if (!set) {                                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_dw_bf3_k<KB_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            set = true;                                                                                                            \
-        }                                                                                                                          \
+        (void)lds_limit(once, (int)lds, &dense_dw_bf3_k<KB_>);                                                                    \
         hipLaunchKernelGGL((dense_dw_bf3_k<KB_>), dim3(grid), dim3(512), lds, st, g, g_ld, x, x_ld, M, N, K, p.nkb, p.nspan,       \
                            p.steps_per_span, p.steps, part, bpart);                                                                \
     } while (0)

@@ -1136,11 +1136,8 @@ extern "C" int dir_din_attention_pool_f32(const float* table, int K, const int64
     DinDims dm{K, T, H1, H2, 4 * K + 4, H1 + 4, H2 + 4};
     const size_t shmem = sizeof(float) * ((size_t)T * (dm.us + dm.z1s + dm.z2s) + ((T + 63) & ~63)) + sizeof(int) * (size_t)T;
     if (shmem > 160 * 1024) return fail(DIR_E_UNSUPPORTED, "dir_din_attention_pool_f32: T=%d K=%d needs %zu B of LDS (> 160 KiB)", T, K, shmem);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&din_k<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static LdsOnce once;
+    if (!lds_limit(once, 160 * 1024, &din_k<5>)) return fail(DIR_E_HIP, "dir_din_attention_pool_f32: cannot reserve 160 KiB of LDS");
     const int per_cu = (int)((160 * 1024) / shmem) < 1 ? 1 : (int)((160 * 1024) / shmem);
     dim3 grid((unsigned)(B < (int64_t)kCUs * per_cu * 4 ? B : (int64_t)kCUs * per_cu * 4));
     hipLaunchKernelGGL((din_k<5>), grid, dim3(256), shmem, as_stream(stream), table, dm, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize, B, out, scores);
@@ -1194,13 +1191,9 @@ extern "C" int dir_din_attention_pool_backward_f32(const float* table, int K, co
     if (!aligned16(table) || !aligned16(gout))
         return fail(DIR_E_BADARG, "%s: table / gout must be 16-byte aligned", name);
     hipStream_t st = as_stream(stream);
-    static bool attr_set = false;
+    static LdsOnce once;
     const size_t shmem = sizeof(DinBwdSh<64, 5, 3>);
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&din_bwd_k<64, 5, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
-            return fail(DIR_E_HIP, "%s: cannot reserve %zu B of LDS", name, shmem);
-        attr_set = true;
-    }
+    if (!lds_limit(once, (int)shmem, &din_bwd_k<64, 5, 3>)) return fail(DIR_E_HIP, "%s: cannot reserve %zu B of LDS", name, shmem);
     int nwg = (int)(B < kDinBwdMaxWg ? B : kDinBwdMaxWg);
     float* partials = static_cast<float*>(workspace);
     if (nwg > 0) {

@@ -866,13 +866,9 @@ static int din_backward_rows(const char* name, bool saved, const float* table, i
                                float*, float*, float*, int);
         const int which = bf3 ? 2 : saved ? 1 : 0;
         static const kern_t kerns[3] = {&din_rows_k<false, DinRowsSh>, &din_rows_k<true, DinRowsSh>, &din_rows_k<true, DinRowsSh3>};
-        static bool attr_set[3] = {false, false, false};
+        static LdsOnce once[3];
         const size_t shmem = bf3 ? sizeof(DinRowsSh3) : sizeof(DinRowsSh);
-        if (!attr_set[which]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[which]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
-                return fail(DIR_E_HIP, "%s: cannot reserve %zu B of LDS", name, shmem);
-            attr_set[which] = true;
-        }
+        if (!lds_limit(once[which], (int)shmem, kerns[which])) return fail(DIR_E_HIP, "%s: cannot reserve %zu B of LDS", name, shmem);
         const char* stat = getenv("DIR_DIN_STATIC");
         const bool static_split = stat && atoi(stat) != 0;
         const int slot = static_split ? -1 : (int)(rb_next_slot.fetch_add(1) % RB_SLOTS);

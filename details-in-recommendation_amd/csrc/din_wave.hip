@@ -694,14 +694,10 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
                            const float*, int, const float*, const float*, int, long long, float*, float*, int, const int64_t*, float*);
     static const kern_t kerns[2][2] = {{&din_wave_k<DinWaveSh, false>, &din_wave_k<DinWaveSh, true>},
                                        {&din_wave_k<DinWaveSh3, false>, &din_wave_k<DinWaveSh3, true>}};
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    static LdsOnce once[2][2];
     const size_t shmem = bf3 ? sizeof(DinWaveSh3) : sizeof(DinWaveSh);
     const kern_t kern = kerns[bf3][save];
-    if (!attr_set[bf3][save]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
-            return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
-        attr_set[bf3][save] = true;
-    }
+    if (!lds_limit(once[bf3][save], (int)shmem, kern)) return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
     // Up to DW_SLOTS launches may be in flight at once (distinct streams); a record is reused only after DW_SLOTS further launches.
     const char* stat = getenv("DIR_DIN_STATIC");
     const bool static_split = stat ? atoi(stat) != 0 : bf3;

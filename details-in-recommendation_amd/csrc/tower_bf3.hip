@@ -391,11 +391,8 @@ static int tower_fill(const char* name, TowerParams& p, int Kd, int L, const int
 
 template <bool GATHER>
 static int tower_launch(const char* name, const TowerParams& p, dir_stream_t stream) {
-    static bool set = false;
-    if (!set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_bf3_k<GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        set = true;
-    }
+    static LdsOnce once;
+    if (!lds_limit(once, 160 * 1024, &tower_bf3_k<GATHER>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
     const int64_t ntiles = (p.M + TW_ROWS - 1) / TW_ROWS;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;            // one persistent workgroup per CU (8 waves x 256 registers, 78 KB of LDS)
     hipLaunchKernelGGL(tower_bf3_k<GATHER>, dim3((unsigned)nwg), dim3(512), 2 * TW_BUFB, as_stream(stream), p);

@@ -142,8 +142,13 @@ class DeepFM(nn.Module):
     def _tablesets(self):
         key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
         if getattr(self, "_ts_key", None) != key:
+            ops.refuse_rebuild_under_sink(self._emb_ts, self._lin_ts)
             self._emb_ts = ops.TableSet([p.data for p in self.embedding_weights]) if len(self.embedding_weights) else None
             self._lin_ts = ops.TableSet([p.data for p in self.linear_weights]) if len(self.linear_weights) else None
+            if self._emb_ts is not None:
+                self._emb_ts.owners = list(self.embedding_weights)      # HIP updates bump the parameters' version counters (ops.mark_written)
+            if self._lin_ts is not None:
+                self._lin_ts.owners = list(self.linear_weights)
             self._ts_key = key
         return self._emb_ts, self._lin_ts
 
@@ -306,6 +311,7 @@ class DeepFM(nn.Module):
                 emb_ts = ops.TableSet.train_rows([p.data for p in self.embedding_weights], initial_accumulator_value)
                 for p, view in zip(self.embedding_weights, emb_ts.tables):
                     p.data = view
+                emb_ts.owners = list(self.embedding_weights)
                 self._emb_ts = emb_ts
                 self._ts_key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
         self._sparse_adagrad = ops.SparseAdagrad(emb_ts, lr, initial_accumulator_value).attach()

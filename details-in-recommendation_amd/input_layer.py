@@ -49,14 +49,16 @@ class InputLayer(nn.Module):
     def _tablesets(self):
         key = tuple(p.data_ptr() for p in self.embedding_weights)
         if self._ts_key != key:
+            ops.refuse_rebuild_under_sink(*[g[0] for g in getattr(self, "_groups", [])])
             self._groups = []  # (TableSet, [indices into self.emb_cols], [combiner per column], max_norm)
             seen = {}
             for i, c in enumerate(self.emb_cols):      # one launch takes one row width and one max_norm; combiners go per slot
                 seen.setdefault((c.dimension, getattr(c, "max_norm", None)), []).append(i)
 
             def close(run, mn):
-                self._groups.append((ops.TableSet([self.embedding_weights[j].data for j in run]), run,
-                                     [self.emb_cols[j].combiner for j in run], mn))
+                ts = ops.TableSet([self.embedding_weights[j].data for j in run])
+                ts.owners = [self.embedding_weights[j] for j in run]       # HIP updates bump the parameters' version counters
+                self._groups.append((ts, run, [self.emb_cols[j].combiner for j in run], mn))
 
             for (dim, mn), idxs in seen.items():
                 run = []
@@ -86,6 +88,7 @@ class InputLayer(nn.Module):
                 continue
             opts.append(ops.SparseAdam(ts, beta1, beta2, eps, clip_norm).attach())
             owned += [self.embedding_weights[i] for i in idxs]
+            opts[-1].owned = [self.embedding_weights[i] for i in idxs]          # parameter of table f of that optimiser's TableSet
         return opts, owned
 
     def _indicator(self, c, features, device, B):

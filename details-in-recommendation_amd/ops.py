@@ -79,6 +79,8 @@ class TableSet:
         # know their ids are heavily skewed should set "reuse" (see include/dir_hip.h).
         self.row_policy = "auto"
         self.nbytes = sum(int(t.shape[0]) * self.ld * 4 for t in tables)
+        self.owners = []        # tensors sharing these tables' storage under ANOTHER version counter (the nn.Parameters whose .data the
+        #                         tables are): written() bumps them too, so caches keyed on parameter._version see HIP updates
         self.grad_sink = None   # callable(ids, d_rows) consuming the gather's row gradients (see SparseAdagrad.attach)
         self.fm_sink = None     # callable(ids, d_rows | None, d_fm, field_sums): the same with the FM backward folded in
 
@@ -119,10 +121,37 @@ class TableSet:
             return STREAM_ROWS
         return 0
 
+    def written(self, *more):
+        """A raw-pointer kernel has just updated the tables (and `more`: optimiser slots) in place: see mark_written."""
+        arena = getattr(self, "arena", None)
+        if arena is not None:
+            mark_written(arena, *self.owners, *more)
+        else:
+            mark_written(*self.tables, *self.owners, *more)
+
     def refresh(self):
         """Rebuild the pointer array (after tables were re-allocated, e.g. .to())."""
         self._ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=self.device)
 
+
+
+def mark_written(*tensors):
+    """A raw-pointer kernel has just written these tensors in place: bump their autograd version counters, as an in-place torch op would
+    have.  Everything cached per weight version (DeepFM's packed serving rows, tower_image / dense_bf3_image, dense._packed_cached,
+    dense._bn_affine, DCN's cross image) keys on tensor._version, so an eval -> train -> eval loop in one process (the reference's
+    train_and_evaluate) rebuilds them after a HIP optimiser step.  Views share their base's counter."""
+    ts = [t for t in tensors if isinstance(t, torch.Tensor)]
+    if ts:
+        torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+
+def refuse_rebuild_under_sink(*tablesets):
+    """The modules rebuild their TableSets when the parameters' storage moved (.to() / .cuda() / a re-pointed .data).  A fused optimiser
+    attached to the old set (grad_sink / fm_sink) holds that set's pointers and its own slots on the old storage: dropping it silently
+    would leave those tables without any optimiser (they get no .grad either).  Refuse instead."""
+    for ts in tablesets:
+        if ts is not None and (ts.grad_sink is not None or ts.fm_sink is not None):
+            raise RuntimeError("the embedding tables moved (model.to() / .cuda() / new storage) after a fused sparse optimiser was attached to "
+                               "them: move the model first, then call fused_sparse_* / TrainStep")
 
 def _as_tableset(tables):
     return tables if isinstance(tables, TableSet) else TableSet(tables)
@@ -898,6 +927,7 @@ def adagrad_dense_(w, accum, grad, lr, eps=0.0):
         if not t.is_contiguous() or t.shape != w.shape:
             raise ValueError("adagrad_dense_: w / accum / grad must be contiguous tensors of one shape")
     _lib.check(_lib.load().dir_adagrad_dense_f32(_ptr(w), _ptr(accum), _ptr(grad), w.numel(), float(lr), float(eps), _stream()))
+    mark_written(w, accum)
     return w
 
 
@@ -909,6 +939,7 @@ def ftrl_dense_(w, accum, linear, grad, lr, l1=0.0, l2=0.0):
         if not t.is_contiguous() or t.shape != w.shape:
             raise ValueError("ftrl_dense_: w / accum / linear / grad must be contiguous tensors of one shape")
     _lib.check(_lib.load().dir_ftrl_dense_f32(_ptr(w), _ptr(accum), _ptr(linear), _ptr(grad), w.numel(), float(lr), float(l1), float(l2), _stream()))
+    mark_written(w, accum, linear)
     return w
 
 
@@ -936,6 +967,7 @@ def bn_train_stats(y, gamma, beta, moving_mean, moving_var, eps, momentum):
             raise ValueError("bn_train_stats: gamma / beta / moving statistics must be contiguous float32 [N] tensors on y's device")
     _lib.check(lib.dir_bn_train_stats_f32(_ptr(y), y.stride(0), B, N, float(eps), float(momentum), _ptr(vecs[0]), _ptr(vecs[1]), _ptr(vecs[2]),
                                           _ptr(vecs[3]), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(part), P, _stream()))
+    mark_written(moving_mean, moving_var)
     return out[0], out[1], out[2], out[3]
 
 
@@ -1711,12 +1743,20 @@ class SparseAdagrad:
         src = self._share.take(self, ids, B, sb, sf) if self._share is not None else None
         args = (_ptr(ts._ptrs), _ptr(self.acc_ptrs), ts.ld, ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad), grad.stride(0) if grad is not None else 0,
                 _ptr(fm_g), _ptr(fm_sum), self.lr, B, _ptr(self.head_base), self.total_rows, ws, need)
+        self._written()
         if src is not None:
             _lib.check(lib.dir_sparse_adagrad_sorted_rows_from_f32(*args, src, _stream()))
             return
         _lib.check(lib.dir_sparse_adagrad_sorted_rows_f32(*args, _stream()))
         if self._share is not None:
             self._share.leave(self, ids, B, sb, sf, ws)
+
+    def _written(self):
+        """The update kernels write the tables and accumulators through raw pointers: version counters bumped here (ops.mark_written)."""
+        if getattr(self.ts, "arena", None) is not None:
+            self.ts.written()
+        else:
+            self.ts.written(*self.accums)
 
     def attach(self):
         """Consume the gather's row gradients directly in backward (autograd.GatherFm): loss.backward() then
@@ -1775,6 +1815,7 @@ class SparseAdagrad:
             _lib.check(lib.dir_sparse_adagrad_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
                                                   _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
                                                   self.total_rows, _ptr(self.head), _ptr(self._next), _stream()))
+            self._written()
             return
         if B == 0:
             return
@@ -1787,6 +1828,7 @@ class SparseAdagrad:
         _lib.check(lib.dir_sparse_adagrad_sorted_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(ids), sb, sf,
                                                      _ptr(grad), grad.stride(0), self.lr, B, _ptr(self.head_base),
                                                      self.total_rows, ctypes.c_void_p(self._ws.data_ptr() + off), need, _stream()))
+        self._written()
 
     def step_payload(self, payload, grad):
         """Owner side of a sharded backward (shard.ShardedTables): payload [n] int64 (local_row * F + slot, < 0 pruned) as
@@ -1804,6 +1846,7 @@ class SparseAdagrad:
         _lib.check(lib.dir_sparse_adagrad_sorted_payload_f32(_ptr(ts.ptrs), _ptr(self.acc_ptrs), ts.F, ts.K, _ptr(payload), n,
                                                              _ptr(grad), self.lr, _ptr(self.head_base), self.total_rows, ws, need,
                                                              _stream()))
+        self._written()
 
 
 class SparseAdam:
@@ -1865,7 +1908,22 @@ class SparseAdam:
         _lib.check(lib.dir_sparse_adam_f32(_ptr(ts.ptrs), _ptr(self.m_ptrs), _ptr(self.v_ptrs), ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad),
                                            grad.stride(0), self.lr_t, self.beta1, self.beta2, self.eps, self.clip_norm, B, _ptr(self.row_base),
                                            self.total_rows, ctypes.c_void_p(self._ws.data_ptr() + off), self._ws.numel() - off, first, _stream()))
+        ts.written(*self.ms, *self.vs)
         self.steps += 1
+
+
+    def step_table_grad(self, f, grad):
+        """Table f's step from a gradient that arrived as its .grad instead of through the sink -- multi-hot / weighted columns, whose
+        backward (autograd.EmbeddingBag) returns sparse row gradients: the same tf.train.AdamOptimizer step of ALL rows (clip_by_norm on
+        the table's gradient first) on this optimiser's m / v, with torch ops (not a hot path: the one-hot lookups take the HIP update)."""
+        t, m, v = self.ts.tables[f], self.ms[f], self.vs[f]
+        g = (grad.coalesce().to_dense() if grad.is_sparse else grad).to(torch.float32)
+        if self.clip_norm > 0:
+            g = g * (self.clip_norm / torch.clamp(torch.linalg.vector_norm(g), min=self.clip_norm))
+        m.mul_(self.beta1).add_(g, alpha=1.0 - self.beta1)
+        v.mul_(self.beta2).addcmul_(g, g, value=1.0 - self.beta2)
+        t.addcdiv_(m, v.sqrt().add_(self.eps), value=-self.lr_t)
+        mark_written(*self.ts.owners[f:f + 1])
 
 
 def _sorted_ws(holder, lib, n_entries, F, K, total_rows, device):
@@ -1926,6 +1984,7 @@ class SparseFtrl:
         args = (_ptr(ts.ptrs), _ptr(self.acc_ptrs), _ptr(self.lin_ptrs), ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad), grad.stride(0), slot_stride,
                 self.lr, self.l1, self.l2, B, _ptr(self.row_base), self.total_rows, ws, need)
         src = self._share.take(self, ids, B, sb, sf) if self._share is not None else None
+        ts.written(*self.accums, *self.linears)
         if src is not None:
             _lib.check(lib.dir_sparse_ftrl_sorted_from_f32(*args, src, _stream()))
             return

@@ -281,6 +281,7 @@ class ShardedTables:
         self.side_cus = side_cus      # None: ordinary side streams; n: the lookup's two side streams are confined to n CUs each
         self._plans = {}
         self._cap = None              # the agreed slab capacity (collective mode); _cap0: its first value (the no-skew demand)
+        self._cap_train = None        # the training pipeline's own capacity (never shrunk by de-duplicated inference verdicts)
         self._cap0 = None
         self._use_exact = mode == "exact"
         self._unchecked = []          # lookups whose overflow verdict has not been read yet (check = lazy / never)
@@ -475,23 +476,31 @@ class ShardedTables:
             td = t.to(self.device)
             dist.all_reduce(td, op=dist.ReduceOp.MAX, group=self.group)
             t = td.cpu()
-        self._cap = self._cap0 = int(t[0])
+        self._cap = self._cap_train = self._cap0 = int(t[0])
         self._share0 = float(t[1]) / self.P               # an owner's share of a micro-batch without skew
 
     def _plan(self, B, slot=0):
         if self._collective():
             if self._cap is None:
                 self._agree_cap(B)
-            cap = self._cap
+            # two capacities: the training pipeline is never de-duplicated (one slab position per entry), so what de-duplicated
+            # inference lookups learn (a SMALLER capacity) must not shrink its slabs -- sharing one number made every training lookup
+            # after an inference lookup overflow and run twice
+            cap = self._cap_train if slot == "train" else self._cap
         else:
             cap = _round_up(max(B * self.F, 16), 16)      # one rank: a slab holds the whole batch, nothing can overflow
         key = (B, slot, cap)
         plan = self._plans.get(key)
         if plan is None:
-            self._plans = {k: v for k, v in self._plans.items() if k[2] == cap and (k[0] != B or k[1] != slot)}
+            def live(k):      # plans of other (batch, slot) pairs whose slabs still have the capacity in use for their kind
+                if (k[0], k[1]) == (B, slot):
+                    return False
+                return not self._collective() or k[2] == (self._cap_train if k[1] == "train" else self._cap)
+            self._plans = {k: v for k, v in self._plans.items() if live(k)}
             if len(self._plans) > 8:
                 self._plans.clear()
             plan = self._plans[key] = _Plan(self, B, cap)
+            plan.train = slot == "train"
         self.stats["cap"] = cap
         return plan
 
@@ -591,16 +600,19 @@ class ShardedTables:
         """Capacity policy after a checked lookup (inputs identical on every rank): grow to the observed demand after an overflow;
         with dedup, shrink to what de-duplication left; give up on fixed slabs (mode auto) when one owner wants more than twice
         the no-skew share -- padding every slab to that size would cost more link bytes than the exact path's host read."""
-        if plan.cap != self._cap:
+        train = getattr(plan, "train", False)
+        if plan.cap != (self._cap_train if train else self._cap):
             return                                         # a verdict about slabs that are no longer in use
         cap = plan.cap
         if over:
             cap = max(cap, _round_up(demand * 1.25 + 64, 16))
-        elif self.dedup:
+        elif self.dedup and not train:                     # only verdicts of de-duplicated lookups say what de-duplication left
             want = _round_up(demand * 1.25 + 64, 16)
             if want < 0.7 * cap:
                 cap = want
-        if cap != self._cap:
+        if train:
+            self._cap_train = cap
+        else:
             self._cap = cap
         if self.mode == "auto" and demand > 2.0 * self._share0 + 16:
             self._use_exact = True

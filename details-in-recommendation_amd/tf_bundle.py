@@ -418,7 +418,10 @@ def write_bundle(prefix, tensors, partitions=None):
             exts, start = [], 0
             for j in range(n):
                 rows = q + 1 if j < r else q
-                ext = [(start, rows)] + [(0, -1)] * (a.ndim - 1)
+                # [TF-upstream] a Saver writes what SaveSliceInfo.spec says, and that spec is "offset,length" for EVERY dimension
+                # ("0,16" for the unpartitioned axis of a [V, 16] variable), never the full-extent marker: explicit lengths in the
+                # TensorSliceProto and in the OrderedCode key
+                ext = [(start, rows)] + [(0, int(d)) for d in a.shape[1:]]
                 exts.append(ext)
                 put(encode_tensor_name_slice(name, ext), np.ascontiguousarray(a[start:start + rows]))
                 start += rows

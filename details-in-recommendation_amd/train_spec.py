@@ -259,6 +259,13 @@ class TrainStep:
             opt.lr_t = lr * math.sqrt(1.0 - self._beta2 ** t) / (1.0 - self._beta1 ** t)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        # Tables owned by the HIP Adam whose gradient did NOT go through the sink this step (multi-hot / weighted columns: their backward
+        # returns sparse .grad): the same step on the same m / v, by torch ops -- never left without an optimiser, never accumulating.
+        for opt in self.sparse_adam:
+            for f, p in enumerate(getattr(opt, "owned", ())):
+                if p.grad is not None:
+                    opt.step_table_grad(f, p.grad)
+                    p.grad = None
         touched, dense = [], []
         for p in self.params:
             g = p.grad

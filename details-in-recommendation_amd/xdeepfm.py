@@ -58,8 +58,12 @@ class XDeepFM(nn.Module):
     def _tablesets(self):
         key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
         if self._ts_key != key:
+            ops.refuse_rebuild_under_sink(getattr(self, "_emb_ts", None), getattr(self, "_lin_ts", None))
             self._emb_ts = ops.TableSet([p.data for p in self.embedding_weights])
+            self._emb_ts.owners = list(self.embedding_weights)          # HIP updates bump the parameters' version counters (ops.mark_written)
             self._lin_ts = ops.TableSet([p.data for p in self.linear_weights]) if len(self.linear_weights) else None
+            if self._lin_ts is not None:
+                self._lin_ts.owners = list(self.linear_weights)
             self._ts_key = key
         return self._emb_ts, self._lin_ts
 

@@ -1803,3 +1803,109 @@ def test_cin_stack_node_matches_float64_and_the_per_layer_nodes(built_lib, B, m,
         _close(a / sw, b / sw, tol=2e-5)
     ls2, _, gxs2, gws2 = run(True)                                      # bitwise reproducible
     assert torch.equal(gxs2, gxs) and all(torch.equal(a, b) for a, b in zip(gws2, gws))
+
+
+def _deepfm_for_eval_train_eval(batch_norm):
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    torch.manual_seed(11)
+    F, K, V = 26, 16, 400
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    return DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats], dnn_hidden_units=[400, 400],
+                  fm_embedding_size=K, batch_norm=batch_norm).cuda(), F, V
+
+
+@pytest.mark.parametrize("batch_norm,packed_rows", [(False, False), (True, False), (False, True)])
+def test_eval_train_eval_sees_the_trained_weights(built_lib, batch_norm, packed_rows):
+    """the inference caches (DeepFM's packed serving rows, tower / dense bf16x3 images, padded weight copies, folded batch
+    norm) key on tensor._version; the HIP optimisers and the training batch norm write through raw pointers.  eval -> train -> eval in one
+    process (the reference's train_and_evaluate): the second eval must equal the layer-by-layer grad-mode forward of the TRAINED model,
+    not the first eval's cached images."""
+    from dir_amd import autograd as ag, ops
+    model, F, V = _deepfm_for_eval_train_eval(batch_norm)
+    model.fused_sparse_adagrad(lr=0.05, packed=packed_rows)
+    model.fused_sparse_ftrl(lr=0.2)
+    skip = {id(p) for p in model.linear_weights} | {id(p) for p in model.embedding_weights} | {id(model.linear_bias)}
+    opt_d = ag.Adagrad([p for p in model.parameters() if id(p) not in skip], lr=0.05, initial_accumulator_value=0.1)
+    opt_l = ag.Ftrl([model.linear_bias], lr=0.2)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    B = 8192                                    # a batch the fused tower / packed rows cover
+    ids = torch.randint(0, V, (B, F), generator=gen, device="cuda")
+    feats = {"C%d" % i: ids[:, i].contiguous() for i in range(F)}
+    y = (torch.rand((B, 1), generator=gen, device="cuda") < 0.3).float()
+
+    def eval_fused():
+        model.eval()
+        with torch.no_grad():
+            return model(feats).clone()
+
+    def eval_plain():                           # the differentiable layer-by-layer forward: reads the parameters themselves
+        model.eval()
+        return model(feats).detach().clone()
+
+    e0 = eval_fused()
+    assert float((e0 - eval_plain()).abs().max()) <= 2e-5 * (1 + float(e0.abs().max()))
+    vers0 = [p._version for p in model.parameters()]
+    model.train()
+    for _ in range(3):
+        opt_d.zero_grad(set_to_none=True)
+        opt_l.zero_grad(set_to_none=True)
+        torch.nn.functional.binary_cross_entropy_with_logits(model(feats), y).backward()
+        opt_d.step()
+        opt_l.step()
+    assert all(p._version > v for p, v in zip(model.parameters(), vers0)), "a HIP update left a parameter's version counter where it was"
+    e1, p1 = eval_fused(), eval_plain()
+    assert float((p1 - e0).abs().max()) > 1e-3, "training did not move the logits: the test would pass vacuously"
+    err = float(((e1 - p1).abs() / (1 + p1.abs())).max())
+    assert err <= 2e-5, "inference after training ran on stale cached weights: %.3e" % err
+    if batch_norm:                              # the moving statistics are written by dir_bn_train_stats_f32 through detached pointers
+        assert all(b.moving_mean._version > 0 and b.moving_variance._version > 0 for b in model.bns)
+    ops.invalidate_caches()
+    assert torch.equal(eval_fused(), e1)        # a forced rebuild of the images gives the same bits: they were current
+
+
+def test_train_step_adam_with_multihot_columns_still_trains_their_tables(built_lib):
+    """TrainStep under Adam hands the embedding tables to the HIP sparse Adam, whose sink only fires for one-hot
+    batches.  A multi-hot (ragged) column's table gets its gradient as sparse .grad instead: it must take the same tf.train.AdamOptimizer
+    step (same m / v, all rows), its .grad must not accumulate, and the result must equal the DIR_TRAIN_HIP_ADAM=0 path."""
+    import os
+    from dir_amd.dcn import DeepCrossNetwork
+    from dir_amd import feature_column as fc
+
+    def build():
+        torch.manual_seed(9)
+        cols = [fc.embedding_column(fc.categorical_column_with_identity("C%02d" % i, 200), 16, combiner="mean") for i in range(4)]
+        cols += [fc.numeric_column("I00")]
+        return DeepCrossNetwork(columns=cols, cross_layer_num=2, dnn_hidden_units=[32], batch_norm=False, optimizer="Adam",
+                                optimizer_spec={"epsilon": 1e-4}, learning_rate_spec={"learning_rate": 0.01}).cuda()
+
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    B = 512
+    lens = torch.randint(0, 4, (B,), generator=gen, device="cuda")
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), lens.cumsum(0)])
+    vals = torch.randint(0, 200, (int(offs[-1]),), generator=gen, device="cuda")
+    onehot = {"C%02d" % i: torch.randint(0, 200, (B,), generator=gen, device="cuda") for i in range(4)}
+    ragged = dict(onehot)
+    for i in range(4):
+        ragged["C%02d" % i] = fc.Ragged(vals, offs)      # every embedding column multi-hot: the group's lookups take the CSR path
+    num = {"I00": torch.rand((B,), generator=gen, device="cuda")}
+    y = (torch.rand((B, 1), generator=gen, device="cuda") < 0.3).float()
+    batches = [dict(onehot, **num), dict(ragged, **num), dict(onehot, **num)]
+
+    def run(hip):
+        os.environ["DIR_TRAIN_HIP_ADAM"] = "1" if hip else "0"
+        try:
+            model = build()
+            op = model.train_step()
+            assert bool(op.sparse_adam) == hip
+            for f in batches:
+                op(torch.nn.functional.binary_cross_entropy_with_logits(model(f), y))
+            tabs = list(model.input_layer.embedding_weights)
+            assert all(t.grad is None or not hip for t in tabs), "an owned table kept a .grad"
+            return [p.detach().clone() for p in model.parameters()]
+        finally:
+            del os.environ["DIR_TRAIN_HIP_ADAM"]
+
+    a, b = run(True), run(False)
+    for x, z in zip(a, b):
+        assert float((x - z).abs().max()) <= 1e-5

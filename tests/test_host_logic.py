@@ -467,6 +467,8 @@ def test_tf_bundle_partitioned_variables_round_trip_and_key_encoding(tmp_path, b
     enc = [tb._oc_signed_increasing(v) for v in sorted(range(-70000, 70000, 997))]
     assert enc == sorted(enc)                                              # the code is order-preserving
     assert tb.encode_tensor_name_slice("a", [(0, 10), (0, -1)]).hex() == "006100010102808a807f"
+    # the form a TensorFlow Saver writes (SaveSliceInfo.spec is "offset,length" for every dimension): explicit length 16 -> 0x80 ^ 16
+    assert tb.encode_tensor_name_slice("a", [(0, 10), (0, 16)]).hex() == "006100010102808a8090"
     rng = np.random.default_rng(8)
     full = rng.standard_normal((1003, 8)).astype(np.float32)
     tensors = {"m/embedding_weights": full, "m/bias": np.arange(5, dtype=np.float32), "global_step": np.array(7, np.int64)}
@@ -481,7 +483,7 @@ def test_tf_bundle_partitioned_variables_round_trip_and_key_encoding(tmp_path, b
     assert head["shape"] == [1003, 8] and len(head["slices"]) == 4 and head["size"] == 0
     for j, ext in enumerate(head["slices"]):
         s0, e0 = div_range(1003, 4, j)
-        assert ext == [(s0, e0 - s0), (0, -1)]
+        assert ext == [(s0, e0 - s0), (0, 8)]                             # explicit extents on the unpartitioned axis too
         part = tb._parse_entry(items[tb.encode_tensor_name_slice("m/embedding_weights", ext)])
         assert part["shape"] == [e0 - s0, 8] and part["size"] == (e0 - s0) * 8 * 4
     only = tb.read_bundle(prefix, names={"m/embedding_weights"})

@@ -189,8 +189,22 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
         if train:
             st = ShardedTables(local, vocab, backend=OracleBackend(), **kw).enable_training(lr=0.05, initial_accumulator_value=0.1)
             gout = rng_b.standard_normal((B, F * K)).astype(np.float32)
+            fb0 = None
+            if opts.get("infer_first"):
+                # de-duplicated inference lookups shrink THEIR slabs; the training pipeline (never de-duplicated) keeps its own
+                # capacity.  Warm both (the skewed ids make the first training lookup grow its slabs once), then: inference, training,
+                # inference -- no lookup may overflow and run twice any more
+                for _ in range(int(opts["infer_first"])):
+                    st.lookup(torch.from_numpy(ids))
+                st.lookup_train(torch.from_numpy(ids))
+                st.lookup(torch.from_numpy(ids))
+                fb0 = st.stats["fallbacks"]
             emb = st.lookup_train(torch.from_numpy(ids))
             fwd_ok = bool(np.array_equal(emb.detach().numpy(), R.embedding_bag_onehot(full, ids)))
+            if fb0 is not None:
+                fwd_ok = fwd_ok and st.stats["fallbacks"] == fb0 and st._cap < st._cap0 <= st._cap_train
+                st.lookup(torch.from_numpy(ids))                         # ... and the next inference lookup still uses its shrunk slabs
+                fwd_ok = fwd_ok and st.stats["fallbacks"] == fb0 and st.stats["cap"] == st._cap < st._cap0
             (emb * torch.from_numpy(gout)).sum().backward()
             # reference: one synchronous Adagrad step on the FULL tables over the batches of all ranks
             allb = [None] * world
@@ -297,11 +311,12 @@ def test_sharded_lookup_matches_full_tables(world, vocab, opts):
         assert (b, w) == (B, len(vocab) * K)
 
 
-@pytest.mark.parametrize("world,vocab,opts", [(2, [10, 7, 33], None), (3, [40, 5, 64, 9], None), (3, [40, 5, 64, 9], {"partitions": [2, 1, 3, 1]})])
+@pytest.mark.parametrize("world,vocab,opts", [(2, [10, 7, 33], None), (3, [40, 5, 64, 9], None), (3, [40, 5, 64, 9], {"partitions": [2, 1, 3, 1]}),
+                                              (2, [200, 300, 100], {"dedup": True, "id_hi": 12, "chunks": 2, "B": 600, "infer_first": 3})])
 def test_sharded_training_step_matches_full_table_adagrad(world, vocab, opts):
     """lookup_train + backward over gloo: every rank's row gradients reach the owners (the forward exchange reversed) and
     the owners' shards end up equal to one synchronous Adagrad step on the full tables over all ranks' batches."""
-    _run(world, vocab, 8, 29, 777, train=True, opts=opts)
+    _run(world, vocab, 8, (opts or {}).get("B", 29), 777, train=True, opts=opts)
 
 
 def test_partitioner_slice_count_rule():
