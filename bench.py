@@ -314,47 +314,51 @@ class CpuBaseline:
             self.p.kill()
 
 
-def measured_ceilings(torch, ops_lib, tables, stream_ptr, nbytes=109_051_904, iters=12):
-    """This box's streaming ceilings, measured in this run with dir_debug_stream_{read,copy}_f32: a linear non-temporal read of
-    ~109 MB (the gather's row bytes) and a copy of the same size (read + write), each over a window that ROTATES through the
-    1.66 GB of tables so that no window is re-read before ~1.5 GB of other traffic went by (nothing is served by the 256 MiB
-    Infinity Cache).  -> GB/s of bytes moved."""
+def measured_ceilings(torch, ops_lib, slab, stream_ptr, sizes=(("at_gather_size", 109_051_904), ("asymptotic", 536_870_912)), iters=12,
+                      scratch_bytes=1 << 30):
+    """This box's streaming ceilings, measured in this run with dir_debug_stream_{read,copy}_f32 (csrc/diag.hip: 16 B per lane, four loads in
+    flight per lane, non-temporal loads): a linear read of n bytes and a copy of n bytes (read n + write n), for n = the gather's own row
+    bytes (109 MB: a ~20 us kernel, ramp and tail included -- what a kernel of the gather's size can reach) and n = 512 MB (the asymptotic
+    rate).  `slab` is ONE allocation holding all tables (1.66 GB at config 2): the source window ROTATES through it, and the destination
+    window rotates through a separate scratch of `scratch_bytes` (1 GiB), so no window is touched again before >= 0.9 GB of other traffic
+    went by -- neither side can sit in the 256 MiB Infinity Cache.  -> {label: {"bytes": n, "read_GBps": .., "copy_GBps": .., "copy_us": ..}}.
+    (round 3's version fell into a 64 MB-window branch with a fixed 64 MB destination that did fit the Infinity Cache.)"""
     import ctypes
-    n = (nbytes // 4) // 4 * 4
-    per = tables[0].numel()
-    wins = []
-    for f in range(len(tables)):          # windows inside single tables (each table is its own allocation)
-        off = 0
-        while off + n <= per:
-            wins.append((tables[f], off))
-            off += n
-    if not wins:                          # small tables (test configurations): whatever fits
-        n = per // 4 * 4
-        wins = [(t, 0) for t in tables]
-    sink = torch.zeros(4, device=tables[0].device)
-    dst = torch.empty(n, dtype=torch.float32, device=tables[0].device)
-    res = {}
-    for name in ("read", "copy"):
-        def run(i):
-            t, off = wins[i % len(wins)]
-            ptr = ctypes.c_void_p(t.data_ptr() + off * 4)
-            if name == "read":
-                rc = ops_lib.dir_debug_stream_read_f32(ptr, n, ctypes.c_void_p(sink.data_ptr()), stream_ptr)
-            else:
-                rc = ops_lib.dir_debug_stream_copy_f32(ptr, ctypes.c_void_p(dst.data_ptr()), n, stream_ptr)
-            assert rc == 0
-        for i in range(3):
-            run(i)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(iters):
-            run(3 + i)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
-        res[name] = (n * 4 * (1 if name == "read" else 2)) / (us * 1e-6) / 1e9
-    return res
+    flat = slab.reshape(-1)
+    total = flat.numel()
+    scratch = torch.empty(min(scratch_bytes, max(total * 4, 4096)) // 4, dtype=torch.float32, device=slab.device)
+    sink = torch.zeros(4, device=slab.device)
+    out = {}
+    for label, nbytes in sizes:
+        n = min(nbytes // 4, total, scratch.numel()) // 4 * 4
+        if n <= 0:
+            continue
+        src_w = [o for o in range(0, total - n + 1, n)] or [0]
+        dst_w = [o for o in range(0, scratch.numel() - n + 1, n)] or [0]
+        res = {"bytes": n * 4, "src_windows": len(src_w), "dst_windows": len(dst_w)}
+        for name in ("read", "copy"):
+            def run(i):
+                sp = ctypes.c_void_p(flat.data_ptr() + src_w[i % len(src_w)] * 4)
+                if name == "read":
+                    rc = ops_lib.dir_debug_stream_read_f32(sp, n, ctypes.c_void_p(sink.data_ptr()), stream_ptr)
+                else:
+                    rc = ops_lib.dir_debug_stream_copy_f32(sp, ctypes.c_void_p(scratch.data_ptr() + dst_w[i % len(dst_w)] * 4), n, stream_ptr)
+                assert rc == 0
+            for i in range(3):
+                run(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(iters):
+                run(3 + i)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            res[name + "_GBps"] = (n * 4 * (1 if name == "read" else 2)) / (us * 1e-6) / 1e9
+            res[name + "_us"] = us
+        out[label] = res
+    del scratch
+    return out
 
 
 def primary_line(args, wl, cfg, roof, units, world, el, dev_ms, traffic, extra):
@@ -626,7 +630,10 @@ def main():
         sigma = 1.0 / (K ** 0.5)  # [TF-upstream] embedding_column default initializer stddev
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "id_layout": args.id_layout})
         if world == 1:
-            tables = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
+            # the F tables are the reference's F separate [V, K] variables; here they are views of ONE allocation so that the ceiling
+            # probe below can stream windows larger than one table through the same memory
+            slab = torch.randn((F * V, K), generator=gen, device=device).mul_(sigma)
+            tables = [slab[f * V:(f + 1) * V] for f in range(F)]
             ts = ops.TableSet(tables)
             if args.id_dist == "zipf":
                 ts.row_policy = "reuse"
@@ -1228,26 +1235,43 @@ def main():
                 res["roofline"]["dram_side_bytes"] = dram
                 res["roofline"]["dram_side_GBps"] = dram / (launch_us * 1e-6) / 1e9
                 # (b) this box's streaming ceilings, measured now (rotating windows of the tables: nothing cache-resident)
+                # (b) this box's streaming ceilings, measured now: at the gather's own size (a ~20 us kernel: ramp and tail included) and
+                # asymptotically (512 MB windows); nothing cache-resident (see measured_ceilings)
                 import ctypes
-                ceil = measured_ceilings(torch, dir_amd.load_library(), tables, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-                res["roofline"]["measured_read_ceiling_GBps"] = ceil["read"]
-                res["roofline"]["measured_copy_ceiling_GBps"] = ceil["copy"]
-                res["roofline"]["frac_of_measured_copy_ceiling"] = ach / ceil["copy"]
-                res["roofline"]["dram_side_frac_of_measured_copy_ceiling"] = res["roofline"]["dram_side_GBps"] / ceil["copy"]
-                # (c) per-launch distribution (median + p10/p90 of >= 100 launches), outside the timed region
-                if args.steps >= 100:
-                    nl = 200
-                    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nl + 1)]
-                    evs[0].record()
-                    for i in range(nl):
-                        step(i)
-                        evs[i + 1].record()
-                    torch.cuda.synchronize()
-                    per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(nl))
-                    res["roofline"]["launch_us_median"] = per[nl // 2]
-                    res["roofline"]["launch_us_p10"] = per[nl // 10]
-                    res["roofline"]["launch_us_p90"] = per[(nl * 9) // 10]
-                    res["roofline"]["frac_at_median"] = roof["alg_bytes"] / (per[nl // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                ceil = measured_ceilings(torch, dir_amd.load_library(), slab, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                res["roofline"]["measured_ceilings"] = ceil
+                big = ceil.get("asymptotic") or next(iter(ceil.values()))
+                res["roofline"]["measured_read_ceiling_GBps"] = big["read_GBps"]
+                res["roofline"]["measured_copy_ceiling_GBps"] = big["copy_GBps"]
+                res["roofline"]["guide_copy_ceiling_GBps"] = HBM_COPY_GBS
+                res["roofline"]["frac_of_measured_copy_ceiling"] = ach / big["copy_GBps"]
+                res["roofline"]["dram_side_frac_of_measured_copy_ceiling"] = res["roofline"]["dram_side_GBps"] / big["copy_GBps"]
+                res["roofline"]["dram_side_frac_of_guide_copy_ceiling"] = res["roofline"]["dram_side_GBps"] / HBM_COPY_GBS
+                # (c) the same kernel at 1x / 2x / 4x the batch: separates the launch's ramp and tail from its steady state (the rate a
+                # 4x longer launch reaches is what the ~60 us one could reach without them)
+                if os.environ.get("DIR_BENCH_NO_SWEEP") != "1":
+                    sweep = []
+                    for mult in (1, 2, 4):
+                        Bs = B * mult
+                        sids = [torch.randint(0, V, (Bs, F), generator=gen, device=device) for _ in range(2)]
+                        so = torch.empty((Bs, F * K), dtype=torch.float32, device=device)
+                        sfm = torch.empty((Bs, 1), dtype=torch.float32, device=device)
+                        run_b = (lambda i: ops.gather_fm(ts, sids[i % 2], out=so, fm=sfm)) if wl == "deepfm_gather_fm" else \
+                                (lambda i: ops.embedding_bag(ts, sids[i % 2], out=so))
+                        for i in range(5):
+                            run_b(i)
+                        torch.cuda.synchronize()
+                        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s0.record()
+                        for i in range(40):
+                            run_b(i)
+                        s1.record()
+                        torch.cuda.synchronize()
+                        us = s0.elapsed_time(s1) * 1e3 / 40
+                        gb = roof["alg_bytes"] * mult / (us * 1e-6) / 1e9
+                        sweep.append({"batch": Bs, "avg_launch_us": us, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS})
+                        del sids, so, sfm
+                    res["roofline"]["batch_sweep"] = sweep
         else:
             # achieved = the algorithmic flops of each kernel priced on the pipe mode it executes on (PIPE_COST), in bf16-MFMA flops per
             # second, against the dense bf16 peak: the share of the step the matrix pipe needs at peak
@@ -1264,6 +1288,25 @@ def main():
                     res["roofline"][k] = roof[k]
             if "dtype" in roof:
                 res["dtype"] = roof["dtype"]
+        if world == 1 and roof["bound"] in ("hbm", "mfma"):
+            # per-launch distribution (median + p10 / p90 of >= 100 launches), at any --steps, outside the timed region: one HIP
+            # event per step on the launch stream (events inside the timed region would put a timestamp packet between the launches)
+            nl = 200 if launch_us < 2000 else 30
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(nl + 1)]
+            evs[0].record()
+            for i in range(nl):
+                step(i)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(nl))
+            res["roofline"]["launch_us_median"] = per[nl // 2]
+            res["roofline"]["launch_us_p10"] = per[nl // 10]
+            res["roofline"]["launch_us_p90"] = per[(nl * 9) // 10]
+            res["roofline"]["launch_us_samples"] = nl
+            if roof["bound"] == "hbm":
+                res["roofline"]["frac_at_median"] = roof["alg_bytes"] / (per[nl // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            else:
+                res["roofline"]["frac_at_median"] = res["roofline"]["pipe_flops_per_step"] / (per[nl // 2] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TF
         if world == 1 and wl == "deepfm_gather_fm" and args.id_dist == "uniform":
             # secondary, cache-assisted case: Zipf(1.05) ids, rows read with the cacheable policy
             import copy
