@@ -9,6 +9,7 @@
 // Fingerprint64 is farmhashna::Hash64 of FarmHash 1.1, restated from the public algorithm; checked
 // against published known answers in tests/ (lengths <= 16; longer branches have no published vector).
 #include "common.hpp"
+#include <type_traits>
 
 namespace dir {
 namespace fh {
@@ -598,6 +599,108 @@ __global__ void bucket_cap_fin_k(int32_t* __restrict__ gcount, int P, int64_t ca
     }
 }
 
+// The finalize step as a device function: wave 0 of the LAST workgroup of a bucket kernel runs it (bucket_cap2_k), so the slab headers,
+// the true demands and the verdict come out of the same launch.  Reads the counters with device-scope atomics (they were written by
+// other workgroups' atomics; nothing is cached for them) and leaves them zero.
+__device__ __forceinline__ void bucket_cap_finalize(int32_t* __restrict__ gcount, int P, int64_t cap, int64_t* __restrict__ payload,
+                                                    int64_t* __restrict__ counts, int32_t* __restrict__ overflow, int64_t* __restrict__ stat) {
+    const int o = threadIdx.x;       // 0..63
+    int over = 0, c32 = 0;
+    int64_t c = 0;
+    if (o < P) {
+        c = atomicExch(&gcount[o], 0);
+        counts[o] = c;
+        over = c > cap ? 1 : 0;
+        c32 = (int)(c < 0x7fffffff ? c : 0x7fffffff);
+    }
+    const unsigned long long any = __ballot(over);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c32 = max(c32, __shfl_xor(c32, d, 64));
+    if (o < P) payload[(int64_t)o * (cap + 1)] = (c < cap ? c : cap) | ((int64_t)c32 << 32);
+    if (o == 0) {
+        overflow[0] = any ? 1 : 0;
+        if (stat) {
+            stat[0] = any ? 1 : 0;
+            stat[1] = c32;
+        }
+    }
+}
+
+// bucket_cap_k, round 4: the same one-pass routing with (a) the finalize step inside (the last workgroup to arrive at a device-scope
+// counter writes headers / demands / verdict: one launch, no 64-thread kernel behind it) and (b) workgroups of NT = 1024 threads.
+// What bounded bucket_cap_k (24 + 4.8 us for 1.7 M ids against ~8 us of traffic) is the returning atomic every workgroup issues on
+// the P slab counters: one address retires ~90 of them per us, all 832 workgroups were resident and issued theirs together, so the
+// last one waited ~9 us with nothing else to do.  Four times the threads per workgroup = a quarter of the reservations (208 at the
+// BASELINE size: ~2.3 us of queue) at the same number of resident waves.  (Tried first and dropped: persistent 256-thread workgroups
+// with the reservation of tile t+1 in flight under the scatter of tile t -- 33-59 us: two register sets per thread cost more
+// occupancy than the overlap bought; and a __threadfence() before the arrival counter -- on gfx950 a device-scope release writes
+// the XCD's L2 back, 84 us.  Nothing but the counters crosses workgroups inside the launch, and those are device-scope atomics whose
+// results the workgroup has consumed before it arrives: no fence is needed; slabs / inv / headers are for LATER kernels.)
+template <int BK_EPT, int NT>
+__global__ __launch_bounds__(NT) void bucket_cap2_k(const int64_t* __restrict__ ids, int64_t n,
+                                                    const int64_t* __restrict__ vocab, const int32_t* __restrict__ parts,
+                                                    const int32_t* __restrict__ first, int F, int P, int64_t cap,
+                                                    int32_t* __restrict__ gcount, int64_t* __restrict__ payload,
+                                                    int64_t* __restrict__ inv, int64_t* __restrict__ counts,
+                                                    int32_t* __restrict__ overflow, int64_t* __restrict__ stat) {
+    __shared__ int cnt[64];
+    __shared__ int basev[64];
+    __shared__ FieldDiv fd[BK_MAXF];
+    __shared__ int s_last;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    for (int f = threadIdx.x; f < F && f < BK_MAXF; f += NT) fd[f] = make_fielddiv(vocab[f], parts ? parts[f] : P, first ? first[f] : 0);
+    __syncthreads();
+    constexpr int BKC_EPB = NT * BK_EPT;
+    static_assert(BKC_EPB <= 65536, "the rank inside a tile is kept in 16 bits");
+    const int64_t base = (int64_t)blockIdx.x * BKC_EPB;
+    const int f0 = (int)(base % F), p0 = (int)(base % P);
+    const int lim = (int)((n - base) < BKC_EPB ? (n - base) : BKC_EPB);
+    int orank[BK_EPT];        // owner << 16 | rank inside the tile; -1: pruned / inactive
+    int64_t pv[BK_EPT];
+#pragma unroll
+    for (int k = 0; k < BK_EPT; ++k) {
+        const int e = k * NT + threadIdx.x;
+        const bool active = e < lim;
+        int o = 0;
+        bool keep = false;
+        pv[k] = -1;
+        if (active) {
+            BK_ROUTE_ELEMENT()
+            (void)i;
+            o = oo_;
+            keep = l >= 0;
+            pv[k] = l * F + f;
+        }
+        const int rank = wave_agg_rank(cnt, o, keep);
+        orank[k] = keep ? (o << 16) | rank : -1;
+    }
+    __syncthreads();
+    if (threadIdx.x < P) basev[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&gcount[threadIdx.x], cnt[threadIdx.x]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BK_EPT; ++k) {
+        const int e = k * NT + threadIdx.x;
+        if (e >= lim) continue;
+        int64_t dst = -1;
+        if (orank[k] >= 0) {
+            const int o = orank[k] >> 16;
+            const int64_t pos = (int64_t)basev[o] + (orank[k] & 0xffff);
+            if (pos < cap) {
+                payload[(int64_t)o * (cap + 1) + 1 + pos] = pv[k];
+                dst = (int64_t)o * cap + pos;
+            }
+        }
+        inv[base + e] = dst;
+    }
+    // arrival: the last workgroup finalizes (see the header comment for why there is no fence)
+    if (threadIdx.x == 0) s_last = atomicAdd(&gcount[64], 1) == (int)gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        bucket_cap_finalize(gcount, P, cap, payload, counts, overflow, stat);
+        if (threadIdx.x == 0) gcount[64] = 0;
+    }
+}
+
 // After the id exchange: n_slabs received slabs (any number of micro-batches x P senders, `cap + 1` words apart) ->
 // stat = {1 iff some sender's demand exceeded cap, the largest demand}: the same two numbers on every rank.
 __global__ void slab_stat_k(const int64_t* __restrict__ recv, int n_slabs, int64_t cap, int64_t* __restrict__ stat) {
@@ -922,7 +1025,8 @@ extern "C" int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vo
     return DIR_OK;
 }
 
-extern "C" int64_t dir_shard_bucket_cap_workspace_bytes(int P) { return P > 0 && P <= 64 ? 64 * (int64_t)sizeof(int32_t) : 0; }
+// 64 slab counters + the arrival counter of bucket_cap2_k (+ padding): all zero before the first call, left zero by every call
+extern "C" int64_t dir_shard_bucket_cap_workspace_bytes(int P) { return P > 0 && P <= 64 ? 128 * (int64_t)sizeof(int32_t) : 0; }
 
 extern "C" int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t* vocab, const int32_t* parts, const int32_t* first,
                                     int F, int P, int64_t cap, int64_t* payload, int64_t* inv, int64_t* counts, int32_t* overflow,
@@ -932,6 +1036,25 @@ extern "C" int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t
     if ((int64_t)P * cap >= (int64_t)1 << 40) return fail(DIR_E_UNSUPPORTED, "dir_shard_bucket_cap: P*cap too large");
     hipStream_t st = as_stream(stream);
     int32_t* gcount = static_cast<int32_t*>(workspace);
+    static const int legacy = getenv("DIR_BUCKET_LEGACY") ? atoi(getenv("DIR_BUCKET_LEGACY")) : 0;      // development A/B switch
+    if (n > 0 && !legacy) {
+        static const int ept_env = getenv("DIR_BUCKET_EPT") ? atoi(getenv("DIR_BUCKET_EPT")) : 0;
+        static const int nt_env = getenv("DIR_BUCKET_NT") ? atoi(getenv("DIR_BUCKET_NT")) : 0;
+        const int nt = nt_env ? nt_env : (n <= 256 * 1024 ? 256 : 1024);
+        const int ept = ept_env ? ept_env : 4;            // (1024 x 4: 16.1 us, x 8: 18.5, x 16: 30.3 at 1.7 M ids)
+#define DIR_BK2(EPT, NT)                                                                                                              \
+    hipLaunchKernelGGL((bucket_cap2_k<EPT, NT>), dim3((unsigned)((n + NT * EPT - 1) / (NT * EPT))), dim3(NT), 0, st, ids, n, vocab, parts, first, F, \
+                       P, cap, gcount, payload, inv, counts, overflow, stat)
+        if (nt == 256 && ept <= 4) DIR_BK2(4, 256);
+        else if (nt == 256) DIR_BK2(8, 256);
+        else if (nt == 512) DIR_BK2(8, 512);
+        else if (ept <= 4) DIR_BK2(4, 1024);
+        else if (ept <= 8) DIR_BK2(8, 1024);
+        else DIR_BK2(16, 1024);
+#undef DIR_BK2
+        DIR_CHECK_LAUNCH("shard_bucket_cap");
+        return DIR_OK;
+    }
     if (n > 0) {
 #define DIR_BK(EPT)                                                                                                            \
     hipLaunchKernelGGL((bucket_cap_k<EPT>), dim3((unsigned)((n + 256 * EPT - 1) / (256 * EPT))), dim3(256), 0, st, ids, n, vocab, \
@@ -992,6 +1115,8 @@ extern "C" int dir_gather_slabs_f32(const float* const* tables, int F, int K, in
     const bool nt = (flags & DIR_GATHER_STREAM_ROWS) != 0;
     const int sanitize = (flags & DIR_SLAB_SANITIZE) ? 1 : 0;
     hipStream_t st = as_stream(stream);
+    // (round 4: a 2-D grid form without per-element divisions and with 8 row loads in flight per lane -- gather_slabs16_k -- measured
+    // 70.0 us against this kernel's 66.1 on the same box and was removed: the kernel sits at the request floor of 64-byte rows, NOTES R4.2)
     if (vec && nt) hipLaunchKernelGGL((gather_slabs_k<4, true>), grid, dim3(256), 0, st, tables, K, lps, F, recv, P, cap, sanitize, out);
     else if (vec) hipLaunchKernelGGL((gather_slabs_k<4, false>), grid, dim3(256), 0, st, tables, K, lps, F, recv, P, cap, sanitize, out);
     else if (nt) hipLaunchKernelGGL((gather_slabs_k<1, true>), grid, dim3(256), 0, st, tables, K, lps, F, recv, P, cap, sanitize, out);

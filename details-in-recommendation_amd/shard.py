@@ -118,7 +118,7 @@ class HipBackend:
 
     # ---- fixed-capacity path ------------------------------------------------------------------------------
     def new_workspace(self, device):
-        return torch.zeros(64, dtype=torch.int32, device=device)
+        return torch.zeros(128, dtype=torch.int32, device=device)      # dir_shard_bucket_cap_workspace_bytes: slab counters + arrival counter
 
     def bucket_cap(self, ids2d, cap, payload, inv, counts, overflow, workspace, stat=None, dedup=False):
         """ids2d [Bc, F] -> slabs (packed headers) + inv; dedup: inv comes back field-major (inv2d() gives the [Bc, F] view)."""

@@ -693,7 +693,7 @@ def test_fixed_capacity_bucket_and_slab_gather(built_lib, P, parts):
     vdev = torch.tensor(vocab, dtype=torch.int64, device="cuda")
     pdev = torch.tensor(pl, dtype=torch.int32, device="cuda") if parts else None
     fdev = torch.tensor(first, dtype=torch.int32, device="cuda") if parts else None
-    ws = torch.zeros(64, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(128, dtype=torch.int32, device="cuda")
     flat = torch.from_numpy(a).cuda()
     for cap in (int(true_counts.max()) + 5, max(1, int(true_counts.max()) // 2)):          # roomy, then overflowing
         payload = torch.full((P * (cap + 1),), -7, dtype=torch.int64, device="cuda")
@@ -771,7 +771,7 @@ def test_fixed_capacity_bucket_dedup(built_lib, P, B, layout):
     if layout == "fb":
         idd = idd.t().contiguous().t()                    # [B, F] view of field-major storage
     vdev = torch.tensor(vocab, dtype=torch.int64, device="cuda")
-    ws = torch.zeros(64, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(128, dtype=torch.int32, device="cuda")
     for cap in (int(uniq.max()) + 3, max(1, int(uniq.max()) // 2)):
         payload = torch.full((P * (cap + 1),), -7, dtype=torch.int64, device="cuda")
         inv = torch.full((F * B,), -9, dtype=torch.int64, device="cuda")

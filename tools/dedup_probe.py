@@ -41,7 +41,7 @@ for dist in ("uniform", "zipf"):
     inv = torch.empty(n, dtype=torch.int64, device="cuda")
     counts = torch.empty(P, dtype=torch.int64, device="cuda")
     over = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ws = torch.zeros(64, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(128, dtype=torch.int32, device="cuda")
     flat = ids.reshape(-1)
     t0 = us(lambda: ops.shard_bucket_cap(flat, vdev, P, cap, payload, inv, counts, over, ws))
     t1 = us(lambda: ops.shard_bucket_cap_dedup(ids, vdev, P, cap, payload, inv, counts, over, ws))
