@@ -16,7 +16,9 @@
 // one partial [2, L, d] and a second launch adds the partials in a fixed order (bitwise reproducible).
 #include <cstdlib>
 #include <cstring>
+#if defined(DIR_WITH_ROCPRIM_SORT)          // development builds only (A/B against the in-tree sort): tools/ab_variant.sh backward.hip rp -DDIR_WITH_ROCPRIM_SORT
 #include <rocprim/device/device_radix_sort.hpp>
+#endif
 #include "common.hpp"
 #include <type_traits>
 
@@ -715,18 +717,26 @@ __global__ __launch_bounds__(256) void adagrad_fix_k(U upd, int F, int K,
     }
 }
 
-// The (row, entry) sort.  rocprim's default onesweep configuration sorts 8 bits per pass: 4 passes for the 25-bit keys of the
-// BASELINE shape (26 x 1 M rows), each ~28 us of mostly fixed cost at 1.7 M pairs.  9 bits per pass (match ranking, 1024 x 8 tiles)
-// needs 3: 144 -> 90 us (tools/sort_probe.hip).  Used whenever it saves a pass; the result is the same stable sort.
+// The (row, entry) sort: csrc/radix_sort.hip (in-tree, kernels only).  Rounds 1-3 called rocPRIM's onesweep sort here (9 bits per pass
+// for the 25-bit keys of the BASELINE shape: 80 us of kernels + 7 hipMemsetAsync = 34 us per sort, and a HIP graph holding those memset
+// nodes faults on replay after other eager sorts have run: NOTES R4.3).  DIR_SORT=rocprim keeps that call for A/B runs.
+#if defined(DIR_WITH_ROCPRIM_SORT)
 using AdaSort9 = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 12>, rocprim::kernel_config<1024, 8>, 9,
                                                                                 rocprim::block_radix_rank_algorithm::match>, 0>;
-static hipError_t ada_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* k0, uint32_t* k1, const uint32_t* v0, uint32_t* v1, size_t n,
-                                 unsigned bits, hipStream_t st) {
+static hipError_t rocprim_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_t* k0, uint32_t* k1, const uint32_t* v0, uint32_t* v1, size_t n,
+                                     unsigned bits, hipStream_t st) {
     if (n >= ((size_t)1 << 18) && (bits + 8) / 9 < (bits + 7) / 8)     // (small inputs keep the library's own choice of algorithm)
         return rocprim::radix_sort_pairs<AdaSort9>(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, bits, st);
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, bits, st);
 }
+static bool use_rocprim_sort() {
+    static const bool v = getenv("DIR_SORT") && !strcmp(getenv("DIR_SORT"), "rocprim");
+    return v;
+}
+#else
+static bool use_rocprim_sort() { return false; }
+#endif
 
 struct AdaSortedPlan { size_t n, ntiles, off_keys[2], off_vals[2], off_carry, off_tmp, tmp_bytes, total; unsigned bits; };
 static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedPlan& p) {
@@ -740,9 +750,12 @@ static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedP
     p.off_keys[0] = take(p.n * 4); p.off_keys[1] = take(p.n * 4);
     p.off_vals[0] = take(p.n * 4); p.off_vals[1] = take(p.n * 4);
     p.off_carry = take(p.ntiles * 2 * (size_t)K * 4);
-    size_t tmp = 0;
-    if (ada_sort_pairs(nullptr, tmp, nullptr, nullptr, nullptr, nullptr, p.n, bits, (hipStream_t)0) != hipSuccess)
-        return false;
+    size_t tmp = radix_sort_temp_bytes(p.n, bits);
+#if defined(DIR_WITH_ROCPRIM_SORT)
+    size_t tmp_r = 0;
+    if (rocprim_sort_pairs(nullptr, tmp_r, nullptr, nullptr, nullptr, nullptr, p.n, bits, (hipStream_t)0) != hipSuccess) return false;
+    if (tmp_r > tmp) tmp = tmp_r;
+#endif
     p.tmp_bytes = tmp;
     p.off_tmp = take(tmp ? tmp : 256);
     p.total = off;
@@ -819,16 +832,30 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
         char* src = const_cast<char*>(static_cast<const char*>(sorted_from));
         k1 = reinterpret_cast<uint32_t*>(src + p.off_keys[1]);
         v1 = reinterpret_cast<uint32_t*>(src + p.off_vals[1]);
-    } else if (payload)
-        hipLaunchKernelGGL(adagrad_keys_payload_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, payload, nt, n, row_base,
-                           (uint32_t)total_rows, k0, v0);
-    else
-        hipLaunchKernelGGL(adagrad_keys_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, row_base,
-                           (uint32_t)total_rows, k0, v0);
+    } else {
+        // the key pass writes where the sort wants its input (an even number of digit passes starts from the second pair of buffers)
+        const bool second = !use_rocprim_sort() && radix_sort_input_buffer((size_t)n, p.bits) == 1;
+        uint32_t* kin = second ? k1 : k0;
+        uint32_t* vin = second ? v1 : v0;
+        if (payload)
+            hipLaunchKernelGGL(adagrad_keys_payload_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, payload, nt, n, row_base,
+                               (uint32_t)total_rows, kin, vin);
+        else
+            hipLaunchKernelGGL(adagrad_keys_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, ids, stride_b, stride_f, F, n, row_base,
+                               (uint32_t)total_rows, kin, vin);
+    }
     DIR_CHECK_LAUNCH(name);
-    size_t tmp = p.tmp_bytes;
-    if (!sorted_from && ada_sort_pairs(ws + p.off_tmp, tmp, k0, k1, v0, v1, (size_t)n, p.bits, st) != hipSuccess)
-        return fail(DIR_E_HIP, "%s: radix sort failed", name);
+    if (!sorted_from) {
+#if defined(DIR_WITH_ROCPRIM_SORT)
+        if (use_rocprim_sort()) {
+            size_t tmp = p.tmp_bytes;
+            if (rocprim_sort_pairs(ws + p.off_tmp, tmp, k0, k1, v0, v1, (size_t)n, p.bits, st) != hipSuccess)
+                return fail(DIR_E_HIP, "%s: radix sort failed", name);
+        } else
+#endif
+        if (radix_sort_pairs_u32(ws + p.off_tmp, k0, k1, v0, v1, (size_t)n, p.bits, st) != hipSuccess)
+            return fail(DIR_E_HIP, "%s: radix sort failed", name);
+    }
     const bool vec = (K % 4 == 0) && (grad_ld % 4 == 0) && (grad_fs % 4 == 0) && aligned16(grad) && (!fm_sum || aligned16(fm_sum));
     int lps = 1;
     while (lps < (vec ? K / 4 : K)) lps <<= 1;
@@ -995,7 +1022,7 @@ extern "C" int dir_dcn_cross_backward_f32(const float* x0, int64_t x_ld, const f
     hipStream_t st = as_stream(stream);
     if (L > 0) DIR_CHECK_ARG(gw && gb, "dir_dcn_cross_backward_f32: null pointer");
     if (B == 0) {   // no rows: the gradients are zero (otherwise the reduce kernel writes every element of gw / gb)
-        if (L > 0 && (hipMemsetAsync(gw, 0, sizeof(float) * L * d, st) != hipSuccess || hipMemsetAsync(gb, 0, sizeof(float) * L * d, st) != hipSuccess))
+        if (L > 0 && (zero_async(gw, sizeof(float) * L * d, st) != hipSuccess || zero_async(gb, sizeof(float) * L * d, st) != hipSuccess))
             return fail(DIR_E_HIP, "dir_dcn_cross_backward_f32: memset failed");
         return DIR_OK;
     }
@@ -1142,11 +1169,11 @@ extern "C" int dir_sparse_adam_f32(float* const* tables, float* const* ms, float
     const int64_t mark_bytes = (total_rows + 255) & ~(int64_t)255;
     char* sorted_ws = ws + 512 + mark_bytes;
     const int64_t sorted_bytes = workspace_bytes - 512 - mark_bytes;
-    if (first_call && hipMemsetAsync(mark, 0, (size_t)mark_bytes, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+    if (first_call && zero_async(mark, (size_t)mark_bytes, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
     if (B > 0) {
         const bool clip = clip_norm > 0.f;
         if (clip) {
-            if (hipMemsetAsync(norm2, 0, 512, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+            if (zero_async(norm2, 512, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
             const int rc = sparse_sorted_update(name, AdamNormUpd{norm2}, F, K, ids, stride_b, stride_f, grad, grad_ld, (int64_t)K, B, row_base,
                                                 total_rows, sorted_ws, sorted_bytes, stream);
             if (rc != DIR_OK) return rc;

@@ -602,7 +602,7 @@ extern "C" int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, 
     if (Kd >= ((int64_t)1 << 30)) return fail(DIR_E_UNSUPPORTED, "dir_cin_dw_f32: Hp*m too large");
     hipStream_t st = as_stream(stream);
     if (B == 0) {
-        if (!accumulate && hipMemsetAsync(dW, 0, n * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "dir_cin_dw_f32: memset failed");
+        if (!accumulate && zero_async(dW, n * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "dir_cin_dw_f32: memset failed");
         return DIR_OK;
     }
     int dshift = 0;
@@ -651,7 +651,7 @@ extern "C" int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp,
     const int ht = nhc == 2 ? 128 : ((H + 31) / 32) * 32;      // slice rows follow H in steps of 32: H = 200 -> 128 + 96, not 2 x 128
     const int hl = nhc == 2 ? ((H - 128 + 31) / 32) * 32 : ht;
     hipStream_t st = as_stream(stream);
-    if (ncb > 1 && hipMemsetAsync(dx0, 0, sizeof(float) * (size_t)B * m * D, st) != hipSuccess)
+    if (ncb > 1 && zero_async(dx0, sizeof(float) * (size_t)B * m * D, st) != hipSuccess)
         return fail(DIR_E_HIP, "dir_cin_dx_f32: memset failed");          // the two column blocks ADD their dx0 shares
     const int rows_last = nhc == 2 ? H - 128 : H;
     CinDxArgs a{x0, xk, Wp, G, m, Hp, H, D, dshift, ncb > 1 ? 1 : 0, ((rows_last + 3) / 4) * 2, R, dxk, dx0,

@@ -239,7 +239,7 @@ extern "C" int dir_cin_dw_sym_bf16x3_f32(const float* x0, const float* G, int m,
     hipStream_t st = as_stream(stream);
     const int64_t n = (int64_t)H * m * m;
     if (B == 0) {                                    // an empty batch has a zero gradient (empty operands have no storage: null allowed)
-        if (!accumulate && hipMemsetAsync(dW, 0, n * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (!accumulate && zero_async(dW, n * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
         return DIR_OK;
     }
     DIR_CHECK_ARG(x0 && G && workspace, "%s: null pointer", name);

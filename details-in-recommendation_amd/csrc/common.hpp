@@ -80,6 +80,14 @@ inline int grid_resident(int64_t work_blocks, int resident) {
     return g < 1 ? 1 : (int)g;
 }
 
+// csrc/radix_sort.hip: the in-tree stable LSD radix sort of (uint32 key, uint32 value) pairs -- kernel launches only, so it can sit inside a
+// HIP-graph capture (rocPRIM's sort issues hipMemsetAsync: memset nodes, see that file's header) -- and zero fills as kernels.
+size_t radix_sort_temp_bytes(size_t n, unsigned bits);
+int radix_sort_input_buffer(size_t n, unsigned bits);       // 0: the input pairs go to k0 / v0, 1: to k1 / v1; sorted pairs always land in k1 / v1
+hipError_t radix_sort_pairs_u32(void* tmp, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, unsigned bits, hipStream_t st);
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st);                                                // p, bytes: multiples of 4
+hipError_t zero_2d_async(void* p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t st);      // as hipMemset2DAsync(.., 0, ..)
+
 // csrc/din_wave.hip: the wave-per-sample DIN forward for the (K = 64, H1 <= 80, H2 <= 48, T <= 64) shape class
 bool din_wave_covers(int K, int T, int H1, int H2);
 int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,

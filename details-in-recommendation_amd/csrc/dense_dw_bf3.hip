@@ -379,8 +379,8 @@ extern "C" int dir_dense_dw_small_f32(const float* g, int64_t g_ld, const float*
                   (long long)dw_ld);
     hipStream_t st = as_stream(stream);
     if (M == 0) {
-        if (hipMemset2DAsync(dW, dw_ld * sizeof(float), 0, K * sizeof(float), N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
-        if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (zero_2d_async(dW, dw_ld * sizeof(float), K * sizeof(float), N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (db && zero_async(db, N * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
         return DIR_OK;
     }
     DIR_CHECK_ARG(g && x && workspace && g_ld >= N && x_ld >= K, "%s: null pointer or row stride smaller than the width", name);
@@ -417,8 +417,8 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
                   (long long)dw_ld);
     hipStream_t st = as_stream(stream);
     if (M == 0) {                                    // an empty batch has a zero gradient (empty operands have no storage: null allowed)
-        if (hipMemset2DAsync(dW, dw_ld * sizeof(float), 0, K * sizeof(float), N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
-        if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (zero_2d_async(dW, dw_ld * sizeof(float), K * sizeof(float), N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (db && zero_async(db, N * sizeof(float), st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
         return DIR_OK;
     }
     DIR_CHECK_ARG(g && x && workspace && g_ld >= N && x_ld >= K, "%s: null pointer or row stride smaller than the width", name);

@@ -605,7 +605,7 @@ extern "C" int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, co
                              dir_stream_t stream) {
     DIR_CHECK_ARG(vocab && ids && bad_count && F > 0 && B >= 0, "dir_check_ids: bad argument");
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess) return fail(DIR_E_HIP, "dir_check_ids: memset failed");
+    if (zero_async(bad_count, sizeof(int32_t), st) != hipSuccess) return fail(DIR_E_HIP, "dir_check_ids: memset failed");
     if (B == 0) return DIR_OK;
     dim3 grid(grid_for((B * F + 255) / 256));
     hipLaunchKernelGGL(check_ids_k, grid, dim3(256), 0, st, vocab, F, ids, offsets, stride_b, stride_f, B, bad_count);

@@ -196,7 +196,7 @@ extern "C" int dir_units1_backward_f32(const float* g, const float* w, const flo
     DIR_CHECK_ARG(dw, "%s: null pointer", name);
     hipStream_t st = as_stream(stream);
     if (B == 0) {
-        if (hipMemsetAsync(dw, 0, sizeof(float) * N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
+        if (zero_async(dw, sizeof(float) * N, st) != hipSuccess) return fail(DIR_E_HIP, "%s: memset failed", name);
         return DIR_OK;
     }
     DIR_CHECK_ARG(g && w && x && partials, "%s: null pointer", name);

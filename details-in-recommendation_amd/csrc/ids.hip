@@ -1010,7 +1010,7 @@ extern "C" int dir_shard_bucket(const int64_t* ids, int64_t n, const int64_t* vo
     DIR_CHECK_ARG(counts && starts, "dir_shard_bucket: null pointer");
     hipStream_t st = as_stream(stream);
     if (n == 0) {
-        if (hipMemsetAsync(counts, 0, sizeof(int64_t) * P, st) != hipSuccess || hipMemsetAsync(starts, 0, sizeof(int64_t) * P, st) != hipSuccess)
+        if (zero_async(counts, sizeof(int64_t) * P, st) != hipSuccess || zero_async(starts, sizeof(int64_t) * P, st) != hipSuccess)
             return fail(DIR_E_HIP, "dir_shard_bucket: memset failed");
         return DIR_OK;
     }

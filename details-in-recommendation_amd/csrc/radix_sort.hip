@@ -1,0 +1,287 @@
+// radix_sort.hip -- stable LSD radix sort of (uint32 key, uint32 value) pairs for gfx950, in-tree, graph-capturable.
+//
+// What it is for: the (row, entry) sort in front of every sorted sparse update (csrc/backward.hip: Adagrad / FTRL / Adam on the
+// embedding tables -- the reference's optimisers, models/DeepFM/deepFM.py:58,61, models/DeepCrossNetwork/DeepCrossNetwork.py:264-290).
+// Rounds 1-3 called rocPRIM's onesweep sort there.  Two things were wrong with that call at 1.7 M pairs (B 65 536 x 26 slots):
+//   * it issues 7 hipMemsetAsync per sort (34 us of a 335 us step), and
+//   * those memsets make a captured HIP graph unusable: a hipGraph holding memset nodes faults on replay once enough EAGER memsets
+//     (another optimiser's sorts) have run in between (profiles/NOTES.md R4.3: tools/graph_part_probe.py isolates it) -- so no
+//     training step that sorts could be replayed from a graph.
+// This sort launches kernels only: init (zero the histograms, tile states and tickets), one histogram pass over the keys for ALL
+// digit positions, then one kernel per digit (8 or 9 bits; 25-bit keys: 3 x 9) with a decoupled look-back over the tiles
+// (Merrill & Garland's single-pass scan, as "onesweep" uses it):
+//   tile = 1024 threads x 8 keys (16 waves, each owning 512 consecutive keys, lane-strided: coalesced loads, memory order = (i, lane));
+//   rank inside the wave by match-any (RB ballots per key) against a per-wave LDS histogram, exclusive scan over the waves per digit,
+//   publish the tile's digit counts (flag | count in ONE 32-bit word: no fence needed), sum the predecessors' counts until a tile
+//   with an inclusive prefix is met, publish the inclusive prefix, scatter.
+// Tiles take their index from a ticket (atomic counter), so a tile only ever waits for tiles that started before it.
+// Stable: equal keys keep their input order (the sparse updates sum a row's entries in entry order: bitwise reproducible results).
+#include "common.hpp"
+
+namespace dir {
+
+namespace {
+
+constexpr int RS_NT = 1024;                 // threads per tile
+constexpr int RS_ITEMS = 8;                 // keys per thread
+constexpr int RS_TILE = RS_NT * RS_ITEMS;   // 8192
+constexpr int RS_NW = RS_NT / 64;           // 16 waves
+constexpr int RS_MAXPASS = 4;
+constexpr uint32_t RS_AGG = 1u << 30, RS_INCL = 2u << 30, RS_VAL = (1u << 30) - 1u;
+
+struct RsLayout {                           // offsets into the temp storage (bytes)
+    size_t hist, ticket, status, total;
+    int rb, passes, bins;
+    int64_t ntiles;
+};
+
+RsLayout rs_layout(size_t n, unsigned bits) {
+    RsLayout L;
+    if (bits < 1) bits = 1;
+    if (bits > 32) bits = 32;
+    const int p8 = (int)((bits + 7) / 8), p9 = (int)((bits + 8) / 9);
+    L.rb = p9 < p8 ? 9 : 8;
+    L.passes = L.rb == 9 ? p9 : p8;
+    L.bins = 1 << L.rb;
+    L.ntiles = (int64_t)((n + RS_TILE - 1) / RS_TILE);
+    if (L.ntiles < 1) L.ntiles = 1;
+    size_t off = 0;
+    auto take = [&](size_t b) { const size_t o = off; off += (b + 255) & ~(size_t)255; return o; };
+    L.hist = take((size_t)RS_MAXPASS * 512 * 4);
+    L.ticket = take(RS_MAXPASS * 4);
+    L.status = take((size_t)L.passes * (size_t)L.ntiles * (size_t)L.bins * 4);
+    L.total = off;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void rs_init_k(uint32_t* __restrict__ w, int64_t nwords) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) w[i] = 0u;
+}
+
+// digit histograms of every pass in one read of the keys: LDS histograms per workgroup, then one non-returning atomic per non-empty bin
+template <int RB>
+__global__ __launch_bounds__(1024) void rs_hist_k(const uint32_t* __restrict__ keys, int64_t n, int passes, unsigned bits, uint32_t* __restrict__ ghist) {
+    constexpr int BINS = 1 << RB;
+    __shared__ uint32_t h[RS_MAXPASS][BINS];
+    for (int i = threadIdx.x; i < RS_MAXPASS * BINS; i += 1024) (&h[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t kmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+        const uint32_t k = keys[i] & kmask;
+#pragma unroll
+        for (int p = 0; p < RS_MAXPASS; ++p)
+            if (p < passes) atomicAdd(&h[p][(k >> (p * RB)) & (BINS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * BINS; i += 1024) {
+        const uint32_t c = (&h[0][0])[i];
+        if (c) atomicAdd(&ghist[(i / BINS) * 512 + (i % BINS)], c);
+    }
+}
+
+__device__ __forceinline__ uint32_t ld_status(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_status(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int RB>
+__global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
+                                                   uint32_t* __restrict__ vout, int64_t n, int shift, unsigned bits,
+                                                   const uint32_t* __restrict__ ghist /* [512] of this pass */,
+                                                   uint32_t* __restrict__ status /* [ntiles][BINS] of this pass */,
+                                                   uint32_t* __restrict__ ticket) {
+    constexpr int BINS = 1 << RB;
+    __shared__ uint32_t whist[RS_NW][BINS];      // per-wave digit counts, then each wave's exclusive offset inside the tile
+    __shared__ uint32_t gbase[BINS];             // where this tile's keys of digit d start in the output
+    __shared__ uint32_t scan[2][BINS];
+    __shared__ int s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+    for (int i = tid; i < RS_NW * BINS; i += RS_NT) (&whist[0][0])[i] = 0u;
+    __syncthreads();
+    const int64_t tile = s_tile;
+    const int64_t cbase = tile * RS_TILE + (int64_t)wave * (64 * RS_ITEMS);
+    const uint32_t kmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    uint32_t key[RS_ITEMS];
+    uint32_t rank[RS_ITEMS];                     // digit << 16 | rank inside the wave's chunk (< 512)
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int64_t idx = cbase + i * 64 + lane;
+        key[i] = idx < n ? kin[idx] : 0xffffffffu;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int64_t idx = cbase + i * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = ((key[i] & kmask) >> shift) & (BINS - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        // every peer reads the wave's running count of its digit, then the lowest peer adds the group (a wave's LDS operations execute
+        // in program order, and no other wave touches this row of whist)
+        uint32_t old = 0;
+        if (valid) old = whist[wave][d];
+        if (valid && (peers & lt) == 0ull) whist[wave][d] = old + (uint32_t)__popcll(peers);
+        rank[i] = (d << 16) | (old + (uint32_t)__popcll(peers & lt));
+    }
+    __syncthreads();
+    // per digit: exclusive scan over the waves, the tile's count, the look-back over earlier tiles
+    uint32_t cnt = 0;
+    if (tid < BINS) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < RS_NW; ++w) {
+            const uint32_t c = whist[w][tid];
+            whist[w][tid] = run;
+            run += c;
+        }
+        cnt = run;
+        if (tile == 0) st_status(status + tid, RS_INCL | cnt);
+        else st_status(status + tile * BINS + tid, RS_AGG | cnt);
+        scan[0][tid] = ghist[tid];
+    }
+    __syncthreads();
+    // exclusive scan of the pass's global digit histogram (Hillis-Steele over BINS values)
+    int cur = 0;
+#pragma unroll
+    for (int off = 1; off < BINS; off <<= 1) {
+        if (tid < BINS) scan[cur ^ 1][tid] = scan[cur][tid] + (tid >= off ? scan[cur][tid - off] : 0u);
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (tid < BINS) {
+        const uint32_t gexcl = scan[cur][tid] - ghist[tid];
+        uint32_t prefix = 0;
+        if (tile > 0) {
+            for (int64_t j = tile - 1; j >= 0; --j) {
+                uint32_t s;
+                while (((s = ld_status(status + j * BINS + tid)) >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
+                prefix += s & RS_VAL;
+                if ((s >> 30) == 2u) break;
+            }
+            st_status(status + tile * BINS + tid, RS_INCL | (prefix + cnt));
+        }
+        gbase[tid] = gexcl + prefix;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int64_t idx = cbase + i * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = rank[i] >> 16;
+            const uint32_t pos = gbase[d] + whist[wave][d] + (rank[i] & 0xffffu);
+            kout[pos] = key[i];
+            vout[pos] = vin[idx];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rs_copy2_k(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
+                                                  uint32_t* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        b[i] = a[i];
+        d[i] = c[i];
+    }
+}
+
+}  // namespace
+
+size_t radix_sort_temp_bytes(size_t n, unsigned bits) { return rs_layout(n, bits).total; }
+
+int radix_sort_input_buffer(size_t n, unsigned bits) { return (rs_layout(n, bits).passes & 1) ? 0 : 1; }
+
+// Sorts n pairs by the low `bits` bits of the key.  The input pairs must be in buffer radix_sort_input_buffer(n, bits) (0: k0 / v0,
+// 1: k1 / v1); the sorted pairs end up in k1 / v1; the other buffer is scratch.  tmp: radix_sort_temp_bytes(n, bits) bytes, 256-byte
+// aligned, any content.  n < 2^30.  Kernel launches only (no memset / memcpy nodes): safe inside a HIP-graph capture.
+hipError_t radix_sort_pairs_u32(void* tmp, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, unsigned bits, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (n >= ((size_t)1 << 30)) return hipErrorInvalidValue;
+    const RsLayout L = rs_layout(n, bits);
+    char* base = static_cast<char*>(tmp);
+    uint32_t* ghist = reinterpret_cast<uint32_t*>(base + L.hist);
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(base + L.ticket);
+    uint32_t* status = reinterpret_cast<uint32_t*>(base + L.status);
+    const int64_t nwords = (int64_t)(L.total / 4);
+    const int64_t ib = (nwords + 255) / 256;
+    hipLaunchKernelGGL(rs_init_k, dim3((unsigned)(ib < 1024 ? ib : 1024)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(base), nwords);
+    uint32_t* kb[2] = {k0, k1};
+    uint32_t* vb[2] = {v0, v1};
+    int cur = (L.passes & 1) ? 0 : 1;
+    const int64_t hb = ((int64_t)n + 8191) / 8192;
+    const unsigned hgrid = (unsigned)(hb < kCUs * 2 ? hb : kCUs * 2);
+    if (L.rb == 9) hipLaunchKernelGGL((rs_hist_k<9>), dim3(hgrid), dim3(1024), 0, st, kb[cur], (int64_t)n, L.passes, bits, ghist);
+    else hipLaunchKernelGGL((rs_hist_k<8>), dim3(hgrid), dim3(1024), 0, st, kb[cur], (int64_t)n, L.passes, bits, ghist);
+    for (int p = 0; p < L.passes; ++p) {
+        uint32_t* stp = status + (size_t)p * (size_t)L.ntiles * (size_t)L.bins;
+        if (L.rb == 9)
+            hipLaunchKernelGGL((rs_pass_k<9>), dim3((unsigned)L.ntiles), dim3(RS_NT), 0, st, kb[cur], vb[cur], kb[cur ^ 1], vb[cur ^ 1], (int64_t)n,
+                               p * 9, bits, ghist + p * 512, stp, ticket + p);
+        else
+            hipLaunchKernelGGL((rs_pass_k<8>), dim3((unsigned)L.ntiles), dim3(RS_NT), 0, st, kb[cur], vb[cur], kb[cur ^ 1], vb[cur ^ 1], (int64_t)n,
+                               p * 8, bits, ghist + p * 512, stp, ticket + p);
+        cur ^= 1;
+    }
+    return hipGetLastError();
+}
+
+// ---- zero fills as kernels (hipMemsetAsync becomes a memset NODE under graph capture, see the header comment) ------------------------
+namespace {
+__global__ __launch_bounds__(256) void zero_words_k(uint32_t* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void zero_2d_k(uint32_t* __restrict__ p, int64_t pitch_words, int64_t width_words, int64_t rows) {
+    const int64_t total = width_words * rows;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / width_words;
+        p[r * pitch_words + (i - r * width_words)] = 0u;
+    }
+}
+}  // namespace
+
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) || (bytes & 3u)) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)(bytes / 4), b = (n + 255) / 256;
+    hipLaunchKernelGGL(zero_words_k, dim3((unsigned)(b < kCUs * 8 ? b : kCUs * 8)), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+    return hipGetLastError();
+}
+
+hipError_t zero_2d_async(void* p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t st) {
+    if (width_bytes == 0 || rows == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) || (pitch_bytes & 3u) || (width_bytes & 3u)) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)(width_bytes / 4) * (int64_t)rows, b = (total + 255) / 256;
+    hipLaunchKernelGGL(zero_2d_k, dim3((unsigned)(b < kCUs * 8 ? b : kCUs * 8)), dim3(256), 0, st, static_cast<uint32_t*>(p), (int64_t)(pitch_bytes / 4),
+                       (int64_t)(width_bytes / 4), (int64_t)rows);
+    return hipGetLastError();
+}
+
+}  // namespace dir
+
+using namespace dir;
+
+extern "C" int64_t dir_debug_radix_sort_workspace_bytes(int64_t n, int bits) {
+    if (n < 0 || n >= ((int64_t)1 << 30) || bits < 1 || bits > 32) return 0;
+    return (int64_t)radix_sort_temp_bytes((size_t)n, (unsigned)bits) + 256;
+}
+
+extern "C" int dir_debug_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, int64_t n, int bits, uint32_t* keys_out, uint32_t* vals_out,
+                                              void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    DIR_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 30) && bits >= 1 && bits <= 32, "dir_debug_radix_sort_pairs_u32: n=%lld bits=%d", (long long)n, bits);
+    if (n == 0) return DIR_OK;
+    DIR_CHECK_ARG(keys_in && vals_in && keys_out && vals_out && workspace, "dir_debug_radix_sort_pairs_u32: null pointer");
+    char* ws = static_cast<char*>(workspace);
+    ws += (256 - (reinterpret_cast<uintptr_t>(ws) & 255u)) & 255u;
+    if ((int64_t)radix_sort_temp_bytes((size_t)n, (unsigned)bits) + (ws - static_cast<char*>(workspace)) > workspace_bytes)
+        return fail(DIR_E_BADARG, "dir_debug_radix_sort_pairs_u32: workspace too small");
+    hipStream_t st = as_stream(stream);
+    if (radix_sort_input_buffer((size_t)n, (unsigned)bits) == 1) {      // an even number of digit passes starts from the output buffers
+        const int64_t b = (n + 255) / 256;
+        hipLaunchKernelGGL(rs_copy2_k, dim3((unsigned)(b < kCUs * 8 ? b : kCUs * 8)), dim3(256), 0, st, keys_in, keys_out, vals_in, vals_out, n);
+    }
+    if (radix_sort_pairs_u32(ws, keys_in, keys_out, vals_in, vals_out, (size_t)n, (unsigned)bits, st) != hipSuccess)
+        return fail(DIR_E_HIP, "dir_debug_radix_sort_pairs_u32: launch failed");
+    return DIR_OK;
+}

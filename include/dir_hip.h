@@ -752,6 +752,15 @@ int dir_debug_cin_stamps(unsigned long long* out8);
 int dir_debug_stream_read_f32(const float* p, int64_t n, float* sink, dir_stream_t stream);
 int dir_debug_stream_copy_f32(const float* p, float* q, int64_t n, dir_stream_t stream);
 
+/* The in-tree stable LSD radix sort of (uint32 key, uint32 value) pairs behind every sorted sparse update (csrc/radix_sort.hip; the
+ * reference's optimisers on the embedding tables: models/DeepFM/deepFM.py:58,61), exposed for the parity tests: sorts n < 2^30 pairs
+ * by the low `bits` (1..32) bits of the key, stable (equal keys keep their input order), into keys_out / vals_out; keys_in / vals_in
+ * are clobbered.  Kernel launches only -- no memset / memcpy nodes -- so the call can sit inside a HIP-graph capture.
+ * workspace: dir_debug_radix_sort_workspace_bytes(n, bits) device bytes, any content. */
+int64_t dir_debug_radix_sort_workspace_bytes(int64_t n, int bits);
+int dir_debug_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, int64_t n, int bits, uint32_t* keys_out, uint32_t* vals_out,
+                                   void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1909,3 +1909,70 @@ def test_train_step_adam_with_multihot_columns_still_trains_their_tables(built_l
     a, b = run(True), run(False)
     for x, z in zip(a, b):
         assert float((x - z).abs().max()) <= 1e-5
+
+
+def test_deepfm_training_step_replays_from_a_hip_graph(built_lib):
+    """one whole DeepFM training step (forward, loss, backward with the fused sorted Adagrad / FTRL inside, the HIP dense
+    Adagrad / FTRL steps) captured in a torch.cuda.CUDAGraph and replayed: parameters bitwise equal to an eager twin after every step,
+    also after the twin ran 70 eager steps in between (what made the round-3 attempt fault: rocPRIM's memset nodes, NOTES R4.3)."""
+    from dir_amd import autograd as ag, feature_column as fc
+    from dir_amd.deepfm import DeepFM
+    B, F, K, V = 8192, 26, 16, 30000
+
+    def build():
+        torch.manual_seed(7)
+        cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+        m = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats], dnn_hidden_units=[400, 400],
+                   fm_embedding_size=K).cuda()
+        m.fused_sparse_adagrad(lr=0.01, packed=True)
+        m.fused_sparse_ftrl(lr=0.2)
+        skip = {id(p) for p in m.linear_weights} | {id(p) for p in m.embedding_weights} | {id(m.linear_bias)}
+        od = ag.Adagrad([p for p in m.parameters() if id(p) not in skip], lr=0.01, initial_accumulator_value=0.1)
+        ol = ag.Ftrl([m.linear_bias], lr=0.2)
+        return m, od, ol
+
+    def step(m, od, ol, feats, y):
+        od.zero_grad(set_to_none=False)
+        ol.zero_grad(set_to_none=False)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(m(feats), y)
+        loss.backward()
+        od.step()
+        ol.step()
+        return loss
+
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    batches = [torch.randint(0, V, (B, F), generator=gen, device="cuda") for _ in range(6)]
+    labels = [(torch.rand((B, 1), generator=gen, device="cuda") < 0.25).float() for _ in range(6)]
+    ma, oda, ola = build()
+    mb, odb, olb = build()
+    ids_s, y_s = batches[0].clone(), labels[0].clone()
+    feats_s = {"C%d" % f: ids_s[:, f] for f in range(F)}
+    feats = lambda i: {"C%d" % f: batches[i][:, f] for f in range(F)}      # noqa: E731
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for i in range(3):
+            ids_s.copy_(batches[i]); y_s.copy_(labels[i])
+            step(mb, odb, olb, feats_s, y_s)
+    torch.cuda.current_stream().wait_stream(s)
+    for i in range(3):
+        step(ma, oda, ola, feats(i), labels[i])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss_s = step(mb, odb, olb, feats_s, y_s)
+    for i in (3, 4, 5):
+        ids_s.copy_(batches[i]); y_s.copy_(labels[i])
+        g.replay()
+        la = step(ma, oda, ola, feats(i), labels[i])
+        torch.cuda.synchronize()
+        assert float(la) == float(loss_s)
+        assert all(torch.equal(x, y) for x, y in zip(ma.parameters(), mb.parameters())), "replayed step %d differs from eager" % i
+    # the twin trains on alone for 70 eager steps (its own sorts, fills, allocations); the graph must still replay afterwards
+    mc, odc, olc = build()
+    for i in range(70):
+        step(mc, odc, olc, feats(i % 6), labels[i % 6])
+    ids_s.copy_(batches[0]); y_s.copy_(labels[0])
+    g.replay()
+    step(ma, oda, ola, feats(0), labels[0])
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(ma.parameters(), mb.parameters()))
