@@ -116,6 +116,9 @@ def parse():
     ap.add_argument("--cin-arith", default=None, choices=["auto", "f32", "bf16x3"],
                     help="cin: arithmetic of ops.cin_layer (default: the library default, 'auto' = bf16x3 where covered)")
     ap.add_argument("--cross-d", type=int, default=416, help="dcn_cross / dcn_cross_backward: row width (416 = 26 x 16; 429 with the 13 dense)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step in HIP graphs (torch.cuda.CUDAGraph, one per rotated id batch) after the warmup and time the replays: "
+                         "what a launch-bound step costs without the host's launch gaps (training workloads; N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-profile", default=None, help="development: write torch.profiler's device time per (op, input shapes) of 4 untimed "
                                                           "steps after the warmup to this file (which torch ops a step still runs beside the HIP kernels)")
@@ -1131,6 +1134,28 @@ def main():
         cfg.update({"m": m, "D": D, "layers": list(Hs)})
 
     # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------
+    if args.graph:
+        if world > 1:
+            sys.stderr.write("bench.py: --graph is a single-GPU option\n")
+            return 2
+        # the standard capture recipe: warm up on a side stream (every cache, workspace and pointer table exists before the capture), then
+        # one graph per rotated id batch (the ids are part of the captured launches), replayed round robin
+        eager_step = step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(max(3, args.rotate)):
+                eager_step(i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = []
+        for i in range(max(1, args.rotate)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eager_step(i)
+            graphs.append(g)
+        step = lambda i: graphs[i % len(graphs)].replay()  # noqa: E731
+        cfg["launch"] = "hipGraph replay (%d graphs, one per rotated id batch)" % len(graphs)
     for i in range(args.warmup):
         step(i)
     if args.torch_profile:

@@ -27,6 +27,7 @@ constexpr int RS_ITEMS = 8;                 // keys per thread
 constexpr int RS_TILE = RS_NT * RS_ITEMS;   // 8192
 constexpr int RS_NW = RS_NT / 64;           // 16 waves
 constexpr int RS_MAXPASS = 4;
+constexpr int RS_WIN = 16;                 // predecessors read per look-back round trip
 constexpr uint32_t RS_AGG = 1u << 30, RS_INCL = 2u << 30, RS_VAL = (1u << 30) - 1u;
 
 struct RsLayout {                           // offsets into the temp storage (bytes)
@@ -60,9 +61,13 @@ __global__ __launch_bounds__(256) void rs_init_k(uint32_t* __restrict__ w, int64
 
 // digit histograms of every pass in one read of the keys: LDS histograms per workgroup, then one non-returning atomic per non-empty bin
 template <int RB>
-__global__ __launch_bounds__(1024) void rs_hist_k(const uint32_t* __restrict__ keys, int64_t n, int passes, unsigned bits, uint32_t* __restrict__ ghist) {
+__global__ __launch_bounds__(1024) void rs_hist_k(const uint32_t* __restrict__ keys, int64_t n, int passes, unsigned bits, uint32_t* __restrict__ ghist,
+                                                  uint32_t* __restrict__ status, int64_t status_words) {
     constexpr int BINS = 1 << RB;
     __shared__ uint32_t h[RS_MAXPASS][BINS];
+    // the tile states of every pass are zeroed here (nothing reads them before the first pass kernel): rs_init_k only clears the 8 KB
+    // of histograms and tickets this kernel's atomics need zero
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < status_words; i += (int64_t)gridDim.x * 1024) status[i] = 0u;
     for (int i = threadIdx.x; i < RS_MAXPASS * BINS; i += 1024) (&h[0][0])[i] = 0u;
     __syncthreads();
     const uint32_t kmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
@@ -87,14 +92,18 @@ __global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ vout, int64_t n, int shift, unsigned bits,
                                                    const uint32_t* __restrict__ ghist /* [512] of this pass */,
                                                    uint32_t* __restrict__ status /* [ntiles][BINS] of this pass */,
-                                                   uint32_t* __restrict__ ticket) {
+                                                   uint32_t* __restrict__ ticket, int dbg /* development: 1 no scatter, 2 no look-back, 4 no ranking */) {
     constexpr int BINS = 1 << RB;
-    __shared__ uint32_t whist[RS_NW][BINS];      // per-wave digit counts, then each wave's exclusive offset inside the tile
-    __shared__ uint32_t gbase[BINS];             // where this tile's keys of digit d start in the output
-    __shared__ uint32_t scan[2][BINS];
-    __shared__ int s_tile;
+    extern __shared__ __attribute__((aligned(16))) uint32_t rs_lds[];
+    uint32_t (*whist)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(rs_lds);     // [RS_NW][BINS] per-wave digit counts, then each wave's exclusive offset inside the tile
+    uint32_t* gbase = rs_lds + RS_NW * BINS;                                      // [BINS] where this tile's keys of digit d start in the output
+    uint32_t* toff = gbase + BINS;                                                // [BINS] where digit d starts inside the tile (digit-sorted order)
+    uint32_t (*scan)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(toff + BINS);   // [4][BINS]: two ping-pong pairs (global histogram, tile counts)
+    uint32_t* lkey = toff + BINS + 4 * BINS;                                      // [RS_TILE] the tile's keys in digit order
+    uint32_t* lval = lkey + RS_TILE;                                              // [RS_TILE]
+    uint32_t& s_tile = lval[RS_TILE];                                             // (all LDS is dynamic: the 160 KiB limit is set for the kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     for (int i = tid; i < RS_NW * BINS; i += RS_NT) (&whist[0][0])[i] = 0u;
     __syncthreads();
     const int64_t tile = s_tile;
@@ -114,6 +123,7 @@ __global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ 
         const bool valid = idx < n;
         const uint32_t d = ((key[i] & kmask) >> shift) & (BINS - 1);
         unsigned long long peers = __ballot(valid);
+        if (!(dbg & 4))
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const bool bit = (d >> b) & 1u;
@@ -142,39 +152,76 @@ __global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ 
         if (tile == 0) st_status(status + tid, RS_INCL | cnt);
         else st_status(status + tile * BINS + tid, RS_AGG | cnt);
         scan[0][tid] = ghist[tid];
+        scan[2][tid] = cnt;
     }
     __syncthreads();
-    // exclusive scan of the pass's global digit histogram (Hillis-Steele over BINS values)
+    // two exclusive scans over the digits at once (Hillis-Steele over BINS values): the pass's global histogram (where digit d starts in
+    // the output) and this tile's counts (where digit d starts inside the tile)
     int cur = 0;
 #pragma unroll
     for (int off = 1; off < BINS; off <<= 1) {
-        if (tid < BINS) scan[cur ^ 1][tid] = scan[cur][tid] + (tid >= off ? scan[cur][tid - off] : 0u);
+        if (tid < BINS) {
+            scan[cur ^ 1][tid] = scan[cur][tid] + (tid >= off ? scan[cur][tid - off] : 0u);
+            scan[2 + (cur ^ 1)][tid] = scan[2 + cur][tid] + (tid >= off ? scan[2 + cur][tid - off] : 0u);
+        }
         cur ^= 1;
         __syncthreads();
     }
-    if (tid < BINS) {
-        const uint32_t gexcl = scan[cur][tid] - ghist[tid];
-        uint32_t prefix = 0;
-        if (tile > 0) {
-            for (int64_t j = tile - 1; j >= 0; --j) {
-                uint32_t s;
-                while (((s = ld_status(status + j * BINS + tid)) >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
-                prefix += s & RS_VAL;
-                if ((s >> 30) == 2u) break;
-            }
-            st_status(status + tile * BINS + tid, RS_INCL | (prefix + cnt));
-        }
-        gbase[tid] = gexcl + prefix;
-    }
+    if (tid < BINS) toff[tid] = scan[2 + cur][tid] - cnt;
     __syncthreads();
+    // the tile in digit order, in LDS (needs nothing from other tiles: it runs while they publish their counts).  Direct stores from the
+    // ranked registers were 12 of a pass's 28 us: every lane of a store hit its own cache line
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         const int64_t idx = cbase + i * 64 + lane;
         if (idx < n) {
             const uint32_t d = rank[i] >> 16;
-            const uint32_t pos = gbase[d] + whist[wave][d] + (rank[i] & 0xffffu);
-            kout[pos] = key[i];
-            vout[pos] = vin[idx];
+            const uint32_t lp = toff[d] + whist[wave][d] + (rank[i] & 0xffffu);
+            lkey[lp] = key[i];
+            lval[lp] = vin[idx];
+        }
+    }
+    if (tid < BINS) {
+        const uint32_t gexcl = scan[cur][tid] - ghist[tid];
+        uint32_t prefix = 0;
+        if (tile > 0 && !(dbg & 2)) {
+            // Windowed look-back: RS_WIN predecessors' words are loaded at once (independent loads: one latency per window, not per
+            // tile).  The tiles of a launch start together: a walk that reads ONE predecessor per round trip needs ~sqrt(2 t) round
+            // trips of a device-scope load for tile t; with a window of 16 the first 16 k (k + 1) / 2 tiles are done after k round trips.
+            bool done = false;
+            for (int64_t j = tile - 1; !done; j -= RS_WIN) {
+                uint32_t s[RS_WIN];
+#pragma unroll
+                for (int u = 0; u < RS_WIN; ++u) s[u] = j - u >= 0 ? ld_status(status + (j - u) * BINS + tid) : RS_INCL;      // "tile -1": inclusive, 0
+#pragma unroll
+                for (int u = 0; u < RS_WIN; ++u) {
+                    if (done) continue;
+                    while ((s[u] >> 30) == 0u) {                       // not published yet (rare: the tiles rank in lockstep)
+                        __builtin_amdgcn_s_sleep(1);
+                        s[u] = ld_status(status + (j - u) * BINS + tid);
+                    }
+                    prefix += s[u] & RS_VAL;
+                    if ((s[u] >> 30) == 2u) done = true;
+                }
+            }
+            st_status(status + tile * BINS + tid, RS_INCL | (prefix + cnt));
+        }
+        gbase[tid] = gexcl + prefix - toff[tid];          // output position of the tile's digit-sorted element j of digit d: gbase[d] + j
+    }
+    __syncthreads();
+    const int64_t left = n - tile * RS_TILE;
+    const int nvalid = (int)(left < RS_TILE ? left : RS_TILE);
+    if (!(dbg & 1)) {
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {
+            const int j = i * RS_NT + tid;                  // consecutive lanes: consecutive elements of a digit's run: consecutive addresses
+            if (j < nvalid) {
+                const uint32_t k = lkey[j];
+                const uint32_t d = ((k & kmask) >> shift) & (BINS - 1);
+                const uint32_t pos = gbase[d] + (uint32_t)j;
+                kout[pos] = k;
+                vout[pos] = lval[j];
+            }
         }
     }
 }
@@ -204,24 +251,28 @@ hipError_t radix_sort_pairs_u32(void* tmp, uint32_t* k0, uint32_t* k1, uint32_t*
     uint32_t* ghist = reinterpret_cast<uint32_t*>(base + L.hist);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(base + L.ticket);
     uint32_t* status = reinterpret_cast<uint32_t*>(base + L.status);
-    const int64_t nwords = (int64_t)(L.total / 4);
-    const int64_t ib = (nwords + 255) / 256;
-    hipLaunchKernelGGL(rs_init_k, dim3((unsigned)(ib < 1024 ? ib : 1024)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(base), nwords);
+    const int64_t nwords = (int64_t)(L.status / 4);          // histograms + tickets (they sit in front of the tile states)
+    const int64_t status_words = (int64_t)((L.total - L.status) / 4);
+    hipLaunchKernelGGL(rs_init_k, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(base), nwords);
     uint32_t* kb[2] = {k0, k1};
     uint32_t* vb[2] = {v0, v1};
     int cur = (L.passes & 1) ? 0 : 1;
+    static const int dbg = getenv("DIR_RS_DBG") ? atoi(getenv("DIR_RS_DBG")) : 0;
     const int64_t hb = ((int64_t)n + 8191) / 8192;
     const unsigned hgrid = (unsigned)(hb < kCUs * 2 ? hb : kCUs * 2);
-    if (L.rb == 9) hipLaunchKernelGGL((rs_hist_k<9>), dim3(hgrid), dim3(1024), 0, st, kb[cur], (int64_t)n, L.passes, bits, ghist);
-    else hipLaunchKernelGGL((rs_hist_k<8>), dim3(hgrid), dim3(1024), 0, st, kb[cur], (int64_t)n, L.passes, bits, ghist);
+    if (L.rb == 9) hipLaunchKernelGGL((rs_hist_k<9>), dim3(hgrid), dim3(1024), 0, st, kb[cur], (int64_t)n, L.passes, bits, ghist, status, status_words);
+    else hipLaunchKernelGGL((rs_hist_k<8>), dim3(hgrid), dim3(1024), 0, st, kb[cur], (int64_t)n, L.passes, bits, ghist, status, status_words);
+    const size_t lds = sizeof(uint32_t) * ((size_t)RS_NW * L.bins + 6 * (size_t)L.bins + 2 * (size_t)RS_TILE + 4);
+    static LdsOnce once8, once9;
+    if (!(L.rb == 9 ? lds_limit(once9, 160 * 1024, &rs_pass_k<9>) : lds_limit(once8, 160 * 1024, &rs_pass_k<8>))) return hipErrorInvalidValue;
     for (int p = 0; p < L.passes; ++p) {
         uint32_t* stp = status + (size_t)p * (size_t)L.ntiles * (size_t)L.bins;
         if (L.rb == 9)
-            hipLaunchKernelGGL((rs_pass_k<9>), dim3((unsigned)L.ntiles), dim3(RS_NT), 0, st, kb[cur], vb[cur], kb[cur ^ 1], vb[cur ^ 1], (int64_t)n,
-                               p * 9, bits, ghist + p * 512, stp, ticket + p);
+            hipLaunchKernelGGL((rs_pass_k<9>), dim3((unsigned)L.ntiles), dim3(RS_NT), lds, st, kb[cur], vb[cur], kb[cur ^ 1], vb[cur ^ 1], (int64_t)n,
+                               p * 9, bits, ghist + p * 512, stp, ticket + p, dbg);
         else
-            hipLaunchKernelGGL((rs_pass_k<8>), dim3((unsigned)L.ntiles), dim3(RS_NT), 0, st, kb[cur], vb[cur], kb[cur ^ 1], vb[cur ^ 1], (int64_t)n,
-                               p * 8, bits, ghist + p * 512, stp, ticket + p);
+            hipLaunchKernelGGL((rs_pass_k<8>), dim3((unsigned)L.ntiles), dim3(RS_NT), lds, st, kb[cur], vb[cur], kb[cur ^ 1], vb[cur ^ 1], (int64_t)n,
+                               p * 8, bits, ghist + p * 512, stp, ticket + p, dbg);
         cur ^= 1;
     }
     return hipGetLastError();
