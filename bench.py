@@ -101,7 +101,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "dcn_cross_backward", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
-                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense", "esmm_full", "esmm_train", "deepfm_full_packed"])
+                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense", "esmm_full", "esmm_train", "deepfm_full_packed",
+                             "din_full"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1000000)
@@ -1012,6 +1013,35 @@ def main():
                 "note": "flops = the MFMAs the kernel issues (masked history positions are skipped, layer 1 is regrouped to a 2K reduction); "
                         "SURVEY 8d's all-T, 4K-wide count is reported as survey_8d_flops and not priced"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
+    elif wl == "din_full":
+        # BASELINE configs[3] as a whole model (dir_amd.din.DIN; paper-derived, README.md:27): behaviour sequence T 50 + candidate through the
+        # local activation unit on the 10 M x 64 goods table, concat([interest vector, candidate embedding]) -> 200-80 MLP -> logit
+        from dir_amd.din import DIN
+        T, Kd, Vd = 50, 64, 10000000
+        att_act = os.environ.get("DIR_BENCH_DIN_ACT", "sigmoid")
+        dnn_act = os.environ.get("DIR_BENCH_DIN_DNN_ACT", "dice")
+        model = DIN(item_vocab_size=Vd, embedding_dim=Kd, attention_hidden_units=(80, 40), attention_activation=att_act, attention_normalize=True,
+                    dnn_hidden_units=(200, 80), dnn_activation_fn=dnn_act).to(device).eval()
+        hists = [torch.randint(0, Vd, (B, T), generator=gen, device=device) for _ in range(2)]
+        hl = torch.randint(1, T + 1, (B,), generator=gen, device=device, dtype=torch.int32)
+        cand = torch.randint(0, Vd, (B,), generator=gen, device=device)
+        featl = [{"hist": h, "hist_len": hl, "cand": cand} for h in hists]
+
+        def step(i):
+            with torch.no_grad():
+                model(featl[i % 2])
+        rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
+        unit = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)                      # as the `din` workload: the MFMAs the unit issues over valid rows
+        mlp = 2.0 * B * (2 * Kd * 200 + 200 * 80)
+        din_arith = "f32" if os.environ.get("DIR_DIN_ARITH") == "f32" else "bf16x3"
+        mlp_modes = {"mlp_%d" % (i + 1): ("bf16x3" if ops.dense_auto_arith(B, a, b_) == "bf16x3" else "f32") for i, (a, b_) in enumerate(((2 * Kd, 200), (200, 80)))}
+        pipe = unit * PIPE_COST[din_arith] + 2.0 * B * (2 * Kd * 200 * PIPE_COST[mlp_modes["mlp_1"]] + 200 * 80 * PIPE_COST[mlp_modes["mlp_2"]])
+        roof = {"bound": "mfma", "alg_flops": unit + mlp, "pipe_flops": pipe, "modes": dict(mlp_modes, din_wave_k=din_arith),
+                "kernel": "DIN forward: din_wave_k (%s unit, %s) + candidate lookup + dense 128-200-80 (%s) + units-1 head" % (att_act, din_arith, dnn_act),
+                "dtype": "f32 via bf16x3 split, f32 accumulate" if din_arith == "bf16x3" else "f32",
+                "note": "flops = the unit's MFMAs over valid history rows + the two hidden layers; the logit layer and the elementwise activations are not priced"}
+        cfg.update({"T": T, "dim": Kd, "vocab": Vd, "attention": [4 * Kd, 80, 40, 1], "attention_activation": att_act, "dnn": [2 * Kd, 200, 80, 1],
+                    "dnn_activation": dnn_act})
     elif wl == "mlp_dense":
         # the three hidden layers of DeepFM's DNN tower (416 -> 400 -> 400 -> 400, ReLU): dir_dense_f32, or torch (rocBLAS GEMM +
         # ReLU pass) with DIR_BENCH_DENSE=torch

@@ -93,7 +93,7 @@ bool din_wave_covers(int K, int T, int H1, int H2);
 int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                     const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                     const float* b3, int normalize, int64_t B, float* out, float* scores, const int64_t* tile_off = nullptr,
-                    float* saved = nullptr);
+                    float* saved = nullptr, int activation = 0 /* 0 sigmoid, 1 PReLU, 2 Dice */, const float* act_params = nullptr);
 // The per-row record the DIN training path keeps between kernels (one per history position inside its sample's length, 16 rows per tile,
 // a sample's tiles consecutive from tile_off[b]): z1 [80] | dpre1 [80] | z2 [48] | d score | 3 pad.  The training forward
 // (dir_din_attention_pool_save_f32) writes z1 and z2; the backward's row pass adds dpre1 and d score; its weight-gradient pass reads all.

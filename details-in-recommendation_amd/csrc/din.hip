@@ -1095,6 +1095,29 @@ constexpr int kDinBwdMaxWg = kCUs;   // one workgroup per CU (153 KB of LDS)
 
 using namespace dir;
 
+extern "C" int dir_din_attention_pool_act_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
+                                              int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
+                                              const float* W3, const float* b3, int normalize, int activation, const float* act_params,
+                                              int64_t B, float* out, float* scores, dir_stream_t stream) {
+    const char* name = "dir_din_attention_pool_act_f32";
+    if (activation == DIR_DIN_ACT_SIGMOID)
+        return dir_din_attention_pool_f32(table, K, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores, stream);
+    DIR_CHECK_ARG(K > 0 && T > 0 && H1 > 0 && H2 > 0 && B >= 0, "%s: K=%d T=%d H1=%d H2=%d", name, K, T, H1, H2);
+    DIR_CHECK_ARG(activation == DIR_DIN_ACT_PRELU || activation == DIR_DIN_ACT_DICE, "%s: activation %d (0 sigmoid, 1 PReLU, 2 Dice)", name, activation);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(table && hist && cand && W1 && b1 && W2 && b2 && W3 && b3 && out && act_params, "%s: null pointer", name);
+    if ((H1 & 3) || (H2 & 3) || !din_wave_covers(K, T, H1, H2))
+        return fail(DIR_E_UNSUPPORTED, "%s: the PReLU / Dice unit covers K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 64 (K=%d T=%d H1=%d H2=%d)", name, K,
+                    T, H1, H2);
+    if (!aligned16(table) || !aligned16(W1) || !aligned16(W2) || !aligned16(b1) || !aligned16(b2))
+        return fail(DIR_E_BADARG, "%s: table / W1 / W2 / b1 / b2 must be 16-byte aligned", name);
+    const int rc = launch_din_wave(as_stream(stream), table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores, nullptr,
+                                   nullptr, activation, act_params);
+    if (rc != DIR_OK) return rc;
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
 extern "C" int dir_din_attention_pool_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
                                           const int64_t* cand, int T, const float* W1, const float* b1, int H1,
                                           const float* W2, const float* b2, int H2, const float* W3,

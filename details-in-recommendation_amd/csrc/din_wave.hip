@@ -87,6 +87,37 @@ __device__ unsigned int dw_queue[DW_SLOTS][16];
 // exponent), so a sigmoid is v_exp + v_add + v_rcp: VALU work is not hidden behind fp32 MFMAs, every instruction saved counts.
 constexpr float DW_NLOG2E = -1.4426950408889634f;
 __device__ __forceinline__ float dw_sigmoid_pre(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
+// The hidden activations of the unit (round 4): ACT 0 = sigmoid (the default; what the public DIN code uses in its attention MLP),
+// 1 = PReLU  f(s) = s > 0 ? s : alpha s, 2 = Dice  f(s) = p s + (1 - p) alpha s with p = sigmoid((s - E[s]) / sqrt(Var[s] + eps))
+// (arXiv:1706.06978 section 5.3; inference form: the moving statistics folded into scale / shift).  For ACT != 0 the weight images carry
+// NO -log2 e factor (the MFMA result is the pre-activation itself) and the per-unit parameters sit in LDS behind the weight images:
+// row 0 = alpha, row 1 = -log2 e * scale, row 2 = -log2 e * shift.  A padded hidden unit has pre-activation 0: f(0) = 0 in both.
+template <int ACT>
+__device__ __forceinline__ float dw_act(float pre, float alpha, float nscale, float nshift) {
+    if constexpr (ACT == 0) return dw_sigmoid_pre(pre);
+    else if constexpr (ACT == 1) return pre > 0.f ? pre : alpha * pre;
+    else {
+        const float pgate = dw_sigmoid_pre(fmaf(pre, nscale, nshift));
+        return pre * fmaf(pgate, 1.0f - alpha, alpha);
+    }
+}
+constexpr int DW_ACT_S1 = 96, DW_ACT_S2 = 48;          // strides of the staged parameter rows (padded units: alpha = scale = shift = 0)
+constexpr int DW_ACT_FLOATS = 3 * DW_ACT_S1 + 3 * DW_ACT_S2;
+// the three parameters of the four hidden units 4-aligned at h (one ds_read_b128 each; nothing is read for the sigmoid)
+template <int ACT>
+__device__ __forceinline__ void dw_act_params(const float* rows, int stride, int h, float (&al)[4], float (&ns)[4], float (&nt)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) al[g] = ns[g] = nt[g] = 0.f;
+    if constexpr (ACT != 0) {
+        const float4 a = *reinterpret_cast<const float4*>(rows + h);
+        al[0] = a.x; al[1] = a.y; al[2] = a.z; al[3] = a.w;
+    }
+    if constexpr (ACT == 2) {
+        const float4 b = *reinterpret_cast<const float4*>(rows + stride + h), c = *reinterpret_cast<const float4*>(rows + 2 * stride + h);
+        ns[0] = b.x; ns[1] = b.y; ns[2] = b.z; ns[3] = b.w;
+        nt[0] = c.x; nt[1] = c.y; nt[2] = c.z; nt[3] = c.w;
+    }
+}
 __device__ __forceinline__ float4 dw_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float dw_dot4(float4 a, float4 b, float acc) {
     acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
@@ -202,8 +233,8 @@ __device__ __forceinline__ void dw_load_rows(const float* __restrict__ table, co
 
 // One pass: NT row tiles whose rows are hv[rt] and whose history ids are id[rt] (-1: masked row).  Updates the online-softmax state.
 // rec[rt] != nullptr (training forward): the row's z1 and z2 go into its record (common.hpp: kDinRec*).
-template <int NT, typename Sh>
-__device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16, const int kk,
+template <int NT, int ACT, typename Sh>
+__device__ __forceinline__ void dw_pass(const Sh& sh, const float* actl, const int w, const int r16, const int kk,
                                         const long long (&id)[NT], const float4 (&hv)[2][4], const float b3, const bool normalize,
                                         const float inv_sqrt_k, float& m_run, float& l_run, float4 (&o)[4], float (&xs)[NT],
                                         float* const (&rec)[NT]) {
@@ -254,11 +285,14 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
         }
         // z1 = sigmoid(pre1) in place: hidden 16 mt + 4 kk + g of row r -- element (mt & 1) * 4 + g of layer 2's k-step mt >> 1
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt)
+        for (int mt = 0; mt < 5; ++mt) {
+            float al[4], ns[4], nt[4];
+            dw_act_params<ACT>(actl, DW_ACT_S1, 16 * mt + 4 * kk, al, ns, nt);
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc1[mt][rt][g] = dw_sigmoid_pre(acc1[mt][rt][g]);
+                for (int g = 0; g < 4; ++g) acc1[mt][rt][g] = dw_act<ACT>(acc1[mt][rt][g], al[g], ns[g], nt[g]);
+        }
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
             if (rec[rt]) {
@@ -322,14 +356,17 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
     }
     // z1 = sigmoid(pre1), in place: lane (kk, r) holds hidden 16 mt + 4 kk + g of row r -- a B operand of layer 2
 #pragma unroll
-    for (int mt = 0; mt < 5; ++mt)
+    for (int mt = 0; mt < 5; ++mt) {
+        float al[4], ns[4], nt[4];
+        dw_act_params<ACT>(actl, DW_ACT_S1, 16 * mt + 4 * kk, al, ns, nt);
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float pre = NA == 2 ? acc1[mt][rt][0][g] + acc1[mt][rt][NA - 1][g] : acc1[mt][rt][0][g];
-                acc1[mt][rt][0][g] = dw_sigmoid_pre(pre);
+                acc1[mt][rt][0][g] = dw_act<ACT>(pre, al[g], ns[g], nt[g]);
             }
+    }
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)
         if (rec[rt]) {
@@ -368,9 +405,11 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
 #pragma unroll
         for (int m2 = 0; m2 < 3; ++m2) {
             float zz[4];
+            float al[4], ns[4], nt[4];
+            dw_act_params<ACT>(actl + 3 * DW_ACT_S1, DW_ACT_S2, 16 * m2 + 4 * kk, al, ns, nt);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                zz[g] = dw_sigmoid_pre(acc2[m2][rt][g]);
+                zz[g] = dw_act<ACT>(acc2[m2][rt][g], al[g], ns[g], nt[g]);
                 sp = fmaf(zz[g], wv[m2][g], sp);
             }
             if (rec[rt]) din_rec_store(rec[rt] + kDinRecZ2 + 16 * m2 + 4 * kk, zz[0], zz[1], zz[2], zz[3]);
@@ -421,17 +460,33 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const int w, const int r16
     }
 }
 
-template <typename Sh, bool SAVE>
+template <typename Sh, bool SAVE, int ACT>
 __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
                                                                const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand,
                                                                int T, const float* __restrict__ W1, const float* __restrict__ b1, int H1,
                                                                const float* __restrict__ W2, const float* __restrict__ b2, int H2,
                                                                const float* __restrict__ W3, const float* __restrict__ b3, int normalize,
                                                                long long B, float* __restrict__ out, float* __restrict__ scores, int slot,
-                                                               const int64_t* __restrict__ tile_off, float* __restrict__ saved) {
+                                                               const int64_t* __restrict__ tile_off, float* __restrict__ saved,
+                                                               const float* __restrict__ act_params /* ACT != 0: [3 H1 + 3 H2] */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
     Sh& sh = *reinterpret_cast<Sh*>(dw_smem);
+    float* const actl = reinterpret_cast<float*>(dw_smem + ((sizeof(Sh) + 15) & ~(size_t)15));      // ACT != 0: [3][96] layer 1, [3][48] layer 2
+    constexpr float SC = ACT == 0 ? DW_NLOG2E : 1.0f;      // what the weight / bias images are multiplied by
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kk = lane >> 4;
+    if constexpr (ACT != 0) {
+        for (int idx = tid; idx < DW_ACT_FLOATS; idx += 64 * DW_WAVES) {
+            float v = 0.f;
+            if (idx < 3 * DW_ACT_S1) {
+                const int row = idx / DW_ACT_S1, h = idx - row * DW_ACT_S1;
+                if (h < H1) v = act_params[row * H1 + h] * (row == 0 ? 1.0f : DW_NLOG2E);
+            } else {
+                const int j = idx - 3 * DW_ACT_S1, row = j / DW_ACT_S2, h = j - row * DW_ACT_S2;
+                if (h < H2) v = act_params[3 * H1 + row * H2 + h] * (row == 0 ? 1.0f : DW_NLOG2E);
+            }
+            actl[idx] = v;
+        }
+    }
     // ---- weight images, once per workgroup ---------------------------------------------------------------------------------------------------
 #pragma unroll 3
     for (int idx = tid; idx < (DW_H1P / 4) * DW_K; idx += 64 * DW_WAVES) {      // 16-byte loads along m (H1 % 4 == 0, W1 16-byte aligned)
@@ -443,7 +498,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
             vd = dw_ld4(W1 + (size_t)(2 * DW_K + f) * H1 + m);
             vp = dw_ld4(W1 + (size_t)(3 * DW_K + f) * H1 + m);
         }
-        const float sc_ = DW_NLOG2E;      // pre-activations come out of the MFMAs already multiplied by -log2 e
+        const float sc_ = SC;      // pre-activations come out of the MFMAs already multiplied by -log2 e
         const float h4[4] = {(vh.x + vd.x) * sc_, (vh.y + vd.y) * sc_, (vh.z + vd.z) * sc_, (vh.w + vd.w) * sc_};
         const float p4[4] = {vp.x * sc_, vp.y * sc_, vp.z * sc_, vp.w * sc_};
         const float c4[4] = {(va.x - vd.x) * sc_, (va.y - vd.y) * sc_, (va.z - vd.z) * sc_, (va.w - vd.w) * sc_};
@@ -468,8 +523,8 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
             if (m < H1) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    hd[e] = (W1[(size_t)(f + e) * H1 + m] + W1[(size_t)(2 * DW_K + f + e) * H1 + m]) * DW_NLOG2E;
-                    pp[e] = W1[(size_t)(3 * DW_K + f + e) * H1 + m] * DW_NLOG2E;
+                    hd[e] = (W1[(size_t)(f + e) * H1 + m] + W1[(size_t)(2 * DW_K + f + e) * H1 + m]) * SC;
+                    pp[e] = W1[(size_t)(3 * DW_K + f + e) * H1 + m] * SC;
                 }
             }
             unsigned int q0, q1, q2;
@@ -490,7 +545,7 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
             float v[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e)      // a padded hidden unit is sigmoid(0) = 0.5: its weights are zero
-                v[e] = (hid + e < H1 && h2 < H2) ? W2[(size_t)(hid + e) * H2 + h2] * DW_NLOG2E : 0.f;
+                v[e] = (hid + e < H1 && h2 < H2) ? W2[(size_t)(hid + e) * H2 + h2] * SC : 0.f;
             unsigned int q0, q1, q2;
             dw_split_pair(v[0], v[1], q0, q1, q2);
             sh.w23[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
@@ -500,12 +555,12 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
     } else {
         for (int idx = tid; idx < DW_H2P * DW_H1P; idx += 64 * DW_WAVES) {
             const int hid = idx / DW_H2P, h2 = idx - hid * DW_H2P;
-            sh.w2[h2 * DW_W2S + hid] = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] * DW_NLOG2E : 0.f;   // a padded hidden unit is sigmoid(0) = 0.5:
+            sh.w2[h2 * DW_W2S + hid] = (hid < H1 && h2 < H2) ? W2[(size_t)hid * H2 + h2] * SC : 0.f;   // a padded hidden unit is sigmoid(0) = 0.5:
         }                                                                                           // its weights are zero
     }
-    for (int idx = tid; idx < DW_H1P; idx += 64 * DW_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * DW_NLOG2E : 0.f;
+    for (int idx = tid; idx < DW_H1P; idx += 64 * DW_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * SC : 0.f;
     for (int idx = tid; idx < DW_H2P; idx += 64 * DW_WAVES) {
-        sh.b2[idx] = idx < H2 ? b2[idx] * DW_NLOG2E : 0.f;
+        sh.b2[idx] = idx < H2 ? b2[idx] * SC : 0.f;
         sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
     }
     __syncthreads();
@@ -600,13 +655,13 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
             const long long idp[2] = {id[0], id[1]};
             float xp[2];
             float* const recp[2] = {record(0), record(1)};
-            dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
+            dw_pass<2, ACT>(sh, actl, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
             xs[0] = xp[0]; xs[1] = xp[1];
         } else if (RT == 1) {
             const long long idp[1] = {id[0]};
             float xp[1];
             float* const recp[1] = {record(0)};
-            dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
+            dw_pass<1, ACT>(sh, actl, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
             xs[0] = xp[0];
         }
 #pragma unroll
@@ -621,13 +676,13 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
                 const long long idp[2] = {id[2], id[3]};
                 float xp[2];
                 float* const recp[2] = {record(2), record(3)};
-                dw_pass<2>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
+                dw_pass<2, ACT>(sh, actl, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
                 xs[2] = xp[0]; xs[3] = xp[1];
             } else {
                 const long long idp[1] = {id[2]};
                 float xp[1];
                 float* const recp[1] = {record(2)};
-                dw_pass<1>(sh, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
+                dw_pass<1, ACT>(sh, actl, w, r16, kk, idp, hv, bias3, normalize != 0, inv_sqrt_k, m_run, l_run, o, xp, recp);
                 xs[2] = xp[0];
             }
 #pragma unroll
@@ -682,7 +737,8 @@ bool din_wave_covers(int K, int T, int H1, int H2) { return K == DW_K && T <= 64
 
 int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                     const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
-                    const float* b3, int normalize, int64_t B, float* out, float* scores, const int64_t* tile_off, float* saved) {
+                    const float* b3, int normalize, int64_t B, float* out, float* scores, const int64_t* tile_off, float* saved, int activation,
+                    const float* act_params) {
     // DIR_DIN_ARITH = bf16x3 (default) | f32: the arithmetic of the two MFMA layers; DIR_DIN_STATIC = 1 | 0: a static stride over the
     // samples instead of the device-side queue (default: static for bf16x3 -- its per-sample time is short enough that the ticket
     // atomics cost more than the imbalance they remove, 0.45 vs 0.50 ms at config 4 -- and the queue for fp32).  Both are read per call
@@ -691,13 +747,19 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
     const bool bf3 = !(arith && strcmp(arith, "f32") == 0);
     const bool save = saved != nullptr;
     typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,
-                           const float*, int, const float*, const float*, int, long long, float*, float*, int, const int64_t*, float*);
-    static const kern_t kerns[2][2] = {{&din_wave_k<DinWaveSh, false>, &din_wave_k<DinWaveSh, true>},
-                                       {&din_wave_k<DinWaveSh3, false>, &din_wave_k<DinWaveSh3, true>}};
-    static LdsOnce once[2][2];
-    const size_t shmem = bf3 ? sizeof(DinWaveSh3) : sizeof(DinWaveSh);
-    const kern_t kern = kerns[bf3][save];
-    if (!lds_limit(once[bf3][save], (int)shmem, kern)) return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
+                           const float*, int, const float*, const float*, int, long long, float*, float*, int, const int64_t*, float*, const float*);
+    // [arithmetic][save | PReLU | Dice]: the training forward (SAVE) exists for the sigmoid unit only
+    static const kern_t kerns[2][4] = {{&din_wave_k<DinWaveSh, false, 0>, &din_wave_k<DinWaveSh, true, 0>, &din_wave_k<DinWaveSh, false, 1>,
+                                        &din_wave_k<DinWaveSh, false, 2>},
+                                       {&din_wave_k<DinWaveSh3, false, 0>, &din_wave_k<DinWaveSh3, true, 0>, &din_wave_k<DinWaveSh3, false, 1>,
+                                        &din_wave_k<DinWaveSh3, false, 2>}};
+    if (activation < 0 || activation > 2 || (activation != 0 && (save || !act_params)))
+        return fail(DIR_E_UNSUPPORTED, "din_wave_k: activation %d (0 sigmoid, 1 PReLU, 2 Dice; the training forward covers the sigmoid unit only)", activation);
+    static LdsOnce once[2][4];
+    const int which = activation ? 1 + activation : (save ? 1 : 0);
+    const size_t shmem = (((bf3 ? sizeof(DinWaveSh3) : sizeof(DinWaveSh)) + 15) & ~(size_t)15) + (activation ? sizeof(float) * DW_ACT_FLOATS : 0);
+    const kern_t kern = kerns[bf3][which];
+    if (!lds_limit(once[bf3][which], (int)shmem, kern)) return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
     // Up to DW_SLOTS launches may be in flight at once (distinct streams); a record is reused only after DW_SLOTS further launches.
     const char* stat = getenv("DIR_DIN_STATIC");
     const bool static_split = stat ? atoi(stat) != 0 : bf3;
@@ -707,7 +769,7 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
     if (nwg > kCUs) nwg = kCUs;
     if (nwg < 1) nwg = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * DW_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3,
-                       normalize, (long long)B, out, scores, slot, tile_off, saved);
+                       normalize, (long long)B, out, scores, slot, tile_off, saved, act_params);
     return DIR_OK;
 }
 

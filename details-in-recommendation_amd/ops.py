@@ -393,8 +393,24 @@ def cross_op(x0, x, w, b, out=None):
     return out
 
 
-def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, want_scores=False):
-    """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T])."""
+DIN_ACTIVATIONS = {"sigmoid": 0, "prelu": 1, "dice": 2}
+
+
+def din_act_params(H1, H2, alpha1, alpha2, scale1=None, shift1=None, scale2=None, shift2=None):
+    """The [3 H1 + 3 H2] parameter vector of the PReLU / Dice unit (include/dir_hip.h: dir_din_attention_pool_act_f32) from per-unit
+    tensors: alpha1, scale1, shift1, alpha2, scale2, shift2 (missing scale -> 1, missing shift -> 0; PReLU reads the alphas only)."""
+    dev = alpha1.device
+    one = lambda n: torch.ones(n, dtype=torch.float32, device=dev)      # noqa: E731
+    zero = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)    # noqa: E731
+    parts = [alpha1, scale1 if scale1 is not None else one(H1), shift1 if shift1 is not None else zero(H1),
+             alpha2, scale2 if scale2 is not None else one(H2), shift2 if shift2 is not None else zero(H2)]
+    return torch.cat([t.detach().to(torch.float32).reshape(-1) for t in parts]).contiguous()
+
+
+def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, want_scores=False, activation="sigmoid",
+                       act_params=None):
+    """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T]).  activation "prelu" / "dice": the
+    paper's own hidden activations (dir_din_attention_pool_act_f32; act_params from din_act_params)."""
     _dev(table, torch.float32, "table")
     _dev(hist, torch.int64, "hist")
     _dev(cand, torch.int64, "cand")
@@ -417,6 +433,17 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
         raise ValueError("DIN: cand and hist_len must have one entry per sample")
     out = torch.empty((B, K), dtype=torch.float32, device=table.device)
     scores = torch.empty((B, T), dtype=torch.float32, device=table.device) if want_scores else None
+    if activation != "sigmoid":
+        if activation not in DIN_ACTIVATIONS:
+            raise ValueError("DIN activation must be one of %s" % sorted(DIN_ACTIVATIONS))
+        if act_params is None or act_params.numel() != 3 * H1 + 3 * H2:
+            raise ValueError("DIN %s unit: act_params must hold 3 H1 + 3 H2 floats (ops.din_act_params)" % activation)
+        ap = _dev(act_params.contiguous(), torch.float32, "act_params")
+        _lib.check(_lib.load().dir_din_attention_pool_act_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
+                                                              _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
+                                                              H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)),
+                                                              DIN_ACTIVATIONS[activation], _ptr(ap), B, _ptr(out), _ptr(scores), _stream()))
+        return (out, scores) if want_scores else out
     _lib.check(_lib.load().dir_din_attention_pool_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
                                                       _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
                                                       H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B,

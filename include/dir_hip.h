@@ -207,6 +207,19 @@ int dir_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
                                int normalize, int64_t B, float* out, float* scores,
                                dir_stream_t stream);
 
+/* The same unit with the paper's own hidden activations (arXiv:1706.06978 section 5.3; no reference code: README.md:27) in place of the
+ * two sigmoids:  activation = DIR_DIN_ACT_PRELU:  f(s) = s > 0 ? s : alpha s;
+ *                activation = DIR_DIN_ACT_DICE:   f(s) = p s + (1 - p) alpha s,  p = sigmoid(scale s + shift)  -- the inference form of
+ *                Dice: scale = 1 / sqrt(Var[s] + eps), shift = -E[s] scale with the layer's moving statistics;
+ *                activation = DIR_DIN_ACT_SIGMOID forwards to dir_din_attention_pool_f32.
+ * act_params: DEVICE float [3 H1 + 3 H2] = alpha1 [H1], scale1 [H1], shift1 [H1], alpha2 [H2], scale2 [H2], shift2 [H2] (PReLU reads
+ * the alphas only).  Inference only; K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 64 (DIR_E_UNSUPPORTED otherwise). */
+enum { DIR_DIN_ACT_SIGMOID = 0, DIR_DIN_ACT_PRELU = 1, DIR_DIN_ACT_DICE = 2 };
+int dir_din_attention_pool_act_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                                   const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                                   const float* b3, int normalize, int activation, const float* act_params, int64_t B, float* out,
+                                   float* scores, dir_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * A14 xDeepFM compressed interaction network, one layer (no reference code: README.md:28 links
  * arXiv:1803.05170).

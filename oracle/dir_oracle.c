@@ -257,13 +257,39 @@ int orc_dcn_cross_f32(const float* x0, int64_t x_ld, const float* w, const float
  * ---------------------------------------------------------------------------------------------- */
 static float orc_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+/* the unit's hidden activation (paper-derived, arXiv:1706.06978 section 5.3; no reference code): 0 sigmoid, 1 PReLU f(s) = s > 0 ? s : alpha s,
+ * 2 Dice (inference form) f(s) = p s + (1 - p) alpha s, p = sigmoid(scale s + shift).  ap = {alpha, scale, shift} rows of n entries. */
+static float orc_din_act(float s, int act, const float* ap, int n, int h) {
+    if (act == 1) return s > 0.0f ? s : ap[h] * s;
+    if (act == 2) {
+        const float pg = orc_sigmoid(ap[n + h] * s + ap[2 * n + h]);
+        return pg * s + (1.0f - pg) * ap[h] * s;
+    }
+    return orc_sigmoid(s);
+}
+
+int orc_din_attention_pool_act_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                                   const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                                   const float* b3, int normalize, int activation, const float* act_params, int64_t B, float* out,
+                                   float* scores, int acc64);
+
 int orc_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
                                const int32_t* hist_len, const int64_t* cand, int T,
                                const float* W1, const float* b1, int H1, const float* W2,
                                const float* b2, int H2, const float* W3, const float* b3,
                                int normalize, int64_t B, float* out, float* scores, int acc64) {
+    return orc_din_attention_pool_act_f32(table, K, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, 0, NULL, B, out, scores, acc64);
+}
+
+int orc_din_attention_pool_act_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                                   const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                                   const float* b3, int normalize, int activation, const float* act_params, int64_t B, float* out,
+                                   float* scores, int acc64) {
     if (!table || !hist || !cand || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !out) return -1;
     if (K <= 0 || T <= 0 || H1 <= 0 || H2 <= 0) return -1;
+    if (activation < 0 || activation > 2 || (activation != 0 && !act_params)) return -1;
+    const float* ap1 = act_params;
+    const float* ap2 = act_params ? act_params + 3 * (size_t)H1 : NULL;
 #pragma omp parallel
     {
         float* u = (float*)malloc(sizeof(float) * (size_t)(4 * K));
@@ -293,22 +319,22 @@ int orc_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
                     if (acc64) {
                         double acc = 0.0;
                         for (int i = 0; i < 4 * K; ++i) acc += (double)u[i] * (double)W1[i * H1 + n];
-                        z1[n] = orc_sigmoid((float)(acc + (double)b1[n]));
+                        z1[n] = orc_din_act((float)(acc + (double)b1[n]), activation, ap1, H1, n);
                     } else {
                         float acc = 0.0f;
                         for (int i = 0; i < 4 * K; ++i) acc = acc + u[i] * W1[i * H1 + n];
-                        z1[n] = orc_sigmoid(acc + b1[n]);
+                        z1[n] = orc_din_act(acc + b1[n], activation, ap1, H1, n);
                     }
                 }
                 for (int n = 0; n < H2; ++n) {
                     if (acc64) {
                         double acc = 0.0;
                         for (int i = 0; i < H1; ++i) acc += (double)z1[i] * (double)W2[i * H2 + n];
-                        z2[n] = orc_sigmoid((float)(acc + (double)b2[n]));
+                        z2[n] = orc_din_act((float)(acc + (double)b2[n]), activation, ap2, H2, n);
                     } else {
                         float acc = 0.0f;
                         for (int i = 0; i < H1; ++i) acc = acc + z1[i] * W2[i * H2 + n];
-                        z2[n] = orc_sigmoid(acc + b2[n]);
+                        z2[n] = orc_din_act(acc + b2[n], activation, ap2, H2, n);
                     }
                 }
                 if (acc64) {

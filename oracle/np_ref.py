@@ -156,10 +156,28 @@ def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
+def din_unit_activation(s, kind, params):
+    """The unit's hidden activation on [n, H] pre-activations: "sigmoid" | "prelu" (params[0] = alpha [H]) | "dice" (params = alpha,
+    scale, shift rows: the inference form of arXiv:1706.06978 section 5.3's Dice, p = sigmoid(scale s + shift), f = p s + (1 - p) alpha s).
+    Paper-derived: the reference holds no DIN code (README.md:27)."""
+    if kind == "prelu":
+        return np.where(s > 0, s, params[0] * s)
+    if kind == "dice":
+        pg = sigmoid(params[1] * s + params[2])
+        return pg * s + (1.0 - pg) * params[0] * s
+    return sigmoid(s)
+
+
 def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False,
-                       dtype=np.float64):
+                       dtype=np.float64, activation="sigmoid", act_params=None):
+    """activation "prelu" / "dice": act_params [3 H1 + 3 H2] = alpha1, scale1, shift1, alpha2, scale2, shift2."""
     B, T = hist.shape
     K = table.shape[1]
+    H1, H2 = W1.shape[1], W2.shape[1]
+    ap1 = ap2 = None
+    if activation != "sigmoid":
+        ap = np.asarray(act_params, dtype).reshape(-1)
+        ap1, ap2 = ap[:3 * H1].reshape(3, H1), ap[3 * H1:].reshape(3, H2)
     out = np.zeros((B, K), dtype)
     scores = np.zeros((B, T), dtype)
     for b in range(B):
@@ -169,8 +187,8 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
             continue
         h = table[hist[b, valid]].astype(dtype)                               # [n,K]
         u = np.concatenate([h, np.broadcast_to(a, h.shape), h - a, h * a], axis=1)
-        z1 = sigmoid(u @ W1.astype(dtype) + b1.astype(dtype))
-        z2 = sigmoid(z1 @ W2.astype(dtype) + b2.astype(dtype))
+        z1 = din_unit_activation(u @ W1.astype(dtype) + b1.astype(dtype), activation, ap1)
+        z2 = din_unit_activation(z1 @ W2.astype(dtype) + b2.astype(dtype), activation, ap2)
         s = z2 @ W3.astype(dtype) + dtype(b3[0])
         if normalize:
             s = s / np.sqrt(dtype(K))
@@ -179,6 +197,23 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
         out[b] = s @ h
         scores[b, valid] = s
     return out, scores
+
+
+def din_model_logits(x_cols, table, hist, hist_len, cand, unit, mlp, head, normalize=False, activation="sigmoid", act_params=None,
+                     dtype=np.float64):
+    """The whole DIN forward (arXiv:1706.06978 figure 2; paper-derived, README.md:27 has no code): concat([profile / context block x_cols
+    [B, W] or None, pooled interest vector, candidate embedding]) -> hidden layers -> logit [B, 1].
+    unit = (W1, b1, W2, b2, W3, b3); mlp = [(W [out, in], b [out], kind, params)] with kind "relu" | "sigmoid" | "prelu" | "dice" and
+    params as din_unit_activation takes them; head = (w [1, in], b [1])."""
+    pooled, _ = din_attention_pool(table, hist, hist_len, cand, *unit, normalize=normalize, dtype=dtype, activation=activation,
+                                   act_params=act_params)
+    ce = np.where((np.asarray(cand) >= 0)[:, None], table[np.maximum(cand, 0)].astype(dtype), 0.0)
+    parts = ([np.asarray(x_cols, dtype)] if x_cols is not None else []) + [pooled, ce]
+    net = np.concatenate(parts, axis=1)
+    for W, b, kind, params in mlp:
+        pre = net @ np.asarray(W, dtype).T + np.asarray(b, dtype)
+        net = np.maximum(pre, 0) if kind == "relu" else din_unit_activation(pre, kind, params)
+    return net @ np.asarray(head[0], dtype).T + np.asarray(head[1], dtype)
 
 
 def cin_layer(x0, xk, W, dtype=np.float64):

@@ -142,8 +142,13 @@ def dcn_cross(x0, w, b, acc64=False):
     return out
 
 
+DIN_ACTIVATIONS = {"sigmoid": 0, "prelu": 1, "dice": 2}
+
+
 def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False,
-                       acc64=False):
+                       acc64=False, activation="sigmoid", act_params=None):
+    """activation "prelu" / "dice" (paper-derived, arXiv:1706.06978 section 5.3): act_params float32 [3 H1 + 3 H2] = alpha1, scale1, shift1,
+    alpha2, scale2, shift2 (Dice in its inference form: p = sigmoid(scale s + shift))."""
     table = _f32(table)
     K = table.shape[1]
     hist = _i64(hist)
@@ -155,11 +160,15 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     out = np.zeros((B, K), np.float32)
     scores = np.zeros((B, T), np.float32)
     f = ctypes.c_float
-    rc = lib().orc_din_attention_pool_f32(_p(table, f), K, _p(hist, ctypes.c_int64),
-                                          _p(hist_len, ctypes.c_int32), _p(cand, ctypes.c_int64), T,
-                                          _p(W1, f), _p(b1, f), H1, _p(W2, f), _p(b2, f), H2, _p(W3, f),
-                                          _p(b3, f), int(normalize), ctypes.c_int64(B), _p(out, f),
-                                          _p(scores, f), int(acc64))
+    ap = None
+    if activation != "sigmoid":
+        ap = _f32(np.asarray(act_params).reshape(-1))
+        assert ap.size == 3 * H1 + 3 * H2, "act_params: [3 H1 + 3 H2]"
+    rc = lib().orc_din_attention_pool_act_f32(_p(table, f), K, _p(hist, ctypes.c_int64),
+                                              _p(hist_len, ctypes.c_int32), _p(cand, ctypes.c_int64), T,
+                                              _p(W1, f), _p(b1, f), H1, _p(W2, f), _p(b2, f), H2, _p(W3, f),
+                                              _p(b3, f), int(normalize), DIN_ACTIVATIONS[activation], _p(ap, f) if ap is not None else None,
+                                              ctypes.c_int64(B), _p(out, f), _p(scores, f), int(acc64))
     assert rc == 0, rc
     return out, scores
 
