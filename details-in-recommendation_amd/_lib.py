@@ -102,6 +102,7 @@ SIGNATURES = {
                                                 ctypes.c_float, ctypes.c_float, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dir_din_attention_pool_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                            c_i32, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "dir_din_activation_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dir_din_attention_pool_act_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                                c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_cin_layer_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp]),

@@ -1095,6 +1095,54 @@ constexpr int kDinBwdMaxWg = kCUs;   // one workgroup per CU (153 KB of LDS)
 
 using namespace dir;
 
+// PReLU / Dice (inference form) over the rows of a [B, N] activation, in place: the hidden layers of DIN's 200-80 MLP (arXiv:1706.06978
+// section 5.3) -- one read and one write instead of the six elementwise library passes of p = sigmoid(scale s + shift),
+// f = s (alpha + p (1 - alpha)).  N % 4 == 0, ld % 4 == 0, 16-byte aligned rows.
+template <int ACT>
+__global__ __launch_bounds__(256) void din_act_rows_k(float* __restrict__ x, int64_t ld, int64_t B, int N, const float* __restrict__ alpha,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift) {
+    const int nv = N >> 2;
+    const int64_t total = B * nv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nv;
+        const int c = (int)(i - r * nv) * 4;
+        float4 v = *reinterpret_cast<float4*>(x + r * ld + c);
+        const float4 a = *reinterpret_cast<const float4*>(alpha + c);
+        float s[4] = {v.x, v.y, v.z, v.w};
+        const float al[4] = {a.x, a.y, a.z, a.w};
+        if (ACT == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = s[e] > 0.f ? s[e] : al[e] * s[e];
+        } else {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pg = 1.0f / (1.0f + __expf(-(s[e] * scv[e] + shv[e])));
+                s[e] = pg * s[e] + (1.0f - pg) * al[e] * s[e];
+            }
+        }
+        *reinterpret_cast<float4*>(x + r * ld + c) = make_float4(s[0], s[1], s[2], s[3]);
+    }
+}
+
+extern "C" int dir_din_activation_rows_f32(float* x, int64_t ld, int64_t B, int N, int activation, const float* alpha, const float* scale,
+                                           const float* shift, dir_stream_t stream) {
+    const char* name = "dir_din_activation_rows_f32";
+    DIR_CHECK_ARG(B >= 0 && N > 0 && ld >= N, "%s: B=%lld N=%d ld=%lld", name, (long long)B, N, (long long)ld);
+    DIR_CHECK_ARG(activation == DIR_DIN_ACT_PRELU || activation == DIR_DIN_ACT_DICE, "%s: activation %d (1 PReLU, 2 Dice)", name, activation);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(x && alpha && (activation == DIR_DIN_ACT_PRELU || (scale && shift)), "%s: null pointer", name);
+    if ((N & 3) || (ld & 3) || !aligned16(x) || !aligned16(alpha) || (scale && !aligned16(scale)) || (shift && !aligned16(shift)))
+        return fail(DIR_E_UNSUPPORTED, "%s: N and ld must be multiples of 4, x / alpha / scale / shift 16-byte aligned", name);
+    const int64_t blocks = (B * (N >> 2) + 255) / 256;
+    dim3 grid((unsigned)grid_for(blocks));
+    if (activation == DIR_DIN_ACT_PRELU) hipLaunchKernelGGL(din_act_rows_k<1>, grid, dim3(256), 0, as_stream(stream), x, ld, B, N, alpha, scale, shift);
+    else hipLaunchKernelGGL(din_act_rows_k<2>, grid, dim3(256), 0, as_stream(stream), x, ld, B, N, alpha, scale, shift);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
+
 extern "C" int dir_din_attention_pool_act_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
                                               int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
                                               const float* W3, const float* b3, int normalize, int activation, const float* act_params,

@@ -231,7 +231,14 @@ class DIN(nn.Module):
             elif self.dnn_activation_fn == "sigmoid":
                 net = torch.sigmoid(dense_act(lin, net, None))
             else:
-                net = act(dense_act(lin, net, None))                       # HIP layer, then the elementwise PReLU / Dice
+                pre = dense_act(lin, net, None)
+                if torch.is_grad_enabled() or not pre.is_cuda or pre.shape[1] % 4 or pre.stride(0) % 4 or pre.data_ptr() % 16:
+                    net = act(pre)                                         # TRAIN mode (batch statistics, autograd): torch ops
+                elif self.dnn_activation_fn == "prelu":
+                    net = ops.din_activation_rows_(pre, "prelu", act.alpha)              # HIP layer, then ONE in-place pass
+                else:
+                    sc, sh = act.scale_shift()
+                    net = ops.din_activation_rows_(pre, "dice", act.alpha, sc, sh)
         return units1(self.logits_layer, net)
 
     def predict(self, features):

@@ -407,6 +407,18 @@ def din_act_params(H1, H2, alpha1, alpha2, scale1=None, shift1=None, scale2=None
     return torch.cat([t.detach().to(torch.float32).reshape(-1) for t in parts]).contiguous()
 
 
+def din_activation_rows_(x, activation, alpha, scale=None, shift=None):
+    """PReLU / Dice (inference form) over the rows of x [B, N], in place (include/dir_hip.h: dir_din_activation_rows_f32)."""
+    _dev(x, torch.float32, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("din_activation_rows_: x must be [B, N] with unit column stride")
+    B, N = x.shape
+    vec = [None if t is None else _dev(t.detach().contiguous(), torch.float32, "activation parameter") for t in (alpha, scale, shift)]
+    _lib.check(_lib.load().dir_din_activation_rows_f32(_ptr(x), x.stride(0) if B > 1 else max(N, x.stride(0)), B, N, DIN_ACTIVATIONS[activation],
+                                                       _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]), _stream()))
+    return x
+
+
 def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, want_scores=False, activation="sigmoid",
                        act_params=None):
     """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T]).  activation "prelu" / "dice": the

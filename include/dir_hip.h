@@ -215,6 +215,10 @@ int dir_din_attention_pool_f32(const float* table, int K, const int64_t* hist,
  * act_params: DEVICE float [3 H1 + 3 H2] = alpha1 [H1], scale1 [H1], shift1 [H1], alpha2 [H2], scale2 [H2], shift2 [H2] (PReLU reads
  * the alphas only).  Inference only; K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 64 (DIR_E_UNSUPPORTED otherwise). */
 enum { DIR_DIN_ACT_SIGMOID = 0, DIR_DIN_ACT_PRELU = 1, DIR_DIN_ACT_DICE = 2 };
+/* PReLU / Dice (the same inference forms) over a [B, N] activation IN PLACE, rows ld floats apart: the hidden layers of DIN's 200-80 MLP.
+ * alpha, scale, shift: DEVICE [N] (PReLU: scale / shift may be NULL).  N and ld multiples of 4, 16-byte aligned. */
+int dir_din_activation_rows_f32(float* x, int64_t ld, int64_t B, int N, int activation, const float* alpha, const float* scale,
+                                const float* shift, dir_stream_t stream);
 int dir_din_attention_pool_act_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                                    const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                                    const float* b3, int normalize, int activation, const float* act_params, int64_t B, float* out,
