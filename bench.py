@@ -1253,6 +1253,16 @@ def main():
         res["world_size"] = dist.get_world_size() if dist.is_initialized() else 1
         res["launcher"] = os.environ.get("DIR_BENCH_LAUNCHED_BY") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                                                       "external" if "WORLD_SIZE" in os.environ else "single process")
+        try:        # whole-model workloads: which hidden layers ran on the HIP dense kernels and which fell to the library (dense.MIN_ROWS)
+            from dir_amd import dense as _dense
+            if _dense.ROUTING["hip"] or _dense.ROUTING["library"]:
+                calls = max(1, args.warmup + args.steps)
+                res["dense_routing"] = {"min_rows_for_hip_dense": _dense.MIN_ROWS,
+                                        "hip_layers_per_step": {k: round(v / calls, 2) for k, v in _dense.ROUTING["hip"].items()},
+                                        "library_layers_per_step": {k: round(v / calls, 2) for k, v in _dense.ROUTING["library"].items()},
+                                        "note": "layers inside fused nodes (tower_bf3_k, mlp_stack / mlp_head autograd nodes) are HIP and not counted here"}
+        except Exception:
+            pass
         if world > 1:
             res["backend"] = backend + (" (exchange staged through host memory)" if os.environ.get("DIR_SHARD_HOST_STAGED") == "1" else "")
             if "link_bytes" in roof:
@@ -1269,16 +1279,18 @@ def main():
                                "hbm": {"alg_bytes_per_launch": roof["alg_bytes"], "achieved_GBps": hbm, "frac_of_8TBps": hbm / HBM_PEAK_GBS}}
         elif roof["bound"] == "hbm":
             ach = roof["alg_bytes"] / (launch_us * 1e-6) / 1e9
-            traffic = None
+            traffic, tmeta = None, {}
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and world == 1:
                 try:
-                    traffic = json.load(open(tpath)).get(wl)
+                    tmeta = json.load(open(tpath))
+                    traffic = tmeta.get(wl)
                 except Exception:
                     traffic = None
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "frac_of_guide_copy_ceiling": ach / HBM_COPY_GBS,
-                               "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of this command; not re-measured in this run)" if traffic else None,
+                               "traffic": traffic, "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc passes of this command at %s; not re-measured in this run)"
+                                                                      % tmeta.get("_measured_at", "an earlier HEAD")) if traffic else None,
                                "kernel": roof["kernel"], "alg_bytes_per_launch": roof["alg_bytes"],
                                "avg_launch_us": launch_us}
             if world == 1 and wl in ("deepfm_gather_fm", "gather_only"):

@@ -573,7 +573,8 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
                                                       int nt /* > 0: payload mode, the table is found from the key among nt tables */,
                                                       float* __restrict__ carry /* [tiles][2][K] */,
                                                       const float* __restrict__ fm_g = nullptr /* FM: d loss / d fm_logit [B] */,
-                                                      const float* __restrict__ fm_sum = nullptr /* FM: S[b] = sum_f e[b,f], [B, K] */) {
+                                                      const float* __restrict__ fm_sum = nullptr /* FM: S[b] = sum_f e[b,f], [B, K] */,
+                                                      int stage_min_dups = 8 /* stage the tile's gradients in LDS when it holds at least this many duplicates */) {
     using V = BV<VEC>;
     using T = typename V::T;
     constexpr int NG = 256 / LPS;
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
         }
     };
     // a tile of (nearly) distinct rows has nothing serial to hide: it skips the LDS round trip (workgroup-uniform choice)
-    const bool staged = STAGE && ne - nruns >= 8;
+    const bool staged = STAGE && ne - nruns >= stage_min_dups;
     if (staged) {
 #pragma unroll
         for (int q = 0; q < LPS; ++q) {                     // ADA_TILE / NG = LPS entries per group
@@ -861,17 +862,18 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
     while (lps < (vec ? K / 4 : K)) lps <<= 1;
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "%s: K=%d too wide", name, K);
     const int64_t ntiles = (int64_t)p.ntiles;
+    static const int stage_min = getenv("DIR_ADA_STAGE_MIN") ? atoi(getenv("DIR_ADA_STAGE_MIN")) : 8;       // development A/B switch
     dim3 gfix((unsigned)((ntiles * lps + 255) / 256));
 #define DIR_CASE(L, V)                                                                                                         \
     do {                                                                                                                       \
         if constexpr (std::is_same<U, AdagradUpd>::value) {                                                                    \
             if (fm_g)                                                                                                          \
                 hipLaunchKernelGGL((adagrad_tile_k<L, V, U, true>), dim3((unsigned)ntiles), dim3(256), 0, st, upd, F, K, n, k1, v1, grad, \
-                                   grad_ld, grad_fs, row_base, (uint32_t)total_rows, nt, carry, fm_g, fm_sum);                  \
+                                   grad_ld, grad_fs, row_base, (uint32_t)total_rows, nt, carry, fm_g, fm_sum, stage_min);       \
         }                                                                                                                      \
         if (!fm_g)                                                                                                             \
             hipLaunchKernelGGL((adagrad_tile_k<L, V, U>), dim3((unsigned)ntiles), dim3(256), 0, st, upd, F, K, n, k1, v1, grad, grad_ld, \
-                               grad_fs, row_base, (uint32_t)total_rows, nt, carry);                                             \
+                               grad_fs, row_base, (uint32_t)total_rows, nt, carry, nullptr, nullptr, stage_min);                \
         hipLaunchKernelGGL((adagrad_fix_k<L, V, U>), gfix, dim3(256), 0, st, upd, F, K, n, ntiles, k1, v1, row_base,             \
                            (uint32_t)total_rows, nt, carry);                                                                    \
     } while (0)

@@ -22,6 +22,20 @@ _RELUS = (torch.relu, F.relu, torch.nn.functional.relu)
 import os as _os
 MIN_ROWS = int(_os.environ.get("DIR_DENSE_MIN_ROWS", "6144"))
 _PACK_CACHE = {}
+# How the hidden layers of the models were routed since the last reset: "hip" (dir_dense_* kernels) or "library" (rocBLAS / hipBLASLt
+# through nn.Linear: batches under MIN_ROWS, uncovered activations, < 16 units), keyed by (in, out): bench.py puts it in the line.
+ROUTING = {"hip": {}, "library": {}}
+
+
+def _route(kind, lin):
+    d = ROUTING[kind]
+    key = "%dx%d" % (lin.in_features, lin.out_features)
+    d[key] = d.get(key, 0) + 1
+
+
+def reset_routing():
+    ROUTING["hip"].clear()
+    ROUTING["library"].clear()
 
 
 def pack_weight(weight):
@@ -360,6 +374,7 @@ def _dense_act(lin, x, activation, bn):
     relu = activation in _RELUS
     prepadded = x.dim() == 2 and x.shape[1] != lin.in_features and x.shape[1] == lin.in_features + (-lin.in_features) % 4
     if (activation is None or relu) and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and lin.out_features >= 16:
+        _route("hip", lin)
         train = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
         fold = bn is not None and not (bn.training and torch.is_grad_enabled())
         ps, psh = _bn_affine(bn) if fold else (None, None)
@@ -385,6 +400,7 @@ def _dense_act(lin, x, activation, bn):
             return y if fold else _apply_bn(bn, y)
     if prepadded:
         x = x[:, :lin.in_features]
+    _route("library", lin)
     y = lin(x)
     return _apply_bn(bn, activation(y) if activation is not None else y)
 
