@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 for pass in "FETCH_SIZE TCC_EA0_RDREQ_sum" "WRITE_SIZE TCC_EA0_WRREQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $pass | cut -d' ' -f1)
   rm -rf gpurun_out/pmc_t_$tag
-  DIR_BENCH_NO_SECONDARY=1 rocprofv3 --pmc $pass --output-format csv -d gpurun_out/pmc_t_$tag -o t -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/pmc_t_$tag.log 2>&1
+  DIR_BENCH_NO_SECONDARY=1 DIR_BENCH_NO_SWEEP=1 rocprofv3 --pmc $pass --output-format csv -d gpurun_out/pmc_t_$tag -o t -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/pmc_t_$tag.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, collections
@@ -24,7 +24,7 @@ fetch = m["FETCH_SIZE"] * 1024
 ids_half = fetch - rows                      # what is left after the exactly-counted 64-byte row requests: the id stream at half
 read = rows + 2 * ids_half
 write = m["WRITE_SIZE"] * 1024
-out = {"command": "DIR_BENCH_NO_SECONDARY=1 rocprofv3 --pmc <one group per pass> --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline",
+out = {"command": "DIR_BENCH_NO_SECONDARY=1 DIR_BENCH_NO_SWEEP=1 rocprofv3 --pmc <one group per pass> --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline",
        "kernel": "gather_onehot_k<4,4,16,26,fm,out,nt> (uniform ids)", "launches_averaged": {c: len(n[c]) for c in n},
        "per_launch_mean": m,
        "derived": {"FETCH_bytes": fetch, "RDREQ_x64B": m.get("TCC_EA0_RDREQ_sum", 0) * 64, "row_read_bytes_exact": rows,
