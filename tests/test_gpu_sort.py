@@ -114,5 +114,6 @@ def test_sparse_training_step_replays_from_a_hip_graph(built_lib):
             for _ in range(80):
                 other()
         torch.cuda.synchronize()
-        assert torch.equal(ts_a.arena, ts_b.arena), "replay %d differs from the eager twin" % r
+        # (the arenas' alignment padding is uninitialised: compare the row blocks -- embeddings and accumulators)
+        assert all(torch.equal(x, y) for x, y in zip(ts_a.rows, ts_b.rows)), "replay %d differs from the eager twin" % r
         assert all(torch.equal(x, y) for x, y in zip(lin_a.tables, lin_b.tables))
