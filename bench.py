@@ -38,7 +38,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the 2:1-sparsity figure is n
 # product; an fp32-input MFMA runs at 1/16 of the bf16 rate (MI355X_MICROARCH.md, Matrix cores).  Every MFMA-bound line prices the
 # ALGORITHMIC flops of each kernel with the factor of the pipe mode that kernel executes on and divides by the dense bf16 peak, so
 # `frac` is the share of the step the matrix pipe would need at peak: never above 1.
-PIPE_COST = {"bf16x3": 6.0, "f32": 16.0}
+PIPE_COST = {"bf16x3": 6.0, "f32": 16.0, "f16x2": 3.0}      # f16x2: two fp16 pieces per operand, three products (csrc/cin_bf3.hip, round 4)
 
 
 def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
@@ -69,12 +69,14 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
             continue
         if forward:
             a = ops.cin_auto_arith(m, D, hp, h) if arith == "auto" else arith
-            if k == 0 and a == "bf16x3" and getattr(ops, "CIN_L1_PAIRS", False) and 8 <= m <= 40:
+            if arith == "auto" and a == "bf16x3" and getattr(ops, "CIN_FWD_SPLIT", "bf16x3") == "f16x2":
+                a = "f16x2"                       # what "auto" gives a forward layer (ops.cin_layer)
+            if k == 0 and a in ("bf16x3", "f16x2") and getattr(ops, "CIN_L1_PAIRS", False) and 8 <= m <= 40:
                 # the first layer (xk is x0): dir_cin_layer1_bf16x3_f32 multiplies the m (m + 1) / 2 unordered pairs only (padded to 64-pair halves)
                 # -- priced on the reduction slots it executes
                 slots = -(-(m * (m + 1) // 2) // 64) * 64
-                alg, pipe = alg + f, pipe + f * slots / float(m * m) * PIPE_COST["bf16x3"]
-                modes["fwd1"] = "bf16x3_pairs"
+                alg, pipe = alg + f, pipe + f * slots / float(m * m) * PIPE_COST[a]
+                modes["fwd1"] = a + "_pairs"
             else:
                 alg, pipe = alg + f, pipe + f * PIPE_COST[a]
                 modes["fwd%d" % (k + 1)] = a
@@ -471,7 +473,9 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
             "lookup": ("ShardedTables.lookup_async of batch i+1 issued before the CIN of batch i (2 all_to_all per chunk, 2 chunks, check lazy, "
                        "side streams on %s CUs each)" % (st.side_cus or "all")
                        if st is not None else "local gather (one GPU holds the table)"), "scaling": "weak",
-            "dtype": "f32 via bf16x3 split, f32 accumulate" if default_is_bf3 else "f32",
+            "dtype": ("f32 via fp16x2 split (layers 1-2) / bf16x3 split (pooled last layer), f32 accumulate"
+                      if getattr(ops, "CIN_FWD_SPLIT", "") == "f16x2" and ops.CIN_ARITH == "auto" else "f32 via bf16x3 split, f32 accumulate")
+            if default_is_bf3 else "f32",
             "per_gpu_fp32_equiv_TFLOPs_lookup_included": tf,
             "per_gpu_bf16_pipe_TFLOPs_executed": pipe_flops * steps / el / 1e12 if default_is_bf3 else None,
             "per_gpu_frac_of_bf16_mfma_peak": pipe_flops * steps / el / 1e12 / MFMA_BF16_PEAK_TF if default_is_bf3 else None,
@@ -1005,11 +1009,11 @@ def main():
         # reduction -> 220 v_mfma_f32_16x16x4_f32 (1024 multiply-adds each) per tile, on the fp32 MFMA pipe
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
         executed = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)
-        din_arith = "f32" if os.environ.get("DIR_DIN_ARITH") == "f32" else "bf16x3"
+        din_arith = os.environ.get("DIR_DIN_ARITH") if os.environ.get("DIR_DIN_ARITH") in ("f32", "bf16x3") else "f16x2"
         roof = {"bound": "mfma", "alg_flops": executed, "pipe_flops": executed * PIPE_COST[din_arith],
-                "kernel": "din_wave_k (%s)" % ("fp32 MFMA 16x16x4" if din_arith == "f32" else "bf16x3 on MFMA 16x16x32"),
+                "kernel": "din_wave_k (%s)" % ("fp32 MFMA 16x16x4" if din_arith == "f32" else din_arith + " on MFMA 16x16x32"),
                 "modes": {"din_wave_k": din_arith}, "survey_8d_flops": survey,
-                "dtype": "f32 via bf16x3 split, f32 accumulate" if din_arith == "bf16x3" else "f32",
+                "dtype": "f32" if din_arith == "f32" else "f32 via %s split, f32 accumulate" % din_arith,
                 "note": "flops = the MFMAs the kernel issues (masked history positions are skipped, layer 1 is regrouped to a 2K reduction); "
                         "SURVEY 8d's all-T, 4K-wide count is reported as survey_8d_flops and not priced"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
@@ -1033,12 +1037,12 @@ def main():
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
         unit = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)                      # as the `din` workload: the MFMAs the unit issues over valid rows
         mlp = 2.0 * B * (2 * Kd * 200 + 200 * 80)
-        din_arith = "f32" if os.environ.get("DIR_DIN_ARITH") == "f32" else "bf16x3"
+        din_arith = os.environ.get("DIR_DIN_ARITH") if os.environ.get("DIR_DIN_ARITH") in ("f32", "bf16x3") else "f16x2"
         mlp_modes = {"mlp_%d" % (i + 1): ("bf16x3" if ops.dense_auto_arith(B, a, b_) == "bf16x3" else "f32") for i, (a, b_) in enumerate(((2 * Kd, 200), (200, 80)))}
         pipe = unit * PIPE_COST[din_arith] + 2.0 * B * (2 * Kd * 200 * PIPE_COST[mlp_modes["mlp_1"]] + 200 * 80 * PIPE_COST[mlp_modes["mlp_2"]])
         roof = {"bound": "mfma", "alg_flops": unit + mlp, "pipe_flops": pipe, "modes": dict(mlp_modes, din_wave_k=din_arith),
                 "kernel": "DIN forward: din_wave_k (%s unit, %s) + candidate lookup + dense 128-200-80 (%s) + units-1 head" % (att_act, din_arith, dnn_act),
-                "dtype": "f32 via bf16x3 split, f32 accumulate" if din_arith == "bf16x3" else "f32",
+                "dtype": "f32" if din_arith == "f32" else "f32 via %s split, f32 accumulate" % din_arith,
                 "note": "flops = the unit's MFMAs over valid history rows + the two hidden layers; the logit layer and the elementwise activations are not priced"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "attention": [4 * Kd, 80, 40, 1], "attention_activation": att_act, "dnn": [2 * Kd, 200, 80, 1],
                     "dnn_activation": dnn_act})
@@ -1096,7 +1100,7 @@ def main():
         survey = 3 * B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
         executed = 2.0 * 1024 * rt * (220 + 660)     # 16x16x4-MFMA equivalents per 16-row tile: forward 220; backward 220 recompute + 440
-        din_arith = "f32" if os.environ.get("DIR_DIN_ARITH") == "f32" else "bf16x3"      # the forward's arithmetic; the backward kernels are fp32 MFMA
+        din_arith = os.environ.get("DIR_DIN_ARITH") if os.environ.get("DIR_DIN_ARITH") in ("f32", "bf16x3") else "f16x2"      # the forward's arithmetic; the backward kernels are fp32 MFMA
         pipe = 2.0 * 1024 * rt * (220 * PIPE_COST[din_arith] + 660 * PIPE_COST["f32"])
         roof = {"bound": "mfma", "alg_flops": executed, "pipe_flops": pipe, "modes": {"din_wave_k": din_arith, "din_rows_k": "f32", "din_wgrad_k": "f32"},
                 "kernel": "din_wave_k (%s) + din_rows_k + din_wgrad_k (fp32 MFMA 16x16x4)" % din_arith, "survey_8d_flops": survey,
@@ -1118,13 +1122,15 @@ def main():
                 off += h
         arith = args.cin_arith or ops.CIN_ARITH
         alg, pipe, modes = cin_flops(ops, B, m, D, Hs, arith=arith)
-        bf3 = "bf16x3" in modes.values()
-        # priced on the pipe it runs on: six bf16 piece products per fp32 product (csrc/cin_bf3.hip) against the dense bf16 peak;
+        bf3 = any(str(v).startswith(("bf16x3", "f16x2", "pooled")) for v in modes.values())
+        f16 = any(str(v).startswith("f16x2") for v in modes.values())
+        # priced on the pipe it runs on: six bf16 (three fp16) piece products per fp32 product (csrc/cin_bf3.hip) against the dense bf16 peak;
         # the fp32-equivalent rate (the algorithm's flops / time) is reported beside it
         roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes, "kernel": ("cin_bf3_k<PAIRS> (layer 1) + cin_bf3_k (layer 2) + the last layer in its pooled form (cin_pool_z_k + dense_bf3_k)"
                            if any(str(v).startswith("pooled") for v in modes.values()) else "cin_bf3_k x3") if bf3 else "cin_k x3",
-                "dtype": "f32 via bf16x3 split, f32 accumulate" if bf3 else "f32"}
-        arith = "bf16x3" if bf3 else "f32"
+                "dtype": ("f32 via fp16x2 split (layers 1-2) / bf16x3 split (pooled last layer), f32 accumulate" if f16 else
+                          "f32 via bf16x3 split, f32 accumulate") if bf3 else "f32"}
+        arith = ("f16x2" if f16 else "bf16x3") if bf3 else "f32"
         cfg.update({"m": m, "D": D, "layers": list(Hs), "outputs": "pooled [B,384]; xout of layers 1-2", "arith": arith})
 
     elif wl == "cin_backward":

@@ -112,6 +112,8 @@ SIGNATURES = {
     "dir_cin_pool_dx_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "dir_cin_layer1_bf16x3_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "dir_cin_layer1_bf16x3_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "dir_cin_layer_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "dir_cin_layer1_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_cin_bf16x3_dot_partials": (c_i32, [c_i32, c_i32, c_i32]),
     "dir_cin_dw_bf16x3_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i64]),
     "dir_cin_dw_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp]),

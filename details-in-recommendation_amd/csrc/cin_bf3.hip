@@ -63,13 +63,64 @@ __device__ __forceinline__ void bt_split_pair(float a, float b, unsigned int& w0
     w2 = bt_pk(sa, sb);
 }
 
+// ---- round 4: a second arithmetic, "fp16 x 2" (NP = 2) -----------------------------------------------------------------------------------
+// An fp32 operand as the sum of TWO fp16 pieces by round-to-nearest, v ~ v0 + v1 (2 x 11 significant bits: relative error <= 2^-22 while
+// the second piece is a normal fp16 number, i.e. |v| >= 2^-3; below that the residual is a subnormal and the ABSOLUTE error is <= 2^-25
+// per element; |v| must stay below fp16's 65 504), and of the four piece products the THREE of weight >= 2^-11 on
+// v_mfma_f32_16x16x32_f16 (same rate as the bf16 form; fp16 x fp16 products are exact in fp32): half the matrix instructions of bf16 x 3
+// and two thirds of its split arithmetic, for a scaled error of 3-6e-7 against the double-accumulating oracle on embedding-scale operands
+// (tools/f16x2_probe.py: about what fp32's own accumulation order costs; bf16 x 3: 2-3e-9) -- inside the 1e-5 bar with a factor 20 to
+// spare.  Used by the FORWARD layers (operands are embeddings / activations / weights: O(1) magnitudes); the data-gradient form keeps
+// bf16 x 3 (its left operand is a gradient: small magnitudes would sit in fp16's subnormal range).  ops.CIN_ARITH / DIR_CIN_ARITH select.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int bt_pk_h(float a, float b) {     // v_cvt_pk_f16_f32 (round to nearest even), a in the low half
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));      // (as bt_pk: float(f16(a)) is then formed from w, not by a second rounding of a)
+    return w;
+}
+__device__ __forceinline__ void bt_split_pair_h(float a, float b, unsigned int& w0, unsigned int& w1) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    w0 = bt_pk_h(a, b);
+    const h2_t h = __builtin_bit_cast(h2_t, w0);
+    w1 = bt_pk_h(a - (float)h[0], b - (float)h[1]);
+}
+template <int NP> struct BtPc;
+template <> struct BtPc<3> {
+    using op_t = bf16x8_t;
+    static constexpr int NMF = 6;                                   // matrix instructions per (k-step, tile)
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[3]) { bt_split_pair(a, b, w[0], w[1], w[2]); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[3], const op_t (&b)[3], f32x4 t) {      // the six products, smallest first
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], t, 0, 0, 0);
+        return t;
+    }
+};
+template <> struct BtPc<2> {
+    using op_t = f16x8_t;
+    static constexpr int NMF = 3;
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[2]) { bt_split_pair_h(a, b, w[0], w[1]); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[2], const op_t (&b)[2], f32x4 t) {      // the three products, smallest first
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], t, 0, 0, 0);
+        return t;
+    }
+};
+
 // W [H, Hp*m] fp32 -> image [column block of CT tiles][half kh][field j][ks][plane][ct][lane][8 e] bf16, element e of lane l of column
 // tile ct in k-step ks = piece of W[h = hoff + 16*(CT*cb + ct) + (l & 15)][i = KS*32*kh + 32*ks + 8*(l >> 4) + e][j]; zero where h >= H or
 // i >= Hp.  One launch per block width (the 128-wide blocks, then the narrower last block).
+template <int NP>
 __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict__ W, int m, int Hp, int H, int KS, int nkh, int ncb, int CT,
                                                         int hoff, unsigned int* __restrict__ img) {
     const int64_t total = (int64_t)ncb * nkh * m * KS * CT * 64 * 4;   // one thread per pair of e
-    const int stepdw = 3 * CT * 64 * 4;                                // dwords per k-step
+    const int stepdw = NP * CT * 64 * 4;                               // dwords per k-step
     for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
         int64_t q = e_;
         const int ep = (int)(q & 3); q >>= 2;
@@ -83,13 +134,12 @@ __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict_
         const int i = KS * 32 * kh + 32 * ks + 8 * (l >> 4) + 2 * ep;
         const float v0 = (h < H && i < Hp) ? W[(int64_t)h * Hp * m + (int64_t)i * m + j] : 0.f;
         const float v1 = (h < H && i + 1 < Hp) ? W[(int64_t)h * Hp * m + (int64_t)(i + 1) * m + j] : 0.f;
-        unsigned int p0, p1, p2;
-        bt_split_pair(v0, v1, p0, p1, p2);
+        unsigned int pw[NP];
+        BtPc<NP>::split(v0, v1, pw);
         const int64_t chunk = ((int64_t)cb * nkh + kh) * m + j;
         const int64_t base = (chunk * KS + ks) * stepdw + (ct * 64 + l) * 4 + ep;     // plane stride: CT*64*4 dwords
-        img[base] = p0;
-        img[base + CT * 64 * 4] = p1;
-        img[base + 2 * CT * 64 * 4] = p2;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) img[base + q * CT * 64 * 4] = pw[q];
     }
 }
 
@@ -106,7 +156,8 @@ __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict_
 // A operand of pair p is the product x0[r, i(p)] * x0[r, j(p)], formed from the LDS-resident x0 slice when the half's operands are split
 // (ptab[p] = i | j << 8; mx = the real field count).  351 reduction slots instead of 26 x 32 = 832 at m = 26.
 template <int KS, int CT /* column tiles of 16 per workgroup: 8 (128 columns), or 6 / 4 / 2 for the last block of a layer */,
-          int RT = 2 /* row tiles of 16 per wave */, bool DOT = false, int FJ = 1 /* fields per staged chunk */, bool PAIRS = false>
+          int RT = 2 /* row tiles of 16 per wave */, bool DOT = false, int FJ = 1 /* fields per staged chunk */, bool PAIRS = false,
+          int NP = 3 /* pieces per operand: 3 = bf16 x 3, 2 = fp16 x 2 (forward only) */>
 __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                      const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
                                                      int nkh, int hoff /* first output column of this launch */, int64_t R,
@@ -116,7 +167,10 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      const float* __restrict__ addp /* optional [B, H] (row stride addp_ld): added to xout[b, h, :] */,
                                                      int64_t addp_ld, const unsigned short* __restrict__ ptab /* PAIRS: i | j << 8 per pair */,
                                                      int mx /* fields of the x0 slice (= m unless PAIRS) */) {
-    constexpr int STEPB = 3 * CT * 1024;                         // bytes of W image per k-step of 32
+    using Pc = BtPc<NP>;
+    using op_t = typename Pc::op_t;
+    static_assert(NP == 3 || !DOT, "the data-gradient form keeps bf16 x 3");
+    constexpr int STEPB = NP * CT * 1024;                        // bytes of W image per k-step of 32
     constexpr int CHB = KS * STEPB;                              // bytes of W image per (half, field); a staged chunk holds FJ of them
     constexpr int BT_ROWS = 8 * 16 * RT;                         // rows per workgroup (shadows the 256 of the forward)
     constexpr int WR = 16 * RT;                                  // rows per wave
@@ -135,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     const unsigned char* gimg = img + (int64_t)blockIdx.y * nchunk * CHB;
 
     auto stage_w = [&](int c, int nf, int buf) {     // fields c .. c + nf - 1: nf * KS * 3 * CT pieces of 1 KB over 8 waves, lane-linear
-        for (int piece = wave; piece < nf * KS * 3 * CT; piece += 8) {
+        for (int piece = wave; piece < nf * KS * NP * CT; piece += 8) {
             const unsigned char* src = gimg + (int64_t)c * CHB + piece * 1024 + lane * 16;
             unsigned char* dst = Wb + buf * (FJ * CHB) + piece * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
@@ -172,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     f32x4 xprev[RT];                                                                 // x0[rows of the lane's accumulator registers, previous field]
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) xprev[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8_t a[KS][RT][3];                                                           // the half's A operands: [k-step][row tile][piece]
+    op_t a[KS][RT][NP];                                                              // the half's A operands: [k-step][row tile][piece]
     // DOT: y in the accumulators' layout (rows 4*lg .. 4*lg+3 of tile rt = four consecutive d of one sample, column 16*ct + n)
     f32x4 yv[DOT ? RT : 1][DOT ? CT : 1];
     if constexpr (DOT) {
@@ -233,11 +287,16 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     v[e] = i < Hp ? x : 0.f;          // the W image is zero there; 0 * garbage must stay 0
                 }
                 }
-                unsigned int w[3][4];
+                unsigned int w[NP][4];
 #pragma unroll
-                for (int pr = 0; pr < 4; ++pr) bt_split_pair(v[2 * pr], v[2 * pr + 1], w[0][pr], w[1][pr], w[2][pr]);
+                for (int pr = 0; pr < 4; ++pr) {
+                    unsigned int pw[NP];
+                    Pc::split(v[2 * pr], v[2 * pr + 1], pw);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[ks][rt][p] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
+                    for (int p = 0; p < NP; ++p) w[p][pr] = pw[p];
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) a[ks][rt][p] = __builtin_bit_cast(op_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
             }
         for (int j0 = 0; j0 < m; j0 += FJ, ++u) {      // one staged chunk = (this half, fields j0 .. j0 + nf - 1)
           const int buf = u & 1;
@@ -261,9 +320,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
             // (two register sets used alternately: the loops are unrolled, the set index is a compile-time constant -- copying "next"
             // into "current" would cost 12 v_mov per group, one VALU instruction per MFMA)
-            bf16x8_t bq[2][3];
+            op_t bq[2][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[0][p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
+            for (int p = 0; p < NP; ++p) bq[0][p] = *reinterpret_cast<const op_t*>(wl + p * CT * 1024);
 #pragma unroll
             for (int ks = 0; ks < KSN; ++ks) {
 #pragma unroll
@@ -273,9 +332,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     if (!lastg) {
                         const unsigned char* wp = wl + (ct + 1 < CT ? ks : ks + 1) * STEPB + ((ct + 1) % CT) * 1024;
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) bq[(gi + 1) & 1][p] = *reinterpret_cast<const bf16x8_t*>(wp + p * CT * 1024);
+                        for (int p = 0; p < NP; ++p) bq[(gi + 1) & 1][p] = *reinterpret_cast<const op_t*>(wp + p * CT * 1024);
                     }
-                    const bf16x8_t (&bc)[3] = bq[gi & 1];
+                    const op_t (&bc)[NP] = bq[gi & 1];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         f32x4 t;
@@ -291,25 +350,21 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                         } else {
                             t = T[rt][ct];
                         }
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][0], bc[2], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][2], bc[0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][1], bc[1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][0], bc[1], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][1], bc[0], t, 0, 0, 0);
-                        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks][rt][0], bc[0], t, 0, 0, 0);
-                        T[rt][ct] = t;
+                        T[rt][ct] = Pc::mma(a[ks][rt], bc, t);
                     }
                     if (!lastg) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                        constexpr int NM = RT * Pc::NMF;                 // matrix instructions of the group (12 for bf16 x 3, 6 for fp16 x 2)
+                        constexpr int NPAIR = NM < 8 ? NM : 8;           // (accumulate fma, MFMA) pairs of the chunk's first k-step
+                        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
                         if (ks == 0) {
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) {
+                            for (int q = 0; q < NPAIR; ++q) {
                                 __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             }
-                            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                            if constexpr (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
                         } else {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -393,7 +448,7 @@ using namespace dir;
 
 // Shape plan shared by the workspace query and the launcher: halves of i, column blocks
 struct Bf3Plan { int KS, nkh, bw, nfull, ctl; int64_t chunks, bytes_full, bytes_last; };
-static Bf3Plan bf3_plan(int m, int Hp, int H, bool dot) {
+static Bf3Plan bf3_plan(int m, int Hp, int H, bool dot, int np = 3) {
     Bf3Plan p;
     p.KS = Hp <= 32 ? 1 : 2;
     p.nkh = (Hp + p.KS * 32 - 1) / (p.KS * 32);
@@ -402,8 +457,8 @@ static Bf3Plan bf3_plan(int m, int Hp, int H, bool dot) {
     const int r = H - 16 * p.bw * p.nfull;
     p.ctl = r ? ((r + 15) / 16 + 1) / 2 * 2 : 0;                              // tiles of the last block: 2, 4, 6 or 8 (dot form: 2 or 4)
     p.chunks = (int64_t)p.nkh * m;
-    p.bytes_full = (int64_t)p.nfull * p.chunks * p.KS * 3 * p.bw * 1024;
-    p.bytes_last = p.chunks * p.KS * 3 * p.ctl * 1024;
+    p.bytes_full = (int64_t)p.nfull * p.chunks * p.KS * np * p.bw * 1024;
+    p.bytes_last = p.chunks * p.KS * np * p.ctl * 1024;
     return p;
 }
 
@@ -417,7 +472,7 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: 64-column blocks, two fields per chunk, dot partials)
 static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                    float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
-                   const float* addp = nullptr, int64_t addp_ld = 0) {
+                   const float* addp = nullptr, int64_t addp_ld = 0, int np = 3 /* 2: the fp16 x 2 forward */) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -432,34 +487,42 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     const int64_t R = B * D;
     hipStream_t st = as_stream(stream);
     const bool dot = y != nullptr;
-    const Bf3Plan pl = bf3_plan(m, Hp, H, dot);
+    if (dot && np != 3) return fail(DIR_E_UNSUPPORTED, "%s: the data-gradient form runs bf16 x 3 only", name);
+    const Bf3Plan pl = bf3_plan(m, Hp, H, dot, np);
     unsigned char* img = static_cast<unsigned char*>(workspace);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
         const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
-        hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
-                           reinterpret_cast<unsigned int*>(dst));
+        if (np == 2)
+            hipLaunchKernelGGL(cin_bf3_pack_w_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
+                               reinterpret_cast<unsigned int*>(dst));
+        else
+            hipLaunchKernelGGL(cin_bf3_pack_w_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
+                               reinterpret_cast<unsigned int*>(dst));
     };
     if (pl.nfull) pack(pl.nfull, pl.bw, 0, img);
     if (pl.ctl) pack(1, pl.ctl, 16 * pl.bw * pl.nfull, img + pl.bytes_full);
     const unsigned nrb = (unsigned)((R + 255) / 256);
     const int64_t dot_block = (int64_t)pl.nkh * B * m * D;         // floats of dot partials per column block
-#define BT_LAUNCH(K, C, DOT_, FJ_, NCB, HOFF, IMG, DOTP)                                                                              \
+#define BT_LAUNCH(K, C, DOT_, FJ_, NP_, NCB, HOFF, IMG, DOTP)                                                                         \
     do {                                                                                                                              \
         static LdsOnce once;                                                                                                      \
-        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_>);                                                        \
-        const size_t shmem = 2 * (size_t)FJ_ * K * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                    \
-        hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, dshift, \
-                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m);                                                        \
+        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_>);                                            \
+        const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256;                                  \
+        hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m);                     \
     } while (0)
-#define BT_LAUNCH_FWD(C, NCB, HOFF, IMG)                                            \
-    do {                                                                            \
-        if (pl.KS == 1) BT_LAUNCH(1, C, false, 1, NCB, HOFF, IMG, nullptr);         \
-        else BT_LAUNCH(2, C, false, 1, NCB, HOFF, IMG, nullptr);                    \
+#define BT_LAUNCH_FWD(C, NCB, HOFF, IMG)                                                 \
+    do {                                                                                 \
+        if (np == 2) {                                                                   \
+            if (pl.KS == 1) BT_LAUNCH(1, C, false, 1, 2, NCB, HOFF, IMG, nullptr);       \
+            else BT_LAUNCH(2, C, false, 1, 2, NCB, HOFF, IMG, nullptr);                  \
+        } else if (pl.KS == 1) BT_LAUNCH(1, C, false, 1, 3, NCB, HOFF, IMG, nullptr);    \
+        else BT_LAUNCH(2, C, false, 1, 3, NCB, HOFF, IMG, nullptr);                      \
     } while (0)
 #define BT_LAUNCH_DOT(C, NCB, HOFF, IMG, DOTP)                                      \
     do {                                                                            \
-        if (pl.KS == 1) BT_LAUNCH(1, C, true, 2, NCB, HOFF, IMG, DOTP);             \
-        else BT_LAUNCH(2, C, true, 2, NCB, HOFF, IMG, DOTP);                        \
+        if (pl.KS == 1) BT_LAUNCH(1, C, true, 2, 3, NCB, HOFF, IMG, DOTP);          \
+        else BT_LAUNCH(2, C, true, 2, 3, NCB, HOFF, IMG, DOTP);                     \
     } while (0)
     const unsigned char* li = img + pl.bytes_full;
     const int lo = 16 * pl.bw * pl.nfull;
@@ -495,6 +558,13 @@ extern "C" int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const 
                    stream);
 }
 
+extern "C" int dir_cin_layer_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
+                                       float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                       dir_stream_t stream) {
+    return bf3_run("dir_cin_layer_f16x2_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace, workspace_bytes,
+                   stream, nullptr, 0, 2);
+}
+
 // ---- the first layer over field pairs (PAIRS) -----------------------------------------------------------------------------------------------
 namespace dir {
 __host__ __device__ __forceinline__ int l1_pair_index(int a, int b, int m) { return a * m - a * (a - 1) / 2 + (b - a); }      // a <= b, row-major over a
@@ -516,10 +586,10 @@ __global__ __launch_bounds__(256) void cin_l1_pairs_k(const float* __restrict__ 
 }  // namespace dir
 
 struct L1Plan { int np, npad; Bf3Plan pl; int64_t off_w2, off_tab, total; };
-static L1Plan l1_plan(int m, int H) {
+static L1Plan l1_plan(int m, int H, int pieces = 3) {
     L1Plan q;
     q.np = m * (m + 1) / 2;
-    q.pl = bf3_plan(1, q.np, H, false);                       // one "field", the pairs as the reduction channels
+    q.pl = bf3_plan(1, q.np, H, false, pieces);               // one "field", the pairs as the reduction channels
     q.npad = q.pl.nkh * q.pl.KS * 32;
     int64_t off = q.pl.bytes_full + q.pl.bytes_last;
     off = (off + 255) & ~(int64_t)255;
@@ -536,9 +606,8 @@ extern "C" int64_t dir_cin_layer1_bf16x3_workspace_bytes(int m, int H) {
     return l1_plan(m, H).total;
 }
 
-extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
-                                         int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
-    const char* name = "dir_cin_layer1_bf16x3_f32";
+static int l1_run(const char* name, int pieces, const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
+                  int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     DIR_CHECK_ARG(m > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d H=%d D=%d", name, m, H, D);
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(x0 && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -546,7 +615,7 @@ extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m,
     if (!(D == 4 || D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 4, 8, 16, 32)", name, D);
     if (m < 8 || m > 40) return fail(DIR_E_UNSUPPORTED, "%s: m=%d (supported: 8..40; use dir_cin_layer_bf16x3_f32)", name, m);
     if (xout && !aligned16(xout)) return fail(DIR_E_BADARG, "%s: xout must be 16-byte aligned", name);
-    const L1Plan q = l1_plan(m, H);
+    const L1Plan q = l1_plan(m, H, pieces);
     DIR_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0 && workspace_bytes >= q.total,
                   "%s: workspace must be 256-byte aligned and hold dir_cin_layer1_bf16x3_workspace_bytes(m, H) bytes", name);
     const Bf3Plan& pl = q.pl;                                  // KS = 2 (m >= 8: more than 32 pairs)
@@ -560,19 +629,28 @@ extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m,
     hipLaunchKernelGGL(cin_l1_pairs_k, dim3(grid_for(((int64_t)H * m * m + 255) / 256)), dim3(256), 0, st, W, m, H, q.np, q.npad, W2, ptab);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
         const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
-        hipLaunchKernelGGL(cin_bf3_pack_w_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W2, 1, q.np, H, pl.KS, pl.nkh, ncb, CT, hoff,
-                           reinterpret_cast<unsigned int*>(dst));
+        if (pieces == 2)
+            hipLaunchKernelGGL(cin_bf3_pack_w_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W2, 1, q.np, H, pl.KS, pl.nkh, ncb, CT,
+                               hoff, reinterpret_cast<unsigned int*>(dst));
+        else
+            hipLaunchKernelGGL(cin_bf3_pack_w_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W2, 1, q.np, H, pl.KS, pl.nkh, ncb, CT,
+                               hoff, reinterpret_cast<unsigned int*>(dst));
     };
     if (pl.nfull) pack(pl.nfull, pl.bw, 0, img);
     if (pl.ctl) pack(1, pl.ctl, 16 * pl.bw * pl.nfull, img + pl.bytes_full);
     const unsigned nrb = (unsigned)((R + 255) / 256);
-#define L1_LAUNCH(C, NCB, HOFF, IMG)                                                                                                    \
+#define L1_LAUNCH_NP(C, NP_, NCB, HOFF, IMG)                                                                                            \
     do {                                                                                                                                \
         static LdsOnce once;                                                                                                      \
-        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true>);                                                   \
-        const size_t shmem = 2 * (size_t)2 * 3 * C * 1024 + sizeof(float) * (size_t)m * 256;                                            \
-        hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, dshift, \
-                           pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m);                              \
+        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true, NP_>);                                              \
+        const size_t shmem = 2 * (size_t)2 * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256;                                          \
+        hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true, NP_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m);                    \
+    } while (0)
+#define L1_LAUNCH(C, NCB, HOFF, IMG)                           \
+    do {                                                       \
+        if (pieces == 2) L1_LAUNCH_NP(C, 2, NCB, HOFF, IMG);   \
+        else L1_LAUNCH_NP(C, 3, NCB, HOFF, IMG);               \
     } while (0)
     const unsigned char* li = img + pl.bytes_full;
     const int lo = 16 * pl.bw * pl.nfull;
@@ -585,8 +663,19 @@ extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m,
         default: L1_LAUNCH(8, 1, lo, li); break;
     }
 #undef L1_LAUNCH
+#undef L1_LAUNCH_NP
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
+                                         int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    return l1_run("dir_cin_layer1_bf16x3_f32", 3, x0, W, m, H, D, B, xout, pooled, pooled_ld, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dir_cin_layer1_f16x2_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
+                                        int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    return l1_run("dir_cin_layer1_f16x2_f32", 2, x0, W, m, H, D, B, xout, pooled, pooled_ld, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dir_cin_bf16x3_dot_partials(int m, int Hp, int H) {

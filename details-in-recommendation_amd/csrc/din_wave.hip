@@ -45,6 +45,7 @@ typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
 
 struct DinWaveSh {
     static constexpr bool kBf3 = false;
+    static constexpr int kNP = 3;          // (unused by the fp32 path)
     float whd[DW_H1P * DW_WS];         // (Wh + Wd)^T
     float wp[DW_H1P * DW_WS];          // Wp^T
     float wc[DW_H1P * DW_WS];          // (Wa - Wd)^T
@@ -68,16 +69,25 @@ struct DinWaveSh {
 // profiles/NOTES.md R3.6).  The round-2 attempt at this kernel failed on exactly that: the packed (row tile 0, row tile 1) sums of
 // layer 3 lost one sigmoid(pre2) * w3 term of the FIRST row tile in 30-150 samples per launch.  tools/check_pk_mfma.py (run by build.py)
 // rejects any kernel that holds both instruction kinds.
-struct DinWaveSh3 {
+// Round 4: the same kernel on "fp16 x 2" (NP = 2; cin_bf3.hip explains the arithmetic): two fp16 pieces per operand, the three products
+// of weight >= 2^-11 on v_mfma_f32_16x16x32_f16 -- half the matrix instructions and 6 instead of 11 split instructions per operand
+// pair.  The unit's operands are table rows, their products with the candidate row, sigmoid / PReLU / Dice outputs and weights:
+// embedding-scale numbers, well inside fp16's range; the result stays within 1e-5 of the oracle with a factor 10-20 to spare
+// (tests/test_gpu_parity.py: the 26-shape DIN test runs every arithmetic).  DIR_DIN_ARITH = f16x2 (default) | bf16x3 | f32.
+template <int NP>
+struct DinWaveShP {
     static constexpr bool kBf3 = true;
-    unsigned int whd3[2 * 5 * 3 * 64 * 4];     // (Wh + Wd)^T pieces
-    unsigned int wp3[2 * 5 * 3 * 64 * 4];      // Wp^T pieces
-    unsigned int w23[3 * 3 * 3 * 64 * 4];      // W2^T pieces; hidden 80..95 of the third k-step are zero
+    static constexpr int kNP = NP;
+    unsigned int whd3[2 * 5 * NP * 64 * 4];    // (Wh + Wd)^T pieces
+    unsigned int wp3[2 * 5 * NP * 64 * 4];     // Wp^T pieces
+    unsigned int w23[3 * 3 * NP * 64 * 4];     // W2^T pieces; hidden 80..95 of the third k-step are zero
     float wc[DW_H1P * DW_WS];                  // (Wa - Wd)^T (the per-sample term stays on the VALU in fp32)
     float b1[DW_H1P], b2[DW_H2P], w3[DW_H2P];
     float cvec[DW_WAVES][DW_H1P];
     float av[DW_WAVES][DW_K];
 };
+using DinWaveSh3 = DinWaveShP<3>;
+using DinWaveSh2 = DinWaveShP<2>;
 
 // [slot][0..7] next sample of each range, [slot][8] waves finished.  All zero between launches (the last wave of a launch
 // clears its record).
@@ -139,6 +149,58 @@ __device__ __forceinline__ void dw_split_pair(float a, float b, unsigned int& w0
     w1 = dw_pk(ra, rb);
     const float sa = ra - __builtin_bit_cast(float, w1 << 16), sb = rb - __builtin_bit_cast(float, w1 & 0xffff0000u);
     w2 = dw_pk(sa, sb);
+}
+typedef _Float16 dw_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int dw_pk_h(float a, float b) {     // v_cvt_pk_f16_f32 (round to nearest even), a in the low half
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));
+    return w;
+}
+template <int NP> struct DwPc;
+template <> struct DwPc<3> {
+    using op_t = dw_bf16x8;
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[3]) { dw_split_pair(a, b, w[0], w[1], w[2]); }
+    __device__ static __forceinline__ f32x4w mma(const op_t (&a)[3], const op_t (&x)[3], f32x4w c) {      // six products, smallest first
+        c = DW_MFMA3(a[0], x[2], c);
+        c = DW_MFMA3(a[2], x[0], c);
+        c = DW_MFMA3(a[1], x[1], c);
+        c = DW_MFMA3(a[0], x[1], c);
+        c = DW_MFMA3(a[1], x[0], c);
+        c = DW_MFMA3(a[0], x[0], c);
+        return c;
+    }
+};
+template <> struct DwPc<2> {
+    using op_t = dw_f16x8;
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[2]) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        w[0] = dw_pk_h(a, b);
+        const h2_t h = __builtin_bit_cast(h2_t, w[0]);
+        w[1] = dw_pk_h(a - (float)h[0], b - (float)h[1]);
+    }
+    __device__ static __forceinline__ f32x4w mma(const op_t (&a)[2], const op_t (&x)[2], f32x4w c) {      // three products, smallest first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], x[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], x[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], x[0], c, 0, 0, 0);
+        return c;
+    }
+};
+// eight fp32 values (two float4) -> the NP operands that sum to them
+template <int NP>
+__device__ __forceinline__ void dw_split8p(const float4 s0, const float4 s1, typename DwPc<NP>::op_t (&x)[NP]) {
+    unsigned int w[NP][4];
+    const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        unsigned int pw[NP];
+        DwPc<NP>::split(v[2 * pr], v[2 * pr + 1], pw);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) w[pc][pr] = pw[pc];
+    }
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) x[pc] = __builtin_bit_cast(typename DwPc<NP>::op_t, (dw_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
 }
 // eight fp32 values (two float4) -> the three bf16x8 operands that sum to them
 __device__ __forceinline__ void dw_split8(const float4 s0, const float4 s1, dw_bf16x8 (&x)[3]) {
@@ -268,18 +330,21 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const float* actl, const i
         for (int part = 0; part < 2; ++part) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                dw_bf16x8 xb[NT][3];
+                constexpr int NP = Sh::kNP;
+                using op_t = typename DwPc<NP>::op_t;
+                op_t xb[NT][NP];
 #pragma unroll
-                for (int rt = 0; rt < NT; ++rt) dw_split8(part ? hp[rt][2 * ks] : hv[rt][2 * ks], part ? hp[rt][2 * ks + 1] : hv[rt][2 * ks + 1], xb[rt]);
+                for (int rt = 0; rt < NT; ++rt)
+                    dw_split8p<NP>(part ? hp[rt][2 * ks] : hv[rt][2 * ks], part ? hp[rt][2 * ks + 1] : hv[rt][2 * ks + 1], xb[rt]);
                 const unsigned int* img = part ? sh.wp3 : sh.whd3;
 #pragma unroll
                 for (int mt = 0; mt < 5; ++mt) {
-                    dw_bf16x8 a[3];
+                    op_t a[NP];
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
-                        a[pc] = __builtin_bit_cast(dw_bf16x8, *reinterpret_cast<const dw_u32x4*>(img + ((ks * 5 + mt) * 3 + pc) * 256 + lane4));
+                    for (int pc = 0; pc < NP; ++pc)
+                        a[pc] = __builtin_bit_cast(op_t, *reinterpret_cast<const dw_u32x4*>(img + ((ks * 5 + mt) * NP + pc) * 256 + lane4));
 #pragma unroll
-                    for (int rt = 0; rt < NT; ++rt) acc1[mt][rt] = dw_mfma6(a, xb[rt], acc1[mt][rt]);
+                    for (int rt = 0; rt < NT; ++rt) acc1[mt][rt] = DwPc<NP>::mma(a, xb[rt], acc1[mt][rt]);
                 }
             }
         }
@@ -303,21 +368,23 @@ __device__ __forceinline__ void dw_pass(const Sh& sh, const float* actl, const i
         // ---- layer 2: pre2^T, three k-steps (hidden 80..95 are zeros on both sides) -------------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-            dw_bf16x8 xb[NT][3];
+            constexpr int NP = Sh::kNP;
+            using op_t = typename DwPc<NP>::op_t;
+            op_t xb[NT][NP];
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) {
                 const f32x4w z0 = acc1[2 * ks][rt];
                 const f32x4w z1 = 2 * ks + 1 < 5 ? acc1[2 * ks + 1 < 5 ? 2 * ks + 1 : 0][rt] : (f32x4w){0.f, 0.f, 0.f, 0.f};
-                dw_split8(make_float4(z0[0], z0[1], z0[2], z0[3]), make_float4(z1[0], z1[1], z1[2], z1[3]), xb[rt]);
+                dw_split8p<NP>(make_float4(z0[0], z0[1], z0[2], z0[3]), make_float4(z1[0], z1[1], z1[2], z1[3]), xb[rt]);
             }
 #pragma unroll
             for (int m2 = 0; m2 < 3; ++m2) {
-                dw_bf16x8 a[3];
+                op_t a[NP];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    a[pc] = __builtin_bit_cast(dw_bf16x8, *reinterpret_cast<const dw_u32x4*>(sh.w23 + ((ks * 3 + m2) * 3 + pc) * 256 + lane4));
+                for (int pc = 0; pc < NP; ++pc)
+                    a[pc] = __builtin_bit_cast(op_t, *reinterpret_cast<const dw_u32x4*>(sh.w23 + ((ks * 3 + m2) * NP + pc) * 256 + lane4));
 #pragma unroll
-                for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = dw_mfma6(a, xb[rt], acc2[m2][rt]);
+                for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = DwPc<NP>::mma(a, xb[rt], acc2[m2][rt]);
             }
         }
     } else {
@@ -527,15 +594,14 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
                     pp[e] = W1[(size_t)(3 * DW_K + f + e) * H1 + m] * SC;
                 }
             }
-            unsigned int q0, q1, q2;
-            dw_split_pair(hd[0], hd[1], q0, q1, q2);
-            sh.whd3[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
-            sh.whd3[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
-            sh.whd3[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
-            dw_split_pair(pp[0], pp[1], q0, q1, q2);
-            sh.wp3[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
-            sh.wp3[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
-            sh.wp3[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
+            constexpr int NP = Sh::kNP;
+            unsigned int qw[NP];
+            DwPc<NP>::split(hd[0], hd[1], qw);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) sh.whd3[(t * NP + pc) * 256 + l * 4 + jp] = qw[pc];
+            DwPc<NP>::split(pp[0], pp[1], qw);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) sh.wp3[(t * NP + pc) * 256 + l * 4 + jp] = qw[pc];
         }
         for (int idx = tid; idx < 3 * 3 * 64 * 4; idx += 64 * DW_WAVES) {
             const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
@@ -546,11 +612,11 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
 #pragma unroll
             for (int e = 0; e < 2; ++e)      // a padded hidden unit is sigmoid(0) = 0.5: its weights are zero
                 v[e] = (hid + e < H1 && h2 < H2) ? W2[(size_t)(hid + e) * H2 + h2] * SC : 0.f;
-            unsigned int q0, q1, q2;
-            dw_split_pair(v[0], v[1], q0, q1, q2);
-            sh.w23[(t * 3 + 0) * 256 + l * 4 + jp] = q0;
-            sh.w23[(t * 3 + 1) * 256 + l * 4 + jp] = q1;
-            sh.w23[(t * 3 + 2) * 256 + l * 4 + jp] = q2;
+            constexpr int NP = Sh::kNP;
+            unsigned int qw[NP];
+            DwPc<NP>::split(v[0], v[1], qw);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) sh.w23[(t * NP + pc) * 256 + l * 4 + jp] = qw[pc];
         }
     } else {
         for (int idx = tid; idx < DW_H2P * DW_H1P; idx += 64 * DW_WAVES) {
@@ -739,27 +805,31 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
                     const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                     const float* b3, int normalize, int64_t B, float* out, float* scores, const int64_t* tile_off, float* saved, int activation,
                     const float* act_params) {
-    // DIR_DIN_ARITH = bf16x3 (default) | f32: the arithmetic of the two MFMA layers; DIR_DIN_STATIC = 1 | 0: a static stride over the
+    // DIR_DIN_ARITH = f16x2 (default) | bf16x3 | f32: the arithmetic of the two MFMA layers; DIR_DIN_STATIC = 1 | 0: a static stride over the
     // samples instead of the device-side queue (default: static for bf16x3 -- its per-sample time is short enough that the ticket
     // atomics cost more than the imbalance they remove, 0.45 vs 0.50 ms at config 4 -- and the queue for fp32).  Both are read per call
     // (A/B runs and tests flip them inside one process).  saved != nullptr: the training forward (z1, z2 records for the backward).
     const char* arith = getenv("DIR_DIN_ARITH");
-    const bool bf3 = !(arith && strcmp(arith, "f32") == 0);
+    const int ar = (arith && strcmp(arith, "f32") == 0) ? 0 : (arith && strcmp(arith, "bf16x3") == 0) ? 1 : 2;      // default: fp16 x 2
+    const bool bf3 = ar != 0;
     const bool save = saved != nullptr;
     typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,
                            const float*, int, const float*, const float*, int, long long, float*, float*, int, const int64_t*, float*, const float*);
     // [arithmetic][save | PReLU | Dice]: the training forward (SAVE) exists for the sigmoid unit only
-    static const kern_t kerns[2][4] = {{&din_wave_k<DinWaveSh, false, 0>, &din_wave_k<DinWaveSh, true, 0>, &din_wave_k<DinWaveSh, false, 1>,
+    static const kern_t kerns[3][4] = {{&din_wave_k<DinWaveSh, false, 0>, &din_wave_k<DinWaveSh, true, 0>, &din_wave_k<DinWaveSh, false, 1>,
                                         &din_wave_k<DinWaveSh, false, 2>},
                                        {&din_wave_k<DinWaveSh3, false, 0>, &din_wave_k<DinWaveSh3, true, 0>, &din_wave_k<DinWaveSh3, false, 1>,
-                                        &din_wave_k<DinWaveSh3, false, 2>}};
+                                        &din_wave_k<DinWaveSh3, false, 2>},
+                                       {&din_wave_k<DinWaveSh2, false, 0>, &din_wave_k<DinWaveSh2, true, 0>, &din_wave_k<DinWaveSh2, false, 1>,
+                                        &din_wave_k<DinWaveSh2, false, 2>}};
     if (activation < 0 || activation > 2 || (activation != 0 && (save || !act_params)))
         return fail(DIR_E_UNSUPPORTED, "din_wave_k: activation %d (0 sigmoid, 1 PReLU, 2 Dice; the training forward covers the sigmoid unit only)", activation);
-    static LdsOnce once[2][4];
+    static LdsOnce once[3][4];
     const int which = activation ? 1 + activation : (save ? 1 : 0);
-    const size_t shmem = (((bf3 ? sizeof(DinWaveSh3) : sizeof(DinWaveSh)) + 15) & ~(size_t)15) + (activation ? sizeof(float) * DW_ACT_FLOATS : 0);
-    const kern_t kern = kerns[bf3][which];
-    if (!lds_limit(once[bf3][which], (int)shmem, kern)) return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
+    const size_t shbytes = ar == 0 ? sizeof(DinWaveSh) : ar == 1 ? sizeof(DinWaveSh3) : sizeof(DinWaveSh2);
+    const size_t shmem = ((shbytes + 15) & ~(size_t)15) + (activation ? sizeof(float) * DW_ACT_FLOATS : 0);
+    const kern_t kern = kerns[ar][which];
+    if (!lds_limit(once[ar][which], (int)shmem, kern)) return fail(DIR_E_HIP, "din_wave_k: cannot reserve %zu B of LDS", shmem);
     // Up to DW_SLOTS launches may be in flight at once (distinct streams); a record is reused only after DW_SLOTS further launches.
     const char* stat = getenv("DIR_DIN_STATIC");
     const bool static_split = stat ? atoi(stat) != 0 : bf3;

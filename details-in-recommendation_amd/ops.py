@@ -1122,8 +1122,12 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
             "gW2": gW2, "gb2": gb2, "gW3": gW3, "gb3": gb3}
 
 
-# default arithmetic of cin_layer: "auto" (bf16x3 on the shapes it covers, fp32 MFMA otherwise) | "f32" | "bf16x3"
+# default arithmetic of cin_layer: "auto" (the split kernels on the shapes they cover, fp32 MFMA otherwise) | "f32" | "bf16x3" | "f16x2"
 CIN_ARITH = os.environ.get("DIR_CIN_ARITH", "auto")
+# which split arithmetic "auto" gives a FORWARD layer (csrc/cin_bf3.hip): "f16x2" (two fp16 pieces per operand, three products: half the
+# matrix instructions; operands are embeddings / activations / weights) or "bf16x3" (three bf16 pieces, six products: fp32's exponent
+# range).  Layers whose left operand is a gradient (the backward's data-gradient forms) always take bf16x3.
+CIN_FWD_SPLIT = os.environ.get("DIR_CIN_FWD_SPLIT", "f16x2")
 
 
 def cin_bf16x3_covers(m, D):
@@ -1191,7 +1195,7 @@ def cin_pool_dx(x0, xk, dZ, add_pooled=None, dx0=None):
     return dxk, out
 
 
-def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None):
+def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, grad_operand=False):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
     want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
@@ -1202,10 +1206,14 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None):
     (dir_cin_layer1_bf16x3_f32): the same sums in another order.
     want_xout=False with arith "auto" / "bf16x3": the pooled sums alone are sum_{i,j} W[h,i,j] Z[b,i,j], Z = sum_d xk x0 (cin_pool_z) --
     the sum over d first, then ONE dense product, 1/D of the layer's matrix work; z_out (a list): Z is appended to it when that form ran
-    (the backward of a stack reuses it)."""
+    (the backward of a stack reuses it).
+    arith "f16x2" = dir_cin_layer_f16x2_f32 / dir_cin_layer1_f16x2_f32: two fp16 pieces per operand, three products (|operands| < 65 504;
+    scaled error 3-6e-7 on embedding-scale data); "auto" picks it for forward layers (CIN_FWD_SPLIT) unless grad_operand says that xk is
+    a gradient (the backward's forward-form contractions): small magnitudes belong on bf16x3."""
     arith = arith or CIN_ARITH
-    if arith not in ("auto", "f32", "bf16x3"):
-        raise ValueError("cin_layer: arith must be 'auto', 'f32' or 'bf16x3'")
+    if arith not in ("auto", "f32", "bf16x3", "f16x2"):
+        raise ValueError("cin_layer: arith must be 'auto', 'f32', 'bf16x3' or 'f16x2'")
+    auto = arith == "auto"
     if (not want_xout and arith != "f32" and CIN_POOLED_LAST and x0.dim() == 3 and xk.dim() == 3 and x0.shape[0] > 0
             and cin_pooled_covers(x0.shape[1], x0.shape[2], xk.shape[1]) and x0.is_cuda and x0.is_contiguous() and xk.is_contiguous()
             and W.dim() == 2 and W.shape[1] == xk.shape[1] * x0.shape[1]):
@@ -1222,6 +1230,8 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None):
         return None, pooled
     if arith == "auto":
         arith = cin_auto_arith(x0.shape[1], x0.shape[2], xk.shape[1], W.shape[0])
+        if arith == "bf16x3" and CIN_FWD_SPLIT == "f16x2" and not grad_operand:
+            arith = "f16x2"
     _dev(x0, torch.float32, "x0")
     _dev(xk, torch.float32, "xk")
     _dev(W, torch.float32, "W")
@@ -1235,23 +1245,24 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None):
     xout = torch.empty((B, H, D), dtype=torch.float32, device=x0.device) if want_xout else None
     if pooled is None:
         pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
-    if arith == "bf16x3":
+    if arith in ("bf16x3", "f16x2"):
         if not cin_bf16x3_covers(m, D):
-            raise ValueError("cin_layer: arith='bf16x3' covers m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (m, D))
+            raise ValueError("cin_layer: arith=%r covers m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (arith, m, D))
         lib = _lib.load()
+        f_l1 = lib.dir_cin_layer1_f16x2_f32 if arith == "f16x2" else lib.dir_cin_layer1_bf16x3_f32
+        f_ly = lib.dir_cin_layer_f16x2_f32 if arith == "f16x2" else lib.dir_cin_layer_bf16x3_f32
         if CIN_L1_PAIRS and xk.data_ptr() == x0.data_ptr() and Hp == m and 8 <= m <= 40 and B > 0:
             # the first layer of a stack (xk IS x0): a quadratic form in x0 -- the kernel multiplies the m (m + 1) / 2 unordered pairs only
             # (dir_cin_layer1_bf16x3_f32)
             nbytes = int(lib.dir_cin_layer1_bf16x3_workspace_bytes(m, H))
             ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x0.device)
             wp = ctypes.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
-            _lib.check(lib.dir_cin_layer1_bf16x3_f32(_ptr(x0), _ptr(W), m, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled),
-                                                     pooled.stride(0), wp, nbytes, _stream()))
+            _lib.check(f_l1(_ptr(x0), _ptr(W), m, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled), pooled.stride(0), wp, nbytes, _stream()))
             return xout, pooled
         nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, Hp, H))
         ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
-        _lib.check(lib.dir_cin_layer_bf16x3_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None,
-                                                _ptr(pooled), pooled.stride(0), _ptr(ws), nbytes, _stream()))
+        _lib.check(f_ly(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled), pooled.stride(0), _ptr(ws),
+                        nbytes, _stream()))
         return xout, pooled
     mt = next((t for t in CIN_FIELD_TILES if t >= m), m)
     if mt != m and B > 0:
@@ -1626,13 +1637,13 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
         need_xk = need_x0 = False
     if need_xk:
         W1 = W3.permute(1, 0, 2).reshape(Hp, H * m).contiguous()
-        dxk, _ = cin_layer(x0, G, W1)
+        dxk, _ = cin_layer(x0, G, W1, grad_operand=True)
     if need_x0:
         for g0 in range(0, Hp, CIN_MAX_FIELDS):
             mg = min(CIN_MAX_FIELDS, Hp - g0)
             xg = xk if mg == Hp else xk[:, g0:g0 + mg, :].contiguous()
             W2 = W3[:, g0:g0 + mg, :].permute(2, 0, 1).reshape(m, H * mg).contiguous()
-            part, _ = cin_layer(xg, G, W2)
+            part, _ = cin_layer(xg, G, W2, grad_operand=True)
             dx0 = part if dx0 is None else dx0.add_(part)
     if need_w:
         dW = cin_dw(x0, xk, G, arith=dw_arith)
@@ -1685,7 +1696,7 @@ def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None, z_top=No
             # tools/cin_l1_dx_probe.py)
             W3 = W.view(H, m, m)
             Ws_ = (W3 + W3.transpose(1, 2)).permute(1, 0, 2).reshape(m, H * m).contiguous()          # [i, h*m + j]
-            tot, _ = cin_layer(x0, G, Ws_, arith=arith)
+            tot, _ = cin_layer(x0, G, Ws_, arith=arith, grad_operand=True)
             return (tot if dx0 is None else dx0.add_(tot)), dWs
         below = gps[k - 1] if k > 0 else None
         a = cin_auto_arith(m, D, H, Hp) if arith == "auto" else arith

@@ -268,6 +268,18 @@ int dir_cin_pool_dx_f32(const float* x0, const float* xk, const float* dZ, int m
 int64_t dir_cin_layer1_bf16x3_workspace_bytes(int m, int H);
 int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled, int64_t pooled_ld,
                               void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+
+/* The same two forward layers on "fp16 x 2" arithmetic (csrc/cin_bf3.hip, round 4): every fp32 operand as two fp16 pieces by
+ * round-to-nearest, the three piece products of weight >= 2^-11 on v_mfma_f32_16x16x32_f16 with fp32 accumulation -- half the matrix
+ * instructions of bf16 x 3.  Preconditions: |x0|, |xk|, |W| < 65 504 (fp16's range; larger values become inf); operand elements below
+ * 2^-3 in magnitude carry an ABSOLUTE representation error of up to 2^-25 each (relative 2^-22 above).  On embedding-scale operands the
+ * result is within 3-6e-7 (scaled) of the double-accumulating oracle.  Same arguments, shapes and workspaces
+ * (dir_cin_bf16x3_workspace_bytes / dir_cin_layer1_bf16x3_workspace_bytes) as the bf16 x 3 entries.  Forward layers only: the
+ * data-gradient form keeps bf16 x 3 (gradients are small numbers). */
+int dir_cin_layer_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
+                            float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+int dir_cin_layer1_f16x2_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled, int64_t pooled_ld,
+                             void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 /* The same kernel with a second result per field, for the layer's data gradients (y's tile in registers; 64-column blocks):
  *   xout[b,h,d] as above, and  dot[b,j,d] = sum_h y[b,h,d] * T_j[(b,d),h],  T_j[r,h] = sum_i xk[r,i] * W[h, i*m+j]
  * written as dir_cin_bf16x3_dot_partials(m, Hp, H) partial sums [P][B, m, D] (one per 64-column block and half of i; the caller adds

@@ -1355,7 +1355,7 @@ def test_din_saved_activations_backward_matches_recompute(built_lib, normalize, 
     cand[3 % B] = -1
     hist, hl, cand = hist.cuda(), hl.cuda(), cand.cuda()
     gout = torch.randn(B, K, generator=g).cuda()
-    for arith in ("bf16x3", "f32"):
+    for arith in ("f16x2", "bf16x3", "f32"):
         monkeypatch.setenv("DIR_DIN_ARITH", arith)
         out0, sc0 = ops.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, want_scores=True)
         out1, sc1, saved = ops.din_attention_pool_save(table, hist, hl, cand, *Ws, normalize=normalize)

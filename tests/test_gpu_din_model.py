@@ -38,7 +38,7 @@ def _unit_case(rng, V, K, B, T, H1, H2):
 
 
 @pytest.mark.parametrize("activation", ["prelu", "dice"])
-@pytest.mark.parametrize("arith", ["bf16x3", "f32"])
+@pytest.mark.parametrize("arith", ["f16x2", "bf16x3", "f32"])
 @pytest.mark.parametrize("B,T,H1,H2,normalize", [(1, 1, 4, 4, False), (37, 50, 80, 40, False), (64, 64, 80, 48, True), (300, 17, 36, 8, True),
                                                  (129, 33, 64, 16, False), (2000, 50, 80, 40, True)])
 def test_din_unit_prelu_dice_match_oracle(built_lib, oracle, activation, arith, B, T, H1, H2, normalize):

@@ -190,9 +190,9 @@ def test_cross_hand_kat(ops):
                                             (40, 50, 64, 64, 32), (40, 33, 64, 16, 4), (40, 50, 32, 20, 8), (40, 21, 16, 12, 4),
                                             (25, 40, 64, 48, 48)])
 @pytest.mark.parametrize("normalize", [False, True])
-@pytest.mark.parametrize("arith", ["bf16x3", "f32"])
+@pytest.mark.parametrize("arith", ["f16x2", "bf16x3", "f32"])
 def test_din_attention_pool(ops, oracle, B, T, K, H1, H2, normalize, arith, monkeypatch):
-    """Both arithmetics of the (K 64, H1 <= 80, H2 <= 48) wave-per-sample kernel (DIR_DIN_ARITH, read per call) against the
+    """The three arithmetics (fp16 x 2: the default since round 4; bf16 x 3; fp32 MFMA) of the (K 64, H1 <= 80, H2 <= 48) wave-per-sample kernel (DIR_DIN_ARITH, read per call) against the
     double-accumulating oracle at the same 1e-5 bar; the other shape classes have one kernel and ignore the switch."""
     monkeypatch.setenv("DIR_DIN_ARITH", arith)
     rng = np.random.default_rng(T * 3 + K)
@@ -240,9 +240,19 @@ def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     bx, bp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="bf16x3")
     _close(bx.cpu().numpy(), ref_x)
     _close(bp.cpu().numpy(), ref_p)
-    ax, ap = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))            # "auto" is one of the two, bitwise
-    want = (bx, bp) if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
+    # round 4: the fp16 x 2 forward (two fp16 pieces per operand, three products: dir_cin_layer_f16x2_f32) at the same bar
+    fx, fp_ = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="f16x2")
+    _close(fx.cpu().numpy(), ref_x)
+    _close(fp_.cpu().numpy(), ref_p)
+    fx2, _ = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="f16x2")
+    assert torch.equal(fx, fx2)                                      # rerun: bitwise equal
+    ax, ap = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))            # "auto" is one of them, bitwise
+    split = (fx, fp_) if ops.CIN_FWD_SPLIT == "f16x2" else (bx, bp)
+    want = split if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
     assert torch.equal(ax, want[0]) and torch.equal(ap, want[1])
+    gx, gp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), grad_operand=True)      # a gradient operand never takes the fp16 split
+    want_g = (bx, bp) if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
+    assert torch.equal(gx, want_g[0]) and torch.equal(gp, want_g[1])
 
 
 def test_bf16x3_kernels_on_empty_and_single_row_batches(ops):
@@ -462,13 +472,21 @@ def test_full_size_properties_cross_cin_din(ops, oracle):
     W = torch.randn((H, H * m), generator=g, device="cuda") * (1.0 / (H * m) ** 0.5)
     xo, po = ops.cin_layer(c0, xk, W)
     xo2, po2 = ops.cin_layer(c0, xk * 2.0, W)
-    assert torch.equal(xo2, xo * 2.0) and torch.equal(po2, po * 2.0)
+    # linearity in xk under a power of two: EXACT for the bf16 x 3 split (the pieces of 2 x are twice the pieces of x: fp32's exponent
+    # range), and within the fp16 x 2 split's error for the default forward arithmetic of round 4 (a second piece that is an fp16
+    # subnormal rounds differently after the scaling): checked at 2e-6 there, bitwise for arith="bf16x3"
+    assert float(((xo2 - xo * 2.0).abs() / (1 + xo2.abs())).max()) <= 2e-6 and float(((po2 - po * 2.0).abs() / (1 + po2.abs())).max()) <= 2e-6
+    bo, bp_ = ops.cin_layer(c0, xk, W, arith="bf16x3")
+    bo2, bp2 = ops.cin_layer(c0, xk * 2.0, W, arith="bf16x3")
+    assert torch.equal(bo2, bo * 2.0) and torch.equal(bp2, bp_ * 2.0)
+    assert float(((bo - xo).abs() / (1 + bo.abs())).max()) <= 2e-6       # fp16 x 2 against bf16 x 3, every element of the full-size layer
+    del bo, bp_, bo2, bp2
     assert torch.allclose(po, xo.sum(2), rtol=1e-5, atol=1e-6)
     sel = torch.arange(0, B, 4099, device="cuda")
     rx, rp = oracle.cin_layer(c0[sel].cpu().numpy(), xk[sel].cpu().numpy(), W.cpu().numpy(), acc64=True)
     assert (np.abs(xo[sel].cpu().double().numpy() - rx) / (1 + np.abs(rx))).max() <= 1e-5
     assert (np.abs(po[sel].cpu().double().numpy() - rp) / (1 + np.abs(rp))).max() <= 1e-5
-    # (the default "auto" ran the bf16x3 kernel above; the fp32-MFMA kernel at the same size, same checks)
+    # (the default "auto" ran the fp16 x 2 kernel above; the fp32-MFMA kernel at the same size, same checks)
     fo, fp_ = ops.cin_layer(c0, xk, W, arith="f32")
     assert (np.abs(fo[sel].cpu().double().numpy() - rx) / (1 + np.abs(rx))).max() <= 1e-5
     assert (np.abs(fp_[sel].cpu().double().numpy() - rp) / (1 + np.abs(rp))).max() <= 1e-5
@@ -718,7 +736,7 @@ def test_full_size_config4_din_on_the_10m_row_table(ops, oracle):
     saved = {k: os.environ.get(k) for k in ("DIR_DIN_ARITH", "DIR_DIN_STATIC")}
     ref_static = {}
     try:
-        for arith, static, reruns in (("bf16x3", "1", 100), ("bf16x3", "0", 100), ("f32", "0", 10)):
+        for arith, static, reruns in (("f16x2", "1", 100), ("bf16x3", "1", 100), ("bf16x3", "0", 100), ("f32", "0", 10)):
             os.environ["DIR_DIN_ARITH"], os.environ["DIR_DIN_STATIC"] = arith, static
             for norm in (True, False):
                 o0, s0 = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=norm, want_scores=True)
