@@ -1070,14 +1070,15 @@ def main():
         modes = {}
         for i in range(3):
             f = 2.0 * B * dims[i] * dims[i + 1]
-            a = ("bf16x3" if use_tower else "f32" if use_torch or ops.DENSE_ARITH == "f32" else ops.DENSE_ARITH if ops.DENSE_ARITH != "auto"
+            a = (getattr(ops, "TOWER_SPLIT", "bf16x3") if use_tower else "f32" if use_torch or ops.DENSE_ARITH == "f32" else ops.DENSE_ARITH if ops.DENSE_ARITH != "auto"
                  else ops.dense_auto_arith(B, dims[i], dims[i + 1]))
             alg, pipe = alg + f, pipe + f * PIPE_COST[a]
             modes["layer%d" % (i + 1)] = a
         roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes,
                 "kernel": "rocBLAS GEMM + relu x3" if use_torch else "tower_bf3_k (three layers, one launch)" if use_tower else
                           "dense_bf3_k<13> x3" if "bf16x3" in modes.values() else "dense_k<80, relu> x3",
-                "dtype": "f32 via bf16x3 split, f32 accumulate" if "bf16x3" in modes.values() else "f32"}
+                "dtype": ("f32 via fp16x2 split, f32 accumulate" if "f16x2" in modes.values() else
+                          "f32 via bf16x3 split, f32 accumulate" if "bf16x3" in modes.values() else "f32")}
         cfg.update({"layers": dims})
     elif wl == "din_train":
         # forward (fused kernel) + backward (autograd.DinAttentionPool: fused HIP backward, sparse table gradient) of the DIN unit

@@ -41,6 +41,7 @@ constexpr int TW_NT = 26;         // column tiles of 16: widths up to 416
 constexpr int TW_ST = 13;         // column tiles per stage (one LDS buffer: 3 pieces x 13 KB)
 constexpr int TW_MAXL = 4;
 constexpr int TW_BUFB = 3 * TW_ST * 1024;
+constexpr int tw_bufb(int np) { return np * TW_ST * 1024; }      // bytes of one stage: np pieces x 13 KB (np = 3: bf16 x 3, np = 2: fp16 x 2)
 
 struct TowerParams {
     const float* X;
@@ -83,12 +84,40 @@ __device__ __forceinline__ void tw_split_pair(float a, float b, unsigned int& w0
     w2 = tw_pk(sa, sb);
 }
 
+// Round 4: "fp16 x 2" (NP = 2; csrc/cin_bf3.hip explains the arithmetic and its preconditions): two fp16 pieces per operand, three products
+// on v_mfma_f32_16x16x32_f16.  For this kernel it is above all LDS traffic: a stage is 2 x 13 KB instead of 3 x 13 KB and every wave
+// reads two 1 KB W pieces per tile instead of three (the kernel was LDS-read bound at ~70 % LDS busy), next to half the matrix
+// instructions and 6 instead of 11 split instructions per operand pair.
+typedef _Float16 tw_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int tw_pk_h(float a, float b) {     // v_cvt_pk_f16_f32 (round to nearest even), a in the low half
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));
+    return w;
+}
+template <int NP> struct TwPc;
+template <> struct TwPc<3> {
+    using op_t = tw_bf16x8;
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[3]) { tw_split_pair(a, b, w[0], w[1], w[2]); }
+};
+template <> struct TwPc<2> {
+    using op_t = tw_f16x8;
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[2]) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        w[0] = tw_pk_h(a, b);
+        const h2_t h = __builtin_bit_cast(h2_t, w[0]);
+        w[1] = tw_pk_h(a - (float)h[0], b - (float)h[1]);
+    }
+};
+
 // input column (k index) of element j of lane group g in k-step ks: the accumulator-register enumeration of the header comment
 __host__ __device__ inline int tw_kmap(int ks, int g, int j) { return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3); }
 
 // W [N, K] fp32 (row stride w_ld) -> image [k-step][stage][piece][13 tile slots][lane][8 e] bf16 (stage st = column tiles
 // [13*st, 13*st + 13)): element e of lane l of tile ct in k-step ks = piece of
 // W[n = 16*ct + (l & 15)][k = tw_kmap(ks, l >> 4, e)]; zero where n >= N or k >= K.
+template <int NP>
 __global__ __launch_bounds__(256) void tower_bf3_pack_k(const float* __restrict__ W, int64_t w_ld, int K, int N, int nks, int nct,
                                                         unsigned int* __restrict__ img) {
     const int64_t total = (int64_t)nks * nct * 64 * 4;            // one thread per pair of e
@@ -102,15 +131,14 @@ __global__ __launch_bounds__(256) void tower_bf3_pack_k(const float* __restrict_
         const int k = tw_kmap(ks, l >> 4, 2 * ep);               // e = 2*ep and 2*ep + 1 are neighbours in k
         const float v0 = (n < N && k < K) ? W[(int64_t)n * w_ld + k] : 0.f;
         const float v1 = (n < N && k + 1 < K) ? W[(int64_t)n * w_ld + k + 1] : 0.f;
-        unsigned int p0, p1, p2;
-        tw_split_pair(v0, v1, p0, p1, p2);
+        unsigned int pw[NP];
+        TwPc<NP>::split(v0, v1, pw);
         const int st = ct / TW_ST, cs = ct - st * TW_ST;
         const int nstg = (nct + TW_ST - 1) / TW_ST;
-        // dwords: every stage is a full 3 x 13 KB block (slots behind the layer's last tile are never loaded): constant piece stride
-        const int64_t base = ((int64_t)ks * nstg + st) * (3 * TW_ST * 256) + (cs * 64 + l) * 4 + ep;
-        img[base] = p0;
-        img[base + TW_ST * 256] = p1;
-        img[base + 2 * TW_ST * 256] = p2;
+        // dwords: every stage is a full NP x 13 KB block (slots behind the layer's last tile are never loaded): constant piece stride
+        const int64_t base = ((int64_t)ks * nstg + st) * (NP * TW_ST * 256) + (cs * 64 + l) * 4 + ep;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) img[base + q * TW_ST * 256] = pw[q];
     }
 }
 
@@ -119,8 +147,9 @@ __global__ __launch_bounds__(256) void tower_bf3_pack_k(const float* __restrict_
 // consumers ride along in the order the gather kernel uses, so the logit is bit for bit the two-launch path's: the FM second-order term
 // 0.5 sum_k ((sum_f e)^2 - sum_f e^2) (field sums f-ascending, then k-ascending across the row's four lanes) and the first-order term
 // sum_f w_f + bias (f-ascending), both added to the head's logit in the epilogue.  The 109 MB concat is never written or read.
-template <bool GATHER>
+template <bool GATHER, int NP = 3>
 __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
+    constexpr int BUFB = tw_bufb(NP);
     extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];      // [2][TW_BUFB]: the W image of one stage
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,10 +166,10 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
         const int nct = (p.N[l] + 15) >> 4;
         const int nstg = nct > TW_ST ? 2 : 1;
         const int nst = nct - st * TW_ST < TW_ST ? nct - st * TW_ST : TW_ST;
-        const unsigned char* src = p.img[l] + ((int64_t)ks * nstg + st) * TW_BUFB + lane * 16;
-        unsigned char* dst = tw_smem + buf * TW_BUFB;
+        const unsigned char* src = p.img[l] + ((int64_t)ks * nstg + st) * BUFB + lane * 16;
+        unsigned char* dst = tw_smem + buf * BUFB;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < NP; ++pc)
             for (int cs = wave_u; cs < nst; cs += 8) {            // wave-uniform trip count
                 const int off = (pc * TW_ST + cs) * 1024;
                 __builtin_amdgcn_global_load_lds((tw_glb_ptr)(src + off), (tw_lds_ptr)(dst + off), 16, 0, 0);
@@ -210,16 +239,21 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
             for (int ks = 0; ks < TW_NT / 2; ++ks) {
                 if (ks < nks) {                                   // workgroup-uniform
                     // this k-step's B operands: the 4 registers of input tiles 2ks and 2ks+1, split three ways
-                    tw_bf16x8 xa[3];
+                    using op_t = typename TwPc<NP>::op_t;
+                    op_t xa[NP];
                     {
                         const tw_f32x4 a0 = act[2 * ks], a1 = act[2 * ks + 1];
-                        unsigned int w[3][4];
-                        tw_split_pair(a0[0], a0[1], w[0][0], w[1][0], w[2][0]);
-                        tw_split_pair(a0[2], a0[3], w[0][1], w[1][1], w[2][1]);
-                        tw_split_pair(a1[0], a1[1], w[0][2], w[1][2], w[2][2]);
-                        tw_split_pair(a1[2], a1[3], w[0][3], w[1][3], w[2][3]);
+                        const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        unsigned int w[NP][4];
 #pragma unroll
-                        for (int pc = 0; pc < 3; ++pc) xa[pc] = __builtin_bit_cast(tw_bf16x8, (tw_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
+                        for (int pr = 0; pr < 4; ++pr) {
+                            unsigned int pw[NP];
+                            TwPc<NP>::split(av[2 * pr], av[2 * pr + 1], pw);
+#pragma unroll
+                            for (int pc = 0; pc < NP; ++pc) w[pc][pr] = pw[pc];
+                        }
+#pragma unroll
+                        for (int pc = 0; pc < NP; ++pc) xa[pc] = __builtin_bit_cast(op_t, (tw_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
                     }
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
@@ -237,9 +271,33 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
                             // ds_read_b128 results return in order, so lgkmcnt(3) = "this tile's three pieces are here, the next tile's may
                             // still be in flight"; an outstanding scalar load can only make that wait longer, never shorter.
                             // sched_barrier: nothing may be moved across the wait (cdna_hip_programming.md 5.4 rule 18).
-                            const unsigned int wl = (unsigned int)(size_t)(tw_smem + buf * TW_BUFB + lane * 16);
-                            tw_u32x4 wq[2][3];
+                            const unsigned int wl = (unsigned int)(size_t)(tw_smem + buf * BUFB + lane * 16);
+                            tw_u32x4 wq[2][NP];
 #define TW_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(wl), "n"(off))
+                            if constexpr (NP == 2) {
+                                // the same hand pipelining with two pieces per tile: lgkmcnt(2) = "this tile's two pieces are here"
+                                TW_DS_READ(wq[0][0], 0);
+                                TW_DS_READ(wq[0][1], TW_ST * 1024);
+#pragma unroll
+                                for (int cs = 0; cs < TW_ST; ++cs) {
+                                    if (cs + 1 < TW_ST) {
+                                        TW_DS_READ(wq[(cs + 1) & 1][0], (cs + 1) * 1024);
+                                        TW_DS_READ(wq[(cs + 1) & 1][1], (TW_ST + cs + 1) * 1024);
+                                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wq[cs & 1][0]), "+v"(wq[cs & 1][1]));
+                                    } else {
+                                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[cs & 1][0]), "+v"(wq[cs & 1][1]));
+                                    }
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    const tw_f16x8 w0 = __builtin_bit_cast(tw_f16x8, wq[cs & 1][0]);
+                                    const tw_f16x8 w1 = __builtin_bit_cast(tw_f16x8, wq[cs & 1][1]);
+                                    tw_f32x4 tt = acc[st * TW_ST + cs];
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa[0], tt, 0, 0, 0);      // the three products, smallest first
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[1], tt, 0, 0, 0);
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[0], tt, 0, 0, 0);
+                                    acc[st * TW_ST + cs] = tt;
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            } else {
                             TW_DS_READ(wq[0][0], 0);
                             TW_DS_READ(wq[0][1], TW_ST * 1024);
                             TW_DS_READ(wq[0][2], 2 * TW_ST * 1024);
@@ -266,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
                                 tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa[0], tt, 0, 0, 0);
                                 acc[st * TW_ST + cs] = tt;
                                 __builtin_amdgcn_sched_barrier(0);
+                            }
                             }
 #undef TW_DS_READ
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage have landed
@@ -340,18 +399,31 @@ extern "C" int64_t dir_tower_bf16x3_image_bytes(int K, int N) {
     return (int64_t)((K + 31) / 32) * (((N + 15) / 16 + TW_ST - 1) / TW_ST) * TW_BUFB;
 }
 
-extern "C" int dir_tower_bf16x3_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
-    const char* name = "dir_tower_bf16x3_pack_f32";
+static int tower_pack(const char* name, int pieces, const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
     DIR_CHECK_ARG(W && image && K > 0 && N > 0 && w_ld >= K, "%s: bad argument (K=%d N=%d w_ld=%lld)", name, K, N, (long long)w_ld);
     DIR_CHECK_ARG(K <= 16 * TW_NT && N <= 16 * TW_NT, "%s: K=%d N=%d exceed %d", name, K, N, 16 * TW_NT);
     DIR_CHECK_ARG(aligned16(image) && image_bytes >= dir_tower_bf16x3_image_bytes(K, N), "%s: image must be 16-byte aligned and hold "
                   "dir_tower_bf16x3_image_bytes(K, N) bytes", name);
     const int nks = (K + 31) / 32, nct = (N + 15) / 16;
     const int64_t threads = (int64_t)nks * nct * 64 * 4;
-    hipLaunchKernelGGL(tower_bf3_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, K, N, nks, nct,
-                       static_cast<unsigned int*>(image));
+    if (pieces == 2)
+        hipLaunchKernelGGL(tower_bf3_pack_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, K, N, nks, nct,
+                           static_cast<unsigned int*>(image));
+    else
+        hipLaunchKernelGGL(tower_bf3_pack_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, K, N, nks, nct,
+                           static_cast<unsigned int*>(image));
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_tower_bf16x3_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
+    return tower_pack("dir_tower_bf16x3_pack_f32", 3, W, w_ld, K, N, image, image_bytes, stream);
+}
+
+// the fp16 x 2 image of the same weight (two pieces per stage; dir_tower_bf16x3_image_bytes(K, N) bytes hold it): for dir_tower_f16x2_f32 /
+// dir_deepfm_tower_f16x2_f32 ONLY -- the two arithmetics' images are not interchangeable
+extern "C" int dir_tower_f16x2_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
+    return tower_pack("dir_tower_f16x2_pack_f32", 2, W, w_ld, K, N, image, image_bytes, stream);
 }
 
 // the layers / head part of the argument checks, shared by the two entries
@@ -389,22 +461,21 @@ static int tower_fill(const char* name, TowerParams& p, int Kd, int L, const int
     return DIR_OK;
 }
 
-template <bool GATHER>
+template <bool GATHER, int NP>
 static int tower_launch(const char* name, const TowerParams& p, dir_stream_t stream) {
     static LdsOnce once;
-    if (!lds_limit(once, 160 * 1024, &tower_bf3_k<GATHER>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
+    if (!lds_limit(once, 160 * 1024, &tower_bf3_k<GATHER, NP>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
     const int64_t ntiles = (p.M + TW_ROWS - 1) / TW_ROWS;
-    const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;            // one persistent workgroup per CU (8 waves x 256 registers, 78 KB of LDS)
-    hipLaunchKernelGGL(tower_bf3_k<GATHER>, dim3((unsigned)nwg), dim3(512), 2 * TW_BUFB, as_stream(stream), p);
+    const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;            // one persistent workgroup per CU (8 waves x 256 registers, 78 / 52 KB of LDS)
+    hipLaunchKernelGGL((tower_bf3_k<GATHER, NP>), dim3((unsigned)nwg), dim3(512), 2 * tw_bufb(NP), as_stream(stream), p);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
 
-extern "C" int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
-                                    const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
-                                    const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
-                                    dir_stream_t stream) {
-    const char* name = "dir_tower_bf16x3_f32";
+static int tower_run(const char* name, int pieces, const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
+                     const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
+                     const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
+                     dir_stream_t stream) {
     DIR_CHECK_ARG(M >= 0, "%s: M=%lld", name, (long long)M);
     if ((x_ld & 3) || x_ld < Kd) return fail(DIR_E_UNSUPPORTED, "%s: x_ld=%lld (a multiple of 4, >= Kd)", name, (long long)x_ld);
     TowerParams p;
@@ -413,15 +484,30 @@ extern "C" int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int
     if (M == 0) return DIR_OK;
     DIR_CHECK_ARG(X && out && aligned16(X), "%s: null or unaligned pointer", name);
     p.X = X; p.x_ld = x_ld; p.M = M;
-    return tower_launch<false>(name, p, stream);
+    return pieces == 2 ? tower_launch<false, 2>(name, p, stream) : tower_launch<false, 3>(name, p, stream);
 }
 
-extern "C" int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
-                                           const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
-                                           const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
-                                           const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
-                                           const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream) {
-    const char* name = "dir_deepfm_tower_bf16x3_f32";
+extern "C" int dir_tower_bf16x3_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
+                                    const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
+                                    const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
+                                    dir_stream_t stream) {
+    return tower_run("dir_tower_bf16x3_f32", 3, X, x_ld, M, Kd, L, N, images, bias, post_scale, post_shift, act, head_w, head_b, add0, add1, out, out_ld,
+                     stream);
+}
+
+extern "C" int dir_tower_f16x2_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
+                                   const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
+                                   const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
+                                   dir_stream_t stream) {
+    return tower_run("dir_tower_f16x2_f32", 2, X, x_ld, M, Kd, L, N, images, bias, post_scale, post_shift, act, head_w, head_b, add0, add1, out, out_ld,
+                     stream);
+}
+
+static int deepfm_tower_run(const char* name, int pieces, const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                            const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
+                            const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
+                            const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                            const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream) {
     DIR_CHECK_ARG(M >= 0 && F > 0, "%s: M=%lld F=%d", name, (long long)M, F);
     if (K != 16 || F > TW_NT) return fail(DIR_E_UNSUPPORTED, "%s: K=%d F=%d (K = 16, F <= %d: one column tile per slot)", name, K, F, TW_NT);
     DIR_CHECK_ARG(want_fm == 0 || want_fm == 1, "%s: want_fm=%d", name, want_fm);
@@ -434,5 +520,23 @@ extern "C" int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int
     DIR_CHECK_ARG(tables && ids && out, "%s: null pointer", name);
     p.M = M; p.tables = tables; p.vocab = vocab; p.ids = ids; p.ids_sb = stride_b; p.ids_sf = stride_f; p.row_ld = ld; p.F = F; p.lin_col = lin_col;
     p.want_fm = want_fm; p.lin_bias = lin_bias;
-    return tower_launch<true>(name, p, stream);
+    return pieces == 2 ? tower_launch<true, 2>(name, p, stream) : tower_launch<true, 3>(name, p, stream);
+}
+
+extern "C" int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                                           const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
+                                           const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
+                                           const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                                           const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream) {
+    return deepfm_tower_run("dir_deepfm_tower_bf16x3_f32", 3, tables, vocab, F, K, ld, lin_col, ids, stride_b, stride_f, want_fm, M, lin_bias, L, N,
+                            images, bias, post_scale, post_shift, act, head_w, head_b, add0, add1, out, out_ld, stream);
+}
+
+extern "C" int dir_deepfm_tower_f16x2_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                                          const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
+                                          const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
+                                          const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                                          const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream) {
+    return deepfm_tower_run("dir_deepfm_tower_f16x2_f32", 2, tables, vocab, F, K, ld, lin_col, ids, stride_b, stride_f, want_fm, M, lin_bias, L, N,
+                            images, bias, post_scale, post_shift, act, head_w, head_b, add0, add1, out, out_ld, stream);
 }

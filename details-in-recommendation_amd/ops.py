@@ -717,11 +717,18 @@ def tower_gather_covers(pt, weights):
         k = int(w.shape[0])
     return True
 
-def tower_image(weight):
-    """The packed bf16x3 image of one layer's [N, K] weight in the tower kernel's k order, cached per tensor until it is modified in
-    place (tensor._version) or goes away."""
+# The split arithmetic of the fused tower (csrc/tower_bf3.hip): "f16x2" (two fp16 pieces per operand, three products: two thirds of the LDS
+# traffic and half the matrix instructions; |activations|, |weights| < 65 504 -- the towers read embedding rows and ReLU activations) or
+# "bf16x3" (three bf16 pieces, six products: fp32's exponent range).
+TOWER_SPLIT = os.environ.get("DIR_TOWER_SPLIT", "f16x2")
+
+
+def tower_image(weight, split=None):
+    """The packed image (bf16 x 3 or fp16 x 2 pieces) of one layer's [N, K] weight in the tower kernel's k order, cached per tensor and
+    split until the tensor is modified in place (tensor._version) or goes away."""
     import weakref
-    key = weight.data_ptr()
+    split = split or TOWER_SPLIT
+    key = (weight.data_ptr(), split)
     sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
     hit = _TOWER_IMAGES.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == sig:
@@ -731,21 +738,27 @@ def tower_image(weight):
     nbytes = int(lib.dir_tower_bf16x3_image_bytes(K, N))
     img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     w = weight if weight.stride(1) == 1 else weight.contiguous()
-    _lib.check(lib.dir_tower_bf16x3_pack_f32(_ptr(w), w.stride(0), K, N, _ptr(img), nbytes, _stream()))
+    pack = lib.dir_tower_f16x2_pack_f32 if split == "f16x2" else lib.dir_tower_bf16x3_pack_f32
+    _lib.check(pack(_ptr(w), w.stride(0), K, N, _ptr(img), nbytes, _stream()))
     if len(_TOWER_IMAGES) > 256:
         _TOWER_IMAGES.clear()
     _TOWER_IMAGES[key] = (weakref.ref(weight), sig, img)
     return img
 
 
-def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, head=None, adds=(), out=None, gather=None):
+def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, head=None, adds=(), out=None, gather=None, split=None):
     """A DNN tower in one launch (include/dir_hip.h: dir_tower_bf16x3_f32; dnn_logit_fn, deepFM.py:284-319).  x [M, Kd]; weights: 1..4
     nn.Linear weights [N_l, K_l]; biases: list of [N_l] or None; relu: bool or per-layer list; post_scale / post_shift: per-layer lists
     of [N_l] vectors or None entries (the folded inference batch-norm).  head = (w [N_last] or [1, N_last], b [1]): -> logits [M, 1]
     (+ the [M] / [M, 1] tensors in adds, at most two); without a head -> the last activation [M, N_last].
     gather = (PackedTables, ids [M, F], linear bias [1] or None) with x = None: DeepFM inference in one launch
     (dir_deepfm_tower_bf16x3_f32) -- the input rows are looked up inside the kernel and the FM and first-order terms join the logit,
-    bit for bit the result of gather_fm_linear + tower(..., adds=(fm, lin))."""
+    bit for bit the result of gather_fm_linear + tower(..., adds=(fm, lin)).
+    split: "f16x2" | "bf16x3" | None = TOWER_SPLIT (env DIR_TOWER_SPLIT): the kernel's split arithmetic (dir_tower_f16x2_f32 /
+    dir_deepfm_tower_f16x2_f32 or the bf16x3 entries)."""
+    split = split or TOWER_SPLIT
+    if split not in ("f16x2", "bf16x3"):
+        raise ValueError("tower: split must be 'f16x2' or 'bf16x3'")
     L = len(weights)
     if gather is not None:
         pt, ids, lin_bias = gather[:3]
@@ -776,7 +789,9 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
         return t.data_ptr()
     Ns = (ctypes.c_int * L)(*[int(w.shape[0]) for w in weights])
     acts = (ctypes.c_int * L)(*[1 if r else 0 for r in relu_l])
-    imgs_t = [tower_image(_dev(w, torch.float32, "weight")) for w in weights]
+    imgs_t = [tower_image(_dev(w, torch.float32, "weight"), split) for w in weights]
+    f_tower = lib.dir_tower_f16x2_f32 if split == "f16x2" else lib.dir_tower_bf16x3_f32
+    f_gather = lib.dir_deepfm_tower_f16x2_f32 if split == "f16x2" else lib.dir_deepfm_tower_bf16x3_f32
     VP = ctypes.c_void_p * L
     imgs = VP(*[t.data_ptr() for t in imgs_t])
     b_arr = VP(*[vec(biases, l, Ns[l], "bias") for l in range(L)])
@@ -797,11 +812,11 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
             out = torch.empty((M, 1), dtype=torch.float32, device=hw.device)
         if gather is not None:
             lb = _dev(lin_bias, torch.float32, "linear bias").reshape(-1) if lin_bias is not None else None
-            _lib.check(lib.dir_deepfm_tower_bf16x3_f32(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, lin_col, _ptr(ids), sb, sf, int(want_fm), M, _ptr(lb),
+            _lib.check(f_gather(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, lin_col, _ptr(ids), sb, sf, int(want_fm), M, _ptr(lb),
                                                        L, Ns, imgs, b_arr, s_arr, h_arr, acts, _ptr(hw), _ptr(hb), _ptr(add[0]) if add else None,
                                                        _ptr(add[1]) if len(add) > 1 else None, _ptr(out), out.stride(0), _stream()))
             return out
-        _lib.check(lib.dir_tower_bf16x3_f32(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, _ptr(hw), _ptr(hb),
+        _lib.check(f_tower(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, _ptr(hw), _ptr(hb),
                                             _ptr(add[0]) if add else None, _ptr(add[1]) if len(add) > 1 else None, _ptr(out), out.stride(0), _stream()))
         return out
     if adds:
@@ -809,12 +824,12 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
     if gather is not None:
         if out is None:
             out = torch.empty((M, Ns[L - 1]), dtype=torch.float32, device=ids.device)
-        _lib.check(lib.dir_deepfm_tower_bf16x3_f32(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, lin_col, _ptr(ids), sb, sf, 0, M, None, L, Ns,
+        _lib.check(f_gather(_ptr(pt.ptrs), _ptr(pt.vocab_dev), pt.F, pt.K, pt.ld, lin_col, _ptr(ids), sb, sf, 0, M, None, L, Ns,
                                                    imgs, b_arr, s_arr, h_arr, acts, None, None, None, None, _ptr(out), out.stride(0), _stream()))
         return out
     if out is None:
         out = torch.empty((M, Ns[L - 1]), dtype=torch.float32, device=x.device)
-    _lib.check(lib.dir_tower_bf16x3_f32(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, None, None, None, None, _ptr(out),
+    _lib.check(f_tower(_ptr(x), x.stride(0), M, Kd, L, Ns, imgs, b_arr, s_arr, h_arr, acts, None, None, None, None, _ptr(out),
                                         out.stride(0), _stream()))
     return out
 

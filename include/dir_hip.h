@@ -478,6 +478,22 @@ int dir_deepfm_tower_bf16x3_f32(const float* const* tables, const int64_t* vocab
                                 const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
                                 const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
                                 const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream);
+
+/* The tower on "fp16 x 2" arithmetic (csrc/tower_bf3.hip, round 4; dir_cin_layer_f16x2_f32 states the arithmetic and its preconditions:
+ * |activations|, |weights| < 65 504, an absolute representation error of up to 2^-25 per operand element below 2^-3): a stage of W is two
+ * 13 KB pieces instead of three -- two thirds of the LDS reads of a kernel that was LDS-read bound -- and a tile costs three matrix
+ * instructions instead of six.  Same arguments as the bf16 x 3 entries; the images come from dir_tower_f16x2_pack_f32
+ * (dir_tower_bf16x3_image_bytes(K, N) bytes hold them) and are NOT interchangeable with the bf16 x 3 images. */
+int dir_tower_f16x2_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream);
+int dir_tower_f16x2_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
+                        const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
+                        const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
+                        dir_stream_t stream);
+int dir_deepfm_tower_f16x2_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                               const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
+                               const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
+                               const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                               const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream);
 /* dir_dense_gated_f32: Y = (gate > 0) ? X . Wt^T : 0 -- the data gradient of a dense layer taken straight through the previous
  * layer's ReLU: X = dL/d(pre-activation of layer l) [M, Kd = units of l], Wt = the TRANSPOSE of layer l's nn.Linear weight
  * ([in_l, units_l] rows), gate = layer l-1's output [M, N = in_l]; the result is dL/d(pre-activation of layer l-1). */
