@@ -161,7 +161,8 @@ class DeepFM(nn.Module):
         kernel's epilogue when that runs, here otherwise."""
         if not _train_mode(self):
             fused = tower_infer(self.hidden, net, self.activation, bns=self.bns if len(self.bns) else None,
-                                head=self.logits_layer if self.units == 1 else None, adds=adds if self.units == 1 else ())
+                                head=self.logits_layer if self.units == 1 else None, adds=adds if self.units == 1 else (),
+                                embedding_input=True)       # net is the concat of the embedding columns (deepFM.py:288-291)
             if fused is not None:                                               # inference: the whole tower (+ logit layer) in one launch
                 out = fused if self.units == 1 else self._logits_of(fused)
                 for a in (adds if self.units != 1 else ()):

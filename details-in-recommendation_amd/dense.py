@@ -405,7 +405,7 @@ def _dense_act(lin, x, activation, bn):
     return _apply_bn(bn, activation(y) if activation is not None else y)
 
 
-def tower_infer(lins, x, activation, bns=None, head=None, adds=(), gather=None):
+def tower_infer(lins, x, activation, bns=None, head=None, adds=(), gather=None, embedding_input=False):
     """Inference of a whole tower -- activation(lin_l(...)) for every nn.Linear in `lins`, each followed by its batch-norm (bns[l], folded
     to an affine), and the units = 1 logit layer `head` on top when given -- in ONE launch of dir_tower_bf16x3_f32 (csrc/tower_bf3.hip:
     the activations of a 128-row tile stay in registers from layer to layer).  -> the logits [B, 1] (+ the [B, 1] tensors in adds, at
@@ -434,5 +434,10 @@ def tower_infer(lins, x, activation, bns=None, head=None, adds=(), gather=None):
         aff = [_bn_affine(b) if b is not None else (None, None) for b in bns]
         aff += [(None, None)] * (len(lins) - len(aff))
         ps, psh = [a[0] for a in aff], [a[1] for a in aff]
+    # embedding_input: the caller vouches that x is a concatenation of embedding rows (DeepFM's dnn input, deepFM.py:288-291) -- the
+    # bounded magnitudes the fp16 x 2 arithmetic wants; a general input layer may carry raw numeric columns (the adult-census
+    # capital_gain column of DeepCrossNetwork/train.py reaches 99 999 > fp16's 65 504) and stays on bf16 x 3.  The gather form reads
+    # embedding rows by construction.
     return ops.tower(x, ws, [l.bias for l in lins], relu=activation is not None, post_scale=ps, post_shift=psh,
-                     head=(head.weight, head.bias) if head is not None else None, adds=adds if head is not None else (), gather=gather)
+                     head=(head.weight, head.bias) if head is not None else None, adds=adds if head is not None else (), gather=gather,
+                     split=None if (gather is not None or embedding_input) else "bf16x3")

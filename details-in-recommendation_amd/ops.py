@@ -720,7 +720,7 @@ def tower_gather_covers(pt, weights):
 # The split arithmetic of the fused tower (csrc/tower_bf3.hip): "f16x2" (two fp16 pieces per operand, three products: two thirds of the LDS
 # traffic and half the matrix instructions; |activations|, |weights| < 65 504 -- the towers read embedding rows and ReLU activations) or
 # "bf16x3" (three bf16 pieces, six products: fp32's exponent range).
-TOWER_SPLIT = os.environ.get("DIR_TOWER_SPLIT", "f16x2")
+TOWER_SPLIT = os.environ.get("DIR_TOWER_SPLIT", "f16x2")      # what split=None means in tower(): callers with unbounded inputs pass "bf16x3"
 
 
 def tower_image(weight, split=None):
