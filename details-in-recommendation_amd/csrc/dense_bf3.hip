@@ -62,6 +62,48 @@ __device__ __forceinline__ void db3_split_pair(float a, float b, unsigned int& w
     w2 = db3_pk(sa, sb);
 }
 
+// Round 4: "fp16 x 2" (NP = 2; csrc/cin_bf3.hip explains the arithmetic and its preconditions): two fp16 pieces per operand, three products on
+// v_mfma_f32_16x16x32_f16.  For layers whose input is bounded by construction (embedding concatenations, ReLU / batch-normalised
+// activations, the CIN's pooled products): NOT for a general input layer that may carry raw numeric columns (fp16 ends at 65 504) and
+// not for gradient operands (small magnitudes would sit in fp16's subnormal range) -- those callers keep bf16 x 3.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int db3_pk_h(float a, float b) {     // v_cvt_pk_f16_f32 (round to nearest even), a in the low half
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));
+    return w;
+}
+template <int NP> struct Db3Pc;
+template <> struct Db3Pc<3> {
+    using op_t = bf16x8_t;
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[3]) { db3_split_pair(a, b, w[0], w[1], w[2]); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&wc)[3], const op_t (&xa)[3], f32x4 tt) {      // six products, smallest first
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[2], tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2], xa[0], tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[1], tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[1], tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[0], tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[0], tt, 0, 0, 0);
+        return tt;
+    }
+};
+template <> struct Db3Pc<2> {
+    using op_t = f16x8_t;
+    __device__ static __forceinline__ void split(float a, float b, unsigned int (&w)[2]) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        w[0] = db3_pk_h(a, b);
+        const h2_t h = __builtin_bit_cast(h2_t, w[0]);
+        w[1] = db3_pk_h(a - (float)h[0], b - (float)h[1]);
+    }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&wc)[2], const op_t (&xa)[2], f32x4 tt) {      // three products, smallest first
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[1], xa[0], tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[0], xa[1], tt, 0, 0, 0);
+        tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[0], xa[0], tt, 0, 0, 0);
+        return tt;
+    }
+};
+
 __host__ __device__ inline int db3_ct_for(int N) {     // column tiles per block: the choice that pads N least (ties: the wider block)
     const int tiles = (N + 15) / 16;
     int best = 16, pad = (tiles + 15) / 16 * 16;
@@ -73,6 +115,7 @@ __host__ __device__ inline int db3_ct_for(int N) {     // column tiles per block
 
 // W [N, Kd] fp32 (row stride w_ld) -> image [column block][k-step][piece][ct][lane][8 e] bf16: element e of lane l of column tile ct =
 // piece of W[n = 16*(cb*CT + ct) + (l & 15)][k = 32*ks + 8*(l >> 4) + e]; zero where n >= N or k >= Kd.
+template <int NP>
 __global__ __launch_bounds__(256) void dense_bf3_pack_k(const float* __restrict__ W, int64_t w_ld, int64_t w_cs /* column stride: 1, or the row
                                                         stride of the tensor whose transpose W is */, int Kd, int N, int CT, int nks, int ncb,
                                                         unsigned int* __restrict__ img) {
@@ -88,24 +131,25 @@ __global__ __launch_bounds__(256) void dense_bf3_pack_k(const float* __restrict_
         const int k = 32 * ks + 8 * (l >> 4) + 2 * ep;
         const float v0 = (n < N && k < Kd) ? W[(int64_t)n * w_ld + k * w_cs] : 0.f;
         const float v1 = (n < N && k + 1 < Kd) ? W[(int64_t)n * w_ld + (k + 1) * w_cs] : 0.f;
-        unsigned int p0, p1, p2;
-        db3_split_pair(v0, v1, p0, p1, p2);
+        unsigned int pw[NP];
+        Db3Pc<NP>::split(v0, v1, pw);
         const int64_t step = (int64_t)cb * nks + ks;
-        const int64_t base = step * (3 * CT * 64 * 4) + (ct * 64 + l) * 4 + ep;     // piece stride: CT*64*4 dwords
-        img[base] = p0;
-        img[base + CT * 64 * 4] = p1;
-        img[base + 2 * CT * 64 * 4] = p2;
+        const int64_t base = step * (NP * CT * 64 * 4) + (ct * 64 + l) * 4 + ep;    // piece stride: CT*64*4 dwords
+#pragma unroll
+        for (int q = 0; q < NP; ++q) img[base + q * CT * 64 * 4] = pw[q];
     }
 }
 
-template <int CT>
+template <int CT, int NP = 3>
 __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ X, int64_t x_ld, const unsigned char* __restrict__ img,
                                                      const float* __restrict__ bias, int relu, const float* __restrict__ post_scale,
                                                      const float* __restrict__ post_shift, const float* __restrict__ gate, int64_t gate_ld,
                                                      int64_t M, int Kd, int N, int nks, int ncb, float* __restrict__ Y, int64_t y_ld,
                                                      const float* __restrict__ head_w /* [N] or nullptr */,
                                                      float* __restrict__ head_part /* [ncb][M]: this column block's share of y . head_w */) {
-    constexpr int STEPB = 3 * CT * 1024;                       // bytes of W image per k-step
+    constexpr int STEPB = NP * CT * 1024;                      // bytes of W image per k-step
+    using Pc = Db3Pc<NP>;
+    using op_t = typename Pc::op_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char db3_smem[];
     unsigned char* Wb = db3_smem;                              // [2][STEPB]
 
@@ -141,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
         }
     };
     auto stage_w = [&](const Tile& tl, int ks, int buf) {     // 3*CT pieces of 1 KB over 8 waves, lane-linear
-        for (int piece = wave; piece < 3 * CT; piece += 8) {
+        for (int piece = wave; piece < NP * CT; piece += 8) {
             const unsigned char* src = tl.gi + (int64_t)ks * STEPB + piece * 1024 + lane * 16;
             unsigned char* dst = Wb + buf * STEPB + piece * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
@@ -187,41 +231,40 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                 load_x(nxt, more ? 0 : ks, xn);
             }
             // split this step's X: three bf16x8 operands per row tile
-            bf16x8_t xa[2][3];
+            op_t xa[2][NP];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                unsigned int w[3][4];
+                unsigned int w[NP][4];
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
-                    db3_split_pair(xv[rt][hq][0], xv[rt][hq][1], w[0][2 * hq], w[1][2 * hq], w[2][2 * hq]);
-                    db3_split_pair(xv[rt][hq][2], xv[rt][hq][3], w[0][2 * hq + 1], w[1][2 * hq + 1], w[2][2 * hq + 1]);
+                    unsigned int pa[NP], pb[NP];
+                    Pc::split(xv[rt][hq][0], xv[rt][hq][1], pa);
+                    Pc::split(xv[rt][hq][2], xv[rt][hq][3], pb);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        w[p][2 * hq] = pa[p];
+                        w[p][2 * hq + 1] = pb[p];
+                    }
                 }
 #pragma unroll
-                for (int p = 0; p < 3; ++p) xa[rt][p] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
+                for (int p = 0; p < NP; ++p) xa[rt][p] = __builtin_bit_cast(op_t, (u32x4_t){w[p][0], w[p][1], w[p][2], w[p][3]});
             }
             const unsigned char* wl = wlane + buf * STEPB;
             // W operands one column tile ahead, in two register sets used alternately (the loop is unrolled: the set index is a
             // compile-time constant; copying "next" into "current" costs 12 v_mov per tile, one VALU instruction per MFMA)
-            bf16x8_t wq[2][3];
+            op_t wq[2][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) wq[0][p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024);
+            for (int p = 0; p < NP; ++p) wq[0][p] = *reinterpret_cast<const op_t*>(wl + p * CT * 1024);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 if (ct + 1 < CT) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wq[(ct + 1) & 1][p] = *reinterpret_cast<const bf16x8_t*>(wl + p * CT * 1024 + (ct + 1) * 1024);
+                    for (int p = 0; p < NP; ++p) wq[(ct + 1) & 1][p] = *reinterpret_cast<const op_t*>(wl + p * CT * 1024 + (ct + 1) * 1024);
                 }
-                const bf16x8_t (&wc)[3] = wq[ct & 1];
+                const op_t (&wc)[NP] = wq[ct & 1];
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    f32x4 tt = acc[rt][ct];
-                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][2], tt, 0, 0, 0);
-                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2], xa[rt][0], tt, 0, 0, 0);
-                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[rt][1], tt, 0, 0, 0);
-                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][1], tt, 0, 0, 0);
-                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1], xa[rt][0], tt, 0, 0, 0);
-                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0], xa[rt][0], tt, 0, 0, 0);
-                    acc[rt][ct] = tt;
+                    acc[rt][ct] = Pc::mma(wc, xa[rt], acc[rt][ct]);
 #if DB3_CHAIN
                     __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (tools/coexec_probe.hip)
 #endif
@@ -282,16 +325,16 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
     }
 }
 
-template <int CT>
+template <int CT, int NP = 3>
 static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const unsigned char* img, const float* bias, int relu,
                              const float* ps, const float* psh, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, int nks, int ncb,
                              float* Y, int64_t y_ld, const float* head_w = nullptr, float* head_part = nullptr) {
-    const size_t shmem = 2 * (size_t)3 * CT * 1024;
+    const size_t shmem = 2 * (size_t)NP * CT * 1024;
     static LdsOnce once;
-    (void)lds_limit(once, 160 * 1024, &dense_bf3_k<CT>);
+    (void)lds_limit(once, 160 * 1024, &dense_bf3_k<CT, NP>);
     const int64_t ntiles = (M + DB3_ROWS - 1) / DB3_ROWS * ncb;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;         // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
-    hipLaunchKernelGGL((dense_bf3_k<CT>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
+    hipLaunchKernelGGL((dense_bf3_k<CT, NP>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
                        nks, ncb, Y, y_ld, head_w, head_part);
 }
 
@@ -306,9 +349,8 @@ extern "C" int64_t dir_dense_bf16x3_image_bytes(int Kd, int N) {
     return (int64_t)ncb * nks * 3 * CT * 1024;
 }
 
-extern "C" int dir_dense_bf16x3_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
-                                                 dir_stream_t stream) {
-    const char* name = "dir_dense_bf16x3_pack_strided_f32";
+static int dense_pack_strided(const char* name, int pieces, const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
+                              dir_stream_t stream) {
     DIR_CHECK_ARG(W && image && Kd > 0 && N > 0 && w_rs >= 1 && w_cs >= 1, "%s: bad argument (Kd=%d N=%d strides %lld, %lld)", name, Kd, N,
                   (long long)w_rs, (long long)w_cs);
     DIR_CHECK_ARG(aligned16(image) && image_bytes >= dir_dense_bf16x3_image_bytes(Kd, N), "%s: image must be 16-byte aligned and hold "
@@ -316,10 +358,25 @@ extern "C" int dir_dense_bf16x3_pack_strided_f32(const float* W, int64_t w_rs, i
     const int CT = db3_ct_for(N);
     const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
     const int64_t threads = (int64_t)ncb * nks * CT * 64 * 4;
-    hipLaunchKernelGGL(dense_bf3_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_rs, w_cs, Kd, N, CT, nks, ncb,
-                       static_cast<unsigned int*>(image));
+    if (pieces == 2)
+        hipLaunchKernelGGL(dense_bf3_pack_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_rs, w_cs, Kd, N, CT, nks,
+                           ncb, static_cast<unsigned int*>(image));
+    else
+        hipLaunchKernelGGL(dense_bf3_pack_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_rs, w_cs, Kd, N, CT, nks,
+                           ncb, static_cast<unsigned int*>(image));
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_dense_bf16x3_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
+                                                 dir_stream_t stream) {
+    return dense_pack_strided("dir_dense_bf16x3_pack_strided_f32", 3, W, w_rs, w_cs, Kd, N, image, image_bytes, stream);
+}
+
+// the fp16 x 2 image (dir_dense_bf16x3_image_bytes(Kd, N) bytes hold it) for dir_dense_f16x2_f32 ONLY
+extern "C" int dir_dense_f16x2_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
+                                                dir_stream_t stream) {
+    return dense_pack_strided("dir_dense_f16x2_pack_strided_f32", 2, W, w_rs, w_cs, Kd, N, image, image_bytes, stream);
 }
 
 extern "C" int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
@@ -330,16 +387,15 @@ extern "C" int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, i
     const int CT = db3_ct_for(N);
     const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
     const int64_t threads = (int64_t)ncb * nks * CT * 64 * 4;
-    hipLaunchKernelGGL(dense_bf3_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, (int64_t)1, Kd, N, CT, nks,
+    hipLaunchKernelGGL(dense_bf3_pack_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, (int64_t)1, Kd, N, CT, nks,
                        ncb, static_cast<unsigned int*>(image));
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
 
-extern "C" int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
-                                    const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y,
-                                    int64_t y_ld, dir_stream_t stream) {
-    const char* name = "dir_dense_bf16x3_f32";
+static int dense_run(const char* name, int pieces, const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                     const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
+                     dir_stream_t stream) {
     DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && y_ld >= N, "%s: bad shape", name);
     DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
     DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
@@ -355,11 +411,26 @@ extern "C" int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* im
     hipStream_t st = as_stream(stream);
     const unsigned char* img = static_cast<const unsigned char*>(image);
     const int relu = act == DIR_ACT_RELU;
-    if (CT == 8) launch_dense_bf3<8>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+    if (pieces == 2) {
+        if (CT == 8) launch_dense_bf3<8, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+        else if (CT == 13) launch_dense_bf3<13, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+        else launch_dense_bf3<16, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
+    } else if (CT == 8) launch_dense_bf3<8>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
     else if (CT == 13) launch_dense_bf3<13>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
     else launch_dense_bf3<16>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                                    const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y,
+                                    int64_t y_ld, dir_stream_t stream) {
+    return dense_run("dir_dense_bf16x3_f32", 3, X, x_ld, image, bias, act, post_scale, post_shift, gate, gate_ld, M, Kd, N, Y, y_ld, stream);
+}
+
+extern "C" int dir_dense_f16x2_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                                   const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
+    return dense_run("dir_dense_f16x2_f32", 2, X, x_ld, image, bias, act, post_scale, post_shift, nullptr, 0, M, Kd, N, Y, y_ld, stream);
 }
 
 // The layer with the head of the tower's output folded into its epilogue (DCN's last deep layer, DeepCrossNetwork.py:136-137: the deep

@@ -176,8 +176,8 @@ class DeepFM(nn.Module):
     def _dnn_logit_layers(self, net):
         if not len(self.bns) and not self.hparams.get("dnn_dropout") and mlp_stack_supported(self.hidden, net, self.activation):
             if self.units == 1 and mlp_head_supported(self.hidden, self.logits_layer, net, self.activation):
-                return mlp_head(self.hidden, self.logits_layer, net)                    # training: tower + logit layer as one autograd node
-            return self._logits_of(mlp_stack(self.hidden, net))                         # training: the whole tower as one autograd node
+                return mlp_head(self.hidden, self.logits_layer, net, embedding_input=True)      # training: tower + logit layer as one autograd node
+            return self._logits_of(mlp_stack(self.hidden, net, embedding_input=True))           # training: the whole tower as one autograd node
         for i, lin in enumerate(self.hidden):                                   # deepFM.py:292-308
             if len(self.bns) and not _train_mode(self):                        # inference: no dropout, BN folded into the layer's epilogue
                 net = dense_act(lin, net, self.activation, bn=self.bns[i])

@@ -191,10 +191,11 @@ class _MlpStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, *params):
+        bounded = bool(_FWD_BOUNDED[0])         # (set by mlp_stack around the apply: a flag, not a tensor argument)
         L = len(params) // 2
         ys, h = [], x
         for l in range(L):
-            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True)
+            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True, arith="auto_bounded" if bounded else None)
             ys.append(h)
         ctx.L = L
         ctx.save_for_backward(x, *params[0::2], *ys)
@@ -232,10 +233,11 @@ class _MlpHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, head_w, head_b, *params):
+        bounded = bool(_FWD_BOUNDED[0])
         L = len(params) // 2
         ys, h = [], x
         for l in range(L):
-            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True)
+            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True, arith="auto_bounded" if bounded else None)
             ys.append(h)
         ctx.L = L
         ctx.save_for_backward(x, head_w, *params[0::2], *ys)
@@ -272,12 +274,21 @@ def mlp_head_supported(lins, head, x, activation):
             and head.in_features == lins[-1].out_features and head.in_features <= 4096)
 
 
-def mlp_head(lins, head, x):
-    """head(relu(lin_L(... relu(lin_1(x))))) -> [B, 1] through _MlpHeadFn (check mlp_head_supported first)."""
+_FWD_BOUNDED = [False]      # the forward of the node being applied may take the fp16 x 2 layers (its input is an embedding concatenation)
+
+
+def mlp_head(lins, head, x, embedding_input=False):
+    """head(relu(lin_L(... relu(lin_1(x))))) -> [B, 1] through _MlpHeadFn (check mlp_head_supported first).  embedding_input: the caller
+    vouches that x is a concatenation of embedding rows (DeepFM's dnn input): the forward layers may then run dir_dense_f16x2_f32; the
+    backward (gradient operands) is bf16 x 3 either way."""
     params = []
     for lin in lins:
         params += [lin.weight, lin.bias]
-    return _MlpHeadFn.apply(x, head.weight, head.bias, *params)
+    _FWD_BOUNDED[0] = bool(embedding_input)
+    try:
+        return _MlpHeadFn.apply(x, head.weight, head.bias, *params)
+    finally:
+        _FWD_BOUNDED[0] = False
 
 
 def mlp_stack_supported(lins, x, activation):
@@ -295,12 +306,16 @@ def mlp_stack_supported(lins, x, activation):
     return True
 
 
-def mlp_stack(lins, x):
-    """relu(lin_L(... relu(lin_1(x)))) through _MlpStackFn (check mlp_stack_supported first)."""
+def mlp_stack(lins, x, embedding_input=False):
+    """relu(lin_L(... relu(lin_1(x)))) through _MlpStackFn (check mlp_stack_supported first); embedding_input as in mlp_head."""
     params = []
     for lin in lins:
         params += [lin.weight, lin.bias]
-    return _MlpStackFn.apply(x, *params)
+    _FWD_BOUNDED[0] = bool(embedding_input)
+    try:
+        return _MlpStackFn.apply(x, *params)
+    finally:
+        _FWD_BOUNDED[0] = False
 
 
 class _Units1Fn(torch.autograd.Function):

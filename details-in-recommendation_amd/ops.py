@@ -540,6 +540,8 @@ def dense_supported(x, weight):
 
 # default arithmetic of dense / dense_gated: "auto" (bf16x3 where covered and not padding-bound, fp32 MFMA otherwise) | "f32" | "bf16x3"
 DENSE_ARITH = os.environ.get("DIR_DENSE_ARITH", "auto")
+# what arith="auto_bounded" puts in bf16x3's place: "f16x2" (csrc/dense_bf3.hip, round 4) or "bf16x3" (A/B switch)
+DENSE_BOUNDED_SPLIT = os.environ.get("DIR_DENSE_BOUNDED_SPLIT", "f16x2")
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
 
@@ -581,11 +583,12 @@ def dense_auto_arith(M, Kd, N):
     return "bf16x3" if pad * kpad <= 1.34 * N * Kd else "f32"
 
 
-def dense_bf3_image(weight):
-    """The packed bf16 image of a [N, Kd] fp32 weight of ANY strides (dir_dense_bf16x3_pack_strided_f32: a `.t()` view is packed straight
-    from the storage of the tensor it transposes), cached per tensor until it is modified in place (tensor._version) or goes away."""
+def dense_bf3_image(weight, split="bf16x3"):
+    """The packed image (bf16 x 3, or fp16 x 2 pieces with split="f16x2") of a [N, Kd] fp32 weight of ANY strides
+    (dir_dense_*_pack_strided_f32: a `.t()` view is packed straight from the storage of the tensor it transposes), cached per tensor and
+    split until the tensor is modified in place (tensor._version) or goes away."""
     import weakref
-    key = weight.data_ptr()
+    key = weight.data_ptr() if split == "bf16x3" else (weight.data_ptr(), split)
     sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
     hit = _DENSE_IMAGES.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == sig:
@@ -594,7 +597,8 @@ def dense_bf3_image(weight):
     lib = _lib.load()
     nbytes = int(lib.dir_dense_bf16x3_image_bytes(Kd, N))
     img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _lib.check(lib.dir_dense_bf16x3_pack_strided_f32(_ptr(weight), weight.stride(0), weight.stride(1), Kd, N, _ptr(img), nbytes, _stream()))
+    pack = lib.dir_dense_f16x2_pack_strided_f32 if split == "f16x2" else lib.dir_dense_bf16x3_pack_strided_f32
+    _lib.check(pack(_ptr(weight), weight.stride(0), weight.stride(1), Kd, N, _ptr(img), nbytes, _stream()))
     if len(_DENSE_IMAGES) > 256:
         _DENSE_IMAGES.clear()
     _DENSE_IMAGES[key] = (weakref.ref(weight), sig, img)
@@ -603,13 +607,16 @@ def dense_bf3_image(weight):
 
 def _dense_arith(arith, x, weight, out, gate):
     arith = arith or DENSE_ARITH
-    if arith not in ("auto", "f32", "bf16x3"):
-        raise ValueError("dense: arith must be 'auto', 'f32' or 'bf16x3'")
+    if arith not in ("auto", "f32", "bf16x3", "f16x2", "auto_bounded"):
+        raise ValueError("dense: arith must be 'auto', 'auto_bounded', 'f32', 'bf16x3' or 'f16x2'")
     covered = dense_bf16x3_covers(x, weight, out, gate)
-    if arith == "auto":
-        return "bf16x3" if covered and dense_auto_arith(x.shape[0], x.shape[1], weight.shape[0]) == "bf16x3" else "f32"
-    if arith == "bf16x3" and not covered:
-        raise ValueError("dense: arith='bf16x3' needs Kd, N and the row strides to be multiples of 4 and 16-byte aligned operands")
+    if arith in ("auto", "auto_bounded"):
+        split = "f16x2" if arith == "auto_bounded" and DENSE_BOUNDED_SPLIT == "f16x2" and gate is None else "bf16x3"
+        return split if covered and dense_auto_arith(x.shape[0], x.shape[1], weight.shape[0]) == "bf16x3" else "f32"
+    if arith in ("bf16x3", "f16x2") and not covered:
+        raise ValueError("dense: arith=%r needs Kd, N and the row strides to be multiples of 4 and 16-byte aligned operands" % arith)
+    if arith == "f16x2" and gate is not None:
+        raise ValueError("dense: the gated (data-gradient) form runs bf16x3")
     return arith
 
 
@@ -617,7 +624,10 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32 / dir_dense_bf16x3_f32).  x [M, Kd], weight [N, Kd] (nn.Linear
     layout), bias [N].  post_scale / post_shift [N]: the inference batch-norm that follows the activation, as
     y * post_scale + post_shift in the same pass.  arith: "f32" (fp32 MFMA), "bf16x3" (three-way bf16 split of both operands on the
-    bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same), "auto" (dense_auto_arith), None = DENSE_ARITH."""
+    bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same), "auto" (dense_auto_arith), None = DENSE_ARITH.
+    "f16x2" (dir_dense_f16x2_f32: two fp16 pieces per operand, three products) / "auto_bounded" (what "auto" picks, with f16x2 in the
+    place of bf16x3): for layers whose input is bounded by construction -- embedding concatenations, ReLU / batch-normalised
+    activations, the CIN's pooled products (|x|, |W| < 65 504)."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     M, Kd = x.shape
@@ -630,13 +640,18 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
             raise ValueError("dense: bias [N]")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    use_bf3 = _dense_arith(arith, x, weight, out, None) == "bf16x3"
+    which = _dense_arith(arith, x, weight, out, None)
+    use_bf3 = which in ("bf16x3", "f16x2")
     if not use_bf3 and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16):
         weight = weight.contiguous()          # (the fp32 kernel reads rows with 16-byte loads; the bf16x3 image is packed from any strides)
     if post_scale is not None:
         post_scale, post_shift = _dev(post_scale, torch.float32, "post_scale").contiguous(), _dev(post_shift, torch.float32, "post_shift").contiguous()
         if post_scale.numel() != N or post_shift.numel() != N:
             raise ValueError("dense: post_scale / post_shift [N]")
+    if which == "f16x2":
+        _lib.check(_lib.load().dir_dense_f16x2_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), _ptr(bias), 1 if relu else 0,
+                                                   _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
+        return out
     if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0,
                                                     _ptr(post_scale), _ptr(post_shift), None, 0, M, Kd, N, _ptr(out), out.stride(0), _stream()))
@@ -1236,10 +1251,11 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
         Z = cin_pool_z(x0, xk)
         if pooled is None:
             pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
+        da = "auto_bounded" if (auto and CIN_FWD_SPLIT == "f16x2" and not grad_operand) or arith == "f16x2" else None     # Z: sums of embedding products
         if pooled.stride(1) == 1 and pooled.stride(0) % 4 == 0 and pooled.data_ptr() % 16 == 0:
-            dense(Z, W, out=pooled)
+            dense(Z, W, out=pooled, arith=da)
         else:
-            pooled.copy_(dense(Z, W))
+            pooled.copy_(dense(Z, W, arith=da))
         if z_out is not None:
             z_out.append(Z)
         return None, pooled

@@ -125,10 +125,10 @@ class XDeepFM(nn.Module):
             if fused is not None:
                 return fused
         if mlp_head_supported(self.hidden, self.dnn_out, net, self.activation):
-            logits = logits + mlp_head(self.hidden, self.dnn_out, net)          # training: the tower + its logit layer as one autograd node
+            logits = logits + mlp_head(self.hidden, self.dnn_out, net, embedding_input=True)   # training: the tower + its logit layer as one autograd node
         else:
             if mlp_stack_supported(self.hidden, net, self.activation):
-                net = mlp_stack(self.hidden, net)                               # training: the whole tower as one autograd node
+                net = mlp_stack(self.hidden, net, embedding_input=True)         # training: the whole tower as one autograd node
             else:
                 for lin in self.hidden:
                     net = dense_act(lin, net, self.activation)                  # dir_dense_f32 when covered

@@ -435,6 +435,15 @@ int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const 
                          const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
                          dir_stream_t stream);
 
+/* The layer on "fp16 x 2" arithmetic (csrc/dense_bf3.hip, round 4; dir_cin_layer_f16x2_f32 states the arithmetic and its preconditions):
+ * for layers whose input is bounded by construction -- embedding concatenations, ReLU / batch-normalised activations, the CIN's pooled
+ * products; |x|, |W| < 65 504.  No gate argument: data gradients stay on bf16 x 3.  The image comes from
+ * dir_dense_f16x2_pack_strided_f32 (dir_dense_bf16x3_image_bytes(Kd, N) bytes hold it; not interchangeable with the bf16 x 3 image). */
+int dir_dense_f16x2_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
+                                     dir_stream_t stream);
+int dir_dense_f16x2_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                        const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
+
 /* dir_dense_bf16x3_f32 (no gate) with the head of a tower folded into the epilogue -- DCN's last deep layer and the deep branch's share of
  * the final dense(1) over concat([cross, deep]) (DeepCrossNetwork.py:136-137): head_part [ncb, M] (DEVICE), ncb =
  * dir_dense_bf16x3_head_blocks(N): head_part[cb][r] = the dot product of row r's activations in column block cb with head_w [N]

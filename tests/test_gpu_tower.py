@@ -243,3 +243,62 @@ def test_esmm_inference_towers_do_their_own_lookups(built_lib):
         ws, bs = [l.weight for l in model.ctr_model.hidden], [l.bias for l in model.ctr_model.hidden]
         emb = ops.embedding_bag(ts, ids)
         assert torch.equal(ops.tower(None, ws, bs, gather=(ts, ids, None, False)), ops.tower(emb, ws, bs))
+
+
+@pytest.mark.parametrize("M,Kd,N,relu,affine", [(1, 4, 4, False, False), (300, 416, 400, True, False), (20000, 416, 400, True, True), (13000, 3328, 128, False, False),
+                                                (700, 128, 200, True, False), (257, 36, 208, False, True)])
+def test_dense_f16x2_matches_float64(built_lib, M, Kd, N, relu, affine):
+    """dir_dense_f16x2_f32 (two fp16 pieces per operand, three products; csrc/dense_bf3.hip) against float64 at the 1e-5 bar of the other
+    arithmetics, on embedding-scale operands; reruns bitwise equal; "auto_bounded" is that kernel wherever "auto" picks bf16x3."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(M + Kd)
+    x = (torch.randn(M, Kd, generator=g) * 0.3).cuda()
+    W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).cuda()
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    ps = (torch.rand(N, generator=g) + 0.5).cuda() if affine else None
+    psh = (torch.randn(N, generator=g) * 0.1).cuda() if affine else None
+    got = ops.dense(x, W, b, relu=relu, post_scale=ps, post_shift=psh, arith="f16x2")
+    ref = x.double() @ W.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if affine:
+        ref = ref * ps.double() + psh.double()
+    err = float(((got.double() - ref).abs() / (1 + ref.abs())).max())
+    assert err <= 1e-5, err
+    assert torch.equal(ops.dense(x, W, b, relu=relu, post_scale=ps, post_shift=psh, arith="f16x2"), got)
+    if ops.dense_auto_arith(M, Kd, N) == "bf16x3" and ops.DENSE_BOUNDED_SPLIT == "f16x2":
+        assert torch.equal(ops.dense(x, W, b, relu=relu, post_scale=ps, post_shift=psh, arith="auto_bounded"), got)
+    with pytest.raises(ValueError):
+        ops.dense(x, W, arith="f16x3")
+
+
+def test_tower_splits_agree_and_general_inputs_stay_on_bf16x3(built_lib):
+    """The two split arithmetics of the fused tower against float64 and against each other; dense.tower_infer routes a general input
+    (no embedding_input hint, no gather) to bf16 x 3 -- raw numeric columns may exceed fp16's range (DeepCrossNetwork/train.py's
+    capital_gain reaches 99 999) -- and an embedding input to fp16 x 2."""
+    from dir_amd import ops
+    from dir_amd import dense as D
+    torch.manual_seed(1)
+    M = 8192
+    lins = [torch.nn.Linear(416, 400).cuda(), torch.nn.Linear(400, 400).cuda()]
+    head = torch.nn.Linear(400, 1).cuda()
+    x = (torch.randn(M, 416, device="cuda") * 0.3)
+    ws, bs = [l.weight.data for l in lins], [l.bias.data for l in lins]
+    ref = x.double()
+    for l in lins:
+        ref = (ref @ l.weight.double().t() + l.bias.double()).clamp_min(0)
+    ref = ref @ head.weight.double().t() + head.bias.double()
+    outs = {}
+    for sp in ("f16x2", "bf16x3"):
+        outs[sp] = ops.tower(x, ws, bs, head=(head.weight.data, head.bias.data), split=sp)
+        assert float(((outs[sp].double() - ref).abs() / (1 + ref.abs())).max()) <= 1e-5, sp
+    assert not torch.equal(outs["f16x2"], outs["bf16x3"])           # two arithmetics, two roundings
+    with torch.no_grad():
+        general = D.tower_infer(lins, x, torch.relu, head=head)
+        emb = D.tower_infer(lins, x, torch.relu, head=head, embedding_input=True)
+    assert torch.equal(general, outs["bf16x3"]) and torch.equal(emb, outs[ops.TOWER_SPLIT])
+    big = x.clone()
+    big[:, 7] = 99999.0                                              # a raw numeric column beyond fp16's 65 504
+    with torch.no_grad():
+        gb = D.tower_infer(lins, big, torch.relu, head=head)
+    assert bool(torch.isfinite(gb).all())
