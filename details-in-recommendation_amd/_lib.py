@@ -67,6 +67,7 @@ SIGNATURES = {
     "dir_dense_bf16x3_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_head_blocks": (c_i32, [c_i32]),
     "dir_dense_bf16x3_head_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "dir_dense_f16x2_head_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_dense_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_din_backward_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "dir_din_attention_pool_backward_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,

@@ -443,10 +443,9 @@ extern "C" int dir_dense_bf16x3_head_blocks(int N) {
     return ((N + 15) / 16 + CT - 1) / CT;
 }
 
-extern "C" int dir_dense_bf16x3_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
-                                         const float* post_shift, int64_t M, int Kd, int N, const float* head_w, float* Y, int64_t y_ld,
-                                         float* head_part, dir_stream_t stream) {
-    const char* name = "dir_dense_bf16x3_head_f32";
+static int dense_head_run(const char* name, int pieces, const float* X, int64_t x_ld, const void* image, const float* bias, int act,
+                          const float* post_scale, const float* post_shift, int64_t M, int Kd, int N, const float* head_w, float* Y, int64_t y_ld,
+                          float* head_part, dir_stream_t stream) {
     DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && (!Y || y_ld >= N), "%s: bad shape", name);
     DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
     DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
@@ -461,9 +460,25 @@ extern "C" int dir_dense_bf16x3_head_f32(const float* X, int64_t x_ld, const voi
     hipStream_t st = as_stream(stream);
     const unsigned char* img = static_cast<const unsigned char*>(image);
     const int relu = act == DIR_ACT_RELU;
-    if (CT == 8) launch_dense_bf3<8>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
+    if (pieces == 2) {
+        if (CT == 8) launch_dense_bf3<8, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
+        else if (CT == 13) launch_dense_bf3<13, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
+        else launch_dense_bf3<16, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
+    } else if (CT == 8) launch_dense_bf3<8>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
     else if (CT == 13) launch_dense_bf3<13>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
     else launch_dense_bf3<16>(st, X, x_ld, img, bias, relu, post_scale, post_shift, nullptr, 0, M, Kd, N, nks, ncb, Y, y_ld, head_w, head_part);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_dense_bf16x3_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                                         const float* post_shift, int64_t M, int Kd, int N, const float* head_w, float* Y, int64_t y_ld,
+                                         float* head_part, dir_stream_t stream) {
+    return dense_head_run("dir_dense_bf16x3_head_f32", 3, X, x_ld, image, bias, act, post_scale, post_shift, M, Kd, N, head_w, Y, y_ld, head_part, stream);
+}
+
+extern "C" int dir_dense_f16x2_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                                        const float* post_shift, int64_t M, int Kd, int N, const float* head_w, float* Y, int64_t y_ld,
+                                        float* head_part, dir_stream_t stream) {
+    return dense_head_run("dir_dense_f16x2_head_f32", 2, X, x_ld, image, bias, act, post_scale, post_shift, M, Kd, N, head_w, Y, y_ld, head_part, stream);
 }

@@ -99,7 +99,9 @@ class DeepCrossNetwork(nn.Module):
         last = self.hidden[-1]
         if net.shape[1] != last.in_features:
             return None
-        return ops.dense_head(net, last.weight, last.bias, wd, relu=self.activation is not None)
+        # the last layer reads the batch-normalised activation of the layer below (:400-403): bounded whatever the raw numeric columns
+        # carried, so the fp16 x 2 form may run; without batch norm (or with one hidden layer: the input layer itself) it is bf16 x 3
+        return ops.dense_head(net, last.weight, last.bias, wd, relu=self.activation is not None, bounded=bool(self.batch_norm) and n >= 2)
 
     def _train_logits(self, x0, cross):
         """Training: the final dense(1) over concat([cross, deep]) (:136-137) as cross . w_c + deep . w_d + bias WITHOUT the concat, the

@@ -665,16 +665,18 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     return out
 
 
-def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=None):
+def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=None, bounded=False):
     """act(x @ weight.T + bias) . head_w without writing the activation (include/dir_hip.h: dir_dense_bf16x3_head_f32): the last layer of a
     tower and its share of a following dense(1), e.g. DCN's deep branch (DeepCrossNetwork.py:136-137).  -> [M, 1], or None when the
-    bf16x3 kernel does not cover the operands (the caller then runs the two steps)."""
+    bf16x3 kernel does not cover the operands (the caller then runs the two steps).  bounded: x is bounded by construction (a
+    batch-normalised activation): the fp16 x 2 form of the kernel (dir_dense_f16x2_head_f32) runs."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     M, Kd = x.shape
     N = weight.shape[0]
     if weight.shape[1] != Kd or x.stride(1) != 1 or M < DENSE_BF3_MIN_ROWS or DENSE_ARITH not in ("auto", "bf16x3"):
         return None
+    f16 = bool(bounded) and DENSE_BOUNDED_SPLIT == "f16x2" and DENSE_ARITH == "auto"
     if weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
         weight = weight.contiguous()
     if not dense_bf16x3_covers(x, weight):
@@ -690,8 +692,9 @@ def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=
     lib = _lib.load()
     ncb = int(lib.dir_dense_bf16x3_head_blocks(N))
     part = torch.empty((ncb, M), dtype=torch.float32, device=x.device)
-    _lib.check(lib.dir_dense_bf16x3_head_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0, _ptr(post_scale),
-                                             _ptr(post_shift), M, Kd, N, _ptr(hw), None, 0, _ptr(part), _stream()))
+    fn = lib.dir_dense_f16x2_head_f32 if f16 else lib.dir_dense_bf16x3_head_f32
+    _lib.check(fn(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2" if f16 else "bf16x3")), _ptr(bias), 1 if relu else 0, _ptr(post_scale),
+                  _ptr(post_shift), M, Kd, N, _ptr(hw), None, 0, _ptr(part), _stream()))
     out = part[0].clone() if ncb > 1 else part[0]
     for cb in range(1, ncb):                              # block order: a fixed order
         out += part[cb]

@@ -443,6 +443,11 @@ int dir_dense_f16x2_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs,
                                      dir_stream_t stream);
 int dir_dense_f16x2_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                         const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
+/* dir_dense_bf16x3_head_f32 on the fp16 x 2 arithmetic (the image from dir_dense_f16x2_pack_strided_f32): the last deep layer of DCN reads a
+ * batch-normalised ReLU activation (DeepCrossNetwork.py:400-403) -- bounded by construction. */
+int dir_dense_f16x2_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                             const float* post_shift, int64_t M, int Kd, int N, const float* head_w, float* Y, int64_t y_ld, float* head_part,
+                             dir_stream_t stream);
 
 /* dir_dense_bf16x3_f32 (no gate) with the head of a tower folded into the epilogue -- DCN's last deep layer and the deep branch's share of
  * the final dense(1) over concat([cross, deep]) (DeepCrossNetwork.py:136-137): head_part [ncb, M] (DEVICE), ncb =
