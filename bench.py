@@ -41,6 +41,11 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (the 2:1-sparsity figure is n
 PIPE_COST = {"bf16x3": 6.0, "f32": 16.0, "f16x2": 3.0}      # f16x2: two fp16 pieces per operand, three products (csrc/cin_bf3.hip, round 4)
 
 
+def _cin_fwd_label(ops):
+    f16 = getattr(ops, "CIN_FWD_SPLIT", "") == "f16x2" and ops.CIN_ARITH == "auto"
+    return "fp16x2 split (layers 1-2) / pooled last layer" if f16 else "bf16x3 split"
+
+
 def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
     """CIN stack -> (fp32-equivalent algorithmic flops, the same in bf16-pipe flops, {kernel: arithmetic}).  Forward: one
     [B*D, Hp*m] x [Hp*m, H] contraction per layer.  Backward: two of that size per layer -- T = G x W (both data gradients, one
@@ -948,7 +953,7 @@ def main():
                     model(featl[i % len(featl)])
             alg, pipe, modes = cin_flops(ops, B, F, K, (128, 128, 128))
             roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "kernel": "xDeepFM forward (CIN flops only): cin_bf3_k x3",
-                    "modes": modes, "dtype": "f32 (CIN: f32 via bf16x3 split, f32 accumulate)"}
+                    "modes": modes, "dtype": "f32 (CIN: f32 via %s, f32 accumulate)" % _cin_fwd_label(ops)}
         else:
             # the DeepFM recipe (deepFM.py:58,61): fused sorted sparse Adagrad on the embedding tables and FTRL on the linear columns
             # inside backward() (one sort for both), torch Adagrad on everything dense
@@ -965,7 +970,7 @@ def main():
             alg, pipe, modes = cin_flops(ops, B, F, K, (128, 128, 128), forward=True, backward=True)
             roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes,
                     "kernel": "xDeepFM training step (CIN forward + backward flops only): cin_bf3_k, cin_bf3_k<DOT>, cin_dw_bf3_k (layer 1: cin_dw_k)",
-                    "dtype": "f32 (CIN: f32 via bf16x3 split, f32 accumulate)"}
+                    "dtype": "f32 (CIN forward: f32 via %s; backward: bf16x3 split; f32 accumulate)" % _cin_fwd_label(ops)}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "cin": [128, 128, 128], "dnn": [400, 400]})
     elif wl == "dcn_cross":
         d, L = args.cross_d, 3
