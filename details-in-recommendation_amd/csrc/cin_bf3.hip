@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict_
 // (ptab[p] = i | j << 8; mx = the real field count).  351 reduction slots instead of 26 x 32 = 832 at m = 26.
 template <int KS, int CT /* column tiles of 16 per workgroup: 8 (128 columns), or 6 / 4 / 2 for the last block of a layer */,
           int RT = 2 /* row tiles of 16 per wave */, bool DOT = false, int FJ = 1 /* fields per staged chunk */, bool PAIRS = false,
-          int NP = 3 /* pieces per operand: 3 = bf16 x 3, 2 = fp16 x 2 (forward only) */>
+          int NP = 3 /* pieces per operand: 3 = bf16 x 3, 2 = fp16 x 2 */,
+          bool RS = false /* fp16 x 2 with a left operand of unknown magnitude (a gradient): every row of xk is scaled by a power of two so
+                             that its largest element lands in [2^14, 2^15), the scale is taken out again where T meets the field factor */>
 __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                      const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
                                                      int nkh, int hoff /* first output column of this launch */, int64_t R,
@@ -169,7 +171,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      int mx /* fields of the x0 slice (= m unless PAIRS) */) {
     using Pc = BtPc<NP>;
     using op_t = typename Pc::op_t;
-    static_assert(NP == 3 || !DOT, "the data-gradient form keeps bf16 x 3");
+    static_assert(NP == 3 || !DOT || RS, "the data-gradient form on fp16 x 2 needs the row-scaled left operand");
+    static_assert(!RS || (NP == 2 && !PAIRS), "row scaling belongs to the fp16 x 2 split of a general left operand");
     constexpr int STEPB = NP * CT * 1024;                        // bytes of W image per k-step of 32
     constexpr int CHB = KS * STEPB;                              // bytes of W image per (half, field); a staged chunk holds FJ of them
     constexpr int BT_ROWS = 8 * 16 * RT;                         // rows per workgroup (shadows the 256 of the forward)
@@ -215,6 +218,35 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         xsrc[rt] = xk + ((grc >> dshift) * Hp) * D + (grc & (D - 1));
     }
 
+    // RS: the power-of-two scale of this lane's A rows and, for the rows of its accumulator registers, the inverse.  A row's largest
+    // |element| over ALL its Hp channels decides (exponent e: scale 2^(141 - e), clamped to 2^+-100 -- an all-zero row stays zero): the
+    // scaled row fits fp16 with its largest elements at 11 + 11 bits; elements more than 2^-17 below the row's largest keep an ABSOLUTE
+    // error of 2^-25 (2^-39 of the largest), which is what a sum over the row's channels needs.  The scaling itself is exact.
+    float rscale[RS ? RT : 1];
+    f32x4 rinv[RS ? RT : 1];
+    if constexpr (RS) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float mx = 0.f;
+            for (int i0 = 8 * lg; i0 < Hp; i0 += 32) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = i0 + e;
+                    const float x = xsrc[rt][(int64_t)(i < Hp ? i : Hp - 1) * D];
+                    mx = fmaxf(mx, fabsf(x));
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            int k = 141 - (int)((__builtin_bit_cast(unsigned int, mx) >> 23) & 0xffu);
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            rscale[rt] = __builtin_bit_cast(float, (unsigned int)(127 + k) << 23);
+            const float inv = __builtin_bit_cast(float, (unsigned int)(127 - k) << 23);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rinv[rt][q] = __shfl(inv, 4 * lg + q, 64);      // lane 4 lg + q holds row 4 lg + q of the tile
+        }
+    }
+
     f32x4 out[RT][CT], T[RT][CT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -238,6 +270,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 const int h = hbase + 16 * ct + n;
                 yv[rt][ct] = (h < H && gr < R) ? *reinterpret_cast<const f32x4*>(y + ((gr >> dshift) * H + h) * D + (gr & (D - 1)))
                                                : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (RS) yv[rt][ct] *= rinv[rt];            // T carries the rows' scales: taken out where it is consumed
             }
         }
     }
@@ -284,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 for (int e = 0; e < 8; ++e) {
                     const int i = KS * 32 * kh + 32 * ks + 8 * lg + e;
                     const float x = xsrc[rt][(int64_t)(i < Hp ? i : Hp - 1) * D];
-                    v[e] = i < Hp ? x : 0.f;          // the W image is zero there; 0 * garbage must stay 0
+                    v[e] = i < Hp ? (RS ? x * rscale[rt] : x) : 0.f;          // the W image is zero there; 0 * garbage must stay 0
                 }
                 }
                 unsigned int w[NP][4];
@@ -314,6 +347,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 xcur[rt] = PAIRS ? (f32x4){1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
+                if constexpr (RS) xcur[rt] *= rinv[rt];
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
@@ -472,7 +506,8 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: 64-column blocks, two fields per chunk, dot partials)
 static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                    float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
-                   const float* addp = nullptr, int64_t addp_ld = 0, int np = 3 /* 2: the fp16 x 2 forward */) {
+                   const float* addp = nullptr, int64_t addp_ld = 0, int np = 3 /* 2: fp16 x 2 */,
+                   bool rs = false /* fp16 x 2 with the left operand scaled per row (a gradient) */) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -487,7 +522,8 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     const int64_t R = B * D;
     hipStream_t st = as_stream(stream);
     const bool dot = y != nullptr;
-    if (dot && np != 3) return fail(DIR_E_UNSUPPORTED, "%s: the data-gradient form runs bf16 x 3 only", name);
+    if (dot && np != 3 && !rs) return fail(DIR_E_UNSUPPORTED, "%s: the data-gradient form on fp16 x 2 needs the row-scaled left operand", name);
+    if (rs && np != 2) return fail(DIR_E_UNSUPPORTED, "%s: row scaling belongs to fp16 x 2", name);
     const Bf3Plan pl = bf3_plan(m, Hp, H, dot, np);
     unsigned char* img = static_cast<unsigned char*>(workspace);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
@@ -503,26 +539,29 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     if (pl.ctl) pack(1, pl.ctl, 16 * pl.bw * pl.nfull, img + pl.bytes_full);
     const unsigned nrb = (unsigned)((R + 255) / 256);
     const int64_t dot_block = (int64_t)pl.nkh * B * m * D;         // floats of dot partials per column block
-#define BT_LAUNCH(K, C, DOT_, FJ_, NP_, NCB, HOFF, IMG, DOTP)                                                                         \
+#define BT_LAUNCH(K, C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                                                                    \
     do {                                                                                                                              \
         static LdsOnce once;                                                                                                      \
-        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_>);                                            \
+        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>);                                       \
         const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256;                                  \
-        hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
+        hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
                            dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m);                     \
+    } while (0)
+#define BT_LAUNCH_KS(C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                       \
+    do {                                                                                 \
+        if (pl.KS == 1) BT_LAUNCH(1, C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP);      \
+        else BT_LAUNCH(2, C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP);                 \
     } while (0)
 #define BT_LAUNCH_FWD(C, NCB, HOFF, IMG)                                                 \
     do {                                                                                 \
-        if (np == 2) {                                                                   \
-            if (pl.KS == 1) BT_LAUNCH(1, C, false, 1, 2, NCB, HOFF, IMG, nullptr);       \
-            else BT_LAUNCH(2, C, false, 1, 2, NCB, HOFF, IMG, nullptr);                  \
-        } else if (pl.KS == 1) BT_LAUNCH(1, C, false, 1, 3, NCB, HOFF, IMG, nullptr);    \
-        else BT_LAUNCH(2, C, false, 1, 3, NCB, HOFF, IMG, nullptr);                      \
+        if (rs) BT_LAUNCH_KS(C, false, 1, 2, true, NCB, HOFF, IMG, nullptr);             \
+        else if (np == 2) BT_LAUNCH_KS(C, false, 1, 2, false, NCB, HOFF, IMG, nullptr);  \
+        else BT_LAUNCH_KS(C, false, 1, 3, false, NCB, HOFF, IMG, nullptr);               \
     } while (0)
 #define BT_LAUNCH_DOT(C, NCB, HOFF, IMG, DOTP)                                      \
     do {                                                                            \
-        if (pl.KS == 1) BT_LAUNCH(1, C, true, 2, 3, NCB, HOFF, IMG, DOTP);          \
-        else BT_LAUNCH(2, C, true, 2, 3, NCB, HOFF, IMG, DOTP);                     \
+        if (rs) BT_LAUNCH_KS(C, true, 2, 2, true, NCB, HOFF, IMG, DOTP);            \
+        else BT_LAUNCH_KS(C, true, 2, 3, false, NCB, HOFF, IMG, DOTP);              \
     } while (0)
     const unsigned char* li = img + pl.bytes_full;
     const int lo = 16 * pl.bw * pl.nfull;
@@ -546,6 +585,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     }
 #undef BT_LAUNCH_DOT
 #undef BT_LAUNCH_FWD
+#undef BT_LAUNCH_KS
 #undef BT_LAUNCH
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
@@ -563,6 +603,15 @@ extern "C" int dir_cin_layer_f16x2_f32(const float* x0, const float* xk, const f
                                        dir_stream_t stream) {
     return bf3_run("dir_cin_layer_f16x2_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace, workspace_bytes,
                    stream, nullptr, 0, 2);
+}
+
+// The forward contraction with a left operand of unknown magnitude (a gradient: the backward's forward-form contractions): fp16 x 2 with
+// every row of xk scaled by a power of two inside the kernel (template parameter RS)
+extern "C" int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
+                                            float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                            dir_stream_t stream) {
+    return bf3_run("dir_cin_layer_grad_f16x2_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace,
+                   workspace_bytes, stream, nullptr, 0, 2, true);
 }
 
 // ---- the first layer over field pairs (PAIRS) -----------------------------------------------------------------------------------------------
@@ -703,6 +752,18 @@ extern "C" int dir_cin_layer_dot_add_bf16x3_f32(const float* x0, const float* xk
     DIR_CHECK_ARG(aligned16(y) && aligned16(dot_partials), "%s: y and dot_partials must be 16-byte aligned", name);
     DIR_CHECK_ARG(!add_pooled || add_pooled_ld >= H, "%s: add_pooled_ld=%lld < H=%d", name, (long long)add_pooled_ld, H);
     return bf3_run(name, x0, xk, W, m, Hp, H, D, B, xout, nullptr, 0, y, dot_partials, workspace, workspace_bytes, stream, add_pooled, add_pooled_ld);
+}
+
+extern "C" int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D,
+                                               int64_t B, const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials,
+                                               void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    const char* name = "dir_cin_layer_dot_add_f16x2_f32";
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(y && dot_partials && xout, "%s: null pointer", name);
+    DIR_CHECK_ARG(aligned16(y) && aligned16(dot_partials), "%s: y and dot_partials must be 16-byte aligned", name);
+    DIR_CHECK_ARG(!add_pooled || add_pooled_ld >= H, "%s: add_pooled_ld=%lld < H=%d", name, (long long)add_pooled_ld, H);
+    return bf3_run(name, x0, xk, W, m, Hp, H, D, B, xout, nullptr, 0, y, dot_partials, workspace, workspace_bytes, stream, add_pooled, add_pooled_ld,
+                   2, true);
 }
 
 // out[e] (+)= sum over p of parts[p][e] in p order, e < n (n % 4 == 0, 16-byte aligned): the dot partials of dir_cin_layer_dot_*_f32 -> dx0,

@@ -51,6 +51,79 @@ __device__ __forceinline__ void dwb_split8(f32x2 v0, f32x2 v1, f32x2 v2, f32x2 v
     for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
 }
 
+// ---- round 4: "fp16 x 2" (cin_bf3.hip states the arithmetic) for the weight gradient -----------------------------------------------------
+// G is an operand here and its magnitude is unknown, so it is scaled by ONE power of two for the whole tensor (its largest |element| lands
+// in [2^12, 2^13): A_j = (s G) x0_j stays below fp16's 65 504 for |x0| < 8), found by a max pass over G (gabs_k; a caller that already
+// knows max |G| passes its bit pattern instead) and taken out again by the reduce pass.  Elements more than 2^-15 below the largest keep an
+// ABSOLUTE error of 2^-25 of the scaled tensor -- the reduction runs over all rows, the large elements decide its size.  xk is split as in
+// the fp16 x 2 forward (same precondition: activations of O(1)).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int dwb_pk_h(float a, float b) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));
+    return w;
+}
+__device__ __forceinline__ void dwb_split8h(f32x2 v0, f32x2 v1, f32x2 v2, f32x2 v3, f16x8_t (&p)[2]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const f32x2 v[4] = {v0, v1, v2, v3};
+    unsigned int w[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w[0][i] = dwb_pk_h(v[i][0], v[i][1]);
+        const h2_t h = __builtin_bit_cast(h2_t, w[0][i]);
+        const f32x2 r = v[i] - (f32x2){(float)h[0], (float)h[1]};
+        w[1][i] = dwb_pk_h(r[0], r[1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) p[q] = __builtin_bit_cast(f16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
+}
+template <int NP> struct DwbPc;
+template <> struct DwbPc<3> {
+    using op_t = bf16x8_t;
+    __device__ static __forceinline__ void split8(f32x2 a, f32x2 b, f32x2 c, f32x2 d, op_t (&p)[3]) { dwb_split8(a, b, c, d, p); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[3], const op_t (&b)[3], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+template <> struct DwbPc<2> {
+    using op_t = f16x8_t;
+    __device__ static __forceinline__ void split8(f32x2 a, f32x2 b, f32x2 c, f32x2 d, op_t (&p)[2]) { dwb_split8h(a, b, c, d, p); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[2], const op_t (&b)[2], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+// scale 2^k / its inverse for a tensor whose largest |element| has the bit pattern `bits`: the largest lands in [2^12, 2^13)
+__device__ __forceinline__ float dwb_scale(unsigned int bits, bool inverse) {
+    int k = 139 - (int)((bits >> 23) & 0xffu);
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return __builtin_bit_cast(float, (unsigned int)(inverse ? 127 - k : 127 + k) << 23);
+}
+// max |G| as a bit pattern (non-negative floats order like their bits): one atomic per workgroup
+__global__ __launch_bounds__(256) void gabs_k(const float* __restrict__ G, int64_t n4, unsigned int* __restrict__ out) {
+    float mx = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G) + e);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __builtin_bit_cast(unsigned int, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+
 struct DwbPlan { int nhb, nib, njb, items, nspan; int64_t steps, steps_per_span; };
 static DwbPlan dwb_plan(int m, int Hp, int H, int D, int64_t B) {
     DwbPlan p;
@@ -67,10 +140,16 @@ static DwbPlan dwb_plan(int m, int Hp, int H, int D, int64_t B) {
     return p;
 }
 
+template <int NP>
 __global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__ x0, const float* __restrict__ xk, const float* __restrict__ G,
                                                        int m, int Hp, int H, int D, int dshift, int nib, int njb, int nspan,
-                                                       int64_t steps_per_span, int64_t steps, int64_t R, float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) unsigned int Bp[2][3][8][64][4];      // xk pieces of one k-step: [buffer][piece][i tile][lane][8 bf16]
+                                                       int64_t steps_per_span, int64_t steps, int64_t R, float* __restrict__ part,
+                                                       const unsigned int* __restrict__ gmax /* NP == 2: bit pattern of max |G| */) {
+    using Pc = DwbPc<NP>;
+    using op_t = typename Pc::op_t;
+    __shared__ __attribute__((aligned(16))) unsigned int Bp[2][NP][8][64][4];     // xk pieces of one k-step: [buffer][piece][i tile][lane][8 halves]
+    float gs = 1.f;
+    if constexpr (NP == 2) gs = dwb_scale(*gmax, false);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, lg = lane >> 4;
     // work item: blockIdx.x = ((hb * nib + ib) * njb + jb) * nspan + span
@@ -120,11 +199,11 @@ __global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__
         octet(xk, icol, Hp, s, rb);
         if (!icol_in) rb[0] = rb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
-    auto split_b = [&](int buf) {                 // this thread's octet of xk -> three pieces in LDS
-        bf16x8_t p[3];
-        dwb_split8((f32x2){rb[0][0], rb[0][1]}, (f32x2){rb[0][2], rb[0][3]}, (f32x2){rb[1][0], rb[1][1]}, (f32x2){rb[1][2], rb[1][3]}, p);
+    auto split_b = [&](int buf) {                 // this thread's octet of xk -> its pieces in LDS
+        op_t p[NP];
+        Pc::split8((f32x2){rb[0][0], rb[0][1]}, (f32x2){rb[0][2], rb[0][3]}, (f32x2){rb[1][0], rb[1][1]}, (f32x2){rb[1][2], rb[1][3]}, p);
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(&Bp[buf][pc][wave][lane][0]) = p[pc];
+        for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<op_t*>(&Bp[buf][pc][wave][lane][0]) = p[pc];
     };
 
     if (s_begin < s_end) {
@@ -137,30 +216,24 @@ __global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__
     int buf = 0;
     for (int64_t s = s_begin; s < s_end; ++s, buf ^= 1) {
         // A operands: G octet of row h times the x0 octet of each of the JB fields, split
-        bf16x8_t a[DWB_JB][3];
-        const f32x2 g0 = {rg[0][0], rg[0][1]}, g1 = {rg[0][2], rg[0][3]}, g2 = {rg[1][0], rg[1][1]}, g3 = {rg[1][2], rg[1][3]};
+        op_t a[DWB_JB][NP];
+        f32x2 g0 = {rg[0][0], rg[0][1]}, g1 = {rg[0][2], rg[0][3]}, g2 = {rg[1][0], rg[1][1]}, g3 = {rg[1][2], rg[1][3]};
+        if constexpr (NP == 2) { g0 *= gs; g1 *= gs; g2 *= gs; g3 *= gs; }
 #pragma unroll
         for (int j = 0; j < DWB_JB; ++j)
-            dwb_split8(g0 * (f32x2){rx[j][0][0], rx[j][0][1]}, g1 * (f32x2){rx[j][0][2], rx[j][0][3]}, g2 * (f32x2){rx[j][1][0], rx[j][1][1]},
+            Pc::split8(g0 * (f32x2){rx[j][0][0], rx[j][0][1]}, g1 * (f32x2){rx[j][0][2], rx[j][0][3]}, g2 * (f32x2){rx[j][1][0], rx[j][1][1]},
                        g3 * (f32x2){rx[j][1][2], rx[j][1][3]}, a[j]);
         if (s + 1 < s_end) split_b(buf ^ 1);
         load_a(s + 1);                                   // (rows past R read as zeros; a step past the span is loaded and not used)
         load_b(s + 2);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            bf16x8_t b[3];
+            op_t b[NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) b[pc] = *reinterpret_cast<const bf16x8_t*>(&Bp[buf][pc][it][lane][0]);
+            for (int pc = 0; pc < NP; ++pc) b[pc] = *reinterpret_cast<const op_t*>(&Bp[buf][pc][it][lane][0]);
 #pragma unroll
             for (int j = 0; j < DWB_JB; ++j) {
-                f32x4 c = acc[j][it];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][0], b[2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][2], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][1], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][0], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][1], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j][0], b[0], c, 0, 0, 0);
-                acc[j][it] = c;
+                acc[j][it] = Pc::mma(a[j], b, acc[j][it]);
 #if DWB_CHAIN
                 __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (dense_bf3.hip: DB3_CHAIN)
 #endif
@@ -180,8 +253,10 @@ __global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__
 
 // dW[h, i*m + j] (+)= sum over spans, in span order
 __global__ __launch_bounds__(256) void cin_dw_bf3_reduce_k(const float* __restrict__ part, int m, int Hp, int H, int nib, int njb, int nspan,
-                                                          int accumulate, float* __restrict__ dW) {
+                                                          int accumulate, float* __restrict__ dW,
+                                                          const unsigned int* __restrict__ gmax /* fp16 x 2: the scale to take out, or null */) {
     const int64_t total = (int64_t)H * Hp * m;
+    const float inv = gmax ? dwb_scale(*gmax, true) : 1.f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int j = (int)(e % m);
         const int i = (int)((e / m) % Hp);
@@ -191,6 +266,7 @@ __global__ __launch_bounds__(256) void cin_dw_bf3_reduce_k(const float* __restri
         const float* p = part + ((item * nspan) * DWB_JB + (j - jb * DWB_JB)) * 128 * 128 + (int64_t)(h & 127) * 128 + (i & 127);
         float s = 0.f;
         for (int sp = 0; sp < nspan; ++sp) s += p[(int64_t)sp * DWB_JB * 128 * 128];
+        s *= inv;
         dW[e] = accumulate ? dW[e] + s : s;
     }
 }
@@ -205,9 +281,8 @@ extern "C" int64_t dir_cin_dw_bf16x3_workspace_bytes(int m, int Hp, int H, int D
     return (int64_t)p.items * p.nspan * DWB_JB * 128 * 128 * (int64_t)sizeof(float);
 }
 
-extern "C" int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
-                                     float* dW, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
-    const char* name = "dir_cin_dw_bf16x3_f32";
+static int dwb_run(const char* name, int np, const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,
+                   int accumulate, float* dW, void* workspace, int64_t workspace_bytes, const unsigned int* gmax_bits, dir_stream_t stream) {
     DIR_CHECK_ARG(dW, "%s: null pointer", name);
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (!(D == 8 || D == 16 || D == 32)) return fail(DIR_E_UNSUPPORTED, "%s: D=%d (supported: 8, 16, 32; use dir_cin_dw_f32)", name, D);
@@ -220,16 +295,45 @@ extern "C" int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const flo
     DIR_CHECK_ARG(x0 && xk && G && workspace, "%s: null pointer", name);
     if (!(aligned16(x0) && aligned16(xk) && aligned16(G) && aligned16(workspace)))
         return fail(DIR_E_BADARG, "%s: x0 / xk / G / workspace must be 16-byte aligned", name);
-    DIR_CHECK_ARG(workspace_bytes >= dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B), "%s: workspace smaller than "
-                  "dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B)", name);
+    const int64_t part_bytes = dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B);
+    DIR_CHECK_ARG(workspace_bytes >= part_bytes + (np == 2 ? 256 : 0), "%s: workspace smaller than its workspace_bytes query", name);
     int dshift = 0;
     while ((1 << dshift) < D) ++dshift;
     const DwbPlan p = dwb_plan(m, Hp, H, D, B);
-    hipLaunchKernelGGL(cin_dw_bf3_k, dim3((unsigned)(p.items * p.nspan)), dim3(512), 0, st, x0, xk, G, m, Hp, H, D, dshift, p.nib, p.njb, p.nspan,
-                       p.steps_per_span, p.steps, B * D, static_cast<float*>(workspace));
+    float* part = static_cast<float*>(workspace);
+    if (np == 2) {
+        if (!gmax_bits) {                      // max |G| by a pass of our own, into the workspace's tail
+            unsigned int* slot = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(workspace) + part_bytes);
+            if (zero_async(slot, 256, st) != hipSuccess) return fail(DIR_E_HIP, "%s: zeroing failed", name);
+            const int64_t n4 = B * H * D / 4;                      // D % 8 == 0: whole vectors
+            hipLaunchKernelGGL(gabs_k, dim3(grid_for((n4 + 255) / 256, 8)), dim3(256), 0, st, G, n4, slot);
+            DIR_CHECK_LAUNCH("cin_dw gabs");
+            gmax_bits = slot;
+        }
+        hipLaunchKernelGGL(cin_dw_bf3_k<2>, dim3((unsigned)(p.items * p.nspan)), dim3(512), 0, st, x0, xk, G, m, Hp, H, D, dshift, p.nib, p.njb,
+                           p.nspan, p.steps_per_span, p.steps, B * D, part, gmax_bits);
+    } else {
+        hipLaunchKernelGGL(cin_dw_bf3_k<3>, dim3((unsigned)(p.items * p.nspan)), dim3(512), 0, st, x0, xk, G, m, Hp, H, D, dshift, p.nib, p.njb,
+                           p.nspan, p.steps_per_span, p.steps, B * D, part, nullptr);
+    }
     DIR_CHECK_LAUNCH(name);
     hipLaunchKernelGGL(cin_dw_bf3_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(workspace), m, Hp, H, p.nib,
-                       p.njb, p.nspan, accumulate, dW);
-    DIR_CHECK_LAUNCH("cin_dw_bf16x3 reduce");
+                       p.njb, p.nspan, accumulate, dW, np == 2 ? gmax_bits : nullptr);
+    DIR_CHECK_LAUNCH("cin_dw reduce");
     return DIR_OK;
+}
+
+extern "C" int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
+                                     float* dW, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    return dwb_run("dir_cin_dw_bf16x3_f32", 3, x0, xk, G, m, Hp, H, D, B, accumulate, dW, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int64_t dir_cin_dw_f16x2_workspace_bytes(int m, int Hp, int H, int D, int64_t B) {
+    if (m <= 0 || Hp <= 0 || H <= 0 || D <= 0 || B < 0) return 0;
+    return dir_cin_dw_bf16x3_workspace_bytes(m, Hp, H, D, B) + 256;
+}
+
+extern "C" int dir_cin_dw_f16x2_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
+                                    float* dW, void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits, dir_stream_t stream) {
+    return dwb_run("dir_cin_dw_f16x2_f32", 2, x0, xk, G, m, Hp, H, D, B, accumulate, dW, workspace, workspace_bytes, g_absmax_bits, stream);
 }

@@ -1163,6 +1163,12 @@ CIN_ARITH = os.environ.get("DIR_CIN_ARITH", "auto")
 CIN_FWD_SPLIT = os.environ.get("DIR_CIN_FWD_SPLIT", "f16x2")
 
 
+# the split of the CIN BACKWARD kernels whose left operand is a gradient (data-gradient form, forward-form contractions, weight gradient):
+# "f16x2" = two fp16 pieces with the gradient scaled by a power of two (per row / per tensor; include/dir_hip.h:
+# dir_cin_layer_dot_add_f16x2_f32, dir_cin_layer_grad_f16x2_f32, dir_cin_dw_f16x2_f32), "bf16x3" = rounds 2-3's arithmetic
+CIN_BWD_SPLIT = os.environ.get("DIR_CIN_BWD_SPLIT", "f16x2")
+
+
 def cin_bf16x3_covers(m, D):
     """Shapes dir_cin_layer_bf16x3_f32 accepts (csrc/cin_bf3.hip)."""
     return 1 <= m <= 40 and D in (4, 8, 16, 32)
@@ -1244,8 +1250,8 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
     scaled error 3-6e-7 on embedding-scale data); "auto" picks it for forward layers (CIN_FWD_SPLIT) unless grad_operand says that xk is
     a gradient (the backward's forward-form contractions): small magnitudes belong on bf16x3."""
     arith = arith or CIN_ARITH
-    if arith not in ("auto", "f32", "bf16x3", "f16x2"):
-        raise ValueError("cin_layer: arith must be 'auto', 'f32', 'bf16x3' or 'f16x2'")
+    if arith not in ("auto", "f32", "bf16x3", "f16x2", "f16x2_grad"):
+        raise ValueError("cin_layer: arith must be 'auto', 'f32', 'bf16x3', 'f16x2' or 'f16x2_grad'")
     auto = arith == "auto"
     if (not want_xout and arith != "f32" and CIN_POOLED_LAST and x0.dim() == 3 and xk.dim() == 3 and x0.shape[0] > 0
             and cin_pooled_covers(x0.shape[1], x0.shape[2], xk.shape[1]) and x0.is_cuda and x0.is_contiguous() and xk.is_contiguous()
@@ -1266,6 +1272,8 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
         arith = cin_auto_arith(x0.shape[1], x0.shape[2], xk.shape[1], W.shape[0])
         if arith == "bf16x3" and CIN_FWD_SPLIT == "f16x2" and not grad_operand:
             arith = "f16x2"
+        elif arith == "bf16x3" and CIN_BWD_SPLIT == "f16x2" and grad_operand and xk.data_ptr() != x0.data_ptr():
+            arith = "f16x2_grad"                                 # xk is a gradient: fp16 x 2 with its rows scaled inside the kernel
     _dev(x0, torch.float32, "x0")
     _dev(xk, torch.float32, "xk")
     _dev(W, torch.float32, "W")
@@ -1279,13 +1287,13 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
     xout = torch.empty((B, H, D), dtype=torch.float32, device=x0.device) if want_xout else None
     if pooled is None:
         pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
-    if arith in ("bf16x3", "f16x2"):
+    if arith in ("bf16x3", "f16x2", "f16x2_grad"):
         if not cin_bf16x3_covers(m, D):
             raise ValueError("cin_layer: arith=%r covers m <= 40 and D in {4,8,16,32} (got m=%d, D=%d)" % (arith, m, D))
         lib = _lib.load()
         f_l1 = lib.dir_cin_layer1_f16x2_f32 if arith == "f16x2" else lib.dir_cin_layer1_bf16x3_f32
-        f_ly = lib.dir_cin_layer_f16x2_f32 if arith == "f16x2" else lib.dir_cin_layer_bf16x3_f32
-        if CIN_L1_PAIRS and xk.data_ptr() == x0.data_ptr() and Hp == m and 8 <= m <= 40 and B > 0:
+        f_ly = {"f16x2": lib.dir_cin_layer_f16x2_f32, "f16x2_grad": lib.dir_cin_layer_grad_f16x2_f32}.get(arith, lib.dir_cin_layer_bf16x3_f32)
+        if arith != "f16x2_grad" and CIN_L1_PAIRS and xk.data_ptr() == x0.data_ptr() and Hp == m and 8 <= m <= 40 and B > 0:
             # the first layer of a stack (xk IS x0): a quadratic form in x0 -- the kernel multiplies the m (m + 1) / 2 unordered pairs only
             # (dir_cin_layer1_bf16x3_f32)
             nbytes = int(lib.dir_cin_layer1_bf16x3_workspace_bytes(m, H))
@@ -1529,11 +1537,13 @@ def cin_dw_auto_arith(m, D, Hp, H):
     return "bf16x3" if pad <= 1.34 * H * Hp * m else "f32"
 
 
-def cin_dw(x0, xk, G, dW=None, accumulate=False, arith=None):
+def cin_dw(x0, xk, G, dW=None, accumulate=False, arith=None, g_absmax_bits=None):
     """Weight gradient of one CIN layer (include/dir_hip.h, dir_cin_dw_f32): x0 [B,m,D], xk [B,Hp,D], G = dL/dxout
     [B,H,D] -> dW [H, Hp*m] (added into `dW` when accumulate).  arith: "f32" | "bf16x3" | "auto" (cin_dw_auto_arith) | None = CIN_ARITH;
     when xk IS x0 (the first layer of a stack: same storage) "auto" and "bf16x3" run the symmetric kernel dir_cin_dw_sym_bf16x3_f32
-    ("bf16x3_sym" asks for it by name)."""
+    ("bf16x3_sym" asks for it by name).  "f16x2" (what "auto" resolves to under CIN_BWD_SPLIT where it used to pick bf16x3):
+    dir_cin_dw_f16x2_f32, G scaled by one power of two; g_absmax_bits: an int32 / uint32 device tensor holding the bit pattern of an upper
+    bound of max |G| (None: the entry runs its own max pass)."""
     for t, n in ((x0, "x0"), (xk, "xk"), (G, "G")):
         _dev(t, torch.float32, n)
         if not t.is_contiguous():
@@ -1561,6 +1571,16 @@ def cin_dw(x0, xk, G, dW=None, accumulate=False, arith=None):
         return dW
     if arith == "auto":
         arith = cin_dw_auto_arith(m, D, Hp, H)
+        if arith == "bf16x3" and CIN_BWD_SPLIT == "f16x2":
+            arith = "f16x2"
+    if arith == "f16x2":
+        if D not in (8, 16, 32):
+            raise ValueError("cin_dw: arith='f16x2' covers D in {8, 16, 32} (got %d)" % D)
+        nbytes = int(lib.dir_cin_dw_f16x2_workspace_bytes(m, Hp, H, D, B))
+        ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+        _lib.check(lib.dir_cin_dw_f16x2_f32(_ptr(x0), _ptr(xk), _ptr(G), m, Hp, H, D, B, 1 if accumulate else 0, _ptr(dW), _ptr(ws), nbytes,
+                                            _ptr(g_absmax_bits), _stream()))
+        return dW
     if arith == "bf16x3":
         if D not in (8, 16, 32):
             raise ValueError("cin_dw: arith='bf16x3' covers D in {8, 16, 32} (got %d)" % D)
@@ -1603,13 +1623,17 @@ def cin_dx(x0, xk, W, G):
     return dxk, dx0
 
 
-def cin_dx_bf16x3(x0, xk, W, G, add_pooled=None, dx0=None):
+def cin_dx_bf16x3(x0, xk, W, G, add_pooled=None, dx0=None, split=None):
     """Both data gradients of one CIN layer on the bf16x3 kernel (include/dir_hip.h, dir_cin_layer_dot_bf16x3_f32): the forward
     contraction on the permuted weight W1[i, h*m+j] = W[h, i*m+j] with G as its left operand gives dxk, and the same T_j tiles dotted
     with xk give dx0 (partial sums per column block and half of i, added in a fixed order by dir_sum_partials_f32).
     add_pooled [B, Hp] (unit column stride): added to dxk[b, i, :] in the kernel's epilogue (dir_cin_layer_dot_add_bf16x3_f32) -- in the
     backward of a stack that sum is the layer below's dL/dxout.  dx0: a [B, m, D] tensor the partial sums are ACCUMULATED into (the
-    running dx0 of a stack); None: a new tensor.  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
+    running dx0 of a stack); None: a new tensor.  split: "bf16x3" | "f16x2" (dir_cin_layer_dot_add_f16x2_f32: G's rows scaled by powers
+    of two inside the kernel) | None = CIN_BWD_SPLIT.  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
+    split = split or CIN_BWD_SPLIT
+    if split not in ("bf16x3", "f16x2"):
+        raise ValueError("cin_dx_bf16x3: split must be 'bf16x3' or 'f16x2'")
     for t, n in ((x0, "x0"), (xk, "xk"), (W, "W"), (G, "G")):
         _dev(t, torch.float32, n)
         if not t.is_contiguous():
@@ -1632,7 +1656,8 @@ def cin_dx_bf16x3(x0, xk, W, G, add_pooled=None, dx0=None):
         _dev(add_pooled, torch.float32, "add_pooled")
         if tuple(add_pooled.shape) != (B, Hp) or (B > 0 and add_pooled.stride(1) != 1):
             raise ValueError("cin_dx_bf16x3: add_pooled must be [B, Hp] with unit column stride")
-    _lib.check(lib.dir_cin_layer_dot_add_bf16x3_f32(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(add_pooled),
+    f_dot = lib.dir_cin_layer_dot_add_f16x2_f32 if split == "f16x2" else lib.dir_cin_layer_dot_add_bf16x3_f32
+    _lib.check(f_dot(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(add_pooled),
                                                     add_pooled.stride(0) if add_pooled is not None and B > 0 else Hp, _ptr(dxk), _ptr(parts),
                                                     _ptr(ws), nbytes, _stream()))
     acc = dx0 is not None
@@ -1661,10 +1686,11 @@ def cin_layer_backward(x0, xk, W, G, need_x0=True, need_xk=True, need_w=True, fo
     dxk = dx0 = dW = None
     arith = arith or CIN_ARITH
     dw_arith = arith                                 # cin_dw resolves "auto" by its own rule
+    split = None if arith == "auto" else "bf16x3"    # an explicit "bf16x3" means that arithmetic; "auto" follows CIN_BWD_SPLIT
     if arith == "auto":
         arith = cin_auto_arith(m, D, H, Hp)          # the data gradients' GEMM: reduction over H, Hp output columns
     if (need_xk or need_x0) and arith == "bf16x3" and cin_bf16x3_covers(m, D) and not force_forward_form:
-        dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G)
+        dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G, split=split)
         need_xk = need_x0 = False
     if (need_xk or need_x0) and H <= 256 and Hp <= 256 and m <= 64 and not force_forward_form:
         dxk, dx0 = cin_dx(x0, xk, W, G)             # one pass for both (G stationary in registers)
@@ -1735,7 +1761,7 @@ def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None, z_top=No
         below = gps[k - 1] if k > 0 else None
         a = cin_auto_arith(m, D, H, Hp) if arith == "auto" else arith
         if a == "bf16x3" and cin_bf16x3_covers(m, D):
-            dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G, add_pooled=below, dx0=dx0)
+            dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G, add_pooled=below, dx0=dx0, split=None if arith == "auto" else "bf16x3")
         else:
             d0, dxk, _ = cin_layer_backward(x0, xk, W, G, need_w=False, arith=arith)
             dx0 = d0 if dx0 is None else dx0.add_(d0)

@@ -274,8 +274,8 @@ int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m, int H, int
  * instructions of bf16 x 3.  Preconditions: |x0|, |xk|, |W| < 65 504 (fp16's range; larger values become inf); operand elements below
  * 2^-3 in magnitude carry an ABSOLUTE representation error of up to 2^-25 each (relative 2^-22 above).  On embedding-scale operands the
  * result is within 3-6e-7 (scaled) of the double-accumulating oracle.  Same arguments, shapes and workspaces
- * (dir_cin_bf16x3_workspace_bytes / dir_cin_layer1_bf16x3_workspace_bytes) as the bf16 x 3 entries.  Forward layers only: the
- * data-gradient form keeps bf16 x 3 (gradients are small numbers). */
+ * (dir_cin_bf16x3_workspace_bytes / dir_cin_layer1_bf16x3_workspace_bytes) as the bf16 x 3 entries.  These two entries are for operands
+ * of O(1); a left operand of unknown magnitude (a gradient) goes through the row-scaled entries below. */
 int dir_cin_layer_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                             float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 int dir_cin_layer1_f16x2_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled, int64_t pooled_ld,
@@ -298,6 +298,19 @@ int dir_cin_layer_dot_add_bf16x3_f32(const float* x0, const float* xk, const flo
                                      const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
                                      int64_t workspace_bytes, dir_stream_t stream);
 int dir_sum_partials_f32(const float* parts, int P, int64_t n, int accumulate, float* out, dir_stream_t stream);
+/* fp16 x 2 with a left operand xk of UNKNOWN magnitude (the backward: xk := G).  Inside the kernel every row r = (b, d) of xk is multiplied
+ * by a power of two chosen from that row's largest |element| over its Hp channels (it lands in [2^14, 2^15): the scaling is exact), split
+ * into two fp16 pieces, and the inverse power of two is applied where the row's T tile meets the field factor (and y, in the dot form) --
+ * again exact.  Elements within 2^-17 of their row's largest carry 22 bits; smaller ones an absolute error of 2^-39 of the row's largest,
+ * which is what the sum over the row's channels needs.  x0, W, y: preconditions of dir_cin_layer_f16x2_f32 (|.| < 65 504, O(1) values).
+ * dir_cin_layer_grad_f16x2_f32: arguments of dir_cin_layer_f16x2_f32 (the forward-form contractions of the backward);
+ * dir_cin_layer_dot_add_f16x2_f32: arguments, partial-sum layout (dir_cin_bf16x3_dot_partials) and workspace of
+ * dir_cin_layer_dot_add_bf16x3_f32. */
+int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
+                                 float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D, int64_t B,
+                                    const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
+                                    int64_t workspace_bytes, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * A3  categorical id paths.
@@ -617,6 +630,14 @@ int64_t dir_cin_dw_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
 int64_t dir_cin_dw_bf16x3_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
 int dir_cin_dw_bf16x3_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate,
                           float* dW, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+/* The same weight gradient on fp16 x 2 (csrc/cin_dw_bf3.hip, round 4): G is multiplied by ONE power of two for the whole tensor (its largest
+ * |element| lands in [2^12, 2^13); exact) before A_j = G x0_j is formed and split, and the reduce pass takes the scale out again; xk is
+ * split as in the fp16 x 2 forward.  Preconditions: |x0| < 8, |xk| < 65 504, both O(1) (embeddings / activations).  g_absmax_bits: device
+ * pointer to the bit pattern of max |G| as an unsigned (any value >= the true maximum works, a power-of-two bound included) or NULL -- then
+ * a max pass over G runs first, into the workspace's tail.  workspace: dir_cin_dw_f16x2_workspace_bytes(...) bytes, 16-byte aligned. */
+int64_t dir_cin_dw_f16x2_workspace_bytes(int m, int Hp, int H, int D, int64_t B);
+int dir_cin_dw_f16x2_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B, int accumulate, float* dW,
+                         void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits, dir_stream_t stream);
 /* The same gradient for the FIRST layer of a stack (xk = x0, Hp = m), where the result is symmetric in (i, j): the m (m + 1) / 2
  * unordered pairs are the GEMM's columns (operand x0_i * x0_j formed and split per k-step, G split once per step), csrc/cin_dw_sym_bf3.hip;
  * dW [H, m*m] gets both halves.  D in {8, 16, 32}, m <= 64; workspace: dir_cin_dw_sym_bf16x3_workspace_bytes(m, H, D, B) bytes, 16-byte

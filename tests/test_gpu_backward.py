@@ -303,12 +303,21 @@ def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
     dx0, dxk, dW = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G), arith="f32")      # dir_cin_dx_f32 / forward form, dir_cin_dw_f32
     _close(dxk, ref_dxk)
     _close(dx0, ref_dx0)
-    if ops.cin_bf16x3_covers(m, D):     # both data gradients in one pass of the bf16x3 kernel (dir_cin_layer_dot_bf16x3_f32), bitwise reproducible
-        bxk, bx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G))
-        _close(bxk, ref_dxk)
-        _close(bx0, ref_dx0)
-        cxk, cx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G))
-        assert torch.equal(cxk, bxk) and torch.equal(cx0, bx0)
+    if ops.cin_bf16x3_covers(m, D):     # both data gradients in one pass of the split-arithmetic kernel (dir_cin_layer_dot_add_*_f32), bitwise reproducible
+        for split in ("bf16x3", "f16x2"):
+            sxk, sx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G), split=split)
+            _close(sxk, ref_dxk)
+            _close(sx0, ref_dx0)
+            cxk, cx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G), split=split)
+            assert torch.equal(cxk, sxk) and torch.equal(cx0, sx0)
+        # fp16 x 2 scales every row of G by a power of two inside the kernel: a gradient 2^-30 times smaller, or whose samples differ by
+        # powers of two over 40 binades, gives the same bits times those powers (nothing underflows into fp16's subnormals)
+        pw = torch.from_numpy(np.ldexp(1.0, rng.integers(-30, 10, size=(B, 1, 1))).astype(np.float32)).cuda()
+        pxk, px0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G) * pw, split="f16x2")
+        assert torch.equal(pxk, sxk * pw) and torch.equal(px0, sx0 * pw)
+        bxk, bx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G))          # split=None: ops.CIN_BWD_SPLIT
+        if ops.CIN_BWD_SPLIT == "f16x2":
+            assert torch.equal(bxk, sxk) and torch.equal(bx0, sx0)
         ax0, axk, _ = ops.cin_layer_backward(dev(x0), dev(xk), dev(W), dev(G), need_w=False)  # "auto": one of the two, bitwise
         want = (bx0, bxk) if ops.cin_auto_arith(m, D, H, Hp) == "bf16x3" else (dx0, dxk)
         assert torch.equal(ax0, want[0]) and torch.equal(axk, want[1])
@@ -327,6 +336,18 @@ def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
         assert torch.equal(ops.cin_dw(dev(x0), dev(xk), dev(G), arith="bf16x3"), bW)
         acc2 = ops.cin_dw(dev(x0), dev(xk), dev(G), dW=bW.clone(), accumulate=True, arith="bf16x3")
         assert torch.allclose(acc2, 2 * bW, rtol=1e-6, atol=1e-6)
+        # fp16 x 2 (dir_cin_dw_f16x2_f32): G scaled by one power of two for the tensor; same bar; a 2^-30 times smaller G gives the same bits
+        hW = ops.cin_dw(dev(x0), dev(xk), dev(G), arith="f16x2")
+        err = np.abs(hW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
+        assert err.max() <= 1e-5, "f16x2 dW max scaled err %.3e" % err.max()
+        assert torch.equal(ops.cin_dw(dev(x0), dev(xk), dev(G), arith="f16x2"), hW)
+        assert torch.equal(ops.cin_dw(dev(x0), dev(xk), dev(G) * 2.0 ** -30, arith="f16x2"), hW * 2.0 ** -30)
+        bound = torch.tensor([np.float32(np.abs(G).max() * 1.5).view(np.int32)], dtype=torch.int32, device="cuda")      # an upper bound's bits
+        gW = ops.cin_dw(dev(x0), dev(xk), dev(G), arith="f16x2", g_absmax_bits=bound)
+        err = np.abs(gW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
+        assert err.max() <= 1e-5, "f16x2 dW (given bound) max scaled err %.3e" % err.max()
+        if ops.CIN_BWD_SPLIT == "f16x2" and ops.cin_dw_auto_arith(m, D, Hp, H) == "bf16x3":
+            bW = hW                                                  # what "auto" runs now
     # accumulate form and bitwise reproducibility
     again = ops.cin_dw(dev(x0), dev(xk), dev(G), arith="f32")
     assert torch.equal(again, dW)

@@ -250,8 +250,17 @@ def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     split = (fx, fp_) if ops.CIN_FWD_SPLIT == "f16x2" else (bx, bp)
     want = split if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
     assert torch.equal(ax, want[0]) and torch.equal(ap, want[1])
-    gx, gp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), grad_operand=True)      # a gradient operand never takes the fp16 split
-    want_g = (bx, bp) if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
+    # a gradient as the left operand never takes the PLAIN fp16 split: it runs the row-scaled form (dir_cin_layer_grad_f16x2_f32: every row
+    # of xk times a power of two inside the kernel) or bf16 x 3.  Same bar; rows that differ by powers of two over 40 binades give the same
+    # bits times those powers; tiny (1e-30-scale) and large (1e+6-scale) operands are as exact as O(1) ones
+    sx, sp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="f16x2_grad")
+    _close(sx.cpu().numpy(), ref_x)
+    _close(sp.cpu().numpy(), ref_p)
+    pw = torch.from_numpy(np.ldexp(1.0, rng.integers(-80, 20, size=(B, 1, 1))).astype(np.float32)).cuda()
+    px, _ = ops.cin_layer(_dev(x0), _dev(xk) * pw, _dev(W), arith="f16x2_grad")
+    assert torch.equal(px, sx * pw)
+    gx, gp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), grad_operand=True)
+    want_g = ((sx, sp) if ops.CIN_BWD_SPLIT == "f16x2" else (bx, bp)) if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
     assert torch.equal(gx, want_g[0]) and torch.equal(gp, want_g[1])
 
 
