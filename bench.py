@@ -86,10 +86,15 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
                 alg, pipe = alg + f, pipe + f * PIPE_COST[a]
                 modes["fwd%d" % (k + 1)] = a
         if backward:
+            bwd16 = arith == "auto" and getattr(ops, "CIN_BWD_SPLIT", "bf16x3") == "f16x2"     # "auto": gradient operands on scaled fp16 x 2
             a = (ops.cin_auto_arith(m, D, h, hp) if arith == "auto" else arith) if ops.cin_bf16x3_covers(m, D) else "f32"
+            if bwd16 and a == "bf16x3":
+                a = "f16x2"
             alg, pipe = alg + f, pipe + f * PIPE_COST[a]
             modes["dx%d" % (k + 1)] = a
             a = ops.cin_dw_auto_arith(m, D, hp, h) if arith == "auto" else arith
+            if bwd16 and a == "bf16x3":
+                a = "f16x2"
             if k == 0 and arith in ("auto", "bf16x3") and getattr(ops, "CIN_DW_SYM", False) and D in (8, 16, 32) and m <= 64:
                 # the first layer (xk is x0): dir_cin_dw_sym_bf16x3_f32 multiplies the m (m + 1) / 2 unordered pairs only -- priced on what it executes
                 alg, pipe = alg + f, pipe + f * (m + 1) / (2.0 * m) * PIPE_COST["bf16x3"]
@@ -970,7 +975,8 @@ def main():
             alg, pipe, modes = cin_flops(ops, B, F, K, (128, 128, 128), forward=True, backward=True)
             roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes,
                     "kernel": "xDeepFM training step (CIN forward + backward flops only): cin_bf3_k, cin_bf3_k<DOT>, cin_dw_bf3_k (layer 1: cin_dw_k)",
-                    "dtype": "f32 (CIN forward: f32 via %s; backward: bf16x3 split; f32 accumulate)" % _cin_fwd_label(ops)}
+                    "dtype": "f32 (CIN forward: f32 via %s; backward: %s; f32 accumulate)" % (
+                        _cin_fwd_label(ops), "scaled fp16x2 / bf16x3 split" if "f16x2" in [v for k_, v in modes.items() if k_.startswith("d")] else "bf16x3 split")}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "cin": [128, 128, 128], "dnn": [400, 400]})
     elif wl == "dcn_cross":
         d, L = args.cross_d, 3
@@ -1172,7 +1178,8 @@ def main():
         alg, pipe, modes = cin_flops(ops, B, m, D, Hs, forward=False, backward=True)
         roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes,
                 "kernel": "cin_bf3_k<DOT> (data gradients) + cin_dw_bf3_k (weight gradient; layer 1: cin_dw_sym_bf3_k over the unordered field pairs; the top layer in its pooled form: dense kernels + cin_pool_dx_k)",
-                "dtype": "f32 via bf16x3 split, f32 accumulate"}
+                "dtype": ("f32 via fp16x2 split with the gradient operand scaled by powers of two (layer-2 kernels, layer-1 contraction) / bf16x3 split "
+                          "(layer-1 dW, pooled top layer), f32 accumulate") if "f16x2" in modes.values() else "f32 via bf16x3 split, f32 accumulate"}
         cfg.update({"m": m, "D": D, "layers": list(Hs)})
 
     # ---- warmup, then EXACTLY --steps timed steps bracketed by barrier + synchronize ------------------

@@ -140,13 +140,26 @@ __global__ __launch_bounds__(256) void dense_bf3_pack_k(const float* __restrict_
     }
 }
 
-template <int CT, int NP = 3>
+// scale 2^k (or its inverse) for a row / tensor whose largest |element| has the bit pattern `bits`: the largest lands in [2^14, 2^15)
+// (k clamped to +-100; all-zero rows stay zero)
+__device__ __forceinline__ float db3_scale(unsigned int bits, bool inverse) {
+    int k = 141 - (int)((bits >> 23) & 0xffu);
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return __builtin_bit_cast(float, (unsigned int)(inverse ? 127 - k : 127 + k) << 23);
+}
+
+// RS (fp16 x 2 with an X of unknown magnitude -- a gradient): row r of X is multiplied by the power of two db3_scale(row_bits[r]) before it
+// is split and the row's accumulators by the inverse before the epilogue (both exact); row_bits[r] = bit pattern of max_k |X[r, k]|
+// (dir_row_absmax_bits_f32).
+template <int CT, int NP = 3, bool RS = false>
 __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ X, int64_t x_ld, const unsigned char* __restrict__ img,
                                                      const float* __restrict__ bias, int relu, const float* __restrict__ post_scale,
                                                      const float* __restrict__ post_shift, const float* __restrict__ gate, int64_t gate_ld,
                                                      int64_t M, int Kd, int N, int nks, int ncb, float* __restrict__ Y, int64_t y_ld,
                                                      const float* __restrict__ head_w /* [N] or nullptr */,
-                                                     float* __restrict__ head_part /* [ncb][M]: this column block's share of y . head_w */) {
+                                                     float* __restrict__ head_part /* [ncb][M]: this column block's share of y . head_w */,
+                                                     const unsigned int* __restrict__ row_bits = nullptr /* RS: [M] */) {
+    static_assert(!RS || NP == 2, "row scaling belongs to the fp16 x 2 split");
     constexpr int STEPB = NP * CT * 1024;                      // bytes of W image per k-step
     using Pc = Db3Pc<NP>;
     using op_t = typename Pc::op_t;
@@ -171,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
     const int t0 = lslot, t1 = (int)ntiles;             // this workgroup's tiles: t0, t0 + G, ... < t1
     if (t0 >= t1) return;
 
-    struct Tile { const float* xs[2]; const unsigned char* gi; int cb; int64_t row0; };
+    struct Tile { const float* xs[2]; const unsigned char* gi; int cb; int64_t row0; float sc[RS ? 2 : 1], inv[RS ? 2 : 1]; };
     auto setup = [&](int t, Tile& tl) {
         tl.cb = t % ncb;
         tl.row0 = (int64_t)(t / ncb) * DB3_ROWS;
@@ -182,6 +195,11 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t r = tl.row0 + wave * 32 + rt * 16 + n;
             tl.xs[rt] = X + (r < M ? r : M - 1) * x_ld + 8 * lg;
+            if constexpr (RS) {
+                const unsigned int rb = row_bits[r < M ? r : M - 1];
+                tl.sc[rt] = db3_scale(rb, false);
+                tl.inv[rt] = db3_scale(rb, true);
+            }
         }
     };
     auto stage_w = [&](const Tile& tl, int ks, int buf) {     // 3*CT pieces of 1 KB over 8 waves, lane-linear
@@ -238,8 +256,10 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
                     unsigned int pa[NP], pb[NP];
-                    Pc::split(xv[rt][hq][0], xv[rt][hq][1], pa);
-                    Pc::split(xv[rt][hq][2], xv[rt][hq][3], pb);
+                    f32x4 xs4 = xv[rt][hq];
+                    if constexpr (RS) xs4 *= cur.sc[rt];
+                    Pc::split(xs4[0], xs4[1], pa);
+                    Pc::split(xs4[2], xs4[3], pb);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         w[p][2 * hq] = pa[p];
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                 const int col = 16 * (cur.cb * CT + ct) + 4 * lg;      // N % 4 == 0: the lane's four columns are inside or outside together
                 if (r < M && col < N) {
                     f32x4 v = acc[rt][ct];
+                    if constexpr (RS) v *= cur.inv[rt];            // (a lane's four accumulators are four columns of ITS row n)
                     if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
                     if (relu) {
 #pragma unroll
@@ -325,17 +346,78 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
     }
 }
 
-template <int CT, int NP = 3>
+template <int CT, int NP = 3, bool RS = false>
 static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const unsigned char* img, const float* bias, int relu,
                              const float* ps, const float* psh, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, int nks, int ncb,
-                             float* Y, int64_t y_ld, const float* head_w = nullptr, float* head_part = nullptr) {
+                             float* Y, int64_t y_ld, const float* head_w = nullptr, float* head_part = nullptr,
+                             const unsigned int* row_bits = nullptr) {
     const size_t shmem = 2 * (size_t)NP * CT * 1024;
     static LdsOnce once;
-    (void)lds_limit(once, 160 * 1024, &dense_bf3_k<CT, NP>);
+    (void)lds_limit(once, 160 * 1024, &dense_bf3_k<CT, NP, RS>);
     const int64_t ntiles = (M + DB3_ROWS - 1) / DB3_ROWS * ncb;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;         // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
-    hipLaunchKernelGGL((dense_bf3_k<CT, NP>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
-                       nks, ncb, Y, y_ld, head_w, head_part);
+    hipLaunchKernelGGL((dense_bf3_k<CT, NP, RS>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
+                       nks, ncb, Y, y_ld, head_w, head_part, row_bits);
+}
+
+// row_bits[r] = bit pattern of max_k |X[r, k]| (non-negative floats order like their bits); *all_bits = the maximum over all rows.  A lane
+// group of 16 per row, float4 loads, eight of a row's loads in flight at once.  all_bits without a zeroing launch and without a same-address
+// atomic per row: every workgroup leaves its maximum in block_bits[blockIdx.x] and takes a ticket; the LAST one to arrive reduces the
+// block maxima, writes *all_bits and puts the ticket counter back to zero (the caller's word of persistent, initially zero memory).
+__global__ __launch_bounds__(256) void row_absmax_k(const float* __restrict__ X, int64_t x_ld, int64_t M, int N, unsigned int* __restrict__ row_bits,
+                                                     unsigned int* __restrict__ all_bits, unsigned int* __restrict__ block_bits,
+                                                     unsigned int* __restrict__ ticket) {
+    const int sub = threadIdx.x & 15;
+    float wmx = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < M; r += (int64_t)gridDim.x * 16) {
+        const float* xr = X + r * x_ld;
+        float mx = 0.f;
+        for (int k0 = 4 * sub; k0 < N; k0 += 512) {
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = k0 + 64 * q < N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + k0 + 64 * q)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[q][0]), fabsf(v[q][1]))), fmaxf(fabsf(v[q][2]), fabsf(v[q][3])));
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (sub == 0) row_bits[r] = __builtin_bit_cast(unsigned int, mx);
+        wmx = fmaxf(wmx, mx);
+    }
+    if (all_bits) {                                        // (uniform)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
+        __shared__ float wm[4];
+        __shared__ unsigned int last;
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // No fence (a device-scope release is an L2 write-back on gfx950: NOTES R4.2): the block maximum is left by a RETURNING
+            // device-scope atomic, whose result is waited for before the ticket is taken -- it has been performed where the last
+            // workgroup's device-scope loads will look.
+            const unsigned int old = __hip_atomic_exchange(block_bits + blockIdx.x,
+                                                           __builtin_bit_cast(unsigned int, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(old) : "memory");
+            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (last) {
+            unsigned int m = 0u;
+            for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256)
+                m = max(m, __hip_atomic_load(block_bits + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
+            __shared__ unsigned int um[4];
+            if ((threadIdx.x & 63) == 0) um[threadIdx.x >> 6] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                *all_bits = max(max(um[0], um[1]), max(um[2], um[3]));
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 }  // namespace dir
@@ -395,7 +477,7 @@ extern "C" int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, i
 
 static int dense_run(const char* name, int pieces, const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                      const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
-                     dir_stream_t stream) {
+                     dir_stream_t stream, const unsigned int* row_bits = nullptr) {
     DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && y_ld >= N, "%s: bad shape", name);
     DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
     DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
@@ -411,7 +493,11 @@ static int dense_run(const char* name, int pieces, const float* X, int64_t x_ld,
     hipStream_t st = as_stream(stream);
     const unsigned char* img = static_cast<const unsigned char*>(image);
     const int relu = act == DIR_ACT_RELU;
-    if (pieces == 2) {
+    if (pieces == 2 && row_bits) {
+        if (CT == 8) launch_dense_bf3<8, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits);
+        else if (CT == 13) launch_dense_bf3<13, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits);
+        else launch_dense_bf3<16, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits);
+    } else if (pieces == 2) {
         if (CT == 8) launch_dense_bf3<8, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
         else if (CT == 13) launch_dense_bf3<13, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
         else launch_dense_bf3<16, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
@@ -431,6 +517,35 @@ extern "C" int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* im
 extern "C" int dir_dense_f16x2_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                                    const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
     return dense_run("dir_dense_f16x2_f32", 2, X, x_ld, image, bias, act, post_scale, post_shift, nullptr, 0, M, Kd, N, Y, y_ld, stream);
+}
+
+// fp16 x 2 for an X of unknown magnitude (the backward's data gradient: X = dL/dy, image = W^T): every row of X scaled by a power of two from
+// row_bits (dir_row_absmax_bits_f32), exact; gate as in dir_dense_bf16x3_f32
+extern "C" int dir_dense_f16x2_rows_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                                        const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y,
+                                        int64_t y_ld, const unsigned int* row_bits, dir_stream_t stream) {
+    DIR_CHECK_ARG(row_bits || M == 0, "dir_dense_f16x2_rows_f32: row_bits is null");
+    return dense_run("dir_dense_f16x2_rows_f32", 2, X, x_ld, image, bias, act, post_scale, post_shift, gate, gate_ld, M, Kd, N, Y, y_ld, stream, row_bits);
+}
+
+extern "C" int dir_row_absmax_workspace_words(void) { return 1 + kCUs * 8; }      // [ticket | block maxima]
+
+extern "C" int dir_row_absmax_bits_f32(const float* X, int64_t x_ld, int64_t M, int N, unsigned int* row_bits, unsigned int* all_bits,
+                                       unsigned int* workspace, dir_stream_t stream) {
+    const char* name = "dir_row_absmax_bits_f32";
+    DIR_CHECK_ARG(M >= 0 && N > 0 && x_ld >= N, "%s: bad shape", name);
+    DIR_CHECK_ARG(!all_bits || workspace, "%s: all_bits needs the workspace", name);
+    hipStream_t st = as_stream(stream);
+    if (M == 0) {
+        if (all_bits && zero_async(all_bits, sizeof(unsigned int), st) != hipSuccess) return fail(DIR_E_HIP, "%s: zeroing failed", name);
+        return DIR_OK;
+    }
+    DIR_CHECK_ARG(X && row_bits, "%s: null pointer", name);
+    if ((N & 3) || (x_ld & 3) || !aligned16(X)) return fail(DIR_E_UNSUPPORTED, "%s: N and x_ld must be multiples of 4, X 16-byte aligned", name);
+    hipLaunchKernelGGL(row_absmax_k, dim3(grid_for((M + 15) / 16, 8)), dim3(256), 0, st, X, x_ld, M, N, row_bits, all_bits,
+                       workspace ? workspace + 1 : nullptr, workspace);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
 }
 
 // The layer with the head of the tower's output folded into its epilogue (DCN's last deep layer, DeepCrossNetwork.py:136-137: the deep

@@ -58,6 +58,61 @@ __device__ __forceinline__ void ddw_split8(const float (&x)[8], bf16x8_t (&p)[3]
     for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
 }
 
+// ---- round 4: "fp16 x 2" (cin_bf3.hip states the arithmetic): g, a gradient of unknown magnitude, is multiplied by ONE power of two for the
+// whole tensor (largest |element| into [2^14, 2^15): exact) before its split, and the reduce pass takes the scale out of dW (the bias
+// gradient sums the raw g); x is split as in the fp16 x 2 forward (the caller vouches for O(1) activations).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int ddw_pk_h(float a, float b) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));
+    return w;
+}
+__device__ __forceinline__ void ddw_split8h(const float (&x)[8], f16x8_t (&p)[2]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    unsigned int w[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = {x[2 * i], x[2 * i + 1]};
+        w[0][i] = ddw_pk_h(v[0], v[1]);
+        const h2_t h = __builtin_bit_cast(h2_t, w[0][i]);
+        const f32x2 r = v - (f32x2){(float)h[0], (float)h[1]};
+        w[1][i] = ddw_pk_h(r[0], r[1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) p[q] = __builtin_bit_cast(f16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
+}
+template <int NP> struct DdwPc;
+template <> struct DdwPc<3> {
+    using op_t = bf16x8_t;
+    __device__ static __forceinline__ void split8(const float (&x)[8], op_t (&p)[3]) { ddw_split8(x, p); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[3], const op_t (&b)[3], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+template <> struct DdwPc<2> {
+    using op_t = f16x8_t;
+    __device__ static __forceinline__ void split8(const float (&x)[8], op_t (&p)[2]) { ddw_split8h(x, p); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[2], const op_t (&b)[2], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+__device__ __forceinline__ float ddw_scale(unsigned int bits, bool inverse) {     // largest |element| into [2^14, 2^15); k clamped to +-100
+    int k = 141 - (int)((bits >> 23) & 0xffu);
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return __builtin_bit_cast(float, (unsigned int)(inverse ? 127 - k : 127 + k) << 23);
+}
+
 __host__ __device__ inline int ddw_kb_for(int K) {     // x tiles per block: the choice that pads K least (ties: the wider block)
     const int tiles = (K + 15) / 16;
     int best = 16, pad = (tiles + 15) / 16 * 16;
@@ -82,12 +137,17 @@ static DdwPlan ddw_plan(int64_t M, int N, int K) {
     return p;
 }
 
-template <int KB>
+template <int KB, int NP = 3>
 __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ x, int64_t x_ld,
                                                           int64_t M, int N, int K, int nkb, int nspan, int64_t steps_per_span, int64_t steps,
-                                                          float* __restrict__ part, float* __restrict__ bpart /* [nspan][N] or NULL */) {
+                                                          float* __restrict__ part, float* __restrict__ bpart /* [nspan][N] or NULL */,
+                                                          const unsigned int* __restrict__ gbits = nullptr /* NP == 2: bit pattern of max |g| */) {
+    using Pc = DdwPc<NP>;
+    using op_t = typename Pc::op_t;
     constexpr int TT = DDW_NT + KB;                   // tiles staged per step: 16 of g, KB of x
-    extern __shared__ __attribute__((aligned(16))) unsigned char ddw_smem[];      // [3 pieces][TT tiles][64 lanes][8 bf16]
+    extern __shared__ __attribute__((aligned(16))) unsigned char ddw_smem[];      // [NP pieces][TT tiles][64 lanes][8 halves]
+    float gsc = 1.f;
+    if constexpr (NP == 2) gsc = ddw_scale(*gbits, false);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, ln = lane & 15;
     int q = blockIdx.x;
@@ -138,12 +198,12 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
             for (int j = 0; j < 4; ++j) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = raw[e][j];
-                bf16x8_t p[3];
-                ddw_split8(v, p);
+                for (int e = 0; e < 8; ++e) v[e] = (NP == 2 && isg) ? raw[e][j] * gsc : raw[e][j];
+                op_t p[NP];
+                Pc::split8(v, p);
                 const int off = sdst + ((j ^ (stile & 3)) * 16);
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(ddw_smem + pc * (TT * 1024) + off) = p[pc];
+                for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<op_t*>(ddw_smem + pc * (TT * 1024) + off) = p[pc];
             }
         }
     };
@@ -166,34 +226,27 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
             // a lane's fragment of tile t sits in slot lane ^ (t & 3)
             const unsigned char* fa = ddw_smem + ((lane ^ (wave & 3)) * 16);
             const unsigned char* fb[4] = {ddw_smem + lane * 16, ddw_smem + ((lane ^ 1) * 16), ddw_smem + ((lane ^ 2) * 16), ddw_smem + ((lane ^ 3) * 16)};
-            bf16x8_t a[2][3];
+            op_t a[2][NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                a[0][pc] = *reinterpret_cast<const bf16x8_t*>(fa + pc * (TT * 1024) + wave * 1024);
-                a[1][pc] = *reinterpret_cast<const bf16x8_t*>(fa + pc * (TT * 1024) + (has1 ? wave + 8 : wave) * 1024);
+            for (int pc = 0; pc < NP; ++pc) {
+                a[0][pc] = *reinterpret_cast<const op_t*>(fa + pc * (TT * 1024) + wave * 1024);
+                a[1][pc] = *reinterpret_cast<const op_t*>(fa + pc * (TT * 1024) + (has1 ? wave + 8 : wave) * 1024);
             }
-            bf16x8_t bq[2][3];
+            op_t bq[2][NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) bq[0][pc] = *reinterpret_cast<const bf16x8_t*>(fb[0] + pc * (TT * 1024) + DDW_NT * 1024);
+            for (int pc = 0; pc < NP; ++pc) bq[0][pc] = *reinterpret_cast<const op_t*>(fb[0] + pc * (TT * 1024) + DDW_NT * 1024);
 #pragma unroll
             for (int kt = 0; kt < KB; ++kt) {
                 if (kt < ktx) {
                     if (kt + 1 < KB) {
 #pragma unroll
-                        for (int pc = 0; pc < 3; ++pc)
-                            bq[(kt + 1) & 1][pc] = *reinterpret_cast<const bf16x8_t*>(fb[(kt + 1) & 3] + pc * (TT * 1024) + (DDW_NT + kt + 1) * 1024);
+                        for (int pc = 0; pc < NP; ++pc)
+                            bq[(kt + 1) & 1][pc] = *reinterpret_cast<const op_t*>(fb[(kt + 1) & 3] + pc * (TT * 1024) + (DDW_NT + kt + 1) * 1024);
                     }
-                    const bf16x8_t (&b)[3] = bq[kt & 1];
+                    const op_t (&b)[NP] = bq[kt & 1];
 #pragma unroll
                     for (int rt = 0; rt < 2; ++rt) {
-                        f32x4 c = acc[rt][kt];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0], b[2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][2], b[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][1], b[1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0], b[1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][1], b[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][0], b[0], c, 0, 0, 0);
-                        acc[rt][kt] = c;
+                        acc[rt][kt] = Pc::mma(a[rt], b, acc[rt][kt]);
 #if DDW_CHAIN
                         __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (dense_bf3.hip: DB3_CHAIN)
 #endif
@@ -237,8 +290,10 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
 // chain of nspan dependent loads: 240 us for the 512 spans of an 80 x 64 gradient.)
 template <int SG>
 __global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __restrict__ part, const float* __restrict__ bpart, int N, int K,
-                                                            int nspan, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db) {
+                                                            int nspan, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
+                                                            const unsigned int* __restrict__ gbits = nullptr /* fp16 x 2: the scale to take out of dW */) {
     constexpr int EPB = 256 / SG;
+    const float inv = gbits ? ddw_scale(*gbits, true) : 1.f;
     __shared__ float red[SG][EPB];
     const int q = threadIdx.x / EPB, el = threadIdx.x % EPB;
     const int64_t total = (int64_t)N * K, all = total + (db != nullptr ? N : 0);
@@ -256,19 +311,20 @@ __global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __rest
             float t = red[0][el];
 #pragma unroll
             for (int i = 1; i < SG; ++i) t += red[i][el];
-            if (e < total) dW[(e / K) * dw_ld + (e % K)] = t;
+            if (e < total) dW[(e / K) * dw_ld + (e % K)] = t * inv;
             else db[e - total] = t;
         }
         __syncthreads();
     }
 }
 
-static void ddw_reduce(const float* part, const float* bpart, int N, int K, int nspan, float* dW, int64_t dw_ld, float* db, hipStream_t st) {
+static void ddw_reduce(const float* part, const float* bpart, int N, int K, int nspan, float* dW, int64_t dw_ld, float* db, hipStream_t st,
+                       const unsigned int* gbits = nullptr) {
     const int64_t all = (int64_t)N * K + (db ? N : 0);
     if (all <= 65536)
-        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<16>, dim3(grid_for((all + 15) / 16)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db);
+        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<16>, dim3(grid_for((all + 15) / 16)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db, gbits);
     else
-        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<4>, dim3(grid_for((all + 63) / 64)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db);
+        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<4>, dim3(grid_for((all + 63) / 64)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db, gbits);
 }
 
 // ---- small gradients (N <= 128, K <= 256): fp32 FMAs on a register tile ---------------------------------------------------------------------
@@ -410,9 +466,8 @@ extern "C" int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K) 
     return (int64_t)p.nspan * ((int64_t)N * K + N) * (int64_t)sizeof(float);      // span partials of dW, then of db
 }
 
-extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
-                                       int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
-    const char* name = "dir_dense_dw_bf16x3_f32";
+static int ddw_run(const char* name, int np, const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
+                   int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, const unsigned int* gbits, dir_stream_t stream) {
     DIR_CHECK_ARG(dW && M >= 0 && N > 0 && K > 0 && dw_ld >= K, "%s: bad argument (M=%lld N=%d K=%d dw_ld=%lld)", name, (long long)M, N, K,
                   (long long)dw_ld);
     hipStream_t st = as_stream(stream);
@@ -431,20 +486,38 @@ extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float
     const unsigned grid = (unsigned)(p.nnb * p.nkb * p.nspan);
     float* part = static_cast<float*>(workspace);
     float* bpart = db ? part + (int64_t)p.nspan * N * K : nullptr;
-#define DDW_LAUNCH(KB_)                                                                                                            \
+    DIR_CHECK_ARG(np == 3 || gbits, "%s: g_absmax_bits is null", name);
+#define DDW_LAUNCH(KB_, NP_)                                                                                                       \
     do {                                                                                                                           \
         static LdsOnce once;                                                                                                      \
-        const size_t lds = 3 * (size_t)(DDW_NT + KB_) * 1024;                                                                      \
-        (void)lds_limit(once, (int)lds, &dense_dw_bf3_k<KB_>);                                                                    \
-        hipLaunchKernelGGL((dense_dw_bf3_k<KB_>), dim3(grid), dim3(512), lds, st, g, g_ld, x, x_ld, M, N, K, p.nkb, p.nspan,       \
-                           p.steps_per_span, p.steps, part, bpart);                                                                \
+        const size_t lds = NP_ * (size_t)(DDW_NT + KB_) * 1024;                                                                    \
+        (void)lds_limit(once, (int)lds, &dense_dw_bf3_k<KB_, NP_>);                                                               \
+        hipLaunchKernelGGL((dense_dw_bf3_k<KB_, NP_>), dim3(grid), dim3(512), lds, st, g, g_ld, x, x_ld, M, N, K, p.nkb, p.nspan,  \
+                           p.steps_per_span, p.steps, part, bpart, gbits);                                                         \
     } while (0)
-    if (p.KB == 13) DDW_LAUNCH(13);
-    else if (p.KB == 8) DDW_LAUNCH(8);
-    else DDW_LAUNCH(16);
+    if (np == 2) {
+        if (p.KB == 13) DDW_LAUNCH(13, 2);
+        else if (p.KB == 8) DDW_LAUNCH(8, 2);
+        else DDW_LAUNCH(16, 2);
+    } else if (p.KB == 13) DDW_LAUNCH(13, 3);
+    else if (p.KB == 8) DDW_LAUNCH(8, 3);
+    else DDW_LAUNCH(16, 3);
 #undef DDW_LAUNCH
     DIR_CHECK_LAUNCH(name);
-    ddw_reduce(part, bpart, N, K, p.nspan, dW, dw_ld, db, st);
-    DIR_CHECK_LAUNCH("dense_dw_bf16x3 reduce");
+    ddw_reduce(part, bpart, N, K, p.nspan, dW, dw_ld, db, st, np == 2 ? gbits : nullptr);
+    DIR_CHECK_LAUNCH("dense_dw reduce");
     return DIR_OK;
+}
+
+extern "C" int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
+                                       int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+    return ddw_run("dir_dense_dw_bf16x3_f32", 3, g, g_ld, x, x_ld, M, N, K, dW, dw_ld, db, workspace, workspace_bytes, nullptr, stream);
+}
+
+// fp16 x 2: g scaled by one power of two from g_absmax_bits (device pointer: the bit pattern of an upper bound of max |g|, e.g. the all_bits
+// of dir_row_absmax_bits_f32), x split as in the fp16 x 2 forward (|x| < 65 504, O(1) activations).  Workspace as the bf16 x 3 entry.
+extern "C" int dir_dense_dw_f16x2_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
+                                      int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits,
+                                      dir_stream_t stream) {
+    return ddw_run("dir_dense_dw_f16x2_f32", 2, g, g_ld, x, x_ld, M, N, K, dW, dw_ld, db, workspace, workspace_bytes, g_absmax_bits, stream);
 }

@@ -125,7 +125,12 @@ class DeepCrossNetwork(nn.Module):
         if not mlp_stack_supported([last], net, self.activation):
             return None
         wl = self.logits_layer.weight                                            # [1, d + h]
-        deep_logit = _MlpHeadFn.apply(net, wl[:, d:], self.logits_layer.bias, last.weight, last.bias)
+        from . import dense as _dense
+        _dense._FWD_BOUNDED[0] = bool(self.batch_norm) and n >= 2              # the last layer reads a batch-normalised activation: fp16 x 2 kernels
+        try:
+            deep_logit = _MlpHeadFn.apply(net, wl[:, d:], self.logits_layer.bias, last.weight, last.bias)
+        finally:
+            _dense._FWD_BOUNDED[0] = False
         return deep_logit + _Units1Fn.apply(cross, wl[:, :d], None)
 
     def _padded_cross_params(self):

@@ -76,14 +76,14 @@ def _packed_cached(weight):
     return packed
 
 
-def _tn_matmul(g, x, splits=16):
+def _tn_matmul(g, x, splits=16, g_bits=None):
     """g^T x for tall operands ([M, N]^T [M, Kd], M = batch rows): the library's single TN GEMM runs at 0.33 of the fp32 MFMA peak
     at 65 536 x 400 x 416 (a 400 x 416 output leaves most CUs idle); sixteen batched row slices + one sum run at 0.53
     (tools/tn_gemm_probe.py: 425 -> 261 us)."""
     M = g.shape[0]
     if g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
             and ops.dense_dw_auto_arith(M, g.shape[1], x.shape[1]) == "bf16x3":
-        return ops.dense_dw(g, x)                       # dir_dense_dw_bf16x3_f32 where the operands are covered (tools/dense_dw_probe.py)
+        return ops.dense_dw(g, x, g_bits=g_bits)        # dir_dense_dw_{bf16x3,f16x2}_f32 where the operands are covered (tools/dense_dw_probe.py)
     if M >= 8192 and M % splits == 0 and g.is_contiguous() and x.is_contiguous():
         return torch.bmm(g.view(splits, M // splits, -1).transpose(1, 2), x.view(splits, M // splits, -1)).sum(dim=0)
     return g.t() @ x
@@ -102,15 +102,32 @@ def _packed_cached_padded(weight, pad):
     return packed
 
 
-def _wb_grads(g, x, need_w, need_b):
+def _wb_grads(g, x, need_w, need_b, g_bits=None):
     """(dL/dW, dL/db) of a dense layer from g = dL/d(pre-activation) and its input x: one pass of dir_dense_dw_bf16x3_f32 for both where
     it covers the shape, otherwise the library GEMM and a column sum."""
     if need_w and need_b and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
             and ops.dense_dw_auto_arith(g.shape[0], g.shape[1], x.shape[1]) == "bf16x3":
-        gw, gb = ops.dense_dw(g, x, want_bias=True)
+        gw, gb = ops.dense_dw(g, x, want_bias=True, g_bits=g_bits)
         if gb is not None:
             return gw, gb
-    return (_tn_matmul(g, x) if need_w else None), (g.sum(dim=0) if need_b else None)
+    return (_tn_matmul(g, x, g_bits=g_bits) if need_w else None), (g.sum(dim=0) if need_b else None)
+
+
+def _gbits(g, x_bounded, Kin, need_x=True, need_w=True):
+    """(row_bits, g_bits) for the fp16 x 2 backward kernels of one layer with Kin inputs: row_bits for dL/dx = g W (its other operand is the
+    weight), g_bits for dL/dW = g^T x only when the layer's input x is bounded by construction (None otherwise: bf16 x 3).  (None, None)
+    when neither product would run a split-arithmetic kernel at this shape (then the max pass over g is not run either)."""
+    if not g.is_cuda or g.dim() != 2:
+        return None, None
+    M, N = g.shape
+    rows = need_x and Kin % 4 == 0 and ops.dense_auto_arith(M, N, Kin) == "bf16x3"
+    allb = need_w and x_bounded and ops.dense_dw_auto_arith(M, N, Kin) == "bf16x3"
+    if not (rows or allb):
+        return None, None
+    gb = ops.grad_bits(g, want_all=allb)
+    if gb is None:
+        return None, None
+    return (gb[0] if rows else None), (gb[1] if allb else None)
 
 
 class _DenseFn(torch.autograd.Function):
@@ -118,9 +135,10 @@ class _DenseFn(torch.autograd.Function):
     dL/db = sum g go through the library (a reduction over the batch rows: a different shape class)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, bounded=False):
         y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu)
         ctx.relu = relu
+        ctx.bounded = bool(bounded)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
         return y
@@ -133,11 +151,12 @@ class _DenseFn(torch.autograd.Function):
             g = g * (y > 0)
         g = g.contiguous()
         gx = gw = gb = None
+        rb, ab = _gbits(g, ctx.bounded, x.shape[1], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
             wt = _kernel_weight(g, weight.t())                     # [Kd, N]: the "weight" of the transposed product
-            gx = ops.dense(g, wt, None, relu=False) if ops.dense_supported(g, wt) else g @ weight
-        gw, gb = _wb_grads(g, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
-        return gx, gw, gb, None
+            gx = ops.dense(g, wt, None, relu=False, row_bits=rb) if ops.dense_supported(g, wt) else g @ weight
+        gw, gb = _wb_grads(g, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], g_bits=ab)
+        return gx, gw, gb, None, None
 
 
 BN_TRAIN_FUSED = _os.environ.get("DIR_BN_TRAIN_FUSED", "1") != "0"      # development switch: 0 keeps the torch formulation of the training batch norm
@@ -151,10 +170,11 @@ class _DenseBnFn(torch.autograd.Function):
     passes, a compare and a mask multiply), then the layer's weight / bias / data gradients as in _DenseFn."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, bn, relu):
+    def forward(ctx, x, weight, bias, gamma, beta, bn, relu, bounded=False):
         y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu)
         mean, inv, scale, shift = ops.bn_train_stats(y, gamma, beta, bn.moving_mean, bn.moving_variance, bn.eps, bn.momentum)
         ctx.relu = relu
+        ctx.bounded = bool(bounded)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y, mean, inv, gamma)
         return torch.addcmul(shift, y, scale)
@@ -167,20 +187,22 @@ class _DenseBnFn(torch.autograd.Function):
             g = g.contiguous()
         gpre, gbeta, ggamma = ops.bn_train_backward(g, y, mean, inv, gamma, relu_gate=ctx.relu)
         gx = None
+        rb, ab = _gbits(gpre, ctx.bounded, x.shape[1], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
             wt = _kernel_weight(gpre, weight.t())
-            gx = ops.dense(gpre, wt, None, relu=False) if ops.dense_supported(gpre, wt) else gpre @ weight
-        gw, gb = _wb_grads(gpre, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+            gx = ops.dense(gpre, wt, None, relu=False, row_bits=rb) if ops.dense_supported(gpre, wt) else gpre @ weight
+        gw, gb = _wb_grads(gpre, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], g_bits=ab)
         return (gx, gw, gb, ggamma if gamma is not None and ctx.needs_input_grad[3] else None, gbeta if ctx.needs_input_grad[4] else None,
-                None, None)
+                None, None, None)
 
 
-def _dense_bn_train(bn, x, weight, bias, relu):
-    """The training forms of a covered hidden layer: with a batch norm in TRAIN mode the fused node, otherwise _DenseFn + the module."""
+def _dense_bn_train(bn, x, weight, bias, relu, bounded=False):
+    """The training forms of a covered hidden layer: with a batch norm in TRAIN mode the fused node, otherwise _DenseFn + the module.
+    bounded: the caller vouches that x is bounded by construction (the weight gradient may then take the fp16 x 2 kernel)."""
     if (bn is not None and BN_TRAIN_FUSED and bn.training and torch.is_grad_enabled() and weight.shape[0] % 4 == 0 and weight.shape[0] <= 4096
             and x.shape[0] > 0):
-        return _DenseBnFn.apply(x, weight, bias, bn.gamma, bn.beta, bn, relu)
-    return _apply_bn(bn, _DenseFn.apply(x, weight, bias, relu))
+        return _DenseBnFn.apply(x, weight, bias, bn.gamma, bn.beta, bn, relu, bounded)
+    return _apply_bn(bn, _DenseFn.apply(x, weight, bias, relu, bounded))
 
 
 class _MlpStackFn(torch.autograd.Function):
@@ -198,6 +220,7 @@ class _MlpStackFn(torch.autograd.Function):
             h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True, arith="auto_bounded" if bounded else None)
             ys.append(h)
         ctx.L = L
+        ctx.bounded = bounded
         ctx.save_for_backward(x, *params[0::2], *ys)
         return h
 
@@ -212,12 +235,13 @@ class _MlpStackFn(torch.autograd.Function):
         gx = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
-            grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l])
+            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[1 + 2 * l])
+            grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l], g_bits=ab)
             wt = _kernel_weight(g, ws[l].t())
             if l > 0:
-                g = ops.dense_gated(g, wt, xin)
+                g = ops.dense_gated(g, wt, xin, row_bits=rb)
             elif ctx.needs_input_grad[0]:
-                gx = ops.dense(g, wt, None, relu=False)
+                gx = ops.dense(g, wt, None, relu=False, row_bits=rb)
         return (gx,) + tuple(grads)
 
 
@@ -240,6 +264,7 @@ class _MlpHeadFn(torch.autograd.Function):
             h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True, arith="auto_bounded" if bounded else None)
             ys.append(h)
         ctx.L = L
+        ctx.bounded = bounded
         ctx.save_for_backward(x, head_w, *params[0::2], *ys)
         return h @ head_w.t() + head_b              # (a [B, N] x [N, 1] GEMM: 26 us at 65 536 x 400; the library's GEMV takes 62)
 
@@ -255,16 +280,17 @@ class _MlpHeadFn(torch.autograd.Function):
         gx = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
+            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[3 + 2 * l])
             if l == L - 1:                                           # the top layer's bias gradient came with the head's backward
-                grads[2 * l] = _tn_matmul(g, xin) if ctx.needs_input_grad[3 + 2 * l] else None
+                grads[2 * l] = _tn_matmul(g, xin, g_bits=ab) if ctx.needs_input_grad[3 + 2 * l] else None
                 grads[2 * l + 1] = gb_top if ctx.needs_input_grad[4 + 2 * l] else None
             else:
-                grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l])
+                grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l], g_bits=ab)
             wt = _kernel_weight(g, ws[l].t())
             if l > 0:
-                g = ops.dense_gated(g, wt, xin)
+                g = ops.dense_gated(g, wt, xin, row_bits=rb)
             elif ctx.needs_input_grad[0]:
-                gx = ops.dense(g, wt, None, relu=False)
+                gx = ops.dense(g, wt, None, relu=False, row_bits=rb)
         return (gx, gw_head.reshape(1, -1) if ctx.needs_input_grad[1] else None, g_head_b) + tuple(grads)
 
 
@@ -372,12 +398,14 @@ def _bn_affine(bn):
     return _BN_CACHE[key][2], _BN_CACHE[key][3]
 
 
-def dense_act(lin, x, activation=None, bn=None):
+def dense_act(lin, x, activation=None, bn=None, bounded_input=False):
     """activation(lin(x)) for an nn.Linear `lin`, on dir_dense_f32 when the layer is covered.  x may arrive row-padded with zero
     columns up to the next multiple of 4 (InputLayer(pad_to=4), inference): then only the weight gets its zero columns.
     bn: the batch-norm module that follows the activation (deepFM.py:303-308, DeepCrossNetwork.py:400-403) -- in inference it is
-    folded into the kernel's epilogue (one pass over the layer's output instead of three); otherwise it is applied here."""
-    y = _dense_act(lin, x, activation, bn)
+    folded into the kernel's epilogue (one pass over the layer's output instead of three); otherwise it is applied here.
+    bounded_input: the caller vouches that x is bounded by construction (a batch-normalised activation, an embedding concatenation): in
+    training the layer's weight gradient may then run the fp16 x 2 kernel."""
+    y = _dense_act(lin, x, activation, bn, bounded_input)
     return y
 
 
@@ -385,7 +413,7 @@ def _apply_bn(bn, y):
     return bn(y) if bn is not None else y
 
 
-def _dense_act(lin, x, activation, bn):
+def _dense_act(lin, x, activation, bn, bounded=False):
     relu = activation in _RELUS
     prepadded = x.dim() == 2 and x.shape[1] != lin.in_features and x.shape[1] == lin.in_features + (-lin.in_features) % 4
     if (activation is None or relu) and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and lin.out_features >= 16:
@@ -405,12 +433,12 @@ def _dense_act(lin, x, activation, bn):
             # to the next multiple of 4 -- one [B, in] copy (45 us at 65 536 x 429) against 200 us saved on the GEMM
             xp = F.pad(x, (0, pad))
             if train:
-                return _dense_bn_train(bn, xp, F.pad(lin.weight, (0, pad)), lin.bias, relu)     # pad's backward slices the gradients back
+                return _dense_bn_train(bn, xp, F.pad(lin.weight, (0, pad)), lin.bias, relu, bounded)     # pad's backward slices the gradients back
             y = ops.dense(xp, _packed_cached_padded(lin.weight, pad), lin.bias, relu=relu, post_scale=ps, post_shift=psh)
             return y if fold else _apply_bn(bn, y)
         if ops.dense_supported(x, lin.weight):
             if train:
-                return _dense_bn_train(bn, x, lin.weight, lin.bias, relu)
+                return _dense_bn_train(bn, x, lin.weight, lin.bias, relu, bounded)
             y = ops.dense(x, _packed_cached(lin.weight), lin.bias, relu=relu, post_scale=ps, post_shift=psh)
             return y if fold else _apply_bn(bn, y)
     if prepadded:

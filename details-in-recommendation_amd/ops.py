@@ -542,6 +542,10 @@ def dense_supported(x, weight):
 DENSE_ARITH = os.environ.get("DIR_DENSE_ARITH", "auto")
 # what arith="auto_bounded" puts in bf16x3's place: "f16x2" (csrc/dense_bf3.hip, round 4) or "bf16x3" (A/B switch)
 DENSE_BOUNDED_SPLIT = os.environ.get("DIR_DENSE_BOUNDED_SPLIT", "f16x2")
+# the split of the dense BACKWARD kernels whose operand is a gradient: "f16x2" = dL/dx on dir_dense_f16x2_rows_f32 (rows of g scaled by powers
+# of two) and, where the layer's input is bounded by construction, dL/dW on dir_dense_dw_f16x2_f32 (g scaled by one power of two);
+# "bf16x3" = rounds 2-3's arithmetic
+DENSE_BWD_SPLIT = os.environ.get("DIR_DENSE_BWD_SPLIT", "f16x2")
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
 
@@ -583,6 +587,28 @@ def dense_auto_arith(M, Kd, N):
     return "bf16x3" if pad * kpad <= 1.34 * N * Kd else "f32"
 
 
+_ABSMAX_WS = {}
+
+
+def grad_bits(g, want_all=True):
+    """(row_bits [M] int32, all_bits [1] int32) of a gradient g [M, N]: the bit patterns of max_k |g[r, k]| and of max |g|
+    (include/dir_hip.h: dir_row_absmax_bits_f32) -- the powers of two the fp16 x 2 backward kernels scale g by -- or None when
+    DENSE_BWD_SPLIT is not "f16x2" or g is not a covered operand (then the callers keep bf16 x 3)."""
+    if (DENSE_BWD_SPLIT != "f16x2" or DENSE_ARITH != "auto" or not g.is_cuda or g.dtype != torch.float32 or g.dim() != 2
+            or g.shape[0] < DENSE_BF3_MIN_ROWS or g.shape[1] % 4 or g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16):
+        return None
+    M, N = g.shape
+    lib = _lib.load()
+    key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
+    ws = _ABSMAX_WS.get(key)
+    if ws is None:                                       # ticket word + block maxima, per (device, stream): calls on one stream are ordered
+        ws = _ABSMAX_WS[key] = torch.zeros(int(lib.dir_row_absmax_workspace_words()), dtype=torch.int32, device=g.device)
+    buf = torch.empty(M + 4, dtype=torch.int32, device=g.device)
+    rb, ab = buf[:M], buf[M:M + 1]
+    _lib.check(lib.dir_row_absmax_bits_f32(_ptr(g), g.stride(0), M, N, _ptr(rb), _ptr(ab) if want_all else None, _ptr(ws), _stream()))
+    return rb, (ab if want_all else None)
+
+
 def dense_bf3_image(weight, split="bf16x3"):
     """The packed image (bf16 x 3, or fp16 x 2 pieces with split="f16x2") of a [N, Kd] fp32 weight of ANY strides
     (dir_dense_*_pack_strided_f32: a `.t()` view is packed straight from the storage of the tensor it transposes), cached per tensor and
@@ -620,14 +646,16 @@ def _dense_arith(arith, x, weight, out, gate):
     return arith
 
 
-def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None, arith=None):
+def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None, arith=None, row_bits=None):
     """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32 / dir_dense_bf16x3_f32).  x [M, Kd], weight [N, Kd] (nn.Linear
     layout), bias [N].  post_scale / post_shift [N]: the inference batch-norm that follows the activation, as
     y * post_scale + post_shift in the same pass.  arith: "f32" (fp32 MFMA), "bf16x3" (three-way bf16 split of both operands on the
     bf16 pipe, fp32 accumulate: fp32-equivalent, not bitwise the same), "auto" (dense_auto_arith), None = DENSE_ARITH.
     "f16x2" (dir_dense_f16x2_f32: two fp16 pieces per operand, three products) / "auto_bounded" (what "auto" picks, with f16x2 in the
     place of bf16x3): for layers whose input is bounded by construction -- embedding concatenations, ReLU / batch-normalised
-    activations, the CIN's pooled products (|x|, |W| < 65 504)."""
+    activations, the CIN's pooled products (|x|, |W| < 65 504).
+    row_bits (grad_bits(x)[0]): x is a gradient; where "auto" would run bf16x3 the row-scaled fp16 x 2 kernel runs
+    (dir_dense_f16x2_rows_f32)."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     M, Kd = x.shape
@@ -641,7 +669,9 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     which = _dense_arith(arith, x, weight, out, None)
-    use_bf3 = which in ("bf16x3", "f16x2")
+    if row_bits is not None and which == "bf16x3" and (arith or DENSE_ARITH) == "auto":
+        which = "f16x2_rows"
+    use_bf3 = which in ("bf16x3", "f16x2", "f16x2_rows")
     if not use_bf3 and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16):
         weight = weight.contiguous()          # (the fp32 kernel reads rows with 16-byte loads; the bf16x3 image is packed from any strides)
     if post_scale is not None:
@@ -651,6 +681,11 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     if which == "f16x2":
         _lib.check(_lib.load().dir_dense_f16x2_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), _ptr(bias), 1 if relu else 0,
                                                    _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
+        return out
+    if which == "f16x2_rows":
+        _lib.check(_lib.load().dir_dense_f16x2_rows_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), _ptr(bias), 1 if relu else 0,
+                                                        _ptr(post_scale), _ptr(post_shift), None, 0, M, Kd, N, _ptr(out), out.stride(0),
+                                                        _ptr(row_bits), _stream()))
         return out
     if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0,
@@ -852,9 +887,9 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
     return out
 
 
-def dense_gated(x, weight, gate, out=None, arith=None):
+def dense_gated(x, weight, gate, out=None, arith=None, row_bits=None):
     """where(gate > 0, x @ weight.T, 0) (include/dir_hip.h: dir_dense_gated_f32 / dir_dense_bf16x3_f32 with a gate): x [M, Kd],
-    weight [N, Kd], gate [M, N]."""
+    weight [N, Kd], gate [M, N].  row_bits (grad_bits(x)[0]): where "auto" would run bf16x3 the row-scaled fp16 x 2 kernel runs."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     _dev(gate, torch.float32, "gate")
@@ -867,6 +902,10 @@ def dense_gated(x, weight, gate, out=None, arith=None):
     use_bf3 = _dense_arith(arith, x, weight, out, gate) == "bf16x3"
     if not use_bf3 and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16):
         weight = weight.contiguous()
+    if use_bf3 and row_bits is not None and (arith or DENSE_ARITH) == "auto":
+        _lib.check(_lib.load().dir_dense_f16x2_rows_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), None, 0, None, None, _ptr(gate),
+                                                        gate.stride(0), M, Kd, N, _ptr(out), out.stride(0), _ptr(row_bits), _stream()))
+        return out
     if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), None, 0, None, None, _ptr(gate),
                                                     gate.stride(0), M, Kd, N, _ptr(out), out.stride(0), _stream()))
@@ -897,11 +936,13 @@ def dense_dw_auto_arith(M, N, K):
     return "bf16x3" if (-(-nt // 16) * 16) * kpad <= 1.4 * nt * kt else "f32"
 
 
-def dense_dw(g, x, arith=None, want_bias=False):
+def dense_dw(g, x, arith=None, want_bias=False, g_bits=None):
     """dW [N, K] = g^T x, the kernel gradient of a dense layer (include/dir_hip.h: dir_dense_dw_bf16x3_f32): g [M, N], x [M, K], unit
     inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the MFMA kernel;
     "small": the fp32 FMA kernel for N <= 128, K <= 256 (dir_dense_dw_small_f32).
-    want_bias: -> (dW, db) with db [N] = g.sum(0), the bias gradient (in the kernel's pass over g on the bf16x3 path)."""
+    want_bias: -> (dW, db) with db [N] = g.sum(0), the bias gradient (in the kernel's pass over g on the bf16x3 path).
+    g_bits (grad_bits(g)[1]) given by a caller who ALSO vouches that x is bounded by construction (an embedding concatenation, an
+    activation of such a tower): where "auto" would run bf16x3, dir_dense_dw_f16x2_f32 runs; "f16x2" asks for it by name."""
     _dev(g, torch.float32, "g")
     _dev(x, torch.float32, "x")
     if g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0] or g.stride(1) != 1 or x.stride(1) != 1:
@@ -912,7 +953,11 @@ def dense_dw(g, x, arith=None, want_bias=False):
     covered = N % 4 == 0 and K % 4 == 0 and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
     if arith == "auto":
         arith = dense_dw_auto_arith(M, N, K) if covered else "f32"
-    if arith in ("bf16x3", "small") and not covered:
+        if arith == "bf16x3" and g_bits is not None and DENSE_BWD_SPLIT == "f16x2":
+            arith = "f16x2"
+    if arith == "f16x2" and g_bits is None:
+        raise ValueError("dense_dw(arith='f16x2') needs g_bits (grad_bits(g)[1])")
+    if arith in ("bf16x3", "small", "f16x2") and not covered:
         raise ValueError("dense_dw(arith='%s'): N, K and the row strides must be multiples of 4, g and x 16-byte aligned" % arith)
     if arith == "small" and (N > 128 or K > 256 or -(-N // 8) * -(-K // 8) > 256):
         raise ValueError("dense_dw(arith='small') covers N <= 128, K <= 256 (at most 256 register tiles of 8 x 8)")
@@ -922,9 +967,17 @@ def dense_dw(g, x, arith=None, want_bias=False):
         else:
             dW = g.t() @ x
         return (dW, g.sum(dim=0)) if want_bias else dW
-    if arith not in ("bf16x3", "small"):
-        raise ValueError("dense_dw: arith must be 'auto', 'f32', 'bf16x3' or 'small'")
+    if arith not in ("bf16x3", "small", "f16x2"):
+        raise ValueError("dense_dw: arith must be 'auto', 'f32', 'bf16x3', 'f16x2' or 'small'")
     lib = _lib.load()
+    if arith == "f16x2":
+        nbytes = int(lib.dir_dense_dw_bf16x3_workspace_bytes(M, N, K))
+        ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=g.device)
+        dW = torch.empty((N, K), dtype=torch.float32, device=g.device)
+        db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
+        _lib.check(lib.dir_dense_dw_f16x2_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(db), _ptr(ws), nbytes,
+                                              _ptr(g_bits), _stream()))
+        return (dW, db) if want_bias else dW
     wsq, run = ((lib.dir_dense_dw_bf16x3_workspace_bytes, lib.dir_dense_dw_bf16x3_f32) if arith == "bf16x3" else
                 (lib.dir_dense_dw_small_workspace_bytes, lib.dir_dense_dw_small_f32))
     nbytes = int(wsq(M, N, K))

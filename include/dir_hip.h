@@ -450,12 +450,26 @@ int dir_dense_bf16x3_f32(const float* X, int64_t x_ld, const void* image, const 
 
 /* The layer on "fp16 x 2" arithmetic (csrc/dense_bf3.hip, round 4; dir_cin_layer_f16x2_f32 states the arithmetic and its preconditions):
  * for layers whose input is bounded by construction -- embedding concatenations, ReLU / batch-normalised activations, the CIN's pooled
- * products; |x|, |W| < 65 504.  No gate argument: data gradients stay on bf16 x 3.  The image comes from
+ * products; |x|, |W| < 65 504.  No gate argument: an X of unknown magnitude (a gradient) goes through dir_dense_f16x2_rows_f32.  The image comes from
  * dir_dense_f16x2_pack_strided_f32 (dir_dense_bf16x3_image_bytes(Kd, N) bytes hold it; not interchangeable with the bf16 x 3 image). */
 int dir_dense_f16x2_pack_strided_f32(const float* W, int64_t w_rs, int64_t w_cs, int Kd, int N, void* image, int64_t image_bytes,
                                      dir_stream_t stream);
 int dir_dense_f16x2_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                         const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
+/* fp16 x 2 for an X of UNKNOWN magnitude -- the backward's data gradient dL/dx = g W (X := g, image := W^T from
+ * dir_dense_f16x2_pack_strided_f32), with dir_dense_bf16x3_f32's gate argument: inside the kernel row r of X is multiplied by a power of two
+ * chosen from row_bits[r] (DEVICE, [M]: the bit pattern of max_k |X[r, k]|; the row's largest element lands in [2^14, 2^15)) before the
+ * split and the row's sums by the inverse before the epilogue -- both exact.  Elements within 2^-17 of their row's largest carry 22 bits,
+ * smaller ones an absolute error of 2^-39 of the largest.  dir_row_absmax_bits_f32 writes row_bits and, if all_bits != NULL, the maximum
+ * over all rows (what dir_dense_dw_f16x2_f32 takes); N, x_ld multiples of 4, X 16-byte aligned.  workspace (needed with all_bits):
+ * dir_row_absmax_workspace_words() unsigned ints of DEVICE memory whose FIRST word is zero before the first call -- the kernel's ticket
+ * counter, which every call leaves at zero again (one launch, no zeroing pass; calls sharing a workspace must be ordered on one stream). */
+int dir_row_absmax_workspace_words(void);
+int dir_row_absmax_bits_f32(const float* X, int64_t x_ld, int64_t M, int N, unsigned int* row_bits, unsigned int* all_bits,
+                            unsigned int* workspace, dir_stream_t stream);
+int dir_dense_f16x2_rows_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
+                             const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
+                             const unsigned int* row_bits, dir_stream_t stream);
 /* dir_dense_bf16x3_head_f32 on the fp16 x 2 arithmetic (the image from dir_dense_f16x2_pack_strided_f32): the last deep layer of DCN reads a
  * batch-normalised ReLU activation (DeepCrossNetwork.py:400-403) -- bounded by construction. */
 int dir_dense_f16x2_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
@@ -537,6 +551,12 @@ int dir_dense_gated_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w
 int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K);
 int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
                             float* db, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+/* The same weight gradient on fp16 x 2: g is multiplied by ONE power of two for the whole tensor (from g_absmax_bits, DEVICE: the bit pattern
+ * of an upper bound of max |g| -- dir_row_absmax_bits_f32's all_bits) before its split and dW by the inverse in the reduce pass (exact; db
+ * sums the raw g); x is split as in the fp16 x 2 forward: |x| < 65 504 and O(1) (embedding concatenations, activations).  Arguments,
+ * workspace and determinism of dir_dense_dw_bf16x3_f32. */
+int dir_dense_dw_f16x2_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
+                           float* db, void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits, dir_stream_t stream);
 /* The same product for small gradients (N <= 128, K <= 256, at most 256 tiles of 8 x 8; multiples of 4): fp32 FMAs on register tiles over row spans (exact fp32 products),
  * for the tall-and-skinny TN products the library runs at 200 us -- the per-sample term of the DIN unit's first layer (S^T a, 80 x 64)
  * and the narrow last layers of the towers.  Same arguments, workspace query and determinism as dir_dense_dw_bf16x3_f32. */

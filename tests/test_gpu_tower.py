@@ -302,3 +302,54 @@ def test_tower_splits_agree_and_general_inputs_stay_on_bf16x3(built_lib):
     with torch.no_grad():
         gb = D.tower_infer(lins, big, torch.relu, head=head)
     assert bool(torch.isfinite(gb).all())
+
+
+@pytest.mark.parametrize("M,N,K,gate", [(12800, 400, 416, True), (12801, 400, 400, True), (13000, 208, 128, False), (12544, 1024, 432, True),
+                                        (12290, 64, 200, False)])
+def test_dense_backward_on_scaled_fp16x2(built_lib, M, N, K, gate):
+    """The fp16 x 2 backward kernels of a dense layer (round 4): dL/dx = g W on dir_dense_f16x2_rows_f32 (every row of g times a power of
+    two from dir_row_absmax_bits_f32, exact) and dL/dW = g^T x on dir_dense_dw_f16x2_f32 (g times ONE power of two).  Against float64 at the
+    bf16 x 3 kernels' bars; a gradient whose rows differ by powers of two over 60 binades gives the same dL/dx bits times those powers,
+    a 2^-40 times smaller g the same dL/dW bits times 2^-40; the bias gradient is the bf16 x 3 kernel's bit for bit."""
+    from dir_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(M + N)
+    g = torch.randn((M, N), generator=gen, device="cuda") * 1e-4 * (torch.rand((M, 1), generator=gen, device="cuda") * 3 + 0.01)
+    x = torch.randn((M, K), generator=gen, device="cuda") * 0.3
+    W = torch.randn((N, K), generator=gen, device="cuda") / K ** 0.5           # nn.Linear layout [out, in]
+    gt = (torch.rand((M, K), generator=gen, device="cuda") > 0.4).float() if gate else None
+    rb, ab = ops.grad_bits(g)
+    assert torch.equal(rb, g.abs().amax(dim=1).view(torch.int32)) and int(ab) == int(g.abs().max().view(torch.int32))
+    # dL/dx
+    ref = g.double() @ W.double()
+    if gate:
+        ref = ref * gt.double()
+        got = ops.dense_gated(g, W.t(), gt, row_bits=rb)
+        old = ops.dense_gated(g, W.t(), gt)
+    else:
+        got = ops.dense(g, W.t(), row_bits=rb)
+        old = ops.dense(g, W.t())
+    scale = float(ref.abs().max())
+    for y in (got, old):
+        assert float(((y.double() - ref).abs() / (scale + ref.abs())).max()) <= 1e-5
+    pw = torch.from_numpy(np.ldexp(1.0, np.random.default_rng(M).integers(-50, 10, size=(M, 1))).astype(np.float32)).cuda()
+    g2 = g * pw
+    rb2, _ = ops.grad_bits(g2)
+    got2 = ops.dense_gated(g2, W.t(), gt, row_bits=rb2) if gate else ops.dense(g2, W.t(), row_bits=rb2)
+    assert torch.equal(got2, got * pw)
+    again = ops.dense_gated(g, W.t(), gt, row_bits=rb) if gate else ops.dense(g, W.t(), row_bits=rb)
+    assert torch.equal(again, got)
+    # dL/dW, dL/db
+    if ops.dense_dw_auto_arith(M, N, K) != "bf16x3":
+        return
+    refw = g.double().t() @ x.double()
+    dW, db = ops.dense_dw(g, x, want_bias=True, g_bits=ab)                      # "auto" + g_bits: the fp16 x 2 kernel
+    bW, bb = ops.dense_dw(g, x, want_bias=True, arith="bf16x3")
+    mag = float(refw.abs().max())
+    for w in (dW, bW):
+        assert float(((w.double() - refw).abs() / (mag + refw.abs())).max()) <= 1e-5
+    assert torch.equal(db, bb)
+    assert torch.equal(ops.dense_dw(g, x, arith="f16x2", g_bits=ab), dW)
+    s = 2.0 ** -40
+    _, ab2 = ops.grad_bits(g * s)
+    assert torch.equal(ops.dense_dw(g * s, x, arith="f16x2", g_bits=ab2), dW * s)
+    assert not torch.equal(dW, bW)                                              # (two arithmetics: not the same bits)
