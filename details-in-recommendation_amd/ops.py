@@ -1795,7 +1795,8 @@ def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None, z_top=No
             dWs[k] = dense_dw(Z, gk).t().contiguous()
             if k == 0 and not need_x0:
                 break
-            dZ = dense(gk, W.t())
+            gb = grad_bits(gk, want_all=False) if (arith == "auto" and CIN_BWD_SPLIT == "f16x2") else None
+            dZ = dense(gk, W.t(), row_bits=gb[0] if gb is not None else None)      # dL/dZ = g W: the gradient's rows scaled inside the fp16 x 2 kernel
             G, dx0 = cin_pool_dx(x0, xk, dZ, add_pooled=gps[k - 1] if k > 0 else None, dx0=dx0)
             continue
         if G is None:                                        # the top layer's map feeds nothing but its pooled sums

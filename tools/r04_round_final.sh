@@ -29,6 +29,7 @@ DIR_DIN_SAVE=0 b din_train_recompute --workload din_train --steps 30 --warmup 5 
 b cin --workload cin --steps 5 --warmup 2
 DIR_CIN_FWD_SPLIT=bf16x3 b cin_bf16x3 --workload cin --steps 5 --warmup 2 --no-cpu-baseline
 b cin_backward --workload cin_backward --steps 5 --warmup 2 --no-cpu-baseline
+DIR_CIN_BWD_SPLIT=bf16x3 DIR_DENSE_BWD_SPLIT=bf16x3 b cin_backward_bf16x3 --workload cin_backward --steps 5 --warmup 2 --no-cpu-baseline
 b mlp_dense --workload mlp_dense --steps 50 --warmup 5 --no-cpu-baseline
 DIR_TOWER_SPLIT=bf16x3 b mlp_dense_bf16x3 --workload mlp_dense --steps 50 --warmup 5 --no-cpu-baseline
 DIR_BENCH_DENSE=layers b mlp_dense_layers --workload mlp_dense --steps 50 --warmup 5 --no-cpu-baseline
@@ -39,6 +40,10 @@ b esmm_full --workload esmm_full --steps 50 --warmup 5 --no-cpu-baseline
 b xdeepfm_full --workload xdeepfm_full --steps 10 --warmup 2 --no-cpu-baseline
 b deepfm_train --workload deepfm_train --steps 100 --warmup 10 --no-cpu-baseline
 b deepfm_train_graph --workload deepfm_train --graph --steps 100 --warmup 10 --no-cpu-baseline
+DIR_DENSE_BWD_SPLIT=bf16x3 b deepfm_train_bwd_bf16x3 --workload deepfm_train --steps 100 --warmup 10 --no-cpu-baseline
+DIR_DENSE_BWD_SPLIT=bf16x3 b dcn_train_bwd_bf16x3 --workload dcn_train --steps 30 --warmup 5 --no-cpu-baseline
+b esmm_train_graph --workload esmm_train --graph --steps 100 --warmup 10 --no-cpu-baseline
+DIR_CIN_BWD_SPLIT=bf16x3 DIR_DENSE_BWD_SPLIT=bf16x3 b xdeepfm_train_bwd_bf16x3 --workload xdeepfm_train --steps 10 --warmup 2 --no-cpu-baseline
 b dcn_train --workload dcn_train --steps 30 --warmup 5 --no-cpu-baseline
 b esmm_train --workload esmm_train --steps 100 --warmup 10 --no-cpu-baseline
 b xdeepfm_train --workload xdeepfm_train --steps 10 --warmup 2 --no-cpu-baseline
@@ -49,7 +54,7 @@ b transform --workload transform --steps 100 --warmup 10 --no-cpu-baseline
 b small_batch --workload small_batch --steps 200 --warmup 20 --no-cpu-baseline
 fi
 if [ $part = lines ]; then exit 0; fi
-for w in default deepfm_full esmm_full dcn_full dcn_train deepfm_train esmm_train train_sparse sharded_1gpu cin cin_backward multihot_bag din din_full din_train xdeepfm_full; do
+for w in default deepfm_full esmm_full dcn_full dcn_train deepfm_train esmm_train train_sparse sharded_1gpu cin cin_backward multihot_bag din din_full din_train xdeepfm_full xdeepfm_train; do
     if [ $w = default ]; then a="--steps 100 --warmup 10 --no-cpu-baseline"; elif [ $w = din ] || [ $w = din_train ] || [ $w = din_full ]; then a="--workload $w --steps 50 --warmup 10 --no-cpu-baseline"; else a="--workload $w --steps 10 --warmup 3 --no-cpu-baseline"; fi
     ROUND=r04 DIR_BENCH_NO_SECONDARY=1 DIR_BENCH_NO_SWEEP=1 bash tools/prof.sh $w -- $a > gpurun_out/prof_$w.txt 2>&1; echo "== $w"; head -5 gpurun_out/prof_$w.txt | cut -c1-150
 done
