@@ -148,6 +148,42 @@ __device__ __forceinline__ float db3_scale(unsigned int bits, bool inverse) {
     return __builtin_bit_cast(float, (unsigned int)(inverse ? 127 - k : 127 + k) << 23);
 }
 
+// The fp16 x 2 image: every row n of W (one output column of the layer) is multiplied by its own power of two before the split -- its largest
+// |element| lands in [2^14, 2^15), so that elements down to 2^-17 of it keep both pieces in fp16's NORMAL range (22 bits) instead of an
+// absolute 2^-25 -- and the inverse goes into the image's tail, invw[n], which the kernel's epilogue multiplies the column by.  Both exact.
+// (Unscaled, a weight of 2e-4 carries an absolute error of 3e-8; times a raw numeric input of 99 999 that is 3e-3 on an output of 20.)
+// One wave per row: the row's maximum, then its 16 dwords per piece and k-step.  Rows N .. 16 CT ncb - 1 are zero, their invw 1.
+__global__ __launch_bounds__(256) void dense_f16x2_pack_rows_k(const float* __restrict__ W, int64_t w_ld, int64_t w_cs, int Kd, int N, int CT, int nks,
+                                                               int ncb, unsigned int* __restrict__ img, float* __restrict__ invw) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= ncb * CT * 16) return;
+    const bool real = n < N;
+    float mx = 0.f;
+    if (real)
+        for (int k = lane; k < Kd; k += 64) mx = fmaxf(mx, fabsf(W[(int64_t)n * w_ld + k * w_cs]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const unsigned int bits = __builtin_bit_cast(unsigned int, mx);
+    const float sc = real ? db3_scale(bits, false) : 1.f;
+    if (lane == 0) invw[n] = real ? db3_scale(bits, true) : 1.f;
+    const int tile = n >> 4, cb = tile / CT, ct = tile - cb * CT;
+    const int ep = lane & 3, lg = (lane >> 2) & 3, ksl = lane >> 4;               // a lane: pair ep of lane group lg of k-step ks0 + ksl
+    const int l = lg * 16 + (n & 15);
+    for (int ks0 = 0; ks0 < nks; ks0 += 4) {
+        const int ks = ks0 + ksl;
+        if (ks >= nks) continue;
+        const int k = 32 * ks + 8 * lg + 2 * ep;
+        const float v0 = (real && k < Kd) ? W[(int64_t)n * w_ld + k * w_cs] * sc : 0.f;
+        const float v1 = (real && k + 1 < Kd) ? W[(int64_t)n * w_ld + (k + 1) * w_cs] * sc : 0.f;
+        unsigned int pw[2];
+        Db3Pc<2>::split(v0, v1, pw);
+        const int64_t base = ((int64_t)cb * nks + ks) * (2 * CT * 64 * 4) + (ct * 64 + l) * 4 + ep;
+        img[base] = pw[0];
+        img[base + CT * 64 * 4] = pw[1];
+    }
+}
+
 // RS (fp16 x 2 with an X of unknown magnitude -- a gradient): row r of X is multiplied by the power of two db3_scale(row_bits[r]) before it
 // is split and the row's accumulators by the inverse before the epilogue (both exact); row_bits[r] = bit pattern of max_k |X[r, k]|
 // (dir_row_absmax_bits_f32).
@@ -234,6 +270,8 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
     __syncthreads();
 
     const unsigned char* wlane = Wb + lane * 16;
+    // fp16 x 2: the image's tail holds the inverse of every output column's weight scale (dense_f16x2_pack_rows_k)
+    const float* invw = reinterpret_cast<const float*>(img + (int64_t)ncb * nks * STEPB);
     int buf = 0;
     for (int t = t0; t < t1; t += G) {
         const bool more = t + G < t1;
@@ -309,6 +347,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                 const int col = 16 * (cur.cb * CT + ct) + 4 * lg;      // N % 4 == 0: the lane's four columns are inside or outside together
                 if (r < M && col < N) {
                     f32x4 v = acc[rt][ct];
+                    if constexpr (NP == 2) v *= *reinterpret_cast<const f32x4*>(invw + col);      // the columns' weight scales out again
                     if constexpr (RS) v *= cur.inv[rt];            // (a lane's four accumulators are four columns of ITS row n)
                     if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
                     if (relu) {
@@ -440,10 +479,12 @@ static int dense_pack_strided(const char* name, int pieces, const float* W, int6
     const int CT = db3_ct_for(N);
     const int ncb = ((N + 15) / 16 + CT - 1) / CT, nks = (Kd + 31) / 32;
     const int64_t threads = (int64_t)ncb * nks * CT * 64 * 4;
-    if (pieces == 2)
-        hipLaunchKernelGGL(dense_bf3_pack_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_rs, w_cs, Kd, N, CT, nks,
-                           ncb, static_cast<unsigned int*>(image));
-    else
+    if (pieces == 2) {
+        unsigned char* base = static_cast<unsigned char*>(image);
+        float* invw = reinterpret_cast<float*>(base + (int64_t)ncb * nks * 2 * CT * 1024);      // behind the two piece planes: inside the 3-plane size
+        hipLaunchKernelGGL(dense_f16x2_pack_rows_k, dim3((unsigned)((ncb * CT * 16 + 3) / 4)), dim3(256), 0, as_stream(stream), W, w_rs, w_cs, Kd, N, CT,
+                           nks, ncb, static_cast<unsigned int*>(image), invw);
+    } else
         hipLaunchKernelGGL(dense_bf3_pack_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_rs, w_cs, Kd, N, CT, nks,
                            ncb, static_cast<unsigned int*>(image));
     DIR_CHECK_LAUNCH(name);

@@ -546,6 +546,10 @@ DENSE_BOUNDED_SPLIT = os.environ.get("DIR_DENSE_BOUNDED_SPLIT", "f16x2")
 # of two) and, where the layer's input is bounded by construction, dL/dW on dir_dense_dw_f16x2_f32 (g scaled by one power of two);
 # "bf16x3" = rounds 2-3's arithmetic
 DENSE_BWD_SPLIT = os.environ.get("DIR_DENSE_BWD_SPLIT", "f16x2")
+# what dense(arith="auto") runs on a GENERAL input (no "bounded by construction" promise) where it used to pick bf16x3: "f16x2_rows" = the
+# row-scaled fp16 x 2 kernel behind one max pass over x (any magnitudes: a raw numeric column of 99 999 next to 0.1-scale embeddings; error
+# relative to each row's largest element 2^-22 .. 2^-39, i.e. below fp32's own rounding of the row's dot products) | "bf16x3"
+DENSE_GENERAL_SPLIT = os.environ.get("DIR_DENSE_GENERAL_SPLIT", "f16x2_rows")
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
 
@@ -590,23 +594,33 @@ def dense_auto_arith(M, Kd, N):
 _ABSMAX_WS = {}
 
 
-def grad_bits(g, want_all=True):
-    """(row_bits [M] int32, all_bits [1] int32) of a gradient g [M, N]: the bit patterns of max_k |g[r, k]| and of max |g|
-    (include/dir_hip.h: dir_row_absmax_bits_f32) -- the powers of two the fp16 x 2 backward kernels scale g by -- or None when
-    DENSE_BWD_SPLIT is not "f16x2" or g is not a covered operand (then the callers keep bf16 x 3)."""
-    if (DENSE_BWD_SPLIT != "f16x2" or DENSE_ARITH != "auto" or not g.is_cuda or g.dtype != torch.float32 or g.dim() != 2
-            or g.shape[0] < DENSE_BF3_MIN_ROWS or g.shape[1] % 4 or g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16):
-        return None
-    M, N = g.shape
+def row_absmax_bits(x, want_all=True):
+    """(row_bits [M] int32, all_bits [1] int32 | None) of x [M, N] (N, the row stride multiples of 4, 16-byte aligned): the bit patterns of
+    max_k |x[r, k]| and of max |x| (include/dir_hip.h: dir_row_absmax_bits_f32) -- the powers of two the row-scaled / tensor-scaled
+    fp16 x 2 kernels multiply x by."""
+    M, N = x.shape
     lib = _lib.load()
-    key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _ABSMAX_WS.get(key)
     if ws is None:                                       # ticket word + block maxima, per (device, stream): calls on one stream are ordered
-        ws = _ABSMAX_WS[key] = torch.zeros(int(lib.dir_row_absmax_workspace_words()), dtype=torch.int32, device=g.device)
-    buf = torch.empty(M + 4, dtype=torch.int32, device=g.device)
+        ws = _ABSMAX_WS[key] = torch.zeros(int(lib.dir_row_absmax_workspace_words()), dtype=torch.int32, device=x.device)
+    buf = torch.empty(M + 4, dtype=torch.int32, device=x.device)
     rb, ab = buf[:M], buf[M:M + 1]
-    _lib.check(lib.dir_row_absmax_bits_f32(_ptr(g), g.stride(0), M, N, _ptr(rb), _ptr(ab) if want_all else None, _ptr(ws), _stream()))
+    _lib.check(lib.dir_row_absmax_bits_f32(_ptr(x), x.stride(0), M, N, _ptr(rb), _ptr(ab) if want_all else None, _ptr(ws), _stream()))
     return rb, (ab if want_all else None)
+
+
+def _rows_covered(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= DENSE_BF3_MIN_ROWS and x.shape[1] % 4 == 0
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def grad_bits(g, want_all=True):
+    """row_absmax_bits of a gradient g [M, N] for the fp16 x 2 BACKWARD kernels, or None when DENSE_BWD_SPLIT is not "f16x2" or g is not a
+    covered operand (then the callers keep bf16 x 3)."""
+    if DENSE_BWD_SPLIT != "f16x2" or DENSE_ARITH != "auto" or not _rows_covered(g):
+        return None
+    return row_absmax_bits(g, want_all)
 
 
 def dense_bf3_image(weight, split="bf16x3"):
@@ -669,8 +683,11 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     which = _dense_arith(arith, x, weight, out, None)
-    if row_bits is not None and which == "bf16x3" and (arith or DENSE_ARITH) == "auto":
-        which = "f16x2_rows"
+    if which == "bf16x3" and (arith or DENSE_ARITH) == "auto":
+        if row_bits is None and DENSE_GENERAL_SPLIT == "f16x2_rows" and _rows_covered(x):
+            row_bits = row_absmax_bits(x, want_all=False)[0]          # a general input: its rows' exponents first (one pass over x)
+        if row_bits is not None:
+            which = "f16x2_rows"
     use_bf3 = which in ("bf16x3", "f16x2", "f16x2_rows")
     if not use_bf3 and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16):
         weight = weight.contiguous()          # (the fp32 kernel reads rows with 16-byte loads; the bf16x3 image is packed from any strides)

@@ -31,7 +31,26 @@ def _np(p):
     return p.detach().cpu().numpy().astype(np.float64)
 
 
-def test_deepfm_config1_forward(built_lib, oracle):
+@pytest.fixture(params=[1, 6144], ids=["hip_layers", "product_routing"])
+def min_rows(request, monkeypatch):
+    """The dense-layer routing threshold: 1 = every covered layer on the HIP kernels (what tests/conftest.py sets for the suite: the kernels
+    are under test), 6144 = the PRODUCT default (details-in-recommendation_amd/dense.py: MIN_ROWS) -- at the reference's own batch sizes (100 / 256 / 1000)
+    the towers' layers then run on nn.Linear (rocBLAS) between the HIP lookup / FM / cross kernels: what a user of the modules gets."""
+    from dir_amd import dense as D
+    monkeypatch.setattr(D, "MIN_ROWS", request.param)
+    D.reset_routing()
+    return request.param
+
+
+def _check_routing(min_rows):
+    from dir_amd import dense as D
+    if min_rows == 1:
+        assert D.ROUTING["hip"], dict(D.ROUTING)
+    else:
+        assert D.ROUTING["library"] and not D.ROUTING["hip"], dict(D.ROUTING)
+
+
+def test_deepfm_config1_forward(built_lib, oracle, min_rows):
     """BASELINE configs[0] shape: 1k rows, 13 dense (bucketised, linear part only) + 26 sparse, dim 8."""
     from dir_amd.deepfm import DeepFM
     from dir_amd import feature_column as fc
@@ -53,6 +72,7 @@ def test_deepfm_config1_forward(built_lib, oracle):
     feats.update({"I%d" % i: torch.from_numpy(dense[:, i].copy()).cuda() for i in range(13)})
     with torch.no_grad():
         pred = model.predict(feats)
+    _check_routing(min_rows)
     # reference graph in float64 (deepFM.py:169-223)
     tabs = [p.detach().cpu().numpy() for p in model.embedding_weights]
     emb = oracle.embedding_bag(tabs, ids).astype(np.float64)
@@ -147,7 +167,7 @@ def test_deepfm_multihot_weighted(built_lib, oracle):
     _close(got, ref)
 
 
-def test_dcn_adult_schema_forward(built_lib, oracle):
+def test_dcn_adult_schema_forward(built_lib, oracle, min_rows):
     """build_model_columns of DeepCrossNetwork/train.py:54-101: 5 numeric, 4 indicator, 1 hashed embedding (dim 8)
     -> d = 51, concatenated in NAME-SORTED order (DeepCrossNetwork.py:126)."""
     from dir_amd.dcn import DeepCrossNetwork
@@ -184,6 +204,7 @@ def test_dcn_adult_schema_forward(built_lib, oracle):
     feats["occupation"] = raw["occupation"]
     with torch.no_grad():
         got = model.predict(feats)
+    _check_routing(min_rows)
     # NumPy restatement with name-sorted concat
     parts = {}
     for n in nums:

@@ -353,3 +353,33 @@ def test_dense_backward_on_scaled_fp16x2(built_lib, M, N, K, gate):
     _, ab2 = ops.grad_bits(g * s)
     assert torch.equal(ops.dense_dw(g * s, x, arith="f16x2", g_bits=ab2), dW * s)
     assert not torch.equal(dW, bW)                                              # (two arithmetics: not the same bits)
+
+
+@pytest.mark.parametrize("M,Kd,N", [(12800, 432, 1024), (13001, 360, 200), (12288, 64, 208)])
+def test_dense_general_inputs_on_row_scaled_fp16x2(built_lib, monkeypatch, M, Kd, N):
+    """dense(arith="auto") on a GENERAL input -- a raw numeric column of 99 999 (DeepCrossNetwork/train.py's capital_gain) beside embedding-scale
+    columns and 1e-6-scale ones, all-zero rows, rows that differ by 60 binades -- runs the row-scaled fp16 x 2 kernel behind one max pass over x
+    (ops.DENSE_GENERAL_SPLIT): finite, within 1e-5 of float64 scaled by each row's own magnitude (the bf16 x 3 kernel's bar), bitwise
+    reproducible, and scaling a row by a power of two scales its outputs by exactly that power."""
+    from dir_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(M + Kd)
+    x = torch.randn((M, Kd), generator=gen, device="cuda") * 0.3
+    x[:, 5] = torch.rand(M, generator=gen, device="cuda") * 99999.0
+    x[:, 7] *= 1e-6
+    x[::97] = 0.0
+    W = torch.randn((N, Kd), generator=gen, device="cuda") / Kd ** 0.5
+    b = torch.randn(N, generator=gen, device="cuda") * 0.1
+    assert ops.DENSE_GENERAL_SPLIT == "f16x2_rows" and ops.dense_auto_arith(M, Kd, N) == "bf16x3"
+    got = ops.dense(x, W, b, relu=False)
+    assert bool(torch.isfinite(got).all())
+    ref = x.double() @ W.double().t() + b.double()
+    mag = (x.double().abs() @ W.double().abs().t()) + 1.0                       # what fp32 rounding of the row's products is relative to
+    assert float(((got.double() - ref).abs() / mag).max()) <= 1e-5
+    b3 = ops.dense(x, W, b, relu=False, arith="bf16x3")
+    assert float(((b3.double() - ref).abs() / mag).max()) <= 1e-5 and not torch.equal(b3, got)
+    assert torch.equal(ops.dense(x, W, b, relu=False), got)
+    pw = torch.from_numpy(np.ldexp(1.0, np.random.default_rng(M).integers(-40, 20, size=(M, 1))).astype(np.float32)).cuda()
+    lin = ops.dense(x, W)
+    assert torch.equal(ops.dense(x * pw, W), lin * pw)
+    monkeypatch.setattr(ops, "DENSE_GENERAL_SPLIT", "bf16x3")
+    assert torch.equal(ops.dense(x, W, b, relu=False), b3)
