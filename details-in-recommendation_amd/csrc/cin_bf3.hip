@@ -168,7 +168,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      float* __restrict__ dotp /* DOT: partials [nkh][B, m, D] of this launch's column block */,
                                                      const float* __restrict__ addp /* optional [B, H] (row stride addp_ld): added to xout[b, h, :] */,
                                                      int64_t addp_ld, const unsigned short* __restrict__ ptab /* PAIRS: i | j << 8 per pair */,
-                                                     int mx /* fields of the x0 slice (= m unless PAIRS) */) {
+                                                     int mx /* fields of the x0 slice (= m unless PAIRS) */,
+                                                     unsigned int* __restrict__ amax_out = nullptr /* RS: atomicMax of the bit pattern of max |xk| */) {
     using Pc = BtPc<NP>;
     using op_t = typename Pc::op_t;
     static_assert(NP == 3 || !DOT || RS, "the data-gradient form on fp16 x 2 needs the row-scaled left operand");
@@ -238,6 +239,12 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (amax_out && blockIdx.y == 0) {          // the tensor's maximum rides along (the weight-gradient kernel scales G by it): one atomic per wave and row tile
+                float wm = mx;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+                if (lane == 0) atomicMax(amax_out, __builtin_bit_cast(unsigned int, wm));
+            }
             int k = 141 - (int)((__builtin_bit_cast(unsigned int, mx) >> 23) & 0xffu);
             k = k > 100 ? 100 : (k < -100 ? -100 : k);
             rscale[rt] = __builtin_bit_cast(float, (unsigned int)(127 + k) << 23);
@@ -507,7 +514,7 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
 static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                    float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
                    const float* addp = nullptr, int64_t addp_ld = 0, int np = 3 /* 2: fp16 x 2 */,
-                   bool rs = false /* fp16 x 2 with the left operand scaled per row (a gradient) */) {
+                   bool rs = false /* fp16 x 2 with the left operand scaled per row (a gradient) */, unsigned int* amax_out = nullptr) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -522,6 +529,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     const int64_t R = B * D;
     hipStream_t st = as_stream(stream);
     const bool dot = y != nullptr;
+    if (amax_out && zero_async(amax_out, sizeof(unsigned int), st) != hipSuccess) return fail(DIR_E_HIP, "%s: zeroing failed", name);
     if (dot && np != 3 && !rs) return fail(DIR_E_UNSUPPORTED, "%s: the data-gradient form on fp16 x 2 needs the row-scaled left operand", name);
     if (rs && np != 2) return fail(DIR_E_UNSUPPORTED, "%s: row scaling belongs to fp16 x 2", name);
     const Bf3Plan pl = bf3_plan(m, Hp, H, dot, np);
@@ -545,7 +553,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>);                                       \
         const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256;                                  \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
-                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m);                     \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr); \
     } while (0)
 #define BT_LAUNCH_KS(C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                       \
     do {                                                                                 \
@@ -756,14 +764,14 @@ extern "C" int dir_cin_layer_dot_add_bf16x3_f32(const float* x0, const float* xk
 
 extern "C" int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D,
                                                int64_t B, const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials,
-                                               void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+                                               void* workspace, int64_t workspace_bytes, unsigned int* xk_absmax_bits_out, dir_stream_t stream) {
     const char* name = "dir_cin_layer_dot_add_f16x2_f32";
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(y && dot_partials && xout, "%s: null pointer", name);
     DIR_CHECK_ARG(aligned16(y) && aligned16(dot_partials), "%s: y and dot_partials must be 16-byte aligned", name);
     DIR_CHECK_ARG(!add_pooled || add_pooled_ld >= H, "%s: add_pooled_ld=%lld < H=%d", name, (long long)add_pooled_ld, H);
     return bf3_run(name, x0, xk, W, m, Hp, H, D, B, xout, nullptr, 0, y, dot_partials, workspace, workspace_bytes, stream, add_pooled, add_pooled_ld,
-                   2, true);
+                   2, true, xk_absmax_bits_out);
 }
 
 // out[e] (+)= sum over p of parts[p][e] in p order, e < n (n % 4 == 0, 16-byte aligned): the dot partials of dir_cin_layer_dot_*_f32 -> dx0,

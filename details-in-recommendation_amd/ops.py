@@ -1693,14 +1693,15 @@ def cin_dx(x0, xk, W, G):
     return dxk, dx0
 
 
-def cin_dx_bf16x3(x0, xk, W, G, add_pooled=None, dx0=None, split=None):
+def cin_dx_bf16x3(x0, xk, W, G, add_pooled=None, dx0=None, split=None, g_bits_out=None):
     """Both data gradients of one CIN layer on the bf16x3 kernel (include/dir_hip.h, dir_cin_layer_dot_bf16x3_f32): the forward
     contraction on the permuted weight W1[i, h*m+j] = W[h, i*m+j] with G as its left operand gives dxk, and the same T_j tiles dotted
     with xk give dx0 (partial sums per column block and half of i, added in a fixed order by dir_sum_partials_f32).
     add_pooled [B, Hp] (unit column stride): added to dxk[b, i, :] in the kernel's epilogue (dir_cin_layer_dot_add_bf16x3_f32) -- in the
     backward of a stack that sum is the layer below's dL/dxout.  dx0: a [B, m, D] tensor the partial sums are ACCUMULATED into (the
     running dx0 of a stack); None: a new tensor.  split: "bf16x3" | "f16x2" (dir_cin_layer_dot_add_f16x2_f32: G's rows scaled by powers
-    of two inside the kernel) | None = CIN_BWD_SPLIT.  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
+    of two inside the kernel) | None = CIN_BWD_SPLIT.  g_bits_out (a list, fp16 x 2 only): a [1] int32 tensor with the bit pattern of
+    max |G| -- a by-product of the kernel's row maxima -- is appended (cin_dw's g_absmax_bits).  -> (dxk [B,Hp,D], dx0 [B,m,D])."""
     split = split or CIN_BWD_SPLIT
     if split not in ("bf16x3", "f16x2"):
         raise ValueError("cin_dx_bf16x3: split must be 'bf16x3' or 'f16x2'")
@@ -1726,10 +1727,16 @@ def cin_dx_bf16x3(x0, xk, W, G, add_pooled=None, dx0=None, split=None):
         _dev(add_pooled, torch.float32, "add_pooled")
         if tuple(add_pooled.shape) != (B, Hp) or (B > 0 and add_pooled.stride(1) != 1):
             raise ValueError("cin_dx_bf16x3: add_pooled must be [B, Hp] with unit column stride")
-    f_dot = lib.dir_cin_layer_dot_add_f16x2_f32 if split == "f16x2" else lib.dir_cin_layer_dot_add_bf16x3_f32
-    _lib.check(f_dot(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(add_pooled),
-                                                    add_pooled.stride(0) if add_pooled is not None and B > 0 else Hp, _ptr(dxk), _ptr(parts),
-                                                    _ptr(ws), nbytes, _stream()))
+    ald = add_pooled.stride(0) if add_pooled is not None and B > 0 else Hp
+    if split == "f16x2":
+        gbits = torch.empty(1, dtype=torch.int32, device=x0.device) if (g_bits_out is not None and B > 0) else None
+        _lib.check(lib.dir_cin_layer_dot_add_f16x2_f32(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(add_pooled), ald, _ptr(dxk),
+                                                       _ptr(parts), _ptr(ws), nbytes, _ptr(gbits), _stream()))
+        if gbits is not None:
+            g_bits_out.append(gbits)
+    else:
+        _lib.check(lib.dir_cin_layer_dot_add_bf16x3_f32(_ptr(x0), _ptr(G), _ptr(W1), _ptr(xk), m, H, Hp, D, B, _ptr(add_pooled), ald, _ptr(dxk),
+                                                        _ptr(parts), _ptr(ws), nbytes, _stream()))
     acc = dx0 is not None
     if acc and (tuple(dx0.shape) != (B, m, D) or not dx0.is_contiguous() or dx0.dtype != torch.float32):
         raise ValueError("cin_dx_bf16x3: dx0 must be a contiguous float32 [B, m, D] tensor")
@@ -1818,6 +1825,17 @@ def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None, z_top=No
             continue
         if G is None:                                        # the top layer's map feeds nothing but its pooled sums
             G = gps[k].reshape(B, H, 1).expand(B, H, D).contiguous()
+        a = cin_auto_arith(m, D, H, Hp) if arith == "auto" else arith
+        dot_first = (k > 0 and arith == "auto" and a == "bf16x3" and cin_bf16x3_covers(m, D) and CIN_BWD_SPLIT == "f16x2"
+                     and cin_dw_auto_arith(m, D, Hp, H) == "bf16x3")
+        if dot_first:
+            # fp16 x 2 on both kernels: the data-gradient kernel runs FIRST and leaves max |G| (its row maxima's by-product) for the weight
+            # gradient's tensor scale -- no max pass over the 537 MB of G (95 us at the BASELINE shape)
+            gb = []
+            dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G, add_pooled=gps[k - 1], dx0=dx0, g_bits_out=gb)
+            dWs[k] = cin_dw(x0, xk, G, arith=arith, g_absmax_bits=gb[0] if gb else None)
+            G = dxk
+            continue
         dWs[k] = cin_dw(x0, xk, G, arith=arith)
         if k == 0 and not need_x0:
             break
@@ -1830,7 +1848,6 @@ def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None, z_top=No
             tot, _ = cin_layer(x0, G, Ws_, arith=arith, grad_operand=True)
             return (tot if dx0 is None else dx0.add_(tot)), dWs
         below = gps[k - 1] if k > 0 else None
-        a = cin_auto_arith(m, D, H, Hp) if arith == "auto" else arith
         if a == "bf16x3" and cin_bf16x3_covers(m, D):
             dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G, add_pooled=below, dx0=dx0, split=None if arith == "auto" else "bf16x3")
         else:

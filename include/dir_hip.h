@@ -305,12 +305,13 @@ int dir_sum_partials_f32(const float* parts, int P, int64_t n, int accumulate, f
  * which is what the sum over the row's channels needs.  x0, W, y: preconditions of dir_cin_layer_f16x2_f32 (|.| < 65 504, O(1) values).
  * dir_cin_layer_grad_f16x2_f32: arguments of dir_cin_layer_f16x2_f32 (the forward-form contractions of the backward);
  * dir_cin_layer_dot_add_f16x2_f32: arguments, partial-sum layout (dir_cin_bf16x3_dot_partials) and workspace of
- * dir_cin_layer_dot_add_bf16x3_f32. */
+ * dir_cin_layer_dot_add_bf16x3_f32, plus xk_absmax_bits_out (DEVICE, one unsigned; NULL: not wanted): the bit pattern of max |xk| over the
+ * whole tensor, a by-product of the kernel's row maxima -- what dir_cin_dw_f16x2_f32 takes as g_absmax_bits. */
 int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                                  float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D, int64_t B,
                                     const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
-                                    int64_t workspace_bytes, dir_stream_t stream);
+                                    int64_t workspace_bytes, unsigned int* xk_absmax_bits_out, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * A3  categorical id paths.

@@ -315,6 +315,9 @@ def test_cin_dw_and_data_grads_vs_oracle(built_lib, B, m, D, Hp, H):
         pw = torch.from_numpy(np.ldexp(1.0, rng.integers(-30, 10, size=(B, 1, 1))).astype(np.float32)).cuda()
         pxk, px0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G) * pw, split="f16x2")
         assert torch.equal(pxk, sxk * pw) and torch.equal(px0, sx0 * pw)
+        gb = []                                                                  # the tensor maximum of G rides along (cin_dw's scale)
+        ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G), split="f16x2", g_bits_out=gb)
+        assert int(gb[0]) == int(np.abs(G).max().view(np.int32))
         bxk, bx0 = ops.cin_dx_bf16x3(dev(x0), dev(xk), dev(W), dev(G))          # split=None: ops.CIN_BWD_SPLIT
         if ops.CIN_BWD_SPLIT == "f16x2":
             assert torch.equal(bxk, sxk) and torch.equal(bx0, sx0)
