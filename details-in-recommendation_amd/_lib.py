@@ -41,11 +41,12 @@ SIGNATURES = {
     "dir_dense_dw_f16x2_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_row_absmax_workspace_words": (c_i32, []),
     "dir_row_absmax_bits_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "dir_dense_f16x2_rows_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    "dir_dense_f16x2_rows_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "dir_dense_dw_small_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
     "dir_dense_dw_small_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "dir_units1_relu_backward_partials": (c_i64, [c_i64, c_i32]),
     "dir_units1_relu_backward_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "dir_units1_relu_backward_bits_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_units1_backward_partials": (c_i64, [c_i64, c_i32]),
     "dir_units1_backward_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "dir_bn_train_partials": (c_i64, [c_i64, c_i32]),

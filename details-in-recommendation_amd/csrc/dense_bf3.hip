@@ -194,7 +194,9 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                                                      int64_t M, int Kd, int N, int nks, int ncb, float* __restrict__ Y, int64_t y_ld,
                                                      const float* __restrict__ head_w /* [N] or nullptr */,
                                                      float* __restrict__ head_part /* [ncb][M]: this column block's share of y . head_w */,
-                                                     const unsigned int* __restrict__ row_bits = nullptr /* RS: [M] */) {
+                                                     const unsigned int* __restrict__ row_bits = nullptr /* RS: [M] */,
+                                                     unsigned int* __restrict__ y_row_bits = nullptr /* [M], zeroed: atomicMax of the bit pattern of max_n |Y[r, n]| */,
+                                                     unsigned int* __restrict__ y_all_bits = nullptr /* one word, zeroed: the same over all rows */) {
     static_assert(!RS || NP == 2, "row scaling belongs to the fp16 x 2 split");
     constexpr int STEPB = NP * CT * 1024;                      // bytes of W image per k-step
     using Pc = Db3Pc<NP>;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    float run_max = 0.f;                                   // y_all_bits: this lane's largest |output| over all tiles of the workgroup
     const unsigned char* wlane = Wb + lane * 16;
     // fp16 x 2: the image's tail holds the inverse of every output column's weight scale (dense_f16x2_pack_rows_k)
     const float* invw = reinterpret_cast<const float*>(img + (int64_t)ncb * nks * STEPB);
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t r = cur.row0 + wave * 32 + rt * 16 + n;
             float hpart = 0.f;                  // head: this lane's share of the row's dot product with head_w (columns of this block)
+            float ymax = 0.f;                   // y_row_bits: the largest |output| of this lane's columns of the row
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int col = 16 * (cur.cb * CT + ct) + 4 * lg;      // N % 4 == 0: the lane's four columns are inside or outside together
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                         for (int q = 0; q < 4; ++q) v[q] = gt[q] > 0.f ? v[q] : 0.f;
                     }
                     if (Y) *reinterpret_cast<f32x4*>(Y + r * y_ld + col) = v;
+                    if (y_row_bits) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                     if (head_w) {
                         const f32x4 h4 = *reinterpret_cast<const f32x4*>(head_w + col);
                         hpart += v[0] * h4[0];
@@ -375,6 +380,15 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
                 }
                 acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            if (y_row_bits) {                   // (uniform) the output's own row maxima for the NEXT row-scaled kernel: no pass over Y
+                ymax = fmaxf(ymax, __shfl_xor(ymax, 16, 64));
+                ymax = fmaxf(ymax, __shfl_xor(ymax, 32, 64));
+                if (lg == 0 && r < M) {
+                    if (ncb == 1) y_row_bits[r] = __builtin_bit_cast(unsigned int, ymax);            // the row is complete in this workgroup
+                    else if (ymax > 0.f) atomicMax(y_row_bits + r, __builtin_bit_cast(unsigned int, ymax));     // one per column block
+                }
+                if (r < M) run_max = fmaxf(run_max, ymax);      // the tensor's maximum: ONE atomic per workgroup, after its last tile
+            }
             if (head_w) {                       // the row's other columns of this block live in the other three lane groups
                 hpart += __shfl_xor(hpart, 16, 64);
                 hpart += __shfl_xor(hpart, 32, 64);
@@ -383,20 +397,33 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
         }
         cur = nxt;
     }
+    if (y_all_bits) {                                       // (uniform) a same-address atomic per wave and tile cost 90 us per launch
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o, 64));
+        float* wmx = reinterpret_cast<float*>(Wb);          // the W stages are dead behind the loop's last barrier
+        if (lane == 0) wmx[wave] = run_max;
+        __syncthreads();
+        if (tid == 0) {
+            float m = wmx[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) m = fmaxf(m, wmx[q]);
+            if (m > 0.f) atomicMax(y_all_bits, __builtin_bit_cast(unsigned int, m));
+        }
+    }
 }
 
 template <int CT, int NP = 3, bool RS = false>
 static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const unsigned char* img, const float* bias, int relu,
                              const float* ps, const float* psh, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, int nks, int ncb,
                              float* Y, int64_t y_ld, const float* head_w = nullptr, float* head_part = nullptr,
-                             const unsigned int* row_bits = nullptr) {
+                             const unsigned int* row_bits = nullptr, unsigned int* y_row_bits = nullptr, unsigned int* y_all_bits = nullptr) {
     const size_t shmem = 2 * (size_t)NP * CT * 1024;
     static LdsOnce once;
     (void)lds_limit(once, 160 * 1024, &dense_bf3_k<CT, NP, RS>);
     const int64_t ntiles = (M + DB3_ROWS - 1) / DB3_ROWS * ncb;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;         // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
     hipLaunchKernelGGL((dense_bf3_k<CT, NP, RS>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
-                       nks, ncb, Y, y_ld, head_w, head_part, row_bits);
+                       nks, ncb, Y, y_ld, head_w, head_part, row_bits, y_row_bits, y_all_bits);
 }
 
 // row_bits[r] = bit pattern of max_k |X[r, k]| (non-negative floats order like their bits); *all_bits = the maximum over all rows.  A lane
@@ -518,7 +545,8 @@ extern "C" int dir_dense_bf16x3_pack_f32(const float* W, int64_t w_ld, int Kd, i
 
 static int dense_run(const char* name, int pieces, const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                      const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
-                     dir_stream_t stream, const unsigned int* row_bits = nullptr) {
+                     dir_stream_t stream, const unsigned int* row_bits = nullptr, unsigned int* y_row_bits = nullptr,
+                     unsigned int* y_all_bits = nullptr) {
     DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && y_ld >= N, "%s: bad shape", name);
     DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
     DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
@@ -535,9 +563,9 @@ static int dense_run(const char* name, int pieces, const float* X, int64_t x_ld,
     const unsigned char* img = static_cast<const unsigned char*>(image);
     const int relu = act == DIR_ACT_RELU;
     if (pieces == 2 && row_bits) {
-        if (CT == 8) launch_dense_bf3<8, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits);
-        else if (CT == 13) launch_dense_bf3<13, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits);
-        else launch_dense_bf3<16, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits);
+        if (CT == 8) launch_dense_bf3<8, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits, y_row_bits, y_all_bits);
+        else if (CT == 13) launch_dense_bf3<13, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits, y_row_bits, y_all_bits);
+        else launch_dense_bf3<16, 2, true>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld, nullptr, nullptr, row_bits, y_row_bits, y_all_bits);
     } else if (pieces == 2) {
         if (CT == 8) launch_dense_bf3<8, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
         else if (CT == 13) launch_dense_bf3<13, 2>(st, X, x_ld, img, bias, relu, post_scale, post_shift, gate, gate_ld, M, Kd, N, nks, ncb, Y, y_ld);
@@ -564,9 +592,20 @@ extern "C" int dir_dense_f16x2_f32(const float* X, int64_t x_ld, const void* ima
 // row_bits (dir_row_absmax_bits_f32), exact; gate as in dir_dense_bf16x3_f32
 extern "C" int dir_dense_f16x2_rows_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                                         const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y,
-                                        int64_t y_ld, const unsigned int* row_bits, dir_stream_t stream) {
+                                        int64_t y_ld, const unsigned int* row_bits, unsigned int* y_row_bits_out, unsigned int* y_all_bits_out,
+                                        dir_stream_t stream) {
     DIR_CHECK_ARG(row_bits || M == 0, "dir_dense_f16x2_rows_f32: row_bits is null");
-    return dense_run("dir_dense_f16x2_rows_f32", 2, X, x_ld, image, bias, act, post_scale, post_shift, gate, gate_ld, M, Kd, N, Y, y_ld, stream, row_bits);
+    DIR_CHECK_ARG((y_row_bits_out == nullptr) == (y_all_bits_out == nullptr), "dir_dense_f16x2_rows_f32: y_row_bits_out and y_all_bits_out come together");
+    if (y_row_bits_out && M > 0 && N > 0) {               // what the epilogue's atomicMax needs zeroed (one column block: plain stores of the rows' bits)
+        const int CT = db3_ct_for(N);
+        const int ncb = ((N + 15) / 16 + CT - 1) / CT;
+        hipStream_t st = as_stream(stream);
+        if (zero_async(y_all_bits_out, sizeof(unsigned int), st) != hipSuccess ||
+            (ncb > 1 && zero_async(y_row_bits_out, (size_t)M * sizeof(unsigned int), st) != hipSuccess))
+            return fail(DIR_E_HIP, "dir_dense_f16x2_rows_f32: zeroing failed");
+    }
+    return dense_run("dir_dense_f16x2_rows_f32", 2, X, x_ld, image, bias, act, post_scale, post_shift, gate, gate_ld, M, Kd, N, Y, y_ld, stream, row_bits,
+                     y_row_bits_out, y_all_bits_out);
 }
 
 extern "C" int dir_row_absmax_workspace_words(void) { return 1 + kCUs * 8; }      // [ticket | block maxima]

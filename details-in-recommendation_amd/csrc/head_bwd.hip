@@ -21,7 +21,9 @@ constexpr int HB_MAXCH = 4;          // float4 column chunks per thread: N <= 4 
 template <int TPR>
 __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ y,
                                                    int64_t y_ld, int64_t B, int N, int64_t rows_per_block, float* __restrict__ gx,
-                                                   int64_t gx_ld, float* __restrict__ part) {
+                                                   int64_t gx_ld, float* __restrict__ part,
+                                                   unsigned int* __restrict__ row_bits = nullptr /* [B]: bit pattern of an upper bound of max_n |gx[r, n]| */,
+                                                   unsigned int* __restrict__ all_bits = nullptr /* the same over all rows: written by workgroup 0 */) {
     constexpr int RPI = 256 / TPR;
     __shared__ float4 red[2][256];
     const int tid = threadIdx.x, c0 = tid % TPR, rr = tid / TPR;
@@ -35,8 +37,39 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
         wv[ch] = c < nv ? *reinterpret_cast<const float4*>(w + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
         sx[ch] = sw[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // row_bits: |g[r]| * max_n |w[n]| bounds row r of gx (it IS the row's maximum when the unit of the largest |w| is active; the fp32
+    // product is monotonic, so the bound is never below a |g[r] * w[n]|) -- what the row-scaled fp16 x 2 kernel needs, without a pass over gx
+    float wmax = 0.f;
+    if (row_bits) {                                  // (uniform)
+        float m = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < HB_MAXCH; ++ch)
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(wv[ch].x), fabsf(wv[ch].y))), fmaxf(fabsf(wv[ch].z), fabsf(wv[ch].w)));
+        float* rf = reinterpret_cast<float*>(&red[0][0]);
+        rf[tid] = m;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) rf[tid] = fmaxf(rf[tid], rf[tid + o]);
+            __syncthreads();
+        }
+        wmax = rf[0];
+        __syncthreads();
+        if (all_bits && blockIdx.x == 0) {           // max_r |g[r]| * wmax: workgroup 0 walks the B gradients itself (256 KB at B = 65 536) -- no
+            float gm = 0.f;                          // atomics (a same-address atomic per workgroup cost 45 us here), nothing to zero
+            for (int64_t r = tid; r < B; r += 256) gm = fmaxf(gm, fabsf(g[r] * wmax));
+            rf[tid] = gm;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) rf[tid] = fmaxf(rf[tid], rf[tid + o]);
+                __syncthreads();
+            }
+            if (tid == 0) *all_bits = __builtin_bit_cast(unsigned int, rf[0]);
+            __syncthreads();
+        }
+    }
     for (int64_t r = r0 + rr; r < r1; r += RPI) {
         const float gr = g[r];
+        if (row_bits && c0 == 0) row_bits[r] = __builtin_bit_cast(unsigned int, fabsf(gr * wmax));
 #pragma unroll
         for (int ch = 0; ch < HB_MAXCH; ++ch) {
             const int c = c0 + ch * TPR;
@@ -158,9 +191,9 @@ extern "C" int64_t dir_units1_relu_backward_partials(int64_t B, int N) {
     return hb_plan(B, N).nblk;
 }
 
-extern "C" int dir_units1_relu_backward_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx,
-                                            int64_t gx_ld, float* partials, int64_t n_partials, dir_stream_t stream) {
-    const char* name = "dir_units1_relu_backward_f32";
+static int units1_relu_backward(const char* name, const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx,
+                                int64_t gx_ld, float* partials, int64_t n_partials, unsigned int* row_bits, unsigned int* all_bits,
+                                dir_stream_t stream) {
     DIR_CHECK_ARG(B >= 0 && N > 0, "%s: B=%lld N=%d", name, (long long)B, N);
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(g && w && y && gx && partials, "%s: null pointer", name);
@@ -175,13 +208,32 @@ extern "C" int dir_units1_relu_backward_f32(const float* g, const float* w, cons
                   (long long)n_partials, (long long)p.nblk);
     hipStream_t st = as_stream(stream);
     if (p.tpr == 64)
-        hipLaunchKernelGGL(head_bwd_k<64>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials);
+        hipLaunchKernelGGL(head_bwd_k<64>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials, row_bits,
+                           all_bits);
     else if (p.tpr == 128)
-        hipLaunchKernelGGL(head_bwd_k<128>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials);
+        hipLaunchKernelGGL(head_bwd_k<128>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials,
+                           row_bits, all_bits);
     else
-        hipLaunchKernelGGL(head_bwd_k<256>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials);
+        hipLaunchKernelGGL(head_bwd_k<256>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials,
+                           row_bits, all_bits);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+extern "C" int dir_units1_relu_backward_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx,
+                                            int64_t gx_ld, float* partials, int64_t n_partials, dir_stream_t stream) {
+    return units1_relu_backward("dir_units1_relu_backward_f32", g, w, y, y_ld, B, N, gx, gx_ld, partials, n_partials, nullptr, nullptr, stream);
+}
+
+// ... and the bit patterns of an upper bound of every gx row's largest |element| (|g[r]| max_n |w[n]|) and of their maximum (all_bits: one
+// unsigned; neither needs zeroing): the scales of the fp16 x 2 backward kernels that consume gx (dir_dense_f16x2_rows_f32,
+// dir_dense_dw_f16x2_f32), without a pass over gx
+extern "C" int dir_units1_relu_backward_bits_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx,
+                                                 int64_t gx_ld, float* partials, int64_t n_partials, unsigned int* gx_row_bits,
+                                                 unsigned int* gx_all_bits, dir_stream_t stream) {
+    DIR_CHECK_ARG(B == 0 || (gx_row_bits && gx_all_bits), "dir_units1_relu_backward_bits_f32: null pointer");
+    return units1_relu_backward("dir_units1_relu_backward_bits_f32", g, w, y, y_ld, B, N, gx, gx_ld, partials, n_partials, gx_row_bits, gx_all_bits,
+                                stream);
 }
 
 extern "C" int64_t dir_units1_backward_partials(int64_t B, int N) {

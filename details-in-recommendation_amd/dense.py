@@ -113,7 +113,7 @@ def _wb_grads(g, x, need_w, need_b, g_bits=None):
     return (_tn_matmul(g, x, g_bits=g_bits) if need_w else None), (g.sum(dim=0) if need_b else None)
 
 
-def _gbits(g, x_bounded, Kin, need_x=True, need_w=True):
+def _gbits(g, x_bounded, Kin, need_x=True, need_w=True, carried=None):
     """(row_bits, g_bits) for the fp16 x 2 backward kernels of one layer with Kin inputs: row_bits for dL/dx = g W (its other operand is the
     weight), g_bits for dL/dW = g^T x only when the layer's input x is bounded by construction (None otherwise: bf16 x 3).  (None, None)
     when neither product would run a split-arithmetic kernel at this shape (then the max pass over g is not run either)."""
@@ -124,7 +124,7 @@ def _gbits(g, x_bounded, Kin, need_x=True, need_w=True):
     allb = need_w and x_bounded and ops.dense_dw_auto_arith(M, N, Kin) == "bf16x3"
     if not (rows or allb):
         return None, None
-    gb = ops.grad_bits(g, want_all=allb)
+    gb = carried if carried is not None else ops.grad_bits(g, want_all=allb)      # carried: left by the kernel that produced g
     if gb is None:
         return None, None
     return (gb[0] if rows else None), (gb[1] if allb else None)
@@ -233,13 +233,16 @@ class _MlpStackFn(torch.autograd.Function):
         g = (g * (ys[-1] > 0)).contiguous()
         grads = [None] * (2 * L)
         gx = None
+        carried = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
-            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[1 + 2 * l])
+            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[1 + 2 * l], carried)
             grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l], g_bits=ab)
             wt = _kernel_weight(g, ws[l].t())
             if l > 0:
-                g = ops.dense_gated(g, wt, xin, row_bits=rb)
+                left = []                           # the row-scaled kernel leaves its output's row / tensor maxima: the next layer's scales
+                g = ops.dense_gated(g, wt, xin, row_bits=rb, bits_out=left)
+                carried = left[0] if left else None
             elif ctx.needs_input_grad[0]:
                 gx = ops.dense(g, wt, None, relu=False, row_bits=rb)
         return (gx,) + tuple(grads)
@@ -275,12 +278,12 @@ class _MlpHeadFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         x, head_w, ws, ys = saved[0], saved[1], saved[2:2 + L], saved[2 + L:]
         g_head_b = g.reshape(-1).sum(dim=0, keepdim=True) if ctx.needs_input_grad[2] else None
-        g, gw_head, gb_top = ops.units1_relu_backward(g, head_w, ys[-1])
+        g, gw_head, gb_top, carried = ops.units1_relu_backward(g, head_w, ys[-1], want_bits=True)
         grads = [None] * (2 * L)
         gx = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
-            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[3 + 2 * l])
+            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[3 + 2 * l], carried)
             if l == L - 1:                                           # the top layer's bias gradient came with the head's backward
                 grads[2 * l] = _tn_matmul(g, xin, g_bits=ab) if ctx.needs_input_grad[3 + 2 * l] else None
                 grads[2 * l + 1] = gb_top if ctx.needs_input_grad[4 + 2 * l] else None
@@ -288,7 +291,9 @@ class _MlpHeadFn(torch.autograd.Function):
                 grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l], g_bits=ab)
             wt = _kernel_weight(g, ws[l].t())
             if l > 0:
-                g = ops.dense_gated(g, wt, xin, row_bits=rb)
+                left = []
+                g = ops.dense_gated(g, wt, xin, row_bits=rb, bits_out=left)
+                carried = left[0] if left else None
             elif ctx.needs_input_grad[0]:
                 gx = ops.dense(g, wt, None, relu=False, row_bits=rb)
         return (gx, gw_head.reshape(1, -1) if ctx.needs_input_grad[1] else None, g_head_b) + tuple(grads)

@@ -550,6 +550,9 @@ DENSE_BWD_SPLIT = os.environ.get("DIR_DENSE_BWD_SPLIT", "f16x2")
 # row-scaled fp16 x 2 kernel behind one max pass over x (any magnitudes: a raw numeric column of 99 999 next to 0.1-scale embeddings; error
 # relative to each row's largest element 2^-22 .. 2^-39, i.e. below fp32's own rounding of the row's dot products) | "bf16x3"
 DENSE_GENERAL_SPLIT = os.environ.get("DIR_DENSE_GENERAL_SPLIT", "f16x2_rows")
+# development switch: 0 = every fp16 x 2 backward kernel gets its scales from a max pass of its own (dir_row_absmax_bits_f32) instead of from
+# the kernel that produced the gradient
+DENSE_BWD_CARRY = os.environ.get("DIR_DENSE_BWD_CARRY", "1") != "0"
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
 
@@ -610,6 +613,17 @@ def row_absmax_bits(x, want_all=True):
     return rb, (ab if want_all else None)
 
 
+def _out_bits(bits_out, M, device):
+    """A (row_bits [M], all_bits [1]) pair for a kernel epilogue to fill (the C entry zeroes what it must), appended to the caller's list;
+    (None, None) if not wanted."""
+    if bits_out is None or not DENSE_BWD_CARRY:
+        return None, None
+    buf = torch.empty(M + 4, dtype=torch.int32, device=device)
+    pair = (buf[:M], buf[M:M + 1])
+    bits_out.append(pair)
+    return pair
+
+
 def _rows_covered(x):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= DENSE_BF3_MIN_ROWS and x.shape[1] % 4 == 0
             and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
@@ -660,7 +674,7 @@ def _dense_arith(arith, x, weight, out, gate):
     return arith
 
 
-def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None, arith=None, row_bits=None):
+def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None, arith=None, row_bits=None, bits_out=None):
     """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32 / dir_dense_bf16x3_f32).  x [M, Kd], weight [N, Kd] (nn.Linear
     layout), bias [N].  post_scale / post_shift [N]: the inference batch-norm that follows the activation, as
     y * post_scale + post_shift in the same pass.  arith: "f32" (fp32 MFMA), "bf16x3" (three-way bf16 split of both operands on the
@@ -669,7 +683,8 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     place of bf16x3): for layers whose input is bounded by construction -- embedding concatenations, ReLU / batch-normalised
     activations, the CIN's pooled products (|x|, |W| < 65 504).
     row_bits (grad_bits(x)[0]): x is a gradient; where "auto" would run bf16x3 the row-scaled fp16 x 2 kernel runs
-    (dir_dense_f16x2_rows_f32)."""
+    (dir_dense_f16x2_rows_f32).  bits_out (a list): when that kernel ran, (row_bits, all_bits) of the OUTPUT is appended -- its epilogue
+    leaves them, for the next layer of a backward chain."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     M, Kd = x.shape
@@ -700,9 +715,10 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
                                                    _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
         return out
     if which == "f16x2_rows":
+        yb = _out_bits(bits_out, M, x.device)
         _lib.check(_lib.load().dir_dense_f16x2_rows_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), _ptr(bias), 1 if relu else 0,
                                                         _ptr(post_scale), _ptr(post_shift), None, 0, M, Kd, N, _ptr(out), out.stride(0),
-                                                        _ptr(row_bits), _stream()))
+                                                        _ptr(row_bits), _ptr(yb[0]), _ptr(yb[1]), _stream()))
         return out
     if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0,
@@ -904,7 +920,7 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
     return out
 
 
-def dense_gated(x, weight, gate, out=None, arith=None, row_bits=None):
+def dense_gated(x, weight, gate, out=None, arith=None, row_bits=None, bits_out=None):
     """where(gate > 0, x @ weight.T, 0) (include/dir_hip.h: dir_dense_gated_f32 / dir_dense_bf16x3_f32 with a gate): x [M, Kd],
     weight [N, Kd], gate [M, N].  row_bits (grad_bits(x)[0]): where "auto" would run bf16x3 the row-scaled fp16 x 2 kernel runs."""
     _dev(x, torch.float32, "x")
@@ -920,8 +936,10 @@ def dense_gated(x, weight, gate, out=None, arith=None, row_bits=None):
     if not use_bf3 and (weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16):
         weight = weight.contiguous()
     if use_bf3 and row_bits is not None and (arith or DENSE_ARITH) == "auto":
+        yb = _out_bits(bits_out, M, x.device)
         _lib.check(_lib.load().dir_dense_f16x2_rows_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), None, 0, None, None, _ptr(gate),
-                                                        gate.stride(0), M, Kd, N, _ptr(out), out.stride(0), _ptr(row_bits), _stream()))
+                                                        gate.stride(0), M, Kd, N, _ptr(out), out.stride(0), _ptr(row_bits), _ptr(yb[0]), _ptr(yb[1]),
+                                                        _stream()))
         return out
     if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), None, 0, None, None, _ptr(gate),
@@ -1011,10 +1029,12 @@ def units1_relu_backward_supported(y):
             and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0)
 
 
-def units1_relu_backward(g, w, y):
+def units1_relu_backward(g, w, y, want_bits=False):
     """Backward of logit = y . w + bias (units = 1; deepFM.py:311-317, ESMM.py:146) through y = relu(pre) in one pass
     (include/dir_hip.h: dir_units1_relu_backward_f32).  g [B] or [B, 1] = dL/dlogit, w [N] or [1, N], y [B, N] ->
-    (dpre [B, N] = where(y > 0, g * w, 0), dw [N] = sum_b g * y, dbias_y [N] = sum_b dpre)."""
+    (dpre [B, N] = where(y > 0, g * w, 0), dw [N] = sum_b g * y, dbias_y [N] = sum_b dpre).  want_bits: a fourth result, (row_bits [B],
+    all_bits [1]) int32 -- upper bounds of dpre's row maxima and of max |dpre| as bit patterns (dir_units1_relu_backward_bits_f32), what
+    grad_bits(dpre) would otherwise make a pass over dpre for; None when the fp16 x 2 backward is off."""
     _dev(g, torch.float32, "g")
     _dev(w, torch.float32, "w")
     _dev(y, torch.float32, "y")
@@ -1032,11 +1052,18 @@ def units1_relu_backward(g, w, y):
     P = int(lib.dir_units1_relu_backward_partials(B, N))
     if P == 0:
         z = torch.zeros(N, dtype=torch.float32, device=y.device)
-        return gx, z, z.clone()
+        return (gx, z, z.clone(), None) if want_bits else (gx, z, z.clone())
     part = torch.empty((P, 2, N), dtype=torch.float32, device=y.device)
-    _lib.check(lib.dir_units1_relu_backward_f32(_ptr(g), _ptr(w), _ptr(y), y.stride(0), B, N, _ptr(gx), gx.stride(0), _ptr(part), P, _stream()))
+    bits = None
+    if want_bits and DENSE_BWD_CARRY and DENSE_BWD_SPLIT == "f16x2" and DENSE_ARITH == "auto" and B >= DENSE_BF3_MIN_ROWS:
+        buf = torch.empty(B + 4, dtype=torch.int32, device=y.device)
+        bits = (buf[:B], buf[B:B + 1])
+        _lib.check(lib.dir_units1_relu_backward_bits_f32(_ptr(g), _ptr(w), _ptr(y), y.stride(0), B, N, _ptr(gx), gx.stride(0), _ptr(part), P,
+                                                         _ptr(bits[0]), _ptr(bits[1]), _stream()))
+    else:
+        _lib.check(lib.dir_units1_relu_backward_f32(_ptr(g), _ptr(w), _ptr(y), y.stride(0), B, N, _ptr(gx), gx.stride(0), _ptr(part), P, _stream()))
     s = part[0] if P == 1 else part.sum(dim=0)
-    return gx, s[1], s[0]
+    return (gx, s[1], s[0], bits) if want_bits else (gx, s[1], s[0])
 
 
 def units1_backward(g, w, x, want_gx=True):

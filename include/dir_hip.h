@@ -468,9 +468,13 @@ int dir_dense_f16x2_f32(const float* X, int64_t x_ld, const void* image, const f
 int dir_row_absmax_workspace_words(void);
 int dir_row_absmax_bits_f32(const float* X, int64_t x_ld, int64_t M, int N, unsigned int* row_bits, unsigned int* all_bits,
                             unsigned int* workspace, dir_stream_t stream);
+/* y_row_bits_out [M] / y_all_bits_out [1] (DEVICE, both or neither; zeroed here where needed): the kernel's epilogue leaves the bit patterns of
+ * max_n |Y[r, n]| and of max |Y| there (atomicMax per column block) -- in a backward chain Y is the next layer's gradient, whose row-scaled
+ * kernels then need no max pass of their own.  dir_units1_relu_backward_bits_f32 does the same for the chain's first gradient (an upper
+ * bound |g[r]| max_n |w[n]| per row). */
 int dir_dense_f16x2_rows_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
                              const float* post_shift, const float* gate, int64_t gate_ld, int64_t M, int Kd, int N, float* Y, int64_t y_ld,
-                             const unsigned int* row_bits, dir_stream_t stream);
+                             const unsigned int* row_bits, unsigned int* y_row_bits_out, unsigned int* y_all_bits_out, dir_stream_t stream);
 /* dir_dense_bf16x3_head_f32 on the fp16 x 2 arithmetic (the image from dir_dense_f16x2_pack_strided_f32): the last deep layer of DCN reads a
  * batch-normalised ReLU activation (DeepCrossNetwork.py:400-403) -- bounded by construction. */
 int dir_dense_f16x2_head_f32(const float* X, int64_t x_ld, const void* image, const float* bias, int act, const float* post_scale,
@@ -575,6 +579,9 @@ int dir_dense_dw_small_f32(const float* g, int64_t g_ld, const float* x, int64_t
 int64_t dir_units1_relu_backward_partials(int64_t B, int N);
 int dir_units1_relu_backward_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx, int64_t gx_ld,
                                  float* partials, int64_t n_partials, dir_stream_t stream);
+int dir_units1_relu_backward_bits_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx, int64_t gx_ld,
+                                      float* partials, int64_t n_partials, unsigned int* gx_row_bits, unsigned int* gx_all_bits,
+                                      dir_stream_t stream);
 
 /* The units = 1 logit layer on top of an activation of any width that is not a ReLU output -- DCN's cross output under the final dense(1)
  * over concat([cross, deep]) (models/DeepCrossNetwork/DeepCrossNetwork.py:136-137), d = 429: gx[b,n] = g[b] * w[n] (gx NULL: skipped),

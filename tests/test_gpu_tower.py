@@ -336,8 +336,22 @@ def test_dense_backward_on_scaled_fp16x2(built_lib, M, N, K, gate):
     rb2, _ = ops.grad_bits(g2)
     got2 = ops.dense_gated(g2, W.t(), gt, row_bits=rb2) if gate else ops.dense(g2, W.t(), row_bits=rb2)
     assert torch.equal(got2, got * pw)
-    again = ops.dense_gated(g, W.t(), gt, row_bits=rb) if gate else ops.dense(g, W.t(), row_bits=rb)
+    left = []                                   # the kernel's epilogue leaves its OUTPUT's row / tensor maxima (the next layer's scales): exact
+    again = ops.dense_gated(g, W.t(), gt, row_bits=rb, bits_out=left) if gate else ops.dense(g, W.t(), row_bits=rb, bits_out=left)
     assert torch.equal(again, got)
+    assert torch.equal(left[0][0], got.abs().amax(dim=1).view(torch.int32)) and int(left[0][1]) == int(got.abs().max().view(torch.int32))
+    # the chain's first gradient: dir_units1_relu_backward_bits_f32 leaves upper bounds |g[r]| max|w| of its rows (tight when the largest
+    # weight's unit is active), never below the row's true maximum
+    yact = torch.relu(torch.randn((M, K), generator=gen, device="cuda"))
+    g1 = torch.randn(M, generator=gen, device="cuda") * 1e-3
+    w1 = torch.randn(K, generator=gen, device="cuda")
+    dpre, dw1, db1, bits1 = ops.units1_relu_backward(g1, w1, yact, want_bits=True)
+    plain = ops.units1_relu_backward(g1, w1, yact)
+    assert torch.equal(dpre, plain[0]) and torch.equal(dw1, plain[1]) and torch.equal(db1, plain[2])
+    true_rows = dpre.abs().amax(dim=1)
+    bound = bits1[0].view(torch.float32)
+    assert bool((bound >= true_rows).all()) and bool(torch.equal(bound, (g1 * w1.abs().max()).abs()))
+    assert float(bits1[1].view(torch.float32)) == float(bound.max())
     # dL/dW, dL/db
     if ops.dense_dw_auto_arith(M, N, K) != "bf16x3":
         return
