@@ -6,6 +6,11 @@ Mirrors models/ESMM/ESMM.py (reference):
   _base_model: input_layer -> (dense(act, glorot_normal))* -> dense(1)       :130-147
   predictions: ctr/cvr sigmoid, ctcvr = product, ctcvr_logits = logit(clip(p, 1e-7, 1-1e-7))   :67-92
 SURVEY.md 8(f) rank 3: the same gather kernel, used twice per step.
+
+ESMM_W_D mirrors models/ESMM/ESMM_wide_deep.py (the wide & deep variant): every sub-model's logits are dnn_logits + linear_logits
+  ESMM_W_D.__init__ kwargs                                  :75-99
+  _base_model: dnn_logit_fn(units=1) + linear_logit_fn(units=1), summed        :194-280
+  _linear_learning_rate = min(0.2, 1 / sqrt(#linear columns)), _DNN_LEARNING_RATE = 0.05    :30,33,72-73
 """
 import torch
 from torch import nn
@@ -55,6 +60,71 @@ class _BaseModel(nn.Module):
             net = dense_act(lin, net, self.activation)                           # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.dropout)                        # ESMM.py:143-144 (TRAIN only)
         return units1(self.logits, net)
+
+
+class _LinearModel(nn.Module):
+    """linear_model(units=1, sparse_combiner='sum') over categorical columns + bias (ESMM_wide_deep.py:247-262 ->
+    [TF-upstream] _linear_logit_fn_builder): one weight per feature value (zeros-initialised, as TF's linear model) and a bias;
+    one-hot columns run dir_linear_sparse_sum_f32 (ops.linear_logit) / its autograd node, multi-hot columns the bag kernel with K = 1."""
+
+    def __init__(self, columns, sparse_combiner="sum"):
+        super().__init__()
+        from ._input import categorical_of
+        self.columns = list(columns)
+        self.sparse_combiner = sparse_combiner
+        self.weights = nn.ParameterList([nn.Parameter(torch.zeros(categorical_of(c).num_buckets)) for c in self.columns])
+        self.bias = nn.Parameter(torch.zeros(1))
+        self._ts = None
+
+    def _tableset(self):
+        from . import ops
+        key = tuple(p.data_ptr() for p in self.weights)
+        if self._ts is None or self._ts[0] != key:
+            ts = ops.TableSet([p.data for p in self.weights])
+            ts.owners = list(self.weights)
+            self._ts = (key, ts)
+        return self._ts[1]
+
+    def forward(self, features, memo=None):
+        from . import ops
+        from . import autograd as ag
+        from ._input import collect_ids
+        ts = self._tableset()
+        got = collect_ids(self.columns, features, self.bias.device, memo)
+        train = torch.is_grad_enabled()
+        if got[0] == "onehot":
+            if train:
+                return ag.linear_logit(ts, got[1], self.bias, list(self.weights))
+            return ops.linear_logit(ts, got[1], bias=self.bias.data)
+        _, vals, offs, wts, B = got
+        if not train:
+            return ops.linear_logit(ts, vals, offs, wts, combiner=self.sparse_combiner, bias=self.bias.data, field_major=True)
+        per = ag.embedding_bag(ts, vals, list(self.weights), combiner=self.sparse_combiner, offsets=offs, weights=wts, field_major=True)
+        return per.view(B, len(self.columns), 1).sum(dim=1) + self.bias
+
+
+class _BaseModelWD(nn.Module):
+    """_base_model of ESMM_wide_deep.py:194-280: dnn tower logits + linear model logits (either part may be absent)."""
+
+    def __init__(self, linear_columns, dnn_columns, hidden_units, activation, dropout=None):
+        super().__init__()
+        if not linear_columns and not dnn_columns:
+            raise ValueError("Either linear_feature_columns or dnn_feature_columns must be defined.")          # :209-211
+        if dnn_columns and not hidden_units:
+            raise ValueError("dnn_hidden_units must be defined when dnn_feature_columns is specified.")          # :228-231
+        self.dnn = _BaseModel(dnn_columns, hidden_units, activation, dropout) if dnn_columns else None
+        self.linear = _LinearModel(linear_columns) if linear_columns else None
+
+    def forward(self, features, memo=None):
+        if not isinstance(features, dict):
+            raise ValueError("features should be a dictionary of `Tensor`s. Given type: {}".format(type(features)))   # :206-208
+        logits = None
+        if self.dnn is not None:
+            logits = self.dnn(features, memo)
+        if self.linear is not None:
+            lin = self.linear(features, memo)
+            logits = lin if logits is None else logits + lin                     # :265-270
+        return logits
 
 
 class ESMM(nn.Module):
@@ -111,3 +181,34 @@ class ESMM(nn.Module):
         return {"probabilities": torch.softmax(two, dim=-1), "logistic": ctcvr_logistic,             # :88-91
                 "class_ids": torch.argmax(two, dim=-1, keepdim=True), "ctr_logistic": ctr_logistic,
                 "ctr_logits": out["ctr_logits"], "ctcvr_logits": out["ctcvr_logits"]}
+
+
+class ESMM_W_D(ESMM):
+    """The wide & deep ESMM (models/ESMM/ESMM_wide_deep.py:75-99): ctr_model and cvr_model are each dnn tower + linear model over their OWN
+    variables; predictions, loss and metrics as ESMM (the reference's two files share them line for line).  linear_optimizer / dnn_optimizer
+    are stored (the reference's defaults: Ftrl at min(0.2, 1 / sqrt(#linear columns)), Adagrad at 0.05 -- learning_rates())."""
+
+    def __init__(self, model_dir=None, linear_feature_columns=None, dnn_feature_columns=None, linear_optimizer="Ftrl",
+                 ctr_weight_column=None, ctcvr_weight_column=None, dnn_hidden_units=None, dnn_dropout=None, config=None,
+                 dnn_optimizer="Adagrad", input_layer_partitioner=None, dnn_activation_fn=torch.relu):
+        nn.Module.__init__(self)
+        self.hparams = dict(model_dir=model_dir, ctr_weight_column=ctr_weight_column, ctcvr_weight_column=ctcvr_weight_column,
+                            dnn_dropout=dnn_dropout, config=config, linear_optimizer=linear_optimizer, dnn_optimizer=dnn_optimizer,
+                            input_layer_partitioner=input_layer_partitioner)
+        lin, dnn, hidden = list(linear_feature_columns or []), list(dnn_feature_columns or []), list(dnn_hidden_units or [])
+        self.n_linear_columns = len(lin)
+        self.ctr_model = _BaseModelWD(lin, dnn, hidden, dnn_activation_fn, dnn_dropout)           # ESMM_wide_deep.py:103-114
+        self.cvr_model = _BaseModelWD(lin, dnn, hidden, dnn_activation_fn, dnn_dropout)           # :115-126
+
+    def learning_rates(self):
+        """(linear, dnn) learning rates of the reference's default optimisers (ESMM_wide_deep.py:30,33,72-73)."""
+        import math
+        return (min(0.2, 1.0 / math.sqrt(self.n_linear_columns)) if self.n_linear_columns else 0.2), 0.05
+
+    def fused_sparse_adagrad(self, lr, initial_accumulator_value=0.1):
+        from . import ops
+        a = self.ctr_model.dnn.input_layer.fused_sparse_adagrad(lr, initial_accumulator_value) if self.ctr_model.dnn is not None else []
+        b = self.cvr_model.dnn.input_layer.fused_sparse_adagrad(lr, initial_accumulator_value) if self.cvr_model.dnn is not None else []
+        for x, y in zip(a, b):
+            ops.share_sorted_entries(x, y)
+        return a + b

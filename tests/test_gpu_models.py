@@ -277,6 +277,79 @@ def test_esmm_two_towers(built_lib, oracle):
     assert model.ctr_model.input_layer.embedding_weights[0].data_ptr() != model.cvr_model.input_layer.embedding_weights[0].data_ptr()
 
 
+def test_esmm_wide_deep(built_lib, oracle):
+    """models/ESMM/ESMM_wide_deep.py: every sub-model = dnn tower + linear model over its own variables, logits summed (:194-270);
+    predictions as ESMM (:127-150).  Forward against a float64 restatement, a training step with finite sparse / dense gradients,
+    the reference's argument checks and default learning rates (:30,33,72-73)."""
+    from dir_amd.esmm import ESMM_W_D
+    from dir_amd import feature_column as fc
+    rng = np.random.default_rng(33)
+    B = 300
+    item = fc.categorical_column_with_identity("item", 500)
+    occupation = fc.categorical_column_with_hash_bucket("occupation", 1000)
+    rel = fc.categorical_column_with_vocabulary_list("rel", ["a", "b", "c", "d"])
+    dnn_cols = [fc.numeric_column("age"), fc.embedding_column(occupation, dimension=8), fc.embedding_column(item, dimension=8)]
+    lin_cols = [item, occupation, rel]
+    model = ESMM_W_D(linear_feature_columns=lin_cols, dnn_feature_columns=dnn_cols, dnn_hidden_units=[32, 16]).cuda()
+    assert model.learning_rates() == (min(0.2, 1.0 / np.sqrt(3)), 0.05)
+    with torch.no_grad():
+        for sub in (model.ctr_model, model.cvr_model):
+            for w in sub.linear.weights:
+                w.normal_(0, 0.1)
+            sub.linear.bias.fill_(0.3)
+    occ = [["Sales", "Tech", "?", "Exec"][i] for i in rng.integers(0, 4, size=B)]
+    rl = [["a", "b", "c", "d", "zz"][i] for i in rng.integers(0, 5, size=B)]
+    it = rng.integers(0, 500, size=B).astype(np.int64)
+    age = rng.uniform(0, 1, B).astype(np.float32)
+    feats = {"age": torch.from_numpy(age).cuda(), "rel": rl, "occupation": occ, "item": torch.from_numpy(it).cuda()}
+    with torch.no_grad():
+        out = model(feats)
+        pred = model.predict(feats)
+    occ_ids = R.hash_bucket_fast(occ, 1000)
+    rel_ids = np.array([("abcd".index(s_) if s_ in "abcd" else -1) for s_ in rl])
+
+    def sub_logits(t):
+        il = t.dnn.input_layer
+        names = [c.name for c in il.emb_cols]
+        parts = {"age": age.astype(np.float64)[:, None],
+                 "occupation_embedding": _np(il.embedding_weights[names.index("occupation_embedding")])[occ_ids],
+                 "item_embedding": _np(il.embedding_weights[names.index("item_embedding")])[it]}
+        assert [c.name for c in il.columns] == sorted(parts)
+        net = np.concatenate([parts[k] for k in sorted(parts)], 1)
+        for l in t.dnn.hidden:
+            net = R.relu(net @ _np(l.weight).T + _np(l.bias))
+        dnn = net @ _np(t.dnn.logits.weight).T + _np(t.dnn.logits.bias)
+        w_item, w_occ, w_rel = [_np(w) for w in t.linear.weights]
+        lin = w_item[it] + w_occ[occ_ids] + np.where(rel_ids >= 0, w_rel[np.maximum(rel_ids, 0)], 0.0) + 0.3      # OOV: no weight
+        return dnn + lin[:, None]
+
+    ctr, cvr = sub_logits(model.ctr_model), sub_logits(model.cvr_model)
+    _close(out["ctr_logits"].cpu().numpy(), ctr)
+    _close(out["cvr_logits"].cpu().numpy(), cvr)
+    p = np.clip(R.sigmoid(ctr) * R.sigmoid(cvr), 1e-7, 1 - 1e-7)
+    _close(out["ctcvr_logits"].cpu().numpy(), np.log(p / (1 - p)), tol=2e-5)
+    _close(pred["logistic"].cpu().numpy(), R.sigmoid(ctr) * R.sigmoid(cvr))
+    # a training step: the linear weights receive (sparse) gradients, the towers dense ones; loss of ESMM_wide_deep.py:283-309
+    labels = {"click_label": torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).cuda(),
+              "convert_label": torch.from_numpy((rng.random(B) < 0.1).astype(np.float32)).cuda()}
+    lg = model(feats)
+    loss, _ = model.get_loss(feats, labels, lg)
+    loss.backward()
+    assert bool(torch.isfinite(loss))
+    for sub in (model.ctr_model, model.cvr_model):
+        assert all(w.grad is not None for w in sub.linear.weights) and sub.linear.bias.grad is not None
+        assert all(l.weight.grad is not None and bool(torch.isfinite(l.weight.grad).all()) for l in sub.dnn.hidden)
+    # the reference's argument checks
+    with pytest.raises(ValueError):
+        ESMM_W_D(dnn_hidden_units=[8])
+    with pytest.raises(ValueError):
+        ESMM_W_D(dnn_feature_columns=dnn_cols)
+    only_wide = ESMM_W_D(linear_feature_columns=lin_cols).cuda()
+    with torch.no_grad():
+        z = only_wide(feats)
+    assert float(z["ctr_logits"].abs().max()) == 0.0                       # zero-initialised linear model
+
+
 def test_xdeepfm_forward(built_lib, oracle):
     from dir_amd.xdeepfm import XDeepFM
     from dir_amd import feature_column as fc
