@@ -1219,11 +1219,13 @@ def main():
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
     ev1.record()
+    issue = time.perf_counter() - t0           # host time to ISSUE the steps: close to the step time = the step is launch-bound on this host
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    cfg["host_issue_ms_per_step"] = round(issue / max(1, args.steps) * 1e3, 4)
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")

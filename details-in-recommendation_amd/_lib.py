@@ -107,6 +107,7 @@ SIGNATURES = {
     "dir_sparse_ftrl_sorted_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_float, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_adagrad_dense_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float, ctypes.c_float, c_vp]),
+    "dir_adagrad_dense_multi_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, ctypes.c_float, c_vp]),
     "dir_ftrl_dense_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp]),
     "dir_sparse_adagrad_sorted_rows_from_f32": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
                                                         ctypes.c_float, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),

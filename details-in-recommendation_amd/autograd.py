@@ -429,6 +429,7 @@ class Adagrad(torch.optim.Adagrad):
         rest = []
         for group in self.param_groups:
             plain = not group["lr_decay"] and not group["weight_decay"] and not group.get("maximize", False)
+            ws, sums, gs = [], [], []
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -439,7 +440,11 @@ class Adagrad(torch.optim.Adagrad):
                     continue
                 st = self.state[p]
                 st["step"] += 1
-                ops.adagrad_dense_(p, st["sum"], g, group["lr"], group["eps"])
+                ws.append(p)
+                sums.append(st["sum"])
+                gs.append(g)
+            if ws:                                 # all of the group's dense variables in one launch per 16 (dir_adagrad_dense_multi_f32)
+                ops.adagrad_dense_multi_(ws, sums, gs, group["lr"], group["eps"])
         if rest:                                   # the library's step for everything else: hide the gradients already applied
             held = [(p, p.grad) for group in self.param_groups for p in group["params"] if p.grad is not None and all(p is not r for r in rest)]
             for p, _ in held:

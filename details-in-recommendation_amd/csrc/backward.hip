@@ -787,9 +787,53 @@ __global__ __launch_bounds__(256) void adagrad_dense_k(float* __restrict__ w, fl
     }
 }
 
+// The same step for up to ADM_MAX variables in ONE launch (a DeepFM tower has 8 dense variables: eight launches of a few microseconds each were
+// 0.1 ms of host time per step): pointers and sizes travel in the kernel arguments, blockIdx.y = variable.
+constexpr int ADM_MAX = 16;
+struct AdagradMultiArgs { float* w[ADM_MAX]; float* acc[ADM_MAX]; const float* g[ADM_MAX]; int64_t n[ADM_MAX]; };
+__global__ __launch_bounds__(256) void adagrad_dense_multi_k(AdagradMultiArgs a, float lr, float eps) {
+    const int v = blockIdx.y;
+    float* __restrict__ w = a.w[v];
+    float* __restrict__ acc = a.acc[v];
+    const float* __restrict__ g = a.g[v];
+    const int64_t count = a.n[v];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float s = acc[i] + gi * gi;
+        acc[i] = s;
+        w[i] = w[i] - lr * (gi / (sqrtf(s) + eps));
+    }
+}
+
 }  // namespace dir
 
 using namespace dir;
+
+extern "C" int dir_adagrad_dense_multi_f32(float* const* w, float* const* accum, const float* const* grad, const int64_t* count, int n_vars,
+                                           float lr, float eps, dir_stream_t stream) {
+    const char* name = "dir_adagrad_dense_multi_f32";
+    DIR_CHECK_ARG(n_vars >= 0 && (n_vars == 0 || (w && accum && grad && count)), "%s: null pointer", name);      // HOST arrays of n_vars entries
+    for (int v0 = 0; v0 < n_vars; v0 += ADM_MAX) {
+        AdagradMultiArgs a;
+        const int nv = n_vars - v0 < ADM_MAX ? n_vars - v0 : ADM_MAX;
+        int64_t big = 0;
+        for (int v = 0; v < ADM_MAX; ++v) {
+            const bool in = v < nv;
+            a.w[v] = in ? w[v0 + v] : nullptr;
+            a.acc[v] = in ? accum[v0 + v] : nullptr;
+            a.g[v] = in ? grad[v0 + v] : nullptr;
+            a.n[v] = in ? count[v0 + v] : 0;
+            if (in) {
+                DIR_CHECK_ARG(a.n[v] >= 0 && (a.n[v] == 0 || (a.w[v] && a.acc[v] && a.g[v])), "%s: variable %d: null pointer or negative count", name, v0 + v);
+                if (a.n[v] > big) big = a.n[v];
+            }
+        }
+        if (big == 0) continue;
+        hipLaunchKernelGGL(adagrad_dense_multi_k, dim3(grid_for((big + 255) / 256, 4), (unsigned)nv), dim3(256), 0, as_stream(stream), a, lr, eps);
+        DIR_CHECK_LAUNCH(name);
+    }
+    return DIR_OK;
+}
 
 extern "C" int64_t dir_sparse_adagrad_sorted_workspace_bytes(int64_t B, int F, int K, int64_t total_rows) {
     if (B <= 0 || F <= 0 || K <= 0 || total_rows <= 0 || total_rows >= 0xffffffffll || B * F >= 0x7fffffffll) return 0;

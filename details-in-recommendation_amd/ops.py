@@ -29,7 +29,9 @@ INFINITY_CACHE_BYTES = 256 << 20
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device as the C ABI takes it.  (torch.cuda.current_stream() builds a Stream object per call:
+    5.7 us, 30 times per DeepFM training step; the raw query is 0.3 us.)"""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _dev(t, dtype, name):
@@ -1098,6 +1100,24 @@ def adagrad_dense_(w, accum, grad, lr, eps=0.0):
     _lib.check(_lib.load().dir_adagrad_dense_f32(_ptr(w), _ptr(accum), _ptr(grad), w.numel(), float(lr), float(eps), _stream()))
     mark_written(w, accum)
     return w
+
+
+def adagrad_dense_multi_(ws, accums, grads, lr, eps=0.0):
+    """adagrad_dense_ on a list of variables in one launch per 16 (include/dir_hip.h: dir_adagrad_dense_multi_f32): the pointers travel in
+    the kernel arguments.  Contiguous float32 CUDA tensors; ws[i], accums[i], grads[i] of one shape."""
+    n = len(ws)
+    if n == 0:
+        return
+    for w, a, g in zip(ws, accums, grads):
+        if not (w.is_cuda and w.dtype == torch.float32 and a.dtype == torch.float32 and g.dtype == torch.float32 and w.is_contiguous()
+                and a.is_contiguous() and g.is_contiguous() and a.shape == w.shape and g.shape == w.shape):
+            raise ValueError("adagrad_dense_multi_: contiguous float32 CUDA tensors, one shape per variable")
+    P = ctypes.c_void_p * n
+    L = ctypes.c_int64 * n
+    _lib.check(_lib.load().dir_adagrad_dense_multi_f32(P(*[w.data_ptr() for w in ws]), P(*[a.data_ptr() for a in accums]),
+                                                       P(*[g.data_ptr() for g in grads]), L(*[w.numel() for w in ws]), n, float(lr), float(eps),
+                                                       _stream()))
+    mark_written(*ws, *accums)
 
 
 def ftrl_dense_(w, accum, linear, grad, lr, l1=0.0, l2=0.0):

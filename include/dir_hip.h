@@ -831,6 +831,10 @@ int dir_ftrl_dense_f32(float* w, float* accum, float* linear, const float* grad,
  * kernels and biases; [TF-upstream] tf.train.AdagradOptimizer): accum += g^2; w -= lr * g / (sqrt(accum) + eps) (eps = 0 is TensorFlow's
  * rule) -- one elementwise pass per variable. */
 int dir_adagrad_dense_f32(float* w, float* accum, const float* grad, int64_t count, float lr, float eps, dir_stream_t stream);
+/* dir_adagrad_dense_f32 on n_vars variables in one launch per 16 of them: w / accum / grad / count are HOST arrays of n_vars DEVICE pointers /
+ * element counts (they travel in the kernel arguments; nothing is copied to the device). */
+int dir_adagrad_dense_multi_f32(float* const* w, float* const* accum, const float* const* grad, const int64_t* count, int n_vars, float lr,
+                                float eps, dir_stream_t stream);
 
 /* The same two updates taking their sorted (row, entry) pairs from the workspace of an EARLIER sorted update of the same entries on the
  * same stream (same ids / strides / B / F and the same vocabularies, i.e. equal row_base and total_rows; sorted_from = that call's
