@@ -546,22 +546,31 @@ __global__ __launch_bounds__(256) void adam_decay_k(float* const* __restrict__ t
     float* __restrict__ m = ms[f];
     float* __restrict__ v = vs[f];
     const int c = threadIdx.x & (LPS - 1);
-    for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPS; row < V; row += (int64_t)gridDim.x * 256 / LPS) {
+    // A workgroup walks ONE contiguous chunk of the table's rows, non-temporal loads and stores: six streams over 1.66 GB each.  (The
+    // grid-stride form of round 3 -- consecutive accesses of a lane 2048 workgroups apart -- ran at 4.3-5.0 TB/s; the same change took the
+    // plain copy kernel from 4.4-5.5 to 5.65-6.2 TB/s, NOTES R4.4.)
+    constexpr int RPI = 256 / LPS;                                     // rows per workgroup iteration
+    const int64_t chunk = ((V + gridDim.x - 1) / gridDim.x + RPI - 1) / RPI * RPI;
+    const int64_t rbeg = (int64_t)blockIdx.x * chunk;
+    const int64_t rend = rbeg + chunk < V ? rbeg + chunk : V;
+    for (int64_t row = rbeg + threadIdx.x / LPS; row < rend; row += RPI) {
         const unsigned char mk = mark[r0 + row];
         if (mk) {
             if (c == 0) mark[r0 + row] = 0;
             continue;
         }
         const int64_t off = row * (LPS * 4) + c * 4;
-        float4 mm = *reinterpret_cast<const float4*>(m + off), vv = *reinterpret_cast<const float4*>(v + off);
-        float4 ww = *reinterpret_cast<const float4*>(w + off);
-        mm = make_float4(mm.x * b1, mm.y * b1, mm.z * b1, mm.w * b1);
-        vv = make_float4(vv.x * b2, vv.y * b2, vv.z * b2, vv.w * b2);
-        ww = make_float4(ww.x - (lr_t * mm.x) / (sqrtf(vv.x) + eps), ww.y - (lr_t * mm.y) / (sqrtf(vv.y) + eps),
-                         ww.z - (lr_t * mm.z) / (sqrtf(vv.z) + eps), ww.w - (lr_t * mm.w) / (sqrtf(vv.w) + eps));
-        *reinterpret_cast<float4*>(m + off) = mm;
-        *reinterpret_cast<float4*>(v + off) = vv;
-        *reinterpret_cast<float4*>(w + off) = ww;
+        typedef float f32x4n __attribute__((ext_vector_type(4)));
+        f32x4n mm = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(m + off));
+        f32x4n vv = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(v + off));
+        f32x4n ww = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(w + off));
+        mm = (f32x4n){mm.x * b1, mm.y * b1, mm.z * b1, mm.w * b1};
+        vv = (f32x4n){vv.x * b2, vv.y * b2, vv.z * b2, vv.w * b2};
+        ww = (f32x4n){ww.x - (lr_t * mm.x) / (sqrtf(vv.x) + eps), ww.y - (lr_t * mm.y) / (sqrtf(vv.y) + eps),
+                      ww.z - (lr_t * mm.z) / (sqrtf(vv.z) + eps), ww.w - (lr_t * mm.w) / (sqrtf(vv.w) + eps)};
+        __builtin_nontemporal_store(mm, reinterpret_cast<f32x4n*>(m + off));
+        __builtin_nontemporal_store(vv, reinterpret_cast<f32x4n*>(v + off));
+        __builtin_nontemporal_store(ww, reinterpret_cast<f32x4n*>(w + off));
     }
 }
 
