@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
                                                    int64_t y_ld, int64_t B, int N, int64_t rows_per_block, float* __restrict__ gx,
                                                    int64_t gx_ld, float* __restrict__ part,
                                                    unsigned int* __restrict__ row_bits = nullptr /* [B]: bit pattern of an upper bound of max_n |gx[r, n]| */,
-                                                   unsigned int* __restrict__ all_bits = nullptr /* the same over all rows: written by workgroup 0 */) {
+                                                   unsigned int* __restrict__ all_bits = nullptr /* the same over all rows: atomicMax, one per workgroup (zeroed by the launcher) */) {
     constexpr int RPI = 256 / TPR;
     __shared__ float4 red[2][256];
     const int tid = threadIdx.x, c0 = tid % TPR, rr = tid / TPR;
@@ -54,22 +54,15 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
         }
         wmax = rf[0];
         __syncthreads();
-        if (all_bits && blockIdx.x == 0) {           // max_r |g[r]| * wmax: workgroup 0 walks the B gradients itself (256 KB at B = 65 536) -- no
-            float gm = 0.f;                          // atomics (a same-address atomic per workgroup cost 45 us here), nothing to zero
-            for (int64_t r = tid; r < B; r += 256) gm = fmaxf(gm, fabsf(g[r] * wmax));
-            rf[tid] = gm;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o) rf[tid] = fmaxf(rf[tid], rf[tid + o]);
-                __syncthreads();
-            }
-            if (tid == 0) *all_bits = __builtin_bit_cast(unsigned int, rf[0]);
-            __syncthreads();
-        }
     }
+    float gmax = 0.f;                                // all_bits: the largest bound of this workgroup's rows, ONE atomic per workgroup at the end
     for (int64_t r = r0 + rr; r < r1; r += RPI) {
         const float gr = g[r];
-        if (row_bits && c0 == 0) row_bits[r] = __builtin_bit_cast(unsigned int, fabsf(gr * wmax));
+        if (row_bits && c0 == 0) {
+            const float bnd = fabsf(gr * wmax);
+            row_bits[r] = __builtin_bit_cast(unsigned int, bnd);
+            gmax = fmaxf(gmax, bnd);
+        }
 #pragma unroll
         for (int ch = 0; ch < HB_MAXCH; ++ch) {
             const int c = c0 + ch * TPR;
@@ -85,6 +78,17 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
                 sw[ch].x += gr * yv.x; sw[ch].y += gr * yv.y; sw[ch].z += gr * yv.z; sw[ch].w += gr * yv.w;
             }
         }
+    }
+    if (all_bits) {                                  // (uniform; workgroup 0 walking all of g instead took 60 us at B = 65 536: a serial chain of loads)
+        float* rf = reinterpret_cast<float*>(&red[0][0]);
+        rf[tid] = gmax;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) rf[tid] = fmaxf(rf[tid], rf[tid + o]);
+            __syncthreads();
+        }
+        if (tid == 0 && rf[0] > 0.f) atomicMax(all_bits, __builtin_bit_cast(unsigned int, rf[0]));
+        __syncthreads();
     }
     float* p0 = part + (int64_t)blockIdx.x * 2 * N;
 #pragma unroll
@@ -207,6 +211,7 @@ static int units1_relu_backward(const char* name, const float* g, const float* w
     DIR_CHECK_ARG(n_partials >= p.nblk, "%s: partials holds %lld row pairs, dir_units1_relu_backward_partials(B, N) = %lld", name,
                   (long long)n_partials, (long long)p.nblk);
     hipStream_t st = as_stream(stream);
+    if (all_bits && zero_async(all_bits, sizeof(unsigned int), st) != hipSuccess) return fail(DIR_E_HIP, "%s: zeroing failed", name);
     if (p.tpr == 64)
         hipLaunchKernelGGL(head_bwd_k<64>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials, row_bits,
                            all_bits);
@@ -226,7 +231,7 @@ extern "C" int dir_units1_relu_backward_f32(const float* g, const float* w, cons
 }
 
 // ... and the bit patterns of an upper bound of every gx row's largest |element| (|g[r]| max_n |w[n]|) and of their maximum (all_bits: one
-// unsigned; neither needs zeroing): the scales of the fp16 x 2 backward kernels that consume gx (dir_dense_f16x2_rows_f32,
+// unsigned, zeroed here): the scales of the fp16 x 2 backward kernels that consume gx (dir_dense_f16x2_rows_f32,
 // dir_dense_dw_f16x2_f32), without a pass over gx
 extern "C" int dir_units1_relu_backward_bits_f32(const float* g, const float* w, const float* y, int64_t y_ld, int64_t B, int N, float* gx,
                                                  int64_t gx_ld, float* partials, int64_t n_partials, unsigned int* gx_row_bits,
