@@ -97,8 +97,9 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
                 a = "f16x2"
             if k == 0 and arith in ("auto", "bf16x3") and getattr(ops, "CIN_DW_SYM", False) and D in (8, 16, 32) and m <= 64:
                 # the first layer (xk is x0): dir_cin_dw_sym_bf16x3_f32 multiplies the m (m + 1) / 2 unordered pairs only -- priced on what it executes
-                alg, pipe = alg + f, pipe + f * (m + 1) / (2.0 * m) * PIPE_COST["bf16x3"]
-                modes["dw1"] = "bf16x3_sym"
+                sym = "f16x2" if bwd16 else "bf16x3"          # (the stack's backward hands the fp16 x 2 kernel the tensor scale of its contraction)
+                alg, pipe = alg + f, pipe + f * (m + 1) / (2.0 * m) * PIPE_COST[sym]
+                modes["dw1"] = sym + "_sym"
             else:
                 alg, pipe = alg + f, pipe + f * PIPE_COST[a]
                 modes["dw%d" % (k + 1)] = a

@@ -132,7 +132,8 @@ SIGNATURES = {
     "dir_cin_dw_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "dir_cin_dw_f16x2_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i64]),
     "dir_cin_dw_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
-    "dir_cin_layer_grad_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "dir_cin_layer_grad_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dir_cin_dw_sym_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_dot_add_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_dot_add_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_sum_partials_f32": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),

@@ -617,9 +617,9 @@ extern "C" int dir_cin_layer_f16x2_f32(const float* x0, const float* xk, const f
 // every row of xk scaled by a power of two inside the kernel (template parameter RS)
 extern "C" int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
                                             float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
-                                            dir_stream_t stream) {
+                                            unsigned int* xk_absmax_bits_out, dir_stream_t stream) {
     return bf3_run("dir_cin_layer_grad_f16x2_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace,
-                   workspace_bytes, stream, nullptr, 0, 2, true);
+                   workspace_bytes, stream, nullptr, 0, 2, true, xk_absmax_bits_out);
 }
 
 // ---- the first layer over field pairs (PAIRS) -----------------------------------------------------------------------------------------------

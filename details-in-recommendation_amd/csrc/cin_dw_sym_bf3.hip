@@ -53,6 +53,61 @@ __device__ __forceinline__ void dws_split8(f32x2 v0, f32x2 v1, f32x2 v2, f32x2 v
     for (int q = 0; q < 3; ++q) p[q] = __builtin_bit_cast(bf16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
 }
 
+// ---- round 4: fp16 x 2 (cin_bf3.hip states the arithmetic; cin_dw_bf3.hip the tensor scale): G times ONE power of two from the bit pattern of
+// max |G| (largest element into [2^14, 2^15): G is an operand on its own here, the pair products x0_i x0_j are the other one and are split as
+// in the fp16 x 2 forward's PAIRS form); the reduce pass takes the scale out again
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int dws_pk_h(float a, float b) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));
+    return w;
+}
+__device__ __forceinline__ void dws_split8h(f32x2 v0, f32x2 v1, f32x2 v2, f32x2 v3, f16x8_t (&p)[2]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const f32x2 v[4] = {v0, v1, v2, v3};
+    unsigned int w[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w[0][i] = dws_pk_h(v[i][0], v[i][1]);
+        const h2_t h = __builtin_bit_cast(h2_t, w[0][i]);
+        const f32x2 r = v[i] - (f32x2){(float)h[0], (float)h[1]};
+        w[1][i] = dws_pk_h(r[0], r[1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) p[q] = __builtin_bit_cast(f16x8_t, (u32x4_t){w[q][0], w[q][1], w[q][2], w[q][3]});
+}
+template <int NP> struct DwsPc;
+template <> struct DwsPc<3> {
+    using op_t = bf16x8_t;
+    __device__ static __forceinline__ void split8(f32x2 a, f32x2 b, f32x2 c, f32x2 d, op_t (&p)[3]) { dws_split8(a, b, c, d, p); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[3], const op_t (&b)[3], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+template <> struct DwsPc<2> {
+    using op_t = f16x8_t;
+    __device__ static __forceinline__ void split8(f32x2 a, f32x2 b, f32x2 c, f32x2 d, op_t (&p)[2]) { dws_split8h(a, b, c, d, p); }
+    __device__ static __forceinline__ f32x4 mma(const op_t (&a)[2], const op_t (&b)[2], f32x4 c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], c, 0, 0, 0);
+        return c;
+    }
+};
+__device__ __forceinline__ float dws_scale(unsigned int bits, bool inverse) {     // largest |element| into [2^14, 2^15); k clamped to +-100
+    int k = 141 - (int)((bits >> 23) & 0xffu);
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return __builtin_bit_cast(float, (unsigned int)(inverse ? 127 - k : 127 + k) << 23);
+}
+
 // pair index of (a <= b) among the m (m + 1) / 2 unordered pairs, row-major over a
 __host__ __device__ __forceinline__ int dws_pair_index(int a, int b, int m) { return a * m - a * (a - 1) / 2 + (b - a); }
 
@@ -72,10 +127,15 @@ static DwsPlan dws_plan(int m, int H, int D, int64_t B) {
     return p;
 }
 
+template <int NP>
 __global__ __launch_bounds__(512, 1) void cin_dw_sym_bf3_k(const float* __restrict__ x0, const float* __restrict__ G, int m, int H, int D, int dshift,
                                                            int npb, int npairs, int nspan, int64_t steps_per_span, int64_t steps, int64_t R,
-                                                           float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) unsigned int Ap[2][3][8][64][4];      // G pieces of one k-step: [buffer][piece][h tile][lane][8 bf16]
+                                                           float* __restrict__ part, const unsigned int* __restrict__ gbits /* NP == 2 */) {
+    using Pc = DwsPc<NP>;
+    using op_t = typename Pc::op_t;
+    __shared__ __attribute__((aligned(16))) unsigned int Ap[2][NP][8][64][4];     // G pieces of one k-step: [buffer][piece][h tile][lane][8 halves]
+    float gs = 1.f;
+    if constexpr (NP == 2) gs = dws_scale(*gbits, false);
     __shared__ unsigned char pair_i[DWS_PAIRS], pair_j[DWS_PAIRS];                 // this item's pairs (padding: 255)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, lg = lane >> 4;
@@ -144,11 +204,13 @@ __global__ __launch_bounds__(512, 1) void cin_dw_sym_bf3_k(const float* __restri
         octet(G, hrow, H, s, rg);
         if (!hrow_in) rg[0] = rg[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
-    auto split_a = [&](int buf) {                 // this thread's octet of G -> three pieces in LDS
-        bf16x8_t p[3];
-        dws_split8((f32x2){rg[0][0], rg[0][1]}, (f32x2){rg[0][2], rg[0][3]}, (f32x2){rg[1][0], rg[1][1]}, (f32x2){rg[1][2], rg[1][3]}, p);
+    auto split_a = [&](int buf) {                 // this thread's octet of G -> its pieces in LDS
+        op_t p[NP];
+        f32x2 g0 = {rg[0][0], rg[0][1]}, g1 = {rg[0][2], rg[0][3]}, g2 = {rg[1][0], rg[1][1]}, g3 = {rg[1][2], rg[1][3]};
+        if constexpr (NP == 2) { g0 *= gs; g1 *= gs; g2 *= gs; g3 *= gs; }
+        Pc::split8(g0, g1, g2, g3, p);
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<bf16x8_t*>(&Ap[buf][pc][wave][lane][0]) = p[pc];
+        for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<op_t*>(&Ap[buf][pc][wave][lane][0]) = p[pc];
     };
 
     if (s_begin < s_end) {
@@ -161,10 +223,10 @@ __global__ __launch_bounds__(512, 1) void cin_dw_sym_bf3_k(const float* __restri
     int buf = 0;
     for (int64_t s = s_begin; s < s_end; ++s, buf ^= 1) {
         // B operands: the x0_i octet times the x0_j octet of each of the wave's pair tiles, split
-        bf16x8_t b[DWS_TPW][3];
+        op_t b[DWS_TPW][NP];
 #pragma unroll
         for (int t = 0; t < DWS_TPW; ++t)
-            dws_split8((f32x2){ri[t][0][0], ri[t][0][1]} * (f32x2){rj[t][0][0], rj[t][0][1]},
+            Pc::split8((f32x2){ri[t][0][0], ri[t][0][1]} * (f32x2){rj[t][0][0], rj[t][0][1]},
                        (f32x2){ri[t][0][2], ri[t][0][3]} * (f32x2){rj[t][0][2], rj[t][0][3]},
                        (f32x2){ri[t][1][0], ri[t][1][1]} * (f32x2){rj[t][1][0], rj[t][1][1]},
                        (f32x2){ri[t][1][2], ri[t][1][3]} * (f32x2){rj[t][1][2], rj[t][1][3]}, b[t]);
@@ -173,19 +235,12 @@ __global__ __launch_bounds__(512, 1) void cin_dw_sym_bf3_k(const float* __restri
         load_a(s + 2);
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) {
-            bf16x8_t a[3];
+            op_t a[NP];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a[pc] = *reinterpret_cast<const bf16x8_t*>(&Ap[buf][pc][ht][lane][0]);
+            for (int pc = 0; pc < NP; ++pc) a[pc] = *reinterpret_cast<const op_t*>(&Ap[buf][pc][ht][lane][0]);
 #pragma unroll
             for (int t = 0; t < DWS_TPW; ++t) {
-                f32x4 c = acc[t][ht];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[t][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[t][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[t][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[t][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[t][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[t][0], c, 0, 0, 0);
-                acc[t][ht] = c;
+                acc[t][ht] = Pc::mma(a, b[t], acc[t][ht]);
                 __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (dense_bf3.hip: DB3_CHAIN)
             }
         }
@@ -203,8 +258,9 @@ __global__ __launch_bounds__(512, 1) void cin_dw_sym_bf3_k(const float* __restri
 
 // dW[h, i*m + j] (+)= sum over spans of C[h, pair(min(i,j), max(i,j))], in span order
 __global__ __launch_bounds__(256) void cin_dw_sym_reduce_k(const float* __restrict__ part, int m, int H, int npb, int nspan, int accumulate,
-                                                          float* __restrict__ dW) {
+                                                          float* __restrict__ dW, const unsigned int* __restrict__ gbits /* fp16 x 2: the scale to take out */) {
     const int64_t total = (int64_t)H * m * m;
+    const float inv = gbits ? dws_scale(*gbits, true) : 1.f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int j = (int)(e % m);
         const int i = (int)((e / m) % m);
@@ -215,6 +271,7 @@ __global__ __launch_bounds__(256) void cin_dw_sym_reduce_k(const float* __restri
         const float* src = part + (item * nspan) * 128 * DWS_PAIRS + (int64_t)(h & 127) * DWS_PAIRS + pl;
         float s = 0.f;
         for (int sp = 0; sp < nspan; ++sp) s += src[(int64_t)sp * 128 * DWS_PAIRS];
+        s *= inv;
         dW[e] = accumulate ? dW[e] + s : s;
     }
 }
@@ -229,9 +286,9 @@ extern "C" int64_t dir_cin_dw_sym_bf16x3_workspace_bytes(int m, int H, int D, in
     return (int64_t)p.items * p.nspan * 128 * DWS_PAIRS * (int64_t)sizeof(float);
 }
 
-extern "C" int dir_cin_dw_sym_bf16x3_f32(const float* x0, const float* G, int m, int H, int D, int64_t B, int accumulate, float* dW, void* workspace,
-                                         int64_t workspace_bytes, dir_stream_t stream) {
-    const char* name = "dir_cin_dw_sym_bf16x3_f32";
+static int dws_run(const char* name, int np, const float* x0, const float* G, int m, int H, int D, int64_t B, int accumulate, float* dW,
+                   void* workspace, int64_t workspace_bytes, const unsigned int* gbits, dir_stream_t stream) {
+    DIR_CHECK_ARG(np == 3 || gbits, "%s: g_absmax_bits is null", name);
     DIR_CHECK_ARG(dW, "%s: null pointer", name);
     DIR_CHECK_ARG(m > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d H=%d D=%d", name, m, H, D);
     if (!(D == 8 || D == 16 || D == 32) || m > DWS_MAXM)
@@ -250,11 +307,27 @@ extern "C" int dir_cin_dw_sym_bf16x3_f32(const float* x0, const float* G, int m,
     int dshift = 0;
     while ((1 << dshift) < D) ++dshift;
     const DwsPlan p = dws_plan(m, H, D, B);
-    hipLaunchKernelGGL(cin_dw_sym_bf3_k, dim3((unsigned)(p.items * p.nspan)), dim3(512), 0, st, x0, G, m, H, D, dshift, p.npb, p.npairs, p.nspan,
-                       p.steps_per_span, p.steps, B * D, static_cast<float*>(workspace));
+    if (np == 2)
+        hipLaunchKernelGGL(cin_dw_sym_bf3_k<2>, dim3((unsigned)(p.items * p.nspan)), dim3(512), 0, st, x0, G, m, H, D, dshift, p.npb, p.npairs, p.nspan,
+                           p.steps_per_span, p.steps, B * D, static_cast<float*>(workspace), gbits);
+    else
+        hipLaunchKernelGGL(cin_dw_sym_bf3_k<3>, dim3((unsigned)(p.items * p.nspan)), dim3(512), 0, st, x0, G, m, H, D, dshift, p.npb, p.npairs, p.nspan,
+                           p.steps_per_span, p.steps, B * D, static_cast<float*>(workspace), nullptr);
     DIR_CHECK_LAUNCH(name);
     hipLaunchKernelGGL(cin_dw_sym_reduce_k, dim3(grid_for((n + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(workspace), m, H, p.npb,
-                       p.nspan, accumulate, dW);
-    DIR_CHECK_LAUNCH("cin_dw_sym_bf16x3 reduce");
+                       p.nspan, accumulate, dW, np == 2 ? gbits : nullptr);
+    DIR_CHECK_LAUNCH("cin_dw_sym reduce");
     return DIR_OK;
+}
+
+extern "C" int dir_cin_dw_sym_bf16x3_f32(const float* x0, const float* G, int m, int H, int D, int64_t B, int accumulate, float* dW, void* workspace,
+                                         int64_t workspace_bytes, dir_stream_t stream) {
+    return dws_run("dir_cin_dw_sym_bf16x3_f32", 3, x0, G, m, H, D, B, accumulate, dW, workspace, workspace_bytes, nullptr, stream);
+}
+
+// fp16 x 2: G scaled by one power of two from g_absmax_bits (DEVICE: the bit pattern of an upper bound of max |G|, e.g. what
+// dir_cin_layer_grad_f16x2_f32 leaves), the pair products x0_i x0_j split as in the fp16 x 2 forward (|x0| of O(1)).  Workspace as the bf16 x 3 entry.
+extern "C" int dir_cin_dw_sym_f16x2_f32(const float* x0, const float* G, int m, int H, int D, int64_t B, int accumulate, float* dW, void* workspace,
+                                        int64_t workspace_bytes, const unsigned int* g_absmax_bits, dir_stream_t stream) {
+    return dws_run("dir_cin_dw_sym_f16x2_f32", 2, x0, G, m, H, D, B, accumulate, dW, workspace, workspace_bytes, g_absmax_bits, stream);
 }

@@ -1351,7 +1351,7 @@ def cin_pool_dx(x0, xk, dZ, add_pooled=None, dx0=None):
     return dxk, out
 
 
-def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, grad_operand=False):
+def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, grad_operand=False, g_bits_out=None):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
     want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
@@ -1420,6 +1420,13 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
             return xout, pooled
         nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, Hp, H))
         ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+        if arith == "f16x2_grad":          # (g_bits_out, a list: the bit pattern of max |xk| -- a by-product of the row maxima -- is appended)
+            gbits = torch.empty(1, dtype=torch.int32, device=x0.device) if (g_bits_out is not None and B > 0) else None
+            _lib.check(f_ly(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled), pooled.stride(0), _ptr(ws),
+                            nbytes, _ptr(gbits), _stream()))
+            if gbits is not None:
+                g_bits_out.append(gbits)
+            return xout, pooled
         _lib.check(f_ly(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled), pooled.stride(0), _ptr(ws),
                         nbytes, _stream()))
         return xout, pooled
@@ -1684,6 +1691,11 @@ def cin_dw(x0, xk, G, dW=None, accumulate=False, arith=None, g_absmax_bits=None)
         # the first layer of a stack (xk is x0): dW is symmetric in (i, j) and the unordered pairs are the GEMM's columns (dir_cin_dw_sym_bf16x3_f32)
         nbytes = int(lib.dir_cin_dw_sym_bf16x3_workspace_bytes(m, H, D, B))
         ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+        if arith == "auto" and CIN_BWD_SPLIT == "f16x2" and g_absmax_bits is not None and B > 0:
+            # fp16 x 2 with G scaled by one power of two (dir_cin_dw_sym_f16x2_f32): the caller brings max |G| (no pass over G here)
+            _lib.check(lib.dir_cin_dw_sym_f16x2_f32(_ptr(x0), _ptr(G), m, H, D, B, 1 if accumulate else 0, _ptr(dW), _ptr(ws), nbytes,
+                                                    _ptr(g_absmax_bits), _stream()))
+            return dW
         _lib.check(lib.dir_cin_dw_sym_bf16x3_f32(_ptr(x0), _ptr(G), m, H, D, B, 1 if accumulate else 0, _ptr(dW), _ptr(ws), nbytes, _stream()))
         return dW
     if arith == "auto":
@@ -1883,17 +1895,20 @@ def cin_stack_backward(x0, xks, Ws, g_pooled, need_x0=True, arith=None, z_top=No
             dWs[k] = cin_dw(x0, xk, G, arith=arith, g_absmax_bits=gb[0] if gb else None)
             G = dxk
             continue
+        first = k == 0 and xk.data_ptr() == x0.data_ptr() and xk.shape == x0.shape
+        if first and need_x0:
+            # The first layer (xk IS x0): x0 receives dL/dxk and dL/dx0 of this layer, and their sum is ONE forward-form contraction of G
+            # with the symmetrised weights W[h,i,j] + W[h,j,i] (0.96 ms against 1.34 ms for the two-output form at the BASELINE shape,
+            # tools/cin_l1_dx_probe.py).  It runs FIRST: its row-scaled fp16 x 2 kernel leaves max |G| for the weight gradient's scale.
+            W3 = W.view(H, m, m)
+            Ws_ = (W3 + W3.transpose(1, 2)).permute(1, 0, 2).reshape(m, H * m).contiguous()          # [i, h*m + j]
+            gb = []
+            tot, _ = cin_layer(x0, G, Ws_, arith=arith, grad_operand=True, g_bits_out=gb)
+            dWs[k] = cin_dw(x0, xk, G, arith=arith, g_absmax_bits=gb[0] if gb else None)
+            return (tot if dx0 is None else dx0.add_(tot)), dWs
         dWs[k] = cin_dw(x0, xk, G, arith=arith)
         if k == 0 and not need_x0:
             break
-        if k == 0 and xk.data_ptr() == x0.data_ptr() and xk.shape == x0.shape:
-            # The first layer (xk IS x0): x0 receives dL/dxk and dL/dx0 of this layer, and their sum is ONE forward-form contraction of G
-            # with the symmetrised weights W[h,i,j] + W[h,j,i] (0.96 ms against 1.34 ms for the two-output form at the BASELINE shape,
-            # tools/cin_l1_dx_probe.py)
-            W3 = W.view(H, m, m)
-            Ws_ = (W3 + W3.transpose(1, 2)).permute(1, 0, 2).reshape(m, H * m).contiguous()          # [i, h*m + j]
-            tot, _ = cin_layer(x0, G, Ws_, arith=arith, grad_operand=True)
-            return (tot if dx0 is None else dx0.add_(tot)), dWs
         below = gps[k - 1] if k > 0 else None
         if a == "bf16x3" and cin_bf16x3_covers(m, D):
             dxk, dx0 = cin_dx_bf16x3(x0, xk, W, G, add_pooled=below, dx0=dx0, split=None if arith == "auto" else "bf16x3")

@@ -303,12 +303,14 @@ int dir_sum_partials_f32(const float* parts, int P, int64_t n, int accumulate, f
  * into two fp16 pieces, and the inverse power of two is applied where the row's T tile meets the field factor (and y, in the dot form) --
  * again exact.  Elements within 2^-17 of their row's largest carry 22 bits; smaller ones an absolute error of 2^-39 of the row's largest,
  * which is what the sum over the row's channels needs.  x0, W, y: preconditions of dir_cin_layer_f16x2_f32 (|.| < 65 504, O(1) values).
- * dir_cin_layer_grad_f16x2_f32: arguments of dir_cin_layer_f16x2_f32 (the forward-form contractions of the backward);
+ * dir_cin_layer_grad_f16x2_f32: arguments of dir_cin_layer_f16x2_f32 (the forward-form contractions of the backward) plus
+ * xk_absmax_bits_out (as below; NULL: not wanted);
  * dir_cin_layer_dot_add_f16x2_f32: arguments, partial-sum layout (dir_cin_bf16x3_dot_partials) and workspace of
  * dir_cin_layer_dot_add_bf16x3_f32, plus xk_absmax_bits_out (DEVICE, one unsigned; NULL: not wanted): the bit pattern of max |xk| over the
  * whole tensor, a by-product of the kernel's row maxima -- what dir_cin_dw_f16x2_f32 takes as g_absmax_bits. */
 int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
-                                 float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+                                 float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, unsigned int* xk_absmax_bits_out,
+                                 dir_stream_t stream);
 int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D, int64_t B,
                                     const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
                                     int64_t workspace_bytes, unsigned int* xk_absmax_bits_out, dir_stream_t stream);
@@ -673,6 +675,11 @@ int dir_cin_dw_f16x2_f32(const float* x0, const float* xk, const float* G, int m
 int64_t dir_cin_dw_sym_bf16x3_workspace_bytes(int m, int H, int D, int64_t B);
 int dir_cin_dw_sym_bf16x3_f32(const float* x0, const float* G, int m, int H, int D, int64_t B, int accumulate, float* dW, void* workspace,
                               int64_t workspace_bytes, dir_stream_t stream);
+/* The same first-layer weight gradient on fp16 x 2: G times one power of two from g_absmax_bits (DEVICE; required: the bit pattern of an upper
+ * bound of max |G| -- dir_cin_layer_grad_f16x2_f32 / dir_cin_layer_dot_add_f16x2_f32 leave it), the pair products split as in the fp16 x 2
+ * forward; workspace and determinism of the bf16 x 3 entry. */
+int dir_cin_dw_sym_f16x2_f32(const float* x0, const float* G, int m, int H, int D, int64_t B, int accumulate, float* dW, void* workspace,
+                             int64_t workspace_bytes, const unsigned int* g_absmax_bits, dir_stream_t stream);
 int dir_cin_dx_f32(const float* x0, const float* xk, const float* Wp, const float* G, int m, int Hp, int H, int D,
                    int64_t B, float* dxk, float* dx0, dir_stream_t stream);
 int dir_cin_dw_f32(const float* x0, const float* xk, const float* G, int m, int Hp, int H, int D, int64_t B,

@@ -1767,6 +1767,23 @@ def test_cin_dw_first_layer_symmetric_kernel(built_lib, B, m, D, H):
     assert torch.equal(ops.cin_dw(x0, x0, G, arith="bf16x3_sym"), dW)
     acc = ops.cin_dw(x0, x0, G, dW=dW.clone(), accumulate=True, arith="bf16x3_sym")
     assert torch.allclose(acc, 2 * dW, rtol=1e-6, atol=1e-6)
+    # fp16 x 2 (dir_cin_dw_sym_f16x2_f32): "auto" with the tensor's maximum given (the forward-form contraction's kernel leaves it) -- same bar,
+    # symmetric, reproducible, and a 2^-30 times smaller G gives the same bits times 2^-30
+    if ops.CIN_BWD_SPLIT == "f16x2":
+        bits = torch.tensor([np.float32(np.abs(Gn).max()).view(np.int32)], dtype=torch.int32, device="cuda")
+        hW = ops.cin_dw(x0, x0, G, g_absmax_bits=bits)
+        err = np.abs(hW.cpu().double().numpy() - ref_dW) / (mag + np.abs(ref_dW))
+        assert err.max() <= 1e-5, "f16x2 sym dW max scaled err %.3e" % err.max()
+        h3 = hW.view(H, m, m)
+        assert torch.equal(h3, h3.transpose(1, 2)) and torch.equal(ops.cin_dw(x0, x0, G, g_absmax_bits=bits), hW) and not torch.equal(hW, dW)
+        small = torch.tensor([np.float32(np.abs(Gn).max() * 2.0 ** -30).view(np.int32)], dtype=torch.int32, device="cuda")
+        assert torch.equal(ops.cin_dw(x0, x0, G * 2.0 ** -30, g_absmax_bits=small), hW * 2.0 ** -30)
+        if m >= 8 and ops.cin_bf16x3_covers(m, D):               # the contraction's by-product IS that maximum
+            gb = []
+            Ws_ = torch.zeros((m, H * m), device="cuda")
+            ops.cin_layer(x0, G, Ws_, grad_operand=True, g_bits_out=gb)
+            if gb:
+                assert int(gb[0]) == int(bits)
     with pytest.raises(ValueError):
         ops.cin_dw(x0, x0.clone(), G, arith="bf16x3_sym")                        # xk must BE x0
     e = ops.cin_dw(x0[:0], x0[:0], G[:0], arith="bf16x3_sym") if False else None  # (an empty batch has no storage to alias: covered by the C entry below)
