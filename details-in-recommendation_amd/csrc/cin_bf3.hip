@@ -225,6 +225,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     // error of 2^-25 (2^-39 of the largest), which is what a sum over the row's channels needs.  The scaling itself is exact.
     float rscale[RS ? RT : 1];
     f32x4 rinv[RS ? RT : 1];
+    float wave_max = 0.f;
+    float* bt_wmax = x0s + (size_t)mx * BT_ROWS;                      // [8]: behind the x0 slice (all LDS is dynamic: the 160 KiB limit is set for the kernel)
     if constexpr (RS) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -239,18 +241,18 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (amax_out && blockIdx.y == 0) {          // the tensor's maximum rides along (the weight-gradient kernel scales G by it): one atomic per wave and row tile
-                float wm = mx;
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
-                if (lane == 0) atomicMax(amax_out, __builtin_bit_cast(unsigned int, wm));
-            }
+            wave_max = fmaxf(wave_max, mx);             // the tensor's maximum rides along (the weight-gradient kernels scale G by it)
             int k = 141 - (int)((__builtin_bit_cast(unsigned int, mx) >> 23) & 0xffu);
             k = k > 100 ? 100 : (k < -100 ? -100 : k);
             rscale[rt] = __builtin_bit_cast(float, (unsigned int)(127 + k) << 23);
             const float inv = __builtin_bit_cast(float, (unsigned int)(127 - k) << 23);
 #pragma unroll
             for (int q = 0; q < 4; ++q) rinv[rt][q] = __shfl(inv, 4 * lg + q, 64);      // lane 4 lg + q holds row 4 lg + q of the tile
+        }
+        if (amax_out) {                                 // (uniform) one value per wave into LDS; ONE atomic per workgroup behind the prologue's barrier
+#pragma unroll                                          //  (an atomic per wave and row tile: 65 536 on one address, +87 us on the 0.79 ms contraction)
+            for (int o = 8; o > 0; o >>= 1) wave_max = fmaxf(wave_max, __shfl_xor(wave_max, o, 64));
+            if (lane == 0) bt_wmax[wave] = wave_max;
         }
     }
 
@@ -284,6 +286,14 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (RS) {
+        if (amax_out && blockIdx.y == 0 && tid == 0) {
+            float wm = bt_wmax[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) wm = fmaxf(wm, bt_wmax[q]);
+            atomicMax(amax_out, __builtin_bit_cast(unsigned int, wm));
+        }
+    }
 
     if constexpr (DOT) dotp += (int64_t)blockIdx.y * nkh * (R >> dshift) * m * D;     // this column block's partials
     const unsigned char* wlane = Wb + lane * 16;
@@ -551,7 +561,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     do {                                                                                                                              \
         static LdsOnce once;                                                                                                      \
         (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>);                                       \
-        const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256;                                  \
+        const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                             \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
                            dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr); \
     } while (0)
@@ -700,7 +710,7 @@ static int l1_run(const char* name, int pieces, const float* x0, const float* W,
     do {                                                                                                                                \
         static LdsOnce once;                                                                                                      \
         (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true, NP_>);                                              \
-        const size_t shmem = 2 * (size_t)2 * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256;                                          \
+        const size_t shmem = 2 * (size_t)2 * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                                     \
         hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true, NP_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, \
                            dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m);                    \
     } while (0)
