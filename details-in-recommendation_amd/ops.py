@@ -118,6 +118,16 @@ class TableSet:
         ts.arena, ts.rows = arena, rows
         return ts
 
+    def absmax(self):
+        """max |embedding value| over the tables, measured once per version of the tables and their owners (one pass + one sync when an
+        in-place update bumped a counter): tower(gather=..., split=None) keeps a table past F16_RANGE_GUARD off the fp16 x 2 kernel."""
+        sig = tuple(t._version for t in self.tables) + tuple(t._version for t in self.owners)
+        hit = getattr(self, "_absmax", None)
+        if hit is None or hit[0] != sig:
+            m = float(torch.stack([t.abs().max() for t in self.tables if t.numel()] or [torch.zeros((), device=self.device)]).max())
+            hit = self._absmax = (sig, m)
+        return hit[1]
+
     def gather_flags(self):
         if self.row_policy == "stream" or (self.row_policy == "auto" and self.nbytes > 2 * INFINITY_CACHE_BYTES):
             return STREAM_ROWS
@@ -809,6 +819,10 @@ def tower_gather_covers(pt, weights):
 # traffic and half the matrix instructions; |activations|, |weights| < 65 504 -- the towers read embedding rows and ReLU activations) or
 # "bf16x3" (three bf16 pieces, six products: fp32's exponent range).
 TOWER_SPLIT = os.environ.get("DIR_TOWER_SPLIT", "f16x2")      # what split=None means in tower(): callers with unbounded inputs pass "bf16x3"
+# split=None also checks what can be checked without a per-call sync: a weight or packed serving row at or above this magnitude (measured
+# once per image build / per version of the tables) routes the launch to "bf16x3".  Activations stay the caller's contract (checking them
+# would cost a pass and a sync per call): callers whose inputs are not embedding rows or ReLU activations of such pass split="bf16x3".
+F16_RANGE_GUARD = 32768.0
 
 
 def tower_image(weight, split=None):
@@ -821,6 +835,8 @@ def tower_image(weight, split=None):
     hit = _TOWER_IMAGES.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == sig:
         return hit[2]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("tower_image: build the weight images (one eager call) before capturing a graph")
     N, K = weight.shape
     lib = _lib.load()
     nbytes = int(lib.dir_tower_bf16x3_image_bytes(K, N))
@@ -830,8 +846,21 @@ def tower_image(weight, split=None):
     _lib.check(pack(_ptr(w), w.stride(0), K, N, _ptr(img), nbytes, _stream()))
     if len(_TOWER_IMAGES) > 256:
         _TOWER_IMAGES.clear()
-    _TOWER_IMAGES[key] = (weakref.ref(weight), sig, img)
+    _TOWER_IMAGES[key] = (weakref.ref(weight), sig, img, float(weight.detach().abs().max()) if weight.numel() else 0.0)
     return img
+
+
+def _tower_split_for(weights, pt=None):
+    """What split=None resolves to: TOWER_SPLIT, or "bf16x3" when a weight or a packed row is outside F16_RANGE_GUARD."""
+    if TOWER_SPLIT != "f16x2":
+        return TOWER_SPLIT
+    if pt is not None and pt.absmax() >= F16_RANGE_GUARD:
+        return "bf16x3"
+    for w in weights:
+        tower_image(w, "f16x2")
+        if _TOWER_IMAGES[(w.data_ptr(), "f16x2")][3] >= F16_RANGE_GUARD:
+            return "bf16x3"
+    return "f16x2"
 
 
 def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, head=None, adds=(), out=None, gather=None, split=None):
@@ -844,8 +873,7 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
     bit for bit the result of gather_fm_linear + tower(..., adds=(fm, lin)).
     split: "f16x2" | "bf16x3" | None = TOWER_SPLIT (env DIR_TOWER_SPLIT): the kernel's split arithmetic (dir_tower_f16x2_f32 /
     dir_deepfm_tower_f16x2_f32 or the bf16x3 entries)."""
-    split = split or TOWER_SPLIT
-    if split not in ("f16x2", "bf16x3"):
+    if split not in (None, "f16x2", "bf16x3"):
         raise ValueError("tower: split must be 'f16x2' or 'bf16x3'")
     L = len(weights)
     if gather is not None:
@@ -862,6 +890,8 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
         if not tower_covers(x, weights):
             raise ValueError("tower: 1..4 layers, input and layer widths multiples of 4 and <= %d, x 16-byte aligned with a row stride multiple of 4" % TOWER_MAX_WIDTH)
         M, Kd = x.shape
+    if split is None:
+        split = _tower_split_for([_dev(w, torch.float32, "weight") for w in weights], pt if gather is not None else None)
     lib = _lib.load()
     relu_l = list(relu) if isinstance(relu, (list, tuple)) else [bool(relu)] * L
     keep = []
@@ -2285,6 +2315,13 @@ class PackedTables:
         self.ptrs = torch.tensor([r.data_ptr() for r in self.rows], dtype=torch.int64, device=self.device)
         self.vocab_dev = torch.tensor(self.vocab, dtype=torch.int64, device=self.device)
         self.nbytes = total * 4
+        self._absmax = None
+
+    def absmax(self):
+        """max |value| over the packed rows, measured once (the rows are a serving snapshot; rebuild the pack after changing them)."""
+        if self._absmax is None:
+            self._absmax = float(self.arena.abs().max()) if self.arena.numel() else 0.0
+        return self._absmax
 
     def flags(self):
         return STREAM_ROWS if self.nbytes > 2 * INFINITY_CACHE_BYTES else 0

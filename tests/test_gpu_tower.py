@@ -304,6 +304,46 @@ def test_tower_splits_agree_and_general_inputs_stay_on_bf16x3(built_lib):
     assert bool(torch.isfinite(gb).all())
 
 
+def test_tower_default_split_checks_the_fp16_range_of_weights_and_packed_rows(built_lib):
+    """split=None measures what it can without a per-call sync: a weight (per image build) or a packed serving row (per PackedTables)
+    at or above ops.F16_RANGE_GUARD routes the launch to bf16 x 3 -- bit for bit the explicit split="bf16x3" result, finite and within
+    the bf16 x 3 bar of float64 -- and back to fp16 x 2 once the value is gone."""
+    from dir_amd import ops
+    if ops.TOWER_SPLIT != "f16x2":
+        pytest.skip("DIR_TOWER_SPLIT overrides the default")
+    torch.manual_seed(5)
+    M = 4096
+    W1 = torch.randn(400, 416, device="cuda") / 20
+    W2 = torch.randn(400, 400, device="cuda") / 20
+    hw, hb = torch.randn(400, device="cuda") / 20, torch.zeros(1, device="cuda")
+    x = torch.randn(M, 416, device="cuda") * 0.3
+    base = ops.tower(x, [W1, W2], head=(hw, hb))
+    assert torch.equal(base, ops.tower(x, [W1, W2], head=(hw, hb), split="f16x2"))
+    W1[3, 5] = 1.0e5
+    x[:, 5] = 1e-3                                                    # keeps the activations themselves in range
+    got = ops.tower(x, [W1, W2], head=(hw, hb))
+    assert torch.equal(got, ops.tower(x, [W1, W2], head=(hw, hb), split="bf16x3")) and bool(torch.isfinite(got).all())
+    ref = ((x.double() @ W1.double().t()).clamp_min(0) @ W2.double().t()).clamp_min(0) @ hw.double().view(-1, 1) + hb.double()
+    assert float(((got.double() - ref).abs() / (1 + ref.abs())).max()) <= 1e-5
+    W1[3, 5] = 0.5
+    assert torch.equal(ops.tower(x, [W1, W2], head=(hw, hb)), ops.tower(x, [W1, W2], head=(hw, hb), split="f16x2"))
+    # packed serving rows: one table value past the range
+    F, K, V = 26, 16, 1000
+    tabs = [torch.randn(V, K, device="cuda") * 0.1 for _ in range(F)]
+    lins = [torch.randn(V, device="cuda") * 0.1 for _ in range(F)]
+    ids = torch.randint(0, V, (M, F), device="cuda")
+    pt = ops.PackedTables(tabs, lins)
+    assert pt.absmax() < ops.F16_RANGE_GUARD
+    a = ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt, ids, None))
+    assert torch.equal(a, ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt, ids, None), split="f16x2"))
+    tabs[2][17, 3] = 7.0e4
+    ids[:8, 2] = 17
+    pt2 = ops.PackedTables(tabs, lins)
+    assert pt2.absmax() == 7.0e4
+    b = ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt2, ids, None))
+    assert torch.equal(b, ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt2, ids, None), split="bf16x3")) and bool(torch.isfinite(b).all())
+
+
 @pytest.mark.parametrize("M,N,K,gate", [(12800, 400, 416, True), (12801, 400, 400, True), (13000, 208, 128, False), (12544, 1024, 432, True),
                                         (12290, 64, 200, False)])
 def test_dense_backward_on_scaled_fp16x2(built_lib, M, N, K, gate):
