@@ -405,9 +405,9 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
         # world == 1 with DIR_BENCH_CFG5_SHARDED=1: the sharded code path with its collectives issued (RCCL, one rank) -- what the
         # exchange costs next to the CIN when it is hidden under it
         if world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            import tempfile
+            dist.init_process_group("nccl", init_method="file://" + os.path.join(tempfile.mkdtemp(prefix="dir_pg_"), "store"), rank=0,
+                                    world_size=1, device_id=device)            # (a FileStore: no TCP port to clash on)
         loc = []
         for f in range(F):
             s0, e0 = div_range(Vf, world, rank)

@@ -145,6 +145,8 @@ SIGNATURES = {
     "dir_debug_stream_copy_f32": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "dir_debug_radix_sort_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "dir_debug_radix_sort_pairs_u32": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "dir_debug_slot_sort_workspace_bytes": (c_i64, [c_i64, c_i32, c_i64]),
+    "dir_debug_slot_sort_entries": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_fingerprint64": (ctypes.c_uint64, [ctypes.c_char_p, c_i64]),
     "dir_hash_bucket_fast": (c_i32, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64), c_i64, c_i64,
                                      ctypes.POINTER(c_i64)]),

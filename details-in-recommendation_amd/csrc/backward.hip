@@ -749,7 +749,7 @@ static bool use_rocprim_sort() { return false; }
 #endif
 
 struct AdaSortedPlan { size_t n, ntiles, off_keys[2], off_vals[2], off_carry, off_tmp, tmp_bytes, total; unsigned bits; };
-static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedPlan& p) {
+static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedPlan& p, int64_t B = 0, int F = 0 /* ids [B, F]: the slot-major sort */) {
     p.n = (size_t)n;
     p.ntiles = (p.n + ADA_TILE - 1) / ADA_TILE;
     unsigned bits = 1;
@@ -761,6 +761,10 @@ static bool adagrad_sorted_plan(int64_t n, int K, int64_t total_rows, AdaSortedP
     p.off_vals[0] = take(p.n * 4); p.off_vals[1] = take(p.n * 4);
     p.off_carry = take(p.ntiles * 2 * (size_t)K * 4);
     size_t tmp = radix_sort_temp_bytes(p.n, bits);
+    if (F > 0 && radix_slot_sort_ok(B, F, bits)) {
+        const size_t t2 = radix_slot_sort_temp_bytes(B, F, bits);
+        if (t2 > tmp) tmp = t2;
+    }
 #if defined(DIR_WITH_ROCPRIM_SORT)
     size_t tmp_r = 0;
     if (rocprim_sort_pairs(nullptr, tmp_r, nullptr, nullptr, nullptr, nullptr, p.n, bits, (hipStream_t)0) != hipSuccess) return false;
@@ -847,7 +851,7 @@ extern "C" int dir_adagrad_dense_multi_f32(float* const* w, float* const* accum,
 extern "C" int64_t dir_sparse_adagrad_sorted_workspace_bytes(int64_t B, int F, int K, int64_t total_rows) {
     if (B <= 0 || F <= 0 || K <= 0 || total_rows <= 0 || total_rows >= 0xffffffffll || B * F >= 0x7fffffffll) return 0;
     AdaSortedPlan p;
-    return adagrad_sorted_plan(B * F, K, total_rows, p) ? (int64_t)p.total : 0;
+    return adagrad_sorted_plan(B * F, K, total_rows, p, B, F) ? (int64_t)p.total : 0;
 }
 
 template <class U>
@@ -871,7 +875,9 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
     if (total_rows <= 0 || total_rows >= 0xffffffffll) return fail(DIR_E_UNSUPPORTED, "%s: total_rows must be in [1, 2^32-1)", name);
     const int64_t n = B * F;
     AdaSortedPlan p;
-    if (!adagrad_sorted_plan(n, K, total_rows, p)) return fail(DIR_E_HIP, "%s: sort size query failed", name);
+    if (!adagrad_sorted_plan(n, K, total_rows, p, payload ? 0 : B, payload ? 0 : F)) return fail(DIR_E_HIP, "%s: sort size query failed", name);
+    // ids [B, F]: the slot-major sort (csrc/radix_sort.hip: the slot is known from the entry's position, the sort runs on local rows)
+    const bool slot_sort = !payload && !sorted_from && !use_rocprim_sort() && radix_slot_sort_ok(B, F, p.bits);
     if ((int64_t)p.total > workspace_bytes || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail(DIR_E_BADARG, "%s: workspace needs %lld bytes, 256-byte aligned", name, (long long)p.total);
     hipStream_t st = as_stream(stream);
@@ -886,6 +892,9 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
         char* src = const_cast<char*>(static_cast<const char*>(sorted_from));
         k1 = reinterpret_cast<uint32_t*>(src + p.off_keys[1]);
         v1 = reinterpret_cast<uint32_t*>(src + p.off_vals[1]);
+    } else if (slot_sort) {
+        if (radix_slot_sort_entries(ws + p.off_tmp, ids, stride_b, stride_f, F, B, row_base, (uint32_t)total_rows, p.bits, k0, k1, v0, v1, st) != hipSuccess)
+            return fail(DIR_E_HIP, "%s: radix sort failed", name);
     } else {
         // the key pass writes where the sort wants its input (an even number of digit passes starts from the second pair of buffers)
         const bool second = !use_rocprim_sort() && radix_sort_input_buffer((size_t)n, p.bits) == 1;
@@ -899,7 +908,7 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
                                (uint32_t)total_rows, kin, vin);
     }
     DIR_CHECK_LAUNCH(name);
-    if (!sorted_from) {
+    if (!sorted_from && !slot_sort) {
 #if defined(DIR_WITH_ROCPRIM_SORT)
         if (use_rocprim_sort()) {
             size_t tmp = p.tmp_bytes;
@@ -1199,7 +1208,7 @@ extern "C" int dir_sparse_adagrad_sorted_payload_f32(float* const* tables, float
 extern "C" int64_t dir_sparse_adam_workspace_bytes(int64_t B, int F, int K, int64_t total_rows) {
     if (B < 0 || F <= 0 || F > 64 || K <= 0 || (K & 3) || 64 % (K / 4) || total_rows <= 0 || total_rows >= 0xffffffffll || B * F >= 0x7fffffffll) return 0;
     AdaSortedPlan p;
-    const int64_t sorted = B > 0 ? (adagrad_sorted_plan(B * F, K, total_rows, p) ? (int64_t)p.total : -1) : 0;
+    const int64_t sorted = B > 0 ? (adagrad_sorted_plan(B * F, K, total_rows, p, B, F) ? (int64_t)p.total : -1) : 0;
     if (sorted < 0) return 0;
     return sorted + 512 + ((total_rows + 255) & ~(int64_t)255);      // + norm2 [64] u64 + the row marks (one byte per row)
 }

@@ -85,6 +85,11 @@ inline int grid_resident(int64_t work_blocks, int resident) {
 size_t radix_sort_temp_bytes(size_t n, unsigned bits);
 int radix_sort_input_buffer(size_t n, unsigned bits);       // 0: the input pairs go to k0 / v0, 1: to k1 / v1; sorted pairs always land in k1 / v1
 hipError_t radix_sort_pairs_u32(void* tmp, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, unsigned bits, hipStream_t st);
+// the slot-major form for one-hot entries ids [B, F] (gbits = bit_length(total_rows)): see csrc/radix_sort.hip
+bool radix_slot_sort_ok(int64_t B, int F, unsigned gbits);
+size_t radix_slot_sort_temp_bytes(int64_t B, int F, unsigned gbits);
+hipError_t radix_slot_sort_entries(void* tmp, const int64_t* ids, int64_t sb, int64_t sf, int F, int64_t B, const int64_t* row_base,
+                                   uint32_t total_rows, unsigned gbits, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, hipStream_t st);
 hipError_t zero_async(void* p, size_t bytes, hipStream_t st);                                                // p, bytes: multiples of 4
 hipError_t zero_2d_async(void* p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t st);      // as hipMemset2DAsync(.., 0, ..)
 

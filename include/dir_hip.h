@@ -880,6 +880,17 @@ int64_t dir_debug_radix_sort_workspace_bytes(int64_t n, int bits);
 int dir_debug_radix_sort_pairs_u32(uint32_t* keys_in, uint32_t* vals_in, int64_t n, int bits, uint32_t* keys_out, uint32_t* vals_out,
                                    void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 
+/* The slot-major form of that sort, which the sorted sparse updates take for one-hot entries ids [B, F] with B >= 4096: slot f's entries
+ * are written as one segment (the slot is known from the entry's position: no sort pass for it) and every segment is sorted by its LOCAL
+ * row, 10 bits per launch -- two launches for a 10^6-row vocabulary where the 25-bit global keys needed three, look-backs inside a segment.
+ * -> keys_out = global rows row_base[f] + id (total_rows for a pruned id: id < 0 or >= slot f's vocabulary), vals_out = entries b F + f,
+ * ordered by (slot, local row with pruned ids last, b).  row_base: [F] device, total_rows < 2^32 - 1.  workspace:
+ * dir_debug_slot_sort_workspace_bytes device bytes (0: the shape is not covered, the updates sort global keys), any content. */
+int64_t dir_debug_slot_sort_workspace_bytes(int64_t B, int F, int64_t total_rows);
+int dir_debug_slot_sort_entries(const int64_t* ids, int64_t stride_b, int64_t stride_f, int F, int64_t B, const int64_t* row_base,
+                                int64_t total_rows, uint32_t* keys_out, uint32_t* vals_out, void* workspace, int64_t workspace_bytes,
+                                dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

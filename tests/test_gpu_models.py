@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 from oracle import np_ref as R  # noqa: E402
 
 
-def _free_port():
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _init_single_rank():
+    """One-rank RCCL process group over a FileStore: no TCP port to clash on (a probed-free port was taken again before the rendezvous
+    bound it on a shared GPU host: EADDRINUSE)."""
+    import tempfile
+    import torch.distributed as dist
+    d = tempfile.mkdtemp(prefix="dir_pg_")
+    dist.init_process_group("nccl", init_method="file://" + os.path.join(d, "store"), rank=0, world_size=1, device_id=torch.device("cuda", 0))
 
 
 def _close(got, ref, tol=1e-5):
@@ -419,11 +419,9 @@ def test_gather_rows_and_sharded_lookup_single_gpu(built_lib, oracle):
     got = ops.gather_rows([torch.from_numpy(t).cuda() for t in full], torch.from_numpy(slot).cuda(), torch.from_numpy(row).cuda())
     ref = np.stack([full[s][r] if r >= 0 else np.zeros(K, np.float32) for s, r in zip(slot, row)])
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(_free_port())        # a fresh port per rendezvous: no TIME_WAIT clashes between tests
     created = False
     if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        _init_single_rank()
         created = True
     try:
         st = ShardedTables.from_full([torch.from_numpy(t).cuda() for t in full], force_collective=True)
@@ -513,11 +511,9 @@ def test_sharded_training_step_single_gpu(built_lib):
     full = [rng.standard_normal((v, K)).astype(np.float32) for v in vocab]
     ids = np.stack([rng.integers(-1, v, size=B) for v in vocab], 1).astype(np.int64)
     gout = (rng.standard_normal((B, F * K)) * 0.5).astype(np.float32)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(_free_port())        # a fresh port per rendezvous: no TIME_WAIT clashes between tests
     created = False
     if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        _init_single_rank()
         created = True
     try:
         tabs = [torch.from_numpy(t.copy()).cuda() for t in full]
@@ -934,11 +930,9 @@ def test_sharded_lookup_fixed_capacity_paths_single_gpu(built_lib, oracle):
     ids = np.stack([rng.integers(-1, v, size=B) for v in vocab], 1).astype(np.int64)
     ref = R.embedding_bag_onehot(full, ids)
     ref_fm = oracle.fm_second_order(ref, F, K)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(_free_port())
     created = False
     if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        _init_single_rank()
         created = True
     try:
         tabs = [torch.from_numpy(t).cuda() for t in full]

@@ -60,6 +60,75 @@ def test_radix_sort_ignores_key_bits_above_bits(built_lib):
     assert np.array_equal(ko.cpu().numpy().view(np.uint32), k[order]) and np.array_equal(vo.cpu().numpy().view(np.uint32), v[order])
 
 
+def _slot_sort(lib, ids, vocab):
+    B, F = ids.shape
+    row_base = torch.tensor(np.concatenate([[0], np.cumsum(vocab)[:-1]]), dtype=torch.int64, device="cuda")
+    total = int(sum(vocab))
+    need = int(lib.dir_debug_slot_sort_workspace_bytes(B, F, total))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    ws.random_(0, 255)                                   # "any content"
+    ko = torch.empty(B * F, dtype=torch.int32, device="cuda")
+    vo = torch.empty(B * F, dtype=torch.int32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())           # noqa: E731
+    rc = lib.dir_debug_slot_sort_entries(p(ids), ids.stride(0), ids.stride(1), F, B, p(row_base), total, p(ko), p(vo), p(ws), need,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.dir_last_error()
+    torch.cuda.synchronize()
+    return ko.cpu().numpy().view(np.uint32), vo.cpu().numpy().view(np.uint32), row_base.cpu().numpy(), total
+
+
+@pytest.mark.parametrize("B,vocab", [
+    (4096, [1000] * 5),                                        # one 10-bit digit per slot
+    (8192, [100000] * 26),                                     # two digits
+    (8193, [7, 1024, 1025, 1 << 20, (1 << 20) - 1, 3000000, 1]),      # 1, 2 (vocab 1024: the pruned key needs an 11th bit), 2, 3, 2, 3 digits, 1
+    (65536, [1000000] * 26),                                   # BASELINE's shape: 3 launches, every segment sits out the first
+    (20000, [40000000, 5, 300]),                               # bits(total_rows) = 26: three launches, one segment uses all of them
+    (5000, [(1 << 31) + 12345, 900]),                          # 32-bit total: four launches
+])
+@pytest.mark.parametrize("kind", ["uniform", "few", "zipf", "strided"])
+def test_slot_sort_matches_stable_cpu_sort(built_lib, B, vocab, kind):
+    """dir_debug_slot_sort_entries (the sort the sorted sparse updates run on ids [B, F], B >= 4096) against numpy: keys = global rows
+    (total_rows for pruned ids: negative, >= the slot's vocabulary), ordered by (slot, local row with pruned last, batch position);
+    slots of very different vocabularies (1 to 4 digit launches) in one call; ids through a strided view."""
+    F = len(vocab)
+    rng = np.random.default_rng(B + F + len(kind))
+    cols = []
+    for v in vocab:
+        if kind == "few":
+            c = rng.choice(rng.integers(0, v, size=4), size=B)
+        elif kind == "zipf":
+            c = np.minimum(rng.zipf(1.1, size=B) - 1, v - 1)
+        else:
+            c = rng.integers(0, v, size=B)
+        c = c.astype(np.int64)
+        c[rng.random(B) < 0.03] = -1                      # pruned
+        c[rng.random(B) < 0.02] = v + int(rng.integers(0, 5))      # out of the vocabulary: pruned too
+        cols.append(c)
+    ids_np = np.stack(cols, axis=1)
+    if kind == "strided":
+        wide = torch.full((B, 2 * F + 3), -7, dtype=torch.int64, device="cuda")
+        ids = wide[:, 1:1 + 2 * F:2]
+        ids.copy_(torch.from_numpy(ids_np))
+    else:
+        ids = torch.from_numpy(ids_np).cuda()
+    ko, vo, row_base, total = _slot_sort(built_lib, ids, vocab)
+    ek, ev = [], []
+    for f, v in enumerate(vocab):
+        c = ids_np[:, f]
+        ok = (c >= 0) & (c < v)
+        local = np.where(ok, c, v)
+        order = np.argsort(local, kind="stable")
+        ek.append(np.where(ok[order], row_base[f] + c[order], total).astype(np.uint32))
+        ev.append((order * F + f).astype(np.uint32))
+    assert np.array_equal(ko, np.concatenate(ek)) and np.array_equal(vo, np.concatenate(ev))
+
+
+def test_slot_sort_covers_what_it_says(built_lib):
+    assert built_lib.dir_debug_slot_sort_workspace_bytes(4095, 26, 26000) == 0          # small batches sort global keys
+    assert built_lib.dir_debug_slot_sort_workspace_bytes(4096, 26, 26000) > 0
+
+
 def _sparse_step_factory(seed, V=50000, B=8192, F=26, K=16):
     from dir_amd import ops
     gen = torch.Generator(device="cuda").manual_seed(seed)
