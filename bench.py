@@ -775,7 +775,7 @@ def main():
                B * ((F * (8 + 8 * K) + 4) + 4 * K + F * (8 + 4 + 4 * K + 4 * 4 * K)))
         roof = {"bound": "hbm", "alg_bytes": alg,
                 "kernel": ("gather_onehot_k + fm_bwd_k + " if layout == "split_unfused" else "gather_packed_rows_k (+ field sums) + ") +
-                          ("adagrad_keys_k + rocprim radix sort + adagrad_tile_k" + ("" if layout == "split_unfused" else "<FM folded in>") +
+                          ("rss_keys_k + rss_hist_k + rs_pass_k<10, slot> (in-tree slot-major radix sort) + adagrad_tile_k" + ("" if layout == "split_unfused" else "<FM folded in>") +
                            " + adagrad_fix_k" if args.adagrad_method == "sorted" else "adagrad_link_k + adagrad_apply_k")}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "adagrad": args.adagrad_method, "ids": args.id_dist, "layout": layout})
     elif wl == "multihot_bag":
