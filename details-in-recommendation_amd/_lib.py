@@ -49,6 +49,7 @@ SIGNATURES = {
     "dir_units1_relu_backward_bits_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_units1_backward_partials": (c_i64, [c_i64, c_i32]),
     "dir_units1_backward_f32": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "dir_units1_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_bn_train_partials": (c_i64, [c_i64, c_i32]),
     "dir_bn_train_stats_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        c_i64, c_vp]),

@@ -186,9 +186,64 @@ static HbPlan hb_plan(int64_t B, int N) {
     return p;
 }
 
+// The FORWARD of a units = 1 layer: y[b] = x[b, :] . w + bias -- the logit heads of the towers in training (deepFM.py:311-317, ESMM.py:146:
+// the hidden activation has to be kept for the backward, so the fused head of the inference kernels does not apply), DCN's final dense(1)
+// over the cross output (DeepCrossNetwork.py:136-137) and xDeepFM's CIN output layer.  One pass over x (the library ran these
+// [B, N] x [N, 1] products as a GEMM with one output column: 26 us at 65 536 x 400 = 4 TB/s of x; its GEMV: 62 us).  LPR lanes share a row
+// (16-byte loads where rows are 16-byte aligned, 4-byte loads otherwise), partial sums meet in a fixed butterfly: bitwise reproducible.
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void units1_fwd_k(const float* __restrict__ x, int64_t x_ld, int64_t B, int N, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ y, int64_t y_ld) {
+    constexpr int RPB = 256 / LPR;                       // rows per workgroup and step
+    const int lane = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const float b0 = bias ? bias[0] : 0.f;
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < B; r0 += (int64_t)gridDim.x * RPB) {
+        const int64_t r = r0 + rl;
+        float acc = 0.f;
+        if (r < B) {
+            const float* __restrict__ xr = x + r * x_ld;
+            if (VEC == 4) {
+                float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = lane * 4; k < N; k += LPR * 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xr + k);
+                    const float4 wv = *reinterpret_cast<const float4*>(w + k);
+                    a4.x = fmaf(xv.x, wv.x, a4.x);
+                    a4.y = fmaf(xv.y, wv.y, a4.y);
+                    a4.z = fmaf(xv.z, wv.z, a4.z);
+                    a4.w = fmaf(xv.w, wv.w, a4.w);
+                }
+                acc = (a4.x + a4.y) + (a4.z + a4.w);
+            } else {
+                for (int k = lane; k < N; k += LPR) acc = fmaf(xr[k], w[k], acc);
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, LPR);
+        if (lane == 0 && r < B) y[r * y_ld] = acc + b0;
+    }
+}
+
 }  // namespace dir
 
 using namespace dir;
+
+extern "C" int dir_units1_f32(const float* x, int64_t x_ld, int64_t B, int N, const float* w, const float* bias, float* y, int64_t y_ld,
+                              dir_stream_t stream) {
+    const char* name = "dir_units1_f32";
+    DIR_CHECK_ARG(B >= 0 && N > 0, "%s: B=%lld N=%d", name, (long long)B, N);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(x && w && y && x_ld >= N && y_ld >= 1, "%s: null pointer or a row stride smaller than the width", name);
+    hipStream_t st = as_stream(stream);
+    const bool vec = N % 4 == 0 && x_ld % 4 == 0 && aligned16(x) && aligned16(w);
+    if (vec && N <= 256)
+        hipLaunchKernelGGL((units1_fwd_k<4, 16>), dim3(grid_for((B + 15) / 16)), dim3(256), 0, st, x, x_ld, B, N, w, bias, y, y_ld);
+    else if (vec)
+        hipLaunchKernelGGL((units1_fwd_k<4, 32>), dim3(grid_for((B + 7) / 8)), dim3(256), 0, st, x, x_ld, B, N, w, bias, y, y_ld);
+    else
+        hipLaunchKernelGGL((units1_fwd_k<1, 64>), dim3(grid_for((B + 3) / 4)), dim3(256), 0, st, x, x_ld, B, N, w, bias, y, y_ld);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
 
 extern "C" int64_t dir_units1_relu_backward_partials(int64_t B, int N) {
     if (B <= 0 || N <= 0) return 0;

@@ -76,13 +76,18 @@ def _packed_cached(weight):
     return packed
 
 
+# dense_dw_auto_arith's answers that are HIP kernels (narrow layers -- an 80-wide last tower layer, ESMM.py:130-147 -- went to the library's
+# batched GEMM + a sum before: 75 us against 47 / 36 on the bf16 x 3 / fp16 x 2 kernels, profiles/r04_small_dw_probe.txt)
+_DW_KERNELS = ("bf16x3", "small")
+
+
 def _tn_matmul(g, x, splits=16, g_bits=None):
     """g^T x for tall operands ([M, N]^T [M, Kd], M = batch rows): the library's single TN GEMM runs at 0.33 of the fp32 MFMA peak
     at 65 536 x 400 x 416 (a 400 x 416 output leaves most CUs idle); sixteen batched row slices + one sum run at 0.53
     (tools/tn_gemm_probe.py: 425 -> 261 us)."""
     M = g.shape[0]
     if g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
-            and ops.dense_dw_auto_arith(M, g.shape[1], x.shape[1]) == "bf16x3":
+            and ops.dense_dw_auto_arith(M, g.shape[1], x.shape[1]) in _DW_KERNELS:
         return ops.dense_dw(g, x, g_bits=g_bits)        # dir_dense_dw_{bf16x3,f16x2}_f32 where the operands are covered (tools/dense_dw_probe.py)
     if M >= 8192 and M % splits == 0 and g.is_contiguous() and x.is_contiguous():
         return torch.bmm(g.view(splits, M // splits, -1).transpose(1, 2), x.view(splits, M // splits, -1)).sum(dim=0)
@@ -106,7 +111,7 @@ def _wb_grads(g, x, need_w, need_b, g_bits=None):
     """(dL/dW, dL/db) of a dense layer from g = dL/d(pre-activation) and its input x: one pass of dir_dense_dw_bf16x3_f32 for both where
     it covers the shape, otherwise the library GEMM and a column sum."""
     if need_w and need_b and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
-            and ops.dense_dw_auto_arith(g.shape[0], g.shape[1], x.shape[1]) == "bf16x3":
+            and ops.dense_dw_auto_arith(g.shape[0], g.shape[1], x.shape[1]) in _DW_KERNELS:
         gw, gb = ops.dense_dw(g, x, want_bias=True, g_bits=g_bits)
         if gb is not None:
             return gw, gb
@@ -269,7 +274,7 @@ class _MlpHeadFn(torch.autograd.Function):
         ctx.L = L
         ctx.bounded = bounded
         ctx.save_for_backward(x, head_w, *params[0::2], *ys)
-        return h @ head_w.t() + head_b              # (a [B, N] x [N, 1] GEMM: 26 us at 65 536 x 400; the library's GEMV takes 62)
+        return ops.units1(h, head_w, head_b)        # (dir_units1_f32; the library ran it as a one-column GEMM: 26 us at 65 536 x 400, its GEMV 62)
 
     @staticmethod
     @torch.no_grad()
@@ -358,6 +363,8 @@ class _Units1Fn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and weight.dtype == torch.float32:
+            return ops.units1(x, weight, bias)      # dir_units1_f32: one pass over x, any width
         y = x @ weight.t()
         return y + bias if bias is not None else y
 
@@ -379,6 +386,9 @@ def units1(lin, x):
     """lin(x) for an nn.Linear with one output unit; the elementwise backward when training on the GPU."""
     if lin.out_features == 1 and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad):
         return _Units1Fn.apply(x, lin.weight, lin.bias)
+    if lin.out_features == 1 and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and lin.weight.dtype == torch.float32 \
+            and not (torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)):
+        return ops.units1(x, lin.weight.detach(), lin.bias.detach() if lin.bias is not None else None)
     return lin(x)
 
 

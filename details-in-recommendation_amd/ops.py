@@ -987,20 +987,20 @@ DENSE_DW_ARITH = os.environ.get("DIR_DENSE_DW_ARITH", "auto")        # "f32": th
 
 
 def dense_dw_auto_arith(M, N, K):
-    """"bf16x3" where dir_dense_dw_bf16x3_f32 (weight and bias gradient in one pass) is the faster formulation (tools/dense_dw_probe.py,
-    M = 65 536: 360 x 416 190 vs 243 us for the library GEMM + column sum, 208 x 416 135 vs 172, 1024 x 128 139 vs 178): a tall reduction
-    (>= 8192 rows), at least 200 output rows and 70 000 elements (200 x 360: 97 vs 120 + the column sum; 128 x 1024 loses: 211 vs 151) and a block grid (256
-    output rows x 8 / 13 / 16 column tiles) that pads the gradient by at most 1.4 (320 x 320 pads 1.6 and loses); otherwise "f32"."""
+    """"bf16x3" where dir_dense_dw_bf16x3_f32 (weight and bias gradient in one pass; dir_dense_dw_f16x2_f32 when the caller has the scales)
+    is the faster formulation.  tools/small_dw_probe.py at 65 536 rows (profiles/r04_small_dw_probe.txt): it beats the library GEMM + column
+    sum at every output from 40 x 80 to 1024 x 128 (80 x 200: 47 vs 75 us, 200 x 80: 34 vs 76, 360 x 416: 190 vs 243, 320 x 320: 153 vs 165)
+    and the fp32 FMA kernel "small" wherever that applies (80 x 64: 30 vs 40 us, 80 x 200: 47 vs 78) -- except very thin outputs (16 x 416:
+    51 vs 43) and a row block that is at least half padding under a long reduction-free side (128 x 1024: 188 vs 147).  Below
+    DENSE_DW_MIN_ROWS rows: "small" for outputs up to 128 x 256, otherwise "f32" (the library GEMM in row slices)."""
     if DENSE_ARITH == "f32" or DENSE_DW_ARITH == "f32" or N % 4 or K % 4:
         return "f32"
-    if N <= 128 and K <= 256 and -(-N // 8) * -(-K // 8) <= 256:
-        # tall and skinny (the DIN unit's per-sample term, 80 x 64: 215 us on the library, 137 on the MFMA kernel, ~25 on the FMA kernel)
-        return "small" if M >= 2048 and N * K >= 512 else "f32"
-    if M < DENSE_DW_MIN_ROWS or N < 200 or N * K < 70000:
+    fits_small = N <= 128 and K <= 256 and -(-N // 8) * -(-K // 8) <= 256 and M >= 2048 and N * K >= 512
+    if M < DENSE_DW_MIN_ROWS or N < 32:
+        return "small" if fits_small else "f32"
+    if -(-N // 256) * 256 >= 2 * N and N * K > 60000:
         return "f32"
-    nt, kt = -(-N // 16), -(-K // 16)
-    kpad = min(-(-kt // 16) * 16, -(-kt // 13) * 13, -(-kt // 8) * 8)
-    return "bf16x3" if (-(-nt // 16) * 16) * kpad <= 1.4 * nt * kt else "f32"
+    return "bf16x3"
 
 
 def dense_dw(g, x, arith=None, want_bias=False, g_bits=None):
@@ -1096,6 +1096,28 @@ def units1_relu_backward(g, w, y, want_bits=False):
         _lib.check(lib.dir_units1_relu_backward_f32(_ptr(g), _ptr(w), _ptr(y), y.stride(0), B, N, _ptr(gx), gx.stride(0), _ptr(part), P, _stream()))
     s = part[0] if P == 1 else part.sum(dim=0)
     return (gx, s[1], s[0], bits) if want_bits else (gx, s[1], s[0])
+
+
+def units1(x, w, bias=None, out=None):
+    """logit = x . w + bias, a dense layer with one unit (include/dir_hip.h: dir_units1_f32; deepFM.py:311-317, ESMM.py:146,
+    DeepCrossNetwork.py:136-137): x [B, N] (unit column stride), w [N] or [1, N], bias [1] or None -> [B, 1]."""
+    _dev(x, torch.float32, "x")
+    _dev(w, torch.float32, "w")
+    if x.dim() != 2 or w.numel() != x.shape[1] or (x.shape[0] > 0 and x.stride(1) != 1):
+        raise ValueError("units1: x [B, N] with unit column stride, w [N]")
+    B, N = x.shape
+    w = w.reshape(N).contiguous()
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "bias").reshape(-1)
+        if bias.numel() != 1:
+            raise ValueError("units1: bias holds one value")
+    if out is None:
+        out = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, 1) or out.dtype != torch.float32 or not out.is_cuda:
+        raise ValueError("units1: out [B, 1] float32 on the GPU")
+    _lib.check(_lib.load().dir_units1_f32(_ptr(x), x.stride(0) if B > 0 else N, B, N, _ptr(w), _ptr(bias), _ptr(out), out.stride(0) if B > 0 else 1,
+                                          _stream()))
+    return out
 
 
 def units1_backward(g, w, x, want_gx=True):

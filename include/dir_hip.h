@@ -585,6 +585,14 @@ int dir_units1_relu_backward_bits_f32(const float* g, const float* w, const floa
                                       float* partials, int64_t n_partials, unsigned int* gx_row_bits, unsigned int* gx_all_bits,
                                       dir_stream_t stream);
 
+/* The forward of a units = 1 layer, y[b * y_ld] = x[b, :] . w + bias[0] (bias NULL: none): the logit heads in training -- where the hidden
+ * activation is kept for the backward, so the inference kernels' fused head does not apply -- (models/DeepFM/deepFM.py:311-317,
+ * models/ESMM/ESMM.py:146), DCN's final dense(1) over concat([cross, deep]) (models/DeepCrossNetwork/DeepCrossNetwork.py:136-137) and
+ * xDeepFM's CIN output layer: one pass over x, any width (16-byte loads when N and x_ld are multiples of 4 and x, w 16-byte aligned),
+ * bitwise reproducible.  x [B, N] row stride x_ld, w [N], bias device [1]. */
+int dir_units1_f32(const float* x, int64_t x_ld, int64_t B, int N, const float* w, const float* bias, float* y, int64_t y_ld,
+                   dir_stream_t stream);
+
 /* The units = 1 logit layer on top of an activation of any width that is not a ReLU output -- DCN's cross output under the final dense(1)
  * over concat([cross, deep]) (models/DeepCrossNetwork/DeepCrossNetwork.py:136-137), d = 429: gx[b,n] = g[b] * w[n] (gx NULL: skipped),
  * dw[n] = sum_b g[b] * x[b,n], one pass over x.  partials: N * dir_units1_backward_partials(B, N) floats of scratch; the column sums are

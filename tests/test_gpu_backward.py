@@ -1043,8 +1043,10 @@ def test_dense_dw_small_matches_float64(built_lib, M, N, K, gpad, xpad):
     again, gb2 = ops.dense_dw(g, x, arith="small", want_bias=True)
     assert torch.equal(again, got) and torch.equal(gb2, gb)
     assert torch.equal(ops.dense_dw(g, x, arith="small"), got)
-    if M >= 2048 and N * K >= 512:
+    if 2048 <= M < ops.DENSE_DW_MIN_ROWS and N * K >= 512:                  # (tall gradients take the MFMA kernel: faster at every such shape)
         assert ops.dense_dw_auto_arith(M, N, K) == "small" and torch.equal(ops.dense_dw(g, x), got)
+    elif M >= ops.DENSE_DW_MIN_ROWS and N >= 32:
+        assert ops.dense_dw_auto_arith(M, N, K) == "bf16x3" and torch.equal(ops.dense_dw(g, x), ops.dense_dw(g, x, arith="bf16x3"))
     with pytest.raises(ValueError):
         ops.dense_dw(torch.zeros(64, 132, device="cuda"), torch.zeros(64, 8, device="cuda"), arith="small")
     with pytest.raises(ValueError):
@@ -1092,9 +1094,10 @@ def test_dense_dw_bf16x3_edges(built_lib):
     with pytest.raises(ValueError):
         ops.dense_dw(torch.randn(64, 24, device="cuda")[:, 1:21], odd_x, arith="bf16x3")        # a view that is not 16-byte aligned
     assert ops.dense_dw_auto_arith(65536, 400, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 200, 360) == "bf16x3"
-    assert ops.dense_dw_auto_arith(65536, 360, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 320, 320) == "f32"
+    assert ops.dense_dw_auto_arith(65536, 360, 416) == "bf16x3" and ops.dense_dw_auto_arith(65536, 320, 320) == "bf16x3"
     assert ops.dense_dw_auto_arith(65536, 128, 1024) == "f32" and ops.dense_dw_auto_arith(65536, 1024, 128) == "bf16x3"
-    assert ops.dense_dw_auto_arith(4096, 400, 416) == "f32"
+    assert ops.dense_dw_auto_arith(65536, 80, 200) == "bf16x3" and ops.dense_dw_auto_arith(65536, 16, 416) == "f32"
+    assert ops.dense_dw_auto_arith(4096, 400, 416) == "f32" and ops.dense_dw_auto_arith(4096, 80, 64) == "small"
 
 
 @pytest.mark.parametrize("B,N,pad", [(300, 400, 0), (1, 16, 0), (65, 64, 4), (1000, 1024, 0), (777, 520, 8), (4096, 4096, 0), (33, 132, 0)])

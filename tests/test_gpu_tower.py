@@ -304,6 +304,46 @@ def test_tower_splits_agree_and_general_inputs_stay_on_bf16x3(built_lib):
     assert bool(torch.isfinite(gb).all())
 
 
+@pytest.mark.parametrize("B,N,strided", [(65536, 400, False), (8193, 429, False), (5000, 80, False), (4097, 1024, True), (3, 7, False), (0, 16, False),
+                                         (777, 4096, False), (1000, 384, True)])
+def test_units1_forward(built_lib, B, N, strided):
+    """dir_units1_f32 (the logit heads in training, DCN's dense(1) over d = 429, xDeepFM's CIN output layer): x . w + bias against float64,
+    bitwise equal run to run, through a column view of a wider tensor (row stride != N), with and without a bias."""
+    from dir_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(B + N)
+    wide = torch.randn((B, N + (12 if strided else 0)), generator=gen, device="cuda")
+    x = wide[:, 4:4 + N] if strided else wide
+    w = torch.randn((1, N), generator=gen, device="cuda") / N ** 0.5
+    b = torch.randn(1, generator=gen, device="cuda")
+    for bias in (b, None):
+        y = ops.units1(x, w, bias)
+        assert tuple(y.shape) == (B, 1)
+        ref = x.double() @ w.double().t() + (bias.double() if bias is not None else 0.0)
+        if B:
+            assert float((y.double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+        assert torch.equal(y, ops.units1(x, w, bias))
+    with pytest.raises(ValueError):
+        ops.units1(x, w[:, :-1], b)
+
+
+def test_narrow_weight_gradients_run_the_hip_kernel(built_lib):
+    """dense._tn_matmul / _wb_grads route narrow outputs (an 80-wide last tower layer, ESMM.py:130-147) to dir_dense_dw_bf16x3_f32 instead
+    of the library's batched GEMM + sum: against float64 and bit for bit the kernel called by name."""
+    from dir_amd import ops
+    from dir_amd import dense as D
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K = 16384, 80, 200
+    g = torch.randn((M, N), generator=gen, device="cuda") * 1e-3
+    x = torch.randn((M, K), generator=gen, device="cuda")
+    assert ops.dense_dw_auto_arith(M, N, K) == "bf16x3"
+    gw, gb = D._wb_grads(g, x, True, True)
+    kw, kb = ops.dense_dw(g, x, arith="bf16x3", want_bias=True)
+    assert torch.equal(gw, kw) and torch.equal(gb, kb) and torch.equal(D._tn_matmul(g, x), kw)
+    ref = g.double().t() @ x.double()
+    assert float((gw.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((gb.double() - g.double().sum(0)).abs().max()) <= 1e-5 * float(g.double().sum(0).abs().max())
+
+
 def test_tower_default_split_checks_the_fp16_range_of_weights_and_packed_rows(built_lib):
     """split=None measures what it can without a per-call sync: a weight (per image build) or a packed serving row (per PackedTables)
     at or above ops.F16_RANGE_GUARD routes the launch to bf16 x 3 -- bit for bit the explicit split="bf16x3" result, finite and within
