@@ -315,8 +315,9 @@ _FWD_BOUNDED = [False]      # the forward of the node being applied may take the
 
 def mlp_head(lins, head, x, embedding_input=False):
     """head(relu(lin_L(... relu(lin_1(x))))) -> [B, 1] through _MlpHeadFn (check mlp_head_supported first).  embedding_input: the caller
-    vouches that x is a concatenation of embedding rows (DeepFM's dnn input): the forward layers may then run dir_dense_f16x2_f32; the
-    backward (gradient operands) is bf16 x 3 either way."""
+    vouches that x is a concatenation of embedding rows (DeepFM's dnn input, ESMM's input layer over embedding columns): the forward layers
+    and the weight gradients (g scaled by one power of two, x as it is) may then run the fp16 x 2 kernels; without it the first layer runs
+    the row-scaled general-input kernel and its weight gradient bf16 x 3."""
     params = []
     for lin in lins:
         params += [lin.weight, lin.bias]

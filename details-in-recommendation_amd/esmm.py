@@ -49,13 +49,14 @@ class _BaseModel(nn.Module):
             if fused is not None:
                 return fused
         net = self.input_layer(features, memo=memo)
-        fused = tower_infer(self.hidden, net, self.activation, head=self.logits)          # inference: tower + logit layer in one launch
+        emb_in = self.input_layer.embedding_only       # the input is a concatenation of embedding rows (ESMM.py:135 over embedding columns)
+        fused = tower_infer(self.hidden, net, self.activation, head=self.logits, embedding_input=emb_in)      # inference: tower + logit layer in one launch
         if fused is not None:
             return fused
         if not self.dropout and mlp_stack_supported(self.hidden, net, self.activation):
             if mlp_head_supported(self.hidden, self.logits, net, self.activation):
-                return mlp_head(self.hidden, self.logits, net)                           # training: tower + logit layer as one autograd node
-            return units1(self.logits, mlp_stack(self.hidden, net))                      # training: the whole tower as one autograd node
+                return mlp_head(self.hidden, self.logits, net, embedding_input=emb_in)   # training: tower + logit layer as one autograd node
+            return units1(self.logits, mlp_stack(self.hidden, net, embedding_input=emb_in))      # training: the whole tower as one autograd node
         for lin in self.hidden:
             net = dense_act(lin, net, self.activation)                           # dir_dense_f32 when covered
             net = _dropout_train(self, net, self.dropout)                        # ESMM.py:143-144 (TRAIN only)

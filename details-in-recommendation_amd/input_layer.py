@@ -35,6 +35,9 @@ class InputLayer(nn.Module):
             d += c.dimension
         self.column_num = d
         self.emb_cols = [c for c in self.columns if isinstance(c, EmbeddingColumn)]
+        # every column an embedding column: the output is a concatenation of (combined) embedding rows -- the bounded magnitudes the
+        # fp16 x 2 dense kernels want (dense.mlp_head(embedding_input=...)); numeric columns carry raw values (capital_gain: 99 999)
+        self.embedding_only = len(self.emb_cols) == len(self.columns)
         self.embedding_weights = nn.ParameterList()
         for c in self.emb_cols:
             w = torch.empty(c.num_buckets, c.dimension)
