@@ -1312,17 +1312,22 @@ def din_attention_pool_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3,
             _ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]), H2,
             _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B, _ptr(g), _ptr(row_off), _ptr(gh), _ptr(ga), _ptr(S), _ptr(gAP),
             _ptr(gW2), _ptr(gb2), _ptr(gW3), _ptr(gb3), _ptr(ws), _stream()))
-    # the per-sample term a.(Wa - Wd) + b1: two [B, .] GEMMs (rocBLAS)
+    # the per-sample term a.(Wa - Wd) + b1: ga += S C^T (dir_dense_f32, C is its [out, in] weight) and C's gradient S^T a
     W1 = args[0]
     C = W1[K:2 * K] - W1[2 * K:3 * K]
     a = table[cand.clamp(min=0)] * (cand >= 0).unsqueeze(1)
-    ga.addmm_(S, C.t())
+    if _DIN_GA_LIBRARY or not dense_supported(S, C):
+        ga.addmm_(S, C.t())                           # (uncovered widths; DIR_DIN_GA_LIBRARY=1: development A/B switch)
+    else:
+        ga.add_(dense(S, C.contiguous(), None, relu=False))
     gCt, gb1 = dense_dw(S, a, want_bias=True)            # S^T a [H1, K] and S's column sums in one pass (dir_dense_dw_small_f32 at 80 x 64)
     gC = gCt.t()
     gA, gWp = gAP[:K], gAP[K:]
     return {"ids_h": _masked_rows(hist, valid, N), "gh": gh, "ga": ga, "grows": grows, "gW1": torch.cat([gA, gC, gA - gC, gWp], dim=0), "gb1": gb1,
             "gW2": gW2, "gb2": gb2, "gW3": gW3, "gb3": gb3}
 
+
+_DIN_GA_LIBRARY = os.environ.get("DIR_DIN_GA_LIBRARY", "0") == "1"
 
 # default arithmetic of cin_layer: "auto" (the split kernels on the shapes they cover, fp32 MFMA otherwise) | "f32" | "bf16x3" | "f16x2"
 CIN_ARITH = os.environ.get("DIR_CIN_ARITH", "auto")

@@ -27,9 +27,9 @@ def wrap(obj, name, label):
     setattr(obj, name, g)
 
 
-for n in ("matmul", "mm", "bmm", "addmm", "baddbmm", "einsum"):
+for n in ("matmul", "mm", "bmm", "addmm", "baddbmm", "einsum", "mv", "addmv", "tensordot", "inner", "addbmm", "chain_matmul"):
     wrap(torch, n, "torch." + n)
-for n in ("__matmul__", "__rmatmul__", "matmul", "mm", "bmm"):
+for n in ("__matmul__", "__rmatmul__", "matmul", "mm", "bmm", "addmm", "addmm_", "mv", "addmv", "addmv_", "baddbmm", "baddbmm_", "addbmm", "addbmm_"):
     wrap(torch.Tensor, n, "Tensor." + n)
 wrap(torch.nn.functional, "linear", "F.linear")
 wl = sys.argv[1]
