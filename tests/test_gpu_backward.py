@@ -233,6 +233,55 @@ def test_sparse_updates_never_write_outside_a_table(built_lib, method):
         assert float(lw[f][torch.from_numpy(untouched).cuda()].abs().sum()) == 0.0
 
 
+def test_sorted_updates_over_the_slot_major_sort(built_lib):
+    """B >= 4096: the sorted updates run the slot-major sort (csrc/radix_sort.hip: local rows, 10 bits per launch; a slot's digit count
+    follows its vocabulary).  Tables of 3, 1030, 70 000 and 2^20 + 5 rows in one update (1, 2, 2 and 3 digits), pruned ids (-1) and ids past
+    the vocabulary (skipped like pruned ones: nothing outside a table is written), heavy duplicates in the small tables: Adagrad against
+    the float64 dedup-sum rule over two steps, bitwise equal to a second run, and FTRL through the same sort."""
+    from dir_amd import ops
+    rng = np.random.default_rng(77)
+    B, K = 9000, 16
+    vocab = [3, 1030, 70000, (1 << 20) + 5]
+    F = len(vocab)
+    assert built_lib.dir_debug_slot_sort_workspace_bytes(B, F, sum(vocab)) > 0
+    tabs = [(rng.standard_normal((v, K)) * 0.1).astype(np.float32) for v in vocab]
+    runs = []
+    for rep in range(2):
+        rng2 = np.random.default_rng(5)
+        dev = [torch.from_numpy(t.copy()).cuda() for t in tabs]
+        opt = ops.SparseAdagrad(dev, lr=0.05, initial_accumulator_value=0.1, method="sorted")
+        ref_w = [t.astype(np.float64) for t in tabs]
+        ref_a = [np.full((v, K), 0.1) for v in vocab]
+        for step in range(2):
+            ids = np.stack([rng2.integers(-1, v + 3, size=B) for v in vocab], 1).astype(np.int64)
+            grad = (rng2.standard_normal((B, F * K)) * 0.5).astype(np.float32)
+            opt.step(torch.from_numpy(ids).cuda(), torch.from_numpy(grad).cuda())
+            if rep:
+                continue
+            for f, v in enumerate(vocab):
+                ok = (ids[:, f] >= 0) & (ids[:, f] < v)
+                rows, inv = np.unique(ids[ok, f], return_inverse=True)
+                gsum = np.zeros((len(rows), K))
+                np.add.at(gsum, inv, grad[ok, f * K:(f + 1) * K].astype(np.float64))
+                ref_a[f][rows] += gsum ** 2
+                ref_w[f][rows] -= 0.05 * gsum / np.sqrt(ref_a[f][rows])
+        if not rep:
+            for f in range(F):
+                _close(dev[f], ref_w[f], tol=2e-5)
+                _close(opt.accums[f], ref_a[f], tol=2e-5)
+        runs.append([d.clone() for d in dev] + [a.clone() for a in opt.accums])
+    assert all(torch.equal(x, y) for x, y in zip(*runs))
+    lw = [torch.zeros(v, device="cuda") for v in vocab]
+    ftrl = ops.SparseFtrl(lw, lr=0.2)
+    ids = np.stack([rng.integers(-1, v + 3, size=B) for v in vocab], 1).astype(np.int64)
+    ftrl.step(torch.from_numpy(ids).cuda(), torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32)).cuda())
+    for f, v in enumerate(vocab):
+        untouched = np.ones(v, bool)
+        untouched[ids[(ids[:, f] >= 0) & (ids[:, f] < v), f]] = False
+        assert float(lw[f][torch.from_numpy(untouched).cuda()].abs().sum()) == 0.0
+        assert float(lw[f][torch.from_numpy(~untouched).cuda()].abs().sum()) > 0.0 or v == 0
+
+
 def test_sorted_adagrad_bitwise_reproducible_on_skewed_ids(built_lib):
     from dir_amd import ops
     g = torch.Generator().manual_seed(9)
