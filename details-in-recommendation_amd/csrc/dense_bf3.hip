@@ -600,9 +600,14 @@ extern "C" int dir_dense_f16x2_rows_f32(const float* X, int64_t x_ld, const void
         const int CT = db3_ct_for(N);
         const int ncb = ((N + 15) / 16 + CT - 1) / CT;
         hipStream_t st = as_stream(stream);
-        if (zero_async(y_all_bits_out, sizeof(unsigned int), st) != hipSuccess ||
-            (ncb > 1 && zero_async(y_row_bits_out, (size_t)M * sizeof(unsigned int), st) != hipSuccess))
-            return fail(DIR_E_HIP, "dir_dense_f16x2_rows_f32: zeroing failed");
+        hipError_t e;
+        if (ncb > 1 && y_all_bits_out == y_row_bits_out + M)            // one allocation (ops._out_bits): one launch
+            e = zero_async(y_row_bits_out, (size_t)(M + 1) * sizeof(unsigned int), st);
+        else {
+            e = zero_async(y_all_bits_out, sizeof(unsigned int), st);
+            if (e == hipSuccess && ncb > 1) e = zero_async(y_row_bits_out, (size_t)M * sizeof(unsigned int), st);
+        }
+        if (e != hipSuccess) return fail(DIR_E_HIP, "dir_dense_f16x2_rows_f32: zeroing failed");
     }
     return dense_run("dir_dense_f16x2_rows_f32", 2, X, x_ld, image, bias, act, post_scale, post_shift, gate, gate_ld, M, Kd, N, Y, y_ld, stream, row_bits,
                      y_row_bits_out, y_all_bits_out);

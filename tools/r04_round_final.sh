@@ -58,4 +58,6 @@ for w in default deepfm_full esmm_full dcn_full dcn_train deepfm_train esmm_trai
     if [ $w = default ]; then a="--steps 100 --warmup 10 --no-cpu-baseline"; elif [ $w = din ] || [ $w = din_train ] || [ $w = din_full ]; then a="--workload $w --steps 50 --warmup 10 --no-cpu-baseline"; else a="--workload $w --steps 10 --warmup 3 --no-cpu-baseline"; fi
     ROUND=r04 DIR_BENCH_NO_SECONDARY=1 DIR_BENCH_NO_SWEEP=1 bash tools/prof.sh $w -- $a > gpurun_out/prof_$w.txt 2>&1; echo "== $w"; head -5 gpurun_out/prof_$w.txt | cut -c1-150
 done
+# library GEMM kernels (Tensile: "Cijk_...") in any of the traced steps; tools/libcall_probe.py is the Python-side view of the same question
+{ echo "traced workloads whose kernel list holds a Tensile (rocBLAS / hipBLASLt) GEMM:"; grep -l "Cijk_" gpurun_out/r04_kernel_stats_*.csv || echo "  none"; } > gpurun_out/r04_library_kernels.txt; cat gpurun_out/r04_library_kernels.txt
 ROUND=r04 bash tools/traffic.sh > gpurun_out/traffic_r04.txt 2>&1; tail -16 gpurun_out/traffic_r04.txt
