@@ -85,6 +85,7 @@ def _slot_sort(lib, ids, vocab):
     (65536, [1000000] * 26),                                   # BASELINE's shape: 3 launches, every segment sits out the first
     (20000, [40000000, 5, 300]),                               # bits(total_rows) = 26: three launches, one segment uses all of them
     (5000, [(1 << 31) + 12345, 900]),                          # 32-bit total: four launches
+    (4100, [50 + 37 * i for i in range(40)]),                  # more than 32 slots: two transposition chunks; 1 and 2 digits mixed
 ])
 @pytest.mark.parametrize("kind", ["uniform", "few", "zipf", "strided"])
 def test_slot_sort_matches_stable_cpu_sort(built_lib, B, vocab, kind):
