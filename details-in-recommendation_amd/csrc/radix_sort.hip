@@ -133,7 +133,7 @@ __global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ 
     uint32_t (*whist)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(rs_lds);     // [RS_NW][BINS] per-wave digit counts, then each wave's exclusive offset inside the tile
     uint32_t* gbase = rs_lds + RS_NW * BINS;                                      // [BINS] where this tile's keys of digit d start in the output
     uint32_t* toff = gbase + BINS;                                                // [BINS] where digit d starts inside the tile (digit-sorted order)
-    uint32_t (*scan)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(toff + BINS);   // [4][BINS]: two ping-pong pairs (global histogram, tile counts)
+    uint32_t (*scan)[BINS] = reinterpret_cast<uint32_t (*)[BINS]>(toff + BINS);   // scan[0..1][wave]: the waves' totals of the two digit scans (the rest of the [4][BINS] block is unused)
     uint32_t* lkey = toff + BINS + 4 * BINS;                                      // [RS_TILE] the tile's keys in digit order
     uint32_t* lval = lkey + RS_TILE;                                              // [RS_TILE]
     uint32_t& s_tile = lval[RS_TILE];                                             // (all LDS is dynamic: the 160 KiB limit is set for the kernel)
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ 
     }
     const int64_t cbase = tloc * RS_TILE + (int64_t)wave * (64 * RS_ITEMS);
     const uint32_t kmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    const uint32_t gh = tid < BINS ? ghist[tid] : 0u;      // (asked for here: its latency runs under the key loads and the ranking)
     uint32_t key[RS_ITEMS], val[RS_ITEMS];
     uint32_t rank[RS_ITEMS];                     // digit << 16 | rank inside the wave's chunk (< 512)
 #pragma unroll
@@ -205,23 +206,38 @@ __global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ 
         }
         cnt = run;
         st_status(status + tile * BINS + tid, (tloc == 0 ? RS_INCL : RS_AGG) | cnt);
-        scan[0][tid] = ghist[tid];
-        scan[2][tid] = cnt;
+    }
+    // two scans over the digits at once -- the pass's global histogram (where digit d starts in the output) and this tile's counts (where
+    // digit d starts inside the tile): inside a wave by shuffles (64 digits per wave), the waves' totals through LDS.  (Ten Hillis-Steele
+    // steps over LDS with a workgroup barrier each were ~1.5 us of every tile's path.)
+    uint32_t gincl = gh, tincl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ua = __shfl_up(gincl, o), ub = __shfl_up(tincl, o);
+        if (lane >= o) {
+            gincl += ua;
+            tincl += ub;
+        }
+    }
+    if (lane == 63) {
+        scan[0][wave] = gincl;
+        scan[1][wave] = tincl;
     }
     __syncthreads();
-    // two exclusive scans over the digits at once (Hillis-Steele over BINS values): the pass's global histogram (where digit d starts in
-    // the output) and this tile's counts (where digit d starts inside the tile)
-    int cur = 0;
+    {
+        uint32_t pa = 0, pb = 0;
 #pragma unroll
-    for (int off = 1; off < BINS; off <<= 1) {
-        if (tid < BINS) {
-            scan[cur ^ 1][tid] = scan[cur][tid] + (tid >= off ? scan[cur][tid - off] : 0u);
-            scan[2 + (cur ^ 1)][tid] = scan[2 + cur][tid] + (tid >= off ? scan[2 + cur][tid - off] : 0u);
+        for (int w = 0; w < RS_NW; ++w) {
+            const uint32_t ta = scan[0][w], tb = scan[1][w];       // (broadcast reads)
+            if (w < wave) {
+                pa += ta;
+                pb += tb;
+            }
         }
-        cur ^= 1;
-        __syncthreads();
+        gincl += pa;
+        tincl += pb;
     }
-    if (tid < BINS) toff[tid] = scan[2 + cur][tid] - cnt;
+    if (tid < BINS) toff[tid] = tincl - cnt;
     __syncthreads();
     // the tile in digit order, in LDS (needs nothing from other tiles: it runs while they publish their counts).  Direct stores from the
     // ranked registers were 12 of a pass's 28 us: every lane of a store hit its own cache line
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(RS_NT) void rs_pass_k(const uint32_t* __restrict__ 
         }
     }
     if (tid < BINS) {
-        const uint32_t gexcl = scan[cur][tid] - ghist[tid];
+        const uint32_t gexcl = gincl - gh;
         uint32_t prefix = 0;
         if (tloc > 0 && !(dbg & 2)) {
             // Windowed look-back: RS_WIN predecessors' words are loaded at once (independent loads: one latency per window, not per
