@@ -18,7 +18,8 @@ namespace dir {
 
 constexpr int HB_MAXCH = 4;          // float4 column chunks per thread: N <= 4 * 4 * 256
 
-template <int TPR>
+// NCH: float4 column chunks per thread (1 while N <= 4 TPR; the chunk arrays are registers: four of them for a one-chunk width cost occupancy)
+template <int TPR, int NCH = HB_MAXCH>
 __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ y,
                                                    int64_t y_ld, int64_t B, int N, int64_t rows_per_block, float* __restrict__ gx,
                                                    int64_t gx_ld, float* __restrict__ part,
@@ -30,9 +31,9 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
     const int nv = N >> 2;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(B, r0 + rows_per_block);
-    float4 wv[HB_MAXCH], sx[HB_MAXCH], sw[HB_MAXCH];
+    float4 wv[NCH], sx[NCH], sw[NCH];
 #pragma unroll
-    for (int ch = 0; ch < HB_MAXCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int c = c0 + ch * TPR;
         wv[ch] = c < nv ? *reinterpret_cast<const float4*>(w + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
         sx[ch] = sw[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
     if (row_bits) {                                  // (uniform)
         float m = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < HB_MAXCH; ++ch)
+        for (int ch = 0; ch < NCH; ++ch)
             m = fmaxf(fmaxf(m, fmaxf(fabsf(wv[ch].x), fabsf(wv[ch].y))), fmaxf(fabsf(wv[ch].z), fabsf(wv[ch].w)));
         float* rf = reinterpret_cast<float*>(&red[0][0]);
         rf[tid] = m;
@@ -56,26 +57,45 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
         __syncthreads();
     }
     float gmax = 0.f;                                // all_bits: the largest bound of this workgroup's rows, ONE atomic per workgroup at the end
-    for (int64_t r = r0 + rr; r < r1; r += RPI) {
-        const float gr = g[r];
-        if (row_bits && c0 == 0) {
-            const float bnd = fabsf(gr * wmax);
-            row_bits[r] = __builtin_bit_cast(unsigned int, bnd);
-            gmax = fmaxf(gmax, bnd);
+    // HB_UNR rows of a thread are loaded before any of them is used (one row per trip left one 16-byte load per thread in flight: 2 TB/s of
+    // y at four workgroups per CU); the sums still take the rows in ascending order: the same bits as the one-row loop.
+    constexpr int HB_UNR = 4;
+    for (int64_t rb = r0 + rr; rb < r1; rb += HB_UNR * RPI) {
+        float gr[HB_UNR];
+        float4 yv[HB_UNR][NCH];
+#pragma unroll
+        for (int u = 0; u < HB_UNR; ++u) {
+            const int64_t r = rb + u * RPI;
+            gr[u] = r < r1 ? g[r] : 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = c0 + ch * TPR;
+                if (c < nv && r < r1) yv[u][ch] = *reinterpret_cast<const float4*>(y + r * y_ld + 4 * c);
+            }
         }
 #pragma unroll
-        for (int ch = 0; ch < HB_MAXCH; ++ch) {
-            const int c = c0 + ch * TPR;
-            if (c < nv) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + r * y_ld + 4 * c);
-                float4 v;
-                v.x = yv.x > 0.f ? gr * wv[ch].x : 0.f;
-                v.y = yv.y > 0.f ? gr * wv[ch].y : 0.f;
-                v.z = yv.z > 0.f ? gr * wv[ch].z : 0.f;
-                v.w = yv.w > 0.f ? gr * wv[ch].w : 0.f;
-                *reinterpret_cast<float4*>(gx + r * gx_ld + 4 * c) = v;
-                sx[ch].x += v.x; sx[ch].y += v.y; sx[ch].z += v.z; sx[ch].w += v.w;
-                sw[ch].x += gr * yv.x; sw[ch].y += gr * yv.y; sw[ch].z += gr * yv.z; sw[ch].w += gr * yv.w;
+        for (int u = 0; u < HB_UNR; ++u) {
+            const int64_t r = rb + u * RPI;
+            if (r >= r1) break;
+            if (row_bits && c0 == 0) {
+                const float bnd = fabsf(gr[u] * wmax);
+                row_bits[r] = __builtin_bit_cast(unsigned int, bnd);
+                gmax = fmaxf(gmax, bnd);
+            }
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = c0 + ch * TPR;
+                if (c < nv) {
+                    const float4 t = yv[u][ch];
+                    float4 v;
+                    v.x = t.x > 0.f ? gr[u] * wv[ch].x : 0.f;
+                    v.y = t.y > 0.f ? gr[u] * wv[ch].y : 0.f;
+                    v.z = t.z > 0.f ? gr[u] * wv[ch].z : 0.f;
+                    v.w = t.w > 0.f ? gr[u] * wv[ch].w : 0.f;
+                    *reinterpret_cast<float4*>(gx + r * gx_ld + 4 * c) = v;
+                    sx[ch].x += v.x; sx[ch].y += v.y; sx[ch].z += v.z; sx[ch].w += v.w;
+                    sw[ch].x += gr[u] * t.x; sw[ch].y += gr[u] * t.y; sw[ch].z += gr[u] * t.z; sw[ch].w += gr[u] * t.w;
+                }
             }
         }
     }
@@ -92,7 +112,7 @@ __global__ __launch_bounds__(256) void head_bwd_k(const float* __restrict__ g, c
     }
     float* p0 = part + (int64_t)blockIdx.x * 2 * N;
 #pragma unroll
-    for (int ch = 0; ch < HB_MAXCH; ++ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
         const int c = c0 + ch * TPR;
         if (ch * TPR < nv) {                        // uniform: the chunk exists for some thread
             red[0][tid] = sx[ch];
@@ -267,15 +287,16 @@ static int units1_relu_backward(const char* name, const float* g, const float* w
                   (long long)n_partials, (long long)p.nblk);
     hipStream_t st = as_stream(stream);
     if (all_bits && zero_async(all_bits, sizeof(unsigned int), st) != hipSuccess) return fail(DIR_E_HIP, "%s: zeroing failed", name);
-    if (p.tpr == 64)
-        hipLaunchKernelGGL(head_bwd_k<64>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials, row_bits,
-                           all_bits);
-    else if (p.tpr == 128)
-        hipLaunchKernelGGL(head_bwd_k<128>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials,
-                           row_bits, all_bits);
-    else
-        hipLaunchKernelGGL(head_bwd_k<256>, dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials,
-                           row_bits, all_bits);
+#define HB_LAUNCH(TPR_, NCH_)                                                                                                                  \
+    hipLaunchKernelGGL((head_bwd_k<TPR_, NCH_>), dim3((unsigned)p.nblk), dim3(256), 0, st, g, w, y, y_ld, B, N, p.rows_per_block, gx, gx_ld, partials, \
+                       row_bits, all_bits)
+    const int nch = (N / 4 + p.tpr - 1) / p.tpr;          // 1 unless N > 1024 (tpr = 256 then)
+    if (p.tpr == 64) HB_LAUNCH(64, 1);
+    else if (p.tpr == 128) HB_LAUNCH(128, 1);
+    else if (nch <= 1) HB_LAUNCH(256, 1);
+    else if (nch == 2) HB_LAUNCH(256, 2);
+    else HB_LAUNCH(256, 4);
+#undef HB_LAUNCH
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
