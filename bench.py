@@ -510,8 +510,10 @@ def launch_ranks(args):
     port = s.getsockname()[1]
     s.close()
     base = dict(os.environ)
+    import tempfile
     base.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                 "DIR_BENCH_LAUNCHED_BY": "bench.py"})
+                 "DIR_BENCH_LAUNCHED_BY": "bench.py", "DIR_BENCH_STORE_FILE": os.path.join(tempfile.mkdtemp(prefix="dir_bench_pg_"), "store")})
+    base.setdefault("GLOO_SOCKET_IFNAME", "lo")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs between processes on these hosts
     base.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
@@ -624,10 +626,14 @@ def main():
         return 4
     if world > 1:
         torch.cuda.set_device(local_rank)
+        # ranks started by launch_ranks() meet over a FileStore (no TCP port to clash on); under a launcher of the caller's the
+        # MASTER_ADDR / MASTER_PORT it exported
+        store = os.environ.get("DIR_BENCH_STORE_FILE")
+        kw = {"init_method": "file://" + store, "rank": rank, "world_size": world} if store else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)

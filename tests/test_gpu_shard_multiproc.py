@@ -3,7 +3,6 @@ P = 2, dir_gather_packed_f32, the fused finish kernel, dir_sparse_adagrad_sorted
 GPU of the test box.  RCCL refuses two ranks on one device, so the all_to_all_single calls are staged through host memory
 over gloo (a subclass overrides ShardedTables._a2a only); on a multi-GPU node the same code runs with backend "nccl"."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -14,11 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous token for one process group: the path of a FileStore file (no TCP port to clash on -- a port probed free here can be
+    taken again before rank 0 binds it on a shared host)."""
+    import tempfile
+    return os.path.join(tempfile.mkdtemp(prefix="dir_pg_"), "store")
 
 
 def _worker(rank, world, port, vocab, K, B, seed, q):
@@ -32,11 +30,10 @@ def _worker(rank, world, port, vocab, K, B, seed, q):
 def _worker_body(rank, world, port, vocab, K, B, seed, q):
     import sys
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     import torch.distributed as dist
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         torch.cuda.set_device(0)
         import dir_amd  # noqa: F401
@@ -128,12 +125,11 @@ def _trainer_worker(rank, world, port, q):
     try:
         import sys
         sys.path.insert(0, ROOT)
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         os.environ["DIR_SHARD_HOST_STAGED"] = "1"          # two ranks on ONE GPU: exchanges staged through host memory over gloo
         import datetime
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
         try:
             torch.cuda.set_device(0)
             import dir_amd  # noqa: F401

@@ -5,7 +5,6 @@ owner, all_to_all of ids, owner-side row gather, all_to_all of rows, un-permute.
 cannot run without a GPU, so a NumPy/oracle backend stands in for them here through the `backend` injection
 point (test infrastructure; the product default is shard.HipBackend)."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -17,11 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous token for one process group: the path of a FileStore file (no TCP port to clash on -- a port probed free here can be
+    taken again before rank 0 binds it on a shared host)."""
+    import tempfile
+    return os.path.join(tempfile.mkdtemp(prefix="dir_pg_"), "store")
 
 
 def _worker(rank, world, port, vocab, K, B, seed, out_q, train=False, opts=None):
@@ -35,10 +33,9 @@ def _worker(rank, world, port, vocab, K, B, seed, out_q, train=False, opts=None)
 def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
     import sys
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         from dir_amd.shard import ShardedTables, div_range, local_slice, place_slices
         from oracle import np_ref as R
@@ -367,10 +364,9 @@ def _allreduce_worker(rank, world, port, out_q):
     try:
         import sys
         sys.path.insert(0, ROOT)
-        os.environ["MASTER_ADDR"] = "127.0.0.1"
-        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import datetime
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        dist.init_process_group("gloo", init_method="file://" + port, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
         try:
             from dir_amd.shard import allreduce_grads
             g = torch.Generator().manual_seed(11)
