@@ -637,6 +637,74 @@ __global__ __launch_bounds__(256) void adagrad_tile_k(U upd, int F, int K,
     };
     // a tile of (nearly) distinct rows has nothing serial to hide: it skips the LDS round trip (workgroup-uniform choice)
     const bool staged = STAGE && ne - nruns >= stage_min_dups;
+    // Adagrad on a tile of (nearly) distinct rows -- the common tile: uniform ids over 10^6-row tables -- is a random 128-byte
+    // read-modify-write stream plus a random gradient row per entry (tools/rmw_probe.hip: 107 us for the BASELINE step's 1.7 M rows; this
+    // kernel took 167).  What it lost was a chain of dependent round trips per run -- the table pointer, the row (for the folded FM
+    // backward), the gradients, then in apply() the accumulator pointer and the accumulator and weight rows -- times the four runs a
+    // thread group walks one after the other.  Here the table pointers and row bases come from LDS, a run's weight and accumulator chunks
+    // are loaded together and the NEXT run's before the current one is worked on; the arithmetic is apply()'s, bit for bit.
+    constexpr bool ADA = std::is_same<U, AdagradUpd>::value;
+    __shared__ float* stab[ADA ? 64 : 1];
+    __shared__ float* sacc[ADA ? 64 : 1];
+    __shared__ int64_t sbase[ADA ? 64 : 1];
+    if constexpr (ADA) {
+        if (!staged && nt == 0 && F <= 64) {                // (workgroup-uniform)
+            if (tid < F) {
+                stab[tid] = upd.tables[tid];
+                sacc[tid] = upd.accums[tid];
+                sbase[tid] = row_base[tid];
+            }
+            __syncthreads();
+            struct Run { int s, e, f; uint32_t rk; float* wp; float* ap; T wv, av; bool live; };
+            auto fetch = [&](int r, Run& q) {
+                q.live = false;
+                if (r >= nruns) return;
+                q.s = rstart[r];
+                q.e = rstart[r + 1];
+                q.rk = skey[q.s];
+                if (q.rk >= total_rows || c >= kv) return;          // pruned ids / idle lanes of a padded group
+                q.f = (int)(sval[q.s] % (uint32_t)F);
+                const int64_t off = ((int64_t)q.rk - sbase[q.f]) * upd.ld + c * VEC;
+                q.wp = stab[q.f] + off;
+                q.ap = sacc[q.f] + off;
+                q.wv = V::ld(q.wp);
+                q.av = V::ld(q.ap);
+                q.live = true;
+            };
+            Run cur, nxt;
+            fetch(g, nxt);
+            for (int r = g; r < nruns; r += NG) {
+                cur = nxt;
+                fetch(r + NG, nxt);
+                if (!cur.live) continue;
+                T sum = V::zero();
+                int i = cur.s;
+                for (; i + 4 <= cur.e; i += 4) {                    // four entries' loads in flight before their (ordered) adds
+                    const T d0 = entry_grad(i, cur.wv, true), d1 = entry_grad(i + 1, cur.wv, true), d2 = entry_grad(i + 2, cur.wv, true),
+                            d3 = entry_grad(i + 3, cur.wv, true);
+                    sum = V::add(V::add(V::add(V::add(sum, d0), d1), d2), d3);
+                }
+                for (; i < cur.e; ++i) sum = V::add(sum, entry_grad(i, cur.wv, true));
+                const bool open_l = r == 0 && cont_l, open_r = r == nruns - 1 && cont_r;
+                if (!open_l && !open_r) {
+                    T acc = cur.av, wv = cur.wv;
+                    if constexpr (VEC == 4) {
+                        acc = make_float4(acc.x + sum.x * sum.x, acc.y + sum.y * sum.y, acc.z + sum.z * sum.z, acc.w + sum.w * sum.w);
+                        wv = make_float4(wv.x - upd.lr * sum.x / sqrtf(acc.x), wv.y - upd.lr * sum.y / sqrtf(acc.y),
+                                         wv.z - upd.lr * sum.z / sqrtf(acc.z), wv.w - upd.lr * sum.w / sqrtf(acc.w));
+                    } else {
+                        acc = acc + sum * sum;
+                        wv = wv - upd.lr * sum / sqrtf(acc);
+                    }
+                    V::st(cur.ap, acc);
+                    V::st(cur.wp, wv);
+                } else {
+                    V::st(carry + (t * 2 + (open_l ? 0 : 1)) * K + c * VEC, sum);   // a run open on both sides goes to slot 0
+                }
+            }
+            return;
+        }
+    }
     if (staged) {
 #pragma unroll
         for (int q = 0; q < LPS; ++q) {                     // ADA_TILE / NG = LPS entries per group
