@@ -45,6 +45,42 @@ __global__ __launch_bounds__(256) void rows_k(f4* __restrict__ arena, const uint
     if (acc.x + acc.y + acc.z + acc.w == 1.2345e38f) sink[0] = acc.x;
 }
 
+// the same row as TWO 64-byte halves: 4 lanes per row, every lane loads its 16-byte chunk of the first half and of the second half in two
+// instructions (how adagrad_tile_k's four-lane groups read [w | accum] rows), the gradient row with all four lanes; stores likewise
+// EXTRA: two more L2-resident reads per entry, as the folded FM backward makes them: a 64-byte row of a 4 MB array and a 4-byte scalar,
+// both indexed by the entry's sample (val / 26)
+template <int U, bool EXTRA = false>
+__global__ __launch_bounds__(256) void rows4_k(f4* __restrict__ arena, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ val,
+                                               const f4* __restrict__ g, int64_t n, const f4* __restrict__ fs = nullptr,
+                                               const float* __restrict__ fg = nullptr) {
+    const int lane4 = threadIdx.x & 3;
+    const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2, ngrp = ((int64_t)gridDim.x * 256) >> 2;
+    for (int64_t i0 = grp * U; i0 < n; i0 += ngrp * U) {
+        f4 a[U], b[U], gv[U];
+        int64_t r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u;
+            r[u] = i < n ? (int64_t)rows[i] : -1;
+            if (r[u] >= 0) {
+                gv[u] = g[(int64_t)val[i] * 4 + lane4];
+                if (EXTRA) {
+                    const uint32_t bsm = val[i] / 26u;
+                    gv[u] = gv[u] + fs[(int64_t)bsm * 4 + lane4] * fg[bsm];
+                }
+                a[u] = arena[r[u] * 8 + lane4];
+                b[u] = arena[r[u] * 8 + 4 + lane4];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r[u] < 0) continue;
+            arena[r[u] * 8 + 4 + lane4] = b[u] + gv[u] * gv[u];
+            arena[r[u] * 8 + lane4] = a[u] * 1.0001f + gv[u];
+        }
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main() {
@@ -85,5 +121,25 @@ int main() {
     RUN(1, 1, 2048); RUN(1, 4, 2048);
     RUN(2, 1, 2048); RUN(2, 2, 2048); RUN(2, 4, 2048); RUN(2, 4, 8192); RUN(2, 8, 2048);
     RUN(3, 1, 2048); RUN(3, 2, 2048); RUN(3, 4, 2048); RUN(3, 4, 8192); RUN(3, 8, 2048);
+#define RUN4(U, GRID)                                                                                                               \
+    do {                                                                                                                            \
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((rows4_k<U>), dim3(GRID), dim3(256), 0, 0, arena, rows + (it % SETS) * N, val, g, N); \
+        CK(hipEventRecord(e0));                                                                                                     \
+        for (int it = 0; it < 24; ++it) hipLaunchKernelGGL((rows4_k<U>), dim3(GRID), dim3(256), 0, 0, arena, rows + (it % SETS) * N, val, g, N); \
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));                                                                        \
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));                                                                             \
+        printf("%-34s U=%d grid=%5d: %7.1f us  %5.2f TB/s\n", "rmw as two 64 B halves + gradient", U, GRID, ms * 1e3 / 24, 320.0 * N * 24 / (ms * 1e-3) / 1e12); \
+    } while (0)
+    RUN4(1, 2048); RUN4(2, 2048); RUN4(1, 6656); RUN4(4, 2048);
+    f4* fs; float* fg;
+    CK(hipMalloc(&fs, 65536 * 64)); CK(hipMemset(fs, 0, 65536 * 64)); CK(hipMalloc(&fg, 65536 * 4)); CK(hipMemset(fg, 0, 65536 * 4));
+    for (int grid : {2048, 6656}) {
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((rows4_k<1, true>), dim3(grid), dim3(256), 0, 0, arena, rows + (it % SETS) * N, val, g, N, fs, fg);
+        CK(hipEventRecord(e0));
+        for (int it = 0; it < 24; ++it) hipLaunchKernelGGL((rows4_k<1, true>), dim3(grid), dim3(256), 0, 0, arena, rows + (it % SETS) * N, val, g, N, fs, fg);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-34s U=1 grid=%5d: %7.1f us\n", "... + 64 B and 4 B L2-resident reads", grid, ms * 1e3 / 24);
+    }
     return 0;
 }
