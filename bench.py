@@ -157,6 +157,81 @@ def make_ids(torch, args, gen, device, vocab):
     return out
 
 
+_SYNTH_C1 = 0x9E3779B97F4A7C15 - (1 << 64)      # splitmix64's constants as signed 64-bit integers (torch int64 arithmetic wraps)
+_SYNTH_C2 = 0xBF58476D1CE4E5B9 - (1 << 64)
+_SYNTH_C3 = 0x94D049BB133111EB - (1 << 64)
+_SYNTH_STD = 37837.22703        # sqrt(4 * (65536^2 - 1) / 12): the standard deviation of a sum of four uniform 16-bit integers
+
+
+def _wrap64(v):
+    """A Python integer reduced to the signed 64-bit value torch's wrapping int64 arithmetic would hold."""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >> 63 else v
+
+
+def synth_rows(torch, f, rows, K, sigma):
+    """Rows `rows` (int64 [n], GLOBAL row ids) of synthetic table f as a closed-form function of (f, row, column): an integer hash
+    (splitmix64's finaliser on f, row * K + column), its four 16-bit fields summed (Irwin-Hall: close to normal), centred and scaled to
+    standard deviation sigma.  Integer arithmetic, one exact int -> float conversion and one fp32 multiply: the same bits on every
+    device and rank, so at N > 1 every rank can regenerate the rows a lookup must return without holding the other ranks' shards."""
+    x = rows.reshape(-1, 1) * K + torch.arange(K, device=rows.device, dtype=torch.int64) + _wrap64((f + 1) * _SYNTH_C1)
+    x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * _SYNTH_C2          # (logical shifts: torch's >> on int64 is arithmetic)
+    x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * _SYNTH_C3
+    x = x ^ ((x >> 31) & ((1 << 33) - 1))
+    s = (x & 0xffff) + ((x >> 16) & 0xffff) + ((x >> 32) & 0xffff) + ((x >> 48) & 0xffff)
+    return (s - 131070).to(torch.float32) * (sigma / _SYNTH_STD)
+
+
+def synth_shard(torch, f, start, end, K, sigma, device, block=1 << 20):
+    """Rows [start, end) of synthetic table f on `device` (generated in blocks: the int64 temporaries are 4 x the block's bytes)."""
+    t = torch.empty((end - start, K), dtype=torch.float32, device=device)
+    for s in range(start, end, block):
+        e = min(end, s + block)
+        t[s - start:e - start] = synth_rows(torch, f, torch.arange(s, e, device=device, dtype=torch.int64), K, sigma)
+    return t
+
+
+def sharded_parity_check(torch, dist, ops, st, ids, K, sigma, world, backend, device, rows=4096):
+    """Before any timing at N > 1: every rank looks up the first `rows` samples of its batch through the sharded pipeline and compares
+    the result BIT FOR BIT with the rows regenerated from the closed form (synth_rows) -- which needs no other rank's memory -- and the
+    fused FM logit with the FM kernel run on those regenerated rows.  Also counts the ranks a collective actually reaches.
+    -> the `parity_check` object of the line (identical on every rank: MIN / SUM over the ranks)."""
+    n = min(rows, ids.shape[0])
+    chk = ids[:n].contiguous()
+    F = chk.shape[1]
+    emb, fm = st.lookup(chk, want_fm=True)
+    want = torch.cat([synth_rows(torch, f, chk[:, f], K, sigma) for f in range(F)], dim=1)
+    want_fm = ops.fm_logit(want, F, K)
+    torch.cuda.synchronize()
+    ok_rows = bool(torch.equal(emb, want))
+    ok_fm = bool(torch.equal(fm, want_fm))
+    nz = float((want != 0).float().mean())
+    cdev = device if backend == "nccl" else "cpu"
+    t = torch.tensor([1.0, float(ok_rows), float(ok_fm)], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = t.tolist()
+    return {"ok": int(t[1]) == world and int(t[2]) == world and nz > 0.99, "ranks_seen": int(t[0]), "ranks_rows_bit_exact": int(t[1]),
+            "ranks_fm_bit_exact": int(t[2]), "samples_per_rank": n, "rows_per_rank": n * F,
+            "against": "closed-form synthetic rows (bench.synth_rows), regenerated on the checking rank; FM logit against dir_fm_second_order_f32 on them",
+            "fallbacks": st.stats["fallbacks"]}
+
+
+def sharded_stage_times(torch, dist, st, ids, world, backend, device, iters=5):
+    """Per-stage microseconds of one sharded lookup (ShardedTables.stage_times: the stages back to back on one stream, HIP events
+    between them), MAX over the ranks."""
+    us, _, _ = st.stage_times(ids, want_fm=True, iters=iters)
+    names = list(st.STAGES)
+    t = torch.tensor([us[k] for k in names], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out = {k: round(v, 2) for k, v in zip(names, t.tolist())}
+    out["sum"] = round(sum(out.values()), 2)
+    out["note"] = ("stages of one lookup run back to back on one stream (max over ranks, median of %d); the timed steps pipeline two "
+                   "chunks on two side streams and neighbouring lookups, so a step costs less than this sum" % iters)
+    return out
+
+
 def torch_profile(torch, step, path, n=4):
     """--torch-profile: device time per step of every (op, input shapes) and kernel, largest first."""
     from torch.profiler import profile, ProfilerActivity
@@ -394,7 +469,7 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
     """BASELINE config 5: xDeepFM CIN (3 x 128, m = 26, D = 16) on a 10^8-row embedding table (26 slots x 3 846 153 rows), the
     table row-sharded 'div' over the ranks with the lookup's two all-to-alls when N > 1.  Per-GPU batch fixed (weak scaling)."""
     B, F, K = args.batch, 26, 16
-    Vf = 100000000 // F
+    Vf = int(os.environ.get("DIR_BENCH_CFG5_ROWS", "100000000")) // F       # (the env switch: a smaller table for the launch tests)
     Hs = (128, 128, 128)
     sigma = 1.0 / (K ** 0.5)
     sharded = world > 1 or os.environ.get("DIR_BENCH_CFG5_SHARDED") == "1"
@@ -411,12 +486,17 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
         loc = []
         for f in range(F):
             s0, e0 = div_range(Vf, world, rank)
-            loc.append(torch.randn((e0 - s0, K), generator=gen, device=device) * sigma)
+            loc.append(synth_shard(torch, f, s0, e0, K, sigma, device))       # closed-form rows: the parity check below regenerates them
         # (side streams confined to a few CUs -- ShardedTables(side_cus=n) -- made this leg SLOWER on one GPU: 9.3 vs 7.8 ms at 8-32 CUs,
         # profiles/r03_cfg5_overlap.md; the default leaves them unmasked)
         side = os.environ.get("DIR_BENCH_CFG5_SIDE_CUS", "0")
         st = ShardedTables(loc, [Vf] * F, force_collective=True, check="lazy", max_batch=B, side_cus=int(side) or None)
     idsl = [torch.randint(0, Vf, (B, F), generator=gen, device=device) for _ in range(2)]
+    parity = None
+    if st is not None:
+        parity = sharded_parity_check(torch, dist, ops, st, idsl[0], K, sigma, world, backend, device)
+        if not parity["ok"]:
+            return {"error": "the sharded lookup failed its parity check before timing", "parity_check": parity}
     Ws, hp = [], F
     for h in Hs:
         Ws.append(torch.randn((h, hp * F), generator=gen, device=device) * (1.0 / (hp * F) ** 0.5))
@@ -492,6 +572,7 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
             "per_gpu_frac_of_bf16_mfma_peak": pipe_flops * steps / el / 1e12 / MFMA_BF16_PEAK_TF if default_is_bf3 else None,
             "fp32_mfma_kernel": {"dtype": "f32", "ms_per_step": el32 * 1e3 / steps, "value": B * world * steps / el32,
                                  "per_gpu_TFLOPs_lookup_included": tf32, "per_gpu_frac_of_fp32_mfma_peak": tf32 / MFMA_F32_PEAK_TF},
+            "parity_check": parity,
             "config": {"workload": "xdeepfm_cin_sharded", "batch_per_gpu": B, "m": F, "D": K, "layers": list(Hs), "table_rows": Vf * F}}
 
 
@@ -650,6 +731,7 @@ def main():
     step = None
     units = B
     cfg = {"workload": wl, "batch": B}
+    multi = {}            # N > 1: parity_check / stage_us of the sharded lookup, measured before the timed region
 
     if wl in ("deepfm_gather_fm", "gather_only", "fm_only", "linear", "deepfm_full", "deepfm_full_packed"):
         sigma = 1.0 / (K ** 0.5)  # [TF-upstream] embedding_column default initializer stddev
@@ -701,12 +783,23 @@ def main():
             roof = {"bound": "hbm", "alg_bytes": alg, "kernel": kname}
             cfg["parallelism"] = "single GPU, tables resident (1.66 GB)"
         else:
+            # tables at N > 1: a closed form of (slot, row, column) instead of a generator stream, so that any rank can regenerate the
+            # rows its lookups must return (the parity check below) without holding the other ranks' shards
             loc = []
             for f in range(F):
                 s, e = div_range(V, world, rank)
-                loc.append(torch.randn((e - s, K), generator=gen, device=device) * sigma)
+                loc.append(synth_shard(torch, f, s, e, K, sigma, device))
             st = ShardedTables(loc, [V] * F, check="lazy", max_batch=B)
             idsl = make_ids(torch, args, gen, device, V)
+            multi["parity_check"] = sharded_parity_check(torch, dist, ops, st, idsl[0], K, sigma, world, backend, device)
+            if not multi["parity_check"]["ok"]:
+                # a number measured on a lookup that returns wrong rows is worth nothing: no line, exit code 6 on every rank
+                if rank == 0:
+                    sys.stderr.write("bench.py: the sharded lookup FAILED its parity check before timing: %s\n" % json.dumps(multi["parity_check"]))
+                dist.destroy_process_group()
+                return 6
+            multi["stage_us"] = sharded_stage_times(torch, dist, st, idsl[0], world, backend, device)
+            cfg["tables"] = "closed-form synthetic rows (bench.synth_rows), sigma 1/sqrt(K)"
             outs = [torch.empty((B, F * K), dtype=torch.float32, device=device) for _ in range(2)]
             fms = [torch.empty((B, 1), dtype=torch.float32, device=device) for _ in range(2)]
             inflight = {}
@@ -1295,7 +1388,16 @@ def main():
             res["backend"] = backend + (" (exchange staged through host memory)" if os.environ.get("DIR_SHARD_HOST_STAGED") == "1" else "")
             if "link_bytes" in roof:
                 res["per_peer_bytes_per_step"] = roof["link_bytes"]
-        launch_us = dev_ms * 1e3 / args.steps
+            # the sharded path checks itself before it is timed: the lookup's rows bit-exact against regenerated table rows on every rank,
+            # the number of ranks a collective reached, the lookup's stages in microseconds (all measured before the timed region)
+            res.update(multi)
+            if "parity_check" in multi:
+                res["rccl_ranks_seen" if backend == "nccl" else "ranks_seen"] = multi["parity_check"]["ranks_seen"]
+        # ONE clock: roofline.achieved / frac come from the same timed region as value and ms_per_step (host clock around
+        # the barrier-bracketed steps, max over ranks); the HIP-event average over the same steps (events on the launch stream) is
+        # carried beside it as hip_event_avg_launch_us / frac_hip_events, and the per-launch median further down as frac_at_median
+        launch_us = ms_per_step * 1e3
+        hip_us = dev_ms * 1e3 / args.steps
         if roof["bound"] == "xgmi":
             link = roof["link_bytes"] / (launch_us * 1e-6) / 1e9
             hbm = roof["alg_bytes"] / (launch_us * 1e-6) / 1e9
@@ -1383,6 +1485,9 @@ def main():
                     res["roofline"][k] = roof[k]
             if "dtype" in roof:
                 res["dtype"] = roof["dtype"]
+        res["roofline"]["clock"] = "host clock over the timed region (the one ms_per_step and value use)"
+        res["roofline"]["hip_event_avg_launch_us"] = hip_us
+        res["roofline"]["frac_hip_events"] = res["roofline"]["frac"] * launch_us / hip_us if hip_us > 0 else None
         if world == 1 and roof["bound"] in ("hbm", "mfma"):
             # per-launch distribution (median + p10 / p90 of >= 100 launches), at any --steps, outside the timed region: one HIP
             # event per step on the launch stream (events inside the timed region would put a timestamp packet between the launches)

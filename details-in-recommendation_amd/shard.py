@@ -675,6 +675,61 @@ class ShardedTables:
             self._unchecked.append(lk)                   # two newest handles only (check_overflow() reads what is still there)
         return lk
 
+    STAGES = ("bucket", "a2a_ids", "owner_gather", "a2a_rows", "finish")
+
+    def stage_times(self, ids, want_fm=True, iters=5):
+        """Diagnostic: the fixed-capacity pipeline of ONE lookup with its five stages run back to back on the caller's stream and a
+        HIP event between them (the product path, _enqueue, overlaps the chunks on two side streams; here nothing overlaps, so the
+        stages add up to MORE than a pipelined lookup costs).  -> ({stage: microseconds}, emb, fm): per stage the sum over the
+        lookup's chunks, median over `iters` runs after one warm-up run, on THIS rank (a collective's time includes waiting for the
+        slowest peer to arrive).  Every rank must call it (the exchanges are collectives).  The results of the last run are returned
+        so that the caller can check them."""
+        import time
+        B, F = ids.shape
+        if F != self.F:
+            raise ValueError("ids must be [B, F=%d]" % self.F)
+        be, cuda = self.backend, self.device.type == "cuda"
+        plan = self._plan(B, "stages")
+        cap = plan.cap
+        out = torch.empty((B, F * self.K), dtype=torch.float32, device=ids.device)
+        fm = torch.empty((B, 1), dtype=torch.float32, device=ids.device) if want_fm else None
+        runs = []
+
+        def mark():
+            if cuda:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                return e
+            return time.perf_counter()
+
+        def wait(w):
+            if w is not None:
+                w.wait()
+
+        for it in range(iters + 1):
+            marks = []
+            for c, (s, e) in enumerate(plan.bounds):
+                m = [mark()]
+                be.bucket_cap(ids[s:e], cap, plan.send[c], plan.inv[c], plan.counts[c], plan.flags[c], plan.ws[c], stat=plan.cstat[c], dedup=self.dedup)
+                m.append(mark())
+                wait(self._a2a_equal(plan.recv[c], plan.send[c]))
+                m.append(mark())
+                be.gather_slabs(plan.recv[c], cap, plan.rows[c])
+                m.append(mark())
+                wait(self._a2a_equal(plan.back[c], plan.rows[c]))
+                m.append(mark())
+                if e > s:
+                    be.finish_chunk(plan.back[c], be.inv2d(plan.inv[c], e - s, F, self.dedup), want_fm, out[s:e], fm[s:e] if want_fm else None)
+                m.append(mark())
+                marks.append(m)
+            if cuda:
+                torch.cuda.synchronize(self.device)
+            if it:
+                runs.append([sum((m[k].elapsed_time(m[k + 1]) * 1e3 if cuda else (m[k + 1] - m[k]) * 1e6) for m in marks) for k in range(5)])
+        runs.sort(key=lambda r: sum(r))
+        med = runs[len(runs) // 2]
+        return dict(zip(self.STAGES, med)), out, fm
+
     def lookup(self, ids, want_fm=False, out=None, fm=None):
         """ids [B_local, F] int64 (global row ids; < 0 or >= vocab_f -> zeros) -> emb [B_local, F*K] fp32
         (and the FM second-order logit [B_local, 1] when want_fm).  out / fm: preallocated results (stable addresses)."""

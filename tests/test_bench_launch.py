@@ -62,3 +62,36 @@ def test_gpus_2_launches_two_ranks(built_lib):
     assert res["steps"] == 3 and res["scaling"] == "weak"
     assert res["roofline"]["bound"] == "xgmi" and res["per_peer_bytes_per_step"] == 8192 * 26 * (64 + 8) / 2
     assert res["value"] > 0
+    # the sharded path checked itself before it was timed: rows bit-exact against regenerated table rows on every rank,
+    # the ranks a collective reached, the lookup's stages in microseconds
+    pc = res["parity_check"]
+    assert pc["ok"] is True and pc["ranks_seen"] == 2 and pc["ranks_rows_bit_exact"] == 2 and pc["ranks_fm_bit_exact"] == 2
+    assert pc["samples_per_rank"] == 4096 and res["ranks_seen"] == 2
+    assert set(res["stage_us"]) >= {"bucket", "a2a_ids", "owner_gather", "a2a_rows", "finish", "sum"}
+    assert all(res["stage_us"][k] > 0 for k in ("bucket", "a2a_ids", "owner_gather", "a2a_rows", "finish"))
+    assert res["roofline"]["hip_event_avg_launch_us"] > 0 and "clock" in res["roofline"]
+
+
+@pytest.mark.gpu
+def test_gpus_2_cfg5_leg_checks_itself(built_lib):
+    """The config-5 secondary leg of the same command (xDeepFM CIN on the row-sharded 1e8-row table; here a small batch): its own parity check."""
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"],
+             {"DIR_BENCH_BACKEND": "gloo", "DIR_BENCH_SAME_DEVICE": "1", "DIR_SHARD_HOST_STAGED": "1", "DIR_BENCH_CFG5_ROWS": "2600000"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.lstrip().startswith("{")][-1])
+    sec = res["secondary_cfg5_xdeepfm_cin"]
+    assert "error" not in sec, sec
+    assert sec["n_gpus"] == 2 and sec["parity_check"]["ok"] is True and sec["parity_check"]["ranks_seen"] == 2
+
+
+def test_synthetic_rows_are_a_closed_form():
+    """bench.synth_rows: any rank can regenerate any row (what the N > 1 parity check relies on); shards are slices of one function."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    full = bench.synth_rows(torch, 5, torch.arange(0, 20000), 16, 0.25)
+    assert torch.equal(bench.synth_shard(torch, 5, 777, 9000, 16, 0.25, "cpu", block=1000), full[777:9000])
+    pick = torch.tensor([19999, 0, 31, 31])
+    assert torch.equal(bench.synth_rows(torch, 5, pick, 16, 0.25), full[pick])
+    assert abs(float(full.mean())) < 5e-3 and abs(float(full.std()) - 0.25) < 5e-3
+    assert not torch.equal(bench.synth_rows(torch, 6, pick, 16, 0.25), full[pick])

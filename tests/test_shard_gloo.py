@@ -250,6 +250,11 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
             refu = R.embedding_bag_onehot(full, idu) if Bu else np.zeros((0, F * K), np.float32)
             gotu = st.lookup(torch.from_numpy(idu))
             ok = ok and tuple(gotu.shape) == (Bu, F * K) and bool(np.array_equal(gotu.numpy(), refu))
+        # the diagnostic form of a lookup (stages back to back, a time per stage): same results
+        if opts.get("stages"):
+            us, es, fs = st.stage_times(torch.from_numpy(ids), want_fm=True, iters=2)
+            ok = ok and set(us) == set(ShardedTables.STAGES) and all(v >= 0 for v in us.values())
+            ok = ok and bool(np.array_equal(es.numpy(), ref)) and bool(np.array_equal(fs.numpy()[:, 0], O.fm_second_order(ref, F, K)))
         # two lookups in flight (double-buffered plans), consumed in order, then a third reusing the first one's buffers
         if opts.get("async"):
             batches = [np.stack([rng_b.integers(-1, v, size=B) for v in vocab], axis=1).astype(np.int64) for _ in range(3)]
@@ -299,6 +304,8 @@ def _run(world, vocab, K, B, seed, train=False, opts=None):
     (2, [40, 25, 60], {"uneven": [[37, 20], [11, 37], [0, 9], [64, 3]]}),          # unequal local batches, incl. an empty one
     (3, [40, 25, 60], {"uneven": [[5, 37, 20], [50, 1, 0]], "dedup": True, "id_hi": 15}),
     (2, [50, 20, 33], {"async": True}),
+    (3, [50, 20, 33, 7], {"stages": True, "chunks": 2}),
+    (2, [50, 20, 33, 7], {"stages": True, "dedup": True, "id_hi": 9}),
     (3, [50, 20, 33], {"async": True, "dedup": True, "chunks": 3, "check": "lazy"}),
 ])
 def test_sharded_lookup_matches_full_tables(world, vocab, opts):
