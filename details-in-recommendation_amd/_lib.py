@@ -39,6 +39,7 @@ SIGNATURES = {
     "dir_dense_dw_bf16x3_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32]),
     "dir_dense_dw_bf16x3_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "dir_dense_dw_f16x2_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "dir_dense_dw_f16x2_scaled_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_row_absmax_workspace_words": (c_i32, []),
     "dir_row_absmax_bits_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dir_dense_f16x2_rows_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
@@ -123,17 +124,20 @@ SIGNATURES = {
     "dir_cin_bf16x3_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "dir_cin_layer_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_cin_pool_z_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp]),
+    "dir_cin_pool_z_bits_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "dir_cin_pool_dx_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "dir_cin_layer1_bf16x3_workspace_bytes": (c_i64, [c_i32, c_i32]),
     "dir_cin_layer1_bf16x3_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_cin_layer_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_cin_layer1_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "dir_cin_layer1_bits_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_bf16x3_dot_partials": (c_i32, [c_i32, c_i32, c_i32]),
     "dir_cin_dw_bf16x3_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i64]),
     "dir_cin_dw_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp]),
     "dir_cin_dw_f16x2_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i64]),
     "dir_cin_dw_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_grad_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dir_cin_layer_rows_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_cin_dw_sym_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_dot_add_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_dot_add_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -116,11 +116,36 @@ template <> struct BtPc<2> {
 // W [H, Hp*m] fp32 -> image [column block of CT tiles][half kh][field j][ks][plane][ct][lane][8 e] bf16, element e of lane l of column
 // tile ct in k-step ks = piece of W[h = hoff + 16*(CT*cb + ct) + (l & 15)][i = KS*32*kh + 32*ks + 8*(l >> 4) + e][j]; zero where h >= H or
 // i >= Hp.  One launch per block width (the 128-wide blocks, then the narrower last block).
+// The tensor scale of a weight that meets a row-scaled left operand (RS): W's largest |element| as WPARTS partial maxima (plain stores: no
+// atomics, nothing to zero between calls); the pack kernel multiplies W by the power of two 2^k that puts it into [2^14, 2^15), the
+// layer kernel takes 2^-k out again together with the rows' scales.  With both operands scaled the fp16 x 2 layer needs no promise about
+// magnitudes at all (any W, any xk that fp32 holds), and W's small elements keep 22 bits relative to its largest instead of an absolute 2^-25.
+constexpr int WPARTS = 32;
+__global__ __launch_bounds__(256) void cin_w_absmax_k(const float* __restrict__ W, int64_t n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float mx = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(W[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ int w_scale_exp(const float* __restrict__ part) {          // k of the scale 2^k (every lane reads the WPARTS values)
+    float mx = 0.f;
+#pragma unroll
+    for (int q = 0; q < WPARTS; ++q) mx = fmaxf(mx, part[q]);
+    int k = 141 - (int)((__builtin_bit_cast(unsigned int, mx) >> 23) & 0xffu);
+    return k > 60 ? 60 : (k < -60 ? -60 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned int)(127 + k) << 23); }     // |k| <= 126
+
 template <int NP>
 __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict__ W, int m, int Hp, int H, int KS, int nkh, int ncb, int CT,
-                                                        int hoff, unsigned int* __restrict__ img) {
+                                                        int hoff, unsigned int* __restrict__ img, const float* __restrict__ wpart = nullptr) {
     const int64_t total = (int64_t)ncb * nkh * m * KS * CT * 64 * 4;   // one thread per pair of e
     const int stepdw = NP * CT * 64 * 4;                               // dwords per k-step
+    const float wsc = wpart ? pow2f(w_scale_exp(wpart)) : 1.f;
     for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
         int64_t q = e_;
         const int ep = (int)(q & 3); q >>= 2;
@@ -132,8 +157,8 @@ __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict_
         const int cb = (int)(q / nkh);
         const int h = hoff + 16 * (CT * cb + ct) + (l & 15);
         const int i = KS * 32 * kh + 32 * ks + 8 * (l >> 4) + 2 * ep;
-        const float v0 = (h < H && i < Hp) ? W[(int64_t)h * Hp * m + (int64_t)i * m + j] : 0.f;
-        const float v1 = (h < H && i + 1 < Hp) ? W[(int64_t)h * Hp * m + (int64_t)(i + 1) * m + j] : 0.f;
+        const float v0 = (h < H && i < Hp) ? W[(int64_t)h * Hp * m + (int64_t)i * m + j] * wsc : 0.f;
+        const float v1 = (h < H && i + 1 < Hp) ? W[(int64_t)h * Hp * m + (int64_t)(i + 1) * m + j] * wsc : 0.f;
         unsigned int pw[NP];
         BtPc<NP>::split(v0, v1, pw);
         const int64_t chunk = ((int64_t)cb * nkh + kh) * m + j;
@@ -169,11 +194,16 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      const float* __restrict__ addp /* optional [B, H] (row stride addp_ld): added to xout[b, h, :] */,
                                                      int64_t addp_ld, const unsigned short* __restrict__ ptab /* PAIRS: i | j << 8 per pair */,
                                                      int mx /* fields of the x0 slice (= m unless PAIRS) */,
-                                                     unsigned int* __restrict__ amax_out = nullptr /* RS: atomicMax of the bit pattern of max |xk| */) {
+                                                     unsigned int* __restrict__ amax_out = nullptr /* RS: atomicMax of the bit pattern of max |xk| */,
+                                                     const float* __restrict__ wpart = nullptr /* RS: cin_w_absmax_k's partial maxima of the W the image was scaled by */,
+                                                     const unsigned int* __restrict__ xk_bits = nullptr /* RS, optional [R]: bit pattern of max_i |xk[r, i]|, left by
+                                                                                                          the kernel that produced xk: no scan of the rows in the prologue */,
+                                                     unsigned int* __restrict__ xout_bits = nullptr /* optional [R]: the same of THIS launch's output rows (the launch
+                                                                                                       must cover all H columns: one column block) */) {
     using Pc = BtPc<NP>;
     using op_t = typename Pc::op_t;
     static_assert(NP == 3 || !DOT || RS, "the data-gradient form on fp16 x 2 needs the row-scaled left operand");
-    static_assert(!RS || (NP == 2 && !PAIRS), "row scaling belongs to the fp16 x 2 split of a general left operand");
+    static_assert(!RS || NP == 2, "row scaling belongs to the fp16 x 2 split");
     constexpr int STEPB = NP * CT * 1024;                        // bytes of W image per k-step of 32
     constexpr int CHB = KS * STEPB;                              // bytes of W image per (half, field); a staged chunk holds FJ of them
     constexpr int BT_ROWS = 8 * 16 * RT;                         // rows per workgroup (shadows the 256 of the forward)
@@ -224,13 +254,19 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     // scaled row fits fp16 with its largest elements at 11 + 11 bits; elements more than 2^-17 below the row's largest keep an ABSOLUTE
     // error of 2^-25 (2^-39 of the largest), which is what a sum over the row's channels needs.  The scaling itself is exact.
     float rscale[RS ? RT : 1];
-    f32x4 rinv[RS ? RT : 1];
+    float rowinv[RS ? RT : 1];          // the inverse scale of the lane's OWN row (row n of tile rt): what its x0 slice entries are multiplied by
+    f32x4 rinv[RS ? RT : 1];            // ... of the rows of the lane's accumulator registers (DOT: y; PAIRS: the pseudo-field's factor)
     float wave_max = 0.f;
     float* bt_wmax = x0s + (size_t)mx * BT_ROWS;                      // [8]: behind the x0 slice (all LDS is dynamic: the 160 KiB limit is set for the kernel)
-    if constexpr (RS) {
+    const int kw = (RS && wpart) ? w_scale_exp(wpart) : 0;     // the W image's tensor scale 2^kw (|kw| <= 60), taken out with the rows' scales
+    if constexpr (RS && !PAIRS) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             float mx = 0.f;
+            if (xk_bits) {                                   // (uniform) the producer of xk left the rows' maxima
+                const int64_t gr = row0 + wave * WR + rt * 16 + n;
+                mx = __builtin_bit_cast(float, xk_bits[gr < R ? gr : R - 1]);
+            } else {
             for (int i0 = 8 * lg; i0 < Hp; i0 += 32) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -241,11 +277,14 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            }
             wave_max = fmaxf(wave_max, mx);             // the tensor's maximum rides along (the weight-gradient kernels scale G by it)
             int k = 141 - (int)((__builtin_bit_cast(unsigned int, mx) >> 23) & 0xffu);
             k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            k = k + kw > 126 ? 126 - kw : (k + kw < -126 ? -126 - kw : k);      // the combined inverse 2^-(k + kw) stays a normal number
             rscale[rt] = __builtin_bit_cast(float, (unsigned int)(127 + k) << 23);
-            const float inv = __builtin_bit_cast(float, (unsigned int)(127 - k) << 23);
+            const float inv = pow2f(-(k + kw));
+            rowinv[rt] = inv;
 #pragma unroll
             for (int q = 0; q < 4; ++q) rinv[rt][q] = __shfl(inv, 4 * lg + q, 64);      // lane 4 lg + q holds row 4 lg + q of the tile
         }
@@ -295,6 +334,40 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         }
     }
 
+    if constexpr (RS && !PAIRS) {
+        // The rows' inverse scales go INTO the LDS-resident x0 slice (x0s[j][r] *= 2^-(k_r + kw), exact): the field factor a chunk reads is
+        // then already the one that takes T's scales out, and the main loop is the unscaled kernel's instruction for instruction.  (A
+        // multiply on the freshly read factor at the top of every chunk cost 8 % of the layer: the wait for that LDS read sat in front of
+        // the chunk's first operand reads.)  A row lives in ONE wave (rows WR * wave ..): its lanes (n, lg) share the fields, no barrier.
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float* xr = x0s + wave * WR + rt * 16 + n;
+            for (int j = lg; j < mx; j += 4) xr[j * BT_ROWS] *= rowinv[rt];
+        }
+    }
+    if constexpr (RS && PAIRS) {
+        // The first layer on scaled fp16 x 2: the A operand of pair (i, j) is the PRODUCT x0[r,i] x0[r,j], so every row r of the LDS-resident x0
+        // slice is scaled by 2^k with its largest |element| in [2^6, 2^7) -- products below 2^14 -- and 2^-2k (times the W image's scale)
+        // is the "field factor" of the one pseudo-field.  A row lives in ONE wave (rows WR * wave ..), its 16 x 4 lanes (n, lg) share the
+        // fields j = lg, lg + 4, ..: no barrier (a wave's LDS operations complete in order).
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float* xr = x0s + wave * WR + rt * 16 + n;
+            float mxr = 0.f;
+            for (int j = lg; j < mx; j += 4) mxr = fmaxf(mxr, fabsf(xr[j * BT_ROWS]));
+            mxr = fmaxf(mxr, __shfl_xor(mxr, 16, 64));
+            mxr = fmaxf(mxr, __shfl_xor(mxr, 32, 64));
+            int k = 133 - (int)((__builtin_bit_cast(unsigned int, mxr) >> 23) & 0xffu);
+            k = k > 50 ? 50 : (k < -50 ? -50 : k);
+            k = 2 * k + kw > 126 ? (126 - kw) / 2 : (2 * k + kw < -126 ? -((126 + kw) / 2) : k);      // 2^-(2k + kw) stays a normal number
+            const float sc = pow2f(k);
+            for (int j = lg; j < mx; j += 4) xr[j * BT_ROWS] *= sc;
+            const float inv2 = pow2f(-(2 * k + kw));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rinv[rt][q] = __shfl(inv2, 4 * lg + q, 64);
+        }
+    }
+
     if constexpr (DOT) dotp += (int64_t)blockIdx.y * nkh * (R >> dshift) * m * D;     // this column block's partials
     const unsigned char* wlane = Wb + lane * 16;
     const float* x0lane = x0s + wave * WR + 4 * lg;      // + j*BT_ROWS + 16*rt: the 4 rows of accumulator registers 0..3 of tile rt
@@ -334,7 +407,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 for (int e = 0; e < 8; ++e) {
                     const int i = KS * 32 * kh + 32 * ks + 8 * lg + e;
                     const float x = xsrc[rt][(int64_t)(i < Hp ? i : Hp - 1) * D];
-                    v[e] = i < Hp ? (RS ? x * rscale[rt] : x) : 0.f;          // the W image is zero there; 0 * garbage must stay 0
+                    v[e] = i < Hp ? ((RS && !PAIRS) ? x * rscale[rt] : x) : 0.f;          // the W image is zero there; 0 * garbage must stay 0
                 }
                 }
                 unsigned int w[NP][4];
@@ -364,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 xcur[rt] = PAIRS ? (f32x4){1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
-                if constexpr (RS) xcur[rt] *= rinv[rt];
+                if constexpr (RS && PAIRS) xcur[rt] *= rinv[rt];          // (not PAIRS: the slice in LDS already carries the rows' inverse scales)
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
@@ -454,6 +527,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         const int64_t gr = row0 + wave * WR + rt * 16 + 4 * lg;     // first of the lane's 4 consecutive rows (same sample: D >= 4)
         const int64_t b = gr >> dshift;
         const int d = (int)(gr & (D - 1));
+        f32x4 rmx = (f32x4){0.f, 0.f, 0.f, 0.f};                   // xout_bits: the largest |output| of the lane's columns, per row
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int h = hbase + 16 * ct + n;
@@ -462,6 +536,17 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 // (the backward of a stack: dL/dxout of the layer below = this data gradient + that layer's pooled gradient, broadcast over d)
                 if (addp) v += addp[b * addp_ld + h];
                 *reinterpret_cast<f32x4*>(xout + (b * H + h) * D + d) = v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rmx[q] = fmaxf(rmx[q], fabsf(v[q]));
+            }
+        }
+        if (xout_bits) {                                            // (uniform) the rows' maxima for the next layer's row scales: its prologue need not scan xk
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float mq = rmx[q];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) mq = fmaxf(mq, __shfl_xor(mq, o, 64));
+                if (n == 0 && gr + q < R) xout_bits[gr + q] = __builtin_bit_cast(unsigned int, mq);
             }
         }
     }
@@ -517,14 +602,15 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     if (m <= 0 || Hp <= 0 || H <= 0) return 0;
     const Bf3Plan p = bf3_plan(m, Hp, H, false), q = bf3_plan(m, Hp, H, true);      // either form of the layer
     const int64_t a = p.bytes_full + p.bytes_last, b = q.bytes_full + q.bytes_last;
-    return a > b ? a : b;
+    return (a > b ? a : b) + 256;                   // + the WPARTS partial maxima of W behind the image (the row-scaled fp16 x 2 forms)
 }
 
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: 64-column blocks, two fields per chunk, dot partials)
 static int bf3_run(const char* name, const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                    float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
                    const float* addp = nullptr, int64_t addp_ld = 0, int np = 3 /* 2: fp16 x 2 */,
-                   bool rs = false /* fp16 x 2 with the left operand scaled per row (a gradient) */, unsigned int* amax_out = nullptr) {
+                   bool rs = false /* fp16 x 2 with the left operand scaled per row (a gradient) */, unsigned int* amax_out = nullptr,
+                   const unsigned int* xk_bits = nullptr, unsigned int* xout_bits = nullptr) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -543,12 +629,17 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     if (dot && np != 3 && !rs) return fail(DIR_E_UNSUPPORTED, "%s: the data-gradient form on fp16 x 2 needs the row-scaled left operand", name);
     if (rs && np != 2) return fail(DIR_E_UNSUPPORTED, "%s: row scaling belongs to fp16 x 2", name);
     const Bf3Plan pl = bf3_plan(m, Hp, H, dot, np);
+    if (xout_bits && (pl.nfull + (pl.ctl ? 1 : 0) != 1 || !xout))
+        return fail(DIR_E_UNSUPPORTED, "%s: xout_row_bits needs xout and ONE column block (H <= %d)", name, 16 * pl.bw);
     unsigned char* img = static_cast<unsigned char*>(workspace);
+    // rs: W is scaled too (one power of two for the tensor): its partial maxima sit behind the image
+    float* wpart = rs ? reinterpret_cast<float*>(img + ((pl.bytes_full + pl.bytes_last + 127) & ~(int64_t)127)) : nullptr;
+    if (rs) hipLaunchKernelGGL(cin_w_absmax_k, dim3(WPARTS), dim3(256), 0, st, W, (int64_t)H * Hp * m, wpart);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
         const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
         if (np == 2)
             hipLaunchKernelGGL(cin_bf3_pack_w_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
-                               reinterpret_cast<unsigned int*>(dst));
+                               reinterpret_cast<unsigned int*>(dst), wpart);
         else
             hipLaunchKernelGGL(cin_bf3_pack_w_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
                                reinterpret_cast<unsigned int*>(dst));
@@ -563,7 +654,8 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>);                                       \
         const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                             \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
-                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr); \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr, wpart, \
+                           xk_bits, xout_bits);                                                                                       \
     } while (0)
 #define BT_LAUNCH_KS(C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                       \
     do {                                                                                 \
@@ -632,6 +724,17 @@ extern "C" int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, co
                    workspace_bytes, stream, nullptr, 0, 2, true, xk_absmax_bits_out);
 }
 
+// The FORWARD layer on scaled fp16 x 2 (round 5: what "auto" runs for every layer but the first): as the entry above, and
+//   xk_row_bits   (optional, [B * D], row r = b * D + d): the bit pattern of max_i |xk[b, i, d]| left by the layer that produced xk (then the
+//                 prologue reads one word per row instead of the row);
+//   xout_row_bits (optional, [B * D]): the same of this layer's output, for the next layer (needs xout and H <= 128: one column block).
+extern "C" int dir_cin_layer_rows_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
+                                            float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                            const unsigned int* xk_row_bits, unsigned int* xout_row_bits, dir_stream_t stream) {
+    return bf3_run("dir_cin_layer_rows_f16x2_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace,
+                   workspace_bytes, stream, nullptr, 0, 2, true, nullptr, xk_row_bits, xout_row_bits);
+}
+
 // ---- the first layer over field pairs (PAIRS) -----------------------------------------------------------------------------------------------
 namespace dir {
 __host__ __device__ __forceinline__ int l1_pair_index(int a, int b, int m) { return a * m - a * (a - 1) / 2 + (b - a); }      // a <= b, row-major over a
@@ -652,7 +755,7 @@ __global__ __launch_bounds__(256) void cin_l1_pairs_k(const float* __restrict__ 
 }
 }  // namespace dir
 
-struct L1Plan { int np, npad; Bf3Plan pl; int64_t off_w2, off_tab, total; };
+struct L1Plan { int np, npad; Bf3Plan pl; int64_t off_w2, off_tab, off_part, total; };
 static L1Plan l1_plan(int m, int H, int pieces = 3) {
     L1Plan q;
     q.np = m * (m + 1) / 2;
@@ -664,6 +767,8 @@ static L1Plan l1_plan(int m, int H, int pieces = 3) {
     off += ((int64_t)H * q.np * 4 + 255) & ~(int64_t)255;
     q.off_tab = off;
     off += ((int64_t)q.npad * 2 + 255) & ~(int64_t)255;
+    q.off_part = off;                                          // WPARTS partial maxima of W2 (the scaled fp16 x 2 form)
+    off += 256;
     q.total = off;
     return q;
 }
@@ -674,7 +779,7 @@ extern "C" int64_t dir_cin_layer1_bf16x3_workspace_bytes(int m, int H) {
 }
 
 static int l1_run(const char* name, int pieces, const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
-                  int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
+                  int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream, unsigned int* xout_bits = nullptr) {
     DIR_CHECK_ARG(m > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d H=%d D=%d", name, m, H, D);
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(x0 && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -686,6 +791,8 @@ static int l1_run(const char* name, int pieces, const float* x0, const float* W,
     DIR_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255u) == 0 && workspace_bytes >= q.total,
                   "%s: workspace must be 256-byte aligned and hold dir_cin_layer1_bf16x3_workspace_bytes(m, H) bytes", name);
     const Bf3Plan& pl = q.pl;                                  // KS = 2 (m >= 8: more than 32 pairs)
+    if (xout_bits && (pl.nfull + (pl.ctl ? 1 : 0) != 1 || !xout))
+        return fail(DIR_E_UNSUPPORTED, "%s: xout_row_bits needs xout and ONE column block (H <= 128)", name);
     int dshift = 0;
     while ((1 << dshift) < D) ++dshift;
     const int64_t R = B * D;
@@ -694,11 +801,15 @@ static int l1_run(const char* name, int pieces, const float* x0, const float* W,
     float* W2 = reinterpret_cast<float*>(img + q.off_w2);
     unsigned short* ptab = reinterpret_cast<unsigned short*>(img + q.off_tab);
     hipLaunchKernelGGL(cin_l1_pairs_k, dim3(grid_for(((int64_t)H * m * m + 255) / 256)), dim3(256), 0, st, W, m, H, q.np, q.npad, W2, ptab);
+    // fp16 x 2: both operands scaled by exact powers of two (rows of the x0 slice inside the kernel, the pair weights as a tensor): no
+    // promise about the magnitudes of x0 or W is needed
+    float* wpart = pieces == 2 ? reinterpret_cast<float*>(img + q.off_part) : nullptr;
+    if (wpart) hipLaunchKernelGGL(cin_w_absmax_k, dim3(WPARTS), dim3(256), 0, st, W2, (int64_t)H * q.np, wpart);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
         const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
         if (pieces == 2)
             hipLaunchKernelGGL(cin_bf3_pack_w_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W2, 1, q.np, H, pl.KS, pl.nkh, ncb, CT,
-                               hoff, reinterpret_cast<unsigned int*>(dst));
+                               hoff, reinterpret_cast<unsigned int*>(dst), wpart);
         else
             hipLaunchKernelGGL(cin_bf3_pack_w_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W2, 1, q.np, H, pl.KS, pl.nkh, ncb, CT,
                                hoff, reinterpret_cast<unsigned int*>(dst));
@@ -709,10 +820,10 @@ static int l1_run(const char* name, int pieces, const float* x0, const float* W,
 #define L1_LAUNCH_NP(C, NP_, NCB, HOFF, IMG)                                                                                            \
     do {                                                                                                                                \
         static LdsOnce once;                                                                                                      \
-        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true, NP_>);                                              \
+        (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true, NP_, NP_ == 2>);                                    \
         const size_t shmem = 2 * (size_t)2 * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                                     \
-        hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true, NP_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, \
-                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m);                    \
+        hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true, NP_, NP_ == 2>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m, nullptr, wpart, nullptr, xout_bits); \
     } while (0)
 #define L1_LAUNCH(C, NCB, HOFF, IMG)                           \
     do {                                                       \
@@ -743,6 +854,14 @@ extern "C" int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m,
 extern "C" int dir_cin_layer1_f16x2_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
                                         int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream) {
     return l1_run("dir_cin_layer1_f16x2_f32", 2, x0, W, m, H, D, B, xout, pooled, pooled_ld, workspace, workspace_bytes, stream);
+}
+
+// ... leaving the rows' maxima of xout ([B * D] words, row r = b * D + d: the bit pattern of max_h |xout[b, h, d]|) for the next layer's
+// row scales (dir_cin_layer_rows_f16x2_f32); needs xout and H <= 128
+extern "C" int dir_cin_layer1_bits_f16x2_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
+                                             int64_t pooled_ld, void* workspace, int64_t workspace_bytes, unsigned int* xout_row_bits,
+                                             dir_stream_t stream) {
+    return l1_run("dir_cin_layer1_bits_f16x2_f32", 2, x0, W, m, H, D, B, xout, pooled, pooled_ld, workspace, workspace_bytes, stream, xout_row_bits);
 }
 
 extern "C" int dir_cin_bf16x3_dot_partials(int m, int Hp, int H) {

@@ -23,13 +23,16 @@ constexpr int CP_MAXM = 64;
 // broadcasts); the Hp x m tile goes through LDS so that the global stores are contiguous 16-byte pieces.
 template <int D, int CP_THREADS>
 __global__ __launch_bounds__(CP_THREADS) void cin_pool_z_k(const float* __restrict__ x0, const float* __restrict__ xk, int m, int Hp, int64_t B,
-                                                            float* __restrict__ Z) {
+                                                            float* __restrict__ Z,
+                                                            unsigned int* __restrict__ zbits = nullptr /* optional [B]: bit pattern of max |Z[b, :]| */) {
     extern __shared__ __attribute__((aligned(16))) float cp_smem[];
     float* x0s = cp_smem;                       // [m][D]
     float* zt = cp_smem + ((m * D + 3) & ~3);   // [chunk of 256 channels][m + 1]
+    float* zmax_s = zt + CP_THREADS * (m + 1);  // [waves]: behind the tile (all LDS of this kernel is dynamic: the 160 KiB attribute is set for it)
     const int tid = threadIdx.x;
     const int zs = m + 1;
     for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        float zmx = 0.f;                        // this thread's largest |Z| of the sample (the row scale of the dense product that follows)
         __syncthreads();                        // the previous sample's tile has been written out
         for (int e = tid; e < m * D; e += CP_THREADS) x0s[e] = x0[b * m * D + e];
         __syncthreads();
@@ -51,13 +54,27 @@ __global__ __launch_bounds__(CP_THREADS) void cin_pool_z_k(const float* __restri
                         const float4 v = *reinterpret_cast<const float4*>(x0s + j * D + d);
                         s.x = fmaf(xv[d], v.x, s.x); s.y = fmaf(xv[d + 1], v.y, s.y); s.z = fmaf(xv[d + 2], v.z, s.z); s.w = fmaf(xv[d + 3], v.w, s.w);
                     }
-                    zt[tid * zs + j] = (s.x + s.y) + (s.z + s.w);
+                    const float zv = (s.x + s.y) + (s.z + s.w);
+                    zt[tid * zs + j] = zv;
+                    zmx = fmaxf(zmx, fabsf(zv));
                 }
             }
             __syncthreads();
             float* dst = Z + (b * Hp + i0) * m;               // the chunk's nch * m values are contiguous in Z
             for (int e = tid; e < nch * m; e += CP_THREADS) dst[e] = zt[(e / m) * zs + (e % m)];
             if (i0 + CP_THREADS < Hp) __syncthreads();
+        }
+        if (zbits) {                                           // (uniform) one workgroup owns the sample's whole row: a plain store
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) zmx = fmaxf(zmx, __shfl_xor(zmx, o, 64));
+            if ((tid & 63) == 0) zmax_s[tid >> 6] = zmx;
+            __syncthreads();
+            if (tid == 0) {
+                float mx = zmax_s[0];
+#pragma unroll
+                for (int w = 1; w < CP_THREADS / 64; ++w) mx = fmaxf(mx, zmax_s[w]);
+                zbits[b] = __builtin_bit_cast(unsigned int, mx);
+            }
         }
     }
 }
@@ -290,22 +307,32 @@ static int cp_check(const char* name, int m, int Hp, int D, int64_t B) {
 
 using namespace dir;
 
+static int cp_z_run(const char* name, const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, unsigned int* zbits, dir_stream_t stream);
 extern "C" int dir_cin_pool_z_f32(const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, dir_stream_t stream) {
-    const char* name = "dir_cin_pool_z_f32";
+    return cp_z_run("dir_cin_pool_z_f32", x0, xk, m, Hp, D, B, Z, nullptr, stream);
+}
+// ... and the bit pattern of max |Z[b, :]| per sample (what dir_dense_f16x2_rows_f32 scales the rows of Z by: no max pass over the
+// [B, Hp * m] matrix -- 872 MB at the BASELINE shape)
+extern "C" int dir_cin_pool_z_bits_f32(const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, unsigned int* z_row_bits,
+                                       dir_stream_t stream) {
+    DIR_CHECK_ARG(z_row_bits || B == 0, "dir_cin_pool_z_bits_f32: z_row_bits is null");
+    return cp_z_run("dir_cin_pool_z_bits_f32", x0, xk, m, Hp, D, B, Z, z_row_bits, stream);
+}
+static int cp_z_run(const char* name, const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, unsigned int* zbits, dir_stream_t stream) {
     if (int rc = cp_check(name, m, Hp, D, B)) return rc;
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(x0 && xk && Z, "%s: null pointer", name);
     if (!(aligned16(x0) && aligned16(xk))) return fail(DIR_E_BADARG, "%s: x0 / xk must be 16-byte aligned", name);
     const int nt = Hp <= 128 ? 128 : 256;
-    const size_t sh = sizeof(float) * (size_t)(((m * D + 3) & ~3) + nt * (m + 1));
+    const size_t sh = sizeof(float) * (size_t)(((m * D + 3) & ~3) + nt * (m + 1) + 4);       // + the waves' row maxima
     const dim3 grid((unsigned)(B < 32 * kCUs ? B : 32 * kCUs));        // one sample per workgroup and turn: many small workgroups hide each other's loads
     hipStream_t st = as_stream(stream);
 #define DIR_CP_Z(DD)                                                                                              \
     do {                                                                                                          \
         static LdsOnce once;                                                                                                      \
         (void)lds_limit(once, 160 * 1024, &cin_pool_z_k<DD, 128>, &cin_pool_z_k<DD, 256>);                                        \
-        if (nt == 128) hipLaunchKernelGGL((cin_pool_z_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, m, Hp, B, Z); \
-        else hipLaunchKernelGGL((cin_pool_z_k<DD, 256>), grid, dim3(256), sh, st, x0, xk, m, Hp, B, Z);           \
+        if (nt == 128) hipLaunchKernelGGL((cin_pool_z_k<DD, 128>), grid, dim3(128), sh, st, x0, xk, m, Hp, B, Z, zbits); \
+        else hipLaunchKernelGGL((cin_pool_z_k<DD, 256>), grid, dim3(256), sh, st, x0, xk, m, Hp, B, Z, zbits);           \
     } while (0)
     switch (D) {
         case 4: DIR_CP_Z(4); break;

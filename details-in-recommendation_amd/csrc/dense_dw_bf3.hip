@@ -141,13 +141,16 @@ template <int KB, int NP = 3>
 __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict__ g, int64_t g_ld, const float* __restrict__ x, int64_t x_ld,
                                                           int64_t M, int N, int K, int nkb, int nspan, int64_t steps_per_span, int64_t steps,
                                                           float* __restrict__ part, float* __restrict__ bpart /* [nspan][N] or NULL */,
-                                                          const unsigned int* __restrict__ gbits = nullptr /* NP == 2: bit pattern of max |g| */) {
+                                                          const unsigned int* __restrict__ gbits = nullptr /* NP == 2: bit pattern of max |g| */,
+                                                          const unsigned int* __restrict__ xbits = nullptr /* NP == 2, optional: bit pattern of max |x| */) {
     using Pc = DdwPc<NP>;
     using op_t = typename Pc::op_t;
     constexpr int TT = DDW_NT + KB;                   // tiles staged per step: 16 of g, KB of x
     extern __shared__ __attribute__((aligned(16))) unsigned char ddw_smem[];      // [NP pieces][TT tiles][64 lanes][8 halves]
     float gsc = 1.f;
     if constexpr (NP == 2) gsc = ddw_scale(*gbits, false);
+    float xsc = 1.f;                                  // x scaled the same way when its bound is known (any magnitudes; without it |x| < 65 504)
+    if constexpr (NP == 2) xsc = xbits ? ddw_scale(*xbits, false) : 1.f;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, ln = lane & 15;
     int q = blockIdx.x;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
             for (int j = 0; j < 4; ++j) {
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (NP == 2 && isg) ? raw[e][j] * gsc : raw[e][j];
+                for (int e = 0; e < 8; ++e) v[e] = NP == 2 ? raw[e][j] * (isg ? gsc : xsc) : raw[e][j];
                 op_t p[NP];
                 Pc::split8(v, p);
                 const int off = sdst + ((j ^ (stile & 3)) * 16);
@@ -291,9 +294,11 @@ __global__ __launch_bounds__(512, 1) void dense_dw_bf3_k(const float* __restrict
 template <int SG>
 __global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __restrict__ part, const float* __restrict__ bpart, int N, int K,
                                                             int nspan, float* __restrict__ dW, int64_t dw_ld, float* __restrict__ db,
-                                                            const unsigned int* __restrict__ gbits = nullptr /* fp16 x 2: the scale to take out of dW */) {
+                                                            const unsigned int* __restrict__ gbits = nullptr /* fp16 x 2: the scale to take out of dW */,
+                                                            const unsigned int* __restrict__ xbits = nullptr /* ... and x's, when x was scaled too */) {
     constexpr int EPB = 256 / SG;
     const float inv = gbits ? ddw_scale(*gbits, true) : 1.f;
+    const float invx = xbits ? ddw_scale(*xbits, true) : 1.f;      // applied one after the other: each is a normal number, their product need not be
     __shared__ float red[SG][EPB];
     const int q = threadIdx.x / EPB, el = threadIdx.x % EPB;
     const int64_t total = (int64_t)N * K, all = total + (db != nullptr ? N : 0);
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __rest
             float t = red[0][el];
 #pragma unroll
             for (int i = 1; i < SG; ++i) t += red[i][el];
-            if (e < total) dW[(e / K) * dw_ld + (e % K)] = t * inv;
+            if (e < total) dW[(e / K) * dw_ld + (e % K)] = (t * inv) * invx;
             else db[e - total] = t;
         }
         __syncthreads();
@@ -319,12 +324,12 @@ __global__ __launch_bounds__(256) void dense_dw_bf3_reduce_k(const float* __rest
 }
 
 static void ddw_reduce(const float* part, const float* bpart, int N, int K, int nspan, float* dW, int64_t dw_ld, float* db, hipStream_t st,
-                       const unsigned int* gbits = nullptr) {
+                       const unsigned int* gbits = nullptr, const unsigned int* xbits = nullptr) {
     const int64_t all = (int64_t)N * K + (db ? N : 0);
     if (all <= 65536)
-        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<16>, dim3(grid_for((all + 15) / 16)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db, gbits);
+        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<16>, dim3(grid_for((all + 15) / 16)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db, gbits, xbits);
     else
-        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<4>, dim3(grid_for((all + 63) / 64)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db, gbits);
+        hipLaunchKernelGGL(dense_dw_bf3_reduce_k<4>, dim3(grid_for((all + 63) / 64)), dim3(256), 0, st, part, bpart, N, K, nspan, dW, dw_ld, db, gbits, xbits);
 }
 
 // ---- small gradients (N <= 128, K <= 256): fp32 FMAs on a register tile ---------------------------------------------------------------------
@@ -467,7 +472,8 @@ extern "C" int64_t dir_dense_dw_bf16x3_workspace_bytes(int64_t M, int N, int K) 
 }
 
 static int ddw_run(const char* name, int np, const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
-                   int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, const unsigned int* gbits, dir_stream_t stream) {
+                   int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, const unsigned int* gbits, dir_stream_t stream,
+                   const unsigned int* xbits = nullptr) {
     DIR_CHECK_ARG(dW && M >= 0 && N > 0 && K > 0 && dw_ld >= K, "%s: bad argument (M=%lld N=%d K=%d dw_ld=%lld)", name, (long long)M, N, K,
                   (long long)dw_ld);
     hipStream_t st = as_stream(stream);
@@ -493,7 +499,7 @@ static int ddw_run(const char* name, int np, const float* g, int64_t g_ld, const
         const size_t lds = NP_ * (size_t)(DDW_NT + KB_) * 1024;                                                                    \
         (void)lds_limit(once, (int)lds, &dense_dw_bf3_k<KB_, NP_>);                                                               \
         hipLaunchKernelGGL((dense_dw_bf3_k<KB_, NP_>), dim3(grid), dim3(512), lds, st, g, g_ld, x, x_ld, M, N, K, p.nkb, p.nspan,  \
-                           p.steps_per_span, p.steps, part, bpart, gbits);                                                         \
+                           p.steps_per_span, p.steps, part, bpart, gbits, np == 2 ? xbits : nullptr);                              \
     } while (0)
     if (np == 2) {
         if (p.KB == 13) DDW_LAUNCH(13, 2);
@@ -504,7 +510,7 @@ static int ddw_run(const char* name, int np, const float* g, int64_t g_ld, const
     else DDW_LAUNCH(16, 3);
 #undef DDW_LAUNCH
     DIR_CHECK_LAUNCH(name);
-    ddw_reduce(part, bpart, N, K, p.nspan, dW, dw_ld, db, st, np == 2 ? gbits : nullptr);
+    ddw_reduce(part, bpart, N, K, p.nspan, dW, dw_ld, db, st, np == 2 ? gbits : nullptr, np == 2 ? xbits : nullptr);
     DIR_CHECK_LAUNCH("dense_dw reduce");
     return DIR_OK;
 }
@@ -520,4 +526,14 @@ extern "C" int dir_dense_dw_f16x2_f32(const float* g, int64_t g_ld, const float*
                                       int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits,
                                       dir_stream_t stream) {
     return ddw_run("dir_dense_dw_f16x2_f32", 2, g, g_ld, x, x_ld, M, N, K, dW, dw_ld, db, workspace, workspace_bytes, g_absmax_bits, stream);
+}
+
+// ... with x scaled by one power of two as well (x_absmax_bits: the bit pattern of an upper bound of max |x|, e.g. the all_bits the
+// row-scaled forward kernel or dir_row_absmax_bits_f32 left for this layer's input): no bound on either operand's magnitude is assumed
+extern "C" int dir_dense_dw_f16x2_scaled_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW,
+                                             int64_t dw_ld, float* db, void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits,
+                                             const unsigned int* x_absmax_bits, dir_stream_t stream) {
+    DIR_CHECK_ARG(x_absmax_bits || M == 0, "dir_dense_dw_f16x2_scaled_f32: x_absmax_bits is null");
+    return ddw_run("dir_dense_dw_f16x2_scaled_f32", 2, g, g_ld, x, x_ld, M, N, K, dW, dw_ld, db, workspace, workspace_bytes, g_absmax_bits, stream,
+                   x_absmax_bits);
 }

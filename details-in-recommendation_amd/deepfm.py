@@ -162,7 +162,7 @@ class DeepFM(nn.Module):
         if not _train_mode(self):
             fused = tower_infer(self.hidden, net, self.activation, bns=self.bns if len(self.bns) else None,
                                 head=self.logits_layer if self.units == 1 else None, adds=adds if self.units == 1 else (),
-                                embedding_input=True)       # net is the concat of the embedding columns (deepFM.py:288-291)
+                                embedding_input=self._tablesets()[0].range_ok())       # net is the concat of the embedding columns (deepFM.py:288-291)
             if fused is not None:                                               # inference: the whole tower (+ logit layer) in one launch
                 out = fused if self.units == 1 else self._logits_of(fused)
                 for a in (adds if self.units != 1 else ()):

@@ -81,14 +81,14 @@ def _packed_cached(weight):
 _DW_KERNELS = ("bf16x3", "small")
 
 
-def _tn_matmul(g, x, splits=16, g_bits=None):
+def _tn_matmul(g, x, splits=16, g_bits=None, x_bits=None):
     """g^T x for tall operands ([M, N]^T [M, Kd], M = batch rows): the library's single TN GEMM runs at 0.33 of the fp32 MFMA peak
     at 65 536 x 400 x 416 (a 400 x 416 output leaves most CUs idle); sixteen batched row slices + one sum run at 0.53
     (tools/tn_gemm_probe.py: 425 -> 261 us)."""
     M = g.shape[0]
     if g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
             and ops.dense_dw_auto_arith(M, g.shape[1], x.shape[1]) in _DW_KERNELS:
-        return ops.dense_dw(g, x, g_bits=g_bits)        # dir_dense_dw_{bf16x3,f16x2}_f32 where the operands are covered (tools/dense_dw_probe.py)
+        return ops.dense_dw(g, x, g_bits=g_bits, x_bits=x_bits)        # dir_dense_dw_{bf16x3,f16x2}_f32 where the operands are covered (tools/dense_dw_probe.py)
     if M >= 8192 and M % splits == 0 and g.is_contiguous() and x.is_contiguous():
         return torch.bmm(g.view(splits, M // splits, -1).transpose(1, 2), x.view(splits, M // splits, -1)).sum(dim=0)
     return g.t() @ x
@@ -107,21 +107,23 @@ def _packed_cached_padded(weight, pad):
     return packed
 
 
-def _wb_grads(g, x, need_w, need_b, g_bits=None):
+def _wb_grads(g, x, need_w, need_b, g_bits=None, x_bits=None):
     """(dL/dW, dL/db) of a dense layer from g = dL/d(pre-activation) and its input x: one pass of dir_dense_dw_bf16x3_f32 for both where
     it covers the shape, otherwise the library GEMM and a column sum."""
     if need_w and need_b and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1 \
             and ops.dense_dw_auto_arith(g.shape[0], g.shape[1], x.shape[1]) in _DW_KERNELS:
-        gw, gb = ops.dense_dw(g, x, want_bias=True, g_bits=g_bits)
+        gw, gb = ops.dense_dw(g, x, want_bias=True, g_bits=g_bits, x_bits=x_bits)
         if gb is not None:
             return gw, gb
-    return (_tn_matmul(g, x, g_bits=g_bits) if need_w else None), (g.sum(dim=0) if need_b else None)
+    return (_tn_matmul(g, x, g_bits=g_bits, x_bits=x_bits) if need_w else None), (g.sum(dim=0) if need_b else None)
 
 
 def _gbits(g, x_bounded, Kin, need_x=True, need_w=True, carried=None):
     """(row_bits, g_bits) for the fp16 x 2 backward kernels of one layer with Kin inputs: row_bits for dL/dx = g W (its other operand is the
-    weight), g_bits for dL/dW = g^T x only when the layer's input x is bounded by construction (None otherwise: bf16 x 3).  (None, None)
-    when neither product would run a split-arithmetic kernel at this shape (then the max pass over g is not run either)."""
+    weight), g_bits for dL/dW = g^T x only when x_bounded -- since round 5: the forward left the bit pattern of max |x| for this layer's
+    input (the weight gradient scales x by a power of two as well: dir_dense_dw_f16x2_scaled_f32), no longer a caller's promise -- and
+    None otherwise (bf16 x 3).  (None, None) when neither product would run a split-arithmetic kernel at this shape (then the max pass
+    over g is not run either)."""
     if not g.is_cuda or g.dim() != 2:
         return None, None
     M, N = g.shape
@@ -141,9 +143,10 @@ class _DenseFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, bounded=False):
-        y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu)
+        xb = []
+        y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu, xbits_out=xb)
         ctx.relu = relu
-        ctx.bounded = bool(bounded)
+        ctx.xbits = xb[0] if xb else None           # max |x| (device): what lets dL/dW run the scaled fp16 x 2 kernel (`bounded` is a hint no more)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
         return y
@@ -156,11 +159,11 @@ class _DenseFn(torch.autograd.Function):
             g = g * (y > 0)
         g = g.contiguous()
         gx = gw = gb = None
-        rb, ab = _gbits(g, ctx.bounded, x.shape[1], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        rb, ab = _gbits(g, ctx.xbits is not None, x.shape[1], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
             wt = _kernel_weight(g, weight.t())                     # [Kd, N]: the "weight" of the transposed product
             gx = ops.dense(g, wt, None, relu=False, row_bits=rb) if ops.dense_supported(g, wt) else g @ weight
-        gw, gb = _wb_grads(g, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], g_bits=ab)
+        gw, gb = _wb_grads(g, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], g_bits=ab, x_bits=ctx.xbits if ab is not None else None)
         return gx, gw, gb, None, None
 
 
@@ -176,10 +179,11 @@ class _DenseBnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, bn, relu, bounded=False):
-        y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu)
+        xb = []
+        y = ops.dense(x, _kernel_weight(x, weight), bias, relu=relu, xbits_out=xb)
         mean, inv, scale, shift = ops.bn_train_stats(y, gamma, beta, bn.moving_mean, bn.moving_variance, bn.eps, bn.momentum)
         ctx.relu = relu
-        ctx.bounded = bool(bounded)
+        ctx.xbits = xb[0] if xb else None
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y, mean, inv, gamma)
         return torch.addcmul(shift, y, scale)
@@ -192,11 +196,11 @@ class _DenseBnFn(torch.autograd.Function):
             g = g.contiguous()
         gpre, gbeta, ggamma = ops.bn_train_backward(g, y, mean, inv, gamma, relu_gate=ctx.relu)
         gx = None
-        rb, ab = _gbits(gpre, ctx.bounded, x.shape[1], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        rb, ab = _gbits(gpre, ctx.xbits is not None, x.shape[1], ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         if ctx.needs_input_grad[0]:
             wt = _kernel_weight(gpre, weight.t())
             gx = ops.dense(gpre, wt, None, relu=False, row_bits=rb) if ops.dense_supported(gpre, wt) else gpre @ weight
-        gw, gb = _wb_grads(gpre, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], g_bits=ab)
+        gw, gb = _wb_grads(gpre, x, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], g_bits=ab, x_bits=ctx.xbits if ab is not None else None)
         return (gx, gw, gb, ggamma if gamma is not None and ctx.needs_input_grad[3] else None, gbeta if ctx.needs_input_grad[4] else None,
                 None, None, None)
 
@@ -210,6 +214,22 @@ def _dense_bn_train(bn, x, weight, bias, relu, bounded=False):
     return _apply_bn(bn, _DenseFn.apply(x, weight, bias, relu, bounded))
 
 
+def _forward_layers(ys, h, params, L, bounded, last_bits):
+    """The forward of a dense + ReLU stack on the row-scaled fp16 x 2 kernel where it is covered: layer 0 runs one max pass over its input,
+    every layer's epilogue leaves the row / tensor maxima of its OUTPUT -- the next layer's row scales and, for the backward, the bound its
+    weight gradient scales that input by.  Appends the activations to ys; -> [max |input of layer l| as a [1] int32 device tensor or None]."""
+    xbits, rb, carried_all = [], None, None
+    for l in range(L):
+        left = [] if (l + 1 < L or last_bits) else None
+        xb = []
+        h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True, arith="auto_bounded" if bounded else None,
+                      row_bits=rb, bits_out=left, xbits_out=xb)
+        xbits.append(xb[0] if xb else carried_all)
+        rb, carried_all = left[0] if left else (None, None)
+        ys.append(h)
+    return xbits
+
+
 class _MlpStackFn(torch.autograd.Function):
     """A stack of dense + ReLU layers as ONE autograd node.  Forward: dir_dense_f32 per layer.  Backward, per layer from the top:
     dL/dW = g^T x (batched library GEMM), dL/db = sum g, and the data gradient goes straight through the previous layer's ReLU in
@@ -221,11 +241,9 @@ class _MlpStackFn(torch.autograd.Function):
         bounded = bool(_FWD_BOUNDED[0])         # (set by mlp_stack around the apply: a flag, not a tensor argument)
         L = len(params) // 2
         ys, h = [], x
-        for l in range(L):
-            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True, arith="auto_bounded" if bounded else None)
-            ys.append(h)
+        ctx.xbits = _forward_layers(ys, h, params, L, bounded, last_bits=False)
+        h = ys[-1]
         ctx.L = L
-        ctx.bounded = bounded
         ctx.save_for_backward(x, *params[0::2], *ys)
         return h
 
@@ -241,8 +259,10 @@ class _MlpStackFn(torch.autograd.Function):
         carried = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
-            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[1 + 2 * l], carried)
-            grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l], g_bits=ab)
+            xb = ctx.xbits[l]
+            rb, ab = _gbits(g, xb is not None, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[1 + 2 * l], carried)
+            grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l], g_bits=ab,
+                                                       x_bits=xb if ab is not None else None)
             wt = _kernel_weight(g, ws[l].t())
             if l > 0:
                 left = []                           # the row-scaled kernel leaves its output's row / tensor maxima: the next layer's scales
@@ -268,11 +288,9 @@ class _MlpHeadFn(torch.autograd.Function):
         bounded = bool(_FWD_BOUNDED[0])
         L = len(params) // 2
         ys, h = [], x
-        for l in range(L):
-            h = ops.dense(h, _kernel_weight(h, params[2 * l]), params[2 * l + 1], relu=True, arith="auto_bounded" if bounded else None)
-            ys.append(h)
+        ctx.xbits = _forward_layers(ys, h, params, L, bounded, last_bits=False)
+        h = ys[-1]
         ctx.L = L
-        ctx.bounded = bounded
         ctx.save_for_backward(x, head_w, *params[0::2], *ys)
         return ops.units1(h, head_w, head_b)        # (dir_units1_f32; the library ran it as a one-column GEMM: 26 us at 65 536 x 400, its GEMV 62)
 
@@ -288,12 +306,14 @@ class _MlpHeadFn(torch.autograd.Function):
         gx = None
         for l in range(L - 1, -1, -1):
             xin = ys[l - 1] if l > 0 else x
-            rb, ab = _gbits(g, ctx.bounded, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[3 + 2 * l], carried)
+            xb = ctx.xbits[l]
+            rb, ab = _gbits(g, xb is not None, xin.shape[1], l > 0 or ctx.needs_input_grad[0], ctx.needs_input_grad[3 + 2 * l], carried)
+            xb = xb if ab is not None else None
             if l == L - 1:                                           # the top layer's bias gradient came with the head's backward
-                grads[2 * l] = _tn_matmul(g, xin, g_bits=ab) if ctx.needs_input_grad[3 + 2 * l] else None
+                grads[2 * l] = _tn_matmul(g, xin, g_bits=ab, x_bits=xb) if ctx.needs_input_grad[3 + 2 * l] else None
                 grads[2 * l + 1] = gb_top if ctx.needs_input_grad[4 + 2 * l] else None
             else:
-                grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l], g_bits=ab)
+                grads[2 * l], grads[2 * l + 1] = _wb_grads(g, xin, ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l], g_bits=ab, x_bits=xb)
             wt = _kernel_weight(g, ws[l].t())
             if l > 0:
                 left = []

@@ -49,7 +49,9 @@ class _BaseModel(nn.Module):
             if fused is not None:
                 return fused
         net = self.input_layer(features, memo=memo)
-        emb_in = self.input_layer.embedding_only       # the input is a concatenation of embedding rows (ESMM.py:135 over embedding columns)
+        # the input is a concatenation of embedding rows (ESMM.py:135 over embedding columns); in inference (the fused tower kernel splits its
+        # input unscaled) the tables' magnitudes are checked as well
+        emb_in = self.input_layer.embedding_only and (torch.is_grad_enabled() or self.input_layer.embedding_range_ok())
         fused = tower_infer(self.hidden, net, self.activation, head=self.logits, embedding_input=emb_in)      # inference: tower + logit layer in one launch
         if fused is not None:
             return fused

@@ -46,6 +46,14 @@ class InputLayer(nn.Module):
             self.embedding_weights.append(nn.Parameter(w))
         self._ts_key = None
 
+    def embedding_range_ok(self):
+        """Whether the layer's output (embedding columns only) may feed the UNSCALED fp16 x 2 tower kernel: every table inside
+        ops.TableSet.range_ok's window (weighted / mean-combined bags stay inside it; sum-combined bags of many rows are the caller's to bound)."""
+        if not self.embedding_only:
+            return False
+        self._tablesets()
+        return all(g[0].range_ok() for g in self._groups)
+
     def _col_offset(self, col):
         return self.offsets[self.columns.index(col)]
 

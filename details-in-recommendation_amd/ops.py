@@ -118,15 +118,27 @@ class TableSet:
         ts.arena, ts.rows = arena, rows
         return ts
 
-    def absmax(self):
+    def absmax(self, every=1):
         """max |embedding value| over the tables, measured once per version of the tables and their owners (one pass + one sync when an
-        in-place update bumped a counter): tower(gather=..., split=None) keeps a table past F16_RANGE_GUARD off the fp16 x 2 kernel."""
+        in-place update bumped a counter): tower(gather=..., split=None) keeps a table past F16_RANGE_GUARD off the fp16 x 2 kernel.
+        every > 1: a measurement may be up to `every` updates old (every table's counter moves once per optimiser step) -- what a
+        training loop that evaluates between steps can afford: one pass and one sync per `every` steps."""
         sig = tuple(t._version for t in self.tables) + tuple(t._version for t in self.owners)
         hit = getattr(self, "_absmax", None)
-        if hit is None or hit[0] != sig:
+        tot = sum(sig)
+        if hit is None or (hit[0] != sig and (every <= 1 or tot - hit[2] >= every * len(sig) or tot < hit[2])):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("TableSet.absmax: measure the tables (one eager call) before capturing a graph")
             m = float(torch.stack([t.abs().max() for t in self.tables if t.numel()] or [torch.zeros((), device=self.device)]).max())
-            hit = self._absmax = (sig, m)
+            hit = self._absmax = (sig, m, tot)
         return hit[1]
+
+    def range_ok(self, every=32):
+        """Whether rows of these tables may feed an UNSCALED fp16 x 2 kernel (the fused inference tower, the DIN unit): the largest |value|
+        inside [F16_SMALL_GUARD, F16_RANGE_GUARD) -- below the upper guard nothing overflows fp16 (a factor 2 of headroom: a table that
+        drifts between two measurements `every` steps apart must more than double to reach 65 504), above the lower one a 1e-5 relative
+        bar holds (an fp16 x 2 element below 2^-3 keeps an ABSOLUTE 2^-25).  Callers fall back to bf16 x 3 (fp32's exponent range)."""
+        return f16_range_ok(self.absmax(every))
 
     def gather_flags(self):
         if self.row_policy == "stream" or (self.row_policy == "auto" and self.nbytes > 2 * INFINITY_CACHE_BYTES):
@@ -145,6 +157,11 @@ class TableSet:
         """Rebuild the pointer array (after tables were re-allocated, e.g. .to())."""
         self._ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=self.device)
 
+
+
+def f16_range_ok(absmax):
+    """The magnitude window of the UNSCALED fp16 x 2 kernels (see TableSet.range_ok); an all-zero operand is fine."""
+    return absmax == 0.0 or (F16_SMALL_GUARD <= absmax < F16_RANGE_GUARD)
 
 
 def mark_written(*tensors):
@@ -426,6 +443,8 @@ def din_activation_rows_(x, activation, alpha, scale=None, shift=None):
         raise ValueError("din_activation_rows_: x must be [B, N] with unit column stride")
     B, N = x.shape
     vec = [None if t is None else _dev(t.detach().contiguous(), torch.float32, "activation parameter") for t in (alpha, scale, shift)]
+    if hasattr(x, "_dir_bits"):
+        del x._dir_bits                         # the rows' maxima a dense kernel left on x no longer describe it
     _lib.check(_lib.load().dir_din_activation_rows_f32(_ptr(x), x.stride(0) if B > 1 else max(N, x.stride(0)), B, N, DIN_ACTIVATIONS[activation],
                                                        _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]), _stream()))
     return x
@@ -552,8 +571,11 @@ def dense_supported(x, weight):
 
 # default arithmetic of dense / dense_gated: "auto" (bf16x3 where covered and not padding-bound, fp32 MFMA otherwise) | "f32" | "bf16x3"
 DENSE_ARITH = os.environ.get("DIR_DENSE_ARITH", "auto")
-# what arith="auto_bounded" puts in bf16x3's place: "f16x2" (csrc/dense_bf3.hip, round 4) or "bf16x3" (A/B switch)
-DENSE_BOUNDED_SPLIT = os.environ.get("DIR_DENSE_BOUNDED_SPLIT", "f16x2")
+# what arith="auto_bounded" puts in bf16x3's place: "f16x2_rows" (round 5: the same row-scaled fp16 x 2 kernel a general input gets -- the
+# rows' exponents carried from the producing kernel's epilogue where the caller has them, one max pass otherwise -- so "bounded by
+# construction" is no longer a promise the forward's correctness rests on), "f16x2" (round 4: the unscaled kernel, |x| < 65 504 and an
+# absolute 2^-25 below 2^-3) or "bf16x3" (A/B switches)
+DENSE_BOUNDED_SPLIT = os.environ.get("DIR_DENSE_BOUNDED_SPLIT", "f16x2_rows")
 # the split of the dense BACKWARD kernels whose operand is a gradient: "f16x2" = dL/dx on dir_dense_f16x2_rows_f32 (rows of g scaled by powers
 # of two) and, where the layer's input is bounded by construction, dL/dW on dir_dense_dw_f16x2_f32 (g scaled by one power of two);
 # "bf16x3" = rounds 2-3's arithmetic
@@ -565,6 +587,8 @@ DENSE_GENERAL_SPLIT = os.environ.get("DIR_DENSE_GENERAL_SPLIT", "f16x2_rows")
 # development switch: 0 = every fp16 x 2 backward kernel gets its scales from a max pass of its own (dir_row_absmax_bits_f32) instead of from
 # the kernel that produced the gradient
 DENSE_BWD_CARRY = os.environ.get("DIR_DENSE_BWD_CARRY", "1") != "0"
+# development switch: 0 = a row-scaled forward layer does not leave its output's maxima on the tensor (every layer runs its own max pass)
+DENSE_FWD_CARRY = os.environ.get("DIR_DENSE_FWD_CARRY", "1") != "0"
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
 
@@ -575,6 +599,7 @@ def invalidate_caches():
     after such a write (checkpoint.load_* do)."""
     _DENSE_IMAGES.clear()
     _TOWER_IMAGES.clear()
+    _WEIGHT_ABSMAX.clear()
 
 
 def dense_bf16x3_covers(x, weight, out=None, gate=None):
@@ -686,7 +711,7 @@ def _dense_arith(arith, x, weight, out, gate):
     return arith
 
 
-def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None, arith=None, row_bits=None, bits_out=None):
+def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shift=None, arith=None, row_bits=None, bits_out=None, xbits_out=None):
     """y = act(x @ weight.T + bias) (include/dir_hip.h: dir_dense_f32 / dir_dense_bf16x3_f32).  x [M, Kd], weight [N, Kd] (nn.Linear
     layout), bias [N].  post_scale / post_shift [N]: the inference batch-norm that follows the activation, as
     y * post_scale + post_shift in the same pass.  arith: "f32" (fp32 MFMA), "bf16x3" (three-way bf16 split of both operands on the
@@ -696,7 +721,8 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
     activations, the CIN's pooled products (|x|, |W| < 65 504).
     row_bits (grad_bits(x)[0]): x is a gradient; where "auto" would run bf16x3 the row-scaled fp16 x 2 kernel runs
     (dir_dense_f16x2_rows_f32).  bits_out (a list): when that kernel ran, (row_bits, all_bits) of the OUTPUT is appended -- its epilogue
-    leaves them, for the next layer of a backward chain."""
+    leaves them, for the next layer of a backward chain.  xbits_out (a list): when the op ran its own max pass over x, x's all_bits ([1]
+    int32: the bit pattern of max |x|) is appended -- what the layer's weight gradient scales x by (dense_dw(x_bits=...))."""
     _dev(x, torch.float32, "x")
     _dev(weight, torch.float32, "weight")
     M, Kd = x.shape
@@ -707,12 +733,20 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
         bias = _dev(bias, torch.float32, "bias").contiguous()
         if bias.numel() != N:
             raise ValueError("dense: bias [N]")
-    if out is None:
+    fresh = out is None
+    if fresh:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     which = _dense_arith(arith, x, weight, out, None)
-    if which == "bf16x3" and (arith or DENSE_ARITH) == "auto":
+    asked = arith or DENSE_ARITH
+    if which == "bf16x3" and (asked == "auto" or (asked == "auto_bounded" and DENSE_BOUNDED_SPLIT == "f16x2_rows")):
         if row_bits is None and DENSE_GENERAL_SPLIT == "f16x2_rows" and _rows_covered(x):
-            row_bits = row_absmax_bits(x, want_all=False)[0]          # a general input: its rows' exponents first (one pass over x)
+            hint = getattr(x, "_dir_bits", None)      # left by the row-scaled kernel that produced x (below), valid while x is unmodified
+            if hint is not None and hint[2] == x._version and hint[0].numel() == M and hint[0].device == x.device:
+                row_bits, xall = hint[0], hint[1]
+            else:
+                row_bits, xall = row_absmax_bits(x, want_all=xbits_out is not None)      # a general input: its rows' exponents first (one pass over x)
+            if xbits_out is not None and xall is not None:
+                xbits_out.append(xall)
         if row_bits is not None:
             which = "f16x2_rows"
     use_bf3 = which in ("bf16x3", "f16x2", "f16x2_rows")
@@ -727,10 +761,15 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
                                                    _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
         return out
     if which == "f16x2_rows":
-        yb = _out_bits(bits_out, M, x.device)
+        # the epilogue leaves the row / tensor maxima of the output: for the caller's list, and (round 5) on a tensor this call created, where
+        # the NEXT row-scaled layer finds them instead of running a max pass (inference chains: DCN's 1024-wide layers, the ESMM towers)
+        carry = fresh and bits_out is None and DENSE_FWD_CARRY and N >= 16
+        yb = _out_bits(bits_out if not carry else [], M, x.device)
         _lib.check(_lib.load().dir_dense_f16x2_rows_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), _ptr(bias), 1 if relu else 0,
                                                         _ptr(post_scale), _ptr(post_shift), None, 0, M, Kd, N, _ptr(out), out.stride(0),
                                                         _ptr(row_bits), _ptr(yb[0]), _ptr(yb[1]), _stream()))
+        if fresh and yb[0] is not None:
+            out._dir_bits = (yb[0], yb[1], out._version)
         return out
     if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0,
@@ -756,7 +795,9 @@ def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=
     N = weight.shape[0]
     if weight.shape[1] != Kd or x.stride(1) != 1 or M < DENSE_BF3_MIN_ROWS or DENSE_ARITH not in ("auto", "bf16x3"):
         return None
-    f16 = bool(bounded) and DENSE_BOUNDED_SPLIT == "f16x2" and DENSE_ARITH == "auto"
+    # (bounded here means a batch-normalised input: |x| <= sqrt(B) by the normalisation itself, not a promise about data; the weight image's
+    # rows carry their own power-of-two scales)
+    f16 = bool(bounded) and DENSE_BOUNDED_SPLIT in ("f16x2", "f16x2_rows") and DENSE_ARITH == "auto"
     if weight.stride(1) != 1 or weight.stride(0) % 4 or weight.data_ptr() % 16:
         weight = weight.contiguous()
     if not dense_bf16x3_covers(x, weight):
@@ -823,6 +864,9 @@ TOWER_SPLIT = os.environ.get("DIR_TOWER_SPLIT", "f16x2")      # what split=None 
 # once per image build / per version of the tables) routes the launch to "bf16x3".  Activations stay the caller's contract (checking them
 # would cost a pass and a sync per call): callers whose inputs are not embedding rows or ReLU activations of such pass split="bf16x3".
 F16_RANGE_GUARD = 32768.0
+# ... and a largest |value| BELOW this routes to bf16 x 3 as well: an unscaled fp16 x 2 element under 2^-3 carries an absolute error of 2^-25,
+# i.e. 2^-25 / rms(x) relative on a dot product -- past the 1e-5 bar once a tensor's values sit around 2^-9 (round 5)
+F16_SMALL_GUARD = 2.0 ** -6
 
 
 def tower_image(weight, split=None):
@@ -846,19 +890,39 @@ def tower_image(weight, split=None):
     _lib.check(pack(_ptr(w), w.stride(0), K, N, _ptr(img), nbytes, _stream()))
     if len(_TOWER_IMAGES) > 256:
         _TOWER_IMAGES.clear()
-    _TOWER_IMAGES[key] = (weakref.ref(weight), sig, img, float(weight.detach().abs().max()) if weight.numel() else 0.0)
+    _TOWER_IMAGES[key] = (weakref.ref(weight), sig, img)
     return img
+
+
+_WEIGHT_ABSMAX = {}
+
+
+def weight_absmax(weight):
+    """max |w| of a weight tensor, measured once per version (one small reduction and one sync when the tensor changed: inference pays it
+    once; nothing is packed for it -- ADVICE r4: the tower's guard used to build the fp16 x 2 image just to read this number)."""
+    import weakref
+    key = weight.data_ptr()
+    sig = (weight._version, tuple(weight.shape))
+    hit = _WEIGHT_ABSMAX.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == sig:
+        return hit[2]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("weight_absmax: run one eager call before capturing a graph (the fp16 range guard reads the weights' magnitudes once)")
+    m = float(weight.detach().abs().max()) if weight.numel() else 0.0
+    if len(_WEIGHT_ABSMAX) > 512:
+        _WEIGHT_ABSMAX.clear()
+    _WEIGHT_ABSMAX[key] = (weakref.ref(weight), sig, m)
+    return m
 
 
 def _tower_split_for(weights, pt=None):
     """What split=None resolves to: TOWER_SPLIT, or "bf16x3" when a weight or a packed row is outside F16_RANGE_GUARD."""
     if TOWER_SPLIT != "f16x2":
         return TOWER_SPLIT
-    if pt is not None and pt.absmax() >= F16_RANGE_GUARD:
+    if pt is not None and not f16_range_ok(pt.absmax()):
         return "bf16x3"
     for w in weights:
-        tower_image(w, "f16x2")
-        if _TOWER_IMAGES[(w.data_ptr(), "f16x2")][3] >= F16_RANGE_GUARD:
+        if not f16_range_ok(weight_absmax(w)):
             return "bf16x3"
     return "f16x2"
 
@@ -1003,13 +1067,15 @@ def dense_dw_auto_arith(M, N, K):
     return "bf16x3"
 
 
-def dense_dw(g, x, arith=None, want_bias=False, g_bits=None):
+def dense_dw(g, x, arith=None, want_bias=False, g_bits=None, x_bits=None):
     """dW [N, K] = g^T x, the kernel gradient of a dense layer (include/dir_hip.h: dir_dense_dw_bf16x3_f32): g [M, N], x [M, K], unit
     inner strides.  arith None / "auto": dense_dw_auto_arith; "f32": the library GEMM in row slices; "bf16x3": the MFMA kernel;
     "small": the fp32 FMA kernel for N <= 128, K <= 256 (dir_dense_dw_small_f32).
     want_bias: -> (dW, db) with db [N] = g.sum(0), the bias gradient (in the kernel's pass over g on the bf16x3 path).
     g_bits (grad_bits(g)[1]) given by a caller who ALSO vouches that x is bounded by construction (an embedding concatenation, an
-    activation of such a tower): where "auto" would run bf16x3, dir_dense_dw_f16x2_f32 runs; "f16x2" asks for it by name."""
+    activation of such a tower): where "auto" would run bf16x3, dir_dense_dw_f16x2_f32 runs; "f16x2" asks for it by name.
+    x_bits (a [1] int32 device tensor: the bit pattern of an upper bound of max |x|, e.g. the all_bits the forward's row-scaled kernel or
+    max pass left for this input): x is scaled by a power of two as well (dir_dense_dw_f16x2_scaled_f32) and nothing has to be vouched."""
     _dev(g, torch.float32, "g")
     _dev(x, torch.float32, "x")
     if g.dim() != 2 or x.dim() != 2 or g.shape[0] != x.shape[0] or g.stride(1) != 1 or x.stride(1) != 1:
@@ -1042,8 +1108,12 @@ def dense_dw(g, x, arith=None, want_bias=False, g_bits=None):
         ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=g.device)
         dW = torch.empty((N, K), dtype=torch.float32, device=g.device)
         db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
-        _lib.check(lib.dir_dense_dw_f16x2_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(db), _ptr(ws), nbytes,
-                                              _ptr(g_bits), _stream()))
+        if x_bits is not None:
+            _lib.check(lib.dir_dense_dw_f16x2_scaled_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(db), _ptr(ws),
+                                                         nbytes, _ptr(g_bits), _ptr(x_bits), _stream()))
+        else:
+            _lib.check(lib.dir_dense_dw_f16x2_f32(_ptr(g), g.stride(0), _ptr(x), x.stride(0), M, N, K, _ptr(dW), dW.stride(0), _ptr(db), _ptr(ws), nbytes,
+                                                  _ptr(g_bits), _stream()))
         return (dW, db) if want_bias else dW
     wsq, run = ((lib.dir_dense_dw_bf16x3_workspace_bytes, lib.dir_dense_dw_bf16x3_f32) if arith == "bf16x3" else
                 (lib.dir_dense_dw_small_workspace_bytes, lib.dir_dense_dw_small_f32))
@@ -1359,6 +1429,11 @@ def cin_auto_arith(m, D, Hp, H):
     return "bf16x3" if hpad * ipad <= 1.8 * H * Hp else "f32"
 
 
+# The forward layers can hand their output's row maxima to the next layer (dir_cin_layer1_bits_f16x2_f32 -> dir_cin_layer_rows_f16x2_f32's
+# xk_row_bits: no scan of xk in the prologue).  Measured SLOWER than scanning (2.31-2.43 against 2.20-2.33 ms for the 128 x 128 layer at
+# B = 65 536, profiles/r05_cin_rs_probe.txt): the scan doubles as a prefetch burst of the workgroup's xk slice, whose loads the main loop
+# otherwise waits for twice.  Off by default; kept (and tested) as an entry-point feature.
+CIN_ROW_BITS_CARRY = os.environ.get("DIR_CIN_ROW_BITS_CARRY", "0") == "1"
 CIN_L1_PAIRS = os.environ.get("DIR_CIN_L1_PAIRS", "1") != "0"      # development switch: 0 runs a stack's first layer on the general kernel
 CIN_POOLED_LAST = os.environ.get("DIR_CIN_POOLED_LAST", "1") != "0"  # development switch: 0 runs a pooled-only layer on the layer kernel
 
@@ -1368,9 +1443,19 @@ def cin_pooled_covers(m, D, Hp):
     return m <= 64 and D in (4, 8, 16, 32) and (Hp * m) % 4 == 0
 
 
-def cin_pool_z(x0, xk):
+def _row_bits_hint(t, n):
+    """The row maxima the kernel that produced `t` left on it (t._dir_row_bits = (bits [n] int32, t._version at that time)), or None: the
+    tensor was modified since (an in-place op bumps its version), is another tensor, or never had them."""
+    hint = getattr(t, "_dir_row_bits", None)
+    if hint is not None and hint[1] == t._version and hint[0].numel() == n and hint[0].device == t.device:
+        return hint[0]
+    return None
+
+
+def cin_pool_z(x0, xk, want_bits=False):
     """Z [B, Hp*m], Z[b, i*m + j] = sum_d xk[b,i,d] x0[b,j,d] (include/dir_hip.h: dir_cin_pool_z_f32): what a layer whose map only feeds its
-    pooled sums needs of its inputs -- pooled = Z @ W.T."""
+    pooled sums needs of its inputs -- pooled = Z @ W.T.  want_bits: -> (Z, row_bits [B] int32: the bit pattern of max |Z[b, :]|, the row
+    scales of the dense product that follows -- dir_cin_pool_z_bits_f32)."""
     _dev(x0, torch.float32, "x0")
     _dev(xk, torch.float32, "xk")
     B, m, D = x0.shape
@@ -1378,6 +1463,10 @@ def cin_pool_z(x0, xk):
     if not (x0.is_contiguous() and xk.is_contiguous()) or xk.shape[0] != B or xk.shape[2] != D:
         raise ValueError("cin_pool_z: contiguous x0 [B,m,D], xk [B,Hp,D]")
     Z = torch.empty((B, Hp * m), dtype=torch.float32, device=x0.device)
+    if want_bits:
+        zb = torch.empty(max(B, 1), dtype=torch.int32, device=x0.device)[:B]
+        _lib.check(_lib.load().dir_cin_pool_z_bits_f32(_ptr(x0), _ptr(xk), m, Hp, D, B, _ptr(Z), _ptr(zb), _stream()))
+        return Z, zb
     _lib.check(_lib.load().dir_cin_pool_z_f32(_ptr(x0), _ptr(xk), m, Hp, D, B, _ptr(Z), _stream()))
     return Z
 
@@ -1431,21 +1520,28 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
             and cin_pooled_covers(x0.shape[1], x0.shape[2], xk.shape[1]) and x0.is_cuda and x0.is_contiguous() and xk.is_contiguous()
             and W.dim() == 2 and W.shape[1] == xk.shape[1] * x0.shape[1]):
         B, H = x0.shape[0], W.shape[0]
-        Z = cin_pool_z(x0, xk)
+        # Z (sums over d of products) is a general input: dense "auto" runs its row-scaled fp16 x 2 kernel on it, the rows' maxima left by
+        # the kernel that forms Z (no max pass over the [B, Hp*m] matrix)
+        Z, zb = cin_pool_z(x0, xk, want_bits=True)
         if pooled is None:
             pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
-        da = "auto_bounded" if (auto and CIN_FWD_SPLIT == "f16x2" and not grad_operand) or arith == "f16x2" else None     # Z: sums of embedding products
         if pooled.stride(1) == 1 and pooled.stride(0) % 4 == 0 and pooled.data_ptr() % 16 == 0:
-            dense(Z, W, out=pooled, arith=da)
+            dense(Z, W, out=pooled, row_bits=zb)
         else:
-            pooled.copy_(dense(Z, W, arith=da))
+            pooled.copy_(dense(Z, W, row_bits=zb))
         if z_out is not None:
             z_out.append(Z)
         return None, pooled
     if arith == "auto":
         arith = cin_auto_arith(x0.shape[1], x0.shape[2], xk.shape[1], W.shape[0])
-        if arith == "bf16x3" and CIN_FWD_SPLIT == "f16x2" and not grad_operand:
-            arith = "f16x2"
+        pairs = CIN_L1_PAIRS and xk.data_ptr() == x0.data_ptr() and xk.shape[1] == x0.shape[1] and 8 <= x0.shape[1] <= 40 and x0.shape[0] > 0
+        if arith == "bf16x3" and CIN_FWD_SPLIT == "f16x2_unscaled" and not grad_operand:
+            arith = "f16x2"                                      # A/B switch: round 4's routing (the general layers on the unscaled kernel)
+        elif arith == "bf16x3" and CIN_FWD_SPLIT == "f16x2" and not grad_operand:
+            # forward layers on SCALED fp16 x 2 (round 5): the first layer's pair form scales the rows of its x0 slice and the pair weights
+            # inside the kernel ("f16x2" below), every other layer runs the row-scaled kernel the gradients use ("f16x2_grad": rows of xk
+            # and the tensor W scaled by exact powers of two) -- no operand's magnitude is assumed any more
+            arith = "f16x2" if pairs else "f16x2_grad"
         elif arith == "bf16x3" and CIN_BWD_SPLIT == "f16x2" and grad_operand and xk.data_ptr() != x0.data_ptr():
             arith = "f16x2_grad"                                 # xk is a gradient: fp16 x 2 with its rows scaled inside the kernel
     _dev(x0, torch.float32, "x0")
@@ -1467,16 +1563,32 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
         lib = _lib.load()
         f_l1 = lib.dir_cin_layer1_f16x2_f32 if arith == "f16x2" else lib.dir_cin_layer1_bf16x3_f32
         f_ly = {"f16x2": lib.dir_cin_layer_f16x2_f32, "f16x2_grad": lib.dir_cin_layer_grad_f16x2_f32}.get(arith, lib.dir_cin_layer_bf16x3_f32)
+        # the rows' maxima of xout ride on the tensor for the next layer's row scales (one column block: H <= 128)
+        ob = torch.empty(B * D, dtype=torch.int32, device=x0.device) if (CIN_ROW_BITS_CARRY and want_xout and H <= 128 and B > 0
+                                                                         and arith in ("f16x2", "f16x2_grad")) else None
         if arith != "f16x2_grad" and CIN_L1_PAIRS and xk.data_ptr() == x0.data_ptr() and Hp == m and 8 <= m <= 40 and B > 0:
             # the first layer of a stack (xk IS x0): a quadratic form in x0 -- the kernel multiplies the m (m + 1) / 2 unordered pairs only
             # (dir_cin_layer1_bf16x3_f32)
             nbytes = int(lib.dir_cin_layer1_bf16x3_workspace_bytes(m, H))
             ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x0.device)
             wp = ctypes.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
+            if arith == "f16x2" and ob is not None:
+                _lib.check(lib.dir_cin_layer1_bits_f16x2_f32(_ptr(x0), _ptr(W), m, H, D, B, _ptr(xout), _ptr(pooled), pooled.stride(0), wp, nbytes,
+                                                             _ptr(ob), _stream()))
+                xout._dir_row_bits = (ob, xout._version)
+                return xout, pooled
             _lib.check(f_l1(_ptr(x0), _ptr(W), m, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled), pooled.stride(0), wp, nbytes, _stream()))
             return xout, pooled
         nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, Hp, H))
         ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=x0.device)
+        if arith == "f16x2_grad" and not grad_operand and g_bits_out is None:
+            # a FORWARD layer on the row-scaled kernel: the producer's row maxima in, this layer's out
+            ib = _row_bits_hint(xk, B * D) if CIN_ROW_BITS_CARRY else None
+            _lib.check(lib.dir_cin_layer_rows_f16x2_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled),
+                                                        pooled.stride(0), _ptr(ws), nbytes, _ptr(ib), _ptr(ob), _stream()))
+            if ob is not None:
+                xout._dir_row_bits = (ob, xout._version)
+            return xout, pooled
         if arith == "f16x2_grad":          # (g_bits_out, a list: the bit pattern of max |xk| -- a by-product of the row maxima -- is appended)
             gbits = torch.empty(1, dtype=torch.int32, device=x0.device) if (g_bits_out is not None and B > 0) else None
             _lib.check(f_ly(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled), pooled.stride(0), _ptr(ws),

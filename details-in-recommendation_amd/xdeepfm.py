@@ -121,7 +121,7 @@ class XDeepFM(nn.Module):
         if self.dnn_out.out_features == 1:
             # inference: the DNN tower and its logit layer in one launch, the CIN's (and the linear term's) logits added in its epilogue
             adds = (logits,) if linear_logit is None else (logits, linear_logit)
-            fused = tower_infer(self.hidden, net, self.activation, head=self.dnn_out, adds=adds, embedding_input=True)   # net = the embedding concat
+            fused = tower_infer(self.hidden, net, self.activation, head=self.dnn_out, adds=adds, embedding_input=self._tablesets()[0].range_ok())   # net = the embedding concat
             if fused is not None:
                 return fused
         if mlp_head_supported(self.hidden, self.dnn_out, net, self.activation):

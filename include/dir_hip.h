@@ -257,6 +257,9 @@ int dir_cin_layer_bf16x3_f32(const float* x0, const float* xk, const float* W, i
  * NULL: none -- the pooled gradient of the layer below), dx0[b,j,d] (+)= sum_i dZ[b,i,j] xk[b,i,d] (accumulate_dx0).
  * m <= 64, D in {4, 8, 16, 32}; x0 / xk / dxk / dx0 16-byte aligned. */
 int dir_cin_pool_z_f32(const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, dir_stream_t stream);
+/* ... and z_row_bits [B]: the bit pattern of max |Z[b, :]| (one workgroup owns a sample's row: plain stores) -- the row scales
+ * dir_dense_f16x2_rows_f32 multiplies Z by, without a max pass over the [B, Hp*m] matrix. */
+int dir_cin_pool_z_bits_f32(const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, unsigned int* z_row_bits, dir_stream_t stream);
 int dir_cin_pool_dx_f32(const float* x0, const float* xk, const float* dZ, int m, int Hp, int D, int64_t B, const float* add_pooled,
                         int64_t add_pooled_ld, float* dxk, float* dx0, int accumulate_dx0, dir_stream_t stream);
 
@@ -271,15 +274,23 @@ int dir_cin_layer1_bf16x3_f32(const float* x0, const float* W, int m, int H, int
 
 /* The same two forward layers on "fp16 x 2" arithmetic (csrc/cin_bf3.hip, round 4): every fp32 operand as two fp16 pieces by
  * round-to-nearest, the three piece products of weight >= 2^-11 on v_mfma_f32_16x16x32_f16 with fp32 accumulation -- half the matrix
- * instructions of bf16 x 3.  Preconditions: |x0|, |xk|, |W| < 65 504 (fp16's range; larger values become inf); operand elements below
- * 2^-3 in magnitude carry an ABSOLUTE representation error of up to 2^-25 each (relative 2^-22 above).  On embedding-scale operands the
- * result is within 3-6e-7 (scaled) of the double-accumulating oracle.  Same arguments, shapes and workspaces
- * (dir_cin_bf16x3_workspace_bytes / dir_cin_layer1_bf16x3_workspace_bytes) as the bf16 x 3 entries.  These two entries are for operands
- * of O(1); a left operand of unknown magnitude (a gradient) goes through the row-scaled entries below. */
+ * instructions of bf16 x 3.  Same arguments, shapes and workspaces (dir_cin_bf16x3_workspace_bytes /
+ * dir_cin_layer1_bf16x3_workspace_bytes) as the bf16 x 3 entries.
+ * dir_cin_layer_f16x2_f32 is the UNSCALED form: preconditions |x0|, |xk|, |W| < 65 504 (fp16's range; larger values become inf), and
+ * operand elements below 2^-3 in magnitude carry an ABSOLUTE representation error of up to 2^-25 each (relative 2^-22 above); on
+ * embedding-scale operands within 3-6e-7 (scaled) of the double-accumulating oracle.  Kept for A/B; nothing routes to it by default.
+ * dir_cin_layer1_f16x2_f32 (round 5) scales BOTH operands by exact powers of two inside the launch: every row r = (b, d) of the x0 slice so
+ * that its largest |element| lands in [2^6, 2^7) (pair products below 2^14), the symmetrised pair weights as a tensor into [2^14, 2^15);
+ * 2^-(2k + kw) is taken out where the products meet the accumulators.  No precondition on magnitudes: scaling x0 by 2^a and W by 2^b
+ * scales the result by exactly 2^(2a + b), bit for bit (tests/test_gpu_range.py).
+ * dir_cin_layer1_bits_f16x2_f32: the same, and xout_row_bits [B * D] (row r = b * D + d) receives the bit pattern of max_h |xout[b, h, d]| --
+ * the next layer's row scales (needs xout and H <= 128: one column block). */
 int dir_cin_layer_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                             float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 int dir_cin_layer1_f16x2_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled, int64_t pooled_ld,
                              void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+int dir_cin_layer1_bits_f16x2_f32(const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled, int64_t pooled_ld,
+                                  void* workspace, int64_t workspace_bytes, unsigned int* xout_row_bits, dir_stream_t stream);
 /* The same kernel with a second result per field, for the layer's data gradients (y's tile in registers; 64-column blocks):
  *   xout[b,h,d] as above, and  dot[b,j,d] = sum_h y[b,h,d] * T_j[(b,d),h],  T_j[r,h] = sum_i xk[r,i] * W[h, i*m+j]
  * written as dir_cin_bf16x3_dot_partials(m, Hp, H) partial sums [P][B, m, D] (one per 64-column block and half of i; the caller adds
@@ -302,7 +313,13 @@ int dir_sum_partials_f32(const float* parts, int P, int64_t n, int accumulate, f
  * by a power of two chosen from that row's largest |element| over its Hp channels (it lands in [2^14, 2^15): the scaling is exact), split
  * into two fp16 pieces, and the inverse power of two is applied where the row's T tile meets the field factor (and y, in the dot form) --
  * again exact.  Elements within 2^-17 of their row's largest carry 22 bits; smaller ones an absolute error of 2^-39 of the row's largest,
- * which is what the sum over the row's channels needs.  x0, W, y: preconditions of dir_cin_layer_f16x2_f32 (|.| < 65 504, O(1) values).
+ * which is what the sum over the row's channels needs.  Since round 5 W is scaled as well -- ONE power of two for the tensor (its largest
+ * |element| into [2^14, 2^15), found by a 32-workgroup max kernel in front of the pack; the inverse leaves with the rows' scales) -- so
+ * neither xk nor W has a magnitude precondition; x0 and y meet the products in fp32 and never had one.
+ * dir_cin_layer_rows_f16x2_f32: the FORWARD layer in this form (what ops.cin_layer's "auto" runs for every layer but the first): arguments
+ * of dir_cin_layer_f16x2_f32 plus xk_row_bits (optional, [B * D]: the bit pattern of max_i |xk[b, i, d]| left by the layer that produced xk
+ * -- the prologue then reads one word per row instead of scanning it) and xout_row_bits (optional, [B * D]: the same of this layer's output;
+ * needs xout and H <= 128).
  * dir_cin_layer_grad_f16x2_f32: arguments of dir_cin_layer_f16x2_f32 (the forward-form contractions of the backward) plus
  * xk_absmax_bits_out (as below; NULL: not wanted);
  * dir_cin_layer_dot_add_f16x2_f32: arguments, partial-sum layout (dir_cin_bf16x3_dot_partials) and workspace of
@@ -311,6 +328,9 @@ int dir_sum_partials_f32(const float* parts, int P, int64_t n, int accumulate, f
 int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                                  float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, unsigned int* xk_absmax_bits_out,
                                  dir_stream_t stream);
+int dir_cin_layer_rows_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
+                                 float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, const unsigned int* xk_row_bits,
+                                 unsigned int* xout_row_bits, dir_stream_t stream);
 int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D, int64_t B,
                                     const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
                                     int64_t workspace_bytes, unsigned int* xk_absmax_bits_out, dir_stream_t stream);
@@ -564,6 +584,12 @@ int dir_dense_dw_bf16x3_f32(const float* g, int64_t g_ld, const float* x, int64_
  * workspace and determinism of dir_dense_dw_bf16x3_f32. */
 int dir_dense_dw_f16x2_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
                            float* db, void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits, dir_stream_t stream);
+/* ... with x scaled by ONE power of two as well (x_absmax_bits, DEVICE: the bit pattern of an upper bound of max |x| -- the all_bits that
+ * dir_row_absmax_bits_f32 or the row-scaled forward kernel's epilogue left for this layer's input): neither operand's magnitude is assumed
+ * (round 5: what the training towers run; the entry above remains for callers that hold no bound for x). */
+int dir_dense_dw_f16x2_scaled_f32(const float* g, int64_t g_ld, const float* x, int64_t x_ld, int64_t M, int N, int K, float* dW, int64_t dw_ld,
+                                  float* db, void* workspace, int64_t workspace_bytes, const unsigned int* g_absmax_bits,
+                                  const unsigned int* x_absmax_bits, dir_stream_t stream);
 /* The same product for small gradients (N <= 128, K <= 256, at most 256 tiles of 8 x 8; multiples of 4): fp32 FMAs on register tiles over row spans (exact fp32 products),
  * for the tall-and-skinny TN products the library runs at 200 us -- the per-sample term of the DIN unit's first layer (S^T a, 80 x 64)
  * and the narrow last layers of the towers.  Same arguments, workspace query and determinism as dir_dense_dw_bf16x3_f32. */

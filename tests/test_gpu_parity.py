@@ -246,10 +246,27 @@ def test_cin_layer(ops, oracle, B, m, D, Hp, H):
     _close(fp_.cpu().numpy(), ref_p)
     fx2, _ = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="f16x2")
     assert torch.equal(fx, fx2)                                      # rerun: bitwise equal
-    ax, ap = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))            # "auto" is one of them, bitwise
-    split = (fx, fp_) if ops.CIN_FWD_SPLIT == "f16x2" else (bx, bp)
+    ax, ap = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))            # "auto" is one of them, bitwise: since round 5 the ROW-SCALED fp16 x 2 form
+    rx, rp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W), arith="f16x2_grad")      # (rows of xk and the tensor W scaled by exact powers of two)
+    split = (rx, rp) if ops.CIN_FWD_SPLIT == "f16x2" else ((fx, fp_) if ops.CIN_FWD_SPLIT == "f16x2_unscaled" else (bx, bp))
     want = split if ops.cin_auto_arith(m, D, Hp, H) == "bf16x3" else (got_x, got_p)
     assert torch.equal(ax, want[0]) and torch.equal(ap, want[1])
+    if H <= 128 and ops.CIN_FWD_SPLIT == "f16x2" and ops.cin_auto_arith(m, D, Hp, H) == "bf16x3":
+        # DIR_CIN_ROW_BITS_CARRY: the layer leaves its output's row maxima on the tensor (the next layer's row scales): exact, and consumed
+        # bit for bit like a scan of the rows
+        keep = ops.CIN_ROW_BITS_CARRY
+        ops.CIN_ROW_BITS_CARRY = True
+        try:
+            cx, cp = ops.cin_layer(_dev(x0), _dev(xk), _dev(W))
+            bits = ops._row_bits_hint(cx, B * D)
+            assert torch.equal(cx, ax) and torch.equal(cp, ap)
+            assert bits is not None and torch.equal(bits.view(B, D), cx.abs().amax(dim=1).view(torch.int32))
+            if Hp == H:
+                nx, np_ = ops.cin_layer(_dev(x0), cx, _dev(W))              # the next layer reads them instead of scanning cx
+                sx2, sp2 = ops.cin_layer(_dev(x0), cx.clone(), _dev(W))
+                assert torch.equal(nx, sx2) and torch.equal(np_, sp2)
+        finally:
+            ops.CIN_ROW_BITS_CARRY = keep
     # a gradient as the left operand never takes the PLAIN fp16 split: it runs the row-scaled form (dir_cin_layer_grad_f16x2_f32: every row
     # of xk times a power of two inside the kernel) or bf16 x 3.  Same bar; rows that differ by powers of two over 40 binades give the same
     # bits times those powers; tiny (1e-30-scale) and large (1e+6-scale) operands are as exact as O(1) ones
