@@ -120,6 +120,10 @@ SIGNATURES = {
     "dir_din_activation_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "dir_din_attention_pool_act_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                                c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dir_din_attention_pool_arith_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                                 c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "dir_din_attention_pool_save_arith_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32,
+                                                      c_i32, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_cin_layer_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "dir_cin_bf16x3_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "dir_cin_layer_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),

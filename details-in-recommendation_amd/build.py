@@ -41,6 +41,11 @@ EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",
          "-Wall", "-Wno-unused-function"]
+# DIR_DEVELOPMENT=1 python build.py --force: a build whose library honours the development A/B switches read from the environment
+# (DIR_RS_DBG timing masks -- results are WRONG under them --, DIR_SORT, DIR_ADA_STAGE_MIN, DIR_BUCKET_EPT / _NT; csrc/common.hpp: dev_env).
+# The production build ignores them and refuses to sort when DIR_RS_DBG is set.
+if os.environ.get("DIR_DEVELOPMENT") == "1":
+    FLAGS.append("-DDIR_DEVELOPMENT")
 
 
 def _deps_mtime():

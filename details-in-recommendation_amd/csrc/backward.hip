@@ -809,7 +809,7 @@ static hipError_t rocprim_sort_pairs(void* tmp, size_t& tmp_bytes, const uint32_
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, k0, k1, v0, v1, n, 0u, bits, st);
 }
 static bool use_rocprim_sort() {
-    static const bool v = getenv("DIR_SORT") && !strcmp(getenv("DIR_SORT"), "rocprim");
+    static const bool v = dev_env("DIR_SORT") && !strcmp(dev_env("DIR_SORT"), "rocprim");
     return v;
 }
 #else
@@ -992,7 +992,7 @@ static int sparse_sorted_update(const char* name, U upd, int F, int K, const int
     while (lps < (vec ? K / 4 : K)) lps <<= 1;
     if (lps > 64) return fail(DIR_E_UNSUPPORTED, "%s: K=%d too wide", name, K);
     const int64_t ntiles = (int64_t)p.ntiles;
-    static const int stage_min = getenv("DIR_ADA_STAGE_MIN") ? atoi(getenv("DIR_ADA_STAGE_MIN")) : 8;       // development A/B switch
+    static const int stage_min = dev_env_int("DIR_ADA_STAGE_MIN", 8);       // development A/B switch
     dim3 gfix((unsigned)((ntiles * lps + 255) / 256));
 #define DIR_CASE(L, V)                                                                                                         \
     do {                                                                                                                       \

@@ -1,12 +1,25 @@
 // common.hpp -- shared host/device helpers for libdir_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdlib>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
 #include <atomic>
 
 #include "../../include/dir_hip.h"
+
+// Cross-workgroup handshakes in this library ("the last workgroup to arrive finalizes": bucket_cap2_k, row_absmax_k, the status words of
+// rs_pass_k's decoupled look-back) use RELAXED agent-scope atomics without release / acquire fences.  Under the HIP / LLVM memory model that
+// is a data race; on gfx950 it is ordered by the hardware: every value a workgroup publishes before its arrival atomic is itself
+// written by a device-scope atomic (or a store that has completed: s_waitcnt vmcnt(0) precedes the arrival), atomics execute at the L2 --
+// the single point of coherence of an agent's memory on one XCD partition mode -- and a returning atomic has completed before the wave issues the next one.  A release fence
+// (__threadfence(): buffer_wbl2) costs 56 us per 800 workgroups here (profiles/NOTES.md R4.2).  The guarantee is this target's, so nothing
+// else may be compiled from these sources:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "details-in-recommendation_amd/csrc relies on gfx950's ordering of device-scope atomics (see the comment above); build with --offload-arch=gfx950 only"
+#endif
 
 namespace dir {
 
@@ -90,6 +103,27 @@ bool radix_slot_sort_ok(int64_t B, int F, unsigned gbits);
 size_t radix_slot_sort_temp_bytes(int64_t B, int F, unsigned gbits);
 hipError_t radix_slot_sort_entries(void* tmp, const int64_t* ids, int64_t sb, int64_t sf, int F, int64_t B, const int64_t* row_base,
                                    uint32_t total_rows, unsigned gbits, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, hipStream_t st);
+// Development A/B switches read from the environment (DIR_RS_DBG, DIR_SORT, DIR_ADA_STAGE_MIN, DIR_BUCKET_EPT, DIR_BUCKET_NT ...) exist only in a
+// build with -DDIR_DEVELOPMENT (DIR_DEVELOPMENT=1 python build.py): some of them produce WRONG results by design (timing masks), so the
+// production library does not look at them at all; dev_env_set() lets an entry point fail loudly when one is set anyway.
+inline const char* dev_env(const char* name) {
+#ifdef DIR_DEVELOPMENT
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+inline int dev_env_int(const char* name, int dflt) { const char* e = dev_env(name); return e ? atoi(e) : dflt; }
+inline bool dev_env_ignored(const char* name) {        // the variable is set, and this build ignores it
+#ifdef DIR_DEVELOPMENT
+    (void)name;
+    return false;
+#else
+    const char* e = getenv(name);
+    return e && *e && strcmp(e, "0") != 0;
+#endif
+}
 hipError_t zero_async(void* p, size_t bytes, hipStream_t st);                                                // p, bytes: multiples of 4
 hipError_t zero_2d_async(void* p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t st);      // as hipMemset2DAsync(.., 0, ..)
 

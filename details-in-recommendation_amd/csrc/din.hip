@@ -1240,6 +1240,41 @@ extern "C" int dir_din_attention_pool_save_f32(const float* table, int K, const 
     return DIR_OK;
 }
 
+// ---- the same entries with the arithmetic of the two MFMA layers given by ARGUMENT (round 5): DIR_DIN_ARITH_F32 (fp32 MFMA: any
+// magnitudes), DIR_DIN_ARITH_BF16X3 (three bf16 pieces: fp32's exponent range), DIR_DIN_ARITH_F16X2 (two fp16 pieces, UNSCALED: table rows,
+// their products with the candidate row and the weights inside fp16's range and not far below 1), DIR_DIN_ARITH_DEFAULT (-1: the
+// DIR_DIN_ARITH environment switch, fp16 x 2 by default).  The Python surface picks bf16 x 3 when the table or a weight leaves the fp16 x 2
+// window (ops.din_attention_pool: measured per version, not assumed).
+namespace dir { extern thread_local int dw_arith_override; }
+namespace {
+struct DwArithScope {
+    int prev;
+    explicit DwArithScope(int a) : prev(dir::dw_arith_override) { dir::dw_arith_override = a; }
+    ~DwArithScope() { dir::dw_arith_override = prev; }
+};
+}  // namespace
+
+extern "C" int dir_din_attention_pool_arith_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
+                                                int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
+                                                const float* W3, const float* b3, int normalize, int activation, const float* act_params,
+                                                int arith, int64_t B, float* out, float* scores, dir_stream_t stream) {
+    DIR_CHECK_ARG(arith >= -1 && arith <= 2, "dir_din_attention_pool_arith_f32: arith %d (-1 default, 0 f32, 1 bf16x3, 2 f16x2)", arith);
+    DwArithScope scope(arith);
+    return dir_din_attention_pool_act_f32(table, K, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, activation, act_params, B,
+                                          out, scores, stream);
+}
+
+extern "C" int dir_din_attention_pool_save_arith_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
+                                                     int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
+                                                     const float* W3, const float* b3, int normalize, int arith, int64_t B, float* out,
+                                                     float* scores, const int64_t* tile_off, int64_t n_tiles, void* workspace,
+                                                     int64_t workspace_bytes, dir_stream_t stream) {
+    DIR_CHECK_ARG(arith >= -1 && arith <= 2, "dir_din_attention_pool_save_arith_f32: arith %d (-1 default, 0 f32, 1 bf16x3, 2 f16x2)", arith);
+    DwArithScope scope(arith);
+    return dir_din_attention_pool_save_f32(table, K, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores, tile_off,
+                                           n_tiles, workspace, workspace_bytes, stream);
+}
+
 extern "C" int64_t dir_din_backward_workspace_bytes(int K, int H1, int H2) {
     if (K != 64 || H1 <= 0 || H2 <= 0 || H1 > 80 || H2 > 48) return 0;
     return (int64_t)(kDinBwdMaxWg + 1) * kDinBwdRec * (int64_t)sizeof(float);   // one record per workgroup + their sum

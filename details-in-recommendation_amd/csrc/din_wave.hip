@@ -798,6 +798,9 @@ __global__ __launch_bounds__(64 * DW_WAVES, 2) void din_wave_k(const float* __re
 }
 
 static std::atomic<unsigned int> dw_next_slot{0};
+// The arithmetic of the call in progress on this thread when an `_arith` entry asked for one by argument (-1: DIR_DIN_ARITH / the default).
+// Set and restored inside that one call (din.hip: DwArithScope): no state survives it.
+thread_local int dw_arith_override = -1;
 
 bool din_wave_covers(int K, int T, int H1, int H2) { return K == DW_K && T <= 64 && H1 <= DW_H1P && H2 <= DW_H2P; }
 
@@ -810,7 +813,8 @@ int launch_din_wave(hipStream_t st, const float* table, const int64_t* hist, con
     // atomics cost more than the imbalance they remove, 0.45 vs 0.50 ms at config 4 -- and the queue for fp32).  Both are read per call
     // (A/B runs and tests flip them inside one process).  saved != nullptr: the training forward (z1, z2 records for the backward).
     const char* arith = getenv("DIR_DIN_ARITH");
-    const int ar = (arith && strcmp(arith, "f32") == 0) ? 0 : (arith && strcmp(arith, "bf16x3") == 0) ? 1 : 2;      // default: fp16 x 2
+    const int ar = dw_arith_override >= 0 ? dw_arith_override
+                                          : (arith && strcmp(arith, "f32") == 0) ? 0 : (arith && strcmp(arith, "bf16x3") == 0) ? 1 : 2;      // default: fp16 x 2
     const bool bf3 = ar != 0;
     const bool save = saved != nullptr;
     typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,

@@ -697,7 +697,7 @@ __global__ __launch_bounds__(NT) void bucket_cap2_k(const int64_t* __restrict__ 
     __syncthreads();
     if (s_last && threadIdx.x < 64) {
         bucket_cap_finalize(gcount, P, cap, payload, counts, overflow, stat);
-        if (threadIdx.x == 0) gcount[64] = 0;
+        if (threadIdx.x == 0) __hip_atomic_store(&gcount[64], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (an atomic like every other access to the word)
     }
 }
 
@@ -1038,13 +1038,15 @@ extern "C" int dir_shard_bucket_cap(const int64_t* ids, int64_t n, const int64_t
     int32_t* gcount = static_cast<int32_t*>(workspace);
     static const int legacy = getenv("DIR_BUCKET_LEGACY") ? atoi(getenv("DIR_BUCKET_LEGACY")) : 0;      // development A/B switch
     if (n > 0 && !legacy) {
-        static const int ept_env = getenv("DIR_BUCKET_EPT") ? atoi(getenv("DIR_BUCKET_EPT")) : 0;
-        static const int nt_env = getenv("DIR_BUCKET_NT") ? atoi(getenv("DIR_BUCKET_NT")) : 0;
+        static const int ept_env = dev_env_int("DIR_BUCKET_EPT", 0);
+        static const int nt_env = dev_env_int("DIR_BUCKET_NT", 0);
         const int nt = nt_env ? nt_env : (n <= 256 * 1024 ? 256 : 1024);
         const int ept = ept_env ? ept_env : 4;            // (1024 x 4: 16.1 us, x 8: 18.5, x 16: 30.3 at 1.7 M ids)
 #define DIR_BK2(EPT, NT)                                                                                                              \
     hipLaunchKernelGGL((bucket_cap2_k<EPT, NT>), dim3((unsigned)((n + NT * EPT - 1) / (NT * EPT))), dim3(NT), 0, st, ids, n, vocab, parts, first, F, \
                        P, cap, gcount, payload, inv, counts, overflow, stat)
+        if (nt != 256 && nt != 512 && nt != 1024) return fail(DIR_E_BADARG, "dir_shard_bucket_cap: DIR_BUCKET_NT must be 256, 512 or 1024");
+        if (nt == 512 && ept != 8) return fail(DIR_E_BADARG, "dir_shard_bucket_cap: DIR_BUCKET_NT=512 is instantiated for DIR_BUCKET_EPT=8 only");
         if (nt == 256 && ept <= 4) DIR_BK2(4, 256);
         else if (nt == 256) DIR_BK2(8, 256);
         else if (nt == 512) DIR_BK2(8, 512);

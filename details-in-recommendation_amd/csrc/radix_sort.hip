@@ -39,7 +39,7 @@ constexpr uint32_t RS_AGG = 1u << 30, RS_INCL = 2u << 30, RS_VAL = (1u << 30) - 
 // addresses are garbage, so 4 switches the scatter off as well (a DIR_RS_DBG=4 run once wrote out of bounds; without the look-back a
 // digit's keys still land inside that digit's range).
 inline int rs_dbg_mask() {
-    int d = getenv("DIR_RS_DBG") ? atoi(getenv("DIR_RS_DBG")) : 0;
+    int d = dev_env_int("DIR_RS_DBG", 0);          // (-DDIR_DEVELOPMENT builds only; radix_sort_dbg_refused() fails the entries otherwise)
     if (d & 4) d |= 1;
     return d;
 }
@@ -414,6 +414,10 @@ int radix_sort_input_buffer(size_t n, unsigned bits) { return (rs_layout(n, bits
 // 1: k1 / v1); the sorted pairs end up in k1 / v1; the other buffer is scratch.  tmp: radix_sort_temp_bytes(n, bits) bytes, 256-byte
 // aligned, any content.  n < 2^30.  Kernel launches only (no memset / memcpy nodes): safe inside a HIP-graph capture.
 hipError_t radix_sort_pairs_u32(void* tmp, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, size_t n, unsigned bits, hipStream_t st) {
+    if (dev_env_ignored("DIR_RS_DBG")) {           // a timing mask that corrupts the sort: never silently ignored, never honoured in a production build
+        fprintf(stderr, "dir_hip: DIR_RS_DBG is set but this library was not built with -DDIR_DEVELOPMENT: refusing to sort\n");
+        return hipErrorInvalidValue;
+    }
     if (n == 0) return hipSuccess;
     if (n >= ((size_t)1 << 30)) return hipErrorInvalidValue;
     const RsLayout L = rs_layout(n, bits);
@@ -450,7 +454,7 @@ hipError_t radix_sort_pairs_u32(void* tmp, uint32_t* k0, uint32_t* k1, uint32_t*
 
 // The slot-major sort (see rss_keys_k): eligible when the entries are ids [B, F] with B large enough to fill tiles.
 bool radix_slot_sort_ok(int64_t B, int F, unsigned gbits) {
-    static const bool off = getenv("DIR_SORT") && !strcmp(getenv("DIR_SORT"), "global");      // development A/B switch
+    static const bool off = dev_env("DIR_SORT") && !strcmp(dev_env("DIR_SORT"), "global");      // development A/B switch
     return !off && B >= RSS_MIN_B && F >= 1 && F <= 65535 && gbits >= 1 && gbits <= 32 && B * F < ((int64_t)1 << 30);
 }
 
@@ -460,6 +464,10 @@ size_t radix_slot_sort_temp_bytes(int64_t B, int F, unsigned gbits) { return rss
 // gbits = bit_length(total_rows).  tmp: radix_slot_sort_temp_bytes bytes, 256-byte aligned, any content.  Kernel launches only.
 hipError_t radix_slot_sort_entries(void* tmp, const int64_t* ids, int64_t sb, int64_t sf, int F, int64_t B, const int64_t* row_base,
                                    uint32_t total_rows, unsigned gbits, uint32_t* k0, uint32_t* k1, uint32_t* v0, uint32_t* v1, hipStream_t st) {
+    if (dev_env_ignored("DIR_RS_DBG")) {
+        fprintf(stderr, "dir_hip: DIR_RS_DBG is set but this library was not built with -DDIR_DEVELOPMENT: refusing to sort\n");
+        return hipErrorInvalidValue;
+    }
     if (!radix_slot_sort_ok(B, F, gbits)) return hipErrorInvalidValue;
     const RssLayout L = rss_layout(B, F, gbits);
     char* base = static_cast<char*>(tmp);

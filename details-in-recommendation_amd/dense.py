@@ -67,9 +67,12 @@ def _packed_cached(weight):
     """Inference: one padded copy per weight tensor, refreshed when the parameter is modified in place (tensor._version)."""
     key = id(weight)
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()      # under capture: pack inside the graph, remember nothing (ops.CapturedStep)
+    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and not capturing:
         return hit[3]
     packed = pack_weight(weight)
+    if capturing:
+        return packed
     if len(_PACK_CACHE) > 256:
         _PACK_CACHE.clear()
     _PACK_CACHE[key] = (weight, weight._version, weight.data_ptr(), packed)
@@ -98,9 +101,12 @@ def _packed_cached_padded(weight, pad):
     """Inference: the weight with `pad` zero input columns appended, packed; cached like _packed_cached."""
     key = (id(weight), pad)
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
+    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and not capturing:
         return hit[3]
     packed = pack_weight(F.pad(weight.detach(), (0, pad)))
+    if capturing:
+        return packed
     if len(_PACK_CACHE) > 256:
         _PACK_CACHE.clear()
     _PACK_CACHE[key] = (weight, weight._version, weight.data_ptr(), packed)
@@ -422,12 +428,15 @@ def _bn_affine(bn):
     ver = (bn.moving_mean._version, bn.moving_variance._version, bn.beta._version, bn.gamma._version if bn.gamma is not None else -1,
            bn.beta.data_ptr())
     hit = _BN_CACHE.get(key)
-    if hit is not None and hit[0] is bn and hit[1] == ver:
+    capturing = bn.moving_mean.is_cuda and torch.cuda.is_current_stream_capturing()
+    if hit is not None and hit[0] is bn and hit[1] == ver and not capturing:
         return hit[2], hit[3]
     inv = torch.rsqrt(bn.moving_variance + bn.eps)
     if bn.gamma is not None:
         inv = inv * bn.gamma.data
     shift = bn.beta.data - bn.moving_mean * inv
+    if capturing:
+        return inv.contiguous(), shift.contiguous()
     if len(_BN_CACHE) > 256:
         _BN_CACHE.clear()
     _BN_CACHE[key] = (bn, ver, inv.contiguous(), shift.contiguous())

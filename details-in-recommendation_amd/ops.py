@@ -128,6 +128,8 @@ class TableSet:
         tot = sum(sig)
         if hit is None or (hit[0] != sig and (every <= 1 or tot - hit[2] >= every * len(sig) or tot < hit[2])):
             if torch.cuda.is_current_stream_capturing():
+                if hit is not None:
+                    return hit[1]                  # (a sync cannot be captured: the last measurement stands)
                 raise RuntimeError("TableSet.absmax: measure the tables (one eager call) before capturing a graph")
             m = float(torch.stack([t.abs().max() for t in self.tables if t.numel()] or [torch.zeros((), device=self.device)]).max())
             hit = self._absmax = (sig, m, tot)
@@ -172,6 +174,51 @@ def mark_written(*tensors):
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
     if ts:
         torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+
+class CapturedStep:
+    """A training (or inference) step captured in a HIP graph, replayed with the bookkeeping eager steps do on the host.
+
+        step = ops.CapturedStep(fn, written=ops.written_of(model))      # warm-up calls, then ONE capture of fn()
+        step.replay()                                                    # graph.replay() + mark_written(*written)
+
+    A replay runs the captured optimiser / batch-norm kernels, which write parameters, tables and moving statistics through raw pointers:
+    nothing on the host moves their version counters, so everything cached per version (serving rows, weight images, folded batch norms)
+    would stay stale for an eager eval after the replays.  replay() bumps the counters of `written` after every replay, exactly as the
+    eager updaters do (mark_written).  Inside the capture every per-version cache is bypassed (dense_bf3_image, tower_image, the modules'
+    packed weights): the pack kernels are part of the graph and read the weights as they are at replay time.  What a captured step must
+    not do: anything that syncs (a first-time range measurement: run one eager step before capturing -- the constructor does)."""
+
+    def __init__(self, fn, written=(), warmup=3, pool=None):
+        self.fn, self.written = fn, [t for t in written if isinstance(t, torch.Tensor)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # the standard recipe: warm up on a side stream (workspaces, caches, pointer tables exist)
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        mark_written(*self.written)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=pool):
+            self.out = fn()
+        mark_written(*self.written)                        # (the capture itself does not run the kernels; counters move like a step's anyway)
+
+    def replay(self):
+        self.graph.replay()
+        mark_written(*self.written)
+        return self.out
+
+
+def written_of(*modules_or_tensors):
+    """Every parameter and buffer of the given modules (and the given tensors): what a captured training step may write."""
+    out = []
+    for m in modules_or_tensors:
+        if isinstance(m, torch.Tensor):
+            out.append(m)
+        else:
+            out += list(m.parameters()) + list(m.buffers())
+    return out
+
 
 def refuse_rebuild_under_sink(*tablesets):
     """The modules rebuild their TableSets when the parameters' storage moved (.to() / .cuda() / a re-pointed .data).  A fused optimiser
@@ -450,10 +497,31 @@ def din_activation_rows_(x, activation, alpha, scale=None, shift=None):
     return x
 
 
+DIN_ARITHS = {"f32": 0, "bf16x3": 1, "f16x2": 2}
+DIN_RANGE_RECHECK = 32          # training: the table / weights are re-measured every this many in-place updates (weight_absmax(every=...))
+
+
+def din_arith(table, weights, arith=None):
+    """The arithmetic code of the DIN unit's MFMA layers for this call (include/dir_hip.h: DIR_DIN_ARITH_*).  arith: "f32" | "bf16x3" |
+    "f16x2" by name; None = "auto": the DIR_DIN_ARITH environment switch when set (A/B runs), otherwise fp16 x 2 (UNSCALED: the kernel splits
+    table rows and their products as they are) while the table and every weight matrix measure inside f16_range_ok's window, bf16 x 3 (fp32's
+    exponent range) outside it -- a table scaled by 2^20 gives the bf16 x 3 answer, not inf; one scaled by 2^-10 keeps a relative 1e-5."""
+    if arith is not None:
+        return DIN_ARITHS[arith]
+    if os.environ.get("DIR_DIN_ARITH"):
+        return -1
+    if not f16_range_ok(weight_absmax(table, DIN_RANGE_RECHECK)):
+        return DIN_ARITHS["bf16x3"]
+    for w in weights:
+        if not f16_range_ok(weight_absmax(w, DIN_RANGE_RECHECK)):
+            return DIN_ARITHS["bf16x3"]
+    return DIN_ARITHS["f16x2"]
+
+
 def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, want_scores=False, activation="sigmoid",
-                       act_params=None):
+                       act_params=None, arith=None):
     """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T]).  activation "prelu" / "dice": the
-    paper's own hidden activations (dir_din_attention_pool_act_f32; act_params from din_act_params)."""
+    paper's own hidden activations (dir_din_attention_pool_act_f32; act_params from din_act_params).  arith: see din_arith."""
     _dev(table, torch.float32, "table")
     _dev(hist, torch.int64, "hist")
     _dev(cand, torch.int64, "cand")
@@ -476,21 +544,18 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
         raise ValueError("DIN: cand and hist_len must have one entry per sample")
     out = torch.empty((B, K), dtype=torch.float32, device=table.device)
     scores = torch.empty((B, T), dtype=torch.float32, device=table.device) if want_scores else None
+    ap = None
     if activation != "sigmoid":
         if activation not in DIN_ACTIVATIONS:
             raise ValueError("DIN activation must be one of %s" % sorted(DIN_ACTIVATIONS))
         if act_params is None or act_params.numel() != 3 * H1 + 3 * H2:
             raise ValueError("DIN %s unit: act_params must hold 3 H1 + 3 H2 floats (ops.din_act_params)" % activation)
         ap = _dev(act_params.contiguous(), torch.float32, "act_params")
-        _lib.check(_lib.load().dir_din_attention_pool_act_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
-                                                              _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
-                                                              H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)),
-                                                              DIN_ACTIVATIONS[activation], _ptr(ap), B, _ptr(out), _ptr(scores), _stream()))
-        return (out, scores) if want_scores else out
-    _lib.check(_lib.load().dir_din_attention_pool_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
-                                                      _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
-                                                      H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B,
-                                                      _ptr(out), _ptr(scores), _stream()))
+    code = din_arith(table, (W1, W2, W3), arith) if B > 0 else -1
+    _lib.check(_lib.load().dir_din_attention_pool_arith_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
+                                                            _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
+                                                            H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)),
+                                                            DIN_ACTIVATIONS[activation], _ptr(ap), code, B, _ptr(out), _ptr(scores), _stream()))
     return (out, scores) if want_scores else out
 
 
@@ -556,9 +621,10 @@ def din_attention_pool_save(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3,
     ws = torch.empty(need, dtype=torch.uint8, device=table.device)       # owned by this call's autograd node until its backward ran
     out = torch.empty((B, K), dtype=torch.float32, device=table.device)
     scores = torch.empty((B, T), dtype=torch.float32, device=table.device)
-    _lib.check(lib.dir_din_attention_pool_save_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1,
-                                                   _ptr(args[2]), _ptr(args[3]), H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), B,
-                                                   _ptr(out), _ptr(scores), _ptr(plan.tile_off), plan.n_tiles, _ptr(ws), need, _stream()))
+    code = din_arith(table, (W1, W2, W3)) if B > 0 else -1
+    _lib.check(lib.dir_din_attention_pool_save_arith_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1,
+                                                         _ptr(args[2]), _ptr(args[3]), H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), code, B,
+                                                         _ptr(out), _ptr(scores), _ptr(plan.tile_off), plan.n_tiles, _ptr(ws), need, _stream()))
     return out, scores, (plan, ws)
 
 
@@ -681,8 +747,9 @@ def dense_bf3_image(weight, split="bf16x3"):
     import weakref
     key = weight.data_ptr() if split == "bf16x3" else (weight.data_ptr(), split)
     sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
     hit = _DENSE_IMAGES.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == sig:
+    if hit is not None and hit[0]() is weight and hit[1] == sig and not capturing:
         return hit[2]
     N, Kd = weight.shape
     lib = _lib.load()
@@ -690,6 +757,12 @@ def dense_bf3_image(weight, split="bf16x3"):
     img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     pack = lib.dir_dense_f16x2_pack_strided_f32 if split == "f16x2" else lib.dir_dense_bf16x3_pack_strided_f32
     _lib.check(pack(_ptr(weight), weight.stride(0), weight.stride(1), Kd, N, _ptr(img), nbytes, _stream()))
+    if capturing:
+        # Under graph capture the caches are bypassed in BOTH directions: a hit would leave the pack kernel out of the graph --
+        # every replay would then run against the image of the weights as they were at capture time, although the replayed optimiser
+        # kernels keep changing them -- and an image stored now would live in the graph's private pool.  The pack is captured, its
+        # image is graph-owned memory, and nothing is remembered.
+        return img
     if len(_DENSE_IMAGES) > 256:
         _DENSE_IMAGES.clear()
     _DENSE_IMAGES[key] = (weakref.ref(weight), sig, img)
@@ -876,11 +949,10 @@ def tower_image(weight, split=None):
     split = split or TOWER_SPLIT
     key = (weight.data_ptr(), split)
     sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
+    capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
     hit = _TOWER_IMAGES.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == sig:
+    if hit is not None and hit[0]() is weight and hit[1] == sig and not capturing:
         return hit[2]
-    if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("tower_image: build the weight images (one eager call) before capturing a graph")
     N, K = weight.shape
     lib = _lib.load()
     nbytes = int(lib.dir_tower_bf16x3_image_bytes(K, N))
@@ -888,6 +960,8 @@ def tower_image(weight, split=None):
     w = weight if weight.stride(1) == 1 else weight.contiguous()
     pack = lib.dir_tower_f16x2_pack_f32 if split == "f16x2" else lib.dir_tower_bf16x3_pack_f32
     _lib.check(pack(_ptr(w), w.stride(0), K, N, _ptr(img), nbytes, _stream()))
+    if capturing:
+        return img                                # (as dense_bf3_image: the pack is part of the graph, the image graph-owned, nothing cached)
     if len(_TOWER_IMAGES) > 256:
         _TOWER_IMAGES.clear()
     _TOWER_IMAGES[key] = (weakref.ref(weight), sig, img)
@@ -897,18 +971,25 @@ def tower_image(weight, split=None):
 _WEIGHT_ABSMAX = {}
 
 
-def weight_absmax(weight):
-    """max |w| of a weight tensor, measured once per version (one small reduction and one sync when the tensor changed: inference pays it
-    once; nothing is packed for it -- ADVICE r4: the tower's guard used to build the fp16 x 2 image just to read this number)."""
+def weight_absmax(weight, every=1):
+    """max |w| of a tensor, measured once per version (one reduction and one sync when the tensor changed: inference pays it once; nothing is
+    packed for it -- ADVICE r4: the tower's guard used to build the fp16 x 2 image just to read this number).  every > 1: a measurement may
+    be up to `every` in-place updates old (training loops: one pass and one sync per `every` steps, see TableSet.absmax)."""
     import weakref
     key = weight.data_ptr()
     sig = (weight._version, tuple(weight.shape))
     hit = _WEIGHT_ABSMAX.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == sig:
+    if hit is not None and hit[0]() is weight and (hit[1] == sig or (every > 1 and hit[1][1] == sig[1] and 0 <= sig[0] - hit[1][0] < every)):
         return hit[2]
-    if torch.cuda.is_current_stream_capturing():
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        if hit is not None and hit[0]() is weight:
+            return hit[2]                          # the magnitude as last measured (a sync cannot be captured): one eager call measures it
         raise RuntimeError("weight_absmax: run one eager call before capturing a graph (the fp16 range guard reads the weights' magnitudes once)")
-    m = float(weight.detach().abs().max()) if weight.numel() else 0.0
+    if weight.numel():
+        lo, hi = torch.aminmax(weight.detach())          # (one pass, no |w| temporary: the DIN item table is 2.56 GB)
+        m = float(torch.maximum(hi, -lo))
+    else:
+        m = 0.0
     if len(_WEIGHT_ABSMAX) > 512:
         _WEIGHT_ABSMAX.clear()
     _WEIGHT_ABSMAX[key] = (weakref.ref(weight), sig, m)

@@ -25,7 +25,8 @@ Partitioned variables.  Under a partitioner scope (models/DeepFM/deepFM.py:163-1
 the full name -> BundleEntryProto {dtype, FULL shape, slices = [TensorSliceProto ...]} (no data of its own) and, per slice, a key
 checkpoint::EncodeTensorNameSlice(name, slice) -> BundleEntryProto {dtype, slice shape, shard_id, offset, size, crc32c}
 (tensorflow/core/util/saved_tensor_slice_util.cc; the key is an OrderedCode string: NumIncreasing(0), String(name),
-NumIncreasing(rank), then SignedNumIncreasing(start), SignedNumIncreasing(length) per dimension, a full dimension as (0, -1);
+NumIncreasing(rank), then SignedNumIncreasing(start), SignedNumIncreasing(length) per dimension -- TensorFlow's encoder may write a full
+dimension as (0, -1), which read_bundle accepts; write_bundle writes the explicit (0, dim) extents since round 4;
 tensorflow/core/lib/strings/ordered_code.cc).  read_bundle assembles such a variable from its slices; write_bundle(partitions=) cuts a
 tensor along axis 0 into the 'div' row ranges of shard.div_range and writes it that way.  Restated from the published sources like the
 rest of the format; KATs of the key encoding in tests/test_host_logic.py.

@@ -777,6 +777,23 @@ int dir_din_attention_pool_save_f32(const float* table, int K, const int64_t* hi
                                     const float* W3, const float* b3, int normalize, int64_t B, float* out, float* scores,
                                     const int64_t* tile_off, int64_t n_tiles, void* workspace, int64_t workspace_bytes,
                                     dir_stream_t stream);
+/* The two entries above with the arithmetic of the unit's two MFMA layers given by argument instead of by the DIR_DIN_ARITH environment
+ * switch (round 5): DIR_DIN_ARITH_F32 = fp32-input MFMA (any magnitudes), DIR_DIN_ARITH_BF16X3 = three bf16 pieces per operand (fp32's
+ * exponent range), DIR_DIN_ARITH_F16X2 = two fp16 pieces, UNSCALED (|table|, |W| < 65 504 and not far below 1: an element under 2^-3 keeps an
+ * absolute 2^-25), DIR_DIN_ARITH_DEFAULT = what the other entries run.  The caller that knows its operands' magnitudes chooses; the Python
+ * surface (ops.din_attention_pool) measures max |table| / max |W| per tensor version and takes bf16 x 3 outside [2^-6, 2^15). */
+#define DIR_DIN_ARITH_DEFAULT (-1)
+#define DIR_DIN_ARITH_F32 0
+#define DIR_DIN_ARITH_BF16X3 1
+#define DIR_DIN_ARITH_F16X2 2
+int dir_din_attention_pool_arith_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                                     const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                                     const float* b3, int normalize, int activation, const float* act_params, int arith, int64_t B, float* out,
+                                     float* scores, dir_stream_t stream);
+int dir_din_attention_pool_save_arith_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                                          const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                                          const float* b3, int normalize, int arith, int64_t B, float* out, float* scores,
+                                          const int64_t* tile_off, int64_t n_tiles, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 int dir_din_attention_pool_backward_saved_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len,
                                               const int64_t* cand, int T, const float* W1, const float* b1, int H1,
                                               const float* W2, const float* b2, int H2, const float* W3, const float* b3,

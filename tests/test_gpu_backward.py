@@ -2069,3 +2069,89 @@ def test_deepfm_training_step_replays_from_a_hip_graph(built_lib):
     step(ma, oda, ola, feats(0), labels[0])
     torch.cuda.synchronize()
     assert all(torch.equal(x, y) for x, y in zip(ma.parameters(), mb.parameters()))
+
+
+def test_captured_step_keeps_caches_honest(built_lib):
+    """(a) graph replays update weights, tables and batch-norm statistics through raw pointers -- ops.CapturedStep bumps
+    the version counters after every replay, so an eager EVAL after the replays sees the trained weights (serving rows, weight images and
+    folded batch norms are rebuilt); (b) a capture taken right after an eager eval forward (every per-version cache holds a VALID entry at
+    capture time) still packs its weight images inside the graph: the replays equal eager steps bit for bit instead of training against
+    the images of the capture-time weights."""
+    from dir_amd import autograd as ag, feature_column as fc, ops
+    from dir_amd.deepfm import DeepFM
+    B, F, K, V = 8192, 26, 16, 20000
+
+    def build():
+        torch.manual_seed(11)
+        cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+        m = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats], dnn_hidden_units=[400, 400],
+                   fm_embedding_size=K, batch_norm=True).cuda()
+        m.fused_sparse_adagrad(lr=0.05, packed=True)
+        m.fused_sparse_ftrl(lr=0.2)
+        skip = {id(p) for p in m.linear_weights} | {id(p) for p in m.embedding_weights} | {id(m.linear_bias)}
+        od = ag.Adagrad([p for p in m.parameters() if id(p) not in skip], lr=0.05, initial_accumulator_value=0.1)
+        ol = ag.Ftrl([m.linear_bias], lr=0.2)
+        return m, od, ol
+
+    def step(m, od, ol, feats, y):
+        od.zero_grad(set_to_none=False)
+        ol.zero_grad(set_to_none=False)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(m(feats), y)
+        loss.backward()
+        od.step()
+        ol.step()
+        return loss
+
+    def evaluate(m, feats):
+        m.eval()
+        with torch.no_grad():
+            out = m(feats).clone()
+        m.train()
+        return out
+
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    batches = [torch.randint(0, V, (B, F), generator=gen, device="cuda") for _ in range(5)]
+    labels = [(torch.rand((B, 1), generator=gen, device="cuda") < 0.25).float() for _ in range(5)]
+    feats = lambda i: {"C%d" % f: batches[i][:, f] for f in range(F)}      # noqa: E731
+    ma, oda, ola = build()          # eager twin
+    mb, odb, olb = build()          # captured
+    ids_s, y_s = batches[0].clone(), labels[0].clone()
+    feats_s = {"C%d" % f: ids_s[:, f] for f in range(F)}
+    # the constructor's warm-up steps are real steps: give the twin the same three
+    cap = ops.CapturedStep(lambda: step(mb, odb, olb, feats_s, y_s), written=ops.written_of(mb), warmup=3)
+    for _ in range(3):
+        step(ma, oda, ola, feats(0), labels[0])
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(ma.parameters(), mb.parameters()))
+    e0 = evaluate(mb, feats(4))                                  # builds serving rows / images / folded batch norms of the CURRENT weights
+    assert torch.equal(e0, evaluate(ma, feats(4)))
+    for i in (1, 2, 3):
+        ids_s.copy_(batches[i]); y_s.copy_(labels[i])
+        cap.replay()
+        step(ma, oda, ola, feats(i), labels[i])
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(ma.parameters(), mb.parameters())), "replays differ from eager steps"
+    assert all(torch.equal(x, y) for x, y in zip(ma.buffers(), mb.buffers())), "batch-norm statistics differ"
+    e1b, e1a = evaluate(mb, feats(4)), evaluate(ma, feats(4))    # (a): the eval after the replays sees the trained weights
+    assert torch.equal(e1b, e1a) and not torch.equal(e1b, e0)
+    # (b): capture AFTER an eager eval forward, with no update in between -- every cache entry is valid when the capture starts
+    mc, odc, olc = build()
+    for _ in range(2):
+        step(mc, odc, olc, feats(0), labels[0])
+    evaluate(mc, feats(4))
+    mc.train()
+    # one hidden-layer image by hand as well: a hit at capture time
+    ops.dense_bf3_image(mc.hidden[0].weight.detach(), "f16x2")
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        step(mc, odc, olc, feats_s, y_s)
+    md, odd, old_ = build()
+    for _ in range(2):
+        step(md, odd, old_, feats(0), labels[0])
+    for i in (1, 2, 3, 4):
+        ids_s.copy_(batches[i]); y_s.copy_(labels[i])
+        g.replay()
+        step(md, odd, old_, feats(i), labels[i])
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(mc.parameters(), md.parameters())), "a graph captured behind valid caches trained against stale images"
