@@ -924,34 +924,53 @@ def main():
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "mlp": [400, 400, 400], "layout": args.train_layout,
                     "optimizers": "sparse Adagrad + sparse FTRL (HIP, sorted, inside backward) + torch Adagrad (MLP)"})
     elif wl == "small_batch":
-        # the reference's own batch size (256, DeepCrossNetwork/train.py:17): launch-bound; eager vs HIP-graph replay
+        # the reference's own batch size (256; 100 for evaluation: DeepCrossNetwork/train.py:16-17): nothing is bound but launch latency and the
+        # longest dependent chain.  DeepFM (26 x 16, 400-400-400) and DCN (d = 429, 3 cross layers, deep 1024-1024) inference, one forward
+        # eager and as a HIP-graph replay; the timed step is the DeepFM replay.  Since round 5 every hidden layer at this size runs
+        # dir_dense_small_f32 (dense_routing.library_layers_per_step == {}).
         from dir_amd.deepfm import DeepFM
+        from dir_amd.dcn import DeepCrossNetwork
         from dir_amd import feature_column as fc
+        from dir_amd import dense as _dense_mod
         from dir_amd.serving import GraphedForward
         Bs = int(os.environ.get("DIR_BENCH_SMALL_BATCH", "256"))
         cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
         model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
-                       dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
+                       dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device).eval()
+        nums = [fc.numeric_column("I%d" % i) for i in range(13)]
+        dcn = DeepCrossNetwork(columns=[fc.embedding_column(c, K) for c in cats] + nums, cross_layer_num=3, dnn_hidden_units=[1024, 1024]).to(device).eval()
         ids = torch.randint(0, V, (Bs, F), generator=gen, device=device)
+        dfeats = {"C%d" % i: ids[:, i].contiguous() for i in range(F)}
+        dfeats.update({"I%d" % i: torch.rand((Bs, 1), generator=gen, device=device) for i in range(13)})
         fwd = lambda x: model.forward_ids(x, x)  # noqa: E731
-        graphed = GraphedForward(fwd, ids)
-        with torch.no_grad():
-            ref = fwd(ids)
-        assert torch.equal(graphed(ids), ref)
-        # eager timing first (reported in config), then the graph replay is the timed step
-        with torch.no_grad():
-            for _ in range(20):
-                fwd(ids)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(200):
-                fwd(ids)
-            torch.cuda.synchronize()
-            eager_us = (time.perf_counter() - t0) / 200 * 1e6
+        fwd_dcn = lambda x: dcn(dfeats)          # noqa: E731
+
+        def latency(fn, n=200):
+            with torch.no_grad():
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e6
+        lat = {}
+        for name, f in (("deepfm", fwd), ("dcn", fwd_dcn)):
+            _dense_mod.reset_routing()
+            g_ = GraphedForward(f, ids)
+            with torch.no_grad():
+                ref = f(ids)
+            assert torch.equal(g_(ids), ref)
+            lat[name] = {"eager_us": round(latency(lambda: f(ids)), 2), "graph_replay_us": round(latency(lambda: g_.graph.replay()), 2),
+                         "library_layers": dict(_dense_mod.ROUTING["library"]), "hip_layers": sorted(_dense_mod.ROUTING["hip"])}
+            if name == "deepfm":
+                graphed = g_
+        _dense_mod.reset_routing()
         step = lambda i: graphed(ids)  # noqa: E731
         units = Bs
-        roof = {"bound": "hbm", "alg_bytes": Bs * (F * (8 + 2 * 4 * K) + 4), "kernel": "DeepFM forward, batch 256, hipGraph replay"}
-        cfg.update({"batch": Bs, "fields": F, "eager_us_per_forward": eager_us})
+        roof = {"bound": "hbm", "alg_bytes": Bs * (F * (8 + 2 * 4 * K) + 4), "kernel": "DeepFM forward, batch %d, hipGraph replay" % Bs}
+        cfg.update({"batch": Bs, "fields": F, "latency_per_forward": lat, "eager_us_per_forward": lat["deepfm"]["eager_us"]})
     elif wl == "transform":
         # raw Criteo-style features -> gather-ready ids on the device
         # (26 integer categorical keys hashed per field, 13 dense values bucketised into 10 buckets)

@@ -256,9 +256,128 @@ static void launch_dense(hipStream_t st, const float* X, int64_t x_ld, const flo
 }
 
 
+// ---- small batches (round 5): the reference's own operating point, batch 100 / 256 (models/DeepCrossNetwork/train.py:16-17) ----------------
+// At a few hundred rows a layer is a few tens of MFLOP: nothing is bound but the LENGTH of the longest dependent chain.  dense_k gives a
+// 128-row workgroup the whole reduction (26 staged chunks, a barrier each: ~30 us per 400-wide layer whatever M is) and the fused tower one
+// workgroup per 128 rows for all its layers (~110 us).  Here ONE WAVE owns a 16 x 16 tile of Y: its operands come straight from L2 /
+// HBM as 16-byte loads (lane (kk, r) reads X[row r][16 j + 4 kk ..+3] and Wt[col r][16 j + 4 kk ..+3]: element e of both feeds the j-th
+// step's e-th v_mfma_f32_16x16x4_f32, whose four k slots are then {e, 4 + e, 8 + e, 12 + e} + 16 j on both sides), no LDS, no barrier; four
+// independent accumulators (one per e) keep the matrix pipe's 8-pass latency out of the chain, and the loads of eight steps are in flight
+// at once; the four waves of a workgroup split the reduction of ONE tile (partials through LDS, added in wave order).  (M / 16) x (N / 16)
+// workgroups: 400 at 256 x 400 -- a layer is a few microseconds, and a forward captured in a HIP graph is the sum of them.  fp32-input
+// MFMA: exact fp32 products, fp32 accumulation.
+template <bool RELU, int RT /* row tiles of 16 per workgroup: 2 halves the weight traffic of the wide layers (1024 x 1024 at M = 256) */>
+__global__ __launch_bounds__(256) void dense_small_k(const float* __restrict__ X, int64_t x_ld, const float* __restrict__ Wt, int64_t w_ld,
+                                                     const float* __restrict__ bias, int64_t M, int Kd, int N, float* __restrict__ Y, int64_t y_ld,
+                                                     const float* __restrict__ pscale, const float* __restrict__ pshift) {
+    // the workgroup's four waves share ONE 16 RT x 16 tile: wave w takes the w-th quarter of the k steps (the chain is a quarter as long),
+    // waves 1..3 leave their partial tiles in LDS and wave 0 adds them in wave order (a fixed order: bitwise reproducible)
+    __shared__ float4 part[3][RT][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, kk = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.y * (16 * RT);
+    const int col0 = blockIdx.x * 16;
+    const int wr = col0 + r < N ? col0 + r : N - 1;                     // rows / columns past the end: clamped loads, results dropped
+    const float* wp = Wt + (int64_t)wr * w_ld + 4 * kk;
+    const float* xp[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int64_t xr = row0 + 16 * t + r < M ? row0 + 16 * t + r : M - 1;
+        xp[t] = X + xr * x_ld + 4 * kk;
+    }
+    f32x4d acc[RT][4];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = (f32x4d){0.f, 0.f, 0.f, 0.f};
+    const int steps = (Kd + 15) / 16;
+    const int jb = (steps * w) / 4, je = (steps * (w + 1)) / 4;          // this wave's k steps
+    constexpr int U = 8;
+    for (int j0 = jb; j0 < je; j0 += U) {
+        float4 xa[U][RT], wb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = 16 * (j0 + u) + 4 * kk;
+            const bool ok = j0 + u < je && k < Kd;                       // Kd % 4 == 0: a 16-byte piece is inside the row or outside it
+            wb[u] = ok ? *reinterpret_cast<const float4*>(wp + 16 * (j0 + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+                xa[u][t] = ok ? *reinterpret_cast<const float4*>(xp[t] + 16 * (j0 + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][t].x, wb[u].x, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][t].y, wb[u].y, acc[t][1], 0, 0, 0);
+                acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][t].z, wb[u].z, acc[t][2], 0, 0, 0);
+                acc[t][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][t].w, wb[u].w, acc[t][3], 0, 0, 0);
+            }
+    }
+    float4 tv[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        tv[t].x = (acc[t][0][0] + acc[t][1][0]) + (acc[t][2][0] + acc[t][3][0]);
+        tv[t].y = (acc[t][0][1] + acc[t][1][1]) + (acc[t][2][1] + acc[t][3][1]);
+        tv[t].z = (acc[t][0][2] + acc[t][1][2]) + (acc[t][2][2] + acc[t][3][2]);
+        tv[t].w = (acc[t][0][3] + acc[t][1][3]) + (acc[t][2][3] + acc[t][3][3]);
+        if (w > 0) part[w - 1][t][lane] = tv[t];
+    }
+    __syncthreads();
+    if (w > 0) return;
+    // D layout: lane (kk, r) holds Y[row0 + 16 t + 4 kk + g][col0 + r]
+    const int col = col0 + r;
+    if (col >= N) return;
+    const float b = bias ? bias[col] : 0.f;
+    const float sc = pscale ? pscale[col] : 1.f, sf = pscale ? pshift[col] : 0.f;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        float4 s4 = tv[t];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 p = part[q][t][lane];
+            s4.x += p.x; s4.y += p.y; s4.z += p.z; s4.w += p.w;
+        }
+        const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t row = row0 + 16 * t + 4 * kk + g;
+            float v = sv[g] + b;
+            if (RELU) v = v > 0.f ? v : 0.f;
+            if (pscale) v = v * sc + sf;
+            if (row < M) Y[row * y_ld + col] = v;
+        }
+    }
+}
+
 }  // namespace dir
 
 using namespace dir;
+
+extern "C" int dir_dense_small_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
+                                   const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
+    const char* name = "dir_dense_small_f32";
+    DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && w_ld >= Kd && y_ld >= N, "%s: M=%lld Kd=%d N=%d x_ld=%lld w_ld=%lld y_ld=%lld", name,
+                  (long long)M, Kd, N, (long long)x_ld, (long long)w_ld, (long long)y_ld);
+    DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
+    DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
+    if (M == 0) return DIR_OK;
+    DIR_CHECK_ARG(X && Wt && Y, "%s: null pointer", name);
+    if ((Kd & 3) || (x_ld & 3) || (w_ld & 3) || !aligned16(X) || !aligned16(Wt))
+        return fail(DIR_E_UNSUPPORTED, "%s: Kd, x_ld and w_ld must be multiples of 4 and X / Wt 16-byte aligned (Kd=%d x_ld=%lld w_ld=%lld)", name, Kd,
+                    (long long)x_ld, (long long)w_ld);
+    if ((M + 15) / 16 > 65535) return fail(DIR_E_UNSUPPORTED, "%s: M=%lld (this entry is for batches of at most ~1 M rows; dir_dense_f32 beyond a few thousand)", name, (long long)M);
+    // two row tiles per workgroup where the weight matrix is large and the batch has rows to pair (halves the weight reads from L2)
+    const bool rt2 = M > 64 && (int64_t)N * Kd >= 512 * 1024;
+    const int rows = rt2 ? 32 : 16;
+    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)((M + rows - 1) / rows));
+    hipStream_t st = as_stream(stream);
+#define DIR_DS(RELU_, RT_) hipLaunchKernelGGL((dense_small_k<RELU_, RT_>), grid, dim3(256), 0, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, post_scale, post_shift)
+    if (act) { if (rt2) DIR_DS(true, 2); else DIR_DS(true, 1); }
+    else { if (rt2) DIR_DS(false, 2); else DIR_DS(false, 1); }
+#undef DIR_DS
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
 
 static int dense_entry(const char* name, const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, int64_t M, int Kd,
                        int N, float* Y, int64_t y_ld, const float* gate, int64_t gate_ld, dir_stream_t stream, const float* ps = nullptr,

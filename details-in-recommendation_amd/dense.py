@@ -19,6 +19,8 @@ _RELUS = (torch.relu, F.relu, torch.nn.functional.relu)
 # Below this many rows a layer stays on the library: a 128-row tile per workgroup leaves most CUs idle on small batches, where
 # the library's small-M kernels win (DeepFM forward as a HIP-graph replay: 78 vs 126 us at batch 256, 127 vs 135 us at 4 096, then
 # 221 vs 177 us at 8 192 -- `DIR_BENCH_SMALL_BATCH=n bench.py --workload small_batch`); DIR_DENSE_MIN_ROWS overrides.
+# Round 5: batches ops.dense_small_covers() accepts (up to 256 rows always -- the reference's own 100 / 256 -- and up to 512 for the narrower
+# layers) run dir_dense_small_f32 instead of the library; the library keeps what lies between that and MIN_ROWS.
 import os as _os
 MIN_ROWS = int(_os.environ.get("DIR_DENSE_MIN_ROWS", "6144"))
 _PACK_CACHE = {}
@@ -461,7 +463,8 @@ def _apply_bn(bn, y):
 def _dense_act(lin, x, activation, bn, bounded=False):
     relu = activation in _RELUS
     prepadded = x.dim() == 2 and x.shape[1] != lin.in_features and x.shape[1] == lin.in_features + (-lin.in_features) % 4
-    if (activation is None or relu) and x.is_cuda and x.dim() == 2 and x.shape[0] >= MIN_ROWS and lin.out_features >= 16:
+    if (activation is None or relu) and x.is_cuda and x.dim() == 2 and lin.out_features >= 16 and (
+            x.shape[0] >= MIN_ROWS or ops.dense_small_covers(x.shape[0], lin.in_features + (-lin.in_features) % 4, lin.out_features)):
         _route("hip", lin)
         train = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
         fold = bn is not None and not (bn.training and torch.is_grad_enabled())

@@ -655,6 +655,16 @@ DENSE_GENERAL_SPLIT = os.environ.get("DIR_DENSE_GENERAL_SPLIT", "f16x2_rows")
 DENSE_BWD_CARRY = os.environ.get("DIR_DENSE_BWD_CARRY", "1") != "0"
 # development switch: 0 = a row-scaled forward layer does not leave its output's maxima on the tensor (every layer runs its own max pass)
 DENSE_FWD_CARRY = os.environ.get("DIR_DENSE_FWD_CARRY", "1") != "0"
+# Small batches run dir_dense_small_f32 where the fp32 kernel would run: up to 256 rows always (the reference's batch sizes, 100 / 256: 3.7-8 us
+# per layer against the library's 7.5-9 and dir_dense_f32's 26-39; only 1024 x 1024 at 256 rows is behind the library, 16 against 11 us),
+# up to DENSE_SMALL_ROWS rows while M N K stays under DENSE_SMALL_MNK (profiles/r05_dense_small_probe.txt; DIR_DENSE_SMALL_ROWS = 0: never)
+DENSE_SMALL_ROWS = int(os.environ.get("DIR_DENSE_SMALL_ROWS", "512"))
+DENSE_SMALL_MNK = 1.2e8
+
+
+def dense_small_covers(M, Kd, N):
+    """Whether dense() runs dir_dense_small_f32 for an [M, Kd] x [N, Kd] layer (given fp32 arithmetic and 16-byte aligned rows)."""
+    return 0 < M <= DENSE_SMALL_ROWS and Kd % 4 == 0 and (M <= 256 or float(M) * N * Kd <= DENSE_SMALL_MNK)
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
 
@@ -829,6 +839,11 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
         post_scale, post_shift = _dev(post_scale, torch.float32, "post_scale").contiguous(), _dev(post_shift, torch.float32, "post_shift").contiguous()
         if post_scale.numel() != N or post_shift.numel() != N:
             raise ValueError("dense: post_scale / post_shift [N]")
+    if which == "f32" and dense_small_covers(M, Kd, N) and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+        # small batches (the reference's 100 / 256): one wave per 16 x 16 tile, no LDS, no barrier (csrc/dense.hip: dense_small_k)
+        _lib.check(_lib.load().dir_dense_small_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), 1 if relu else 0,
+                                                   _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
+        return out
     if which == "f16x2":
         _lib.check(_lib.load().dir_dense_f16x2_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), _ptr(bias), 1 if relu else 0,
                                                    _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))

@@ -451,6 +451,13 @@ int dir_dense_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, c
  * (gamma = 1 for contrib batch_norm).  Multiply then add, unfused.  One pass over Y instead of three. */
 int dir_dense_affine_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
                          const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
+/* The same layer for SMALL batches (round 5): the reference trains and evaluates at batch 100 / 256 (models/DeepCrossNetwork/train.py:16-17),
+ * where a layer is bound by the longest dependent chain, not by any throughput.  One wave per 16 x 16 output tile, operands straight from
+ * L2 as 16-byte loads, v_mfma_f32_16x16x4_f32 on four independent accumulators, no LDS, no barrier: (M / 16) x (N / 16) waves.  Arguments
+ * of dir_dense_affine_f32 (post_scale / post_shift NULL: none); Kd, x_ld, w_ld multiples of 4, X / Wt 16-byte aligned; any N.  What
+ * ops.dense routes batches of at most ops.DENSE_SMALL_ROWS rows to. */
+int dir_dense_small_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
+                        const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
 /* The same layer on the bf16 matrix pipe with fp32-equivalent arithmetic (csrc/dense_bf3.hip; the recipe of
  * dir_cin_layer_bf16x3_f32): X and W are each split into three bf16 pieces (round to nearest; the pieces sum to the operand exactly,
  * fp32 exponent range), the six piece products of weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Same 1e-5

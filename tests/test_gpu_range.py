@@ -168,3 +168,45 @@ def test_mlp_head_trains_on_large_inputs(built_lib):
     _bar(out.detach(), o.detach())
     for gg, rr in zip(got, refs):
         _bar(gg, rr, tol=5e-5)
+
+
+@pytest.mark.parametrize("log2s", [20, -10, 0])
+def test_din_unit_checks_its_operands_range(built_lib, oracle, log2s, monkeypatch):
+    """The DIN unit's fp16 x 2 kernel splits table rows unscaled, so ops.din_attention_pool MEASURES max |table| / max |W| (per tensor
+    version) and takes bf16 x 3 outside [2^-6, 2^15): a table scaled by 2^20 returns the float64 answer (round 4's default returned inf),
+    one scaled by 2^-10 keeps a relative 1e-5.  W1's blocks are scaled back so that the unit sees the same pre-activations."""
+    from dir_amd import ops
+    monkeypatch.delenv("DIR_DIN_ARITH", raising=False)
+    rng = np.random.default_rng(7)
+    B, T, K, H1, H2, V = 256, 50, 64, 80, 40, 2000
+    s = 2.0 ** log2s
+    table = (rng.standard_normal((V, K)) * 0.3 * s).astype(np.float32)
+    hist = rng.integers(-1, V, size=(B, T)).astype(np.int64)
+    hl = rng.integers(0, T + 1, size=B).astype(np.int32)
+    cand = rng.integers(0, V, size=B).astype(np.int64)
+    W1 = (rng.standard_normal((4 * K, H1)) * 0.1).astype(np.float32)
+    W1[:3 * K] /= s                                        # [h, a, h - a] blocks
+    W1[3 * K:] /= s * s                                    # h * a block
+    b1 = (rng.standard_normal(H1) * 0.1).astype(np.float32)
+    W2 = (rng.standard_normal((H1, H2)) * 0.2).astype(np.float32); b2 = (rng.standard_normal(H2) * 0.1).astype(np.float32)
+    W3 = (rng.standard_normal(H2) * 0.3).astype(np.float32); b3 = np.array([0.05], np.float32)
+    dev = lambda a: torch.from_numpy(a).cuda()             # noqa: E731
+    t, w1, w2, w3 = dev(table), dev(W1), dev(W2), dev(W3)
+    code = ops.din_arith(t, (w1, w2, w3))
+    assert code == (ops.DIN_ARITHS["f16x2"] if log2s == 0 else ops.DIN_ARITHS["bf16x3"])
+    for normalize in (False, True):
+        ref_o, ref_s = oracle.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=normalize, acc64=True)
+        got_o, got_s = ops.din_attention_pool(t, dev(hist), dev(hl), dev(cand), w1, dev(b1), w2, dev(b2), w3, dev(b3), normalize=normalize,
+                                              want_scores=True)
+        _bar(got_s, torch.from_numpy(ref_s).cuda())
+        _bar(got_o, torch.from_numpy(ref_o).cuda())
+    # the measurement follows the tensor's version: an in-place rescale is seen (inference: every change; training: within DIN_RANGE_RECHECK updates)
+    t2 = dev((rng.standard_normal((V, K)) * 0.3).astype(np.float32))
+    assert ops.din_arith(t2, ()) == ops.DIN_ARITHS["f16x2"]
+    t2.mul_(2.0 ** 18)
+    keep = ops.DIN_RANGE_RECHECK
+    ops.DIN_RANGE_RECHECK = 1
+    try:
+        assert ops.din_arith(t2, ()) == ops.DIN_ARITHS["bf16x3"]
+    finally:
+        ops.DIN_RANGE_RECHECK = keep
