@@ -42,10 +42,14 @@ def min_rows(request, monkeypatch):
     return request.param
 
 
-def _check_routing(min_rows):
+def _check_routing(min_rows, batch=None):
+    """product routing (round 5): a batch ops.dense_small_covers() accepts -- up to 256 rows always, the reference's own 100 / 256 -- runs
+    dir_dense_small_f32 (only layers under 16 units stay library code); larger batches below dense.MIN_ROWS go to nn.Linear."""
     from dir_amd import dense as D
     if min_rows == 1:
         assert D.ROUTING["hip"], dict(D.ROUTING)
+    elif batch is not None and batch <= 256:
+        assert D.ROUTING["hip"] and all(int(k.split("x")[1]) < 16 for k in D.ROUTING["library"]), dict(D.ROUTING)
     else:
         assert D.ROUTING["library"] and not D.ROUTING["hip"], dict(D.ROUTING)
 
@@ -204,7 +208,7 @@ def test_dcn_adult_schema_forward(built_lib, oracle, min_rows):
     feats["occupation"] = raw["occupation"]
     with torch.no_grad():
         got = model.predict(feats)
-    _check_routing(min_rows)
+    _check_routing(min_rows, B)
     # NumPy restatement with name-sorted concat
     parts = {}
     for n in nums:

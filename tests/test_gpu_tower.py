@@ -477,3 +477,43 @@ def test_dense_general_inputs_on_row_scaled_fp16x2(built_lib, monkeypatch, M, Kd
     assert torch.equal(ops.dense(x * pw, W), lin * pw)
     monkeypatch.setattr(ops, "DENSE_GENERAL_SPLIT", "bf16x3")
     assert torch.equal(ops.dense(x, W, b, relu=False), b3)
+
+
+@pytest.mark.parametrize("M,Kd,N", [(1, 4, 1), (100, 416, 400), (256, 400, 400), (37, 432, 1024), (256, 1024, 1024), (65, 1024, 520), (17, 20, 33),
+                                     (512, 360, 200), (300, 200, 80), (16, 16, 16), (255, 52, 7)])
+def test_dense_small_batches(built_lib, M, Kd, N):
+    """dir_dense_small_f32 (round 5: the layers at the reference's batch sizes, DeepCrossNetwork/train.py:16-17): one wave per 16 x 16 tile, the
+    workgroup's four waves splitting the reduction -- row / column / k tails, the two-row-tile form of the wide layers, bias, ReLU and the
+    folded inference batch norm, against float64; rerun bitwise equal; and ops.dense routes to it by itself."""
+    from dir_amd import ops, _lib
+    import ctypes
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M * 7 + N)
+    x = torch.randn((M, Kd), generator=g, device=dev) * 0.5
+    W = torch.randn((N, Kd), generator=g, device=dev) * 0.1
+    b = torch.randn((N,), generator=g, device=dev) * 0.2
+    ps = torch.rand((N,), generator=g, device=dev) + 0.5
+    sh = torch.randn((N,), generator=g, device=dev) * 0.1
+    lib = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for relu, bias, post in ((True, b, None), (False, None, None), (True, b, (ps, sh))):
+        y = torch.full((M, N + 3), 7.0, device=dev)                  # a wider output buffer: the row stride is honoured, the pad untouched
+        _lib.check(lib.dir_dense_small_f32(p(x), x.stride(0), p(W), W.stride(0), p(bias), 1 if relu else 0, p(post[0]) if post else None,
+                                           p(post[1]) if post else None, M, Kd, N, p(y), y.stride(0), st))
+        ref = x.double() @ W.double().t()
+        if bias is not None:
+            ref = ref + bias.double()
+        if relu:
+            ref = torch.relu(ref)
+        if post:
+            ref = ref * post[0].double() + post[1].double()
+        err = float(((y[:, :N].double() - ref).abs() / (1 + ref.abs())).max())
+        assert err <= 1e-5, err
+        assert bool((y[:, N:] == 7.0).all())
+        y2 = torch.empty((M, N), device=dev)
+        _lib.check(lib.dir_dense_small_f32(p(x), x.stride(0), p(W), W.stride(0), p(bias), 1 if relu else 0, p(post[0]) if post else None,
+                                           p(post[1]) if post else None, M, Kd, N, p(y2), y2.stride(0), st))
+        assert torch.equal(y2, y[:, :N])
+    if ops.dense_small_covers(M, Kd, N) and N >= 16:
+        assert torch.equal(ops.dense(x, W, b, relu=True), torch.relu(y2) if False else ops.dense(x, W, b, relu=True, arith="f32"))
