@@ -1228,6 +1228,19 @@ def main():
             for w in ws:
                 w.grad = None
             ag.din_attention_pool(table, hist, hl, cand, *ws, normalize=True).backward(gout)
+        att_act = os.environ.get("DIR_BENCH_DIN_ACT", "sigmoid")
+        if att_act in ("prelu", "dice"):
+            # the paper's own unit activations in TRAIN mode (Dice: mini-batch statistics): the row-list path on HIP kernels (din.DINAttentionPool._rows_train,
+            # csrc/din_rows_train.hip; DIR_DIN_ROWS_TRAIN=0: round 4's torch formulation)
+            from dir_amd.din import DINAttentionPool
+            unit = DINAttentionPool(Vd, Kd, (H1, H2), normalize=True, activation=att_act).to(device).train()
+            del table
+
+            def step(i):           # noqa: F811
+                for p_ in unit.parameters():
+                    p_.grad = None
+                unit(hist, hl, cand).backward(gout)
+            cfg["activation"] = att_act
         survey = 3 * B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)
         rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
         executed = 2.0 * 1024 * rt * (220 + 660)     # 16x16x4-MFMA equivalents per 16-row tile: forward 220; backward 220 recompute + 440

@@ -119,6 +119,14 @@ SIGNATURES = {
     "dir_din_attention_pool_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                            c_i32, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "dir_din_activation_rows_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "dir_din_feat_rows_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dir_din_feat_rows_backward_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "dir_act_rows_train_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "dir_act_rows_backward_partials": (c_i32, [c_i64, c_i32]),
+    "dir_act_rows_backward_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                                          c_i32, c_vp]),
+    "dir_din_pool_rows_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "dir_din_pool_rows_backward_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "dir_din_attention_pool_act_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                                c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_din_attention_pool_arith_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,

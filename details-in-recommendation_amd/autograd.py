@@ -391,6 +391,93 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     return DinAttentionPool.apply(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize)
 
 
+# ---- PReLU / Dice layers and the DIN unit's row-list training path (round 5; csrc/din_rows_train.hip) -----------------------------------------
+class ActRows(torch.autograd.Function):
+    """y = PReLU / Dice (s) over rows s [M, N] with HIP forward and backward (no reference code: arXiv:1706.06978 section 5.3, din.Dice).
+    Dice in TRAIN mode: the batch statistics come from dir_bn_train_stats_f32 (which also advances the module's moving statistics with
+    its momentum), the backward is the direct term + the batch-norm backward of the gradient with respect to the normalised
+    pre-activation (dir_bn_train_backward_f32) + dL/dalpha; in eval mode (grad enabled, module.eval()) the moving statistics are
+    constants.  PReLU: one pass each way."""
+
+    @staticmethod
+    def forward(ctx, s, alpha, kind, stats):
+        # stats: None (PReLU) | ("batch", moving_mean, moving_variance, eps, momentum) | ("moving", scale, shift)
+        ctx.kind = kind
+        mean = inv = scale = shift = None
+        if kind == "dice":
+            if stats[0] == "batch":
+                mean, inv, scale, shift = ops.bn_train_stats(s, None, None, stats[1], stats[2], stats[3], stats[4])
+            else:
+                scale, shift = stats[1], stats[2]
+        y = ops.act_rows_train(s, kind, alpha, scale, shift)
+        ctx.batch = kind == "dice" and stats[0] == "batch"
+        ctx.save_for_backward(s, alpha, *([scale, shift] if kind == "dice" else []), *([mean, inv] if ctx.batch else []))
+        return y
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        s, alpha = saved[0], saved[1]
+        scale, shift = (saved[2], saved[3]) if ctx.kind == "dice" else (None, None)
+        d1, gx, galpha = ops.act_rows_backward(g, s, ctx.kind, alpha, scale, shift)
+        if ctx.batch:
+            mean, inv = saved[4], saved[5]
+            dbn, _, _ = ops.bn_train_backward(gx, s, mean, inv, gamma=None)      # the statistics' share of dL/ds
+            d1.add_(dbn)
+        return d1, galpha.reshape(alpha.shape) if ctx.needs_input_grad[1] else None, None, None
+
+
+def act_rows(s, module):
+    """module: din.Dice / din._PReLU.  The HIP training form of module(s) for a [M, N] activation it covers (ops.act_rows_supported)."""
+    kind = "dice" if hasattr(module, "moving_mean") else "prelu"
+    if kind == "prelu":
+        return ActRows.apply(s, module.alpha, "prelu", None)
+    if module.training:
+        return ActRows.apply(s, module.alpha, "dice", ("batch", module.moving_mean, module.moving_variance, module.eps, module.momentum))
+    sc, sh = module.scale_shift()
+    return ActRows.apply(s, module.alpha, "dice", ("moving", sc, sh))
+
+
+class DinFeatRows(torch.autograd.Function):
+    """(X [N, 3K], Hc [N, K]) of the valid (sample, position) rows; backward: a sparse gradient for the item table (history rows, then candidates)."""
+
+    @staticmethod
+    def forward(ctx, table, ids_h, b_idx, row_off, cand):
+        X, Hc = ops.din_feat_rows(table.detach(), ids_h, b_idx, cand)
+        ctx.save_for_backward(table, ids_h, row_off, cand)
+        return X, Hc
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, dX, dH):
+        table, ids_h, row_off, cand = ctx.saved_tensors
+        N, K = ids_h.numel(), table.shape[1]
+        if dX is None:
+            dX = torch.zeros((N, 3 * K), dtype=torch.float32, device=table.device)
+        if dH is None:
+            dH = torch.zeros((N, K), dtype=torch.float32, device=table.device)
+        grows = ops.din_feat_rows_backward(table, ids_h, row_off, cand, dX, dH)
+        idx = torch.cat([ids_h, cand.clamp(min=0)]).unsqueeze(0)
+        return torch.sparse_coo_tensor(idx, grows, table.shape), None, None, None, None
+
+
+class DinPoolRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, Hc, row_off, B, normalize):
+        out, w = ops.din_pool_rows(scores.detach(), Hc.detach(), row_off, B, normalize)
+        ctx.normalize = bool(normalize)
+        ctx.save_for_backward(Hc, w, row_off)
+        return out
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g):
+        Hc, w, row_off = ctx.saved_tensors
+        ds, dH = ops.din_pool_rows_backward(g, Hc, w, row_off, ctx.normalize)
+        return ds, dH, None, None, None
+
+
 def gather_fm(ts, ids, tables):
     return GatherFm.apply(ts, ids, *tables)
 

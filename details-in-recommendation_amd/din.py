@@ -22,6 +22,8 @@ from . import ops
 from .dense import dense_act, units1
 
 ACTIVATIONS = ("sigmoid", "prelu", "dice")
+import os as _os
+ROWS_TRAIN = _os.environ.get("DIR_DIN_ROWS_TRAIN", "1") != "0"      # development switch: 0 = PReLU / Dice train through the torch formulation (round 4)
 
 
 class Dice(nn.Module):
@@ -88,8 +90,9 @@ def _make_act(kind, n):
 class DINAttentionPool(nn.Module):
     """history ids [B,T] + lengths [B] + candidate ids [B] -> pooled interest vector [B,K].  activation: the two hidden layers'
     activation -- "sigmoid" (default), "prelu" or "dice" (arXiv:1706.06978 section 5.3).  Inference runs the HIP unit for all three
-    (dir_din_attention_pool[_act]_f32); training runs the HIP forward / backward for the sigmoid unit and a differentiable torch
-    formulation of the same arithmetic for PReLU / Dice (their backward kernels are not written)."""
+    (dir_din_attention_pool[_act]_f32); training runs the fused HIP forward / backward for the sigmoid unit and, for PReLU / Dice, the unit
+    over the compact row list on HIP kernels (_rows_train: Dice normalises with the mini-batch's statistics, so its layers are whole-batch
+    passes); the differentiable torch formulation (_composite) remains for shapes those kernels do not take."""
 
     def __init__(self, vocab_size, embedding_dim=64, hidden_units=(80, 40), normalize=False, activation="sigmoid"):
         super().__init__()
@@ -151,13 +154,46 @@ class DINAttentionPool(nn.Module):
             w = s * valid
         return (w.unsqueeze(-1) * h).sum(dim=1)
 
+    def _rows_train(self, hist, hist_len, cand):
+        """PReLU / Dice in training on HIP kernels (round 5; csrc/din_rows_train.hip): the unit over the compact list of valid (sample, position)
+        rows -- X' = [h | h * a | a] (dir_din_feat_rows_f32), pre1 = X' [Wh + Wd; Wp; Wa - Wd] + b1 and pre2 = y1 W2 + b2 on the dense
+        kernels (forward, dL/dx and dL/dW: dense._DenseFn), the activations with the batch's statistics (autograd.ActRows: Dice =
+        dir_bn_train_stats_f32 + dir_act_rows_train_f32, backward dir_act_rows_backward_f32 + dir_bn_train_backward_f32), the score layer
+        (dir_units1_f32) and the per-sample weights + pooling (dir_din_pool_rows_f32).  Same definition as _composite (the torch
+        formulation, kept for shapes these kernels do not take); the table gets a sparse gradient.  -> [B, K], or None: not covered."""
+        from .dense import _DenseFn, _Units1Fn
+        B, T = hist.shape
+        K, H1, H2 = self.table.shape[1], self.b1.numel(), self.b2.numel()
+        if (not self.table.is_cuda or self.table.dtype != torch.float32 or K % 4 or K > 256 or H1 % 4 or H2 % 4 or H1 < 16 or H2 < 16
+                or H1 > 1024 or H2 > 1024 or B == 0):
+            return None
+        valid = hist >= 0
+        if hist_len is not None:
+            valid = valid & (torch.arange(T, device=hist.device).unsqueeze(0) < hist_len.clamp(0, T).unsqueeze(1))
+        b_idx, j_idx = valid.nonzero(as_tuple=True)                  # rows in (b, j) order (the one host read of the step)
+        if b_idx.numel() == 0:
+            return None
+        ids_h = hist[b_idx, j_idx]
+        cnt = valid.sum(dim=1)
+        row_off = (torch.cumsum(cnt, 0) - cnt).contiguous()
+        X, Hc = ag.DinFeatRows.apply(self.table, ids_h, b_idx, row_off, cand)
+        Wh, Wa, Wd, Wp = self.W1[:K], self.W1[K:2 * K], self.W1[2 * K:3 * K], self.W1[3 * K:]
+        Wc = torch.cat([Wh + Wd, Wp, Wa - Wd], dim=0)               # [3K, H1]: autograd hands dL/dW1 back through this regrouping
+        pre1 = _DenseFn.apply(X, Wc.t(), self.b1, False)
+        y1 = ag.act_rows(pre1, self.act1) if ops.act_rows_supported(pre1) else self.act1(pre1)
+        pre2 = _DenseFn.apply(y1, self.W2.t(), self.b2, False)
+        y2 = ag.act_rows(pre2, self.act2) if ops.act_rows_supported(pre2) else self.act2(pre2)
+        sc = _Units1Fn.apply(y2, self.W3.reshape(1, -1), self.b3)   # [N, 1]
+        return ag.DinPoolRows.apply(sc.reshape(-1), Hc, row_off, B, self.normalize)
+
     def forward(self, hist, hist_len, cand, want_scores=False):
         train = torch.is_grad_enabled() and not want_scores and any(p.requires_grad for p in self.parameters())
         if train and self.activation == "sigmoid":
             return ag.din_attention_pool(self.table, hist, hist_len, cand, self.W1, self.b1, self.W2, self.b2, self.W3,
                                          self.b3, normalize=self.normalize)       # sparse table gradient
         if train:
-            return self._composite(hist, hist_len, cand)
+            out = self._rows_train(hist, hist_len, cand) if ROWS_TRAIN else None
+            return out if out is not None else self._composite(hist, hist_len, cand)
         return ops.din_attention_pool(self.table.data, hist, hist_len, cand, self.W1.data, self.b1.data, self.W2.data,
                                       self.b2.data, self.W3.data, self.b3.data, normalize=self.normalize,
                                       want_scores=want_scores, activation=self.activation, act_params=self.act_params())
@@ -248,8 +284,10 @@ class DIN(nn.Module):
                 net = torch.sigmoid(dense_act(lin, net, None))
             else:
                 pre = dense_act(lin, net, None)
-                if torch.is_grad_enabled() or not pre.is_cuda or pre.shape[1] % 4 or pre.stride(0) % 4 or pre.data_ptr() % 16:
-                    net = act(pre)                                         # TRAIN mode (batch statistics, autograd): torch ops
+                if torch.is_grad_enabled() and ROWS_TRAIN and ops.act_rows_supported(pre):
+                    net = ag.act_rows(pre, act)                            # TRAIN mode on HIP kernels (batch statistics: autograd.ActRows)
+                elif torch.is_grad_enabled() or not pre.is_cuda or pre.shape[1] % 4 or pre.stride(0) % 4 or pre.data_ptr() % 16:
+                    net = act(pre)                                         # uncovered shapes: torch ops
                 elif self.dnn_activation_fn == "prelu":
                     net = ops.din_activation_rows_(pre, "prelu", act.alpha)              # HIP layer, then ONE in-place pass
                 else:

@@ -559,6 +559,91 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
     return (out, scores) if want_scores else out
 
 
+# ---- the DIN unit's PReLU / Dice TRAINING path over the compact row list (csrc/din_rows_train.hip; no reference code: arXiv:1706.06978) -----
+def act_rows_supported(s):
+    """Shapes dir_act_rows_train_f32 / _backward_f32 (and dir_bn_train_stats_f32) take: float32 CUDA [M > 0, N], N % 4 == 0, N <= 1024."""
+    return (s.is_cuda and s.dtype == torch.float32 and s.dim() == 2 and s.shape[0] > 0 and s.shape[1] % 4 == 0 and s.shape[1] <= 1024
+            and s.stride(1) == 1 and s.stride(0) % 4 == 0 and s.data_ptr() % 16 == 0)
+
+
+def _vec16(t, n, what):
+    t = _dev(t.detach().reshape(-1).contiguous(), torch.float32, what)
+    if t.numel() != n:
+        raise ValueError("%s must hold %d values" % (what, n))
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+def din_feat_rows(table, ids_h, b_idx, cand):
+    """X [N, 3K] = [h_n | h_n * a_b | a_b] and Hc [N, K] = h_n over the valid (sample, position) rows (dir_din_feat_rows_f32)."""
+    _dev(table, torch.float32, "table")
+    N, K = ids_h.numel(), table.shape[1]
+    X = torch.empty((N, 3 * K), dtype=torch.float32, device=table.device)
+    Hc = torch.empty((N, K), dtype=torch.float32, device=table.device)
+    _lib.check(_lib.load().dir_din_feat_rows_f32(_ptr(table), K, _ptr(_dev(ids_h, torch.int64, "ids_h").contiguous()),
+                                                 _ptr(_dev(b_idx, torch.int64, "b_idx").contiguous()), _ptr(_dev(cand, torch.int64, "cand").contiguous()),
+                                                 N, _ptr(X), _ptr(Hc), _stream()))
+    return X, Hc
+
+
+def din_feat_rows_backward(table, ids_h, row_off, cand, dX, dH):
+    """-> grows [N + B, K]: dL/dh_n for the N history rows, then dL/da_b for the B candidates (dir_din_feat_rows_backward_f32)."""
+    N, K, B = ids_h.numel(), table.shape[1], cand.numel()
+    grows = torch.empty((N + B, K), dtype=torch.float32, device=table.device)
+    _lib.check(_lib.load().dir_din_feat_rows_backward_f32(_ptr(table), K, _ptr(ids_h.contiguous()), _ptr(row_off.contiguous()), _ptr(cand.contiguous()),
+                                                          B, N, _ptr(dX.contiguous()), _ptr(dH.contiguous()), _ptr(grows), _stream()))
+    return grows
+
+
+def act_rows_train(s, activation, alpha, scale=None, shift=None):
+    """y = PReLU / Dice (s) out of place (dir_act_rows_train_f32); Dice: (scale, shift) of the statistics that normalise (the batch's in TRAIN mode)."""
+    M, N = s.shape
+    y = torch.empty((M, N), dtype=torch.float32, device=s.device)
+    vec = [_vec16(alpha, N, "alpha")] + [None if t is None else _vec16(t, N, "scale / shift") for t in (scale, shift)]
+    _lib.check(_lib.load().dir_act_rows_train_f32(_ptr(s), s.stride(0), M, N, DIN_ACTIVATIONS[activation], _ptr(vec[0]), _ptr(vec[1]), _ptr(vec[2]),
+                                                  _ptr(y), y.stride(0), _stream()))
+    return y
+
+
+def act_rows_backward(g, s, activation, alpha, scale=None, shift=None):
+    """g = dL/dy -> (d1 [M, N], gx [M, N] | None, galpha [N]) (dir_act_rows_backward_f32): d1 = g df/ds with the normalised pre-activation held
+    fixed (PReLU: all of dL/ds), gx = dL/d(normalised pre-activation) (Dice), galpha = dL/dalpha."""
+    M, N = s.shape
+    if g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16:
+        g = g.contiguous()
+    lib = _lib.load()
+    P = int(lib.dir_act_rows_backward_partials(M, N))
+    d1 = torch.empty((M, N), dtype=torch.float32, device=s.device)
+    gx = torch.empty((M, N), dtype=torch.float32, device=s.device) if activation == "dice" else None
+    galpha = torch.empty(N, dtype=torch.float32, device=s.device)
+    part = torch.empty((max(P, 1), N), dtype=torch.float32, device=s.device)
+    vec = [_vec16(alpha, N, "alpha")] + [None if t is None else _vec16(t, N, "scale / shift") for t in (scale, shift)]
+    _lib.check(lib.dir_act_rows_backward_f32(_ptr(g), g.stride(0), _ptr(s), s.stride(0), M, N, DIN_ACTIVATIONS[activation], _ptr(vec[0]), _ptr(vec[1]),
+                                             _ptr(vec[2]), _ptr(d1), d1.stride(0), _ptr(gx), gx.stride(0) if gx is not None else N, _ptr(galpha),
+                                             _ptr(part), P, _stream()))
+    return d1, gx, galpha
+
+
+def din_pool_rows(scores, Hc, row_off, B, normalize):
+    """-> (out [B, K], w [N]): the attention weights of every sample's rows and the weighted sum of its history rows (dir_din_pool_rows_f32)."""
+    N, K = Hc.shape
+    out = torch.empty((B, K), dtype=torch.float32, device=Hc.device)
+    w = torch.empty(max(N, 1), dtype=torch.float32, device=Hc.device)[:N]
+    _lib.check(_lib.load().dir_din_pool_rows_f32(_ptr(scores.contiguous()), _ptr(Hc), K, _ptr(row_off.contiguous()), B, N, int(bool(normalize)), _ptr(w),
+                                                 _ptr(out), _stream()))
+    return out, w
+
+
+def din_pool_rows_backward(g, Hc, w, row_off, normalize):
+    """g [B, K] -> (ds [N], dH [N, K]) (dir_din_pool_rows_backward_f32)."""
+    N, K = Hc.shape
+    B = g.shape[0]
+    ds = torch.empty(max(N, 1), dtype=torch.float32, device=Hc.device)[:N]
+    dH = torch.empty((N, K), dtype=torch.float32, device=Hc.device)
+    _lib.check(_lib.load().dir_din_pool_rows_backward_f32(_ptr(g.contiguous()), _ptr(Hc), K, _ptr(w), _ptr(row_off.contiguous()), B, N,
+                                                          int(bool(normalize)), _ptr(ds), _ptr(dH), _stream()))
+    return ds, dH
+
+
 def _masked_rows(x, mask, n):
     """x[mask] when the number of selected elements n is already known on the host: no second device-to-host read (boolean indexing
     sizes its result through one)."""

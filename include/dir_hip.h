@@ -949,6 +949,39 @@ int dir_debug_slot_sort_entries(const int64_t* ids, int64_t stride_b, int64_t st
                                 int64_t total_rows, uint32_t* keys_out, uint32_t* vals_out, void* workspace, int64_t workspace_bytes,
                                 dir_stream_t stream);
 
+/* ---- round 5: TRAINING of the DIN unit with PReLU / Dice activations, and of PReLU / Dice layers in general (csrc/din_rows_train.hip) --------
+ * NO REFERENCE CODE (README.md:27 -> arXiv:1706.06978; Dice: section 5.3).  Dice in TRAIN mode normalises with the mini-batch's statistics over
+ * all valid (sample, position) rows, so the unit trains as a chain of whole-batch passes over the compact row list n = (b, j) in (b, j)
+ * order (N rows; row_off [B] = first row of sample b; b_idx [N] = its sample; ids_h [N] = its history id): these entries + the dense /
+ * weight-gradient / batch-norm entries above.  Everything bitwise reproducible (fixed summation orders).
+ *
+ * dir_din_feat_rows_f32: X [N, 3K] = [h_n | h_n * a_b | a_b] (h_n = table[ids_h[n]], a_b = table[cand[b]], zeros for cand < 0) and Hc [N, K] = h_n:
+ *   [h, a, h - a, h * a] W1 + b1 = X [Wh + Wd; Wp; Wa - Wd] + b1.  K a multiple of 4, <= 256.
+ * dir_din_feat_rows_backward_f32: from dX [N, 3K] and dH [N, K]: grows [N + B, K], rows 0..N-1 = dL/dh_n = dX[n, 0:K] + dX[n, K:2K] * a_b + dH[n],
+ *   rows N.. = dL/da_b = sum over the sample's rows (in order) of dX[n, K:2K] * h_n + dX[n, 2K:3K]  (0 for a pruned candidate).
+ * dir_act_rows_train_f32: y = f(s) out of place, s [M, N] (N % 4 == 0, <= 1024): activation DIR_DIN_ACT_PRELU  y = s > 0 ? s : alpha s;
+ *   DIR_DIN_ACT_DICE  y = s (alpha + (1 - alpha) sigmoid(scale s + shift)) with (scale, shift) = (rsqrt(var + eps), -mean scale) of the batch
+ *   (dir_bn_train_stats_f32 without gamma / beta gives them and advances the moving statistics).
+ * dir_act_rows_backward_f32: g = dL/dy -> d1 = g df/ds with the normalised pre-activation held fixed (PReLU: all of dL/ds); Dice: gx = dL/d(normalised
+ *   pre-activation) = g s (1 - alpha) p (1 - p) -- dir_bn_train_backward_f32(gx, s, mean, inv) turns it into the statistics' share, to be
+ *   added to d1; galpha [N] = sum over rows of g * (PReLU: min(s, 0); Dice: s (1 - p)).  partials: dir_act_rows_backward_partials(M, N) * N floats.
+ * dir_din_pool_rows_f32: per sample w = scores of its rows (normalize: softmax of score / sqrt(K)), out [B, K] = sum_n w_n Hc[n]; w [N] is kept.
+ * dir_din_pool_rows_backward_f32: g [B, K] -> ds [N] (through the softmax when normalize) and dH [N, K] = w_n g_b. */
+int dir_din_feat_rows_f32(const float* table, int K, const int64_t* ids_h, const int64_t* b_idx, const int64_t* cand, int64_t N, float* X, float* Hc,
+                          dir_stream_t stream);
+int dir_din_feat_rows_backward_f32(const float* table, int K, const int64_t* ids_h, const int64_t* row_off, const int64_t* cand, int64_t B, int64_t N,
+                                   const float* dX, const float* dH, float* grows, dir_stream_t stream);
+int dir_act_rows_train_f32(const float* s, int64_t s_ld, int64_t M, int N, int activation, const float* alpha, const float* scale, const float* shift,
+                           float* y, int64_t y_ld, dir_stream_t stream);
+int dir_act_rows_backward_partials(int64_t M, int N);
+int dir_act_rows_backward_f32(const float* g, int64_t g_ld, const float* s, int64_t s_ld, int64_t M, int N, int activation, const float* alpha,
+                              const float* scale, const float* shift, float* d1, int64_t d1_ld, float* gx, int64_t gx_ld, float* galpha,
+                              float* partials, int n_partials, dir_stream_t stream);
+int dir_din_pool_rows_f32(const float* scores, const float* Hc, int K, const int64_t* row_off, int64_t B, int64_t N, int normalize, float* w, float* out,
+                          dir_stream_t stream);
+int dir_din_pool_rows_backward_f32(const float* g, const float* Hc, int K, const float* w, const int64_t* row_off, int64_t B, int64_t N, int normalize,
+                                   float* ds, float* dH, dir_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

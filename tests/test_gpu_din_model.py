@@ -195,3 +195,90 @@ def test_din_model_trains(built_lib, att_act):
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("activation", ["prelu", "dice"])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_din_unit_trains_prelu_dice_on_hip_rows(built_lib, activation, normalize):
+    """the PReLU / Dice unit in TRAIN mode on HIP kernels (din.DINAttentionPool._rows_train: Dice with the mini-batch's
+    statistics) against float64 autograd of the torch formulation of the same definition (DINAttentionPool._composite restated in double):
+    the interest vector, dL/dtable (sparse), dL/dW1..b3, dL/dalpha, and the moving statistics Dice advances -- at 5e-5."""
+    from dir_amd.din import DINAttentionPool
+    import dir_amd.din as din_mod
+    dev = torch.device("cuda:0")
+    torch.manual_seed(17)
+    V, K, B, T = 300, 64, 96, 50
+    unit = DINAttentionPool(V, K, (80, 40), normalize=normalize, activation=activation).to(dev).train()
+    with torch.no_grad():
+        unit.b1.normal_(0, 0.1); unit.b2.normal_(0, 0.1); unit.b3.fill_(0.05)
+        unit.act1.alpha.uniform_(0.05, 0.4); unit.act2.alpha.uniform_(0.05, 0.4)
+    ref = DINAttentionPool(V, K, (80, 40), normalize=normalize, activation=activation).to(dev).double().train()
+    ref.load_state_dict({k: v.double() for k, v in unit.state_dict().items()})
+    g = torch.Generator(device=dev).manual_seed(3)
+    hist = torch.randint(-1, V, (B, T), generator=g, device=dev)
+    hl = torch.randint(0, T + 1, (B,), generator=g, device=dev, dtype=torch.int32)
+    hl[0] = 0
+    cand = torch.randint(0, V, (B,), generator=g, device=dev)
+    cand[3] = -1
+    gout = torch.randn((B, K), generator=g, device=dev)
+    assert din_mod.ROWS_TRAIN
+    out = unit(hist, hl, cand)
+    out.backward(gout)
+    rout = ref._composite(hist, hl, cand)
+    rout.backward(gout.double())
+
+    def close(a, b, tol=5e-5, what=""):
+        err = float(((a.double() - b.double()).abs() / (1 + b.double().abs())).max())
+        assert err <= tol, "%s: %.2e" % (what, err)
+    close(out, rout, what="interest vector")
+    close(unit.table.grad.to_dense(), ref.table.grad.to_dense(), what="dL/dtable")
+    for n in ("W1", "b1", "W2", "b2", "W3", "b3"):
+        close(getattr(unit, n).grad, getattr(ref, n).grad, what="dL/d" + n)
+    close(unit.act1.alpha.grad, ref.act1.alpha.grad, what="dL/dalpha1")
+    close(unit.act2.alpha.grad, ref.act2.alpha.grad, what="dL/dalpha2")
+    if activation == "dice":
+        close(unit.act1.moving_mean, ref.act1.moving_mean, what="moving mean")
+        close(unit.act2.moving_variance, ref.act2.moving_variance, what="moving variance")
+    # a second identical step: bitwise the same gradients (fixed summation orders)
+    g1 = [p.grad.clone() if not p.grad.is_sparse else p.grad.coalesce().values().clone() for p in unit.parameters()]
+    unit2 = DINAttentionPool(V, K, (80, 40), normalize=normalize, activation=activation).to(dev).train()
+    sd = {k: v.float() for k, v in ref.state_dict().items()}
+    if activation == "dice":                                   # the moving statistics of BEFORE the step
+        for k in list(sd):
+            if "moving_mean" in k:
+                sd[k] = torch.zeros_like(sd[k])
+            if "moving_variance" in k:
+                sd[k] = torch.ones_like(sd[k])
+    unit2.load_state_dict(sd)
+    unit2(hist, hl, cand).backward(gout)
+    g2 = [p.grad.clone() if not p.grad.is_sparse else p.grad.coalesce().values().clone() for p in unit2.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+
+
+@pytest.mark.parametrize("activation", ["prelu", "dice"])
+def test_act_rows_layers_train_on_hip(built_lib, activation):
+    """autograd.ActRows on a [B, 200] layer output (the DIN model's PReLU / Dice MLP layers in TRAIN mode): forward, dL/ds, dL/dalpha and the
+    moving statistics against float64 autograd of din.Dice / din._PReLU."""
+    from dir_amd import autograd as ag
+    from dir_amd.din import Dice, _PReLU
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    M, N = 4099, 200
+    mod = (Dice(N) if activation == "dice" else _PReLU(N)).to(dev).train()
+    with torch.no_grad():
+        mod.alpha.uniform_(-0.2, 0.5)
+    ref = (Dice(N) if activation == "dice" else _PReLU(N)).to(dev).double().train()
+    ref.load_state_dict({k: v.double() for k, v in mod.state_dict().items()})
+    s = (torch.randn((M, N), device=dev) * 1.5 + 0.3).requires_grad_(True)
+    sd = s.detach().double().requires_grad_(True)
+    gy = torch.randn((M, N), device=dev)
+    y = ag.act_rows(s, mod)
+    y.backward(gy)
+    yr = ref(sd)
+    yr.backward(gy.double())
+    for a, b, what in ((y, yr, "y"), (s.grad, sd.grad, "dL/ds"), (mod.alpha.grad, ref.alpha.grad, "dL/dalpha")):
+        err = float(((a.double() - b).abs() / (1 + b.abs())).max())
+        assert err <= 5e-5, "%s: %.2e" % (what, err)
+    if activation == "dice":
+        assert float((mod.moving_mean.double() - ref.moving_mean).abs().max()) <= 1e-6
+        assert float((mod.moving_variance.double() - ref.moving_variance).abs().max()) <= 1e-6
