@@ -23,42 +23,43 @@ namespace dir {
 // one wave per row, lane = 16-byte piece of the K-wide row (K <= 256, K % 4 == 0); pruned candidate (cand < 0): a = 0
 __global__ __launch_bounds__(256) void din_feat_rows_k(const float* __restrict__ table, int K, const int64_t* __restrict__ ids_h,
                                                         const int64_t* __restrict__ b_idx, const int64_t* __restrict__ cand, int64_t N,
-                                                        float* __restrict__ X /* [N, 3K] */, float* __restrict__ Hc /* [N, K] */) {
-    const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N || 4 * lane >= K) return;
+                                                        float* __restrict__ X /* [N, 3K] */, float* __restrict__ Hc /* [N, K] */, int lpr) {
+    // lpr lanes per row (16 for K <= 64: four rows per wave -- one row per wave left 48 of 64 lanes idle: 749 -> 389 us at 1.7 M rows)
+    const int sub = threadIdx.x % lpr;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
+    if (n >= N || 4 * sub >= K) return;
     const int64_t b = b_idx[n], c = cand[b];
-    const float4 h = *reinterpret_cast<const float4*>(table + ids_h[n] * K + 4 * lane);
-    const float4 a = c >= 0 ? *reinterpret_cast<const float4*>(table + c * K + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* x = X + n * 3 * K + 4 * lane;
+    const float4 h = *reinterpret_cast<const float4*>(table + ids_h[n] * K + 4 * sub);
+    const float4 a = c >= 0 ? *reinterpret_cast<const float4*>(table + c * K + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* x = X + n * 3 * K + 4 * sub;
     *reinterpret_cast<float4*>(x) = h;
     *reinterpret_cast<float4*>(x + K) = make_float4(h.x * a.x, h.y * a.y, h.z * a.z, h.w * a.w);
     *reinterpret_cast<float4*>(x + 2 * K) = a;
-    *reinterpret_cast<float4*>(Hc + n * K + 4 * lane) = h;
+    *reinterpret_cast<float4*>(Hc + n * K + 4 * sub) = h;
 }
 
 // gh_n = dX'[n, 0:K] + dX'[n, K:2K] * a_b + dH_n;   ga_b = sum over the sample's rows of (dX'[n, K:2K] * h_n + dX'[n, 2K:3K])   (rows in order)
 // one wave per SAMPLE (its rows are contiguous: row_off[b] .. row_off[b] + cnt), lane = 16-byte piece; grows = [gh (N rows) | ga (B rows)]
 __global__ __launch_bounds__(256) void din_feat_rows_bwd_k(const float* __restrict__ table, int K, const int64_t* __restrict__ ids_h,
                                                             const int64_t* __restrict__ row_off, const int64_t* __restrict__ cand, int64_t B, int64_t N,
-                                                            const float* __restrict__ dX, const float* __restrict__ dH, float* __restrict__ grows) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B || 4 * lane >= K) return;
+                                                            const float* __restrict__ dX, const float* __restrict__ dH, float* __restrict__ grows, int lpr) {
+    const int sub = threadIdx.x % lpr;                                  // lpr lanes per SAMPLE (16 for K <= 64: four samples per wave)
+    const int64_t b = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
+    if (b >= B || 4 * sub >= K) return;
     const int64_t n0 = row_off[b], n1 = b + 1 < B ? row_off[b + 1] : N, c = cand[b];
-    const float4 a = c >= 0 ? *reinterpret_cast<const float4*>(table + c * K + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = c >= 0 ? *reinterpret_cast<const float4*>(table + c * K + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ga = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t n = n0; n < n1; ++n) {
-        const float* dx = dX + n * 3 * K + 4 * lane;
+        const float* dx = dX + n * 3 * K + 4 * sub;
         const float4 d0 = *reinterpret_cast<const float4*>(dx), d1 = *reinterpret_cast<const float4*>(dx + K), d2 = *reinterpret_cast<const float4*>(dx + 2 * K);
-        const float4 dh = *reinterpret_cast<const float4*>(dH + n * K + 4 * lane);
-        const float4 h = *reinterpret_cast<const float4*>(table + ids_h[n] * K + 4 * lane);
-        *reinterpret_cast<float4*>(grows + n * K + 4 * lane) =
+        const float4 dh = *reinterpret_cast<const float4*>(dH + n * K + 4 * sub);
+        const float4 h = *reinterpret_cast<const float4*>(table + ids_h[n] * K + 4 * sub);
+        *reinterpret_cast<float4*>(grows + n * K + 4 * sub) =
             make_float4(fmaf(d1.x, a.x, d0.x) + dh.x, fmaf(d1.y, a.y, d0.y) + dh.y, fmaf(d1.z, a.z, d0.z) + dh.z, fmaf(d1.w, a.w, d0.w) + dh.w);
         ga.x += fmaf(d1.x, h.x, d2.x); ga.y += fmaf(d1.y, h.y, d2.y); ga.z += fmaf(d1.z, h.z, d2.z); ga.w += fmaf(d1.w, h.w, d2.w);
     }
     if (c < 0) ga = make_float4(0.f, 0.f, 0.f, 0.f);                 // a pruned candidate contributed the zero vector: no gradient
-    *reinterpret_cast<float4*>(grows + (N + b) * K + 4 * lane) = ga;
+    *reinterpret_cast<float4*>(grows + (N + b) * K + 4 * sub) = ga;
 }
 
 // ---- PReLU / Dice over rows, training form ------------------------------------------------------------------------------------------------------
@@ -155,13 +156,23 @@ __global__ __launch_bounds__(256) void act_rows_bwd_k(const float* __restrict__ 
     }
 }
 
-// galpha[c] = sum over blocks (in block order, fp64) of part[block][c]
+// galpha[c] = sum of part[block][c] over the blocks: 16 columns per workgroup, thread (q, c) adds blocks q, q + 16, .. in order (fp64), the 16
+// partial sums are added in q order -- a fixed order.  (One thread walking all 2048 blocks of a column: 650 us per call.)
 __global__ __launch_bounds__(256) void act_rows_alpha_fin_k(const float* __restrict__ part, int nblocks, int N, float* __restrict__ galpha) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ double red[16][16];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += (double)part[(int64_t)b * N + c];
-    galpha[c] = (float)t;
+    if (c < N)
+        for (int b = q; b < nblocks; b += 16) t += (double)part[(int64_t)b * N + c];
+    red[q][cl] = t;
+    __syncthreads();
+    if (q == 0 && c < N) {
+        double u = red[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) u += red[k][cl];
+        galpha[c] = (float)u;
+    }
 }
 
 // ---- pooling over a sample's rows ------------------------------------------------------------------------------------------------------------------
@@ -169,71 +180,75 @@ __global__ __launch_bounds__(256) void act_rows_alpha_fin_k(const float* __restr
 // An empty sample: zeros.  w is written for the backward.
 __global__ __launch_bounds__(256) void din_pool_rows_k(const float* __restrict__ sc, const float* __restrict__ Hc, int K, const int64_t* __restrict__ row_off,
                                                         int64_t B, int64_t N, int normalize, float inv_sqrt_k, float* __restrict__ w,
-                                                        float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int64_t n0 = row_off[b], n1 = b + 1 < B ? row_off[b + 1] : N;
+                                                        float* __restrict__ out, int lpr) {
+    const int sub = threadIdx.x % lpr;                                  // lpr lanes per sample (16 for K <= 64: four samples per wave)
+    const int64_t b = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const bool live = b < B;
+    const int64_t n0 = live ? row_off[b] : 0, n1 = live ? (b + 1 < B ? row_off[b + 1] : N) : 0;
     float mx = -INFINITY, inv_l = 1.f;
-    if (normalize) {
-        for (int64_t n = n0 + lane; n < n1; n += 64) mx = fmaxf(mx, sc[n] * inv_sqrt_k);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (normalize) {                                                    // (the group's shuffles: every lane of the wave takes part, dead groups with empty ranges)
+        for (int64_t n = n0 + sub; n < n1; n += lpr) mx = fmaxf(mx, sc[n] * inv_sqrt_k);
+        for (int o = lpr >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         float l = 0.f;
-        for (int64_t n = n0 + lane; n < n1; n += 64) l += __expf(sc[n] * inv_sqrt_k - mx);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+        for (int64_t n = n0 + sub; n < n1; n += lpr) l += __expf(sc[n] * inv_sqrt_k - mx);
+        for (int o = lpr >> 1; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
         inv_l = l > 0.f ? 1.f / l : 0.f;
     }
+    if (!live) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool col = 4 * lane < K;
+    const bool col = 4 * sub < K;
     for (int64_t n = n0; n < n1; ++n) {
         const float wn = normalize ? __expf(sc[n] * inv_sqrt_k - mx) * inv_l : sc[n];
-        if (lane == 0) w[n] = wn;
+        if (sub == 0) w[n] = wn;
         if (col) {
-            const float4 h = *reinterpret_cast<const float4*>(Hc + n * K + 4 * lane);
+            const float4 h = *reinterpret_cast<const float4*>(Hc + n * K + 4 * sub);
             acc.x = fmaf(wn, h.x, acc.x); acc.y = fmaf(wn, h.y, acc.y); acc.z = fmaf(wn, h.z, acc.z); acc.w = fmaf(wn, h.w, acc.w);
         }
     }
-    if (col) *reinterpret_cast<float4*>(out + b * K + 4 * lane) = acc;
+    if (col) *reinterpret_cast<float4*>(out + b * K + 4 * sub) = acc;
 }
 
 // backward: dw_n = g_b . h_n;  normalize: ds_n = w_n (dw_n - sum_m w_m dw_m) / sqrt(K), else ds_n = dw_n;  dH_n = w_n g_b
 __global__ __launch_bounds__(256) void din_pool_rows_bwd_k(const float* __restrict__ g, const float* __restrict__ Hc, int K, const float* __restrict__ w,
                                                             const int64_t* __restrict__ row_off, int64_t B, int64_t N, int normalize, float inv_sqrt_k,
-                                                            float* __restrict__ ds, float* __restrict__ dH) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int64_t n0 = row_off[b], n1 = b + 1 < B ? row_off[b + 1] : N;
-    const bool col = 4 * lane < K;
-    const float4 gb = col ? *reinterpret_cast<const float4*>(g + b * K + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                                                            float* __restrict__ ds, float* __restrict__ dH, int lpr) {
+    const int sub = threadIdx.x % lpr;
+    const int64_t b = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
+    const bool live = b < B;
+    const int64_t n0 = live ? row_off[b] : 0, n1 = live ? (b + 1 < B ? row_off[b + 1] : N) : 0;
+    // the four groups of a wave walk their own samples: the loop runs to the LONGEST of them so that every lane reaches the shuffles
+    int64_t cnt = n1 - n0;
+    for (int o = 32; o >= lpr; o >>= 1) cnt = max(cnt, (int64_t)__shfl_xor((long long)cnt, o, 64));
+    const bool col = live && 4 * sub < K;
+    const float4 gb = col ? *reinterpret_cast<const float4*>(g + b * K + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
     // two walks over the sample's rows (the second one's reads hit L2): first t = sum_m w_m dw_m and dH, then ds -- no value is handed from
     // one lane to the others through memory
     float t = 0.f;
-    for (int64_t n = n0; n < n1; ++n) {
+    for (int64_t i = 0; i < cnt; ++i) {
+        const int64_t n = n0 + i;
+        const bool in = n < n1;
         float d = 0.f;
-        const float wn = w[n];
-        if (col) {
-            const float4 h = *reinterpret_cast<const float4*>(Hc + n * K + 4 * lane);
+        const float wn = in ? w[n] : 0.f;
+        if (col && in) {
+            const float4 h = *reinterpret_cast<const float4*>(Hc + n * K + 4 * sub);
             d = (gb.x * h.x + gb.y * h.y) + (gb.z * h.z + gb.w * h.w);
-            *reinterpret_cast<float4*>(dH + n * K + 4 * lane) = make_float4(wn * gb.x, wn * gb.y, wn * gb.z, wn * gb.w);
+            *reinterpret_cast<float4*>(dH + n * K + 4 * sub) = make_float4(wn * gb.x, wn * gb.y, wn * gb.z, wn * gb.w);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-        if (!normalize && lane == 0) ds[n] = d;
+        for (int o = lpr >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (!normalize && in && sub == 0) ds[n] = d;
         t = fmaf(wn, d, t);
     }
     if (normalize) {
-        for (int64_t n = n0; n < n1; ++n) {
+        for (int64_t i = 0; i < cnt; ++i) {
+            const int64_t n = n0 + i;
+            const bool in = n < n1;
             float d = 0.f;
-            if (col) {
-                const float4 h = *reinterpret_cast<const float4*>(Hc + n * K + 4 * lane);
+            if (col && in) {
+                const float4 h = *reinterpret_cast<const float4*>(Hc + n * K + 4 * sub);
                 d = (gb.x * h.x + gb.y * h.y) + (gb.z * h.z + gb.w * h.w);
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-            if (lane == 0) ds[n] = w[n] * (d - t) * inv_sqrt_k;
+            for (int o = lpr >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (in && sub == 0) ds[n] = w[n] * (d - t) * inv_sqrt_k;
         }
     }
 }
@@ -249,7 +264,8 @@ extern "C" int dir_din_feat_rows_f32(const float* table, int K, const int64_t* i
     if (N == 0) return DIR_OK;
     DIR_CHECK_ARG(table && ids_h && b_idx && cand && X && Hc, "%s: null pointer", name);
     if (!aligned16(table) || !aligned16(X) || !aligned16(Hc)) return fail(DIR_E_BADARG, "%s: table / X / Hc must be 16-byte aligned", name);
-    hipLaunchKernelGGL(din_feat_rows_k, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, as_stream(stream), table, K, ids_h, b_idx, cand, N, X, Hc);
+    const int lpr = K <= 64 ? 16 : 64;
+    hipLaunchKernelGGL(din_feat_rows_k, dim3((unsigned)((N * lpr + 255) / 256)), dim3(256), 0, as_stream(stream), table, K, ids_h, b_idx, cand, N, X, Hc, lpr);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
@@ -261,8 +277,9 @@ extern "C" int dir_din_feat_rows_backward_f32(const float* table, int K, const i
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(table && row_off && cand && grows && (N == 0 || (ids_h && dX && dH)), "%s: null pointer", name);
     if (!aligned16(table) || !aligned16(dX) || !aligned16(dH) || !aligned16(grows)) return fail(DIR_E_BADARG, "%s: operands must be 16-byte aligned", name);
-    hipLaunchKernelGGL(din_feat_rows_bwd_k, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, as_stream(stream), table, K, ids_h, row_off, cand, B, N, dX, dH,
-                       grows);
+    const int lpr = K <= 64 ? 16 : 64;
+    hipLaunchKernelGGL(din_feat_rows_bwd_k, dim3((unsigned)((B * lpr + 255) / 256)), dim3(256), 0, as_stream(stream), table, K, ids_h, row_off, cand, B, N, dX,
+                       dH, grows, lpr);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
@@ -319,7 +336,7 @@ extern "C" int dir_act_rows_backward_f32(const float* g, int64_t g_ld, const flo
     else
         hipLaunchKernelGGL(act_rows_bwd_k<2>, dim3((unsigned)n_partials), dim3(256), 0, st, g, g_ld, s, s_ld, M, N, alpha, scale, shift, rpb, d1, d1_ld, gx,
                            gx_ld, partials);
-    hipLaunchKernelGGL(act_rows_alpha_fin_k, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partials, n_partials, N, galpha);
+    hipLaunchKernelGGL(act_rows_alpha_fin_k, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, st, partials, n_partials, N, galpha);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
@@ -331,8 +348,9 @@ extern "C" int dir_din_pool_rows_f32(const float* scores, const float* Hc, int K
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(row_off && out && (N == 0 || (scores && Hc && w)), "%s: null pointer", name);
     if (!aligned16(Hc) || !aligned16(out)) return fail(DIR_E_BADARG, "%s: Hc / out must be 16-byte aligned", name);
-    hipLaunchKernelGGL(din_pool_rows_k, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, as_stream(stream), scores, Hc, K, row_off, B, N, normalize ? 1 : 0,
-                       1.0f / sqrtf((float)K), w, out);
+    const int lpr = K <= 64 ? 16 : 64;
+    hipLaunchKernelGGL(din_pool_rows_k, dim3((unsigned)((B * lpr + 255) / 256)), dim3(256), 0, as_stream(stream), scores, Hc, K, row_off, B, N,
+                       normalize ? 1 : 0, 1.0f / sqrtf((float)K), w, out, lpr);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
@@ -344,8 +362,9 @@ extern "C" int dir_din_pool_rows_backward_f32(const float* g, const float* Hc, i
     if (B == 0 || N == 0) return DIR_OK;
     DIR_CHECK_ARG(g && Hc && w && row_off && ds && dH, "%s: null pointer", name);
     if (!aligned16(g) || !aligned16(Hc) || !aligned16(dH)) return fail(DIR_E_BADARG, "%s: g / Hc / dH must be 16-byte aligned", name);
-    hipLaunchKernelGGL(din_pool_rows_bwd_k, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, as_stream(stream), g, Hc, K, w, row_off, B, N, normalize ? 1 : 0,
-                       1.0f / sqrtf((float)K), ds, dH);
+    const int lpr = K <= 64 ? 16 : 64;
+    hipLaunchKernelGGL(din_pool_rows_bwd_k, dim3((unsigned)((B * lpr + 255) / 256)), dim3(256), 0, as_stream(stream), g, Hc, K, w, row_off, B, N,
+                       normalize ? 1 : 0, 1.0f / sqrtf((float)K), ds, dH, lpr);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
