@@ -151,6 +151,7 @@ SIGNATURES = {
     "dir_cin_dw_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_grad_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_rows_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dir_cin_layer_auto_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_cin_dw_sym_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_dot_add_f16x2_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "dir_cin_layer_dot_add_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),

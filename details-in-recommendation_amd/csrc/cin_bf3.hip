@@ -140,11 +140,45 @@ __device__ __forceinline__ int w_scale_exp(const float* __restrict__ part) {    
 }
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned int)(127 + k) << 23); }     // |k| <= 126
 
+// The VERDICT of a forward layer whose producer left xk's row maxima (round 5): when max |xk| sits in [2^-4, 2^15) -- where splitting the rows
+// unscaled loses nothing that matters (an element below 2^-3 keeps an absolute 2^-25, at most 2^-21 of the tensor's largest) -- the plain kernel
+// runs (8-9 % faster than the row-scaled form: no scan of the rows, profiles/r05_cin_rs_probe.txt), otherwise the row-scaled one.  W is
+// scaled by its tensor power of two in BOTH (typical CIN weights sit around 2^-5: unscaled they cost the plain form a factor ten in accuracy).
+// Decided ON THE DEVICE from the partial maxima (wpart [WPARTS] then xpart [XPARTS], contiguous): both kernels are launched, each leaves at
+// once unless the verdict names it.  No host read, graph-capturable.
+constexpr int XPARTS = 256;
+__global__ __launch_bounds__(256) void cin_bits_absmax_k(const unsigned int* __restrict__ bits, int64_t n, float* __restrict__ xpart) {
+    __shared__ unsigned int red[4];
+    unsigned int mx = 0u;                                     // bit patterns of non-negative floats order like the floats
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) mx = max(mx, bits[e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) xpart[blockIdx.x] = __builtin_bit_cast(float, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+__device__ __forceinline__ bool cin_plain_verdict(const float* __restrict__ vparts) {      // wave-uniform; every lane of the wave calls it
+    const int lane = threadIdx.x & 63;
+    float wm = lane < WPARTS ? vparts[lane] : 0.f, xm = 0.f;
+#pragma unroll
+    for (int q = 0; q < XPARTS / 64; ++q) xm = fmaxf(xm, vparts[WPARTS + 64 * q + lane]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+        xm = fmaxf(xm, __shfl_xor(xm, o, 64));
+    }
+    (void)wm;            // W is scaled in BOTH forms (the pack kernel's tensor scale costs nothing; the plain kernel takes 2^-kw out of its
+                         // accumulators in the epilogue): only the row operand's magnitude decides
+    return xm >= 0x1p-4f && xm < 0x1p15f;
+}
+
 template <int NP>
 __global__ __launch_bounds__(256) void cin_bf3_pack_w_k(const float* __restrict__ W, int m, int Hp, int H, int KS, int nkh, int ncb, int CT,
-                                                        int hoff, unsigned int* __restrict__ img, const float* __restrict__ wpart = nullptr) {
+                                                        int hoff, unsigned int* __restrict__ img, const float* __restrict__ wpart = nullptr,
+                                                        int verdict = 0 /* 1: wpart is followed by xpart, and a "plain" verdict leaves W unscaled */) {
     const int64_t total = (int64_t)ncb * nkh * m * KS * CT * 64 * 4;   // one thread per pair of e
     const int stepdw = NP * CT * 64 * 4;                               // dwords per k-step
+    (void)verdict;                                                     // (W is scaled under either verdict)
     const float wsc = wpart ? pow2f(w_scale_exp(wpart)) : 1.f;
     for (int64_t e_ = (int64_t)blockIdx.x * 256 + threadIdx.x; e_ < total; e_ += (int64_t)gridDim.x * 256) {
         int64_t q = e_;
@@ -199,7 +233,11 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      const unsigned int* __restrict__ xk_bits = nullptr /* RS, optional [R]: bit pattern of max_i |xk[r, i]|, left by
                                                                                                           the kernel that produced xk: no scan of the rows in the prologue */,
                                                      unsigned int* __restrict__ xout_bits = nullptr /* optional [R]: the same of THIS launch's output rows (the launch
-                                                                                                       must cover all H columns: one column block) */) {
+                                                                                                       must cover all H columns: one column block) */,
+                                                     int vwant = -1 /* 1 / 0: wpart is followed by xpart; run only under the plain / the row-scaled verdict */) {
+    if (vwant >= 0) {                                              // (before anything else: the kernel the verdict does not name costs an empty launch)
+        if (cin_plain_verdict(wpart) != (vwant == 1)) return;
+    }
     using Pc = BtPc<NP>;
     using op_t = typename Pc::op_t;
     static_assert(NP == 3 || !DOT || RS, "the data-gradient form on fp16 x 2 needs the row-scaled left operand");
@@ -521,6 +559,15 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         if constexpr (DOT) store_dot(sd, nkh - 1, m - 1);
     }
 
+    if constexpr (!RS && NP == 2 && !DOT && !PAIRS) {
+        if (vwant == 1) {                                           // (uniform) the plain kernel under the verdict: the image carries W's tensor scale
+            const float winv = pow2f(-w_scale_exp(wpart));
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) out[rt][ct] *= winv;
+        }
+    }
     // ---- epilogue: C/D map of 16x16x32: col = lane & 15, row = 4*(lane >> 4) + reg
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -602,7 +649,7 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     if (m <= 0 || Hp <= 0 || H <= 0) return 0;
     const Bf3Plan p = bf3_plan(m, Hp, H, false), q = bf3_plan(m, Hp, H, true);      // either form of the layer
     const int64_t a = p.bytes_full + p.bytes_last, b = q.bytes_full + q.bytes_last;
-    return (a > b ? a : b) + 256;                   // + the WPARTS partial maxima of W behind the image (the row-scaled fp16 x 2 forms)
+    return (a > b ? a : b) + 128 + 4 * (WPARTS + XPARTS);      // + the partial maxima of W (and of xk's row maxima: the verdict) behind the image
 }
 
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: 64-column blocks, two fields per chunk, dot partials)
@@ -610,7 +657,8 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
                    float* pooled, int64_t pooled_ld, const float* y, float* dotp, void* workspace, int64_t workspace_bytes, dir_stream_t stream,
                    const float* addp = nullptr, int64_t addp_ld = 0, int np = 3 /* 2: fp16 x 2 */,
                    bool rs = false /* fp16 x 2 with the left operand scaled per row (a gradient) */, unsigned int* amax_out = nullptr,
-                   const unsigned int* xk_bits = nullptr, unsigned int* xout_bits = nullptr) {
+                   const unsigned int* xk_bits = nullptr, unsigned int* xout_bits = nullptr,
+                   const unsigned int* verdict_bits = nullptr /* rs forward: xk's row maxima [B * D] -> the device-side plain / row-scaled verdict */) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -635,11 +683,13 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     // rs: W is scaled too (one power of two for the tensor): its partial maxima sit behind the image
     float* wpart = rs ? reinterpret_cast<float*>(img + ((pl.bytes_full + pl.bytes_last + 127) & ~(int64_t)127)) : nullptr;
     if (rs) hipLaunchKernelGGL(cin_w_absmax_k, dim3(WPARTS), dim3(256), 0, st, W, (int64_t)H * Hp * m, wpart);
+    const int verdict = (rs && verdict_bits && !dot) ? 1 : 0;
+    if (verdict) hipLaunchKernelGGL(cin_bits_absmax_k, dim3(XPARTS), dim3(256), 0, st, verdict_bits, R, wpart + WPARTS);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
         const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
         if (np == 2)
             hipLaunchKernelGGL(cin_bf3_pack_w_k<2>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
-                               reinterpret_cast<unsigned int*>(dst), wpart);
+                               reinterpret_cast<unsigned int*>(dst), wpart, verdict);
         else
             hipLaunchKernelGGL(cin_bf3_pack_w_k<3>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, m, Hp, H, pl.KS, pl.nkh, ncb, CT, hoff,
                                reinterpret_cast<unsigned int*>(dst));
@@ -655,7 +705,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                             \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
                            dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr, wpart, \
-                           xk_bits, xout_bits);                                                                                       \
+                           xk_bits, xout_bits, verdict ? ((RS_) ? 0 : 1) : -1);                                                       \
     } while (0)
 #define BT_LAUNCH_KS(C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                       \
     do {                                                                                 \
@@ -664,6 +714,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     } while (0)
 #define BT_LAUNCH_FWD(C, NCB, HOFF, IMG)                                                 \
     do {                                                                                 \
+        if (verdict) BT_LAUNCH_KS(C, false, 1, 2, false, NCB, HOFF, IMG, nullptr);       \
         if (rs) BT_LAUNCH_KS(C, false, 1, 2, true, NCB, HOFF, IMG, nullptr);             \
         else if (np == 2) BT_LAUNCH_KS(C, false, 1, 2, false, NCB, HOFF, IMG, nullptr);  \
         else BT_LAUNCH_KS(C, false, 1, 3, false, NCB, HOFF, IMG, nullptr);               \
@@ -733,6 +784,16 @@ extern "C" int dir_cin_layer_rows_f16x2_f32(const float* x0, const float* xk, co
                                             const unsigned int* xk_row_bits, unsigned int* xout_row_bits, dir_stream_t stream) {
     return bf3_run("dir_cin_layer_rows_f16x2_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace,
                    workspace_bytes, stream, nullptr, 0, 2, true, nullptr, xk_row_bits, xout_row_bits);
+}
+
+// ... with the DEVICE-SIDE verdict (see cin_plain_verdict): xk_row_bits is required (the producer's row maxima); inside the window the plain
+// fp16 x 2 kernel does the work, outside it the row-scaled one -- both are launched, one of them leaves at once.  xout_row_bits as above.
+extern "C" int dir_cin_layer_auto_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B,
+                                            float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                            const unsigned int* xk_row_bits, unsigned int* xout_row_bits, dir_stream_t stream) {
+    DIR_CHECK_ARG(xk_row_bits || B == 0, "dir_cin_layer_auto_f16x2_f32: xk_row_bits is null (dir_cin_layer_rows_f16x2_f32 takes no verdict)");
+    return bf3_run("dir_cin_layer_auto_f16x2_f32", x0, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace,
+                   workspace_bytes, stream, nullptr, 0, 2, true, nullptr, nullptr, xout_row_bits, xk_row_bits);
 }
 
 // ---- the first layer over field pairs (PAIRS) -----------------------------------------------------------------------------------------------

@@ -1610,11 +1610,12 @@ def cin_auto_arith(m, D, Hp, H):
     return "bf16x3" if hpad * ipad <= 1.8 * H * Hp else "f32"
 
 
-# The forward layers can hand their output's row maxima to the next layer (dir_cin_layer1_bits_f16x2_f32 -> dir_cin_layer_rows_f16x2_f32's
-# xk_row_bits: no scan of xk in the prologue).  Measured SLOWER than scanning (2.31-2.43 against 2.20-2.33 ms for the 128 x 128 layer at
-# B = 65 536, profiles/r05_cin_rs_probe.txt): the scan doubles as a prefetch burst of the workgroup's xk slice, whose loads the main loop
-# otherwise waits for twice.  Off by default; kept (and tested) as an entry-point feature.
-CIN_ROW_BITS_CARRY = os.environ.get("DIR_CIN_ROW_BITS_CARRY", "0") == "1"
+# The forward layers leave their output's row maxima on the tensor (dir_cin_layer1_bits_f16x2_f32, xout_row_bits).  The next layer does NOT
+# read them instead of scanning its rows (measured slower: 2.31-2.43 against 2.20-2.33 ms for the 128 x 128 layer at B = 65 536,
+# profiles/r05_cin_rs_probe.txt: the scan doubles as a prefetch burst of the workgroup's xk slice); it uses them for the DEVICE-SIDE VERDICT
+# of dir_cin_layer_auto_f16x2_f32: inside the magnitude window where the unscaled split is as accurate, the plain kernel runs (2.03-2.13 ms),
+# outside it the row-scaled one.  DIR_CIN_ROW_BITS_CARRY=0: no maxima are left, every later layer runs the row-scaled kernel.
+CIN_ROW_BITS_CARRY = os.environ.get("DIR_CIN_ROW_BITS_CARRY", "1") != "0"
 CIN_L1_PAIRS = os.environ.get("DIR_CIN_L1_PAIRS", "1") != "0"      # development switch: 0 runs a stack's first layer on the general kernel
 CIN_POOLED_LAST = os.environ.get("DIR_CIN_POOLED_LAST", "1") != "0"  # development switch: 0 runs a pooled-only layer on the layer kernel
 
@@ -1765,8 +1766,12 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
         if arith == "f16x2_grad" and not grad_operand and g_bits_out is None:
             # a FORWARD layer on the row-scaled kernel: the producer's row maxima in, this layer's out
             ib = _row_bits_hint(xk, B * D) if CIN_ROW_BITS_CARRY else None
-            _lib.check(lib.dir_cin_layer_rows_f16x2_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled),
-                                                        pooled.stride(0), _ptr(ws), nbytes, _ptr(ib), _ptr(ob), _stream()))
+            if ib is not None and B > 0:        # the producer's row maxima: the plain / row-scaled verdict is taken on the device
+                _lib.check(lib.dir_cin_layer_auto_f16x2_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled),
+                                                            pooled.stride(0), _ptr(ws), nbytes, _ptr(ib), _ptr(ob), _stream()))
+            else:
+                _lib.check(lib.dir_cin_layer_rows_f16x2_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled),
+                                                            pooled.stride(0), _ptr(ws), nbytes, None, _ptr(ob), _stream()))
             if ob is not None:
                 xout._dir_row_bits = (ob, xout._version)
             return xout, pooled

@@ -331,6 +331,15 @@ int dir_cin_layer_grad_f16x2_f32(const float* x0, const float* xk, const float* 
 int dir_cin_layer_rows_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                                  float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, const unsigned int* xk_row_bits,
                                  unsigned int* xout_row_bits, dir_stream_t stream);
+/* dir_cin_layer_auto_f16x2_f32: the forward layer with a DEVICE-SIDE verdict between the plain fp16 x 2 kernel (dir_cin_layer_f16x2_f32's) and
+ * the row-scaled one: xk_row_bits (required: the producer's row maxima, dir_cin_layer1_bits_f16x2_f32 / xout_row_bits of these entries) and W are
+ * reduced to their largest magnitudes by two small kernels; with max |xk| in [2^-4, 2^15) -- where splitting the rows unscaled loses nothing
+ * that matters -- the plain kernel does the work (8-9 % faster: no scan of the rows), outside it the row-scaled kernel; W carries its tensor
+ * scale in both; both kernels are launched and the one the verdict does not name leaves at once.  No host read: capturable in a HIP graph.
+ * Results are those of whichever kernel ran (each bitwise reproducible). */
+int dir_cin_layer_auto_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
+                                 float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, const unsigned int* xk_row_bits,
+                                 unsigned int* xout_row_bits, dir_stream_t stream);
 int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D, int64_t B,
                                     const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
                                     int64_t workspace_bytes, unsigned int* xk_absmax_bits_out, dir_stream_t stream);

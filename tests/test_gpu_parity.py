@@ -262,9 +262,22 @@ def test_cin_layer(ops, oracle, B, m, D, Hp, H):
             assert torch.equal(cx, ax) and torch.equal(cp, ap)
             assert bits is not None and torch.equal(bits.view(B, D), cx.abs().amax(dim=1).view(torch.int32))
             if Hp == H:
-                nx, np_ = ops.cin_layer(_dev(x0), cx, _dev(W))              # the next layer reads them instead of scanning cx
-                sx2, sp2 = ops.cin_layer(_dev(x0), cx.clone(), _dev(W))
-                assert torch.equal(nx, sx2) and torch.equal(np_, sp2)
+                # the next layer takes its device-side verdict from them (dir_cin_layer_auto_f16x2_f32): inside the magnitude window the
+                # plain fp16 x 2 kernel's bits, outside it the row-scaled kernel's
+                nx, np_ = ops.cin_layer(_dev(x0), cx, _dev(W))
+                xmax = float(cx.abs().max())
+                if 2.0 ** -4 <= xmax < 2.0 ** 15:        # the plain kernel on the tensor-scaled W image: its own bits, at the same bar
+                    _close(nx.cpu().numpy(), oracle.cin_layer(x0, cx.cpu().numpy(), W, acc64=True)[0])
+                    nx2, _ = ops.cin_layer(_dev(x0), cx, _dev(W))
+                    assert torch.equal(nx, nx2)
+                else:
+                    ex, ep = ops.cin_layer(_dev(x0), cx.clone(), _dev(W), arith="f16x2_grad")
+                    assert torch.equal(nx, ex) and torch.equal(np_, ep)
+                big = cx * 2.0 ** 20                                        # outside the window: the row-scaled kernel, the same rows' maxima scaled
+                big._dir_row_bits = (bits + (20 << 23), big._version)
+                bx, _ = ops.cin_layer(_dev(x0), big, _dev(W))
+                rx2, _ = ops.cin_layer(_dev(x0), big.clone(), _dev(W), arith="f16x2_grad")
+                assert torch.equal(bx, rx2) and bool(torch.isfinite(bx).all())
         finally:
             ops.CIN_ROW_BITS_CARRY = keep
     # a gradient as the left operand never takes the PLAIN fp16 split: it runs the row-scaled form (dir_cin_layer_grad_f16x2_f32: every row
