@@ -1501,6 +1501,29 @@ def main():
                         sweep.append({"batch": Bs, "avg_launch_us": us, "achieved_GBps": gb, "frac": gb / HBM_PEAK_GBS})
                         del sids, so, sfm
                     res["roofline"]["batch_sweep"] = sweep
+                    # (d) why the 4 x B point is 10-12 % slower per row: the [B, 416] output.  One 109 MB buffer overwritten
+                    # by every launch lives in the 256 MiB Infinity Cache (behind L2: invisible to the L2 <-> fabric counters), so most of its
+                    # write-back never reaches HBM; rotate the output through 4 buffers (436 MB written before a line is reused, what the
+                    # 4 x B launch does by itself) and the same kernel at the same B pays for it (tools/gather_out_window_probe.py).
+                    ow = []
+                    for nb_ in (1, 4):
+                        outs_ = [torch.empty((B, F * K), dtype=torch.float32, device=device) for _ in range(nb_)]
+                        run_o = (lambda i: ops.gather_fm(ts, idsl[i % len(idsl)], out=outs_[i % nb_], fm=fm)) if wl == "deepfm_gather_fm" else \
+                                (lambda i: ops.embedding_bag(ts, idsl[i % len(idsl)], out=outs_[i % nb_]))
+                        for i in range(8):
+                            run_o(i)
+                        torch.cuda.synchronize()
+                        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s0.record()
+                        for i in range(40):
+                            run_o(i)
+                        s1.record()
+                        torch.cuda.synchronize()
+                        us = s0.elapsed_time(s1) * 1e3 / 40
+                        ow.append({"out_buffers": nb_, "MB_written_before_reuse": round(nb_ * B * F * K * 4 / 1e6), "avg_launch_us": us,
+                                   "frac": roof["alg_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                        del outs_
+                    res["roofline"]["output_window"] = ow
         else:
             # achieved = the algorithmic flops of each kernel priced on the pipe mode it executes on (PIPE_COST), in bf16-MFMA flops per
             # second, against the dense bf16 peak: the share of the step the matrix pipe needs at peak
