@@ -304,10 +304,12 @@ class DinAttentionPool(torch.autograd.Function):
         if fused and B > 0 and _DIN_SAVE_ACTIVATIONS:
             # the forward leaves z1 / z2 of every history row in a workspace this node owns: the backward recomputes nothing
             out, scores, ctx.saved_state = ops.din_attention_pool_save(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(),
-                                                                       W2.detach(), b2.detach(), W3.detach(), b3.detach(), normalize=normalize)
+                                                                       W2.detach(), b2.detach(), W3.detach(), b3.detach(), normalize=normalize,
+                                                                       range_of=(table, W1, W2, W3))
         else:
             res = ops.din_attention_pool(table.detach(), hist, hist_len, cand, W1.detach(), b1.detach(), W2.detach(),
-                                         b2.detach(), W3.detach(), b3.detach(), normalize=normalize, want_scores=fused)
+                                         b2.detach(), W3.detach(), b3.detach(), normalize=normalize, want_scores=fused,
+                                         range_of=(table, W1, W2, W3))
             out, scores = res if fused else (res, None)   # the attention weights [B, T] feed the backward (no softmax recompute)
         ctx.has_scores = scores is not None
         ctx.save_for_backward(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, *([scores] if scores is not None else []))

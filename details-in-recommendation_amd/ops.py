@@ -519,9 +519,12 @@ def din_arith(table, weights, arith=None):
 
 
 def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, want_scores=False, activation="sigmoid",
-                       act_params=None, arith=None):
+                       act_params=None, arith=None, range_of=None):
     """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T]).  activation "prelu" / "dice": the
-    paper's own hidden activations (dir_din_attention_pool_act_f32; act_params from din_act_params).  arith: see din_arith."""
+    paper's own hidden activations (dir_din_attention_pool_act_f32; act_params from din_act_params).  arith: see din_arith.
+    range_of: (table, W1, W2, W3) as the LONG-LIVED tensors whose magnitudes din_arith measures and remembers per version -- a module passes
+    its nn.Parameters here and `.data` views as operands (a `.data` view is a new tensor object with its own version counter on every
+    call: measured afresh each time, a 2.56 GB pass for the cfg-4 table)."""
     _dev(table, torch.float32, "table")
     _dev(hist, torch.int64, "hist")
     _dev(cand, torch.int64, "cand")
@@ -551,7 +554,8 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
         if act_params is None or act_params.numel() != 3 * H1 + 3 * H2:
             raise ValueError("DIN %s unit: act_params must hold 3 H1 + 3 H2 floats (ops.din_act_params)" % activation)
         ap = _dev(act_params.contiguous(), torch.float32, "act_params")
-    code = din_arith(table, (W1, W2, W3), arith) if B > 0 else -1
+    rsrc = range_of if range_of is not None else (table, W1, W2, W3)
+    code = din_arith(rsrc[0], rsrc[1:], arith) if B > 0 else -1
     _lib.check(_lib.load().dir_din_attention_pool_arith_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
                                                             _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
                                                             H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)),
@@ -675,7 +679,7 @@ class DinTrainPlan:
         self.N, self.n_tiles = (int(v) for v in torch.stack([incl[-1], tincl[-1]]).tolist()) if B else (0, 0)     # the one host read
 
 
-def din_attention_pool_save(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, plan=None):
+def din_attention_pool_save(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, plan=None, range_of=None):
     """Training forward of the (K 64, H1 <= 80, H2 <= 48, T <= 64) unit (include/dir_hip.h: dir_din_attention_pool_save_f32): as
     din_attention_pool(..., want_scores=True), and every history row's hidden activations stay in a workspace for
     din_attention_pool_backward(..., saved=...), which then recomputes nothing.  -> out, scores, (plan, workspace)."""
@@ -706,7 +710,8 @@ def din_attention_pool_save(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3,
     ws = torch.empty(need, dtype=torch.uint8, device=table.device)       # owned by this call's autograd node until its backward ran
     out = torch.empty((B, K), dtype=torch.float32, device=table.device)
     scores = torch.empty((B, T), dtype=torch.float32, device=table.device)
-    code = din_arith(table, (W1, W2, W3)) if B > 0 else -1
+    rsrc = range_of if range_of is not None else (table, W1, W2, W3)
+    code = din_arith(rsrc[0], rsrc[1:]) if B > 0 else -1
     _lib.check(lib.dir_din_attention_pool_save_arith_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1,
                                                          _ptr(args[2]), _ptr(args[3]), H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)), code, B,
                                                          _ptr(out), _ptr(scores), _ptr(plan.tile_off), plan.n_tiles, _ptr(ws), need, _stream()))
