@@ -515,3 +515,22 @@ def test_export_tf_checkpoint_with_parameter_server_partitions(tmp_path, built_l
     assert not missing and step == 3
     for a, b in zip(model.parameters(), other.parameters()):
         assert torch.equal(a, b)
+
+
+def test_round5_routing_rules():
+    """Host-side rules added in round 5 (no GPU): the unscaled fp16 x 2 window, the small-batch dense rule, the stale-measurement policy."""
+    from dir_amd import ops
+    assert ops.f16_range_ok(0.0) and ops.f16_range_ok(1.0) and ops.f16_range_ok(2.0 ** -6) and ops.f16_range_ok(2.0 ** 15 - 1)
+    assert not ops.f16_range_ok(2.0 ** 15) and not ops.f16_range_ok(65504.0) and not ops.f16_range_ok(2.0 ** -7) and not ops.f16_range_ok(float("inf"))
+    # the reference's batch sizes (models/DeepCrossNetwork/train.py:16-17) always run the small kernel; larger ones while M N K stays small
+    assert ops.dense_small_covers(100, 416, 400) and ops.dense_small_covers(256, 1024, 1024) and ops.dense_small_covers(1, 4, 1)
+    assert ops.dense_small_covers(512, 416, 400) and not ops.dense_small_covers(512, 1024, 1024) and not ops.dense_small_covers(513, 16, 16)
+    assert not ops.dense_small_covers(256, 430, 400) and not ops.dense_small_covers(0, 16, 16)
+    import torch
+    w = torch.nn.Parameter(torch.full((4, 4), 3.0))
+    assert ops.weight_absmax(w) == 3.0
+    with torch.no_grad():
+        w.mul_(2.0 ** 16)                                          # one in-place update: version + 1
+    assert ops.weight_absmax(w, every=32) == 3.0                   # training policy: a measurement may be up to `every` updates old
+    assert ops.weight_absmax(w) == 3.0 * 2.0 ** 16                  # inference policy: every change is seen
+    assert ops.din_arith(w, (), arith="bf16x3") == ops.DIN_ARITHS["bf16x3"]
