@@ -210,3 +210,35 @@ def test_din_unit_checks_its_operands_range(built_lib, oracle, log2s, monkeypatc
         assert ops.din_arith(t2, ()) == ops.DIN_ARITHS["bf16x3"]
     finally:
         ops.DIN_RANGE_RECHECK = keep
+
+
+def test_cin_rows_of_very_different_magnitudes_and_zero_operands(built_lib):
+    """Rows of xk spread over 50 binades in ONE batch (samples scaled by 2^-20 .. 2^30): the device-side verdict sees a tensor outside the plain
+    kernel's window and names the row-scaled kernel, whose per-row scales keep EVERY row accurate relative to its own size (a per-row bar, not
+    the batch's rms); all-zero operands give exact zeros, never NaN (a zero row's scale is clamped, a zero W's too)."""
+    from dir_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(21)
+    B, m, D, H = 12288, 26, 16, 128
+    x0 = torch.randn((B, m, D), generator=g, device=dev) * 0.25
+    W1 = torch.randn((H, m * m), generator=g, device=dev) / m
+    W2 = torch.randn((H, H * m), generator=g, device=dev) / (H * m) ** 0.5
+    sc = torch.pow(2.0, torch.randint(-20, 31, (B, 1, 1), generator=g, device=dev).float())
+    x0s = x0 * sc                                          # every sample at its own scale
+    x1, _ = ops.cin_layer(x0s, x0s, W1)
+    x2, p2 = ops.cin_layer(x0s, x1, W2)                    # x1 carries the first layer's row maxima: the verdict path
+    r1 = _cin_ref(x0s, x0s, W1)
+    r2 = _cin_ref(x0s, x1, W2)
+    for got, ref in ((x1, r1), (x2, r2)):
+        assert bool(torch.isfinite(got).all())
+        rms = ref.pow(2).mean(dim=(1, 2), keepdim=True).sqrt()                 # per SAMPLE
+        worst = float(((got.double() - ref).abs() / (ref.abs() + rms)).max())
+        assert worst <= 1e-5, worst
+    prms = r2.sum(-1).pow(2).mean(dim=1, keepdim=True).sqrt()
+    assert float(((p2.double() - r2.sum(-1)).abs() / (r2.sum(-1).abs() + prms)).max()) <= 1e-5
+    z = torch.zeros_like(x0)
+    for a, b, w in ((z, z, W1), (x0, x0, torch.zeros_like(W1))):
+        y, p = ops.cin_layer(a, b, w)
+        assert not bool(y.any()) and not bool(p.any())
+        y2, p2_ = ops.cin_layer(x0, y, W2)                  # a zero xk with its (zero) row maxima: the verdict takes the row-scaled kernel
+        assert not bool(y2.any()) and not bool(p2_.any())
