@@ -241,3 +241,98 @@ def test_fuzz_dense(ops, seed):
     refg = np.where(gate > 0, x[:, :Kd].astype(np.float64) @ w[:, :Kd].astype(np.float64).T, 0.0)
     gotg = ops.dense_gated(xd, wd, _dev(gate)).cpu().numpy()
     assert (np.abs(gotg - refg) / (1 + np.abs(refg))).max() <= 1e-5, (M, Kd, N)
+
+
+@pytest.mark.parametrize("K", [4, 16, 64, 128, 256])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_din_row_list_kernels_fuzz(built_lib, K, normalize):
+    """dir_din_feat_rows / dir_din_pool_rows and their backwards (round 5, csrc/din_rows_train.hip) on ragged histories -- empty samples, a
+    pruned candidate, lengths 0..T -- for every lane layout (K <= 64: four rows / samples per wave; wider: one), against NumPy float64."""
+    from dir_amd import ops
+    rng = np.random.default_rng(K + (7 if normalize else 0))
+    dev = torch.device("cuda:0")
+    V, B, T = 97, 203, 37
+    table = rng.standard_normal((V, K)).astype(np.float32)
+    lens = rng.integers(0, T + 1, size=B)
+    lens[[0, 5, B - 1]] = 0
+    cand = rng.integers(0, V, size=B).astype(np.int64)
+    cand[3] = -1
+    b_idx = np.repeat(np.arange(B), lens).astype(np.int64)
+    N = int(lens.sum())
+    ids_h = rng.integers(0, V, size=N).astype(np.int64)
+    row_off = (np.cumsum(lens) - lens).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(dev)          # noqa: E731
+    X, Hc = ops.din_feat_rows(t(table), t(ids_h), t(b_idx), t(cand))
+    h = table[ids_h].astype(np.float64)
+    a = np.where((cand >= 0)[:, None], table[np.maximum(cand, 0)], 0.0).astype(np.float64)[b_idx]
+    assert np.array_equal(X.cpu().numpy(), np.concatenate([h, (h.astype(np.float32) * a.astype(np.float32)), a], axis=1).astype(np.float32))
+    assert np.array_equal(Hc.cpu().numpy(), table[ids_h])
+    sc = rng.standard_normal(N).astype(np.float32)
+    out, w = ops.din_pool_rows(t(sc), Hc, t(row_off), B, normalize)
+    wref = np.zeros(N)
+    oref = np.zeros((B, K))
+    for b in range(B):
+        s0, s1 = row_off[b], row_off[b] + lens[b]
+        if s1 > s0:
+            x = sc[s0:s1].astype(np.float64)
+            if normalize:
+                x = x / np.sqrt(K)
+                e = np.exp(x - x.max())
+                x = e / e.sum()
+            wref[s0:s1] = x
+            oref[b] = (x[:, None] * h[s0:s1]).sum(0)
+    assert np.abs(w.cpu().numpy() - wref).max() <= 1e-6 and np.abs(out.cpu().numpy() - oref).max() <= 1e-5 * (1 + np.abs(oref).max())
+    g = rng.standard_normal((B, K)).astype(np.float32)
+    ds, dH = ops.din_pool_rows_backward(t(g), Hc, w, t(row_off), normalize)
+    dw = (g.astype(np.float64)[b_idx] * h).sum(1)
+    if normalize:
+        tsum = np.zeros(B)
+        np.add.at(tsum, b_idx, wref * dw)
+        dsr = wref * (dw - tsum[b_idx]) / np.sqrt(K)
+    else:
+        dsr = dw
+    assert np.abs(ds.cpu().numpy() - dsr).max() <= 2e-5 * (1 + np.abs(dsr).max())
+    assert np.abs(dH.cpu().numpy() - wref[:, None] * g.astype(np.float64)[b_idx]).max() <= 1e-5 * (1 + np.abs(g).max())
+    dX = rng.standard_normal((N, 3 * K)).astype(np.float32)
+    dHin = rng.standard_normal((N, K)).astype(np.float32)
+    grows = ops.din_feat_rows_backward(t(table), t(ids_h), t(row_off), t(cand), t(dX), t(dHin)).cpu().numpy()
+    gh = dX[:, :K].astype(np.float64) + dX[:, K:2 * K] * a + dHin
+    ga = np.zeros((B, K))
+    np.add.at(ga, b_idx, dX[:, K:2 * K].astype(np.float64) * h + dX[:, 2 * K:])
+    ga[cand < 0] = 0
+    assert np.abs(grows[:N] - gh).max() <= 1e-5 * (1 + np.abs(gh).max()) and np.abs(grows[N:] - ga).max() <= 2e-5 * (1 + np.abs(ga).max())
+
+
+@pytest.mark.parametrize("M,N", [(1, 4), (37, 16), (300, 80), (5000, 200), (70000, 40), (1025, 1024)])
+@pytest.mark.parametrize("activation", ["prelu", "dice"])
+def test_act_rows_kernels_fuzz(built_lib, M, N, activation):
+    """dir_act_rows_train_f32 / dir_act_rows_backward_f32 over layer shapes from one row to 70 000 x 40 and 1 025 x 1 024 (the partial-sum grid's
+    corner cases), against float64."""
+    from dir_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    s = torch.randn((M, N), generator=g, device=dev) * 2
+    gy = torch.randn((M, N), generator=g, device=dev)
+    alpha = torch.rand((N,), generator=g, device=dev) - 0.3
+    scale = torch.rand((N,), generator=g, device=dev) + 0.5
+    shift = torch.randn((N,), generator=g, device=dev)
+    sd, gd, ad, scd, shd = s.double(), gy.double(), alpha.double(), scale.double(), shift.double()
+    if activation == "prelu":
+        y_ref = torch.where(sd > 0, sd, ad * sd)
+        d1_ref = gd * torch.where(sd > 0, torch.ones_like(sd), ad.expand_as(sd))
+        ga_ref = (gd * torch.clamp(sd, max=0)).sum(0)
+        gx_ref = None
+    else:
+        p = torch.sigmoid(sd * scd + shd)
+        y_ref = sd * (ad + (1 - ad) * p)
+        d1_ref = gd * (ad + (1 - ad) * p)
+        gx_ref = gd * sd * (1 - ad) * p * (1 - p)
+        ga_ref = (gd * sd * (1 - p)).sum(0)
+    y = ops.act_rows_train(s, activation, alpha, scale, shift)
+    d1, gx, ga = ops.act_rows_backward(gy, s, activation, alpha, scale, shift)
+    close = lambda a, b, tol: float(((a.double() - b).abs() / (1 + b.abs())).max()) <= tol      # noqa: E731
+    assert close(y, y_ref, 1e-5) and close(d1, d1_ref, 1e-5) and close(ga, ga_ref, 5e-5 * max(1, M ** 0.5 / 30))
+    if gx_ref is not None:
+        assert close(gx, gx_ref, 1e-5)
+    d1b, _, gab = ops.act_rows_backward(gy, s, activation, alpha, scale, shift)
+    assert torch.equal(d1, d1b) and torch.equal(ga, gab)
