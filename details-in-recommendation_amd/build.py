@@ -46,6 +46,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # The production build ignores them and refuses to sort when DIR_RS_DBG is set.
 if os.environ.get("DIR_DEVELOPMENT") == "1":
     FLAGS.append("-DDIR_DEVELOPMENT")
+# DIR_ABLATE="cin_bf3.hip:CIN_ABL=1": one timing-ablation macro for one translation unit (development; results are WRONG under most of them)
+if os.environ.get("DIR_ABLATE"):
+    _f, _m = os.environ["DIR_ABLATE"].split(":", 1)
+    EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + ["-D" + _m]
 
 
 def _deps_mtime():

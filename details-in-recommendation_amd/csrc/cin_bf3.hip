@@ -36,6 +36,11 @@
 // What is left above the bare-MFMA time (timing ablations): the W image's LDS-DMA writes 0.26 ms (they share the LDS with the operand
 // reads), the accumulate fmas 0.14 ms, barriers 0.04 ms.
 #include "common.hpp"
+#include <type_traits>
+
+#ifndef DOT_VALU_SLOT
+#define DOT_VALU_SLOT 2      // dot form: VALU instructions scheduled in front of each matrix instruction of a chunk's first k-step
+#endif
 
 namespace dir {
 
@@ -234,7 +239,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                                                                           the kernel that produced xk: no scan of the rows in the prologue */,
                                                      unsigned int* __restrict__ xout_bits = nullptr /* optional [R]: the same of THIS launch's output rows (the launch
                                                                                                        must cover all H columns: one column block) */,
-                                                     int vwant = -1 /* 1 / 0: wpart is followed by xpart; run only under the plain / the row-scaled verdict */) {
+                                                     int vwant = -1 /* 1 / 0: wpart is followed by xpart; run only under the plain / the row-scaled verdict */,
+                                                     float* __restrict__ sink = nullptr /* DOT: one writable word nobody reads (behind the workspace's partial maxima) */) {
     if (vwant >= 0) {                                              // (before anything else: the kernel the verdict does not name costs an empty launch)
         if (cin_plain_verdict(wpart) != (vwant == 1)) return;
     }
@@ -333,30 +339,52 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         }
     }
 
-    f32x4 out[RT][CT], T[RT][CT];
+    // DOT: the accumulators are TRANSPOSED (the W image is the matrix instruction's A operand, the rows its B operand: same registers, swapped):
+    // lane (n, lg) holds T[column 16 ct + 4 lg + q, row 16 rt + n].  The field factor x0[r, j] is then ONE value per lane and row tile, and
+    // the dot over the columns runs inside the lane (16 fmas + 2 cross-group adds per row tile and chunk; in the forward's layout it was a
+    // 16-lane reduction of four values per row tile: ~80 of the chunk's ~160 VALU instructions).  T has two buffers used alternately by
+    // the two fields of a staged chunk: the fmas that consume chunk c - 1 sit between the matrix instructions of chunk c and read registers
+    // those do not write (one buffer: the compiler copied all of T once per chunk and kept the fmas in a block behind the chunk).
+    constexpr int NTB = DOT ? 2 : 1;
+    static_assert(!DOT || FJ == 2, "the dot form alternates two T buffers over the two fields of a staged chunk");
+    f32x4 out[RT][CT], T[NTB][RT][CT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             out[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            T[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tb = 0; tb < NTB; ++tb) T[tb][rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     f32x4 xprev[RT];                                                                 // x0[rows of the lane's accumulator registers, previous field]
-#pragma unroll
+#pragma unroll                                                                       //  (DOT: the lane's ONE row per tile, in element 0)
     for (int rt = 0; rt < RT; ++rt) xprev[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     op_t a[KS][RT][NP];                                                              // the half's A operands: [k-step][row tile][piece]
-    // DOT: y in the accumulators' layout (rows 4*lg .. 4*lg+3 of tile rt = four consecutive d of one sample, column 16*ct + n)
+    // DOT: y in the accumulators' (transposed) layout: row 16*rt + n, columns 16*ct + 4*lg + q
     f32x4 yv[DOT ? RT : 1][DOT ? CT : 1];
     if constexpr (DOT) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int64_t gr = row0 + wave * WR + rt * 16 + 4 * lg;
+            const int64_t gr = row0 + wave * WR + rt * 16 + n;
+            const int64_t grc = gr < R ? gr : R - 1;
+            const float* yr = y + ((grc >> dshift) * H) * D + (grc & (D - 1));
+            // (clamped, unconditional loads, selected afterwards: a load inside the branch of its guard is waited for there, one round trip each)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int h = hbase + 16 * ct + 4 * lg + q;
+                    yv[rt][ct][q] = yr[(int64_t)(h < H ? h : H - 1) * D];
+                }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const int h = hbase + 16 * ct + n;
-                yv[rt][ct] = (h < H && gr < R) ? *reinterpret_cast<const f32x4*>(y + ((gr >> dshift) * H + h) * D + (gr & (D - 1)))
-                                               : (f32x4){0.f, 0.f, 0.f, 0.f};
-                if constexpr (RS) yv[rt][ct] *= rinv[rt];            // T carries the rows' scales: taken out where it is consumed
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int h = hbase + 16 * ct + 4 * lg + q;
+                    asm volatile("" : "+v"(yv[rt][ct][q]));
+                    if (!(h < H && gr < R)) yv[rt][ct][q] = 0.f;
+                }
+                if constexpr (RS) yv[rt][ct] *= rowinv[rt];          // T carries the rows' scales: taken out where it is consumed
             }
         }
     }
@@ -408,22 +436,58 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 
     if constexpr (DOT) dotp += (int64_t)blockIdx.y * nkh * (R >> dshift) * m * D;     // this column block's partials
     const unsigned char* wlane = Wb + lane * 16;
-    const float* x0lane = x0s + wave * WR + 4 * lg;      // + j*BT_ROWS + 16*rt: the 4 rows of accumulator registers 0..3 of tile rt
-    // DOT: the finished dot of one chunk (field jd of half khd): reduce over the 16 columns of a lane group, lane n == 0 stores
-    auto store_dot = [&](const f32x4 (&sd)[RT], int khd, int jd) {
+    const float* x0lane = x0s + wave * WR + (DOT ? n : 4 * lg);      // + j*BT_ROWS + 16*rt: the 4 rows of accumulator registers 0..3 of tile rt
+                                                                      //   (DOT: the one row of the lane's transposed accumulators)
+    // DOT: the finished dot of one chunk (field jd of half khd): a lane's four partial sums, then the four lane groups; group 0 stores the
+    // 16 rows of the tile (16 consecutive floats when D = 16)
+    float* dlane[RT];                           // the lane's row in the dot partials: + ((half * rows + 0) * m + field) * D, a uniform offset
+    bool drow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int64_t gr = row0 + wave * WR + rt * 16 + n;
+        drow[rt] = DOT && gr < R;
+        dlane[rt] = DOT ? dotp + ((gr >> dshift) * m) * D + (gr & (D - 1)) : nullptr;
+    }
+    auto store_dot = [&](const f32x4 (&sd)[RT], int khd, int jd, bool live = true) {
+        const int64_t uoff = ((int64_t)khd * (R >> dshift) * m + jd) * D;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            f32x4 v;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = row16_sum(sd[rt][q]);
-            const int64_t gr = row0 + wave * WR + rt * 16 + 4 * lg;
-            if (n == 0 && gr < R)
-                *reinterpret_cast<f32x4*>(dotp + (((int64_t)khd * (R >> dshift) + (gr >> dshift)) * m + jd) * D + (gr & (D - 1))) = v;
+            float v = (sd[rt][0] + sd[rt][1]) + (sd[rt][2] + sd[rt][3]);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            // NO branch: every lane stores (the four lane groups hold the same sum and write the same word); a row past R, or the call in front
+            // of the first chunk, goes to the sink word.  A predicated store is a basic-block boundary, and the compiler sinks the fmas whose
+            // results are only needed later (all of `out`, the second row tile's dot) behind it -- out of the matrix instructions' shadow.
+            float* dst = (live && drow[rt]) ? dlane[rt] + uoff : sink;
+            *dst = v;
         }
     };
+    // one tile of the previous chunk goes into `out` (and the dot)
+    auto consume = [&](int rt, int ct, const f32x4& t, f32x4 (&sd)[RT]) {
+        if constexpr (DOT) {
+            // explicit pairs (v_pk_fma_f32 on register-adjacent halves): left to itself the compiler pairs the dot's fmas ACROSS tiles, with two
+            // v_mov per packed fma, and moves them behind the chunk
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 xb = {xprev[rt][0], xprev[rt][0]};
+            const f32x2 tl = __builtin_shufflevector(t, t, 0, 1), th = __builtin_shufflevector(t, t, 2, 3);
+            const f32x4 o = out[rt][ct], y4 = yv[rt][ct], s4 = sd[rt];
+            const f32x2 ol = __builtin_elementwise_fma(xb, tl, __builtin_shufflevector(o, o, 0, 1));
+            const f32x2 oh = __builtin_elementwise_fma(xb, th, __builtin_shufflevector(o, o, 2, 3));
+            const f32x2 sl = __builtin_elementwise_fma(__builtin_shufflevector(y4, y4, 0, 1), tl, __builtin_shufflevector(s4, s4, 0, 1));
+            const f32x2 sh = __builtin_elementwise_fma(__builtin_shufflevector(y4, y4, 2, 3), th, __builtin_shufflevector(s4, s4, 2, 3));
+            out[rt][ct] = (f32x4){ol[0], ol[1], oh[0], oh[1]};
+            sd[rt] = (f32x4){sl[0], sl[1], sh[0], sh[1]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], t[q], out[rt][ct][q]);
+        }
+    };
+    bool dot_pending = false;                   // DOT: T[1] (T[0] behind an odd chunk) holds a chunk that has not been consumed
 
-    int c = 0;                                  // (half, field) index = kh * m + j
     int u = 0;                                  // staged chunk index (its LDS buffer: u & 1)
+#ifdef CIN_ABL
+    if (DOT && (CIN_ABL & 1)) nkh = 0;          // timing ablation: no main loop
+#endif
     for (int kh = 0; kh < nkh; ++kh) {
         // ---- A operands of this half: xk[r, KS*32*kh + 32*ks + 8*lg + e], split once, used by all m fields
 #pragma unroll
@@ -441,11 +505,21 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                         v[e] = xr[(ent & 255u) * BT_ROWS] * xr[(ent >> 8) * BT_ROWS];
                     }
                 } else {
+                // All eight loads are issued before any value is used, and issued UNCONDITIONALLY (clamped index): left alone the compiler sinks
+                // each load into the `i < Hp` branch of its only use and waits for it there -- 16 to 32 dependent memory round trips per half
+                // and workgroup, with nothing else running on the CU (one workgroup per CU).
+                float x[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int i = KS * 32 * kh + 32 * ks + 8 * lg + e;
-                    const float x = xsrc[rt][(int64_t)(i < Hp ? i : Hp - 1) * D];
-                    v[e] = i < Hp ? ((RS && !PAIRS) ? x * rscale[rt] : x) : 0.f;          // the W image is zero there; 0 * garbage must stay 0
+                    x[e] = xsrc[rt][(int64_t)(i < Hp ? i : Hp - 1) * D];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(x[e]));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = KS * 32 * kh + 32 * ks + 8 * lg + e;
+                    v[e] = i < Hp ? ((RS && !PAIRS) ? x[e] * rscale[rt] : x[e]) : 0.f;    // the W image is zero there; 0 * garbage must stay 0
                 }
                 }
                 unsigned int w[NP][4];
@@ -466,15 +540,19 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
               const int cn = kh * m + j0 + nf;        // first field of the next chunk (the next half starts at a chunk boundary)
               if (cn < nchunk) stage_w(cn, min(FJ, m - (j0 + nf < m ? j0 + nf : 0)), buf ^ 1);
           }
-#pragma unroll 1
-          for (int f = 0; f < nf; ++f, ++c) {
+          // field f of the staged chunk: a compile-time index in the dot form (it selects the T buffer the chunk writes)
+          auto field = [&](auto fc) __attribute__((always_inline)) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int cur = DOT ? (f & 1) : 0, prv = DOT ? (cur ^ 1) : 0;
             constexpr int KSN = KS;
             const int j = j0 + f;
             const unsigned char* wl = wlane + buf * (FJ * CHB) + f * CHB;
             f32x4 xcur[RT], sd[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                xcur[rt] = PAIRS ? (f32x4){1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
+                if constexpr (PAIRS) xcur[rt] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                else if constexpr (DOT) xcur[rt] = (f32x4){x0lane[j * BT_ROWS + 16 * rt], 0.f, 0.f, 0.f};
+                else xcur[rt] = *reinterpret_cast<const f32x4*>(x0lane + j * BT_ROWS + 16 * rt);
                 if constexpr (RS && PAIRS) xcur[rt] *= rinv[rt];          // (not PAIRS: the slice in LDS already carries the rows' inverse scales)
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -501,27 +579,25 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     for (int rt = 0; rt < RT; ++rt) {
                         f32x4 t;
                         if (ks == 0) {
-                            // the previous chunk's T tile goes into `out` just before this chunk's first MFMA chain overwrites it
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
-                            if constexpr (DOT) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) sd[rt][q] = __builtin_fmaf(yv[rt][ct][q], T[rt][ct][q], sd[rt][q]);
-                            }
+                            // the previous chunk's T tile goes into `out` just before this chunk's first MFMA chain overwrites it (DOT: beside
+                            // the chain that fills the other buffer)
+                            consume(rt, ct, T[prv][rt][ct], sd);
                             t = (f32x4){0.f, 0.f, 0.f, 0.f};
                         } else {
-                            t = T[rt][ct];
+                            t = T[cur][rt][ct];
                         }
-                        T[rt][ct] = Pc::mma(a[ks][rt], bc, t);
+                        if constexpr (DOT) T[cur][rt][ct] = Pc::mma(bc, a[ks][rt], t);     // W image x rows: the transposed tile
+                        else T[cur][rt][ct] = Pc::mma(a[ks][rt], bc, t);
                     }
                     if (!lastg) {
                         constexpr int NM = RT * Pc::NMF;                 // matrix instructions of the group (12 for bf16 x 3, 6 for fp16 x 2)
                         constexpr int NPAIR = NM < 8 ? NM : 8;           // (accumulate fma, MFMA) pairs of the chunk's first k-step
+                        constexpr int NV = DOT ? DOT_VALU_SLOT : 1;      // VALU instructions in front of each of those MFMAs
                         __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
                         if (ks == 0) {
 #pragma unroll
                             for (int q = 0; q < NPAIR; ++q) {
-                                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             }
                             if constexpr (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
@@ -535,28 +611,58 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) xprev[rt] = xcur[rt];
             if constexpr (DOT) {          // sd holds the dot of the PREVIOUS chunk (its T tiles were consumed during this chunk's first k-step)
-                if (c > 0) store_dot(sd, j == 0 ? kh - 1 : kh, j == 0 ? m - 1 : j - 1);
+                // (only the store is predicated: a branch around the reduction lets the compiler sink the chunk's fmas into it, behind the MFMAs)
+                store_dot(sd, j == 0 ? kh - 1 : kh, j == 0 ? m - 1 : j - 1, dot_pending);
+                dot_pending = true;
             }
+          };
+          field(std::integral_constant<int, 0>{});
+          if constexpr (FJ == 2) {
+              if (nf > 1) field(std::integral_constant<int, 1>{});
+              if constexpr (DOT) {
+                  if (nf == 1) {          // an odd field count: the half's last chunk sits in T[0], which the next staged chunk's first field overwrites
+                      f32x4 sd[RT];
+#pragma unroll
+                      for (int rt = 0; rt < RT; ++rt) {
+                          sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                          for (int ct = 0; ct < CT; ++ct) {
+                              consume(rt, ct, T[0][rt][ct], sd);
+                              T[1][rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                          }
+                          xprev[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                      }
+                      store_dot(sd, kh, j0);
+                      dot_pending = false;
+                  }
+              }
           }
+          if constexpr (DOT) {
+              // The interval's 2 * RT dot stores are YOUNGER than the W pieces staged at its top: vector memory operations retire in order, so
+              // "at most 2 * RT outstanding" means the pieces have landed -- without waiting for the stores' write acknowledgements (vmcnt(0),
+              // also the fence inside __syncthreads(), cost a memory round trip per interval: the whole gap between this form and the forward).
+              static_assert(RT == 2, "the counted wait below is written for two row tiles (four dot stores per interval)");
+              asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+          } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's W pieces of the next chunk have landed in LDS
           __syncthreads();
+          }
         }
     }
     // the last chunk's T
     {
         f32x4 sd[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt) sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!DOT || dot_pending) {
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], T[rt][ct][q], out[rt][ct][q]);
-                    if constexpr (DOT) sd[rt][q] = __builtin_fmaf(yv[rt][ct][q], T[rt][ct][q], sd[rt][q]);
-                }
+                for (int ct = 0; ct < CT; ++ct) consume(rt, ct, T[NTB - 1][rt][ct], sd);
+            if constexpr (DOT) store_dot(sd, nkh - 1, m - 1);
         }
-        if constexpr (DOT) store_dot(sd, nkh - 1, m - 1);
     }
 
     if constexpr (!RS && NP == 2 && !DOT && !PAIRS) {
@@ -569,6 +675,50 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         }
     }
     // ---- epilogue: C/D map of 16x16x32: col = lane & 15, row = 4*(lane >> 4) + reg
+    if constexpr (DOT) {
+        // transposed accumulators: the lane's row 16*rt + n, columns 16*ct + 4*lg + q (a store instruction writes 16 consecutive d of four columns)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t gr = row0 + wave * WR + rt * 16 + n;
+            const int64_t b = (gr < R ? gr : R - 1) >> dshift;
+            const int d = (int)(gr & (D - 1));
+            float rmx = 0.f;
+            if (addp) {                                              // (uniform) all of the lane's pooled-gradient terms in one batch of loads
+                f32x4 ap[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int h = hbase + 16 * ct + 4 * lg + q;
+                        ap[ct][q] = addp[b * addp_ld + (h < H ? h : H - 1)];
+                    }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm volatile("" : "+v"(ap[ct][q]));
+                        out[rt][ct][q] += ap[ct][q];
+                    }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int h = hbase + 16 * ct + 4 * lg + q;
+                    if (xout && h < H && gr < R) {
+                        const float v = out[rt][ct][q];
+                        xout[(b * H + h) * D + d] = v;
+                        rmx = fmaxf(rmx, fabsf(v));
+                    }
+                }
+            }
+            if (xout_bits) {
+                rmx = fmaxf(rmx, __shfl_xor(rmx, 16, 64));
+                rmx = fmaxf(rmx, __shfl_xor(rmx, 32, 64));
+                if (lg == 0 && gr < R) xout_bits[gr] = __builtin_bit_cast(unsigned int, rmx);
+            }
+        }
+    } else {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int64_t gr = row0 + wave * WR + rt * 16 + 4 * lg;     // first of the lane's 4 consecutive rows (same sample: D >= 4)
@@ -597,9 +747,10 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             }
         }
     }
+    }
     if (pooled) {
         static_assert(RT == 2 || DOT, "the pooled sums are written by the forward configuration (two row tiles per wave)");
-        if constexpr (RT == 2) {
+        if constexpr (RT == 2 && !DOT) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int h = hbase + 16 * ct + n;
@@ -649,7 +800,7 @@ extern "C" int64_t dir_cin_bf16x3_workspace_bytes(int m, int Hp, int H) {
     if (m <= 0 || Hp <= 0 || H <= 0) return 0;
     const Bf3Plan p = bf3_plan(m, Hp, H, false), q = bf3_plan(m, Hp, H, true);      // either form of the layer
     const int64_t a = p.bytes_full + p.bytes_last, b = q.bytes_full + q.bytes_last;
-    return (a > b ? a : b) + 128 + 4 * (WPARTS + XPARTS);      // + the partial maxima of W (and of xk's row maxima: the verdict) behind the image
+    return (a > b ? a : b) + 128 + 4 * (WPARTS + XPARTS) + 64;      // + the partial maxima of W (and of xk's row maxima: the verdict) behind the image, + the dot form's sink word
 }
 
 // Shared launcher of the forward (y == nullptr) and the data-gradient form (y, dotp given: 64-column blocks, two fields per chunk, dot partials)
@@ -681,7 +832,9 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         return fail(DIR_E_UNSUPPORTED, "%s: xout_row_bits needs xout and ONE column block (H <= %d)", name, 16 * pl.bw);
     unsigned char* img = static_cast<unsigned char*>(workspace);
     // rs: W is scaled too (one power of two for the tensor): its partial maxima sit behind the image
-    float* wpart = rs ? reinterpret_cast<float*>(img + ((pl.bytes_full + pl.bytes_last + 127) & ~(int64_t)127)) : nullptr;
+    float* wtail = reinterpret_cast<float*>(img + ((pl.bytes_full + pl.bytes_last + 127) & ~(int64_t)127));
+    float* wpart = rs ? wtail : nullptr;
+    float* sink = wtail + WPARTS + XPARTS;
     if (rs) hipLaunchKernelGGL(cin_w_absmax_k, dim3(WPARTS), dim3(256), 0, st, W, (int64_t)H * Hp * m, wpart);
     const int verdict = (rs && verdict_bits && !dot) ? 1 : 0;
     if (verdict) hipLaunchKernelGGL(cin_bits_absmax_k, dim3(XPARTS), dim3(256), 0, st, verdict_bits, R, wpart + WPARTS);
@@ -705,7 +858,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                             \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
                            dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr, wpart, \
-                           xk_bits, xout_bits, verdict ? ((RS_) ? 0 : 1) : -1);                                                       \
+                           xk_bits, xout_bits, verdict ? ((RS_) ? 0 : 1) : -1, sink);                                                 \
     } while (0)
 #define BT_LAUNCH_KS(C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                       \
     do {                                                                                 \

@@ -340,59 +340,87 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
         }
 
         // ---- epilogue: D = W-piece x X-piece, C/D map of 16x16x32: col = lane & 15 = batch row, row = 4*lg + reg = output column.
-        // The stores are not waited for here.
+        // The stores are not waited for here.  The epilogue's operands (the columns' weight scales / bias / affine / head weights: one
+        // float4 per column tile; the gate: one per row tile too) are loaded UNCONDITIONALLY from clamped addresses, one column tile AHEAD
+        // of their use: written as `if (r < M && col < N) v += bias[col]` every load sits inside the guard's branch and is waited for right
+        // there -- up to six dependent memory round trips per tile, 32 tiles per lane, with the matrix pipe idle (round 5, tools/serial_loads.py).
+        struct EpiOps { f32x4 iw, bs, sc, sh, hw, gt[2]; };
+        const int64_t er[2] = {cur.row0 + wave * 32 + n, cur.row0 + wave * 32 + 16 + n};
+        const int64_t erc[2] = {er[0] < M ? er[0] : M - 1, er[1] < M ? er[1] : M - 1};
+        auto epi_load = [&](int ct, EpiOps& o) {
+            const int col = 16 * (cur.cb * CT + ct) + 4 * lg;
+            const int cc = col < N ? col : N - 4;                // N % 4 == 0
+            if constexpr (NP == 2) o.iw = *reinterpret_cast<const f32x4*>(invw + cc);
+            if (bias) o.bs = *reinterpret_cast<const f32x4*>(bias + cc);
+            if (post_scale) {
+                o.sc = *reinterpret_cast<const f32x4*>(post_scale + cc);
+                o.sh = *reinterpret_cast<const f32x4*>(post_shift + cc);
+            }
+            if (head_w) o.hw = *reinterpret_cast<const f32x4*>(head_w + cc);
+            if (gate) {
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int64_t r = cur.row0 + wave * 32 + rt * 16 + n;
-            float hpart = 0.f;                  // head: this lane's share of the row's dot product with head_w (columns of this block)
-            float ymax = 0.f;                   // y_row_bits: the largest |output| of this lane's columns of the row
+                for (int rt = 0; rt < 2; ++rt) o.gt[rt] = *reinterpret_cast<const f32x4*>(gate + erc[rt] * gate_ld + cc);
+            }
+        };
+        float hpart[2] = {0.f, 0.f};            // head: this lane's share of the row's dot product with head_w (columns of this block)
+        float ymax[2] = {0.f, 0.f};             // y_row_bits: the largest |output| of this lane's columns of the row
+        EpiOps eo[2];
+        epi_load(0, eo[0]);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int col = 16 * (cur.cb * CT + ct) + 4 * lg;      // N % 4 == 0: the lane's four columns are inside or outside together
+        for (int ct = 0; ct < CT; ++ct) {
+            if (ct + 1 < CT) epi_load(ct + 1, eo[(ct + 1) & 1]);
+            const EpiOps& o = eo[ct & 1];
+            const int col = 16 * (cur.cb * CT + ct) + 4 * lg;      // N % 4 == 0: the lane's four columns are inside or outside together
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int64_t r = er[rt];
+                f32x4 v = acc[rt][ct];
+                if constexpr (NP == 2) v *= o.iw;                  // the columns' weight scales out again
+                if constexpr (RS) v *= cur.inv[rt];                // (a lane's four accumulators are four columns of ITS row n)
+                if (bias) v += o.bs;
+                if (relu) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                }
+                if (post_scale) {               // multiply then add, unfused (dense.hip's affine epilogue)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] * o.sc[q] + o.sh[q];
+                }
+                if (gate) {                     // data gradient through the previous layer's ReLU: y = (x W^T) where gate > 0, else 0
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = o.gt[rt][q] > 0.f ? v[q] : 0.f;
+                }
                 if (r < M && col < N) {
-                    f32x4 v = acc[rt][ct];
-                    if constexpr (NP == 2) v *= *reinterpret_cast<const f32x4*>(invw + col);      // the columns' weight scales out again
-                    if constexpr (RS) v *= cur.inv[rt];            // (a lane's four accumulators are four columns of ITS row n)
-                    if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
-                    if (relu) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                    }
-                    if (post_scale) {           // multiply then add, unfused (dense.hip's affine epilogue)
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(post_scale + col), sh = *reinterpret_cast<const f32x4*>(post_shift + col);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q] + sh[q];
-                    }
-                    if (gate) {                 // data gradient through the previous layer's ReLU: y = (x W^T) where gate > 0, else 0
-                        const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + r * gate_ld + col);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = gt[q] > 0.f ? v[q] : 0.f;
-                    }
                     if (Y) *reinterpret_cast<f32x4*>(Y + r * y_ld + col) = v;
-                    if (y_row_bits) ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    if (y_row_bits) ymax[rt] = fmaxf(fmaxf(ymax[rt], fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
                     if (head_w) {
-                        const f32x4 h4 = *reinterpret_cast<const f32x4*>(head_w + col);
-                        hpart += v[0] * h4[0];
-                        hpart += v[1] * h4[1];
-                        hpart += v[2] * h4[2];
-                        hpart += v[3] * h4[3];
+                        hpart[rt] += v[0] * o.hw[0];
+                        hpart[rt] += v[1] * o.hw[1];
+                        hpart[rt] += v[2] * o.hw[2];
+                        hpart[rt] += v[3] * o.hw[3];
                     }
                 }
                 acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t r = er[rt];
             if (y_row_bits) {                   // (uniform) the output's own row maxima for the NEXT row-scaled kernel: no pass over Y
-                ymax = fmaxf(ymax, __shfl_xor(ymax, 16, 64));
-                ymax = fmaxf(ymax, __shfl_xor(ymax, 32, 64));
+                float ym = ymax[rt];
+                ym = fmaxf(ym, __shfl_xor(ym, 16, 64));
+                ym = fmaxf(ym, __shfl_xor(ym, 32, 64));
                 if (lg == 0 && r < M) {
-                    if (ncb == 1) y_row_bits[r] = __builtin_bit_cast(unsigned int, ymax);            // the row is complete in this workgroup
-                    else if (ymax > 0.f) atomicMax(y_row_bits + r, __builtin_bit_cast(unsigned int, ymax));     // one per column block
+                    if (ncb == 1) y_row_bits[r] = __builtin_bit_cast(unsigned int, ym);            // the row is complete in this workgroup
+                    else if (ym > 0.f) atomicMax(y_row_bits + r, __builtin_bit_cast(unsigned int, ym));     // one per column block
                 }
-                if (r < M) run_max = fmaxf(run_max, ymax);      // the tensor's maximum: ONE atomic per workgroup, after its last tile
+                if (r < M) run_max = fmaxf(run_max, ym);        // the tensor's maximum: ONE atomic per workgroup, after its last tile
             }
             if (head_w) {                       // the row's other columns of this block live in the other three lane groups
-                hpart += __shfl_xor(hpart, 16, 64);
-                hpart += __shfl_xor(hpart, 32, 64);
-                if (lg == 0 && r < M) head_part[(int64_t)cur.cb * M + r] = hpart;
+                float hp = hpart[rt];
+                hp += __shfl_xor(hp, 16, 64);
+                hp += __shfl_xor(hp, 32, 64);
+                if (lg == 0 && r < M) head_part[(int64_t)cur.cb * M + r] = hp;
             }
         }
         cur = nxt;
