@@ -38,6 +38,9 @@
 #include "common.hpp"
 #include <type_traits>
 
+#ifndef DOT_CHAINS
+#define DOT_CHAINS 0        // dot form: one dependent MFMA chain per accumulator tile (0: the forward's k-step-major order)
+#endif
 #ifndef DOT_VALU_SLOT
 #define DOT_VALU_SLOT 2      // dot form: VALU instructions scheduled in front of each matrix instruction of a chunk's first k-step
 #endif
@@ -440,30 +443,41 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                                       //   (DOT: the one row of the lane's transposed accumulators)
     // DOT: the finished dot of one chunk (field jd of half khd): a lane's four partial sums, then the four lane groups; group 0 stores the
     // 16 rows of the tile (16 consecutive floats when D = 16)
-    float* dlane[RT];                           // the lane's row in the dot partials: + ((half * rows + 0) * m + field) * D, a uniform offset
-    bool drow[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int64_t gr = row0 + wave * WR + rt * 16 + n;
-        drow[rt] = DOT && gr < R;
-        dlane[rt] = DOT ? dotp + ((gr >> dshift) * m) * D + (gr & (D - 1)) : nullptr;
+    // DOT: the dot partials' address of the row this LANE stores: lane group 0 stores row tile 0's sums, group 1 row tile 1's (below);
+    // + ((half * rows) * m + field) * D, a uniform offset.  nullptr: the lane stores to the sink word.
+    float* dsel = nullptr;
+    if constexpr (DOT) {
+        static_assert(RT == 2, "the dot form's reduction folds exactly two row tiles");
+        const int64_t gr = row0 + wave * WR + (lg & 1) * 16 + n;
+        if (lg < 2 && gr < R) dsel = dotp + ((gr >> dshift) * m) * D + (gr & (D - 1));
     }
     auto store_dot = [&](const f32x4 (&sd)[RT], int khd, int jd, bool live = true) {
         const int64_t uoff = ((int64_t)khd * (R >> dshift) * m + jd) * D;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            float v = (sd[rt][0] + sd[rt][1]) + (sd[rt][2] + sd[rt][3]);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            // NO branch: every lane stores (the four lane groups hold the same sum and write the same word); a row past R, or the call in front
-            // of the first chunk, goes to the sink word.  A predicated store is a basic-block boundary, and the compiler sinks the fmas whose
-            // results are only needed later (all of `out`, the second row tile's dot) behind it -- out of the matrix instructions' shadow.
-            float* dst = (live && drow[rt]) ? dlane[rt] + uoff : sink;
-            *dst = v;
-        }
+        // The sums over the four lane groups (rows of 16 lanes) of BOTH row tiles in five VALU instructions, no LDS round trip:
+        // v_permlane16_swap exchanges a's odd rows with b's even rows, so a + b holds tile 0's pair sums in rows 0 / 2 and tile 1's in rows
+        // 1 / 3; v_permlane32_swap of that with a copy of itself brings the other pair across.  (Two ds_bpermute per tile, each waited for
+        // with lgkmcnt(0) behind the chunk's matrix instructions: four exposed LDS round trips per chunk -- 0.3 of the chunk's MFMA time.)
+        // The additions are the ones of the butterfly, (g0 + g1) + (g2 + g3): the same bits.
+        float a = (sd[0][0] + sd[0][1]) + (sd[0][2] + sd[0][3]);
+        float b = (sd[RT - 1][0] + sd[RT - 1][1]) + (sd[RT - 1][2] + sd[RT - 1][3]);
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        float c = a + b, d = c;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
+        const float v = c + d;
+        // NO branch: every lane stores; lane groups 2 and 3 (copies), a row past R, or the call in front of the first chunk, go to the sink
+        // word.  A predicated store is a basic-block boundary, and the compiler sinks the fmas whose results are only needed later (all of
+        // `out`, the second row tile's dot) behind it -- out of the matrix instructions' shadow.
+        float* dst = (live && dsel) ? dsel + uoff : sink;
+#ifdef CIN_ABL
+        if (CIN_ABL & 2) { if (v == 12345.678f) *dst = v; } else
+#endif
+        *dst = v;
     };
     // one tile of the previous chunk goes into `out` (and the dot)
     auto consume = [&](int rt, int ct, const f32x4& t, f32x4 (&sd)[RT]) {
+#ifdef CIN_ABL
+        if (DOT && (CIN_ABL & 8)) { asm volatile("" :: "v"(t)); return; }          // no consume fmas; the tile stays "used"
+#endif
         if constexpr (DOT) {
             // explicit pairs (v_pk_fma_f32 on register-adjacent halves): left to itself the compiler pairs the dot's fmas ACROSS tiles, with two
             // v_mov per packed fma, and moves them behind the chunk
@@ -538,6 +552,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
           const int nf = min(FJ, m - j0);
           {
               const int cn = kh * m + j0 + nf;        // first field of the next chunk (the next half starts at a chunk boundary)
+#ifdef CIN_ABL
+              if (!(DOT && (CIN_ABL & 4)))
+#endif
               if (cn < nchunk) stage_w(cn, min(FJ, m - (j0 + nf < m ? j0 + nf : 0)), buf ^ 1);
           }
           // field f of the staged chunk: a compile-time index in the dot form (it selects the T buffer the chunk writes)
@@ -556,13 +573,59 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 if constexpr (RS && PAIRS) xcur[rt] *= rinv[rt];          // (not PAIRS: the slice in LDS already carries the rows' inverse scales)
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            if constexpr (DOT && DOT_CHAINS) {
+                // Column tile outermost, both k-steps inside: a tile's KS * NMF matrix instructions form ONE dependent chain on its accumulator.
+                // Dependent 4-pass MFMAs issue back to back at no cost to the chain, and only while a wave waits on such a dependency does the
+                // SIMD hand issue slots to its other wave (tools/coexec_probe.hip: a stream that rotates over independent accumulators hides
+                // 1-3 % of the partner's VALU work, one chain 56-59 %): the chunk's ~70 VALU instructions were costing 1.4 of the layer's 2.9 ms.
+                op_t bq[2][KSN][NP];
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bq[0][ks][p] = *reinterpret_cast<const op_t*>(wl + ks * STEPB + p * CT * 1024);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (ct + 1 < CT) {
+#pragma unroll
+                        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                bq[(ct + 1) & 1][ks][p] = *reinterpret_cast<const op_t*>(wl + ks * STEPB + (ct + 1) * 1024 + p * CT * 1024);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) consume(rt, ct, T[prv][rt][ct], sd);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KSN; ++ks) t = Pc::mma(bq[ct & 1][ks], a[ks][rt], t);
+                        T[cur][rt][ct] = t;
+#if DOT_CHAINS == 2
+                        __builtin_amdgcn_sched_barrier(0);      // strictly one chain after the other (1: the compiler alternates the two row tiles' chains)
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
             // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
             // (two register sets used alternately: the loops are unrolled, the set index is a compile-time constant -- copying "next"
             // into "current" would cost 12 v_mov per group, one VALU instruction per MFMA)
-            op_t bq[2][NP];
+            // The reads are issued by hand (inline asm) and waited for with a COUNTED lgkmcnt: LDS reads return in order, so "at most NP
+            // outstanding" = this group's NP pieces are here, the next group's may still be in flight.  Left to the compiler, the wait in
+            // front of a group's first MFMA was lgkmcnt(0) placed BEHIND the next group's reads: every second group stood through a whole
+            // LDS round trip with nothing else in flight in its wave (round 5; the tower kernel has had this pipeline since round 3).
+            // An outstanding LDS operation of the compiler's own (the field factor, a dot's ds_bpermute) only makes a counted wait wait longer.
+            const unsigned int wl32 = (unsigned int)(size_t)wl;
+            u32x4_t bq[2][NP];
+#define BT_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(wl32), "n"(off))
+#define BT_DS_WAIT(cnt, set)                                                                                          \
+    do {                                                                                                              \
+        if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(bq[set][0]), "+v"(bq[set][1]));      \
+        else asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][NP - 1])); \
+    } while (0)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) bq[0][p] = *reinterpret_cast<const op_t*>(wl + p * CT * 1024);
+            for (int p = 0; p < NP; ++p) BT_DS_READ(bq[0][p], p * CT * 1024);
 #pragma unroll
             for (int ks = 0; ks < KSN; ++ks) {
 #pragma unroll
@@ -570,11 +633,20 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     const bool lastg = (ks == KSN - 1 && ct == CT - 1);
                     const int gi = ks * CT + ct;                     // group index inside the chunk (compile-time after unrolling)
                     if (!lastg) {
-                        const unsigned char* wp = wl + (ct + 1 < CT ? ks : ks + 1) * STEPB + ((ct + 1) % CT) * 1024;
+#ifdef CIN_ABL
+                        if (DOT && (CIN_ABL & 64)) { asm volatile("" : "+v"(bq[(gi + 1) & 1][0]), "+v"(bq[(gi + 1) & 1][1])); } else   // no LDS reads behind the chunk's first
+#endif
 #pragma unroll
-                        for (int p = 0; p < NP; ++p) bq[(gi + 1) & 1][p] = *reinterpret_cast<const op_t*>(wp + p * CT * 1024);
+                        for (int p = 0; p < NP; ++p)
+                            BT_DS_READ(bq[(gi + 1) & 1][p], (ct + 1 < CT ? ks : ks + 1) * STEPB + ((ct + 1) % CT) * 1024 + p * CT * 1024);
+                        if constexpr (NP == 2) BT_DS_WAIT(2, gi & 1); else BT_DS_WAIT(3, gi & 1);
+                    } else {
+                        BT_DS_WAIT(0, gi & 1);
                     }
-                    const op_t (&bc)[NP] = bq[gi & 1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    op_t bc[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bc[p] = __builtin_bit_cast(op_t, bq[gi & 1][p]);
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         f32x4 t;
@@ -586,14 +658,16 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                         } else {
                             t = T[cur][rt][ct];
                         }
+#ifdef CIN_ABL
+                        if (DOT && (CIN_ABL & 32)) { asm volatile("" : "+v"(t) : "v"(bc[0]), "v"(bc[1]), "v"(a[ks][rt][0]), "v"(a[ks][rt][1])); T[cur][rt][ct] = t; } else   // no MFMAs
+#endif
                         if constexpr (DOT) T[cur][rt][ct] = Pc::mma(bc, a[ks][rt], t);     // W image x rows: the transposed tile
                         else T[cur][rt][ct] = Pc::mma(a[ks][rt], bc, t);
                     }
-                    if (!lastg) {
+                    {
                         constexpr int NM = RT * Pc::NMF;                 // matrix instructions of the group (12 for bf16 x 3, 6 for fp16 x 2)
                         constexpr int NPAIR = NM < 8 ? NM : 8;           // (accumulate fma, MFMA) pairs of the chunk's first k-step
                         constexpr int NV = DOT ? DOT_VALU_SLOT : 1;      // VALU instructions in front of each of those MFMAs
-                        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
                         if (ks == 0) {
 #pragma unroll
                             for (int q = 0; q < NPAIR; ++q) {
@@ -607,6 +681,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+            }
+#undef BT_DS_WAIT
+#undef BT_DS_READ
             }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) xprev[rt] = xcur[rt];
@@ -638,11 +715,13 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
               }
           }
           if constexpr (DOT) {
-              // The interval's 2 * RT dot stores are YOUNGER than the W pieces staged at its top: vector memory operations retire in order, so
-              // "at most 2 * RT outstanding" means the pieces have landed -- without waiting for the stores' write acknowledgements (vmcnt(0),
+              // The interval's two dot stores (one per field; field + flush behind an odd field count) are YOUNGER than the W pieces staged at its top: vector memory operations retire in order, so
+              // "at most two outstanding" means the pieces have landed -- without waiting for the stores' write acknowledgements (vmcnt(0),
               // also the fence inside __syncthreads(), cost a memory round trip per interval: the whole gap between this form and the forward).
-              static_assert(RT == 2, "the counted wait below is written for two row tiles (four dot stores per interval)");
-              asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+              asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+#ifdef CIN_ABL
+              if (!(CIN_ABL & 128))
+#endif
               __builtin_amdgcn_s_barrier();
               asm volatile("" ::: "memory");
           } else {

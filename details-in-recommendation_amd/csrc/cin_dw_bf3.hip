@@ -226,18 +226,41 @@ __global__ __launch_bounds__(512, 1) void cin_dw_bf3_k(const float* __restrict__
         if (s + 1 < s_end) split_b(buf ^ 1);
         load_a(s + 1);                                   // (rows past R read as zeros; a step past the span is loaded and not used)
         load_b(s + 2);
+        // The xk pieces of i tile `it + 1` are read while tile `it` multiplies: by hand (inline asm + a counted lgkmcnt; LDS operations return
+        // in order, so "at most NP outstanding" = tile it's pieces are here).  The compiler read a tile's pieces, waited for them with
+        // lgkmcnt(0) and only then issued its 12 matrix instructions -- an LDS round trip exposed per tile, eight per step (round 5).
+        {
+            typedef unsigned int dwb_u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned int bl32 = (unsigned int)(size_t)&Bp[buf][0][0][lane][0];
+            dwb_u32x4 bq[2][NP];
+#define DWB_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(bl32), "n"(off))
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            op_t b[NP];
+            for (int pc = 0; pc < NP; ++pc) DWB_DS_READ(bq[0][pc], pc * 8 * 1024);
 #pragma unroll
-            for (int pc = 0; pc < NP; ++pc) b[pc] = *reinterpret_cast<const op_t*>(&Bp[buf][pc][it][lane][0]);
+            for (int it = 0; it < 8; ++it) {
+                if (it + 1 < 8) {
 #pragma unroll
-            for (int j = 0; j < DWB_JB; ++j) {
-                acc[j][it] = Pc::mma(a[j], b, acc[j][it]);
+                    for (int pc = 0; pc < NP; ++pc) DWB_DS_READ(bq[(it + 1) & 1][pc], (pc * 8 + it + 1) * 1024);
+                    if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bq[it & 1][0]), "+v"(bq[it & 1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bq[it & 1][0]), "+v"(bq[it & 1][1]), "+v"(bq[it & 1][NP - 1]));
+                } else {
+                    if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[it & 1][0]), "+v"(bq[it & 1][1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[it & 1][0]), "+v"(bq[it & 1][1]), "+v"(bq[it & 1][NP - 1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                op_t b[NP];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) b[pc] = __builtin_bit_cast(op_t, bq[it & 1][pc]);
+#pragma unroll
+                for (int j = 0; j < DWB_JB; ++j) {
+                    acc[j][it] = Pc::mma(a[j], b, acc[j][it]);
 #if DWB_CHAIN
-                __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (dense_bf3.hip: DB3_CHAIN)
+                    __builtin_amdgcn_sched_barrier(0);      // one dependent chain per accumulator (dense_bf3.hip: DB3_CHAIN)
 #endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+#undef DWB_DS_READ
         }
         __syncthreads();
     }
