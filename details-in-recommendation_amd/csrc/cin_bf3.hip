@@ -38,9 +38,6 @@
 #include "common.hpp"
 #include <type_traits>
 
-#ifndef DOT_CHAINS
-#define DOT_CHAINS 0        // dot form: one dependent MFMA chain per accumulator tile (0: the forward's k-step-major order)
-#endif
 #ifndef DOT_VALU_SLOT
 #define DOT_VALU_SLOT 2      // dot form: VALU instructions scheduled in front of each matrix instruction of a chunk's first k-step
 #endif
@@ -573,40 +570,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 if constexpr (RS && PAIRS) xcur[rt] *= rinv[rt];          // (not PAIRS: the slice in LDS already carries the rows' inverse scales)
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if constexpr (DOT && DOT_CHAINS) {
-                // Column tile outermost, both k-steps inside: a tile's KS * NMF matrix instructions form ONE dependent chain on its accumulator.
-                // Dependent 4-pass MFMAs issue back to back at no cost to the chain, and only while a wave waits on such a dependency does the
-                // SIMD hand issue slots to its other wave (tools/coexec_probe.hip: a stream that rotates over independent accumulators hides
-                // 1-3 % of the partner's VALU work, one chain 56-59 %): the chunk's ~70 VALU instructions were costing 1.4 of the layer's 2.9 ms.
-                op_t bq[2][KSN][NP];
-#pragma unroll
-                for (int ks = 0; ks < KSN; ++ks)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) bq[0][ks][p] = *reinterpret_cast<const op_t*>(wl + ks * STEPB + p * CT * 1024);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    if (ct + 1 < CT) {
-#pragma unroll
-                        for (int ks = 0; ks < KSN; ++ks)
-#pragma unroll
-                            for (int p = 0; p < NP; ++p)
-                                bq[(ct + 1) & 1][ks][p] = *reinterpret_cast<const op_t*>(wl + ks * STEPB + (ct + 1) * 1024 + p * CT * 1024);
-                    }
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) consume(rt, ct, T[prv][rt][ct], sd);
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int ks = 0; ks < KSN; ++ks) t = Pc::mma(bq[ct & 1][ks], a[ks][rt], t);
-                        T[cur][rt][ct] = t;
-#if DOT_CHAINS == 2
-                        __builtin_amdgcn_sched_barrier(0);      // strictly one chain after the other (1: the compiler alternates the two row tiles' chains)
-#endif
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
+            {
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
             // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
             // (two register sets used alternately: the loops are unrolled, the set index is a compile-time constant -- copying "next"
