@@ -49,7 +49,7 @@ if os.environ.get("DIR_DEVELOPMENT") == "1":
 # DIR_ABLATE="cin_bf3.hip:CIN_ABL=1": one timing-ablation macro for one translation unit (development; results are WRONG under most of them)
 if os.environ.get("DIR_ABLATE"):
     _f, _m = os.environ["DIR_ABLATE"].split(":", 1)
-    EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + (NO_PACKED_FP32 if _m == "NO_PACKED_FP32" else ["-D" + _m])
+    EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + (NO_PACKED_FP32 if _m == "NO_PACKED_FP32" else ["-D" + d for d in _m.split(",")])
 
 
 def _deps_mtime():

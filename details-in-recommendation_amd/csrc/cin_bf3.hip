@@ -38,9 +38,6 @@
 #include "common.hpp"
 #include <type_traits>
 
-#ifndef DOT_VALU_SLOT
-#define DOT_VALU_SLOT 2      // dot form: VALU instructions scheduled in front of each matrix instruction of a chunk's first k-step
-#endif
 
 namespace dir {
 
@@ -341,20 +338,15 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 
     // DOT: the accumulators are TRANSPOSED (the W image is the matrix instruction's A operand, the rows its B operand: same registers, swapped):
     // lane (n, lg) holds T[column 16 ct + 4 lg + q, row 16 rt + n].  The field factor x0[r, j] is then ONE value per lane and row tile, and
-    // the dot over the columns runs inside the lane (16 fmas + 2 cross-group adds per row tile and chunk; in the forward's layout it was a
-    // 16-lane reduction of four values per row tile: ~80 of the chunk's ~160 VALU instructions).  T has two buffers used alternately by
-    // the two fields of a staged chunk: the fmas that consume chunk c - 1 sit between the matrix instructions of chunk c and read registers
-    // those do not write (one buffer: the compiler copied all of T once per chunk and kept the fmas in a block behind the chunk).
-    constexpr int NTB = DOT ? 2 : 1;
-    static_assert(!DOT || FJ == 2, "the dot form alternates two T buffers over the two fields of a staged chunk");
-    f32x4 out[RT][CT], T[NTB][RT][CT];
+    // the dot over the columns runs inside the lane (16 fmas + a two-step fold of the lane groups per row tile and chunk; in the forward's
+    // layout it was a 16-lane reduction of four values per row tile: ~80 of the chunk's ~160 VALU instructions).
+    f32x4 out[RT][CT], T[1][RT][CT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             out[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tb = 0; tb < NTB; ++tb) T[tb][rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            T[0][rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     f32x4 xprev[RT];                                                                 // x0[rows of the lane's accumulator registers, previous field]
 #pragma unroll                                                                       //  (DOT: the lane's ONE row per tile, in element 0)
@@ -470,8 +462,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #endif
         *dst = v;
     };
-    // one tile of the previous chunk goes into `out` (and the dot)
-    auto consume = [&](int rt, int ct, const f32x4& t, f32x4 (&sd)[RT]) {
+    // one tile of a chunk goes into `out` (and the dot); xf: the chunk's field factors
+    auto consume = [&](int rt, int ct, const f32x4& t, f32x4 (&sd)[RT], const f32x4 (&xf)[RT]) {
 #ifdef CIN_ABL
         if (DOT && (CIN_ABL & 8)) { asm volatile("" :: "v"(t)); return; }          // no consume fmas; the tile stays "used"
 #endif
@@ -479,7 +471,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             // explicit pairs (v_pk_fma_f32 on register-adjacent halves): left to itself the compiler pairs the dot's fmas ACROSS tiles, with two
             // v_mov per packed fma, and moves them behind the chunk
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const f32x2 xb = {xprev[rt][0], xprev[rt][0]};
+            const f32x2 xb = {xf[rt][0], xf[rt][0]};
             const f32x2 tl = __builtin_shufflevector(t, t, 0, 1), th = __builtin_shufflevector(t, t, 2, 3);
             const f32x4 o = out[rt][ct], y4 = yv[rt][ct], s4 = sd[rt];
             const f32x2 ol = __builtin_elementwise_fma(xb, tl, __builtin_shufflevector(o, o, 0, 1));
@@ -490,10 +482,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             sd[rt] = (f32x4){sl[0], sl[1], sh[0], sh[1]};
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xprev[rt][q], t[q], out[rt][ct][q]);
+            for (int q = 0; q < 4; ++q) out[rt][ct][q] = __builtin_fmaf(xf[rt][q], t[q], out[rt][ct][q]);
         }
     };
-    bool dot_pending = false;                   // DOT: T[1] (T[0] behind an odd chunk) holds a chunk that has not been consumed
 
     int u = 0;                                  // staged chunk index (its LDS buffer: u & 1)
 #ifdef CIN_ABL
@@ -554,10 +545,10 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 #endif
               if (cn < nchunk) stage_w(cn, min(FJ, m - (j0 + nf < m ? j0 + nf : 0)), buf ^ 1);
           }
-          // field f of the staged chunk: a compile-time index in the dot form (it selects the T buffer the chunk writes)
+          // field f of the staged chunk
           auto field = [&](auto fc) __attribute__((always_inline)) {
             constexpr int f = decltype(fc)::value;
-            constexpr int cur = DOT ? (f & 1) : 0, prv = DOT ? (cur ^ 1) : 0;
+            constexpr int cur = 0, prv = 0;
             constexpr int KSN = KS;
             const int j = j0 + f;
             const unsigned char* wl = wlane + buf * (FJ * CHB) + f * CHB;
@@ -570,6 +561,53 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 if constexpr (RS && PAIRS) xcur[rt] *= rinv[rt];          // (not PAIRS: the slice in LDS already carries the rows' inverse scales)
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            if constexpr (DOT) {
+                // The dot form: a chunk's matrix instructions as ONE block -- column tile outermost, both k-steps inside, so that a tile's
+                // KS * NMF instructions are one dependent chain on its accumulator --, then its accumulate fmas as one block.  The SIMD's
+                // arbiter serves the oldest / highest-priority READY wave: a wave inside a dependent chain is not ready three cycles out of
+                // four, and only then does its partner's VALU work get issued (tools/coexec_probe.hip: beside a stream of INDEPENDENT MFMAs,
+                // or under a prioritised VALU stream, the partner gets nothing: the times add).  With the fmas interleaved between the chunk's
+                // own matrix instructions both waves of a SIMD were in the same mixed phase all the time; as two blocks the partner's
+                // block of fmas falls beside this wave's chains once the two drift apart: cin_backward 7.60 -> 7.46 ms on one box, the same
+                // with s_setprio 0 / 1 / 2 / 3 around the chains, less (7.52-7.57) with the fmas first or with the halves of the workgroup
+                // in opposite orders (profiles/r05_ab_dot_blocks.txt).
+                op_t bq[2][KSN][NP];
+#pragma unroll
+                for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bq[0][ks][p] = *reinterpret_cast<const op_t*>(wl + ks * STEPB + p * CT * 1024);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (ct + 1 < CT) {
+#ifdef CIN_ABL
+                        if (!(CIN_ABL & 64))          // no LDS reads behind the chunk's first
+#endif
+#pragma unroll
+                        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                bq[(ct + 1) & 1][ks][p] = *reinterpret_cast<const op_t*>(wl + ks * STEPB + (ct + 1) * 1024 + p * CT * 1024);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef CIN_ABL
+                        if (CIN_ABL & 32) asm volatile("" : "+v"(t) : "v"(bq[ct & 1][0][0]), "v"(bq[ct & 1][KSN - 1][NP - 1]), "v"(a[0][rt][0]), "v"(a[KSN - 1][rt][NP - 1])); else   // no MFMAs
+#endif
+#pragma unroll
+                        for (int ks = 0; ks < KSN; ++ks) t = Pc::mma(bq[ct & 1][ks], a[ks][rt], t);     // W image x rows: the transposed tile
+                        T[0][rt][ct] = t;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) consume(rt, ct, T[0][rt][ct], sd, xcur);
+                store_dot(sd, kh, j);
+            } else
             {
             // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
             // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
@@ -597,9 +635,6 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     const bool lastg = (ks == KSN - 1 && ct == CT - 1);
                     const int gi = ks * CT + ct;                     // group index inside the chunk (compile-time after unrolling)
                     if (!lastg) {
-#ifdef CIN_ABL
-                        if (DOT && (CIN_ABL & 64)) { asm volatile("" : "+v"(bq[(gi + 1) & 1][0]), "+v"(bq[(gi + 1) & 1][1])); } else   // no LDS reads behind the chunk's first
-#endif
 #pragma unroll
                         for (int p = 0; p < NP; ++p)
                             BT_DS_READ(bq[(gi + 1) & 1][p], (ct + 1 < CT ? ks : ks + 1) * STEPB + ((ct + 1) % CT) * 1024 + p * CT * 1024);
@@ -617,21 +652,17 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                         if (ks == 0) {
                             // the previous chunk's T tile goes into `out` just before this chunk's first MFMA chain overwrites it (DOT: beside
                             // the chain that fills the other buffer)
-                            consume(rt, ct, T[prv][rt][ct], sd);
+                            consume(rt, ct, T[prv][rt][ct], sd, xprev);
                             t = (f32x4){0.f, 0.f, 0.f, 0.f};
                         } else {
                             t = T[cur][rt][ct];
                         }
-#ifdef CIN_ABL
-                        if (DOT && (CIN_ABL & 32)) { asm volatile("" : "+v"(t) : "v"(bc[0]), "v"(bc[1]), "v"(a[ks][rt][0]), "v"(a[ks][rt][1])); T[cur][rt][ct] = t; } else   // no MFMAs
-#endif
-                        if constexpr (DOT) T[cur][rt][ct] = Pc::mma(bc, a[ks][rt], t);     // W image x rows: the transposed tile
-                        else T[cur][rt][ct] = Pc::mma(a[ks][rt], bc, t);
+                        T[cur][rt][ct] = Pc::mma(a[ks][rt], bc, t);
                     }
                     {
                         constexpr int NM = RT * Pc::NMF;                 // matrix instructions of the group (12 for bf16 x 3, 6 for fp16 x 2)
                         constexpr int NPAIR = NM < 8 ? NM : 8;           // (accumulate fma, MFMA) pairs of the chunk's first k-step
-                        constexpr int NV = DOT ? DOT_VALU_SLOT : 1;      // VALU instructions in front of each of those MFMAs
+                        constexpr int NV = 1;                            // VALU instructions in front of each of those MFMAs
                         if (ks == 0) {
 #pragma unroll
                             for (int q = 0; q < NPAIR; ++q) {
@@ -651,38 +682,17 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) xprev[rt] = xcur[rt];
-            if constexpr (DOT) {          // sd holds the dot of the PREVIOUS chunk (its T tiles were consumed during this chunk's first k-step)
-                // (only the store is predicated: a branch around the reduction lets the compiler sink the chunk's fmas into it, behind the MFMAs)
-                store_dot(sd, j == 0 ? kh - 1 : kh, j == 0 ? m - 1 : j - 1, dot_pending);
-                dot_pending = true;
-            }
           };
           field(std::integral_constant<int, 0>{});
           if constexpr (FJ == 2) {
               if (nf > 1) field(std::integral_constant<int, 1>{});
-              if constexpr (DOT) {
-                  if (nf == 1) {          // an odd field count: the half's last chunk sits in T[0], which the next staged chunk's first field overwrites
-                      f32x4 sd[RT];
-#pragma unroll
-                      for (int rt = 0; rt < RT; ++rt) {
-                          sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                          for (int ct = 0; ct < CT; ++ct) {
-                              consume(rt, ct, T[0][rt][ct], sd);
-                              T[1][rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                          }
-                          xprev[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                      }
-                      store_dot(sd, kh, j0);
-                      dot_pending = false;
-                  }
-              }
           }
           if constexpr (DOT) {
-              // The interval's two dot stores (one per field; field + flush behind an odd field count) are YOUNGER than the W pieces staged at its top: vector memory operations retire in order, so
-              // "at most two outstanding" means the pieces have landed -- without waiting for the stores' write acknowledgements (vmcnt(0),
-              // also the fence inside __syncthreads(), cost a memory round trip per interval: the whole gap between this form and the forward).
-              asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+              // The interval's dot stores (one per field) are YOUNGER than the W pieces staged at its top: vector memory operations retire in
+              // order, so "at most nf outstanding" means the pieces have landed -- without waiting for the stores' write acknowledgements
+              // (vmcnt(0), also the fence inside __syncthreads(), cost a memory round trip per interval).
+              if (nf > 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
 #ifdef CIN_ABL
               if (!(CIN_ABL & 128))
 #endif
@@ -694,18 +704,15 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
           }
         }
     }
-    // the last chunk's T
-    {
+    // the last chunk's T (the dot form consumes a chunk's tiles behind its own matrix instructions)
+    if constexpr (!DOT) {
         f32x4 sd[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!DOT || dot_pending) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) consume(rt, ct, T[NTB - 1][rt][ct], sd);
-            if constexpr (DOT) store_dot(sd, nkh - 1, m - 1);
-        }
+            for (int ct = 0; ct < CT; ++ct) consume(rt, ct, T[0][rt][ct], sd, xprev);
     }
 
     if constexpr (!RS && NP == 2 && !DOT && !PAIRS) {
