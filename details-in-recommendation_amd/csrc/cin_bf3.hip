@@ -21,8 +21,10 @@
 // Work split.  A workgroup of 8 waves (two per SIMD, <= 256 VGPRs, MFMA results kept in VGPRs) owns 256 rows x 128 columns; wave w
 // rows [32w, 32w+32) = 2 row tiles x 8 column tiles of 16 x 16: 64 registers for T_j and 64 for out.  i runs in halves of KS*32
 // values (KS = 2; 1 when Hp <= 32); a chunk is one (half, field j): KS k-steps x 16 tiles x 6 = 192 MFMAs per wave, one barrier
-// per chunk.  B operands are read one (k-step, column tile) group ahead of their 12 MFMAs; the accumulate fmas of a tile sit
-// between the MFMAs of the chain that overwrites it.  H's columns are cut into 128-wide blocks plus ONE narrower last block of
+// per chunk.  Since round 5 a chunk is two blocks: its matrix instructions, column tile outermost so that a tile's KS * NMF instructions
+// form one dependent chain (B operands read one column tile ahead), then its accumulate fmas -- see the comment in the kernel and
+// profiles/NOTES.md R5.9 / R5.10 for why (rounds 2-4 placed the fmas of the PREVIOUS chunk between the matrix instructions of the first
+// k-step).  H's columns are cut into 128-wide blocks plus ONE narrower last block of
 // 2 / 4 / 6 column tiles (template parameter CT; its own launch with a column offset).
 // Operand registers and two waves per SIMD: the A operands are rewritten once per half behind a barrier, the B operands arrive by
 // LDS reads into alternating registers -- no VALU instruction writes an MFMA source register close behind the MFMAs that read it
@@ -348,9 +350,6 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
             out[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
             T[0][rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    f32x4 xprev[RT];                                                                 // x0[rows of the lane's accumulator registers, previous field]
-#pragma unroll                                                                       //  (DOT: the lane's ONE row per tile, in element 0)
-    for (int rt = 0; rt < RT; ++rt) xprev[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     op_t a[KS][RT][NP];                                                              // the half's A operands: [k-step][row tile][piece]
     // DOT: y in the accumulators' (transposed) layout: row 16*rt + n, columns 16*ct + 4*lg + q
     f32x4 yv[DOT ? RT : 1][DOT ? CT : 1];
@@ -548,7 +547,6 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
           // field f of the staged chunk
           auto field = [&](auto fc) __attribute__((always_inline)) {
             constexpr int f = decltype(fc)::value;
-            constexpr int cur = 0, prv = 0;
             constexpr int KSN = KS;
             const int j = j0 + f;
             const unsigned char* wl = wlane + buf * (FJ * CHB) + f * CHB;
@@ -561,8 +559,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 if constexpr (RS && PAIRS) xcur[rt] *= rinv[rt];          // (not PAIRS: the slice in LDS already carries the rows' inverse scales)
                 sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if constexpr (DOT) {
-                // The dot form: a chunk's matrix instructions as ONE block -- column tile outermost, both k-steps inside, so that a tile's
+            {
+                // A chunk's matrix instructions as ONE block -- column tile outermost, both k-steps inside, so that a tile's
                 // KS * NMF instructions are one dependent chain on its accumulator --, then its accumulate fmas as one block.  The SIMD's
                 // arbiter serves the oldest / highest-priority READY wave: a wave inside a dependent chain is not ready three cycles out of
                 // four, and only then does its partner's VALU work get issued (tools/coexec_probe.hip: beside a stream of INDEPENDENT MFMAs,
@@ -596,7 +594,10 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                         if (CIN_ABL & 32) asm volatile("" : "+v"(t) : "v"(bq[ct & 1][0][0]), "v"(bq[ct & 1][KSN - 1][NP - 1]), "v"(a[0][rt][0]), "v"(a[KSN - 1][rt][NP - 1])); else   // no MFMAs
 #endif
 #pragma unroll
-                        for (int ks = 0; ks < KSN; ++ks) t = Pc::mma(bq[ct & 1][ks], a[ks][rt], t);     // W image x rows: the transposed tile
+                        for (int ks = 0; ks < KSN; ++ks) {
+                            if constexpr (DOT) t = Pc::mma(bq[ct & 1][ks], a[ks][rt], t);     // W image x rows: the transposed tile
+                            else t = Pc::mma(a[ks][rt], bq[ct & 1][ks], t);
+                        }
                         T[0][rt][ct] = t;
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -606,82 +607,8 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) consume(rt, ct, T[0][rt][ct], sd, xcur);
-                store_dot(sd, kh, j);
-            } else
-            {
-            // B operands one (k-step, column tile) group ahead of their 12 MFMAs (the compiler issues the reads right in front of
-            // their use otherwise); a group's issue order is fixed below: LDS reads, then MFMAs with the accumulate fmas between them
-            // (two register sets used alternately: the loops are unrolled, the set index is a compile-time constant -- copying "next"
-            // into "current" would cost 12 v_mov per group, one VALU instruction per MFMA)
-            // The reads are issued by hand (inline asm) and waited for with a COUNTED lgkmcnt: LDS reads return in order, so "at most NP
-            // outstanding" = this group's NP pieces are here, the next group's may still be in flight.  Left to the compiler, the wait in
-            // front of a group's first MFMA was lgkmcnt(0) placed BEHIND the next group's reads: every second group stood through a whole
-            // LDS round trip with nothing else in flight in its wave (round 5; the tower kernel has had this pipeline since round 3).
-            // An outstanding LDS operation of the compiler's own (the field factor, a dot's ds_bpermute) only makes a counted wait wait longer.
-            const unsigned int wl32 = (unsigned int)(size_t)wl;
-            u32x4_t bq[2][NP];
-#define BT_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(wl32), "n"(off))
-#define BT_DS_WAIT(cnt, set)                                                                                          \
-    do {                                                                                                              \
-        if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(bq[set][0]), "+v"(bq[set][1]));      \
-        else asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(bq[set][0]), "+v"(bq[set][1]), "+v"(bq[set][NP - 1])); \
-    } while (0)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) BT_DS_READ(bq[0][p], p * CT * 1024);
-#pragma unroll
-            for (int ks = 0; ks < KSN; ++ks) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const bool lastg = (ks == KSN - 1 && ct == CT - 1);
-                    const int gi = ks * CT + ct;                     // group index inside the chunk (compile-time after unrolling)
-                    if (!lastg) {
-#pragma unroll
-                        for (int p = 0; p < NP; ++p)
-                            BT_DS_READ(bq[(gi + 1) & 1][p], (ct + 1 < CT ? ks : ks + 1) * STEPB + ((ct + 1) % CT) * 1024 + p * CT * 1024);
-                        if constexpr (NP == 2) BT_DS_WAIT(2, gi & 1); else BT_DS_WAIT(3, gi & 1);
-                    } else {
-                        BT_DS_WAIT(0, gi & 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    op_t bc[NP];
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) bc[p] = __builtin_bit_cast(op_t, bq[gi & 1][p]);
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        f32x4 t;
-                        if (ks == 0) {
-                            // the previous chunk's T tile goes into `out` just before this chunk's first MFMA chain overwrites it (DOT: beside
-                            // the chain that fills the other buffer)
-                            consume(rt, ct, T[prv][rt][ct], sd, xprev);
-                            t = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        } else {
-                            t = T[cur][rt][ct];
-                        }
-                        T[cur][rt][ct] = Pc::mma(a[ks][rt], bc, t);
-                    }
-                    {
-                        constexpr int NM = RT * Pc::NMF;                 // matrix instructions of the group (12 for bf16 x 3, 6 for fp16 x 2)
-                        constexpr int NPAIR = NM < 8 ? NM : 8;           // (accumulate fma, MFMA) pairs of the chunk's first k-step
-                        constexpr int NV = 1;                            // VALU instructions in front of each of those MFMAs
-                        if (ks == 0) {
-#pragma unroll
-                            for (int q = 0; q < NPAIR; ++q) {
-                                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            }
-                            if constexpr (NM > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NPAIR, 0);
-                        } else {
-                            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                if constexpr (DOT) store_dot(sd, kh, j);
             }
-#undef BT_DS_WAIT
-#undef BT_DS_READ
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) xprev[rt] = xcur[rt];
           };
           field(std::integral_constant<int, 0>{});
           if constexpr (FJ == 2) {
@@ -704,17 +631,6 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
           }
         }
     }
-    // the last chunk's T (the dot form consumes a chunk's tiles behind its own matrix instructions)
-    if constexpr (!DOT) {
-        f32x4 sd[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) sd[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) consume(rt, ct, T[0][rt][ct], sd, xprev);
-    }
-
     if constexpr (!RS && NP == 2 && !DOT && !PAIRS) {
         if (vwant == 1) {                                           // (uniform) the plain kernel under the verdict: the image carries W's tensor scale
             const float winv = pow2f(-w_scale_exp(wpart));
