@@ -162,11 +162,20 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
     const int kv = K >> 2;
     const bool cact = c < kv;
     const bool want_lin = lin_out != nullptr && lin_col >= 0;
+    // Line mode (round 5): the launcher gives a sample enough lanes to cover the first-order column too (K = 16, lin_col = 16: 8 lanes of
+    // 16 bytes = the whole 128-byte row), so the weight arrives with the row's ONE request; lane cl holds it and keeps the running sum.
+    // (Four lanes + a separate 4-byte load by lane 0 were two requests per row: the second one hits the line in L2 but costs its own slot
+    // on the way to the CU -- 76.8 us against the plain gather's 61.)
+    const int cl = want_lin ? (lin_col >> 2) : -1;
+    const bool line = cl >= kv && cl < LPS;                 // (kernel-uniform)
+    const int lw_lane = line ? cl : 0;
+    const bool lact = line ? (c * 4 + 4 <= ld) : cact;      // lanes that load a piece of the row
     const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
     for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
         const int64_t b = g * SPW + s;
         const bool act = cact && (b < B);
-        const int64_t* idp = ids + (act ? b * sb : 0);
+        const bool ldact = lact && (b < B);
+        const int64_t* idp = ids + (ldact ? b * sb : 0);
         float* op = out ? out + (act ? b * out_ld : 0) + c * 4 : nullptr;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
         float lin = 0.f;
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
 #pragma unroll
             for (int u = 0; u < UF; ++u) {
                 const int f = f0 + u;
-                id[u] = (act && f < F) ? idp[(int64_t)f * sf] : (int64_t)-1;
+                id[u] = (ldact && f < F) ? idp[(int64_t)f * sf] : (int64_t)-1;
             }
             float4 row[UF];
             float lw[UF];
@@ -187,7 +196,15 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
                 if (f < F && (uint64_t)id[u] < id_bound(vocab, f)) {
                     const float* t = tables[f] + id[u] * ld;
                     row[u] = NT ? ldv_nt(t + c * 4, (float4*)nullptr) : ldv(t + c * 4, (float4*)nullptr);
-                    if (want_lin && c == 0) lw[u] = NT ? ldv_nt(t + lin_col, (float*)nullptr) : t[lin_col];
+                    if (want_lin && !line && c == 0) lw[u] = NT ? ldv_nt(t + lin_col, (float*)nullptr) : t[lin_col];
+                }
+            }
+            if (line) {                                     // the weight is element lin_col & 3 of lane cl's piece; lanes past the embedding add nothing
+#pragma unroll
+                for (int u = 0; u < UF; ++u) {
+                    const int e = lin_col & 3;
+                    lw[u] = c == cl ? (e == 0 ? row[u].x : e == 1 ? row[u].y : e == 2 ? row[u].z : row[u].w) : 0.f;
+                    if (!cact) row[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
@@ -206,7 +223,7 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
             const float r = fm_tail<LPS>(sum, sq, lane, c);
             if (c == LPS - 1 && b < B) fm[b] = r;
         }
-        if (want_lin && c == 0 && b < B) lin_out[b] = lin + (bias ? bias[0] : 0.f);
+        if (want_lin && c == lw_lane && b < B) lin_out[b] = lin + (bias ? bias[0] : 0.f);
     }
 }
 
@@ -623,8 +640,10 @@ static int gather_packed_launch(const float* const* tables, const int64_t* vocab
     DIR_CHECK_ARG(!out || out_ld >= (int64_t)F * K, "dir_gather_fm_linear_packed_f32: out_ld");
     if ((K & 3) || (ld & 3) || (out && ((out_ld & 3) || !aligned16(out))))
         return fail(DIR_E_UNSUPPORTED, "dir_gather_fm_linear_packed_f32: K, ld, out_ld must be multiples of 4 and out 16-byte aligned");
-    const int lps = next_pow2(K / 4);
+    int lps = next_pow2(K / 4);
     if (lps > 16) return fail(DIR_E_UNSUPPORTED, "dir_gather_fm_linear_packed_f32: K=%d (supported: up to 64)", K);
+    // line mode (see the kernel): twice the lanes per sample when that brings the first-order column into the row's own request
+    if (lin_out && lin_col >= K && next_pow2(lin_col / 4 + 1) == 2 * lps && 2 * lps <= 16) lps *= 2;
     const int spw = 64 / lps;
     const int64_t waves = (B + spw - 1) / spw;
     const int64_t work = (waves + 3) / 4;
