@@ -260,10 +260,19 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     const int wave = tid >> 6;
     const int n = lane & 15;
     const int lg = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * BT_ROWS;
-    const int hbase = hoff + blockIdx.y * (16 * CT);
+    // (row block, column block) of this workgroup.  With TWO column blocks (the dot form at H = 128) the pair that shares a row block --
+    // and so reads the same 128 KB of xk rows -- is made two CONSECUTIVE workgroups of one XCD (workgroup L runs on XCD L % 8): the second
+    // one finds the rows in that XCD's L2 instead of reading them from HBM a second time (x-fastest dispatch put them 4096 workgroups apart).
+    unsigned int rbi = blockIdx.x, cbi = blockIdx.y;
+    if (gridDim.y == 2 && (gridDim.x & 7) == 0) {
+        const unsigned int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, k = L >> 3;
+        cbi = k & 1;
+        rbi = (k >> 1) * 8 + xcd;
+    }
+    const int64_t row0 = (int64_t)rbi * BT_ROWS;
+    const int hbase = hoff + cbi * (16 * CT);
     const int nchunk = nkh * m;
-    const unsigned char* gimg = img + (int64_t)blockIdx.y * nchunk * CHB;
+    const unsigned char* gimg = img + (int64_t)cbi * nchunk * CHB;
 
     auto stage_w = [&](int c, int nf, int buf) {     // fields c .. c + nf - 1: nf * KS * 3 * CT pieces of 1 KB over 8 waves, lane-linear
         for (int piece = wave; piece < nf * KS * NP * CT; piece += 8) {
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if constexpr (RS) {
-        if (amax_out && blockIdx.y == 0 && tid == 0) {
+        if (amax_out && cbi == 0 && tid == 0) {
             float wm = bt_wmax[0];
 #pragma unroll
             for (int q = 1; q < 8; ++q) wm = fmaxf(wm, bt_wmax[q]);
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         }
     }
 
-    if constexpr (DOT) dotp += (int64_t)blockIdx.y * nkh * (R >> dshift) * m * D;     // this column block's partials
+    if constexpr (DOT) dotp += (int64_t)cbi * nkh * (R >> dshift) * m * D;     // this column block's partials
     const unsigned char* wlane = Wb + lane * 16;
     const float* x0lane = x0s + wave * WR + (DOT ? n : 4 * lg);      // + j*BT_ROWS + 16*rt: the 4 rows of accumulator registers 0..3 of tile rt
                                                                       //   (DOT: the one row of the lane's transposed accumulators)
