@@ -114,7 +114,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="deepfm_gather_fm",
                     choices=["deepfm_gather_fm", "gather_only", "fm_only", "linear", "dcn_cross", "dcn_cross_backward", "din", "din_train", "cin", "cin_backward", "deepfm_full", "multihot_bag", "deepfm_train", "dcn_train", "xdeepfm_full", "xdeepfm_train",
-                             "sharded_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense", "esmm_full", "esmm_train", "deepfm_full_packed",
+                             "sharded_1gpu", "sharded_deepfm_1gpu", "transform", "dcn_full", "train_sparse", "small_batch", "deepfm_sparse_packed", "mlp_dense", "esmm_full", "esmm_train", "deepfm_full_packed",
                              "din_full"])
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--fields", type=int, default=26)
@@ -825,6 +825,34 @@ def main():
         step = lambda i: st.lookup(idsl[i % len(idsl)], want_fm=True)  # noqa: E731
         roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K) + 4), "kernel": "bucket + gather_packed + gather_onehot_k"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K})
+    elif wl == "sharded_deepfm_1gpu":
+        # Sharded lookup -> DeepFM tower (FM term + 400-400-400 + head) on one GPU without collectives, two ways:
+        #   DIR_BENCH_SHARD_CONSUME=1 (default): ShardedTables.lookup_consume -- the tower kernel reads the received rows through the inverse
+        #     positions; rank-local passes: bucket + owner gather, then the tower's own lookups (no [B, F*K] concatenation exists);
+        #   DIR_BENCH_SHARD_CONSUME=0: lookup(want_fm=True) (bucket + owner gather + finish pass) + the plain tower with the FM addend.
+        from dir_amd.shard import rows_as_tables
+        sigma = 1.0 / (K ** 0.5)
+        loc = [torch.randn((V, K), generator=gen, device=device) * sigma for _ in range(F)]
+        st = ShardedTables(loc, [V] * F)
+        idsl = make_ids(torch, args, gen, device, V)
+        Ws = [torch.randn((400, F * K), generator=gen, device=device) * 0.05, torch.randn((400, 400), generator=gen, device=device) * 0.05,
+              torch.randn((400, 400), generator=gen, device=device) * 0.05]
+        bs = [torch.zeros(400, device=device) for _ in Ws]
+        hw, hb = torch.randn((400,), generator=gen, device=device) * 0.05, torch.zeros(1, device=device)
+        logit = torch.empty((B, 1), dtype=torch.float32, device=device)
+        consume = os.environ.get("DIR_BENCH_SHARD_CONSUME", "1") != "0"
+
+        def consumer(s, e, rows, inv):
+            ops.tower(None, Ws, bs, head=(hw, hb), gather=(rows_as_tables(rows, F), inv, None, True), out=logit[s:e], split="f16x2")
+
+        if consume:
+            step = lambda i: st.lookup_consume(idsl[i % len(idsl)], consumer)  # noqa: E731
+        else:
+            def step(i):
+                emb, fm = st.lookup(idsl[i % len(idsl)], want_fm=True)
+                ops.tower(emb, Ws, bs, head=(hw, hb), adds=(fm,), out=logit, split="f16x2")
+        roof = {"bound": "hbm", "alg_bytes": B * (F * (8 + 2 * 4 * K) + 4), "kernel": "bucket + gather_slabs + " + ("tower_bf3_k<GATHER> over the received rows" if consume else "gather_onehot_k (finish) + tower_bf3_k")}
+        cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "finish_pass": not consume, "tower": "416-400-400-400-1 + FM"})
     elif wl == "deepfm_sparse_packed":
         # DeepFM's three sparse terms (concat, FM, linear) from packed 128-byte rows in ONE pass, vs gather_fm + linear
         sigma = 1.0 / (K ** 0.5)

@@ -154,6 +154,22 @@ class HipBackend:
             ops.embedding_bag(ts, inv2d, out=out)
 
 
+_ROWS_TS = {}
+
+
+def rows_as_tables(rows, F):
+    """The received row buffer of a lookup_consume() micro-batch as a TableSet of F identical "tables" (one per slot), cached by
+    address: what ops.gather_fm / ops.tower(gather=...) take as their tables, with the inverse positions as ids."""
+    key = (rows.data_ptr(), rows.shape[0], rows.shape[1], F)
+    ts = _ROWS_TS.get(key)
+    if ts is None:
+        if len(_ROWS_TS) > 64:
+            _ROWS_TS.clear()
+        ts = _ROWS_TS[key] = ops.TableSet([rows] * F)
+        ts.row_policy = "reuse"      # just received: largely cache-resident
+    return ts
+
+
 class _Plan:
     """Persistent buffers of the fixed-capacity pipeline for one (local batch size, buffer slot, slab capacity): stable addresses,
     so nothing is allocated per lookup and a lookup can be captured in a HIP graph.  Only the slab capacity has to agree across
@@ -189,9 +205,10 @@ class _Lookup:
     applies the overflow policy and returns emb (or (emb, fm)).  Issue the NEXT lookup before calling result() -- or before the
     compute that consumes this one -- and the exchange runs under that compute."""
 
-    def __init__(self, st, plan, ids, want_fm, out, fm, done, exact=None):
+    def __init__(self, st, plan, ids, want_fm, out, fm, done, exact=None, consumer=None):
         self.st, self.plan, self.ids, self.want_fm, self.out, self.fm, self.done = st, plan, ids, want_fm, out, fm, done
         self.exact = exact
+        self.consumer = consumer
         self.fin = plan.fin if plan is not None else None      # this lookup's completion events on the side streams
         self.joined = exact is not None
         self.checked = exact is not None or done is False
@@ -218,7 +235,7 @@ class _Lookup:
                 st._learn(self.plan, over, demand)
                 if over:                                      # rare: repeat on the exact path (results overwrite out / fm in stream order)
                     st.stats["fallbacks"] += 1
-                    st._lookup_exact(self.ids, self.want_fm, out=self.out, fm=self.fm)
+                    st._lookup_exact(self.ids, self.want_fm, out=self.out, fm=self.fm, consumer=self.consumer)
         return (self.out, self.fm) if self.want_fm else self.out
 
 
@@ -437,7 +454,7 @@ class ShardedTables:
         self.backend.apply_adagrad(self.optimizer, recv, grecv)
 
     # ---- the exact, variable-size lookup (one host read of the split sizes) --------------------------------
-    def _lookup_exact(self, ids, want_fm, out=None, fm=None):
+    def _lookup_exact(self, ids, want_fm, out=None, fm=None, consumer=None):
         B, F = ids.shape
         K, be = self.K, self.backend
         flat = ids.reshape(-1).contiguous()
@@ -452,6 +469,9 @@ class ShardedTables:
         rows = be.gather_packed(recv)                                       # HIP (owner side)
         back = be.back_buffer(n, K, flat.device)
         self._a2a(back.view(-1), rows.reshape(-1), [c * K for c in sc], [c * K for c in rc])
+        if consumer is not None:                                            # (lookup_consume: the caller's kernel reads the rows where they are)
+            consumer(0, B, back, inv.view(B, F))
+            return None, None
         return be.finish(back, inv, B, F, want_fm, out=out, fm=fm)          # HIP: un-permute (+ FM)
 
     # ---- the fixed-capacity, pipelined lookup ---------------------------------------------------------------
@@ -513,7 +533,7 @@ class ShardedTables:
             self._chk_stream = torch.cuda.Stream(device=self.device)
         return self._streams
 
-    def _enqueue(self, plan, ids, want_fm, out, fm, dedup):
+    def _enqueue(self, plan, ids, want_fm, out, fm, dedup, consumer=None):
         """Enqueue one lookup's pipeline.  -> False (nothing to check: one rank, slabs hold the whole batch), None (statistic in
         plan.stat, no event: CPU backend) or the event after which plan.host holds [overflow, demand]."""
         B, F = ids.shape
@@ -524,7 +544,9 @@ class ShardedTables:
             # one rank, no exchange: the three kernels back to back on the caller's stream
             be.bucket_cap(ids, cap, plan.send[0], plan.inv[0], plan.counts[0], plan.flags[0], plan.ws[0], stat=plan.cstat[0], dedup=dedup)
             be.gather_slabs(plan.recv[0], cap, plan.rows[0])
-            if B:
+            if B and consumer is not None:
+                consumer(0, B, plan.back[0], be.inv2d(plan.inv[0], B, F, dedup))
+            elif B:
                 be.finish_chunk(plan.back[0], be.inv2d(plan.inv[0], B, F, dedup), want_fm, out, fm if want_fm else None)
             return False
         S = self._ensure_streams()
@@ -547,7 +569,9 @@ class ShardedTables:
 
         def finish(c):
             s, e = plan.bounds[c]
-            if e > s:
+            if e > s and consumer is not None:
+                consumer(s, e, plan.back[c], be.inv2d(plan.inv[c], e - s, F, dedup))
+            elif e > s:
                 be.finish_chunk(plan.back[c], be.inv2d(plan.inv[c], e - s, F, dedup), want_fm, out[s:e], fm[s:e] if want_fm else None)
 
         wi, wr = [None] * C, [None] * C
@@ -640,17 +664,18 @@ class ShardedTables:
         self._drain_unchecked(block=True)
         return False
 
-    def lookup_async(self, ids, want_fm=False, out=None, fm=None):
+    def lookup_async(self, ids, want_fm=False, out=None, fm=None, consumer=None):
         """Enqueue a lookup and return a handle; handle.result() -> emb [B_local, F*K] (or (emb, fm)).  Two lookups can be in
-        flight (double-buffered plans): issue lookup i+1, then consume lookup i -- the exchange of i+1 runs under that compute."""
+        flight (double-buffered plans): issue lookup i+1, then consume lookup i -- the exchange of i+1 runs under that compute.
+        consumer: see lookup_consume (no emb / fm are produced then)."""
         B, F = ids.shape
         if F != self.F:
             raise ValueError("ids must be [B, F=%d]" % self.F)
         self.stats["lookups"] += 1
         if self._use_exact or (B == 0 and not self._collective()):
-            emb, fmo = self._lookup_exact(ids, want_fm, out=out, fm=fm)
-            return _Lookup(self, None, ids, want_fm, emb, fmo, None, exact=(emb, fmo) if want_fm else emb)
-        if out is None:
+            emb, fmo = self._lookup_exact(ids, want_fm, out=out, fm=fm, consumer=consumer)
+            return _Lookup(self, None, ids, want_fm, emb, fmo, None, exact=(emb, fmo) if want_fm else (emb if consumer is None else ()), consumer=consumer)
+        if out is None and consumer is None:
             out = torch.empty((B, F * self.K), dtype=torch.float32, device=ids.device)
         if want_fm and fm is None:
             fm = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
@@ -660,8 +685,8 @@ class ShardedTables:
         if prev is not None:
             prev.join()                                   # its buffers are about to be reused
         plan = self._plan(B, slot)
-        done = self._enqueue(plan, ids, want_fm, out, fm, dedup=self.dedup)
-        lk = _Lookup(self, plan, ids, want_fm, out, fm, done)
+        done = self._enqueue(plan, ids, want_fm, out, fm, dedup=self.dedup, consumer=consumer)
+        lk = _Lookup(self, plan, ids, want_fm, out, fm, done, consumer=consumer)
         if done is False:
             lk.joined = True                              # ran on the caller's stream
         self._inflight[slot] = lk
@@ -729,6 +754,19 @@ class ShardedTables:
         runs.sort(key=lambda r: sum(r))
         med = runs[len(runs) // 2]
         return dict(zip(self.STAGES, med)), out, fm
+
+    def lookup_consume(self, ids, consumer):
+        """The lookup WITHOUT its finish pass (round 5).  consumer(s, e, rows, inv) is called once per micro-batch (on the stream that
+        micro-batch's pipeline runs on) with the received rows of local samples [s, e): rows [n, K] fp32 exactly as the exchange
+        left them, inv [e - s, F] int64 = the position of (sample, slot)'s row in `rows`, < 0 where the id was pruned / out of range --
+        what the finish pass would gather from.  A consumer that looks its input rows up itself -- ops.tower(gather=(rows_as_tables(rows,
+        F), inv, ...)): the DeepFM tower kernel with the FM term, or ops.gather_fm -- reads them there, and the [B, F*K] concatenation is
+        never written or read: the rank-local passes of a lookup are bucket + owner gather only.
+        On a slab overflow (check="eager") the lookup is repeated on the exact path and the consumer called again for the whole batch:
+        its outputs must be plain overwrites.  Returns after the caller's stream has been made to wait for the consumer's kernels."""
+        if self.check != "eager":
+            raise ValueError("lookup_consume needs check='eager' (the overflow repair calls the consumer again)")
+        self.lookup_async(ids, want_fm=False, consumer=consumer).result()
 
     def lookup(self, ids, want_fm=False, out=None, fm=None):
         """ids [B_local, F] int64 (global row ids; < 0 or >= vocab_f -> zeros) -> emb [B_local, F*K] fp32

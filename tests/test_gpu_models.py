@@ -504,6 +504,50 @@ def test_deepfm_packed_serving_equals_reference_layout(built_lib):
     assert float((got - ref).abs().max()) <= 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("collective", [False, True])
+def test_lookup_consume_feeds_the_tower_without_a_finish_pass(built_lib, collective):
+    """ShardedTables.lookup_consume (round 5): the DeepFM tower kernel reads the rows where the exchange left them, through the inverse
+    positions (ops.tower(gather=(rows_as_tables(rows, F), inv, ...)): lookups, FM term, hidden layers and head in one launch per micro-batch)
+    -- bit for bit the logit of lookup(want_fm=True) + tower(adds=(fm,)), with no [B, F*K] concatenation written.  Pruned and
+    out-of-range ids, a batch that is no multiple of the tile, one rank with and without the exchange code path."""
+    import torch.distributed as dist
+    from dir_amd import ops
+    from dir_amd.shard import ShardedTables, rows_as_tables
+    rng = np.random.default_rng(28)
+    F, K, B = 26, 16, 1000
+    vocab = [int(v) for v in rng.integers(5, 3000, size=F)]
+    full = [torch.from_numpy((rng.standard_normal((v, K)) * 0.3).astype(np.float32)).cuda() for v in vocab]
+    ids = np.stack([rng.integers(-1, v + 3, size=B) for v in vocab], 1).astype(np.int64)       # -1 pruned, >= vocab out of range
+    ids_t = torch.from_numpy(ids).cuda()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    Ws = [torch.randn((400, F * K), generator=g, device=dev) * 0.05, torch.randn((400, 400), generator=g, device=dev) * 0.05]
+    bs = [torch.randn((400,), generator=g, device=dev) * 0.1 for _ in Ws]
+    hw, hb = torch.randn((400,), generator=g, device=dev) * 0.05, torch.randn((1,), generator=g, device=dev)
+    created = False
+    if collective and not dist.is_initialized():
+        _init_single_rank()
+        created = True
+    try:
+        st = ShardedTables.from_full(full, force_collective=collective)
+        emb, fm = st.lookup(ids_t, want_fm=True)
+        ref = ops.tower(emb, Ws, bs, head=(hw, hb), adds=(fm,), split="f16x2")
+        out = torch.full((B, 1), float("nan"), device=dev)
+        calls = []
+
+        def consumer(s, e, rows, inv):
+            calls.append((s, e))
+            ops.tower(None, Ws, bs, head=(hw, hb), gather=(rows_as_tables(rows, F), inv, None, True), out=out[s:e], split="f16x2")
+        st.lookup_consume(ids_t, consumer)
+        torch.cuda.synchronize()
+        assert calls and calls[0][0] == 0 and calls[-1][1] == B
+        assert torch.equal(out, ref)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_sharded_training_step_single_gpu(built_lib):
     """ShardedTables.enable_training + lookup_train + backward on ONE GPU under nccl (RCCL) with world_size 1: the row-gradient
     exchange code path and the owner-side dir_sparse_adagrad_sorted_payload_f32 against a float64 dedup-sum Adagrad."""

@@ -255,6 +255,20 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
             us, es, fs = st.stage_times(torch.from_numpy(ids), want_fm=True, iters=2)
             ok = ok and set(us) == set(ShardedTables.STAGES) and all(v >= 0 for v in us.values())
             ok = ok and bool(np.array_equal(es.numpy(), ref)) and bool(np.array_equal(fs.numpy()[:, 0], O.fm_second_order(ref, F, K)))
+        # the lookup without its finish pass: the consumer gathers from the received rows through the inverse positions itself
+        if opts.get("consume"):
+            got_c = torch.full((B, F * K), float("nan"))
+            calls = []
+
+            def consumer(s_, e_, rows, inv):
+                calls.append((s_, e_))
+                r3 = rows[inv.clamp(min=0)] * (inv >= 0).unsqueeze(-1).to(rows.dtype)        # [e - s, F, K]; pruned -> zeros
+                got_c[s_:e_] = r3.reshape(e_ - s_, F * K)
+            fb = st.stats["fallbacks"]
+            st.lookup_consume(torch.from_numpy(ids), consumer)
+            ok = ok and bool(np.array_equal(got_c.numpy(), ref)) and len(calls) >= 1
+            if want == "fallback":          # (slabs still too small on this call: the repair calls the consumer again, for the whole batch)
+                ok = ok and (st.stats["fallbacks"] == fb or calls[-1] == (0, B))
         # two lookups in flight (double-buffered plans), consumed in order, then a third reusing the first one's buffers
         if opts.get("async"):
             batches = [np.stack([rng_b.integers(-1, v, size=B) for v in vocab], axis=1).astype(np.int64) for _ in range(3)]
@@ -292,6 +306,9 @@ def _run(world, vocab, K, B, seed, train=False, opts=None):
 
 @pytest.mark.parametrize("world,vocab,opts", [
     (2, [10, 7, 33], {"expect": "no_fallback"}),                                    # fixed-capacity pipeline, default slack
+    (2, [10, 7, 33], {"expect": "no_fallback", "consume": True}),                  # ... and the lookup without its finish pass
+    (3, [100, 5, 64, 9], {"chunks": 3, "out_of_range": True, "consume": True}),
+    (2, [50, 50, 50], {"slack": 0.5, "mode": "fixed", "expect": "fallback", "consume": True}),   # the overflow repair re-runs the consumer
     (3, [100, 5, 64, 9], {"chunks": 3, "out_of_range": True}),
     (2, [1000] * 6, {"chunks": 1}),
     (2, [50, 50, 50], {"slack": 0.5, "mode": "fixed", "expect": "fallback", "repeats": 2}),   # slabs too small: exact fallback, then grown

@@ -50,6 +50,8 @@ b xdeepfm_train --workload xdeepfm_train --steps 10 --warmup 2 --no-cpu-baseline
 b train_sparse --workload train_sparse --steps 100 --warmup 10 --no-cpu-baseline
 b train_sparse_graph --workload train_sparse --graph --steps 100 --warmup 10 --no-cpu-baseline
 b sharded_1gpu --workload sharded_1gpu --steps 100 --warmup 10 --no-cpu-baseline
+b sharded_deepfm_1gpu --workload sharded_deepfm_1gpu --steps 100 --warmup 10 --no-cpu-baseline
+DIR_BENCH_SHARD_CONSUME=0 b sharded_deepfm_1gpu_finish --workload sharded_deepfm_1gpu --steps 100 --warmup 10 --no-cpu-baseline
 b transform --workload transform --steps 100 --warmup 10 --no-cpu-baseline
 b small_batch --workload small_batch --steps 200 --warmup 20 --no-cpu-baseline
 DIR_BENCH_SMALL_BATCH=100 b small_batch_100 --workload small_batch --steps 200 --warmup 20 --no-cpu-baseline
