@@ -40,6 +40,13 @@
 #include "common.hpp"
 #include <type_traits>
 
+#ifdef CIN_ABL
+#ifndef CIN_ABL_FWD
+#define CIN_ABL_FWD 0      // timing ablations apply to the dot form (0) or to the forward / pair forms (1)
+#endif
+#define CIN_ABL_ON (CIN_ABL_FWD ? !DOT : DOT)
+#endif
+
 
 namespace dir {
 
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
     // one tile of a chunk goes into `out` (and the dot); xf: the chunk's field factors
     auto consume = [&](int rt, int ct, const f32x4& t, f32x4 (&sd)[RT], const f32x4 (&xf)[RT]) {
 #ifdef CIN_ABL
-        if (DOT && (CIN_ABL & 8)) { asm volatile("" :: "v"(t)); return; }          // no consume fmas; the tile stays "used"
+        if (CIN_ABL_ON && (CIN_ABL & 8)) { asm volatile("" :: "v"(t)); return; }          // no consume fmas; the tile stays "used"
 #endif
         if constexpr (DOT) {
             // explicit pairs (v_pk_fma_f32 on register-adjacent halves): left to itself the compiler pairs the dot's fmas ACROSS tiles, with two
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
 
     int u = 0;                                  // staged chunk index (its LDS buffer: u & 1)
 #ifdef CIN_ABL
-    if (DOT && (CIN_ABL & 1)) nkh = 0;          // timing ablation: no main loop
+    if (CIN_ABL_ON && (CIN_ABL & 1)) nkh = 0;          // timing ablation: no main loop
 #endif
     for (int kh = 0; kh < nkh; ++kh) {
         // ---- A operands of this half: xk[r, KS*32*kh + 32*ks + 8*lg + e], split once, used by all m fields
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
           {
               const int cn = kh * m + j0 + nf;        // first field of the next chunk (the next half starts at a chunk boundary)
 #ifdef CIN_ABL
-              if (!(DOT && (CIN_ABL & 4)))
+              if (!(CIN_ABL_ON && (CIN_ABL & 4)))
 #endif
               if (cn < nchunk) stage_w(cn, min(FJ, m - (j0 + nf < m ? j0 + nf : 0)), buf ^ 1);
           }
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                 for (int ct = 0; ct < CT; ++ct) {
                     if (ct + 1 < CT) {
 #ifdef CIN_ABL
-                        if (!(CIN_ABL & 64))          // no LDS reads behind the chunk's first
+                        if (!(CIN_ABL_ON && (CIN_ABL & 64)))          // no LDS reads behind the chunk's first
 #endif
 #pragma unroll
                         for (int ks = 0; ks < KSN; ++ks)
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     for (int rt = 0; rt < RT; ++rt) {
                         f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifdef CIN_ABL
-                        if (CIN_ABL & 32) asm volatile("" : "+v"(t) : "v"(bq[ct & 1][0][0]), "v"(bq[ct & 1][KSN - 1][NP - 1]), "v"(a[0][rt][0]), "v"(a[KSN - 1][rt][NP - 1])); else   // no MFMAs
+                        if (CIN_ABL_ON && (CIN_ABL & 32)) asm volatile("" : "+v"(t) : "v"(bq[ct & 1][0][0]), "v"(bq[ct & 1][KSN - 1][NP - 1]), "v"(a[0][rt][0]), "v"(a[KSN - 1][rt][NP - 1])); else   // no MFMAs
 #endif
 #pragma unroll
                         for (int ks = 0; ks < KSN; ++ks) {
