@@ -689,6 +689,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                     const int h = hbase + 16 * ct + 4 * lg + q;
                     if (xout && h < H && gr < R) {
                         const float v = out[rt][ct][q];
+#ifdef CIN_ABL
+                        if ((CIN_ABL & 256) && v != 12345.678f) {} else      // timing ablation: no data-gradient stores
+#endif
                         xout[(b * H + h) * D + d] = v;
                         rmx = fmaxf(rmx, fabsf(v));
                     }
