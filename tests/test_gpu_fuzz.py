@@ -1,5 +1,6 @@
 """Seeded shape fuzzing on the GPU: random (B, F, K, vocab, strides, bag lengths, d, L) through the C ABI against the
 oracle (DIR_FUZZ_SEEDS=n extends every sweep to n seeds).  Same bars as test_gpu_parity.py: bit-exact for gather / bags / FM / linear, 1e-5 scaled for cross."""
+import ctypes
 import os
 
 import numpy as np
@@ -336,3 +337,56 @@ def test_act_rows_kernels_fuzz(built_lib, M, N, activation):
         assert close(gx, gx_ref, 1e-5)
     d1b, _, gab = ops.act_rows_backward(gy, s, activation, alpha, scale, shift)
     assert torch.equal(d1, d1b) and torch.equal(ga, gab)
+
+
+@pytest.mark.parametrize("K,ld,lin_col", [(16, 32, 16), (16, 32, 19), (16, 32, 31), (16, 20, 17), (16, 24, 20), (8, 32, 8), (8, 12, 11), (8, 32, 20),
+                                           (4, 8, 4), (4, 8, 7), (32, 64, 32), (32, 36, 35), (16, 32, -1), (16, 32, 3)])
+def test_packed_gather_layouts(built_lib, K, ld, lin_col):
+    """dir_gather_fm_linear_packed_f32 over row layouts beyond PackedTables' (K = 16, ld = 32, lin_col = 16): the first-order column inside
+    the lanes' doubled span (line mode, round 5: the weight arrives with the row's own request), beyond it, inside the embedding
+    columns, absent; rows shorter than a line; pruned and out-of-range ids -- concat, FM and first-order sums bit for bit the
+    f-ascending fp32 sums of the separate kernels' definition (NumPy, same order)."""
+    from dir_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(K * 100 + ld + lin_col)
+    dev = torch.device("cuda:0")
+    F, B = 7, 777
+    vocab = [int(v) for v in rng.integers(3, 200, size=F)]
+    rows = [torch.from_numpy(rng.standard_normal((v, ld)).astype(np.float32)).to(dev) for v in vocab]
+    ids = np.stack([rng.integers(-1, v + 2, size=B) for v in vocab], 1).astype(np.int64)
+    ptrs = torch.tensor([r.data_ptr() for r in rows], dtype=torch.int64, device=dev)
+    vdev = torch.tensor(vocab, dtype=torch.int64, device=dev)
+    ids_t = torch.from_numpy(ids).to(dev)
+    out = torch.full((B, F * K), float("nan"), device=dev)
+    fm = torch.full((B, 1), float("nan"), device=dev)
+    lin = torch.full((B, 1), float("nan"), device=dev)
+    bias = torch.tensor([0.25], device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    rc = lib.dir_gather_fm_linear_packed_f32(p(ptrs), p(vdev), F, K, ld, lin_col, p(ids_t), F, 1, 0, B, p(out), F * K, p(fm), p(bias),
+                                             p(lin) if lin_col >= 0 else None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    ok = (ids >= 0) & (ids < np.array(vocab)[None, :])
+    emb = np.zeros((B, F, K), np.float32)
+    lw = np.zeros((B, F), np.float32)
+    for f in range(F):
+        r = rows[f].cpu().numpy()
+        sel = ok[:, f]
+        emb[sel, f] = r[ids[sel, f], :K]
+        if lin_col >= 0:
+            lw[sel, f] = r[ids[sel, f], lin_col]
+    assert np.array_equal(out.cpu().numpy(), emb.reshape(B, F * K))
+    s = np.zeros((B, K), np.float32)
+    sq = np.zeros((B, K), np.float32)
+    ls = np.zeros(B, np.float32)
+    for f in range(F):                       # f-ascending fp32 sums
+        s = s + emb[:, f]
+        sq = sq + emb[:, f] * emb[:, f]
+        ls = ls + lw[:, f]
+    d = s * s - sq
+    acc = np.zeros(B, np.float32)
+    for k in range(K):
+        acc = acc + d[:, k]
+    assert np.array_equal(fm.cpu().numpy()[:, 0], np.float32(0.5) * acc)
+    if lin_col >= 0:
+        assert np.array_equal(lin.cpu().numpy()[:, 0], ls + np.float32(0.25))
