@@ -86,6 +86,28 @@ def _scenarios(rank, world, device, transport):
     ok = all(bool(torch.equal(e, _ref_rows(full, b, K))) for e, b in ((e0, batches[0]), (e1, batches[1]), (e2, batches[2])))
     ok = ok and fm_ok(_ref_rows(full, batches[0], K), f0, F) and fm_ok(_ref_rows(full, batches[2], K), f2, F)
     out.append(("lookup_async_double_buffered", ok, ""))
+
+    # 2b. lookup_consume (round 5): no finish pass -- the DeepFM tower kernel gathers from the received rows through the inverse positions,
+    #     per micro-batch on the pipeline's side streams; against lookup(want_fm) + the plain tower: the same logit bit for bit.  (The
+    #     tower's gather form wants K = 16 and F <= 26.)
+    from dir_amd import ops
+    from dir_amd.shard import rows_as_tables
+    gw = torch.Generator().manual_seed(77)                       # the same weights on every rank
+    Ws = [(torch.randn((64, F * K), generator=gw) * 0.1).to(device), (torch.randn((32, 64), generator=gw) * 0.1).to(device)]
+    bs = [(torch.randn((64,), generator=gw) * 0.1).to(device), (torch.randn((32,), generator=gw) * 0.1).to(device)]
+    hw, hb = (torch.randn((32,), generator=gw) * 0.1).to(device), torch.zeros(1, device=device)
+    ok = True
+    for B in (700 + 13 * rank, 64):
+        ids = _ids(gen, vocab, B, device)
+        emb, fm = st.lookup(ids, want_fm=True)
+        ref = ops.tower(emb, Ws, bs, head=(hw, hb), adds=(fm,), split="f16x2")
+        got = torch.full((B, 1), float("nan"), device=device)
+
+        def consumer(s_, e_, rows, inv):
+            ops.tower(None, Ws, bs, head=(hw, hb), gather=(rows_as_tables(rows, F), inv, None, True), out=got[s_:e_], split="f16x2")
+        st.lookup_consume(ids, consumer)
+        ok = ok and bool(torch.equal(got, ref))
+    out.append(("lookup_consume_tower", ok, ""))
     del st
 
     # 3. the reference partitioner's slice-count rule (deepFM.py:163-167): a table past 2 x 64 MiB is cut, the small ones stay whole and
@@ -241,7 +263,7 @@ def _check(res, world):
         assert not isinstance(got, str), "rank %d raised:\n%s" % (rank, got)
         bad = [(n, d) for n, ok, d in got if not ok]
         assert not bad, "rank %d: %s" % (rank, bad)
-        assert len(got) == 9
+        assert len(got) == 10
 
 
 def test_sharded_lookup_over_rccl_one_rank_per_gpu(built_lib):
