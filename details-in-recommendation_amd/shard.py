@@ -157,9 +157,12 @@ class HipBackend:
 _ROWS_TS = {}
 
 
-def rows_as_tables(rows, F):
+def rows_as_tables(rows, F, absmax=None):
     """The received row buffer of a lookup_consume() micro-batch as a TableSet of F identical "tables" (one per slot), cached by
-    address: what ops.gather_fm / ops.tower(gather=...) take as their tables, with the inverse positions as ids."""
+    address: what ops.gather_fm / ops.tower(gather=...) take as their tables, with the inverse positions as ids.
+    absmax: the largest |value| of the SHARDED tables (ShardedTables.absmax()): the magnitude bound a kernel that picks its split
+    arithmetic by the tables' range (ops.tower(split=None)) must see -- the buffer's own contents change with every lookup, behind the
+    back of TableSet.absmax()'s version-keyed cache."""
     key = (rows.data_ptr(), rows.shape[0], rows.shape[1], F)
     ts = _ROWS_TS.get(key)
     if ts is None:
@@ -167,6 +170,8 @@ def rows_as_tables(rows, F):
             _ROWS_TS.clear()
         ts = _ROWS_TS[key] = ops.TableSet([rows] * F)
         ts.row_policy = "reuse"      # just received: largely cache-resident
+    if absmax is not None:
+        ts.absmax = lambda every=1, _v=float(absmax): _v
     return ts
 
 
@@ -755,6 +760,25 @@ class ShardedTables:
         med = runs[len(runs) // 2]
         return dict(zip(self.STAGES, med)), out, fm
 
+    def absmax(self, every=32):
+        """The largest |value| over ALL ranks' slices of the tables: the local TableSet.absmax(every) (one pass + one sync per `every`
+        optimiser steps at most), then -- only when that local figure was re-measured -- a MAX all-reduce; every rank's tables move in
+        the same steps, so the ranks reach the collective together (SPMD).  Inference between steps reuses the cached figure."""
+        ts = getattr(self.backend, "ts", None)
+        loc = float(ts.absmax(every)) if ts is not None else 0.0
+        hit = getattr(self, "_absmax_all", None)
+        if hit is not None and hit[0] == loc:
+            return hit[1]
+        val = loc
+        if self._collective():
+            t = torch.tensor([loc], dtype=torch.float32, device=self.device)
+            if self._host_staged(t):
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            val = float(t[0])
+        self._absmax_all = (loc, val)
+        return val
+
     def lookup_consume(self, ids, consumer):
         """The lookup WITHOUT its finish pass (round 5).  consumer(s, e, rows, inv) is called once per micro-batch (on the stream that
         micro-batch's pipeline runs on) with the received rows of local samples [s, e): rows [n, K] fp32 exactly as the exchange
@@ -888,3 +912,35 @@ class ShardedDeepFMTrainer:
         allreduce_grads(self.dense_params, self.group)
         self.dense_optimizer.step()
         return loss.detach()
+
+    @torch.no_grad()
+    def predict(self, ids):
+        """Inference logits [B_local, 1] of the same FM + DNN model over the row-sharded tables.  Where the one-launch tower kernel covers
+        the model (dense.tower_infer's gather form: K = 16, F <= 26, ReLU tower with a units = 1 head) the lookup runs WITHOUT its finish
+        pass (lookup_consume): per micro-batch the tower kernel reads the received rows through the inverse positions and folds the FM
+        term -- the [B, F*K] concatenation is never written; otherwise lookup(want_fm=True) + dnn_logit_fn.  Bit for bit the same logits."""
+        from .dense import tower_infer
+        m = self.model
+        was_training = m.training
+        m.eval()
+        try:
+            B = ids.shape[0]
+            out = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
+            amax = self.tables.absmax()
+            state = {"fused": True}
+
+            def consumer(s, e, rows, inv):
+                lg = tower_infer(m.hidden, None, m.activation, bns=m.bns if len(m.bns) else None, head=m.logits_layer,
+                                 gather=(rows_as_tables(rows, m.F, absmax=amax), inv, None, True)) if state["fused"] else None
+                if lg is None:                                      # not covered (or too few rows): the finish pass's job, here
+                    state["fused"] = False
+                    emb, fm = ops.gather_fm(rows_as_tables(rows, m.F), inv)
+                    lg = m.dnn_logit_fn(emb, adds=(fm,))
+                out[s:e] = lg
+            if m.units == 1 and self.tables.check == "eager":
+                self.tables.lookup_consume(ids, consumer)
+                return out
+            emb, fm = self.tables.lookup(ids, want_fm=True)
+            return m.dnn_logit_fn(emb, adds=(fm,))
+        finally:
+            m.train(was_training)

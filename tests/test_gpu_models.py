@@ -548,6 +548,36 @@ def test_lookup_consume_feeds_the_tower_without_a_finish_pass(built_lib, collect
             dist.destroy_process_group()
 
 
+def test_sharded_trainer_predict_runs_the_tower_over_the_received_rows(built_lib):
+    """ShardedDeepFMTrainer.predict on a DeepFM the one-launch tower kernel covers (K = 16, 26 slots, 400-400 ReLU tower, units = 1): the
+    lookup without its finish pass + the tower in gather form, bit for bit lookup(want_fm=True) + dnn_logit_fn; and ShardedTables.absmax
+    is the tables' largest magnitude."""
+    from dir_amd import feature_column as fc
+    from dir_amd.deepfm import DeepFM
+    from dir_amd.shard import ShardedTables, ShardedDeepFMTrainer
+    torch.manual_seed(11)
+    F, K, V, B = 26, 16, 300, 2048
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    model = DeepFM(linear_feature_columns=[], dnn_feature_columns=[fc.embedding_column(c, K) for c in cats], dnn_hidden_units=[400, 400],
+                   fm_embedding_size=K).cuda()
+    full = [p.detach().clone() for p in model.embedding_weights]
+    st = ShardedTables.from_full(full)
+    tr = ShardedDeepFMTrainer(model, st, lr_sparse=0.05, dense_optimizer=torch.optim.SGD([p for n, p in model.named_parameters()
+                                                                                           if n.startswith(("hidden", "logits"))], lr=0.0))
+    ids = torch.randint(-1, V + 2, (B, F), device="cuda")
+    assert abs(st.absmax() - max(float(t.abs().max()) for t in full)) == 0.0
+    seen = []
+    orig = st.lookup_consume
+    st.lookup_consume = lambda i, c: (seen.append(1), orig(i, c))[1]
+    got = tr.predict(ids)
+    assert seen, "predict() did not take the lookup_consume route"
+    model.eval()
+    with torch.no_grad():
+        emb, fm = st.lookup(ids, want_fm=True)
+        ref = model.dnn_logit_fn(emb, adds=(fm,))
+    assert torch.equal(got, ref)
+
+
 def test_sharded_training_step_single_gpu(built_lib):
     """ShardedTables.enable_training + lookup_train + backward on ONE GPU under nccl (RCCL) with world_size 1: the row-gradient
     exchange code path and the owner-side dir_sparse_adagrad_sorted_payload_f32 against a float64 dedup-sum Adagrad."""

@@ -182,6 +182,19 @@ def _trainer_worker(rank, world, port, q):
                         a += g ** 2
                         p -= 0.05 * g / a.sqrt()
             worst = 0.0
+            # predict(): inference over the sharded tables (K = 8: the one-launch tower does not cover it -> lookup_consume's consumer takes
+            # the gather_fm + dnn_logit_fn route) against the float64 model after the three steps, on this rank's last batch
+            lg = tr.predict(ids).double().cpu()
+            with torch.no_grad():
+                emb = torch.cat([t64[f][ids_all[rank * B:(rank + 1) * B, f]] for f in range(F)], dim=1)
+                e3 = emb.view(-1, F, K)
+                ref = 0.5 * ((e3.sum(1) ** 2) - (e3 ** 2).sum(1)).sum(1, keepdim=True)
+                net = emb
+                pd = dict(zip(names, d64))
+                for i in range(2):
+                    net = torch.relu(net @ pd["hidden.%d.weight" % i].t() + pd["hidden.%d.bias" % i])
+                ref = ref + net @ pd["logits_layer.weight"].t() + pd["logits_layer.bias"]
+            worst = max(worst, float(((lg - ref).abs() / (1 + ref.abs())).max()))
             for p, r in zip(dense, d64):
                 worst = max(worst, float(((p.detach().double().cpu() - r.detach()).abs() / (1 + r.detach().abs())).max()))
             for f in range(F):
