@@ -9,7 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int KIND, int CHAIN, int PRIO = 0>      // PRIO: s_setprio of the VALU waves (round 5); KIND: 0 v_fma_f32, 1 v_cvt_pk_bf16_f32, 2 v_pk_add_f32, 3 integer shift/and, 4 v_sub_f32; CHAIN: MFMAs on 1 | 4 accumulators
+template <int KIND, int CHAIN, int PRIO = 0, int SHAPE = 16>      // SHAPE: 16 = v_mfma_f32_16x16x32_bf16 (4 passes), 32 = v_mfma_f32_32x32x16_bf16 (8 passes; round 5); PRIO: s_setprio of the VALU waves (round 5); KIND: 0 v_fma_f32, 1 v_cvt_pk_bf16_f32, 2 v_pk_add_f32, 3 integer shift/and, 4 v_sub_f32; CHAIN: MFMAs on 1 | 4 accumulators
 __global__ __launch_bounds__(512) void probe(float* sink, int iters, int run_mfma, int run_valu) {
     const int wave = threadIdx.x >> 6;
     float keep = 0.f;
@@ -18,15 +18,27 @@ __global__ __launch_bounds__(512) void probe(float* sink, int iters, int run_mfm
         u32x4 ma = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, mb = ma;
         asm volatile("" : "+v"(ma), "+v"(mb));
         f32x4 acc[4];
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        f32x16 big[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) {
+            acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 16; ++e) big[i][e] = 0.f;
+        }
         for (int it = 0; it < iters; ++it) {
+            if constexpr (SHAPE == 16) {
 #pragma unroll
-            for (int i = 0; i < 24; ++i)
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[CHAIN == 1 ? 0 : (i & 3)]) : "v"(ma), "v"(mb));
+                for (int i = 0; i < 24; ++i)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[CHAIN == 1 ? 0 : (i & 3)]) : "v"(ma), "v"(mb));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; ++i)          // the same flops per iteration: 12 x (32 x 32 x 16)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(big[CHAIN == 1 ? 0 : (i & 3)]) : "v"(ma), "v"(mb));
+            }
         }
         asm volatile("s_nop 15\n s_nop 15" ::: "memory");
-        keep = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
+        keep = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] + big[0][0] + big[1][0] + big[2][0] + big[3][0];
     } else {
         if (!run_valu) return;
         if (PRIO == 1) asm volatile("s_setprio 1");
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(512) void probe(float* sink, int iters, int run_mfm
     if (keep == 12345.678f) sink[threadIdx.x] = keep;
 }
 
-template <int KIND, int CHAIN, int PRIO = 0>
+template <int KIND, int CHAIN, int PRIO = 0, int SHAPE = 16>
 static void run(float* sink) {
     const int iters = 4000;
     float ms[3];
@@ -70,17 +82,17 @@ static void run(float* sink) {
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int cfg[3][2] = {{1, 0}, {0, 1}, {1, 1}};
     for (int c = 0; c < 3; ++c) {
-        hipLaunchKernelGGL((probe<KIND, CHAIN, PRIO>), dim3(256), dim3(512), 0, 0, sink, 100, cfg[c][0], cfg[c][1]);
+        hipLaunchKernelGGL((probe<KIND, CHAIN, PRIO, SHAPE>), dim3(256), dim3(512), 0, 0, sink, 100, cfg[c][0], cfg[c][1]);
         (void)hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((probe<KIND, CHAIN, PRIO>), dim3(256), dim3(512), 0, 0, sink, iters, cfg[c][0], cfg[c][1]);
+        hipLaunchKernelGGL((probe<KIND, CHAIN, PRIO, SHAPE>), dim3(256), dim3(512), 0, 0, sink, iters, cfg[c][0], cfg[c][1]);
         (void)hipEventRecord(e1, 0);
         (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms[c], e0, e1);
     }
     const char* kinds[5] = {"v_fma_f32", "v_cvt_pk_bf16_f32", "v_pk_add_f32", "v_lshlrev_b32", "v_sub_f32"};
     const float mn = ms[0] < ms[1] ? ms[0] : ms[1];
-    printf("%-18s (VALU waves at s_setprio %d) MFMAs on %d accumulator(s): matrix alone %.3f ms, vector alone %.3f ms, both %.3f ms -> %.0f %% of the shorter one overlapped\n",
-           kinds[KIND], PRIO, CHAIN == 1 ? 1 : 4, ms[0], ms[1], ms[2], 100.f * (ms[0] + ms[1] - ms[2]) / mn);
+    printf("%-18s (VALU waves at s_setprio %d, MFMA %dx%d) MFMAs on %d accumulator(s): matrix alone %.3f ms, vector alone %.3f ms, both %.3f ms -> %.0f %% of the shorter one overlapped\n",
+           kinds[KIND], PRIO, SHAPE, SHAPE, CHAIN == 1 ? 1 : 4, ms[0], ms[1], ms[2], 100.f * (ms[0] + ms[1] - ms[2]) / mn);
     fflush(stdout);
 }
 
@@ -90,5 +102,6 @@ int main() {
     run<0, 4>(sink); run<1, 4>(sink); run<2, 4>(sink); run<3, 4>(sink); run<4, 4>(sink);
     run<0, 1>(sink); run<1, 1>(sink); run<4, 1>(sink);
     run<0, 4, 1>(sink); run<0, 4, 3>(sink); run<2, 4, 3>(sink); run<0, 1, 3>(sink);      // round 5: does priority give the VALU wave the slots?
+    run<0, 4, 0, 32>(sink); run<0, 1, 0, 32>(sink); run<2, 4, 0, 32>(sink); run<1, 4, 0, 32>(sink);      // round 5: the 8-pass shape
     return 0;
 }
