@@ -931,7 +931,7 @@ def main():
         model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
                        dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
         model.fused_sparse_adagrad(lr=0.01, packed=(args.train_layout == "packed"))
-        model.fused_sparse_ftrl(lr=0.2)
+        model.fused_sparse_ftrl(lr=0.2, packed=(args.train_layout == "packed" and os.environ.get("DIR_BENCH_FTRL_ROWS", "1") != "0"))
         lin = [model.linear_bias]                          # the weight columns are updated by the fused kernel inside backward()
         skip = {id(p) for p in model.linear_weights} | {id(p) for p in lin} | {id(p) for p in model.embedding_weights}
         opt_dense = ag_opt.Adagrad([p for p in model.parameters() if id(p) not in skip], lr=0.01, initial_accumulator_value=0.1)

@@ -25,10 +25,15 @@ SIGNATURES = {
                                           c_i64, c_vp, c_i64, c_vp]),
     "dir_check_ids": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "dir_fm_second_order_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "dir_linear_onehot_rows_f32": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    "dir_sparse_ftrl_rows_sorted_f32": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_float, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dir_gather_fm_fused_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "dir_gather_fm_linear_packed_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64,
                                                 c_vp, c_vp, c_vp, c_vp]),
     "dir_gather_fm_rows_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "dir_gather_fm_rows_bits_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
+                                            c_vp, c_vp, c_vp]),
     "dir_linear_sparse_sum_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64,
                                           c_vp, c_vp]),
     "dir_dcn_cross_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp]),

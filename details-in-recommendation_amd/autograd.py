@@ -37,7 +37,7 @@ class GatherFm(torch.autograd.Function):
         if ctx.fused:
             # a fused optimiser that also takes the FM backward (ops.SparseAdagrad.step_fm): keep the [B, K] field sums, not emb
             fsum = torch.empty((ids.shape[0], ts.K), dtype=torch.float32, device=ts.device)
-            emb, fm = ops.gather_fm(ts, ids, fsum=fsum)
+            emb, fm = ops.gather_fm(ts, ids, fsum=fsum, want_bits=ops.GATHER_BITS)      # (+ emb's row maxima, for the first dense layer)
             ctx.save_for_backward(ids, fsum)
         else:
             if ts.ld != ts.K:
@@ -156,6 +156,8 @@ class LinearLogit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ts, ids, bias, *weights):
+        if ts.ld != ts.K and ts.grad_sink is None:
+            raise ValueError("packed linear training rows train through a fused optimiser (ops.SparseFtrl(...).attach())")
         out = ops.linear_logit(ts, ids, bias=bias.detach())
         ctx.ts = ts
         ctx.save_for_backward(ids)

@@ -47,6 +47,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 if os.environ.get("DIR_DEVELOPMENT") == "1":
     FLAGS.append("-DDIR_DEVELOPMENT")
 # DIR_ABLATE="cin_bf3.hip:CIN_ABL=1": one timing-ablation macro for one translation unit (development; results are WRONG under most of them)
+# DIR_NO_PK="a.hip,b.hip": those translation units without packed fp32 VALU instructions (development A/B)
+for _f in filter(None, os.environ.get("DIR_NO_PK", "").split(",")):
+    EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + NO_PACKED_FP32
 if os.environ.get("DIR_ABLATE"):
     _f, _m = os.environ["DIR_ABLATE"].split(":", 1)
     EXTRA_FLAGS[_f] = EXTRA_FLAGS.get(_f, []) + (NO_PACKED_FP32 if _m == "NO_PACKED_FP32" else ["-D" + d for d in _m.split(",")])

@@ -451,6 +451,7 @@ struct FtrlUpd {      // FTRL-Proximal, learning_rate_power = -0.5 ([TF-upstream
     float* const* linears;   // z
     float lr, l1, l2;
     int64_t ld;
+    bool rows = false;       // tables[f] are packed [vocab, 4] rows [w | n | z | -] (K = 1): one 16-byte read and write per touched id
     __device__ __forceinline__ void one(float g, float& n, float& z, float& w) const {
         const float n_new = n + g * g;
         const float sigma = (sqrtf(n_new) - sqrtf(n)) / lr;
@@ -464,6 +465,15 @@ struct FtrlUpd {      // FTRL-Proximal, learning_rate_power = -0.5 ([TF-upstream
     template <int VEC>
     __device__ __forceinline__ void apply(int f, int64_t id, int col, typename BV<VEC>::T g) const {
         using V = BV<VEC>;
+        if constexpr (VEC == 1) {
+            if (rows) {                                    // (uniform)
+                float4* rp = reinterpret_cast<float4*>(tables[f] + id * 4);
+                float4 r = *rp;
+                one(g, r.y, r.z, r.x);
+                *rp = r;
+                return;
+            }
+        }
         const int64_t off = id * ld + col;
         float* np_ = accums[f] + off;
         float* zp = linears[f] + off;
@@ -1095,6 +1105,21 @@ extern "C" int dir_sparse_ftrl_sorted_from_f32(float* const* tables, float* cons
     return sparse_sorted_update(name, FtrlUpd{tables, accums, linears, lr, l1, l2, (int64_t)K}, F, K, ids, stride_b, stride_f, grad, grad_ld,
                                 grad_slot_stride, B, row_base, total_rows, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr,
                                 sorted_from);
+}
+
+// FTRL on packed linear training rows: rows[f] is [vocab_f, 4] = [w | n | z | unused], 16-byte aligned (units = 1).  sorted_from (optional):
+// as dir_sparse_ftrl_sorted_from_f32.  grad is [B, 1] (grad_slot_stride 0: one d logit for every column of a sample) or [B, F].
+extern "C" int dir_sparse_ftrl_rows_sorted_f32(float* const* rows, int F, const int64_t* ids, int64_t stride_b, int64_t stride_f,
+                                               const float* grad, int64_t grad_ld, int64_t grad_slot_stride, float lr, float l1, float l2,
+                                               int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
+                                               int64_t workspace_bytes, const void* sorted_from, dir_stream_t stream) {
+    const char* name = "dir_sparse_ftrl_rows_sorted_f32";
+    DIR_CHECK_ARG(rows, "%s: null pointer", name);
+    DIR_CHECK_ARG(lr > 0.f && l1 >= 0.f && l2 >= 0.f, "%s: lr=%g l1=%g l2=%g", name, lr, l1, l2);
+    FtrlUpd upd{rows, rows, rows, lr, l1, l2, (int64_t)4};
+    upd.rows = true;
+    return sparse_sorted_update(name, upd, F, 1, ids, stride_b, stride_f, grad, grad_ld, grad_slot_stride, B, row_base, total_rows, workspace,
+                                workspace_bytes, stream, nullptr, nullptr, nullptr, sorted_from);
 }
 
 extern "C" int dir_fm_second_order_backward_f32(const float* emb, int64_t emb_ld, const float* g, const float* add_in,

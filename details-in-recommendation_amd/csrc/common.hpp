@@ -72,6 +72,47 @@ inline int resident_blocks(K kernel, size_t shmem = 0, int block = 256) {
     return n;
 }
 
+#if defined(__HIPCC__)
+// The maximum (as a bit pattern: non-negative floats order like their bits) over ALL workgroups of a launch of 256-thread blocks, without a
+// zeroing launch and without a same-address atomic per row: every workgroup leaves its maximum in block_bits[blockIdx.x] and takes a
+// ticket; the LAST one to arrive reduces the block maxima, writes *all_bits and puts the ticket back to zero (the caller's word of
+// persistent, initially zero memory; block_bits holds gridDim.x words).  Called by all threads of the block; wmx: the thread's maximum.
+__device__ __forceinline__ void grid_max_bits(float wmx, unsigned int* __restrict__ all_bits, unsigned int* __restrict__ block_bits,
+                                              unsigned int* __restrict__ ticket) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
+    __shared__ float gm_wm[4];
+    __shared__ unsigned int gm_last;
+    if ((threadIdx.x & 63) == 0) gm_wm[threadIdx.x >> 6] = wmx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // No fence (a device-scope release is an L2 write-back on gfx950: NOTES R4.2): the block maximum is left by a RETURNING
+        // device-scope atomic, whose result is waited for before the ticket is taken -- it has been performed where the last
+        // workgroup's device-scope loads will look.
+        const unsigned int old = __hip_atomic_exchange(block_bits + blockIdx.x,
+                                                       __builtin_bit_cast(unsigned int, fmaxf(fmaxf(gm_wm[0], gm_wm[1]), fmaxf(gm_wm[2], gm_wm[3]))),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old) : "memory");
+        gm_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (gm_last) {
+        unsigned int m = 0u;
+        for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256)
+            m = max(m, __hip_atomic_load(block_bits + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
+        __shared__ unsigned int gm_um[4];
+        if ((threadIdx.x & 63) == 0) gm_um[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            *all_bits = max(max(gm_um[0], gm_um[1]), max(gm_um[2], gm_um[3]));
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+#endif
+
 // hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE): one LdsOnce per call site, one bit per device, set only after the
 // runtime accepted the call (two host threads racing both make the idempotent call; a process that launches on a second GPU sets it there
 // too).  -> false if the runtime refused: the launch that follows then fails and DIR_CHECK_LAUNCH reports it.

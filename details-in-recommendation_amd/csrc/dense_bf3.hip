@@ -479,39 +479,7 @@ __global__ __launch_bounds__(256) void row_absmax_k(const float* __restrict__ X,
         if (sub == 0) row_bits[r] = __builtin_bit_cast(unsigned int, mx);
         wmx = fmaxf(wmx, mx);
     }
-    if (all_bits) {                                        // (uniform)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, 64));
-        __shared__ float wm[4];
-        __shared__ unsigned int last;
-        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = wmx;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // No fence (a device-scope release is an L2 write-back on gfx950: NOTES R4.2): the block maximum is left by a RETURNING
-            // device-scope atomic, whose result is waited for before the ticket is taken -- it has been performed where the last
-            // workgroup's device-scope loads will look.
-            const unsigned int old = __hip_atomic_exchange(block_bits + blockIdx.x,
-                                                           __builtin_bit_cast(unsigned int, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))),
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" ::"v"(old) : "memory");
-            last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-        }
-        __syncthreads();
-        if (last) {
-            unsigned int m = 0u;
-            for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256)
-                m = max(m, __hip_atomic_load(block_bits + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
-            __shared__ unsigned int um[4];
-            if ((threadIdx.x & 63) == 0) um[threadIdx.x >> 6] = m;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                *all_bits = max(max(um[0], um[1]), max(um[2], um[3]));
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
+    if (all_bits) grid_max_bits(wmx, all_bits, block_bits, ticket);      // (uniform)
 }
 
 }  // namespace dir

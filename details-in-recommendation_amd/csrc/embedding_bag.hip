@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
                                                             float* __restrict__ out, int64_t out_ld,
                                                             float* __restrict__ fm, const float* __restrict__ bias,
                                                             float* __restrict__ lin_out,
-                                                            float* __restrict__ fsum /* [B, K] field sums S[b] = sum_f e[b,f] or NULL */) {
+                                                            float* __restrict__ fsum /* [B, K] field sums S[b] = sum_f e[b,f] or NULL */,
+                                                            unsigned int* __restrict__ row_bits = nullptr /* [B]: bit pattern of max |out[b, :]| */,
+                                                            unsigned int* __restrict__ all_bits = nullptr /* ... of max |out| (with row_bits) */,
+                                                            unsigned int* __restrict__ block_bits = nullptr, unsigned int* __restrict__ ticket = nullptr) {
     constexpr int SPW = 64 / LPS;
     const int lane = threadIdx.x & 63;
     const int c = lane & (LPS - 1);
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
     const int lw_lane = line ? cl : 0;
     const bool lact = line ? (c * 4 + 4 <= ld) : cact;      // lanes that load a piece of the row
     const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+    float wmx = 0.f;
     for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); g * SPW < B; g += nwave) {
         const int64_t b = g * SPW + s;
         const bool act = cact && (b < B);
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
         float* op = out ? out + (act ? b * out_ld : 0) + c * 4 : nullptr;
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
         float lin = 0.f;
+        float4 mx4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int f0 = 0; f0 < F; f0 += UF) {
             int64_t id[UF];
 #pragma unroll
@@ -215,8 +220,18 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
                     sum = vadd(sum, row[u]);
                     sq = vadd(sq, vmul(row[u], row[u]));
                     lin = lin + lw[u];                    // slot order, as linear_onehot_k / the oracle
+                    if (row_bits)                         // (uniform) rows of lanes past the embedding are zero
+                        mx4 = make_float4(fmaxf(mx4.x, fabsf(row[u].x)), fmaxf(mx4.y, fabsf(row[u].y)), fmaxf(mx4.z, fabsf(row[u].z)),
+                                          fmaxf(mx4.w, fabsf(row[u].w)));
                 }
             }
+        }
+        if (row_bits) {                                      // (uniform) the sample's LPS lanes hold its whole output row
+            float mx = fmaxf(fmaxf(mx4.x, mx4.y), fmaxf(mx4.z, mx4.w));
+#pragma unroll
+            for (int o = LPS >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if (c == 0 && b < B) row_bits[b] = __builtin_bit_cast(unsigned int, mx);
+            wmx = fmaxf(wmx, (b < B) ? mx : 0.f);
         }
         if (fsum && act) stv(fsum + b * K + c * 4, sum);     // f-ascending fp32 sums: the S of the FM backward, bit for bit
         if (fm) {
@@ -225,6 +240,7 @@ __global__ __launch_bounds__(256) void gather_packed_rows_k(const float* const* 
         }
         if (want_lin && c == lw_lane && b < B) lin_out[b] = lin + (bias ? bias[0] : 0.f);
     }
+    if (all_bits) grid_max_bits(wmx, all_bits, block_bits, ticket);      // (uniform; every workgroup of the grid gets here)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -633,7 +649,8 @@ extern "C" int dir_check_ids(const int64_t* vocab, int F, const int64_t* ids, co
 static int gather_packed_launch(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
                                 const int64_t* ids, int64_t stride_b, int64_t stride_f, int flags,
                                 int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
-                                float* lin_out, float* fsum, dir_stream_t stream) {
+                                float* lin_out, float* fsum, dir_stream_t stream, unsigned int* row_bits = nullptr,
+                                unsigned int* all_bits = nullptr, unsigned int* bits_ws = nullptr) {
     DIR_CHECK_ARG(F > 0 && K > 0 && B >= 0 && ld >= K && lin_col < ld, "dir_gather_fm_linear_packed_f32: F=%d K=%d ld=%lld lin_col=%d", F, K, (long long)ld, lin_col);
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(tables && ids && (out || fm || lin_out || fsum), "dir_gather_fm_linear_packed_f32: null pointer");
@@ -653,7 +670,7 @@ static int gather_packed_launch(const float* const* tables, const int64_t* vocab
     do {                                                                                                        \
         dim3 grid(grid_resident(work, resident_blocks(gather_packed_rows_k<L, 13, NTV>)));                     \
         hipLaunchKernelGGL((gather_packed_rows_k<L, 13, NTV>), grid, dim3(256), 0, st, tables, vocab, ids, stride_b, stride_f, F, K, ld, \
-                           lin_col, B, out, out_ld, fm, bias, lin_out, fsum);                                        \
+                           lin_col, B, out, out_ld, fm, bias, lin_out, fsum, row_bits, all_bits, bits_ws ? bits_ws + 1 : nullptr, bits_ws); \
     } while (0)
 #define DIR_L(L) do { if (nt) DIR_GO(L, true); else DIR_GO(L, false); } while (0)
     switch (lps) {
@@ -674,6 +691,22 @@ extern "C" int dir_gather_fm_linear_packed_f32(const float* const* tables, const
                                                int64_t B, float* out, int64_t out_ld, float* fm, const float* bias,
                                                float* lin_out, dir_stream_t stream) {
     return gather_packed_launch(tables, vocab, F, K, ld, lin_col, ids, stride_b, stride_f, flags, B, out, out_ld, fm, bias, lin_out, nullptr, stream);
+}
+
+// dir_gather_fm_rows_f32 that also leaves what the row-scaled fp16 x 2 layer reading `out` needs (dir_row_absmax_bits_f32's outputs, without
+// its pass over out): row_bits[b] = bit pattern of max_k |out[b, k]|, *all_bits = of max |out|; workspace as dir_row_absmax_bits_f32's
+// (dir_row_absmax_workspace_words() words of device memory, the first one zero before the first call).
+extern "C" int dir_gather_fm_rows_bits_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, const int64_t* ids,
+                                           int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out, int64_t out_ld,
+                                           float* fm, float* fsum, unsigned int* row_bits, unsigned int* all_bits, unsigned int* workspace,
+                                           dir_stream_t stream) {
+    DIR_CHECK_ARG(row_bits && all_bits && workspace, "dir_gather_fm_rows_bits_f32: null pointer");
+    if (B == 0) {
+        if (zero_async(all_bits, sizeof(unsigned int), as_stream(stream)) != hipSuccess) return fail(DIR_E_HIP, "dir_gather_fm_rows_bits_f32: zeroing failed");
+        return DIR_OK;
+    }
+    return gather_packed_launch(tables, vocab, F, K, ld, -1, ids, stride_b, stride_f, flags, B, out, out_ld, fm, nullptr, nullptr, fsum, stream,
+                                row_bits, all_bits, workspace);
 }
 
 extern "C" int dir_gather_fm_rows_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, const int64_t* ids,

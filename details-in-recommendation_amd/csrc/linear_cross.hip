@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void linear_onehot_k(const float* const* __res
                                                        const int64_t* __restrict__ vocab,
                                                        const int64_t* __restrict__ ids, int64_t sb, int64_t sf,
                                                        int F, const float* __restrict__ bias, int accumulate,
-                                                       int64_t B, float* __restrict__ out) {
+                                                       int64_t B, float* __restrict__ out, int64_t ld /* floats between two weights: 1, or
+                                                       the stride of packed linear training rows [w | n | z | -] */) {
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
         const int64_t* idp = ids + b * sb;
         float acc = 0.f;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void linear_onehot_k(const float* const* __res
                 if (f0 + u < F) {
                     const float* w = wts[f0 + u];
                     const uint64_t bound = vocab ? (uint64_t)vocab[f0 + u] : (uint64_t)1 << 63;   // id < 0 / id >= vocab_f: pruned
-                    if ((uint64_t)id[u] < bound) v[u] = w[id[u]];
+                    if ((uint64_t)id[u] < bound) v[u] = w[id[u] * ld];
                 }
             }
 #pragma unroll
@@ -213,11 +214,26 @@ extern "C" int dir_linear_sparse_sum_f32(const float* const* weights, const int6
     hipStream_t st = as_stream(stream);
     dim3 grid(grid_for((B + 255) / 256));
     if (!offsets) {
-        hipLaunchKernelGGL((linear_onehot_k<13>), grid, dim3(256), 0, st, weights, vocab, ids, stride_b, stride_f, F, bias, accumulate, B, out);
+        hipLaunchKernelGGL((linear_onehot_k<13>), grid, dim3(256), 0, st, weights, vocab, ids, stride_b, stride_f, F, bias, accumulate, B, out, (int64_t)1);
     } else {
         hipLaunchKernelGGL(linear_csr_k, grid, dim3(256), 0, st, weights, vocab, ids, offsets, entry_weights, stride_b, stride_f, F, combiner, bias, accumulate, B, out);
     }
     DIR_CHECK_LAUNCH("linear_sparse_sum");
+    return DIR_OK;
+}
+
+// The first-order term read from packed linear TRAINING rows (dir_sparse_ftrl_rows_sorted_f32): rows[f] is [vocab_f, row_ld] with the weight
+// in column 0 -- the row's FTRL state (n, z) shares its 16 bytes, so the update moves one memory slot per touched id instead of three.
+extern "C" int dir_linear_onehot_rows_f32(const float* const* rows, int64_t row_ld, const int64_t* vocab, int F, const int64_t* ids,
+                                          int64_t stride_b, int64_t stride_f, const float* bias, int accumulate, int64_t B, float* out,
+                                          dir_stream_t stream) {
+    DIR_CHECK_ARG(rows && ids && out, "dir_linear_onehot_rows_f32: null pointer");
+    DIR_CHECK_ARG(F > 0 && B >= 0 && row_ld >= 1, "dir_linear_onehot_rows_f32: F=%d B=%lld row_ld=%lld", F, (long long)B, (long long)row_ld);
+    if (B == 0) return DIR_OK;
+    hipStream_t st = as_stream(stream);
+    dim3 grid(grid_for((B + 255) / 256));
+    hipLaunchKernelGGL((linear_onehot_k<13>), grid, dim3(256), 0, st, rows, vocab, ids, stride_b, stride_f, F, bias, accumulate, B, out, row_ld);
+    DIR_CHECK_LAUNCH("linear_onehot_rows");
     return DIR_OK;
 }
 

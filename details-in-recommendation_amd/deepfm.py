@@ -319,12 +319,24 @@ class DeepFM(nn.Module):
         self._link_sparse_optimisers()
         return self._sparse_adagrad
 
-    def fused_sparse_ftrl(self, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
+    def fused_sparse_ftrl(self, lr=0.2, initial_accumulator_value=0.1, l1=0.0, l2=0.0, packed=False):
         """Attach the fused HIP sparse FTRL update to the linear weight columns (linear_optimizer='Ftrl', deepFM.py:58):
-        backward() then updates them in place; the bias keeps a dense gradient for a dense optimiser."""
+        backward() then updates them in place; the bias keeps a dense gradient for a dense optimiser.  packed=True (units = 1) moves
+        the columns into the packed linear training layout (ops.TableSet.ftrl_rows: [w | n | z | -] rows, a touched id's weight and FTRL
+        state in ONE 16-byte row); the weight parameters become [vocab, 1] views of it -- same values, same checkpoints, one-hot
+        columns only."""
         _, lin_ts = self._tablesets()
         if lin_ts is None:
             raise ValueError("fused_sparse_ftrl: the model has no linear feature columns")
+        if packed and lin_ts.ld == lin_ts.K:
+            if self.units != 1:
+                raise ValueError("fused_sparse_ftrl(packed=True): the packed linear rows hold one weight per id (units = 1)")
+            lin_ts = ops.TableSet.ftrl_rows([p.data for p in self.linear_weights], initial_accumulator_value)
+            for p, view in zip(self.linear_weights, lin_ts.tables):
+                p.data = view.view(p.data.shape)                 # ([vocab] or [vocab, 1]: the parameter keeps its shape, row stride 4)
+            lin_ts.owners = list(self.linear_weights)
+            self._lin_ts = lin_ts
+            self._ts_key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
         self._sparse_ftrl = ops.SparseFtrl(lin_ts, lr, initial_accumulator_value, l1, l2).attach()
         self._link_sparse_optimisers()
         return self._sparse_ftrl

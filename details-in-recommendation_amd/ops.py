@@ -118,6 +118,30 @@ class TableSet:
         ts.arena, ts.rows = arena, rows
         return ts
 
+    @classmethod
+    def ftrl_rows(cls, weights, initial_accumulator_value=0.1):
+        """Packed linear TRAINING layout (include/dir_hip.h: dir_linear_onehot_rows_f32 / dir_sparse_ftrl_rows_sorted_f32): every
+        column's first-order weights become [vocab, 4] rows = [w | n | z | unused] in one arena -- a touched id's FTRL update reads and
+        writes one 16-byte row instead of one element of three arrays.  .tables are [vocab, 1] VIEWS (row stride 4) initialised from
+        `weights` ([vocab] or [vocab, 1]), .accums / .linears the n / z views (n = initial_accumulator_value, z = 0)."""
+        weights = [w.reshape(-1, 1) for w in weights]
+        vocab = [int(w.shape[0]) for w in weights]
+        dev = weights[0].device
+        arena = torch.zeros(sum(vocab) * 4 + 4, dtype=torch.float32, device=dev)
+        off = (-(arena.data_ptr() // 4)) % 4               # rows 16-byte aligned
+        rows = []
+        for w, v in zip(weights, vocab):
+            blk = arena[off:off + v * 4].view(v, 4)
+            blk[:, 0:1] = w
+            blk[:, 1] = initial_accumulator_value
+            rows.append(blk)
+            off += v * 4
+        ts = cls([r[:, 0:1] for r in rows], ld=4)
+        ts.accums = [r[:, 1:2] for r in rows]
+        ts.linears = [r[:, 2:3] for r in rows]
+        ts.arena, ts.rows = arena, rows
+        return ts
+
     def absmax(self, every=1):
         """max |embedding value| over the tables, measured once per version of the tables and their owners (one pass + one sync when an
         in-place update bumped a counter): tower(gather=..., split=None) keeps a table past F16_RANGE_GUARD off the fp16 x 2 kernel.
@@ -343,10 +367,12 @@ def fm_logit(emb, F, K, out=None):
     return out
 
 
-def gather_fm(tables, ids, want_emb=True, out=None, fm=None, fsum=None):
+def gather_fm(tables, ids, want_emb=True, out=None, fm=None, fsum=None, want_bits=False):
     """Fused one-hot gather + FM second-order: returns (emb [B, F*K] or None, fm_logit [B, 1]).  fsum [B, K] (optional
     output): the field sums S[b] = sum_f e[b,f] the FM backward needs (dir_gather_fm_rows_f32; also the kernel that reads
-    packed training rows, TableSet.train_rows)."""
+    packed training rows, TableSet.train_rows).  want_bits (with the rows kernel: packed training rows or fsum): the gather also leaves
+    emb's row / tensor maxima on it (dir_gather_fm_rows_bits_f32), where the row-scaled fp16 x 2 layer that reads emb finds them
+    instead of running dir_row_absmax_bits_f32's pass over emb (36 us of a 1.5 ms DeepFM training step)."""
     ts = _as_tableset(tables)
     _dev(ids, torch.int64, "ids")
     B, sb, sf = _onehot_strides(ids, ts.F)
@@ -357,6 +383,19 @@ def gather_fm(tables, ids, want_emb=True, out=None, fm=None, fsum=None):
     if ts.ld != ts.K or fsum is not None:
         if fsum is not None and (fsum.shape != (B, ts.K) or not fsum.is_contiguous()):
             raise ValueError("fsum must be a contiguous [B, K] tensor")
+        if want_bits and want_emb and B > 0 and ts.K % 4 == 0:
+            lib = _lib.load()
+            key = (ts.device.index, torch.cuda.current_stream(ts.device).cuda_stream)
+            ws = _ABSMAX_WS.get(key)
+            if ws is None:                               # (the workspace of row_absmax_bits: calls on one stream are ordered)
+                ws = _ABSMAX_WS[key] = torch.zeros(int(lib.dir_row_absmax_workspace_words()), dtype=torch.int32, device=ts.device)
+            buf = torch.empty(B + 4, dtype=torch.int32, device=ts.device)
+            rb, ab = buf[:B], buf[B:B + 1]
+            _lib.check(lib.dir_gather_fm_rows_bits_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, ts.ld, _ptr(ids), sb, sf,
+                                                       ts.gather_flags(), B, _ptr(out), out.stride(0), _ptr(fm), _ptr(fsum), _ptr(rb), _ptr(ab),
+                                                       _ptr(ws), _stream()))
+            out._dir_bits = (rb, ab, out._version)
+            return out, fm
         _lib.check(_lib.load().dir_gather_fm_rows_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, ts.ld, _ptr(ids), sb, sf,
                                                       ts.gather_flags(), B, _ptr(out) if want_emb else None,
                                                       out.stride(0) if want_emb else 0, _ptr(fm), _ptr(fsum), _stream()))
@@ -386,6 +425,12 @@ def linear_logit(weights, ids, offsets=None, entry_weights=None, combiner="sum",
         out = torch.empty((B, 1), dtype=torch.float32, device=ts.device)
     if bias is not None:
         _dev(bias, torch.float32, "bias")
+    if ts.ld != ts.K:                           # packed linear training rows (TableSet.ftrl_rows): the weight is column 0 of a 16-byte row
+        if offsets is not None:
+            raise ValueError("linear_logit: packed linear training rows serve one-hot columns only")
+        _lib.check(_lib.load().dir_linear_onehot_rows_f32(_ptr(ts._ptrs), ts.ld, _ptr(ts.vocab_dev), ts.F, _ptr(ids), sb, sf, _ptr(bias),
+                                                          int(accumulate), B, _ptr(out), _stream()))
+        return out
     _lib.check(_lib.load().dir_linear_sparse_sum_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), ts.F, _ptr(ids), _ptr(offsets), _ptr(entry_weights),
                                                      sb, sf, _COMBINERS[combiner], _ptr(bias), int(accumulate), B,
                                                      _ptr(out), _stream()))
@@ -798,6 +843,10 @@ def dense_auto_arith(M, Kd, N):
 
 
 _ABSMAX_WS = {}
+
+
+# development switch: 0 = the training gather leaves no row maxima on its output (the first dense layer runs its own max pass)
+GATHER_BITS = os.environ.get("DIR_GATHER_BITS", "1") != "0"
 
 
 def row_absmax_bits(x, want_all=True):
@@ -2566,8 +2615,14 @@ class SparseFtrl:
         self.ts = _as_tableset(tables)
         self.lr, self.l1, self.l2 = float(lr), float(l1), float(l2)
         dev = self.ts.device
-        self.accums = [torch.full_like(t, initial_accumulator_value) for t in self.ts.tables]
-        self.linears = [torch.zeros_like(t) for t in self.ts.tables]
+        self.packed = getattr(self.ts, "linears", None) is not None      # TableSet.ftrl_rows: n and z live in the weights' rows
+        if self.packed:
+            self.accums, self.linears = self.ts.accums, self.ts.linears
+        else:
+            if self.ts.ld != self.ts.K:
+                raise ValueError("SparseFtrl: tables with a row stride must be TableSet.ftrl_rows")
+            self.accums = [torch.full_like(t, initial_accumulator_value) for t in self.ts.tables]
+            self.linears = [torch.zeros_like(t) for t in self.ts.tables]
         self.acc_ptrs = torch.tensor([a.data_ptr() for a in self.accums], dtype=torch.int64, device=dev)
         self.lin_ptrs = torch.tensor([z.data_ptr() for z in self.linears], dtype=torch.int64, device=dev)
         base = [0]
@@ -2601,10 +2656,17 @@ class SparseFtrl:
             self._ws = torch.empty(need + 256, dtype=torch.uint8, device=ts.device)
         off = (-self._ws.data_ptr()) % 256
         ws = ctypes.c_void_p(self._ws.data_ptr() + off)
-        args = (_ptr(ts.ptrs), _ptr(self.acc_ptrs), _ptr(self.lin_ptrs), ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad), grad.stride(0), slot_stride,
-                self.lr, self.l1, self.l2, B, _ptr(self.row_base), self.total_rows, ws, need)
         src = self._share.take(self, ids, B, sb, sf) if self._share is not None else None
         ts.written(*self.accums, *self.linears)
+        if self.packed:
+            _lib.check(lib.dir_sparse_ftrl_rows_sorted_f32(_ptr(ts._ptrs), ts.F, _ptr(ids), sb, sf, _ptr(grad), grad.stride(0), slot_stride,
+                                                           self.lr, self.l1, self.l2, B, _ptr(self.row_base), self.total_rows, ws, need, src,
+                                                           _stream()))
+            if src is None and self._share is not None:
+                self._share.leave(self, ids, B, sb, sf, ws)
+            return
+        args = (_ptr(ts.ptrs), _ptr(self.acc_ptrs), _ptr(self.lin_ptrs), ts.F, ts.K, _ptr(ids), sb, sf, _ptr(grad), grad.stride(0), slot_stride,
+                self.lr, self.l1, self.l2, B, _ptr(self.row_base), self.total_rows, ws, need)
         if src is not None:
             _lib.check(lib.dir_sparse_ftrl_sorted_from_f32(*args, src, _stream()))
             return

@@ -152,6 +152,13 @@ int dir_gather_fm_linear_packed_f32(const float* const* tables, const int64_t* v
 int dir_gather_fm_rows_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, const int64_t* ids,
                            int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out, int64_t out_ld,
                            float* fm, float* fsum, dir_stream_t stream);
+/* dir_gather_fm_rows_f32 that ALSO leaves what a row-scaled fp16 x 2 layer reading `out` needs (the outputs of dir_row_absmax_bits_f32,
+ * without that entry's pass over out): row_bits[b] = bit pattern of max_k |out[b, k]|, *all_bits = of max |out|.  workspace: as
+ * dir_row_absmax_bits_f32's (dir_row_absmax_workspace_words() unsigned ints of device memory, the first one zero before the first call). */
+int dir_gather_fm_rows_bits_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, const int64_t* ids,
+                                int64_t stride_b, int64_t stride_f, int flags, int64_t B, float* out, int64_t out_ld,
+                                float* fm, float* fsum, unsigned int* row_bits, unsigned int* all_bits, unsigned int* workspace,
+                                dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * A6  first-order (linear) term, units = 1.
@@ -925,6 +932,21 @@ int dir_sparse_ftrl_sorted_from_f32(float* const* tables, float* const* accums, 
                                     int64_t grad_slot_stride, float lr, float l1, float l2, int64_t B, const int64_t* row_base,
                                     int64_t total_rows, void* workspace, int64_t workspace_bytes, const void* sorted_from,
                                     dir_stream_t stream);
+
+/* The first-order weights as packed linear TRAINING rows: rows[f] is [vocab_f, 4] floats = [w | n | z | unused], 16-byte aligned -- the
+ * weight (linear_model's column, deepFM.py:258-263) beside its FTRL state (linear_optimizer='Ftrl', deepFM.py:58), so that the update of a
+ * touched id reads and writes ONE 16-byte row instead of three 4-byte elements of three arrays (each of them a memory slot of its own).
+ *   dir_linear_onehot_rows_f32       the forward: out[b] (+)= bias + sum_f rows[f][ids[b, f] * row_ld] (ids outside [0, vocab_f) pruned),
+ *                                    the arithmetic and order of dir_linear_sparse_sum_f32's one-hot case, bit for bit;
+ *   dir_sparse_ftrl_rows_sorted_f32  dir_sparse_ftrl_sorted_f32 / _from_f32 (sorted_from optional) on those rows, units = 1: the same bits
+ *                                    in w, n and z as the three-array form. */
+int dir_linear_onehot_rows_f32(const float* const* rows, int64_t row_ld, const int64_t* vocab, int F, const int64_t* ids,
+                               int64_t stride_b, int64_t stride_f, const float* bias, int accumulate, int64_t B, float* out,
+                               dir_stream_t stream);
+int dir_sparse_ftrl_rows_sorted_f32(float* const* rows, int F, const int64_t* ids, int64_t stride_b, int64_t stride_f,
+                                    const float* grad, int64_t grad_ld, int64_t grad_slot_stride, float lr, float l1, float l2,
+                                    int64_t B, const int64_t* row_base, int64_t total_rows, void* workspace,
+                                    int64_t workspace_bytes, const void* sorted_from, dir_stream_t stream);
 
 /* Diagnostic only (never on the product path): cycle stamps of the DIR_CIN_STAMP=1 build of the CIN kernel, summed
  * over waves since the last call: [0] chunk start -> end of its MFMA stream, [1] -> past the chunk barrier,

@@ -665,6 +665,154 @@ def test_fused_sparse_ftrl(built_lib, B, F, K, V, shared):
         _close(opt.linears[f].reshape(V, K), z[f], tol=5e-5)
 
 
+@pytest.mark.parametrize("B,F,V,per_slot", [(300, 5, 20, False), (4096, 26, 1000, False), (2000, 2, 3, False), (65536, 3, 50000, False),
+                                            (777, 4, 33, True)])
+def test_fused_sparse_ftrl_packed_rows_bit_exact(built_lib, B, F, V, per_slot):
+    """The packed linear training rows (TableSet.ftrl_rows: [w | n | z | -], dir_sparse_ftrl_rows_sorted_f32 and the forward
+    dir_linear_onehot_rows_f32) against the three-array form on the same ids and gradients (pruned ids, duplicates, l1 / l2 active):
+    w, n, z and the forward's logits bit for bit over three steps."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(B + F)
+    w0 = [(torch.randn(V, generator=g) * 0.1).cuda() for _ in range(F)]
+    plain = [w.clone() for w in w0]
+    opt_a = ops.SparseFtrl(plain, lr=0.2, initial_accumulator_value=0.1, l1=0.01, l2=0.05)
+    rows = ops.TableSet.ftrl_rows([w.clone() for w in w0], 0.1)
+    assert rows.ld == 4 and all(r.data_ptr() % 16 == 0 for r in rows.rows)
+    opt_b = ops.SparseFtrl(rows, lr=0.2, initial_accumulator_value=0.1, l1=0.01, l2=0.05)
+    assert opt_b.packed and not opt_a.packed
+    bias = torch.tensor([0.25], device="cuda")
+    for step in range(3):
+        ids = torch.randint(-1, V, (B, F), generator=g).cuda()
+        if step == 1:
+            ids = ids.t().contiguous().t()            # field-major strides
+        grad = (torch.randn(B, F if per_slot else 1, generator=g) * 0.5).cuda()
+        la = ops.linear_logit(plain, ids, bias=bias)
+        lb = ops.linear_logit(rows, ids, bias=bias)
+        assert torch.equal(la, lb)
+        acc = torch.randn(B, 1, generator=g).cuda()
+        a2, b2 = acc.clone(), acc.clone()
+        ops.linear_logit(plain, ids, out=a2, accumulate=True)
+        ops.linear_logit(rows, ids, out=b2, accumulate=True)
+        assert torch.equal(a2, b2)
+        opt_a.step(ids, grad)
+        opt_b.step(ids, grad)
+        for f in range(F):
+            assert torch.equal(rows.tables[f].reshape(-1), plain[f]), (step, f)
+            assert torch.equal(rows.accums[f].reshape(-1), opt_a.accums[f].reshape(-1)), (step, f)
+            assert torch.equal(rows.linears[f].reshape(-1), opt_a.linears[f].reshape(-1)), (step, f)
+            assert float(rows.rows[f][:, 3].abs().max()) == 0.0          # the row's fourth float is never written
+    with pytest.raises(ValueError, match="one-hot"):
+        ops.linear_logit(rows, torch.zeros(4, dtype=torch.int64, device="cuda"), offsets=torch.arange(0, F + 1, device="cuda"))
+
+
+def test_deepfm_packed_ftrl_rows_train_like_the_plain_columns(built_lib):
+    """DeepFM.fused_sparse_ftrl(packed=True) beside fused_sparse_adagrad(packed=True) (one shared sort per step): logits, linear weights
+    and embedding tables bit-identical to the unpacked fused optimisers after three steps; the parameters stay [vocab, 1] views of the
+    rows and inference afterwards (the packed SERVING rows are rebuilt from them) agrees too."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    B, F, K, V = 512, 5, 16, 40
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+
+    def make(packed):
+        torch.manual_seed(3)
+        m = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[32, 16], fm_embedding_size=K).cuda()
+        with torch.no_grad():
+            for p in m.linear_weights:
+                p.normal_(0, 0.05)
+        m.fused_sparse_adagrad(lr=0.05, packed=packed)
+        f = m.fused_sparse_ftrl(lr=0.2, l1=0.001, packed=packed)
+        assert f.packed == packed
+        return m
+    a, b = make(False), make(True)
+    assert all(p.data.stride(0) == 4 and p.data.shape == q.data.shape for p, q in zip(b.linear_weights, a.linear_weights))
+    g = torch.Generator().manual_seed(5)
+    for _ in range(3):
+        ids = torch.randint(0, V, (B, F), generator=g)
+        labels = torch.randint(0, 2, (B, 1), generator=g).float().cuda()
+        feats = {"C%d" % i: ids[:, i].cuda() for i in range(F)}
+        outs = []
+        for m in (a, b):
+            m.train()
+            m.zero_grad(set_to_none=True)
+            out = m(feats)
+            torch.nn.functional.binary_cross_entropy_with_logits(out, labels, reduction="sum").backward()
+            outs.append(out.detach())
+        assert torch.equal(outs[0], outs[1])
+        assert b.linear_weights[0].grad is None and b.linear_bias.grad is not None
+        with torch.no_grad():                       # (the dense parameters: plain SGD, the same on both)
+            for m in (a, b):
+                for p in m.parameters():
+                    if p.grad is not None:
+                        p -= 0.01 * p.grad
+    for pa, pb in zip(a.linear_weights, b.linear_weights):
+        assert torch.equal(pa.data, pb.data)
+    for pa, pb in zip(a.embedding_weights, b.embedding_weights):
+        assert torch.equal(pa.data, pb.data)
+    a.eval(); b.eval()
+    with torch.no_grad():
+        assert torch.equal(a(feats), b(feats))
+    sa, sd = a.state_dict(), b.state_dict()
+    assert all(sd[k].shape == sa[k].shape for k in sd if "linear_weights" in k)
+
+
+@pytest.mark.parametrize("B,F,K,V", [(1000, 26, 16, 500), (65, 3, 8, 20), (4097, 5, 4, 9), (16, 2, 32, 7), (300, 39, 16, 100)])
+def test_gather_fm_rows_leaves_row_maxima(built_lib, B, F, K, V):
+    """dir_gather_fm_rows_bits_f32: emb, fm and the field sums bit-identical to dir_gather_fm_rows_f32, and the row / tensor maxima it leaves
+    on emb equal to dir_row_absmax_bits_f32's pass over emb (pruned ids, ragged tails; packed training rows and plain tables + fsum)."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(B + K)
+    tabs = [(torch.randn(V, K, generator=g) * (0.01 + f)).cuda() for f in range(F)]
+    ids = torch.randint(-1, V + 1, (B, F), generator=g).cuda()
+    for ts in (ops.TableSet.train_rows([t.clone() for t in tabs]), ops.TableSet(tabs)):
+        f0 = torch.empty(B, K, device="cuda"); f1 = torch.empty(B, K, device="cuda")
+        e0, m0 = ops.gather_fm(ts, ids, fsum=f0)
+        e1, m1 = ops.gather_fm(ts, ids, fsum=f1, want_bits=True)
+        assert torch.equal(e0, e1) and torch.equal(m0, m1) and torch.equal(f0, f1)
+        assert not hasattr(e0, "_dir_bits")
+        rb, ab, ver = e1._dir_bits
+        want_rb, want_ab = ops.row_absmax_bits(e1.clone())
+        assert ver == e1._version and torch.equal(rb, want_rb) and torch.equal(ab, want_ab)
+        assert float(ab.view(torch.float32)) == float(e1.abs().max())
+        e2, _ = ops.gather_fm(ts, ids, fsum=f1, want_bits=True)       # the ticket word is back at zero: a second call gives the same
+        assert torch.equal(e2._dir_bits[1], want_ab) and torch.equal(e2._dir_bits[0], want_rb)
+
+
+def test_deepfm_train_step_takes_the_first_layers_row_maxima_from_the_gather(built_lib, monkeypatch):
+    """A DeepFM training step on packed training rows: with the gather's row maxima (default) the first dense layer runs no max pass of its
+    own over the embedding output, and logits, losses and updated tables are bit-identical to the step without them."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc, ops
+    B, F, K, V = 16384, 26, 16, 300          # (>= ops.DENSE_BF3_MIN_ROWS: the layers run the row-scaled kernel)
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, V, (B, F), generator=g)
+    labels = torch.randint(0, 2, (B, 1), generator=g).float().cuda()
+    feats = {"C%d" % i: ids[:, i].cuda() for i in range(F)}
+    res = []
+    for bits in (True, False):
+        monkeypatch.setattr(ops, "GATHER_BITS", bits)
+        torch.manual_seed(4)
+        m = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).cuda()
+        m.fused_sparse_adagrad(lr=0.05, packed=True)
+        m.fused_sparse_ftrl(lr=0.2, packed=True)
+        calls = []
+        real = ops.row_absmax_bits
+        monkeypatch.setattr(ops, "row_absmax_bits", lambda x, want_all=True: (calls.append(tuple(x.shape)), real(x, want_all))[1])
+        m.train()
+        out = m(feats)
+        torch.nn.functional.binary_cross_entropy_with_logits(out, labels, reduction="sum").backward()
+        monkeypatch.setattr(ops, "row_absmax_bits", real)
+        first = [c for c in calls if c == (B, F * K)]
+        assert (len(first) == 0) if bits else (len(first) >= 1), calls
+        res.append((out.detach().clone(), [p.data.clone() for p in m.embedding_weights], [p.grad.clone() for p in m.hidden.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert torch.equal(a, b)
+
+
 def test_deepfm_fused_ftrl_matches_torch_ftrl(built_lib):
     from dir_amd.deepfm import DeepFM
     from dir_amd import feature_column as fc
