@@ -168,6 +168,40 @@ def raise_pending(block=None):
             raise ValueError(describe())
 
 
+_IDS_ALIAS = os.environ.get("DIR_IDS_ALIAS", "1") != "0"      # development switch: 0 = always stack the id columns (round 4's behaviour)
+
+
+def _columns_of_one_matrix(got):
+    """The one-hot id columns as ONE strided [B, F] view when they already are the columns (or rows) of one int64 matrix -- what an input
+    pipeline that batches the categorical features into one tensor hands over as a dict of views --, else None.  The kernels take ids
+    with any (stride_b, stride_f): no stacked copy (13.6 MB per step at B = 65 536, F = 26)."""
+    t0 = got[0]
+    F, B = len(got), t0.numel()
+    if t0.dim() != 1 or t0.dtype != torch.int64 or B == 0:
+        return None
+    sb = t0.stride(0) if B > 1 else 1
+    base = t0.untyped_storage().data_ptr()
+    step = 1
+    for f, g in enumerate(got):
+        if (g.dim() != 1 or g.dtype != torch.int64 or g.device != t0.device or g.untyped_storage().data_ptr() != base
+                or (B > 1 and g.stride(0) != sb)):
+            return None
+        d = g.storage_offset() - t0.storage_offset()
+        if f == 1:
+            step = d
+        if d != f * step:
+            return None
+    if step <= 0 or sb <= 0:
+        return None
+    if sb != 1 and not torch.is_grad_enabled():
+        # Sample-major ids ([B, F] rows): the training kernels (4-8 lanes per sample) read them as they are -- deepfm_train 1.489 -> 1.465 ms
+        # without the stack --, but the fused inference kernels give a LANE a sample, and 64 lanes then read 64 different rows of the id
+        # matrix per field: the stack (a transposing copy: field-major ids, coalesced across samples) is worth its 15 us there
+        # (deepfm_full 0.2757 vs 0.2782 ms, esmm_full 0.410 vs 0.420 ms aliased; profiles/r05_ab_ids_alias.txt).
+        return None
+    return torch.as_strided(t0, (B, F), (sb, step))
+
+
 def collect_ids(columns, features, device, memo=None):
     """columns: categorical columns (or embedding/indicator wrappers).
     -> ("onehot", ids_view [B,F])  or  ("ragged", values, offsets [F*B+1], weights|None, B)
@@ -188,7 +222,9 @@ def collect_ids(columns, features, device, memo=None):
         for g in got:
             if g.numel() != B:
                 raise ValueError("features disagree on the batch size")
-        ids_bf = torch.stack(got, dim=0).t()
+        ids_bf = _columns_of_one_matrix(got) if _IDS_ALIAS else None
+        if ids_bf is None:
+            ids_bf = torch.stack(got, dim=0).t()
         if ids_bf.is_cuda:
             check_onehot_matrix(cats, ids_bf, device)     # one fused pass over the matrix the gather is about to read
         else:

@@ -39,6 +39,38 @@ def test_collect_ids_onehot_is_a_strided_view(built_lib):
         collect_ids(cols[:2], {"C0": torch.arange(5), "C1": torch.arange(4)}, "cpu")
 
 
+def test_collect_ids_takes_the_columns_of_one_matrix_without_a_copy(built_lib):
+    """Feature columns that are views of ONE int64 matrix (a batched input pipeline's dict) become a strided [B, F] view of that matrix:
+    same values as the stacked copy, no copy; anything else (separate tensors, other dtypes, columns out of order, a repeated column)
+    still stacks."""
+    from dir_amd import feature_column as fc
+    from dir_amd._input import collect_ids
+    cols = [fc.categorical_column_with_identity("C%d" % i, 1000) for i in range(4)]
+    g = torch.Generator().manual_seed(0)
+    wide = torch.randint(0, 1000, (7, 9), generator=g)                                   # [B, 9]: columns 2..5 of a wider batch
+    kind, ids = collect_ids(cols, {"C%d" % i: wide[:, 2 + i] for i in range(4)}, "cpu")
+    assert kind == "onehot" and ids.data_ptr() == wide[:, 2].data_ptr() and ids.stride() == (9, 1)
+    assert torch.equal(ids, wide[:, 2:6])
+    with torch.no_grad():                    # inference keeps the transposing stack for sample-major ids (its kernels want field-major)
+        ids = collect_ids(cols, {"C%d" % i: wide[:, 2 + i] for i in range(4)}, "cpu")[1]
+        assert ids.stride() == (1, 7) and torch.equal(ids, wide[:, 2:6])
+    fm = torch.randint(0, 1000, (4, 7), generator=g)                                     # field-major [F, B] rows
+    kind, ids = collect_ids(cols, {"C%d" % i: fm[i] for i in range(4)}, "cpu")
+    assert ids.data_ptr() == fm.data_ptr() and ids.stride() == (1, 7) and torch.equal(ids, fm.t())
+    kind, ids = collect_ids(cols, {"C%d" % i: wide[:, 2 * i] for i in range(4)}, "cpu")     # every second column: still one view
+    assert ids.stride() == (9, 2) and torch.equal(ids, wide[:, 0:8:2])
+    for feats in ({"C%d" % i: wide[:, 5 - i] for i in range(4)},                          # descending columns
+                  {"C%d" % i: wide[:, 3] for i in range(4)},                              # the same column four times
+                  {"C%d" % i: wide[:, i].clone() for i in range(4)},                      # separate tensors
+                  {"C0": wide[:, 0], "C1": wide[:, 1], "C2": wide[:, 3], "C3": wide[:, 4]},   # uneven steps
+                  {"C%d" % i: wide[:, i].to(torch.int32) for i in range(4)}):             # another dtype (converted per column)
+        kind, ids = collect_ids(cols, feats, "cpu")
+        want = torch.stack([feats["C%d" % i].to(torch.int64) for i in range(4)], dim=1)
+        assert ids.stride() == (1, 7) and torch.equal(ids, want)
+    one = collect_ids(cols[:1], {"C0": wide[:, 4]}, "cpu")[1]                              # F = 1
+    assert tuple(one.shape) == (7, 1) and torch.equal(one[:, 0], wide[:, 4])
+
+
 def test_collect_ids_ragged_field_major_csr(built_lib):
     from dir_amd import feature_column as fc
     from dir_amd._input import collect_ids
