@@ -89,7 +89,8 @@ class EmbeddingBag(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ts, ids, offsets, weights, combiner, field_major, out, max_norm, *tables):
-        res = ops.embedding_bag(ts, ids, offsets, weights, combiner=combiner, field_major=field_major, out=out, max_norm=max_norm)
+        res = ops.embedding_bag(ts, ids, offsets, weights, combiner=combiner, field_major=field_major, out=out, max_norm=max_norm,
+                                want_bits=ops.GATHER_BITS and offsets is None and out is None)
         ctx.ts, ctx.combiner, ctx.field_major, ctx.max_norm = ts, combiner, field_major, max_norm
         ctx.save_for_backward(ids, offsets if offsets is not None else torch.empty(0), weights if weights is not None else torch.empty(0))
         ctx.has_offsets, ctx.has_weights = offsets is not None, weights is not None

@@ -300,8 +300,18 @@ def slot_max_norms(ts, max_norm):
     return cache[key], 0.0
 
 
+def _bits_ws(device):
+    """The ticket / block-maxima workspace of the kernels that leave a tensor maximum (row_absmax_bits, the bits gathers): one per
+    (device, stream) -- calls on one stream are ordered."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ABSMAX_WS.get(key)
+    if ws is None:
+        ws = _ABSMAX_WS[key] = torch.zeros(int(_lib.load().dir_row_absmax_workspace_words()), dtype=torch.int32, device=device)
+    return ws
+
+
 def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", field_major=False, flags=0,
-                  out=None, max_norm=None):
+                  out=None, max_norm=None, want_bits=False):
     """Multi-slot embedding bag -> [B, F*K] (slot order).
 
     one-hot : ids LongTensor [B, F] (arbitrary strides, e.g. torch.stack(per_field).t()).
@@ -334,6 +344,17 @@ def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", fiel
         flags |= ts.gather_flags()
     slot_comb, comb = slot_combiners(ts, combiner)
     slot_mn, mn = slot_max_norms(ts, max_norm)
+    if (want_bits and offsets is None and slot_mn is None and not mn and K % 4 == 0 and B > 0 and out.stride(0) % 4 == 0
+            and out.data_ptr() % 16 == 0 and out.stride(1) == 1):
+        # one-hot lookups whose output feeds a row-scaled fp16 x 2 layer (an input layer made of embedding columns: the ESMM towers): the
+        # rows kernel copies the same rows and leaves the output's row / tensor maxima on it (dir_gather_fm_rows_bits_f32) -- no
+        # dir_row_absmax_bits_f32 pass over the [B, F*K] output in front of the first dense layer
+        buf = torch.empty(B + 4, dtype=torch.int32, device=ts.device)
+        rb, ab = buf[:B], buf[B:B + 1]
+        _lib.check(lib.dir_gather_fm_rows_bits_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), F, K, ts.ld, _ptr(ids), sb, sf, flags, B, _ptr(out),
+                                                   out.stride(0), None, None, _ptr(rb), _ptr(ab), _ptr(_bits_ws(ts.device)), _stream()))
+        out._dir_bits = (rb, ab, out._version)
+        return out
     _lib.check(lib.dir_embedding_bag_ex2_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
                                              _ptr(slot_comb), comb, _ptr(slot_mn), mn, flags, B, _ptr(out), out.stride(0), _stream()))
     return out

@@ -779,6 +779,26 @@ def test_gather_fm_rows_leaves_row_maxima(built_lib, B, F, K, V):
         assert torch.equal(e2._dir_bits[1], want_ab) and torch.equal(e2._dir_bits[0], want_rb)
 
 
+@pytest.mark.parametrize("B,F,K,V", [(1000, 26, 16, 500), (65, 3, 8, 20), (4097, 5, 4, 9), (300, 39, 16, 100)])
+def test_onehot_embedding_bag_leaves_row_maxima(built_lib, B, F, K, V):
+    """ops.embedding_bag(want_bits=True) on one-hot ids (what an input layer of embedding columns runs under training): the same output,
+    bit for bit, as the bag entry (pruned ids, field-major ids), with dir_row_absmax_bits_f32's row / tensor maxima left on it; multi-hot
+    or clipped lookups ignore the request."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(B + 3 * K)
+    tabs = [(torch.randn(V, K, generator=g) * (0.02 + 0.5 * f)).cuda() for f in range(F)]
+    ts = ops.TableSet(tabs)
+    for ids in (torch.randint(-1, V + 1, (B, F), generator=g).cuda(), torch.randint(0, V, (F, B), generator=g).cuda().t()):
+        e0 = ops.embedding_bag(ts, ids)
+        e1 = ops.embedding_bag(ts, ids, want_bits=True)
+        assert torch.equal(e0, e1) and not hasattr(e0, "_dir_bits")
+        rb, ab, ver = e1._dir_bits
+        want_rb, want_ab = ops.row_absmax_bits(e1.clone())
+        assert ver == e1._version and torch.equal(rb, want_rb) and torch.equal(ab, want_ab)
+    clipped = ops.embedding_bag(ts, ids, max_norm=0.5, want_bits=True)
+    assert not hasattr(clipped, "_dir_bits") and torch.equal(clipped, ops.embedding_bag(ts, ids, max_norm=0.5))
+
+
 def test_deepfm_train_step_takes_the_first_layers_row_maxima_from_the_gather(built_lib, monkeypatch):
     """A DeepFM training step on packed training rows: with the gather's row maxima (default) the first dense layer runs no max pass of its
     own over the embedding output, and logits, losses and updated tables are bit-identical to the step without them."""
