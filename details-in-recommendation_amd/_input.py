@@ -176,21 +176,21 @@ def _columns_of_one_matrix(got):
     pipeline that batches the categorical features into one tensor hands over as a dict of views --, else None.  The kernels take ids
     with any (stride_b, stride_f): no stacked copy (13.6 MB per step at B = 65 536, F = 26)."""
     t0 = got[0]
-    F, B = len(got), t0.numel()
-    if t0.dim() != 1 or t0.dtype != torch.int64 or B == 0:
+    base = t0._base                                        # (views of one tensor share ._base: separate tensors leave here at once)
+    if base is None or base.dtype != torch.int64 or t0.dim() != 1:
         return None
-    sb = t0.stride(0) if B > 1 else 1
-    base = t0.untyped_storage().data_ptr()
-    step = 1
-    for f, g in enumerate(got):
-        if (g.dim() != 1 or g.dtype != torch.int64 or g.device != t0.device or g.untyped_storage().data_ptr() != base
-                or (B > 1 and g.stride(0) != sb)):
+    F, B = len(got), t0.numel()
+    if B == 0:
+        return None
+    shape, stride = t0.shape, t0.stride()
+    for g in got:
+        if g._base is not base or g.shape != shape or (B > 1 and g.stride() != stride):
             return None
-        d = g.storage_offset() - t0.storage_offset()
-        if f == 1:
-            step = d
-        if d != f * step:
-            return None
+    sb = stride[0] if B > 1 else 1
+    ptrs = [g.data_ptr() for g in got]
+    step = (ptrs[1] - ptrs[0]) // 8 if F > 1 else 1
+    if any(ptrs[f] - ptrs[0] != 8 * f * step for f in range(F)):
+        return None
     if step <= 0 or sb <= 0:
         return None
     if sb != 1 and not torch.is_grad_enabled():
