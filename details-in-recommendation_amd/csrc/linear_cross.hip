@@ -51,6 +51,59 @@ __global__ __launch_bounds__(256) void linear_onehot_k(const float* const* __res
     }
 }
 
+// The same sum with FOUR lanes per sample (round 5): one thread per sample left 4 waves per CU to cover 26 dependent-free but
+// latency-long reads each (33.7 us for 1.7 M reads, 0.077 of HBM by bytes); lane c of a sample's quad reads the weights of fields
+// 4 j + c, and the quad adds them up in FIELD order through quad broadcasts (DPP) -- the oracle's sequential fp32 sum, bit for bit.
+template <int UFL>
+__global__ __launch_bounds__(256) void linear_onehot4_k(const float* const* __restrict__ wts, const int64_t* __restrict__ vocab,
+                                                        const int64_t* __restrict__ ids, int64_t sb, int64_t sf, int F,
+                                                        const float* __restrict__ bias, int accumulate, int64_t B, float* __restrict__ out,
+                                                        int64_t ld) {
+    const int c = threadIdx.x & 3;
+    const int64_t per_grid = ((int64_t)gridDim.x * blockDim.x) >> 2;
+    for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x) >> 2; b0 < B; b0 += per_grid) {      // (block-uniform trip count: the DPP reads see live lanes)
+        const int64_t b = b0 + (threadIdx.x >> 2);
+        const bool live = b < B;
+        const int64_t* idp = ids + (live ? b : 0) * sb;
+        float acc = 0.f;
+        for (int f0 = 0; f0 < F; f0 += 4 * UFL) {
+            int64_t id[UFL];
+            float v[UFL];
+#pragma unroll
+            for (int j = 0; j < UFL; ++j) {
+                const int f = f0 + 4 * j + c;
+                id[j] = (live && f < F) ? idp[(int64_t)f * sf] : (int64_t)-1;
+            }
+#pragma unroll
+            for (int j = 0; j < UFL; ++j) {
+                const int f = f0 + 4 * j + c;
+                v[j] = 0.f;
+                if (f < F) {
+                    const uint64_t bound = vocab ? (uint64_t)vocab[f] : (uint64_t)1 << 63;   // id < 0 / id >= vocab_f: pruned
+                    if ((uint64_t)id[j] < bound) v[j] = wts[f][id[j] * ld];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UFL; ++j) {
+                const int vi = __builtin_bit_cast(int, v[j]);
+                const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0x00, 0xf, 0xf, true));   // quad_perm [0,0,0,0]
+                const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0x55, 0xf, 0xf, true));   // [1,1,1,1]
+                const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0xaa, 0xf, 0xf, true));   // [2,2,2,2]
+                const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0xff, 0xf, 0xf, true));   // [3,3,3,3]
+                const int f = f0 + 4 * j;
+                if (f < F) acc = acc + q0;
+                if (f + 1 < F) acc = acc + q1;
+                if (f + 2 < F) acc = acc + q2;
+                if (f + 3 < F) acc = acc + q3;
+            }
+        }
+        if (live && c == 0) {
+            const float r = acc + (bias ? bias[0] : 0.f);
+            out[b] = accumulate ? out[b] + r : r;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void linear_csr_k(const float* const* __restrict__ wts,
                                                     const int64_t* __restrict__ vocab,
                                                     const int64_t* __restrict__ ids,
@@ -198,6 +251,11 @@ __global__ __launch_bounds__(256) void cross_k(const float* __restrict__ x0, int
     }
 }
 
+static bool linear_quads() {          // development A/B switch (DIR_DEVELOPMENT builds only): DIR_LINEAR_QUADS=0 = one thread per sample
+    static const int v = dev_env_int("DIR_LINEAR_QUADS", 1);
+    return v != 0;
+}
+
 }  // namespace dir
 
 using namespace dir;
@@ -214,6 +272,10 @@ extern "C" int dir_linear_sparse_sum_f32(const float* const* weights, const int6
     hipStream_t st = as_stream(stream);
     dim3 grid(grid_for((B + 255) / 256));
     if (!offsets) {
+        if (linear_quads())
+            hipLaunchKernelGGL((linear_onehot4_k<7>), dim3(grid_for((B + 63) / 64)), dim3(256), 0, st, weights, vocab, ids, stride_b, stride_f, F, bias,
+                               accumulate, B, out, (int64_t)1);
+        else
         hipLaunchKernelGGL((linear_onehot_k<13>), grid, dim3(256), 0, st, weights, vocab, ids, stride_b, stride_f, F, bias, accumulate, B, out, (int64_t)1);
     } else {
         hipLaunchKernelGGL(linear_csr_k, grid, dim3(256), 0, st, weights, vocab, ids, offsets, entry_weights, stride_b, stride_f, F, combiner, bias, accumulate, B, out);
@@ -232,6 +294,10 @@ extern "C" int dir_linear_onehot_rows_f32(const float* const* rows, int64_t row_
     if (B == 0) return DIR_OK;
     hipStream_t st = as_stream(stream);
     dim3 grid(grid_for((B + 255) / 256));
+    if (linear_quads())
+        hipLaunchKernelGGL((linear_onehot4_k<7>), dim3(grid_for((B + 63) / 64)), dim3(256), 0, st, rows, vocab, ids, stride_b, stride_f, F, bias, accumulate,
+                           B, out, row_ld);
+    else
     hipLaunchKernelGGL((linear_onehot_k<13>), grid, dim3(256), 0, st, rows, vocab, ids, stride_b, stride_f, F, bias, accumulate, B, out, row_ld);
     DIR_CHECK_LAUNCH("linear_onehot_rows");
     return DIR_OK;
