@@ -406,10 +406,7 @@ def gather_fm(tables, ids, want_emb=True, out=None, fm=None, fsum=None, want_bit
             raise ValueError("fsum must be a contiguous [B, K] tensor")
         if want_bits and want_emb and B > 0 and ts.K % 4 == 0:
             lib = _lib.load()
-            key = (ts.device.index, torch.cuda.current_stream(ts.device).cuda_stream)
-            ws = _ABSMAX_WS.get(key)
-            if ws is None:                               # (the workspace of row_absmax_bits: calls on one stream are ordered)
-                ws = _ABSMAX_WS[key] = torch.zeros(int(lib.dir_row_absmax_workspace_words()), dtype=torch.int32, device=ts.device)
+            ws = _bits_ws(ts.device)
             buf = torch.empty(B + 4, dtype=torch.int32, device=ts.device)
             rb, ab = buf[:B], buf[B:B + 1]
             _lib.check(lib.dir_gather_fm_rows_bits_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, ts.ld, _ptr(ids), sb, sf,
@@ -876,10 +873,7 @@ def row_absmax_bits(x, want_all=True):
     fp16 x 2 kernels multiply x by."""
     M, N = x.shape
     lib = _lib.load()
-    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-    ws = _ABSMAX_WS.get(key)
-    if ws is None:                                       # ticket word + block maxima, per (device, stream): calls on one stream are ordered
-        ws = _ABSMAX_WS[key] = torch.zeros(int(lib.dir_row_absmax_workspace_words()), dtype=torch.int32, device=x.device)
+    ws = _bits_ws(x.device)                              # ticket word + block maxima, per (device, stream)
     buf = torch.empty(M + 4, dtype=torch.int32, device=x.device)
     rb, ab = buf[:M], buf[M:M + 1]
     _lib.check(lib.dir_row_absmax_bits_f32(_ptr(x), x.stride(0), M, N, _ptr(rb), _ptr(ab) if want_all else None, _ptr(ws), _stream()))
