@@ -35,7 +35,11 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-constexpr int DB3_ROWS = 256;
+#ifndef DB3_NW
+#define DB3_NW 4           // waves per workgroup: 4 = two 256-thread workgroups per CU, each with barriers of its own (round 5: the two drift apart, one's loads and
+                           // epilogue fall beside the other's matrix instructions: dense_bf3_k<13,2> 85.9 -> 81.7 us, deepfm_train 1.472 -> 1.442 ms); 8 = one 512-thread workgroup
+#endif
+constexpr int DB3_ROWS = 32 * DB3_NW;
 // DB3_CHAIN: a scheduling fence behind every accumulator's six MFMAs keeps them one dependent chain.  A SIMD gives its other wave's VALU
 // instructions (the next k-step's operand split) issue slots only while this wave waits on a dependent MFMA -- none while it has
 // independent MFMAs to issue (tools/coexec_probe.hip); left alone the compiler interleaves the chains of the two row tiles.  Same
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void dense_f16x2_pack_rows_k(const float* __re
 // is split and the row's accumulators by the inverse before the epilogue (both exact); row_bits[r] = bit pattern of max_k |X[r, k]|
 // (dir_row_absmax_bits_f32).
 template <int CT, int NP = 3, bool RS = false>
-__global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ X, int64_t x_ld, const unsigned char* __restrict__ img,
+__global__ __launch_bounds__(64 * DB3_NW, 8 / DB3_NW) void dense_bf3_k(const float* __restrict__ X, int64_t x_ld, const unsigned char* __restrict__ img,
                                                      const float* __restrict__ bias, int relu, const float* __restrict__ post_scale,
                                                      const float* __restrict__ post_shift, const float* __restrict__ gate, int64_t gate_ld,
                                                      int64_t M, int Kd, int N, int nks, int ncb, float* __restrict__ Y, int64_t y_ld,
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
         }
     };
     auto stage_w = [&](const Tile& tl, int ks, int buf) {     // 3*CT pieces of 1 KB over 8 waves, lane-linear
-        for (int piece = wave; piece < NP * CT; piece += 8) {
+        for (int piece = wave; piece < NP * CT; piece += DB3_NW) {
             const unsigned char* src = tl.gi + (int64_t)ks * STEPB + piece * 1024 + lane * 16;
             unsigned char* dst = Wb + buf * STEPB + piece * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(512, 1) void dense_bf3_k(const float* __restrict__ 
         if (tid == 0) {
             float m = wmx[0];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) m = fmaxf(m, wmx[q]);
+            for (int q = 1; q < DB3_NW; ++q) m = fmaxf(m, wmx[q]);
             if (m > 0.f) atomicMax(y_all_bits, __builtin_bit_cast(unsigned int, m));
         }
     }
@@ -449,8 +453,9 @@ static void launch_dense_bf3(hipStream_t st, const float* X, int64_t x_ld, const
     static LdsOnce once;
     (void)lds_limit(once, 160 * 1024, &dense_bf3_k<CT, NP, RS>);
     const int64_t ntiles = (M + DB3_ROWS - 1) / DB3_ROWS * ncb;
-    const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;         // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
-    hipLaunchKernelGGL((dense_bf3_k<CT, NP, RS>), dim3((unsigned)nwg), dim3(512), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
+    const int64_t cap = (int64_t)kCUs * (8 / DB3_NW);
+    const int64_t nwg = ntiles < cap ? ntiles : cap;           // one persistent workgroup per CU (512 threads, 78-96 KB of LDS)
+    hipLaunchKernelGGL((dense_bf3_k<CT, NP, RS>), dim3((unsigned)nwg), dim3(64 * DB3_NW), shmem, st, X, x_ld, img, bias, relu, ps, psh, gate, gate_ld, M, Kd, N,
                        nks, ncb, Y, y_ld, head_w, head_part, row_bits, y_row_bits, y_all_bits);
 }
 

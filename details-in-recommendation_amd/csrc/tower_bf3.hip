@@ -36,7 +36,10 @@ typedef unsigned int tw_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* tw_lds_ptr;
 typedef const __attribute__((address_space(1))) void* tw_glb_ptr;
 
-constexpr int TW_ROWS = 128;      // rows per workgroup (8 waves x 16)
+#ifndef TW_NW
+#define TW_NW 8            // waves per workgroup: 8 = one 512-thread workgroup per CU, 4 = two 256-thread workgroups with barriers of their own
+#endif
+constexpr int TW_ROWS = 16 * TW_NW;      // rows per workgroup (TW_NW waves x 16)
 constexpr int TW_NT = 26;         // column tiles of 16: widths up to 416
 constexpr int TW_ST = 13;         // column tiles per stage (one LDS buffer: 3 pieces x 13 KB)
 constexpr int TW_MAXL = 4;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void tower_bf3_pack_k(const float* __restrict_
 // 0.5 sum_k ((sum_f e)^2 - sum_f e^2) (field sums f-ascending, then k-ascending across the row's four lanes) and the first-order term
 // sum_f w_f + bias (f-ascending), both added to the head's logit in the epilogue.  The 109 MB concat is never written or read.
 template <bool GATHER, int NP = 3>
-__global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
+__global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p) {
     constexpr int BUFB = tw_bufb(NP);
     extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];      // [2][TW_BUFB]: the W image of one stage
     const int tid = threadIdx.x;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void tower_bf3_k(const TowerParams p) {
         unsigned char* dst = tw_smem + buf * BUFB;
 #pragma unroll
         for (int pc = 0; pc < NP; ++pc)
-            for (int cs = wave_u; cs < nst; cs += 8) {            // wave-uniform trip count
+            for (int cs = wave_u; cs < nst; cs += TW_NW) {        // wave-uniform trip count
                 const int off = (pc * TW_ST + cs) * 1024;
                 __builtin_amdgcn_global_load_lds((tw_glb_ptr)(src + off), (tw_lds_ptr)(dst + off), 16, 0, 0);
             }
@@ -466,8 +469,9 @@ static int tower_launch(const char* name, const TowerParams& p, dir_stream_t str
     static LdsOnce once;
     if (!lds_limit(once, 160 * 1024, &tower_bf3_k<GATHER, NP>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
     const int64_t ntiles = (p.M + TW_ROWS - 1) / TW_ROWS;
-    const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;            // one persistent workgroup per CU (8 waves x 256 registers, 78 / 52 KB of LDS)
-    hipLaunchKernelGGL((tower_bf3_k<GATHER, NP>), dim3((unsigned)nwg), dim3(512), 2 * tw_bufb(NP), as_stream(stream), p);
+    const int64_t cap = (int64_t)kCUs * (8 / TW_NW);
+    const int64_t nwg = ntiles < cap ? ntiles : cap;              // persistent workgroups: 8 waves x 256 registers per CU, 78 / 52 KB of LDS each
+    hipLaunchKernelGGL((tower_bf3_k<GATHER, NP>), dim3((unsigned)nwg), dim3(64 * TW_NW), 2 * tw_bufb(NP), as_stream(stream), p);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
