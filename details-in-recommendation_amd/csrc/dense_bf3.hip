@@ -18,11 +18,12 @@
 // rows = output columns) x X-piece (B operand: columns = batch rows), so that a lane's four accumulator registers are four
 // CONSECUTIVE output columns of one row: bias / ReLU / affine / gate on float4s and 16-byte stores.
 //
-// Work split.  A workgroup of 8 waves (two per SIMD) owns 256 rows x one column block of CT tiles (CT = 13: 208 columns, 16: 256,
-// 8: 128 -- the host picks the one that pads N least); wave w rows [32w, 32w+32) = 2 row tiles x CT column tiles.  One k-step of 32
-// per barrier: 12*CT MFMAs per wave.  One persistent workgroup per CU walks a contiguous range of tiles (the column blocks of a row
-// block back to back: the second finds X in the L2), software-pipelined across tiles so that a tile's stores drain under the next
-// tile's first k-step.
+// Work split.  A workgroup of DB3_NW = 4 waves (one per SIMD; 8 until round 5) owns 32 DB3_NW = 128 rows x one column block of CT tiles
+// (CT = 13: 208 columns, 16: 256, 8: 128 -- the host picks the one that pads N least); wave w rows [32w, 32w+32) = 2 row tiles x CT
+// column tiles.  One k-step of 32 per barrier: 12*CT MFMAs per wave (6*CT on fp16 x 2).  TWO persistent workgroups per CU, each with
+// barriers of its own (they drift apart: one's loads, waits and epilogue fall beside the other's matrix instructions), walk the tiles
+// in rounds (the column blocks of a row block on one XCD at the same time: the second finds X in the L2), software-pipelined across
+// tiles so that a tile's stores drain under the next tile's first k-step.
 //
 // LDS: Wb [2][3 pieces][CT][64 lanes][8 bf16] -- the k-step's W image, in the order dense_bf3_pack_k writes the global image.
 #include "common.hpp"
