@@ -931,7 +931,8 @@ def main():
         model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
                        dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).to(device)
         model.fused_sparse_adagrad(lr=0.01, packed=(args.train_layout == "packed"))
-        model.fused_sparse_ftrl(lr=0.2, packed=(args.train_layout == "packed" and os.environ.get("DIR_BENCH_FTRL_ROWS", "1") != "0"))
+        ftrl_rows = args.train_layout == "packed" and os.environ.get("DIR_BENCH_FTRL_ROWS", "1") != "0"
+        model.fused_sparse_ftrl(lr=0.2, packed=ftrl_rows)       # packed linear training rows [w | n | z | -] beside the packed embedding rows
         lin = [model.linear_bias]                          # the weight columns are updated by the fused kernel inside backward()
         skip = {id(p) for p in model.linear_weights} | {id(p) for p in lin} | {id(p) for p in model.embedding_weights}
         opt_dense = ag_opt.Adagrad([p for p in model.parameters() if id(p) not in skip], lr=0.01, initial_accumulator_value=0.1)
@@ -950,6 +951,7 @@ def main():
         roof = {"bound": "hbm", "alg_bytes": B * ((F * (8 + 8 * K) + 4) + 3 * 4 * F * K + F * (8 + 4 + 4 * K + 4 * 4 * K)),
                 "kernel": "whole training step; bytes = the sparse side only (gather+FM, FM backward, sparse Adagrad)"}
         cfg.update({"fields": F, "vocab_per_field": V, "dim": K, "ids": args.id_dist, "mlp": [400, 400, 400], "layout": args.train_layout,
+                    "linear_rows": "packed [w|n|z|-]" if ftrl_rows else "three arrays",
                     "optimizers": "sparse Adagrad + sparse FTRL (HIP, sorted, inside backward) + torch Adagrad (MLP)"})
     elif wl == "small_batch":
         # the reference's own batch size (256; 100 for evaluation: DeepCrossNetwork/train.py:16-17): nothing is bound but launch latency and the
