@@ -140,7 +140,7 @@ class DeepFM(nn.Module):
 
     # ---- TableSets follow the parameters' storage (rebuilt when .to()/.cuda() moved them) ------------
     def _tablesets(self):
-        key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
+        key = tuple([p.data_ptr() for p in ops.plain_list(self.embedding_weights)] + [p.data_ptr() for p in ops.plain_list(self.linear_weights)])
         if getattr(self, "_ts_key", None) != key:
             ops.refuse_rebuild_under_sink(self._emb_ts, self._lin_ts)
             self._emb_ts = ops.TableSet([p.data for p in self.embedding_weights]) if len(self.embedding_weights) else None

@@ -58,7 +58,7 @@ class InputLayer(nn.Module):
         return self.offsets[self.columns.index(col)]
 
     def _tablesets(self):
-        key = tuple(p.data_ptr() for p in self.embedding_weights)
+        key = tuple([p.data_ptr() for p in ops.plain_list(self.embedding_weights)])
         if self._ts_key != key:
             ops.refuse_rebuild_under_sink(*[g[0] for g in getattr(self, "_groups", [])])
             self._groups = []  # (TableSet, [indices into self.emb_cols], [combiner per column], max_norm)

@@ -253,6 +253,16 @@ def refuse_rebuild_under_sink(*tablesets):
             raise RuntimeError("the embedding tables moved (model.to() / .cuda() / new storage) after a fused sparse optimiser was attached to "
                                "them: move the model first, then call fused_sparse_* / TrainStep")
 
+def plain_list(plist):
+    """The parameters of an nn.ParameterList as a plain Python list: iterating a ParameterList resolves every element through
+    __getitem__ / _get_abs_string_index -- 52 tables cost a forward ~0.15 ms of host time where the per-step key over their data_ptr()s
+    is built (DeepFM._tablesets); the module's own parameter dict holds them in order (always current: replaced elements keep their slot)."""
+    params = getattr(plist, "_parameters", None)
+    if params is not None and len(params) == len(plist):
+        return list(params.values())
+    return list(plist)
+
+
 def _as_tableset(tables):
     return tables if isinstance(tables, TableSet) else TableSet(tables)
 

@@ -56,7 +56,7 @@ class XDeepFM(nn.Module):
         self._ts_key = None
 
     def _tablesets(self):
-        key = tuple(p.data_ptr() for p in self.embedding_weights) + tuple(p.data_ptr() for p in self.linear_weights)
+        key = tuple([p.data_ptr() for p in ops.plain_list(self.embedding_weights)] + [p.data_ptr() for p in ops.plain_list(self.linear_weights)])
         if self._ts_key != key:
             ops.refuse_rebuild_under_sink(getattr(self, "_emb_ts", None), getattr(self, "_lin_ts", None))
             self._emb_ts = ops.TableSet([p.data for p in self.embedding_weights])
