@@ -199,20 +199,20 @@ class DeepFM(nn.Module):
         max_norm = self._max_norm()
         if got[0] == "onehot" and max_norm:                                      # clipping needs the bag kernel: one-entry bags
             ids = got[1]
-            emb = (ag.embedding_bag(emb_ts, ids, list(self.embedding_weights), max_norm=max_norm) if train
+            emb = (ag.embedding_bag(emb_ts, ids, ops.plain_list(self.embedding_weights), max_norm=max_norm) if train
                    else ops.embedding_bag(emb_ts, ids, max_norm=max_norm))
             fm = ag.fm_logit(emb, self.F, self.K) if train else ops.fm_logit(emb, self.F, self.K)
             return self.dnn_logit_fn(emb, adds=(fm,))
         if got[0] == "onehot":
             if train:
-                emb, fm = ag.gather_fm(emb_ts, got[1], list(self.embedding_weights))
+                emb, fm = ag.gather_fm(emb_ts, got[1], ops.plain_list(self.embedding_weights))
             else:
                 emb, fm = ops.gather_fm(emb_ts, got[1])                          # inputs + fm_logit_fn, one pass
         else:
             _, vals, offs, wts, _ = got
             comb = [c.combiner for c in self.dnn_feature_columns]                # every embedding_column carries its own combiner
             if train:
-                emb = ag.embedding_bag(emb_ts, vals, list(self.embedding_weights), offs, wts, combiner=comb, field_major=True,
+                emb = ag.embedding_bag(emb_ts, vals, ops.plain_list(self.embedding_weights), offs, wts, combiner=comb, field_major=True,
                                        max_norm=max_norm)
                 fm = ag.fm_logit(emb, self.F, self.K)
             else:
@@ -242,7 +242,7 @@ class DeepFM(nn.Module):
         train = torch.is_grad_enabled()
         if self.units == 1 and got[0] == "onehot":
             if train:
-                return ag.linear_logit(lin_ts, got[1], self.linear_bias, list(self.linear_weights))
+                return ag.linear_logit(lin_ts, got[1], self.linear_bias, ops.plain_list(self.linear_weights))
             return ops.linear_logit(lin_ts, got[1], bias=self.linear_bias.data)
         if self.units == 1 and not train:
             _, vals, offs, wts, _ = got
@@ -252,7 +252,7 @@ class DeepFM(nn.Module):
         # linear_model's sparse_combiner, summed over the columns; the bag op's backward gives the weights sparse gradients
         Fl = len(self.linear_feature_columns)
         comb = self.linear_sparse_combiner
-        tabs = list(self.linear_weights)
+        tabs = ops.plain_list(self.linear_weights)
         if got[0] == "onehot":
             args, kw = (got[1],), {}
             B = got[1].shape[0]
@@ -416,7 +416,7 @@ class DeepFM(nn.Module):
         emb_ts, lin_ts = self._tablesets()
         train = torch.is_grad_enabled()
         if train:                                                                # differentiable: the tables get (sparse) gradients
-            emb, fm = ag.gather_fm(emb_ts, dnn_ids, list(self.embedding_weights))
+            emb, fm = ag.gather_fm(emb_ts, dnn_ids, ops.plain_list(self.embedding_weights))
         else:
             emb, fm = ops.gather_fm(emb_ts, dnn_ids)
         logits = self.dnn_logit_fn(emb, adds=(fm,))
@@ -424,7 +424,7 @@ class DeepFM(nn.Module):
             if self.units != 1:
                 raise NotImplementedError("forward_ids: the multi-class head takes the features-dict path")
             if train:
-                logits = logits + ag.linear_logit(lin_ts, linear_ids, self.linear_bias, list(self.linear_weights))
+                logits = logits + ag.linear_logit(lin_ts, linear_ids, self.linear_bias, ops.plain_list(self.linear_weights))
             else:
                 logits = logits + ops.linear_logit(lin_ts, linear_ids, bias=self.linear_bias.data)
         return logits

@@ -123,7 +123,8 @@ class InputLayer(nn.Module):
         blocks, inside = {}, set()
         for ts, idxs, comb, mn in self._tablesets():
             cols = [self.emb_cols[i] for i in idxs]
-            tabs = [self.embedding_weights[i] for i in idxs]
+            ew = ops.plain_list(self.embedding_weights)
+            tabs = [ew[i] for i in idxs]
             got = collect_ids(cols, features, device, memo)
             if got[0] == "onehot":
                 blk = ag.embedding_bag(ts, got[1], tabs, max_norm=mn)

@@ -145,7 +145,7 @@ class XDeepFM(nn.Module):
         got = collect_ids(self.dnn_feature_columns, features, device)
         comb = self.dnn_feature_columns[0].combiner
         if train:      # sparse table gradients (autograd.EmbeddingBag / LinearLogit)
-            tabs = list(self.embedding_weights)
+            tabs = ops.plain_list(self.embedding_weights)
             emb = ag.embedding_bag(emb_ts, got[1], tabs) if got[0] == "onehot" else \
                 ag.embedding_bag(emb_ts, got[1], tabs, got[2], got[3], combiner=comb, field_major=True)
         elif got[0] == "onehot":
