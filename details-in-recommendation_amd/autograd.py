@@ -430,6 +430,10 @@ class ActRows(torch.autograd.Function):
             mean, inv = saved[4], saved[5]
             dbn, _, _ = ops.bn_train_backward(gx, s, mean, inv, gamma=None)      # the statistics' share of dL/ds
             d1.add_(dbn)
+        elif ctx.kind == "dice":
+            # moving statistics (module.eval() with grad enabled): x_hat = scale * s + shift still depends on s, so its share
+            # gx * scale joins dL/ds (only d1 used to be returned -- frozen-statistics fine-tuning got wrong gradients)
+            d1.addcmul_(gx, scale.reshape(1, -1))
         return d1, galpha.reshape(alpha.shape) if ctx.needs_input_grad[1] else None, None, None
 
 

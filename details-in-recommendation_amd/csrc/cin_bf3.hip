@@ -152,35 +152,52 @@ __device__ __forceinline__ int w_scale_exp(const float* __restrict__ part) {    
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned int)(127 + k) << 23); }     // |k| <= 126
 
 // The VERDICT of a forward layer whose producer left xk's row maxima (round 5): when max |xk| sits in [2^-4, 2^15) -- where splitting the rows
-// unscaled loses nothing that matters (an element below 2^-3 keeps an absolute 2^-25, at most 2^-21 of the tensor's largest) -- the plain kernel
-// runs (8-9 % faster than the row-scaled form: no scan of the rows, profiles/r05_cin_rs_probe.txt), otherwise the row-scaled one.  W is
+// unscaled loses nothing that matters (an element below 2^-3 keeps an absolute 2^-25, at most 2^-21 of the tensor's largest) -- AND the smallest
+// non-zero row maximum is at least 2^-8 (round 6, ADVICE r5: a tensor inside the window may still hold tiny rows; an element's absolute 2^-25
+// is 2^-17 of such a row's largest at worst, inside the 1e-5 bar PER ROW, not just per tensor) the plain kernel runs (8-9 % faster than the
+// row-scaled form: no scan of the rows, profiles/r05_cin_rs_probe.txt), otherwise the row-scaled one.  W is
 // scaled by its tensor power of two in BOTH (typical CIN weights sit around 2^-5: unscaled they cost the plain form a factor ten in accuracy).
-// Decided ON THE DEVICE from the partial maxima (wpart [WPARTS] then xpart [XPARTS], contiguous): both kernels are launched, each leaves at
-// once unless the verdict names it.  No host read, graph-capturable.
+// Decided ON THE DEVICE from the partial maxima (wpart [WPARTS] then xpart [XPARTS] = XBLOCKS maxima + XBLOCKS minima of the non-zero row
+// maxima, contiguous): both kernels are launched, each leaves at once unless the verdict names it.  No host read, graph-capturable.
 constexpr int XPARTS = 256;
+constexpr int XBLOCKS = XPARTS / 2;
 __global__ __launch_bounds__(256) void cin_bits_absmax_k(const unsigned int* __restrict__ bits, int64_t n, float* __restrict__ xpart) {
-    __shared__ unsigned int red[4];
-    unsigned int mx = 0u;                                     // bit patterns of non-negative floats order like the floats
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) mx = max(mx, bits[e]);
+    __shared__ unsigned int red[8];
+    unsigned int mx = 0u, mn = 0x7f800000u;                   // bit patterns of non-negative floats order like the floats; mn over NON-ZERO rows
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const unsigned int b = bits[e];
+        mx = max(mx, b);
+        mn = b ? min(mn, b) : mn;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
+        mn = min(mn, (unsigned int)__shfl_xor((int)mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; red[4 + (threadIdx.x >> 6)] = mn; }
     __syncthreads();
-    if (threadIdx.x == 0) xpart[blockIdx.x] = __builtin_bit_cast(float, max(max(red[0], red[1]), max(red[2], red[3])));
+    if (threadIdx.x == 0) {
+        xpart[blockIdx.x] = __builtin_bit_cast(float, max(max(red[0], red[1]), max(red[2], red[3])));
+        xpart[XBLOCKS + blockIdx.x] = __builtin_bit_cast(float, min(min(red[4], red[5]), min(red[6], red[7])));
+    }
 }
 __device__ __forceinline__ bool cin_plain_verdict(const float* __restrict__ vparts) {      // wave-uniform; every lane of the wave calls it
     const int lane = threadIdx.x & 63;
-    float wm = lane < WPARTS ? vparts[lane] : 0.f, xm = 0.f;
+    float wm = lane < WPARTS ? vparts[lane] : 0.f, xm = 0.f, xn = __builtin_inff();
 #pragma unroll
-    for (int q = 0; q < XPARTS / 64; ++q) xm = fmaxf(xm, vparts[WPARTS + 64 * q + lane]);
+    for (int q = 0; q < XBLOCKS / 64; ++q) {
+        xm = fmaxf(xm, vparts[WPARTS + 64 * q + lane]);
+        xn = fminf(xn, vparts[WPARTS + XBLOCKS + 64 * q + lane]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         wm = fmaxf(wm, __shfl_xor(wm, o, 64));
         xm = fmaxf(xm, __shfl_xor(xm, o, 64));
+        xn = fminf(xn, __shfl_xor(xn, o, 64));
     }
     (void)wm;            // W is scaled in BOTH forms (the pack kernel's tensor scale costs nothing; the plain kernel takes 2^-kw out of its
-                         // accumulators in the epilogue): only the row operand's magnitude decides
-    return xm >= 0x1p-4f && xm < 0x1p15f;
+                         // accumulators in the epilogue): only the row operand's magnitudes decide
+    return xm >= 0x1p-4f && xm < 0x1p15f && xn >= 0x1p-8f;
 }
 
 template <int NP>
@@ -822,7 +839,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
     float* sink = wtail + WPARTS + XPARTS;
     if (rs) hipLaunchKernelGGL(cin_w_absmax_k, dim3(WPARTS), dim3(256), 0, st, W, (int64_t)H * Hp * m, wpart);
     const int verdict = (rs && verdict_bits && !dot) ? 1 : 0;
-    if (verdict) hipLaunchKernelGGL(cin_bits_absmax_k, dim3(XPARTS), dim3(256), 0, st, verdict_bits, R, wpart + WPARTS);
+    if (verdict) hipLaunchKernelGGL(cin_bits_absmax_k, dim3(XBLOCKS), dim3(256), 0, st, verdict_bits, R, wpart + WPARTS);
     auto pack = [&](int ncb, int CT, int hoff, unsigned char* dst) {
         const int64_t threads = (int64_t)ncb * pl.chunks * pl.KS * CT * 64 * 4;
         if (np == 2)

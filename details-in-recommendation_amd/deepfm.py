@@ -156,13 +156,18 @@ class DeepFM(nn.Module):
     def _logits_of(self, net):
         return units1(self.logits_layer, net) if self.units == 1 else self.logits_layer(net)
 
-    def dnn_logit_fn(self, net, adds=()):
+    def dnn_logit_fn(self, net, adds=(), range_ok=None):
         """deepFM.py:284-319.  adds: [B, 1] logits to add to the result (fm_logit_fn's, deepFM.py:337-338) -- inside the fused tower
-        kernel's epilogue when that runs, here otherwise."""
+        kernel's epilogue when that runs, here otherwise.  range_ok: whether the rows `net` was gathered from sit inside the unscaled
+        fp16 x 2 window (ops.f16_range_ok of THEIR tables' largest magnitude); None = net came from this model's own embedding_weights
+        (the model's feature path).  A caller that feeds rows of other tables (ShardedDeepFMTrainer.predict: the sharded tables) passes
+        its own verdict -- the guard used to measure the model's unused tables instead; False is always safe (bf16 x 3)."""
         if not _train_mode(self):
+            if range_ok is None:
+                range_ok = self._tablesets()[0].range_ok()
             fused = tower_infer(self.hidden, net, self.activation, bns=self.bns if len(self.bns) else None,
                                 head=self.logits_layer if self.units == 1 else None, adds=adds if self.units == 1 else (),
-                                embedding_input=self._tablesets()[0].range_ok())       # net is the concat of the embedding columns (deepFM.py:288-291)
+                                embedding_input=bool(range_ok))       # net is the concat of the embedding columns (deepFM.py:288-291)
             if fused is not None:                                               # inference: the whole tower (+ logit layer) in one launch
                 out = fused if self.units == 1 else self._logits_of(fused)
                 for a in (adds if self.units != 1 else ()):

@@ -145,18 +145,25 @@ class TableSet:
     def absmax(self, every=1):
         """max |embedding value| over the tables, measured once per version of the tables and their owners (one pass + one sync when an
         in-place update bumped a counter): tower(gather=..., split=None) keeps a table past F16_RANGE_GUARD off the fp16 x 2 kernel.
-        every > 1: a measurement may be up to `every` updates old (every table's counter moves once per optimiser step) -- what a
-        training loop that evaluates between steps can afford: one pass and one sync per `every` steps."""
-        sig = tuple(t._version for t in self.tables) + tuple(t._version for t in self.owners)
+        every > 1: a measurement may be up to `every` OPTIMISER STEPS old -- version bumps that the fused updaters made through
+        mark_written (the ledger hip_bumps counts them): what a training loop that evaluates between steps can afford, one pass and one
+        sync per `every` steps.  Any other version change (load_state_dict, a copy_, a torch optimiser) re-measures at once, and so does
+        invalidate_caches() (a checkpoint loaded after one eval forward used to keep the pre-load figure for 32 x F bumps)."""
+        watched = list(self.tables) + list(self.owners)
+        sig = tuple(t._version for t in watched)
         hit = getattr(self, "_absmax", None)
-        tot = sum(sig)
-        if hit is None or (hit[0] != sig and (every <= 1 or tot - hit[2] >= every * len(sig) or tot < hit[2])):
-            if torch.cuda.is_current_stream_capturing():
+        stale = hit is None or hit[3] != _CACHE_GEN[0] or len(hit[0]) != len(sig)
+        if not stale and hit[0] != sig:
+            bumps = tuple(hip_bumps(t) for t in watched)
+            moved = [v - v0 for v, v0 in zip(sig, hit[0])]
+            stale = every <= 1 or any(d != b - b0 or d < 0 or d >= every for d, b, b0 in zip(moved, bumps, hit[2]))
+        if stale:
+            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
                 if hit is not None:
                     return hit[1]                  # (a sync cannot be captured: the last measurement stands)
                 raise RuntimeError("TableSet.absmax: measure the tables (one eager call) before capturing a graph")
             m = float(torch.stack([t.abs().max() for t in self.tables if t.numel()] or [torch.zeros((), device=self.device)]).max())
-            hit = self._absmax = (sig, m, tot)
+            hit = self._absmax = (sig, m, tuple(hip_bumps(t) for t in watched), _CACHE_GEN[0])
         return hit[1]
 
     def range_ok(self, every=32):
@@ -190,14 +197,38 @@ def f16_range_ok(absmax):
     return absmax == 0.0 or (F16_SMALL_GUARD <= absmax < F16_RANGE_GUARD)
 
 
+_CACHE_GEN = [0]                 # bumped by invalidate_caches(): every magnitude measurement taken before it is stale
+_HIP_BUMPS = None                # version-counter owner (a view's base) -> how many of its version bumps mark_written made
+
+
+def _vc_owner(t):
+    return t._base if t._base is not None else t
+
+
+def hip_bumps(t):
+    """How many of tensor t's version bumps came from mark_written (a fused updater's step), not from torch ops: the magnitude caches
+    (TableSet.absmax / weight_absmax with every > 1) tolerate only those."""
+    return 0 if _HIP_BUMPS is None else _HIP_BUMPS.get(_vc_owner(t), 0)
+
+
 def mark_written(*tensors):
     """A raw-pointer kernel has just written these tensors in place: bump their autograd version counters, as an in-place torch op would
     have.  Everything cached per weight version (DeepFM's packed serving rows, tower_image / dense_bf3_image, dense._packed_cached,
     dense._bn_affine, DCN's cross image) keys on tensor._version, so an eval -> train -> eval loop in one process (the reference's
     train_and_evaluate) rebuilds them after a HIP optimiser step.  Views share their base's counter."""
+    global _HIP_BUMPS
     ts = [t for t in tensors if isinstance(t, torch.Tensor)]
     if ts:
         torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+        if _HIP_BUMPS is None:
+            from torch.utils.weak import WeakIdKeyDictionary
+            _HIP_BUMPS = WeakIdKeyDictionary()
+        seen = set()
+        for t in ts:
+            o = _vc_owner(t)
+            if id(o) not in seen:
+                seen.add(id(o))
+                _HIP_BUMPS[o] = _HIP_BUMPS.get(o, 0) + 1
 
 class CapturedStep:
     """A training (or inference) step captured in a HIP graph, replayed with the bookkeeping eager steps do on the host.
@@ -310,6 +341,14 @@ def slot_max_norms(ts, max_norm):
     return cache[key], 0.0
 
 
+def _leave_hint(t, name, *bits):
+    """Attach the maxima a kernel left beside tensor t as t.<name> = (*bits, t._version): valid while t is unmodified.  Tensors created under
+    torch.inference_mode() track no version counter (reading ._version raises), so nothing could tell a later in-place write: no hint is
+    left on them and their consumers run their own max pass (DCN / ESMM / xDeepFM inference under inference_mode raised)."""
+    if not t.is_inference():
+        setattr(t, name, (*bits, t._version))
+
+
 def _bits_ws(device):
     """The ticket / block-maxima workspace of the kernels that leave a tensor maximum (row_absmax_bits, the bits gathers): one per
     (device, stream) -- calls on one stream are ordered."""
@@ -363,7 +402,7 @@ def embedding_bag(tables, ids, offsets=None, weights=None, combiner="mean", fiel
         rb, ab = buf[:B], buf[B:B + 1]
         _lib.check(lib.dir_gather_fm_rows_bits_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), F, K, ts.ld, _ptr(ids), sb, sf, flags, B, _ptr(out),
                                                    out.stride(0), None, None, _ptr(rb), _ptr(ab), _ptr(_bits_ws(ts.device)), _stream()))
-        out._dir_bits = (rb, ab, out._version)
+        _leave_hint(out, '_dir_bits', rb, ab)
         return out
     _lib.check(lib.dir_embedding_bag_ex2_f32(_ptr(ts.ptrs), _ptr(ts.vocab_dev), F, K, _ptr(ids), _ptr(offsets), _ptr(weights), sb, sf,
                                              _ptr(slot_comb), comb, _ptr(slot_mn), mn, flags, B, _ptr(out), out.stride(0), _stream()))
@@ -422,7 +461,7 @@ def gather_fm(tables, ids, want_emb=True, out=None, fm=None, fsum=None, want_bit
             _lib.check(lib.dir_gather_fm_rows_bits_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, ts.ld, _ptr(ids), sb, sf,
                                                        ts.gather_flags(), B, _ptr(out), out.stride(0), _ptr(fm), _ptr(fsum), _ptr(rb), _ptr(ab),
                                                        _ptr(ws), _stream()))
-            out._dir_bits = (rb, ab, out._version)
+            _leave_hint(out, '_dir_bits', rb, ab)
             return out, fm
         _lib.check(_lib.load().dir_gather_fm_rows_f32(_ptr(ts._ptrs), _ptr(ts.vocab_dev), ts.F, ts.K, ts.ld, _ptr(ids), sb, sf,
                                                       ts.gather_flags(), B, _ptr(out) if want_emb else None,
@@ -839,6 +878,7 @@ def invalidate_caches():
     _DENSE_IMAGES.clear()
     _TOWER_IMAGES.clear()
     _WEIGHT_ABSMAX.clear()
+    _CACHE_GEN[0] += 1             # TableSet.absmax / ShardedTables.absmax measurements taken before this call are stale
 
 
 def dense_bf16x3_covers(x, weight, out=None, gate=None):
@@ -1021,7 +1061,7 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
                                                         _ptr(post_scale), _ptr(post_shift), None, 0, M, Kd, N, _ptr(out), out.stride(0),
                                                         _ptr(row_bits), _ptr(yb[0]), _ptr(yb[1]), _stream()))
         if fresh and yb[0] is not None:
-            out._dir_bits = (yb[0], yb[1], out._version)
+            _leave_hint(out, '_dir_bits', yb[0], yb[1])
         return out
     if use_bf3:
         _lib.check(_lib.load().dir_dense_bf16x3_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight)), _ptr(bias), 1 if relu else 0,
@@ -1158,8 +1198,11 @@ def weight_absmax(weight, every=1):
     key = weight.data_ptr()
     sig = (weight._version, tuple(weight.shape))
     hit = _WEIGHT_ABSMAX.get(key)
-    if hit is not None and hit[0]() is weight and (hit[1] == sig or (every > 1 and hit[1][1] == sig[1] and 0 <= sig[0] - hit[1][0] < every)):
-        return hit[2]
+    if hit is not None and hit[0]() is weight and hit[1][1] == sig[1]:
+        moved = sig[0] - hit[1][0]
+        # `every` covers only the bumps fused updaters made (mark_written's ledger); any other write re-measures
+        if moved == 0 or (every > 1 and 0 < moved < every and hip_bumps(weight) - hit[3] == moved):
+            return hit[2]
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
         if hit is not None and hit[0]() is weight:
             return hit[2]                          # the magnitude as last measured (a sync cannot be captured): one eager call measures it
@@ -1171,7 +1214,7 @@ def weight_absmax(weight, every=1):
         m = 0.0
     if len(_WEIGHT_ABSMAX) > 512:
         _WEIGHT_ABSMAX.clear()
-    _WEIGHT_ABSMAX[key] = (weakref.ref(weight), sig, m)
+    _WEIGHT_ABSMAX[key] = (weakref.ref(weight), sig, m, hip_bumps(weight))
     return m
 
 
@@ -1836,7 +1879,7 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
             if arith == "f16x2" and ob is not None:
                 _lib.check(lib.dir_cin_layer1_bits_f16x2_f32(_ptr(x0), _ptr(W), m, H, D, B, _ptr(xout), _ptr(pooled), pooled.stride(0), wp, nbytes,
                                                              _ptr(ob), _stream()))
-                xout._dir_row_bits = (ob, xout._version)
+                _leave_hint(xout, '_dir_row_bits', ob)
                 return xout, pooled
             _lib.check(f_l1(_ptr(x0), _ptr(W), m, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled), pooled.stride(0), wp, nbytes, _stream()))
             return xout, pooled
@@ -1852,7 +1895,7 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
                 _lib.check(lib.dir_cin_layer_rows_f16x2_f32(_ptr(x0), _ptr(xk), _ptr(W), m, Hp, H, D, B, _ptr(xout) if want_xout else None, _ptr(pooled),
                                                             pooled.stride(0), _ptr(ws), nbytes, None, _ptr(ob), _stream()))
             if ob is not None:
-                xout._dir_row_bits = (ob, xout._version)
+                _leave_hint(xout, '_dir_row_bits', ob)
             return xout, pooled
         if arith == "f16x2_grad":          # (g_bits_out, a list: the bit pattern of max |xk| -- a by-product of the row maxima -- is appended)
             gbits = torch.empty(1, dtype=torch.int32, device=x0.device) if (g_bits_out is not None and B > 0) else None

@@ -311,6 +311,8 @@ class ShardedTables:
         self._inflight = {}
         self._streams = None
         self.stats = {"lookups": 0, "fallbacks": 0, "cap": None}
+        self._updates = 0             # owner-side optimiser steps applied so far (the same on every rank: absmax()'s collective decision)
+        self._absmax_all = None
 
     @classmethod
     def from_full(cls, full_tables, group=None, **kw):
@@ -421,6 +423,7 @@ class ShardedTables:
 
     def _backward_apply(self, saved, g_emb):
         K = self.K
+        self._updates += 1
         if saved[0] == "fixed":
             plan = saved[1]
             P, cap = self.P, plan.cap
@@ -761,22 +764,25 @@ class ShardedTables:
         return dict(zip(self.STAGES, med)), out, fm
 
     def absmax(self, every=32):
-        """The largest |value| over ALL ranks' slices of the tables: the local TableSet.absmax(every) (one pass + one sync per `every`
-        optimiser steps at most), then -- only when that local figure was re-measured -- a MAX all-reduce; every rank's tables move in
-        the same steps, so the ranks reach the collective together (SPMD).  Inference between steps reuses the cached figure."""
+        """The largest |value| over ALL ranks' slices of the tables: the local TableSet.absmax(), then a MAX all-reduce.  WHETHER the
+        collective runs is decided from rank-invariant state only -- no cached figure yet, `every` owner-side updates since the last one
+        (_backward_apply counts them: every rank applies every step, SPMD), or an ops.invalidate_caches() -- never from a rank-local
+        float (the ranks used to compare their re-measured local maxima with the cached ones; sparse updates that left one
+        rank's largest row untouched sent that rank past the all-reduce while its peers entered it).  Tables written by any other route
+        (a checkpoint loaded into the shards): call ops.invalidate_caches() on every rank."""
+        hit = self._absmax_all
+        gen = ops._CACHE_GEN[0]
+        if hit is not None and hit[0] == gen and (self._updates == hit[1] or (every > 1 and 0 < self._updates - hit[1] < every)):
+            return hit[2]
         ts = getattr(self.backend, "ts", None)
-        loc = float(ts.absmax(every)) if ts is not None else 0.0
-        hit = getattr(self, "_absmax_all", None)
-        if hit is not None and hit[0] == loc:
-            return hit[1]
-        val = loc
+        val = float(ts.absmax()) if ts is not None else 0.0
         if self._collective():
-            t = torch.tensor([loc], dtype=torch.float32, device=self.device)
+            t = torch.tensor([val], dtype=torch.float32, device=self.device)
             if self._host_staged(t):
                 t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             val = float(t[0])
-        self._absmax_all = (loc, val)
+        self._absmax_all = (gen, self._updates, val)
         return val
 
     def lookup_consume(self, ids, consumer):
@@ -935,12 +941,12 @@ class ShardedDeepFMTrainer:
                 if lg is None:                                      # not covered (or too few rows): the finish pass's job, here
                     state["fused"] = False
                     emb, fm = ops.gather_fm(rows_as_tables(rows, m.F), inv)
-                    lg = m.dnn_logit_fn(emb, adds=(fm,))
+                    lg = m.dnn_logit_fn(emb, adds=(fm,), range_ok=ops.f16_range_ok(amax))
                 out[s:e] = lg
             if m.units == 1 and self.tables.check == "eager":
                 self.tables.lookup_consume(ids, consumer)
                 return out
             emb, fm = self.tables.lookup(ids, want_fm=True)
-            return m.dnn_logit_fn(emb, adds=(fm,))
+            return m.dnn_logit_fn(emb, adds=(fm,), range_ok=ops.f16_range_ok(amax))      # the SHARDED tables' magnitude, not the model's own
         finally:
             m.train(was_training)

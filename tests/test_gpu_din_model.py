@@ -282,3 +282,34 @@ def test_act_rows_layers_train_on_hip(built_lib, activation):
     if activation == "dice":
         assert float((mod.moving_mean.double() - ref.moving_mean).abs().max()) <= 1e-6
         assert float((mod.moving_variance.double() - ref.moving_variance).abs().max()) <= 1e-6
+
+
+def test_dice_rows_eval_mode_gradient(built_lib):
+    """Dice with MOVING statistics (module.eval(), grad enabled -- frozen-statistics fine-tuning): the normalised pre-activation
+    scale * s + shift still depends on s, so dL/ds = d1 + gx * scale.  Against float64 autograd of din.Dice in eval mode."""
+    from dir_amd import autograd as ag
+    from dir_amd.din import Dice
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    M, N = 2053, 80
+    mod = Dice(N).to(dev)
+    with torch.no_grad():
+        mod.alpha.uniform_(-0.2, 0.5)
+        mod.moving_mean.normal_(0.2, 0.5)
+        mod.moving_variance.uniform_(0.3, 2.5)
+    mod.eval()
+    ref = Dice(N).to(dev).double()
+    ref.load_state_dict({k: v.double() for k, v in mod.state_dict().items()})
+    ref.eval()
+    s = (torch.randn((M, N), device=dev) * 1.5 + 0.3).requires_grad_(True)
+    sd = s.detach().double().requires_grad_(True)
+    gy = torch.randn((M, N), device=dev)
+    mm, mv = mod.moving_mean.clone(), mod.moving_variance.clone()
+    y = ag.act_rows(s, mod)
+    y.backward(gy)
+    yr = ref(sd)
+    yr.backward(gy.double())
+    for a, b, what in ((y, yr, "y"), (s.grad, sd.grad, "dL/ds"), (mod.alpha.grad, ref.alpha.grad, "dL/dalpha")):
+        err = float(((a.double() - b).abs() / (1 + b.abs())).max())
+        assert err <= 5e-5, "%s: %.2e" % (what, err)
+    assert torch.equal(mm, mod.moving_mean) and torch.equal(mv, mod.moving_variance)      # eval mode: the statistics do not move

@@ -242,3 +242,30 @@ def test_cin_rows_of_very_different_magnitudes_and_zero_operands(built_lib):
         assert not bool(y.any()) and not bool(p.any())
         y2, p2_ = ops.cin_layer(x0, y, W2)                  # a zero xk with its (zero) row maxima: the verdict takes the row-scaled kernel
         assert not bool(y2.any()) and not bool(p2_.any())
+
+
+def test_cin_verdict_sees_tiny_rows_inside_an_in_window_tensor(built_lib):
+    """a batch whose LARGEST value sits inside the plain kernel's window [2^-4, 2^15) while some samples are 2^-14 .. 2^-9 of it.  The
+    device-side verdict used to look at the tensor maximum only and ran the unscaled kernel, leaving those rows an absolute 2^-25 per
+    element; it now also needs the smallest non-zero row maximum >= 2^-8 and otherwise names the row-scaled kernel -- held to the PER-SAMPLE
+    bar of the test above."""
+    from dir_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(33)
+    B, m, D, H = 12288, 26, 16, 128
+    x0 = torch.randn((B, m, D), generator=g, device=dev) * 0.5
+    W1 = torch.randn((H, m * m), generator=g, device=dev) / m
+    W2 = torch.randn((H, H * m), generator=g, device=dev) / (H * m) ** 0.5
+    sc = torch.ones((B, 1, 1), device=dev)
+    sc[::7] = torch.pow(2.0, torch.randint(-7, -4, (len(sc[::7]), 1, 1), generator=g, device=dev).float())     # x1 rows scale with sc^2: 2^-14 .. 2^-10
+    x0s = x0 * sc
+    x1, _ = ops.cin_layer(x0s, x0s, W1)
+    amax = float(x1.abs().max())
+    assert 2.0 ** -4 <= amax < 2.0 ** 15                   # the tensor is inside the window: only the row floor can name the row-scaled kernel
+    x2, p2 = ops.cin_layer(x0s, x1, W2)
+    r2 = _cin_ref(x0s, x1, W2)
+    rms = r2.pow(2).mean(dim=(1, 2), keepdim=True).sqrt()
+    worst = float(((x2.double() - r2).abs() / (r2.abs() + rms)).max())
+    assert worst <= 1e-5, worst
+    prms = r2.sum(-1).pow(2).mean(dim=1, keepdim=True).sqrt()
+    assert float(((p2.double() - r2.sum(-1)).abs() / (r2.sum(-1).abs() + prms)).max()) <= 1e-5

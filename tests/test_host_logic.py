@@ -561,8 +561,25 @@ def test_round5_routing_rules():
     import torch
     w = torch.nn.Parameter(torch.full((4, 4), 3.0))
     assert ops.weight_absmax(w) == 3.0
+    w.data.mul_(2.0)                                               # what a fused updater does: a raw write ...
+    ops.mark_written(w)                                            # ... + the version bump it reports (the ledger counts it)
+    assert ops.weight_absmax(w, every=32) == 3.0                   # training policy: a measurement may be up to `every` OPTIMISER steps old
+    assert ops.weight_absmax(w) == 6.0                             # inference policy: every change is seen
     with torch.no_grad():
-        w.mul_(2.0 ** 16)                                          # one in-place update: version + 1
-    assert ops.weight_absmax(w, every=32) == 3.0                   # training policy: a measurement may be up to `every` updates old
-    assert ops.weight_absmax(w) == 3.0 * 2.0 ** 16                  # inference policy: every change is seen
+        w.mul_(2.0 ** 15)                                          # any OTHER write (load_state_dict, copy_, a torch op): re-measured at once
+    assert ops.weight_absmax(w, every=32) == 6.0 * 2.0 ** 15
+    # TableSet.absmax: the same policy over the tables and their owners; invalidate_caches() drops the measurement
+    t = torch.full((8, 4), 0.5)
+    ts = ops.TableSet.__new__(ops.TableSet)
+    ts.tables, ts.owners, ts.device = [t], [], t.device
+    assert ts.absmax(every=32) == 0.5
+    t.data.mul_(4.0)
+    ops.mark_written(t)
+    assert ts.absmax(every=32) == 0.5 and ts.absmax(every=1) == 2.0
+    t.mul_(2.0)                                                    # not a fused updater's step
+    assert ts.absmax(every=32) == 4.0
+    t.data.mul_(2.0)                                               # a write nothing reports: invalidate_caches() is the caller's duty
+    assert ts.absmax(every=32) == 4.0
+    ops.invalidate_caches()
+    assert ts.absmax(every=32) == 8.0
     assert ops.din_arith(w, (), arith="bf16x3") == ops.DIN_ARITHS["bf16x3"]

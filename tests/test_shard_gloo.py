@@ -183,6 +183,53 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
                     local[f].copy_(torch.from_numpy(w.astype(np.float32)))
 
         kw = {k: opts[k] for k in ("partitions", "chunks", "slack", "mode", "check", "dedup") if k in opts}
+        if opts.get("absmax"):
+            # ShardedTables.absmax must decide its MAX all-reduce from rank-invariant state.  Sparse updates move the
+            # largest |value| of ONE rank's shard only; the ranks must still enter (or skip) the collective together, and the lookup's
+            # all_to_all that follows must pair up.
+            class _TS:
+                def absmax(self, every=1):
+                    return max([float(t.abs().max()) for t in local if t.numel()] or [0.0])
+            be = OracleBackend()
+            be.ts = _TS()
+            st = ShardedTables(local, vocab, backend=be, **kw).enable_training(lr=0.05, initial_accumulator_value=0.1)
+            calls = [0]
+            real = dist.all_reduce
+
+            def absmax(**k):                                   # st.absmax with its all-reduces counted
+                def counted(*a, **kk):
+                    calls[0] += 1
+                    return real(*a, **kk)
+                dist.all_reduce = counted
+                try:
+                    return st.absmax(**k)
+                finally:
+                    dist.all_reduce = real
+            tid = torch.from_numpy(ids)
+
+            def gmax():
+                m = [None] * world
+                dist.all_gather_object(m, be.ts.absmax())
+                return float(np.float32(max(m)))
+            ok = absmax() == gmax() and calls[0] == 1
+            ok = ok and absmax() == gmax() and calls[0] == 1          # nothing moved: cached, no collective
+            want_calls, held = 1, gmax()
+            for step in range(1, 41):
+                if rank == 1:                                  # only rank 1's largest value moves (what a sparse owner-side update does)
+                    local[0][0, 0] = 100.0 + step
+                emb = st.lookup_train(tid)
+                emb.sum().backward()
+                if step == 32:
+                    want_calls, held = want_calls + 1, gmax()
+                got = absmax(every=32)
+                ok = ok and calls[0] == want_calls and got == held      # the same decision and the same figure on EVERY rank
+                st.lookup(tid)                                  # the exchange that follows must pair up on every rank
+            ok = ok and held > 100.0
+            from dir_amd import ops as _ops
+            _ops.invalidate_caches()                           # a checkpoint load: every rank re-measures together
+            ok = ok and absmax(every=32) == gmax() and calls[0] == want_calls + 1
+            out_q.put((rank, bool(ok), calls[0], 0))
+            return
         if train:
             st = ShardedTables(local, vocab, backend=OracleBackend(), **kw).enable_training(lr=0.05, initial_accumulator_value=0.1)
             gout = rng_b.standard_normal((B, F * K)).astype(np.float32)
@@ -338,6 +385,13 @@ def test_sharded_training_step_matches_full_table_adagrad(world, vocab, opts):
     """lookup_train + backward over gloo: every rank's row gradients reach the owners (the forward exchange reversed) and
     the owners' shards end up equal to one synchronous Adagrad step on the full tables over all ranks' batches."""
     _run(world, vocab, 8, (opts or {}).get("B", 29), 777, train=True, opts=opts)
+
+
+def test_sharded_absmax_collective_is_rank_invariant():
+    """Two ranks: predict-style absmax(), 40 owner-side updates that move only rank 1's largest value, absmax(every=32) after each: both
+    ranks issue the SAME number of MAX all-reduces (one at start, one at update 32, one after invalidate_caches) and read the same value."""
+    res = _run(2, [10, 7, 33], 8, 16, 99, opts={"absmax": True})
+    assert len({r[2] for r in res}) == 1 and res[0][2] == 3
 
 
 def test_partitioner_slice_count_rule():
