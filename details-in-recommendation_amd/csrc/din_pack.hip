@@ -1,0 +1,756 @@
+// din_pack.hip -- DIN local activation unit + pooling, forward, fp16 x 2 arithmetic, for the (K = 64, H1 <= 80, H2 <= 48) shape class of
+// BASELINE.json configs[3]: the PACKED form of din_wave.hip's kernel (round 6).  NO REFERENCE CODE (README.md:27 links arXiv:1706.06978);
+// the definition is include/dir_hip.h (A13) and oracle/dir_oracle.c.
+//
+// What din_wave_k pays per SAMPLE, and this kernel does not:
+//   * tile padding.  A wave there owns one sample and computes its history in 16-row MFMA tiles: lengths U{1..50} cost 33.3 rows for
+//     25.5.  Here a wave owns a RUN of consecutive samples and lays their valid rows end to end: row q of a block of 16 samples is row
+//     (q & 15) of tile (q >> 4) whatever sample it belongs to, and only the last tile of a block is partly empty (~2 %).
+//   * the per-sample term c = (Wa - Wd)^T a + b1 on the VALU (80 fmas + 20 conflicting LDS reads + 10 shuffles per sample: the
+//     5.6 M LDS bank conflicts of profiles/r05_pmc_din.json).  Here the 16 candidate rows of a block are ONE MFMA operand
+//     (n = sample): 30 matrix instructions per 16 samples from a pre-split image of (Wa - Wd)^T.
+//   * a queue ticket, descriptor loads and four alternative pass bodies per sample.  Samples are dealt to the waves statically, in
+//     contiguous ranges of EQUAL WEIGHT (rows + a per-sample constant), found from per-chunk weight sums a small kernel leaves in the
+//     caller's workspace: no atomics, the same result bit for bit on every run.
+// What stays: everything is computed transposed so that layers chain in registers (lane (kk, r) holds features {16 i + 4 kk + e} of ITS
+// OWN row r straight from HBM -- the history never goes through LDS --, the MFMA result is the next layer's operand), weight images in
+// MFMA A-operand order in LDS, two waves per SIMD, passes of two row tiles, loads a pass (rows) and two passes (ids) ahead.
+// Rows of different samples in one tile need their own sample's candidate row (for h * a) and term c (the accumulators' start): both sit
+// in a per-wave LDS slot per block and are read with per-lane addresses (rows of one tile belong to 1-3 samples: broadcasts; the slot
+// strides 72 / 84 floats keep neighbouring samples on different banks).  The masked softmax and the pooling run per SEGMENT (the rows of
+// one sample inside a pass; wave-uniform loop, 2.25 segments per pass at the BASELINE length mix) with the online form across passes.
+// THIS FILE IS COMPILED WITHOUT PACKED fp32 VALU INSTRUCTIONS (build.py; the hazard is described in din_wave.hip).
+#include <cstring>
+
+#include "common.hpp"
+
+namespace dir {
+namespace {
+
+typedef float dp_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 dp_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int dp_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DP_K = 64, DP_H1P = 80, DP_H2P = 48;
+constexpr int DP_WAVES = 8;            // waves per workgroup (two per SIMD), one workgroup per CU
+constexpr int DP_BLK = 16;             // samples per block (the n of the per-sample term's MFMA)
+constexpr int DP_AVS = 72, DP_CVS = 84;      // floats between samples in the candidate-row / per-sample-term slots
+constexpr int DP_ACT_S1 = 96, DP_ACT_S2 = 48;
+constexpr int DP_ACT_FLOATS = 3 * DP_ACT_S1 + 3 * DP_ACT_S2;
+constexpr float DP_NLOG2E = -1.4426950408889634f;
+constexpr int DP_SUB = 1024;           // samples one wave scans per step of the range search (16 per lane)
+
+struct DpSh {
+    unsigned int whd3[2 * 5 * 2 * 256];     // (Wh + Wd)^T: [k-step][m tile][piece][lane][4 dwords]
+    unsigned int wp3[2 * 5 * 2 * 256];      // Wp^T
+    unsigned int wc3[2 * 5 * 2 * 256];      // (Wa - Wd)^T
+    unsigned int w23[3 * 3 * 2 * 256];      // W2^T; hidden 80..95 of the third k-step are zero
+    float b1[DP_H1P], b2[DP_H2P], w3[DP_H2P];
+    float av[DP_WAVES][DP_BLK * DP_AVS];    // per wave: the candidate rows of the block being computed
+    float cv[DP_WAVES][DP_BLK * DP_CVS];    // per wave: their terms c (+ b1); before the sample loop: scratch of the range search
+};
+static_assert(sizeof(DpSh) + sizeof(float) * DP_ACT_FLOATS <= 160 * 1024, "LDS");
+
+__device__ __forceinline__ float4 dp_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float dp_sigmoid_pre(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
+// ACT 0 = sigmoid (the weight images carry -log2 e: the MFMA result IS the exponent), 1 = PReLU, 2 = Dice (din_wave.hip: dw_act)
+template <int ACT>
+__device__ __forceinline__ float dp_act(float pre, float alpha, float nscale, float nshift) {
+    if constexpr (ACT == 0) return dp_sigmoid_pre(pre);
+    else if constexpr (ACT == 1) return pre > 0.f ? pre : alpha * pre;
+    else {
+        const float pgate = dp_sigmoid_pre(fmaf(pre, nscale, nshift));
+        return pre * fmaf(pgate, 1.0f - alpha, alpha);
+    }
+}
+template <int ACT>
+__device__ __forceinline__ void dp_act_params(const float* rows, int stride, int h, float (&al)[4], float (&ns)[4], float (&nt)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) al[g] = ns[g] = nt[g] = 0.f;
+    if constexpr (ACT != 0) {
+        const float4 a = dp_ld4(rows + h);
+        al[0] = a.x; al[1] = a.y; al[2] = a.z; al[3] = a.w;
+    }
+    if constexpr (ACT == 2) {
+        const float4 b = dp_ld4(rows + stride + h), c = dp_ld4(rows + 2 * stride + h);
+        ns[0] = b.x; ns[1] = b.y; ns[2] = b.z; ns[3] = b.w;
+        nt[0] = c.x; nt[1] = c.y; nt[2] = c.z; nt[3] = c.w;
+    }
+}
+
+// fp16 x 2 (cin_bf3.hip explains the arithmetic): an fp32 operand is the sum of two fp16 pieces by round-to-nearest, the three products
+// of weight >= 2^-11 accumulate in fp32 on v_mfma_f32_16x16x32_f16
+__device__ __forceinline__ unsigned int dp_pk_h(float a, float b) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)a, (_Float16)b};
+    unsigned int w = __builtin_bit_cast(unsigned int, v);
+    asm("" : "+v"(w));      // keeps the compiler from folding the split away (dense_bf3.hip: db3_pk)
+    return w;
+}
+__device__ __forceinline__ void dp_split2(float a, float b, unsigned int& hi, unsigned int& lo) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    hi = dp_pk_h(a, b);
+    const h2_t h = __builtin_bit_cast(h2_t, hi);
+    lo = dp_pk_h(a - (float)h[0], b - (float)h[1]);
+}
+__device__ __forceinline__ void dp_split8(const float4 s0, const float4 s1, dp_f16x8 (&x)[2]) {
+    unsigned int w[2][4];
+    dp_split2(s0.x, s0.y, w[0][0], w[1][0]);
+    dp_split2(s0.z, s0.w, w[0][1], w[1][1]);
+    dp_split2(s1.x, s1.y, w[0][2], w[1][2]);
+    dp_split2(s1.z, s1.w, w[0][3], w[1][3]);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) x[pc] = __builtin_bit_cast(dp_f16x8, (dp_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
+}
+__device__ __forceinline__ dp_f32x4 dp_mma(const dp_f16x8 (&a)[2], const dp_f16x8 (&x)[2], dp_f32x4 c) {      // three products, smallest first
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], x[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], x[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], x[0], c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ void dp_lda(const unsigned int* img, int tile, int lane4, dp_f16x8 (&a)[2]) {
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) a[pc] = __builtin_bit_cast(dp_f16x8, *reinterpret_cast<const dp_u32x4*>(img + (tile * 2 + pc) * 256 + lane4));
+}
+
+__device__ __forceinline__ int dp_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ int dp_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long dp_uni64(long long v) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)v);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+// inclusive prefix sum over the 16 lanes of a DPP row (row_shr:n, out-of-row sources read 0)
+__device__ __forceinline__ int dp_row_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    return v;
+}
+
+// rows of two tiles: this lane's 16 features {16 i + 4 kk + e} of its own rows; no row (id < 0): zeros
+__device__ __forceinline__ void dp_load_rows(const float* __restrict__ table, const int kk, const long long id0, const long long id1,
+                                             float4 (&hv)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hv[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hv[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (id0 >= 0) hv[0][i] = dp_ld4(table + id0 * DP_K + 16 * i + 4 * kk);
+        if (id1 >= 0) hv[1][i] = dp_ld4(table + id1 * DP_K + 16 * i + 4 * kk);
+    }
+}
+
+// One pass of a block: which rows it holds, and what the loads ahead of it fetched.
+struct DpDesc {
+    int valid;              // wave-uniform: 0 beyond the wave's last pass
+    int first;              // the first pass of its block
+    int ns;                 // samples in the block
+    int rowbase;            // block-relative index of the pass's first row
+    int nrows;              // rows of the block inside the pass (0 .. 32; 0 only for a block of empty samples)
+    long long sb;           // the block's first sample
+    int sj[2];              // per lane and tile: (sample in block << 16) | history position; -1: no row
+    long long id[2];        // per lane and tile: the row's history id (-1: no row, or a masked position)
+    long long cid;          // per lane (first pass of a block): candidate id of sample sb + (lane & 15), -1: none
+};
+
+// The three layers for the NT row tiles of a pass -> the rows' scores sc (b3 included), identical in the four lane groups of a row.
+template <int NT, int ACT>
+__device__ __forceinline__ void dp_mlp(const DpSh& sh, const float* actl, const float* avs, const float* cvs, const int r16, const int kk,
+                                       const int (&so)[2], const float4 (&hv)[2][4], const float b3, float (&sc)[NT]) {
+    const int lane4 = 4 * (16 * kk + r16);          // dword offset of this lane's 16 bytes inside a 1 KB operand tile
+    // ---- layer 1: pre1^T = (Wh+Wd)^T h^T + Wp^T (h*a)^T + c 1^T, the accumulators start at the row's own sample's c ---------------------
+    dp_f32x4 acc1[5][NT];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            const float4 c4 = dp_ld4(cvs + so[rt] * DP_CVS + 16 * mt + 4 * kk);
+            acc1[mt][rt] = (dp_f32x4){c4.x, c4.y, c4.z, c4.w};
+        }
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            dp_f16x8 xb[NT][2];
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) {
+                float4 s0 = hv[rt][2 * ks], s1 = hv[rt][2 * ks + 1];
+                if (part) {
+                    const float4 a0 = dp_ld4(avs + so[rt] * DP_AVS + 16 * (2 * ks) + 4 * kk);
+                    const float4 a1 = dp_ld4(avs + so[rt] * DP_AVS + 16 * (2 * ks + 1) + 4 * kk);
+                    s0 = make_float4(s0.x * a0.x, s0.y * a0.y, s0.z * a0.z, s0.w * a0.w);
+                    s1 = make_float4(s1.x * a1.x, s1.y * a1.y, s1.z * a1.z, s1.w * a1.w);
+                }
+                dp_split8(s0, s1, xb[rt]);
+            }
+            const unsigned int* img = part ? sh.wp3 : sh.whd3;
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                dp_f16x8 a[2];
+                dp_lda(img, ks * 5 + mt, lane4, a);
+#pragma unroll
+                for (int rt = 0; rt < NT; ++rt) acc1[mt][rt] = dp_mma(a, xb[rt], acc1[mt][rt]);
+            }
+        }
+    }
+    // z1 = act(pre1) in place: hidden 16 mt + 4 kk + g of row r -- element (mt & 1) * 4 + g of layer 2's k-step mt >> 1
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+        float al[4], ns[4], nt[4];
+        dp_act_params<ACT>(actl, DP_ACT_S1, 16 * mt + 4 * kk, al, ns, nt);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc1[mt][rt][g] = dp_act<ACT>(acc1[mt][rt][g], al[g], ns[g], nt[g]);
+    }
+    // ---- layer 2: pre2^T, three k-steps (hidden 80..95 are zeros on both sides) -------------------------------------------------------------
+    dp_f32x4 acc2[3][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 3; ++m2) {
+        const float4 c4 = dp_ld4(&sh.b2[16 * m2 + 4 * kk]);
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = (dp_f32x4){c4.x, c4.y, c4.z, c4.w};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        dp_f16x8 xb[NT][2];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) {
+            const dp_f32x4 z0 = acc1[2 * ks][rt];
+            const dp_f32x4 z1 = 2 * ks + 1 < 5 ? acc1[2 * ks + 1 < 5 ? 2 * ks + 1 : 0][rt] : (dp_f32x4){0.f, 0.f, 0.f, 0.f};
+            dp_split8(make_float4(z0[0], z0[1], z0[2], z0[3]), make_float4(z1[0], z1[1], z1[2], z1[3]), xb[rt]);
+        }
+#pragma unroll
+        for (int m2 = 0; m2 < 3; ++m2) {
+            dp_f16x8 a[2];
+            dp_lda(sh.w23, ks * 3 + m2, lane4, a);
+#pragma unroll
+            for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = dp_mma(a, xb[rt], acc2[m2][rt]);
+        }
+    }
+    // ---- layer 3 -----------------------------------------------------------------------------------------------------------------------------
+    float wv[3][4];
+#pragma unroll
+    for (int m2 = 0; m2 < 3; ++m2) {
+        const float4 t4 = dp_ld4(&sh.w3[16 * m2 + 4 * kk]);
+        wv[m2][0] = t4.x; wv[m2][1] = t4.y; wv[m2][2] = t4.z; wv[m2][3] = t4.w;
+    }
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+        float sp = 0.f;
+#pragma unroll
+        for (int m2 = 0; m2 < 3; ++m2) {
+            float al[4], ns[4], nt[4];
+            dp_act_params<ACT>(actl + 3 * DP_ACT_S1, DP_ACT_S2, 16 * m2 + 4 * kk, al, ns, nt);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sp = fmaf(dp_act<ACT>(acc2[m2][rt][g], al[g], ns[g], nt[g]), wv[m2][g], sp);
+        }
+        sp += __shfl_xor(sp, 16, 64);        // the four lane groups hold the four quarters of the H2 sum of row r
+        sp += __shfl_xor(sp, 32, 64);
+        sc[rt] = sp + b3;
+    }
+}
+
+// per-chunk weight sums: weight of a sample = its valid history positions + w0 (what a sample costs beyond its rows)
+__global__ __launch_bounds__(256) void din_pack_sums_k(const int32_t* __restrict__ hist_len, int T, long long B, long long chunk, int w0,
+                                                       int* __restrict__ csum) {
+    __shared__ int red[4];
+    const long long base = (long long)blockIdx.x * chunk;
+    const long long endb = base + chunk < B ? base + chunk : B;
+    int s = 0;
+    for (long long b = base + threadIdx.x; b < endb; b += 256) {
+        const int len = hist_len ? hist_len[b] : T;
+        s += (len < 0 ? 0 : len > T ? T : len) + w0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) csum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// scores written raw by the main kernel -> attention weights: softmax weights exp(x - m_b) / l_b (normalize), zeros beyond the length
+__global__ __launch_bounds__(256) void din_pack_scores_k(float* __restrict__ scores, const int32_t* __restrict__ hist_len, int T, long long B,
+                                                         int normalize, const float* __restrict__ ml) {
+    const long long n = B * T;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long b = e / T;
+        const int j = (int)(e - b * T);
+        const int len = hist_len ? hist_len[b] : T;
+        float v = 0.f;
+        if (j < len) {
+            const float x = scores[e];
+            v = normalize ? (x > -INFINITY ? __expf(x - ml[2 * b]) * ml[2 * b + 1] : 0.f) : x;
+        }
+        scores[e] = v;
+    }
+}
+
+template <int ACT, bool SCORES>
+__global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
+                                                               const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand, int T,
+                                                               const float* __restrict__ W1, const float* __restrict__ b1, int H1,
+                                                               const float* __restrict__ W2, const float* __restrict__ b2, int H2,
+                                                               const float* __restrict__ W3, const float* __restrict__ b3, int normalize,
+                                                               long long B, float* __restrict__ out, float* __restrict__ scores,
+                                                               float* __restrict__ ml, const int* __restrict__ csum, int nchunk,
+                                                               long long chunk, int w0, const float* __restrict__ act_params) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dp_smem[];
+    DpSh& sh = *reinterpret_cast<DpSh*>(dp_smem);
+    float* const actl = reinterpret_cast<float*>(dp_smem + ((sizeof(DpSh) + 15) & ~(size_t)15));
+    constexpr float SC = ACT == 0 ? DP_NLOG2E : 1.0f;      // what the weight / bias images are multiplied by
+    const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int w = dp_uni(tid >> 6);
+    // ---- the chunk sums -> their exclusive prefix (the range search's first level), in the cv slots ------------------------------------------
+    long long* const cpre = reinterpret_cast<long long*>(&sh.cv[0][0]);      // [nchunk + 1], nchunk <= 1024
+    for (int idx = tid; idx < nchunk; idx += 64 * DP_WAVES) cpre[idx + 1] = csum[idx];
+    if (tid == 0) cpre[0] = 0;
+    if constexpr (ACT != 0) {
+        for (int idx = tid; idx < DP_ACT_FLOATS; idx += 64 * DP_WAVES) {
+            float v = 0.f;
+            if (idx < 3 * DP_ACT_S1) {
+                const int row = idx / DP_ACT_S1, h = idx - row * DP_ACT_S1;
+                if (h < H1) v = act_params[row * H1 + h] * (row == 0 ? 1.0f : DP_NLOG2E);
+            } else {
+                const int j = idx - 3 * DP_ACT_S1, row = j / DP_ACT_S2, h = j - row * DP_ACT_S2;
+                if (h < H2) v = act_params[3 * H1 + row * H2 + h] * (row == 0 ? 1.0f : DP_NLOG2E);
+            }
+            actl[idx] = v;
+        }
+    }
+    // ---- weight images, once per workgroup: dword jp of lane l of tile (ks, mt) holds elements j = 2 jp, 2 jp + 1 = W[m = 16 mt + (l & 15)][k], k + 1,
+    // k = 16 (2 ks + (j >> 2)) + 4 (l >> 4) + (j & 3)
+    for (int idx = tid; idx < 2 * 5 * 64 * 4; idx += 64 * DP_WAVES) {
+        const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+        const int ks = t / 5, mt = t - 5 * ks;
+        const int m = 16 * mt + (l & 15);
+        const int f = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+        float hd[2] = {0.f, 0.f}, pp[2] = {0.f, 0.f}, cc[2] = {0.f, 0.f};
+        if (m < H1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float vh = W1[(size_t)(f + e) * H1 + m], va = W1[(size_t)(DP_K + f + e) * H1 + m];
+                const float vd = W1[(size_t)(2 * DP_K + f + e) * H1 + m], vp = W1[(size_t)(3 * DP_K + f + e) * H1 + m];
+                hd[e] = (vh + vd) * SC;
+                pp[e] = vp * SC;
+                cc[e] = (va - vd) * SC;
+            }
+        }
+        unsigned int hi, lo;
+        dp_split2(hd[0], hd[1], hi, lo);
+        sh.whd3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        sh.whd3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+        dp_split2(pp[0], pp[1], hi, lo);
+        sh.wp3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        sh.wp3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+        dp_split2(cc[0], cc[1], hi, lo);
+        sh.wc3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        sh.wc3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+    }
+    for (int idx = tid; idx < 3 * 3 * 64 * 4; idx += 64 * DP_WAVES) {
+        const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+        const int ks = t / 3, m2 = t - 3 * ks;
+        const int h2 = 16 * m2 + (l & 15);
+        const int hid = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)      // a padded hidden unit is sigmoid(0) = 0.5: its weights are zero
+            v[e] = (hid + e < H1 && h2 < H2) ? W2[(size_t)(hid + e) * H2 + h2] * SC : 0.f;
+        unsigned int hi, lo;
+        dp_split2(v[0], v[1], hi, lo);
+        sh.w23[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        sh.w23[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+    }
+    for (int idx = tid; idx < DP_H1P; idx += 64 * DP_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * SC : 0.f;
+    for (int idx = tid; idx < DP_H2P; idx += 64 * DP_WAVES) {
+        sh.b2[idx] = idx < H2 ? b2[idx] * SC : 0.f;
+        sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
+    }
+    __syncthreads();
+    if (w == 0) {                // inclusive scan of cpre[1 ..] in place: per = entries per lane, then the lane totals
+        const int per = (nchunk + 63) >> 6;
+        long long run = 0;
+        for (int i = 0; i < per; ++i) {
+            const int c = lane * per + i;
+            if (c < nchunk) {
+                run += cpre[c + 1];
+                cpre[c + 1] = run;
+            }
+        }
+        long long off = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long t = __shfl_up(off, o, 64);
+            if (lane >= o) off += t;
+        }
+        off -= run;              // exclusive prefix of the lane totals
+        for (int i = 0; i < per; ++i) {
+            const int c = lane * per + i;
+            if (c < nchunk) cpre[c + 1] += off;
+        }
+    }
+    __syncthreads();
+    // ---- this wave's samples [s_lo, s_hi): wave g of G takes the samples whose exclusive weight prefix P(b) lies in [ceil(g W / G), ceil((g + 1) W / G)) ----
+    auto len_of = [&](const long long b) {
+        const int len = hist_len ? hist_len[b] : T;
+        return len < 0 ? 0 : len > T ? T : len;
+    };
+    auto first_at = [&](const long long t) -> long long {      // min b with P(b) >= t (B when there is none); wave-uniform
+        int lo_c = 0, hi_c = nchunk;                          // the last chunk whose start prefix is < t (chunk 0 when t == 0)
+        while (hi_c - lo_c > 1) {
+            const int mid = (lo_c + hi_c) >> 1;
+            if (cpre[mid] < t) lo_c = mid; else hi_c = mid;
+        }
+        const long long base = (long long)lo_c * chunk, endb = base + chunk < B ? base + chunk : B;
+        const long long tt = t - cpre[lo_c];                   // samples of the chunk with a chunk-relative prefix < tt come before the answer
+        long long carry = 0;
+        int cnt = 0;
+        for (long long sub = base; sub < endb && carry < tt; sub += DP_SUB) {
+            const long long b0 = sub + (long long)lane * 16;
+            int wv_[16];
+            int tot = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                wv_[i] = b0 + i < endb ? len_of(b0 + i) + w0 : 0;
+                tot += wv_[i];
+            }
+            long long off = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const long long u = __shfl_up(off, o, 64);
+                if (lane >= o) off += u;
+            }
+            const long long wave_tot = __shfl(off, 63, 64);
+            long long pre = carry + off - tot;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                cnt += (b0 + i < endb && pre < tt) ? 1 : 0;
+                pre += wv_[i];
+            }
+            carry += wave_tot;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        return dp_uni64(base + cnt);
+    };
+    const long long Wtot = cpre[nchunk];
+    const long long G = (long long)gridDim.x * DP_WAVES, g = (long long)blockIdx.x * DP_WAVES + w;
+    const long long s_lo = first_at((g * Wtot + G - 1) / G);
+    const long long s_hi = g + 1 == G ? B : first_at(((g + 1) * Wtot + G - 1) / G);
+    __syncthreads();             // the cv slots are scratch no longer
+    const float bias3 = b3[0];
+    const float inv_sqrt_k = 1.0f / sqrtf((float)DP_K);
+    float* const avs = sh.av[w];
+    float* const cvs = sh.cv[w];
+    const int lane4 = 4 * (16 * kk + r16);
+
+    // ---- the cursor two passes ahead of the computation: which rows a pass holds, their history ids ------------------------------------------
+    long long a_sb = 0;
+    int a_ns = 0, a_np = 0, a_pass = -1, a_R = 0, a_cur = 0, a_endv = 0;
+    bool a_started = false, a_done = s_lo >= s_hi;
+    auto block_len = [&](const long long sb) {                // lane r's sample of the block at sb (0 beyond the wave's range)
+        const long long b = sb + r16;
+        return b < s_hi ? len_of(b) : 0;
+    };
+    int a_lens_next = a_done ? 0 : block_len(s_lo);
+    auto advance = [&](DpDesc& d) {
+        d.valid = 0;
+        d.first = 0;
+        d.sj[0] = d.sj[1] = -1;
+        d.id[0] = d.id[1] = -1;
+        d.cid = -1;
+        d.ns = 0; d.rowbase = 0; d.nrows = 0; d.sb = 0;
+        if (a_done) return;
+        ++a_pass;
+        if (a_pass >= a_np) {                                  // the next block
+            const long long nb = a_started ? a_sb + DP_BLK : s_lo;
+            a_started = true;
+            if (nb >= s_hi) {
+                a_done = true;
+                return;
+            }
+            a_sb = nb;
+            a_ns = (int)(s_hi - nb < DP_BLK ? s_hi - nb : DP_BLK);
+            a_endv = dp_row_scan(a_lens_next);
+            a_R = dp_readlane(a_endv, 15);
+            a_np = a_R > 0 ? (a_R + 31) >> 5 : 1;
+            a_pass = 0;
+            a_cur = 0;
+            a_lens_next = block_len(nb + DP_BLK);
+            d.first = 1;
+            d.cid = r16 < a_ns ? (long long)cand[nb + r16] : -1;
+        }
+        d.valid = 1;
+        d.sb = a_sb;
+        d.ns = a_ns;
+        d.rowbase = a_pass * 32;
+        d.nrows = a_R - d.rowbase > 32 ? 32 : a_R - d.rowbase;
+        // row q belongs to the first sample whose end (inclusive prefix) is > q: samples before a_cur ended before this pass
+        const int q0 = d.rowbase + r16, q1 = q0 + 16, qlast = d.rowbase + 31;
+        const int base = a_cur ? dp_readlane(a_endv, a_cur - 1) : 0;
+        int s0 = a_cur, s1 = a_cur, p0 = base, p1 = base;
+        int i = a_cur;
+        while (i < a_ns) {
+            const int e = dp_readlane(a_endv, i);
+            if (e > qlast) break;
+            s0 += q0 >= e ? 1 : 0;
+            p0 = q0 >= e ? e : p0;
+            s1 += q1 >= e ? 1 : 0;
+            p1 = q1 >= e ? e : p1;
+            ++i;
+        }
+        a_cur = i;
+        if (q0 < a_R) {
+            d.sj[0] = (s0 << 16) | (q0 - p0);
+            d.id[0] = hist[(a_sb + s0) * T + (q0 - p0)];
+        }
+        if (q1 < a_R) {
+            d.sj[1] = (s1 << 16) | (q1 - p1);
+            d.id[1] = hist[(a_sb + s1) * T + (q1 - p1)];
+        }
+    };
+
+    // ---- state of the computation: the block's sample ends, the first unfinished sample, the open sample's online softmax --------------------
+    int c_endv = 0, c_cur = 0, c_lens = 0, c_R = 0;
+    float m_run = -INFINITY, l_run = 0.f;
+    float4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 hv[2][4], hvn[2][4], an[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) an[i] = hv[0][i] = hv[1][i] = hvn[0][i] = hvn[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto fetch = [&](const DpDesc& d, float4 (&h)[2][4]) {    // a pass's rows; with a block's first pass its lengths and candidate rows
+        if (!d.valid) return;
+        dp_load_rows(table, kk, d.id[0], d.id[1], h);
+        if (d.first) {
+            c_lens = r16 < d.ns ? len_of(d.sb + r16) : 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                an[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d.cid >= 0) an[i] = dp_ld4(table + d.cid * DP_K + 16 * i + 4 * kk);
+            }
+        }
+    };
+    auto finalize = [&](const long long b) {                  // the open sample is complete: pooled output, state reset
+        const float inv_l = normalize ? (l_run > 0.f ? 1.0f / l_run : 0.f) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 t4;
+            t4.x = row16_sum(o[i].x) * inv_l; t4.y = row16_sum(o[i].y) * inv_l;
+            t4.z = row16_sum(o[i].z) * inv_l; t4.w = row16_sum(o[i].w) * inv_l;
+            if (r16 == 0) *reinterpret_cast<float4*>(out + b * DP_K + 16 * i + 4 * kk) = t4;
+            o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (SCORES && normalize && lane == 0) {
+            ml[2 * b] = m_run;
+            ml[2 * b + 1] = inv_l;
+        }
+        m_run = -INFINITY;
+        l_run = 0.f;
+    };
+
+    DpDesc dC, dB, dA;
+    advance(dC);
+    fetch(dC, hv);
+    advance(dB);
+    while (dC.valid) {
+        if (dC.first) {
+            // ---- a new block: its candidate rows -> the av slot; c[m] = sum_f a[f] (Wa - Wd)[f][m] + b1[m] for the 16 samples at once -> the cv slot --
+            c_endv = dp_row_scan(c_lens);
+            c_R = dp_readlane(c_endv, 15);
+            c_cur = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(avs + r16 * DP_AVS + 16 * i + 4 * kk) = an[i];
+            dp_f32x4 accc[5];
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                const float4 c4 = dp_ld4(&sh.b1[16 * mt + 4 * kk]);
+                accc[mt] = (dp_f32x4){c4.x, c4.y, c4.z, c4.w};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                dp_f16x8 xb[2];
+                dp_split8(an[2 * ks], an[2 * ks + 1], xb);
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    dp_f16x8 a[2];
+                    dp_lda(sh.wc3, ks * 5 + mt, lane4, a);
+                    accc[mt] = dp_mma(a, xb, accc[mt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+                *reinterpret_cast<float4*>(cvs + r16 * DP_CVS + 16 * mt + 4 * kk) = make_float4(accc[mt][0], accc[mt][1], accc[mt][2], accc[mt][3]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // same-wave LDS hand-off: the DS queue is in order, the fences
+            __builtin_amdgcn_wave_barrier();                         // only keep the compiler from moving the reads above the writes
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        fetch(dB, hvn);          // the next pass's rows (its ids were issued a pass ago)
+        advance(dA);             // the ids of the pass after it
+        // ---- this pass: the three layers for its rows ---------------------------------------------------------------------------------------
+        const int sA[2] = {dC.sj[0] >> 16, dC.sj[1] >> 16};      // -1: no row
+        const int so[2] = {sA[0] < 0 ? 0 : sA[0], sA[1] < 0 ? 0 : sA[1]};
+        float sc[2] = {0.f, 0.f};
+        if (dC.nrows > 16) {
+            dp_mlp<2, ACT>(sh, actl, avs, cvs, r16, kk, so, hv, bias3, sc);
+        } else if (dC.nrows > 0) {
+            float s1_[1];
+            dp_mlp<1, ACT>(sh, actl, avs, cvs, r16, kk, so, hv, bias3, s1_);
+            sc[0] = s1_[0];
+        }
+        // ---- its segments: masked (online) softmax + pooling per sample; a sample that ends inside the pass is written out ------------------------
+        {
+            const int pend = dC.rowbase + 32;
+            const bool last = pend >= c_R;               // the block's last pass: every sample still open or not begun (an empty one) ends here
+            int i = c_cur;
+            while (i < dC.ns) {
+                const int st = i ? dp_readlane(c_endv, i - 1) : 0;
+                if (st >= pend && !last) break;
+                const int en = dp_readlane(c_endv, i);
+                if (en > st && en > dC.rowbase) {
+                    const bool mem0 = sA[0] == i && dC.id[0] >= 0, mem1 = sA[1] == i && dC.id[1] >= 0;
+                    if (normalize) {
+                        const float x0 = mem0 ? sc[0] * inv_sqrt_k : -INFINITY, x1 = mem1 ? sc[1] * inv_sqrt_k : -INFINITY;
+                        const float mx = fmaxf(m_run, row16_max(fmaxf(x0, x1)));
+                        if (mx > -INFINITY) {            // wave-uniform (row maxima are identical in the four lane groups)
+                            const float rescale = __expf(m_run - mx);      // m_run = -inf: 0
+                            const float p0 = mem0 ? __expf(x0 - mx) : 0.f, p1 = mem1 ? __expf(x1 - mx) : 0.f;
+                            l_run = l_run * rescale + (row16_sum(p0) + row16_sum(p1));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float4 acc = make_float4(o[q].x * rescale, o[q].y * rescale, o[q].z * rescale, o[q].w * rescale);
+                                acc.x = fmaf(p0, hv[0][q].x, acc.x); acc.y = fmaf(p0, hv[0][q].y, acc.y);
+                                acc.z = fmaf(p0, hv[0][q].z, acc.z); acc.w = fmaf(p0, hv[0][q].w, acc.w);
+                                acc.x = fmaf(p1, hv[1][q].x, acc.x); acc.y = fmaf(p1, hv[1][q].y, acc.y);
+                                acc.z = fmaf(p1, hv[1][q].z, acc.z); acc.w = fmaf(p1, hv[1][q].w, acc.w);
+                                o[q] = acc;
+                            }
+                            m_run = mx;
+                        }
+                        if (SCORES && kk == 0) {
+                            const long long row = (dC.sb + i) * T;
+                            if (sA[0] == i) scores[row + (dC.sj[0] & 0xffff)] = x0;
+                            if (sA[1] == i) scores[row + (dC.sj[1] & 0xffff)] = x1;
+                        }
+                    } else {
+                        const float x0 = mem0 ? sc[0] : 0.f, x1 = mem1 ? sc[1] : 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            o[q].x = fmaf(x0, hv[0][q].x, o[q].x); o[q].y = fmaf(x0, hv[0][q].y, o[q].y);
+                            o[q].z = fmaf(x0, hv[0][q].z, o[q].z); o[q].w = fmaf(x0, hv[0][q].w, o[q].w);
+                            o[q].x = fmaf(x1, hv[1][q].x, o[q].x); o[q].y = fmaf(x1, hv[1][q].y, o[q].y);
+                            o[q].z = fmaf(x1, hv[1][q].z, o[q].z); o[q].w = fmaf(x1, hv[1][q].w, o[q].w);
+                        }
+                        if (SCORES && kk == 0) {
+                            const long long row = (dC.sb + i) * T;
+                            if (sA[0] == i) scores[row + (dC.sj[0] & 0xffff)] = x0;
+                            if (sA[1] == i) scores[row + (dC.sj[1] & 0xffff)] = x1;
+                        }
+                    }
+                }
+                if (en > pend) break;                    // the sample goes on in the next pass
+                finalize(dC.sb + i);
+                ++i;
+            }
+            c_cur = i;
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[rt][i] = hvn[rt][i];
+        dC = dB;
+        dB = dA;
+    }
+}
+
+}  // namespace
+
+bool din_pack_covers(int K, int T, int H1, int H2) {
+    return K == DP_K && T >= 1 && T <= 65535 && H1 > 0 && H2 > 0 && H1 <= DP_H1P && H2 <= DP_H2P && !(H1 & 3) && !(H2 & 3);
+}
+
+static void din_pack_chunks(int64_t B, int64_t& chunk, int& nchunk) {
+    chunk = 1024;
+    while ((B + chunk - 1) / chunk > 1024) chunk *= 2;
+    nchunk = (int)((B + chunk - 1) / chunk);
+    if (nchunk < 1) nchunk = 1;
+}
+
+int64_t din_pack_workspace_bytes(int64_t B, int want_scores) {
+    int64_t chunk;
+    int nchunk;
+    din_pack_chunks(B < 1 ? 1 : B, chunk, nchunk);
+    int64_t n = ((int64_t)nchunk * 4 + 255) & ~(int64_t)255;
+    if (want_scores) n += B * 8;
+    return n;
+}
+
+int launch_din_pack(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T, const float* W1,
+                    const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3, const float* b3, int normalize, int64_t B,
+                    float* out, float* scores, int activation, const float* act_params, void* workspace) {
+    int64_t chunk;
+    int nchunk;
+    din_pack_chunks(B, chunk, nchunk);
+    int* csum = static_cast<int*>(workspace);
+    float* ml = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + (((int64_t)nchunk * 4 + 255) & ~(int64_t)255));
+    // the weight of a sample beyond its rows, in rows: what its candidate row, its share of a block's term and its output cost
+    // (DIR_DIN_PACK_W0: an A/B switch read per call like DIR_DIN_ARITH; any value gives the same results up to the summation order across passes)
+    const char* w0e = getenv("DIR_DIN_PACK_W0");
+    const int w0 = w0e ? (atoi(w0e) < 0 ? 0 : atoi(w0e) > 64 ? 64 : atoi(w0e)) : 5;
+    typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,
+                           const float*, int, const float*, const float*, int, long long, float*, float*, float*, const int*, int, long long, int,
+                           const float*);
+    static const kern_t kerns[3][2] = {{&din_pack_k<0, false>, &din_pack_k<0, true>},
+                                       {&din_pack_k<1, false>, &din_pack_k<1, true>},
+                                       {&din_pack_k<2, false>, &din_pack_k<2, true>}};
+    if (activation < 0 || activation > 2 || (activation != 0 && !act_params))
+        return fail(DIR_E_UNSUPPORTED, "din_pack_k: activation %d (0 sigmoid, 1 PReLU, 2 Dice)", activation);
+    static LdsOnce once[3][2];
+    const int sco = scores ? 1 : 0;
+    const size_t shmem = ((sizeof(DpSh) + 15) & ~(size_t)15) + (activation ? sizeof(float) * DP_ACT_FLOATS : 0);
+    const kern_t kern = kerns[activation][sco];
+    if (!lds_limit(once[activation][sco], (int)shmem, kern)) return fail(DIR_E_HIP, "din_pack_k: cannot reserve %zu B of LDS", shmem);
+    hipLaunchKernelGGL(din_pack_sums_k, dim3((unsigned)nchunk), dim3(256), 0, st, hist_len, T, (long long)B, (long long)chunk, w0, csum);
+    const int64_t waves_wanted = (B + 1) / 2;            // a wave should see at least a couple of samples
+    int64_t nwg = (waves_wanted + DP_WAVES - 1) / DP_WAVES;
+    if (nwg > kCUs) nwg = kCUs;
+    if (nwg < 1) nwg = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * DP_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3,
+                       normalize, (long long)B, out, scores, ml, csum, nchunk, (long long)chunk, w0, act_params);
+    if (scores) {
+        const int64_t n = B * T;
+        int64_t nb = (n + 255) / 256;
+        if (nb > kCUs * 8) nb = kCUs * 8;
+        hipLaunchKernelGGL(din_pack_scores_k, dim3((unsigned)nb), dim3(256), 0, st, scores, hist_len, T, (long long)B, normalize, ml);
+    }
+    return DIR_OK;
+}
+
+}  // namespace dir
+
+extern "C" int64_t dir_din_pack_workspace_bytes(int64_t B, int want_scores) { return B < 0 ? 0 : dir::din_pack_workspace_bytes(B, want_scores); }
+
+extern "C" int dir_din_attention_pool_packed_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
+                                                 int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
+                                                 const float* W3, const float* b3, int normalize, int activation, const float* act_params,
+                                                 int64_t B, float* out, float* scores, void* workspace, int64_t workspace_bytes,
+                                                 dir_stream_t stream) {
+    using namespace dir;
+    const char* name = "dir_din_attention_pool_packed_f32";
+    DIR_CHECK_ARG(K > 0 && T > 0 && H1 > 0 && H2 > 0 && B >= 0, "%s: K=%d T=%d H1=%d H2=%d", name, K, T, H1, H2);
+    if (!din_pack_covers(K, T, H1, H2))
+        return fail(DIR_E_UNSUPPORTED, "%s: covers K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 65535 (K=%d T=%d H1=%d H2=%d)", name, K, T, H1, H2);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(table && hist && cand && W1 && b1 && W2 && b2 && W3 && b3 && out && workspace, "%s: null pointer", name);
+    if (!aligned16(table) || !aligned16(workspace) || !aligned16(out))
+        return fail(DIR_E_BADARG, "%s: table / out / workspace must be 16-byte aligned", name);
+    const int64_t need = din_pack_workspace_bytes(B, scores != nullptr);
+    if (workspace_bytes < need) return fail(DIR_E_BADARG, "%s: workspace needs %lld bytes (dir_din_pack_workspace_bytes)", name, (long long)need);
+    const int rc = launch_din_pack(as_stream(stream), table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores,
+                                   activation, act_params, workspace);
+    if (rc != DIR_OK) return rc;
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}

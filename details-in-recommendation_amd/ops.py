@@ -630,6 +630,25 @@ def din_arith(table, weights, arith=None):
     return DIN_ARITHS["f16x2"]
 
 
+# development switch: 0 = the fp16 x 2 forward stays on din_wave_k (one wave per sample) instead of the packed kernel of round 6
+DIN_PACKED = os.environ.get("DIR_DIN_PACKED", "1") != "0"
+_DIN_PACK_WS = {}
+
+
+def din_pack_covers(K, T, H1, H2):
+    """Shapes dir_din_attention_pool_packed_f32 takes (include/dir_hip.h)."""
+    return K == 64 and 1 <= T <= 65535 and 0 < H1 <= 80 and 0 < H2 <= 48 and H1 % 4 == 0 and H2 % 4 == 0
+
+
+def _din_pack_ws(device, nbytes):
+    """The packed DIN kernel's workspace: one per (device, stream), grown on demand -- calls on one stream are ordered, so they may share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _DIN_PACK_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _DIN_PACK_WS[key] = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
+    return ws
+
+
 def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, normalize=False, want_scores=False, activation="sigmoid",
                        act_params=None, arith=None, range_of=None):
     """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T]).  activation "prelu" / "dice": the
@@ -668,6 +687,15 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
         ap = _dev(act_params.contiguous(), torch.float32, "act_params")
     rsrc = range_of if range_of is not None else (table, W1, W2, W3)
     code = din_arith(rsrc[0], rsrc[1:], arith) if B > 0 else -1
+    if code == DIN_ARITHS["f16x2"] and DIN_PACKED and din_pack_covers(K, T, H1, H2):
+        # round 6: the packed kernel (rows of consecutive samples end to end in the MFMA tiles, a static equal-weight partition of the samples)
+        lib = _lib.load()
+        ws = _din_pack_ws(table.device, int(lib.dir_din_pack_workspace_bytes(B, 1 if want_scores else 0)))
+        _lib.check(lib.dir_din_attention_pool_packed_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1,
+                                                         _ptr(args[2]), _ptr(args[3]), H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)),
+                                                         DIN_ACTIVATIONS[activation], _ptr(ap), B, _ptr(out), _ptr(scores), _ptr(ws), ws.numel(),
+                                                         _stream()))
+        return (out, scores) if want_scores else out
     _lib.check(_lib.load().dir_din_attention_pool_arith_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
                                                             _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
                                                             H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)),

@@ -813,6 +813,19 @@ int dir_din_attention_pool_arith_f32(const float* table, int K, const int64_t* h
                                      const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                                      const float* b3, int normalize, int activation, const float* act_params, int arith, int64_t B, float* out,
                                      float* scores, dir_stream_t stream);
+/* The PACKED form of the (K = 64, H1 <= 80, H2 <= 48; any T <= 65 535) unit on fp16 x 2 (round 6; csrc/din_pack.hip): a wave lays the valid
+ * history rows of a run of consecutive samples end to end in 16-row MFMA tiles (no per-sample tile padding: lengths U{1..50} cost 26 rows, not
+ * 33), forms the per-sample term of 16 samples as one MFMA operand, and takes its samples from a STATIC equal-weight partition (no queue
+ * atomics; bit for bit the same result on every run).  Same definition, arguments and outputs as dir_din_attention_pool_arith_f32 with
+ * arith = DIR_DIN_ARITH_F16X2 (operands UNSCALED: the caller vouches for |table|, |W| inside fp16 x 2's window, as there), plus
+ *   workspace: dir_din_pack_workspace_bytes(B, scores != NULL) device bytes, 16-byte aligned (the partition's per-chunk weight sums; with
+ *              scores also the samples' softmax maxima / sums, from which a second small kernel turns the raw scores into weights).
+ * Three launches on `stream` (two without scores); graph-capturable.  No reference code (README.md:27 -> arXiv:1706.06978). */
+int64_t dir_din_pack_workspace_bytes(int64_t B, int want_scores);
+int dir_din_attention_pool_packed_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                                      const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                                      const float* b3, int normalize, int activation, const float* act_params, int64_t B, float* out,
+                                      float* scores, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 int dir_din_attention_pool_save_arith_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                                           const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                                           const float* b3, int normalize, int arith, int64_t B, float* out, float* scores,
