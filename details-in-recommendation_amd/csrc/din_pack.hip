@@ -141,7 +141,9 @@ __device__ __forceinline__ void dp_load_rows(const float* __restrict__ table, co
     }
 }
 
-// One pass of a block: which rows it holds, and what the loads ahead of it fetched.
+// One pass of a block: which rows it holds.  The wave-uniform members live in scalar registers; the ids the loads ahead of the pass
+// fetched travel beside it (idA / idB, cidA / cidB in the kernel) so that a descriptor costs two vector registers to hand on.
+constexpr int DP_MASKED = 0x40000000;      // sj: the row's history id is < 0 (a masked position inside the length): in no softmax, pooled as zeros
 struct DpDesc {
     int valid;              // wave-uniform: 0 beyond the wave's last pass
     int first;              // the first pass of its block
@@ -149,9 +151,7 @@ struct DpDesc {
     int rowbase;            // block-relative index of the pass's first row
     int nrows;              // rows of the block inside the pass (0 .. 32; 0 only for a block of empty samples)
     long long sb;           // the block's first sample
-    int sj[2];              // per lane and tile: (sample in block << 16) | history position; -1: no row
-    long long id[2];        // per lane and tile: the row's history id (-1: no row, or a masked position)
-    long long cid;          // per lane (first pass of a block): candidate id of sample sb + (lane & 15), -1: none
+    int sj[2];              // per lane and tile: (sample in block << 16) | history position (| DP_MASKED once the id has landed); -1: no row
 };
 
 // The three layers for the NT row tiles of a pass -> the rows' scores sc (b3 included), identical in the four lane groups of a row.
@@ -281,18 +281,18 @@ __global__ __launch_bounds__(256) void din_pack_scores_k(float* __restrict__ sco
         float v = 0.f;
         if (j < len) {
             const float x = scores[e];
-            v = normalize ? (x > -INFINITY ? __expf(x - ml[2 * b]) * ml[2 * b + 1] : 0.f) : x;
+            v = normalize ? (x > -INFINITY ? __builtin_amdgcn_exp2f(x - ml[2 * b]) * ml[2 * b + 1] : 0.f) : x;      // x, m: log2 domain
         }
         scores[e] = v;
     }
 }
 
-template <int ACT, bool SCORES>
+template <int ACT, bool SCORES, bool NORM>
 __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
                                                                const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand, int T,
                                                                const float* __restrict__ W1, const float* __restrict__ b1, int H1,
                                                                const float* __restrict__ W2, const float* __restrict__ b2, int H2,
-                                                               const float* __restrict__ W3, const float* __restrict__ b3, int normalize,
+                                                               const float* __restrict__ W3, const float* __restrict__ b3,
                                                                long long B, float* __restrict__ out, float* __restrict__ scores,
                                                                float* __restrict__ ml, const int* __restrict__ csum, int nchunk,
                                                                long long chunk, int w0, const float* __restrict__ act_params) {
@@ -454,12 +454,11 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
         return b < s_hi ? len_of(b) : 0;
     };
     int a_lens_next = a_done ? 0 : block_len(s_lo);
-    auto advance = [&](DpDesc& d) {
+    auto advance = [&](DpDesc& d, long long (&id)[2], long long& cid) __attribute__((always_inline)) {
         d.valid = 0;
         d.first = 0;
         d.sj[0] = d.sj[1] = -1;
-        d.id[0] = d.id[1] = -1;
-        d.cid = -1;
+        id[0] = id[1] = -1;
         d.ns = 0; d.rowbase = 0; d.nrows = 0; d.sb = 0;
         if (a_done) return;
         ++a_pass;
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             a_cur = 0;
             a_lens_next = block_len(nb + DP_BLK);
             d.first = 1;
-            d.cid = r16 < a_ns ? (long long)cand[nb + r16] : -1;
+            cid = r16 < a_ns ? (long long)cand[nb + r16] : -1;
         }
         d.valid = 1;
         d.sb = a_sb;
@@ -501,61 +500,77 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             ++i;
         }
         a_cur = i;
+        const int64_t* const hb = hist + a_sb * T;              // wave-uniform base: the loads take a 32-bit per-lane offset
         if (q0 < a_R) {
             d.sj[0] = (s0 << 16) | (q0 - p0);
-            d.id[0] = hist[(a_sb + s0) * T + (q0 - p0)];
+            id[0] = hb[(unsigned int)(s0 * T + (q0 - p0))];
         }
         if (q1 < a_R) {
             d.sj[1] = (s1 << 16) | (q1 - p1);
-            d.id[1] = hist[(a_sb + s1) * T + (q1 - p1)];
+            id[1] = hb[(unsigned int)(s1 * T + (q1 - p1))];
         }
     };
 
     // ---- state of the computation: the block's sample ends, the first unfinished sample, the open sample's online softmax --------------------
+    // NORM: scores and running maximum in the log2 domain (x log2 e / sqrt K), so that a weight is one v_exp
     int c_endv = 0, c_cur = 0, c_lens = 0, c_R = 0;
     float m_run = -INFINITY, l_run = 0.f;
-    float4 o[4];
+    float o[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 hv[2][4], hvn[2][4], an[4];
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    float4 hvA[2][4], hvB[2][4], an[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) an[i] = hv[0][i] = hv[1][i] = hvn[0][i] = hvn[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) an[i] = hvA[0][i] = hvA[1][i] = hvB[0][i] = hvB[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float xscale = NORM ? inv_sqrt_k * 1.4426950408889634f : 1.0f;
+    const bool hi8 = (r16 & 8) != 0, hi4 = (r16 & 4) != 0, hi2 = (r16 & 2) != 0, hi1 = (r16 & 1) != 0;
 
-    auto fetch = [&](const DpDesc& d, float4 (&h)[2][4]) {    // a pass's rows; with a block's first pass its lengths and candidate rows
-        if (!d.valid) return;
-        dp_load_rows(table, kk, d.id[0], d.id[1], h);
+    auto fetch = [&](DpDesc& d, const long long (&id)[2], const long long cid, float4 (&h)[2][4]) __attribute__((always_inline)) {
+        if (!d.valid) return;   // a pass's rows; with a block's first pass its lengths and candidate rows
+        dp_load_rows(table, kk, id[0], id[1], h);
+        if (d.sj[0] >= 0 && id[0] < 0) d.sj[0] |= DP_MASKED;
+        if (d.sj[1] >= 0 && id[1] < 0) d.sj[1] |= DP_MASKED;
         if (d.first) {
             c_lens = r16 < d.ns ? len_of(d.sb + r16) : 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 an[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (d.cid >= 0) an[i] = dp_ld4(table + d.cid * DP_K + 16 * i + 4 * kk);
+                if (cid >= 0) an[i] = dp_ld4(table + cid * DP_K + 16 * i + 4 * kk);
             }
         }
     };
-    auto finalize = [&](const long long b) {                  // the open sample is complete: pooled output, state reset
-        const float inv_l = normalize ? (l_run > 0.f ? 1.0f / l_run : 0.f) : 1.0f;
+    // The open sample is complete: its pooled output.  The 16 sums over the 16 rows of a lane group by a transposing butterfly (each step
+    // halves the values a lane keeps: 15 x (2 selects + 1 DPP add) instead of 16 x 4 DPP adds); lane r ends with value r = 4 i + e, feature
+    // 16 i + 4 kk + e.
+    auto finalize = [&](const long long b) __attribute__((always_inline)) {
+        const float inv_l = NORM ? (l_run > 0.f ? __builtin_amdgcn_rcpf(l_run) : 0.f) : 1.0f;
+        float n8[8], n4[4], n2[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float4 t4;
-            t4.x = row16_sum(o[i].x) * inv_l; t4.y = row16_sum(o[i].y) * inv_l;
-            t4.z = row16_sum(o[i].z) * inv_l; t4.w = row16_sum(o[i].w) * inv_l;
-            if (r16 == 0) *reinterpret_cast<float4*>(out + b * DP_K + 16 * i + 4 * kk) = t4;
-            o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (SCORES && normalize && lane == 0) {
+        for (int j = 0; j < 8; ++j) n8[j] = (hi8 ? o[8 + j] : o[j]) + dpp_mov<0x140>(hi8 ? o[j] : o[8 + j]);          // row_mirror: r <-> 15 - r
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n4[j] = (hi4 ? n8[4 + j] : n8[j]) + dpp_mov<0x141>(hi4 ? n8[j] : n8[4 + j]);      // row_half_mirror: r <-> 7 - r
+#pragma unroll
+        for (int j = 0; j < 2; ++j) n2[j] = (hi2 ? n4[2 + j] : n4[j]) + dpp_mov<0x4E>(hi2 ? n4[j] : n4[2 + j]);       // r <-> r ^ 2
+        const float tot = (hi1 ? n2[1] : n2[0]) + dpp_mov<0xB1>(hi1 ? n2[0] : n2[1]);                                   // r <-> r ^ 1
+        out[b * DP_K + 16 * (r16 >> 2) + 4 * kk + (r16 & 3)] = tot * inv_l;
+        if (SCORES && NORM && lane == 0) {
             ml[2 * b] = m_run;
             ml[2 * b + 1] = inv_l;
         }
         m_run = -INFINITY;
         l_run = 0.f;
+        if (!NORM) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = 0.f;        // (NORM: the next sample's first rescale factor exp2(-inf) = 0 wipes them)
+        }
     };
 
     DpDesc dC, dB, dA;
-    advance(dC);
-    fetch(dC, hv);
-    advance(dB);
-    while (dC.valid) {
+    long long idB[2], idA[2], cidB = -1, cidA = -1;
+    advance(dC, idB, cidB);
+    fetch(dC, idB, cidB, hvA);
+    advance(dB, idB, cidB);
+
+    auto step = [&](float4 (&hv)[2][4], float4 (&hvn)[2][4]) __attribute__((always_inline)) {
         if (dC.first) {
             // ---- a new block: its candidate rows -> the av slot; c[m] = sum_f a[f] (Wa - Wd)[f][m] + b1[m] for the 16 samples at once -> the cv slot --
             c_endv = dp_row_scan(c_lens);
@@ -587,11 +602,12 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             __builtin_amdgcn_wave_barrier();                         // only keep the compiler from moving the reads above the writes
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        fetch(dB, hvn);          // the next pass's rows (its ids were issued a pass ago)
-        advance(dA);             // the ids of the pass after it
+        fetch(dB, idB, cidB, hvn);          // the next pass's rows (its ids were issued a pass ago)
+        advance(dA, idA, cidA);             // the ids of the pass after it
         // ---- this pass: the three layers for its rows ---------------------------------------------------------------------------------------
-        const int sA[2] = {dC.sj[0] >> 16, dC.sj[1] >> 16};      // -1: no row
-        const int so[2] = {sA[0] < 0 ? 0 : sA[0], sA[1] < 0 ? 0 : sA[1]};
+        const int srow[2] = {dC.sj[0] < 0 ? -1 : (dC.sj[0] >> 16) & 0xff, dC.sj[1] < 0 ? -1 : (dC.sj[1] >> 16) & 0xff};      // the row's sample, -1: no row
+        const int smem[2] = {(dC.sj[0] & DP_MASKED) ? -1 : srow[0], (dC.sj[1] & DP_MASKED) ? -1 : srow[1]};                  // ... -1 also for a masked position
+        const int so[2] = {srow[0] < 0 ? 0 : srow[0], srow[1] < 0 ? 0 : srow[1]};
         float sc[2] = {0.f, 0.f};
         if (dC.nrows > 16) {
             dp_mlp<2, ACT>(sh, actl, avs, cvs, r16, kk, so, hv, bias3, sc);
@@ -600,6 +616,8 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             dp_mlp<1, ACT>(sh, actl, avs, cvs, r16, kk, so, hv, bias3, s1_);
             sc[0] = s1_[0];
         }
+        sc[0] *= xscale;
+        sc[1] *= xscale;
         // ---- its segments: masked (online) softmax + pooling per sample; a sample that ends inside the pass is written out ------------------------
         {
             const int pend = dC.rowbase + 32;
@@ -610,44 +628,39 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
                 if (st >= pend && !last) break;
                 const int en = dp_readlane(c_endv, i);
                 if (en > st && en > dC.rowbase) {
-                    const bool mem0 = sA[0] == i && dC.id[0] >= 0, mem1 = sA[1] == i && dC.id[1] >= 0;
-                    if (normalize) {
-                        const float x0 = mem0 ? sc[0] * inv_sqrt_k : -INFINITY, x1 = mem1 ? sc[1] * inv_sqrt_k : -INFINITY;
+                    const bool mem0 = smem[0] == i, mem1 = smem[1] == i;
+                    float w0_, w1_;                      // the two rows' pooling weights
+                    if constexpr (NORM) {
+                        const float x0 = mem0 ? sc[0] : -INFINITY, x1 = mem1 ? sc[1] : -INFINITY;
                         const float mx = fmaxf(m_run, row16_max(fmaxf(x0, x1)));
-                        if (mx > -INFINITY) {            // wave-uniform (row maxima are identical in the four lane groups)
-                            const float rescale = __expf(m_run - mx);      // m_run = -inf: 0
-                            const float p0 = mem0 ? __expf(x0 - mx) : 0.f, p1 = mem1 ? __expf(x1 - mx) : 0.f;
-                            l_run = l_run * rescale + (row16_sum(p0) + row16_sum(p1));
+                        const float mxs = mx > -INFINITY ? mx : 0.f;           // (nothing to pool yet: every factor below is exp2(-inf) = 0)
+                        const float rescale = __builtin_amdgcn_exp2f(m_run - mxs);
+                        w0_ = __builtin_amdgcn_exp2f(x0 - mxs);
+                        w1_ = __builtin_amdgcn_exp2f(x1 - mxs);
+                        l_run = l_run * rescale + row16_sum(w0_ + w1_);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float4 acc = make_float4(o[q].x * rescale, o[q].y * rescale, o[q].z * rescale, o[q].w * rescale);
-                                acc.x = fmaf(p0, hv[0][q].x, acc.x); acc.y = fmaf(p0, hv[0][q].y, acc.y);
-                                acc.z = fmaf(p0, hv[0][q].z, acc.z); acc.w = fmaf(p0, hv[0][q].w, acc.w);
-                                acc.x = fmaf(p1, hv[1][q].x, acc.x); acc.y = fmaf(p1, hv[1][q].y, acc.y);
-                                acc.z = fmaf(p1, hv[1][q].z, acc.z); acc.w = fmaf(p1, hv[1][q].w, acc.w);
-                                o[q] = acc;
-                            }
-                            m_run = mx;
-                        }
+                        for (int q = 0; q < 16; ++q) o[q] *= rescale;
+                        m_run = mx;
                         if (SCORES && kk == 0) {
                             const long long row = (dC.sb + i) * T;
-                            if (sA[0] == i) scores[row + (dC.sj[0] & 0xffff)] = x0;
-                            if (sA[1] == i) scores[row + (dC.sj[1] & 0xffff)] = x1;
+                            if (srow[0] == i) scores[row + (dC.sj[0] & 0xffff)] = x0;
+                            if (srow[1] == i) scores[row + (dC.sj[1] & 0xffff)] = x1;
                         }
                     } else {
-                        const float x0 = mem0 ? sc[0] : 0.f, x1 = mem1 ? sc[1] : 0.f;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            o[q].x = fmaf(x0, hv[0][q].x, o[q].x); o[q].y = fmaf(x0, hv[0][q].y, o[q].y);
-                            o[q].z = fmaf(x0, hv[0][q].z, o[q].z); o[q].w = fmaf(x0, hv[0][q].w, o[q].w);
-                            o[q].x = fmaf(x1, hv[1][q].x, o[q].x); o[q].y = fmaf(x1, hv[1][q].y, o[q].y);
-                            o[q].z = fmaf(x1, hv[1][q].z, o[q].z); o[q].w = fmaf(x1, hv[1][q].w, o[q].w);
-                        }
+                        w0_ = mem0 ? sc[0] : 0.f;
+                        w1_ = mem1 ? sc[1] : 0.f;
                         if (SCORES && kk == 0) {
                             const long long row = (dC.sb + i) * T;
-                            if (sA[0] == i) scores[row + (dC.sj[0] & 0xffff)] = x0;
-                            if (sA[1] == i) scores[row + (dC.sj[1] & 0xffff)] = x1;
+                            if (srow[0] == i) scores[row + (dC.sj[0] & 0xffff)] = w0_;
+                            if (srow[1] == i) scores[row + (dC.sj[1] & 0xffff)] = w1_;
                         }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[4 * q + 0] = fmaf(w0_, hv[0][q].x, o[4 * q + 0]); o[4 * q + 1] = fmaf(w0_, hv[0][q].y, o[4 * q + 1]);
+                        o[4 * q + 2] = fmaf(w0_, hv[0][q].z, o[4 * q + 2]); o[4 * q + 3] = fmaf(w0_, hv[0][q].w, o[4 * q + 3]);
+                        o[4 * q + 0] = fmaf(w1_, hv[1][q].x, o[4 * q + 0]); o[4 * q + 1] = fmaf(w1_, hv[1][q].y, o[4 * q + 1]);
+                        o[4 * q + 2] = fmaf(w1_, hv[1][q].z, o[4 * q + 2]); o[4 * q + 3] = fmaf(w1_, hv[1][q].w, o[4 * q + 3]);
                     }
                 }
                 if (en > pend) break;                    // the sample goes on in the next pass
@@ -656,12 +669,16 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             }
             c_cur = i;
         }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hv[rt][i] = hvn[rt][i];
         dC = dB;
         dB = dA;
+        idB[0] = idA[0]; idB[1] = idA[1];
+        cidB = cidA;
+    };
+    while (true) {               // two passes per trip: the row buffers swap roles (no copies)
+        if (!dC.valid) break;
+        step(hvA, hvB);
+        if (!dC.valid) break;
+        step(hvB, hvA);
     }
 }
 
@@ -700,25 +717,25 @@ int launch_din_pack(hipStream_t st, const float* table, const int64_t* hist, con
     const char* w0e = getenv("DIR_DIN_PACK_W0");
     const int w0 = w0e ? (atoi(w0e) < 0 ? 0 : atoi(w0e) > 64 ? 64 : atoi(w0e)) : 5;
     typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,
-                           const float*, int, const float*, const float*, int, long long, float*, float*, float*, const int*, int, long long, int,
+                           const float*, int, const float*, const float*, long long, float*, float*, float*, const int*, int, long long, int,
                            const float*);
-    static const kern_t kerns[3][2] = {{&din_pack_k<0, false>, &din_pack_k<0, true>},
-                                       {&din_pack_k<1, false>, &din_pack_k<1, true>},
-                                       {&din_pack_k<2, false>, &din_pack_k<2, true>}};
+    static const kern_t kerns[3][2][2] = {{{&din_pack_k<0, false, false>, &din_pack_k<0, false, true>}, {&din_pack_k<0, true, false>, &din_pack_k<0, true, true>}},
+                                          {{&din_pack_k<1, false, false>, &din_pack_k<1, false, true>}, {&din_pack_k<1, true, false>, &din_pack_k<1, true, true>}},
+                                          {{&din_pack_k<2, false, false>, &din_pack_k<2, false, true>}, {&din_pack_k<2, true, false>, &din_pack_k<2, true, true>}}};
     if (activation < 0 || activation > 2 || (activation != 0 && !act_params))
         return fail(DIR_E_UNSUPPORTED, "din_pack_k: activation %d (0 sigmoid, 1 PReLU, 2 Dice)", activation);
-    static LdsOnce once[3][2];
-    const int sco = scores ? 1 : 0;
+    static LdsOnce once[3][2][2];
+    const int sco = scores ? 1 : 0, nrm = normalize ? 1 : 0;
     const size_t shmem = ((sizeof(DpSh) + 15) & ~(size_t)15) + (activation ? sizeof(float) * DP_ACT_FLOATS : 0);
-    const kern_t kern = kerns[activation][sco];
-    if (!lds_limit(once[activation][sco], (int)shmem, kern)) return fail(DIR_E_HIP, "din_pack_k: cannot reserve %zu B of LDS", shmem);
+    const kern_t kern = kerns[activation][sco][nrm];
+    if (!lds_limit(once[activation][sco][nrm], (int)shmem, kern)) return fail(DIR_E_HIP, "din_pack_k: cannot reserve %zu B of LDS", shmem);
     hipLaunchKernelGGL(din_pack_sums_k, dim3((unsigned)nchunk), dim3(256), 0, st, hist_len, T, (long long)B, (long long)chunk, w0, csum);
     const int64_t waves_wanted = (B + 1) / 2;            // a wave should see at least a couple of samples
     int64_t nwg = (waves_wanted + DP_WAVES - 1) / DP_WAVES;
     if (nwg > kCUs) nwg = kCUs;
     if (nwg < 1) nwg = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * DP_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3,
-                       normalize, (long long)B, out, scores, ml, csum, nchunk, (long long)chunk, w0, act_params);
+                       (long long)B, out, scores, ml, csum, nchunk, (long long)chunk, w0, act_params);
     if (scores) {
         const int64_t n = B * T;
         int64_t nb = (n + 255) / 256;
