@@ -137,8 +137,10 @@ SIGNATURES = {
     "dir_din_attention_pool_arith_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                                  c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "dir_din_pack_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "dir_din_pack_image_bytes": (c_i64, []),
+    "dir_din_pack_weights_f32": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "dir_din_attention_pool_packed_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
-                                                  c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+                                                  c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_din_attention_pool_save_arith_f32": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32,
                                                       c_i32, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "dir_cin_layer_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp]),

@@ -38,18 +38,25 @@ constexpr int DP_AVS = 72, DP_CVS = 84;      // floats between samples in the ca
 constexpr int DP_ACT_S1 = 96, DP_ACT_S2 = 48;
 constexpr int DP_ACT_FLOATS = 3 * DP_ACT_S1 + 3 * DP_ACT_S2;
 constexpr float DP_NLOG2E = -1.4426950408889634f;
-constexpr int DP_SUB = 1024;           // samples one wave scans per step of the range search (16 per lane)
 
-struct DpSh {
+// The weight image: what a workgroup keeps in LDS for the whole launch.  Built ONCE per weight version by din_pack_image_k into global
+// memory (the first build of this kernel staged it from W1 / W2 in every workgroup's prologue: ~20 us of a 230 us launch), copied into LDS
+// with 16-byte loads by every workgroup.
+struct DpImg {
     unsigned int whd3[2 * 5 * 2 * 256];     // (Wh + Wd)^T: [k-step][m tile][piece][lane][4 dwords]
     unsigned int wp3[2 * 5 * 2 * 256];      // Wp^T
     unsigned int wc3[2 * 5 * 2 * 256];      // (Wa - Wd)^T
     unsigned int w23[3 * 3 * 2 * 256];      // W2^T; hidden 80..95 of the third k-step are zero
     float b1[DP_H1P], b2[DP_H2P], w3[DP_H2P];
+    float act[DP_ACT_FLOATS];               // PReLU / Dice: [3][96] layer 1, [3][48] layer 2 (alpha, -log2 e scale, -log2 e shift); sigmoid: unused
+};
+static_assert(sizeof(DpImg) % 16 == 0, "16-byte copies");
+struct DpSh {
+    DpImg w;
     float av[DP_WAVES][DP_BLK * DP_AVS];    // per wave: the candidate rows of the block being computed
     float cv[DP_WAVES][DP_BLK * DP_CVS];    // per wave: their terms c (+ b1); before the sample loop: scratch of the range search
 };
-static_assert(sizeof(DpSh) + sizeof(float) * DP_ACT_FLOATS <= 160 * 1024, "LDS");
+static_assert(sizeof(DpSh) <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ float4 dp_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float dp_sigmoid_pre(float y) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y)); }
@@ -109,6 +116,9 @@ __device__ __forceinline__ dp_f32x4 dp_mma(const dp_f16x8 (&a)[2], const dp_f16x
     return c;
 }
 __device__ __forceinline__ void dp_lda(const unsigned int* img, int tile, int lane4, dp_f16x8 (&a)[2]) {
+#ifdef DP_ABL_LDS      // timing ablation (WRONG results): every weight operand is the image's first tile, which the compiler reads once per pass
+    tile = 0;
+#endif
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc) a[pc] = __builtin_bit_cast(dp_f16x8, *reinterpret_cast<const dp_u32x4*>(img + (tile * 2 + pc) * 256 + lane4));
 }
@@ -129,15 +139,18 @@ __device__ __forceinline__ int dp_row_scan(int v) {
     return v;
 }
 
-// rows of two tiles: this lane's 16 features {16 i + 4 kk + e} of its own rows; no row (id < 0): zeros
-__device__ __forceinline__ void dp_load_rows(const float* __restrict__ table, const int kk, const long long id0, const long long id1,
+// rows of two tiles: this lane's 16 features {16 i + 4 kk + e} of its own rows.  The loads are UNCONDITIONAL (a lane without a row, or with a
+// masked position, reads row 0: such rows are in no softmax and pooled with weight 0, so what they hold does not matter as long as it is
+// finite): a load under a branch makes the compiler's count of outstanding loads imprecise, and every wait behind it becomes vmcnt(0) --
+// which, issued after a pass's row loads, exposes their whole HBM latency in every pass (the first build of this kernel did exactly that).
+__device__ __forceinline__ void dp_load_rows(const float* __restrict__ table, const int kk, const unsigned int r0, const unsigned int r1,
                                              float4 (&hv)[2][4]) {
+    const float* const p0 = table + (size_t)r0 * DP_K + 4 * kk;
+    const float* const p1 = table + (size_t)r1 * DP_K + 4 * kk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hv[0][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        hv[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (id0 >= 0) hv[0][i] = dp_ld4(table + id0 * DP_K + 16 * i + 4 * kk);
-        if (id1 >= 0) hv[1][i] = dp_ld4(table + id1 * DP_K + 16 * i + 4 * kk);
+        hv[0][i] = dp_ld4(p0 + 16 * i);
+        hv[1][i] = dp_ld4(p1 + 16 * i);
     }
 }
 
@@ -184,7 +197,7 @@ __device__ __forceinline__ void dp_mlp(const DpSh& sh, const float* actl, const 
                 }
                 dp_split8(s0, s1, xb[rt]);
             }
-            const unsigned int* img = part ? sh.wp3 : sh.whd3;
+            const unsigned int* img = part ? sh.w.wp3 : sh.w.whd3;
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
                 dp_f16x8 a[2];
@@ -208,7 +221,7 @@ __device__ __forceinline__ void dp_mlp(const DpSh& sh, const float* actl, const 
     dp_f32x4 acc2[3][NT];
 #pragma unroll
     for (int m2 = 0; m2 < 3; ++m2) {
-        const float4 c4 = dp_ld4(&sh.b2[16 * m2 + 4 * kk]);
+        const float4 c4 = dp_ld4(&sh.w.b2[16 * m2 + 4 * kk]);
 #pragma unroll
         for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = (dp_f32x4){c4.x, c4.y, c4.z, c4.w};
     }
@@ -224,7 +237,7 @@ __device__ __forceinline__ void dp_mlp(const DpSh& sh, const float* actl, const 
 #pragma unroll
         for (int m2 = 0; m2 < 3; ++m2) {
             dp_f16x8 a[2];
-            dp_lda(sh.w23, ks * 3 + m2, lane4, a);
+            dp_lda(sh.w.w23, ks * 3 + m2, lane4, a);
 #pragma unroll
             for (int rt = 0; rt < NT; ++rt) acc2[m2][rt] = dp_mma(a, xb[rt], acc2[m2][rt]);
         }
@@ -233,41 +246,122 @@ __device__ __forceinline__ void dp_mlp(const DpSh& sh, const float* actl, const 
     float wv[3][4];
 #pragma unroll
     for (int m2 = 0; m2 < 3; ++m2) {
-        const float4 t4 = dp_ld4(&sh.w3[16 * m2 + 4 * kk]);
+        const float4 t4 = dp_ld4(&sh.w.w3[16 * m2 + 4 * kk]);
         wv[m2][0] = t4.x; wv[m2][1] = t4.y; wv[m2][2] = t4.z; wv[m2][3] = t4.w;
     }
+    float sp[NT];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
-        float sp = 0.f;
+        sp[rt] = 0.f;
 #pragma unroll
         for (int m2 = 0; m2 < 3; ++m2) {
             float al[4], ns[4], nt[4];
             dp_act_params<ACT>(actl + 3 * DP_ACT_S1, DP_ACT_S2, 16 * m2 + 4 * kk, al, ns, nt);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) sp = fmaf(dp_act<ACT>(acc2[m2][rt][g], al[g], ns[g], nt[g]), wv[m2][g], sp);
+            for (int g = 0; g < 4; ++g) sp[rt] = fmaf(dp_act<ACT>(acc2[m2][rt][g], al[g], ns[g], nt[g]), wv[m2][g], sp[rt]);
         }
-        sp += __shfl_xor(sp, 16, 64);        // the four lane groups hold the four quarters of the H2 sum of row r
-        sp += __shfl_xor(sp, 32, 64);
-        sc[rt] = sp + b3;
+    }
+    // The four lane groups hold the four quarters of a row's H2 sum.  The sums over the groups of BOTH tiles inside the VALU (cin_bf3.hip:
+    // store_dot): v_permlane16_swap exchanges a's odd rows of 16 lanes with b's even rows, v_permlane32_swap a's upper half with b's lower
+    // half -- no ds_bpermute round trips at the end of the pass's matrix work.  (g0 + g1) + (g2 + g3), in every lane group.
+    float a = sp[0], b = sp[NT - 1];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float c = a + b, d = c;          // rows 0 / 2: tile 0's pair sums, rows 1 / 3: the last tile's
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
+    float t0 = c + d, t1 = t0;       // rows 0 / 2: tile 0's total, rows 1 / 3: the last tile's
+    if constexpr (NT == 2) {
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(t0), "+v"(t1));      // t0: tile 0's total everywhere, t1: tile 1's
+        sc[0] = t0 + b3;
+        sc[1] = t1 + b3;
+    } else {
+        sc[0] = t0 + b3;
     }
 }
 
-// per-chunk weight sums: weight of a sample = its valid history positions + w0 (what a sample costs beyond its rows)
-__global__ __launch_bounds__(256) void din_pack_sums_k(const int32_t* __restrict__ hist_len, int T, long long B, long long chunk, int w0,
+// per-chunk weight sums: weight of a sample = its valid history positions + w0 (what a sample costs beyond its rows).  One wave per chunk.
+__global__ __launch_bounds__(256) void din_pack_sums_k(const int32_t* __restrict__ hist_len, int T, long long B, long long chunk, int nchunk, int w0,
                                                        int* __restrict__ csum) {
-    __shared__ int red[4];
-    const long long base = (long long)blockIdx.x * chunk;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= nchunk) return;
+    const long long base = (long long)c * chunk;
     const long long endb = base + chunk < B ? base + chunk : B;
     int s = 0;
-    for (long long b = base + threadIdx.x; b < endb; b += 256) {
+    for (long long b = base + lane; b < endb; b += 64) {
         const int len = hist_len ? hist_len[b] : T;
         s += (len < 0 ? 0 : len > T ? T : len) + w0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) csum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (lane == 0) csum[c] = s;
+}
+
+// The weight image (see DpImg) from W1 [4K, H1], b1, W2 [H1, H2], b2, W3 and the PReLU / Dice parameters.  A-operand images: dword jp of lane
+// l of tile (ks, mt) holds elements j = 2 jp, 2 jp + 1 = W[m = 16 mt + (l & 15)][k], k + 1, k = 16 (2 ks + (j >> 2)) + 4 (l >> 4) + (j & 3).
+template <int ACT>
+__global__ __launch_bounds__(256) void din_pack_image_k(const float* __restrict__ W1, const float* __restrict__ b1, int H1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2, int H2,
+                                                        const float* __restrict__ W3, const float* __restrict__ act_params, DpImg* __restrict__ img) {
+    constexpr float SC = ACT == 0 ? DP_NLOG2E : 1.0f;      // sigmoid: the MFMA result IS the exponent of 2
+    const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    for (int idx = gtid; idx < 2 * 5 * 64 * 4; idx += gsz) {
+        const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+        const int ks = t / 5, mt = t - 5 * ks;
+        const int m = 16 * mt + (l & 15);
+        const int f = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+        float hd[2] = {0.f, 0.f}, pp[2] = {0.f, 0.f}, cc[2] = {0.f, 0.f};
+        if (m < H1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float vh = W1[(size_t)(f + e) * H1 + m], va = W1[(size_t)(DP_K + f + e) * H1 + m];
+                const float vd = W1[(size_t)(2 * DP_K + f + e) * H1 + m], vp = W1[(size_t)(3 * DP_K + f + e) * H1 + m];
+                hd[e] = (vh + vd) * SC;
+                pp[e] = vp * SC;
+                cc[e] = (va - vd) * SC;
+            }
+        }
+        unsigned int hi, lo;
+        dp_split2(hd[0], hd[1], hi, lo);
+        img->whd3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        img->whd3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+        dp_split2(pp[0], pp[1], hi, lo);
+        img->wp3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        img->wp3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+        dp_split2(cc[0], cc[1], hi, lo);
+        img->wc3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        img->wc3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+    }
+    for (int idx = gtid; idx < 3 * 3 * 64 * 4; idx += gsz) {
+        const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
+        const int ks = t / 3, m2 = t - 3 * ks;
+        const int h2 = 16 * m2 + (l & 15);
+        const int hid = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)      // a padded hidden unit is sigmoid(0) = 0.5: its weights are zero
+            v[e] = (hid + e < H1 && h2 < H2) ? W2[(size_t)(hid + e) * H2 + h2] * SC : 0.f;
+        unsigned int hi, lo;
+        dp_split2(v[0], v[1], hi, lo);
+        img->w23[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
+        img->w23[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
+    }
+    for (int idx = gtid; idx < DP_H1P; idx += gsz) img->b1[idx] = idx < H1 ? b1[idx] * SC : 0.f;
+    for (int idx = gtid; idx < DP_H2P; idx += gsz) {
+        img->b2[idx] = idx < H2 ? b2[idx] * SC : 0.f;
+        img->w3[idx] = idx < H2 ? W3[idx] : 0.f;
+    }
+    for (int idx = gtid; idx < DP_ACT_FLOATS; idx += gsz) {
+        float v = 0.f;
+        if constexpr (ACT != 0) {
+            if (idx < 3 * DP_ACT_S1) {
+                const int row = idx / DP_ACT_S1, h = idx - row * DP_ACT_S1;
+                if (h < H1) v = act_params[row * H1 + h] * (row == 0 ? 1.0f : DP_NLOG2E);
+            } else {
+                const int j = idx - 3 * DP_ACT_S1, row = j / DP_ACT_S2, h = j - row * DP_ACT_S2;
+                if (h < H2) v = act_params[3 * H1 + row * H2 + h] * (row == 0 ? 1.0f : DP_NLOG2E);
+            }
+        }
+        img->act[idx] = v;
+    }
 }
 
 // scores written raw by the main kernel -> attention weights: softmax weights exp(x - m_b) / l_b (normalize), zeros beyond the length
@@ -290,82 +384,26 @@ __global__ __launch_bounds__(256) void din_pack_scores_k(float* __restrict__ sco
 template <int ACT, bool SCORES, bool NORM>
 __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __restrict__ table, const int64_t* __restrict__ hist,
                                                                const int32_t* __restrict__ hist_len, const int64_t* __restrict__ cand, int T,
-                                                               const float* __restrict__ W1, const float* __restrict__ b1, int H1,
-                                                               const float* __restrict__ W2, const float* __restrict__ b2, int H2,
-                                                               const float* __restrict__ W3, const float* __restrict__ b3,
+                                                               const DpImg* __restrict__ img, const float* __restrict__ b3,
                                                                long long B, float* __restrict__ out, float* __restrict__ scores,
                                                                float* __restrict__ ml, const int* __restrict__ csum, int nchunk,
-                                                               long long chunk, int w0, const float* __restrict__ act_params) {
+                                                               long long chunk, int w0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dp_smem[];
     DpSh& sh = *reinterpret_cast<DpSh*>(dp_smem);
-    float* const actl = reinterpret_cast<float*>(dp_smem + ((sizeof(DpSh) + 15) & ~(size_t)15));
-    constexpr float SC = ACT == 0 ? DP_NLOG2E : 1.0f;      // what the weight / bias images are multiplied by
+    const float* const actl = sh.w.act;
     const int tid = threadIdx.x, lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int w = dp_uni(tid >> 6);
     // ---- the chunk sums -> their exclusive prefix (the range search's first level), in the cv slots ------------------------------------------
     long long* const cpre = reinterpret_cast<long long*>(&sh.cv[0][0]);      // [nchunk + 1], nchunk <= 1024
     for (int idx = tid; idx < nchunk; idx += 64 * DP_WAVES) cpre[idx + 1] = csum[idx];
     if (tid == 0) cpre[0] = 0;
-    if constexpr (ACT != 0) {
-        for (int idx = tid; idx < DP_ACT_FLOATS; idx += 64 * DP_WAVES) {
-            float v = 0.f;
-            if (idx < 3 * DP_ACT_S1) {
-                const int row = idx / DP_ACT_S1, h = idx - row * DP_ACT_S1;
-                if (h < H1) v = act_params[row * H1 + h] * (row == 0 ? 1.0f : DP_NLOG2E);
-            } else {
-                const int j = idx - 3 * DP_ACT_S1, row = j / DP_ACT_S2, h = j - row * DP_ACT_S2;
-                if (h < H2) v = act_params[3 * H1 + row * H2 + h] * (row == 0 ? 1.0f : DP_NLOG2E);
-            }
-            actl[idx] = v;
-        }
-    }
-    // ---- weight images, once per workgroup: dword jp of lane l of tile (ks, mt) holds elements j = 2 jp, 2 jp + 1 = W[m = 16 mt + (l & 15)][k], k + 1,
-    // k = 16 (2 ks + (j >> 2)) + 4 (l >> 4) + (j & 3)
-    for (int idx = tid; idx < 2 * 5 * 64 * 4; idx += 64 * DP_WAVES) {
-        const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
-        const int ks = t / 5, mt = t - 5 * ks;
-        const int m = 16 * mt + (l & 15);
-        const int f = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
-        float hd[2] = {0.f, 0.f}, pp[2] = {0.f, 0.f}, cc[2] = {0.f, 0.f};
-        if (m < H1) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float vh = W1[(size_t)(f + e) * H1 + m], va = W1[(size_t)(DP_K + f + e) * H1 + m];
-                const float vd = W1[(size_t)(2 * DP_K + f + e) * H1 + m], vp = W1[(size_t)(3 * DP_K + f + e) * H1 + m];
-                hd[e] = (vh + vd) * SC;
-                pp[e] = vp * SC;
-                cc[e] = (va - vd) * SC;
-            }
-        }
-        unsigned int hi, lo;
-        dp_split2(hd[0], hd[1], hi, lo);
-        sh.whd3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
-        sh.whd3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
-        dp_split2(pp[0], pp[1], hi, lo);
-        sh.wp3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
-        sh.wp3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
-        dp_split2(cc[0], cc[1], hi, lo);
-        sh.wc3[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
-        sh.wc3[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
-    }
-    for (int idx = tid; idx < 3 * 3 * 64 * 4; idx += 64 * DP_WAVES) {
-        const int jp = idx & 3, l = (idx >> 2) & 63, t = idx >> 8;
-        const int ks = t / 3, m2 = t - 3 * ks;
-        const int h2 = 16 * m2 + (l & 15);
-        const int hid = 16 * (2 * ks + (jp >> 1)) + 4 * (l >> 4) + 2 * (jp & 1);
-        float v[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e)      // a padded hidden unit is sigmoid(0) = 0.5: its weights are zero
-            v[e] = (hid + e < H1 && h2 < H2) ? W2[(size_t)(hid + e) * H2 + h2] * SC : 0.f;
-        unsigned int hi, lo;
-        dp_split2(v[0], v[1], hi, lo);
-        sh.w23[(t * 2 + 0) * 256 + l * 4 + jp] = hi;
-        sh.w23[(t * 2 + 1) * 256 + l * 4 + jp] = lo;
-    }
-    for (int idx = tid; idx < DP_H1P; idx += 64 * DP_WAVES) sh.b1[idx] = idx < H1 ? b1[idx] * SC : 0.f;
-    for (int idx = tid; idx < DP_H2P; idx += 64 * DP_WAVES) {
-        sh.b2[idx] = idx < H2 ? b2[idx] * SC : 0.f;
-        sh.w3[idx] = idx < H2 ? W3[idx] : 0.f;
+    // ---- the weight image: global -> LDS, 16 bytes per thread and trip -----------------------------------------------------------------------
+    {
+        const dp_u32x4* const src = reinterpret_cast<const dp_u32x4*>(img);
+        dp_u32x4* const dst = reinterpret_cast<dp_u32x4*>(&sh.w);
+        constexpr int N16 = (int)(sizeof(DpImg) / 16);
+#pragma unroll 4
+        for (int idx = tid; idx < N16; idx += 64 * DP_WAVES) dst[idx] = src[idx];
     }
     __syncthreads();
     if (w == 0) {                // inclusive scan of cpre[1 ..] in place: per = entries per lane, then the lane totals
@@ -403,32 +441,19 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             if (cpre[mid] < t) lo_c = mid; else hi_c = mid;
         }
         const long long base = (long long)lo_c * chunk, endb = base + chunk < B ? base + chunk : B;
-        const long long tt = t - cpre[lo_c];                   // samples of the chunk with a chunk-relative prefix < tt come before the answer
-        long long carry = 0;
-        int cnt = 0;
-        for (long long sub = base; sub < endb && carry < tt; sub += DP_SUB) {
-            const long long b0 = sub + (long long)lane * 16;
-            int wv_[16];
-            int tot = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                wv_[i] = b0 + i < endb ? len_of(b0 + i) + w0 : 0;
-                tot += wv_[i];
-            }
-            long long off = tot;
+        const int tt = (int)(t - cpre[lo_c]);                  // samples of the chunk with a chunk-relative prefix < tt come before the answer
+        int carry = 0, cnt = 0;                                // (a chunk's weight fits 31 bits: din_pack_chunks)
+        for (long long sub = base; sub < endb && carry < tt; sub += 64) {      // 64 consecutive samples per trip, one per lane
+            const long long b = sub + lane;
+            const int wgt = b < endb ? len_of(b) + w0 : 0;
+            int incl = wgt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
-                const long long u = __shfl_up(off, o, 64);
-                if (lane >= o) off += u;
+                const int u = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += u;
             }
-            const long long wave_tot = __shfl(off, 63, 64);
-            long long pre = carry + off - tot;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                cnt += (b0 + i < endb && pre < tt) ? 1 : 0;
-                pre += wv_[i];
-            }
-            carry += wave_tot;
+            cnt += (b < endb && carry + incl - wgt < tt) ? 1 : 0;
+            carry += __shfl(incl, 63, 64);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
@@ -446,74 +471,92 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
     const int lane4 = 4 * (16 * kk + r16);
 
     // ---- the cursor two passes ahead of the computation: which rows a pass holds, their history ids ------------------------------------------
+    // Every load below is unconditional (clamped addresses, the result selected afterwards): see dp_load_rows.
     long long a_sb = 0;
     int a_ns = 0, a_np = 0, a_pass = -1, a_R = 0, a_cur = 0, a_endv = 0;
     bool a_started = false, a_done = s_lo >= s_hi;
-    auto block_len = [&](const long long sb) {                // lane r's sample of the block at sb (0 beyond the wave's range)
+    // lane r's length in the block at sb: the load (raw, from a clamped address) now, the clamp when it is consumed -- a value that is
+    // touched right behind its load makes the wave wait for that load and for everything issued before it (the pass's row loads)
+    auto block_len_raw = [&](const long long sb) {
         const long long b = sb + r16;
-        return b < s_hi ? len_of(b) : 0;
+        return hist_len ? hist_len[b < B ? b : B - 1] : T;
     };
-    int a_lens_next = a_done ? 0 : block_len(s_lo);
+    auto block_len_of = [&](const long long sb, const int raw) {      // 0 beyond the wave's range
+        return sb + r16 < s_hi ? (raw < 0 ? 0 : raw > T ? T : raw) : 0;
+    };
+    int a_lens_next = block_len_raw(s_lo);
     auto advance = [&](DpDesc& d, long long (&id)[2], long long& cid) __attribute__((always_inline)) {
         d.valid = 0;
         d.first = 0;
         d.sj[0] = d.sj[1] = -1;
-        id[0] = id[1] = -1;
         d.ns = 0; d.rowbase = 0; d.nrows = 0; d.sb = 0;
-        if (a_done) return;
-        ++a_pass;
-        if (a_pass >= a_np) {                                  // the next block
-            const long long nb = a_started ? a_sb + DP_BLK : s_lo;
-            a_started = true;
-            if (nb >= s_hi) {
-                a_done = true;
-                return;
+        bool live = !a_done;
+        if (live) {
+            ++a_pass;
+            if (a_pass >= a_np) {                              // the next block
+                const long long nb = a_started ? a_sb + DP_BLK : s_lo;
+                a_started = true;
+                if (nb >= s_hi) {
+                    a_done = true;
+                    live = false;
+                } else {
+                    a_sb = nb;
+                    a_ns = (int)(s_hi - nb < DP_BLK ? s_hi - nb : DP_BLK);
+                    a_endv = dp_row_scan(block_len_of(nb, a_lens_next));
+                    a_R = dp_readlane(a_endv, 15);
+                    a_np = a_R > 0 ? (a_R + 31) >> 5 : 1;
+                    a_pass = 0;
+                    a_cur = 0;
+                    d.first = 1;
+                }
             }
-            a_sb = nb;
-            a_ns = (int)(s_hi - nb < DP_BLK ? s_hi - nb : DP_BLK);
-            a_endv = dp_row_scan(a_lens_next);
-            a_R = dp_readlane(a_endv, 15);
-            a_np = a_R > 0 ? (a_R + 31) >> 5 : 1;
-            a_pass = 0;
-            a_cur = 0;
-            a_lens_next = block_len(nb + DP_BLK);
-            d.first = 1;
-            cid = r16 < a_ns ? (long long)cand[nb + r16] : -1;
         }
-        d.valid = 1;
-        d.sb = a_sb;
-        d.ns = a_ns;
-        d.rowbase = a_pass * 32;
-        d.nrows = a_R - d.rowbase > 32 ? 32 : a_R - d.rowbase;
-        // row q belongs to the first sample whose end (inclusive prefix) is > q: samples before a_cur ended before this pass
-        const int q0 = d.rowbase + r16, q1 = q0 + 16, qlast = d.rowbase + 31;
-        const int base = a_cur ? dp_readlane(a_endv, a_cur - 1) : 0;
-        int s0 = a_cur, s1 = a_cur, p0 = base, p1 = base;
-        int i = a_cur;
-        while (i < a_ns) {
-            const int e = dp_readlane(a_endv, i);
-            if (e > qlast) break;
-            s0 += q0 >= e ? 1 : 0;
-            p0 = q0 >= e ? e : p0;
-            s1 += q1 >= e ? 1 : 0;
-            p1 = q1 >= e ? e : p1;
-            ++i;
+        unsigned int off0 = 0, off1 = 0;
+        if (live) {
+            d.valid = 1;
+            d.sb = a_sb;
+            d.ns = a_ns;
+            d.rowbase = a_pass * 32;
+            d.nrows = a_R - d.rowbase > 32 ? 32 : a_R - d.rowbase;
+            // row q belongs to the first sample whose end (inclusive prefix) is > q: samples before a_cur ended before this pass
+            const int q0 = d.rowbase + r16, q1 = q0 + 16, qlast = d.rowbase + 31;
+            const int base = a_cur ? dp_readlane(a_endv, a_cur - 1) : 0;
+            int s0 = a_cur, s1 = a_cur, p0 = base, p1 = base;
+            int i = a_cur;
+            while (i < a_ns) {
+                const int e = dp_readlane(a_endv, i);
+                if (e > qlast) break;
+                s0 += q0 >= e ? 1 : 0;
+                p0 = q0 >= e ? e : p0;
+                s1 += q1 >= e ? 1 : 0;
+                p1 = q1 >= e ? e : p1;
+                ++i;
+            }
+            a_cur = i;
+            if (q0 < a_R) {
+                d.sj[0] = (s0 << 16) | (q0 - p0);
+                off0 = (unsigned int)(s0 * T + (q0 - p0));
+            }
+            if (q1 < a_R) {
+                d.sj[1] = (s1 << 16) | (q1 - p1);
+                off1 = (unsigned int)(s1 * T + (q1 - p1));
+            }
         }
-        a_cur = i;
+        // the loads of the step, all of them every time: the two history ids (entry 0 of the block for a lane without a row), the
+        // candidate id of lane r's sample and the NEXT block's length of lane r's sample (consumed when the cursor enters a block)
         const int64_t* const hb = hist + a_sb * T;              // wave-uniform base: the loads take a 32-bit per-lane offset
-        if (q0 < a_R) {
-            d.sj[0] = (s0 << 16) | (q0 - p0);
-            id[0] = hb[(unsigned int)(s0 * T + (q0 - p0))];
-        }
-        if (q1 < a_R) {
-            d.sj[1] = (s1 << 16) | (q1 - p1);
-            id[1] = hb[(unsigned int)(s1 * T + (q1 - p1))];
-        }
+        id[0] = hb[off0];
+        id[1] = hb[off1];
+        const long long bc = a_sb + r16;
+        cid = cand[bc < B ? bc : B - 1];
+        a_lens_next = block_len_raw(a_sb + DP_BLK);
     };
 
     // ---- state of the computation: the block's sample ends, the first unfinished sample, the open sample's online softmax --------------------
     // NORM: scores and running maximum in the log2 domain (x log2 e / sqrt K), so that a weight is one v_exp
     int c_endv = 0, c_cur = 0, c_lens = 0, c_R = 0;
+    long long c_sb_f = 0;
+    bool c_has = false;            // lane r's sample of the block being fetched has a candidate row (id >= 0): otherwise a = 0
     float m_run = -INFINITY, l_run = 0.f;
     float o[16];
 #pragma unroll
@@ -525,17 +568,19 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
     const bool hi8 = (r16 & 8) != 0, hi4 = (r16 & 4) != 0, hi2 = (r16 & 2) != 0, hi1 = (r16 & 1) != 0;
 
     auto fetch = [&](DpDesc& d, const long long (&id)[2], const long long cid, float4 (&h)[2][4]) __attribute__((always_inline)) {
-        if (!d.valid) return;   // a pass's rows; with a block's first pass its lengths and candidate rows
-        dp_load_rows(table, kk, id[0], id[1], h);
-        if (d.sj[0] >= 0 && id[0] < 0) d.sj[0] |= DP_MASKED;
-        if (d.sj[1] >= 0 && id[1] < 0) d.sj[1] |= DP_MASKED;
-        if (d.first) {
-            c_lens = r16 < d.ns ? len_of(d.sb + r16) : 0;
+        // a pass's rows; with a block's first pass its lengths and candidate rows.  (Row ids fit 32 bits: 2^31 rows of 256 bytes are 512 GB.)
+        const bool neg0 = id[0] < 0, neg1 = id[1] < 0;
+        dp_load_rows(table, kk, neg0 ? 0u : (unsigned int)id[0], neg1 ? 0u : (unsigned int)id[1], h);
+        if (d.sj[0] >= 0 && neg0) d.sj[0] |= DP_MASKED;
+        if (d.sj[1] >= 0 && neg1) d.sj[1] |= DP_MASKED;
+        if (d.first) {          // (the only loads under a branch: the LAST ones a step issues, and nothing waits before the next step's start)
+            const bool has = r16 < d.ns && cid >= 0;
+            c_lens = block_len_raw(d.sb);       // (raw: clamped at the block switch)
+            c_sb_f = d.sb;
+            const float* const pa = table + (size_t)(has ? (unsigned int)cid : 0u) * DP_K + 4 * kk;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                an[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cid >= 0) an[i] = dp_ld4(table + cid * DP_K + 16 * i + 4 * kk);
-            }
+            for (int i = 0; i < 4; ++i) an[i] = dp_ld4(pa + 16 * i);
+            c_has = has;
         }
     };
     // The open sample is complete: its pooled output.  The 16 sums over the 16 rows of a lane group by a transposing butterfly (each step
@@ -571,9 +616,16 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
     advance(dB, idB, cidB);
 
     auto step = [&](float4 (&hv)[2][4], float4 (&hvn)[2][4]) __attribute__((always_inline)) {
+        // Everything outstanding was issued at least a pass ago: one wait here, and no load this step issues is consumed before the next
+        // step's wait -- the computation below never waits for memory.
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
         if (dC.first) {
+            if (!c_has) {            // (a sample without a candidate row, or a lane beyond the block's samples: a = 0)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) an[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             // ---- a new block: its candidate rows -> the av slot; c[m] = sum_f a[f] (Wa - Wd)[f][m] + b1[m] for the 16 samples at once -> the cv slot --
-            c_endv = dp_row_scan(c_lens);
+            c_endv = dp_row_scan(block_len_of(c_sb_f, c_lens));
             c_R = dp_readlane(c_endv, 15);
             c_cur = 0;
 #pragma unroll
@@ -581,7 +633,7 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             dp_f32x4 accc[5];
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
-                const float4 c4 = dp_ld4(&sh.b1[16 * mt + 4 * kk]);
+                const float4 c4 = dp_ld4(&sh.w.b1[16 * mt + 4 * kk]);
                 accc[mt] = (dp_f32x4){c4.x, c4.y, c4.z, c4.w};
             }
 #pragma unroll
@@ -591,7 +643,7 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
 #pragma unroll
                 for (int mt = 0; mt < 5; ++mt) {
                     dp_f16x8 a[2];
-                    dp_lda(sh.wc3, ks * 5 + mt, lane4, a);
+                    dp_lda(sh.w.wc3, ks * 5 + mt, lane4, a);
                     accc[mt] = dp_mma(a, xb, accc[mt]);
                 }
             }
@@ -609,6 +661,8 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
         const int smem[2] = {(dC.sj[0] & DP_MASKED) ? -1 : srow[0], (dC.sj[1] & DP_MASKED) ? -1 : srow[1]};                  // ... -1 also for a masked position
         const int so[2] = {srow[0] < 0 ? 0 : srow[0], srow[1] < 0 ? 0 : srow[1]};
         float sc[2] = {0.f, 0.f};
+        // the wave inside its matrix work outranks its SIMD partner (whose scalar-heavy bookkeeping fills the gaps): -2.6 % at config 4
+        __builtin_amdgcn_s_setprio(1);
         if (dC.nrows > 16) {
             dp_mlp<2, ACT>(sh, actl, avs, cvs, r16, kk, so, hv, bias3, sc);
         } else if (dC.nrows > 0) {
@@ -616,6 +670,7 @@ __global__ __launch_bounds__(64 * DP_WAVES, 2) void din_pack_k(const float* __re
             dp_mlp<1, ACT>(sh, actl, avs, cvs, r16, kk, so, hv, bias3, s1_);
             sc[0] = s1_[0];
         }
+        __builtin_amdgcn_s_setprio(0);
         sc[0] *= xscale;
         sc[1] *= xscale;
         // ---- its segments: masked (online) softmax + pooling per sample; a sample that ends inside the pass is written out ------------------------
@@ -689,53 +744,64 @@ bool din_pack_covers(int K, int T, int H1, int H2) {
 }
 
 static void din_pack_chunks(int64_t B, int64_t& chunk, int& nchunk) {
-    chunk = 1024;
+    chunk = 64;                  // the range search scans one chunk per boundary: small chunks, at most 1024 of them
     while ((B + chunk - 1) / chunk > 1024) chunk *= 2;
     nchunk = (int)((B + chunk - 1) / chunk);
     if (nchunk < 1) nchunk = 1;
 }
+static int64_t round256(int64_t n) { return (n + 255) & ~(int64_t)255; }
 
+int64_t din_pack_image_bytes() { return round256((int64_t)sizeof(DpImg)); }
+
+// workspace: [chunk sums | (scores: the samples' softmax maxima / sums) | a weight image for callers that pass none]
 int64_t din_pack_workspace_bytes(int64_t B, int want_scores) {
     int64_t chunk;
     int nchunk;
     din_pack_chunks(B < 1 ? 1 : B, chunk, nchunk);
-    int64_t n = ((int64_t)nchunk * 4 + 255) & ~(int64_t)255;
-    if (want_scores) n += B * 8;
-    return n;
+    return round256((int64_t)nchunk * 4) + (want_scores ? round256(B * 8) : 0) + din_pack_image_bytes();
 }
 
-int launch_din_pack(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T, const float* W1,
-                    const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3, const float* b3, int normalize, int64_t B,
-                    float* out, float* scores, int activation, const float* act_params, void* workspace) {
+int launch_din_pack_image(hipStream_t st, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                          int activation, const float* act_params, void* image) {
+    if (activation < 0 || activation > 2 || (activation != 0 && !act_params))
+        return fail(DIR_E_UNSUPPORTED, "din_pack_image_k: activation %d (0 sigmoid, 1 PReLU, 2 Dice)", activation);
+    DpImg* img = static_cast<DpImg*>(image);
+    const dim3 grid(11), block(256);
+    if (activation == 0) hipLaunchKernelGGL(din_pack_image_k<0>, grid, block, 0, st, W1, b1, H1, W2, b2, H2, W3, act_params, img);
+    else if (activation == 1) hipLaunchKernelGGL(din_pack_image_k<1>, grid, block, 0, st, W1, b1, H1, W2, b2, H2, W3, act_params, img);
+    else hipLaunchKernelGGL(din_pack_image_k<2>, grid, block, 0, st, W1, b1, H1, W2, b2, H2, W3, act_params, img);
+    return DIR_OK;
+}
+
+int launch_din_pack(hipStream_t st, const float* table, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
+                    const void* image, const float* b3, int normalize, int64_t B, float* out, float* scores, int activation, void* workspace) {
     int64_t chunk;
     int nchunk;
     din_pack_chunks(B, chunk, nchunk);
     int* csum = static_cast<int*>(workspace);
-    float* ml = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + (((int64_t)nchunk * 4 + 255) & ~(int64_t)255));
+    float* ml = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + round256((int64_t)nchunk * 4));
     // the weight of a sample beyond its rows, in rows: what its candidate row, its share of a block's term and its output cost
     // (DIR_DIN_PACK_W0: an A/B switch read per call like DIR_DIN_ARITH; any value gives the same results up to the summation order across passes)
     const char* w0e = getenv("DIR_DIN_PACK_W0");
     const int w0 = w0e ? (atoi(w0e) < 0 ? 0 : atoi(w0e) > 64 ? 64 : atoi(w0e)) : 5;
-    typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const float*, const float*, int, const float*,
-                           const float*, int, const float*, const float*, long long, float*, float*, float*, const int*, int, long long, int,
-                           const float*);
+    typedef void (*kern_t)(const float*, const int64_t*, const int32_t*, const int64_t*, int, const DpImg*, const float*, long long, float*, float*,
+                           float*, const int*, int, long long, int);
     static const kern_t kerns[3][2][2] = {{{&din_pack_k<0, false, false>, &din_pack_k<0, false, true>}, {&din_pack_k<0, true, false>, &din_pack_k<0, true, true>}},
                                           {{&din_pack_k<1, false, false>, &din_pack_k<1, false, true>}, {&din_pack_k<1, true, false>, &din_pack_k<1, true, true>}},
                                           {{&din_pack_k<2, false, false>, &din_pack_k<2, false, true>}, {&din_pack_k<2, true, false>, &din_pack_k<2, true, true>}}};
-    if (activation < 0 || activation > 2 || (activation != 0 && !act_params))
-        return fail(DIR_E_UNSUPPORTED, "din_pack_k: activation %d (0 sigmoid, 1 PReLU, 2 Dice)", activation);
+    if (activation < 0 || activation > 2) return fail(DIR_E_UNSUPPORTED, "din_pack_k: activation %d (0 sigmoid, 1 PReLU, 2 Dice)", activation);
     static LdsOnce once[3][2][2];
     const int sco = scores ? 1 : 0, nrm = normalize ? 1 : 0;
-    const size_t shmem = ((sizeof(DpSh) + 15) & ~(size_t)15) + (activation ? sizeof(float) * DP_ACT_FLOATS : 0);
+    const size_t shmem = sizeof(DpSh);
     const kern_t kern = kerns[activation][sco][nrm];
     if (!lds_limit(once[activation][sco][nrm], (int)shmem, kern)) return fail(DIR_E_HIP, "din_pack_k: cannot reserve %zu B of LDS", shmem);
-    hipLaunchKernelGGL(din_pack_sums_k, dim3((unsigned)nchunk), dim3(256), 0, st, hist_len, T, (long long)B, (long long)chunk, w0, csum);
+    hipLaunchKernelGGL(din_pack_sums_k, dim3((unsigned)((nchunk + 3) / 4)), dim3(256), 0, st, hist_len, T, (long long)B, (long long)chunk, nchunk, w0, csum);
     const int64_t waves_wanted = (B + 1) / 2;            // a wave should see at least a couple of samples
     int64_t nwg = (waves_wanted + DP_WAVES - 1) / DP_WAVES;
     if (nwg > kCUs) nwg = kCUs;
     if (nwg < 1) nwg = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * DP_WAVES), shmem, st, table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3,
-                       (long long)B, out, scores, ml, csum, nchunk, (long long)chunk, w0, act_params);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * DP_WAVES), shmem, st, table, hist, hist_len, cand, T, static_cast<const DpImg*>(image), b3,
+                       (long long)B, out, scores, ml, csum, nchunk, (long long)chunk, w0);
     if (scores) {
         const int64_t n = B * T;
         int64_t nb = (n + 255) / 256;
@@ -748,25 +814,45 @@ int launch_din_pack(hipStream_t st, const float* table, const int64_t* hist, con
 }  // namespace dir
 
 extern "C" int64_t dir_din_pack_workspace_bytes(int64_t B, int want_scores) { return B < 0 ? 0 : dir::din_pack_workspace_bytes(B, want_scores); }
+extern "C" int64_t dir_din_pack_image_bytes(void) { return dir::din_pack_image_bytes(); }
+
+extern "C" int dir_din_pack_weights_f32(const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                                        int activation, const float* act_params, void* image, dir_stream_t stream) {
+    using namespace dir;
+    const char* name = "dir_din_pack_weights_f32";
+    if (!din_pack_covers(DP_K, 1, H1, H2)) return fail(DIR_E_UNSUPPORTED, "%s: H1 <= 80, H2 <= 48, multiples of 4 (H1=%d H2=%d)", name, H1, H2);
+    DIR_CHECK_ARG(W1 && b1 && W2 && b2 && W3 && image, "%s: null pointer", name);
+    if (!aligned16(image)) return fail(DIR_E_BADARG, "%s: image must be 16-byte aligned", name);
+    const int rc = launch_din_pack_image(as_stream(stream), W1, b1, H1, W2, b2, H2, W3, activation, act_params, image);
+    if (rc != DIR_OK) return rc;
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
 
 extern "C" int dir_din_attention_pool_packed_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand,
                                                  int T, const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2,
                                                  const float* W3, const float* b3, int normalize, int activation, const float* act_params,
-                                                 int64_t B, float* out, float* scores, void* workspace, int64_t workspace_bytes,
-                                                 dir_stream_t stream) {
+                                                 const void* image, int64_t B, float* out, float* scores, void* workspace,
+                                                 int64_t workspace_bytes, dir_stream_t stream) {
     using namespace dir;
     const char* name = "dir_din_attention_pool_packed_f32";
     DIR_CHECK_ARG(K > 0 && T > 0 && H1 > 0 && H2 > 0 && B >= 0, "%s: K=%d T=%d H1=%d H2=%d", name, K, T, H1, H2);
     if (!din_pack_covers(K, T, H1, H2))
         return fail(DIR_E_UNSUPPORTED, "%s: covers K = 64, H1 <= 80, H2 <= 48 (multiples of 4), T <= 65535 (K=%d T=%d H1=%d H2=%d)", name, K, T, H1, H2);
     if (B == 0) return DIR_OK;
-    DIR_CHECK_ARG(table && hist && cand && W1 && b1 && W2 && b2 && W3 && b3 && out && workspace, "%s: null pointer", name);
-    if (!aligned16(table) || !aligned16(workspace) || !aligned16(out))
-        return fail(DIR_E_BADARG, "%s: table / out / workspace must be 16-byte aligned", name);
+    DIR_CHECK_ARG(table && hist && cand && b3 && out && workspace && (image || (W1 && b1 && W2 && b2 && W3)), "%s: null pointer", name);
+    if (!aligned16(table) || !aligned16(workspace) || !aligned16(out) || !aligned16(image))
+        return fail(DIR_E_BADARG, "%s: table / out / workspace / image must be 16-byte aligned", name);
     const int64_t need = din_pack_workspace_bytes(B, scores != nullptr);
     if (workspace_bytes < need) return fail(DIR_E_BADARG, "%s: workspace needs %lld bytes (dir_din_pack_workspace_bytes)", name, (long long)need);
-    const int rc = launch_din_pack(as_stream(stream), table, hist, hist_len, cand, T, W1, b1, H1, W2, b2, H2, W3, b3, normalize, B, out, scores,
-                                   activation, act_params, workspace);
+    hipStream_t st = as_stream(stream);
+    if (!image) {                // no image of the caller's: one built in the workspace's tail, every call
+        void* own = static_cast<unsigned char*>(workspace) + need - din_pack_image_bytes();
+        const int rc = launch_din_pack_image(st, W1, b1, H1, W2, b2, H2, W3, activation, act_params, own);
+        if (rc != DIR_OK) return rc;
+        image = own;
+    }
+    const int rc = launch_din_pack(st, table, hist, hist_len, cand, T, image, b3, normalize, B, out, scores, activation, workspace);
     if (rc != DIR_OK) return rc;
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;

@@ -197,7 +197,7 @@ class DINAttentionPool(nn.Module):
         return ops.din_attention_pool(self.table.data, hist, hist_len, cand, self.W1.data, self.b1.data, self.W2.data,
                                       self.b2.data, self.W3.data, self.b3.data, normalize=self.normalize,
                                       want_scores=want_scores, activation=self.activation, act_params=self.act_params(),
-                                      range_of=(self.table, self.W1, self.W2, self.W3))
+                                      range_of=(self.table, self.W1, self.W2, self.W3, self.b1, self.b2))
 
 
 class DIN(nn.Module):

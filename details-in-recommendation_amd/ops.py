@@ -640,6 +640,35 @@ def din_pack_covers(K, T, H1, H2):
     return K == 64 and 1 <= T <= 65535 and 0 < H1 <= 80 and 0 < H2 <= 48 and H1 % 4 == 0 and H2 % 4 == 0
 
 
+_DIN_PACK_IMAGES = {}
+
+
+def din_pack_image(owners, args, activation, ap):
+    """The packed DIN kernel's weight image (include/dir_hip.h: dir_din_pack_weights_f32), built once per version of the weights: keyed on
+    the LONG-LIVED tensors `owners` (W1, W2, W3 -- a module's nn.Parameters; their .data views are new objects on every call) plus b1, b2
+    and the activation parameters, by identity, version and storage.  While a stream is capturing no cache is consulted or filled: the pack
+    kernel becomes part of the graph and reads the weights as they are at replay time (the rule of every per-version cache here)."""
+    import weakref
+    W1, b1, W2, b2, W3, b3 = args
+    lib = _lib.load()
+    H1, H2 = W1.shape[1], W2.shape[1]
+    watched = list(owners) + ([] if len(owners) >= 5 else [b1, b2]) + ([ap] if ap is not None else [])      # range_of may name b1 / b2's owners too
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = tuple(t.data_ptr() for t in (W1, b1, W2, b2, W3)) + (activation, ap.data_ptr() if ap is not None else 0, W1.device.index)
+    sig = tuple((id(t), t._version if not t.is_inference() else -1) for t in watched) + (_CACHE_GEN[0],)
+    hit = _DIN_PACK_IMAGES.get(key)
+    if hit is not None and not capturing and hit[0] == sig and all(r() is t for r, t in zip(hit[1], watched)):
+        return hit[2]
+    img = torch.empty(int(lib.dir_din_pack_image_bytes()), dtype=torch.uint8, device=W1.device)
+    _lib.check(lib.dir_din_pack_weights_f32(_ptr(W1), _ptr(b1), H1, _ptr(W2), _ptr(b2), H2, _ptr(W3), DIN_ACTIVATIONS[activation], _ptr(ap),
+                                            _ptr(img), _stream()))
+    if not capturing and not any(t.is_inference() for t in watched):
+        if len(_DIN_PACK_IMAGES) > 64:
+            _DIN_PACK_IMAGES.clear()
+        _DIN_PACK_IMAGES[key] = (sig, [weakref.ref(t) for t in watched], img)
+    return img
+
+
 def _din_pack_ws(device, nbytes):
     """The packed DIN kernel's workspace: one per (device, stream), grown on demand -- calls on one stream are ordered, so they may share it."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -653,7 +682,8 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
                        act_params=None, arith=None, range_of=None):
     """DIN local activation unit + pooling (include/dir_hip.h A13): -> out [B,K] (, scores [B,T]).  activation "prelu" / "dice": the
     paper's own hidden activations (dir_din_attention_pool_act_f32; act_params from din_act_params).  arith: see din_arith.
-    range_of: (table, W1, W2, W3) as the LONG-LIVED tensors whose magnitudes din_arith measures and remembers per version -- a module passes
+    range_of: (table, W1, W2, W3[, b1, b2]) as the LONG-LIVED tensors whose magnitudes din_arith measures and remembers per version (and whose
+    versions key the packed kernel's weight image) -- a module passes
     its nn.Parameters here and `.data` views as operands (a `.data` view is a new tensor object with its own version counter on every
     call: measured afresh each time, a 2.56 GB pass for the cfg-4 table)."""
     _dev(table, torch.float32, "table")
@@ -686,15 +716,16 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
             raise ValueError("DIN %s unit: act_params must hold 3 H1 + 3 H2 floats (ops.din_act_params)" % activation)
         ap = _dev(act_params.contiguous(), torch.float32, "act_params")
     rsrc = range_of if range_of is not None else (table, W1, W2, W3)
-    code = din_arith(rsrc[0], rsrc[1:], arith) if B > 0 else -1
+    code = din_arith(rsrc[0], rsrc[1:4], arith) if B > 0 else -1
     if code == DIN_ARITHS["f16x2"] and DIN_PACKED and din_pack_covers(K, T, H1, H2):
         # round 6: the packed kernel (rows of consecutive samples end to end in the MFMA tiles, a static equal-weight partition of the samples)
         lib = _lib.load()
         ws = _din_pack_ws(table.device, int(lib.dir_din_pack_workspace_bytes(B, 1 if want_scores else 0)))
+        img = din_pack_image(rsrc[1:], args, activation, ap)
         _lib.check(lib.dir_din_attention_pool_packed_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T, _ptr(args[0]), _ptr(args[1]), H1,
                                                          _ptr(args[2]), _ptr(args[3]), H2, _ptr(args[4]), _ptr(args[5]), int(bool(normalize)),
-                                                         DIN_ACTIVATIONS[activation], _ptr(ap), B, _ptr(out), _ptr(scores), _ptr(ws), ws.numel(),
-                                                         _stream()))
+                                                         DIN_ACTIVATIONS[activation], _ptr(ap), _ptr(img), B, _ptr(out), _ptr(scores), _ptr(ws),
+                                                         ws.numel(), _stream()))
         return (out, scores) if want_scores else out
     _lib.check(_lib.load().dir_din_attention_pool_arith_f32(_ptr(table), K, _ptr(hist), _ptr(hist_len), _ptr(cand), T,
                                                             _ptr(args[0]), _ptr(args[1]), H1, _ptr(args[2]), _ptr(args[3]),
@@ -906,6 +937,7 @@ def invalidate_caches():
     _DENSE_IMAGES.clear()
     _TOWER_IMAGES.clear()
     _WEIGHT_ABSMAX.clear()
+    _DIN_PACK_IMAGES.clear()
     _CACHE_GEN[0] += 1             # TableSet.absmax / ShardedTables.absmax measurements taken before this call are stale
 
 

@@ -818,14 +818,22 @@ int dir_din_attention_pool_arith_f32(const float* table, int K, const int64_t* h
  * 33), forms the per-sample term of 16 samples as one MFMA operand, and takes its samples from a STATIC equal-weight partition (no queue
  * atomics; bit for bit the same result on every run).  Same definition, arguments and outputs as dir_din_attention_pool_arith_f32 with
  * arith = DIR_DIN_ARITH_F16X2 (operands UNSCALED: the caller vouches for |table|, |W| inside fp16 x 2's window, as there), plus
+ *   image:     the unit's weights in the kernel's operand order, dir_din_pack_image_bytes() device bytes, 16-byte aligned, built by
+ *              dir_din_pack_weights_f32 -- once per weight version: every workgroup copies it into LDS instead of re-deriving it from
+ *              W1 / W2 (20 us of a 230 us launch).  NULL: the entry builds one in the workspace on every call (W1 .. W3 and act_params
+ *              are read then, and only then).
  *   workspace: dir_din_pack_workspace_bytes(B, scores != NULL) device bytes, 16-byte aligned (the partition's per-chunk weight sums; with
- *              scores also the samples' softmax maxima / sums, from which a second small kernel turns the raw scores into weights).
- * Three launches on `stream` (two without scores); graph-capturable.  No reference code (README.md:27 -> arXiv:1706.06978). */
+ *              scores also the samples' softmax maxima / sums, from which a second small kernel turns the raw scores into weights; room
+ *              for an image).
+ * Two launches on `stream` (+ 1 with scores, + 1 without an image); graph-capturable.  No reference code (README.md:27 -> arXiv:1706.06978). */
 int64_t dir_din_pack_workspace_bytes(int64_t B, int want_scores);
+int64_t dir_din_pack_image_bytes(void);
+int dir_din_pack_weights_f32(const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
+                             int activation, const float* act_params, void* image, dir_stream_t stream);
 int dir_din_attention_pool_packed_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                                       const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
-                                      const float* b3, int normalize, int activation, const float* act_params, int64_t B, float* out,
-                                      float* scores, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
+                                      const float* b3, int normalize, int activation, const float* act_params, const void* image, int64_t B,
+                                      float* out, float* scores, void* workspace, int64_t workspace_bytes, dir_stream_t stream);
 int dir_din_attention_pool_save_arith_f32(const float* table, int K, const int64_t* hist, const int32_t* hist_len, const int64_t* cand, int T,
                                           const float* W1, const float* b1, int H1, const float* W2, const float* b2, int H2, const float* W3,
                                           const float* b3, int normalize, int arith, int64_t B, float* out, float* scores,

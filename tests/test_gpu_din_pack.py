@@ -159,10 +159,52 @@ def test_packed_din_argument_errors(ops, built_lib):
     import ctypes
     lib = built_lib
     assert lib.dir_din_pack_workspace_bytes(65536, 0) >= 64 * 4 and lib.dir_din_pack_workspace_bytes(65536, 1) >= 65536 * 8
+    assert lib.dir_din_pack_image_bytes() > 79872
     p = ctypes.c_void_p(256)
-    rc = lib.dir_din_attention_pool_packed_f32(p, 32, p, p, p, 50, p, p, 80, p, p, 40, p, p, 0, 0, None, 4, p, None, p, 4096, None)
+    rc = lib.dir_din_attention_pool_packed_f32(p, 32, p, p, p, 50, p, p, 80, p, p, 40, p, p, 0, 0, None, None, 4, p, None, p, 1 << 20, None)
     assert rc == -4 and b"covers K = 64" in lib.dir_last_error()
-    rc = lib.dir_din_attention_pool_packed_f32(p, 64, p, p, p, 50, p, p, 80, p, p, 40, p, p, 0, 0, None, 4, p, None, p, 1, None)
+    rc = lib.dir_din_attention_pool_packed_f32(p, 64, p, p, p, 50, p, p, 80, p, p, 40, p, p, 0, 0, None, None, 4, p, None, p, 1, None)
     assert rc == -1 and b"workspace needs" in lib.dir_last_error()
-    rc = lib.dir_din_attention_pool_packed_f32(p, 64, p, p, p, 50, p, p, 80, p, p, 40, p, p, 0, 0, None, 4, p, None, None, 4096, None)
+    rc = lib.dir_din_attention_pool_packed_f32(p, 64, p, p, p, 50, p, p, 80, p, p, 40, p, p, 0, 0, None, None, 4, p, None, None, 1 << 20, None)
     assert rc == -1 and b"null pointer" in lib.dir_last_error()
+    rc = lib.dir_din_attention_pool_packed_f32(p, 64, p, p, p, 50, None, p, 80, p, p, 40, p, p, 0, 0, None, None, 4, p, None, p, 1 << 20, None)
+    assert rc == -1 and b"null pointer" in lib.dir_last_error()          # neither an image nor the weights to build one from
+    rc = lib.dir_din_pack_weights_f32(p, p, 84, p, p, 40, p, 0, None, p, None)
+    assert rc == -4 and b"H1 <= 80" in lib.dir_last_error()
+
+
+def test_packed_din_image_follows_the_weights(ops):
+    """The weight image is cached per version of the weights: an in-place update (a torch op, or a raw write reported through
+    ops.mark_written) rebuilds it; calling with the entry's own image (NULL) gives the same bits."""
+    import ctypes
+    from dir_amd import _lib
+    K, V, B, T, H1, H2 = 64, 5000, 257, 30, 80, 40
+    g = torch.Generator(device="cuda").manual_seed(3)
+    table = torch.randn((V, K), generator=g, device="cuda") * 0.2
+    hist = torch.randint(0, V, (B, T), generator=g, device="cuda")
+    hl = torch.randint(0, T + 1, (B,), generator=g, device="cuda", dtype=torch.int32)
+    cand = torch.randint(0, V, (B,), generator=g, device="cuda")
+    W1 = torch.randn((4 * K, H1), generator=g, device="cuda") * 0.1
+    W2 = torch.randn((H1, H2), generator=g, device="cuda") * 0.2
+    W3 = torch.randn((H2,), generator=g, device="cuda") * 0.3
+    b1, b2, b3 = torch.randn(H1, generator=g, device="cuda") * 0.1, torch.randn(H2, generator=g, device="cuda") * 0.1, torch.zeros(1, device="cuda")
+    a = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True, arith="f16x2")
+    n_img = len(ops._DIN_PACK_IMAGES)
+    a2 = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True, arith="f16x2")
+    assert torch.equal(a, a2) and len(ops._DIN_PACK_IMAGES) == n_img
+    # the entry with no image: the same bits
+    lib = _lib.load()
+    ws = torch.empty(int(lib.dir_din_pack_workspace_bytes(B, 0)), dtype=torch.uint8, device="cuda")
+    out = torch.empty((B, K), device="cuda")
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.dir_din_attention_pool_packed_f32(ptr(table), K, ptr(hist), ptr(hl), ptr(cand), T, ptr(W1), ptr(b1), H1, ptr(W2), ptr(b2), H2, ptr(W3),
+                                                     ptr(b3), 1, 0, None, None, B, ptr(out), None, ptr(ws), ws.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, a)
+    W2.mul_(1.5)                                  # a torch op bumps the version: a new image
+    b = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True, arith="f16x2")
+    assert not torch.equal(a, b)
+    W2.data.div_(1.5)                             # a raw write ...
+    ops.mark_written(W2)                          # ... reported as the fused updaters do
+    c = ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True, arith="f16x2")
+    assert float((c - a).abs().max()) <= 1e-6
