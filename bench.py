@@ -1165,17 +1165,26 @@ def main():
         b3 = torch.zeros(1, device=device)
         step = lambda i: ops.din_attention_pool(table, hist, hl, cand, W1, b1, W2, b2, W3, b3, normalize=True)  # noqa: E731
         survey = B * T * 2 * (4 * Kd * H1 + H1 * H2 + H2)   # every one of the T positions, 4K-wide layer 1 (not what is priced)
-        # what the kernel executes, and what is priced: valid history rows only (in 16-row MFMA tiles), layer 1 regrouped to a 2K
-        # reduction -> 220 v_mfma_f32_16x16x4_f32 (1024 multiply-adds each) per tile, on the fp32 MFMA pipe
-        rt = ((hl.clamp(max=T) + 15) // 16).double().sum().item()
-        executed = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)
+        # what the kernel executes, and what is priced: valid history rows only, layer 1 regrouped to a 2K reduction -> 220
+        # v_mfma_f32_16x16x4_f32 equivalents (1024 multiply-adds each) per 16 rows.  Round 6: the packed kernel (din_pack_k) lays the rows of
+        # consecutive samples end to end, so the rows are counted as they are (rows / 16 tiles; the wave-per-sample kernel -- DIR_DIN_PACKED=0,
+        # or an arithmetic other than fp16 x 2 -- pads every sample to whole tiles and is priced on those)
         din_arith = os.environ.get("DIR_DIN_ARITH") if os.environ.get("DIR_DIN_ARITH") in ("f32", "bf16x3") else "f16x2"
+        packed = ops.DIN_PACKED and din_arith == "f16x2" and not os.environ.get("DIR_DIN_ARITH")
+        rows = hl.clamp(max=T).double().sum().item()
+        rt = rows / 16.0 if packed else ((hl.clamp(max=T) + 15) // 16).double().sum().item()
+        executed = 2.0 * 1024 * rt * (4 * 32 + 4 * 8 + 3 * 20)
+        kname = "din_pack_k" if packed else "din_wave_k"
+        # SURVEY 8d's bytes: (T + 1)(4K + 8) + 4 + 4K per sample at full T; length-aware: the rows and ids the kernel reads
+        bytes_full = B * ((T + 1) * (4 * Kd + 8) + 4 + 4 * Kd)
+        bytes_len = rows * (4 * Kd + 8) + B * (4 * Kd + 8 + 4 + 4 * Kd)
         roof = {"bound": "mfma", "alg_flops": executed, "pipe_flops": executed * PIPE_COST[din_arith],
-                "kernel": "din_wave_k (%s)" % ("fp32 MFMA 16x16x4" if din_arith == "f32" else din_arith + " on MFMA 16x16x32"),
-                "modes": {"din_wave_k": din_arith}, "survey_8d_flops": survey,
+                "kernel": "%s (%s)" % (kname, "fp32 MFMA 16x16x4" if din_arith == "f32" else din_arith + " on MFMA 16x16x32"),
+                "modes": {kname: din_arith}, "survey_8d_flops": survey, "hbm_bytes_full_T": bytes_full, "hbm_bytes_length_aware": bytes_len,
                 "dtype": "f32" if din_arith == "f32" else "f32 via %s split, f32 accumulate" % din_arith,
-                "note": "flops = the MFMAs the kernel issues (masked history positions are skipped, layer 1 is regrouped to a 2K reduction); "
-                        "SURVEY 8d's all-T, 4K-wide count is reported as survey_8d_flops and not priced"}
+                "note": "flops = the MFMAs of the valid history rows (masked positions are skipped, layer 1 is regrouped to a 2K reduction); "
+                        "SURVEY 8d's all-T, 4K-wide count is reported as survey_8d_flops and not priced; hbm_frac = SURVEY 8d's 13 724 B per "
+                        "sample (full T) / ms_per_step / 8 TB/s, hbm_frac_length_aware on the rows actually read"}
         cfg.update({"T": T, "dim": Kd, "vocab": Vd, "mlp": [4 * Kd, H1, H2, 1]})
     elif wl == "din_full":
         # BASELINE configs[3] as a whole model (dir_amd.din.DIN; paper-derived, README.md:27): behaviour sequence T 50 + candidate through the
@@ -1568,6 +1577,11 @@ def main():
             for k in ("modes", "note", "survey_8d_flops"):
                 if k in roof:
                     res["roofline"][k] = roof[k]
+            if "hbm_bytes_full_T" in roof:        # the DIN unit: SURVEY 8d's bytes beside the matrix-pipe share
+                res["roofline"]["hbm_frac"] = roof["hbm_bytes_full_T"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                res["roofline"]["hbm_frac_length_aware"] = roof["hbm_bytes_length_aware"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                res["roofline"]["hbm_bytes_full_T"] = roof["hbm_bytes_full_T"]
+                res["roofline"]["hbm_bytes_length_aware"] = roof["hbm_bytes_length_aware"]
             if "dtype" in roof:
                 res["dtype"] = roof["dtype"]
         res["roofline"]["clock"] = "host clock over the timed region (the one ms_per_step and value use)"

@@ -116,9 +116,6 @@ __device__ __forceinline__ dp_f32x4 dp_mma(const dp_f16x8 (&a)[2], const dp_f16x
     return c;
 }
 __device__ __forceinline__ void dp_lda(const unsigned int* img, int tile, int lane4, dp_f16x8 (&a)[2]) {
-#ifdef DP_ABL_LDS      // timing ablation (WRONG results): every weight operand is the image's first tile, which the compiler reads once per pass
-    tile = 0;
-#endif
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc) a[pc] = __builtin_bit_cast(dp_f16x8, *reinterpret_cast<const dp_u32x4*>(img + (tile * 2 + pc) * 256 + lane4));
 }

@@ -1102,8 +1102,14 @@ def test_din_saved_activations_edges(built_lib):
         gout = torch.randn(B, K, generator=g).cuda()
         for normalize in (True, False):
             out, sc, saved = ops.din_attention_pool_save(table, hist, hl, cand, *Ws, normalize=normalize)
-            out0, sc0 = ops.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, want_scores=True)
+            packed, ops.DIN_PACKED = ops.DIN_PACKED, False          # the inference form of the SAME kernel (din_wave_k): bit for bit
+            try:
+                out0, sc0 = ops.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, want_scores=True)
+            finally:
+                ops.DIN_PACKED = packed
             assert torch.equal(out, out0) and torch.equal(sc, sc0)
+            outp, scp = ops.din_attention_pool(table, hist, hl, cand, *Ws, normalize=normalize, want_scores=True)     # round 6: the packed kernel (another summation order)
+            assert float((outp - out).abs().max()) <= 2e-6 * (1 + float(out.abs().max())) and float((scp - sc).abs().max()) <= 2e-6 * (1 + float(sc.abs().max()))
             assert saved[0].n_tiles == int(((hl.clamp(0, T).long() + 15) // 16).sum())
             ref = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=sc0)
             got = ops.din_attention_pool_backward(table, hist, hl, cand, *Ws, gout, normalize=normalize, scores=sc, saved=saved)
