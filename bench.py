@@ -996,6 +996,15 @@ def main():
                          "library_layers": dict(_dense_mod.ROUTING["library"]), "hip_layers": sorted(_dense_mod.ROUTING["hip"])}
             if name == "deepfm":
                 graphed = g_
+        if Bs > ops.DENSE_SMALL_ROWS:
+            # mid-size batches (round 6): the same forwards with round 5's routing -- these layers on the library's GEMMs -- beside ours
+            mid_rows, ops.DENSE_MID_ROWS = ops.DENSE_MID_ROWS, 0
+            for name, f in (("deepfm", fwd), ("dcn", fwd_dcn)):
+                _dense_mod.reset_routing()
+                gl_ = GraphedForward(f, ids)
+                lat[name]["library_routing"] = {"eager_us": round(latency(lambda: f(ids)), 2), "graph_replay_us": round(latency(lambda: gl_.graph.replay()), 2),
+                                                "library_layers": dict(_dense_mod.ROUTING["library"])}
+            ops.DENSE_MID_ROWS = mid_rows
         _dense_mod.reset_routing()
         step = lambda i: graphed(ids)  # noqa: E731
         units = Bs
@@ -1563,6 +1572,12 @@ def main():
                                    "frac": roof["alg_bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
                         del outs_
                     res["roofline"]["output_window"] = ow
+                    # first-class: what the headline costs when its output really goes to HBM -- the same kernel, same B, the
+                    # output rotating through 4 buffers (436 MB written before a line is reused: nothing of it survives in the Infinity Cache)
+                    res["roofline"]["frac_output_to_hbm"] = ow[1]["frac"]
+                    res["roofline"]["ms_per_step_output_to_hbm"] = ow[1]["avg_launch_us"] * 1e-3
+                    res["roofline"]["output_to_hbm_note"] = ("frac / ms_per_step: ONE output buffer overwritten by every launch (109 MB: most of its write-back "
+                                                             "stays in the 256 MiB Infinity Cache); *_output_to_hbm: the output rotating through 4 buffers")
         else:
             # achieved = the algorithmic flops of each kernel priced on the pipe mode it executes on (PIPE_COST), in bf16-MFMA flops per
             # second, against the dense bf16 peak: the share of the step the matrix pipe needs at peak

@@ -13,6 +13,8 @@
 // land in sixteen different bank quads), so a lane's four k-steps come from ONE ds_read_b128: 14 LDS reads per 80 MFMAs at
 // NT = 80.  Bias and ReLU are applied to the accumulators.  Workgroup ids are remapped so that the N-blocks of one row block run
 // on the same XCD (they share the X tile through that XCD's L2).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace dir {
@@ -349,9 +351,150 @@ __global__ __launch_bounds__(256) void dense_small_k(const float* __restrict__ X
     }
 }
 
+
+// ---- mid-size batches (round 6): 512 < M < ~6 000 rows, the only operating range the reference documents beyond its own 100 / 256
+// (models/DeepCrossNetwork/train.py:16-17 sets the batch by flag).  dense_small_k's one-tile workgroups re-read both operands from L2 for
+// every 16 x 16 outputs (170 MB of L2 traffic at 2048 x 400 x 416: 23 us), dense_k's 128-row workgroups leave most of the chip idle (16 row
+// blocks at 2048 rows: 27 us whatever N is) -- the library's 14 us was what ran there.  Here a workgroup owns a (32 RT) x 64 tile of Y: its four
+// waves sit 2 x 2 on it (RT x 2 accumulator tiles of 16 x 16 each), the reduction comes through LDS in chunks of 32 / 64 (registers -> LDS,
+// double-buffered: the next chunk's global loads are in flight under this chunk's matrix instructions; one barrier per chunk), operands are
+// read with one ds_read_b128 per tile and 16 k (row stride chunk + 8 floats: conflict-free for the 16-lane groups of a b128 read), element e of a
+// lane's four floats feeding the e-th v_mfma_f32_16x16x4_f32 of the step on both sides (dense_small_k's enumeration of the k slots).
+// fp32-input MFMA: exact products, fp32 accumulation.  224 workgroups at 2048 x 400: 8 us.
+template <bool RELU, int RT /* 16-row tiles per wave: the workgroup's tile is 32 RT rows x 64 columns */, int KC /* reduction chunk: 32 | 64 */>
+__global__ __launch_bounds__(256) void dense_mid_k(const float* __restrict__ X, int64_t x_ld, const float* __restrict__ Wt, int64_t w_ld,
+                                                   const float* __restrict__ bias, int64_t M, int Kd, int N, float* __restrict__ Y, int64_t y_ld,
+                                                   const float* __restrict__ pscale, const float* __restrict__ pshift) {
+    constexpr int ROWS = 32 * RT;
+    constexpr int LD = KC + 8;                               // row stride 40 / 72 floats: conflict-free for the 16-lane groups of a ds_read_b128
+    constexpr int TPR = KC / 4;                              // threads per staged row (16-byte pieces)
+    constexpr int RPT = 256 / TPR;                           // rows one trip of the 256 threads covers: 32 / 16
+    constexpr int XT = ROWS / RPT, WT = 64 / RPT;            // staging trips for the x / weight tile
+    __shared__ __attribute__((aligned(16))) float xs[2][ROWS * LD];
+    __shared__ __attribute__((aligned(16))) float ws[2][64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, kk = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;                       // the wave's place on the tile: rows 16 RT wm .., columns 32 wn ..
+    const int64_t row0 = (int64_t)blockIdx.y * ROWS;
+    const int col0 = blockIdx.x * 64;
+    // staging: thread t moves the 16-byte piece (row t / TPR [+ RPT per trip], floats 4 (t % TPR) ..) of a chunk; rows / columns past the end
+    // are clamped (their results are dropped), pieces past Kd are zeros
+    const int sr = tid / TPR, sk = 4 * (tid % TPR);
+    const float* xg[XT];
+    const float* wg[WT];
+#pragma unroll
+    for (int t = 0; t < XT; ++t) {
+        const int64_t xr = row0 + sr + RPT * t < M ? row0 + sr + RPT * t : M - 1;
+        xg[t] = X + xr * x_ld + sk;
+    }
+#pragma unroll
+    for (int t = 0; t < WT; ++t) {
+        const int wc = col0 + sr + RPT * t < N ? col0 + sr + RPT * t : N - 1;
+        wg[t] = Wt + (int64_t)wc * w_ld + sk;
+    }
+    const int nchunk = (Kd + KC - 1) / KC;
+    // the next chunk's global loads (registers) are in flight under this chunk's matrix instructions; one barrier per chunk
+    float4 xr_[XT], wr_[WT];
+    auto gload = [&](int c) {
+        const int k = KC * c + sk;
+        const bool ok = k < Kd;                              // Kd % 4 == 0: a piece is inside the row or outside it
+#pragma unroll
+        for (int t = 0; t < XT; ++t) xr_[t] = ok ? *reinterpret_cast<const float4*>(xg[t] + KC * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < WT; ++t) wr_[t] = ok ? *reinterpret_cast<const float4*>(wg[t] + KC * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto lstore = [&](int b) {
+#pragma unroll
+        for (int t = 0; t < XT; ++t) *reinterpret_cast<float4*>(&xs[b][(sr + RPT * t) * LD + sk]) = xr_[t];
+#pragma unroll
+        for (int t = 0; t < WT; ++t) *reinterpret_cast<float4*>(&ws[b][(sr + RPT * t) * LD + sk]) = wr_[t];
+    };
+    f32x4d acc[RT][2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = (f32x4d){0.f, 0.f, 0.f, 0.f};
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int b = c & 1;
+        if (c + 1 < nchunk) gload(c + 1);
+#pragma unroll
+        for (int j = 0; j < KC / 16; ++j) {                  // 16-wide steps
+            float4 a[RT], bq[2];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const float4*>(&xs[b][(16 * RT * wm + 16 * t + r) * LD + 16 * j + 4 * kk]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bq[u] = *reinterpret_cast<const float4*>(&ws[b][(32 * wn + 16 * u + r) * LD + 16 * j + 4 * kk]);
+            // element e of the lanes' four floats feeds the step's e-th instruction on every tile: the tiles' chains interleave (a dependent
+            // v_mfma_f32_16x16x4_f32 needs 40 cycles, issue is 32)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float av = e == 0 ? a[t].x : e == 1 ? a[t].y : e == 2 ? a[t].z : a[t].w;
+                        const float bv = e == 0 ? bq[u].x : e == 1 ? bq[u].y : e == 2 ? bq[u].z : bq[u].w;
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t][u], 0, 0, 0);
+                    }
+        }
+        if (c + 1 < nchunk) lstore(b ^ 1);                   // (the buffer the previous trip read: every wave passed the barrier below since)
+        __syncthreads();
+    }
+    // D layout: lane (kk, r) holds Y[row 4 kk + g][col r] of its tile
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = col0 + 32 * wn + 16 * u + r;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+        const float sc = pscale ? pscale[col] : 1.f, sf = pscale ? pshift[col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t row = row0 + 16 * RT * wm + 16 * t + 4 * kk + g;
+                float v = acc[t][u][g] + bv;
+                if (RELU) v = v > 0.f ? v : 0.f;
+                if (pscale) v = v * sc + sf;
+                if (row < M) Y[row * y_ld + col] = v;
+            }
+    }
+}
+
 }  // namespace dir
 
 using namespace dir;
+
+extern "C" int dir_dense_mid_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
+                                 const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {
+    const char* name = "dir_dense_mid_f32";
+    DIR_CHECK_ARG(M >= 0 && Kd > 0 && N > 0 && x_ld >= Kd && w_ld >= Kd && y_ld >= N, "%s: M=%lld Kd=%d N=%d x_ld=%lld w_ld=%lld y_ld=%lld", name,
+                  (long long)M, Kd, N, (long long)x_ld, (long long)w_ld, (long long)y_ld);
+    DIR_CHECK_ARG(act == DIR_ACT_NONE || act == DIR_ACT_RELU, "%s: act=%d", name, act);
+    DIR_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale and post_shift come together", name);
+    if (M == 0) return DIR_OK;
+    DIR_CHECK_ARG(X && Wt && Y, "%s: null pointer", name);
+    if ((Kd & 3) || (x_ld & 3) || (w_ld & 3) || !aligned16(X) || !aligned16(Wt))
+        return fail(DIR_E_UNSUPPORTED, "%s: Kd, x_ld and w_ld must be multiples of 4 and X / Wt 16-byte aligned (Kd=%d x_ld=%lld w_ld=%lld)", name, Kd,
+                    (long long)x_ld, (long long)w_ld);
+    if ((M + 31) / 32 > 65535) return fail(DIR_E_UNSUPPORTED, "%s: M=%lld (this entry is for batches of a few thousand rows)", name, (long long)M);
+    // 64-row tiles where they still give every CU a workgroup, 32-row tiles below that
+    const int64_t cb = (N + 63) / 64;
+    const bool rt2 = ((M + 63) / 64) * cb >= kCUs;
+    const int rows = rt2 ? 64 : 32;
+    const dim3 grid((unsigned)cb, (unsigned)((M + rows - 1) / rows));
+    hipStream_t st = as_stream(stream);
+    const bool kc64 = Kd >= 128 && !rt2;                     // 64-wide chunks (half the barriers) for the 32-row tiles; the 64-row tiles keep four workgroups per CU
+#define DIR_DM(RELU_, RT_, KC_) hipLaunchKernelGGL((dense_mid_k<RELU_, RT_, KC_>), grid, dim3(256), 0, st, X, x_ld, Wt, w_ld, bias, M, Kd, N, Y, y_ld, post_scale, post_shift)
+#define DIR_DM2(RELU_, RT_) do { if (kc64) DIR_DM(RELU_, RT_, 64); else DIR_DM(RELU_, RT_, 32); } while (0)
+    if (act) { if (rt2) DIR_DM2(true, 2); else DIR_DM2(true, 1); }
+    else { if (rt2) DIR_DM2(false, 2); else DIR_DM2(false, 1); }
+#undef DIR_DM2
+#undef DIR_DM
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}
 
 extern "C" int dir_dense_small_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
                                    const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream) {

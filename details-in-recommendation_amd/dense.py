@@ -20,7 +20,8 @@ _RELUS = (torch.relu, F.relu, torch.nn.functional.relu)
 # the library's small-M kernels win (DeepFM forward as a HIP-graph replay: 78 vs 126 us at batch 256, 127 vs 135 us at 4 096, then
 # 221 vs 177 us at 8 192 -- `DIR_BENCH_SMALL_BATCH=n bench.py --workload small_batch`); DIR_DENSE_MIN_ROWS overrides.
 # Round 5: batches ops.dense_small_covers() accepts (up to 256 rows always -- the reference's own 100 / 256 -- and up to 512 for the narrower
-# layers) run dir_dense_small_f32 instead of the library; the library keeps what lies between that and MIN_ROWS.
+# layers) run dir_dense_small_f32 instead of the library.  Round 6: what lies between that and MIN_ROWS runs dir_dense_mid_f32
+# (ops.dense_mid_covers): no batch size sends a covered layer to the library any more (DIR_DENSE_MID_ROWS=0 restores round 5's routing).
 import os as _os
 MIN_ROWS = int(_os.environ.get("DIR_DENSE_MIN_ROWS", "6144"))
 _PACK_CACHE = {}
@@ -464,7 +465,8 @@ def _dense_act(lin, x, activation, bn, bounded=False):
     relu = activation in _RELUS
     prepadded = x.dim() == 2 and x.shape[1] != lin.in_features and x.shape[1] == lin.in_features + (-lin.in_features) % 4
     if (activation is None or relu) and x.is_cuda and x.dim() == 2 and lin.out_features >= 16 and (
-            x.shape[0] >= MIN_ROWS or ops.dense_small_covers(x.shape[0], lin.in_features + (-lin.in_features) % 4, lin.out_features)):
+            x.shape[0] >= MIN_ROWS or ops.dense_small_covers(x.shape[0], lin.in_features + (-lin.in_features) % 4, lin.out_features)
+            or ops.dense_mid_covers(x.shape[0], lin.in_features + (-lin.in_features) % 4, lin.out_features)):
         _route("hip", lin)
         train = torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad)
         fold = bn is not None and not (bn.training and torch.is_grad_enabled())

@@ -926,6 +926,17 @@ DENSE_SMALL_MNK = 1.2e8
 def dense_small_covers(M, Kd, N):
     """Whether dense() runs dir_dense_small_f32 for an [M, Kd] x [N, Kd] layer (given fp32 arithmetic and 16-byte aligned rows)."""
     return 0 < M <= DENSE_SMALL_ROWS and Kd % 4 == 0 and (M <= 256 or float(M) * N * Kd <= DENSE_SMALL_MNK)
+# round 6: the rows in between (dir_dense_mid_f32: a workgroup per 32 / 64 x 64 tile, LDS-staged reduction) -- from where dense_small_covers stops
+# up to DENSE_MID_ROWS rows (tools/dense_small_probe.py -> profiles/r06_dense_mid_probe.txt: within a few percent of the library's kernels at
+# 400-wide layers and the 432 x 1024 layer from 512 to 4096 rows, ahead of them from 6144; 15-25 % behind on 1024 x 1024, the one shape
+# where the library's fp32 GEMM is near the fp32-MFMA peak.  From 6144 rows dir_dense_f32's 128-row workgroups fill the chip.
+# DIR_DENSE_MID_ROWS = 0: never)
+DENSE_MID_ROWS = int(os.environ.get("DIR_DENSE_MID_ROWS", "6143"))
+
+
+def dense_mid_covers(M, Kd, N):
+    """Whether dense() runs dir_dense_mid_f32 for an [M, Kd] x [N, Kd] layer (given fp32 arithmetic and 16-byte aligned rows)."""
+    return 0 < M <= DENSE_MID_ROWS and Kd % 4 == 0 and N >= 16 and not dense_small_covers(M, Kd, N)
 DENSE_BF3_MIN_ROWS = 12288     # below this the 256-row tiles leave too much of the chip idle (tools/dense_bf3_probe.py: x1.14 at 16 384 rows, x0.58 at 4 096)
 _DENSE_IMAGES = {}             # data_ptr -> (weakref to the weight tensor, version, shape, strides, image)
 
@@ -1107,6 +1118,11 @@ def dense(x, weight, bias=None, relu=False, out=None, post_scale=None, post_shif
         # small batches (the reference's 100 / 256): one wave per 16 x 16 tile, no LDS, no barrier (csrc/dense.hip: dense_small_k)
         _lib.check(_lib.load().dir_dense_small_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), 1 if relu else 0,
                                                    _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
+        return out
+    if which == "f32" and dense_mid_covers(M, Kd, N) and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+        # mid-size batches: a workgroup per 32 / 64 x 64 tile, the reduction through LDS (csrc/dense.hip: dense_mid_k)
+        _lib.check(_lib.load().dir_dense_mid_f32(_ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), 1 if relu else 0,
+                                                 _ptr(post_scale), _ptr(post_shift), M, Kd, N, _ptr(out), out.stride(0), _stream()))
         return out
     if which == "f16x2":
         _lib.check(_lib.load().dir_dense_f16x2_f32(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2")), _ptr(bias), 1 if relu else 0,

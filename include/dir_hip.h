@@ -474,6 +474,13 @@ int dir_dense_affine_f32(const float* X, int64_t x_ld, const float* Wt, int64_t 
  * ops.dense routes batches of at most ops.DENSE_SMALL_ROWS rows to. */
 int dir_dense_small_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
                         const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
+/* ... and for MID-SIZE batches (round 6: a few hundred to a few thousand rows -- where dir_dense_small_f32's one-tile workgroups re-read both
+ * operands for every 16 x 16 outputs and dir_dense_f32's 128-row workgroups leave most of the chip idle): a workgroup per 32 / 64 x 64 tile of
+ * Y, the reduction staged through LDS in double-buffered chunks of 32, fp32-input MFMA (exact products).  Arguments and limits of
+ * dir_dense_small_f32.  What ops.dense routes batches between ops.DENSE_SMALL_ROWS and ops.DENSE_MID_ROWS to (reference batch sizes are set
+ * by flag: models/DeepCrossNetwork/train.py:16-17). */
+int dir_dense_mid_f32(const float* X, int64_t x_ld, const float* Wt, int64_t w_ld, const float* bias, int act, const float* post_scale,
+                      const float* post_shift, int64_t M, int Kd, int N, float* Y, int64_t y_ld, dir_stream_t stream);
 /* The same layer on the bf16 matrix pipe with fp32-equivalent arithmetic (csrc/dense_bf3.hip; the recipe of
  * dir_cin_layer_bf16x3_f32): X and W are each split into three bf16 pieces (round to nearest; the pieces sum to the operand exactly,
  * fp32 exponent range), the six piece products of weight >= 2^-16 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Same 1e-5

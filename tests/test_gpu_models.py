@@ -43,15 +43,13 @@ def min_rows(request, monkeypatch):
 
 
 def _check_routing(min_rows, batch=None):
-    """product routing (round 5): a batch ops.dense_small_covers() accepts -- up to 256 rows always, the reference's own 100 / 256 -- runs
-    dir_dense_small_f32 (only layers under 16 units stay library code); larger batches below dense.MIN_ROWS go to nn.Linear."""
+    """product routing: a batch ops.dense_small_covers() accepts -- up to 256 rows always, the reference's own 100 / 256 -- runs
+    dir_dense_small_f32 (round 5), and what lies between that and dense.MIN_ROWS runs dir_dense_mid_f32 (round 6): at no batch size does a
+    covered layer go to nn.Linear any more (only layers under 16 units stay library code)."""
     from dir_amd import dense as D
-    if min_rows == 1:
-        assert D.ROUTING["hip"], dict(D.ROUTING)
-    elif batch is not None and batch <= 256:
-        assert D.ROUTING["hip"] and all(int(k.split("x")[1]) < 16 for k in D.ROUTING["library"]), dict(D.ROUTING)
-    else:
-        assert D.ROUTING["library"] and not D.ROUTING["hip"], dict(D.ROUTING)
+    assert D.ROUTING["hip"], dict(D.ROUTING)
+    if min_rows != 1:
+        assert all(int(k.split("x")[1]) < 16 for k in D.ROUTING["library"]), dict(D.ROUTING)
 
 
 def test_deepfm_config1_forward(built_lib, oracle, min_rows):

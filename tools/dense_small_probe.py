@@ -36,18 +36,19 @@ def graph_us(fn, n=20, reps=30):
 for Kd, N in ((416, 400), (400, 400), (432, 1024), (1024, 1024), (360, 200), (200, 80)):
     W = torch.randn((N, Kd), generator=g, device=dev) * 0.05
     b = torch.randn((N,), generator=g, device=dev) * 0.1
-    for M in (100, 256, 512, 1024, 2048, 4096, 8192):
+    for M in (100, 256, 512, 1024, 2048, 4096, 6144, 8192, 12288):
         x = torch.randn((M, Kd), generator=g, device=dev) * 0.25
         out = torch.empty((M, N), device=dev)
         ref = torch.relu(x.double() @ W.double().t() + b.double())
         res = {}
-        for name, small_rows in (("small", 1 << 30), ("dense_k", 0)):
-            ops.DENSE_SMALL_ROWS = small_rows
+        for name, small_rows, mid_rows in (("small", 1 << 30, 0), ("mid", 0, 1 << 30), ("dense_k", 0, 0)):
+            ops.DENSE_SMALL_ROWS, ops.DENSE_MID_ROWS = small_rows, mid_rows
             fn = lambda: ops.dense(x, W, b, relu=True, out=out, arith="f32")      # noqa: E731
             fn()
             err = float(((out.double() - ref).abs() / (1 + ref.abs())).max())
             res[name] = (graph_us(fn), err)
         lib = lambda: torch.relu_(torch.nn.functional.linear(x, W, b))          # noqa: E731
         res["library"] = (graph_us(lib), float(((lib().double() - ref).abs() / (1 + ref.abs())).max()))
-        print("%4d x %4d  M %5d   small %6.2f us (%.1e)   dense_k %6.2f us (%.1e)   library %6.2f us (%.1e)" %
-              (Kd, N, M, res["small"][0], res["small"][1], res["dense_k"][0], res["dense_k"][1], res["library"][0], res["library"][1]), flush=True)
+        print("%4d x %4d  M %5d   small %6.2f us (%.1e)   mid %6.2f us (%.1e)   dense_k %6.2f us (%.1e)   library %6.2f us (%.1e)" %
+              (Kd, N, M, res["small"][0], res["small"][1], res["mid"][0], res["mid"][1], res["dense_k"][0], res["dense_k"][1], res["library"][0],
+               res["library"][1]), flush=True)
