@@ -36,10 +36,11 @@ typedef unsigned int tw_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* tw_lds_ptr;
 typedef const __attribute__((address_space(1))) void* tw_glb_ptr;
 
-#ifndef TW_NW
-#define TW_NW 8            // waves per workgroup: 8 = one 512-thread workgroup per CU, 4 = two 256-thread workgroups with barriers of their own
-#endif
-constexpr int TW_ROWS = 16 * TW_NW;      // rows per workgroup (TW_NW waves x 16)
+// Round 6: RT row tiles of 16 per wave.  RT = 1: eight waves of 16 rows (two per SIMD, <= 256 registers each); RT = 2: FOUR waves of 32 rows
+// (one per SIMD, the whole 512-register file): a weight piece read from LDS feeds the matrix instructions of two row tiles, so the
+// workgroup reads HALF the LDS bytes per row (VERDICT r5 item 3's experiment; measured SLOWER, see tower_launch: kept as an A/B switch).  A
+// workgroup is 128 rows either way.
+constexpr int TW_ROWS = 128;      // rows per workgroup
 constexpr int TW_NT = 26;         // column tiles of 16: widths up to 416
 constexpr int TW_ST = 13;         // column tiles per stage (one LDS buffer: 3 pieces x 13 KB)
 constexpr int TW_MAXL = 4;
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(256) void tower_bf3_pack_k(const float* __restrict_
 // consumers ride along in the order the gather kernel uses, so the logit is bit for bit the two-launch path's: the FM second-order term
 // 0.5 sum_k ((sum_f e)^2 - sum_f e^2) (field sums f-ascending, then k-ascending across the row's four lanes) and the first-order term
 // sum_f w_f + bias (f-ascending), both added to the head's logit in the epilogue.  The 109 MB concat is never written or read.
-template <bool GATHER, int NP = 3>
-__global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p) {
+template <bool GATHER, int NP = 3, int RT = 1>
+__global__ __launch_bounds__(512 / RT, RT == 1 ? 2 : 1) void tower_bf3_k(const TowerParams p) {
+    constexpr int TW_NW = 8 / RT;             // waves per workgroup
     constexpr int BUFB = tw_bufb(NP);
     extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];      // [2][TW_BUFB]: the W image of one stage
     const int tid = threadIdx.x;
@@ -179,12 +181,18 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
             }
     };
 
-    tw_f32x4 act[TW_NT], acc[TW_NT];
+    tw_f32x4 act[RT][TW_NT], acc[RT][TW_NT];
     int buf = 0;
     stage(0, 0, 0, 0);
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t r = t * TW_ROWS + wave * 16 + r16;
-        float fm_r = 0.f, lin_r = 0.f;                 // GATHER: the row's FM and first-order terms, both valid in lane group g == 0
+        int64_t rrow[RT];
+        float fm_r[RT], lin_r[RT];                     // GATHER: the rows' FM and first-order terms, both valid in lane group g == 0
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+        const int64_t r = t * TW_ROWS + (wave * RT + rt) * 16 + r16;
+        rrow[rt] = r;
+        fm_r[rt] = 0.f;
+        lin_r[rt] = 0.f;
         if constexpr (GATHER) {
             const int64_t rr = r < p.M ? r : p.M - 1;
             const int64_t* idp = p.ids + rr * p.ids_sb;
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
                         if (g == 0 && p.lin_col >= 0) lw = t[p.lin_col];
                     }
                 }
-                act[ct] = v;
+                act[rt][ct] = v;
                 sum += v;                              // f-ascending fp32 sums, as gather_packed_rows_k
                 sq += v * v;
                 lin = lin + lw;
@@ -217,14 +225,15 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
                     const float carry = __shfl(acc_fm, r16 + 16 * (cc > 0 ? cc - 1 : 0), 64);
                     if (g == cc) acc_fm = ((((cc == 0 ? 0.f : carry) + d[0]) + d[1]) + d[2]) + d[3];
                 }
-                fm_r = __shfl(0.5f * acc_fm, r16 + 48, 64);
+                fm_r[rt] = __shfl(0.5f * acc_fm, r16 + 48, 64);
             }
-            lin_r = lin + (p.lin_bias ? p.lin_bias[0] : 0.f);
+            lin_r[rt] = lin + (p.lin_bias ? p.lin_bias[0] : 0.f);
         } else {   // X -> act, accumulator layout: register e of tile ct = X[row][16*ct + 4*g + e] (Kd % 4 == 0: a piece is in or out)
             const float* xr = p.X + (r < p.M ? r : p.M - 1) * p.x_ld + 4 * g;
 #pragma unroll
             for (int ct = 0; ct < TW_NT; ++ct)
-                act[ct] = 16 * ct + 4 * g < p.Kd ? *reinterpret_cast<const tw_f32x4*>(xr + 16 * ct) : (tw_f32x4){0.f, 0.f, 0.f, 0.f};
+                act[rt][ct] = 16 * ct + 4 * g < p.Kd ? *reinterpret_cast<const tw_f32x4*>(xr + 16 * ct) : (tw_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first stage's W pieces (issued before the loop / by the previous tile)
         __syncthreads();
@@ -236,16 +245,19 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
             const int nstg = nct > TW_ST ? 2 : 1;
             const bool last = l + 1 == p.L;
 #pragma unroll
-            for (int ct = 0; ct < TW_NT; ++ct) acc[ct] = (tw_f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < TW_NT; ++ct) acc[rt][ct] = (tw_f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
             for (int ks = 0; ks < TW_NT / 2; ++ks) {
                 if (ks < nks) {                                   // workgroup-uniform
                     // this k-step's B operands: the 4 registers of input tiles 2ks and 2ks+1, split three ways
                     using op_t = typename TwPc<NP>::op_t;
-                    op_t xa[NP];
-                    {
-                        const tw_f32x4 a0 = act[2 * ks], a1 = act[2 * ks + 1];
+                    op_t xa[RT][NP];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const tw_f32x4 a0 = act[rt][2 * ks], a1 = act[rt][2 * ks + 1];
                         const float av[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                         unsigned int w[NP][4];
 #pragma unroll
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
                             for (int pc = 0; pc < NP; ++pc) w[pc][pr] = pw[pc];
                         }
 #pragma unroll
-                        for (int pc = 0; pc < NP; ++pc) xa[pc] = __builtin_bit_cast(op_t, (tw_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
+                        for (int pc = 0; pc < NP; ++pc) xa[rt][pc] = __builtin_bit_cast(op_t, (tw_u32x4){w[pc][0], w[pc][1], w[pc][2], w[pc][3]});
                     }
 #pragma unroll
                     for (int st = 0; st < 2; ++st) {
@@ -293,11 +305,14 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
                                     __builtin_amdgcn_sched_barrier(0);
                                     const tw_f16x8 w0 = __builtin_bit_cast(tw_f16x8, wq[cs & 1][0]);
                                     const tw_f16x8 w1 = __builtin_bit_cast(tw_f16x8, wq[cs & 1][1]);
-                                    tw_f32x4 tt = acc[st * TW_ST + cs];
-                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa[0], tt, 0, 0, 0);      // the three products, smallest first
-                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[1], tt, 0, 0, 0);
-                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[0], tt, 0, 0, 0);
-                                    acc[st * TW_ST + cs] = tt;
+#pragma unroll
+                                    for (int rt = 0; rt < RT; ++rt) {
+                                        tw_f32x4 tt = acc[rt][st * TW_ST + cs];
+                                        tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xa[rt][0], tt, 0, 0, 0);      // the three products, smallest first
+                                        tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[rt][1], tt, 0, 0, 0);
+                                        tt = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, xa[rt][0], tt, 0, 0, 0);
+                                        acc[rt][st * TW_ST + cs] = tt;
+                                    }
                                     __builtin_amdgcn_sched_barrier(0);
                                 }
                             } else {
@@ -318,14 +333,17 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
                                 const tw_bf16x8 w0 = __builtin_bit_cast(tw_bf16x8, wq[cs & 1][0]);
                                 const tw_bf16x8 w1 = __builtin_bit_cast(tw_bf16x8, wq[cs & 1][1]);
                                 const tw_bf16x8 w2 = __builtin_bit_cast(tw_bf16x8, wq[cs & 1][2]);
-                                tw_f32x4 tt = acc[st * TW_ST + cs];
-                                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa[2], tt, 0, 0, 0);
-                                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xa[0], tt, 0, 0, 0);
-                                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xa[1], tt, 0, 0, 0);
-                                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa[1], tt, 0, 0, 0);
-                                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xa[0], tt, 0, 0, 0);
-                                tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa[0], tt, 0, 0, 0);
-                                acc[st * TW_ST + cs] = tt;
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt) {
+                                    tw_f32x4 tt = acc[rt][st * TW_ST + cs];
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa[rt][2], tt, 0, 0, 0);
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xa[rt][0], tt, 0, 0, 0);
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xa[rt][1], tt, 0, 0, 0);
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa[rt][1], tt, 0, 0, 0);
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xa[rt][0], tt, 0, 0, 0);
+                                    tt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xa[rt][0], tt, 0, 0, 0);
+                                    acc[rt][st * TW_ST + cs] = tt;
+                                }
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             }
@@ -343,11 +361,14 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
             const float* sc = p.scale[l];
             const float* sh = p.shift[l];
             const int relu = p.relu[l];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+            const int64_t r = rrow[rt];
             float part = 0.f;                                     // head: this lane's share of the logit
 #pragma unroll
             for (int ct = 0; ct < TW_NT; ++ct) {
                 const int col = 16 * ct + 4 * g;                  // N % 4 == 0: the lane's four columns are inside or outside together
-                tw_f32x4 v = acc[ct];
+                tw_f32x4 v = acc[rt][ct];
                 if (col < N) {
                     if (bias) v += *reinterpret_cast<const tw_f32x4*>(bias + col);
                     if (relu) {
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
                 } else {
                     v = (tw_f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                act[ct] = v;
+                act[rt][ct] = v;
             }
             if (last && p.head_w) {
                 part += __shfl_xor(part, 16, 64);                 // the row's other columns live in the other three lane groups
@@ -381,13 +402,14 @@ __global__ __launch_bounds__(64 * TW_NW, 2) void tower_bf3_k(const TowerParams p
                 if (g == 0 && r < p.M) {
                     float o = part + p.head_b[0];
                     if constexpr (GATHER) {
-                        if (p.want_fm) o += fm_r;                 // the order of ops.tower(..., adds=(fm, lin))
-                        if (p.lin_col >= 0) o += lin_r;
+                        if (p.want_fm) o += fm_r[rt];             // the order of ops.tower(..., adds=(fm, lin))
+                        if (p.lin_col >= 0) o += lin_r[rt];
                     }
                     if (p.add0) o += p.add0[r];
                     if (p.add1) o += p.add1[r];
                     p.out[r * p.out_ld] = o;
                 }
+            }
             }
         }
     }
@@ -464,14 +486,26 @@ static int tower_fill(const char* name, TowerParams& p, int Kd, int L, const int
     return DIR_OK;
 }
 
+template <bool GATHER, int NP, int RT>
+static int tower_launch_rt(const char* name, const TowerParams& p, dir_stream_t stream) {
+    static LdsOnce once;
+    if (!lds_limit(once, 160 * 1024, &tower_bf3_k<GATHER, NP, RT>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
+    const int64_t ntiles = (p.M + TW_ROWS - 1) / TW_ROWS;
+    const int64_t cap = kCUs;
+    const int64_t nwg = ntiles < cap ? ntiles : cap;              // persistent workgroups: one per CU (8 waves x 256 or 4 x 512 registers), 78 / 52 KB of LDS
+    hipLaunchKernelGGL((tower_bf3_k<GATHER, NP, RT>), dim3((unsigned)nwg), dim3(512 / RT), 2 * tw_bufb(NP), as_stream(stream), p);
+    return DIR_OK;
+}
 template <bool GATHER, int NP>
 static int tower_launch(const char* name, const TowerParams& p, dir_stream_t stream) {
-    static LdsOnce once;
-    if (!lds_limit(once, 160 * 1024, &tower_bf3_k<GATHER, NP>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
-    const int64_t ntiles = (p.M + TW_ROWS - 1) / TW_ROWS;
-    const int64_t cap = (int64_t)kCUs * (8 / TW_NW);
-    const int64_t nwg = ntiles < cap ? ntiles : cap;              // persistent workgroups: 8 waves x 256 registers per CU, 78 / 52 KB of LDS each
-    hipLaunchKernelGGL((tower_bf3_k<GATHER, NP>), dim3((unsigned)nwg), dim3(64 * TW_NW), 2 * tw_bufb(NP), as_stream(stream), p);
+    // DIR_TOWER_RT = 1 | 2 (read per call: an A/B switch): row tiles per wave, see TW_ROWS.  Default 1: with RT = 2 the workgroup reads half the
+    // LDS bytes, but ONE wave per SIMD hides nothing -- mlp_dense 0.240 -> 0.286 ms, deepfm_full 0.278 -> 0.371, pipe busy 0.38 -> 0.29, the
+    // wave issuing a third of its cycles (profiles/NOTES.md R6.4): the stage's LDS reads (812 cycles per k-step and CU at fp16 x 2) were not
+    // what bounds this kernel.
+    const char* e = getenv("DIR_TOWER_RT");
+    const int rt = e ? atoi(e) : 1;
+    const int rc = rt == 2 ? tower_launch_rt<GATHER, NP, 2>(name, p, stream) : tower_launch_rt<GATHER, NP, 1>(name, p, stream);
+    if (rc != DIR_OK) return rc;
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
