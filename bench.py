@@ -61,7 +61,11 @@ def cin_flops(ops, B, m, D, Hs, arith=None, forward=True, backward=False):
             # The last layer's map only feeds its pooled sums: the sum over d is taken first (csrc/cin_pool.hip, on the vector ALUs) and the
             # contraction with W is ONE dense product on [B, hp*m] rows -- 1/D of the definition's flops reach the matrix pipe; the backward
             # is two more such products (dW on dense_dw's arithmetic, dZ on the dense kernel's).
-            if forward:
+            if forward and not backward and getattr(ops, "CIN_POOLED_FUSED", False) and ops.cin_pooled_fused_covers(m, hp, h, D):
+                # round 6, inference: the two passes fused (csrc/cin_pooled.hip): bf16 x 3, one 32-wide k-step per input channel (m fields padded to 32)
+                alg, pipe = alg + f, pipe + f / D * (32.0 / m) * PIPE_COST["bf16x3"]
+                modes["fwd%d" % (k + 1)] = "pooled, fused (Z in registers; bf16x3, 1/D of the flops on the pipe, fields padded to 32)"
+            elif forward:
                 alg, pipe = alg + f, pipe + f / D * PIPE_COST["bf16x3" if ops.dense_auto_arith(B, hp * m, h) == "bf16x3" else "f32"]
                 modes["fwd%d" % (k + 1)] = "pooled (sum over d first; 1/D of the flops on the pipe)"
             if backward:
@@ -1318,7 +1322,7 @@ def main():
         f16 = any(str(v).startswith("f16x2") for v in modes.values())
         # priced on the pipe it runs on: six bf16 (three fp16) piece products per fp32 product (csrc/cin_bf3.hip) against the dense bf16 peak;
         # the fp32-equivalent rate (the algorithm's flops / time) is reported beside it
-        roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes, "kernel": ("cin_bf3_k<PAIRS> (layer 1) + cin_bf3_k (layer 2) + the last layer in its pooled form (cin_pool_z_k + dense_bf3_k)"
+        roof = {"bound": "mfma", "alg_flops": alg, "pipe_flops": pipe, "modes": modes, "kernel": ("cin_bf3_k<PAIRS> (layer 1) + cin_bf3_k (layer 2) + the last layer in its pooled form (cin_pooled_k: fused; training: cin_pool_z_k + dense_bf3_k)"
                            if any(str(v).startswith("pooled") for v in modes.values()) else "cin_bf3_k x3") if bf3 else "cin_k x3",
                 "dtype": ("f32 via fp16x2 split (layers 1-2) / bf16x3 split (pooled last layer), f32 accumulate" if f16 else
                           "f32 via bf16x3 split, f32 accumulate") if bf3 else "f32"}

@@ -168,6 +168,9 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 2 : 1) void tower_bf3_k(const T
     // A stage = the W image of (layer l, k-step ks, column tiles [13*st, 13*st + 13)): 3 pieces x nst slots of 1 KB, lane-linear, in a fixed
     // [piece][13 slots] layout.  Wave w brings slots w and w + 8 of every piece (up to six LDS-DMA instructions per stage).
     auto stage = [&](int l, int ks, int st, int buf) {
+#ifdef TW_ABL_DMA          // timing ablation (WRONG results): the W image is streamed into LDS once per row tile only
+        if (l | ks | st) return;
+#endif
         const int nct = (p.N[l] + 15) >> 4;
         const int nstg = nct > TW_ST ? 2 : 1;
         const int nst = nct - st * TW_ST < TW_ST ? nct - st * TW_ST : TW_ST;
@@ -288,7 +291,11 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 2 : 1) void tower_bf3_k(const T
                             // sched_barrier: nothing may be moved across the wait (cdna_hip_programming.md 5.4 rule 18).
                             const unsigned int wl = (unsigned int)(size_t)(tw_smem + buf * BUFB + lane * 16);
                             tw_u32x4 wq[2][NP];
+#ifdef TW_ABL_LDS          // timing ablation (WRONG results): the W operands are whatever the registers hold; no LDS read, nothing to wait for
+#define TW_DS_READ(dst, off) asm volatile("" : "=v"(dst) : "v"(wl), "n"(off))
+#else
 #define TW_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(wl), "n"(off))
+#endif
                             if constexpr (NP == 2) {
                                 // the same hand pipelining with two pieces per tile: lgkmcnt(2) = "this tile's two pieces are here"
                                 TW_DS_READ(wq[0][0], 0);
@@ -349,7 +356,9 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 2 : 1) void tower_bf3_k(const T
                             }
 #undef TW_DS_READ
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next stage have landed
+#ifndef TW_ABL_BAR         // timing ablation (WRONG results): no barrier between the stages
                             __syncthreads();                                    // ... everyone's have, and everyone is done reading this stage
+#endif
                             buf ^= 1;
                         }
                     }

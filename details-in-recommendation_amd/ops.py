@@ -949,6 +949,7 @@ def invalidate_caches():
     _TOWER_IMAGES.clear()
     _WEIGHT_ABSMAX.clear()
     _DIN_PACK_IMAGES.clear()
+    _CIN_POOLED_IMAGES.clear()
     _CACHE_GEN[0] += 1             # TableSet.absmax / ShardedTables.absmax measurements taken before this call are stale
 
 
@@ -1818,6 +1819,41 @@ CIN_L1_PAIRS = os.environ.get("DIR_CIN_L1_PAIRS", "1") != "0"      # development
 CIN_POOLED_LAST = os.environ.get("DIR_CIN_POOLED_LAST", "1") != "0"  # development switch: 0 runs a pooled-only layer on the layer kernel
 
 
+# development switch: 0 = the pooled last layer of an inference stack stays on the two-pass form (cin_pool_z + the dense kernel)
+CIN_POOLED_FUSED = os.environ.get("DIR_CIN_POOLED_FUSED", "1") != "0"
+_CIN_POOLED_IMAGES = {}
+
+
+def cin_pooled_fused_covers(m, Hp, H, D):
+    """Shapes dir_cin_pooled_last_bf16x3_f32 takes (include/dir_hip.h)."""
+    return D == 16 and 1 <= m <= 32 and Hp >= 1 and 4 <= H <= 128 and H % 4 == 0
+
+
+def cin_pooled_image(W, m, Hp, D, owner=None):
+    """The fused pooled layer's weight image (dir_cin_pooled_pack_f32), once per version of W (while a stream is capturing: packed inside the
+    graph, nothing remembered -- the rule of every per-version cache here).  owner: the LONG-LIVED tensor whose identity and version stand for
+    W's (a module passes its nn.Parameter and `.data` as W: a `.data` view is a new object with a fresh version counter on every call)."""
+    import weakref
+    lib = _lib.load()
+    H = W.shape[0]
+    own = W if owner is None else owner
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (W.data_ptr(), tuple(W.shape), tuple(W.stride()), m, Hp)
+    sig = (own._version if not own.is_inference() else -1, _CACHE_GEN[0])
+    hit = _CIN_POOLED_IMAGES.get(key)
+    if hit is not None and not capturing and hit[0]() is own and hit[1] == sig:
+        return hit[2]
+    Wc = W if W.is_contiguous() else W.contiguous()
+    nbytes = int(lib.dir_cin_pooled_image_bytes(m, Hp, H, D))
+    img = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+    _lib.check(lib.dir_cin_pooled_pack_f32(_ptr(Wc), m, Hp, H, D, _ptr(img), nbytes, _stream()))
+    if not capturing and not own.is_inference():
+        if len(_CIN_POOLED_IMAGES) > 64:
+            _CIN_POOLED_IMAGES.clear()
+        _CIN_POOLED_IMAGES[key] = (weakref.ref(own), sig, img)
+    return img
+
+
 def cin_pooled_covers(m, D, Hp):
     """Shapes of the pooled-only form of a layer (csrc/cin_pool.hip + the dense kernels): m <= 64, D in {4, 8, 16, 32}, Hp * m a multiple of 4."""
     return m <= 64 and D in (4, 8, 16, 32) and (Hp * m) % 4 == 0
@@ -1877,7 +1913,7 @@ def cin_pool_dx(x0, xk, dZ, add_pooled=None, dx0=None):
     return dxk, out
 
 
-def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, grad_operand=False, g_bits_out=None):
+def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, grad_operand=False, g_bits_out=None, w_owner=None):
     """One CIN layer (include/dir_hip.h A14): x0 [B,m,D], xk [B,Hp,D], W [H, Hp*m] ->
     (xout [B,H,D], pooled [B,H]); `pooled` may be a [B,H] view into a wider buffer (row stride kept).
     want_xout=False skips the [B,H,D] write (the last layer of a stack only feeds its pooled sums): xout is None.
@@ -1900,11 +1936,19 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
             and cin_pooled_covers(x0.shape[1], x0.shape[2], xk.shape[1]) and x0.is_cuda and x0.is_contiguous() and xk.is_contiguous()
             and W.dim() == 2 and W.shape[1] == xk.shape[1] * x0.shape[1]):
         B, H = x0.shape[0], W.shape[0]
+        if pooled is None:
+            pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
+        if (z_out is None and CIN_POOLED_FUSED and arith in ("auto", "bf16x3") and cin_pooled_fused_covers(x0.shape[1], xk.shape[1], H, x0.shape[2])
+                and pooled.stride(1) == 1 and pooled.stride(0) % 4 == 0 and pooled.data_ptr() % 16 == 0):
+            # round 6 (inference: nobody asks for Z): the two passes fused -- Z is formed in registers and fed to the matrix pipe, its 872 MB at
+            # the BASELINE shape neither written nor read (include/dir_hip.h: dir_cin_pooled_last_bf16x3_f32)
+            m, D, Hp = x0.shape[1], x0.shape[2], xk.shape[1]
+            _lib.check(_lib.load().dir_cin_pooled_last_bf16x3_f32(_ptr(x0), _ptr(xk), _ptr(cin_pooled_image(W, m, Hp, D, owner=w_owner)), m, Hp, H, D, B, _ptr(pooled),
+                                                                  pooled.stride(0), _stream()))
+            return None, pooled
         # Z (sums over d of products) is a general input: dense "auto" runs its row-scaled fp16 x 2 kernel on it, the rows' maxima left by
         # the kernel that forms Z (no max pass over the [B, Hp*m] matrix)
         Z, zb = cin_pool_z(x0, xk, want_bits=True)
-        if pooled is None:
-            pooled = torch.empty((B, H), dtype=torch.float32, device=x0.device)
         if pooled.stride(1) == 1 and pooled.stride(0) % 4 == 0 and pooled.data_ptr() % 16 == 0:
             dense(Z, W, out=pooled, row_bits=zb)
         else:

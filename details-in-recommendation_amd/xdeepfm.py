@@ -110,7 +110,7 @@ class XDeepFM(nn.Module):
         last = len(self.cin_layer_sizes) - 1
         for k, (W, h) in enumerate(zip(self.cin_W, self.cin_layer_sizes)):
             # the last layer's [B,H,D] map feeds nothing: only its pooled sums are written
-            xk, _ = ops.cin_layer(x0, xk, W.data, pooled=pooled[:, off:off + h], want_xout=k < last)
+            xk, _ = ops.cin_layer(x0, xk, W.data, pooled=pooled[:, off:off + h], want_xout=k < last, w_owner=W)
             off += h
         return pooled
 

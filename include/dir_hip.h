@@ -267,6 +267,17 @@ int dir_cin_pool_z_f32(const float* x0, const float* xk, int m, int Hp, int D, i
 /* ... and z_row_bits [B]: the bit pattern of max |Z[b, :]| (one workgroup owns a sample's row: plain stores) -- the row scales
  * dir_dense_f16x2_rows_f32 multiplies Z by, without a max pass over the [B, Hp*m] matrix. */
 int dir_cin_pool_z_bits_f32(const float* x0, const float* xk, int m, int Hp, int D, int64_t B, float* Z, unsigned int* z_row_bits, dir_stream_t stream);
+/* The pooled last layer FUSED (round 6; inference, where nothing else reads Z): pooled[b,h] = sum_{i,j} W[h,i,j] sum_d xk[b,i,d] x0[b,j,d] in one
+ * launch, Z formed in registers and fed to the bf16 matrix pipe as three bf16 pieces (fp32's exponent range: no row maxima needed; the sums
+ * over d in cin_pool_z_k's order) -- the 872 MB of Z at the BASELINE shape are neither written nor read (0.64 -> 0.2 ms for the layer).
+ *   image: dir_cin_pooled_image_bytes(m, Hp, H, D) device bytes, 16-byte aligned, built by dir_cin_pooled_pack_f32 from W [H, Hp * m] once per
+ *          weight version (the weights of one input channel as [H / 16 tiles][3 pieces] of MFMA operands, streamed through LDS).
+ * Covers D = 16, m <= 32, H <= 128 (a multiple of 4), any Hp (dir_cin_pooled_image_bytes returns 0 / DIR_E_UNSUPPORTED otherwise); pooled rows
+ * pooled_ld floats apart (a multiple of 4), 16-byte aligned.  No reference code (README.md:28 -> arXiv:1803.05170). */
+int64_t dir_cin_pooled_image_bytes(int m, int Hp, int H, int D);
+int dir_cin_pooled_pack_f32(const float* W, int m, int Hp, int H, int D, void* image, int64_t image_bytes, dir_stream_t stream);
+int dir_cin_pooled_last_bf16x3_f32(const float* x0, const float* xk, const void* image, int m, int Hp, int H, int D, int64_t B, float* pooled,
+                                   int64_t pooled_ld, dir_stream_t stream);
 int dir_cin_pool_dx_f32(const float* x0, const float* xk, const float* dZ, int m, int Hp, int D, int64_t B, const float* add_pooled,
                         int64_t add_pooled_ld, float* dxk, float* dx0, int accumulate_dx0, dir_stream_t stream);
 

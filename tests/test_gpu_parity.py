@@ -932,7 +932,20 @@ def test_cin_pooled_form_of_the_last_layer(ops, oracle, B, m, D, Hp, H):
     assert (np.abs(p.cpu().double().numpy() - ref_p) / (1.0 + np.abs(ref_p))).max() <= 1e-5
     z64 = torch.einsum("bid,bjd->bij", torch.from_numpy(xkn).double(), torch.from_numpy(x0n).double()).reshape(B, Hp * m)
     assert float((zl[0].cpu().double() - z64).abs().max()) <= 2e-6 * (1 + float(z64.abs().max()))
-    assert torch.equal(ops.cin_layer(x0, xk, W, want_xout=False)[1], p) and torch.equal(ops.cin_pool_z(x0, xk), zl[0])
+    assert torch.equal(ops.cin_pool_z(x0, xk), zl[0])
+    # inference (nobody asks for Z): since round 6 the two passes are ONE kernel where it covers the shape (dir_cin_pooled_last_bf16x3_f32: Z formed
+    # in registers, never written) -- against the oracle at the same bar, bitwise equal reruns; DIR_CIN_POOLED_FUSED=0 is the two-pass form, bit for bit
+    pf = ops.cin_layer(x0, xk, W, want_xout=False)[1]
+    assert (np.abs(pf.cpu().double().numpy() - ref_p) / (1.0 + np.abs(ref_p))).max() <= 1e-5
+    assert torch.equal(ops.cin_layer(x0, xk, W, want_xout=False)[1], pf)
+    fused, ops.CIN_POOLED_FUSED = ops.CIN_POOLED_FUSED, False
+    try:
+        assert torch.equal(ops.cin_layer(x0, xk, W, want_xout=False)[1], p)
+    finally:
+        ops.CIN_POOLED_FUSED = fused
+    assert ops.cin_pooled_fused_covers(m, Hp, H, D) == (D == 16 and m <= 32 and H <= 128 and H % 4 == 0)
+    if not ops.cin_pooled_fused_covers(m, Hp, H, D):
+        assert torch.equal(pf, p)                                    # (an uncovered shape keeps the two-pass form)
     wide = torch.zeros((B, H + 5), device="cuda")                    # a pooled view that is not 16-byte aligned: through a copy
     ops.cin_layer(x0, xk, W, pooled=wide[:, 3:3 + H], want_xout=False)
     assert torch.equal(wide[:, 3:3 + H], p) and float(wide[:, :3].abs().max()) == 0.0
@@ -950,3 +963,27 @@ def test_cin_pooled_form_of_the_last_layer(ops, oracle, B, m, D, Hp, H):
     k2, z2 = ops.cin_pool_dx(x0, xk, dZ, add_pooled=add)
     k3, z3 = ops.cin_pool_dx(x0, xk, dZ, add_pooled=add)
     assert torch.equal(k2, dxk) and torch.equal(k3, k2) and torch.equal(z3, z2)
+
+
+def test_cin_pooled_fused_entry_checks(ops):
+    """dir_cin_pooled_last_bf16x3_f32 / dir_cin_pooled_pack_f32 (round 6): shapes outside D = 16, m <= 32, H <= 128 are refused, a pooled view
+    into a wider buffer is written in place, an odd channel count and a partial last row tile are handled."""
+    import ctypes
+    from dir_amd import _lib
+    lib = _lib.load()
+    assert lib.dir_cin_pooled_image_bytes(26, 128, 128, 16) == 128 * 8 * 3 * 1024 and lib.dir_cin_pooled_image_bytes(26, 128, 128, 8) == 0
+    assert lib.dir_cin_pooled_image_bytes(40, 128, 128, 16) == 0 and lib.dir_cin_pooled_image_bytes(26, 128, 132, 16) == 0
+    p = ctypes.c_void_p(256)
+    assert lib.dir_cin_pooled_last_bf16x3_f32(p, p, p, 26, 128, 128, 8, 4, p, 128, None) == -4
+    assert lib.dir_cin_pooled_last_bf16x3_f32(p, p, None, 26, 128, 128, 16, 4, p, 128, None) == -1
+    assert lib.dir_cin_pooled_last_bf16x3_f32(p, p, p, 26, 128, 128, 16, 4, p, 126, None) == -1
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B, m, Hp, H = 1037, 26, 7, 36                                    # an odd channel count, H not a multiple of 16, a partial row tile
+    x0 = torch.randn((B, m, 16), generator=g, device="cuda") * 0.5
+    xk = torch.randn((B, Hp, 16), generator=g, device="cuda") * 0.5
+    W = torch.randn((H, Hp * m), generator=g, device="cuda") / (Hp * m) ** 0.5
+    wide = torch.full((B, 3 * H + 4), 7.0, device="cuda")
+    ops.cin_layer(x0, xk, W, pooled=wide[:, H:2 * H], want_xout=False)
+    ref = torch.einsum("bid,bjd->bij", xk.double(), x0.double()).reshape(B, -1) @ W.double().t()
+    assert float(((wide[:, H:2 * H].double() - ref).abs() / (1 + ref.abs())).max()) <= 1e-5
+    assert bool((wide[:, :H] == 7.0).all()) and bool((wide[:, 2 * H:] == 7.0).all())
