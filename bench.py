@@ -517,6 +517,8 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
 
     def step(i, arith):
         if st is None:
+            # (round 6: the gather of batch i + 1 on a side stream under the CIN of batch i measured SLOWER -- 3.23 vs 3.10 ms: the persistent CIN
+            # workgroups lose the CUs and the bandwidth the gather takes; the local lookup stays in front of its CIN)
             return cin(ops.embedding_bag(ts, idsl[i % 2], out=embs[i % 2]).view(B, F, K), arith)
         # software pipeline: the lookup of batch i+1 is enqueued (side streams) BEFORE the CIN of batch i, so its two exchanges and
         # three kernels run under 7 ms of matrix work: the step costs max(CIN, exchange), not their sum
