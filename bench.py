@@ -469,10 +469,15 @@ def primary_line(args, wl, cfg, roof, units, world, el, dev_ms, traffic, extra):
     return res
 
 
-def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, device, gen, backend, steps=5, warmup=2):
+def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, device, gen, backend, steps=5, warmup=None):
     """BASELINE config 5: xDeepFM CIN (3 x 128, m = 26, D = 16) on a 10^8-row embedding table (26 slots x 3 846 153 rows), the
     table row-sharded 'div' over the ranks with the lookup's two all-to-alls when N > 1.  Per-GPU batch fixed (weak scaling)."""
     B, F, K = args.batch, 26, 16
+    # warm-up of this leg: 40 steps (120 ms) by default -- the matrix-pipe clocks need tens of milliseconds of load to come up after the
+    # host-side set-up before this leg, and with 2 warm-up steps the 5 timed ones (15 ms) lay inside that ramp: 3.26 vs 2.97 ms on one box
+    # (profiles/r06_warm.txt); the fp32-MFMA comparison leg warms up for 10 of its 14 ms steps
+    if warmup is None:
+        warmup = int(os.environ.get("DIR_BENCH_CFG5_WARMUP", "40"))
     Vf = int(os.environ.get("DIR_BENCH_CFG5_ROWS", "100000000")) // F       # (the env switch: a smaller table for the launch tests)
     Hs = (128, 128, 128)
     sigma = 1.0 / (K ** 0.5)
@@ -526,7 +531,7 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
         inflight[i + 1] = st.lookup_async(idsl[(i + 1) % 2], out=embs[(i + 1) % 2])
         cin(cur.result().view(B, F, K), arith)
 
-    def run(arith, fn=None):     # the contract's timing (barrier + synchronize on both sides, max over ranks) for one arithmetic
+    def run(arith, fn=None, warmup=warmup):     # the contract's timing (barrier + synchronize on both sides, max over ranks) for one arithmetic
         fn = fn or step
         inflight.clear()
         for i in range(warmup):
@@ -558,7 +563,7 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
     el = run(None)
     x_fixed = embs[0].view(B, F, K)
     el_cin = run(None, fn=lambda i, arith: cin(x_fixed, arith))          # the CIN alone on a resident x0: what the lookup adds on top
-    el32 = run("f32")
+    el32 = run("f32", warmup=min(10, warmup))
     tf, tf32 = flops * steps / el / 1e12, flops * steps / el32 / 1e12
     default_is_bf3 = ops.CIN_ARITH in ("auto", "bf16x3")
     _, pipe_flops, _ = cin_flops(ops, B, F, K, Hs)          # bf16-pipe flops the default arithmetic executes (the first layer over field pairs)
@@ -1634,7 +1639,7 @@ def main():
             zargs.id_dist = "zipf"
             zids = make_ids(torch, zargs, gen, device, V)
             ts.row_policy = "reuse"
-            for i in range(10):
+            for i in range(200):                 # (10 ms: keeps the clocks where the primary leg left them)
                 ops.gather_fm(ts, zids[i % len(zids)], out=out, fm=fm)
             torch.cuda.synchronize()
             z0, z1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

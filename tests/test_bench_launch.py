@@ -76,7 +76,7 @@ def test_gpus_2_launches_two_ranks(built_lib):
 def test_gpus_2_cfg5_leg_checks_itself(built_lib):
     """The config-5 secondary leg of the same command (xDeepFM CIN on the row-sharded 1e8-row table; here a small batch): its own parity check."""
     r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"],
-             {"DIR_BENCH_BACKEND": "gloo", "DIR_BENCH_SAME_DEVICE": "1", "DIR_SHARD_HOST_STAGED": "1", "DIR_BENCH_CFG5_ROWS": "2600000"})
+             {"DIR_BENCH_BACKEND": "gloo", "DIR_BENCH_SAME_DEVICE": "1", "DIR_SHARD_HOST_STAGED": "1", "DIR_BENCH_CFG5_ROWS": "2600000", "DIR_BENCH_CFG5_WARMUP": "2"})
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.lstrip().startswith("{")][-1])
     sec = res["secondary_cfg5_xdeepfm_cin"]
