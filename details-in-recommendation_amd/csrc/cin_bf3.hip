@@ -263,7 +263,9 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      unsigned int* __restrict__ xout_bits = nullptr /* optional [R]: the same of THIS launch's output rows (the launch
                                                                                                        must cover all H columns: one column block) */,
                                                      int vwant = -1 /* 1 / 0: wpart is followed by xpart; run only under the plain / the row-scaled verdict */,
-                                                     float* __restrict__ sink = nullptr /* DOT: one writable word nobody reads (behind the workspace's partial maxima) */) {
+                                                     float* __restrict__ sink = nullptr /* DOT: one writable word nobody reads (behind the workspace's partial maxima) */,
+                                                     const int64_t* __restrict__ x0_inv = nullptr /* x0 is a ROW LIST [n, D] and x0_inv [B, mx] the position of
+                                                        (sample, field)'s row in it (< 0: a zero row): the sharded lookup's received rows, no finish pass */) {
     if (vwant >= 0) {                                              // (before anything else: the kernel the verdict does not name costs an empty launch)
         if (cin_plain_verdict(wpart) != (vwant == 1)) return;
     }
@@ -312,8 +314,17 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         constexpr int TPR = 512 / BT_ROWS;                           // threads sharing a row: they take the fields j = t / BT_ROWS, + TPR, ...
         const int r = tid % BT_ROWS;
         const int64_t srow = (row0 + r < R) ? row0 + r : R - 1;     // a row >= R only feeds output rows that are never stored
-        const float* x0src = x0 + ((srow >> dshift) * mx) * D + (srow & (D - 1));
-        for (int j = tid / BT_ROWS; j < mx; j += TPR) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
+        if (x0_inv) {
+            const int64_t* iv = x0_inv + (srow >> dshift) * mx;
+            const float* x0d = x0 + (srow & (D - 1));
+            for (int j = tid / BT_ROWS; j < mx; j += TPR) {
+                const int64_t pos = iv[j];
+                x0s[j * BT_ROWS + r] = pos >= 0 ? x0d[pos * D] : 0.f;
+            }
+        } else {
+            const float* x0src = x0 + ((srow >> dshift) * mx) * D + (srow & (D - 1));
+            for (int j = tid / BT_ROWS; j < mx; j += TPR) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
+        }
     }
 
     // this lane's A rows: row tile rt -> row WR*wave + 16*rt + n of the workgroup; k slot 8*lg + e of each k-step
@@ -811,7 +822,8 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
                    const float* addp = nullptr, int64_t addp_ld = 0, int np = 3 /* 2: fp16 x 2 */,
                    bool rs = false /* fp16 x 2 with the left operand scaled per row (a gradient) */, unsigned int* amax_out = nullptr,
                    const unsigned int* xk_bits = nullptr, unsigned int* xout_bits = nullptr,
-                   const unsigned int* verdict_bits = nullptr /* rs forward: xk's row maxima [B * D] -> the device-side plain / row-scaled verdict */) {
+                   const unsigned int* verdict_bits = nullptr /* rs forward: xk's row maxima [B * D] -> the device-side plain / row-scaled verdict */,
+                   const int64_t* x0_inv = nullptr /* x0 is a row list read through these positions [B, m] */) {
     DIR_CHECK_ARG(m > 0 && Hp > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d Hp=%d H=%d D=%d", name, m, Hp, H, D);
     if (B == 0) return DIR_OK;                      // nothing to compute or write (empty tensors have no storage: their pointers may be null)
     DIR_CHECK_ARG(x0 && xk && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -860,7 +872,7 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                             \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
                            dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr, wpart, \
-                           xk_bits, xout_bits, verdict ? ((RS_) ? 0 : 1) : -1, sink);                                                 \
+                           xk_bits, xout_bits, verdict ? ((RS_) ? 0 : 1) : -1, sink, x0_inv);                                         \
     } while (0)
 #define BT_LAUNCH_KS(C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                       \
     do {                                                                                 \
@@ -995,7 +1007,8 @@ extern "C" int64_t dir_cin_layer1_bf16x3_workspace_bytes(int m, int H) {
 }
 
 static int l1_run(const char* name, int pieces, const float* x0, const float* W, int m, int H, int D, int64_t B, float* xout, float* pooled,
-                  int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream, unsigned int* xout_bits = nullptr) {
+                  int64_t pooled_ld, void* workspace, int64_t workspace_bytes, dir_stream_t stream, unsigned int* xout_bits = nullptr,
+                  const int64_t* x0_inv = nullptr) {
     DIR_CHECK_ARG(m > 0 && H > 0 && D > 0 && B >= 0, "%s: m=%d H=%d D=%d", name, m, H, D);
     if (B == 0) return DIR_OK;
     DIR_CHECK_ARG(x0 && W && (xout || pooled) && workspace, "%s: null pointer", name);
@@ -1039,7 +1052,7 @@ static int l1_run(const char* name, int pieces, const float* x0, const float* W,
         (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true, NP_, NP_ == 2>);                                    \
         const size_t shmem = 2 * (size_t)2 * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                                     \
         hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true, NP_, NP_ == 2>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, \
-                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m, nullptr, wpart, nullptr, xout_bits); \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m, nullptr, wpart, nullptr, xout_bits, -1, nullptr, x0_inv); \
     } while (0)
 #define L1_LAUNCH(C, NCB, HOFF, IMG)                           \
     do {                                                       \
@@ -1078,6 +1091,29 @@ extern "C" int dir_cin_layer1_bits_f16x2_f32(const float* x0, const float* W, in
                                              int64_t pooled_ld, void* workspace, int64_t workspace_bytes, unsigned int* xout_row_bits,
                                              dir_stream_t stream) {
     return l1_run("dir_cin_layer1_bits_f16x2_f32", 2, x0, W, m, H, D, B, xout, pooled, pooled_ld, workspace, workspace_bytes, stream, xout_row_bits);
+}
+
+// The two forward layers of an inference stack with x0 READ THROUGH INVERSE POSITIONS (round 6: the sharded lookup without its finish pass,
+// ShardedTables.lookup_rows): x0_rows [n, D] is the row list the exchange left, x0_inv [B, m] int64 the position of (sample, field)'s row in it
+// (< 0: a zero row -- a pruned or out-of-range id).  Only the staging of the workgroup's x0 slice differs from the entries above (one int64
+// per (sample, field) more, the rows come from where they are): results are bit for bit those of the plain entries on the materialised x0.
+//   layer 1 (xk = x0, field pairs, rows scaled inside the kernel; xout_row_bits optional as in dir_cin_layer1_bits_f16x2_f32)
+extern "C" int dir_cin_layer1_f16x2_gather_f32(const float* x0_rows, const int64_t* x0_inv, const float* W, int m, int H, int D, int64_t B, float* xout,
+                                               float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, unsigned int* xout_row_bits,
+                                               dir_stream_t stream) {
+    DIR_CHECK_ARG(x0_inv || B == 0, "dir_cin_layer1_f16x2_gather_f32: x0_inv is null");
+    return l1_run("dir_cin_layer1_f16x2_gather_f32", 2, x0_rows, W, m, H, D, B, xout, pooled, pooled_ld, workspace, workspace_bytes, stream, xout_row_bits,
+                  x0_inv);
+}
+
+//   a later layer (xk [B, Hp, D] contiguous as the previous layer wrote it): dir_cin_layer_auto_f16x2_f32 when xk_row_bits is given (the
+//   device-side plain / row-scaled verdict), dir_cin_layer_rows_f16x2_f32 otherwise
+extern "C" int dir_cin_layer_f16x2_gather_f32(const float* x0_rows, const int64_t* x0_inv, const float* xk, const float* W, int m, int Hp, int H, int D,
+                                              int64_t B, float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                              const unsigned int* xk_row_bits, unsigned int* xout_row_bits, dir_stream_t stream) {
+    DIR_CHECK_ARG(x0_inv || B == 0, "dir_cin_layer_f16x2_gather_f32: x0_inv is null");
+    return bf3_run("dir_cin_layer_f16x2_gather_f32", x0_rows, xk, W, m, Hp, H, D, B, xout, pooled, pooled_ld, nullptr, nullptr, workspace, workspace_bytes,
+                   stream, nullptr, 0, 2, true, nullptr, nullptr, xout_row_bits, xk_row_bits, x0_inv);
 }
 
 extern "C" int dir_cin_bf16x3_dot_partials(int m, int Hp, int H) {

@@ -75,7 +75,9 @@ constexpr int CQ_RING = 3;        // stages of weights / of xk rows in LDS: what
 template <int HT>
 __global__ __launch_bounds__(64 * CQ_NW, 2) void cin_pooled_k(const float* __restrict__ x0, const float* __restrict__ xk,
                                                               const unsigned char* __restrict__ img, int m, int Hp, int H, int64_t B,
-                                                              float* __restrict__ pooled, int64_t pooled_ld) {
+                                                              float* __restrict__ pooled, int64_t pooled_ld,
+                                                              const int64_t* __restrict__ x0_inv /* nullable: x0 is then a row list [n, 16] and
+                                                                 x0_inv [B, m] the position of (sample, field)'s row in it, < 0 = a zero row */) {
     constexpr int STAGE = HT * 3 * 1024;                          // bytes of one channel's weights
     constexpr int NS = (HT * 3 + CQ_NW - 1) / CQ_NW;              // weight pieces a wave brings per stage (a slot behind the last is the last again)
     constexpr int XSLOT = 1024;                                   // a wave's 16 samples x 64 bytes of one channel
@@ -112,11 +114,18 @@ __global__ __launch_bounds__(64 * CQ_NW, 2) void cin_pooled_k(const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int f = 8 * kk + j;
-            const float* p = x0 + (bb * m + (f < m ? f : 0)) * CQ_D;
+            int64_t e = bb * m + (f < m ? f : 0);
+            bool live = f < m;
+            if (x0_inv) {                                          // the sharded lookup's received rows, read through the inverse positions
+                const int64_t pos = x0_inv[e];
+                live = live && pos >= 0;
+                e = pos >= 0 ? pos : 0;
+            }
+            const float* p = x0 + e * CQ_D;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
-                xr[j][q] = f < m ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                xr[j][q] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         cq_f32x4 acc[HT];
@@ -243,9 +252,8 @@ extern "C" int dir_cin_pooled_pack_f32(const float* W, int m, int Hp, int H, int
     return DIR_OK;
 }
 
-extern "C" int dir_cin_pooled_last_bf16x3_f32(const float* x0, const float* xk, const void* image, int m, int Hp, int H, int D, int64_t B,
-                                              float* pooled, int64_t pooled_ld, dir_stream_t stream) {
-    const char* name = "dir_cin_pooled_last_bf16x3_f32";
+static int cin_pooled_run(const char* name, const float* x0, const int64_t* x0_inv, const float* xk, const void* image, int m, int Hp, int H, int D,
+                          int64_t B, float* pooled, int64_t pooled_ld, dir_stream_t stream) {
     DIR_CHECK_ARG(B >= 0 && m > 0 && Hp > 0 && H > 0, "%s: B=%lld m=%d Hp=%d H=%d", name, (long long)B, m, Hp, H);
     if (!cin_pooled_fused_covers(m, Hp, H, D))
         return fail(DIR_E_UNSUPPORTED, "%s: covers D = 16, m <= 32, H <= 128 (a multiple of 4) (m=%d Hp=%d H=%d D=%d)", name, m, Hp, H, D);
@@ -259,7 +267,7 @@ extern "C" int dir_cin_pooled_last_bf16x3_f32(const float* x0, const float* xk, 
     const size_t shmem = (size_t)CQ_RING * ((size_t)HT * 3 * 1024 + CQ_NW * 1024);
     hipStream_t st = as_stream(stream);
     const unsigned char* im = static_cast<const unsigned char*>(image);
-#define DIR_CQ(HT_) hipLaunchKernelGGL((cin_pooled_k<HT_>), dim3((unsigned)nwg), dim3(64 * CQ_NW), shmem, st, x0, xk, im, m, Hp, H, B, pooled, pooled_ld)
+#define DIR_CQ(HT_) hipLaunchKernelGGL((cin_pooled_k<HT_>), dim3((unsigned)nwg), dim3(64 * CQ_NW), shmem, st, x0, xk, im, m, Hp, H, B, pooled, pooled_ld, x0_inv)
     switch (HT) {
         case 1: DIR_CQ(1); break;
         case 2: DIR_CQ(2); break;
@@ -274,3 +282,17 @@ extern "C" int dir_cin_pooled_last_bf16x3_f32(const float* x0, const float* xk, 
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
+
+extern "C" int dir_cin_pooled_last_bf16x3_f32(const float* x0, const float* xk, const void* image, int m, int Hp, int H, int D, int64_t B,
+                                              float* pooled, int64_t pooled_ld, dir_stream_t stream) {
+    return cin_pooled_run("dir_cin_pooled_last_bf16x3_f32", x0, nullptr, xk, image, m, Hp, H, D, B, pooled, pooled_ld, stream);
+}
+
+// ... with x0 read through inverse positions (the sharded lookup without its finish pass, include/dir_hip.h): x0_rows [n, D] row list,
+// x0_inv [B, m] int64 positions into it (< 0: a zero row -- a pruned / out-of-range id)
+extern "C" int dir_cin_pooled_last_bf16x3_gather_f32(const float* x0_rows, const int64_t* x0_inv, const float* xk, const void* image, int m, int Hp,
+                                                     int H, int D, int64_t B, float* pooled, int64_t pooled_ld, dir_stream_t stream) {
+    DIR_CHECK_ARG(x0_inv || B == 0, "dir_cin_pooled_last_bf16x3_gather_f32: x0_inv is null");
+    return cin_pooled_run("dir_cin_pooled_last_bf16x3_gather_f32", x0_rows, x0_inv, xk, image, m, Hp, H, D, B, pooled, pooled_ld, stream);
+}
+
