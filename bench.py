@@ -482,6 +482,7 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
     Hs = (128, 128, 128)
     sigma = 1.0 / (K ** 0.5)
     sharded = world > 1 or os.environ.get("DIR_BENCH_CFG5_SHARDED") == "1"
+    consume = False
     if not sharded:
         ts = ops.TableSet([torch.randn((Vf, K), generator=gen, device=device) * sigma for _ in range(F)])
         st = None
@@ -499,7 +500,10 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
         # (side streams confined to a few CUs -- ShardedTables(side_cus=n) -- made this leg SLOWER on one GPU: 9.3 vs 7.8 ms at 8-32 CUs,
         # profiles/r03_cfg5_overlap.md; the default leaves them unmasked)
         side = os.environ.get("DIR_BENCH_CFG5_SIDE_CUS", "0")
-        st = ShardedTables(loc, [Vf] * F, force_collective=True, check="lazy", max_batch=B, side_cus=int(side) or None)
+        # round 6: the lookup WITHOUT its finish pass -- the CIN layers stage x0 through the inverse positions of the received rows
+        # (ShardedTables.lookup_rows_async + ops.cin_stack_gather); DIR_BENCH_CFG5_CONSUME=0: lookup_async(out=) + the plain layers
+        consume = os.environ.get("DIR_BENCH_CFG5_CONSUME", "1") == "1" and ops.cin_gather_covers(F, K, (128, 128, 128))
+        st = ShardedTables(loc, [Vf] * F, force_collective=True, check="eager" if consume else "lazy", max_batch=B, side_cus=int(side) or None)
     idsl = [torch.randint(0, Vf, (B, F), generator=gen, device=device) for _ in range(2)]
     parity = None
     if st is not None:
@@ -527,6 +531,12 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
             return cin(ops.embedding_bag(ts, idsl[i % 2], out=embs[i % 2]).view(B, F, K), arith)
         # software pipeline: the lookup of batch i+1 is enqueued (side streams) BEFORE the CIN of batch i, so its two exchanges and
         # three kernels run under 7 ms of matrix work: the step costs max(CIN, exchange), not their sum
+        if consume and arith is None:
+            cur = inflight.pop(i, None) or st.lookup_rows_async(idsl[i % 2])
+            inflight[i + 1] = st.lookup_rows_async(idsl[(i + 1) % 2])
+            for s_, e_, rows, inv in cur.result():
+                ops.cin_stack_gather(rows, inv, Ws, pooled[s_:e_])
+            return
         cur = inflight.pop(i, None) or st.lookup_async(idsl[i % 2], out=embs[i % 2])
         inflight[i + 1] = st.lookup_async(idsl[(i + 1) % 2], out=embs[(i + 1) % 2])
         cin(cur.result().view(B, F, K), arith)
@@ -561,6 +571,8 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
     # Two arithmetics of the same layer: the default is the bf16x3 kernel (every fp32 operand split into three bf16 pieces,
     # six piece products on the bf16 matrix pipe, fp32 accumulate: same 1e-5 parity bar); the fp32-MFMA kernel is timed beside it.
     el = run(None)
+    if consume:
+        st.lookup(idsl[0], out=embs[0])                                   # (the rows form never wrote the concatenation: the CIN-only leg needs one)
     x_fixed = embs[0].view(B, F, K)
     el_cin = run(None, fn=lambda i, arith: cin(x_fixed, arith))          # the CIN alone on a resident x0: what the lookup adds on top
     el32 = run("f32", warmup=min(10, warmup))
@@ -572,8 +584,9 @@ def cfg5_leg(torch, dist, ops, ShardedTables, div_range, args, world, rank, devi
     return {"metric": "samples/sec (xDeepFM CIN 3x128 + embedding lookup, table 1e8 x 16%s)" % (" row-sharded" if world > 1 else ""),
             "value": B * world * steps / el, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": el * 1e3 / steps, "cin_only_ms_per_step": el_cin * 1e3 / steps, "lookup_exposed_frac": (el - el_cin) / el_cin,
-            "lookup": ("ShardedTables.lookup_async of batch i+1 issued before the CIN of batch i (2 all_to_all per chunk, 2 chunks, check lazy, "
-                       "side streams on %s CUs each)" % (st.side_cus or "all")
+            "lookup": ("ShardedTables.lookup_async of batch i+1 issued before the CIN of batch i (2 all_to_all per chunk, 2 chunks, check %s, "
+                       "side streams on %s CUs each)%s" % (st.check, st.side_cus or "all", "; NO finish pass: the CIN layers read x0 through the inverse positions "
+                                                          "of the received rows (lookup_rows_async + cin_stack_gather)" if consume else "")
                        if st is not None else "local gather (one GPU holds the table)"), "scaling": "weak",
             "dtype": ("f32 via fp16x2 split (layers 1-2) / bf16x3 split (pooled last layer), f32 accumulate"
                       if getattr(ops, "CIN_FWD_SPLIT", "") == "f16x2" and ops.CIN_ARITH == "auto" else "f32 via bf16x3 split, f32 accumulate")

@@ -151,6 +151,9 @@ SIGNATURES = {
     "dir_cin_pooled_image_bytes": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "dir_cin_pooled_pack_f32": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_cin_pooled_last_bf16x3_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp]),
+    "dir_cin_pooled_last_bf16x3_gather_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp]),
+    "dir_cin_layer1_f16x2_gather_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    "dir_cin_layer_f16x2_gather_f32": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "dir_cin_pool_z_bits_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "dir_cin_pool_dx_f32": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
     "dir_cin_layer1_bf16x3_workspace_bytes": (c_i64, [c_i32, c_i32]),

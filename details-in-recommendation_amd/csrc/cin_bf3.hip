@@ -251,7 +251,10 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      const unsigned char* __restrict__ img, int m, int Hp, int H, int D, int dshift,
                                                      int nkh, int hoff /* first output column of this launch */, int64_t R,
                                                      float* __restrict__ xout, float* __restrict__ pooled, int64_t pooled_ld,
-                                                     const float* __restrict__ y /* DOT: [B, H, D] */,
+                                                     const float* __restrict__ y /* DOT: [B, H, D].  Forward kernels: null, or x0's INVERSE POSITIONS
+                                                        (int64 [B, mx], round 6): x0 is then a ROW LIST [n, D] and entry (b, j) the position of (sample,
+                                                        field)'s row in it, < 0 = a zero row -- the sharded lookup's received rows, no finish pass.  (The
+                                                        slot is shared because one more kernel argument made the 256-register dot form spill.) */,
                                                      float* __restrict__ dotp /* DOT: partials [nkh][B, m, D] of this launch's column block */,
                                                      const float* __restrict__ addp /* optional [B, H] (row stride addp_ld): added to xout[b, h, :] */,
                                                      int64_t addp_ld, const unsigned short* __restrict__ ptab /* PAIRS: i | j << 8 per pair */,
@@ -263,9 +266,7 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
                                                      unsigned int* __restrict__ xout_bits = nullptr /* optional [R]: the same of THIS launch's output rows (the launch
                                                                                                        must cover all H columns: one column block) */,
                                                      int vwant = -1 /* 1 / 0: wpart is followed by xpart; run only under the plain / the row-scaled verdict */,
-                                                     float* __restrict__ sink = nullptr /* DOT: one writable word nobody reads (behind the workspace's partial maxima) */,
-                                                     const int64_t* __restrict__ x0_inv = nullptr /* x0 is a ROW LIST [n, D] and x0_inv [B, mx] the position of
-                                                        (sample, field)'s row in it (< 0: a zero row): the sharded lookup's received rows, no finish pass */) {
+                                                     float* __restrict__ sink = nullptr /* DOT: one writable word nobody reads (behind the workspace's partial maxima) */) {
     if (vwant >= 0) {                                              // (before anything else: the kernel the verdict does not name costs an empty launch)
         if (cin_plain_verdict(wpart) != (vwant == 1)) return;
     }
@@ -314,13 +315,23 @@ __global__ __launch_bounds__(512, 1) void cin_bf3_k(const float* __restrict__ x0
         constexpr int TPR = 512 / BT_ROWS;                           // threads sharing a row: they take the fields j = t / BT_ROWS, + TPR, ...
         const int r = tid % BT_ROWS;
         const int64_t srow = (row0 + r < R) ? row0 + r : R - 1;     // a row >= R only feeds output rows that are never stored
+        const int64_t* x0_inv = DOT ? nullptr : reinterpret_cast<const int64_t*>(y);
         if (x0_inv) {
+            // the positions first, then every row read, then the LDS stores: written as one loop the compiler waits for each position and
+            // each row in turn -- 2 x 13 dependent round trips per workgroup with nothing else resident on the CU (+ 0.2 ms per stack)
+            constexpr int MAXJ = (40 + TPR - 1) / TPR;
             const int64_t* iv = x0_inv + (srow >> dshift) * mx;
             const float* x0d = x0 + (srow & (D - 1));
-            for (int j = tid / BT_ROWS; j < mx; j += TPR) {
-                const int64_t pos = iv[j];
-                x0s[j * BT_ROWS + r] = pos >= 0 ? x0d[pos * D] : 0.f;
-            }
+            const int j0 = tid / BT_ROWS;
+            int64_t pos[MAXJ];
+            float v[MAXJ];
+#pragma unroll
+            for (int q = 0; q < MAXJ; ++q) pos[q] = j0 + q * TPR < mx ? iv[j0 + q * TPR] : -1;
+#pragma unroll
+            for (int q = 0; q < MAXJ; ++q) v[q] = x0d[(pos[q] >= 0 ? pos[q] : 0) * D];          // (a clamped address: the load is unconditional)
+#pragma unroll
+            for (int q = 0; q < MAXJ; ++q)
+                if (j0 + q * TPR < mx) x0s[(j0 + q * TPR) * BT_ROWS + r] = pos[q] >= 0 ? v[q] : 0.f;
         } else {
             const float* x0src = x0 + ((srow >> dshift) * mx) * D + (srow & (D - 1));
             for (int j = tid / BT_ROWS; j < mx; j += TPR) x0s[j * BT_ROWS + r] = x0src[(int64_t)j * D];
@@ -871,8 +882,8 @@ static int bf3_run(const char* name, const float* x0, const float* xk, const flo
         (void)lds_limit(once, 160 * 1024, &cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>);                                       \
         const size_t shmem = 2 * (size_t)FJ_ * K * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                             \
         hipLaunchKernelGGL((cin_bf3_k<K, C, 2, DOT_, FJ_, false, NP_, RS_>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, xk, IMG, m, Hp, H, D, \
-                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, y, DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr, wpart, \
-                           xk_bits, xout_bits, verdict ? ((RS_) ? 0 : 1) : -1, sink, x0_inv);                                         \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, (DOT_) ? y : reinterpret_cast<const float*>(x0_inv), DOTP, addp, addp_ld, nullptr, m, (HOFF) == 0 ? amax_out : nullptr, wpart, \
+                           xk_bits, xout_bits, verdict ? ((RS_) ? 0 : 1) : -1, sink);                                                 \
     } while (0)
 #define BT_LAUNCH_KS(C, DOT_, FJ_, NP_, RS_, NCB, HOFF, IMG, DOTP)                       \
     do {                                                                                 \
@@ -1052,7 +1063,7 @@ static int l1_run(const char* name, int pieces, const float* x0, const float* W,
         (void)lds_limit(once, 160 * 1024, &cin_bf3_k<2, C, 2, false, 1, true, NP_, NP_ == 2>);                                    \
         const size_t shmem = 2 * (size_t)2 * NP_ * C * 1024 + sizeof(float) * (size_t)m * 256 + 32;                                     \
         hipLaunchKernelGGL((cin_bf3_k<2, C, 2, false, 1, true, NP_, NP_ == 2>), dim3(nrb, (unsigned)(NCB)), dim3(512), shmem, st, x0, x0, IMG, 1, q.np, H, D, \
-                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, nullptr, nullptr, nullptr, 0, ptab, m, nullptr, wpart, nullptr, xout_bits, -1, nullptr, x0_inv); \
+                           dshift, pl.nkh, HOFF, R, xout, pooled, pooled_ld, reinterpret_cast<const float*>(x0_inv), nullptr, nullptr, 0, ptab, m, nullptr, wpart, nullptr, xout_bits); \
     } while (0)
 #define L1_LAUNCH(C, NCB, HOFF, IMG)                           \
     do {                                                       \

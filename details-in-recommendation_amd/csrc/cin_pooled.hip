@@ -111,17 +111,17 @@ __global__ __launch_bounds__(64 * CQ_NW, 2) void cin_pooled_k(const float* __res
         fetch(Hp > 1 ? 1 : 0, 1, xkb);
         // the x0 rows of this lane's eight fields of its sample (a field >= m: zeros, and its weights are zeros too)
         float4 xr[8][4];
+        int64_t xe[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xe[j] = bb * m + (8 * kk + j < m ? 8 * kk + j : 0);
+        if (x0_inv) {                                              // the sharded lookup's received rows, read through the inverse positions
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xe[j] = x0_inv[xe[j]];     // (all eight positions in flight before the first row read)
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int f = 8 * kk + j;
-            int64_t e = bb * m + (f < m ? f : 0);
-            bool live = f < m;
-            if (x0_inv) {                                          // the sharded lookup's received rows, read through the inverse positions
-                const int64_t pos = x0_inv[e];
-                live = live && pos >= 0;
-                e = pos >= 0 ? pos : 0;
-            }
-            const float* p = x0 + e * CQ_D;
+            const bool live = 8 * kk + j < m && xe[j] >= 0;
+            const float* p = x0 + (xe[j] >= 0 ? xe[j] : 0) * CQ_D;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);

@@ -2040,6 +2040,75 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
     return xout, pooled
 
 
+def cin_gather_covers(m, D, Hs):
+    """Shapes and routing switches under which cin_stack_gather runs EXACTLY the kernels cin_layer(arith=None) would run on the materialised
+    x0 (the default forward routing: the first layer over field pairs on scaled fp16 x 2, later layers behind the device-side verdict, the
+    last layer in its fused pooled form)."""
+    Hs = list(Hs)
+    if not Hs or not (CIN_ARITH == "auto" and CIN_FWD_SPLIT == "f16x2" and CIN_L1_PAIRS and CIN_ROW_BITS_CARRY and CIN_POOLED_LAST and CIN_POOLED_FUSED):
+        return False
+    if not (cin_bf16x3_covers(m, D) and 8 <= m <= 40) or any(h > 128 for h in Hs[:-1]):
+        return False
+    hp = m
+    for h in Hs[:-1]:
+        if cin_auto_arith(m, D, hp, h) != "bf16x3":
+            return False
+        hp = h
+    return len(Hs) >= 2 and cin_pooled_covers(m, D, hp) and cin_pooled_fused_covers(m, hp, Hs[-1], D)
+
+
+def cin_stack_gather(rows, inv, Ws, pooled, w_owners=None):
+    """The CIN stack of an inference forward with x0 read THROUGH INVERSE POSITIONS (round 6: the row-sharded lookup without its finish pass,
+    shard.ShardedTables.lookup_rows): rows [n, D] fp32 as the exchange left them, inv [B, m] int64 = the position of (sample, field)'s row
+    in `rows` (< 0: a zero row).  Ws: the layers' weights [H_k, H_{k-1} * m]; pooled [B, sum H_k] (a view with a row stride is fine) receives
+    every layer's pooled sums.  The [B, m * D] concatenation is never written or read; bit for bit what cin_layer gives on it
+    (dir_cin_layer1_f16x2_gather_f32, dir_cin_layer_f16x2_gather_f32, dir_cin_pooled_last_bf16x3_gather_f32).  Raises where
+    cin_gather_covers says no: the caller then materialises x0 (ops.gather_fm over shard.rows_as_tables) and runs cin_layer."""
+    _dev(rows, torch.float32, "rows")
+    _dev(inv, torch.int64, "inv")
+    if rows.dim() != 2 or inv.dim() != 2 or not rows.is_contiguous() or not inv.is_contiguous():
+        raise ValueError("cin_stack_gather: rows must be a contiguous [n, D], inv a contiguous [B, m]")
+    B, m = inv.shape
+    D = rows.shape[1]
+    Hs = [int(W.shape[0]) for W in Ws]
+    if not cin_gather_covers(m, D, Hs):
+        raise ValueError("cin_stack_gather: shape / routing not covered (cin_gather_covers): m=%d D=%d layers=%r" % (m, D, Hs))
+    if pooled.shape != (B, sum(Hs)) or pooled.stride(1) != 1:
+        raise ValueError("cin_stack_gather: pooled must be [B, sum(H_k)] with unit column stride")
+    if B == 0:
+        return pooled
+    lib = _lib.load()
+    dev = rows.device
+    xk, ib, hp, off = None, None, m, 0
+    for k, (W, h) in enumerate(zip(Ws, Hs)):
+        _dev(W, torch.float32, "W")
+        if W.shape[1] != hp * m or not W.is_contiguous():
+            raise ValueError("cin_stack_gather: layer %d's W must be a contiguous [H, Hp*m]" % k)
+        pk = pooled[:, off:off + h]
+        if k == len(Hs) - 1:
+            if not (pk.stride(0) % 4 == 0 and pk.data_ptr() % 16 == 0):
+                raise ValueError("cin_stack_gather: the last layer's pooled view must be 16-byte aligned with a row stride that is a multiple of 4")
+            img = cin_pooled_image(W, m, hp, D, owner=None if w_owners is None else w_owners[k])
+            _lib.check(lib.dir_cin_pooled_last_bf16x3_gather_f32(_ptr(rows), _ptr(inv), _ptr(xk), _ptr(img), m, hp, h, D, B, _ptr(pk), pk.stride(0), _stream()))
+            break
+        xout = torch.empty((B, h, D), dtype=torch.float32, device=dev)
+        ob = torch.empty(B * D, dtype=torch.int32, device=dev)
+        if k == 0:
+            nbytes = int(lib.dir_cin_layer1_bf16x3_workspace_bytes(m, h))
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            wp = ctypes.c_void_p(ws.data_ptr() + (-ws.data_ptr()) % 256)
+            _lib.check(lib.dir_cin_layer1_f16x2_gather_f32(_ptr(rows), _ptr(inv), _ptr(W), m, h, D, B, _ptr(xout), _ptr(pk), pk.stride(0), wp, nbytes, _ptr(ob),
+                                                           _stream()))
+        else:
+            nbytes = int(lib.dir_cin_bf16x3_workspace_bytes(m, hp, h))
+            ws = torch.empty(max(16, nbytes), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dir_cin_layer_f16x2_gather_f32(_ptr(rows), _ptr(inv), _ptr(xk), _ptr(W), m, hp, h, D, B, _ptr(xout), _ptr(pk), pk.stride(0), _ptr(ws),
+                                                          nbytes, _ptr(ib), _ptr(ob), _stream()))
+        xk, ib, hp = xout, ob, h
+        off += h
+    return pooled
+
+
 # ---- id paths (A3) ---------------------------------------------------------------------------------
 def fingerprint64(s):
     if isinstance(s, str):

@@ -244,6 +244,17 @@ class _Lookup:
         return (self.out, self.fm) if self.want_fm else self.out
 
 
+class _RowsLookup:
+    """Handle of ShardedTables.lookup_rows_async."""
+
+    def __init__(self, lk, chunks):
+        self.lk, self.chunks = lk, chunks
+
+    def result(self):
+        self.lk.result()
+        return list(self.chunks)
+
+
 class ShardedTables:
     """This rank's row slices of F tables [vocab_f, K].
 
@@ -798,6 +809,28 @@ class ShardedTables:
             raise ValueError("lookup_consume needs check='eager' (the overflow repair calls the consumer again)")
         self.lookup_async(ids, want_fm=False, consumer=consumer).result()
 
+    def lookup_rows_async(self, ids):
+        """Enqueue a lookup WITHOUT its finish pass and hand the received rows to the caller (round 6: what lookup_consume gives a callback,
+        as a handle -- so that the NEXT lookup can be issued before this one's rows are consumed, like lookup_async).  handle.result() makes
+        the caller's stream wait for the exchange, applies the overflow policy and returns a list of (s, e, rows, inv) -- one entry per
+        non-empty micro-batch, samples [s, e) of the local batch: rows [n, K] fp32 exactly as the exchange left them, inv [e - s, F] int64 =
+        the position of (sample, slot)'s row in `rows`, < 0 where the id was pruned / out of range.  A kernel that takes (tables, ids) reads
+        them as (rows_as_tables(rows, F), inv); ops.cin_stack_gather and ops.tower(gather=) take them directly: the [B, F*K] concatenation
+        is never written.  The buffers belong to the lookup's plan slot: valid until the lookup after the next one is enqueued (two slots).
+        Needs check='eager' (an overflow is repaired on the exact path before the rows are handed out: then ONE entry for the whole batch)."""
+        if self.check != "eager":
+            raise ValueError("lookup_rows needs check='eager' (an overflow is repaired before the rows are handed out)")
+        chunks = []
+
+        def collect(s, e, rows, inv):
+            if s == 0:
+                chunks.clear()                     # (the repair on the exact path calls again, for the whole batch)
+            chunks.append((s, e, rows, inv))
+        return _RowsLookup(self.lookup_async(ids, want_fm=False, consumer=collect), chunks)
+
+    def lookup_rows(self, ids):
+        return self.lookup_rows_async(ids).result()
+
     def lookup(self, ids, want_fm=False, out=None, fm=None):
         """ids [B_local, F] int64 (global row ids; < 0 or >= vocab_f -> zeros) -> emb [B_local, F*K] fp32
         (and the FM second-order logit [B_local, 1] when want_fm).  out / fm: preallocated results (stable addresses)."""
@@ -889,6 +922,29 @@ def allreduce_grads(params, group=None, bucket_bytes=64 << 20, average=False):
             n = g.numel()
             g.copy_(flat[off:off + n].view_as(g).to(g.device) * scale if average else flat[off:off + n].view_as(g))
             off += n
+
+
+@torch.no_grad()
+def xdeepfm_predict(model, tables, ids, linear_logit=None):
+    """Inference logits [B_local, 1] of an xdeepfm.XDeepFM over ROW-SHARDED embedding tables (BASELINE config 5: the config the reference's
+    README.md:28 model shards; partitioner precedent deepFM.py:163-167).  With check='eager' the lookup runs WITHOUT its finish pass
+    (lookup_rows): per micro-batch the CIN layers and the tower read the received rows through the inverse positions
+    (XDeepFM.forward_rows) -- the rank-local passes of the lookup are bucket + owner gather only; otherwise lookup() + forward_embedded().
+    Bit for bit the same logits either way.  `model`'s own embedding tables are not used; linear_logit [B_local, 1]: the first-order term,
+    computed by the caller (its 4-byte rows live wherever the caller keeps them)."""
+    amax = tables.absmax()
+    B = ids.shape[0]
+    was_training = model.training
+    model.eval()
+    try:
+        if tables.check == "eager":
+            out = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
+            for s, e, rows, inv in tables.lookup_rows(ids):
+                out[s:e] = model.forward_rows(rows, inv, None if linear_logit is None else linear_logit[s:e], absmax=amax)
+            return out
+        return model.forward_embedded(tables.lookup(ids), linear_logit, range_ok=ops.f16_range_ok(amax))
+    finally:
+        model.train(was_training)
 
 
 class ShardedDeepFMTrainer:

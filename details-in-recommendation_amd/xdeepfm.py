@@ -114,14 +114,50 @@ class XDeepFM(nn.Module):
             off += h
         return pooled
 
-    def forward_embedded(self, emb, linear_logit=None):
+    def forward_embedded(self, emb, linear_logit=None, range_ok=None):
+        """emb [B, m*D] (the embedding concatenation) -> logits.  range_ok: the fp16-range verdict of the tables the rows came from when those
+        are not this module's own (the row-sharded tables: ops.f16_range_ok(ShardedTables.absmax()))."""
         B = emb.shape[0]
         logits = units1(self.cin_out, self.cin(emb.view(B, self.m, self.D)))      # (training: one pass for the layer's two gradients)
+        return self._dnn_and_sum(emb, logits, linear_logit, self._tablesets()[0].range_ok() if range_ok is None else range_ok)
+
+    @torch.no_grad()
+    def forward_rows(self, rows, inv, linear_logit=None, absmax=None):
+        """Inference logits [B, 1] from a row-sharded lookup WITHOUT its finish pass (round 6; shard.ShardedTables.lookup_rows): rows [n, D]
+        as the exchange left them, inv [B, m] int64 = the position of (sample, field)'s row in `rows` (< 0: a zero row).  The CIN layers stage
+        their x0 slices through `inv` (ops.cin_stack_gather) and the DNN tower looks its input rows up the same way inside its one launch
+        (dense.tower_infer's gather form): the [B, m*D] concatenation is never written or read.  Bit for bit forward_embedded() on the
+        materialised rows; where a kernel does not cover the shape the rows are materialised for it (the finish pass's work, here).
+        absmax: the SHARDED tables' largest |value| (ShardedTables.absmax()) -- the tower's fp16-range verdict must not come from this
+        module's own (unused) tables."""
+        from .shard import rows_as_tables
+        B = inv.shape[0]
+        Hs = list(self.cin_layer_sizes)
+        inv = inv if inv.is_contiguous() else inv.contiguous()
+        emb = None
+        if rows.is_cuda and B > 0 and ops.cin_gather_covers(self.m, self.D, Hs):
+            pooled = torch.empty((B, sum(Hs)), dtype=torch.float32, device=rows.device)
+            ops.cin_stack_gather(rows, inv, [W.data for W in self.cin_W], pooled, w_owners=list(self.cin_W))
+        else:
+            emb = ops.embedding_bag(rows_as_tables(rows, self.m), inv)
+            pooled = self.cin(emb.view(B, self.m, self.D))
+        logits = units1(self.cin_out, pooled)
+        if self.dnn_out.out_features == 1 and emb is None:
+            adds = (logits,) if linear_logit is None else (logits, linear_logit)
+            fused = tower_infer(self.hidden, None, self.activation, head=self.dnn_out, adds=adds,
+                                gather=(rows_as_tables(rows, self.m, absmax=absmax), inv, None, False))
+            if fused is not None:
+                return fused
+        if emb is None:
+            emb = ops.embedding_bag(rows_as_tables(rows, self.m), inv)
+        return self._dnn_and_sum(emb, logits, linear_logit, True if absmax is None else ops.f16_range_ok(absmax))
+
+    def _dnn_and_sum(self, emb, logits, linear_logit, range_ok):
         net = emb
         if self.dnn_out.out_features == 1:
             # inference: the DNN tower and its logit layer in one launch, the CIN's (and the linear term's) logits added in its epilogue
             adds = (logits,) if linear_logit is None else (logits, linear_logit)
-            fused = tower_infer(self.hidden, net, self.activation, head=self.dnn_out, adds=adds, embedding_input=self._tablesets()[0].range_ok())   # net = the embedding concat
+            fused = tower_infer(self.hidden, net, self.activation, head=self.dnn_out, adds=adds, embedding_input=range_ok)   # net = the embedding concat
             if fused is not None:
                 return fused
         if mlp_head_supported(self.hidden, self.dnn_out, net, self.activation):

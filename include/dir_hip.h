@@ -358,6 +358,24 @@ int dir_cin_layer_rows_f16x2_f32(const float* x0, const float* xk, const float* 
 int dir_cin_layer_auto_f16x2_f32(const float* x0, const float* xk, const float* W, int m, int Hp, int H, int D, int64_t B, float* xout,
                                  float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes, const unsigned int* xk_row_bits,
                                  unsigned int* xout_row_bits, dir_stream_t stream);
+
+/* The CIN forward of an inference stack with x0 READ THROUGH INVERSE POSITIONS (round 6: the row-sharded lookup WITHOUT its finish pass --
+ * ShardedTables.lookup_rows; precedent for the sharding: /root/reference/models/DeepFM/deepFM.py:163-167, the CIN itself README.md:28).
+ *   x0_rows [n, D] fp32: the rows as the exchange left them (any order);  x0_inv [B, m] int64: the position of (sample, field)'s row in
+ *   x0_rows, < 0 = a zero row (a pruned / out-of-range id).
+ * Only the staging of x0 differs from the entries above (the [B, m*D] concatenation is never written or read); results are bit for bit
+ * those of dir_cin_layer1_bits_f16x2_f32 / dir_cin_layer_auto_f16x2_f32 (xk_row_bits given) / dir_cin_layer_rows_f16x2_f32 (xk_row_bits
+ * null) / dir_cin_pooled_last_bf16x3_f32 on the materialised x0.  Same workspaces, coverage and errors as those entries; a null x0_inv
+ * with B > 0 is DIR_E_BADARG. */
+int dir_cin_layer1_f16x2_gather_f32(const float* x0_rows, const int64_t* x0_inv, const float* W, int m, int H, int D, int64_t B, float* xout,
+                                    float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                    unsigned int* xout_row_bits /* nullable */, dir_stream_t stream);
+int dir_cin_layer_f16x2_gather_f32(const float* x0_rows, const int64_t* x0_inv, const float* xk, const float* W, int m, int Hp, int H, int D,
+                                   int64_t B, float* xout, float* pooled, int64_t pooled_ld, void* workspace, int64_t workspace_bytes,
+                                   const unsigned int* xk_row_bits /* nullable */, unsigned int* xout_row_bits /* nullable */,
+                                   dir_stream_t stream);
+int dir_cin_pooled_last_bf16x3_gather_f32(const float* x0_rows, const int64_t* x0_inv, const float* xk, const void* image, int m, int Hp, int H,
+                                          int D, int64_t B, float* pooled, int64_t pooled_ld, dir_stream_t stream);
 int dir_cin_layer_dot_add_f16x2_f32(const float* x0, const float* xk, const float* W, const float* y, int m, int Hp, int H, int D, int64_t B,
                                     const float* add_pooled, int64_t add_pooled_ld, float* xout, float* dot_partials, void* workspace,
                                     int64_t workspace_bytes, unsigned int* xk_absmax_bits_out, dir_stream_t stream);

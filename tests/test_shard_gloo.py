@@ -316,6 +316,18 @@ def _worker_body(rank, world, port, vocab, K, B, seed, out_q, train, opts):
             ok = ok and bool(np.array_equal(got_c.numpy(), ref)) and len(calls) >= 1
             if want == "fallback":          # (slabs still too small on this call: the repair calls the consumer again, for the whole batch)
                 ok = ok and (st.stats["fallbacks"] == fb or calls[-1] == (0, B))
+            # the handle form (round 6: lookup_rows_async): two lookups in flight, the rows of the first consumed after the second is issued
+            ids_b = np.ascontiguousarray(ids[::-1])
+            h_a = st.lookup_rows_async(torch.from_numpy(ids))
+            h_b = st.lookup_rows_async(torch.from_numpy(ids_b))
+            for h_, ref_ in ((h_a, ref), (h_b, ref[::-1])):
+                got_r = torch.full((B, F * K), float("nan"))
+                cover = 0
+                for s_, e_, rows, inv in h_.result():
+                    r3 = rows[inv.clamp(min=0)] * (inv >= 0).unsqueeze(-1).to(rows.dtype)
+                    got_r[s_:e_] = r3.reshape(e_ - s_, F * K)
+                    cover += e_ - s_
+                ok = ok and cover == B and bool(np.array_equal(got_r.numpy(), ref_))
         # two lookups in flight (double-buffered plans), consumed in order, then a third reusing the first one's buffers
         if opts.get("async"):
             batches = [np.stack([rng_b.integers(-1, v, size=B) for v in vocab], axis=1).astype(np.int64) for _ in range(3)]
