@@ -930,7 +930,8 @@ def xdeepfm_predict(model, tables, ids, linear_logit=None):
     README.md:28 model shards; partitioner precedent deepFM.py:163-167).  With check='eager' the lookup runs WITHOUT its finish pass
     (lookup_rows): per micro-batch the CIN layers and the tower read the received rows through the inverse positions
     (XDeepFM.forward_rows) -- the rank-local passes of the lookup are bucket + owner gather only; otherwise lookup() + forward_embedded().
-    Bit for bit the same logits either way.  `model`'s own embedding tables are not used; linear_logit [B_local, 1]: the first-order term,
+    Bit for bit the same logits either way wherever a micro-batch and the whole batch take the same dense kernels (those are chosen by row
+    count: ops.dense_small_covers / dense_mid_covers / TOWER_MIN_ROWS).  `model`'s own embedding tables are not used; linear_logit [B_local, 1]: the first-order term,
     computed by the caller (its 4-byte rows live wherever the caller keeps them)."""
     amax = tables.absmax()
     B = ids.shape[0]

@@ -110,6 +110,29 @@ def _scenarios(rank, world, device, transport):
     out.append(("lookup_consume_tower", ok, ""))
     del st
 
+    # 2c. xDeepFM over the sharded tables WITHOUT a finish pass (round 6: lookup_rows + the CIN layers' and the tower's gather forms) against
+    #     lookup() + forward_embedded(): the same logits bit for bit.  20 slots (the CIN's pair form wants >= 18 at these widths).
+    from dir_amd import shard as _shard
+    from dir_amd.xdeepfm import XDeepFM
+    from dir_amd import feature_column as fc
+    vocab_x = [500 + 41 * f for f in range(20)]
+    full_x = _full_tables(vocab_x, K, device, seed=21)
+    stx = ShardedTables.from_full(full_x, check="eager")
+    torch.manual_seed(4242)                                      # the same model on every rank
+    cats = [fc.categorical_column_with_identity("C%d" % i, 50) for i in range(20)]
+    xm = XDeepFM(linear_feature_columns=None, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats], cin_layer_sizes=(64, 32),
+                 dnn_hidden_units=(128, 128)).to(device).eval()
+    ok = ops.cin_gather_covers(20, K, (64, 32))
+    for B in (1400 + 17 * rank, 8300):       # (row counts at which a micro-batch and the whole batch take the same dense kernels: those are chosen by row count)
+        ids = _ids(gen, vocab_x, B, device)
+        lin = (torch.randn((B, 1), generator=gen) * 0.1).to(device)
+        with torch.no_grad():
+            ref = xm.forward_embedded(stx.lookup(ids), lin, range_ok=ops.f16_range_ok(stx.absmax()))
+        got = _shard.xdeepfm_predict(xm, stx, ids, lin)
+        ok = ok and bool(torch.equal(got, ref))
+    out.append(("xdeepfm_predict_no_finish_pass", ok, ""))
+    del stx, full_x
+
     # 3. the reference partitioner's slice-count rule (deepFM.py:163-167): a table past 2 x 64 MiB is cut, the small ones stay whole and
     #    are dealt round-robin; + an explicit slice-count list
     vocab3 = [2_200_000, 50, 900]                                    # 2.2 M x 16 x 4 B = 134 MiB -> min(world, 3) slices
@@ -263,7 +286,7 @@ def _check(res, world):
         assert not isinstance(got, str), "rank %d raised:\n%s" % (rank, got)
         bad = [(n, d) for n, ok, d in got if not ok]
         assert not bad, "rank %d: %s" % (rank, bad)
-        assert len(got) == 10
+        assert len(got) == 11
 
 
 def test_sharded_lookup_over_rccl_one_rank_per_gpu(built_lib):
