@@ -73,6 +73,11 @@ SIGNATURES = {
     "dir_tower_f16x2_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_deepfm_tower_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "dir_tower_cs_image_bytes": (c_i64, [c_i32, c_i32]),
+    "dir_tower_cs_f16x2_pack_f32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "dir_tower_cs_f16x2_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "dir_deepfm_tower_cs_f16x2_f32": (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i64, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                              c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "dir_dense_f16x2_pack_strided_f32": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_f16x2_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_bf16x3_image_bytes": (c_i64, [c_i32, c_i32]),

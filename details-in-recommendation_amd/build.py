@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libdir_hip.so")
-SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "din_wave.hip", "din_pack.hip", "din_bwd_rows.hip", "din_rows_train.hip", "cin.hip", "cin_bf3.hip", "cin_dw_bf3.hip", "cin_dw_sym_bf3.hip", "cin_pool.hip", "cin_pooled.hip", "cin_bwd.hip", "backward.hip", "radix_sort.hip", "dense.hip", "dense_bf3.hip", "tower_bf3.hip", "dense_dw_bf3.hip", "head_bwd.hip", "bn_train.hip", "diag.hip"]
+SOURCES = ["capi.cpp", "embedding_bag.hip", "linear_cross.hip", "ids.hip", "din.hip", "din_wave.hip", "din_pack.hip", "din_bwd_rows.hip", "din_rows_train.hip", "cin.hip", "cin_bf3.hip", "cin_dw_bf3.hip", "cin_dw_sym_bf3.hip", "cin_pool.hip", "cin_pooled.hip", "cin_bwd.hip", "backward.hip", "radix_sort.hip", "dense.hip", "dense_bf3.hip", "tower_bf3.hip", "tower_cs.hip", "dense_dw_bf3.hip", "head_bwd.hip", "bn_train.hip", "diag.hip"]
 # per-file flags: cin_bwd's epilogues read the MFMA results on the VALU, so keep them in VGPRs (no v_accvgpr_read)
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
@@ -39,6 +39,7 @@ EXTRA_FLAGS = {"cin_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "din_wave.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + NO_PACKED_FP32,
                "din_pack.hip": NO_PACKED_FP32,
                "cin_pooled.hip": NO_PACKED_FP32,
+               "tower_cs.hip": NO_PACKED_FP32,
                "din_bwd_rows.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"] + NO_PACKED_FP32}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip",

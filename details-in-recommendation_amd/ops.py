@@ -1194,6 +1194,11 @@ def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=
 TOWER_MAX_WIDTH = 416
 TOWER_MIN_ROWS = 4096          # below this the 128-row tiles leave most of the chip idle: the per-layer kernels run
 TOWER_GATHER = os.environ.get("DIR_TOWER_GATHER", "1")      # 0: DeepFM inference as two launches (packed gather, then the tower)
+# "rows": tower_bf3_k (a wave owns 16 rows and all columns; default) / "cs": tower_cs_k (round 6: 64-row workgroups, a wave owns output columns, the
+# layer input in LDS) for the fp16 x 2 arithmetic.  Measured on one box (profiles/r06_tower_cs.txt): the plain form 0.1965 against 0.2063 ms, the
+# DeepFM one-launch form (lookups inside) 0.260 against 0.2495 -- its input phase is two dependent HBM round trips with half the waves idle -- so
+# the default stays "rows" (the two kernels agree to rounding, not bit for bit: one switch for both forms keeps gather == plain bitwise)
+TOWER_KERNEL = os.environ.get("DIR_TOWER_KERNEL", "rows")
 TOWER_MIN_WIDTH = 128          # dense.tower_infer: a stage always computes 13 column tiles, so a narrower layer (ESMM's 80-wide one) pads more
                                # than the fusion saves (ESMM forward 0.574 ms layer by layer, 0.580 fused)
 TOWER = os.environ.get("DIR_TOWER", "auto")      # "0": never fuse (per-layer kernels)
@@ -1251,10 +1256,10 @@ def tower_image(weight, split=None):
         return hit[2]
     N, K = weight.shape
     lib = _lib.load()
-    nbytes = int(lib.dir_tower_bf16x3_image_bytes(K, N))
+    nbytes = int(lib.dir_tower_cs_image_bytes(K, N) if split == "f16x2cs" else lib.dir_tower_bf16x3_image_bytes(K, N))
     img = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     w = weight if weight.stride(1) == 1 else weight.contiguous()
-    pack = lib.dir_tower_f16x2_pack_f32 if split == "f16x2" else lib.dir_tower_bf16x3_pack_f32
+    pack = {"f16x2": lib.dir_tower_f16x2_pack_f32, "f16x2cs": lib.dir_tower_cs_f16x2_pack_f32}.get(split, lib.dir_tower_bf16x3_pack_f32)
     _lib.check(pack(_ptr(w), w.stride(0), K, N, _ptr(img), nbytes, _stream()))
     if capturing:
         return img                                # (as dense_bf3_image: the pack is part of the graph, the image graph-owned, nothing cached)
@@ -1351,9 +1356,11 @@ def tower(x, weights, biases=None, relu=True, post_scale=None, post_shift=None, 
         return t.data_ptr()
     Ns = (ctypes.c_int * L)(*[int(w.shape[0]) for w in weights])
     acts = (ctypes.c_int * L)(*[1 if r else 0 for r in relu_l])
-    imgs_t = [tower_image(_dev(w, torch.float32, "weight"), split) for w in weights]
-    f_tower = lib.dir_tower_f16x2_f32 if split == "f16x2" else lib.dir_tower_bf16x3_f32
-    f_gather = lib.dir_deepfm_tower_f16x2_f32 if split == "f16x2" else lib.dir_deepfm_tower_bf16x3_f32
+    # fp16 x 2: the column-split kernel (csrc/tower_cs.hip, round 6) unless DIR_TOWER_KERNEL=rows asks for tower_bf3_k's fp16 x 2 form
+    cs = split == "f16x2" and TOWER_KERNEL == "cs"
+    imgs_t = [tower_image(_dev(w, torch.float32, "weight"), "f16x2cs" if cs else split) for w in weights]
+    f_tower = lib.dir_tower_cs_f16x2_f32 if cs else (lib.dir_tower_f16x2_f32 if split == "f16x2" else lib.dir_tower_bf16x3_f32)
+    f_gather = lib.dir_deepfm_tower_cs_f16x2_f32 if cs else (lib.dir_deepfm_tower_f16x2_f32 if split == "f16x2" else lib.dir_deepfm_tower_bf16x3_f32)
     VP = ctypes.c_void_p * L
     imgs = VP(*[t.data_ptr() for t in imgs_t])
     b_arr = VP(*[vec(biases, l, Ns[l], "bias") for l in range(L)])

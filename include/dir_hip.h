@@ -621,6 +621,26 @@ int dir_deepfm_tower_f16x2_f32(const float* const* tables, const int64_t* vocab,
                                const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
                                const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
                                const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream);
+/* The same tower, COLUMN-SPLIT (csrc/tower_cs.hip, round 6; reference dnn_logit_fn, /root/reference/models/DeepFM/deepFM.py:284-319, and with
+ * the lookups inside the _model_fn graph, deepFM.py:217-223,321-335): a workgroup is 64 batch rows whose layer input sits in LDS as fp16 hi / lo
+ * pieces; every wave owns 3-4 output column tiles for all rows and reads ITS weight fragments straight from the L2-resident image (no LDS copy
+ * of the weights, two barriers per layer instead of one per stage).  fp16 x 2 arithmetic and every argument as dir_tower_f16x2_f32 /
+ * dir_deepfm_tower_f16x2_f32 (same preconditions, same error behaviour); the images come from dir_tower_cs_f16x2_pack_f32
+ * (dir_tower_cs_image_bytes(K, N) bytes: [k-step][column tile][piece][lane] in the matrix instruction's natural k order) and are NOT
+ * interchangeable with the other tower images.  Results agree with dir_tower_f16x2_f32 to rounding (another summation order inside a k-step and in
+ * the head's dot product), not bit for bit; the GATHER form and the plain form of THIS kernel agree bit for bit, and its FM / first-order terms are
+ * bit for bit dir_gather_fm_linear_packed_f32's. */
+int64_t dir_tower_cs_image_bytes(int K, int N);
+int dir_tower_cs_f16x2_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream);
+int dir_tower_cs_f16x2_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
+                           const float* const* bias, const float* const* post_scale, const float* const* post_shift, const int* act,
+                           const float* head_w, const float* head_b, const float* add0, const float* add1, float* out, int64_t out_ld,
+                           dir_stream_t stream);
+int dir_deepfm_tower_cs_f16x2_f32(const float* const* tables, const int64_t* vocab, int F, int K, int64_t ld, int lin_col,
+                                  const int64_t* ids, int64_t stride_b, int64_t stride_f, int want_fm, int64_t M, const float* lin_bias, int L,
+                                  const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
+                                  const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
+                                  const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream);
 /* dir_dense_gated_f32: Y = (gate > 0) ? X . Wt^T : 0 -- the data gradient of a dense layer taken straight through the previous
  * layer's ReLU: X = dL/d(pre-activation of layer l) [M, Kd = units of l], Wt = the TRANSPOSE of layer l's nn.Linear weight
  * ([in_l, units_l] rows), gate = layer l-1's output [M, N = in_l]; the result is dL/d(pre-activation of layer l-1). */

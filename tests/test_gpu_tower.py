@@ -7,6 +7,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["rows", "cs"])
+def _tower_kernel(request):
+    """Every test of this file under both tower kernels: tower_bf3_k (the default) and the column-split tower_cs_k (csrc/tower_cs.hip,
+    DIR_TOWER_KERNEL=cs; fp16 x 2 only -- bf16 x 3 requests run tower_bf3_k under either setting)."""
+    from dir_amd import ops
+    old = ops.TOWER_KERNEL
+    ops.TOWER_KERNEL = request.param
+    yield
+    ops.TOWER_KERNEL = old
+
+
 def _ref64(x, Ws, bs, relus, scales, shifts, head=None, adds=()):
     h = x.astype(np.float64)
     for W, b, r, sc, sh in zip(Ws, bs, relus, scales, shifts):

@@ -8,7 +8,7 @@ for spec in $1; do
     line="$w"
     for rep in 1 2; do
         for lib in "${libs[@]}"; do
-            ms=$(DIR_HIP_LIBRARY=$PWD/$lib DIR_BENCH_NO_SECONDARY=1 DIR_BENCH_NO_SWEEP=1 timeout -k 10 300 python3 bench.py --workload $w --steps ${STEPS:-30} --warmup 5 --no-cpu-baseline ${extra//,/ } 2>/dev/null | grep '^{' | tail -1 | python3 -c "import json,sys; print(round(json.loads(sys.stdin.read())['ms_per_step'],4))")
+            ms=$(DIR_HIP_LIBRARY=$PWD/$lib DIR_BENCH_NO_SECONDARY=1 DIR_BENCH_NO_SWEEP=1 timeout -k 10 300 python3 bench.py --workload $w --steps ${STEPS:-30} --warmup ${WARMUP:-5} --no-cpu-baseline ${extra//,/ } 2>/dev/null | grep '^{' | tail -1 | python3 -c "import json,sys; print(round(json.loads(sys.stdin.read())['ms_per_step'],4))")
             line="$line  $(basename $lib .so)=$ms"
         done
     done
