@@ -95,10 +95,21 @@ __device__ __forceinline__ unsigned int dp_pk_h(float a, float b) {
     return w;
 }
 __device__ __forceinline__ void dp_split2(float a, float b, unsigned int& hi, unsigned int& lo) {
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     hi = dp_pk_h(a, b);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_FMA_MIX)
+    // The residual a - float(fp16(a)) as ONE mixed-precision fma per element (v_fma_mix_f32 takes the fp16 half straight from the packed
+    // word; exact, bit for bit the convert + subtract it replaces).  The compiler does not select it (profiles/NOTES.md R5.8: in din_wave_k
+    // the asm cost more than it saved); THIS kernel is bound by VALU issue, and 583 -> 481 VALU instructions per 32-row pass of the MLP
+    // are 0.208 -> 0.199 ms at config 4 (R6.10).
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+    lo = dp_pk_h(ra, rb);
+#else
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const h2_t h = __builtin_bit_cast(h2_t, hi);
     lo = dp_pk_h(a - (float)h[0], b - (float)h[1]);
+#endif
 }
 __device__ __forceinline__ void dp_split8(const float4 s0, const float4 s1, dp_f16x8 (&x)[2]) {
     unsigned int w[2][4];

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
             TC_MARK();                                 // 3 + 4 l: main loop done
             // the epilogue's per-column vectors, requested BEFORE the barrier (unconditional loads from clamped addresses; a vector that does
             // not exist reads the weight image and is zeroed): their latency passes while the workgroup's slowest wave finishes its k loop
-            // (issued inside the epilogue they cost it ~2 000 cycles per layer: profiles/NOTES.md R6.10)
+            // (issued inside the epilogue they cost it ~2 000 cycles per layer: profiles/NOTES.md R6.9)
             const float* bias = p.bias[l];
             const float* sc = p.scale[l];
             const float* sh = p.shift[l];
