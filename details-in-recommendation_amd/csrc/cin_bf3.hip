@@ -135,7 +135,13 @@ constexpr int WPARTS = 32;
 __global__ __launch_bounds__(256) void cin_w_absmax_k(const float* __restrict__ W, int64_t n, float* __restrict__ part) {
     __shared__ float red[4];
     float mx = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(W[e]));
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(W) & 15) == 0 ? n >> 2 : 0;      // (16-byte loads: 10 -> ~4 us for a 128 x 3 328 weight)
+    const float4* W4 = reinterpret_cast<const float4*>(W);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const float4 v = W4[e];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int64_t e = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(W[e]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -164,7 +170,19 @@ constexpr int XBLOCKS = XPARTS / 2;
 __global__ __launch_bounds__(256) void cin_bits_absmax_k(const unsigned int* __restrict__ bits, int64_t n, float* __restrict__ xpart) {
     __shared__ unsigned int red[8];
     unsigned int mx = 0u, mn = 0x7f800000u;                   // bit patterns of non-negative floats order like the floats; mn over NON-ZERO rows
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    // (16-byte loads: with one word per load a thread walked 32 dependent-latency iterations over the 4 MB of a config-5 layer: 13.6 us)
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(bits) & 15) == 0 ? n >> 2 : 0;
+    const uint4* b4 = reinterpret_cast<const uint4*>(bits);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const uint4 v = b4[e];
+        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mx = max(mx, w[q]);
+            mn = w[q] ? min(mn, w[q]) : mn;
+        }
+    }
+    for (int64_t e = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const unsigned int b = bits[e];
         mx = max(mx, b);
         mn = b ? min(mn, b) : mn;
