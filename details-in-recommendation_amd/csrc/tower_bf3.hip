@@ -184,6 +184,16 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 2 : 1) void tower_bf3_k(const T
             }
     };
 
+    // GATHER: every slot's vocabulary bound and table base, once per workgroup, behind the two W stage buffers
+    uint64_t* const slot_info = reinterpret_cast<uint64_t*>(tw_smem + 2 * BUFB);
+    if constexpr (GATHER) {
+        if (tid < p.F) {
+            slot_info[2 * tid] = p.vocab ? (uint64_t)p.vocab[tid] : (uint64_t)1 << 63;
+            slot_info[2 * tid + 1] = reinterpret_cast<uint64_t>(p.tables[tid]);
+        }
+        __syncthreads();
+    }
+
     tw_f32x4 act[RT][TW_NT], acc[RT][TW_NT];
     int buf = 0;
     stage(0, 0, 0, 0);
@@ -201,18 +211,32 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 2 : 1) void tower_bf3_k(const T
             const int64_t* idp = p.ids + rr * p.ids_sb;
             tw_f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = sum;
             float lin = 0.f;
+            // Every slot's id first, then every row read (unconditional, from a clamped address), then the sums: written as one loop with the
+            // loads under their guards, each slot cost a chain of waited-for round trips (id -> bound -> table pointer -> row: 60 x
+            // s_waitcnt vmcnt(0) in the prologue's machine code, profiles/NOTES.md R6.11); the arithmetic and its order are unchanged.
+            int64_t idv[TW_NT];
+#pragma unroll
+            for (int ct = 0; ct < TW_NT; ++ct) idv[ct] = idp[(int64_t)(ct < p.F ? ct : 0) * p.ids_sf];
+            float lwv[TW_NT];
 #pragma unroll
             for (int ct = 0; ct < TW_NT; ++ct) {
-                tw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                float lw = 0.f;
-                if (ct < p.F) {
-                    const int64_t id = idp[(int64_t)ct * p.ids_sf];
-                    const uint64_t bound = p.vocab ? (uint64_t)p.vocab[ct] : (uint64_t)1 << 63;
-                    if ((uint64_t)id < bound) {
-                        const float* t = p.tables[ct] + id * p.row_ld;
-                        v = *reinterpret_cast<const tw_f32x4*>(t + 4 * g);
-                        if (g == 0 && p.lin_col >= 0) lw = t[p.lin_col];
-                    }
+                const int cc = ct < p.F ? ct : 0;
+                // the slot's bound and table base from LDS (staged once per workgroup: as global loads of p.vocab[cc] / p.tables[cc] each was a
+                // waited-for round trip in front of the slot's row read)
+                const uint64_t bound = slot_info[2 * cc];
+                const bool ok = ct < p.F && (uint64_t)idv[ct] < bound;
+                const float* t = reinterpret_cast<const float*>(slot_info[2 * cc + 1]) + (ok ? idv[ct] : 0) * p.row_ld;
+                act[rt][ct] = *reinterpret_cast<const tw_f32x4*>(t + 4 * g);
+                lwv[ct] = p.lin_col >= 0 ? t[g == 0 ? p.lin_col : 0] : 0.f;
+                idv[ct] = ok ? 1 : 0;                  // (from here on: the slot's validity)
+            }
+#pragma unroll
+            for (int ct = 0; ct < TW_NT; ++ct) {
+                tw_f32x4 v = act[rt][ct];
+                float lw = g == 0 ? lwv[ct] : 0.f;
+                if (!idv[ct]) {
+                    v = (tw_f32x4){0.f, 0.f, 0.f, 0.f};
+                    lw = 0.f;
                 }
                 act[rt][ct] = v;
                 sum += v;                              // f-ascending fp32 sums, as gather_packed_rows_k
@@ -502,7 +526,7 @@ static int tower_launch_rt(const char* name, const TowerParams& p, dir_stream_t 
     const int64_t ntiles = (p.M + TW_ROWS - 1) / TW_ROWS;
     const int64_t cap = kCUs;
     const int64_t nwg = ntiles < cap ? ntiles : cap;              // persistent workgroups: one per CU (8 waves x 256 or 4 x 512 registers), 78 / 52 KB of LDS
-    hipLaunchKernelGGL((tower_bf3_k<GATHER, NP, RT>), dim3((unsigned)nwg), dim3(512 / RT), 2 * tw_bufb(NP), as_stream(stream), p);
+    hipLaunchKernelGGL((tower_bf3_k<GATHER, NP, RT>), dim3((unsigned)nwg), dim3(512 / RT), 2 * tw_bufb(NP) + (GATHER ? 16 * TW_NT : 0), as_stream(stream), p);
     return DIR_OK;
 }
 template <bool GATHER, int NP>

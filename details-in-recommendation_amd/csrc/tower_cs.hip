@@ -50,7 +50,8 @@ constexpr int TC_STRIDE = 16 * TC_NT + 8;       // halves per LDS row: 848 bytes
 constexpr int TC_PIECE = TC_ROWS * TC_STRIDE;   // halves per piece plane
 constexpr int TC_ACT_BYTES = 2 * TC_PIECE * 2;  // 108 544
 constexpr int TC_DUMP = TC_ACT_BYTES + TC_NW * TC_ROWS * 4;      // 256 bytes the input prefetch's LDS-DMA lands in (never read)
-constexpr int TC_SMEM = TC_DUMP + 256;                           // act + the head's partial dots [wave][row] + the dump
+constexpr int TC_SLOTS = TC_DUMP + 256;                          // GATHER: every slot's vocabulary bound and table base (16 bytes each), staged once
+constexpr int TC_SMEM = TC_SLOTS + 16 * TC_NT;                   // act + the head's partial dots [wave][row] + the dump + the slot table
 
 struct TowerCsParams {
     const float* X;
@@ -136,6 +137,14 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
     const int r16 = lane & 15;
     const int g = lane >> 4;
     const int64_t ntiles = (p.M + TC_ROWS - 1) / TC_ROWS;
+    uint64_t* const slot_info = reinterpret_cast<uint64_t*>(tc_smem + TC_SLOTS);
+    if constexpr (GATHER) {          // (as global loads of p.vocab[ct] / p.tables[ct] each was a waited-for round trip in front of the slot's row read)
+        if (tid < p.F) {
+            slot_info[2 * tid] = p.vocab ? (uint64_t)p.vocab[tid] : (uint64_t)1 << 63;
+            slot_info[2 * tid + 1] = reinterpret_cast<uint64_t>(p.tables[tid]);
+        }
+        __syncthreads();
+    }
 
 #ifdef TC_STAMP
     int stamp_n = 0;
@@ -168,11 +177,12 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
 #pragma unroll
                 for (int ct = 0; ct < TC_NT; ++ct) {
                     const int cc = ct < p.F ? ct : 0;
-                    const uint64_t bound = p.vocab ? (uint64_t)p.vocab[cc] : (uint64_t)1 << 63;
+                    const uint64_t bound = slot_info[2 * cc];
                     const bool ok = ct < p.F && (uint64_t)idv[ct] < bound;
-                    const float* tr = p.tables[cc] + (ok ? idv[ct] : 0) * p.row_ld;
+                    const float* tr = reinterpret_cast<const float*>(slot_info[2 * cc + 1]) + (ok ? idv[ct] : 0) * p.row_ld;
                     vv[ct] = *reinterpret_cast<const tc_f32x4*>(tr + 4 * g);
-                    lwv[ct] = (g == 0 && p.lin_col >= 0) ? tr[p.lin_col] : 0.f;
+                    lwv[ct] = p.lin_col >= 0 ? tr[g == 0 ? p.lin_col : 0] : 0.f;
+                    if (g != 0) lwv[ct] = 0.f;
                     if (!ok) {
                         vv[ct] = (tc_f32x4){0.f, 0.f, 0.f, 0.f};
                         lwv[ct] = 0.f;

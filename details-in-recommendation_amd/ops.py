@@ -1194,11 +1194,12 @@ def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=
 TOWER_MAX_WIDTH = 416
 TOWER_MIN_ROWS = 4096          # below this the 128-row tiles leave most of the chip idle: the per-layer kernels run
 TOWER_GATHER = os.environ.get("DIR_TOWER_GATHER", "1")      # 0: DeepFM inference as two launches (packed gather, then the tower)
-# "rows": tower_bf3_k (a wave owns 16 rows and all columns; default) / "cs": tower_cs_k (round 6: 64-row workgroups, a wave owns output columns, the
-# layer input in LDS) for the fp16 x 2 arithmetic.  Measured on one box (profiles/r06_tower_cs.txt): the plain form 0.1965 against 0.2063 ms, the
-# DeepFM one-launch form (lookups inside) 0.260 against 0.2495 -- its input phase is two dependent HBM round trips with half the waves idle -- so
-# the default stays "rows" (the two kernels agree to rounding, not bit for bit: one switch for both forms keeps gather == plain bitwise)
-TOWER_KERNEL = os.environ.get("DIR_TOWER_KERNEL", "rows")
+# "cs": tower_cs_k (round 6, default: 64-row workgroups, the layer input in LDS, a wave owns output columns and reads its weights straight from L2) /
+# "rows": tower_bf3_k (a wave owns 16 rows and all columns) for the fp16 x 2 arithmetic; bf16 x 3 requests run tower_bf3_k under either setting.
+# One box, A B A B (profiles/r06_tower_cs.txt, r06_tower_cs_gather.txt): on a given input 0.1965 against 0.2063 ms, DeepFM in one launch 0.2142
+# against 0.2262, ESMM 0.3239 against 0.3372.  The two kernels agree to rounding, not bit for bit: ONE switch for the plain and the gather form keeps
+# those two bitwise equal.
+TOWER_KERNEL = os.environ.get("DIR_TOWER_KERNEL", "cs")
 TOWER_MIN_WIDTH = 128          # dense.tower_infer: a stage always computes 13 column tiles, so a narrower layer (ESMM's 80-wide one) pads more
                                # than the fusion saves (ESMM forward 0.574 ms layer by layer, 0.580 fused)
 TOWER = os.environ.get("DIR_TOWER", "auto")      # "0": never fuse (per-layer kernels)

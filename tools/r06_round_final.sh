@@ -38,8 +38,10 @@ DIR_CIN_BWD_SPLIT=bf16x3 DIR_DENSE_BWD_SPLIT=bf16x3 b cin_backward_bf16x3 --work
 b mlp_dense --workload mlp_dense --steps 200 --warmup 1000 --no-cpu-baseline
 DIR_TOWER_SPLIT=bf16x3 b mlp_dense_bf16x3 --workload mlp_dense --steps 200 --warmup 700 --no-cpu-baseline
 DIR_BENCH_DENSE=layers b mlp_dense_layers --workload mlp_dense --steps 200 --warmup 800 --no-cpu-baseline
-DIR_TOWER_RT=2 b mlp_dense_rt2 --workload mlp_dense --steps 200 --warmup 1000 --no-cpu-baseline
+DIR_TOWER_KERNEL=rows b mlp_dense_rows --workload mlp_dense --steps 200 --warmup 1000 --no-cpu-baseline
+DIR_TOWER_KERNEL=rows DIR_TOWER_RT=2 b mlp_dense_rt2 --workload mlp_dense --steps 200 --warmup 1000 --no-cpu-baseline
 b deepfm_full --workload deepfm_full --steps 200 --warmup 1000 --no-cpu-baseline
+DIR_TOWER_KERNEL=rows b deepfm_full_rows --workload deepfm_full --steps 200 --warmup 1000 --no-cpu-baseline
 DIR_TOWER_SPLIT=bf16x3 b deepfm_full_bf16x3 --workload deepfm_full --steps 200 --warmup 700 --no-cpu-baseline
 b dcn_full --workload dcn_full --steps 100 --warmup 400 --no-cpu-baseline
 b esmm_full --workload esmm_full --steps 200 --warmup 600 --no-cpu-baseline
@@ -83,7 +85,8 @@ if [ $part = pmc ] || [ $part = all ]; then
 export ROUND=r06
 bash tools/pmc.sh din din_pack_k -- --workload din --steps 5 --warmup 1 --no-cpu-baseline
 DIR_DIN_PACKED=0 bash tools/pmc.sh din_wave din_wave_k -- --workload din --steps 5 --warmup 1 --no-cpu-baseline
-bash tools/pmc.sh tower tower_bf3_k -- --workload mlp_dense --steps 5 --warmup 1 --no-cpu-baseline
+bash tools/pmc.sh tower tower_cs_k -- --workload mlp_dense --steps 5 --warmup 1 --no-cpu-baseline
+DIR_TOWER_KERNEL=rows bash tools/pmc.sh tower_rows tower_bf3_k -- --workload mlp_dense --steps 5 --warmup 1 --no-cpu-baseline
 bash tools/pmc.sh cin cin_ -- --workload cin --steps 3 --warmup 1 --no-cpu-baseline
 bash tools/pmc.sh cin_backward cin_ -- --workload cin_backward --steps 3 --warmup 1 --no-cpu-baseline
 bash tools/pmc_kernels.sh sharded_1gpu
