@@ -398,37 +398,83 @@ __global__ __launch_bounds__(512 / RT, RT == 1 ? 2 : 1) void tower_bf3_k(const T
             for (int rt = 0; rt < RT; ++rt) {
             const int64_t r = rrow[rt];
             float part = 0.f;                                     // head: this lane's share of the logit
+            // Three passes over the 26 tiles, each with its per-column vectors requested in two batches of 13 (unconditional loads from clamped
+            // addresses; a vector that does not exist reads the weight image and is not used): written as one loop with each load under its
+            // guard, every tile waited for its bias (and scale, shift, head weight) in turn -- 26 to 104 L2 round trips per layer and row tile,
+            // 144 x s_waitcnt vmcnt(0) in the kernel (profiles/NOTES.md R6.12).  Per element the operations and their order are unchanged.
+            const float* dummy = reinterpret_cast<const float*>(p.img[l]);
+            constexpr int HB = TW_NT / 2;
+            auto vec13 = [&](const float* src, int half, tw_f32x4 (&o)[HB]) {
 #pragma unroll
-            for (int ct = 0; ct < TW_NT; ++ct) {
-                const int col = 16 * ct + 4 * g;                  // N % 4 == 0: the lane's four columns are inside or outside together
-                tw_f32x4 v = acc[rt][ct];
-                if (col < N) {
-                    if (bias) v += *reinterpret_cast<const tw_f32x4*>(bias + col);
-                    if (relu) {
+                for (int q = 0; q < HB; ++q) {
+                    const int col = 16 * (half * HB + q) + 4 * g;
+                    o[q] = *reinterpret_cast<const tw_f32x4*>((src ? src : dummy) + (col < N ? col : 0));
+                }
+            };
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int half = 0; half < 2; ++half) {               // bias + activation
+                tw_f32x4 b4[HB];
+                vec13(bias, half, b4);
+#pragma unroll
+                for (int q = 0; q < HB; ++q) {
+                    const int ct = half * HB + q, col = 16 * ct + 4 * g;      // N % 4 == 0: the lane's four columns are inside or outside together
+                    tw_f32x4 v = acc[rt][ct];
+                    if (col < N) {
+                        if (bias) v += b4[q];
+                        if (relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        }
+                    } else {
+                        v = (tw_f32x4){0.f, 0.f, 0.f, 0.f};
                     }
-                    if (sc) {                                     // multiply then add, unfused (dense.hip's affine epilogue)
-                        const tw_f32x4 s4 = *reinterpret_cast<const tw_f32x4*>(sc + col), h4 = *reinterpret_cast<const tw_f32x4*>(sh + col);
+                    acc[rt][ct] = v;
+                }
+            }
+            if (sc) {                                            // (kernel-uniform) the inference batch-norm affine: multiply then add, unfused (dense.hip's affine epilogue)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] * s4[e] + h4[e];
-                    }
-                    if (last) {
-                        if (p.head_w) {
-                            const tw_f32x4 w4 = *reinterpret_cast<const tw_f32x4*>(p.head_w + col);
-                            part += v[0] * w4[0];
-                            part += v[1] * w4[1];
-                            part += v[2] * w4[2];
-                            part += v[3] * w4[3];
-                        } else if (r < p.M) {
-                            *reinterpret_cast<tw_f32x4*>(p.out + r * p.out_ld + col) = v;
+                for (int half = 0; half < 2; ++half) {
+                    tw_f32x4 s4[HB], h4[HB];
+                    vec13(sc, half, s4);
+                    vec13(sh, half, h4);
+#pragma unroll
+                    for (int q = 0; q < HB; ++q) {
+                        const int ct = half * HB + q, col = 16 * ct + 4 * g;
+                        if (col < N) {
+                            tw_f32x4 v = acc[rt][ct];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] * s4[q][e] + h4[q][e];
+                            acc[rt][ct] = v;
                         }
                     }
-                } else {
-                    v = (tw_f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                act[rt][ct] = v;
             }
+            if (last && p.head_w) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    tw_f32x4 w4[HB];
+                    vec13(p.head_w, half, w4);
+#pragma unroll
+                    for (int q = 0; q < HB; ++q) {
+                        const int ct = half * HB + q, col = 16 * ct + 4 * g;
+                        if (col < N) {
+                            const tw_f32x4 v = acc[rt][ct];
+                            part += v[0] * w4[q][0];
+                            part += v[1] * w4[q][1];
+                            part += v[2] * w4[q][2];
+                            part += v[3] * w4[q][3];
+                        }
+                    }
+                }
+            } else if (last && r < p.M) {
+#pragma unroll
+                for (int ct = 0; ct < TW_NT; ++ct) {
+                    const int col = 16 * ct + 4 * g;
+                    if (col < N) *reinterpret_cast<tw_f32x4*>(p.out + r * p.out_ld + col) = acc[rt][ct];
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < TW_NT; ++ct) act[rt][ct] = acc[rt][ct];
             if (last && p.head_w) {
                 part += __shfl_xor(part, 16, 64);                 // the row's other columns live in the other three lane groups
                 part += __shfl_xor(part, 32, 64);
