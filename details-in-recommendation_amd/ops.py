@@ -1192,7 +1192,10 @@ def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=
 
 
 TOWER_MAX_WIDTH = 416
-TOWER_MIN_ROWS = 4096          # below this the 128-row tiles leave most of the chip idle: the per-layer kernels run
+# Below this many rows the per-layer kernels run.  A one-launch forward costs one tile's time whatever the batch (63.5 us from a HIP graph for DeepFM
+# at B <= 4096: profiles/r06_tower_min_rows.txt); the per-layer route takes 48 / 57 / 66 / 78 us at B = 256 / 512 / 1024 / 2048 -- break-even near
+# 1000 rows (round 5's 4096 was set for tower_bf3_k's 128-row tiles and its serialised lookups)
+TOWER_MIN_ROWS = int(os.environ.get("DIR_TOWER_MIN_ROWS", "1024"))
 TOWER_GATHER = os.environ.get("DIR_TOWER_GATHER", "1")      # 0: DeepFM inference as two launches (packed gather, then the tower)
 # "cs": tower_cs_k (round 6, default: 64-row workgroups, the layer input in LDS, a wave owns output columns and reads its weights straight from L2) /
 # "rows": tower_bf3_k (a wave owns 16 rows and all columns) for the fp16 x 2 arithmetic; bf16 x 3 requests run tower_bf3_k under either setting.

@@ -46,7 +46,7 @@ def test_dense_mid_argument_errors(built_lib):
     assert rc == -1 and b"null pointer" in built_lib.dir_last_error()
 
 
-@pytest.mark.parametrize("B", [1024, 2048, 4096])
+@pytest.mark.parametrize("B", [768, 1024, 2048, 4096])      # (768: under ops.TOWER_MIN_ROWS, where DeepFM's layers run one by one too)
 @pytest.mark.parametrize("which", ["deepfm", "dcn"])
 def test_models_at_mid_batches_stay_on_hip_kernels(built_lib, monkeypatch, B, which):
     """DeepFM (26 x 16, 400-400-400) and DCN (d = 429, cross 3, deep 1024-1024 with batch norm) inference with the PRODUCT's routing threshold:

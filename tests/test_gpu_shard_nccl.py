@@ -123,7 +123,7 @@ def _scenarios(rank, world, device, transport):
     xm = XDeepFM(linear_feature_columns=None, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats], cin_layer_sizes=(64, 32),
                  dnn_hidden_units=(128, 128)).to(device).eval()
     ok = ops.cin_gather_covers(20, K, (64, 32))
-    for B in (1400 + 17 * rank, 8300):       # (row counts at which a micro-batch and the whole batch take the same dense kernels: those are chosen by row count)
+    for B in (2100 + 17 * rank, 8300):       # (row counts at which a micro-batch and the whole batch take the same kernels -- here the one-launch tower: they are chosen by row count)
         ids = _ids(gen, vocab_x, B, device)
         lin = (torch.randn((B, 1), generator=gen) * 0.1).to(device)
         with torch.no_grad():
