@@ -45,7 +45,10 @@ constexpr int TC_RT = TC_ROWS / 16;     // row tiles (all of them in every wave)
 constexpr int TC_CT = 4;                // column tiles a wave owns at most (26 tiles over 8 waves: 4 4 3 3 3 3 3 3)
 constexpr int TC_NT = 26;               // column tiles of 16: widths up to 416
 constexpr int TC_MAXL = 4;
-constexpr int TC_STRIDE = 16 * TC_NT + 8;       // halves per LDS row: 848 bytes = 212 words, 212 mod 32 = 20 -> eight consecutive rows' 16-byte pieces
+#ifndef TC_PAD
+#define TC_PAD 8
+#endif
+constexpr int TC_STRIDE = 16 * TC_NT + TC_PAD;       // halves per LDS row: 848 bytes = 212 words, 212 mod 32 = 20 -> eight consecutive rows' 16-byte pieces
                                                 // fall into eight different bank quads (conflict-free ds_read_b128 per eight lanes)
 constexpr int TC_PIECE = TC_ROWS * TC_STRIDE;   // halves per piece plane
 constexpr int TC_ACT_BYTES = 2 * TC_PIECE * 2;  // 108 544

@@ -941,7 +941,8 @@ def xdeepfm_predict(model, tables, ids, linear_logit=None):
         if tables.check == "eager":
             out = torch.empty((B, 1), dtype=torch.float32, device=ids.device)
             for s, e, rows, inv in tables.lookup_rows(ids):
-                out[s:e] = model.forward_rows(rows, inv, None if linear_logit is None else linear_logit[s:e], absmax=amax)
+                if e > s:
+                    out[s:e] = model.forward_rows(rows, inv, None if linear_logit is None else linear_logit[s:e], absmax=amax)
             return out
         return model.forward_embedded(tables.lookup(ids), linear_logit, range_ok=ops.f16_range_ok(amax))
     finally:
