@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """tools/vmcnt_scan.py: compile every csrc/*.hip to gfx950 assembly with the library's flags and list, per kernel, how many vector-memory LOADS are
-waited for with `s_waitcnt vmcnt(0)` before the NEXT load is issued (a chain of round trips: the pattern behind NOTES R6.2 / R6.8 / R6.11).  CPU-side."""
+waited for with `s_waitcnt vmcnt(0)` before the NEXT load is issued (a chain of round trips: the pattern behind NOTES R6.2 / R6.8 / R6.11 / R6.12).
+Kernels with at least SCAN_MIN (default 6) such waits are listed.  A long chain matters where nothing else on the CU hides it (one workgroup per
+CU: the towers, the packed DIN unit); bag_csr_k shows 15-23 and runs at the one-hot gather's row rate all the same (many resident waves).  CPU-side."""
 import os, re, subprocess, sys
 here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "details-in-recommendation_amd")
 sys.path.insert(0, here)
@@ -37,7 +39,7 @@ def scan(src):
         elif op in ("s_barrier", "s_endpgm") or op.startswith("s_cbranch") and False:
             pass
     for k, v in sorted(best.items(), key=lambda kv: -kv[1]):
-        if v >= 6:
+        if v >= int(os.environ.get("SCAN_MIN", "6")):
             d = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()
             print("%-22s %4d load-then-vmcnt(0) waits   %s" % (src, v, d[:150]))
 
