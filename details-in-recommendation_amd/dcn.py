@@ -152,18 +152,22 @@ class DeepCrossNetwork(nn.Module):
         x0p = self.input_layer(features, pad_to=4)
         wp, bp = self._padded_cross_params()
         wl = self.logits_layer.weight                                            # [1, d + h]
-        wc = torch.nn.functional.pad(wl[:, :d], (0, dp - d))
+        key = (wl._version, wl.data_ptr())
+        if getattr(self, "_logit_split_key", None) != key:                       # the two halves of the final dense(1)'s weight, aligned copies, once per version
+            self._logit_split = (torch.nn.functional.pad(wl.data[:, :d], (0, dp - d)), wl.data[:, d:].clone())
+            self._logit_split_key = key
+        wc, wd = self._logit_split
         cross_logit = ops.cross_network_head(x0p, wp, bp, wc)                    # [B, 1] = x_L . w_c in the cross kernel's epilogue: x_L is not written
         out = cross_logit.add_(self.logits_layer.bias)
-        deep_logit = self._deep_logit(x0p, wl[:, d:])                            # the last deep layer with deep . w_d in its epilogue, when covered
+        deep_logit = self._deep_logit(x0p, wd)                                   # the last deep layer with deep . w_d in its epilogue, when covered
         if deep_logit is not None:
             out.add_(deep_logit)
         else:
             deep = self.deep_architecture(x0p)                                   # dense_act pads the first weight (in_features d -> dp)
             if deep.is_cuda and deep.dtype == torch.float32 and deep.stride(1) == 1:
-                out.add_(ops.units1(deep, wl[:, d:]))                            # dir_units1_f32 (the library runs this one-column product as a GEMM: 27 us at 256 x 1024)
+                out.add_(ops.units1(deep, wd))                                   # dir_units1_f32 (the library runs this one-column product as a GEMM: 27 us at 256 x 1024)
             else:
-                out.addmm_(deep, wl[:, d:].t())
+                out.addmm_(deep, wd.t())
         raise_pending()
         return out
 

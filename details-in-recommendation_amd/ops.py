@@ -1185,6 +1185,10 @@ def dense_head(x, weight, bias, head_w, relu=False, post_scale=None, post_shift=
     fn = lib.dir_dense_f16x2_head_f32 if f16 else lib.dir_dense_bf16x3_head_f32
     _lib.check(fn(_ptr(x), x.stride(0), _ptr(dense_bf3_image(weight, "f16x2" if f16 else "bf16x3")), _ptr(bias), 1 if relu else 0, _ptr(post_scale),
                   _ptr(post_shift), M, Kd, N, _ptr(hw), None, 0, _ptr(part), _stream()))
+    if ncb > 1 and M % 4 == 0:                            # the column blocks' partial dots, added in block order by ONE launch (ncb launches as torch ops)
+        out = torch.empty(M, dtype=torch.float32, device=x.device)
+        _lib.check(lib.dir_sum_partials_f32(_ptr(part), ncb, M, 0, _ptr(out), _stream()))
+        return out.reshape(M, 1)
     out = part[0].clone() if ncb > 1 else part[0]
     for cb in range(1, ncb):                              # block order: a fixed order
         out += part[cb]
