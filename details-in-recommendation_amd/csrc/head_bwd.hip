@@ -344,3 +344,28 @@ extern "C" int dir_units1_backward_f32(const float* g, const float* w, const flo
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }
+
+// ESMM's prediction head in inference (models/ESMM/ESMM.py:67-77, stated here as in esmm.ESMM.forward): p = sigmoid(ctr) * sigmoid(cvr),
+// clipped to [1e-7, 1 - 1e-7], ctcvr_logit = log(p / (1 - p)) -- seven elementwise library launches over [B, 1] as one.  The operations and
+// their order are the reference's; exp / log are the device library's single-precision functions.
+namespace dir {
+__global__ __launch_bounds__(256) void esmm_head_k(const float* __restrict__ ctr, const float* __restrict__ cvr, int64_t B, float eps,
+                                                   float* __restrict__ ctcvr_logit) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256) {
+        const float a = 1.0f / (1.0f + expf(-ctr[i])), b = 1.0f / (1.0f + expf(-cvr[i]));
+        float p = a * b;
+        p = fminf(fmaxf(p, eps), 1.0f - eps);
+        ctcvr_logit[i] = logf(p / (1.0f - p));
+    }
+}
+}  // namespace dir
+
+extern "C" int dir_esmm_head_f32(const float* ctr_logit, const float* cvr_logit, int64_t B, float eps, float* ctcvr_logit, dir_stream_t stream) {
+    const char* name = "dir_esmm_head_f32";
+    DIR_CHECK_ARG(B >= 0 && eps > 0.f && eps < 0.5f, "%s: B=%lld eps=%g", name, (long long)B, eps);
+    if (B == 0) return DIR_OK;
+    DIR_CHECK_ARG(ctr_logit && cvr_logit && ctcvr_logit, "%s: null pointer", name);
+    hipLaunchKernelGGL(dir::esmm_head_k, dim3(grid_for((B + 255) / 256)), dim3(256), 0, as_stream(stream), ctr_logit, cvr_logit, B, eps, ctcvr_logit);
+    DIR_CHECK_LAUNCH(name);
+    return DIR_OK;
+}

@@ -20,6 +20,7 @@ from .dcn import _glorot_normal_
 from .deepfm import _dropout_train, _glorot_uniform_
 from .input_layer import InputLayer
 from ._input import checked_forward as _checked_forward
+from . import ops
 
 _EPSILON = 1e-7                                                                  # ESMM.py:19
 
@@ -147,9 +148,14 @@ class ESMM(nn.Module):
         memo = {}                                                                # both towers read the same columns: one id matrix
         ctr_logits = self.ctr_model(features, memo)
         cvr_logits = self.cvr_model(features, memo)
-        ctcvr_logistic = torch.sigmoid(ctr_logits) * torch.sigmoid(cvr_logits)  # :69-71
-        p = ctcvr_logistic.clamp(_EPSILON, 1 - _EPSILON)                         # :73-74
-        out = {"ctr_logits": ctr_logits, "ctcvr_logits": torch.log(p / (1 - p)), "cvr_logits": cvr_logits}
+        if (not torch.is_grad_enabled() and ctr_logits.is_cuda and ctr_logits.dtype == torch.float32 and ctr_logits.is_contiguous()
+                and cvr_logits.is_contiguous() and ctr_logits.shape == cvr_logits.shape):
+            ctcvr_logits = ops.esmm_head(ctr_logits, cvr_logits, _EPSILON)      # inference: :69-74 in one launch (seven library launches otherwise)
+        else:
+            ctcvr_logistic = torch.sigmoid(ctr_logits) * torch.sigmoid(cvr_logits)  # :69-71
+            p = ctcvr_logistic.clamp(_EPSILON, 1 - _EPSILON)                         # :73-74
+            ctcvr_logits = torch.log(p / (1 - p))
+        out = {"ctr_logits": ctr_logits, "ctcvr_logits": ctcvr_logits, "cvr_logits": cvr_logits}
         from ._input import raise_pending
         raise_pending()                                                          # id-range verdicts of both towers' input layers
         return out

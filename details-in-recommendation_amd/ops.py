@@ -2055,6 +2055,18 @@ def cin_layer(x0, xk, W, pooled=None, want_xout=True, arith=None, z_out=None, gr
     return xout, pooled
 
 
+def esmm_head(ctr_logits, cvr_logits, eps=1e-7):
+    """ESMM's ctcvr logit from the two towers' logits (include/dir_hip.h: dir_esmm_head_f32; ESMM.py:67-77): log(p / (1 - p)) with
+    p = clip(sigmoid(ctr) * sigmoid(cvr), eps, 1 - eps).  Inference only (no autograd)."""
+    _dev(ctr_logits, torch.float32, "ctr_logits")
+    _dev(cvr_logits, torch.float32, "cvr_logits")
+    if ctr_logits.shape != cvr_logits.shape or not ctr_logits.is_contiguous() or not cvr_logits.is_contiguous():
+        raise ValueError("esmm_head: two contiguous tensors of one shape")
+    out = torch.empty_like(ctr_logits)
+    _lib.check(_lib.load().dir_esmm_head_f32(_ptr(ctr_logits), _ptr(cvr_logits), ctr_logits.numel(), float(eps), _ptr(out), _stream()))
+    return out
+
+
 def cin_gather_covers(m, D, Hs):
     """Shapes and routing switches under which cin_stack_gather runs EXACTLY the kernels cin_layer(arith=None) would run on the materialised
     x0 (the default forward routing: the first layer over field pairs on scaled fp16 x 2, later layers behind the device-side verdict, the

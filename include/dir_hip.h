@@ -641,6 +641,9 @@ int dir_deepfm_tower_cs_f16x2_f32(const float* const* tables, const int64_t* voc
                                   const int* N, const void* const* images, const float* const* bias, const float* const* post_scale,
                                   const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
                                   const float* add0, const float* add1, float* out, int64_t out_ld, dir_stream_t stream);
+/* dir_esmm_head_f32: ESMM's prediction head in inference (/root/reference/models/ESMM/ESMM.py:67-77): p = sigmoid(ctr_logit) * sigmoid(cvr_logit),
+ * clipped to [eps, 1 - eps] (the reference's 1e-7), ctcvr_logit = log(p / (1 - p)); [B] contiguous each.  One launch for seven elementwise ops. */
+int dir_esmm_head_f32(const float* ctr_logit, const float* cvr_logit, int64_t B, float eps, float* ctcvr_logit, dir_stream_t stream);
 /* dir_dense_gated_f32: Y = (gate > 0) ? X . Wt^T : 0 -- the data gradient of a dense layer taken straight through the previous
  * layer's ReLU: X = dL/d(pre-activation of layer l) [M, Kd = units of l], Wt = the TRANSPOSE of layer l's nn.Linear weight
  * ([in_l, units_l] rows), gate = layer l-1's output [M, N = in_l]; the result is dL/d(pre-activation of layer l-1). */

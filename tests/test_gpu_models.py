@@ -1040,3 +1040,22 @@ def test_sharded_lookup_fixed_capacity_paths_single_gpu(built_lib, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_esmm_head_entry_matches_the_reference_op_sequence(built_lib):
+    """dir_esmm_head_f32 (ESMM.py:67-77 in one launch) against the same ops in float64, incl. saturated logits where the clip to [1e-7, 1 - 1e-7] decides."""
+    from dir_amd import ops
+    g = torch.Generator().manual_seed(12)
+    ctr = torch.cat([torch.randn(5000, generator=g) * 3, torch.tensor([40.0, -40.0, 0.0, 25.0, 90.0, -90.0])]).reshape(-1, 1).cuda()
+    cvr = torch.cat([torch.randn(5000, generator=g) * 3, torch.tensor([40.0, 40.0, 0.0, -25.0, 90.0, -90.0])]).reshape(-1, 1).cuda()
+    got = ops.esmm_head(ctr, cvr, 1e-7)
+    p = (torch.sigmoid(ctr.double()) * torch.sigmoid(cvr.double())).clamp(1e-7, 1 - 1e-7)
+    ref = torch.log(p / (1 - p))
+    p32 = (torch.sigmoid(ctr) * torch.sigmoid(cvr)).clamp(1e-7, 1 - 1e-7)
+    lib_form = torch.log(p32 / (1 - p32))                                     # the library's fp32 op sequence (esmm.ESMM.forward under autograd)
+    assert got.shape == ctr.shape and bool(torch.isfinite(got).all())
+    # fp32 evaluates 1 - p at p near 1 with one bit to spare: hold the kernel to the fp32 library form's own distance from float64
+    err = float(((got.double() - ref).abs() / (1 + ref.abs())).max())
+    err_lib = float(((lib_form.double() - ref).abs() / (1 + ref.abs())).max())
+    assert err <= max(2e-6, 2 * err_lib), (err, err_lib)
+    assert built_lib.dir_esmm_head_f32(None, None, 8, 1e-7, None, None) != 0 and b"null pointer" in built_lib.dir_last_error()
