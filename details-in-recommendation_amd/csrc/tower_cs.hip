@@ -24,6 +24,10 @@
 // tower_bf3_k<GATHER>'s lanes, so the FM and first-order terms are formed in the same order and are bit for bit gather_packed_rows_k's),
 // split them and store them as layer 1's input.
 //
+// Row scaling (RS, the default; DIR_TOWER_RS=0 switches it off for A/B timing): every stored layer input row carries its own power-of-two
+// scale (see tc_row_sft below), so that activations of any magnitude -- not only the caller's inputs and weights, which the host checks --
+// survive the split into fp16 pieces.  Costs 5-6 % of the launch at B = 65 536 (profiles/NOTES.md R6.17).
+//
 // This file holds matrix instructions and is compiled without packed fp32 VALU instructions (build.py; isa_check.py).
 #include <type_traits>
 
@@ -45,6 +49,11 @@ constexpr int TC_RT = TC_ROWS / 16;     // row tiles (all of them in every wave)
 constexpr int TC_CT = 4;                // column tiles a wave owns at most (26 tiles over 8 waves: 4 4 3 3 3 3 3 3)
 constexpr int TC_NT = 26;               // column tiles of 16: widths up to 416
 constexpr int TC_MAXL = 4;
+#ifndef TC_WIN_MAX_E
+#define TC_WIN_MAX_E -3
+#endif
+constexpr int TC_WIN_MAX = TC_WIN_MAX_E;          // RS: a row whose exact max |element| is in [2^-3, 2^15) is stored unscaled (second piece's resolution 2^-24 <= 2^-21 max)
+constexpr int TC_WIN_BOUND = 2;         // RS: ... whose BOUND is in [2^2, 2^15): the bound overestimates by 10-100 (<= 2^7: the same 2^-21)
 #ifndef TC_PAD
 #define TC_PAD 8
 #endif
@@ -54,7 +63,10 @@ constexpr int TC_PIECE = TC_ROWS * TC_STRIDE;   // halves per piece plane
 constexpr int TC_ACT_BYTES = 2 * TC_PIECE * 2;  // 108 544
 constexpr int TC_DUMP = TC_ACT_BYTES + TC_NW * TC_ROWS * 4;      // 256 bytes the input prefetch's LDS-DMA lands in (never read)
 constexpr int TC_SLOTS = TC_DUMP + 256;                          // GATHER: every slot's vocabulary bound and table base (16 bytes each), staged once
-constexpr int TC_SMEM = TC_SLOTS + 16 * TC_NT;                   // act + the head's partial dots [wave][row] + the dump + the slot table
+constexpr int TC_ROWF = TC_SLOTS + 16 * TC_NT;                   // RS: [layer parity][batch row] 2^s, s the power of two the stored layer input was divided by
+constexpr int TC_ROWMAX = TC_ROWF + 2 * 4 * TC_ROWS;             // RS: [layer parity][batch row] the bit pattern of max |layer input| before scaling (LDS atomic max)
+constexpr int TC_CST = TC_ROWMAX + 2 * 4 * TC_ROWS;              // RS: per layer (a, b): max |output| <= a * max |input| + b (tc_layer_bound)
+constexpr int TC_SMEM = TC_CST + 8 * TC_MAXL;                    // act + the head's partial dots [wave][row] + the dump + the slot table + the rows' scales
 
 struct TowerCsParams {
     const float* X;
@@ -62,6 +74,7 @@ struct TowerCsParams {
     int Kd, L;
     int N[TC_MAXL];
     const unsigned char* img[TC_MAXL];
+    const float* wnorm[TC_MAXL];     // the image's trailer: max over output columns of sum_k |W[n][k]|
     const float* bias[TC_MAXL];
     const float* scale[TC_MAXL];
     const float* shift[TC_MAXL];
@@ -92,10 +105,42 @@ __device__ __forceinline__ unsigned int tc_pk_h(float a, float b) {     // v_cvt
 }
 // (a, b) -> the packed hi pair and the packed lo pair (the residuals after rounding to fp16)
 __device__ __forceinline__ void tc_split(float a, float b, unsigned int& hi, unsigned int& lo) {
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     hi = tc_pk_h(a, b);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TC_NO_FMA_MIX)
+    // the residual as one mixed-precision fma per element (din_pack.hip: dp_split2; exact, bit for bit the convert + subtract): the epilogue
+    // between two layers is bound by VALU issue (two waves per SIMD, ~25 instructions per four values)
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+    lo = tc_pk_h(ra, rb);
+#else
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const h2_t h = __builtin_bit_cast(h2_t, hi);
     lo = tc_pk_h(a - (float)h[0], b - (float)h[1]);
+#endif
+}
+// Row scaling (RS): a stored row is multiplied by a power of two 2^-s -- exact -- and the layer's result by 2^s again in the epilogue (exact):
+// whatever the activations' magnitudes, the fp16 pieces neither overflow (65 504) nor lose their second piece to fp16's subnormals.
+// Layer 1's input: s puts the row's largest |element| into [2^13, 2^14).  A later layer's input is stored by eight waves that each see their own
+// columns only; instead of a second pass behind a barrier, s comes from a BOUND the waves all know before they store:
+//     max_n |out[n]| <= a * max_k |in[k]| + b,    a = max_n |scale[n]| * max_n sum_k |W[n][k]|,   b = max_n |scale[n]| * max_n |bias[n]| + max_n |shift[n]|
+// (the weight norm from the image's trailer, pack time; the bias / affine maxima once per workgroup; max |in| is the ACTUAL maximum of the row,
+// collected with LDS atomics while the previous layer stored it, so the bounds do not compound).  The bound puts the row's largest element
+// at or below 2^14; it may overestimate by 2^17 before the second piece's resolution (2^-24 absolute) exceeds 2^-22 of the row's maximum --
+// sum |w| against a dot product's sqrt(K) is a factor 10-100.
+// tc_row_sft -> s from the bit pattern of the row's maximum or bound (0 / subnormal: 0).
+// A maximum in [2^lo, 2^15) leaves the row as it is (s = 0): the workgroup's ordinary case, which skips the multiplications.
+__device__ __forceinline__ int tc_row_sft(unsigned int maxbits, int lo) {
+    const int e = (int)((maxbits >> 23) & 0xffu);
+    const int sft = (e == 0 || (e - 127 >= lo && e - 127 <= 14)) ? 0 : e - 127 - 13;
+    return sft < -100 ? -100 : (sft > 100 ? 100 : sft);
+}
+__device__ __forceinline__ float tc_pow2(int s) { return __builtin_bit_cast(float, (unsigned int)(127 + s) << 23); }
+__device__ __forceinline__ int tc_byte(unsigned int packed, int i) { return (int)(signed char)(packed >> (8 * i)); }
+// max(m, |v[0..3]|): two v_max3_f32 with |.| source modifiers (m >= 0; as a bit pattern it orders like the float)
+__device__ __forceinline__ float tc_absmax(const tc_f32x4 v, float m) {
+    m = fmaxf(fmaxf(m, fabsf(v[0])), fabsf(v[1]));
+    return fmaxf(fmaxf(m, fabsf(v[2])), fabsf(v[3]));
 }
 // four consecutive values of one batch row -> the 8 bytes of each piece plane
 __device__ __forceinline__ void tc_store4(_Float16* act, int row, int col, const tc_f32x4 v) {
@@ -129,7 +174,17 @@ __global__ __launch_bounds__(256) void tower_cs_pack_k(const float* __restrict__
     }
 }
 
-template <bool GATHER>
+// the image's trailer: max_n sum_k |W[n][k]| as a bit pattern (atomic max over the rows; zeroed by the caller).  One wave per output column.
+__global__ __launch_bounds__(64) void tower_cs_norm_k(const float* __restrict__ W, int64_t w_ld, int K, unsigned int* __restrict__ out) {
+    const float* w = W + (int64_t)blockIdx.x * w_ld;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) s += fabsf(w[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) atomicMax(out, __builtin_bit_cast(unsigned int, s * 1.0001f));      // (the sum's own rounding: K 2^-24)
+}
+
+template <bool GATHER, bool RS>
 __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
     _Float16* const act = reinterpret_cast<_Float16*>(tc_smem);                 // [2 pieces][64 rows][TC_STRIDE]
@@ -141,6 +196,49 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
     const int g = lane >> 4;
     const int64_t ntiles = (p.M + TC_ROWS - 1) / TC_ROWS;
     uint64_t* const slot_info = reinterpret_cast<uint64_t*>(tc_smem + TC_SLOTS);
+    int* const rowsft = reinterpret_cast<int*>(tc_smem + TC_ROWF);                   // RS: [layer parity][row] s of the stored layer input's row (it holds x 2^-s)
+    unsigned int* const rowmax = reinterpret_cast<unsigned int*>(tc_smem + TC_ROWMAX);   // RS: [layer parity][row] max |unscaled layer input|
+    float* const cst = reinterpret_cast<float*>(tc_smem + TC_CST);                   // RS: [layer] (a, b) of the output bound
+    if constexpr (RS) {
+        // the layers' bound constants, once per workgroup, by a wave the GATHER input phase leaves idle; read behind the first input barrier.
+        // (Tried: the reductions as LDS atomics instead of shuffles, and the whole block moved behind the wave's first k loop -- both slower
+        // by 2-4 % of the launch, profiles/NOTES.md R6.17.)
+#ifndef TC_ABL_RS_PRO
+        if (wave == TC_NW - 1) {
+            for (int l = 0; l + 1 < p.L; ++l) {
+                const int N = p.N[l];
+                const float* dummy = reinterpret_cast<const float*>(p.img[l]);
+                const float* bias = p.bias[l];
+                const float* sc = p.scale[l];
+                const float* sh = p.shift[l];
+                float bm = 0.f, sm = 0.f, hm = 0.f;
+#pragma unroll
+                for (int i = 0; i < (16 * TC_NT + 63) / 64; ++i) {
+                    const int j = lane + 64 * i;
+                    const int jj = j < N ? j : 0;
+                    const float b = (bias ? bias : dummy)[jj], s1 = (sc ? sc : dummy)[jj], h = (sh ? sh : dummy)[jj];
+                    if (j < N) {
+                        bm = fmaxf(bm, fabsf(b));
+                        sm = fmaxf(sm, fabsf(s1));
+                        hm = fmaxf(hm, fabsf(h));
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    bm = fmaxf(bm, __shfl_xor(bm, o, 64));
+                    sm = fmaxf(sm, __shfl_xor(sm, o, 64));
+                    hm = fmaxf(hm, __shfl_xor(hm, o, 64));
+                }
+                if (!bias) bm = 0.f;
+                if (!sc) { sm = 1.f; hm = 0.f; }
+                if (lane == 0) {
+                    cst[2 * l] = sm * p.wnorm[l][0];
+                    cst[2 * l + 1] = sm * bm + hm;
+                }
+            }
+        }
+#endif
+    }
     if constexpr (GATHER) {          // (as global loads of p.vocab[ct] / p.tables[ct] each was a waited-for round trip in front of the slot's row read)
         if (tid < p.F) {
             slot_info[2 * tid] = p.vocab ? (uint64_t)p.vocab[tid] : (uint64_t)1 << 63;
@@ -191,14 +289,36 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
                         lwv[ct] = 0.f;
                     }
                 }
+                float mf = 0.f;
 #pragma unroll
                 for (int ct = 0; ct < TC_NT; ++ct) {
                     const tc_f32x4 v = vv[ct];
                     sum += v;                          // f-ascending fp32 sums, as gather_packed_rows_k
                     sq += v * v;
                     lin = lin + lwv[ct];
-                    if (16 * ct < kd32) tc_store4(act, lr, 16 * ct + 4 * g, v);
+                    if constexpr (RS) mf = tc_absmax(v, mf);
+                    if (16 * ct < kd32) tc_store4(act, lr, 16 * ct + 4 * g, v);      // as the rows arrive
                 }
+#ifndef TC_ABL_RS_IN
+                if constexpr (RS) {                    // the row's largest |element| over its four lanes -> its power-of-two scale; a row outside
+                    mf = fmaxf(mf, __shfl_xor(mf, 16, 64));                        // the window is stored again, scaled (the rare case)
+                    mf = fmaxf(mf, __shfl_xor(mf, 32, 64));
+                    const unsigned int mb = __builtin_bit_cast(unsigned int, mf);
+                    const int sft = tc_row_sft(mb, TC_WIN_MAX);
+                    const float down = tc_pow2(-sft);
+                    if (g == 0) {
+                        rowsft[lr] = sft;
+                        rowmax[lr] = mb;
+                    }
+                    if (sft != 0) {
+#pragma unroll
+                        for (int ct = 0; ct < TC_NT; ++ct)
+                            if (16 * ct < kd32) tc_store4(act, lr, 16 * ct + 4 * g, vv[ct] * down);
+                    }
+                }
+#else
+                if (g == 0) { rowsft[lr] = 0; rowmax[lr] = 0x3f800000u; }
+#endif
                 if (p.want_fm) {                       // 0.5 * sum_k (sum^2 - sq), k ascending through the row's four lanes: fm_tail<4>'s chain
                     const tc_f32x4 d = sum * sum - sq;
                     float acc_fm = 0.f;
@@ -227,11 +347,40 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
 #endif
                 if (k >= p.Kd) vv[i] = (tc_f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            float mf = 0.f;
 #pragma unroll
-            for (int i = 0; i < 13; ++i) {
+            for (int i = 0; i < 13; ++i) {             // stored as they arrive
                 const int k = 4 * (seg + 8 * i);
+                if constexpr (RS) mf = tc_absmax(vv[i], mf);
                 if (k < kd32) tc_store4(act, lr, k, vv[i]);
             }
+#ifndef TC_ABL_RS_IN
+            if constexpr (RS) {                        // eight consecutive lanes hold a row; a row outside the window is stored again, scaled
+                // (DPP: lanes 1 and 2 apart inside the quad, then the other quad of the eight -- a shuffle is an LDS round trip each)
+                int mi = __builtin_bit_cast(int, mf);
+                mf = fmaxf(mf, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(mi, 0xB1, 0xf, 0xf, true)));     // quad_perm [1,0,3,2]
+                mi = __builtin_bit_cast(int, mf);
+                mf = fmaxf(mf, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(mi, 0x4E, 0xf, 0xf, true)));     // quad_perm [2,3,0,1]
+                mi = __builtin_bit_cast(int, mf);
+                mf = fmaxf(mf, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(mi, 0x141, 0xf, 0xf, true)));    // row_half_mirror
+                const unsigned int mb = __builtin_bit_cast(unsigned int, mf);
+                const int sft = tc_row_sft(mb, TC_WIN_MAX);
+                const float down = tc_pow2(-sft);
+                if (seg == 0) {
+                    rowsft[lr] = sft;
+                    rowmax[lr] = mb;
+                }
+                if (sft != 0) {
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) {
+                        const int k = 4 * (seg + 8 * i);
+                        if (k < kd32) tc_store4(act, lr, k, vv[i] * down);
+                    }
+                }
+            }
+#else
+            if (seg == 0) { rowsft[lr] = 0; rowmax[lr] = 0x3f800000u; }
+#endif
         }
         TC_MARK();                                     // 1: input stored
         __syncthreads();
@@ -268,6 +417,9 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
             const int c0 = wave * base + (wave < rem ? wave : rem);
             const int cnt = base + (wave < rem ? 1 : 0);                 // tiles this wave stores (<= TC_CT)
             const int creal = nct - c0 < cnt ? (nct - c0 > 0 ? nct - c0 : 0) : cnt;      // ... of which these have matrix work
+            if constexpr (RS) {     // the maxima this layer's epilogue collects: last read one layer ago (a barrier back), first written a barrier ahead
+                if (tid < TC_ROWS) rowmax[((l + 1) & 1) * TC_ROWS + tid] = 0u;
+            }
 
             tc_f32x4 acc[TC_CT][TC_RT];
 #pragma unroll
@@ -290,6 +442,29 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
             // The k loop once per tile count (a compile-time NC: straight-line blocks of 12 NC matrix instructions; with the count as a run-time
             // guard inside the loop the compiler emitted a branch around every four of them and the matrix pipe ran at half rate).
             // (TC_ABL_*: timing ablations, WRONG results -- development builds through tools/ab_variant.sh only)
+            // RS: the exponents of this layer's input rows (s) and of the rows it stores (s'), one byte per row tile, and whether any differs
+            // from 0 -- LDS reads, the bound, a vote: a dependent chain, run behind the first k-step's loads (two registers instead of twelve
+            // across the k loop)
+            unsigned int pin = 0u, pout = 0u;
+            bool scaled = false;                       // wave-uniform
+            auto rs_chain = [&]() {
+#ifndef TC_ABL_RS_CHAIN
+                if constexpr (RS) {
+                    const int cur = (l & 1) * TC_ROWS;
+#pragma unroll
+                    for (int rt = 0; rt < TC_RT; ++rt) pin |= ((unsigned int)rowsft[cur + 16 * rt + r16] & 0xffu) << (8 * rt);
+                    if (!last) {
+                        const float ca = cst[2 * l], cb = cst[2 * l + 1];
+#pragma unroll
+                        for (int rt = 0; rt < TC_RT; ++rt) {
+                            const float bound = ca * __builtin_bit_cast(float, rowmax[cur + 16 * rt + r16]) + cb;
+                            pout |= ((unsigned int)tc_row_sft(__builtin_bit_cast(unsigned int, bound), TC_WIN_BOUND) & 0xffu) << (8 * rt);
+                        }
+                    }
+                    scaled = __any((pin | pout) != 0u);
+                }
+#endif
+            };
             auto mainloop = [&](auto nc_tag) {
                 constexpr int NC = decltype(nc_tag)::value;
                 auto load_w = [&](int ks, tc_u32x4 (&w)[TC_CT][2]) {
@@ -323,6 +498,7 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
                 tc_u32x4 wA[TC_CT][2], wB[TC_CT][2], xA[TC_RT][2], xB[TC_RT][2];
                 load_w(0, wA);
                 load_x(0, xA);
+                rs_chain();
 #ifdef TC_ABL_W
 #define TC_LOAD_W(k, w)
                 load_w(0, wB);
@@ -366,7 +542,7 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
                 case 3: mainloop(std::integral_constant<int, 3>{}); break;
                 case 2: mainloop(std::integral_constant<int, 2>{}); break;
                 case 1: mainloop(std::integral_constant<int, 1>{}); break;
-                default: break;
+                default: rs_chain(); break;
             }
 
             TC_MARK();                                 // 3 + 4 l: main loop done
@@ -395,46 +571,79 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
             //      the caller's output, or the head's dot product
             const int relu = p.relu[l];
             float hp[TC_RT] = {0.f, 0.f, 0.f, 0.f};    // head: this lane's share of the logit of row 16 rt + r16
+            float fin[TC_RT], down[TC_RT];             // RS: 2^s of this layer's input rows (what the accumulators are multiplied by first), 2^-s' of the rows it stores
+            float mxf[TC_RT] = {0.f, 0.f, 0.f, 0.f};   // RS: max |output| of the lane's values per row
 #pragma unroll
-            for (int c = 0; c < TC_CT; ++c) {
-                if (c < cnt) {                         // wave-uniform
-                    const int col = 16 * (c0 + c) + 4 * g;       // N % 4 == 0: the lane's four columns are inside or outside together
-                    const bool in = col < N;
-                    const tc_f32x4 b4 = b4v[c], s4 = s4v[c], h4 = h4v[c];
-                    const tc_f32x4 w4 = (in && hw) ? w4v[c] : (tc_f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < TC_RT; ++rt) {
+                fin[rt] = RS ? tc_pow2(tc_byte(pin, rt)) : 1.f;
+                down[rt] = RS ? tc_pow2(-tc_byte(pout, rt)) : 1.f;
+            }
+            // The body once per combination of flags: as run-time tests inside the loops every group of four values crossed ~10 scalar branches
+            // and the epilogue was bound by instruction issue (5 300 cycles per layer and tile, two waves per SIMD).  The two shapes the
+            // reference's towers have between layers (bias + ReLU, with or without the batch-norm affine) are compile-time; everything else,
+            // and the last layer, takes the flags as run-time values.  SCALED = false: every row of the wave has 2^s = 1 on both sides.
+            auto epi = [&](auto f_bias, auto f_relu, auto f_sc, auto f_last, auto f_scaled) {
 #pragma unroll
-                    for (int rt = 0; rt < TC_RT; ++rt) {
-                        tc_f32x4 v = acc[c][rt];
-                        if (in) {
-                            if (bias) v += b4;
-                            if (relu) {
+                for (int c = 0; c < TC_CT; ++c) {
+                    if (c < cnt) {                         // wave-uniform
+                        const int col = 16 * (c0 + c) + 4 * g;       // N % 4 == 0: the lane's four columns are inside or outside together
+                        const bool in = col < N;
+                        const tc_f32x4 b4 = b4v[c], s4 = s4v[c], h4 = h4v[c];
+                        const tc_f32x4 w4 = (in && hw) ? w4v[c] : (tc_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int rt = 0; rt < TC_RT; ++rt) {
+                            tc_f32x4 v = acc[c][rt];
+                            if (RS && f_scaled) {          // (acc * 2^s is exact: the fused form rounds once, like the sum it replaces)
+                                if (f_bias) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], fin[rt], b4[e]);
+                                } else {
+                                    v = v * fin[rt];
+                                }
+                            } else if (f_bias) {
+                                v += b4;
+                            }
+                            if (f_relu) {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                             }
-                            if (sc) {                  // multiply then add, unfused (dense.hip's affine epilogue)
+                            if (f_sc) {                    // multiply then add, unfused (dense.hip's affine epilogue)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = v[e] * s4[e] + h4[e];
                             }
-                        } else {
-                            v = (tc_f32x4){0.f, 0.f, 0.f, 0.f};
-                        }
-                        if (!last) {
-#ifdef TC_ABL_EPI          // timing ablation: the epilogue's split + LDS stores only where the compiler cannot drop the values
-                            if (v[0] == 123.456f) tc_store4(act, 16 * rt + r16, col, v);
-#else
-                            tc_store4(act, 16 * rt + r16, col, v);
+                            if (!in) v = (tc_f32x4){0.f, 0.f, 0.f, 0.f};
+                            if (!f_last) {
+#ifndef TC_ABL_RS_MAX
+                                if constexpr (RS) mxf[rt] = tc_absmax(v, mxf[rt]);
 #endif
-                        } else if (p.head_w) {
-                            hp[rt] += v[0] * w4[0];
-                            hp[rt] += v[1] * w4[1];
-                            hp[rt] += v[2] * w4[2];
-                            hp[rt] += v[3] * w4[3];
-                        } else if (in) {
-                            const int64_t r = row0 + 16 * rt + r16;
-                            if (r < p.M) *reinterpret_cast<tc_f32x4*>(p.out + r * p.out_ld + col) = v;
+#ifdef TC_ABL_EPI          // timing ablation: the epilogue's split + LDS stores only where the compiler cannot drop the values
+                                if (v[0] == 123.456f) tc_store4(act, 16 * rt + r16, col, v);
+#else
+                                tc_store4(act, 16 * rt + r16, col, (RS && f_scaled) ? v * down[rt] : v);
+#endif
+                            } else if (p.head_w) {
+                                hp[rt] += v[0] * w4[0];
+                                hp[rt] += v[1] * w4[1];
+                                hp[rt] += v[2] * w4[2];
+                                hp[rt] += v[3] * w4[3];
+                            } else if (in) {
+                                const int64_t r = row0 + 16 * rt + r16;
+                                if (r < p.M) *reinterpret_cast<tc_f32x4*>(p.out + r * p.out_ld + col) = v;
+                            }
                         }
                     }
                 }
+            };
+            {
+                constexpr std::true_type T{};
+                constexpr std::false_type F{};
+                const bool fb = bias != nullptr, fr = relu != 0, fs = sc != nullptr;
+                if (!last && fb && fr && !fs && !scaled) epi(T, T, F, F, F);
+                else if (!last && fb && fr && fs && !scaled) epi(T, T, T, F, F);
+                else if (!last && fb && fr && !fs) epi(T, T, F, F, T);
+                else if (!last && fb && fr) epi(T, T, T, F, T);
+                else if (!last) epi(fb, fr, fs, F, T);
+                else epi(fb, fr, fs, T, T);
             }
             if (last && p.head_w) {
 #pragma unroll
@@ -443,6 +652,19 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
                     s += __shfl_xor(s, 16, 64);        // the wave's other columns live in the other three lane groups
                     s += __shfl_xor(s, 32, 64);
                     if (g == 0) part[wave * TC_ROWS + 16 * rt + r16] = s;
+                }
+            }
+            if constexpr (RS) {
+                if (!last) {         // (workgroup-uniform) the stored rows' actual maxima and scales, for the next layer's epilogue (a barrier ahead)
+                    const int nxt = ((l + 1) & 1) * TC_ROWS;
+#pragma unroll
+                    for (int rt = 0; rt < TC_RT; ++rt) {
+                        // (from every lane: four lanes per address cost the LDS a few cycles; two shuffles per row cost the wave their latency)
+#ifndef TC_ABL_RS_ATOM
+                        if (cnt > 0) atomicMax(&rowmax[nxt + 16 * rt + r16], __builtin_bit_cast(unsigned int, mxf[rt]));
+#endif
+                        if (wave == 0 && g == 0) rowsft[nxt + 16 * rt + r16] = tc_byte(pout, rt);
+                    }
                 }
             }
             TC_MARK();                                 // 5 + 4 l: epilogue done
@@ -469,6 +691,8 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
     }
 }
 
+inline int64_t tc_image_body(int K, int N) { return (int64_t)((K + 31) / 32) * ((N + 15) / 16) * 2048; }
+
 int tower_cs_fill(const char* name, TowerCsParams& p, int Kd, int L, const int* N, const void* const* images, const float* const* bias,
                   const float* const* post_scale, const float* const* post_shift, const int* act, const float* head_w, const float* head_b,
                   const float* add0, const float* add1, float* out, int64_t out_ld) {
@@ -478,7 +702,7 @@ int tower_cs_fill(const char* name, TowerCsParams& p, int Kd, int L, const int* 
     DIR_CHECK_ARG(head_w || (!add0 && !add1), "%s: add0 / add1 are addends of the head's logit", name);
     p.Kd = Kd; p.L = L;
     for (int l = 0; l < TC_MAXL; ++l) {
-        p.N[l] = 0; p.img[l] = nullptr; p.bias[l] = p.scale[l] = p.shift[l] = nullptr; p.relu[l] = 0;
+        p.N[l] = 0; p.img[l] = nullptr; p.wnorm[l] = nullptr; p.bias[l] = p.scale[l] = p.shift[l] = nullptr; p.relu[l] = 0;
     }
     for (int l = 0; l < L; ++l) {
         if (N[l] <= 0 || N[l] > 16 * TC_NT || (N[l] & 3)) return fail(DIR_E_UNSUPPORTED, "%s: layer %d width %d (a multiple of 4, <= %d)", name, l, N[l], 16 * TC_NT);
@@ -490,6 +714,7 @@ int tower_cs_fill(const char* name, TowerCsParams& p, int Kd, int L, const int* 
         const float* b = bias ? bias[l] : nullptr;
         if ((b && !aligned16(b)) || (sc && (!aligned16(sc) || !aligned16(sh)))) return fail(DIR_E_UNSUPPORTED, "%s: bias / affine vectors must be 16-byte aligned", name);
         p.N[l] = N[l]; p.img[l] = static_cast<const unsigned char*>(images[l]); p.bias[l] = b; p.scale[l] = sc; p.shift[l] = sh;
+        p.wnorm[l] = reinterpret_cast<const float*>(p.img[l] + tc_image_body(l ? N[l - 1] : Kd, N[l]));
         p.relu[l] = act[l] == DIR_ACT_RELU;
     }
     if (head_w) {
@@ -503,10 +728,10 @@ int tower_cs_fill(const char* name, TowerCsParams& p, int Kd, int L, const int* 
     return DIR_OK;
 }
 
-template <bool GATHER>
-int tower_cs_launch(const char* name, const TowerCsParams& p, dir_stream_t stream) {
+template <bool GATHER, bool RS>
+int tower_cs_launch_rs(const char* name, const TowerCsParams& p, dir_stream_t stream) {
     static LdsOnce once;
-    if (!lds_limit(once, 160 * 1024, &tower_cs_k<GATHER>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
+    if (!lds_limit(once, 160 * 1024, &tower_cs_k<GATHER, RS>)) return fail(DIR_E_HIP, "%s: cannot reserve 160 KiB of LDS", name);
     const int64_t ntiles = (p.M + TC_ROWS - 1) / TC_ROWS;
     const int64_t nwg = ntiles < kCUs ? ntiles : kCUs;            // persistent workgroups, one per CU (108 KB of LDS)
 #ifdef TC_STAMP
@@ -516,7 +741,7 @@ int tower_cs_launch(const char* name, const TowerCsParams& p, dir_stream_t strea
     TowerCsParams q = p;
     q.stamps = d_st;
     (void)hipMemsetAsync(d_st, 0, 8 * 64 * 8, as_stream(stream));
-    hipLaunchKernelGGL((tower_cs_k<GATHER>), dim3((unsigned)nwg), dim3(64 * TC_NW), TC_SMEM, as_stream(stream), q);
+    hipLaunchKernelGGL((tower_cs_k<GATHER, RS>), dim3((unsigned)nwg), dim3(64 * TC_NW), TC_SMEM, as_stream(stream), q);
     if (++calls == 300) {
         unsigned long long h[8 * 64];
         (void)hipMemcpy(h, d_st, sizeof(h), hipMemcpyDeviceToHost);
@@ -529,9 +754,16 @@ int tower_cs_launch(const char* name, const TowerCsParams& p, dir_stream_t strea
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 #endif
-    hipLaunchKernelGGL((tower_cs_k<GATHER>), dim3((unsigned)nwg), dim3(64 * TC_NW), TC_SMEM, as_stream(stream), p);
+    hipLaunchKernelGGL((tower_cs_k<GATHER, RS>), dim3((unsigned)nwg), dim3(64 * TC_NW), TC_SMEM, as_stream(stream), p);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
+}
+
+// DIR_TOWER_RS = 1 (default) | 0, read per call (an A/B switch): the rows of every layer's input scaled by powers of two (see tc_row_sft)
+template <bool GATHER>
+int tower_cs_launch(const char* name, const TowerCsParams& p, dir_stream_t stream) {
+    const char* e = getenv("DIR_TOWER_RS");
+    return (e && e[0] == '0') ? tower_cs_launch_rs<GATHER, false>(name, p, stream) : tower_cs_launch_rs<GATHER, true>(name, p, stream);
 }
 
 }  // namespace
@@ -541,7 +773,7 @@ using namespace dir;
 
 extern "C" int64_t dir_tower_cs_image_bytes(int K, int N) {
     if (K <= 0 || N <= 0) return 0;
-    return (int64_t)((K + 31) / 32) * ((N + 15) / 16) * 2048;
+    return tc_image_body(K, N) + 256;           // + the trailer: max_n sum_k |W[n][k]| (one float)
 }
 
 extern "C" int dir_tower_cs_f16x2_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
@@ -554,6 +786,10 @@ extern "C" int dir_tower_cs_f16x2_pack_f32(const float* W, int64_t w_ld, int K, 
     const int64_t threads = (int64_t)nks * nct * 64 * 4;
     hipLaunchKernelGGL(tower_cs_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, K, N, nks, nct,
                        static_cast<unsigned int*>(image));
+    DIR_CHECK_LAUNCH(name);
+    unsigned int* trailer = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(image) + tc_image_body(K, N));
+    if (hipMemsetAsync(trailer, 0, 256, as_stream(stream)) != hipSuccess) return fail(DIR_E_HIP, "%s: hipMemsetAsync failed", name);
+    hipLaunchKernelGGL(tower_cs_norm_k, dim3((unsigned)N), dim3(64), 0, as_stream(stream), W, w_ld, K, trailer);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }

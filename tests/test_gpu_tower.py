@@ -528,3 +528,78 @@ def test_dense_small_batches(built_lib, M, Kd, N):
         assert torch.equal(y2, y[:, :N])
     if ops.dense_small_covers(M, Kd, N) and N >= 16:
         assert torch.equal(ops.dense(x, W, b, relu=True), torch.relu(y2) if False else ops.dense(x, W, b, relu=True, arith="f32"))
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_tower_interior_activations_of_any_magnitude(built_lib, gather):
+    """VERDICT r5 item 3 (the range hole): weights and inputs inside fp16's range whose INTERIOR activations are not -- all-positive operands
+    grow from O(1) to ~2e3 behind layer 1 and ~1e6 behind layer 2, past fp16's 65 504.  tower_cs_k scales every stored row by a power of two
+    (DIR_TOWER_RS, default on): the result stays within the scale-invariant 1e-5 of float64; tower_bf3_k (and DIR_TOWER_RS=0) overflow there."""
+    import os
+    from dir_amd import ops
+    if ops.TOWER_KERNEL != "cs":
+        pytest.skip("tower_bf3_k splits interior activations unscaled (DESIGN.md section 7, item 9): this test is tower_cs_k's")
+    rng = np.random.default_rng(3)
+    M, F, K = 1500, 26, 16
+    Kd, Ns = F * K, [400, 400, 64]
+    tabs = [np.abs(rng.standard_normal((50, K))).astype(np.float32) * 4 for _ in range(F)]
+    ids = rng.integers(0, 50, size=(M, F)).astype(np.int64)
+    x = np.concatenate([tabs[f][ids[:, f]] for f in range(F)], axis=1)
+    dims = [Kd] + Ns
+    Ws = [np.abs(rng.standard_normal((dims[i + 1], dims[i]))).astype(np.float32) * 2 for i in range(3)]
+    bs = [(rng.standard_normal(n) * 0.1).astype(np.float32) for n in Ns]
+    hw = (rng.standard_normal(Ns[-1]) / np.sqrt(Ns[-1])).astype(np.float32)
+    hb = np.array([0.5], np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()      # noqa: E731
+    ref = _ref64(x, Ws, bs, [True] * 3, [None] * 3, [None] * 3, (hw, hb), [])
+    assert np.abs(ref).max() > 1e6                                       # (the activations really are out of fp16's range)
+    if gather:
+        ts = ops.TableSet([d(t) for t in tabs])
+        got = ops.tower(None, [d(w) for w in Ws], [d(b) for b in bs], head=(d(hw), d(hb)), gather=(ts, d(ids), None, False), split="f16x2")
+    else:
+        got = ops.tower(d(x), [d(w) for w in Ws], [d(b) for b in bs], head=(d(hw), d(hb)), split="f16x2")
+    g = got.cpu().numpy().astype(np.float64)
+    assert np.isfinite(g).all()
+    assert np.abs(g - ref).max() <= 1e-5 * (np.abs(ref).max())
+    os.environ["DIR_TOWER_RS"] = "0"
+    try:
+        raw = ops.tower(d(x), [d(w) for w in Ws], [d(b) for b in bs], head=(d(hw), d(hb)), split="f16x2").cpu().numpy()
+    finally:
+        del os.environ["DIR_TOWER_RS"]
+    assert not np.isfinite(raw).all() or np.abs(raw - ref).max() > 1e-3 * np.abs(ref).max()      # what the scaling is for
+
+
+@pytest.mark.parametrize("affine", [False, True])
+def test_tower_rows_of_very_different_magnitudes_in_one_workgroup(built_lib, affine):
+    """Row scaling is per batch row: neighbours whose inputs differ by 2^40 (some far below fp16's subnormals, some whose activations pass
+    65 504) in the same 64-row tile, each held to 1e-5 of ITS OWN largest output -- a per-tensor scale could not do that.  With the affine
+    (|scale| up to 500, shifts of either sign) the bound's constants (max |scale|, max |scale x bias| + max |shift|) are exercised too."""
+    from dir_amd import ops
+    if ops.TOWER_KERNEL != "cs":
+        pytest.skip("tower_cs_k's row scaling")
+    rng = np.random.default_rng(11)
+    M, Kd, Ns = 700, 96, [200, 120, 48]
+    x = rng.standard_normal((M, Kd)).astype(np.float32)
+    expo = rng.integers(-30, 11, size=M)
+    x = (x * np.exp2(expo)[:, None]).astype(np.float32)
+    x[5] = 0.0                                                # an all-zero row
+    dims = [Kd] + Ns
+    Ws = [(rng.standard_normal((dims[i + 1], dims[i])) * 1.5).astype(np.float32) for i in range(3)]
+    if affine:
+        bs = [(rng.standard_normal(n) * 0.01).astype(np.float32) for n in Ns]
+        scs = [(rng.standard_normal(n) * 200).astype(np.float32) for n in Ns]
+        shs = [(rng.standard_normal(n) * 3).astype(np.float32) for n in Ns]
+    else:
+        bs, scs, shs = [None] * 3, [None] * 3, [None] * 3     # homogeneous: every row's outputs scale with its input
+    d = lambda a: None if a is None else torch.from_numpy(a).cuda()      # noqa: E731
+    ref = _ref64(x, Ws, bs, [True] * 3, scs, shs)
+    got = ops.tower(d(x), [d(w) for w in Ws], None if bs[0] is None else [d(b) for b in bs], relu=True,
+                    post_scale=None if not affine else [d(s) for s in scs], post_shift=None if not affine else [d(s) for s in shs],
+                    split="f16x2").cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    rowmax = np.abs(ref).max(axis=1, keepdims=True)
+    err = np.abs(got - ref) / np.maximum(rowmax, 1e-300)
+    assert float(err[rowmax[:, 0] > 0].max()) <= 1e-5
+    if not affine:
+        assert not got[5].any()
+        assert rowmax.max() / rowmax[rowmax > 0].min() > 1e9  # (the rows really span many orders of magnitude)
