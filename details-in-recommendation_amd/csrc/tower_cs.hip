@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
             // and the epilogue was bound by instruction issue (5 300 cycles per layer and tile, two waves per SIMD).  The two shapes the
             // reference's towers have between layers (bias + ReLU, with or without the batch-norm affine) are compile-time; everything else,
             // and the last layer, takes the flags as run-time values.  SCALED = false: every row of the wave has 2^s = 1 on both sides.
-            auto epi = [&](auto f_bias, auto f_relu, auto f_sc, auto f_last, auto f_scaled) {
+            auto epi = [&](auto f_bias, auto f_relu, auto f_sc, auto f_last, auto f_head, auto f_scaled) {
 #pragma unroll
                 for (int c = 0; c < TC_CT; ++c) {
                     if (c < cnt) {                         // wave-uniform
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
 #else
                                 tc_store4(act, 16 * rt + r16, col, (RS && f_scaled) ? v * down[rt] : v);
 #endif
-                            } else if (p.head_w) {
+                            } else if (f_head) {
                                 hp[rt] += v[0] * w4[0];
                                 hp[rt] += v[1] * w4[1];
                                 hp[rt] += v[2] * w4[2];
@@ -638,12 +638,17 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
                 constexpr std::true_type T{};
                 constexpr std::false_type F{};
                 const bool fb = bias != nullptr, fr = relu != 0, fs = sc != nullptr;
-                if (!last && fb && fr && !fs && !scaled) epi(T, T, F, F, F);
-                else if (!last && fb && fr && fs && !scaled) epi(T, T, T, F, F);
-                else if (!last && fb && fr && !fs) epi(T, T, F, F, T);
-                else if (!last && fb && fr) epi(T, T, T, F, T);
-                else if (!last) epi(fb, fr, fs, F, T);
-                else epi(fb, fr, fs, T, T);
+                const bool fh = hw != nullptr;
+                if (!last && fb && fr && !fs && !scaled) epi(T, T, F, F, F, F);
+                else if (!last && fb && fr && fs && !scaled) epi(T, T, T, F, F, F);
+                else if (!last && fb && fr && !fs) epi(T, T, F, F, F, T);
+                else if (!last && fb && fr) epi(T, T, T, F, F, T);
+                else if (!last) epi(fb, fr, fs, F, F, T);
+                else if (fb && fr && !fs && fh && !scaled) epi(T, T, F, T, T, F);       // the last hidden layer under the units = 1 head
+                else if (fb && fr && !fs && fh) epi(T, T, F, T, T, T);
+                else if (fb && fr && !fs && !scaled) epi(T, T, F, T, F, F);            // ... written out
+                else if (fb && fr && !fs) epi(T, T, F, T, F, T);
+                else epi(fb, fr, fs, T, fh, T);
             }
             if (last && p.head_w) {
 #pragma unroll
