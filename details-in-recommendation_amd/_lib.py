@@ -61,6 +61,8 @@ SIGNATURES = {
                                        c_i64, c_vp]),
     "dir_bn_train_backward_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64,
                                           c_vp]),
+    "dir_dice_train_backward_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64,
+                                            c_vp]),
     "dir_dense_affine_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_small_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "dir_dense_mid_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -397,6 +397,9 @@ def din_attention_pool(table, hist, hist_len, cand, W1, b1, W2, b2, W3, b3, norm
 
 
 # ---- PReLU / Dice layers and the DIN unit's row-list training path (round 5; csrc/din_rows_train.hip) -----------------------------------------
+_DICE_FUSED_BWD = os.environ.get("DIR_DICE_FUSED_BWD", "1") != "0"      # development switch: 0 keeps the three-kernel backward of training-mode Dice
+
+
 class ActRows(torch.autograd.Function):
     """y = PReLU / Dice (s) over rows s [M, N] with HIP forward and backward (no reference code: arXiv:1706.06978 section 5.3, din.Dice).
     Dice in TRAIN mode: the batch statistics come from dir_bn_train_stats_f32 (which also advances the module's moving statistics with
@@ -425,6 +428,9 @@ class ActRows(torch.autograd.Function):
         saved = ctx.saved_tensors
         s, alpha = saved[0], saved[1]
         scale, shift = (saved[2], saved[3]) if ctx.kind == "dice" else (None, None)
+        if ctx.batch and _DICE_FUSED_BWD and ops.bn_train_supported(s):      # two passes over (g, s) instead of three kernels and an add
+            d1, galpha = ops.dice_train_backward(g, s, alpha, scale, shift, saved[4], saved[5])
+            return d1, galpha.reshape(alpha.shape) if ctx.needs_input_grad[1] else None, None, None
         d1, gx, galpha = ops.act_rows_backward(g, s, ctx.kind, alpha, scale, shift)
         if ctx.batch:
             mean, inv = saved[4], saved[5]

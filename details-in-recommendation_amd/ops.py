@@ -798,6 +798,26 @@ def act_rows_backward(g, s, activation, alpha, scale=None, shift=None):
     return d1, gx, galpha
 
 
+def dice_train_backward(g, s, alpha, scale, shift, mean, inv):
+    """Dice in training mode, the whole backward over rows in two passes (include/dir_hip.h: dir_dice_train_backward_f32): g = dL/dy [M, N],
+    s the pre-activations, (scale, shift, mean, inv) this batch's statistics from bn_train_stats -> (ds [M, N], galpha [N]); what
+    act_rows_backward + bn_train_backward + an add computed in seven reads and four writes of [M, N]."""
+    M, N = s.shape
+    if g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16:
+        g = g.contiguous()
+    if not bn_train_supported(s) or not bn_train_supported(g):
+        raise ValueError("dice_train_backward: g and s must be float32 [M > 0, N] with N and the row strides multiples of 4, 16-byte aligned")
+    lib = _lib.load()
+    P = int(lib.dir_bn_train_partials(M, N))
+    ds = torch.empty((M, N), dtype=torch.float32, device=s.device)
+    vec = torch.empty((4, N), dtype=torch.float32, device=s.device)           # galpha, the three coefficients
+    part = torch.empty((P, 3, N), dtype=torch.float32, device=s.device)
+    al, sc, sh = _vec16(alpha, N, "alpha"), _vec16(scale, N, "scale"), _vec16(shift, N, "shift")
+    _lib.check(lib.dir_dice_train_backward_f32(_ptr(g), g.stride(0), _ptr(s), s.stride(0), M, N, _ptr(al), _ptr(sc), _ptr(sh), _ptr(mean.contiguous()),
+                                               _ptr(inv.contiguous()), _ptr(ds), ds.stride(0), _ptr(vec[0]), _ptr(vec[1]), _ptr(part), P, _stream()))
+    return ds, vec[0]
+
+
 def din_pool_rows(scores, Hc, row_off, B, normalize):
     """-> (out [B, K], w [N]): the attention weights of every sample's rows and the weighted sum of its history rows (dir_din_pool_rows_f32)."""
     N, K = Hc.shape

@@ -728,6 +728,16 @@ int dir_bn_train_stats_f32(const float* y, int64_t y_ld, int64_t B, int N, float
 int dir_bn_train_backward_f32(const float* g, int64_t g_ld, const float* y, int64_t y_ld, int64_t B, int N, const float* mean,
                               const float* inv, const float* gamma, int relu_gate, float* gy, int64_t gy_ld, float* gbeta, float* ggamma,
                               float* coef, float* partials, int64_t n_partials, dir_stream_t stream);
+/* dir_dice_train_backward_f32 (round 6): the whole backward of Dice in TRAINING mode over rows s [B, N] -- y = s (alpha + (1 - alpha) p),
+ *   p = sigmoid(scale s + shift) with THIS batch's statistics (mean, inv, scale = inv, shift = -mean inv from dir_bn_train_stats_f32) -- in two
+ *   passes over (g, s): ds = g (alpha + (1 - alpha) p) + the batch-norm backward of gx = g s (1 - alpha) p (1 - p); galpha[n] = sum_b g s (1 - p).
+ *   Replaces dir_act_rows_backward_f32 + dir_bn_train_backward_f32 + an add (4 writes, 7 reads of [B, N] -> 1 write, 4 reads); the same
+ *   expressions, column sums fp32 within a workgroup and fp64 across workgroups in workgroup order (bitwise reproducible).
+ *   coef: 3 * N floats of scratch; partials: 3 * N * dir_bn_train_partials(B, N) floats.  Limits as dir_bn_train_backward_f32; alpha / scale /
+ *   shift 16-byte aligned.  No reference code: arXiv:1706.06978 section 5.3 (README.md:25 lists DIN). */
+int dir_dice_train_backward_f32(const float* g, int64_t g_ld, const float* s, int64_t s_ld, int64_t B, int N, const float* alpha,
+                                const float* scale, const float* shift, const float* mean, const float* inv, float* ds, int64_t ds_ld,
+                                float* galpha, float* coef, float* partials, int64_t n_partials, dir_stream_t stream);
 
 /* --------------------------------------------------------------------------------------------
  * Backward of the HBM-bound interaction ops: derivatives of the same reference

@@ -339,6 +339,44 @@ def test_act_rows_kernels_fuzz(built_lib, M, N, activation):
     assert torch.equal(d1, d1b) and torch.equal(ga, gab)
 
 
+@pytest.mark.parametrize("M,N", [(1, 4), (37, 16), (300, 80), (5000, 200), (70000, 40), (1025, 1024), (200000, 80)])
+def test_dice_train_backward_fused_fuzz(built_lib, M, N):
+    """dir_dice_train_backward_f32 (round 6: Dice's training backward in two passes over (g, s)) against float64 autograd of
+    y = s (alpha + (1 - alpha) sigmoid((s - mean) / sqrt(var + eps))) with the batch's own statistics, and against the three-kernel route
+    it replaces (dir_act_rows_backward_f32 + dir_bn_train_backward_f32 + add: the same expressions, another order of the column sums)."""
+    from dir_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3 * M + N)
+    s = torch.randn((M, N), generator=g, device=dev) * 1.7 + 0.2
+    gy = torch.randn((M, N), generator=g, device=dev)
+    alpha = torch.rand((N,), generator=g, device=dev) - 0.3
+    eps = 1e-8
+    mean, inv, scale, shift = ops.bn_train_stats(s, None, None, None, None, eps, 0.99)
+    ds, ga = ops.dice_train_backward(gy, s, alpha, scale, shift, mean, inv)
+    sd = s.double().requires_grad_(True)
+    ad = alpha.double().requires_grad_(True)
+    m = sd.mean(0, keepdim=True)
+    v = ((sd - m) ** 2).mean(0, keepdim=True)
+    p = torch.sigmoid((sd - m) / torch.sqrt(v + eps))
+    (sd * (ad + (1 - ad) * p)).backward(gy.double())
+    tol = 5e-5 if M > 1 else 1e-3                              # (one row: the statistics' share cancels the direct term to rounding)
+    close = lambda a, b, t: float(((a.double() - b).abs() / (1 + b.abs())).max()) <= t      # noqa: E731
+    assert close(ds, sd.grad, tol), float(((ds.double() - sd.grad).abs() / (1 + sd.grad.abs())).max())
+    assert close(ga, ad.grad, 5e-5 * max(1, M ** 0.5 / 30))
+    d1, gx, ga3 = ops.act_rows_backward(gy, s, "dice", alpha, scale, shift)
+    dbn, _, _ = ops.bn_train_backward(gx, s, mean, inv, gamma=None)
+    assert close(ds, (d1 + dbn).double(), 2e-5) and close(ga, ga3.double(), 2e-5 * max(1, M ** 0.5 / 30))
+    ds2, ga2 = ops.dice_train_backward(gy, s, alpha, scale, shift, mean, inv)
+    assert torch.equal(ds, ds2) and torch.equal(ga, ga2)       # fixed-order sums: bitwise reproducible
+    # a strided gradient (a column block of a wider tensor) and strided pre-activations
+    wide_g = torch.randn((M, N + 8), generator=g, device=dev)
+    wide_s = torch.zeros((M, N + 4), device=dev)
+    wide_s[:, :N] = s
+    ds3, _ = ops.dice_train_backward(wide_g[:, 4:4 + N], wide_s[:, :N], alpha, scale, shift, mean, inv)
+    ds4, _ = ops.dice_train_backward(wide_g[:, 4:4 + N].contiguous(), s, alpha, scale, shift, mean, inv)
+    assert torch.equal(ds3, ds4)
+
+
 @pytest.mark.parametrize("K,ld,lin_col", [(16, 32, 16), (16, 32, 19), (16, 32, 31), (16, 20, 17), (16, 24, 20), (8, 32, 8), (8, 12, 11), (8, 32, 20),
                                            (4, 8, 4), (4, 8, 7), (32, 64, 32), (32, 36, 35), (16, 32, -1), (16, 32, 3)])
 def test_packed_gather_layouts(built_lib, K, ld, lin_col):
