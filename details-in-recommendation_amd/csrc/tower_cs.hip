@@ -74,7 +74,7 @@ struct TowerCsParams {
     int Kd, L;
     int N[TC_MAXL];
     const unsigned char* img[TC_MAXL];
-    const float* wnorm[TC_MAXL];     // the image's trailer: max over output columns of sum_k |W[n][k]|
+    const float* wnorm[TC_MAXL];     // the image's trailer: 64 floats whose maximum is max over output columns of sum_k |W[n][k]|
     const float* bias[TC_MAXL];
     const float* scale[TC_MAXL];
     const float* shift[TC_MAXL];
@@ -153,10 +153,33 @@ __device__ __forceinline__ void tc_store4(_Float16* act, int row, int col, const
 
 // W [N, K] fp32 (row stride w_ld) -> image [k-step][column tile][piece][lane][8 halves]: element e of lane l of tile ct in k-step ks = piece of
 // W[n = 16*ct + (l & 15)][k = 32*ks + 8*(l >> 4) + e] (the A operand of v_mfma_f32_16x16x32_f16 in its natural k order); zero where n >= N or k >= K.
+// Workgroups [npack, npack + TC_NORM_WGS) do not pack: they form the image's TRAILER, TC_NORM_SLOTS floats whose maximum is
+// max_n sum_k |W[n][k]| (row scaling's weight norm): workgroup j's rows j, j + TC_NORM_WGS, .. four at a time (a wave per row), its maximum
+// into slot j -- no atomics, nothing to zero first, and no second launch (a HIP graph of a small-batch forward re-packs on every replay:
+// as a memset and a kernel of their own the norms cost it 11 us per layer).
+constexpr int TC_NORM_SLOTS = 64;
+constexpr int TC_NORM_WGS = 64;                // one slot each: a wave sums at most two rows of a 416-wide layer
 __global__ __launch_bounds__(256) void tower_cs_pack_k(const float* __restrict__ W, int64_t w_ld, int K, int N, int nks, int nct,
-                                                       unsigned int* __restrict__ img) {
+                                                       unsigned int* __restrict__ img, int npack, float* __restrict__ trailer) {
+    if ((int)blockIdx.x >= npack) {
+        __shared__ float wmax[4];
+        const int j = blockIdx.x - npack, wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        float m = 0.f;
+        for (int n = 4 * j + wv; n < N; n += 4 * TC_NORM_WGS) {
+            const float* w = W + (int64_t)n * w_ld;
+            float a = 0.f;
+            for (int k = ln; k < K; k += 64) a += fabsf(w[k]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            m = fmaxf(m, a * 1.0001f);                             // (the sum's own rounding: K 2^-24)
+        }
+        if (ln == 0) wmax[wv] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) trailer[j] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        return;
+    }
     const int64_t total = (int64_t)nks * nct * 64 * 4;            // one thread per pair of e
-    for (int64_t q_ = (int64_t)blockIdx.x * 256 + threadIdx.x; q_ < total; q_ += (int64_t)gridDim.x * 256) {
+    for (int64_t q_ = (int64_t)blockIdx.x * 256 + threadIdx.x; q_ < total; q_ += (int64_t)npack * 256) {
         int64_t q = q_;
         const int ep = (int)(q & 3); q >>= 2;
         const int l = (int)(q & 63); q >>= 6;
@@ -172,16 +195,6 @@ __global__ __launch_bounds__(256) void tower_cs_pack_k(const float* __restrict__
         img[base] = hi;
         img[base + 256] = lo;
     }
-}
-
-// the image's trailer: max_n sum_k |W[n][k]| as a bit pattern (atomic max over the rows; zeroed by the caller).  One wave per output column.
-__global__ __launch_bounds__(64) void tower_cs_norm_k(const float* __restrict__ W, int64_t w_ld, int K, unsigned int* __restrict__ out) {
-    const float* w = W + (int64_t)blockIdx.x * w_ld;
-    float s = 0.f;
-    for (int k = threadIdx.x; k < K; k += 64) s += fabsf(w[k]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (threadIdx.x == 0) atomicMax(out, __builtin_bit_cast(unsigned int, s * 1.0001f));      // (the sum's own rounding: K 2^-24)
 }
 
 template <bool GATHER, bool RS>
@@ -205,22 +218,39 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
         // by 2-4 % of the launch, profiles/NOTES.md R6.17.)
 #ifndef TC_ABL_RS_PRO
         if (wave == TC_NW - 1) {
-            for (int l = 0; l + 1 < p.L; ++l) {
-                const int N = p.N[l];
-                const float* dummy = reinterpret_cast<const float*>(p.img[l]);
-                const float* bias = p.bias[l];
-                const float* sc = p.scale[l];
-                const float* sh = p.shift[l];
-                float bm = 0.f, sm = 0.f, hm = 0.f;
+            // every layer's vectors asked for first (unconditional loads from clamped addresses), then the reductions: layer by layer the
+            // cold round trips stood one behind the other (a small-batch forward is one tile: 7 us of its 70)
+            constexpr int NV = (16 * TC_NT + 63) / 64;
+            float bv[TC_MAXL - 1][NV], sv[TC_MAXL - 1][NV], hv[TC_MAXL - 1][NV], wnv[TC_MAXL - 1];
 #pragma unroll
-                for (int i = 0; i < (16 * TC_NT + 63) / 64; ++i) {
+            for (int l = 0; l < TC_MAXL - 1; ++l) {
+                const bool on = l + 1 < p.L;
+                const int N = on ? p.N[l] : 1;
+                const float* dummy = reinterpret_cast<const float*>(p.img[0]);
+                const float* bias = on && p.bias[l] ? p.bias[l] : dummy;
+                const float* sc = on && p.scale[l] ? p.scale[l] : dummy;
+                const float* sh = on && p.shift[l] ? p.shift[l] : dummy;
+                wnv[l] = (on ? p.wnorm[l] : p.wnorm[0])[lane];           // TC_NORM_SLOTS = 64 partial maxima
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
                     const int j = lane + 64 * i;
                     const int jj = j < N ? j : 0;
-                    const float b = (bias ? bias : dummy)[jj], s1 = (sc ? sc : dummy)[jj], h = (sh ? sh : dummy)[jj];
-                    if (j < N) {
-                        bm = fmaxf(bm, fabsf(b));
-                        sm = fmaxf(sm, fabsf(s1));
-                        hm = fmaxf(hm, fabsf(h));
+                    bv[l][i] = bias[jj];
+                    sv[l][i] = sc[jj];
+                    hv[l][i] = sh[jj];
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < TC_MAXL - 1; ++l) {
+                const bool on = l + 1 < p.L;
+                const int N = on ? p.N[l] : 1;
+                float bm = 0.f, sm = 0.f, hm = 0.f, wn = wnv[l];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    if (lane + 64 * i < N) {
+                        bm = fmaxf(bm, fabsf(bv[l][i]));
+                        sm = fmaxf(sm, fabsf(sv[l][i]));
+                        hm = fmaxf(hm, fabsf(hv[l][i]));
                     }
                 }
 #pragma unroll
@@ -228,11 +258,12 @@ __global__ __launch_bounds__(64 * TC_NW, 2) void tower_cs_k(const TowerCsParams 
                     bm = fmaxf(bm, __shfl_xor(bm, o, 64));
                     sm = fmaxf(sm, __shfl_xor(sm, o, 64));
                     hm = fmaxf(hm, __shfl_xor(hm, o, 64));
+                    wn = fmaxf(wn, __shfl_xor(wn, o, 64));
                 }
-                if (!bias) bm = 0.f;
-                if (!sc) { sm = 1.f; hm = 0.f; }
-                if (lane == 0) {
-                    cst[2 * l] = sm * p.wnorm[l][0];
+                if (!on || !p.bias[l]) bm = 0.f;
+                if (!on || !p.scale[l]) { sm = 1.f; hm = 0.f; }
+                if (on && lane == 0) {
+                    cst[2 * l] = sm * wn;
                     cst[2 * l + 1] = sm * bm + hm;
                 }
             }
@@ -778,7 +809,7 @@ using namespace dir;
 
 extern "C" int64_t dir_tower_cs_image_bytes(int K, int N) {
     if (K <= 0 || N <= 0) return 0;
-    return tc_image_body(K, N) + 256;           // + the trailer: max_n sum_k |W[n][k]| (one float)
+    return tc_image_body(K, N) + 4 * TC_NORM_SLOTS;           // + the trailer: TC_NORM_SLOTS floats whose maximum is max_n sum_k |W[n][k]|
 }
 
 extern "C" int dir_tower_cs_f16x2_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream) {
@@ -789,12 +820,10 @@ extern "C" int dir_tower_cs_f16x2_pack_f32(const float* W, int64_t w_ld, int K, 
                   "dir_tower_cs_image_bytes(K, N) bytes", name);
     const int nks = (K + 31) / 32, nct = (N + 15) / 16;
     const int64_t threads = (int64_t)nks * nct * 64 * 4;
-    hipLaunchKernelGGL(tower_cs_pack_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), W, w_ld, K, N, nks, nct,
-                       static_cast<unsigned int*>(image));
-    DIR_CHECK_LAUNCH(name);
-    unsigned int* trailer = reinterpret_cast<unsigned int*>(static_cast<unsigned char*>(image) + tc_image_body(K, N));
-    if (hipMemsetAsync(trailer, 0, 256, as_stream(stream)) != hipSuccess) return fail(DIR_E_HIP, "%s: hipMemsetAsync failed", name);
-    hipLaunchKernelGGL(tower_cs_norm_k, dim3((unsigned)N), dim3(64), 0, as_stream(stream), W, w_ld, K, trailer);
+    const int npack = (int)((threads + 255) / 256);
+    float* trailer = reinterpret_cast<float*>(static_cast<unsigned char*>(image) + tc_image_body(K, N));
+    hipLaunchKernelGGL(tower_cs_pack_k, dim3((unsigned)(npack + TC_NORM_WGS)), dim3(256), 0, as_stream(stream), W, w_ld, K, N, nks, nct,
+                       static_cast<unsigned int*>(image), npack, trailer);
     DIR_CHECK_LAUNCH(name);
     return DIR_OK;
 }

@@ -40,7 +40,9 @@ DIR_TOWER_SPLIT=bf16x3 b mlp_dense_bf16x3 --workload mlp_dense --steps 200 --war
 DIR_BENCH_DENSE=layers b mlp_dense_layers --workload mlp_dense --steps 200 --warmup 800 --no-cpu-baseline
 DIR_TOWER_KERNEL=rows b mlp_dense_rows --workload mlp_dense --steps 200 --warmup 1000 --no-cpu-baseline
 DIR_TOWER_KERNEL=rows DIR_TOWER_RT=2 b mlp_dense_rt2 --workload mlp_dense --steps 200 --warmup 1000 --no-cpu-baseline
+DIR_TOWER_RS=0 b mlp_dense_rs0 --workload mlp_dense --steps 200 --warmup 1000 --no-cpu-baseline
 b deepfm_full --workload deepfm_full --steps 200 --warmup 1000 --no-cpu-baseline
+DIR_TOWER_RS=0 b deepfm_full_rs0 --workload deepfm_full --steps 200 --warmup 1000 --no-cpu-baseline
 DIR_TOWER_KERNEL=rows b deepfm_full_rows --workload deepfm_full --steps 200 --warmup 1000 --no-cpu-baseline
 DIR_TOWER_SPLIT=bf16x3 b deepfm_full_bf16x3 --workload deepfm_full --steps 200 --warmup 700 --no-cpu-baseline
 b dcn_full --workload dcn_full --steps 100 --warmup 400 --no-cpu-baseline
@@ -68,6 +70,7 @@ DIR_BENCH_SMALL_BATCH=2048 b small_batch_2048 --workload small_batch --steps 200
 DIR_BENCH_SMALL_BATCH=4096 b small_batch_4096 --workload small_batch --steps 200 --warmup 20 --no-cpu-baseline
 DIR_BENCH_DIN_ACT=dice b din_train_dice --workload din_train --steps 20 --warmup 30 --no-cpu-baseline
 DIR_BENCH_DIN_ACT=prelu b din_train_prelu --workload din_train --steps 20 --warmup 40 --no-cpu-baseline
+DIR_BENCH_DIN_ACT=dice DIR_DICE_FUSED_BWD=0 b din_train_dice_3k --workload din_train --steps 20 --warmup 30 --no-cpu-baseline
 DIR_BENCH_DIN_ACT=dice DIR_DIN_ROWS_TRAIN=0 b din_train_dice_torch --workload din_train --steps 5 --warmup 2 --no-cpu-baseline
 DIR_CIN_ROW_BITS_CARRY=0 b cin_rowscaled --workload cin --steps 10 --warmup 80 --no-cpu-baseline
 fi
