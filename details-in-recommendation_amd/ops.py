@@ -1332,7 +1332,9 @@ def _tower_split_for(weights, pt=None):
     """What split=None resolves to: TOWER_SPLIT, or "bf16x3" when a weight or a packed row is outside F16_RANGE_GUARD."""
     if TOWER_SPLIT != "f16x2":
         return TOWER_SPLIT
-    if pt is not None and not f16_range_ok(pt.absmax()):
+    # tower_cs_k scales every stored row by its own power of two (round 6, DIR_TOWER_RS): the magnitude of the rows it looks up no longer matters
+    row_scaled = TOWER_KERNEL == "cs" and os.environ.get("DIR_TOWER_RS", "1") != "0"
+    if pt is not None and not row_scaled and not f16_range_ok(pt.absmax()):
         return "bf16x3"
     for w in weights:
         if not f16_range_ok(weight_absmax(w)):

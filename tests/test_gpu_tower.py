@@ -392,7 +392,13 @@ def test_tower_default_split_checks_the_fp16_range_of_weights_and_packed_rows(bu
     pt2 = ops.PackedTables(tabs, lins)
     assert pt2.absmax() == 7.0e4
     b = ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt2, ids, None))
-    assert torch.equal(b, ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt2, ids, None), split="bf16x3")) and bool(torch.isfinite(b).all())
+    wide = ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt2, ids, None), split="bf16x3")
+    assert bool(torch.isfinite(b).all())
+    if ops.TOWER_KERNEL == "cs":      # round 6: tower_cs_k scales every stored row, the looked-up rows' magnitude no longer routes -- and need not
+        assert torch.equal(b, ops.tower(None, [W1, W2], head=(hw, hb), gather=(pt2, ids, None), split="f16x2"))
+        assert float(((b.double() - wide.double()).abs() / (1 + wide.double().abs())).max()) <= 1e-5
+    else:
+        assert torch.equal(b, wide)
 
 
 @pytest.mark.parametrize("M,N,K,gate", [(12800, 400, 416, True), (12801, 400, 400, True), (13000, 208, 128, False), (12544, 1024, 432, True),
@@ -603,3 +609,29 @@ def test_tower_rows_of_very_different_magnitudes_in_one_workgroup(built_lib, aff
     if not affine:
         assert not got[5].any()
         assert rowmax.max() / rowmax[rowmax > 0].min() > 1e9  # (the rows really span many orders of magnitude)
+
+
+@pytest.mark.parametrize("mag", [1e-7, 3e4])
+def test_one_launch_tower_takes_tables_of_any_magnitude_on_the_split_kernel(built_lib, mag):
+    """split=None used to send packed serving rows outside [2^-6, 2^15) to the bf16 x 3 kernel (the unscaled fp16 pieces lose their second
+    piece below, overflow above); tower_cs_k's row scaling makes the looked-up rows' magnitude irrelevant, so the guard now only reads the
+    weights.  Rows of magnitude 1e-7 and 3e4 (x 26 slots: FM terms up to ~1e10) through the one-launch DeepFM form, against float64."""
+    from dir_amd import ops
+    if ops.TOWER_KERNEL != "cs":
+        pytest.skip("tower_cs_k's row scaling")
+    rng = np.random.default_rng(5)
+    M, F, K = 900, 26, 16
+    Kd, Ns = F * K, [200, 80]
+    tabs = [(rng.standard_normal((40, K)) * mag).astype(np.float32) for _ in range(F)]
+    ids = rng.integers(0, 40, size=(M, F)).astype(np.int64)
+    x = np.concatenate([tabs[f][ids[:, f]] for f in range(F)], axis=1)
+    dims = [Kd] + Ns
+    Ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(2)]
+    hw = (rng.standard_normal(Ns[-1]) / np.sqrt(Ns[-1])).astype(np.float32)
+    hb = np.array([0.0], np.float32)
+    d = lambda a: torch.from_numpy(a).cuda()      # noqa: E731
+    ref = _ref64(x, Ws, [None, None], [True] * 2, [None] * 2, [None] * 2, (hw, hb), [])
+    ts = ops.TableSet([d(t) for t in tabs])
+    assert ops._tower_split_for([d(w) for w in Ws], ts) == "f16x2"
+    got = ops.tower(None, [d(w) for w in Ws], None, head=(d(hw), d(hb)), gather=(ts, d(ids), None, False)).cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
