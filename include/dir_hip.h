@@ -629,7 +629,12 @@ int dir_deepfm_tower_f16x2_f32(const float* const* tables, const int64_t* vocab,
  * (dir_tower_cs_image_bytes(K, N) bytes: [k-step][column tile][piece][lane] in the matrix instruction's natural k order) and are NOT
  * interchangeable with the other tower images.  Results agree with dir_tower_f16x2_f32 to rounding (another summation order inside a k-step and in
  * the head's dot product), not bit for bit; the GATHER form and the plain form of THIS kernel agree bit for bit, and its FM / first-order terms are
- * bit for bit dir_gather_fm_linear_packed_f32's. */
+ * bit for bit dir_gather_fm_linear_packed_f32's.
+ * Row scaling (round 6; environment DIR_TOWER_RS = 1 (default) | 0, read per call): every row the kernel stores as a layer's input -- the
+ * looked-up / given input rows and the activations between layers -- is multiplied by its own power of two first (exact; the reading layer's
+ * accumulators are multiplied back), so that neither the inputs' nor the interior activations' magnitudes are a precondition: only the WEIGHTS
+ * must lie inside fp16's range (|w| < 65 504; the host routes on max |W|).  The image ends in a 256-byte trailer, 64 floats whose maximum is
+ * max_n sum_k |W[n][k]| (formed by the pack launch): the scales of layers 2.. come from a bound through it. */
 int64_t dir_tower_cs_image_bytes(int K, int N);
 int dir_tower_cs_f16x2_pack_f32(const float* W, int64_t w_ld, int K, int N, void* image, int64_t image_bytes, dir_stream_t stream);
 int dir_tower_cs_f16x2_f32(const float* X, int64_t x_ld, int64_t M, int Kd, int L, const int* N, const void* const* images,
