@@ -635,3 +635,31 @@ def test_one_launch_tower_takes_tables_of_any_magnitude_on_the_split_kernel(buil
     assert ops._tower_split_for([d(w) for w in Ws], ts) == "f16x2"
     got = ops.tower(None, [d(w) for w in Ws], None, head=(d(hw), d(hb)), gather=(ts, d(ids), None, False)).cpu().numpy().astype(np.float64)
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_row_scaling_changes_nothing_for_ordinary_magnitudes(built_lib):
+    """Rows whose maxima (bounds) lie inside the no-scale windows keep s = 0 and take the epilogue without the multiplications: with inputs
+    and weights of ordinary magnitude tower_cs_k's result with DIR_TOWER_RS on and off is the same, bit for bit (the DeepFM tower's shape,
+    plain and with an affine; a batch with a partial last tile)."""
+    import os
+    from dir_amd import ops
+    if ops.TOWER_KERNEL != "cs":
+        pytest.skip("tower_cs_k's row scaling")
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    M, dims = 5000, [416, 400, 400, 400]
+    x = torch.randn((M, dims[0]), generator=gen, device="cuda") * 0.25
+    Ws = [torch.randn((dims[i + 1], dims[i]), generator=gen, device="cuda") / dims[i] ** 0.5 for i in range(3)]
+    bs = [torch.randn((dims[i + 1],), generator=gen, device="cuda") * 0.1 for i in range(3)]
+    sc = [1 + 0.2 * torch.randn((dims[i + 1],), generator=gen, device="cuda") for i in range(3)]
+    sh = [0.1 * torch.randn((dims[i + 1],), generator=gen, device="cuda") for i in range(3)]
+    hw, hb = torch.randn((1, 400), generator=gen, device="cuda") / 20, torch.full((1,), 0.1, device="cuda")
+    for kw in (dict(), dict(post_scale=sc, post_shift=sh)):
+        on = ops.tower(x, Ws, bs, head=(hw, hb), split="f16x2", **kw)
+        on_act = ops.tower(x, Ws, bs, split="f16x2", **kw)
+        os.environ["DIR_TOWER_RS"] = "0"
+        try:
+            off = ops.tower(x, Ws, bs, head=(hw, hb), split="f16x2", **kw)
+            off_act = ops.tower(x, Ws, bs, split="f16x2", **kw)
+        finally:
+            del os.environ["DIR_TOWER_RS"]
+        assert torch.equal(on, off) and torch.equal(on_act, off_act)
