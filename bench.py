@@ -1018,6 +1018,9 @@ def main():
             assert torch.equal(g_(ids), ref)
             lat[name] = {"eager_us": round(latency(lambda: f(ids)), 2), "graph_replay_us": round(latency(lambda: g_.graph.replay()), 2),
                          "library_layers": dict(_dense_mod.ROUTING["library"]), "hip_layers": sorted(_dense_mod.ROUTING["hip"])}
+            gf_ = GraphedForward(f, ids, frozen_weights=True)      # the serving form: weight images of the warm-up calls, no pack launch per replay
+            assert torch.equal(gf_(ids), ref)
+            lat[name]["graph_replay_frozen_weights_us"] = round(latency(lambda: gf_.graph.replay()), 2)
             if name == "deepfm":
                 graphed = g_
         if Bs > ops.DENSE_SMALL_ROWS:

@@ -71,7 +71,7 @@ def _packed_cached(weight):
     key = id(weight)
     hit = _PACK_CACHE.get(key)
     capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()      # under capture: pack inside the graph, remember nothing (ops.CapturedStep)
-    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and not capturing:
+    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and not ops.capture_bypasses_caches(weight):
         return hit[3]
     packed = pack_weight(weight)
     if capturing:
@@ -105,7 +105,7 @@ def _packed_cached_padded(weight, pad):
     key = (id(weight), pad)
     hit = _PACK_CACHE.get(key)
     capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
-    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and not capturing:
+    if hit is not None and hit[0] is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and not ops.capture_bypasses_caches(weight):
         return hit[3]
     packed = pack_weight(F.pad(weight.detach(), (0, pad)))
     if capturing:
@@ -432,7 +432,7 @@ def _bn_affine(bn):
            bn.beta.data_ptr())
     hit = _BN_CACHE.get(key)
     capturing = bn.moving_mean.is_cuda and torch.cuda.is_current_stream_capturing()
-    if hit is not None and hit[0] is bn and hit[1] == ver and not capturing:
+    if hit is not None and hit[0] is bn and hit[1] == ver and not ops.capture_bypasses_caches(bn.moving_mean):
         return hit[2], hit[3]
     inv = torch.rsqrt(bn.moving_variance + bn.eps)
     if bn.gamma is not None:

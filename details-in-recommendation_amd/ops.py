@@ -230,6 +230,31 @@ def mark_written(*tensors):
                 seen.add(id(o))
                 _HIP_BUMPS[o] = _HIP_BUMPS.get(o, 0) + 1
 
+_FROZEN_WEIGHTS = [False]
+
+
+class frozen_weights:
+    """with ops.frozen_weights(): ... capture ...  -- a capture taken inside takes the VALID per-version cache entries (weight images, packed
+    weights, folded batch norms: built by an earlier eager call on the same versions) instead of re-packing inside the graph.  For SERVING
+    graphs whose weights do not change between replays: a one-launch DeepFM forward at 1 024-4 096 rows carries three pack launches
+    otherwise (15-20 us of ~70).  The price is the rule CapturedStep keeps: a replay after an in-place weight update still runs the images
+    of capture time -- capture again after loading new weights.  serving.GraphedForward(..., frozen_weights=True) uses it."""
+
+    def __enter__(self):
+        self._old = _FROZEN_WEIGHTS[0]
+        _FROZEN_WEIGHTS[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _FROZEN_WEIGHTS[0] = self._old
+        return False
+
+
+def capture_bypasses_caches(t=None):
+    """True while the current stream is capturing and the per-version caches must not be read (the default rule; see frozen_weights)."""
+    return (t is None or t.is_cuda) and torch.cuda.is_current_stream_capturing() and not _FROZEN_WEIGHTS[0]
+
+
 class CapturedStep:
     """A training (or inference) step captured in a HIP graph, replayed with the bookkeeping eager steps do on the host.
 
@@ -657,7 +682,7 @@ def din_pack_image(owners, args, activation, ap):
     key = tuple(t.data_ptr() for t in (W1, b1, W2, b2, W3)) + (activation, ap.data_ptr() if ap is not None else 0, W1.device.index)
     sig = tuple((id(t), t._version if not t.is_inference() else -1) for t in watched) + (_CACHE_GEN[0],)
     hit = _DIN_PACK_IMAGES.get(key)
-    if hit is not None and not capturing and hit[0] == sig and all(r() is t for r, t in zip(hit[1], watched)):
+    if hit is not None and not capture_bypasses_caches() and hit[0] == sig and all(r() is t for r, t in zip(hit[1], watched)):
         return hit[2]
     img = torch.empty(int(lib.dir_din_pack_image_bytes()), dtype=torch.uint8, device=W1.device)
     _lib.check(lib.dir_din_pack_weights_f32(_ptr(W1), _ptr(b1), H1, _ptr(W2), _ptr(b2), H2, _ptr(W3), DIN_ACTIVATIONS[activation], _ptr(ap),
@@ -1055,7 +1080,7 @@ def dense_bf3_image(weight, split="bf16x3"):
     sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
     capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
     hit = _DENSE_IMAGES.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == sig and not capturing:
+    if hit is not None and hit[0]() is weight and hit[1] == sig and not capture_bypasses_caches(weight):
         return hit[2]
     N, Kd = weight.shape
     lib = _lib.load()
@@ -1280,7 +1305,7 @@ def tower_image(weight, split=None):
     sig = (weight._version, tuple(weight.shape), tuple(weight.stride()))
     capturing = weight.is_cuda and torch.cuda.is_current_stream_capturing()
     hit = _TOWER_IMAGES.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == sig and not capturing:
+    if hit is not None and hit[0]() is weight and hit[1] == sig and not capture_bypasses_caches(weight):
         return hit[2]
     N, K = weight.shape
     lib = _lib.load()

@@ -1059,3 +1059,31 @@ def test_esmm_head_entry_matches_the_reference_op_sequence(built_lib):
     err_lib = float(((lib_form.double() - ref).abs() / (1 + ref.abs())).max())
     assert err <= max(2e-6, 2 * err_lib), (err, err_lib)
     assert built_lib.dir_esmm_head_f32(None, None, 8, 1e-7, None, None) != 0 and b"null pointer" in built_lib.dir_last_error()
+
+
+def test_graphed_forward_with_frozen_weights_takes_the_cached_images(built_lib):
+    """serving.GraphedForward(..., frozen_weights=True): the capture reads the weight images the warm-up calls built (no pack launch per replay)
+    -- the same logits as the eager forward and as the default capture, bit for bit; and, as documented, a replay after an in-place weight
+    update still runs the capture-time images while the default capture follows the update."""
+    from dir_amd.deepfm import DeepFM
+    from dir_amd import feature_column as fc
+    from dir_amd.serving import GraphedForward
+    torch.manual_seed(3)
+    B, F, K, V = 2048, 26, 16, 3000
+    cats = [fc.categorical_column_with_identity("C%d" % i, V) for i in range(F)]
+    model = DeepFM(linear_feature_columns=cats, dnn_feature_columns=[fc.embedding_column(c, K) for c in cats],
+                   dnn_hidden_units=[400, 400, 400], fm_embedding_size=K).cuda().eval()
+    ids = torch.randint(0, V, (B, F), device="cuda")
+    f = lambda x: model.forward_ids(x, x)      # noqa: E731
+    with torch.no_grad():
+        ref = f(ids).clone()
+    g_default = GraphedForward(f, ids)
+    g_frozen = GraphedForward(f, ids, frozen_weights=True)
+    assert torch.equal(g_default(ids), ref) and torch.equal(g_frozen(ids), ref)
+    with torch.no_grad():
+        model.hidden[1].weight.mul_(0.5)
+        new = f(ids).clone()
+    assert not torch.equal(new, ref)
+    assert torch.equal(g_default(ids), new)        # re-packs inside the graph: follows the update
+    assert torch.equal(g_frozen(ids), ref)         # frozen: the images of capture time (build a new GraphedForward after loading weights)
+    assert torch.equal(GraphedForward(f, ids, frozen_weights=True)(ids), new)
