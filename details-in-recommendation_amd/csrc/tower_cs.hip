@@ -63,9 +63,9 @@ constexpr int TC_PIECE = TC_ROWS * TC_STRIDE;   // halves per piece plane
 constexpr int TC_ACT_BYTES = 2 * TC_PIECE * 2;  // 108 544
 constexpr int TC_DUMP = TC_ACT_BYTES + TC_NW * TC_ROWS * 4;      // 256 bytes the input prefetch's LDS-DMA lands in (never read)
 constexpr int TC_SLOTS = TC_DUMP + 256;                          // GATHER: every slot's vocabulary bound and table base (16 bytes each), staged once
-constexpr int TC_ROWF = TC_SLOTS + 16 * TC_NT;                   // RS: [layer parity][batch row] 2^s, s the power of two the stored layer input was divided by
+constexpr int TC_ROWF = TC_SLOTS + 16 * TC_NT;                   // RS: [layer parity][batch row] s (an int): the stored layer input row holds x * 2^-s
 constexpr int TC_ROWMAX = TC_ROWF + 2 * 4 * TC_ROWS;             // RS: [layer parity][batch row] the bit pattern of max |layer input| before scaling (LDS atomic max)
-constexpr int TC_CST = TC_ROWMAX + 2 * 4 * TC_ROWS;              // RS: per layer (a, b): max |output| <= a * max |input| + b (tc_layer_bound)
+constexpr int TC_CST = TC_ROWMAX + 2 * 4 * TC_ROWS;              // RS: per layer (a, b): max |output| <= a * max |input| + b (the comment above tc_row_sft)
 constexpr int TC_SMEM = TC_CST + 8 * TC_MAXL;                    // act + the head's partial dots [wave][row] + the dump + the slot table + the rows' scales
 
 struct TowerCsParams {
